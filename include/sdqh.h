@@ -1,0 +1,228 @@
+/*
+ * sdqh.h — C ABI of the MI355X-native execution backend for sdqlpy's hot path.
+ *
+ * One header, two implementations with identical exports:
+ *   - sdqlpy_amd/csrc/libsdqlhip.so   hand-written HIP kernels for gfx950 (the product)
+ *   - oracle/libsdqloracle.so         CPU restatement of the reference plan (test infrastructure only)
+ *
+ * What each entry point replaces in the reference (edin-dal/sdqlpy, paths relative to its root):
+ *
+ *   The reference has no FFI for this path: `@sdql_compile` imports a generated CPython
+ *   extension and calls `<fn>_compiled(db)` with db = list[table] of list[column] of numpy
+ *   arrays (src/sdqlpy/sdql_lib.py:401-424).  The generated C++ binds every column to a raw
+ *   typed pointer (src/sdqlpy/lib/sdql_compiler.py:638-672) and then runs one emitted loop per
+ *   SumExpr (src/sdqlpy/lib/sdql_ir_cpp_generator_par.py:176-570).  This ABI cuts at exactly
+ *   that level: columns in, one call per emitted loop shape, struct-of-arrays results out.
+ *
+ *   sdqh_column_upload        <- column binding, sdql_compiler.py:638-672 (long* / double* /
+ *                                VarChar<n>* over numpy buffers; include/varchar.h:1-3)
+ *   sdqh_set_threads          <- tbb::task_scheduler_init scheduler(N), sdql_compiler.py:485
+ *   sdqh_scan_filter_sum      <- K-A  tbb::parallel_reduce loop, ...generator_par.py:258-291
+ *   sdqh_groupby_small        <- K-C  aggregating-dict loop + AddMap merge for small key domains,
+ *                                ...generator_par.py:402-440, include/map_helper.h:1-23,
+ *                                include/tuple_helper.h:36-41,79-84
+ *   sdqh_hash_build_unique    <- K-B  unique-dict build (joinBuild / joinProbe(...,False)),
+ *                                ...generator_par.py:331-369, lib/sdql_ir.py:424-454,
+ *                                lookups ...generator_par.py:85-96 (contains / at)
+ *   sdqh_hash_probe_aggregate <- K-C  probe + group-by loop, ...generator_par.py:402-440
+ *   sdqh_table_compact        <- K-F  finalise loop `out[tuple_cat(k,v)] = true`,
+ *                                ...generator_par.py:520-568 and result hand-over 871-877
+ *   sdqh_scan_compact / sdqh_partition_by_key / sdqh_table_* (bitmap)
+ *                             <- no reference counterpart: the multi-GPU redistribution step
+ *                                
+ *
+ * Conventions: plain C, opaque handles, every call returns an int status (0 = ok) and leaves a
+ * message retrievable with sdqh_last_error().  Inputs are never written.  Host pointers are
+ * only used for the duration of the call.  The library owns all device memory behind `ctx`.
+ * One ctx per host thread; no global mutable state.
+ */
+#ifndef SDQH_H
+#define SDQH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDQH_ABI_VERSION 1
+
+/* ---- status codes ---------------------------------------------------------------------- */
+#define SDQH_OK              0
+#define SDQH_ERR_INVALID     1   /* bad argument (null, dtype mismatch, row-count mismatch) */
+#define SDQH_ERR_UNSUPPORTED 2   /* shape outside this backend's vocabulary                 */
+#define SDQH_ERR_DEVICE      3   /* HIP runtime error (message holds hipGetErrorString)     */
+#define SDQH_ERR_OVERFLOW    4   /* small-domain group-by saw more keys than max_groups     */
+#define SDQH_ERR_NOMEM       5
+
+/* ---- column element types (the reference's three storage classes) ------------------------
+ * I64: int / date columns, numpy int64, dates as yyyymmdd (sdql_lib.py:83-84)
+ * F64: float columns, numpy float64
+ * STR: string(n) columns, numpy '<U n' = n UCS4 code units per row, zero padded
+ *      (include/varchar.h:1-3: VarChar<n>{ wchar_t data[n] })
+ */
+#define SDQH_I64 0
+#define SDQH_F64 1
+#define SDQH_STR 2
+
+/* ---- value tuples ------------------------------------------------------------------------
+ * The right-hand side of `+=` in an emitted loop is a tuple of doubles/longs computed from the
+ * row (AdditionCodeGenerator, ...generator_par.py:712-795).  The kernels are specialised per
+ * tuple shape; operands a..d are F64 columns bound at call time.  Every product is evaluated in
+ * the reference's association order with FMA contraction off (test/test_all.py:52,171,293,480).
+ */
+#define SDQH_TUPLE_A            1  /* { a }                                      1 double          */
+#define SDQH_TUPLE_AB           2  /* { a*b }                         (Q6)       1 double          */
+#define SDQH_TUPLE_A_1MB        3  /* { a*(1.0-b) }                   (Q3,Q5)    1 double          */
+#define SDQH_TUPLE_PRICING      4  /* { a, b, b*(1.0-c), (b*(1.0-c))*(1.0+d), 1 }   (Q1)
+                                      4 doubles; the trailing COUNT is the row count output */
+#define SDQH_TUPLE_A_1MB_M_CD   5  /* { a*(1.0-b) - c*d }             (Q9)       1 double          */
+#define SDQH_TUPLE_COUNT        6  /* { 1 }                                      0 doubles         */
+#define SDQH_TUPLE_MAX_VALUES   4
+
+typedef struct sdqh_ctx    sdqh_ctx;
+typedef struct sdqh_column sdqh_column;
+typedef struct sdqh_table  sdqh_table;
+
+/* ---- row filter: a conjunction, every term a closed range or a string equality ------------
+ * `x < c` on ints is passed as hi = c-1; on doubles as hi = nextafter(c,-inf); NaN fails every
+ * active range, as in C.  An empty filter passes every row.
+ */
+#define SDQH_MAX_IPRED 4
+#define SDQH_MAX_FPRED 4
+#define SDQH_MAX_SPRED 1
+#define SDQH_MAX_STR_CONST 64
+
+typedef struct sdqh_ipred { const sdqh_column* col; int64_t lo, hi; } sdqh_ipred;
+typedef struct sdqh_fpred { const sdqh_column* col; double  lo, hi; } sdqh_fpred;
+typedef struct sdqh_spred {                     /* col == value  (VarChar::operator==, include/varchar.h:61-77) */
+    const sdqh_column* col;
+    int32_t  len;                               /* code units in value, <= column width */
+    int32_t  negate;                            /* 1: col != value */
+    uint32_t value[SDQH_MAX_STR_CONST];
+} sdqh_spred;
+
+typedef struct sdqh_filter {
+    int32_t n_ipred, n_fpred, n_spred, _pad;
+    sdqh_ipred ipred[SDQH_MAX_IPRED];
+    sdqh_fpred fpred[SDQH_MAX_FPRED];
+    sdqh_spred spred[SDQH_MAX_SPRED];
+} sdqh_filter;
+
+typedef struct sdqh_tuple {
+    int32_t shape;                              /* SDQH_TUPLE_* */
+    int32_t _pad;
+    const sdqh_column* a;
+    const sdqh_column* b;
+    const sdqh_column* c;
+    const sdqh_column* d;
+} sdqh_tuple;
+
+/* A semi-join step evaluated after the filter: keep the row iff table contains key[row]
+ * (`(tbl).contains(k)`, ...generator_par.py:86-96). */
+#define SDQH_MAX_PROBE 2
+typedef struct sdqh_probe { const sdqh_table* table; const sdqh_column* key; } sdqh_probe;
+
+/* ---- context ----------------------------------------------------------------------------- */
+int         sdqh_abi_version(void);
+const char* sdqh_backend_name(void);                    /* "hip-gfx950" or "cpu-oracle" */
+int         sdqh_create(int device, sdqh_ctx** out);
+void        sdqh_destroy(sdqh_ctx* ctx);
+const char* sdqh_last_error(const sdqh_ctx* ctx);
+int         sdqh_set_threads(sdqh_ctx* ctx, int threads);   /* CPU build: worker count; HIP build: accepted, ignored */
+int         sdqh_synchronize(sdqh_ctx* ctx);
+/* Milliseconds spent on the device by the most recent pattern call (HIP events on the ctx
+ * stream; CPU build: wall clock of the call). */
+int         sdqh_last_device_ms(const sdqh_ctx* ctx, double* ms);
+/* Name and duration (ms) of each kernel launched by the most recent pattern call, measured with
+ * HIP events on the ctx stream when profiling is enabled (sdqh_set_profiling). */
+int         sdqh_set_profiling(sdqh_ctx* ctx, int enabled);
+int         sdqh_profile_count(const sdqh_ctx* ctx);
+int         sdqh_profile_entry(const sdqh_ctx* ctx, int i, const char** name, double* ms);
+/* Raw hipStream_t the ctx launches on (NULL in the CPU build). */
+void*       sdqh_stream(const sdqh_ctx* ctx);
+
+/* ---- columns ----------------------------------------------------------------------------- */
+/* Copy a host column into device memory through a pinned staging ring (chunked, async H2D on
+ * the ctx stream) and record min/max for I64 columns.  width = code units per row for STR, else 0. */
+int     sdqh_column_upload(sdqh_ctx* ctx, const void* host, int64_t nrows, int dtype, int width, sdqh_column** out);
+/* Wrap device memory owned by the caller (e.g. a torch tensor); 16-byte aligned. */
+int     sdqh_column_wrap(sdqh_ctx* ctx, void* device_ptr, int64_t nrows, int dtype, int width, sdqh_column** out);
+/* Uninitialised device column owned by the library. */
+int     sdqh_column_alloc(sdqh_ctx* ctx, int64_t nrows, int dtype, int width, sdqh_column** out);
+int     sdqh_column_download(sdqh_ctx* ctx, const sdqh_column* col, int64_t row0, int64_t nrows, void* host);
+void*   sdqh_column_data(const sdqh_column* col);
+int64_t sdqh_column_rows(const sdqh_column* col);
+int     sdqh_column_dtype(const sdqh_column* col);
+int     sdqh_column_width(const sdqh_column* col);
+int     sdqh_column_minmax(sdqh_ctx* ctx, const sdqh_column* col, int64_t* min, int64_t* max);
+void    sdqh_column_free(sdqh_ctx* ctx, sdqh_column* col);
+
+/* ---- K-A: scan -> filter -> scalar / record reduce ------------------------------------------
+ * out_values[SDQH_TUPLE_MAX_VALUES] receives the tuple's doubles, *out_count the rows that passed. */
+int sdqh_scan_filter_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter,
+                         const sdqh_tuple* tuple, double* out_values, int64_t* out_count);
+
+/* ---- K-C small: scan -> filter -> group-by over a small key domain -------------------------
+ * Keys: 1..2 columns, each STR of width 1 or I64 with values in [0, 2^32-2].  Results, one row
+ * per group in unspecified order: out_keys[g*nkeys + k] (code point or integer),
+ * out_values[g*SDQH_TUPLE_MAX_VALUES + v], out_counts[g].  SDQH_ERR_OVERFLOW if the data holds
+ * more than max_groups (<= 64) distinct keys. */
+#define SDQH_MAX_GROUPKEYS 2
+#define SDQH_MAX_SMALL_GROUPS 64
+int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter,
+                       int nkeys, const sdqh_column* const* keys, const sdqh_tuple* tuple,
+                       int max_groups, int64_t* out_keys, double* out_values, int64_t* out_counts,
+                       int32_t* out_ngroups);
+
+/* ---- K-B: scan -> filter -> semi-join probes -> unique hash build ----------------------------
+ * Builds key -> (payload columns of the same row); the first row (lowest index) wins on a
+ * duplicate key, as `emplace`/`insert(range)` do in row order (...generator_par.py:366-367,766-773).
+ * Payload columns are I64 or F64 (carried as 8 raw bytes).  With accumulate != 0 the table also
+ * carries SDQH_TUPLE_MAX_VALUES double accumulators and a hit counter per entry for
+ * sdqh_hash_probe_aggregate. */
+#define SDQH_MAX_PAYLOAD 4
+int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter,
+                           int nprobes, const sdqh_probe* probes,
+                           const sdqh_column* key, int npayload, const sdqh_column* const* payload,
+                           int accumulate, sdqh_table** out);
+int  sdqh_table_size(sdqh_ctx* ctx, const sdqh_table* table, int64_t* entries);
+void sdqh_table_free(sdqh_ctx* ctx, sdqh_table* table);
+
+/* ---- K-C large: scan -> filter -> probe -> aggregate into the matched entry -------------------
+ * For each passing row whose key is in `table`: entry.acc += tuple(row), entry.hits += 1.  This is
+ * the reference's group-by on (probe key, fields of the matched entry), where the group is
+ * functionally determined by the probe key (test/test_all.py:164-172). */
+int sdqh_hash_probe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter,
+                              sdqh_table* table, const sdqh_column* key, const sdqh_tuple* tuple);
+
+/* ---- K-F: compact the entries that received at least min_hits rows into host arrays ---------
+ * out_keys[i], out_payload[p*capacity + i] (8 raw bytes each), out_values[v*capacity + i],
+ * out_hits[i]; *out_n = rows written.  min_hits = 0 returns every entry.  Any out_* may be NULL. */
+int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, int64_t capacity,
+                       int64_t* out_keys, int64_t* out_payload, double* out_values,
+                       int64_t* out_hits, int64_t* out_n);
+
+/* ---- multi-GPU redistribution helpers (no reference counterpart) -------------- */
+/* Filter + semi-join probes, then gather `ncols` columns of the surviving rows into freshly
+ * allocated device columns (order of rows unspecified but identical across the ncols outputs). */
+#define SDQH_MAX_COMPACT_COLS 6
+int sdqh_scan_compact(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter,
+                      int nprobes, const sdqh_probe* probes,
+                      int ncols, const sdqh_column* const* cols, sdqh_column** out_cols, int64_t* out_rows);
+/* Reorder rows so that all rows with part(key) == p are contiguous, p ascending, where
+ * part(key) = mix64(key) % nparts (the same function in both builds).  counts[nparts] on host. */
+int sdqh_partition_by_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int nparts,
+                          int ncols, const sdqh_column* const* cols, sdqh_column** out_cols,
+                          int64_t* counts);
+/* Exact key bitmap of a table over [lo, hi] (bit i = key lo+i present), as device words; used to
+ * pre-filter probe rows before they are exchanged.  words = ceil((hi-lo+1)/32). */
+int sdqh_table_export_bitmap(sdqh_ctx* ctx, const sdqh_table* table, int64_t lo, int64_t hi, sdqh_column** out_words);
+/* Build a key-only membership table from a bitmap (device I64 column viewed as 32-bit words). */
+int sdqh_table_from_bitmap(sdqh_ctx* ctx, const sdqh_column* words, int64_t lo, int64_t hi, sdqh_table** out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDQH_H */

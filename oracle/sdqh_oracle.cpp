@@ -1,0 +1,617 @@
+// sdqh_oracle.cpp — CPU restatement of the reference's hot path behind the sdqh C ABI.
+//
+// TEST INFRASTRUCTURE ONLY.  Nothing under sdqlpy_amd/ imports, links or executes this file; it is
+// used by tests/ (as the parity checker), by __graft_entry__.smoke() (to check one GPU run) and by
+// bench.py's cpu_baseline leg (as the timed CPU port).  The product path is libsdqlhip.so.
+//
+// Parity status: PINNED.  The reference has no expected-value tests (reference
+// test/test_all.py:1187-1208 only prints), so the pins are the reference's own results: the
+// reference is imported unmodified in Python mode in the build container and its q1/q3/q5/q6/q9
+// outputs on generated inputs are committed as tests/golden/tpch_golden.json by
+// tests/golden/make_golden.py; tests/test_oracle_golden.py checks this file against every one of
+// them (ints exact; with threads = 1 the doubles are bit-identical because the summation order is
+// row order, exactly the interpreter's: reference src/sdqlpy/sdql_lib.py:220-236).
+//
+// The reference's compiled (TBB + phmap) mode is NOT buildable here: its generator needs Python
+// 3.8's ast.Index, the emitted C++ needs TBB headers (task_scheduler_init was removed from oneTBB)
+// and the numpy-1 C API.  Writing stand-ins for those is not allowed, so no oracle/_ref exists.
+//
+// What is restated, loop shape by loop shape (reference src/sdqlpy/lib/sdql_ir_cpp_generator_par.py):
+//   K-A scalar reduce        258-291  tbb::parallel_reduce: per-range partial, combined with plus<>
+//   K-B unique dict build    331-369  per-thread vector<pair<K,V>>::emplace_back, then the global
+//                                     map inserts each thread's range serially: first insert wins
+//   K-C aggregating dict     402-440  per-thread map `local[key] += tuple`, then AddMap(global, local)
+//                                     per thread in order (reference src/sdqlpy/include/map_helper.h:1-23)
+//   lookups                   85-96   contains(k) / at(k)
+//   K-F finalise             520-568  out[tuple_cat(k, v)] = true
+//   tuple +=                          reference src/sdqlpy/include/tuple_helper.h:36-41,79-84
+//   string ==                         reference src/sdqlpy/include/varchar.h:61-77
+// Row ranges are cut into `threads` contiguous blocks (TBB's blocked_range split, made static).
+//
+// Build: see oracle/Makefile (g++ -O3 -ffp-contract=off; no FMA so a*(1.0-b) rounds twice as in
+// the reference's generated C++ built with plain -O3 on x86-64).
+
+#include "sdqh.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+// ---------------------------------------------------------------------------------------------
+struct sdqh_ctx {
+    int threads = 1;
+    std::string err;
+    double last_ms = 0.0;
+};
+
+struct sdqh_column {
+    void* data = nullptr;
+    int64_t nrows = 0;
+    int dtype = SDQH_I64;
+    int width = 0;
+    bool owned = false;
+    bool have_minmax = false;
+    int64_t mn = 0, mx = 0;
+    size_t row_bytes() const { return dtype == SDQH_STR ? (size_t)width * 4 : 8; }
+};
+
+namespace {
+
+inline uint64_t mix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31; return x;
+}
+
+// open-addressing int64 -> dense entry index map; entries keep insertion order
+struct I64Index {
+    std::vector<int64_t> slot_key;
+    std::vector<int64_t> slot_val;   // -1 = empty
+    size_t used = 0;
+    I64Index() { rehash(16); }
+    void rehash(size_t cap) {
+        std::vector<int64_t> ok, ov;
+        ok.swap(slot_key); ov.swap(slot_val);
+        slot_key.assign(cap, 0); slot_val.assign(cap, -1); used = 0;
+        for (size_t i = 0; i < ov.size(); ++i) if (ov[i] >= 0) put_new(ok[i], ov[i]);
+    }
+    void put_new(int64_t k, int64_t v) {
+        size_t m = slot_key.size() - 1, h = (size_t)mix64((uint64_t)k) & m;
+        while (slot_val[h] >= 0) h = (h + 1) & m;
+        slot_key[h] = k; slot_val[h] = v; ++used;
+    }
+    int64_t find(int64_t k) const {
+        size_t m = slot_key.size() - 1, h = (size_t)mix64((uint64_t)k) & m;
+        while (slot_val[h] >= 0) { if (slot_key[h] == k) return slot_val[h]; h = (h + 1) & m; }
+        return -1;
+    }
+    // returns existing value, or inserts v and returns -1
+    int64_t find_or_insert(int64_t k, int64_t v) {
+        if ((used + 1) * 2 > slot_key.size()) rehash(slot_key.size() * 2);
+        size_t m = slot_key.size() - 1, h = (size_t)mix64((uint64_t)k) & m;
+        while (slot_val[h] >= 0) { if (slot_key[h] == k) return slot_val[h]; h = (h + 1) & m; }
+        slot_key[h] = k; slot_val[h] = v; ++used;
+        return -1;
+    }
+};
+
+struct Acc { double v[SDQH_TUPLE_MAX_VALUES]; int64_t n; };
+
+}  // namespace
+
+struct sdqh_table {
+    I64Index index;
+    std::vector<int64_t> keys;                       // entry -> key, insertion order
+    int npayload = 0;
+    std::vector<int64_t> payload;                    // entry * npayload + p (raw 8 bytes)
+    bool accumulate = false;
+    std::vector<Acc> acc;                            // entry -> accumulators + hits
+    // bitmap-only membership table (sdqh_table_from_bitmap)
+    bool bitmap_only = false;
+    int64_t bm_lo = 0, bm_hi = -1;
+    std::vector<uint32_t> bm;
+    bool contains(int64_t k) const {
+        if (bitmap_only) {
+            if (k < bm_lo || k > bm_hi) return false;
+            uint64_t off = (uint64_t)(k - bm_lo);
+            return (bm[off >> 5] >> (off & 31)) & 1u;
+        }
+        return index.find(k) >= 0;
+    }
+};
+
+namespace {
+
+int fail(sdqh_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+struct Timer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+// ---- filter ------------------------------------------------------------------------------------
+struct FilterView {
+    int ni = 0, nf = 0, ns = 0;
+    const int64_t* ic[SDQH_MAX_IPRED]; int64_t ilo[SDQH_MAX_IPRED], ihi[SDQH_MAX_IPRED];
+    const double* fc[SDQH_MAX_FPRED]; double flo[SDQH_MAX_FPRED], fhi[SDQH_MAX_FPRED];
+    const uint32_t* sc[SDQH_MAX_SPRED]; int swidth[SDQH_MAX_SPRED]; int slen[SDQH_MAX_SPRED]; int sneg[SDQH_MAX_SPRED];
+    const uint32_t* sval[SDQH_MAX_SPRED];
+    int np = 0;
+    const sdqh_table* pt[SDQH_MAX_PROBE]; const int64_t* pk[SDQH_MAX_PROBE];
+
+    inline bool pass(int64_t r) const {
+        for (int i = 0; i < ni; ++i) { int64_t x = ic[i][r]; if (!(x >= ilo[i] && x <= ihi[i])) return false; }
+        for (int i = 0; i < nf; ++i) { double x = fc[i][r]; if (!(x >= flo[i] && x <= fhi[i])) return false; }
+        for (int i = 0; i < ns; ++i) {
+            // VarChar::operator==(const wchar_t*): reference include/varchar.h:61-77
+            const uint32_t* s = sc[i] + (size_t)r * swidth[i];
+            bool eq = slen[i] <= swidth[i];
+            for (int k = 0; eq && k < slen[i]; ++k) eq = s[k] == sval[i][k];
+            for (int k = slen[i]; eq && k < swidth[i]; ++k) eq = s[k] == 0;
+            if (eq == (sneg[i] != 0)) return false;
+        }
+        for (int i = 0; i < np; ++i) if (!pt[i]->contains(pk[i][r])) return false;   // (tbl).contains(k): generator 86-96
+        return true;
+    }
+};
+
+int check_col(sdqh_ctx* ctx, const sdqh_column* c, int dtype, int64_t nrows, const char* what) {
+    if (!c) return fail(ctx, SDQH_ERR_INVALID, std::string(what) + ": null column");
+    if (c->dtype != dtype) return fail(ctx, SDQH_ERR_INVALID, std::string(what) + ": wrong dtype");
+    if (c->nrows < nrows) return fail(ctx, SDQH_ERR_INVALID, std::string(what) + ": column shorter than nrows");
+    return SDQH_OK;
+}
+
+int make_filter(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* f, int nprobes, const sdqh_probe* probes, FilterView* v) {
+    if (f) {
+        if (f->n_ipred < 0 || f->n_ipred > SDQH_MAX_IPRED || f->n_fpred < 0 || f->n_fpred > SDQH_MAX_FPRED ||
+            f->n_spred < 0 || f->n_spred > SDQH_MAX_SPRED)
+            return fail(ctx, SDQH_ERR_INVALID, "filter: predicate count out of range");
+        v->ni = f->n_ipred; v->nf = f->n_fpred; v->ns = f->n_spred;
+        for (int i = 0; i < v->ni; ++i) {
+            if (int rc = check_col(ctx, f->ipred[i].col, SDQH_I64, nrows, "ipred")) return rc;
+            v->ic[i] = (const int64_t*)f->ipred[i].col->data; v->ilo[i] = f->ipred[i].lo; v->ihi[i] = f->ipred[i].hi;
+        }
+        for (int i = 0; i < v->nf; ++i) {
+            if (int rc = check_col(ctx, f->fpred[i].col, SDQH_F64, nrows, "fpred")) return rc;
+            v->fc[i] = (const double*)f->fpred[i].col->data; v->flo[i] = f->fpred[i].lo; v->fhi[i] = f->fpred[i].hi;
+        }
+        for (int i = 0; i < v->ns; ++i) {
+            if (int rc = check_col(ctx, f->spred[i].col, SDQH_STR, nrows, "spred")) return rc;
+            if (f->spred[i].len < 0 || f->spred[i].len > SDQH_MAX_STR_CONST) return fail(ctx, SDQH_ERR_INVALID, "spred: constant too long");
+            v->sc[i] = (const uint32_t*)f->spred[i].col->data; v->swidth[i] = f->spred[i].col->width;
+            v->slen[i] = f->spred[i].len; v->sneg[i] = f->spred[i].negate; v->sval[i] = f->spred[i].value;
+        }
+    }
+    if (nprobes < 0 || nprobes > SDQH_MAX_PROBE) return fail(ctx, SDQH_ERR_INVALID, "too many probes");
+    v->np = nprobes;
+    for (int i = 0; i < nprobes; ++i) {
+        if (!probes[i].table) return fail(ctx, SDQH_ERR_INVALID, "probe: null table");
+        if (int rc = check_col(ctx, probes[i].key, SDQH_I64, nrows, "probe key")) return rc;
+        v->pt[i] = probes[i].table; v->pk[i] = (const int64_t*)probes[i].key->data;
+    }
+    return SDQH_OK;
+}
+
+// ---- value tuples ------------------------------------------------------------------------------
+struct TupleView {
+    int shape = 0, nv = 0;
+    const double *a = nullptr, *b = nullptr, *c = nullptr, *d = nullptr;
+    // products in the reference's association order (test/test_all.py:52,171,293,480)
+    inline void eval(int64_t r, double* o) const {
+        switch (shape) {
+            case SDQH_TUPLE_A: o[0] = a[r]; break;
+            case SDQH_TUPLE_AB: o[0] = a[r] * b[r]; break;
+            case SDQH_TUPLE_A_1MB: o[0] = a[r] * (1.0 - b[r]); break;
+            case SDQH_TUPLE_PRICING: {
+                double dp = b[r] * (1.0 - c[r]);
+                o[0] = a[r]; o[1] = b[r]; o[2] = dp; o[3] = dp * (1.0 + d[r]);
+                break;
+            }
+            case SDQH_TUPLE_A_1MB_M_CD: o[0] = a[r] * (1.0 - b[r]) - c[r] * d[r]; break;
+            default: break;
+        }
+    }
+};
+
+int tuple_arity(int shape, int* nops) {
+    switch (shape) {
+        case SDQH_TUPLE_A: *nops = 1; return 1;
+        case SDQH_TUPLE_AB: *nops = 2; return 1;
+        case SDQH_TUPLE_A_1MB: *nops = 2; return 1;
+        case SDQH_TUPLE_PRICING: *nops = 4; return 4;
+        case SDQH_TUPLE_A_1MB_M_CD: *nops = 4; return 1;
+        case SDQH_TUPLE_COUNT: *nops = 0; return 0;
+        default: *nops = -1; return -1;
+    }
+}
+
+int make_tuple(sdqh_ctx* ctx, int64_t nrows, const sdqh_tuple* t, TupleView* v) {
+    if (!t) return fail(ctx, SDQH_ERR_INVALID, "null tuple");
+    int nops; int nv = tuple_arity(t->shape, &nops);
+    if (nv < 0) return fail(ctx, SDQH_ERR_UNSUPPORTED, "unknown tuple shape");
+    const sdqh_column* ops[4] = {t->a, t->b, t->c, t->d};
+    const double* p[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < nops; ++i) {
+        if (int rc = check_col(ctx, ops[i], SDQH_F64, nrows, "tuple operand")) return rc;
+        p[i] = (const double*)ops[i]->data;
+    }
+    v->shape = t->shape; v->nv = nv; v->a = p[0]; v->b = p[1]; v->c = p[2]; v->d = p[3];
+    return SDQH_OK;
+}
+
+template <class F>
+void run_blocks(int threads, int64_t nrows, F f) {
+    int T = std::max(1, threads);
+    if (nrows < 2048) T = 1;
+    if (T == 1) { f(0, (int64_t)0, nrows); return; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < T; ++t) {
+        int64_t b = nrows * t / T, e = nrows * (t + 1) / T;
+        pool.emplace_back([=] { f(t, b, e); });
+    }
+    for (auto& th : pool) th.join();
+}
+int eff_threads(int threads, int64_t nrows) { return nrows < 2048 ? 1 : std::max(1, threads); }
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int sdqh_abi_version(void) { return SDQH_ABI_VERSION; }
+const char* sdqh_backend_name(void) { return "cpu-oracle"; }
+
+int sdqh_create(int device, sdqh_ctx** out) {
+    (void)device;
+    if (!out) return SDQH_ERR_INVALID;
+    *out = new sdqh_ctx();
+    return SDQH_OK;
+}
+void sdqh_destroy(sdqh_ctx* ctx) { delete ctx; }
+const char* sdqh_last_error(const sdqh_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+int sdqh_set_threads(sdqh_ctx* ctx, int threads) {
+    if (!ctx || threads < 1) return SDQH_ERR_INVALID;
+    ctx->threads = threads;
+    return SDQH_OK;
+}
+int sdqh_synchronize(sdqh_ctx* ctx) { return ctx ? SDQH_OK : SDQH_ERR_INVALID; }
+int sdqh_last_device_ms(const sdqh_ctx* ctx, double* ms) { if (!ctx || !ms) return SDQH_ERR_INVALID; *ms = ctx->last_ms; return SDQH_OK; }
+int sdqh_set_profiling(sdqh_ctx* ctx, int) { return ctx ? SDQH_OK : SDQH_ERR_INVALID; }
+int sdqh_profile_count(const sdqh_ctx*) { return 0; }
+int sdqh_profile_entry(const sdqh_ctx*, int, const char**, double*) { return SDQH_ERR_INVALID; }
+void* sdqh_stream(const sdqh_ctx*) { return nullptr; }
+
+// ---- columns -----------------------------------------------------------------------------------
+static int new_column(sdqh_ctx* ctx, int64_t nrows, int dtype, int width, sdqh_column** out) {
+    if (!ctx || !out || nrows < 0) return fail(ctx, SDQH_ERR_INVALID, "column: bad arguments");
+    if (dtype != SDQH_I64 && dtype != SDQH_F64 && dtype != SDQH_STR) return fail(ctx, SDQH_ERR_INVALID, "column: bad dtype");
+    if (dtype == SDQH_STR && width < 1) return fail(ctx, SDQH_ERR_INVALID, "column: STR needs width >= 1");
+    sdqh_column* c = new sdqh_column();
+    c->nrows = nrows; c->dtype = dtype; c->width = dtype == SDQH_STR ? width : 0;
+    *out = c;
+    return SDQH_OK;
+}
+
+int sdqh_column_upload(sdqh_ctx* ctx, const void* host, int64_t nrows, int dtype, int width, sdqh_column** out) {
+    if (nrows > 0 && !host) return fail(ctx, SDQH_ERR_INVALID, "column_upload: null host pointer");
+    if (int rc = new_column(ctx, nrows, dtype, width, out)) return rc;
+    sdqh_column* c = *out;
+    size_t bytes = (size_t)nrows * c->row_bytes();
+    c->data = std::malloc(bytes ? bytes : 1); c->owned = true;
+    if (!c->data) { delete c; *out = nullptr; return fail(ctx, SDQH_ERR_NOMEM, "column_upload: out of memory"); }
+    if (bytes) std::memcpy(c->data, host, bytes);
+    return SDQH_OK;
+}
+int sdqh_column_wrap(sdqh_ctx* ctx, void* ptr, int64_t nrows, int dtype, int width, sdqh_column** out) {
+    if (int rc = new_column(ctx, nrows, dtype, width, out)) return rc;
+    (*out)->data = ptr; (*out)->owned = false;
+    return SDQH_OK;
+}
+int sdqh_column_alloc(sdqh_ctx* ctx, int64_t nrows, int dtype, int width, sdqh_column** out) {
+    if (int rc = new_column(ctx, nrows, dtype, width, out)) return rc;
+    size_t bytes = (size_t)nrows * (*out)->row_bytes();
+    (*out)->data = std::calloc(bytes ? bytes : 1, 1); (*out)->owned = true;
+    return SDQH_OK;
+}
+int sdqh_column_download(sdqh_ctx* ctx, const sdqh_column* col, int64_t row0, int64_t nrows, void* host) {
+    if (!ctx || !col || row0 < 0 || nrows < 0 || row0 + nrows > col->nrows || (nrows && !host))
+        return fail(ctx, SDQH_ERR_INVALID, "column_download: bad arguments");
+    std::memcpy(host, (const char*)col->data + (size_t)row0 * col->row_bytes(), (size_t)nrows * col->row_bytes());
+    return SDQH_OK;
+}
+void* sdqh_column_data(const sdqh_column* col) { return col ? col->data : nullptr; }
+int64_t sdqh_column_rows(const sdqh_column* col) { return col ? col->nrows : -1; }
+int sdqh_column_dtype(const sdqh_column* col) { return col ? col->dtype : -1; }
+int sdqh_column_width(const sdqh_column* col) { return col ? col->width : -1; }
+int sdqh_column_minmax(sdqh_ctx* ctx, const sdqh_column* col, int64_t* mn, int64_t* mx) {
+    if (!ctx || !col || col->dtype != SDQH_I64 || !mn || !mx) return fail(ctx, SDQH_ERR_INVALID, "column_minmax: needs an I64 column");
+    sdqh_column* c = const_cast<sdqh_column*>(col);
+    if (!c->have_minmax) {
+        int64_t lo = INT64_MAX, hi = INT64_MIN;
+        const int64_t* p = (const int64_t*)c->data;
+        for (int64_t i = 0; i < c->nrows; ++i) { lo = std::min(lo, p[i]); hi = std::max(hi, p[i]); }
+        c->mn = lo; c->mx = hi; c->have_minmax = true;
+    }
+    *mn = c->mn; *mx = c->mx;
+    return SDQH_OK;
+}
+void sdqh_column_free(sdqh_ctx*, sdqh_column* col) {
+    if (!col) return;
+    if (col->owned) std::free(col->data);
+    delete col;
+}
+
+// ---- K-A ---------------------------------------------------------------------------------------
+int sdqh_scan_filter_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, const sdqh_tuple* tuple,
+                         double* out_values, int64_t* out_count) {
+    if (!ctx || nrows < 0) return fail(ctx, SDQH_ERR_INVALID, "scan_filter_sum: bad arguments");
+    Timer tm;
+    FilterView fv; TupleView tv;
+    if (int rc = make_filter(ctx, nrows, filter, 0, nullptr, &fv)) return rc;
+    if (int rc = make_tuple(ctx, nrows, tuple, &tv)) return rc;
+    int T = eff_threads(ctx->threads, nrows);
+    std::vector<Acc> part((size_t)T);
+    run_blocks(T, nrows, [&](int t, int64_t b, int64_t e) {
+        Acc a{}; double v[SDQH_TUPLE_MAX_VALUES] = {0, 0, 0, 0};
+        for (int64_t r = b; r < e; ++r) {
+            if (!fv.pass(r)) continue;
+            tv.eval(r, v);
+            for (int k = 0; k < tv.nv; ++k) a.v[k] += v[k];
+            a.n += 1;
+        }
+        part[(size_t)t] = a;
+    });
+    Acc total{};
+    for (int t = 0; t < T; ++t) { for (int k = 0; k < tv.nv; ++k) total.v[k] += part[(size_t)t].v[k]; total.n += part[(size_t)t].n; }
+    if (out_values) for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) out_values[k] = k < tv.nv ? total.v[k] : 0.0;
+    if (out_count) *out_count = total.n;
+    ctx->last_ms = tm.ms();
+    return SDQH_OK;
+}
+
+// ---- K-C small ---------------------------------------------------------------------------------
+int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nkeys,
+                       const sdqh_column* const* keys, const sdqh_tuple* tuple, int max_groups,
+                       int64_t* out_keys, double* out_values, int64_t* out_counts, int32_t* out_ngroups) {
+    if (!ctx || nrows < 0 || nkeys < 1 || nkeys > SDQH_MAX_GROUPKEYS || !keys || max_groups < 1 ||
+        max_groups > SDQH_MAX_SMALL_GROUPS || !out_ngroups)
+        return fail(ctx, SDQH_ERR_INVALID, "groupby_small: bad arguments");
+    Timer tm;
+    FilterView fv; TupleView tv;
+    if (int rc = make_filter(ctx, nrows, filter, 0, nullptr, &fv)) return rc;
+    if (int rc = make_tuple(ctx, nrows, tuple, &tv)) return rc;
+    const void* kp[SDQH_MAX_GROUPKEYS]; bool kstr[SDQH_MAX_GROUPKEYS];
+    for (int k = 0; k < nkeys; ++k) {
+        if (!keys[k] || keys[k]->nrows < nrows) return fail(ctx, SDQH_ERR_INVALID, "groupby_small: bad key column");
+        if (keys[k]->dtype == SDQH_STR) { if (keys[k]->width != 1) return fail(ctx, SDQH_ERR_UNSUPPORTED, "groupby_small: STR keys must have width 1"); kstr[k] = true; }
+        else if (keys[k]->dtype == SDQH_I64) kstr[k] = false;
+        else return fail(ctx, SDQH_ERR_UNSUPPORTED, "groupby_small: key dtype");
+        kp[k] = keys[k]->data;
+    }
+    struct Group { int64_t key[SDQH_MAX_GROUPKEYS]; Acc acc; };
+    int T = eff_threads(ctx->threads, nrows);
+    std::vector<std::vector<Group>> local((size_t)T);
+    std::vector<int> bad((size_t)T, 0);
+    run_blocks(T, nrows, [&](int t, int64_t b, int64_t e) {
+        auto& groups = local[(size_t)t];
+        double v[SDQH_TUPLE_MAX_VALUES] = {0, 0, 0, 0};
+        for (int64_t r = b; r < e; ++r) {
+            if (!fv.pass(r)) continue;
+            int64_t key[SDQH_MAX_GROUPKEYS] = {0, 0};
+            for (int k = 0; k < nkeys; ++k) {
+                key[k] = kstr[k] ? (int64_t)((const uint32_t*)kp[k])[r] : ((const int64_t*)kp[k])[r];
+                if (!kstr[k] && (key[k] < 0 || key[k] > 0xFFFFFFFEll)) bad[(size_t)t] = 1;
+            }
+            Group* g = nullptr;
+            for (auto& x : groups) if (x.key[0] == key[0] && x.key[1] == key[1]) { g = &x; break; }
+            if (!g) { groups.push_back(Group{{key[0], key[1]}, Acc{}}); g = &groups.back(); }
+            tv.eval(r, v);                                           // local[key] += tuple  (generator 402-440)
+            for (int k = 0; k < tv.nv; ++k) g->acc.v[k] += v[k];
+            g->acc.n += 1;
+        }
+    });
+    for (int t = 0; t < T; ++t) if (bad[(size_t)t]) return fail(ctx, SDQH_ERR_UNSUPPORTED, "groupby_small: I64 key outside [0, 2^32-2]");
+    std::vector<Group> global;                                        // AddMap(global, local) per thread, in order
+    for (int t = 0; t < T; ++t)
+        for (auto& x : local[(size_t)t]) {
+            Group* g = nullptr;
+            for (auto& y : global) if (y.key[0] == x.key[0] && y.key[1] == x.key[1]) { g = &y; break; }
+            if (!g) global.push_back(x);
+            else { for (int k = 0; k < tv.nv; ++k) g->acc.v[k] += x.acc.v[k]; g->acc.n += x.acc.n; }
+        }
+    if ((int)global.size() > max_groups) { *out_ngroups = (int32_t)global.size(); return fail(ctx, SDQH_ERR_OVERFLOW, "groupby_small: more groups than max_groups"); }
+    for (size_t g = 0; g < global.size(); ++g) {
+        if (out_keys) for (int k = 0; k < nkeys; ++k) out_keys[g * (size_t)nkeys + k] = global[g].key[k];
+        if (out_values) for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) out_values[g * SDQH_TUPLE_MAX_VALUES + k] = k < tv.nv ? global[g].acc.v[k] : 0.0;
+        if (out_counts) out_counts[g] = global[g].acc.n;
+    }
+    *out_ngroups = (int32_t)global.size();
+    ctx->last_ms = tm.ms();
+    return SDQH_OK;
+}
+
+// ---- K-B ---------------------------------------------------------------------------------------
+int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nprobes, const sdqh_probe* probes,
+                           const sdqh_column* key, int npayload, const sdqh_column* const* payload, int accumulate,
+                           sdqh_table** out) {
+    if (!ctx || nrows < 0 || !out || npayload < 0 || npayload > SDQH_MAX_PAYLOAD) return fail(ctx, SDQH_ERR_INVALID, "hash_build_unique: bad arguments");
+    Timer tm;
+    FilterView fv;
+    if (int rc = make_filter(ctx, nrows, filter, nprobes, probes, &fv)) return rc;
+    if (int rc = check_col(ctx, key, SDQH_I64, nrows, "build key")) return rc;
+    const int64_t* kc = (const int64_t*)key->data;
+    const int64_t* pc[SDQH_MAX_PAYLOAD];
+    for (int p = 0; p < npayload; ++p) {
+        if (!payload || !payload[p] || payload[p]->nrows < nrows || payload[p]->dtype == SDQH_STR)
+            return fail(ctx, SDQH_ERR_INVALID, "hash_build_unique: payload columns must be I64/F64 and cover nrows");
+        pc[p] = (const int64_t*)payload[p]->data;
+    }
+    int T = eff_threads(ctx->threads, nrows);
+    std::vector<std::vector<int64_t>> local((size_t)T);             // per-thread vector of surviving row ids
+    run_blocks(T, nrows, [&](int t, int64_t b, int64_t e) {          // emplace_back(key, payload): generator 331-369
+        auto& v = local[(size_t)t];
+        for (int64_t r = b; r < e; ++r) if (fv.pass(r)) v.push_back(r);
+    });
+    sdqh_table* tb = new sdqh_table();
+    tb->npayload = npayload; tb->accumulate = accumulate != 0;
+    for (int t = 0; t < T; ++t)                                       // global.insert(local.begin(), local.end()): first wins
+        for (int64_t r : local[(size_t)t]) {
+            int64_t e = (int64_t)tb->keys.size();
+            if (tb->index.find_or_insert(kc[r], e) >= 0) continue;
+            tb->keys.push_back(kc[r]);
+            for (int p = 0; p < npayload; ++p) tb->payload.push_back(pc[p][r]);
+        }
+    if (tb->accumulate) tb->acc.assign(tb->keys.size(), Acc{});
+    *out = tb;
+    ctx->last_ms = tm.ms();
+    return SDQH_OK;
+}
+int sdqh_table_size(sdqh_ctx* ctx, const sdqh_table* table, int64_t* entries) {
+    if (!ctx || !table || !entries) return fail(ctx, SDQH_ERR_INVALID, "table_size: bad arguments");
+    if (table->bitmap_only) { int64_t n = 0; for (uint32_t w : table->bm) n += __builtin_popcount(w); *entries = n; }
+    else *entries = (int64_t)table->keys.size();
+    return SDQH_OK;
+}
+void sdqh_table_free(sdqh_ctx*, sdqh_table* table) { delete table; }
+
+// ---- K-C large ---------------------------------------------------------------------------------
+int sdqh_hash_probe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, sdqh_table* table,
+                              const sdqh_column* key, const sdqh_tuple* tuple) {
+    if (!ctx || nrows < 0 || !table) return fail(ctx, SDQH_ERR_INVALID, "hash_probe_aggregate: bad arguments");
+    if (!table->accumulate) return fail(ctx, SDQH_ERR_INVALID, "hash_probe_aggregate: table was built without accumulators");
+    Timer tm;
+    FilterView fv; TupleView tv;
+    if (int rc = make_filter(ctx, nrows, filter, 0, nullptr, &fv)) return rc;
+    if (int rc = make_tuple(ctx, nrows, tuple, &tv)) return rc;
+    if (int rc = check_col(ctx, key, SDQH_I64, nrows, "probe key")) return rc;
+    const int64_t* kc = (const int64_t*)key->data;
+    int T = eff_threads(ctx->threads, nrows);
+    struct Local { I64Index idx; std::vector<int64_t> entry; std::vector<Acc> acc; };
+    std::vector<Local> local((size_t)T);
+    run_blocks(T, nrows, [&](int t, int64_t b, int64_t e) {          // local[key] += tuple: generator 402-440
+        Local& L = local[(size_t)t];
+        double v[SDQH_TUPLE_MAX_VALUES] = {0, 0, 0, 0};
+        for (int64_t r = b; r < e; ++r) {
+            if (!fv.pass(r)) continue;
+            int64_t ent = table->index.find(kc[r]);                  // contains + at: generator 86-96
+            if (ent < 0) continue;
+            int64_t li = L.idx.find_or_insert(ent, (int64_t)L.entry.size());
+            if (li < 0) { li = (int64_t)L.entry.size(); L.entry.push_back(ent); L.acc.push_back(Acc{}); }
+            tv.eval(r, v);
+            Acc& a = L.acc[(size_t)li];
+            for (int k = 0; k < tv.nv; ++k) a.v[k] += v[k];
+            a.n += 1;
+        }
+    });
+    for (int t = 0; t < T; ++t) {                                     // AddMap(global, local) per thread, in order
+        Local& L = local[(size_t)t];
+        for (size_t i = 0; i < L.entry.size(); ++i) {
+            Acc& g = table->acc[(size_t)L.entry[i]];
+            for (int k = 0; k < tv.nv; ++k) g.v[k] += L.acc[i].v[k];
+            g.n += L.acc[i].n;
+        }
+    }
+    ctx->last_ms = tm.ms();
+    return SDQH_OK;
+}
+
+// ---- K-F ---------------------------------------------------------------------------------------
+int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, int64_t capacity,
+                       int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n) {
+    if (!ctx || !table || !out_n || capacity < 0) return fail(ctx, SDQH_ERR_INVALID, "table_compact: bad arguments");
+    if (table->bitmap_only) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_compact: bitmap-only table");
+    Timer tm;
+    int64_t n = 0;
+    for (size_t e = 0; e < table->keys.size(); ++e) {                 // for (auto& x : dict) out[tuple_cat(k,v)] = true: generator 520-568
+        int64_t hits = table->accumulate ? table->acc[e].n : 0;
+        if (hits < min_hits) continue;
+        if (n >= capacity) return fail(ctx, SDQH_ERR_OVERFLOW, "table_compact: capacity too small");
+        if (out_keys) out_keys[n] = table->keys[e];
+        if (out_payload) for (int p = 0; p < table->npayload; ++p) out_payload[(size_t)p * (size_t)capacity + (size_t)n] = table->payload[e * (size_t)table->npayload + (size_t)p];
+        if (out_values) for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) out_values[(size_t)k * (size_t)capacity + (size_t)n] = table->accumulate ? table->acc[e].v[k] : 0.0;
+        if (out_hits) out_hits[n] = hits;
+        ++n;
+    }
+    *out_n = n;
+    ctx->last_ms = tm.ms();
+    return SDQH_OK;
+}
+
+// ---- multi-GPU helpers -------------------------------------------------------------------------
+int sdqh_scan_compact(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nprobes, const sdqh_probe* probes,
+                      int ncols, const sdqh_column* const* cols, sdqh_column** out_cols, int64_t* out_rows) {
+    if (!ctx || nrows < 0 || ncols < 1 || ncols > SDQH_MAX_COMPACT_COLS || !cols || !out_cols || !out_rows)
+        return fail(ctx, SDQH_ERR_INVALID, "scan_compact: bad arguments");
+    Timer tm;
+    FilterView fv;
+    if (int rc = make_filter(ctx, nrows, filter, nprobes, probes, &fv)) return rc;
+    for (int c = 0; c < ncols; ++c) if (!cols[c] || cols[c]->nrows < nrows || cols[c]->dtype == SDQH_STR) return fail(ctx, SDQH_ERR_INVALID, "scan_compact: columns must be I64/F64 and cover nrows");
+    std::vector<int64_t> rows;
+    for (int64_t r = 0; r < nrows; ++r) if (fv.pass(r)) rows.push_back(r);
+    for (int c = 0; c < ncols; ++c) {
+        if (int rc = sdqh_column_alloc(ctx, (int64_t)rows.size(), cols[c]->dtype, 0, &out_cols[c])) return rc;
+        const int64_t* src = (const int64_t*)cols[c]->data; int64_t* dst = (int64_t*)out_cols[c]->data;
+        for (size_t i = 0; i < rows.size(); ++i) dst[i] = src[rows[i]];
+    }
+    *out_rows = (int64_t)rows.size();
+    ctx->last_ms = tm.ms();
+    return SDQH_OK;
+}
+
+int sdqh_partition_by_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int nparts, int ncols,
+                          const sdqh_column* const* cols, sdqh_column** out_cols, int64_t* counts) {
+    if (!ctx || nrows < 0 || nparts < 1 || ncols < 1 || ncols > SDQH_MAX_COMPACT_COLS || !cols || !out_cols || !counts)
+        return fail(ctx, SDQH_ERR_INVALID, "partition_by_key: bad arguments");
+    if (int rc = check_col(ctx, key, SDQH_I64, nrows, "partition key")) return rc;
+    Timer tm;
+    const int64_t* kc = (const int64_t*)key->data;
+    std::vector<int64_t> start((size_t)nparts + 1, 0);
+    for (int64_t r = 0; r < nrows; ++r) start[(size_t)(mix64((uint64_t)kc[r]) % (uint64_t)nparts) + 1]++;
+    for (int p = 0; p < nparts; ++p) { counts[p] = start[(size_t)p + 1]; start[(size_t)p + 1] += start[(size_t)p]; }
+    std::vector<int64_t> dest((size_t)nrows), cur(start.begin(), start.end() - 1);
+    for (int64_t r = 0; r < nrows; ++r) dest[(size_t)r] = cur[(size_t)(mix64((uint64_t)kc[r]) % (uint64_t)nparts)]++;
+    for (int c = 0; c < ncols; ++c) {
+        if (!cols[c] || cols[c]->nrows < nrows || cols[c]->dtype == SDQH_STR) return fail(ctx, SDQH_ERR_INVALID, "partition_by_key: columns must be I64/F64");
+        if (int rc = sdqh_column_alloc(ctx, nrows, cols[c]->dtype, 0, &out_cols[c])) return rc;
+        const int64_t* src = (const int64_t*)cols[c]->data; int64_t* dst = (int64_t*)out_cols[c]->data;
+        for (int64_t r = 0; r < nrows; ++r) dst[dest[(size_t)r]] = src[r];
+    }
+    ctx->last_ms = tm.ms();
+    return SDQH_OK;
+}
+
+int sdqh_table_export_bitmap(sdqh_ctx* ctx, const sdqh_table* table, int64_t lo, int64_t hi, sdqh_column** out_words) {
+    if (!ctx || !table || !out_words || hi < lo) return fail(ctx, SDQH_ERR_INVALID, "table_export_bitmap: bad arguments");
+    uint64_t bits = (uint64_t)(hi - lo) + 1;
+    int64_t words32 = (int64_t)((bits + 31) / 32), words64 = (words32 + 1) / 2;
+    if (int rc = sdqh_column_alloc(ctx, words64, SDQH_I64, 0, out_words)) return rc;
+    uint32_t* w = (uint32_t*)(*out_words)->data;
+    auto set = [&](int64_t k) { if (k >= lo && k <= hi) { uint64_t off = (uint64_t)(k - lo); w[off >> 5] |= 1u << (off & 31); } };
+    if (table->bitmap_only) { for (int64_t k = table->bm_lo; k <= table->bm_hi; ++k) if (table->contains(k)) set(k); }
+    else for (int64_t k : table->keys) set(k);
+    return SDQH_OK;
+}
+
+int sdqh_table_from_bitmap(sdqh_ctx* ctx, const sdqh_column* words, int64_t lo, int64_t hi, sdqh_table** out) {
+    if (!ctx || !words || !out || hi < lo || words->dtype != SDQH_I64) return fail(ctx, SDQH_ERR_INVALID, "table_from_bitmap: bad arguments");
+    uint64_t bits = (uint64_t)(hi - lo) + 1;
+    size_t words32 = (size_t)((bits + 31) / 32);
+    if ((size_t)words->nrows * 2 < words32) return fail(ctx, SDQH_ERR_INVALID, "table_from_bitmap: bitmap too short");
+    sdqh_table* tb = new sdqh_table();
+    tb->bitmap_only = true; tb->bm_lo = lo; tb->bm_hi = hi;
+    tb->bm.assign((const uint32_t*)words->data, (const uint32_t*)words->data + words32);
+    *out = tb;
+    return SDQH_OK;
+}
+
+}  // extern "C"

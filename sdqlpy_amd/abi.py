@@ -1,0 +1,392 @@
+"""ctypes binding of include/sdqh.h.
+
+`Library(path)` loads one implementation of the C ABI and exposes thin, typed wrappers.  The
+product (engine.py) only ever loads sdqlpy_amd/csrc/libsdqlhip.so; the test-suite loads the CPU
+oracle through the same class to compare the two implementations call for call.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_OVERFLOW, ERR_NOMEM = range(6)
+I64, F64, STR = 0, 1, 2
+TUPLE_A, TUPLE_AB, TUPLE_A_1MB, TUPLE_PRICING, TUPLE_A_1MB_M_CD, TUPLE_COUNT = 1, 2, 3, 4, 5, 6
+TUPLE_MAX_VALUES = 4
+TUPLE_NVALUES = {TUPLE_A: 1, TUPLE_AB: 1, TUPLE_A_1MB: 1, TUPLE_PRICING: 4, TUPLE_A_1MB_M_CD: 1, TUPLE_COUNT: 0}
+TUPLE_NOPERANDS = {TUPLE_A: 1, TUPLE_AB: 2, TUPLE_A_1MB: 2, TUPLE_PRICING: 4, TUPLE_A_1MB_M_CD: 4, TUPLE_COUNT: 0}
+MAX_IPRED, MAX_FPRED, MAX_SPRED, MAX_STR_CONST = 4, 4, 1, 64
+MAX_PROBE, MAX_PAYLOAD, MAX_GROUPKEYS, MAX_SMALL_GROUPS, MAX_COMPACT_COLS = 2, 4, 2, 64, 6
+
+INT64_MIN, INT64_MAX = -(1 << 63), (1 << 63) - 1
+
+
+class SdqhError(RuntimeError):
+    def __init__(self, code, message):
+        RuntimeError.__init__(self, "sdqh error %d: %s" % (code, message))
+        self.code = code
+
+
+class _IPred(C.Structure):
+    _fields_ = [("col", C.c_void_p), ("lo", C.c_int64), ("hi", C.c_int64)]
+
+
+class _FPred(C.Structure):
+    _fields_ = [("col", C.c_void_p), ("lo", C.c_double), ("hi", C.c_double)]
+
+
+class _SPred(C.Structure):
+    _fields_ = [("col", C.c_void_p), ("len", C.c_int32), ("negate", C.c_int32), ("value", C.c_uint32 * MAX_STR_CONST)]
+
+
+class Filter(C.Structure):
+    _fields_ = [("n_ipred", C.c_int32), ("n_fpred", C.c_int32), ("n_spred", C.c_int32), ("_pad", C.c_int32),
+                ("ipred", _IPred * MAX_IPRED), ("fpred", _FPred * MAX_FPRED), ("spred", _SPred * MAX_SPRED)]
+
+
+class Tuple(C.Structure):
+    _fields_ = [("shape", C.c_int32), ("_pad", C.c_int32),
+                ("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p), ("d", C.c_void_p)]
+
+
+class Probe(C.Structure):
+    _fields_ = [("table", C.c_void_p), ("key", C.c_void_p)]
+
+
+EXPORTS = [
+    "sdqh_abi_version", "sdqh_backend_name", "sdqh_create", "sdqh_destroy", "sdqh_last_error", "sdqh_set_threads",
+    "sdqh_synchronize", "sdqh_last_device_ms", "sdqh_set_profiling", "sdqh_profile_count", "sdqh_profile_entry",
+    "sdqh_stream",
+    "sdqh_column_upload", "sdqh_column_wrap", "sdqh_column_alloc", "sdqh_column_download", "sdqh_column_data",
+    "sdqh_column_rows", "sdqh_column_dtype", "sdqh_column_width", "sdqh_column_minmax", "sdqh_column_free",
+    "sdqh_scan_filter_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_table_size", "sdqh_table_free",
+    "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_scan_compact", "sdqh_partition_by_key",
+    "sdqh_table_export_bitmap", "sdqh_table_from_bitmap",
+]
+
+
+def _np_ptr(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(None)
+
+
+class Column:
+    """Device (or, for the oracle, host) resident column handle."""
+
+    def __init__(self, ctx, handle, nrows, dtype, width, keepalive=None):
+        self.ctx, self.handle, self.nrows, self.dtype, self.width = ctx, handle, int(nrows), dtype, width
+        self._keepalive = keepalive
+
+    def free(self):
+        if self.handle is not None:
+            self.ctx.lib.sdqh_column_free(self.ctx.handle, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def download(self, row0=0, nrows=None):
+        n = self.nrows - row0 if nrows is None else nrows
+        if self.dtype == I64:
+            out = np.empty(n, np.int64)
+        elif self.dtype == F64:
+            out = np.empty(n, np.float64)
+        else:
+            out = np.empty(n, "<U%d" % self.width)
+        self.ctx._check(self.ctx.lib.sdqh_column_download(self.ctx.handle, self.handle, C.c_int64(row0), C.c_int64(n), _np_ptr(out)))
+        return out
+
+    def minmax(self):
+        lo, hi = C.c_int64(), C.c_int64()
+        self.ctx._check(self.ctx.lib.sdqh_column_minmax(self.ctx.handle, self.handle, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def data_ptr(self):
+        return self.ctx.lib.sdqh_column_data(self.handle)
+
+
+class Table:
+    def __init__(self, ctx, handle, npayload=0, accumulate=False):
+        self.ctx, self.handle, self.npayload, self.accumulate = ctx, handle, npayload, accumulate
+
+    def free(self):
+        if self.handle is not None:
+            self.ctx.lib.sdqh_table_free(self.ctx.handle, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def size(self):
+        n = C.c_int64()
+        self.ctx._check(self.ctx.lib.sdqh_table_size(self.ctx.handle, self.handle, C.byref(n)))
+        return n.value
+
+
+def make_filter(ipreds=(), fpreds=(), spreds=()):
+    """ipreds: [(Column, lo, hi)], fpreds: [(Column, lo, hi)], spreds: [(Column, 'text', negate)]."""
+    f = Filter()
+    if len(ipreds) > MAX_IPRED or len(fpreds) > MAX_FPRED or len(spreds) > MAX_SPRED:
+        raise SdqhError(ERR_UNSUPPORTED, "too many predicates for one filter")
+    f.n_ipred, f.n_fpred, f.n_spred = len(ipreds), len(fpreds), len(spreds)
+    for i, (col, lo, hi) in enumerate(ipreds):
+        f.ipred[i].col, f.ipred[i].lo, f.ipred[i].hi = col.handle, max(INT64_MIN, lo), min(INT64_MAX, hi)
+    for i, (col, lo, hi) in enumerate(fpreds):
+        f.fpred[i].col, f.fpred[i].lo, f.fpred[i].hi = col.handle, lo, hi
+    for i, (col, text, negate) in enumerate(spreds):
+        if len(text) > MAX_STR_CONST:
+            raise SdqhError(ERR_UNSUPPORTED, "string constant longer than %d" % MAX_STR_CONST)
+        f.spred[i].col, f.spred[i].len, f.spred[i].negate = col.handle, len(text), 1 if negate else 0
+        for k, ch in enumerate(text):
+            f.spred[i].value[k] = ord(ch)
+    f._keep = (ipreds, fpreds, spreds)
+    return f
+
+
+def make_tuple(shape, operands=()):
+    t = Tuple()
+    t.shape = shape
+    if len(operands) != TUPLE_NOPERANDS[shape]:
+        raise SdqhError(ERR_INVALID, "tuple shape %d takes %d operands" % (shape, TUPLE_NOPERANDS[shape]))
+    for name, col in zip("abcd", operands):
+        setattr(t, name, col.handle)
+    t._keep = operands
+    return t
+
+
+def lt_float(c):
+    """hi bound equivalent to `x < c`."""
+    return math.nextafter(c, -math.inf)
+
+
+def gt_float(c):
+    """lo bound equivalent to `x > c`."""
+    return math.nextafter(c, math.inf)
+
+
+class Context:
+    def __init__(self, lib, device=0, threads=1):
+        self.lib = lib.cdll
+        self.library = lib
+        h = C.c_void_p()
+        rc = self.lib.sdqh_create(C.c_int(device), C.byref(h))
+        if rc != OK:
+            raise SdqhError(rc, "sdqh_create(device=%d) failed" % device)
+        self.handle = h
+        self.device = device
+        self._check(self.lib.sdqh_set_threads(self.handle, C.c_int(max(1, threads))))
+
+    def close(self):
+        if self.handle is not None:
+            self.lib.sdqh_destroy(self.handle)
+            self.handle = None
+
+    def _check(self, rc):
+        if rc != OK:
+            raise SdqhError(rc, self.lib.sdqh_last_error(self.handle).decode())
+
+    # -- plumbing ----------------------------------------------------------------------------
+    def set_threads(self, n):
+        self._check(self.lib.sdqh_set_threads(self.handle, C.c_int(n)))
+
+    def synchronize(self):
+        self._check(self.lib.sdqh_synchronize(self.handle))
+
+    def last_device_ms(self):
+        ms = C.c_double()
+        self._check(self.lib.sdqh_last_device_ms(self.handle, C.byref(ms)))
+        return ms.value
+
+    def set_profiling(self, on):
+        self._check(self.lib.sdqh_set_profiling(self.handle, C.c_int(1 if on else 0)))
+
+    def profile(self):
+        out = []
+        for i in range(self.lib.sdqh_profile_count(self.handle)):
+            name, ms = C.c_char_p(), C.c_double()
+            self._check(self.lib.sdqh_profile_entry(self.handle, C.c_int(i), C.byref(name), C.byref(ms)))
+            out.append((name.value.decode(), ms.value))
+        return out
+
+    def stream(self):
+        return self.lib.sdqh_stream(self.handle)
+
+    # -- columns -----------------------------------------------------------------------------
+    @staticmethod
+    def _classify(arr):
+        if arr.dtype == np.int64:
+            return I64, 0
+        if arr.dtype == np.float64:
+            return F64, 0
+        if arr.dtype.kind == "U":
+            return STR, arr.dtype.itemsize // 4
+        raise SdqhError(ERR_INVALID, "unsupported column dtype %s (int64 / float64 / '<U n' only)" % arr.dtype)
+
+    def upload(self, arr):
+        """numpy column -> resident Column.  Validates what the reference silently assumes
+        (reference sdql_compiler.py:644-668 does no dtype / contiguity checks)."""
+        if not isinstance(arr, np.ndarray) or arr.ndim != 1:
+            raise SdqhError(ERR_INVALID, "a column must be a 1-d numpy array")
+        if not arr.flags.c_contiguous:
+            raise SdqhError(ERR_INVALID, "a column must be C-contiguous")
+        if arr.dtype.kind == "U" and arr.dtype.byteorder == ">":
+            raise SdqhError(ERR_INVALID, "big-endian unicode columns are not supported")
+        dtype, width = self._classify(arr)
+        h = C.c_void_p()
+        self._check(self.lib.sdqh_column_upload(self.handle, _np_ptr(arr), C.c_int64(len(arr)), C.c_int(dtype), C.c_int(width), C.byref(h)))
+        return Column(self, h, len(arr), dtype, width)
+
+    def wrap(self, device_ptr, nrows, dtype, width=0, keepalive=None):
+        h = C.c_void_p()
+        self._check(self.lib.sdqh_column_wrap(self.handle, C.c_void_p(device_ptr), C.c_int64(nrows), C.c_int(dtype), C.c_int(width), C.byref(h)))
+        return Column(self, h, nrows, dtype, width, keepalive)
+
+    def alloc(self, nrows, dtype, width=0):
+        h = C.c_void_p()
+        self._check(self.lib.sdqh_column_alloc(self.handle, C.c_int64(nrows), C.c_int(dtype), C.c_int(width), C.byref(h)))
+        return Column(self, h, nrows, dtype, width)
+
+    # -- pattern calls -----------------------------------------------------------------------
+    def scan_filter_sum(self, nrows, flt, tup):
+        vals = (C.c_double * TUPLE_MAX_VALUES)()
+        cnt = C.c_int64()
+        self._check(self.lib.sdqh_scan_filter_sum(self.handle, C.c_int64(nrows), C.byref(flt), C.byref(tup), vals, C.byref(cnt)))
+        return list(vals)[: TUPLE_NVALUES[tup.shape]], cnt.value
+
+    def groupby_small(self, nrows, flt, keys, tup, max_groups=MAX_SMALL_GROUPS):
+        nk = len(keys)
+        karr = (C.c_void_p * nk)(*[k.handle for k in keys])
+        out_keys = np.zeros((max_groups, nk), np.int64)
+        out_vals = np.zeros((max_groups, TUPLE_MAX_VALUES), np.float64)
+        out_cnt = np.zeros(max_groups, np.int64)
+        ng = C.c_int32()
+        self._check(self.lib.sdqh_groupby_small(self.handle, C.c_int64(nrows), C.byref(flt), C.c_int(nk), karr, C.byref(tup),
+                                                C.c_int(max_groups), _np_ptr(out_keys), _np_ptr(out_vals), _np_ptr(out_cnt), C.byref(ng)))
+        n = ng.value
+        return out_keys[:n], out_vals[:n, : TUPLE_NVALUES[tup.shape]], out_cnt[:n]
+
+    def hash_build_unique(self, nrows, flt, probes, key, payload=(), accumulate=False):
+        parr = (Probe * max(1, len(probes)))()
+        for i, (tbl, kcol) in enumerate(probes):
+            parr[i].table, parr[i].key = tbl.handle, kcol.handle
+        pl = (C.c_void_p * max(1, len(payload)))(*[p.handle for p in payload])
+        h = C.c_void_p()
+        self._check(self.lib.sdqh_hash_build_unique(self.handle, C.c_int64(nrows), C.byref(flt), C.c_int(len(probes)), parr, key.handle,
+                                                    C.c_int(len(payload)), pl, C.c_int(1 if accumulate else 0), C.byref(h)))
+        t = Table(self, h, len(payload), accumulate)
+        t._keep = (probes, key, payload)
+        return t
+
+    def hash_probe_aggregate(self, nrows, flt, table, key, tup):
+        self._check(self.lib.sdqh_hash_probe_aggregate(self.handle, C.c_int64(nrows), C.byref(flt), table.handle, key.handle, C.byref(tup)))
+
+    def table_compact(self, table, min_hits, capacity, want_payload=True, want_values=True):
+        cap = max(1, int(capacity))
+        keys = np.empty(cap, np.int64)
+        payload = np.empty((max(1, table.npayload), cap), np.int64) if want_payload and table.npayload else None
+        values = np.empty((TUPLE_MAX_VALUES, cap), np.float64) if want_values and table.accumulate else None
+        hits = np.empty(cap, np.int64)
+        n = C.c_int64()
+        self._check(self.lib.sdqh_table_compact(self.handle, table.handle, C.c_int64(min_hits), C.c_int64(cap), _np_ptr(keys),
+                                                _np_ptr(payload), _np_ptr(values), _np_ptr(hits), C.byref(n)))
+        n = n.value
+        return (keys[:n], None if payload is None else payload[:, :n], None if values is None else values[:, :n], hits[:n])
+
+    def scan_compact(self, nrows, flt, probes, cols):
+        parr = (Probe * max(1, len(probes)))()
+        for i, (tbl, kcol) in enumerate(probes):
+            parr[i].table, parr[i].key = tbl.handle, kcol.handle
+        carr = (C.c_void_p * len(cols))(*[c.handle for c in cols])
+        outs = (C.c_void_p * len(cols))()
+        n = C.c_int64()
+        self._check(self.lib.sdqh_scan_compact(self.handle, C.c_int64(nrows), C.byref(flt), C.c_int(len(probes)), parr,
+                                               C.c_int(len(cols)), carr, outs, C.byref(n)))
+        return [Column(self, C.c_void_p(outs[i]), n.value, cols[i].dtype, 0) for i in range(len(cols))], n.value
+
+    def partition_by_key(self, nrows, key, nparts, cols):
+        carr = (C.c_void_p * len(cols))(*[c.handle for c in cols])
+        outs = (C.c_void_p * len(cols))()
+        counts = np.zeros(nparts, np.int64)
+        self._check(self.lib.sdqh_partition_by_key(self.handle, C.c_int64(nrows), key.handle, C.c_int(nparts), C.c_int(len(cols)),
+                                                   carr, outs, _np_ptr(counts)))
+        return [Column(self, C.c_void_p(outs[i]), nrows, cols[i].dtype, 0) for i in range(len(cols))], counts
+
+    def table_export_bitmap(self, table, lo, hi):
+        h = C.c_void_p()
+        self._check(self.lib.sdqh_table_export_bitmap(self.handle, table.handle, C.c_int64(lo), C.c_int64(hi), C.byref(h)))
+        words32 = ((hi - lo + 1) + 31) // 32
+        return Column(self, h, (words32 + 1) // 2, I64, 0)
+
+    def table_from_bitmap(self, words, lo, hi):
+        h = C.c_void_p()
+        self._check(self.lib.sdqh_table_from_bitmap(self.handle, words.handle, C.c_int64(lo), C.c_int64(hi), C.byref(h)))
+        t = Table(self, h, 0, False)
+        t._keep = (words,)
+        return t
+
+
+class Library:
+    """One loaded implementation of the ABI."""
+
+    def __init__(self, path):
+        self.path = path
+        self.cdll = C.CDLL(path)
+        missing = [s for s in EXPORTS if not hasattr(self.cdll, s)]
+        if missing:
+            raise OSError("%s does not export: %s" % (path, ", ".join(missing)))
+        L = self.cdll
+        L.sdqh_backend_name.restype = C.c_char_p
+        L.sdqh_last_error.restype = C.c_char_p
+        L.sdqh_last_error.argtypes = [C.c_void_p]
+        L.sdqh_destroy.restype = None
+        L.sdqh_destroy.argtypes = [C.c_void_p]
+        L.sdqh_stream.restype = C.c_void_p
+        L.sdqh_stream.argtypes = [C.c_void_p]
+        L.sdqh_column_data.restype = C.c_void_p
+        L.sdqh_column_data.argtypes = [C.c_void_p]
+        L.sdqh_column_rows.restype = C.c_int64
+        L.sdqh_column_rows.argtypes = [C.c_void_p]
+        L.sdqh_column_dtype.argtypes = [C.c_void_p]
+        L.sdqh_column_width.argtypes = [C.c_void_p]
+        L.sdqh_column_free.restype = None
+        L.sdqh_column_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.sdqh_table_free.restype = None
+        L.sdqh_table_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.sdqh_set_threads.argtypes = [C.c_void_p, C.c_int]
+        L.sdqh_synchronize.argtypes = [C.c_void_p]
+        L.sdqh_last_device_ms.argtypes = [C.c_void_p, C.c_void_p]
+        L.sdqh_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.sdqh_profile_count.argtypes = [C.c_void_p]
+        L.sdqh_profile_entry.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.sdqh_column_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
+        L.sdqh_column_wrap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
+        L.sdqh_column_alloc.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
+        L.sdqh_column_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.sdqh_column_minmax.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sdqh_scan_filter_sum.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sdqh_groupby_small.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sdqh_hash_build_unique.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                             C.c_void_p, C.c_int, C.c_void_p]
+        L.sdqh_table_size.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sdqh_hash_probe_aggregate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sdqh_table_compact.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]
+        L.sdqh_scan_compact.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]
+        L.sdqh_partition_by_key.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sdqh_table_export_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.sdqh_table_from_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        if L.sdqh_abi_version() != 1:
+            raise OSError("%s: ABI version %d, expected 1" % (path, L.sdqh_abi_version()))
+
+    def backend_name(self):
+        return self.cdll.sdqh_backend_name().decode()
+
+    def context(self, device=0, threads=1):
+        return Context(self, device, threads)

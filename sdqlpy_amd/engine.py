@@ -1,0 +1,418 @@
+"""Planner + executor: scan-operator IR (frontend.py) -> pattern calls of the C ABI (include/sdqh.h).
+
+An `Engine` owns one ABI context (one GPU, one stream) and a cache of resident columns, so that —
+like the reference, which times queries with the tables already loaded in RAM
+(reference src/sdqlpy/sdql_lib.py:445-451) — repeated runs of a query find their columns in HBM.
+
+Mapping of the reference's emitted loop shapes (src/sdqlpy/lib/sdql_ir_cpp_generator_par.py) to calls:
+
+    K-A  scalar reduce            258-291  -> sdqh_scan_filter_sum
+    K-C  aggregating dict, small  402-440  -> sdqh_groupby_small
+    K-B  unique dict build        331-369  -> sdqh_hash_build_unique  (semi-join probes fused in)
+    K-C  probe + aggregate        402-440  -> sdqh_hash_probe_aggregate (group = matched entry)
+    K-F  finalise                 520-568  -> sdqh_table_compact / host reshape of <=64 groups
+
+Anything else raises frontend.UnsupportedQuery.  There is no CPU execution path here.
+"""
+import os
+
+import numpy as np
+
+from . import abi, build
+from .frontend import (And, Bin, Call, Cmp, Col, Const, Contains, FinalizeOp, Lookup, PayloadField, RecordCons,
+                       ScanOp, StrIn, UnsupportedQuery)
+from .result import DictResult, ResultSet
+
+# value-tuple vocabulary: canonical shape of the whole value record -> (ABI shape, index of the COUNT field or None)
+TUPLE_SHAPES = {
+    "c0": (abi.TUPLE_A, None),
+    "(c0*c1)": (abi.TUPLE_AB, None),
+    "(c0*(1.0-c1))": (abi.TUPLE_A_1MB, None),
+    "c0;c1;(c1*(1.0-c2));((c1*(1.0-c2))*(1.0+c3));1": (abi.TUPLE_PRICING, 4),
+    "((c0*(1.0-c1))-(c2*c3))": (abi.TUPLE_A_1MB_M_CD, None),
+    "1": (abi.TUPLE_COUNT, 0),
+}
+
+_engine = None
+
+
+def load_hip_library():
+    """Load libsdqlhip.so, building it in-tree if it is missing.  Raises if that is impossible."""
+    path = build.HIP_LIB
+    if not os.path.exists(path) or os.environ.get("SDQLPY_AMD_REBUILD") == "1":
+        build.build_hip(force=True)
+    lib = abi.Library(path)
+    if lib.backend_name() != "hip-gfx950":
+        raise RuntimeError("%s is not the HIP backend (reports '%s')" % (path, lib.backend_name()))
+    return lib
+
+
+def default_engine(device=None, threads=1):
+    global _engine
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    if _engine is None or _engine.ctx.device != device:
+        _engine = Engine(load_hip_library().context(device=device, threads=threads))
+    return _engine
+
+
+def reset_default_engine():
+    global _engine
+    if _engine is not None:
+        _engine.close()
+    _engine = None
+
+
+class Engine:
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self._columns = {}         # id(ndarray) -> (ndarray, abi.Column)
+        self.resident_bytes = 0
+        self.last_ops = []         # [(label, device_ms)] of the most recent query
+
+    def close(self):
+        self.clear()
+        self.ctx.close()
+
+    def clear(self):
+        for _, col in self._columns.values():
+            col.free()
+        self._columns.clear()
+        self.resident_bytes = 0
+
+    def column(self, arr):
+        """Resident column for a host array (uploaded on first use, then cached by identity)."""
+        hit = self._columns.get(id(arr))
+        if hit is not None and hit[0] is arr:
+            return hit[1]
+        col = self.ctx.upload(arr)
+        self._columns[id(arr)] = (arr, col)
+        self.resident_bytes += arr.nbytes
+        return col
+
+    def adopt(self, arr, col):
+        """Register an already-resident column for a host array identity (multi-GPU exchange buffers)."""
+        self._columns[id(arr)] = (arr, col)
+
+
+# ---- tables as the planner sees them -----------------------------------------------------------
+class HostTable:
+    """A columnar table argument: header name -> numpy array."""
+    def __init__(self, name, srdict):
+        c = srdict.getContainer()
+        if not (isinstance(c, dict) and "headers" in c and "data" in c):
+            raise TypeError("argument '%s' is not a columnar table (read_csv / tpch.generate output)" % name)
+        self.name = name
+        self.cols = dict(zip(c["headers"], c["data"]))
+        self.nrows = len(c["data"][0]) if c["data"] else 0
+
+    def array(self, col, op):
+        if col not in self.cols:
+            raise UnsupportedQuery("line %d: table '%s' has no column '%s'" % (op.lineno, self.name, col))
+        return self.cols[col]
+
+
+class BuiltTable:
+    """Result of a unique build, resident on the device."""
+    def __init__(self, table, key_name, key_is_record, val_fields, val_is_record, row_arrays):
+        self.table = table                  # abi.Table
+        self.key_name, self.key_is_record = key_name, key_is_record
+        self.val_fields = val_fields        # [(field name, "key" | payload index)]
+        self.val_is_record = val_is_record
+        self.payload_dtypes = row_arrays    # payload index -> numpy dtype
+        self.agg = None                     # set by a fused probe-aggregate: (key_fields, val_names, tuple shape)
+
+
+# ---- predicate / tuple lowering ----------------------------------------------------------------
+def _flip(op):
+    return {"<": ">", "<=": ">=", ">": "<", ">=": "<=", "==": "==", "!=": "!="}[op]
+
+
+def _build_filter(eng, op, htab, conds):
+    """conds -> (abi.Filter, [semi-join lookups])."""
+    iranges, franges, spreds, lookups = {}, {}, [], []
+    for c in conds:
+        if isinstance(c, Contains):
+            lookups.append(c.lookup)
+            continue
+        if isinstance(c, StrIn):
+            raise UnsupportedQuery("line %d: substring predicates are not in the HIP backend's vocabulary yet" % op.lineno)
+        if not isinstance(c, Cmp):
+            raise UnsupportedQuery("line %d: unsupported condition %r" % (op.lineno, c))
+        left, right, sym = c.left, c.right, c.op
+        if isinstance(left, Const) and isinstance(right, Col):
+            left, right, sym = right, left, _flip(sym)
+        if not (isinstance(left, Col) and isinstance(right, Const)):
+            raise UnsupportedQuery("line %d: only <column> <op> <constant> comparisons are supported (%r)" % (op.lineno, c))
+        arr = htab.array(left.name, op)
+        v = right.value
+        if arr.dtype.kind == "U":
+            if sym not in ("==", "!=") or not isinstance(v, str):
+                raise UnsupportedQuery("line %d: string columns support == / != against a literal" % op.lineno)
+            spreds.append((eng.column(arr), v, sym == "!="))
+        elif arr.dtype == np.int64:
+            lo, hi = iranges.get(left.name, (abi.INT64_MIN, abi.INT64_MAX))
+            if isinstance(v, float) and v != int(v):      # x < 24.5  <=>  x <= 24
+                fl = int(np.floor(v))
+                v_lt, v_le, v_gt, v_ge = fl, fl, fl + 1, fl + 1
+            else:
+                v = int(v)
+                v_lt, v_le, v_gt, v_ge = v - 1, v, v + 1, v
+            if sym == "<": hi = min(hi, v_lt)
+            elif sym == "<=": hi = min(hi, v_le)
+            elif sym == ">": lo = max(lo, v_gt)
+            elif sym == ">=": lo = max(lo, v_ge)
+            elif sym == "==":
+                if isinstance(v, float):
+                    lo, hi = 1, 0
+                else:
+                    lo, hi = max(lo, v), min(hi, v)
+            else:
+                raise UnsupportedQuery("line %d: != on numeric columns is not supported" % op.lineno)
+            iranges[left.name] = (lo, hi)
+        elif arr.dtype == np.float64:
+            lo, hi = franges.get(left.name, (-np.inf, np.inf))
+            v = float(v)
+            if sym == "<": hi = min(hi, abi.lt_float(v))
+            elif sym == "<=": hi = min(hi, v)
+            elif sym == ">": lo = max(lo, abi.gt_float(v))
+            elif sym == ">=": lo = max(lo, v)
+            elif sym == "==": lo, hi = max(lo, v), min(hi, v)
+            else:
+                raise UnsupportedQuery("line %d: != on numeric columns is not supported" % op.lineno)
+            franges[left.name] = (lo, hi)
+        else:
+            raise UnsupportedQuery("line %d: column '%s' has unsupported dtype %s" % (op.lineno, left.name, arr.dtype))
+    ip = [(eng.column(htab.array(n, op)), lo, hi) for n, (lo, hi) in iranges.items()]
+    fp = [(eng.column(htab.array(n, op)), lo, hi) for n, (lo, hi) in franges.items()]
+    try:
+        return abi.make_filter(ip, fp, spreds), lookups
+    except abi.SdqhError as exc:
+        raise UnsupportedQuery("line %d: %s" % (op.lineno, exc))
+
+
+def _build_tuple(eng, op, htab, val):
+    """value record / scalar -> (abi.Tuple, [field names], count field index or None)."""
+    if isinstance(val, RecordCons):
+        names = [n for n, _ in val.fields]
+        exprs = [e for _, e in val.fields]
+    else:
+        names, exprs = [None], [val]
+    slots = []
+    try:
+        shape = ";".join(e.shape(slots) for e in exprs)
+    except NotImplementedError:
+        raise UnsupportedQuery("line %d: value expression outside the backend's vocabulary: %r" % (op.lineno, val))
+    if shape not in TUPLE_SHAPES:
+        raise UnsupportedQuery("line %d: value tuple shape '%s' is not in the HIP backend's vocabulary %s"
+                               % (op.lineno, shape, sorted(TUPLE_SHAPES)))
+    abi_shape, count_idx = TUPLE_SHAPES[shape]
+    operands = []
+    for kind in slots:
+        if kind[0] != "col":
+            raise UnsupportedQuery("line %d: value operands must be columns of the scanned table" % op.lineno)
+        arr = htab.array(kind[1], op)
+        if arr.dtype != np.float64:
+            raise UnsupportedQuery("line %d: value operand '%s' must be a float column" % (op.lineno, kind[1]))
+        operands.append(eng.column(arr))
+    return abi.make_tuple(abi_shape, operands), names, count_idx
+
+
+def _value_arrays(names, count_idx, values, counts):
+    """Scatter the ABI's (doubles, count) outputs back to the value record's fields."""
+    out, v = [], 0
+    for i, n in enumerate(names):
+        if count_idx is not None and i == count_idx:
+            out.append((n, np.asarray(counts, np.int64)))
+        else:
+            out.append((n, np.asarray(values[v], np.float64)))
+            v += 1
+    return out
+
+
+# ---- operator execution ------------------------------------------------------------------------
+def _probe_list(eng, op, htab, env, lookups):
+    probes = []
+    for lk in lookups:
+        if lk.dict_name not in env or not isinstance(env[lk.dict_name], BuiltTable):
+            raise UnsupportedQuery("line %d: '%s' is not a built table" % (op.lineno, lk.dict_name))
+        if not isinstance(lk.key, Col):
+            raise UnsupportedQuery("line %d: composite / derived lookup keys are not in the HIP backend's vocabulary yet" % op.lineno)
+        arr = htab.array(lk.key.name, op)
+        if arr.dtype != np.int64:
+            raise UnsupportedQuery("line %d: lookup key '%s' must be an int column" % (op.lineno, lk.key.name))
+        probes.append((env[lk.dict_name].table, eng.column(arr)))
+    return probes
+
+
+def _run_scan(eng, op, htab, env, accumulate_into):
+    ctx = eng.ctx
+    flt, lookups = _build_filter(eng, op, htab, op.conds)
+    n = htab.nrows
+
+    if op.kind == "scalar":
+        if lookups or op.probe:
+            raise UnsupportedQuery("line %d: scalar sums with lookups are not supported yet" % op.lineno)
+        tup, _, count_idx = _build_tuple(eng, op, htab, op.val)
+        vals, cnt = ctx.scan_filter_sum(n, flt, tup)
+        return float(cnt) if count_idx is not None else float(vals[0])
+
+    # ---- dictionary outputs ----
+    key_is_record = isinstance(op.key, RecordCons)
+    key_fields = op.key.fields if key_is_record else [(None, op.key)]
+
+    if op.unique:
+        # K-B: unique build keyed by one int column of the scanned row
+        if len(key_fields) != 1 or not isinstance(key_fields[0][1], Col):
+            raise UnsupportedQuery("line %d: unique builds need a single int column as key (composite keys: not yet)" % op.lineno)
+        kname = key_fields[0][1].name
+        karr = htab.array(kname, op)
+        if karr.dtype != np.int64:
+            raise UnsupportedQuery("line %d: build key '%s' must be an int column" % (op.lineno, kname))
+        val_is_record = isinstance(op.val, RecordCons)
+        vfields = op.val.fields if val_is_record else ([] if (isinstance(op.val, Const) and op.val.value is True) else [(None, op.val)])
+        payload_cols, payload_dtypes, val_fields = [], [], []
+        for fname, e in vfields:
+            if not isinstance(e, Col):
+                raise UnsupportedQuery("line %d: build payloads must be columns of the scanned row (derived payloads: not yet)" % op.lineno)
+            if e.name == kname:
+                val_fields.append((fname, "key"))
+                continue
+            arr = htab.array(e.name, op)
+            if arr.dtype.kind == "U":
+                raise UnsupportedQuery("line %d: string payloads are not supported yet" % op.lineno)
+            val_fields.append((fname, len(payload_cols)))
+            payload_cols.append(eng.column(arr))
+            payload_dtypes.append(arr.dtype)
+        probes = _probe_list(eng, op, htab, env, ([op.probe] if op.probe else []) + lookups)
+        table = ctx.hash_build_unique(n, flt, probes, eng.column(karr), payload_cols, accumulate=op.out in accumulate_into)
+        return BuiltTable(table, key_fields[0][0] or kname, key_is_record, val_fields, val_is_record, payload_dtypes)
+
+    # ---- aggregations ----
+    tup, vnames, count_idx = _build_tuple(eng, op, htab, op.val)
+    val_is_record = isinstance(op.val, RecordCons)
+
+    if op.probe is None and not lookups:
+        # K-C small domain: every key field is a column of the scanned row
+        kcols, decoders = [], []
+        for fname, e in key_fields:
+            if not isinstance(e, Col):
+                raise UnsupportedQuery("line %d: group keys must be columns of the scanned row" % op.lineno)
+            arr = htab.array(e.name, op)
+            if arr.dtype.kind == "U" and arr.dtype.itemsize == 4:
+                decoders.append("U1")
+            elif arr.dtype == np.int64:
+                decoders.append("i8")
+            else:
+                raise UnsupportedQuery("line %d: group key '%s' must be a string(1) or int column" % (op.lineno, e.name))
+            kcols.append(eng.column(arr))
+        try:
+            keys, vals, cnts = ctx.groupby_small(n, flt, kcols, tup)
+        except abi.SdqhError as exc:
+            if exc.code == abi.ERR_OVERFLOW:
+                raise UnsupportedQuery("line %d: more than %d groups: large-domain group-by on row columns is not in the "
+                                       "HIP backend's vocabulary yet" % (op.lineno, abi.MAX_SMALL_GROUPS))
+            raise
+        kf = []
+        for i, (fname, e) in enumerate(key_fields):
+            col = keys[:, i]
+            kf.append((fname or e.name, col.astype(np.uint32).view("<U1") if decoders[i] == "U1" else col.copy()))
+        vf = _value_arrays(vnames, count_idx, [vals[:, j] for j in range(vals.shape[1])], cnts)
+        return DictResult(kf, vf, key_is_record, val_is_record)
+
+    # K-C large: the group is the matched entry of the probed table
+    if op.probe is None or lookups:
+        raise UnsupportedQuery("line %d: aggregations with extra lookups are not supported yet" % op.lineno)
+    bt = env.get(op.probe.dict_name)
+    if not isinstance(bt, BuiltTable) or not isinstance(op.probe.key, Col):
+        raise UnsupportedQuery("line %d: joinProbe index must be a built table probed by a column" % op.lineno)
+    pk = op.probe.key.name
+    out_key_fields = []
+    for fname, e in key_fields:
+        if isinstance(e, Col) and e.name == pk:
+            out_key_fields.append((fname or pk, "key"))
+        elif isinstance(e, PayloadField) and e.lookup.dict_name == op.probe.dict_name and repr(e.lookup.key) == repr(op.probe.key):
+            src = dict(bt.val_fields).get(e.field) if e.field is not None else (bt.val_fields[0][1] if bt.val_fields else None)
+            if src is None:
+                raise UnsupportedQuery("line %d: '%s' has no field '%s'" % (op.lineno, op.probe.dict_name, e.field))
+            out_key_fields.append((fname or e.field, src))
+        else:
+            raise UnsupportedQuery("line %d: group keys of a probe-aggregate must be the probe key or fields of the matched "
+                                   "entry (the group must be determined by the probe key)" % op.lineno)
+    if not any(src == "key" for _, src in out_key_fields):
+        raise UnsupportedQuery("line %d: group key does not include the probe key; grouping on payload alone is not supported yet" % op.lineno)
+    if not bt.table.accumulate or bt.agg is not None:
+        raise UnsupportedQuery("line %d: table '%s' cannot take this aggregation" % (op.lineno, op.probe.dict_name))
+    karr = htab.array(pk, op)
+    if karr.dtype != np.int64:
+        raise UnsupportedQuery("line %d: probe key '%s' must be an int column" % (op.lineno, pk))
+    ctx.hash_probe_aggregate(n, flt, bt.table, eng.column(karr), tup)
+    bt.agg = (out_key_fields, vnames, count_idx, key_is_record, val_is_record, tup.shape)
+    return ("aggregated", op.probe.dict_name)
+
+
+def _materialize(eng, value, env):
+    """Device-resident intermediate -> DictResult on the host (K-F's input)."""
+    if isinstance(value, DictResult):
+        return value
+    if isinstance(value, tuple) and value and value[0] == "aggregated":
+        bt = env[value[1]]
+        out_key_fields, vnames, count_idx, key_is_record, val_is_record, shape = bt.agg
+        n = bt.table.size()
+        keys, payload, values, hits = eng.ctx.table_compact(bt.table, 1, n)
+        kf = []
+        for fname, src in out_key_fields:
+            if src == "key":
+                kf.append((fname, keys))
+            else:
+                kf.append((fname, payload[src].view(bt.payload_dtypes[src])))
+        nv = abi.TUPLE_NVALUES[shape]
+        vf = _value_arrays(vnames, count_idx, [values[j] for j in range(nv)], hits)
+        return DictResult(kf, vf, key_is_record, val_is_record)
+    if isinstance(value, BuiltTable):
+        n = value.table.size()
+        keys, payload, _, _ = eng.ctx.table_compact(value.table, 0, n, want_values=False)
+        vf = [(fname, keys if src == "key" else payload[src].view(value.payload_dtypes[src])) for fname, src in value.val_fields]
+        return DictResult([(value.key_name, keys)], vf, value.key_is_record, value.val_is_record)
+    raise UnsupportedQuery("cannot materialise %r" % (value,))
+
+
+def _finalize(eng, op, env):
+    d = _materialize(eng, env[op.source], env)
+    if op.fields is None:                                   # p[0].concat(p[1])
+        fields = d.key_fields + d.val_fields
+    else:
+        fields = []
+        for name, which in op.fields:
+            src = d.key_fields if which == 0 else d.val_fields
+            if len(src) != 1:
+                raise UnsupportedQuery("line %d: p[%d] is a record; use concat" % (op.lineno, which))
+            fields.append((name, src[0][1]))
+    return ResultSet([n for n, _ in fields], [a for _, a in fields])
+
+
+def execute_plan(eng, plan, args):
+    if len(args) != len(plan.params):
+        raise TypeError("%s expects %d tables, got %d" % (plan.name, len(plan.params), len(args)))
+    tables = {p: HostTable(p, a) for p, a in zip(plan.params, args)}
+    # tables that a later probe-aggregate folds its group-by into must carry accumulators
+    accumulate_into = {op.probe.dict_name for op in plan.ops
+                       if isinstance(op, ScanOp) and op.kind == "dict" and not op.unique and op.probe is not None}
+    env = {}
+    eng.last_ops = []
+    for op in plan.ops:
+        if isinstance(op, ScanOp):
+            env[op.out] = _run_scan(eng, op, tables[op.table], env, accumulate_into)
+        elif isinstance(op, FinalizeOp):
+            env[op.out] = _finalize(eng, op, env)
+        try:
+            eng.last_ops.append((op.out, eng.ctx.last_device_ms()))
+        except abi.SdqhError:
+            pass
+    res = env[plan.result]
+    if isinstance(res, (BuiltTable, tuple)):
+        res = _materialize(eng, res, env)
+    for v in env.values():                                   # release device tables of this run
+        if isinstance(v, BuiltTable):
+            v.table.free()
+    return res

@@ -1,0 +1,477 @@
+"""Front end: Python AST of an @sdql_compile function -> scan-operator IR.
+
+The reference does the same job in src/sdqlpy/lib/sdql_compiler.py (an ast.NodeVisitor that prints
+IR-constructor text: sum 43-82, joinBuild 162-187, joinProbe 189-210, and/or 277-292, if/else
+223-231) followed by type inference and a C++ printer.  This front end is written from scratch for
+the HIP backend: it produces one `ScanOp` per table-scanning `sum` / `joinBuild` / `joinProbe` —
+exactly the loops the reference's generator emits for `SumExpr` nodes over database tables
+(src/sdqlpy/lib/sdql_ir_cpp_generator_par.py:188) — plus a `FinalizeOp` for the trailing
+"reshape (key, value) into one record" sum (K-F, generator 520-568).  planner.py then maps each
+operator onto a pattern call of include/sdqh.h; an operator outside the backend's vocabulary raises
+`UnsupportedQuery` with the offending source line (never a silent fallback).
+"""
+import ast
+import inspect
+import textwrap
+
+
+class UnsupportedQuery(NotImplementedError):
+    pass
+
+
+# ---- expression IR ------------------------------------------------------------------------------
+class Expr:
+    def shape(self, names):
+        """Canonical string with columns replaced by c0, c1, ... in first-occurrence order."""
+        raise NotImplementedError
+
+
+class Col(Expr):
+    """A field of the scanned row (`p[0].x`, `probeDictKey.x`)."""
+    def __init__(self, name):
+        self.name = name
+
+    def shape(self, names):
+        key = ("col", self.name)
+        if key not in names:
+            names.append(key)
+        return "c%d" % names.index(key)
+
+    def __repr__(self):
+        return "Col(%s)" % self.name
+
+
+class PayloadField(Expr):
+    """A field of the entry matched by a lookup (`indexedDictValue.x`, `tbl[key].x`); field None =
+    the entry's whole value (a scalar payload)."""
+    def __init__(self, lookup, field):
+        self.lookup, self.field = lookup, field
+
+    def shape(self, names):
+        key = ("payload", self.lookup.dict_name, repr(self.lookup.key), self.field)
+        if key not in names:
+            names.append(key)
+        return "c%d" % names.index(key)
+
+    def __repr__(self):
+        return "Payload(%s[%r].%s)" % (self.lookup.dict_name, self.lookup.key, self.field)
+
+
+class Lookup(Expr):
+    """`tbl[key]`: key is an Expr or a RecordCons."""
+    def __init__(self, dict_name, key):
+        self.dict_name, self.key = dict_name, key
+
+    def __repr__(self):
+        return "Lookup(%s, %r)" % (self.dict_name, self.key)
+
+
+class Const(Expr):
+    def __init__(self, value):
+        self.value = value
+
+    def shape(self, names):
+        return repr(self.value)
+
+    def __repr__(self):
+        return "Const(%r)" % (self.value,)
+
+
+class Bin(Expr):
+    def __init__(self, op, left, right):
+        self.op, self.left, self.right = op, left, right
+
+    def shape(self, names):
+        return "(%s%s%s)" % (self.left.shape(names), self.op, self.right.shape(names))
+
+    def __repr__(self):
+        return "(%r %s %r)" % (self.left, self.op, self.right)
+
+
+class Cmp(Expr):
+    def __init__(self, op, left, right):
+        self.op, self.left, self.right = op, left, right
+
+    def __repr__(self):
+        return "(%r %s %r)" % (self.left, self.op, self.right)
+
+
+class And(Expr):
+    def __init__(self, terms):
+        self.terms = terms
+
+    def __repr__(self):
+        return "And(%s)" % ", ".join(map(repr, self.terms))
+
+
+class Contains(Expr):
+    """`tbl[key] != None` — the lookup must hit."""
+    def __init__(self, lookup):
+        self.lookup = lookup
+
+    def __repr__(self):
+        return "Contains(%r)" % self.lookup
+
+
+class StrIn(Expr):
+    """`"needle" in p[0].col`."""
+    def __init__(self, needle, col):
+        self.needle, self.col = needle, col
+
+
+class Call(Expr):
+    def __init__(self, fn, args):
+        self.fn, self.args = fn, args
+
+    def shape(self, names):
+        return "%s(%s)" % (self.fn, ",".join(a.shape(names) for a in self.args))
+
+    def __repr__(self):
+        return "%s(%s)" % (self.fn, ", ".join(map(repr, self.args)))
+
+
+class RecordCons(Expr):
+    def __init__(self, fields):
+        self.fields = fields          # list of (name, Expr)
+
+    def __repr__(self):
+        return "record(%s)" % ", ".join("%s=%r" % f for f in self.fields)
+
+
+class WholeKey(Expr):
+    """`p[0]` / `p[1]` of a sum over a result dictionary."""
+    def __init__(self, which):
+        self.which = which            # 0 = key, 1 = value
+
+
+class ConcatKV(Expr):
+    """`p[0].concat(p[1])`."""
+
+
+TRUE = Const(True)
+
+
+# ---- operator IR --------------------------------------------------------------------------------
+class ScanOp:
+    """One loop over a database table."""
+    def __init__(self, out, table, lineno):
+        self.out, self.table, self.lineno = out, table, lineno
+        self.conds = []         # conjunction of Cmp / Contains / StrIn
+        self.kind = None        # "scalar" | "dict"
+        self.key = None         # Expr | RecordCons                  (dict)
+        self.val = None         # Expr | RecordCons | TRUE           (dict) / Expr (scalar)
+        self.unique = False     # assignment sum: first insert wins, no aggregation
+        self.dense = None       # dense(N, ...) size hint (ignored: sized from data)
+        self.probe = None       # Lookup for joinProbe's index (must hit)
+
+    def __repr__(self):
+        return "ScanOp(%s <- %s%s: if %r: {%r: %r}%s)" % (self.out, self.table, " probe " + repr(self.probe) if self.probe else "",
+                                                          self.conds, self.key, self.val, " unique" if self.unique else "")
+
+
+class FinalizeOp:
+    """Sum over a result dictionary that only reshapes (key, value) into one record set (K-F)."""
+    def __init__(self, out, source, fields, lineno):
+        self.out, self.source, self.fields, self.lineno = out, source, fields, lineno   # fields: None = concat, else [(name, WholeKey)]
+
+
+class Plan:
+    def __init__(self, name, params, ops, result, consts):
+        self.name, self.params, self.ops, self.result, self.consts = name, params, ops, result, consts
+
+    def __repr__(self):
+        return "Plan(%s(%s)):\n  " % (self.name, ", ".join(self.params)) + "\n  ".join(map(repr, self.ops)) + "\n  return " + str(self.result)
+
+
+# ---- lowering -----------------------------------------------------------------------------------
+_BINOPS = {ast.Add: "+", ast.Sub: "-", ast.Mult: "*", ast.Div: "/"}
+_CMPOPS = {ast.Lt: "<", ast.LtE: "<=", ast.Gt: ">", ast.GtE: ">=", ast.Eq: "==", ast.NotEq: "!="}
+
+
+class _Lowerer:
+    def __init__(self, fn_name, source_lines, first_line):
+        self.fn_name, self.lines, self.first_line = fn_name, source_lines, first_line
+        self.consts = {}
+        self.params = []
+        self.dicts = set()      # names bound to operator outputs
+
+    def fail(self, node, why):
+        ln = getattr(node, "lineno", 0)
+        text = self.lines[ln - 1].strip() if 0 < ln <= len(self.lines) else ""
+        raise UnsupportedQuery("%s, line %d: %s\n    %s" % (self.fn_name, self.first_line + ln - 1, why, text))
+
+    # -- expressions ------------------------------------------------------------------------
+    def expr(self, node, env):
+        """env: {python name: ("row",) | ("payload", Lookup) | ("kv",)}"""
+        if isinstance(node, ast.Constant):
+            return Const(node.value)
+        if isinstance(node, ast.Name):
+            if node.id in self.consts:
+                return Const(self.consts[node.id])
+            if node.id in env and env[node.id][0] == "payload":
+                return PayloadField(env[node.id][1], None)
+            self.fail(node, "unknown name '%s'" % node.id)
+        if isinstance(node, ast.UnaryOp) and isinstance(node.op, ast.USub) and isinstance(node.operand, ast.Constant):
+            return Const(-node.operand.value)
+        if isinstance(node, ast.Attribute):
+            base = node.value
+            # p[0].x
+            if isinstance(base, ast.Subscript) and isinstance(base.value, ast.Name) and env.get(base.value.id, (None,))[0] in ("rowpair", "kv"):
+                idx = self._index(base)
+                kind = env[base.value.id][0]
+                if kind == "rowpair" and idx == 0:
+                    return Col(node.attr)
+                self.fail(node, "only p[0].<column> is supported inside a table sum")
+            if isinstance(base, ast.Name) and base.id in env:
+                kind = env[base.id]
+                if kind[0] == "row":
+                    return Col(node.attr)
+                if kind[0] == "payload":
+                    return PayloadField(kind[1], node.attr)
+            inner = self.expr(base, env)
+            if isinstance(inner, Lookup):
+                return PayloadField(inner, node.attr)
+            self.fail(node, "unsupported attribute access")
+        if isinstance(node, ast.Subscript):
+            if isinstance(node.value, ast.Name) and node.value.id in self.dicts:
+                key = self.expr(self._slice(node), env)
+                return Lookup(node.value.id, key)
+            if isinstance(node.value, ast.Name) and env.get(node.value.id, (None,))[0] == "kv":
+                return WholeKey(self._index(node))
+            self.fail(node, "unsupported subscript")
+        if isinstance(node, ast.BinOp) and type(node.op) in _BINOPS:
+            left, right = self.expr(node.left, env), self.expr(node.right, env)
+            if isinstance(node.op, ast.Mult) and self._is_bool(left) and self._is_bool(right):
+                return And(self._terms(left) + self._terms(right))    # `a * b` on booleans is AND (ref sdql_compiler.py:277-292)
+            return Bin(_BINOPS[type(node.op)], left, right)
+        if isinstance(node, ast.BoolOp) and isinstance(node.op, ast.And):
+            terms = []
+            for v in node.values:
+                terms += self._terms(self.expr(v, env))
+            return And(terms)
+        if isinstance(node, ast.Compare) and len(node.ops) == 1:
+            op = node.ops[0]
+            left, right = self.expr(node.left, env), self.expr(node.comparators[0], env)
+            if isinstance(op, ast.In):
+                if isinstance(left, Const) and isinstance(left.value, str) and isinstance(right, Col):
+                    return StrIn(left.value, right)
+                self.fail(node, "`in` is only supported as \"text\" in <string column>")
+            if type(op) not in _CMPOPS:
+                self.fail(node, "unsupported comparison")
+            sym = _CMPOPS[type(op)]
+            if isinstance(left, Lookup) and isinstance(right, Const) and right.value is None and sym == "!=":
+                return Contains(left)
+            if isinstance(left, PayloadField) and left.field is None and isinstance(right, Const) and right.value is None and sym == "!=":
+                return Contains(left.lookup)
+            return Cmp(sym, left, right)
+        if isinstance(node, ast.Call):
+            fn = node.func
+            if isinstance(fn, ast.Name):
+                if fn.id == "record" and len(node.args) == 1 and isinstance(node.args[0], ast.Dict):
+                    d = node.args[0]
+                    fields = []
+                    for k, v in zip(d.keys, d.values):
+                        if not (isinstance(k, ast.Constant) and isinstance(k.value, str)):
+                            self.fail(node, "record field names must be string literals")
+                        fields.append((k.value, self.expr(v, env)))
+                    return RecordCons(fields)
+                if fn.id == "unique" and len(node.args) == 1:
+                    return Call("unique", [self.expr(node.args[0], env)])
+                if fn.id == "dense" and len(node.args) == 2:
+                    return Call("dense", [self.expr(node.args[0], env), self.expr(node.args[1], env)])
+                if fn.id == "extractYear" and len(node.args) == 1:
+                    return Call("extractYear", [self.expr(node.args[0], env)])
+            if isinstance(fn, ast.Attribute) and fn.attr == "concat" and len(node.args) == 1:
+                a, b = self.expr(fn.value, env), self.expr(node.args[0], env)
+                if isinstance(a, WholeKey) and isinstance(b, WholeKey) and a.which == 0 and b.which == 1:
+                    return ConcatKV()
+            self.fail(node, "unsupported call")
+        self.fail(node, "unsupported expression (%s)" % type(node).__name__)
+
+    @staticmethod
+    def _slice(node):
+        s = node.slice
+        return s.value if isinstance(s, ast.Index) else s        # py3.8 compatibility
+
+    def _index(self, node):
+        s = self._slice(node)
+        if isinstance(s, ast.Constant) and s.value in (0, 1):
+            return s.value
+        self.fail(node, "expected [0] or [1]")
+
+    @staticmethod
+    def _is_bool(e):
+        return isinstance(e, (Cmp, And, Contains, StrIn)) or (isinstance(e, Const) and isinstance(e.value, bool))
+
+    @staticmethod
+    def _terms(e):
+        if isinstance(e, And):
+            return list(e.terms)
+        if isinstance(e, Const) and e.value is True:
+            return []
+        return [e]
+
+    # -- lambda bodies ----------------------------------------------------------------------
+    def split_ifelse(self, node, env):
+        """`BODY if COND else <zero>` -> (BODY node, [cond terms]); plain BODY -> (BODY, [])."""
+        conds = []
+        while isinstance(node, ast.IfExp):
+            orelse = node.orelse
+            zero = (isinstance(orelse, ast.Constant) and orelse.value in (None, 0, 0.0)) or \
+                   (isinstance(orelse, ast.Call) and isinstance(orelse.func, ast.Name) and orelse.func.id == "sr_dict" and not orelse.args)
+            if not zero:
+                self.fail(node, "the else arm of a conditional sum must be None / 0.0 / sr_dict()")
+            cond = self.expr(node.test, env)
+            if not self._is_bool(cond):
+                self.fail(node.test, "condition is not a comparison")
+            conds += self._terms(cond)
+            node = node.body
+        return node, conds
+
+    def dict_body(self, op, node, env):
+        """{K: V}"""
+        if not (isinstance(node, ast.Dict) and len(node.keys) == 1):
+            self.fail(node, "expected a one-entry dictionary {key: value}")
+        key = self.expr(node.keys[0], env)
+        while isinstance(key, Call) and key.fn in ("unique", "dense"):
+            if key.fn == "unique":
+                op.unique = True
+                key = key.args[0]
+            else:
+                op.dense = key.args[0].value if isinstance(key.args[0], Const) else None
+                key = key.args[1]
+        op.key = key
+        op.val = self.expr(node.values[0], env)
+        op.kind = "dict"
+
+    # -- statements -------------------------------------------------------------------------
+    def lambda_of(self, node, nparams):
+        if not (isinstance(node, ast.Lambda) and len(node.args.args) == nparams):
+            self.fail(node, "expected a lambda with %d parameter(s)" % nparams)
+        return [a.arg for a in node.args.args], node.body
+
+    def lower_call(self, out, call):
+        fn = call.func
+        table = fn.value.id
+        ln = call.lineno
+        if table in self.params:
+            op = ScanOp(out, table, ln)
+            if fn.attr == "sum":
+                if not 1 <= len(call.args) <= 2:
+                    self.fail(call, "sum takes (lambda[, is_update])")
+                (p,), body = self.lambda_of(call.args[0], 1)
+                env = {p: ("rowpair",)}
+                body, conds = self.split_ifelse(body, env)
+                op.conds = conds
+                if isinstance(body, ast.Dict):
+                    self.dict_body(op, body, env)
+                else:
+                    op.kind, op.val = "scalar", self.expr(body, env)
+                if len(call.args) == 2 and isinstance(call.args[1], ast.Constant) and call.args[1].value is False:
+                    op.unique = True
+                return op
+            if fn.attr == "joinBuild":
+                if len(call.args) != 3:
+                    self.fail(call, "joinBuild takes (column, filter, outCols)")
+                colname = self._const_str(call.args[0])
+                (p,), body = self.lambda_of(call.args[1], 1)
+                env = {p: ("rowpair",)}
+                cond = self.expr(body, env)
+                op.conds = self._terms(cond) if self._is_bool(cond) else self.fail(body, "filter is not a comparison")
+                if not isinstance(call.args[2], ast.List):
+                    self.fail(call, "outCols must be a list literal")
+                outcols = [self._const_str(e) for e in call.args[2].elts]
+                op.kind, op.unique = "dict", True
+                op.key = Col(colname)
+                # outCols == [] keeps the key itself as the value (ref lib/sdql_ir.py:428-429)
+                op.val = RecordCons([(c, Col(c)) for c in (outcols or [colname])])
+                return op
+            if fn.attr == "joinProbe":
+                if not 4 <= len(call.args) <= 5:
+                    self.fail(call, "joinProbe takes (index, column, filter, outputFunc[, is_update])")
+                if not (isinstance(call.args[0], ast.Name) and call.args[0].id in self.dicts):
+                    self.fail(call, "joinProbe's index must be the result of an earlier build")
+                colname = self._const_str(call.args[1])
+                (p,), fbody = self.lambda_of(call.args[2], 1)
+                cond = self.expr(fbody, {p: ("rowpair",)})
+                op.conds = self._terms(cond) if self._is_bool(cond) else self.fail(fbody, "filter is not a comparison")
+                op.probe = Lookup(call.args[0].id, Col(colname))
+                (pv, pk), body = self.lambda_of(call.args[3], 2)
+                env = {pv: ("payload", op.probe), pk: ("row",)}
+                body, conds = self.split_ifelse(body, env)
+                op.conds += conds
+                self.dict_body(op, body, env)
+                if len(call.args) == 5:
+                    if not isinstance(call.args[4], ast.Constant):
+                        self.fail(call, "is_update must be a literal")
+                    if call.args[4].value is False:
+                        op.unique = True        # 5th arg False => assignment sum (ref sdql_compiler.py:203-205)
+                return op
+            self.fail(call, "unsupported table method '%s'" % fn.attr)
+        if table in self.dicts and fn.attr == "sum":
+            (p,), body = self.lambda_of(call.args[0], 1)
+            env = {p: ("kv",)}
+            tmp = ScanOp(out, table, ln)
+            if not isinstance(body, ast.Dict):
+                self.fail(call, "a sum over a result dictionary must build {unique(record): True}")
+            self.dict_body(tmp, body, env)
+            if not (tmp.unique and isinstance(tmp.val, Const) and tmp.val.value is True):
+                self.fail(call, "only the finalising reshape {unique(<record>): True} is supported over a result dictionary")
+            if isinstance(tmp.key, ConcatKV):
+                return FinalizeOp(out, table, None, ln)
+            if isinstance(tmp.key, RecordCons) and all(isinstance(e, WholeKey) for _, e in tmp.key.fields):
+                return FinalizeOp(out, table, [(n, e.which) for n, e in tmp.key.fields], ln)
+            self.fail(call, "unsupported finalising record")
+        self.fail(call, "'%s' is neither a table parameter nor an earlier result" % table)
+
+    def _const_str(self, node):
+        if isinstance(node, ast.Constant) and isinstance(node.value, str):
+            return node.value
+        self.fail(node, "expected a string literal")
+
+    def lower(self, fdef):
+        self.params = [a.arg for a in fdef.args.args]
+        ops, result = [], None
+        for st in fdef.body:
+            if isinstance(st, ast.Expr) and isinstance(st.value, ast.Constant):
+                continue                                    # docstring
+            if isinstance(st, ast.Assign) and len(st.targets) == 1 and isinstance(st.targets[0], ast.Name):
+                name, val = st.targets[0].id, st.value
+                if isinstance(val, ast.Constant):
+                    self.consts[name] = val.value
+                    continue
+                if isinstance(val, ast.Call) and isinstance(val.func, ast.Attribute) and isinstance(val.func.value, ast.Name):
+                    ops.append(self.lower_call(name, val))
+                    self.dicts.add(name)
+                    continue
+                self.fail(st, "unsupported assignment")
+            if isinstance(st, ast.Return):
+                if isinstance(st.value, ast.Name) and st.value.id in self.dicts:
+                    result = st.value.id
+                    continue
+                self.fail(st, "a query must return one of its results by name")
+            self.fail(st, "unsupported statement")
+        if result is None:
+            raise UnsupportedQuery("%s: no return statement" % self.fn_name)
+        return Plan(self.fn_name, self.params, ops, result, dict(self.consts))
+
+
+def lower_source(source, fn_name=None, first_line=1):
+    tree = ast.parse(textwrap.dedent(source))
+    fdefs = [n for n in tree.body if isinstance(n, ast.FunctionDef) and (fn_name is None or n.name == fn_name)]
+    if len(fdefs) != 1:
+        raise UnsupportedQuery("expected exactly one function definition")
+    return _Lowerer(fdefs[0].name, textwrap.dedent(source).splitlines(), first_line).lower(fdefs[0])
+
+
+def lower_function(func, in_type=None):
+    """Plan for a decorated query function.  ``in_type`` (the decorator's dict) fixes the positional
+    order of the table parameters; it must list them in the function's own parameter order."""
+    func = getattr(func, "__sdql_func__", func)
+    source = inspect.getsource(func)
+    first = func.__code__.co_firstlineno
+    plan = lower_source(source, func.__name__, first)
+    if in_type is not None and len(in_type) != len(plan.params):
+        raise UnsupportedQuery("%s: decorator lists %d tables, function takes %d" % (func.__name__, len(in_type), len(plan.params)))
+    plan.in_type = in_type
+    return plan

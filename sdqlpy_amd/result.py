@@ -1,0 +1,79 @@
+"""Result containers handed back by compiled queries.
+
+The reference returns `sdqlpy.fastd.fastd` around a generated `FastDict_<abbr>_b` object — a
+phmap set of result records with size() / to_dict() / print (reference src/sdqlpy/fastd.py:31-51,
+src/sdqlpy/lib/fast_dict_generator.py:203-356).  Here a result is struct-of-arrays: one numpy
+array per record field, rows in unspecified order (the reference's set is unordered too), with the
+same size() / to_dict() surface.
+"""
+import numpy as np
+
+from .sdql_lib import record, sr_dict
+
+
+class ResultSet:
+    """Set of records: {record(field...): True}."""
+
+    def __init__(self, columns, arrays):
+        self.columns = list(columns)
+        self.arrays = [np.asarray(a) for a in arrays]
+        n = len(self.arrays[0]) if self.arrays else 0
+        for a in self.arrays:
+            if len(a) != n:
+                raise ValueError("ragged result")
+        self._n = n
+
+    def size(self):
+        return self._n
+
+    def __len__(self):
+        return self._n
+
+    def column(self, name):
+        return self.arrays[self.columns.index(name)]
+
+    def rows(self):
+        """Sorted list of plain-Python tuples (ints, floats, strs) — for comparisons."""
+        cols = [a.tolist() for a in self.arrays]
+        return sorted(zip(*cols)) if cols else []
+
+    def to_dict(self):
+        out = {}
+        cols = [a.tolist() for a in self.arrays]
+        for row in zip(*cols):
+            out[record(dict(zip(self.columns, row)))] = True
+        return sr_dict(out)
+
+    def __str__(self):
+        return str(self.to_dict())
+
+
+class DictResult:
+    """Dictionary from key record (or scalar) to value record (or scalar), struct-of-arrays."""
+
+    def __init__(self, key_fields, val_fields, key_is_record=True, val_is_record=True):
+        self.key_fields = list(key_fields)      # [(name, array)]
+        self.val_fields = list(val_fields)
+        self.key_is_record, self.val_is_record = key_is_record, val_is_record
+
+    def size(self):
+        fields = self.key_fields or self.val_fields
+        return len(fields[0][1]) if fields else 0
+
+    def __len__(self):
+        return self.size()
+
+    def to_dict(self):
+        out = {}
+        kcols = [a.tolist() for _, a in self.key_fields]
+        vcols = [a.tolist() for _, a in self.val_fields]
+        knames = [n for n, _ in self.key_fields]
+        vnames = [n for n, _ in self.val_fields]
+        for i in range(self.size()):
+            k = record({n: c[i] for n, c in zip(knames, kcols)}) if self.key_is_record else kcols[0][i]
+            v = record({n: c[i] for n, c in zip(vnames, vcols)}) if self.val_is_record else (vcols[0][i] if vcols else True)
+            out[k] = v
+        return sr_dict(out)
+
+    def __str__(self):
+        return str(self.to_dict())

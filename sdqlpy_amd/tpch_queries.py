@@ -1,0 +1,131 @@
+"""The TPCH queries of the hot path, written in the sdqlpy DSL against sdqlpy_amd.
+
+These are the workload, the way SQL text is for a SQL engine: q6, q1, q3 (then q5, q9) expressed
+with the same combinators, filters and arithmetic as the reference's TPCH script, so that the
+golden results captured from the reference (tests/golden) apply to them verbatim
+(reference test/test_all.py: q1 46-62, q3 145-176, q5 215-281, q6 285-295, q9 431-491).
+Call ``sdqlpy_init(3)`` (or 1) before running them.
+"""
+from .sdql_lib import *      # noqa: F401,F403
+from .tpch import (customer_type, lineitem_type, nation_type, order_type, part_type, partsupp_type,
+                   region_type, supplier_type)
+
+
+@sdql_compile({"li": lineitem_type})
+def q6(li):
+    results = li.sum(lambda p: p[0].l_extendedprice * p[0].l_discount
+                     if (p[0].l_shipdate >= 19940101) and (p[0].l_shipdate < 19950101)
+                     and (p[0].l_discount >= 0.05) and (p[0].l_discount <= 0.07) and (p[0].l_quantity < 24.0)
+                     else 0.0)
+    return results
+
+
+@sdql_compile({"li": lineitem_type})
+def q1(li):
+    lineitem_probed = li.sum(lambda p: {
+        record({"l_returnflag": p[0].l_returnflag, "l_linestatus": p[0].l_linestatus}):
+        record({"sum_qty": p[0].l_quantity,
+                "sum_base_price": p[0].l_extendedprice,
+                "sum_disc_price": (p[0].l_extendedprice * (1.0 - p[0].l_discount)),
+                "sum_charge": ((p[0].l_extendedprice * (1.0 - p[0].l_discount)) * (1.0 + p[0].l_tax)),
+                "count_order": 1})
+    } if p[0].l_shipdate <= 19980902 else None)
+    results = lineitem_probed.sum(lambda p: {unique(p[0].concat(p[1])): True})
+    return results
+
+
+@sdql_compile({"li": lineitem_type, "cu": customer_type, "ord": order_type})
+def q3(li, cu, ord):
+    building = "BUILDING"
+    customer_indexed = cu.joinBuild("c_custkey", lambda p: p[0].c_mktsegment == building, [])
+    order_probed = ord.joinProbe(
+        customer_indexed, "o_custkey",
+        lambda p: p[0].o_orderdate < 19950315,
+        lambda indexedDictValue, probeDictKey: {
+            probeDictKey.o_orderkey:
+            record({"o_orderdate": probeDictKey.o_orderdate, "o_shippriority": probeDictKey.o_shippriority})},
+        False)
+    lineitem_probed = li.joinProbe(
+        order_probed, "l_orderkey",
+        lambda p: p[0].l_shipdate > 19950315,
+        lambda indexedDictValue, probeDictKey: {
+            record({"l_orderkey": probeDictKey.l_orderkey, "o_orderdate": indexedDictValue.o_orderdate,
+                    "o_shippriority": indexedDictValue.o_shippriority}):
+            record({"revenue": probeDictKey.l_extendedprice * (1.0 - probeDictKey.l_discount)})})
+    results = lineitem_probed.sum(lambda p: {unique(p[0].concat(p[1])): True})
+    return results
+
+
+@sdql_compile({"li": lineitem_type, "cu": customer_type, "ord": order_type, "re": region_type,
+               "na": nation_type, "su": supplier_type})
+def q5(li, cu, ord, re, na, su):
+    asia = "ASIA"
+    region_indexed = re.joinBuild("r_regionkey", lambda p: p[0].r_name == asia, [])
+    nation_probed = na.joinProbe(
+        region_indexed, "n_regionkey", lambda p: True,
+        lambda indexedDictValue, probeDictKey: {probeDictKey.n_nationkey: probeDictKey.n_name},
+        False)
+    customer_probed = cu.joinProbe(
+        nation_probed, "c_nationkey", lambda p: True,
+        lambda indexedDictValue, probeDictKey: {
+            probeDictKey.c_custkey: record({"n_name": indexedDictValue, "c_nationkey": probeDictKey.c_nationkey})},
+        False)
+    order_probed = ord.joinProbe(
+        customer_probed, "o_custkey",
+        lambda p: (p[0].o_orderdate < 19950101) * (p[0].o_orderdate >= 19940101),
+        lambda indexedDictValue, probeDictKey: {
+            probeDictKey.o_orderkey:
+            record({"n_name": indexedDictValue.n_name, "c_nationkey": indexedDictValue.c_nationkey})},
+        False)
+    supplier_project = su.sum(lambda p: {
+        unique(record({"s_suppkey": p[0].s_suppkey, "s_nationkey": p[0].s_nationkey})): True})
+    lineitem_probed = li.joinProbe(
+        order_probed, "l_orderkey", lambda p: True,
+        lambda indexedDictValue, probeDictKey: {
+            indexedDictValue.n_name: probeDictKey.l_extendedprice * (1.0 - probeDictKey.l_discount)}
+        if supplier_project[record({"l_suppkey": probeDictKey.l_suppkey,
+                                    "c_nationkey": indexedDictValue.c_nationkey})] != None      # noqa: E711
+        else None)
+    results = lineitem_probed.sum(lambda p: {unique(record({"n_name": p[0], "revenue": p[1]})): True})
+    return results
+
+
+@sdql_compile({"li": lineitem_type, "ord": order_type, "na": nation_type, "su": supplier_type,
+               "pa": part_type, "ps": partsupp_type})
+def q9(li, ord, na, su, pa, ps):
+    nation_indexed = na.joinBuild("n_nationkey", lambda p: True, ["n_name"])
+    supplier_probed = su.sum(lambda p: {unique(p[0].s_suppkey): nation_indexed[p[0].s_nationkey].n_name})
+    green = "green"
+    part_indexed = pa.joinBuild("p_partkey", lambda p: green in p[0].p_name, [])
+    partsupp_probe = ps.joinProbe(
+        part_indexed, "ps_partkey", lambda p: True,
+        lambda indexedDictValue, probeDictKey: {
+            record({"ps_partkey": probeDictKey.ps_partkey, "ps_suppkey": probeDictKey.ps_suppkey}):
+            record({"n_name": supplier_probed[probeDictKey.ps_suppkey], "ps_supplycost": probeDictKey.ps_supplycost})},
+        False)
+    ord_indexed = ord.sum(lambda p: {dense(6000000, unique(p[0].o_orderkey)): p[0].o_orderdate})
+    li_probed = li.sum(lambda p: {
+        record({"nation": partsupp_probe[record({"ps_partkey": p[0].l_partkey, "ps_suppkey": p[0].l_suppkey})].n_name,
+                "o_year": extractYear(ord_indexed[p[0].l_orderkey])}):
+        record({"sum_profit": p[0].l_extendedprice * (1.0 - p[0].l_discount)
+                - partsupp_probe[record({"ps_partkey": p[0].l_partkey, "ps_suppkey": p[0].l_suppkey})].ps_supplycost
+                * p[0].l_quantity})
+    } if partsupp_probe[record({"ps_partkey": p[0].l_partkey, "ps_suppkey": p[0].l_suppkey})] != None      # noqa: E711
+        else None)
+    results = li_probed.sum(lambda p: {unique(p[0].concat(p[1])): True})
+    return results
+
+
+# positional table order of each query (the decorator dict order == call order)
+QUERY_TABLES = {
+    "q6": ["lineitem"],
+    "q1": ["lineitem"],
+    "q3": ["lineitem", "customer", "orders"],
+    "q5": ["lineitem", "customer", "orders", "region", "nation", "supplier"],
+    "q9": ["lineitem", "orders", "nation", "supplier", "part", "partsupp"],
+}
+QUERIES = {"q6": q6, "q1": q1, "q3": q3, "q5": q5, "q9": q9}
+
+
+def run(name, db):
+    return QUERIES[name](*[db[t] for t in QUERY_TABLES[name]])

@@ -1,0 +1,35 @@
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    """The CPU oracle behind the same C ABI (test infrastructure; built by oracle/Makefile)."""
+    from sdqlpy_amd import abi
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    return abi.Library(os.path.join(ROOT, "oracle", "libsdqloracle.so"))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    with open(os.path.join(ROOT, "tests", "golden", "tpch_golden.json")) as fh:
+        return json.load(fh)
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """The product library.  On a box without a GPU only loading / symbol checks are possible."""
+    from sdqlpy_amd import engine
+    return engine.load_hip_library()

@@ -1,0 +1,44 @@
+"""The CPU oracle (oracle/sdqh_oracle.cpp) against the reference's own results (tests/golden).
+
+This is what pins the oracle: every golden vector captured from the reference's Python-mode
+interpreter must be reproduced — integers exactly, and with threads=1 the doubles bit-for-bit,
+because the oracle then sums in row order exactly as the interpreter does.  The queries go through
+the product's front end and planner (frontend.py / engine.py) driving the oracle's ABI, so the
+host logic is covered too.
+"""
+import pytest
+
+import helpers
+from sdqlpy_amd import engine
+
+SUPPORTED = ("q1", "q3", "q6")
+
+
+def _cases(golden):
+    for case in golden["cases"]:
+        for q in case["results"]:
+            if q in SUPPORTED:
+                yield case, q
+
+
+def test_golden_file_has_all_config_queries(golden):
+    names = {c["name"] for c in golden["cases"]}
+    assert {"tiny", "small", "medium"} <= names
+    for c in golden["cases"]:
+        if c["variant"] == "base":
+            assert set(c["results"]) == {"q1", "q3", "q5", "q6", "q9"}
+
+
+@pytest.mark.parametrize("threads,rel", [(1, 0.0), (4, 1e-12)])
+def test_oracle_reproduces_reference(oracle_lib, golden, threads, rel):
+    eng = engine.Engine(oracle_lib.context(threads=threads))
+    try:
+        n = 0
+        for case, q in _cases(golden):
+            db = helpers.case_db(case)
+            res = helpers.run_query(eng, q, db)
+            helpers.check_against_golden(res, case["results"][q], rel, "%s/%s/threads=%d" % (case["name"], q, threads))
+            n += 1
+        assert n >= 15
+    finally:
+        eng.close()

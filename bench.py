@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""bench.py — TPCH Q1 + Q3 at SF=10 per GPU on MI355X (BASELINE.json metric: rows/sec + ms/query).
+
+A step = one pass of the hot path over the resident tables: q1(lineitem) then
+q3(lineitem, customer, orders), both through the public decorator API (front end -> planner ->
+C ABI -> HIP kernels), result materialised on the host.  Inputs are synthetic (sdqlpy_amd/tpch.py,
+seed fixed) and already resident in HBM when the timed region starts.  rows/sec = rows of every
+table scanned by the step / step time.
+
+    python bench.py                       # 1 GPU, defaults finish in a few minutes
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+N > 1 is weak scaling: every rank holds an SF=10 shard of a global SF=10*N database; q1 shards by
+rows, q3 is the partitioned join of sdqlpy_amd/dist.py (RCCL all-to-all for the redistribution step).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--sf", type=float, default=10.0, help="scale factor PER GPU")
+    ap.add_argument("--queries", default="q1,q3")
+    ap.add_argument("--profile-iters", type=int, default=5, help="extra untimed passes with per-kernel HIP events")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-sf", type=float, default=0.0, help="0 = pick so the CPU leg takes ~10-30 s")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(q, rows):
+    """every referenced column read once at the reference's own widths."""
+    if q == "q1":
+        return 48 * rows["lineitem"]
+    if q == "q3":
+        return 48 * rows["customer"] + 32 * rows["orders"] + 32 * rows["lineitem"]
+    if q == "q6":
+        return 32 * rows["lineitem"]
+    raise KeyError(q)
+
+
+def scanned_rows(q, rows):
+    return {"q1": rows["lineitem"], "q6": rows["lineitem"],
+            "q3": rows["lineitem"] + rows["customer"] + rows["orders"]}[q]
+
+
+def main():
+    args = parse()
+    queries = [q for q in args.queries.split(",") if q]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torchrun (one process per GPU)" % args.gpus)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from sdqlpy_amd import engine, tpch
+    from sdqlpy_amd import tpch_queries as Q
+    from sdqlpy_amd.sdql_lib import sdqlpy_init
+
+    t0 = time.time()
+    need = tpch.columns_for(queries)
+    tables = sorted(need)
+    shard = (rank, world) if world > 1 else None
+    db = tpch.generate(args.sf * world, tables=tables, columns=need, shard=shard)
+    rows = {t: len(db[t].getContainer()["data"][0]) for t in tables}
+    gen_s = time.time() - t0
+
+    sdqlpy_init(3, 1, device=local_rank)
+    eng = engine.default_engine(device=local_rank)
+    if world > 1:
+        from sdqlpy_amd import dist as sdist
+        runner = sdist.DistributedRunner(eng, rank, world)
+        run_query = lambda q: runner.run(q, db)           # noqa: E731
+    else:
+        run_query = lambda q: Q.run(q, db)                # noqa: E731
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        eng.ctx.synchronize()
+        torch.cuda.synchronize()
+
+    # first pass uploads the columns (pinned-staged H2D) — the PCIe-inclusive number
+    barrier()
+    t0 = time.time()
+    for q in queries:
+        run_query(q)
+    barrier()
+    first_pass_s = time.time() - t0
+
+    for _ in range(args.warmup):
+        for q in queries:
+            run_query(q)
+
+    per_query_ms = {q: 0.0 for q in queries}
+    barrier()
+    t_begin = time.perf_counter()
+    for _ in range(args.steps):
+        for q in queries:
+            tq = time.perf_counter()
+            run_query(q)
+            per_query_ms[q] += (time.perf_counter() - tq) * 1e3
+    barrier()
+    elapsed = time.perf_counter() - t_begin
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        rows_t = torch.tensor([sum(scanned_rows(q, rows) for q in queries)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(rows_t)
+        total_rows_per_step = float(rows_t.item())
+    else:
+        total_rows_per_step = float(sum(scanned_rows(q, rows) for q in queries))
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_rows_per_step * args.steps / elapsed
+
+    # ---- per-kernel device time, measured live with HIP events on the stream the kernels run on ----
+    kernel_ms, device_ms = {}, {q: 0.0 for q in queries}
+    eng.ctx.set_profiling(True)
+    for _ in range(args.profile_iters):
+        for q in queries:
+            eng.ctx.kernel_log, eng.ctx.device_log = [], []
+            run_query(q)
+            for name, ms in eng.ctx.kernel_log:
+                kernel_ms[(q, name)] = kernel_ms.get((q, name), 0.0) + ms
+            device_ms[q] += sum(ms for _, ms in eng.ctx.device_log)
+    eng.ctx.set_profiling(False)
+    iters = max(1, args.profile_iters)
+    device_ms = {q: v / iters for q, v in device_ms.items()}
+    # a kernel may be launched more than once per query (q3 builds two tables): ms per query pass
+    kernels = {"%s:%s" % (q, name): v / iters for (q, name), v in kernel_ms.items()}
+
+    out = None
+    if rank == 0:
+        dom_q = "q1" if "q1" in queries else queries[0]
+        dom_name = {"q1": "k_groupby_reg", "q3": "k_probe_agg", "q6": "k_scan_sum"}[dom_q]
+        dom_ms = kernels.get("%s:%s" % (dom_q, dom_name))
+        roofline = None
+        if dom_ms:
+            per_launch_bytes = {"q1": 48 * rows["lineitem"], "q3": 32 * rows["lineitem"], "q6": 32 * rows["lineitem"]}[dom_q]
+            achieved = per_launch_bytes / (dom_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": round(dom_ms, 4)}
+        per_query = {}
+        for q in queries:
+            ab = algorithmic_bytes(q, rows)
+            wall = per_query_ms[q] / args.steps
+            per_query[q] = {"ms_wall": round(wall, 4), "ms_device": round(device_ms[q], 4),
+                            "rows_per_s_wall": round(scanned_rows(q, rows) / (wall * 1e-3), 1),
+                            "algorithmic_GBs_device": round(ab / (device_ms[q] * 1e-3) / 1e9, 1) if device_ms[q] else None,
+                            "roofline_frac_device": round(ab / (device_ms[q] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if device_ms[q] else None}
+        out = {
+            "metric": "tpch_q1_q3_sf10_rows_per_sec", "value": round(value, 1), "unit": "rows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "TPCH " + "+".join(q.upper() for q in queries) + " SF=%g per GPU (q1 = BASELINE configs[1], q3 = configs[2])" % args.sf,
+                       "sf_per_gpu": args.sf, "rows_per_gpu": rows, "partitioning": "none" if world == 1 else "q1 row-sharded; q3 partitioned on o_orderkey, RCCL all-to-all"},
+            "ms_per_query": per_query,
+            "kernels_ms": {k: round(v, 4) for k, v in sorted(kernels.items())},
+            "roofline": roofline,
+            "first_pass_with_upload_s": round(first_pass_s, 3), "generate_s": round(gen_s, 2),
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, queries, db, rows)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+def cpu_baseline(args, queries, db, rows):
+    """The CPU port (oracle/, same plan as the reference's TBB code: per-thread partials + merge)
+    timed on this box's host cores on a bounded sample of the same workload."""
+    import numpy as np
+    from sdqlpy_amd import abi, engine, frontend, tpch
+    from sdqlpy_amd import tpch_queries as Q
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    cores = os.cpu_count() or 1
+    lib = abi.Library(os.path.join(ROOT, "oracle", "libsdqloracle.so"))
+    eng = engine.Engine(lib.context(threads=cores))
+    # bounded sample: a prefix of the same generated tables (lineitem cut on the same order boundary)
+    frac = args.cpu_sample_sf / args.sf if args.cpu_sample_sf > 0 else min(1.0, 2.0 / args.sf)
+    sample = {}
+    n_ord = int(rows.get("orders", 0) * frac)
+    for t, table in db.items():
+        c = table.getContainer()
+        if t == "lineitem":
+            ok = c["data"][c["headers"].index("l_orderkey")] if "l_orderkey" in c["headers"] else None
+            if ok is not None and "orders" in db:
+                last_key = tpch.column(db["orders"], "o_orderkey")[max(0, n_ord - 1)]
+                n = int(np.searchsorted(ok, last_key, side="right"))
+            else:
+                n = int(len(c["data"][0]) * frac)
+        elif t in ("orders",):
+            n = n_ord
+        else:
+            n = len(c["data"][0])               # dimension-side tables stay whole so key references resolve
+        sample[t] = tpch.table_from_columns(c["headers"], [np.ascontiguousarray(a[:n]) for a in c["data"]])
+    srows = {t: len(sample[t].getContainer()["data"][0]) for t in sample}
+    plans = {q: frontend.lower_function(Q.QUERIES[q]) for q in queries}
+    run = lambda q: engine.execute_plan(eng, plans[q], [sample[t] for t in Q.QUERY_TABLES[q]])   # noqa: E731
+    for q in queries:
+        run(q)                                   # warm-up (also copies the columns into the oracle's memory)
+    iters, t0 = 0, time.perf_counter()
+    per_q = {q: 0.0 for q in queries}
+    while iters < 5 and (time.perf_counter() - t0) < 20.0:
+        for q in queries:
+            tq = time.perf_counter()
+            run(q)
+            per_q[q] += time.perf_counter() - tq
+        iters += 1
+    elapsed = time.perf_counter() - t0
+    total_rows = sum(scanned_rows(q, srows) for q in queries)
+    eng.close()
+    return {"value": round(total_rows * iters / elapsed, 1), "unit": "rows/s", "cores": cores, "kind": "port",
+            "sample": "same generator, first %.0f%% of orders + their lineitems (%d lineitem rows), customer whole; %d passes of %s"
+                      % (100 * frac, srows.get("lineitem", 0), iters, "+".join(queries)),
+            "ms_per_query": {q: round(per_q[q] / iters * 1e3, 2) for q in queries}}
+
+
+if __name__ == "__main__":
+    main()

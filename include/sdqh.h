@@ -199,7 +199,9 @@ int sdqh_hash_probe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* f
 
 /* ---- K-F: compact the entries that received at least min_hits rows into host arrays ---------
  * out_keys[i], out_payload[p*capacity + i] (8 raw bytes each), out_values[v*capacity + i],
- * out_hits[i]; *out_n = rows written.  min_hits = 0 returns every entry.  Any out_* may be NULL. */
+ * out_hits[i]; *out_n = rows written.  min_hits = 0 returns every entry.  Any out_* may be NULL;
+ * with all four NULL the call only counts (capacity ignored), and a following call with the same
+ * min_hits copies the already-compacted rows out. */
 int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, int64_t capacity,
                        int64_t* out_keys, int64_t* out_payload, double* out_values,
                        int64_t* out_hits, int64_t* out_n);

@@ -532,9 +532,11 @@ int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits,
     if (table->bitmap_only) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_compact: bitmap-only table");
     Timer tm;
     int64_t n = 0;
+    const bool count_only = !out_keys && !out_payload && !out_values && !out_hits;
     for (size_t e = 0; e < table->keys.size(); ++e) {                 // for (auto& x : dict) out[tuple_cat(k,v)] = true: generator 520-568
         int64_t hits = table->accumulate ? table->acc[e].n : 0;
         if (hits < min_hits) continue;
+        if (count_only) { ++n; continue; }
         if (n >= capacity) return fail(ctx, SDQH_ERR_OVERFLOW, "table_compact: capacity too small");
         if (out_keys) out_keys[n] = table->keys[e];
         if (out_payload) for (int p = 0; p < table->npayload; ++p) out_payload[(size_t)p * (size_t)capacity + (size_t)n] = table->payload[e * (size_t)table->npayload + (size_t)p];

@@ -179,6 +179,9 @@ class Context:
             raise SdqhError(rc, "sdqh_create(device=%d) failed" % device)
         self.handle = h
         self.device = device
+        self._profiling = False
+        self.kernel_log = []       # [(kernel name, ms)] of every pattern call since the log was cleared (profiling on)
+        self.device_log = []       # [(pattern call, device ms)]
         self._check(self.lib.sdqh_set_threads(self.handle, C.c_int(max(1, threads))))
 
     def close(self):
@@ -204,6 +207,15 @@ class Context:
 
     def set_profiling(self, on):
         self._check(self.lib.sdqh_set_profiling(self.handle, C.c_int(1 if on else 0)))
+        self._profiling = bool(on)
+        self.kernel_log, self.device_log = [], []
+
+    def _after_call(self, name):
+        """With profiling on, log the device time of the call and of each kernel it launched
+        (HIP events recorded on the ctx stream around every launch).  Synchronises; off by default."""
+        if self._profiling:
+            self.device_log.append((name, self.last_device_ms()))
+            self.kernel_log.extend(self.profile())
 
     def profile(self):
         out = []
@@ -256,6 +268,7 @@ class Context:
         vals = (C.c_double * TUPLE_MAX_VALUES)()
         cnt = C.c_int64()
         self._check(self.lib.sdqh_scan_filter_sum(self.handle, C.c_int64(nrows), C.byref(flt), C.byref(tup), vals, C.byref(cnt)))
+        self._after_call("scan_filter_sum")
         return list(vals)[: TUPLE_NVALUES[tup.shape]], cnt.value
 
     def groupby_small(self, nrows, flt, keys, tup, max_groups=MAX_SMALL_GROUPS):
@@ -267,6 +280,7 @@ class Context:
         ng = C.c_int32()
         self._check(self.lib.sdqh_groupby_small(self.handle, C.c_int64(nrows), C.byref(flt), C.c_int(nk), karr, C.byref(tup),
                                                 C.c_int(max_groups), _np_ptr(out_keys), _np_ptr(out_vals), _np_ptr(out_cnt), C.byref(ng)))
+        self._after_call("groupby_small")
         n = ng.value
         return out_keys[:n], out_vals[:n, : TUPLE_NVALUES[tup.shape]], out_cnt[:n]
 
@@ -278,12 +292,22 @@ class Context:
         h = C.c_void_p()
         self._check(self.lib.sdqh_hash_build_unique(self.handle, C.c_int64(nrows), C.byref(flt), C.c_int(len(probes)), parr, key.handle,
                                                     C.c_int(len(payload)), pl, C.c_int(1 if accumulate else 0), C.byref(h)))
+        self._after_call("hash_build_unique")
         t = Table(self, h, len(payload), accumulate)
         t._keep = (probes, key, payload)
         return t
 
     def hash_probe_aggregate(self, nrows, flt, table, key, tup):
         self._check(self.lib.sdqh_hash_probe_aggregate(self.handle, C.c_int64(nrows), C.byref(flt), table.handle, key.handle, C.byref(tup)))
+        self._after_call("hash_probe_aggregate")
+
+    def table_compact_count(self, table, min_hits):
+        """Run the compaction on the device and return the row count; a following table_compact
+        with the same min_hits only copies the rows out."""
+        n = C.c_int64()
+        self._check(self.lib.sdqh_table_compact(self.handle, table.handle, C.c_int64(min_hits), C.c_int64(0), None, None, None, None, C.byref(n)))
+        self._after_call("table_compact")
+        return n.value
 
     def table_compact(self, table, min_hits, capacity, want_payload=True, want_values=True):
         cap = max(1, int(capacity))

@@ -1,0 +1,726 @@
+// sdqh_hip.hip — the C ABI (include/sdqh.h) over the gfx950 kernels of sdqh_kernels.hpp.
+//
+// One ctx = one GPU + one HIP stream.  Device memory comes from a per-ctx caching pool (tables ask
+// for worst-case-sized buffers and touch only what the data needs: 288 GB of HBM3E makes virtual
+// head-room cheap, and it lets every size decision stay on the device, so a query runs without a
+// single host round trip until its result is fetched).  No torch types, no global mutable state.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sdqh.h"
+#include "sdqh_kernels.hpp"
+
+using namespace sdqh;
+
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct PoolBlock { void* ptr; size_t size; bool free; };
+
+struct ProfEntry { const char* name; hipEvent_t e0, e1; double ms; };
+
+constexpr size_t STAGING_BYTES = 32u << 20;       // pinned H2D staging ring: 2 x 32 MiB
+constexpr size_t RESULT_BYTES = 64u << 10;        // pinned buffer for small results
+
+}  // namespace
+
+struct sdqh_ctx {
+    int device = 0;
+    int num_cu = 256;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<PoolBlock> pool;
+    void* staging[2] = {nullptr, nullptr};
+    hipEvent_t staging_done[2] = {nullptr, nullptr};
+    bool staging_busy[2] = {false, false};
+    void* result_host = nullptr;                   // pinned
+    void* result_dev = nullptr;
+    hipEvent_t call_begin = nullptr, call_end = nullptr;
+    bool call_timed = false;
+    bool profiling = false;
+    std::vector<ProfEntry> prof;
+    std::vector<hipEvent_t> event_pool;
+    size_t event_next = 0;
+    // hint: key columns whose group count overflowed the register kernel last time
+    const void* lds_hint[SDQH_MAX_GROUPKEYS] = {nullptr, nullptr};
+    int threads = 1;
+};
+
+struct sdqh_column {
+    void* data = nullptr;
+    int64_t nrows = 0;
+    int dtype = SDQH_I64;
+    int width = 0;
+    bool owned = false;
+    long long* d_minmax = nullptr;     // device [2], I64 only
+    bool minmax_pending = false, have_minmax = false;
+    int64_t mn = 0, mx = 0;
+    size_t row_bytes() const { return dtype == SDQH_STR ? (size_t)width * 4 : 8; }
+};
+
+constexpr int MAX_STAGE_PAY = SDQH_MAX_COMPACT_COLS - 1;
+
+struct sdqh_table {
+    DevTable dev{};
+    DevStage stage{};
+    TableHeader* hdr = nullptr;
+    uint32_t* bm = nullptr;
+    int npay = 0;
+    bool accumulate = false;
+    bool bitmap_only = false;
+    int64_t nrows_build = 0;
+    uint64_t capmax = 0;
+    std::vector<void*> owned;          // pool blocks to release
+    // cached compaction (device buffers) for the two-step count / fetch protocol
+    bool compact_valid = false;
+    int64_t compact_min_hits = 0, compact_n = 0;
+    DevCompactOut compact{};
+};
+
+namespace {
+
+int fail(sdqh_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+#define HIP_TRY(ctx, expr)                                                                              \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+// ---- pool --------------------------------------------------------------------------------------
+void* pool_alloc(sdqh_ctx* ctx, size_t bytes) {
+    bytes = std::max<size_t>(256, (bytes + 255) & ~(size_t)255);
+    int best = -1;
+    for (size_t i = 0; i < ctx->pool.size(); ++i) {
+        PoolBlock& b = ctx->pool[i];
+        if (b.free && b.size >= bytes && b.size <= bytes * 2 + (1u << 20) && (best < 0 || b.size < ctx->pool[(size_t)best].size)) best = (int)i;
+    }
+    if (best >= 0) { ctx->pool[(size_t)best].free = false; return ctx->pool[(size_t)best].ptr; }
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        // release cached free blocks and retry once
+        for (auto& b : ctx->pool) if (b.free && b.ptr) { (void)hipFree(b.ptr); b.ptr = nullptr; }
+        ctx->pool.erase(std::remove_if(ctx->pool.begin(), ctx->pool.end(), [](const PoolBlock& b) { return b.ptr == nullptr; }), ctx->pool.end());
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
+    ctx->pool.push_back({p, bytes, false});
+    return p;
+}
+void pool_free(sdqh_ctx* ctx, void* p) {
+    if (!p) return;
+    for (auto& b : ctx->pool) if (b.ptr == p) { b.free = true; return; }
+}
+
+// ---- profiling / timing ------------------------------------------------------------------------
+hipEvent_t next_event(sdqh_ctx* ctx) {
+    if (ctx->event_next == ctx->event_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); ctx->event_pool.push_back(e); }
+    return ctx->event_pool[ctx->event_next++];
+}
+void call_begin(sdqh_ctx* ctx) {
+    ctx->prof.clear(); ctx->event_next = 0;
+    (void)hipEventRecord(ctx->call_begin, ctx->stream);
+    ctx->call_timed = false;
+}
+void call_end(sdqh_ctx* ctx) {
+    (void)hipEventRecord(ctx->call_end, ctx->stream);
+    ctx->call_timed = true;
+}
+struct KernelScope {
+    sdqh_ctx* ctx; size_t idx = (size_t)-1;
+    KernelScope(sdqh_ctx* c, const char* name) : ctx(c) {
+        if (!c->profiling) return;
+        ProfEntry e{name, next_event(c), next_event(c), 0.0};
+        (void)hipEventRecord(e.e0, c->stream);
+        idx = c->prof.size(); c->prof.push_back(e);
+    }
+    ~KernelScope() { if (idx != (size_t)-1) (void)hipEventRecord(ctx->prof[idx].e1, ctx->stream); }
+};
+#define LAUNCH(ctx, name, kernel, grid, ...)                                         \
+    do { KernelScope _ks(ctx, name); hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3(TPB), 0, (ctx)->stream, __VA_ARGS__); } while (0)
+
+int sync_stream(sdqh_ctx* ctx) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->profiling) for (auto& e : ctx->prof) { float ms = 0; if (hipEventElapsedTime(&ms, e.e0, e.e1) == hipSuccess) e.ms = ms; }
+    return SDQH_OK;
+}
+
+// ---- argument conversion -------------------------------------------------------------------------
+int tuple_nops(int shape) {
+    switch (shape) {
+        case SDQH_TUPLE_A: return 1; case SDQH_TUPLE_AB: return 2; case SDQH_TUPLE_A_1MB: return 2;
+        case SDQH_TUPLE_PRICING: return 4; case SDQH_TUPLE_A_1MB_M_CD: return 4; case SDQH_TUPLE_COUNT: return 0;
+        default: return -1;
+    }
+}
+int tuple_nv(int shape) {
+    switch (shape) {
+        case SDQH_TUPLE_PRICING: return 4; case SDQH_TUPLE_COUNT: return 0;
+        case SDQH_TUPLE_A: case SDQH_TUPLE_AB: case SDQH_TUPLE_A_1MB: case SDQH_TUPLE_A_1MB_M_CD: return 1;
+        default: return -1;
+    }
+}
+
+int check_col(sdqh_ctx* ctx, const sdqh_column* c, int dtype, int64_t nrows, const char* what) {
+    if (!c) return fail(ctx, SDQH_ERR_INVALID, std::string(what) + ": null column");
+    if (c->dtype != dtype) return fail(ctx, SDQH_ERR_INVALID, std::string(what) + ": wrong dtype");
+    if (c->nrows < nrows) return fail(ctx, SDQH_ERR_INVALID, std::string(what) + ": column shorter than nrows");
+    return SDQH_OK;
+}
+
+int make_tuple(sdqh_ctx* ctx, int64_t nrows, const sdqh_tuple* t, DevTuple* out) {
+    if (!t) return fail(ctx, SDQH_ERR_INVALID, "null tuple");
+    int nops = tuple_nops(t->shape);
+    if (nops < 0) return fail(ctx, SDQH_ERR_UNSUPPORTED, "unknown tuple shape");
+    const sdqh_column* ops[4] = {t->a, t->b, t->c, t->d};
+    for (int j = 0; j < 4; ++j) out->op[j] = nullptr;
+    for (int j = 0; j < nops; ++j) {
+        if (int rc = check_col(ctx, ops[j], SDQH_F64, nrows, "tuple operand")) return rc;
+        out->op[j] = static_cast<const double*>(ops[j]->data);
+    }
+    return SDQH_OK;
+}
+
+// f-predicates on a column that is also a value operand become ranges on the operand slot.
+int make_filter(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* f, const sdqh_tuple* t, DevFilter* d) {
+    std::memset(d, 0, sizeof(*d));
+    if (!f) return SDQH_OK;
+    if (f->n_ipred < 0 || f->n_ipred > SDQH_MAX_IPRED || f->n_fpred < 0 || f->n_fpred > SDQH_MAX_FPRED || f->n_spred < 0 || f->n_spred > SDQH_MAX_SPRED)
+        return fail(ctx, SDQH_ERR_INVALID, "filter: predicate count out of range");
+    for (int i = 0; i < f->n_ipred; ++i) {
+        if (int rc = check_col(ctx, f->ipred[i].col, SDQH_I64, nrows, "ipred")) return rc;
+        d->ic[d->ni] = static_cast<const int64_t*>(f->ipred[i].col->data); d->ilo[d->ni] = f->ipred[i].lo; d->ihi[d->ni] = f->ipred[i].hi; d->ni++;
+    }
+    const int nops = t ? tuple_nops(t->shape) : 0;
+    const sdqh_column* ops[4] = {t ? t->a : nullptr, t ? t->b : nullptr, t ? t->c : nullptr, t ? t->d : nullptr};
+    for (int i = 0; i < f->n_fpred; ++i) {
+        if (int rc = check_col(ctx, f->fpred[i].col, SDQH_F64, nrows, "fpred")) return rc;
+        int alias = -1;
+        for (int j = 0; j < nops; ++j) if (ops[j] && ops[j]->data == f->fpred[i].col->data) { alias = j; break; }
+        if (alias >= 0) {
+            if ((d->omask >> alias) & 1u) { d->olo[alias] = std::max(d->olo[alias], f->fpred[i].lo); d->ohi[alias] = std::min(d->ohi[alias], f->fpred[i].hi); }
+            else { d->omask |= 1u << alias; d->olo[alias] = f->fpred[i].lo; d->ohi[alias] = f->fpred[i].hi; }
+        } else {
+            d->fc[d->nf] = static_cast<const double*>(f->fpred[i].col->data); d->flo[d->nf] = f->fpred[i].lo; d->fhi[d->nf] = f->fpred[i].hi; d->nf++;
+        }
+    }
+    if (f->n_spred == 1) {
+        if (int rc = check_col(ctx, f->spred[0].col, SDQH_STR, nrows, "spred")) return rc;
+        if (f->spred[0].len < 0 || f->spred[0].len > SDQH_MAX_STR_CONST) return fail(ctx, SDQH_ERR_INVALID, "spred: constant too long");
+        d->ns = 1; d->sc = static_cast<const uint32_t*>(f->spred[0].col->data); d->swidth = f->spred[0].col->width;
+        d->slen = f->spred[0].len; d->sneg = f->spred[0].negate;
+        std::memcpy(d->sval, f->spred[0].value, sizeof(uint32_t) * SDQH_MAX_STR_CONST);
+    }
+    return SDQH_OK;
+}
+
+int make_probes(sdqh_ctx* ctx, int64_t nrows, int nprobes, const sdqh_probe* probes, DevProbes* d) {
+    std::memset(d, 0, sizeof(*d));
+    if (nprobes < 0 || nprobes > SDQH_MAX_PROBE) return fail(ctx, SDQH_ERR_INVALID, "too many probes");
+    for (int i = 0; i < nprobes; ++i) {
+        if (!probes[i].table) return fail(ctx, SDQH_ERR_INVALID, "probe: null table");
+        if (int rc = check_col(ctx, probes[i].key, SDQH_I64, nrows, "probe key")) return rc;
+        d->table[i] = probes[i].table->dev; d->key[i] = static_cast<const int64_t*>(probes[i].key->data);
+    }
+    d->n = nprobes;
+    return SDQH_OK;
+}
+
+unsigned stream_grid(const sdqh_ctx* ctx, int64_t nrows, int blocks_per_cu) {
+    int64_t tiles = (nrows + TILE_ROWS - 1) / TILE_ROWS;
+    int64_t cap = (int64_t)ctx->num_cu * blocks_per_cu;
+    return (unsigned)std::max<int64_t>(1, std::min(tiles, cap));
+}
+
+int ensure_minmax(sdqh_ctx* ctx, sdqh_column* c) {
+    if (c->have_minmax) return SDQH_OK;
+    if (c->dtype != SDQH_I64) return fail(ctx, SDQH_ERR_INVALID, "minmax: needs an I64 column");
+    if (!c->minmax_pending) {
+        if (!c->d_minmax) { c->d_minmax = static_cast<long long*>(pool_alloc(ctx, 16)); if (!c->d_minmax) return fail(ctx, SDQH_ERR_NOMEM, "minmax: out of device memory"); }
+        const long long init[2] = {INT64_MAX, INT64_MIN};
+        HIP_TRY(ctx, hipMemcpyAsync(c->d_minmax, init, 16, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // `init` is on the stack
+        if (c->nrows > 0) LAUNCH(ctx, "k_minmax", k_minmax, stream_grid(ctx, c->nrows, 4), static_cast<const int64_t*>(c->data), c->nrows, c->d_minmax);
+        c->minmax_pending = true;
+    }
+    long long host[2];
+    HIP_TRY(ctx, hipMemcpyAsync(host, c->d_minmax, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    c->mn = host[0]; c->mx = host[1]; c->have_minmax = true; c->minmax_pending = false;
+    return SDQH_OK;
+}
+
+#define DISPATCH_SHAPE(shape, CALL)                                                  \
+    switch (shape) {                                                                 \
+        case SDQH_TUPLE_A: { CALL(SDQH_TUPLE_A); break; }                             \
+        case SDQH_TUPLE_AB: { CALL(SDQH_TUPLE_AB); break; }                           \
+        case SDQH_TUPLE_A_1MB: { CALL(SDQH_TUPLE_A_1MB); break; }                     \
+        case SDQH_TUPLE_PRICING: { CALL(SDQH_TUPLE_PRICING); break; }                 \
+        case SDQH_TUPLE_A_1MB_M_CD: { CALL(SDQH_TUPLE_A_1MB_M_CD); break; }           \
+        case SDQH_TUPLE_COUNT: { CALL(SDQH_TUPLE_COUNT); break; }                     \
+        default: return fail(ctx, SDQH_ERR_UNSUPPORTED, "unknown tuple shape");       \
+    }
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int sdqh_abi_version(void) { return SDQH_ABI_VERSION; }
+const char* sdqh_backend_name(void) { return "hip-gfx950"; }
+
+int sdqh_create(int device, sdqh_ctx** out) {
+    if (!out) return SDQH_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return SDQH_ERR_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return SDQH_ERR_DEVICE;
+    sdqh_ctx* ctx = new sdqh_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->num_cu = prop.multiProcessorCount;
+    bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreate(&ctx->call_begin) == hipSuccess && hipEventCreate(&ctx->call_end) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i) {
+        ok = hipHostMalloc(&ctx->staging[i], STAGING_BYTES, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&ctx->staging_done[i], hipEventDisableTiming) == hipSuccess;
+    }
+    ok = ok && hipHostMalloc(&ctx->result_host, RESULT_BYTES, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMalloc(&ctx->result_dev, RESULT_BYTES) == hipSuccess;
+    if (!ok) { sdqh_destroy(ctx); return SDQH_ERR_DEVICE; }
+    *out = ctx;
+    return SDQH_OK;
+}
+
+void sdqh_destroy(sdqh_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& b : ctx->pool) if (b.ptr) (void)hipFree(b.ptr);
+    for (int i = 0; i < 2; ++i) { if (ctx->staging[i]) (void)hipHostFree(ctx->staging[i]); if (ctx->staging_done[i]) (void)hipEventDestroy(ctx->staging_done[i]); }
+    if (ctx->result_host) (void)hipHostFree(ctx->result_host);
+    if (ctx->result_dev) (void)hipFree(ctx->result_dev);
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->call_begin) (void)hipEventDestroy(ctx->call_begin);
+    if (ctx->call_end) (void)hipEventDestroy(ctx->call_end);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* sdqh_last_error(const sdqh_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+int sdqh_set_threads(sdqh_ctx* ctx, int threads) { if (!ctx || threads < 1) return SDQH_ERR_INVALID; ctx->threads = threads; return SDQH_OK; }
+int sdqh_synchronize(sdqh_ctx* ctx) { if (!ctx) return SDQH_ERR_INVALID; return sync_stream(ctx); }
+int sdqh_last_device_ms(const sdqh_ctx* cctx, double* ms) {
+    sdqh_ctx* ctx = const_cast<sdqh_ctx*>(cctx);
+    if (!ctx || !ms) return SDQH_ERR_INVALID;
+    if (!ctx->call_timed) { *ms = 0.0; return SDQH_OK; }
+    HIP_TRY(ctx, hipEventSynchronize(ctx->call_end));
+    float f = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&f, ctx->call_begin, ctx->call_end));
+    *ms = f;
+    return SDQH_OK;
+}
+int sdqh_set_profiling(sdqh_ctx* ctx, int enabled) { if (!ctx) return SDQH_ERR_INVALID; ctx->profiling = enabled != 0; return SDQH_OK; }
+int sdqh_profile_count(const sdqh_ctx* ctx) { return ctx ? (int)ctx->prof.size() : 0; }
+int sdqh_profile_entry(const sdqh_ctx* cctx, int i, const char** name, double* ms) {
+    sdqh_ctx* ctx = const_cast<sdqh_ctx*>(cctx);
+    if (!ctx || i < 0 || i >= (int)ctx->prof.size() || !name || !ms) return SDQH_ERR_INVALID;
+    ProfEntry& e = ctx->prof[(size_t)i];
+    if (e.ms == 0.0) { (void)hipEventSynchronize(e.e1); float f = 0; if (hipEventElapsedTime(&f, e.e0, e.e1) == hipSuccess) e.ms = f; }
+    *name = e.name; *ms = e.ms;
+    return SDQH_OK;
+}
+void* sdqh_stream(const sdqh_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+// ---- columns -----------------------------------------------------------------------------------
+static int new_column(sdqh_ctx* ctx, int64_t nrows, int dtype, int width, sdqh_column** out) {
+    if (!ctx || !out || nrows < 0) return fail(ctx, SDQH_ERR_INVALID, "column: bad arguments");
+    if (dtype != SDQH_I64 && dtype != SDQH_F64 && dtype != SDQH_STR) return fail(ctx, SDQH_ERR_INVALID, "column: bad dtype");
+    if (dtype == SDQH_STR && width < 1) return fail(ctx, SDQH_ERR_INVALID, "column: STR needs width >= 1");
+    sdqh_column* c = new sdqh_column();
+    c->nrows = nrows; c->dtype = dtype; c->width = dtype == SDQH_STR ? width : 0;
+    *out = c;
+    return SDQH_OK;
+}
+
+int sdqh_column_alloc(sdqh_ctx* ctx, int64_t nrows, int dtype, int width, sdqh_column** out) {
+    if (int rc = new_column(ctx, nrows, dtype, width, out)) return rc;
+    sdqh_column* c = *out;
+    (void)hipSetDevice(ctx->device);
+    c->data = pool_alloc(ctx, (size_t)nrows * c->row_bytes() + 64);
+    c->owned = true;
+    if (!c->data) { delete c; *out = nullptr; return fail(ctx, SDQH_ERR_NOMEM, "column_alloc: out of device memory"); }
+    return SDQH_OK;
+}
+
+int sdqh_column_upload(sdqh_ctx* ctx, const void* host, int64_t nrows, int dtype, int width, sdqh_column** out) {
+    if (nrows > 0 && !host) return fail(ctx, SDQH_ERR_INVALID, "column_upload: null host pointer");
+    if (int rc = sdqh_column_alloc(ctx, nrows, dtype, width, out)) return rc;
+    sdqh_column* c = *out;
+    const size_t bytes = (size_t)nrows * c->row_bytes();
+    // pinned staging ring: memcpy into buffer i while buffer 1-i is in flight to the device
+    size_t off = 0; int i = 0;
+    while (off < bytes) {
+        const size_t n = std::min(STAGING_BYTES, bytes - off);
+        if (ctx->staging_busy[i]) { HIP_TRY(ctx, hipEventSynchronize(ctx->staging_done[i])); ctx->staging_busy[i] = false; }
+        std::memcpy(ctx->staging[i], static_cast<const char*>(host) + off, n);
+        HIP_TRY(ctx, hipMemcpyAsync(static_cast<char*>(c->data) + off, ctx->staging[i], n, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->staging_done[i], ctx->stream));
+        ctx->staging_busy[i] = true;
+        off += n; i ^= 1;
+    }
+    for (int k = 0; k < 2; ++k) if (ctx->staging_busy[k]) { HIP_TRY(ctx, hipEventSynchronize(ctx->staging_done[k])); ctx->staging_busy[k] = false; }
+    return SDQH_OK;
+}
+
+int sdqh_column_wrap(sdqh_ctx* ctx, void* device_ptr, int64_t nrows, int dtype, int width, sdqh_column** out) {
+    if (nrows > 0 && (!device_ptr || (reinterpret_cast<uintptr_t>(device_ptr) & 15u))) return fail(ctx, SDQH_ERR_INVALID, "column_wrap: device pointer must be 16-byte aligned");
+    if (int rc = new_column(ctx, nrows, dtype, width, out)) return rc;
+    (*out)->data = device_ptr; (*out)->owned = false;
+    return SDQH_OK;
+}
+
+int sdqh_column_download(sdqh_ctx* ctx, const sdqh_column* col, int64_t row0, int64_t nrows, void* host) {
+    if (!ctx || !col || row0 < 0 || nrows < 0 || row0 + nrows > col->nrows || (nrows && !host)) return fail(ctx, SDQH_ERR_INVALID, "column_download: bad arguments");
+    if (nrows == 0) return SDQH_OK;
+    HIP_TRY(ctx, hipMemcpyAsync(host, static_cast<const char*>(col->data) + (size_t)row0 * col->row_bytes(), (size_t)nrows * col->row_bytes(), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return SDQH_OK;
+}
+void* sdqh_column_data(const sdqh_column* col) { return col ? col->data : nullptr; }
+int64_t sdqh_column_rows(const sdqh_column* col) { return col ? col->nrows : -1; }
+int sdqh_column_dtype(const sdqh_column* col) { return col ? col->dtype : -1; }
+int sdqh_column_width(const sdqh_column* col) { return col ? col->width : -1; }
+int sdqh_column_minmax(sdqh_ctx* ctx, const sdqh_column* col, int64_t* mn, int64_t* mx) {
+    if (!ctx || !col || !mn || !mx) return fail(ctx, SDQH_ERR_INVALID, "column_minmax: bad arguments");
+    if (int rc = ensure_minmax(ctx, const_cast<sdqh_column*>(col))) return rc;
+    *mn = col->mn; *mx = col->mx;
+    return SDQH_OK;
+}
+void sdqh_column_free(sdqh_ctx* ctx, sdqh_column* col) {
+    if (!col) return;
+    if (ctx) { if (col->owned) pool_free(ctx, col->data); pool_free(ctx, col->d_minmax); }
+    delete col;
+}
+
+// ---- K-A ---------------------------------------------------------------------------------------
+int sdqh_scan_filter_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, const sdqh_tuple* tuple,
+                         double* out_values, int64_t* out_count) {
+    if (!ctx || nrows < 0) return fail(ctx, SDQH_ERR_INVALID, "scan_filter_sum: bad arguments");
+    (void)hipSetDevice(ctx->device);
+    DevFilter f; DevTuple t;
+    if (int rc = make_tuple(ctx, nrows, tuple, &t)) return rc;
+    if (int rc = make_filter(ctx, nrows, filter, tuple, &f)) return rc;
+    const unsigned grid = stream_grid(ctx, nrows, 8);
+    double* partial = static_cast<double*>(pool_alloc(ctx, (size_t)grid * 5 * sizeof(double)));
+    if (!partial) return fail(ctx, SDQH_ERR_NOMEM, "scan_filter_sum: out of device memory");
+    double* out_dev = static_cast<double*>(ctx->result_dev);
+    call_begin(ctx);
+#define CALL(S) LAUNCH(ctx, "k_scan_sum", (k_scan_sum<S>), grid, f, t, nrows, partial)
+    DISPATCH_SHAPE(tuple->shape, CALL)
+#undef CALL
+    LAUNCH(ctx, "k_sum_partials", k_sum_partials, 1, partial, (int)grid, out_dev);
+    call_end(ctx);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->result_host, out_dev, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    int rc = sync_stream(ctx);
+    pool_free(ctx, partial);
+    if (rc) return rc;
+    const double* h = static_cast<const double*>(ctx->result_host);
+    const int nv = tuple_nv(tuple->shape);
+    if (out_values) for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) out_values[k] = k < nv ? h[k] : 0.0;
+    if (out_count) *out_count = reinterpret_cast<const int64_t*>(h)[4];
+    return SDQH_OK;
+}
+
+// ---- K-C small ---------------------------------------------------------------------------------
+int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nkeys, const sdqh_column* const* keys,
+                       const sdqh_tuple* tuple, int max_groups, int64_t* out_keys, double* out_values, int64_t* out_counts,
+                       int32_t* out_ngroups) {
+    if (!ctx || nrows < 0 || nkeys < 1 || nkeys > SDQH_MAX_GROUPKEYS || !keys || max_groups < 1 || max_groups > SDQH_MAX_SMALL_GROUPS || !out_ngroups)
+        return fail(ctx, SDQH_ERR_INVALID, "groupby_small: bad arguments");
+    (void)hipSetDevice(ctx->device);
+    DevFilter f; DevTuple t; DevGroupKeys gk;
+    std::memset(&gk, 0, sizeof(gk));
+    if (int rc = make_tuple(ctx, nrows, tuple, &t)) return rc;
+    if (int rc = make_filter(ctx, nrows, filter, tuple, &f)) return rc;
+    for (int k = 0; k < nkeys; ++k) {
+        if (!keys[k] || keys[k]->nrows < nrows) return fail(ctx, SDQH_ERR_INVALID, "groupby_small: bad key column");
+        if (keys[k]->dtype == SDQH_STR) { if (keys[k]->width != 1) return fail(ctx, SDQH_ERR_UNSUPPORTED, "groupby_small: STR keys must have width 1"); gk.is_str[k] = 1; }
+        else if (keys[k]->dtype == SDQH_I64) gk.is_str[k] = 0;
+        else return fail(ctx, SDQH_ERR_UNSUPPORTED, "groupby_small: key dtype");
+        gk.col[k] = keys[k]->data;
+    }
+    gk.nkeys = nkeys;
+    constexpr int GREG = 8, GMAX = SDQH_MAX_SMALL_GROUPS;
+    const unsigned grid = stream_grid(ctx, nrows, 4);
+    // partials sized for the LDS variant (64 groups) so one allocation serves both attempts
+    const size_t nslots = (size_t)grid * GMAX;
+    char* blob = static_cast<char*>(pool_alloc(ctx, nslots * (8 + 32 + 8 + 1) + 256));
+    if (!blob) return fail(ctx, SDQH_ERR_NOMEM, "groupby_small: out of device memory");
+    unsigned long long* pkeys = reinterpret_cast<unsigned long long*>(blob);
+    double* pacc = reinterpret_cast<double*>(blob + nslots * 8);
+    int64_t* pcnt = reinterpret_cast<int64_t*>(blob + nslots * 40);
+    signed char* slotmap = reinterpret_cast<signed char*>(blob + nslots * 48);
+    // result block in ctx->result_dev: keys[64] | acc[64][4] | cnt[64] | ngroups | flags
+    char* rd = static_cast<char*>(ctx->result_dev);
+    unsigned long long* r_keys = reinterpret_cast<unsigned long long*>(rd);
+    double* r_acc = reinterpret_cast<double*>(rd + GMAX * 8);
+    int64_t* r_cnt = reinterpret_cast<int64_t*>(rd + GMAX * 40);
+    int* r_ng = reinterpret_cast<int*>(rd + GMAX * 48);
+    int* r_flags = r_ng + 1;
+    const size_t rbytes = GMAX * 48 + 8;
+
+    bool use_lds = true;
+    for (int k = 0; k < nkeys; ++k) use_lds = use_lds && (ctx->lds_hint[k] == gk.col[k]);
+    for (int k = nkeys; k < SDQH_MAX_GROUPKEYS; ++k) use_lds = use_lds && (ctx->lds_hint[k] == nullptr);
+    int rc = SDQH_OK;
+    const char* h = static_cast<const char*>(ctx->result_host);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        call_begin(ctx);
+        HIP_TRY(ctx, hipMemsetAsync(r_ng, 0, 8, ctx->stream));
+        const int G = use_lds ? GMAX : GREG;
+        if (!use_lds) {
+#define CALL(S) LAUNCH(ctx, "k_groupby_reg", (k_groupby_reg<S, GREG>), grid, f, t, gk, nrows, pkeys, pacc, pcnt, r_flags)
+            DISPATCH_SHAPE(tuple->shape, CALL)
+#undef CALL
+        } else {
+#define CALL(S) LAUNCH(ctx, "k_groupby_lds", (k_groupby_lds<S>), grid, f, t, gk, nrows, pkeys, pacc, pcnt, r_flags)
+            DISPATCH_SHAPE(tuple->shape, CALL)
+#undef CALL
+        }
+        LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, 1, pkeys, pacc, pcnt, (int)grid, G, max_groups, slotmap, r_keys, r_acc, r_cnt, r_ng, r_flags);
+        call_end(ctx);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->result_host, rd, rbytes, hipMemcpyDeviceToHost, ctx->stream));
+        rc = sync_stream(ctx);
+        if (rc) break;
+        const int flags = *reinterpret_cast<const int*>(h + GMAX * 48 + 4);
+        if (flags & 2) { rc = fail(ctx, SDQH_ERR_UNSUPPORTED, "groupby_small: I64 key outside [0, 2^32-2]"); break; }
+        if (flags & 1) {
+            if (!use_lds) { use_lds = true; for (int k = 0; k < SDQH_MAX_GROUPKEYS; ++k) ctx->lds_hint[k] = k < nkeys ? gk.col[k] : nullptr; continue; }
+            *out_ngroups = *reinterpret_cast<const int*>(h + GMAX * 48);
+            rc = fail(ctx, SDQH_ERR_OVERFLOW, "groupby_small: more groups than max_groups");
+        }
+        break;
+    }
+    pool_free(ctx, blob);
+    if (rc) return rc;
+    const int ng = *reinterpret_cast<const int*>(h + GMAX * 48);
+    const unsigned long long* hk = reinterpret_cast<const unsigned long long*>(h);
+    const double* ha = reinterpret_cast<const double*>(h + GMAX * 8);
+    const int64_t* hc = reinterpret_cast<const int64_t*>(h + GMAX * 40);
+    const int nv = tuple_nv(tuple->shape);
+    for (int g = 0; g < ng; ++g) {
+        if (out_keys) for (int k = 0; k < nkeys; ++k) out_keys[g * nkeys + k] = (int64_t)((hk[g] >> (32 * k)) & 0xFFFFFFFFull);
+        if (out_values) for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) out_values[g * SDQH_TUPLE_MAX_VALUES + k] = k < nv ? ha[g * 4 + k] : 0.0;
+        if (out_counts) out_counts[g] = hc[g];
+    }
+    *out_ngroups = ng;
+    return SDQH_OK;
+}
+
+// ---- K-B ---------------------------------------------------------------------------------------
+static void table_release(sdqh_ctx* ctx, sdqh_table* t) {
+    for (void* p : t->owned) pool_free(ctx, p);
+    t->owned.clear();
+}
+static void* table_alloc(sdqh_ctx* ctx, sdqh_table* t, size_t bytes) {
+    void* p = pool_alloc(ctx, bytes);
+    if (p) t->owned.push_back(p);
+    return p;
+}
+
+// stage layout shared by hash_build_unique and scan_compact
+static int setup_stage(sdqh_ctx* ctx, sdqh_table* tb, int64_t nrows, const sdqh_column* key, int npay, const sdqh_column* const* payload) {
+    DevStage& st = tb->stage;
+    std::memset(&st, 0, sizeof(st));
+    const int64_t target_segs = (int64_t)ctx->num_cu * 4 * (TPB / WAVE);        // 4 workgroups per CU, one segment per wave
+    int64_t seg_rows = (nrows + target_segs - 1) / target_segs;
+    seg_rows = std::max<int64_t>(128, (seg_rows + 127) / 128 * 128);
+    st.seg_rows = seg_rows;
+    st.nseg = (int32_t)std::max<int64_t>(1, (nrows + seg_rows - 1) / seg_rows);
+    st.npay = npay;
+    const size_t col_bytes = (size_t)std::max<int64_t>(nrows, 1) * 8 + 64;
+    st.key = static_cast<int64_t*>(table_alloc(ctx, tb, col_bytes));
+    st.src_key = static_cast<const int64_t*>(key->data);
+    bool ok = st.key != nullptr;
+    for (int p = 0; p < npay && ok; ++p) {
+        st.pay[p] = static_cast<int64_t*>(table_alloc(ctx, tb, col_bytes));
+        st.src_pay[p] = static_cast<const int64_t*>(payload[p]->data);
+        ok = st.pay[p] != nullptr;
+    }
+    st.seg_count = static_cast<uint32_t*>(table_alloc(ctx, tb, (size_t)st.nseg * 4 + 64));
+    ok = ok && st.seg_count != nullptr;
+    if (!ok) return fail(ctx, SDQH_ERR_NOMEM, "out of device memory for the build stage");
+    return SDQH_OK;
+}
+
+int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nprobes, const sdqh_probe* probes,
+                           const sdqh_column* key, int npayload, const sdqh_column* const* payload, int accumulate, sdqh_table** out) {
+    if (!ctx || nrows < 0 || !out || npayload < 0 || npayload > SDQH_MAX_PAYLOAD) return fail(ctx, SDQH_ERR_INVALID, "hash_build_unique: bad arguments");
+    if (nrows >= 0xFFFFFFFEll) return fail(ctx, SDQH_ERR_UNSUPPORTED, "hash_build_unique: build side limited to 2^32-2 rows per GPU");
+    (void)hipSetDevice(ctx->device);
+    DevFilter f; DevProbes pr;
+    if (int rc = make_filter(ctx, nrows, filter, nullptr, &f)) return rc;
+    if (int rc = make_probes(ctx, nrows, nprobes, probes, &pr)) return rc;
+    if (int rc = check_col(ctx, key, SDQH_I64, nrows, "build key")) return rc;
+    for (int p = 0; p < npayload; ++p)
+        if (!payload || !payload[p] || payload[p]->nrows < nrows || payload[p]->dtype == SDQH_STR)
+            return fail(ctx, SDQH_ERR_INVALID, "hash_build_unique: payload columns must be I64/F64 and cover nrows");
+    // exact key bitmap when the key range is dense enough to be worth it
+    int64_t lo = 0, hi = -1; bool want_bm = false;
+    if (nrows > 0) {
+        if (int rc = ensure_minmax(ctx, const_cast<sdqh_column*>(key))) return rc;
+        lo = key->mn; hi = key->mx;
+        if (hi >= lo && lo > INT64_MIN / 2 && hi < INT64_MAX / 2) {        // no overflow in hi - lo
+            const uint64_t range = (uint64_t)(hi - lo) + 1;
+            want_bm = range <= (1ull << 31) && range <= 64ull * (uint64_t)std::max<int64_t>(nrows, 1024);
+        }
+    }
+    sdqh_table* tb = new sdqh_table();
+    tb->npay = npayload; tb->accumulate = accumulate != 0; tb->nrows_build = nrows;
+    int rc = setup_stage(ctx, tb, nrows, key, npayload, payload);
+    uint64_t capmax = 1024;
+    while (capmax < 2 * (uint64_t)std::max<int64_t>(nrows, 1)) capmax <<= 1;
+    tb->capmax = capmax;
+    Slot* slots = nullptr; double* acc = nullptr;
+    if (!rc) {
+        tb->hdr = static_cast<TableHeader*>(table_alloc(ctx, tb, sizeof(TableHeader)));
+        slots = static_cast<Slot*>(table_alloc(ctx, tb, (capmax + 1) * sizeof(Slot)));
+        if (tb->accumulate) acc = static_cast<double*>(table_alloc(ctx, tb, (capmax + 1) * 4 * sizeof(double)));
+        size_t words = 0;
+        if (want_bm) { words = (size_t)(((uint64_t)(hi - lo) + 32) / 32); tb->bm = static_cast<uint32_t*>(table_alloc(ctx, tb, words * 4 + 64)); }
+        if (!tb->hdr || !slots || (tb->accumulate && !acc) || (want_bm && !tb->bm)) rc = fail(ctx, SDQH_ERR_NOMEM, "hash_build_unique: out of device memory");
+        else {
+            tb->dev.slots = slots; tb->dev.hdr = tb->hdr; tb->dev.acc = acc; tb->dev.bm = tb->bm;
+            tb->dev.bm_lo = lo; tb->dev.bm_hi = hi; tb->dev.bitmap_only = 0;
+            call_begin(ctx);
+            const unsigned seg_grid = (unsigned)((tb->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
+            LAUNCH(ctx, "k_stage", k_stage, seg_grid, f, pr, tb->stage, nrows);
+            LAUNCH(ctx, "k_clear", k_clear, (unsigned)ctx->num_cu * 4, tb->stage.seg_count, tb->stage.nseg, capmax, tb->hdr, slots);
+            if (want_bm) { hipError_t e = hipMemsetAsync(tb->bm, 0, words * 4, ctx->stream); if (e != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e)); }
+            LAUNCH(ctx, "k_insert", k_insert, seg_grid, tb->stage, tb->dev, tb->bm, tb->accumulate ? 1 : 0);
+            call_end(ctx);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, std::string("hash_build_unique launch: ") + hipGetErrorString(e));
+        }
+    }
+    if (rc) { table_release(ctx, tb); delete tb; return rc; }
+    *out = tb;
+    return SDQH_OK;
+}
+
+int sdqh_table_size(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t* entries) {
+    sdqh_table* table = const_cast<sdqh_table*>(ctable);
+    if (!ctx || !table || !entries) return fail(ctx, SDQH_ERR_INVALID, "table_size: bad arguments");
+    if (table->bitmap_only) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_size: bitmap-only table");
+    (void)hipSetDevice(ctx->device);
+    HIP_TRY(ctx, hipMemsetAsync(&table->hdr->distinct, 0, 8, ctx->stream));
+    LAUNCH(ctx, "k_count", k_count, (unsigned)ctx->num_cu * 4, table->dev.slots, table->hdr);
+    TableHeader* h = static_cast<TableHeader*>(ctx->result_host);
+    HIP_TRY(ctx, hipMemcpyAsync(h, table->hdr, sizeof(TableHeader), hipMemcpyDeviceToHost, ctx->stream));
+    if (int rc = sync_stream(ctx)) return rc;
+    *entries = (int64_t)h->distinct;
+    return SDQH_OK;
+}
+
+void sdqh_table_free(sdqh_ctx* ctx, sdqh_table* table) {
+    if (!table) return;
+    if (ctx) table_release(ctx, table);
+    delete table;
+}
+
+// ---- K-C large ---------------------------------------------------------------------------------
+int sdqh_hash_probe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, sdqh_table* table,
+                              const sdqh_column* key, const sdqh_tuple* tuple) {
+    if (!ctx || nrows < 0 || !table) return fail(ctx, SDQH_ERR_INVALID, "hash_probe_aggregate: bad arguments");
+    if (!table->accumulate || table->bitmap_only) return fail(ctx, SDQH_ERR_INVALID, "hash_probe_aggregate: table was built without accumulators");
+    (void)hipSetDevice(ctx->device);
+    DevFilter f; DevTuple t;
+    if (int rc = make_tuple(ctx, nrows, tuple, &t)) return rc;
+    if (int rc = make_filter(ctx, nrows, filter, tuple, &f)) return rc;
+    if (int rc = check_col(ctx, key, SDQH_I64, nrows, "probe key")) return rc;
+    table->compact_valid = false;
+    const int64_t* kc = static_cast<const int64_t*>(key->data);
+    const unsigned grid = stream_grid(ctx, nrows, 8);
+    call_begin(ctx);
+#define CALL(S) LAUNCH(ctx, "k_probe_agg", (k_probe_agg<S>), grid, f, t, table->dev, kc, nrows)
+    DISPATCH_SHAPE(tuple->shape, CALL)
+#undef CALL
+    call_end(ctx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, std::string("hash_probe_aggregate launch: ") + hipGetErrorString(e));
+    return SDQH_OK;
+}
+
+// ---- K-F ---------------------------------------------------------------------------------------
+// Runs the compaction into device buffers (cached on the table) and returns the row count.
+static int run_compact(sdqh_ctx* ctx, sdqh_table* table, int64_t min_hits) {
+    if (table->compact_valid && table->compact_min_hits == min_hits) return SDQH_OK;
+    DevCompactOut& o = table->compact;
+    const size_t rows = (size_t)std::max<int64_t>(table->nrows_build, 1) + 1;
+    if (!o.keys) {
+        o.keys = static_cast<int64_t*>(table_alloc(ctx, table, rows * 8));
+        o.hits = static_cast<int64_t*>(table_alloc(ctx, table, rows * 8));
+        o.counter = static_cast<unsigned long long*>(table_alloc(ctx, table, 64));
+        bool ok = o.keys && o.hits && o.counter;
+        for (int p = 0; p < table->npay && ok; ++p) { o.pay[p] = static_cast<int64_t*>(table_alloc(ctx, table, rows * 8)); ok = o.pay[p] != nullptr; }
+        if (table->accumulate) for (int k = 0; k < SDQH_TUPLE_MAX_VALUES && ok; ++k) { o.val[k] = static_cast<double*>(table_alloc(ctx, table, rows * 8)); ok = o.val[k] != nullptr; }
+        if (!ok) return fail(ctx, SDQH_ERR_NOMEM, "table_compact: out of device memory");
+        o.npay = table->npay; o.nval = table->accumulate ? SDQH_TUPLE_MAX_VALUES : 0;
+    }
+    call_begin(ctx);
+    HIP_TRY(ctx, hipMemsetAsync(o.counter, 0, 8, ctx->stream));
+    uint32_t mh = (uint32_t)std::min<int64_t>(std::max<int64_t>(min_hits, 0), 0xFFFFFFFFll);
+    LAUNCH(ctx, "k_compact", k_compact, (unsigned)ctx->num_cu * 4, table->dev, table->stage, o, mh);
+    call_end(ctx);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->result_host, o.counter, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (int rc = sync_stream(ctx)) return rc;
+    table->compact_n = (int64_t)*static_cast<const unsigned long long*>(ctx->result_host);
+    table->compact_min_hits = min_hits; table->compact_valid = true;
+    return SDQH_OK;
+}
+
+int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_hits, int64_t capacity,
+                       int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n) {
+    sdqh_table* table = const_cast<sdqh_table*>(ctable);
+    if (!ctx || !table || !out_n || capacity < 0) return fail(ctx, SDQH_ERR_INVALID, "table_compact: bad arguments");
+    if (table->bitmap_only) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_compact: bitmap-only table");
+    (void)hipSetDevice(ctx->device);
+    if (int rc = run_compact(ctx, table, min_hits)) return rc;
+    const int64_t n = table->compact_n;
+    *out_n = n;
+    if (!out_keys && !out_payload && !out_values && !out_hits) return SDQH_OK;        // count-only call
+    if (n > capacity) return fail(ctx, SDQH_ERR_OVERFLOW, "table_compact: capacity too small");
+    if (n == 0) return SDQH_OK;
+    const DevCompactOut& o = table->compact;
+    const size_t nb = (size_t)n * 8;
+    if (out_keys) HIP_TRY(ctx, hipMemcpyAsync(out_keys, o.keys, nb, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_payload) for (int p = 0; p < table->npay; ++p) HIP_TRY(ctx, hipMemcpyAsync(out_payload + (size_t)p * (size_t)capacity, o.pay[p], nb, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_values && table->accumulate) for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) HIP_TRY(ctx, hipMemcpyAsync(out_values + (size_t)k * (size_t)capacity, o.val[k], nb, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_values && !table->accumulate) std::memset(out_values, 0, (size_t)capacity * SDQH_TUPLE_MAX_VALUES * 8);
+    if (out_hits) HIP_TRY(ctx, hipMemcpyAsync(out_hits, o.hits, nb, hipMemcpyDeviceToHost, ctx->stream));
+    return sync_stream(ctx);
+}
+
+// ---- multi-GPU helpers -------------------------------------------------------------------------
+int sdqh_scan_compact(sdqh_ctx* ctx, int64_t, const sdqh_filter*, int, const sdqh_probe*, int, const sdqh_column* const*, sdqh_column**, int64_t*) {
+    return fail(ctx, SDQH_ERR_UNSUPPORTED, "scan_compact: not implemented in this build");
+}
+int sdqh_partition_by_key(sdqh_ctx* ctx, int64_t, const sdqh_column*, int, int, const sdqh_column* const*, sdqh_column**, int64_t*) {
+    return fail(ctx, SDQH_ERR_UNSUPPORTED, "partition_by_key: not implemented in this build");
+}
+int sdqh_table_export_bitmap(sdqh_ctx* ctx, const sdqh_table*, int64_t, int64_t, sdqh_column**) {
+    return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_export_bitmap: not implemented in this build");
+}
+int sdqh_table_from_bitmap(sdqh_ctx* ctx, const sdqh_column*, int64_t, int64_t, sdqh_table**) {
+    return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_from_bitmap: not implemented in this build");
+}
+
+}  // extern "C"

@@ -68,7 +68,6 @@ class Engine:
         self.ctx = ctx
         self._columns = {}         # id(ndarray) -> (ndarray, abi.Column)
         self.resident_bytes = 0
-        self.last_ops = []         # [(label, device_ms)] of the most recent query
 
     def close(self):
         self.clear()
@@ -358,7 +357,7 @@ def _materialize(eng, value, env):
     if isinstance(value, tuple) and value and value[0] == "aggregated":
         bt = env[value[1]]
         out_key_fields, vnames, count_idx, key_is_record, val_is_record, shape = bt.agg
-        n = bt.table.size()
+        n = eng.ctx.table_compact_count(bt.table, 1)
         keys, payload, values, hits = eng.ctx.table_compact(bt.table, 1, n)
         kf = []
         for fname, src in out_key_fields:
@@ -370,7 +369,7 @@ def _materialize(eng, value, env):
         vf = _value_arrays(vnames, count_idx, [values[j] for j in range(nv)], hits)
         return DictResult(kf, vf, key_is_record, val_is_record)
     if isinstance(value, BuiltTable):
-        n = value.table.size()
+        n = eng.ctx.table_compact_count(value.table, 0)
         keys, payload, _, _ = eng.ctx.table_compact(value.table, 0, n, want_values=False)
         vf = [(fname, keys if src == "key" else payload[src].view(value.payload_dtypes[src])) for fname, src in value.val_fields]
         return DictResult([(value.key_name, keys)], vf, value.key_is_record, value.val_is_record)
@@ -399,16 +398,11 @@ def execute_plan(eng, plan, args):
     accumulate_into = {op.probe.dict_name for op in plan.ops
                        if isinstance(op, ScanOp) and op.kind == "dict" and not op.unique and op.probe is not None}
     env = {}
-    eng.last_ops = []
     for op in plan.ops:
         if isinstance(op, ScanOp):
             env[op.out] = _run_scan(eng, op, tables[op.table], env, accumulate_into)
         elif isinstance(op, FinalizeOp):
             env[op.out] = _finalize(eng, op, env)
-        try:
-            eng.last_ops.append((op.out, eng.ctx.last_device_ms()))
-        except abi.SdqhError:
-            pass
     res = env[plan.result]
     if isinstance(res, (BuiltTable, tuple)):
         res = _materialize(eng, res, env)

@@ -1,0 +1,50 @@
+"""CPU-side checks of the drop-in boundary: both libraries export every symbol include/sdqh.h
+declares; the HIP library refuses to create a context without a GPU (no silent fall-back)."""
+import os
+import re
+
+import pytest
+
+from sdqlpy_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sdqh.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sdqh_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_binding_lists_every_declared_symbol():
+    assert sorted(abi.EXPORTS) == declared_symbols()
+
+
+def test_oracle_exports_every_symbol(oracle_lib):
+    for s in declared_symbols():
+        assert hasattr(oracle_lib.cdll, s), s
+    assert oracle_lib.backend_name() == "cpu-oracle"
+
+
+def test_hip_library_builds_loads_and_exports_every_symbol(hip_lib):
+    for s in declared_symbols():
+        assert hasattr(hip_lib.cdll, s), s
+    assert hip_lib.backend_name() == "hip-gfx950"
+
+
+def test_hip_library_fails_loudly_without_a_gpu(hip_lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(abi.SdqhError):
+        hip_lib.context(device=0)
+
+
+def test_python_mode_is_not_a_fallback():
+    from sdqlpy_amd.sdql_lib import sdqlpy_init, sr_dict
+    from sdqlpy_amd import tpch_queries as Q
+    sdqlpy_init(0, 1)
+    with pytest.raises(NotImplementedError):
+        Q.q6(sr_dict({"headers": [], "data": []}, None, True))
+    with pytest.raises(NotImplementedError):
+        sr_dict({}).sum(lambda p: p)

@@ -142,6 +142,10 @@ int         sdqh_profile_count(const sdqh_ctx* ctx);
 int         sdqh_profile_entry(const sdqh_ctx* ctx, int i, const char** name, double* ms);
 /* Raw hipStream_t the ctx launches on (NULL in the CPU build). */
 void*       sdqh_stream(const sdqh_ctx* ctx);
+/* Tuning knobs of the HIP build ("resident_cap", "probe_unroll", "stage_batch", "stage_eager",
+ * "stage_waves_per_cu", "direct_index"); results never depend on them.  The CPU build accepts and
+ * ignores any name. */
+int         sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value);
 
 /* ---- columns ----------------------------------------------------------------------------- */
 /* Copy a host column into device memory through a pinned staging ring (chunked, async H2D on

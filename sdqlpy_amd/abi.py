@@ -56,7 +56,7 @@ class Probe(C.Structure):
 EXPORTS = [
     "sdqh_abi_version", "sdqh_backend_name", "sdqh_create", "sdqh_destroy", "sdqh_last_error", "sdqh_set_threads",
     "sdqh_synchronize", "sdqh_last_device_ms", "sdqh_set_profiling", "sdqh_profile_count", "sdqh_profile_entry",
-    "sdqh_stream",
+    "sdqh_stream", "sdqh_set_option",
     "sdqh_column_upload", "sdqh_column_wrap", "sdqh_column_alloc", "sdqh_column_download", "sdqh_column_data",
     "sdqh_column_rows", "sdqh_column_dtype", "sdqh_column_width", "sdqh_column_minmax", "sdqh_column_free",
     "sdqh_scan_filter_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_table_size", "sdqh_table_free",
@@ -228,6 +228,9 @@ class Context:
     def stream(self):
         return self.lib.sdqh_stream(self.handle)
 
+    def set_option(self, name, value):
+        self._check(self.lib.sdqh_set_option(self.handle, name.encode(), C.c_int64(int(value))))
+
     # -- columns -----------------------------------------------------------------------------
     @staticmethod
     def _classify(arr):
@@ -385,6 +388,7 @@ class Library:
         L.sdqh_synchronize.argtypes = [C.c_void_p]
         L.sdqh_last_device_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.sdqh_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.sdqh_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         L.sdqh_profile_count.argtypes = [C.c_void_p]
         L.sdqh_profile_entry.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.sdqh_column_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]

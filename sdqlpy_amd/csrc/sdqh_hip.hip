@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "sdqh.h"
@@ -51,6 +52,14 @@ struct sdqh_ctx {
     // hint: key columns whose group count overflowed the register kernel last time
     const void* lds_hint[SDQH_MAX_GROUPKEYS] = {nullptr, nullptr};
     int threads = 1;
+    std::vector<std::pair<const void*, int>> occupancy;   // kernel -> resident workgroups per CU
+    // tuning knobs (sdqh_set_option)
+    int opt_resident_cap = 6;
+    int opt_probe_unroll = PROBE_UNROLL;
+    int opt_stage_batch = STAGE_BATCH;
+    int opt_stage_eager = 1;
+    int opt_stage_waves_per_cu = 16;
+    int opt_direct_index = 1;
 };
 
 struct sdqh_column {
@@ -65,8 +74,6 @@ struct sdqh_column {
     size_t row_bytes() const { return dtype == SDQH_STR ? (size_t)width * 4 : 8; }
 };
 
-constexpr int MAX_STAGE_PAY = SDQH_MAX_COMPACT_COLS - 1;
-
 struct sdqh_table {
     DevTable dev{};
     DevStage stage{};
@@ -77,12 +84,16 @@ struct sdqh_table {
     bool bitmap_only = false;
     int64_t nrows_build = 0;
     uint64_t capmax = 0;
+    bool index_built = false;
+    uint64_t nwords = 0;               // bitmap words (direct layout)
     std::vector<void*> owned;          // pool blocks to release
     // cached compaction (device buffers) for the two-step count / fetch protocol
     bool compact_valid = false;
     int64_t compact_min_hits = 0, compact_n = 0;
     DevCompactOut compact{};
 };
+
+static int ensure_index(sdqh_ctx* ctx, sdqh_table* tb);
 
 namespace {
 
@@ -228,15 +239,32 @@ int make_probes(sdqh_ctx* ctx, int64_t nrows, int nprobes, const sdqh_probe* pro
     for (int i = 0; i < nprobes; ++i) {
         if (!probes[i].table) return fail(ctx, SDQH_ERR_INVALID, "probe: null table");
         if (int rc = check_col(ctx, probes[i].key, SDQH_I64, nrows, "probe key")) return rc;
-        d->table[i] = probes[i].table->dev; d->key[i] = static_cast<const int64_t*>(probes[i].key->data);
+        sdqh_table* pt = const_cast<sdqh_table*>(probes[i].table);
+        if (!pt->bm) { if (int rc = ensure_index(ctx, pt)) return rc; }        // hash layout: contains() walks the slots
+        d->table[i] = pt->dev; d->key[i] = static_cast<const int64_t*>(probes[i].key->data);
     }
     d->n = nprobes;
     return SDQH_OK;
 }
 
-unsigned stream_grid(const sdqh_ctx* ctx, int64_t nrows, int blocks_per_cu) {
-    int64_t tiles = (nrows + TILE_ROWS - 1) / TILE_ROWS;
-    int64_t cap = (int64_t)ctx->num_cu * blocks_per_cu;
+// Workgroups of `kernel` that are resident per CU.  Streaming kernels are launched with exactly
+// num_cu * resident workgroups (a persistent grid striding over the tiles): a grid one wave of
+// workgroups larger than what fits leaves a tail in which most of the chip idles.
+// The occupancy API over-reports by one for SGPR-heavy 256-thread kernels on gfx950 / ROCm 7.2
+// (MI355X_MICROARCH.md, residency); these kernels all sit in that band, hence the cap of 6.
+template <class K>
+int resident_per_cu(sdqh_ctx* ctx, K kernel) {
+    const void* key = reinterpret_cast<const void*>(kernel);
+    for (auto& e : ctx->occupancy) if (e.first == key) return std::min(e.second, ctx->opt_resident_cap);
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, TPB, 0) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 2; }
+    ctx->occupancy.push_back({key, n});
+    return std::min(n, ctx->opt_resident_cap);
+}
+template <class K>
+unsigned stream_grid(sdqh_ctx* ctx, K kernel, int64_t nrows, int tile_rows = TILE_ROWS) {
+    int64_t tiles = (nrows + tile_rows - 1) / tile_rows;
+    int64_t cap = (int64_t)ctx->num_cu * resident_per_cu(ctx, kernel);
     return (unsigned)std::max<int64_t>(1, std::min(tiles, cap));
 }
 
@@ -248,7 +276,7 @@ int ensure_minmax(sdqh_ctx* ctx, sdqh_column* c) {
         const long long init[2] = {INT64_MAX, INT64_MIN};
         HIP_TRY(ctx, hipMemcpyAsync(c->d_minmax, init, 16, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // `init` is on the stack
-        if (c->nrows > 0) LAUNCH(ctx, "k_minmax", k_minmax, stream_grid(ctx, c->nrows, 4), static_cast<const int64_t*>(c->data), c->nrows, c->d_minmax);
+        if (c->nrows > 0) LAUNCH(ctx, "k_minmax", k_minmax, (unsigned)std::min<int64_t>((c->nrows + TPB - 1) / TPB, (int64_t)ctx->num_cu * 4), static_cast<const int64_t*>(c->data), c->nrows, c->d_minmax);
         c->minmax_pending = true;
     }
     long long host[2];
@@ -258,16 +286,44 @@ int ensure_minmax(sdqh_ctx* ctx, sdqh_column* c) {
     return SDQH_OK;
 }
 
-#define DISPATCH_SHAPE(shape, CALL)                                                  \
-    switch (shape) {                                                                 \
-        case SDQH_TUPLE_A: { CALL(SDQH_TUPLE_A); break; }                             \
-        case SDQH_TUPLE_AB: { CALL(SDQH_TUPLE_AB); break; }                           \
-        case SDQH_TUPLE_A_1MB: { CALL(SDQH_TUPLE_A_1MB); break; }                     \
-        case SDQH_TUPLE_PRICING: { CALL(SDQH_TUPLE_PRICING); break; }                 \
-        case SDQH_TUPLE_A_1MB_M_CD: { CALL(SDQH_TUPLE_A_1MB_M_CD); break; }           \
-        case SDQH_TUPLE_COUNT: { CALL(SDQH_TUPLE_COUNT); break; }                     \
-        default: return fail(ctx, SDQH_ERR_UNSUPPORTED, "unknown tuple shape");       \
+// ---- dispatch onto the compiled menu of kernel instances -------------------------------------------
+template <int S> using ShapeC = std::integral_constant<int, S>;
+template <class Fn>
+int with_shape(sdqh_ctx* ctx, int shape, Fn&& fn) {
+    switch (shape) {
+        case SDQH_TUPLE_A: return fn(ShapeC<SDQH_TUPLE_A>{});
+        case SDQH_TUPLE_AB: return fn(ShapeC<SDQH_TUPLE_AB>{});
+        case SDQH_TUPLE_A_1MB: return fn(ShapeC<SDQH_TUPLE_A_1MB>{});
+        case SDQH_TUPLE_PRICING: return fn(ShapeC<SDQH_TUPLE_PRICING>{});
+        case SDQH_TUPLE_A_1MB_M_CD: return fn(ShapeC<SDQH_TUPLE_A_1MB_M_CD>{});
+        case SDQH_TUPLE_COUNT: return fn(ShapeC<SDQH_TUPLE_COUNT>{});
+        default: return fail(ctx, SDQH_ERR_UNSUPPORTED, "unknown tuple shape");
     }
+}
+// filter layouts with their own instances; everything else runs on the generic instance
+template <class Fn>
+int with_scan_filter(const DevFilter& f, Fn&& fn) {          // K-A / K-C small / K-C large (no probes)
+    if (f.ns == 0 && f.nf == 0 && f.ni == 1) return fn(FCfg<1, 0, 0, 0>{});
+    if (f.ns == 0 && f.nf == 0 && f.ni == 0) return fn(FCfg<0, 0, 0, 0>{});
+    if (f.ns == 0 && f.nf == 1 && f.ni == 1) return fn(FCfg<1, 1, 0, 0>{});
+    return fn(FGeneric{});
+}
+template <class Fn>
+int with_stage_filter(const DevFilter& f, int nprobes, Fn&& fn) {      // K-B staging
+    if (f.ns == 0 && f.nf == 0 && f.ni == 1 && nprobes == 1) return fn(FCfg<1, 0, 0, 1>{});
+    if (f.ns == 0 && f.nf == 0 && f.ni == 1 && nprobes == 0) return fn(FCfg<1, 0, 0, 0>{});
+    if (f.ns == 1 && f.nf == 0 && f.ni == 0 && nprobes == 0) return fn(FCfg<0, 0, 1, 0>{});
+    if (f.ns == 0 && f.nf == 0 && f.ni == 0 && nprobes == 0) return fn(FCfg<0, 0, 0, 0>{});
+    if (f.ns == 0 && f.nf == 0 && f.ni == 0 && nprobes == 1) return fn(FCfg<0, 0, 0, 1>{});
+    return fn(FGeneric{});
+}
+template <class Fn>
+int with_group_keys(const DevGroupKeys& gk, Fn&& fn) {
+    if (gk.nkeys == 2 && gk.is_str[0] && gk.is_str[1]) return fn(KCfg<1, 1>{});
+    if (gk.nkeys == 1 && gk.is_str[0]) return fn(KCfg<1, 0>{});
+    if (gk.nkeys == 1 && !gk.is_str[0]) return fn(KCfg<2, 0>{});
+    return fn(KGeneric{});
+}
 
 }  // namespace
 
@@ -338,6 +394,18 @@ int sdqh_profile_entry(const sdqh_ctx* cctx, int i, const char** name, double* m
     return SDQH_OK;
 }
 void* sdqh_stream(const sdqh_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
+    if (!ctx || !name) return SDQH_ERR_INVALID;
+    const std::string n(name);
+    if (n == "resident_cap" && value >= 1 && value <= 8) ctx->opt_resident_cap = (int)value;
+    else if (n == "probe_unroll" && (value == 1 || value == 2 || value == 4)) ctx->opt_probe_unroll = (int)value;
+    else if (n == "stage_batch" && (value == 2 || value == 4 || value == 8)) ctx->opt_stage_batch = (int)value;
+    else if (n == "stage_eager" && (value == 0 || value == 1)) ctx->opt_stage_eager = (int)value;
+    else if (n == "stage_waves_per_cu" && value >= 4 && value <= 64) ctx->opt_stage_waves_per_cu = (int)value;
+    else if (n == "direct_index" && (value == 0 || value == 1)) ctx->opt_direct_index = (int)value;
+    else return fail(ctx, SDQH_ERR_INVALID, "set_option: unknown option or value out of range: " + n);
+    return SDQH_OK;
+}
 
 // ---- columns -----------------------------------------------------------------------------------
 static int new_column(sdqh_ctx* ctx, int64_t nrows, int dtype, int width, sdqh_column** out) {
@@ -418,14 +486,21 @@ int sdqh_scan_filter_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter
     DevFilter f; DevTuple t;
     if (int rc = make_tuple(ctx, nrows, tuple, &t)) return rc;
     if (int rc = make_filter(ctx, nrows, filter, tuple, &f)) return rc;
-    const unsigned grid = stream_grid(ctx, nrows, 8);
-    double* partial = static_cast<double*>(pool_alloc(ctx, (size_t)grid * 5 * sizeof(double)));
-    if (!partial) return fail(ctx, SDQH_ERR_NOMEM, "scan_filter_sum: out of device memory");
+    unsigned grid = 1;
+    double* partial = nullptr;
     double* out_dev = static_cast<double*>(ctx->result_dev);
-    call_begin(ctx);
-#define CALL(S) LAUNCH(ctx, "k_scan_sum", (k_scan_sum<S>), grid, f, t, nrows, partial)
-    DISPATCH_SHAPE(tuple->shape, CALL)
-#undef CALL
+    int lrc = with_shape(ctx, tuple->shape, [&](auto S) {
+        return with_scan_filter(f, [&](auto FC) {
+            auto kern = k_scan_sum<decltype(S)::value, decltype(FC)>;
+            grid = stream_grid(ctx, kern, nrows);
+            partial = static_cast<double*>(pool_alloc(ctx, (size_t)grid * 5 * sizeof(double)));
+            if (!partial) return fail(ctx, SDQH_ERR_NOMEM, "scan_filter_sum: out of device memory");
+            call_begin(ctx);
+            LAUNCH(ctx, "k_scan_sum", kern, grid, f, t, nrows, partial);
+            return SDQH_OK;
+        });
+    });
+    if (lrc) return lrc;
     LAUNCH(ctx, "k_sum_partials", k_sum_partials, 1, partial, (int)grid, out_dev);
     call_end(ctx);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->result_host, out_dev, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -459,15 +534,9 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
     }
     gk.nkeys = nkeys;
     constexpr int GREG = 8, GMAX = SDQH_MAX_SMALL_GROUPS;
-    const unsigned grid = stream_grid(ctx, nrows, 4);
-    // partials sized for the LDS variant (64 groups) so one allocation serves both attempts
-    const size_t nslots = (size_t)grid * GMAX;
-    char* blob = static_cast<char*>(pool_alloc(ctx, nslots * (8 + 32 + 8 + 1) + 256));
-    if (!blob) return fail(ctx, SDQH_ERR_NOMEM, "groupby_small: out of device memory");
-    unsigned long long* pkeys = reinterpret_cast<unsigned long long*>(blob);
-    double* pacc = reinterpret_cast<double*>(blob + nslots * 8);
-    int64_t* pcnt = reinterpret_cast<int64_t*>(blob + nslots * 40);
-    signed char* slotmap = reinterpret_cast<signed char*>(blob + nslots * 48);
+    bool use_lds = true;
+    for (int k = 0; k < nkeys; ++k) use_lds = use_lds && (ctx->lds_hint[k] == gk.col[k]);
+    for (int k = nkeys; k < SDQH_MAX_GROUPKEYS; ++k) use_lds = use_lds && (ctx->lds_hint[k] == nullptr);
     // result block in ctx->result_dev: keys[64] | acc[64][4] | cnt[64] | ngroups | flags
     char* rd = static_cast<char*>(ctx->result_dev);
     unsigned long long* r_keys = reinterpret_cast<unsigned long long*>(rd);
@@ -476,42 +545,62 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
     int* r_ng = reinterpret_cast<int*>(rd + GMAX * 48);
     int* r_flags = r_ng + 1;
     const size_t rbytes = GMAX * 48 + 8;
-
-    bool use_lds = true;
-    for (int k = 0; k < nkeys; ++k) use_lds = use_lds && (ctx->lds_hint[k] == gk.col[k]);
-    for (int k = nkeys; k < SDQH_MAX_GROUPKEYS; ++k) use_lds = use_lds && (ctx->lds_hint[k] == nullptr);
     int rc = SDQH_OK;
     const char* h = static_cast<const char*>(ctx->result_host);
     for (int attempt = 0; attempt < 2; ++attempt) {
-        call_begin(ctx);
-        HIP_TRY(ctx, hipMemsetAsync(r_ng, 0, 8, ctx->stream));
         const int G = use_lds ? GMAX : GREG;
-        if (!use_lds) {
-#define CALL(S) LAUNCH(ctx, "k_groupby_reg", (k_groupby_reg<S, GREG>), grid, f, t, gk, nrows, pkeys, pacc, pcnt, r_flags)
-            DISPATCH_SHAPE(tuple->shape, CALL)
-#undef CALL
-        } else {
-#define CALL(S) LAUNCH(ctx, "k_groupby_lds", (k_groupby_lds<S>), grid, f, t, gk, nrows, pkeys, pacc, pcnt, r_flags)
-            DISPATCH_SHAPE(tuple->shape, CALL)
-#undef CALL
-        }
-        LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, 1, pkeys, pacc, pcnt, (int)grid, G, max_groups, slotmap, r_keys, r_acc, r_cnt, r_ng, r_flags);
+        unsigned grid = 1;
+        char* blob = nullptr;
+        unsigned long long* pkeys = nullptr; double* pacc = nullptr; int64_t* pcnt = nullptr;
+        auto carve = [&]() {
+            const size_t nslots = (size_t)grid * G;
+            blob = static_cast<char*>(pool_alloc(ctx, nslots * 48 + 256));
+            if (!blob) return fail(ctx, SDQH_ERR_NOMEM, "groupby_small: out of device memory");
+            pkeys = reinterpret_cast<unsigned long long*>(blob);
+            pacc = reinterpret_cast<double*>(blob + nslots * 8);
+            pcnt = reinterpret_cast<int64_t*>(blob + nslots * 40);
+            call_begin(ctx);
+            hipError_t e = hipMemsetAsync(r_ng, 0, 8, ctx->stream);
+            return e == hipSuccess ? SDQH_OK : fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e));
+        };
+        int lrc = with_shape(ctx, tuple->shape, [&](auto S) {
+            constexpr int SH = decltype(S)::value;
+            if (use_lds) {
+                auto kern = k_groupby_lds<SH>;
+                grid = stream_grid(ctx, kern, nrows);
+                if (int c = carve()) return c;
+                LAUNCH(ctx, "k_groupby_lds", kern, grid, f, t, gk, nrows, pkeys, pacc, pcnt, r_flags);
+                return SDQH_OK;
+            }
+            return with_scan_filter(f, [&](auto FC) {
+                return with_group_keys(gk, [&](auto KC) {
+                    auto kern = k_groupby_reg<SH, GREG, decltype(FC), decltype(KC)>;
+                    grid = stream_grid(ctx, kern, nrows);
+                    if (int c = carve()) return c;
+                    LAUNCH(ctx, "k_groupby_reg", kern, grid, f, t, gk, nrows, pkeys, pacc, pcnt, r_flags);
+                    return SDQH_OK;
+                });
+            });
+        });
+        if (lrc) { if (blob) pool_free(ctx, blob); return lrc; }
+        LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, GMAX, pkeys, pacc, pcnt, (int)grid, G, r_keys, r_acc, r_cnt, r_ng, r_flags);
         call_end(ctx);
         HIP_TRY(ctx, hipMemcpyAsync(ctx->result_host, rd, rbytes, hipMemcpyDeviceToHost, ctx->stream));
         rc = sync_stream(ctx);
+        pool_free(ctx, blob);
         if (rc) break;
         const int flags = *reinterpret_cast<const int*>(h + GMAX * 48 + 4);
         if (flags & 2) { rc = fail(ctx, SDQH_ERR_UNSUPPORTED, "groupby_small: I64 key outside [0, 2^32-2]"); break; }
         if (flags & 1) {
             if (!use_lds) { use_lds = true; for (int k = 0; k < SDQH_MAX_GROUPKEYS; ++k) ctx->lds_hint[k] = k < nkeys ? gk.col[k] : nullptr; continue; }
-            *out_ngroups = *reinterpret_cast<const int*>(h + GMAX * 48);
+            *out_ngroups = GMAX + 1;
             rc = fail(ctx, SDQH_ERR_OVERFLOW, "groupby_small: more groups than max_groups");
         }
         break;
     }
-    pool_free(ctx, blob);
     if (rc) return rc;
     const int ng = *reinterpret_cast<const int*>(h + GMAX * 48);
+    if (ng > max_groups) { *out_ngroups = ng; return fail(ctx, SDQH_ERR_OVERFLOW, "groupby_small: more groups than max_groups"); }
     const unsigned long long* hk = reinterpret_cast<const unsigned long long*>(h);
     const double* ha = reinterpret_cast<const double*>(h + GMAX * 8);
     const int64_t* hc = reinterpret_cast<const int64_t*>(h + GMAX * 40);
@@ -540,9 +629,10 @@ static void* table_alloc(sdqh_ctx* ctx, sdqh_table* t, size_t bytes) {
 static int setup_stage(sdqh_ctx* ctx, sdqh_table* tb, int64_t nrows, const sdqh_column* key, int npay, const sdqh_column* const* payload) {
     DevStage& st = tb->stage;
     std::memset(&st, 0, sizeof(st));
-    const int64_t target_segs = (int64_t)ctx->num_cu * 4 * (TPB / WAVE);        // 4 workgroups per CU, one segment per wave
+    const int64_t target_segs = (int64_t)ctx->num_cu * ctx->opt_stage_waves_per_cu;   // one segment per wave
     int64_t seg_rows = (nrows + target_segs - 1) / target_segs;
-    seg_rows = std::max<int64_t>(128, (seg_rows + 127) / 128 * 128);
+    const int64_t gran = (int64_t)WAVE * ROWS_PER_LOAD * 8;                      // a whole number of k_stage iterations for every batch depth
+    seg_rows = std::max<int64_t>(gran, (seg_rows + gran - 1) / gran * gran);
     st.seg_rows = seg_rows;
     st.nseg = (int32_t)std::max<int64_t>(1, (nrows + seg_rows - 1) / seg_rows);
     st.npay = npay;
@@ -556,8 +646,42 @@ static int setup_stage(sdqh_ctx* ctx, sdqh_table* tb, int64_t nrows, const sdqh_
         ok = st.pay[p] != nullptr;
     }
     st.seg_count = static_cast<uint32_t*>(table_alloc(ctx, tb, (size_t)st.nseg * 4 + 64));
-    ok = ok && st.seg_count != nullptr;
+    st.shits = static_cast<uint32_t*>(table_alloc(ctx, tb, (size_t)std::max<int64_t>(nrows, 1) * 4 + 64));
+    ok = ok && st.seg_count != nullptr && st.shits != nullptr;
+    if (ok && tb->accumulate) { st.sacc = static_cast<double*>(table_alloc(ctx, tb, (size_t)std::max<int64_t>(nrows, 1) * 32 + 64)); ok = st.sacc != nullptr; }
     if (!ok) return fail(ctx, SDQH_ERR_NOMEM, "out of device memory for the build stage");
+    return SDQH_OK;
+}
+
+// The key -> stage-row index is built on first need: a table that is only ever used as a
+// semi-join filter through its exact bitmap never pays for one.
+static int ensure_index(sdqh_ctx* ctx, sdqh_table* tb) {
+    if (tb->index_built || tb->bitmap_only) return SDQH_OK;
+    const unsigned seg_grid = (unsigned)((tb->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
+    const size_t rows = (size_t)std::max<int64_t>(tb->nrows_build, 1);
+    if (tb->bm) {                                                          // direct layout
+        const int nblocks = (int)((tb->nwords + RANK_BLOCK_WORDS - 1) / RANK_BLOCK_WORDS);
+        uint32_t* wprefix = static_cast<uint32_t*>(table_alloc(ctx, tb, tb->nwords * 4 + 64));
+        uint32_t* bprefix = static_cast<uint32_t*>(table_alloc(ctx, tb, (size_t)nblocks * 4 + 64));
+        uint32_t* dense = static_cast<uint32_t*>(table_alloc(ctx, tb, rows * 4 + 64));
+        if (!wprefix || !bprefix || !dense) return fail(ctx, SDQH_ERR_NOMEM, "table index: out of device memory");
+        tb->dev.wprefix = wprefix; tb->dev.bprefix = bprefix; tb->dev.dense_ref = dense;
+        LAUNCH(ctx, "k_rank_words", k_rank_words, (unsigned)nblocks, tb->bm, tb->nwords, wprefix, bprefix);
+        LAUNCH(ctx, "k_rank_blocks", k_rank_blocks, 1, bprefix, nblocks, tb->hdr);
+        LAUNCH(ctx, "k_fill_refs", k_fill_refs, (unsigned)ctx->num_cu * 2, tb->stage, tb->dev);
+        LAUNCH(ctx, "k_insert_direct", k_insert_direct, seg_grid, tb->stage, tb->dev);
+    } else {                                                               // hash layout
+        int64_t* keys = static_cast<int64_t*>(table_alloc(ctx, tb, (tb->capmax + 2) * 8));
+        uint32_t* rowref = static_cast<uint32_t*>(table_alloc(ctx, tb, (tb->capmax + 2) * 4));
+        if (!keys || !rowref) return fail(ctx, SDQH_ERR_NOMEM, "table index: out of device memory");
+        tb->dev.keys = keys; tb->dev.rowref = rowref;
+        LAUNCH(ctx, "k_clear", k_clear, (unsigned)ctx->num_cu * 4, tb->stage.seg_count, tb->stage.nseg, tb->capmax, tb->hdr, keys, rowref);
+        LAUNCH(ctx, "k_insert", k_insert, seg_grid, tb->stage, tb->dev);
+        LAUNCH(ctx, "k_insert_fixup", k_insert_fixup, seg_grid, tb->stage, tb->dev);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, std::string("table index launch: ") + hipGetErrorString(e));
+    tb->index_built = true;
     return SDQH_OK;
 }
 
@@ -589,25 +713,38 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
     uint64_t capmax = 1024;
     while (capmax < 2 * (uint64_t)std::max<int64_t>(nrows, 1)) capmax <<= 1;
     tb->capmax = capmax;
-    Slot* slots = nullptr; double* acc = nullptr;
     if (!rc) {
         tb->hdr = static_cast<TableHeader*>(table_alloc(ctx, tb, sizeof(TableHeader)));
-        slots = static_cast<Slot*>(table_alloc(ctx, tb, (capmax + 1) * sizeof(Slot)));
-        if (tb->accumulate) acc = static_cast<double*>(table_alloc(ctx, tb, (capmax + 1) * 4 * sizeof(double)));
-        size_t words = 0;
-        if (want_bm) { words = (size_t)(((uint64_t)(hi - lo) + 32) / 32); tb->bm = static_cast<uint32_t*>(table_alloc(ctx, tb, words * 4 + 64)); }
-        if (!tb->hdr || !slots || (tb->accumulate && !acc) || (want_bm && !tb->bm)) rc = fail(ctx, SDQH_ERR_NOMEM, "hash_build_unique: out of device memory");
+        if (want_bm && ctx->opt_direct_index) { tb->nwords = ((uint64_t)(hi - lo) + 32) / 32; tb->bm = static_cast<uint32_t*>(table_alloc(ctx, tb, tb->nwords * 4 + 64)); }
+        if (!tb->hdr || (tb->nwords && !tb->bm)) rc = fail(ctx, SDQH_ERR_NOMEM, "hash_build_unique: out of device memory");
         else {
-            tb->dev.slots = slots; tb->dev.hdr = tb->hdr; tb->dev.acc = acc; tb->dev.bm = tb->bm;
-            tb->dev.bm_lo = lo; tb->dev.bm_hi = hi; tb->dev.bitmap_only = 0;
+            tb->dev.hdr = tb->hdr; tb->dev.shits = tb->stage.shits; tb->dev.sacc = tb->stage.sacc;
+            tb->dev.bm = tb->bm; tb->dev.bm_lo = lo; tb->dev.bm_hi = hi; tb->dev.bitmap_only = 0;
+            tb->stage.bm = tb->bm; tb->stage.bm_lo = lo; tb->stage.bm_hi = hi; tb->stage.hdr = tb->hdr;
             call_begin(ctx);
             const unsigned seg_grid = (unsigned)((tb->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
-            LAUNCH(ctx, "k_stage", k_stage, seg_grid, f, pr, tb->stage, nrows);
-            LAUNCH(ctx, "k_clear", k_clear, (unsigned)ctx->num_cu * 4, tb->stage.seg_count, tb->stage.nseg, capmax, tb->hdr, slots);
-            if (want_bm) { hipError_t e = hipMemsetAsync(tb->bm, 0, words * 4, ctx->stream); if (e != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e)); }
-            LAUNCH(ctx, "k_insert", k_insert, seg_grid, tb->stage, tb->dev, tb->bm, tb->accumulate ? 1 : 0);
+            hipError_t e = hipMemsetAsync(tb->hdr, 0, sizeof(TableHeader), ctx->stream);
+            if (e == hipSuccess && tb->bm) e = hipMemsetAsync(tb->bm, 0, tb->nwords * 4, ctx->stream);
+            if (e != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e));
+            with_stage_filter(f, nprobes, [&](auto FC) {
+                using FCT = decltype(FC);
+                if constexpr (std::is_same_v<FCT, FCfg<1, 0, 0, 1>>) {          // the tuned instance family (orders-like build side)
+                    const int sb = ctx->opt_stage_batch, eg = ctx->opt_stage_eager;
+                    if (npayload == 2) {
+#define STAGE_VARIANT(SB_, EG_) if (sb == SB_ && eg == EG_) { auto kern = k_stage<FCT, 2, SB_, EG_ != 0>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows); return SDQH_OK; }
+                        STAGE_VARIANT(2, 1) STAGE_VARIANT(4, 1) STAGE_VARIANT(8, 1) STAGE_VARIANT(2, 0) STAGE_VARIANT(4, 0)
+#undef STAGE_VARIANT
+                    }
+                }
+                if (npayload == 0) { auto kern = k_stage<FCT, 0>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows); return SDQH_OK; }
+                if (npayload == 1) { auto kern = k_stage<FCT, 1>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows); return SDQH_OK; }
+                if (npayload == 2) { auto kern = k_stage<FCT, 2>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows); return SDQH_OK; }
+                auto kern = k_stage<FCT, -1>;
+                LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows);
+                return SDQH_OK;
+            });
             call_end(ctx);
-            hipError_t e = hipGetLastError();
+            e = hipGetLastError();
             if (e != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, std::string("hash_build_unique launch: ") + hipGetErrorString(e));
         }
     }
@@ -621,12 +758,13 @@ int sdqh_table_size(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t* entries) {
     if (!ctx || !table || !entries) return fail(ctx, SDQH_ERR_INVALID, "table_size: bad arguments");
     if (table->bitmap_only) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_size: bitmap-only table");
     (void)hipSetDevice(ctx->device);
-    HIP_TRY(ctx, hipMemsetAsync(&table->hdr->distinct, 0, 8, ctx->stream));
-    LAUNCH(ctx, "k_count", k_count, (unsigned)ctx->num_cu * 4, table->dev.slots, table->hdr);
+    if (int rc = ensure_index(ctx, table)) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(&table->hdr->counted, 0, 8, ctx->stream));
+    LAUNCH(ctx, "k_count", k_count, (unsigned)((table->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE)), table->stage, table->dev);
     TableHeader* h = static_cast<TableHeader*>(ctx->result_host);
     HIP_TRY(ctx, hipMemcpyAsync(h, table->hdr, sizeof(TableHeader), hipMemcpyDeviceToHost, ctx->stream));
     if (int rc = sync_stream(ctx)) return rc;
-    *entries = (int64_t)h->distinct;
+    *entries = (int64_t)h->counted;
     return SDQH_OK;
 }
 
@@ -648,11 +786,23 @@ int sdqh_hash_probe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* f
     if (int rc = check_col(ctx, key, SDQH_I64, nrows, "probe key")) return rc;
     table->compact_valid = false;
     const int64_t* kc = static_cast<const int64_t*>(key->data);
-    const unsigned grid = stream_grid(ctx, nrows, 8);
     call_begin(ctx);
-#define CALL(S) LAUNCH(ctx, "k_probe_agg", (k_probe_agg<S>), grid, f, t, table->dev, kc, nrows)
-    DISPATCH_SHAPE(tuple->shape, CALL)
-#undef CALL
+    if (int rc = ensure_index(ctx, table)) return rc;
+    int lrc = with_shape(ctx, tuple->shape, [&](auto S) {
+        return with_scan_filter(f, [&](auto FC) {
+            constexpr int SH = decltype(S)::value; using FCT = decltype(FC);
+            if constexpr (SH == SDQH_TUPLE_A_1MB && std::is_same_v<FCT, FCfg<1, 0, 0, 0>>) {     // the tuned instance family
+#define PROBE_VARIANT(PU_) if (ctx->opt_probe_unroll == PU_) { auto kern = k_probe_agg<SH, FCT, PU_>; \
+        LAUNCH(ctx, "k_probe_agg", kern, stream_grid(ctx, kern, nrows, TPB * ROWS_PER_LOAD * PU_), f, t, table->dev, kc, nrows); return SDQH_OK; }
+                PROBE_VARIANT(2) PROBE_VARIANT(1)
+#undef PROBE_VARIANT
+            }
+            auto kern = k_probe_agg<SH, FCT>;
+            LAUNCH(ctx, "k_probe_agg", kern, stream_grid(ctx, kern, nrows, PROBE_TILE), f, t, table->dev, kc, nrows);
+            return SDQH_OK;
+        });
+    });
+    if (lrc) return lrc;
     call_end(ctx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, std::string("hash_probe_aggregate launch: ") + hipGetErrorString(e));
@@ -676,9 +826,10 @@ static int run_compact(sdqh_ctx* ctx, sdqh_table* table, int64_t min_hits) {
         o.npay = table->npay; o.nval = table->accumulate ? SDQH_TUPLE_MAX_VALUES : 0;
     }
     call_begin(ctx);
+    if (int rc = ensure_index(ctx, table)) return rc;
     HIP_TRY(ctx, hipMemsetAsync(o.counter, 0, 8, ctx->stream));
     uint32_t mh = (uint32_t)std::min<int64_t>(std::max<int64_t>(min_hits, 0), 0xFFFFFFFFll);
-    LAUNCH(ctx, "k_compact", k_compact, (unsigned)ctx->num_cu * 4, table->dev, table->stage, o, mh);
+    LAUNCH(ctx, "k_compact", k_compact, (unsigned)((table->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE)), table->dev, table->stage, o, mh);
     call_end(ctx);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->result_host, o.counter, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (int rc = sync_stream(ctx)) return rc;

@@ -45,24 +45,43 @@ struct DevTuple {
     const double* op[4];
 };
 
-struct Slot {                 // 16 bytes, one open-addressing slot
-    int64_t key;
-    uint32_t rowref;          // stage index of the winning (lowest) build row
-    uint32_t hits;            // rows aggregated into this entry
-};
-
 struct TableHeader {          // lives in device memory: sized on the device, no host round trip
     uint64_t cap_mask;        // capacity - 1 (capacity is a power of two); slot[capacity] is the EMPTY_KEY slot
     uint64_t staged;          // rows that survived the build-side filter (>= distinct keys)
-    uint64_t distinct;        // filled by k_count
-    uint64_t _pad;
+    uint64_t distinct;        // direct layout: number of distinct keys (set bits), written by k_rank_blocks
+    uint32_t has_dups;        // a build row met its own key already in the table
+    uint32_t _pad;
+    uint64_t counted;         // filled by k_count (table_size)
+    uint64_t _pad2;
 };
 
+// A built table maps a key to the stage index of the build row that owns the entry; everything else
+// about an entry — payload, hit counter, accumulators — lives in the stage arrays at that index,
+// which are dense per wave segment: they are initialised with coalesced stores while staging and
+// the final compaction walks them instead of a slot array.  Two index layouts:
+//
+//   direct  (key range dense enough for an exact bitmap over [bm_lo, bm_hi]):
+//           bm[w]       bit per key                         (set while staging)
+//           wprefix[w]  set bits before word w inside its 2048-word block, bprefix[b] before block b
+//           dense_ref[rank(key)] = stage index                (plain stores: no atomics at all)
+//   hash    (any int64 keys): open addressing, linear probing, capacity = pow2 >= 2 * entries
+//           keys[s]     the key, EMPTY_KEY if free        (reset by k_clear)
+//           rowref[s]   stage index of the owning row     (written by the claimer)
+//
+//   shits[i]    rows aggregated into entry i   (stage-indexed)
+//   sacc[i*4+k] accumulators of entry i        (stage-indexed)
+constexpr int RANK_BLOCK_WORDS = 2048;        // bitmap words per prefix block (one workgroup, 8 words per thread)
+
 struct DevTable {
-    Slot* slots;
-    const TableHeader* hdr;
-    double* acc;              // (capacity+1) * SDQH_TUPLE_MAX_VALUES, or null
+    int64_t* keys;
+    uint32_t* rowref;
+    TableHeader* hdr;
+    uint32_t* shits;
+    double* sacc;             // null when the table carries no accumulators
     const uint32_t* bm;       // exact key bitmap over [bm_lo, bm_hi], or null
+    const uint32_t* wprefix;
+    const uint32_t* bprefix;
+    uint32_t* dense_ref;
     int64_t bm_lo, bm_hi;
     int32_t bitmap_only, _pad;
 };
@@ -102,6 +121,22 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
 template <class T> struct Pair { T x, y; };
+
+// ---- compile-time specialisation of the row filter / group key layout -----------------------------
+// A kernel that decides at run time how many predicate columns it has ends up with its loads
+// inside uniform branches, each followed by s_waitcnt vmcnt(0): the loads of a tile serialise and
+// the stream stalls.  So the hot kernels are instantiated for the filter layouts the TPCH loops
+// use (counts known at compile time: every load of a tile is issued up front) plus one generic
+// instance (-1 = read the count from the arguments) that keeps every other query correct.
+template <int NI_, int NF_, int NS_, int NP_> struct FCfg { static constexpr int NI = NI_, NF = NF_, NS = NS_, NP = NP_; };
+using FGeneric = FCfg<-1, -1, -1, -1>;
+template <class FC> __device__ __forceinline__ int cfg_ni(const int32_t n) { if constexpr (FC::NI >= 0) return FC::NI; else return n; }
+template <class FC> __device__ __forceinline__ int cfg_nf(const int32_t n) { if constexpr (FC::NF >= 0) return FC::NF; else return n; }
+template <class FC> __device__ __forceinline__ int cfg_ns(const int32_t n) { if constexpr (FC::NS >= 0) return FC::NS; else return n; }
+template <class FC> __device__ __forceinline__ int cfg_np(const int32_t n) { if constexpr (FC::NP >= 0) return FC::NP; else return n; }
+// group-key slots: 0 absent, 1 string(1) (UCS4 code unit), 2 int64, -1 decided at run time
+template <int K0_, int K1_> struct KCfg { static constexpr int K0 = K0_, K1 = K1_; };
+using KGeneric = KCfg<-1, -1>;
 
 // Two consecutive 8-byte rows.  Full tiles: one aligned 16-byte load.  Tail: clamped scalar loads.
 template <bool TAIL, class T>
@@ -145,59 +180,89 @@ __device__ __forceinline__ bool table_contains(const DevTable& t, int64_t key, u
         uint64_t off = (uint64_t)(key - t.bm_lo);
         return (t.bm[off >> 5] >> (off & 31)) & 1u;
     }
-    if (key == EMPTY_KEY) return t.slots[cap_mask + 1].rowref != NO_ROW;
+    if (key == EMPTY_KEY) return t.rowref[cap_mask + 1] != NO_ROW;
     uint64_t h = hash_key(key) & cap_mask;
     for (;;) {
-        int64_t k = t.slots[h].key;
+        int64_t k = t.keys[h];
         if (k == key) return true;
         if (k == EMPTY_KEY) return false;
         h = (h + 1) & cap_mask;
     }
 }
 
-// slot index of key, or -1
+// position of `key` in the index (direct: its rank; hash: its slot), or -1; `word` = the bitmap
+// word of the key when the caller has already fetched it (direct layout only)
+__device__ __forceinline__ int64_t direct_rank(const DevTable& t, uint64_t off, uint32_t word) {
+    const uint64_t w = off >> 5;
+    return (int64_t)t.bprefix[w / RANK_BLOCK_WORDS] + (int64_t)t.wprefix[w] + __popc(word & ((1u << (off & 31)) - 1u));
+}
 __device__ __forceinline__ int64_t table_find(const DevTable& t, int64_t key, uint64_t cap_mask) {
     if (t.bm) {
         if (key < t.bm_lo || key > t.bm_hi) return -1;
-        uint64_t off = (uint64_t)(key - t.bm_lo);
-        if (!((t.bm[off >> 5] >> (off & 31)) & 1u)) return -1;
+        const uint64_t off = (uint64_t)(key - t.bm_lo);
+        const uint32_t word = t.bm[off >> 5];
+        if (!((word >> (off & 31)) & 1u)) return -1;
+        return direct_rank(t, off, word);
     }
-    if (key == EMPTY_KEY) return t.slots[cap_mask + 1].rowref != NO_ROW ? (int64_t)(cap_mask + 1) : -1;
+    if (key == EMPTY_KEY) return t.rowref[cap_mask + 1] != NO_ROW ? (int64_t)(cap_mask + 1) : -1;
     uint64_t h = hash_key(key) & cap_mask;
     for (;;) {
-        int64_t k = t.slots[h].key;
+        int64_t k = t.keys[h];
         if (k == key) return (int64_t)h;
         if (k == EMPTY_KEY) return -1;
         h = (h + 1) & cap_mask;
     }
 }
+// stage index of the entry at an index position
+__device__ __forceinline__ uint32_t table_ref(const DevTable& t, int64_t pos) { return t.bm ? t.dense_ref[pos] : t.rowref[pos]; }
+__device__ __forceinline__ uint32_t* table_ref_ptr(const DevTable& t, int64_t pos) { return t.bm ? &t.dense_ref[pos] : &t.rowref[pos]; }
 
 // ---- row filter on a pair of rows --------------------------------------------------------------
 // Integer and double range predicates with their own columns, plus the optional string equality.
 // Operand-slot ranges are applied by the caller on the loaded operands.
-template <bool TAIL>
-__device__ __forceinline__ void filter_pair(const DevFilter& f, int64_t r, int64_t nrows, bool& p0, bool& p1) {
+// The predicate columns of a row pair, fetched ahead of their use so that every load of a tile is
+// in flight before the first one is consumed.
+struct FilterRegs {
+    Pair<int64_t> iv[SDQH_MAX_IPRED];
+    Pair<double> fv[SDQH_MAX_FPRED];
+};
+
+template <class FC, bool TAIL>
+__device__ __forceinline__ void filter_load(const DevFilter& f, int64_t r, int64_t nrows, FilterRegs& fr) {
+#pragma unroll
+    for (int i = 0; i < SDQH_MAX_IPRED; ++i) if (i < cfg_ni<FC>(f.ni)) fr.iv[i] = load2<TAIL>(f.ic[i], r, nrows);
+#pragma unroll
+    for (int i = 0; i < SDQH_MAX_FPRED; ++i) if (i < cfg_nf<FC>(f.nf)) fr.fv[i] = load2<TAIL>(f.fc[i], r, nrows);
+}
+
+template <class FC, bool TAIL>
+__device__ __forceinline__ void filter_eval(const DevFilter& f, const FilterRegs& fr, int64_t r, int64_t nrows, bool& p0, bool& p1) {
 #pragma unroll
     for (int i = 0; i < SDQH_MAX_IPRED; ++i) {
-        if (i < f.ni) {
-            Pair<int64_t> v = load2<TAIL>(f.ic[i], r, nrows);
-            p0 &= (v.x >= f.ilo[i]) & (v.x <= f.ihi[i]);
-            p1 &= (v.y >= f.ilo[i]) & (v.y <= f.ihi[i]);
+        if (i < cfg_ni<FC>(f.ni)) {
+            p0 &= (fr.iv[i].x >= f.ilo[i]) & (fr.iv[i].x <= f.ihi[i]);
+            p1 &= (fr.iv[i].y >= f.ilo[i]) & (fr.iv[i].y <= f.ihi[i]);
         }
     }
 #pragma unroll
     for (int i = 0; i < SDQH_MAX_FPRED; ++i) {
-        if (i < f.nf) {
-            Pair<double> v = load2<TAIL>(f.fc[i], r, nrows);
-            p0 &= (v.x >= f.flo[i]) & (v.x <= f.fhi[i]);
-            p1 &= (v.y >= f.flo[i]) & (v.y <= f.fhi[i]);
+        if (i < cfg_nf<FC>(f.nf)) {
+            p0 &= (fr.fv[i].x >= f.flo[i]) & (fr.fv[i].x <= f.fhi[i]);
+            p1 &= (fr.fv[i].y >= f.flo[i]) & (fr.fv[i].y <= f.fhi[i]);
         }
     }
-    if (f.ns) {
+    if (cfg_ns<FC>(f.ns)) {
         int64_t r0 = r < nrows ? r : nrows - 1, r1 = r + 1 < nrows ? r + 1 : nrows - 1;
         if (p0) p0 = str_equal(f.sc + r0 * f.swidth, f.swidth, f.sval, f.slen) != (f.sneg != 0);
         if (p1) p1 = str_equal(f.sc + r1 * f.swidth, f.swidth, f.sval, f.slen) != (f.sneg != 0);
     }
+}
+
+template <class FC, bool TAIL>
+__device__ __forceinline__ void filter_pair(const DevFilter& f, int64_t r, int64_t nrows, bool& p0, bool& p1) {
+    FilterRegs fr;
+    filter_load<FC, TAIL>(f, r, nrows, fr);
+    filter_eval<FC, TAIL>(f, fr, r, nrows, p0, p1);
 }
 
 template <int NOPS>
@@ -215,18 +280,27 @@ __device__ __forceinline__ bool operand_ranges(const DevFilter& f, const double 
 // result is bit-reproducible run to run.
 // partial layout: [grid][5] = NV doubles (padded to 4) + count (as int64 bits)
 // =================================================================================================
-template <int SHAPE, bool TAIL>
+template <int SHAPE, class FC, bool TAIL>
 __device__ __forceinline__ void scan_sum_tile(const DevFilter& f, const DevTuple& t, int64_t base, int64_t nrows,
                                               double (&acc)[4], int64_t& cnt) {
     constexpr int NOPS = TupleTraits<SHAPE>::NOPS, NV = TupleTraits<SHAPE>::NV;
+    Pair<double> xv[UNROLL][4];
+    FilterRegs fr[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {                               // every load of the tile first
+        const int64_t r = base + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
+#pragma unroll
+        for (int j = 0; j < NOPS; ++j) xv[u][j] = load2<TAIL>(t.op[j], r, nrows);
+        filter_load<FC, TAIL>(f, r, nrows, fr[u]);
+    }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-        int64_t r = base + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
+        const int64_t r = base + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
         bool p0 = TAIL ? (r < nrows) : true, p1 = TAIL ? (r + 1 < nrows) : true;
         double x0[4] = {0, 0, 0, 0}, x1[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int j = 0; j < NOPS; ++j) { Pair<double> v = load2<TAIL>(t.op[j], r, nrows); x0[j] = v.x; x1[j] = v.y; }
-        filter_pair<TAIL>(f, r, nrows, p0, p1);
+        for (int j = 0; j < NOPS; ++j) { x0[j] = xv[u][j].x; x1[j] = xv[u][j].y; }
+        filter_eval<FC, TAIL>(f, fr[u], r, nrows, p0, p1);
         p0 &= operand_ranges<NOPS>(f, x0);
         p1 &= operand_ranges<NOPS>(f, x1);
         double o0[4] = {0, 0, 0, 0}, o1[4] = {0, 0, 0, 0};
@@ -238,16 +312,16 @@ __device__ __forceinline__ void scan_sum_tile(const DevFilter& f, const DevTuple
     }
 }
 
-template <int SHAPE>
+template <int SHAPE, class FC>
 __global__ __launch_bounds__(TPB) void k_scan_sum(DevFilter f, DevTuple t, int64_t nrows, double* __restrict__ partial) {
     constexpr int NV = TupleTraits<SHAPE>::NV;
     double acc[4] = {0, 0, 0, 0};
     int64_t cnt = 0;
     const int64_t full = nrows / TILE_ROWS;
     for (int64_t tile = blockIdx.x; tile < full; tile += gridDim.x)
-        scan_sum_tile<SHAPE, false>(f, t, tile * TILE_ROWS, nrows, acc, cnt);
+        scan_sum_tile<SHAPE, FC, false>(f, t, tile * TILE_ROWS, nrows, acc, cnt);
     if (full * TILE_ROWS < nrows && blockIdx.x == (unsigned)(full % gridDim.x))
-        scan_sum_tile<SHAPE, true>(f, t, full * TILE_ROWS, nrows, acc, cnt);
+        scan_sum_tile<SHAPE, FC, true>(f, t, full * TILE_ROWS, nrows, acc, cnt);
 
     __shared__ double s_acc[TPB / WAVE][4];
     __shared__ int64_t s_cnt[TPB / WAVE];
@@ -303,12 +377,14 @@ __global__ __launch_bounds__(TPB) void k_sum_partials(const double* __restrict__
 // =================================================================================================
 // K-C small: group-by over a small key domain.
 //   Key: up to two 32-bit parts (UCS4 code unit of a string(1) column, or an int in [0, 2^32-2])
-//   packed into one 64-bit word.  The workgroup keeps its key table in LDS (claimed by CAS in
-//   first-come order); k_groupby_reg keeps G x NV accumulators per lane in registers and adds each
-//   row under a per-group predicate (no atomics, no divergence); k_groupby_lds is the G <= 64
-//   fall-back with LDS f64 atomics.  Both write one partial per workgroup; k_groupby_merge maps the
-//   workgroups' local slots to global groups and folds them in a fixed order.
-// partial layout per workgroup: keys[G] (u64) | acc[G][4] (f64) | cnt[G] (i64)
+//   packed into one 64-bit word.  Each workgroup keeps its own key table in LDS (claimed by LDS CAS
+//   in first-come order; a global table would serialise thousands of CAS on a handful of
+//   addresses).  k_groupby_reg keeps G x NV accumulators per lane in registers and adds each row
+//   under a per-group predicate (no atomics, no divergence); k_groupby_lds is the G <= 64
+//   fall-back with LDS f64 atomics.  Both write one partial per workgroup; k_groupby_merge ranks
+//   the distinct keys (ascending) and folds the partials of the g-th key in workgroup order, so
+//   sums and output order are bit-reproducible run to run.
+// partial layout: pkeys[wg*G + s], pacc[(wg*G + s)*4 + k], pcnt[wg*G + s]
 // =================================================================================================
 struct DevGroupKeys {
     const void* col[SDQH_MAX_GROUPKEYS];
@@ -316,69 +392,88 @@ struct DevGroupKeys {
     int32_t nkeys, _pad;
 };
 
-template <bool TAIL>
-__device__ __forceinline__ void load_group_keys(const DevGroupKeys& gk, int64_t r, int64_t nrows, uint64_t& k0, uint64_t& k1, bool& bad) {
-    uint32_t part0[2] = {0, 0}, part1[2] = {0, 0};
-#pragma unroll
-    for (int j = 0; j < SDQH_MAX_GROUPKEYS; ++j) {
-        if (j < gk.nkeys) {
-            int64_t r0 = (!TAIL || r < nrows) ? r : nrows - 1, r1 = (!TAIL || r + 1 < nrows) ? r + 1 : nrows - 1;
-            if (gk.is_str[j]) {
-                const uint32_t* c = static_cast<const uint32_t*>(gk.col[j]);
-                if constexpr (!TAIL) { uint2 v = *reinterpret_cast<const uint2*>(c + r); part0[j] = v.x; part1[j] = v.y; }
-                else { part0[j] = c[r0]; part1[j] = c[r1]; }
-            } else {
-                Pair<int64_t> v = load2<TAIL>(static_cast<const int64_t*>(gk.col[j]), r, nrows);
-                bad |= (v.x < 0) | (v.x > 0xFFFFFFFEll) | (v.y < 0) | (v.y > 0xFFFFFFFEll);
-                part0[j] = (uint32_t)v.x; part1[j] = (uint32_t)v.y;
-            }
-        }
+// one key slot of a row pair -> two 32-bit parts; KIND: 0 absent, 1 string(1), 2 int64, -1 run time
+template <int KIND, bool TAIL>
+__device__ __forceinline__ void load_key_part(const DevGroupKeys& gk, int j, int64_t r, int64_t nrows, uint32_t& a, uint32_t& b, bool& bad) {
+    a = 0; b = 0;
+    const bool present = KIND >= 0 ? KIND != 0 : j < gk.nkeys;
+    if (!present) return;
+    const bool is_str = KIND >= 0 ? KIND == 1 : gk.is_str[j] != 0;
+    const int64_t r0 = (!TAIL || r < nrows) ? r : nrows - 1, r1 = (!TAIL || r + 1 < nrows) ? r + 1 : nrows - 1;
+    if (is_str) {
+        const uint32_t* c = static_cast<const uint32_t*>(gk.col[j]);
+        if constexpr (!TAIL) { uint2 v = *reinterpret_cast<const uint2*>(c + r); a = v.x; b = v.y; }
+        else { a = c[r0]; b = c[r1]; }
+    } else {
+        Pair<int64_t> v = load2<TAIL>(static_cast<const int64_t*>(gk.col[j]), r, nrows);
+        bad |= (v.x < 0) | (v.x > 0xFFFFFFFEll) | (v.y < 0) | (v.y > 0xFFFFFFFEll);
+        a = (uint32_t)v.x; b = (uint32_t)v.y;
     }
-    k0 = (uint64_t)part0[0] | ((uint64_t)part0[1] << 32);
-    k1 = (uint64_t)part1[0] | ((uint64_t)part1[1] << 32);
+}
+
+template <class KC, bool TAIL>
+__device__ __forceinline__ void load_group_keys(const DevGroupKeys& gk, int64_t r, int64_t nrows, uint64_t& k0, uint64_t& k1, bool& bad) {
+    uint32_t a0, b0, a1, b1;
+    load_key_part<KC::K0, TAIL>(gk, 0, r, nrows, a0, b0, bad);
+    load_key_part<KC::K1, TAIL>(gk, 1, r, nrows, a1, b1, bad);
+    k0 = (uint64_t)a0 | ((uint64_t)a1 << 32);
+    k1 = (uint64_t)b0 | ((uint64_t)b1 << 32);
 }
 
 // claim-or-find in the workgroup's LDS key table; -1 when the table is full
 template <int G>
 __device__ __forceinline__ int lds_claim(unsigned long long* s_keys, uint64_t key) {
     for (int j = 0; j < G; ++j) {
+        unsigned long long cur = s_keys[j];
+        if (cur == key) return j;
+        if (cur != EMPTY_GROUP) continue;
         unsigned long long old = atomicCAS(&s_keys[j], (unsigned long long)EMPTY_GROUP, (unsigned long long)key);
         if (old == EMPTY_GROUP || old == key) return j;
     }
     return -1;
 }
 
-template <int SHAPE, int G, bool TAIL>
+template <int SHAPE, int G, class FC, class KC, bool TAIL>
 __device__ __forceinline__ void groupby_reg_tile(const DevFilter& f, const DevTuple& t, const DevGroupKeys& gk, int64_t base, int64_t nrows,
                                                  unsigned long long* s_keys, int* s_flags,
                                                  double (&acc)[G][4], int32_t (&cnt)[G]) {
     constexpr int NOPS = TupleTraits<SHAPE>::NOPS, NV = TupleTraits<SHAPE>::NV;
+    Pair<double> xv[UNROLL][4];
+    FilterRegs fr[UNROLL];
+    uint64_t key[UNROLL][2];
+    bool bad = false;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {                               // every load of the tile first
+        const int64_t r = base + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
+#pragma unroll
+        for (int j = 0; j < NOPS; ++j) xv[u][j] = load2<TAIL>(t.op[j], r, nrows);
+        load_group_keys<KC, TAIL>(gk, r, nrows, key[u][0], key[u][1], bad);
+        filter_load<FC, TAIL>(f, r, nrows, fr[u]);
+    }
     uint64_t rk[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) rk[g] = s_keys[g];          // register copy of the key table (LDS broadcast reads)
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-        int64_t r = base + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
+        const int64_t r = base + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
         bool p[2] = {TAIL ? (r < nrows) : true, TAIL ? (r + 1 < nrows) : true};
-        double x[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-#pragma unroll
-        for (int j = 0; j < NOPS; ++j) { Pair<double> v = load2<TAIL>(t.op[j], r, nrows); x[0][j] = v.x; x[1][j] = v.y; }
-        uint64_t key[2]; bool bad = false;
-        load_group_keys<TAIL>(gk, r, nrows, key[0], key[1], bad);
-        filter_pair<TAIL>(f, r, nrows, p[0], p[1]);
+        filter_eval<FC, TAIL>(f, fr[u], r, nrows, p[0], p[1]);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            p[q] &= operand_ranges<NOPS>(f, x[q]);
+            double x[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < NOPS; ++j) x[j] = q == 0 ? xv[u][j].x : xv[u][j].y;
+            p[q] &= operand_ranges<NOPS>(f, x);
             int slot = -1;
 #pragma unroll
-            for (int g = 0; g < G; ++g) slot = (rk[g] == key[q]) ? g : slot;
+            for (int g = 0; g < G; ++g) slot = (rk[g] == key[u][q]) ? g : slot;
             if (p[q] && slot < 0) {                              // rare: first sight of a key in this workgroup
-                slot = lds_claim<G>(s_keys, key[q]);
+                slot = lds_claim<G>(s_keys, key[u][q]);
                 if (slot < 0) atomicOr(&s_flags[0], 1);           // more than G groups
             }
             if (p[q] && bad) atomicOr(&s_flags[0], 2);            // int key outside [0, 2^32-2]
             double o[4] = {0, 0, 0, 0};
-            tuple_eval<SHAPE>(x[q], o);
+            tuple_eval<SHAPE>(x, o);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const bool m = p[q] && (slot == g);
@@ -390,7 +485,7 @@ __device__ __forceinline__ void groupby_reg_tile(const DevFilter& f, const DevTu
     }
 }
 
-template <int SHAPE, int G>
+template <int SHAPE, int G, class FC, class KC>
 __global__ __launch_bounds__(TPB) void k_groupby_reg(DevFilter f, DevTuple t, DevGroupKeys gk, int64_t nrows,
                                                      unsigned long long* __restrict__ pkeys, double* __restrict__ pacc,
                                                      int64_t* __restrict__ pcnt, int* __restrict__ flags) {
@@ -410,9 +505,9 @@ __global__ __launch_bounds__(TPB) void k_groupby_reg(DevFilter f, DevTuple t, De
 
     const int64_t full = nrows / TILE_ROWS;
     for (int64_t tile = blockIdx.x; tile < full; tile += gridDim.x)
-        groupby_reg_tile<SHAPE, G, false>(f, t, gk, tile * TILE_ROWS, nrows, s_keys, s_flags, acc, cnt);
+        groupby_reg_tile<SHAPE, G, FC, KC, false>(f, t, gk, tile * TILE_ROWS, nrows, s_keys, s_flags, acc, cnt);
     if (full * TILE_ROWS < nrows && blockIdx.x == (unsigned)(full % gridDim.x))
-        groupby_reg_tile<SHAPE, G, true>(f, t, gk, full * TILE_ROWS, nrows, s_keys, s_flags, acc, cnt);
+        groupby_reg_tile<SHAPE, G, FC, KC, true>(f, t, gk, full * TILE_ROWS, nrows, s_keys, s_flags, acc, cnt);
 
     const int w = threadIdx.x / WAVE;
 #pragma unroll
@@ -441,7 +536,8 @@ __global__ __launch_bounds__(TPB) void k_groupby_reg(DevFilter f, DevTuple t, De
 // Fall-back for up to 64 groups: accumulators in LDS, f64 LDS atomics (ds_add_f64).
 template <int SHAPE, bool TAIL>
 __device__ __forceinline__ void groupby_lds_tile(const DevFilter& f, const DevTuple& t, const DevGroupKeys& gk, int64_t base, int64_t nrows,
-                                                 unsigned long long* s_keys, double (*s_acc)[4], unsigned long long* s_cnt, int* s_flags) {
+                                                 unsigned long long* s_keys, double (*s_acc)[4],
+                                                 unsigned long long* s_cnt, int* s_flags) {
     constexpr int NOPS = TupleTraits<SHAPE>::NOPS, NV = TupleTraits<SHAPE>::NV, G = SDQH_MAX_SMALL_GROUPS;
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
@@ -451,16 +547,14 @@ __device__ __forceinline__ void groupby_lds_tile(const DevFilter& f, const DevTu
 #pragma unroll
         for (int j = 0; j < NOPS; ++j) { Pair<double> v = load2<TAIL>(t.op[j], r, nrows); x[0][j] = v.x; x[1][j] = v.y; }
         uint64_t key[2]; bool bad = false;
-        load_group_keys<TAIL>(gk, r, nrows, key[0], key[1], bad);
-        filter_pair<TAIL>(f, r, nrows, p[0], p[1]);
+        load_group_keys<KGeneric, TAIL>(gk, r, nrows, key[0], key[1], bad);
+        filter_pair<FGeneric, TAIL>(f, r, nrows, p[0], p[1]);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             p[q] &= operand_ranges<NOPS>(f, x[q]);
             if (!p[q]) continue;
             if (bad) atomicOr(&s_flags[0], 2);
-            int slot = -1;
-            for (int g = 0; g < G; ++g) { unsigned long long k = s_keys[g]; if (k == key[q]) { slot = g; break; } if (k == EMPTY_GROUP) break; }
-            if (slot < 0) slot = lds_claim<G>(s_keys, key[q]);
+            const int slot = lds_claim<G>(s_keys, key[q]);
             if (slot < 0) { atomicOr(&s_flags[0], 1); continue; }
             double o[4] = {0, 0, 0, 0};
             tuple_eval<SHAPE>(x[q], o);
@@ -498,67 +592,74 @@ __global__ __launch_bounds__(TPB) void k_groupby_lds(DevFilter f, DevTuple t, De
     if (threadIdx.x == 0 && s_flags[0]) atomicOr(flags, s_flags[0]);
 }
 
-// One workgroup.  Phase 1: map every (workgroup, local slot) with rows to a global group (LDS
-// CAS table, <= 64 groups).  Phase 2: per global group, fold the partials in a fixed
-// thread-strided order and tree-reduce in LDS.  out: keys[64] | acc[64][4] | cnt[64] | ngroups.
+// One workgroup per output group (launch SDQH_MAX_SMALL_GROUPS of them).  Every workgroup collects
+// the distinct keys of all partials in an LDS CAS table and ranks them ascending, so "group g" is
+// the same key in every workgroup and in every run; workgroup g then folds the partials of that
+// key in workgroup order (thread-strided, then an LDS tree).
 __global__ __launch_bounds__(TPB) void k_groupby_merge(const unsigned long long* __restrict__ pkeys, const double* __restrict__ pacc,
-                                                       const int64_t* __restrict__ pcnt, int nparts, int G, int max_groups,
-                                                       signed char* __restrict__ slotmap,
+                                                       const int64_t* __restrict__ pcnt, int nparts, int G,
                                                        unsigned long long* __restrict__ out_keys, double* __restrict__ out_acc,
                                                        int64_t* __restrict__ out_cnt, int* __restrict__ out_ngroups, int* __restrict__ flags) {
     constexpr int GMAX = SDQH_MAX_SMALL_GROUPS;
-    __shared__ unsigned long long s_keys[GMAX];
+    __shared__ unsigned long long s_keys[GMAX], s_sorted[GMAX];
     __shared__ double s_red[5][TPB];
-    __shared__ int s_over;
-    if (threadIdx.x < GMAX) s_keys[threadIdx.x] = EMPTY_GROUP;
-    if (threadIdx.x == 0) s_over = 0;
+    __shared__ int s_over, s_ng;
+    if (threadIdx.x < GMAX) { s_keys[threadIdx.x] = EMPTY_GROUP; s_sorted[threadIdx.x] = EMPTY_GROUP; }
+    if (threadIdx.x == 0) { s_over = 0; s_ng = 0; }
     __syncthreads();
     const int total = nparts * G;
-    for (int e = threadIdx.x; e < total; e += TPB) {
-        signed char gs = -1;
-        if (pcnt[e] > 0) {
-            int s = lds_claim<GMAX>(s_keys, pkeys[e]);
-            if (s < 0) s_over = 1;
-            gs = (signed char)s;
-        }
-        slotmap[e] = gs;
+    constexpr int MB = 8;                                             // entries per thread fetched before any is claimed
+    for (int e0 = 0; e0 < total; e0 += TPB * MB) {
+        unsigned long long k[MB]; int64_t c[MB];
+#pragma unroll
+        for (int j = 0; j < MB; ++j) { const int e = e0 + j * TPB + threadIdx.x; k[j] = e < total ? pkeys[e] : EMPTY_GROUP; c[j] = e < total ? pcnt[e] : 0; }
+#pragma unroll
+        for (int j = 0; j < MB; ++j) if (c[j] > 0 && lds_claim<GMAX>(s_keys, k[j]) < 0) s_over = 1;
     }
     __syncthreads();
-    int ng = 0;
-    for (int g = 0; g < GMAX; ++g) if (s_keys[g] != EMPTY_GROUP) ng = g + 1;    // claims are dense from slot 0
-    if (threadIdx.x == 0) {
-        *out_ngroups = ng;
-        if (s_over || ng > max_groups) atomicOr(flags, 1);
+    if (threadIdx.x < GMAX) {
+        const unsigned long long k = s_keys[threadIdx.x];
+        if (k != EMPTY_GROUP) {
+            int rank = 0;
+            for (int j = 0; j < GMAX; ++j) rank += (s_keys[j] < k) ? 1 : 0;     // EMPTY_GROUP is the largest value
+            s_sorted[rank] = k;
+            atomicAdd(&s_ng, 1);
+        }
     }
-    for (int g = 0; g < ng; ++g) {
-        double a[4] = {0, 0, 0, 0};
-        int64_t c = 0;
-        for (int e = threadIdx.x; e < total; e += TPB) {
-            if (slotmap[e] == g) {
+    __syncthreads();
+    const int g = blockIdx.x, ng = s_ng;
+    if (g == 0 && threadIdx.x == 0) { *out_ngroups = ng; if (s_over) atomicOr(flags, 1); }
+    if (g >= ng) return;
+    const unsigned long long key = s_sorted[g];
+    double a[4] = {0, 0, 0, 0};
+    int64_t c = 0;
+    for (int b = threadIdx.x; b < nparts; b += TPB) {
+        for (int sl = 0; sl < G; ++sl) {
+            const size_t e = (size_t)b * G + sl;
+            if (pkeys[e] == key && pcnt[e] > 0) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) a[k] += pacc[(size_t)e * 4 + k];
+                for (int k = 0; k < 4; ++k) a[k] += pacc[e * 4 + k];
                 c += pcnt[e];
             }
         }
+    }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s_red[k][threadIdx.x] = a[k];
-        reinterpret_cast<int64_t*>(s_red[4])[threadIdx.x] = c;
-        __syncthreads();
-        for (int off = TPB / 2; off > 0; off >>= 1) {
-            if ((int)threadIdx.x < off) {
+    for (int k = 0; k < 4; ++k) s_red[k][threadIdx.x] = a[k];
+    reinterpret_cast<int64_t*>(s_red[4])[threadIdx.x] = c;
+    __syncthreads();
+    for (int off = TPB / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) s_red[k][threadIdx.x] += s_red[k][threadIdx.x + off];
-                reinterpret_cast<int64_t*>(s_red[4])[threadIdx.x] += reinterpret_cast<int64_t*>(s_red[4])[threadIdx.x + off];
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            out_keys[g] = s_keys[g];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) out_acc[g * 4 + k] = s_red[k][0];
-            out_cnt[g] = reinterpret_cast<int64_t*>(s_red[4])[0];
+            for (int k = 0; k < 4; ++k) s_red[k][threadIdx.x] += s_red[k][threadIdx.x + off];
+            reinterpret_cast<int64_t*>(s_red[4])[threadIdx.x] += reinterpret_cast<int64_t*>(s_red[4])[threadIdx.x + off];
         }
         __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out_keys[g] = key;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out_acc[g * 4 + k] = s_red[k][0];
+        out_cnt[g] = reinterpret_cast<int64_t*>(s_red[4])[0];
     }
 }
 
@@ -566,10 +667,16 @@ __global__ __launch_bounds__(TPB) void k_groupby_merge(const unsigned long long*
 // K-B: unique hash build.
 //   k_stage   each wave64 owns a contiguous row segment; filter + semi-join probes; survivors are
 //             compacted in row order with ballot + popcount prefix into the segment's own slice of
-//             the stage arrays (no global atomics, no workgroup barrier)
-//   k_clear   sizes the table on the device (capacity = pow2 >= 2 * staged rows) and resets slots
-//   k_insert  wave per segment: CAS claim of the key, atomicMin of the stage index so the lowest
-//             build row wins a duplicate key, exact key bitmap by atomicOr
+//             the stage arrays (no global atomics, no workgroup barrier).  Four 128-row batches
+//             are in flight per wave so the dependent chain date -> probe key -> bitmap word is
+//             overlapped four deep.  The entry state (hits, accumulators) is zeroed and the exact
+//             key bitmap is set here, under the streaming reads.
+//   k_clear   sizes the table on the device (capacity = pow2 >= 2 * staged rows) and resets keys
+//   k_insert  wave per segment: one CAS per row claims the key, the claimer stores its stage
+//             index.  Scattered atomics run at a fixed chip-wide rate, so the common case (unique
+//             build keys) pays exactly one.  A row that meets its own key already present only
+//             raises has_dups; k_insert_fixup (a no-op otherwise) then lowers every entry to its
+//             lowest build row with atomicMin — first insert wins, as in the reference.
 // =================================================================================================
 struct DevProbes {
     DevTable table[SDQH_MAX_PROBE];
@@ -577,97 +684,170 @@ struct DevProbes {
     int32_t n, _pad;
 };
 
+constexpr int MAX_STAGE_COLS = SDQH_MAX_COMPACT_COLS - 1;     // payload columns a stage can carry
+constexpr uint32_t DEAD_ROW = 0xFFFFFFFFu;
+constexpr int STAGE_BATCH = 4;                                // 128-row batches in flight per wave
+
 struct DevStage {
     int64_t* key;                         // [nrows]
-    int64_t* pay[SDQH_MAX_PAYLOAD];       // [nrows] each
+    int64_t* pay[MAX_STAGE_COLS];         // [nrows] each
     const int64_t* src_key;
-    const int64_t* src_pay[SDQH_MAX_PAYLOAD];
-    int32_t npay, _pad;
+    const int64_t* src_pay[MAX_STAGE_COLS];
+    int32_t npay, nseg;
     uint32_t* seg_count;                  // [nseg]
-    int64_t seg_rows;                     // rows per wave segment (multiple of 128)
-    int32_t nseg, _pad2;
+    int64_t seg_rows;                     // rows per wave segment (multiple of 128 * STAGE_BATCH)
+    uint32_t* shits;                      // [nrows] entry hit counters, zeroed while staging
+    double* sacc;                         // [nrows*4] entry accumulators, zeroed while staging (or null)
+    uint32_t* bm;                         // exact key bitmap to fill, or null
+    int64_t bm_lo, bm_hi;
+    TableHeader* hdr;
 };
 
+template <class FC>
 __device__ __forceinline__ bool row_passes(const DevFilter& f, const DevProbes& pr, int64_t r, const uint64_t* cap_masks) {
     bool p = true;
 #pragma unroll
-    for (int i = 0; i < SDQH_MAX_IPRED; ++i) if (i < f.ni && p) { int64_t v = f.ic[i][r]; p = (v >= f.ilo[i]) & (v <= f.ihi[i]); }
+    for (int i = 0; i < SDQH_MAX_IPRED; ++i) if (i < cfg_ni<FC>(f.ni) && p) { int64_t v = f.ic[i][r]; p = (v >= f.ilo[i]) & (v <= f.ihi[i]); }
 #pragma unroll
-    for (int i = 0; i < SDQH_MAX_FPRED; ++i) if (i < f.nf && p) { double v = f.fc[i][r]; p = (v >= f.flo[i]) & (v <= f.fhi[i]); }
-    if (f.ns && p) p = str_equal(f.sc + r * f.swidth, f.swidth, f.sval, f.slen) != (f.sneg != 0);
+    for (int i = 0; i < SDQH_MAX_FPRED; ++i) if (i < cfg_nf<FC>(f.nf) && p) { double v = f.fc[i][r]; p = (v >= f.flo[i]) & (v <= f.fhi[i]); }
+    if (cfg_ns<FC>(f.ns) && p) p = str_equal(f.sc + r * f.swidth, f.swidth, f.sval, f.slen) != (f.sneg != 0);
 #pragma unroll
-    for (int i = 0; i < SDQH_MAX_PROBE; ++i) if (i < pr.n && p) p = table_contains(pr.table[i], pr.key[i][r], cap_masks[i]);
+    for (int i = 0; i < SDQH_MAX_PROBE; ++i) if (i < cfg_np<FC>(pr.n) && p) p = table_contains(pr.table[i], pr.key[i][r], cap_masks[i]);
     return p;
 }
 
-// Generic pair evaluation for the probing kernels: the first integer predicate (typically the date
-// filter that removes most rows) is read with 16-byte loads for every row; everything else is
-// read lazily, only by lanes still alive.
-template <bool TAIL>
-__device__ __forceinline__ void pass_pair(const DevFilter& f, const DevProbes& pr, int64_t r, int64_t nrows,
-                                          const uint64_t* cap_masks, bool& p0, bool& p1) {
-    int first = 0;
-    if (f.ni > 0) {
-        Pair<int64_t> v = load2<TAIL>(f.ic[0], r, nrows);
-        p0 &= (v.x >= f.ilo[0]) & (v.x <= f.ihi[0]);
-        p1 &= (v.y >= f.ilo[0]) & (v.y <= f.ihi[0]);
-        first = 1;
+// Filter + semi-join probes for NB pairs of rows at once.  Every stage of the dependent chain is
+// issued for all NB pairs before the next stage consumes it: first predicate column with 16-byte
+// loads for every row, the remaining predicates and the probe keys only by lanes still alive.
+template <int NB, class FC, bool EAGER = true>
+__device__ __forceinline__ void pass_pairs(const DevFilter& f, const DevProbes& pr, const int64_t (&r)[NB], int64_t nrows,
+                                           const uint64_t* cap_masks, bool (&p)[NB][2]) {
+    // EAGER: the first probe's key column is streamed with 16-byte loads alongside the first
+    // predicate instead of being fetched afterwards by the surviving lanes only.  When a good part
+    // of the rows survive, every cache line of the key column is touched anyway, and one stage of
+    // the dependent chain (predicate -> key -> bitmap word) disappears.
+    Pair<int64_t> ek[NB];
+    const bool eager = EAGER && cfg_np<FC>(pr.n) > 0;
+    if (eager) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) ek[j] = load2<false>(pr.key[0], r[j], nrows);
+    }
+    if (cfg_ni<FC>(f.ni) > 0) {
+        Pair<int64_t> d[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) d[j] = load2<false>(f.ic[0], r[j], nrows);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            p[j][0] &= (d[j].x >= f.ilo[0]) & (d[j].x <= f.ihi[0]);
+            p[j][1] &= (d[j].y >= f.ilo[0]) & (d[j].y <= f.ihi[0]);
+        }
     }
 #pragma unroll
-    for (int i = 1; i < SDQH_MAX_IPRED; ++i) if (i >= first && i < f.ni) {
-        if (p0) { int64_t v = f.ic[i][r]; p0 = (v >= f.ilo[i]) & (v <= f.ihi[i]); }
-        if (p1) { int64_t v = f.ic[i][r + 1]; p1 = (v >= f.ilo[i]) & (v <= f.ihi[i]); }
+    for (int i = 1; i < SDQH_MAX_IPRED; ++i) if (i < cfg_ni<FC>(f.ni)) {
+        int64_t v[NB][2];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { v[j][0] = p[j][0] ? f.ic[i][r[j]] : f.ilo[i]; v[j][1] = p[j][1] ? f.ic[i][r[j] + 1] : f.ilo[i]; }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { p[j][0] &= (v[j][0] >= f.ilo[i]) & (v[j][0] <= f.ihi[i]); p[j][1] &= (v[j][1] >= f.ilo[i]) & (v[j][1] <= f.ihi[i]); }
     }
 #pragma unroll
-    for (int i = 0; i < SDQH_MAX_FPRED; ++i) if (i < f.nf) {
-        if (p0) { double v = f.fc[i][r]; p0 = (v >= f.flo[i]) & (v <= f.fhi[i]); }
-        if (p1) { double v = f.fc[i][r + 1]; p1 = (v >= f.flo[i]) & (v <= f.fhi[i]); }
+    for (int i = 0; i < SDQH_MAX_FPRED; ++i) if (i < cfg_nf<FC>(f.nf)) {
+        double v[NB][2];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { v[j][0] = p[j][0] ? f.fc[i][r[j]] : f.flo[i]; v[j][1] = p[j][1] ? f.fc[i][r[j] + 1] : f.flo[i]; }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { p[j][0] &= (v[j][0] >= f.flo[i]) & (v[j][0] <= f.fhi[i]); p[j][1] &= (v[j][1] >= f.flo[i]) & (v[j][1] <= f.fhi[i]); }
     }
-    if (f.ns) {
-        if (p0) p0 = str_equal(f.sc + r * f.swidth, f.swidth, f.sval, f.slen) != (f.sneg != 0);
-        if (p1) p1 = str_equal(f.sc + (r + 1) * f.swidth, f.swidth, f.sval, f.slen) != (f.sneg != 0);
+    if (cfg_ns<FC>(f.ns)) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (p[j][0]) p[j][0] = str_equal(f.sc + r[j] * f.swidth, f.swidth, f.sval, f.slen) != (f.sneg != 0);
+            if (p[j][1]) p[j][1] = str_equal(f.sc + (r[j] + 1) * f.swidth, f.swidth, f.sval, f.slen) != (f.sneg != 0);
+        }
     }
 #pragma unroll
-    for (int i = 0; i < SDQH_MAX_PROBE; ++i) if (i < pr.n) {
-        if (p0) p0 = table_contains(pr.table[i], pr.key[i][r], cap_masks[i]);
-        if (p1) p1 = table_contains(pr.table[i], pr.key[i][r + 1], cap_masks[i]);
+    for (int i = 0; i < SDQH_MAX_PROBE; ++i) if (i < cfg_np<FC>(pr.n)) {
+        int64_t k[NB][2];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (i == 0 && eager) { k[j][0] = ek[j].x; k[j][1] = ek[j].y; }
+            else { k[j][0] = p[j][0] ? pr.key[i][r[j]] : 0; k[j][1] = p[j][1] ? pr.key[i][r[j] + 1] : 0; }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (p[j][0]) p[j][0] = table_contains(pr.table[i], k[j][0], cap_masks[i]);
+            if (p[j][1]) p[j][1] = table_contains(pr.table[i], k[j][1], cap_masks[i]);
+        }
     }
 }
 
+// payload column count known at compile time (NPAY >= 0) or read from the arguments (-1)
+template <int NPAY> __device__ __forceinline__ int cfg_npay(const int32_t n) { if constexpr (NPAY >= 0) return NPAY; else return n; }
+
+template <int NPAY>
+__device__ __forceinline__ void stage_store(const DevStage& st, int64_t pos, int64_t key, const int64_t (&pay)[MAX_STAGE_COLS]) {
+    st.key[pos] = key;
+#pragma unroll
+    for (int q = 0; q < MAX_STAGE_COLS; ++q) if (q < cfg_npay<NPAY>(st.npay)) st.pay[q][pos] = pay[q];
+    if (st.shits) st.shits[pos] = 0;
+    if (st.sacc) { double4 z = {0, 0, 0, 0}; *reinterpret_cast<double4*>(st.sacc + pos * 4) = z; }
+    if (st.bm && key >= st.bm_lo && key <= st.bm_hi) {
+        const uint64_t off = (uint64_t)(key - st.bm_lo);
+        const uint32_t bit = 1u << (off & 31);
+        if (atomicOr(&st.bm[off >> 5], bit) & bit) st.hdr->has_dups = 1;      // the key was staged before: duplicate build key
+    }
+}
+
+template <class FC, int NPAY = -1, int SB = STAGE_BATCH, bool EAGER = true>
 __global__ __launch_bounds__(TPB) void k_stage(DevFilter f, DevProbes pr, DevStage st, int64_t nrows) {
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
     if (seg >= st.nseg) return;
     uint64_t cap_masks[SDQH_MAX_PROBE] = {0, 0};
 #pragma unroll
-    for (int i = 0; i < SDQH_MAX_PROBE; ++i) if (i < pr.n && pr.table[i].hdr) cap_masks[i] = pr.table[i].hdr->cap_mask;
+    for (int i = 0; i < SDQH_MAX_PROBE; ++i) if (i < cfg_np<FC>(pr.n) && pr.table[i].hdr && !pr.table[i].bm) cap_masks[i] = pr.table[i].hdr->cap_mask;
     const int64_t begin = (int64_t)seg * st.seg_rows;
     int64_t end = begin + st.seg_rows; if (end > nrows) end = nrows;
     const int lane = lane_id();
     const uint64_t lt = lanemask_lt();
+    constexpr int64_t BATCH_ROWS = WAVE * ROWS_PER_LOAD;                 // 128
     int64_t out = begin;                                   // wave-uniform write cursor into the segment's stage slice
-    for (int64_t b = begin; b < end; b += WAVE * ROWS_PER_LOAD) {
-        const int64_t r = b + (int64_t)lane * ROWS_PER_LOAD;
-        bool p0, p1;
-        if (b + WAVE * ROWS_PER_LOAD <= end) { p0 = p1 = true; pass_pair<false>(f, pr, r, nrows, cap_masks, p0, p1); }
-        else {
-            p0 = r < end; p1 = r + 1 < end;
-            if (p0) p0 = row_passes(f, pr, r, cap_masks);
-            if (p1) p1 = row_passes(f, pr, r + 1, cap_masks);
-        }
-        const uint64_t b0 = __ballot(p0), b1 = __ballot(p1);
-        const int64_t pos0 = out + __popcll(b0 & lt) + __popcll(b1 & lt);
-        const int64_t pos1 = pos0 + (p0 ? 1 : 0);
-        if (p0) {
-            st.key[pos0] = st.src_key[r];
+    for (int64_t b = begin; b < end; b += BATCH_ROWS * SB) {
+        int64_t r[SB];
+        bool p[SB][2];
 #pragma unroll
-            for (int q = 0; q < SDQH_MAX_PAYLOAD; ++q) if (q < st.npay) st.pay[q][pos0] = st.src_pay[q][r];
-        }
-        if (p1) {
-            st.key[pos1] = st.src_key[r + 1];
+        for (int j = 0; j < SB; ++j) r[j] = b + j * BATCH_ROWS + (int64_t)lane * ROWS_PER_LOAD;
+        if (b + BATCH_ROWS * SB <= end) {
 #pragma unroll
-            for (int q = 0; q < SDQH_MAX_PAYLOAD; ++q) if (q < st.npay) st.pay[q][pos1] = st.src_pay[q][r + 1];
+            for (int j = 0; j < SB; ++j) p[j][0] = p[j][1] = true;
+            pass_pairs<SB, FC, EAGER>(f, pr, r, nrows, cap_masks, p);
+        } else {
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                p[j][0] = r[j] < end; p[j][1] = r[j] + 1 < end;
+                if (p[j][0]) p[j][0] = row_passes<FC>(f, pr, r[j], cap_masks);
+                if (p[j][1]) p[j][1] = row_passes<FC>(f, pr, r[j] + 1, cap_masks);
+            }
         }
-        out += __popcll(b0) + __popcll(b1);
+        // Gather key + payload of every survivor of all SB batches before the first store: one
+        // memory latency for the whole step, not one per divergent `if (survivor)` region.
+        int64_t kx[SB][2], px[SB][2][MAX_STAGE_COLS];
+#pragma unroll
+        for (int j = 0; j < SB; ++j) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                kx[j][q] = p[j][q] ? st.src_key[r[j] + q] : 0;
+#pragma unroll
+                for (int c = 0; c < MAX_STAGE_COLS; ++c) px[j][q][c] = (c < cfg_npay<NPAY>(st.npay) && p[j][q]) ? st.src_pay[c][r[j] + q] : 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SB; ++j) {
+            const uint64_t b0 = __ballot(p[j][0]), b1 = __ballot(p[j][1]);
+            const int64_t pos0 = out + __popcll(b0 & lt) + __popcll(b1 & lt);
+            if (p[j][0]) stage_store<NPAY>(st, pos0, kx[j][0], px[j][0]);
+            if (p[j][1]) stage_store<NPAY>(st, pos0 + (p[j][0] ? 1 : 0), kx[j][1], px[j][1]);
+            out += __popcll(b0) + __popcll(b1);
+        }
     }
     if (lane == 0) st.seg_count[seg] = (uint32_t)(out - begin);
 }
@@ -675,7 +855,7 @@ __global__ __launch_bounds__(TPB) void k_stage(DevFilter f, DevProbes pr, DevSta
 // Every workgroup recomputes the staged total from the segment counts (a few KB from L2), so the
 // capacity is agreed on without a grid barrier; workgroup 0 publishes the header for later kernels.
 __global__ __launch_bounds__(TPB) void k_clear(const uint32_t* __restrict__ seg_count, int nseg, uint64_t capmax,
-                                               TableHeader* __restrict__ hdr, Slot* __restrict__ slots) {
+                                               TableHeader* __restrict__ hdr, int64_t* __restrict__ keys, uint32_t* __restrict__ rowref) {
     __shared__ unsigned long long s_part[TPB];
     unsigned long long t = 0;
     for (int i = threadIdx.x; i < nseg; i += TPB) t += seg_count[i];
@@ -686,13 +866,82 @@ __global__ __launch_bounds__(TPB) void k_clear(const uint32_t* __restrict__ seg_
     uint64_t cap = 1024;
     while (cap < 2 * staged) cap <<= 1;
     if (cap > capmax) cap = capmax;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { hdr->cap_mask = cap - 1; hdr->staged = staged; hdr->distinct = 0; hdr->_pad = 0; }
-    const uint4 empty = {0u, 0x80000000u, NO_ROW, 0u};          // key = INT64_MIN, rowref = NO_ROW, hits = 0
-    uint4* s4 = reinterpret_cast<uint4*>(slots);
-    for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i <= cap; i += (uint64_t)gridDim.x * TPB) s4[i] = empty;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        hdr->cap_mask = cap - 1; hdr->staged = staged;
+        keys[cap] = EMPTY_KEY; rowref[cap] = NO_ROW;          // the extra slot that holds a real key == EMPTY_KEY
+    }
+    using V = long long __attribute__((ext_vector_type(2)));
+    const V empty = {(long long)EMPTY_KEY, (long long)EMPTY_KEY};
+    V* k2 = reinterpret_cast<V*>(keys);
+    for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < cap / 2; i += (uint64_t)gridDim.x * TPB) k2[i] = empty;
 }
 
-__global__ __launch_bounds__(TPB) void k_insert(DevStage st, DevTable t, uint32_t* __restrict__ bm, int zero_acc) {
+// ---- direct layout: prefix popcounts over the bitmap, then plain stores ---------------------------
+// One workgroup per 2048 bitmap words: popcount, exclusive scan inside the block, block total.
+__global__ __launch_bounds__(TPB) void k_rank_words(const uint32_t* __restrict__ bm, uint64_t nwords,
+                                                    uint32_t* __restrict__ wprefix, uint32_t* __restrict__ btotal) {
+    __shared__ uint32_t s_wave[TPB / WAVE];
+    constexpr int WPT = RANK_BLOCK_WORDS / TPB;                        // 8 consecutive words per thread
+    const uint64_t w0 = (uint64_t)blockIdx.x * RANK_BLOCK_WORDS + (uint64_t)threadIdx.x * WPT;
+    uint32_t word[WPT], mine = 0;
+    if (w0 + WPT <= nwords) {
+        const uint4 a = *reinterpret_cast<const uint4*>(bm + w0), b = *reinterpret_cast<const uint4*>(bm + w0 + 4);
+        word[0] = a.x; word[1] = a.y; word[2] = a.z; word[3] = a.w; word[4] = b.x; word[5] = b.y; word[6] = b.z; word[7] = b.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) word[j] = (w0 + j < nwords) ? bm[w0 + j] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) mine += __popc(word[j]);
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) { uint32_t v = __shfl_up(incl, off, WAVE); if (lane_id() >= off) incl += v; }
+    const int w = threadIdx.x / WAVE;
+    if (lane_id() == WAVE - 1) s_wave[w] = incl;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (int i = 0; i < TPB / WAVE; ++i) { if (i < w) base += s_wave[i]; total += s_wave[i]; }
+    uint32_t run = base + incl - mine;
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) { if (w0 + j < nwords) wprefix[w0 + j] = run; run += __popc(word[j]); }
+    if (threadIdx.x == 0) btotal[blockIdx.x] = total;
+}
+// one workgroup: exclusive scan of the block totals, in place; hdr->distinct = number of set bits
+__global__ __launch_bounds__(TPB) void k_rank_blocks(uint32_t* __restrict__ btotal, int nblocks, TableHeader* __restrict__ hdr) {
+    __shared__ uint32_t s_part[TPB];
+    const int per = (nblocks + TPB - 1) / TPB;
+    const int b0 = threadIdx.x * per, b1 = min(nblocks, b0 + per);
+    uint32_t sum = 0;
+    for (int b = b0; b < b1; ++b) sum += btotal[b];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t run = 0; for (int i = 0; i < TPB; ++i) { uint32_t v = s_part[i]; s_part[i] = run; run += v; } hdr->distinct = run; }
+    __syncthreads();
+    uint32_t run = s_part[threadIdx.x];
+    for (int b = b0; b < b1; ++b) { uint32_t v = btotal[b]; btotal[b] = run; run += v; }
+}
+// dense_ref[rank(key)] = stage index.  Unique build keys: plain stores, every row its own rank.
+// After a duplicate was seen while staging: atomicMin into a NO_ROW-filled array (lowest row wins).
+__global__ __launch_bounds__(TPB) void k_fill_refs(DevStage st, DevTable t) {        // no-op unless duplicates
+    if (t.hdr->has_dups == 0) return;
+    const uint64_t n = t.hdr->distinct;
+    for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) t.dense_ref[i] = NO_ROW;
+}
+__global__ __launch_bounds__(TPB) void k_insert_direct(DevStage st, DevTable t) {
+    const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
+    if (seg >= st.nseg) return;
+    const bool dups = t.hdr->has_dups != 0;
+    const int64_t base = (int64_t)seg * st.seg_rows;
+    const uint32_t count = st.seg_count[seg];
+    for (uint32_t i = lane_id(); i < count; i += WAVE) {
+        const int64_t idx = base + i;
+        const int64_t pos = table_find(t, st.key[idx], 0);
+        if (pos < 0) continue;                                         // cannot happen: the key's bit was set while staging
+        if (dups) atomicMin(&t.dense_ref[pos], (uint32_t)idx); else t.dense_ref[pos] = (uint32_t)idx;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_insert(DevStage st, DevTable t) {
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
     if (seg >= st.nseg) return;
     const uint64_t mask = t.hdr->cap_mask;
@@ -701,141 +950,212 @@ __global__ __launch_bounds__(TPB) void k_insert(DevStage st, DevTable t, uint32_
     for (uint32_t i = lane_id(); i < count; i += WAVE) {
         const int64_t idx = base + i;
         const int64_t key = st.key[idx];
-        uint64_t h;
-        bool fresh = false;
-        if (key == EMPTY_KEY) h = mask + 1;                             // the sentinel value itself lives in the extra slot
-        else {
-            h = hash_key(key) & mask;
-            for (;;) {
-                unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&t.slots[h].key),
-                                                   (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-                if (old == (unsigned long long)EMPTY_KEY) { fresh = true; break; }   // claimed a fresh slot
-                if ((int64_t)old == key) break;                                       // duplicate key: lowest row wins below
-                h = (h + 1) & mask;
-            }
+        if (key == EMPTY_KEY) {                                          // the sentinel value itself lives in the extra slot
+            if (atomicMin(&t.rowref[mask + 1], (uint32_t)idx) != NO_ROW) t.hdr->has_dups = 1;
+            continue;
         }
-        const uint32_t prev = atomicMin(&t.slots[h].rowref, (uint32_t)idx);
-        if (key == EMPTY_KEY) fresh = (prev == NO_ROW);
-        if (fresh && zero_acc) { double4 z = {0, 0, 0, 0}; *reinterpret_cast<double4*>(t.acc + h * 4) = z; }
-        if (bm && key >= t.bm_lo && key <= t.bm_hi) { uint64_t off = (uint64_t)(key - t.bm_lo); atomicOr(&bm[off >> 5], 1u << (off & 31)); }
+        uint64_t h = hash_key(key) & mask;
+        for (;;) {
+            unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&t.keys[h]),
+                                               (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+            if (old == (unsigned long long)EMPTY_KEY) { t.rowref[h] = (uint32_t)idx; break; }   // claimed a fresh slot
+            if ((int64_t)old == key) { t.hdr->has_dups = 1; break; }      // duplicate build key: settled by k_insert_fixup
+            h = (h + 1) & mask;
+        }
     }
 }
 
+// Only does work when k_insert saw a duplicate build key: every staged row then lowers its entry's
+// rowref to its own stage index, so the lowest build row wins whatever the insertion order was.
+// (Stage order is row order: segments are cut in row order and compacted in row order.)
+__global__ __launch_bounds__(TPB) void k_insert_fixup(DevStage st, DevTable t) {
+    if (t.hdr->has_dups == 0) return;
+    const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
+    if (seg >= st.nseg) return;
+    const uint64_t mask = t.hdr->cap_mask;
+    const int64_t base = (int64_t)seg * st.seg_rows;
+    const uint32_t count = st.seg_count[seg];
+    for (uint32_t i = lane_id(); i < count; i += WAVE) {
+        const int64_t idx = base + i;
+        const int64_t h = table_find(t, st.key[idx], mask);
+        if (h >= 0) atomicMin(&t.rowref[h], (uint32_t)idx);
+    }
+}
+
+// Is stage row idx the owner of its entry?  Always, unless the build met duplicate keys.
+__device__ __forceinline__ bool stage_row_owns(const DevStage& st, const DevTable& t, int64_t idx, uint64_t mask) {
+    if (t.hdr->has_dups == 0) return true;
+    const int64_t h = table_find(t, st.key[idx], mask);
+    return h >= 0 && table_ref(t, h) == (uint32_t)idx;
+}
+
 // distinct entries (table_size)
-__global__ __launch_bounds__(TPB) void k_count(const Slot* __restrict__ slots, TableHeader* __restrict__ hdr) {
-    const uint64_t cap = hdr->cap_mask + 1;
+__global__ __launch_bounds__(TPB) void k_count(DevStage st, DevTable t) {
+    const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
+    if (seg >= st.nseg) return;
+    const uint64_t mask = t.bm ? 0 : t.hdr->cap_mask;
+    const int64_t base = (int64_t)seg * st.seg_rows;
+    const uint32_t count = st.seg_count[seg];
     unsigned long long n = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i <= cap; i += (uint64_t)gridDim.x * TPB)
-        n += (slots[i].rowref != NO_ROW) ? 1 : 0;
+    for (uint32_t i = lane_id(); i < count; i += WAVE) n += stage_row_owns(st, t, base + i, mask) ? 1 : 0;
     n = (unsigned long long)wave_sum_i64((int64_t)n);
-    if (lane_id() == 0 && n) atomicAdd(reinterpret_cast<unsigned long long*>(&hdr->distinct), n);
+    if (lane_id() == 0 && n) atomicAdd(reinterpret_cast<unsigned long long*>(&t.hdr->counted), n);
 }
 
 // =================================================================================================
 // K-C large: probe + aggregate into the matched entry.  The date-like first predicate and the probe
-// key are streamed with 16-byte loads; the value operands are only read by the lanes that hit (the
-// reference short-circuits the same way: `if (pred) if (contains) { ... += ep*(1.0-disc) }`).
-// Hits are rare and scattered, so native f64 global atomics are the right tool here.
+// key are streamed with 16-byte loads, PROBE_UNROLL pairs per lane in flight; the bitmap word, the
+// slot and the value operands are only read by the lanes that are still alive (the reference
+// short-circuits the same way: `if (pred) if (contains) { ... += ep*(1.0-disc) }`).  Hits are rare
+// and scattered, so native f64 global atomics are the right tool here.
 // =================================================================================================
-template <int SHAPE, bool TAIL>
-__device__ __forceinline__ void probe_agg_pair(const DevFilter& f, const DevTuple& t, const DevTable& tb, const int64_t* __restrict__ keycol,
-                                               uint64_t mask, int64_t r, int64_t nrows) {
+constexpr int PROBE_UNROLL = 4;
+constexpr int PROBE_TILE = TPB * ROWS_PER_LOAD * PROBE_UNROLL;       // 2048 rows per workgroup step
+
+// a row whose key is in the table: add its tuple to the owning entry
+template <int SHAPE>
+__device__ __forceinline__ void probe_add(const DevFilter& f, const DevTuple& t, const DevTable& tb, int64_t pos, int64_t r) {
     constexpr int NOPS = TupleTraits<SHAPE>::NOPS, NV = TupleTraits<SHAPE>::NV;
-    bool p[2] = {TAIL ? (r < nrows) : true, TAIL ? (r + 1 < nrows) : true};
-    DevProbes none; none.n = 0;
-    uint64_t nomask[SDQH_MAX_PROBE] = {0, 0};
-    Pair<int64_t> kv = load2<TAIL>(keycol, r, nrows);
-    if constexpr (!TAIL) pass_pair<false>(f, none, r, nrows, nomask, p[0], p[1]);
-    else {
-        if (p[0]) p[0] = row_passes(f, none, r, nomask);
-        if (p[1]) p[1] = row_passes(f, none, r + 1, nomask);
-    }
-    const int64_t key[2] = {kv.x, kv.y};
+    double x[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        if (!p[q]) continue;
-        const int64_t slot = table_find(tb, key[q], mask);
-        if (slot < 0) continue;
-        double x[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0};
+    for (int j = 0; j < NOPS; ++j) x[j] = t.op[j][r];
+    if (!operand_ranges<NOPS>(f, x)) return;
+    tuple_eval<SHAPE>(x, o);
+    const uint32_t idx = table_ref(tb, pos);
 #pragma unroll
-        for (int j = 0; j < NOPS; ++j) x[j] = t.op[j][r + q];
-        if (!operand_ranges<NOPS>(f, x)) continue;
-        tuple_eval<SHAPE>(x, o);
-#pragma unroll
-        for (int k = 0; k < NV; ++k) atomicAdd(&tb.acc[slot * 4 + k], o[k]);
-        atomicAdd(&tb.slots[slot].hits, 1u);
-    }
+    for (int k = 0; k < NV; ++k) atomicAdd(&tb.sacc[(size_t)idx * 4 + k], o[k]);
+    atomicAdd(&tb.shits[idx], 1u);
 }
+
+// Rows that pass the filter (and, with the direct layout, the bitmap test) are rare and scattered
+// over the lanes.  Handling each where it is found would make every `if (hit)` region run its own
+// chain of dependent loads (index -> owner row -> operands -> atomics), one after another, in most
+// waves.  Instead each wave appends its candidates to a small queue in LDS (ballot + popcount
+// prefix) and keeps streaming; whenever 64 are queued they are processed one per lane, converged:
+// one chain of latencies per 64 candidates.
+constexpr int PROBE_QCAP = 192;                                      // 63 left over + 128 appended per sub-step
 
 template <int SHAPE>
-__global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevTable tb, const int64_t* __restrict__ keycol, int64_t nrows) {
-    const uint64_t mask = tb.hdr->cap_mask;
-    const int64_t full = nrows / TILE_ROWS;
-    for (int64_t tile = blockIdx.x; tile < full; tile += gridDim.x) {
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-            probe_agg_pair<SHAPE, false>(f, t, tb, keycol, mask, tile * TILE_ROWS + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD, nrows);
-    }
-    if (full * TILE_ROWS < nrows && blockIdx.x == (unsigned)(full % gridDim.x)) {
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-            probe_agg_pair<SHAPE, true>(f, t, tb, keycol, mask, full * TILE_ROWS + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD, nrows);
+__device__ __forceinline__ void probe_drain(const DevFilter& f, const DevTuple& t, const DevTable& tb, uint64_t mask,
+                                            const int64_t* q_row, const int64_t* q_key, int first, int n) {
+    const int lane = lane_id();
+    if (lane < n) {
+        const int64_t r = q_row[first + lane], key = q_key[first + lane];
+        const int64_t pos = table_find(tb, key, mask);
+        if (pos >= 0) probe_add<SHAPE>(f, t, tb, pos, r);
     }
 }
 
+template <int SHAPE, class FC, int PU = PROBE_UNROLL>
+__global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevTable tb, const int64_t* __restrict__ keycol, int64_t nrows) {
+    constexpr int TILE = TPB * ROWS_PER_LOAD * PU;
+    __shared__ int64_t s_row[TPB / WAVE][PROBE_QCAP], s_key[TPB / WAVE][PROBE_QCAP];
+    int64_t* q_row = s_row[threadIdx.x / WAVE];
+    int64_t* q_key = s_key[threadIdx.x / WAVE];
+    int qn = 0;                                                       // wave-uniform queue length
+    const uint64_t lt = lanemask_lt();
+    const uint64_t mask = tb.bm ? 0 : tb.hdr->cap_mask;
+    DevProbes none; none.n = 0;
+    const uint64_t nomask[SDQH_MAX_PROBE] = {0, 0};
+    const int64_t full = nrows / TILE;
+    for (int64_t tile = blockIdx.x; tile < full; tile += gridDim.x) {
+        int64_t r[PU];
+        Pair<int64_t> kv[PU];
+        bool p[PU][2];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            r[u] = tile * TILE + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
+            kv[u] = load2<false>(keycol, r[u], nrows);
+            p[u][0] = p[u][1] = true;
+        }
+        pass_pairs<PU, FC, false>(f, none, r, nrows, nomask, p);
+        if (tb.bm) {                                                   // direct layout: all bitmap words requested before any is tested
+            uint32_t w[PU][2];
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                const int64_t k0 = kv[u].x, k1 = kv[u].y;
+                p[u][0] &= (k0 >= tb.bm_lo) & (k0 <= tb.bm_hi);
+                p[u][1] &= (k1 >= tb.bm_lo) & (k1 <= tb.bm_hi);
+                w[u][0] = p[u][0] ? tb.bm[(uint64_t)(k0 - tb.bm_lo) >> 5] : 0u;
+                w[u][1] = p[u][1] ? tb.bm[(uint64_t)(k1 - tb.bm_lo) >> 5] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                p[u][0] = p[u][0] && ((w[u][0] >> ((uint64_t)(kv[u].x - tb.bm_lo) & 31)) & 1u);
+                p[u][1] = p[u][1] && ((w[u][1] >> ((uint64_t)(kv[u].y - tb.bm_lo) & 31)) & 1u);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const uint64_t b0 = __ballot(p[u][0]), b1 = __ballot(p[u][1]);
+            if (b0 | b1) {
+                const int at = qn + __popcll(b0 & lt) + __popcll(b1 & lt);
+                if (p[u][0]) { q_row[at] = r[u]; q_key[at] = kv[u].x; }
+                if (p[u][1]) { const int a1 = at + (p[u][0] ? 1 : 0); q_row[a1] = r[u] + 1; q_key[a1] = kv[u].y; }
+                qn += __popcll(b0) + __popcll(b1);
+                while (qn >= WAVE) { qn -= WAVE; probe_drain<SHAPE>(f, t, tb, mask, q_row, q_key, qn, WAVE); }
+            }
+        }
+    }
+    if (full * TILE < nrows && blockIdx.x == (unsigned)(full % gridDim.x)) {
+        for (int64_t r = full * TILE + threadIdx.x; r < nrows; r += TPB)
+            if (row_passes<FC>(f, none, r, nomask)) { const int64_t pos = table_find(tb, keycol[r], mask); if (pos >= 0) probe_add<SHAPE>(f, t, tb, pos, r); }
+    }
+    if (qn > 0) probe_drain<SHAPE>(f, t, tb, mask, q_row, q_key, 0, qn);
+}
+
 // =================================================================================================
-// K-F: compact the entries with hits >= min_hits.  Each workgroup scans a contiguous run of slots,
-// counts its survivors (ballot + LDS), reserves its output range with ONE global atomic, and writes
-// key / payload (gathered from the stage arrays through rowref) / accumulators / hits.
+// K-F: compact the entries with hits >= min_hits.  The entries are the owning stage rows, dense
+// per wave segment, so this reads 4 bytes per entry instead of scanning the slot array.  Each wave
+// walks its segment twice: first to count its survivors (the workgroup then reserves its output
+// range with ONE global atomic), then to write key / payload / accumulators / hits at
+// ballot-prefix positions.
 // =================================================================================================
 struct DevCompactOut {
     int64_t* keys; int64_t* pay[SDQH_MAX_PAYLOAD]; double* val[SDQH_TUPLE_MAX_VALUES]; int64_t* hits;
     unsigned long long* counter;
     int32_t npay, nval;
 };
-constexpr int COMPACT_SLOTS_PER_THREAD = 8;
 
 __global__ __launch_bounds__(TPB) void k_compact(DevTable t, DevStage st, DevCompactOut o, uint32_t min_hits) {
     __shared__ uint32_t s_wave[TPB / WAVE];
     __shared__ unsigned long long s_base;
-    const uint64_t cap = t.hdr->cap_mask + 1;                       // slots [0, cap] inclusive (cap = EMPTY_KEY slot)
-    const uint64_t chunk = (uint64_t)TPB * COMPACT_SLOTS_PER_THREAD;
-    for (uint64_t c0 = (uint64_t)blockIdx.x * chunk; c0 <= cap; c0 += (uint64_t)gridDim.x * chunk) {
-        bool keep[COMPACT_SLOTS_PER_THREAD];
-        uint32_t mine = 0;
+    const int w = threadIdx.x / WAVE, lane = lane_id();
+    const int seg = blockIdx.x * (TPB / WAVE) + w;
+    const uint64_t mask = t.bm ? 0 : t.hdr->cap_mask;
+    const int64_t base = (int64_t)seg * st.seg_rows;
+    const uint32_t count = seg < st.nseg ? st.seg_count[seg] : 0u;
+    const uint64_t lt = lanemask_lt();
+    uint32_t mine = 0;
+    for (uint32_t i0 = 0; i0 < count; i0 += WAVE) {
+        const uint32_t i = i0 + lane;
+        const bool keep = i < count && st.shits[base + i] >= min_hits && stage_row_owns(st, t, base + i, mask);
+        mine += (uint32_t)__popcll(__ballot(keep));
+    }
+    if (lane == 0) s_wave[w] = mine;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+    for (int i = 0; i < TPB / WAVE; ++i) { if (i < w) wbase += s_wave[i]; total += s_wave[i]; }
+    if (threadIdx.x == 0) s_base = total ? atomicAdd(o.counter, (unsigned long long)total) : 0ull;
+    __syncthreads();
+    if (mine == 0) return;
+    uint64_t pos = s_base + wbase;
+    for (uint32_t i0 = 0; i0 < count; i0 += WAVE) {
+        const uint32_t i = i0 + lane;
+        const int64_t idx = base + i;
+        const uint32_t hits = i < count ? st.shits[idx] : 0u;
+        const bool keep = i < count && hits >= min_hits && stage_row_owns(st, t, idx, mask);
+        const uint64_t b = __ballot(keep);
+        if (keep) {
+            const uint64_t at = pos + __popcll(b & lt);
+            if (o.keys) o.keys[at] = st.key[idx];
 #pragma unroll
-        for (int j = 0; j < COMPACT_SLOTS_PER_THREAD; ++j) {
-            const uint64_t s = c0 + (uint64_t)j * TPB + threadIdx.x;
-            bool k = false;
-            if (s <= cap) { const Slot sl = t.slots[s]; k = (sl.rowref != NO_ROW) && (sl.hits >= min_hits); }
-            keep[j] = k; mine += k ? 1u : 0u;
+            for (int q = 0; q < SDQH_MAX_PAYLOAD; ++q) if (q < o.npay && o.pay[q]) o.pay[q][at] = st.pay[q][idx];
+#pragma unroll
+            for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) if (k < o.nval && o.val[k]) o.val[k][at] = st.sacc[(size_t)idx * 4 + k];
+            if (o.hits) o.hits[at] = (int64_t)hits;
         }
-        // exclusive prefix of `mine` over the workgroup
-        uint32_t incl = mine;
-#pragma unroll
-        for (int off = 1; off < WAVE; off <<= 1) { uint32_t v = __shfl_up(incl, off, WAVE); if (lane_id() >= off) incl += v; }
-        const int w = threadIdx.x / WAVE;
-        if (lane_id() == WAVE - 1) s_wave[w] = incl;
-        __syncthreads();
-        uint32_t wbase = 0, total = 0;
-        for (int i = 0; i < TPB / WAVE; ++i) { if (i < w) wbase += s_wave[i]; total += s_wave[i]; }
-        if (threadIdx.x == 0) s_base = total ? atomicAdd(o.counter, (unsigned long long)total) : 0ull;
-        __syncthreads();
-        uint64_t pos = s_base + wbase + (incl - mine);
-#pragma unroll
-        for (int j = 0; j < COMPACT_SLOTS_PER_THREAD; ++j) {
-            if (!keep[j]) continue;
-            const uint64_t s = c0 + (uint64_t)j * TPB + threadIdx.x;
-            const Slot sl = t.slots[s];
-            if (o.keys) o.keys[pos] = (s == cap) ? EMPTY_KEY : sl.key;
-#pragma unroll
-            for (int q = 0; q < SDQH_MAX_PAYLOAD; ++q) if (q < o.npay && o.pay[q]) o.pay[q][pos] = st.pay[q][sl.rowref];
-#pragma unroll
-            for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) if (k < o.nval && o.val[k]) o.val[k][pos] = t.acc[s * 4 + k];
-            if (o.hits) o.hits[pos] = (int64_t)sl.hits;
-            ++pos;
-        }
-        __syncthreads();
+        pos += __popcll(b);
     }
 }
 

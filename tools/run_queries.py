@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Run the hot-path queries a few times with no instrumentation of our own — the target program for
+rocprofv3 (--kernel-trace --stats, or --pmc in a separate run).
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 tools/run_queries.py --sf 10 --queries q1,q3 --iters 10"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sf", type=float, default=10.0)
+    ap.add_argument("--queries", default="q1,q3")
+    ap.add_argument("--iters", type=int, default=10)
+    args = ap.parse_args()
+    qs = args.queries.split(",")
+    from sdqlpy_amd import tpch
+    from sdqlpy_amd import tpch_queries as Q
+    from sdqlpy_amd.sdql_lib import sdqlpy_init
+    sdqlpy_init(3, 1, device=0)
+    db = tpch.generate(args.sf, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+    for _ in range(args.iters):
+        for q in qs:
+            Q.run(q, db)
+
+
+if __name__ == "__main__":
+    main()

@@ -110,7 +110,10 @@ def main():
         for q in queries:
             run_query(q)
 
+    # Timed region.  HIP events are recorded around every kernel launch on the stream the kernels
+    # run on (profiling mode 2: record only, nothing synchronises); they are read after the region.
     per_query_ms = {q: 0.0 for q in queries}
+    eng.ctx.set_profiling(2)
     barrier()
     t_begin = time.perf_counter()
     for _ in range(args.steps):
@@ -120,6 +123,8 @@ def main():
             per_query_ms[q] += (time.perf_counter() - tq) * 1e3
     barrier()
     elapsed = time.perf_counter() - t_begin
+    launches = eng.ctx.profile()                         # [(kernel, ms)] of every launch in the timed region
+    eng.ctx.set_profiling(0)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -132,42 +137,38 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rows_per_step * args.steps / elapsed
 
-    # ---- per-kernel device time, measured live with HIP events on the stream the kernels run on ----
-    kernel_ms, device_ms = {}, {q: 0.0 for q in queries}
-    eng.ctx.set_profiling(True)
-    for _ in range(args.profile_iters):
-        for q in queries:
-            eng.ctx.kernel_log, eng.ctx.device_log = [], []
-            run_query(q)
-            for name, ms in eng.ctx.kernel_log:
-                kernel_ms[(q, name)] = kernel_ms.get((q, name), 0.0) + ms
-            device_ms[q] += sum(ms for _, ms in eng.ctx.device_log)
-    eng.ctx.set_profiling(False)
-    iters = max(1, args.profile_iters)
-    device_ms = {q: v / iters for q, v in device_ms.items()}
-    # a kernel may be launched more than once per query (q3 builds two tables): ms per query pass
-    kernels = {"%s:%s" % (q, name): v / iters for (q, name), v in kernel_ms.items()}
+    kstat = {}
+    for name, ms in launches:
+        tot, n = kstat.get(name, (0.0, 0))
+        kstat[name] = (tot + ms, n + 1)
+    kernels = {name: {"launches_per_step": n / args.steps, "avg_launch_ms": tot / n, "ms_per_step": tot / args.steps}
+               for name, (tot, n) in kstat.items()}
+    q_of = lambda k: "q1" if k.startswith("k_groupby") else ("q6" if k in ("k_scan_sum", "k_sum_partials") else "q3")   # noqa: E731
+    device_ms = {q: sum(v["ms_per_step"] for k, v in kernels.items() if q_of(k) == q) for q in queries}
 
     out = None
     if rank == 0:
         dom_q = "q1" if "q1" in queries else queries[0]
         dom_name = {"q1": "k_groupby_reg", "q3": "k_probe_agg", "q6": "k_scan_sum"}[dom_q]
-        dom_ms = kernels.get("%s:%s" % (dom_q, dom_name))
         roofline = None
-        if dom_ms:
+        if dom_name in kernels:
+            dom_ms = kernels[dom_name]["avg_launch_ms"]
             per_launch_bytes = {"q1": 48 * rows["lineitem"], "q3": 32 * rows["lineitem"], "q6": 32 * rows["lineitem"]}[dom_q]
             achieved = per_launch_bytes / (dom_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                        "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": round(dom_ms, 4)}
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom_name, rows),
+                        "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": round(dom_ms, 4),
+                        "launches_timed": int(kernels[dom_name]["launches_per_step"] * args.steps)}
         per_query = {}
         for q in queries:
             ab = algorithmic_bytes(q, rows)
             wall = per_query_ms[q] / args.steps
-            per_query[q] = {"ms_wall": round(wall, 4), "ms_device": round(device_ms[q], 4),
+            per_query[q] = {"ms_wall": round(wall, 4), "ms_kernels": round(device_ms[q], 4),
                             "rows_per_s_wall": round(scanned_rows(q, rows) / (wall * 1e-3), 1),
-                            "algorithmic_GBs_device": round(ab / (device_ms[q] * 1e-3) / 1e9, 1) if device_ms[q] else None,
-                            "roofline_frac_device": round(ab / (device_ms[q] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if device_ms[q] else None}
+                            "algorithmic_bytes": ab,
+                            "algorithmic_GBs_wall": round(ab / (wall * 1e-3) / 1e9, 1),
+                            "algorithmic_GBs_kernels": round(ab / (device_ms[q] * 1e-3) / 1e9, 1) if device_ms[q] else None,
+                            "roofline_frac_kernels": round(ab / (device_ms[q] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if device_ms[q] else None}
         out = {
             "metric": "tpch_q1_q3_sf10_rows_per_sec", "value": round(value, 1), "unit": "rows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -175,7 +176,7 @@ def main():
             "config": {"workload": "TPCH " + "+".join(q.upper() for q in queries) + " SF=%g per GPU (q1 = BASELINE configs[1], q3 = configs[2])" % args.sf,
                        "sf_per_gpu": args.sf, "rows_per_gpu": rows, "partitioning": "none" if world == 1 else "q1 row-sharded; q3 partitioned on o_orderkey, RCCL all-to-all"},
             "ms_per_query": per_query,
-            "kernels_ms": {k: round(v, 4) for k, v in sorted(kernels.items())},
+            "kernels": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in sorted(kernels.items())},
             "roofline": roofline,
             "first_pass_with_upload_s": round(first_pass_s, 3), "generate_s": round(gen_s, 2),
         }
@@ -186,6 +187,22 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return out
+
+
+def pmc_traffic(kernel, rows):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (FETCH_SIZE doubled
+    as MI355X_MICROARCH.md prescribes for 16-byte-per-lane streaming reads on gfx950, + WRITE_SIZE),
+    if that summary was taken on the same row counts; else None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    k = rec.get("kernels", {}).get(kernel)
+    if not k or rec.get("rows", {}).get("lineitem") != rows.get("lineitem"):
+        return None
+    return k.get("hbm_bytes_per_launch")
 
 
 def cpu_baseline(args, queries, db, rows):

@@ -135,9 +135,11 @@ int         sdqh_synchronize(sdqh_ctx* ctx);
 /* Milliseconds spent on the device by the most recent pattern call (HIP events on the ctx
  * stream; CPU build: wall clock of the call). */
 int         sdqh_last_device_ms(const sdqh_ctx* ctx, double* ms);
-/* Name and duration (ms) of each kernel launched by the most recent pattern call, measured with
- * HIP events on the ctx stream when profiling is enabled (sdqh_set_profiling). */
-int         sdqh_set_profiling(sdqh_ctx* ctx, int enabled);
+/* Name and duration (ms) of each kernel launch, measured with HIP events recorded on the ctx
+ * stream around the launch.  mode 1: entries of the most recent pattern call; mode 2: entries
+ * accumulate over all calls (events are only recorded, nothing synchronises) until the mode is set
+ * again — read them with sdqh_profile_count / sdqh_profile_entry after the timed region. */
+int         sdqh_set_profiling(sdqh_ctx* ctx, int mode);
 int         sdqh_profile_count(const sdqh_ctx* ctx);
 int         sdqh_profile_entry(const sdqh_ctx* ctx, int i, const char** name, double* ms);
 /* Raw hipStream_t the ctx launches on (NULL in the CPU build). */

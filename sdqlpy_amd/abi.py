@@ -205,9 +205,12 @@ class Context:
         self._check(self.lib.sdqh_last_device_ms(self.handle, C.byref(ms)))
         return ms.value
 
-    def set_profiling(self, on):
-        self._check(self.lib.sdqh_set_profiling(self.handle, C.c_int(1 if on else 0)))
-        self._profiling = bool(on)
+    def set_profiling(self, mode):
+        """0/False off; 1/True per call (kernel_log / device_log filled after every pattern call,
+        synchronising); 2 record only — read everything afterwards with profile()."""
+        mode = int(mode)
+        self._check(self.lib.sdqh_set_profiling(self.handle, C.c_int(mode)))
+        self._profiling = mode == 1
         self.kernel_log, self.device_log = [], []
 
     def _after_call(self, name):
@@ -312,17 +315,17 @@ class Context:
         self._after_call("table_compact")
         return n.value
 
-    def table_compact(self, table, min_hits, capacity, want_payload=True, want_values=True):
+    def table_compact(self, table, min_hits, capacity, want_payload=True, want_values=True, want_hits=True):
         cap = max(1, int(capacity))
         keys = np.empty(cap, np.int64)
         payload = np.empty((max(1, table.npayload), cap), np.int64) if want_payload and table.npayload else None
         values = np.empty((TUPLE_MAX_VALUES, cap), np.float64) if want_values and table.accumulate else None
-        hits = np.empty(cap, np.int64)
+        hits = np.empty(cap, np.int64) if want_hits else None
         n = C.c_int64()
         self._check(self.lib.sdqh_table_compact(self.handle, table.handle, C.c_int64(min_hits), C.c_int64(cap), _np_ptr(keys),
                                                 _np_ptr(payload), _np_ptr(values), _np_ptr(hits), C.byref(n)))
         n = n.value
-        return (keys[:n], None if payload is None else payload[:, :n], None if values is None else values[:, :n], hits[:n])
+        return (keys[:n], None if payload is None else payload[:, :n], None if values is None else values[:, :n], None if hits is None else hits[:n])
 
     def scan_compact(self, nrows, flt, probes, cols):
         parr = (Probe * max(1, len(probes)))()

@@ -43,9 +43,11 @@ struct sdqh_ctx {
     bool staging_busy[2] = {false, false};
     void* result_host = nullptr;                   // pinned
     void* result_dev = nullptr;
+    void* bulk_host = nullptr;                     // pinned landing zone for result rows (grown on demand)
+    size_t bulk_bytes = 0;
     hipEvent_t call_begin = nullptr, call_end = nullptr;
     bool call_timed = false;
-    bool profiling = false;
+    int profiling = 0;                             // 0 off, 1 per call, 2 accumulate across calls (read at the end)
     std::vector<ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;
     size_t event_next = 0;
@@ -58,6 +60,7 @@ struct sdqh_ctx {
     int opt_probe_unroll = PROBE_UNROLL;
     int opt_stage_batch = STAGE_BATCH;
     int opt_stage_eager = 1;
+    int opt_stage_eager_pay = 1;
     int opt_stage_waves_per_cu = 16;
     int opt_direct_index = 1;
 };
@@ -91,6 +94,8 @@ struct sdqh_table {
     bool compact_valid = false;
     int64_t compact_min_hits = 0, compact_n = 0;
     DevCompactOut compact{};
+    uint32_t* seg_kept = nullptr;
+    int nv = SDQH_TUPLE_MAX_VALUES;    // value count of the tuple aggregated into the table
 };
 
 static int ensure_index(sdqh_ctx* ctx, sdqh_table* tb);
@@ -137,7 +142,7 @@ hipEvent_t next_event(sdqh_ctx* ctx) {
     return ctx->event_pool[ctx->event_next++];
 }
 void call_begin(sdqh_ctx* ctx) {
-    ctx->prof.clear(); ctx->event_next = 0;
+    if (ctx->profiling != 2) { ctx->prof.clear(); ctx->event_next = 0; }
     (void)hipEventRecord(ctx->call_begin, ctx->stream);
     ctx->call_timed = false;
 }
@@ -160,7 +165,7 @@ struct KernelScope {
 
 int sync_stream(sdqh_ctx* ctx) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->profiling) for (auto& e : ctx->prof) { float ms = 0; if (hipEventElapsedTime(&ms, e.e0, e.e1) == hipSuccess) e.ms = ms; }
+    if (ctx->profiling == 1) for (auto& e : ctx->prof) { float ms = 0; if (hipEventElapsedTime(&ms, e.e0, e.e1) == hipSuccess) e.ms = ms; }
     return SDQH_OK;
 }
 
@@ -362,6 +367,7 @@ void sdqh_destroy(sdqh_ctx* ctx) {
     for (auto& b : ctx->pool) if (b.ptr) (void)hipFree(b.ptr);
     for (int i = 0; i < 2; ++i) { if (ctx->staging[i]) (void)hipHostFree(ctx->staging[i]); if (ctx->staging_done[i]) (void)hipEventDestroy(ctx->staging_done[i]); }
     if (ctx->result_host) (void)hipHostFree(ctx->result_host);
+    if (ctx->bulk_host) (void)hipHostFree(ctx->bulk_host);
     if (ctx->result_dev) (void)hipFree(ctx->result_dev);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->call_begin) (void)hipEventDestroy(ctx->call_begin);
@@ -383,7 +389,11 @@ int sdqh_last_device_ms(const sdqh_ctx* cctx, double* ms) {
     *ms = f;
     return SDQH_OK;
 }
-int sdqh_set_profiling(sdqh_ctx* ctx, int enabled) { if (!ctx) return SDQH_ERR_INVALID; ctx->profiling = enabled != 0; return SDQH_OK; }
+int sdqh_set_profiling(sdqh_ctx* ctx, int mode) {
+    if (!ctx || mode < 0 || mode > 2) return SDQH_ERR_INVALID;
+    ctx->profiling = mode; ctx->prof.clear(); ctx->event_next = 0;
+    return SDQH_OK;
+}
 int sdqh_profile_count(const sdqh_ctx* ctx) { return ctx ? (int)ctx->prof.size() : 0; }
 int sdqh_profile_entry(const sdqh_ctx* cctx, int i, const char** name, double* ms) {
     sdqh_ctx* ctx = const_cast<sdqh_ctx*>(cctx);
@@ -401,6 +411,7 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "probe_unroll" && (value == 1 || value == 2 || value == 4)) ctx->opt_probe_unroll = (int)value;
     else if (n == "stage_batch" && (value == 2 || value == 4 || value == 8)) ctx->opt_stage_batch = (int)value;
     else if (n == "stage_eager" && (value == 0 || value == 1)) ctx->opt_stage_eager = (int)value;
+    else if (n == "stage_eager_pay" && (value == 0 || value == 1)) ctx->opt_stage_eager_pay = (int)value;
     else if (n == "stage_waves_per_cu" && value >= 4 && value <= 64) ctx->opt_stage_waves_per_cu = (int)value;
     else if (n == "direct_index" && (value == 0 || value == 1)) ctx->opt_direct_index = (int)value;
     else return fail(ctx, SDQH_ERR_INVALID, "set_option: unknown option or value out of range: " + n);
@@ -551,16 +562,16 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
         const int G = use_lds ? GMAX : GREG;
         unsigned grid = 1;
         char* blob = nullptr;
-        unsigned long long* pkeys = nullptr; double* pacc = nullptr; int64_t* pcnt = nullptr;
+        double* pacc = nullptr; int64_t* pcnt = nullptr;
         auto carve = [&]() {
-            const size_t nslots = (size_t)grid * G;
-            blob = static_cast<char*>(pool_alloc(ctx, nslots * 48 + 256));
+            const size_t nslots = (size_t)grid * GMAX;                 // every workgroup writes all GMAX global slots
+            blob = static_cast<char*>(pool_alloc(ctx, nslots * 40 + 256));
             if (!blob) return fail(ctx, SDQH_ERR_NOMEM, "groupby_small: out of device memory");
-            pkeys = reinterpret_cast<unsigned long long*>(blob);
-            pacc = reinterpret_cast<double*>(blob + nslots * 8);
-            pcnt = reinterpret_cast<int64_t*>(blob + nslots * 40);
+            pacc = reinterpret_cast<double*>(blob);
+            pcnt = reinterpret_cast<int64_t*>(blob + nslots * 32);
             call_begin(ctx);
-            hipError_t e = hipMemsetAsync(r_ng, 0, 8, ctx->stream);
+            hipError_t e = hipMemsetAsync(r_keys, 0xFF, GMAX * 8, ctx->stream);       // every global group slot EMPTY_GROUP
+            if (e == hipSuccess) e = hipMemsetAsync(r_ng, 0, 8, ctx->stream);
             return e == hipSuccess ? SDQH_OK : fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e));
         };
         int lrc = with_shape(ctx, tuple->shape, [&](auto S) {
@@ -569,7 +580,7 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
                 auto kern = k_groupby_lds<SH>;
                 grid = stream_grid(ctx, kern, nrows);
                 if (int c = carve()) return c;
-                LAUNCH(ctx, "k_groupby_lds", kern, grid, f, t, gk, nrows, pkeys, pacc, pcnt, r_flags);
+                LAUNCH(ctx, "k_groupby_lds", kern, grid, f, t, gk, nrows, r_keys, pacc, pcnt, r_flags);
                 return SDQH_OK;
             }
             return with_scan_filter(f, [&](auto FC) {
@@ -577,13 +588,13 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
                     auto kern = k_groupby_reg<SH, GREG, decltype(FC), decltype(KC)>;
                     grid = stream_grid(ctx, kern, nrows);
                     if (int c = carve()) return c;
-                    LAUNCH(ctx, "k_groupby_reg", kern, grid, f, t, gk, nrows, pkeys, pacc, pcnt, r_flags);
+                    LAUNCH(ctx, "k_groupby_reg", kern, grid, f, t, gk, nrows, r_keys, pacc, pcnt, r_flags);
                     return SDQH_OK;
                 });
             });
         });
         if (lrc) { if (blob) pool_free(ctx, blob); return lrc; }
-        LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, GMAX, pkeys, pacc, pcnt, (int)grid, G, r_keys, r_acc, r_cnt, r_ng, r_flags);
+        LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, GMAX, r_keys, pacc, pcnt, (int)grid, r_acc, r_cnt);
         call_end(ctx);
         HIP_TRY(ctx, hipMemcpyAsync(ctx->result_host, rd, rbytes, hipMemcpyDeviceToHost, ctx->stream));
         rc = sync_stream(ctx);
@@ -599,16 +610,19 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
         break;
     }
     if (rc) return rc;
-    const int ng = *reinterpret_cast<const int*>(h + GMAX * 48);
-    if (ng > max_groups) { *out_ngroups = ng; return fail(ctx, SDQH_ERR_OVERFLOW, "groupby_small: more groups than max_groups"); }
     const unsigned long long* hk = reinterpret_cast<const unsigned long long*>(h);
     const double* ha = reinterpret_cast<const double*>(h + GMAX * 8);
     const int64_t* hc = reinterpret_cast<const int64_t*>(h + GMAX * 40);
     const int nv = tuple_nv(tuple->shape);
-    for (int g = 0; g < ng; ++g) {
-        if (out_keys) for (int k = 0; k < nkeys; ++k) out_keys[g * nkeys + k] = (int64_t)((hk[g] >> (32 * k)) & 0xFFFFFFFFull);
-        if (out_values) for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) out_values[g * SDQH_TUPLE_MAX_VALUES + k] = k < nv ? ha[g * 4 + k] : 0.0;
-        if (out_counts) out_counts[g] = hc[g];
+    int order[GMAX], ng = 0;
+    for (int g = 0; g < GMAX; ++g) if (hk[g] != EMPTY_GROUP && hc[g] > 0) order[ng++] = g;
+    std::sort(order, order + ng, [&](int a, int b) { return hk[a] < hk[b]; });       // global slots are claimed in racy order
+    if (ng > max_groups) { *out_ngroups = ng; return fail(ctx, SDQH_ERR_OVERFLOW, "groupby_small: more groups than max_groups"); }
+    for (int i = 0; i < ng; ++i) {
+        const int g = order[i];
+        if (out_keys) for (int k = 0; k < nkeys; ++k) out_keys[i * nkeys + k] = (int64_t)((hk[g] >> (32 * k)) & 0xFFFFFFFFull);
+        if (out_values) for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) out_values[i * SDQH_TUPLE_MAX_VALUES + k] = k < nv ? ha[g * 4 + k] : 0.0;
+        if (out_counts) out_counts[i] = hc[g];
     }
     *out_ngroups = ng;
     return SDQH_OK;
@@ -667,7 +681,7 @@ static int ensure_index(sdqh_ctx* ctx, sdqh_table* tb) {
         if (!wprefix || !bprefix || !dense) return fail(ctx, SDQH_ERR_NOMEM, "table index: out of device memory");
         tb->dev.wprefix = wprefix; tb->dev.bprefix = bprefix; tb->dev.dense_ref = dense;
         LAUNCH(ctx, "k_rank_words", k_rank_words, (unsigned)nblocks, tb->bm, tb->nwords, wprefix, bprefix);
-        LAUNCH(ctx, "k_rank_blocks", k_rank_blocks, 1, bprefix, nblocks, tb->hdr);
+        LAUNCH(ctx, "k_rank_blocks", k_rank_blocks, 1, bprefix, nblocks, tb->stage.seg_count, tb->stage.nseg, tb->hdr);
         LAUNCH(ctx, "k_fill_refs", k_fill_refs, (unsigned)ctx->num_cu * 2, tb->stage, tb->dev);
         LAUNCH(ctx, "k_insert_direct", k_insert_direct, seg_grid, tb->stage, tb->dev);
     } else {                                                               // hash layout
@@ -731,8 +745,9 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
                 if constexpr (std::is_same_v<FCT, FCfg<1, 0, 0, 1>>) {          // the tuned instance family (orders-like build side)
                     const int sb = ctx->opt_stage_batch, eg = ctx->opt_stage_eager;
                     if (npayload == 2) {
-#define STAGE_VARIANT(SB_, EG_) if (sb == SB_ && eg == EG_) { auto kern = k_stage<FCT, 2, SB_, EG_ != 0>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows); return SDQH_OK; }
-                        STAGE_VARIANT(2, 1) STAGE_VARIANT(4, 1) STAGE_VARIANT(8, 1) STAGE_VARIANT(2, 0) STAGE_VARIANT(4, 0)
+                        const int ep = ctx->opt_stage_eager_pay;
+#define STAGE_VARIANT(SB_, EG_, EP_) if (sb == SB_ && eg == EG_ && ep == EP_) { auto kern = k_stage<FCT, 2, SB_, EG_ != 0, EP_ != 0>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows); return SDQH_OK; }
+                        STAGE_VARIANT(2, 1, 1) STAGE_VARIANT(4, 1, 1) STAGE_VARIANT(2, 1, 0) STAGE_VARIANT(4, 1, 0) STAGE_VARIANT(8, 1, 0) STAGE_VARIANT(4, 0, 0)
 #undef STAGE_VARIANT
                     }
                 }
@@ -785,6 +800,7 @@ int sdqh_hash_probe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* f
     if (int rc = make_filter(ctx, nrows, filter, tuple, &f)) return rc;
     if (int rc = check_col(ctx, key, SDQH_I64, nrows, "probe key")) return rc;
     table->compact_valid = false;
+    table->nv = std::max(0, tuple_nv(tuple->shape));
     const int64_t* kc = static_cast<const int64_t*>(key->data);
     call_begin(ctx);
     if (int rc = ensure_index(ctx, table)) return rc;
@@ -823,13 +839,16 @@ static int run_compact(sdqh_ctx* ctx, sdqh_table* table, int64_t min_hits) {
         for (int p = 0; p < table->npay && ok; ++p) { o.pay[p] = static_cast<int64_t*>(table_alloc(ctx, table, rows * 8)); ok = o.pay[p] != nullptr; }
         if (table->accumulate) for (int k = 0; k < SDQH_TUPLE_MAX_VALUES && ok; ++k) { o.val[k] = static_cast<double*>(table_alloc(ctx, table, rows * 8)); ok = o.val[k] != nullptr; }
         if (!ok) return fail(ctx, SDQH_ERR_NOMEM, "table_compact: out of device memory");
-        o.npay = table->npay; o.nval = table->accumulate ? SDQH_TUPLE_MAX_VALUES : 0;
     }
+    o.npay = table->npay; o.nval = table->accumulate ? table->nv : 0;
     call_begin(ctx);
     if (int rc = ensure_index(ctx, table)) return rc;
-    HIP_TRY(ctx, hipMemsetAsync(o.counter, 0, 8, ctx->stream));
     uint32_t mh = (uint32_t)std::min<int64_t>(std::max<int64_t>(min_hits, 0), 0xFFFFFFFFll);
-    LAUNCH(ctx, "k_compact", k_compact, (unsigned)((table->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE)), table->dev, table->stage, o, mh);
+    const unsigned seg_grid = (unsigned)((table->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
+    if (!table->seg_kept) { table->seg_kept = static_cast<uint32_t*>(table_alloc(ctx, table, (size_t)table->stage.nseg * 4 + 64)); if (!table->seg_kept) return fail(ctx, SDQH_ERR_NOMEM, "table_compact: out of device memory"); }
+    LAUNCH(ctx, "k_compact_count", k_compact_count, seg_grid, table->dev, table->stage, o, mh, table->seg_kept);
+    LAUNCH(ctx, "k_compact_scan", k_compact_scan, 1, table->seg_kept, table->stage.nseg, o.counter);
+    LAUNCH(ctx, "k_compact_write", k_compact_write, seg_grid, table->dev, table->stage, o, mh, table->seg_kept);
     call_end(ctx);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->result_host, o.counter, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (int rc = sync_stream(ctx)) return rc;
@@ -852,12 +871,33 @@ int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_hits
     if (n == 0) return SDQH_OK;
     const DevCompactOut& o = table->compact;
     const size_t nb = (size_t)n * 8;
-    if (out_keys) HIP_TRY(ctx, hipMemcpyAsync(out_keys, o.keys, nb, hipMemcpyDeviceToHost, ctx->stream));
-    if (out_payload) for (int p = 0; p < table->npay; ++p) HIP_TRY(ctx, hipMemcpyAsync(out_payload + (size_t)p * (size_t)capacity, o.pay[p], nb, hipMemcpyDeviceToHost, ctx->stream));
-    if (out_values && table->accumulate) for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) HIP_TRY(ctx, hipMemcpyAsync(out_values + (size_t)k * (size_t)capacity, o.val[k], nb, hipMemcpyDeviceToHost, ctx->stream));
-    if (out_values && !table->accumulate) std::memset(out_values, 0, (size_t)capacity * SDQH_TUPLE_MAX_VALUES * 8);
-    if (out_hits) HIP_TRY(ctx, hipMemcpyAsync(out_hits, o.hits, nb, hipMemcpyDeviceToHost, ctx->stream));
-    return sync_stream(ctx);
+    // D2H lands in pinned memory (a copy into pageable numpy memory is several times slower and
+    // serialises inside the runtime), then one memcpy per array into the caller's buffers.
+    const int nv = table->accumulate ? table->nv : 0;
+    const int narr = (out_keys ? 1 : 0) + (out_payload ? table->npay : 0) + (out_values ? nv : 0) + (out_hits ? 1 : 0);
+    const size_t need = nb * (size_t)narr;
+    if (need > ctx->bulk_bytes && need <= ((size_t)1 << 30)) {
+        if (ctx->bulk_host) (void)hipHostFree(ctx->bulk_host);
+        ctx->bulk_host = nullptr; ctx->bulk_bytes = 0;
+        size_t want = std::max<size_t>(need * 2, (size_t)8 << 20);
+        if (hipHostMalloc(&ctx->bulk_host, want, hipHostMallocDefault) == hipSuccess) ctx->bulk_bytes = want; else (void)hipGetLastError();
+    }
+    const bool pinned = need <= ctx->bulk_bytes;
+    char* land = static_cast<char*>(ctx->bulk_host);
+    std::vector<std::pair<void*, const void*>> copies;       // (destination, pinned source)
+    auto fetch = [&](void* dst, const void* dev) -> int {
+        if (pinned) { HIP_TRY(ctx, hipMemcpyAsync(land, dev, nb, hipMemcpyDeviceToHost, ctx->stream)); copies.push_back({dst, land}); land += nb; }
+        else HIP_TRY(ctx, hipMemcpyAsync(dst, dev, nb, hipMemcpyDeviceToHost, ctx->stream));
+        return SDQH_OK;
+    };
+    if (out_keys) if (int rc = fetch(out_keys, o.keys)) return rc;
+    if (out_payload) for (int p = 0; p < table->npay; ++p) if (int rc = fetch(out_payload + (size_t)p * (size_t)capacity, o.pay[p])) return rc;
+    if (out_values) for (int k = 0; k < nv; ++k) if (int rc = fetch(out_values + (size_t)k * (size_t)capacity, o.val[k])) return rc;
+    if (out_values) for (int k = nv; k < SDQH_TUPLE_MAX_VALUES; ++k) std::memset(out_values + (size_t)k * (size_t)capacity, 0, (size_t)n * 8);
+    if (out_hits) if (int rc = fetch(out_hits, o.hits)) return rc;
+    if (int rc = sync_stream(ctx)) return rc;
+    for (auto& c : copies) std::memcpy(c.first, c.second, nb);
+    return SDQH_OK;
 }
 
 // ---- multi-GPU helpers -------------------------------------------------------------------------

@@ -378,13 +378,15 @@ __global__ __launch_bounds__(TPB) void k_sum_partials(const double* __restrict__
 // K-C small: group-by over a small key domain.
 //   Key: up to two 32-bit parts (UCS4 code unit of a string(1) column, or an int in [0, 2^32-2])
 //   packed into one 64-bit word.  Each workgroup keeps its own key table in LDS (claimed by LDS CAS
-//   in first-come order; a global table would serialise thousands of CAS on a handful of
-//   addresses).  k_groupby_reg keeps G x NV accumulators per lane in registers and adds each row
-//   under a per-group predicate (no atomics, no divergence); k_groupby_lds is the G <= 64
-//   fall-back with LDS f64 atomics.  Both write one partial per workgroup; k_groupby_merge ranks
-//   the distinct keys (ascending) and folds the partials of the g-th key in workgroup order, so
-//   sums and output order are bit-reproducible run to run.
-// partial layout: pkeys[wg*G + s], pacc[(wg*G + s)*4 + k], pcnt[wg*G + s]
+//   in first-come order while it streams; doing that on a global table would serialise hundreds of
+//   thousands of CAS on a handful of addresses).  k_groupby_reg keeps G x NV accumulators per lane
+//   in registers and adds each row under a per-group predicate (no atomics, no divergence);
+//   k_groupby_lds is the G <= 64 fall-back with LDS f64 atomics.  Only when a workgroup is done
+//   does it map its few local slots to GLOBAL group slots (one agent-scope CAS per key, usually
+//   just an atomic load) and write its partials at the global slot, so k_groupby_merge is a plain
+//   fold of slot g over the workgroups in workgroup order: the sums are bit-reproducible run to
+//   run (the order of the groups is not; the host sorts the handful of groups by key).
+// partial layout (slot-major, coalesced for the merge): pacc[(g*nwg + wg)*4 + k], pcnt[g*nwg + wg]
 // =================================================================================================
 struct DevGroupKeys {
     const void* col[SDQH_MAX_GROUPKEYS];
@@ -423,7 +425,8 @@ __device__ __forceinline__ void load_group_keys(const DevGroupKeys& gk, int64_t 
 // claim-or-find in the workgroup's LDS key table; -1 when the table is full
 template <int G>
 __device__ __forceinline__ int lds_claim(unsigned long long* s_keys, uint64_t key) {
-    for (int j = 0; j < G; ++j) {
+#pragma unroll 1
+    for (int j = 0; j < G; ++j) {                            // cold path: keep it a real loop (unrolled copies thrash the I-cache)
         unsigned long long cur = s_keys[j];
         if (cur == key) return j;
         if (cur != EMPTY_GROUP) continue;
@@ -431,6 +434,41 @@ __device__ __forceinline__ int lds_claim(unsigned long long* s_keys, uint64_t ke
         if (old == EMPTY_GROUP || old == key) return j;
     }
     return -1;
+}
+
+// claim-or-find `key` in the global group table: atomic loads first (the key is almost always
+// there already), one agent-scope CAS only on an empty entry.  -1 when all GMAX entries are taken.
+__device__ __forceinline__ int global_group_slot(unsigned long long* gkeys, unsigned long long key) {
+#pragma unroll 1
+    for (int j = 0; j < SDQH_MAX_SMALL_GROUPS; ++j) {
+        unsigned long long cur = __hip_atomic_load(&gkeys[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == EMPTY_GROUP) cur = atomicCAS(&gkeys[j], (unsigned long long)EMPTY_GROUP, key);
+        if (cur == EMPTY_GROUP || cur == key) return j;
+    }
+    return -1;
+}
+
+// Workgroup epilogue shared by both group-by kernels: local slot -> global slot, then every one of
+// the GMAX global slots of this workgroup's partial row is written (zeros where it saw no rows).
+template <int G>
+__device__ __forceinline__ void write_group_partials(const unsigned long long* s_keys, const double (*l_acc)[4], const int64_t* l_cnt,
+                                                     unsigned long long* gkeys, double* __restrict__ pacc, int64_t* __restrict__ pcnt,
+                                                     int* s_map, int* s_flags) {
+    constexpr int GMAX = SDQH_MAX_SMALL_GROUPS;
+    if (threadIdx.x < GMAX) s_map[threadIdx.x] = -1;
+    __syncthreads();
+    if (threadIdx.x < G && s_keys[threadIdx.x] != EMPTY_GROUP && l_cnt[threadIdx.x] > 0) {
+        const int gs = global_group_slot(gkeys, s_keys[threadIdx.x]);
+        if (gs < 0) atomicOr(&s_flags[0], 1); else s_map[gs] = threadIdx.x;
+    }
+    __syncthreads();
+    if (threadIdx.x < GMAX) {
+        const int l = s_map[threadIdx.x];
+        const size_t e = (size_t)threadIdx.x * gridDim.x + blockIdx.x;
+        pcnt[e] = l >= 0 ? l_cnt[l] : 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pacc[e * 4 + k] = l >= 0 ? l_acc[l][k] : 0.0;
+    }
 }
 
 template <int SHAPE, int G, class FC, class KC, bool TAIL>
@@ -487,7 +525,7 @@ __device__ __forceinline__ void groupby_reg_tile(const DevFilter& f, const DevTu
 
 template <int SHAPE, int G, class FC, class KC>
 __global__ __launch_bounds__(TPB) void k_groupby_reg(DevFilter f, DevTuple t, DevGroupKeys gk, int64_t nrows,
-                                                     unsigned long long* __restrict__ pkeys, double* __restrict__ pacc,
+                                                     unsigned long long* __restrict__ gkeys, double* __restrict__ pacc,
                                                      int64_t* __restrict__ pcnt, int* __restrict__ flags) {
     constexpr int NV = TupleTraits<SHAPE>::NV;
     __shared__ unsigned long long s_keys[G];
@@ -518,18 +556,23 @@ __global__ __launch_bounds__(TPB) void k_groupby_reg(DevFilter f, DevTuple t, De
         if (lane_id() == 0) s_cnt[w][g] = c;
     }
     __syncthreads();
+    __shared__ double s_tot[G][4];
+    __shared__ int64_t s_totc[G];
+    __shared__ int s_map[SDQH_MAX_SMALL_GROUPS];
     if (threadIdx.x < G) {
         const int g = threadIdx.x;
-        pkeys[(size_t)blockIdx.x * G + g] = s_keys[g];
         int64_t c = 0;
         for (int i = 0; i < TPB / WAVE; ++i) c += s_cnt[i][g];
-        pcnt[(size_t)blockIdx.x * G + g] = c;
+        s_totc[g] = c;
         for (int k = 0; k < 4; ++k) {
             double v = 0.0;
             if (k < NV) for (int i = 0; i < TPB / WAVE; ++i) v += s_acc[i][g][k];
-            pacc[((size_t)blockIdx.x * G + g) * 4 + k] = v;
+            s_tot[g][k] = v;
         }
     }
+    __syncthreads();
+    write_group_partials<G>(s_keys, s_tot, s_totc, gkeys, pacc, pcnt, s_map, s_flags);
+    __syncthreads();
     if (threadIdx.x == 0 && s_flags[0]) atomicOr(flags, s_flags[0]);
 }
 
@@ -567,7 +610,7 @@ __device__ __forceinline__ void groupby_lds_tile(const DevFilter& f, const DevTu
 
 template <int SHAPE>
 __global__ __launch_bounds__(TPB) void k_groupby_lds(DevFilter f, DevTuple t, DevGroupKeys gk, int64_t nrows,
-                                                     unsigned long long* __restrict__ pkeys, double* __restrict__ pacc,
+                                                     unsigned long long* __restrict__ gkeys, double* __restrict__ pacc,
                                                      int64_t* __restrict__ pcnt, int* __restrict__ flags) {
     constexpr int G = SDQH_MAX_SMALL_GROUPS;
     __shared__ unsigned long long s_keys[G];
@@ -583,65 +626,37 @@ __global__ __launch_bounds__(TPB) void k_groupby_lds(DevFilter f, DevTuple t, De
     if (full * TILE_ROWS < nrows && blockIdx.x == (unsigned)(full % gridDim.x))
         groupby_lds_tile<SHAPE, true>(f, t, gk, full * TILE_ROWS, nrows, s_keys, s_acc, s_cnt, s_flags);
     __syncthreads();
-    if (threadIdx.x < G) {
-        const int g = threadIdx.x;
-        pkeys[(size_t)blockIdx.x * G + g] = s_keys[g];
-        pcnt[(size_t)blockIdx.x * G + g] = (int64_t)s_cnt[g];
-        for (int k = 0; k < 4; ++k) pacc[((size_t)blockIdx.x * G + g) * 4 + k] = s_acc[g][k];
-    }
+    __shared__ int64_t s_totc[G];
+    __shared__ int s_map[SDQH_MAX_SMALL_GROUPS];
+    if (threadIdx.x < G) s_totc[threadIdx.x] = (int64_t)s_cnt[threadIdx.x];
+    __syncthreads();
+    write_group_partials<G>(s_keys, s_acc, s_totc, gkeys, pacc, pcnt, s_map, s_flags);
+    __syncthreads();
     if (threadIdx.x == 0 && s_flags[0]) atomicOr(flags, s_flags[0]);
 }
 
-// One workgroup per output group (launch SDQH_MAX_SMALL_GROUPS of them).  Every workgroup collects
-// the distinct keys of all partials in an LDS CAS table and ranks them ascending, so "group g" is
-// the same key in every workgroup and in every run; workgroup g then folds the partials of that
-// key in workgroup order (thread-strided, then an LDS tree).
-__global__ __launch_bounds__(TPB) void k_groupby_merge(const unsigned long long* __restrict__ pkeys, const double* __restrict__ pacc,
-                                                       const int64_t* __restrict__ pcnt, int nparts, int G,
-                                                       unsigned long long* __restrict__ out_keys, double* __restrict__ out_acc,
-                                                       int64_t* __restrict__ out_cnt, int* __restrict__ out_ngroups, int* __restrict__ flags) {
-    constexpr int GMAX = SDQH_MAX_SMALL_GROUPS;
-    __shared__ unsigned long long s_keys[GMAX], s_sorted[GMAX];
+// One workgroup per global group slot: fold that slot's partials over the workgroups in workgroup
+// order (thread-strided, then an LDS tree).  out: acc[g*4+k], cnt[g]; the keys are gkeys[g].
+__global__ __launch_bounds__(TPB) void k_groupby_merge(const unsigned long long* __restrict__ gkeys, const double* __restrict__ pacc,
+                                                       const int64_t* __restrict__ pcnt, int nparts,
+                                                       double* __restrict__ out_acc, int64_t* __restrict__ out_cnt) {
     __shared__ double s_red[5][TPB];
-    __shared__ int s_over, s_ng;
-    if (threadIdx.x < GMAX) { s_keys[threadIdx.x] = EMPTY_GROUP; s_sorted[threadIdx.x] = EMPTY_GROUP; }
-    if (threadIdx.x == 0) { s_over = 0; s_ng = 0; }
-    __syncthreads();
-    const int total = nparts * G;
-    constexpr int MB = 8;                                             // entries per thread fetched before any is claimed
-    for (int e0 = 0; e0 < total; e0 += TPB * MB) {
-        unsigned long long k[MB]; int64_t c[MB];
-#pragma unroll
-        for (int j = 0; j < MB; ++j) { const int e = e0 + j * TPB + threadIdx.x; k[j] = e < total ? pkeys[e] : EMPTY_GROUP; c[j] = e < total ? pcnt[e] : 0; }
-#pragma unroll
-        for (int j = 0; j < MB; ++j) if (c[j] > 0 && lds_claim<GMAX>(s_keys, k[j]) < 0) s_over = 1;
-    }
-    __syncthreads();
-    if (threadIdx.x < GMAX) {
-        const unsigned long long k = s_keys[threadIdx.x];
-        if (k != EMPTY_GROUP) {
-            int rank = 0;
-            for (int j = 0; j < GMAX; ++j) rank += (s_keys[j] < k) ? 1 : 0;     // EMPTY_GROUP is the largest value
-            s_sorted[rank] = k;
-            atomicAdd(&s_ng, 1);
-        }
-    }
-    __syncthreads();
-    const int g = blockIdx.x, ng = s_ng;
-    if (g == 0 && threadIdx.x == 0) { *out_ngroups = ng; if (s_over) atomicOr(flags, 1); }
-    if (g >= ng) return;
-    const unsigned long long key = s_sorted[g];
+    const int g = blockIdx.x;
+    if (gkeys[g] == EMPTY_GROUP) { if (threadIdx.x == 0) out_cnt[g] = 0; return; }
     double a[4] = {0, 0, 0, 0};
     int64_t c = 0;
-    for (int b = threadIdx.x; b < nparts; b += TPB) {
-        for (int sl = 0; sl < G; ++sl) {
-            const size_t e = (size_t)b * G + sl;
-            if (pkeys[e] == key && pcnt[e] > 0) {
+    constexpr int BB = 4;
+    for (int b0 = threadIdx.x; b0 < nparts; b0 += TPB * BB) {
+        double4 v[BB]; int64_t n[BB];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) a[k] += pacc[e * 4 + k];
-                c += pcnt[e];
-            }
+        for (int i = 0; i < BB; ++i) {
+            const int b = b0 + i * TPB;
+            const size_t e = (size_t)g * nparts + (b < nparts ? b : 0);
+            v[i] = *reinterpret_cast<const double4*>(pacc + e * 4);
+            n[i] = b < nparts ? pcnt[e] : 0;
         }
+#pragma unroll
+        for (int i = 0; i < BB; ++i) if (n[i] > 0) { a[0] += v[i].x; a[1] += v[i].y; a[2] += v[i].z; a[3] += v[i].w; c += n[i]; }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) s_red[k][threadIdx.x] = a[k];
@@ -656,7 +671,6 @@ __global__ __launch_bounds__(TPB) void k_groupby_merge(const unsigned long long*
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        out_keys[g] = key;
 #pragma unroll
         for (int k = 0; k < 4; ++k) out_acc[g * 4 + k] = s_red[k][0];
         out_cnt[g] = reinterpret_cast<int64_t*>(s_red[4])[0];
@@ -793,12 +807,11 @@ __device__ __forceinline__ void stage_store(const DevStage& st, int64_t pos, int
     if (st.sacc) { double4 z = {0, 0, 0, 0}; *reinterpret_cast<double4*>(st.sacc + pos * 4) = z; }
     if (st.bm && key >= st.bm_lo && key <= st.bm_hi) {
         const uint64_t off = (uint64_t)(key - st.bm_lo);
-        const uint32_t bit = 1u << (off & 31);
-        if (atomicOr(&st.bm[off >> 5], bit) & bit) st.hdr->has_dups = 1;      // the key was staged before: duplicate build key
+        atomicOr(&st.bm[off >> 5], 1u << (off & 31));     // fire and forget; duplicates show up as distinct < staged (k_rank_blocks)
     }
 }
 
-template <class FC, int NPAY = -1, int SB = STAGE_BATCH, bool EAGER = true>
+template <class FC, int NPAY = -1, int SB = STAGE_BATCH, bool EAGER = true, bool EAGER_PAY = false>
 __global__ __launch_bounds__(TPB) void k_stage(DevFilter f, DevProbes pr, DevStage st, int64_t nrows) {
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
     if (seg >= st.nseg) return;
@@ -816,7 +829,24 @@ __global__ __launch_bounds__(TPB) void k_stage(DevFilter f, DevProbes pr, DevSta
         bool p[SB][2];
 #pragma unroll
         for (int j = 0; j < SB; ++j) r[j] = b + j * BATCH_ROWS + (int64_t)lane * ROWS_PER_LOAD;
-        if (b + BATCH_ROWS * SB <= end) {
+        int64_t kx[SB][2], px[SB][2][MAX_STAGE_COLS];
+        const bool full_step = b + BATCH_ROWS * SB <= end;
+        if (full_step) {
+            if constexpr (EAGER_PAY) {
+                // key + payload streamed with 16-byte loads for every row, survivor or not: when a
+                // tenth or more of the rows survive, most cache lines of these columns are touched
+                // anyway, and sparse 8-byte gathers after the filter cost more than they save
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    Pair<int64_t> kk = load2<false>(st.src_key, r[j], nrows);
+                    kx[j][0] = kk.x; kx[j][1] = kk.y;
+#pragma unroll
+                    for (int c = 0; c < MAX_STAGE_COLS; ++c) if (c < cfg_npay<NPAY>(st.npay)) {
+                        Pair<int64_t> pp = load2<false>(st.src_pay[c], r[j], nrows);
+                        px[j][0][c] = pp.x; px[j][1][c] = pp.y;
+                    }
+                }
+            }
 #pragma unroll
             for (int j = 0; j < SB; ++j) p[j][0] = p[j][1] = true;
             pass_pairs<SB, FC, EAGER>(f, pr, r, nrows, cap_masks, p);
@@ -828,16 +858,17 @@ __global__ __launch_bounds__(TPB) void k_stage(DevFilter f, DevProbes pr, DevSta
                 if (p[j][1]) p[j][1] = row_passes<FC>(f, pr, r[j] + 1, cap_masks);
             }
         }
-        // Gather key + payload of every survivor of all SB batches before the first store: one
-        // memory latency for the whole step, not one per divergent `if (survivor)` region.
-        int64_t kx[SB][2], px[SB][2][MAX_STAGE_COLS];
+        // Otherwise gather key + payload of every survivor of all SB batches before the first
+        // store: one memory latency for the whole step, not one per divergent `if (survivor)` region.
+        if (!(EAGER_PAY && full_step)) {
 #pragma unroll
-        for (int j = 0; j < SB; ++j) {
+            for (int j = 0; j < SB; ++j) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                kx[j][q] = p[j][q] ? st.src_key[r[j] + q] : 0;
+                for (int q = 0; q < 2; ++q) {
+                    kx[j][q] = p[j][q] ? st.src_key[r[j] + q] : 0;
 #pragma unroll
-                for (int c = 0; c < MAX_STAGE_COLS; ++c) px[j][q][c] = (c < cfg_npay<NPAY>(st.npay) && p[j][q]) ? st.src_pay[c][r[j] + q] : 0;
+                    for (int c = 0; c < MAX_STAGE_COLS; ++c) px[j][q][c] = (c < cfg_npay<NPAY>(st.npay) && p[j][q]) ? st.src_pay[c][r[j] + q] : 0;
+                }
             }
         }
 #pragma unroll
@@ -906,16 +937,26 @@ __global__ __launch_bounds__(TPB) void k_rank_words(const uint32_t* __restrict__
     for (int j = 0; j < WPT; ++j) { if (w0 + j < nwords) wprefix[w0 + j] = run; run += __popc(word[j]); }
     if (threadIdx.x == 0) btotal[blockIdx.x] = total;
 }
-// one workgroup: exclusive scan of the block totals, in place; hdr->distinct = number of set bits
-__global__ __launch_bounds__(TPB) void k_rank_blocks(uint32_t* __restrict__ btotal, int nblocks, TableHeader* __restrict__ hdr) {
+// one workgroup: exclusive scan of the block totals, in place.  hdr->distinct = number of set bits,
+// hdr->staged = staged rows; fewer distinct keys than staged rows means duplicate build keys.
+__global__ __launch_bounds__(TPB) void k_rank_blocks(uint32_t* __restrict__ btotal, int nblocks, const uint32_t* __restrict__ seg_count, int nseg,
+                                                     TableHeader* __restrict__ hdr) {
     __shared__ uint32_t s_part[TPB];
+    __shared__ unsigned long long s_staged[TPB];
     const int per = (nblocks + TPB - 1) / TPB;
     const int b0 = threadIdx.x * per, b1 = min(nblocks, b0 + per);
     uint32_t sum = 0;
     for (int b = b0; b < b1; ++b) sum += btotal[b];
     s_part[threadIdx.x] = sum;
+    unsigned long long st = 0;
+    for (int i = threadIdx.x; i < nseg; i += TPB) st += seg_count[i];
+    s_staged[threadIdx.x] = st;
     __syncthreads();
-    if (threadIdx.x == 0) { uint32_t run = 0; for (int i = 0; i < TPB; ++i) { uint32_t v = s_part[i]; s_part[i] = run; run += v; } hdr->distinct = run; }
+    if (threadIdx.x == 0) {
+        uint32_t run = 0; unsigned long long staged = 0;
+        for (int i = 0; i < TPB; ++i) { uint32_t v = s_part[i]; s_part[i] = run; run += v; staged += s_staged[i]; }
+        hdr->distinct = run; hdr->staged = staged; hdr->has_dups = (staged != run) ? 1u : 0u;
+    }
     __syncthreads();
     uint32_t run = s_part[threadIdx.x];
     for (int b = b0; b < b1; ++b) { uint32_t v = btotal[b]; btotal[b] = run; run += v; }
@@ -1106,10 +1147,9 @@ __global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevT
 
 // =================================================================================================
 // K-F: compact the entries with hits >= min_hits.  The entries are the owning stage rows, dense
-// per wave segment, so this reads 4 bytes per entry instead of scanning the slot array.  Each wave
-// walks its segment twice: first to count its survivors (the workgroup then reserves its output
-// range with ONE global atomic), then to write key / payload / accumulators / hits at
-// ballot-prefix positions.
+// per wave segment, so this reads 4 bytes per entry instead of scanning a slot array.  Three small
+// kernels and no global atomics: survivors per segment, exclusive scan of the counts, write at
+// ballot-prefix positions — the output keeps build-row order, so it is the same in every run.
 // =================================================================================================
 struct DevCompactOut {
     int64_t* keys; int64_t* pay[SDQH_MAX_PAYLOAD]; double* val[SDQH_TUPLE_MAX_VALUES]; int64_t* hits;
@@ -1117,46 +1157,106 @@ struct DevCompactOut {
     int32_t npay, nval;
 };
 
-__global__ __launch_bounds__(TPB) void k_compact(DevTable t, DevStage st, DevCompactOut o, uint32_t min_hits) {
-    __shared__ uint32_t s_wave[TPB / WAVE];
-    __shared__ unsigned long long s_base;
-    const int w = threadIdx.x / WAVE, lane = lane_id();
-    const int seg = blockIdx.x * (TPB / WAVE) + w;
-    const uint64_t mask = t.bm ? 0 : t.hdr->cap_mask;
+constexpr int COMPACT_BATCH = 8;                                     // 64-entry groups whose hit counters are fetched together
+
+// one survivor per lane, converged: every load of the copy is in flight before the first store
+__device__ __forceinline__ void compact_copy(const DevStage& st, const DevCompactOut& o, int64_t idx, uint64_t at, uint32_t hits) {
+    int64_t k = 0, pay[SDQH_MAX_PAYLOAD] = {0, 0, 0, 0};
+    double val[SDQH_TUPLE_MAX_VALUES] = {0, 0, 0, 0};
+    if (o.keys) k = st.key[idx];
+#pragma unroll
+    for (int q = 0; q < SDQH_MAX_PAYLOAD; ++q) if (q < o.npay && o.pay[q]) pay[q] = st.pay[q][idx];
+#pragma unroll
+    for (int v = 0; v < SDQH_TUPLE_MAX_VALUES; ++v) if (v < o.nval && o.val[v]) val[v] = st.sacc[(size_t)idx * 4 + v];
+    if (o.keys) o.keys[at] = k;
+#pragma unroll
+    for (int q = 0; q < SDQH_MAX_PAYLOAD; ++q) if (q < o.npay && o.pay[q]) o.pay[q][at] = pay[q];
+#pragma unroll
+    for (int v = 0; v < SDQH_TUPLE_MAX_VALUES; ++v) if (v < o.nval && o.val[v]) o.val[v][at] = val[v];
+    if (o.hits) o.hits[at] = (int64_t)hits;
+}
+
+// Survivors of one wave segment, counted (WRITE = false) or written from out0 on (WRITE = true).
+// When writing, the survivors' stage indices are first queued in LDS (ballot + popcount prefix, in
+// row order) and copied 64 at a time, one per lane — the same converged-drain idea as k_probe_agg.
+constexpr int COMPACT_QCAP = 64 * (COMPACT_BATCH + 1);
+template <bool WRITE>
+__device__ __forceinline__ uint32_t compact_segment(const DevTable& t, const DevStage& st, const DevCompactOut& o, uint32_t min_hits,
+                                                    int seg, uint64_t out0, uint32_t* q_idx, uint32_t* q_hits) {
+    const int lane = lane_id();
+    const bool dups = t.hdr->has_dups != 0;
+    const uint64_t mask = (t.bm || !dups) ? 0 : t.hdr->cap_mask;
     const int64_t base = (int64_t)seg * st.seg_rows;
-    const uint32_t count = seg < st.nseg ? st.seg_count[seg] : 0u;
+    const uint32_t count = st.seg_count[seg];
     const uint64_t lt = lanemask_lt();
     uint32_t mine = 0;
-    for (uint32_t i0 = 0; i0 < count; i0 += WAVE) {
-        const uint32_t i = i0 + lane;
-        const bool keep = i < count && st.shits[base + i] >= min_hits && stage_row_owns(st, t, base + i, mask);
-        mine += (uint32_t)__popcll(__ballot(keep));
-    }
-    if (lane == 0) s_wave[w] = mine;
-    __syncthreads();
-    uint32_t wbase = 0, total = 0;
-    for (int i = 0; i < TPB / WAVE; ++i) { if (i < w) wbase += s_wave[i]; total += s_wave[i]; }
-    if (threadIdx.x == 0) s_base = total ? atomicAdd(o.counter, (unsigned long long)total) : 0ull;
-    __syncthreads();
-    if (mine == 0) return;
-    uint64_t pos = s_base + wbase;
-    for (uint32_t i0 = 0; i0 < count; i0 += WAVE) {
-        const uint32_t i = i0 + lane;
-        const int64_t idx = base + i;
-        const uint32_t hits = i < count ? st.shits[idx] : 0u;
-        const bool keep = i < count && hits >= min_hits && stage_row_owns(st, t, idx, mask);
-        const uint64_t b = __ballot(keep);
-        if (keep) {
-            const uint64_t at = pos + __popcll(b & lt);
-            if (o.keys) o.keys[at] = st.key[idx];
+    int qn = 0;
+    uint64_t written = out0;
+    for (uint32_t i0 = 0; i0 < count; i0 += WAVE * COMPACT_BATCH) {
+        uint32_t h[COMPACT_BATCH];
 #pragma unroll
-            for (int q = 0; q < SDQH_MAX_PAYLOAD; ++q) if (q < o.npay && o.pay[q]) o.pay[q][at] = st.pay[q][idx];
+        for (int j = 0; j < COMPACT_BATCH; ++j) { const uint32_t i = i0 + j * WAVE + lane; h[j] = i < count ? st.shits[base + i] : 0u; }
 #pragma unroll
-            for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) if (k < o.nval && o.val[k]) o.val[k][at] = st.sacc[(size_t)idx * 4 + k];
-            if (o.hits) o.hits[at] = (int64_t)hits;
+        for (int j = 0; j < COMPACT_BATCH; ++j) {
+            const uint32_t i = i0 + j * WAVE + lane;
+            bool keep = i < count && h[j] >= min_hits;
+            if (dups && keep) keep = stage_row_owns(st, t, base + i, mask);
+            const uint64_t b = __ballot(keep);
+            if (WRITE && keep) { const int at = qn + __popcll(b & lt); q_idx[at] = i; q_hits[at] = h[j]; }
+            qn += WRITE ? __popcll(b) : 0;
+            mine += (uint32_t)__popcll(b);
         }
-        pos += __popcll(b);
+        if (WRITE) {
+            int done = 0;
+            while (qn - done >= WAVE) { compact_copy(st, o, base + q_idx[done + lane], written + lane, q_hits[done + lane]); done += WAVE; written += WAVE; }
+            if (done) {                                               // move the leftover (< 64 entries) to the front
+                const int left = qn - done;
+                uint32_t a = 0, c = 0;
+                if (lane < left) { a = q_idx[done + lane]; c = q_hits[done + lane]; }
+                if (lane < left) { q_idx[lane] = a; q_hits[lane] = c; }
+                qn = left;
+            }
+        }
     }
+    if (WRITE && lane < qn) compact_copy(st, o, base + q_idx[lane], written + lane, q_hits[lane]);
+    return mine;
+}
+
+// 1. survivors per segment
+__global__ __launch_bounds__(TPB) void k_compact_count(DevTable t, DevStage st, DevCompactOut o, uint32_t min_hits, uint32_t* __restrict__ seg_kept) {
+    const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
+    if (seg >= st.nseg) return;
+    const uint32_t n = compact_segment<false>(t, st, o, min_hits, seg, 0, nullptr, nullptr);
+    if (lane_id() == 0) seg_kept[seg] = n;
+}
+// 2. one workgroup: exclusive scan of the per-segment counts, in place; total -> *o.counter
+__global__ __launch_bounds__(TPB) void k_compact_scan(uint32_t* __restrict__ seg_kept, int nseg, unsigned long long* __restrict__ counter) {
+    __shared__ unsigned long long s_part[TPB];
+    const int per = (nseg + TPB - 1) / TPB;
+    const int b0 = threadIdx.x * per, b1 = min(nseg, b0 + per);
+    unsigned long long sum = 0;
+    for (int b = b0; b < b1; ++b) sum += seg_kept[b];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over the 256 partial sums
+    for (int off = 1; off < TPB; off <<= 1) {
+        unsigned long long v = (int)threadIdx.x >= off ? s_part[threadIdx.x - off] : 0ull;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (threadIdx.x == TPB - 1) *counter = s_part[TPB - 1];
+    unsigned long long run = s_part[threadIdx.x] - sum;              // exclusive
+    // offsets are kept in 32 bits per segment + a 64-bit base per thread chunk would be needed past
+    // 2^32 result rows; a build side is limited to 2^32-2 rows, so 32 bits are enough
+    for (int b = b0; b < b1; ++b) { const uint32_t v = seg_kept[b]; seg_kept[b] = (uint32_t)run; run += v; }
+}
+// 3. write: output order = stage order = build-row order (deterministic)
+__global__ __launch_bounds__(TPB) void k_compact_write(DevTable t, DevStage st, DevCompactOut o, uint32_t min_hits, const uint32_t* __restrict__ seg_off) {
+    __shared__ uint32_t s_idx[TPB / WAVE][COMPACT_QCAP], s_hits[TPB / WAVE][COMPACT_QCAP];
+    const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
+    if (seg >= st.nseg) return;
+    compact_segment<true>(t, st, o, min_hits, seg, (uint64_t)seg_off[seg], s_idx[threadIdx.x / WAVE], s_hits[threadIdx.x / WAVE]);
 }
 
 // ---- column statistics ---------------------------------------------------------------------------

@@ -68,6 +68,7 @@ class Engine:
         self.ctx = ctx
         self._columns = {}         # id(ndarray) -> (ndarray, abi.Column)
         self.resident_bytes = 0
+        self.generation = 0        # bumped by clear(): prepared plans bound to freed columns are rebuilt
 
     def close(self):
         self.clear()
@@ -78,6 +79,7 @@ class Engine:
             col.free()
         self._columns.clear()
         self.resident_bytes = 0
+        self.generation += 1
 
     def column(self, arr):
         """Resident column for a host array (uploaded on first use, then cached by identity)."""
@@ -120,6 +122,7 @@ class BuiltTable:
         self.val_is_record = val_is_record
         self.payload_dtypes = row_arrays    # payload index -> numpy dtype
         self.agg = None                     # set by a fused probe-aggregate: (key_fields, val_names, tuple shape)
+        self.agg_spec = None
 
 
 # ---- predicate / tuple lowering ----------------------------------------------------------------
@@ -229,22 +232,33 @@ def _value_arrays(names, count_idx, values, counts):
     return out
 
 
-# ---- operator execution ------------------------------------------------------------------------
-def _probe_list(eng, op, htab, env, lookups):
-    probes = []
+# ---- operator preparation -----------------------------------------------------------------------
+# Lowering an operator (predicate ranges, tuple shape, column binding, ctypes structs) does not
+# depend on the data, only on the plan and on which tables it is bound to.  It is done once per
+# (plan, tables) and yields a closure; running a query is then just the sequence of C-ABI calls.
+def _probe_specs(eng, op, htab, lookups):
+    specs = []
     for lk in lookups:
-        if lk.dict_name not in env or not isinstance(env[lk.dict_name], BuiltTable):
-            raise UnsupportedQuery("line %d: '%s' is not a built table" % (op.lineno, lk.dict_name))
         if not isinstance(lk.key, Col):
             raise UnsupportedQuery("line %d: composite / derived lookup keys are not in the HIP backend's vocabulary yet" % op.lineno)
         arr = htab.array(lk.key.name, op)
         if arr.dtype != np.int64:
             raise UnsupportedQuery("line %d: lookup key '%s' must be an int column" % (op.lineno, lk.key.name))
-        probes.append((env[lk.dict_name].table, eng.column(arr)))
+        specs.append((lk.dict_name, eng.column(arr)))
+    return specs
+
+
+def _resolve_probes(op, env, specs):
+    probes = []
+    for name, col in specs:
+        bt = env.get(name)
+        if not isinstance(bt, BuiltTable):
+            raise UnsupportedQuery("line %d: '%s' is not a built table" % (op.lineno, name))
+        probes.append((bt.table, col))
     return probes
 
 
-def _run_scan(eng, op, htab, env, accumulate_into):
+def _prepare_scan(eng, op, htab, accumulate_into):
     ctx = eng.ctx
     flt, lookups = _build_filter(eng, op, htab, op.conds)
     n = htab.nrows
@@ -253,8 +267,11 @@ def _run_scan(eng, op, htab, env, accumulate_into):
         if lookups or op.probe:
             raise UnsupportedQuery("line %d: scalar sums with lookups are not supported yet" % op.lineno)
         tup, _, count_idx = _build_tuple(eng, op, htab, op.val)
-        vals, cnt = ctx.scan_filter_sum(n, flt, tup)
-        return float(cnt) if count_idx is not None else float(vals[0])
+
+        def run_scalar(env):
+            vals, cnt = ctx.scan_filter_sum(n, flt, tup)
+            return float(cnt) if count_idx is not None else float(vals[0])
+        return run_scalar
 
     # ---- dictionary outputs ----
     key_is_record = isinstance(op.key, RecordCons)
@@ -283,9 +300,15 @@ def _run_scan(eng, op, htab, env, accumulate_into):
             val_fields.append((fname, len(payload_cols)))
             payload_cols.append(eng.column(arr))
             payload_dtypes.append(arr.dtype)
-        probes = _probe_list(eng, op, htab, env, ([op.probe] if op.probe else []) + lookups)
-        table = ctx.hash_build_unique(n, flt, probes, eng.column(karr), payload_cols, accumulate=op.out in accumulate_into)
-        return BuiltTable(table, key_fields[0][0] or kname, key_is_record, val_fields, val_is_record, payload_dtypes)
+        specs = _probe_specs(eng, op, htab, ([op.probe] if op.probe else []) + lookups)
+        kcol = eng.column(karr)
+        accumulate = op.out in accumulate_into
+        key_name = key_fields[0][0] or kname
+
+        def run_build(env):
+            table = ctx.hash_build_unique(n, flt, _resolve_probes(op, env, specs), kcol, payload_cols, accumulate=accumulate)
+            return BuiltTable(table, key_name, key_is_record, val_fields, val_is_record, payload_dtypes)
+        return run_build
 
     # ---- aggregations ----
     tup, vnames, count_idx = _build_tuple(eng, op, htab, op.val)
@@ -305,49 +328,61 @@ def _run_scan(eng, op, htab, env, accumulate_into):
             else:
                 raise UnsupportedQuery("line %d: group key '%s' must be a string(1) or int column" % (op.lineno, e.name))
             kcols.append(eng.column(arr))
-        try:
-            keys, vals, cnts = ctx.groupby_small(n, flt, kcols, tup)
-        except abi.SdqhError as exc:
-            if exc.code == abi.ERR_OVERFLOW:
-                raise UnsupportedQuery("line %d: more than %d groups: large-domain group-by on row columns is not in the "
-                                       "HIP backend's vocabulary yet" % (op.lineno, abi.MAX_SMALL_GROUPS))
-            raise
-        kf = []
-        for i, (fname, e) in enumerate(key_fields):
-            col = keys[:, i]
-            kf.append((fname or e.name, col.astype(np.uint32).view("<U1") if decoders[i] == "U1" else col.copy()))
-        vf = _value_arrays(vnames, count_idx, [vals[:, j] for j in range(vals.shape[1])], cnts)
-        return DictResult(kf, vf, key_is_record, val_is_record)
+
+        def run_groupby(env):
+            try:
+                keys, vals, cnts = ctx.groupby_small(n, flt, kcols, tup)
+            except abi.SdqhError as exc:
+                if exc.code == abi.ERR_OVERFLOW:
+                    raise UnsupportedQuery("line %d: more than %d groups: large-domain group-by on row columns is not in the "
+                                           "HIP backend's vocabulary yet" % (op.lineno, abi.MAX_SMALL_GROUPS))
+                raise
+            kf = []
+            for i, (fname, e) in enumerate(key_fields):
+                col = keys[:, i]
+                kf.append((fname or e.name, col.astype(np.uint32).view("<U1") if decoders[i] == "U1" else col.copy()))
+            vf = _value_arrays(vnames, count_idx, [vals[:, j] for j in range(vals.shape[1])], cnts)
+            return DictResult(kf, vf, key_is_record, val_is_record)
+        return run_groupby
 
     # K-C large: the group is the matched entry of the probed table
     if op.probe is None or lookups:
         raise UnsupportedQuery("line %d: aggregations with extra lookups are not supported yet" % op.lineno)
-    bt = env.get(op.probe.dict_name)
-    if not isinstance(bt, BuiltTable) or not isinstance(op.probe.key, Col):
-        raise UnsupportedQuery("line %d: joinProbe index must be a built table probed by a column" % op.lineno)
+    if not isinstance(op.probe.key, Col):
+        raise UnsupportedQuery("line %d: joinProbe index must be probed by a column" % op.lineno)
     pk = op.probe.key.name
-    out_key_fields = []
-    for fname, e in key_fields:
-        if isinstance(e, Col) and e.name == pk:
-            out_key_fields.append((fname or pk, "key"))
-        elif isinstance(e, PayloadField) and e.lookup.dict_name == op.probe.dict_name and repr(e.lookup.key) == repr(op.probe.key):
-            src = dict(bt.val_fields).get(e.field) if e.field is not None else (bt.val_fields[0][1] if bt.val_fields else None)
-            if src is None:
-                raise UnsupportedQuery("line %d: '%s' has no field '%s'" % (op.lineno, op.probe.dict_name, e.field))
-            out_key_fields.append((fname or e.field, src))
-        else:
-            raise UnsupportedQuery("line %d: group keys of a probe-aggregate must be the probe key or fields of the matched "
-                                   "entry (the group must be determined by the probe key)" % op.lineno)
-    if not any(src == "key" for _, src in out_key_fields):
-        raise UnsupportedQuery("line %d: group key does not include the probe key; grouping on payload alone is not supported yet" % op.lineno)
-    if not bt.table.accumulate or bt.agg is not None:
-        raise UnsupportedQuery("line %d: table '%s' cannot take this aggregation" % (op.lineno, op.probe.dict_name))
     karr = htab.array(pk, op)
     if karr.dtype != np.int64:
         raise UnsupportedQuery("line %d: probe key '%s' must be an int column" % (op.lineno, pk))
-    ctx.hash_probe_aggregate(n, flt, bt.table, eng.column(karr), tup)
-    bt.agg = (out_key_fields, vnames, count_idx, key_is_record, val_is_record, tup.shape)
-    return ("aggregated", op.probe.dict_name)
+    kcol = eng.column(karr)
+    probe_name = op.probe.dict_name
+
+    def run_probe_aggregate(env):
+        bt = env.get(probe_name)
+        if not isinstance(bt, BuiltTable):
+            raise UnsupportedQuery("line %d: joinProbe index must be a built table" % op.lineno)
+        if bt.agg_spec is None:                      # resolve the group key against the table's fields once
+            out_key_fields = []
+            for fname, e in key_fields:
+                if isinstance(e, Col) and e.name == pk:
+                    out_key_fields.append((fname or pk, "key"))
+                elif isinstance(e, PayloadField) and e.lookup.dict_name == probe_name and repr(e.lookup.key) == repr(op.probe.key):
+                    src = dict(bt.val_fields).get(e.field) if e.field is not None else (bt.val_fields[0][1] if bt.val_fields else None)
+                    if src is None:
+                        raise UnsupportedQuery("line %d: '%s' has no field '%s'" % (op.lineno, probe_name, e.field))
+                    out_key_fields.append((fname or e.field, src))
+                else:
+                    raise UnsupportedQuery("line %d: group keys of a probe-aggregate must be the probe key or fields of the matched "
+                                           "entry (the group must be determined by the probe key)" % op.lineno)
+            if not any(src == "key" for _, src in out_key_fields):
+                raise UnsupportedQuery("line %d: group key does not include the probe key; grouping on payload alone is not supported yet" % op.lineno)
+            bt.agg_spec = out_key_fields
+        if not bt.table.accumulate or bt.agg is not None:
+            raise UnsupportedQuery("line %d: table '%s' cannot take this aggregation" % (op.lineno, probe_name))
+        ctx.hash_probe_aggregate(n, flt, bt.table, kcol, tup)
+        bt.agg = (bt.agg_spec, vnames, count_idx, key_is_record, val_is_record, tup.shape)
+        return ("aggregated", probe_name)
+    return run_probe_aggregate
 
 
 def _materialize(eng, value, env):
@@ -358,7 +393,7 @@ def _materialize(eng, value, env):
         bt = env[value[1]]
         out_key_fields, vnames, count_idx, key_is_record, val_is_record, shape = bt.agg
         n = eng.ctx.table_compact_count(bt.table, 1)
-        keys, payload, values, hits = eng.ctx.table_compact(bt.table, 1, n)
+        keys, payload, values, hits = eng.ctx.table_compact(bt.table, 1, n, want_hits=count_idx is not None)
         kf = []
         for fname, src in out_key_fields:
             if src == "key":
@@ -390,23 +425,46 @@ def _finalize(eng, op, env):
     return ResultSet([n for n, _ in fields], [a for _, a in fields])
 
 
+class PreparedPlan:
+    """A plan bound to one engine and one set of tables: every operator lowered to a closure."""
+
+    def __init__(self, eng, plan, args):
+        if len(args) != len(plan.params):
+            raise TypeError("%s expects %d tables, got %d" % (plan.name, len(plan.params), len(args)))
+        self.eng, self.plan, self.args = eng, plan, tuple(args)       # keeps the tables (and so their ids) alive
+        self.generation = eng.generation
+        tables = {p: HostTable(p, a) for p, a in zip(plan.params, args)}
+        # tables that a later probe-aggregate folds its group-by into must carry accumulators
+        accumulate_into = {op.probe.dict_name for op in plan.ops
+                           if isinstance(op, ScanOp) and op.kind == "dict" and not op.unique and op.probe is not None}
+        self.steps = []
+        for op in plan.ops:
+            if isinstance(op, ScanOp):
+                self.steps.append((op.out, _prepare_scan(eng, op, tables[op.table], accumulate_into)))
+            elif isinstance(op, FinalizeOp):
+                self.steps.append((op.out, (lambda env, op=op: _finalize(eng, op, env))))
+
+    def run(self):
+        env = {}
+        try:
+            for out, step in self.steps:
+                env[out] = step(env)
+            res = env[self.plan.result]
+            if isinstance(res, (BuiltTable, tuple)):
+                res = _materialize(self.eng, res, env)
+            return res
+        finally:
+            for v in env.values():                           # release device tables of this run
+                if isinstance(v, BuiltTable):
+                    v.table.free()
+
+
 def execute_plan(eng, plan, args):
-    if len(args) != len(plan.params):
-        raise TypeError("%s expects %d tables, got %d" % (plan.name, len(plan.params), len(args)))
-    tables = {p: HostTable(p, a) for p, a in zip(plan.params, args)}
-    # tables that a later probe-aggregate folds its group-by into must carry accumulators
-    accumulate_into = {op.probe.dict_name for op in plan.ops
-                       if isinstance(op, ScanOp) and op.kind == "dict" and not op.unique and op.probe is not None}
-    env = {}
-    for op in plan.ops:
-        if isinstance(op, ScanOp):
-            env[op.out] = _run_scan(eng, op, tables[op.table], env, accumulate_into)
-        elif isinstance(op, FinalizeOp):
-            env[op.out] = _finalize(eng, op, env)
-    res = env[plan.result]
-    if isinstance(res, (BuiltTable, tuple)):
-        res = _materialize(eng, res, env)
-    for v in env.values():                                   # release device tables of this run
-        if isinstance(v, BuiltTable):
-            v.table.free()
-    return res
+    cache = plan.__dict__.setdefault("_prepared", {})
+    key = (id(eng),) + tuple(id(a) for a in args)
+    prepared = cache.get(key)
+    if prepared is None or prepared.generation != eng.generation or any(x is not y for x, y in zip(prepared.args, args)):
+        if len(cache) > 16:
+            cache.clear()
+        prepared = cache[key] = PreparedPlan(eng, plan, args)
+    return prepared.run()

@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--queries", default="q1,q3")
     ap.add_argument("--profile-iters", type=int, default=5, help="extra untimed passes with per-kernel HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="use the distributed plan even with one rank (exercises the RCCL path)")
+    ap.add_argument("--partition", default="auto", choices=["auto", "range", "hash"])
     ap.add_argument("--cpu-sample-sf", type=float, default=0.0, help="0 = pick so the CPU leg takes ~10-30 s")
     return ap.parse_args()
 
@@ -57,6 +59,11 @@ def scanned_rows(q, rows):
 
 def main():
     args = parse()
+    # RCCL prints a version banner on stdout when a communicator is created; the contract is ONE
+    # JSON line on stdout, so everything else (including C-level writes) is sent to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     queries = [q for q in args.queries.split(",") if q]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -67,8 +74,12 @@ def main():
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from sdqlpy_amd import engine, tpch
@@ -85,15 +96,16 @@ def main():
 
     sdqlpy_init(3, 1, device=local_rank)
     eng = engine.default_engine(device=local_rank)
-    if world > 1:
+    runner = None
+    if use_dist:
         from sdqlpy_amd import dist as sdist
-        runner = sdist.DistributedRunner(eng, rank, world)
+        runner = sdist.DistributedRunner(eng, rank, world, partition=args.partition)
         run_query = lambda q: runner.run(q, db)           # noqa: E731
     else:
         run_query = lambda q: Q.run(q, db)                # noqa: E731
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         eng.ctx.synchronize()
         torch.cuda.synchronize()
@@ -174,7 +186,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "TPCH " + "+".join(q.upper() for q in queries) + " SF=%g per GPU (q1 = BASELINE configs[1], q3 = configs[2])" % args.sf,
-                       "sf_per_gpu": args.sf, "rows_per_gpu": rows, "partitioning": "none" if world == 1 else "q1 row-sharded; q3 partitioned on o_orderkey, RCCL all-to-all"},
+                       "sf_per_gpu": args.sf, "rows_per_gpu": rows, "partitioning": "none" if not use_dist else "q1 row-sharded; q3 partitioned on o_orderkey (%s), RCCL all-to-all; exchanged rows %s"
+                                       % (runner.last_partitioning, runner.exchanged_rows)},
             "ms_per_query": per_query,
             "kernels": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in sorted(kernels.items())},
             "roofline": roofline,
@@ -182,8 +195,8 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, queries, db, rows)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     return out

@@ -219,13 +219,23 @@ int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits,
 int sdqh_scan_compact(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter,
                       int nprobes, const sdqh_probe* probes,
                       int ncols, const sdqh_column* const* cols, sdqh_column** out_cols, int64_t* out_rows);
-/* Reorder rows so that all rows with part(key) == p are contiguous, p ascending, where
- * part(key) = mix64(key) % nparts (the same function in both builds).  counts[nparts] on host. */
-int sdqh_partition_by_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int nparts,
+/* Reorder rows so that all rows with part(key) == p are contiguous, p ascending (row order inside a
+ * part unspecified, identical across the ncols outputs).  range_upper == NULL: part(key) =
+ * mix64(key) % nparts (the same function in both builds).  Otherwise range_upper[nparts-1] holds
+ * ascending inclusive upper bounds and part(key) = number of bounds below key (keys above the
+ * last bound go to the last part).  counts[nparts] on host.  nparts <= 64. */
+#define SDQH_MAX_PARTS 64
+int sdqh_partition_by_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int nparts, const int64_t* range_upper,
                           int ncols, const sdqh_column* const* cols, sdqh_column** out_cols,
                           int64_t* counts);
-/* Exact key bitmap of a table over [lo, hi] (bit i = key lo+i present), as device words; used to
- * pre-filter probe rows before they are exchanged.  words = ceil((hi-lo+1)/32). */
+/* Device-to-device (CPU build: memcpy) copy of rows [row0, row0+nrows) of an I64/F64 column to or
+ * from caller-owned memory of the same kind (e.g. a torch tensor used as a collective buffer).
+ * Returns after the copy has completed. */
+int sdqh_column_copy_out(sdqh_ctx* ctx, const sdqh_column* col, int64_t row0, int64_t nrows, void* dst);
+int sdqh_column_copy_in(sdqh_ctx* ctx, sdqh_column* col, int64_t row0, int64_t nrows, const void* src);
+/* Exact key bitmap of a table over [lo, hi] (bit i = key lo+i present), as device words.  If
+ * *out_words is NULL on entry a column of ceil(bits/64) I64 rows is allocated; otherwise the given
+ * I64 column (at least that long, e.g. a wrapped collective buffer) is cleared and filled. */
 int sdqh_table_export_bitmap(sdqh_ctx* ctx, const sdqh_table* table, int64_t lo, int64_t hi, sdqh_column** out_words);
 /* Build a key-only membership table from a bitmap (device I64 column viewed as 32-bit words). */
 int sdqh_table_from_bitmap(sdqh_ctx* ctx, const sdqh_column* words, int64_t lo, int64_t hi, sdqh_table** out);

@@ -571,18 +571,25 @@ int sdqh_scan_compact(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, i
     return SDQH_OK;
 }
 
-int sdqh_partition_by_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int nparts, int ncols,
+static inline int part_of(int64_t k, int nparts, const int64_t* range_upper) {
+    if (!range_upper) return (int)(mix64((uint64_t)k) % (uint64_t)nparts);
+    int p = 0;
+    while (p < nparts - 1 && k > range_upper[p]) ++p;
+    return p;
+}
+
+int sdqh_partition_by_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int nparts, const int64_t* range_upper, int ncols,
                           const sdqh_column* const* cols, sdqh_column** out_cols, int64_t* counts) {
-    if (!ctx || nrows < 0 || nparts < 1 || ncols < 1 || ncols > SDQH_MAX_COMPACT_COLS || !cols || !out_cols || !counts)
+    if (!ctx || nrows < 0 || nparts < 1 || nparts > SDQH_MAX_PARTS || ncols < 1 || ncols > SDQH_MAX_COMPACT_COLS || !cols || !out_cols || !counts)
         return fail(ctx, SDQH_ERR_INVALID, "partition_by_key: bad arguments");
     if (int rc = check_col(ctx, key, SDQH_I64, nrows, "partition key")) return rc;
     Timer tm;
     const int64_t* kc = (const int64_t*)key->data;
     std::vector<int64_t> start((size_t)nparts + 1, 0);
-    for (int64_t r = 0; r < nrows; ++r) start[(size_t)(mix64((uint64_t)kc[r]) % (uint64_t)nparts) + 1]++;
+    for (int64_t r = 0; r < nrows; ++r) start[(size_t)part_of(kc[r], nparts, range_upper) + 1]++;
     for (int p = 0; p < nparts; ++p) { counts[p] = start[(size_t)p + 1]; start[(size_t)p + 1] += start[(size_t)p]; }
     std::vector<int64_t> dest((size_t)nrows), cur(start.begin(), start.end() - 1);
-    for (int64_t r = 0; r < nrows; ++r) dest[(size_t)r] = cur[(size_t)(mix64((uint64_t)kc[r]) % (uint64_t)nparts)]++;
+    for (int64_t r = 0; r < nrows; ++r) dest[(size_t)r] = cur[(size_t)part_of(kc[r], nparts, range_upper)]++;
     for (int c = 0; c < ncols; ++c) {
         if (!cols[c] || cols[c]->nrows < nrows || cols[c]->dtype == SDQH_STR) return fail(ctx, SDQH_ERR_INVALID, "partition_by_key: columns must be I64/F64");
         if (int rc = sdqh_column_alloc(ctx, nrows, cols[c]->dtype, 0, &out_cols[c])) return rc;
@@ -593,11 +600,24 @@ int sdqh_partition_by_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, 
     return SDQH_OK;
 }
 
+int sdqh_column_copy_out(sdqh_ctx* ctx, const sdqh_column* col, int64_t row0, int64_t nrows, void* dst) {
+    if (!ctx || !col || col->dtype == SDQH_STR || row0 < 0 || nrows < 0 || row0 + nrows > col->nrows || (nrows && !dst)) return fail(ctx, SDQH_ERR_INVALID, "column_copy_out: bad arguments");
+    std::memcpy(dst, (const char*)col->data + (size_t)row0 * 8, (size_t)nrows * 8);
+    return SDQH_OK;
+}
+int sdqh_column_copy_in(sdqh_ctx* ctx, sdqh_column* col, int64_t row0, int64_t nrows, const void* src) {
+    if (!ctx || !col || col->dtype == SDQH_STR || row0 < 0 || nrows < 0 || row0 + nrows > col->nrows || (nrows && !src)) return fail(ctx, SDQH_ERR_INVALID, "column_copy_in: bad arguments");
+    std::memcpy((char*)col->data + (size_t)row0 * 8, src, (size_t)nrows * 8);
+    col->have_minmax = false;
+    return SDQH_OK;
+}
+
 int sdqh_table_export_bitmap(sdqh_ctx* ctx, const sdqh_table* table, int64_t lo, int64_t hi, sdqh_column** out_words) {
     if (!ctx || !table || !out_words || hi < lo) return fail(ctx, SDQH_ERR_INVALID, "table_export_bitmap: bad arguments");
     uint64_t bits = (uint64_t)(hi - lo) + 1;
     int64_t words32 = (int64_t)((bits + 31) / 32), words64 = (words32 + 1) / 2;
-    if (int rc = sdqh_column_alloc(ctx, words64, SDQH_I64, 0, out_words)) return rc;
+    if (*out_words) { if ((*out_words)->dtype != SDQH_I64 || (*out_words)->nrows < words64) return fail(ctx, SDQH_ERR_INVALID, "table_export_bitmap: destination column too short"); std::memset((*out_words)->data, 0, (size_t)words64 * 8); }
+    else if (int rc = sdqh_column_alloc(ctx, words64, SDQH_I64, 0, out_words)) return rc;
     uint32_t* w = (uint32_t*)(*out_words)->data;
     auto set = [&](int64_t k) { if (k >= lo && k <= hi) { uint64_t off = (uint64_t)(k - lo); w[off >> 5] |= 1u << (off & 31); } };
     if (table->bitmap_only) { for (int64_t k = table->bm_lo; k <= table->bm_hi; ++k) if (table->contains(k)) set(k); }

@@ -61,7 +61,7 @@ EXPORTS = [
     "sdqh_column_rows", "sdqh_column_dtype", "sdqh_column_width", "sdqh_column_minmax", "sdqh_column_free",
     "sdqh_scan_filter_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_table_size", "sdqh_table_free",
     "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_scan_compact", "sdqh_partition_by_key",
-    "sdqh_table_export_bitmap", "sdqh_table_from_bitmap",
+    "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in",
 ]
 
 
@@ -338,17 +338,31 @@ class Context:
                                                C.c_int(len(cols)), carr, outs, C.byref(n)))
         return [Column(self, C.c_void_p(outs[i]), n.value, cols[i].dtype, 0) for i in range(len(cols))], n.value
 
-    def partition_by_key(self, nrows, key, nparts, cols):
+    def partition_by_key(self, nrows, key, nparts, cols, range_upper=None):
         carr = (C.c_void_p * len(cols))(*[c.handle for c in cols])
         outs = (C.c_void_p * len(cols))()
         counts = np.zeros(nparts, np.int64)
-        self._check(self.lib.sdqh_partition_by_key(self.handle, C.c_int64(nrows), key.handle, C.c_int(nparts), C.c_int(len(cols)),
+        ru = None
+        if range_upper is not None:
+            ru = np.ascontiguousarray(range_upper, np.int64)
+            assert len(ru) == nparts - 1
+        self._check(self.lib.sdqh_partition_by_key(self.handle, C.c_int64(nrows), key.handle, C.c_int(nparts), _np_ptr(ru), C.c_int(len(cols)),
                                                    carr, outs, _np_ptr(counts)))
         return [Column(self, C.c_void_p(outs[i]), nrows, cols[i].dtype, 0) for i in range(len(cols))], counts
 
-    def table_export_bitmap(self, table, lo, hi):
-        h = C.c_void_p()
+    def copy_out(self, col, row0, nrows, dst_ptr):
+        self._check(self.lib.sdqh_column_copy_out(self.handle, col.handle, C.c_int64(row0), C.c_int64(nrows), C.c_void_p(dst_ptr)))
+
+    def copy_in(self, col, row0, nrows, src_ptr):
+        self._check(self.lib.sdqh_column_copy_in(self.handle, col.handle, C.c_int64(row0), C.c_int64(nrows), C.c_void_p(src_ptr)))
+
+    def table_export_bitmap(self, table, lo, hi, into=None):
+        """Exact key bitmap of `table` over [lo, hi].  `into`: an I64 Column of at least
+        ceil(bits/64) rows to fill (e.g. a wrapped collective buffer); otherwise a new column."""
+        h = C.c_void_p(into.handle.value if into is not None else None)
         self._check(self.lib.sdqh_table_export_bitmap(self.handle, table.handle, C.c_int64(lo), C.c_int64(hi), C.byref(h)))
+        if into is not None:
+            return into
         words32 = ((hi - lo + 1) + 31) // 32
         return Column(self, h, (words32 + 1) // 2, I64, 0)
 
@@ -410,7 +424,9 @@ class Library:
                                          C.c_void_p, C.c_void_p]
         L.sdqh_scan_compact.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_void_p]
-        L.sdqh_partition_by_key.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sdqh_partition_by_key.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sdqh_column_copy_out.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.sdqh_column_copy_in.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.sdqh_table_export_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.sdqh_table_from_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         if L.sdqh_abi_version() != 1:

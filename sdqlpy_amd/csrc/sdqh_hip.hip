@@ -901,17 +901,129 @@ int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_hits
 }
 
 // ---- multi-GPU helpers -------------------------------------------------------------------------
-int sdqh_scan_compact(sdqh_ctx* ctx, int64_t, const sdqh_filter*, int, const sdqh_probe*, int, const sdqh_column* const*, sdqh_column**, int64_t*) {
-    return fail(ctx, SDQH_ERR_UNSUPPORTED, "scan_compact: not implemented in this build");
+int sdqh_scan_compact(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nprobes, const sdqh_probe* probes,
+                      int ncols, const sdqh_column* const* cols, sdqh_column** out_cols, int64_t* out_rows) {
+    if (!ctx || nrows < 0 || ncols < 1 || ncols > SDQH_MAX_COMPACT_COLS || !cols || !out_cols || !out_rows)
+        return fail(ctx, SDQH_ERR_INVALID, "scan_compact: bad arguments");
+    (void)hipSetDevice(ctx->device);
+    DevFilter f; DevProbes pr;
+    if (int rc = make_filter(ctx, nrows, filter, nullptr, &f)) return rc;
+    if (int rc = make_probes(ctx, nrows, nprobes, probes, &pr)) return rc;
+    for (int c = 0; c < ncols; ++c) if (!cols[c] || cols[c]->nrows < nrows || cols[c]->dtype == SDQH_STR) return fail(ctx, SDQH_ERR_INVALID, "scan_compact: columns must be I64/F64 and cover nrows");
+    // a throw-away stage: column 0 plays the key, the others the payload
+    sdqh_table tmp;
+    int rc = setup_stage(ctx, &tmp, nrows, cols[0], ncols - 1, cols + 1);
+    uint64_t* seg_off = nullptr; unsigned long long* total = nullptr;
+    sdqh_column* outs[SDQH_MAX_COMPACT_COLS] = {nullptr};
+    if (!rc) {
+        seg_off = static_cast<uint64_t*>(table_alloc(ctx, &tmp, (size_t)tmp.stage.nseg * 8 + 64));
+        total = static_cast<unsigned long long*>(table_alloc(ctx, &tmp, 64));
+        if (!seg_off || !total) rc = fail(ctx, SDQH_ERR_NOMEM, "scan_compact: out of device memory");
+    }
+    DevGather g; std::memset(&g, 0, sizeof(g)); g.ncols = ncols;
+    for (int c = 0; c < ncols && !rc; ++c) {
+        rc = sdqh_column_alloc(ctx, nrows, cols[c]->dtype, 0, &outs[c]);
+        if (!rc) g.out[c] = static_cast<int64_t*>(outs[c]->data);
+    }
+    if (!rc) {
+        const unsigned seg_grid = (unsigned)((tmp.stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
+        call_begin(ctx);
+        with_stage_filter(f, nprobes, [&](auto FC) { auto kern = k_stage<decltype(FC), -1>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tmp.stage, nrows); return SDQH_OK; });
+        LAUNCH(ctx, "k_seg_scan", k_seg_scan, 1, tmp.stage.seg_count, tmp.stage.nseg, seg_off, total);
+        LAUNCH(ctx, "k_gather_segments", k_gather_segments, seg_grid, tmp.stage, seg_off, g);
+        call_end(ctx);
+        hipError_t e = hipMemcpyAsync(ctx->result_host, total, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e));
+        if (!rc) rc = sync_stream(ctx);
+    }
+    table_release(ctx, &tmp);
+    if (rc) { for (int c = 0; c < ncols; ++c) if (outs[c]) sdqh_column_free(ctx, outs[c]); return rc; }
+    const int64_t n = (int64_t)*static_cast<const unsigned long long*>(ctx->result_host);
+    for (int c = 0; c < ncols; ++c) { outs[c]->nrows = n; out_cols[c] = outs[c]; }
+    *out_rows = n;
+    return SDQH_OK;
 }
-int sdqh_partition_by_key(sdqh_ctx* ctx, int64_t, const sdqh_column*, int, int, const sdqh_column* const*, sdqh_column**, int64_t*) {
-    return fail(ctx, SDQH_ERR_UNSUPPORTED, "partition_by_key: not implemented in this build");
+
+int sdqh_partition_by_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int nparts, const int64_t* range_upper, int ncols,
+                          const sdqh_column* const* cols, sdqh_column** out_cols, int64_t* counts) {
+    if (!ctx || nrows < 0 || nparts < 1 || nparts > SDQH_MAX_PARTS || ncols < 1 || ncols > SDQH_MAX_COMPACT_COLS || !cols || !out_cols || !counts)
+        return fail(ctx, SDQH_ERR_INVALID, "partition_by_key: bad arguments");
+    (void)hipSetDevice(ctx->device);
+    if (int rc = check_col(ctx, key, SDQH_I64, nrows, "partition key")) return rc;
+    DevPartition pt; std::memset(&pt, 0, sizeof(pt)); pt.nparts = nparts; pt.by_range = range_upper ? 1 : 0;
+    if (range_upper) for (int p = 0; p < nparts - 1; ++p) pt.upper[p] = range_upper[p];
+    DevGather src, dst; std::memset(&src, 0, sizeof(src)); std::memset(&dst, 0, sizeof(dst)); src.ncols = dst.ncols = ncols;
+    sdqh_column* outs[SDQH_MAX_COMPACT_COLS] = {nullptr};
+    int rc = SDQH_OK;
+    for (int c = 0; c < ncols && !rc; ++c) {
+        if (!cols[c] || cols[c]->nrows < nrows || cols[c]->dtype == SDQH_STR) { rc = fail(ctx, SDQH_ERR_INVALID, "partition_by_key: columns must be I64/F64"); break; }
+        rc = sdqh_column_alloc(ctx, nrows, cols[c]->dtype, 0, &outs[c]);
+        if (!rc) { src.out[c] = static_cast<int64_t*>(cols[c]->data); dst.out[c] = static_cast<int64_t*>(outs[c]->data); }
+    }
+    unsigned long long* dcounts = static_cast<unsigned long long*>(pool_alloc(ctx, 2 * SDQH_MAX_PARTS * 8));
+    if (!rc && !dcounts) rc = fail(ctx, SDQH_ERR_NOMEM, "partition_by_key: out of device memory");
+    if (!rc) {
+        unsigned long long* cursor = dcounts + SDQH_MAX_PARTS;
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + TPB - 1) / TPB, (int64_t)ctx->num_cu * 4));
+        const int64_t* kc = static_cast<const int64_t*>(key->data);
+        call_begin(ctx);
+        hipError_t e = hipMemsetAsync(dcounts, 0, 2 * SDQH_MAX_PARTS * 8, ctx->stream);
+        if (e != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e));
+        LAUNCH(ctx, "k_part_count", k_part_count, grid, kc, nrows, pt, dcounts);
+        { KernelScope ks(ctx, "k_part_offsets"); hipLaunchKernelGGL(k_part_offsets, dim3(1), dim3(64), 0, ctx->stream, dcounts, nparts, cursor); }
+        LAUNCH(ctx, "k_part_scatter", k_part_scatter, grid, kc, nrows, pt, cursor, src, dst);
+        call_end(ctx);
+        e = hipMemcpyAsync(ctx->result_host, dcounts, (size_t)nparts * 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e));
+        if (!rc) rc = sync_stream(ctx);
+    }
+    pool_free(ctx, dcounts);
+    if (rc) { for (int c = 0; c < ncols; ++c) if (outs[c]) sdqh_column_free(ctx, outs[c]); return rc; }
+    for (int p = 0; p < nparts; ++p) counts[p] = (int64_t)static_cast<const unsigned long long*>(ctx->result_host)[p];
+    for (int c = 0; c < ncols; ++c) out_cols[c] = outs[c];
+    return SDQH_OK;
 }
-int sdqh_table_export_bitmap(sdqh_ctx* ctx, const sdqh_table*, int64_t, int64_t, sdqh_column**) {
-    return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_export_bitmap: not implemented in this build");
+
+int sdqh_column_copy_out(sdqh_ctx* ctx, const sdqh_column* col, int64_t row0, int64_t nrows, void* dst) {
+    if (!ctx || !col || col->dtype == SDQH_STR || row0 < 0 || nrows < 0 || row0 + nrows > col->nrows || (nrows && !dst)) return fail(ctx, SDQH_ERR_INVALID, "column_copy_out: bad arguments");
+    if (nrows == 0) return SDQH_OK;
+    (void)hipSetDevice(ctx->device);
+    HIP_TRY(ctx, hipMemcpyAsync(dst, static_cast<const char*>(col->data) + (size_t)row0 * 8, (size_t)nrows * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    return sync_stream(ctx);
 }
-int sdqh_table_from_bitmap(sdqh_ctx* ctx, const sdqh_column*, int64_t, int64_t, sdqh_table**) {
-    return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_from_bitmap: not implemented in this build");
+int sdqh_column_copy_in(sdqh_ctx* ctx, sdqh_column* col, int64_t row0, int64_t nrows, const void* src) {
+    if (!ctx || !col || col->dtype == SDQH_STR || row0 < 0 || nrows < 0 || row0 + nrows > col->nrows || (nrows && !src)) return fail(ctx, SDQH_ERR_INVALID, "column_copy_in: bad arguments");
+    if (nrows == 0) return SDQH_OK;
+    (void)hipSetDevice(ctx->device);
+    HIP_TRY(ctx, hipMemcpyAsync(static_cast<char*>(col->data) + (size_t)row0 * 8, src, (size_t)nrows * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    col->have_minmax = false; col->minmax_pending = false;
+    return sync_stream(ctx);
+}
+
+int sdqh_table_export_bitmap(sdqh_ctx* ctx, const sdqh_table* table, int64_t lo, int64_t hi, sdqh_column** out_words) {
+    if (!ctx || !table || !out_words || hi < lo || table->bitmap_only) return fail(ctx, SDQH_ERR_INVALID, "table_export_bitmap: bad arguments");
+    (void)hipSetDevice(ctx->device);
+    const uint64_t bits = (uint64_t)(hi - lo) + 1;
+    if (bits > (1ull << 34)) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_export_bitmap: key range too wide");
+    const int64_t words32 = (int64_t)((bits + 31) / 32), words64 = (words32 + 1) / 2;
+    if (*out_words) { if ((*out_words)->dtype != SDQH_I64 || (*out_words)->nrows < words64) return fail(ctx, SDQH_ERR_INVALID, "table_export_bitmap: destination column too short"); }
+    else if (int rc = sdqh_column_alloc(ctx, words64, SDQH_I64, 0, out_words)) return rc;
+    HIP_TRY(ctx, hipMemsetAsync((*out_words)->data, 0, (size_t)words64 * 8, ctx->stream));
+    LAUNCH(ctx, "k_export_bitmap", k_export_bitmap, (unsigned)((table->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE)), table->stage, lo, hi, static_cast<uint32_t*>((*out_words)->data));
+    return sync_stream(ctx);
+}
+
+int sdqh_table_from_bitmap(sdqh_ctx* ctx, const sdqh_column* words, int64_t lo, int64_t hi, sdqh_table** out) {
+    if (!ctx || !words || !out || hi < lo || words->dtype != SDQH_I64) return fail(ctx, SDQH_ERR_INVALID, "table_from_bitmap: bad arguments");
+    const uint64_t bits = (uint64_t)(hi - lo) + 1;
+    if ((uint64_t)words->nrows * 64 < bits) return fail(ctx, SDQH_ERR_INVALID, "table_from_bitmap: bitmap too short");
+    sdqh_table* tb = new sdqh_table();
+    tb->bitmap_only = true; tb->index_built = true;
+    tb->dev.bm = static_cast<const uint32_t*>(words->data); tb->dev.bm_lo = lo; tb->dev.bm_hi = hi; tb->dev.bitmap_only = 1;
+    tb->bm = static_cast<uint32_t*>(words->data);          // borrowed: the caller keeps `words` alive
+    tb->nwords = (bits + 31) / 32;
+    *out = tb;
+    return SDQH_OK;
 }
 
 }  // extern "C"

@@ -1259,8 +1259,113 @@ __global__ __launch_bounds__(TPB) void k_compact_write(DevTable t, DevStage st, 
     compact_segment<true>(t, st, o, min_hits, seg, (uint64_t)seg_off[seg], s_idx[threadIdx.x / WAVE], s_hits[threadIdx.x / WAVE]);
 }
 
+// =================================================================================================
+// Redistribution helpers for the multi-GPU join (no reference counterpart).
+// =================================================================================================
+// exclusive scan of the per-segment counts into seg_off (separate array), total -> *total
+__global__ __launch_bounds__(TPB) void k_seg_scan(const uint32_t* __restrict__ seg_count, int nseg, uint64_t* __restrict__ seg_off,
+                                                  unsigned long long* __restrict__ total) {
+    __shared__ unsigned long long s_part[TPB];
+    const int per = (nseg + TPB - 1) / TPB;
+    const int b0 = threadIdx.x * per, b1 = min(nseg, b0 + per);
+    unsigned long long sum = 0;
+    for (int b = b0; b < b1; ++b) sum += seg_count[b];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < TPB; off <<= 1) {
+        unsigned long long v = (int)threadIdx.x >= off ? s_part[threadIdx.x - off] : 0ull;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (threadIdx.x == TPB - 1) *total = s_part[TPB - 1];
+    unsigned long long run = s_part[threadIdx.x] - sum;
+    for (int b = b0; b < b1; ++b) { seg_off[b] = run; run += seg_count[b]; }
+}
+// dense output columns from the segmented stage: wave per segment, coalesced copies
+struct DevGather { int64_t* out[SDQH_MAX_COMPACT_COLS]; int32_t ncols, _pad; };
+__global__ __launch_bounds__(TPB) void k_gather_segments(DevStage st, const uint64_t* __restrict__ seg_off, DevGather g) {
+    const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
+    if (seg >= st.nseg) return;
+    const int64_t base = (int64_t)seg * st.seg_rows;
+    const uint32_t count = st.seg_count[seg];
+    const uint64_t off = seg_off[seg];
+    for (uint32_t i = lane_id(); i < count; i += WAVE) {
+        g.out[0][off + i] = st.key[base + i];
+#pragma unroll
+        for (int c = 1; c < SDQH_MAX_COMPACT_COLS; ++c) if (c < g.ncols) g.out[c][off + i] = st.pay[c - 1][base + i];
+    }
+}
+
+// partition function shared with the CPU build: mix64(key) % nparts, or range lookup
+struct DevPartition { int64_t upper[SDQH_MAX_PARTS]; int32_t nparts, by_range; };
+__device__ __forceinline__ int part_of(const DevPartition& pt, int64_t key) {
+    if (!pt.by_range) return (int)(mix64((uint64_t)key) % (uint64_t)pt.nparts);
+    int p = 0;
+    while (p < pt.nparts - 1 && key > pt.upper[p]) ++p;
+    return p;
+}
+__global__ __launch_bounds__(TPB) void k_part_count(const int64_t* __restrict__ key, int64_t nrows, DevPartition pt, unsigned long long* __restrict__ counts) {
+    __shared__ unsigned int s_hist[SDQH_MAX_PARTS];
+    if (threadIdx.x < SDQH_MAX_PARTS) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * TPB) atomicAdd(&s_hist[part_of(pt, key[r])], 1u);
+    __syncthreads();
+    if ((int)threadIdx.x < pt.nparts && s_hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
+}
+// counts -> exclusive offsets (cursor), one thread
+__global__ void k_part_offsets(const unsigned long long* __restrict__ counts, int nparts, unsigned long long* __restrict__ cursor) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { unsigned long long run = 0; for (int p = 0; p < nparts; ++p) { cursor[p] = run; run += counts[p]; } }
+}
+// scatter: a workgroup takes 2048 rows at a time, ranks them inside their part with LDS atomics,
+// reserves the part's output range with ONE global atomic per part, then writes
+constexpr int PART_ROWS_PER_THREAD = 8;
+__global__ __launch_bounds__(TPB) void k_part_scatter(const int64_t* __restrict__ key, int64_t nrows, DevPartition pt,
+                                                      unsigned long long* __restrict__ cursor, DevGather src, DevGather dst) {
+    __shared__ unsigned int s_hist[SDQH_MAX_PARTS];
+    __shared__ unsigned long long s_base[SDQH_MAX_PARTS];
+    constexpr int64_t CHUNK = (int64_t)TPB * PART_ROWS_PER_THREAD;
+    for (int64_t c0 = (int64_t)blockIdx.x * CHUNK; c0 < nrows; c0 += (int64_t)gridDim.x * CHUNK) {
+        if (threadIdx.x < SDQH_MAX_PARTS) s_hist[threadIdx.x] = 0;
+        __syncthreads();
+        int part[PART_ROWS_PER_THREAD]; unsigned int local[PART_ROWS_PER_THREAD];
+#pragma unroll
+        for (int j = 0; j < PART_ROWS_PER_THREAD; ++j) {
+            const int64_t r = c0 + (int64_t)j * TPB + threadIdx.x;
+            part[j] = r < nrows ? part_of(pt, key[r]) : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < PART_ROWS_PER_THREAD; ++j) local[j] = part[j] >= 0 ? atomicAdd(&s_hist[part[j]], 1u) : 0u;
+        __syncthreads();
+        if ((int)threadIdx.x < pt.nparts) s_base[threadIdx.x] = s_hist[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]) : 0ull;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PART_ROWS_PER_THREAD; ++j) {
+            if (part[j] < 0) continue;
+            const int64_t r = c0 + (int64_t)j * TPB + threadIdx.x;
+            const uint64_t at = s_base[part[j]] + local[j];
+#pragma unroll
+            for (int c = 0; c < SDQH_MAX_COMPACT_COLS; ++c) if (c < src.ncols) dst.out[c][at] = src.out[c][r];
+        }
+        __syncthreads();
+    }
+}
+
+// exact bitmap of a table's keys over [lo, hi] from its stage rows
+__global__ __launch_bounds__(TPB) void k_export_bitmap(DevStage st, int64_t lo, int64_t hi, uint32_t* __restrict__ words) {
+    const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
+    if (seg >= st.nseg) return;
+    const int64_t base = (int64_t)seg * st.seg_rows;
+    const uint32_t count = st.seg_count[seg];
+    for (uint32_t i = lane_id(); i < count; i += WAVE) {
+        const int64_t k = st.key[base + i];
+        if (k >= lo && k <= hi) { const uint64_t off = (uint64_t)(k - lo); atomicOr(&words[off >> 5], 1u << (off & 31)); }
+    }
+}
+
 // ---- column statistics ---------------------------------------------------------------------------
 __global__ __launch_bounds__(TPB) void k_minmax(const int64_t* __restrict__ col, int64_t nrows, long long* __restrict__ out /*[2]*/) {
+    __shared__ long long s_lo[TPB / WAVE], s_hi[TPB / WAVE];
     long long lo = INT64_MAX, hi = INT64_MIN;
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nrows; i += (int64_t)gridDim.x * TPB) {
         long long v = col[i]; lo = v < lo ? v : lo; hi = v > hi ? v : hi;
@@ -1270,7 +1375,12 @@ __global__ __launch_bounds__(TPB) void k_minmax(const int64_t* __restrict__ col,
         long long l2 = __shfl_down(lo, off, WAVE), h2 = __shfl_down(hi, off, WAVE);
         lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
     }
-    if (lane_id() == 0) { atomicMin(&out[0], lo); atomicMax(&out[1], hi); }
+    if (lane_id() == 0) { s_lo[threadIdx.x / WAVE] = lo; s_hi[threadIdx.x / WAVE] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {                                           // one atomic pair per workgroup
+        for (int i = 1; i < TPB / WAVE; ++i) { lo = s_lo[i] < lo ? s_lo[i] : lo; hi = s_hi[i] > hi ? s_hi[i] : hi; }
+        atomicMin(&out[0], lo); atomicMax(&out[1], hi);
+    }
 }
 
 }  // namespace sdqh

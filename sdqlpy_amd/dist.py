@@ -1,0 +1,433 @@
+"""Multi-GPU execution of the hot-path queries: one process per GPU, torch.distributed over RCCL.
+
+The reference has no distributed execution at all; this is the sharding scheme of
+SURVEY.md §8(e), written against the same C ABI as the single-GPU path:
+
+  q6 / q1   rows are independent: every rank runs the query on its row shard; the partial scalar /
+            the <= 64 partial groups are all-gathered (a few hundred bytes) and folded in rank order.
+
+  q3        build 1 (customer keys that pass the filter) is small: every rank compacts the keys of
+            its shard (sdqh_scan_compact), the keys are all-gathered, and each rank builds the
+            replicated set.  The orders <-> lineitem join is PARTITIONED ON THE BUILD-SIDE KEY
+            (o_orderkey):
+              * range partitioning when the ranks' build shards cover disjoint, ascending key ranges
+                (dbgen data is clustered on o_orderkey, so both tables are already where they
+                belong): the build side stays put, and only the probe rows whose key falls into
+                another rank's range are exchanged;
+              * hash partitioning (mix64(key) mod G) otherwise: build survivors and filtered probe
+                rows are redistributed.
+            Either way the redistribution step is a count exchange followed by one all-to-all per
+            column (torch.distributed.all_to_all_single = RCCL all-to-all over xGMI), and every
+            rank then probes / aggregates its own key partition.  Group keys are disjoint across
+            ranks, so the result is the concatenation of the ranks' results.
+
+The collectives carry exactly the bytes that have to move; there is no collective in the data path
+of q1 / q6 beyond the final few hundred bytes.  `backend` only needs all_gather, all_to_all_single
+(or point-to-point for gloo) and barrier, so the same code runs under gloo on CPU tensors with the
+CPU oracle behind the ABI — that is how tests/test_dist_cpu.py covers the N > 1 path without GPUs.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import abi, engine, frontend
+from . import tpch_queries as Q
+from .frontend import Col, FinalizeOp, PayloadField, RecordCons, ScanOp
+from .result import ResultSet
+
+
+class DistributedRunner:
+    def __init__(self, eng, rank, world, group=None, device=None, partition="auto"):
+        self.eng, self.ctx = eng, eng.ctx
+        self.rank, self.world, self.group = rank, world, group
+        self.backend = dist.get_backend(group)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
+        self.device = device
+        self.partition = partition          # "auto" | "range" | "hash"
+        self.last_partitioning = None
+        self.exchanged_rows = {}
+        self._plans = {}
+        self._gather_bufs = {}
+
+    # ---- small collectives ---------------------------------------------------------------------
+    def _all_gather_array(self, arr):
+        """Fixed-shape numpy array -> list of the ranks' arrays (rank order).  On GPUs the staging
+        tensors (pinned host in / out, device in / out) are cached per shape, the copies are
+        asynchronous on torch's stream and there is exactly one stream synchronisation."""
+        arr = np.ascontiguousarray(arr)
+        if self.backend != "nccl":
+            t = torch.from_numpy(arr)
+            out = [torch.empty_like(t) for _ in range(self.world)]
+            dist.all_gather(out, t, group=self.group)
+            return [o.numpy() for o in out]
+        key = (arr.shape, arr.dtype.str)
+        bufs = self._gather_bufs.get(key)
+        if bufs is None:
+            tdt = torch.from_numpy(np.zeros(1, arr.dtype)).dtype
+            n = arr.size
+            bufs = (torch.empty(n, dtype=tdt).pin_memory(), torch.empty(n, dtype=tdt, device=self.device),
+                    torch.empty(n * self.world, dtype=tdt, device=self.device), torch.empty(n * self.world, dtype=tdt).pin_memory())
+            self._gather_bufs[key] = bufs
+        h_in, d_in, d_out, h_out = bufs
+        h_in.numpy()[:] = arr.reshape(-1)
+        d_in.copy_(h_in, non_blocking=True)
+        dist.all_gather_into_tensor(d_out, d_in, group=self.group)
+        h_out.copy_(d_out, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        flat = h_out.numpy().copy()
+        return [flat[r * arr.size:(r + 1) * arr.size].reshape(arr.shape) for r in range(self.world)]
+
+    def _all_gather_varlen(self, arr):
+        """1-d int64 array of any length per rank -> concatenation in rank order."""
+        n = np.array([len(arr)], np.int64)
+        sizes = [int(x[0]) for x in self._all_gather_array(n)]
+        m = max(sizes + [1])
+        pad = np.zeros(m, np.int64)
+        pad[: len(arr)] = arr
+        parts = self._all_gather_array(pad)
+        return np.concatenate([p[:s] for p, s in zip(parts, sizes)]) if sum(sizes) else np.zeros(0, np.int64)
+
+    def _all_gather_column(self, col, n):
+        """Concatenate an int64 / f64 Column of n rows per rank over all ranks (rank order), staying
+        in device memory: sizes are exchanged first, the payload is one padded all_gather."""
+        sizes = [int(x[0]) for x in self._all_gather_array(np.array([n], np.int64))]
+        total, m = sum(sizes), max(sizes + [1])
+        send = torch.zeros(m, dtype=torch.int64, device=self.device)
+        if n:
+            self.ctx.copy_out(col, 0, n, send.data_ptr())
+        recv = torch.empty(m * self.world, dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(recv, send, group=self.group) if self.backend == "nccl" else \
+            dist.all_gather(list(recv.view(self.world, m).unbind(0)), send, group=self.group)
+        if self.backend == "nccl":
+            torch.cuda.current_stream().synchronize()
+        out = self.ctx.alloc(total, col.dtype)
+        at = 0
+        for r, s in enumerate(sizes):
+            if s:
+                self.ctx.copy_in(out, at, s, recv.data_ptr() + r * m * 8)
+                at += s
+        return out, total
+
+    def _all_to_all_counts(self, counts):
+        send = torch.from_numpy(np.ascontiguousarray(counts, np.int64)).to(self.device)
+        recv = torch.empty_like(send)
+        self._a2a(recv, send, [1] * self.world, [1] * self.world)
+        return recv.cpu().numpy()
+
+    def _a2a(self, recv, send, out_splits, in_splits):
+        """all_to_all_single; gloo has no all-to-all, so there it is spelled as isend / irecv pairs."""
+        if self.backend == "nccl":
+            dist.all_to_all_single(recv, send, out_splits, in_splits, group=self.group)
+            return
+        so = np.concatenate([[0], np.cumsum(in_splits)]).astype(int)
+        ro = np.concatenate([[0], np.cumsum(out_splits)]).astype(int)
+        recv[ro[self.rank]:ro[self.rank + 1]] = send[so[self.rank]:so[self.rank + 1]]
+        ops = []
+        for peer in range(self.world):
+            if peer == self.rank:
+                continue
+            if in_splits[peer]:
+                ops.append(dist.P2POp(dist.isend, send[so[peer]:so[peer + 1]], peer, group=self.group))
+            if out_splits[peer]:
+                ops.append(dist.P2POp(dist.irecv, recv[ro[peer]:ro[peer + 1]], peer, group=self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def _exchange(self, cols, counts):
+        """cols: Columns whose rows are contiguous per destination rank (counts[dest] rows each).
+        Returns the received Columns (rows grouped by source rank) and their row count.  The whole
+        G x G count matrix is gathered first (G*8 bytes per rank), so every rank knows what it will
+        receive and all ranks agree when nothing at all has to move and skip the data collectives."""
+        matrix = np.stack(self._all_gather_array(np.ascontiguousarray(counts, np.int64)))     # [source, dest]
+        recv_counts = matrix[:, self.rank]
+        n_send, n_recv = int(counts.sum()), int(recv_counts.sum())
+        out = []
+        for col in cols:
+            new = self.ctx.alloc(n_recv, col.dtype)
+            if matrix.sum() > 0:
+                send = torch.empty(max(n_send, 1), dtype=torch.int64, device=self.device)
+                if n_send:
+                    self.ctx.copy_out(col, 0, n_send, send.data_ptr())
+                recv = torch.empty(max(n_recv, 1), dtype=torch.int64, device=self.device)
+                self._a2a(recv[:n_recv], send[:n_send], [int(c) for c in recv_counts], [int(c) for c in counts])
+                if self.backend == "nccl":
+                    torch.cuda.current_stream().synchronize()
+                if n_recv:
+                    self.ctx.copy_in(new, 0, n_recv, recv.data_ptr())
+            out.append(new)
+        return out, n_recv
+
+    # ---- queries ---------------------------------------------------------------------------------
+    def _plan(self, name):
+        if name not in self._plans:
+            self._plans[name] = frontend.lower_function(Q.QUERIES[name])
+        return self._plans[name]
+
+    def run(self, name, db):
+        """Run query `name` on this rank's shard `db`; returns this rank's share of the result
+        (q6: the global scalar on every rank; q1: the global groups on every rank; q3: the groups
+        of this rank's key partition)."""
+        args = [db[t] for t in Q.QUERY_TABLES[name]]
+        plan = self._plan(name)
+        if name == "q6":
+            local = engine.execute_plan(self.eng, plan, args)
+            parts = self._all_gather_array(np.array([local], np.float64))
+            total = 0.0
+            for p in parts:                                   # fixed (rank) order
+                total += float(p[0])
+            return total
+        if name == "q1":
+            return self._row_sharded_groupby(plan, args)
+        if name == "q3":
+            return self._partitioned_join(plan, args)
+        raise frontend.UnsupportedQuery("no distributed plan for %s" % name)
+
+    def _row_sharded_groupby(self, plan, args):
+        """Every rank aggregates its shard; the <= 64 partial groups per rank travel in ONE small
+        all_gather (header + schema + rows, 8 KiB) and are folded in rank order."""
+        op = plan.ops[0]
+        nkey = len(op.key.fields) if isinstance(op.key, RecordCons) else 1
+        local = engine.execute_plan(self.eng, plan, args)      # ResultSet of this shard's groups
+        cap, maxc = abi.MAX_SMALL_GROUPS, 16
+        n = local.size() if local is not None else 0
+        buf = np.zeros(2 + maxc + cap * maxc, np.int64)
+        if n:
+            ncols = len(local.columns)
+            buf[0], buf[1] = n, ncols
+            body = buf[2 + maxc:].reshape(cap, maxc)
+            for j, a in enumerate(local.arrays):
+                if a.dtype.kind == "U":
+                    body[:n, j] = a.astype("<U1").view(np.uint32).astype(np.int64); buf[2 + j] = ord("U")
+                elif a.dtype.kind == "f":
+                    body[:n, j] = a.astype(np.float64).view(np.int64); buf[2 + j] = ord("f")
+                else:
+                    body[:n, j] = a.astype(np.int64); buf[2 + j] = ord("i")
+        parts = self._all_gather_array(buf)
+        src = next((p for p in parts if p[0] > 0), None)
+        if src is None:
+            return local
+        ncols = int(src[1])
+        kinds = [chr(int(x)) for x in src[2:2 + ncols]]
+        cols = local.columns if n else ([f for f, _ in op.key.fields] + [f for f, _ in op.val.fields])
+        merged = {}
+        for p in parts:                                          # rank order: deterministic sums
+            body = p[2 + maxc:].reshape(cap, maxc)
+            for g in range(int(p[0])):
+                key = tuple(int(x) for x in body[g, :nkey])
+                vals = [body[g, nkey + j:nkey + j + 1].view(np.float64)[0] if kinds[nkey + j] == "f" else int(body[g, nkey + j]) for j in range(ncols - nkey)]
+                acc = merged.get(key)
+                if acc is None:
+                    merged[key] = vals
+                else:
+                    for j, v in enumerate(vals):
+                        acc[j] += v
+        keys = sorted(merged)
+        arrays = []
+        for j in range(nkey):
+            col = np.array([k[j] for k in keys], np.int64)
+            arrays.append(col.astype(np.uint32).view("<U1") if kinds[j] == "U" else col)
+        for j in range(ncols - nkey):
+            arrays.append(np.array([merged[k][j] for k in keys], np.float64 if kinds[nkey + j] == "f" else np.int64))
+        return ResultSet(cols, arrays)
+
+    # ---- q3-shaped plans: build(A) -> build(B, semi-join A) -> probe-aggregate(C into B) -> finalise --
+    def _prepare_join(self, plan, args):
+        """Everything about the distributed join that depends only on the plan and on which tables
+        it is bound to: lowered filters / tuples, resident columns, and the (static) facts gathered
+        once from all ranks — global key range of A, per-rank key ranges of B, whether every rank's
+        probe keys already lie in its own range."""
+        eng, ctx = self.eng, self.ctx
+        ops = plan.ops
+        if not (len(ops) == 4 and all(isinstance(o, ScanOp) for o in ops[:3]) and isinstance(ops[3], FinalizeOp)
+                and ops[0].unique and ops[0].probe is None and ops[1].unique and ops[1].probe is not None
+                and ops[1].probe.dict_name == ops[0].out and not ops[2].unique and ops[2].probe is not None
+                and ops[2].probe.dict_name == ops[1].out):
+            raise frontend.UnsupportedQuery("%s does not have the build / build / probe-aggregate shape" % plan.name)
+        tabs = {p: engine.HostTable(p, a) for p, a in zip(plan.params, args)}
+        a_op, b_op, c_op, _ = ops
+        ta, tb, tc = tabs[a_op.table], tabs[b_op.table], tabs[c_op.table]
+        st = type("JoinState", (), {})()
+        st.args = tuple(args)
+        st.generation = eng.generation
+        st.na, st.nb, st.nc = ta.nrows, tb.nrows, tc.nrows
+
+        st.flt_a, look_a = engine._build_filter(eng, a_op, ta, a_op.conds)
+        if look_a or not isinstance(a_op.key, Col):
+            raise frontend.UnsupportedQuery("unsupported first build in the distributed join")
+        st.key_a = eng.column(ta.array(a_op.key.name, a_op))
+
+        st.flt_b, look_b = engine._build_filter(eng, b_op, tb, b_op.conds)
+        if look_b or not isinstance(b_op.key, Col) or not isinstance(b_op.probe.key, Col):
+            raise frontend.UnsupportedQuery("unsupported second build in the distributed join")
+        st.key_b = eng.column(tb.array(b_op.key.name, b_op))
+        st.probe_b = eng.column(tb.array(b_op.probe.key.name, b_op))
+        st.pay_names = [e.name for _, e in b_op.val.fields] if isinstance(b_op.val, RecordCons) else []
+        st.pay_b = [eng.column(tb.array(nm, b_op)) for nm in st.pay_names]
+        st.pay_dtypes = [tb.array(nm, b_op).dtype for nm in st.pay_names]
+
+        st.flt_c, look_c = engine._build_filter(eng, c_op, tc, c_op.conds)
+        if look_c or not isinstance(c_op.probe.key, Col):
+            raise frontend.UnsupportedQuery("unsupported probe side in the distributed join")
+        st.tup_c, st.vnames, st.count_idx = engine._build_tuple(eng, c_op, tc, c_op.val)
+        st.ckey_name = c_op.probe.key.name
+        st.key_c = eng.column(tc.array(st.ckey_name, c_op))
+        slots = []
+        for _, e in (c_op.val.fields if isinstance(c_op.val, RecordCons) else [(None, c_op.val)]):
+            e.shape(slots)
+        st.ops_c = [eng.column(tc.array(s[1], c_op)) for s in slots]
+        st.key_fields = c_op.key.fields if isinstance(c_op.key, RecordCons) else [(None, c_op.key)]
+
+        # ---- static facts, gathered once ---------------------------------------------------------
+        a_lo, a_hi = st.key_a.minmax() if st.na else (abi.INT64_MAX, abi.INT64_MIN)
+        b_lo, b_hi = st.key_b.minmax() if st.nb else (abi.INT64_MAX, abi.INT64_MIN)
+        c_lo, c_hi = st.key_c.minmax() if st.nc else (b_lo, b_hi)
+        facts = self._all_gather_array(np.array([a_lo, a_hi, b_lo, b_hi, st.nb, c_lo, c_hi, st.nc], np.int64))
+        st.a_range = (min(int(f[0]) for f in facts), max(int(f[1]) for f in facts))
+        a_bits = st.a_range[1] - st.a_range[0] + 1
+        st.a_bitmap = 0 < a_bits <= (1 << 31)
+        st.b_ranges = [(int(f[2]), int(f[3])) for f in facts]
+        nonempty = all(int(f[4]) > 0 for f in facts)
+        disjoint = nonempty and all(st.b_ranges[i][1] < st.b_ranges[i + 1][0] for i in range(self.world - 1))
+        mode = self.partition
+        if mode == "auto":
+            mode = "range" if disjoint else "hash"
+        if mode == "range" and not disjoint:
+            raise frontend.UnsupportedQuery("range partitioning needs disjoint ascending build-key ranges per rank")
+        st.mode = mode
+        st.upper = np.array([r[1] for r in st.b_ranges[:-1]], np.int64)
+        # does every rank's probe shard only hold keys of its own build range?  (true for dbgen data:
+        # lineitem is clustered on l_orderkey like orders on o_orderkey)
+        st.all_local = mode == "range" and all(int(f[7]) == 0 or (int(f[5]) >= int(f[2]) and int(f[6]) <= int(f[3])) for f in facts)
+        base_ip = [(f.col_obj, f.lo, f.hi) for f in _ipreds(st.flt_c)]
+        my_lo, my_hi = st.b_ranges[self.rank]
+        st.flt_own = abi.make_filter(base_ip + [(st.key_c, my_lo, my_hi)], _fpreds(st.flt_c), [])
+        st.flt_foreign = [abi.make_filter(base_ip + [(st.key_c, lo_f, hi_f)], _fpreds(st.flt_c), [])
+                          for lo_f, hi_f in ((abi.INT64_MIN, my_lo - 1), (my_hi + 1, abi.INT64_MAX)) if lo_f <= hi_f]
+        st.empty = abi.make_filter()
+        return st
+
+    def _replicated_set(self, st):
+        """Table A on every rank.  Dense key range: every rank builds its shard's table, exports the
+        exact key bitmap over the GLOBAL key range, and one all-reduce (SUM = OR, the keys of a unique
+        build are disjoint across ranks) makes it global.  Otherwise the surviving keys are
+        all-gathered and the set is built from them."""
+        ctx = self.ctx
+        if st.a_bitmap:
+            local = ctx.hash_build_unique(st.na, st.flt_a, [], st.key_a, [])
+            lo, hi = st.a_range
+            n64 = ((hi - lo + 1 + 31) // 32 + 1) // 2
+            # the bitmap is exported straight into the collective's buffer (a torch tensor wrapped as a column)
+            buf = torch.empty(max(n64, 1), dtype=torch.int64, device=self.device)
+            words = ctx.wrap(buf.data_ptr(), n64, abi.I64, keepalive=buf)
+            ctx.table_export_bitmap(local, lo, hi, into=words)
+            local.free()
+            dist.all_reduce(buf, group=self.group)
+            if self.backend == "nccl":
+                torch.cuda.current_stream().synchronize()
+            return ctx.table_from_bitmap(words, lo, hi), [words]
+        (ka,), n_a = ctx.scan_compact(st.na, st.flt_a, [], [st.key_a])
+        rep_keys, n_rep = self._all_gather_column(ka, n_a)
+        ka.free()
+        return ctx.hash_build_unique(n_rep, st.empty, [], rep_keys, []), [rep_keys]
+
+    def _partitioned_join(self, plan, args):
+        ctx = self.ctx
+        cache = plan.__dict__.setdefault("_dist_prepared", {})
+        key = (id(self),) + tuple(id(a) for a in args)
+        st = cache.get(key)
+        if st is None or st.generation != self.eng.generation or any(x is not y for x, y in zip(st.args, args)):
+            st = cache[key] = self._prepare_join(plan, args)
+        self.last_partitioning = st.mode
+        table_a, keep_a = self._replicated_set(st)
+        recv, n_recv = None, 0
+        if st.mode == "range":
+            # the build side is already partitioned on its key: build in place
+            table_b = ctx.hash_build_unique(st.nb, st.flt_b, [(table_a, st.probe_b)], st.key_b, st.pay_b, accumulate=True)
+            if st.all_local:
+                ctx.hash_probe_aggregate(st.nc, st.flt_c, table_b, st.key_c, st.tup_c)
+                self.exchanged_rows = {"build": 0, "probe_sent": 0, "probe_received": 0}
+            else:
+                ctx.hash_probe_aggregate(st.nc, st.flt_own, table_b, st.key_c, st.tup_c)
+                pieces = [ctx.scan_compact(st.nc, flt, [], [st.key_c] + st.ops_c) for flt in st.flt_foreign]
+                foreign_n = sum(n for _, n in pieces)
+                merged = _concat_columns(ctx, pieces, [abi.I64] + [abi.F64] * len(st.ops_c))
+                part_cols, counts = ctx.partition_by_key(foreign_n, merged[0], self.world, merged, range_upper=st.upper)
+                recv, n_recv = self._exchange(part_cols, counts)
+                self.exchanged_rows = {"build": 0, "probe_sent": int(foreign_n), "probe_received": int(n_recv)}
+        else:
+            # hash partitioning: redistribute the build survivors, then the filtered probe rows
+            bcols, nb = ctx.scan_compact(st.nb, st.flt_b, [(table_a, st.probe_b)], [st.key_b] + st.pay_b)
+            part_cols, counts = ctx.partition_by_key(nb, bcols[0], self.world, bcols)
+            brecv, nb_recv = self._exchange(part_cols, counts)
+            table_b = ctx.hash_build_unique(nb_recv, st.empty, [], brecv[0], brecv[1:], accumulate=True)
+            ccols, nc = ctx.scan_compact(st.nc, st.flt_c, [], [st.key_c] + st.ops_c)
+            part_cols, counts = ctx.partition_by_key(nc, ccols[0], self.world, ccols)
+            recv, n_recv = self._exchange(part_cols, counts)
+            self.exchanged_rows = {"build": int(nb), "probe_sent": int(nc), "probe_received": int(n_recv)}
+        if n_recv:
+            ctx.hash_probe_aggregate(n_recv, st.empty, table_b, recv[0], abi.make_tuple(st.tup_c.shape, recv[1:]))
+
+        # ---- finalise this rank's partition --------------------------------------------------------
+        n = ctx.table_compact_count(table_b, 1)
+        keys, payload, values, hits = ctx.table_compact(table_b, 1, n, want_hits=st.count_idx is not None)
+        names, arrays = [], []
+        for fname, e in st.key_fields:
+            if isinstance(e, Col) and e.name == st.ckey_name:
+                names.append(fname or st.ckey_name); arrays.append(keys)
+            elif isinstance(e, PayloadField):
+                j = st.pay_names.index(e.field)
+                names.append(fname or e.field); arrays.append(payload[j].view(st.pay_dtypes[j]))
+            else:
+                raise frontend.UnsupportedQuery("unsupported group key in the distributed join")
+        nv = abi.TUPLE_NVALUES[st.tup_c.shape]
+        for nm, arr in engine._value_arrays(st.vnames, st.count_idx, [values[j] for j in range(nv)], hits):
+            names.append(nm); arrays.append(arr)
+        table_b.free(); table_a.free()
+        for c in keep_a:
+            c.free()
+        return ResultSet(names, arrays)
+
+    # ---- helpers for tests / reporting ---------------------------------------------------------------
+    def gather_rows(self, res):
+        """Concatenate the ranks' ResultSet rows on every rank (validation only, not timed)."""
+        rows = res.rows() if isinstance(res, ResultSet) else []
+        out = [None] * self.world
+        dist.all_gather_object(out, rows, group=self.group)
+        merged = []
+        for r in out:
+            merged += r
+        return sorted(merged)
+
+
+def _ipreds(flt):
+    """(column object, lo, hi) triples kept by abi.make_filter."""
+    class P:   # noqa: N801
+        pass
+    out = []
+    for col, lo, hi in flt._keep[0]:
+        p = P(); p.col_obj, p.lo, p.hi = col, lo, hi
+        out.append(p)
+    return out
+
+
+def _fpreds(flt):
+    return list(flt._keep[1])
+
+
+def _concat_columns(ctx, pieces, dtypes):
+    """Concatenate compacted column sets [(cols, n), ...] into one set of columns."""
+    total = sum(n for _, n in pieces)
+    if len(pieces) == 1:
+        return pieces[0][0]
+    out = []
+    for c, dtype in enumerate(dtypes):
+        new = ctx.alloc(total, dtype)
+        at = 0
+        for cols, n in pieces:
+            if n:
+                ctx.copy_in(new, at, n, cols[c].data_ptr())
+                at += n
+        out.append(new)
+    return out

@@ -41,6 +41,13 @@ def load_hip_library():
     path = build.HIP_LIB
     if not os.path.exists(path) or os.environ.get("SDQLPY_AMD_REBUILD") == "1":
         build.build_hip(force=True)
+    # PyTorch-ROCm bundles its own HIP runtime.  If this library pulled in the system runtime first,
+    # torch would later find "no GPUs" (two runtimes in one process); importing torch first makes
+    # both share the runtime torch loads.  torch is only plumbing here (collectives, exchange buffers).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = abi.Library(path)
     if lib.backend_name() != "hip-gfx950":
         raise RuntimeError("%s is not the HIP backend (reports '%s')" % (path, lib.backend_name()))

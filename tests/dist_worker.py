@@ -1,0 +1,67 @@
+"""Worker for tests/test_dist_cpu.py: one rank of a gloo process group driving the CPU oracle
+through the same distributed plan the GPUs run (sdqlpy_amd/dist.py)."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def shard_rows(table, rank, world, perm=None):
+    from sdqlpy_amd import tpch
+    c = table.getContainer()
+    n = len(c["data"][0])
+    idx = np.arange(n) if perm is None else perm
+    mine = idx[n * rank // world: n * (rank + 1) // world]
+    return tpch.table_from_columns(c["headers"], [np.ascontiguousarray(a[mine]) for a in c["data"]])
+
+
+def main(rank, world, port, sf, mode, out_path):
+    import torch.distributed as dist
+    from sdqlpy_amd import abi, engine, frontend, tpch
+    from sdqlpy_amd import dist as sdist
+    from sdqlpy_amd import tpch_queries as Q
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    lib = abi.Library(os.path.join(ROOT, "oracle", "libsdqloracle.so"))
+    eng = engine.Engine(lib.context(threads=2))
+    qs = ["q1", "q3", "q6"]
+    cols = tpch.columns_for(qs)
+    if mode == "shuffled":
+        # rows of every table dealt to the ranks at random: key ranges overlap -> hash partitioning
+        full = tpch.generate(sf, tables=sorted(cols), columns=cols, threads=2)
+        rng = np.random.default_rng(5)
+        db = {t: shard_rows(full[t], rank, world, rng.permutation(len(full[t].getContainer()["data"][0]))) for t in sorted(full)}
+        partition = "auto"
+    elif mode == "range_foreign":
+        # build side clustered per rank (disjoint key ranges), probe side dealt at random: range
+        # partitioning with probe rows that really have to travel
+        full = tpch.generate(sf, tables=sorted(cols), columns=cols, threads=2)
+        db = tpch.generate(sf, tables=sorted(cols), columns=cols, threads=2, shard=(rank, world))
+        rng = np.random.default_rng(9)
+        db["lineitem"] = shard_rows(full["lineitem"], rank, world, rng.permutation(len(full["lineitem"].getContainer()["data"][0])))
+        partition = "auto"
+    else:
+        db = tpch.generate(sf, tables=sorted(cols), columns=cols, threads=2, shard=(rank, world))
+        partition = {"range": "auto", "hash": "hash"}[mode]
+    runner = sdist.DistributedRunner(eng, rank, world, partition=partition)
+    out = {"rank": rank}
+    out["q6"] = runner.run("q6", db)
+    r1 = runner.run("q1", db)
+    out["q1"] = {"columns": r1.columns, "rows": r1.rows()}
+    r3 = runner.run("q3", db)
+    out["q3"] = {"columns": r3.columns, "rows": runner.gather_rows(r3), "local_rows": r3.size(),
+                 "partitioning": runner.last_partitioning, "exchanged": runner.exchanged_rows}
+    if rank == 0:
+        with open(out_path, "w") as fh:
+            json.dump(out, fh)
+    dist.barrier()
+    dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), sys.argv[5], sys.argv[6])

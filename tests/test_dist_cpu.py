@@ -1,0 +1,66 @@
+"""The N > 1 path on CPU: world_size = 2 over gloo, the CPU oracle behind the ABI, the same
+distributed plan as on GPUs (sdqlpy_amd/dist.py).  Checked against the single-process oracle on the
+whole database: integers and group keys exactly, sums to 1e-12 (rank-order folding)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+import helpers
+from sdqlpy_amd import engine, tpch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SF = 0.01
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_world(mode, tmp_path, world=2):
+    port = free_port()
+    out = str(tmp_path / ("dist_%s.json" % mode))
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r), str(world), str(port), str(SF), mode, out],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-3000:]
+    with open(out) as fh:
+        return json.load(fh)
+
+
+@pytest.fixture(scope="module")
+def single(oracle_lib):
+    eng = engine.Engine(oracle_lib.context(threads=2))
+    qs = ["q1", "q3", "q6"]
+    db = tpch.generate(SF, tables=("lineitem", "customer", "orders"), columns=tpch.columns_for(qs), threads=2)
+    res = {q: helpers.run_query(eng, q, db) for q in qs}
+    eng.close()
+    return res
+
+
+def as_rows(rows):
+    return [tuple(r) for r in rows]
+
+
+@pytest.mark.parametrize("mode", ["range", "range_foreign", "hash", "shuffled"])
+def test_two_ranks_match_single_process(mode, tmp_path, single, oracle_lib):
+    got = run_world(mode, tmp_path)
+    assert abs(got["q6"] - single["q6"]) <= 1e-12 * abs(single["q6"])
+    w1 = single["q1"]
+    helpers.assert_rows_match(sorted(as_rows(got["q1"]["rows"])), helpers.result_rows(w1, got["q1"]["columns"]), 1e-12, mode + "/q1")
+    w3 = single["q3"]
+    helpers.assert_rows_match(sorted(as_rows(got["q3"]["rows"])), helpers.result_rows(w3, got["q3"]["columns"]), 1e-12, mode + "/q3")
+    if mode == "range":
+        # dbgen-shaped shards are co-clustered on o_orderkey: nothing has to move
+        assert got["q3"]["partitioning"] == "range" and got["q3"]["exchanged"]["probe_sent"] == 0
+    elif mode == "range_foreign":
+        assert got["q3"]["partitioning"] == "range" and got["q3"]["exchanged"]["probe_sent"] > 0
+    else:
+        assert got["q3"]["partitioning"] == "hash" and got["q3"]["exchanged"]["build"] > 0
+    assert 0 < got["q3"]["local_rows"] < len(got["q3"]["rows"])

@@ -176,3 +176,63 @@ def test_duplicate_build_keys_first_row_wins(hip_engine, oracle_engine):
     for i, k in enumerate(keys.tolist()):
         first.setdefault(k, i)
     assert dict(zip(out["hip"][0].tolist(), out["hip"][1].tolist())) == first
+
+
+def test_redistribution_helpers_match_oracle(hip_engine, oracle_engine):
+    """scan_compact / partition_by_key (hash and range) / bitmap export-import / column copies:
+    same multisets of rows from both implementations of the ABI."""
+    from sdqlpy_amd import abi
+    rng = np.random.default_rng(21)
+    n = 70001
+    key = rng.integers(0, 5000, n).astype(np.int64) * 3 + 7
+    date = rng.integers(19920101, 19981231, n).astype(np.int64)
+    val = rng.random(n)
+    out = {}
+    for name, eng in (("hip", hip_engine), ("cpu", oracle_engine)):
+        ctx = eng.ctx
+        kc, dc, vc = ctx.upload(key), ctx.upload(date), ctx.upload(val)
+        flt = abi.make_filter([(dc, 19950101, 19961231)])
+        cols, m = ctx.scan_compact(n, flt, [], [kc, vc])
+        rows = sorted(zip(cols[0].download(0, m).tolist(), cols[1].download(0, m).tolist()))
+        parts_h, counts_h = ctx.partition_by_key(m, cols[0], 5, cols)
+        upper = np.array([2000, 6000, 9000, 12000], np.int64)
+        parts_r, counts_r = ctx.partition_by_key(m, cols[0], 5, cols, range_upper=upper)
+        kh, vh = parts_h[0].download(0, m), parts_h[1].download(0, m)
+        kr = parts_r[0].download(0, m)
+        # every partition holds exactly the rows the partition function sends there
+        off = np.concatenate([[0], np.cumsum(counts_h)])
+        per_part = [sorted(zip(kh[off[p]:off[p + 1]].tolist(), vh[off[p]:off[p + 1]].tolist())) for p in range(5)]
+        offr = np.concatenate([[0], np.cumsum(counts_r)])
+        for p in range(5):
+            seg = kr[offr[p]:offr[p + 1]]
+            lo = -1 if p == 0 else upper[p - 1]
+            assert ((seg > lo) & ((seg <= upper[p]) if p < 4 else True)).all()
+        t = ctx.hash_build_unique(n, abi.make_filter(), [], kc, [])
+        words = ctx.table_export_bitmap(t, 7, 7 + 3 * 5000)
+        t2 = ctx.table_from_bitmap(words, 7, 7 + 3 * 5000)
+        probe = ctx.upload(np.arange(0, 16000, dtype=np.int64))
+        (hit,), nh = ctx.scan_compact(16000, abi.make_filter(), [(t2, probe)], [probe])
+        out[name] = (m, rows, counts_h.tolist(), per_part, counts_r.tolist(), sorted(hit.download(0, nh).tolist()))
+    assert out["hip"] == out["cpu"]
+    assert out["hip"][5] == sorted(set(key.tolist()))
+
+
+def test_distributed_runner_world1_nccl(hip_lib, golden):
+    """The distributed plan end to end on one GPU (RCCL group of size 1): exercises the torch-tensor
+    exchange buffers, the count exchange and all_to_all_single on device memory."""
+    import torch
+    import torch.distributed as dist
+    from sdqlpy_amd import dist as sdist
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29591", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    eng = engine.Engine(hip_lib.context(device=0))
+    try:
+        case = next(c for c in golden["cases"] if c["name"] == "small")
+        db = helpers.case_db(case)
+        for part in ("auto", "hash"):
+            runner = sdist.DistributedRunner(eng, 0, 1, partition=part)
+            for q in SUPPORTED:
+                helpers.check_against_golden(runner.run(q, db), case["results"][q], REL, "dist1/%s/%s" % (part, q))
+    finally:
+        eng.close()
+        dist.destroy_process_group()

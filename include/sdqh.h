@@ -99,7 +99,8 @@ typedef struct sdqh_fpred { const sdqh_column* col; double  lo, hi; } sdqh_fpred
 typedef struct sdqh_spred {                     /* col == value  (VarChar::operator==, include/varchar.h:61-77) */
     const sdqh_column* col;
     int32_t  len;                               /* code units in value, <= column width */
-    int32_t  negate;                            /* 1: col != value */
+    int32_t  negate;                            /* 0: col == value, 1: col != value, 2: value is a substring of col
+                                                   (`"x" in col` -> VarChar::contains / wcsstr, include/varchar.h:84-89) */
     uint32_t value[SDQH_MAX_STR_CONST];
 } sdqh_spred;
 
@@ -211,6 +212,50 @@ int sdqh_hash_probe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* f
 int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, int64_t capacity,
                        int64_t* out_keys, int64_t* out_payload, double* out_values,
                        int64_t* out_hits, int64_t* out_n);
+
+/* ---- generalised lookups: multi-join chains (Q5, Q9) -------------------------------------------
+ * Where a value comes from inside an emitted loop body: a column of the scanned row, or a field of
+ * the entry matched by an earlier lookup (`indexedDictValue.x`, `tbl[key].x` -> `.at(key)`,
+ * ...generator_par.py:85-96), optionally through extractYear (sdql_lib.py:341-342).  All values are
+ * 8 raw bytes (int64, or the bits of a double). */
+#define SDQH_SRC_COLUMN      0
+#define SDQH_SRC_LOOKUP      1
+#define SDQH_SRC_LOOKUP_YEAR 2   /* payload / 10000 */
+typedef struct sdqh_source {
+    int32_t kind;                /* SDQH_SRC_* */
+    int32_t lookup;              /* SDQH_SRC_LOOKUP*: index of the lookup step */
+    int32_t field;               /* SDQH_SRC_LOOKUP*: payload field of the matched entry */
+    int32_t _pad;
+    const sdqh_column* col;      /* SDQH_SRC_COLUMN */
+} sdqh_source;
+
+/* A lookup step, evaluated after the filter in order: the row survives only if `table` contains
+ * the key (joinProbe / `tbl[key] != None`).  nkey = 2: composite record key, the two parts (each in
+ * [0, 2^32)) packed as (key[0] << 32) | key[1] — the same packing a two-part build uses. */
+#define SDQH_MAX_LOOKUP 3
+typedef struct sdqh_lookup {
+    const sdqh_table* table;
+    int32_t nkey, _pad;
+    sdqh_source key[2];
+} sdqh_lookup;
+
+/* Generalised K-B (...generator_par.py:331-369 with lookups 85-96): filter -> lookups -> unique
+ * build keyed by 1 or 2 sources, payload fields from sources.  First (lowest) row wins. */
+int sdqh_build(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter,
+               int nlookups, const sdqh_lookup* lookups,
+               int nkey, const sdqh_source* key, int npayload, const sdqh_source* payload,
+               int accumulate, sdqh_table** out);
+
+/* Generalised K-C over a small group domain (...generator_par.py:402-440 with lookups): filter ->
+ * lookups -> group key of 1..2 parts (each in [0, 2^32-2]) from sources -> value tuple whose
+ * operands a..d come from sources (F64 columns or F64 payload bits).  Up to SDQH_MAX_LOOKUP_GROUPS
+ * groups; outputs as sdqh_groupby_small. */
+#define SDQH_MAX_LOOKUP_GROUPS 256
+int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter,
+                          int nlookups, const sdqh_lookup* lookups,
+                          int nkeys, const sdqh_source* keys, int tuple_shape, const sdqh_source* operands,
+                          int max_groups, int64_t* out_keys, double* out_values, int64_t* out_counts,
+                          int32_t* out_ngroups);
 
 /* ---- multi-GPU redistribution helpers (no reference counterpart) -------------- */
 /* Filter + semi-join probes, then gather `ncols` columns of the surviving rows into freshly

@@ -154,6 +154,17 @@ struct FilterView {
         for (int i = 0; i < ns; ++i) {
             // VarChar::operator==(const wchar_t*): reference include/varchar.h:61-77
             const uint32_t* s = sc[i] + (size_t)r * swidth[i];
+            if (sneg[i] == 2) {                                     // VarChar::contains -> wcsstr: reference include/varchar.h:84-89
+                int len = 0; while (len < swidth[i] && s[len] != 0) ++len;          // the string ends at the first NUL
+                bool found = slen[i] == 0;
+                for (int st = 0; !found && st + slen[i] <= len; ++st) {
+                    bool m = true;
+                    for (int k = 0; m && k < slen[i]; ++k) m = s[st + k] == sval[i][k];
+                    found = m;
+                }
+                if (!found) return false;
+                continue;
+            }
             bool eq = slen[i] <= swidth[i];
             for (int k = 0; eq && k < slen[i]; ++k) eq = s[k] == sval[i][k];
             for (int k = slen[i]; eq && k < swidth[i]; ++k) eq = s[k] == 0;
@@ -546,6 +557,162 @@ int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits,
         ++n;
     }
     *out_n = n;
+    ctx->last_ms = tm.ms();
+    return SDQH_OK;
+}
+
+// ---- generalised lookups (Q5 / Q9) ---------------------------------------------------------------
+namespace {
+struct LookupView { const sdqh_table* table; int nkey; sdqh_source key[2]; };
+
+inline bool eval_source(const sdqh_source& s, int64_t r, const int64_t* ent, const LookupView* lk, int64_t* out) {
+    if (s.kind == SDQH_SRC_COLUMN) { *out = ((const int64_t*)s.col->data)[r]; return true; }
+    const sdqh_table* t = lk[s.lookup].table;
+    int64_t v = t->payload[(size_t)ent[s.lookup] * (size_t)t->npayload + (size_t)s.field];
+    *out = s.kind == SDQH_SRC_LOOKUP_YEAR ? v / 10000 : v;
+    return true;
+}
+inline bool pack_key(int nkey, const int64_t* part, int64_t* key) {
+    if (nkey == 1) { *key = part[0]; return true; }
+    if (part[0] < 0 || part[0] > 0xFFFFFFFFll || part[1] < 0 || part[1] > 0xFFFFFFFFll) return false;
+    *key = (int64_t)(((uint64_t)part[0] << 32) | (uint64_t)part[1]);
+    return true;
+}
+// returns 1 = all lookups hit (ent[] filled), 0 = some lookup missed, -1 = a composite key part out of range
+inline int run_lookups(int nl, const LookupView* lk, int64_t r, int64_t* ent) {
+    for (int l = 0; l < nl; ++l) {
+        int64_t part[2] = {0, 0}, key;
+        for (int k = 0; k < lk[l].nkey; ++k) eval_source(lk[l].key[k], r, ent, lk, &part[k]);
+        if (!pack_key(lk[l].nkey, part, &key)) return -1;
+        if (lk[l].table->bitmap_only) { if (!lk[l].table->contains(key)) return 0; ent[l] = 0; continue; }
+        int64_t e = lk[l].table->index.find(key);              // contains + at: generator 85-96
+        if (e < 0) return 0;
+        ent[l] = e;
+    }
+    return 1;
+}
+int check_source(sdqh_ctx* ctx, const sdqh_source& s, int64_t nrows, int nl, const LookupView* lk, int upto, const char* what) {
+    if (s.kind == SDQH_SRC_COLUMN) {
+        if (!s.col || s.col->dtype == SDQH_STR || s.col->nrows < nrows) return fail(ctx, SDQH_ERR_INVALID, std::string(what) + ": column sources must be I64/F64 and cover nrows");
+        return SDQH_OK;
+    }
+    if (s.kind != SDQH_SRC_LOOKUP && s.kind != SDQH_SRC_LOOKUP_YEAR) return fail(ctx, SDQH_ERR_INVALID, std::string(what) + ": bad source kind");
+    if (s.lookup < 0 || s.lookup >= upto) return fail(ctx, SDQH_ERR_INVALID, std::string(what) + ": source refers to a later or unknown lookup");
+    if (lk[s.lookup].table->bitmap_only || s.field < 0 || s.field >= lk[s.lookup].table->npayload) return fail(ctx, SDQH_ERR_INVALID, std::string(what) + ": no such payload field");
+    return SDQH_OK;
+}
+int make_lookups(sdqh_ctx* ctx, int64_t nrows, int nl, const sdqh_lookup* lookups, LookupView* lk) {
+    if (nl < 0 || nl > SDQH_MAX_LOOKUP || (nl && !lookups)) return fail(ctx, SDQH_ERR_INVALID, "too many lookups");
+    for (int l = 0; l < nl; ++l) {
+        if (!lookups[l].table || lookups[l].nkey < 1 || lookups[l].nkey > 2) return fail(ctx, SDQH_ERR_INVALID, "lookup: bad table / key arity");
+        lk[l].table = lookups[l].table; lk[l].nkey = lookups[l].nkey;
+        for (int k = 0; k < lk[l].nkey; ++k) { lk[l].key[k] = lookups[l].key[k]; if (int rc = check_source(ctx, lk[l].key[k], nrows, nl, lk, l, "lookup key")) return rc; }
+    }
+    return SDQH_OK;
+}
+}  // namespace
+
+int sdqh_build(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nlookups, const sdqh_lookup* lookups,
+               int nkey, const sdqh_source* key, int npayload, const sdqh_source* payload, int accumulate, sdqh_table** out) {
+    if (!ctx || nrows < 0 || !out || nkey < 1 || nkey > 2 || !key || npayload < 0 || npayload > SDQH_MAX_PAYLOAD || (npayload && !payload))
+        return fail(ctx, SDQH_ERR_INVALID, "build: bad arguments");
+    Timer tm;
+    FilterView fv; LookupView lk[SDQH_MAX_LOOKUP];
+    if (int rc = make_filter(ctx, nrows, filter, 0, nullptr, &fv)) return rc;
+    if (int rc = make_lookups(ctx, nrows, nlookups, lookups, lk)) return rc;
+    for (int k = 0; k < nkey; ++k) if (int rc = check_source(ctx, key[k], nrows, nlookups, lk, nlookups, "build key")) return rc;
+    for (int p = 0; p < npayload; ++p) if (int rc = check_source(ctx, payload[p], nrows, nlookups, lk, nlookups, "build payload")) return rc;
+    struct Row { int64_t key; int64_t pay[SDQH_MAX_PAYLOAD]; };
+    int T = eff_threads(ctx->threads, nrows);
+    std::vector<std::vector<Row>> local((size_t)T);
+    std::vector<int> bad((size_t)T, 0);
+    run_blocks(T, nrows, [&](int t, int64_t b, int64_t e) {          // emplace_back(key, payload): generator 331-369
+        auto& v = local[(size_t)t];
+        for (int64_t r = b; r < e; ++r) {
+            if (!fv.pass(r)) continue;
+            int64_t ent[SDQH_MAX_LOOKUP] = {0, 0, 0};
+            int h = run_lookups(nlookups, lk, r, ent);
+            if (h < 0) { bad[(size_t)t] = 1; continue; }
+            if (h == 0) continue;
+            Row row{}; int64_t part[2] = {0, 0};
+            for (int k = 0; k < nkey; ++k) eval_source(key[k], r, ent, lk, &part[k]);
+            if (!pack_key(nkey, part, &row.key)) { bad[(size_t)t] = 1; continue; }
+            for (int p = 0; p < npayload; ++p) eval_source(payload[p], r, ent, lk, &row.pay[p]);
+            v.push_back(row);
+        }
+    });
+    for (int t = 0; t < T; ++t) if (bad[(size_t)t]) return fail(ctx, SDQH_ERR_UNSUPPORTED, "build: composite key part outside [0, 2^32)");
+    sdqh_table* tb = new sdqh_table();
+    tb->npayload = npayload; tb->accumulate = accumulate != 0;
+    for (int t = 0; t < T; ++t)                                       // global.insert(range): first wins
+        for (const Row& row : local[(size_t)t]) {
+            int64_t e = (int64_t)tb->keys.size();
+            if (tb->index.find_or_insert(row.key, e) >= 0) continue;
+            tb->keys.push_back(row.key);
+            for (int p = 0; p < npayload; ++p) tb->payload.push_back(row.pay[p]);
+        }
+    if (tb->accumulate) tb->acc.assign(tb->keys.size(), Acc{});
+    *out = tb;
+    ctx->last_ms = tm.ms();
+    return SDQH_OK;
+}
+
+int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nlookups, const sdqh_lookup* lookups,
+                          int nkeys, const sdqh_source* keys, int tuple_shape, const sdqh_source* operands, int max_groups,
+                          int64_t* out_keys, double* out_values, int64_t* out_counts, int32_t* out_ngroups) {
+    if (!ctx || nrows < 0 || nkeys < 1 || nkeys > SDQH_MAX_GROUPKEYS || !keys || max_groups < 1 || max_groups > SDQH_MAX_LOOKUP_GROUPS || !out_ngroups)
+        return fail(ctx, SDQH_ERR_INVALID, "lookup_aggregate: bad arguments");
+    Timer tm;
+    FilterView fv; LookupView lk[SDQH_MAX_LOOKUP];
+    if (int rc = make_filter(ctx, nrows, filter, 0, nullptr, &fv)) return rc;
+    if (int rc = make_lookups(ctx, nrows, nlookups, lookups, lk)) return rc;
+    int nops; int nv = tuple_arity(tuple_shape, &nops);
+    if (nv < 0) return fail(ctx, SDQH_ERR_UNSUPPORTED, "unknown tuple shape");
+    for (int k = 0; k < nkeys; ++k) if (int rc = check_source(ctx, keys[k], nrows, nlookups, lk, nlookups, "group key")) return rc;
+    for (int j = 0; j < nops; ++j) if (int rc = check_source(ctx, operands[j], nrows, nlookups, lk, nlookups, "tuple operand")) return rc;
+    struct Group { int64_t key[SDQH_MAX_GROUPKEYS]; Acc acc; };
+    int T = eff_threads(ctx->threads, nrows);
+    std::vector<std::vector<Group>> local((size_t)T);
+    std::vector<int> bad((size_t)T, 0);
+    run_blocks(T, nrows, [&](int t, int64_t b, int64_t e) {
+        auto& groups = local[(size_t)t];
+        I64Index idx;                                                   // packed group key -> local group
+        for (int64_t r = b; r < e; ++r) {
+            if (!fv.pass(r)) continue;
+            int64_t ent[SDQH_MAX_LOOKUP] = {0, 0, 0};
+            int h = run_lookups(nlookups, lk, r, ent);
+            if (h < 0) { bad[(size_t)t] = 1; continue; }
+            if (h == 0) continue;
+            int64_t key[SDQH_MAX_GROUPKEYS] = {0, 0};
+            for (int k = 0; k < nkeys; ++k) { eval_source(keys[k], r, ent, lk, &key[k]); if (key[k] < 0 || key[k] > 0xFFFFFFFEll) bad[(size_t)t] = 1; }
+            int64_t packed = (int64_t)(((uint64_t)key[1] << 32) | (uint64_t)(key[0] & 0xFFFFFFFFll));
+            int64_t g = idx.find_or_insert(packed, (int64_t)groups.size());
+            if (g < 0) { g = (int64_t)groups.size(); groups.push_back(Group{{key[0], key[1]}, Acc{}}); }
+            double x[4] = {0, 0, 0, 0}, v[SDQH_TUPLE_MAX_VALUES] = {0, 0, 0, 0};
+            for (int j = 0; j < nops; ++j) { int64_t bits; eval_source(operands[j], r, ent, lk, &bits); std::memcpy(&x[j], &bits, 8); }
+            TupleView tv; tv.shape = tuple_shape; tv.nv = nv; tv.a = &x[0]; tv.b = &x[1]; tv.c = &x[2]; tv.d = &x[3];
+            tv.eval(0, v);                                              // local[key] += tuple  (generator 402-440)
+            Acc& a = groups[(size_t)g].acc;
+            for (int k = 0; k < nv; ++k) a.v[k] += v[k];
+            a.n += 1;
+        }
+    });
+    for (int t = 0; t < T; ++t) if (bad[(size_t)t]) return fail(ctx, SDQH_ERR_UNSUPPORTED, "lookup_aggregate: key part out of range");
+    std::vector<Group> global;                                          // AddMap(global, local) per thread, in order
+    for (int t = 0; t < T; ++t)
+        for (auto& x : local[(size_t)t]) {
+            Group* g = nullptr;
+            for (auto& y : global) if (y.key[0] == x.key[0] && y.key[1] == x.key[1]) { g = &y; break; }
+            if (!g) global.push_back(x);
+            else { for (int k = 0; k < nv; ++k) g->acc.v[k] += x.acc.v[k]; g->acc.n += x.acc.n; }
+        }
+    if ((int)global.size() > max_groups) { *out_ngroups = (int32_t)global.size(); return fail(ctx, SDQH_ERR_OVERFLOW, "lookup_aggregate: more groups than max_groups"); }
+    for (size_t g = 0; g < global.size(); ++g) {
+        if (out_keys) for (int k = 0; k < nkeys; ++k) out_keys[g * (size_t)nkeys + k] = global[g].key[k];
+        if (out_values) for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) out_values[g * SDQH_TUPLE_MAX_VALUES + k] = k < nv ? global[g].acc.v[k] : 0.0;
+        if (out_counts) out_counts[g] = global[g].acc.n;
+    }
+    *out_ngroups = (int32_t)global.size();
     ctx->last_ms = tm.ms();
     return SDQH_OK;
 }

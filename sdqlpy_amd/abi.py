@@ -53,6 +53,54 @@ class Probe(C.Structure):
     _fields_ = [("table", C.c_void_p), ("key", C.c_void_p)]
 
 
+SRC_COLUMN, SRC_LOOKUP, SRC_LOOKUP_YEAR = 0, 1, 2
+MAX_LOOKUP, MAX_LOOKUP_GROUPS = 3, 256
+
+
+class Source(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("lookup", C.c_int32), ("field", C.c_int32), ("_pad", C.c_int32), ("col", C.c_void_p)]
+
+
+class Lookup(C.Structure):
+    _fields_ = [("table", C.c_void_p), ("nkey", C.c_int32), ("_pad", C.c_int32), ("key", Source * 2)]
+
+
+def src_col(col):
+    """Source: a column of the scanned row."""
+    return ("col", col)
+
+
+def src_lookup(lookup, field, year=False):
+    """Source: payload field `field` of the entry matched by lookup step `lookup` (optionally // 10000)."""
+    return ("year" if year else "lookup", lookup, field)
+
+
+def _fill_source(dst, spec):
+    if spec[0] == "col":
+        dst.kind, dst.col = SRC_COLUMN, spec[1].handle
+    else:
+        dst.kind, dst.lookup, dst.field = (SRC_LOOKUP_YEAR if spec[0] == "year" else SRC_LOOKUP), spec[1], spec[2]
+
+
+def _sources(specs):
+    arr = (Source * max(1, len(specs)))()
+    for i, sp in enumerate(specs):
+        _fill_source(arr[i], sp)
+    return arr
+
+
+def _lookups(lookups):
+    """lookups: [(Table, [key source specs (1 or 2)])]."""
+    if len(lookups) > MAX_LOOKUP:
+        raise SdqhError(ERR_UNSUPPORTED, "more than %d lookups in one loop" % MAX_LOOKUP)
+    arr = (Lookup * max(1, len(lookups)))()
+    for i, (table, keys) in enumerate(lookups):
+        arr[i].table, arr[i].nkey = table.handle, len(keys)
+        for k, sp in enumerate(keys):
+            _fill_source(arr[i].key[k], sp)
+    return arr
+
+
 EXPORTS = [
     "sdqh_abi_version", "sdqh_backend_name", "sdqh_create", "sdqh_destroy", "sdqh_last_error", "sdqh_set_threads",
     "sdqh_synchronize", "sdqh_last_device_ms", "sdqh_set_profiling", "sdqh_profile_count", "sdqh_profile_entry",
@@ -62,6 +110,7 @@ EXPORTS = [
     "sdqh_scan_filter_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_table_size", "sdqh_table_free",
     "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_scan_compact", "sdqh_partition_by_key",
     "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in",
+    "sdqh_build", "sdqh_lookup_aggregate",
 ]
 
 
@@ -141,7 +190,7 @@ def make_filter(ipreds=(), fpreds=(), spreds=()):
     for i, (col, text, negate) in enumerate(spreds):
         if len(text) > MAX_STR_CONST:
             raise SdqhError(ERR_UNSUPPORTED, "string constant longer than %d" % MAX_STR_CONST)
-        f.spred[i].col, f.spred[i].len, f.spred[i].negate = col.handle, len(text), 1 if negate else 0
+        f.spred[i].col, f.spred[i].len, f.spred[i].negate = col.handle, len(text), int(negate)      # 0 ==, 1 !=, 2 substring
         for k, ch in enumerate(text):
             f.spred[i].value[k] = ord(ch)
     f._keep = (ipreds, fpreds, spreds)
@@ -303,6 +352,30 @@ class Context:
         t._keep = (probes, key, payload)
         return t
 
+    def build(self, nrows, flt, lookups, key, payload=(), accumulate=False):
+        """Generalised unique build: lookups [(Table, [key sources])], key [1-2 sources], payload [sources]."""
+        larr, karr, parr = _lookups(lookups), _sources(key), _sources(payload)
+        h = C.c_void_p()
+        self._check(self.lib.sdqh_build(self.handle, C.c_int64(nrows), C.byref(flt), C.c_int(len(lookups)), larr, C.c_int(len(key)), karr,
+                                        C.c_int(len(payload)), parr, C.c_int(1 if accumulate else 0), C.byref(h)))
+        self._after_call("build")
+        t = Table(self, h, len(payload), accumulate)
+        t._keep = (lookups, key, payload)
+        return t
+
+    def lookup_aggregate(self, nrows, flt, lookups, keys, shape, operands, max_groups=MAX_LOOKUP_GROUPS):
+        larr, karr, oarr = _lookups(lookups), _sources(keys), _sources(operands)
+        nk = len(keys)
+        out_keys = np.zeros((max_groups, nk), np.int64)
+        out_vals = np.zeros((max_groups, TUPLE_MAX_VALUES), np.float64)
+        out_cnt = np.zeros(max_groups, np.int64)
+        ng = C.c_int32()
+        self._check(self.lib.sdqh_lookup_aggregate(self.handle, C.c_int64(nrows), C.byref(flt), C.c_int(len(lookups)), larr, C.c_int(nk), karr,
+                                                   C.c_int(shape), oarr, C.c_int(max_groups), _np_ptr(out_keys), _np_ptr(out_vals), _np_ptr(out_cnt), C.byref(ng)))
+        self._after_call("lookup_aggregate")
+        n = ng.value
+        return out_keys[:n], out_vals[:n, : TUPLE_NVALUES[shape]], out_cnt[:n]
+
     def hash_probe_aggregate(self, nrows, flt, table, key, tup):
         self._check(self.lib.sdqh_hash_probe_aggregate(self.handle, C.c_int64(nrows), C.byref(flt), table.handle, key.handle, C.byref(tup)))
         self._after_call("hash_probe_aggregate")
@@ -429,6 +502,9 @@ class Library:
         L.sdqh_column_copy_in.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.sdqh_table_export_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.sdqh_table_from_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.sdqh_build.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.sdqh_lookup_aggregate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         if L.sdqh_abi_version() != 1:
             raise OSError("%s: ABI version %d, expected 1" % (path, L.sdqh_abi_version()))
 

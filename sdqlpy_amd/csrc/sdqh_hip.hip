@@ -245,7 +245,7 @@ int make_probes(sdqh_ctx* ctx, int64_t nrows, int nprobes, const sdqh_probe* pro
         if (!probes[i].table) return fail(ctx, SDQH_ERR_INVALID, "probe: null table");
         if (int rc = check_col(ctx, probes[i].key, SDQH_I64, nrows, "probe key")) return rc;
         sdqh_table* pt = const_cast<sdqh_table*>(probes[i].table);
-        if (!pt->bm) { if (int rc = ensure_index(ctx, pt)) return rc; }        // hash layout: contains() walks the slots
+        if (!pt->bm || pt->dev.bm_shift) { if (int rc = ensure_index(ctx, pt)) return rc; }   // hash layout: contains() walks the slots
         d->table[i] = pt->dev; d->key[i] = static_cast<const int64_t*>(probes[i].key->data);
     }
     d->n = nprobes;
@@ -673,7 +673,7 @@ static int ensure_index(sdqh_ctx* ctx, sdqh_table* tb) {
     if (tb->index_built || tb->bitmap_only) return SDQH_OK;
     const unsigned seg_grid = (unsigned)((tb->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
     const size_t rows = (size_t)std::max<int64_t>(tb->nrows_build, 1);
-    if (tb->bm) {                                                          // direct layout
+    if (tb->bm && tb->dev.bm_shift == 0) {                                 // direct layout
         const int nblocks = (int)((tb->nwords + RANK_BLOCK_WORDS - 1) / RANK_BLOCK_WORDS);
         uint32_t* wprefix = static_cast<uint32_t*>(table_alloc(ctx, tb, tb->nwords * 4 + 64));
         uint32_t* bprefix = static_cast<uint32_t*>(table_alloc(ctx, tb, (size_t)nblocks * 4 + 64));
@@ -733,8 +733,9 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
         if (!tb->hdr || (tb->nwords && !tb->bm)) rc = fail(ctx, SDQH_ERR_NOMEM, "hash_build_unique: out of device memory");
         else {
             tb->dev.hdr = tb->hdr; tb->dev.shits = tb->stage.shits; tb->dev.sacc = tb->stage.sacc;
-            tb->dev.bm = tb->bm; tb->dev.bm_lo = lo; tb->dev.bm_hi = hi; tb->dev.bitmap_only = 0;
-            tb->stage.bm = tb->bm; tb->stage.bm_lo = lo; tb->stage.bm_hi = hi; tb->stage.hdr = tb->hdr;
+            tb->dev.bm = tb->bm; tb->dev.bm_lo = lo; tb->dev.bm_hi = hi; tb->dev.bitmap_only = 0; tb->dev.bm_shift = 0;
+            for (int p = 0; p < npayload; ++p) tb->dev.pay[p] = tb->stage.pay[p];
+            tb->stage.bm = tb->bm; tb->stage.bm_lo = lo; tb->stage.bm_hi = hi; tb->stage.hdr = tb->hdr; tb->stage.bm_shift = 0;
             call_begin(ctx);
             const unsigned seg_grid = (unsigned)((tb->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
             hipError_t e = hipMemsetAsync(tb->hdr, 0, sizeof(TableHeader), ctx->stream);
@@ -897,6 +898,177 @@ int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_hits
     if (out_hits) if (int rc = fetch(out_hits, o.hits)) return rc;
     if (int rc = sync_stream(ctx)) return rc;
     for (auto& c : copies) std::memcpy(c.first, c.second, nb);
+    return SDQH_OK;
+}
+
+// ---- generalised lookups (Q5 / Q9) ---------------------------------------------------------------
+static int make_source(sdqh_ctx* ctx, const sdqh_source& s, int64_t nrows, int nl, const sdqh_lookup* lookups, int upto, const char* what, DevSource* d) {
+    std::memset(d, 0, sizeof(*d));
+    d->kind = s.kind;
+    if (s.kind == SDQH_SRC_COLUMN) {
+        if (!s.col || s.col->dtype == SDQH_STR || s.col->nrows < nrows) return fail(ctx, SDQH_ERR_INVALID, std::string(what) + ": column sources must be I64/F64 and cover nrows");
+        d->col = static_cast<const int64_t*>(s.col->data);
+        return SDQH_OK;
+    }
+    if (s.kind != SDQH_SRC_LOOKUP && s.kind != SDQH_SRC_LOOKUP_YEAR) return fail(ctx, SDQH_ERR_INVALID, std::string(what) + ": bad source kind");
+    if (s.lookup < 0 || s.lookup >= upto || s.lookup >= nl) return fail(ctx, SDQH_ERR_INVALID, std::string(what) + ": source refers to a later or unknown lookup");
+    const sdqh_table* t = lookups[s.lookup].table;
+    if (t->bitmap_only || s.field < 0 || s.field >= t->npay) return fail(ctx, SDQH_ERR_INVALID, std::string(what) + ": no such payload field");
+    d->lookup = s.lookup; d->field = s.field;
+    return SDQH_OK;
+}
+
+static int make_lookups(sdqh_ctx* ctx, int64_t nrows, int nl, const sdqh_lookup* lookups, DevLookups* L, bool* composite) {
+    std::memset(L, 0, sizeof(*L));
+    if (nl < 0 || nl > SDQH_MAX_LOOKUP || (nl && !lookups)) return fail(ctx, SDQH_ERR_INVALID, "too many lookups");
+    for (int l = 0; l < nl; ++l) {
+        if (!lookups[l].table || lookups[l].nkey < 1 || lookups[l].nkey > 2) return fail(ctx, SDQH_ERR_INVALID, "lookup: bad table / key arity");
+        sdqh_table* t = const_cast<sdqh_table*>(lookups[l].table);
+        if (int rc = ensure_index(ctx, t)) return rc;
+        L->l[l].table = t->dev; L->l[l].nkey = lookups[l].nkey;
+        if (lookups[l].nkey == 2) *composite = true;
+        for (int k = 0; k < lookups[l].nkey; ++k) if (int rc = make_source(ctx, lookups[l].key[k], nrows, nl, lookups, l, "lookup key", &L->l[l].key[k])) return rc;
+    }
+    L->n = nl;
+    return SDQH_OK;
+}
+
+int sdqh_build(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nlookups, const sdqh_lookup* lookups,
+               int nkey, const sdqh_source* key, int npayload, const sdqh_source* payload, int accumulate, sdqh_table** out) {
+    if (!ctx || nrows < 0 || !out || nkey < 1 || nkey > 2 || !key || npayload < 0 || npayload > SDQH_MAX_PAYLOAD || (npayload && !payload))
+        return fail(ctx, SDQH_ERR_INVALID, "build: bad arguments");
+    if (nrows >= 0xFFFFFFFEll) return fail(ctx, SDQH_ERR_UNSUPPORTED, "build: build side limited to 2^32-2 rows per GPU");
+    (void)hipSetDevice(ctx->device);
+    DevFilter f; DevLookups L; DevBuildSpec spec;
+    std::memset(&spec, 0, sizeof(spec));
+    bool composite = nkey == 2;
+    if (int rc = make_filter(ctx, nrows, filter, nullptr, &f)) return rc;
+    if (int rc = make_lookups(ctx, nrows, nlookups, lookups, &L, &composite)) return rc;
+    spec.nkey = nkey; spec.npay = npayload;
+    for (int k = 0; k < nkey; ++k) if (int rc = make_source(ctx, key[k], nrows, nlookups, lookups, nlookups, "build key", &spec.key[k])) return rc;
+    for (int p = 0; p < npayload; ++p) if (int rc = make_source(ctx, payload[p], nrows, nlookups, lookups, nlookups, "build payload", &spec.pay[p])) return rc;
+    // bitmap over the key (single part: exact -> direct layout) or over its high part (composite:
+    // a pre-filter in front of the hash layout), when that part is a plain column with a dense range
+    int64_t lo = 0, hi = -1; bool want_bm = false;
+    if (nrows > 0 && key[0].kind == SDQH_SRC_COLUMN && key[0].col->dtype == SDQH_I64) {
+        if (int rc = ensure_minmax(ctx, const_cast<sdqh_column*>(key[0].col))) return rc;
+        lo = key[0].col->mn; hi = key[0].col->mx;
+        if (hi >= lo && lo > INT64_MIN / 2 && hi < INT64_MAX / 2) {
+            const uint64_t range = (uint64_t)(hi - lo) + 1;
+            want_bm = range <= (1ull << 31) && range <= 64ull * (uint64_t)std::max<int64_t>(nrows, 1024);
+            if (nkey == 2 && (lo < 0 || hi > 0xFFFFFFFFll)) want_bm = false;
+        }
+    }
+    sdqh_table* tb = new sdqh_table();
+    tb->npay = npayload; tb->accumulate = accumulate != 0; tb->nrows_build = nrows;
+    // stage without source columns: the kernel evaluates sources itself
+    sdqh_column fake; fake.data = nullptr;
+    const sdqh_column* fakes[SDQH_MAX_PAYLOAD] = {&fake, &fake, &fake, &fake};
+    int rc = setup_stage(ctx, tb, nrows, &fake, npayload, fakes);
+    uint64_t capmax = 1024;
+    while (capmax < 2 * (uint64_t)std::max<int64_t>(nrows, 1)) capmax <<= 1;
+    tb->capmax = capmax;
+    int* flags = nullptr;
+    if (!rc) {
+        tb->hdr = static_cast<TableHeader*>(table_alloc(ctx, tb, sizeof(TableHeader)));
+        flags = static_cast<int*>(table_alloc(ctx, tb, 64));
+        if (want_bm && ctx->opt_direct_index) { tb->nwords = ((uint64_t)(hi - lo) + 32) / 32; tb->bm = static_cast<uint32_t*>(table_alloc(ctx, tb, tb->nwords * 4 + 64)); }
+        if (!tb->hdr || !flags || (tb->nwords && !tb->bm)) rc = fail(ctx, SDQH_ERR_NOMEM, "build: out of device memory");
+    }
+    if (!rc) {
+        tb->dev.hdr = tb->hdr; tb->dev.shits = tb->stage.shits; tb->dev.sacc = tb->stage.sacc;
+        tb->dev.bm = tb->bm; tb->dev.bm_lo = lo; tb->dev.bm_hi = hi; tb->dev.bitmap_only = 0; tb->dev.bm_shift = nkey == 2 ? 32 : 0;
+        for (int p = 0; p < npayload; ++p) tb->dev.pay[p] = tb->stage.pay[p];
+        tb->stage.bm = tb->bm; tb->stage.bm_lo = lo; tb->stage.bm_hi = hi; tb->stage.hdr = tb->hdr; tb->stage.bm_shift = nkey == 2 ? 32 : 0;
+        call_begin(ctx);
+        const unsigned seg_grid = (unsigned)((tb->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
+        hipError_t e = hipMemsetAsync(tb->hdr, 0, sizeof(TableHeader), ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(flags, 0, 8, ctx->stream);
+        if (e == hipSuccess && tb->bm) e = hipMemsetAsync(tb->bm, 0, tb->nwords * 4, ctx->stream);
+        if (e != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e));
+        with_scan_filter(f, [&](auto FC) { auto kern = k_build_lookup<decltype(FC)>; LAUNCH(ctx, "k_build_lookup", kern, seg_grid, f, L, spec, tb->stage, nrows, flags); return SDQH_OK; });
+        call_end(ctx);
+        e = hipGetLastError();
+        if (e != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, std::string("build launch: ") + hipGetErrorString(e));
+        if (!rc && composite) {                        // a key part outside [0, 2^32) cannot be packed: report it now
+            e = hipMemcpyAsync(ctx->result_host, flags, 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (e != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e));
+            if (!rc) rc = sync_stream(ctx);
+            if (!rc && (*static_cast<const int*>(ctx->result_host) & 2)) rc = fail(ctx, SDQH_ERR_UNSUPPORTED, "build: composite key part outside [0, 2^32)");
+        }
+    }
+    if (rc) { table_release(ctx, tb); delete tb; return rc; }
+    *out = tb;
+    return SDQH_OK;
+}
+
+int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nlookups, const sdqh_lookup* lookups,
+                          int nkeys, const sdqh_source* keys, int tuple_shape, const sdqh_source* operands, int max_groups,
+                          int64_t* out_keys, double* out_values, int64_t* out_counts, int32_t* out_ngroups) {
+    if (!ctx || nrows < 0 || nkeys < 1 || nkeys > SDQH_MAX_GROUPKEYS || !keys || max_groups < 1 || max_groups > SDQH_MAX_LOOKUP_GROUPS || !out_ngroups)
+        return fail(ctx, SDQH_ERR_INVALID, "lookup_aggregate: bad arguments");
+    (void)hipSetDevice(ctx->device);
+    const int nops = tuple_nops(tuple_shape), nv = tuple_nv(tuple_shape);
+    if (nops < 0) return fail(ctx, SDQH_ERR_UNSUPPORTED, "unknown tuple shape");
+    DevFilter f; DevLookups L; DevAggSpec spec;
+    std::memset(&spec, 0, sizeof(spec));
+    bool composite = false;
+    if (int rc = make_filter(ctx, nrows, filter, nullptr, &f)) return rc;
+    if (int rc = make_lookups(ctx, nrows, nlookups, lookups, &L, &composite)) return rc;
+    spec.nkeys = nkeys; spec.shape = tuple_shape;
+    for (int k = 0; k < nkeys; ++k) if (int rc = make_source(ctx, keys[k], nrows, nlookups, lookups, nlookups, "group key", &spec.key[k])) return rc;
+    for (int j = 0; j < nops; ++j) if (int rc = make_source(ctx, operands[j], nrows, nlookups, lookups, nlookups, "tuple operand", &spec.op[j])) return rc;
+    // result block in ctx->result_dev: gkeys[LG_SLOTS] | acc[LG_SLOTS][4] | cnt[LG_SLOTS] | flags
+    char* rd = static_cast<char*>(ctx->result_dev);
+    unsigned long long* r_keys = reinterpret_cast<unsigned long long*>(rd);
+    double* r_acc = reinterpret_cast<double*>(rd + LG_SLOTS * 8);
+    int64_t* r_cnt = reinterpret_cast<int64_t*>(rd + LG_SLOTS * 40);
+    int* r_flags = reinterpret_cast<int*>(rd + LG_SLOTS * 48);
+    const size_t rbytes = LG_SLOTS * 48 + 8;
+    static_assert(LG_SLOTS * 48 + 8 <= RESULT_BYTES, "result block too small");
+    unsigned grid = 1; char* blob = nullptr;
+    int lrc = with_shape(ctx, tuple_shape, [&](auto S) {
+        return with_scan_filter(f, [&](auto FC) {
+            auto kern = k_lookup_agg<decltype(S)::value, decltype(FC)>;
+            grid = stream_grid(ctx, kern, nrows, TPB * ROWS_PER_LOAD * 2);
+            const size_t nslots = (size_t)grid * LG_SLOTS;
+            blob = static_cast<char*>(pool_alloc(ctx, nslots * 40 + 256));
+            if (!blob) return fail(ctx, SDQH_ERR_NOMEM, "lookup_aggregate: out of device memory");
+            double* pacc = reinterpret_cast<double*>(blob);
+            int64_t* pcnt = reinterpret_cast<int64_t*>(blob + nslots * 32);
+            call_begin(ctx);
+            hipError_t e = hipMemsetAsync(r_keys, 0xFF, LG_SLOTS * 8, ctx->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(r_flags, 0, 8, ctx->stream);
+            if (e != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e));
+            LAUNCH(ctx, "k_lookup_agg", kern, grid, f, L, spec, nrows, r_keys, pacc, pcnt, r_flags);
+            LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, r_keys, pacc, pcnt, (int)grid, r_acc, r_cnt);
+            call_end(ctx);
+            return SDQH_OK;
+        });
+    });
+    if (lrc) { if (blob) pool_free(ctx, blob); return lrc; }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->result_host, rd, rbytes, hipMemcpyDeviceToHost, ctx->stream));
+    int rc = sync_stream(ctx);
+    pool_free(ctx, blob);
+    if (rc) return rc;
+    const char* h = static_cast<const char*>(ctx->result_host);
+    const int flags = *reinterpret_cast<const int*>(h + LG_SLOTS * 48);
+    if (flags & 2) return fail(ctx, SDQH_ERR_UNSUPPORTED, "lookup_aggregate: key part out of range");
+    const unsigned long long* hk = reinterpret_cast<const unsigned long long*>(h);
+    const double* ha = reinterpret_cast<const double*>(h + LG_SLOTS * 8);
+    const int64_t* hc = reinterpret_cast<const int64_t*>(h + LG_SLOTS * 40);
+    std::vector<int> order;
+    for (int g = 0; g < LG_SLOTS; ++g) if (hk[g] != EMPTY_GROUP && hc[g] > 0) order.push_back(g);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return hk[a] < hk[b]; });
+    const int ng = (int)order.size();
+    if ((flags & 1) || ng > max_groups) { *out_ngroups = std::max(ng, max_groups + 1); return fail(ctx, SDQH_ERR_OVERFLOW, "lookup_aggregate: more groups than max_groups"); }
+    for (int i = 0; i < ng; ++i) {
+        const int g = order[(size_t)i];
+        if (out_keys) for (int k = 0; k < nkeys; ++k) out_keys[i * nkeys + k] = (int64_t)((hk[g] >> (32 * k)) & 0xFFFFFFFFull);
+        if (out_values) for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) out_values[i * SDQH_TUPLE_MAX_VALUES + k] = k < nv ? ha[g * 4 + k] : 0.0;
+        if (out_counts) out_counts[i] = hc[g];
+    }
+    *out_ngroups = ng;
     return SDQH_OK;
 }
 

@@ -78,12 +78,15 @@ struct DevTable {
     TableHeader* hdr;
     uint32_t* shits;
     double* sacc;             // null when the table carries no accumulators
-    const uint32_t* bm;       // exact key bitmap over [bm_lo, bm_hi], or null
+    const uint32_t* bm;       // key bitmap over [bm_lo, bm_hi], or null
     const uint32_t* wprefix;
     const uint32_t* bprefix;
     uint32_t* dense_ref;
     int64_t bm_lo, bm_hi;
-    int32_t bitmap_only, _pad;
+    int32_t bitmap_only;
+    int32_t bm_shift;         // 0: bm is exact over the key (direct layout); 32: composite key, bm covers
+                              //    the high part only (a pre-filter in front of the hash layout)
+    const int64_t* pay[SDQH_MAX_PAYLOAD];   // stage payload arrays (entry payload by stage index)
 };
 
 template <int SHAPE> struct TupleTraits;
@@ -172,9 +175,30 @@ __device__ __forceinline__ bool str_equal(const uint32_t* __restrict__ s, int wi
     for (int k = len; k < width; ++k) if (s[k] != 0u) return false;
     return true;
 }
+// VarChar::contains -> wcsstr (reference include/varchar.h:84-89): the field ends at its first NUL
+__device__ __forceinline__ bool str_contains(const uint32_t* __restrict__ s, int width, const uint32_t* val, int len) {
+    if (len == 0) return true;
+    int n = 0;
+    while (n < width && s[n] != 0u) ++n;
+    for (int st = 0; st + len <= n; ++st) {
+        if (s[st] != val[0]) continue;
+        int k = 1;
+        while (k < len && s[st + k] == val[k]) ++k;
+        if (k == len) return true;
+    }
+    return false;
+}
+// the string predicate of a filter: mode 0 `==`, 1 `!=`, 2 substring
+__device__ __forceinline__ bool str_pred(const uint32_t* __restrict__ s, int width, const uint32_t* val, int len, int mode) {
+    if (mode == 2) return str_contains(s, width, val, len);
+    return str_equal(s, width, val, len) != (mode != 0);
+}
+
+__device__ __forceinline__ int64_t table_find(const DevTable& t, int64_t key, uint64_t cap_mask);
 
 // contains(key): exact bitmap when the table has one, else open-addressing probe.
 __device__ __forceinline__ bool table_contains(const DevTable& t, int64_t key, uint64_t cap_mask) {
+    if (t.bm && t.bm_shift) return table_find(t, key, cap_mask) >= 0;
     if (t.bm) {
         if (key < t.bm_lo || key > t.bm_hi) return false;
         uint64_t off = (uint64_t)(key - t.bm_lo);
@@ -198,11 +222,13 @@ __device__ __forceinline__ int64_t direct_rank(const DevTable& t, uint64_t off, 
 }
 __device__ __forceinline__ int64_t table_find(const DevTable& t, int64_t key, uint64_t cap_mask) {
     if (t.bm) {
-        if (key < t.bm_lo || key > t.bm_hi) return -1;
-        const uint64_t off = (uint64_t)(key - t.bm_lo);
+        const int64_t v = t.bm_shift ? (int64_t)((uint64_t)key >> 32) : key;
+        if (v < t.bm_lo || v > t.bm_hi) return -1;
+        const uint64_t off = (uint64_t)(v - t.bm_lo);
         const uint32_t word = t.bm[off >> 5];
         if (!((word >> (off & 31)) & 1u)) return -1;
-        return direct_rank(t, off, word);
+        if (t.bitmap_only) return 0;
+        if (t.bm_shift == 0) return direct_rank(t, off, word);
     }
     if (key == EMPTY_KEY) return t.rowref[cap_mask + 1] != NO_ROW ? (int64_t)(cap_mask + 1) : -1;
     uint64_t h = hash_key(key) & cap_mask;
@@ -214,8 +240,8 @@ __device__ __forceinline__ int64_t table_find(const DevTable& t, int64_t key, ui
     }
 }
 // stage index of the entry at an index position
-__device__ __forceinline__ uint32_t table_ref(const DevTable& t, int64_t pos) { return t.bm ? t.dense_ref[pos] : t.rowref[pos]; }
-__device__ __forceinline__ uint32_t* table_ref_ptr(const DevTable& t, int64_t pos) { return t.bm ? &t.dense_ref[pos] : &t.rowref[pos]; }
+__device__ __forceinline__ bool table_is_direct(const DevTable& t) { return t.bm && t.bm_shift == 0; }
+__device__ __forceinline__ uint32_t table_ref(const DevTable& t, int64_t pos) { return table_is_direct(t) ? t.dense_ref[pos] : t.rowref[pos]; }
 
 // ---- row filter on a pair of rows --------------------------------------------------------------
 // Integer and double range predicates with their own columns, plus the optional string equality.
@@ -253,8 +279,8 @@ __device__ __forceinline__ void filter_eval(const DevFilter& f, const FilterRegs
     }
     if (cfg_ns<FC>(f.ns)) {
         int64_t r0 = r < nrows ? r : nrows - 1, r1 = r + 1 < nrows ? r + 1 : nrows - 1;
-        if (p0) p0 = str_equal(f.sc + r0 * f.swidth, f.swidth, f.sval, f.slen) != (f.sneg != 0);
-        if (p1) p1 = str_equal(f.sc + r1 * f.swidth, f.swidth, f.sval, f.slen) != (f.sneg != 0);
+        if (p0) p0 = str_pred(f.sc + r0 * f.swidth, f.swidth, f.sval, f.slen, f.sneg);
+        if (p1) p1 = str_pred(f.sc + r1 * f.swidth, f.swidth, f.sval, f.slen, f.sneg);
     }
 }
 
@@ -712,9 +738,10 @@ struct DevStage {
     int64_t seg_rows;                     // rows per wave segment (multiple of 128 * STAGE_BATCH)
     uint32_t* shits;                      // [nrows] entry hit counters, zeroed while staging
     double* sacc;                         // [nrows*4] entry accumulators, zeroed while staging (or null)
-    uint32_t* bm;                         // exact key bitmap to fill, or null
+    uint32_t* bm;                         // key bitmap to fill, or null
     int64_t bm_lo, bm_hi;
     TableHeader* hdr;
+    int32_t bm_shift, _pad2;              // 32: the bitmap covers the high part of a composite key
 };
 
 template <class FC>
@@ -724,7 +751,7 @@ __device__ __forceinline__ bool row_passes(const DevFilter& f, const DevProbes& 
     for (int i = 0; i < SDQH_MAX_IPRED; ++i) if (i < cfg_ni<FC>(f.ni) && p) { int64_t v = f.ic[i][r]; p = (v >= f.ilo[i]) & (v <= f.ihi[i]); }
 #pragma unroll
     for (int i = 0; i < SDQH_MAX_FPRED; ++i) if (i < cfg_nf<FC>(f.nf) && p) { double v = f.fc[i][r]; p = (v >= f.flo[i]) & (v <= f.fhi[i]); }
-    if (cfg_ns<FC>(f.ns) && p) p = str_equal(f.sc + r * f.swidth, f.swidth, f.sval, f.slen) != (f.sneg != 0);
+    if (cfg_ns<FC>(f.ns) && p) p = str_pred(f.sc + r * f.swidth, f.swidth, f.sval, f.slen, f.sneg);
 #pragma unroll
     for (int i = 0; i < SDQH_MAX_PROBE; ++i) if (i < cfg_np<FC>(pr.n) && p) p = table_contains(pr.table[i], pr.key[i][r], cap_masks[i]);
     return p;
@@ -775,8 +802,8 @@ __device__ __forceinline__ void pass_pairs(const DevFilter& f, const DevProbes& 
     if (cfg_ns<FC>(f.ns)) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            if (p[j][0]) p[j][0] = str_equal(f.sc + r[j] * f.swidth, f.swidth, f.sval, f.slen) != (f.sneg != 0);
-            if (p[j][1]) p[j][1] = str_equal(f.sc + (r[j] + 1) * f.swidth, f.swidth, f.sval, f.slen) != (f.sneg != 0);
+            if (p[j][0]) p[j][0] = str_pred(f.sc + r[j] * f.swidth, f.swidth, f.sval, f.slen, f.sneg);
+            if (p[j][1]) p[j][1] = str_pred(f.sc + (r[j] + 1) * f.swidth, f.swidth, f.sval, f.slen, f.sneg);
         }
     }
 #pragma unroll
@@ -805,9 +832,12 @@ __device__ __forceinline__ void stage_store(const DevStage& st, int64_t pos, int
     for (int q = 0; q < MAX_STAGE_COLS; ++q) if (q < cfg_npay<NPAY>(st.npay)) st.pay[q][pos] = pay[q];
     if (st.shits) st.shits[pos] = 0;
     if (st.sacc) { double4 z = {0, 0, 0, 0}; *reinterpret_cast<double4*>(st.sacc + pos * 4) = z; }
-    if (st.bm && key >= st.bm_lo && key <= st.bm_hi) {
-        const uint64_t off = (uint64_t)(key - st.bm_lo);
-        atomicOr(&st.bm[off >> 5], 1u << (off & 31));     // fire and forget; duplicates show up as distinct < staged (k_rank_blocks)
+    if (st.bm) {
+        const int64_t v = st.bm_shift ? (int64_t)((uint64_t)key >> 32) : key;
+        if (v >= st.bm_lo && v <= st.bm_hi) {
+            const uint64_t off = (uint64_t)(v - st.bm_lo);
+            atomicOr(&st.bm[off >> 5], 1u << (off & 31));     // fire and forget; duplicates show up as distinct < staged (k_rank_blocks)
+        }
     }
 }
 
@@ -817,7 +847,7 @@ __global__ __launch_bounds__(TPB) void k_stage(DevFilter f, DevProbes pr, DevSta
     if (seg >= st.nseg) return;
     uint64_t cap_masks[SDQH_MAX_PROBE] = {0, 0};
 #pragma unroll
-    for (int i = 0; i < SDQH_MAX_PROBE; ++i) if (i < cfg_np<FC>(pr.n) && pr.table[i].hdr && !pr.table[i].bm) cap_masks[i] = pr.table[i].hdr->cap_mask;
+    for (int i = 0; i < SDQH_MAX_PROBE; ++i) if (i < cfg_np<FC>(pr.n) && pr.table[i].hdr && !table_is_direct(pr.table[i]) && !pr.table[i].bitmap_only) cap_masks[i] = pr.table[i].hdr->cap_mask;
     const int64_t begin = (int64_t)seg * st.seg_rows;
     int64_t end = begin + st.seg_rows; if (end > nrows) end = nrows;
     const int lane = lane_id();
@@ -1034,7 +1064,7 @@ __device__ __forceinline__ bool stage_row_owns(const DevStage& st, const DevTabl
 __global__ __launch_bounds__(TPB) void k_count(DevStage st, DevTable t) {
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
     if (seg >= st.nseg) return;
-    const uint64_t mask = t.bm ? 0 : t.hdr->cap_mask;
+    const uint64_t mask = table_is_direct(t) ? 0 : t.hdr->cap_mask;
     const int64_t base = (int64_t)seg * st.seg_rows;
     const uint32_t count = st.seg_count[seg];
     unsigned long long n = 0;
@@ -1095,7 +1125,7 @@ __global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevT
     int64_t* q_key = s_key[threadIdx.x / WAVE];
     int qn = 0;                                                       // wave-uniform queue length
     const uint64_t lt = lanemask_lt();
-    const uint64_t mask = tb.bm ? 0 : tb.hdr->cap_mask;
+    const uint64_t mask = table_is_direct(tb) ? 0 : tb.hdr->cap_mask;
     DevProbes none; none.n = 0;
     const uint64_t nomask[SDQH_MAX_PROBE] = {0, 0};
     const int64_t full = nrows / TILE;
@@ -1110,7 +1140,7 @@ __global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevT
             p[u][0] = p[u][1] = true;
         }
         pass_pairs<PU, FC, false>(f, none, r, nrows, nomask, p);
-        if (tb.bm) {                                                   // direct layout: all bitmap words requested before any is tested
+        if (table_is_direct(tb)) {                                     // direct layout: all bitmap words requested before any is tested
             uint32_t w[PU][2];
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
@@ -1143,6 +1173,271 @@ __global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevT
             if (row_passes<FC>(f, none, r, nomask)) { const int64_t pos = table_find(tb, keycol[r], mask); if (pos >= 0) probe_add<SHAPE>(f, t, tb, pos, r); }
     }
     if (qn > 0) probe_drain<SHAPE>(f, t, tb, mask, q_row, q_key, 0, qn);
+}
+
+// =================================================================================================
+// Multi-join chains (Q5, Q9): lookups whose keys / payloads / operands come from earlier lookups.
+// The streaming part of both kernels is the usual one — first predicate and, when it is a plain
+// column, the first lookup's key streamed with 16-byte loads, pre-filtered by that table's bitmap —
+// and everything that follows a surviving row (the chain of dependent lookups, payload gathers,
+// key packing) runs in the converged drain of an LDS candidate queue, one row per lane.
+// =================================================================================================
+struct DevSource { int32_t kind, lookup, field, _pad; const int64_t* col; };
+struct DevLookup { DevTable table; int32_t nkey, _pad; DevSource key[2]; };
+struct DevLookups { DevLookup l[SDQH_MAX_LOOKUP]; int32_t n, _pad; };
+
+__device__ __forceinline__ uint32_t pick3(const uint32_t (&e)[SDQH_MAX_LOOKUP], int i) { return i == 0 ? e[0] : (i == 1 ? e[1] : e[2]); }
+
+__device__ __forceinline__ int64_t source_value(const DevSource& s, const DevLookups& L, int64_t r, const uint32_t (&ent)[SDQH_MAX_LOOKUP]) {
+    if (s.kind == SDQH_SRC_COLUMN) return s.col[r];
+    const DevTable& t = s.lookup == 0 ? L.l[0].table : (s.lookup == 1 ? L.l[1].table : L.l[2].table);
+    const int64_t* pay = s.field == 0 ? t.pay[0] : (s.field == 1 ? t.pay[1] : (s.field == 2 ? t.pay[2] : t.pay[3]));
+    const int64_t v = pay[pick3(ent, s.lookup)];
+    return s.kind == SDQH_SRC_LOOKUP_YEAR ? v / 10000 : v;
+}
+// 0 = ok; 1 = a part of a composite key is outside [0, 2^32)
+__device__ __forceinline__ int pack_parts(int nkey, int64_t p0, int64_t p1, int64_t& key) {
+    if (nkey == 1) { key = p0; return 0; }
+    if (p0 < 0 || p0 > 0xFFFFFFFFll || p1 < 0 || p1 > 0xFFFFFFFFll) return 1;
+    key = (int64_t)(((uint64_t)p0 << 32) | (uint64_t)p1);
+    return 0;
+}
+// run every lookup for row r: 1 = all hit (ent filled with stage rows), 0 = a miss, -1 = bad key part
+__device__ __forceinline__ int run_lookups(const DevLookups& L, int64_t r, uint32_t (&ent)[SDQH_MAX_LOOKUP]) {
+#pragma unroll 1
+    for (int l = 0; l < L.n; ++l) {
+        const DevLookup& lk = L.l[l];
+        const int64_t p0 = source_value(lk.key[0], L, r, ent);
+        const int64_t p1 = lk.nkey == 2 ? source_value(lk.key[1], L, r, ent) : 0;
+        int64_t key;
+        if (pack_parts(lk.nkey, p0, p1, key)) return -1;
+        const uint64_t mask = (table_is_direct(lk.table) || lk.table.bitmap_only) ? 0 : lk.table.hdr->cap_mask;
+        const int64_t pos = table_find(lk.table, key, mask);
+        if (pos < 0) return 0;
+        ent[l] = lk.table.bitmap_only ? 0u : table_ref(lk.table, pos);
+    }
+    return 1;
+}
+// cheap test on the first lookup alone, usable before queueing: false = the row cannot survive
+__device__ __forceinline__ bool first_lookup_may_hit(const DevLookups& L, int64_t part0) {
+    const DevTable& t = L.l[0].table;
+    if (!t.bm) return true;
+    if (L.l[0].nkey == 2 && t.bm_shift == 0) return true;
+    if (part0 < t.bm_lo || part0 > t.bm_hi) return false;
+    const uint64_t off = (uint64_t)(part0 - t.bm_lo);
+    return (t.bm[off >> 5] >> (off & 31)) & 1u;
+}
+
+constexpr int LQ_CAP = 192;                                           // 63 left over + 128 appended per pair step
+
+struct DevBuildSpec {                                                 // what a surviving row contributes to the build
+    int32_t nkey, npay;
+    DevSource key[2];
+    DevSource pay[SDQH_MAX_PAYLOAD];
+};
+
+// Generalised staging: one wave per row segment (row order is kept: the queue is drained from the
+// front), survivors compacted into the segment's stage slice exactly as k_stage does.
+template <class FC>
+__global__ __launch_bounds__(TPB) void k_build_lookup(DevFilter f, DevLookups L, DevBuildSpec spec, DevStage st, int64_t nrows, int* __restrict__ flags) {
+    __shared__ int64_t s_row[TPB / WAVE][LQ_CAP];
+    const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
+    if (seg >= st.nseg) return;
+    int64_t* q_row = s_row[threadIdx.x / WAVE];
+    const int64_t begin = (int64_t)seg * st.seg_rows;
+    int64_t end = begin + st.seg_rows; if (end > nrows) end = nrows;
+    const int lane = lane_id();
+    const uint64_t lt = lanemask_lt();
+    constexpr int64_t BATCH_ROWS = WAVE * ROWS_PER_LOAD;
+    const bool eager0 = L.n > 0 && L.l[0].key[0].kind == SDQH_SRC_COLUMN;
+    DevProbes none; none.n = 0;
+    const uint64_t nomask[SDQH_MAX_PROBE] = {0, 0};
+    int64_t out = begin;
+    int qn = 0;
+    bool bad = false;
+    auto drain = [&](int count) {                                      // rows q_row[0..count) one per lane, in row order
+        bool keep = false; int64_t key = 0; int64_t pay[MAX_STAGE_COLS] = {0, 0, 0, 0, 0};
+        if (lane < count) {
+            const int64_t r = q_row[lane];
+            uint32_t ent[SDQH_MAX_LOOKUP] = {0, 0, 0};
+            const int h = run_lookups(L, r, ent);
+            if (h < 0) bad = true;
+            if (h > 0) {
+                const int64_t p0 = source_value(spec.key[0], L, r, ent);
+                const int64_t p1 = spec.nkey == 2 ? source_value(spec.key[1], L, r, ent) : 0;
+                if (pack_parts(spec.nkey, p0, p1, key)) bad = true;
+                else {
+                    keep = true;
+#pragma unroll
+                    for (int q = 0; q < SDQH_MAX_PAYLOAD; ++q) if (q < spec.npay) pay[q] = source_value(spec.pay[q], L, r, ent);
+                }
+            }
+        }
+        const uint64_t b = __ballot(keep);
+        if (keep) stage_store<-1>(st, out + __popcll(b & lt), key, pay);
+        out += __popcll(b);
+    };
+    for (int64_t b = begin; b < end; b += BATCH_ROWS) {
+        const int64_t r = b + (int64_t)lane * ROWS_PER_LOAD;
+        bool p[1][2];
+        int64_t rr[1] = {r};
+        if (b + BATCH_ROWS <= end) {
+            p[0][0] = p[0][1] = true;
+            Pair<int64_t> k0 = {0, 0};
+            if (eager0) k0 = load2<false>(L.l[0].key[0].col, r, nrows);
+            pass_pairs<1, FC, false>(f, none, rr, nrows, nomask, p);
+            if (eager0) { p[0][0] = p[0][0] && first_lookup_may_hit(L, k0.x); p[0][1] = p[0][1] && first_lookup_may_hit(L, k0.y); }
+        } else {
+            p[0][0] = r < end; p[0][1] = r + 1 < end;
+            if (p[0][0]) p[0][0] = row_passes<FC>(f, none, r, nomask);
+            if (p[0][1]) p[0][1] = row_passes<FC>(f, none, r + 1, nomask);
+        }
+        const uint64_t b0 = __ballot(p[0][0]), b1 = __ballot(p[0][1]);
+        if (b0 | b1) {
+            const int at = qn + __popcll(b0 & lt) + __popcll(b1 & lt);
+            if (p[0][0]) q_row[at] = r;
+            if (p[0][1]) q_row[at + (p[0][0] ? 1 : 0)] = r + 1;
+            qn += __popcll(b0) + __popcll(b1);
+            while (qn >= WAVE) {                                       // drain the FRONT 64 (row order), shift the rest down
+                drain(WAVE);
+                const int left = qn - WAVE;
+                int64_t a0 = 0, a1 = 0;
+                if (lane < left) a0 = q_row[WAVE + lane];
+                if (lane + WAVE < left) a1 = q_row[2 * WAVE + lane];
+                if (lane < left) q_row[lane] = a0;
+                if (lane + WAVE < left) q_row[WAVE + lane] = a1;
+                qn = left;
+            }
+        }
+    }
+    if (qn > 0) drain(qn);
+    if (lane == 0) st.seg_count[seg] = (uint32_t)(out - begin);
+    if (__ballot(bad) && lane == 0) atomicOr(flags, 2);
+}
+
+// ---- lookups -> group-by over a small domain ------------------------------------------------------------
+constexpr int LG_SLOTS = 2 * SDQH_MAX_LOOKUP_GROUPS;                  // LDS / global group table slots (load factor <= 1/2)
+
+struct DevAggSpec {
+    int32_t nkeys, shape;
+    DevSource key[SDQH_MAX_GROUPKEYS];
+    DevSource op[4];
+};
+
+// claim-or-find with a hashed start; -1 when the table is full
+__device__ __forceinline__ int group_slot(unsigned long long* keys, unsigned long long key, bool global) {
+    int h = (int)(mix64(key) & (LG_SLOTS - 1));
+#pragma unroll 1
+    for (int i = 0; i < LG_SLOTS; ++i) {
+        unsigned long long cur = global ? __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : keys[h];
+        if (cur == EMPTY_GROUP) cur = atomicCAS(&keys[h], (unsigned long long)EMPTY_GROUP, key);
+        if (cur == EMPTY_GROUP || cur == key) return h;
+        h = (h + 1) & (LG_SLOTS - 1);
+    }
+    return -1;
+}
+
+template <int SHAPE, class FC>
+__global__ __launch_bounds__(TPB) void k_lookup_agg(DevFilter f, DevLookups L, DevAggSpec spec, int64_t nrows,
+                                                    unsigned long long* __restrict__ gkeys, double* __restrict__ pacc,
+                                                    int64_t* __restrict__ pcnt, int* __restrict__ flags) {
+    constexpr int NOPS = TupleTraits<SHAPE>::NOPS, NV = TupleTraits<SHAPE>::NV;
+    constexpr int PU = 2, TILE = TPB * ROWS_PER_LOAD * PU;
+    __shared__ unsigned long long s_keys[LG_SLOTS];
+    __shared__ double s_acc[LG_SLOTS][4];
+    __shared__ unsigned long long s_cnt[LG_SLOTS];
+    __shared__ int64_t s_row[TPB / WAVE][LQ_CAP];
+    __shared__ int s_map[LG_SLOTS];
+    __shared__ int s_flags[1];
+    for (int i = threadIdx.x; i < LG_SLOTS; i += TPB) { s_keys[i] = EMPTY_GROUP; s_cnt[i] = 0; for (int k = 0; k < 4; ++k) s_acc[i][k] = 0.0; s_map[i] = -1; }
+    if (threadIdx.x == 0) s_flags[0] = 0;
+    __syncthreads();
+    int64_t* q_row = s_row[threadIdx.x / WAVE];
+    const int lane = lane_id();
+    const uint64_t lt = lanemask_lt();
+    const bool eager0 = L.n > 0 && L.l[0].key[0].kind == SDQH_SRC_COLUMN;
+    DevProbes none; none.n = 0;
+    const uint64_t nomask[SDQH_MAX_PROBE] = {0, 0};
+    int qn = 0;
+    auto drain = [&](int first, int count) {
+        if (lane >= count) return;
+        const int64_t r = q_row[first + lane];
+        uint32_t ent[SDQH_MAX_LOOKUP] = {0, 0, 0};
+        const int h = run_lookups(L, r, ent);
+        if (h < 0) atomicOr(&s_flags[0], 2);
+        if (h <= 0) return;
+        const int64_t k0 = source_value(spec.key[0], L, r, ent);
+        const int64_t k1 = spec.nkeys == 2 ? source_value(spec.key[1], L, r, ent) : 0;
+        if (k0 < 0 || k0 > 0xFFFFFFFEll || k1 < 0 || k1 > 0xFFFFFFFEll) { atomicOr(&s_flags[0], 2); return; }
+        double x[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < NOPS; ++j) x[j] = __longlong_as_double(source_value(spec.op[j], L, r, ent));
+        if (!operand_ranges<NOPS>(f, x)) return;
+        tuple_eval<SHAPE>(x, o);
+        const int slot = group_slot(s_keys, (unsigned long long)k0 | ((unsigned long long)k1 << 32), false);
+        if (slot < 0) { atomicOr(&s_flags[0], 1); return; }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) atomicAdd(&s_acc[slot][k], o[k]);
+        atomicAdd(&s_cnt[slot], 1ull);
+    };
+    const int64_t full = nrows / TILE;
+    for (int64_t tile = blockIdx.x; tile < full; tile += gridDim.x) {
+        int64_t r[PU];
+        Pair<int64_t> k0[PU];
+        bool p[PU][2];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            r[u] = tile * TILE + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
+            if (eager0) k0[u] = load2<false>(L.l[0].key[0].col, r[u], nrows);
+            p[u][0] = p[u][1] = true;
+        }
+        pass_pairs<PU, FC, false>(f, none, r, nrows, nomask, p);
+        if (eager0) {
+#pragma unroll
+            for (int u = 0; u < PU; ++u) { p[u][0] = p[u][0] && first_lookup_may_hit(L, k0[u].x); p[u][1] = p[u][1] && first_lookup_may_hit(L, k0[u].y); }
+        }
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const uint64_t b0 = __ballot(p[u][0]), b1 = __ballot(p[u][1]);
+            if (b0 | b1) {
+                const int at = qn + __popcll(b0 & lt) + __popcll(b1 & lt);
+                if (p[u][0]) q_row[at] = r[u];
+                if (p[u][1]) q_row[at + (p[u][0] ? 1 : 0)] = r[u] + 1;
+                qn += __popcll(b0) + __popcll(b1);
+                while (qn >= WAVE) { qn -= WAVE; drain(qn, WAVE); }
+            }
+        }
+    }
+    if (full * TILE < nrows && blockIdx.x == (unsigned)(full % gridDim.x)) {
+        for (int64_t r0 = full * TILE; r0 < nrows; r0 += TPB) {           // tail: one row per lane through the same queue
+            const int64_t r = r0 + threadIdx.x;
+            const bool pass = r < nrows && row_passes<FC>(f, none, r, nomask);
+            const uint64_t b = __ballot(pass);
+            if (b) {
+                if (pass) q_row[qn + __popcll(b & lt)] = r;
+                qn += __popcll(b);
+                while (qn >= WAVE) { qn -= WAVE; drain(qn, WAVE); }
+            }
+        }
+    }
+    if (qn > 0) drain(0, qn);
+    __syncthreads();
+    // publish this workgroup's groups at GLOBAL slots (slot-major partials, as k_groupby_*)
+    for (int i = threadIdx.x; i < LG_SLOTS; i += TPB) {
+        if (s_keys[i] != EMPTY_GROUP && s_cnt[i] > 0) {
+            const int gs = group_slot(gkeys, s_keys[i], true);
+            if (gs < 0) atomicOr(&s_flags[0], 1); else s_map[gs] = i;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LG_SLOTS; i += TPB) {
+        const int l = s_map[i];
+        const size_t e = (size_t)i * gridDim.x + blockIdx.x;
+        pcnt[e] = l >= 0 ? (int64_t)s_cnt[l] : 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pacc[e * 4 + k] = l >= 0 ? s_acc[l][k] : 0.0;
+    }
+    if (threadIdx.x == 0 && s_flags[0]) atomicOr(flags, s_flags[0]);
 }
 
 // =================================================================================================
@@ -1185,7 +1480,7 @@ __device__ __forceinline__ uint32_t compact_segment(const DevTable& t, const Dev
                                                     int seg, uint64_t out0, uint32_t* q_idx, uint32_t* q_hits) {
     const int lane = lane_id();
     const bool dups = t.hdr->has_dups != 0;
-    const uint64_t mask = (t.bm || !dups) ? 0 : t.hdr->cap_mask;
+    const uint64_t mask = (table_is_direct(t) || !dups) ? 0 : t.hdr->cap_mask;
     const int64_t base = (int64_t)seg * st.seg_rows;
     const uint32_t count = st.seg_count[seg];
     const uint64_t lt = lanemask_lt();

@@ -76,6 +76,7 @@ class Engine:
         self._columns = {}         # id(ndarray) -> (ndarray, abi.Column)
         self.resident_bytes = 0
         self.generation = 0        # bumped by clear(): prepared plans bound to freed columns are rebuilt
+        self._rowids = {}
 
     def close(self):
         self.clear()
@@ -97,6 +98,14 @@ class Engine:
         self._columns[id(arr)] = (arr, col)
         self.resident_bytes += arr.nbytes
         return col
+
+    def rowid_column(self, nrows):
+        """Resident int64 column 0..nrows-1: how a string column travels as a payload or a group key
+        (the device carries the row reference; the text is looked up when the result is built)."""
+        arr = self._rowids.get(nrows)
+        if arr is None:
+            arr = self._rowids[nrows] = np.arange(nrows, dtype=np.int64)
+        return self.column(arr)
 
     def adopt(self, arr, col):
         """Register an already-resident column for a host array identity (multi-GPU exchange buffers)."""
@@ -130,6 +139,20 @@ class BuiltTable:
         self.payload_dtypes = row_arrays    # payload index -> numpy dtype
         self.agg = None                     # set by a fused probe-aggregate: (key_fields, val_names, tuple shape)
         self.agg_spec = None
+        self.decoders = {}                  # payload index -> string array (the payload holds row references into it)
+        self.key_parts = None               # composite key: [part names]; the stored key is (part0 << 32) | part1
+
+    def field_index(self, field, op):
+        """Payload index of a value field (None = the scalar value)."""
+        if field is None:
+            if len(self.val_fields) != 1:
+                raise UnsupportedQuery("line %d: the looked-up value is a record; name a field" % op.lineno)
+            src = self.val_fields[0][1]
+        else:
+            src = dict(self.val_fields).get(field)
+        if src is None or src == "key":
+            raise UnsupportedQuery("line %d: looked-up field '%s' is not a payload of the table" % (op.lineno, field))
+        return src
 
 
 # ---- predicate / tuple lowering ----------------------------------------------------------------
@@ -145,7 +168,11 @@ def _build_filter(eng, op, htab, conds):
             lookups.append(c.lookup)
             continue
         if isinstance(c, StrIn):
-            raise UnsupportedQuery("line %d: substring predicates are not in the HIP backend's vocabulary yet" % op.lineno)
+            arr = htab.array(c.col.name, op)
+            if arr.dtype.kind != "U":
+                raise UnsupportedQuery("line %d: `in` needs a string column" % op.lineno)
+            spreds.append((eng.column(arr), c.needle, 2))
+            continue
         if not isinstance(c, Cmp):
             raise UnsupportedQuery("line %d: unsupported condition %r" % (op.lineno, c))
         left, right, sym = c.left, c.right, c.op
@@ -265,10 +292,228 @@ def _resolve_probes(op, env, specs):
     return probes
 
 
+def _walk_lookups(e, found):
+    """Collect the Lookup nodes an expression depends on, in first-use order."""
+    if isinstance(e, Lookup):
+        _walk_lookups(e.key, found)
+        if repr(e) not in [repr(x) for x in found]:
+            found.append(e)
+    elif isinstance(e, PayloadField):
+        _walk_lookups(e.lookup, found)
+    elif isinstance(e, RecordCons):
+        for _, x in e.fields:
+            _walk_lookups(x, found)
+    elif isinstance(e, Bin):
+        _walk_lookups(e.left, found); _walk_lookups(e.right, found)
+    elif isinstance(e, Call):
+        for x in e.args:
+            _walk_lookups(x, found)
+
+
+class _Src:
+    """A value source resolved at run time into an abi source spec (+ how to decode it for the result)."""
+    def __init__(self, kind, col=None, lookup=None, field=None, year=False, decoder=None, dtype=np.int64):
+        self.kind, self.col, self.lookup, self.field, self.year, self.decoder, self.dtype = kind, col, lookup, field, year, decoder, dtype
+
+    def spec(self, op, env, lookups):
+        if self.kind == "col":
+            return abi.src_col(self.col)
+        bt = env[lookups[self.lookup].dict_name]
+        return abi.src_lookup(self.lookup, bt.field_index(self.field, op), self.year)
+
+    def decode_info(self, op, env, lookups):
+        """(decoder string array or None, numpy dtype) — a payload inherits them from its table."""
+        if self.kind == "col":
+            return self.decoder, self.dtype
+        bt = env[lookups[self.lookup].dict_name]
+        idx = bt.field_index(self.field, op)
+        return (None, np.dtype(np.int64)) if self.year else (bt.decoders.get(idx), np.dtype(bt.payload_dtypes[idx]))
+
+
+def _source_of(eng, op, htab, e, lookups):
+    idx_of = lambda lk: [repr(x) for x in lookups].index(repr(lk))      # noqa: E731
+    if isinstance(e, Col):
+        arr = htab.array(e.name, op)
+        if arr.dtype.kind == "U":
+            return _Src("col", col=eng.rowid_column(htab.nrows), decoder=arr, dtype=np.dtype(np.int64))
+        return _Src("col", col=eng.column(arr), dtype=arr.dtype)
+    if isinstance(e, PayloadField):
+        return _Src("lookup", lookup=idx_of(e.lookup), field=e.field)
+    if isinstance(e, Lookup):
+        return _Src("lookup", lookup=idx_of(e), field=None)
+    if isinstance(e, Call) and e.fn == "extractYear" and isinstance(e.args[0], (PayloadField, Lookup)):
+        inner = e.args[0]
+        lk, field = (inner.lookup, inner.field) if isinstance(inner, PayloadField) else (inner, None)
+        return _Src("lookup", lookup=idx_of(lk), field=field, year=True)
+    raise UnsupportedQuery("line %d: unsupported value source %r" % (op.lineno, e))
+
+
+def _decode_column(values, decoder, dtype):
+    if decoder is not None:
+        return decoder[values]
+    return values.view(dtype) if np.dtype(dtype) != values.dtype else values
+
+
+def _prepare_general(eng, op, htab, flt, contains_lookups):
+    """Loops with derived keys / payloads / operands (multi-join chains): sdqh_build and
+    sdqh_lookup_aggregate with explicit lookup steps."""
+    ctx = eng.ctx
+    n = htab.nrows
+    lookups = []
+    if op.probe is not None:
+        _walk_lookups(op.probe, lookups)
+    for lk in contains_lookups:
+        _walk_lookups(lk, lookups)
+    _walk_lookups(op.key, lookups)
+    if not (isinstance(op.val, Const)):
+        _walk_lookups(op.val, lookups)
+    if len(lookups) > abi.MAX_LOOKUP:
+        raise UnsupportedQuery("line %d: more than %d lookups in one loop" % (op.lineno, abi.MAX_LOOKUP))
+    lookup_keys = []
+    for lk in lookups:
+        parts = [x for _, x in lk.key.fields] if isinstance(lk.key, RecordCons) else [lk.key]
+        if len(parts) > 2:
+            raise UnsupportedQuery("line %d: lookup keys of more than two fields are not supported" % op.lineno)
+        lookup_keys.append([_source_of(eng, op, htab, x, lookups) for x in parts])
+
+    def resolve_lookups(env):
+        out = []
+        for lk, keys in zip(lookups, lookup_keys):
+            bt = env.get(lk.dict_name)
+            if not isinstance(bt, BuiltTable):
+                raise UnsupportedQuery("line %d: '%s' is not a built table" % (op.lineno, lk.dict_name))
+            if (bt.key_parts is not None) != (len(keys) == 2):
+                raise UnsupportedQuery("line %d: lookup into '%s' does not match its key shape" % (op.lineno, lk.dict_name))
+            out.append((bt.table, [k.spec(op, env, lookups) for k in keys]))
+        return out
+
+    key_is_record = isinstance(op.key, RecordCons)
+    key_fields = op.key.fields if key_is_record else [(None, op.key)]
+    if len(key_fields) > 2:
+        raise UnsupportedQuery("line %d: keys of more than two fields are not supported" % op.lineno)
+    key_srcs = [_source_of(eng, op, htab, e, lookups) for _, e in key_fields]
+
+    if op.unique:
+        val_is_record = isinstance(op.val, RecordCons)
+        vfields = op.val.fields if val_is_record else ([] if (isinstance(op.val, Const) and op.val.value is True) else [(None, op.val)])
+        if len(vfields) > abi.MAX_PAYLOAD:
+            raise UnsupportedQuery("line %d: more than %d payload fields" % (op.lineno, abi.MAX_PAYLOAD))
+        pay_srcs = [_source_of(eng, op, htab, e, lookups) for _, e in vfields]
+        key_names = [fname or (e.name if isinstance(e, Col) else "key%d" % i) for i, (fname, e) in enumerate(key_fields)]
+
+        def run_build(env):
+            table = ctx.build(n, flt, resolve_lookups(env), [k.spec(op, env, lookups) for k in key_srcs],
+                              [p.spec(op, env, lookups) for p in pay_srcs], accumulate=False)
+            infos = [p.decode_info(op, env, lookups) for p in pay_srcs]
+            bt = BuiltTable(table, key_names[0], key_is_record, [(fname, i) for i, (fname, _) in enumerate(vfields)], val_is_record,
+                            [info[1] for info in infos])
+            bt.decoders = {i: info[0] for i, info in enumerate(infos) if info[0] is not None}
+            if len(key_srcs) == 2:
+                bt.key_parts = key_names
+            bt.key_decoder = key_srcs[0].decode_info(op, env, lookups)[0] if len(key_srcs) == 1 else None
+            return bt
+        return run_build
+
+    if op.kind != "dict":
+        raise UnsupportedQuery("line %d: scalar sums with lookups are not supported yet" % op.lineno)
+    # aggregation over a small group domain with lookups
+    val_is_record = isinstance(op.val, RecordCons)
+    names = [nm for nm, _ in op.val.fields] if val_is_record else [None]
+    exprs = [e for _, e in op.val.fields] if val_is_record else [op.val]
+    slots = []
+    try:
+        shape = ";".join(e.shape(slots) for e in exprs)
+    except NotImplementedError:
+        raise UnsupportedQuery("line %d: value expression outside the backend's vocabulary: %r" % (op.lineno, op.val))
+    if shape not in TUPLE_SHAPES:
+        raise UnsupportedQuery("line %d: value tuple shape '%s' is not in the HIP backend's vocabulary %s" % (op.lineno, shape, sorted(TUPLE_SHAPES)))
+    abi_shape, count_idx = TUPLE_SHAPES[shape]
+    operand_srcs = []
+    for slot in slots:
+        if slot[0] == "col":
+            arr = htab.array(slot[1], op)
+            if arr.dtype != np.float64:
+                raise UnsupportedQuery("line %d: value operand '%s' must be a float column" % (op.lineno, slot[1]))
+            operand_srcs.append(_Src("col", col=eng.column(arr), dtype=arr.dtype))
+        else:                                                   # ("payload", dict_name, key repr, field)
+            j = [repr(x.key) + x.dict_name for x in lookups].index(slot[2] + slot[1])
+            operand_srcs.append(_Src("lookup", lookup=j, field=slot[3]))
+
+    def run_lookup_aggregate(env):
+        for o in operand_srcs:
+            if o.kind == "lookup" and np.dtype(o.decode_info(op, env, lookups)[1]) != np.float64:
+                raise UnsupportedQuery("line %d: a looked-up value operand must be a float payload" % op.lineno)
+        try:
+            keys, vals, cnts = ctx.lookup_aggregate(n, flt, resolve_lookups(env), [k.spec(op, env, lookups) for k in key_srcs], abi_shape,
+                                                    [o.spec(op, env, lookups) for o in operand_srcs])
+        except abi.SdqhError as exc:
+            if exc.code == abi.ERR_OVERFLOW:
+                raise UnsupportedQuery("line %d: more than %d groups" % (op.lineno, abi.MAX_LOOKUP_GROUPS))
+            raise
+        kf = []
+        for i, (fname, e) in enumerate(key_fields):
+            decoder, dtype = key_srcs[i].decode_info(op, env, lookups)
+            kf.append((fname or "key%d" % i, _decode_column(keys[:, i].copy(), decoder, dtype)))
+        vf = _value_arrays(names, count_idx, [vals[:, j] for j in range(vals.shape[1])], cnts)
+        return _merge_equal_keys(DictResult(kf, vf, key_is_record, val_is_record))
+    return run_lookup_aggregate
+
+
+def _merge_equal_keys(d):
+    """Groups were formed on row references; two references may decode to the same text.  Fold them."""
+    n = d.size()
+    if n < 2:
+        return d
+    rows = list(zip(*[a.tolist() for _, a in d.key_fields]))
+    if len(set(rows)) == n:
+        return d
+    order, merged = [], {}
+    for i, k in enumerate(rows):
+        if k not in merged:
+            merged[k] = [a[i] for _, a in d.val_fields]; order.append(k)
+        else:
+            merged[k] = [x + a[i] for x, (_, a) in zip(merged[k], d.val_fields)]
+    kf = [(nm, np.array([k[j] for k in order], dtype=a.dtype)) for j, (nm, a) in enumerate(d.key_fields)]
+    vf = [(nm, np.array([merged[k][j] for k in order], dtype=a.dtype)) for j, (nm, a) in enumerate(d.val_fields)]
+    return DictResult(kf, vf, d.key_is_record, d.val_is_record)
+
+
+def _is_simple(op, htab, lookups):
+    """True when the specialised single-purpose calls cover the loop (all keys / payloads / operands are
+    plain columns of the scanned row, lookups keyed by one int column)."""
+    def plain(e):
+        return isinstance(e, Col) and htab.cols.get(e.name) is not None and htab.cols[e.name].dtype.kind != "U"
+    for lk in ([op.probe] if op.probe else []) + list(lookups):
+        if not (isinstance(lk.key, Col) and plain(lk.key)):
+            return False
+    if op.kind == "scalar":
+        return not lookups and op.probe is None
+    key_fields = op.key.fields if isinstance(op.key, RecordCons) else [(None, op.key)]
+    if op.unique:
+        if len(key_fields) != 1 or not plain(key_fields[0][1]):
+            return False
+        vals = op.val.fields if isinstance(op.val, RecordCons) else ([] if isinstance(op.val, Const) else [(None, op.val)])
+        return all(plain(e) for _, e in vals)
+    found = []
+    _walk_lookups(op.val, found)
+    if found:
+        return False
+    if op.probe is None and not lookups:
+        return all(isinstance(e, Col) for _, e in key_fields)
+    if op.probe is not None and not lookups:           # fused probe-aggregate: the group is the matched entry
+        pk = op.probe.key.name
+        has_key = any(isinstance(e, Col) and e.name == pk for _, e in key_fields)
+        rest = all((isinstance(e, Col) and e.name == pk) or (isinstance(e, PayloadField) and repr(e.lookup) == repr(op.probe)) for _, e in key_fields)
+        return has_key and rest
+    return False
+
+
 def _prepare_scan(eng, op, htab, accumulate_into):
     ctx = eng.ctx
     flt, lookups = _build_filter(eng, op, htab, op.conds)
     n = htab.nrows
+    if not _is_simple(op, htab, lookups):
+        return _prepare_general(eng, op, htab, flt, lookups)
 
     if op.kind == "scalar":
         if lookups or op.probe:
@@ -413,8 +658,13 @@ def _materialize(eng, value, env):
     if isinstance(value, BuiltTable):
         n = eng.ctx.table_compact_count(value.table, 0)
         keys, payload, _, _ = eng.ctx.table_compact(value.table, 0, n, want_values=False)
-        vf = [(fname, keys if src == "key" else payload[src].view(value.payload_dtypes[src])) for fname, src in value.val_fields]
-        return DictResult([(value.key_name, keys)], vf, value.key_is_record, value.val_is_record)
+        vf = [(fname, keys if src == "key" else _decode_column(payload[src], value.decoders.get(src), value.payload_dtypes[src]))
+              for fname, src in value.val_fields]
+        if value.key_parts is not None:
+            kf = [(value.key_parts[0], keys >> 32), (value.key_parts[1], keys & 0xFFFFFFFF)]
+        else:
+            kf = [(value.key_name, _decode_column(keys, getattr(value, "key_decoder", None), np.int64))]
+        return DictResult(kf, vf, value.key_is_record, value.val_is_record)
     raise UnsupportedQuery("cannot materialise %r" % (value,))
 
 

@@ -16,7 +16,7 @@ from sdqlpy_amd import tpch_queries as Q
 
 pytestmark = pytest.mark.gpu
 REL = 1e-10
-SUPPORTED = ("q1", "q3", "q6")
+SUPPORTED = ("q1", "q3", "q5", "q6", "q9")
 
 
 @pytest.fixture(scope="module")
@@ -50,7 +50,7 @@ def test_golden_vectors(hip_engine, golden):
             helpers.check_against_golden(res, case["results"][q], REL, "%s/%s/hip" % (case["name"], q))
             n += 1
         hip_engine.clear()
-    assert n >= 15
+    assert n >= 21
 
 
 def test_decorated_queries_through_public_api(golden):
@@ -68,7 +68,7 @@ def test_decorated_queries_through_public_api(golden):
 def test_against_oracle_sf1(hip_engine, oracle_engine, sf):
     """Same seeded inputs through both implementations of the ABI at SF=1 (the reference's own
     CPU-runnable scale, BASELINE.json configs[0])."""
-    db = tpch.generate(sf, tables=("lineitem", "customer", "orders"), columns=tpch.columns_for(SUPPORTED))
+    db = tpch.generate(sf, tables=sorted(tpch.columns_for(SUPPORTED)), columns=tpch.columns_for(SUPPORTED))
     for q in SUPPORTED:
         got = helpers.run_query(hip_engine, q, db)
         want = helpers.run_query(oracle_engine, q, db)
@@ -94,7 +94,7 @@ def test_q1_q6_are_bit_reproducible(hip_engine):
 def test_row_order_invariance(hip_engine):
     """Size-independent property: a permutation of the probe-side rows leaves every result
     unchanged (exactly for counts and keys, to rounding for sums)."""
-    db = tpch.generate(0.05, tables=("lineitem", "customer", "orders"), columns=tpch.columns_for(SUPPORTED))
+    db = tpch.generate(0.05, tables=sorted(tpch.columns_for(SUPPORTED)), columns=tpch.columns_for(SUPPORTED))
     li = db["lineitem"].getContainer()
     perm = np.random.default_rng(7).permutation(len(li["data"][0]))
     shuffled = dict(db)
@@ -110,7 +110,7 @@ def test_row_order_invariance(hip_engine):
 
 def test_ragged_sizes(hip_engine, oracle_engine):
     """Row counts around the tile (1024), sub-tile (512), wave (64) and pair (2) boundaries, and empty."""
-    base = tpch.generate(0.002, tables=("lineitem", "customer", "orders"), columns=tpch.columns_for(SUPPORTED))
+    base = tpch.generate(0.002, tables=sorted(tpch.columns_for(SUPPORTED)), columns=tpch.columns_for(SUPPORTED))
     li = base["lineitem"].getContainer()
     total = len(li["data"][0])
     for n in [0, 1, 2, 3, 63, 64, 65, 127, 129, 511, 513, 1023, 1024, 1025, 2047, 2049, 4097, total]:
@@ -231,7 +231,7 @@ def test_distributed_runner_world1_nccl(hip_lib, golden):
         db = helpers.case_db(case)
         for part in ("auto", "hash"):
             runner = sdist.DistributedRunner(eng, 0, 1, partition=part)
-            for q in SUPPORTED:
+            for q in ("q1", "q3", "q6"):
                 helpers.check_against_golden(runner.run(q, db), case["results"][q], REL, "dist1/%s/%s" % (part, q))
     finally:
         eng.close()

@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--sf", type=float, default=10.0, help="scale factor PER GPU")
-    ap.add_argument("--queries", default="q1,q3")
+    ap.add_argument("--queries", default="q1,q3,q5")
     ap.add_argument("--profile-iters", type=int, default=5, help="extra untimed passes with per-kernel HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="use the distributed plan even with one rank (exercises the RCCL path)")
@@ -49,12 +49,15 @@ def algorithmic_bytes(q, rows):
         return 48 * rows["customer"] + 32 * rows["orders"] + 32 * rows["lineitem"]
     if q == "q6":
         return 32 * rows["lineitem"]
+    if q == "q5":
+        return 16 * rows["customer"] + 24 * rows["orders"] + 16 * rows["supplier"] + 32 * rows["lineitem"]
     raise KeyError(q)
 
 
 def scanned_rows(q, rows):
-    return {"q1": rows["lineitem"], "q6": rows["lineitem"],
-            "q3": rows["lineitem"] + rows["customer"] + rows["orders"]}[q]
+    return {"q1": lambda: rows["lineitem"], "q6": lambda: rows["lineitem"],
+            "q3": lambda: rows["lineitem"] + rows["customer"] + rows["orders"],
+            "q5": lambda: rows["lineitem"] + rows["customer"] + rows["orders"] + rows["supplier"] + rows["nation"] + rows["region"]}[q]()
 
 
 def main():
@@ -66,6 +69,8 @@ def main():
     os.dup2(2, 1)
     queries = [q for q in args.queries.split(",") if q]
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if (world > 1 or args.force_dist) and "q5" in queries:
+        queries.remove("q5")        # the multi-GPU runner covers q1 / q3 / q6 this round
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -128,15 +133,21 @@ def main():
     eng.ctx.set_profiling(2)
     barrier()
     t_begin = time.perf_counter()
+    marks = []                                           # (query, number of launches recorded so far)
     for _ in range(args.steps):
         for q in queries:
             tq = time.perf_counter()
             run_query(q)
             per_query_ms[q] += (time.perf_counter() - tq) * 1e3
+            marks.append((q, eng.ctx.lib.sdqh_profile_count(eng.ctx.handle)))
     barrier()
     elapsed = time.perf_counter() - t_begin
     launches = eng.ctx.profile()                         # [(kernel, ms)] of every launch in the timed region
     eng.ctx.set_profiling(0)
+    launch_log, at = [], 0
+    for q, upto in marks:
+        launch_log += [(q, name, ms) for name, ms in launches[at:upto]]
+        at = upto
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -150,25 +161,26 @@ def main():
     value = total_rows_per_step * args.steps / elapsed
 
     kstat = {}
-    for name, ms in launches:
+    for q, name, ms in launch_log:
+        name = "%s:%s" % (q, name)
         tot, n = kstat.get(name, (0.0, 0))
         kstat[name] = (tot + ms, n + 1)
     kernels = {name: {"launches_per_step": n / args.steps, "avg_launch_ms": tot / n, "ms_per_step": tot / args.steps}
                for name, (tot, n) in kstat.items()}
-    q_of = lambda k: "q1" if k.startswith("k_groupby") else ("q6" if k in ("k_scan_sum", "k_sum_partials") else "q3")   # noqa: E731
-    device_ms = {q: sum(v["ms_per_step"] for k, v in kernels.items() if q_of(k) == q) for q in queries}
+    # kernels are attributed to the query that was running when they were launched
+    device_ms = {q: sum(ms for qq, _, ms in launch_log if qq == q) / args.steps for q in queries}
 
     out = None
     if rank == 0:
         dom_q = "q1" if "q1" in queries else queries[0]
-        dom_name = {"q1": "k_groupby_reg", "q3": "k_probe_agg", "q6": "k_scan_sum"}[dom_q]
+        dom_name = dom_q + ":" + {"q1": "k_groupby_reg", "q3": "k_probe_agg", "q6": "k_scan_sum", "q5": "k_lookup_agg"}[dom_q]
         roofline = None
         if dom_name in kernels:
             dom_ms = kernels[dom_name]["avg_launch_ms"]
-            per_launch_bytes = {"q1": 48 * rows["lineitem"], "q3": 32 * rows["lineitem"], "q6": 32 * rows["lineitem"]}[dom_q]
+            per_launch_bytes = {"q1": 48 * rows["lineitem"], "q3": 32 * rows["lineitem"], "q6": 32 * rows["lineitem"], "q5": 32 * rows["lineitem"]}[dom_q]
             achieved = per_launch_bytes / (dom_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom_name, rows),
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom_name.split(":")[1], rows),
                         "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": round(dom_ms, 4),
                         "launches_timed": int(kernels[dom_name]["launches_per_step"] * args.steps)}
         per_query = {}
@@ -182,10 +194,10 @@ def main():
                             "algorithmic_GBs_kernels": round(ab / (device_ms[q] * 1e-3) / 1e9, 1) if device_ms[q] else None,
                             "roofline_frac_kernels": round(ab / (device_ms[q] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if device_ms[q] else None}
         out = {
-            "metric": "tpch_q1_q3_sf10_rows_per_sec", "value": round(value, 1), "unit": "rows/s",
+            "metric": "tpch_" + "_".join(queries) + "_sf%g_rows_per_sec" % args.sf, "value": round(value, 1), "unit": "rows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "TPCH " + "+".join(q.upper() for q in queries) + " SF=%g per GPU (q1 = BASELINE configs[1], q3 = configs[2])" % args.sf,
+            "config": {"workload": "TPCH " + "+".join(q.upper() for q in queries) + " SF=%g per GPU (BASELINE metric: Q1/Q3/Q5 at SF=10; q1 = configs[1], q3 = configs[2])" % args.sf,
                        "sf_per_gpu": args.sf, "rows_per_gpu": rows, "partitioning": "none" if not use_dist else "q1 row-sharded; q3 partitioned on o_orderkey (%s), RCCL all-to-all; exchanged rows %s"
                                        % (runner.last_partitioning, runner.exchanged_rows)},
             "ms_per_query": per_query,

@@ -699,6 +699,49 @@ static int ensure_index(sdqh_ctx* ctx, sdqh_table* tb) {
     return SDQH_OK;
 }
 
+// Dense layout (the reference's `dense(N, key)` arrays, ...generator_par.py:191-224, sized from the
+// data instead of a hard-coded N): the build table's own columns are the stage, the index is one
+// array over the key range.
+static int build_dense(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int npayload, const sdqh_column* const* payload,
+                       int64_t lo, int64_t hi, sdqh_table** out) {
+    sdqh_table* tb = new sdqh_table();
+    tb->npay = npayload; tb->nrows_build = nrows; tb->index_built = true;
+    DevStage& st = tb->stage;
+    std::memset(&st, 0, sizeof(st));
+    const int64_t target_segs = (int64_t)ctx->num_cu * ctx->opt_stage_waves_per_cu;
+    const int64_t gran = (int64_t)WAVE * ROWS_PER_LOAD * 8;
+    int64_t seg_rows = (nrows + target_segs - 1) / target_segs;
+    st.seg_rows = std::max<int64_t>(gran, (seg_rows + gran - 1) / gran * gran);
+    st.nseg = (int32_t)std::max<int64_t>(1, (nrows + st.seg_rows - 1) / st.seg_rows);
+    st.npay = npayload;
+    st.key = const_cast<int64_t*>(static_cast<const int64_t*>(key->data));           // aliases, never written
+    for (int p = 0; p < npayload; ++p) st.pay[p] = const_cast<int64_t*>(static_cast<const int64_t*>(payload[p]->data));
+    const uint64_t range = (uint64_t)(hi - lo) + 1;
+    st.seg_count = static_cast<uint32_t*>(table_alloc(ctx, tb, (size_t)st.nseg * 4 + 64));
+    st.shits = static_cast<uint32_t*>(table_alloc(ctx, tb, (size_t)nrows * 4 + 64));
+    tb->hdr = static_cast<TableHeader*>(table_alloc(ctx, tb, sizeof(TableHeader)));
+    uint32_t* arr = static_cast<uint32_t*>(table_alloc(ctx, tb, range * 4 + 64));
+    if (!st.seg_count || !st.shits || !tb->hdr || !arr) { table_release(ctx, tb); delete tb; return fail(ctx, SDQH_ERR_NOMEM, "dense build: out of device memory"); }
+    st.hdr = tb->hdr;
+    tb->dev.hdr = tb->hdr; tb->dev.shits = st.shits; tb->dev.bm_lo = lo; tb->dev.bm_hi = hi; tb->dev.dense_arr = arr;
+    for (int p = 0; p < npayload; ++p) tb->dev.pay[p] = st.pay[p];
+    const int64_t* kc = static_cast<const int64_t*>(key->data);
+    const unsigned grid = (unsigned)std::min<int64_t>((nrows + TPB - 1) / TPB, (int64_t)ctx->num_cu * 8);
+    call_begin(ctx);
+    HIP_TRY(ctx, hipMemsetAsync(tb->hdr, 0, sizeof(TableHeader), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(st.shits, 0, (size_t)nrows * 4, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(arr, 0xFF, range * 4, ctx->stream));
+    LAUNCH(ctx, "k_full_counts", k_full_counts, (unsigned)((st.nseg + TPB - 1) / TPB), st.seg_count, st.nseg, st.seg_rows, nrows);
+    LAUNCH(ctx, "k_dense_fill", k_dense_fill, grid, kc, nrows, lo, arr);
+    LAUNCH(ctx, "k_dense_verify", k_dense_verify, grid, kc, nrows, lo, arr, tb->hdr);
+    LAUNCH(ctx, "k_dense_fixup", k_dense_fixup, grid, kc, nrows, lo, arr, tb->hdr);
+    call_end(ctx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { table_release(ctx, tb); delete tb; return fail(ctx, SDQH_ERR_DEVICE, std::string("dense build launch: ") + hipGetErrorString(e)); }
+    *out = tb;
+    return SDQH_OK;
+}
+
 int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nprobes, const sdqh_probe* probes,
                            const sdqh_column* key, int npayload, const sdqh_column* const* payload, int accumulate, sdqh_table** out) {
     if (!ctx || nrows < 0 || !out || npayload < 0 || npayload > SDQH_MAX_PAYLOAD) return fail(ctx, SDQH_ERR_INVALID, "hash_build_unique: bad arguments");
@@ -721,6 +764,11 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
             want_bm = range <= (1ull << 31) && range <= 64ull * (uint64_t)std::max<int64_t>(nrows, 1024);
         }
     }
+    // dense layout: an unfiltered, unprobed build on a dense key range indexes the source columns in place
+    const bool unfiltered = f.ni == 0 && f.nf == 0 && f.ns == 0 && nprobes == 0;
+    if (unfiltered && !accumulate && nrows > 0 && ctx->opt_direct_index && hi >= lo && lo > INT64_MIN / 2 && hi < INT64_MAX / 2 &&
+        (uint64_t)(hi - lo) + 1 <= 16ull * (uint64_t)nrows && (uint64_t)(hi - lo) + 1 <= (1ull << 30))
+        return build_dense(ctx, nrows, key, npayload, payload, lo, hi, out);
     sdqh_table* tb = new sdqh_table();
     tb->npay = npayload; tb->accumulate = accumulate != 0; tb->nrows_build = nrows;
     int rc = setup_stage(ctx, tb, nrows, key, npayload, payload);
@@ -943,6 +991,7 @@ int sdqh_build(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nloo
     std::memset(&spec, 0, sizeof(spec));
     bool composite = nkey == 2;
     if (int rc = make_filter(ctx, nrows, filter, nullptr, &f)) return rc;
+    call_begin(ctx);                                   // the lookups may have to build their tables' indexes first
     if (int rc = make_lookups(ctx, nrows, nlookups, lookups, &L, &composite)) return rc;
     spec.nkey = nkey; spec.npay = npayload;
     for (int k = 0; k < nkey; ++k) if (int rc = make_source(ctx, key[k], nrows, nlookups, lookups, nlookups, "build key", &spec.key[k])) return rc;
@@ -980,7 +1029,6 @@ int sdqh_build(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nloo
         tb->dev.bm = tb->bm; tb->dev.bm_lo = lo; tb->dev.bm_hi = hi; tb->dev.bitmap_only = 0; tb->dev.bm_shift = nkey == 2 ? 32 : 0;
         for (int p = 0; p < npayload; ++p) tb->dev.pay[p] = tb->stage.pay[p];
         tb->stage.bm = tb->bm; tb->stage.bm_lo = lo; tb->stage.bm_hi = hi; tb->stage.hdr = tb->hdr; tb->stage.bm_shift = nkey == 2 ? 32 : 0;
-        call_begin(ctx);
         const unsigned seg_grid = (unsigned)((tb->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
         hipError_t e = hipMemsetAsync(tb->hdr, 0, sizeof(TableHeader), ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(flags, 0, 8, ctx->stream);
@@ -1014,6 +1062,7 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
     std::memset(&spec, 0, sizeof(spec));
     bool composite = false;
     if (int rc = make_filter(ctx, nrows, filter, nullptr, &f)) return rc;
+    call_begin(ctx);
     if (int rc = make_lookups(ctx, nrows, nlookups, lookups, &L, &composite)) return rc;
     spec.nkeys = nkeys; spec.shape = tuple_shape;
     for (int k = 0; k < nkeys; ++k) if (int rc = make_source(ctx, keys[k], nrows, nlookups, lookups, nlookups, "group key", &spec.key[k])) return rc;
@@ -1036,7 +1085,6 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
             if (!blob) return fail(ctx, SDQH_ERR_NOMEM, "lookup_aggregate: out of device memory");
             double* pacc = reinterpret_cast<double*>(blob);
             int64_t* pcnt = reinterpret_cast<int64_t*>(blob + nslots * 32);
-            call_begin(ctx);
             hipError_t e = hipMemsetAsync(r_keys, 0xFF, LG_SLOTS * 8, ctx->stream);
             if (e == hipSuccess) e = hipMemsetAsync(r_flags, 0, 8, ctx->stream);
             if (e != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e));

@@ -64,6 +64,9 @@ struct TableHeader {          // lives in device memory: sized on the device, no
 //           bm[w]       bit per key                         (set while staging)
 //           wprefix[w]  set bits before word w inside its 2048-word block, bprefix[b] before block b
 //           dense_ref[rank(key)] = stage index                (plain stores: no atomics at all)
+//   dense   (an unfiltered build on a dense key range — the reference's `dense(N, key)` hint,
+//           ...generator_par.py:191-224): dense_arr[key - lo] = build row, the source columns
+//           themselves serve as the stage (nothing is copied), a lookup is one load
 //   hash    (any int64 keys): open addressing, linear probing, capacity = pow2 >= 2 * entries
 //           keys[s]     the key, EMPTY_KEY if free        (reset by k_clear)
 //           rowref[s]   stage index of the owning row     (written by the claimer)
@@ -87,6 +90,7 @@ struct DevTable {
     int32_t bm_shift;         // 0: bm is exact over the key (direct layout); 32: composite key, bm covers
                               //    the high part only (a pre-filter in front of the hash layout)
     const int64_t* pay[SDQH_MAX_PAYLOAD];   // stage payload arrays (entry payload by stage index)
+    uint32_t* dense_arr;      // dense layout: dense_arr[key - bm_lo] = build row (NO_ROW if absent), bm == null
 };
 
 template <int SHAPE> struct TupleTraits;
@@ -198,7 +202,7 @@ __device__ __forceinline__ int64_t table_find(const DevTable& t, int64_t key, ui
 
 // contains(key): exact bitmap when the table has one, else open-addressing probe.
 __device__ __forceinline__ bool table_contains(const DevTable& t, int64_t key, uint64_t cap_mask) {
-    if (t.bm && t.bm_shift) return table_find(t, key, cap_mask) >= 0;
+    if (t.dense_arr || (t.bm && t.bm_shift)) return table_find(t, key, cap_mask) >= 0;
     if (t.bm) {
         if (key < t.bm_lo || key > t.bm_hi) return false;
         uint64_t off = (uint64_t)(key - t.bm_lo);
@@ -221,6 +225,11 @@ __device__ __forceinline__ int64_t direct_rank(const DevTable& t, uint64_t off, 
     return (int64_t)t.bprefix[w / RANK_BLOCK_WORDS] + (int64_t)t.wprefix[w] + __popc(word & ((1u << (off & 31)) - 1u));
 }
 __device__ __forceinline__ int64_t table_find(const DevTable& t, int64_t key, uint64_t cap_mask) {
+    if (t.dense_arr) {
+        if (key < t.bm_lo || key > t.bm_hi) return -1;
+        const uint32_t ref = t.dense_arr[key - t.bm_lo];
+        return ref == NO_ROW ? -1 : (int64_t)ref;
+    }
     if (t.bm) {
         const int64_t v = t.bm_shift ? (int64_t)((uint64_t)key >> 32) : key;
         if (v < t.bm_lo || v > t.bm_hi) return -1;
@@ -240,8 +249,8 @@ __device__ __forceinline__ int64_t table_find(const DevTable& t, int64_t key, ui
     }
 }
 // stage index of the entry at an index position
-__device__ __forceinline__ bool table_is_direct(const DevTable& t) { return t.bm && t.bm_shift == 0; }
-__device__ __forceinline__ uint32_t table_ref(const DevTable& t, int64_t pos) { return table_is_direct(t) ? t.dense_ref[pos] : t.rowref[pos]; }
+__device__ __forceinline__ bool table_is_direct(const DevTable& t) { return t.dense_arr || (t.bm && t.bm_shift == 0); }     // no hash slots: cap_mask unused
+__device__ __forceinline__ uint32_t table_ref(const DevTable& t, int64_t pos) { return t.dense_arr ? (uint32_t)pos : (t.bm && t.bm_shift == 0 ? t.dense_ref[pos] : t.rowref[pos]); }
 
 // ---- row filter on a pair of rows --------------------------------------------------------------
 // Integer and double range predicates with their own columns, plus the optional string equality.
@@ -1012,6 +1021,29 @@ __global__ __launch_bounds__(TPB) void k_insert_direct(DevStage st, DevTable t) 
     }
 }
 
+// ---- dense layout ---------------------------------------------------------------------------------------
+// every row of the build table is an entry: segment counts are simply the segment lengths
+__global__ __launch_bounds__(TPB) void k_full_counts(uint32_t* __restrict__ seg_count, int nseg, int64_t seg_rows, int64_t nrows) {
+    const int s = blockIdx.x * TPB + threadIdx.x;
+    if (s < nseg) { int64_t b = (int64_t)s * seg_rows, e = b + seg_rows; if (e > nrows) e = nrows; seg_count[s] = (uint32_t)(e - b); }
+}
+// dense_arr[key - lo] = row: plain stores (a unique key writes its own cell; sorted keys coalesce)
+__global__ __launch_bounds__(TPB) void k_dense_fill(const int64_t* __restrict__ key, int64_t nrows, int64_t lo, uint32_t* __restrict__ arr) {
+    for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * TPB) arr[key[r] - lo] = (uint32_t)r;
+}
+// a row that does not find itself in its cell lost to a duplicate key
+__global__ __launch_bounds__(TPB) void k_dense_verify(const int64_t* __restrict__ key, int64_t nrows, int64_t lo, const uint32_t* __restrict__ arr, TableHeader* __restrict__ hdr) {
+    bool dup = false;
+    for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * TPB) dup |= arr[key[r] - lo] != (uint32_t)r;
+    if (__ballot(dup) && lane_id() == 0) hdr->has_dups = 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) hdr->staged = (uint64_t)nrows;
+}
+// only with duplicates: the lowest row wins
+__global__ __launch_bounds__(TPB) void k_dense_fixup(const int64_t* __restrict__ key, int64_t nrows, int64_t lo, uint32_t* __restrict__ arr, const TableHeader* __restrict__ hdr) {
+    if (hdr->has_dups == 0) return;
+    for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * TPB) atomicMin(&arr[key[r] - lo], (uint32_t)r);
+}
+
 __global__ __launch_bounds__(TPB) void k_insert(DevStage st, DevTable t) {
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
     if (seg >= st.nseg) return;
@@ -1140,7 +1172,7 @@ __global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevT
             p[u][0] = p[u][1] = true;
         }
         pass_pairs<PU, FC, false>(f, none, r, nrows, nomask, p);
-        if (table_is_direct(tb)) {                                     // direct layout: all bitmap words requested before any is tested
+        if (tb.bm && tb.bm_shift == 0) {                               // direct layout: all bitmap words requested before any is tested
             uint32_t w[PU][2];
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
@@ -1203,18 +1235,21 @@ __device__ __forceinline__ int pack_parts(int nkey, int64_t p0, int64_t p1, int6
     return 0;
 }
 // run every lookup for row r: 1 = all hit (ent filled with stage rows), 0 = a miss, -1 = bad key part
+// (fully unrolled: `ent` is indexed statically and stays in registers)
 __device__ __forceinline__ int run_lookups(const DevLookups& L, int64_t r, uint32_t (&ent)[SDQH_MAX_LOOKUP]) {
-#pragma unroll 1
-    for (int l = 0; l < L.n; ++l) {
-        const DevLookup& lk = L.l[l];
-        const int64_t p0 = source_value(lk.key[0], L, r, ent);
-        const int64_t p1 = lk.nkey == 2 ? source_value(lk.key[1], L, r, ent) : 0;
-        int64_t key;
-        if (pack_parts(lk.nkey, p0, p1, key)) return -1;
-        const uint64_t mask = (table_is_direct(lk.table) || lk.table.bitmap_only) ? 0 : lk.table.hdr->cap_mask;
-        const int64_t pos = table_find(lk.table, key, mask);
-        if (pos < 0) return 0;
-        ent[l] = lk.table.bitmap_only ? 0u : table_ref(lk.table, pos);
+#pragma unroll
+    for (int l = 0; l < SDQH_MAX_LOOKUP; ++l) {
+        if (l < L.n) {
+            const DevLookup& lk = L.l[l];
+            const int64_t p0 = source_value(lk.key[0], L, r, ent);
+            const int64_t p1 = lk.nkey == 2 ? source_value(lk.key[1], L, r, ent) : 0;
+            int64_t key;
+            if (pack_parts(lk.nkey, p0, p1, key)) return -1;
+            const uint64_t mask = (table_is_direct(lk.table) || lk.table.bitmap_only) ? 0 : lk.table.hdr->cap_mask;
+            const int64_t pos = table_find(lk.table, key, mask);
+            if (pos < 0) return 0;
+            ent[l] = lk.table.bitmap_only ? 0u : table_ref(lk.table, pos);
+        }
     }
     return 1;
 }
@@ -1344,12 +1379,13 @@ __global__ __launch_bounds__(TPB) void k_lookup_agg(DevFilter f, DevLookups L, D
     constexpr int NOPS = TupleTraits<SHAPE>::NOPS, NV = TupleTraits<SHAPE>::NV;
     constexpr int PU = 2, TILE = TPB * ROWS_PER_LOAD * PU;
     __shared__ unsigned long long s_keys[LG_SLOTS];
-    __shared__ double s_acc[LG_SLOTS][4];
+    constexpr int NVS = NV > 0 ? NV : 1;
+    __shared__ double s_acc[LG_SLOTS][NVS];
     __shared__ unsigned long long s_cnt[LG_SLOTS];
     __shared__ int64_t s_row[TPB / WAVE][LQ_CAP];
     __shared__ int s_map[LG_SLOTS];
     __shared__ int s_flags[1];
-    for (int i = threadIdx.x; i < LG_SLOTS; i += TPB) { s_keys[i] = EMPTY_GROUP; s_cnt[i] = 0; for (int k = 0; k < 4; ++k) s_acc[i][k] = 0.0; s_map[i] = -1; }
+    for (int i = threadIdx.x; i < LG_SLOTS; i += TPB) { s_keys[i] = EMPTY_GROUP; s_cnt[i] = 0; for (int k = 0; k < NVS; ++k) s_acc[i][k] = 0.0; s_map[i] = -1; }
     if (threadIdx.x == 0) s_flags[0] = 0;
     __syncthreads();
     int64_t* q_row = s_row[threadIdx.x / WAVE];
@@ -1435,7 +1471,7 @@ __global__ __launch_bounds__(TPB) void k_lookup_agg(DevFilter f, DevLookups L, D
         const size_t e = (size_t)i * gridDim.x + blockIdx.x;
         pcnt[e] = l >= 0 ? (int64_t)s_cnt[l] : 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pacc[e * 4 + k] = l >= 0 ? s_acc[l][k] : 0.0;
+        for (int k = 0; k < 4; ++k) pacc[e * 4 + k] = (l >= 0 && k < NV) ? s_acc[l][k < NVS ? k : 0] : 0.0;
     }
     if (threadIdx.x == 0 && s_flags[0]) atomicOr(flags, s_flags[0]);
 }

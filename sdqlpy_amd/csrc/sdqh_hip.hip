@@ -56,13 +56,16 @@ struct sdqh_ctx {
     int threads = 1;
     std::vector<std::pair<const void*, int>> occupancy;   // kernel -> resident workgroups per CU
     // tuning knobs (sdqh_set_option)
-    int opt_resident_cap = 6;
+    int opt_resident_cap = 6;                      // probing kernels (latency chains to hide)
+    int opt_resident_stream = 2;                   // pure streaming kernels: fewer concurrent DRAM streams run faster (tools/microbench_q1.hip)
     int opt_probe_unroll = PROBE_UNROLL;
     int opt_stage_batch = STAGE_BATCH;
     int opt_stage_eager = 1;
     int opt_stage_eager_pay = 1;
     int opt_stage_waves_per_cu = 16;
     int opt_direct_index = 1;
+    int opt_groupby_regs = 0;                      // 0 = adaptive (4 when the last run of these key columns had <= 4 groups), 4, 8
+    const void* g4_hint[SDQH_MAX_GROUPKEYS] = {nullptr, nullptr};
 };
 
 struct sdqh_column {
@@ -267,9 +270,10 @@ int resident_per_cu(sdqh_ctx* ctx, K kernel) {
     return std::min(n, ctx->opt_resident_cap);
 }
 template <class K>
-unsigned stream_grid(sdqh_ctx* ctx, K kernel, int64_t nrows, int tile_rows = TILE_ROWS) {
+unsigned stream_grid(sdqh_ctx* ctx, K kernel, int64_t nrows, int tile_rows = TILE_ROWS, bool pure_stream = false) {
     int64_t tiles = (nrows + tile_rows - 1) / tile_rows;
-    int64_t cap = (int64_t)ctx->num_cu * resident_per_cu(ctx, kernel);
+    if (pure_stream) tiles = (tiles + SDQH_TILE_CHUNK - 1) / SDQH_TILE_CHUNK;
+    int64_t cap = (int64_t)ctx->num_cu * (pure_stream ? std::min(resident_per_cu(ctx, kernel), ctx->opt_resident_stream) : resident_per_cu(ctx, kernel));
     return (unsigned)std::max<int64_t>(1, std::min(tiles, cap));
 }
 
@@ -408,12 +412,14 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return SDQH_ERR_INVALID;
     const std::string n(name);
     if (n == "resident_cap" && value >= 1 && value <= 8) ctx->opt_resident_cap = (int)value;
+    else if (n == "resident_stream" && value >= 1 && value <= 8) ctx->opt_resident_stream = (int)value;
     else if (n == "probe_unroll" && (value == 1 || value == 2 || value == 4)) ctx->opt_probe_unroll = (int)value;
     else if (n == "stage_batch" && (value == 2 || value == 4 || value == 8)) ctx->opt_stage_batch = (int)value;
     else if (n == "stage_eager" && (value == 0 || value == 1)) ctx->opt_stage_eager = (int)value;
     else if (n == "stage_eager_pay" && (value == 0 || value == 1)) ctx->opt_stage_eager_pay = (int)value;
     else if (n == "stage_waves_per_cu" && value >= 4 && value <= 64) ctx->opt_stage_waves_per_cu = (int)value;
     else if (n == "direct_index" && (value == 0 || value == 1)) ctx->opt_direct_index = (int)value;
+    else if (n == "groupby_regs" && (value == 0 || value == 4 || value == 8)) ctx->opt_groupby_regs = (int)value;
     else return fail(ctx, SDQH_ERR_INVALID, "set_option: unknown option or value out of range: " + n);
     return SDQH_OK;
 }
@@ -503,7 +509,7 @@ int sdqh_scan_filter_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter
     int lrc = with_shape(ctx, tuple->shape, [&](auto S) {
         return with_scan_filter(f, [&](auto FC) {
             auto kern = k_scan_sum<decltype(S)::value, decltype(FC)>;
-            grid = stream_grid(ctx, kern, nrows);
+            grid = stream_grid(ctx, kern, nrows, TILE_ROWS, true);
             partial = static_cast<double*>(pool_alloc(ctx, (size_t)grid * 5 * sizeof(double)));
             if (!partial) return fail(ctx, SDQH_ERR_NOMEM, "scan_filter_sum: out of device memory");
             call_begin(ctx);
@@ -558,8 +564,12 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
     const size_t rbytes = GMAX * 48 + 8;
     int rc = SDQH_OK;
     const char* h = static_cast<const char*>(ctx->result_host);
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        const int G = use_lds ? GMAX : GREG;
+    // register kernel with 4 groups when these key columns produced <= 4 groups last time (or on
+    // request), else 8; more than that falls back to the LDS kernel
+    bool g4 = ctx->opt_groupby_regs == 4;
+    if (ctx->opt_groupby_regs == 0) { g4 = true; for (int k = 0; k < SDQH_MAX_GROUPKEYS; ++k) g4 = g4 && ctx->g4_hint[k] == (k < nkeys ? gk.col[k] : nullptr); }
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        const int G = use_lds ? GMAX : (g4 ? 4 : GREG);
         unsigned grid = 1;
         char* blob = nullptr;
         double* pacc = nullptr; int64_t* pcnt = nullptr;
@@ -585,8 +595,15 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
             }
             return with_scan_filter(f, [&](auto FC) {
                 return with_group_keys(gk, [&](auto KC) {
+                    if (g4) {
+                        auto kern = k_groupby_reg<SH, 4, decltype(FC), decltype(KC)>;
+                        grid = stream_grid(ctx, kern, nrows, TILE_ROWS, true);
+                        if (int c = carve()) return c;
+                        LAUNCH(ctx, "k_groupby_reg", kern, grid, f, t, gk, nrows, r_keys, pacc, pcnt, r_flags);
+                        return SDQH_OK;
+                    }
                     auto kern = k_groupby_reg<SH, GREG, decltype(FC), decltype(KC)>;
-                    grid = stream_grid(ctx, kern, nrows);
+                    grid = stream_grid(ctx, kern, nrows, TILE_ROWS, true);
                     if (int c = carve()) return c;
                     LAUNCH(ctx, "k_groupby_reg", kern, grid, f, t, gk, nrows, r_keys, pacc, pcnt, r_flags);
                     return SDQH_OK;
@@ -603,6 +620,7 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
         const int flags = *reinterpret_cast<const int*>(h + GMAX * 48 + 4);
         if (flags & 2) { rc = fail(ctx, SDQH_ERR_UNSUPPORTED, "groupby_small: I64 key outside [0, 2^32-2]"); break; }
         if (flags & 1) {
+            if (!use_lds && g4) { g4 = false; for (int k = 0; k < SDQH_MAX_GROUPKEYS; ++k) ctx->g4_hint[k] = nullptr; continue; }
             if (!use_lds) { use_lds = true; for (int k = 0; k < SDQH_MAX_GROUPKEYS; ++k) ctx->lds_hint[k] = k < nkeys ? gk.col[k] : nullptr; continue; }
             *out_ngroups = GMAX + 1;
             rc = fail(ctx, SDQH_ERR_OVERFLOW, "groupby_small: more groups than max_groups");
@@ -618,6 +636,7 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
     for (int g = 0; g < GMAX; ++g) if (hk[g] != EMPTY_GROUP && hc[g] > 0) order[ng++] = g;
     std::sort(order, order + ng, [&](int a, int b) { return hk[a] < hk[b]; });       // global slots are claimed in racy order
     if (ng > max_groups) { *out_ngroups = ng; return fail(ctx, SDQH_ERR_OVERFLOW, "groupby_small: more groups than max_groups"); }
+    for (int k = 0; k < SDQH_MAX_GROUPKEYS; ++k) ctx->g4_hint[k] = (ng <= 4 && k < nkeys) ? gk.col[k] : nullptr;   // next time: the 4-group kernel
     for (int i = 0; i < ng; ++i) {
         const int g = order[i];
         if (out_keys) for (int k = 0; k < nkeys; ++k) out_keys[i * nkeys + k] = (int64_t)((hk[g] >> (32 * k)) & 0xFFFFFFFFull);

@@ -20,7 +20,16 @@ namespace sdqh {
 constexpr int TPB = 256;                 // threads per workgroup = 4 wave64
 constexpr int WAVE = 64;
 constexpr int ROWS_PER_LOAD = 2;         // two 8-byte rows = one 16-byte load per lane
-constexpr int UNROLL = 2;                // 16-byte loads per column per thread per tile
+#ifndef SDQH_UNROLL
+#define SDQH_UNROLL 2
+#endif
+#ifndef SDQH_NT_LOADS
+#define SDQH_NT_LOADS 1                  // streamed columns are read once: non-temporal loads (+7 % on MI355X, tools/microbench_q1.hip)
+#endif
+#ifndef SDQH_TILE_CHUNK
+#define SDQH_TILE_CHUNK 4                // consecutive tiles a workgroup takes per step of its stride loop (32 KiB runs per column)
+#endif
+constexpr int UNROLL = SDQH_UNROLL;      // 16-byte loads per column per thread per tile
 constexpr int TILE_ROWS = TPB * ROWS_PER_LOAD * UNROLL;     // 1024 rows per workgroup step
 constexpr int SUB_ROWS = TPB * ROWS_PER_LOAD;                // 512 rows per unrolled sub-step
 
@@ -151,7 +160,11 @@ __device__ __forceinline__ Pair<T> load2(const T* __restrict__ p, int64_t r, int
     Pair<T> v;
     if constexpr (!TAIL) {
         using V = T __attribute__((ext_vector_type(2)));
+#if SDQH_NT_LOADS
+        V t = __builtin_nontemporal_load(reinterpret_cast<const V*>(p + r));
+#else
         V t = *reinterpret_cast<const V*>(p + r);
+#endif
         v.x = t.x; v.y = t.y;
     } else {
         int64_t r0 = r < nrows ? r : nrows - 1, r1 = r + 1 < nrows ? r + 1 : nrows - 1;
@@ -353,8 +366,9 @@ __global__ __launch_bounds__(TPB) void k_scan_sum(DevFilter f, DevTuple t, int64
     double acc[4] = {0, 0, 0, 0};
     int64_t cnt = 0;
     const int64_t full = nrows / TILE_ROWS;
-    for (int64_t tile = blockIdx.x; tile < full; tile += gridDim.x)
-        scan_sum_tile<SHAPE, FC, false>(f, t, tile * TILE_ROWS, nrows, acc, cnt);
+    for (int64_t t0 = (int64_t)blockIdx.x * SDQH_TILE_CHUNK; t0 < full; t0 += (int64_t)gridDim.x * SDQH_TILE_CHUNK)
+        for (int64_t tile = t0; tile < t0 + SDQH_TILE_CHUNK && tile < full; ++tile)
+            scan_sum_tile<SHAPE, FC, false>(f, t, tile * TILE_ROWS, nrows, acc, cnt);
     if (full * TILE_ROWS < nrows && blockIdx.x == (unsigned)(full % gridDim.x))
         scan_sum_tile<SHAPE, FC, true>(f, t, full * TILE_ROWS, nrows, acc, cnt);
 
@@ -577,8 +591,9 @@ __global__ __launch_bounds__(TPB) void k_groupby_reg(DevFilter f, DevTuple t, De
     for (int g = 0; g < G; ++g) { cnt[g] = 0; for (int k = 0; k < 4; ++k) acc[g][k] = 0.0; }
 
     const int64_t full = nrows / TILE_ROWS;
-    for (int64_t tile = blockIdx.x; tile < full; tile += gridDim.x)
-        groupby_reg_tile<SHAPE, G, FC, KC, false>(f, t, gk, tile * TILE_ROWS, nrows, s_keys, s_flags, acc, cnt);
+    for (int64_t t0 = (int64_t)blockIdx.x * SDQH_TILE_CHUNK; t0 < full; t0 += (int64_t)gridDim.x * SDQH_TILE_CHUNK)
+        for (int64_t tile = t0; tile < t0 + SDQH_TILE_CHUNK && tile < full; ++tile)
+            groupby_reg_tile<SHAPE, G, FC, KC, false>(f, t, gk, tile * TILE_ROWS, nrows, s_keys, s_flags, acc, cnt);
     if (full * TILE_ROWS < nrows && blockIdx.x == (unsigned)(full % gridDim.x))
         groupby_reg_tile<SHAPE, G, FC, KC, true>(f, t, gk, full * TILE_ROWS, nrows, s_keys, s_flags, acc, cnt);
 

@@ -57,12 +57,13 @@ struct sdqh_ctx {
     std::vector<std::pair<const void*, int>> occupancy;   // kernel -> resident workgroups per CU
     // tuning knobs (sdqh_set_option)
     int opt_resident_cap = 6;                      // probing kernels (latency chains to hide)
+    int opt_probe_chunk = 1;
     int opt_resident_stream = 2;                   // pure streaming kernels: fewer concurrent DRAM streams run faster (tools/microbench_q1.hip)
     int opt_probe_unroll = PROBE_UNROLL;
     int opt_stage_batch = STAGE_BATCH;
     int opt_stage_eager = 1;
     int opt_stage_eager_pay = 1;
-    int opt_stage_waves_per_cu = 16;
+    int opt_stage_waves_per_cu = 24;
     int opt_direct_index = 1;
     int opt_groupby_regs = 0;                      // 0 = adaptive (4 when the last run of these key columns had <= 4 groups), 4, 8
     const void* g4_hint[SDQH_MAX_GROUPKEYS] = {nullptr, nullptr};
@@ -329,9 +330,12 @@ int with_stage_filter(const DevFilter& f, int nprobes, Fn&& fn) {      // K-B st
 template <class Fn>
 int with_group_keys(const DevGroupKeys& gk, Fn&& fn) {
     if (gk.nkeys == 2 && gk.is_str[0] && gk.is_str[1]) return fn(KCfg<1, 1>{});
-    if (gk.nkeys == 1 && gk.is_str[0]) return fn(KCfg<1, 0>{});
-    if (gk.nkeys == 1 && !gk.is_str[0]) return fn(KCfg<2, 0>{});
     return fn(KGeneric{});
+}
+template <class Fn>
+int with_groupby_filter(const DevFilter& f, Fn&& fn) {          // the register group-by kernels: one tuned layout + generic
+    if (f.ns == 0 && f.nf == 0 && f.ni == 1) return fn(FCfg<1, 0, 0, 0>{});
+    return fn(FGeneric{});
 }
 
 }  // namespace
@@ -413,6 +417,7 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     const std::string n(name);
     if (n == "resident_cap" && value >= 1 && value <= 8) ctx->opt_resident_cap = (int)value;
     else if (n == "resident_stream" && value >= 1 && value <= 8) ctx->opt_resident_stream = (int)value;
+    else if (n == "probe_chunk" && value >= 1 && value <= 64) ctx->opt_probe_chunk = (int)value;
     else if (n == "probe_unroll" && (value == 1 || value == 2 || value == 4)) ctx->opt_probe_unroll = (int)value;
     else if (n == "stage_batch" && (value == 2 || value == 4 || value == 8)) ctx->opt_stage_batch = (int)value;
     else if (n == "stage_eager" && (value == 0 || value == 1)) ctx->opt_stage_eager = (int)value;
@@ -593,16 +598,19 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
                 LAUNCH(ctx, "k_groupby_lds", kern, grid, f, t, gk, nrows, r_keys, pacc, pcnt, r_flags);
                 return SDQH_OK;
             }
-            return with_scan_filter(f, [&](auto FC) {
+            return with_groupby_filter(f, [&](auto FC) {
                 return with_group_keys(gk, [&](auto KC) {
-                    if (g4) {
-                        auto kern = k_groupby_reg<SH, 4, decltype(FC), decltype(KC)>;
-                        grid = stream_grid(ctx, kern, nrows, TILE_ROWS, true);
-                        if (int c = carve()) return c;
-                        LAUNCH(ctx, "k_groupby_reg", kern, grid, f, t, gk, nrows, r_keys, pacc, pcnt, r_flags);
-                        return SDQH_OK;
+                    using FCT = decltype(FC); using KCT = decltype(KC);
+                    if constexpr (std::is_same_v<FCT, FCfg<1, 0, 0, 0>> && std::is_same_v<KCT, KCfg<1, 1>>) {      // the tuned family also has a 4-group form
+                        if (g4) {
+                            auto kern = k_groupby_reg<SH, 4, FCT, KCT>;
+                            grid = stream_grid(ctx, kern, nrows, TILE_ROWS, true);
+                            if (int c = carve()) return c;
+                            LAUNCH(ctx, "k_groupby_reg", kern, grid, f, t, gk, nrows, r_keys, pacc, pcnt, r_flags);
+                            return SDQH_OK;
+                        }
                     }
-                    auto kern = k_groupby_reg<SH, GREG, decltype(FC), decltype(KC)>;
+                    auto kern = k_groupby_reg<SH, GREG, FCT, KCT>;
                     grid = stream_grid(ctx, kern, nrows, TILE_ROWS, true);
                     if (int c = carve()) return c;
                     LAUNCH(ctx, "k_groupby_reg", kern, grid, f, t, gk, nrows, r_keys, pacc, pcnt, r_flags);
@@ -877,12 +885,12 @@ int sdqh_hash_probe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* f
             constexpr int SH = decltype(S)::value; using FCT = decltype(FC);
             if constexpr (SH == SDQH_TUPLE_A_1MB && std::is_same_v<FCT, FCfg<1, 0, 0, 0>>) {     // the tuned instance family
 #define PROBE_VARIANT(PU_) if (ctx->opt_probe_unroll == PU_) { auto kern = k_probe_agg<SH, FCT, PU_>; \
-        LAUNCH(ctx, "k_probe_agg", kern, stream_grid(ctx, kern, nrows, TPB * ROWS_PER_LOAD * PU_), f, t, table->dev, kc, nrows); return SDQH_OK; }
+        LAUNCH(ctx, "k_probe_agg", kern, stream_grid(ctx, kern, nrows, TPB * ROWS_PER_LOAD * PU_ * ctx->opt_probe_chunk), f, t, table->dev, kc, nrows, ctx->opt_probe_chunk); return SDQH_OK; }
                 PROBE_VARIANT(2) PROBE_VARIANT(1)
 #undef PROBE_VARIANT
             }
             auto kern = k_probe_agg<SH, FCT>;
-            LAUNCH(ctx, "k_probe_agg", kern, stream_grid(ctx, kern, nrows, PROBE_TILE), f, t, table->dev, kc, nrows);
+            LAUNCH(ctx, "k_probe_agg", kern, stream_grid(ctx, kern, nrows, PROBE_TILE * ctx->opt_probe_chunk), f, t, table->dev, kc, nrows, ctx->opt_probe_chunk);
             return SDQH_OK;
         });
     });
@@ -1098,7 +1106,7 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
     int lrc = with_shape(ctx, tuple_shape, [&](auto S) {
         return with_scan_filter(f, [&](auto FC) {
             auto kern = k_lookup_agg<decltype(S)::value, decltype(FC)>;
-            grid = stream_grid(ctx, kern, nrows, TPB * ROWS_PER_LOAD * 2);
+            grid = stream_grid(ctx, kern, nrows, TPB * ROWS_PER_LOAD * 2 * ctx->opt_probe_chunk);
             const size_t nslots = (size_t)grid * LG_SLOTS;
             blob = static_cast<char*>(pool_alloc(ctx, nslots * 40 + 256));
             if (!blob) return fail(ctx, SDQH_ERR_NOMEM, "lookup_aggregate: out of device memory");
@@ -1107,7 +1115,7 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
             hipError_t e = hipMemsetAsync(r_keys, 0xFF, LG_SLOTS * 8, ctx->stream);
             if (e == hipSuccess) e = hipMemsetAsync(r_flags, 0, 8, ctx->stream);
             if (e != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e));
-            LAUNCH(ctx, "k_lookup_agg", kern, grid, f, L, spec, nrows, r_keys, pacc, pcnt, r_flags);
+            LAUNCH(ctx, "k_lookup_agg", kern, grid, f, L, spec, nrows, r_keys, pacc, pcnt, r_flags, ctx->opt_probe_chunk);
             LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, r_keys, pacc, pcnt, (int)grid, r_acc, r_cnt);
             call_end(ctx);
             return SDQH_OK;

@@ -1165,7 +1165,7 @@ __device__ __forceinline__ void probe_drain(const DevFilter& f, const DevTuple& 
 }
 
 template <int SHAPE, class FC, int PU = PROBE_UNROLL>
-__global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevTable tb, const int64_t* __restrict__ keycol, int64_t nrows) {
+__global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevTable tb, const int64_t* __restrict__ keycol, int64_t nrows, int chunk) {
     constexpr int TILE = TPB * ROWS_PER_LOAD * PU;
     __shared__ int64_t s_row[TPB / WAVE][PROBE_QCAP], s_key[TPB / WAVE][PROBE_QCAP];
     int64_t* q_row = s_row[threadIdx.x / WAVE];
@@ -1176,7 +1176,8 @@ __global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevT
     DevProbes none; none.n = 0;
     const uint64_t nomask[SDQH_MAX_PROBE] = {0, 0};
     const int64_t full = nrows / TILE;
-    for (int64_t tile = blockIdx.x; tile < full; tile += gridDim.x) {
+    for (int64_t t0 = (int64_t)blockIdx.x * chunk; t0 < full; t0 += (int64_t)gridDim.x * chunk)
+    for (int64_t tile = t0; tile < t0 + chunk && tile < full; ++tile) {       // `chunk` consecutive tiles: longer contiguous runs per workgroup
         int64_t r[PU];
         Pair<int64_t> kv[PU];
         bool p[PU][2];
@@ -1390,7 +1391,7 @@ __device__ __forceinline__ int group_slot(unsigned long long* keys, unsigned lon
 template <int SHAPE, class FC>
 __global__ __launch_bounds__(TPB) void k_lookup_agg(DevFilter f, DevLookups L, DevAggSpec spec, int64_t nrows,
                                                     unsigned long long* __restrict__ gkeys, double* __restrict__ pacc,
-                                                    int64_t* __restrict__ pcnt, int* __restrict__ flags) {
+                                                    int64_t* __restrict__ pcnt, int* __restrict__ flags, int chunk) {
     constexpr int NOPS = TupleTraits<SHAPE>::NOPS, NV = TupleTraits<SHAPE>::NV;
     constexpr int PU = 2, TILE = TPB * ROWS_PER_LOAD * PU;
     __shared__ unsigned long long s_keys[LG_SLOTS];
@@ -1432,7 +1433,8 @@ __global__ __launch_bounds__(TPB) void k_lookup_agg(DevFilter f, DevLookups L, D
         atomicAdd(&s_cnt[slot], 1ull);
     };
     const int64_t full = nrows / TILE;
-    for (int64_t tile = blockIdx.x; tile < full; tile += gridDim.x) {
+    for (int64_t t0 = (int64_t)blockIdx.x * chunk; t0 < full; t0 += (int64_t)gridDim.x * chunk)
+    for (int64_t tile = t0; tile < t0 + chunk && tile < full; ++tile) {
         int64_t r[PU];
         Pair<int64_t> k0[PU];
         bool p[PU][2];

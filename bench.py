@@ -69,8 +69,6 @@ def main():
     os.dup2(2, 1)
     queries = [q for q in args.queries.split(",") if q]
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if (world > 1 or args.force_dist) and "q5" in queries:
-        queries.remove("q5")        # the multi-GPU runner covers q1 / q3 / q6 this round
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -198,7 +196,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "TPCH " + "+".join(q.upper() for q in queries) + " SF=%g per GPU (BASELINE metric: Q1/Q3/Q5 at SF=10; q1 = configs[1], q3 = configs[2])" % args.sf,
-                       "sf_per_gpu": args.sf, "rows_per_gpu": rows, "partitioning": "none" if not use_dist else "q1 row-sharded; q3 partitioned on o_orderkey (%s), RCCL all-to-all; exchanged rows %s"
+                       "sf_per_gpu": args.sf, "rows_per_gpu": rows, "partitioning": "none" if not use_dist else "q1 row-sharded; q5 small builds replicated, orders-lineitem join co-partitioned; q3 partitioned on o_orderkey (%s), RCCL all-to-all; exchanged rows %s"
                                        % (runner.last_partitioning, runner.exchanged_rows)},
             "ms_per_query": per_query,
             "kernels": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in sorted(kernels.items())},

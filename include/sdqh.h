@@ -213,6 +213,10 @@ int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits,
                        int64_t* out_keys, int64_t* out_payload, double* out_values,
                        int64_t* out_hits, int64_t* out_n);
 
+/* The entries of a table (every owner row: key, then the npayload payload fields) as resident
+ * columns, for re-distribution without a host round trip.  out_cols[1 + npayload]. */
+int sdqh_table_entries(sdqh_ctx* ctx, const sdqh_table* table, sdqh_column** out_cols, int64_t* out_rows);
+
 /* ---- generalised lookups: multi-join chains (Q5, Q9) -------------------------------------------
  * Where a value comes from inside an emitted loop body: a column of the scanned row, or a field of
  * the entry matched by an earlier lookup (`indexedDictValue.x`, `tbl[key].x` -> `.at(key)`,

@@ -561,6 +561,18 @@ int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits,
     return SDQH_OK;
 }
 
+int sdqh_table_entries(sdqh_ctx* ctx, const sdqh_table* table, sdqh_column** out_cols, int64_t* out_rows) {
+    if (!ctx || !table || !out_cols || !out_rows || table->bitmap_only) return fail(ctx, SDQH_ERR_INVALID, "table_entries: bad arguments");
+    const int64_t n = (int64_t)table->keys.size();
+    for (int c = 0; c < 1 + table->npayload; ++c) {
+        if (int rc = sdqh_column_alloc(ctx, n, SDQH_I64, 0, &out_cols[c])) return rc;
+        int64_t* dst = (int64_t*)out_cols[c]->data;
+        for (int64_t e = 0; e < n; ++e) dst[e] = c == 0 ? table->keys[(size_t)e] : table->payload[(size_t)e * (size_t)table->npayload + (size_t)(c - 1)];
+    }
+    *out_rows = n;
+    return SDQH_OK;
+}
+
 // ---- generalised lookups (Q5 / Q9) ---------------------------------------------------------------
 namespace {
 struct LookupView { const sdqh_table* table; int nkey; sdqh_source key[2]; };

@@ -110,7 +110,7 @@ EXPORTS = [
     "sdqh_scan_filter_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_table_size", "sdqh_table_free",
     "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_scan_compact", "sdqh_partition_by_key",
     "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in",
-    "sdqh_build", "sdqh_lookup_aggregate",
+    "sdqh_build", "sdqh_lookup_aggregate", "sdqh_table_entries",
 ]
 
 
@@ -400,6 +400,14 @@ class Context:
         n = n.value
         return (keys[:n], None if payload is None else payload[:, :n], None if values is None else values[:, :n], None if hits is None else hits[:n])
 
+    def table_entries(self, table):
+        """(Columns [key, payload...], n): the table's entries as resident columns."""
+        k = 1 + table.npayload
+        outs = (C.c_void_p * k)()
+        n = C.c_int64()
+        self._check(self.lib.sdqh_table_entries(self.handle, table.handle, outs, C.byref(n)))
+        return [Column(self, C.c_void_p(outs[i]), n.value, I64, 0) for i in range(k)], n.value
+
     def scan_compact(self, nrows, flt, probes, cols):
         parr = (Probe * max(1, len(probes)))()
         for i, (tbl, kcol) in enumerate(probes):
@@ -502,6 +510,7 @@ class Library:
         L.sdqh_column_copy_in.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.sdqh_table_export_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.sdqh_table_from_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.sdqh_table_entries.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sdqh_build.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.sdqh_lookup_aggregate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -976,6 +976,21 @@ int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_hits
     return SDQH_OK;
 }
 
+int sdqh_table_entries(sdqh_ctx* ctx, const sdqh_table* ctable, sdqh_column** out_cols, int64_t* out_rows) {
+    sdqh_table* table = const_cast<sdqh_table*>(ctable);
+    if (!ctx || !table || !out_cols || !out_rows || table->bitmap_only) return fail(ctx, SDQH_ERR_INVALID, "table_entries: bad arguments");
+    (void)hipSetDevice(ctx->device);
+    if (int rc = run_compact(ctx, table, 0)) return rc;
+    const int64_t n = table->compact_n;
+    const DevCompactOut& o = table->compact;
+    for (int c = 0; c < 1 + table->npay; ++c) {
+        if (int rc = sdqh_column_alloc(ctx, n, SDQH_I64, 0, &out_cols[c])) return rc;
+        if (n) HIP_TRY(ctx, hipMemcpyAsync(out_cols[c]->data, c == 0 ? o.keys : o.pay[c - 1], (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    *out_rows = n;
+    return sync_stream(ctx);
+}
+
 // ---- generalised lookups (Q5 / Q9) ---------------------------------------------------------------
 static int make_source(sdqh_ctx* ctx, const sdqh_source& s, int64_t nrows, int nl, const sdqh_lookup* lookups, int upto, const char* what, DevSource* d) {
     std::memset(d, 0, sizeof(*d));

@@ -88,26 +88,34 @@ class DistributedRunner:
         parts = self._all_gather_array(pad)
         return np.concatenate([p[:s] for p, s in zip(parts, sizes)]) if sum(sizes) else np.zeros(0, np.int64)
 
-    def _all_gather_column(self, col, n):
-        """Concatenate an int64 / f64 Column of n rows per rank over all ranks (rank order), staying
-        in device memory: sizes are exchanged first, the payload is one padded all_gather."""
+    def _all_gather_columns(self, cols, n):
+        """Concatenate int64 / f64 Columns of n rows per rank over all ranks (rank order), staying in
+        device memory: the sizes are exchanged once, then one padded all_gather per column."""
         sizes = [int(x[0]) for x in self._all_gather_array(np.array([n], np.int64))]
         total, m = sum(sizes), max(sizes + [1])
-        send = torch.zeros(m, dtype=torch.int64, device=self.device)
-        if n:
-            self.ctx.copy_out(col, 0, n, send.data_ptr())
-        recv = torch.empty(m * self.world, dtype=torch.int64, device=self.device)
-        dist.all_gather_into_tensor(recv, send, group=self.group) if self.backend == "nccl" else \
-            dist.all_gather(list(recv.view(self.world, m).unbind(0)), send, group=self.group)
-        if self.backend == "nccl":
-            torch.cuda.current_stream().synchronize()
-        out = self.ctx.alloc(total, col.dtype)
-        at = 0
-        for r, s in enumerate(sizes):
-            if s:
-                self.ctx.copy_in(out, at, s, recv.data_ptr() + r * m * 8)
-                at += s
-        return out, total
+        outs = []
+        for col in cols:
+            send = torch.zeros(m, dtype=torch.int64, device=self.device)
+            if n:
+                self.ctx.copy_out(col, 0, n, send.data_ptr())
+            recv = torch.empty(m * self.world, dtype=torch.int64, device=self.device)
+            if self.backend == "nccl":
+                dist.all_gather_into_tensor(recv, send, group=self.group)
+                torch.cuda.current_stream().synchronize()
+            else:
+                dist.all_gather(list(recv.view(self.world, m).unbind(0)), send, group=self.group)
+            out = self.ctx.alloc(total, col.dtype)
+            at = 0
+            for r, sz in enumerate(sizes):
+                if sz:
+                    self.ctx.copy_in(out, at, sz, recv.data_ptr() + r * m * 8)
+                    at += sz
+            outs.append(out)
+        return outs, total
+
+    def _all_gather_column(self, col, n):
+        outs, total = self._all_gather_columns([col], n)
+        return outs[0], total
 
     def _all_to_all_counts(self, counts):
         send = torch.from_numpy(np.ascontiguousarray(counts, np.int64)).to(self.device)
@@ -165,10 +173,11 @@ class DistributedRunner:
             self._plans[name] = frontend.lower_function(Q.QUERIES[name])
         return self._plans[name]
 
-    def run(self, name, db):
+    def run(self, name, db, whole_tables=("region", "nation")):
         """Run query `name` on this rank's shard `db`; returns this rank's share of the result
-        (q6: the global scalar on every rank; q1: the global groups on every rank; q3: the groups
-        of this rank's key partition)."""
+        (q6: the global scalar on every rank; group-bys over a small domain (q1, q5, q9): the global
+        groups on every rank; q3: the groups of this rank's key partition).  `whole_tables` names the
+        tables every rank holds completely (the rest are row-sharded)."""
         args = [db[t] for t in Q.QUERY_TABLES[name]]
         plan = self._plan(name)
         if name == "q6":
@@ -182,7 +191,135 @@ class DistributedRunner:
             return self._row_sharded_groupby(plan, args)
         if name == "q3":
             return self._partitioned_join(plan, args)
-        raise frontend.UnsupportedQuery("no distributed plan for %s" % name)
+        whole = {p for p, t in zip(plan.params, Q.QUERY_TABLES[name]) if t in whole_tables}
+        return self._sharded_chain(plan, args, whole)
+
+    # ---- multi-join chains (q5, q9): replicate what is probed across shards, keep co-partitioned joins local ----
+    def _prepare_chain(self, plan, args, whole):
+        eng = self.eng
+        tabs = {p: engine.HostTable(p, a) for p, a in zip(plan.params, args)}
+        st = type("ChainState", (), {})()
+        st.args, st.generation = tuple(args), eng.generation
+        st.steps, st.replicate = [], {}
+        scan_ops = [o for o in plan.ops if isinstance(o, ScanOp)]
+        built_by = {o.out: o for o in scan_ops if o.kind == "dict" and o.unique}
+        # which scans look a built table up, and by which key expression
+        consumers = {name: [] for name in built_by}
+        for o in scan_ops:
+            found = []
+            if o.probe is not None:
+                engine._walk_lookups(o.probe, found)
+            for c in o.conds:
+                if isinstance(c, frontend.Contains):
+                    engine._walk_lookups(c.lookup, found)
+            if o.kind == "dict":
+                engine._walk_lookups(o.key, found)
+            if not isinstance(o.val, frontend.Const):
+                engine._walk_lookups(o.val, found)
+            for lk in found:
+                if lk.dict_name in consumers:
+                    consumers[lk.dict_name].append((o, lk))
+        facts_req = []                                           # (table name, build col array, probe col array)
+        for name, bop in built_by.items():
+            if bop.table in whole:
+                st.replicate[name] = False                       # identical on every rank already
+                continue
+            need = False
+            for cop, lk in consumers[name]:
+                local_ok = (cop.table not in whole and isinstance(bop.key, Col) and isinstance(lk.key, Col)
+                            and tabs[bop.table].cols.get(bop.key.name) is not None and tabs[cop.table].cols.get(lk.key.name) is not None)
+                if local_ok:
+                    facts_req.append((name, tabs[bop.table].array(bop.key.name, bop), tabs[cop.table].array(lk.key.name, cop)))
+                else:
+                    need = True
+            st.replicate[name] = need
+        # co-partitioning test: every rank's probe keys must lie inside its own build-key range,
+        # and the build ranges must be disjoint and ascending (so no other rank holds a matching key)
+        for name, barr, carr in facts_req:
+            b = (int(barr.min()), int(barr.max())) if len(barr) else (abi.INT64_MAX, abi.INT64_MIN)
+            c = (int(carr.min()), int(carr.max())) if len(carr) else b
+            facts = self._all_gather_array(np.array([b[0], b[1], c[0], c[1], len(barr), len(carr)], np.int64))
+            ok = all(int(f[4]) > 0 for f in facts) and all(int(facts[i][1]) < int(facts[i + 1][0]) for i in range(self.world - 1)) \
+                and all(int(f[5]) == 0 or (int(f[2]) >= int(f[0]) and int(f[3]) <= int(f[1])) for f in facts)
+            if not ok:
+                st.replicate[name] = True
+        accumulate_into = set()
+        for op in plan.ops:
+            if isinstance(op, ScanOp):
+                st.steps.append((op, engine._prepare_scan(eng, op, tabs[op.table], accumulate_into)))
+            else:
+                st.steps.append((op, None))
+        st.sharded = {op.out: (op.table not in whole) for op in scan_ops}
+        return st
+
+    def _replicate_table(self, bt):
+        """All ranks' entries of a built table on every rank, without leaving device memory:
+        entries -> all-gather -> rebuild.  A composite key travels packed; lookups pack the same way."""
+        ctx = self.ctx
+        cols, n = ctx.table_entries(bt.table)
+        gathered, total = self._all_gather_columns(cols, n)
+        for c in cols:
+            c.free()
+        table = ctx.hash_build_unique(total, abi.make_filter(), [], gathered[0], gathered[1:])
+        new = engine.BuiltTable(table, bt.key_name, bt.key_is_record, bt.val_fields, bt.val_is_record, bt.payload_dtypes)
+        new.decoders, new.key_parts = bt.decoders, bt.key_parts
+        new.key_decoder = getattr(bt, "key_decoder", None)
+        new._keep = gathered
+        bt.table.free()
+        return new
+
+    def _sharded_chain(self, plan, args, whole):
+        cache = plan.__dict__.setdefault("_dist_chain", {})
+        key = (id(self),) + tuple(id(a) for a in args)
+        st = cache.get(key)
+        if st is None or st.generation != self.eng.generation or any(x is not y for x, y in zip(st.args, args)):
+            st = cache[key] = self._prepare_chain(plan, args, whole)
+        env = {}
+        try:
+            for op, step in st.steps:
+                if isinstance(op, ScanOp):
+                    res = step(env)
+                    if isinstance(res, engine.BuiltTable) and st.replicate.get(op.out):
+                        res = self._replicate_table(res)
+                    elif isinstance(res, engine.DictResult) and st.sharded[op.out]:
+                        res = self._merge_groups(res)
+                    elif isinstance(res, float) and st.sharded[op.out]:
+                        res = sum(float(p[0]) for p in self._all_gather_array(np.array([res], np.float64)))
+                    elif isinstance(res, tuple):
+                        raise frontend.UnsupportedQuery("a fused probe-aggregate needs the partitioned-join plan")
+                    env[op.out] = res
+                else:
+                    env[op.out] = engine._finalize(self.eng, op, env)
+            return env[plan.result]
+        finally:
+            for v in env.values():
+                if isinstance(v, engine.BuiltTable):
+                    v.table.free()
+
+    def _merge_groups(self, d):
+        """Partial groups of every rank -> the global groups on every rank (folded in rank order)."""
+        knames = [n for n, _ in d.key_fields]
+        rows = list(zip(*[a.tolist() for _, a in d.key_fields])) if d.size() else []
+        vals = list(zip(*[a.tolist() for _, a in d.val_fields])) if d.size() else []
+        mine = {"k": rows, "v": vals, "kd": [str(a.dtype) for _, a in d.key_fields], "vd": [str(a.dtype) for _, a in d.val_fields]}
+        parts = [None] * self.world
+        dist.all_gather_object(parts, mine, group=self.group)
+        merged, order = {}, []
+        kd = vd = None
+        for p in parts:
+            if p["k"]:
+                kd, vd = p["kd"], p["vd"]
+            for k, v in zip(p["k"], p["v"]):
+                if k not in merged:
+                    merged[k] = list(v); order.append(k)
+                else:
+                    merged[k] = [a + b for a, b in zip(merged[k], v)]
+        if kd is None:
+            return d
+        order.sort()
+        kf = [(nm, np.array([k[j] for k in order], dtype=kd[j])) for j, nm in enumerate(knames)]
+        vf = [(nm, np.array([merged[k][j] for k in order], dtype=vd[j])) for j, (nm, _) in enumerate(d.val_fields)]
+        return engine.DictResult(kf, vf, d.key_is_record, d.val_is_record)
 
     def _row_sharded_groupby(self, plan, args):
         """Every rank aggregates its shard; the <= 64 partial groups per rank travel in ONE small

@@ -28,13 +28,14 @@ def main(rank, world, port, sf, mode, out_path):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     lib = abi.Library(os.path.join(ROOT, "oracle", "libsdqloracle.so"))
     eng = engine.Engine(lib.context(threads=2))
-    qs = ["q1", "q3", "q6"]
+    qs = ["q1", "q3", "q5", "q6", "q9"]
     cols = tpch.columns_for(qs)
     if mode == "shuffled":
         # rows of every table dealt to the ranks at random: key ranges overlap -> hash partitioning
         full = tpch.generate(sf, tables=sorted(cols), columns=cols, threads=2)
         rng = np.random.default_rng(5)
-        db = {t: shard_rows(full[t], rank, world, rng.permutation(len(full[t].getContainer()["data"][0]))) for t in sorted(full)}
+        db = {t: (full[t] if t in ("region", "nation") else
+                  shard_rows(full[t], rank, world, rng.permutation(len(full[t].getContainer()["data"][0])))) for t in sorted(full)}
         partition = "auto"
     elif mode == "range_foreign":
         # build side clustered per rank (disjoint key ranges), probe side dealt at random: range
@@ -52,6 +53,9 @@ def main(rank, world, port, sf, mode, out_path):
     out["q6"] = runner.run("q6", db)
     r1 = runner.run("q1", db)
     out["q1"] = {"columns": r1.columns, "rows": r1.rows()}
+    for q in ("q5", "q9"):
+        r = runner.run(q, db)
+        out[q] = {"columns": r.columns, "rows": r.rows()}
     r3 = runner.run("q3", db)
     out["q3"] = {"columns": r3.columns, "rows": runner.gather_rows(r3), "local_rows": r3.size(),
                  "partitioning": runner.last_partitioning, "exchanged": runner.exchanged_rows}

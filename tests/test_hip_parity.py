@@ -231,7 +231,7 @@ def test_distributed_runner_world1_nccl(hip_lib, golden):
         db = helpers.case_db(case)
         for part in ("auto", "hash"):
             runner = sdist.DistributedRunner(eng, 0, 1, partition=part)
-            for q in ("q1", "q3", "q6"):
+            for q in SUPPORTED:
                 helpers.check_against_golden(runner.run(q, db), case["results"][q], REL, "dist1/%s/%s" % (part, q))
     finally:
         eng.close()

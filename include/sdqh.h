@@ -213,6 +213,16 @@ int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits,
                        int64_t* out_keys, int64_t* out_payload, double* out_values,
                        int64_t* out_hits, int64_t* out_n);
 
+/* Result memory the device can write: when every out_* array of a first sdqh_table_compact call
+ * (no count-only call before it) lies inside one sdqh_host_alloc block, the compaction kernel
+ * stores the rows there itself - no staging copy, one synchronisation.  If the result does not fit
+ * `capacity` the call returns SDQH_ERR_OVERFLOW with *out_n set; retry with a larger block.  The
+ * block belongs to the caller and may outlive the context (sdqh_host_free accepts ctx = NULL).
+ * Replaces nothing in the reference, whose results are built in process memory
+ * (...generator_par.py:871-877). */
+int  sdqh_host_alloc(sdqh_ctx* ctx, size_t bytes, void** out);
+void sdqh_host_free(sdqh_ctx* ctx, void* block);
+
 /* The entries of a table (every owner row: key, then the npayload payload fields) as resident
  * columns, for re-distribution without a host round trip.  out_cols[1 + npayload]. */
 int sdqh_table_entries(sdqh_ctx* ctx, const sdqh_table* table, sdqh_column** out_cols, int64_t* out_rows);

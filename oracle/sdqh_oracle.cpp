@@ -548,8 +548,7 @@ int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits,
     for (size_t e = 0; e < table->keys.size(); ++e) {                 // for (auto& x : dict) out[tuple_cat(k,v)] = true: generator 520-568
         int64_t hits = table->accumulate ? table->acc[e].n : 0;
         if (hits < min_hits) continue;
-        if (count_only) { ++n; continue; }
-        if (n >= capacity) return fail(ctx, SDQH_ERR_OVERFLOW, "table_compact: capacity too small");
+        if (count_only || n >= capacity) { ++n; continue; }          // past capacity: keep counting, report below
         if (out_keys) out_keys[n] = table->keys[e];
         if (out_payload) for (int p = 0; p < table->npayload; ++p) out_payload[(size_t)p * (size_t)capacity + (size_t)n] = table->payload[e * (size_t)table->npayload + (size_t)p];
         if (out_values) for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) out_values[(size_t)k * (size_t)capacity + (size_t)n] = table->accumulate ? table->acc[e].v[k] : 0.0;
@@ -558,8 +557,19 @@ int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits,
     }
     *out_n = n;
     ctx->last_ms = tm.ms();
+    if (!count_only && n > capacity) return fail(ctx, SDQH_ERR_OVERFLOW, "table_compact: capacity too small");
     return SDQH_OK;
 }
+
+// Result blocks: plain process memory here (the product hands out pinned, device-visible memory).
+int sdqh_host_alloc(sdqh_ctx* ctx, size_t bytes, void** out) {
+    if (!ctx || !out || bytes == 0) return fail(ctx, SDQH_ERR_INVALID, "host_alloc: bad arguments");
+    void* p = std::malloc(bytes);
+    if (!p) return fail(ctx, SDQH_ERR_NOMEM, "host_alloc: out of memory");
+    *out = p;
+    return SDQH_OK;
+}
+void sdqh_host_free(sdqh_ctx*, void* block) { std::free(block); }
 
 int sdqh_table_entries(sdqh_ctx* ctx, const sdqh_table* table, sdqh_column** out_cols, int64_t* out_rows) {
     if (!ctx || !table || !out_cols || !out_rows || table->bitmap_only) return fail(ctx, SDQH_ERR_INVALID, "table_entries: bad arguments");

@@ -5,6 +5,7 @@ product (engine.py) only ever loads sdqlpy_amd/csrc/libsdqlhip.so; the test-suit
 oracle through the same class to compare the two implementations call for call.
 """
 import ctypes as C
+import weakref
 import math
 
 import numpy as np
@@ -110,7 +111,7 @@ EXPORTS = [
     "sdqh_scan_filter_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_table_size", "sdqh_table_free",
     "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_scan_compact", "sdqh_partition_by_key",
     "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in",
-    "sdqh_build", "sdqh_lookup_aggregate", "sdqh_table_entries",
+    "sdqh_build", "sdqh_lookup_aggregate", "sdqh_table_entries", "sdqh_host_alloc", "sdqh_host_free",
 ]
 
 
@@ -232,11 +233,43 @@ class Context:
         self.kernel_log = []       # [(kernel name, ms)] of every pattern call since the log was cleared (profiling on)
         self.device_log = []       # [(pattern call, device ms)]
         self._check(self.lib.sdqh_set_threads(self.handle, C.c_int(max(1, threads))))
+        self._host_pool = {}       # block bytes -> [free block addresses]
 
     def close(self):
         if self.handle is not None:
+            for blocks in self._host_pool.values():
+                for addr in blocks:
+                    self.lib.sdqh_host_free(self.handle, C.c_void_p(addr))
+            self._host_pool = {}
             self.lib.sdqh_destroy(self.handle)
             self.handle = None
+
+    # -- result memory the device can write (sdqh_host_alloc) -------------------------------------
+    def host_block(self, nbytes):
+        """A ctypes byte array over a device-visible block of at least nbytes.  numpy views made
+        from it keep it alive; when the last one dies the block returns to this context's pool (or
+        is freed if the context is gone)."""
+        size = 1 << 16
+        while size < nbytes:
+            size <<= 1
+        free = self._host_pool.get(size)
+        if free:
+            addr = free.pop()
+        else:
+            p = C.c_void_p()
+            self._check(self.lib.sdqh_host_alloc(self.handle, C.c_size_t(size), C.byref(p)))
+            addr = p.value
+        buf = (C.c_char * size).from_address(addr)
+        weakref.finalize(buf, Context._release_block, weakref.ref(self), self.lib, addr, size)
+        return buf
+
+    @staticmethod
+    def _release_block(ctx_ref, lib, addr, size):
+        ctx = ctx_ref()
+        if ctx is not None and ctx.handle is not None:
+            ctx._host_pool.setdefault(size, []).append(addr)
+        else:
+            lib.sdqh_host_free(None, C.c_void_p(addr))
 
     def _check(self, rc):
         if rc != OK:
@@ -400,6 +433,33 @@ class Context:
         n = n.value
         return (keys[:n], None if payload is None else payload[:, :n], None if values is None else values[:, :n], None if hits is None else hits[:n])
 
+    def table_compact_into_block(self, table, min_hits, capacity_hint, want_payload=True, want_values=True, want_hits=True):
+        """One-call K-F: the result arrays are views of an sdqh_host_alloc block sized from
+        capacity_hint, which the compaction kernel writes itself; a result that does not fit is
+        fetched again with the exact size.  Returns (keys, payload, values, hits, n)."""
+        npay = table.npayload if want_payload else 0
+        nval = TUPLE_MAX_VALUES if want_values and table.accumulate else 0
+        narr = 1 + npay + nval + (1 if want_hits else 0)
+        cap = max(1024, int(capacity_hint))
+        for attempt in (0, 1):
+            buf = self.host_block(narr * cap * 8)
+            flat = np.frombuffer(buf, dtype=np.int64, count=narr * cap).reshape(narr, cap)
+            keys = flat[0]
+            payload = flat[1:1 + npay] if npay else None
+            values = flat[1 + npay:1 + npay + nval].view(np.float64) if nval else None
+            hits = flat[narr - 1] if want_hits else None
+            n = C.c_int64()
+            rc = self.lib.sdqh_table_compact(self.handle, table.handle, C.c_int64(min_hits), C.c_int64(cap), _np_ptr(keys),
+                                             _np_ptr(payload), _np_ptr(values), _np_ptr(hits), C.byref(n))
+            if rc == ERR_OVERFLOW and attempt == 0:
+                cap = max(1024, n.value)
+                continue
+            self._check(rc)
+            break
+        self._after_call("table_compact")
+        n = n.value
+        return (keys[:n], None if payload is None else payload[:, :n], None if values is None else values[:, :n], None if hits is None else hits[:n], n)
+
     def table_entries(self, table):
         """(Columns [key, payload...], n): the table's entries as resident columns."""
         k = 1 + table.npayload
@@ -511,6 +571,9 @@ class Library:
         L.sdqh_table_export_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.sdqh_table_from_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.sdqh_table_entries.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sdqh_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.sdqh_host_free.restype = None
+        L.sdqh_host_free.argtypes = [C.c_void_p, C.c_void_p]
         L.sdqh_build.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.sdqh_lookup_aggregate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

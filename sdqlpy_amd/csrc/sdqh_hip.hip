@@ -13,6 +13,7 @@
 #include <cstring>
 #include <string>
 #include <type_traits>
+#include <map>
 #include <vector>
 
 #include "sdqh.h"
@@ -45,6 +46,8 @@ struct sdqh_ctx {
     void* result_dev = nullptr;
     void* bulk_host = nullptr;                     // pinned landing zone for result rows (grown on demand)
     size_t bulk_bytes = 0;
+    std::map<const char*, size_t> host_blocks;     // sdqh_host_alloc blocks (base -> bytes): result arrays the device may write
+    void* count_host = nullptr;                    // pinned line the compaction kernel writes its row count to
     hipEvent_t call_begin = nullptr, call_end = nullptr;
     bool call_timed = false;
     int profiling = 0;                             // 0 off, 1 per call, 2 accumulate across calls (read at the end)
@@ -376,6 +379,7 @@ void sdqh_destroy(sdqh_ctx* ctx) {
     for (int i = 0; i < 2; ++i) { if (ctx->staging[i]) (void)hipHostFree(ctx->staging[i]); if (ctx->staging_done[i]) (void)hipEventDestroy(ctx->staging_done[i]); }
     if (ctx->result_host) (void)hipHostFree(ctx->result_host);
     if (ctx->bulk_host) (void)hipHostFree(ctx->bulk_host);
+    if (ctx->count_host) (void)hipHostFree(ctx->count_host);
     if (ctx->result_dev) (void)hipFree(ctx->result_dev);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->call_begin) (void)hipEventDestroy(ctx->call_begin);
@@ -903,7 +907,19 @@ int sdqh_hash_probe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* f
 
 // ---- K-F ---------------------------------------------------------------------------------------
 // Runs the compaction into device buffers (cached on the table) and returns the row count.
-static int run_compact(sdqh_ctx* ctx, sdqh_table* table, int64_t min_hits) {
+struct HostDest { int64_t* keys = nullptr; int64_t* payload = nullptr; double* values = nullptr; int64_t* hits = nullptr; int64_t capacity = 0; };
+static bool in_host_block(sdqh_ctx* ctx, const void* p, size_t bytes) {
+    const char* c = static_cast<const char*>(p);
+    auto it = ctx->host_blocks.upper_bound(c);
+    if (it == ctx->host_blocks.begin()) return false;
+    --it;
+    return c >= it->first && c + bytes <= it->first + it->second;
+}
+// Runs the compaction and returns the row count in table->compact_n.  Without `dest` the rows go to
+// device buffers cached on the table; with a device-visible `dest` that is large enough the write
+// kernel stores them in the caller's arrays (*direct = true) and nothing is cached.
+static int run_compact(sdqh_ctx* ctx, sdqh_table* table, int64_t min_hits, const HostDest* dest = nullptr, bool* direct = nullptr) {
+    if (direct) *direct = false;
     if (table->compact_valid && table->compact_min_hits == min_hits) return SDQH_OK;
     DevCompactOut& o = table->compact;
     const size_t rows = (size_t)std::max<int64_t>(table->nrows_build, 1) + 1;
@@ -917,6 +933,26 @@ static int run_compact(sdqh_ctx* ctx, sdqh_table* table, int64_t min_hits) {
         if (!ok) return fail(ctx, SDQH_ERR_NOMEM, "table_compact: out of device memory");
     }
     o.npay = table->npay; o.nval = table->accumulate ? table->nv : 0;
+    if (!ctx->count_host && hipHostMalloc(&ctx->count_host, 256, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->count_host = nullptr; }
+    o.h_counter = static_cast<unsigned long long*>(ctx->count_host);
+    o.direct = 0; o.host_rows = 0;
+    o.h_keys = nullptr; o.h_hits = nullptr;
+    for (int p = 0; p < SDQH_MAX_PAYLOAD; ++p) o.h_pay[p] = nullptr;
+    for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) o.h_val[k] = nullptr;
+    if (dest && dest->capacity > 0 && o.h_counter) {
+        const size_t cb = (size_t)dest->capacity * 8;
+        bool ok = (dest->keys || dest->payload || dest->values || dest->hits);
+        if (dest->keys) ok = ok && in_host_block(ctx, dest->keys, cb);
+        if (dest->payload) ok = ok && in_host_block(ctx, dest->payload, cb * (size_t)std::max(1, table->npay));
+        if (dest->values) ok = ok && in_host_block(ctx, dest->values, cb * SDQH_TUPLE_MAX_VALUES);
+        if (dest->hits) ok = ok && in_host_block(ctx, dest->hits, cb);
+        if (ok) {
+            o.direct = 1; o.host_rows = (uint64_t)dest->capacity;
+            o.h_keys = dest->keys; o.h_hits = dest->hits;
+            if (dest->payload) for (int p = 0; p < table->npay; ++p) o.h_pay[p] = dest->payload + (size_t)p * (size_t)dest->capacity;
+            if (dest->values) for (int k = 0; k < o.nval; ++k) o.h_val[k] = dest->values + (size_t)k * (size_t)dest->capacity;
+        }
+    }
     call_begin(ctx);
     if (int rc = ensure_index(ctx, table)) return rc;
     uint32_t mh = (uint32_t)std::min<int64_t>(std::max<int64_t>(min_hits, 0), 0xFFFFFFFFll);
@@ -926,10 +962,17 @@ static int run_compact(sdqh_ctx* ctx, sdqh_table* table, int64_t min_hits) {
     LAUNCH(ctx, "k_compact_scan", k_compact_scan, 1, table->seg_kept, table->stage.nseg, o.counter);
     LAUNCH(ctx, "k_compact_write", k_compact_write, seg_grid, table->dev, table->stage, o, mh, table->seg_kept);
     call_end(ctx);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->result_host, o.counter, 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (int rc = sync_stream(ctx)) return rc;
-    table->compact_n = (int64_t)*static_cast<const unsigned long long*>(ctx->result_host);
-    table->compact_min_hits = min_hits; table->compact_valid = true;
+    if (o.h_counter) {
+        if (int rc = sync_stream(ctx)) return rc;
+        table->compact_n = (int64_t)*o.h_counter;
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->result_host, o.counter, 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (int rc = sync_stream(ctx)) return rc;
+        table->compact_n = (int64_t)*static_cast<const unsigned long long*>(ctx->result_host);
+    }
+    const bool went_direct = o.direct && (uint64_t)table->compact_n <= o.host_rows;
+    table->compact_min_hits = min_hits; table->compact_valid = !went_direct;     // the device buffers hold the rows unless they went to the caller
+    if (direct) *direct = went_direct;
     return SDQH_OK;
 }
 
@@ -939,7 +982,9 @@ int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_hits
     if (!ctx || !table || !out_n || capacity < 0) return fail(ctx, SDQH_ERR_INVALID, "table_compact: bad arguments");
     if (table->bitmap_only) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_compact: bitmap-only table");
     (void)hipSetDevice(ctx->device);
-    if (int rc = run_compact(ctx, table, min_hits)) return rc;
+    HostDest dest; dest.keys = out_keys; dest.payload = out_payload; dest.values = out_values; dest.hits = out_hits; dest.capacity = capacity;
+    bool direct = false;
+    if (int rc = run_compact(ctx, table, min_hits, &dest, &direct)) return rc;
     const int64_t n = table->compact_n;
     *out_n = n;
     if (!out_keys && !out_payload && !out_values && !out_hits) return SDQH_OK;        // count-only call
@@ -947,6 +992,10 @@ int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_hits
     if (n == 0) return SDQH_OK;
     const DevCompactOut& o = table->compact;
     const size_t nb = (size_t)n * 8;
+    if (direct) {                                                                      // the kernel already wrote the rows
+        if (out_values) for (int k = o.nval; k < SDQH_TUPLE_MAX_VALUES; ++k) std::memset(out_values + (size_t)k * (size_t)capacity, 0, nb);
+        return SDQH_OK;
+    }
     // D2H lands in pinned memory (a copy into pageable numpy memory is several times slower and
     // serialises inside the runtime), then one memcpy per array into the caller's buffers.
     const int nv = table->accumulate ? table->nv : 0;
@@ -974,6 +1023,21 @@ int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_hits
     if (int rc = sync_stream(ctx)) return rc;
     for (auto& c : copies) std::memcpy(c.first, c.second, nb);
     return SDQH_OK;
+}
+
+int sdqh_host_alloc(sdqh_ctx* ctx, size_t bytes, void** out) {
+    if (!ctx || !out || bytes == 0) return fail(ctx, SDQH_ERR_INVALID, "host_alloc: bad arguments");
+    (void)hipSetDevice(ctx->device);
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, SDQH_ERR_NOMEM, "host_alloc: out of pinned host memory"); }
+    ctx->host_blocks[static_cast<const char*>(p)] = bytes;
+    *out = p;
+    return SDQH_OK;
+}
+void sdqh_host_free(sdqh_ctx* ctx, void* block) {
+    if (!block) return;
+    if (ctx) ctx->host_blocks.erase(static_cast<const char*>(block));
+    (void)hipHostFree(block);
 }
 
 int sdqh_table_entries(sdqh_ctx* ctx, const sdqh_table* ctable, sdqh_column** out_cols, int64_t* out_rows) {

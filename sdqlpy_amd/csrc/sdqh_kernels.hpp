@@ -1503,6 +1503,13 @@ struct DevCompactOut {
     int64_t* keys; int64_t* pay[SDQH_MAX_PAYLOAD]; double* val[SDQH_TUPLE_MAX_VALUES]; int64_t* hits;
     unsigned long long* counter;
     int32_t npay, nval;
+    // When the caller's result arrays are device-visible host memory and the result fits them, the
+    // write kernel stores the rows there itself (coalesced stores over PCIe): no copy-engine
+    // launches afterwards, one synchronisation for the whole query.
+    int64_t* h_keys; int64_t* h_pay[SDQH_MAX_PAYLOAD]; double* h_val[SDQH_TUPLE_MAX_VALUES]; int64_t* h_hits;
+    unsigned long long* h_counter;
+    uint64_t host_rows;
+    int32_t direct, _pad;
 };
 
 constexpr int COMPACT_BATCH = 8;                                     // 64-entry groups whose hit counters are fetched together
@@ -1603,7 +1610,16 @@ __global__ __launch_bounds__(TPB) void k_compact_scan(uint32_t* __restrict__ seg
 __global__ __launch_bounds__(TPB) void k_compact_write(DevTable t, DevStage st, DevCompactOut o, uint32_t min_hits, const uint32_t* __restrict__ seg_off) {
     __shared__ uint32_t s_idx[TPB / WAVE][COMPACT_QCAP], s_hits[TPB / WAVE][COMPACT_QCAP];
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
+    const unsigned long long total = *o.counter;
+    if (o.h_counter && blockIdx.x == 0 && threadIdx.x == 0) *o.h_counter = total;
     if (seg >= st.nseg) return;
+    if (o.direct && total <= o.host_rows) {                            // the result fits the caller's arrays: write it there
+        o.keys = o.h_keys; o.hits = o.h_hits;
+#pragma unroll
+        for (int q = 0; q < SDQH_MAX_PAYLOAD; ++q) o.pay[q] = o.h_pay[q];
+#pragma unroll
+        for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) o.val[k] = o.h_val[k];
+    }
     compact_segment<true>(t, st, o, min_hits, seg, (uint64_t)seg_off[seg], s_idx[threadIdx.x / WAVE], s_hits[threadIdx.x / WAVE]);
 }
 

@@ -507,8 +507,10 @@ class DistributedRunner:
             ctx.hash_probe_aggregate(n_recv, st.empty, table_b, recv[0], abi.make_tuple(st.tup_c.shape, recv[1:]))
 
         # ---- finalise this rank's partition --------------------------------------------------------
-        n = ctx.table_compact_count(table_b, 1)
-        keys, payload, values, hits = ctx.table_compact(table_b, 1, n, want_hits=st.count_idx is not None)
+        hint = getattr(st, "result_rows", None)
+        keys, payload, values, hits, n = ctx.table_compact_into_block(table_b, 1, 4096 if hint is None else hint + hint // 8 + 1024,
+                                                                      want_hits=st.count_idx is not None)
+        st.result_rows = n
         names, arrays = [], []
         for fname, e in st.key_fields:
             if isinstance(e, Col) and e.name == st.ckey_name:

@@ -76,6 +76,7 @@ class Engine:
         self._columns = {}         # id(ndarray) -> (ndarray, abi.Column)
         self.resident_bytes = 0
         self.generation = 0        # bumped by clear(): prepared plans bound to freed columns are rebuilt
+        self.compact_hints = {}    # plan step -> rows its last K-F produced (sizes the next run's result block)
         self._rowids = {}
 
     def close(self):
@@ -637,15 +638,24 @@ def _prepare_scan(eng, op, htab, accumulate_into):
     return run_probe_aggregate
 
 
-def _materialize(eng, value, env):
+def _compact(eng, table, min_hits, hint_key, **want):
+    """K-F in one call: the result size of the previous run of the same plan step (+ slack) sizes
+    the device-writable result block, so the count and the rows arrive with one synchronisation."""
+    hint = eng.compact_hints.get(hint_key)
+    cap = 4096 if hint is None else hint + hint // 8 + 1024
+    keys, payload, values, hits, n = eng.ctx.table_compact_into_block(table, min_hits, cap, **want)
+    eng.compact_hints[hint_key] = n
+    return keys, payload, values, hits
+
+
+def _materialize(eng, value, env, hint_key=None):
     """Device-resident intermediate -> DictResult on the host (K-F's input)."""
     if isinstance(value, DictResult):
         return value
     if isinstance(value, tuple) and value and value[0] == "aggregated":
         bt = env[value[1]]
         out_key_fields, vnames, count_idx, key_is_record, val_is_record, shape = bt.agg
-        n = eng.ctx.table_compact_count(bt.table, 1)
-        keys, payload, values, hits = eng.ctx.table_compact(bt.table, 1, n, want_hits=count_idx is not None)
+        keys, payload, values, hits = _compact(eng, bt.table, 1, hint_key, want_hits=count_idx is not None)
         kf = []
         for fname, src in out_key_fields:
             if src == "key":
@@ -656,8 +666,7 @@ def _materialize(eng, value, env):
         vf = _value_arrays(vnames, count_idx, [values[j] for j in range(nv)], hits)
         return DictResult(kf, vf, key_is_record, val_is_record)
     if isinstance(value, BuiltTable):
-        n = eng.ctx.table_compact_count(value.table, 0)
-        keys, payload, _, _ = eng.ctx.table_compact(value.table, 0, n, want_values=False)
+        keys, payload, _, _ = _compact(eng, value.table, 0, hint_key, want_values=False, want_hits=False)
         vf = [(fname, keys if src == "key" else _decode_column(payload[src], value.decoders.get(src), value.payload_dtypes[src]))
               for fname, src in value.val_fields]
         if value.key_parts is not None:
@@ -669,7 +678,7 @@ def _materialize(eng, value, env):
 
 
 def _finalize(eng, op, env):
-    d = _materialize(eng, env[op.source], env)
+    d = _materialize(eng, env[op.source], env, hint_key=id(op))
     if op.fields is None:                                   # p[0].concat(p[1])
         fields = d.key_fields + d.val_fields
     else:
@@ -708,7 +717,7 @@ class PreparedPlan:
                 env[out] = step(env)
             res = env[self.plan.result]
             if isinstance(res, (BuiltTable, tuple)):
-                res = _materialize(self.eng, res, env)
+                res = _materialize(self.eng, res, env, hint_key=id(self.plan))
             return res
         finally:
             for v in env.values():                           # release device tables of this run

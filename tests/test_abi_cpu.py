@@ -48,3 +48,13 @@ def test_python_mode_is_not_a_fallback():
         Q.q6(sr_dict({"headers": [], "data": []}, None, True))
     with pytest.raises(NotImplementedError):
         sr_dict({}).sum(lambda p: p)
+
+
+def test_oracle_compaction_into_blocks(oracle_lib):
+    """sdqh_host_alloc / one-call K-F with overflow retry on the CPU implementation of the ABI."""
+    from helpers import compaction_block_case
+    ctx = oracle_lib.context(threads=2)
+    try:
+        compaction_block_case(ctx)
+    finally:
+        ctx.close()

@@ -178,6 +178,15 @@ def test_duplicate_build_keys_first_row_wins(hip_engine, oracle_engine):
     assert dict(zip(out["hip"][0].tolist(), out["hip"][1].tolist())) == first
 
 
+def test_compaction_into_device_writable_blocks(hip_engine, oracle_engine):
+    """K-F through sdqh_host_alloc blocks: rows the kernel wrote into the caller's block, the
+    overflow -> retry path, and the pageable-array path all return the same rows, in build order."""
+    from helpers import compaction_block_case
+    hip, cpu = compaction_block_case(hip_engine.ctx), compaction_block_case(oracle_engine.ctx)
+    assert (hip[0] == cpu[0]).all() and (hip[1] == cpu[1]).all() and (hip[3] == cpu[3]).all()
+    np.testing.assert_allclose(hip[2], cpu[2], rtol=1e-12)
+
+
 def test_redistribution_helpers_match_oracle(hip_engine, oracle_engine):
     """scan_compact / partition_by_key (hash and range) / bitmap export-import / column copies:
     same multisets of rows from both implementations of the ABI."""

@@ -141,6 +141,9 @@ int         sdqh_last_device_ms(const sdqh_ctx* ctx, double* ms);
  * accumulate over all calls (events are only recorded, nothing synchronises) until the mode is set
  * again — read them with sdqh_profile_count / sdqh_profile_entry after the timed region. */
 int         sdqh_set_profiling(sdqh_ctx* ctx, int mode);
+/* Restrict the recording to launches of one kernel (exact name; NULL or "" = every kernel), so a
+ * timed region can carry events around its dominant kernel only. */
+int         sdqh_set_profile_filter(sdqh_ctx* ctx, const char* kernel_name);
 int         sdqh_profile_count(const sdqh_ctx* ctx);
 int         sdqh_profile_entry(const sdqh_ctx* ctx, int i, const char** name, double* ms);
 /* Raw hipStream_t the ctx launches on (NULL in the CPU build). */

@@ -298,6 +298,7 @@ int sdqh_set_threads(sdqh_ctx* ctx, int threads) {
 int sdqh_synchronize(sdqh_ctx* ctx) { return ctx ? SDQH_OK : SDQH_ERR_INVALID; }
 int sdqh_last_device_ms(const sdqh_ctx* ctx, double* ms) { if (!ctx || !ms) return SDQH_ERR_INVALID; *ms = ctx->last_ms; return SDQH_OK; }
 int sdqh_set_profiling(sdqh_ctx* ctx, int) { return ctx ? SDQH_OK : SDQH_ERR_INVALID; }
+int sdqh_set_profile_filter(sdqh_ctx* ctx, const char*) { return ctx ? SDQH_OK : SDQH_ERR_INVALID; }
 int sdqh_profile_count(const sdqh_ctx*) { return 0; }
 int sdqh_profile_entry(const sdqh_ctx*, int, const char**, double*) { return SDQH_ERR_INVALID; }
 void* sdqh_stream(const sdqh_ctx*) { return nullptr; }

@@ -104,7 +104,7 @@ def _lookups(lookups):
 
 EXPORTS = [
     "sdqh_abi_version", "sdqh_backend_name", "sdqh_create", "sdqh_destroy", "sdqh_last_error", "sdqh_set_threads",
-    "sdqh_synchronize", "sdqh_last_device_ms", "sdqh_set_profiling", "sdqh_profile_count", "sdqh_profile_entry",
+    "sdqh_synchronize", "sdqh_last_device_ms", "sdqh_set_profiling", "sdqh_set_profile_filter", "sdqh_profile_count", "sdqh_profile_entry",
     "sdqh_stream", "sdqh_set_option",
     "sdqh_column_upload", "sdqh_column_wrap", "sdqh_column_alloc", "sdqh_column_download", "sdqh_column_data",
     "sdqh_column_rows", "sdqh_column_dtype", "sdqh_column_width", "sdqh_column_minmax", "sdqh_column_free",
@@ -287,10 +287,12 @@ class Context:
         self._check(self.lib.sdqh_last_device_ms(self.handle, C.byref(ms)))
         return ms.value
 
-    def set_profiling(self, mode):
+    def set_profiling(self, mode, only=None):
         """0/False off; 1/True per call (kernel_log / device_log filled after every pattern call,
-        synchronising); 2 record only — read everything afterwards with profile()."""
+        synchronising); 2 record only — read everything afterwards with profile().  only = name of
+        the one kernel to record (None: all)."""
         mode = int(mode)
+        self._check(self.lib.sdqh_set_profile_filter(self.handle, only.encode() if only else None))
         self._check(self.lib.sdqh_set_profiling(self.handle, C.c_int(mode)))
         self._profiling = mode == 1
         self.kernel_log, self.device_log = [], []
@@ -571,6 +573,7 @@ class Library:
         L.sdqh_table_export_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.sdqh_table_from_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.sdqh_table_entries.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sdqh_set_profile_filter.argtypes = [C.c_void_p, C.c_char_p]
         L.sdqh_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.sdqh_host_free.restype = None
         L.sdqh_host_free.argtypes = [C.c_void_p, C.c_void_p]

@@ -51,6 +51,7 @@ struct sdqh_ctx {
     hipEvent_t call_begin = nullptr, call_end = nullptr;
     bool call_timed = false;
     int profiling = 0;                             // 0 off, 1 per call, 2 accumulate across calls (read at the end)
+    std::string prof_filter;                       // record only launches of this kernel (empty = all)
     std::vector<ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;
     size_t event_next = 0;
@@ -98,6 +99,7 @@ struct sdqh_table {
     uint64_t nwords = 0;               // bitmap words (direct layout)
     std::vector<void*> owned;          // pool blocks to release
     // cached compaction (device buffers) for the two-step count / fetch protocol
+    bool refs_prefilled = false;                   // small direct tables: dense_ref was allocated and NO_ROW-filled with the header
     bool compact_valid = false;
     int64_t compact_min_hits = 0, compact_n = 0;
     DevCompactOut compact{};
@@ -161,6 +163,7 @@ struct KernelScope {
     sdqh_ctx* ctx; size_t idx = (size_t)-1;
     KernelScope(sdqh_ctx* c, const char* name) : ctx(c) {
         if (!c->profiling) return;
+        if (!c->prof_filter.empty() && c->prof_filter != name) return;
         ProfEntry e{name, next_event(c), next_event(c), 0.0};
         (void)hipEventRecord(e.e0, c->stream);
         idx = c->prof.size(); c->prof.push_back(e);
@@ -174,6 +177,23 @@ int sync_stream(sdqh_ctx* ctx) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->profiling == 1) for (auto& e : ctx->prof) { float ms = 0; if (hipEventElapsedTime(&ms, e.e0, e.e1) == hipSuccess) e.ms = ms; }
     return SDQH_OK;
+}
+
+// One launch that sets up to FILL_MAX regions to a byte value each (see k_fill).
+struct FillList {
+    DevFill f; uint64_t most = 0;
+    FillList() { std::memset(&f, 0, sizeof(f)); }
+    void add(void* p, size_t bytes, unsigned char byte) {
+        if (!p || !bytes) return;
+        f.p[f.n] = p; f.bytes[f.n] = bytes; f.word[f.n] = 0x01010101u * byte; ++f.n;
+        most = std::max<uint64_t>(most, bytes);
+    }
+};
+static void launch_fill(sdqh_ctx* ctx, const FillList& fl) {
+    if (!fl.f.n) return;
+    const uint64_t want = (fl.most / 16 + TPB - 1) / TPB;
+    const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(want, 1), (uint64_t)ctx->num_cu * 8);
+    LAUNCH(ctx, "k_fill", k_fill, grid, fl.f);
 }
 
 // ---- argument conversion -------------------------------------------------------------------------
@@ -406,6 +426,11 @@ int sdqh_set_profiling(sdqh_ctx* ctx, int mode) {
     ctx->profiling = mode; ctx->prof.clear(); ctx->event_next = 0;
     return SDQH_OK;
 }
+int sdqh_set_profile_filter(sdqh_ctx* ctx, const char* kernel_name) {
+    if (!ctx) return SDQH_ERR_INVALID;
+    ctx->prof_filter = kernel_name ? kernel_name : "";
+    return SDQH_OK;
+}
 int sdqh_profile_count(const sdqh_ctx* ctx) { return ctx ? (int)ctx->prof.size() : 0; }
 int sdqh_profile_entry(const sdqh_ctx* cctx, int i, const char** name, double* ms) {
     sdqh_ctx* ctx = const_cast<sdqh_ctx*>(cctx);
@@ -589,9 +614,11 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
             pacc = reinterpret_cast<double*>(blob);
             pcnt = reinterpret_cast<int64_t*>(blob + nslots * 32);
             call_begin(ctx);
-            hipError_t e = hipMemsetAsync(r_keys, 0xFF, GMAX * 8, ctx->stream);       // every global group slot EMPTY_GROUP
-            if (e == hipSuccess) e = hipMemsetAsync(r_ng, 0, 8, ctx->stream);
-            return e == hipSuccess ? SDQH_OK : fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e));
+            FillList fl;
+            fl.add(r_keys, GMAX * 8, 0xFF);                                          // every global group slot EMPTY_GROUP
+            fl.add(r_ng, 8, 0);
+            launch_fill(ctx, fl);
+            return SDQH_OK;
         };
         int lrc = with_shape(ctx, tuple->shape, [&](auto S) {
             constexpr int SH = decltype(S)::value;
@@ -698,6 +725,18 @@ static int setup_stage(sdqh_ctx* ctx, sdqh_table* tb, int64_t nrows, const sdqh_
     return SDQH_OK;
 }
 
+// Small direct-layout tables get their rank -> row array with the header and pre-filled with NO_ROW
+// by the same fill launch, so the index build needs no separate (conditional) fill launch later.
+static void prefill_refs(sdqh_ctx* ctx, sdqh_table* tb, FillList* fl) {
+    if (!tb->bm || tb->dev.bm_shift != 0) return;
+    const size_t rows = (size_t)std::max<int64_t>(tb->nrows_build, 1);
+    if (rows * 4 > ((size_t)8 << 20)) return;
+    uint32_t* dense = static_cast<uint32_t*>(table_alloc(ctx, tb, rows * 4 + 64));
+    if (!dense) return;                                                    // ensure_index allocates (and reports) later
+    tb->dev.dense_ref = dense; tb->refs_prefilled = true;
+    fl->add(dense, (rows * 4 + 15) & ~(size_t)15, 0xFF);
+}
+
 // The key -> stage-row index is built on first need: a table that is only ever used as a
 // semi-join filter through its exact bitmap never pays for one.
 static int ensure_index(sdqh_ctx* ctx, sdqh_table* tb) {
@@ -707,13 +746,11 @@ static int ensure_index(sdqh_ctx* ctx, sdqh_table* tb) {
     if (tb->bm && tb->dev.bm_shift == 0) {                                 // direct layout
         const int nblocks = (int)((tb->nwords + RANK_BLOCK_WORDS - 1) / RANK_BLOCK_WORDS);
         uint32_t* wprefix = static_cast<uint32_t*>(table_alloc(ctx, tb, tb->nwords * 4 + 64));
-        uint32_t* bprefix = static_cast<uint32_t*>(table_alloc(ctx, tb, (size_t)nblocks * 4 + 64));
-        uint32_t* dense = static_cast<uint32_t*>(table_alloc(ctx, tb, rows * 4 + 64));
-        if (!wprefix || !bprefix || !dense) return fail(ctx, SDQH_ERR_NOMEM, "table index: out of device memory");
-        tb->dev.wprefix = wprefix; tb->dev.bprefix = bprefix; tb->dev.dense_ref = dense;
-        LAUNCH(ctx, "k_rank_words", k_rank_words, (unsigned)nblocks, tb->bm, tb->nwords, wprefix, bprefix);
-        LAUNCH(ctx, "k_rank_blocks", k_rank_blocks, 1, bprefix, nblocks, tb->stage.seg_count, tb->stage.nseg, tb->hdr);
-        LAUNCH(ctx, "k_fill_refs", k_fill_refs, (unsigned)ctx->num_cu * 2, tb->stage, tb->dev);
+        uint32_t* dense = tb->refs_prefilled ? tb->dev.dense_ref : static_cast<uint32_t*>(table_alloc(ctx, tb, rows * 4 + 64));
+        if (!wprefix || !dense) return fail(ctx, SDQH_ERR_NOMEM, "table index: out of device memory");
+        tb->dev.wprefix = wprefix; tb->dev.dense_ref = dense;
+        LAUNCH(ctx, "k_rank_words", k_rank_words, (unsigned)nblocks, tb->bm, tb->nwords, wprefix, tb->stage.seg_count, tb->stage.nseg, tb->hdr);
+        if (!tb->refs_prefilled) LAUNCH(ctx, "k_fill_refs", k_fill_refs, (unsigned)ctx->num_cu * 2, tb->stage, tb->dev);
         LAUNCH(ctx, "k_insert_direct", k_insert_direct, seg_grid, tb->stage, tb->dev);
     } else {                                                               // hash layout
         int64_t* keys = static_cast<int64_t*>(table_alloc(ctx, tb, (tb->capmax + 2) * 8));
@@ -759,9 +796,7 @@ static int build_dense(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int
     const int64_t* kc = static_cast<const int64_t*>(key->data);
     const unsigned grid = (unsigned)std::min<int64_t>((nrows + TPB - 1) / TPB, (int64_t)ctx->num_cu * 8);
     call_begin(ctx);
-    HIP_TRY(ctx, hipMemsetAsync(tb->hdr, 0, sizeof(TableHeader), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(st.shits, 0, (size_t)nrows * 4, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(arr, 0xFF, range * 4, ctx->stream));
+    { FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); fl.add(st.shits, (size_t)nrows * 4, 0); fl.add(arr, range * 4, 0xFF); launch_fill(ctx, fl); }
     LAUNCH(ctx, "k_full_counts", k_full_counts, (unsigned)((st.nseg + TPB - 1) / TPB), st.seg_count, st.nseg, st.seg_rows, nrows);
     LAUNCH(ctx, "k_dense_fill", k_dense_fill, grid, kc, nrows, lo, arr);
     LAUNCH(ctx, "k_dense_verify", k_dense_verify, grid, kc, nrows, lo, arr, tb->hdr);
@@ -817,9 +852,7 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
             tb->stage.bm = tb->bm; tb->stage.bm_lo = lo; tb->stage.bm_hi = hi; tb->stage.hdr = tb->hdr; tb->stage.bm_shift = 0;
             call_begin(ctx);
             const unsigned seg_grid = (unsigned)((tb->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
-            hipError_t e = hipMemsetAsync(tb->hdr, 0, sizeof(TableHeader), ctx->stream);
-            if (e == hipSuccess && tb->bm) e = hipMemsetAsync(tb->bm, 0, tb->nwords * 4, ctx->stream);
-            if (e != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e));
+            { FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); if (tb->bm) fl.add(tb->bm, tb->nwords * 4, 0); prefill_refs(ctx, tb, &fl); launch_fill(ctx, fl); }
             with_stage_filter(f, nprobes, [&](auto FC) {
                 using FCT = decltype(FC);
                 if constexpr (std::is_same_v<FCT, FCfg<1, 0, 0, 1>>) {          // the tuned instance family (orders-like build side)
@@ -839,7 +872,7 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
                 return SDQH_OK;
             });
             call_end(ctx);
-            e = hipGetLastError();
+            hipError_t e = hipGetLastError();
             if (e != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, std::string("hash_build_unique launch: ") + hipGetErrorString(e));
         }
     }
@@ -1114,6 +1147,17 @@ int sdqh_build(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nloo
             if (nkey == 2 && (lo < 0 || hi > 0xFFFFFFFFll)) want_bm = false;
         }
     }
+    // composite key whose two plain-column parts span a small rectangle: exact bitmap over the
+    // linearised offset -> direct layout (no hash slots, no CAS) instead of hash + high-part pre-filter
+    int64_t lin_rb = 0, lin_b0 = 0; uint64_t lin_bits = 0;
+    if (want_bm && nkey == 2 && ctx->opt_direct_index && key[1].kind == SDQH_SRC_COLUMN && key[1].col->dtype == SDQH_I64) {
+        if (int rc = ensure_minmax(ctx, const_cast<sdqh_column*>(key[1].col))) return rc;
+        const int64_t blo = key[1].col->mn, bhi = key[1].col->mx;
+        if (bhi >= blo && blo >= 0 && bhi <= 0xFFFFFFFFll) {
+            const uint64_t ra = (uint64_t)(hi - lo) + 1, rb = (uint64_t)(bhi - blo) + 1;
+            if (rb <= (1ull << 31) / ra && ra * rb <= 64ull * (uint64_t)std::max<int64_t>(nrows, 1024)) { lin_rb = (int64_t)rb; lin_b0 = blo; lin_bits = ra * rb; }
+        }
+    }
     sdqh_table* tb = new sdqh_table();
     tb->npay = npayload; tb->accumulate = accumulate != 0; tb->nrows_build = nrows;
     // stage without source columns: the kernel evaluates sources itself
@@ -1127,19 +1171,19 @@ int sdqh_build(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nloo
     if (!rc) {
         tb->hdr = static_cast<TableHeader*>(table_alloc(ctx, tb, sizeof(TableHeader)));
         flags = static_cast<int*>(table_alloc(ctx, tb, 64));
-        if (want_bm && ctx->opt_direct_index) { tb->nwords = ((uint64_t)(hi - lo) + 32) / 32; tb->bm = static_cast<uint32_t*>(table_alloc(ctx, tb, tb->nwords * 4 + 64)); }
+        if (want_bm && ctx->opt_direct_index) { tb->nwords = lin_rb ? (lin_bits + 31) / 32 : ((uint64_t)(hi - lo) + 32) / 32; tb->bm = static_cast<uint32_t*>(table_alloc(ctx, tb, tb->nwords * 4 + 64)); }
         if (!tb->hdr || !flags || (tb->nwords && !tb->bm)) rc = fail(ctx, SDQH_ERR_NOMEM, "build: out of device memory");
     }
     if (!rc) {
         tb->dev.hdr = tb->hdr; tb->dev.shits = tb->stage.shits; tb->dev.sacc = tb->stage.sacc;
-        tb->dev.bm = tb->bm; tb->dev.bm_lo = lo; tb->dev.bm_hi = hi; tb->dev.bitmap_only = 0; tb->dev.bm_shift = nkey == 2 ? 32 : 0;
+        const int shift = (nkey == 2 && !(tb->bm && lin_rb)) ? 32 : 0;
+        tb->dev.bm = tb->bm; tb->dev.bm_lo = lo; tb->dev.bm_hi = hi; tb->dev.bitmap_only = 0; tb->dev.bm_shift = shift;
         for (int p = 0; p < npayload; ++p) tb->dev.pay[p] = tb->stage.pay[p];
-        tb->stage.bm = tb->bm; tb->stage.bm_lo = lo; tb->stage.bm_hi = hi; tb->stage.hdr = tb->hdr; tb->stage.bm_shift = nkey == 2 ? 32 : 0;
+        tb->stage.bm = tb->bm; tb->stage.bm_lo = lo; tb->stage.bm_hi = hi; tb->stage.hdr = tb->hdr; tb->stage.bm_shift = shift;
+        if (tb->bm && lin_rb) { tb->dev.lin_rb = tb->stage.lin_rb = lin_rb; tb->dev.lin_b0 = tb->stage.lin_b0 = lin_b0; }
         const unsigned seg_grid = (unsigned)((tb->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
-        hipError_t e = hipMemsetAsync(tb->hdr, 0, sizeof(TableHeader), ctx->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(flags, 0, 8, ctx->stream);
-        if (e == hipSuccess && tb->bm) e = hipMemsetAsync(tb->bm, 0, tb->nwords * 4, ctx->stream);
-        if (e != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e));
+        { FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); fl.add(flags, 8, 0); if (tb->bm) fl.add(tb->bm, tb->nwords * 4, 0); prefill_refs(ctx, tb, &fl); launch_fill(ctx, fl); }
+        hipError_t e;
         with_scan_filter(f, [&](auto FC) { auto kern = k_build_lookup<decltype(FC)>; LAUNCH(ctx, "k_build_lookup", kern, seg_grid, f, L, spec, tb->stage, nrows, flags); return SDQH_OK; });
         call_end(ctx);
         e = hipGetLastError();
@@ -1191,9 +1235,7 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
             if (!blob) return fail(ctx, SDQH_ERR_NOMEM, "lookup_aggregate: out of device memory");
             double* pacc = reinterpret_cast<double*>(blob);
             int64_t* pcnt = reinterpret_cast<int64_t*>(blob + nslots * 32);
-            hipError_t e = hipMemsetAsync(r_keys, 0xFF, LG_SLOTS * 8, ctx->stream);
-            if (e == hipSuccess) e = hipMemsetAsync(r_flags, 0, 8, ctx->stream);
-            if (e != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e));
+            { FillList fl; fl.add(r_keys, LG_SLOTS * 8, 0xFF); fl.add(r_flags, 8, 0); launch_fill(ctx, fl); }
             LAUNCH(ctx, "k_lookup_agg", kern, grid, f, L, spec, nrows, r_keys, pacc, pcnt, r_flags, ctx->opt_probe_chunk);
             LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, r_keys, pacc, pcnt, (int)grid, r_acc, r_cnt);
             call_end(ctx);

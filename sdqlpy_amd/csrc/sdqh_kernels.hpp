@@ -57,11 +57,12 @@ struct DevTuple {
 struct TableHeader {          // lives in device memory: sized on the device, no host round trip
     uint64_t cap_mask;        // capacity - 1 (capacity is a power of two); slot[capacity] is the EMPTY_KEY slot
     uint64_t staged;          // rows that survived the build-side filter (>= distinct keys)
-    uint64_t distinct;        // direct layout: number of distinct keys (set bits), written by k_rank_blocks
+    uint64_t distinct;        // direct layout: number of distinct keys (set bits), written by k_rank_words
     uint32_t has_dups;        // a build row met its own key already in the table
     uint32_t _pad;
     uint64_t counted;         // filled by k_count (table_size)
-    uint64_t _pad2;
+    uint32_t _pad3;
+    uint32_t _pad2;
 };
 
 // A built table maps a key to the stage index of the build row that owns the entry; everything else
@@ -71,8 +72,10 @@ struct TableHeader {          // lives in device memory: sized on the device, no
 //
 //   direct  (key range dense enough for an exact bitmap over [bm_lo, bm_hi]):
 //           bm[w]       bit per key                         (set while staging)
-//           wprefix[w]  set bits before word w inside its 2048-word block, bprefix[b] before block b
-//           dense_ref[rank(key)] = stage index                (plain stores: no atomics at all)
+//           wprefix[w]  rank of the first key of word w: set bits before it inside its 2048-word
+//                       block + a base the block claimed with one atomicAdd (a bijection onto
+//                       [0, distinct), not monotone across blocks)
+//           dense_ref[rank(key)] = stage index                (plain stores)
 //   dense   (an unfiltered build on a dense key range — the reference's `dense(N, key)` hint,
 //           ...generator_par.py:191-224): dense_arr[key - lo] = build row, the source columns
 //           themselves serve as the stage (nothing is copied), a lookup is one load
@@ -92,7 +95,6 @@ struct DevTable {
     double* sacc;             // null when the table carries no accumulators
     const uint32_t* bm;       // key bitmap over [bm_lo, bm_hi], or null
     const uint32_t* wprefix;
-    const uint32_t* bprefix;
     uint32_t* dense_ref;
     int64_t bm_lo, bm_hi;
     int32_t bitmap_only;
@@ -100,7 +102,24 @@ struct DevTable {
                               //    the high part only (a pre-filter in front of the hash layout)
     const int64_t* pay[SDQH_MAX_PAYLOAD];   // stage payload arrays (entry payload by stage index)
     uint32_t* dense_arr;      // dense layout: dense_arr[key - bm_lo] = build row (NO_ROW if absent), bm == null
+    int64_t lin_rb, lin_b0;   // lin_rb != 0: composite key (a << 32 | b) with a small a-range x b-range: bm is exact over the
+                              //    linearised offset (a - bm_lo) * lin_rb + (b - lin_b0) (direct layout, bm_shift == 0)
 };
+
+// offset of `key` in a bitmap described by bm_lo / bm_hi / bm_shift / lin_rb / lin_b0 (DevTable or DevStage); false = out of range
+template <class T>
+__device__ __forceinline__ bool bm_locate(const T& t, int64_t key, uint64_t& off) {
+    const int64_t rb = t.lin_rb;
+    const int64_t v = (t.bm_shift || rb) ? (int64_t)((uint64_t)key >> 32) : key;
+    if (v < t.bm_lo || v > t.bm_hi) return false;
+    off = (uint64_t)(v - t.bm_lo);
+    if (rb) {
+        const int64_t b = (int64_t)((uint64_t)key & 0xFFFFFFFFull) - t.lin_b0;
+        if (b < 0 || b >= rb) return false;
+        off = off * (uint64_t)rb + (uint64_t)b;
+    }
+    return true;
+}
 
 template <int SHAPE> struct TupleTraits;
 template <> struct TupleTraits<SDQH_TUPLE_A>          { static constexpr int NOPS = 1, NV = 1; };
@@ -215,7 +234,7 @@ __device__ __forceinline__ int64_t table_find(const DevTable& t, int64_t key, ui
 
 // contains(key): exact bitmap when the table has one, else open-addressing probe.
 __device__ __forceinline__ bool table_contains(const DevTable& t, int64_t key, uint64_t cap_mask) {
-    if (t.dense_arr || (t.bm && t.bm_shift)) return table_find(t, key, cap_mask) >= 0;
+    if (t.dense_arr || (t.bm && (t.bm_shift || t.lin_rb))) return table_find(t, key, cap_mask) >= 0;
     if (t.bm) {
         if (key < t.bm_lo || key > t.bm_hi) return false;
         uint64_t off = (uint64_t)(key - t.bm_lo);
@@ -235,7 +254,7 @@ __device__ __forceinline__ bool table_contains(const DevTable& t, int64_t key, u
 // word of the key when the caller has already fetched it (direct layout only)
 __device__ __forceinline__ int64_t direct_rank(const DevTable& t, uint64_t off, uint32_t word) {
     const uint64_t w = off >> 5;
-    return (int64_t)t.bprefix[w / RANK_BLOCK_WORDS] + (int64_t)t.wprefix[w] + __popc(word & ((1u << (off & 31)) - 1u));
+    return (int64_t)t.wprefix[w] + __popc(word & ((1u << (off & 31)) - 1u));
 }
 __device__ __forceinline__ int64_t table_find(const DevTable& t, int64_t key, uint64_t cap_mask) {
     if (t.dense_arr) {
@@ -244,9 +263,8 @@ __device__ __forceinline__ int64_t table_find(const DevTable& t, int64_t key, ui
         return ref == NO_ROW ? -1 : (int64_t)ref;
     }
     if (t.bm) {
-        const int64_t v = t.bm_shift ? (int64_t)((uint64_t)key >> 32) : key;
-        if (v < t.bm_lo || v > t.bm_hi) return -1;
-        const uint64_t off = (uint64_t)(v - t.bm_lo);
+        uint64_t off;
+        if (!bm_locate(t, key, off)) return -1;
         const uint32_t word = t.bm[off >> 5];
         if (!((word >> (off & 31)) & 1u)) return -1;
         if (t.bitmap_only) return 0;
@@ -766,6 +784,7 @@ struct DevStage {
     int64_t bm_lo, bm_hi;
     TableHeader* hdr;
     int32_t bm_shift, _pad2;              // 32: the bitmap covers the high part of a composite key
+    int64_t lin_rb, lin_b0;               // linearised composite key (see DevTable)
 };
 
 template <class FC>
@@ -857,10 +876,9 @@ __device__ __forceinline__ void stage_store(const DevStage& st, int64_t pos, int
     if (st.shits) st.shits[pos] = 0;
     if (st.sacc) { double4 z = {0, 0, 0, 0}; *reinterpret_cast<double4*>(st.sacc + pos * 4) = z; }
     if (st.bm) {
-        const int64_t v = st.bm_shift ? (int64_t)((uint64_t)key >> 32) : key;
-        if (v >= st.bm_lo && v <= st.bm_hi) {
-            const uint64_t off = (uint64_t)(v - st.bm_lo);
-            atomicOr(&st.bm[off >> 5], 1u << (off & 31));     // fire and forget; duplicates show up as distinct < staged (k_rank_blocks)
+        uint64_t off;
+        if (bm_locate(st, key, off)) {
+            atomicOr(&st.bm[off >> 5], 1u << (off & 31));     // fire and forget; duplicates show up as distinct < staged (k_rank_words)
         }
     }
 }
@@ -962,10 +980,16 @@ __global__ __launch_bounds__(TPB) void k_clear(const uint32_t* __restrict__ seg_
 }
 
 // ---- direct layout: prefix popcounts over the bitmap, then plain stores ---------------------------
-// One workgroup per 2048 bitmap words: popcount, exclusive scan inside the block, block total.
-__global__ __launch_bounds__(TPB) void k_rank_words(const uint32_t* __restrict__ bm, uint64_t nwords,
-                                                    uint32_t* __restrict__ wprefix, uint32_t* __restrict__ btotal) {
+// One workgroup per 2048 bitmap words: popcount, exclusive scan inside the block, and a base for
+// the block claimed with one atomicAdd on hdr->distinct, folded into the per-word prefix.  Ranks
+// are a bijection onto [0, distinct), not monotone in the key: nothing needs more (the rank only
+// indexes dense_ref), and a claimed base needs no scan pass, no second launch and no device-wide
+// fence (a release fence writes back a whole XCD L2 here).  hdr->staged is summed on the side;
+// fewer distinct keys than staged rows means duplicate build keys (see direct_has_dups).
+__global__ __launch_bounds__(TPB) void k_rank_words(const uint32_t* __restrict__ bm, uint64_t nwords, uint32_t* __restrict__ wprefix,
+                                                    const uint32_t* __restrict__ seg_count, int nseg, TableHeader* __restrict__ hdr) {
     __shared__ uint32_t s_wave[TPB / WAVE];
+    __shared__ uint32_t s_base;
     constexpr int WPT = RANK_BLOCK_WORDS / TPB;                        // 8 consecutive words per thread
     const uint64_t w0 = (uint64_t)blockIdx.x * RANK_BLOCK_WORDS + (uint64_t)threadIdx.x * WPT;
     uint32_t word[WPT], mine = 0;
@@ -983,49 +1007,35 @@ __global__ __launch_bounds__(TPB) void k_rank_words(const uint32_t* __restrict__
     for (int off = 1; off < WAVE; off <<= 1) { uint32_t v = __shfl_up(incl, off, WAVE); if (lane_id() >= off) incl += v; }
     const int w = threadIdx.x / WAVE;
     if (lane_id() == WAVE - 1) s_wave[w] = incl;
+    // staged rows: every workgroup adds its share of the segment counts
+    uint32_t stg = 0;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < nseg; i += gridDim.x * TPB) stg += seg_count[i];
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) stg += __shfl_down(stg, off, WAVE);
+    if (lane_id() == 0 && stg) atomicAdd(reinterpret_cast<unsigned long long*>(&hdr->staged), (unsigned long long)stg);
     __syncthreads();
     uint32_t base = 0, total = 0;
     for (int i = 0; i < TPB / WAVE; ++i) { if (i < w) base += s_wave[i]; total += s_wave[i]; }
-    uint32_t run = base + incl - mine;
+    if (threadIdx.x == 0) s_base = total ? (uint32_t)atomicAdd(reinterpret_cast<unsigned long long*>(&hdr->distinct), (unsigned long long)total) : 0u;
+    __syncthreads();
+    uint32_t run = s_base + base + incl - mine;
 #pragma unroll
     for (int j = 0; j < WPT; ++j) { if (w0 + j < nwords) wprefix[w0 + j] = run; run += __popc(word[j]); }
-    if (threadIdx.x == 0) btotal[blockIdx.x] = total;
 }
-// one workgroup: exclusive scan of the block totals, in place.  hdr->distinct = number of set bits,
-// hdr->staged = staged rows; fewer distinct keys than staged rows means duplicate build keys.
-__global__ __launch_bounds__(TPB) void k_rank_blocks(uint32_t* __restrict__ btotal, int nblocks, const uint32_t* __restrict__ seg_count, int nseg,
-                                                     TableHeader* __restrict__ hdr) {
-    __shared__ uint32_t s_part[TPB];
-    __shared__ unsigned long long s_staged[TPB];
-    const int per = (nblocks + TPB - 1) / TPB;
-    const int b0 = threadIdx.x * per, b1 = min(nblocks, b0 + per);
-    uint32_t sum = 0;
-    for (int b = b0; b < b1; ++b) sum += btotal[b];
-    s_part[threadIdx.x] = sum;
-    unsigned long long st = 0;
-    for (int i = threadIdx.x; i < nseg; i += TPB) st += seg_count[i];
-    s_staged[threadIdx.x] = st;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0; unsigned long long staged = 0;
-        for (int i = 0; i < TPB; ++i) { uint32_t v = s_part[i]; s_part[i] = run; run += v; staged += s_staged[i]; }
-        hdr->distinct = run; hdr->staged = staged; hdr->has_dups = (staged != run) ? 1u : 0u;
-    }
-    __syncthreads();
-    uint32_t run = s_part[threadIdx.x];
-    for (int b = b0; b < b1; ++b) { uint32_t v = btotal[b]; btotal[b] = run; run += v; }
-}
+// direct layout, after k_rank_words: duplicate build keys <=> fewer set bits than staged rows
+__device__ __forceinline__ bool direct_has_dups(const TableHeader* hdr) { return hdr->staged != hdr->distinct; }
 // dense_ref[rank(key)] = stage index.  Unique build keys: plain stores, every row its own rank.
 // After a duplicate was seen while staging: atomicMin into a NO_ROW-filled array (lowest row wins).
 __global__ __launch_bounds__(TPB) void k_fill_refs(DevStage st, DevTable t) {        // no-op unless duplicates
-    if (t.hdr->has_dups == 0) return;
+    if (!direct_has_dups(t.hdr)) return;
     const uint64_t n = t.hdr->distinct;
     for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) t.dense_ref[i] = NO_ROW;
 }
 __global__ __launch_bounds__(TPB) void k_insert_direct(DevStage st, DevTable t) {
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
+    const bool dups = direct_has_dups(t.hdr);
+    if (blockIdx.x == 0 && threadIdx.x == 0) t.hdr->has_dups = dups ? 1u : 0u;     // for every later reader
     if (seg >= st.nseg) return;
-    const bool dups = t.hdr->has_dups != 0;
     const int64_t base = (int64_t)seg * st.seg_rows;
     const uint32_t count = st.seg_count[seg];
     for (uint32_t i = lane_id(); i < count; i += WAVE) {
@@ -1188,7 +1198,7 @@ __global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevT
             p[u][0] = p[u][1] = true;
         }
         pass_pairs<PU, FC, false>(f, none, r, nrows, nomask, p);
-        if (tb.bm && tb.bm_shift == 0) {                               // direct layout: all bitmap words requested before any is tested
+        if (tb.bm && tb.bm_shift == 0 && !tb.lin_rb) {                 // direct layout: all bitmap words requested before any is tested
             uint32_t w[PU][2];
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
@@ -1238,8 +1248,13 @@ __device__ __forceinline__ uint32_t pick3(const uint32_t (&e)[SDQH_MAX_LOOKUP], 
 
 __device__ __forceinline__ int64_t source_value(const DevSource& s, const DevLookups& L, int64_t r, const uint32_t (&ent)[SDQH_MAX_LOOKUP]) {
     if (s.kind == SDQH_SRC_COLUMN) return s.col[r];
-    const DevTable& t = s.lookup == 0 ? L.l[0].table : (s.lookup == 1 ? L.l[1].table : L.l[2].table);
-    const int64_t* pay = s.field == 0 ? t.pay[0] : (s.field == 1 ? t.pay[1] : (s.field == 2 ? t.pay[2] : t.pay[3]));
+    // select among the loaded pointers, never among addresses inside the by-value argument: an
+    // address select becomes a run-time index into L and forces a scratch copy of the whole struct
+    const int64_t* pay = nullptr;
+#pragma unroll
+    for (int l = 0; l < SDQH_MAX_LOOKUP; ++l)
+#pragma unroll
+        for (int q = 0; q < SDQH_MAX_PAYLOAD; ++q) { const int64_t* c = L.l[l].table.pay[q]; if (s.lookup == l && s.field == q) pay = c; }
     const int64_t v = pay[pick3(ent, s.lookup)];
     return s.kind == SDQH_SRC_LOOKUP_YEAR ? v / 10000 : v;
 }
@@ -1575,6 +1590,24 @@ __device__ __forceinline__ uint32_t compact_segment(const DevTable& t, const Dev
     }
     if (WRITE && lane < qn) compact_copy(st, o, base + q_idx[lane], written + lane, q_hits[lane]);
     return mine;
+}
+
+// Several small regions set to a byte value by ONE launch (a hipMemsetAsync per region costs a
+// launch each, and most builds need two or three).  Regions are 4-byte multiples, 16-byte aligned.
+constexpr int FILL_MAX = 4;
+struct DevFill { void* p[FILL_MAX]; uint64_t bytes[FILL_MAX]; uint32_t word[FILL_MAX]; int32_t n, _pad; };
+__global__ __launch_bounds__(TPB) void k_fill(DevFill f) {
+    const uint64_t tid = (uint64_t)blockIdx.x * TPB + threadIdx.x, nth = (uint64_t)gridDim.x * TPB;
+#pragma unroll
+    for (int r = 0; r < FILL_MAX; ++r) {
+        if (r >= f.n) break;
+        const uint32_t w = f.word[r];
+        const uint64_t n16 = f.bytes[r] / 16, n4 = f.bytes[r] / 4;
+        uint4* p16 = static_cast<uint4*>(f.p[r]);
+        for (uint64_t i = tid; i < n16; i += nth) p16[i] = make_uint4(w, w, w, w);
+        uint32_t* p4 = static_cast<uint32_t*>(f.p[r]);
+        for (uint64_t i = n16 * 4 + tid; i < n4; i += nth) p4[i] = w;
+    }
 }
 
 // 1. survivors per segment

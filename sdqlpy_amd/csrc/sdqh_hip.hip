@@ -172,6 +172,8 @@ struct KernelScope {
 };
 #define LAUNCH(ctx, name, kernel, grid, ...)                                         \
     do { KernelScope _ks(ctx, name); hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3(TPB), 0, (ctx)->stream, __VA_ARGS__); } while (0)
+#define LAUNCH_LDS(ctx, name, kernel, grid, lds_bytes, ...)                           \
+    do { KernelScope _ks(ctx, name); hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3(TPB), (lds_bytes), (ctx)->stream, __VA_ARGS__); } while (0)
 
 int sync_stream(sdqh_ctx* ctx) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -698,12 +700,15 @@ static void* table_alloc(sdqh_ctx* ctx, sdqh_table* t, size_t bytes) {
 }
 
 // stage layout shared by hash_build_unique and scan_compact
-static int setup_stage(sdqh_ctx* ctx, sdqh_table* tb, int64_t nrows, const sdqh_column* key, int npay, const sdqh_column* const* payload) {
+// `batch`: 128-row batches the staging kernel handles per loop step; a segment is a whole number
+// of steps.  Small tables get short segments (down to one step per wave): their staging is bound
+// by the dependent-load chain of a step times the steps per wave, not by bytes.
+static int setup_stage(sdqh_ctx* ctx, sdqh_table* tb, int64_t nrows, const sdqh_column* key, int npay, const sdqh_column* const* payload, int batch) {
     DevStage& st = tb->stage;
     std::memset(&st, 0, sizeof(st));
     const int64_t target_segs = (int64_t)ctx->num_cu * ctx->opt_stage_waves_per_cu;   // one segment per wave
     int64_t seg_rows = (nrows + target_segs - 1) / target_segs;
-    const int64_t gran = (int64_t)WAVE * ROWS_PER_LOAD * 8;                      // a whole number of k_stage iterations for every batch depth
+    const int64_t gran = (int64_t)WAVE * ROWS_PER_LOAD * std::max(1, batch);
     seg_rows = std::max<int64_t>(gran, (seg_rows + gran - 1) / gran * gran);
     st.seg_rows = seg_rows;
     st.nseg = (int32_t)std::max<int64_t>(1, (nrows + seg_rows - 1) / seg_rows);
@@ -837,7 +842,10 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
         return build_dense(ctx, nrows, key, npayload, payload, lo, hi, out);
     sdqh_table* tb = new sdqh_table();
     tb->npay = npayload; tb->accumulate = accumulate != 0; tb->nrows_build = nrows;
-    int rc = setup_stage(ctx, tb, nrows, key, npayload, payload);
+    // the tuned orders-like instance family runs opt_stage_batch batches per step, every other instance STAGE_BATCH
+    const bool tuned_family = f.ns == 0 && f.nf == 0 && f.ni == 1 && nprobes == 1 && npayload == 2;
+    const bool string_family = f.ns == 1 && f.nf == 0 && f.ni == 0 && nprobes == 0;
+    int rc = setup_stage(ctx, tb, nrows, key, npayload, payload, tuned_family ? ctx->opt_stage_batch : (string_family ? 1 : STAGE_BATCH));
     uint64_t capmax = 1024;
     while (capmax < 2 * (uint64_t)std::max<int64_t>(nrows, 1)) capmax <<= 1;
     tb->capmax = capmax;
@@ -853,6 +861,10 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
             call_begin(ctx);
             const unsigned seg_grid = (unsigned)((tb->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
             { FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); if (tb->bm) fl.add(tb->bm, tb->nwords * 4, 0); prefill_refs(ctx, tb, &fl); launch_fill(ctx, fl); }
+            // string predicate: fields staged through LDS, 64 rows per wave at a time (up to 64 KB per workgroup)
+            const unsigned str_rows = (f.ns && f.swidth > 0 && f.swidth <= 128) ? (f.swidth <= 64 ? 64u : 32u) : 0u;
+            const size_t stage_lds = (size_t)(TPB / WAVE) * str_rows * (size_t)f.swidth * 4;       // at most 64 KB per workgroup
+            f.slds = str_rows;
             with_stage_filter(f, nprobes, [&](auto FC) {
                 using FCT = decltype(FC);
                 if constexpr (std::is_same_v<FCT, FCfg<1, 0, 0, 1>>) {          // the tuned instance family (orders-like build side)
@@ -864,12 +876,19 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
 #undef STAGE_VARIANT
                     }
                 }
-                if (npayload == 0) { auto kern = k_stage<FCT, 0>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows); return SDQH_OK; }
-                if (npayload == 1) { auto kern = k_stage<FCT, 1>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows); return SDQH_OK; }
-                if (npayload == 2) { auto kern = k_stage<FCT, 2>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows); return SDQH_OK; }
+                if constexpr (FCT::NS == 1) {                                   // string family: one batch per step (few registers, many waves)
+                    if (npayload == 0) { auto kern = k_stage<FCT, 0, 1>; LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows); return SDQH_OK; }
+                    auto kern = k_stage<FCT, -1, 1>;
+                    LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows);
+                    return SDQH_OK;
+                } else {
+                if (npayload == 0) { auto kern = k_stage<FCT, 0>; LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows); return SDQH_OK; }
+                if (npayload == 1) { auto kern = k_stage<FCT, 1>; LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows); return SDQH_OK; }
+                if (npayload == 2) { auto kern = k_stage<FCT, 2>; LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows); return SDQH_OK; }
                 auto kern = k_stage<FCT, -1>;
-                LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows);
+                LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows);
                 return SDQH_OK;
+                }
             });
             call_end(ctx);
             hipError_t e = hipGetLastError();
@@ -1163,7 +1182,7 @@ int sdqh_build(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nloo
     // stage without source columns: the kernel evaluates sources itself
     sdqh_column fake; fake.data = nullptr;
     const sdqh_column* fakes[SDQH_MAX_PAYLOAD] = {&fake, &fake, &fake, &fake};
-    int rc = setup_stage(ctx, tb, nrows, &fake, npayload, fakes);
+    int rc = setup_stage(ctx, tb, nrows, &fake, npayload, fakes, 1);          // k_build_lookup steps one 128-row batch at a time
     uint64_t capmax = 1024;
     while (capmax < 2 * (uint64_t)std::max<int64_t>(nrows, 1)) capmax <<= 1;
     tb->capmax = capmax;
@@ -1280,7 +1299,7 @@ int sdqh_scan_compact(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, i
     for (int c = 0; c < ncols; ++c) if (!cols[c] || cols[c]->nrows < nrows || cols[c]->dtype == SDQH_STR) return fail(ctx, SDQH_ERR_INVALID, "scan_compact: columns must be I64/F64 and cover nrows");
     // a throw-away stage: column 0 plays the key, the others the payload
     sdqh_table tmp;
-    int rc = setup_stage(ctx, &tmp, nrows, cols[0], ncols - 1, cols + 1);
+    int rc = setup_stage(ctx, &tmp, nrows, cols[0], ncols - 1, cols + 1, STAGE_BATCH);
     uint64_t* seg_off = nullptr; unsigned long long* total = nullptr;
     sdqh_column* outs[SDQH_MAX_COMPACT_COLS] = {nullptr};
     if (!rc) {

@@ -46,7 +46,7 @@ struct DevFilter {
     uint32_t sval[SDQH_MAX_STR_CONST];
     // ranges on tuple operand slots (an f-predicate whose column is also a value operand is
     // checked on the already-loaded operand instead of being loaded twice)
-    uint32_t omask, _pad;
+    uint32_t omask, slds;     // slds = 64 or 32: the launch carries slds * swidth words of dynamic LDS per wave (str_stage_mask)
     double olo[4], ohi[4];
 };
 
@@ -228,6 +228,78 @@ __device__ __forceinline__ bool str_contains(const uint32_t* __restrict__ s, int
 __device__ __forceinline__ bool str_pred(const uint32_t* __restrict__ s, int width, const uint32_t* val, int len, int mode) {
     if (mode == 2) return str_contains(s, width, val, len);
     return str_equal(s, width, val, len) != (mode != 0);
+}
+// ---- the string predicate on fields staged in LDS -------------------------------------------------
+// Branch-free over the whole fixed width, so every LDS read of a field is independent of the
+// comparisons (the per-lane early-exit loops above chain one read latency per character).
+// equality: first `len` units equal, the rest zero.
+__device__ __forceinline__ bool lds_str_equal(const uint32_t* s, int width, const uint32_t* val, int len) {
+    if (len > width) return false;
+    uint32_t diff = 0;
+#pragma unroll 4
+    for (int k = 0; k < width; ++k) diff |= s[k] ^ (k < len ? val[k] : 0u);
+    return diff == 0;
+}
+// substring: one pass over the field builds two position masks per 32 units — "equals the first
+// unit of the needle" and "is NUL" — with no branch and no dependence between the LDS reads; only
+// the (few) first-unit hits before the first NUL are then verified.  wcsstr semantics: the field
+// ends at its first NUL (reference include/varchar.h:84-89).
+__device__ __forceinline__ bool lds_str_contains(const uint32_t* s, int width, const uint32_t* val, int len) {
+    const uint32_t v0 = val[0];
+    bool found = false, ended = false;
+    for (int w0 = 0; w0 < width && !ended && !found; w0 += 32) {          // per-lane state, usually one or two rounds
+        uint32_t first = 0, nul = 0;
+        const int nk = min(32, width - w0);
+        if (nk == 32) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) { const uint32_t c = s[w0 + k]; first |= (c == v0 ? 1u : 0u) << k; nul |= (c == 0u ? 1u : 0u) << k; }
+        } else {
+#pragma unroll 4
+            for (int k = 0; k < nk; ++k) { const uint32_t c = s[w0 + k]; first |= (c == v0 ? 1u : 0u) << k; nul |= (c == 0u ? 1u : 0u) << k; }
+            nul |= nk < 32 ? (1u << nk) : 0u;                              // the field ends with its width
+        }
+        if (nul) { first &= (nul & (0u - nul)) - 1u; ended = true; }      // only hits before the first NUL
+        while (first) {
+            const int pos = w0 + __builtin_ctz(first);
+            first &= first - 1u;
+            if (pos + len > width) break;
+            int k = 1;
+            while (k < len && s[pos + k] == val[k]) ++k;                  // a NUL inside stops the comparison: the needle has none
+            if (k == len) { found = true; break; }
+        }
+    }
+    return found;
+}
+__device__ __forceinline__ bool lds_str_pred(const uint32_t* s, int width, const uint32_t* val, int len, int mode) {
+    if (mode == 2) {
+        if (len == 0) return true;
+        return lds_str_contains(s, width, val, len);
+    }
+    return lds_str_equal(s, width, val, len) != (mode != 0);
+}
+// The string predicate over `rows` (64 or 32) consecutive rows (row0 + lane), staged through LDS:
+// the wave copies the fixed-width fields with coalesced 16-byte loads (all in flight before the
+// first LDS store), then lane i < rows scans field i out of LDS.  Per-lane character loops straight
+// from global memory touch 64 different cache lines per instruction.  Returns the ballot of rows
+// that pass.  row0 is a multiple of 32, so the block is 16-byte aligned; rows * swidth <= 4096.
+__device__ __forceinline__ uint64_t str_stage_mask(const DevFilter& f, uint32_t* __restrict__ s_str, int64_t row0, int rows) {
+    const int lane = lane_id();
+    const int nvec = (rows * f.swidth) / 4;                               // a whole number of 16-byte vectors, <= 1024
+    using V4 = uint32_t __attribute__((ext_vector_type(4)));
+    const V4* __restrict__ src = reinterpret_cast<const V4*>(f.sc + row0 * f.swidth);
+    V4* dst = reinterpret_cast<V4*>(s_str);
+    __builtin_amdgcn_wave_barrier();
+    for (int i0 = 0; i0 < nvec; i0 += 8 * WAVE) {
+        V4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * WAVE + lane; if (i < nvec) t[u] = __builtin_nontemporal_load(src + i); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * WAVE + lane; if (i < nvec) dst[i] = t[u]; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool ok = lane < rows && lds_str_pred(s_str + lane * f.swidth, f.swidth, f.sval, f.slen, f.sneg);
+    __builtin_amdgcn_wave_barrier();
+    return __ballot(ok);
 }
 
 __device__ __forceinline__ int64_t table_find(const DevTable& t, int64_t key, uint64_t cap_mask);
@@ -805,7 +877,7 @@ __device__ __forceinline__ bool row_passes(const DevFilter& f, const DevProbes& 
 // loads for every row, the remaining predicates and the probe keys only by lanes still alive.
 template <int NB, class FC, bool EAGER = true>
 __device__ __forceinline__ void pass_pairs(const DevFilter& f, const DevProbes& pr, const int64_t (&r)[NB], int64_t nrows,
-                                           const uint64_t* cap_masks, bool (&p)[NB][2]) {
+                                           const uint64_t* cap_masks, bool (&p)[NB][2], uint32_t* s_str = nullptr) {
     // EAGER: the first probe's key column is streamed with 16-byte loads alongside the first
     // predicate instead of being fetched afterwards by the surviving lanes only.  When a good part
     // of the rows survive, every cache line of the key column is touched anyway, and one stage of
@@ -843,10 +915,34 @@ __device__ __forceinline__ void pass_pairs(const DevFilter& f, const DevProbes& 
         for (int j = 0; j < NB; ++j) { p[j][0] &= (v[j][0] >= f.flo[i]) & (v[j][0] <= f.fhi[i]); p[j][1] &= (v[j][1] >= f.flo[i]) & (v[j][1] <= f.fhi[i]); }
     }
     if (cfg_ns<FC>(f.ns)) {
+        if (s_str) {
+            // lane L holds rows 2L, 2L+1 of each 128-row batch: rows 0..63 belong to lanes 0..31, 64..127 to lanes 32..63
+            const int lane = lane_id();
+            const int half = lane >> 5, sh = (2 * lane) & 63;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            if (p[j][0]) p[j][0] = str_pred(f.sc + r[j] * f.swidth, f.swidth, f.sval, f.slen, f.sneg);
-            if (p[j][1]) p[j][1] = str_pred(f.sc + (r[j] + 1) * f.swidth, f.swidth, f.sval, f.slen, f.sneg);
+            for (int j = 0; j < NB; ++j) {
+                const int64_t base = r[j] - 2 * lane;
+                const uint64_t live = __ballot(p[j][0] | p[j][1]);
+                uint64_t m[2] = {0, 0};
+                if (f.slds == 64) {
+                    if (live & 0x00000000FFFFFFFFull) m[0] = str_stage_mask(f, s_str, base, 64);
+                    if (live & 0xFFFFFFFF00000000ull) m[1] = str_stage_mask(f, s_str, base + 64, 64);
+                } else {                                                  // wide fields: 32 rows per staging keeps the LDS footprint of a wave small
+                    if (live & 0x000000000000FFFFull) m[0] = str_stage_mask(f, s_str, base, 32);
+                    if (live & 0x00000000FFFF0000ull) m[0] |= str_stage_mask(f, s_str, base + 32, 32) << 32;
+                    if (live & 0x0000FFFF00000000ull) m[1] = str_stage_mask(f, s_str, base + 64, 32);
+                    if (live & 0xFFFF000000000000ull) m[1] |= str_stage_mask(f, s_str, base + 96, 32) << 32;
+                }
+                const uint64_t mine = half ? m[1] : m[0];
+                p[j][0] = p[j][0] && ((mine >> sh) & 1ull);
+                p[j][1] = p[j][1] && ((mine >> (sh + 1)) & 1ull);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (p[j][0]) p[j][0] = str_pred(f.sc + r[j] * f.swidth, f.swidth, f.sval, f.slen, f.sneg);
+                if (p[j][1]) p[j][1] = str_pred(f.sc + (r[j] + 1) * f.swidth, f.swidth, f.sval, f.slen, f.sneg);
+            }
         }
     }
 #pragma unroll
@@ -885,8 +981,10 @@ __device__ __forceinline__ void stage_store(const DevStage& st, int64_t pos, int
 
 template <class FC, int NPAY = -1, int SB = STAGE_BATCH, bool EAGER = true, bool EAGER_PAY = false>
 __global__ __launch_bounds__(TPB) void k_stage(DevFilter f, DevProbes pr, DevStage st, int64_t nrows) {
+    extern __shared__ __align__(16) uint32_t s_dyn[];                   // f.slds * swidth words per wave (string predicate staging)
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
     if (seg >= st.nseg) return;
+    uint32_t* s_str = (cfg_ns<FC>(f.ns) && f.slds) ? s_dyn + (size_t)(threadIdx.x / WAVE) * f.slds * f.swidth : nullptr;
     uint64_t cap_masks[SDQH_MAX_PROBE] = {0, 0};
 #pragma unroll
     for (int i = 0; i < SDQH_MAX_PROBE; ++i) if (i < cfg_np<FC>(pr.n) && pr.table[i].hdr && !table_is_direct(pr.table[i]) && !pr.table[i].bitmap_only) cap_masks[i] = pr.table[i].hdr->cap_mask;
@@ -921,7 +1019,7 @@ __global__ __launch_bounds__(TPB) void k_stage(DevFilter f, DevProbes pr, DevSta
             }
 #pragma unroll
             for (int j = 0; j < SB; ++j) p[j][0] = p[j][1] = true;
-            pass_pairs<SB, FC, EAGER>(f, pr, r, nrows, cap_masks, p);
+            pass_pairs<SB, FC, EAGER>(f, pr, r, nrows, cap_masks, p, s_str);
         } else {
 #pragma unroll
             for (int j = 0; j < SB; ++j) {

@@ -1,4 +1,4 @@
-"""In-tree native builds: the HIP library (hipcc, gfx950), the TPCH generator (g++).
+"""In-tree native builds: the HIP library (hipcc, gfx950), the TPCH generator and the text-table loader (g++).
 
 Everything is built next to its sources so the .so files travel with the repository snapshot to
 the GPU box; nothing is installed into site-packages and nothing is JIT-cached under ~/.cache.
@@ -14,6 +14,7 @@ INCLUDE = os.path.join(ROOT, "include")
 
 HIP_LIB = os.path.join(CSRC, "libsdqlhip.so")
 GEN_LIB = os.path.join(CSRC, "libtpchgen.so")
+TBL_LIB = os.path.join(CSRC, "libsdqltbl.so")
 
 HIP_SOURCES = [os.path.join(CSRC, "sdqh_hip.hip")]
 HIP_HEADERS = [os.path.join(INCLUDE, "sdqh.h"), os.path.join(CSRC, "sdqh_kernels.hpp")]
@@ -47,6 +48,13 @@ def build_tpchgen(force=False):
     return GEN_LIB
 
 
+def build_tblload(force=False):
+    src = os.path.join(CSRC, "tblload.cpp")
+    if force or _stale(TBL_LIB, [src]):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", TBL_LIB, src])
+    return TBL_LIB
+
+
 def hipcc_path():
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -69,7 +77,7 @@ def build_hip(force=False, save_temps=False):
 
 
 def build_all(force=False):
-    return {"tpchgen": build_tpchgen(force), "hip": build_hip(force)}
+    return {"tpchgen": build_tpchgen(force), "tblload": build_tblload(force), "hip": build_hip(force)}
 
 
 if __name__ == "__main__":

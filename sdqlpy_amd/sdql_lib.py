@@ -19,7 +19,6 @@ hand-written HIP kernels for gfx950.  There is no CPU execution path in this pac
 library cannot be loaded, or a query uses a loop shape outside the backend's vocabulary, the call
 raises — it never falls back to interpreting the query in Python.
 """
-import csv
 import functools
 import inspect
 import os
@@ -29,7 +28,7 @@ import time
 import numpy as np
 
 __all__ = [
-    "string", "date", "read_csv", "sr_dict", "record", "vector",
+    "string", "date", "read_csv", "write_columns", "read_columns", "sr_dict", "record", "vector",
     "extractYear", "firstIndex", "startsWith", "endsWith", "dictSize", "substr", "unique", "dense",
     "sdqlpy_init", "sdql_compile", "benchmark",
 ]
@@ -248,30 +247,27 @@ def table_from_columns(headers, columns):
 def read_csv(file_path, header_type_dict, dataset_name, delimiter='|'):
     """Load a dbgen-style text table into one numpy array per column: int -> int64, float ->
     float64, date -> yyyymmdd int64, string(n) -> '<U n' (ref sdql_lib.py:69-129).  A trailing
-    empty field produced by the line-terminating delimiter lands in the schema's *_NA column."""
+    empty field produced by the line-terminating delimiter lands in the schema's *_NA column.
+    Parsing is native and parallel (loader.py / csrc/tblload.cpp)."""
+    from . import loader
     headers, types = _column_types(header_type_dict)
-    raw = [[] for _ in headers]
-    with open(file_path, newline="\n") as fh:
-        for row in csv.reader(fh, delimiter=delimiter):
-            for i, cell in enumerate(row):
-                t = types[i]
-                if t == date:
-                    raw[i].append(int(cell.replace("-", "")))
-                elif isinstance(t, string):
-                    raw[i].append(cell)
-                else:
-                    raw[i].append(t(cell))
-    cols = []
-    for t, values in zip(types, raw):
-        if isinstance(t, string):
-            cols.append(np.array(values, "<U" + str(t.max_size)))
-        elif t == float:
-            cols.append(np.array(values, np.float64))
-        elif t == int or t == date:
-            cols.append(np.array(values, np.int64))
-        else:
-            cols.append(np.array(values))
+    cols = loader.read_text(file_path, types, delimiter)
     print("Reading " + file_path + " Finished.")
+    return sr_dict({"headers": headers, "data": cols}, None, True)
+
+
+def write_columns(directory, table):
+    """Store a columnar table (read_csv / table_from_columns) in the binary column format."""
+    from . import loader
+    c = table.getContainer()
+    return loader.write_columns(directory, c["headers"], c["data"])
+
+
+def read_columns(directory, header_type_dict=None, mmap=True):
+    """Load a table stored by write_columns; with a schema, its columns in schema order."""
+    from . import loader
+    want = _column_types(header_type_dict)[0] if header_type_dict is not None else None
+    headers, cols = loader.read_columns(directory, want, mmap)
     return sr_dict({"headers": headers, "data": cols}, None, True)
 
 

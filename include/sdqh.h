@@ -226,6 +226,24 @@ int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits,
 int  sdqh_host_alloc(sdqh_ctx* ctx, size_t bytes, void** out);
 void sdqh_host_free(sdqh_ctx* ctx, void* block);
 
+/* ---- top-k of the entries (ORDER BY ... LIMIT k on top of K-F) ---------------------------------
+ * The k first entries with at least min_hits rows in the order given by `sort` (1..SDQH_MAX_SORT_KEYS
+ * keys: the entry key, payload field `index`, accumulator `index` or the hit count; ascending or
+ * descending; is_f64 says a payload field holds a double), ties broken by build-row order — a total
+ * order.  Outputs as sdqh_table_compact with capacity = k: out_payload[p*k + i], out_values[v*k + i];
+ * *out_n = rows written (<= k).  Not in the reference, whose Q3 returns the unsorted set
+ * (test/test_all.py:174); BASELINE config 3 names it ("hash joins + top-k"). */
+#define SDQH_MAX_TOPK 128
+#define SDQH_MAX_SORT_KEYS 3
+#define SDQH_SORT_KEY 0
+#define SDQH_SORT_PAYLOAD 1
+#define SDQH_SORT_VALUE 2
+#define SDQH_SORT_HITS 3
+typedef struct sdqh_sort_key { int32_t kind, index, descending, is_f64; } sdqh_sort_key;
+int sdqh_table_topk(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, int k,
+                    int nsort, const sdqh_sort_key* sort,
+                    int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n);
+
 /* The entries of a table (every owner row: key, then the npayload payload fields) as resident
  * columns, for re-distribution without a host round trip.  out_cols[1 + npayload]. */
 int sdqh_table_entries(sdqh_ctx* ctx, const sdqh_table* table, sdqh_column** out_cols, int64_t* out_rows);

@@ -562,6 +562,58 @@ int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits,
     return SDQH_OK;
 }
 
+// ORDER BY ... LIMIT k over the entries: the sort keys, then insertion (= build-row) order.
+int sdqh_table_topk(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, int k, int nsort, const sdqh_sort_key* sort,
+                    int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n) {
+    if (!ctx || !table || !out_n || !sort || nsort < 1 || nsort > SDQH_MAX_SORT_KEYS) return fail(ctx, SDQH_ERR_INVALID, "table_topk: bad arguments");
+    if (k < 1 || k > SDQH_MAX_TOPK) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_topk: k must be 1..SDQH_MAX_TOPK");
+    if (table->bitmap_only) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_topk: bitmap-only table");
+    for (int i = 0; i < nsort; ++i) {
+        const sdqh_sort_key& sk = sort[i];
+        const bool ok = (sk.kind == SDQH_SORT_KEY) || (sk.kind == SDQH_SORT_PAYLOAD && sk.index >= 0 && sk.index < table->npayload) ||
+                        (sk.kind == SDQH_SORT_VALUE && sk.index >= 0 && sk.index < SDQH_TUPLE_MAX_VALUES && table->accumulate) ||
+                        (sk.kind == SDQH_SORT_HITS && table->accumulate);
+        if (!ok) return fail(ctx, SDQH_ERR_INVALID, "table_topk: sort key names a field the table does not have");
+    }
+    auto bits = [](int64_t raw, bool is_f64, bool desc) {
+        uint64_t u = (uint64_t)raw;
+        if (is_f64) u = (u >> 63) ? ~u : (u | (1ull << 63)); else u ^= (1ull << 63);
+        return desc ? ~u : u;
+    };
+    struct Cand { uint64_t k[SDQH_MAX_SORT_KEYS]; size_t e; };
+    std::vector<Cand> cands;
+    for (size_t e = 0; e < table->keys.size(); ++e) {
+        const int64_t hits = table->accumulate ? table->acc[e].n : 0;
+        if (hits < min_hits) continue;
+        Cand c{}; c.e = e;
+        for (int i = 0; i < nsort; ++i) {
+            const sdqh_sort_key& sk = sort[i];
+            int64_t raw; bool f64 = false;
+            if (sk.kind == SDQH_SORT_KEY) raw = table->keys[e];
+            else if (sk.kind == SDQH_SORT_PAYLOAD) { raw = table->payload[e * (size_t)table->npayload + (size_t)sk.index]; f64 = sk.is_f64 != 0; }
+            else if (sk.kind == SDQH_SORT_VALUE) { std::memcpy(&raw, &table->acc[e].v[sk.index], 8); f64 = true; }
+            else raw = hits;
+            c.k[i] = bits(raw, f64, sk.descending != 0);
+        }
+        cands.push_back(c);
+    }
+    auto less = [nsort](const Cand& a, const Cand& b) {
+        for (int i = 0; i < nsort; ++i) if (a.k[i] != b.k[i]) return a.k[i] < b.k[i];
+        return a.e < b.e;
+    };
+    const size_t n = std::min<size_t>((size_t)k, cands.size());
+    std::partial_sort(cands.begin(), cands.begin() + (std::ptrdiff_t)n, cands.end(), less);
+    for (size_t i = 0; i < n; ++i) {
+        const size_t e = cands[i].e;
+        if (out_keys) out_keys[i] = table->keys[e];
+        if (out_payload) for (int p = 0; p < table->npayload; ++p) out_payload[(size_t)p * (size_t)k + i] = table->payload[e * (size_t)table->npayload + (size_t)p];
+        if (out_values) for (int v = 0; v < SDQH_TUPLE_MAX_VALUES; ++v) out_values[(size_t)v * (size_t)k + i] = table->accumulate ? table->acc[e].v[v] : 0.0;
+        if (out_hits) out_hits[i] = table->accumulate ? table->acc[e].n : 0;
+    }
+    *out_n = (int64_t)n;
+    return SDQH_OK;
+}
+
 // Result blocks: plain process memory here (the product hands out pinned, device-visible memory).
 int sdqh_host_alloc(sdqh_ctx* ctx, size_t bytes, void** out) {
     if (!ctx || !out || bytes == 0) return fail(ctx, SDQH_ERR_INVALID, "host_alloc: bad arguments");

@@ -14,6 +14,8 @@ OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_OVERFLOW, ERR_NOMEM = range(6)
 I64, F64, STR = 0, 1, 2
 TUPLE_A, TUPLE_AB, TUPLE_A_1MB, TUPLE_PRICING, TUPLE_A_1MB_M_CD, TUPLE_COUNT = 1, 2, 3, 4, 5, 6
 TUPLE_MAX_VALUES = 4
+SORT_KEY, SORT_PAYLOAD, SORT_VALUE, SORT_HITS = 0, 1, 2, 3
+MAX_TOPK, MAX_SORT_KEYS = 128, 3
 TUPLE_NVALUES = {TUPLE_A: 1, TUPLE_AB: 1, TUPLE_A_1MB: 1, TUPLE_PRICING: 4, TUPLE_A_1MB_M_CD: 1, TUPLE_COUNT: 0}
 TUPLE_NOPERANDS = {TUPLE_A: 1, TUPLE_AB: 2, TUPLE_A_1MB: 2, TUPLE_PRICING: 4, TUPLE_A_1MB_M_CD: 4, TUPLE_COUNT: 0}
 MAX_IPRED, MAX_FPRED, MAX_SPRED, MAX_STR_CONST = 4, 4, 1, 64
@@ -52,6 +54,10 @@ class Tuple(C.Structure):
 
 class Probe(C.Structure):
     _fields_ = [("table", C.c_void_p), ("key", C.c_void_p)]
+
+
+class SortKey(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("index", C.c_int32), ("descending", C.c_int32), ("is_f64", C.c_int32)]
 
 
 SRC_COLUMN, SRC_LOOKUP, SRC_LOOKUP_YEAR = 0, 1, 2
@@ -111,7 +117,7 @@ EXPORTS = [
     "sdqh_scan_filter_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_table_size", "sdqh_table_free",
     "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_scan_compact", "sdqh_partition_by_key",
     "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in",
-    "sdqh_build", "sdqh_lookup_aggregate", "sdqh_table_entries", "sdqh_host_alloc", "sdqh_host_free",
+    "sdqh_build", "sdqh_lookup_aggregate", "sdqh_table_entries", "sdqh_host_alloc", "sdqh_host_free", "sdqh_table_topk",
 ]
 
 
@@ -461,6 +467,24 @@ class Context:
         self._after_call("table_compact")
         n = n.value
         return (keys[:n], None if payload is None else payload[:, :n], None if values is None else values[:, :n], None if hits is None else hits[:n], n)
+
+    def table_topk(self, table, min_hits, k, sort, want_hits=True):
+        """ORDER BY ... LIMIT k over the entries.  sort: [(kind, index, descending, is_f64)] with kind
+        in SORT_KEY / SORT_PAYLOAD / SORT_VALUE / SORT_HITS.  Returns (keys, payload, values, hits) of n <= k rows, in order."""
+        k = int(k)
+        arr = (SortKey * len(sort))()
+        for i, (kind, index, desc, is_f64) in enumerate(sort):
+            arr[i].kind, arr[i].index, arr[i].descending, arr[i].is_f64 = int(kind), int(index), int(bool(desc)), int(bool(is_f64))
+        keys = np.empty(k, np.int64)
+        payload = np.empty((max(1, table.npayload), k), np.int64) if table.npayload else None
+        values = np.empty((TUPLE_MAX_VALUES, k), np.float64) if table.accumulate else None
+        hits = np.empty(k, np.int64) if want_hits else None
+        n = C.c_int64()
+        self._check(self.lib.sdqh_table_topk(self.handle, table.handle, C.c_int64(min_hits), C.c_int(k), C.c_int(len(sort)), arr,
+                                             _np_ptr(keys), _np_ptr(payload), _np_ptr(values), _np_ptr(hits), C.byref(n)))
+        self._after_call("table_topk")
+        n = n.value
+        return (keys[:n], None if payload is None else payload[:, :n], None if values is None else values[:, :n], None if hits is None else hits[:n])
 
     def table_entries(self, table):
         """(Columns [key, payload...], n): the table's entries as resident columns."""

@@ -1077,6 +1077,69 @@ int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_hits
     return SDQH_OK;
 }
 
+int sdqh_table_topk(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_hits, int k, int nsort, const sdqh_sort_key* sort,
+                    int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n) {
+    sdqh_table* table = const_cast<sdqh_table*>(ctable);
+    if (!ctx || !table || !out_n || !sort || nsort < 1 || nsort > SDQH_MAX_SORT_KEYS) return fail(ctx, SDQH_ERR_INVALID, "table_topk: bad arguments");
+    if (k < 1 || k > SDQH_MAX_TOPK) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_topk: k must be 1..SDQH_MAX_TOPK");
+    if (table->bitmap_only) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_topk: bitmap-only table");
+    (void)hipSetDevice(ctx->device);
+    DevTopSpec spec; std::memset(&spec, 0, sizeof(spec));
+    spec.nsort = nsort; spec.k = k;
+    const int nv = table->accumulate ? table->nv : 0;
+    for (int i = 0; i < nsort; ++i) {
+        const sdqh_sort_key& sk = sort[i];
+        const bool ok = (sk.kind == SDQH_SORT_KEY) || (sk.kind == SDQH_SORT_PAYLOAD && sk.index >= 0 && sk.index < table->npay) ||
+                        (sk.kind == SDQH_SORT_VALUE && sk.index >= 0 && sk.index < nv) || (sk.kind == SDQH_SORT_HITS && table->accumulate);
+        if (!ok) return fail(ctx, SDQH_ERR_INVALID, "table_topk: sort key names a field the table does not have");
+        spec.key[i].kind = sk.kind; spec.key[i].index = sk.index; spec.key[i].desc = sk.descending ? 1 : 0;
+        spec.key[i].is_f64 = sk.kind == SDQH_SORT_VALUE ? 1 : (sk.kind == SDQH_SORT_PAYLOAD ? (sk.is_f64 ? 1 : 0) : 0);
+    }
+    call_begin(ctx);
+    if (int rc = ensure_index(ctx, table)) return rc;
+    // level 0 grid: enough workgroups to stream the stage, few enough that k padded candidates each stay small
+    const unsigned g0 = (unsigned)std::max(1, std::min(table->stage.nseg, 4 * ctx->num_cu));
+    const size_t cand = (size_t)g0 * (size_t)k;
+    const size_t rec = 8 * 3 + 4;
+    char* blob = static_cast<char*>(pool_alloc(ctx, 2 * (cand * rec + 64 * 4) + (size_t)k * 8 * 10 + 256));
+    if (!blob) return fail(ctx, SDQH_ERR_NOMEM, "table_topk: out of device memory");
+    auto carve = [&](char*& p, DevTopBuf& b) {
+        b.k0 = reinterpret_cast<uint64_t*>(p); p += cand * 8; b.k1 = reinterpret_cast<uint64_t*>(p); p += cand * 8;
+        b.k2 = reinterpret_cast<uint64_t*>(p); p += cand * 8; b.ref = reinterpret_cast<uint32_t*>(p); p += (cand * 4 + 63) / 64 * 64;
+    };
+    char* p = blob;
+    DevTopBuf buf[2]; carve(p, buf[0]); carve(p, buf[1]);
+    DevTopOut fin; std::memset(&fin, 0, sizeof(fin));
+    int64_t* packed = reinterpret_cast<int64_t*>(p);                          // [count | keys k | hits k | pay 4k | val 4k]
+    fin.count = reinterpret_cast<unsigned long long*>(packed);
+    fin.keys = packed + 8; fin.hits = packed + 8 + k; fin.pay = packed + 8 + 2 * (size_t)k; fin.val = reinterpret_cast<double*>(packed + 8 + 6 * (size_t)k);
+    fin.npay = table->npay; fin.nval = nv;
+    const uint32_t mh = (uint32_t)std::min<int64_t>(std::max<int64_t>(min_hits, 0), 0xFFFFFFFFll);
+    LAUNCH(ctx, "k_topk_scan", k_topk_scan, g0, table->dev, table->stage, spec, mh, buf[0], fin);
+    int n_in = (int)cand, cur = 0;
+    while (g0 > 1) {
+        const unsigned g = (unsigned)((n_in + TOPK_CHUNK - 1) / TOPK_CHUNK);
+        LAUNCH(ctx, "k_topk_reduce", k_topk_reduce, g, buf[cur], n_in, table->stage, spec, buf[cur ^ 1], fin);
+        if (g == 1) break;
+        n_in = (int)g * k; cur ^= 1;
+    }
+    call_end(ctx);
+    const size_t packed_bytes = (8 + 10 * (size_t)k) * 8;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->result_host, packed, packed_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    int rc = sync_stream(ctx);
+    pool_free(ctx, blob);
+    if (rc) return rc;
+    const int64_t* h = static_cast<const int64_t*>(ctx->result_host);
+    const int64_t n = h[0];
+    *out_n = n;
+    const size_t nb = (size_t)n * 8;
+    if (out_keys) std::memcpy(out_keys, h + 8, nb);
+    if (out_hits) std::memcpy(out_hits, h + 8 + k, nb);
+    if (out_payload) for (int q = 0; q < table->npay; ++q) std::memcpy(out_payload + (size_t)q * k, h + 8 + 2 * (size_t)k + (size_t)q * k, nb);
+    if (out_values) for (int v = 0; v < SDQH_TUPLE_MAX_VALUES; ++v) std::memcpy(out_values + (size_t)v * k, h + 8 + 6 * (size_t)k + (size_t)v * k, nb);
+    return SDQH_OK;
+}
+
 int sdqh_host_alloc(sdqh_ctx* ctx, size_t bytes, void** out) {
     if (!ctx || !out || bytes == 0) return fail(ctx, SDQH_ERR_INVALID, "host_alloc: bad arguments");
     (void)hipSetDevice(ctx->device);

@@ -1755,6 +1755,180 @@ __global__ __launch_bounds__(TPB) void k_compact_write(DevTable t, DevStage st, 
 }
 
 // =================================================================================================
+// Top-k over the entries of a table (ORDER BY ... LIMIT k after K-F; BASELINE config "Q3 ... + top-k",
+// SURVEY.md §8f.2 — the reference has no such operator, its Q3 returns the whole set).
+// Order: up to three sort keys (the entry's key, a payload field, an accumulator or its hit count,
+// each ascending or descending), then build-row order — a total order, so the result is the same in
+// every run and on every implementation of the ABI.
+//   level 0  k_topk_scan    each workgroup walks its share of the stage segments, keeps the entries
+//                           with hits >= min_hits in a 1024-slot LDS buffer and cuts it back to its k
+//                           best whenever the next batch might not fit; writes k candidates (padded)
+//   level i  k_topk_reduce  1024 candidates per workgroup -> k, until one workgroup is left; that
+//                           one writes the result rows
+// Selection is k rounds of "argmin of the rest" by one wave (top_block_select), cheap for the k of a
+// LIMIT clause (k <= SDQH_MAX_TOPK).
+// =================================================================================================
+constexpr int TOPK_CHUNK = 1024;
+constexpr int TOPK_PER_LANE = TOPK_CHUNK / WAVE;                       // 16 slots per lane of the selecting wave
+struct DevSortKey { int32_t kind, index, desc, is_f64; };
+struct DevTopSpec { DevSortKey key[SDQH_MAX_SORT_KEYS]; int32_t nsort, k; };
+struct DevTopBuf { uint64_t* k0; uint64_t* k1; uint64_t* k2; uint32_t* ref; };
+struct DevTopOut { int64_t* keys; int64_t* pay; double* val; int64_t* hits; unsigned long long* count; int32_t npay, nval; };   // pay[p*k+i], val[v*k+i]
+
+// order-preserving map onto uint64 where smaller sorts first in the requested direction
+__device__ __forceinline__ uint64_t sort_bits(int64_t raw, int is_f64, int desc) {
+    uint64_t u = (uint64_t)raw;
+    if (is_f64) u = (u >> 63) ? ~u : (u | (1ull << 63)); else u ^= (1ull << 63);
+    return desc ? ~u : u;
+}
+__device__ __forceinline__ uint64_t top_sort_value(const DevSortKey& sk, const DevStage& st, int64_t idx, uint32_t hits) {
+    int64_t raw = 0;
+    if (sk.kind == SDQH_SORT_KEY) raw = st.key[idx];
+    else if (sk.kind == SDQH_SORT_PAYLOAD) { const int64_t* p = sk.index == 0 ? st.pay[0] : (sk.index == 1 ? st.pay[1] : (sk.index == 2 ? st.pay[2] : st.pay[3])); raw = p[idx]; }
+    else if (sk.kind == SDQH_SORT_VALUE) raw = __double_as_longlong(st.sacc[(size_t)idx * 4 + sk.index]);
+    else raw = (int64_t)hits;
+    return sort_bits(raw, sk.is_f64, sk.desc);
+}
+
+struct TopLds {
+    uint64_t k0[TOPK_CHUNK], k1[TOPK_CHUNK], k2[TOPK_CHUNK];
+    uint32_t ref[TOPK_CHUNK];
+    uint64_t o0[SDQH_MAX_TOPK], o1[SDQH_MAX_TOPK], o2[SDQH_MAX_TOPK];     // the selection, in order
+    uint32_t oref[SDQH_MAX_TOPK];
+    int count;
+};
+__device__ __forceinline__ bool top_less(const TopLds& s, int a, int b) {       // slot a sorts strictly before slot b
+    if (s.k0[a] != s.k0[b]) return s.k0[a] < s.k0[b];
+    if (s.k1[a] != s.k1[b]) return s.k1[a] < s.k1[b];
+    if (s.k2[a] != s.k2[b]) return s.k2[a] < s.k2[b];
+    if (s.ref[a] != s.ref[b]) return s.ref[a] < s.ref[b];
+    return a < b;                                   // padding slots are all alike: the slot number keeps the order strict, so every lane of the butterfly agrees on the winner
+}
+// best live slot of this lane (slots lane + 64*i): smallest primary key, equal primaries compared in LDS
+__device__ __forceinline__ void top_lane_best(const TopLds& s, const uint64_t (&kk)[TOPK_PER_LANE], uint32_t live, int lane, int& best, uint64_t& bk) {
+    best = -1; bk = ~0ull;
+#pragma unroll
+    for (int i = 0; i < TOPK_PER_LANE; ++i) {
+        const bool lv = (live >> i) & 1u;
+        bool lt = lv && (best < 0 || kk[i] < bk);
+        if (lv && best >= 0 && kk[i] == bk) lt = top_less(s, lane + WAVE * i, best);      // rare: the branch is skipped when no lane ties
+        if (lt) { best = lane + WAVE * i; bk = kk[i]; }
+    }
+}
+// The k best of slots [0, count) moved to the front in order; returns min(count, k).  All threads
+// call it (workgroup barriers inside).  The selection itself is done by ONE wave, barrier-free:
+// each lane keeps the primary keys of its 16 slots in registers and its current best slot; a round
+// is a 6-step butterfly on (primary key, slot) — equal primaries go back to LDS for the other keys —
+// after which only the lane that owned the winner looks for its next best.
+__device__ __forceinline__ int top_block_select(TopLds& s, int count, int k) {
+    const int rounds = min(count, k);
+    __syncthreads();
+    if (threadIdx.x < WAVE) {
+        const int lane = (int)threadIdx.x;
+        uint64_t kk[TOPK_PER_LANE];
+        uint32_t live = 0;                                                // bit i: slot lane + 64*i is a candidate not yet taken
+#pragma unroll
+        for (int i = 0; i < TOPK_PER_LANE; ++i) { const int j = lane + WAVE * i; kk[i] = j < count ? s.k0[j] : ~0ull; if (j < count) live |= 1u << i; }
+        int mine; uint64_t mk;
+        top_lane_best(s, kk, live, lane, mine, mk);
+        for (int it = 0; it < rounds; ++it) {
+            int best = mine; uint64_t bk = mk;
+#pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) {
+                const int ob = __shfl_xor(best, off, WAVE);
+                const uint64_t ok = (uint64_t)__shfl_xor((long long)bk, off, WAVE);
+                bool take = ob >= 0 && (best < 0 || ok < bk);
+                if (ob >= 0 && best >= 0 && ok == bk && ob != best) take = top_less(s, ob, best);
+                if (take) { best = ob; bk = ok; }
+            }
+            // every lane now holds the same winner (top_less is a strict total order on slots)
+            if (lane == 0) { s.o0[it] = s.k0[best]; s.o1[it] = s.k1[best]; s.o2[it] = s.k2[best]; s.oref[it] = s.ref[best]; }
+            if (best == mine) { live &= ~(1u << (best / WAVE)); top_lane_best(s, kk, live, lane, mine, mk); }
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < rounds; j += TPB) { s.k0[j] = s.o0[j]; s.k1[j] = s.o1[j]; s.k2[j] = s.o2[j]; s.ref[j] = s.oref[j]; }
+    __syncthreads();
+    return rounds;
+}
+__device__ __forceinline__ void top_write_padded(const TopLds& s, int have, int k, const DevTopBuf& out, size_t at) {
+    for (int j = threadIdx.x; j < k; j += TPB) {
+        const bool real = j < have;
+        out.k0[at + j] = real ? s.k0[j] : ~0ull; out.k1[at + j] = real ? s.k1[j] : ~0ull; out.k2[at + j] = real ? s.k2[j] : ~0ull;
+        out.ref[at + j] = real ? s.ref[j] : NO_ROW;
+    }
+}
+// result rows of the final selection, in order; padding slots are not rows
+__device__ __forceinline__ void top_emit(const TopLds& s, int have, int k, const DevStage& st, const DevTopOut& o) {
+    int rows = 0;
+    for (int j = 0; j < have; ++j) if (s.ref[j] != NO_ROW) rows = j + 1;           // real entries sort before padding
+    for (int j = threadIdx.x; j < rows; j += TPB) {
+        const int64_t idx = (int64_t)s.ref[j];
+        if (o.keys) o.keys[j] = st.key[idx];
+#pragma unroll
+        for (int p = 0; p < SDQH_MAX_PAYLOAD; ++p) if (p < o.npay && o.pay) o.pay[(size_t)p * k + j] = st.pay[p][idx];
+#pragma unroll
+        for (int v = 0; v < SDQH_TUPLE_MAX_VALUES; ++v) if (o.val) o.val[(size_t)v * k + j] = v < o.nval ? st.sacc[(size_t)idx * 4 + v] : 0.0;
+        if (o.hits) o.hits[j] = st.shits ? (int64_t)st.shits[idx] : 0;
+    }
+    if (threadIdx.x == 0) *o.count = (unsigned long long)rows;
+}
+
+__global__ __launch_bounds__(TPB) void k_topk_scan(DevTable t, DevStage st, DevTopSpec spec, uint32_t min_hits, DevTopBuf out, DevTopOut fin) {
+    __shared__ TopLds s;
+    if (threadIdx.x == 0) s.count = 0;
+    __syncthreads();
+    const bool dups = t.hdr->has_dups != 0;
+    const uint64_t mask = (table_is_direct(t) || !dups) ? 0 : t.hdr->cap_mask;
+    const int per = (st.nseg + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int s0 = blockIdx.x * per, s1 = min(st.nseg, s0 + per);
+    const uint64_t lt = lanemask_lt();
+    for (int seg = s0; seg < s1; ++seg) {
+        const int64_t base = (int64_t)seg * st.seg_rows;
+        const uint32_t count = st.seg_count[seg];
+        for (uint32_t i0 = 0; i0 < count; i0 += TPB) {                       // uniform across the workgroup
+            const uint32_t i = i0 + threadIdx.x;
+            uint32_t hits = 0;
+            bool keep = i < count;
+            if (keep) { hits = st.shits ? st.shits[base + i] : 0u; keep = hits >= min_hits; }
+            if (keep && dups) keep = stage_row_owns(st, t, base + i, mask);
+            const uint64_t b = __ballot(keep);
+            int wbase = 0;
+            if (lane_id() == 0 && b) wbase = atomicAdd(&s.count, __popcll(b));
+            wbase = __shfl(wbase, 0, WAVE);
+            if (keep) {
+                const int at = wbase + __popcll(b & lt);
+                const int64_t idx = base + i;
+                s.k0[at] = top_sort_value(spec.key[0], st, idx, hits);
+                s.k1[at] = spec.nsort > 1 ? top_sort_value(spec.key[1], st, idx, hits) : 0ull;
+                s.k2[at] = spec.nsort > 2 ? top_sort_value(spec.key[2], st, idx, hits) : 0ull;
+                s.ref[at] = (uint32_t)idx;
+            }
+            __syncthreads();
+            if (s.count > TOPK_CHUNK - TPB) {                               // the next batch might not fit; uniform: everybody reads the same LDS word
+                const int have = top_block_select(s, s.count, spec.k);
+                if (threadIdx.x == 0) s.count = have;
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+    const int have = top_block_select(s, s.count, spec.k);
+    if (gridDim.x == 1) top_emit(s, have, spec.k, st, fin);
+    else top_write_padded(s, have, spec.k, out, (size_t)blockIdx.x * spec.k);
+}
+
+__global__ __launch_bounds__(TPB) void k_topk_reduce(DevTopBuf in, int n_in, DevStage st, DevTopSpec spec, DevTopBuf out, DevTopOut fin) {
+    __shared__ TopLds s;
+    const int lo = blockIdx.x * TOPK_CHUNK, n = min(TOPK_CHUNK, n_in - lo);
+    for (int j = threadIdx.x; j < n; j += TPB) { s.k0[j] = in.k0[lo + j]; s.k1[j] = in.k1[lo + j]; s.k2[j] = in.k2[lo + j]; s.ref[j] = in.ref[lo + j]; }
+    __syncthreads();
+    const int have = top_block_select(s, n, spec.k);
+    if (gridDim.x == 1) top_emit(s, have, spec.k, st, fin);
+    else top_write_padded(s, have, spec.k, out, (size_t)blockIdx.x * spec.k);
+}
+
+// =================================================================================================
 // Redistribution helpers for the multi-GPU join (no reference counterpart).
 // =================================================================================================
 // exclusive scan of the per-segment counts into seg_off (separate array), total -> *total

@@ -173,11 +173,32 @@ class DistributedRunner:
             self._plans[name] = frontend.lower_function(Q.QUERIES[name])
         return self._plans[name]
 
-    def run(self, name, db, whole_tables=("region", "nation")):
+    def run(self, name, db, whole_tables=("region", "nation"), top=None):
         """Run query `name` on this rank's shard `db`; returns this rank's share of the result
         (q6: the global scalar on every rank; group-bys over a small domain (q1, q5, q9): the global
         groups on every rank; q3: the groups of this rank's key partition).  `whole_tables` names the
-        tables every rank holds completely (the rest are row-sharded)."""
+        tables every rank holds completely (the rest are row-sharded).  top = (k, [(column, "asc" |
+        "desc")]) adds ORDER BY ... LIMIT k: every rank returns the same global first k rows (q3: each
+        rank's device top-k of its partition, k rows per rank gathered and ordered again)."""
+        if top is not None:
+            k, order = int(top[0]), [(str(n), str(d)) for n, d in top[1]]
+            if name == "q6":
+                raise frontend.UnsupportedQuery("top(k) applies to queries that end in a result set")
+            if name == "q3":
+                self._top = (k, order)
+                try:
+                    local = self.run(name, db, whole_tables)
+                finally:
+                    self._top = None
+                cols = [[] for _ in local.columns]
+                out = [None] * self.world
+                dist.all_gather_object(out, [a.tolist() for a in local.arrays], group=self.group)
+                for part in out:                                  # rank order, then each rank's own order
+                    for c, vals in zip(cols, part):
+                        c += vals
+                merged = ResultSet(local.columns, [np.array(c, a.dtype) for c, a in zip(cols, local.arrays)])
+                return merged.top(k, order)
+            return self.run(name, db, whole_tables).top(k, order)
         args = [db[t] for t in Q.QUERY_TABLES[name]]
         plan = self._plan(name)
         if name == "q6":
@@ -507,10 +528,14 @@ class DistributedRunner:
             ctx.hash_probe_aggregate(n_recv, st.empty, table_b, recv[0], abi.make_tuple(st.tup_c.shape, recv[1:]))
 
         # ---- finalise this rank's partition --------------------------------------------------------
-        hint = getattr(st, "result_rows", None)
-        keys, payload, values, hits, n = ctx.table_compact_into_block(table_b, 1, 4096 if hint is None else hint + hint // 8 + 1024,
-                                                                      want_hits=st.count_idx is not None)
-        st.result_rows = n
+        spec = self._join_sort_spec(st) if getattr(self, "_top", None) else None
+        if spec is not None and 1 <= self._top[0] <= abi.MAX_TOPK:
+            keys, payload, values, hits = ctx.table_topk(table_b, 1, self._top[0], spec)
+        else:
+            hint = getattr(st, "result_rows", None)
+            keys, payload, values, hits, n = ctx.table_compact_into_block(table_b, 1, 4096 if hint is None else hint + hint // 8 + 1024,
+                                                                          want_hits=st.count_idx is not None)
+            st.result_rows = n
         names, arrays = [], []
         for fname, e in st.key_fields:
             if isinstance(e, Col) and e.name == st.ckey_name:
@@ -527,6 +552,29 @@ class DistributedRunner:
         for c in keep_a:
             c.free()
         return ResultSet(names, arrays)
+
+    def _join_sort_spec(self, st):
+        """sdqh_table_topk sort keys for the partitioned join's result columns, or None (host ordering)."""
+        spec = []
+        for name, direction in self._top[1]:
+            desc = direction == "desc"
+            found = False
+            for fname, e in st.key_fields:
+                if isinstance(e, Col) and e.name == st.ckey_name and name == (fname or st.ckey_name):
+                    spec.append((abi.SORT_KEY, 0, desc, False)); found = True
+                elif isinstance(e, PayloadField) and name == (fname or e.field):
+                    j = st.pay_names.index(e.field)
+                    spec.append((abi.SORT_PAYLOAD, j, desc, np.dtype(st.pay_dtypes[j]).kind == "f")); found = True
+            if not found and name in st.vnames:
+                i = st.vnames.index(name)
+                if st.count_idx is not None and i == st.count_idx:
+                    spec.append((abi.SORT_HITS, 0, desc, False))
+                else:
+                    spec.append((abi.SORT_VALUE, i - (1 if st.count_idx is not None and st.count_idx < i else 0), desc, True))
+                found = True
+            if not found:
+                raise KeyError("top: the result has no column %r" % name)
+        return spec if len(spec) <= abi.MAX_SORT_KEYS else None
 
     # ---- helpers for tests / reporting ---------------------------------------------------------------
     def gather_rows(self, res):

@@ -648,14 +648,54 @@ def _compact(eng, table, min_hits, hint_key, **want):
     return keys, payload, values, hits
 
 
-def _materialize(eng, value, env, hint_key=None):
-    """Device-resident intermediate -> DictResult on the host (K-F's input)."""
+def _device_sort_spec(bt, key_fields, vnames, count_idx, order):
+    """[(kind, index, descending, is_f64)] for sdqh_table_topk, or None when a column of `order`
+    cannot be ordered on the device (text travels as row references; composite keys are packed)."""
+    spec = []
+    for name, direction in order:
+        desc = direction == "desc"
+        hit = [src for fname, src in key_fields if fname == name]
+        if hit:
+            src = hit[0]
+            if src == "key":
+                if bt.key_parts is not None or getattr(bt, "key_decoder", None) is not None:
+                    return None
+                spec.append((abi.SORT_KEY, 0, desc, False))
+            else:
+                if bt.decoders.get(src) is not None:
+                    return None
+                spec.append((abi.SORT_PAYLOAD, src, desc, np.dtype(bt.payload_dtypes[src]).kind == "f"))
+        elif name in vnames:
+            i = vnames.index(name)
+            if count_idx is not None and i == count_idx:
+                spec.append((abi.SORT_HITS, 0, desc, False))
+            else:
+                spec.append((abi.SORT_VALUE, i - (1 if count_idx is not None and count_idx < i else 0), desc, True))
+        else:
+            raise KeyError("top: the result has no column %r" % name)
+    return spec
+
+
+def _fetch_entries(eng, bt_table, min_hits, hint_key, top, spec, **want):
+    """K-F rows of a table: all of them, or with `top` = (k, order) only the first k in that order
+    when the device can order them (spec) — otherwise all, ordered afterwards on the host."""
+    if top is not None and spec is not None and 1 <= top[0] <= abi.MAX_TOPK and len(spec) <= abi.MAX_SORT_KEYS:
+        keys, payload, values, hits = eng.ctx.table_topk(bt_table, min_hits, top[0], spec, want_hits=want.get("want_hits", True))
+        return keys, payload, values, hits, True
+    keys, payload, values, hits = _compact(eng, bt_table, min_hits, hint_key, **want)
+    return keys, payload, values, hits, False
+
+
+def _materialize(eng, value, env, hint_key=None, top=None):
+    """Device-resident intermediate -> DictResult on the host (K-F's input).  With `top`, the
+    DictResult carries `.ordered = True` when the device already applied ORDER BY / LIMIT."""
     if isinstance(value, DictResult):
         return value
     if isinstance(value, tuple) and value and value[0] == "aggregated":
         bt = env[value[1]]
         out_key_fields, vnames, count_idx, key_is_record, val_is_record, shape = bt.agg
-        keys, payload, values, hits = _compact(eng, bt.table, 1, hint_key, want_hits=count_idx is not None)
+        spec = _device_sort_spec(bt, out_key_fields, vnames, count_idx, top[1]) if top is not None else None
+        keys, payload, values, hits, ordered = _fetch_entries(eng, bt.table, 1, hint_key, top, spec, want_hits=count_idx is not None or (spec is not None and any(s[0] == abi.SORT_HITS for s in spec)))
         kf = []
         for fname, src in out_key_fields:
             if src == "key":
@@ -664,21 +704,50 @@ def _materialize(eng, value, env, hint_key=None):
                 kf.append((fname, payload[src].view(bt.payload_dtypes[src])))
         nv = abi.TUPLE_NVALUES[shape]
         vf = _value_arrays(vnames, count_idx, [values[j] for j in range(nv)], hits)
-        return DictResult(kf, vf, key_is_record, val_is_record)
+        d = DictResult(kf, vf, key_is_record, val_is_record)
+        d.ordered = ordered
+        return d
     if isinstance(value, BuiltTable):
-        keys, payload, _, _ = _compact(eng, value.table, 0, hint_key, want_values=False, want_hits=False)
+        spec = _device_sort_spec(value, [(value.key_name, "key")] + [(f, src) for f, src in value.val_fields if src != "key"], [], None, top[1]) \
+            if top is not None and value.key_parts is None else None
+        if top is not None and spec is not None and 1 <= top[0] <= abi.MAX_TOPK and len(spec) <= abi.MAX_SORT_KEYS:
+            keys, payload, _, _ = eng.ctx.table_topk(value.table, 0, top[0], spec, want_hits=False)
+            ordered = True
+        else:
+            keys, payload, _, _ = _compact(eng, value.table, 0, hint_key, want_values=False, want_hits=False)
+            ordered = False
         vf = [(fname, keys if src == "key" else _decode_column(payload[src], value.decoders.get(src), value.payload_dtypes[src]))
               for fname, src in value.val_fields]
         if value.key_parts is not None:
             kf = [(value.key_parts[0], keys >> 32), (value.key_parts[1], keys & 0xFFFFFFFF)]
         else:
             kf = [(value.key_name, _decode_column(keys, getattr(value, "key_decoder", None), np.int64))]
-        return DictResult(kf, vf, value.key_is_record, value.val_is_record)
+        d = DictResult(kf, vf, value.key_is_record, value.val_is_record)
+        d.ordered = ordered
+        return d
     raise UnsupportedQuery("cannot materialise %r" % (value,))
 
 
-def _finalize(eng, op, env):
-    d = _materialize(eng, env[op.source], env, hint_key=id(op))
+def _finalize(eng, op, env, top=None):
+    """K-F.  `top` = (k, [(result column, "asc" | "desc")]) adds ORDER BY ... LIMIT k: on the device
+    (sdqh_table_topk) when the source is a device table and the columns are numeric, else on the host."""
+    src_val = env[op.source]
+    inner_top = top
+    if top is not None and op.fields is not None:           # result columns are aliases of single-field sides
+        names = {}
+        probe = src_val
+        if isinstance(probe, tuple) and probe and probe[0] == "aggregated":
+            kf_names, vf_names = [f for f, _ in env[probe[1]].agg[0]], list(env[probe[1]].agg[1])
+        elif isinstance(probe, BuiltTable):
+            kf_names, vf_names = [probe.key_name], [f for f, _ in probe.val_fields]
+        else:
+            kf_names, vf_names = [n for n, _ in probe.key_fields], [n for n, _ in probe.val_fields]
+        for name, which in op.fields:
+            side = kf_names if which == 0 else vf_names
+            if len(side) == 1:
+                names[name] = side[0]
+        inner_top = (top[0], [(names.get(n, n), d) for n, d in top[1]])
+    d = _materialize(eng, src_val, env, hint_key=id(op), top=inner_top)
     if op.fields is None:                                   # p[0].concat(p[1])
         fields = d.key_fields + d.val_fields
     else:
@@ -688,7 +757,10 @@ def _finalize(eng, op, env):
             if len(src) != 1:
                 raise UnsupportedQuery("line %d: p[%d] is a record; use concat" % (op.lineno, which))
             fields.append((name, src[0][1]))
-    return ResultSet([n for n, _ in fields], [a for _, a in fields])
+    rs = ResultSet([n for n, _ in fields], [a for _, a in fields])
+    if top is not None and not getattr(d, "ordered", False):
+        rs = rs.top(top[0], top[1])
+    return rs
 
 
 class PreparedPlan:
@@ -708,16 +780,24 @@ class PreparedPlan:
             if isinstance(op, ScanOp):
                 self.steps.append((op.out, _prepare_scan(eng, op, tables[op.table], accumulate_into)))
             elif isinstance(op, FinalizeOp):
-                self.steps.append((op.out, (lambda env, op=op: _finalize(eng, op, env))))
+                is_result = op.out == plan.result
+                self.steps.append((op.out, (lambda env, op=op, is_result=is_result: _finalize(eng, op, env, env.get("__top__") if is_result else None))))
 
-    def run(self):
+    def run(self, top=None):
+        """top = (k, [(result column, "asc" | "desc"), ...]): ORDER BY ... LIMIT k on the final K-F."""
         env = {}
+        if top is not None:
+            env["__top__"] = (int(top[0]), [(str(n), str(d)) for n, d in top[1]])
+            if any(d not in ("asc", "desc") for _, d in env["__top__"][1]):
+                raise ValueError("top: directions are 'asc' or 'desc'")
         try:
             for out, step in self.steps:
                 env[out] = step(env)
             res = env[self.plan.result]
             if isinstance(res, (BuiltTable, tuple)):
                 res = _materialize(self.eng, res, env, hint_key=id(self.plan))
+            if top is not None and not isinstance(res, ResultSet):
+                raise UnsupportedQuery("top(k) applies to queries that end in a result set")
             return res
         finally:
             for v in env.values():                           # release device tables of this run
@@ -725,7 +805,7 @@ class PreparedPlan:
                     v.table.free()
 
 
-def execute_plan(eng, plan, args):
+def execute_plan(eng, plan, args, top=None):
     cache = plan.__dict__.setdefault("_prepared", {})
     key = (id(eng),) + tuple(id(a) for a in args)
     prepared = cache.get(key)
@@ -733,4 +813,4 @@ def execute_plan(eng, plan, args):
         if len(cache) > 16:
             cache.clear()
         prepared = cache[key] = PreparedPlan(eng, plan, args)
-    return prepared.run()
+    return prepared.run(top)

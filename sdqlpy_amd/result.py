@@ -37,6 +37,29 @@ class ResultSet:
         cols = [a.tolist() for a in self.arrays]
         return sorted(zip(*cols)) if cols else []
 
+    def ordered_rows(self):
+        """Rows as plain-Python tuples in the order they are stored (the order of a top-k result)."""
+        return list(zip(*[a.tolist() for a in self.arrays])) if self.arrays else []
+
+    def top(self, k, order):
+        """ORDER BY ... LIMIT k on the host: order = [(column, "asc" | "desc")], ties keep the stored
+        row order (for K-F results that is build-row order, the same total order the device
+        operator sdqh_table_topk uses).  Used for results that are small or not device tables."""
+        keys = []
+        for name, direction in reversed(list(order)):
+            if name not in self.columns:
+                raise KeyError("top: the result has no column %r" % name)
+            a = self.column(name)
+            if direction == "desc":
+                if a.dtype.kind in "iuf":
+                    a = -a if a.dtype.kind == "f" else ~a
+                else:                                        # strings: rank them, then negate the rank
+                    a = -np.unique(a, return_inverse=True)[1]
+            keys.append(a)
+        idx = np.lexsort(keys) if keys else np.arange(self._n)         # lexsort is stable
+        idx = idx[:max(0, int(k))]
+        return ResultSet(self.columns, [a[idx] for a in self.arrays])
+
     def to_dict(self):
         out = {}
         cols = [a.tolist() for a in self.arrays]

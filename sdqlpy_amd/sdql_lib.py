@@ -304,8 +304,7 @@ def sdql_compile(in_type):
     def actual_decorator(func):
         cache = {}
 
-        @functools.wraps(func)
-        def wrapper(*args, **kwargs):
+        def run(args, top=None):
             if _state["mode"] is None:
                 raise RuntimeError("call sdqlpy_init(...) before running a compiled query")
             if _state["mode"] == MODE_PYTHON:
@@ -316,8 +315,19 @@ def sdql_compile(in_type):
             if "plan" not in cache:
                 cache["plan"] = frontend.lower_function(func, in_type)
             eng = engine.default_engine(device=_state["device"], threads=_state["threads"])
-            return engine.execute_plan(eng, cache["plan"], args)
+            return engine.execute_plan(eng, cache["plan"], args, top)
 
+        @functools.wraps(func)
+        def wrapper(*args, **kwargs):
+            return run(args)
+
+        def top(k, order):
+            """The same query finished with ORDER BY ... LIMIT k: order = [(column, "asc" | "desc")],
+            e.g. ``q3.top(10, [("revenue", "desc"), ("o_orderdate", "asc")])(li, cu, ord)``.  Not in
+            the reference (its Q3 returns the unordered set); ties keep build-row order."""
+            return lambda *args: run(args, (k, list(order)))
+
+        wrapper.top = top
         wrapper.__sdql_in_type__ = in_type
         wrapper.__sdql_func__ = func
         return wrapper

@@ -127,5 +127,16 @@ QUERY_TABLES = {
 QUERIES = {"q6": q6, "q1": q1, "q3": q3, "q5": q5, "q9": q9}
 
 
-def run(name, db):
-    return QUERIES[name](*[db[t] for t in QUERY_TABLES[name]])
+def run(name, db, top=None):
+    """Run a query on a database dict; top = (k, [(column, "asc" | "desc")]) adds ORDER BY ... LIMIT k."""
+    args = [db[t] for t in QUERY_TABLES[name]]
+    return QUERIES[name].top(*top)(*args) if top is not None else QUERIES[name](*args)
+
+
+# TPCH's own ORDER BY / LIMIT for the queries above (the reference's versions return unordered sets)
+TPCH_ORDER = {
+    "q1": (100, [("l_returnflag", "asc"), ("l_linestatus", "asc")]),
+    "q3": (10, [("revenue", "desc"), ("o_orderdate", "asc")]),
+    "q5": (100, [("revenue", "desc")]),
+    "q9": (128, [("nation", "asc"), ("o_year", "desc")]),
+}

@@ -59,6 +59,10 @@ def main(rank, world, port, sf, mode, out_path):
     r3 = runner.run("q3", db)
     out["q3"] = {"columns": r3.columns, "rows": runner.gather_rows(r3), "local_rows": r3.size(),
                  "partitioning": runner.last_partitioning, "exchanged": runner.exchanged_rows}
+    t3 = runner.run("q3", db, top=Q.TPCH_ORDER["q3"])                  # device top-k per rank, k rows gathered, ordered again
+    out["q3_top"] = {"columns": t3.columns, "rows": t3.ordered_rows()}
+    t5 = runner.run("q5", db, top=(3, [("revenue", "desc")]))
+    out["q5_top"] = {"columns": t5.columns, "rows": t5.ordered_rows()}
     if rank == 0:
         with open(out_path, "w") as fh:
             json.dump(out, fh)

@@ -129,3 +129,55 @@ def compaction_block_case(ctx):
     expect = [kk for kk, ok in zip(keys.tolist(), sel.tolist()) if ok and want.get(kk, 0) >= 2]
     assert got[0][0].tolist() == expect
     return got[0]
+
+
+def topk_case(ctx, n=400000, seed=9):
+    """sdqh_table_topk on a probed table against a numpy restatement: several sort specs (value desc,
+    payload asc/desc incl. a double payload, hits, key), k from 1 to 128, ties broken by build-row
+    order, duplicate build keys, and min_hits filtering.  Returns the rows for cross-implementation
+    comparison."""
+    import numpy as np
+    from sdqlpy_amd import abi
+    rng = np.random.default_rng(seed)
+    keys = rng.permutation(n).astype(np.int64) * 5 + 3
+    keys[1000:1200] = keys[:200]                                   # duplicate build keys: the first row owns the entry
+    pay_i = rng.integers(0, 50, n).astype(np.int64)                # few distinct values: many ties
+    pay_f = (rng.integers(-500, 500, n) / 4.0).astype(np.float64)  # doubles incl. negatives and -0.0/0.0 neighbours
+    pk = keys[rng.integers(0, n, 3 * n)]
+    pv = rng.integers(1, 1000, 3 * n).astype(np.float64)           # integer-valued: sums are exact in any order
+    ck, ci, cf, cpk, cpv = ctx.upload(keys), ctx.upload(pay_i), ctx.upload(pay_f.view(np.int64)), ctx.upload(pk), ctx.upload(pv)
+    t = ctx.hash_build_unique(n, abi.make_filter(), [], ck, [ci, cf], accumulate=True)
+    ctx.hash_probe_aggregate(3 * n, abi.make_filter(), t, cpk, abi.make_tuple(abi.TUPLE_A, [cpv]))
+    # numpy restatement of the table: owner rows in build order
+    first = {}
+    for i, k in enumerate(keys.tolist()):
+        first.setdefault(k, i)
+    owners = np.array(sorted(first.values()), np.int64)
+    pos = {k: j for j, k in enumerate(keys[owners].tolist())}
+    hits = np.zeros(len(owners), np.int64); sums = np.zeros(len(owners))
+    idx = np.fromiter((pos[k] for k in pk.tolist()), np.int64, len(pk))
+    np.add.at(hits, idx, 1); np.add.at(sums, idx, pv)
+    ek, ei, ef = keys[owners], pay_i[owners], pay_f[owners]
+    out = []
+    specs = [
+        (10, 1, [(abi.SORT_VALUE, 0, True, True), (abi.SORT_PAYLOAD, 0, False, False)]),
+        (128, 1, [(abi.SORT_PAYLOAD, 0, True, False)]),                                 # heavy ties -> build order decides
+        (37, 2, [(abi.SORT_PAYLOAD, 1, False, True), (abi.SORT_HITS, 0, True, False), (abi.SORT_KEY, 0, True, False)]),
+        (1, 0, [(abi.SORT_KEY, 0, False, False)]),
+        (64, 5, [(abi.SORT_HITS, 0, True, False), (abi.SORT_VALUE, 0, False, True)]),
+    ]
+    cols = {abi.SORT_KEY: lambda i: ek, abi.SORT_PAYLOAD: lambda i: (ei, ef)[i], abi.SORT_VALUE: lambda i: sums, abi.SORT_HITS: lambda i: hits}
+    for k, min_hits, spec in specs:
+        gk, gp, gv, gh = ctx.table_topk(t, min_hits, k, spec)
+        sel = np.nonzero(hits >= min_hits)[0]
+        lex = [sel]                                                 # last key of lexsort is the primary: build order first (least significant)
+        for kind, index, desc, _ in reversed(spec):
+            a = cols[kind](index)[sel]
+            lex.append(-a if desc else a)
+        order = sel[np.lexsort(lex)][:k]
+        assert gk.tolist() == ek[order].tolist(), (k, spec)
+        assert gp[0].tolist() == ei[order].tolist() and gp[1].view(np.float64).tolist() == ef[order].tolist()
+        assert gv[0].tolist() == sums[order].tolist() and gh.tolist() == hits[order].tolist()
+        out.append((gk.copy(), gv[0].copy()))
+    t.free()
+    return out

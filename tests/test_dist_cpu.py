@@ -58,6 +58,15 @@ def test_two_ranks_match_single_process(mode, tmp_path, single, oracle_lib):
         helpers.assert_rows_match(sorted(as_rows(got[q]["rows"])), helpers.result_rows(single[q], got[q]["columns"]), 1e-12, mode + "/" + q)
     w3 = single["q3"]
     helpers.assert_rows_match(sorted(as_rows(got["q3"]["rows"])), helpers.result_rows(w3, got["q3"]["columns"]), 1e-12, mode + "/q3")
+    # ORDER BY ... LIMIT k: the same first rows, in the same order, as ordering the single-process result
+    from sdqlpy_amd import tpch_queries as Q
+    for q, top in (("q3", Q.TPCH_ORDER["q3"]), ("q5", (3, [("revenue", "desc")]))):
+        want = single[q].top(*top)
+        cols = got[q + "_top"]["columns"]
+        want_rows = list(zip(*[want.column(c).tolist() for c in cols]))
+        assert len(got[q + "_top"]["rows"]) == len(want_rows) == min(top[0], single[q].size())
+        assert [r[0] for r in got[q + "_top"]["rows"]] == [r[0] for r in want_rows], mode + "/" + q + "_top order"
+        helpers.assert_rows_match(as_rows(got[q + "_top"]["rows"]), want_rows, 1e-12, mode + "/" + q + "_top")
     if mode == "range":
         # dbgen-shaped shards are co-clustered on o_orderkey: nothing has to move
         assert got["q3"]["partitioning"] == "range" and got["q3"]["exchanged"]["probe_sent"] == 0

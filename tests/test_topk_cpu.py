@@ -1,0 +1,73 @@
+"""ORDER BY ... LIMIT k (BASELINE config 3 "hash joins + top-k") on the CPU
+implementation of the ABI and through the engine: the device operator, the host ordering used for
+small / non-table results, and their agreement."""
+import os
+
+import pytest
+
+from sdqlpy_amd import abi, engine, frontend, tpch
+from sdqlpy_amd import tpch_queries as Q
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    eng = engine.Engine(abi.Library(os.path.join(ROOT, "oracle", "libsdqloracle.so")).context(threads=4))
+    yield eng
+    eng.close()
+
+
+def test_table_topk_against_numpy(oracle):
+    from helpers import topk_case
+    topk_case(oracle.ctx, n=60000)
+
+
+def test_topk_arguments_are_checked(oracle):
+    import numpy as np
+    ctx = oracle.ctx
+    t = ctx.hash_build_unique(10, abi.make_filter(), [], ctx.upload(np.arange(10, dtype=np.int64)), [], accumulate=False)
+    for k, spec in ((0, [(abi.SORT_KEY, 0, False, False)]), (abi.MAX_TOPK + 1, [(abi.SORT_KEY, 0, False, False)])):
+        with pytest.raises(abi.SdqhError) as e:
+            ctx.table_topk(t, 0, k, spec)
+        assert e.value.code == abi.ERR_UNSUPPORTED
+    for spec in ([(abi.SORT_PAYLOAD, 0, False, False)], [(abi.SORT_VALUE, 0, False, True)], [(abi.SORT_HITS, 0, False, False)]):
+        with pytest.raises(abi.SdqhError) as e:
+            ctx.table_topk(t, 0, 3, spec)
+        assert e.value.code == abi.ERR_INVALID
+    k, _, _, _ = ctx.table_topk(t, 0, 3, [(abi.SORT_KEY, 0, True, False)], want_hits=False)
+    assert k.tolist() == [9, 8, 7]
+    t.free()
+
+
+@pytest.mark.parametrize("q", ["q1", "q3", "q5", "q9"])
+def test_query_top_equals_ordering_the_full_result(oracle, q):
+    qs = (q,)
+    db = tpch.generate(0.02, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+    plan = frontend.lower_function(Q.QUERIES[q].__sdql_func__, Q.QUERIES[q].__sdql_in_type__)
+    args = [db[t] for t in Q.QUERY_TABLES[q]]
+    full = engine.execute_plan(oracle, plan, args)
+    k, order = Q.TPCH_ORDER[q]
+    for kk in (k, 3, 500):                                  # 500 > SDQH_MAX_TOPK: ordered on the host
+        got = engine.execute_plan(oracle, plan, args, top=(kk, order))
+        want = full.top(kk, order)
+        assert got.columns == want.columns and got.ordered_rows() == want.ordered_rows()
+        assert got.size() == min(kk, full.size())
+    assert sorted(full.top(10 ** 6, order).ordered_rows()) == full.rows()      # ordering loses nothing
+    with pytest.raises(KeyError):
+        engine.execute_plan(oracle, plan, args, top=(3, [("no_such_column", "asc")]))
+    with pytest.raises(ValueError):
+        engine.execute_plan(oracle, plan, args, top=(3, [(order[0][0], "up")]))
+
+
+def test_q3_top10_runs_on_the_device_operator(oracle):
+    db = tpch.generate(0.02, tables=["lineitem", "customer", "orders"], columns=tpch.columns_for(("q3",)))
+    plan = frontend.lower_function(Q.QUERIES["q3"].__sdql_func__, Q.QUERIES["q3"].__sdql_in_type__)
+    calls = []
+    real = oracle.ctx.table_topk
+    oracle.ctx.table_topk = lambda *a, **kw: (calls.append(a[2:4]), real(*a, **kw))[1]
+    try:
+        engine.execute_plan(oracle, plan, [db[t] for t in Q.QUERY_TABLES["q3"]], top=Q.TPCH_ORDER["q3"])
+    finally:
+        del oracle.ctx.table_topk
+    assert calls == [(10, [(abi.SORT_VALUE, 0, True, True), (abi.SORT_PAYLOAD, 0, False, False)])]

@@ -181,3 +181,59 @@ def topk_case(ctx, n=400000, seed=9):
         out.append((gk.copy(), gv[0].copy()))
     t.free()
     return out
+
+
+def string_predicate_case(ctx, widths=(1, 2, 3, 7, 10, 25, 31, 32, 33, 55, 64, 65, 100, 128, 129), rows=5000, seed=3):
+    """The build-side string predicate (==, !=, substring) over fixed-width UCS4 fields of many
+    widths, against a plain-Python restatement of VarChar::operator== / contains (reference
+    include/varchar.h:61-89: equality = first len units equal and the rest NUL; substring = wcsstr,
+    the field ends at its first NUL).  Fields include embedded NULs, needles at both ends,
+    overlapping partial matches and non-ASCII units."""
+    import numpy as np
+    from sdqlpy_amd import abi
+    rng = np.random.default_rng(seed)
+    alphabet = np.array([ord(c) for c in "abgren "] + [0x00E9, 0x65E5], np.uint32)      # small: matches are frequent
+    checked = 0
+    for width in widths:
+        raw = alphabet[rng.integers(0, len(alphabet), (rows, width))]
+        lens = rng.integers(0, width + 1, rows)
+        raw[np.arange(width)[None, :] >= lens[:, None]] = 0                           # zero padding after a random length
+        holes = rng.random(rows) < 0.15                                               # embedded NUL with text after it
+        pos = rng.integers(0, width, rows)
+        raw[holes, pos[holes]] = 0
+        needles = ["g", "green", "gre", "ab", "a", "é", "日", "green ab", "nnnnnnnnn", "x"]
+        needles = [n for n in needles if len(n) <= max(1, width)] + ["".join(chr(c) for c in raw[7, :min(width, 12)] if c)]
+        # plant needles at the start, at the very end and after a NUL
+        for i, nd in enumerate(needles):
+            u = np.array([ord(c) for c in nd], np.uint32)
+            if 0 < len(u) <= width:
+                raw[100 + i, :] = 0; raw[100 + i, :len(u)] = u                          # exactly the needle (equality hit)
+                raw[200 + i, :] = ord("b"); raw[200 + i, width - len(u):] = u           # at the very end, field full
+                if len(u) + 2 <= width:
+                    raw[300 + i, :] = 0; raw[300 + i, 0] = ord("b"); raw[300 + i, 2:2 + len(u)] = u   # after an embedded NUL: not visible
+        col = np.ascontiguousarray(raw).view("<U%d" % width).reshape(rows)
+        fields = [[int(c) for c in r] for r in raw]
+        ccol, ckey = ctx.upload(col), ctx.upload(np.arange(rows, dtype=np.int64))
+        for nd in needles:
+            if not nd:
+                continue
+            nu = [ord(c) for c in nd]
+            for mode, name in ((0, "=="), (1, "!="), (2, "in")):
+                want = []
+                for r, f in enumerate(fields):
+                    if mode == 2:
+                        end = f.index(0) if 0 in f else width
+                        hit = any(f[s:s + len(nu)] == nu for s in range(0, end - len(nu) + 1))
+                    else:
+                        eq = len(nu) <= width and f[:len(nu)] == nu and not any(f[len(nu):])
+                        hit = eq != (mode == 1)
+                    if hit:
+                        want.append(r)
+                t = ctx.hash_build_unique(rows, abi.make_filter(spreds=[(ccol, nd, mode)]), [], ckey, [])
+                n = ctx.table_compact_count(t, 0)
+                got = ctx.table_compact(t, 0, n, want_values=False, want_hits=False)[0].tolist()
+                t.free()
+                assert got == want, "width %d, %r %s field: %d rows, expected %d (first difference %s)" % (
+                    width, nd, name, len(got), len(want), sorted(set(got) ^ set(want))[:5])
+                checked += 1
+    return checked

@@ -58,3 +58,14 @@ def test_oracle_compaction_into_blocks(oracle_lib):
         compaction_block_case(ctx)
     finally:
         ctx.close()
+
+
+def test_oracle_string_predicates_follow_varchar_semantics(oracle_lib):
+    """==, != and substring on fixed-width UCS4 fields against a plain-Python restatement of the
+    reference's VarChar (include/varchar.h:61-89), embedded NULs included."""
+    from helpers import string_predicate_case
+    ctx = oracle_lib.context(threads=2)
+    try:
+        assert string_predicate_case(ctx, widths=(1, 3, 10, 33, 55), rows=1200) > 100
+    finally:
+        ctx.close()

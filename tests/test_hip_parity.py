@@ -187,6 +187,14 @@ def test_compaction_into_device_writable_blocks(hip_engine, oracle_engine):
     np.testing.assert_allclose(hip[2], cpu[2], rtol=1e-12)
 
 
+def test_string_predicates_all_widths(hip_engine):
+    """The LDS-staged string predicate of the staging kernel (64- and 32-row staging, the global
+    fallback beyond 128 units, equality / inequality / substring with needles up to and beyond 8
+    units) against the Python restatement of VarChar semantics."""
+    from helpers import string_predicate_case
+    assert string_predicate_case(hip_engine.ctx) > 400
+
+
 def test_table_topk_matches_numpy_and_oracle(hip_engine, oracle_engine):
     """sdqh_table_topk (multi-level selection on the device) against a numpy restatement and the CPU
     implementation: same rows in the same order for every sort spec of the shared case."""

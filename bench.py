@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--force-dist", action="store_true", help="use the distributed plan even with one rank (exercises the RCCL path)")
     ap.add_argument("--partition", default="auto", choices=["auto", "range", "hash"])
     ap.add_argument("--cpu-sample-sf", type=float, default=0.0, help="0 = pick so the CPU leg takes ~10-30 s")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def algorithmic_bytes(q, rows):
@@ -60,8 +60,13 @@ def scanned_rows(q, rows):
             "q5": lambda: rows["lineitem"] + rows["customer"] + rows["orders"] + rows["supplier"] + rows["nation"] + rows["region"]}[q]()
 
 
-def main():
-    args = parse()
+def main(argv=None, hooks=None):
+    """hooks: injection points for the CPU test of the multi-process control flow
+    (tests/bench_gloo_worker.py): {"backend": "gloo", "device": "cpu", "engine": Engine}.  The
+    product run passes none: RCCL, cuda:LOCAL_RANK, the HIP engine."""
+    args = parse(argv)
+    hooks = hooks or {}
+    device = hooks.get("device", "cuda")
     # RCCL prints a version banner on stdout when a communicator is created; the contract is ONE
     # JSON line on stdout, so everything else (including C-level writes) is sent to stderr.
     sys.stdout.flush()
@@ -76,14 +81,18 @@ def main():
             raise SystemExit("--gpus %d needs torchrun (one process per GPU)" % args.gpus)
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
+    if device == "cuda":
+        torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if device == "cuda":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(hooks.get("backend", "gloo"))
 
     from sdqlpy_amd import engine, tpch
     from sdqlpy_amd import tpch_queries as Q
@@ -97,8 +106,11 @@ def main():
     rows = {t: len(db[t].getContainer()["data"][0]) for t in tables}
     gen_s = time.time() - t0
 
-    sdqlpy_init(3, 1, device=local_rank)
-    eng = engine.default_engine(device=local_rank)
+    if "engine" in hooks:
+        eng = engine.use_engine(hooks["engine"])
+    else:
+        sdqlpy_init(3, 1, device=local_rank)
+        eng = engine.default_engine(device=local_rank)
     runner = None
     if use_dist:
         from sdqlpy_amd import dist as sdist
@@ -111,7 +123,8 @@ def main():
         if use_dist:
             dist.barrier()
         eng.ctx.synchronize()
-        torch.cuda.synchronize()
+        if device == "cuda":
+            torch.cuda.synchronize()
 
     # first pass uploads the columns (pinned-staged H2D) — the PCIe-inclusive number
     barrier()
@@ -159,10 +172,10 @@ def main():
     profile_steps = max(1, min(args.steps, 10))
     _, _, launch_log = run_steps(profile_steps, None)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        rows_t = torch.tensor([sum(scanned_rows(q, rows) for q in queries)], dtype=torch.float64, device="cuda")
+        rows_t = torch.tensor([sum(scanned_rows(q, rows) for q in queries)], dtype=torch.float64, device=device)
         dist.all_reduce(rows_t)
         total_rows_per_step = float(rows_t.item())
     else:

@@ -63,6 +63,16 @@ def default_engine(device=None, threads=1):
     return _engine
 
 
+def use_engine(eng):
+    """Route the decorator API (sdql_compile) to an explicitly constructed Engine.  Test plumbing:
+    the suite drives the same front end over the CPU implementation of the ABI this way."""
+    global _engine
+    from . import sdql_lib
+    _engine = eng
+    sdql_lib._state.update(mode=sdql_lib.MODE_HIP, device=getattr(eng.ctx, "device", 0))
+    return eng
+
+
 def reset_default_engine():
     global _engine
     if _engine is not None:

@@ -75,3 +75,26 @@ def test_two_ranks_match_single_process(mode, tmp_path, single, oracle_lib):
     else:
         assert got["q3"]["partitioning"] == "hash" and got["q3"]["exchanged"]["build"] > 0
     assert 0 < got["q3"]["local_rows"] < len(got["q3"]["rows"])
+
+
+def test_bench_contract_under_a_two_rank_launch(tmp_path):
+    """bench.py as the driver launches it for N > 1 (RANK / WORLD_SIZE / MASTER_* in the
+    environment), on CPU: gloo + the CPU implementation of the ABI injected through bench.main's
+    hooks.  Rank 0 prints exactly one JSON line with the contract's fields; the other rank prints none."""
+    port = free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "bench_gloo_worker.py"), str(r), "2", str(port), "0.01"],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    lines = [ln for ln in outs[0][0].splitlines() if ln.strip()]
+    assert len(lines) == 1 and not outs[1][0].strip(), (outs[0][0][-500:], outs[1][0][-500:])
+    rec = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in rec, key
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak" and rec["vs_baseline"] is None
+    assert rec["unit"] == "rows/s" and rec["higher_is_better"] is True and rec["value"] > 0 and rec["ms_per_step"] > 0
+    assert "workload" in rec["config"] and "q3 partitioned" in rec["config"]["partitioning"]
+    # whole-job aggregate: rows of BOTH ranks per step over the max-over-ranks time
+    per_rank = sum(rec["config"]["rows_per_gpu"][t] for t in ("lineitem",)) * 3 + rec["config"]["rows_per_gpu"]["customer"] * 2 + rec["config"]["rows_per_gpu"]["orders"] * 2
+    assert rec["value"] * rec["ms_per_step"] * 1e-3 > 1.5 * per_rank

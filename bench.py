@@ -228,7 +228,7 @@ def main(argv=None, hooks=None):
             "roofline": roofline,
             "first_pass_with_upload_s": round(first_pass_s, 3), "generate_s": round(gen_s, 2),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg is reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, queries, db, rows)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:

@@ -100,15 +100,27 @@ typedef struct sdqh_spred {                     /* col == value  (VarChar::opera
     const sdqh_column* col;
     int32_t  len;                               /* code units in value, <= column width */
     int32_t  negate;                            /* 0: col == value, 1: col != value, 2: value is a substring of col
-                                                   (`"x" in col` -> VarChar::contains / wcsstr, include/varchar.h:84-89) */
+                                                   (`"x" in col` -> VarChar::contains / wcsstr, include/varchar.h:84-89),
+                                                   3: col starts with value (startsWith, include/varchar.h:99-110),
+                                                   4: col ends with value (endsWith, include/varchar.h:112-124; the text
+                                                      is the field up to its first NUL; Python str.endswith semantics) */
     uint32_t value[SDQH_MAX_STR_CONST];
 } sdqh_spred;
 
+/* column-vs-column comparison `a[row] op b[row]` (e.g. Q4 `l_commitdate < l_receiptdate`): both I64 or both F64 */
+#define SDQH_MAX_CPRED 2
+#define SDQH_CMP_LT 0
+#define SDQH_CMP_LE 1
+#define SDQH_CMP_EQ 2
+#define SDQH_CMP_NE 3
+typedef struct sdqh_cpred { const sdqh_column* a; const sdqh_column* b; int32_t op; int32_t _pad; } sdqh_cpred;
+
 typedef struct sdqh_filter {
-    int32_t n_ipred, n_fpred, n_spred, _pad;
+    int32_t n_ipred, n_fpred, n_spred, n_cpred;
     sdqh_ipred ipred[SDQH_MAX_IPRED];
     sdqh_fpred fpred[SDQH_MAX_FPRED];
     sdqh_spred spred[SDQH_MAX_SPRED];
+    sdqh_cpred cpred[SDQH_MAX_CPRED];
 } sdqh_filter;
 
 typedef struct sdqh_tuple {
@@ -173,6 +185,13 @@ void    sdqh_column_free(sdqh_ctx* ctx, sdqh_column* col);
  * out_values[SDQH_TUPLE_MAX_VALUES] receives the tuple's doubles, *out_count the rows that passed. */
 int sdqh_scan_filter_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter,
                          const sdqh_tuple* tuple, double* out_values, int64_t* out_count);
+
+/* K-A with semi-join steps: as sdqh_scan_filter_sum, over the rows that also pass every probe
+ * (`expr if tbl[key] != None else 0.0` inside a scalar sum — Q14's promo revenue,
+ * test/test_all.py:703-711; lookups ...generator_par.py:85-96). */
+int sdqh_scan_probe_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter,
+                        int nprobes, const sdqh_probe* probes, const sdqh_tuple* tuple,
+                        double* out_values, int64_t* out_count);
 
 /* ---- K-C small: scan -> filter -> group-by over a small key domain -------------------------
  * Keys: 1..2 columns, each STR of width 1 or I64 with values in [0, 2^32-2].  Results, one row

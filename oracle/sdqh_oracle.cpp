@@ -147,6 +147,8 @@ struct FilterView {
     const uint32_t* sval[SDQH_MAX_SPRED];
     int np = 0;
     const sdqh_table* pt[SDQH_MAX_PROBE]; const int64_t* pk[SDQH_MAX_PROBE];
+    int nc = 0;                                                    // column-vs-column comparisons (e.g. test/test_all.py:189)
+    const int64_t* ca[SDQH_MAX_CPRED]; const int64_t* cb[SDQH_MAX_CPRED]; int cop[SDQH_MAX_CPRED]; bool cf64[SDQH_MAX_CPRED];
 
     inline bool pass(int64_t r) const {
         for (int i = 0; i < ni; ++i) { int64_t x = ic[i][r]; if (!(x >= ilo[i] && x <= ihi[i])) return false; }
@@ -165,10 +167,30 @@ struct FilterView {
                 if (!found) return false;
                 continue;
             }
+            if (sneg[i] == 3) {                                     // VarChar::startsWith: reference include/varchar.h:99-110
+                bool m = slen[i] <= swidth[i];
+                for (int k = 0; m && k < slen[i]; ++k) m = s[k] != 0 && s[k] == sval[i][k];
+                if (!m) return false;
+                continue;
+            }
+            if (sneg[i] == 4) {                                     // endsWith, Python-mode semantics (sdql_lib.py:350-351): the text ends with the needle
+                int len = 0; while (len < swidth[i] && s[len] != 0) ++len;
+                bool m = slen[i] <= len;
+                for (int k = 0; m && k < slen[i]; ++k) m = s[len - slen[i] + k] == sval[i][k];
+                if (!m) return false;
+                continue;
+            }
             bool eq = slen[i] <= swidth[i];
             for (int k = 0; eq && k < slen[i]; ++k) eq = s[k] == sval[i][k];
             for (int k = slen[i]; eq && k < swidth[i]; ++k) eq = s[k] == 0;
             if (eq == (sneg[i] != 0)) return false;
+        }
+        for (int i = 0; i < nc; ++i) {
+            bool lt, eq;
+            if (cf64[i]) { double a, b; std::memcpy(&a, &ca[i][r], 8); std::memcpy(&b, &cb[i][r], 8); lt = a < b; eq = a == b; }
+            else { lt = ca[i][r] < cb[i][r]; eq = ca[i][r] == cb[i][r]; }
+            const bool ok = cop[i] == SDQH_CMP_LT ? lt : (cop[i] == SDQH_CMP_LE ? (lt || eq) : (cop[i] == SDQH_CMP_EQ ? eq : !eq));
+            if (!ok) return false;
         }
         for (int i = 0; i < np; ++i) if (!pt[i]->contains(pk[i][r])) return false;   // (tbl).contains(k): generator 86-96
         return true;
@@ -201,6 +223,14 @@ int make_filter(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* f, int nprobes,
             if (f->spred[i].len < 0 || f->spred[i].len > SDQH_MAX_STR_CONST) return fail(ctx, SDQH_ERR_INVALID, "spred: constant too long");
             v->sc[i] = (const uint32_t*)f->spred[i].col->data; v->swidth[i] = f->spred[i].col->width;
             v->slen[i] = f->spred[i].len; v->sneg[i] = f->spred[i].negate; v->sval[i] = f->spred[i].value;
+        }
+        if (f->n_cpred < 0 || f->n_cpred > SDQH_MAX_CPRED) return fail(ctx, SDQH_ERR_INVALID, "filter: too many column comparisons");
+        v->nc = f->n_cpred;
+        for (int i = 0; i < v->nc; ++i) {
+            const sdqh_cpred& c = f->cpred[i];
+            if (!c.a || !c.b || c.a->dtype != c.b->dtype || c.a->dtype == SDQH_STR || c.a->nrows < nrows || c.b->nrows < nrows || c.op < SDQH_CMP_LT || c.op > SDQH_CMP_NE)
+                return fail(ctx, SDQH_ERR_INVALID, "cpred: two I64 or two F64 columns covering nrows, op LT/LE/EQ/NE");
+            v->ca[i] = (const int64_t*)c.a->data; v->cb[i] = (const int64_t*)c.b->data; v->cop[i] = c.op; v->cf64[i] = c.a->dtype == SDQH_F64;
         }
     }
     if (nprobes < 0 || nprobes > SDQH_MAX_PROBE) return fail(ctx, SDQH_ERR_INVALID, "too many probes");
@@ -389,6 +419,32 @@ int sdqh_scan_filter_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter
     if (out_values) for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) out_values[k] = k < tv.nv ? total.v[k] : 0.0;
     if (out_count) *out_count = total.n;
     ctx->last_ms = tm.ms();
+    return SDQH_OK;
+}
+
+// K-A with semi-join probes: `expr if tbl[key] != None else 0.0` inside a scalar sum (test/test_all.py:703-711)
+int sdqh_scan_probe_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nprobes, const sdqh_probe* probes,
+                        const sdqh_tuple* tuple, double* out_values, int64_t* out_count) {
+    if (!ctx || nrows < 0 || !tuple) return fail(ctx, SDQH_ERR_INVALID, "scan_probe_sum: bad arguments");
+    FilterView fv; TupleView tv;
+    if (int rc = make_filter(ctx, nrows, filter, nprobes, probes, &fv)) return rc;
+    if (int rc = make_tuple(ctx, nrows, tuple, &tv)) return rc;
+    int T = eff_threads(ctx->threads, nrows);
+    std::vector<Acc> part((size_t)T);
+    run_blocks(T, nrows, [&](int t, int64_t b, int64_t e) {
+        Acc a{}; double v[SDQH_TUPLE_MAX_VALUES] = {0, 0, 0, 0};
+        for (int64_t r = b; r < e; ++r) {
+            if (!fv.pass(r)) continue;
+            tv.eval(r, v);
+            for (int k = 0; k < tv.nv; ++k) a.v[k] += v[k];
+            a.n += 1;
+        }
+        part[(size_t)t] = a;
+    });
+    Acc total{};
+    for (int t = 0; t < T; ++t) { for (int k = 0; k < tv.nv; ++k) total.v[k] += part[(size_t)t].v[k]; total.n += part[(size_t)t].n; }
+    if (out_values) for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) out_values[k] = k < tv.nv ? total.v[k] : 0.0;
+    if (out_count) *out_count = total.n;
     return SDQH_OK;
 }
 

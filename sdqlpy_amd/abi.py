@@ -42,9 +42,19 @@ class _SPred(C.Structure):
     _fields_ = [("col", C.c_void_p), ("len", C.c_int32), ("negate", C.c_int32), ("value", C.c_uint32 * MAX_STR_CONST)]
 
 
+MAX_CPRED = 2
+CMP_LT, CMP_LE, CMP_EQ, CMP_NE = 0, 1, 2, 3
+STR_EQ, STR_NE, STR_CONTAINS, STR_PREFIX, STR_SUFFIX = 0, 1, 2, 3, 4
+
+
+class _CPred(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("op", C.c_int32), ("_pad", C.c_int32)]
+
+
 class Filter(C.Structure):
-    _fields_ = [("n_ipred", C.c_int32), ("n_fpred", C.c_int32), ("n_spred", C.c_int32), ("_pad", C.c_int32),
-                ("ipred", _IPred * MAX_IPRED), ("fpred", _FPred * MAX_FPRED), ("spred", _SPred * MAX_SPRED)]
+    _fields_ = [("n_ipred", C.c_int32), ("n_fpred", C.c_int32), ("n_spred", C.c_int32), ("n_cpred", C.c_int32),
+                ("ipred", _IPred * MAX_IPRED), ("fpred", _FPred * MAX_FPRED), ("spred", _SPred * MAX_SPRED),
+                ("cpred", _CPred * MAX_CPRED)]
 
 
 class Tuple(C.Structure):
@@ -114,7 +124,7 @@ EXPORTS = [
     "sdqh_stream", "sdqh_set_option",
     "sdqh_column_upload", "sdqh_column_wrap", "sdqh_column_alloc", "sdqh_column_download", "sdqh_column_data",
     "sdqh_column_rows", "sdqh_column_dtype", "sdqh_column_width", "sdqh_column_minmax", "sdqh_column_free",
-    "sdqh_scan_filter_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_table_size", "sdqh_table_free",
+    "sdqh_scan_filter_sum", "sdqh_scan_probe_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_table_size", "sdqh_table_free",
     "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_scan_compact", "sdqh_partition_by_key",
     "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in",
     "sdqh_build", "sdqh_lookup_aggregate", "sdqh_table_entries", "sdqh_host_alloc", "sdqh_host_free", "sdqh_table_topk",
@@ -184,12 +194,15 @@ class Table:
         return n.value
 
 
-def make_filter(ipreds=(), fpreds=(), spreds=()):
-    """ipreds: [(Column, lo, hi)], fpreds: [(Column, lo, hi)], spreds: [(Column, 'text', negate)]."""
+def make_filter(ipreds=(), fpreds=(), spreds=(), cpreds=()):
+    """ipreds: [(Column, lo, hi)], fpreds: [(Column, lo, hi)], spreds: [(Column, 'text', mode)] with mode
+    STR_EQ / STR_NE / STR_CONTAINS / STR_PREFIX / STR_SUFFIX, cpreds: [(Column a, Column b, CMP_*)] meaning a op b."""
     f = Filter()
-    if len(ipreds) > MAX_IPRED or len(fpreds) > MAX_FPRED or len(spreds) > MAX_SPRED:
+    if len(ipreds) > MAX_IPRED or len(fpreds) > MAX_FPRED or len(spreds) > MAX_SPRED or len(cpreds) > MAX_CPRED:
         raise SdqhError(ERR_UNSUPPORTED, "too many predicates for one filter")
-    f.n_ipred, f.n_fpred, f.n_spred = len(ipreds), len(fpreds), len(spreds)
+    f.n_ipred, f.n_fpred, f.n_spred, f.n_cpred = len(ipreds), len(fpreds), len(spreds), len(cpreds)
+    for i, (a, b, op) in enumerate(cpreds):
+        f.cpred[i].a, f.cpred[i].b, f.cpred[i].op = a.handle, b.handle, int(op)
     for i, (col, lo, hi) in enumerate(ipreds):
         f.ipred[i].col, f.ipred[i].lo, f.ipred[i].hi = col.handle, max(INT64_MIN, lo), min(INT64_MAX, hi)
     for i, (col, lo, hi) in enumerate(fpreds):
@@ -200,7 +213,7 @@ def make_filter(ipreds=(), fpreds=(), spreds=()):
         f.spred[i].col, f.spred[i].len, f.spred[i].negate = col.handle, len(text), int(negate)      # 0 ==, 1 !=, 2 substring
         for k, ch in enumerate(text):
             f.spred[i].value[k] = ord(ch)
-    f._keep = (ipreds, fpreds, spreds)
+    f._keep = (ipreds, fpreds, spreds, cpreds)
     return f
 
 
@@ -365,6 +378,17 @@ class Context:
         cnt = C.c_int64()
         self._check(self.lib.sdqh_scan_filter_sum(self.handle, C.c_int64(nrows), C.byref(flt), C.byref(tup), vals, C.byref(cnt)))
         self._after_call("scan_filter_sum")
+        return list(vals)[: TUPLE_NVALUES[tup.shape]], cnt.value
+
+    def scan_probe_sum(self, nrows, flt, probes, tup):
+        """scan_filter_sum over the rows that also pass every (table, key column) semi-join probe."""
+        parr = (Probe * max(1, len(probes)))()
+        for i, (tbl, kcol) in enumerate(probes):
+            parr[i].table, parr[i].key = tbl.handle, kcol.handle
+        vals = (C.c_double * TUPLE_MAX_VALUES)()
+        cnt = C.c_int64()
+        self._check(self.lib.sdqh_scan_probe_sum(self.handle, C.c_int64(nrows), C.byref(flt), C.c_int(len(probes)), parr, C.byref(tup), vals, C.byref(cnt)))
+        self._after_call("scan_probe_sum")
         return list(vals)[: TUPLE_NVALUES[tup.shape]], cnt.value
 
     def groupby_small(self, nrows, flt, keys, tup, max_groups=MAX_SMALL_GROUPS):

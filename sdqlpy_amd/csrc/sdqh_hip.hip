@@ -257,6 +257,15 @@ int make_filter(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* f, const sdqh_t
             d->fc[d->nf] = static_cast<const double*>(f->fpred[i].col->data); d->flo[d->nf] = f->fpred[i].lo; d->fhi[d->nf] = f->fpred[i].hi; d->nf++;
         }
     }
+    if (f->n_cpred < 0 || f->n_cpred > SDQH_MAX_CPRED) return fail(ctx, SDQH_ERR_INVALID, "filter: too many column comparisons");
+    d->nc = f->n_cpred;
+    for (int i = 0; i < f->n_cpred; ++i) {
+        const sdqh_cpred& c = f->cpred[i];
+        if (!c.a || !c.b || c.a->dtype != c.b->dtype || c.a->dtype == SDQH_STR || c.a->nrows < nrows || c.b->nrows < nrows || c.op < SDQH_CMP_LT || c.op > SDQH_CMP_NE)
+            return fail(ctx, SDQH_ERR_INVALID, "cpred: two I64 or two F64 columns covering nrows, op LT/LE/EQ/NE");
+        d->ca[i] = static_cast<const int64_t*>(c.a->data); d->cb[i] = static_cast<const int64_t*>(c.b->data);
+        d->cop[i] = c.op; d->cf64[i] = c.a->dtype == SDQH_F64 ? 1 : 0;
+    }
     if (f->n_spred == 1) {
         if (int rc = check_col(ctx, f->spred[0].col, SDQH_STR, nrows, "spred")) return rc;
         if (f->spred[0].len < 0 || f->spred[0].len > SDQH_MAX_STR_CONST) return fail(ctx, SDQH_ERR_INVALID, "spred: constant too long");
@@ -338,6 +347,7 @@ int with_shape(sdqh_ctx* ctx, int shape, Fn&& fn) {
 // filter layouts with their own instances; everything else runs on the generic instance
 template <class Fn>
 int with_scan_filter(const DevFilter& f, Fn&& fn) {          // K-A / K-C small / K-C large (no probes)
+    if (f.nc) return fn(FGeneric{});
     if (f.ns == 0 && f.nf == 0 && f.ni == 1) return fn(FCfg<1, 0, 0, 0>{});
     if (f.ns == 0 && f.nf == 0 && f.ni == 0) return fn(FCfg<0, 0, 0, 0>{});
     if (f.ns == 0 && f.nf == 1 && f.ni == 1) return fn(FCfg<1, 1, 0, 0>{});
@@ -345,6 +355,7 @@ int with_scan_filter(const DevFilter& f, Fn&& fn) {          // K-A / K-C small 
 }
 template <class Fn>
 int with_stage_filter(const DevFilter& f, int nprobes, Fn&& fn) {      // K-B staging
+    if (f.nc) return fn(FGeneric{});
     if (f.ns == 0 && f.nf == 0 && f.ni == 1 && nprobes == 1) return fn(FCfg<1, 0, 0, 1>{});
     if (f.ns == 0 && f.nf == 0 && f.ni == 1 && nprobes == 0) return fn(FCfg<1, 0, 0, 0>{});
     if (f.ns == 1 && f.nf == 0 && f.ni == 0 && nprobes == 0) return fn(FCfg<0, 0, 1, 0>{});
@@ -359,6 +370,7 @@ int with_group_keys(const DevGroupKeys& gk, Fn&& fn) {
 }
 template <class Fn>
 int with_groupby_filter(const DevFilter& f, Fn&& fn) {          // the register group-by kernels: one tuned layout + generic
+    if (f.nc) return fn(FGeneric{});
     if (f.ns == 0 && f.nf == 0 && f.ni == 1) return fn(FCfg<1, 0, 0, 0>{});
     return fn(FGeneric{});
 }
@@ -554,6 +566,41 @@ int sdqh_scan_filter_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter
         });
     });
     if (lrc) return lrc;
+    LAUNCH(ctx, "k_sum_partials", k_sum_partials, 1, partial, (int)grid, out_dev);
+    call_end(ctx);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->result_host, out_dev, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    int rc = sync_stream(ctx);
+    pool_free(ctx, partial);
+    if (rc) return rc;
+    const double* h = static_cast<const double*>(ctx->result_host);
+    const int nv = tuple_nv(tuple->shape);
+    if (out_values) for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) out_values[k] = k < nv ? h[k] : 0.0;
+    if (out_count) *out_count = reinterpret_cast<const int64_t*>(h)[4];
+    return SDQH_OK;
+}
+
+int sdqh_scan_probe_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nprobes, const sdqh_probe* probes,
+                        const sdqh_tuple* tuple, double* out_values, int64_t* out_count) {
+    if (!ctx || nrows < 0 || !tuple) return fail(ctx, SDQH_ERR_INVALID, "scan_probe_sum: bad arguments");
+    if (nprobes == 0) return sdqh_scan_filter_sum(ctx, nrows, filter, tuple, out_values, out_count);
+    (void)hipSetDevice(ctx->device);
+    DevFilter f; DevTuple t; DevProbes pr;
+    if (int rc = make_tuple(ctx, nrows, tuple, &t)) return rc;
+    if (int rc = make_filter(ctx, nrows, filter, tuple, &f)) return rc;
+    call_begin(ctx);                                   // a hash-layout probe table may have to build its index first
+    if (int rc = make_probes(ctx, nrows, nprobes, probes, &pr)) return rc;
+    double* out_dev = static_cast<double*>(ctx->result_dev);
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + TPB * ROWS_PER_LOAD * 2 - 1) / (TPB * ROWS_PER_LOAD * 2), (int64_t)ctx->num_cu * ctx->opt_resident_cap));
+    double* partial = static_cast<double*>(pool_alloc(ctx, (size_t)grid * 5 * sizeof(double)));
+    if (!partial) return fail(ctx, SDQH_ERR_NOMEM, "scan_probe_sum: out of device memory");
+    const bool tuned = f.ni == 1 && f.nf == 0 && f.ns == 0 && f.nc == 0 && nprobes == 1;
+    int lrc = with_shape(ctx, tuple->shape, [&](auto S) {
+        constexpr int SH = decltype(S)::value;
+        if (tuned) { auto kern = k_scan_probe_sum<SH, FCfg<1, 0, 0, 1>>; LAUNCH(ctx, "k_scan_probe_sum", kern, grid, f, pr, t, nrows, partial); }
+        else { auto kern = k_scan_probe_sum<SH, FGeneric>; LAUNCH(ctx, "k_scan_probe_sum", kern, grid, f, pr, t, nrows, partial); }
+        return SDQH_OK;
+    });
+    if (lrc) { pool_free(ctx, partial); return lrc; }
     LAUNCH(ctx, "k_sum_partials", k_sum_partials, 1, partial, (int)grid, out_dev);
     call_end(ctx);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->result_host, out_dev, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -46,6 +46,8 @@ struct DevFilter {
     uint32_t sval[SDQH_MAX_STR_CONST];
     // ranges on tuple operand slots (an f-predicate whose column is also a value operand is
     // checked on the already-loaded operand instead of being loaded twice)
+    // column-vs-column comparisons (generic filter instances only): a op b on raw 8-byte values
+    int32_t nc, _padc; const int64_t* ca[SDQH_MAX_CPRED]; const int64_t* cb[SDQH_MAX_CPRED]; int32_t cop[SDQH_MAX_CPRED], cf64[SDQH_MAX_CPRED];
     uint32_t omask, slds;     // slds = 64 or 32: the launch carries slds * swidth words of dynamic LDS per wave (str_stage_mask)
     double olo[4], ohi[4];
 };
@@ -169,6 +171,8 @@ template <class FC> __device__ __forceinline__ int cfg_ni(const int32_t n) { if 
 template <class FC> __device__ __forceinline__ int cfg_nf(const int32_t n) { if constexpr (FC::NF >= 0) return FC::NF; else return n; }
 template <class FC> __device__ __forceinline__ int cfg_ns(const int32_t n) { if constexpr (FC::NS >= 0) return FC::NS; else return n; }
 template <class FC> __device__ __forceinline__ int cfg_np(const int32_t n) { if constexpr (FC::NP >= 0) return FC::NP; else return n; }
+// column-vs-column predicates exist in the generic instance only (the dispatchers send filters that carry one there)
+template <class FC> __device__ __forceinline__ int cfg_nc(const int32_t n) { if constexpr (FC::NI >= 0) return 0; else return n; }
 // group-key slots: 0 absent, 1 string(1) (UCS4 code unit), 2 int64, -1 decided at run time
 template <int K0_, int K1_> struct KCfg { static constexpr int K0 = K0_, K1 = K1_; };
 using KGeneric = KCfg<-1, -1>;
@@ -225,10 +229,43 @@ __device__ __forceinline__ bool str_contains(const uint32_t* __restrict__ s, int
     return false;
 }
 // the string predicate of a filter: mode 0 `==`, 1 `!=`, 2 substring
+// startsWith (reference include/varchar.h:99-110): every unit of the needle matches and no NUL comes first
+__device__ __forceinline__ bool str_prefix(const uint32_t* s, int width, const uint32_t* val, int len) {
+    if (len > width) return false;
+    for (int k = 0; k < len; ++k) if (s[k] == 0u || s[k] != val[k]) return false;
+    return true;
+}
+// endsWith: the text (field up to its first NUL) ends with the needle
+__device__ __forceinline__ bool str_suffix(const uint32_t* s, int width, const uint32_t* val, int len) {
+    int n = 0;
+    while (n < width && s[n] != 0u) ++n;
+    if (len > n) return false;
+    for (int k = 0; k < len; ++k) if (s[n - len + k] != val[k]) return false;
+    return true;
+}
 __device__ __forceinline__ bool str_pred(const uint32_t* __restrict__ s, int width, const uint32_t* val, int len, int mode) {
     if (mode == 2) return str_contains(s, width, val, len);
+    if (mode == 3) return str_prefix(s, width, val, len);
+    if (mode == 4) return str_suffix(s, width, val, len);
     return str_equal(s, width, val, len) != (mode != 0);
 }
+// `a[r] op b[r]` on two columns of one type (ints compare as int64, doubles as double)
+__device__ __forceinline__ bool col_pred(const DevFilter& f, int i, int64_t r) {
+    const int64_t x = f.ca[i][r], y = f.cb[i][r];
+    bool lt, eq;
+    if (f.cf64[i]) { const double a = __longlong_as_double(x), b = __longlong_as_double(y); lt = a < b; eq = a == b; }
+    else { lt = x < y; eq = x == y; }
+    const int op = f.cop[i];
+    return op == SDQH_CMP_LT ? lt : (op == SDQH_CMP_LE ? (lt || eq) : (op == SDQH_CMP_EQ ? eq : !eq));
+}
+template <class FC>
+__device__ __forceinline__ bool col_preds(const DevFilter& f, int64_t r) {
+    bool p = true;
+#pragma unroll
+    for (int i = 0; i < SDQH_MAX_CPRED; ++i) if (i < cfg_nc<FC>(f.nc) && p) p = col_pred(f, i, r);
+    return p;
+}
+
 // ---- the string predicate on fields staged in LDS -------------------------------------------------
 // Branch-free over the whole fixed width, so every LDS read of a field is independent of the
 // comparisons (the per-lane early-exit loops above chain one read latency per character).
@@ -275,6 +312,8 @@ __device__ __forceinline__ bool lds_str_pred(const uint32_t* s, int width, const
         if (len == 0) return true;
         return lds_str_contains(s, width, val, len);
     }
+    if (mode == 3) return str_prefix(s, width, val, len);          // at most `len` reads, early exit
+    if (mode == 4) return str_suffix(s, width, val, len);
     return lds_str_equal(s, width, val, len) != (mode != 0);
 }
 // The string predicate over `rows` (64 or 32) consecutive rows (row0 + lane), staged through LDS:
@@ -393,6 +432,11 @@ __device__ __forceinline__ void filter_eval(const DevFilter& f, const FilterRegs
         int64_t r0 = r < nrows ? r : nrows - 1, r1 = r + 1 < nrows ? r + 1 : nrows - 1;
         if (p0) p0 = str_pred(f.sc + r0 * f.swidth, f.swidth, f.sval, f.slen, f.sneg);
         if (p1) p1 = str_pred(f.sc + r1 * f.swidth, f.swidth, f.sval, f.slen, f.sneg);
+    }
+    if (cfg_nc<FC>(f.nc)) {
+        int64_t r0 = r < nrows ? r : nrows - 1, r1 = r + 1 < nrows ? r + 1 : nrows - 1;
+        if (p0) p0 = col_preds<FC>(f, r0);
+        if (p1) p1 = col_preds<FC>(f, r1);
     }
 }
 
@@ -867,6 +911,7 @@ __device__ __forceinline__ bool row_passes(const DevFilter& f, const DevProbes& 
 #pragma unroll
     for (int i = 0; i < SDQH_MAX_FPRED; ++i) if (i < cfg_nf<FC>(f.nf) && p) { double v = f.fc[i][r]; p = (v >= f.flo[i]) & (v <= f.fhi[i]); }
     if (cfg_ns<FC>(f.ns) && p) p = str_pred(f.sc + r * f.swidth, f.swidth, f.sval, f.slen, f.sneg);
+    if (cfg_nc<FC>(f.nc) && p) p = col_preds<FC>(f, r);
 #pragma unroll
     for (int i = 0; i < SDQH_MAX_PROBE; ++i) if (i < cfg_np<FC>(pr.n) && p) p = table_contains(pr.table[i], pr.key[i][r], cap_masks[i]);
     return p;
@@ -943,6 +988,13 @@ __device__ __forceinline__ void pass_pairs(const DevFilter& f, const DevProbes& 
                 if (p[j][0]) p[j][0] = str_pred(f.sc + r[j] * f.swidth, f.swidth, f.sval, f.slen, f.sneg);
                 if (p[j][1]) p[j][1] = str_pred(f.sc + (r[j] + 1) * f.swidth, f.swidth, f.sval, f.slen, f.sneg);
             }
+        }
+    }
+    if (cfg_nc<FC>(f.nc)) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (p[j][0]) p[j][0] = col_preds<FC>(f, r[j]);
+            if (p[j][1]) p[j][1] = col_preds<FC>(f, r[j] + 1);
         }
     }
 #pragma unroll
@@ -1329,6 +1381,57 @@ __global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevT
             if (row_passes<FC>(f, none, r, nomask)) { const int64_t pos = table_find(tb, keycol[r], mask); if (pos >= 0) probe_add<SHAPE>(f, t, tb, pos, r); }
     }
     if (qn > 0) probe_drain<SHAPE>(f, t, tb, mask, q_row, q_key, 0, qn);
+}
+
+// K-A with semi-join probes (sdqh_scan_probe_sum): the streaming part of k_probe_agg — first
+// predicate and first probe key with 16-byte loads, bitmap test — but survivors add their tuple to
+// per-lane registers; workgroup partials are folded by k_sum_partials in a fixed order.
+template <int SHAPE, class FC>
+__global__ __launch_bounds__(TPB) void k_scan_probe_sum(DevFilter f, DevProbes pr, DevTuple t, int64_t nrows, double* __restrict__ partial) {
+    constexpr int NOPS = TupleTraits<SHAPE>::NOPS, NV = TupleTraits<SHAPE>::NV;
+    constexpr int PU = 2, TILE = TPB * ROWS_PER_LOAD * PU;
+    uint64_t cap_masks[SDQH_MAX_PROBE] = {0, 0};
+#pragma unroll
+    for (int i = 0; i < SDQH_MAX_PROBE; ++i) if (i < cfg_np<FC>(pr.n) && pr.table[i].hdr && !table_is_direct(pr.table[i]) && !pr.table[i].bitmap_only) cap_masks[i] = pr.table[i].hdr->cap_mask;
+    double acc[4] = {0, 0, 0, 0};
+    int64_t cnt = 0;
+    auto add_row = [&](int64_t r) {
+        double x[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < NOPS; ++j) x[j] = t.op[j][r];
+        if (!operand_ranges<NOPS>(f, x)) return;
+        tuple_eval<SHAPE>(x, o);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) acc[k] += o[k];
+        ++cnt;
+    };
+    const int64_t full = nrows / TILE;
+    for (int64_t tile = blockIdx.x; tile < full; tile += gridDim.x) {
+        int64_t r[PU];
+        bool p[PU][2];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) { r[u] = tile * TILE + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD; p[u][0] = p[u][1] = true; }
+        pass_pairs<PU, FC, true>(f, pr, r, nrows, cap_masks, p);
+#pragma unroll
+        for (int u = 0; u < PU; ++u) { if (p[u][0]) add_row(r[u]); if (p[u][1]) add_row(r[u] + 1); }
+    }
+    if (full * TILE < nrows && blockIdx.x == (unsigned)(full % gridDim.x))
+        for (int64_t r = full * TILE + threadIdx.x; r < nrows; r += TPB) if (row_passes<FC>(f, pr, r, cap_masks)) add_row(r);
+    __shared__ double s_acc[TPB / WAVE][4];
+    __shared__ int64_t s_cnt[TPB / WAVE];
+    const int w = threadIdx.x / WAVE;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { double v = wave_sum(acc[k]); if (lane_id() == 0) s_acc[w][k] = v; }
+    { int64_t c = wave_sum_i64(cnt); if (lane_id() == 0) s_cnt[w] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* out = partial + (size_t)blockIdx.x * 5;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { double v = 0.0; if (k < NV) for (int i = 0; i < TPB / WAVE; ++i) v += s_acc[i][k]; out[k] = v; }
+        int64_t c = 0;
+        for (int i = 0; i < TPB / WAVE; ++i) c += s_cnt[i];
+        reinterpret_cast<int64_t*>(out)[4] = c;
+    }
 }
 
 // =================================================================================================

@@ -20,7 +20,7 @@ import numpy as np
 
 from . import abi, build
 from .frontend import (And, Bin, Call, Cmp, Col, Const, Contains, FinalizeOp, Lookup, PayloadField, RecordCons,
-                       ScanOp, StrIn, UnsupportedQuery)
+                       ScalarExprOp, ScalarField, ScanOp, StrIn, UnsupportedQuery)
 from .result import DictResult, ResultSet
 
 # value-tuple vocabulary: canonical shape of the whole value record -> (ABI shape, index of the COUNT field or None)
@@ -88,6 +88,7 @@ class Engine:
         self.generation = 0        # bumped by clear(): prepared plans bound to freed columns are rebuilt
         self.compact_hints = {}    # plan step -> rows its last K-F produced (sizes the next run's result block)
         self._rowids = {}
+        self._dicts = {}           # id(string ndarray) -> (ndarray, codes int64 ndarray, distinct values)
 
     def close(self):
         self.clear()
@@ -117,6 +118,18 @@ class Engine:
         if arr is None:
             arr = self._rowids[nrows] = np.arange(nrows, dtype=np.int64)
         return self.column(arr)
+
+    def dict_column(self, arr, max_distinct=4096):
+        """(resident int64 code column, distinct values) for a low-cardinality string column, or None:
+        how a string column of the scanned table serves as a group key (Q4's o_orderpriority).  The
+        dictionary is built once per host array (np.unique) and cached like an upload."""
+        hit = self._dicts.get(id(arr))
+        if hit is None or hit[0] is not arr:
+            values, codes = np.unique(arr, return_inverse=True)
+            hit = self._dicts[id(arr)] = (arr, np.ascontiguousarray(codes.astype(np.int64)), values)
+        if len(hit[2]) > max_distinct:
+            return None
+        return self.column(hit[1]), hit[2]
 
     def adopt(self, arr, col):
         """Register an already-resident column for a host array identity (multi-GPU exchange buffers)."""
@@ -173,7 +186,7 @@ def _flip(op):
 
 def _build_filter(eng, op, htab, conds):
     """conds -> (abi.Filter, [semi-join lookups])."""
-    iranges, franges, spreds, lookups = {}, {}, [], []
+    iranges, franges, spreds, cpreds, lookups = {}, {}, [], [], []
     for c in conds:
         if isinstance(c, Contains):
             lookups.append(c.lookup)
@@ -182,15 +195,23 @@ def _build_filter(eng, op, htab, conds):
             arr = htab.array(c.col.name, op)
             if arr.dtype.kind != "U":
                 raise UnsupportedQuery("line %d: `in` needs a string column" % op.lineno)
-            spreds.append((eng.column(arr), c.needle, 2))
+            spreds.append((eng.column(arr), c.needle, {"in": abi.STR_CONTAINS, "prefix": abi.STR_PREFIX, "suffix": abi.STR_SUFFIX}[c.how]))
             continue
         if not isinstance(c, Cmp):
             raise UnsupportedQuery("line %d: unsupported condition %r" % (op.lineno, c))
         left, right, sym = c.left, c.right, c.op
         if isinstance(left, Const) and isinstance(right, Col):
             left, right, sym = right, left, _flip(sym)
+        if isinstance(left, Col) and isinstance(right, Col):         # column vs column (Q4 `l_commitdate < l_receiptdate`)
+            a, b = htab.array(left.name, op), htab.array(right.name, op)
+            if a.dtype != b.dtype or a.dtype.kind not in "if":
+                raise UnsupportedQuery("line %d: column comparison needs two int or two float columns (%r)" % (op.lineno, c))
+            if sym in (">", ">="):
+                a, b, sym = b, a, _flip(sym)
+            cpreds.append((eng.column(a), eng.column(b), {"<": abi.CMP_LT, "<=": abi.CMP_LE, "==": abi.CMP_EQ, "!=": abi.CMP_NE}[sym]))
+            continue
         if not (isinstance(left, Col) and isinstance(right, Const)):
-            raise UnsupportedQuery("line %d: only <column> <op> <constant> comparisons are supported (%r)" % (op.lineno, c))
+            raise UnsupportedQuery("line %d: only <column> <op> <constant | column> comparisons are supported (%r)" % (op.lineno, c))
         arr = htab.array(left.name, op)
         v = right.value
         if arr.dtype.kind == "U":
@@ -233,7 +254,7 @@ def _build_filter(eng, op, htab, conds):
     ip = [(eng.column(htab.array(n, op)), lo, hi) for n, (lo, hi) in iranges.items()]
     fp = [(eng.column(htab.array(n, op)), lo, hi) for n, (lo, hi) in franges.items()]
     try:
-        return abi.make_filter(ip, fp, spreds), lookups
+        return abi.make_filter(ip, fp, spreds, cpreds), lookups
     except abi.SdqhError as exc:
         raise UnsupportedQuery("line %d: %s" % (op.lineno, exc))
 
@@ -341,11 +362,14 @@ class _Src:
         return (None, np.dtype(np.int64)) if self.year else (bt.decoders.get(idx), np.dtype(bt.payload_dtypes[idx]))
 
 
-def _source_of(eng, op, htab, e, lookups):
+def _source_of(eng, op, htab, e, lookups, as_group_key=False):
     idx_of = lambda lk: [repr(x) for x in lookups].index(repr(lk))      # noqa: E731
     if isinstance(e, Col):
         arr = htab.array(e.name, op)
         if arr.dtype.kind == "U":
+            coded = eng.dict_column(arr) if as_group_key else None
+            if coded is not None:                                # group key: dictionary codes, one group per distinct text
+                return _Src("col", col=coded[0], decoder=coded[1], dtype=np.dtype(np.int64))
             return _Src("col", col=eng.rowid_column(htab.nrows), decoder=arr, dtype=np.dtype(np.int64))
         return _Src("col", col=eng.column(arr), dtype=arr.dtype)
     if isinstance(e, PayloadField):
@@ -402,7 +426,7 @@ def _prepare_general(eng, op, htab, flt, contains_lookups):
     key_fields = op.key.fields if key_is_record else [(None, op.key)]
     if len(key_fields) > 2:
         raise UnsupportedQuery("line %d: keys of more than two fields are not supported" % op.lineno)
-    key_srcs = [_source_of(eng, op, htab, e, lookups) for _, e in key_fields]
+    key_srcs = [_source_of(eng, op, htab, e, lookups, as_group_key=not op.unique) for _, e in key_fields]
 
     if op.unique:
         val_is_record = isinstance(op.val, RecordCons)
@@ -519,22 +543,50 @@ def _is_simple(op, htab, lookups):
     return False
 
 
+def _prepare_scalar(eng, op, htab, conds, val):
+    """One scalar sum `Σ val over rows passing conds` -> closure(env) -> float.  Conditions of the
+    form `tbl[col] != None` become semi-join probes (sdqh_scan_probe_sum)."""
+    ctx, n = eng.ctx, htab.nrows
+    flt, lookups = _build_filter(eng, op, htab, conds)
+    if op.probe is not None:
+        raise UnsupportedQuery("line %d: scalar sums inside joinProbe are not supported" % op.lineno)
+    specs = _probe_specs(eng, op, htab, lookups)
+    tup, _, count_idx = _build_tuple(eng, op, htab, val)
+
+    def run_scalar(env):
+        if specs:
+            vals, cnt = ctx.scan_probe_sum(n, flt, _resolve_probes(op, env, specs), tup)
+        else:
+            vals, cnt = ctx.scan_filter_sum(n, flt, tup)
+        return float(cnt) if count_idx is not None else float(vals[0])
+    return run_scalar
+
+
+def _eval_scalar_expr(e, env, lineno):
+    if isinstance(e, Const):
+        return float(e.value)
+    if isinstance(e, ScalarField):
+        v = env[e.name]
+        if e.field is None:
+            return float(v)
+        return float(v[e.field])
+    if isinstance(e, Bin):
+        a, b = _eval_scalar_expr(e.left, env, lineno), _eval_scalar_expr(e.right, env, lineno)
+        return {"+": a + b, "-": a - b, "*": a * b, "/": (a / b) if b != 0.0 else float("nan")}[e.op]
+    raise UnsupportedQuery("line %d: unsupported scalar expression %r" % (lineno, e))
+
+
 def _prepare_scan(eng, op, htab, accumulate_into):
     ctx = eng.ctx
+    if op.kind == "scalar":
+        return _prepare_scalar(eng, op, htab, op.conds, op.val)
+    if op.kind == "scalar_record":
+        runs = [(name, _prepare_scalar(eng, op, htab, op.conds + fconds, expr)) for name, expr, fconds in op.fields]
+        return lambda env: {name: run(env) for name, run in runs}
     flt, lookups = _build_filter(eng, op, htab, op.conds)
     n = htab.nrows
     if not _is_simple(op, htab, lookups):
         return _prepare_general(eng, op, htab, flt, lookups)
-
-    if op.kind == "scalar":
-        if lookups or op.probe:
-            raise UnsupportedQuery("line %d: scalar sums with lookups are not supported yet" % op.lineno)
-        tup, _, count_idx = _build_tuple(eng, op, htab, op.val)
-
-        def run_scalar(env):
-            vals, cnt = ctx.scan_filter_sum(n, flt, tup)
-            return float(cnt) if count_idx is not None else float(vals[0])
-        return run_scalar
 
     # ---- dictionary outputs ----
     key_is_record = isinstance(op.key, RecordCons)
@@ -789,6 +841,8 @@ class PreparedPlan:
         for op in plan.ops:
             if isinstance(op, ScanOp):
                 self.steps.append((op.out, _prepare_scan(eng, op, tables[op.table], accumulate_into)))
+            elif isinstance(op, ScalarExprOp):
+                self.steps.append((op.out, (lambda env, op=op: _eval_scalar_expr(op.expr, env, op.lineno))))
             elif isinstance(op, FinalizeOp):
                 is_result = op.out == plan.result
                 self.steps.append((op.out, (lambda env, op=op, is_result=is_result: _finalize(eng, op, env, env.get("__top__") if is_result else None))))

@@ -114,9 +114,13 @@ class Contains(Expr):
 
 
 class StrIn(Expr):
-    """`"needle" in p[0].col`."""
-    def __init__(self, needle, col):
-        self.needle, self.col = needle, col
+    """`"needle" in p[0].col` (how = "in"), `startsWith(p[0].col, "needle")` ("prefix"),
+    `endsWith(p[0].col, "needle")` ("suffix")."""
+    def __init__(self, needle, col, how="in"):
+        self.needle, self.col, self.how = needle, col, how
+
+    def __repr__(self):
+        return "StrIn(%r %s %r)" % (self.needle, self.how, self.col)
 
 
 class Call(Expr):
@@ -157,7 +161,8 @@ class ScanOp:
     def __init__(self, out, table, lineno):
         self.out, self.table, self.lineno = out, table, lineno
         self.conds = []         # conjunction of Cmp / Contains / StrIn
-        self.kind = None        # "scalar" | "dict"
+        self.kind = None        # "scalar" | "scalar_record" | "dict"
+        self.fields = None      # scalar_record: [(name, Expr, [extra cond terms of that field])]
         self.key = None         # Expr | RecordCons                  (dict)
         self.val = None         # Expr | RecordCons | TRUE           (dict) / Expr (scalar)
         self.unique = False     # assignment sum: first insert wins, no aggregation
@@ -167,6 +172,24 @@ class ScanOp:
     def __repr__(self):
         return "ScanOp(%s <- %s%s: if %r: {%r: %r}%s)" % (self.out, self.table, " probe " + repr(self.probe) if self.probe else "",
                                                           self.conds, self.key, self.val, " unique" if self.unique else "")
+
+
+class ScalarField(Expr):
+    """`name.field` of an earlier scalar-record sum (or `name` itself for a plain scalar sum)."""
+    def __init__(self, name, field):
+        self.name, self.field = name, field
+
+    def __repr__(self):
+        return "ScalarField(%s.%s)" % (self.name, self.field)
+
+
+class ScalarExprOp:
+    """Arithmetic over earlier scalar results, e.g. `(100.0 * li_probed.A) / li_probed.B` (Q14)."""
+    def __init__(self, out, expr, lineno):
+        self.out, self.expr, self.lineno = out, expr, lineno
+
+    def __repr__(self):
+        return "ScalarExprOp(%s = %r)" % (self.out, self.expr)
 
 
 class FinalizeOp:
@@ -192,6 +215,7 @@ class _Lowerer:
     def __init__(self, fn_name, source_lines, first_line):
         self.fn_name, self.lines, self.first_line = fn_name, source_lines, first_line
         self.consts = {}
+        self.scalars = set()     # names bound to scalar / scalar-record sums
         self.params = []
         self.dicts = set()      # names bound to operator outputs
 
@@ -210,6 +234,8 @@ class _Lowerer:
                 return Const(self.consts[node.id])
             if node.id in env and env[node.id][0] == "payload":
                 return PayloadField(env[node.id][1], None)
+            if node.id in self.scalars:
+                return ScalarField(node.id, None)
             self.fail(node, "unknown name '%s'" % node.id)
         if isinstance(node, ast.UnaryOp) and isinstance(node.op, ast.USub) and isinstance(node.operand, ast.Constant):
             return Const(-node.operand.value)
@@ -222,6 +248,8 @@ class _Lowerer:
                 if kind == "rowpair" and idx == 0:
                     return Col(node.attr)
                 self.fail(node, "only p[0].<column> is supported inside a table sum")
+            if isinstance(base, ast.Name) and base.id in self.scalars and base.id not in env:
+                return ScalarField(base.id, node.attr)
             if isinstance(base, ast.Name) and base.id in env:
                 kind = env[base.id]
                 if kind[0] == "row":
@@ -281,6 +309,11 @@ class _Lowerer:
                     return Call("dense", [self.expr(node.args[0], env), self.expr(node.args[1], env)])
                 if fn.id == "extractYear" and len(node.args) == 1:
                     return Call("extractYear", [self.expr(node.args[0], env)])
+                if fn.id in ("startsWith", "endsWith") and len(node.args) == 2:       # ref sdql_lib.py:347-351
+                    col, needle = self.expr(node.args[0], env), self.expr(node.args[1], env)
+                    if isinstance(col, Col) and isinstance(needle, Const) and isinstance(needle.value, str):
+                        return StrIn(needle.value, col, "prefix" if fn.id == "startsWith" else "suffix")
+                    self.fail(node, "%s needs (<string column>, \"text\")" % fn.id)
             if isinstance(fn, ast.Attribute) and fn.attr == "concat" and len(node.args) == 1:
                 a, b = self.expr(fn.value, env), self.expr(node.args[0], env)
                 if isinstance(a, WholeKey) and isinstance(b, WholeKey) and a.which == 0 and b.which == 1:
@@ -365,8 +398,19 @@ class _Lowerer:
                 op.conds = conds
                 if isinstance(body, ast.Dict):
                     self.dict_body(op, body, env)
+                elif isinstance(body, ast.Call) and isinstance(body.func, ast.Name) and body.func.id == "record" \
+                        and len(body.args) == 1 and isinstance(body.args[0], ast.Dict):
+                    # record of independent sums, each possibly under its own condition (Q14: test/test_all.py:703-711)
+                    op.kind, op.fields = "scalar_record", []
+                    for k, v in zip(body.args[0].keys, body.args[0].values):
+                        if not (isinstance(k, ast.Constant) and isinstance(k.value, str)):
+                            self.fail(body, "record field names must be string literals")
+                        fbody, fconds = self.split_ifelse(v, env)
+                        op.fields.append((k.value, self.expr(fbody, env), fconds))
+                    self.scalars.add(out)
                 else:
                     op.kind, op.val = "scalar", self.expr(body, env)
+                    self.scalars.add(out)
                 if len(call.args) == 2 and isinstance(call.args[1], ast.Constant) and call.args[1].value is False:
                     op.unique = True
                 return op
@@ -424,6 +468,14 @@ class _Lowerer:
             self.fail(call, "unsupported finalising record")
         self.fail(call, "'%s' is neither a table parameter nor an earlier result" % table)
 
+    @staticmethod
+    def _only_scalars(e):
+        if isinstance(e, (Const, ScalarField)):
+            return not isinstance(e, Const) or isinstance(e.value, (int, float))
+        if isinstance(e, Bin):
+            return _Lowerer._only_scalars(e.left) and _Lowerer._only_scalars(e.right)
+        return False
+
     def _const_str(self, node):
         if isinstance(node, ast.Constant) and isinstance(node.value, str):
             return node.value
@@ -444,6 +496,12 @@ class _Lowerer:
                     ops.append(self.lower_call(name, val))
                     self.dicts.add(name)
                     continue
+                if isinstance(val, (ast.BinOp, ast.Name, ast.Attribute)):
+                    e = self.expr(val, {})
+                    if self._only_scalars(e):
+                        ops.append(ScalarExprOp(name, e, st.lineno))
+                        self.dicts.add(name); self.scalars.add(name)
+                        continue
                 self.fail(st, "unsupported assignment")
             if isinstance(st, ast.Return):
                 if isinstance(st.value, ast.Name) and st.value.id in self.dicts:

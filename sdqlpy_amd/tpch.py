@@ -60,6 +60,37 @@ GENERATED = {
                  ("l_receiptdate", "i8")],
 }
 
+# Text columns derived in numpy from a generated key column (deterministic hash of the key, TPCH
+# value lists): enough for the queries beyond the five configured ones (Q4, Q12, Q14, Q19 ...).
+_PRIORITIES = ["1-URGENT", "2-HIGH", "3-MEDIUM", "4-NOT SPECIFIED", "5-LOW"]
+_TYPE_1 = ["STANDARD", "SMALL", "MEDIUM", "LARGE", "ECONOMY", "PROMO"]
+_TYPE_2 = ["ANODIZED", "BURNISHED", "PLATED", "POLISHED", "BRUSHED"]
+_TYPE_3 = ["TIN", "NICKEL", "BRASS", "STEEL", "COPPER"]
+_SHIPMODES = ["REG AIR", "AIR", "RAIL", "SHIP", "TRUCK", "MAIL", "FOB"]
+_INSTRUCT = ["DELIVER IN PERSON", "COLLECT COD", "NONE", "TAKE BACK RETURN"]
+
+
+def _mix(a, salt):
+    """splitmix64 of an int64 array (+ salt) -> uint64."""
+    z = a.astype(np.uint64) + np.uint64((0x9E3779B97F4A7C15 * (salt + 1)) & 0xFFFFFFFFFFFFFFFF)
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def _pick(values, width, h):
+    return np.array(values, "<U%d" % width)[(h % np.uint64(len(values))).astype(np.int64)]
+
+
+DERIVED = {   # table -> {column: (dtype, base columns, function(base arrays...) -> array)}
+    "orders": {"o_orderpriority": ("U15", ["o_orderkey"], lambda k: _pick(_PRIORITIES, 15, _mix(k, 1)))},
+    "part": {"p_type": ("U25", ["p_partkey"], lambda k: np.char.add(np.char.add(np.char.add(_pick(_TYPE_1, 25, _mix(k, 2)), " "),
+                                                                                  np.char.add(_pick(_TYPE_2, 25, _mix(k, 3)), " ")),
+                                                                      _pick(_TYPE_3, 25, _mix(k, 4))).astype("<U25"))},
+    "lineitem": {"l_shipmode": ("U10", ["l_orderkey", "l_linenumber"], lambda k, n: _pick(_SHIPMODES, 10, _mix(k * 8 + n, 5))),
+                 "l_shipinstruct": ("U25", ["l_orderkey", "l_linenumber"], lambda k, n: _pick(_INSTRUCT, 25, _mix(k * 8 + n, 6)))},
+}
+
 # the columns each hot-path query references (SURVEY.md §8a); used to keep SF=10 generation small
 QUERY_COLUMNS = {
     "q6": {"lineitem": ["l_shipdate", "l_discount", "l_quantity", "l_extendedprice"]},
@@ -73,6 +104,9 @@ QUERY_COLUMNS = {
            "orders": ["o_orderkey", "o_custkey", "o_orderdate"],
            "region": ["r_regionkey", "r_name"], "nation": ["n_nationkey", "n_name", "n_regionkey"],
            "supplier": ["s_suppkey", "s_nationkey"]},
+    "q4": {"lineitem": ["l_orderkey", "l_commitdate", "l_receiptdate"],
+           "orders": ["o_orderkey", "o_orderdate", "o_orderpriority"]},
+    "q14": {"lineitem": ["l_partkey", "l_shipdate", "l_extendedprice", "l_discount"], "part": ["p_partkey", "p_type"]},
     "q9": {"lineitem": ["l_orderkey", "l_partkey", "l_suppkey", "l_quantity", "l_extendedprice", "l_discount"],
            "orders": ["o_orderkey", "o_orderdate"], "nation": ["n_nationkey", "n_name"],
            "supplier": ["s_suppkey", "s_nationkey"], "part": ["p_partkey", "p_name"],
@@ -86,7 +120,7 @@ def columns_for(queries):
     for q in queries:
         for t, cols in QUERY_COLUMNS[q].items():
             need.setdefault(t, set()).update(cols)
-    return {t: [c for c, _ in GENERATED[t] if c in cs] for t, cs in need.items()}
+    return {t: [c for c, _ in GENERATED[t] if c in cs] + [c for c in DERIVED.get(t, {}) if c in cs] for t, cs in need.items()}
 
 
 _lib = None
@@ -179,6 +213,21 @@ def generate_table(table, sf, seed=DEFAULT_SEED, columns=None, row_range=None, t
     return table_from_columns(headers, [a[h] for h in headers])
 
 
+def _with_derived(table, sf, seed, columns, row_range, threads):
+    """generate_table + the DERIVED text columns that were asked for (or all, with columns=None)."""
+    derived = DERIVED.get(table, {})
+    want_d = [c for c in derived if columns is None or c in columns]
+    if not want_d:
+        return generate_table(table, sf, seed, columns, row_range, threads)
+    base = None if columns is None else sorted(set(c for c in columns if c not in derived) | {b for c in want_d for b in derived[c][1]})
+    t = generate_table(table, sf, seed, base, row_range, threads).getContainer()
+    cols = dict(zip(t["headers"], t["data"]))
+    for c in want_d:
+        cols[c] = derived[c][2](*[cols[b] for b in derived[c][1]])
+    order = [c for c in next(iter(SCHEMAS[table].keys())).getContainer() if c in cols and (columns is None or c in columns)]
+    return table_from_columns(order, [cols[c] for c in order])
+
+
 def generate(sf, seed=DEFAULT_SEED, tables=("lineitem", "customer", "orders"), columns=None, threads=None,
              shard=None):
     """Dict name -> columnar table.  ``columns`` = {table: [names]} (see columns_for).  ``shard`` =
@@ -193,7 +242,7 @@ def generate(sf, seed=DEFAULT_SEED, tables=("lineitem", "customer", "orders"), c
             rank, world = shard
             total = table_rows("orders" if t == "lineitem" else t, sf)
             rr = (total * rank // world, total * (rank + 1) // world)
-        db[t] = generate_table(t, sf, seed, cols, rr, threads)
+        db[t] = _with_derived(t, sf, seed, cols, rr, threads)
     return db
 
 

@@ -3,7 +3,8 @@
 These are the workload, the way SQL text is for a SQL engine: q6, q1, q3 (then q5, q9) expressed
 with the same combinators, filters and arithmetic as the reference's TPCH script, so that the
 golden results captured from the reference (tests/golden) apply to them verbatim
-(reference test/test_all.py: q1 46-62, q3 145-176, q5 215-281, q6 285-295, q9 431-491).
+(reference test/test_all.py: q1 46-62, q3 145-176, q5 215-281, q6 285-295, q9 431-491; beyond the
+configured five, SURVEY.md §8f.3: q4 180-211, q14 695-716).
 Call ``sdqlpy_init(3)`` (or 1) before running them.
 """
 from .sdql_lib import *      # noqa: F401,F403
@@ -116,6 +117,30 @@ def q9(li, ord, na, su, pa, ps):
     return results
 
 
+@sdql_compile({"ord": order_type, "li": lineitem_type})
+def q4(ord, li):
+    li_indexed = li.sum(lambda p: {dense(6000000, unique(p[0].l_orderkey)): True}
+                        if p[0].l_commitdate < p[0].l_receiptdate else None)
+    ord_probed = ord.joinProbe(
+        li_indexed, "o_orderkey",
+        lambda p: p[0].o_orderdate >= 19930701 and p[0].o_orderdate < 19931001,
+        lambda indexedDictValue, probeDictKey: {probeDictKey.o_orderpriority: 1})
+    results = ord_probed.sum(lambda p: {unique(record({"o_orderpriority": p[0], "order_count": p[1]})): True})
+    return results
+
+
+@sdql_compile({"li": lineitem_type, "pa": part_type})
+def q14(li, pa):
+    promo = "PROMO"
+    pa_indexed = pa.joinBuild("p_partkey", lambda p: startsWith(p[0].p_type, promo), [])
+    li_probed = li.sum(lambda p: record({
+        "A": p[0].l_extendedprice * (1.0 - p[0].l_discount) if pa_indexed[p[0].l_partkey] != None else 0.0,      # noqa: E711
+        "B": p[0].l_extendedprice * (1.0 - p[0].l_discount)})
+        if p[0].l_shipdate >= 19950901 and p[0].l_shipdate < 19951001 else None)
+    results = (100.0 * li_probed.A) / li_probed.B
+    return results
+
+
 # positional table order of each query (the decorator dict order == call order)
 QUERY_TABLES = {
     "q6": ["lineitem"],
@@ -123,8 +148,10 @@ QUERY_TABLES = {
     "q3": ["lineitem", "customer", "orders"],
     "q5": ["lineitem", "customer", "orders", "region", "nation", "supplier"],
     "q9": ["lineitem", "orders", "nation", "supplier", "part", "partsupp"],
+    "q4": ["orders", "lineitem"],
+    "q14": ["lineitem", "part"],
 }
-QUERIES = {"q6": q6, "q1": q1, "q3": q3, "q5": q5, "q9": q9}
+QUERIES = {"q6": q6, "q1": q1, "q3": q3, "q5": q5, "q9": q9, "q4": q4, "q14": q14}
 
 
 def run(name, db, top=None):
@@ -139,4 +166,5 @@ TPCH_ORDER = {
     "q3": (10, [("revenue", "desc"), ("o_orderdate", "asc")]),
     "q5": (100, [("revenue", "desc")]),
     "q9": (128, [("nation", "asc"), ("o_year", "desc")]),
+    "q4": (100, [("o_orderpriority", "asc")]),
 }

@@ -29,6 +29,13 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_more():
+    """Reference results for queries beyond the configured five (q4, q14): make_golden.py --more."""
+    with open(os.path.join(ROOT, "tests", "golden", "tpch_golden_more.json")) as fh:
+        return json.load(fh)
+
+
+@pytest.fixture(scope="session")
 def hip_lib():
     """The product library.  On a box without a GPU only loading / symbol checks are possible."""
     from sdqlpy_amd import engine

@@ -36,12 +36,15 @@ REF_ROOT = "/root/reference"
 from sdqlpy_amd import tpch  # noqa: E402
 
 QUERIES = ["q1", "q3", "q5", "q6", "q9"]
+MORE_QUERIES = ["q4", "q14"]       # beyond the configured five (test/test_all.py:180-211, 695-716)
 QUERY_TABLES = {   # positional argument order of each reference query (test/test_all.py decorators)
     "q1": ["lineitem"],
     "q3": ["lineitem", "customer", "orders"],
     "q5": ["lineitem", "customer", "orders", "region", "nation", "supplier"],
     "q6": ["lineitem"],
     "q9": ["lineitem", "orders", "nation", "supplier", "part", "partsupp"],
+    "q4": ["orders", "lineitem"],
+    "q14": ["lineitem", "part"],
 }
 ALL_TABLES = ["lineitem", "customer", "orders", "region", "nation", "supplier", "part", "partsupp"]
 
@@ -142,9 +145,9 @@ def load_reference():
         if isinstance(node, ast.Assign) and isinstance(node.targets[0], ast.Name) and node.targets[0].id.endswith("_type"):
             exec(compile(ast.Module([node], []), "test_all.py", "exec"), ns)
     for node in tree.body:
-        if isinstance(node, ast.FunctionDef) and node.name in QUERIES:
+        if isinstance(node, ast.FunctionDef) and node.name in QUERIES + MORE_QUERIES:
             exec(compile(ast.Module([node], []), "test_all.py", "exec"), ns)
-    return ref, {q: ns[q] for q in QUERIES}
+    return ref, {q: ns[q] for q in QUERIES + MORE_QUERIES}
 
 
 def to_ref_table(ref, table):
@@ -184,13 +187,23 @@ def encode_result(ref, res):
     return {"kind": "set", "columns": cols or [], "rows": rows}
 
 
+MORE_CASES = [
+    ("tiny", 0.0003, "base", MORE_QUERIES),
+    ("tiny_nothing_passes", 0.0003, "nothing_passes", ["q14"]),
+    ("small", 0.01, "base", MORE_QUERIES),
+    ("medium", 0.05, "base", MORE_QUERIES),
+]
+
+
 def main():
+    more = "--more" in sys.argv          # python tests/golden/make_golden.py --more  -> tpch_golden_more.json (q4, q14)
+    cases = MORE_CASES if more else CASES
     ref, queries = load_reference()
     out = {"meta": {"generator_seed": tpch.DEFAULT_SEED,
                     "reference": "edin-dal/sdqlpy Python mode (sdqlpy_init(0,1)), queries from test/test_all.py",
                     "made_by": "tests/golden/make_golden.py"},
            "cases": []}
-    for name, sf, variant, qs in CASES:
+    for name, sf, variant, qs in cases:
         tables = sorted({t for q in qs for t in QUERY_TABLES[q]})
         base = tpch.generate(sf, tpch.DEFAULT_SEED, tables=tables, columns=tpch.columns_for(qs), threads=4)
         db = VARIANTS[variant](base)
@@ -212,7 +225,7 @@ def main():
             print("%-22s %s  %6.1fs  %s" % (name, q, time.time() - t0,
                                            r["value"] if r["kind"] == "scalar" else "%d rows" % len(r["rows"])), flush=True)
         out["cases"].append(case)
-    path = os.path.join(HERE, "tpch_golden.json")
+    path = os.path.join(HERE, "tpch_golden_more.json" if more else "tpch_golden.json")
     with open(path, "w") as fh:
         json.dump(out, fh, separators=(",", ":"))
     print("wrote", path, os.path.getsize(path), "bytes")

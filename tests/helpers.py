@@ -21,7 +21,7 @@ _db_cache = {}
 
 def case_db(case):
     """Regenerate the inputs of a golden case and check they are the ones the reference saw."""
-    key = case["name"]
+    key = (case["name"], tuple(sorted(case["results"])))
     if key not in _db_cache:
         qs = list(case["results"].keys())
         base = tpch.generate(case["sf"], case["seed"], tables=case["tables"], columns=tpch.columns_for(qs), threads=4)
@@ -83,7 +83,10 @@ def check_against_golden(res, gold, rel, what):
         return
     want = golden_rows(gold)
     if not gold["columns"]:
-        assert res is None or res.size() == 0, "%s: expected an empty result" % what
+        # the reference's interpreter raises on an empty aggregate (recorded as an empty set); a scalar
+        # expression over empty sums is 0/0 = NaN here, as in the reference's compiled mode
+        assert res is None or (isinstance(res, float) and math.isnan(res)) or (not isinstance(res, float) and res.size() == 0), \
+            "%s: expected an empty result" % what
         return
     assert_rows_match(result_rows(res, gold["columns"]), want, rel, what)
 
@@ -218,12 +221,16 @@ def string_predicate_case(ctx, widths=(1, 2, 3, 7, 10, 25, 31, 32, 33, 55, 64, 6
             if not nd:
                 continue
             nu = [ord(c) for c in nd]
-            for mode, name in ((0, "=="), (1, "!="), (2, "in")):
+            for mode, name in ((0, "=="), (1, "!="), (2, "in"), (3, "startsWith"), (4, "endsWith")):
                 want = []
                 for r, f in enumerate(fields):
+                    end = f.index(0) if 0 in f else width
                     if mode == 2:
-                        end = f.index(0) if 0 in f else width
                         hit = any(f[s:s + len(nu)] == nu for s in range(0, end - len(nu) + 1))
+                    elif mode == 3:
+                        hit = len(nu) <= end and f[:len(nu)] == nu
+                    elif mode == 4:
+                        hit = len(nu) <= end and f[end - len(nu):end] == nu
                     else:
                         eq = len(nu) <= width and f[:len(nu)] == nu and not any(f[len(nu):])
                         hit = eq != (mode == 1)
@@ -236,4 +243,42 @@ def string_predicate_case(ctx, widths=(1, 2, 3, 7, 10, 25, 31, 32, 33, 55, 64, 6
                 assert got == want, "width %d, %r %s field: %d rows, expected %d (first difference %s)" % (
                     width, nd, name, len(got), len(want), sorted(set(got) ^ set(want))[:5])
                 checked += 1
+    return checked
+
+
+def column_compare_case(ctx, n=70001, seed=12):
+    """Column-vs-column predicates (a op b on two int64 or two float64 columns, every operator,
+    alone / paired / next to a range predicate) through scan_filter_sum, groupby_small and
+    hash_build_unique, against numpy."""
+    import numpy as np
+    from sdqlpy_amd import abi
+    rng = np.random.default_rng(seed)
+    ia, ib = rng.integers(-50, 50, n).astype(np.int64), rng.integers(-50, 50, n).astype(np.int64)
+    fa = rng.integers(-40, 40, n) / 8.0
+    fb = rng.integers(-40, 40, n) / 8.0
+    fa[::97] = -0.0; fb[::97] = 0.0                                   # -0.0 == 0.0
+    v = rng.integers(1, 100, n).astype(np.float64)
+    g = rng.integers(0, 7, n).astype(np.int64)
+    cia, cib, cfa, cfb, cv, cg, ck = ctx.upload(ia), ctx.upload(ib), ctx.upload(fa), ctx.upload(fb), ctx.upload(v), ctx.upload(g), ctx.upload(np.arange(n, dtype=np.int64))
+    ops = {abi.CMP_LT: np.less, abi.CMP_LE: np.less_equal, abi.CMP_EQ: np.equal, abi.CMP_NE: np.not_equal}
+    checked = 0
+    for op, fn in ops.items():
+        for (ca, cb, a, b) in ((cia, cib, ia, ib), (cfa, cfb, fa, fb)):
+            m = fn(a, b)
+            vals, cnt = ctx.scan_filter_sum(n, abi.make_filter(cpreds=[(ca, cb, op)]), abi.make_tuple(abi.TUPLE_A, [cv]))
+            assert cnt == int(m.sum()) and vals[0] == float(v[m].sum()), (op, cnt, int(m.sum()))
+            checked += 1
+        # two comparisons and a range predicate together
+        m = fn(ia, ib) & (fb < fa) & (g >= 2) & (g <= 5)
+        flt = abi.make_filter(ipreds=[(cg, 2, 5)], cpreds=[(cia, cib, op), (cfb, cfa, abi.CMP_LT)])
+        keys, vals, cnts = ctx.groupby_small(n, flt, [cg], abi.make_tuple(abi.TUPLE_A, [cv]))
+        got = {int(k[0]): (float(x[0]), int(c)) for k, x, c in zip(keys, vals, cnts)}
+        want = {int(k): (float(v[m & (g == k)].sum()), int((m & (g == k)).sum())) for k in np.unique(g[m])}
+        assert got == want, (op, got, want)
+        t = ctx.hash_build_unique(n, flt, [], ck, [])
+        cnt = ctx.table_compact_count(t, 0)
+        rows = ctx.table_compact(t, 0, cnt, want_values=False, want_hits=False)[0]
+        t.free()
+        assert rows.tolist() == np.nonzero(m)[0].tolist(), op
+        checked += 2
     return checked

@@ -69,3 +69,12 @@ def test_oracle_string_predicates_follow_varchar_semantics(oracle_lib):
         assert string_predicate_case(ctx, widths=(1, 3, 10, 33, 55), rows=1200) > 100
     finally:
         ctx.close()
+
+
+def test_oracle_column_comparisons(oracle_lib):
+    from helpers import column_compare_case
+    ctx = oracle_lib.context(threads=3)
+    try:
+        assert column_compare_case(ctx) == 16
+    finally:
+        ctx.close()

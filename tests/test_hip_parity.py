@@ -195,6 +195,29 @@ def test_string_predicates_all_widths(hip_engine):
     assert string_predicate_case(hip_engine.ctx) > 400
 
 
+def test_column_comparisons(hip_engine):
+    """a op b on two columns (Q4's `l_commitdate < l_receiptdate`): every operator, ints and
+    doubles, in the scan, group-by and staging kernels (generic filter instances)."""
+    from helpers import column_compare_case
+    assert column_compare_case(hip_engine.ctx) == 16
+
+
+def test_queries_beyond_the_configured_five(hip_engine, oracle_engine, golden_more):
+    """q4 and q14: the reference's golden results, then SF=1 against the oracle."""
+    import helpers
+    from sdqlpy_amd import tpch
+    for case in golden_more["cases"]:
+        for q in case["results"]:
+            res = helpers.run_query(hip_engine, q, helpers.case_db(case))
+            helpers.check_against_golden(res, case["results"][q], 1e-10, "%s/%s" % (case["name"], q))
+    qs = ("q4", "q14")
+    db = tpch.generate(1.0, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+    got4, want4 = helpers.run_query(hip_engine, "q4", db), helpers.run_query(oracle_engine, "q4", db)
+    assert got4.rows() == want4.rows() and got4.size() == 5
+    got14, want14 = helpers.run_query(hip_engine, "q14", db), helpers.run_query(oracle_engine, "q14", db)
+    assert abs(got14 - want14) <= 1e-10 * abs(want14) and 10.0 < got14 < 25.0
+
+
 def test_table_topk_matches_numpy_and_oracle(hip_engine, oracle_engine):
     """sdqh_table_topk (multi-level selection on the device) against a numpy restatement and the CPU
     implementation: same rows in the same order for every sort spec of the shared case."""

@@ -42,3 +42,21 @@ def test_oracle_reproduces_reference(oracle_lib, golden, threads, rel):
         assert n >= 21
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("threads,rel", [(1, 0.0), (3, 1e-12)])
+def test_oracle_reproduces_reference_beyond_the_configured_queries(oracle_lib, golden_more, threads, rel):
+    """q4 (column-vs-column predicate, dense set build, COUNT grouped by a text column) and q14
+    (prefix predicate, two conditional scalar sums, scalar arithmetic): SURVEY.md §8f.3."""
+    eng = engine.Engine(oracle_lib.context(threads=threads))
+    try:
+        n = 0
+        for case in golden_more["cases"]:
+            for q in case["results"]:
+                db = helpers.case_db(case)
+                res = helpers.run_query(eng, q, db)
+                helpers.check_against_golden(res, case["results"][q], rel, "%s/%s/threads=%d" % (case["name"], q, threads))
+                n += 1
+        assert n >= 7
+    finally:
+        eng.close()

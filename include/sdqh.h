@@ -216,6 +216,15 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
                            int nprobes, const sdqh_probe* probes,
                            const sdqh_column* key, int npayload, const sdqh_column* const* payload,
                            int accumulate, sdqh_table** out);
+/* Membership-only build: the set of key[row] over the rows that pass filter + probes, kept as an
+ * exact bitmap over the key range — what a `{unique(key): True}` build is for when it only ever
+ * answers `tbl[k] != None` (EXISTS sub-queries: Q4's late-lineitem orders, test/test_all.py:183-193).
+ * Nothing is staged: one streaming pass that ORs bits.  The table supports semi-join probes,
+ * payload-less lookups and sdqh_table_size only (as tables from sdqh_table_from_bitmap).
+ * SDQH_ERR_UNSUPPORTED when the key range is too wide or sparse for a bitmap (range > 2^31 or
+ * > 64 x nrows): use sdqh_hash_build_unique then. */
+int  sdqh_build_key_set(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter,
+                        int nprobes, const sdqh_probe* probes, const sdqh_column* key, sdqh_table** out);
 int  sdqh_table_size(sdqh_ctx* ctx, const sdqh_table* table, int64_t* entries);
 void sdqh_table_free(sdqh_ctx* ctx, sdqh_table* table);
 

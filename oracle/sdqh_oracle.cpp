@@ -545,6 +545,29 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
     ctx->last_ms = tm.ms();
     return SDQH_OK;
 }
+// membership-only build: an exact bitmap of the surviving keys (same range rule as the product)
+int sdqh_build_key_set(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nprobes, const sdqh_probe* probes,
+                       const sdqh_column* key, sdqh_table** out) {
+    if (!ctx || nrows < 0 || !out) return fail(ctx, SDQH_ERR_INVALID, "build_key_set: bad arguments");
+    FilterView fv;
+    if (int rc = make_filter(ctx, nrows, filter, nprobes, probes, &fv)) return rc;
+    if (int rc = check_col(ctx, key, SDQH_I64, nrows, "build key")) return rc;
+    const int64_t* kc = (const int64_t*)key->data;
+    int64_t lo = 0, hi = 0;
+    if (nrows > 0) {
+        lo = hi = kc[0];
+        for (int64_t r = 1; r < nrows; ++r) { lo = std::min(lo, kc[r]); hi = std::max(hi, kc[r]); }
+        const bool fits = lo > INT64_MIN / 2 && hi < INT64_MAX / 2 && (uint64_t)(hi - lo) + 1 <= (1ull << 31) &&
+                          (uint64_t)(hi - lo) + 1 <= 64ull * (uint64_t)std::max<int64_t>(nrows, 1024);
+        if (!fits) return fail(ctx, SDQH_ERR_UNSUPPORTED, "build_key_set: key range too wide or sparse for a bitmap");
+    }
+    sdqh_table* tb = new sdqh_table();
+    tb->bitmap_only = true; tb->bm_lo = lo; tb->bm_hi = hi;
+    tb->bm.assign((size_t)(((uint64_t)(hi - lo) + 32) / 32), 0u);
+    for (int64_t r = 0; r < nrows; ++r) if (fv.pass(r)) { const uint64_t off = (uint64_t)(kc[r] - lo); tb->bm[off >> 5] |= 1u << (off & 31); }
+    *out = tb;
+    return SDQH_OK;
+}
 int sdqh_table_size(sdqh_ctx* ctx, const sdqh_table* table, int64_t* entries) {
     if (!ctx || !table || !entries) return fail(ctx, SDQH_ERR_INVALID, "table_size: bad arguments");
     if (table->bitmap_only) { int64_t n = 0; for (uint32_t w : table->bm) n += __builtin_popcount(w); *entries = n; }

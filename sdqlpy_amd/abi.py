@@ -124,7 +124,7 @@ EXPORTS = [
     "sdqh_stream", "sdqh_set_option",
     "sdqh_column_upload", "sdqh_column_wrap", "sdqh_column_alloc", "sdqh_column_download", "sdqh_column_data",
     "sdqh_column_rows", "sdqh_column_dtype", "sdqh_column_width", "sdqh_column_minmax", "sdqh_column_free",
-    "sdqh_scan_filter_sum", "sdqh_scan_probe_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_table_size", "sdqh_table_free",
+    "sdqh_scan_filter_sum", "sdqh_scan_probe_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_build_key_set", "sdqh_table_size", "sdqh_table_free",
     "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_scan_compact", "sdqh_partition_by_key",
     "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in",
     "sdqh_build", "sdqh_lookup_aggregate", "sdqh_table_entries", "sdqh_host_alloc", "sdqh_host_free", "sdqh_table_topk",
@@ -415,6 +415,19 @@ class Context:
         self._after_call("hash_build_unique")
         t = Table(self, h, len(payload), accumulate)
         t._keep = (probes, key, payload)
+        return t
+
+    def build_key_set(self, nrows, flt, probes, key):
+        """Membership-only build (exact bitmap of the surviving keys); SdqhError(ERR_UNSUPPORTED)
+        when the key range does not suit a bitmap."""
+        parr = (Probe * max(1, len(probes)))()
+        for i, (tbl, kcol) in enumerate(probes):
+            parr[i].table, parr[i].key = tbl.handle, kcol.handle
+        h = C.c_void_p()
+        self._check(self.lib.sdqh_build_key_set(self.handle, C.c_int64(nrows), C.byref(flt), C.c_int(len(probes)), parr, key.handle, C.byref(h)))
+        self._after_call("build_key_set")
+        t = Table(self, h, 0, False)
+        t._keep = (probes, key)
         return t
 
     def build(self, nrows, flt, lookups, key, payload=(), accumulate=False):

@@ -947,11 +947,63 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
     return SDQH_OK;
 }
 
+int sdqh_build_key_set(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nprobes, const sdqh_probe* probes,
+                       const sdqh_column* key, sdqh_table** out) {
+    if (!ctx || nrows < 0 || !out) return fail(ctx, SDQH_ERR_INVALID, "build_key_set: bad arguments");
+    (void)hipSetDevice(ctx->device);
+    DevFilter f; DevProbes pr;
+    if (int rc = make_filter(ctx, nrows, filter, nullptr, &f)) return rc;
+    if (int rc = check_col(ctx, key, SDQH_I64, nrows, "build key")) return rc;
+    int64_t lo = 0, hi = -1;
+    if (nrows > 0) {
+        if (int rc = ensure_minmax(ctx, const_cast<sdqh_column*>(key))) return rc;
+        lo = key->mn; hi = key->mx;
+        const bool fits = hi >= lo && lo > INT64_MIN / 2 && hi < INT64_MAX / 2 && (uint64_t)(hi - lo) + 1 <= (1ull << 31) &&
+                          (uint64_t)(hi - lo) + 1 <= 64ull * (uint64_t)std::max<int64_t>(nrows, 1024);
+        if (!fits) return fail(ctx, SDQH_ERR_UNSUPPORTED, "build_key_set: key range too wide or sparse for a bitmap");
+    } else { lo = 0; hi = 0; }
+    call_begin(ctx);
+    if (int rc = make_probes(ctx, nrows, nprobes, probes, &pr)) return rc;
+    sdqh_table* tb = new sdqh_table();
+    tb->bitmap_only = true; tb->index_built = true; tb->nrows_build = nrows;
+    tb->nwords = ((uint64_t)(hi - lo) + 32) / 32;
+    tb->bm = static_cast<uint32_t*>(table_alloc(ctx, tb, tb->nwords * 4 + 64));
+    tb->hdr = static_cast<TableHeader*>(table_alloc(ctx, tb, sizeof(TableHeader)));
+    if (!tb->bm || !tb->hdr) { table_release(ctx, tb); delete tb; return fail(ctx, SDQH_ERR_NOMEM, "build_key_set: out of device memory"); }
+    tb->dev.bm = tb->bm; tb->dev.bm_lo = lo; tb->dev.bm_hi = hi; tb->dev.bitmap_only = 1; tb->dev.hdr = tb->hdr;
+    { FillList fl; fl.add(tb->bm, (tb->nwords * 4 + 15) & ~(uint64_t)15, 0); fl.add(tb->hdr, sizeof(TableHeader), 0); launch_fill(ctx, fl); }
+    if (nrows > 0) {
+        const int64_t* kc = static_cast<const int64_t*>(key->data);
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + TPB * ROWS_PER_LOAD * 2 - 1) / (TPB * ROWS_PER_LOAD * 2), (int64_t)ctx->num_cu * ctx->opt_resident_cap));
+        const unsigned str_rows = (f.ns && f.swidth > 0 && f.swidth <= 128) ? (f.swidth <= 64 ? 64u : 32u) : 0u;
+        const size_t lds = (size_t)(TPB / WAVE) * str_rows * (size_t)f.swidth * 4;
+        f.slds = str_rows;
+        with_stage_filter(f, nprobes, [&](auto FC) {
+            auto kern = k_key_set<decltype(FC)>;
+            LAUNCH_LDS(ctx, "k_key_set", kern, grid, lds, f, pr, kc, nrows, lo, hi, tb->bm);
+            return SDQH_OK;
+        });
+    }
+    call_end(ctx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { table_release(ctx, tb); delete tb; return fail(ctx, SDQH_ERR_DEVICE, std::string("build_key_set launch: ") + hipGetErrorString(e)); }
+    *out = tb;
+    return SDQH_OK;
+}
+
 int sdqh_table_size(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t* entries) {
     sdqh_table* table = const_cast<sdqh_table*>(ctable);
     if (!ctx || !table || !entries) return fail(ctx, SDQH_ERR_INVALID, "table_size: bad arguments");
-    if (table->bitmap_only) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_size: bitmap-only table");
     (void)hipSetDevice(ctx->device);
+    if (table->bitmap_only) {                                   // membership-only table: its size is the population count
+        if (!table->hdr) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_size: a table made from an imported bitmap has no size");
+        HIP_TRY(ctx, hipMemsetAsync(&table->hdr->counted, 0, 8, ctx->stream));
+        LAUNCH(ctx, "k_popcount", k_popcount, (unsigned)ctx->num_cu * 4, table->bm, table->nwords, reinterpret_cast<unsigned long long*>(&table->hdr->counted));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->result_host, &table->hdr->counted, 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (int rc = sync_stream(ctx)) return rc;
+        *entries = *static_cast<const int64_t*>(ctx->result_host);
+        return SDQH_OK;
+    }
     if (int rc = ensure_index(ctx, table)) return rc;
     HIP_TRY(ctx, hipMemsetAsync(&table->hdr->counted, 0, 8, ctx->stream));
     LAUNCH(ctx, "k_count", k_count, (unsigned)((table->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE)), table->stage, table->dev);

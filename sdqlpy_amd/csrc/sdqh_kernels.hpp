@@ -250,14 +250,14 @@ __device__ __forceinline__ bool str_pred(const uint32_t* __restrict__ s, int wid
     return str_equal(s, width, val, len) != (mode != 0);
 }
 // `a[r] op b[r]` on two columns of one type (ints compare as int64, doubles as double)
-__device__ __forceinline__ bool col_pred(const DevFilter& f, int i, int64_t r) {
-    const int64_t x = f.ca[i][r], y = f.cb[i][r];
+__device__ __forceinline__ bool col_cmp(const DevFilter& f, int i, int64_t x, int64_t y) {
     bool lt, eq;
     if (f.cf64[i]) { const double a = __longlong_as_double(x), b = __longlong_as_double(y); lt = a < b; eq = a == b; }
     else { lt = x < y; eq = x == y; }
     const int op = f.cop[i];
     return op == SDQH_CMP_LT ? lt : (op == SDQH_CMP_LE ? (lt || eq) : (op == SDQH_CMP_EQ ? eq : !eq));
 }
+__device__ __forceinline__ bool col_pred(const DevFilter& f, int i, int64_t r) { return col_cmp(f, i, f.ca[i][r], f.cb[i][r]); }
 template <class FC>
 __device__ __forceinline__ bool col_preds(const DevFilter& f, int64_t r) {
     bool p = true;
@@ -990,12 +990,13 @@ __device__ __forceinline__ void pass_pairs(const DevFilter& f, const DevProbes& 
             }
         }
     }
-    if (cfg_nc<FC>(f.nc)) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            if (p[j][0]) p[j][0] = col_preds<FC>(f, r[j]);
-            if (p[j][1]) p[j][1] = col_preds<FC>(f, r[j] + 1);
-        }
+    for (int i = 0; i < SDQH_MAX_CPRED; ++i) if (i < cfg_nc<FC>(f.nc)) {        // both sides streamed with 16-byte loads, all in flight first
+        Pair<int64_t> a[NB], b[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { a[j] = load2<false>(f.ca[i], r[j], nrows); b[j] = load2<false>(f.cb[i], r[j], nrows); }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { p[j][0] = p[j][0] && col_cmp(f, i, a[j].x, b[j].x); p[j][1] = p[j][1] && col_cmp(f, i, a[j].y, b[j].y); }
     }
 #pragma unroll
     for (int i = 0; i < SDQH_MAX_PROBE; ++i) if (i < cfg_np<FC>(pr.n)) {
@@ -1381,6 +1382,71 @@ __global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevT
             if (row_passes<FC>(f, none, r, nomask)) { const int64_t pos = table_find(tb, keycol[r], mask); if (pos >= 0) probe_add<SHAPE>(f, t, tb, pos, r); }
     }
     if (qn > 0) probe_drain<SHAPE>(f, t, tb, mask, q_row, q_key, 0, qn);
+}
+
+// Membership-only build (sdqh_build_key_set): stream filter + key, OR the survivors' bits.  A lane
+// holds two consecutive rows; keys of neighbouring rows usually share a bitmap word (a fact table
+// clustered on the key), so equal words of the pair are merged before the atomic.
+template <class FC>
+__global__ __launch_bounds__(TPB) void k_key_set(DevFilter f, DevProbes pr, const int64_t* __restrict__ key, int64_t nrows,
+                                                 int64_t lo, int64_t hi, uint32_t* __restrict__ bm) {
+    constexpr int PU = 2, TILE = TPB * ROWS_PER_LOAD * PU;
+    extern __shared__ __align__(16) uint32_t s_dyn[];                   // f.slds * swidth words per wave (string predicate staging)
+    uint32_t* s_str = (cfg_ns<FC>(f.ns) && f.slds) ? s_dyn + (size_t)(threadIdx.x / WAVE) * f.slds * f.swidth : nullptr;
+    uint64_t cap_masks[SDQH_MAX_PROBE] = {0, 0};
+#pragma unroll
+    for (int i = 0; i < SDQH_MAX_PROBE; ++i) if (i < cfg_np<FC>(pr.n) && pr.table[i].hdr && !table_is_direct(pr.table[i]) && !pr.table[i].bitmap_only) cap_masks[i] = pr.table[i].hdr->cap_mask;
+    // One (word, bits) per lane, merged across the wave before the atomic: with keys in row order the
+    // 128 rows of a wave step fall into a handful of bitmap words.  Segmented OR-scan over runs of
+    // equal words (6 shuffle steps); the last lane of each run issues one atomic for the run.  Equal
+    // words that are not adjacent are merely issued more than once (OR is idempotent).
+    auto wave_set = [&](bool valid, uint32_t w, uint32_t bits) {
+        if (!valid) { w = 0xFFFFFFFFu; bits = 0u; }
+        const int lane = lane_id();
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const uint32_t ow = __shfl_up(w, off, WAVE), ob = __shfl_up(bits, off, WAVE);
+            if (lane >= off && ow == w) bits |= ob;
+        }
+        const uint32_t nw = __shfl_down(w, 1, WAVE);
+        if (w != 0xFFFFFFFFu && (lane == WAVE - 1 || nw != w)) atomicOr(&bm[w], bits);
+    };
+    auto set_pair = [&](bool p0, int64_t k0, bool p1, int64_t k1) {       // converged: every lane calls it
+        p0 = p0 && k0 >= lo && k0 <= hi; p1 = p1 && k1 >= lo && k1 <= hi;
+        const uint64_t o0 = (uint64_t)(k0 - lo), o1 = (uint64_t)(k1 - lo);
+        const uint32_t w0 = (uint32_t)(o0 >> 5), w1 = (uint32_t)(o1 >> 5), b0 = 1u << (o0 & 31), b1 = 1u << (o1 & 31);
+        const bool both = p0 && p1 && w0 == w1;
+        wave_set(p0, w0, both ? (b0 | b1) : b0);
+        if (__ballot(p1 && !both)) wave_set(p1 && !both, w1, b1);
+    };
+    const int64_t full = nrows / TILE;
+    for (int64_t tile = blockIdx.x; tile < full; tile += gridDim.x) {
+        int64_t r[PU];
+        Pair<int64_t> kv[PU];
+        bool p[PU][2];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            r[u] = tile * TILE + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
+            kv[u] = load2<false>(key, r[u], nrows);
+            p[u][0] = p[u][1] = true;
+        }
+        pass_pairs<PU, FC, true>(f, pr, r, nrows, cap_masks, p, s_str);
+#pragma unroll
+        for (int u = 0; u < PU; ++u) set_pair(p[u][0], kv[u].x, p[u][1], kv[u].y);
+    }
+    if (full * TILE < nrows && blockIdx.x == (unsigned)(full % gridDim.x))
+        for (int64_t r0 = full * TILE; r0 < nrows; r0 += TPB) {
+            const int64_t r = r0 + threadIdx.x;
+            const bool ok = r < nrows && row_passes<FC>(f, pr, r, cap_masks);
+            set_pair(ok, ok ? key[r] : lo, false, lo);
+        }
+}
+// population count of a bitmap (sdqh_table_size of a membership-only table)
+__global__ __launch_bounds__(TPB) void k_popcount(const uint32_t* __restrict__ bm, uint64_t nwords, unsigned long long* __restrict__ out) {
+    unsigned long long n = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < nwords; i += (uint64_t)gridDim.x * TPB) n += __popc(bm[i]);
+    n = (unsigned long long)wave_sum_i64((int64_t)n);
+    if (lane_id() == 0 && n) atomicAdd(out, n);
 }
 
 // K-A with semi-join probes (sdqh_scan_probe_sum): the streaming part of k_probe_agg — first

@@ -576,7 +576,7 @@ def _eval_scalar_expr(e, env, lineno):
     raise UnsupportedQuery("line %d: unsupported scalar expression %r" % (lineno, e))
 
 
-def _prepare_scan(eng, op, htab, accumulate_into):
+def _prepare_scan(eng, op, htab, accumulate_into, member_only=False):
     ctx = eng.ctx
     if op.kind == "scalar":
         return _prepare_scalar(eng, op, htab, op.conds, op.val)
@@ -621,7 +621,15 @@ def _prepare_scan(eng, op, htab, accumulate_into):
         key_name = key_fields[0][0] or kname
 
         def run_build(env):
-            table = ctx.hash_build_unique(n, flt, _resolve_probes(op, env, specs), kcol, payload_cols, accumulate=accumulate)
+            table = None
+            if member_only and not payload_cols and not accumulate:
+                try:
+                    table = ctx.build_key_set(n, flt, _resolve_probes(op, env, specs), kcol)
+                except abi.SdqhError as exc:
+                    if exc.code != abi.ERR_UNSUPPORTED:          # key range unsuitable for a bitmap: ordinary build
+                        raise
+            if table is None:
+                table = ctx.hash_build_unique(n, flt, _resolve_probes(op, env, specs), kcol, payload_cols, accumulate=accumulate)
             return BuiltTable(table, key_name, key_is_record, val_fields, val_is_record, payload_dtypes)
         return run_build
 
@@ -825,6 +833,53 @@ def _finalize(eng, op, env, top=None):
     return rs
 
 
+def _membership_only(plan):
+    """Names of unique builds that are only used as `tbl[key] != None` / joinProbe index with no
+    payload access, and are not the plan's result."""
+    builds = {op.out for op in plan.ops if isinstance(op, ScanOp) and op.kind == "dict" and op.unique and op.probe is None
+              and not (isinstance(op.val, RecordCons) and any(not (isinstance(e, Col) and isinstance(op.key, Col) and e.name == op.key.name) for _, e in op.val.fields))}
+    used_for_payload = set()
+
+    def walk(e, as_cond=False):
+        if isinstance(e, PayloadField):
+            if e.field is not None or not as_cond:
+                used_for_payload.add(e.lookup.dict_name)
+            walk(e.lookup.key)
+        elif isinstance(e, Lookup):
+            if not as_cond:
+                used_for_payload.add(e.dict_name)
+            walk(e.key)
+        elif isinstance(e, Contains):
+            walk(e.lookup.key)
+        elif isinstance(e, (Bin, Cmp)):
+            walk(e.left); walk(e.right)
+        elif isinstance(e, And):
+            for t in e.terms:
+                walk(t)
+        elif isinstance(e, Call):
+            for a in e.args:
+                walk(a)
+        elif isinstance(e, RecordCons):
+            for _, x in e.fields:
+                walk(x)
+
+    for op in plan.ops:
+        if isinstance(op, ScanOp):
+            for c in op.conds:
+                walk(c, as_cond=True)
+            if op.probe is not None:
+                walk(op.probe.key)                               # the joinProbe index itself: membership
+            for e in [op.key, op.val] + ([x for _, x, _ in op.fields] if op.fields else []):
+                if e is not None:
+                    walk(e)
+            for _, _, fconds in (op.fields or []):
+                for c in fconds:
+                    walk(c, as_cond=True)
+        elif isinstance(op, FinalizeOp):
+            used_for_payload.add(op.source)
+    return {b for b in builds if b not in used_for_payload and b != plan.result}
+
+
 class PreparedPlan:
     """A plan bound to one engine and one set of tables: every operator lowered to a closure."""
 
@@ -836,11 +891,15 @@ class PreparedPlan:
         tables = {p: HostTable(p, a) for p, a in zip(plan.params, args)}
         # tables that a later probe-aggregate folds its group-by into must carry accumulators
         accumulate_into = {op.probe.dict_name for op in plan.ops
-                           if isinstance(op, ScanOp) and op.kind == "dict" and not op.unique and op.probe is not None}
+                           if isinstance(op, ScanOp) and op.kind == "dict" and not op.unique and op.probe is not None
+                           and _is_simple(op, tables[op.table], [c.lookup for c in op.conds if isinstance(c, Contains)])}
+        # builds that only ever answer `tbl[k] != None` (never probed for a payload, never materialised):
+        # membership-only tables (sdqh_build_key_set)
+        member_only = _membership_only(plan)
         self.steps = []
         for op in plan.ops:
             if isinstance(op, ScanOp):
-                self.steps.append((op.out, _prepare_scan(eng, op, tables[op.table], accumulate_into)))
+                self.steps.append((op.out, _prepare_scan(eng, op, tables[op.table], accumulate_into, op.out in member_only)))
             elif isinstance(op, ScalarExprOp):
                 self.steps.append((op.out, (lambda env, op=op: _eval_scalar_expr(op.expr, env, op.lineno))))
             elif isinstance(op, FinalizeOp):

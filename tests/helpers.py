@@ -282,3 +282,42 @@ def column_compare_case(ctx, n=70001, seed=12):
         assert rows.tolist() == np.nonzero(m)[0].tolist(), op
         checked += 2
     return checked
+
+
+def key_set_case(ctx, n=200000, seed=8):
+    """sdqh_build_key_set: the same membership as sdqh_hash_build_unique gives (probe results,
+    size = distinct surviving keys), with duplicates, filters of every kind and a chained probe;
+    a key range that does not suit a bitmap is refused with SDQH_ERR_UNSUPPORTED."""
+    import numpy as np
+    import pytest
+    from sdqlpy_amd import abi
+    rng = np.random.default_rng(seed)
+    keys = np.sort(rng.integers(1000, 1000 + n // 2, n)).astype(np.int64)        # clustered, ~2 rows per key
+    a, b = rng.integers(0, 100, n).astype(np.int64), rng.integers(0, 100, n).astype(np.int64)
+    txt = np.array(["BUILDING", "MACHINERY", "AUTOMOBILE"], "<U10")[rng.integers(0, 3, n)]
+    probe_keys = rng.integers(0, 2000 + n // 2, 3 * n).astype(np.int64)
+    v = rng.integers(1, 50, 3 * n).astype(np.float64)
+    ck, ca, cb, ct, cpk, cv = ctx.upload(keys), ctx.upload(a), ctx.upload(b), ctx.upload(txt), ctx.upload(probe_keys), ctx.upload(v)
+    filters = [
+        (abi.make_filter(), np.ones(n, bool)),
+        (abi.make_filter(ipreds=[(ca, 10, 60)]), (a >= 10) & (a <= 60)),
+        (abi.make_filter(cpreds=[(ca, cb, abi.CMP_LT)]), a < b),
+        (abi.make_filter(spreds=[(ct, "BUILDING", abi.STR_EQ)]), txt == "BUILDING"),
+        (abi.make_filter(ipreds=[(ca, 0, -1)]), np.zeros(n, bool)),              # nothing passes: empty set
+    ]
+    for flt, mask in filters:
+        members = np.unique(keys[mask])
+        s = ctx.build_key_set(n, flt, [], ck)
+        assert s.size() == len(members)
+        vals, cnt = ctx.scan_probe_sum(3 * n, abi.make_filter(), [(s, cpk)], abi.make_tuple(abi.TUPLE_A, [cv]))
+        hit = np.isin(probe_keys, members)
+        assert cnt == int(hit.sum()) and vals[0] == float(v[hit].sum())
+        # chained: a second set built from the rows whose key is in the first
+        s2 = ctx.build_key_set(3 * n, abi.make_filter(), [(s, cpk)], cpk)
+        assert s2.size() == len(np.unique(probe_keys[hit]))
+        s2.free(); s.free()
+    sparse = ctx.upload(np.array([1, 1 << 40], np.int64))
+    with pytest.raises(abi.SdqhError) as e:
+        ctx.build_key_set(2, abi.make_filter(), [], sparse)
+    assert e.value.code == abi.ERR_UNSUPPORTED
+    return len(filters)

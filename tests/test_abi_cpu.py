@@ -78,3 +78,12 @@ def test_oracle_column_comparisons(oracle_lib):
         assert column_compare_case(ctx) == 16
     finally:
         ctx.close()
+
+
+def test_oracle_key_sets(oracle_lib):
+    from helpers import key_set_case
+    ctx = oracle_lib.context(threads=3)
+    try:
+        assert key_set_case(ctx, n=20000) == 5
+    finally:
+        ctx.close()

@@ -195,6 +195,13 @@ def test_string_predicates_all_widths(hip_engine):
     assert string_predicate_case(hip_engine.ctx) > 400
 
 
+def test_membership_only_builds(hip_engine):
+    """sdqh_build_key_set (bitmap-only build used for `tbl[k] != None`) against numpy."""
+    from helpers import key_set_case
+    assert key_set_case(hip_engine.ctx) == 5
+    assert key_set_case(hip_engine.ctx, n=1000, seed=2) == 5
+
+
 def test_column_comparisons(hip_engine):
     """a op b on two columns (Q4's `l_commitdate < l_receiptdate`): every operator, ints and
     doubles, in the scan, group-by and staging kernels (generic filter instances)."""

@@ -90,25 +90,28 @@ class DistributedRunner:
 
     def _all_gather_columns(self, cols, n):
         """Concatenate int64 / f64 Columns of n rows per rank over all ranks (rank order), staying in
-        device memory: the sizes are exchanged once, then one padded all_gather per column."""
+        device memory: the sizes are exchanged once, then ONE padded all_gather carries every column
+        (column-major inside each rank's slot)."""
         sizes = [int(x[0]) for x in self._all_gather_array(np.array([n], np.int64))]
         total, m = sum(sizes), max(sizes + [1])
+        k = len(cols)
+        send = torch.empty(m * k, dtype=torch.int64, device=self.device)     # padding rows are never read back; no fill kernel
+        if n:                                                                # on torch's stream to race the library's copies
+            for j, col in enumerate(cols):
+                self.ctx.copy_out(col, 0, n, send.data_ptr() + j * m * 8)      # synchronises the library's stream
+        recv = torch.empty(m * k * self.world, dtype=torch.int64, device=self.device)
+        if self.backend == "nccl":
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+            torch.cuda.current_stream().synchronize()
+        else:
+            dist.all_gather(list(recv.view(self.world, m * k).unbind(0)), send, group=self.group)
         outs = []
-        for col in cols:
-            send = torch.zeros(m, dtype=torch.int64, device=self.device)
-            if n:
-                self.ctx.copy_out(col, 0, n, send.data_ptr())
-            recv = torch.empty(m * self.world, dtype=torch.int64, device=self.device)
-            if self.backend == "nccl":
-                dist.all_gather_into_tensor(recv, send, group=self.group)
-                torch.cuda.current_stream().synchronize()
-            else:
-                dist.all_gather(list(recv.view(self.world, m).unbind(0)), send, group=self.group)
+        for j, col in enumerate(cols):
             out = self.ctx.alloc(total, col.dtype)
             at = 0
             for r, sz in enumerate(sizes):
                 if sz:
-                    self.ctx.copy_in(out, at, sz, recv.data_ptr() + r * m * 8)
+                    self.ctx.copy_in(out, at, sz, recv.data_ptr() + (r * k + j) * m * 8)
                     at += sz
             outs.append(out)
         return outs, total
@@ -318,28 +321,50 @@ class DistributedRunner:
                     v.table.free()
 
     def _merge_groups(self, d):
-        """Partial groups of every rank -> the global groups on every rank (folded in rank order)."""
-        knames = [n for n, _ in d.key_fields]
-        rows = list(zip(*[a.tolist() for _, a in d.key_fields])) if d.size() else []
-        vals = list(zip(*[a.tolist() for _, a in d.val_fields])) if d.size() else []
-        mine = {"k": rows, "v": vals, "kd": [str(a.dtype) for _, a in d.key_fields], "vd": [str(a.dtype) for _, a in d.val_fields]}
-        parts = [None] * self.world
-        dist.all_gather_object(parts, mine, group=self.group)
+        """Partial groups of every rank -> the global groups on every rank (folded in rank order).
+        The rows travel as raw bytes in ONE fixed-size all_gather (<= 256 groups per rank: the
+        group-by kernels' own limit), not as pickled objects."""
+        fields = list(d.key_fields) + list(d.val_fields)
+        dtypes = [np.dtype(a.dtype) for _, a in fields]
+        rowbytes = sum(dt.itemsize for dt in dtypes)
+        cap = abi.MAX_LOOKUP_GROUPS
+        n = d.size()
+        if n > cap:
+            raise frontend.UnsupportedQuery("more than %d partial groups on one rank" % cap)
+        body_words = (cap * rowbytes + 7) // 8
+        buf = np.zeros(2 + body_words, np.int64)
+        buf[0], buf[1] = n, rowbytes
+        body = buf[2:].view(np.uint8)[: cap * rowbytes].reshape(cap, rowbytes)
+        at = 0
+        for (_, a), dt in zip(fields, dtypes):
+            if n:
+                body[:n, at:at + dt.itemsize] = np.ascontiguousarray(a).view(np.uint8).reshape(n, dt.itemsize)
+            at += dt.itemsize
+        parts = self._all_gather_array(buf)
         merged, order = {}, []
-        kd = vd = None
+        nk = len(d.key_fields)
         for p in parts:
-            if p["k"]:
-                kd, vd = p["kd"], p["vd"]
-            for k, v in zip(p["k"], p["v"]):
+            pn = int(p[0])
+            if not pn:
+                continue
+            if int(p[1]) != rowbytes:
+                raise RuntimeError("ranks disagree on the group row layout")
+            pbody = p[2:].view(np.uint8)[: cap * rowbytes].reshape(cap, rowbytes)
+            cols, at = [], 0
+            for dt in dtypes:
+                cols.append(np.ascontiguousarray(pbody[:pn, at:at + dt.itemsize]).view(dt).reshape(pn).tolist())
+                at += dt.itemsize
+            for row in zip(*cols):
+                k, v = row[:nk], row[nk:]
                 if k not in merged:
                     merged[k] = list(v); order.append(k)
                 else:
-                    merged[k] = [a + b for a, b in zip(merged[k], v)]
-        if kd is None:
+                    merged[k] = [x + y for x, y in zip(merged[k], v)]
+        if not order:
             return d
         order.sort()
-        kf = [(nm, np.array([k[j] for k in order], dtype=kd[j])) for j, nm in enumerate(knames)]
-        vf = [(nm, np.array([merged[k][j] for k in order], dtype=vd[j])) for j, (nm, _) in enumerate(d.val_fields)]
+        kf = [(nm, np.array([k[j] for k in order], dtype=dtypes[j])) for j, (nm, _) in enumerate(d.key_fields)]
+        vf = [(nm, np.array([merged[k][j] for k in order], dtype=dtypes[nk + j])) for j, (nm, _) in enumerate(d.val_fields)]
         return engine.DictResult(kf, vf, d.key_is_record, d.val_is_record)
 
     def _row_sharded_groupby(self, plan, args):

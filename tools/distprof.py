@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Host profile of the distributed plan on one rank (RCCL group of size 1): where the fixed cost of
+the multi-GPU path goes.  python tools/distprof.py q3,q5"""
+import cProfile
+import os
+import pstats
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29591")
+os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from sdqlpy_amd import dist as sdist, engine, tpch
+from sdqlpy_amd.sdql_lib import sdqlpy_init
+
+qs = sys.argv[1].split(",") if len(sys.argv) > 1 else ["q3", "q5"]
+sdqlpy_init(3, 1, device=0)
+db = tpch.generate(10, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+runner = sdist.DistributedRunner(engine.default_engine(device=0), 0, 1)
+for q in qs:
+    for _ in range(5):
+        runner.run(q, db)
+    t0 = time.perf_counter()
+    for _ in range(50):
+        runner.run(q, db)
+    print(q, "mean wall ms", (time.perf_counter() - t0) * 20, flush=True)
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(50):
+        runner.run(q, db)
+    pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(16)
+dist.destroy_process_group()

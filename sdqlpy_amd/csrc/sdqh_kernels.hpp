@@ -1934,8 +1934,8 @@ __global__ __launch_bounds__(TPB) void k_compact_write(DevTable t, DevStage st, 
 //                           best whenever the next batch might not fit; writes k candidates (padded)
 //   level i  k_topk_reduce  1024 candidates per workgroup -> k, until one workgroup is left; that
 //                           one writes the result rows
-// Selection is k rounds of "argmin of the rest" by one wave (top_block_select), cheap for the k of a
-// LIMIT clause (k <= SDQH_MAX_TOPK).
+// Selection inside a workgroup: k <= 16 -> k rounds of "argmin of the rest" by one wave; larger k ->
+// a bitonic sort of the slot numbers by all four waves (top_block_select / top_block_sort).
 // =================================================================================================
 constexpr int TOPK_CHUNK = 1024;
 constexpr int TOPK_PER_LANE = TOPK_CHUNK / WAVE;                       // 16 slots per lane of the selecting wave
@@ -1964,6 +1964,7 @@ struct TopLds {
     uint32_t ref[TOPK_CHUNK];
     uint64_t o0[SDQH_MAX_TOPK], o1[SDQH_MAX_TOPK], o2[SDQH_MAX_TOPK];     // the selection, in order
     uint32_t oref[SDQH_MAX_TOPK];
+    uint16_t perm[TOPK_CHUNK];                                             // sorting network: slot numbers in sorted order
     int count;
 };
 __device__ __forceinline__ bool top_less(const TopLds& s, int a, int b) {       // slot a sorts strictly before slot b
@@ -1989,7 +1990,36 @@ __device__ __forceinline__ void top_lane_best(const TopLds& s, const uint64_t (&
 // each lane keeps the primary keys of its 16 slots in registers and its current best slot; a round
 // is a 6-step butterfly on (primary key, slot) — equal primaries go back to LDS for the other keys —
 // after which only the lane that owned the winner looks for its next best.
+// Larger k: sort the slot numbers of [0, count) with a bitonic network (all four waves; 55 passes of
+// two compare-exchanges per thread for 1024 slots, independent of k) and take the first k.
+__device__ __forceinline__ int top_block_sort(TopLds& s, int count, int k) {
+    const int rounds = min(count, k);
+    int n2 = 2;
+    while (n2 < count) n2 <<= 1;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n2; i += TPB) s.perm[i] = i < count ? (uint16_t)i : (uint16_t)0xFFFF;
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < n2 / 2; t += TPB) {
+                const int i = 2 * t - (t & (stride - 1)), j = i + stride;
+                const bool up = (i & size) == 0;
+                const int a = s.perm[i], b = s.perm[j];
+                const bool a_lt_b = a != 0xFFFF && (b == 0xFFFF || top_less(s, a, b));      // padding sorts last
+                const bool b_lt_a = b != 0xFFFF && (a == 0xFFFF || top_less(s, b, a));
+                if (up ? b_lt_a : a_lt_b) { s.perm[i] = (uint16_t)b; s.perm[j] = (uint16_t)a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int j = threadIdx.x; j < rounds; j += TPB) { const int p = s.perm[j]; s.o0[j] = s.k0[p]; s.o1[j] = s.k1[p]; s.o2[j] = s.k2[p]; s.oref[j] = s.ref[p]; }
+    __syncthreads();
+    for (int j = threadIdx.x; j < rounds; j += TPB) { s.k0[j] = s.o0[j]; s.k1[j] = s.o1[j]; s.k2[j] = s.o2[j]; s.ref[j] = s.oref[j]; }
+    __syncthreads();
+    return rounds;
+}
 __device__ __forceinline__ int top_block_select(TopLds& s, int count, int k) {
+    if (k > 16) return top_block_sort(s, count, k);                      // k rounds of argmin cost more than one sort beyond that
     const int rounds = min(count, k);
     __syncthreads();
     if (threadIdx.x < WAVE) {

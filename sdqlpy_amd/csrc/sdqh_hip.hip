@@ -1410,7 +1410,7 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
     int lrc = with_shape(ctx, tuple_shape, [&](auto S) {
         return with_scan_filter(f, [&](auto FC) {
             auto kern = k_lookup_agg<decltype(S)::value, decltype(FC)>;
-            grid = stream_grid(ctx, kern, nrows, TPB * ROWS_PER_LOAD * 2 * ctx->opt_probe_chunk);
+            grid = stream_grid(ctx, kern, nrows, TPB * ROWS_PER_LOAD * LOOKUP_PU * ctx->opt_probe_chunk);
             const size_t nslots = (size_t)grid * LG_SLOTS;
             blob = static_cast<char*>(pool_alloc(ctx, nslots * 40 + 256));
             if (!blob) return fail(ctx, SDQH_ERR_NOMEM, "lookup_aggregate: out of device memory");

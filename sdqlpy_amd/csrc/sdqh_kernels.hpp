@@ -1561,6 +1561,7 @@ __device__ __forceinline__ bool first_lookup_may_hit(const DevLookups& L, int64_
     return (t.bm[off >> 5] >> (off & 31)) & 1u;
 }
 
+constexpr int LOOKUP_PU = 2;                                          // row pairs per lane in flight in k_lookup_agg's streaming part (4 measured the same: the kernel is bound by the 128-byte lines its sparse gathers pull in, not by step latency)
 constexpr int LQ_CAP = 192;                                           // 63 left over + 128 appended per pair step
 
 struct DevBuildSpec {                                                 // what a surviving row contributes to the build
@@ -1675,7 +1676,7 @@ __global__ __launch_bounds__(TPB) void k_lookup_agg(DevFilter f, DevLookups L, D
                                                     unsigned long long* __restrict__ gkeys, double* __restrict__ pacc,
                                                     int64_t* __restrict__ pcnt, int* __restrict__ flags, int chunk) {
     constexpr int NOPS = TupleTraits<SHAPE>::NOPS, NV = TupleTraits<SHAPE>::NV;
-    constexpr int PU = 2, TILE = TPB * ROWS_PER_LOAD * PU;
+    constexpr int PU = LOOKUP_PU, TILE = TPB * ROWS_PER_LOAD * PU;
     __shared__ unsigned long long s_keys[LG_SLOTS];
     constexpr int NVS = NV > 0 ? NV : 1;
     __shared__ double s_acc[LG_SLOTS][NVS];

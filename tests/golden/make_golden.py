@@ -108,6 +108,17 @@ def v_wide_doubles(db):
     return _replace(db, "lineitem", l_extendedprice=ep * scale)
 
 
+def v_signed_denormal(db):
+    """negative prices (returns / credits), exact zeros, denormals and values next to DBL_MAX/1e300
+    scale in the summed columns: sign handling of the order-preserving maps and non-finite-free
+    extremes of SUM(double)."""
+    ep = tpch.column(db["lineitem"], "l_extendedprice").copy()
+    n = len(ep)
+    pattern = np.array([1.0, -1.0, 0.0, 5e-324, -2.5e-310, 1e150, 2e150, -3.0], np.float64)[np.arange(n) % 8]    # huge terms share a sign: no catastrophic cancellation
+    ep = np.where(pattern == 0.0, 0.0, np.where(np.abs(pattern) < 1e-300, pattern, np.where(np.abs(pattern) > 1e100, pattern, ep * pattern)))
+    return _replace(db, "lineitem", l_extendedprice=ep)
+
+
 VARIANTS = {
     "base": v_identity,
     "nothing_passes": v_nothing_passes,
@@ -115,6 +126,7 @@ VARIANTS = {
     "one_group": v_one_group,
     "big_keys": v_big_keys,
     "wide_doubles": v_wide_doubles,
+    "signed_denormal": v_signed_denormal,
 }
 
 # (name, sf, variant, queries)
@@ -190,6 +202,8 @@ def encode_result(ref, res):
 MORE_CASES = [
     ("tiny", 0.0003, "base", MORE_QUERIES),
     ("tiny_nothing_passes", 0.0003, "nothing_passes", ["q14"]),
+    ("tiny_signed_denormal", 0.0003, "signed_denormal", ["q1", "q3", "q6", "q14"]),
+    ("small_signed_denormal", 0.01, "signed_denormal", ["q1", "q6"]),
     ("small", 0.01, "base", MORE_QUERIES),
     ("medium", 0.05, "base", MORE_QUERIES),
 ]

@@ -652,7 +652,6 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
     bool g4 = ctx->opt_groupby_regs == 4;
     if (ctx->opt_groupby_regs == 0) { g4 = true; for (int k = 0; k < SDQH_MAX_GROUPKEYS; ++k) g4 = g4 && ctx->g4_hint[k] == (k < nkeys ? gk.col[k] : nullptr); }
     for (int attempt = 0; attempt < 3; ++attempt) {
-        const int G = use_lds ? GMAX : (g4 ? 4 : GREG);
         unsigned grid = 1;
         char* blob = nullptr;
         double* pacc = nullptr; int64_t* pcnt = nullptr;

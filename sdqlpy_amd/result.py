@@ -70,6 +70,40 @@ class ResultSet:
     def __str__(self):
         return str(self.to_dict())
 
+    # -- the rest of the reference container's surface (reference src/sdqlpy/fastd.py:31-51) --------
+    def _row_of(self, key):
+        fields = key.getContainer() if hasattr(key, "getContainer") else dict(key)
+        if set(fields) != set(self.columns):
+            raise KeyError("record fields %s do not match the result columns %s" % (sorted(fields), self.columns))
+        return tuple(fields[c] for c in self.columns)
+
+    def get(self, key):
+        """True if the record is in the set, else None (`fastd.get`)."""
+        if getattr(self, "_index", None) is None:
+            self._index = set(zip(*[a.tolist() for a in self.arrays])) if self.arrays else set()
+        return True if self._row_of(key) in self._index else None
+
+    def set(self, key, value=True):
+        """Add a record to the set (`fastd.set`; the value of a result set entry is always True)."""
+        if value is not True:
+            raise ValueError("a result set maps records to True")
+        if self.get(key) is None:
+            row = self._row_of(key)
+            self.arrays = [np.append(a, np.array([v], dtype=a.dtype)) for a, v in zip(self.arrays, row)]
+            self._n += 1
+            self._index.add(row)
+
+    def from_dict(self, data):
+        """Replace the contents with {record: True, ...} (`fastd.from_dict`)."""
+        recs = list((data.getContainer() if hasattr(data, "getContainer") else data).keys())
+        rows = [self._row_of(r) for r in recs]
+        self.arrays = [np.array([r[j] for r in rows], dtype=self.arrays[j].dtype) for j in range(len(self.columns))]
+        self._n, self._index = len(rows), None
+        return self
+
+    def print(self):
+        print(str(self.to_dict()))
+
 
 class DictResult:
     """Dictionary from key record (or scalar) to value record (or scalar), struct-of-arrays."""

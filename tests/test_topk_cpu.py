@@ -71,3 +71,27 @@ def test_q3_top10_runs_on_the_device_operator(oracle):
     finally:
         del oracle.ctx.table_topk
     assert calls == [(10, [(abi.SORT_VALUE, 0, True, True), (abi.SORT_PAYLOAD, 0, False, False)])]
+
+
+def test_result_set_has_the_reference_containers_surface(oracle, capsys):
+    """size / to_dict / get / set / from_dict / print, as the reference's fastd wrapper offers them
+    (reference src/sdqlpy/fastd.py:31-51)."""
+    from sdqlpy_amd.sdql_lib import record
+    db = tpch.generate(0.005, tables=["lineitem"], columns=tpch.columns_for(("q1",)))
+    plan = frontend.lower_function(Q.QUERIES["q1"].__sdql_func__, Q.QUERIES["q1"].__sdql_in_type__)
+    res = engine.execute_plan(oracle, plan, [db["lineitem"]])
+    assert res.size() == len(res) == 4
+    d = res.to_dict().getContainer()
+    assert len(d) == 4 and all(v is True for v in d.values())
+    some = next(iter(d))
+    assert res.get(some) is True
+    other = record({**some.getContainer(), "count_order": -1})
+    assert res.get(other) is None
+    res.set(other, True)
+    assert res.size() == 5 and res.get(other) is True
+    res.print()
+    assert "count_order" in capsys.readouterr().out
+    back = res.from_dict(res.to_dict())
+    assert back.size() == 5
+    with pytest.raises(KeyError):
+        res.get(record({"nope": 1}))

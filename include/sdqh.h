@@ -161,7 +161,7 @@ int         sdqh_profile_entry(const sdqh_ctx* ctx, int i, const char** name, do
 /* Raw hipStream_t the ctx launches on (NULL in the CPU build). */
 void*       sdqh_stream(const sdqh_ctx* ctx);
 /* Tuning knobs of the HIP build ("resident_cap", "probe_unroll", "stage_batch", "stage_eager",
- * "stage_waves_per_cu", "direct_index"); results never depend on them.  The CPU build accepts and
+ * "stage_waves_per_cu", "direct_index", "async_copies"); results never depend on them.  The CPU build accepts and
  * ignores any name. */
 int         sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value);
 
@@ -338,7 +338,9 @@ int sdqh_partition_by_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, 
                           int64_t* counts);
 /* Device-to-device (CPU build: memcpy) copy of rows [row0, row0+nrows) of an I64/F64 column to or
  * from caller-owned memory of the same kind (e.g. a torch tensor used as a collective buffer).
- * Returns after the copy has completed. */
+ * Returns after the copy has completed — unless the option "async_copies" is 1: then the copy is
+ * only queued on the ctx stream and the caller calls sdqh_synchronize once per batch of copies (and
+ * keeps a copy_in source alive until then). */
 int sdqh_column_copy_out(sdqh_ctx* ctx, const sdqh_column* col, int64_t row0, int64_t nrows, void* dst);
 int sdqh_column_copy_in(sdqh_ctx* ctx, sdqh_column* col, int64_t row0, int64_t nrows, const void* src);
 /* Exact key bitmap of a table over [lo, hi] (bit i = key lo+i present), as device words.  If

@@ -61,6 +61,7 @@ struct sdqh_ctx {
     std::vector<std::pair<const void*, int>> occupancy;   // kernel -> resident workgroups per CU
     // tuning knobs (sdqh_set_option)
     int opt_resident_cap = 6;                      // probing kernels (latency chains to hide)
+    int opt_async_copies = 0;                      // sdqh_column_copy_in/_out do not wait (the caller synchronises once per batch)
     int opt_probe_chunk = 1;
     int opt_resident_stream = 2;                   // pure streaming kernels: fewer concurrent DRAM streams run faster (tools/microbench_q1.hip)
     int opt_probe_unroll = PROBE_UNROLL;
@@ -459,6 +460,7 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return SDQH_ERR_INVALID;
     const std::string n(name);
     if (n == "resident_cap" && value >= 1 && value <= 8) ctx->opt_resident_cap = (int)value;
+    else if (n == "async_copies" && (value == 0 || value == 1)) ctx->opt_async_copies = (int)value;
     else if (n == "resident_stream" && value >= 1 && value <= 8) ctx->opt_resident_stream = (int)value;
     else if (n == "probe_chunk" && value >= 1 && value <= 64) ctx->opt_probe_chunk = (int)value;
     else if (n == "probe_unroll" && (value == 1 || value == 2 || value == 4)) ctx->opt_probe_unroll = (int)value;
@@ -1537,7 +1539,7 @@ int sdqh_column_copy_out(sdqh_ctx* ctx, const sdqh_column* col, int64_t row0, in
     if (nrows == 0) return SDQH_OK;
     (void)hipSetDevice(ctx->device);
     HIP_TRY(ctx, hipMemcpyAsync(dst, static_cast<const char*>(col->data) + (size_t)row0 * 8, (size_t)nrows * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    return sync_stream(ctx);
+    return ctx->opt_async_copies ? SDQH_OK : sync_stream(ctx);
 }
 int sdqh_column_copy_in(sdqh_ctx* ctx, sdqh_column* col, int64_t row0, int64_t nrows, const void* src) {
     if (!ctx || !col || col->dtype == SDQH_STR || row0 < 0 || nrows < 0 || row0 + nrows > col->nrows || (nrows && !src)) return fail(ctx, SDQH_ERR_INVALID, "column_copy_in: bad arguments");
@@ -1545,7 +1547,7 @@ int sdqh_column_copy_in(sdqh_ctx* ctx, sdqh_column* col, int64_t row0, int64_t n
     (void)hipSetDevice(ctx->device);
     HIP_TRY(ctx, hipMemcpyAsync(static_cast<char*>(col->data) + (size_t)row0 * 8, src, (size_t)nrows * 8, hipMemcpyDeviceToDevice, ctx->stream));
     col->have_minmax = false; col->minmax_pending = false;
-    return sync_stream(ctx);
+    return ctx->opt_async_copies ? SDQH_OK : sync_stream(ctx);
 }
 
 int sdqh_table_export_bitmap(sdqh_ctx* ctx, const sdqh_table* table, int64_t lo, int64_t hi, sdqh_column** out_words) {

@@ -49,6 +49,7 @@ class DistributedRunner:
         self.exchanged_rows = {}
         self._plans = {}
         self._gather_bufs = {}
+        self._inflight = []                 # collective buffers that queued copy_ins still read (dropped at the next run)
 
     # ---- small collectives ---------------------------------------------------------------------
     def _all_gather_array(self, arr):
@@ -98,7 +99,8 @@ class DistributedRunner:
         send = torch.empty(m * k, dtype=torch.int64, device=self.device)     # padding rows are never read back; no fill kernel
         if n:                                                                # on torch's stream to race the library's copies
             for j, col in enumerate(cols):
-                self.ctx.copy_out(col, 0, n, send.data_ptr() + j * m * 8)      # synchronises the library's stream
+                self.ctx.copy_out(col, 0, n, send.data_ptr() + j * m * 8)      # queued ("async_copies")
+            self.ctx.synchronize()                                           # one wait for all of them before the collective reads
         recv = torch.empty(m * k * self.world, dtype=torch.int64, device=self.device)
         if self.backend == "nccl":
             dist.all_gather_into_tensor(recv, send, group=self.group)
@@ -114,6 +116,7 @@ class DistributedRunner:
                     self.ctx.copy_in(out, at, sz, recv.data_ptr() + (r * k + j) * m * 8)
                     at += sz
             outs.append(out)
+        self._inflight.append(recv)                                          # the queued copy_ins read it; released at the next run
         return outs, total
 
     def _all_gather_column(self, col, n):
@@ -161,12 +164,14 @@ class DistributedRunner:
                 send = torch.empty(max(n_send, 1), dtype=torch.int64, device=self.device)
                 if n_send:
                     self.ctx.copy_out(col, 0, n_send, send.data_ptr())
+                    self.ctx.synchronize()
                 recv = torch.empty(max(n_recv, 1), dtype=torch.int64, device=self.device)
                 self._a2a(recv[:n_recv], send[:n_send], [int(c) for c in recv_counts], [int(c) for c in counts])
                 if self.backend == "nccl":
                     torch.cuda.current_stream().synchronize()
                 if n_recv:
                     self.ctx.copy_in(new, 0, n_recv, recv.data_ptr())
+                    self._inflight.append(recv)
             out.append(new)
         return out, n_recv
 
@@ -177,12 +182,23 @@ class DistributedRunner:
         return self._plans[name]
 
     def run(self, name, db, whole_tables=("region", "nation"), top=None):
+        """See _run.  Column copies to / from collective buffers are only queued while a run is in
+        progress (option "async_copies"); the runner synchronises once per batch."""
+        self.ctx.set_option("async_copies", 1)
+        try:
+            return self._run(name, db, whole_tables, top)
+        finally:
+            self.ctx.synchronize()
+            self.ctx.set_option("async_copies", 0)
+
+    def _run(self, name, db, whole_tables=("region", "nation"), top=None):
         """Run query `name` on this rank's shard `db`; returns this rank's share of the result
         (q6: the global scalar on every rank; group-bys over a small domain (q1, q5, q9): the global
         groups on every rank; q3: the groups of this rank's key partition).  `whole_tables` names the
         tables every rank holds completely (the rest are row-sharded).  top = (k, [(column, "asc" |
         "desc")]) adds ORDER BY ... LIMIT k: every rank returns the same global first k rows (q3: each
         rank's device top-k of its partition, k rows per rank gathered and ordered again)."""
+        self._inflight.clear()              # the previous run ended synchronised
         if top is not None:
             k, order = int(top[0]), [(str(n), str(d)) for n, d in top[1]]
             if name == "q6":
@@ -190,7 +206,7 @@ class DistributedRunner:
             if name == "q3":
                 self._top = (k, order)
                 try:
-                    local = self.run(name, db, whole_tables)
+                    local = self._run(name, db, whole_tables)
                 finally:
                     self._top = None
                 cols = [[] for _ in local.columns]
@@ -201,7 +217,7 @@ class DistributedRunner:
                         c += vals
                 merged = ResultSet(local.columns, [np.array(c, a.dtype) for c, a in zip(cols, local.arrays)])
                 return merged.top(k, order)
-            return self.run(name, db, whole_tables).top(k, order)
+            return self._run(name, db, whole_tables).top(k, order)
         args = [db[t] for t in Q.QUERY_TABLES[name]]
         plan = self._plan(name)
         if name == "q6":

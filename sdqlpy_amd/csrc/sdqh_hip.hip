@@ -67,8 +67,8 @@ struct sdqh_ctx {
     int opt_probe_unroll = PROBE_UNROLL;
     int opt_stage_batch = STAGE_BATCH;
     int opt_stage_eager = 1;
-    int opt_stage_eager_pay = 1;
-    int opt_stage_waves_per_cu = 24;
+    int opt_stage_eager_pay = 0;                   // measured after the queued stage output: gathers for the ~10 % survivors beat streaming every payload row
+    int opt_stage_waves_per_cu = 12;               // tuned k_stage family: fewer, longer streams (12 x 256 x 5 columns) keep DRAM pages open; 24 was 15 % slower, 8 latency-bound
     int opt_direct_index = 1;
     int opt_groupby_regs = 0;                      // 0 = adaptive (4 when the last run of these key columns had <= 4 groups), 4, 8
     const void* g4_hint[SDQH_MAX_GROUPKEYS] = {nullptr, nullptr};
@@ -751,10 +751,10 @@ static void* table_alloc(sdqh_ctx* ctx, sdqh_table* t, size_t bytes) {
 // `batch`: 128-row batches the staging kernel handles per loop step; a segment is a whole number
 // of steps.  Small tables get short segments (down to one step per wave): their staging is bound
 // by the dependent-load chain of a step times the steps per wave, not by bytes.
-static int setup_stage(sdqh_ctx* ctx, sdqh_table* tb, int64_t nrows, const sdqh_column* key, int npay, const sdqh_column* const* payload, int batch) {
+static int setup_stage(sdqh_ctx* ctx, sdqh_table* tb, int64_t nrows, const sdqh_column* key, int npay, const sdqh_column* const* payload, int batch, int waves_per_cu = 24) {
     DevStage& st = tb->stage;
     std::memset(&st, 0, sizeof(st));
-    const int64_t target_segs = (int64_t)ctx->num_cu * ctx->opt_stage_waves_per_cu;   // one segment per wave
+    const int64_t target_segs = (int64_t)ctx->num_cu * waves_per_cu;                  // one segment per wave
     int64_t seg_rows = (nrows + target_segs - 1) / target_segs;
     const int64_t gran = (int64_t)WAVE * ROWS_PER_LOAD * std::max(1, batch);
     seg_rows = std::max<int64_t>(gran, (seg_rows + gran - 1) / gran * gran);
@@ -893,7 +893,9 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
     // the tuned orders-like instance family runs opt_stage_batch batches per step, every other instance STAGE_BATCH
     const bool tuned_family = f.ns == 0 && f.nf == 0 && f.ni == 1 && nprobes == 1 && npayload == 2;
     const bool string_family = f.ns == 1 && f.nf == 0 && f.ni == 0 && nprobes == 0;
-    int rc = setup_stage(ctx, tb, nrows, key, npayload, payload, tuned_family ? ctx->opt_stage_batch : (string_family ? 1 : STAGE_BATCH));
+    // the streaming-heavy tuned family wants fewer, longer segments (DRAM page locality); everything else more waves (latency chains)
+    int rc = setup_stage(ctx, tb, nrows, key, npayload, payload, tuned_family ? ctx->opt_stage_batch : (string_family ? 1 : STAGE_BATCH),
+                         tuned_family ? ctx->opt_stage_waves_per_cu : 24);
     uint64_t capmax = 1024;
     while (capmax < 2 * (uint64_t)std::max<int64_t>(nrows, 1)) capmax <<= 1;
     tb->capmax = capmax;

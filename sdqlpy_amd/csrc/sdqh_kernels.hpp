@@ -1035,8 +1035,10 @@ __device__ __forceinline__ void stage_store(const DevStage& st, int64_t pos, int
 template <class FC, int NPAY = -1, int SB = STAGE_BATCH, bool EAGER = true, bool EAGER_PAY = false>
 __global__ __launch_bounds__(TPB) void k_stage(DevFilter f, DevProbes pr, DevStage st, int64_t nrows) {
     extern __shared__ __align__(16) uint32_t s_dyn[];                   // f.slds * swidth words per wave (string predicate staging)
+    __shared__ uint16_t s_queue[TPB / WAVE][WAVE * ROWS_PER_LOAD * SB];   // survivors of a step (row offsets), in row order
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
     if (seg >= st.nseg) return;
+    uint16_t* q_off = s_queue[threadIdx.x / WAVE];
     uint32_t* s_str = (cfg_ns<FC>(f.ns) && f.slds) ? s_dyn + (size_t)(threadIdx.x / WAVE) * f.slds * f.swidth : nullptr;
     uint64_t cap_masks[SDQH_MAX_PROBE] = {0, 0};
 #pragma unroll
@@ -1080,6 +1082,38 @@ __global__ __launch_bounds__(TPB) void k_stage(DevFilter f, DevProbes pr, DevSta
                 if (p[j][0]) p[j][0] = row_passes<FC>(f, pr, r[j], cap_masks);
                 if (p[j][1]) p[j][1] = row_passes<FC>(f, pr, r[j] + 1, cap_masks);
             }
+        }
+        // Full step without eager payloads: the survivors of all SB batches are queued in LDS (row
+        // order: ballot + popcount prefix) and drained 64 at a time — one gather and one store
+        // instruction per column per 64 survivors.  Storing from inside the 2 x SB `if (survivor)`
+        // regions instead issues every store with a tenth of its lanes; the vector-memory issue slot
+        // per instruction, not bytes, bounded this kernel (same bytes, 17 % fewer: same time).
+        if (!EAGER_PAY && full_step) {
+            int qn = 0;
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                const uint64_t b0 = __ballot(p[j][0]), b1 = __ballot(p[j][1]);
+                const int at = qn + __popcll(b0 & lt) + __popcll(b1 & lt);
+                const int off = j * (int)BATCH_ROWS + lane * ROWS_PER_LOAD;
+                if (p[j][0]) q_off[at] = (uint16_t)off;
+                if (p[j][1]) q_off[at + (p[j][0] ? 1 : 0)] = (uint16_t)(off + 1);
+                qn += __popcll(b0) + __popcll(b1);
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int i0 = 0; i0 < qn; i0 += WAVE) {
+                const int i = i0 + lane;
+                if (i < qn) {
+                    const int64_t row = b + q_off[i];
+                    int64_t pay[MAX_STAGE_COLS];
+                    const int64_t key = st.src_key[row];
+#pragma unroll
+                    for (int c = 0; c < MAX_STAGE_COLS; ++c) pay[c] = c < cfg_npay<NPAY>(st.npay) ? st.src_pay[c][row] : 0;
+                    stage_store<NPAY>(st, out + i, key, pay);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            out += qn;
+            continue;
         }
         // Otherwise gather key + payload of every survivor of all SB batches before the first
         // store: one memory latency for the whole step, not one per divergent `if (survivor)` region.

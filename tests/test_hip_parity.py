@@ -254,6 +254,35 @@ def test_query_top_k_through_the_api(hip_engine, oracle_engine):
                 assert (abs(x - y) <= 1e-10 * max(abs(x), abs(y))) if isinstance(y, float) else x == y, (q, a, b)
 
 
+@pytest.mark.parametrize("sf", [0.03, 0.37, 1.3])
+def test_every_query_across_sizes(hip_engine, oracle_engine, sf):
+    """All seven queries and their top-k variants (k on both sides of the selection / sorting
+    switch and of the per-workgroup buffer) at sizes that move every segment, tile and level
+    boundary: HIP against the oracle on the same generated database."""
+    import helpers
+    from sdqlpy_amd import engine, frontend, tpch
+    from sdqlpy_amd import tpch_queries as Q
+    qs = sorted(Q.QUERIES)
+    db = tpch.generate(sf, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+    for q in qs:
+        got, want = helpers.run_query(hip_engine, q, db), helpers.run_query(oracle_engine, q, db)
+        if isinstance(want, float):
+            assert abs(got - want) <= 1e-10 * abs(want), (sf, q, got, want)
+            continue
+        helpers.assert_rows_match(got.rows(), want.rows(), 1e-10, "sf=%g/%s" % (sf, q))
+        if q not in Q.TPCH_ORDER:
+            continue
+        plan = frontend.lower_function(Q.QUERIES[q])
+        args = [db[t] for t in Q.QUERY_TABLES[q]]
+        for k in (1, 7, 16, 17, 100, 128):
+            t = engine.execute_plan(hip_engine, plan, args, top=(k, Q.TPCH_ORDER[q][1])).ordered_rows()
+            w = want.top(k, Q.TPCH_ORDER[q][1]).ordered_rows()
+            assert len(t) == len(w), (sf, q, k)
+            for a, b in zip(t, w):
+                for x, y in zip(a, b):
+                    assert (abs(x - y) <= 1e-10 * max(abs(x), abs(y))) if isinstance(y, float) else x == y, (sf, q, k, a, b)
+
+
 def test_redistribution_helpers_match_oracle(hip_engine, oracle_engine):
     """scan_compact / partition_by_key (hash and range) / bitmap export-import / column copies:
     same multisets of rows from both implementations of the ABI."""

@@ -235,6 +235,22 @@ void sdqh_table_free(sdqh_ctx* ctx, sdqh_table* table);
 int sdqh_hash_probe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter,
                               sdqh_table* table, const sdqh_column* key, const sdqh_tuple* tuple);
 
+/* ---- K-C with a large key domain, keyed by a column of the scanned row ---------------------------
+ * `{row.key: tuple}` summed per distinct key of an int column (Q18's sum of l_quantity per
+ * l_orderkey, test/test_all.py:877; emitted as the aggregating-dict loop ...generator_par.py:402-440).
+ * The result is a table whose entries are the distinct keys of the passing rows, each with the
+ * accumulated tuple and its row count: what sdqh_hash_build_unique(accumulate) on the rows followed
+ * by sdqh_hash_probe_aggregate of the same rows would leave, in one call. */
+int sdqh_groupby_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, const sdqh_column* key,
+                     const sdqh_tuple* tuple, sdqh_table** out);
+
+/* HAVING: the keys of the entries with at least min_hits rows whose accumulator `value_index` lies
+ * in [lo, hi], as a membership-only table (`{unique(k): True} if v > 300` over an aggregated
+ * dictionary, test/test_all.py:879-885).  The source must be a table with a dense key range (what
+ * sdqh_groupby_key and the direct layout of sdqh_hash_build_unique produce); SDQH_ERR_UNSUPPORTED otherwise. */
+int sdqh_table_select_keys(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, int value_index,
+                           double lo, double hi, sdqh_table** out);
+
 /* ---- K-F: compact the entries that received at least min_hits rows into host arrays ---------
  * out_keys[i], out_payload[p*capacity + i] (8 raw bytes each), out_values[v*capacity + i],
  * out_hits[i]; *out_n = rows written.  min_hits = 0 returns every entry.  Any out_* may be NULL;

@@ -116,6 +116,12 @@ struct sdqh_table {
     bool bitmap_only = false;
     int64_t bm_lo = 0, bm_hi = -1;
     std::vector<uint32_t> bm;
+    // key-column statistics of the build side (all rows): decide, as the product does, whether the keys have a dense range
+    int64_t col_lo = 0, col_hi = -1, nrows_build = 0;
+    bool dense_range() const {
+        return col_hi >= col_lo && col_lo > INT64_MIN / 2 && col_hi < INT64_MAX / 2 && (uint64_t)(col_hi - col_lo) + 1 <= (1ull << 31) &&
+               (uint64_t)(col_hi - col_lo) + 1 <= 64ull * (uint64_t)std::max<int64_t>(nrows_build, 1024);
+    }
     bool contains(int64_t k) const {
         if (bitmap_only) {
             if (k < bm_lo || k > bm_hi) return false;
@@ -533,6 +539,8 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
     });
     sdqh_table* tb = new sdqh_table();
     tb->npayload = npayload; tb->accumulate = accumulate != 0;
+    tb->nrows_build = nrows;
+    if (nrows > 0) { tb->col_lo = tb->col_hi = kc[0]; for (int64_t r = 1; r < nrows; ++r) { tb->col_lo = std::min(tb->col_lo, kc[r]); tb->col_hi = std::max(tb->col_hi, kc[r]); } }
     for (int t = 0; t < T; ++t)                                       // global.insert(local.begin(), local.end()): first wins
         for (int64_t r : local[(size_t)t]) {
             int64_t e = (int64_t)tb->keys.size();
@@ -638,6 +646,36 @@ int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits,
     *out_n = n;
     ctx->last_ms = tm.ms();
     if (!count_only && n > capacity) return fail(ctx, SDQH_ERR_OVERFLOW, "table_compact: capacity too small");
+    return SDQH_OK;
+}
+
+// K-C with a large key domain on a row key: `local[key] += tuple` per distinct key (generator 402-440);
+// restated as the unique build of the keys followed by the aggregation of the same rows into it.
+int sdqh_groupby_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, const sdqh_column* key, const sdqh_tuple* tuple, sdqh_table** out) {
+    if (!ctx || nrows < 0 || !out || !tuple) return fail(ctx, SDQH_ERR_INVALID, "groupby_key: bad arguments");
+    sdqh_table* tb = nullptr;
+    if (int rc = sdqh_hash_build_unique(ctx, nrows, filter, 0, nullptr, key, 0, nullptr, 1, &tb)) return rc;
+    if (int rc = sdqh_hash_probe_aggregate(ctx, nrows, filter, tb, key, tuple)) { delete tb; return rc; }
+    *out = tb;
+    return SDQH_OK;
+}
+
+// HAVING: keys of the entries whose accumulator lies in [lo, hi] (test/test_all.py:879-885)
+int sdqh_table_select_keys(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, int value_index, double lo, double hi, sdqh_table** out) {
+    if (!ctx || !table || !out || value_index < 0 || value_index >= SDQH_TUPLE_MAX_VALUES) return fail(ctx, SDQH_ERR_INVALID, "table_select_keys: bad arguments");
+    if (!table->accumulate || table->bitmap_only) return fail(ctx, SDQH_ERR_INVALID, "table_select_keys: the table carries no accumulators");
+    if (!table->dense_range()) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_select_keys: the table's keys have no dense range");
+    sdqh_table* tb = new sdqh_table();
+    tb->bitmap_only = true; tb->bm_lo = table->col_lo; tb->bm_hi = table->col_hi;
+    tb->bm.assign((size_t)(((uint64_t)(tb->bm_hi - tb->bm_lo) + 32) / 32), 0u);
+    for (size_t e = 0; e < table->keys.size(); ++e) {
+        if (table->acc[e].n < min_hits) continue;
+        const double x = table->acc[e].v[value_index];
+        if (!(x >= lo && x <= hi)) continue;
+        const uint64_t off = (uint64_t)(table->keys[e] - tb->bm_lo);
+        tb->bm[off >> 5] |= 1u << (off & 31);
+    }
+    *out = tb;
     return SDQH_OK;
 }
 

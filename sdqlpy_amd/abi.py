@@ -124,7 +124,7 @@ EXPORTS = [
     "sdqh_stream", "sdqh_set_option",
     "sdqh_column_upload", "sdqh_column_wrap", "sdqh_column_alloc", "sdqh_column_download", "sdqh_column_data",
     "sdqh_column_rows", "sdqh_column_dtype", "sdqh_column_width", "sdqh_column_minmax", "sdqh_column_free",
-    "sdqh_scan_filter_sum", "sdqh_scan_probe_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_build_key_set", "sdqh_table_size", "sdqh_table_free",
+    "sdqh_scan_filter_sum", "sdqh_scan_probe_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_build_key_set", "sdqh_groupby_key", "sdqh_table_select_keys", "sdqh_table_size", "sdqh_table_free",
     "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_scan_compact", "sdqh_partition_by_key",
     "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in",
     "sdqh_build", "sdqh_lookup_aggregate", "sdqh_table_entries", "sdqh_host_alloc", "sdqh_host_free", "sdqh_table_topk",
@@ -429,6 +429,22 @@ class Context:
         t = Table(self, h, 0, False)
         t._keep = (probes, key)
         return t
+
+    def groupby_key(self, nrows, flt, key, tup):
+        """Aggregating dictionary keyed by an int column of any cardinality -> accumulating Table."""
+        h = C.c_void_p()
+        self._check(self.lib.sdqh_groupby_key(self.handle, C.c_int64(nrows), C.byref(flt), key.handle, C.byref(tup), C.byref(h)))
+        self._after_call("groupby_key")
+        t = Table(self, h, 0, True)
+        t._keep = (key, flt, tup)
+        return t
+
+    def table_select_keys(self, table, min_hits, value_index, lo, hi):
+        """HAVING lo <= accumulator <= hi -> membership-only Table of the keys."""
+        h = C.c_void_p()
+        self._check(self.lib.sdqh_table_select_keys(self.handle, table.handle, C.c_int64(min_hits), C.c_int(value_index), C.c_double(lo), C.c_double(hi), C.byref(h)))
+        self._after_call("table_select_keys")
+        return Table(self, h, 0, False)
 
     def build(self, nrows, flt, lookups, key, payload=(), accumulate=False):
         """Generalised unique build: lookups [(Table, [key sources])], key [1-2 sources], payload [sources]."""

@@ -1059,6 +1059,98 @@ int sdqh_hash_probe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* f
     return SDQH_OK;
 }
 
+// ---- K-C large domain on a row key; HAVING -------------------------------------------------------------
+int sdqh_groupby_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, const sdqh_column* key, const sdqh_tuple* tuple, sdqh_table** out) {
+    if (!ctx || nrows < 0 || !out || !tuple) return fail(ctx, SDQH_ERR_INVALID, "groupby_key: bad arguments");
+    if (nrows >= 0xFFFFFFFEll) return fail(ctx, SDQH_ERR_UNSUPPORTED, "groupby_key: limited to 2^32-2 rows per GPU");
+    (void)hipSetDevice(ctx->device);
+    if (int rc = check_col(ctx, key, SDQH_I64, nrows, "group key")) return rc;
+    int64_t lo = 0, hi = -1; bool dense = false;
+    if (nrows > 0) {
+        if (int rc = ensure_minmax(ctx, const_cast<sdqh_column*>(key))) return rc;
+        lo = key->mn; hi = key->mx;
+        dense = ctx->opt_direct_index && hi >= lo && lo > INT64_MIN / 2 && hi < INT64_MAX / 2 && (uint64_t)(hi - lo) + 1 <= (1ull << 31) &&
+                (uint64_t)(hi - lo) + 1 <= 64ull * (uint64_t)std::max<int64_t>(nrows, 1024);
+    }
+    if (!dense) {                                      // any int64 keys: stage every passing row, index (first row owns the entry), add the rows
+        sdqh_table* tb = nullptr;
+        if (int rc = sdqh_hash_build_unique(ctx, nrows, filter, 0, nullptr, key, 0, nullptr, 1, &tb)) return rc;
+        if (int rc = sdqh_hash_probe_aggregate(ctx, nrows, filter, tb, key, tuple)) { sdqh_table_free(ctx, tb); return rc; }
+        *out = tb;
+        return SDQH_OK;
+    }
+    // dense key range: distinct keys from a bitmap, entries laid out by rank, rows added by the probe kernel
+    DevFilter f; DevProbes pr; std::memset(&pr, 0, sizeof(pr));
+    if (int rc = make_filter(ctx, nrows, filter, nullptr, &f)) return rc;
+    sdqh_table* tb = new sdqh_table();
+    tb->accumulate = true; tb->npay = 0; tb->nrows_build = nrows; tb->index_built = true;
+    const uint64_t range = (uint64_t)(hi - lo) + 1;
+    const uint64_t dmax = std::min<uint64_t>((uint64_t)nrows, range);           // at most this many distinct keys
+    tb->nwords = (range + 31) / 32;
+    DevStage& st = tb->stage;
+    std::memset(&st, 0, sizeof(st));
+    st.seg_rows = (int64_t)WAVE * ROWS_PER_LOAD * 16;                           // 2048 entries per compaction wave
+    st.nseg = (int32_t)std::max<uint64_t>(1, (dmax + (uint64_t)st.seg_rows - 1) / (uint64_t)st.seg_rows);
+    tb->bm = static_cast<uint32_t*>(table_alloc(ctx, tb, tb->nwords * 4 + 64));
+    tb->hdr = static_cast<TableHeader*>(table_alloc(ctx, tb, sizeof(TableHeader)));
+    uint32_t* wprefix = static_cast<uint32_t*>(table_alloc(ctx, tb, tb->nwords * 4 + 64));
+    uint32_t* dense_ref = static_cast<uint32_t*>(table_alloc(ctx, tb, dmax * 4 + 64));
+    st.key = static_cast<int64_t*>(table_alloc(ctx, tb, dmax * 8 + 64));
+    st.shits = static_cast<uint32_t*>(table_alloc(ctx, tb, dmax * 4 + 64));
+    st.sacc = static_cast<double*>(table_alloc(ctx, tb, dmax * 32 + 64));
+    st.seg_count = static_cast<uint32_t*>(table_alloc(ctx, tb, (size_t)st.nseg * 4 + 64));
+    if (!tb->bm || !tb->hdr || !wprefix || !dense_ref || !st.key || !st.shits || !st.sacc || !st.seg_count) {
+        table_release(ctx, tb); delete tb; return fail(ctx, SDQH_ERR_NOMEM, "groupby_key: out of device memory");
+    }
+    st.hdr = tb->hdr; st.bm = tb->bm; st.bm_lo = lo; st.bm_hi = hi;
+    tb->dev.hdr = tb->hdr; tb->dev.bm = tb->bm; tb->dev.bm_lo = lo; tb->dev.bm_hi = hi; tb->dev.wprefix = wprefix; tb->dev.dense_ref = dense_ref;
+    tb->dev.shits = st.shits; tb->dev.sacc = st.sacc;
+    call_begin(ctx);
+    { FillList fl; fl.add(tb->bm, (tb->nwords * 4 + 15) & ~(uint64_t)15, 0); fl.add(tb->hdr, sizeof(TableHeader), 0); launch_fill(ctx, fl); }
+    const int64_t* kc = static_cast<const int64_t*>(key->data);
+    const unsigned sgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + TPB * ROWS_PER_LOAD * 2 - 1) / (TPB * ROWS_PER_LOAD * 2), (int64_t)ctx->num_cu * ctx->opt_resident_cap));
+    with_stage_filter(f, 0, [&](auto FC) {
+        auto kern = k_key_set<decltype(FC)>;
+        LAUNCH_LDS(ctx, "k_key_set", kern, sgrid, 0, f, pr, kc, nrows, lo, hi, tb->bm);
+        return SDQH_OK;
+    });
+    const int nblocks = (int)((tb->nwords + RANK_BLOCK_WORDS - 1) / RANK_BLOCK_WORDS);
+    LAUNCH(ctx, "k_rank_words", k_rank_words, (unsigned)nblocks, tb->bm, tb->nwords, wprefix, static_cast<const uint32_t*>(nullptr), 0, tb->hdr);
+    LAUNCH(ctx, "k_gk_layout", k_gk_layout, (unsigned)ctx->num_cu * 8, st, tb->dev, lo, tb->nwords);
+    call_end(ctx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { table_release(ctx, tb); delete tb; return fail(ctx, SDQH_ERR_DEVICE, std::string("groupby_key launch: ") + hipGetErrorString(e)); }
+    if (int rc = sdqh_hash_probe_aggregate(ctx, nrows, filter, tb, key, tuple)) { sdqh_table_free(ctx, tb); return rc; }
+    *out = tb;
+    return SDQH_OK;
+}
+
+int sdqh_table_select_keys(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_hits, int value_index, double lo, double hi, sdqh_table** out) {
+    sdqh_table* table = const_cast<sdqh_table*>(ctable);
+    if (!ctx || !table || !out || value_index < 0 || value_index >= SDQH_TUPLE_MAX_VALUES) return fail(ctx, SDQH_ERR_INVALID, "table_select_keys: bad arguments");
+    if (!table->accumulate || table->bitmap_only) return fail(ctx, SDQH_ERR_INVALID, "table_select_keys: the table carries no accumulators");
+    if (!table->bm || table->dev.bm_shift != 0 || table->dev.lin_rb != 0) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_select_keys: the table's keys have no dense range");
+    (void)hipSetDevice(ctx->device);
+    call_begin(ctx);
+    if (int rc = ensure_index(ctx, table)) return rc;
+    sdqh_table* tb = new sdqh_table();
+    tb->bitmap_only = true; tb->index_built = true; tb->nrows_build = table->nrows_build;
+    tb->nwords = table->nwords;
+    tb->bm = static_cast<uint32_t*>(table_alloc(ctx, tb, tb->nwords * 4 + 64));
+    tb->hdr = static_cast<TableHeader*>(table_alloc(ctx, tb, sizeof(TableHeader)));
+    if (!tb->bm || !tb->hdr) { table_release(ctx, tb); delete tb; return fail(ctx, SDQH_ERR_NOMEM, "table_select_keys: out of device memory"); }
+    tb->dev.bm = tb->bm; tb->dev.bm_lo = table->dev.bm_lo; tb->dev.bm_hi = table->dev.bm_hi; tb->dev.bitmap_only = 1; tb->dev.hdr = tb->hdr;
+    { FillList fl; fl.add(tb->bm, (tb->nwords * 4 + 15) & ~(uint64_t)15, 0); fl.add(tb->hdr, sizeof(TableHeader), 0); launch_fill(ctx, fl); }
+    const uint32_t mh = (uint32_t)std::min<int64_t>(std::max<int64_t>(min_hits, 0), 0xFFFFFFFFll);
+    const unsigned seg_grid = (unsigned)((table->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
+    LAUNCH(ctx, "k_select_keys", k_select_keys, seg_grid, table->dev, table->stage, mh, value_index, lo, hi, table->dev.bm_lo, tb->bm);
+    call_end(ctx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { table_release(ctx, tb); delete tb; return fail(ctx, SDQH_ERR_DEVICE, std::string("table_select_keys launch: ") + hipGetErrorString(e)); }
+    *out = tb;
+    return SDQH_OK;
+}
+
 // ---- K-F ---------------------------------------------------------------------------------------
 // Runs the compaction into device buffers (cached on the table) and returns the row count.
 struct HostDest { int64_t* keys = nullptr; int64_t* payload = nullptr; double* values = nullptr; int64_t* hits = nullptr; int64_t capacity = 0; };

@@ -1483,6 +1483,49 @@ __global__ __launch_bounds__(TPB) void k_popcount(const uint32_t* __restrict__ b
     if (lane_id() == 0 && n) atomicAdd(out, n);
 }
 
+// ---- group-by on a row key with a large domain (sdqh_groupby_key) --------------------------------------
+// The distinct keys come from k_key_set's bitmap, ranked by k_rank_words; entry i (= rank) is then
+// laid out directly: key[i] from the bit position, zeroed accumulators, identity dense_ref, segment
+// counts from the device-resident distinct count.  The rows are added by k_probe_agg.
+__global__ __launch_bounds__(TPB) void k_gk_layout(DevStage st, DevTable t, int64_t lo, uint64_t nwords) {
+    const uint64_t D = t.hdr->distinct;
+    const uint64_t tid = (uint64_t)blockIdx.x * TPB + threadIdx.x, nth = (uint64_t)gridDim.x * TPB;
+    if (tid == 0) { t.hdr->staged = D; t.hdr->has_dups = 0; }
+    for (uint64_t s = tid; s < (uint64_t)st.nseg; s += nth) {
+        const uint64_t b = s * (uint64_t)st.seg_rows;
+        st.seg_count[s] = (uint32_t)(D > b ? min((uint64_t)st.seg_rows, D - b) : 0);
+    }
+    for (uint64_t i = tid; i < D; i += nth) {
+        t.dense_ref[i] = (uint32_t)i;
+        st.shits[i] = 0u;
+        if (st.sacc) { double4 z = {0, 0, 0, 0}; *reinterpret_cast<double4*>(st.sacc + i * 4) = z; }
+    }
+    for (uint64_t w = tid; w < nwords; w += nth) {                      // keys of the set bits of word w, at their ranks
+        uint32_t bits = t.bm[w];
+        uint64_t at = t.wprefix[w];
+        while (bits) { const int bit = __builtin_ctz(bits); bits &= bits - 1u; st.key[at++] = lo + (int64_t)(w * 32 + (uint64_t)bit); }
+    }
+}
+// HAVING (sdqh_table_select_keys): bits of the owner entries with hits >= min_hits and lo <= acc[v] <= hi
+__global__ __launch_bounds__(TPB) void k_select_keys(DevTable t, DevStage st, uint32_t min_hits, int v, double lo, double hi,
+                                                     int64_t key_lo, uint32_t* __restrict__ out_bm) {
+    const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
+    if (seg >= st.nseg) return;
+    const bool dups = t.hdr->has_dups != 0;
+    const uint64_t mask = (table_is_direct(t) || !dups) ? 0 : t.hdr->cap_mask;
+    const int64_t base = (int64_t)seg * st.seg_rows;
+    const uint32_t count = st.seg_count[seg];
+    for (uint32_t i = lane_id(); i < count; i += WAVE) {
+        const int64_t idx = base + i;
+        if (st.shits[idx] < min_hits) continue;
+        const double x = st.sacc[(size_t)idx * 4 + v];
+        if (!(x >= lo && x <= hi)) continue;
+        if (dups && !stage_row_owns(st, t, idx, mask)) continue;
+        const uint64_t off = (uint64_t)(st.key[idx] - key_lo);
+        atomicOr(&out_bm[off >> 5], 1u << (off & 31));
+    }
+}
+
 // K-A with semi-join probes (sdqh_scan_probe_sum): the streaming part of k_probe_agg — first
 // predicate and first probe key with 16-byte loads, bitmap test — but survivors add their tuple to
 // per-lane registers; workgroup partials are folded by k_sum_partials in a fixed order.

@@ -321,3 +321,48 @@ def key_set_case(ctx, n=200000, seed=8):
         ctx.build_key_set(2, abi.make_filter(), [], sparse)
     assert e.value.code == abi.ERR_UNSUPPORTED
     return len(filters)
+
+
+def groupby_key_case(ctx, n=250000, seed=14):
+    """sdqh_groupby_key on clustered and on shuffled keys, dense and sparse key ranges, with a
+    filter; then HAVING (sdqh_table_select_keys) and the selected set used as a semi-join.  Checked
+    against numpy (integer-valued doubles: sums are exact in any order)."""
+    import numpy as np
+    import pytest
+    from sdqlpy_amd import abi
+    rng = np.random.default_rng(seed)
+    checked = 0
+    for name, keys in (("clustered", np.sort(rng.integers(5, 5 + n // 4, n)).astype(np.int64)),
+                       ("shuffled", rng.integers(-1000, 3000, n).astype(np.int64)),
+                       ("sparse", (rng.integers(0, 2000, n).astype(np.int64) << 33) + 7)):
+        v = rng.integers(1, 60, n).astype(np.float64)
+        w = rng.integers(0, 10, n).astype(np.int64)
+        ck, cv, cw = ctx.upload(keys), ctx.upload(v), ctx.upload(w)
+        mask = (w >= 2)
+        t = ctx.groupby_key(n, abi.make_filter(ipreds=[(cw, 2, 99)]), ck, abi.make_tuple(abi.TUPLE_A, [cv]))
+        cnt = ctx.table_compact_count(t, 1)
+        k, _, vals, hits = ctx.table_compact(t, 1, cnt)
+        uk, inv = np.unique(keys[mask], return_inverse=True)
+        sums = np.zeros(len(uk)); np.add.at(sums, inv, v[mask])
+        counts = np.bincount(inv, minlength=len(uk))
+        order = np.argsort(k)
+        assert k[order].tolist() == uk.tolist(), name
+        assert vals[0][order].tolist() == sums.tolist() and hits[order].tolist() == counts.tolist(), name
+        assert t.size() == len(uk)
+        thr = float(np.median(sums))
+        if name == "sparse":
+            with pytest.raises(abi.SdqhError) as e:
+                ctx.table_select_keys(t, 1, 0, thr, np.inf)
+            assert e.value.code == abi.ERR_UNSUPPORTED
+        else:
+            sel = ctx.table_select_keys(t, 1, 0, abi.gt_float(thr), np.inf)          # HAVING sum > thr
+            want = uk[sums > thr]
+            assert sel.size() == len(want)
+            pk = rng.integers(int(keys.min()) - 5, int(keys.max()) + 5, n).astype(np.int64)
+            vals2, c2 = ctx.scan_probe_sum(n, abi.make_filter(), [(sel, ctx.upload(pk))], abi.make_tuple(abi.TUPLE_A, [cv]))
+            hit = np.isin(pk, want)
+            assert c2 == int(hit.sum()) and vals2[0] == float(v[hit].sum()), name
+            sel.free()
+        t.free()
+        checked += 1
+    return checked

@@ -87,3 +87,12 @@ def test_oracle_key_sets(oracle_lib):
         assert key_set_case(ctx, n=20000) == 5
     finally:
         ctx.close()
+
+
+def test_oracle_groupby_key_and_having(oracle_lib):
+    from helpers import groupby_key_case
+    ctx = oracle_lib.context(threads=3)
+    try:
+        assert groupby_key_case(ctx, n=30000) == 3
+    finally:
+        ctx.close()

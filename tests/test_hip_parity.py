@@ -202,6 +202,13 @@ def test_membership_only_builds(hip_engine):
     assert key_set_case(hip_engine.ctx, n=1000, seed=2) == 5
 
 
+def test_groupby_key_and_having(hip_engine):
+    """sdqh_groupby_key (dense-range layout and the staged fallback) and sdqh_table_select_keys."""
+    from helpers import groupby_key_case
+    assert groupby_key_case(hip_engine.ctx) == 3
+    assert groupby_key_case(hip_engine.ctx, n=900, seed=3) == 3
+
+
 def test_column_comparisons(hip_engine):
     """a op b on two columns (Q4's `l_commitdate < l_receiptdate`): every operator, ints and
     doubles, in the scan, group-by and staging kernels (generic filter instances)."""

@@ -20,7 +20,7 @@ import numpy as np
 
 from . import abi, build
 from .frontend import (And, Bin, Call, Cmp, Col, Const, Contains, FinalizeOp, Lookup, PayloadField, RecordCons,
-                       ScalarExprOp, ScalarField, ScanOp, StrIn, UnsupportedQuery)
+                       ScalarExprOp, ScalarField, ScanOp, SelectKeysOp, StrIn, UnsupportedQuery)
 from .result import DictResult, ResultSet
 
 # value-tuple vocabulary: canonical shape of the whole value record -> (ABI shape, index of the COUNT field or None)
@@ -389,16 +389,18 @@ def _decode_column(values, decoder, dtype):
     return values.view(dtype) if np.dtype(dtype) != values.dtype else values
 
 
-def _prepare_general(eng, op, htab, flt, contains_lookups):
+def _prepare_general(eng, op, htab, flt, contains_lookups, accumulate_into=()):
     """Loops with derived keys / payloads / operands (multi-join chains): sdqh_build and
     sdqh_lookup_aggregate with explicit lookup steps."""
     ctx = eng.ctx
     n = htab.nrows
     lookups = []
-    if op.probe is not None:
-        _walk_lookups(op.probe, lookups)
+    # pure membership conditions first: they are the selective ones (a HAVING set, a filtered build),
+    # and the first lookup is the one the kernels test on the streamed key before queueing a row
     for lk in contains_lookups:
         _walk_lookups(lk, lookups)
+    if op.probe is not None:
+        _walk_lookups(op.probe, lookups)
     _walk_lookups(op.key, lookups)
     if not (isinstance(op.val, Const)):
         _walk_lookups(op.val, lookups)
@@ -431,16 +433,24 @@ def _prepare_general(eng, op, htab, flt, contains_lookups):
     if op.unique:
         val_is_record = isinstance(op.val, RecordCons)
         vfields = op.val.fields if val_is_record else ([] if (isinstance(op.val, Const) and op.val.value is True) else [(None, op.val)])
-        if len(vfields) > abi.MAX_PAYLOAD:
+        # a value field that repeats the (single-column) key needs no payload slot: it is read back from the key
+        is_key = [len(key_fields) == 1 and isinstance(key_fields[0][1], Col) and isinstance(e, Col) and e.name == key_fields[0][1].name for _, e in vfields]
+        stored = [(fname, e) for (fname, e), k in zip(vfields, is_key) if not k]
+        if len(stored) > abi.MAX_PAYLOAD:
             raise UnsupportedQuery("line %d: more than %d payload fields" % (op.lineno, abi.MAX_PAYLOAD))
-        pay_srcs = [_source_of(eng, op, htab, e, lookups) for _, e in vfields]
+        pay_srcs = [_source_of(eng, op, htab, e, lookups) for _, e in stored]
+        slot_of, nxt = [], 0
+        for k in is_key:
+            slot_of.append("key" if k else nxt)
+            nxt += 0 if k else 1
         key_names = [fname or (e.name if isinstance(e, Col) else "key%d" % i) for i, (fname, e) in enumerate(key_fields)]
+        accumulate = op.out in accumulate_into
 
         def run_build(env):
             table = ctx.build(n, flt, resolve_lookups(env), [k.spec(op, env, lookups) for k in key_srcs],
-                              [p.spec(op, env, lookups) for p in pay_srcs], accumulate=False)
+                              [p.spec(op, env, lookups) for p in pay_srcs], accumulate=accumulate)
             infos = [p.decode_info(op, env, lookups) for p in pay_srcs]
-            bt = BuiltTable(table, key_names[0], key_is_record, [(fname, i) for i, (fname, _) in enumerate(vfields)], val_is_record,
+            bt = BuiltTable(table, key_names[0], key_is_record, [(fname, slot_of[i]) for i, (fname, _) in enumerate(vfields)], val_is_record,
                             [info[1] for info in infos])
             bt.decoders = {i: info[0] for i, info in enumerate(infos) if info[0] is not None}
             if len(key_srcs) == 2:
@@ -537,9 +547,8 @@ def _is_simple(op, htab, lookups):
         return all(isinstance(e, Col) for _, e in key_fields)
     if op.probe is not None and not lookups:           # fused probe-aggregate: the group is the matched entry
         pk = op.probe.key.name
-        has_key = any(isinstance(e, Col) and e.name == pk for _, e in key_fields)
-        rest = all((isinstance(e, Col) and e.name == pk) or (isinstance(e, PayloadField) and repr(e.lookup) == repr(op.probe)) for _, e in key_fields)
-        return has_key and rest
+        # the group is the matched entry: every key field is the probe key or a field of the entry
+        return all((isinstance(e, Col) and e.name == pk) or (isinstance(e, PayloadField) and repr(e.lookup) == repr(op.probe)) for _, e in key_fields)
     return False
 
 
@@ -586,7 +595,7 @@ def _prepare_scan(eng, op, htab, accumulate_into, member_only=False):
     flt, lookups = _build_filter(eng, op, htab, op.conds)
     n = htab.nrows
     if not _is_simple(op, htab, lookups):
-        return _prepare_general(eng, op, htab, flt, lookups)
+        return _prepare_general(eng, op, htab, flt, lookups, accumulate_into)
 
     # ---- dictionary outputs ----
     key_is_record = isinstance(op.key, RecordCons)
@@ -636,6 +645,25 @@ def _prepare_scan(eng, op, htab, accumulate_into, member_only=False):
     # ---- aggregations ----
     tup, vnames, count_idx = _build_tuple(eng, op, htab, op.val)
     val_is_record = isinstance(op.val, RecordCons)
+
+    if op.probe is None and not lookups and len(key_fields) == 1 and isinstance(key_fields[0][1], Col) \
+            and htab.array(key_fields[0][1].name, op).dtype == np.int64:
+        # K-C keyed by one int column: a small value range goes to the register / LDS group-by below,
+        # anything else to the large-domain group-by (sdqh_groupby_key): the result is a table
+        gname = key_fields[0][1].name
+        gcol = eng.column(htab.array(gname, op))
+        glo, ghi = gcol.minmax() if n else (0, 0)
+        if ghi - glo + 1 > abi.MAX_SMALL_GROUPS:
+            hidden = op.out + "$groups"
+            key_name = key_fields[0][0] or gname
+
+            def run_groupby_key(env):
+                table = ctx.groupby_key(n, flt, gcol, tup)
+                bt = BuiltTable(table, key_name, key_is_record, [], val_is_record, [])
+                bt.agg = ([(key_name, "key")], vnames, count_idx, key_is_record, val_is_record, tup.shape)
+                env[hidden] = bt
+                return ("aggregated", hidden)
+            return run_groupby_key
 
     if op.probe is None and not lookups:
         # K-C small domain: every key field is a column of the scanned row
@@ -697,9 +725,7 @@ def _prepare_scan(eng, op, htab, accumulate_into, member_only=False):
                 else:
                     raise UnsupportedQuery("line %d: group keys of a probe-aggregate must be the probe key or fields of the matched "
                                            "entry (the group must be determined by the probe key)" % op.lineno)
-            if not any(src == "key" for _, src in out_key_fields):
-                raise UnsupportedQuery("line %d: group key does not include the probe key; grouping on payload alone is not supported yet" % op.lineno)
-            bt.agg_spec = out_key_fields
+            bt.agg_spec = out_key_fields                # the group is the matched entry whether or not its key is among the output fields
         if not bt.table.accumulate or bt.agg is not None:
             raise UnsupportedQuery("line %d: table '%s' cannot take this aggregation" % (op.lineno, probe_name))
         ctx.hash_probe_aggregate(n, flt, bt.table, kcol, tup)
@@ -771,7 +797,7 @@ def _materialize(eng, value, env, hint_key=None, top=None):
             if src == "key":
                 kf.append((fname, keys))
             else:
-                kf.append((fname, payload[src].view(bt.payload_dtypes[src])))
+                kf.append((fname, _decode_column(payload[src], bt.decoders.get(src), bt.payload_dtypes[src])))
         nv = abi.TUPLE_NVALUES[shape]
         vf = _value_arrays(vnames, count_idx, [values[j] for j in range(nv)], hits)
         d = DictResult(kf, vf, key_is_record, val_is_record)
@@ -880,6 +906,32 @@ def _membership_only(plan):
     return {b for b in builds if b not in used_for_payload and b != plan.result}
 
 
+def _select_keys(eng, op, env):
+    """HAVING over an aggregated dictionary -> membership-only BuiltTable of the passing keys."""
+    src = env[op.source]
+    if not (isinstance(src, tuple) and src and src[0] == "aggregated"):
+        raise UnsupportedQuery("line %d: '%s' is not an aggregated dictionary" % (op.lineno, op.source))
+    bt = env[src[1]]
+    _, vnames, count_idx, _, val_is_record, shape = bt.agg
+    if val_is_record or count_idx is not None or abi.TUPLE_NVALUES[shape] != 1:
+        raise UnsupportedQuery("line %d: HAVING needs a dictionary with one summed value" % op.lineno)
+    lo, hi = -np.inf, np.inf
+    for c in op.conds:
+        v = float(c.right.value)
+        if c.op == ">": lo = max(lo, abi.gt_float(v))
+        elif c.op == ">=": lo = max(lo, v)
+        elif c.op == "<": hi = min(hi, abi.lt_float(v))
+        elif c.op == "<=": hi = min(hi, v)
+        else: lo, hi = max(lo, v), min(hi, v)
+    try:
+        table = eng.ctx.table_select_keys(bt.table, 1, 0, lo, hi)
+    except abi.SdqhError as exc:
+        if exc.code == abi.ERR_UNSUPPORTED:
+            raise UnsupportedQuery("line %d: %s" % (op.lineno, exc))
+        raise
+    return BuiltTable(table, bt.key_name, False, [], False, [])
+
+
 class PreparedPlan:
     """A plan bound to one engine and one set of tables: every operator lowered to a closure."""
 
@@ -900,6 +952,8 @@ class PreparedPlan:
         for op in plan.ops:
             if isinstance(op, ScanOp):
                 self.steps.append((op.out, _prepare_scan(eng, op, tables[op.table], accumulate_into, op.out in member_only)))
+            elif isinstance(op, SelectKeysOp):
+                self.steps.append((op.out, (lambda env, op=op: _select_keys(eng, op, env))))
             elif isinstance(op, ScalarExprOp):
                 self.steps.append((op.out, (lambda env, op=op: _eval_scalar_expr(op.expr, env, op.lineno))))
             elif isinstance(op, FinalizeOp):

@@ -192,6 +192,16 @@ class ScalarExprOp:
         return "ScalarExprOp(%s = %r)" % (self.out, self.expr)
 
 
+class SelectKeysOp:
+    """HAVING: `{unique(p[0]): True} if p[1] <op> <const> else None` over an aggregated dictionary
+    (Q18 `li_filtered`, test/test_all.py:879-885) — the keys whose value passes, as a set."""
+    def __init__(self, out, source, conds, lineno):
+        self.out, self.source, self.conds, self.lineno = out, source, conds, lineno
+
+    def __repr__(self):
+        return "SelectKeysOp(%s <- keys of %s where %r)" % (self.out, self.source, self.conds)
+
+
 class FinalizeOp:
     """Sum over a result dictionary that only reshapes (key, value) into one record set (K-F)."""
     def __init__(self, out, source, fields, lineno):
@@ -456,9 +466,17 @@ class _Lowerer:
             (p,), body = self.lambda_of(call.args[0], 1)
             env = {p: ("kv",)}
             tmp = ScanOp(out, table, ln)
+            body, kv_conds = self.split_ifelse(body, env)
             if not isinstance(body, ast.Dict):
                 self.fail(call, "a sum over a result dictionary must build {unique(record): True}")
             self.dict_body(tmp, body, env)
+            if kv_conds:
+                ok = tmp.unique and isinstance(tmp.val, Const) and tmp.val.value is True and isinstance(tmp.key, WholeKey) and tmp.key.which == 0 \
+                    and all(isinstance(c, Cmp) and isinstance(c.left, WholeKey) and c.left.which == 1 and isinstance(c.right, Const)
+                            and isinstance(c.right.value, (int, float)) and c.op in ("<", "<=", ">", ">=", "==") for c in kv_conds)
+                if not ok:
+                    self.fail(call, "a conditional sum over a result dictionary must be {unique(p[0]): True} if p[1] <op> <number> else None")
+                return SelectKeysOp(out, table, kv_conds, ln)
             if not (tmp.unique and isinstance(tmp.val, Const) and tmp.val.value is True):
                 self.fail(call, "only the finalising reshape {unique(<record>): True} is supported over a result dictionary")
             if isinstance(tmp.key, ConcatKV):

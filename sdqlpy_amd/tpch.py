@@ -84,6 +84,7 @@ def _pick(values, width, h):
 
 DERIVED = {   # table -> {column: (dtype, base columns, function(base arrays...) -> array)}
     "orders": {"o_orderpriority": ("U15", ["o_orderkey"], lambda k: _pick(_PRIORITIES, 15, _mix(k, 1)))},
+    "customer": {"c_name": ("U25", ["c_custkey"], lambda k: np.char.add("Customer#", np.char.zfill(k.astype("<U9"), 9)).astype("<U25"))},
     "part": {"p_type": ("U25", ["p_partkey"], lambda k: np.char.add(np.char.add(np.char.add(_pick(_TYPE_1, 25, _mix(k, 2)), " "),
                                                                                   np.char.add(_pick(_TYPE_2, 25, _mix(k, 3)), " ")),
                                                                       _pick(_TYPE_3, 25, _mix(k, 4))).astype("<U25"))},
@@ -107,6 +108,8 @@ QUERY_COLUMNS = {
     "q4": {"lineitem": ["l_orderkey", "l_commitdate", "l_receiptdate"],
            "orders": ["o_orderkey", "o_orderdate", "o_orderpriority"]},
     "q14": {"lineitem": ["l_partkey", "l_shipdate", "l_extendedprice", "l_discount"], "part": ["p_partkey", "p_type"]},
+    "q18": {"lineitem": ["l_orderkey", "l_quantity"], "customer": ["c_custkey", "c_name"],
+            "orders": ["o_orderkey", "o_custkey", "o_orderdate", "o_totalprice"]},
     "q9": {"lineitem": ["l_orderkey", "l_partkey", "l_suppkey", "l_quantity", "l_extendedprice", "l_discount"],
            "orders": ["o_orderkey", "o_orderdate"], "nation": ["n_nationkey", "n_name"],
            "supplier": ["s_suppkey", "s_nationkey"], "part": ["p_partkey", "p_name"],

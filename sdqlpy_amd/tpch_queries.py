@@ -4,7 +4,7 @@ These are the workload, the way SQL text is for a SQL engine: q6, q1, q3 (then q
 with the same combinators, filters and arithmetic as the reference's TPCH script, so that the
 golden results captured from the reference (tests/golden) apply to them verbatim
 (reference test/test_all.py: q1 46-62, q3 145-176, q5 215-281, q6 285-295, q9 431-491; beyond the
-configured five, SURVEY.md §8f.3: q4 180-211, q14 695-716).
+configured five, SURVEY.md §8f.3: q4 180-211, q14 695-716, q18 874-913).
 Call ``sdqlpy_init(3)`` (or 1) before running them.
 """
 from .sdql_lib import *      # noqa: F401,F403
@@ -141,6 +141,31 @@ def q14(li, pa):
     return results
 
 
+@sdql_compile({"li": lineitem_type, "cu": customer_type, "ord": order_type})
+def q18(li, cu, ord):
+    li_aggregated = li.sum(lambda b: {b[0].l_orderkey: b[0].l_quantity})
+    li_filtered = li_aggregated.sum(lambda z: {unique(z[0]): True} if z[1] > 300 else None)
+    cu_indexed = cu.joinBuild("c_custkey", lambda p: True, ["c_name"])
+    order_probed = ord.joinProbe(
+        cu_indexed, "o_custkey",
+        lambda p: li_filtered[p[0].o_orderkey] != None,      # noqa: E711
+        lambda indexedDictValue, probeDictKey: {
+            probeDictKey.o_orderkey:
+            record({"c_name": indexedDictValue.c_name, "o_custkey": probeDictKey.o_custkey,
+                    "o_orderkey": probeDictKey.o_orderkey, "o_orderdate": probeDictKey.o_orderdate,
+                    "o_totalprice": probeDictKey.o_totalprice})},
+        False)
+    li_probed = li.joinProbe(
+        order_probed, "l_orderkey", lambda p: True,
+        lambda indexedDictValue, probeDictKey: {
+            record({"c_name": indexedDictValue.c_name, "o_custkey": indexedDictValue.o_custkey,
+                    "o_orderkey": indexedDictValue.o_orderkey, "o_orderdate": indexedDictValue.o_orderdate,
+                    "o_totalprice": indexedDictValue.o_totalprice}):
+            record({"quantitysum": probeDictKey.l_quantity})})
+    results = li_probed.sum(lambda p: {unique(p[0].concat(p[1])): True})
+    return results
+
+
 # positional table order of each query (the decorator dict order == call order)
 QUERY_TABLES = {
     "q6": ["lineitem"],
@@ -150,8 +175,9 @@ QUERY_TABLES = {
     "q9": ["lineitem", "orders", "nation", "supplier", "part", "partsupp"],
     "q4": ["orders", "lineitem"],
     "q14": ["lineitem", "part"],
+    "q18": ["lineitem", "customer", "orders"],
 }
-QUERIES = {"q6": q6, "q1": q1, "q3": q3, "q5": q5, "q9": q9, "q4": q4, "q14": q14}
+QUERIES = {"q6": q6, "q1": q1, "q3": q3, "q5": q5, "q9": q9, "q4": q4, "q14": q14, "q18": q18}
 
 
 def run(name, db, top=None):
@@ -167,4 +193,5 @@ TPCH_ORDER = {
     "q5": (100, [("revenue", "desc")]),
     "q9": (128, [("nation", "asc"), ("o_year", "desc")]),
     "q4": (100, [("o_orderpriority", "asc")]),
+    "q18": (100, [("o_totalprice", "desc"), ("o_orderdate", "asc")]),
 }

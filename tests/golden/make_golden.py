@@ -36,7 +36,7 @@ REF_ROOT = "/root/reference"
 from sdqlpy_amd import tpch  # noqa: E402
 
 QUERIES = ["q1", "q3", "q5", "q6", "q9"]
-MORE_QUERIES = ["q4", "q14"]       # beyond the configured five (test/test_all.py:180-211, 695-716)
+MORE_QUERIES = ["q4", "q14", "q18"]       # beyond the configured five (test/test_all.py:180-211, 695-716, 874-913)
 QUERY_TABLES = {   # positional argument order of each reference query (test/test_all.py decorators)
     "q1": ["lineitem"],
     "q3": ["lineitem", "customer", "orders"],
@@ -45,6 +45,7 @@ QUERY_TABLES = {   # positional argument order of each reference query (test/tes
     "q9": ["lineitem", "orders", "nation", "supplier", "part", "partsupp"],
     "q4": ["orders", "lineitem"],
     "q14": ["lineitem", "part"],
+    "q18": ["lineitem", "customer", "orders"],
 }
 ALL_TABLES = ["lineitem", "customer", "orders", "region", "nation", "supplier", "part", "partsupp"]
 
@@ -108,6 +109,12 @@ def v_wide_doubles(db):
     return _replace(db, "lineitem", l_extendedprice=ep * scale)
 
 
+def v_big_orders(db):
+    """quantities x6: many orders pass Q18's HAVING sum(l_quantity) > 300 (on plain data almost none do)."""
+    q = tpch.column(db["lineitem"], "l_quantity")
+    return _replace(db, "lineitem", l_quantity=q * 6.0)
+
+
 def v_signed_denormal(db):
     """negative prices (returns / credits), exact zeros, denormals and values next to DBL_MAX/1e300
     scale in the summed columns: sign handling of the order-preserving maps and non-finite-free
@@ -127,6 +134,7 @@ VARIANTS = {
     "big_keys": v_big_keys,
     "wide_doubles": v_wide_doubles,
     "signed_denormal": v_signed_denormal,
+    "big_orders": v_big_orders,
 }
 
 # (name, sf, variant, queries)
@@ -202,6 +210,8 @@ def encode_result(ref, res):
 MORE_CASES = [
     ("tiny", 0.0003, "base", MORE_QUERIES),
     ("tiny_nothing_passes", 0.0003, "nothing_passes", ["q14"]),
+    ("tiny_big_orders", 0.0003, "big_orders", ["q18"]),
+    ("small_big_orders", 0.01, "big_orders", ["q18"]),
     ("tiny_signed_denormal", 0.0003, "signed_denormal", ["q1", "q3", "q6", "q14"]),
     ("small_signed_denormal", 0.01, "signed_denormal", ["q1", "q6"]),
     ("small", 0.01, "base", MORE_QUERIES),

@@ -231,6 +231,8 @@ class DistributedRunner:
             return self._row_sharded_groupby(plan, args)
         if name == "q3":
             return self._partitioned_join(plan, args)
+        if name == "q18":
+            raise frontend.UnsupportedQuery("q18's group-by on l_orderkey needs the partitioned plan for a row-keyed group-by: not distributed yet")
         whole = {p for p, t in zip(plan.params, Q.QUERY_TABLES[name]) if t in whole_tables}
         return self._sharded_chain(plan, args, whole)
 
@@ -249,13 +251,15 @@ class DistributedRunner:
             found = []
             if o.probe is not None:
                 engine._walk_lookups(o.probe, found)
-            for c in o.conds:
+            for c in list(o.conds) + [c for _, _, fc in (o.fields or []) for c in fc]:
                 if isinstance(c, frontend.Contains):
                     engine._walk_lookups(c.lookup, found)
             if o.kind == "dict":
                 engine._walk_lookups(o.key, found)
-            if not isinstance(o.val, frontend.Const):
+            if o.val is not None and not isinstance(o.val, frontend.Const):
                 engine._walk_lookups(o.val, found)
+            for _, e, _ in (o.fields or []):
+                engine._walk_lookups(e, found)
             for lk in found:
                 if lk.dict_name in consumers:
                     consumers[lk.dict_name].append((o, lk))
@@ -325,11 +329,19 @@ class DistributedRunner:
                         res = self._merge_groups(res)
                     elif isinstance(res, float) and st.sharded[op.out]:
                         res = sum(float(p[0]) for p in self._all_gather_array(np.array([res], np.float64)))
+                    elif isinstance(res, dict) and st.sharded[op.out]:       # scalar record: one partial sum per field, folded in rank order
+                        names = sorted(res)
+                        parts = self._all_gather_array(np.array([res[k] for k in names], np.float64))
+                        res = {k: sum(float(p[j]) for p in parts) for j, k in enumerate(names)}
                     elif isinstance(res, tuple):
                         raise frontend.UnsupportedQuery("a fused probe-aggregate needs the partitioned-join plan")
                     env[op.out] = res
-                else:
+                elif isinstance(op, FinalizeOp):
                     env[op.out] = engine._finalize(self.eng, op, env)
+                elif isinstance(op, frontend.ScalarExprOp):
+                    env[op.out] = engine._eval_scalar_expr(op.expr, env, op.lineno)
+                else:
+                    raise frontend.UnsupportedQuery("%s is not part of the distributed chain plan yet" % type(op).__name__)
             return env[plan.result]
         finally:
             for v in env.values():

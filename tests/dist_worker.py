@@ -28,7 +28,7 @@ def main(rank, world, port, sf, mode, out_path):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     lib = abi.Library(os.path.join(ROOT, "oracle", "libsdqloracle.so"))
     eng = engine.Engine(lib.context(threads=2))
-    qs = ["q1", "q3", "q5", "q6", "q9"]
+    qs = ["q1", "q3", "q5", "q6", "q9", "q4", "q14"]
     cols = tpch.columns_for(qs)
     if mode == "shuffled":
         # rows of every table dealt to the ranks at random: key ranges overlap -> hash partitioning
@@ -53,9 +53,10 @@ def main(rank, world, port, sf, mode, out_path):
     out["q6"] = runner.run("q6", db)
     r1 = runner.run("q1", db)
     out["q1"] = {"columns": r1.columns, "rows": r1.rows()}
-    for q in ("q5", "q9"):
+    for q in ("q5", "q9", "q4"):
         r = runner.run(q, db)
         out[q] = {"columns": r.columns, "rows": r.rows()}
+    out["q14"] = runner.run("q14", db)
     r3 = runner.run("q3", db)
     out["q3"] = {"columns": r3.columns, "rows": runner.gather_rows(r3), "local_rows": r3.size(),
                  "partitioning": runner.last_partitioning, "exchanged": runner.exchanged_rows}

@@ -37,7 +37,7 @@ def run_world(mode, tmp_path, world=2):
 @pytest.fixture(scope="module")
 def single(oracle_lib):
     eng = engine.Engine(oracle_lib.context(threads=2))
-    qs = ["q1", "q3", "q5", "q6", "q9"]
+    qs = ["q1", "q3", "q5", "q6", "q9", "q4", "q14"]
     db = tpch.generate(SF, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs), threads=2)
     res = {q: helpers.run_query(eng, q, db) for q in qs}
     eng.close()
@@ -54,8 +54,9 @@ def test_two_ranks_match_single_process(mode, tmp_path, single, oracle_lib):
     assert abs(got["q6"] - single["q6"]) <= 1e-12 * abs(single["q6"])
     w1 = single["q1"]
     helpers.assert_rows_match(sorted(as_rows(got["q1"]["rows"])), helpers.result_rows(w1, got["q1"]["columns"]), 1e-12, mode + "/q1")
-    for q in ("q5", "q9"):
+    for q in ("q5", "q9", "q4"):
         helpers.assert_rows_match(sorted(as_rows(got[q]["rows"])), helpers.result_rows(single[q], got[q]["columns"]), 1e-12, mode + "/" + q)
+    assert abs(got["q14"] - single["q14"]) <= 1e-12 * abs(single["q14"])
     w3 = single["q3"]
     helpers.assert_rows_match(sorted(as_rows(got["q3"]["rows"])), helpers.result_rows(w3, got["q3"]["columns"]), 1e-12, mode + "/q3")
     # ORDER BY ... LIMIT k: the same first rows, in the same order, as ordering the single-process result

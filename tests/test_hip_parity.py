@@ -331,7 +331,7 @@ def test_redistribution_helpers_match_oracle(hip_engine, oracle_engine):
     assert out["hip"][5] == sorted(set(key.tolist()))
 
 
-def test_distributed_runner_world1_nccl(hip_lib, golden):
+def test_distributed_runner_world1_nccl(hip_lib, golden, golden_more):
     """The distributed plan end to end on one GPU (RCCL group of size 1): exercises the torch-tensor
     exchange buffers, the count exchange and all_to_all_single on device memory."""
     import torch
@@ -347,6 +347,13 @@ def test_distributed_runner_world1_nccl(hip_lib, golden):
             runner = sdist.DistributedRunner(eng, 0, 1, partition=part)
             for q in SUPPORTED:
                 helpers.check_against_golden(runner.run(q, db), case["results"][q], REL, "dist1/%s/%s" % (part, q))
+        more = next(c for c in golden_more["cases"] if c["name"] == "small")
+        db = helpers.case_db(more)
+        runner = sdist.DistributedRunner(eng, 0, 1)
+        for q in ("q4", "q14"):                              # the chain executor beyond q5 / q9
+            helpers.check_against_golden(runner.run(q, db), more["results"][q], REL, "dist1/%s" % q)
+        top = runner.run("q3", helpers.case_db(case), top=(10, [("revenue", "desc"), ("o_orderdate", "asc")]))
+        assert top.size() == 10 and top.column("revenue").tolist() == sorted(top.column("revenue").tolist(), reverse=True)
     finally:
         eng.close()
         dist.destroy_process_group()

@@ -884,7 +884,7 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
         }
     }
     // dense layout: an unfiltered, unprobed build on a dense key range indexes the source columns in place
-    const bool unfiltered = f.ni == 0 && f.nf == 0 && f.ns == 0 && nprobes == 0;
+    const bool unfiltered = f.ni == 0 && f.nf == 0 && f.ns == 0 && f.nc == 0 && nprobes == 0;
     if (unfiltered && !accumulate && nrows > 0 && ctx->opt_direct_index && hi >= lo && lo > INT64_MIN / 2 && hi < INT64_MAX / 2 &&
         (uint64_t)(hi - lo) + 1 <= 16ull * (uint64_t)nrows && (uint64_t)(hi - lo) + 1 <= (1ull << 30))
         return build_dense(ctx, nrows, key, npayload, payload, lo, hi, out);

@@ -280,6 +280,14 @@ def column_compare_case(ctx, n=70001, seed=12):
         rows = ctx.table_compact(t, 0, cnt, want_values=False, want_hits=False)[0]
         t.free()
         assert rows.tolist() == np.nonzero(m)[0].tolist(), op
+        # a comparison as the ONLY predicate of a build on a dense, unique key column: must not be
+        # mistaken for an unfiltered build (which indexes the source columns in place)
+        m1 = fn(ia, ib)
+        t = ctx.hash_build_unique(n, abi.make_filter(cpreds=[(cia, cib, op)]), [], ck, [])
+        assert t.size() == int(m1.sum()), op
+        cnt = ctx.table_compact_count(t, 0)
+        assert ctx.table_compact(t, 0, cnt, want_values=False, want_hits=False)[0].tolist() == np.nonzero(m1)[0].tolist(), op
+        t.free()
         checked += 2
     return checked
 

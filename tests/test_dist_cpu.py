@@ -78,6 +78,17 @@ def test_two_ranks_match_single_process(mode, tmp_path, single, oracle_lib):
     assert 0 < got["q3"]["local_rows"] < len(got["q3"]["rows"])
 
 
+def test_four_ranks_match_single_process(tmp_path, single, oracle_lib):
+    """world_size 4 (an odd row split per rank, three peers per exchange) on the shuffled layout:
+    hash partitioning with real traffic between every pair of ranks."""
+    got = run_world("shuffled", tmp_path, world=4)
+    assert abs(got["q6"] - single["q6"]) <= 1e-12 * abs(single["q6"])
+    for q in ("q1", "q5", "q9", "q4", "q3"):
+        helpers.assert_rows_match(sorted(as_rows(got[q]["rows"])), helpers.result_rows(single[q], got[q]["columns"]), 1e-12, "world4/" + q)
+    assert abs(got["q14"] - single["q14"]) <= 1e-12 * abs(single["q14"])
+    assert got["q3"]["partitioning"] == "hash" and got["q3"]["exchanged"]["probe_sent"] > 0
+
+
 def test_bench_contract_under_a_two_rank_launch(tmp_path):
     """bench.py as the driver launches it for N > 1 (RANK / WORLD_SIZE / MASTER_* in the
     environment), on CPU: gloo + the CPU implementation of the ABI injected through bench.main's

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define SDQH_ABI_VERSION 1
+#define SDQH_ABI_VERSION 2   /* 2: sdqh_filter carries column-vs-column predicates; string modes 3 / 4 */
 
 /* ---- status codes ---------------------------------------------------------------------- */
 #define SDQH_OK              0

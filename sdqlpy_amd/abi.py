@@ -10,6 +10,7 @@ import math
 
 import numpy as np
 
+ABI_VERSION = 2            # include/sdqh.h: SDQH_ABI_VERSION (struct layouts below must match the library's)
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_OVERFLOW, ERR_NOMEM = range(6)
 I64, F64, STR = 0, 1, 2
 TUPLE_A, TUPLE_AB, TUPLE_A_1MB, TUPLE_PRICING, TUPLE_A_1MB_M_CD, TUPLE_COUNT = 1, 2, 3, 4, 5, 6
@@ -603,6 +604,9 @@ class Library:
         missing = [s for s in EXPORTS if not hasattr(self.cdll, s)]
         if missing:
             raise OSError("%s does not export: %s" % (path, ", ".join(missing)))
+        if self.cdll.sdqh_abi_version() != ABI_VERSION:
+            raise OSError("%s implements ABI version %d, this binding is for version %d: rebuild the library"
+                          % (path, self.cdll.sdqh_abi_version(), ABI_VERSION))
         L = self.cdll
         L.sdqh_backend_name.restype = C.c_char_p
         L.sdqh_last_error.restype = C.c_char_p

@@ -661,8 +661,6 @@ class Library:
         L.sdqh_build.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.sdqh_lookup_aggregate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        if L.sdqh_abi_version() != 1:
-            raise OSError("%s: ABI version %d, expected 1" % (path, L.sdqh_abi_version()))
 
     def backend_name(self):
         return self.cdll.sdqh_backend_name().decode()

@@ -193,6 +193,65 @@ int sdql_tbl_parse(void* handle, int ncols, const int* types, const int* widths,
     return status.load();
 }
 
+// Dictionary encoding of a fixed-width UCS4 column (numpy '<U width'): codes[i] = index of row i's
+// text in the sorted list of distinct texts, for columns with at most max_distinct of them (text
+// group keys and low-cardinality string predicates are then integer work on the device).
+// Returns the number of distinct values, or -1 when there are more than max_distinct.
+// dict_out: max_distinct * width code units, filled in sorted (code) order.
+int64_t sdql_dict_encode(const uint32_t* data, int64_t nrows, int width, int max_distinct, int nthreads,
+                         int64_t* codes, uint32_t* dict_out) {
+    if (!data || nrows < 0 || width < 1 || max_distinct < 1 || !codes || !dict_out) return -2;
+    const size_t cap = 1u << 14;                                         // open addressing, >= 4 x max_distinct
+    if ((size_t)max_distinct * 4 > cap) return -2;
+    auto hash_of = [width](const uint32_t* s) { uint64_t h = 1469598103934665603ull; for (int k = 0; k < width; ++k) { h ^= s[k]; h *= 1099511628211ull; } return h; };
+    // pass 1 (serial over a sample-free scan, early exit): collect the distinct values
+    std::vector<int32_t> slot_row(cap, -1);                              // slot -> first row with that text
+    std::vector<int64_t> first_rows;
+    for (int64_t r = 0; r < nrows; ++r) {
+        const uint32_t* s = data + (size_t)r * width;
+        size_t h = hash_of(s) & (cap - 1);
+        for (;;) {
+            const int32_t e = slot_row[h];
+            if (e < 0) {
+                if ((int)first_rows.size() == max_distinct) return -1;
+                slot_row[h] = (int32_t)first_rows.size(); first_rows.push_back(r);
+                break;
+            }
+            if (std::memcmp(data + (size_t)first_rows[(size_t)e] * width, s, (size_t)width * 4) == 0) break;
+            h = (h + 1) & (cap - 1);
+        }
+    }
+    const int nd = (int)first_rows.size();
+    // sorted order = numpy's: lexicographic on code units (UCS4 values), zero padded
+    std::vector<int> order((size_t)nd), rank((size_t)nd);
+    for (int i = 0; i < nd; ++i) order[(size_t)i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) {
+        const uint32_t* x = data + (size_t)first_rows[(size_t)a] * width; const uint32_t* y = data + (size_t)first_rows[(size_t)b] * width;
+        for (int k = 0; k < width; ++k) if (x[k] != y[k]) return x[k] < y[k];
+        return false;
+    });
+    for (int i = 0; i < nd; ++i) { rank[(size_t)order[(size_t)i]] = i; std::memcpy(dict_out + (size_t)i * width, data + (size_t)first_rows[(size_t)order[(size_t)i]] * width, (size_t)width * 4); }
+    // pass 2 (parallel): codes
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(1, nthreads), nrows / 65536 + 1));
+    auto work = [&](int k) {
+        const int64_t r0 = nrows * k / nt, r1 = nrows * (k + 1) / nt;
+        for (int64_t r = r0; r < r1; ++r) {
+            const uint32_t* s = data + (size_t)r * width;
+            size_t h = hash_of(s) & (cap - 1);
+            for (;;) {
+                const int32_t e = slot_row[h];
+                if (std::memcmp(data + (size_t)first_rows[(size_t)e] * width, s, (size_t)width * 4) == 0) { codes[r] = rank[(size_t)e]; break; }
+                h = (h + 1) & (cap - 1);
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < nt; ++k) th.emplace_back(work, k);
+    work(0);
+    for (auto& x : th) x.join();
+    return nd;
+}
+
 const char* sdql_tbl_error(void* handle) { return handle ? static_cast<Table*>(handle)->error.c_str() : "no handle"; }
 
 void sdql_tbl_close(void* handle) {

@@ -120,14 +120,16 @@ class Engine:
         return self.column(arr)
 
     def dict_column(self, arr, max_distinct=4096):
-        """(resident int64 code column, distinct values) for a low-cardinality string column, or None:
-        how a string column of the scanned table serves as a group key (Q4's o_orderpriority).  The
-        dictionary is built once per host array (np.unique) and cached like an upload."""
+        """(resident int64 code column, distinct values in sorted order) for a low-cardinality string
+        column, or None: how a string column of the scanned table serves as a group key (Q4's
+        o_orderpriority) and how `==` / startsWith on it become an integer range on the codes.  The
+        dictionary is built once per host array (loader.dict_encode) and cached like an upload."""
         hit = self._dicts.get(id(arr))
         if hit is None or hit[0] is not arr:
-            values, codes = np.unique(arr, return_inverse=True)
-            hit = self._dicts[id(arr)] = (arr, np.ascontiguousarray(codes.astype(np.int64)), values)
-        if len(hit[2]) > max_distinct:
+            from . import loader
+            enc = loader.dict_encode(arr, max_distinct)          # native hash pass; None = too many distinct values
+            hit = self._dicts[id(arr)] = (arr,) + (enc if enc is not None else (None, None))
+        if hit[1] is None:
             return None
         return self.column(hit[1]), hit[2]
 
@@ -184,6 +186,28 @@ def _flip(op):
     return {"<": ">", "<=": ">=", ">": "<", ">=": "<=", "==": "==", "!=": "!="}[op]
 
 
+def _code_range(eng, arr, name, passes, iranges):
+    """A predicate on a low-cardinality text column as an integer range on its dictionary codes:
+    evaluate `passes` on the (sorted) distinct values; if the passing codes are one contiguous range
+    (equality: one code; a prefix: a run of the sorted dictionary; nothing passes: an empty range)
+    record it in iranges under a name of its own and return True.  The kernels then read 8-byte codes
+    instead of 4 bytes per code unit, and need no string instance."""
+    coded = eng.dict_column(arr)
+    if coded is None:
+        return False
+    hit = np.nonzero(passes(coded[1]))[0]
+    if len(hit) == 0:
+        lo, hi = 1, 0
+    elif hit[-1] - hit[0] + 1 == len(hit):
+        lo, hi = int(hit[0]), int(hit[-1])
+    else:
+        return False
+    key = "\0codes:" + name
+    plo, phi = iranges.get(key, (abi.INT64_MIN, abi.INT64_MAX))[:2]
+    iranges[key] = (max(plo, lo), min(phi, hi), coded[0])
+    return True
+
+
 def _build_filter(eng, op, htab, conds):
     """conds -> (abi.Filter, [semi-join lookups])."""
     iranges, franges, spreds, cpreds, lookups = {}, {}, [], [], []
@@ -195,6 +219,8 @@ def _build_filter(eng, op, htab, conds):
             arr = htab.array(c.col.name, op)
             if arr.dtype.kind != "U":
                 raise UnsupportedQuery("line %d: `in` needs a string column" % op.lineno)
+            if c.how == "prefix" and _code_range(eng, arr, c.col.name, lambda values: np.char.startswith(values, c.needle), iranges):
+                continue
             spreds.append((eng.column(arr), c.needle, {"in": abi.STR_CONTAINS, "prefix": abi.STR_PREFIX, "suffix": abi.STR_SUFFIX}[c.how]))
             continue
         if not isinstance(c, Cmp):
@@ -217,6 +243,8 @@ def _build_filter(eng, op, htab, conds):
         if arr.dtype.kind == "U":
             if sym not in ("==", "!=") or not isinstance(v, str):
                 raise UnsupportedQuery("line %d: string columns support == / != against a literal" % op.lineno)
+            if sym == "==" and _code_range(eng, arr, left.name, lambda values: values == v, iranges):
+                continue
             spreds.append((eng.column(arr), v, sym == "!="))
         elif arr.dtype == np.int64:
             lo, hi = iranges.get(left.name, (abi.INT64_MIN, abi.INT64_MAX))
@@ -251,7 +279,7 @@ def _build_filter(eng, op, htab, conds):
             franges[left.name] = (lo, hi)
         else:
             raise UnsupportedQuery("line %d: column '%s' has unsupported dtype %s" % (op.lineno, left.name, arr.dtype))
-    ip = [(eng.column(htab.array(n, op)), lo, hi) for n, (lo, hi) in iranges.items()]
+    ip = [(r[2], r[0], r[1]) if len(r) == 3 else (eng.column(htab.array(n, op)), r[0], r[1]) for n, r in iranges.items()]
     fp = [(eng.column(htab.array(n, op)), lo, hi) for n, (lo, hi) in franges.items()]
     try:
         return abi.make_filter(ip, fp, spreds, cpreds), lookups

@@ -37,6 +37,8 @@ def _native():
         lib.sdql_tbl_error.restype = C.c_char_p
         lib.sdql_tbl_close.argtypes = [C.c_void_p]
         lib.sdql_tbl_close.restype = None
+        lib.sdql_dict_encode.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.sdql_dict_encode.restype = C.c_int64
         _lib = lib
     return _lib
 
@@ -116,6 +118,28 @@ def read_text(path, types, delimiter="|"):
         return read_text_native(path, types, delimiter)
     except Declined:
         return _read_text_general(path, types, delimiter)
+
+
+def dict_encode(arr, max_distinct=4096, threads=None):
+    """(codes int64, distinct values in sorted order) of a '<U n' column with at most max_distinct
+    distinct values, else None.  Same result as np.unique(arr, return_inverse=True), in one hash pass
+    plus a parallel encode instead of a sort of every row."""
+    arr = np.ascontiguousarray(arr)
+    if arr.dtype.kind != "U" or arr.ndim != 1:
+        raise TypeError("dict_encode needs a 1-d '<U n' array")
+    width = arr.dtype.itemsize // 4
+    n = len(arr)
+    if width < 1 or n == 0:
+        vals, codes = np.unique(arr, return_inverse=True)
+        return codes.astype(np.int64), vals
+    codes = np.empty(n, np.int64)
+    dic = np.zeros(max_distinct * width, np.uint32)
+    nd = _native().sdql_dict_encode(arr.ctypes.data, n, width, max_distinct, threads or min(32, os.cpu_count() or 1), codes.ctypes.data, dic.ctypes.data)
+    if nd == -1:
+        return None
+    if nd < 0:
+        raise ValueError("dict_encode: bad arguments")
+    return codes, dic[: nd * width].view(arr.dtype).copy()
 
 
 # ---- binary columnar format ------------------------------------------------------------------------

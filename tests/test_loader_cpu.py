@@ -108,3 +108,19 @@ def test_binary_column_format_round_trip(tmp_path):
     assert sub["headers"] == ["l_shipdate", "l_quantity"] and len(sub["data"][0]) == len(a["data"][0])
     with pytest.raises(KeyError):
         L.read_columns(d, {L.record({"nope": int}): bool})
+
+
+def test_dictionary_encoding_equals_numpy_unique():
+    """loader.dict_encode (what text group keys and low-cardinality text predicates run on): the same
+    codes and sorted dictionary as np.unique, None beyond the distinct-value limit."""
+    rng = np.random.default_rng(3)
+    vals = np.array(["MAIL", "SHIP", "AIR", "REG AIR", "日本", "", "é", "TRUCK", "FOB", "RAIL", "A", "AB", "a"], "<U7")
+    a = vals[rng.integers(0, len(vals), 200000)]
+    codes, dic = loader.dict_encode(a, threads=3)
+    u, inv = np.unique(a, return_inverse=True)
+    assert dic.dtype == a.dtype and (dic == u).all() and (codes == inv).all()
+    assert loader.dict_encode(np.array(["x%d" % i for i in range(300)], "<U5"), max_distinct=256) is None
+    one = loader.dict_encode(np.array(["same"] * 10, "<U4"))
+    assert one[0].tolist() == [0] * 10 and one[1].tolist() == ["same"]
+    empty = loader.dict_encode(np.array([], "<U3"))
+    assert len(empty[0]) == 0 and len(empty[1]) == 0

@@ -374,3 +374,33 @@ def groupby_key_case(ctx, n=250000, seed=14):
         t.free()
         checked += 1
     return checked
+
+
+def empty_input_case(ctx):
+    """Zero-row inputs through every table-producing entry point and what consumes them."""
+    import numpy as np
+    from sdqlpy_amd import abi
+    e_i, e_f = ctx.upload(np.zeros(0, np.int64)), ctx.upload(np.zeros(0, np.float64))
+    keys = ctx.upload(np.arange(100, dtype=np.int64)); vals = ctx.upload(np.ones(100))
+    flt = abi.make_filter()
+    s = ctx.build_key_set(0, flt, [], e_i)
+    assert s.size() == 0
+    v, c = ctx.scan_probe_sum(100, flt, [(s, keys)], abi.make_tuple(abi.TUPLE_A, [vals]))
+    assert c == 0 and v[0] == 0.0
+    v, c = ctx.scan_probe_sum(0, flt, [(s, e_i)], abi.make_tuple(abi.TUPLE_A, [e_f]))
+    assert c == 0
+    g = ctx.groupby_key(0, flt, e_i, abi.make_tuple(abi.TUPLE_A, [e_f]))
+    assert g.size() == 0 and ctx.table_compact_count(g, 1) == 0
+    k, p, vv, h = ctx.table_topk(g, 0, 5, [(abi.SORT_VALUE, 0, True, True)])
+    assert len(k) == 0
+    t = ctx.hash_build_unique(0, flt, [], e_i, [], accumulate=True)
+    assert t.size() == 0 and len(ctx.table_topk(t, 0, 3, [(abi.SORT_KEY, 0, False, False)])[0]) == 0
+    ctx.hash_probe_aggregate(100, flt, t, keys, abi.make_tuple(abi.TUPLE_A, [vals]))
+    assert ctx.table_compact_count(t, 1) == 0
+    g2 = ctx.groupby_key(100, abi.make_filter(ipreds=[(keys, 1000, 2000)]), keys, abi.make_tuple(abi.TUPLE_A, [vals]))   # nothing passes
+    assert g2.size() == 0
+    sel = ctx.table_select_keys(g2, 1, 0, -np.inf, np.inf)
+    assert sel.size() == 0
+    for x in (s, g, t, g2, sel):
+        x.free()
+    return True

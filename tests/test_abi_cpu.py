@@ -96,3 +96,12 @@ def test_oracle_groupby_key_and_having(oracle_lib):
         assert groupby_key_case(ctx, n=30000) == 3
     finally:
         ctx.close()
+
+
+def test_oracle_empty_inputs(oracle_lib):
+    from helpers import empty_input_case
+    ctx = oracle_lib.context(threads=2)
+    try:
+        assert empty_input_case(ctx)
+    finally:
+        ctx.close()

@@ -209,6 +209,13 @@ def test_groupby_key_and_having(hip_engine):
     assert groupby_key_case(hip_engine.ctx, n=900, seed=3) == 3
 
 
+def test_empty_inputs(hip_engine):
+    """Zero-row tables and filters that pass nothing through the newer entry points (key sets,
+    row-keyed group-by, HAVING, top-k, probe sums)."""
+    from helpers import empty_input_case
+    assert empty_input_case(hip_engine.ctx)
+
+
 def test_column_comparisons(hip_engine):
     """a op b on two columns (Q4's `l_commitdate < l_receiptdate`): every operator, ints and
     doubles, in the scan, group-by and staging kernels (generic filter instances)."""

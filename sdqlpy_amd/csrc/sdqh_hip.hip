@@ -1439,7 +1439,7 @@ int sdqh_build(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nloo
     // stage without source columns: the kernel evaluates sources itself
     sdqh_column fake; fake.data = nullptr;
     const sdqh_column* fakes[SDQH_MAX_PAYLOAD] = {&fake, &fake, &fake, &fake};
-    int rc = setup_stage(ctx, tb, nrows, &fake, npayload, fakes, 1);          // k_build_lookup steps one 128-row batch at a time
+    int rc = setup_stage(ctx, tb, nrows, &fake, npayload, fakes, nrows >= (int64_t)ctx->num_cu * 24 * 512 ? BUILD_LB : 1);   // whole steps for big tables; small ones keep one batch per wave (partial steps take the per-row path)
     uint64_t capmax = 1024;
     while (capmax < 2 * (uint64_t)std::max<int64_t>(nrows, 1)) capmax <<= 1;
     tb->capmax = capmax;

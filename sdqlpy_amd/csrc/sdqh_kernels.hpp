@@ -1672,6 +1672,7 @@ __device__ __forceinline__ bool first_lookup_may_hit(const DevLookups& L, int64_
     return (t.bm[off >> 5] >> (off & 31)) & 1u;
 }
 
+constexpr int BUILD_LB = 4;                                           // 128-row batches per step of k_build_lookup
 constexpr int LOOKUP_PU = 2;                                          // row pairs per lane in flight in k_lookup_agg's streaming part (4 measured the same: the kernel is bound by the 128-byte lines its sparse gathers pull in, not by step latency)
 constexpr int LQ_CAP = 192;                                           // 63 left over + 128 appended per pair step
 
@@ -1722,26 +1723,15 @@ __global__ __launch_bounds__(TPB) void k_build_lookup(DevFilter f, DevLookups L,
         if (keep) stage_store<-1>(st, out + __popcll(b & lt), key, pay);
         out += __popcll(b);
     };
-    for (int64_t b = begin; b < end; b += BATCH_ROWS) {
-        const int64_t r = b + (int64_t)lane * ROWS_PER_LOAD;
-        bool p[1][2];
-        int64_t rr[1] = {r};
-        if (b + BATCH_ROWS <= end) {
-            p[0][0] = p[0][1] = true;
-            Pair<int64_t> k0 = {0, 0};
-            if (eager0) k0 = load2<false>(L.l[0].key[0].col, r, nrows);
-            pass_pairs<1, FC, false>(f, none, rr, nrows, nomask, p);
-            if (eager0) { p[0][0] = p[0][0] && first_lookup_may_hit(L, k0.x); p[0][1] = p[0][1] && first_lookup_may_hit(L, k0.y); }
-        } else {
-            p[0][0] = r < end; p[0][1] = r + 1 < end;
-            if (p[0][0]) p[0][0] = row_passes<FC>(f, none, r, nomask);
-            if (p[0][1]) p[0][1] = row_passes<FC>(f, none, r + 1, nomask);
-        }
-        const uint64_t b0 = __ballot(p[0][0]), b1 = __ballot(p[0][1]);
+    // BUILD_LB batches of 128 rows per step: the first predicate and the first lookup's key of all of
+    // them are loaded, and their bitmap words requested, before any is consumed (one dependent chain
+    // per step instead of one per batch: the orders build of Q5 is latency-bound, 19 -> 5 steps per wave)
+    auto enqueue = [&](int64_t r, bool p0, bool p1) {
+        const uint64_t b0 = __ballot(p0), b1 = __ballot(p1);
         if (b0 | b1) {
             const int at = qn + __popcll(b0 & lt) + __popcll(b1 & lt);
-            if (p[0][0]) q_row[at] = r;
-            if (p[0][1]) q_row[at + (p[0][0] ? 1 : 0)] = r + 1;
+            if (p0) q_row[at] = r;
+            if (p1) q_row[at + (p0 ? 1 : 0)] = r + 1;
             qn += __popcll(b0) + __popcll(b1);
             while (qn >= WAVE) {                                       // drain the FRONT 64 (row order), shift the rest down
                 drain(WAVE);
@@ -1752,6 +1742,44 @@ __global__ __launch_bounds__(TPB) void k_build_lookup(DevFilter f, DevLookups L,
                 if (lane < left) q_row[lane] = a0;
                 if (lane + WAVE < left) q_row[WAVE + lane] = a1;
                 qn = left;
+            }
+        }
+    };
+    for (int64_t b = begin; b < end; b += BATCH_ROWS * BUILD_LB) {
+        if (b + BATCH_ROWS * BUILD_LB <= end) {
+            int64_t rr[BUILD_LB];
+            bool p[BUILD_LB][2];
+            Pair<int64_t> k0[BUILD_LB];
+#pragma unroll
+            for (int j = 0; j < BUILD_LB; ++j) {
+                rr[j] = b + (int64_t)j * BATCH_ROWS + (int64_t)lane * ROWS_PER_LOAD;
+                p[j][0] = p[j][1] = true;
+                if (eager0) k0[j] = load2<false>(L.l[0].key[0].col, rr[j], nrows);
+            }
+            pass_pairs<BUILD_LB, FC, false>(f, none, rr, nrows, nomask, p);
+            if (eager0) {
+#pragma unroll
+                for (int j = 0; j < BUILD_LB; ++j) { p[j][0] = p[j][0] && first_lookup_may_hit(L, k0[j].x); p[j][1] = p[j][1] && first_lookup_may_hit(L, k0[j].y); }
+            }
+#pragma unroll
+            for (int j = 0; j < BUILD_LB; ++j) enqueue(rr[j], p[j][0], p[j][1]);
+        } else {
+            for (int64_t bb = b; bb < end; bb += BATCH_ROWS) {       // short segments (small tables) and tails: one batch at a time
+                const int64_t r = bb + (int64_t)lane * ROWS_PER_LOAD;
+                bool p1b[1][2];
+                if (bb + BATCH_ROWS <= end) {
+                    int64_t r1[1] = {r};
+                    p1b[0][0] = p1b[0][1] = true;
+                    Pair<int64_t> k1 = {0, 0};
+                    if (eager0) k1 = load2<false>(L.l[0].key[0].col, r, nrows);
+                    pass_pairs<1, FC, false>(f, none, r1, nrows, nomask, p1b);
+                    if (eager0) { p1b[0][0] = p1b[0][0] && first_lookup_may_hit(L, k1.x); p1b[0][1] = p1b[0][1] && first_lookup_may_hit(L, k1.y); }
+                } else {
+                    p1b[0][0] = r < end; p1b[0][1] = r + 1 < end;
+                    if (p1b[0][0]) p1b[0][0] = row_passes<FC>(f, none, r, nomask);
+                    if (p1b[0][1]) p1b[0][1] = row_passes<FC>(f, none, r + 1, nomask);
+                }
+                enqueue(r, p1b[0][0], p1b[0][1]);
             }
         }
     }

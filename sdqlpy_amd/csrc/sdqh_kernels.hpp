@@ -7,9 +7,15 @@
 // two-level reductions instead of global float atomics where a result is a handful of sums.
 //
 // Reference loop shapes these replace (edin-dal/sdqlpy, src/sdqlpy/lib/sdql_ir_cpp_generator_par.py):
-//   k_scan_sum        K-A 258-291   k_groupby_reg / k_groupby_lds   K-C 402-440 (small key domain)
-//   k_stage/k_insert  K-B 331-369   k_probe_agg                     K-C 402-440 (group = matched entry)
-//   k_compact         K-F 520-568
+//   k_scan_sum, k_scan_probe_sum     K-A 258-291 (the latter with `tbl[k] != None` conditions, lookups 85-96)
+//   k_groupby_reg / k_groupby_lds    K-C 402-440, small key domain
+//   k_stage (+ index kernels)        K-B 331-369, unique builds; k_key_set: builds that only answer membership
+//   k_build_lookup                   K-B with keys / payloads derived through lookups (multi-join chains)
+//   k_probe_agg                      K-C 402-440, group = matched entry; also the row-keyed group-by (k_gk_layout)
+//   k_lookup_agg                     K-C 402-440 with chained lookups, <= 256 groups
+//   k_compact_*, k_topk_*            K-F 520-568; ORDER BY ... LIMIT k on top of it (not in the reference)
+//   k_select_keys                    a conditional sum over an aggregated dictionary (HAVING)
+//   k_seg_scan ... k_export_bitmap   redistribution helpers of the multi-GPU plans (no reference counterpart)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

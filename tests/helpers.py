@@ -404,3 +404,79 @@ def empty_input_case(ctx):
     for x in (s, g, t, g2, sel):
         x.free()
     return True
+
+
+def fuzz_case(hip, cpu, seed, rounds=12):
+    """Differential fuzzing of the pattern calls: random row counts around tile / wave boundaries,
+    random filters (int / float ranges, column comparisons, text predicates of every mode), random
+    semi-join probes, payload counts, duplicate and sparse / dense / negative keys — the HIP library
+    against the CPU implementation of the same ABI.  Values are integer-valued doubles so that sums
+    are exact in any order."""
+    import numpy as np
+    from sdqlpy_amd import abi
+    rng = np.random.default_rng(seed)
+    sizes = [0, 1, 63, 64, 65, 127, 128, 129, 511, 512, 513, 1023, 1025, 2047, 2049, 4097, 10000, 33333]
+    words = np.array(["", "a", "ab", "abc", "b", "ba", "PROMO X", "PROMO", "PRO", "xPROMO", "green", "gre en"], "<U8")
+    for rnd in range(rounds):
+        n = int(rng.choice(sizes))
+        style = rng.integers(0, 4)
+        if style == 0:
+            keys = rng.permutation(max(n, 1))[:n].astype(np.int64) * 3 - 50                      # unique, dense-ish, some negative
+        elif style == 1:
+            keys = rng.integers(-20, 40, n).astype(np.int64)                                       # heavy duplicates
+        elif style == 2:
+            keys = np.sort(rng.integers(0, max(4 * n, 4), n)).astype(np.int64)                     # clustered with duplicates
+        else:
+            keys = (rng.integers(0, 1 << 20, n).astype(np.int64) << 24) + rng.integers(0, 5, n)   # sparse, wide
+        ia, ib = rng.integers(0, 30, n).astype(np.int64), rng.integers(0, 30, n).astype(np.int64)
+        fa = rng.integers(0, 40, n) / 4.0
+        txt = words[rng.integers(0, len(words), n)]
+        pay = rng.integers(-(1 << 40), 1 << 40, n).astype(np.int64)
+        v = rng.integers(1, 50, n).astype(np.float64)
+        m = int(rng.choice(sizes))
+        pk = (keys[rng.integers(0, n, m)] if n else rng.integers(0, 10, m)).astype(np.int64)
+        pv = rng.integers(1, 9, m).astype(np.float64)
+        pd_ = rng.integers(0, 30, m).astype(np.int64)
+
+        def spec(ctx):
+            c = {k: ctx.upload(a) for k, a in dict(keys=keys, ia=ia, ib=ib, fa=fa, txt=txt, pay=pay, v=v, pk=pk, pv=pv, pd=pd_).items()}
+            r = np.random.default_rng(seed * 1000 + rnd)                   # the same choices for both implementations
+            ip = [(c["ia"], int(r.integers(0, 10)), int(r.integers(10, 30)))] if r.random() < 0.6 else []
+            fp = [(c["fa"], float(r.integers(0, 4)), float(r.integers(4, 10)))] if r.random() < 0.4 else []
+            cp = [(c["ia"], c["ib"], int(r.integers(0, 4)))] if r.random() < 0.4 else []
+            sp = [(c["txt"], str(r.choice(["PROMO", "a", "b", "green", "", "ab"])), int(r.integers(0, 5)))] if r.random() < 0.4 else []
+            return c, abi.make_filter(ip, fp, sp, cp), r
+
+        out = []
+        for ctx in (hip, cpu):
+            c, flt, r = spec(ctx)
+            res = []
+            npay = int(r.integers(0, 2))
+            t = ctx.hash_build_unique(n, flt, [], c["keys"], [c["pay"]][:npay], accumulate=True)
+            res.append(("size", t.size()))
+            pflt = abi.make_filter(ipreds=[(c["pd"], 0, int(r.integers(5, 30)))]) if r.random() < 0.5 else abi.make_filter()
+            ctx.hash_probe_aggregate(m, pflt, t, c["pk"], abi.make_tuple(abi.TUPLE_A, [c["pv"]]))
+            cnt = ctx.table_compact_count(t, 1)
+            k, p, vals, h = ctx.table_compact(t, 1, cnt)
+            order = np.argsort(k, kind="stable")
+            res.append(("agg", k[order].tolist(), vals[0][order].tolist(), h[order].tolist(), p[0][order].tolist() if npay else None))
+            try:
+                s = ctx.build_key_set(n, flt, [], c["keys"])
+                res.append(("set", s.size(), ctx.scan_probe_sum(m, abi.make_filter(), [(s, c["pk"])], abi.make_tuple(abi.TUPLE_A, [c["pv"]]))))
+                s.free()
+            except abi.SdqhError as exc:
+                res.append(("set-unsupported", exc.code))
+            g = ctx.groupby_key(n, flt, c["keys"], abi.make_tuple(abi.TUPLE_A, [c["v"]]))
+            gc = ctx.table_compact_count(g, 1)
+            gk, _, gv, gh = ctx.table_compact(g, 1, gc)
+            go = np.argsort(gk, kind="stable")
+            res.append(("groupby", gk[go].tolist(), gv[0][go].tolist(), gh[go].tolist()))
+            kk = int(r.choice([1, 5, 16, 17, 64, 128]))
+            tk, _, tv, th = ctx.table_topk(g, 1, kk, [(abi.SORT_VALUE, 0, True, True), (abi.SORT_KEY, 0, False, False)])
+            res.append(("topk", tk.tolist(), tv[0].tolist(), th.tolist()))
+            res.append(("scan", ctx.scan_filter_sum(n, flt, abi.make_tuple(abi.TUPLE_A, [c["v"]]))))
+            t.free(); g.free()
+            out.append(res)
+        assert out[0] == out[1], "seed %d round %d (n=%d, m=%d, key style %d): %s" % (
+            seed, rnd, n, m, style, next((a[0], str(a)[:300], str(b)[:300]) for a, b in zip(out[0], out[1]) if a != b))
+    return rounds

@@ -209,6 +209,12 @@ def test_groupby_key_and_having(hip_engine):
     assert groupby_key_case(hip_engine.ctx, n=900, seed=3) == 3
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_differential_fuzz_against_the_cpu_implementation(hip_engine, oracle_engine, seed):
+    from helpers import fuzz_case
+    assert fuzz_case(hip_engine.ctx, oracle_engine.ctx, seed) == 12
+
+
 def test_empty_inputs(hip_engine):
     """Zero-row tables and filters that pass nothing through the newer entry points (key sets,
     row-keyed group-by, HAVING, top-k, probe sums)."""

@@ -298,7 +298,24 @@ def cpu_baseline(args, queries, db, rows):
     elapsed = time.perf_counter() - t0
     total_rows = sum(scanned_rows(q, srows) for q in queries)
     eng.close()
+    # one-thread figure: the same sample, one pass, one worker
+    eng1 = engine.Engine(lib.context(threads=1))
+    run1 = lambda q: engine.execute_plan(eng1, plans[q], [sample[t] for t in Q.QUERY_TABLES[q]])   # noqa: E731
+    for q in queries:
+        run1(q)
+    t1 = time.perf_counter()
+    for q in queries:
+        run1(q)
+    one_thread = total_rows / (time.perf_counter() - t1)
+    eng1.close()
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "")
+    except OSError:
+        pass
     return {"value": round(total_rows * iters / elapsed, 1), "unit": "rows/s", "cores": cores, "kind": "port",
+            "cpu_model": model, "value_one_thread": round(one_thread, 1),
             "sample": "same generator, first %.0f%% of orders + their lineitems (%d lineitem rows), customer whole; %d passes of %s"
                       % (100 * frac, srows.get("lineitem", 0), iters, "+".join(queries)),
             "ms_per_query": {q: round(per_q[q] / iters * 1e3, 2) for q in queries}}

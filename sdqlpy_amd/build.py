@@ -22,7 +22,7 @@ HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off",          # keep the reference's a*(1.0-b) association: no FMA contraction
     "-munsafe-fp-atomics",        # native global_atomic_add_f64, no CAS loop
-    "-fno-gpu-rdc",
+    "-fno-gpu-rdc", "-pthread",
     "-Wall", "-Wno-unused-function",
 ]
 

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <map>
 #include <vector>
@@ -495,6 +496,22 @@ int sdqh_column_alloc(sdqh_ctx* ctx, int64_t nrows, int dtype, int width, sdqh_c
     return SDQH_OK;
 }
 
+// pageable -> pinned copy of a staging chunk on several host threads: one thread moves ~10 GB/s, the
+// link takes ~50 (the first pass over SF=10's 3.9 GB of columns: 0.25 s -> PCIe-bound)
+static void staging_copy(void* dst, const void* src, size_t n) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t parts = n < ((size_t)4 << 20) ? 1 : std::min<size_t>(8, std::max<unsigned>(1, hw / 2));
+    if (parts <= 1) { std::memcpy(dst, src, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = ((n / parts) + 4095) & ~(size_t)4095;
+    for (size_t k = 1; k < parts; ++k) {
+        const size_t b = std::min(n, k * per), e = std::min(n, (k + 1) * per);
+        if (e > b) th.emplace_back([=] { std::memcpy(static_cast<char*>(dst) + b, static_cast<const char*>(src) + b, e - b); });
+    }
+    std::memcpy(dst, src, std::min(n, per));
+    for (auto& t : th) t.join();
+}
+
 int sdqh_column_upload(sdqh_ctx* ctx, const void* host, int64_t nrows, int dtype, int width, sdqh_column** out) {
     if (nrows > 0 && !host) return fail(ctx, SDQH_ERR_INVALID, "column_upload: null host pointer");
     if (int rc = sdqh_column_alloc(ctx, nrows, dtype, width, out)) return rc;
@@ -505,7 +522,7 @@ int sdqh_column_upload(sdqh_ctx* ctx, const void* host, int64_t nrows, int dtype
     while (off < bytes) {
         const size_t n = std::min(STAGING_BYTES, bytes - off);
         if (ctx->staging_busy[i]) { HIP_TRY(ctx, hipEventSynchronize(ctx->staging_done[i])); ctx->staging_busy[i] = false; }
-        std::memcpy(ctx->staging[i], static_cast<const char*>(host) + off, n);
+        staging_copy(ctx->staging[i], static_cast<const char*>(host) + off, n);
         HIP_TRY(ctx, hipMemcpyAsync(static_cast<char*>(c->data) + off, ctx->staging[i], n, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->staging_done[i], ctx->stream));
         ctx->staging_busy[i] = true;

@@ -24,7 +24,7 @@ def main():
     only_scratch = "--scratch" in sys.argv
     src = os.path.join(ROOT, "sdqlpy_amd", "csrc", "sdqh_hip.hip")
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-munsafe-fp-atomics", "-fno-gpu-rdc", "-I", os.path.join(ROOT, "include"), "-I", os.path.dirname(src),
+           "-munsafe-fp-atomics", "-fno-gpu-rdc", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", os.path.dirname(src),
            "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/_kernel_resources.so", src]
     err = subprocess.run(cmd, capture_output=True, text=True).stderr
     rows, cur = [], None

@@ -306,7 +306,7 @@ class DistributedRunner:
             c.free()
         table = ctx.hash_build_unique(total, abi.make_filter(), [], gathered[0], gathered[1:])
         new = engine.BuiltTable(table, bt.key_name, bt.key_is_record, bt.val_fields, bt.val_is_record, bt.payload_dtypes)
-        new.decoders, new.key_parts = bt.decoders, bt.key_parts
+        new.decoders, new.key_parts, new.field_decoders = bt.decoders, bt.key_parts, bt.field_decoders
         new.key_decoder = getattr(bt, "key_decoder", None)
         new._keep = gathered
         bt.table.free()

@@ -166,7 +166,18 @@ class BuiltTable:
         self.agg = None                     # set by a fused probe-aggregate: (key_fields, val_names, tuple shape)
         self.agg_spec = None
         self.decoders = {}                  # payload index -> string array (the payload holds row references into it)
+        self.field_decoders = {}            # field name -> string array: several text fields of one source row share ONE
+                                            # row-reference payload slot and differ only in what it indexes (late materialisation)
         self.key_parts = None               # composite key: [part names]; the stored key is (part0 << 32) | part1
+
+    def slot_of(self, field):
+        """"key" | payload index of a value field, or None."""
+        if field is None:
+            return self.val_fields[0][1] if len(self.val_fields) == 1 else None
+        return dict(self.val_fields).get(field)
+
+    def decoder_of(self, field, slot):
+        return self.field_decoders.get(field, self.decoders.get(slot))
 
     def field_index(self, field, op):
         """Payload index of a value field (None = the scalar value)."""
@@ -370,15 +381,28 @@ def _walk_lookups(e, found):
             _walk_lookups(x, found)
 
 
+def _link_key_sources(srcs, lookup_keys):
+    for sr in srcs:
+        if sr.kind == "lookup" and sr.key_src is None and len(lookup_keys[sr.lookup]) == 1:
+            sr.key_src = lookup_keys[sr.lookup][0]
+
+
 class _Src:
     """A value source resolved at run time into an abi source spec (+ how to decode it for the result)."""
     def __init__(self, kind, col=None, lookup=None, field=None, year=False, decoder=None, dtype=np.int64):
         self.kind, self.col, self.lookup, self.field, self.year, self.decoder, self.dtype = kind, col, lookup, field, year, decoder, dtype
 
+    key_src = None        # lookup kind: the source of the lookup's (single) key — what a field that IS the table's key reads
+
+    def _is_key_field(self, bt):
+        return self.kind == "lookup" and self.key_src is not None and bt.slot_of(self.field) == "key"
+
     def spec(self, op, env, lookups):
         if self.kind == "col":
             return abi.src_col(self.col)
         bt = env[lookups[self.lookup].dict_name]
+        if self._is_key_field(bt):                               # the matched entry's key equals the key it was looked up with
+            return self.key_src.spec(op, env, lookups)
         return abi.src_lookup(self.lookup, bt.field_index(self.field, op), self.year)
 
     def decode_info(self, op, env, lookups):
@@ -386,8 +410,15 @@ class _Src:
         if self.kind == "col":
             return self.decoder, self.dtype
         bt = env[lookups[self.lookup].dict_name]
+        if self._is_key_field(bt):
+            return self.key_src.decode_info(op, env, lookups)
         idx = bt.field_index(self.field, op)
-        return (None, np.dtype(np.int64)) if self.year else (bt.decoders.get(idx), np.dtype(bt.payload_dtypes[idx]))
+        return (None, np.dtype(np.int64)) if self.year else (bt.decoder_of(self.field, idx), np.dtype(bt.payload_dtypes[idx]))
+
+    def same_slot(self, other, op, env, lookups):
+        """Do two payload sources read the same device values (one slot can serve both)?"""
+        a, b = self.spec(op, env, lookups), other.spec(op, env, lookups)
+        return a[0] == b[0] and all(x is y or x == y for x, y in zip(a[1:], b[1:]))
 
 
 def _source_of(eng, op, htab, e, lookups, as_group_key=False):
@@ -464,23 +495,36 @@ def _prepare_general(eng, op, htab, flt, contains_lookups, accumulate_into=()):
         # a value field that repeats the (single-column) key needs no payload slot: it is read back from the key
         is_key = [len(key_fields) == 1 and isinstance(key_fields[0][1], Col) and isinstance(e, Col) and e.name == key_fields[0][1].name for _, e in vfields]
         stored = [(fname, e) for (fname, e), k in zip(vfields, is_key) if not k]
-        if len(stored) > abi.MAX_PAYLOAD:
-            raise UnsupportedQuery("line %d: more than %d payload fields" % (op.lineno, abi.MAX_PAYLOAD))
         pay_srcs = [_source_of(eng, op, htab, e, lookups) for _, e in stored]
-        slot_of, nxt = [], 0
-        for k in is_key:
-            slot_of.append("key" if k else nxt)
-            nxt += 0 if k else 1
+        _link_key_sources(pay_srcs + key_srcs + [k for ks in lookup_keys for k in ks], lookup_keys)
         key_names = [fname or (e.name if isinstance(e, Col) else "key%d" % i) for i, (fname, e) in enumerate(key_fields)]
         accumulate = op.out in accumulate_into
 
         def run_build(env):
-            table = ctx.build(n, flt, resolve_lookups(env), [k.spec(op, env, lookups) for k in key_srcs],
-                              [p.spec(op, env, lookups) for p in pay_srcs], accumulate=accumulate)
+            # fields that read the same device values share one payload slot: the text fields of one
+            # source row are one row reference (they differ in the host array it indexes), a field that
+            # is the looked-up table's key is the lookup key itself
+            specs = [p.spec(op, env, lookups) for p in pay_srcs]
             infos = [p.decode_info(op, env, lookups) for p in pay_srcs]
-            bt = BuiltTable(table, key_names[0], key_is_record, [(fname, slot_of[i]) for i, (fname, _) in enumerate(vfields)], val_is_record,
-                            [info[1] for info in infos])
-            bt.decoders = {i: info[0] for i, info in enumerate(infos) if info[0] is not None}
+            uniq, slot_idx = [], []
+            for sp in specs:
+                j = next((j for j, u in enumerate(uniq) if len(u) == len(sp) and all(x is y or (not hasattr(x, "handle") and x == y) for x, y in zip(u, sp))), None)
+                if j is None:
+                    uniq.append(sp); j = len(uniq) - 1
+                slot_idx.append(j)
+            if len(uniq) > abi.MAX_PAYLOAD:
+                raise UnsupportedQuery("line %d: more than %d distinct payload values per entry" % (op.lineno, abi.MAX_PAYLOAD))
+            table = ctx.build(n, flt, resolve_lookups(env), [k.spec(op, env, lookups) for k in key_srcs], uniq, accumulate=accumulate)
+            it = iter(slot_idx)
+            val_fields = [(fname, "key" if k else next(it)) for (fname, _), k in zip(vfields, is_key)]
+            slot_dtype, slot_decoder = {}, {}
+            for j, info in zip(slot_idx, infos):
+                slot_dtype.setdefault(j, info[1])
+                if info[0] is not None:
+                    slot_decoder.setdefault(j, info[0])
+            bt = BuiltTable(table, key_names[0], key_is_record, val_fields, val_is_record, [slot_dtype[j] for j in range(len(uniq))])
+            bt.decoders = slot_decoder
+            bt.field_decoders = {fname: info[0] for (fname, _), info in zip(stored, infos) if info[0] is not None}
             if len(key_srcs) == 2:
                 bt.key_parts = key_names
             bt.key_decoder = key_srcs[0].decode_info(op, env, lookups)[0] if len(key_srcs) == 1 else None
@@ -511,6 +555,7 @@ def _prepare_general(eng, op, htab, flt, contains_lookups, accumulate_into=()):
         else:                                                   # ("payload", dict_name, key repr, field)
             j = [repr(x.key) + x.dict_name for x in lookups].index(slot[2] + slot[1])
             operand_srcs.append(_Src("lookup", lookup=j, field=slot[3]))
+    _link_key_sources(operand_srcs + key_srcs + [k for ks in lookup_keys for k in ks], lookup_keys)
 
     def run_lookup_aggregate(env):
         for o in operand_srcs:
@@ -532,11 +577,43 @@ def _prepare_general(eng, op, htab, flt, contains_lookups, accumulate_into=()):
     return run_lookup_aggregate
 
 
+_DENSE_MERGE_CELLS = 1 << 26
+
+
+def _all_distinct(a):
+    if a.dtype.kind in "iu" and len(a):
+        lo, hi = int(a.min()), int(a.max())
+        if hi - lo < _DENSE_MERGE_CELLS:
+            seen = np.zeros(hi - lo + 1, bool); seen[a - lo] = True
+            return int(seen.sum()) == len(a)
+    return len(np.unique(a)) == len(a)
+
+
 def _merge_equal_keys(d):
-    """Groups were formed on row references; two references may decode to the same text.  Fold them."""
+    """Groups were formed on row references (two may decode to the same text) or on the matched entry
+    of a probed table while the output key names only fields several entries share (Q10: orders of one
+    customer): fold rows with equal keys, the reference's `AddMap` of the last mile (map_helper.h:1-23)."""
     n = d.size()
     if n < 2:
         return d
+    if n > 4096:                                             # large results: sort-based grouping in numpy
+        cols = [a for _, a in d.key_fields]
+        order = np.lexsort([c if c.dtype.kind != "U" else np.unique(c, return_inverse=True)[1] for c in reversed(cols)])
+        sorted_cols = [c[order] for c in cols]
+        new_group = np.zeros(n, bool); new_group[0] = True
+        for c in sorted_cols:
+            new_group[1:] |= c[1:] != c[:-1]
+        if new_group.all():
+            return d
+        gid = np.cumsum(new_group) - 1
+        first = np.nonzero(new_group)[0]
+        kf = [(nm, c[first]) for (nm, _), c in zip(d.key_fields, sorted_cols)]
+        vf = []
+        for nm, a in d.val_fields:
+            acc = np.zeros(len(first), a.dtype)
+            np.add.at(acc, gid, a[order])
+            vf.append((nm, acc))
+        return DictResult(kf, vf, d.key_is_record, d.val_is_record)
     rows = list(zip(*[a.tolist() for _, a in d.key_fields]))
     if len(set(rows)) == n:
         return d
@@ -750,6 +827,7 @@ def _prepare_scan(eng, op, htab, accumulate_into, member_only=False):
                     if src is None:
                         raise UnsupportedQuery("line %d: '%s' has no field '%s'" % (op.lineno, probe_name, e.field))
                     out_key_fields.append((fname or e.field, src))
+                    bt.__dict__.setdefault("agg_fields", {})[fname or e.field] = e.field      # output name -> entry field (its decoder)
                 else:
                     raise UnsupportedQuery("line %d: group keys of a probe-aggregate must be the probe key or fields of the matched "
                                            "entry (the group must be determined by the probe key)" % op.lineno)
@@ -818,18 +896,76 @@ def _materialize(eng, value, env, hint_key=None, top=None):
     if isinstance(value, tuple) and value and value[0] == "aggregated":
         bt = env[value[1]]
         out_key_fields, vnames, count_idx, key_is_record, val_is_record, shape = bt.agg
-        spec = _device_sort_spec(bt, out_key_fields, vnames, count_idx, top[1]) if top is not None else None
+        entry_is_group = any(src == "key" for _, src in out_key_fields)
+        spec = _device_sort_spec(bt, out_key_fields, vnames, count_idx, top[1]) if top is not None and entry_is_group else None
         keys, payload, values, hits, ordered = _fetch_entries(eng, bt.table, 1, hint_key, top, spec, want_hits=count_idx is not None or (spec is not None and any(s[0] == abi.SORT_HITS for s in spec)))
-        kf = []
-        for fname, src in out_key_fields:
-            if src == "key":
-                kf.append((fname, keys))
-            else:
-                kf.append((fname, _decode_column(payload[src], bt.decoders.get(src), bt.payload_dtypes[src])))
         nv = abi.TUPLE_NVALUES[shape]
-        vf = _value_arrays(vnames, count_idx, [values[j] for j in range(nv)], hits)
-        d = DictResult(kf, vf, key_is_record, val_is_record)
-        d.ordered = ordered
+        values = [values[j] for j in range(nv)]
+        fields_of = getattr(bt, "agg_fields", {})
+        def decode(fname, src, sel=None):
+            raw = keys if src == "key" else payload[src]
+            if sel is not None:
+                raw = raw[sel]
+            return raw if src == "key" else _decode_column(raw, bt.decoder_of(fields_of.get(fname), src), bt.payload_dtypes[src])
+        if entry_is_group or ordered:
+            d = DictResult([(f, decode(f, src)) for f, src in out_key_fields], _value_arrays(vnames, count_idx, values, hits),
+                           key_is_record, val_is_record)
+            d.ordered = ordered
+            return d
+        # The output key does not identify the entry (Q10: one entry per order, the key names customer
+        # fields): fold entries that reference the same source rows first — integer work on the row
+        # references — then decode, text last and only for the rows that survive ORDER BY / LIMIT.
+        slots = sorted({src for _, src in out_key_fields})
+        n = len(payload[slots[0]]) if slots else 0
+        if n:
+            refs = [np.asarray(payload[sl]) for sl in slots]
+            lo = [int(r.min()) for r in refs]
+            span = [int(r.max()) - l + 1 for r, l in zip(refs, lo)]
+            cells = int(np.prod([float(x) for x in span]))
+            want_counts = hits is not None and count_idx is not None
+            if cells <= _DENSE_MERGE_CELLS:                  # row references span a small rectangle: bucket, no sort
+                code = np.zeros(n, np.int64)
+                for r, l, w in zip(refs, lo, span):
+                    code = code * w + (r - l)
+                present = np.zeros(cells, bool); present[code] = True
+                cell_of_group = np.nonzero(present)[0]
+                group_of_cell = np.cumsum(present) - 1
+                gid = group_of_cell[code]
+                values = [np.bincount(gid, weights=v, minlength=len(cell_of_group)) for v in values]
+                if want_counts:
+                    hits = np.bincount(gid, weights=np.asarray(hits), minlength=len(cell_of_group)).astype(np.int64)
+                rest, merged = cell_of_group, []
+                for l, w in zip(reversed(lo), reversed(span)):
+                    merged.append(rest % w + l); rest = rest // w
+                payload = dict(zip(slots, [m.astype(r.dtype) for m, r in zip(reversed(merged), refs)]))
+            else:
+                order = np.lexsort(list(reversed(refs)))
+                sorted_refs = [r[order] for r in refs]
+                new_group = np.zeros(n, bool); new_group[0] = True
+                for c in sorted_refs:
+                    new_group[1:] |= c[1:] != c[:-1]
+                first = np.nonzero(new_group)[0]
+                payload = dict(zip(slots, [c[first] for c in sorted_refs]))
+                values = [np.add.reduceat(v[order], first) for v in values]
+                if want_counts:
+                    hits = np.add.reduceat(np.asarray(hits)[order], first)
+        vf = _value_arrays(vnames, count_idx, values, hits)
+        numeric = {f: decode(f, src) for f, src in out_key_fields
+                   if bt.decoder_of(fields_of.get(f), src) is None or bt.decoder_of(fields_of.get(f), src).dtype.kind != "U"}
+        distinct = any(_all_distinct(a) for a in numeric.values())
+        if not distinct:                                     # different rows may still decode to equal fields
+            d = _merge_equal_keys(DictResult([(f, numeric[f] if f in numeric else decode(f, src)) for f, src in out_key_fields],
+                                             vf, key_is_record, val_is_record))
+            d.ordered = False
+            return d
+        sel = None
+        by_name = dict(numeric); by_name.update(dict(vf))
+        if top is not None and all(nm in by_name for nm, _ in top[1]):
+            sel = ResultSet([nm for nm, _ in top[1]], [by_name[nm] for nm, _ in top[1]]).top_index(top[0], top[1])
+            vf = [(nm, a[sel]) for nm, a in vf]
+        d = DictResult([(f, (numeric[f] if sel is None else numeric[f][sel]) if f in numeric else decode(f, src, sel)) for f, src in out_key_fields],
+                       vf, key_is_record, val_is_record)
+        d.ordered = sel is not None
         return d
     if isinstance(value, BuiltTable):
         spec = _device_sort_spec(value, [(value.key_name, "key")] + [(f, src) for f, src in value.val_fields if src != "key"], [], None, top[1]) \
@@ -840,7 +976,7 @@ def _materialize(eng, value, env, hint_key=None, top=None):
         else:
             keys, payload, _, _ = _compact(eng, value.table, 0, hint_key, want_values=False, want_hits=False)
             ordered = False
-        vf = [(fname, keys if src == "key" else _decode_column(payload[src], value.decoders.get(src), value.payload_dtypes[src]))
+        vf = [(fname, keys if src == "key" else _decode_column(payload[src], value.decoder_of(fname, src), value.payload_dtypes[src]))
               for fname, src in value.val_fields]
         if value.key_parts is not None:
             kf = [(value.key_parts[0], keys >> 32), (value.key_parts[1], keys & 0xFFFFFFFF)]
@@ -866,9 +1002,12 @@ def _finalize(eng, op, env, top=None):
             kf_names, vf_names = [probe.key_name], [f for f, _ in probe.val_fields]
         else:
             kf_names, vf_names = [n for n, _ in probe.key_fields], [n for n, _ in probe.val_fields]
-        for name, which in op.fields:
+        for spec in op.fields:
+            name, which = spec[0], spec[1]
             side = kf_names if which == 0 else vf_names
-            if len(side) == 1:
+            if len(spec) == 3:
+                names[name] = spec[2]
+            elif len(side) == 1:
                 names[name] = side[0]
         inner_top = (top[0], [(names.get(n, n), d) for n, d in top[1]])
     d = _materialize(eng, src_val, env, hint_key=id(op), top=inner_top)
@@ -876,10 +1015,17 @@ def _finalize(eng, op, env, top=None):
         fields = d.key_fields + d.val_fields
     else:
         fields = []
-        for name, which in op.fields:
+        for spec in op.fields:
+            name, which = spec[0], spec[1]
             src = d.key_fields if which == 0 else d.val_fields
+            if len(spec) == 3:                                  # p[which].field
+                hit = [a for n, a in src if n == spec[2]]
+                if not hit:
+                    raise UnsupportedQuery("line %d: p[%d] has no field '%s'" % (op.lineno, which, spec[2]))
+                fields.append((name, hit[0]))
+                continue
             if len(src) != 1:
-                raise UnsupportedQuery("line %d: p[%d] is a record; use concat" % (op.lineno, which))
+                raise UnsupportedQuery("line %d: p[%d] is a record; name a field or use concat" % (op.lineno, which))
             fields.append((name, src[0][1]))
     rs = ResultSet([n for n, _ in fields], [a for _, a in fields])
     if top is not None and not getattr(d, "ordered", False):

@@ -143,9 +143,9 @@ class RecordCons(Expr):
 
 
 class WholeKey(Expr):
-    """`p[0]` / `p[1]` of a sum over a result dictionary."""
-    def __init__(self, which):
-        self.which = which            # 0 = key, 1 = value
+    """`p[0]` / `p[1]` of a sum over a result dictionary; with `field`, `p[0].field` / `p[1].field`."""
+    def __init__(self, which, field=None):
+        self.which, self.field = which, field            # which: 0 = key, 1 = value
 
 
 class ConcatKV(Expr):
@@ -205,7 +205,7 @@ class SelectKeysOp:
 class FinalizeOp:
     """Sum over a result dictionary that only reshapes (key, value) into one record set (K-F)."""
     def __init__(self, out, source, fields, lineno):
-        self.out, self.source, self.fields, self.lineno = out, source, fields, lineno   # fields: None = concat, else [(name, WholeKey)]
+        self.out, self.source, self.fields, self.lineno = out, source, fields, lineno   # fields: None = concat, else [(name, 0 | 1[, field of that side])]
 
 
 class Plan:
@@ -257,6 +257,8 @@ class _Lowerer:
                 kind = env[base.value.id][0]
                 if kind == "rowpair" and idx == 0:
                     return Col(node.attr)
+                if kind == "kv":
+                    return WholeKey(idx, node.attr)
                 self.fail(node, "only p[0].<column> is supported inside a table sum")
             if isinstance(base, ast.Name) and base.id in self.scalars and base.id not in env:
                 return ScalarField(base.id, node.attr)
@@ -482,7 +484,7 @@ class _Lowerer:
             if isinstance(tmp.key, ConcatKV):
                 return FinalizeOp(out, table, None, ln)
             if isinstance(tmp.key, RecordCons) and all(isinstance(e, WholeKey) for _, e in tmp.key.fields):
-                return FinalizeOp(out, table, [(n, e.which) for n, e in tmp.key.fields], ln)
+                return FinalizeOp(out, table, [(n, e.which) if e.field is None else (n, e.which, e.field) for n, e in tmp.key.fields], ln)
             self.fail(call, "unsupported finalising record")
         self.fail(call, "'%s' is neither a table parameter nor an earlier result" % table)
 

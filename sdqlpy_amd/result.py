@@ -42,6 +42,10 @@ class ResultSet:
         return list(zip(*[a.tolist() for a in self.arrays])) if self.arrays else []
 
     def top(self, k, order):
+        idx = self.top_index(k, order)
+        return ResultSet(self.columns, [a[idx] for a in self.arrays])
+
+    def top_index(self, k, order):
         """ORDER BY ... LIMIT k on the host: order = [(column, "asc" | "desc")], ties keep the stored
         row order (for K-F results that is build-row order, the same total order the device
         operator sdqh_table_topk uses).  Used for results that are small or not device tables."""
@@ -57,8 +61,7 @@ class ResultSet:
                     a = -np.unique(a, return_inverse=True)[1]
             keys.append(a)
         idx = np.lexsort(keys) if keys else np.arange(self._n)         # lexsort is stable
-        idx = idx[:max(0, int(k))]
-        return ResultSet(self.columns, [a[idx] for a in self.arrays])
+        return idx[:max(0, int(k))]
 
     def to_dict(self):
         out = {}

@@ -84,7 +84,10 @@ def _pick(values, width, h):
 
 DERIVED = {   # table -> {column: (dtype, base columns, function(base arrays...) -> array)}
     "orders": {"o_orderpriority": ("U15", ["o_orderkey"], lambda k: _pick(_PRIORITIES, 15, _mix(k, 1)))},
-    "customer": {"c_name": ("U25", ["c_custkey"], lambda k: np.char.add("Customer#", np.char.zfill(k.astype("<U9"), 9)).astype("<U25"))},
+    "customer": {"c_name": ("U25", ["c_custkey"], lambda k: np.char.add("Customer#", np.char.zfill(k.astype("<U9"), 9)).astype("<U25")),
+                 "c_address": ("U40", ["c_custkey"], lambda k: np.char.add(np.char.add(_pick(_TYPE_2, 40, _mix(k, 7)), " "), (_mix(k, 8) % np.uint64(9973)).astype("<U5")).astype("<U40")),
+                 "c_phone": ("U15", ["c_custkey", "c_nationkey"], lambda k, n: np.char.add(np.char.add((n + 10).astype("<U2"), "-"), np.char.zfill((_mix(k, 9) % np.uint64(10 ** 10)).astype("<U10"), 10)).astype("<U15")),
+                 "c_comment": ("U117", ["c_custkey"], lambda k: np.char.add(np.char.add(_pick(_INSTRUCT, 117, _mix(k, 10)), " / "), _pick(_SHIPMODES, 117, _mix(k, 11))).astype("<U117"))},
     "part": {"p_type": ("U25", ["p_partkey"], lambda k: np.char.add(np.char.add(np.char.add(_pick(_TYPE_1, 25, _mix(k, 2)), " "),
                                                                                   np.char.add(_pick(_TYPE_2, 25, _mix(k, 3)), " ")),
                                                                       _pick(_TYPE_3, 25, _mix(k, 4))).astype("<U25"))},
@@ -110,6 +113,9 @@ QUERY_COLUMNS = {
     "q14": {"lineitem": ["l_partkey", "l_shipdate", "l_extendedprice", "l_discount"], "part": ["p_partkey", "p_type"]},
     "q18": {"lineitem": ["l_orderkey", "l_quantity"], "customer": ["c_custkey", "c_name"],
             "orders": ["o_orderkey", "o_custkey", "o_orderdate", "o_totalprice"]},
+    "q10": {"lineitem": ["l_orderkey", "l_returnflag", "l_extendedprice", "l_discount"],
+            "customer": ["c_custkey", "c_name", "c_acctbal", "c_address", "c_nationkey", "c_phone", "c_comment"],
+            "orders": ["o_orderkey", "o_custkey", "o_orderdate"], "nation": ["n_nationkey", "n_name"]},
     "q9": {"lineitem": ["l_orderkey", "l_partkey", "l_suppkey", "l_quantity", "l_extendedprice", "l_discount"],
            "orders": ["o_orderkey", "o_orderdate"], "nation": ["n_nationkey", "n_name"],
            "supplier": ["s_suppkey", "s_nationkey"], "part": ["p_partkey", "p_name"],

@@ -4,7 +4,7 @@ These are the workload, the way SQL text is for a SQL engine: q6, q1, q3 (then q
 with the same combinators, filters and arithmetic as the reference's TPCH script, so that the
 golden results captured from the reference (tests/golden) apply to them verbatim
 (reference test/test_all.py: q1 46-62, q3 145-176, q5 215-281, q6 285-295, q9 431-491; beyond the
-configured five, SURVEY.md §8f.3: q4 180-211, q14 695-716, q18 874-913).
+configured five, SURVEY.md §8f.3: q4 180-211, q10 495-558, q14 695-716, q18 874-913).
 Call ``sdqlpy_init(3)`` (or 1) before running them.
 """
 from .sdql_lib import *      # noqa: F401,F403
@@ -166,6 +166,38 @@ def q18(li, cu, ord):
     return results
 
 
+@sdql_compile({"cu": customer_type, "ord": order_type, "li": lineitem_type, "na": nation_type})
+def q10(cu, ord, li, na):
+    r = "R"
+    na_indexed = na.joinBuild("n_nationkey", lambda p: True, ["n_name"])
+    cu_indexed = cu.joinBuild("c_custkey", lambda p: True,
+                              ["c_custkey", "c_name", "c_acctbal", "c_address", "c_nationkey", "c_phone", "c_comment"])
+    ord_probed = ord.joinProbe(
+        cu_indexed, "o_custkey",
+        lambda p: p[0].o_orderdate >= 19931001 and p[0].o_orderdate < 19940101,
+        lambda indexedDictValue, probeDictKey: {
+            probeDictKey.o_orderkey:
+            record({"c_custkey": indexedDictValue.c_custkey, "c_name": indexedDictValue.c_name,
+                    "c_acctbal": indexedDictValue.c_acctbal, "c_address": indexedDictValue.c_address,
+                    "c_phone": indexedDictValue.c_phone, "c_comment": indexedDictValue.c_comment,
+                    "n_name": na_indexed[indexedDictValue.c_nationkey].n_name})},
+        False)
+    li_probed = li.joinProbe(
+        ord_probed, "l_orderkey",
+        lambda p: p[0].l_returnflag == r,
+        lambda indexedDictValue, probeDictKey: {
+            record({"c_custkey": indexedDictValue.c_custkey, "c_name": indexedDictValue.c_name,
+                    "c_acctbal": indexedDictValue.c_acctbal, "n_name": indexedDictValue.n_name,
+                    "c_address": indexedDictValue.c_address, "c_phone": indexedDictValue.c_phone,
+                    "c_comment": indexedDictValue.c_comment}):
+            probeDictKey.l_extendedprice * (1.0 - probeDictKey.l_discount)},
+        True)
+    results = li_probed.sum(lambda p: {unique(record({
+        "c_custkey": p[0].c_custkey, "c_name": p[0].c_name, "revenue": p[1], "c_acctbal": p[0].c_acctbal,
+        "n_name": p[0].n_name, "c_address": p[0].c_address, "c_phone": p[0].c_phone, "c_comment": p[0].c_comment})): True})
+    return results
+
+
 # positional table order of each query (the decorator dict order == call order)
 QUERY_TABLES = {
     "q6": ["lineitem"],
@@ -176,8 +208,9 @@ QUERY_TABLES = {
     "q4": ["orders", "lineitem"],
     "q14": ["lineitem", "part"],
     "q18": ["lineitem", "customer", "orders"],
+    "q10": ["customer", "orders", "lineitem", "nation"],
 }
-QUERIES = {"q6": q6, "q1": q1, "q3": q3, "q5": q5, "q9": q9, "q4": q4, "q14": q14, "q18": q18}
+QUERIES = {"q6": q6, "q1": q1, "q3": q3, "q5": q5, "q9": q9, "q4": q4, "q14": q14, "q18": q18, "q10": q10}
 
 
 def run(name, db, top=None):
@@ -194,4 +227,5 @@ TPCH_ORDER = {
     "q9": (128, [("nation", "asc"), ("o_year", "desc")]),
     "q4": (100, [("o_orderpriority", "asc")]),
     "q18": (100, [("o_totalprice", "desc"), ("o_orderdate", "asc")]),
+    "q10": (20, [("revenue", "desc")]),
 }

@@ -36,7 +36,7 @@ REF_ROOT = "/root/reference"
 from sdqlpy_amd import tpch  # noqa: E402
 
 QUERIES = ["q1", "q3", "q5", "q6", "q9"]
-MORE_QUERIES = ["q4", "q14", "q18"]       # beyond the configured five (test/test_all.py:180-211, 695-716, 874-913)
+MORE_QUERIES = ["q4", "q10", "q14", "q18"]       # beyond the configured five (test/test_all.py:180-211, 495-558, 695-716, 874-913)
 QUERY_TABLES = {   # positional argument order of each reference query (test/test_all.py decorators)
     "q1": ["lineitem"],
     "q3": ["lineitem", "customer", "orders"],
@@ -46,6 +46,7 @@ QUERY_TABLES = {   # positional argument order of each reference query (test/tes
     "q4": ["orders", "lineitem"],
     "q14": ["lineitem", "part"],
     "q18": ["lineitem", "customer", "orders"],
+    "q10": ["customer", "orders", "lineitem", "nation"],
 }
 ALL_TABLES = ["lineitem", "customer", "orders", "region", "nation", "supplier", "part", "partsupp"]
 

@@ -230,15 +230,18 @@ def test_column_comparisons(hip_engine):
 
 
 def test_queries_beyond_the_configured_five(hip_engine, oracle_engine, golden_more):
-    """q4, q14 and q18: the reference's golden results, then SF=1 against the oracle."""
+    """q4, q10, q14 and q18: the reference's golden results, then SF=1 against the oracle."""
     import helpers
     from sdqlpy_amd import tpch
     for case in golden_more["cases"]:
         for q in case["results"]:
             res = helpers.run_query(hip_engine, q, helpers.case_db(case))
             helpers.check_against_golden(res, case["results"][q], 1e-10, "%s/%s" % (case["name"], q))
-    qs = ("q4", "q14", "q18")
+    qs = ("q4", "q10", "q14", "q18")
     db = tpch.generate(1.0, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+    got10, want10 = helpers.run_query(hip_engine, "q10", db), helpers.run_query(oracle_engine, "q10", db)
+    helpers.assert_rows_match(got10.rows(), want10.rows(), 1e-10, "sf1/q10")
+    assert got10.size() > 10000
     got18, want18 = helpers.run_query(hip_engine, "q18", db), helpers.run_query(oracle_engine, "q18", db)
     assert got18.rows() == want18.rows() and got18.size() > 0
     got4, want4 = helpers.run_query(hip_engine, "q4", db), helpers.run_query(oracle_engine, "q4", db)

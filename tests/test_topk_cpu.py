@@ -40,7 +40,7 @@ def test_topk_arguments_are_checked(oracle):
     t.free()
 
 
-@pytest.mark.parametrize("q", ["q1", "q3", "q5", "q9"])
+@pytest.mark.parametrize("q", ["q1", "q3", "q5", "q9", "q10", "q18"])
 def test_query_top_equals_ordering_the_full_result(oracle, q):
     qs = (q,)
     db = tpch.generate(0.02, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
@@ -95,3 +95,21 @@ def test_result_set_has_the_reference_containers_surface(oracle, capsys):
     assert back.size() == 5
     with pytest.raises(KeyError):
         res.get(record({"nope": 1}))
+
+
+def test_q10_row_reference_merge_paths_agree(oracle, monkeypatch):
+    """Q10 aggregates per matched order and folds the orders of one customer afterwards on the row
+    references: the bucketed merge and the sort-based one (large reference rectangles) agree."""
+    qs = ("q10",)
+    db = tpch.generate(0.05, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+    plan = frontend.lower_function(Q.q10.__sdql_func__, Q.q10.__sdql_in_type__)
+    args = [db[t] for t in Q.QUERY_TABLES["q10"]]
+    want = engine.execute_plan(oracle, plan, args)
+    top_want = engine.execute_plan(oracle, plan, args, top=Q.TPCH_ORDER["q10"])
+    monkeypatch.setattr(engine, "_DENSE_MERGE_CELLS", 0)
+    got = engine.execute_plan(oracle, plan, args)
+    assert got.columns == want.columns and got.size() == want.size() > 100
+    for a, b in zip(got.rows(), want.rows()):
+        assert a[:2] == b[:2] and a[3:] == b[3:] and abs(a[2] - b[2]) <= 1e-12 * abs(b[2])
+    top_got = engine.execute_plan(oracle, plan, args, top=Q.TPCH_ORDER["q10"])
+    assert [r[0] for r in top_got.ordered_rows()] == [r[0] for r in top_want.ordered_rows()]

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define SDQH_ABI_VERSION 2   /* 2: sdqh_filter carries column-vs-column predicates; string modes 3 / 4 */
+#define SDQH_ABI_VERSION 3   /* 2: sdqh_filter carries column-vs-column predicates; string modes 3 / 4.  3: sdqh_table_share_groups */
 
 /* ---- status codes ---------------------------------------------------------------------- */
 #define SDQH_OK              0
@@ -250,6 +250,20 @@ int sdqh_groupby_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, co
  * sdqh_groupby_key and the direct layout of sdqh_hash_build_unique produce); SDQH_ERR_UNSUPPORTED otherwise. */
 int sdqh_table_select_keys(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, int value_index,
                            double lo, double hi, sdqh_table** out);
+
+/* The aggregating probe whose output key is made of fields of the matched entry only, not of the
+ * probe key (Q10: lineitem probes the order -> customer-fields dictionary and sums revenue per
+ * customer record, test/test_all.py:524-541; emitted as the aggregating-dict loop
+ * ...generator_par.py:402-440 keyed by `indexedDictValue` fields): entries of an accumulating table
+ * whose payload fields fields[0..nfields) are all equal form ONE group.  After this call rows that
+ * match any entry of a group (sdqh_hash_probe_aggregate) are added to the group's first entry
+ * (lowest build row); the other entries keep zero hits, so K-F / top-k with min_hits >= 1 return one
+ * entry per group.  Field i takes values in [lo[i], lo[i] + span[i]) (row references, dictionary
+ * codes); an entry with a value outside keeps its own accumulators.  The product of the spans is
+ * limited to SDQH_MAX_SHARE_CELLS (SDQH_ERR_UNSUPPORTED beyond).  Call before the first aggregate. */
+#define SDQH_MAX_SHARE_CELLS (1ll << 28)
+int sdqh_table_share_groups(sdqh_ctx* ctx, sdqh_table* table, int nfields, const int32_t* fields,
+                            const int64_t* lo, const int64_t* span);
 
 /* ---- K-F: compact the entries that received at least min_hits rows into host arrays ---------
  * out_keys[i], out_payload[p*capacity + i] (8 raw bytes each), out_values[v*capacity + i],

@@ -41,6 +41,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 // ---------------------------------------------------------------------------------------------
@@ -112,6 +113,7 @@ struct sdqh_table {
     std::vector<int64_t> payload;                    // entry * npayload + p (raw 8 bytes)
     bool accumulate = false;
     std::vector<Acc> acc;                            // entry -> accumulators + hits
+    std::vector<int64_t> alias;                      // sdqh_table_share_groups: entry -> entry whose accumulators it uses
     // bitmap-only membership table (sdqh_table_from_bitmap)
     bool bitmap_only = false;
     int64_t bm_lo = 0, bm_hi = -1;
@@ -605,6 +607,7 @@ int sdqh_hash_probe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* f
             if (!fv.pass(r)) continue;
             int64_t ent = table->index.find(kc[r]);                  // contains + at: generator 86-96
             if (ent < 0) continue;
+            if (!table->alias.empty()) ent = table->alias[(size_t)ent];
             int64_t li = L.idx.find_or_insert(ent, (int64_t)L.entry.size());
             if (li < 0) { li = (int64_t)L.entry.size(); L.entry.push_back(ent); L.acc.push_back(Acc{}); }
             tv.eval(r, v);
@@ -657,6 +660,36 @@ int sdqh_groupby_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, co
     if (int rc = sdqh_hash_build_unique(ctx, nrows, filter, 0, nullptr, key, 0, nullptr, 1, &tb)) return rc;
     if (int rc = sdqh_hash_probe_aggregate(ctx, nrows, filter, tb, key, tuple)) { delete tb; return rc; }
     *out = tb;
+    return SDQH_OK;
+}
+
+// Groups named by fields of the matched entry (Q10, test/test_all.py:524-541): entries with equal
+// payload fields use the first such entry's accumulators.
+int sdqh_table_share_groups(sdqh_ctx* ctx, sdqh_table* table, int nfields, const int32_t* fields, const int64_t* lo, const int64_t* span) {
+    if (!ctx || !table || !fields || !lo || !span) return fail(ctx, SDQH_ERR_INVALID, "table_share_groups: bad arguments");
+    if (!table->accumulate || table->bitmap_only) return fail(ctx, SDQH_ERR_INVALID, "table_share_groups: the table carries no accumulators");
+    if (nfields < 1 || nfields > table->npayload) return fail(ctx, SDQH_ERR_INVALID, "table_share_groups: 1..npayload fields");
+    uint64_t cells = 1;
+    for (int i = 0; i < nfields; ++i) {
+        if (fields[i] < 0 || fields[i] >= table->npayload) return fail(ctx, SDQH_ERR_INVALID, "table_share_groups: no such payload field");
+        if (span[i] < 1) return fail(ctx, SDQH_ERR_INVALID, "table_share_groups: empty value range");
+        if ((uint64_t)span[i] > (uint64_t)SDQH_MAX_SHARE_CELLS || cells * (uint64_t)span[i] > (uint64_t)SDQH_MAX_SHARE_CELLS)
+            return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_share_groups: the fields' value rectangle exceeds SDQH_MAX_SHARE_CELLS");
+        cells *= (uint64_t)span[i];
+    }
+    const size_t n = table->keys.size();
+    table->alias.resize(n);
+    std::unordered_map<uint64_t, int64_t> first;
+    for (size_t e = 0; e < n; ++e) {                                  // entries are in build-row order: the first one met is the lowest row
+        bool inside = true;
+        uint64_t cell = 0;
+        for (int i = 0; i < nfields; ++i) {
+            const int64_t v = table->payload[e * (size_t)table->npayload + (size_t)fields[i]] - lo[i];
+            inside = inside && v >= 0 && v < span[i];
+            cell = cell * (uint64_t)span[i] + (uint64_t)v;
+        }
+        table->alias[e] = inside ? first.emplace(cell, (int64_t)e).first->second : (int64_t)e;
+    }
     return SDQH_OK;
 }
 

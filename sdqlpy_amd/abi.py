@@ -10,7 +10,8 @@ import math
 
 import numpy as np
 
-ABI_VERSION = 2            # include/sdqh.h: SDQH_ABI_VERSION (struct layouts below must match the library's)
+MAX_SHARE_CELLS = 1 << 28  # SDQH_MAX_SHARE_CELLS
+ABI_VERSION = 3            # include/sdqh.h: SDQH_ABI_VERSION (struct layouts below must match the library's)
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_OVERFLOW, ERR_NOMEM = range(6)
 I64, F64, STR = 0, 1, 2
 TUPLE_A, TUPLE_AB, TUPLE_A_1MB, TUPLE_PRICING, TUPLE_A_1MB_M_CD, TUPLE_COUNT = 1, 2, 3, 4, 5, 6
@@ -125,7 +126,7 @@ EXPORTS = [
     "sdqh_stream", "sdqh_set_option",
     "sdqh_column_upload", "sdqh_column_wrap", "sdqh_column_alloc", "sdqh_column_download", "sdqh_column_data",
     "sdqh_column_rows", "sdqh_column_dtype", "sdqh_column_width", "sdqh_column_minmax", "sdqh_column_free",
-    "sdqh_scan_filter_sum", "sdqh_scan_probe_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_build_key_set", "sdqh_groupby_key", "sdqh_table_select_keys", "sdqh_table_size", "sdqh_table_free",
+    "sdqh_scan_filter_sum", "sdqh_scan_probe_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_build_key_set", "sdqh_groupby_key", "sdqh_table_select_keys", "sdqh_table_share_groups", "sdqh_table_size", "sdqh_table_free",
     "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_scan_compact", "sdqh_partition_by_key",
     "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in",
     "sdqh_build", "sdqh_lookup_aggregate", "sdqh_table_entries", "sdqh_host_alloc", "sdqh_host_free", "sdqh_table_topk",
@@ -446,6 +447,13 @@ class Context:
         self._check(self.lib.sdqh_table_select_keys(self.handle, table.handle, C.c_int64(min_hits), C.c_int(value_index), C.c_double(lo), C.c_double(hi), C.byref(h)))
         self._after_call("table_select_keys")
         return Table(self, h, 0, False)
+
+    def table_share_groups(self, table, fields, lo, span):
+        """Entries with equal payload `fields` (values in [lo, lo + span) each) share one accumulator from now on."""
+        n = len(fields)
+        self._check(self.lib.sdqh_table_share_groups(self.handle, table.handle, C.c_int(n), (C.c_int32 * max(n, 1))(*fields),
+                                                     (C.c_int64 * max(n, 1))(*lo), (C.c_int64 * max(n, 1))(*span)))
+        self._after_call("table_share_groups")
 
     def build(self, nrows, flt, lookups, key, payload=(), accumulate=False):
         """Generalised unique build: lookups [(Table, [key sources])], key [1-2 sources], payload [sources]."""

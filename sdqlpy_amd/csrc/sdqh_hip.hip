@@ -1142,6 +1142,42 @@ int sdqh_groupby_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, co
     return SDQH_OK;
 }
 
+int sdqh_table_share_groups(sdqh_ctx* ctx, sdqh_table* table, int nfields, const int32_t* fields, const int64_t* lo, const int64_t* span) {
+    if (!ctx || !table || !fields || !lo || !span) return fail(ctx, SDQH_ERR_INVALID, "table_share_groups: bad arguments");
+    if (!table->accumulate || table->bitmap_only) return fail(ctx, SDQH_ERR_INVALID, "table_share_groups: the table carries no accumulators");
+    if (nfields < 1 || nfields > table->npay) return fail(ctx, SDQH_ERR_INVALID, "table_share_groups: 1..npayload fields");
+    DevShare sh; std::memset(&sh, 0, sizeof(sh));
+    sh.n = nfields;
+    uint64_t cells = 1;
+    for (int i = 0; i < nfields; ++i) {
+        if (fields[i] < 0 || fields[i] >= table->npay) return fail(ctx, SDQH_ERR_INVALID, "table_share_groups: no such payload field");
+        if (span[i] < 1) return fail(ctx, SDQH_ERR_INVALID, "table_share_groups: empty value range");
+        if ((uint64_t)span[i] > (uint64_t)SDQH_MAX_SHARE_CELLS || cells * (uint64_t)span[i] > (uint64_t)SDQH_MAX_SHARE_CELLS)
+            return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_share_groups: the fields' value rectangle exceeds SDQH_MAX_SHARE_CELLS");
+        cells *= (uint64_t)span[i];
+        sh.col[i] = table->stage.pay[fields[i]]; sh.lo[i] = lo[i]; sh.span[i] = span[i];
+    }
+    (void)hipSetDevice(ctx->device);
+    call_begin(ctx);
+    if (int rc = ensure_index(ctx, table)) return rc;
+    const DevStage& st = table->stage;
+    const uint64_t stage_rows = (uint64_t)st.nseg * (uint64_t)st.seg_rows;
+    uint32_t* first = static_cast<uint32_t*>(pool_alloc(ctx, cells * 4 + 64));
+    uint32_t* alias = static_cast<uint32_t*>(table_alloc(ctx, table, stage_rows * 4 + 64));
+    if (!first || !alias) { if (first) pool_free(ctx, first); return fail(ctx, SDQH_ERR_NOMEM, "table_share_groups: out of device memory"); }
+    { FillList fl; fl.add(first, (cells * 4 + 15) & ~(uint64_t)15, 0xFF); launch_fill(ctx, fl); }
+    const unsigned grid = (unsigned)((st.nseg + TPB / WAVE - 1) / (TPB / WAVE));
+    LAUNCH(ctx, "k_share_groups", k_share_groups<true>, grid, table->dev, st, sh, first, alias);
+    LAUNCH(ctx, "k_share_groups", k_share_groups<false>, grid, table->dev, st, sh, first, alias);
+    table->dev.alias = alias;
+    table->compact_valid = false;
+    call_end(ctx);
+    hipError_t e = hipGetLastError();
+    pool_free(ctx, first);                               // stream order: later users of the block run after the two kernels
+    if (e != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, std::string("table_share_groups launch: ") + hipGetErrorString(e));
+    return SDQH_OK;
+}
+
 int sdqh_table_select_keys(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_hits, int value_index, double lo, double hi, sdqh_table** out) {
     sdqh_table* table = const_cast<sdqh_table*>(ctable);
     if (!ctx || !table || !out || value_index < 0 || value_index >= SDQH_TUPLE_MAX_VALUES) return fail(ctx, SDQH_ERR_INVALID, "table_select_keys: bad arguments");

@@ -112,6 +112,7 @@ struct DevTable {
     uint32_t* dense_arr;      // dense layout: dense_arr[key - bm_lo] = build row (NO_ROW if absent), bm == null
     int64_t lin_rb, lin_b0;   // lin_rb != 0: composite key (a << 32 | b) with a small a-range x b-range: bm is exact over the
                               //    linearised offset (a - bm_lo) * lin_rb + (b - lin_b0) (direct layout, bm_shift == 0)
+    const uint32_t* alias;    // sdqh_table_share_groups: stage row -> the stage row whose accumulators it uses, or null
 };
 
 // offset of `key` in a bitmap described by bm_lo / bm_hi / bm_shift / lin_rb / lin_b0 (DevTable or DevStage); false = out of range
@@ -1321,6 +1322,36 @@ __global__ __launch_bounds__(TPB) void k_count(DevStage st, DevTable t) {
     if (lane_id() == 0 && n) atomicAdd(reinterpret_cast<unsigned long long*>(&t.hdr->counted), n);
 }
 
+// sdqh_table_share_groups: entries whose payload fields agree become one group.  Pass 1 finds the
+// lowest owning stage row of every cell of the fields' value rectangle (atomicMin), pass 2 points every
+// stage row at it.  One wave per stage segment, as the compaction; 4 + 8 * nfields bytes per entry.
+struct DevShare { const int64_t* col[SDQH_MAX_PAYLOAD]; int64_t lo[SDQH_MAX_PAYLOAD], span[SDQH_MAX_PAYLOAD]; int32_t n, _pad; };
+template <bool FIRST>
+__global__ __launch_bounds__(TPB) void k_share_groups(DevTable t, DevStage st, DevShare s, uint32_t* __restrict__ first, uint32_t* __restrict__ alias) {
+    const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
+    if (seg >= st.nseg) return;
+    const uint64_t mask = table_is_direct(t) ? 0 : t.hdr->cap_mask;
+    const int64_t base = (int64_t)seg * st.seg_rows;
+    const uint32_t count = st.seg_count[seg];
+    for (uint32_t i = lane_id(); i < count; i += WAVE) {
+        const int64_t idx = base + i;
+        bool inside = true;
+        uint64_t cell = 0;
+#pragma unroll
+        for (int q = 0; q < SDQH_MAX_PAYLOAD; ++q) if (q < s.n) {
+            const int64_t v = s.col[q][idx] - s.lo[q];
+            inside = inside && v >= 0 && v < s.span[q];
+            cell = cell * (uint64_t)s.span[q] + (uint64_t)v;
+        }
+        if (FIRST) {
+            if (inside && stage_row_owns(st, t, idx, mask)) atomicMin(&first[cell], (uint32_t)idx);
+        } else {
+            const uint32_t a = inside ? first[cell] : NO_ROW;
+            alias[idx] = a == NO_ROW ? (uint32_t)idx : a;
+        }
+    }
+}
+
 // =================================================================================================
 // K-C large: probe + aggregate into the matched entry.  The date-like first predicate and the probe
 // key are streamed with 16-byte loads, PROBE_UNROLL pairs per lane in flight; the bitmap word, the
@@ -1340,7 +1371,8 @@ __device__ __forceinline__ void probe_add(const DevFilter& f, const DevTuple& t,
     for (int j = 0; j < NOPS; ++j) x[j] = t.op[j][r];
     if (!operand_ranges<NOPS>(f, x)) return;
     tuple_eval<SHAPE>(x, o);
-    const uint32_t idx = table_ref(tb, pos);
+    uint32_t idx = table_ref(tb, pos);
+    if (tb.alias) idx = tb.alias[idx];
 #pragma unroll
     for (int k = 0; k < NV; ++k) atomicAdd(&tb.sacc[(size_t)idx * 4 + k], o[k]);
     atomicAdd(&tb.shits[idx], 1u);
@@ -1372,7 +1404,10 @@ __device__ __forceinline__ void probe_drain(const DevFilter& f, const DevTuple& 
             double x[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < NOPS; ++j) x[j] = t.op[j][r];
-            if (operand_ranges<NOPS>(f, x)) { tuple_eval<SHAPE>(x, o); idx = table_ref(tb, pos); cnt = 1; }
+            if (operand_ranges<NOPS>(f, x)) {
+                tuple_eval<SHAPE>(x, o); idx = table_ref(tb, pos); cnt = 1;
+                if (tb.alias) idx = tb.alias[idx];                 // entries of one group share the first one's accumulators
+            }
         }
     }
     const uint32_t prev = __shfl_up(idx, 1, WAVE);

@@ -393,6 +393,8 @@ class _Src:
         self.kind, self.col, self.lookup, self.field, self.year, self.decoder, self.dtype = kind, col, lookup, field, year, decoder, dtype
 
     key_src = None        # lookup kind: the source of the lookup's (single) key — what a field that IS the table's key reads
+    host = None           # col kind, plain int column: the host array (its value range is known)
+    is_rowid = False      # col kind: the row number of the scanned table
 
     def _is_key_field(self, bt):
         return self.kind == "lookup" and self.key_src is not None and bt.slot_of(self.field) == "key"
@@ -429,8 +431,12 @@ def _source_of(eng, op, htab, e, lookups, as_group_key=False):
             coded = eng.dict_column(arr) if as_group_key else None
             if coded is not None:                                # group key: dictionary codes, one group per distinct text
                 return _Src("col", col=coded[0], decoder=coded[1], dtype=np.dtype(np.int64))
-            return _Src("col", col=eng.rowid_column(htab.nrows), decoder=arr, dtype=np.dtype(np.int64))
-        return _Src("col", col=eng.column(arr), dtype=arr.dtype)
+            src = _Src("col", col=eng.rowid_column(htab.nrows), decoder=arr, dtype=np.dtype(np.int64))
+            src.is_rowid, src.host = True, (0, htab.nrows)
+            return src
+        src = _Src("col", col=eng.column(arr), dtype=arr.dtype)
+        src.host = arr if arr.dtype == np.int64 else None
+        return src
     if isinstance(e, PayloadField):
         return _Src("lookup", lookup=idx_of(e.lookup), field=e.field)
     if isinstance(e, Lookup):
@@ -525,6 +531,13 @@ def _prepare_general(eng, op, htab, flt, contains_lookups, accumulate_into=()):
             bt = BuiltTable(table, key_names[0], key_is_record, val_fields, val_is_record, [slot_dtype[j] for j in range(len(uniq))])
             bt.decoders = slot_decoder
             bt.field_decoders = {fname: info[0] for (fname, _), info in zip(stored, infos) if info[0] is not None}
+            bt.slot_roots, bt.slot_plain = {}, {}           # what each payload slot is a function of (see _share_spec)
+            for j, src in zip(slot_idx, pay_srcs):
+                if j not in bt.slot_roots:
+                    bt.slot_roots[j] = _roots_of(src, env, lookups, lookup_keys)
+                    rng = _plain_range(eng, src, env, lookups)
+                    if rng is not None:
+                        bt.slot_plain[j] = rng
             if len(key_srcs) == 2:
                 bt.key_parts = key_names
             bt.key_decoder = key_srcs[0].decode_info(op, env, lookups)[0] if len(key_srcs) == 1 else None
@@ -834,10 +847,86 @@ def _prepare_scan(eng, op, htab, accumulate_into, member_only=False):
             bt.agg_spec = out_key_fields                # the group is the matched entry whether or not its key is among the output fields
         if not bt.table.accumulate or bt.agg is not None:
             raise UnsupportedQuery("line %d: table '%s' cannot take this aggregation" % (op.lineno, probe_name))
+        if not any(src == "key" for _, src in bt.agg_spec):
+            # the output key names fields of the matched entry only (Q10: customer fields of an order):
+            # entries whose row references agree form one group on the device
+            share = _share_spec(eng, bt)
+            if share is not None:
+                ctx.table_share_groups(bt.table, *share)
+                bt.shared_groups = True
         ctx.hash_probe_aggregate(n, flt, bt.table, kcol, tup)
         bt.agg = (bt.agg_spec, vnames, count_idx, key_is_record, val_is_record, tup.shape)
         return ("aggregated", probe_name)
     return run_probe_aggregate
+
+
+def _roots_of(src, env, lookups, lookup_keys):
+    """The columns of the scanned row a payload source is a function of ("row": the row number)."""
+    if src.kind == "col":
+        return frozenset(["row" if src.is_rowid else id(src.col)])
+    if src._is_key_field(env[lookups[src.lookup].dict_name]):
+        return _roots_of(src.key_src, env, lookups, lookup_keys)
+    out = frozenset()
+    for k in lookup_keys[src.lookup]:
+        out |= _roots_of(k, env, lookups, lookup_keys)
+    return out
+
+
+def _plain_range(eng, src, env, lookups):
+    """(lo, span) when the source is a plain int column of the scanned row (possibly read as the key
+    of a looked-up entry) or its row number — a value that identifies its root; None otherwise."""
+    while src.kind == "lookup":
+        if not src._is_key_field(env[lookups[src.lookup].dict_name]):
+            return None
+        src = src.key_src
+    if src.host is None or src.decoder is not None and not src.is_rowid:
+        return None
+    if src.is_rowid:
+        return 0, max(1, src.host[1])
+    cache = eng.__dict__.setdefault("_range_cache", {})
+    hit = cache.get(id(src.host))
+    if hit is None or hit[0] is not src.host:
+        arr = src.host
+        hit = cache[id(arr)] = (arr, (int(arr.min()), int(arr.max()) - int(arr.min()) + 1) if len(arr) else (0, 1))
+    return hit[1]
+
+
+def _share_spec(eng, bt):
+    """(fields, lo, span) for sdqh_table_share_groups: the payload slots that determine the output
+    record of an aggregation keyed by entry fields only.  A slot holding a plain column of the
+    build's scanned row (Q10: o_custkey, read as the key of the looked-up customer entry) identifies
+    that column's value, and every slot computed from the same columns (fields of the looked-up
+    entry, of entries looked up through them) follows from it.  Slots not covered that way must be
+    row references / dictionary codes whose decoder has no repeated value.  None: fold on the host."""
+    fields_of = getattr(bt, "agg_fields", {})
+    roots, plain = getattr(bt, "slot_roots", None), getattr(bt, "slot_plain", {})
+    slots = sorted({src for _, src in bt.agg_spec})
+    if roots is None:
+        return None
+    group = [s for s in slots if s in plain]
+    covered = frozenset().union(*[roots[s] for s in group]) if group else frozenset()
+    lo, span = [plain[s][0] for s in group], [plain[s][1] for s in group]
+    for slot in slots:
+        if slot in plain or "row" in covered or roots[slot] <= covered:
+            continue
+        decs = [bt.decoder_of(fields_of.get(fname), src) for fname, src in bt.agg_spec if src == slot]
+        if any(d is None for d in decs) or not any(_distinct_cached(eng, d) for d in decs):
+            return None
+        group.append(slot); lo.append(0); span.append(max(1, max(len(d) for d in decs)))
+    cells = 1
+    for w in span:
+        cells *= w
+    if not group or cells > abi.MAX_SHARE_CELLS:
+        return None
+    return group, lo, span
+
+
+def _distinct_cached(eng, arr):
+    cache = eng.__dict__.setdefault("_distinct_cache", {})
+    hit = cache.get(id(arr))
+    if hit is None or hit[0] is not arr:
+        hit = cache[id(arr)] = (arr, _all_distinct(arr))
+    return hit[1]
 
 
 def _compact(eng, table, min_hits, hint_key, **want):
@@ -896,7 +985,7 @@ def _materialize(eng, value, env, hint_key=None, top=None):
     if isinstance(value, tuple) and value and value[0] == "aggregated":
         bt = env[value[1]]
         out_key_fields, vnames, count_idx, key_is_record, val_is_record, shape = bt.agg
-        entry_is_group = any(src == "key" for _, src in out_key_fields)
+        entry_is_group = any(src == "key" for _, src in out_key_fields) or getattr(bt, "shared_groups", False)
         spec = _device_sort_spec(bt, out_key_fields, vnames, count_idx, top[1]) if top is not None and entry_is_group else None
         keys, payload, values, hits, ordered = _fetch_entries(eng, bt.table, 1, hint_key, top, spec, want_hits=count_idx is not None or (spec is not None and any(s[0] == abi.SORT_HITS for s in spec)))
         nv = abi.TUPLE_NVALUES[shape]

@@ -376,6 +376,75 @@ def groupby_key_case(ctx, n=250000, seed=14):
     return checked
 
 
+def share_groups_case(ctx, n_build=40000, n_probe=300000, seed=21):
+    """sdqh_table_share_groups: entries with equal payload fields become one group (Q10: orders of
+    one customer).  Unique and duplicate build keys, dense and sparse key ranges, one and two
+    fields, values outside the declared range, then K-F and top-k.  Checked against numpy
+    (integer-valued doubles: sums are exact in any order)."""
+    import numpy as np
+    import pytest
+    from sdqlpy_amd import abi
+    rng = np.random.default_rng(seed)
+    checked = 0
+    for name, keys in (("dense", rng.permutation(n_build * 2)[:n_build].astype(np.int64) + 100),
+                       ("dups", rng.integers(0, n_build // 2, n_build).astype(np.int64)),
+                       ("sparse", (rng.permutation(n_build).astype(np.int64) << 24) + 3)):
+        for nfields in (1, 2):
+            pa = rng.integers(0, max(4, n_build // 8), n_build).astype(np.int64)          # "customer row"
+            pb = (pa % 5 if nfields == 1 else rng.integers(-1, 4, n_build)).astype(np.int64)   # -1: outside the declared range
+            ck, ca, cb = ctx.upload(keys), ctx.upload(pa), ctx.upload(pb)
+            t = ctx.hash_build_unique(n_build, abi.make_filter(), [], ck, [ca, cb], accumulate=True)
+            fields, lo, span = ([0], [0], [int(pa.max()) + 1]) if nfields == 1 else ([0, 1], [0, 0], [int(pa.max()) + 1, 4])
+            ctx.table_share_groups(t, fields, lo, span)
+            pk = keys[rng.integers(0, n_build, n_probe)].copy()
+            pk[rng.random(n_probe) < 0.2] = -7                                              # misses
+            v = rng.integers(1, 50, n_probe).astype(np.float64)
+            w = rng.integers(0, 10, n_probe).astype(np.int64)
+            flt = abi.make_filter(ipreds=[(ctx.upload(w), 1, 99)])
+            ctx.hash_probe_aggregate(n_probe, flt, t, ctx.upload(pk), abi.make_tuple(abi.TUPLE_A, [ctx.upload(v)]))
+            # expectation: first build row per key owns the entry; groups by the owner's fields
+            uk, first_row = np.unique(keys, return_index=True)
+            ea, eb = pa[first_row], pb[first_row]
+            inside = (eb >= 0) if nfields == 2 else np.ones(len(uk), bool)
+            gid_fields = ea * 16 + (eb if nfields == 2 else 0)
+            rep = {}
+            for e in np.argsort(first_row, kind="stable"):                                 # build-row order
+                if inside[e]:
+                    rep.setdefault(int(gid_fields[e]), int(e))
+            owner_of = np.array([rep[int(g)] if ins else int(e) for e, (g, ins) in enumerate(zip(gid_fields, inside))])
+            ok = (w >= 1) & (pk != -7)
+            ent = np.searchsorted(uk, pk[ok])
+            tgt = owner_of[ent]
+            sums = np.bincount(tgt, weights=v[ok], minlength=len(uk)); counts = np.bincount(tgt, minlength=len(uk))
+            live = counts > 0
+            cnt = ctx.table_compact_count(t, 1)
+            k, pay, vals, hits = ctx.table_compact(t, 1, cnt)
+            order = np.argsort(k)
+            assert k[order].tolist() == uk[live].tolist(), (name, nfields)
+            assert vals[0][order].tolist() == sums[live].tolist() and hits[order].tolist() == counts[live].tolist(), (name, nfields)
+            assert pay[0][order].tolist() == ea[live].tolist() and pay[1][order].tolist() == eb[live].tolist(), (name, nfields)
+            tk, _, tv, _ = ctx.table_topk(t, 1, 5, [(abi.SORT_VALUE, 0, True, True), (abi.SORT_KEY, 0, False, False)])
+            want = sorted(zip((-sums[live]).tolist(), uk[live].tolist()))[:5]
+            assert list(zip((-tv[0]).tolist(), tk.tolist())) == want, (name, nfields)
+            t.free()
+            checked += 1
+    # argument checking
+    ck = ctx.upload(np.arange(10, dtype=np.int64))
+    t = ctx.hash_build_unique(10, abi.make_filter(), [], ck, [ck], accumulate=True)
+    for fields, lo, span, code in (([1], [0], [10], abi.ERR_INVALID), ([0], [0], [0], abi.ERR_INVALID), ([], [], [], abi.ERR_INVALID),
+                                   ([0], [0], [(1 << 28) + 1], abi.ERR_UNSUPPORTED)):
+        with pytest.raises(abi.SdqhError) as e:
+            ctx.table_share_groups(t, fields, lo, span)
+        assert e.value.code == code
+    t.free()
+    plain = ctx.hash_build_unique(10, abi.make_filter(), [], ck, [ck], accumulate=False)
+    with pytest.raises(abi.SdqhError) as e:
+        ctx.table_share_groups(plain, [0], [0], [10])
+    assert e.value.code == abi.ERR_INVALID
+    plain.free()
+    return checked
+
+
 def empty_input_case(ctx):
     """Zero-row inputs through every table-producing entry point and what consumes them."""
     import numpy as np

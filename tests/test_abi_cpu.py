@@ -89,6 +89,15 @@ def test_oracle_key_sets(oracle_lib):
         ctx.close()
 
 
+def test_oracle_share_groups(oracle_lib):
+    from helpers import share_groups_case
+    ctx = oracle_lib.context(threads=3)
+    try:
+        assert share_groups_case(ctx, n_build=6000, n_probe=40000) == 6
+    finally:
+        ctx.close()
+
+
 def test_oracle_groupby_key_and_having(oracle_lib):
     from helpers import groupby_key_case
     ctx = oracle_lib.context(threads=3)

@@ -202,6 +202,13 @@ def test_membership_only_builds(hip_engine):
     assert key_set_case(hip_engine.ctx, n=1000, seed=2) == 5
 
 
+def test_share_groups(hip_engine):
+    """sdqh_table_share_groups: groups named by fields of the matched entry (Q10)."""
+    from helpers import share_groups_case
+    assert share_groups_case(hip_engine.ctx) == 6
+    assert share_groups_case(hip_engine.ctx, n_build=700, n_probe=5000, seed=4) == 6
+
+
 def test_groupby_key_and_having(hip_engine):
     """sdqh_groupby_key (dense-range layout and the staged fallback) and sdqh_table_select_keys."""
     from helpers import groupby_key_case

@@ -97,19 +97,29 @@ def test_result_set_has_the_reference_containers_surface(oracle, capsys):
         res.get(record({"nope": 1}))
 
 
-def test_q10_row_reference_merge_paths_agree(oracle, monkeypatch):
-    """Q10 aggregates per matched order and folds the orders of one customer afterwards on the row
-    references: the bucketed merge and the sort-based one (large reference rectangles) agree."""
+def test_q10_group_sharing_and_host_fold_agree(oracle, monkeypatch):
+    """Q10's output key names customer fields of the matched order.  Default: the orders of one
+    customer share an accumulator on the device (sdqh_table_share_groups), so ORDER BY / LIMIT runs
+    there too.  Without it the entries are folded on the host on the row references — bucketed, or
+    sort-based for large reference rectangles.  All three agree."""
     qs = ("q10",)
     db = tpch.generate(0.05, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
     plan = frontend.lower_function(Q.q10.__sdql_func__, Q.q10.__sdql_in_type__)
     args = [db[t] for t in Q.QUERY_TABLES["q10"]]
+    calls = []
+    real_share, real_topk = oracle.ctx.table_share_groups, oracle.ctx.table_topk
+    monkeypatch.setattr(oracle.ctx, "table_share_groups", lambda *a: (calls.append("share"), real_share(*a))[1])
+    monkeypatch.setattr(oracle.ctx, "table_topk", lambda *a, **k: (calls.append("topk"), real_topk(*a, **k))[1])
     want = engine.execute_plan(oracle, plan, args)
     top_want = engine.execute_plan(oracle, plan, args, top=Q.TPCH_ORDER["q10"])
-    monkeypatch.setattr(engine, "_DENSE_MERGE_CELLS", 0)
-    got = engine.execute_plan(oracle, plan, args)
-    assert got.columns == want.columns and got.size() == want.size() > 100
-    for a, b in zip(got.rows(), want.rows()):
-        assert a[:2] == b[:2] and a[3:] == b[3:] and abs(a[2] - b[2]) <= 1e-12 * abs(b[2])
-    top_got = engine.execute_plan(oracle, plan, args, top=Q.TPCH_ORDER["q10"])
-    assert [r[0] for r in top_got.ordered_rows()] == [r[0] for r in top_want.ordered_rows()]
+    assert calls == ["share", "share", "topk"] and want.size() > 100
+    monkeypatch.setattr(engine, "_share_spec", lambda eng, bt: None)
+    for cells in (1 << 26, 0):
+        monkeypatch.setattr(engine, "_DENSE_MERGE_CELLS", cells)
+        got = engine.execute_plan(oracle, plan, args)
+        assert got.columns == want.columns and got.size() == want.size()
+        for a, b in zip(got.rows(), want.rows()):
+            assert a[:2] == b[:2] and a[3:] == b[3:] and abs(a[2] - b[2]) <= 1e-12 * abs(b[2])
+        top_got = engine.execute_plan(oracle, plan, args, top=Q.TPCH_ORDER["q10"])
+        assert [r[0] for r in top_got.ordered_rows()] == [r[0] for r in top_want.ordered_rows()]
+    assert calls == ["share", "share", "topk"]

@@ -108,6 +108,60 @@ def test_row_order_invariance(hip_engine):
     hip_engine.clear()
 
 
+def test_full_size_properties_sf10(hip_engine):
+    """BASELINE.json's full size (SF=10, 60 M lineitem rows), where the CPU oracle is too slow for a
+    test: properties that hold at any size.  Totals against numpy reductions of the same columns,
+    additivity over a split of the probe side (q(A) + q(B) == q(A ∪ B) group by group), counts exact,
+    a second run identical."""
+    qs = ("q1", "q3", "q5", "q6")
+    db = tpch.generate(10, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+    li = db["lineitem"].getContainer()
+    col = dict(zip(li["headers"], li["data"]))
+    n = len(col["l_shipdate"])
+    assert n > 59_000_000
+    # q6: the scalar against numpy
+    m = (col["l_shipdate"] >= 19940101) & (col["l_shipdate"] < 19950101) & (col["l_discount"] >= 0.05) & (col["l_discount"] <= 0.07) & (col["l_quantity"] < 24.0)
+    want6 = float(np.sum(col["l_extendedprice"][m] * col["l_discount"][m]))
+    got6 = helpers.run_query(hip_engine, "q6", db)
+    assert abs(got6 - want6) <= 1e-9 * abs(want6)
+    # q1: counts exact and totals against numpy; bit-identical when run again
+    q1 = helpers.run_query(hip_engine, "q1", db)
+    m1 = col["l_shipdate"] <= 19980902
+    assert int(q1.column("count_order").sum()) == int(m1.sum())
+    assert abs(float(q1.column("sum_qty").sum()) - float(col["l_quantity"][m1].sum())) <= 1e-9 * float(col["l_quantity"][m1].sum())
+    base = float((col["l_extendedprice"][m1] * (1.0 - col["l_discount"][m1])).sum())
+    assert abs(float(q1.column("sum_disc_price").sum()) - base) <= 1e-9 * base
+    again = helpers.run_query(hip_engine, "q1", db)
+    assert again.rows() == q1.rows()
+    del m, m1
+    # q3 / q5 / q1: additive over a split of lineitem at an odd row (not a tile boundary)
+    cut = n // 2 + 333
+    halves = []
+    for lo, hi in ((0, cut), (cut, n)):
+        part = dict(db)
+        part["lineitem"] = tpch.table_from_columns(li["headers"], [c[lo:hi] for c in li["data"]])
+        halves.append(part)
+    for q in ("q1", "q3", "q5"):
+        whole = helpers.run_query(hip_engine, q, db)
+        value_cols = [c for c in whole.columns if whole.column(c).dtype.kind == "f" or c.startswith("count")]
+        key_cols = [c for c in whole.columns if c not in value_cols]
+        sums = {}
+        for part in halves:
+            r = helpers.run_query(hip_engine, q, part)
+            for row in zip(*[r.column(c).tolist() for c in key_cols + value_cols]):
+                k, v = row[:len(key_cols)], row[len(key_cols):]
+                sums[k] = [a + b for a, b in zip(sums.get(k, [0] * len(v)), v)]
+        want = {row[:len(key_cols)]: row[len(key_cols):] for row in zip(*[whole.column(c).tolist() for c in key_cols + value_cols])}
+        assert sums.keys() == want.keys() and len(want) > 0, q
+        for k, v in want.items():
+            for c, a, b in zip(value_cols, sums[k], v):
+                if isinstance(b, int):
+                    assert a == b, (q, k, c)
+                elif not c.startswith("avg"):                  # averages are not additive
+                    assert abs(a - b) <= 1e-9 * abs(b), (q, k, c, a, b)
+    hip_engine.clear()
+
+
 def test_ragged_sizes(hip_engine, oracle_engine):
     """Row counts around the tile (1024), sub-tile (512), wave (64) and pair (2) boundaries, and empty."""
     base = tpch.generate(0.002, tables=sorted(tpch.columns_for(SUPPORTED)), columns=tpch.columns_for(SUPPORTED))

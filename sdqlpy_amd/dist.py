@@ -21,6 +21,16 @@ SURVEY.md §8(e), written against the same C ABI as the single-GPU path:
             rank then probes / aggregates its own key partition.  Group keys are disjoint across
             ranks, so the result is the concatenation of the ranks' results.
 
+  q5 / q9 / q4 / q14 / q18   the chain executor: builds over a sharded table that another shard's rows look
+            up are replicated (entries all-gathered on device memory, rebuilt), joins whose two sides
+            are co-partitioned on the key stay local (an all-gathered min / max test decides, so every
+            rank decides alike), partial groups over a small domain and partial scalars are folded in
+            rank order.  A row-keyed group-by (q18's sum per l_orderkey), its HAVING key set and a
+            probe-aggregate into a co-partitioned build are local too when the shards are partitioned
+            by that key: each rank finishes the groups of its key partition and the result is the
+            concatenation, as for q3.  Shards that are not partitioned that way are refused (by every
+            rank), as is replicating a build whose text payload refers to one rank's rows.
+
 The collectives carry exactly the bytes that have to move; there is no collective in the data path
 of q1 / q6 beyond the final few hundred bytes.  `backend` only needs all_gather, all_to_all_single
 (or point-to-point for gloo) and barrier, so the same code runs under gloo on CPU tensors with the
@@ -203,21 +213,23 @@ class DistributedRunner:
             k, order = int(top[0]), [(str(n), str(d)) for n, d in top[1]]
             if name == "q6":
                 raise frontend.UnsupportedQuery("top(k) applies to queries that end in a result set")
-            if name == "q3":
-                self._top = (k, order)
-                try:
-                    local = self._run(name, db, whole_tables)
-                finally:
-                    self._top = None
-                cols = [[] for _ in local.columns]
-                out = [None] * self.world
-                dist.all_gather_object(out, [a.tolist() for a in local.arrays], group=self.group)
-                for part in out:                                  # rank order, then each rank's own order
-                    for c, vals in zip(cols, part):
-                        c += vals
-                merged = ResultSet(local.columns, [np.array(c, a.dtype) for c, a in zip(cols, local.arrays)])
-                return merged.top(k, order)
-            return self._run(name, db, whole_tables).top(k, order)
+            # a result partitioned over the ranks (q3; chains that end in a local aggregation, q18): top-k per
+            # rank first, k rows per rank gathered and ordered again.  Global results are ordered as they are.
+            self._top, self._partitioned_result = (k, order), False
+            try:
+                local = self._run(name, db, whole_tables)
+            finally:
+                self._top = None
+            if not self._partitioned_result:
+                return local.top(k, order)
+            cols = [[] for _ in local.columns]
+            out = [None] * self.world
+            dist.all_gather_object(out, [a.tolist() for a in local.arrays], group=self.group)
+            for part in out:                                  # rank order, then each rank's own order
+                for c, vals in zip(cols, part):
+                    c += vals
+            merged = ResultSet(local.columns, [np.array(c, a.dtype) for c, a in zip(cols, local.arrays)])
+            return merged.top(k, order)
         args = [db[t] for t in Q.QUERY_TABLES[name]]
         plan = self._plan(name)
         if name == "q6":
@@ -230,11 +242,10 @@ class DistributedRunner:
         if name == "q1":
             return self._row_sharded_groupby(plan, args)
         if name == "q3":
+            self._partitioned_result = True
             return self._partitioned_join(plan, args)
-        if name == "q18":
-            raise frontend.UnsupportedQuery("q18's group-by on l_orderkey needs the partitioned plan for a row-keyed group-by: not distributed yet")
         whole = {p for p, t in zip(plan.params, Q.QUERY_TABLES[name]) if t in whole_tables}
-        return self._sharded_chain(plan, args, whole)
+        return self._sharded_chain(plan, args, whole, getattr(self, "_top", None))
 
     # ---- multi-join chains (q5, q9): replicate what is probed across shards, keep co-partitioned joins local ----
     def _prepare_chain(self, plan, args, whole):
@@ -263,7 +274,33 @@ class DistributedRunner:
             for lk in found:
                 if lk.dict_name in consumers:
                     consumers[lk.dict_name].append((o, lk))
+        # HAVING key sets (SelectKeysOp over a row-keyed group-by): usable where they are computed only if every
+        # consumer's keys live on the same rank as the groups — the co-partitioning test below, with the
+        # group-by's key column as the build side; a key set cannot be replicated
+        st.local_only = {}                                       # name -> why it must stay local
+        group_ops = {o.out: o for o in scan_ops if o.kind == "dict" and not o.unique and o.probe is None
+                     and isinstance(o.key, Col) and o.table not in whole}
+        select_src = {o.out: group_ops[o.source] for o in plan.ops if isinstance(o, frontend.SelectKeysOp) and o.source in group_ops}
         facts_req = []                                           # (table name, build col array, probe col array)
+        for name, gop in list(group_ops.items()) + list(select_src.items()):
+            garr = tabs[gop.table].array(gop.key.name, gop)
+            st.local_only[name] = "the groups of '%s' are not partitioned by key over the ranks" % name
+            facts_req.append((name, garr, garr))
+        for o in scan_ops:
+            found = []
+            for c in list(o.conds) + [c for _, _, fc in (o.fields or []) for c in fc]:
+                if isinstance(c, frontend.Contains):
+                    engine._walk_lookups(c.lookup, found)
+            if o.probe is not None:
+                engine._walk_lookups(o.probe, found)
+            for lk in found:
+                if lk.dict_name in select_src:
+                    gop = select_src[lk.dict_name]
+                    if o.table in whole or not isinstance(lk.key, Col):
+                        st.local_only[lk.dict_name] = "'%s' is looked up from a table every rank holds whole" % lk.dict_name
+                        facts_req.append((lk.dict_name, np.zeros(0, np.int64), np.zeros(0, np.int64)))
+                    else:
+                        facts_req.append((lk.dict_name, tabs[gop.table].array(gop.key.name, gop), tabs[o.table].array(lk.key.name, o)))
         for name, bop in built_by.items():
             if bop.table in whole:
                 st.replicate[name] = False                       # identical on every rank already
@@ -287,19 +324,49 @@ class DistributedRunner:
                 and all(int(f[5]) == 0 or (int(f[2]) >= int(f[0]) and int(f[3]) <= int(f[1])) for f in facts)
             if not ok:
                 st.replicate[name] = True
-        accumulate_into = set()
+        st.unsupported = None
+        checked = {}
+        for name, _, _ in facts_req:
+            if name in st.local_only:
+                checked[name] = checked.get(name, True) and not st.replicate.get(name, False)
+        for name, ok in checked.items():
+            if not ok:
+                st.unsupported = st.local_only[name]
+            st.replicate.pop(name, None)
+        # a probe-aggregate folds its groups into the probed table: that table carries accumulators, and the
+        # join must be local (co-partitioned) — each rank then holds the finished groups of its key partition
+        accumulate_into = {op.probe.dict_name for op in scan_ops
+                           if op.kind == "dict" and not op.unique and op.probe is not None and op.probe.dict_name in built_by
+                           and engine._is_simple(op, tabs[op.table], [c.lookup for c in op.conds if isinstance(c, frontend.Contains)])}
+        for name in accumulate_into:
+            if st.replicate.get(name) or built_by[name].table in whole:
+                st.unsupported = "the probe-aggregate into '%s' is not local to the ranks' shards: it needs the partitioned-join plan" % name
         for op in plan.ops:
             if isinstance(op, ScanOp):
                 st.steps.append((op, engine._prepare_scan(eng, op, tabs[op.table], accumulate_into)))
             else:
                 st.steps.append((op, None))
         st.sharded = {op.out: (op.table not in whole) for op in scan_ops}
+        # text that only means something on this rank: string columns of sharded tables and their dictionaries
+        st.local_text = set()
+        for p_, t_ in tabs.items():
+            if p_ not in whole:
+                for arr in t_.cols.values():
+                    if arr is not None and arr.dtype.kind == "U":
+                        st.local_text.add(id(arr))
+                        hit = eng._dicts.get(id(arr))
+                        if hit is not None and hit[0] is arr and hit[2] is not None:
+                            st.local_text.add(id(hit[2]))
         return st
 
     def _replicate_table(self, bt):
         """All ranks' entries of a built table on every rank, without leaving device memory:
         entries -> all-gather -> rebuild.  A composite key travels packed; lookups pack the same way."""
         ctx = self.ctx
+        local = getattr(self, "_local_text", set())          # text arrays / dictionaries of this rank's shards (see _prepare_chain)
+        if any(id(d) in local for d in list(bt.decoders.values()) + list(bt.field_decoders.values()) if d is not None):
+            raise frontend.UnsupportedQuery("'%s' carries text as references to this rank's rows: it cannot be replicated yet "
+                                            "(hold its table whole on every rank)" % bt.key_name)
         cols, n = ctx.table_entries(bt.table)
         gathered, total = self._all_gather_columns(cols, n)
         for c in cols:
@@ -312,12 +379,15 @@ class DistributedRunner:
         bt.table.free()
         return new
 
-    def _sharded_chain(self, plan, args, whole):
+    def _sharded_chain(self, plan, args, whole, top=None):
         cache = plan.__dict__.setdefault("_dist_chain", {})
         key = (id(self),) + tuple(id(a) for a in args)
         st = cache.get(key)
         if st is None or st.generation != self.eng.generation or any(x is not y for x, y in zip(st.args, args)):
             st = cache[key] = self._prepare_chain(plan, args, whole)
+        if st.unsupported:
+            raise frontend.UnsupportedQuery(st.unsupported)          # decided from all-gathered facts: every rank raises
+        self._local_text = st.local_text
         env = {}
         try:
             for op, step in st.steps:
@@ -333,11 +403,16 @@ class DistributedRunner:
                         names = sorted(res)
                         parts = self._all_gather_array(np.array([res[k] for k in names], np.float64))
                         res = {k: sum(float(p[j]) for p in parts) for j, k in enumerate(names)}
-                    elif isinstance(res, tuple):
-                        raise frontend.UnsupportedQuery("a fused probe-aggregate needs the partitioned-join plan")
-                    env[op.out] = res
+                    elif isinstance(res, tuple) and st.sharded[op.out] and op.probe is None and op.out not in st.local_only:
+                        raise frontend.UnsupportedQuery("a group-by over a large key domain must be keyed by one column of a sharded table")
+                    env[op.out] = res                            # ("aggregated", table): the finished groups of this rank's key partition
+                elif isinstance(op, frontend.SelectKeysOp):
+                    env[op.out] = engine._select_keys(self.eng, op, env)
                 elif isinstance(op, FinalizeOp):
-                    env[op.out] = engine._finalize(self.eng, op, env)
+                    local_groups = isinstance(env.get(op.source), tuple)           # finished groups of this rank's key partition
+                    if op.out == plan.result:
+                        self._partitioned_result = local_groups
+                    env[op.out] = engine._finalize(self.eng, op, env, top if op.out == plan.result and local_groups else None)
                 elif isinstance(op, frontend.ScalarExprOp):
                     env[op.out] = engine._eval_scalar_expr(op.expr, env, op.lineno)
                 else:

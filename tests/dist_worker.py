@@ -28,7 +28,7 @@ def main(rank, world, port, sf, mode, out_path):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     lib = abi.Library(os.path.join(ROOT, "oracle", "libsdqloracle.so"))
     eng = engine.Engine(lib.context(threads=2))
-    qs = ["q1", "q3", "q5", "q6", "q9", "q4", "q14"]
+    qs = ["q1", "q3", "q5", "q6", "q9", "q4", "q14", "q18"]
     cols = tpch.columns_for(qs)
     if mode == "shuffled":
         # rows of every table dealt to the ranks at random: key ranges overlap -> hash partitioning
@@ -64,6 +64,19 @@ def main(rank, world, port, sf, mode, out_path):
     out["q3_top"] = {"columns": t3.columns, "rows": t3.ordered_rows()}
     t5 = runner.run("q5", db, top=(3, [("revenue", "desc")]))
     out["q5_top"] = {"columns": t5.columns, "rows": t5.ordered_rows()}
+    # q18: row-keyed group-by + HAVING + joins; lineitem / orders sharded, customer (its names travel as
+    # row references) whole on every rank.  Local when the shards are co-partitioned on the order key.
+    import dist_queries
+    dist_queries.register()
+    db18 = dict(db)
+    db18["customer"] = tpch.generate(sf, tables=["customer"], columns=cols, threads=2)["customer"]
+    try:
+        r18 = runner.run("q18_low", db18, whole_tables=("region", "nation", "customer"))
+        out["q18"] = {"columns": r18.columns, "rows": runner.gather_rows(r18), "local_rows": r18.size()}
+        t18 = runner.run("q18_low", db18, whole_tables=("region", "nation", "customer"), top=Q.TPCH_ORDER["q18"])
+        out["q18_top"] = {"columns": t18.columns, "rows": t18.ordered_rows()}
+    except frontend.UnsupportedQuery as exc:
+        out["q18"] = {"unsupported": str(exc)}
     if rank == 0:
         with open(out_path, "w") as fh:
             json.dump(out, fh)

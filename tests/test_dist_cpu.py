@@ -37,9 +37,13 @@ def run_world(mode, tmp_path, world=2):
 @pytest.fixture(scope="module")
 def single(oracle_lib):
     eng = engine.Engine(oracle_lib.context(threads=2))
-    qs = ["q1", "q3", "q5", "q6", "q9", "q4", "q14"]
+    qs = ["q1", "q3", "q5", "q6", "q9", "q4", "q14", "q18"]
     db = tpch.generate(SF, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs), threads=2)
     res = {q: helpers.run_query(eng, q, db) for q in qs}
+    import dist_queries
+    dist_queries.register()
+    res["q18"] = helpers.run_query(eng, "q18_low", db)          # q18 with a threshold that leaves rows at this scale
+    assert res["q18"].size() > 3
     eng.close()
     return res
 
@@ -68,6 +72,17 @@ def test_two_ranks_match_single_process(mode, tmp_path, single, oracle_lib):
         assert len(got[q + "_top"]["rows"]) == len(want_rows) == min(top[0], single[q].size())
         assert [r[0] for r in got[q + "_top"]["rows"]] == [r[0] for r in want_rows], mode + "/" + q + "_top order"
         helpers.assert_rows_match(as_rows(got[q + "_top"]["rows"]), want_rows, 1e-12, mode + "/" + q + "_top")
+    # q18 (row-keyed group-by, HAVING, joins): local when lineitem and orders are co-partitioned on the order
+    # key, each rank returning its partition's groups; refused — by every rank alike — otherwise
+    if mode in ("range", "hash"):                               # the same co-partitioned shards ("hash" only forces q3's exchange)
+        cols = got["q18"]["columns"]
+        helpers.assert_rows_match(sorted(as_rows(got["q18"]["rows"])), helpers.result_rows(single["q18"], cols), 1e-12, mode + "/q18")
+        assert 0 <= got["q18"]["local_rows"] <= len(got["q18"]["rows"]) and len(got["q18"]["rows"]) > 0
+        want = single["q18"].top(*Q.TPCH_ORDER["q18"])
+        tcols = got["q18_top"]["columns"]
+        helpers.assert_rows_match(as_rows(got["q18_top"]["rows"]), list(zip(*[want.column(c).tolist() for c in tcols])), 1e-12, mode + "/q18_top")
+    else:
+        assert "unsupported" in got["q18"], got["q18"]
     if mode == "range":
         # dbgen-shaped shards are co-clustered on o_orderkey: nothing has to move
         assert got["q3"]["partitioning"] == "range" and got["q3"]["exchanged"]["probe_sent"] == 0
@@ -87,6 +102,7 @@ def test_four_ranks_match_single_process(tmp_path, single, oracle_lib):
         helpers.assert_rows_match(sorted(as_rows(got[q]["rows"])), helpers.result_rows(single[q], got[q]["columns"]), 1e-12, "world4/" + q)
     assert abs(got["q14"] - single["q14"]) <= 1e-12 * abs(single["q14"])
     assert got["q3"]["partitioning"] == "hash" and got["q3"]["exchanged"]["probe_sent"] > 0
+    assert "unsupported" in got["q18"]                         # every rank refuses alike: groups and joins would span ranks
 
 
 def test_bench_contract_under_a_two_rank_launch(tmp_path):

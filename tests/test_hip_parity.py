@@ -429,6 +429,8 @@ def test_distributed_runner_world1_nccl(hip_lib, golden, golden_more):
         runner = sdist.DistributedRunner(eng, 0, 1)
         for q in ("q4", "q14"):                              # the chain executor beyond q5 / q9
             helpers.check_against_golden(runner.run(q, db), more["results"][q], REL, "dist1/%s" % q)
+        # q18: row-keyed group-by, HAVING key set and a local probe-aggregate; customer (text payload) held whole
+        helpers.check_against_golden(runner.run("q18", db, whole_tables=("region", "nation", "customer")), more["results"]["q18"], REL, "dist1/q18")
         top = runner.run("q3", helpers.case_db(case), top=(10, [("revenue", "desc"), ("o_orderdate", "asc")]))
         assert top.size() == 10 and top.column("revenue").tolist() == sorted(top.column("revenue").tolist(), reverse=True)
     finally:

@@ -341,9 +341,12 @@ class DistributedRunner:
         for name in accumulate_into:
             if st.replicate.get(name) or built_by[name].table in whole:
                 st.unsupported = "the probe-aggregate into '%s' is not local to the ranks' shards: it needs the partitioned-join plan" % name
+        # builds that only answer `tbl[k] != None` and stay on their rank are key sets, as on one GPU
+        # (a key set has no entries to export, so one that must be replicated stays an ordinary table)
+        member_only = {name for name in engine._membership_only(plan) if not st.replicate.get(name, False)}
         for op in plan.ops:
             if isinstance(op, ScanOp):
-                st.steps.append((op, engine._prepare_scan(eng, op, tabs[op.table], accumulate_into)))
+                st.steps.append((op, engine._prepare_scan(eng, op, tabs[op.table], accumulate_into, op.out in member_only)))
             else:
                 st.steps.append((op, None))
         st.sharded = {op.out: (op.table not in whole) for op in scan_ops}

@@ -1716,7 +1716,8 @@ __device__ __forceinline__ bool first_lookup_may_hit(const DevLookups& L, int64_
 constexpr int BUILD_LB = 4;                                           // 128-row batches per step of k_build_lookup
 constexpr int LOOKUP_PU = 2;                                          // row pairs per lane in flight in k_lookup_agg's streaming part.  Measured the same on Q9 (0.78 ms): 4 pairs;
                                                                       // streaming every gathered column through the LDS queue instead of gathering it (0.87 ms); key, row reference
-                                                                      // and payloads of a hash entry in one 32-byte slot, i.e. one line per probe instead of four (0.79 ms)
+                                                                      // and payloads of a hash entry in one 32-byte slot, i.e. one line per probe instead of four (0.79 ms); every
+                                                                      // plain-column key part and operand of a candidate requested before the lookup chain (0.78 ms).  DESIGN.md §7
 constexpr int LQ_CAP = 192;                                           // 63 left over + 128 appended per pair step
 
 struct DevBuildSpec {                                                 // what a surviving row contributes to the build

@@ -793,6 +793,7 @@ static int setup_stage(sdqh_ctx* ctx, sdqh_table* tb, int64_t nrows, const sdqh_
     st.seg_count = static_cast<uint32_t*>(table_alloc(ctx, tb, (size_t)st.nseg * 4 + 64));
     st.shits = static_cast<uint32_t*>(table_alloc(ctx, tb, (size_t)std::max<int64_t>(nrows, 1) * 4 + 64));
     ok = ok && st.seg_count != nullptr && st.shits != nullptr;
+    st.acc_stride = 4;                                   // the tuple is not known yet: room for every shape
     if (ok && tb->accumulate) { st.sacc = static_cast<double*>(table_alloc(ctx, tb, (size_t)std::max<int64_t>(nrows, 1) * 32 + 64)); ok = st.sacc != nullptr; }
     if (!ok) return fail(ctx, SDQH_ERR_NOMEM, "out of device memory for the build stage");
     return SDQH_OK;
@@ -924,7 +925,7 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
         if (want_bm && ctx->opt_direct_index) { tb->nwords = ((uint64_t)(hi - lo) + 32) / 32; tb->bm = static_cast<uint32_t*>(table_alloc(ctx, tb, tb->nwords * 4 + 64)); }
         if (!tb->hdr || (tb->nwords && !tb->bm)) rc = fail(ctx, SDQH_ERR_NOMEM, "hash_build_unique: out of device memory");
         else {
-            tb->dev.hdr = tb->hdr; tb->dev.shits = tb->stage.shits; tb->dev.sacc = tb->stage.sacc;
+            tb->dev.hdr = tb->hdr; tb->dev.shits = tb->stage.shits; tb->dev.sacc = tb->stage.sacc; tb->dev.acc_stride = tb->stage.acc_stride;
             tb->dev.bm = tb->bm; tb->dev.bm_lo = lo; tb->dev.bm_hi = hi; tb->dev.bitmap_only = 0; tb->dev.bm_shift = 0;
             for (int p = 0; p < npayload; ++p) tb->dev.pay[p] = tb->stage.pay[p];
             tb->stage.bm = tb->bm; tb->stage.bm_lo = lo; tb->stage.bm_hi = hi; tb->stage.hdr = tb->hdr; tb->stage.bm_shift = 0;
@@ -1053,6 +1054,7 @@ int sdqh_hash_probe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* f
     if (int rc = make_tuple(ctx, nrows, tuple, &t)) return rc;
     if (int rc = make_filter(ctx, nrows, filter, tuple, &f)) return rc;
     if (int rc = check_col(ctx, key, SDQH_I64, nrows, "probe key")) return rc;
+    if (tuple_nv(tuple->shape) > table->stage.acc_stride) return fail(ctx, SDQH_ERR_INVALID, "hash_probe_aggregate: the table's entries have room for fewer values than this tuple has");
     table->compact_valid = false;
     table->nv = std::max(0, tuple_nv(tuple->shape));
     const int64_t* kc = static_cast<const int64_t*>(key->data);
@@ -1122,14 +1124,15 @@ int sdqh_groupby_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, co
     uint32_t* dense_ref = static_cast<uint32_t*>(table_alloc(ctx, tb, dmax * 4 + 64));
     st.key = static_cast<int64_t*>(table_alloc(ctx, tb, dmax * 8 + 64));
     st.shits = static_cast<uint32_t*>(table_alloc(ctx, tb, dmax * 4 + 64));
-    st.sacc = static_cast<double*>(table_alloc(ctx, tb, dmax * 32 + 64));
+    st.acc_stride = std::max(1, tuple_nv(tuple->shape));               // the tuple is known here: no room for values it does not have
+    st.sacc = static_cast<double*>(table_alloc(ctx, tb, dmax * 8 * (size_t)st.acc_stride + 64));
     st.seg_count = static_cast<uint32_t*>(table_alloc(ctx, tb, (size_t)st.nseg * 4 + 64));
     if (!tb->bm || !tb->hdr || !wprefix || !dense_ref || !st.key || !st.shits || !st.sacc || !st.seg_count) {
         table_release(ctx, tb); delete tb; return fail(ctx, SDQH_ERR_NOMEM, "groupby_key: out of device memory");
     }
     st.hdr = tb->hdr; st.bm = tb->bm; st.bm_lo = lo; st.bm_hi = hi;
     tb->dev.hdr = tb->hdr; tb->dev.bm = tb->bm; tb->dev.bm_lo = lo; tb->dev.bm_hi = hi; tb->dev.wprefix = wprefix; tb->dev.dense_ref = dense_ref;
-    tb->dev.shits = st.shits; tb->dev.sacc = st.sacc;
+    tb->dev.shits = st.shits; tb->dev.sacc = st.sacc; tb->dev.acc_stride = st.acc_stride;
     call_begin(ctx);
     { FillList fl; fl.add(tb->bm, (tb->nwords * 4 + 15) & ~(uint64_t)15, 0); fl.add(tb->hdr, sizeof(TableHeader), 0); launch_fill(ctx, fl); }
     const int64_t* kc = static_cast<const int64_t*>(key->data);
@@ -1515,7 +1518,7 @@ int sdqh_build(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nloo
         if (!tb->hdr || !flags || (tb->nwords && !tb->bm)) rc = fail(ctx, SDQH_ERR_NOMEM, "build: out of device memory");
     }
     if (!rc) {
-        tb->dev.hdr = tb->hdr; tb->dev.shits = tb->stage.shits; tb->dev.sacc = tb->stage.sacc;
+        tb->dev.hdr = tb->hdr; tb->dev.shits = tb->stage.shits; tb->dev.sacc = tb->stage.sacc; tb->dev.acc_stride = tb->stage.acc_stride;
         const int shift = (nkey == 2 && !(tb->bm && lin_rb)) ? 32 : 0;
         tb->dev.bm = tb->bm; tb->dev.bm_lo = lo; tb->dev.bm_hi = hi; tb->dev.bitmap_only = 0; tb->dev.bm_shift = shift;
         for (int p = 0; p < npayload; ++p) tb->dev.pay[p] = tb->stage.pay[p];

@@ -113,6 +113,7 @@ struct DevTable {
     int64_t lin_rb, lin_b0;   // lin_rb != 0: composite key (a << 32 | b) with a small a-range x b-range: bm is exact over the
                               //    linearised offset (a - bm_lo) * lin_rb + (b - lin_b0) (direct layout, bm_shift == 0)
     const uint32_t* alias;    // sdqh_table_share_groups: stage row -> the stage row whose accumulators it uses, or null
+    int32_t acc_stride, _pad3; // doubles per entry in sacc: 4, or the tuple's value count when it is known at build time (sdqh_groupby_key)
 };
 
 // offset of `key` in a bitmap described by bm_lo / bm_hi / bm_shift / lin_rb / lin_b0 (DevTable or DevStage); false = out of range
@@ -902,13 +903,19 @@ struct DevStage {
     uint32_t* seg_count;                  // [nseg]
     int64_t seg_rows;                     // rows per wave segment (multiple of 128 * STAGE_BATCH)
     uint32_t* shits;                      // [nrows] entry hit counters, zeroed while staging
-    double* sacc;                         // [nrows*4] entry accumulators, zeroed while staging (or null)
+    double* sacc;                         // [nrows*acc_stride] entry accumulators, zeroed while staging (or null)
+    int32_t acc_stride, _pad3;
     uint32_t* bm;                         // key bitmap to fill, or null
     int64_t bm_lo, bm_hi;
     TableHeader* hdr;
     int32_t bm_shift, _pad2;              // 32: the bitmap covers the high part of a composite key
     int64_t lin_rb, lin_b0;               // linearised composite key (see DevTable)
 };
+
+__device__ __forceinline__ void zero_acc(const DevStage& st, int64_t pos) {
+    if (st.acc_stride == 4) { double4 z = {0, 0, 0, 0}; *reinterpret_cast<double4*>(st.sacc + pos * 4) = z; }
+    else for (int k = 0; k < st.acc_stride; ++k) st.sacc[pos * st.acc_stride + k] = 0.0;
+}
 
 template <class FC>
 __device__ __forceinline__ bool row_passes(const DevFilter& f, const DevProbes& pr, int64_t r, const uint64_t* cap_masks) {
@@ -1030,7 +1037,7 @@ __device__ __forceinline__ void stage_store(const DevStage& st, int64_t pos, int
 #pragma unroll
     for (int q = 0; q < MAX_STAGE_COLS; ++q) if (q < cfg_npay<NPAY>(st.npay)) st.pay[q][pos] = pay[q];
     if (st.shits) st.shits[pos] = 0;
-    if (st.sacc) { double4 z = {0, 0, 0, 0}; *reinterpret_cast<double4*>(st.sacc + pos * 4) = z; }
+    if (st.sacc) zero_acc(st, pos);
     if (st.bm) {
         uint64_t off;
         if (bm_locate(st, key, off)) {
@@ -1374,7 +1381,7 @@ __device__ __forceinline__ void probe_add(const DevFilter& f, const DevTuple& t,
     uint32_t idx = table_ref(tb, pos);
     if (tb.alias) idx = tb.alias[idx];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) atomicAdd(&tb.sacc[(size_t)idx * 4 + k], o[k]);
+    for (int k = 0; k < NV; ++k) atomicAdd(&tb.sacc[(size_t)idx * tb.acc_stride + k], o[k]);
     atomicAdd(&tb.shits[idx], 1u);
 }
 
@@ -1429,7 +1436,7 @@ __device__ __forceinline__ void probe_drain(const DevFilter& f, const DevTuple& 
     }
     if (tail) {
 #pragma unroll
-        for (int k = 0; k < NV; ++k) atomicAdd(&tb.sacc[(size_t)idx * 4 + k], o[k]);
+        for (int k = 0; k < NV; ++k) atomicAdd(&tb.sacc[(size_t)idx * tb.acc_stride + k], o[k]);
         atomicAdd(&tb.shits[idx], cnt);
     }
 }
@@ -1573,7 +1580,7 @@ __global__ __launch_bounds__(TPB) void k_gk_layout(DevStage st, DevTable t, int6
     for (uint64_t i = tid; i < D; i += nth) {
         t.dense_ref[i] = (uint32_t)i;
         st.shits[i] = 0u;
-        if (st.sacc) { double4 z = {0, 0, 0, 0}; *reinterpret_cast<double4*>(st.sacc + i * 4) = z; }
+        if (st.sacc) zero_acc(st, (int64_t)i);
     }
     for (uint64_t w = tid; w < nwords; w += nth) {                      // keys of the set bits of word w, at their ranks
         uint32_t bits = t.bm[w];
@@ -1593,7 +1600,7 @@ __global__ __launch_bounds__(TPB) void k_select_keys(DevTable t, DevStage st, ui
     for (uint32_t i = lane_id(); i < count; i += WAVE) {
         const int64_t idx = base + i;
         if (st.shits[idx] < min_hits) continue;
-        const double x = st.sacc[(size_t)idx * 4 + v];
+        const double x = v < st.acc_stride ? st.sacc[(size_t)idx * st.acc_stride + v] : 0.0;    // a value the entries have no room for is 0
         if (!(x >= lo && x <= hi)) continue;
         if (dups && !stage_row_owns(st, t, idx, mask)) continue;
         const uint64_t off = (uint64_t)(st.key[idx] - key_lo);
@@ -1988,7 +1995,7 @@ __device__ __forceinline__ void compact_copy(const DevStage& st, const DevCompac
 #pragma unroll
     for (int q = 0; q < SDQH_MAX_PAYLOAD; ++q) if (q < o.npay && o.pay[q]) pay[q] = st.pay[q][idx];
 #pragma unroll
-    for (int v = 0; v < SDQH_TUPLE_MAX_VALUES; ++v) if (v < o.nval && o.val[v]) val[v] = st.sacc[(size_t)idx * 4 + v];
+    for (int v = 0; v < SDQH_TUPLE_MAX_VALUES; ++v) if (v < o.nval && o.val[v]) val[v] = st.sacc[(size_t)idx * st.acc_stride + v];
     if (o.keys) o.keys[at] = k;
 #pragma unroll
     for (int q = 0; q < SDQH_MAX_PAYLOAD; ++q) if (q < o.npay && o.pay[q]) o.pay[q][at] = pay[q];
@@ -2138,7 +2145,7 @@ __device__ __forceinline__ uint64_t top_sort_value(const DevSortKey& sk, const D
     int64_t raw = 0;
     if (sk.kind == SDQH_SORT_KEY) raw = st.key[idx];
     else if (sk.kind == SDQH_SORT_PAYLOAD) { const int64_t* p = sk.index == 0 ? st.pay[0] : (sk.index == 1 ? st.pay[1] : (sk.index == 2 ? st.pay[2] : st.pay[3])); raw = p[idx]; }
-    else if (sk.kind == SDQH_SORT_VALUE) raw = __double_as_longlong(st.sacc[(size_t)idx * 4 + sk.index]);
+    else if (sk.kind == SDQH_SORT_VALUE) raw = __double_as_longlong(st.sacc[(size_t)idx * st.acc_stride + sk.index]);
     else raw = (int64_t)hits;
     return sort_bits(raw, sk.is_f64, sk.desc);
 }
@@ -2251,7 +2258,7 @@ __device__ __forceinline__ void top_emit(const TopLds& s, int have, int k, const
 #pragma unroll
         for (int p = 0; p < SDQH_MAX_PAYLOAD; ++p) if (p < o.npay && o.pay) o.pay[(size_t)p * k + j] = st.pay[p][idx];
 #pragma unroll
-        for (int v = 0; v < SDQH_TUPLE_MAX_VALUES; ++v) if (o.val) o.val[(size_t)v * k + j] = v < o.nval ? st.sacc[(size_t)idx * 4 + v] : 0.0;
+        for (int v = 0; v < SDQH_TUPLE_MAX_VALUES; ++v) if (o.val) o.val[(size_t)v * k + j] = v < o.nval ? st.sacc[(size_t)idx * st.acc_stride + v] : 0.0;
         if (o.hits) o.hits[j] = st.shits ? (int64_t)st.shits[idx] : 0;
     }
     if (threadIdx.x == 0) *o.count = (unsigned long long)rows;

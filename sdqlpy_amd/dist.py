@@ -60,6 +60,9 @@ class DistributedRunner:
         self._plans = {}
         self._gather_bufs = {}
         self._inflight = []                 # collective buffers that queued copy_ins still read (dropped at the next run)
+        self._top = None                    # (k, order) while a run carries ORDER BY ... LIMIT k
+        self._partitioned_result = False    # the last run returned this rank's key partition (else the global result)
+        self._local_text = set()            # ids of text arrays / dictionaries that only mean something on this rank
 
     # ---- small collectives ---------------------------------------------------------------------
     def _all_gather_array(self, arr):
@@ -245,7 +248,7 @@ class DistributedRunner:
             self._partitioned_result = True
             return self._partitioned_join(plan, args)
         whole = {p for p, t in zip(plan.params, Q.QUERY_TABLES[name]) if t in whole_tables}
-        return self._sharded_chain(plan, args, whole, getattr(self, "_top", None))
+        return self._sharded_chain(plan, args, whole, self._top)
 
     # ---- multi-join chains (q5, q9): replicate what is probed across shards, keep co-partitioned joins local ----
     def _prepare_chain(self, plan, args, whole):
@@ -366,7 +369,7 @@ class DistributedRunner:
         """All ranks' entries of a built table on every rank, without leaving device memory:
         entries -> all-gather -> rebuild.  A composite key travels packed; lookups pack the same way."""
         ctx = self.ctx
-        local = getattr(self, "_local_text", set())          # text arrays / dictionaries of this rank's shards (see _prepare_chain)
+        local = self._local_text          # text arrays / dictionaries of this rank's shards (see _prepare_chain)
         if any(id(d) in local for d in list(bt.decoders.values()) + list(bt.field_decoders.values()) if d is not None):
             raise frontend.UnsupportedQuery("'%s' carries text as references to this rank's rows: it cannot be replicated yet "
                                             "(hold its table whole on every rank)" % bt.key_name)
@@ -377,7 +380,7 @@ class DistributedRunner:
         table = ctx.hash_build_unique(total, abi.make_filter(), [], gathered[0], gathered[1:])
         new = engine.BuiltTable(table, bt.key_name, bt.key_is_record, bt.val_fields, bt.val_is_record, bt.payload_dtypes)
         new.decoders, new.key_parts, new.field_decoders = bt.decoders, bt.key_parts, bt.field_decoders
-        new.key_decoder = getattr(bt, "key_decoder", None)
+        new.key_decoder = bt.key_decoder
         new._keep = gathered
         bt.table.free()
         return new
@@ -659,7 +662,7 @@ class DistributedRunner:
             ctx.hash_probe_aggregate(n_recv, st.empty, table_b, recv[0], abi.make_tuple(st.tup_c.shape, recv[1:]))
 
         # ---- finalise this rank's partition --------------------------------------------------------
-        spec = self._join_sort_spec(st) if getattr(self, "_top", None) else None
+        spec = self._join_sort_spec(st) if self._top else None
         if spec is not None and 1 <= self._top[0] <= abi.MAX_TOPK:
             keys, payload, values, hits = ctx.table_topk(table_b, 1, self._top[0], spec)
         else:

@@ -89,6 +89,8 @@ class Engine:
         self.compact_hints = {}    # plan step -> rows its last K-F produced (sizes the next run's result block)
         self._rowids = {}
         self._dicts = {}           # id(string ndarray) -> (ndarray, codes int64 ndarray, distinct values)
+        self._range_cache = {}     # id(int64 ndarray) -> (ndarray, (min, span))
+        self._distinct_cache = {}  # id(ndarray) -> (ndarray, has no repeated value)
 
     def close(self):
         self.clear()
@@ -98,6 +100,8 @@ class Engine:
         for _, col in self._columns.values():
             col.free()
         self._columns.clear()
+        self._range_cache.clear()
+        self._distinct_cache.clear()
         self.resident_bytes = 0
         self.generation += 1
 
@@ -169,6 +173,11 @@ class BuiltTable:
         self.field_decoders = {}            # field name -> string array: several text fields of one source row share ONE
                                             # row-reference payload slot and differ only in what it indexes (late materialisation)
         self.key_parts = None               # composite key: [part names]; the stored key is (part0 << 32) | part1
+        self.key_decoder = None             # single key that is a row reference / dictionary code: what it indexes
+        self.agg_fields = {}                # fused probe-aggregate: output key field -> entry field (whose decoder applies)
+        self.shared_groups = False          # sdqh_table_share_groups ran: one live entry per output key
+        self.slot_roots = None              # payload index -> the scanned-row columns it is a function of (_share_spec)
+        self.slot_plain = {}                # payload index -> (lo, span) when it holds a plain int column / row number
 
     def slot_of(self, field):
         """"key" | payload index of a value field, or None."""
@@ -840,7 +849,7 @@ def _prepare_scan(eng, op, htab, accumulate_into, member_only=False):
                     if src is None:
                         raise UnsupportedQuery("line %d: '%s' has no field '%s'" % (op.lineno, probe_name, e.field))
                     out_key_fields.append((fname or e.field, src))
-                    bt.__dict__.setdefault("agg_fields", {})[fname or e.field] = e.field      # output name -> entry field (its decoder)
+                    bt.agg_fields[fname or e.field] = e.field      # output name -> entry field (its decoder)
                 else:
                     raise UnsupportedQuery("line %d: group keys of a probe-aggregate must be the probe key or fields of the matched "
                                            "entry (the group must be determined by the probe key)" % op.lineno)
@@ -883,7 +892,7 @@ def _plain_range(eng, src, env, lookups):
         return None
     if src.is_rowid:
         return 0, max(1, src.host[1])
-    cache = eng.__dict__.setdefault("_range_cache", {})
+    cache = eng._range_cache
     hit = cache.get(id(src.host))
     if hit is None or hit[0] is not src.host:
         arr = src.host
@@ -898,8 +907,8 @@ def _share_spec(eng, bt):
     that column's value, and every slot computed from the same columns (fields of the looked-up
     entry, of entries looked up through them) follows from it.  Slots not covered that way must be
     row references / dictionary codes whose decoder has no repeated value.  None: fold on the host."""
-    fields_of = getattr(bt, "agg_fields", {})
-    roots, plain = getattr(bt, "slot_roots", None), getattr(bt, "slot_plain", {})
+    fields_of = bt.agg_fields
+    roots, plain = bt.slot_roots, bt.slot_plain
     slots = sorted({src for _, src in bt.agg_spec})
     if roots is None:
         return None
@@ -922,7 +931,7 @@ def _share_spec(eng, bt):
 
 
 def _distinct_cached(eng, arr):
-    cache = eng.__dict__.setdefault("_distinct_cache", {})
+    cache = eng._distinct_cache
     hit = cache.get(id(arr))
     if hit is None or hit[0] is not arr:
         hit = cache[id(arr)] = (arr, _all_distinct(arr))
@@ -949,7 +958,7 @@ def _device_sort_spec(bt, key_fields, vnames, count_idx, order):
         if hit:
             src = hit[0]
             if src == "key":
-                if bt.key_parts is not None or getattr(bt, "key_decoder", None) is not None:
+                if bt.key_parts is not None or bt.key_decoder is not None:
                     return None
                 spec.append((abi.SORT_KEY, 0, desc, False))
             else:
@@ -985,12 +994,12 @@ def _materialize(eng, value, env, hint_key=None, top=None):
     if isinstance(value, tuple) and value and value[0] == "aggregated":
         bt = env[value[1]]
         out_key_fields, vnames, count_idx, key_is_record, val_is_record, shape = bt.agg
-        entry_is_group = any(src == "key" for _, src in out_key_fields) or getattr(bt, "shared_groups", False)
+        entry_is_group = any(src == "key" for _, src in out_key_fields) or bt.shared_groups
         spec = _device_sort_spec(bt, out_key_fields, vnames, count_idx, top[1]) if top is not None and entry_is_group else None
         keys, payload, values, hits, ordered = _fetch_entries(eng, bt.table, 1, hint_key, top, spec, want_hits=count_idx is not None or (spec is not None and any(s[0] == abi.SORT_HITS for s in spec)))
         nv = abi.TUPLE_NVALUES[shape]
         values = [values[j] for j in range(nv)]
-        fields_of = getattr(bt, "agg_fields", {})
+        fields_of = bt.agg_fields
         def decode(fname, src, sel=None):
             raw = keys if src == "key" else payload[src]
             if sel is not None:
@@ -1070,7 +1079,7 @@ def _materialize(eng, value, env, hint_key=None, top=None):
         if value.key_parts is not None:
             kf = [(value.key_parts[0], keys >> 32), (value.key_parts[1], keys & 0xFFFFFFFF)]
         else:
-            kf = [(value.key_name, _decode_column(keys, getattr(value, "key_decoder", None), np.int64))]
+            kf = [(value.key_name, _decode_column(keys, value.key_decoder, np.int64))]
         d = DictResult(kf, vf, value.key_is_record, value.val_is_record)
         d.ordered = ordered
         return d

@@ -360,6 +360,7 @@ int with_scan_filter(const DevFilter& f, Fn&& fn) {          // K-A / K-C small 
 }
 template <class Fn>
 int with_stage_filter(const DevFilter& f, int nprobes, Fn&& fn) {      // K-B staging
+    if (f.nc == 1 && f.ns == 0 && f.nf == 0 && f.ni == 0 && nprobes == 0) return fn(FCfg<0, 0, 0, 0, 1>{});   // Q4: one column comparison
     if (f.nc) return fn(FGeneric{});
     if (f.ns == 0 && f.nf == 0 && f.ni == 1 && nprobes == 1) return fn(FCfg<1, 0, 0, 1>{});
     if (f.ns == 0 && f.nf == 0 && f.ni == 1 && nprobes == 0) return fn(FCfg<1, 0, 0, 0>{});

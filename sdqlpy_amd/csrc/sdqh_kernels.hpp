@@ -173,14 +173,14 @@ template <class T> struct Pair { T x, y; };
 // the stream stalls.  So the hot kernels are instantiated for the filter layouts the TPCH loops
 // use (counts known at compile time: every load of a tile is issued up front) plus one generic
 // instance (-1 = read the count from the arguments) that keeps every other query correct.
-template <int NI_, int NF_, int NS_, int NP_> struct FCfg { static constexpr int NI = NI_, NF = NF_, NS = NS_, NP = NP_; };
+template <int NI_, int NF_, int NS_, int NP_, int NC_ = 0> struct FCfg { static constexpr int NI = NI_, NF = NF_, NS = NS_, NP = NP_, NC = NC_; };
 using FGeneric = FCfg<-1, -1, -1, -1>;
 template <class FC> __device__ __forceinline__ int cfg_ni(const int32_t n) { if constexpr (FC::NI >= 0) return FC::NI; else return n; }
 template <class FC> __device__ __forceinline__ int cfg_nf(const int32_t n) { if constexpr (FC::NF >= 0) return FC::NF; else return n; }
 template <class FC> __device__ __forceinline__ int cfg_ns(const int32_t n) { if constexpr (FC::NS >= 0) return FC::NS; else return n; }
 template <class FC> __device__ __forceinline__ int cfg_np(const int32_t n) { if constexpr (FC::NP >= 0) return FC::NP; else return n; }
 // column-vs-column predicates exist in the generic instance only (the dispatchers send filters that carry one there)
-template <class FC> __device__ __forceinline__ int cfg_nc(const int32_t n) { if constexpr (FC::NI >= 0) return 0; else return n; }
+template <class FC> __device__ __forceinline__ int cfg_nc(const int32_t n) { if constexpr (FC::NI >= 0) return FC::NC; else return n; }
 // group-key slots: 0 absent, 1 string(1) (UCS4 code unit), 2 int64, -1 decided at run time
 template <int K0_, int K1_> struct KCfg { static constexpr int K0 = K0_, K1 = K1_; };
 using KGeneric = KCfg<-1, -1>;

@@ -1513,19 +1513,31 @@ __global__ __launch_bounds__(TPB) void k_key_set(DevFilter f, DevProbes pr, cons
 #pragma unroll
     for (int i = 0; i < SDQH_MAX_PROBE; ++i) if (i < cfg_np<FC>(pr.n) && pr.table[i].hdr && !table_is_direct(pr.table[i]) && !pr.table[i].bitmap_only) cap_masks[i] = pr.table[i].hdr->cap_mask;
     // One (word, bits) per lane, merged across the wave before the atomic: with keys in row order the
-    // 128 rows of a wave step fall into a handful of bitmap words.  Segmented OR-scan over runs of
-    // equal words (6 shuffle steps); the last lane of each run issues one atomic for the run.  Equal
-    // words that are not adjacent are merely issued more than once (OR is idempotent).
+    // 128 rows of a wave step fall into a handful of bitmap words.  The lanes OR their bits into a
+    // 64-word LDS window that starts at the first live lane's word (LDS atomics: a few instructions,
+    // where a segmented OR-scan over the wave costs six shuffle rounds), then lane i flushes window word
+    // i with one global atomic if it is set.  Words outside the window (keys not in row order) go
+    // straight to memory.
+    __shared__ uint32_t s_win[TPB / WAVE][WAVE];
+    uint32_t* win = s_win[threadIdx.x / WAVE];
+    win[lane_id()] = 0u;
     auto wave_set = [&](bool valid, uint32_t w, uint32_t bits) {
-        if (!valid) { w = 0xFFFFFFFFu; bits = 0u; }
+        const uint64_t live = __ballot(valid);
+        if (!live) return;
         const int lane = lane_id();
-#pragma unroll
-        for (int off = 1; off < WAVE; off <<= 1) {
-            const uint32_t ow = __shfl_up(w, off, WAVE), ob = __shfl_up(bits, off, WAVE);
-            if (lane >= off && ow == w) bits |= ob;
-        }
-        const uint32_t nw = __shfl_down(w, 1, WAVE);
-        if (w != 0xFFFFFFFFu && (lane == WAVE - 1 || nw != w)) atomicOr(&bm[w], bits);
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)w, __ffsll((long long)live) - 1);
+        const uint32_t d = w - base;                                       // a word below the base wraps to a huge distance
+        // the two atomics stay apart: as the arms of one if / else the compiler folds them into ONE flat
+        // atomic on a selected address, and a flat access to LDS is not ordered with the ds_read below
+        // Window word i is written by other lanes: it is read and reset with atomic accesses between
+        // wavefront fences — a plain load would be a data race to the compiler, which then reads the word
+        // only in the lanes that issued an OR themselves (and keeps "0" for the rest).
+        if (valid && d < (uint32_t)WAVE) atomicOr(&win[d], bits);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t v = __hip_atomic_load(&win[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (v) { atomicOr(&bm[base + lane], v); __hip_atomic_store(&win[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (valid && d >= (uint32_t)WAVE) atomicOr(&bm[w], bits);
     };
     auto set_pair = [&](bool p0, int64_t k0, bool p1, int64_t k1) {       // converged: every lane calls it
         p0 = p0 && k0 >= lo && k0 <= hi; p1 = p1 && k1 >= lo && k1 <= hi;

@@ -21,7 +21,7 @@ import numpy as np
 from . import abi, build
 from .frontend import (And, Bin, Call, Cmp, Col, Const, Contains, FinalizeOp, Lookup, PayloadField, RecordCons,
                        ScalarExprOp, ScalarField, ScanOp, SelectKeysOp, StrIn, UnsupportedQuery)
-from .result import DictResult, ResultSet
+from .result import DictResult, ResultSet, decode_text
 
 # value-tuple vocabulary: canonical shape of the whole value record -> (ABI shape, index of the COUNT field or None)
 TUPLE_SHAPES = {
@@ -1005,8 +1005,11 @@ def _materialize(eng, value, env, hint_key=None, top=None):
             if sel is not None:
                 raw = raw[sel]
             return raw if src == "key" else _decode_column(raw, bt.decoder_of(fields_of.get(fname), src), bt.payload_dtypes[src])
+        def decode_late(fname, src):                         # text of a large result is gathered when it is first read
+            dec = None if src == "key" else bt.decoder_of(fields_of.get(fname), src)
+            return decode_text(payload[src], dec) if dec is not None and dec.dtype.kind == "U" else decode(fname, src)
         if entry_is_group or ordered:
-            d = DictResult([(f, decode(f, src)) for f, src in out_key_fields], _value_arrays(vnames, count_idx, values, hits),
+            d = DictResult([(f, decode_late(f, src)) for f, src in out_key_fields], _value_arrays(vnames, count_idx, values, hits),
                            key_is_record, val_is_record)
             d.ordered = ordered
             return d

@@ -11,17 +11,66 @@ import numpy as np
 from .sdql_lib import record, sr_dict
 
 
+class TextRefs:
+    """A text column of a large result, not decoded yet: row references (or dictionary codes) as they
+    came from the device, and the host array they index.  The reference's result object defers its
+    Python conversion to `to_dict()` in the same way (src/sdqlpy/fastd.py:31-51); here K-F's transfer is
+    done when the query returns and only the gather of the (wide, UCS-4) strings waits for the first
+    read — a 389 K-row Q10 result spends 70 of its 72 ms in that gather."""
+
+    def __init__(self, refs, decoder):
+        self.refs, self.decoder = refs, decoder
+
+    dtype = property(lambda self: self.decoder.dtype)
+    shape = property(lambda self: self.refs.shape)
+
+    def __len__(self):
+        return len(self.refs)
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.decoder[self.refs]
+        return a if dtype is None else a.astype(dtype)
+
+    def __getitem__(self, idx):
+        if isinstance(idx, (int, np.integer)):
+            return self.decoder[self.refs[idx]]
+        return TextRefs(self.refs[idx], self.decoder)            # slices / index arrays stay references
+
+    def tolist(self):
+        return self.decoder[self.refs].tolist()
+
+
+LAZY_TEXT_ROWS = 4096        # results with at least this many rows keep their text columns as TextRefs
+
+
+def decode_text(refs, decoder):
+    """decoder[refs], deferred for large results."""
+    return TextRefs(refs, decoder) if len(refs) >= LAZY_TEXT_ROWS else decoder[refs]
+
+
 class ResultSet:
     """Set of records: {record(field...): True}."""
 
     def __init__(self, columns, arrays):
         self.columns = list(columns)
-        self.arrays = [np.asarray(a) for a in arrays]
-        n = len(self.arrays[0]) if self.arrays else 0
-        for a in self.arrays:
+        self._cols = [a if isinstance(a, TextRefs) else np.asarray(a) for a in arrays]
+        n = len(self._cols[0]) if self._cols else 0
+        for a in self._cols:
             if len(a) != n:
                 raise ValueError("ragged result")
         self._n = n
+
+    @property
+    def arrays(self):
+        """One numpy array per column (text columns of a large result are decoded on first use)."""
+        for i, a in enumerate(self._cols):
+            if isinstance(a, TextRefs):
+                self._cols[i] = np.asarray(a)
+        return self._cols
+
+    @arrays.setter
+    def arrays(self, value):
+        self._cols = list(value)
 
     def size(self):
         return self._n
@@ -30,7 +79,10 @@ class ResultSet:
         return self._n
 
     def column(self, name):
-        return self.arrays[self.columns.index(name)]
+        i = self.columns.index(name)
+        if isinstance(self._cols[i], TextRefs):
+            self._cols[i] = np.asarray(self._cols[i])
+        return self._cols[i]
 
     def rows(self):
         """Sorted list of plain-Python tuples (ints, floats, strs) — for comparisons."""
@@ -43,7 +95,7 @@ class ResultSet:
 
     def top(self, k, order):
         idx = self.top_index(k, order)
-        return ResultSet(self.columns, [a[idx] for a in self.arrays])
+        return ResultSet(self.columns, [a[idx] for a in self._cols])     # undecoded text stays undecoded
 
     def top_index(self, k, order):
         """ORDER BY ... LIMIT k on the host: order = [(column, "asc" | "desc")], ties keep the stored

@@ -123,3 +123,27 @@ def test_q10_group_sharing_and_host_fold_agree(oracle, monkeypatch):
         top_got = engine.execute_plan(oracle, plan, args, top=Q.TPCH_ORDER["q10"])
         assert [r[0] for r in top_got.ordered_rows()] == [r[0] for r in top_want.ordered_rows()]
     assert calls == ["share", "share", "topk"]
+
+
+def test_text_columns_of_large_results_are_decoded_on_first_read(oracle, monkeypatch):
+    """Large results keep their text columns as row references until they are read (result.TextRefs):
+    the same rows either way, through every accessor, and ordering / slicing keeps them undecoded."""
+    from sdqlpy_amd import result
+    qs = ("q10", "q18")
+    db = tpch.generate(0.1, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+    for q in qs:
+        plan = frontend.lower_function(Q.QUERIES[q].__sdql_func__, Q.QUERIES[q].__sdql_in_type__)
+        args = [db[t] for t in Q.QUERY_TABLES[q]]
+        monkeypatch.setattr(result, "LAZY_TEXT_ROWS", 1 << 30)
+        eager = engine.execute_plan(oracle, plan, args)
+        assert not any(isinstance(a, result.TextRefs) for a in eager._cols)
+        monkeypatch.setattr(result, "LAZY_TEXT_ROWS", 1)
+        lazy = engine.execute_plan(oracle, plan, args)
+        assert any(isinstance(a, result.TextRefs) for a in lazy._cols) and lazy.size() == eager.size() > 0
+        k, order = Q.TPCH_ORDER[q]
+        top = lazy.top(3, order)                                        # ordering reads the sort columns only
+        assert any(isinstance(a, result.TextRefs) for a in top._cols) and top.ordered_rows() == eager.top(3, order).ordered_rows()
+        name = next(c for c in lazy.columns if lazy._cols[lazy.columns.index(c)].dtype.kind == "U")
+        assert lazy.column(name).tolist() == eager.column(name).tolist()
+        assert lazy.rows() == eager.rows() and lazy.to_dict() == eager.to_dict()
+        assert not any(isinstance(a, result.TextRefs) for a in lazy._cols)

@@ -416,6 +416,13 @@ class DistributedRunner:
                     env[op.out] = engine._select_keys(self.eng, op, env)
                 elif isinstance(op, FinalizeOp):
                     local_groups = isinstance(env.get(op.source), tuple)           # finished groups of this rank's key partition
+                    if local_groups:
+                        agg_table = env[env[op.source][1]]
+                        if not any(src == "key" for _, src in agg_table.agg[0]):
+                            # Q10: groups named by fields of the matched entry (a customer's orders) are not
+                            # partitioned with the build key — the same group can finish on several ranks
+                            raise frontend.UnsupportedQuery("groups keyed by fields of the matched entry may span ranks: "
+                                                            "their partial sums would have to be merged by key (not distributed yet)")
                     if op.out == plan.result:
                         self._partitioned_result = local_groups
                     env[op.out] = engine._finalize(self.eng, op, env, top if op.out == plan.result and local_groups else None)

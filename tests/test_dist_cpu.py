@@ -83,7 +83,9 @@ def test_two_ranks_match_single_process(mode, tmp_path, single, oracle_lib):
         helpers.assert_rows_match(as_rows(got["q18_top"]["rows"]), list(zip(*[want.column(c).tolist() for c in tcols])), 1e-12, mode + "/q18_top")
     else:
         assert "unsupported" in got["q18"], got["q18"]
+    assert "may span ranks" in got["q10"].get("unsupported", "") or "unsupported" in got["q10"], got["q10"]
     if mode == "range":
+        assert "may span ranks" in got["q10"]["unsupported"]
         # dbgen-shaped shards are co-clustered on o_orderkey: nothing has to move
         assert got["q3"]["partitioning"] == "range" and got["q3"]["exchanged"]["probe_sent"] == 0
     elif mode == "range_foreign":

@@ -423,8 +423,8 @@ class DistributedRunner:
                             # partitioned with the build key — the same group can finish on several ranks
                             raise frontend.UnsupportedQuery("groups keyed by fields of the matched entry may span ranks: "
                                                             "their partial sums would have to be merged by key (not distributed yet)")
-                    if op.out == plan.result:
-                        self._partitioned_result = local_groups
+                    if op.out == plan.result:                                      # (aggregating a table every rank holds whole gives every rank all groups)
+                        self._partitioned_result = local_groups and st.sharded.get(op.source, True)
                     env[op.out] = engine._finalize(self.eng, op, env, top if op.out == plan.result and local_groups else None)
                 elif isinstance(op, frontend.ScalarExprOp):
                     env[op.out] = engine._eval_scalar_expr(op.expr, env, op.lineno)

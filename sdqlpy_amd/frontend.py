@@ -147,9 +147,15 @@ class WholeKey(Expr):
     def __init__(self, which, field=None):
         self.which, self.field = which, field            # which: 0 = key, 1 = value
 
+    def __repr__(self):
+        return "kv[%d]%s" % (self.which, "" if self.field is None else "." + self.field)
+
 
 class ConcatKV(Expr):
     """`p[0].concat(p[1])`."""
+
+    def __repr__(self):
+        return "kv[0].concat(kv[1])"
 
 
 TRUE = Const(True)
@@ -215,6 +221,41 @@ class Plan:
     def __repr__(self):
         return "Plan(%s(%s)):\n  " % (self.name, ", ".join(self.params)) + "\n  ".join(map(repr, self.ops)) + "\n  return " + str(self.result)
 
+    def fingerprint(self):
+        """The plan with every user-chosen name removed: table parameters become T0, T1, ... in order of
+        first use, intermediate results D0, D1, ... in order of definition, and the terms of a
+        conjunction are sorted.  Two formulations of one query that lower to the same loops have the
+        same fingerprint whatever they call things (tests/golden/make_lowering_fixture.py)."""
+        import re
+        tables, dicts = [], [op.out for op in self.ops]
+        for op in self.ops:
+            t = getattr(op, "table", None)
+            if t in self.params and t not in tables:
+                tables.append(t)
+        def canon(text):
+            for i, n in enumerate(dicts):
+                text = re.sub(r"(?<![\w.])%s(?![\w])" % re.escape(n), "D%d" % i, text)
+            for i, n in enumerate(tables):
+                text = re.sub(r"(?<![\w.])%s(?![\w])" % re.escape(n), "T%d" % i, text)
+            return text
+        lines = []
+        for op in self.ops:
+            if isinstance(op, ScanOp):
+                conds = sorted(canon(repr(c)) for c in op.conds)
+                fields = [(n, canon(repr(e)), sorted(canon(repr(c)) for c in fc)) for n, e, fc in (op.fields or [])]
+                lines.append("scan %s <- %s probe=%s kind=%s unique=%s conds=%s key=%s val=%s fields=%s" % (
+                    canon(op.out), canon(op.table), canon(repr(op.probe)), op.kind, op.unique, conds, canon(repr(op.key)), canon(repr(op.val)), fields))
+            elif isinstance(op, FinalizeOp):
+                lines.append("finalize %s <- %s fields=%r" % (canon(op.out), canon(op.source), op.fields))
+            elif isinstance(op, SelectKeysOp):
+                lines.append("select %s <- %s where %s" % (canon(op.out), canon(op.source), sorted(canon(repr(c)) for c in op.conds)))
+            elif isinstance(op, ScalarExprOp):
+                lines.append("scalar %s = %s" % (canon(op.out), canon(repr(op.expr))))
+            else:
+                lines.append(canon(repr(op)))
+        lines.append("return " + canon(self.result))
+        return "\n".join(lines)
+
 
 # ---- lowering -----------------------------------------------------------------------------------
 _BINOPS = {ast.Add: "+", ast.Sub: "-", ast.Mult: "*", ast.Div: "/"}
@@ -222,9 +263,9 @@ _CMPOPS = {ast.Lt: "<", ast.LtE: "<=", ast.Gt: ">", ast.GtE: ">=", ast.Eq: "==",
 
 
 class _Lowerer:
-    def __init__(self, fn_name, source_lines, first_line):
+    def __init__(self, fn_name, source_lines, first_line, outer_consts=None):
         self.fn_name, self.lines, self.first_line = fn_name, source_lines, first_line
-        self.consts = {}
+        self.consts = dict(outer_consts or {})      # numbers / text bound outside the function (closure, module) + local literals
         self.scalars = set()     # names bound to scalar / scalar-record sums
         self.params = []
         self.dicts = set()      # names bound to operator outputs
@@ -289,6 +330,14 @@ class _Lowerer:
             for v in node.values:
                 terms += self._terms(self.expr(v, env))
             return And(terms)
+        if isinstance(node, ast.Compare) and len(node.ops) > 1:
+            # chained comparison `a <= x < b`: the conjunction of its links (Python evaluates it that way)
+            terms, left = [], node.left
+            for op, right in zip(node.ops, node.comparators):
+                link = ast.copy_location(ast.Compare(left=left, ops=[op], comparators=[right]), node)
+                terms += self._terms(self.expr(link, env))
+                left = right
+            return And(terms)
         if isinstance(node, ast.Compare) and len(node.ops) == 1:
             op = node.ops[0]
             left, right = self.expr(node.left, env), self.expr(node.comparators[0], env)
@@ -303,6 +352,8 @@ class _Lowerer:
                 return Contains(left)
             if isinstance(left, PayloadField) and left.field is None and isinstance(right, Const) and right.value is None and sym == "!=":
                 return Contains(left.lookup)
+            if isinstance(left, Const) and not isinstance(right, Const):          # constant on the right: `5 <= x` is `x >= 5`
+                left, right, sym = right, left, {"<": ">", "<=": ">=", ">": "<", ">=": "<=", "==": "==", "!=": "!="}[sym]
             return Cmp(sym, left, right)
         if isinstance(node, ast.Call):
             fn = node.func
@@ -425,6 +476,7 @@ class _Lowerer:
                     self.scalars.add(out)
                 if len(call.args) == 2 and isinstance(call.args[1], ast.Constant) and call.args[1].value is False:
                     op.unique = True
+                self._promote_probe(op)
                 return op
             if fn.attr == "joinBuild":
                 if len(call.args) != 3:
@@ -489,6 +541,37 @@ class _Lowerer:
         self.fail(call, "'%s' is neither a table parameter nor an earlier result" % table)
 
     @staticmethod
+    def _promote_probe(op):
+        """`T.sum(lambda r: {K: V} if ... and idx[r[0].col] != None else None)` IS
+        `T.joinProbe(idx, "col", ..., lambda entry, row: {K: V})` (reference lib/sdql_ir.py:443-454
+        defines joinProbe as exactly that sum): give both spellings one IR.  The promoted lookup is the
+        one whose entry the body reads fields of, else the first membership condition on a plain column."""
+        if op.kind != "dict" or op.probe is not None:
+            return
+        cands = [c for c in op.conds if isinstance(c, Contains) and isinstance(c.lookup.key, Col)]
+        if not cands:
+            return
+        used = []
+
+        def walk(e):
+            if isinstance(e, PayloadField):
+                used.append(repr(e.lookup)); walk(e.lookup.key)
+            elif isinstance(e, Lookup):
+                used.append(repr(e)); walk(e.key)
+            elif isinstance(e, RecordCons):
+                for _, x in e.fields:
+                    walk(x)
+            elif isinstance(e, (Bin, Cmp)):
+                walk(e.left); walk(e.right)
+            elif isinstance(e, Call):
+                for x in e.args:
+                    walk(x)
+        walk(op.key); walk(op.val)
+        pick = next((c for c in cands if repr(c.lookup) in used), cands[0])
+        op.conds = [c for c in op.conds if c is not pick]
+        op.probe = pick.lookup
+
+    @staticmethod
     def _only_scalars(e):
         if isinstance(e, (Const, ScalarField)):
             return not isinstance(e, Const) or isinstance(e.value, (int, float))
@@ -534,12 +617,27 @@ class _Lowerer:
         return Plan(self.fn_name, self.params, ops, result, dict(self.consts))
 
 
-def lower_source(source, fn_name=None, first_line=1):
+def lower_source(source, fn_name=None, first_line=1, outer_consts=None):
     tree = ast.parse(textwrap.dedent(source))
     fdefs = [n for n in tree.body if isinstance(n, ast.FunctionDef) and (fn_name is None or n.name == fn_name)]
     if len(fdefs) != 1:
         raise UnsupportedQuery("expected exactly one function definition")
-    return _Lowerer(fdefs[0].name, textwrap.dedent(source).splitlines(), first_line).lower(fdefs[0])
+    return _Lowerer(fdefs[0].name, textwrap.dedent(source).splitlines(), first_line, outer_consts).lower(fdefs[0])
+
+
+def _outer_constants(func):
+    """Numbers and text a query function refers to by a name bound outside it (a parameter of the
+    factory that made it, a module-level constant): they are constants of the plan."""
+    try:
+        cv = inspect.getclosurevars(func)
+    except TypeError:
+        return {}
+    out = {}
+    for scope in (cv.globals, cv.nonlocals):
+        for name, value in scope.items():
+            if isinstance(value, (int, float, str)) and not isinstance(value, bool):
+                out[name] = value
+    return out
 
 
 def lower_function(func, in_type=None):
@@ -548,7 +646,7 @@ def lower_function(func, in_type=None):
     func = getattr(func, "__sdql_func__", func)
     source = inspect.getsource(func)
     first = func.__code__.co_firstlineno
-    plan = lower_source(source, func.__name__, first)
+    plan = lower_source(source, func.__name__, first, _outer_constants(func))
     if in_type is not None and len(in_type) != len(plan.params):
         raise UnsupportedQuery("%s: decorator lists %d tables, function takes %d" % (func.__name__, len(in_type), len(plan.params)))
     plan.in_type = in_type

@@ -41,17 +41,39 @@ def _run(cmd):
     return proc.stdout
 
 
+def _build_to(target, cmd_for, sources, force):
+    """Compile into a temporary file and rename it over `target`, under a lock on the csrc directory:
+    with one process per GPU several ranks can find the library stale at once, and a peer must never
+    dlopen a half-written file.  The staleness test is repeated under the lock (the winner built it)."""
+    import fcntl
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not (force or _stale(target, sources)):
+                return target
+            tmp = "%s.tmp.%d" % (target, os.getpid())
+            try:
+                out = _run(cmd_for(tmp))
+                os.replace(tmp, target)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+            return out
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
 def build_tpchgen(force=False):
     src = os.path.join(CSRC, "tpchgen.cpp")
     if force or _stale(GEN_LIB, [src]):
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", GEN_LIB, src])
+        _build_to(GEN_LIB, lambda out: ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", out, src], [src], force)
     return GEN_LIB
 
 
 def build_tblload(force=False):
     src = os.path.join(CSRC, "tblload.cpp")
     if force or _stale(TBL_LIB, [src]):
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", TBL_LIB, src])
+        _build_to(TBL_LIB, lambda out: ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", out, src], [src], force)
     return TBL_LIB
 
 
@@ -69,10 +91,12 @@ def build_hip(force=False, save_temps=False):
     hipcc = hipcc_path()
     if hipcc is None:
         raise RuntimeError("hipcc not found: the HIP backend cannot be built")
-    cmd = [hipcc] + HIP_FLAGS + ["-I", INCLUDE, "-I", CSRC, "-o", HIP_LIB] + HIP_SOURCES
-    if save_temps:
-        cmd.insert(1, "-save-temps=obj")
-    _run(cmd)
+    def cmd_for(out):
+        cmd = [hipcc] + HIP_FLAGS + ["-I", INCLUDE, "-I", CSRC, "-o", out] + HIP_SOURCES
+        if save_temps:
+            cmd.insert(1, "-save-temps=obj")
+        return cmd
+    _build_to(HIP_LIB, cmd_for, HIP_SOURCES + HIP_HEADERS, force)
     return HIP_LIB
 
 

@@ -189,66 +189,133 @@ class DistributedRunner:
         return out, n_recv
 
     # ---- queries ---------------------------------------------------------------------------------
-    def _plan(self, name):
-        if name not in self._plans:
-            self._plans[name] = frontend.lower_function(Q.QUERIES[name])
-        return self._plans[name]
+    def _resolve(self, query, db):
+        """(decorated function, plan, positional table arguments) of a query given by registry name or
+        as the decorated function itself; `db` is a {table name: table} dict or the positional list."""
+        fn = Q.QUERIES[query] if isinstance(query, str) else query
+        key = id(fn)
+        if key not in self._plans:
+            self._plans[key] = (fn, frontend.lower_function(fn, getattr(fn, "__sdql_in_type__", None)))
+        plan = self._plans[key][1]
+        args = [db[t] for t in Q.tables_of(fn)] if isinstance(db, dict) else list(db)
+        if len(args) != len(plan.params):
+            raise TypeError("%s expects %d tables, got %d" % (plan.name, len(plan.params), len(args)))
+        return fn, plan, args
 
-    def run(self, name, db, whole_tables=("region", "nation"), top=None):
+    def _whole_params(self, fn, plan, args, whole_tables):
+        """Parameters whose table every rank holds completely.  Explicit `whole_tables` (database table
+        names) wins; otherwise the tables say it themselves: a table cut by tpch.generate(shard=...) /
+        sdql_lib.shard_rows carries `.shard = (rank, world)`, every other table is whole."""
+        if whole_tables is not None:
+            return {p for p, t in zip(plan.params, Q.tables_of(fn)) if t in whole_tables}
+        return {p for p, a in zip(plan.params, args) if getattr(a, "shard", None) is None}
+
+    @staticmethod
+    def _shape(plan):
+        """Which distributed plan a query gets, decided from its loops alone:
+        "scalar"   one scalar sum over one table                      (q6)
+        "groups"   one small-domain group-by + its reshape            (q1)
+        "join"     build A -> build B (semi-join A) -> probe-aggregate C into B -> reshape   (q3)
+        "chain"    everything else the chain executor understands     (q5, q9, q4, q14, q18)"""
+        ops = plan.ops
+        if len(ops) == 1 and isinstance(ops[0], ScanOp) and ops[0].kind == "scalar" and not any(isinstance(c, frontend.Contains) for c in ops[0].conds):
+            return "scalar"
+        if len(ops) == 2 and isinstance(ops[0], ScanOp) and isinstance(ops[1], FinalizeOp) and ops[0].kind == "dict" and not ops[0].unique \
+                and ops[0].probe is None and not any(isinstance(c, frontend.Contains) for c in ops[0].conds):
+            found = []
+            engine._walk_lookups(ops[0].key, found); engine._walk_lookups(ops[0].val, found)
+            if not found:
+                return "groups"
+        if _is_join_shape(ops):
+            return "join"
+        return "chain"
+
+    def run(self, query, db, whole_tables=None, top=None):
         """See _run.  Column copies to / from collective buffers are only queued while a run is in
         progress (option "async_copies"); the runner synchronises once per batch."""
         self.ctx.set_option("async_copies", 1)
         try:
-            return self._run(name, db, whole_tables, top)
+            return self._run(query, db, whole_tables, top)
         finally:
             self.ctx.synchronize()
             self.ctx.set_option("async_copies", 0)
 
-    def _run(self, name, db, whole_tables=("region", "nation"), top=None):
-        """Run query `name` on this rank's shard `db`; returns this rank's share of the result
-        (q6: the global scalar on every rank; group-bys over a small domain (q1, q5, q9): the global
-        groups on every rank; q3: the groups of this rank's key partition).  `whole_tables` names the
-        tables every rank holds completely (the rest are row-sharded).  top = (k, [(column, "asc" |
-        "desc")]) adds ORDER BY ... LIMIT k: every rank returns the same global first k rows (q3: each
-        rank's device top-k of its partition, k rows per rank gathered and ordered again)."""
+    def _run(self, query, db, whole_tables=None, top=None):
+        """Run a query (registry name or decorated function) on this rank's shard `db`; returns this
+        rank's share of the result (a scalar: the global value on every rank; group-bys over a small
+        domain (q1, q5, q9): the global groups on every rank; the partitioned join (q3) and chains that
+        end in a local aggregation (q18): the groups of this rank's key partition).  `whole_tables`
+        names the tables every rank holds completely; by default the tables' own `.shard` marks decide.
+        top = (k, [(column, "asc" | "desc")]) adds ORDER BY ... LIMIT k: every rank returns the same
+        global first k rows (partitioned results: each rank's device top-k, k rows per rank gathered
+        and ordered again)."""
         self._inflight.clear()              # the previous run ended synchronised
+        fn, plan, args = self._resolve(query, db)
+        whole = self._whole_params(fn, plan, args, whole_tables)
+        shape = self._shape(plan)
         if top is not None:
             k, order = int(top[0]), [(str(n), str(d)) for n, d in top[1]]
-            if name == "q6":
+            if shape == "scalar":
                 raise frontend.UnsupportedQuery("top(k) applies to queries that end in a result set")
-            # a result partitioned over the ranks (q3; chains that end in a local aggregation, q18): top-k per
-            # rank first, k rows per rank gathered and ordered again.  Global results are ordered as they are.
+            # a result partitioned over the ranks: top-k per rank first, k rows per rank gathered and
+            # ordered again.  Global results are ordered as they are.
             self._top, self._partitioned_result = (k, order), False
             try:
-                local = self._run(name, db, whole_tables)
+                local = self._run(query, db, whole_tables)
             finally:
                 self._top = None
             if not self._partitioned_result:
                 return local.top(k, order)
-            cols = [[] for _ in local.columns]
-            out = [None] * self.world
-            dist.all_gather_object(out, [a.tolist() for a in local.arrays], group=self.group)
-            for part in out:                                  # rank order, then each rank's own order
-                for c, vals in zip(cols, part):
-                    c += vals
-            merged = ResultSet(local.columns, [np.array(c, a.dtype) for c, a in zip(cols, local.arrays)])
-            return merged.top(k, order)
-        args = [db[t] for t in Q.QUERY_TABLES[name]]
-        plan = self._plan(name)
-        if name == "q6":
+            return self._gather_result(local).top(k, order)
+        self._partitioned_result = False
+        if len(whole) == len(plan.params):
+            # nothing is sharded: every rank holds the whole database and computes the whole answer
+            return engine.execute_plan(self.eng, plan, args, self._top)
+        if shape == "scalar":
             local = engine.execute_plan(self.eng, plan, args)
             parts = self._all_gather_array(np.array([local], np.float64))
             total = 0.0
             for p in parts:                                   # fixed (rank) order
                 total += float(p[0])
             return total
-        if name == "q1":
+        if shape == "groups":
             return self._row_sharded_groupby(plan, args)
-        if name == "q3":
+        if shape == "join":
+            a_op, b_op, c_op = plan.ops[0], plan.ops[1], plan.ops[2]
+            if b_op.table in whole or c_op.table in whole:
+                # decided from the arguments' marks, the same on every rank: all raise alike
+                raise frontend.UnsupportedQuery("the partitioned join needs its build side '%s' and probe side '%s' row-sharded; a table held "
+                                                "whole on every rank would put every group on every rank" % (b_op.table, c_op.table))
             self._partitioned_result = True
-            return self._partitioned_join(plan, args)
-        whole = {p for p, t in zip(plan.params, Q.QUERY_TABLES[name]) if t in whole_tables}
+            return self._partitioned_join(plan, args, a_whole=a_op.table in whole)
         return self._sharded_chain(plan, args, whole, self._top)
+
+    def _gather_result(self, local):
+        """The ranks' ResultSet rows concatenated on every rank (rank order, then each rank's own
+        order): one size exchange and one padded fixed-shape all_gather per column of raw bytes — text
+        travels as its UCS-4 code units, nothing is pickled."""
+        n = local.size()
+        sizes = [int(x[0]) for x in self._all_gather_array(np.array([n], np.int64))]
+        m = max(sizes + [1])
+        arrays = []
+        for a in local.arrays:
+            a = np.ascontiguousarray(a)
+            width = np.array([a.dtype.itemsize], np.int64)
+            widths = [int(x[0]) for x in self._all_gather_array(width)]
+            w = max(widths)
+            if a.dtype.kind == "U" and a.dtype.itemsize != w:   # text columns decoded from differently sized dictionaries
+                a = a.astype("<U%d" % (w // 4))
+            elif a.dtype.kind != "U" and len(set(widths)) != 1:
+                raise RuntimeError("ranks disagree on a result column's type")
+            words = (w + 7) // 8
+            buf = np.zeros((m, words), np.int64)
+            if n:
+                buf.view(np.uint8).reshape(m, words * 8)[:n, :w] = a.view(np.uint8).reshape(n, w)
+            parts = self._all_gather_array(buf)
+            rows = [p.view(np.uint8).reshape(m, words * 8)[:sz, :w] for p, sz in zip(parts, sizes)]
+            flat = np.ascontiguousarray(np.concatenate(rows, axis=0))
+            arrays.append(flat.view(a.dtype).reshape(sum(sizes)))
+        return ResultSet(local.columns, arrays)
 
     # ---- multi-join chains (q5, q9): replicate what is probed across shards, keep co-partitioned joins local ----
     def _prepare_chain(self, plan, args, whole):
@@ -387,7 +454,7 @@ class DistributedRunner:
 
     def _sharded_chain(self, plan, args, whole, top=None):
         cache = plan.__dict__.setdefault("_dist_chain", {})
-        key = (id(self),) + tuple(id(a) for a in args)
+        key = (id(self), tuple(sorted(whole))) + tuple(id(a) for a in args)
         st = cache.get(key)
         if st is None or st.generation != self.eng.generation or any(x is not y for x, y in zip(st.args, args)):
             st = cache[key] = self._prepare_chain(plan, args, whole)
@@ -532,17 +599,14 @@ class DistributedRunner:
         return ResultSet(cols, arrays)
 
     # ---- q3-shaped plans: build(A) -> build(B, semi-join A) -> probe-aggregate(C into B) -> finalise --
-    def _prepare_join(self, plan, args):
+    def _prepare_join(self, plan, args, a_whole=False):
         """Everything about the distributed join that depends only on the plan and on which tables
         it is bound to: lowered filters / tuples, resident columns, and the (static) facts gathered
         once from all ranks — global key range of A, per-rank key ranges of B, whether every rank's
         probe keys already lie in its own range."""
         eng, ctx = self.eng, self.ctx
         ops = plan.ops
-        if not (len(ops) == 4 and all(isinstance(o, ScanOp) for o in ops[:3]) and isinstance(ops[3], FinalizeOp)
-                and ops[0].unique and ops[0].probe is None and ops[1].unique and ops[1].probe is not None
-                and ops[1].probe.dict_name == ops[0].out and not ops[2].unique and ops[2].probe is not None
-                and ops[2].probe.dict_name == ops[1].out):
+        if not _is_join_shape(ops):
             raise frontend.UnsupportedQuery("%s does not have the build / build / probe-aggregate shape" % plan.name)
         tabs = {p: engine.HostTable(p, a) for p, a in zip(plan.params, args)}
         a_op, b_op, c_op, _ = ops
@@ -550,6 +614,7 @@ class DistributedRunner:
         st = type("JoinState", (), {})()
         st.args = tuple(args)
         st.generation = eng.generation
+        st.a_whole = a_whole
         st.na, st.nb, st.nc = ta.nrows, tb.nrows, tc.nrows
 
         st.flt_a, look_a = engine._build_filter(eng, a_op, ta, a_op.conds)
@@ -613,6 +678,10 @@ class DistributedRunner:
         build are disjoint across ranks) makes it global.  Otherwise the surviving keys are
         all-gathered and the set is built from them."""
         ctx = self.ctx
+        if st.a_whole:
+            # every rank holds table A completely: its set is built locally and no collective runs.
+            # (Summing the ranks' bitmaps of identical sets would carry bits into their neighbours.)
+            return ctx.hash_build_unique(st.na, st.flt_a, [], st.key_a, []), []
         if st.a_bitmap:
             local = ctx.hash_build_unique(st.na, st.flt_a, [], st.key_a, [])
             lo, hi = st.a_range
@@ -631,13 +700,13 @@ class DistributedRunner:
         ka.free()
         return ctx.hash_build_unique(n_rep, st.empty, [], rep_keys, []), [rep_keys]
 
-    def _partitioned_join(self, plan, args):
+    def _partitioned_join(self, plan, args, a_whole=False):
         ctx = self.ctx
         cache = plan.__dict__.setdefault("_dist_prepared", {})
-        key = (id(self),) + tuple(id(a) for a in args)
+        key = (id(self), a_whole, self.partition) + tuple(id(a) for a in args)
         st = cache.get(key)
         if st is None or st.generation != self.eng.generation or any(x is not y for x, y in zip(st.args, args)):
-            st = cache[key] = self._prepare_join(plan, args)
+            st = cache[key] = self._prepare_join(plan, args, a_whole)
         self.last_partitioning = st.mode
         table_a, keep_a = self._replicated_set(st)
         recv, n_recv = None, 0
@@ -727,6 +796,35 @@ class DistributedRunner:
         for r in out:
             merged += r
         return sorted(merged)
+
+
+def default_runner(eng, devices, partition="auto"):
+    """The runner behind sdqlpy_init(3, devices=N): joins (or creates, from the launcher's RANK /
+    WORLD_SIZE / MASTER_* environment) the process group of this job — RCCL when the engine runs on a
+    GPU — and checks that the job really has one process per requested device."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not dist.is_initialized():
+        if world != devices:
+            raise RuntimeError("sdqlpy_init(devices=%d) needs one process per GPU (python -m torch.distributed.run "
+                               "--nproc-per-node %d ...); this process sees WORLD_SIZE=%d" % (devices, devices, world))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        on_gpu = eng.ctx.library.backend_name() == "hip-gfx950"
+        if on_gpu:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+        else:
+            dist.init_process_group("gloo")
+    if dist.get_world_size() != devices:
+        raise RuntimeError("sdqlpy_init(devices=%d): the process group has %d ranks" % (devices, dist.get_world_size()))
+    return DistributedRunner(eng, dist.get_rank(), dist.get_world_size(), partition=partition)
+
+
+def _is_join_shape(ops):
+    return (len(ops) == 4 and all(isinstance(o, ScanOp) for o in ops[:3]) and isinstance(ops[3], FinalizeOp)
+            and ops[0].kind == "dict" and ops[0].unique and ops[0].probe is None
+            and ops[1].kind == "dict" and ops[1].unique and ops[1].probe is not None and ops[1].probe.dict_name == ops[0].out
+            and ops[2].kind == "dict" and not ops[2].unique and ops[2].probe is not None and ops[2].probe.dict_name == ops[1].out)
 
 
 def _ipreds(flt):

@@ -19,7 +19,9 @@ class TextRefs:
     read — a 389 K-row Q10 result spends 70 of its 72 ms in that gather."""
 
     def __init__(self, refs, decoder):
-        self.refs, self.decoder = refs, decoder
+        # own copy of the references: the array handed in may view the pinned result block of the call
+        # that produced it, and a lazy column must not keep that block out of the pool
+        self.refs, self.decoder = np.array(refs, copy=True), decoder
 
     dtype = property(lambda self: self.decoder.dtype)
     shape = property(lambda self: self.refs.shape)
@@ -34,10 +36,25 @@ class TextRefs:
     def __getitem__(self, idx):
         if isinstance(idx, (int, np.integer)):
             return self.decoder[self.refs[idx]]
-        return TextRefs(self.refs[idx], self.decoder)            # slices / index arrays stay references
+        out = TextRefs.__new__(TextRefs)                          # slices / index arrays stay references
+        out.refs, out.decoder = self.refs[idx], self.decoder
+        return out
 
     def tolist(self):
         return self.decoder[self.refs].tolist()
+
+    # comparisons are element-wise on the decoded text, as for an ndarray (identity comparison of two
+    # lazy columns would silently yield one bool)
+    def __eq__(self, other):
+        return np.asarray(self) == (np.asarray(other) if isinstance(other, TextRefs) else other)
+
+    def __ne__(self, other):
+        return np.asarray(self) != (np.asarray(other) if isinstance(other, TextRefs) else other)
+
+    __hash__ = None
+
+    def astype(self, dtype):
+        return np.asarray(self).astype(dtype)
 
 
 LAZY_TEXT_ROWS = 4096        # results with at least this many rows keep their text columns as TextRefs

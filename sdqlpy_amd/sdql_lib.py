@@ -28,7 +28,7 @@ import time
 import numpy as np
 
 __all__ = [
-    "string", "date", "read_csv", "write_columns", "read_columns", "sr_dict", "record", "vector",
+    "string", "date", "read_csv", "write_columns", "read_columns", "shard_rows", "sr_dict", "record", "vector",
     "extractYear", "firstIndex", "startsWith", "endsWith", "dictSize", "substr", "unique", "dense",
     "sdqlpy_init", "sdql_compile", "benchmark",
 ]
@@ -244,6 +244,18 @@ def table_from_columns(headers, columns):
     return sr_dict({"headers": list(headers), "data": cols}, None, True)
 
 
+def shard_rows(table, rank, world):
+    """Rows [n*rank/world, n*(rank+1)/world) of a columnar table, marked as this rank's shard
+    (`.shard = (rank, world)`): what a rank of a multi-GPU run passes for a table it does not hold
+    whole.  A table without the mark is taken to be complete on every rank."""
+    c = table.getContainer()
+    n = len(c["data"][0]) if c["data"] else 0
+    lo, hi = n * rank // world, n * (rank + 1) // world
+    out = sr_dict({"headers": list(c["headers"]), "data": [np.ascontiguousarray(a[lo:hi]) for a in c["data"]]}, None, True)
+    out.shard = (rank, world)
+    return out
+
+
 def read_csv(file_path, header_type_dict, dataset_name, delimiter='|'):
     """Load a dbgen-style text table into one numpy array per column: int -> int64, float ->
     float64, date -> yyyymmdd int64, string(n) -> '<U n' (ref sdql_lib.py:69-129).  A trailing
@@ -274,17 +286,30 @@ def read_columns(directory, header_type_dict=None, mmap=True):
 # ------------------------------------------------------------------------------------------------
 # init / compile / benchmark
 # ------------------------------------------------------------------------------------------------
-_state = {"mode": None, "threads": 1, "device": None}
+_state = {"mode": None, "threads": 1, "device": None, "runner": None}
 
 
-def sdqlpy_init(execution_mode=0, threads_count=1, device=None):
+def use_runner(runner):
+    """Route decorated queries through a multi-GPU runner (dist.DistributedRunner), or back to the
+    single-GPU engine with None.  sdqlpy_init(3, devices=N) does this itself; tests install a runner
+    built over a gloo group and the CPU implementation of the ABI."""
+    _state["runner"] = runner
+
+
+def sdqlpy_init(execution_mode=0, threads_count=1, device=None, devices=None):
     """Select how decorated queries run (ref sdql_lib.py:372-387).
 
     1 / 2 (the reference's "compile" / "reuse compiled") and 3 all select the HIP backend here:
     there is nothing to compile at init time, plans are lowered on first call and cached.
     0 (interpret in Python) is the reference's own oracle mode and is not provided.
     ``threads_count`` is accepted for signature compatibility; the GPU grid is not capped by it.
-    ``device`` picks the GPU (default: LOCAL_RANK or 0)."""
+    ``device`` picks the GPU (default: LOCAL_RANK or 0).
+    ``devices=N`` (N > 1) runs every decorated query on N GPUs: one process per GPU (launch with
+    ``python -m torch.distributed.run --nproc-per-node N``), each calling sdqlpy_init(3, devices=N)
+    and passing its own row shards (tables marked by `shard_rows` / `tpch.generate(shard=...)`; an
+    unmarked table is taken to be whole on every rank).  Scalars and small group-bys come back
+    complete on every rank; a partitioned join returns this rank's key partition (dist.py)."""
+    _state["runner"] = None
     if execution_mode == MODE_PYTHON:
         _state["mode"] = MODE_PYTHON
         return
@@ -295,7 +320,10 @@ def sdqlpy_init(execution_mode=0, threads_count=1, device=None):
     _state["threads"] = int(threads_count)
     _state["device"] = device
     from . import engine
-    engine.default_engine(device=device, threads=int(threads_count))   # fails loudly if libsdqlhip.so is missing
+    eng = engine.default_engine(device=device, threads=int(threads_count))   # fails loudly if libsdqlhip.so is missing
+    if devices is not None and int(devices) > 1:
+        from . import dist as sdist
+        _state["runner"] = sdist.default_runner(eng, int(devices))
 
 
 def sdql_compile(in_type):
@@ -311,6 +339,8 @@ def sdql_compile(in_type):
                 raise NotImplementedError(
                     "execution_mode 0 (interpret in Python) is not part of the MI355X backend; "
                     "it exists only in the reference, where it serves as the parity oracle")
+            if _state.get("runner") is not None:                 # sdqlpy_init(3, devices=N): this rank's part of a multi-GPU run
+                return _state["runner"].run(wrapper, list(args), top=top)
             from . import engine, frontend
             if "plan" not in cache:
                 cache["plan"] = frontend.lower_function(func, in_type)

@@ -252,6 +252,8 @@ def generate(sf, seed=DEFAULT_SEED, tables=("lineitem", "customer", "orders"), c
             total = table_rows("orders" if t == "lineitem" else t, sf)
             rr = (total * rank // world, total * (rank + 1) // world)
         db[t] = _with_derived(t, sf, seed, cols, rr, threads)
+        if rr is not None:
+            db[t].shard = tuple(shard)          # this rank holds a row range of the table, not all of it (dist.DistributedRunner)
     return db
 
 

@@ -17,7 +17,9 @@ def shard_rows(table, rank, world, perm=None):
     n = len(c["data"][0])
     idx = np.arange(n) if perm is None else perm
     mine = idx[n * rank // world: n * (rank + 1) // world]
-    return tpch.table_from_columns(c["headers"], [np.ascontiguousarray(a[mine]) for a in c["data"]])
+    out = tpch.table_from_columns(c["headers"], [np.ascontiguousarray(a[mine]) for a in c["data"]])
+    out.shard = (rank, world)                # a row shard, not the whole table (dist.DistributedRunner._whole_params)
+    return out
 
 
 def main(rank, world, port, sf, mode, out_path):
@@ -77,6 +79,32 @@ def main(rank, world, port, sf, mode, out_path):
         out["q18_top"] = {"columns": t18.columns, "rows": t18.ordered_rows()}
     except frontend.UnsupportedQuery as exc:
         out["q18"] = {"unsupported": str(exc)}
+    # q3 with its small build side (customer) held whole on every rank: the set is built locally, no
+    # collective touches it (an all-reduce of identical bitmaps would corrupt it); a whole build or probe
+    # side of the partitioned join is refused by every rank alike
+    r3w = runner.run("q3", db18)
+    out["q3_customer_whole"] = {"columns": r3w.columns, "rows": runner.gather_rows(r3w)}
+    db3o = dict(db)
+    db3o["orders"] = tpch.generate(sf, tables=["orders"], columns=cols, threads=2)["orders"]
+    try:
+        runner.run("q3", db3o)
+        out["q3_orders_whole"] = {"ran": True}
+    except frontend.UnsupportedQuery as exc:
+        out["q3_orders_whole"] = {"unsupported": str(exc)}
+    # the decorated function itself instead of a registry name, tables passed positionally
+    r1f = runner.run(Q.q1, [db["lineitem"]])
+    out["q1_by_function"] = {"columns": r1f.columns, "rows": r1f.rows()}
+    # the public route: decorated functions called directly once a runner is installed (what
+    # sdqlpy_init(3, devices=N) sets up over RCCL)
+    from sdqlpy_amd import sdql_lib
+    engine.use_engine(eng)
+    sdql_lib.use_runner(runner)
+    out["q6_decorated"] = Q.q6(db["lineitem"])
+    r3d = Q.q3(db["customer"], db["orders"], db["lineitem"])
+    out["q3_decorated"] = {"columns": r3d.columns, "rows": runner.gather_rows(r3d)}
+    t3d = Q.q3.top(*Q.TPCH_ORDER["q3"])(db["customer"], db["orders"], db["lineitem"])
+    out["q3_decorated_top"] = t3d.ordered_rows()
+    sdql_lib.use_runner(None)
     # q10's groups (customers) are not partitioned with the order key: refused, by every rank alike
     cols10 = tpch.columns_for(["q10"])
     db10 = tpch.generate(sf, tables=sorted(cols10), columns=cols10, threads=2, shard=(rank, world))

@@ -93,6 +93,14 @@ def test_two_ranks_match_single_process(mode, tmp_path, single, oracle_lib):
     else:
         assert got["q3"]["partitioning"] == "hash" and got["q3"]["exchanged"]["build"] > 0
     assert 0 < got["q3"]["local_rows"] < len(got["q3"]["rows"])
+    # customer whole on every rank: same result as with the sharded customer; orders whole: refused
+    helpers.assert_rows_match(sorted(as_rows(got["q3_customer_whole"]["rows"])), helpers.result_rows(w3, got["q3_customer_whole"]["columns"]), 1e-12, mode + "/q3 customer whole")
+    assert "row-sharded" in got["q3_orders_whole"].get("unsupported", ""), got["q3_orders_whole"]
+    assert sorted(as_rows(got["q1_by_function"]["rows"])) == sorted(as_rows(got["q1"]["rows"]))
+    # decorated functions called directly with a runner installed (the sdqlpy_init(3, devices=N) route)
+    assert got["q6_decorated"] == got["q6"]
+    assert sorted(as_rows(got["q3_decorated"]["rows"])) == sorted(as_rows(got["q3"]["rows"]))
+    assert as_rows(got["q3_decorated_top"]) == as_rows(got["q3_top"]["rows"])
 
 
 def test_four_ranks_match_single_process(tmp_path, single, oracle_lib):

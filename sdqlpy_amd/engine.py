@@ -91,6 +91,7 @@ class Engine:
         self._dicts = {}           # id(string ndarray) -> (ndarray, codes int64 ndarray, distinct values)
         self._range_cache = {}     # id(int64 ndarray) -> (ndarray, (min, span))
         self._distinct_cache = {}  # id(ndarray) -> (ndarray, has no repeated value)
+        self._frozen = {}          # id(ndarray) -> ndarray made read-only on adoption (see column())
 
     def close(self):
         self.clear()
@@ -100,20 +101,56 @@ class Engine:
         for _, col in self._columns.values():
             col.free()
         self._columns.clear()
+        for arr in self._frozen.values():
+            arr.flags.writeable = True
+        self._frozen.clear()
         self._range_cache.clear()
         self._distinct_cache.clear()
         self.resident_bytes = 0
         self.generation += 1
 
     def column(self, arr):
-        """Resident column for a host array (uploaded on first use, then cached by identity)."""
+        """Resident column for a host array (uploaded on first use, then cached by identity).
+
+        The reference reads the caller's live buffers on every call (sdql_compiler.py:644-668); here the
+        first call copies them to HBM, so a later in-place edit of the host array would silently leave the
+        device (and the cached min/max, dictionaries, distinctness facts) describing the old data.  An
+        adopted array is therefore made read-only: writing to it raises at the writer.  To change data,
+        call `invalidate(table_or_array)` first (or pass new arrays)."""
         hit = self._columns.get(id(arr))
         if hit is not None and hit[0] is arr:
             return hit[1]
         col = self.ctx.upload(arr)
         self._columns[id(arr)] = (arr, col)
         self.resident_bytes += arr.nbytes
+        if isinstance(arr, np.ndarray) and arr.flags.writeable:
+            arr.flags.writeable = False
+            self._frozen[id(arr)] = arr
         return col
+
+    def invalidate(self, what):
+        """Forget everything derived from a table (columnar sr_dict) or a single host array — resident
+        column, min/max, dictionary codes, distinctness — and make the arrays writable again.  Plans
+        prepared against them are rebuilt on their next run."""
+        if hasattr(what, "getContainer"):
+            arrays = list(what.getContainer().get("data", []))
+        else:
+            arrays = [what]
+        for arr in arrays:
+            key = id(arr)
+            hit = self._columns.pop(key, None)
+            if hit is not None and hit[0] is arr:
+                hit[1].free()
+                self.resident_bytes -= arr.nbytes
+            d = self._dicts.pop(key, None)
+            if d is not None and d[1] is not None:
+                self.invalidate(d[1])                        # the code column built from it
+            self._range_cache.pop(key, None)
+            self._distinct_cache.pop(key, None)
+            frozen = self._frozen.pop(key, None)
+            if frozen is not None:
+                frozen.flags.writeable = True
+        self.generation += 1
 
     def rowid_column(self, nrows):
         """Resident int64 column 0..nrows-1: how a string column travels as a payload or a group key

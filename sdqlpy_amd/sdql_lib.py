@@ -30,7 +30,7 @@ import numpy as np
 __all__ = [
     "string", "date", "read_csv", "write_columns", "read_columns", "shard_rows", "sr_dict", "record", "vector",
     "extractYear", "firstIndex", "startsWith", "endsWith", "dictSize", "substr", "unique", "dense",
-    "sdqlpy_init", "sdql_compile", "benchmark",
+    "sdqlpy_init", "sdql_compile", "benchmark", "invalidate",
 ]
 
 # execution modes: 0 python (reference only), 1 compile + run, 2 run previously compiled, 3 HIP
@@ -324,6 +324,16 @@ def sdqlpy_init(execution_mode=0, threads_count=1, device=None, devices=None):
     if devices is not None and int(devices) > 1:
         from . import dist as sdist
         _state["runner"] = sdist.default_runner(eng, int(devices))
+
+
+def invalidate(table):
+    """Tell the backend that a table's host arrays are about to change: its resident copy and every
+    fact derived from it are dropped and the arrays become writable again.  (Arrays handed to a query
+    are read-only afterwards — the device holds a copy, so a silent in-place edit would give answers
+    for the old data; the reference re-reads the caller's buffers on every call.)"""
+    from . import engine
+    if engine._engine is not None:
+        engine._engine.invalidate(table)
 
 
 def sdql_compile(in_type):

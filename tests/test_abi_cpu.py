@@ -114,3 +114,33 @@ def test_oracle_empty_inputs(oracle_lib):
         assert empty_input_case(ctx)
     finally:
         ctx.close()
+
+
+def test_host_arrays_are_frozen_until_invalidated(oracle_lib):
+    """A column handed to a query lives on as a device copy: the host array becomes read-only, so an
+    in-place edit raises instead of silently leaving stale answers; after invalidate() the edit is
+    allowed and the next run sees it (the reference re-reads the caller's buffers on every call)."""
+    import numpy as np
+    import pytest
+    from sdqlpy_amd import engine, frontend, tpch
+    from sdqlpy_amd import tpch_queries as Q
+    eng = engine.Engine(oracle_lib.context(threads=1))
+    try:
+        db = tpch.generate(0.001, tables=["lineitem"], columns=tpch.columns_for(["q6", "q1"]), threads=1)
+        plan6, plan1 = frontend.lower_function(Q.q6), frontend.lower_function(Q.q1)
+        before6 = engine.execute_plan(eng, plan6, [db["lineitem"]])
+        before1 = engine.execute_plan(eng, plan1, [db["lineitem"]])
+        price = tpch.column(db["lineitem"], "l_extendedprice")
+        flag = tpch.column(db["lineitem"], "l_returnflag")
+        with pytest.raises(ValueError):
+            price[:] = 0.0
+        eng.invalidate(db["lineitem"])
+        price *= 2.0                                   # exact in binary: every product and sum doubles
+        flag[:] = "Z"                                  # the dictionary / group keys must be rebuilt too
+        after6 = engine.execute_plan(eng, plan6, [db["lineitem"]])
+        after1 = engine.execute_plan(eng, plan1, [db["lineitem"]])
+        assert after6 == 2.0 * before6 and before6 != 0.0
+        assert set(after1.column("l_returnflag").tolist()) == {"Z"} and set(before1.column("l_returnflag").tolist()) != {"Z"}
+        assert abs(after1.column("sum_base_price").sum() - 2.0 * before1.column("sum_base_price").sum()) <= 1e-9 * abs(after1.column("sum_base_price").sum())
+    finally:
+        eng.close()

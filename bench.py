@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py — TPCH Q1 + Q3 at SF=10 per GPU on MI355X (BASELINE.json metric: rows/sec + ms/query).
+"""bench.py — TPCH Q1 + Q3 + Q5 at SF=10 per GPU on MI355X (BASELINE.json metric: rows/sec + ms/query).
 
-A step = one pass of the hot path over the resident tables: q1(lineitem) then
-q3(lineitem, customer, orders), both through the public decorator API (front end -> planner ->
-C ABI -> HIP kernels), result materialised on the host.  Inputs are synthetic (sdqlpy_amd/tpch.py,
-seed fixed) and already resident in HBM when the timed region starts.  rows/sec = rows of every
-table scanned by the step / step time.
+A step = one pass of the hot path over the resident tables: q1(lineitem), q3(customer, orders,
+lineitem), q5(six tables), through the public decorator API (front end -> planner -> C ABI -> HIP
+kernels), result materialised on the host.  Inputs are synthetic (sdqlpy_amd/tpch.py, seed fixed)
+and already resident in HBM when the timed region starts.  rows/sec = rows of every table scanned
+by the step / step time.  `--extra-queries` (q6, q9: BASELINE configs[0] and [4]) are measured in the
+same run with the same protocol after the timed region; they are reported per query and are not part
+of `value`.
 
     python bench.py                       # 1 GPU, defaults finish in a few minutes
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    ... bench.py --gpus 8 --global-sf 100     # BASELINE configs[3] / [4]: SF=100 over the 8 GPUs
 
-N > 1 is weak scaling: every rank holds an SF=10 shard of a global SF=10*N database; q1 shards by
-rows, q3 is the partitioned join of sdqlpy_amd/dist.py (RCCL all-to-all for the redistribution step).
+N > 1 is weak scaling by default (every rank holds an SF=10 shard of a global SF=10*N database); q1
+shards by rows, q5 runs the chain plan, q3 is the partitioned join of sdqlpy_amd/dist.py.  The timed
+step HASH-partitions q3 on o_orderkey — build survivors and filtered probe rows really travel through
+the RCCL all-to-all — because that is the redistribution step the metric names; the range shortcut
+(dbgen-clustered shards: nothing moves) is timed beside it and reported, not counted in `value`.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -32,11 +38,14 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--sf", type=float, default=10.0, help="scale factor PER GPU")
-    ap.add_argument("--queries", default="q1,q3,q5")
+    ap.add_argument("--global-sf", type=float, default=0.0, help="scale factor of the WHOLE database, cut over the ranks (overrides --sf; "
+                                                                 "--gpus 8 --global-sf 100 = BASELINE configs[3]/[4])")
+    ap.add_argument("--queries", default="q1,q3,q5", help="the timed step (BASELINE metric: Q1/Q3/Q5)")
+    ap.add_argument("--extra-queries", default=None, help="measured after the timed region, reported per query only (default q6,q9 at N=1, none at N>1)")
     ap.add_argument("--profile-iters", type=int, default=5, help="extra untimed passes with per-kernel HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="use the distributed plan even with one rank (exercises the RCCL path)")
-    ap.add_argument("--partition", default="auto", choices=["auto", "range", "hash"])
+    ap.add_argument("--partition", default="hash", choices=["auto", "range", "hash"], help="q3's partitioning in the timed step at N > 1")
     ap.add_argument("--cpu-sample-sf", type=float, default=0.0, help="0 = pick so the CPU leg takes ~10-30 s")
     return ap.parse_args(argv)
 
@@ -51,13 +60,22 @@ def algorithmic_bytes(q, rows):
         return 32 * rows["lineitem"]
     if q == "q5":
         return 16 * rows["customer"] + 24 * rows["orders"] + 16 * rows["supplier"] + 32 * rows["lineitem"]
+    if q == "q9":
+        return 228 * rows["part"] + 24 * rows["partsupp"] + 16 * rows["orders"] + 16 * rows["supplier"] + 48 * rows["lineitem"]
     raise KeyError(q)
 
 
 def scanned_rows(q, rows):
     return {"q1": lambda: rows["lineitem"], "q6": lambda: rows["lineitem"],
             "q3": lambda: rows["lineitem"] + rows["customer"] + rows["orders"],
-            "q5": lambda: rows["lineitem"] + rows["customer"] + rows["orders"] + rows["supplier"] + rows["nation"] + rows["region"]}[q]()
+            "q5": lambda: rows["lineitem"] + rows["customer"] + rows["orders"] + rows["supplier"] + rows["nation"] + rows["region"],
+            "q9": lambda: rows["lineitem"] + rows["orders"] + rows["part"] + rows["partsupp"] + rows["supplier"] + rows["nation"]}[q]()
+
+
+# the kernel that streams the big table of each query, and the algorithmic bytes one launch of it covers
+DOMINANT = {"q1": ("k_groupby_reg", lambda r: 48 * r["lineitem"]), "q3": ("k_probe_agg", lambda r: 32 * r["lineitem"]),
+            "q6": ("k_scan_sum", lambda r: 32 * r["lineitem"]), "q5": ("k_lookup_agg", lambda r: 32 * r["lineitem"]),
+            "q9": ("k_lookup_agg", lambda r: 48 * r["lineitem"])}
 
 
 def main(argv=None, hooks=None):
@@ -74,6 +92,8 @@ def main(argv=None, hooks=None):
     os.dup2(2, 1)
     queries = [q for q in args.queries.split(",") if q]
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    extra = args.extra_queries if args.extra_queries is not None else ("q6,q9" if world == 1 else "")
+    extra = [q for q in extra.split(",") if q and q not in queries]
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -99,10 +119,12 @@ def main(argv=None, hooks=None):
     from sdqlpy_amd.sdql_lib import sdqlpy_init
 
     t0 = time.time()
-    need = tpch.columns_for(queries)
+    need = tpch.columns_for(queries + extra)
     tables = sorted(need)
     shard = (rank, world) if world > 1 else None
-    db = tpch.generate(args.sf * world, tables=tables, columns=need, shard=shard)
+    sf_global = args.global_sf if args.global_sf > 0 else args.sf * world
+    sf_per_gpu = sf_global / world
+    db = tpch.generate(sf_global, tables=tables, columns=need, shard=shard)
     rows = {t: len(db[t].getContainer()["data"][0]) for t in tables}
     gen_s = time.time() - t0
 
@@ -111,10 +133,11 @@ def main(argv=None, hooks=None):
     else:
         sdqlpy_init(3, 1, device=local_rank)
         eng = engine.default_engine(device=local_rank)
-    runner = None
+    runner = runner_range = None
     if use_dist:
         from sdqlpy_amd import dist as sdist
         runner = sdist.DistributedRunner(eng, rank, world, partition=args.partition)
+        runner_range = sdist.DistributedRunner(eng, rank, world, partition="auto")      # the clustered-shard shortcut, timed beside
         run_query = lambda q: runner.run(q, db)           # noqa: E731
     else:
         run_query = lambda q: Q.run(q, db)                # noqa: E731
@@ -133,6 +156,7 @@ def main(argv=None, hooks=None):
         run_query(q)
     barrier()
     first_pass_s = time.time() - t0
+    uploaded_bytes = int(eng.resident_bytes)              # host columns copied to HBM by that pass (pinned-staged H2D)
 
     for _ in range(args.warmup):
         for q in queries:
@@ -142,18 +166,20 @@ def main(argv=None, hooks=None):
     # of the dominant kernel (profiling mode 2: record only, nothing synchronises; events around
     # all ~45 launches of a step would add ~0.1 ms of event packets per query); read afterwards.
     dom_q = "q1" if "q1" in queries else queries[0]
-    dom_kernel = {"q1": "k_groupby_reg", "q3": "k_probe_agg", "q6": "k_scan_sum", "q5": "k_lookup_agg", "q9": "k_lookup_agg"}[dom_q]
+    dom_kernel = DOMINANT[dom_q][0]
 
-    def run_steps(nsteps, only):
-        per_q = {q: 0.0 for q in queries}
+    def run_steps(nsteps, only, qs=None, run=None):
+        qs = queries if qs is None else qs
+        run = run or run_query
+        per_q = {q: 0.0 for q in qs}
         eng.ctx.set_profiling(2, only=only)
         barrier()
         t_begin = time.perf_counter()
         marks = []                                       # (query, number of launches recorded so far)
         for _ in range(nsteps):
-            for q in queries:
+            for q in qs:
                 tq = time.perf_counter()
-                run_query(q)
+                run(q)
                 per_q[q] += (time.perf_counter() - tq) * 1e3
                 marks.append((q, eng.ctx.lib.sdqh_profile_count(eng.ctx.handle)))
         barrier()
@@ -171,6 +197,34 @@ def main(argv=None, hooks=None):
     # per-kernel table: a separate pass with events around every launch, after the timed region
     profile_steps = max(1, min(args.steps, 10))
     _, _, launch_log = run_steps(profile_steps, None)
+    exchange = None
+    if use_dist and "q3" in queries:
+        # q3's redistribution step, both ways, outside `value`: what moved and what it cost
+        exchange = {}
+        for label, rn in ((args.partition, runner), ("auto", runner_range)):
+            rn.run("q3", db)
+            took, _, _ = run_steps(max(1, min(args.steps, 10)), "-", ["q3"], lambda q, rn=rn: rn.run(q, db))
+            ms = took / max(1, min(args.steps, 10)) * 1e3
+            if world > 1:
+                t = torch.tensor([ms], dtype=torch.float64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ms = float(t.item())
+                moved = torch.tensor([rn.exchanged_bytes], dtype=torch.float64, device=device)
+                dist.all_reduce(moved)
+                total_bytes = float(moved.item())
+            else:
+                total_bytes = float(rn.exchanged_bytes)
+            exchange[label if label != "auto" else "auto(" + str(rn.last_partitioning) + ")"] = {
+                "ms_q3": round(ms, 4), "partitioning": rn.last_partitioning, "exchanged_rows_rank0": rn.exchanged_rows,
+                "exchanged_bytes_all_ranks": int(total_bytes),
+                "all_to_all_GBs_all_ranks": round(total_bytes / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
+    extra_ms, extra_log, extra_steps = {}, [], max(1, min(args.steps, 10))
+    if extra:
+        for q in extra:                                   # upload + warm-up, then the same protocol per query
+            for _ in range(1 + args.warmup):
+                run_query(q)
+        took_x, extra_ms, _ = run_steps(extra_steps, "-", extra)
+        _, _, extra_log = run_steps(extra_steps, None, extra)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -184,7 +238,7 @@ def main(argv=None, hooks=None):
     value = total_rows_per_step * args.steps / elapsed
 
     kstat = {}
-    for q, name, ms in launch_log:
+    for q, name, ms in launch_log + extra_log:
         name = "%s:%s" % (q, name)
         tot, n = kstat.get(name, (0.0, 0))
         kstat[name] = (tot + ms, n + 1)
@@ -192,6 +246,7 @@ def main(argv=None, hooks=None):
                for name, (tot, n) in kstat.items()}
     # kernels are attributed to the query that was running when they were launched
     device_ms = {q: sum(ms for qq, _, ms in launch_log if qq == q) / profile_steps for q in queries}
+    device_ms.update({q: sum(ms for qq, _, ms in extra_log if qq == q) / extra_steps for q in extra})
 
     out = None
     if rank == 0:
@@ -199,35 +254,47 @@ def main(argv=None, hooks=None):
         roofline = None
         if dom_launches:
             dom_ms = sum(dom_launches) / len(dom_launches)       # HIP events inside the timed region
-            per_launch_bytes = {"q1": 48 * rows["lineitem"], "q3": 32 * rows["lineitem"], "q6": 32 * rows["lineitem"], "q5": 32 * rows["lineitem"], "q9": 56 * rows["lineitem"]}[dom_q]
+            per_launch_bytes = DOMINANT[dom_q][1](rows)
             achieved = per_launch_bytes / (dom_ms * 1e-3) / 1e9
+            traffic, traffic_source = pmc_traffic(dom_q, dom_kernel, rows)
             roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom_name.split(":")[1], rows),
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                         "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": round(dom_ms, 4),
                         "launches_timed": len(dom_launches)}
         per_query = {}
-        for q in queries:
+        for q in queries + extra:
             ab = algorithmic_bytes(q, rows)
-            wall = per_query_ms[q] / args.steps
+            wall = (per_query_ms[q] / args.steps) if q in per_query_ms else (extra_ms[q] / extra_steps)
+            phys, phys_source = pmc_traffic(q, None, rows)
             per_query[q] = {"ms_wall": round(wall, 4), "ms_kernels": round(device_ms[q], 4),
+                            "in_timed_step": q in queries,
                             "rows_per_s_wall": round(scanned_rows(q, rows) / (wall * 1e-3), 1),
                             "algorithmic_bytes": ab,
                             "algorithmic_GBs_wall": round(ab / (wall * 1e-3) / 1e9, 1),
                             "algorithmic_GBs_kernels": round(ab / (device_ms[q] * 1e-3) / 1e9, 1) if device_ms[q] else None,
-                            "roofline_frac_kernels": round(ab / (device_ms[q] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if device_ms[q] else None}
+                            "roofline_frac_kernels": round(ab / (device_ms[q] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if device_ms[q] else None,
+                            # physical bytes moved beside the algorithmic figure
+                            "physical_bytes": phys,
+                            "physical_GBs_kernels": round(phys / (device_ms[q] * 1e-3) / 1e9, 1) if phys and device_ms[q] else None,
+                            "traffic_source": phys_source}
         out = {
-            "metric": "tpch_" + "_".join(queries) + "_sf%g_rows_per_sec" % args.sf, "value": round(value, 1), "unit": "rows/s",
+            "metric": "tpch_" + "_".join(queries) + "_sf%g_rows_per_sec" % sf_per_gpu, "value": round(value, 1), "unit": "rows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "TPCH " + "+".join(q.upper() for q in queries) + " SF=%g per GPU (BASELINE metric: Q1/Q3/Q5 at SF=10; q1 = configs[1], q3 = configs[2])" % args.sf,
-                       "sf_per_gpu": args.sf, "rows_per_gpu": rows, "partitioning": "none" if not use_dist else "q1 row-sharded; q5 small builds replicated, orders-lineitem join co-partitioned; q3 partitioned on o_orderkey (%s), RCCL all-to-all; exchanged rows %s"
+            "config": {"workload": "TPCH " + "+".join(q.upper() for q in queries) + " SF=%g per GPU (BASELINE metric: Q1/Q3/Q5 at SF=10; q1 = configs[1], q3 = configs[2])" % sf_per_gpu,
+                       "sf_per_gpu": sf_per_gpu, "sf_global": sf_global, "rows_per_gpu": rows,
+                       "partitioning": "none" if not use_dist else "q1 row-sharded; q5 small builds replicated, orders-lineitem join co-partitioned; q3 partitioned on o_orderkey (%s), RCCL all-to-all; exchanged rows %s"
                                        % (runner.last_partitioning, runner.exchanged_rows)},
             "ms_per_query": per_query,
             "kernels_pass": "separate pass of %d steps after the timed region, HIP events around every launch" % profile_steps,
             "kernels": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in sorted(kernels.items())},
             "roofline": roofline,
             "first_pass_with_upload_s": round(first_pass_s, 3), "generate_s": round(gen_s, 2),
+            # the boundary hands over host buffers: the PCIe-inclusive first pass (never the reported value)
+            "first_pass_upload": {"bytes": uploaded_bytes, "GBs_including_plan_lowering": round(uploaded_bytes / first_pass_s / 1e9, 2) if first_pass_s > 0 else None},
         }
+        if exchange is not None:
+            out["q3_exchange"] = exchange
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, queries, db, rows)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
@@ -237,20 +304,48 @@ def main(argv=None, hooks=None):
     return out
 
 
-def pmc_traffic(kernel, rows):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (FETCH_SIZE doubled
-    as MI355X_MICROARCH.md prescribes for 16-byte-per-lane streaming reads on gfx950, + WRITE_SIZE),
-    if that summary was taken on the same row counts; else None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+def pmc_traffic(q, kernel, rows):
+    """(HBM bytes, source tag) from the committed rocprofv3 PMC summary profiles/r02_pmc_traffic.json
+    (tools/pmc_per_query.py: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes per query;
+    bytes = 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950): with `kernel`,
+    bytes per launch of that kernel inside query `q`; without, bytes of one whole run of `q`.  The
+    numbers are constants of that committed run, valid only for the same row counts; else (None, None)."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     try:
         with open(path) as fh:
             rec = json.load(fh)
     except (OSError, ValueError):
-        return None
-    k = rec.get("kernels", {}).get(kernel)
-    if not k or rec.get("rows", {}).get("lineitem") != rows.get("lineitem"):
-        return None
-    return k.get("hbm_bytes_per_launch")
+        return None, None
+    entry = rec.get("queries", {}).get(q)
+    if not entry or any(rec.get("rows", {}).get(t) != rows.get(t) for t in entry.get("tables", ["lineitem"])):
+        return None, None
+    source = "committed rocprofv3 PMC run (profiles/r02_pmc_traffic.json), not this run"
+    if kernel is None:
+        return entry.get("hbm_bytes_per_run"), source
+    k = entry.get("kernels", {}).get(kernel)
+    return (k.get("hbm_bytes_per_launch") if k else None), source
+
+
+def physical_cores():
+    """(physical cores, logical CPUs) of this host."""
+    logical = os.cpu_count() or 1
+    try:
+        seen, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("physical id"):
+                    phys = ln.split(":")[1].strip()
+                elif ln.startswith("core id"):
+                    core = ln.split(":")[1].strip()
+                elif not ln.strip():
+                    if phys is not None and core is not None:
+                        seen.add((phys, core))
+                    phys = core = None
+        if seen:
+            return len(seen), logical
+    except OSError:
+        pass
+    return logical, logical
 
 
 def cpu_baseline(args, queries, db, rows):
@@ -261,11 +356,13 @@ def cpu_baseline(args, queries, db, rows):
     from sdqlpy_amd import tpch_queries as Q
     import subprocess
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
-    cores = os.cpu_count() or 1
+    cores_phys, cores = physical_cores()
     lib = abi.Library(os.path.join(ROOT, "oracle", "libsdqloracle.so"))
     eng = engine.Engine(lib.context(threads=cores))
-    # bounded sample: a prefix of the same generated tables (lineitem cut on the same order boundary)
-    frac = args.cpu_sample_sf / args.sf if args.cpu_sample_sf > 0 else min(1.0, 2.0 / args.sf)
+    # the sample: by default the WHOLE workload (a pass over SF=10 costs the CPU port under a second on
+    # a many-core host); --cpu-sample-sf bounds it to a prefix of the same generated tables (lineitem cut
+    # on an order boundary) for hosts where that would take minutes
+    frac = min(1.0, args.cpu_sample_sf / args.sf) if args.cpu_sample_sf > 0 else 1.0
     sample = {}
     n_ord = int(rows.get("orders", 0) * frac)
     for t, table in db.items():
@@ -281,7 +378,7 @@ def cpu_baseline(args, queries, db, rows):
             n = n_ord
         else:
             n = len(c["data"][0])               # dimension-side tables stay whole so key references resolve
-        sample[t] = tpch.table_from_columns(c["headers"], [np.ascontiguousarray(a[:n]) for a in c["data"]])
+        sample[t] = table if n == len(c["data"][0]) else tpch.table_from_columns(c["headers"], [np.ascontiguousarray(a[:n]) for a in c["data"]])
     srows = {t: len(sample[t].getContainer()["data"][0]) for t in sample}
     plans = {q: frontend.lower_function(Q.QUERIES[q]) for q in queries}
     run = lambda q: engine.execute_plan(eng, plans[q], [sample[t] for t in Q.QUERY_TABLES[q]])   # noqa: E731
@@ -314,10 +411,11 @@ def cpu_baseline(args, queries, db, rows):
             model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "")
     except OSError:
         pass
-    return {"value": round(total_rows * iters / elapsed, 1), "unit": "rows/s", "cores": cores, "kind": "port",
+    return {"value": round(total_rows * iters / elapsed, 1), "unit": "rows/s", "cores": cores, "threads": cores, "cores_physical": cores_phys, "kind": "port",
             "cpu_model": model, "value_one_thread": round(one_thread, 1),
-            "sample": "same generator, first %.0f%% of orders + their lineitems (%d lineitem rows), customer whole; %d passes of %s"
-                      % (100 * frac, srows.get("lineitem", 0), iters, "+".join(queries)),
+            "sample": ("the whole workload (%d lineitem rows)" % srows.get("lineitem", 0) if frac >= 1.0 else
+                       "same generator, first %.0f%% of orders + their lineitems (%d lineitem rows), dimension tables whole" % (100 * frac, srows.get("lineitem", 0)))
+                      + "; %d passes of %s, data resident in host RAM" % (iters, "+".join(queries)),
             "ms_per_query": {q: round(per_q[q] / iters * 1e3, 2) for q in queries}}
 
 

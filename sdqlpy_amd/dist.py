@@ -57,6 +57,7 @@ class DistributedRunner:
         self.partition = partition          # "auto" | "range" | "hash"
         self.last_partitioning = None
         self.exchanged_rows = {}
+        self.exchanged_bytes = 0            # bytes this rank sent to OTHER ranks through the all-to-all of its last partitioned join
         self._plans = {}
         self._gather_bufs = {}
         self._inflight = []                 # collective buffers that queued copy_ins still read (dropped at the next run)
@@ -170,6 +171,7 @@ class DistributedRunner:
         matrix = np.stack(self._all_gather_array(np.ascontiguousarray(counts, np.int64)))     # [source, dest]
         recv_counts = matrix[:, self.rank]
         n_send, n_recv = int(counts.sum()), int(recv_counts.sum())
+        self.exchanged_bytes += 8 * len(cols) * (n_send - int(counts[self.rank]))
         out = []
         for col in cols:
             new = self.ctx.alloc(n_recv, col.dtype)
@@ -708,6 +710,7 @@ class DistributedRunner:
         if st is None or st.generation != self.eng.generation or any(x is not y for x, y in zip(st.args, args)):
             st = cache[key] = self._prepare_join(plan, args, a_whole)
         self.last_partitioning = st.mode
+        self.exchanged_bytes = 0
         table_a, keep_a = self._replicated_set(st)
         recv, n_recv = None, 0
         if st.mode == "range":

@@ -91,6 +91,64 @@ def check_against_golden(res, gold, rel, what):
     assert_rows_match(result_rows(res, gold["columns"]), want, rel, what)
 
 
+def check_tbl_queries(ctx_engine, rel, rel_q10):
+    """Load the committed text tables with this package's read_csv, run every recorded query on
+    `ctx_engine`, compare with the reference's results on the same files."""
+    import json
+    from sdqlpy_amd import sdql_lib as L
+    tbl = os.path.join(ROOT, "tests", "golden", "tbl")
+    with open(os.path.join(ROOT, "tests", "golden", "tbl_query_golden.json")) as fh:
+        gold = json.load(fh)
+    db = {t: L.read_csv(os.path.join(tbl, t + ".tbl"), tpch.SCHEMAS[t], t) for t in gold["rows"]}
+    for t, n in gold["rows"].items():
+        assert len(db[t].getContainer()["data"][0]) == n, t
+    assert len(gold["results"]) >= 8
+    for q, want in gold["results"].items():
+        check_against_golden(run_query(ctx_engine, q, db), want, rel_q10 if q == "q10" else rel, "tbl/" + q)
+
+
+def hash_layout_case(ctx, nb, npr):
+    """Unique build + probe-aggregate on keys spread over 2^44 (no bitmap / direct index applies: the
+    open-addressing layout), checked against numpy."""
+    from sdqlpy_amd import abi
+    rng = np.random.default_rng(11)
+    keys = (rng.permutation(nb).astype(np.int64) << 20) + (np.int64(1) << 40) + rng.integers(0, 1 << 20, nb)
+    pay = rng.integers(0, 1 << 50, nb).astype(np.int64)
+    sel = rng.random(nb) < 0.5                                       # build filter: pay parity stands in for a predicate
+    pay = np.where(sel, pay | 1, pay & ~np.int64(1))
+    pidx = rng.integers(0, nb, npr)
+    pk = keys[pidx].copy()
+    miss = rng.random(npr) < 0.3
+    pk[miss] += 1 << 19                                              # not a build key (low 20 bits of a key are < 2^20; +2^19 may collide rarely: recomputed below)
+    pv = rng.random(npr)
+    ckeys, cpay, cpk, cpv = ctx.upload(keys), ctx.upload(pay), ctx.upload(pk), ctx.upload(pv)
+    odd = ctx.upload((pay & 1).astype(np.int64))
+    t = ctx.hash_build_unique(nb, abi.make_filter(ipreds=[(odd, 1, 1)]), [], ckeys, [cpay], accumulate=True)
+    assert t.size() == int(sel.sum())
+    ctx.hash_probe_aggregate(npr, abi.make_filter(), t, cpk, abi.make_tuple(abi.TUPLE_A, [cpv]))
+    cnt = ctx.table_compact_count(t, 1)
+    k, p, v, h = ctx.table_compact(t, 1, cnt)
+    t.free()
+    order = np.argsort(keys)
+    skeys = keys[order]
+    pos = np.searchsorted(skeys, pk)
+    pos[pos >= nb] = 0
+    hit = (skeys[pos] == pk) & sel[order][pos]
+    owner = order[pos[hit]]
+    want_hits = np.bincount(owner, minlength=nb)
+    want_sum = np.bincount(owner, weights=pv[hit], minlength=nb)
+    live = np.nonzero(want_hits)[0]
+    assert cnt == len(live)
+    got_order = np.argsort(k)
+    want_order = live[np.argsort(keys[live])]
+    assert (k[got_order] == keys[want_order]).all()
+    assert (p[0][got_order] == pay[want_order]).all()
+    assert (h[got_order] == want_hits[want_order]).all()
+    np.testing.assert_allclose(v[0][got_order], want_sum[want_order], rtol=1e-10)
+    for c in (ckeys, cpay, cpk, cpv, odd):
+        c.free()
+
+
 def compaction_block_case(ctx):
     """Build + probe-aggregate one table three times and finalise it (a) into a device-writable
     block that fits, (b) into one that overflows and is retried, (c) into pageable arrays; the three

@@ -144,3 +144,14 @@ def test_host_arrays_are_frozen_until_invalidated(oracle_lib):
         assert abs(after1.column("sum_base_price").sum() - 2.0 * before1.column("sum_base_price").sum()) <= 1e-9 * abs(after1.column("sum_base_price").sum())
     finally:
         eng.close()
+
+
+def test_hash_layout_case_on_the_cpu_implementation(oracle_lib):
+    """The scale test of the open-addressing layout (tests/test_hip_parity.py runs it at 12 M keys on
+    the GPU), small, against the CPU implementation: pins the test's own numpy model."""
+    import helpers
+    ctx = oracle_lib.context(threads=2)
+    try:
+        helpers.hash_layout_case(ctx, 50_000, 200_000)
+    finally:
+        ctx.close()

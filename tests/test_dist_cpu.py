@@ -133,6 +133,12 @@ def test_bench_contract_under_a_two_rank_launch(tmp_path):
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak" and rec["vs_baseline"] is None
     assert rec["unit"] == "rows/s" and rec["higher_is_better"] is True and rec["value"] > 0 and rec["ms_per_step"] > 0
     assert "workload" in rec["config"] and "q3 partitioned" in rec["config"]["partitioning"]
+    # the timed step hash-partitions q3: build and probe rows really cross ranks; the clustered-shard
+    # shortcut is reported beside it and moves nothing
+    ex = rec["q3_exchange"]
+    assert ex["hash"]["partitioning"] == "hash" and ex["hash"]["exchanged_rows_rank0"]["probe_sent"] > 0 and ex["hash"]["exchanged_bytes_all_ranks"] > 0
+    assert ex["auto(range)"]["exchanged_bytes_all_ranks"] == 0 and ex["auto(range)"]["exchanged_rows_rank0"]["probe_sent"] == 0
+    assert "hash" in rec["config"]["partitioning"]
     # whole-job aggregate: rows of BOTH ranks per step over the max-over-ranks time
     per_rank = sum(rec["config"]["rows_per_gpu"][t] for t in ("lineitem",)) * 3 + rec["config"]["rows_per_gpu"]["customer"] * 2 + rec["config"]["rows_per_gpu"]["orders"] * 2
     assert rec["value"] * rec["ms_per_step"] * 1e-3 > 1.5 * per_rank

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import helpers
-from sdqlpy_amd import engine, tpch
+from sdqlpy_amd import engine, frontend, tpch
 from sdqlpy_amd import tpch_queries as Q
 
 pytestmark = pytest.mark.gpu
@@ -159,6 +159,75 @@ def test_full_size_properties_sf10(hip_engine):
                     assert a == b, (q, k, c)
                 elif not c.startswith("avg"):                  # averages are not additive
                     assert abs(a - b) <= 1e-9 * abs(b), (q, k, c, a, b)
+    hip_engine.clear()
+
+
+def test_full_size_q9_and_topk_sf10(hip_engine):
+    """The two size holes of the SF=10 suite: q9 (composite-key probe + dense order lookup, 60 M probe rows)
+    through additivity over a lineitem split and a numpy total, and ORDER BY ... LIMIT on the device
+    against ordering the full SF=10 result on the host."""
+    qs = ("q3", "q9")
+    db = tpch.generate(10, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+    li = db["lineitem"].getContainer()
+    n = len(li["data"][0])
+    whole = helpers.run_query(hip_engine, "q9", db)
+    assert 100 <= whole.size() <= 175 and sorted(whole.columns) == ["nation", "o_year", "sum_profit"]
+    again = helpers.run_query(hip_engine, "q9", db)
+    helpers.assert_rows_match(helpers.result_rows(again, whole.columns), helpers.result_rows(whole, whole.columns), 1e-10, "q9 rerun")
+    cut = n // 3 + 77
+    sums = {}
+    for lo, hi in ((0, cut), (cut, n)):
+        part = dict(db)
+        part["lineitem"] = tpch.table_from_columns(li["headers"], [c[lo:hi] for c in li["data"]])
+        r = helpers.run_query(hip_engine, "q9", part)
+        for nat, yr, v in zip(r.column("nation").tolist(), r.column("o_year").tolist(), r.column("sum_profit").tolist()):
+            sums[(nat, yr)] = sums.get((nat, yr), 0.0) + v
+    want = dict(zip(zip(whole.column("nation").tolist(), whole.column("o_year").tolist()), whole.column("sum_profit").tolist()))
+    assert sums.keys() == want.keys()
+    for k, v in want.items():
+        assert abs(sums[k] - v) <= 1e-9 * abs(v), (k, sums[k], v)
+    # grand total against numpy: rows whose part is green (name contains the word) — every (part, supplier)
+    # pair of lineitem exists in partsupp, so the join drops nothing else
+    pa = db["part"].getContainer(); pcol = dict(zip(pa["headers"], pa["data"]))
+    ps = db["partsupp"].getContainer(); pscol = dict(zip(ps["headers"], ps["data"]))
+    green = np.zeros(int(pcol["p_partkey"].max()) + 1, bool)
+    green[pcol["p_partkey"][np.char.find(pcol["p_name"], "green") >= 0]] = True
+    col = dict(zip(li["headers"], li["data"]))
+    m = green[col["l_partkey"]]
+    nsupp = int(pscol["ps_suppkey"].max()) + 1
+    order = np.argsort(pscol["ps_partkey"] * nsupp + pscol["ps_suppkey"], kind="stable")
+    skeys = (pscol["ps_partkey"] * nsupp + pscol["ps_suppkey"])[order]
+    lk = col["l_partkey"][m] * nsupp + col["l_suppkey"][m]
+    pos = np.searchsorted(skeys, lk)
+    assert (skeys[pos] == lk).all()
+    sc = pscol["ps_supplycost"][order][pos]
+    total = float(np.sum(col["l_extendedprice"][m] * (1.0 - col["l_discount"][m]) - sc * col["l_quantity"][m]))
+    got_total = float(whole.column("sum_profit").sum())
+    assert abs(got_total - total) <= 1e-9 * abs(total), (got_total, total)
+    del m, lk, pos, sc, green
+    # top-k on the device == ordering the full result
+    full = helpers.run_query(hip_engine, "q3", db)
+    assert full.size() > 100000
+    for k in (1, 10, 100):
+        order_by = Q.TPCH_ORDER["q3"][1]
+        plan = frontend.lower_function(Q.QUERIES["q3"])
+        got = engine.execute_plan(hip_engine, plan, [db[t] for t in Q.QUERY_TABLES["q3"]], top=(k, order_by)).ordered_rows()
+        want_rows = full.top(k, order_by).ordered_rows()
+        assert [r[0] for r in got] == [r[0] for r in want_rows], k
+        helpers.assert_rows_match(got, want_rows, 1e-10, "q3 top %d" % k)
+    hip_engine.clear()
+
+
+def test_hash_layout_at_scale(hip_engine):
+    """The open-addressing layout (k_clear / k_insert / hash probes) at 12 M build keys: keys spread
+    over 2^44 so no bitmap / direct index applies.  Join + aggregation against numpy."""
+    helpers.hash_layout_case(hip_engine.ctx, 12_000_000, 40_000_000)
+
+
+@pytest.mark.gpu
+def test_text_tables_to_query_results_match_the_reference(hip_engine):
+    """.tbl -> read_csv -> HIP kernels against the reference's own load + query of the same files."""
+    helpers.check_tbl_queries(hip_engine, REL, 1e-10)
     hip_engine.clear()
 
 

@@ -124,3 +124,15 @@ def test_dictionary_encoding_equals_numpy_unique():
     assert one[0].tolist() == [0] * 10 and one[1].tolist() == ["same"]
     empty = loader.dict_encode(np.array([], "<U3"))
     assert len(empty[0]) == 0 and len(empty[1]) == 0
+
+
+def test_text_tables_to_query_results_match_the_reference(oracle_lib):
+    """.tbl -> read_csv -> front end / planner -> C ABI (CPU implementation) against what the reference
+    gets from ITS read_csv + ITS queries on the same files (tests/golden/make_tbl_query_golden.py)."""
+    import helpers
+    from sdqlpy_amd import engine
+    eng = engine.Engine(oracle_lib.context(threads=1))
+    try:
+        helpers.check_tbl_queries(eng, 0.0, 1e-12)
+    finally:
+        eng.close()

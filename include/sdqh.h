@@ -39,14 +39,23 @@
 #ifndef SDQH_H
 #define SDQH_H
 
+#ifndef __HIPCC_RTC__
 #include <stddef.h>
 #include <stdint.h>
+#else   /* hiprtc (run-time kernel specialisation): no libc headers; the fixed-width types live in __hip_internal */
+using __hip_internal::int8_t;  using __hip_internal::uint8_t;  using __hip_internal::int16_t; using __hip_internal::uint16_t;
+using __hip_internal::int32_t; using __hip_internal::uint32_t; using __hip_internal::int64_t; using __hip_internal::uint64_t;
+#ifndef INT64_MIN
+#define INT64_MIN (-9223372036854775807ll - 1)
+#define INT64_MAX 9223372036854775807ll
+#endif
+#endif
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define SDQH_ABI_VERSION 3   /* 2: sdqh_filter carries column-vs-column predicates; string modes 3 / 4.  3: sdqh_table_share_groups */
+#define SDQH_ABI_VERSION 4   /* 2: sdqh_filter carries column-vs-column predicates; string modes 3 / 4.  3: sdqh_table_share_groups.  4: row programs (sdqh_x*) */
 
 /* ---- status codes ---------------------------------------------------------------------- */
 #define SDQH_OK              0
@@ -140,7 +149,10 @@ typedef struct sdqh_probe { const sdqh_table* table; const sdqh_column* key; } s
 /* ---- context ----------------------------------------------------------------------------- */
 int         sdqh_abi_version(void);
 const char* sdqh_backend_name(void);                    /* "hip-gfx950" or "cpu-oracle" */
-int         sdqh_create(int device, sdqh_ctx** out);
+int         sdqh_create(int device, sdqh_ctx** out);       /* HIP build, device = -1: a compile-only context for build checks on a host without a GPU —
+                                                              columns can be wrapped (never dereferenced) and every sdqh_x* call stops after specialising its
+                                                              kernel, returning SDQH_ERR_DEVICE with "kernel specialised" (sdqh_xbuild / sdqh_xkey_set: SDQH_OK and a
+                                                              placeholder table later programs can name); every other call is invalid on it */
 void        sdqh_destroy(sdqh_ctx* ctx);
 const char* sdqh_last_error(const sdqh_ctx* ctx);
 int         sdqh_set_threads(sdqh_ctx* ctx, int threads);   /* CPU build: worker count; HIP build: accepted, ignored */
@@ -349,6 +361,114 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
                           int nkeys, const sdqh_source* keys, int tuple_shape, const sdqh_source* operands,
                           int max_groups, int64_t* out_keys, double* out_values, int64_t* out_counts,
                           int32_t* out_ngroups);
+
+/* ---- row programs: the open expression / predicate vocabulary (ABI 4) -----------------------------
+ * What the reference's generator prints as the C++ body of an emitted loop — any boolean expression
+ * (`and` / `or` printed as `*` / `+`, src/sdqlpy/lib/sdql_compiler.py:277-292), conditional values
+ * (IfExpr, lib/sdql_ir.py:294-303), arithmetic on columns and looked-up fields (AdditionCodeGenerator
+ * targets, lib/sdql_ir_cpp_generator_par.py:712-795), lookups `.at(k)` / `contains(k)` (85-96), the
+ * VarChar methods (include/varchar.h:61-124) — travels here as DATA: a list of typed operations in
+ * single-assignment form, operation i computing value i from earlier values.  The HIP build
+ * specialises a hand-written kernel skeleton on the program at run time (hiprtc; code objects are
+ * cached by program structure, as the reference caches its compiled module, sdql_lib.py:377-387);
+ * the CPU build interprets it row by row.  Constants and column / table bindings are arguments of the
+ * specialised kernel, not part of its code.
+ *
+ * A row is processed as: gates in order (all must be true; a later gate is not evaluated once one
+ * fails, so a gate may guard the lookups of the next), then `key` and `vals`.  A FIELD / ACC of a lookup
+ * that missed reads as 0.  Arithmetic is evaluated exactly as written (no reassociation, no FMA).
+ */
+#define SDQH_T_I64  0
+#define SDQH_T_F64  1
+#define SDQH_T_BOOL 2
+
+#define SDQH_X_COL     1   /* col[row]; the type is the column's (I64 / F64)                                              */
+#define SDQH_X_ROWID   2   /* the row number, i64                                                                         */
+#define SDQH_X_CONST   3   /* imm_i (i64, bool) or imm_f (f64), by `type`                                                 */
+#define SDQH_X_LOOKUP  4   /* `table` looked up by key value a (i64; a PACK2 value for a two-part key): bool = found       */
+#define SDQH_X_FIELD   5   /* payload field `aux` of the entry matched by LOOKUP op a, read as `type` (8 raw bytes)       */
+#define SDQH_X_ACC     6   /* accumulator `aux` (f64) of the entry matched by LOOKUP op a; aux = -1: its row count (i64)  */
+#define SDQH_X_ADD    10   /* a + b   (both i64 or both f64)                                                              */
+#define SDQH_X_SUB    11
+#define SDQH_X_MUL    12
+#define SDQH_X_DIV    13   /* f64 only                                                                                   */
+#define SDQH_X_NEG    14
+#define SDQH_X_I2F    15   /* (double)a                                                                                  */
+#define SDQH_X_YEAR   16   /* a / 10000 on a yyyymmdd integer (extractYear, sdql_lib.py:341-342)                          */
+#define SDQH_X_PACK2  17   /* (a << 32) | b for a, b in [0, 2^32): the packing of a two-part key; a part outside fails the call (SDQH_ERR_UNSUPPORTED) */
+#define SDQH_X_LT     20   /* a < b  (both i64 or both f64) -> bool; NaN compares false, as in C                           */
+#define SDQH_X_LE     21
+#define SDQH_X_GT     22
+#define SDQH_X_GE     23
+#define SDQH_X_EQ     24
+#define SDQH_X_NE     25
+#define SDQH_X_AND    30   /* bool, bool -> bool                                                                          */
+#define SDQH_X_OR     31
+#define SDQH_X_NOT    32
+#define SDQH_X_SELECT 33   /* a ? b : c  (b, c of one type)                                                               */
+#define SDQH_X_STR    40   /* predicate `aux` (SDQH_STR_*) of STR column `col` against the constant str[0..slen): bool     */
+#define SDQH_X_STRIDX 41   /* firstIndex(col, constant): position of the first occurrence, -1 if none (varchar.h:91-97), i64 */
+#define SDQH_X_CHAR   42   /* code unit `aux` of STR column `col` (0 past the text), i64 — substr() as group-key parts     */
+
+#define SDQH_STR_EQ 0      /* the modes of sdqh_spred.negate */
+#define SDQH_STR_NE 1
+#define SDQH_STR_CONTAINS 2
+#define SDQH_STR_PREFIX 3
+#define SDQH_STR_SUFFIX 4
+
+#define SDQH_MAX_XOPS    96
+#define SDQH_MAX_XCOLS   16   /* distinct columns a program may read                   */
+#define SDQH_MAX_XTABLES 6    /* distinct tables it may look up                        */
+#define SDQH_MAX_XGATES  16
+#define SDQH_MAX_XSTR    256  /* code units of all string constants together          */
+
+typedef struct sdqh_xop {
+    int32_t code, type;             /* SDQH_X_*, SDQH_T_* of the result */
+    int32_t a, b, c;                /* operand operation indices, -1 = unused */
+    int32_t aux;
+    int64_t imm_i;
+    double  imm_f;
+    const sdqh_column* col;         /* COL / STR / STRIDX / CHAR */
+    const sdqh_table*  table;       /* LOOKUP */
+    const uint32_t*    str;         /* STR / STRIDX: the constant's code units (host memory, read during the call) */
+    int32_t slen, _pad;
+} sdqh_xop;
+
+typedef struct sdqh_program {
+    int32_t nops, ngates;
+    const sdqh_xop* ops;
+    const int32_t*  gates;          /* bool operations */
+    int32_t key;                    /* i64 operation: group / build / set key; -1 = none */
+    int32_t nvals;
+    const int32_t* vals;            /* summed values (f64; an i64 value is summed as an integer count) or payload fields (8 raw bytes) */
+} sdqh_program;
+
+/* K-A (...generator_par.py:258-291): out_values[v] = sum of value v over the passing rows, *out_count = passing rows.
+ * nvals <= SDQH_TUPLE_MAX_VALUES, every value f64. */
+int sdqh_xscan_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, double* out_values, int64_t* out_count);
+/* K-C over a small group domain (402-440): groups keyed by the program's key (any i64 >= 0), <= max_groups
+ * (<= SDQH_MAX_LOOKUP_GROUPS) of them; outputs as sdqh_groupby_small with nkeys = 1. */
+int sdqh_xgroupby(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int max_groups,
+                  int64_t* out_keys, double* out_values, int64_t* out_counts, int32_t* out_ngroups);
+/* K-B (331-369): unique build keyed by the program's key, payload = its vals (<= SDQH_MAX_PAYLOAD); first row wins.
+ * [key_lo, key_hi]: bounds of the key the caller knows from its sources (key_lo > key_hi: none known) — a
+ * dense range gets the direct (bitmap + rank) index, anything else open addressing.  A key outside given
+ * bounds fails the call (SDQH_ERR_UNSUPPORTED). */
+int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t key_lo, int64_t key_hi, int accumulate, sdqh_table** out);
+/* Membership-only K-B: the set of keys of the passing rows (exact bitmap over [key_lo, key_hi], which the
+ * caller knows from the key's sources); SDQH_ERR_UNSUPPORTED if a key falls outside. */
+int sdqh_xkey_set(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t key_lo, int64_t key_hi, sdqh_table** out);
+/* K-C large: for every passing row, the entry of `table` matched by LOOKUP operation `lookup_op` (which must
+ * be among the gates) gets acc += vals, hits += 1 (the group is the matched entry, test/test_all.py:164-172). */
+int sdqh_xprobe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int lookup_op, sdqh_table* table);
+/* The entries of a table with at least min_hits rows as resident columns — key, the npayload payload
+ * fields, the SDQH_TUPLE_MAX_VALUES accumulators (F64), the hit count — so that a sum over a result
+ * dictionary (K-F / HAVING with lookups, ...generator_par.py:520-568) is a scan like any other.
+ * out_cols[1 + npayload + SDQH_TUPLE_MAX_VALUES + 1]; tables without accumulators yield zero columns there. */
+int sdqh_table_columns(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, sdqh_column** out_cols, int64_t* out_rows);
+/* HIP build: number of kernels specialised so far in this process / how many of them came from the on-disk
+ * cache; CPU build: zeros.  Diagnostics for tests and the bench. */
+int sdqh_jit_stats(sdqh_ctx* ctx, int64_t* compiled, int64_t* from_cache);
 
 /* ---- multi-GPU redistribution helpers (no reference counterpart) -------------- */
 /* Filter + semi-join probes, then gather `ncols` columns of the surviving rows into freshly

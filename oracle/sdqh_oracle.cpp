@@ -942,6 +942,392 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
     return SDQH_OK;
 }
 
+// ---- row programs (ABI 4): the open expression / predicate vocabulary, interpreted row by row ---------
+// What the reference's generator prints as the body of a loop (conditions: sdql_compiler.py:277-292,
+// IfExpr: sdql_ir.py:294-303, arithmetic / lookups: sdql_ir_cpp_generator_par.py:85-96,712-795, VarChar
+// methods: include/varchar.h:61-124) arrives as a list of typed operations; this is its interpreter.
+namespace {
+
+struct XRow {                      // values of one row, one slot per operation
+    int64_t i[SDQH_MAX_XOPS];      // i64 / bool values; f64 values as raw bits
+    int64_t ent[SDQH_MAX_XOPS];    // LOOKUP: matched entry, -1 = miss
+    bool bad[SDQH_MAX_XOPS];       // PACK2 with a part outside [0, 2^32)
+    double f(int k) const { double d; std::memcpy(&d, &i[k], 8); return d; }
+    void setf(int k, double d) { std::memcpy(&i[k], &d, 8); }
+};
+
+struct XProg {
+    const sdqh_program* p = nullptr;
+    int upto_gate[SDQH_MAX_XGATES];            // operations [0, upto) are evaluated before gate g is tested
+    int nvals = 0;
+
+    static int text_len(const uint32_t* s, int width) { int n = 0; while (n < width && s[n] != 0) ++n; return n; }
+    // VarChar::firstIndex (include/varchar.h:91-97) with Python's str.find semantics on the text up to the first NUL
+    static int64_t first_index(const uint32_t* s, int width, const uint32_t* val, int len) {
+        const int n = text_len(s, width);
+        for (int st = 0; st + len <= n; ++st) {
+            int k = 0;
+            while (k < len && s[st + k] == val[k]) ++k;
+            if (k == len) return st;
+        }
+        return -1;
+    }
+    static bool str_pred(const uint32_t* s, int width, const uint32_t* val, int len, int mode) {
+        if (mode == SDQH_STR_CONTAINS) return first_index(s, width, val, len) >= 0;
+        if (mode == SDQH_STR_PREFIX) { bool m = len <= width; for (int k = 0; m && k < len; ++k) m = s[k] != 0 && s[k] == val[k]; return m; }
+        if (mode == SDQH_STR_SUFFIX) { const int n = text_len(s, width); bool m = len <= n; for (int k = 0; m && k < len; ++k) m = s[n - len + k] == val[k]; return m; }
+        bool eq = len <= width;
+        for (int k = 0; eq && k < len; ++k) eq = s[k] == val[k];
+        for (int k = len; eq && k < width; ++k) eq = s[k] == 0;
+        return mode == SDQH_STR_EQ ? eq : !eq;
+    }
+
+    void eval_ops(int64_t r, int from, int upto, XRow& x) const {
+        for (int k = from; k < upto; ++k) {
+            const sdqh_xop& o = p->ops[k];
+            x.bad[k] = false; x.ent[k] = -1;
+            const bool fa = o.a >= 0 && p->ops[o.a].type == SDQH_T_F64;
+            switch (o.code) {
+                case SDQH_X_COL: x.i[k] = ((const int64_t*)o.col->data)[r]; break;
+                case SDQH_X_ROWID: x.i[k] = r; break;
+                case SDQH_X_CONST: if (o.type == SDQH_T_F64) x.setf(k, o.imm_f); else x.i[k] = o.imm_i; break;
+                case SDQH_X_LOOKUP: {
+                    int64_t e = -1;
+                    if (!x.bad[o.a]) {
+                        if (o.table->bitmap_only) e = o.table->contains(x.i[o.a]) ? 0 : -1;
+                        else e = o.table->index.find(x.i[o.a]);                 // contains + at: generator 85-96
+                    }
+                    x.ent[k] = e; x.i[k] = e >= 0;
+                    break;
+                }
+                case SDQH_X_FIELD: {
+                    const int64_t e = x.ent[o.a]; const sdqh_table* t = p->ops[o.a].table;
+                    x.i[k] = e >= 0 ? t->payload[(size_t)e * (size_t)t->npayload + (size_t)o.aux] : 0;
+                    break;
+                }
+                case SDQH_X_ACC: {
+                    int64_t e = x.ent[o.a]; const sdqh_table* t = p->ops[o.a].table;
+                    if (e >= 0 && !t->alias.empty()) e = t->alias[(size_t)e];
+                    if (o.aux < 0) x.i[k] = e >= 0 ? t->acc[(size_t)e].n : 0;
+                    else x.setf(k, e >= 0 ? t->acc[(size_t)e].v[o.aux] : 0.0);
+                    break;
+                }
+                case SDQH_X_ADD: if (fa) x.setf(k, x.f(o.a) + x.f(o.b)); else x.i[k] = x.i[o.a] + x.i[o.b]; break;
+                case SDQH_X_SUB: if (fa) x.setf(k, x.f(o.a) - x.f(o.b)); else x.i[k] = x.i[o.a] - x.i[o.b]; break;
+                case SDQH_X_MUL: if (fa) x.setf(k, x.f(o.a) * x.f(o.b)); else x.i[k] = x.i[o.a] * x.i[o.b]; break;
+                case SDQH_X_DIV: x.setf(k, x.f(o.a) / x.f(o.b)); break;
+                case SDQH_X_NEG: if (fa) x.setf(k, -x.f(o.a)); else x.i[k] = -x.i[o.a]; break;
+                case SDQH_X_I2F: x.setf(k, (double)x.i[o.a]); break;
+                case SDQH_X_YEAR: x.i[k] = x.i[o.a] / 10000; break;
+                case SDQH_X_PACK2: {
+                    const int64_t a = x.i[o.a], b = x.i[o.b];
+                    x.bad[k] = x.bad[o.a] || x.bad[o.b] || a < 0 || a > 0xFFFFFFFFll || b < 0 || b > 0xFFFFFFFFll;
+                    x.i[k] = (int64_t)(((uint64_t)a << 32) | ((uint64_t)b & 0xFFFFFFFFull));
+                    break;
+                }
+                case SDQH_X_LT: x.i[k] = fa ? x.f(o.a) < x.f(o.b) : x.i[o.a] < x.i[o.b]; break;
+                case SDQH_X_LE: x.i[k] = fa ? x.f(o.a) <= x.f(o.b) : x.i[o.a] <= x.i[o.b]; break;
+                case SDQH_X_GT: x.i[k] = fa ? x.f(o.a) > x.f(o.b) : x.i[o.a] > x.i[o.b]; break;
+                case SDQH_X_GE: x.i[k] = fa ? x.f(o.a) >= x.f(o.b) : x.i[o.a] >= x.i[o.b]; break;
+                case SDQH_X_EQ: x.i[k] = fa ? x.f(o.a) == x.f(o.b) : x.i[o.a] == x.i[o.b]; break;
+                case SDQH_X_NE: x.i[k] = fa ? x.f(o.a) != x.f(o.b) : x.i[o.a] != x.i[o.b]; break;
+                case SDQH_X_AND: x.i[k] = (x.i[o.a] != 0) && (x.i[o.b] != 0); break;
+                case SDQH_X_OR: x.i[k] = (x.i[o.a] != 0) || (x.i[o.b] != 0); break;
+                case SDQH_X_NOT: x.i[k] = x.i[o.a] == 0; break;
+                case SDQH_X_SELECT: x.i[k] = x.i[o.a] != 0 ? x.i[o.b] : x.i[o.c]; x.bad[k] = x.i[o.a] != 0 ? x.bad[o.b] : x.bad[o.c]; break;
+                case SDQH_X_STR: x.i[k] = str_pred((const uint32_t*)o.col->data + (size_t)r * (size_t)o.col->width, o.col->width, o.str, o.slen, o.aux); break;
+                case SDQH_X_STRIDX: x.i[k] = first_index((const uint32_t*)o.col->data + (size_t)r * (size_t)o.col->width, o.col->width, o.str, o.slen); break;
+                case SDQH_X_CHAR: {
+                    const uint32_t* sp = (const uint32_t*)o.col->data + (size_t)r * (size_t)o.col->width;
+                    x.i[k] = (o.aux >= 0 && o.aux < text_len(sp, o.col->width)) ? (int64_t)sp[o.aux] : 0;
+                    break;
+                }
+                default: x.i[k] = 0; break;
+            }
+        }
+    }
+    // gates in order, then everything else; false = the row does not pass
+    bool row(int64_t r, XRow& x) const {
+        int done = 0;
+        for (int g = 0; g < p->ngates; ++g) {
+            if (upto_gate[g] > done) { eval_ops(r, done, upto_gate[g], x); done = upto_gate[g]; }
+            if (x.i[p->gates[g]] == 0) return false;
+        }
+        if (done < p->nops) eval_ops(r, done, p->nops, x);
+        return true;
+    }
+};
+
+// validate a program against the ABI's rules (both builds apply the same ones) and prepare it
+int make_xprog(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* p, int max_vals, bool need_key, bool vals_f64, XProg* out) {
+    if (!p || p->nops < 0 || p->nops > SDQH_MAX_XOPS || (p->nops && !p->ops) || p->ngates < 0 || p->ngates > SDQH_MAX_XGATES || (p->ngates && !p->gates) ||
+        p->nvals < 0 || p->nvals > max_vals || (p->nvals && !p->vals))
+        return fail(ctx, SDQH_ERR_INVALID, "program: bad counts");
+    int ncols = 0, ntabs = 0, nstr = 0;
+    const void* cols[SDQH_MAX_XOPS]; const void* tabs[SDQH_MAX_XOPS];
+    for (int k = 0; k < p->nops; ++k) {
+        const sdqh_xop& o = p->ops[k];
+        auto ty = [&](int j) { return (j >= 0 && j < k) ? p->ops[j].type : -1; };
+        auto need = [&](bool ok, const char* what) { return ok ? SDQH_OK : fail(ctx, SDQH_ERR_INVALID, std::string("program: operation ") + std::to_string(k) + ": " + what); };
+        int rc = SDQH_OK;
+        switch (o.code) {
+            case SDQH_X_COL:
+                rc = need(o.col && o.col->dtype != SDQH_STR && o.col->nrows >= nrows && o.type == (o.col->dtype == SDQH_F64 ? SDQH_T_F64 : SDQH_T_I64), "COL needs an I64 / F64 column covering nrows, typed alike");
+                break;
+            case SDQH_X_ROWID: rc = need(o.type == SDQH_T_I64, "ROWID is i64"); break;
+            case SDQH_X_CONST: rc = need(o.type >= SDQH_T_I64 && o.type <= SDQH_T_BOOL, "CONST type"); break;
+            case SDQH_X_LOOKUP: rc = need(o.table && ty(o.a) == SDQH_T_I64 && o.type == SDQH_T_BOOL, "LOOKUP needs a table and an i64 key"); break;
+            case SDQH_X_FIELD:
+                rc = need(o.a >= 0 && o.a < k && p->ops[o.a].code == SDQH_X_LOOKUP && !p->ops[o.a].table->bitmap_only && o.aux >= 0 && o.aux < p->ops[o.a].table->npayload &&
+                          (o.type == SDQH_T_I64 || o.type == SDQH_T_F64), "FIELD needs an earlier LOOKUP and one of its payload fields");
+                break;
+            case SDQH_X_ACC:
+                rc = need(o.a >= 0 && o.a < k && p->ops[o.a].code == SDQH_X_LOOKUP && p->ops[o.a].table->accumulate && o.aux >= -1 && o.aux < SDQH_TUPLE_MAX_VALUES &&
+                          o.type == (o.aux < 0 ? SDQH_T_I64 : SDQH_T_F64), "ACC needs an earlier LOOKUP into a table with accumulators");
+                break;
+            case SDQH_X_ADD: case SDQH_X_SUB: case SDQH_X_MUL:
+                rc = need(ty(o.a) == ty(o.b) && (ty(o.a) == SDQH_T_I64 || ty(o.a) == SDQH_T_F64) && o.type == ty(o.a), "arithmetic needs two operands of one numeric type"); break;
+            case SDQH_X_DIV: rc = need(ty(o.a) == SDQH_T_F64 && ty(o.b) == SDQH_T_F64 && o.type == SDQH_T_F64, "DIV is f64"); break;
+            case SDQH_X_NEG: rc = need((ty(o.a) == SDQH_T_I64 || ty(o.a) == SDQH_T_F64) && o.type == ty(o.a), "NEG operand"); break;
+            case SDQH_X_I2F: rc = need(ty(o.a) == SDQH_T_I64 && o.type == SDQH_T_F64, "I2F operand"); break;
+            case SDQH_X_YEAR: rc = need(ty(o.a) == SDQH_T_I64 && o.type == SDQH_T_I64, "YEAR operand"); break;
+            case SDQH_X_PACK2: rc = need(ty(o.a) == SDQH_T_I64 && ty(o.b) == SDQH_T_I64 && o.type == SDQH_T_I64, "PACK2 operands"); break;
+            case SDQH_X_LT: case SDQH_X_LE: case SDQH_X_GT: case SDQH_X_GE: case SDQH_X_EQ: case SDQH_X_NE:
+                rc = need(ty(o.a) == ty(o.b) && (ty(o.a) == SDQH_T_I64 || ty(o.a) == SDQH_T_F64 || (ty(o.a) == SDQH_T_BOOL && (o.code == SDQH_X_EQ || o.code == SDQH_X_NE))) && o.type == SDQH_T_BOOL,
+                          "comparison needs two operands of one type"); break;
+            case SDQH_X_AND: case SDQH_X_OR: rc = need(ty(o.a) == SDQH_T_BOOL && ty(o.b) == SDQH_T_BOOL && o.type == SDQH_T_BOOL, "boolean operands"); break;
+            case SDQH_X_NOT: rc = need(ty(o.a) == SDQH_T_BOOL && o.type == SDQH_T_BOOL, "boolean operand"); break;
+            case SDQH_X_SELECT: rc = need(ty(o.a) == SDQH_T_BOOL && ty(o.b) == ty(o.c) && ty(o.b) >= 0 && o.type == ty(o.b), "SELECT needs a bool and two values of one type"); break;
+            case SDQH_X_STR: case SDQH_X_STRIDX:
+                rc = need(o.col && o.col->dtype == SDQH_STR && o.col->nrows >= nrows && o.slen >= 0 && o.slen <= SDQH_MAX_STR_CONST && (o.slen == 0 || o.str) &&
+                          o.type == (o.code == SDQH_X_STR ? SDQH_T_BOOL : SDQH_T_I64) && (o.code != SDQH_X_STR || (o.aux >= SDQH_STR_EQ && o.aux <= SDQH_STR_SUFFIX)), "string operation needs a STR column and a constant");
+                nstr += o.slen;
+                break;
+            case SDQH_X_CHAR: rc = need(o.col && o.col->dtype == SDQH_STR && o.col->nrows >= nrows && o.type == SDQH_T_I64 && o.aux >= 0, "CHAR needs a STR column"); break;
+            default: rc = fail(ctx, SDQH_ERR_UNSUPPORTED, "program: unknown operation code " + std::to_string(o.code));
+        }
+        if (rc) return rc;
+        if (o.col) { bool seen = false; for (int j = 0; j < ncols; ++j) seen = seen || cols[j] == o.col; if (!seen) cols[ncols++] = o.col; }
+        if (o.table) { bool seen = false; for (int j = 0; j < ntabs; ++j) seen = seen || tabs[j] == o.table; if (!seen) tabs[ntabs++] = o.table; }
+    }
+    if (ncols > SDQH_MAX_XCOLS || ntabs > SDQH_MAX_XTABLES || nstr > SDQH_MAX_XSTR) return fail(ctx, SDQH_ERR_UNSUPPORTED, "program: too many columns / tables / string constants");
+    for (int g = 0; g < p->ngates; ++g)
+        if (p->gates[g] < 0 || p->gates[g] >= p->nops || p->ops[p->gates[g]].type != SDQH_T_BOOL) return fail(ctx, SDQH_ERR_INVALID, "program: a gate must be a bool operation");
+    if (need_key ? !(p->key >= 0 && p->key < p->nops && p->ops[p->key].type == SDQH_T_I64) : p->key != -1) return fail(ctx, SDQH_ERR_INVALID, "program: key");
+    for (int v = 0; v < p->nvals; ++v) {
+        if (p->vals[v] < 0 || p->vals[v] >= p->nops) return fail(ctx, SDQH_ERR_INVALID, "program: value index");
+        const int t = p->ops[p->vals[v]].type;
+        if (vals_f64 ? t != SDQH_T_F64 : (t != SDQH_T_I64 && t != SDQH_T_F64)) return fail(ctx, SDQH_ERR_INVALID, "program: value type");
+    }
+    out->p = p; out->nvals = p->nvals;
+    // a gate is tested as soon as the operations it depends on are done: operations are in dependency
+    // order, so everything up to the gate's own index
+    for (int g = 0; g < p->ngates; ++g) out->upto_gate[g] = p->gates[g] + 1;
+    for (int g = 1; g < p->ngates; ++g) out->upto_gate[g] = std::max(out->upto_gate[g], out->upto_gate[g - 1]);
+    return SDQH_OK;
+}
+
+}  // namespace
+
+int sdqh_xscan_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, double* out_values, int64_t* out_count) {
+    if (!ctx || nrows < 0) return fail(ctx, SDQH_ERR_INVALID, "xscan_sum: bad arguments");
+    Timer tm;
+    XProg xp;
+    if (int rc = make_xprog(ctx, nrows, prog, SDQH_TUPLE_MAX_VALUES, false, true, &xp)) return rc;
+    int T = eff_threads(ctx->threads, nrows);
+    std::vector<Acc> part((size_t)T);
+    run_blocks(T, nrows, [&](int t, int64_t b, int64_t e) {          // parallel_reduce: generator 258-291
+        Acc a{}; XRow x;
+        for (int64_t r = b; r < e; ++r) {
+            if (!xp.row(r, x)) continue;
+            for (int k = 0; k < xp.nvals; ++k) a.v[k] += x.f(prog->vals[k]);
+            a.n += 1;
+        }
+        part[(size_t)t] = a;
+    });
+    Acc total{};
+    for (int t = 0; t < T; ++t) { for (int k = 0; k < xp.nvals; ++k) total.v[k] += part[(size_t)t].v[k]; total.n += part[(size_t)t].n; }
+    if (out_values) for (int k = 0; k < xp.nvals; ++k) out_values[k] = total.v[k];
+    if (out_count) *out_count = total.n;
+    ctx->last_ms = tm.ms();
+    return SDQH_OK;
+}
+
+int sdqh_xgroupby(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int max_groups,
+                  int64_t* out_keys, double* out_values, int64_t* out_counts, int32_t* out_ngroups) {
+    if (!ctx || nrows < 0 || max_groups < 1 || max_groups > SDQH_MAX_LOOKUP_GROUPS || !out_ngroups) return fail(ctx, SDQH_ERR_INVALID, "xgroupby: bad arguments");
+    Timer tm;
+    XProg xp;
+    if (int rc = make_xprog(ctx, nrows, prog, SDQH_TUPLE_MAX_VALUES, true, true, &xp)) return rc;
+    struct Group { int64_t key; Acc acc; };
+    int T = eff_threads(ctx->threads, nrows);
+    std::vector<std::vector<Group>> local((size_t)T);
+    std::vector<int> bad((size_t)T, 0);
+    run_blocks(T, nrows, [&](int t, int64_t b, int64_t e) {          // local[key] += tuple: generator 402-440
+        auto& groups = local[(size_t)t];
+        I64Index idx; XRow x;
+        for (int64_t r = b; r < e; ++r) {
+            if (!xp.row(r, x)) continue;
+            const int64_t key = x.i[prog->key];
+            if (key < 0 || x.bad[prog->key]) { bad[(size_t)t] = 1; continue; }
+            int64_t g = idx.find_or_insert(key, (int64_t)groups.size());
+            if (g < 0) { g = (int64_t)groups.size(); groups.push_back(Group{key, Acc{}}); }
+            Acc& a = groups[(size_t)g].acc;
+            for (int k = 0; k < xp.nvals; ++k) a.v[k] += x.f(prog->vals[k]);
+            a.n += 1;
+        }
+    });
+    for (int t = 0; t < T; ++t) if (bad[(size_t)t]) return fail(ctx, SDQH_ERR_UNSUPPORTED, "xgroupby: negative group key");
+    std::vector<Group> global;                                        // AddMap(global, local) per thread, in order
+    I64Index gidx;
+    for (int t = 0; t < T; ++t)
+        for (auto& g : local[(size_t)t]) {
+            int64_t at = gidx.find_or_insert(g.key, (int64_t)global.size());
+            if (at < 0) global.push_back(g);
+            else { for (int k = 0; k < xp.nvals; ++k) global[(size_t)at].acc.v[k] += g.acc.v[k]; global[(size_t)at].acc.n += g.acc.n; }
+        }
+    if ((int)global.size() > max_groups) { *out_ngroups = (int32_t)global.size(); return fail(ctx, SDQH_ERR_OVERFLOW, "xgroupby: more groups than max_groups"); }
+    for (size_t g = 0; g < global.size(); ++g) {
+        if (out_keys) out_keys[g] = global[g].key;
+        if (out_values) for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) out_values[g * SDQH_TUPLE_MAX_VALUES + k] = k < xp.nvals ? global[g].acc.v[k] : 0.0;
+        if (out_counts) out_counts[g] = global[g].acc.n;
+    }
+    *out_ngroups = (int32_t)global.size();
+    ctx->last_ms = tm.ms();
+    return SDQH_OK;
+}
+
+int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t key_lo, int64_t key_hi, int accumulate, sdqh_table** out) {
+    if (!ctx || nrows < 0 || !out) return fail(ctx, SDQH_ERR_INVALID, "xbuild: bad arguments");
+    Timer tm;
+    XProg xp;
+    if (int rc = make_xprog(ctx, nrows, prog, SDQH_MAX_PAYLOAD, true, false, &xp)) return rc;
+    struct Row { int64_t key; int64_t pay[SDQH_MAX_PAYLOAD]; };
+    int T = eff_threads(ctx->threads, nrows);
+    std::vector<std::vector<Row>> local((size_t)T);
+    std::vector<int> bad((size_t)T, 0);
+    const bool bounded = key_lo <= key_hi;
+    run_blocks(T, nrows, [&](int t, int64_t b, int64_t e) {          // emplace_back(key, payload): generator 331-369
+        auto& v = local[(size_t)t];
+        XRow x;
+        for (int64_t r = b; r < e; ++r) {
+            if (!xp.row(r, x)) continue;
+            Row row{};
+            row.key = x.i[prog->key];
+            if (x.bad[prog->key] || (bounded && (row.key < key_lo || row.key > key_hi))) { bad[(size_t)t] = 1; continue; }
+            for (int k = 0; k < xp.nvals; ++k) row.pay[k] = x.i[prog->vals[k]];
+            v.push_back(row);
+        }
+    });
+    for (int t = 0; t < T; ++t) if (bad[(size_t)t]) return fail(ctx, SDQH_ERR_UNSUPPORTED, "xbuild: a key outside the given bounds / a key part outside [0, 2^32)");
+    sdqh_table* tb = new sdqh_table();
+    tb->npayload = xp.nvals; tb->accumulate = accumulate != 0;
+    tb->nrows_build = nrows;
+    if (bounded) { tb->col_lo = key_lo; tb->col_hi = key_hi; }
+    for (int t = 0; t < T; ++t)                                       // global.insert(range): first wins
+        for (const Row& row : local[(size_t)t]) {
+            int64_t e = (int64_t)tb->keys.size();
+            if (tb->index.find_or_insert(row.key, e) >= 0) continue;
+            tb->keys.push_back(row.key);
+            for (int k = 0; k < xp.nvals; ++k) tb->payload.push_back(row.pay[k]);
+        }
+    if (tb->accumulate) tb->acc.assign(tb->keys.size(), Acc{});
+    *out = tb;
+    ctx->last_ms = tm.ms();
+    return SDQH_OK;
+}
+
+int sdqh_xkey_set(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t key_lo, int64_t key_hi, sdqh_table** out) {
+    if (!ctx || nrows < 0 || !out) return fail(ctx, SDQH_ERR_INVALID, "xkey_set: bad arguments");
+    XProg xp;
+    if (int rc = make_xprog(ctx, nrows, prog, 0, true, false, &xp)) return rc;
+    if (key_lo > key_hi) { key_lo = 0; key_hi = 0; if (nrows > 0) return fail(ctx, SDQH_ERR_UNSUPPORTED, "xkey_set: needs the key's bounds"); }
+    if (key_lo <= INT64_MIN / 2 || key_hi >= INT64_MAX / 2 || (uint64_t)(key_hi - key_lo) + 1 > (1ull << 31))
+        return fail(ctx, SDQH_ERR_UNSUPPORTED, "xkey_set: key range too wide for a bitmap");
+    sdqh_table* tb = new sdqh_table();
+    tb->bitmap_only = true; tb->bm_lo = key_lo; tb->bm_hi = key_hi;
+    tb->bm.assign((size_t)(((uint64_t)(key_hi - key_lo) + 32) / 32), 0u);
+    XRow x; bool bad = false;
+    for (int64_t r = 0; r < nrows; ++r) {
+        if (!xp.row(r, x)) continue;
+        const int64_t k = x.i[prog->key];
+        if (x.bad[prog->key] || k < key_lo || k > key_hi) { bad = true; continue; }
+        const uint64_t off = (uint64_t)(k - key_lo);
+        tb->bm[off >> 5] |= 1u << (off & 31);
+    }
+    if (bad) { delete tb; return fail(ctx, SDQH_ERR_UNSUPPORTED, "xkey_set: a key outside the given bounds"); }
+    *out = tb;
+    return SDQH_OK;
+}
+
+int sdqh_xprobe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int lookup_op, sdqh_table* table) {
+    if (!ctx || nrows < 0 || !table) return fail(ctx, SDQH_ERR_INVALID, "xprobe_aggregate: bad arguments");
+    if (!table->accumulate) return fail(ctx, SDQH_ERR_INVALID, "xprobe_aggregate: table was built without accumulators");
+    Timer tm;
+    XProg xp;
+    if (int rc = make_xprog(ctx, nrows, prog, SDQH_TUPLE_MAX_VALUES, false, true, &xp)) return rc;
+    bool gated = false;
+    for (int g = 0; g < prog->ngates; ++g) gated = gated || prog->gates[g] == lookup_op;
+    if (lookup_op < 0 || lookup_op >= prog->nops || prog->ops[lookup_op].code != SDQH_X_LOOKUP || prog->ops[lookup_op].table != table || !gated)
+        return fail(ctx, SDQH_ERR_INVALID, "xprobe_aggregate: lookup_op must be a gate that looks `table` up");
+    int T = eff_threads(ctx->threads, nrows);
+    struct Local { I64Index idx; std::vector<int64_t> entry; std::vector<Acc> acc; };
+    std::vector<Local> local((size_t)T);
+    run_blocks(T, nrows, [&](int t, int64_t b, int64_t e) {          // local[key] += tuple: generator 402-440
+        Local& L = local[(size_t)t];
+        XRow x;
+        for (int64_t r = b; r < e; ++r) {
+            if (!xp.row(r, x)) continue;
+            int64_t ent = x.ent[lookup_op];
+            if (!table->alias.empty()) ent = table->alias[(size_t)ent];
+            int64_t li = L.idx.find_or_insert(ent, (int64_t)L.entry.size());
+            if (li < 0) { li = (int64_t)L.entry.size(); L.entry.push_back(ent); L.acc.push_back(Acc{}); }
+            Acc& a = L.acc[(size_t)li];
+            for (int k = 0; k < xp.nvals; ++k) a.v[k] += x.f(prog->vals[k]);
+            a.n += 1;
+        }
+    });
+    for (int t = 0; t < T; ++t) {                                     // AddMap(global, local) per thread, in order
+        Local& L = local[(size_t)t];
+        for (size_t i = 0; i < L.entry.size(); ++i) {
+            Acc& g = table->acc[(size_t)L.entry[i]];
+            for (int k = 0; k < xp.nvals; ++k) g.v[k] += L.acc[i].v[k];
+            g.n += L.acc[i].n;
+        }
+    }
+    ctx->last_ms = tm.ms();
+    return SDQH_OK;
+}
+
+int sdqh_table_columns(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, sdqh_column** out_cols, int64_t* out_rows) {
+    if (!ctx || !table || !out_cols || !out_rows || table->bitmap_only) return fail(ctx, SDQH_ERR_INVALID, "table_columns: bad arguments");
+    std::vector<size_t> keep;
+    for (size_t e = 0; e < table->keys.size(); ++e) if ((table->accumulate ? table->acc[e].n : 0) >= min_hits) keep.push_back(e);
+    const int64_t n = (int64_t)keep.size();
+    const int ncols = 1 + table->npayload + SDQH_TUPLE_MAX_VALUES + 1;
+    for (int c = 0; c < ncols; ++c) {
+        const bool is_acc = c > table->npayload && c <= table->npayload + SDQH_TUPLE_MAX_VALUES;
+        if (int rc = sdqh_column_alloc(ctx, n, is_acc ? SDQH_F64 : SDQH_I64, 0, &out_cols[c])) return rc;
+        int64_t* dst = (int64_t*)out_cols[c]->data;
+        for (int64_t i = 0; i < n; ++i) {
+            const size_t e = keep[(size_t)i];
+            if (c == 0) dst[i] = table->keys[e];
+            else if (c <= table->npayload) dst[i] = table->payload[e * (size_t)table->npayload + (size_t)(c - 1)];
+            else if (is_acc) { const double v = table->accumulate ? table->acc[e].v[c - 1 - table->npayload] : 0.0; std::memcpy(&dst[i], &v, 8); }
+            else dst[i] = table->accumulate ? table->acc[e].n : 0;
+        }
+    }
+    *out_rows = n;
+    return SDQH_OK;
+}
+
+int sdqh_jit_stats(sdqh_ctx* ctx, int64_t* compiled, int64_t* from_cache) {
+    if (!ctx) return SDQH_ERR_INVALID;
+    if (compiled) *compiled = 0;
+    if (from_cache) *from_cache = 0;
+    return SDQH_OK;
+}
+
 // ---- multi-GPU helpers -------------------------------------------------------------------------
 int sdqh_scan_compact(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nprobes, const sdqh_probe* probes,
                       int ncols, const sdqh_column* const* cols, sdqh_column** out_cols, int64_t* out_rows) {

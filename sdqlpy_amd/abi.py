@@ -11,7 +11,7 @@ import math
 import numpy as np
 
 MAX_SHARE_CELLS = 1 << 28  # SDQH_MAX_SHARE_CELLS
-ABI_VERSION = 3            # include/sdqh.h: SDQH_ABI_VERSION (struct layouts below must match the library's)
+ABI_VERSION = 4            # include/sdqh.h: SDQH_ABI_VERSION (struct layouts below must match the library's)
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_OVERFLOW, ERR_NOMEM = range(6)
 I64, F64, STR = 0, 1, 2
 TUPLE_A, TUPLE_AB, TUPLE_A_1MB, TUPLE_PRICING, TUPLE_A_1MB_M_CD, TUPLE_COUNT = 1, 2, 3, 4, 5, 6
@@ -120,6 +120,88 @@ def _lookups(lookups):
     return arr
 
 
+# ---- row programs (ABI 4) ---------------------------------------------------------------------------
+T_I64, T_F64, T_BOOL = 0, 1, 2
+X_COL, X_ROWID, X_CONST, X_LOOKUP, X_FIELD, X_ACC = 1, 2, 3, 4, 5, 6
+X_ADD, X_SUB, X_MUL, X_DIV, X_NEG, X_I2F, X_YEAR, X_PACK2 = 10, 11, 12, 13, 14, 15, 16, 17
+X_LT, X_LE, X_GT, X_GE, X_EQ, X_NE = 20, 21, 22, 23, 24, 25
+X_AND, X_OR, X_NOT, X_SELECT = 30, 31, 32, 33
+X_STR, X_STRIDX, X_CHAR = 40, 41, 42
+MAX_XOPS, MAX_XCOLS, MAX_XTABLES, MAX_XGATES, MAX_XSTR = 96, 16, 6, 16, 256
+
+
+class XOp(C.Structure):
+    _fields_ = [("code", C.c_int32), ("type", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("c", C.c_int32), ("aux", C.c_int32),
+                ("imm_i", C.c_int64), ("imm_f", C.c_double), ("col", C.c_void_p), ("table", C.c_void_p), ("str", C.c_void_p),
+                ("slen", C.c_int32), ("_pad", C.c_int32)]
+
+
+class XProgram(C.Structure):
+    _fields_ = [("nops", C.c_int32), ("ngates", C.c_int32), ("ops", C.c_void_p), ("gates", C.c_void_p),
+                ("key", C.c_int32), ("nvals", C.c_int32), ("vals", C.c_void_p)]
+
+
+class Program:
+    """A row program under construction: `op(...)` appends an operation and returns its index.
+    Columns and tables are given as Column / Table objects (tables may be bound late with `bind_table`:
+    a program is built once per plan, its tables are rebuilt every run)."""
+
+    def __init__(self):
+        self.ops = []            # dicts
+        self.gates, self.vals, self.key = [], [], -1
+        self._struct = None
+
+    def op(self, code, typ, a=-1, b=-1, c=-1, aux=0, imm_i=0, imm_f=0.0, col=None, table=None, text=None):
+        if len(self.ops) >= MAX_XOPS:
+            raise SdqhError(ERR_UNSUPPORTED, "expression program longer than %d operations" % MAX_XOPS)
+        self.ops.append(dict(code=code, type=typ, a=a, b=b, c=c, aux=aux, imm_i=int(imm_i), imm_f=float(imm_f), col=col, table=table, text=text))
+        self._struct = None
+        return len(self.ops) - 1
+
+    def type_of(self, i):
+        return self.ops[i]["type"]
+
+    def bind_table(self, i, table):
+        self.ops[i]["table"] = table
+        if self._struct is not None:
+            self._struct[1][i].table = table.handle
+
+    def struct(self):
+        """The ctypes sdqh_program.  The operation array is cached (table handles are refreshed by
+        bind_table, constants by set_const); gates / key / values are re-read on every call."""
+        if self._struct is None:
+            n = len(self.ops)
+            arr = (XOp * max(1, n))()
+            keep = []
+            for i, o in enumerate(self.ops):
+                x = arr[i]
+                x.code, x.type, x.a, x.b, x.c, x.aux, x.imm_i, x.imm_f = o["code"], o["type"], o["a"], o["b"], o["c"], o["aux"], o["imm_i"], o["imm_f"]
+                x.col = o["col"].handle if o["col"] is not None else None
+                x.table = o["table"].handle if o["table"] is not None else None
+                if o["text"] is not None:
+                    units = (C.c_uint32 * max(1, len(o["text"])))(*[ord(ch) for ch in o["text"]])
+                    keep.append(units)
+                    x.str, x.slen = C.cast(units, C.c_void_p), len(o["text"])
+            self._struct = [XProgram(), arr, None, None, keep]
+        p, arr = self._struct[0], self._struct[1]
+        gates = (C.c_int32 * max(1, len(self.gates)))(*self.gates)
+        vals = (C.c_int32 * max(1, len(self.vals)))(*self.vals)
+        self._struct[2], self._struct[3] = gates, vals
+        p.nops, p.ngates, p.ops, p.gates = len(self.ops), len(self.gates), C.cast(arr, C.c_void_p), C.cast(gates, C.c_void_p)
+        p.key, p.nvals, p.vals = self.key, len(self.vals), C.cast(vals, C.c_void_p)
+        return p
+
+    def set_const(self, i, value):
+        """Rebind the value of CONST operation i (a scalar computed by an earlier loop of the same run)."""
+        o = self.ops[i]
+        if o["type"] == T_F64:
+            o["imm_f"] = float(value)
+        else:
+            o["imm_i"] = int(value)
+        if self._struct is not None:
+            self._struct[1][i].imm_f, self._struct[1][i].imm_i = o["imm_f"], o["imm_i"]
+
+
 EXPORTS = [
     "sdqh_abi_version", "sdqh_backend_name", "sdqh_create", "sdqh_destroy", "sdqh_last_error", "sdqh_set_threads",
     "sdqh_synchronize", "sdqh_last_device_ms", "sdqh_set_profiling", "sdqh_set_profile_filter", "sdqh_profile_count", "sdqh_profile_entry",
@@ -130,6 +212,7 @@ EXPORTS = [
     "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_scan_compact", "sdqh_partition_by_key",
     "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in",
     "sdqh_build", "sdqh_lookup_aggregate", "sdqh_table_entries", "sdqh_host_alloc", "sdqh_host_free", "sdqh_table_topk",
+    "sdqh_xscan_sum", "sdqh_xgroupby", "sdqh_xbuild", "sdqh_xkey_set", "sdqh_xprobe_aggregate", "sdqh_table_columns", "sdqh_jit_stats",
 ]
 
 
@@ -479,6 +562,56 @@ class Context:
         n = ng.value
         return out_keys[:n], out_vals[:n, : TUPLE_NVALUES[shape]], out_cnt[:n]
 
+    # -- row programs (ABI 4) ------------------------------------------------------------------------
+    def xscan_sum(self, nrows, prog):
+        vals = np.zeros(TUPLE_MAX_VALUES, np.float64)
+        cnt = C.c_int64()
+        self._check(self.lib.sdqh_xscan_sum(self.handle, C.c_int64(nrows), C.byref(prog.struct()), _np_ptr(vals), C.byref(cnt)))
+        self._after_call("xscan_sum")
+        return vals[:len(prog.vals)], cnt.value
+
+    def xgroupby(self, nrows, prog, max_groups=MAX_LOOKUP_GROUPS):
+        out_keys = np.zeros(max_groups, np.int64)
+        out_vals = np.zeros((max_groups, TUPLE_MAX_VALUES), np.float64)
+        out_cnt = np.zeros(max_groups, np.int64)
+        ng = C.c_int32()
+        self._check(self.lib.sdqh_xgroupby(self.handle, C.c_int64(nrows), C.byref(prog.struct()), C.c_int(max_groups),
+                                           _np_ptr(out_keys), _np_ptr(out_vals), _np_ptr(out_cnt), C.byref(ng)))
+        self._after_call("xgroupby")
+        n = ng.value
+        return out_keys[:n], out_vals[:n, :len(prog.vals)], out_cnt[:n]
+
+    def xbuild(self, nrows, prog, key_lo=1, key_hi=0, accumulate=False):
+        h = C.c_void_p()
+        self._check(self.lib.sdqh_xbuild(self.handle, C.c_int64(nrows), C.byref(prog.struct()), C.c_int64(key_lo), C.c_int64(key_hi),
+                                         C.c_int(1 if accumulate else 0), C.byref(h)))
+        self._after_call("xbuild")
+        return Table(self, h, len(prog.vals), accumulate)
+
+    def xkey_set(self, nrows, prog, key_lo, key_hi):
+        h = C.c_void_p()
+        self._check(self.lib.sdqh_xkey_set(self.handle, C.c_int64(nrows), C.byref(prog.struct()), C.c_int64(key_lo), C.c_int64(key_hi), C.byref(h)))
+        self._after_call("xkey_set")
+        return Table(self, h, 0, False)
+
+    def xprobe_aggregate(self, nrows, prog, lookup_op, table):
+        self._check(self.lib.sdqh_xprobe_aggregate(self.handle, C.c_int64(nrows), C.byref(prog.struct()), C.c_int(lookup_op), table.handle))
+        self._after_call("xprobe_aggregate")
+
+    def table_columns(self, table, min_hits=0):
+        """(key Column, [payload Columns], [accumulator Columns (F64)], hits Column, n) of the entries with >= min_hits rows."""
+        k = 1 + table.npayload + TUPLE_MAX_VALUES + 1
+        outs = (C.c_void_p * k)()
+        n = C.c_int64()
+        self._check(self.lib.sdqh_table_columns(self.handle, table.handle, C.c_int64(min_hits), outs, C.byref(n)))
+        cols = [Column(self, C.c_void_p(outs[i]), n.value, F64 if table.npayload < i <= table.npayload + TUPLE_MAX_VALUES else I64, 0) for i in range(k)]
+        return cols[0], cols[1:1 + table.npayload], cols[1 + table.npayload:k - 1], cols[k - 1], n.value
+
+    def jit_stats(self):
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self.lib.sdqh_jit_stats(self.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def hash_probe_aggregate(self, nrows, flt, table, key, tup):
         self._check(self.lib.sdqh_hash_probe_aggregate(self.handle, C.c_int64(nrows), C.byref(flt), table.handle, key.handle, C.byref(tup)))
         self._after_call("hash_probe_aggregate")
@@ -666,6 +799,13 @@ class Library:
         L.sdqh_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.sdqh_host_free.restype = None
         L.sdqh_host_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.sdqh_xscan_sum.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sdqh_xgroupby.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sdqh_xbuild.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
+        L.sdqh_xkey_set.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.sdqh_xprobe_aggregate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
+        L.sdqh_table_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.sdqh_jit_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.sdqh_build.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.sdqh_lookup_aggregate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -1,0 +1,141 @@
+// sdqh_host.hpp — host-side internals shared by the two translation units of libsdqlhip.so:
+//   sdqh_hip.hip   the C ABI over the kernels compiled ahead of time (sdqh_kernels.hpp)
+//   sdqh_x.hip     row programs (ABI 4): code generation, hiprtc specialisation, sdqh_x* entry points
+// Not part of the public boundary (that is include/sdqh.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "sdqh.h"
+#include "sdqh_kernels.hpp"
+
+namespace sdqh_host {
+
+struct PoolBlock { void* ptr; size_t size; bool free; };
+struct ProfEntry { const char* name; hipEvent_t e0, e1; double ms; };
+
+constexpr size_t STAGING_BYTES = 32u << 20;       // pinned H2D staging ring: 2 x 32 MiB
+constexpr size_t RESULT_BYTES = 64u << 10;        // pinned buffer for small results
+
+}  // namespace sdqh_host
+
+using namespace sdqh;
+
+struct sdqh_ctx {
+    int device = 0;
+    bool compile_only = false;                     // sdqh_create(-1): no GPU behind this ctx; sdqh_x* calls stop after specialising their kernel (build check)
+    int num_cu = 256;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<sdqh_host::PoolBlock> pool;
+    void* staging[2] = {nullptr, nullptr};
+    hipEvent_t staging_done[2] = {nullptr, nullptr};
+    bool staging_busy[2] = {false, false};
+    void* result_host = nullptr;                   // pinned
+    void* result_dev = nullptr;
+    void* bulk_host = nullptr;                     // pinned landing zone for result rows (grown on demand)
+    size_t bulk_bytes = 0;
+    std::map<const char*, size_t> host_blocks;     // sdqh_host_alloc blocks (base -> bytes): result arrays the device may write
+    void* count_host = nullptr;                    // pinned line the compaction kernel writes its row count to
+    hipEvent_t call_begin = nullptr, call_end = nullptr;
+    bool call_timed = false;
+    int profiling = 0;                             // 0 off, 1 per call, 2 accumulate across calls (read at the end)
+    std::string prof_filter;                       // record only launches of this kernel (empty = all)
+    std::vector<sdqh_host::ProfEntry> prof;
+    std::vector<hipEvent_t> event_pool;
+    size_t event_next = 0;
+    // hint: key columns whose group count overflowed the register kernel last time
+    const void* lds_hint[SDQH_MAX_GROUPKEYS] = {nullptr, nullptr};
+    int threads = 1;
+    std::vector<std::pair<const void*, int>> occupancy;   // kernel -> resident workgroups per CU
+    // tuning knobs (sdqh_set_option)
+    int opt_resident_cap = 6;                      // probing kernels (latency chains to hide)
+    int opt_async_copies = 0;                      // sdqh_column_copy_in/_out do not wait (the caller synchronises once per batch)
+    int opt_probe_chunk = 1;
+    int opt_resident_stream = 2;                   // pure streaming kernels: fewer concurrent DRAM streams run faster (tools/microbench_q1.hip)
+    int opt_probe_unroll = PROBE_UNROLL;
+    int opt_stage_batch = STAGE_BATCH;
+    int opt_stage_eager = 1;
+    int nested = 0;                                // > 0 while an entry point runs other entry points (call_begin / call_end)
+    int opt_stage_eager_pay = 0;                   // measured after the queued stage output: gathers for the ~10 % survivors beat streaming every payload row
+    int opt_stage_waves_per_cu = 12;               // tuned k_stage family: fewer, longer streams (12 x 256 x 5 columns) keep DRAM pages open; 24 was 15 % slower, 8 latency-bound
+    int opt_direct_index = 1;
+    int opt_groupby_regs = 0;                      // 0 = adaptive (4 when the last run of these key columns had <= 4 groups), 4, 8
+    const void* g4_hint[SDQH_MAX_GROUPKEYS] = {nullptr, nullptr};
+};
+
+struct sdqh_column {
+    void* data = nullptr;
+    int64_t nrows = 0;
+    int dtype = SDQH_I64;
+    int width = 0;
+    bool owned = false;
+    long long* d_minmax = nullptr;     // device [2], I64 only
+    bool minmax_pending = false, have_minmax = false;
+    int64_t mn = 0, mx = 0;
+    size_t row_bytes() const { return dtype == SDQH_STR ? (size_t)width * 4 : 8; }
+};
+
+struct sdqh_table {
+    sdqh::DevTable dev{};
+    DevStage stage{};
+    TableHeader* hdr = nullptr;
+    uint32_t* bm = nullptr;
+    int npay = 0;
+    bool accumulate = false;
+    bool bitmap_only = false;
+    int64_t nrows_build = 0;
+    uint64_t capmax = 0;
+    bool index_built = false;
+    uint64_t nwords = 0;               // bitmap words (direct layout)
+    std::vector<void*> owned;          // pool blocks to release
+    // cached compaction (device buffers) for the two-step count / fetch protocol
+    bool refs_prefilled = false;                   // small direct tables: dense_ref was allocated and NO_ROW-filled with the header
+    bool compact_valid = false;
+    int64_t compact_min_hits = 0, compact_n = 0;
+    DevCompactOut compact{};
+    uint32_t* seg_kept = nullptr;
+    int nv = SDQH_TUPLE_MAX_VALUES;    // value count of the tuple aggregated into the table
+};
+
+
+namespace sdqh_host {
+
+// ---- helpers defined in sdqh_hip.hip ----------------------------------------------------------------
+int fail(sdqh_ctx* ctx, int code, const std::string& msg);
+void* pool_alloc(sdqh_ctx* ctx, size_t bytes);
+void pool_free(sdqh_ctx* ctx, void* p);
+void call_begin(sdqh_ctx* ctx);
+void call_end(sdqh_ctx* ctx);
+hipEvent_t next_event(sdqh_ctx* ctx);
+int sync_stream(sdqh_ctx* ctx);
+void* tb_alloc(sdqh_ctx* ctx, sdqh_table* t, size_t bytes);
+void tb_release(sdqh_ctx* ctx, sdqh_table* t);
+// stage arrays of a build whose key / payload the kernel computes itself (no source columns)
+int stage_setup_computed(sdqh_ctx* ctx, sdqh_table* tb, int64_t nrows, int npay, int batch);
+int index_ensure(sdqh_ctx* ctx, sdqh_table* tb);
+int column_minmax(sdqh_ctx* ctx, sdqh_column* c);
+// launches of ahead-of-time kernels the run-time specialised path needs
+void fill_regions(sdqh_ctx* ctx, void* const* ptr, const size_t* bytes, const unsigned char* byte, int n);
+void launch_sum_partials(sdqh_ctx* ctx, const double* partial, int nparts, double* out);
+void launch_groupby_merge_lg(sdqh_ctx* ctx, const unsigned long long* gkeys, const double* pacc, const int64_t* pcnt, int nparts, double* out_acc, int64_t* out_cnt);
+// small direct-layout tables: the rank -> row array is allocated up front; *ptr / *bytes = a region to fill with 0xFF (null: none)
+void prefill_direct_refs(sdqh_ctx* ctx, sdqh_table* tb, void** ptr, size_t* bytes);
+
+// event pair around one launch when profiling is on (same bookkeeping as the LAUNCH macro)
+struct KernelScope {
+    sdqh_ctx* ctx; size_t idx = (size_t)-1;
+    KernelScope(sdqh_ctx* c, const char* name) : ctx(c) {
+        if (!c->profiling) return;
+        if (!c->prof_filter.empty() && c->prof_filter != name) return;
+        ProfEntry e{name, next_event(c), next_event(c), 0.0};
+        (void)hipEventRecord(e.e0, c->stream);
+        idx = c->prof.size(); c->prof.push_back(e);
+    }
+    ~KernelScope() { if (idx != (size_t)-1) (void)hipEventRecord(ctx->prof[idx].e1, ctx->stream); }
+};
+
+}  // namespace sdqh_host

@@ -17,9 +17,20 @@
 //   k_select_keys                    a conditional sum over an aggregated dictionary (HAVING)
 //   k_seg_scan ... k_export_bitmap   redistribution helpers of the multi-GPU plans (no reference counterpart)
 #pragma once
+#ifndef __HIPCC_RTC__           // hiprtc (the run-time specialiser, sdqh_jit.hpp) brings its own runtime declarations
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 #include "sdqh.h"
+
+// Kernels that are not templates are compiled by hipcc into the library.  When this header is parsed by
+// hiprtc for a run-time specialised kernel (sdqh_jit.hpp) they become uninstantiated templates: parsed,
+// never compiled, so a specialisation costs a fraction of a second.
+#if defined(__HIPCC_RTC__) || defined(SDQH_DECLS_ONLY)      // SDQH_DECLS_ONLY: sdqh_x.hip wants the argument structs, not a second copy of the kernels
+#define SDQH_KERNEL template <int SDQH_RTC_UNUSED = 0> __global__
+#else
+#define SDQH_KERNEL __global__
+#endif
 
 namespace sdqh {
 
@@ -536,7 +547,7 @@ __global__ __launch_bounds__(TPB) void k_scan_sum(DevFilter f, DevTuple t, int64
 }
 
 // out[0..3] doubles, out[4] count (int64 bits); one workgroup, fixed summation order
-__global__ __launch_bounds__(TPB) void k_sum_partials(const double* __restrict__ partial, int nparts, double* __restrict__ out) {
+SDQH_KERNEL __launch_bounds__(TPB) void k_sum_partials(const double* __restrict__ partial, int nparts, double* __restrict__ out) {
     __shared__ double s[5][TPB];
     double a[4] = {0, 0, 0, 0};
     int64_t c = 0;
@@ -829,7 +840,7 @@ __global__ __launch_bounds__(TPB) void k_groupby_lds(DevFilter f, DevTuple t, De
 
 // One workgroup per global group slot: fold that slot's partials over the workgroups in workgroup
 // order (thread-strided, then an LDS tree).  out: acc[g*4+k], cnt[g]; the keys are gkeys[g].
-__global__ __launch_bounds__(TPB) void k_groupby_merge(const unsigned long long* __restrict__ gkeys, const double* __restrict__ pacc,
+SDQH_KERNEL __launch_bounds__(TPB) void k_groupby_merge(const unsigned long long* __restrict__ gkeys, const double* __restrict__ pacc,
                                                        const int64_t* __restrict__ pcnt, int nparts,
                                                        double* __restrict__ out_acc, int64_t* __restrict__ out_cnt) {
     __shared__ double s_red[5][TPB];
@@ -1156,7 +1167,7 @@ __global__ __launch_bounds__(TPB) void k_stage(DevFilter f, DevProbes pr, DevSta
 
 // Every workgroup recomputes the staged total from the segment counts (a few KB from L2), so the
 // capacity is agreed on without a grid barrier; workgroup 0 publishes the header for later kernels.
-__global__ __launch_bounds__(TPB) void k_clear(const uint32_t* __restrict__ seg_count, int nseg, uint64_t capmax,
+SDQH_KERNEL __launch_bounds__(TPB) void k_clear(const uint32_t* __restrict__ seg_count, int nseg, uint64_t capmax,
                                                TableHeader* __restrict__ hdr, int64_t* __restrict__ keys, uint32_t* __restrict__ rowref) {
     __shared__ unsigned long long s_part[TPB];
     unsigned long long t = 0;
@@ -1185,7 +1196,7 @@ __global__ __launch_bounds__(TPB) void k_clear(const uint32_t* __restrict__ seg_
 // indexes dense_ref), and a claimed base needs no scan pass, no second launch and no device-wide
 // fence (a release fence writes back a whole XCD L2 here).  hdr->staged is summed on the side;
 // fewer distinct keys than staged rows means duplicate build keys (see direct_has_dups).
-__global__ __launch_bounds__(TPB) void k_rank_words(const uint32_t* __restrict__ bm, uint64_t nwords, uint32_t* __restrict__ wprefix,
+SDQH_KERNEL __launch_bounds__(TPB) void k_rank_words(const uint32_t* __restrict__ bm, uint64_t nwords, uint32_t* __restrict__ wprefix,
                                                     const uint32_t* __restrict__ seg_count, int nseg, TableHeader* __restrict__ hdr) {
     __shared__ uint32_t s_wave[TPB / WAVE];
     __shared__ uint32_t s_base;
@@ -1225,12 +1236,12 @@ __global__ __launch_bounds__(TPB) void k_rank_words(const uint32_t* __restrict__
 __device__ __forceinline__ bool direct_has_dups(const TableHeader* hdr) { return hdr->staged != hdr->distinct; }
 // dense_ref[rank(key)] = stage index.  Unique build keys: plain stores, every row its own rank.
 // After a duplicate was seen while staging: atomicMin into a NO_ROW-filled array (lowest row wins).
-__global__ __launch_bounds__(TPB) void k_fill_refs(DevStage st, DevTable t) {        // no-op unless duplicates
+SDQH_KERNEL __launch_bounds__(TPB) void k_fill_refs(DevStage st, DevTable t) {        // no-op unless duplicates
     if (!direct_has_dups(t.hdr)) return;
     const uint64_t n = t.hdr->distinct;
     for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) t.dense_ref[i] = NO_ROW;
 }
-__global__ __launch_bounds__(TPB) void k_insert_direct(DevStage st, DevTable t) {
+SDQH_KERNEL __launch_bounds__(TPB) void k_insert_direct(DevStage st, DevTable t) {
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
     const bool dups = direct_has_dups(t.hdr);
     if (blockIdx.x == 0 && threadIdx.x == 0) t.hdr->has_dups = dups ? 1u : 0u;     // for every later reader
@@ -1247,28 +1258,28 @@ __global__ __launch_bounds__(TPB) void k_insert_direct(DevStage st, DevTable t) 
 
 // ---- dense layout ---------------------------------------------------------------------------------------
 // every row of the build table is an entry: segment counts are simply the segment lengths
-__global__ __launch_bounds__(TPB) void k_full_counts(uint32_t* __restrict__ seg_count, int nseg, int64_t seg_rows, int64_t nrows) {
+SDQH_KERNEL __launch_bounds__(TPB) void k_full_counts(uint32_t* __restrict__ seg_count, int nseg, int64_t seg_rows, int64_t nrows) {
     const int s = blockIdx.x * TPB + threadIdx.x;
     if (s < nseg) { int64_t b = (int64_t)s * seg_rows, e = b + seg_rows; if (e > nrows) e = nrows; seg_count[s] = (uint32_t)(e - b); }
 }
 // dense_arr[key - lo] = row: plain stores (a unique key writes its own cell; sorted keys coalesce)
-__global__ __launch_bounds__(TPB) void k_dense_fill(const int64_t* __restrict__ key, int64_t nrows, int64_t lo, uint32_t* __restrict__ arr) {
+SDQH_KERNEL __launch_bounds__(TPB) void k_dense_fill(const int64_t* __restrict__ key, int64_t nrows, int64_t lo, uint32_t* __restrict__ arr) {
     for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * TPB) arr[key[r] - lo] = (uint32_t)r;
 }
 // a row that does not find itself in its cell lost to a duplicate key
-__global__ __launch_bounds__(TPB) void k_dense_verify(const int64_t* __restrict__ key, int64_t nrows, int64_t lo, const uint32_t* __restrict__ arr, TableHeader* __restrict__ hdr) {
+SDQH_KERNEL __launch_bounds__(TPB) void k_dense_verify(const int64_t* __restrict__ key, int64_t nrows, int64_t lo, const uint32_t* __restrict__ arr, TableHeader* __restrict__ hdr) {
     bool dup = false;
     for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * TPB) dup |= arr[key[r] - lo] != (uint32_t)r;
     if (__ballot(dup) && lane_id() == 0) hdr->has_dups = 1;
     if (blockIdx.x == 0 && threadIdx.x == 0) hdr->staged = (uint64_t)nrows;
 }
 // only with duplicates: the lowest row wins
-__global__ __launch_bounds__(TPB) void k_dense_fixup(const int64_t* __restrict__ key, int64_t nrows, int64_t lo, uint32_t* __restrict__ arr, const TableHeader* __restrict__ hdr) {
+SDQH_KERNEL __launch_bounds__(TPB) void k_dense_fixup(const int64_t* __restrict__ key, int64_t nrows, int64_t lo, uint32_t* __restrict__ arr, const TableHeader* __restrict__ hdr) {
     if (hdr->has_dups == 0) return;
     for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * TPB) atomicMin(&arr[key[r] - lo], (uint32_t)r);
 }
 
-__global__ __launch_bounds__(TPB) void k_insert(DevStage st, DevTable t) {
+SDQH_KERNEL __launch_bounds__(TPB) void k_insert(DevStage st, DevTable t) {
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
     if (seg >= st.nseg) return;
     const uint64_t mask = t.hdr->cap_mask;
@@ -1295,7 +1306,7 @@ __global__ __launch_bounds__(TPB) void k_insert(DevStage st, DevTable t) {
 // Only does work when k_insert saw a duplicate build key: every staged row then lowers its entry's
 // rowref to its own stage index, so the lowest build row wins whatever the insertion order was.
 // (Stage order is row order: segments are cut in row order and compacted in row order.)
-__global__ __launch_bounds__(TPB) void k_insert_fixup(DevStage st, DevTable t) {
+SDQH_KERNEL __launch_bounds__(TPB) void k_insert_fixup(DevStage st, DevTable t) {
     if (t.hdr->has_dups == 0) return;
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
     if (seg >= st.nseg) return;
@@ -1317,7 +1328,7 @@ __device__ __forceinline__ bool stage_row_owns(const DevStage& st, const DevTabl
 }
 
 // distinct entries (table_size)
-__global__ __launch_bounds__(TPB) void k_count(DevStage st, DevTable t) {
+SDQH_KERNEL __launch_bounds__(TPB) void k_count(DevStage st, DevTable t) {
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
     if (seg >= st.nseg) return;
     const uint64_t mask = table_is_direct(t) ? 0 : t.hdr->cap_mask;
@@ -1570,7 +1581,7 @@ __global__ __launch_bounds__(TPB) void k_key_set(DevFilter f, DevProbes pr, cons
         }
 }
 // population count of a bitmap (sdqh_table_size of a membership-only table)
-__global__ __launch_bounds__(TPB) void k_popcount(const uint32_t* __restrict__ bm, uint64_t nwords, unsigned long long* __restrict__ out) {
+SDQH_KERNEL __launch_bounds__(TPB) void k_popcount(const uint32_t* __restrict__ bm, uint64_t nwords, unsigned long long* __restrict__ out) {
     unsigned long long n = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < nwords; i += (uint64_t)gridDim.x * TPB) n += __popc(bm[i]);
     n = (unsigned long long)wave_sum_i64((int64_t)n);
@@ -1581,7 +1592,7 @@ __global__ __launch_bounds__(TPB) void k_popcount(const uint32_t* __restrict__ b
 // The distinct keys come from k_key_set's bitmap, ranked by k_rank_words; entry i (= rank) is then
 // laid out directly: key[i] from the bit position, zeroed accumulators, identity dense_ref, segment
 // counts from the device-resident distinct count.  The rows are added by k_probe_agg.
-__global__ __launch_bounds__(TPB) void k_gk_layout(DevStage st, DevTable t, int64_t lo, uint64_t nwords) {
+SDQH_KERNEL __launch_bounds__(TPB) void k_gk_layout(DevStage st, DevTable t, int64_t lo, uint64_t nwords) {
     const uint64_t D = t.hdr->distinct;
     const uint64_t tid = (uint64_t)blockIdx.x * TPB + threadIdx.x, nth = (uint64_t)gridDim.x * TPB;
     if (tid == 0) { t.hdr->staged = D; t.hdr->has_dups = 0; }
@@ -1601,7 +1612,7 @@ __global__ __launch_bounds__(TPB) void k_gk_layout(DevStage st, DevTable t, int6
     }
 }
 // HAVING (sdqh_table_select_keys): bits of the owner entries with hits >= min_hits and lo <= acc[v] <= hi
-__global__ __launch_bounds__(TPB) void k_select_keys(DevTable t, DevStage st, uint32_t min_hits, int v, double lo, double hi,
+SDQH_KERNEL __launch_bounds__(TPB) void k_select_keys(DevTable t, DevStage st, uint32_t min_hits, int v, double lo, double hi,
                                                      int64_t key_lo, uint32_t* __restrict__ out_bm) {
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
     if (seg >= st.nseg) return;
@@ -2066,7 +2077,7 @@ __device__ __forceinline__ uint32_t compact_segment(const DevTable& t, const Dev
 // launch each, and most builds need two or three).  Regions are 4-byte multiples, 16-byte aligned.
 constexpr int FILL_MAX = 4;
 struct DevFill { void* p[FILL_MAX]; uint64_t bytes[FILL_MAX]; uint32_t word[FILL_MAX]; int32_t n, _pad; };
-__global__ __launch_bounds__(TPB) void k_fill(DevFill f) {
+SDQH_KERNEL __launch_bounds__(TPB) void k_fill(DevFill f) {
     const uint64_t tid = (uint64_t)blockIdx.x * TPB + threadIdx.x, nth = (uint64_t)gridDim.x * TPB;
 #pragma unroll
     for (int r = 0; r < FILL_MAX; ++r) {
@@ -2081,14 +2092,14 @@ __global__ __launch_bounds__(TPB) void k_fill(DevFill f) {
 }
 
 // 1. survivors per segment
-__global__ __launch_bounds__(TPB) void k_compact_count(DevTable t, DevStage st, DevCompactOut o, uint32_t min_hits, uint32_t* __restrict__ seg_kept) {
+SDQH_KERNEL __launch_bounds__(TPB) void k_compact_count(DevTable t, DevStage st, DevCompactOut o, uint32_t min_hits, uint32_t* __restrict__ seg_kept) {
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
     if (seg >= st.nseg) return;
     const uint32_t n = compact_segment<false>(t, st, o, min_hits, seg, 0, nullptr, nullptr);
     if (lane_id() == 0) seg_kept[seg] = n;
 }
 // 2. one workgroup: exclusive scan of the per-segment counts, in place; total -> *o.counter
-__global__ __launch_bounds__(TPB) void k_compact_scan(uint32_t* __restrict__ seg_kept, int nseg, unsigned long long* __restrict__ counter) {
+SDQH_KERNEL __launch_bounds__(TPB) void k_compact_scan(uint32_t* __restrict__ seg_kept, int nseg, unsigned long long* __restrict__ counter) {
     __shared__ unsigned long long s_part[TPB];
     const int per = (nseg + TPB - 1) / TPB;
     const int b0 = threadIdx.x * per, b1 = min(nseg, b0 + per);
@@ -2110,7 +2121,7 @@ __global__ __launch_bounds__(TPB) void k_compact_scan(uint32_t* __restrict__ seg
     for (int b = b0; b < b1; ++b) { const uint32_t v = seg_kept[b]; seg_kept[b] = (uint32_t)run; run += v; }
 }
 // 3. write: output order = stage order = build-row order (deterministic)
-__global__ __launch_bounds__(TPB) void k_compact_write(DevTable t, DevStage st, DevCompactOut o, uint32_t min_hits, const uint32_t* __restrict__ seg_off) {
+SDQH_KERNEL __launch_bounds__(TPB) void k_compact_write(DevTable t, DevStage st, DevCompactOut o, uint32_t min_hits, const uint32_t* __restrict__ seg_off) {
     __shared__ uint32_t s_idx[TPB / WAVE][COMPACT_QCAP], s_hits[TPB / WAVE][COMPACT_QCAP];
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
     const unsigned long long total = *o.counter;
@@ -2276,7 +2287,7 @@ __device__ __forceinline__ void top_emit(const TopLds& s, int have, int k, const
     if (threadIdx.x == 0) *o.count = (unsigned long long)rows;
 }
 
-__global__ __launch_bounds__(TPB) void k_topk_scan(DevTable t, DevStage st, DevTopSpec spec, uint32_t min_hits, DevTopBuf out, DevTopOut fin) {
+SDQH_KERNEL __launch_bounds__(TPB) void k_topk_scan(DevTable t, DevStage st, DevTopSpec spec, uint32_t min_hits, DevTopBuf out, DevTopOut fin) {
     __shared__ TopLds s;
     if (threadIdx.x == 0) s.count = 0;
     __syncthreads();
@@ -2320,7 +2331,7 @@ __global__ __launch_bounds__(TPB) void k_topk_scan(DevTable t, DevStage st, DevT
     else top_write_padded(s, have, spec.k, out, (size_t)blockIdx.x * spec.k);
 }
 
-__global__ __launch_bounds__(TPB) void k_topk_reduce(DevTopBuf in, int n_in, DevStage st, DevTopSpec spec, DevTopBuf out, DevTopOut fin) {
+SDQH_KERNEL __launch_bounds__(TPB) void k_topk_reduce(DevTopBuf in, int n_in, DevStage st, DevTopSpec spec, DevTopBuf out, DevTopOut fin) {
     __shared__ TopLds s;
     const int lo = blockIdx.x * TOPK_CHUNK, n = min(TOPK_CHUNK, n_in - lo);
     for (int j = threadIdx.x; j < n; j += TPB) { s.k0[j] = in.k0[lo + j]; s.k1[j] = in.k1[lo + j]; s.k2[j] = in.k2[lo + j]; s.ref[j] = in.ref[lo + j]; }
@@ -2334,7 +2345,7 @@ __global__ __launch_bounds__(TPB) void k_topk_reduce(DevTopBuf in, int n_in, Dev
 // Redistribution helpers for the multi-GPU join (no reference counterpart).
 // =================================================================================================
 // exclusive scan of the per-segment counts into seg_off (separate array), total -> *total
-__global__ __launch_bounds__(TPB) void k_seg_scan(const uint32_t* __restrict__ seg_count, int nseg, uint64_t* __restrict__ seg_off,
+SDQH_KERNEL __launch_bounds__(TPB) void k_seg_scan(const uint32_t* __restrict__ seg_count, int nseg, uint64_t* __restrict__ seg_off,
                                                   unsigned long long* __restrict__ total) {
     __shared__ unsigned long long s_part[TPB];
     const int per = (nseg + TPB - 1) / TPB;
@@ -2355,7 +2366,7 @@ __global__ __launch_bounds__(TPB) void k_seg_scan(const uint32_t* __restrict__ s
 }
 // dense output columns from the segmented stage: wave per segment, coalesced copies
 struct DevGather { int64_t* out[SDQH_MAX_COMPACT_COLS]; int32_t ncols, _pad; };
-__global__ __launch_bounds__(TPB) void k_gather_segments(DevStage st, const uint64_t* __restrict__ seg_off, DevGather g) {
+SDQH_KERNEL __launch_bounds__(TPB) void k_gather_segments(DevStage st, const uint64_t* __restrict__ seg_off, DevGather g) {
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
     if (seg >= st.nseg) return;
     const int64_t base = (int64_t)seg * st.seg_rows;
@@ -2376,7 +2387,7 @@ __device__ __forceinline__ int part_of(const DevPartition& pt, int64_t key) {
     while (p < pt.nparts - 1 && key > pt.upper[p]) ++p;
     return p;
 }
-__global__ __launch_bounds__(TPB) void k_part_count(const int64_t* __restrict__ key, int64_t nrows, DevPartition pt, unsigned long long* __restrict__ counts) {
+SDQH_KERNEL __launch_bounds__(TPB) void k_part_count(const int64_t* __restrict__ key, int64_t nrows, DevPartition pt, unsigned long long* __restrict__ counts) {
     __shared__ unsigned int s_hist[SDQH_MAX_PARTS];
     if (threadIdx.x < SDQH_MAX_PARTS) s_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -2385,13 +2396,13 @@ __global__ __launch_bounds__(TPB) void k_part_count(const int64_t* __restrict__ 
     if ((int)threadIdx.x < pt.nparts && s_hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
 }
 // counts -> exclusive offsets (cursor), one thread
-__global__ void k_part_offsets(const unsigned long long* __restrict__ counts, int nparts, unsigned long long* __restrict__ cursor) {
+SDQH_KERNEL void k_part_offsets(const unsigned long long* __restrict__ counts, int nparts, unsigned long long* __restrict__ cursor) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { unsigned long long run = 0; for (int p = 0; p < nparts; ++p) { cursor[p] = run; run += counts[p]; } }
 }
 // scatter: a workgroup takes 2048 rows at a time, ranks them inside their part with LDS atomics,
 // reserves the part's output range with ONE global atomic per part, then writes
 constexpr int PART_ROWS_PER_THREAD = 8;
-__global__ __launch_bounds__(TPB) void k_part_scatter(const int64_t* __restrict__ key, int64_t nrows, DevPartition pt,
+SDQH_KERNEL __launch_bounds__(TPB) void k_part_scatter(const int64_t* __restrict__ key, int64_t nrows, DevPartition pt,
                                                       unsigned long long* __restrict__ cursor, DevGather src, DevGather dst) {
     __shared__ unsigned int s_hist[SDQH_MAX_PARTS];
     __shared__ unsigned long long s_base[SDQH_MAX_PARTS];
@@ -2423,7 +2434,7 @@ __global__ __launch_bounds__(TPB) void k_part_scatter(const int64_t* __restrict_
 }
 
 // exact bitmap of a table's keys over [lo, hi] from its stage rows
-__global__ __launch_bounds__(TPB) void k_export_bitmap(DevStage st, int64_t lo, int64_t hi, uint32_t* __restrict__ words) {
+SDQH_KERNEL __launch_bounds__(TPB) void k_export_bitmap(DevStage st, int64_t lo, int64_t hi, uint32_t* __restrict__ words) {
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
     if (seg >= st.nseg) return;
     const int64_t base = (int64_t)seg * st.seg_rows;
@@ -2435,7 +2446,7 @@ __global__ __launch_bounds__(TPB) void k_export_bitmap(DevStage st, int64_t lo, 
 }
 
 // ---- column statistics ---------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_minmax(const int64_t* __restrict__ col, int64_t nrows, long long* __restrict__ out /*[2]*/) {
+SDQH_KERNEL __launch_bounds__(TPB) void k_minmax(const int64_t* __restrict__ col, int64_t nrows, long long* __restrict__ out /*[2]*/) {
     __shared__ long long s_lo[TPB / WAVE], s_hi[TPB / WAVE];
     long long lo = INT64_MAX, hi = INT64_MIN;
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nrows; i += (int64_t)gridDim.x * TPB) {

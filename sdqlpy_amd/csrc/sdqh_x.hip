@@ -1,0 +1,716 @@
+// sdqh_x.hip — row programs (ABI 4, include/sdqh.h): the open expression / predicate vocabulary.
+//
+// The reference compiles every query file into C++ of its own (src/sdqlpy/lib/sdql_ir_cpp_generator_par.py
+// prints the loop bodies; sdql_lib.py:372-387 builds and caches the module).  The MI355X counterpart of that
+// step is here: a program — the conditions, lookups and arithmetic of ONE loop, as data — is turned into a
+// small struct of device functions, and hiprtc specialises a hand-written kernel skeleton
+// (sdqh_xkernels.hpp: streaming, LDS survivor queue, converged drain, sinks) on it for gfx950.  Code
+// objects are cached in memory and on disk by a hash of the generated source, so a plan pays for its
+// specialisation once (about half a second), like the reference's mode 2 reuses its compiled module.
+// There is no interpreter and no CPU path in this library: if hiprtc or its headers are missing the
+// sdqh_x* calls fail with SDQH_ERR_DEVICE and the message says why.
+#define SDQH_DECLS_ONLY 1            // argument structs and constants of the kernel headers, not the kernels
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "sdqh_host.hpp"
+#include "sdqh_xkernels.hpp"
+
+using namespace sdqh_host;
+
+namespace {
+
+#define HIP_TRYX(ctx, expr)                                                                             \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+enum Sink { SINK_SUM, SINK_GROUP, SINK_STAGE, SINK_KEYSET, SINK_ENTRY };
+const char* sink_name(Sink s) { return s == SINK_SUM ? "XSum" : s == SINK_GROUP ? "XGroup" : s == SINK_STAGE ? "XStage" : s == SINK_KEYSET ? "XKeySet" : "XEntry"; }
+
+// ---- program analysis -------------------------------------------------------------------------------
+struct XInfo {
+    const sdqh_program* p = nullptr;
+    int ncols = 0; const sdqh_column* cols[SDQH_MAX_XCOLS]; int col_of[SDQH_MAX_XOPS];
+    int ntabs = 0; sdqh_table* tabs[SDQH_MAX_XTABLES]; int tab_of[SDQH_MAX_XOPS];
+    int nci = 0, ncf = 0; int const_of[SDQH_MAX_XOPS]; int64_t ci[X_MAX_CONST]; double cf[X_MAX_CONST];
+    int nstr = 0; int str_off[SDQH_MAX_XOPS]; uint32_t spool[SDQH_MAX_XSTR];
+    bool direct = false;                     // every operation is register arithmetic on numeric columns
+    int nstream_gates = 0;                   // leading gates that depend on numeric columns / constants only
+    std::vector<int> scols;                  // streamed columns (indices into cols)
+    int probe_op = -1;                       // XEntry: the LOOKUP whose entry receives the values
+};
+
+bool op_is_light(const sdqh_xop& o) {        // evaluable on streamed registers
+    switch (o.code) {
+        case SDQH_X_LOOKUP: case SDQH_X_FIELD: case SDQH_X_ACC: case SDQH_X_STR: case SDQH_X_STRIDX: case SDQH_X_CHAR: return false;
+        default: return true;
+    }
+}
+void closure(const sdqh_program* p, int k, std::vector<char>& seen) {       // the operations value k depends on (itself included)
+    if (k < 0 || k >= p->nops || seen[(size_t)k]) return;
+    seen[(size_t)k] = 1;
+    const sdqh_xop& o = p->ops[k];
+    if (o.code == SDQH_X_COL || o.code == SDQH_X_ROWID || o.code == SDQH_X_CONST || o.code == SDQH_X_STR || o.code == SDQH_X_STRIDX || o.code == SDQH_X_CHAR) return;
+    if (o.a < k) closure(p, o.a, seen);
+    if (o.b < k) closure(p, o.b, seen);
+    if (o.c < k) closure(p, o.c, seen);
+}
+
+// the ABI's rules for a program (the CPU implementation applies the same ones)
+int analyse(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* p, int max_vals, bool need_key, bool vals_f64, XInfo* x) {
+    if (!p || p->nops < 0 || p->nops > SDQH_MAX_XOPS || (p->nops && !p->ops) || p->ngates < 0 || p->ngates > SDQH_MAX_XGATES || (p->ngates && !p->gates) ||
+        p->nvals < 0 || p->nvals > max_vals || (p->nvals && !p->vals))
+        return fail(ctx, SDQH_ERR_INVALID, "program: bad counts");
+    x->p = p;
+    for (int k = 0; k < p->nops; ++k) {
+        const sdqh_xop& o = p->ops[k];
+        x->col_of[k] = x->tab_of[k] = x->const_of[k] = x->str_off[k] = -1;
+        auto ty = [&](int j) { return (j >= 0 && j < k) ? p->ops[j].type : -1; };
+        auto need = [&](bool ok, const char* what) { return ok ? SDQH_OK : fail(ctx, SDQH_ERR_INVALID, std::string("program: operation ") + std::to_string(k) + ": " + what); };
+        int rc = SDQH_OK;
+        switch (o.code) {
+            case SDQH_X_COL:
+                rc = need(o.col && o.col->dtype != SDQH_STR && o.col->nrows >= nrows && o.type == (o.col->dtype == SDQH_F64 ? SDQH_T_F64 : SDQH_T_I64), "COL needs an I64 / F64 column covering nrows, typed alike"); break;
+            case SDQH_X_ROWID: rc = need(o.type == SDQH_T_I64, "ROWID is i64"); break;
+            case SDQH_X_CONST: rc = need(o.type >= SDQH_T_I64 && o.type <= SDQH_T_BOOL, "CONST type"); break;
+            case SDQH_X_LOOKUP: rc = need(o.table && ty(o.a) == SDQH_T_I64 && o.type == SDQH_T_BOOL, "LOOKUP needs a table and an i64 key"); break;
+            case SDQH_X_FIELD:
+                rc = need(o.a >= 0 && o.a < k && p->ops[o.a].code == SDQH_X_LOOKUP && !p->ops[o.a].table->bitmap_only && o.aux >= 0 && o.aux < p->ops[o.a].table->npay &&
+                          (o.type == SDQH_T_I64 || o.type == SDQH_T_F64), "FIELD needs an earlier LOOKUP and one of its payload fields"); break;
+            case SDQH_X_ACC:
+                rc = need(o.a >= 0 && o.a < k && p->ops[o.a].code == SDQH_X_LOOKUP && p->ops[o.a].table->accumulate && !p->ops[o.a].table->bitmap_only && o.aux >= -1 && o.aux < SDQH_TUPLE_MAX_VALUES &&
+                          o.type == (o.aux < 0 ? SDQH_T_I64 : SDQH_T_F64), "ACC needs an earlier LOOKUP into a table with accumulators"); break;
+            case SDQH_X_ADD: case SDQH_X_SUB: case SDQH_X_MUL:
+                rc = need(ty(o.a) == ty(o.b) && (ty(o.a) == SDQH_T_I64 || ty(o.a) == SDQH_T_F64) && o.type == ty(o.a), "arithmetic needs two operands of one numeric type"); break;
+            case SDQH_X_DIV: rc = need(ty(o.a) == SDQH_T_F64 && ty(o.b) == SDQH_T_F64 && o.type == SDQH_T_F64, "DIV is f64"); break;
+            case SDQH_X_NEG: rc = need((ty(o.a) == SDQH_T_I64 || ty(o.a) == SDQH_T_F64) && o.type == ty(o.a), "NEG operand"); break;
+            case SDQH_X_I2F: rc = need(ty(o.a) == SDQH_T_I64 && o.type == SDQH_T_F64, "I2F operand"); break;
+            case SDQH_X_YEAR: rc = need(ty(o.a) == SDQH_T_I64 && o.type == SDQH_T_I64, "YEAR operand"); break;
+            case SDQH_X_PACK2: rc = need(ty(o.a) == SDQH_T_I64 && ty(o.b) == SDQH_T_I64 && o.type == SDQH_T_I64, "PACK2 operands"); break;
+            case SDQH_X_LT: case SDQH_X_LE: case SDQH_X_GT: case SDQH_X_GE: case SDQH_X_EQ: case SDQH_X_NE:
+                rc = need(ty(o.a) == ty(o.b) && (ty(o.a) == SDQH_T_I64 || ty(o.a) == SDQH_T_F64 || (ty(o.a) == SDQH_T_BOOL && (o.code == SDQH_X_EQ || o.code == SDQH_X_NE))) && o.type == SDQH_T_BOOL,
+                          "comparison needs two operands of one type"); break;
+            case SDQH_X_AND: case SDQH_X_OR: rc = need(ty(o.a) == SDQH_T_BOOL && ty(o.b) == SDQH_T_BOOL && o.type == SDQH_T_BOOL, "boolean operands"); break;
+            case SDQH_X_NOT: rc = need(ty(o.a) == SDQH_T_BOOL && o.type == SDQH_T_BOOL, "boolean operand"); break;
+            case SDQH_X_SELECT: rc = need(ty(o.a) == SDQH_T_BOOL && ty(o.b) == ty(o.c) && ty(o.b) >= 0 && o.type == ty(o.b), "SELECT needs a bool and two values of one type"); break;
+            case SDQH_X_STR: case SDQH_X_STRIDX:
+                rc = need(o.col && o.col->dtype == SDQH_STR && o.col->nrows >= nrows && o.slen >= 0 && o.slen <= SDQH_MAX_STR_CONST && (o.slen == 0 || o.str) &&
+                          o.type == (o.code == SDQH_X_STR ? SDQH_T_BOOL : SDQH_T_I64) && (o.code != SDQH_X_STR || (o.aux >= SDQH_STR_EQ && o.aux <= SDQH_STR_SUFFIX)), "string operation needs a STR column and a constant");
+                if (!rc) {
+                    if (x->nstr + o.slen > SDQH_MAX_XSTR) return fail(ctx, SDQH_ERR_UNSUPPORTED, "program: string constants exceed SDQH_MAX_XSTR code units");
+                    x->str_off[k] = x->nstr;
+                    for (int i = 0; i < o.slen; ++i) x->spool[x->nstr++] = o.str[i];
+                }
+                break;
+            case SDQH_X_CHAR: rc = need(o.col && o.col->dtype == SDQH_STR && o.col->nrows >= nrows && o.type == SDQH_T_I64 && o.aux >= 0, "CHAR needs a STR column"); break;
+            default: rc = fail(ctx, SDQH_ERR_UNSUPPORTED, "program: unknown operation code " + std::to_string(o.code));
+        }
+        if (rc) return rc;
+        if (o.col) {
+            int j = 0; while (j < x->ncols && x->cols[j] != o.col) ++j;
+            if (j == x->ncols) { if (x->ncols == SDQH_MAX_XCOLS) return fail(ctx, SDQH_ERR_UNSUPPORTED, "program: more than SDQH_MAX_XCOLS columns"); x->cols[x->ncols++] = o.col; }
+            x->col_of[k] = j;
+        }
+        if (o.code == SDQH_X_LOOKUP) {
+            sdqh_table* t = const_cast<sdqh_table*>(o.table);
+            int j = 0; while (j < x->ntabs && x->tabs[j] != t) ++j;
+            if (j == x->ntabs) { if (x->ntabs == SDQH_MAX_XTABLES) return fail(ctx, SDQH_ERR_UNSUPPORTED, "program: more than SDQH_MAX_XTABLES tables"); x->tabs[x->ntabs++] = t; }
+            x->tab_of[k] = j;
+        }
+        if (o.code == SDQH_X_CONST) {
+            if (o.type == SDQH_T_F64) { if (x->ncf == X_MAX_CONST) return fail(ctx, SDQH_ERR_UNSUPPORTED, "program: too many constants"); x->cf[x->ncf] = o.imm_f; x->const_of[k] = x->ncf++; }
+            else { if (x->nci == X_MAX_CONST) return fail(ctx, SDQH_ERR_UNSUPPORTED, "program: too many constants"); x->ci[x->nci] = o.imm_i; x->const_of[k] = x->nci++; }
+        }
+    }
+    for (int g = 0; g < p->ngates; ++g)
+        if (p->gates[g] < 0 || p->gates[g] >= p->nops || p->ops[p->gates[g]].type != SDQH_T_BOOL) return fail(ctx, SDQH_ERR_INVALID, "program: a gate must be a bool operation");
+    if (need_key ? !(p->key >= 0 && p->key < p->nops && p->ops[p->key].type == SDQH_T_I64) : p->key != -1) return fail(ctx, SDQH_ERR_INVALID, "program: key");
+    for (int v = 0; v < p->nvals; ++v) {
+        if (p->vals[v] < 0 || p->vals[v] >= p->nops) return fail(ctx, SDQH_ERR_INVALID, "program: value index");
+        const int t = p->ops[p->vals[v]].type;
+        if (vals_f64 ? t != SDQH_T_F64 : (t != SDQH_T_I64 && t != SDQH_T_F64)) return fail(ctx, SDQH_ERR_INVALID, "program: value type");
+    }
+    // DIRECT: nothing but register arithmetic on numeric columns
+    x->direct = x->ncols <= 12;
+    for (int k = 0; k < p->nops; ++k) x->direct = x->direct && op_is_light(p->ops[k]);
+    // leading gates that only need numeric columns: tested on the streamed registers
+    std::vector<char> scol((size_t)SDQH_MAX_XCOLS, 0);
+    for (int g = 0; g < p->ngates; ++g) {
+        std::vector<char> seen((size_t)p->nops, 0);
+        closure(p, p->gates[g], seen);
+        bool light = true; std::vector<int> cols;
+        for (int k = 0; k < p->nops; ++k) if (seen[(size_t)k]) { light = light && op_is_light(p->ops[k]); if (p->ops[k].code == SDQH_X_COL) cols.push_back(x->col_of[k]); }
+        int extra = 0; for (int c : cols) if (!scol[(size_t)c]) ++extra;
+        int have = 0; for (char c : scol) have += c;
+        if (!light || have + extra > 6) break;
+        for (int c : cols) scol[(size_t)c] = 1;
+        x->nstream_gates = g + 1;
+    }
+    for (int c = 0; c < x->ncols; ++c) if (scol[(size_t)c]) x->scols.push_back(c);
+    return SDQH_OK;
+}
+
+// ---- code generation ----------------------------------------------------------------------------------
+struct Gen {
+    const XInfo& x; std::ostringstream os; std::vector<char> done; int mode = 0;      // mode 0: columns gathered by row r; 1: from streamed registers, half H; 2: stest (explicit .x / .y)
+    const char* half = "";
+    std::vector<int> slot_of;                  // column -> slot in the streamed register array
+    explicit Gen(const XInfo& xi) : x(xi), done((size_t)xi.p->nops, 0), slot_of((size_t)SDQH_MAX_XCOLS, -1) {}
+
+    static const char* ctype(int t) { return t == SDQH_T_F64 ? "double" : t == SDQH_T_BOOL ? "bool" : "int64_t"; }
+    std::string bad(int k) const {
+        const int c = x.p->ops[k].code;
+        return (c == SDQH_X_PACK2 || c == SDQH_X_SELECT) ? "b" + std::to_string(k) : std::string("false");
+    }
+    std::string col_expr(int k) {
+        const sdqh_xop& o = x.p->ops[k];
+        const int c = x.col_of[k];
+        std::string raw;
+        if (mode == 0) return std::string("static_cast<const ") + (o.type == SDQH_T_F64 ? "double" : "int64_t") + "*>(a.col[" + std::to_string(c) + "])[r]";
+        if (mode == 1) raw = "(H == 0 ? s[" + std::to_string(slot_of[(size_t)c]) + "].x : s[" + std::to_string(slot_of[(size_t)c]) + "].y)";
+        else raw = "s[" + std::to_string(slot_of[(size_t)c]) + "]." + half;
+        return o.type == SDQH_T_F64 ? "x_f(" + raw + ")" : raw;
+    }
+    void emit(int k) {
+        if (k < 0 || done[(size_t)k]) return;
+        const sdqh_xop& o = x.p->ops[k];
+        auto v = [](int j) { return "v" + std::to_string(j); };
+        const std::string K = std::to_string(k);
+        std::string e;
+        switch (o.code) {
+            case SDQH_X_COL: e = col_expr(k); break;
+            case SDQH_X_ROWID: e = "r"; break;
+            case SDQH_X_CONST:
+                e = o.type == SDQH_T_F64 ? "a.cf[" + std::to_string(x.const_of[k]) + "]" : (o.type == SDQH_T_BOOL ? "(a.ci[" + std::to_string(x.const_of[k]) + "] != 0)" : "a.ci[" + std::to_string(x.const_of[k]) + "]");
+                break;
+            case SDQH_X_LOOKUP:
+                emit(o.a);
+                os << "        const uint32_t e" << K << " = x_lookup(a.tab[" << x.tab_of[k] << "], " << v(o.a) << ", " << bad(o.a) << ");\n";
+                e = "(e" + K + " != NO_ROW)";
+                break;
+            case SDQH_X_FIELD:
+                emit(o.a);
+                e = "x_field(a.tab[" + std::to_string(x.tab_of[o.a]) + "], " + std::to_string(o.aux) + ", e" + std::to_string(o.a) + ")";
+                if (o.type == SDQH_T_F64) e = "x_f(" + e + ")";
+                break;
+            case SDQH_X_ACC:
+                emit(o.a);
+                e = o.aux < 0 ? "x_hits(a.tab[" + std::to_string(x.tab_of[o.a]) + "], e" + std::to_string(o.a) + ")"
+                              : "x_acc(a.tab[" + std::to_string(x.tab_of[o.a]) + "], " + std::to_string(o.aux) + ", e" + std::to_string(o.a) + ")";
+                break;
+            case SDQH_X_ADD: emit(o.a); emit(o.b); e = "(" + v(o.a) + " + " + v(o.b) + ")"; break;
+            case SDQH_X_SUB: emit(o.a); emit(o.b); e = "(" + v(o.a) + " - " + v(o.b) + ")"; break;
+            case SDQH_X_MUL: emit(o.a); emit(o.b); e = "(" + v(o.a) + " * " + v(o.b) + ")"; break;
+            case SDQH_X_DIV: emit(o.a); emit(o.b); e = "(" + v(o.a) + " / " + v(o.b) + ")"; break;
+            case SDQH_X_NEG: emit(o.a); e = "(-" + v(o.a) + ")"; break;
+            case SDQH_X_I2F: emit(o.a); e = "(double)" + v(o.a); break;
+            case SDQH_X_YEAR: emit(o.a); e = "(" + v(o.a) + " / 10000)"; break;
+            case SDQH_X_PACK2:
+                emit(o.a); emit(o.b);
+                os << "        const bool b" << K << " = " << bad(o.a) << " || " << bad(o.b) << " || " << v(o.a) << " < 0 || " << v(o.a) << " > 0xFFFFFFFFll || " << v(o.b) << " < 0 || " << v(o.b) << " > 0xFFFFFFFFll;\n";
+                e = "(int64_t)(((uint64_t)" + v(o.a) + " << 32) | ((uint64_t)" + v(o.b) + " & 0xFFFFFFFFull))";
+                break;
+            case SDQH_X_LT: emit(o.a); emit(o.b); e = "(" + v(o.a) + " < " + v(o.b) + ")"; break;
+            case SDQH_X_LE: emit(o.a); emit(o.b); e = "(" + v(o.a) + " <= " + v(o.b) + ")"; break;
+            case SDQH_X_GT: emit(o.a); emit(o.b); e = "(" + v(o.a) + " > " + v(o.b) + ")"; break;
+            case SDQH_X_GE: emit(o.a); emit(o.b); e = "(" + v(o.a) + " >= " + v(o.b) + ")"; break;
+            case SDQH_X_EQ: emit(o.a); emit(o.b); e = "(" + v(o.a) + " == " + v(o.b) + ")"; break;
+            case SDQH_X_NE: emit(o.a); emit(o.b); e = "(" + v(o.a) + " != " + v(o.b) + ")"; break;
+            case SDQH_X_AND: emit(o.a); emit(o.b); e = "(" + v(o.a) + " && " + v(o.b) + ")"; break;
+            case SDQH_X_OR: emit(o.a); emit(o.b); e = "(" + v(o.a) + " || " + v(o.b) + ")"; break;
+            case SDQH_X_NOT: emit(o.a); e = "(!" + v(o.a) + ")"; break;
+            case SDQH_X_SELECT:
+                emit(o.a); emit(o.b); emit(o.c);
+                os << "        const bool b" << K << " = " << v(o.a) << " ? " << bad(o.b) << " : " << bad(o.c) << ";\n";
+                e = "(" + v(o.a) + " ? " + v(o.b) + " : " + v(o.c) + ")";
+                break;
+            case SDQH_X_STR: case SDQH_X_STRIDX: case SDQH_X_CHAR: {
+                const std::string c = std::to_string(x.col_of[k]);
+                const std::string field = "static_cast<const uint32_t*>(a.col[" + c + "]) + r * (int64_t)a.width[" + c + "], a.width[" + c + "]";
+                if (o.code == SDQH_X_STR) e = "str_pred(" + field + ", a.spool + " + std::to_string(x.str_off[k]) + ", " + std::to_string(o.slen) + ", " + std::to_string(o.aux) + ")";
+                else if (o.code == SDQH_X_STRIDX) e = "x_first_index(" + field + ", a.spool + " + std::to_string(x.str_off[k]) + ", " + std::to_string(o.slen) + ")";
+                else e = "x_char(" + field + ", " + std::to_string(o.aux) + ")";
+                break;
+            }
+            default: e = "0";
+        }
+        os << "        const " << ctype(o.type) << " v" << K << " = " << e << ";\n";
+        done[(size_t)k] = 1;
+    }
+    void reset() { std::fill(done.begin(), done.end(), 0); }
+};
+
+std::string generate(const XInfo& x, Sink sink, bool direct) {
+    const sdqh_program* p = x.p;
+    Gen g(x);
+    std::vector<int> scols = x.scols;
+    int first_gate = x.nstream_gates;
+    if (direct) { scols.clear(); for (int c = 0; c < x.ncols; ++c) scols.push_back(c); first_gate = 0; }
+    for (size_t i = 0; i < scols.size(); ++i) g.slot_of[(size_t)scols[i]] = (int)i;
+    const int ns = (int)scols.size(), nsx = std::max(1, ns);
+    std::ostringstream out;
+    out << "#include \"sdqh_xkernels.hpp\"\nusing namespace sdqh;\n";
+    out << "struct P {\n    static constexpr int NS = " << ns << ", NV = " << p->nvals << ";\n";
+    out << "    template <bool TAIL> __device__ __forceinline__ static void sload(const XArgs& a, int64_t r, int64_t nrows, Pair<int64_t> (&s)[" << nsx << "]) {\n";
+    for (int i = 0; i < ns; ++i) out << "        s[" << i << "] = load2<TAIL>(static_cast<const int64_t*>(a.col[" << scols[(size_t)i] << "]), r, nrows);\n";
+    out << "    }\n";
+    // streamed conditions, both rows of the pair
+    out << "    __device__ __forceinline__ static void stest(const XArgs& a, const Pair<int64_t> (&s)[" << nsx << "], bool& p0, bool& p1) {\n";
+    if (!direct) for (int h = 0; h < 2; ++h) {
+        g.reset(); g.mode = 2; g.half = h ? "y" : "x"; g.os.str("");
+        out << "      {\n";
+        for (int q = 0; q < x.nstream_gates; ++q) { g.emit(p->gates[q]); g.os << "        p" << h << " = p" << h << " && v" << p->gates[q] << ";\n"; }
+        out << g.os.str() << "      }\n";
+    }
+    out << "    }\n";
+    auto body = [&](int mode, int from_gate) {
+        g.reset(); g.mode = mode; g.os.str("");
+        for (int q = from_gate; q < p->ngates; ++q) { g.emit(p->gates[q]); g.os << "        if (!v" << p->gates[q] << ") return false;\n"; }
+        if (p->key >= 0) { g.emit(p->key); g.os << "        o.key = v" << p->key << "; o.bad = " << g.bad(p->key) << ";\n"; }
+        else g.os << "        o.key = 0; o.bad = false;\n";
+        for (int v = 0; v < p->nvals; ++v) {
+            g.emit(p->vals[v]);
+            g.os << "        o.val[" << v << "] = " << (p->ops[p->vals[v]].type == SDQH_T_F64 ? "x_bits(v" + std::to_string(p->vals[v]) + ")" : "v" + std::to_string(p->vals[v])) << ";\n";
+        }
+        if (x.probe_op >= 0) { g.emit(x.probe_op); g.os << "        o.ent = e" << x.probe_op << ";\n"; } else g.os << "        o.ent = NO_ROW;\n";
+        g.os << "        return true;\n";
+        return g.os.str();
+    };
+    out << "    template <int H> __device__ __forceinline__ static bool eval_regs(const XArgs& a, const Pair<int64_t> (&s)[" << nsx << "], int64_t r, XOut<NV>& o) {\n";
+    if (direct) out << body(1, 0); else out << "        return false;\n";
+    out << "    }\n";
+    out << "    __device__ __forceinline__ static bool eval_row(const XArgs& a, int64_t r, XOut<NV>& o) {\n";
+    if (!direct) out << body(0, first_gate); else out << "        return false;\n";
+    out << "    }\n};\n";
+    const std::string sn = sink_name(sink);
+    out << "extern \"C\" __global__ __launch_bounds__(256) void xk(XArgs a, " << sn << "<P::NV>::Args s, int64_t nrows, int64_t seg_rows, int nseg) {\n";
+    if (direct) out << "    x_direct<P, " << sn << ">(a, s, nrows);\n";
+    else out << "    x_queue<P, " << sn << ", " << (sink == SINK_STAGE ? "true" : "false") << ">(a, s, nrows, seg_rows, nseg);\n";
+    out << "}\n";
+    return out.str();
+}
+
+// ---- specialisation: hiprtc + caches --------------------------------------------------------------------
+struct JitState {
+    std::mutex mu;
+    bool headers_loaded = false; std::string h_abi, h_kernels, h_xkernels, src_dir, cache_dir, why_unusable;
+    std::map<std::string, hipFunction_t> kernels;          // hash (+ device) -> function
+    int64_t compiled = 0, from_disk = 0;
+};
+JitState& jit() { static JitState s; return s; }
+
+std::string slurp(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return std::string();
+    std::stringstream ss; ss << f.rdbuf();
+    return ss.str();
+}
+uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
+    for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+    return h;
+}
+
+bool load_headers(JitState& J) {
+    if (J.headers_loaded) return J.why_unusable.empty();
+    J.headers_loaded = true;
+    std::string dir;
+    if (const char* env = std::getenv("SDQLPY_AMD_CSRC")) dir = env;
+    else {
+        Dl_info info;
+        if (dladdr(reinterpret_cast<const void*>(&sdqh_jit_stats), &info) && info.dli_fname) { dir = info.dli_fname; const size_t at = dir.rfind('/'); dir = at == std::string::npos ? "." : dir.substr(0, at); }
+    }
+    J.src_dir = dir;
+    J.h_kernels = slurp(dir + "/sdqh_kernels.hpp");
+    J.h_xkernels = slurp(dir + "/sdqh_xkernels.hpp");
+    J.h_abi = slurp(dir + "/../../include/sdqh.h");
+    if (J.h_abi.empty()) J.h_abi = slurp(dir + "/sdqh.h");
+    if (J.h_kernels.empty() || J.h_xkernels.empty() || J.h_abi.empty()) {
+        J.why_unusable = "run-time specialisation needs sdqh_kernels.hpp, sdqh_xkernels.hpp next to libsdqlhip.so and include/sdqh.h (looked in " + dir + ")";
+        return false;
+    }
+    if (const char* env = std::getenv("SDQLPY_AMD_JIT_CACHE")) J.cache_dir = env;
+    else J.cache_dir = dir + "/../jit_cache";
+    (void)mkdir(J.cache_dir.c_str(), 0777);
+    return true;
+}
+
+int specialise(sdqh_ctx* ctx, const std::string& source, hipFunction_t* fn) {
+    JitState& J = jit();
+    std::lock_guard<std::mutex> lock(J.mu);
+    if (!load_headers(J)) return fail(ctx, SDQH_ERR_DEVICE, J.why_unusable);
+    int rtc_major = 0, rtc_minor = 0;
+    (void)hiprtcVersion(&rtc_major, &rtc_minor);
+    uint64_t h = fnv1a(source);
+    h = fnv1a(J.h_xkernels, h); h = fnv1a(J.h_kernels, h); h = fnv1a(J.h_abi, h);
+    h = fnv1a("gfx950 rtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor), h);
+    char name[64];
+    std::snprintf(name, sizeof(name), "%016llx", (unsigned long long)h);
+    const std::string key = std::string(name) + "@" + std::to_string(ctx->device);
+    auto hit = J.kernels.find(key);
+    if (hit != J.kernels.end()) { *fn = hit->second; return SDQH_OK; }
+    const std::string path = J.cache_dir + "/" + name + ".hsaco";
+    std::string code = slurp(path);
+    if (!code.empty()) ++J.from_disk;
+    else {
+        hiprtcProgram prog;
+        const char* hs[3] = {J.h_abi.c_str(), J.h_kernels.c_str(), J.h_xkernels.c_str()};
+        const char* hn[3] = {"sdqh.h", "sdqh_kernels.hpp", "sdqh_xkernels.hpp"};
+        if (hiprtcCreateProgram(&prog, source.c_str(), "sdqh_specialised.hip", 3, hs, hn) != HIPRTC_SUCCESS)
+            return fail(ctx, SDQH_ERR_DEVICE, "hiprtcCreateProgram failed");
+        const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics"};
+        const hiprtcResult r = hiprtcCompileProgram(prog, 5, opts);
+        if (r != HIPRTC_SUCCESS) {
+            size_t n = 0; (void)hiprtcGetProgramLogSize(prog, &n);
+            std::string log(n + 1, '\0');
+            if (n) (void)hiprtcGetProgramLog(prog, &log[0]);
+            (void)hiprtcDestroyProgram(&prog);
+            if (std::getenv("SDQLPY_AMD_JIT_DUMP")) std::fprintf(stderr, "---- specialised source ----\n%s\n", source.c_str());
+            return fail(ctx, SDQH_ERR_DEVICE, std::string("hiprtc: ") + hiprtcGetErrorString(r) + "\n" + log.substr(0, 4000));
+        }
+        size_t n = 0; (void)hiprtcGetCodeSize(prog, &n);
+        code.resize(n);
+        (void)hiprtcGetCode(prog, &code[0]);
+        (void)hiprtcDestroyProgram(&prog);
+        ++J.compiled;
+        const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+        { std::ofstream f(tmp, std::ios::binary); f.write(code.data(), (std::streamsize)code.size()); }
+        (void)std::rename(tmp.c_str(), path.c_str());                  // atomic: a peer rank never sees half a file
+    }
+    if (ctx->compile_only) return fail(ctx, SDQH_ERR_DEVICE, "compile-only context: kernel specialised (" + std::to_string(code.size()) + " bytes of gfx950 code), not run");
+    hipModule_t mod;
+    if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, SDQH_ERR_DEVICE, "hipModuleLoadData failed for a specialised kernel"); }
+    hipFunction_t f;
+    if (hipModuleGetFunction(&f, mod, "xk") != hipSuccess) { (void)hipGetLastError(); return fail(ctx, SDQH_ERR_DEVICE, "specialised kernel has no entry point"); }
+    J.kernels[key] = f;
+    *fn = f;
+    return SDQH_OK;
+}
+
+// ---- launch --------------------------------------------------------------------------------------------
+template <class SA> struct Packed { XArgs a; SA s; int64_t nrows; int64_t seg_rows; int32_t nseg; };
+
+int fill_xargs(sdqh_ctx* ctx, const XInfo& x, XArgs* a, int32_t* flags, int64_t key_lo, int64_t key_hi) {
+    std::memset(a, 0, sizeof(*a));
+    for (int c = 0; c < x.ncols; ++c) { a->col[c] = x.cols[c]->data; a->width[c] = x.cols[c]->width; }
+    for (int t = 0; t < x.ntabs; ++t) {
+        if (int rc = index_ensure(ctx, x.tabs[t])) return rc;
+        a->tab[t] = x.tabs[t]->dev;
+    }
+    std::memcpy(a->ci, x.ci, sizeof(x.ci[0]) * (size_t)x.nci);
+    std::memcpy(a->cf, x.cf, sizeof(x.cf[0]) * (size_t)x.ncf);
+    std::memcpy(a->spool, x.spool, sizeof(uint32_t) * (size_t)x.nstr);
+    a->flags = flags; a->key_lo = key_lo; a->key_hi = key_hi;
+    return SDQH_OK;
+}
+
+struct Geometry { unsigned grid; int64_t seg_rows; int nseg; };
+Geometry geometry(sdqh_ctx* ctx, int64_t nrows, bool direct, int waves_per_cu) {
+    Geometry g{1, 0, 0};
+    if (direct) {
+        const int64_t tiles = ((nrows + TILE_ROWS - 1) / TILE_ROWS + SDQH_TILE_CHUNK - 1) / SDQH_TILE_CHUNK;
+        g.grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)ctx->num_cu * ctx->opt_resident_stream));
+        return g;
+    }
+    const int64_t gran = (int64_t)WAVE * ROWS_PER_LOAD * X_LB;
+    const int64_t target = (int64_t)ctx->num_cu * waves_per_cu;
+    int64_t seg_rows = (nrows + target - 1) / target;
+    seg_rows = std::max<int64_t>(gran, (seg_rows + gran - 1) / gran * gran);
+    g.seg_rows = seg_rows;
+    g.nseg = (int)std::max<int64_t>(1, (nrows + seg_rows - 1) / seg_rows);
+    g.grid = (unsigned)((g.nseg + TPB / WAVE - 1) / (TPB / WAVE));
+    return g;
+}
+
+template <class SA>
+int launch(sdqh_ctx* ctx, hipFunction_t fn, const char* name, const XArgs& a, const SA& sa, int64_t nrows, const Geometry& g) {
+    Packed<SA> pk;
+    std::memset(&pk, 0, sizeof(pk));
+    pk.a = a; pk.s = sa; pk.nrows = nrows; pk.seg_rows = g.seg_rows; pk.nseg = g.nseg;
+    size_t size = sizeof(pk);
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &pk, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    KernelScope ks(ctx, name);
+    HIP_TRYX(ctx, hipModuleLaunchKernel(fn, g.grid, 1, 1, TPB, 1, 1, 0, ctx->stream, nullptr, config));
+    return SDQH_OK;
+}
+
+int read_flags(sdqh_ctx* ctx, const int32_t* d_flags, int* out) {
+    HIP_TRYX(ctx, hipMemcpyAsync(ctx->result_host, d_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (int rc = sync_stream(ctx)) return rc;
+    *out = *static_cast<const int*>(ctx->result_host);
+    return SDQH_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int sdqh_jit_stats(sdqh_ctx* ctx, int64_t* compiled, int64_t* from_cache) {
+    if (!ctx) return SDQH_ERR_INVALID;
+    JitState& J = jit();
+    std::lock_guard<std::mutex> lock(J.mu);
+    if (compiled) *compiled = J.compiled;
+    if (from_cache) *from_cache = J.from_disk;
+    return SDQH_OK;
+}
+
+int sdqh_xscan_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, double* out_values, int64_t* out_count) {
+    if (!ctx || nrows < 0) return fail(ctx, SDQH_ERR_INVALID, "xscan_sum: bad arguments");
+    if (!ctx->compile_only) (void)hipSetDevice(ctx->device);
+    XInfo x;
+    if (int rc = analyse(ctx, nrows, prog, SDQH_TUPLE_MAX_VALUES, false, true, &x)) return rc;
+    hipFunction_t fn;
+    if (int rc = specialise(ctx, generate(x, SINK_SUM, x.direct), &fn)) return rc;
+    call_begin(ctx);
+    XArgs a;
+    int32_t* d_flags = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->result_dev) + 1024);
+    if (int rc = fill_xargs(ctx, x, &a, d_flags, 1, 0)) return rc;
+    const Geometry g = geometry(ctx, nrows, x.direct, 16);
+    double* partial = static_cast<double*>(pool_alloc(ctx, (size_t)g.grid * 5 * sizeof(double)));
+    if (!partial) return fail(ctx, SDQH_ERR_NOMEM, "xscan_sum: out of device memory");
+    XSum<1>::Args sa{partial};
+    double* out_dev = static_cast<double*>(ctx->result_dev);
+    int rc = launch(ctx, fn, "x_scan_sum", a, sa, nrows, g);
+    if (!rc) {
+        launch_sum_partials(ctx, partial, (int)g.grid, out_dev);
+        call_end(ctx);
+        hipError_t e = hipMemcpyAsync(ctx->result_host, out_dev, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e));
+        if (!rc) rc = sync_stream(ctx);
+    }
+    pool_free(ctx, partial);
+    if (rc) return rc;
+    const double* h = static_cast<const double*>(ctx->result_host);
+    if (out_values) for (int k = 0; k < prog->nvals; ++k) out_values[k] = h[k];
+    if (out_count) *out_count = reinterpret_cast<const int64_t*>(h)[4];
+    return SDQH_OK;
+}
+
+int sdqh_xgroupby(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int max_groups,
+                  int64_t* out_keys, double* out_values, int64_t* out_counts, int32_t* out_ngroups) {
+    if (!ctx || nrows < 0 || max_groups < 1 || max_groups > SDQH_MAX_LOOKUP_GROUPS || !out_ngroups) return fail(ctx, SDQH_ERR_INVALID, "xgroupby: bad arguments");
+    if (!ctx->compile_only) (void)hipSetDevice(ctx->device);
+    XInfo x;
+    if (int rc = analyse(ctx, nrows, prog, SDQH_TUPLE_MAX_VALUES, true, true, &x)) return rc;
+    hipFunction_t fn;
+    if (int rc = specialise(ctx, generate(x, SINK_GROUP, x.direct), &fn)) return rc;
+    call_begin(ctx);
+    // result block in ctx->result_dev: gkeys[LG_SLOTS] | acc[LG_SLOTS][4] | cnt[LG_SLOTS] | flags
+    char* rd = static_cast<char*>(ctx->result_dev);
+    unsigned long long* r_keys = reinterpret_cast<unsigned long long*>(rd);
+    double* r_acc = reinterpret_cast<double*>(rd + LG_SLOTS * 8);
+    int64_t* r_cnt = reinterpret_cast<int64_t*>(rd + LG_SLOTS * 40);
+    int* r_flags = reinterpret_cast<int*>(rd + LG_SLOTS * 48);
+    const size_t rbytes = LG_SLOTS * 48 + 8;
+    static_assert(LG_SLOTS * 48 + 8 <= RESULT_BYTES, "result block too small");
+    XArgs a;
+    if (int rc = fill_xargs(ctx, x, &a, r_flags, 1, 0)) return rc;
+    const Geometry g = geometry(ctx, nrows, x.direct, 16);
+    const size_t nslots = (size_t)g.grid * LG_SLOTS;
+    char* blob = static_cast<char*>(pool_alloc(ctx, nslots * 40 + 256));
+    if (!blob) return fail(ctx, SDQH_ERR_NOMEM, "xgroupby: out of device memory");
+    double* pacc = reinterpret_cast<double*>(blob);
+    int64_t* pcnt = reinterpret_cast<int64_t*>(blob + nslots * 32);
+    { void* ptr[2] = {r_keys, r_flags}; size_t bytes[2] = {LG_SLOTS * 8, 8}; unsigned char byte[2] = {0xFF, 0}; fill_regions(ctx, ptr, bytes, byte, 2); }
+    XGroup<1>::Args sa{r_keys, pacc, pcnt, r_flags};
+    int rc = launch(ctx, fn, "x_groupby", a, sa, nrows, g);
+    if (!rc) {
+        launch_groupby_merge_lg(ctx, r_keys, pacc, pcnt, (int)g.grid, r_acc, r_cnt);
+        call_end(ctx);
+        hipError_t e = hipMemcpyAsync(ctx->result_host, rd, rbytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e));
+        if (!rc) rc = sync_stream(ctx);
+    }
+    pool_free(ctx, blob);
+    if (rc) return rc;
+    const char* h = static_cast<const char*>(ctx->result_host);
+    const int flags = *reinterpret_cast<const int*>(h + LG_SLOTS * 48);
+    if (flags & 2) return fail(ctx, SDQH_ERR_UNSUPPORTED, "xgroupby: negative group key");
+    const unsigned long long* hk = reinterpret_cast<const unsigned long long*>(h);
+    const double* ha = reinterpret_cast<const double*>(h + LG_SLOTS * 8);
+    const int64_t* hc = reinterpret_cast<const int64_t*>(h + LG_SLOTS * 40);
+    std::vector<int> order;
+    for (int s = 0; s < LG_SLOTS; ++s) if (hk[s] != EMPTY_GROUP && hc[s] > 0) order.push_back(s);
+    std::sort(order.begin(), order.end(), [&](int p, int q) { return hk[p] < hk[q]; });
+    const int ng = (int)order.size();
+    if ((flags & 1) || ng > max_groups) { *out_ngroups = std::max(ng, max_groups + 1); return fail(ctx, SDQH_ERR_OVERFLOW, "xgroupby: more groups than max_groups"); }
+    for (int i = 0; i < ng; ++i) {
+        const int s = order[(size_t)i];
+        if (out_keys) out_keys[i] = (int64_t)hk[s];
+        if (out_values) for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) out_values[i * SDQH_TUPLE_MAX_VALUES + k] = k < prog->nvals ? ha[s * 4 + k] : 0.0;
+        if (out_counts) out_counts[i] = hc[s];
+    }
+    *out_ngroups = ng;
+    return SDQH_OK;
+}
+
+int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t key_lo, int64_t key_hi, int accumulate, sdqh_table** out) {
+    if (!ctx || nrows < 0 || !out) return fail(ctx, SDQH_ERR_INVALID, "xbuild: bad arguments");
+    if (nrows >= 0xFFFFFFFEll) return fail(ctx, SDQH_ERR_UNSUPPORTED, "xbuild: build side limited to 2^32-2 rows per GPU");
+    if (!ctx->compile_only) (void)hipSetDevice(ctx->device);
+    XInfo x;
+    if (int rc = analyse(ctx, nrows, prog, SDQH_MAX_PAYLOAD, true, false, &x)) return rc;
+    hipFunction_t fn;
+    if (int rc = specialise(ctx, generate(x, SINK_STAGE, false), &fn)) {
+        if (!ctx->compile_only || ctx->err.find("kernel specialised") == std::string::npos) return rc;
+        sdqh_table* dummy = new sdqh_table();                 // compile-only: a table later programs can name (never dereferenced)
+        dummy->npay = prog->nvals; dummy->accumulate = accumulate != 0; dummy->stage.acc_stride = 4;
+        *out = dummy;
+        return SDQH_OK;
+    }
+    const bool bounded = key_lo <= key_hi && key_lo > INT64_MIN / 2 && key_hi < INT64_MAX / 2;
+    bool want_bm = false;
+    if (bounded && ctx->opt_direct_index) {
+        const uint64_t range = (uint64_t)(key_hi - key_lo) + 1;
+        want_bm = range <= (1ull << 31) && range <= 64ull * (uint64_t)std::max<int64_t>(nrows, 1024);
+    }
+    sdqh_table* tb = new sdqh_table();
+    tb->npay = prog->nvals; tb->accumulate = accumulate != 0; tb->nrows_build = nrows;
+    call_begin(ctx);
+    int rc = stage_setup_computed(ctx, tb, nrows, prog->nvals, X_LB);
+    uint64_t capmax = 1024;
+    while (capmax < 2 * (uint64_t)std::max<int64_t>(nrows, 1)) capmax <<= 1;
+    tb->capmax = capmax;
+    int32_t* flags = nullptr;
+    if (!rc) {
+        tb->hdr = static_cast<TableHeader*>(tb_alloc(ctx, tb, sizeof(TableHeader)));
+        flags = static_cast<int32_t*>(tb_alloc(ctx, tb, 64));
+        if (want_bm) { tb->nwords = ((uint64_t)(key_hi - key_lo) + 32) / 32; tb->bm = static_cast<uint32_t*>(tb_alloc(ctx, tb, tb->nwords * 4 + 64)); }
+        if (!tb->hdr || !flags || (tb->nwords && !tb->bm)) rc = fail(ctx, SDQH_ERR_NOMEM, "xbuild: out of device memory");
+    }
+    if (!rc) {
+        tb->dev.hdr = tb->hdr; tb->dev.shits = tb->stage.shits; tb->dev.sacc = tb->stage.sacc; tb->dev.acc_stride = tb->stage.acc_stride;
+        tb->dev.bm = tb->bm; tb->dev.bm_lo = key_lo; tb->dev.bm_hi = key_hi; tb->dev.bitmap_only = 0; tb->dev.bm_shift = 0;
+        for (int p = 0; p < prog->nvals; ++p) tb->dev.pay[p] = tb->stage.pay[p];
+        tb->stage.bm = tb->bm; tb->stage.bm_lo = key_lo; tb->stage.bm_hi = key_hi; tb->stage.hdr = tb->hdr; tb->stage.bm_shift = 0;
+        void* ptr[4]; size_t bytes[4]; unsigned char byte[4]; int n = 0;
+        ptr[n] = tb->hdr; bytes[n] = sizeof(TableHeader); byte[n++] = 0;
+        ptr[n] = flags; bytes[n] = 8; byte[n++] = 0;
+        if (tb->bm) { ptr[n] = tb->bm; bytes[n] = tb->nwords * 4; byte[n++] = 0; }
+        { void* rp = nullptr; size_t rb = 0; prefill_direct_refs(ctx, tb, &rp, &rb); if (rp) { ptr[n] = rp; bytes[n] = rb; byte[n++] = 0xFF; } }
+        fill_regions(ctx, ptr, bytes, byte, n);
+        XArgs a;
+        rc = fill_xargs(ctx, x, &a, flags, bounded ? key_lo : 1, bounded ? key_hi : 0);
+        if (!rc) {
+            // the segments were cut by stage_setup_computed: the kernel's geometry must be the stage's
+            Geometry g{(unsigned)((tb->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE)), tb->stage.seg_rows, tb->stage.nseg};
+            XStage<1>::Args sa{tb->stage};
+            rc = launch(ctx, fn, "x_build", a, sa, nrows, g);
+        }
+        call_end(ctx);
+        int f = 0;
+        if (!rc) rc = read_flags(ctx, flags, &f);
+        if (!rc && (f & 2)) rc = fail(ctx, SDQH_ERR_UNSUPPORTED, "xbuild: a key outside the given bounds / a key part outside [0, 2^32)");
+    }
+    if (rc) { tb_release(ctx, tb); delete tb; return rc; }
+    *out = tb;
+    return SDQH_OK;
+}
+
+int sdqh_xkey_set(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t key_lo, int64_t key_hi, sdqh_table** out) {
+    if (!ctx || nrows < 0 || !out) return fail(ctx, SDQH_ERR_INVALID, "xkey_set: bad arguments");
+    if (!ctx->compile_only) (void)hipSetDevice(ctx->device);
+    XInfo x;
+    if (int rc = analyse(ctx, nrows, prog, 0, true, false, &x)) return rc;
+    if (key_lo > key_hi) { if (nrows > 0) return fail(ctx, SDQH_ERR_UNSUPPORTED, "xkey_set: needs the key's bounds"); key_lo = key_hi = 0; }
+    if (key_lo <= INT64_MIN / 2 || key_hi >= INT64_MAX / 2 || (uint64_t)(key_hi - key_lo) + 1 > (1ull << 31))
+        return fail(ctx, SDQH_ERR_UNSUPPORTED, "xkey_set: key range too wide for a bitmap");
+    hipFunction_t fn;
+    if (int rc = specialise(ctx, generate(x, SINK_KEYSET, false), &fn)) {
+        if (!ctx->compile_only || ctx->err.find("kernel specialised") == std::string::npos) return rc;
+        sdqh_table* dummy = new sdqh_table();
+        dummy->bitmap_only = true; dummy->index_built = true;
+        *out = dummy;
+        return SDQH_OK;
+    }
+    call_begin(ctx);
+    sdqh_table* tb = new sdqh_table();
+    tb->bitmap_only = true; tb->index_built = true; tb->nrows_build = nrows;
+    tb->nwords = ((uint64_t)(key_hi - key_lo) + 32) / 32;
+    tb->bm = static_cast<uint32_t*>(tb_alloc(ctx, tb, tb->nwords * 4 + 64));
+    tb->hdr = static_cast<TableHeader*>(tb_alloc(ctx, tb, sizeof(TableHeader) + 64));
+    if (!tb->bm || !tb->hdr) { tb_release(ctx, tb); delete tb; return fail(ctx, SDQH_ERR_NOMEM, "xkey_set: out of device memory"); }
+    int32_t* flags = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(tb->hdr) + sizeof(TableHeader));
+    tb->dev.bm = tb->bm; tb->dev.bm_lo = key_lo; tb->dev.bm_hi = key_hi; tb->dev.bitmap_only = 1; tb->dev.hdr = tb->hdr;
+    { void* ptr[2] = {tb->bm, tb->hdr}; size_t bytes[2] = {(size_t)((tb->nwords * 4 + 15) & ~(uint64_t)15), sizeof(TableHeader) + 16}; unsigned char byte[2] = {0, 0}; fill_regions(ctx, ptr, bytes, byte, 2); }
+    XArgs a;
+    int rc = fill_xargs(ctx, x, &a, flags, key_lo, key_hi);
+    if (!rc && nrows > 0) {
+        const Geometry g = geometry(ctx, nrows, false, 16);
+        XKeySet<1>::Args sa{tb->bm};
+        rc = launch(ctx, fn, "x_key_set", a, sa, nrows, g);
+    }
+    call_end(ctx);
+    int f = 0;
+    if (!rc) rc = read_flags(ctx, flags, &f);
+    if (!rc && (f & 2)) rc = fail(ctx, SDQH_ERR_UNSUPPORTED, "xkey_set: a key outside the given bounds");
+    if (rc) { tb_release(ctx, tb); delete tb; return rc; }
+    *out = tb;
+    return SDQH_OK;
+}
+
+int sdqh_xprobe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int lookup_op, sdqh_table* table) {
+    if (!ctx || nrows < 0 || !table) return fail(ctx, SDQH_ERR_INVALID, "xprobe_aggregate: bad arguments");
+    if (!table->accumulate || table->bitmap_only) return fail(ctx, SDQH_ERR_INVALID, "xprobe_aggregate: table was built without accumulators");
+    if (!ctx->compile_only) (void)hipSetDevice(ctx->device);
+    XInfo x;
+    if (int rc = analyse(ctx, nrows, prog, SDQH_TUPLE_MAX_VALUES, false, true, &x)) return rc;
+    bool gated = false;
+    for (int g = 0; g < prog->ngates; ++g) gated = gated || prog->gates[g] == lookup_op;
+    if (lookup_op < 0 || lookup_op >= prog->nops || prog->ops[lookup_op].code != SDQH_X_LOOKUP || prog->ops[lookup_op].table != table || !gated)
+        return fail(ctx, SDQH_ERR_INVALID, "xprobe_aggregate: lookup_op must be a gate that looks `table` up");
+    if (prog->nvals > table->stage.acc_stride) return fail(ctx, SDQH_ERR_INVALID, "xprobe_aggregate: the table's entries have room for fewer values than the program sums");
+    x.probe_op = lookup_op;
+    hipFunction_t fn;
+    if (int rc = specialise(ctx, generate(x, SINK_ENTRY, false), &fn)) return rc;
+    table->compact_valid = false;
+    table->nv = prog->nvals;
+    call_begin(ctx);
+    XArgs a;
+    int32_t* d_flags = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->result_dev) + 1024);
+    if (int rc = fill_xargs(ctx, x, &a, d_flags, 1, 0)) return rc;
+    const Geometry g = geometry(ctx, nrows, false, 24);
+    XEntry<1>::Args sa{table->dev};
+    int rc = launch(ctx, fn, "x_probe_agg", a, sa, nrows, g);
+    call_end(ctx);
+    return rc;
+}
+
+int sdqh_table_columns(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_hits, sdqh_column** out_cols, int64_t* out_rows) {
+    if (!ctx || !ctable || !out_cols || !out_rows || ctable->bitmap_only) return fail(ctx, SDQH_ERR_INVALID, "table_columns: bad arguments");
+    // O(entries), like K-F itself: compacted through the K-F path, then made resident again
+    int64_t n = 0;
+    if (int rc = sdqh_table_compact(ctx, ctable, min_hits, 0, nullptr, nullptr, nullptr, nullptr, &n)) return rc;
+    const int npay = ctable->npay, ncols = 1 + npay + SDQH_TUPLE_MAX_VALUES + 1;
+    const size_t cap = (size_t)std::max<int64_t>(n, 1);
+    std::vector<int64_t> keys(cap), pay(cap * (size_t)std::max(npay, 1)), hits(cap);
+    std::vector<double> vals(cap * SDQH_TUPLE_MAX_VALUES, 0.0);
+    int64_t got = 0;
+    if (int rc = sdqh_table_compact(ctx, ctable, min_hits, (int64_t)cap, keys.data(), npay ? pay.data() : nullptr, ctable->accumulate ? vals.data() : nullptr, hits.data(), &got)) return rc;
+    for (int c = 0; c < ncols; ++c) {
+        const bool is_acc = c > npay && c <= npay + SDQH_TUPLE_MAX_VALUES;
+        const void* src = c == 0 ? (const void*)keys.data() : c <= npay ? (const void*)(pay.data() + (size_t)(c - 1) * cap)
+                          : is_acc ? (const void*)(vals.data() + (size_t)(c - 1 - npay) * cap) : (const void*)hits.data();
+        if (int rc = sdqh_column_upload(ctx, src, got, is_acc ? SDQH_F64 : SDQH_I64, 0, &out_cols[c])) return rc;
+    }
+    *out_rows = got;
+    return SDQH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,358 @@
+// sdqh_xkernels.hpp — kernel skeletons that are specialised at run time on a row program (ABI 4).
+//
+// The hand-written part of a specialised kernel lives here: how rows are streamed (16-byte loads
+// of the columns the cheap leading conditions need, every load of a step issued before the first
+// use), how survivors are queued in LDS in row order and drained 64 at a time, one row per lane,
+// so that the dependent chain of a row (lookups -> payload gathers -> arithmetic) runs converged,
+// and the five things a loop can do with a row that passed (the "sinks" below).  What the front
+// end's expression compiler contributes is one small struct P generated from the program
+// (sdqh_x.hip, codegen): the loads of the streamed columns, the conditions on them, and the
+// evaluation of everything else for one row.  hiprtc compiles   skeleton<P, sink>   for gfx950;
+// nothing here is ever compiled by hipcc into the library.
+//
+// Reference loop shapes (edin-dal/sdqlpy, src/sdqlpy/lib/sdql_ir_cpp_generator_par.py): K-A 258-291
+// (XSum), K-C 402-440 (XGroup: small domain; XEntry: the group is the matched entry), K-B 331-369
+// (XStage, XKeySet), with lookups 85-96 and conditions / values of any shape (712-795).
+#pragma once
+#include "sdqh_kernels.hpp"
+
+namespace sdqh {
+
+constexpr int X_MAX_CONST = 32;
+template <bool B> struct XBool { static constexpr bool value = B; };
+
+// by-value argument of every specialised kernel: the bindings of the program (columns, tables,
+// constants).  The program's structure is in the code; these can change from run to run.
+struct XArgs {
+    const void* col[SDQH_MAX_XCOLS];
+    int32_t width[SDQH_MAX_XCOLS];              // STR columns: code units per row
+    DevTable tab[SDQH_MAX_XTABLES];
+    int64_t ci[X_MAX_CONST];
+    double cf[X_MAX_CONST];
+    uint32_t spool[SDQH_MAX_XSTR];              // string constants, back to back
+    int32_t* flags;                             // |= 2: a key outside its bounds / an unpackable key part
+    int64_t key_lo, key_hi;                     // bounds the key must respect (key_lo > key_hi: none)
+};
+
+template <int NV> struct XOut {
+    int64_t key;
+    int64_t val[NV > 0 ? NV : 1];               // raw 8 bytes each (f64 values as bits)
+    uint32_t ent;                               // stage row of the entry matched by the designated lookup (XEntry)
+    bool bad;                                   // the key could not be formed (PACK2 part out of range)
+};
+
+__device__ __forceinline__ double x_f(int64_t bits) { return __longlong_as_double(bits); }
+__device__ __forceinline__ int64_t x_bits(double v) { return __double_as_longlong(v); }
+
+// VarChar::firstIndex (reference include/varchar.h:91-97), str.find on the text up to the first NUL
+__device__ __forceinline__ int64_t x_first_index(const uint32_t* __restrict__ s, int width, const uint32_t* val, int len) {
+    int n = 0;
+    while (n < width && s[n] != 0u) ++n;
+    for (int st = 0; st + len <= n; ++st) {
+        if (len && s[st] != val[0]) continue;
+        int k = len ? 1 : 0;
+        while (k < len && s[st + k] == val[k]) ++k;
+        if (k == len) return st;
+    }
+    return -1;
+}
+__device__ __forceinline__ int64_t x_char(const uint32_t* __restrict__ s, int width, int pos) {
+    if (pos >= width) return 0;
+    for (int k = 0; k < pos; ++k) if (s[k] == 0u) return 0;
+    return (int64_t)s[pos];
+}
+// one lookup: stage row of the matched entry, NO_ROW on a miss (key sets: 0 on a hit)
+__device__ __forceinline__ uint32_t x_lookup(const DevTable& t, int64_t key, bool bad) {
+    if (bad) return NO_ROW;
+    const uint64_t mask = (table_is_direct(t) || t.bitmap_only) ? 0 : t.hdr->cap_mask;
+    const int64_t pos = table_find(t, key, mask);
+    if (pos < 0) return NO_ROW;
+    return t.bitmap_only ? 0u : table_ref(t, pos);
+}
+__device__ __forceinline__ int64_t x_field(const DevTable& t, int f, uint32_t ent) { return ent == NO_ROW ? 0 : t.pay[f][ent]; }
+__device__ __forceinline__ double x_acc(const DevTable& t, int k, uint32_t ent) {
+    if (ent == NO_ROW) return 0.0;
+    if (t.alias) ent = t.alias[ent];
+    return k < t.acc_stride ? t.sacc[(size_t)ent * t.acc_stride + k] : 0.0;
+}
+__device__ __forceinline__ int64_t x_hits(const DevTable& t, uint32_t ent) {
+    if (ent == NO_ROW) return 0;
+    if (t.alias) ent = t.alias[ent];
+    return (int64_t)t.shits[ent];
+}
+
+// =================================================================================================
+// Sinks.  consume() is called by all 64 lanes of a wave together (pass = false for lanes without a
+// row), so a sink may use ballots and wave scans.
+// =================================================================================================
+
+// ---- K-A: sums of NV doubles + a row count; one partial per workgroup, folded by k_sum_partials ----
+template <int NV> struct XSum {
+    struct Args { double* partial; };
+    double acc[NV > 0 ? NV : 1];
+    int64_t cnt;
+    __device__ __forceinline__ void init(const Args&) { for (int k = 0; k < (NV > 0 ? NV : 1); ++k) acc[k] = 0.0; cnt = 0; }
+    __device__ __forceinline__ void consume(const XArgs&, const Args&, bool pass, int64_t, const XOut<NV>& o) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) acc[k] += pass ? x_f(o.val[k]) : 0.0;
+        cnt += pass ? 1 : 0;
+    }
+    __device__ __forceinline__ void finish(const XArgs&, const Args& s) {           // workgroup-converged
+        __shared__ double s_acc[TPB / WAVE][4];
+        __shared__ int64_t s_cnt[TPB / WAVE];
+        const int w = threadIdx.x / WAVE;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) { double v = wave_sum(acc[k]); if (lane_id() == 0) s_acc[w][k] = v; }
+        { int64_t c = wave_sum_i64(cnt); if (lane_id() == 0) s_cnt[w] = c; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double* out = s.partial + (size_t)blockIdx.x * 5;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { double v = 0.0; if (k < NV) for (int i = 0; i < TPB / WAVE; ++i) v += s_acc[i][k]; out[k] = v; }
+            int64_t c = 0;
+            for (int i = 0; i < TPB / WAVE; ++i) c += s_cnt[i];
+            reinterpret_cast<int64_t*>(out)[4] = c;
+        }
+    }
+};
+
+// ---- K-C over a small group domain: LDS hash table per workgroup, f64 LDS atomics, slot-major partials ----
+template <int NV> struct XGroup {
+    struct Args { unsigned long long* gkeys; double* pacc; int64_t* pcnt; int* flags; };
+    static constexpr int NVS = NV > 0 ? NV : 1;
+    unsigned long long* s_keys; double (*s_acc)[NVS]; unsigned long long* s_cnt; int* s_map; int* s_flags;
+    __device__ __forceinline__ void init(const Args&) {
+        __shared__ unsigned long long sk[LG_SLOTS];
+        __shared__ double sa[LG_SLOTS][NVS];
+        __shared__ unsigned long long sc[LG_SLOTS];
+        __shared__ int sm[LG_SLOTS];
+        __shared__ int sf[1];
+        s_keys = sk; s_acc = sa; s_cnt = sc; s_map = sm; s_flags = sf;
+        for (int i = threadIdx.x; i < LG_SLOTS; i += TPB) { sk[i] = EMPTY_GROUP; sc[i] = 0; for (int k = 0; k < NVS; ++k) sa[i][k] = 0.0; sm[i] = -1; }
+        if (threadIdx.x == 0) sf[0] = 0;
+        __syncthreads();
+    }
+    __device__ __forceinline__ void consume(const XArgs&, const Args&, bool pass, int64_t, const XOut<NV>& o) {
+        if (!pass) return;
+        if (o.bad || o.key < 0) { atomicOr(&s_flags[0], 2); return; }
+        const int slot = group_slot(s_keys, (unsigned long long)o.key, false);
+        if (slot < 0) { atomicOr(&s_flags[0], 1); return; }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) atomicAdd(&s_acc[slot][k], x_f(o.val[k]));
+        atomicAdd(&s_cnt[slot], 1ull);
+    }
+    __device__ __forceinline__ void finish(const XArgs&, const Args& s) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < LG_SLOTS; i += TPB) {
+            if (s_keys[i] != EMPTY_GROUP && s_cnt[i] > 0) {
+                const int gs = group_slot(s.gkeys, s_keys[i], true);
+                if (gs < 0) atomicOr(&s_flags[0], 1); else s_map[gs] = i;
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < LG_SLOTS; i += TPB) {
+            const int l = s_map[i];
+            const size_t e = (size_t)i * gridDim.x + blockIdx.x;
+            s.pcnt[e] = l >= 0 ? (int64_t)s_cnt[l] : 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s.pacc[e * 4 + k] = (l >= 0 && k < NV) ? s_acc[l][k < NVS ? k : 0] : 0.0;
+        }
+        if (threadIdx.x == 0 && s_flags[0]) atomicOr(s.flags, s_flags[0]);
+    }
+};
+
+// ---- K-B: survivors compacted in row order into the wave segment's slice of the stage ----
+template <int NV> struct XStage {
+    struct Args { DevStage st; };
+    int64_t out;
+    __device__ __forceinline__ void init(const Args&) { out = 0; }
+    __device__ __forceinline__ void begin_segment(int64_t begin) { out = begin; }
+    __device__ __forceinline__ void consume(const XArgs& a, const Args& s, bool pass, int64_t, const XOut<NV>& o) {
+        bool keep = pass;
+        if (pass && (o.bad || (a.key_lo <= a.key_hi && (o.key < a.key_lo || o.key > a.key_hi)))) { atomicOr(a.flags, 2); keep = false; }
+        const uint64_t b = __ballot(keep);
+        if (keep) {
+            int64_t pay[MAX_STAGE_COLS] = {0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < NV; ++k) pay[k] = o.val[k];
+            stage_store<-1>(s.st, out + __popcll(b & lanemask_lt()), o.key, pay);
+        }
+        out += __popcll(b);
+    }
+    __device__ __forceinline__ void end_segment(const Args& s, int seg, int64_t begin) { if (lane_id() == 0) s.st.seg_count[seg] = (uint32_t)(out - begin); }
+    __device__ __forceinline__ void finish(const XArgs&, const Args&) {}
+};
+
+// ---- membership-only K-B: OR the bits of the passing keys ----
+template <int NV> struct XKeySet {
+    struct Args { uint32_t* bm; };
+    __device__ __forceinline__ void init(const Args&) {}
+    __device__ __forceinline__ void consume(const XArgs& a, const Args& s, bool pass, int64_t, const XOut<NV>& o) {
+        if (!pass) return;
+        if (o.bad || o.key < a.key_lo || o.key > a.key_hi) { atomicOr(a.flags, 2); return; }
+        const uint64_t off = (uint64_t)(o.key - a.key_lo);
+        atomicOr(&s.bm[off >> 5], 1u << (off & 31));
+    }
+    __device__ __forceinline__ void finish(const XArgs&, const Args&) {}
+};
+
+// ---- K-C where the group is the matched entry: segmented wave scan over runs of equal entries, then
+//      one native f64 atomic per run and value (rows of one group sit in adjacent lanes when the probe side is
+//      clustered on the key) ----
+template <int NV> struct XEntry {
+    struct Args { DevTable tb; };
+    __device__ __forceinline__ void init(const Args&) {}
+    __device__ __forceinline__ void consume(const XArgs&, const Args& s, bool pass, int64_t, const XOut<NV>& o) {
+        const int lane = lane_id();
+        uint32_t idx = NO_ROW, cnt = 0;
+        double v[NV > 0 ? NV : 1];
+#pragma unroll
+        for (int k = 0; k < (NV > 0 ? NV : 1); ++k) v[k] = 0.0;
+        if (pass && o.ent != NO_ROW) {
+            idx = o.ent; cnt = 1;
+            if (s.tb.alias) idx = s.tb.alias[idx];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[k] = x_f(o.val[k]);
+        }
+        if (!__ballot(idx != NO_ROW)) return;
+        const uint32_t prev = __shfl_up(idx, 1, WAVE);
+        uint32_t head = (lane == 0 || prev != idx) ? 1u : 0u;
+        const uint32_t next_head = __shfl_down(head, 1, WAVE);
+        const bool tail = idx != NO_ROW && (lane == WAVE - 1 || next_head != 0u);
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const uint32_t oc = __shfl_up(cnt, off, WAVE), oh = __shfl_up(head, off, WAVE);
+            double ov[NV > 0 ? NV : 1];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) ov[k] = __shfl_up(v[k], off, WAVE);
+            if (lane >= off && !head) {
+                cnt += oc;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) v[k] += ov[k];
+                head |= oh;
+            }
+        }
+        if (tail) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) atomicAdd(&s.tb.sacc[(size_t)idx * s.tb.acc_stride + k], v[k]);
+            atomicAdd(&s.tb.shits[idx], cnt);
+        }
+    }
+    __device__ __forceinline__ void finish(const XArgs&, const Args&) {}
+};
+
+// =================================================================================================
+// DIRECT: every column the program reads is streamed with 16-byte loads and the whole program is
+// evaluated in registers on both rows of a lane's pair — for programs without lookups / string
+// operations feeding order-free sinks (XSum, XGroup).  Persistent grid over 1024-row tiles, as k_scan_sum.
+// P::NS streamed columns; P::sload<TAIL>(a, r, nrows, regs); P::eval_regs<H>(a, regs, r, out) -> pass.
+// =================================================================================================
+template <class P, template <int> class SinkT>
+__device__ __forceinline__ void x_direct(const XArgs& a, const typename SinkT<P::NV>::Args& sa, int64_t nrows) {
+    using Sink = SinkT<P::NV>;
+    constexpr int NS = P::NS > 0 ? P::NS : 1;
+    Sink sink;
+    sink.init(sa);
+    auto tile = [&](int64_t base, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        Pair<int64_t> s[UNROLL][NS];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+            P::template sload<TAIL>(a, base + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD, nrows, s[u]);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t r = base + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
+            XOut<P::NV> o0, o1;
+            bool p0 = TAIL ? (r < nrows) : true, p1 = TAIL ? (r + 1 < nrows) : true;
+            p0 = p0 && P::template eval_regs<0>(a, s[u], r, o0);
+            p1 = p1 && P::template eval_regs<1>(a, s[u], r + 1, o1);
+            sink.consume(a, sa, p0, r, o0);
+            sink.consume(a, sa, p1, r + 1, o1);
+        }
+    };
+    const int64_t full = nrows / TILE_ROWS;
+    for (int64_t t0 = (int64_t)blockIdx.x * SDQH_TILE_CHUNK; t0 < full; t0 += (int64_t)gridDim.x * SDQH_TILE_CHUNK)
+        for (int64_t t = t0; t < t0 + SDQH_TILE_CHUNK && t < full; ++t) tile(t * TILE_ROWS, XBool<false>{});
+    if (full * TILE_ROWS < nrows && blockIdx.x == (unsigned)(full % gridDim.x)) tile(full * TILE_ROWS, XBool<true>{});
+    sink.finish(a, sa);
+}
+
+// =================================================================================================
+// QUEUE: one wave per contiguous row segment.  Per step of X_LB batches of 128 rows: the columns of
+// the cheap leading conditions are streamed with 16-byte loads (all in flight before the first is
+// tested), survivors are appended to the wave's LDS queue in row order, and whenever 64 are queued
+// the FRONT 64 are evaluated, one row per lane, converged.  P::sload / P::stest(a, regs, p0, p1) for
+// the streamed part (NS may be 0: every row is queued), P::eval_row(a, r, out) -> pass for the rest.
+// =================================================================================================
+constexpr int X_LB = 4;
+constexpr int XQ_CAP = 192;
+
+template <class P, template <int> class SinkT, bool SEGMENTED>
+__device__ __forceinline__ void x_queue(const XArgs& a, const typename SinkT<P::NV>::Args& sa, int64_t nrows, int64_t seg_rows, int nseg) {
+    using Sink = SinkT<P::NV>;
+    constexpr int NS = P::NS > 0 ? P::NS : 1;
+    __shared__ int64_t s_row[TPB / WAVE][XQ_CAP];
+    Sink sink;
+    sink.init(sa);
+    const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
+    const bool live = seg < nseg;
+    int64_t* q_row = s_row[threadIdx.x / WAVE];
+    const int lane = lane_id();
+    const uint64_t lt = lanemask_lt();
+    constexpr int64_t BATCH_ROWS = WAVE * ROWS_PER_LOAD;
+    const int64_t begin = (int64_t)seg * seg_rows;
+    int64_t end = begin + seg_rows; if (end > nrows) end = nrows;
+    if constexpr (SEGMENTED) sink.begin_segment(begin);
+    int qn = 0;
+    auto drain = [&](int count) {                                      // rows q_row[0..count), one per lane, in row order
+        XOut<P::NV> o;
+        bool pass = false; int64_t r = 0;
+        if (lane < count) { r = q_row[lane]; pass = P::eval_row(a, r, o); }
+        sink.consume(a, sa, pass, r, o);
+    };
+    auto enqueue = [&](int64_t r, bool p0, bool p1) {
+        const uint64_t b0 = __ballot(p0), b1 = __ballot(p1);
+        if (b0 | b1) {
+            const int at = qn + __popcll(b0 & lt) + __popcll(b1 & lt);
+            if (p0) q_row[at] = r;
+            if (p1) q_row[at + (p0 ? 1 : 0)] = r + 1;
+            qn += __popcll(b0) + __popcll(b1);
+            while (qn >= WAVE) {                                       // drain the FRONT 64, shift the rest down
+                drain(WAVE);
+                const int left = qn - WAVE;
+                int64_t a0 = 0, a1 = 0;
+                if (lane < left) a0 = q_row[WAVE + lane];
+                if (lane + WAVE < left) a1 = q_row[2 * WAVE + lane];
+                if (lane < left) q_row[lane] = a0;
+                if (lane + WAVE < left) q_row[WAVE + lane] = a1;
+                qn = left;
+            }
+        }
+    };
+    if (live) {
+        for (int64_t b = begin; b < end; b += BATCH_ROWS * X_LB) {
+            if (b + BATCH_ROWS * X_LB <= end) {
+                Pair<int64_t> s[X_LB][NS];
+                int64_t rr[X_LB];
+#pragma unroll
+                for (int j = 0; j < X_LB; ++j) { rr[j] = b + (int64_t)j * BATCH_ROWS + (int64_t)lane * ROWS_PER_LOAD; P::template sload<false>(a, rr[j], nrows, s[j]); }
+#pragma unroll
+                for (int j = 0; j < X_LB; ++j) { bool p0 = true, p1 = true; P::stest(a, s[j], p0, p1); enqueue(rr[j], p0, p1); }
+            } else {
+                for (int64_t bb = b; bb < end; bb += BATCH_ROWS) {
+                    const int64_t r = bb + (int64_t)lane * ROWS_PER_LOAD;
+                    Pair<int64_t> s1[NS];
+                    P::template sload<true>(a, r, end, s1);
+                    bool p0 = r < end, p1 = r + 1 < end;
+                    P::stest(a, s1, p0, p1);
+                    enqueue(r, p0, p1);
+                }
+            }
+        }
+        if (qn > 0) drain(qn);
+        if constexpr (SEGMENTED) sink.end_segment(sa, seg, begin);
+    }
+    sink.finish(a, sa);
+}
+
+}  // namespace sdqh

@@ -104,6 +104,34 @@ class And(Expr):
         return "And(%s)" % ", ".join(map(repr, self.terms))
 
 
+class Or(Expr):
+    def __init__(self, terms):
+        self.terms = terms
+
+    def __repr__(self):
+        return "Or(%s)" % ", ".join(map(repr, self.terms))
+
+
+class Not(Expr):
+    def __init__(self, term):
+        self.term = term
+
+    def __repr__(self):
+        return "Not(%r)" % (self.term,)
+
+
+class IfElse(Expr):
+    """`a if cond else b` inside a value (reference IfExpr, lib/sdql_ir.py:294-303)."""
+    def __init__(self, cond, then, other):
+        self.cond, self.then, self.other = cond, then, other
+
+    def shape(self, names):
+        raise NotImplementedError           # not in the closed tuple vocabulary: goes through a row program
+
+    def __repr__(self):
+        return "(%r if %r else %r)" % (self.then, self.cond, self.other)
+
+
 class Contains(Expr):
     """`tbl[key] != None` — the lookup must hit."""
     def __init__(self, lookup):
@@ -206,6 +234,26 @@ class SelectKeysOp:
 
     def __repr__(self):
         return "SelectKeysOp(%s <- keys of %s where %r)" % (self.out, self.source, self.conds)
+
+
+class HostDictOp:
+    """A sum over a RESULT dictionary that is more than a reshape: conditions on its values, lookups
+    into other results, arithmetic on its fields (reference K-F, generator 520-568, with lookups 85-96).
+    O(groups), not O(rows): evaluated on the host over the materialised dictionaries."""
+    def __init__(self, out, source, conds, key, val, unique, lineno):
+        self.out, self.source, self.conds, self.key, self.val, self.unique, self.lineno = out, source, conds, key, val, unique, lineno
+
+    def __repr__(self):
+        return "HostDictOp(%s <- %s: if %r: {%r: %r})" % (self.out, self.source, self.conds, self.key, self.val)
+
+
+class WrapScalarOp:
+    """`sr_dict({record({"name": scalar}): True})`: a scalar result presented as a one-row result set (Q19)."""
+    def __init__(self, out, fields, lineno):
+        self.out, self.fields, self.lineno = out, fields, lineno          # [(name, Expr over earlier scalars)]
+
+    def __repr__(self):
+        return "WrapScalarOp(%s = %r)" % (self.out, self.fields)
 
 
 class FinalizeOp:
@@ -330,6 +378,24 @@ class _Lowerer:
             for v in node.values:
                 terms += self._terms(self.expr(v, env))
             return And(terms)
+        if isinstance(node, ast.BoolOp) and isinstance(node.op, ast.Or):           # reference prints `or` as `+` on 0/1 values (sdql_compiler.py:277-292)
+            terms = []
+            for v in node.values:
+                t = self.expr(v, env)
+                if not self._is_bool(t):
+                    self.fail(v, "operand of `or` is not a condition")
+                terms += t.terms if isinstance(t, Or) else [t]
+            return Or(terms)
+        if isinstance(node, ast.UnaryOp) and isinstance(node.op, ast.Not):
+            t = self.expr(node.operand, env)
+            if not self._is_bool(t):
+                self.fail(node, "operand of `not` is not a condition")
+            return t.term if isinstance(t, Not) else Not(t)
+        if isinstance(node, ast.IfExp):                                          # a conditional VALUE: `x if c else y`
+            cond = self.expr(node.test, env)
+            if not self._is_bool(cond):
+                self.fail(node.test, "condition is not a comparison")
+            return IfElse(cond, self.expr(node.body, env), self.expr(node.orelse, env))
         if isinstance(node, ast.Compare) and len(node.ops) > 1:
             # chained comparison `a <= x < b`: the conjunction of its links (Python evaluates it that way)
             terms, left = [], node.left
@@ -348,10 +414,13 @@ class _Lowerer:
             if type(op) not in _CMPOPS:
                 self.fail(node, "unsupported comparison")
             sym = _CMPOPS[type(op)]
-            if isinstance(left, Lookup) and isinstance(right, Const) and right.value is None and sym == "!=":
-                return Contains(left)
-            if isinstance(left, PayloadField) and left.field is None and isinstance(right, Const) and right.value is None and sym == "!=":
-                return Contains(left.lookup)
+            if isinstance(right, Const) and right.value is None and sym in ("!=", "=="):      # `tbl[k] != None` / `== None`
+                lk = left if isinstance(left, Lookup) else (left.lookup if isinstance(left, PayloadField) and left.field is None else None)
+                if lk is None:
+                    self.fail(node, "only a dictionary lookup can be compared with None")
+                return Contains(lk) if sym == "!=" else Not(Contains(lk))
+            if isinstance(right, Const) and isinstance(right.value, bool) and self._is_bool(left) and sym in ("==", "!="):   # `(cond) == False`
+                return left if (right.value is True) == (sym == "==") else Not(left)
             if isinstance(left, Const) and not isinstance(right, Const):          # constant on the right: `5 <= x` is `x >= 5`
                 left, right, sym = right, left, {"<": ">", "<=": ">=", ">": "<", ">=": "<=", "==": "==", "!=": "!="}[sym]
             return Cmp(sym, left, right)
@@ -377,6 +446,16 @@ class _Lowerer:
                     if isinstance(col, Col) and isinstance(needle, Const) and isinstance(needle.value, str):
                         return StrIn(needle.value, col, "prefix" if fn.id == "startsWith" else "suffix")
                     self.fail(node, "%s needs (<string column>, \"text\")" % fn.id)
+                if fn.id == "firstIndex" and len(node.args) == 2:                       # ref sdql_lib.py:344-345, include/varchar.h:91-97
+                    col, needle = self.expr(node.args[0], env), self.expr(node.args[1], env)
+                    if isinstance(col, Col) and isinstance(needle, Const) and isinstance(needle.value, str):
+                        return Call("firstIndex", [col, needle])
+                    self.fail(node, "firstIndex needs (<string column>, \"text\")")
+                if fn.id == "substr" and len(node.args) == 3:                           # ref sdql_lib.py:362-363: source[start:end + 1]
+                    col, a, b = (self.expr(x, env) for x in node.args)
+                    if isinstance(col, Col) and all(isinstance(x, Const) and isinstance(x.value, int) for x in (a, b)) and 0 <= a.value <= b.value:
+                        return Call("substr", [col, a, b])
+                    self.fail(node, "substr needs (<string column>, start, end) with literal bounds")
             if isinstance(fn, ast.Attribute) and fn.attr == "concat" and len(node.args) == 1:
                 a, b = self.expr(fn.value, env), self.expr(node.args[0], env)
                 if isinstance(a, WholeKey) and isinstance(b, WholeKey) and a.which == 0 and b.which == 1:
@@ -397,7 +476,7 @@ class _Lowerer:
 
     @staticmethod
     def _is_bool(e):
-        return isinstance(e, (Cmp, And, Contains, StrIn)) or (isinstance(e, Const) and isinstance(e.value, bool))
+        return isinstance(e, (Cmp, And, Or, Not, Contains, StrIn)) or (isinstance(e, Const) and isinstance(e.value, bool))
 
     @staticmethod
     def _terms(e):
@@ -423,6 +502,12 @@ class _Lowerer:
             conds += self._terms(cond)
             node = node.body
         return node, conds
+
+    @staticmethod
+    def _is_dict_valued(node):
+        while isinstance(node, ast.IfExp):
+            node = node.body
+        return isinstance(node, ast.Dict)
 
     def dict_body(self, op, node, env):
         """{K: V}"""
@@ -506,6 +591,13 @@ class _Lowerer:
                 op.probe = Lookup(call.args[0].id, Col(colname))
                 (pv, pk), body = self.lambda_of(call.args[3], 2)
                 env = {pv: ("payload", op.probe), pk: ("row",)}
+                if not self._is_dict_valued(body):
+                    # a scalar body: `joinProbe(idx, col, f, lambda e, r: x if c else 0.0)` sums x over the matching rows (Q17, Q19)
+                    body, conds = self.split_ifelse(body, env)
+                    op.conds += conds
+                    op.kind, op.val = "scalar", self.expr(body, env)
+                    self.scalars.add(out)
+                    return op
                 body, conds = self.split_ifelse(body, env)
                 op.conds += conds
                 self.dict_body(op, body, env)
@@ -522,22 +614,22 @@ class _Lowerer:
             tmp = ScanOp(out, table, ln)
             body, kv_conds = self.split_ifelse(body, env)
             if not isinstance(body, ast.Dict):
-                self.fail(call, "a sum over a result dictionary must build {unique(record): True}")
+                self.fail(call, "a sum over a result dictionary must build a dictionary {key: value}")
             self.dict_body(tmp, body, env)
+            set_valued = isinstance(tmp.val, Const) and tmp.val.value is True
             if kv_conds:
-                ok = tmp.unique and isinstance(tmp.val, Const) and tmp.val.value is True and isinstance(tmp.key, WholeKey) and tmp.key.which == 0 \
-                    and all(isinstance(c, Cmp) and isinstance(c.left, WholeKey) and c.left.which == 1 and isinstance(c.right, Const)
+                simple = tmp.unique and set_valued and isinstance(tmp.key, WholeKey) and tmp.key.which == 0 and tmp.key.field is None \
+                    and all(isinstance(c, Cmp) and isinstance(c.left, WholeKey) and c.left.which == 1 and c.left.field is None and isinstance(c.right, Const)
                             and isinstance(c.right.value, (int, float)) and c.op in ("<", "<=", ">", ">=", "==") for c in kv_conds)
-                if not ok:
-                    self.fail(call, "a conditional sum over a result dictionary must be {unique(p[0]): True} if p[1] <op> <number> else None")
-                return SelectKeysOp(out, table, kv_conds, ln)
-            if not (tmp.unique and isinstance(tmp.val, Const) and tmp.val.value is True):
-                self.fail(call, "only the finalising reshape {unique(<record>): True} is supported over a result dictionary")
-            if isinstance(tmp.key, ConcatKV):
-                return FinalizeOp(out, table, None, ln)
-            if isinstance(tmp.key, RecordCons) and all(isinstance(e, WholeKey) for _, e in tmp.key.fields):
-                return FinalizeOp(out, table, [(n, e.which) if e.field is None else (n, e.which, e.field) for n, e in tmp.key.fields], ln)
-            self.fail(call, "unsupported finalising record")
+                if simple:
+                    return SelectKeysOp(out, table, kv_conds, ln)
+            elif set_valued:                                        # the reference's own queries write the reshape without unique() at times (Q16)
+                if isinstance(tmp.key, ConcatKV):
+                    return FinalizeOp(out, table, None, ln)
+                if isinstance(tmp.key, RecordCons) and all(isinstance(e, WholeKey) for _, e in tmp.key.fields):
+                    return FinalizeOp(out, table, [(n, e.which) if e.field is None else (n, e.which, e.field) for n, e in tmp.key.fields], ln)
+            # anything else over a result dictionary (HAVING with lookups, arithmetic on its fields): host-side, O(groups)
+            return HostDictOp(out, table, kv_conds, tmp.key, tmp.val, tmp.unique, ln)
         self.fail(call, "'%s' is neither a table parameter nor an earlier result" % table)
 
     @staticmethod
@@ -599,6 +691,15 @@ class _Lowerer:
                     ops.append(self.lower_call(name, val))
                     self.dicts.add(name)
                     continue
+                if isinstance(val, ast.Call) and isinstance(val.func, ast.Name) and val.func.id == "sr_dict" and len(val.args) == 1 \
+                        and isinstance(val.args[0], ast.Dict) and len(val.args[0].keys) == 1:
+                    k, v = val.args[0].keys[0], val.args[0].values[0]
+                    rec = self.expr(k, {})
+                    if isinstance(rec, RecordCons) and all(self._only_scalars(e) for _, e in rec.fields) and isinstance(v, ast.Constant) and v.value is True:
+                        ops.append(WrapScalarOp(name, rec.fields, st.lineno))
+                        self.dicts.add(name)
+                        continue
+                    self.fail(st, "sr_dict({...}) is only supported as a one-row result {record({name: <scalar>}): True}")
                 if isinstance(val, (ast.BinOp, ast.Name, ast.Attribute)):
                     e = self.expr(val, {})
                     if self._only_scalars(e):

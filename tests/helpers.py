@@ -149,6 +149,183 @@ def hash_layout_case(ctx, nb, npr):
         c.free()
 
 
+def xprogram_cases(ctx, n=20000, seed=3):
+    """Row programs (ABI 4) through every sdqh_x* entry point against numpy: boolean structure (or /
+    not / select), mixed int / float arithmetic, string operations, lookups with payload fields and
+    accumulators, composite keys, bounded (direct index) and unbounded (open addressing) builds,
+    key sets and anti-joins, probe-aggregate into the matched entry.  Returns the number of checks."""
+    from sdqlpy_amd import abi as A
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 1000, n).astype(np.int64)
+    b = rng.integers(19920101, 19981231, n).astype(np.int64)
+    f = np.round(rng.random(n) * 100.0, 2)
+    g = np.round(rng.random(n), 2)
+    words = np.array(["special requests", "no requests here", "special", "xx special yy requests", "", "requests special", "13-555", "31-777", "29-1"], "<U24")
+    txt = words[rng.integers(0, len(words), n)]
+    ca, cb, cf, cg, ct = ctx.upload(a), ctx.upload(b), ctx.upload(f), ctx.upload(g), ctx.upload(txt)
+    checks = 0
+
+    def near(x, y, what):
+        assert abs(x - y) <= 1e-9 * max(abs(y), 1.0), (what, x, y)
+
+    # 1. K-A, register path: (a < 10 or a >= 500) and not (b < 19950101); values f*(1-g) and select(a even, f, 0.0) + a as double
+    P = A.Program()
+    xa = P.op(A.X_COL, A.T_I64, col=ca); xb = P.op(A.X_COL, A.T_I64, col=cb); xf = P.op(A.X_COL, A.T_F64, col=cf); xg = P.op(A.X_COL, A.T_F64, col=cg)
+    c10 = P.op(A.X_CONST, A.T_I64, imm_i=10); c500 = P.op(A.X_CONST, A.T_I64, imm_i=500); cd = P.op(A.X_CONST, A.T_I64, imm_i=19950101)
+    lt = P.op(A.X_LT, A.T_BOOL, a=xa, b=c10); ge = P.op(A.X_GE, A.T_BOOL, a=xa, b=c500); o1 = P.op(A.X_OR, A.T_BOOL, a=lt, b=ge)
+    early = P.op(A.X_LT, A.T_BOOL, a=xb, b=cd); late = P.op(A.X_NOT, A.T_BOOL, a=early)
+    one = P.op(A.X_CONST, A.T_F64, imm_f=1.0); omg = P.op(A.X_SUB, A.T_F64, a=one, b=xg); v1 = P.op(A.X_MUL, A.T_F64, a=xf, b=omg)
+    two = P.op(A.X_CONST, A.T_I64, imm_i=2); half = P.op(A.X_YEAR, A.T_I64, a=xa)          # a / 10000 == 0: exercises YEAR
+    twice = P.op(A.X_MUL, A.T_I64, a=P.op(A.X_SUB, A.T_I64, a=xa, b=P.op(A.X_MUL, A.T_I64, a=P.op(A.X_ADD, A.T_I64, a=half, b=xa), b=two)), b=two)   # (a - 2a) * 2 = -2a
+    neg = P.op(A.X_NEG, A.T_I64, a=twice)                                                  # 2a
+    even_t = P.op(A.X_EQ, A.T_BOOL, a=P.op(A.X_SUB, A.T_I64, a=neg, b=P.op(A.X_MUL, A.T_I64, a=two, b=xa)), b=P.op(A.X_CONST, A.T_I64, imm_i=0))   # always true
+    zero = P.op(A.X_CONST, A.T_F64, imm_f=0.0)
+    big = P.op(A.X_GT, A.T_BOOL, a=xf, b=P.op(A.X_CONST, A.T_F64, imm_f=50.0))
+    v2 = P.op(A.X_ADD, A.T_F64, a=P.op(A.X_SELECT, A.T_F64, a=P.op(A.X_AND, A.T_BOOL, a=big, b=even_t), b=xf, c=zero), b=P.op(A.X_I2F, A.T_F64, a=xa))
+    P.gates = [o1, late]; P.vals = [v1, v2]
+    m = ((a < 10) | (a >= 500)) & ~(b < 19950101)
+    vals, cnt = ctx.xscan_sum(n, P)
+    assert cnt == int(m.sum())
+    near(vals[0], float((f[m] * (1.0 - g[m])).sum()), "x1 v1"); near(vals[1], float((np.where(f[m] > 50.0, f[m], 0.0) + a[m]).sum()), "x1 v2")
+    checks += 3
+
+    # 2. K-A with string operations (queue path): firstIndex / contains / prefix / char
+    P = A.Program()
+    i_sp = P.op(A.X_STRIDX, A.T_I64, col=ct, text="special"); i_rq = P.op(A.X_STRIDX, A.T_I64, col=ct, text="requests")
+    has = P.op(A.X_NE, A.T_BOOL, a=i_sp, b=P.op(A.X_CONST, A.T_I64, imm_i=-1))
+    after = P.op(A.X_GT, A.T_BOOL, a=i_rq, b=P.op(A.X_ADD, A.T_I64, a=i_sp, b=P.op(A.X_CONST, A.T_I64, imm_i=6)))
+    both = P.op(A.X_AND, A.T_BOOL, a=has, b=after)
+    p13 = P.op(A.X_STR, A.T_BOOL, col=ct, aux=A.STR_PREFIX, text="13"); p31 = P.op(A.X_STR, A.T_BOOL, col=ct, aux=A.STR_PREFIX, text="31")
+    sfx = P.op(A.X_STR, A.T_BOOL, col=ct, aux=A.STR_SUFFIX, text="here"); eq = P.op(A.X_STR, A.T_BOOL, col=ct, aux=A.STR_EQ, text="special")
+    anyp = P.op(A.X_OR, A.T_BOOL, a=P.op(A.X_OR, A.T_BOOL, a=both, b=p13), b=P.op(A.X_OR, A.T_BOOL, a=P.op(A.X_OR, A.T_BOOL, a=p31, b=sfx), b=eq))
+    ch = P.op(A.X_CHAR, A.T_I64, col=ct, aux=1)
+    P.gates = [anyp]; P.vals = [P.op(A.X_I2F, A.T_F64, a=ch), P.op(A.X_COL, A.T_F64, col=cf)]
+    sp, rq = np.char.find(txt, "special"), np.char.find(txt, "requests")
+    m = ((sp != -1) & (rq > sp + 6)) | np.char.startswith(txt, "13") | np.char.startswith(txt, "31") | np.char.endswith(txt, "here") | (txt == "special")
+    second = np.array([ord(t[1]) if len(t) > 1 else 0 for t in txt.tolist()], np.float64)
+    vals, cnt = ctx.xscan_sum(n, P)
+    assert cnt == int(m.sum()) and cnt > 0
+    near(vals[0], float(second[m].sum()), "x2 char"); near(vals[1], float(f[m].sum()), "x2 f")
+    checks += 3
+
+    # 3. K-C small, register path: key = (a % ... ) via year of b and a < 500
+    P = A.Program()
+    xa = P.op(A.X_COL, A.T_I64, col=ca); xb = P.op(A.X_COL, A.T_I64, col=cb); xf = P.op(A.X_COL, A.T_F64, col=cf)
+    yr = P.op(A.X_SUB, A.T_I64, a=P.op(A.X_YEAR, A.T_I64, a=xb), b=P.op(A.X_CONST, A.T_I64, imm_i=1992))
+    lowa = P.op(A.X_SELECT, A.T_I64, a=P.op(A.X_LT, A.T_BOOL, a=xa, b=P.op(A.X_CONST, A.T_I64, imm_i=500)), b=P.op(A.X_CONST, A.T_I64, imm_i=1), c=P.op(A.X_CONST, A.T_I64, imm_i=0))
+    P.key = P.op(A.X_ADD, A.T_I64, a=P.op(A.X_MUL, A.T_I64, a=yr, b=P.op(A.X_CONST, A.T_I64, imm_i=2)), b=lowa)
+    P.gates = [P.op(A.X_GE, A.T_BOOL, a=xf, b=P.op(A.X_CONST, A.T_F64, imm_f=5.0))]; P.vals = [xf, P.op(A.X_I2F, A.T_F64, a=xa)]
+    keys, vals, cnts = ctx.xgroupby(n, P)
+    m = f >= 5.0
+    want_key = (b // 10000 - 1992) * 2 + (a < 500)
+    for k, v, c in zip(keys.tolist(), vals, cnts.tolist()):
+        sel = m & (want_key == k)
+        assert c == int(sel.sum()) and c > 0
+        near(v[0], float(f[sel].sum()), "x3 f"); near(v[1], float(a[sel].sum()), "x3 a")
+    assert sorted(keys.tolist()) == sorted(np.unique(want_key[m]).tolist())
+    checks += 1 + 3 * len(keys)
+
+    # 4. K-B: bounded key (direct index) and composite key (open addressing), first row wins; lookups read fields
+    bk = rng.permutation(4 * n)[:n].astype(np.int64) + 7          # unique keys in [7, 4n+7)
+    bk[100:120] = bk[:20]                                          # duplicates: the first row owns the entry
+    pay = rng.integers(0, 1 << 40, n).astype(np.int64)
+    cbk, cpay = ctx.upload(bk), ctx.upload(pay)
+    P = A.Program()
+    k = P.op(A.X_COL, A.T_I64, col=cbk); pv = P.op(A.X_COL, A.T_I64, col=cpay); fv = P.op(A.X_COL, A.T_F64, col=cf)
+    P.key = k; P.gates = [P.op(A.X_GE, A.T_BOOL, a=pv, b=P.op(A.X_CONST, A.T_I64, imm_i=1 << 38))]; P.vals = [pv, fv]
+    t_direct = ctx.xbuild(n, P, 7, 4 * n + 7, accumulate=True)
+    keep = pay >= (1 << 38)
+    first = {}
+    for i in np.nonzero(keep)[0].tolist():
+        first.setdefault(int(bk[i]), i)
+    assert t_direct.size() == len(first)
+    P2 = A.Program()
+    hi = P2.op(A.X_COL, A.T_I64, col=cbk); lo = P2.op(A.X_COL, A.T_I64, col=ca)
+    P2.key = P2.op(A.X_PACK2, A.T_I64, a=hi, b=lo); P2.vals = [P2.op(A.X_COL, A.T_F64, col=cg)]
+    t_hash = ctx.xbuild(n, P2)
+    firstc = {}
+    for i in range(n):
+        firstc.setdefault((int(bk[i]), int(a[i])), i)
+    assert t_hash.size() == len(firstc)
+    probe = rng.integers(0, 4 * n + 20, n).astype(np.int64)
+    probe[: n // 2] = bk[rng.integers(0, n, n // 2)]
+    cpr = ctx.upload(probe)
+    P3 = A.Program()
+    pk = P3.op(A.X_COL, A.T_I64, col=cpr); lk = P3.op(A.X_LOOKUP, A.T_BOOL, a=pk, table=t_direct)
+    ck = P3.op(A.X_PACK2, A.T_I64, a=P3.op(A.X_COL, A.T_I64, col=cbk), b=P3.op(A.X_COL, A.T_I64, col=ca)); lk2 = P3.op(A.X_LOOKUP, A.T_BOOL, a=ck, table=t_hash)
+    P3.gates = [lk, lk2]
+    P3.vals = [P3.op(A.X_FIELD, A.T_F64, a=lk, aux=1), P3.op(A.X_I2F, A.T_F64, a=P3.op(A.X_FIELD, A.T_I64, a=lk, aux=0)), P3.op(A.X_FIELD, A.T_F64, a=lk2, aux=0)]
+    vals, cnt = ctx.xscan_sum(n, P3)
+    hit = np.array([int(x) in first for x in probe.tolist()])
+    src = np.array([first.get(int(x), 0) for x in probe.tolist()])
+    srcc = np.array([firstc[(int(x), int(y))] for x, y in zip(bk.tolist(), a.tolist())])
+    assert cnt == int(hit.sum()) and cnt > n // 8
+    near(vals[0], float(f[src[hit]].sum()), "x4 field f"); near(vals[1], float(pay[src[hit]].astype(np.float64).sum()), "x4 field i"); near(vals[2], float(g[srcc[hit]].sum()), "x4 composite")
+    checks += 6
+
+    # 5. key set + anti-join: rows whose key is NOT in the set
+    P = A.Program()
+    k = P.op(A.X_COL, A.T_I64, col=cbk); P.key = k
+    P.gates = [P.op(A.X_STR, A.T_BOOL, col=ct, aux=A.STR_CONTAINS, text="requests")]
+    t_set = ctx.xkey_set(n, P, 0, 4 * n + 7)
+    members = set(bk[np.char.find(txt, "requests") >= 0].tolist())
+    assert t_set.size() == len(members)
+    P = A.Program()
+    lk = P.op(A.X_LOOKUP, A.T_BOOL, a=P.op(A.X_COL, A.T_I64, col=cpr), table=t_set)
+    P.gates = [P.op(A.X_NOT, A.T_BOOL, a=lk)]; P.vals = [P.op(A.X_COL, A.T_F64, col=cf)]
+    vals, cnt = ctx.xscan_sum(n, P)
+    notin = np.array([int(x) not in members for x in probe.tolist()])
+    assert cnt == int(notin.sum()); near(vals[0], float(f[notin].sum()), "x5 anti")
+    checks += 3
+
+    # 6. K-C into the matched entry, then its accumulators / row count read by a later loop
+    P = A.Program()
+    lk = P.op(A.X_LOOKUP, A.T_BOOL, a=P.op(A.X_COL, A.T_I64, col=cpr), table=t_direct)
+    P.gates = [lk, P.op(A.X_LT, A.T_BOOL, a=P.op(A.X_COL, A.T_F64, col=cg), b=P.op(A.X_CONST, A.T_F64, imm_f=0.75))]
+    P.vals = [P.op(A.X_COL, A.T_F64, col=cf), P.op(A.X_CONST, A.T_F64, imm_f=1.0)]
+    ctx.xprobe_aggregate(n, P, lk, t_direct)
+    sel = hit & (g < 0.75)
+    acc_sum, acc_cnt = {}, {}
+    for x, v in zip(probe[sel].tolist(), f[sel].tolist()):
+        acc_sum[x] = acc_sum.get(x, 0.0) + v; acc_cnt[x] = acc_cnt.get(x, 0) + 1
+    kcol, pcols, acols, hcol, nent = ctx.table_columns(t_direct, 1)
+    assert nent == len(acc_sum)
+    got_k, got_s, got_c, got_h = kcol.download(), acols[0].download(), acols[1].download(), hcol.download()
+    for kk, ss, cc, hh in zip(got_k.tolist(), got_s.tolist(), got_c.tolist(), got_h.tolist()):
+        near(ss, acc_sum[kk], "x6 sum"); assert cc == hh == acc_cnt[kk]
+    P = A.Program()
+    lk = P.op(A.X_LOOKUP, A.T_BOOL, a=P.op(A.X_COL, A.T_I64, col=cbk), table=t_direct)
+    avg = P.op(A.X_DIV, A.T_F64, a=P.op(A.X_ACC, A.T_F64, a=lk, aux=0), b=P.op(A.X_I2F, A.T_F64, a=P.op(A.X_ACC, A.T_I64, a=lk, aux=-1)))
+    P.gates = [lk, P.op(A.X_GT, A.T_BOOL, a=P.op(A.X_ACC, A.T_I64, a=lk, aux=-1), b=P.op(A.X_CONST, A.T_I64, imm_i=0)),
+               P.op(A.X_GT, A.T_BOOL, a=P.op(A.X_COL, A.T_F64, col=cf), b=avg)]
+    P.vals = [P.op(A.X_COL, A.T_F64, col=cf)]
+    vals, cnt = ctx.xscan_sum(n, P)
+    want = [(fi) for ki, fi in zip(bk.tolist(), f.tolist()) if ki in acc_sum and fi > acc_sum[ki] / acc_cnt[ki]]
+    assert cnt == len(want); near(vals[0], float(sum(want)), "x6 acc read")
+    checks += 3 + nent
+
+    # 7. K-C small with lookups (queue path): group by a field of the matched entry's payload (mod 7) and the year
+    P = A.Program()
+    lk = P.op(A.X_LOOKUP, A.T_BOOL, a=P.op(A.X_COL, A.T_I64, col=cpr), table=t_direct)
+    fld = P.op(A.X_FIELD, A.T_I64, a=lk, aux=0)
+    bucket = P.op(A.X_SUB, A.T_I64, a=fld, b=P.op(A.X_MUL, A.T_I64, a=P.op(A.X_YEAR, A.T_I64, a=P.op(A.X_MUL, A.T_I64, a=fld, b=P.op(A.X_CONST, A.T_I64, imm_i=10000 // 8 * 0 + 1))), b=P.op(A.X_CONST, A.T_I64, imm_i=10000)))   # fld % 10000
+    low = P.op(A.X_LT, A.T_BOOL, a=bucket, b=P.op(A.X_CONST, A.T_I64, imm_i=5000))
+    yr = P.op(A.X_SUB, A.T_I64, a=P.op(A.X_YEAR, A.T_I64, a=P.op(A.X_COL, A.T_I64, col=cb)), b=P.op(A.X_CONST, A.T_I64, imm_i=1992))
+    P.key = P.op(A.X_ADD, A.T_I64, a=P.op(A.X_MUL, A.T_I64, a=yr, b=P.op(A.X_CONST, A.T_I64, imm_i=2)),
+                 b=P.op(A.X_SELECT, A.T_I64, a=low, b=P.op(A.X_CONST, A.T_I64, imm_i=1), c=P.op(A.X_CONST, A.T_I64, imm_i=0)))
+    P.gates = [lk]; P.vals = [P.op(A.X_COL, A.T_F64, col=cg)]
+    keys, vals, cnts = ctx.xgroupby(n, P)
+    wk = (b // 10000 - 1992) * 2 + ((pay[src] % 10000) < 5000)
+    for kk, vv, cc in zip(keys.tolist(), vals, cnts.tolist()):
+        s_ = hit & (wk == kk)
+        assert cc == int(s_.sum()); near(vv[0], float(g[s_].sum()), "x7")
+    assert sorted(keys.tolist()) == sorted(np.unique(wk[hit]).tolist())
+    checks += 1 + 2 * len(keys)
+    for t in (t_direct, t_hash, t_set):
+        t.free()
+    return checks
+
+
 def compaction_block_case(ctx):
     """Build + probe-aggregate one table three times and finalise it (a) into a device-writable
     block that fits, (b) into one that overflows and is retried, (c) into pageable arrays; the three

@@ -155,3 +155,53 @@ def test_hash_layout_case_on_the_cpu_implementation(oracle_lib):
         helpers.hash_layout_case(ctx, 50_000, 200_000)
     finally:
         ctx.close()
+
+
+def test_row_programs_on_the_cpu_implementation(oracle_lib):
+    """ABI 4 (row programs) through every sdqh_x* entry point of the CPU implementation against numpy:
+    pins the interpreter the GPU specialisations are compared with (tests/test_hip_parity.py runs the same cases)."""
+    import helpers
+    for threads in (1, 3):
+        ctx = oracle_lib.context(threads=threads)
+        try:
+            assert helpers.xprogram_cases(ctx) > 40
+        finally:
+            ctx.close()
+
+
+def test_specialised_kernels_compile_without_a_gpu(hip_lib):
+    """Build check of the run-time specialisation path on a host without a GPU: a compile-only
+    context (sdqh_create(-1)) generates and compiles the kernel of each sink for gfx950 and stops."""
+    from sdqlpy_amd import abi as A
+    ctx = hip_lib.context(device=-1)
+    try:
+        n = 1000
+        ci, cf, cs = ctx.wrap(0x10000, n, A.I64), ctx.wrap(0x20000, n, A.F64), ctx.wrap(0x30000, n, A.STR, 12)
+        P = A.Program()
+        x = P.op(A.X_COL, A.T_I64, col=ci); v = P.op(A.X_COL, A.T_F64, col=cf)
+        P.gates = [P.op(A.X_OR, A.T_BOOL, a=P.op(A.X_LT, A.T_BOOL, a=x, b=P.op(A.X_CONST, A.T_I64, imm_i=5)), b=P.op(A.X_STR, A.T_BOOL, col=cs, aux=A.STR_PREFIX, text="ab"))]
+        P.vals = [v]
+
+        def compiled(call):
+            with pytest.raises(A.SdqhError) as exc:
+                call()
+            assert exc.value.code == A.ERR_DEVICE and "kernel specialised" in str(exc.value), str(exc.value)[:2000]
+        compiled(lambda: ctx.xscan_sum(n, P))
+        P.key = x
+        compiled(lambda: ctx.xgroupby(n, P))
+        table = ctx.xbuild(n, P, 0, 100, accumulate=True)                     # placeholder table: later programs can name it
+        Q = A.Program()
+        lk = Q.op(A.X_LOOKUP, A.T_BOOL, a=Q.op(A.X_COL, A.T_I64, col=ci), table=table)
+        Q.gates = [lk]; Q.vals = [Q.op(A.X_ADD, A.T_F64, a=Q.op(A.X_FIELD, A.T_F64, a=lk, aux=0), b=Q.op(A.X_ACC, A.T_F64, a=lk, aux=0))]
+        compiled(lambda: ctx.xprobe_aggregate(n, Q, lk, table))
+        Q.key, Q.vals = Q.op(A.X_COL, A.T_I64, col=ci), []
+        assert ctx.xkey_set(n, Q, 0, 100).handle is not None
+        assert sum(ctx.jit_stats()) >= 5
+        # a malformed program is refused before anything is generated
+        bad = A.Program()
+        bad.vals = [bad.op(A.X_ADD, A.T_F64, a=bad.op(A.X_COL, A.T_I64, col=ci), b=bad.op(A.X_COL, A.T_F64, col=cf))]
+        with pytest.raises(A.SdqhError) as exc:
+            ctx.xscan_sum(n, bad)
+        assert exc.value.code == A.ERR_INVALID
+    finally:
+        ctx.close()

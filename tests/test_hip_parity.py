@@ -218,6 +218,19 @@ def test_full_size_q9_and_topk_sf10(hip_engine):
     hip_engine.clear()
 
 
+def test_row_programs_specialised_kernels(hip_engine):
+    """ABI 4: every sdqh_x* entry point — kernels specialised at run time (hiprtc) on the program —
+    against numpy, on the cases the CPU implementation is pinned with; at three sizes around the
+    queue / tile boundaries, and once more from the code-object cache."""
+    ctx = hip_engine.ctx
+    for n in (300, 20000, 70001):
+        assert helpers.xprogram_cases(ctx, n) > 40
+    before = ctx.jit_stats()
+    assert before[0] + before[1] > 0                    # something was specialised (compiled now, or loaded from the disk cache)
+    assert helpers.xprogram_cases(ctx, 4097, seed=9) > 40
+    assert ctx.jit_stats() == before                    # same program structures: nothing new to compile
+
+
 def test_hash_layout_at_scale(hip_engine):
     """The open-addressing layout (k_clear / k_insert / hash probes) at 12 M build keys: keys spread
     over 2^44 so no bitmap / direct index applies.  Join + aggregation against numpy."""

@@ -19,8 +19,8 @@ import os
 import numpy as np
 
 from . import abi, build
-from .frontend import (And, Bin, Call, Cmp, Col, Const, Contains, FinalizeOp, Lookup, PayloadField, RecordCons,
-                       ScalarExprOp, ScalarField, ScanOp, SelectKeysOp, StrIn, UnsupportedQuery)
+from .frontend import (And, Bin, Call, Cmp, Col, Const, Contains, FinalizeOp, HostDictOp, IfElse, Lookup, Not, Or, PayloadField, RecordCons,
+                       ScalarExprOp, ScalarField, ScanOp, SelectKeysOp, StrIn, UnsupportedQuery, WrapScalarOp)
 from .result import DictResult, ResultSet, decode_text
 
 # value-tuple vocabulary: canonical shape of the whole value record -> (ABI shape, index of the COUNT field or None)
@@ -204,7 +204,7 @@ class BuiltTable:
         self.val_fields = val_fields        # [(field name, "key" | payload index)]
         self.val_is_record = val_is_record
         self.payload_dtypes = row_arrays    # payload index -> numpy dtype
-        self.agg = None                     # set by a fused probe-aggregate: (key_fields, val_names, tuple shape)
+        self.agg = None                     # set by a fused probe-aggregate: (key_fields, val_names, count field index, key / value is a record, number of summed doubles)
         self.agg_spec = None
         self.decoders = {}                  # payload index -> string array (the payload holds row references into it)
         self.field_decoders = {}            # field name -> string array: several text fields of one source row share ONE
@@ -425,6 +425,17 @@ def _walk_lookups(e, found):
     elif isinstance(e, Call):
         for x in e.args:
             _walk_lookups(x, found)
+    elif isinstance(e, Cmp):
+        _walk_lookups(e.left, found); _walk_lookups(e.right, found)
+    elif isinstance(e, (And, Or)):
+        for x in e.terms:
+            _walk_lookups(x, found)
+    elif isinstance(e, Not):
+        _walk_lookups(e.term, found)
+    elif isinstance(e, Contains):
+        _walk_lookups(e.lookup, found)
+    elif isinstance(e, IfElse):
+        _walk_lookups(e.cond, found); _walk_lookups(e.then, found); _walk_lookups(e.other, found)
 
 
 def _link_key_sources(srcs, lookup_keys):
@@ -586,6 +597,7 @@ def _prepare_general(eng, op, htab, flt, contains_lookups, accumulate_into=()):
                         bt.slot_plain[j] = rng
             if len(key_srcs) == 2:
                 bt.key_parts = key_names
+                bt.key_part_decoders = [k.decode_info(op, env, lookups)[0] for k in key_srcs]
             bt.key_decoder = key_srcs[0].decode_info(op, env, lookups)[0] if len(key_srcs) == 1 else None
             return bt
         return run_build
@@ -749,7 +761,45 @@ def _eval_scalar_expr(e, env, lineno):
     raise UnsupportedQuery("line %d: unsupported scalar expression %r" % (lineno, e))
 
 
-def _prepare_scan(eng, op, htab, accumulate_into, member_only=False):
+def _prepare_scan(eng, op, htab, accumulate_into, member_only=False, as_table=False):
+    """closure(env) for one table loop: the tuned fixed-shape calls when the loop is one of their shapes,
+    a row program (xplan.py: a kernel specialised on the loop's own conditions and values) otherwise.
+    A fixed-shape closure can still refuse at run time (a group count beyond its kernels): the loop then
+    moves to its row program for good."""
+    from . import xplan
+    if as_table and op.kind == "dict" and not op.unique and not (op.probe is not None and xplan.groups_by_entry(op)):
+        # an aggregated dictionary that later loops look up has to be a table whatever its size: the small-domain
+        # group-by calls return their groups to the host
+        kf = op.key.fields if isinstance(op.key, RecordCons) else [(None, op.key)]
+        single_int = len(kf) == 1 and isinstance(kf[0][1], Col) and htab.cols.get(kf[0][1].name) is not None and htab.cols[kf[0][1].name].dtype == np.int64
+        if not single_int or op.probe is not None or any(not isinstance(c, Cmp) for c in op.conds):
+            return xplan.prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=True)
+    try:
+        fixed = _prepare_scan_fixed(eng, op, htab, accumulate_into, member_only, as_table)
+    except UnsupportedQuery as first:
+        try:
+            return xplan.prepare_scan(eng, op, htab, accumulate_into, member_only, as_table)
+        except UnsupportedQuery as second:
+            raise UnsupportedQuery("%s\n  (as a row program: %s)" % (first, second))
+    state = {"x": None}
+
+    def run(env):
+        if state["x"] is None:
+            try:
+                return fixed(env)
+            except UnsupportedQuery as first:
+                try:
+                    x = xplan.prepare_scan(eng, op, htab, accumulate_into, member_only, as_table)
+                    out = x(env)
+                except UnsupportedQuery as second:
+                    raise UnsupportedQuery("%s\n  (as a row program: %s)" % (first, second))
+                state["x"] = x
+                return out
+        return state["x"](env)
+    return run
+
+
+def _prepare_scan_fixed(eng, op, htab, accumulate_into, member_only=False, as_table=False):
     ctx = eng.ctx
     if op.kind == "scalar":
         return _prepare_scalar(eng, op, htab, op.conds, op.val)
@@ -817,14 +867,14 @@ def _prepare_scan(eng, op, htab, accumulate_into, member_only=False):
         gname = key_fields[0][1].name
         gcol = eng.column(htab.array(gname, op))
         glo, ghi = gcol.minmax() if n else (0, 0)
-        if ghi - glo + 1 > abi.MAX_SMALL_GROUPS:
+        if ghi - glo + 1 > abi.MAX_SMALL_GROUPS or as_table:
             hidden = op.out + "$groups"
             key_name = key_fields[0][0] or gname
 
             def run_groupby_key(env):
                 table = ctx.groupby_key(n, flt, gcol, tup)
                 bt = BuiltTable(table, key_name, key_is_record, [], val_is_record, [])
-                bt.agg = ([(key_name, "key")], vnames, count_idx, key_is_record, val_is_record, tup.shape)
+                bt.agg = ([(key_name, "key")], vnames, count_idx, key_is_record, val_is_record, abi.TUPLE_NVALUES[tup.shape])
                 env[hidden] = bt
                 return ("aggregated", hidden)
             return run_groupby_key
@@ -901,7 +951,7 @@ def _prepare_scan(eng, op, htab, accumulate_into, member_only=False):
                 ctx.table_share_groups(bt.table, *share)
                 bt.shared_groups = True
         ctx.hash_probe_aggregate(n, flt, bt.table, kcol, tup)
-        bt.agg = (bt.agg_spec, vnames, count_idx, key_is_record, val_is_record, tup.shape)
+        bt.agg = (bt.agg_spec, vnames, count_idx, key_is_record, val_is_record, abi.TUPLE_NVALUES[tup.shape])
         return ("aggregated", probe_name)
     return run_probe_aggregate
 
@@ -1030,11 +1080,10 @@ def _materialize(eng, value, env, hint_key=None, top=None):
         return value
     if isinstance(value, tuple) and value and value[0] == "aggregated":
         bt = env[value[1]]
-        out_key_fields, vnames, count_idx, key_is_record, val_is_record, shape = bt.agg
+        out_key_fields, vnames, count_idx, key_is_record, val_is_record, nv = bt.agg
         entry_is_group = any(src == "key" for _, src in out_key_fields) or bt.shared_groups
         spec = _device_sort_spec(bt, out_key_fields, vnames, count_idx, top[1]) if top is not None and entry_is_group else None
         keys, payload, values, hits, ordered = _fetch_entries(eng, bt.table, 1, hint_key, top, spec, want_hits=count_idx is not None or (spec is not None and any(s[0] == abi.SORT_HITS for s in spec)))
-        nv = abi.TUPLE_NVALUES[shape]
         values = [values[j] for j in range(nv)]
         fields_of = bt.agg_fields
         def decode(fname, src, sel=None):
@@ -1117,7 +1166,8 @@ def _materialize(eng, value, env, hint_key=None, top=None):
         vf = [(fname, keys if src == "key" else _decode_column(payload[src], value.decoder_of(fname, src), value.payload_dtypes[src]))
               for fname, src in value.val_fields]
         if value.key_parts is not None:
-            kf = [(value.key_parts[0], keys >> 32), (value.key_parts[1], keys & 0xFFFFFFFF)]
+            decs = getattr(value, "key_part_decoders", None) or [None, None]
+            kf = [(value.key_parts[0], _decode_column(keys >> 32, decs[0], np.int64)), (value.key_parts[1], _decode_column(keys & 0xFFFFFFFF, decs[1], np.int64))]
         else:
             kf = [(value.key_name, _decode_column(keys, value.key_decoder, np.int64))]
         d = DictResult(kf, vf, value.key_is_record, value.val_is_record)
@@ -1171,6 +1221,29 @@ def _finalize(eng, op, env, top=None):
     return rs
 
 
+def _looked_up(plan):
+    """Names of the results that a table loop looks up (`d[key]`, joinProbe index)."""
+    found = []
+    for op in plan.ops:
+        if isinstance(op, ScanOp):
+            if op.probe is not None:
+                _walk_lookups(op.probe, found)
+            for e in list(op.conds) + [op.key, op.val] + [x for _, x, _ in (op.fields or [])] + [c for _, _, fc in (op.fields or []) for c in fc]:
+                if e is not None:
+                    _walk_lookups(e, found)
+    return {lk.dict_name for lk in found}
+
+
+def _host_dict(eng, op, env, is_result):
+    """A sum over a result dictionary with conditions / lookups / arithmetic (frontend.HostDictOp)."""
+    from . import xplan
+    out = xplan.run_host_dict(eng, op, env, lambda v: _materialize(eng, v, env, hint_key=(id(op), id(v) if isinstance(v, BuiltTable) else 0)))
+    top = env.get("__top__") if is_result else None
+    if top is not None and isinstance(out, ResultSet):
+        out = out.top(top[0], top[1])
+    return out
+
+
 def _membership_only(plan):
     """Names of unique builds that are only used as `tbl[key] != None` / joinProbe index with no
     payload access, and are not the plan's result."""
@@ -1191,9 +1264,13 @@ def _membership_only(plan):
             walk(e.lookup.key)
         elif isinstance(e, (Bin, Cmp)):
             walk(e.left); walk(e.right)
-        elif isinstance(e, And):
+        elif isinstance(e, (And, Or)):
             for t in e.terms:
-                walk(t)
+                walk(t, as_cond)
+        elif isinstance(e, Not):
+            walk(e.term, as_cond)
+        elif isinstance(e, IfElse):
+            walk(e.cond, True); walk(e.then); walk(e.other)
         elif isinstance(e, Call):
             for a in e.args:
                 walk(a)
@@ -1215,6 +1292,13 @@ def _membership_only(plan):
                     walk(c, as_cond=True)
         elif isinstance(op, FinalizeOp):
             used_for_payload.add(op.source)
+        elif isinstance(op, HostDictOp):                        # evaluated on the materialised dictionaries: all of them need entries
+            used_for_payload.add(op.source)
+            found = []
+            for e in list(op.conds) + [op.key, op.val]:
+                _walk_lookups(e, found)
+            for lk in found:
+                used_for_payload.add(lk.dict_name)
     return {b for b in builds if b not in used_for_payload and b != plan.result}
 
 
@@ -1224,8 +1308,8 @@ def _select_keys(eng, op, env):
     if not (isinstance(src, tuple) and src and src[0] == "aggregated"):
         raise UnsupportedQuery("line %d: '%s' is not an aggregated dictionary" % (op.lineno, op.source))
     bt = env[src[1]]
-    _, vnames, count_idx, _, val_is_record, shape = bt.agg
-    if val_is_record or count_idx is not None or abi.TUPLE_NVALUES[shape] != 1:
+    _, vnames, count_idx, _, val_is_record, nv = bt.agg
+    if val_is_record or count_idx is not None or nv != 1:
         raise UnsupportedQuery("line %d: HAVING needs a dictionary with one summed value" % op.lineno)
     lo, hi = -np.inf, np.inf
     for c in op.conds:
@@ -1254,16 +1338,18 @@ class PreparedPlan:
         self.generation = eng.generation
         tables = {p: HostTable(p, a) for p, a in zip(plan.params, args)}
         # tables that a later probe-aggregate folds its group-by into must carry accumulators
+        from . import xplan
         accumulate_into = {op.probe.dict_name for op in plan.ops
                            if isinstance(op, ScanOp) and op.kind == "dict" and not op.unique and op.probe is not None
-                           and _is_simple(op, tables[op.table], [c.lookup for c in op.conds if isinstance(c, Contains)])}
+                           and (_is_simple(op, tables[op.table], [c.lookup for c in op.conds if isinstance(c, Contains)]) or xplan.groups_by_entry(op))}
         # builds that only ever answer `tbl[k] != None` (never probed for a payload, never materialised):
         # membership-only tables (sdqh_build_key_set)
         member_only = _membership_only(plan)
+        looked_up = _looked_up(plan)
         self.steps = []
         for op in plan.ops:
             if isinstance(op, ScanOp):
-                self.steps.append((op.out, _prepare_scan(eng, op, tables[op.table], accumulate_into, op.out in member_only)))
+                self.steps.append((op.out, _prepare_scan(eng, op, tables[op.table], accumulate_into, op.out in member_only, op.out in looked_up)))
             elif isinstance(op, SelectKeysOp):
                 self.steps.append((op.out, (lambda env, op=op: _select_keys(eng, op, env))))
             elif isinstance(op, ScalarExprOp):
@@ -1271,6 +1357,10 @@ class PreparedPlan:
             elif isinstance(op, FinalizeOp):
                 is_result = op.out == plan.result
                 self.steps.append((op.out, (lambda env, op=op, is_result=is_result: _finalize(eng, op, env, env.get("__top__") if is_result else None))))
+            elif isinstance(op, HostDictOp):
+                self.steps.append((op.out, (lambda env, op=op: _host_dict(eng, op, env, op.out == plan.result))))
+            elif isinstance(op, WrapScalarOp):
+                self.steps.append((op.out, (lambda env, op=op: ResultSet([n for n, _ in op.fields], [np.array([_eval_scalar_expr(e, env, op.lineno)]) for _, e in op.fields]))))
 
     def run(self, top=None):
         """top = (k, [(result column, "asc" | "desc"), ...]): ORDER BY ... LIMIT k on the final K-F."""
@@ -1285,6 +1375,10 @@ class PreparedPlan:
             res = env[self.plan.result]
             if isinstance(res, (BuiltTable, tuple)):
                 res = _materialize(self.eng, res, env, hint_key=id(self.plan))
+                if isinstance(res, DictResult) and not res.val_fields:      # {record: True}: a set of records, the reference's result container
+                    res = ResultSet([n for n, _ in res.key_fields], [a for _, a in res.key_fields])
+                    if top is not None:
+                        res = res.top(env["__top__"][0], env["__top__"][1])
             if top is not None and not isinstance(res, ResultSet):
                 raise UnsupportedQuery("top(k) applies to queries that end in a result set")
             return res

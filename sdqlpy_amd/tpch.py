@@ -82,13 +82,32 @@ def _pick(values, width, h):
     return np.array(values, "<U%d" % width)[(h % np.uint64(len(values))).astype(np.int64)]
 
 
+_CONTAINERS = [a + " " + b for a in ("SM", "LG", "MED", "JUMBO", "WRAP") for b in ("CASE", "BOX", "BAG", "JAR", "PKG", "PACK", "CAN", "DRUM")]
+_COMMENTS = ["furiously final deposits sleep", "carefully special packages haggle requests", "special requests nag blithely", "requests above the special ideas",
+             "ironic accounts boost slyly", "quickly special asymptotes wake", "pending requests use carefully", "express special theodolites; bold requests",
+             "even platelets are", "regular pinto beans cajole", "blithely unusual courts", "silent foxes against the requests"]
+_SUPP_COMMENTS = ["slyly regular accounts", "Customer insists on Complaints about late ones", "blithely Customer accounts", "Complaints precede the Customer",
+                  "furiously bold deposits", "Customer Complaints", "carefully even requests"]
+
+
+def _numbered(prefix, k, digits, width):
+    return np.char.add(prefix, np.char.zfill(k.astype("<U%d" % digits), digits)).astype("<U%d" % width)
+
+
 DERIVED = {   # table -> {column: (dtype, base columns, function(base arrays...) -> array)}
-    "orders": {"o_orderpriority": ("U15", ["o_orderkey"], lambda k: _pick(_PRIORITIES, 15, _mix(k, 1)))},
+    "orders": {"o_orderpriority": ("U15", ["o_orderkey"], lambda k: _pick(_PRIORITIES, 15, _mix(k, 1))),
+               "o_comment": ("U79", ["o_orderkey"], lambda k: _pick(_COMMENTS, 79, _mix(k, 12)))},
+    "supplier": {"s_name": ("U25", ["s_suppkey"], lambda k: _numbered("Supplier#", k, 9, 25)),
+                 "s_address": ("U40", ["s_suppkey"], lambda k: np.char.add(np.char.add(_pick(_TYPE_3, 40, _mix(k, 13)), " "), (_mix(k, 14) % np.uint64(99991)).astype("<U5")).astype("<U40")),
+                 "s_phone": ("U15", ["s_suppkey", "s_nationkey"], lambda k, n: np.char.add(np.char.add((n + 10).astype("<U2"), "-"), np.char.zfill((_mix(k, 15) % np.uint64(10 ** 10)).astype("<U10"), 10)).astype("<U15")),
+                 "s_comment": ("U101", ["s_suppkey"], lambda k: _pick(_SUPP_COMMENTS, 101, _mix(k, 16)))},
     "customer": {"c_name": ("U25", ["c_custkey"], lambda k: np.char.add("Customer#", np.char.zfill(k.astype("<U9"), 9)).astype("<U25")),
                  "c_address": ("U40", ["c_custkey"], lambda k: np.char.add(np.char.add(_pick(_TYPE_2, 40, _mix(k, 7)), " "), (_mix(k, 8) % np.uint64(9973)).astype("<U5")).astype("<U40")),
                  "c_phone": ("U15", ["c_custkey", "c_nationkey"], lambda k, n: np.char.add(np.char.add((n + 10).astype("<U2"), "-"), np.char.zfill((_mix(k, 9) % np.uint64(10 ** 10)).astype("<U10"), 10)).astype("<U15")),
                  "c_comment": ("U117", ["c_custkey"], lambda k: np.char.add(np.char.add(_pick(_INSTRUCT, 117, _mix(k, 10)), " / "), _pick(_SHIPMODES, 117, _mix(k, 11))).astype("<U117"))},
-    "part": {"p_type": ("U25", ["p_partkey"], lambda k: np.char.add(np.char.add(np.char.add(_pick(_TYPE_1, 25, _mix(k, 2)), " "),
+    "part": {"p_brand": ("U10", ["p_partkey"], lambda k: np.char.add("Brand#", ((_mix(k, 17) % np.uint64(5) + np.uint64(1)) * np.uint64(10) + _mix(k, 18) % np.uint64(5) + np.uint64(1)).astype("<U2")).astype("<U10")),
+             "p_container": ("U10", ["p_partkey"], lambda k: _pick(_CONTAINERS, 10, _mix(k, 19))),
+             "p_type": ("U25", ["p_partkey"], lambda k: np.char.add(np.char.add(np.char.add(_pick(_TYPE_1, 25, _mix(k, 2)), " "),
                                                                                   np.char.add(_pick(_TYPE_2, 25, _mix(k, 3)), " ")),
                                                                       _pick(_TYPE_3, 25, _mix(k, 4))).astype("<U25"))},
     "lineitem": {"l_shipmode": ("U10", ["l_orderkey", "l_linenumber"], lambda k, n: _pick(_SHIPMODES, 10, _mix(k * 8 + n, 5))),
@@ -116,6 +135,21 @@ QUERY_COLUMNS = {
     "q10": {"lineitem": ["l_orderkey", "l_returnflag", "l_extendedprice", "l_discount"],
             "customer": ["c_custkey", "c_name", "c_acctbal", "c_address", "c_nationkey", "c_phone", "c_comment"],
             "orders": ["o_orderkey", "o_custkey", "o_orderdate"], "nation": ["n_nationkey", "n_name"]},
+    "q7": {"supplier": ["s_suppkey", "s_nationkey"], "lineitem": ["l_suppkey", "l_orderkey", "l_shipdate", "l_extendedprice", "l_discount"],
+           "orders": ["o_orderkey", "o_custkey"], "customer": ["c_custkey", "c_nationkey"], "nation": ["n_nationkey", "n_name"]},
+    "q8": {"part": ["p_partkey", "p_type"], "supplier": ["s_suppkey", "s_nationkey"],
+           "lineitem": ["l_partkey", "l_suppkey", "l_orderkey", "l_extendedprice", "l_discount"],
+           "orders": ["o_orderkey", "o_custkey", "o_orderdate"], "customer": ["c_custkey", "c_nationkey"],
+           "nation": ["n_nationkey", "n_name", "n_regionkey"], "region": ["r_regionkey", "r_name"]},
+    "q13": {"customer": ["c_custkey"], "orders": ["o_custkey", "o_comment"]},
+    "q15": {"lineitem": ["l_suppkey", "l_shipdate", "l_extendedprice", "l_discount"], "supplier": ["s_suppkey", "s_name", "s_address", "s_phone"]},
+    "q17": {"lineitem": ["l_partkey", "l_quantity", "l_extendedprice"], "part": ["p_partkey", "p_brand", "p_container"]},
+    "q19": {"lineitem": ["l_partkey", "l_quantity", "l_extendedprice", "l_discount", "l_shipinstruct", "l_shipmode"],
+            "part": ["p_partkey", "p_brand", "p_size", "p_container"]},
+    "q20": {"supplier": ["s_suppkey", "s_name", "s_address", "s_nationkey"], "nation": ["n_nationkey", "n_name"],
+            "partsupp": ["ps_partkey", "ps_suppkey", "ps_availqty"], "part": ["p_partkey", "p_name"],
+            "lineitem": ["l_partkey", "l_suppkey", "l_quantity", "l_shipdate"]},
+    "q22": {"customer": ["c_custkey", "c_phone", "c_acctbal"], "orders": ["o_custkey"]},
     "q9": {"lineitem": ["l_orderkey", "l_partkey", "l_suppkey", "l_quantity", "l_extendedprice", "l_discount"],
            "orders": ["o_orderkey", "o_orderdate"], "nation": ["n_nationkey", "n_name"],
            "supplier": ["s_suppkey", "s_nationkey"], "part": ["p_partkey", "p_name"],

@@ -209,7 +209,177 @@ def q10(nation, customer, orders, lineitem):
     return lost_revenue
 
 
-QUERIES = {"q6": q6, "q1": q1, "q3": q3, "q5": q5, "q9": q9, "q4": q4, "q14": q14, "q18": q18, "q10": q10}
+# =================================================================================================
+# Queries whose loops need the open expression vocabulary (row programs, xplan.py): `or`, conditional
+# values, text functions, conditions on looked-up fields and on aggregated values.
+# =================================================================================================
+
+# ---- q7: volume shipping between two nations, per year --------------------------------------------------
+@sdql_compile({"nation": nation_type, "supplier": supplier_type, "customer": customer_type, "orders": order_type, "lineitem": lineitem_type})
+def q7(nation, supplier, customer, orders, lineitem):
+    two_nations = nation.sum(
+        lambda n: {unique(n[0].n_nationkey): n[0].n_name} if n[0].n_name == "FRANCE" or n[0].n_name == "GERMANY" else None)
+    supplier_nation = supplier.sum(
+        lambda s: {unique(s[0].s_suppkey): two_nations[s[0].s_nationkey]} if two_nations[s[0].s_nationkey] != None else None)      # noqa: E711
+    customer_nation = customer.sum(
+        lambda c: {unique(c[0].c_custkey): two_nations[c[0].c_nationkey]} if two_nations[c[0].c_nationkey] != None else None)      # noqa: E711
+    order_nation = orders.sum(
+        lambda o: {unique(o[0].o_orderkey): customer_nation[o[0].o_custkey]} if customer_nation[o[0].o_custkey] != None else None)  # noqa: E711
+    shipped = lineitem.sum(
+        lambda l: {
+            record({"supp_nation": supplier_nation[l[0].l_suppkey], "cust_nation": order_nation[l[0].l_orderkey],
+                    "l_year": extractYear(l[0].l_shipdate)}):
+            record({"revenue": l[0].l_extendedprice * (1.0 - l[0].l_discount)})}
+        if 19950101 <= l[0].l_shipdate <= 19961231
+        and supplier_nation[l[0].l_suppkey] != None and order_nation[l[0].l_orderkey] != None      # noqa: E711
+        and ((supplier_nation[l[0].l_suppkey] == "FRANCE" and order_nation[l[0].l_orderkey] == "GERMANY")
+             or (supplier_nation[l[0].l_suppkey] == "GERMANY" and order_nation[l[0].l_orderkey] == "FRANCE"))
+        else None)
+    volume = shipped.sum(lambda g: {unique(g[0].concat(g[1])): True})
+    return volume
+
+
+# ---- q8: national market share within a region, per year --------------------------------------------------
+@sdql_compile({"region": region_type, "nation": nation_type, "customer": customer_type, "supplier": supplier_type,
+               "part": part_type, "orders": order_type, "lineitem": lineitem_type})
+def q8(region, nation, customer, supplier, part, orders, lineitem):
+    america = region.sum(lambda r: {unique(r[0].r_regionkey): True} if r[0].r_name == "AMERICA" else None)
+    american_nations = nation.sum(lambda n: {unique(n[0].n_nationkey): True} if america[n[0].n_regionkey] != None else None)      # noqa: E711
+    nation_names = nation.sum(lambda n: {unique(n[0].n_nationkey): n[0].n_name})
+    supplier_nation = supplier.sum(lambda s: {unique(s[0].s_suppkey): s[0].s_nationkey})
+    customer_nation = customer.sum(lambda c: {unique(c[0].c_custkey): c[0].c_nationkey})
+    steel_parts = part.sum(lambda p: {unique(p[0].p_partkey): True} if p[0].p_type == "ECONOMY ANODIZED STEEL" else None)
+    orders_95_96 = orders.sum(
+        lambda o: {unique(o[0].o_orderkey): record({"o_custkey": o[0].o_custkey, "o_orderdate": o[0].o_orderdate})}
+        if 19950101 <= o[0].o_orderdate <= 19961231 else None)
+    volume = lineitem.sum(
+        lambda l: {
+            extractYear(orders_95_96[l[0].l_orderkey].o_orderdate):
+            record({"A": l[0].l_extendedprice * (1.0 - l[0].l_discount)
+                    if nation_names[supplier_nation[l[0].l_suppkey]] == "BRAZIL" else 0.0,
+                    "B": l[0].l_extendedprice * (1.0 - l[0].l_discount)})}
+        if steel_parts[l[0].l_partkey] != None and orders_95_96[l[0].l_orderkey] != None      # noqa: E711
+        and american_nations[customer_nation[orders_95_96[l[0].l_orderkey].o_custkey]] != None      # noqa: E711
+        else None)
+    share = volume.sum(lambda g: {unique(record({"o_year": g[0], "mkt_share": g[1].A / g[1].B})): True})
+    return share
+
+
+# ---- q13: customer distribution by number of (non-special) orders --------------------------------------------
+@sdql_compile({"orders": order_type, "customer": customer_type})
+def q13(orders, customer):
+    orders_per_customer = orders.sum(
+        lambda o: {o[0].o_custkey: 1}
+        if not (firstIndex(o[0].o_comment, "special") != -1
+                and firstIndex(o[0].o_comment, "requests") > firstIndex(o[0].o_comment, "special") + 6)
+        else None)
+    distribution = customer.sum(
+        lambda c: {record({"c_count": orders_per_customer[c[0].c_custkey] if orders_per_customer[c[0].c_custkey] != None else 0}):      # noqa: E711
+                   record({"custdist": 1})})
+    histogram = distribution.sum(lambda g: {unique(g[0].concat(g[1])): True})
+    return histogram
+
+
+# ---- q15: revenue per supplier for one quarter; TPCH's "top supplier" is `.top(1, [("total_revenue", "desc")])` ----
+@sdql_compile({"lineitem": lineitem_type, "supplier": supplier_type})
+def q15(lineitem, supplier):
+    revenue = lineitem.sum(
+        lambda l: {l[0].l_suppkey: l[0].l_extendedprice * (1.0 - l[0].l_discount)}
+        if 19960101 <= l[0].l_shipdate < 19960401 else None)
+    suppliers = supplier.joinBuild("s_suppkey", lambda s: True, ["s_name", "s_address", "s_phone"])
+    ranked = revenue.sum(lambda g: {unique(record({
+        "s_suppkey": g[0], "s_name": suppliers[g[0]].s_name, "s_address": suppliers[g[0]].s_address,
+        "s_phone": suppliers[g[0]].s_phone, "total_revenue": g[1]})): True})
+    return ranked
+
+
+# ---- q17: small-quantity-order revenue: rows below a fifth of their part's average quantity ------------------------
+@sdql_compile({"part": part_type, "lineitem": lineitem_type})
+def q17(part, lineitem):
+    boxed = part.sum(lambda p: {unique(p[0].p_partkey): True}
+                     if p[0].p_brand == "Brand#23" and p[0].p_container == "MED BOX" else None)
+    quantity_per_part = lineitem.joinProbe(
+        boxed, "l_partkey", lambda l: True,
+        lambda hit, item: {item.l_partkey: record({"l_quantity": item.l_quantity, "count": 1.0})})
+    small_orders = lineitem.joinProbe(
+        quantity_per_part, "l_partkey", lambda l: True,
+        lambda part_total, item: item.l_extendedprice
+        if 0.2 * (part_total.l_quantity / part_total.count) > item.l_quantity else 0.0)
+    yearly = small_orders / 7.0
+    return yearly
+
+
+# ---- q19: discounted revenue: three brand / container / quantity / size combinations -----------------------------------
+@sdql_compile({"part": part_type, "lineitem": lineitem_type})
+def q19(part, lineitem):
+    candidates = part.sum(
+        lambda p: {unique(p[0].p_partkey): record({"p_brand": p[0].p_brand})}
+        if (p[0].p_brand == "Brand#12" and 1 <= p[0].p_size <= 5
+            and (p[0].p_container == "SM CASE" or p[0].p_container == "SM BOX" or p[0].p_container == "SM PACK" or p[0].p_container == "SM PKG"))
+        or (p[0].p_brand == "Brand#23" and 1 <= p[0].p_size <= 10
+            and (p[0].p_container == "MED BAG" or p[0].p_container == "MED BOX" or p[0].p_container == "MED PKG" or p[0].p_container == "MED PACK"))
+        or (p[0].p_brand == "Brand#34" and 1 <= p[0].p_size <= 15
+            and (p[0].p_container == "LG CASE" or p[0].p_container == "LG BOX" or p[0].p_container == "LG PACK" or p[0].p_container == "LG PKG"))
+        else None)
+    discounted = lineitem.joinProbe(
+        candidates, "l_partkey",
+        lambda l: l[0].l_shipinstruct == "DELIVER IN PERSON" and (l[0].l_shipmode == "AIR" or l[0].l_shipmode == "AIR REG"),
+        lambda cand, item: item.l_extendedprice * (1.0 - item.l_discount)
+        if (cand.p_brand == "Brand#12" and 1 <= item.l_quantity <= 11)
+        or (cand.p_brand == "Brand#23" and 10 <= item.l_quantity <= 20)
+        or (cand.p_brand == "Brand#34" and 20 <= item.l_quantity <= 30)
+        else 0.0)
+    result = sr_dict({record({"revenue": discounted}): True})
+    return result
+
+
+# ---- q20: potential part promotion: suppliers of one nation with excess stock of forest parts ------------------------
+@sdql_compile({"nation": nation_type, "supplier": supplier_type, "part": part_type, "partsupp": partsupp_type, "lineitem": lineitem_type})
+def q20(nation, supplier, part, partsupp, lineitem):
+    canada = nation.sum(lambda n: {unique(n[0].n_nationkey): True} if n[0].n_name == "CANADA" else None)
+    canadian_suppliers = supplier.sum(lambda s: {unique(s[0].s_suppkey): True} if canada[s[0].s_nationkey] != None else None)      # noqa: E711
+    forest_parts = part.sum(lambda p: {unique(p[0].p_partkey): True} if startsWith(p[0].p_name, "forest") else None)
+    half_shipped_1994 = lineitem.sum(
+        lambda l: {record({"l_partkey": l[0].l_partkey, "l_suppkey": l[0].l_suppkey}): 0.5 * l[0].l_quantity}
+        if 19940101 <= l[0].l_shipdate < 19950101
+        and forest_parts[l[0].l_partkey] != None and canadian_suppliers[l[0].l_suppkey] != None      # noqa: E711
+        else None)
+    overstocked = partsupp.sum(
+        lambda ps: {unique(ps[0].ps_suppkey): True}
+        if half_shipped_1994[record({"l_partkey": ps[0].ps_partkey, "l_suppkey": ps[0].ps_suppkey})] != None      # noqa: E711
+        and ps[0].ps_availqty > half_shipped_1994[record({"l_partkey": ps[0].ps_partkey, "l_suppkey": ps[0].ps_suppkey})]
+        else None)
+    promotion = supplier.sum(
+        lambda s: {unique(record({"s_name": s[0].s_name, "s_address": s[0].s_address})): True}
+        if overstocked[s[0].s_suppkey] != None else None)      # noqa: E711
+    return promotion
+
+
+# ---- q22: global sales opportunity: well-funded customers of seven country codes without orders -------------------------
+@sdql_compile({"orders": order_type, "customer": customer_type})
+def q22(orders, customer):
+    customers_with_orders = orders.sum(lambda o: {unique(o[0].o_custkey): True})
+    positive = customer.sum(
+        lambda c: record({"c_acctbal": c[0].c_acctbal, "count": 1.0})
+        if c[0].c_acctbal > 0.0
+        and (startsWith(c[0].c_phone, "13") or startsWith(c[0].c_phone, "31") or startsWith(c[0].c_phone, "23")
+             or startsWith(c[0].c_phone, "29") or startsWith(c[0].c_phone, "30") or startsWith(c[0].c_phone, "18")
+             or startsWith(c[0].c_phone, "17"))
+        else None)
+    average_balance = positive.c_acctbal / positive.count
+    idle_rich = customer.sum(
+        lambda c: {record({"cntrycode": substr(c[0].c_phone, 0, 1)}): record({"numcust": 1, "totalacctbal": c[0].c_acctbal})}
+        if c[0].c_acctbal > average_balance and customers_with_orders[c[0].c_custkey] == None      # noqa: E711
+        and (startsWith(c[0].c_phone, "13") or startsWith(c[0].c_phone, "31") or startsWith(c[0].c_phone, "23")
+             or startsWith(c[0].c_phone, "29") or startsWith(c[0].c_phone, "30") or startsWith(c[0].c_phone, "18")
+             or startsWith(c[0].c_phone, "17"))
+        else None)
+    opportunity = idle_rich.sum(lambda g: {unique(g[0].concat(g[1])): True})
+    return opportunity
+
+
+QUERIES = {"q6": q6, "q1": q1, "q3": q3, "q5": q5, "q9": q9, "q4": q4, "q14": q14, "q18": q18, "q10": q10,
+           "q7": q7, "q8": q8, "q13": q13, "q15": q15, "q17": q17, "q19": q19, "q20": q20, "q22": q22}
 
 _TABLE_OF_PARAM = {"lineitem": "lineitem", "orders": "orders", "customer": "customer", "supplier": "supplier", "part": "part",
                    "partsupp": "partsupp", "nation": "nation", "region": "region"}
@@ -246,4 +416,10 @@ TPCH_ORDER = {
     "q4": (100, [("o_orderpriority", "asc")]),
     "q18": (100, [("o_totalprice", "desc"), ("o_orderdate", "asc")]),
     "q10": (20, [("revenue", "desc")]),
+    "q7": (100, [("supp_nation", "asc"), ("cust_nation", "asc"), ("l_year", "asc")]),
+    "q8": (100, [("o_year", "asc")]),
+    "q13": (100, [("custdist", "desc"), ("c_count", "desc")]),
+    "q15": (1, [("total_revenue", "desc")]),
+    "q20": (100, [("s_name", "asc")]),
+    "q22": (100, [("cntrycode", "asc")]),
 }

@@ -40,3 +40,11 @@ def hip_lib():
     """The product library.  On a box without a GPU only loading / symbol checks are possible."""
     from sdqlpy_amd import engine
     return engine.load_hip_library()
+
+
+@pytest.fixture(scope="session")
+def golden_wide():
+    """Reference results for the queries that need the open expression vocabulary (q7, q8, q13, q15, q17, q19,
+    q20, q22): make_golden.py --wide."""
+    with open(os.path.join(ROOT, "tests", "golden", "tpch_golden_wide.json")) as fh:
+        return json.load(fh)

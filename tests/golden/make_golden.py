@@ -48,6 +48,19 @@ QUERY_TABLES = {   # positional argument order of each reference query (test/tes
     "q18": ["lineitem", "customer", "orders"],
     "q10": ["customer", "orders", "lineitem", "nation"],
 }
+# SURVEY.md §8f.3, second step: queries that need the open expression vocabulary (test/test_all.py:299-367, 371-427,
+# 656-691, 720-756, 831-870, 917-981, 985-1028, 1113-1183).  Argument order = the reference's decorators.
+WIDE_QUERIES = ["q7", "q8", "q13", "q15", "q17", "q19", "q20", "q22"]
+QUERY_TABLES.update({
+    "q7": ["supplier", "lineitem", "orders", "customer", "nation"],
+    "q8": ["part", "supplier", "lineitem", "orders", "customer", "nation", "region"],
+    "q13": ["customer", "orders"],
+    "q15": ["lineitem", "supplier"],
+    "q17": ["lineitem", "part"],
+    "q19": ["lineitem", "part"],
+    "q20": ["supplier", "nation", "partsupp", "part", "lineitem"],
+    "q22": ["customer", "orders"],
+})
 ALL_TABLES = ["lineitem", "customer", "orders", "region", "nation", "supplier", "part", "partsupp"]
 
 # ---- input variants: edge cases the parity tests must cover -------------------------------------
@@ -166,9 +179,18 @@ def load_reference():
         if isinstance(node, ast.Assign) and isinstance(node.targets[0], ast.Name) and node.targets[0].id.endswith("_type"):
             exec(compile(ast.Module([node], []), "test_all.py", "exec"), ns)
     for node in tree.body:
-        if isinstance(node, ast.FunctionDef) and node.name in QUERIES + MORE_QUERIES:
+        if isinstance(node, ast.FunctionDef) and node.name in QUERIES + MORE_QUERIES + WIDE_QUERIES:
+            if node.name == "q15":
+                # The reference's Q15 compares each supplier's revenue with the constant 1772627.2087 — the answer
+                # for dbgen's SF=1 data, typed in by hand (test/test_all.py:733; the `max` it stands for is commented
+                # out on the next line).  On any other data that selects nothing, so the ONE statement that binds
+                # the constant is replaced by the maximum of the dictionary the query has just computed.
+                for i, st in enumerate(node.body):
+                    if isinstance(st, ast.Assign) and isinstance(st.targets[0], ast.Name) and st.targets[0].id == "max_revenue":
+                        node.body[i] = ast.copy_location(ast.parse("max_revenue = max(li_aggr.getContainer().values())").body[0], st)
+                ast.fix_missing_locations(node)
             exec(compile(ast.Module([node], []), "test_all.py", "exec"), ns)
-    return ref, {q: ns[q] for q in QUERIES + MORE_QUERIES}
+    return ref, {q: ns[q] for q in QUERIES + MORE_QUERIES + WIDE_QUERIES}
 
 
 def to_ref_table(ref, table):
@@ -177,6 +199,8 @@ def to_ref_table(ref, table):
 
 
 def enc(v):
+    if hasattr(v, "getContainer") and not v.getContainer():
+        return {"f": (0.0).hex()}            # a scalar sum over no rows is the empty dictionary in the interpreter: the semiring zero
     if isinstance(v, (float, np.floating)):
         return {"f": float(v).hex()}
     if isinstance(v, (int, np.integer)):
@@ -220,9 +244,17 @@ MORE_CASES = [
 ]
 
 
+WIDE_CASES = [
+    ("tiny", 0.0003, "base", WIDE_QUERIES),
+    ("small", 0.01, "base", WIDE_QUERIES),
+    ("medium", 0.1, "base", WIDE_QUERIES),
+]
+
+
 def main():
     more = "--more" in sys.argv          # python tests/golden/make_golden.py --more  -> tpch_golden_more.json (q4, q14)
-    cases = MORE_CASES if more else CASES
+    wide = "--wide" in sys.argv          # python tests/golden/make_golden.py --wide  -> tpch_golden_wide.json (q7, q8, q13, q15, q17, q19, q20, q22)
+    cases = WIDE_CASES if wide else MORE_CASES if more else CASES
     ref, queries = load_reference()
     out = {"meta": {"generator_seed": tpch.DEFAULT_SEED,
                     "reference": "edin-dal/sdqlpy Python mode (sdqlpy_init(0,1)), queries from test/test_all.py",
@@ -241,7 +273,7 @@ def main():
             try:
                 res = queries[q](*args)
                 note = None
-            except (AttributeError, TypeError) as exc:   # the interpreter cannot sum an empty aggregate
+            except (AttributeError, TypeError, ValueError) as exc:   # the interpreter cannot sum an empty aggregate
                 res, note = None, "reference raised %s: recorded as empty" % type(exc).__name__
             r = encode_result(ref, res)
             if note:
@@ -250,7 +282,7 @@ def main():
             print("%-22s %s  %6.1fs  %s" % (name, q, time.time() - t0,
                                            r["value"] if r["kind"] == "scalar" else "%d rows" % len(r["rows"])), flush=True)
         out["cases"].append(case)
-    path = os.path.join(HERE, "tpch_golden_more.json" if more else "tpch_golden.json")
+    path = os.path.join(HERE, "tpch_golden_wide.json" if wide else "tpch_golden_more.json" if more else "tpch_golden.json")
     with open(path, "w") as fh:
         json.dump(out, fh, separators=(",", ":"))
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -218,6 +218,23 @@ def test_full_size_q9_and_topk_sf10(hip_engine):
     hip_engine.clear()
 
 
+def test_open_vocabulary_queries_against_the_reference(hip_engine, golden_wide, oracle_engine):
+    """q7, q8, q13, q15, q17, q19, q20, q22 through kernels specialised on their own conditions and values
+    (row programs), against the reference's results; then at SF 1 against the CPU implementation."""
+    assert helpers.check_wide_goldens(hip_engine, golden_wide, REL, "hip") >= 23
+    qs = ("q7", "q8", "q13", "q15", "q17", "q19", "q20", "q22")
+    db = tpch.generate(1.0, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+    for q in qs:
+        got, want = helpers.run_query(hip_engine, q, db), helpers.run_query(oracle_engine, q, db)
+        if isinstance(want, float):
+            assert abs(got - want) <= REL * abs(want), (q, got, want)
+        else:
+            assert want.size() > 0, q
+            helpers.assert_rows_match(helpers.result_rows(got, want.columns), helpers.result_rows(want, want.columns), REL, "sf1/" + q)
+    hip_engine.clear()
+    oracle_engine.clear()
+
+
 def test_row_programs_specialised_kernels(hip_engine):
     """ABI 4: every sdqh_x* entry point — kernels specialised at run time (hiprtc) on the program —
     against numpy, on the cases the CPU implementation is pinned with; at three sizes around the

@@ -421,6 +421,7 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
 #define SDQH_MAX_XTABLES 6    /* distinct tables it may look up                        */
 #define SDQH_MAX_XGATES  16
 #define SDQH_MAX_XSTR    256  /* code units of all string constants together          */
+#define SDQH_MAX_XCONST  48   /* CONST operations of one type (i64 + bool / f64)       */
 
 typedef struct sdqh_xop {
     int32_t code, type;             /* SDQH_X_*, SDQH_T_* of the result */

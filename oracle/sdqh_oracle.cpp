@@ -1063,7 +1063,7 @@ int make_xprog(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* p, int max_vals
     if (!p || p->nops < 0 || p->nops > SDQH_MAX_XOPS || (p->nops && !p->ops) || p->ngates < 0 || p->ngates > SDQH_MAX_XGATES || (p->ngates && !p->gates) ||
         p->nvals < 0 || p->nvals > max_vals || (p->nvals && !p->vals))
         return fail(ctx, SDQH_ERR_INVALID, "program: bad counts");
-    int ncols = 0, ntabs = 0, nstr = 0;
+    int ncols = 0, ntabs = 0, nstr = 0, nci = 0, ncf = 0;
     const void* cols[SDQH_MAX_XOPS]; const void* tabs[SDQH_MAX_XOPS];
     for (int k = 0; k < p->nops; ++k) {
         const sdqh_xop& o = p->ops[k];
@@ -1075,7 +1075,7 @@ int make_xprog(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* p, int max_vals
                 rc = need(o.col && o.col->dtype != SDQH_STR && o.col->nrows >= nrows && o.type == (o.col->dtype == SDQH_F64 ? SDQH_T_F64 : SDQH_T_I64), "COL needs an I64 / F64 column covering nrows, typed alike");
                 break;
             case SDQH_X_ROWID: rc = need(o.type == SDQH_T_I64, "ROWID is i64"); break;
-            case SDQH_X_CONST: rc = need(o.type >= SDQH_T_I64 && o.type <= SDQH_T_BOOL, "CONST type"); break;
+            case SDQH_X_CONST: rc = need(o.type >= SDQH_T_I64 && o.type <= SDQH_T_BOOL, "CONST type"); if (o.type == SDQH_T_F64) ++ncf; else ++nci; break;
             case SDQH_X_LOOKUP: rc = need(o.table && ty(o.a) == SDQH_T_I64 && o.type == SDQH_T_BOOL, "LOOKUP needs a table and an i64 key"); break;
             case SDQH_X_FIELD:
                 rc = need(o.a >= 0 && o.a < k && p->ops[o.a].code == SDQH_X_LOOKUP && !p->ops[o.a].table->bitmap_only && o.aux >= 0 && o.aux < p->ops[o.a].table->npayload &&
@@ -1110,7 +1110,8 @@ int make_xprog(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* p, int max_vals
         if (o.col) { bool seen = false; for (int j = 0; j < ncols; ++j) seen = seen || cols[j] == o.col; if (!seen) cols[ncols++] = o.col; }
         if (o.table) { bool seen = false; for (int j = 0; j < ntabs; ++j) seen = seen || tabs[j] == o.table; if (!seen) tabs[ntabs++] = o.table; }
     }
-    if (ncols > SDQH_MAX_XCOLS || ntabs > SDQH_MAX_XTABLES || nstr > SDQH_MAX_XSTR) return fail(ctx, SDQH_ERR_UNSUPPORTED, "program: too many columns / tables / string constants");
+    if (ncols > SDQH_MAX_XCOLS || ntabs > SDQH_MAX_XTABLES || nstr > SDQH_MAX_XSTR || nci > SDQH_MAX_XCONST || ncf > SDQH_MAX_XCONST)
+        return fail(ctx, SDQH_ERR_UNSUPPORTED, "program: too many columns / tables / constants");
     for (int g = 0; g < p->ngates; ++g)
         if (p->gates[g] < 0 || p->gates[g] >= p->nops || p->ops[p->gates[g]].type != SDQH_T_BOOL) return fail(ctx, SDQH_ERR_INVALID, "program: a gate must be a bool operation");
     if (need_key ? !(p->key >= 0 && p->key < p->nops && p->ops[p->key].type == SDQH_T_I64) : p->key != -1) return fail(ctx, SDQH_ERR_INVALID, "program: key");

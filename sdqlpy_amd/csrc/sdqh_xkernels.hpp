@@ -18,7 +18,7 @@
 
 namespace sdqh {
 
-constexpr int X_MAX_CONST = 32;
+constexpr int X_MAX_CONST = SDQH_MAX_XCONST;
 template <bool B> struct XBool { static constexpr bool value = B; };
 
 // by-value argument of every specialised kernel: the bindings of the program (columns, tables,

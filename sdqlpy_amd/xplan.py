@@ -58,13 +58,17 @@ class Compiler:
 
     # -- leaves ------------------------------------------------------------------------------------
     def const(self, v):
-        if isinstance(v, bool):
-            return XV(self.P.op(abi.X_CONST, abi.T_BOOL, imm_i=int(v)), "b")
-        if isinstance(v, (int, np.integer)):
-            return XV(self.P.op(abi.X_CONST, abi.T_I64, imm_i=int(v)), "i", rng=(int(v), int(v)))
-        if isinstance(v, (float, np.floating)):
-            return XV(self.P.op(abi.X_CONST, abi.T_F64, imm_f=float(v)), "f")
-        self.fail("constant %r has no place in an expression" % (v,))
+        key = ("const", type(v).__name__, repr(v))
+        if key not in self.memo:
+            if isinstance(v, bool):
+                self.memo[key] = XV(self.P.op(abi.X_CONST, abi.T_BOOL, imm_i=int(v)), "b")
+            elif isinstance(v, (int, np.integer)):
+                self.memo[key] = XV(self.P.op(abi.X_CONST, abi.T_I64, imm_i=int(v)), "i", rng=(int(v), int(v)))
+            elif isinstance(v, (float, np.floating)):
+                self.memo[key] = XV(self.P.op(abi.X_CONST, abi.T_F64, imm_f=float(v)), "f")
+            else:
+                self.fail("constant %r has no place in an expression" % (v,))
+        return self.memo[key]
 
     def column(self, name):
         arr = self.htab.array(name, self.op)
@@ -180,7 +184,7 @@ class Compiler:
         if isinstance(e, Col):
             return self.column(e.name)
         if isinstance(e, ScalarField):
-            x = self.const(0.0)
+            x = XV(self.P.op(abi.X_CONST, abi.T_F64, imm_f=0.0), "f")       # its own operation: rebound on every run
             self.scalars.append((x.id, e))
             return x
         if isinstance(e, PayloadField):

@@ -614,25 +614,33 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
         return c, parts, radix, count_idx
 
     def compile_large(env):
-        """any number of groups: a unique build of the keys with accumulators, then the same rows summed into it"""
-        c = Compiler(eng, op, htab, env)
-        gates, _ = gates_of(c, op.conds)
-        parts = c.key_parts(key_fields)
-        flat = [v for _, vs, _ in parts for v in vs]
-        if len(flat) > 2:
-            raise UnsupportedQuery("line %d: group keys of more than two parts over a large domain are not supported" % op.lineno)
-        bounds = (1, 0)
-        if len(flat) == 1:
-            kid = flat[0].id
-            r = c.resolve_rng(flat[0])
-            if r is not None:
-                bounds = r
-        else:
-            kid = c.P.op(abi.X_PACK2, abi.T_I64, a=flat[0].id, b=flat[1].id)
-        vals, count_idx = summed_values(c, vexprs)
-        c.P.gates, c.P.key = gates, kid
+        """any number of groups: a unique build of the keys with accumulators, then the same rows summed into
+        it.  Two programs (the second looks the first one's table up): a program never names a table that
+        is not alive when it runs."""
+        def half(with_values):
+            c = Compiler(eng, op, htab, env)
+            gates, _ = gates_of(c, op.conds)
+            parts = c.key_parts(key_fields)
+            flat = [v for _, vs, _ in parts for v in vs]
+            if len(flat) > 2:
+                raise UnsupportedQuery("line %d: group keys of more than two parts over a large domain are not supported" % op.lineno)
+            bounds = (1, 0)
+            if len(flat) == 1:
+                kid = flat[0].id
+                r = c.resolve_rng(flat[0])
+                if r is not None:
+                    bounds = r
+            else:
+                kid = c.P.op(abi.X_PACK2, abi.T_I64, a=flat[0].id, b=flat[1].id)
+            c.P.gates = gates
+            vals, count_idx = summed_values(c, vexprs) if with_values else ([], None)
+            return c, kid, vals, count_idx, bounds, flat
+        cb, kid, _, _, bounds, flat = half(False)
+        cb.P.key = kid
+        cp, pkid, vals, count_idx, _, _ = half(True)
+        cp.P.vals = vals
         key_names = [nm or (e.name if isinstance(e, Col) else "key%d" % i) for i, (nm, e) in enumerate(key_fields)]
-        return c, kid, vals, count_idx, bounds, key_names, (flat[0].dec if len(flat) == 1 else None), len(flat) == 2
+        return cb, cp, pkid, count_idx, bounds, key_names, (flat[0].dec if len(flat) == 1 else None), len(flat) == 2
 
     def run_aggregate(env):
         mode = state.get("mode")
@@ -691,23 +699,20 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
                     raise
                 state["mode"] = "large"
         st = state.get("c")
-        if st is None or not st[0].still_valid(env):
+        if st is None or not (st[0].still_valid(env) and st[1].still_valid(env)):
             st = state["c"] = compile_large(env)
-        c, kid, vals, count_idx, bounds, key_names, key_dec, composite = st
-        c.bind(env)
-        c.P.vals = []
-        table = ctx.xbuild(n, c.P, bounds[0], bounds[1], accumulate=True)
+            state["look"] = None
+        cb, cp, pkid, count_idx, bounds, key_names, key_dec, composite = st
+        cb.bind(env); cp.bind(env)
+        table = ctx.xbuild(n, cb.P, bounds[0], bounds[1], accumulate=True)
         look = state.get("look")
         if look is None:
-            look = state["look"] = c.P.op(abi.X_LOOKUP, abi.T_BOOL, a=kid, table=table)
+            look = state["look"] = cp.P.op(abi.X_LOOKUP, abi.T_BOOL, a=pkid, table=table)
+            cp.P.gates = list(cp.P.gates) + [look]
         else:
-            c.P.bind_table(look, table)
-        saved = list(c.P.gates)
-        c.P.gates, c.P.vals, c.P.key = saved + [look], list(vals), -1
-        try:
-            ctx.xprobe_aggregate(n, c.P, look, table)
-        finally:
-            c.P.gates, c.P.vals, c.P.key = saved, [], kid
+            cp.P.bind_table(look, table)
+        ctx.xprobe_aggregate(n, cp.P, look, table)
+        vals = cp.P.vals
         bt = BuiltTable(table, key_names[0], key_is_record, [], val_is_record, [])
         if composite:
             bt.key_parts = key_names

@@ -54,6 +54,9 @@ struct XInfo {
     int nstream_gates = 0;                   // leading gates that depend on numeric columns / constants only
     std::vector<int> scols;                  // streamed columns (indices into cols)
     int probe_op = -1;                       // XEntry: the LOOKUP whose entry receives the values
+    int prefilter_op = -1;                   // first LOOKUP gate after the streamed ones whose key is made of plain columns:
+    int prefilter_part0 = -1;                //   its table's key bitmap is tested on the streamed key (operation of the first key part)
+    bool prefilter_composite = false;
 };
 
 bool op_is_light(const sdqh_xop& o) {        // evaluable on streamed registers
@@ -161,6 +164,22 @@ int analyse(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* p, int max_vals, b
         if (!light || have + extra > 6) break;
         for (int c : cols) scol[(size_t)c] = 1;
         x->nstream_gates = g + 1;
+    }
+    // the next gate, when it is a lookup keyed by plain int columns: stream its key and test the table's key
+    // bitmap (exact for key sets / the direct layout, the high part's for composite keys) before queueing
+    if (x->nstream_gates < p->ngates) {
+        const sdqh_xop& g = p->ops[p->gates[x->nstream_gates]];
+        if (g.code == SDQH_X_LOOKUP) {
+            const sdqh_xop& k = p->ops[g.a];
+            int part0 = -1, part1 = -1;
+            if (k.code == SDQH_X_COL && k.type == SDQH_T_I64) part0 = g.a;
+            else if (k.code == SDQH_X_PACK2 && p->ops[k.a].code == SDQH_X_COL && p->ops[k.b].code == SDQH_X_COL) { part0 = k.a; part1 = k.b; }
+            int have = 0; for (char c : scol) have += c;
+            if (part0 >= 0 && have + (scol[(size_t)x->col_of[part0]] ? 0 : 1) <= 7) {
+                scol[(size_t)x->col_of[part0]] = 1;
+                x->prefilter_op = p->gates[x->nstream_gates]; x->prefilter_part0 = part0; x->prefilter_composite = part1 >= 0;
+            }
+        }
     }
     for (int c = 0; c < x->ncols; ++c) if (scol[(size_t)c]) x->scols.push_back(c);
     return SDQH_OK;
@@ -276,6 +295,10 @@ std::string generate(const XInfo& x, Sink sink, bool direct) {
         g.reset(); g.mode = 2; g.half = h ? "y" : "x"; g.os.str("");
         out << "      {\n";
         for (int q = 0; q < x.nstream_gates; ++q) { g.emit(p->gates[q]); g.os << "        p" << h << " = p" << h << " && v" << p->gates[q] << ";\n"; }
+        if (x.prefilter_op >= 0) {
+            g.emit(x.prefilter_part0);
+            g.os << "        p" << h << " = p" << h << " && x_may_hit(a.tab[" << x.tab_of[x.prefilter_op] << "], v" << x.prefilter_part0 << ", " << (x.prefilter_composite ? "true" : "false") << ");\n";
+        }
         out << g.os.str() << "      }\n";
     }
     out << "    }\n";

@@ -69,6 +69,17 @@ __device__ __forceinline__ uint32_t x_lookup(const DevTable& t, int64_t key, boo
     if (pos < 0) return NO_ROW;
     return t.bitmap_only ? 0u : table_ref(t, pos);
 }
+// cheap necessary condition for `key in table`, usable on a streamed key before the row is queued: the
+// table's key bitmap when it has one (exact for key sets and the direct layout; over the high part of a
+// composite key), else true
+__device__ __forceinline__ bool x_may_hit(const DevTable& t, int64_t part0, bool composite) {
+    if (!t.bm) return true;
+    if (composite ? (t.bm_shift == 0 && !t.lin_rb) : (t.bm_shift != 0 || t.lin_rb != 0)) return true;     // the bitmap is not over this part
+    if (composite && t.lin_rb) return true;
+    if (part0 < t.bm_lo || part0 > t.bm_hi) return false;
+    const uint64_t off = (uint64_t)(part0 - t.bm_lo);
+    return (t.bm[off >> 5] >> (off & 31)) & 1u;
+}
 __device__ __forceinline__ int64_t x_field(const DevTable& t, int f, uint32_t ent) { return ent == NO_ROW ? 0 : t.pay[f][ent]; }
 __device__ __forceinline__ double x_acc(const DevTable& t, int k, uint32_t ent) {
     if (ent == NO_ROW) return 0.0;

@@ -92,6 +92,7 @@ class Engine:
         self._range_cache = {}     # id(int64 ndarray) -> (ndarray, (min, span))
         self._distinct_cache = {}  # id(ndarray) -> (ndarray, has no repeated value)
         self._frozen = {}          # id(ndarray) -> ndarray made read-only on adoption (see column())
+        self.force_programs = os.environ.get("SDQLPY_AMD_FORCE_PROGRAMS") == "1"   # every loop as a row program (xplan.py), none through the fixed-shape calls
 
     def close(self):
         self.clear()
@@ -767,6 +768,12 @@ def _prepare_scan(eng, op, htab, accumulate_into, member_only=False, as_table=Fa
     A fixed-shape closure can still refuse at run time (a group count beyond its kernels): the loop then
     moves to its row program for good."""
     from . import xplan
+    if getattr(eng, "force_programs", False):
+        # every loop through a row program (tests / A-B measurements: the specialised kernels against the tuned ones)
+        try:
+            return xplan.prepare_scan(eng, op, htab, accumulate_into, member_only, as_table)
+        except UnsupportedQuery:
+            pass
     if as_table and op.kind == "dict" and not op.unique and not (op.probe is not None and xplan.groups_by_entry(op)):
         # an aggregated dictionary that later loops look up has to be a table whatever its size: the small-domain
         # group-by calls return their groups to the host
@@ -853,7 +860,9 @@ def _prepare_scan_fixed(eng, op, htab, accumulate_into, member_only=False, as_ta
                         raise
             if table is None:
                 table = ctx.hash_build_unique(n, flt, _resolve_probes(op, env, specs), kcol, payload_cols, accumulate=accumulate)
-            return BuiltTable(table, key_name, key_is_record, val_fields, val_is_record, payload_dtypes)
+            bt = BuiltTable(table, key_name, key_is_record, val_fields, val_is_record, payload_dtypes)
+            bt.slot_cols = payload_cols                     # where each payload slot's values come from (ranges on demand, xplan._slot_range)
+            return bt
         return run_build
 
     # ---- aggregations ----
@@ -1086,6 +1095,13 @@ def _materialize(eng, value, env, hint_key=None, top=None):
         keys, payload, values, hits, ordered = _fetch_entries(eng, bt.table, 1, hint_key, top, spec, want_hits=count_idx is not None or (spec is not None and any(s[0] == abi.SORT_HITS for s in spec)))
         values = [values[j] for j in range(nv)]
         fields_of = bt.agg_fields
+        if bt.key_parts is not None and out_key_fields == [(bt.key_name, "key")]:        # a composite group key: its two packed parts
+            decs = getattr(bt, "key_part_decoders", None) or [None, None]
+            d = DictResult([(bt.key_parts[0], _decode_column(keys >> 32, decs[0], np.int64)), (bt.key_parts[1], _decode_column(keys & 0xFFFFFFFF, decs[1], np.int64))],
+                           _value_arrays(vnames, count_idx, values, hits), True, val_is_record)
+            d.ordered = ordered
+            return d
+
         def decode(fname, src, sel=None):
             raw = keys if src == "key" else payload[src]
             if sel is not None:

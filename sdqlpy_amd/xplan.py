@@ -81,15 +81,19 @@ class Compiler:
             return XV(self.P.op(abi.X_COL, abi.T_F64, col=col), "f")
         self.fail("column '%s' has unsupported dtype %s" % (name, arr.dtype))
 
-    def text_as_int(self, tx):
-        """Dictionary code (low-cardinality column) or row number of a text column: an int the device can carry."""
-        key = ("textint", tx.name)
+    def text_as_int(self, tx, coded_ok=True):
+        """Dictionary code (low-cardinality column) or row number of a text column: an int the device can
+        carry.  A build payload takes the row number (coded_ok = False): every text field of a row then
+        shares ONE payload slot and differs only in the array the reference indexes."""
+        key = ("textint", tx.name, coded_ok)
         if key not in self.memo:
-            coded = self.eng.dict_column(tx.arr)
+            coded = self.eng.dict_column(tx.arr) if coded_ok else None
             if coded is not None:
                 self.memo[key] = XV(self.P.op(abi.X_COL, abi.T_I64, col=coded[0]), "i", dec=coded[1], rng=(0, max(0, len(coded[1]) - 1)))
             else:
-                self.memo[key] = XV(self.P.op(abi.X_ROWID, abi.T_I64), "i", dec=tx.arr, rng=(0, max(0, self.htab.nrows - 1)))
+                if "rowid" not in self.memo:
+                    self.memo["rowid"] = self.P.op(abi.X_ROWID, abi.T_I64)      # one row reference serves every text column of the row
+                self.memo[key] = XV(self.memo["rowid"], "i", dec=tx.arr, rng=(0, max(0, self.htab.nrows - 1)))
         return self.memo[key]
 
     def resolve_rng(self, v):
@@ -149,9 +153,13 @@ class Compiler:
             return keyvals[0]
         dt = np.dtype(bt.payload_dtypes[slot])
         dec = bt.decoder_of(fname, slot)
+        fkey = ("field", oid, slot)                              # one operation per slot: fields that share a slot (text of one row) share it
+        if fkey not in self.memo:
+            self.memo[fkey] = self.P.op(abi.X_FIELD, abi.T_F64 if dt.kind == "f" else abi.T_I64, a=oid, aux=slot)
         if dt.kind == "f":
-            return XV(self.P.op(abi.X_FIELD, abi.T_F64, a=oid, aux=slot), "f")
-        return XV(self.P.op(abi.X_FIELD, abi.T_I64, a=oid, aux=slot), "i", dec=dec, rng=(0, len(dec) - 1) if dec is not None else None)
+            return XV(self.memo[fkey], "f")
+        rng = (0, len(dec) - 1) if dec is not None else _slot_range(bt, slot)
+        return XV(self.memo[fkey], "i", dec=dec, rng=rng)
 
     # -- expressions ----------------------------------------------------------------------------------
     def as_int(self, v, what):
@@ -277,7 +285,10 @@ class Compiler:
         if isinstance(v, Text):
             coded = self.eng.dict_column(v.arr)
             if coded is not None:
-                return self.code_set(self.text_as_int(v), fns[mode])
+                try:
+                    return self.code_set(self.text_as_int(v), fns[mode])
+                except UnsupportedQuery:
+                    pass                                              # too many scattered codes: test the text itself
             return XV(self.P.op(abi.X_STR, abi.T_BOOL, col=self.eng.column(v.arr), aux=mode, text=text), "b")
         if isinstance(v, XV) and v.dec is not None:
             return self.code_set(v, fns[mode])
@@ -390,6 +401,20 @@ class Compiler:
             if not hasattr(bt, "table") or _table_signature(bt) != sig:
                 return False
         return True
+
+
+def _slot_range(bt, slot):
+    """(lo, hi) of an int payload slot when the build recorded where its values came from."""
+    rng = getattr(bt, "slot_rng", {}).get(slot)
+    if rng is not None:
+        return rng
+    cols = getattr(bt, "slot_cols", None)
+    if cols is not None and slot < len(cols) and cols[slot].dtype == abi.I64 and cols[slot].nrows:
+        return cols[slot].minmax()
+    plain = bt.slot_plain.get(slot) if bt.slot_plain else None
+    if plain is not None:
+        return (plain[0], plain[0] + plain[1] - 1)
+    return None
 
 
 def _table_signature(bt):
@@ -532,8 +557,17 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
         vfields = op.val.fields if val_is_record else ([] if (isinstance(op.val, Const) and op.val.value is True) else [(None, op.val)])
         accumulate = op.out in accumulate_into
 
-        def compile_build(env):
+        def compile_build(env, coded=True):
+            """coded: text payloads of low-cardinality columns travel as dictionary codes (later loops can compare
+            and group them cheaply); if that needs more payload slots than an entry has, every text field falls
+            back to the shared row reference."""
             c = Compiler(eng, op, htab, env)
+            if coded:
+                # a row reference is one slot however many text fields share it; a dictionary code is a slot per field.
+                # So once one text payload needs the reference (its column has too many distinct values to code), all take it.
+                for _, e in vfields:
+                    if isinstance(e, Col) and htab.cols.get(e.name) is not None and htab.cols[e.name].dtype.kind == "U" and eng.dict_column(htab.cols[e.name]) is None:
+                        coded = False
             gates, _ = gates_of(c, op.conds)
             parts = c.key_parts(key_fields)
             flat = [v for _, vs, _ in parts for v in vs]
@@ -548,14 +582,14 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
                     bounds = r
             else:
                 kid = c.P.op(abi.X_PACK2, abi.T_I64, a=flat[0].id, b=flat[1].id)
-            val_fields, pay_ids, dtypes, decoders = [], [], [], {}
+            val_fields, pay_ids, dtypes, decoders, field_decoders, slot_rng = [], [], [], {}, {}, {}
             for fname, e in vfields:
                 if len(key_fields) == 1 and repr(e) == repr(key_fields[0][1]):
                     val_fields.append((fname, "key"))
                     continue
                 v = c.value(e)
                 if isinstance(v, Text):
-                    v = c.text_as_int(v)
+                    v = c.text_as_int(v, coded_ok=coded)
                 if not isinstance(v, XV) or v.t == "b":
                     raise UnsupportedQuery("line %d: a build payload must be a number or a text: %r" % (op.lineno, e))
                 j = next((j for j, pid in enumerate(pay_ids) if pid == v.id), None)
@@ -564,11 +598,19 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
                     pay_ids.append(v.id); dtypes.append(np.dtype(np.float64 if v.t == "f" else np.int64))
                     if v.dec is not None:
                         decoders[j] = v.dec
+                    elif v.t == "i":
+                        r = c.resolve_rng(v)
+                        if r is not None:
+                            slot_rng[j] = r
+                if v.dec is not None:
+                    field_decoders[fname] = v.dec                  # text fields of one row share a row-reference slot: the text differs per field
                 val_fields.append((fname, j))
             if len(pay_ids) > abi.MAX_PAYLOAD:
+                if coded:
+                    return compile_build(env, False)
                 raise UnsupportedQuery("line %d: more than %d distinct payload values per entry" % (op.lineno, abi.MAX_PAYLOAD))
             c.P.gates, c.P.key, c.P.vals = gates, kid, pay_ids
-            return c, key_names, bounds, val_fields, dtypes, decoders, (flat[0].dec if len(flat) == 1 else [v.dec for v in flat]), len(flat) == 2
+            return c, key_names, bounds, val_fields, dtypes, (decoders, field_decoders, slot_rng), (flat[0].dec if len(flat) == 1 else [v.dec for v in flat]), len(flat) == 2
 
         def run_build(env):
             st = state.get("c")
@@ -583,7 +625,7 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
             if table is None:
                 table = ctx.xbuild(n, c.P, bounds[0], bounds[1], accumulate=accumulate)
             bt = BuiltTable(table, key_names[0], key_is_record, val_fields, val_is_record, dtypes)
-            bt.decoders = dict(decoders)
+            bt.decoders, bt.field_decoders, bt.slot_rng = dict(decoders[0]), dict(decoders[1]), dict(decoders[2])
             if composite:
                 bt.key_parts = key_names
                 bt.key_part_decoders = key_dec
@@ -637,6 +679,7 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
             return c, kid, vals, count_idx, bounds, flat
         cb, kid, _, _, bounds, flat = half(False)
         cb.P.key = kid
+        state["part_decs"] = [v.dec for v in flat] if len(flat) == 2 else None
         cp, pkid, vals, count_idx, _, _ = half(True)
         cp.P.vals = vals
         key_names = [nm or (e.name if isinstance(e, Col) else "key%d" % i) for i, (nm, e) in enumerate(key_fields)]
@@ -646,10 +689,14 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
         mode = state.get("mode")
         if mode is None:
             bt = env.get(op.probe.dict_name) if op.probe is not None else None
-            if groups_by_entry(op) and isinstance(bt, BuiltTable) and bt.table.accumulate and bt.agg is None and not _is_key_set(bt):
-                mode = "entry"
+            entry_ok = groups_by_entry(op) and isinstance(bt, BuiltTable) and bt.table.accumulate and bt.agg is None and not _is_key_set(bt)
+            state["entry_ok"] = entry_ok
+            if entry_ok and any(isinstance(e, Col) for _, e in key_fields):
+                mode = "entry"                                     # the probe key is part of the group: the group IS the matched entry
+            elif as_table:
+                mode = "large"                                     # a dictionary that later loops look up must be a table
             else:
-                mode = "large" if as_table else "groups"          # a dictionary that later loops look up must be a table
+                mode = "groups"                                    # fields of the entry only: usually a handful of groups (else see below)
             state["mode"] = mode
         if mode == "entry":
             bt = env[op.probe.dict_name]
@@ -689,15 +736,21 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
                         vf.append((nm, np.asarray(cnts, np.int64)))
                     else:
                         vf.append((nm, np.ascontiguousarray(vals[:, at]))); at += 1
-                return DictResult(kf, vf, key_is_record, val_is_record)
+                d = DictResult(kf, vf, key_is_record, val_is_record)
+                if any(kind[0] == "int" and kind[1] is not None for _, _, kind in parts):
+                    from .engine import _merge_equal_keys
+                    d = _merge_equal_keys(d)                          # two references may decode to the same text
+                return d
             except abi.SdqhError as exc:
                 if exc.code != abi.ERR_OVERFLOW:
                     raise
-                state["mode"], state["c"] = "large", None              # more groups than the LDS table holds
+                state["mode"], state["c"] = ("entry" if state.get("entry_ok") else "large"), None      # more groups than the LDS table holds
+                return run_aggregate(env)
             except UnsupportedQuery:
                 if state.get("c") is not None:
                     raise
-                state["mode"] = "large"
+                state["mode"] = "entry" if state.get("entry_ok") else "large"
+                return run_aggregate(env)
         st = state.get("c")
         if st is None or not (st[0].still_valid(env) and st[1].still_valid(env)):
             st = state["c"] = compile_large(env)
@@ -716,6 +769,7 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
         bt = BuiltTable(table, key_names[0], key_is_record, [], val_is_record, [])
         if composite:
             bt.key_parts = key_names
+            bt.key_part_decoders = state.get("part_decs")
         bt.key_decoder = key_dec
         bt.agg = ([(key_names[0], "key")], vnames, count_idx, key_is_record, val_is_record, len(vals))
         hidden = op.out + "$groups"

@@ -235,6 +235,13 @@ def test_open_vocabulary_queries_against_the_reference(hip_engine, golden_wide, 
     oracle_engine.clear()
 
 
+def test_every_golden_vector_through_specialised_kernels(hip_engine, golden, golden_more, golden_wide):
+    """All reference results again with every table loop forced through a run-time specialised kernel
+    (no ahead-of-time kernel shape): the general path must agree with the tuned one on its home turf."""
+    assert helpers.check_all_goldens_as_programs(hip_engine, [golden, golden_more, golden_wide], REL, 1e-10, "hip") >= 70
+    hip_engine.clear()
+
+
 def test_row_programs_specialised_kernels(hip_engine):
     """ABI 4: every sdqh_x* entry point — kernels specialised at run time (hiprtc) on the program —
     against numpy, on the cases the CPU implementation is pinned with; at three sizes around the

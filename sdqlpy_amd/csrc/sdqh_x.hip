@@ -373,6 +373,42 @@ bool load_headers(JitState& J) {
     return true;
 }
 
+// The kernel of a program depends on its STRUCTURE only (operations, operand wiring, which operations share a
+// column / table / constant slot, string constants, outputs, sink): a cheap hash of that finds the function of
+// a plan that has run before without regenerating its source.
+uint64_t structure_hash(const XInfo& x, Sink sink, bool direct) {
+    const sdqh_program* p = x.p;
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { for (int i = 0; i < 8; ++i) { h ^= (v >> (8 * i)) & 0xFF; h *= 1099511628211ull; } };
+    mix((uint64_t)sink * 2 + (direct ? 1 : 0)); mix((uint64_t)p->nops); mix((uint64_t)(int64_t)p->key); mix((uint64_t)(int64_t)x.probe_op);
+    for (int k = 0; k < p->nops; ++k) {
+        const sdqh_xop& o = p->ops[k];
+        mix(((uint64_t)(uint32_t)o.code << 32) | (uint32_t)o.type); mix(((uint64_t)(uint32_t)o.a << 32) | (uint32_t)o.b); mix(((uint64_t)(uint32_t)o.c << 32) | (uint32_t)o.aux);
+        mix(((uint64_t)(uint32_t)x.col_of[k] << 32) | (uint32_t)x.tab_of[k]); mix(((uint64_t)(uint32_t)x.const_of[k] << 32) | (uint32_t)x.str_off[k]);
+        if (o.code == SDQH_X_STR || o.code == SDQH_X_STRIDX) { mix((uint64_t)o.slen); for (int i = 0; i < o.slen; ++i) mix(o.str[i]); }
+    }
+    mix((uint64_t)p->ngates); for (int g = 0; g < p->ngates; ++g) mix((uint64_t)p->gates[g]);
+    mix((uint64_t)p->nvals); for (int v = 0; v < p->nvals; ++v) mix((uint64_t)p->vals[v]);
+    return h;
+}
+
+int specialise(sdqh_ctx* ctx, const std::string& source, hipFunction_t* fn);
+
+int kernel_for(sdqh_ctx* ctx, const XInfo& x, Sink sink, bool direct, hipFunction_t* fn) {
+    JitState& J = jit();
+    char name[64];
+    std::snprintf(name, sizeof(name), "s%016llx@%d", (unsigned long long)structure_hash(x, sink, direct), ctx->device);
+    if (!ctx->compile_only) {
+        std::lock_guard<std::mutex> lock(J.mu);
+        auto hit = J.kernels.find(name);
+        if (hit != J.kernels.end()) { *fn = hit->second; return SDQH_OK; }
+    }
+    if (int rc = specialise(ctx, generate(x, sink, direct), fn)) return rc;
+    std::lock_guard<std::mutex> lock(J.mu);
+    J.kernels[name] = *fn;
+    return SDQH_OK;
+}
+
 int specialise(sdqh_ctx* ctx, const std::string& source, hipFunction_t* fn) {
     JitState& J = jit();
     std::lock_guard<std::mutex> lock(J.mu);
@@ -499,7 +535,7 @@ int sdqh_xscan_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, doubl
     XInfo x;
     if (int rc = analyse(ctx, nrows, prog, SDQH_TUPLE_MAX_VALUES, false, true, &x)) return rc;
     hipFunction_t fn;
-    if (int rc = specialise(ctx, generate(x, SINK_SUM, x.direct), &fn)) return rc;
+    if (int rc = kernel_for(ctx, x, SINK_SUM, x.direct, &fn)) return rc;
     call_begin(ctx);
     XArgs a;
     int32_t* d_flags = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->result_dev) + 1024);
@@ -532,7 +568,7 @@ int sdqh_xgroupby(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int ma
     XInfo x;
     if (int rc = analyse(ctx, nrows, prog, SDQH_TUPLE_MAX_VALUES, true, true, &x)) return rc;
     hipFunction_t fn;
-    if (int rc = specialise(ctx, generate(x, SINK_GROUP, x.direct), &fn)) return rc;
+    if (int rc = kernel_for(ctx, x, SINK_GROUP, x.direct, &fn)) return rc;
     call_begin(ctx);
     // result block in ctx->result_dev: gkeys[LG_SLOTS] | acc[LG_SLOTS][4] | cnt[LG_SLOTS] | flags
     char* rd = static_cast<char*>(ctx->result_dev);
@@ -590,7 +626,7 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
     XInfo x;
     if (int rc = analyse(ctx, nrows, prog, SDQH_MAX_PAYLOAD, true, false, &x)) return rc;
     hipFunction_t fn;
-    if (int rc = specialise(ctx, generate(x, SINK_STAGE, false), &fn)) {
+    if (int rc = kernel_for(ctx, x, SINK_STAGE, false, &fn)) {
         if (!ctx->compile_only || ctx->err.find("kernel specialised") == std::string::npos) return rc;
         sdqh_table* dummy = new sdqh_table();                 // compile-only: a table later programs can name (never dereferenced)
         dummy->npay = prog->nvals; dummy->accumulate = accumulate != 0; dummy->stage.acc_stride = 4;
@@ -638,7 +674,9 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
         }
         call_end(ctx);
         int f = 0;
-        if (!rc) rc = read_flags(ctx, flags, &f);
+        const int kc = prog->ops[prog->key].code;
+        const bool can_fail = bounded || kc == SDQH_X_PACK2 || kc == SDQH_X_SELECT;      // otherwise nothing can raise a flag: no round trip
+        if (!rc && can_fail) rc = read_flags(ctx, flags, &f);
         if (!rc && (f & 2)) rc = fail(ctx, SDQH_ERR_UNSUPPORTED, "xbuild: a key outside the given bounds / a key part outside [0, 2^32)");
     }
     if (rc) { tb_release(ctx, tb); delete tb; return rc; }
@@ -655,7 +693,7 @@ int sdqh_xkey_set(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_
     if (key_lo <= INT64_MIN / 2 || key_hi >= INT64_MAX / 2 || (uint64_t)(key_hi - key_lo) + 1 > (1ull << 31))
         return fail(ctx, SDQH_ERR_UNSUPPORTED, "xkey_set: key range too wide for a bitmap");
     hipFunction_t fn;
-    if (int rc = specialise(ctx, generate(x, SINK_KEYSET, false), &fn)) {
+    if (int rc = kernel_for(ctx, x, SINK_KEYSET, false, &fn)) {
         if (!ctx->compile_only || ctx->err.find("kernel specialised") == std::string::npos) return rc;
         sdqh_table* dummy = new sdqh_table();
         dummy->bitmap_only = true; dummy->index_built = true;
@@ -701,7 +739,7 @@ int sdqh_xprobe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog
     if (prog->nvals > table->stage.acc_stride) return fail(ctx, SDQH_ERR_INVALID, "xprobe_aggregate: the table's entries have room for fewer values than the program sums");
     x.probe_op = lookup_op;
     hipFunction_t fn;
-    if (int rc = specialise(ctx, generate(x, SINK_ENTRY, false), &fn)) return rc;
+    if (int rc = kernel_for(ctx, x, SINK_ENTRY, false, &fn)) return rc;
     table->compact_valid = false;
     table->nv = prog->nvals;
     call_begin(ctx);

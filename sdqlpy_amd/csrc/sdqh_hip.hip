@@ -235,6 +235,24 @@ int ensure_minmax(sdqh_ctx* ctx, sdqh_column* c) {
     return SDQH_OK;
 }
 
+// Do neighbouring rows of an I64 column hold near-by values (a fact table clustered on this key)?  Sampled once
+// per column on the host side of a tiny download: 2048 adjacent pairs spread over the column; "near" = within 4096.
+bool column_is_clustered(sdqh_ctx* ctx, sdqh_column* c) {
+    if (c->clustered >= 0) return c->clustered == 1;
+    if (c->dtype != SDQH_I64 || c->nrows < 4096) { c->clustered = 1; return true; }
+    const int samples = 2048;
+    const int64_t step = (c->nrows - 2) / samples;
+    int64_t* host = static_cast<int64_t*>(ctx->result_host);              // 64 KiB pinned: 2048 pairs = 32 KiB
+    bool ok = true;
+    for (int i = 0; i < samples && ok; ++i)
+        ok = hipMemcpyAsync(host + 2 * i, static_cast<const int64_t*>(c->data) + (int64_t)i * step, 16, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+    if (!ok || hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipGetLastError(); return true; }
+    int near = 0;
+    for (int i = 0; i < samples; ++i) { const int64_t d = host[2 * i + 1] - host[2 * i]; near += (d >= -4096 && d <= 4096) ? 1 : 0; }
+    c->clustered = near * 10 >= samples * 9 ? 1 : 0;
+    return c->clustered == 1;
+}
+
 // ---- dispatch onto the compiled menu of kernel instances -------------------------------------------
 template <int S> using ShapeC = std::integral_constant<int, S>;
 template <class Fn>
@@ -381,6 +399,9 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "stage_eager_pay" && (value == 0 || value == 1)) ctx->opt_stage_eager_pay = (int)value;
     else if (n == "stage_waves_per_cu" && value >= 4 && value <= 64) ctx->opt_stage_waves_per_cu = (int)value;
     else if (n == "direct_index" && (value == 0 || value == 1)) ctx->opt_direct_index = (int)value;
+    else if (n == "row_pack" && (value == 0 || value == 1)) ctx->opt_row_pack = (int)value;
+    else if (n == "coarse_kb" && value >= 0 && value <= 96) ctx->opt_coarse_kb = (int)value;
+    else if (n == "packed_slots" && (value == 0 || value == 1)) ctx->opt_packed_slots = (int)value;
     else if (n == "groupby_regs" && (value == 0 || value == 4 || value == 8)) ctx->opt_groupby_regs = (int)value;
     else return fail(ctx, SDQH_ERR_INVALID, "set_option: unknown option or value out of range: " + n);
     return SDQH_OK;
@@ -469,7 +490,15 @@ int sdqh_column_minmax(sdqh_ctx* ctx, const sdqh_column* col, int64_t* mn, int64
 }
 void sdqh_column_free(sdqh_ctx* ctx, sdqh_column* col) {
     if (!col) return;
-    if (ctx) { if (col->owned) pool_free(ctx, col->data); pool_free(ctx, col->d_minmax); }
+    if (ctx) {
+        for (size_t i = 0; i < ctx->packs.size();) {                 // a row pack does not outlive any of its columns
+            auto& pk = ctx->packs[i];
+            if (std::find(pk.cols.begin(), pk.cols.end(), (const void*)col->data) != pk.cols.end()) { pool_free(ctx, pk.data); ctx->packs.erase(ctx->packs.begin() + (long)i); }
+            else ++i;
+        }
+        if (col->owned) pool_free(ctx, col->data);
+        pool_free(ctx, col->d_minmax);
+    }
     delete col;
 }
 
@@ -735,13 +764,17 @@ static int ensure_index(sdqh_ctx* ctx, sdqh_table* tb) {
         if (!tb->refs_prefilled) LAUNCH(ctx, "k_fill_refs", k_fill_refs, (unsigned)ctx->num_cu * 2, tb->stage, tb->dev);
         LAUNCH(ctx, "k_insert_direct", k_insert_direct, seg_grid, tb->stage, tb->dev);
     } else {                                                               // hash layout
-        int64_t* keys = static_cast<int64_t*>(table_alloc(ctx, tb, (tb->capmax + 2) * 8));
-        uint32_t* rowref = static_cast<uint32_t*>(table_alloc(ctx, tb, (tb->capmax + 2) * 4));
-        if (!keys || !rowref) return fail(ctx, SDQH_ERR_NOMEM, "table index: out of device memory");
-        tb->dev.keys = keys; tb->dev.rowref = rowref;
-        LAUNCH(ctx, "k_clear", k_clear, (unsigned)ctx->num_cu * 4, tb->stage.seg_count, tb->stage.nseg, tb->capmax, tb->hdr, keys, rowref);
+        // tables with payload get packed 32-byte slots (key, payload 0 / 1, owner row): one line per probe hit
+        const bool packed = ctx->opt_packed_slots && tb->npay >= 1 && tb->capmax <= (1ull << 27);
+        int64_t* keys = nullptr; uint32_t* rowref = nullptr; int64_t* slots = nullptr;
+        if (packed) slots = static_cast<int64_t*>(table_alloc(ctx, tb, (tb->capmax + 2) * 32));
+        else { keys = static_cast<int64_t*>(table_alloc(ctx, tb, (tb->capmax + 2) * 8)); rowref = static_cast<uint32_t*>(table_alloc(ctx, tb, (tb->capmax + 2) * 4)); }
+        if (packed ? !slots : (!keys || !rowref)) return fail(ctx, SDQH_ERR_NOMEM, "table index: out of device memory");
+        tb->dev.keys = keys; tb->dev.rowref = rowref; tb->dev.slots = slots;
+        LAUNCH(ctx, "k_clear", k_clear, (unsigned)ctx->num_cu * 4, tb->stage.seg_count, tb->stage.nseg, tb->capmax, tb->hdr, keys, rowref, slots);
         LAUNCH(ctx, "k_insert", k_insert, seg_grid, tb->stage, tb->dev);
         LAUNCH(ctx, "k_insert_fixup", k_insert_fixup, seg_grid, tb->stage, tb->dev);
+        if (packed) LAUNCH(ctx, "k_insert_repack", k_insert_repack, seg_grid, tb->stage, tb->dev);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, std::string("table index launch: ") + hipGetErrorString(e));
@@ -1353,6 +1386,12 @@ static int make_source(sdqh_ctx* ctx, const sdqh_source& s, int64_t nrows, int n
     const sdqh_table* t = lookups[s.lookup].table;
     if (t->bitmap_only || s.field < 0 || s.field >= t->npay) return fail(ctx, SDQH_ERR_INVALID, std::string(what) + ": no such payload field");
     d->lookup = s.lookup; d->field = s.field;
+    // where the payload is read from, resolved here (the table's index exists: make_lookups ensured it) — see DevSource
+    const bool direct = t->dev.dense_arr || (t->dev.bm && t->dev.bm_shift == 0);
+    if (t->dev.slots && !direct) {
+        d->col = t->dev.slots;
+        if (s.field < 2) d->pack = 1; else { d->pack = 2; d->col2 = t->dev.pay[s.field]; }
+    } else { d->pack = 0; d->col = t->dev.pay[s.field]; }
     return SDQH_OK;
 }
 
@@ -1468,6 +1507,57 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
     spec.nkeys = nkeys; spec.shape = tuple_shape;
     for (int k = 0; k < nkeys; ++k) if (int rc = make_source(ctx, keys[k], nrows, nlookups, lookups, nlookups, "group key", &spec.key[k])) return rc;
     for (int j = 0; j < nops; ++j) if (int rc = make_source(ctx, operands[j], nrows, nlookups, lookups, nlookups, "tuple operand", &spec.op[j])) return rc;
+    // Coarse key filter in LDS for the first lookup when its keys come in no order and its bitmap does not fit L1
+    size_t coarse_lds = 0;
+    if (ctx->opt_coarse_kb > 0 && nlookups > 0 && nrows >= (1 << 22) && lookups[0].key[0].kind == SDQH_SRC_COLUMN && lookups[0].key[0].col->dtype == SDQH_I64) {
+        sdqh_table* t0 = const_cast<sdqh_table*>(lookups[0].table);
+        const bool part_bitmap = t0->bm && !t0->dev.lin_rb && (lookups[0].nkey == 1 ? t0->dev.bm_shift == 0 : t0->dev.bm_shift != 0);
+        if (part_bitmap && t0->nwords * 4 > (32u << 10) && !column_is_clustered(ctx, const_cast<sdqh_column*>(lookups[0].key[0].col))) {
+            if (!t0->coarse) {
+                const uint64_t nbits = t0->nwords * 32, budget = (uint64_t)ctx->opt_coarse_kb * 1024 * 8;
+                int shift = 0;
+                while ((nbits >> shift) > budget) ++shift;
+                const int cwords = (int)(((nbits >> shift) + 32) / 32);
+                uint32_t* c = static_cast<uint32_t*>(table_alloc(ctx, t0, (size_t)cwords * 4 + 64));
+                if (c) {
+                    LAUNCH(ctx, "k_coarsen", k_coarsen, (unsigned)std::min<int>((cwords + TPB - 1) / TPB, ctx->num_cu * 4), t0->bm, nbits, shift, c, cwords);
+                    t0->coarse = c; t0->coarse_words = cwords; t0->coarse_shift = shift;
+                }
+            }
+            if (t0->coarse && t0->coarse_shift > 0) { L.coarse = t0->coarse; L.coarse_words = t0->coarse_words; L.coarse_shift = t0->coarse_shift; coarse_lds = (size_t)t0->coarse_words * 4; }
+        }
+    }
+    // Row pack: every plain column the drain gathers (lookup key parts, group key parts, operands), interleaved once
+    // and kept resident.  Only worth it for big scans with several gathered columns.
+    if (ctx->opt_row_pack && nlookups > 0 && nrows >= (1 << 20)) {
+        std::vector<DevSource*> srcs;
+        for (int l = 0; l < nlookups; ++l) for (int k = 0; k < L.l[l].nkey; ++k) srcs.push_back(&L.l[l].key[k]);
+        for (int k = 0; k < nkeys; ++k) srcs.push_back(&spec.key[k]);
+        for (int j = 0; j < nops; ++j) srcs.push_back(&spec.op[j]);
+        std::vector<const void*> cols;
+        for (DevSource* sr : srcs) if (sr->kind == SDQH_SRC_COLUMN && std::find(cols.begin(), cols.end(), (const void*)sr->col) == cols.end()) cols.push_back(sr->col);
+        if (cols.size() >= 5 && cols.size() <= (size_t)MAX_PACK && (size_t)nrows * cols.size() * 8 <= ((size_t)48 << 30)) {
+            const int k = (int)((cols.size() + 1) & ~(size_t)1);               // even: rows stay 16-byte aligned
+            sdqh_ctx::RowPack* found = nullptr;
+            for (auto& pk : ctx->packs) if (pk.cols == cols && pk.nrows == nrows) found = &pk;
+            if (!found) {
+                void* data = pool_alloc(ctx, (size_t)nrows * (size_t)k * 8 + 64);
+                if (data) {
+                    DevPackCols pc; std::memset(&pc, 0, sizeof(pc));
+                    for (size_t j = 0; j < cols.size(); ++j) pc.col[j] = static_cast<const int64_t*>(cols[j]);
+                    pc.ncols = (int)cols.size(); pc.k = k;
+                    LAUNCH(ctx, "k_interleave", k_interleave, (unsigned)std::min<int64_t>((nrows + TPB - 1) / TPB, (int64_t)ctx->num_cu * 16), pc, nrows, static_cast<int64_t*>(data));
+                    ctx->packs.push_back({cols, nrows, k, data});
+                    found = &ctx->packs.back();
+                }
+            }
+            if (found) {
+                L.pack = static_cast<const int64_t*>(found->data); L.pack_k = found->k;
+                for (DevSource* sr : srcs) if (sr->kind == SDQH_SRC_COLUMN)
+                    sr->pack = 1 + (int)(std::find(cols.begin(), cols.end(), (const void*)sr->col) - cols.begin());
+            }
+        }
+    }
     // result block in ctx->result_dev: gkeys[LG_SLOTS] | acc[LG_SLOTS][4] | cnt[LG_SLOTS] | flags
     char* rd = static_cast<char*>(ctx->result_dev);
     unsigned long long* r_keys = reinterpret_cast<unsigned long long*>(rd);
@@ -1481,13 +1571,15 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
         return with_scan_filter(f, [&](auto FC) {
             auto kern = k_lookup_agg<decltype(S)::value, decltype(FC)>;
             grid = stream_grid(ctx, kern, nrows, TPB * ROWS_PER_LOAD * LOOKUP_PU * ctx->opt_probe_chunk);
+            if (coarse_lds) grid = std::min<unsigned>(grid, (unsigned)ctx->num_cu * (unsigned)std::max<size_t>(1, ((size_t)156 << 10) / (((size_t)24 << 10) + coarse_lds)));   // what really fits with the dynamic LDS
             const size_t nslots = (size_t)grid * LG_SLOTS;
             blob = static_cast<char*>(pool_alloc(ctx, nslots * 40 + 256));
             if (!blob) return fail(ctx, SDQH_ERR_NOMEM, "lookup_aggregate: out of device memory");
             double* pacc = reinterpret_cast<double*>(blob);
             int64_t* pcnt = reinterpret_cast<int64_t*>(blob + nslots * 32);
             { FillList fl; fl.add(r_keys, LG_SLOTS * 8, 0xFF); fl.add(r_flags, 8, 0); launch_fill(ctx, fl); }
-            LAUNCH(ctx, "k_lookup_agg", kern, grid, f, L, spec, nrows, r_keys, pacc, pcnt, r_flags, ctx->opt_probe_chunk);
+            LAUNCH_LDS(ctx, "k_lookup_agg", kern, grid, coarse_lds, f, L, spec, nrows, r_keys, pacc, pcnt, r_flags, ctx->opt_probe_chunk);
+            (void)0;
             LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, r_keys, pacc, pcnt, (int)grid, r_acc, r_cnt);
             call_end(ctx);
             return SDQH_OK;

@@ -63,6 +63,12 @@ struct sdqh_ctx {
     int opt_stage_eager_pay = 0;                   // measured after the queued stage output: gathers for the ~10 % survivors beat streaming every payload row
     int opt_stage_waves_per_cu = 12;               // tuned k_stage family: fewer, longer streams (12 x 256 x 5 columns) keep DRAM pages open; 24 was 15 % slower, 8 latency-bound
     int opt_direct_index = 1;
+    int opt_packed_slots = 1;                      // hash-layout tables with payload: 32-byte slots { key, payload 0 / 1, owner row }
+    int opt_coarse_kb = 0;                         // LDS budget (KiB) of the coarse key filter in front of an unclustered first lookup; 0 = off (default: on Q9 the
+                                                   // occupancy its LDS costs outweighs the L2 requests it saves — 0.70 -> 0.67 ms at 32 KiB, 1.4 ms at 64 KiB)
+    int opt_row_pack = 1;                          // final loops with lookups gather their columns from an interleaved row pack (see DevLookups)
+    struct RowPack { std::vector<const void*> cols; int64_t nrows; int k; void* data; };
+    std::vector<RowPack> packs;                    // resident row packs, by column set
     int opt_groupby_regs = 0;                      // 0 = adaptive (4 when the last run of these key columns had <= 4 groups), 4, 8
     const void* g4_hint[SDQH_MAX_GROUPKEYS] = {nullptr, nullptr};
 };
@@ -75,6 +81,7 @@ struct sdqh_column {
     bool owned = false;
     long long* d_minmax = nullptr;     // device [2], I64 only
     bool minmax_pending = false, have_minmax = false;
+    int clustered = -1;                // -1 unknown; 1: neighbouring rows hold near-by values (sampled), 0: no order
     int64_t mn = 0, mx = 0;
     size_t row_bytes() const { return dtype == SDQH_STR ? (size_t)width * 4 : 8; }
 };
@@ -99,6 +106,7 @@ struct sdqh_table {
     DevCompactOut compact{};
     uint32_t* seg_kept = nullptr;
     int nv = SDQH_TUPLE_MAX_VALUES;    // value count of the tuple aggregated into the table
+    uint32_t* coarse = nullptr; int coarse_words = 0, coarse_shift = 0;     // coarse key filter (see DevLookups), built on first need
 };
 
 

@@ -125,7 +125,14 @@ struct DevTable {
                               //    linearised offset (a - bm_lo) * lin_rb + (b - lin_b0) (direct layout, bm_shift == 0)
     const uint32_t* alias;    // sdqh_table_share_groups: stage row -> the stage row whose accumulators it uses, or null
     int32_t acc_stride, _pad3; // doubles per entry in sacc: 4, or the tuple's value count when it is known at build time (sdqh_groupby_key)
+    int64_t* slots;           // hash layout, packed form (tables with payload): slot h = { key, payload 0, payload 1, stage row } in 32
+                              //    bytes, so a probe that hits finds the key, the owner and the first two payload fields in ONE
+                              //    cache line instead of four (keys[], rowref[], pay[0][], pay[1][]); keys / rowref are null then
 };
+
+// hash-layout accessors (separate arrays, or the packed 32-byte slots)
+__device__ __forceinline__ int64_t slot_key(const DevTable& t, uint64_t h) { return t.slots ? t.slots[h * 4] : t.keys[h]; }
+__device__ __forceinline__ uint32_t slot_row(const DevTable& t, uint64_t h) { return t.slots ? (uint32_t)t.slots[h * 4 + 3] : t.rowref[h]; }
 
 // offset of `key` in a bitmap described by bm_lo / bm_hi / bm_shift / lin_rb / lin_b0 (DevTable or DevStage); false = out of range
 template <class T>
@@ -370,10 +377,10 @@ __device__ __forceinline__ bool table_contains(const DevTable& t, int64_t key, u
         uint64_t off = (uint64_t)(key - t.bm_lo);
         return (t.bm[off >> 5] >> (off & 31)) & 1u;
     }
-    if (key == EMPTY_KEY) return t.rowref[cap_mask + 1] != NO_ROW;
+    if (key == EMPTY_KEY) return slot_row(t, cap_mask + 1) != NO_ROW;
     uint64_t h = hash_key(key) & cap_mask;
     for (;;) {
-        int64_t k = t.keys[h];
+        int64_t k = slot_key(t, h);
         if (k == key) return true;
         if (k == EMPTY_KEY) return false;
         h = (h + 1) & cap_mask;
@@ -400,10 +407,10 @@ __device__ __forceinline__ int64_t table_find(const DevTable& t, int64_t key, ui
         if (t.bitmap_only) return 0;
         if (t.bm_shift == 0) return direct_rank(t, off, word);
     }
-    if (key == EMPTY_KEY) return t.rowref[cap_mask + 1] != NO_ROW ? (int64_t)(cap_mask + 1) : -1;
+    if (key == EMPTY_KEY) return slot_row(t, cap_mask + 1) != NO_ROW ? (int64_t)(cap_mask + 1) : -1;
     uint64_t h = hash_key(key) & cap_mask;
     for (;;) {
-        int64_t k = t.keys[h];
+        int64_t k = slot_key(t, h);
         if (k == key) return (int64_t)h;
         if (k == EMPTY_KEY) return -1;
         h = (h + 1) & cap_mask;
@@ -411,7 +418,7 @@ __device__ __forceinline__ int64_t table_find(const DevTable& t, int64_t key, ui
 }
 // stage index of the entry at an index position
 __device__ __forceinline__ bool table_is_direct(const DevTable& t) { return t.dense_arr || (t.bm && t.bm_shift == 0); }     // no hash slots: cap_mask unused
-__device__ __forceinline__ uint32_t table_ref(const DevTable& t, int64_t pos) { return t.dense_arr ? (uint32_t)pos : (t.bm && t.bm_shift == 0 ? t.dense_ref[pos] : t.rowref[pos]); }
+__device__ __forceinline__ uint32_t table_ref(const DevTable& t, int64_t pos) { return t.dense_arr ? (uint32_t)pos : (t.bm && t.bm_shift == 0 ? t.dense_ref[pos] : slot_row(t, (uint64_t)pos)); }
 
 // ---- row filter on a pair of rows --------------------------------------------------------------
 // Integer and double range predicates with their own columns, plus the optional string equality.
@@ -1168,7 +1175,7 @@ __global__ __launch_bounds__(TPB) void k_stage(DevFilter f, DevProbes pr, DevSta
 // Every workgroup recomputes the staged total from the segment counts (a few KB from L2), so the
 // capacity is agreed on without a grid barrier; workgroup 0 publishes the header for later kernels.
 SDQH_KERNEL __launch_bounds__(TPB) void k_clear(const uint32_t* __restrict__ seg_count, int nseg, uint64_t capmax,
-                                               TableHeader* __restrict__ hdr, int64_t* __restrict__ keys, uint32_t* __restrict__ rowref) {
+                                               TableHeader* __restrict__ hdr, int64_t* __restrict__ keys, uint32_t* __restrict__ rowref, int64_t* __restrict__ slots) {
     __shared__ unsigned long long s_part[TPB];
     unsigned long long t = 0;
     for (int i = threadIdx.x; i < nseg; i += TPB) t += seg_count[i];
@@ -1181,9 +1188,16 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_clear(const uint32_t* __restrict__ seg
     if (cap > capmax) cap = capmax;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         hdr->cap_mask = cap - 1; hdr->staged = staged;
-        keys[cap] = EMPTY_KEY; rowref[cap] = NO_ROW;          // the extra slot that holds a real key == EMPTY_KEY
+        if (slots) { slots[cap * 4] = EMPTY_KEY; slots[cap * 4 + 3] = (int64_t)NO_ROW; }
+        else { keys[cap] = EMPTY_KEY; rowref[cap] = NO_ROW; }  // the extra slot that holds a real key == EMPTY_KEY
     }
     using V = long long __attribute__((ext_vector_type(2)));
+    if (slots) {                                               // packed: { EMPTY_KEY, 0 } { 0, NO_ROW } per slot, two 16-byte stores
+        const V a = {(long long)EMPTY_KEY, 0}, b = {0, (long long)NO_ROW};
+        V* s2 = reinterpret_cast<V*>(slots);
+        for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * TPB) { s2[2 * i] = a; s2[2 * i + 1] = b; }
+        return;
+    }
     const V empty = {(long long)EMPTY_KEY, (long long)EMPTY_KEY};
     V* k2 = reinterpret_cast<V*>(keys);
     for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < cap / 2; i += (uint64_t)gridDim.x * TPB) k2[i] = empty;
@@ -1289,14 +1303,22 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_insert(DevStage st, DevTable t) {
         const int64_t idx = base + i;
         const int64_t key = st.key[idx];
         if (key == EMPTY_KEY) {                                          // the sentinel value itself lives in the extra slot
-            if (atomicMin(&t.rowref[mask + 1], (uint32_t)idx) != NO_ROW) t.hdr->has_dups = 1;
+            uint32_t* ref = t.slots ? reinterpret_cast<uint32_t*>(&t.slots[(mask + 1) * 4 + 3]) : &t.rowref[mask + 1];
+            if (atomicMin(ref, (uint32_t)idx) != NO_ROW) t.hdr->has_dups = 1;
+            else if (t.slots) { t.slots[(mask + 1) * 4 + 1] = st.npay > 0 ? st.pay[0][idx] : 0; t.slots[(mask + 1) * 4 + 2] = st.npay > 1 ? st.pay[1][idx] : 0; }
             continue;
         }
         uint64_t h = hash_key(key) & mask;
         for (;;) {
-            unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&t.keys[h]),
+            unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(t.slots ? &t.slots[h * 4] : &t.keys[h]),
                                                (unsigned long long)EMPTY_KEY, (unsigned long long)key);
-            if (old == (unsigned long long)EMPTY_KEY) { t.rowref[h] = (uint32_t)idx; break; }   // claimed a fresh slot
+            if (old == (unsigned long long)EMPTY_KEY) {                  // claimed a fresh slot
+                if (t.slots) {
+                    t.slots[h * 4 + 1] = st.npay > 0 ? st.pay[0][idx] : 0; t.slots[h * 4 + 2] = st.npay > 1 ? st.pay[1][idx] : 0;
+                    t.slots[h * 4 + 3] = (int64_t)(uint32_t)idx;
+                } else t.rowref[h] = (uint32_t)idx;
+                break;
+            }
             if ((int64_t)old == key) { t.hdr->has_dups = 1; break; }      // duplicate build key: settled by k_insert_fixup
             h = (h + 1) & mask;
         }
@@ -1316,7 +1338,23 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_insert_fixup(DevStage st, DevTable t) 
     for (uint32_t i = lane_id(); i < count; i += WAVE) {
         const int64_t idx = base + i;
         const int64_t h = table_find(t, st.key[idx], mask);
-        if (h >= 0) atomicMin(&t.rowref[h], (uint32_t)idx);
+        if (h >= 0) atomicMin(t.slots ? reinterpret_cast<uint32_t*>(&t.slots[h * 4 + 3]) : &t.rowref[h], (uint32_t)idx);
+    }
+}
+// packed slots after a fix-up: the payload in the slot must be the owner's (its own launch: every atomicMin above has landed)
+SDQH_KERNEL __launch_bounds__(TPB) void k_insert_repack(DevStage st, DevTable t) {
+    if (t.hdr->has_dups == 0 || !t.slots) return;
+    const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
+    if (seg >= st.nseg) return;
+    const uint64_t mask = t.hdr->cap_mask;
+    const int64_t base = (int64_t)seg * st.seg_rows;
+    const uint32_t count = st.seg_count[seg];
+    for (uint32_t i = lane_id(); i < count; i += WAVE) {
+        const int64_t idx = base + i;
+        const int64_t h = table_find(t, st.key[idx], mask);
+        if (h >= 0 && slot_row(t, (uint64_t)h) == (uint32_t)idx) {
+            t.slots[h * 4 + 1] = st.npay > 0 ? st.pay[0][idx] : 0; t.slots[h * 4 + 2] = st.npay > 1 ? st.pay[1][idx] : 0;
+        }
     }
 }
 
@@ -1689,22 +1727,54 @@ __global__ __launch_bounds__(TPB) void k_scan_probe_sum(DevFilter f, DevProbes p
 // and everything that follows a surviving row (the chain of dependent lookups, payload gathers,
 // key packing) runs in the converged drain of an LDS candidate queue, one row per lane.
 // =================================================================================================
-struct DevSource { int32_t kind, lookup, field, _pad; const int64_t* col; };
+// pack: 1 + the column's position in the loop's row pack (DevLookups::pack), 0 = read the column itself
+// pack: COLUMN sources: 1 + the column's position in the loop's row pack (DevLookups::pack), 0 = read the column itself.
+//       LOOKUP sources: how the payload is read, resolved by the host (no selection among the tables' pointers on the device):
+//       0: col[entry] (col = the table's stage payload array of `field`); 1: col[slot * 4 + 1 + field] (col = packed hash slots);
+//       2: col2[(uint32_t)col[slot * 4 + 3]] (packed slots, a payload field beyond the two kept in the slot)
+struct DevSource { int32_t kind, lookup, field, pack; const int64_t* col; const int64_t* col2; };
 struct DevLookup { DevTable table; int32_t nkey, _pad; DevSource key[2]; };
-struct DevLookups { DevLookup l[SDQH_MAX_LOOKUP]; int32_t n, _pad; };
+// Row pack: the columns a loop GATHERS for its (sparse) surviving rows — key parts of later lookups, value
+// operands — interleaved row-major, pack[r * pack_k + j], built once per column set (k_interleave) and kept
+// resident.  A survivor then touches one or two cache lines instead of one per column: with 3-5 % of the
+// rows surviving, the column gathers of Q5 / Q9's final loops pulled 40-60 % of every gathered column's lines
+// for 8 useful bytes each.
+constexpr int MAX_PACK = 8;
+// Coarse key filter of the first lookup, held in LDS: bit j of `coarse` = "some key of the table lies in
+// [lo + j * 2^shift, lo + (j + 1) * 2^shift)".  When the probe keys arrive in no order (l_partkey), every row's
+// test of the table's exact key bitmap is its own L2 request — 60 M of them made Q9's final loop L2-request-bound
+// (88 M L2 reads for 3.2 M useful rows) — while a test in LDS costs nothing; only the rows that pass it go on to
+// the exact bitmap.  Built once per table (k_coarsen) and copied into LDS by every workgroup.
+struct DevLookups { DevLookup l[SDQH_MAX_LOOKUP]; int32_t n, pack_k; const int64_t* pack; const uint32_t* coarse; int32_t coarse_words, coarse_shift; };
+struct PackRow { int64_t v0, v1, v2, v3, v4, v5, v6, v7; };      // named, not an array: a run-time pick must stay a select chain on registers
+
+// all pack_k values of row r with 16-byte loads (pack_k is even: padded by the host), into registers
+__device__ __forceinline__ void pack_load(const DevLookups& L, int64_t r, PackRow& pr) {
+    using V = long long __attribute__((ext_vector_type(2)));
+    const V* p = reinterpret_cast<const V*>(L.pack + r * L.pack_k);
+    const V a = p[0];
+    V b = {0, 0}, c = {0, 0}, d = {0, 0};
+    if (L.pack_k > 2) b = p[1];
+    if (L.pack_k > 4) c = p[2];
+    if (L.pack_k > 6) d = p[3];
+    pr.v0 = a.x; pr.v1 = a.y; pr.v2 = b.x; pr.v3 = b.y; pr.v4 = c.x; pr.v5 = c.y; pr.v6 = d.x; pr.v7 = d.y;
+}
+__device__ __forceinline__ int64_t pack_pick(const PackRow& pr, int idx) {
+    return idx == 0 ? pr.v0 : idx == 1 ? pr.v1 : idx == 2 ? pr.v2 : idx == 3 ? pr.v3 : idx == 4 ? pr.v4 : idx == 5 ? pr.v5 : idx == 6 ? pr.v6 : pr.v7;
+}
 
 __device__ __forceinline__ uint32_t pick3(const uint32_t (&e)[SDQH_MAX_LOOKUP], int i) { return i == 0 ? e[0] : (i == 1 ? e[1] : e[2]); }
 
-__device__ __forceinline__ int64_t source_value(const DevSource& s, const DevLookups& L, int64_t r, const uint32_t (&ent)[SDQH_MAX_LOOKUP]) {
-    if (s.kind == SDQH_SRC_COLUMN) return s.col[r];
-    // select among the loaded pointers, never among addresses inside the by-value argument: an
-    // address select becomes a run-time index into L and forces a scratch copy of the whole struct
-    const int64_t* pay = nullptr;
-#pragma unroll
-    for (int l = 0; l < SDQH_MAX_LOOKUP; ++l)
-#pragma unroll
-        for (int q = 0; q < SDQH_MAX_PAYLOAD; ++q) { const int64_t* c = L.l[l].table.pay[q]; if (s.lookup == l && s.field == q) pay = c; }
-    const int64_t v = pay[pick3(ent, s.lookup)];
+// PACKED: the row's gathered columns are already in registers (pr); false: pr is never read
+template <bool PACKED = false>
+__device__ __forceinline__ int64_t source_value(const DevSource& s, const DevLookups& L, int64_t r, const uint32_t (&ent)[SDQH_MAX_LOOKUP], const PackRow& pr) {
+    if (s.kind == SDQH_SRC_COLUMN) { if constexpr (PACKED) { if (s.pack) return pack_pick(pr, s.pack - 1); } return s.col[r]; }
+    const uint32_t e = pick3(ent, s.lookup);
+    // one load at a selected index (no branch between the loads of a drain: they must all be in flight together);
+    // only a packed table's third / fourth payload field pays a second, dependent load
+    const uint64_t idx = s.pack == 0 ? (uint64_t)e : (uint64_t)e * 4 + (s.pack == 1 ? 1 + (uint64_t)s.field : 3);
+    int64_t v = s.col[idx];
+    if (s.pack == 2) v = s.col2[(uint32_t)v];
     return s.kind == SDQH_SRC_LOOKUP_YEAR ? v / 10000 : v;
 }
 // 0 = ok; 1 = a part of a composite key is outside [0, 2^32)
@@ -1716,24 +1786,50 @@ __device__ __forceinline__ int pack_parts(int nkey, int64_t p0, int64_t p1, int6
 }
 // run every lookup for row r: 1 = all hit (ent filled with stage rows), 0 = a miss, -1 = bad key part
 // (fully unrolled: `ent` is indexed statically and stays in registers)
-__device__ __forceinline__ int run_lookups(const DevLookups& L, int64_t r, uint32_t (&ent)[SDQH_MAX_LOOKUP]) {
+template <bool PACKED = false>
+__device__ __forceinline__ int run_lookups(const DevLookups& L, int64_t r, uint32_t (&ent)[SDQH_MAX_LOOKUP], const PackRow& pr) {
 #pragma unroll
     for (int l = 0; l < SDQH_MAX_LOOKUP; ++l) {
         if (l < L.n) {
             const DevLookup& lk = L.l[l];
-            const int64_t p0 = source_value(lk.key[0], L, r, ent);
-            const int64_t p1 = lk.nkey == 2 ? source_value(lk.key[1], L, r, ent) : 0;
+            const int64_t p0 = source_value<PACKED>(lk.key[0], L, r, ent, pr);
+            const int64_t p1 = lk.nkey == 2 ? source_value<PACKED>(lk.key[1], L, r, ent, pr) : 0;
             int64_t key;
             if (pack_parts(lk.nkey, p0, p1, key)) return -1;
             const uint64_t mask = (table_is_direct(lk.table) || lk.table.bitmap_only) ? 0 : lk.table.hdr->cap_mask;
             const int64_t pos = table_find(lk.table, key, mask);
             if (pos < 0) return 0;
-            ent[l] = lk.table.bitmap_only ? 0u : table_ref(lk.table, pos);
+            ent[l] = lk.table.bitmap_only ? 0u : (lk.table.slots && !table_is_direct(lk.table) ? (uint32_t)pos : table_ref(lk.table, pos));
         }
     }
     return 1;
 }
 // cheap test on the first lookup alone, usable before queueing: false = the row cannot survive
+__device__ __forceinline__ bool coarse_may_hit(const DevLookups& L, const uint32_t* s_coarse, int64_t part0) {
+    const DevTable& t = L.l[0].table;
+    if (part0 < t.bm_lo || part0 > t.bm_hi) return false;
+    const uint64_t j = (uint64_t)(part0 - t.bm_lo) >> L.coarse_shift;
+    return (s_coarse[j >> 5] >> (j & 31)) & 1u;
+}
+// coarse[w] bit b = any fine bit in [(32 w + b) << shift, (32 w + b + 1) << shift)
+SDQH_KERNEL __launch_bounds__(TPB) void k_coarsen(const uint32_t* __restrict__ bm, uint64_t nbits, int shift, uint32_t* __restrict__ coarse, int cwords) {
+    for (int w = blockIdx.x * TPB + threadIdx.x; w < cwords; w += gridDim.x * TPB) {
+        uint32_t out = 0;
+        for (int b = 0; b < 32; ++b) {
+            const uint64_t f0 = ((uint64_t)w * 32 + (uint64_t)b) << shift, f1 = f0 + (1ull << shift);
+            bool any = false;
+            for (uint64_t f = f0; f < f1 && f < nbits && !any; ) {
+                const uint32_t word = bm[f >> 5];
+                const uint32_t lo = (uint32_t)(f & 31), span = (uint32_t)min((uint64_t)(32 - lo), f1 - f);
+                const uint32_t mask = (span >= 32 ? 0xFFFFFFFFu : ((1u << span) - 1u)) << lo;
+                any = (word & mask) != 0u;
+                f += span;
+            }
+            out |= any ? (1u << b) : 0u;
+        }
+        coarse[w] = out;
+    }
+}
 __device__ __forceinline__ bool first_lookup_may_hit(const DevLookups& L, int64_t part0) {
     const DevTable& t = L.l[0].table;
     if (!t.bm) return true;
@@ -1780,16 +1876,17 @@ __global__ __launch_bounds__(TPB) void k_build_lookup(DevFilter f, DevLookups L,
         if (lane < count) {
             const int64_t r = q_row[lane];
             uint32_t ent[SDQH_MAX_LOOKUP] = {0, 0, 0};
-            const int h = run_lookups(L, r, ent);
+            const PackRow nopack{};
+            const int h = run_lookups(L, r, ent, nopack);
             if (h < 0) bad = true;
             if (h > 0) {
-                const int64_t p0 = source_value(spec.key[0], L, r, ent);
-                const int64_t p1 = spec.nkey == 2 ? source_value(spec.key[1], L, r, ent) : 0;
+                const int64_t p0 = source_value(spec.key[0], L, r, ent, nopack);
+                const int64_t p1 = spec.nkey == 2 ? source_value(spec.key[1], L, r, ent, nopack) : 0;
                 if (pack_parts(spec.nkey, p0, p1, key)) bad = true;
                 else {
                     keep = true;
 #pragma unroll
-                    for (int q = 0; q < SDQH_MAX_PAYLOAD; ++q) if (q < spec.npay) pay[q] = source_value(spec.pay[q], L, r, ent);
+                    for (int q = 0; q < SDQH_MAX_PAYLOAD; ++q) if (q < spec.npay) pay[q] = source_value(spec.pay[q], L, r, ent, nopack);
                 }
             }
         }
@@ -1862,6 +1959,18 @@ __global__ __launch_bounds__(TPB) void k_build_lookup(DevFilter f, DevLookups L,
     if (__ballot(bad) && lane == 0) atomicOr(flags, 2);
 }
 
+// row pack builder: out[r * k + j] = col[j][r] (j >= ncols: padding)
+struct DevPackCols { const int64_t* col[MAX_PACK]; int32_t ncols, k; };
+SDQH_KERNEL __launch_bounds__(TPB) void k_interleave(DevPackCols c, int64_t nrows, int64_t* __restrict__ out) {
+    for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * TPB) {
+        int64_t v[MAX_PACK];
+#pragma unroll
+        for (int j = 0; j < MAX_PACK; ++j) v[j] = j < c.ncols ? c.col[j][r] : 0;
+#pragma unroll
+        for (int j = 0; j < MAX_PACK; ++j) if (j < c.k) out[r * c.k + j] = v[j];
+    }
+}
+
 // ---- lookups -> group-by over a small domain ------------------------------------------------------------
 constexpr int LG_SLOTS = 2 * SDQH_MAX_LOOKUP_GROUPS;                  // LDS / global group table slots (load factor <= 1/2)
 
@@ -1900,6 +2009,9 @@ __global__ __launch_bounds__(TPB) void k_lookup_agg(DevFilter f, DevLookups L, D
     for (int i = threadIdx.x; i < LG_SLOTS; i += TPB) { s_keys[i] = EMPTY_GROUP; s_cnt[i] = 0; for (int k = 0; k < NVS; ++k) s_acc[i][k] = 0.0; s_map[i] = -1; }
     if (threadIdx.x == 0) s_flags[0] = 0;
     __syncthreads();
+    extern __shared__ __align__(16) uint32_t s_coarse[];                 // L.coarse_words words (0: no coarse filter)
+    for (int i = threadIdx.x; i < L.coarse_words; i += TPB) s_coarse[i] = L.coarse[i];
+    if (L.coarse_words) __syncthreads();
     int64_t* q_row = s_row[threadIdx.x / WAVE];
     const int lane = lane_id();
     const uint64_t lt = lanemask_lt();
@@ -1911,15 +2023,17 @@ __global__ __launch_bounds__(TPB) void k_lookup_agg(DevFilter f, DevLookups L, D
         if (lane >= count) return;
         const int64_t r = q_row[first + lane];
         uint32_t ent[SDQH_MAX_LOOKUP] = {0, 0, 0};
-        const int h = run_lookups(L, r, ent);
+        PackRow prow{};
+        if (L.pack) pack_load(L, r, prow);                            // every gathered column of the row from its pack: one or two lines
+        double x[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0};
+        const int h = run_lookups<true>(L, r, ent, prow);             // <true>: a source with pack != 0 reads the registers, any other its column
         if (h < 0) atomicOr(&s_flags[0], 2);
         if (h <= 0) return;
-        const int64_t k0 = source_value(spec.key[0], L, r, ent);
-        const int64_t k1 = spec.nkeys == 2 ? source_value(spec.key[1], L, r, ent) : 0;
-        if (k0 < 0 || k0 > 0xFFFFFFFEll || k1 < 0 || k1 > 0xFFFFFFFEll) { atomicOr(&s_flags[0], 2); return; }
-        double x[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0};
+        const int64_t k0 = source_value<true>(spec.key[0], L, r, ent, prow);
+        const int64_t k1 = spec.nkeys == 2 ? source_value<true>(spec.key[1], L, r, ent, prow) : 0;
 #pragma unroll
-        for (int j = 0; j < NOPS; ++j) x[j] = __longlong_as_double(source_value(spec.op[j], L, r, ent));
+        for (int j = 0; j < NOPS; ++j) x[j] = __longlong_as_double(source_value<true>(spec.op[j], L, r, ent, prow));
+        if (k0 < 0 || k0 > 0xFFFFFFFEll || k1 < 0 || k1 > 0xFFFFFFFEll) { atomicOr(&s_flags[0], 2); return; }
         if (!operand_ranges<NOPS>(f, x)) return;
         tuple_eval<SHAPE>(x, o);
         const int slot = group_slot(s_keys, (unsigned long long)k0 | ((unsigned long long)k1 << 32), false);
@@ -1943,7 +2057,10 @@ __global__ __launch_bounds__(TPB) void k_lookup_agg(DevFilter f, DevLookups L, D
         pass_pairs<PU, FC, false>(f, none, r, nrows, nomask, p);
         if (eager0) {
 #pragma unroll
-            for (int u = 0; u < PU; ++u) { p[u][0] = p[u][0] && first_lookup_may_hit(L, k0[u].x); p[u][1] = p[u][1] && first_lookup_may_hit(L, k0[u].y); }
+            for (int u = 0; u < PU; ++u) {
+                if (L.coarse_words) { p[u][0] = p[u][0] && coarse_may_hit(L, s_coarse, k0[u].x); p[u][1] = p[u][1] && coarse_may_hit(L, s_coarse, k0[u].y); }
+                p[u][0] = p[u][0] && first_lookup_may_hit(L, k0[u].x); p[u][1] = p[u][1] && first_lookup_may_hit(L, k0[u].y);
+            }
         }
 #pragma unroll
         for (int u = 0; u < PU; ++u) {

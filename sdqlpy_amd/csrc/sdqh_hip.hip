@@ -715,6 +715,7 @@ static int setup_stage(sdqh_ctx* ctx, sdqh_table* tb, int64_t nrows, const sdqh_
     int64_t seg_rows = (nrows + target_segs - 1) / target_segs;
     const int64_t gran = (int64_t)WAVE * ROWS_PER_LOAD * std::max(1, batch);
     seg_rows = std::max<int64_t>(gran, (seg_rows + gran - 1) / gran * gran);
+    if (seg_rows >= ((int64_t)1 << 31)) return fail(ctx, SDQH_ERR_UNSUPPORTED, "build: more than 2^31 rows per staging segment");   // k_build_lookup queues 32-bit offsets into its segment
     st.seg_rows = seg_rows;
     st.nseg = (int32_t)std::max<int64_t>(1, (nrows + seg_rows - 1) / seg_rows);
     st.npay = npay;
@@ -1572,6 +1573,8 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
             auto kern = k_lookup_agg<decltype(S)::value, decltype(FC)>;
             grid = stream_grid(ctx, kern, nrows, TPB * ROWS_PER_LOAD * LOOKUP_PU * ctx->opt_probe_chunk);
             if (coarse_lds) grid = std::min<unsigned>(grid, (unsigned)ctx->num_cu * (unsigned)std::max<size_t>(1, ((size_t)156 << 10) / (((size_t)24 << 10) + coarse_lds)));   // what really fits with the dynamic LDS
+            // the kernel queues candidate rows as 32-bit offsets from its current chunk and rebases them by one grid stride
+            if ((int64_t)grid * ctx->opt_probe_chunk * (TPB * ROWS_PER_LOAD * LOOKUP_PU) >= ((int64_t)1 << 31)) return fail(ctx, SDQH_ERR_UNSUPPORTED, "lookup_aggregate: probe_chunk too large for this grid");
             const size_t nslots = (size_t)grid * LG_SLOTS;
             blob = static_cast<char*>(pool_alloc(ctx, nslots * 40 + 256));
             if (!blob) return fail(ctx, SDQH_ERR_NOMEM, "lookup_aggregate: out of device memory");

@@ -1844,7 +1844,8 @@ constexpr int LOOKUP_PU = 2;                                          // row pai
                                                                       // streaming every gathered column through the LDS queue instead of gathering it (0.87 ms); key, row reference
                                                                       // and payloads of a hash entry in one 32-byte slot, i.e. one line per probe instead of four (0.79 ms); every
                                                                       // plain-column key part and operand of a candidate requested before the lookup chain (0.78 ms).  DESIGN.md §7
-constexpr int LQ_CAP = 192;                                           // 63 left over + 128 appended per pair step
+constexpr int LAQ_CAP = 64 + LOOKUP_PU * 128;                            // k_lookup_agg's queue: 63 left over + a whole tile's candidates
+constexpr int LBQ_CAP = 64 + BUILD_LB * 128;                             // k_build_lookup's queue: 63 left over + a whole step's candidates
 
 struct DevBuildSpec {                                                 // what a surviving row contributes to the build
     int32_t nkey, npay;
@@ -1856,10 +1857,10 @@ struct DevBuildSpec {                                                 // what a 
 // front), survivors compacted into the segment's stage slice exactly as k_stage does.
 template <class FC>
 __global__ __launch_bounds__(TPB) void k_build_lookup(DevFilter f, DevLookups L, DevBuildSpec spec, DevStage st, int64_t nrows, int* __restrict__ flags) {
-    __shared__ int64_t s_row[TPB / WAVE][LQ_CAP];
+    __shared__ int32_t s_row[TPB / WAVE][LBQ_CAP];
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
     if (seg >= st.nseg) return;
-    int64_t* q_row = s_row[threadIdx.x / WAVE];
+    int32_t* q_row = s_row[threadIdx.x / WAVE];
     const int64_t begin = (int64_t)seg * st.seg_rows;
     int64_t end = begin + st.seg_rows; if (end > nrows) end = nrows;
     const int lane = lane_id();
@@ -1871,10 +1872,10 @@ __global__ __launch_bounds__(TPB) void k_build_lookup(DevFilter f, DevLookups L,
     int64_t out = begin;
     int qn = 0;
     bool bad = false;
-    auto drain = [&](int count) {                                      // rows q_row[0..count) one per lane, in row order
+    auto drain = [&](int first, int count) {                           // rows q_row[first .. first + count) one per lane, in row order
         bool keep = false; int64_t key = 0; int64_t pay[MAX_STAGE_COLS] = {0, 0, 0, 0, 0};
         if (lane < count) {
-            const int64_t r = q_row[lane];
+            const int64_t r = begin + (int64_t)q_row[first + lane];
             uint32_t ent[SDQH_MAX_LOOKUP] = {0, 0, 0};
             const PackRow nopack{};
             const int h = run_lookups(L, r, ent, nopack);
@@ -1894,30 +1895,27 @@ __global__ __launch_bounds__(TPB) void k_build_lookup(DevFilter f, DevLookups L,
         if (keep) stage_store<-1>(st, out + __popcll(b & lt), key, pay);
         out += __popcll(b);
     };
-    // BUILD_LB batches of 128 rows per step: the first predicate and the first lookup's key of all of
-    // them are loaded, and their bitmap words requested, before any is consumed (one dependent chain
-    // per step instead of one per batch: the orders build of Q5 is latency-bound, 19 -> 5 steps per wave)
+    // queue entries: 32-bit offsets from the segment's first row (a segment is far shorter than 2^31 rows: the host checks)
     auto enqueue = [&](int64_t r, bool p0, bool p1) {
         const uint64_t b0 = __ballot(p0), b1 = __ballot(p1);
         if (b0 | b1) {
             const int at = qn + __popcll(b0 & lt) + __popcll(b1 & lt);
-            if (p0) q_row[at] = r;
-            if (p1) q_row[at + (p0 ? 1 : 0)] = r + 1;
+            const int32_t off = (int32_t)(r - begin);
+            if (p0) q_row[at] = off;
+            if (p1) q_row[at + (p0 ? 1 : 0)] = off + 1;
             qn += __popcll(b0) + __popcll(b1);
-            while (qn >= WAVE) {                                       // drain the FRONT 64 (row order), shift the rest down
-                drain(WAVE);
-                const int left = qn - WAVE;
-                int64_t a0 = 0, a1 = 0;
-                if (lane < left) a0 = q_row[WAVE + lane];
-                if (lane + WAVE < left) a1 = q_row[2 * WAVE + lane];
-                if (lane < left) q_row[lane] = a0;
-                if (lane + WAVE < left) q_row[WAVE + lane] = a1;
-                qn = left;
-            }
         }
     };
-    for (int64_t b = begin; b < end; b += BATCH_ROWS * BUILD_LB) {
-        if (b + BATCH_ROWS * BUILD_LB <= end) {
+    // One loop, one drain site (the drain — three unrolled lookups over every table layout — is most of this kernel's
+    // code; inlined at each enqueue it made 104 KB of it, past the instruction cache two CUs share).  Every step
+    // produces candidates, then drains the FRONT full waves of the queue (row order) and moves what is left down.
+    // A full step takes BUILD_LB batches of 128 rows: the first predicate and the first lookup's key of all of them
+    // are loaded, and their bitmap words requested, before any is consumed (one dependent chain per step instead of
+    // one per batch: the orders build of Q5 is latency-bound, 19 -> 5 steps per wave).
+    for (int64_t b = begin;;) {
+        const bool last = b >= end;
+        if (last) {
+        } else if (b + BATCH_ROWS * BUILD_LB <= end) {
             int64_t rr[BUILD_LB];
             bool p[BUILD_LB][2];
             Pair<int64_t> k0[BUILD_LB];
@@ -1934,27 +1932,40 @@ __global__ __launch_bounds__(TPB) void k_build_lookup(DevFilter f, DevLookups L,
             }
 #pragma unroll
             for (int j = 0; j < BUILD_LB; ++j) enqueue(rr[j], p[j][0], p[j][1]);
-        } else {
-            for (int64_t bb = b; bb < end; bb += BATCH_ROWS) {       // short segments (small tables) and tails: one batch at a time
-                const int64_t r = bb + (int64_t)lane * ROWS_PER_LOAD;
-                bool p1b[1][2];
-                if (bb + BATCH_ROWS <= end) {
-                    int64_t r1[1] = {r};
-                    p1b[0][0] = p1b[0][1] = true;
-                    Pair<int64_t> k1 = {0, 0};
-                    if (eager0) k1 = load2<false>(L.l[0].key[0].col, r, nrows);
-                    pass_pairs<1, FC, false>(f, none, r1, nrows, nomask, p1b);
-                    if (eager0) { p1b[0][0] = p1b[0][0] && first_lookup_may_hit(L, k1.x); p1b[0][1] = p1b[0][1] && first_lookup_may_hit(L, k1.y); }
-                } else {
-                    p1b[0][0] = r < end; p1b[0][1] = r + 1 < end;
-                    if (p1b[0][0]) p1b[0][0] = row_passes<FC>(f, none, r, nomask);
-                    if (p1b[0][1]) p1b[0][1] = row_passes<FC>(f, none, r + 1, nomask);
-                }
-                enqueue(r, p1b[0][0], p1b[0][1]);
+            b += BATCH_ROWS * BUILD_LB;
+        } else {                                                         // short segments (small tables) and tails: one batch at a time
+            const int64_t r = b + (int64_t)lane * ROWS_PER_LOAD;
+            bool p1b[1][2];
+            if (b + BATCH_ROWS <= end) {
+                int64_t r1[1] = {r};
+                p1b[0][0] = p1b[0][1] = true;
+                Pair<int64_t> k1 = {0, 0};
+                if (eager0) k1 = load2<false>(L.l[0].key[0].col, r, nrows);
+                pass_pairs<1, FC, false>(f, none, r1, nrows, nomask, p1b);
+                if (eager0) { p1b[0][0] = p1b[0][0] && first_lookup_may_hit(L, k1.x); p1b[0][1] = p1b[0][1] && first_lookup_may_hit(L, k1.y); }
+            } else {
+                p1b[0][0] = r < end; p1b[0][1] = r + 1 < end;
+                if (p1b[0][0]) p1b[0][0] = row_passes<FC>(f, none, r, nomask);
+                if (p1b[0][1]) p1b[0][1] = row_passes<FC>(f, none, r + 1, nomask);
             }
+            enqueue(r, p1b[0][0], p1b[0][1]);
+            b += BATCH_ROWS;
+        }
+        int head = 0;
+        while (qn - head >= WAVE || (last && qn > head)) {
+            const int n = qn - head >= WAVE ? WAVE : qn - head;
+            drain(head, n);
+            head += n;
+        }
+        if (last) break;
+        if (head) {
+            const int left = qn - head;                                   // < 64
+            int32_t keepv = 0;
+            if (lane < left) keepv = q_row[head + lane];
+            if (lane < left) q_row[lane] = keepv;
+            qn = left;
         }
     }
-    if (qn > 0) drain(qn);
     if (lane == 0) st.seg_count[seg] = (uint32_t)(out - begin);
     if (__ballot(bad) && lane == 0) atomicOr(flags, 2);
 }
@@ -2003,7 +2014,7 @@ __global__ __launch_bounds__(TPB) void k_lookup_agg(DevFilter f, DevLookups L, D
     constexpr int NVS = NV > 0 ? NV : 1;
     __shared__ double s_acc[LG_SLOTS][NVS];
     __shared__ unsigned long long s_cnt[LG_SLOTS];
-    __shared__ int64_t s_row[TPB / WAVE][LQ_CAP];
+    __shared__ int32_t s_row[TPB / WAVE][LAQ_CAP];
     __shared__ int s_map[LG_SLOTS];
     __shared__ int s_flags[1];
     for (int i = threadIdx.x; i < LG_SLOTS; i += TPB) { s_keys[i] = EMPTY_GROUP; s_cnt[i] = 0; for (int k = 0; k < NVS; ++k) s_acc[i][k] = 0.0; s_map[i] = -1; }
@@ -2012,16 +2023,17 @@ __global__ __launch_bounds__(TPB) void k_lookup_agg(DevFilter f, DevLookups L, D
     extern __shared__ __align__(16) uint32_t s_coarse[];                 // L.coarse_words words (0: no coarse filter)
     for (int i = threadIdx.x; i < L.coarse_words; i += TPB) s_coarse[i] = L.coarse[i];
     if (L.coarse_words) __syncthreads();
-    int64_t* q_row = s_row[threadIdx.x / WAVE];
+    int32_t* q_row = s_row[threadIdx.x / WAVE];
     const int lane = lane_id();
     const uint64_t lt = lanemask_lt();
     const bool eager0 = L.n > 0 && L.l[0].key[0].kind == SDQH_SRC_COLUMN;
     DevProbes none; none.n = 0;
     const uint64_t nomask[SDQH_MAX_PROBE] = {0, 0};
     int qn = 0;
+    int64_t qbase = 0;
     auto drain = [&](int first, int count) {
         if (lane >= count) return;
-        const int64_t r = q_row[first + lane];
+        const int64_t r = qbase + (int64_t)q_row[first + lane];
         uint32_t ent[SDQH_MAX_LOOKUP] = {0, 0, 0};
         PackRow prow{};
         if (L.pack) pack_load(L, r, prow);                            // every gathered column of the row from its pack: one or two lines
@@ -2042,51 +2054,78 @@ __global__ __launch_bounds__(TPB) void k_lookup_agg(DevFilter f, DevLookups L, D
         for (int k = 0; k < NV; ++k) atomicAdd(&s_acc[slot][k], o[k]);
         atomicAdd(&s_cnt[slot], 1ull);
     };
+    // One loop, one drain site: every step PRODUCES candidates (a whole tile of the block's current chunk, then — in the
+    // block that owns it — one workgroup-width of the tail) and then drains the full waves of the queue; the last step
+    // drains what is left.  The drain is the bulk of this kernel's code (three unrolled lookups over every table layout):
+    // inlined at each of the four places that used to call it, the kernel outgrew the instruction cache two CUs share
+    // (93 KB of code; Q5's final loop 0.222 -> 0.243 ms when the packed-slot paths were added).  Queue entries are
+    // 32-bit offsets from `qbase` (the first row of the chunk being produced; what is left over from the previous chunk
+    // is rebased), so 63 + PU * 128 of them cost less LDS than the 191 64-bit rows did.
     const int64_t full = nrows / TILE;
-    for (int64_t t0 = (int64_t)blockIdx.x * chunk; t0 < full; t0 += (int64_t)gridDim.x * chunk)
-    for (int64_t tile = t0; tile < t0 + chunk && tile < full; ++tile) {
-        int64_t r[PU];
-        Pair<int64_t> k0[PU];
-        bool p[PU][2];
-#pragma unroll
-        for (int u = 0; u < PU; ++u) {
-            r[u] = tile * TILE + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
-            if (eager0) k0[u] = load2<false>(L.l[0].key[0].col, r[u], nrows);
-            p[u][0] = p[u][1] = true;
-        }
-        pass_pairs<PU, FC, false>(f, none, r, nrows, nomask, p);
-        if (eager0) {
+    const bool tail_owner = full * TILE < nrows && blockIdx.x == (unsigned)(full % gridDim.x);
+    int64_t t0 = (int64_t)blockIdx.x * chunk, tail_r0 = full * TILE;
+    int c = 0, phase = t0 < full ? 0 : (tail_owner ? 1 : 2);                // 0: tiles, 1: tail, 2: last drain
+    qbase = phase == 0 ? t0 * TILE : tail_r0;
+    for (;;) {
+        if (phase == 0) {
+            const int64_t tile = t0 + c;
+            int64_t r[PU];
+            Pair<int64_t> k0[PU];
+            bool p[PU][2];
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
-                if (L.coarse_words) { p[u][0] = p[u][0] && coarse_may_hit(L, s_coarse, k0[u].x); p[u][1] = p[u][1] && coarse_may_hit(L, s_coarse, k0[u].y); }
-                p[u][0] = p[u][0] && first_lookup_may_hit(L, k0[u].x); p[u][1] = p[u][1] && first_lookup_may_hit(L, k0[u].y);
+                r[u] = tile * TILE + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
+                if (eager0) k0[u] = load2<false>(L.l[0].key[0].col, r[u], nrows);
+                p[u][0] = p[u][1] = true;
             }
-        }
+            pass_pairs<PU, FC, false>(f, none, r, nrows, nomask, p);
+            if (eager0) {
 #pragma unroll
-        for (int u = 0; u < PU; ++u) {
-            const uint64_t b0 = __ballot(p[u][0]), b1 = __ballot(p[u][1]);
-            if (b0 | b1) {
-                const int at = qn + __popcll(b0 & lt) + __popcll(b1 & lt);
-                if (p[u][0]) q_row[at] = r[u];
-                if (p[u][1]) q_row[at + (p[u][0] ? 1 : 0)] = r[u] + 1;
-                qn += __popcll(b0) + __popcll(b1);
-                while (qn >= WAVE) { qn -= WAVE; drain(qn, WAVE); }
+                for (int u = 0; u < PU; ++u) {
+                    if (L.coarse_words) { p[u][0] = p[u][0] && coarse_may_hit(L, s_coarse, k0[u].x); p[u][1] = p[u][1] && coarse_may_hit(L, s_coarse, k0[u].y); }
+                    p[u][0] = p[u][0] && first_lookup_may_hit(L, k0[u].x); p[u][1] = p[u][1] && first_lookup_may_hit(L, k0[u].y);
+                }
             }
-        }
-    }
-    if (full * TILE < nrows && blockIdx.x == (unsigned)(full % gridDim.x)) {
-        for (int64_t r0 = full * TILE; r0 < nrows; r0 += TPB) {           // tail: one row per lane through the same queue
-            const int64_t r = r0 + threadIdx.x;
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                const uint64_t b0 = __ballot(p[u][0]), b1 = __ballot(p[u][1]);
+                if (b0 | b1) {
+                    const int at = qn + __popcll(b0 & lt) + __popcll(b1 & lt);
+                    const int32_t off = (int32_t)(r[u] - qbase);
+                    if (p[u][0]) q_row[at] = off;
+                    if (p[u][1]) q_row[at + (p[u][0] ? 1 : 0)] = off + 1;
+                    qn += __popcll(b0) + __popcll(b1);
+                }
+            }
+            if (++c == chunk || t0 + c >= full) {                              // next chunk of this block, or the tail, or the end
+                c = 0; t0 += (int64_t)gridDim.x * chunk;
+                if (t0 >= full) phase = tail_owner ? 1 : 2;
+                const int64_t nbase = phase == 0 ? t0 * TILE : tail_r0;
+                if (phase != 2) {
+                    const int32_t delta = (int32_t)(nbase - qbase);               // < 2^31: one stride of the grid (checked by the host)
+                    for (int i = lane; i < qn; i += WAVE) q_row[i] -= delta;
+                    qbase = nbase;
+                }
+            }
+        } else if (phase == 1) {                                               // tail: one row per lane through the same queue
+            const int64_t r = tail_r0 + threadIdx.x;
             const bool pass = r < nrows && row_passes<FC>(f, none, r, nomask);
             const uint64_t b = __ballot(pass);
             if (b) {
-                if (pass) q_row[qn + __popcll(b & lt)] = r;
+                if (pass) q_row[qn + __popcll(b & lt)] = (int32_t)(r - qbase);
                 qn += __popcll(b);
-                while (qn >= WAVE) { qn -= WAVE; drain(qn, WAVE); }
             }
+            tail_r0 += TPB;
+            if (tail_r0 >= nrows) phase = 2;
         }
+        const bool last = phase == 2;
+        while (qn >= WAVE || (last && qn > 0)) {
+            const int n = qn >= WAVE ? WAVE : qn;
+            qn -= n;
+            drain(qn, n);
+        }
+        if (last) break;
     }
-    if (qn > 0) drain(0, qn);
     __syncthreads();
     // publish this workgroup's groups at GLOBAL slots (slot-major partials, as k_groupby_*)
     for (int i = threadIdx.x; i < LG_SLOTS; i += TPB) {

@@ -401,6 +401,7 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "direct_index" && (value == 0 || value == 1)) ctx->opt_direct_index = (int)value;
     else if (n == "row_pack" && (value == 0 || value == 1)) ctx->opt_row_pack = (int)value;
     else if (n == "coarse_kb" && value >= 0 && value <= 96) ctx->opt_coarse_kb = (int)value;
+    else if (n == "lookup_pipeline" && value >= -1 && value <= 1) ctx->opt_lookup_pipeline = (int)value;
     else if (n == "packed_slots" && (value == 0 || value == 1)) ctx->opt_packed_slots = (int)value;
     else if (n == "groupby_regs" && (value == 0 || value == 4 || value == 8)) ctx->opt_groupby_regs = (int)value;
     else return fail(ctx, SDQH_ERR_INVALID, "set_option: unknown option or value out of range: " + n);
@@ -1508,6 +1509,10 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
     spec.nkeys = nkeys; spec.shape = tuple_shape;
     for (int k = 0; k < nkeys; ++k) if (int rc = make_source(ctx, keys[k], nrows, nlookups, lookups, nlookups, "group key", &spec.key[k])) return rc;
     for (int j = 0; j < nops; ++j) if (int rc = make_source(ctx, operands[j], nrows, nlookups, lookups, nlookups, "tuple operand", &spec.op[j])) return rc;
+    // software-pipelined streaming part (k_lookup_agg): pays where the first lookup's key column is clustered
+    L.pipeline = 0;
+    if (nlookups > 0 && lookups[0].key[0].kind == SDQH_SRC_COLUMN && lookups[0].key[0].col->dtype == SDQH_I64)
+        L.pipeline = ctx->opt_lookup_pipeline >= 0 ? ctx->opt_lookup_pipeline : (column_is_clustered(ctx, const_cast<sdqh_column*>(lookups[0].key[0].col)) ? 1 : 0);
     // Coarse key filter in LDS for the first lookup when its keys come in no order and its bitmap does not fit L1
     size_t coarse_lds = 0;
     if (ctx->opt_coarse_kb > 0 && nlookups > 0 && nrows >= (1 << 22) && lookups[0].key[0].kind == SDQH_SRC_COLUMN && lookups[0].key[0].col->dtype == SDQH_I64) {

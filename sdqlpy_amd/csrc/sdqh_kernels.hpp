@@ -1745,7 +1745,7 @@ constexpr int MAX_PACK = 8;
 // test of the table's exact key bitmap is its own L2 request — 60 M of them made Q9's final loop L2-request-bound
 // (88 M L2 reads for 3.2 M useful rows) — while a test in LDS costs nothing; only the rows that pass it go on to
 // the exact bitmap.  Built once per table (k_coarsen) and copied into LDS by every workgroup.
-struct DevLookups { DevLookup l[SDQH_MAX_LOOKUP]; int32_t n, pack_k; const int64_t* pack; const uint32_t* coarse; int32_t coarse_words, coarse_shift; };
+struct DevLookups { DevLookup l[SDQH_MAX_LOOKUP]; int32_t n, pack_k; const int64_t* pack; const uint32_t* coarse; int32_t coarse_words, coarse_shift; int32_t pipeline, _pad; };
 struct PackRow { int64_t v0, v1, v2, v3, v4, v5, v6, v7; };      // named, not an array: a run-time pick must stay a select chain on registers
 
 // all pack_k values of row r with 16-byte loads (pack_k is even: padded by the host), into registers
@@ -1837,6 +1837,26 @@ __device__ __forceinline__ bool first_lookup_may_hit(const DevLookups& L, int64_
     if (part0 < t.bm_lo || part0 > t.bm_hi) return false;
     const uint64_t off = (uint64_t)(part0 - t.bm_lo);
     return (t.bm[off >> 5] >> (off & 31)) & 1u;
+}
+
+template <bool B> struct BoolC { static constexpr bool value = B; };
+// The same test in two halves, so that a streaming loop can put other loads between them: the bitmap word of the key
+// (requested unconditionally, at word 0 when the key is out of range — no divergent branch around the load), and the
+// test of its bit.  `none`: the table has no usable bitmap (every row goes on to the full lookup).
+__device__ __forceinline__ bool first_lookup_none(const DevLookups& L) {
+    const DevTable& t = L.l[0].table;
+    return !t.bm || (L.l[0].nkey == 2 && t.bm_shift == 0);
+}
+__device__ __forceinline__ uint32_t first_lookup_word(const DevLookups& L, int64_t part0) {
+    const DevTable& t = L.l[0].table;
+    const bool in = part0 >= t.bm_lo && part0 <= t.bm_hi;
+    const uint64_t off = in ? (uint64_t)(part0 - t.bm_lo) : 0;
+    return t.bm[off >> 5];
+}
+__device__ __forceinline__ bool first_lookup_bit(const DevLookups& L, int64_t part0, uint32_t word) {
+    const DevTable& t = L.l[0].table;
+    const bool in = part0 >= t.bm_lo && part0 <= t.bm_hi;
+    return in && ((word >> ((uint64_t)(part0 - t.bm_lo) & 31)) & 1u);
 }
 
 constexpr int BUILD_LB = 4;                                           // 128-row batches per step of k_build_lookup
@@ -2066,37 +2086,68 @@ __global__ __launch_bounds__(TPB) void k_lookup_agg(DevFilter f, DevLookups L, D
     int64_t t0 = (int64_t)blockIdx.x * chunk, tail_r0 = full * TILE;
     int c = 0, phase = t0 < full ? 0 : (tail_owner ? 1 : 2);                // 0: tiles, 1: tail, 2: last drain
     qbase = phase == 0 ? t0 * TILE : tail_r0;
+    // Software pipeline of the streaming part: the first lookup's keys of the NEXT tile are requested after this tile's
+    // bitmap words and before anything waits, so a step costs one memory round trip (keys of i+1, words and filter
+    // columns of i in flight together), not the two dependent ones (keys, then words) it would otherwise.
+    // Chosen by the host (L.pipeline) where the key column is clustered (Q5's l_orderkey: -23 %); with keys in no order
+    // (Q9's l_partkey) every bitmap test is its own L2 request, the loop is bound by those, and the deeper queue of
+    // requests costs 5-8 %.
+    const bool pipe = L.pipeline && eager0 && !first_lookup_none(L);
+    Pair<int64_t> k0n[PU];
+#pragma unroll
+    for (int u = 0; u < PU; ++u) { k0n[u].x = 0; k0n[u].y = 0; }
+    if (phase == 0 && pipe) {
+#pragma unroll
+        for (int u = 0; u < PU; ++u) k0n[u] = load2<false>(L.l[0].key[0].col, t0 * TILE + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD, nrows);
+    }
+    // one streaming step over tile t0 + c: candidates into the queue.  PIPE: keys of this tile were requested a step ago
+    auto step = [&](auto PIPE_C) {
+        constexpr bool PIPE = decltype(PIPE_C)::value;
+        const int64_t tile = t0 + c;
+        int64_t r[PU];
+        Pair<int64_t> k0[PU];
+        uint32_t w[PU][2];
+        bool p[PU][2];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            r[u] = tile * TILE + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
+            if constexpr (PIPE) k0[u] = k0n[u];
+            else if (eager0) k0[u] = load2<false>(L.l[0].key[0].col, r[u], nrows);
+            p[u][0] = p[u][1] = true;
+            w[u][0] = w[u][1] = 0;
+        }
+        if constexpr (PIPE) {
+#pragma unroll
+            for (int u = 0; u < PU; ++u) { w[u][0] = first_lookup_word(L, k0[u].x); w[u][1] = first_lookup_word(L, k0[u].y); }
+            // (after the block's last tile: that tile again — an unconditional load keeps the step free of a branch the waits would pile up at)
+            const int64_t nt = (c + 1 < chunk && tile + 1 < full) ? tile + 1 : (t0 + (int64_t)gridDim.x * chunk < full ? t0 + (int64_t)gridDim.x * chunk : tile);
+#pragma unroll
+            for (int u = 0; u < PU; ++u) k0n[u] = load2<false>(L.l[0].key[0].col, nt * TILE + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD, nrows);
+        }
+        pass_pairs<PU, FC, false>(f, none, r, nrows, nomask, p);
+        if (eager0) {
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                if (L.coarse_words) { p[u][0] = p[u][0] && coarse_may_hit(L, s_coarse, k0[u].x); p[u][1] = p[u][1] && coarse_may_hit(L, s_coarse, k0[u].y); }
+                if constexpr (PIPE) { p[u][0] = p[u][0] && first_lookup_bit(L, k0[u].x, w[u][0]); p[u][1] = p[u][1] && first_lookup_bit(L, k0[u].y, w[u][1]); }
+                else { p[u][0] = p[u][0] && first_lookup_may_hit(L, k0[u].x); p[u][1] = p[u][1] && first_lookup_may_hit(L, k0[u].y); }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const uint64_t b0 = __ballot(p[u][0]), b1 = __ballot(p[u][1]);
+            if (b0 | b1) {
+                const int at = qn + __popcll(b0 & lt) + __popcll(b1 & lt);
+                const int32_t off = (int32_t)(r[u] - qbase);
+                if (p[u][0]) q_row[at] = off;
+                if (p[u][1]) q_row[at + (p[u][0] ? 1 : 0)] = off + 1;
+                qn += __popcll(b0) + __popcll(b1);
+            }
+        }
+    };
     for (;;) {
         if (phase == 0) {
-            const int64_t tile = t0 + c;
-            int64_t r[PU];
-            Pair<int64_t> k0[PU];
-            bool p[PU][2];
-#pragma unroll
-            for (int u = 0; u < PU; ++u) {
-                r[u] = tile * TILE + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
-                if (eager0) k0[u] = load2<false>(L.l[0].key[0].col, r[u], nrows);
-                p[u][0] = p[u][1] = true;
-            }
-            pass_pairs<PU, FC, false>(f, none, r, nrows, nomask, p);
-            if (eager0) {
-#pragma unroll
-                for (int u = 0; u < PU; ++u) {
-                    if (L.coarse_words) { p[u][0] = p[u][0] && coarse_may_hit(L, s_coarse, k0[u].x); p[u][1] = p[u][1] && coarse_may_hit(L, s_coarse, k0[u].y); }
-                    p[u][0] = p[u][0] && first_lookup_may_hit(L, k0[u].x); p[u][1] = p[u][1] && first_lookup_may_hit(L, k0[u].y);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < PU; ++u) {
-                const uint64_t b0 = __ballot(p[u][0]), b1 = __ballot(p[u][1]);
-                if (b0 | b1) {
-                    const int at = qn + __popcll(b0 & lt) + __popcll(b1 & lt);
-                    const int32_t off = (int32_t)(r[u] - qbase);
-                    if (p[u][0]) q_row[at] = off;
-                    if (p[u][1]) q_row[at + (p[u][0] ? 1 : 0)] = off + 1;
-                    qn += __popcll(b0) + __popcll(b1);
-                }
-            }
+            if (pipe) step(BoolC<true>{}); else step(BoolC<false>{});
             if (++c == chunk || t0 + c >= full) {                              // next chunk of this block, or the tail, or the end
                 c = 0; t0 += (int64_t)gridDim.x * chunk;
                 if (t0 >= full) phase = tail_owner ? 1 : 2;

@@ -65,6 +65,7 @@ struct sdqh_ctx {
     int opt_direct_index = 1;
     int opt_packed_slots = 1;                      // hash-layout tables with payload: 32-byte slots { key, payload 0 / 1, owner row }
     int opt_lookup_pipeline = -1;                  // k_lookup_agg requests the next tile's first-lookup keys a step ahead: -1 = when that key column is clustered, 0 / 1 = never / always
+    int opt_probe_pipeline = 0;                    // the same for k_probe_agg (keys + first predicate column a step ahead): 0 / 1
     int opt_coarse_kb = 0;                         // LDS budget (KiB) of the coarse key filter in front of an unclustered first lookup; 0 = off (default: on Q9 the
                                                    // occupancy its LDS costs outweighs the L2 requests it saves — 0.70 -> 0.67 ms at 32 KiB, 1.4 ms at 64 KiB)
     int opt_row_pack = 1;                          // final loops with lookups gather their columns from an interleaved row pack (see DevLookups)

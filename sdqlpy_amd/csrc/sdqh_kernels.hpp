@@ -191,6 +191,7 @@ template <class T> struct Pair { T x, y; };
 // the stream stalls.  So the hot kernels are instantiated for the filter layouts the TPCH loops
 // use (counts known at compile time: every load of a tile is issued up front) plus one generic
 // instance (-1 = read the count from the arguments) that keeps every other query correct.
+template <bool B> struct BoolC { static constexpr bool value = B; };
 template <int NI_, int NF_, int NS_, int NP_, int NC_ = 0> struct FCfg { static constexpr int NI = NI_, NF = NF_, NS = NS_, NP = NP_, NC = NC_; };
 using FGeneric = FCfg<-1, -1, -1, -1>;
 template <class FC> __device__ __forceinline__ int cfg_ni(const int32_t n) { if constexpr (FC::NI >= 0) return FC::NI; else return n; }
@@ -952,7 +953,7 @@ __device__ __forceinline__ bool row_passes(const DevFilter& f, const DevProbes& 
 // Filter + semi-join probes for NB pairs of rows at once.  Every stage of the dependent chain is
 // issued for all NB pairs before the next stage consumes it: first predicate column with 16-byte
 // loads for every row, the remaining predicates and the probe keys only by lanes still alive.
-template <int NB, class FC, bool EAGER = true>
+template <int NB, class FC, bool EAGER = true, bool SKIP_FIRST = false>      // SKIP_FIRST: the caller has applied the first integer predicate itself
 __device__ __forceinline__ void pass_pairs(const DevFilter& f, const DevProbes& pr, const int64_t (&r)[NB], int64_t nrows,
                                            const uint64_t* cap_masks, bool (&p)[NB][2], uint32_t* s_str = nullptr) {
     // EAGER: the first probe's key column is streamed with 16-byte loads alongside the first
@@ -965,7 +966,7 @@ __device__ __forceinline__ void pass_pairs(const DevFilter& f, const DevProbes& 
 #pragma unroll
         for (int j = 0; j < NB; ++j) ek[j] = load2<false>(pr.key[0], r[j], nrows);
     }
-    if (cfg_ni<FC>(f.ni) > 0) {
+    if (!SKIP_FIRST && cfg_ni<FC>(f.ni) > 0) {
         Pair<int64_t> d[NB];
 #pragma unroll
         for (int j = 0; j < NB; ++j) d[j] = load2<false>(f.ic[0], r[j], nrows);
@@ -1415,7 +1416,7 @@ __global__ __launch_bounds__(TPB) void k_share_groups(DevTable t, DevStage st, D
 // short-circuits the same way: `if (pred) if (contains) { ... += ep*(1.0-disc) }`).  Hits are rare
 // and scattered, so native f64 global atomics are the right tool here.
 // =================================================================================================
-constexpr int PROBE_UNROLL = 4;
+constexpr int PROBE_UNROLL = 2;
 constexpr int PROBE_TILE = TPB * ROWS_PER_LOAD * PROBE_UNROLL;       // 2048 rows per workgroup step
 
 // a row whose key is in the table: add its tuple to the owning entry
@@ -1440,7 +1441,6 @@ __device__ __forceinline__ void probe_add(const DevFilter& f, const DevTuple& t,
 // waves.  Instead each wave appends its candidates to a small queue in LDS (ballot + popcount
 // prefix) and keeps streaming; whenever 64 are queued they are processed one per lane, converged:
 // one chain of latencies per 64 candidates.
-constexpr int PROBE_QCAP = 192;                                      // 63 left over + 128 appended per sub-step
 
 // Candidates are queued in row order, so rows of one group (the lineitems of an order; every row of
 // a group-by on a clustered key) sit in adjacent lanes: a segmented scan over runs of equal entries
@@ -1448,13 +1448,13 @@ constexpr int PROBE_QCAP = 192;                                      // 63 left 
 // l_orderkey: 4.5 -> ~1.2 ms for 60 M rows).  Head flags keep it exact for any order of entries.
 template <int SHAPE>
 __device__ __forceinline__ void probe_drain(const DevFilter& f, const DevTuple& t, const DevTable& tb, uint64_t mask,
-                                            const int64_t* q_row, const int64_t* q_key, int first, int n) {
+                                            int64_t qbase, const int32_t* q_row, const int64_t* q_key, int first, int n) {
     constexpr int NOPS = TupleTraits<SHAPE>::NOPS, NV = TupleTraits<SHAPE>::NV;
     const int lane = lane_id();
     uint32_t idx = NO_ROW, cnt = 0;
     double o[4] = {0, 0, 0, 0};
     if (lane < n) {
-        const int64_t r = q_row[first + lane], key = q_key[first + lane];
+        const int64_t r = qbase + (int64_t)q_row[first + lane], key = q_key[first + lane];
         const int64_t pos = table_find(tb, key, mask);
         if (pos >= 0) {
             double x[4] = {0, 0, 0, 0};
@@ -1491,39 +1491,89 @@ __device__ __forceinline__ void probe_drain(const DevFilter& f, const DevTuple& 
 }
 
 template <int SHAPE, class FC, int PU = PROBE_UNROLL>
-__global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevTable tb, const int64_t* __restrict__ keycol, int64_t nrows, int chunk) {
+__global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevTable tb, const int64_t* __restrict__ keycol, int64_t nrows, int chunk, int pipeline) {
     constexpr int TILE = TPB * ROWS_PER_LOAD * PU;
-    __shared__ int64_t s_row[TPB / WAVE][PROBE_QCAP], s_key[TPB / WAVE][PROBE_QCAP];
-    int64_t* q_row = s_row[threadIdx.x / WAVE];
+    constexpr int QCAP = 64 + PU * 128;                               // 63 left over + a whole tile's candidates
+    __shared__ int32_t s_row[TPB / WAVE][QCAP];                       // row offsets from qbase (the chunk being produced), as in k_lookup_agg
+    __shared__ int64_t s_key[TPB / WAVE][QCAP];
+    int32_t* q_row = s_row[threadIdx.x / WAVE];
     int64_t* q_key = s_key[threadIdx.x / WAVE];
     int qn = 0;                                                       // wave-uniform queue length
+    int64_t qbase = 0;
+    const int lane = lane_id();
     const uint64_t lt = lanemask_lt();
     const uint64_t mask = table_is_direct(tb) ? 0 : tb.hdr->cap_mask;
+    const bool direct_bm = tb.bm && tb.bm_shift == 0 && !tb.lin_rb;
     DevProbes none; none.n = 0;
     const uint64_t nomask[SDQH_MAX_PROBE] = {0, 0};
     const int64_t full = nrows / TILE;
-    for (int64_t t0 = (int64_t)blockIdx.x * chunk; t0 < full; t0 += (int64_t)gridDim.x * chunk)
-    for (int64_t tile = t0; tile < t0 + chunk && tile < full; ++tile) {       // `chunk` consecutive tiles: longer contiguous runs per workgroup
+    const bool tail_owner = full * TILE < nrows && blockIdx.x == (unsigned)(full % gridDim.x);
+    int64_t t0 = (int64_t)blockIdx.x * chunk, tail_r0 = full * TILE;
+    int c = 0, phase = t0 < full ? 0 : (tail_owner ? 1 : 2);                // 0: tiles, 1: tail, 2: last drain
+    qbase = phase == 0 ? t0 * TILE : tail_r0;
+    // Software pipeline (host's choice: a clustered key column): the keys and the first predicate column of the NEXT tile are
+    // requested after this tile's bitmap words and before anything waits — a step costs one memory round trip, and the
+    // requests stay in flight across the drain.
+    constexpr bool HAS_I0 = FC::NI != 0;                                       // the filter may have a first integer predicate
+    const bool first_pred = cfg_ni<FC>(f.ni) > 0;
+    const bool pipe = pipeline != 0;
+    Pair<int64_t> kvn[PU], dn[PU];
+#pragma unroll
+    for (int u = 0; u < PU; ++u) { kvn[u].x = kvn[u].y = 0; dn[u].x = dn[u].y = 0; }
+    if (phase == 0 && pipe) {
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const int64_t rr = t0 * TILE + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
+            kvn[u] = load2<false>(keycol, rr, nrows);
+            if (HAS_I0 && first_pred) dn[u] = load2<false>(f.ic[0], rr, nrows);
+        }
+    }
+    auto step = [&](auto PIPE_C) {
+        constexpr bool PIPE = decltype(PIPE_C)::value;
+        const int64_t tile = t0 + c;
         int64_t r[PU];
         Pair<int64_t> kv[PU];
         bool p[PU][2];
 #pragma unroll
         for (int u = 0; u < PU; ++u) {
             r[u] = tile * TILE + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
-            kv[u] = load2<false>(keycol, r[u], nrows);
+            if constexpr (PIPE) kv[u] = kvn[u]; else kv[u] = load2<false>(keycol, r[u], nrows);
             p[u][0] = p[u][1] = true;
         }
-        pass_pairs<PU, FC, false>(f, none, r, nrows, nomask, p);
-        if (tb.bm && tb.bm_shift == 0 && !tb.lin_rb) {                 // direct layout: all bitmap words requested before any is tested
-            uint32_t w[PU][2];
+        if constexpr (PIPE) {
+            if (HAS_I0 && first_pred) {
+#pragma unroll
+                for (int u = 0; u < PU; ++u) {
+                    p[u][0] = (dn[u].x >= f.ilo[0]) & (dn[u].x <= f.ihi[0]);
+                    p[u][1] = (dn[u].y >= f.ilo[0]) & (dn[u].y <= f.ihi[0]);
+                }
+            }
+            pass_pairs<PU, FC, false, true>(f, none, r, nrows, nomask, p);
+        } else {
+            pass_pairs<PU, FC, false>(f, none, r, nrows, nomask, p);
+        }
+        uint32_t w[PU][2];
+        if (direct_bm) {                                               // direct layout: all bitmap words requested before any is tested
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
                 const int64_t k0 = kv[u].x, k1 = kv[u].y;
                 p[u][0] &= (k0 >= tb.bm_lo) & (k0 <= tb.bm_hi);
                 p[u][1] &= (k1 >= tb.bm_lo) & (k1 <= tb.bm_hi);
-                w[u][0] = p[u][0] ? tb.bm[(uint64_t)(k0 - tb.bm_lo) >> 5] : 0u;
-                w[u][1] = p[u][1] ? tb.bm[(uint64_t)(k1 - tb.bm_lo) >> 5] : 0u;
+                w[u][0] = tb.bm[p[u][0] ? (uint64_t)(k0 - tb.bm_lo) >> 5 : 0];
+                w[u][1] = tb.bm[p[u][1] ? (uint64_t)(k1 - tb.bm_lo) >> 5 : 0];
             }
+        }
+        if constexpr (PIPE) {
+            // (after the block's last tile: that tile again — an unconditional load keeps the step free of a branch the waits would pile up at)
+            const int64_t nt = (c + 1 < chunk && tile + 1 < full) ? tile + 1 : (t0 + (int64_t)gridDim.x * chunk < full ? t0 + (int64_t)gridDim.x * chunk : tile);
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                const int64_t rr = nt * TILE + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
+                kvn[u] = load2<false>(keycol, rr, nrows);
+                if (HAS_I0 && first_pred) dn[u] = load2<false>(f.ic[0], rr, nrows);
+            }
+        }
+        if (direct_bm) {
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
                 p[u][0] = p[u][0] && ((w[u][0] >> ((uint64_t)(kv[u].x - tb.bm_lo) & 31)) & 1u);
@@ -1535,18 +1585,46 @@ __global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevT
             const uint64_t b0 = __ballot(p[u][0]), b1 = __ballot(p[u][1]);
             if (b0 | b1) {
                 const int at = qn + __popcll(b0 & lt) + __popcll(b1 & lt);
-                if (p[u][0]) { q_row[at] = r[u]; q_key[at] = kv[u].x; }
-                if (p[u][1]) { const int a1 = at + (p[u][0] ? 1 : 0); q_row[a1] = r[u] + 1; q_key[a1] = kv[u].y; }
+                const int32_t off = (int32_t)(r[u] - qbase);
+                if (p[u][0]) { q_row[at] = off; q_key[at] = kv[u].x; }
+                if (p[u][1]) { const int a1 = at + (p[u][0] ? 1 : 0); q_row[a1] = off + 1; q_key[a1] = kv[u].y; }
                 qn += __popcll(b0) + __popcll(b1);
-                while (qn >= WAVE) { qn -= WAVE; probe_drain<SHAPE>(f, t, tb, mask, q_row, q_key, qn, WAVE); }
             }
         }
+    };
+    // one loop, one drain site (see k_lookup_agg): a step produces candidates, then the full waves of the queue are drained
+    for (;;) {
+        if (phase == 0) {
+            if (pipe) step(BoolC<true>{}); else step(BoolC<false>{});
+            if (++c == chunk || t0 + c >= full) {                              // next chunk of this block, or the tail, or the end
+                c = 0; t0 += (int64_t)gridDim.x * chunk;
+                if (t0 >= full) phase = tail_owner ? 1 : 2;
+                const int64_t nbase = phase == 0 ? t0 * TILE : tail_r0;
+                if (phase != 2) {
+                    const int32_t delta = (int32_t)(nbase - qbase);               // < 2^31: one stride of the grid (checked by the host)
+                    for (int i = lane; i < qn; i += WAVE) q_row[i] -= delta;
+                    qbase = nbase;
+                }
+            }
+        } else if (phase == 1) {                                               // tail: one row per lane through the same queue
+            const int64_t r = tail_r0 + threadIdx.x;
+            const bool pass = r < nrows && row_passes<FC>(f, none, r, nomask);
+            const uint64_t b = __ballot(pass);
+            if (b) {
+                if (pass) { const int at = qn + __popcll(b & lt); q_row[at] = (int32_t)(r - qbase); q_key[at] = keycol[r]; }
+                qn += __popcll(b);
+            }
+            tail_r0 += TPB;
+            if (tail_r0 >= nrows) phase = 2;
+        }
+        const bool last = phase == 2;
+        while (qn >= WAVE || (last && qn > 0)) {
+            const int n = qn >= WAVE ? WAVE : qn;
+            qn -= n;
+            probe_drain<SHAPE>(f, t, tb, mask, qbase, q_row, q_key, qn, n);
+        }
+        if (last) break;
     }
-    if (full * TILE < nrows && blockIdx.x == (unsigned)(full % gridDim.x)) {
-        for (int64_t r = full * TILE + threadIdx.x; r < nrows; r += TPB)
-            if (row_passes<FC>(f, none, r, nomask)) { const int64_t pos = table_find(tb, keycol[r], mask); if (pos >= 0) probe_add<SHAPE>(f, t, tb, pos, r); }
-    }
-    if (qn > 0) probe_drain<SHAPE>(f, t, tb, mask, q_row, q_key, 0, qn);
 }
 
 // Membership-only build (sdqh_build_key_set): stream filter + key, OR the survivors' bits.  A lane
@@ -1839,7 +1917,6 @@ __device__ __forceinline__ bool first_lookup_may_hit(const DevLookups& L, int64_
     return (t.bm[off >> 5] >> (off & 31)) & 1u;
 }
 
-template <bool B> struct BoolC { static constexpr bool value = B; };
 // The same test in two halves, so that a streaming loop can put other loads between them: the bitmap word of the key
 // (requested unconditionally, at word 0 when the key is out of range — no divergent branch around the load), and the
 // test of its bit.  `none`: the table has no usable bitmap (every row goes on to the full lookup).

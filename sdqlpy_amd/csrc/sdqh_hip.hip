@@ -253,6 +253,26 @@ bool column_is_clustered(sdqh_ctx* ctx, sdqh_column* c) {
     return c->clustered == 1;
 }
 
+// Is an I64 column strictly increasing?  One pass over the column the first time it is asked, cached like min / max.
+bool column_is_increasing(sdqh_ctx* ctx, sdqh_column* c) {
+    if (c->increasing >= 0) return c->increasing == 1;
+    if (c->dtype != SDQH_I64) { c->increasing = 0; return false; }
+    if (c->nrows < 2) { c->increasing = 1; return true; }
+    int* flag = static_cast<int*>(pool_alloc(ctx, 64));
+    if (!flag) return false;
+    bool ok = hipMemsetAsync(flag, 0, 4, ctx->stream) == hipSuccess;
+    if (ok) {
+        const unsigned grid = (unsigned)std::min<int64_t>((c->nrows + TPB - 1) / TPB, (int64_t)ctx->num_cu * 8);
+        hipLaunchKernelGGL(k_check_increasing, dim3(grid), dim3(TPB), 0, ctx->stream, static_cast<const int64_t*>(c->data), c->nrows, flag);
+        int* host = static_cast<int*>(ctx->result_host);
+        ok = hipMemcpyAsync(host, flag, 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+        if (ok) c->increasing = host[0] == 0 ? 1 : 0;
+    }
+    if (!ok) (void)hipGetLastError();
+    pool_free(ctx, flag);
+    return ok && c->increasing == 1;
+}
+
 // ---- dispatch onto the compiled menu of kernel instances -------------------------------------------
 template <int S> using ShapeC = std::integral_constant<int, S>;
 template <class Fn>
@@ -403,6 +423,8 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "coarse_kb" && value >= 0 && value <= 96) ctx->opt_coarse_kb = (int)value;
     else if (n == "lookup_pipeline" && value >= -1 && value <= 1) ctx->opt_lookup_pipeline = (int)value;
     else if (n == "probe_pipeline" && value >= 0 && value <= 1) ctx->opt_probe_pipeline = (int)value;
+    else if (n == "lookup_debug") ctx->opt_lookup_debug = (int)value;
+    else if (n == "dense_increasing" && value >= 0 && value <= 1) ctx->opt_dense_increasing = (int)value;
     else if (n == "packed_slots" && (value == 0 || value == 1)) ctx->opt_packed_slots = (int)value;
     else if (n == "groupby_regs" && (value == 0 || value == 4 || value == 8)) ctx->opt_groupby_regs = (int)value;
     else return fail(ctx, SDQH_ERR_INVALID, "set_option: unknown option or value out of range: " + n);
@@ -813,12 +835,21 @@ static int build_dense(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int
     for (int p = 0; p < npayload; ++p) tb->dev.pay[p] = st.pay[p];
     const int64_t* kc = static_cast<const int64_t*>(key->data);
     const unsigned grid = (unsigned)std::min<int64_t>((nrows + TPB - 1) / TPB, (int64_t)ctx->num_cu * 8);
+    // a strictly increasing key column (orders by o_orderkey, any table by its primary key) fills the array in one pass:
+    // no prefill of the cells, no verification pass (Q9's orders at SF=10: 0.226 -> see DESIGN.md §3)
+    const bool increasing = ctx->opt_dense_increasing && column_is_increasing(ctx, const_cast<sdqh_column*>(key));
     call_begin(ctx);
-    { FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); fl.add(st.shits, (size_t)nrows * 4, 0); fl.add(arr, range * 4, 0xFF); launch_fill(ctx, fl); }
-    LAUNCH(ctx, "k_full_counts", k_full_counts, (unsigned)((st.nseg + TPB - 1) / TPB), st.seg_count, st.nseg, st.seg_rows, nrows);
-    LAUNCH(ctx, "k_dense_fill", k_dense_fill, grid, kc, nrows, lo, arr);
-    LAUNCH(ctx, "k_dense_verify", k_dense_verify, grid, kc, nrows, lo, arr, tb->hdr);
-    LAUNCH(ctx, "k_dense_fixup", k_dense_fixup, grid, kc, nrows, lo, arr, tb->hdr);
+    if (increasing) {
+        { FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); fl.add(st.shits, (size_t)nrows * 4, 0); launch_fill(ctx, fl); }
+        LAUNCH(ctx, "k_full_counts", k_full_counts, (unsigned)((st.nseg + TPB - 1) / TPB), st.seg_count, st.nseg, st.seg_rows, nrows);
+        LAUNCH(ctx, "k_dense_fill_increasing", k_dense_fill_increasing, grid, kc, nrows, lo, arr, tb->hdr);
+    } else {
+        { FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); fl.add(st.shits, (size_t)nrows * 4, 0); fl.add(arr, range * 4, 0xFF); launch_fill(ctx, fl); }
+        LAUNCH(ctx, "k_full_counts", k_full_counts, (unsigned)((st.nseg + TPB - 1) / TPB), st.seg_count, st.nseg, st.seg_rows, nrows);
+        LAUNCH(ctx, "k_dense_fill", k_dense_fill, grid, kc, nrows, lo, arr);
+        LAUNCH(ctx, "k_dense_verify", k_dense_verify, grid, kc, nrows, lo, arr, tb->hdr);
+        LAUNCH(ctx, "k_dense_fixup", k_dense_fixup, grid, kc, nrows, lo, arr, tb->hdr);
+    }
     call_end(ctx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { table_release(ctx, tb); delete tb; return fail(ctx, SDQH_ERR_DEVICE, std::string("dense build launch: ") + hipGetErrorString(e)); }
@@ -1516,6 +1547,7 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
     spec.nkeys = nkeys; spec.shape = tuple_shape;
     for (int k = 0; k < nkeys; ++k) if (int rc = make_source(ctx, keys[k], nrows, nlookups, lookups, nlookups, "group key", &spec.key[k])) return rc;
     for (int j = 0; j < nops; ++j) if (int rc = make_source(ctx, operands[j], nrows, nlookups, lookups, nlookups, "tuple operand", &spec.op[j])) return rc;
+    L.debug = ctx->opt_lookup_debug;
     // software-pipelined streaming part (k_lookup_agg): pays where the first lookup's key column is clustered
     L.pipeline = 0;
     if (nlookups > 0 && lookups[0].key[0].kind == SDQH_SRC_COLUMN && lookups[0].key[0].col->dtype == SDQH_I64)
@@ -1582,9 +1614,38 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
     unsigned grid = 1; char* blob = nullptr;
     int lrc = with_shape(ctx, tuple_shape, [&](auto S) {
         return with_scan_filter(f, [&](auto FC) {
-            auto kern = k_lookup_agg<decltype(S)::value, decltype(FC)>;
+            using FCT = decltype(FC);
+            constexpr int SH = decltype(S)::value;
+            // With the coarse key filter: 1024-thread workgroups (one copy of the filter per 16 waves), 4 row pairs per lane.
+            // Compiled for unfiltered scans only (the shape it exists for: Q9); any other loop runs without the filter.
+            constexpr bool BIG_OK = std::is_same_v<FCT, FCfg<0, 0, 0, 0, 0>>;
+            constexpr int BIG_BT = 1024, BIG_PU = 4;
+            if (coarse_lds && !BIG_OK) { L.coarse = nullptr; L.coarse_words = 0; L.coarse_shift = 0; coarse_lds = 0; }
+            if constexpr (BIG_OK) if (coarse_lds) {
+                auto big = k_lookup_agg<SH, FCT, BIG_BT, BIG_PU>;
+                int per_cu = 0;
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(big), hipFuncAttributeMaxDynamicSharedMemorySize, (int)coarse_lds) != hipSuccess ||
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, big, BIG_BT, coarse_lds) != hipSuccess || per_cu < 1) {
+                    (void)hipGetLastError();
+                    L.coarse = nullptr; L.coarse_words = 0; L.coarse_shift = 0; coarse_lds = 0;        // does not fit: run without the filter
+                } else {
+                    const int64_t tile_rows = (int64_t)BIG_BT * ROWS_PER_LOAD * BIG_PU * ctx->opt_probe_chunk;
+                    grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + tile_rows - 1) / tile_rows, (int64_t)ctx->num_cu * per_cu));
+                    if ((int64_t)grid * tile_rows >= ((int64_t)1 << 31)) return fail(ctx, SDQH_ERR_UNSUPPORTED, "lookup_aggregate: probe_chunk too large for this grid");
+                    const size_t nslots = (size_t)grid * LG_SLOTS;
+                    blob = static_cast<char*>(pool_alloc(ctx, nslots * 40 + 256));
+                    if (!blob) return fail(ctx, SDQH_ERR_NOMEM, "lookup_aggregate: out of device memory");
+                    double* pacc = reinterpret_cast<double*>(blob);
+                    int64_t* pcnt = reinterpret_cast<int64_t*>(blob + nslots * 32);
+                    { FillList fl; fl.add(r_keys, LG_SLOTS * 8, 0xFF); fl.add(r_flags, 8, 0); launch_fill(ctx, fl); }
+                    { KernelScope _ks(ctx, "k_lookup_agg"); hipLaunchKernelGGL(big, dim3(grid), dim3(BIG_BT), coarse_lds, ctx->stream, f, L, spec, nrows, r_keys, pacc, pcnt, r_flags, ctx->opt_probe_chunk); }
+                    LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, r_keys, pacc, pcnt, (int)grid, r_acc, r_cnt);
+                    call_end(ctx);
+                    return SDQH_OK;
+                }
+            }
+            auto kern = k_lookup_agg<SH, FCT>;
             grid = stream_grid(ctx, kern, nrows, TPB * ROWS_PER_LOAD * LOOKUP_PU * ctx->opt_probe_chunk);
-            if (coarse_lds) grid = std::min<unsigned>(grid, (unsigned)ctx->num_cu * (unsigned)std::max<size_t>(1, ((size_t)156 << 10) / (((size_t)24 << 10) + coarse_lds)));   // what really fits with the dynamic LDS
             // the kernel queues candidate rows as 32-bit offsets from its current chunk and rebases them by one grid stride
             if ((int64_t)grid * ctx->opt_probe_chunk * (TPB * ROWS_PER_LOAD * LOOKUP_PU) >= ((int64_t)1 << 31)) return fail(ctx, SDQH_ERR_UNSUPPORTED, "lookup_aggregate: probe_chunk too large for this grid");
             const size_t nslots = (size_t)grid * LG_SLOTS;
@@ -1593,8 +1654,7 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
             double* pacc = reinterpret_cast<double*>(blob);
             int64_t* pcnt = reinterpret_cast<int64_t*>(blob + nslots * 32);
             { FillList fl; fl.add(r_keys, LG_SLOTS * 8, 0xFF); fl.add(r_flags, 8, 0); launch_fill(ctx, fl); }
-            LAUNCH_LDS(ctx, "k_lookup_agg", kern, grid, coarse_lds, f, L, spec, nrows, r_keys, pacc, pcnt, r_flags, ctx->opt_probe_chunk);
-            (void)0;
+            LAUNCH(ctx, "k_lookup_agg", kern, grid, f, L, spec, nrows, r_keys, pacc, pcnt, r_flags, ctx->opt_probe_chunk);
             LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, r_keys, pacc, pcnt, (int)grid, r_acc, r_cnt);
             call_end(ctx);
             return SDQH_OK;
@@ -1722,7 +1782,7 @@ int sdqh_column_copy_in(sdqh_ctx* ctx, sdqh_column* col, int64_t row0, int64_t n
     if (nrows == 0) return SDQH_OK;
     (void)hipSetDevice(ctx->device);
     HIP_TRY(ctx, hipMemcpyAsync(static_cast<char*>(col->data) + (size_t)row0 * 8, src, (size_t)nrows * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    col->have_minmax = false; col->minmax_pending = false;
+    col->have_minmax = false; col->minmax_pending = false; col->clustered = -1; col->increasing = -1;
     return ctx->opt_async_copies ? SDQH_OK : sync_stream(ctx);
 }
 

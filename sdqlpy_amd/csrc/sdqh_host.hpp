@@ -65,9 +65,11 @@ struct sdqh_ctx {
     int opt_direct_index = 1;
     int opt_packed_slots = 1;                      // hash-layout tables with payload: 32-byte slots { key, payload 0 / 1, owner row }
     int opt_lookup_pipeline = -1;                  // k_lookup_agg requests the next tile's first-lookup keys a step ahead: -1 = when that key column is clustered, 0 / 1 = never / always
+    int opt_lookup_debug = 0;
+    int opt_dense_increasing = 1;                  // dense layout over a strictly increasing key column is filled in one pass (no prefill, no verification)
     int opt_probe_pipeline = 0;                    // the same for k_probe_agg (keys + first predicate column a step ahead): 0 / 1
-    int opt_coarse_kb = 0;                         // LDS budget (KiB) of the coarse key filter in front of an unclustered first lookup; 0 = off (default: on Q9 the
-                                                   // occupancy its LDS costs outweighs the L2 requests it saves — 0.70 -> 0.67 ms at 32 KiB, 1.4 ms at 64 KiB)
+    int opt_coarse_kb = 64;                        // LDS budget (KiB) of the coarse key filter in front of an unclustered first lookup; 0 = off.  One copy per
+                                                   // 1024-thread workgroup (a copy per 256 threads cost more occupancy than it saved: 0.70 -> 0.67 ms at 32 KiB, 1.4 ms at 64 KiB)
     int opt_row_pack = 1;                          // final loops with lookups gather their columns from an interleaved row pack (see DevLookups)
     struct RowPack { std::vector<const void*> cols; int64_t nrows; int k; void* data; };
     std::vector<RowPack> packs;                    // resident row packs, by column set
@@ -84,6 +86,7 @@ struct sdqh_column {
     long long* d_minmax = nullptr;     // device [2], I64 only
     bool minmax_pending = false, have_minmax = false;
     int clustered = -1;                // -1 unknown; 1: neighbouring rows hold near-by values (sampled), 0: no order
+    int increasing = -1;               // -1 unknown; 1: strictly increasing (sorted, no duplicates), 0: not — checked once on the device
     int64_t mn = 0, mx = 0;
     size_t row_bytes() const { return dtype == SDQH_STR ? (size_t)width * 4 : 8; }
 };

@@ -400,21 +400,33 @@ __device__ __forceinline__ int64_t table_find(const DevTable& t, int64_t key, ui
         const uint32_t ref = t.dense_arr[key - t.bm_lo];
         return ref == NO_ROW ? -1 : (int64_t)ref;
     }
+    // What follows the bitmap test is requested WITH the bitmap word, not after it (one memory round trip less in every
+    // lookup of a latency-bound drain): the rank prefix of the word (direct layout), or the first hash slot (hash layout
+    // behind a bitmap of the key's high part).  A miss wastes that request; the loops that call this mostly hit.
+    const bool direct = t.bm && t.bm_shift == 0 && !t.bitmap_only;
+    const bool hashed = !t.bitmap_only && !(t.bm && t.bm_shift == 0);
+    uint64_t h = 0;
+    int64_t k_first = EMPTY_KEY;
     if (t.bm) {
         uint64_t off;
         if (!bm_locate(t, key, off)) return -1;
         const uint32_t word = t.bm[off >> 5];
+        uint32_t pre = 0;
+        if (direct) pre = t.wprefix[off >> 5];
+        if (hashed) { h = hash_key(key) & cap_mask; k_first = slot_key(t, h); }
         if (!((word >> (off & 31)) & 1u)) return -1;
         if (t.bitmap_only) return 0;
-        if (t.bm_shift == 0) return direct_rank(t, off, word);
+        if (t.bm_shift == 0) return (int64_t)pre + __popc(word & ((1u << (off & 31)) - 1u));
+    } else {
+        h = hash_key(key) & cap_mask; k_first = slot_key(t, h);
     }
     if (key == EMPTY_KEY) return slot_row(t, cap_mask + 1) != NO_ROW ? (int64_t)(cap_mask + 1) : -1;
-    uint64_t h = hash_key(key) & cap_mask;
+    int64_t k = k_first;
     for (;;) {
-        int64_t k = slot_key(t, h);
         if (k == key) return (int64_t)h;
         if (k == EMPTY_KEY) return -1;
         h = (h + 1) & cap_mask;
+        k = slot_key(t, h);
     }
 }
 // stage index of the entry at an index position
@@ -1281,6 +1293,57 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_full_counts(uint32_t* __restrict__ seg
 SDQH_KERNEL __launch_bounds__(TPB) void k_dense_fill(const int64_t* __restrict__ key, int64_t nrows, int64_t lo, uint32_t* __restrict__ arr) {
     for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * TPB) arr[key[r] - lo] = (uint32_t)r;
 }
+// Is the column strictly increasing (sorted, no duplicates)?  flag[0] |= 1 where it is not.  A property of the resident
+// column, asked once (sdqh_column::sorted_unique) like its min / max.
+SDQH_KERNEL __launch_bounds__(TPB) void k_check_increasing(const int64_t* __restrict__ key, int64_t nrows, int* __restrict__ flag) {
+    bool bad = false;
+    for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r + 1 < nrows; r += (int64_t)gridDim.x * TPB) bad |= key[r] >= key[r + 1];
+    if (__ballot(bad) && lane_id() == 0) atomicOr(flag, 1);
+}
+// Dense layout over a strictly increasing key column, in ONE pass: row r writes its own cell and NO_ROW into the cells up to
+// the next key, so the array needs no prefill (240 MB for Q9's orders) and — no duplicates possible — no verification pass
+// (another read of keys and cells).  Every cell in [lo, hi] is written exactly once; lo / hi are the column's min / max.
+constexpr int DENSE_SPAN = 2048;                                      // cells a wave assembles in LDS per step (8 KiB)
+SDQH_KERNEL __launch_bounds__(TPB) void k_dense_fill_increasing(const int64_t* __restrict__ key, int64_t nrows, int64_t lo, uint32_t* __restrict__ arr, TableHeader* __restrict__ hdr) {
+    // A wave takes 128 consecutive rows, assembles the cells from its first key up to (not including) the first key of
+    // the next 128 rows in LDS — NO_ROW everywhere, then each row number at its key — and writes them out with
+    // 16-byte stores.  (One thread per row storing its own gap ran 3x slower: 4-byte stores at a stride of a few cells.)
+    __shared__ __align__(16) uint32_t s_cells[TPB / WAVE][DENSE_SPAN];
+    uint32_t* cells = s_cells[threadIdx.x / WAVE];
+    const int lane = lane_id();
+    constexpr int ROWS = 2 * WAVE;
+    const int64_t nsteps = (nrows + ROWS - 1) / ROWS;
+    const int64_t wave = (int64_t)blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE, nwaves = (int64_t)gridDim.x * (TPB / WAVE);
+    for (int64_t step = wave; step < nsteps; step += nwaves) {
+        const int64_t r0 = step * ROWS;
+        const int64_t ra = r0 + lane, rb = r0 + WAVE + lane;
+        const int64_t ka = ra < nrows ? key[ra] : 0, kb = rb < nrows ? key[rb] : 0;
+        const int64_t first = __shfl(ka, 0, WAVE);
+        const int64_t rend = r0 + ROWS;
+        const int64_t last = rend < nrows ? key[rend] : key[nrows - 1] + 1;      // exclusive end of this wave's cells (uniform address)
+        for (int64_t w0 = first; w0 < last; w0 += DENSE_SPAN) {                 // one window, except across a rare wide gap
+            const int64_t span = last - w0 < DENSE_SPAN ? last - w0 : DENSE_SPAN;
+            for (int i = lane * 4; i < span; i += WAVE * 4) *reinterpret_cast<uint4*>(&cells[i]) = make_uint4(NO_ROW, NO_ROW, NO_ROW, NO_ROW);
+            __builtin_amdgcn_wave_barrier();
+            if (ra < nrows && ka >= w0 && ka < w0 + span) cells[ka - w0] = (uint32_t)ra;
+            if (rb < nrows && kb >= w0 && kb < w0 + span) cells[kb - w0] = (uint32_t)rb;
+            __builtin_amdgcn_wave_barrier();
+            uint32_t* out = arr + (w0 - lo);
+            // head up to 16-byte alignment of the destination, 16-byte body, tail
+            const int head = (int)((4 - (((unsigned long long)out >> 2) & 3)) & 3);
+            if (lane < head && lane < span) out[lane] = cells[lane];
+            const int64_t body = span > head ? (span - head) / 4 : 0;
+            for (int64_t v = lane; v < body; v += WAVE) {
+                const int c = head + (int)v * 4;
+                *reinterpret_cast<uint4*>(out + c) = make_uint4(cells[c], cells[c + 1], cells[c + 2], cells[c + 3]);
+            }
+            const int64_t done = head + body * 4;
+            if (done + lane < span) out[done + lane] = cells[done + lane];
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { hdr->staged = (uint64_t)nrows; hdr->has_dups = 0; }
+}
 // a row that does not find itself in its cell lost to a duplicate key
 SDQH_KERNEL __launch_bounds__(TPB) void k_dense_verify(const int64_t* __restrict__ key, int64_t nrows, int64_t lo, const uint32_t* __restrict__ arr, TableHeader* __restrict__ hdr) {
     bool dup = false;
@@ -1823,7 +1886,7 @@ constexpr int MAX_PACK = 8;
 // test of the table's exact key bitmap is its own L2 request — 60 M of them made Q9's final loop L2-request-bound
 // (88 M L2 reads for 3.2 M useful rows) — while a test in LDS costs nothing; only the rows that pass it go on to
 // the exact bitmap.  Built once per table (k_coarsen) and copied into LDS by every workgroup.
-struct DevLookups { DevLookup l[SDQH_MAX_LOOKUP]; int32_t n, pack_k; const int64_t* pack; const uint32_t* coarse; int32_t coarse_words, coarse_shift; int32_t pipeline, _pad; };
+struct DevLookups { DevLookup l[SDQH_MAX_LOOKUP]; int32_t n, pack_k; const int64_t* pack; const uint32_t* coarse; int32_t coarse_words, coarse_shift; int32_t pipeline, debug; };
 struct PackRow { int64_t v0, v1, v2, v3, v4, v5, v6, v7; };      // named, not an array: a run-time pick must stay a select chain on registers
 
 // all pack_k values of row r with 16-byte loads (pack_k is even: padded by the host), into registers
@@ -1864,11 +1927,12 @@ __device__ __forceinline__ int pack_parts(int nkey, int64_t p0, int64_t p1, int6
 }
 // run every lookup for row r: 1 = all hit (ent filled with stage rows), 0 = a miss, -1 = bad key part
 // (fully unrolled: `ent` is indexed statically and stays in registers)
+// skip0: the caller has tested the first lookup's table already and that table is a key set (nothing to fetch from it)
 template <bool PACKED = false>
-__device__ __forceinline__ int run_lookups(const DevLookups& L, int64_t r, uint32_t (&ent)[SDQH_MAX_LOOKUP], const PackRow& pr) {
+__device__ __forceinline__ int run_lookups(const DevLookups& L, int64_t r, uint32_t (&ent)[SDQH_MAX_LOOKUP], const PackRow& pr, bool skip0 = false) {
 #pragma unroll
     for (int l = 0; l < SDQH_MAX_LOOKUP; ++l) {
-        if (l < L.n) {
+        if (l < L.n && !(l == 0 && skip0)) {
             const DevLookup& lk = L.l[l];
             const int64_t p0 = source_value<PACKED>(lk.key[0], L, r, ent, pr);
             const int64_t p1 = lk.nkey == 2 ? source_value<PACKED>(lk.key[1], L, r, ent, pr) : 0;
@@ -1941,7 +2005,6 @@ constexpr int LOOKUP_PU = 2;                                          // row pai
                                                                       // streaming every gathered column through the LDS queue instead of gathering it (0.87 ms); key, row reference
                                                                       // and payloads of a hash entry in one 32-byte slot, i.e. one line per probe instead of four (0.79 ms); every
                                                                       // plain-column key part and operand of a candidate requested before the lookup chain (0.78 ms).  DESIGN.md §7
-constexpr int LAQ_CAP = 64 + LOOKUP_PU * 128;                            // k_lookup_agg's queue: 63 left over + a whole tile's candidates
 constexpr int LBQ_CAP = 64 + BUILD_LB * 128;                             // k_build_lookup's queue: 63 left over + a whole step's candidates
 
 struct DevBuildSpec {                                                 // what a surviving row contributes to the build
@@ -2101,24 +2164,27 @@ __device__ __forceinline__ int group_slot(unsigned long long* keys, unsigned lon
     return -1;
 }
 
-template <int SHAPE, class FC>
-__global__ __launch_bounds__(TPB) void k_lookup_agg(DevFilter f, DevLookups L, DevAggSpec spec, int64_t nrows,
+// BT: threads per workgroup.  256 everywhere, except with the coarse key filter: 1024 (16 waves share ONE copy of the filter in LDS —
+// a copy per 256 threads cost more occupancy than the filter saved), and then PU = 4 row pairs per lane in flight to make up for
+// the fewer waves per CU.
+template <int SHAPE, class FC, int BT = TPB, int PUV = LOOKUP_PU>
+__global__ __launch_bounds__(BT) void k_lookup_agg(DevFilter f, DevLookups L, DevAggSpec spec, int64_t nrows,
                                                     unsigned long long* __restrict__ gkeys, double* __restrict__ pacc,
                                                     int64_t* __restrict__ pcnt, int* __restrict__ flags, int chunk) {
     constexpr int NOPS = TupleTraits<SHAPE>::NOPS, NV = TupleTraits<SHAPE>::NV;
-    constexpr int PU = LOOKUP_PU, TILE = TPB * ROWS_PER_LOAD * PU;
+    constexpr int PU = PUV, TILE = BT * ROWS_PER_LOAD * PU, SUBR = BT * ROWS_PER_LOAD, QCAP = 64 + PU * 128;
     __shared__ unsigned long long s_keys[LG_SLOTS];
     constexpr int NVS = NV > 0 ? NV : 1;
     __shared__ double s_acc[LG_SLOTS][NVS];
     __shared__ unsigned long long s_cnt[LG_SLOTS];
-    __shared__ int32_t s_row[TPB / WAVE][LAQ_CAP];
+    __shared__ int32_t s_row[BT / WAVE][QCAP];
     __shared__ int s_map[LG_SLOTS];
     __shared__ int s_flags[1];
-    for (int i = threadIdx.x; i < LG_SLOTS; i += TPB) { s_keys[i] = EMPTY_GROUP; s_cnt[i] = 0; for (int k = 0; k < NVS; ++k) s_acc[i][k] = 0.0; s_map[i] = -1; }
+    for (int i = threadIdx.x; i < LG_SLOTS; i += BT) { s_keys[i] = EMPTY_GROUP; s_cnt[i] = 0; for (int k = 0; k < NVS; ++k) s_acc[i][k] = 0.0; s_map[i] = -1; }
     if (threadIdx.x == 0) s_flags[0] = 0;
     __syncthreads();
     extern __shared__ __align__(16) uint32_t s_coarse[];                 // L.coarse_words words (0: no coarse filter)
-    for (int i = threadIdx.x; i < L.coarse_words; i += TPB) s_coarse[i] = L.coarse[i];
+    for (int i = threadIdx.x; i < L.coarse_words; i += BT) s_coarse[i] = L.coarse[i];
     if (L.coarse_words) __syncthreads();
     int32_t* q_row = s_row[threadIdx.x / WAVE];
     const int lane = lane_id();
@@ -2127,15 +2193,18 @@ __global__ __launch_bounds__(TPB) void k_lookup_agg(DevFilter f, DevLookups L, D
     DevProbes none; none.n = 0;
     const uint64_t nomask[SDQH_MAX_PROBE] = {0, 0};
     int qn = 0;
+    // the streaming part's test of the first lookup is exact for a key set over a plain one-part key: its candidates skip that lookup in the drain
+    const bool skip0 = eager0 && !first_lookup_none(L) && L.l[0].table.bitmap_only && L.l[0].nkey == 1 && L.l[0].table.bm_shift == 0 && L.l[0].table.lin_rb == 0 && !(L.debug & 2);
     int64_t qbase = 0;
     auto drain = [&](int first, int count) {
         if (lane >= count) return;
+        if (L.debug & 1) return;
         const int64_t r = qbase + (int64_t)q_row[first + lane];
         uint32_t ent[SDQH_MAX_LOOKUP] = {0, 0, 0};
         PackRow prow{};
         if (L.pack) pack_load(L, r, prow);                            // every gathered column of the row from its pack: one or two lines
         double x[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0};
-        const int h = run_lookups<true>(L, r, ent, prow);             // <true>: a source with pack != 0 reads the registers, any other its column
+        const int h = run_lookups<true>(L, r, ent, prow, skip0);      // <true>: a source with pack != 0 reads the registers, any other its column
         if (h < 0) atomicOr(&s_flags[0], 2);
         if (h <= 0) return;
         const int64_t k0 = source_value<true>(spec.key[0], L, r, ent, prow);
@@ -2175,7 +2244,7 @@ __global__ __launch_bounds__(TPB) void k_lookup_agg(DevFilter f, DevLookups L, D
     for (int u = 0; u < PU; ++u) { k0n[u].x = 0; k0n[u].y = 0; }
     if (phase == 0 && pipe) {
 #pragma unroll
-        for (int u = 0; u < PU; ++u) k0n[u] = load2<false>(L.l[0].key[0].col, t0 * TILE + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD, nrows);
+        for (int u = 0; u < PU; ++u) k0n[u] = load2<false>(L.l[0].key[0].col, t0 * TILE + (int64_t)u * SUBR + (int64_t)threadIdx.x * ROWS_PER_LOAD, nrows);
     }
     // one streaming step over tile t0 + c: candidates into the queue.  PIPE: keys of this tile were requested a step ago
     auto step = [&](auto PIPE_C) {
@@ -2187,7 +2256,7 @@ __global__ __launch_bounds__(TPB) void k_lookup_agg(DevFilter f, DevLookups L, D
         bool p[PU][2];
 #pragma unroll
         for (int u = 0; u < PU; ++u) {
-            r[u] = tile * TILE + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
+            r[u] = tile * TILE + (int64_t)u * SUBR + (int64_t)threadIdx.x * ROWS_PER_LOAD;
             if constexpr (PIPE) k0[u] = k0n[u];
             else if (eager0) k0[u] = load2<false>(L.l[0].key[0].col, r[u], nrows);
             p[u][0] = p[u][1] = true;
@@ -2199,7 +2268,7 @@ __global__ __launch_bounds__(TPB) void k_lookup_agg(DevFilter f, DevLookups L, D
             // (after the block's last tile: that tile again — an unconditional load keeps the step free of a branch the waits would pile up at)
             const int64_t nt = (c + 1 < chunk && tile + 1 < full) ? tile + 1 : (t0 + (int64_t)gridDim.x * chunk < full ? t0 + (int64_t)gridDim.x * chunk : tile);
 #pragma unroll
-            for (int u = 0; u < PU; ++u) k0n[u] = load2<false>(L.l[0].key[0].col, nt * TILE + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD, nrows);
+            for (int u = 0; u < PU; ++u) k0n[u] = load2<false>(L.l[0].key[0].col, nt * TILE + (int64_t)u * SUBR + (int64_t)threadIdx.x * ROWS_PER_LOAD, nrows);
         }
         pass_pairs<PU, FC, false>(f, none, r, nrows, nomask, p);
         if (eager0) {
@@ -2207,6 +2276,7 @@ __global__ __launch_bounds__(TPB) void k_lookup_agg(DevFilter f, DevLookups L, D
             for (int u = 0; u < PU; ++u) {
                 if (L.coarse_words) { p[u][0] = p[u][0] && coarse_may_hit(L, s_coarse, k0[u].x); p[u][1] = p[u][1] && coarse_may_hit(L, s_coarse, k0[u].y); }
                 if constexpr (PIPE) { p[u][0] = p[u][0] && first_lookup_bit(L, k0[u].x, w[u][0]); p[u][1] = p[u][1] && first_lookup_bit(L, k0[u].y, w[u][1]); }
+                else if (L.debug & 2) { p[u][0] = p[u][0] && k0[u].x == -12345; p[u][1] = p[u][1] && k0[u].y == -12345; }
                 else { p[u][0] = p[u][0] && first_lookup_may_hit(L, k0[u].x); p[u][1] = p[u][1] && first_lookup_may_hit(L, k0[u].y); }
             }
         }
@@ -2237,13 +2307,14 @@ __global__ __launch_bounds__(TPB) void k_lookup_agg(DevFilter f, DevLookups L, D
             }
         } else if (phase == 1) {                                               // tail: one row per lane through the same queue
             const int64_t r = tail_r0 + threadIdx.x;
-            const bool pass = r < nrows && row_passes<FC>(f, none, r, nomask);
+            bool pass = r < nrows && row_passes<FC>(f, none, r, nomask);
+            if (pass && eager0) pass = first_lookup_may_hit(L, L.l[0].key[0].col[r]);
             const uint64_t b = __ballot(pass);
             if (b) {
                 if (pass) q_row[qn + __popcll(b & lt)] = (int32_t)(r - qbase);
                 qn += __popcll(b);
             }
-            tail_r0 += TPB;
+            tail_r0 += BT;
             if (tail_r0 >= nrows) phase = 2;
         }
         const bool last = phase == 2;
@@ -2256,14 +2327,14 @@ __global__ __launch_bounds__(TPB) void k_lookup_agg(DevFilter f, DevLookups L, D
     }
     __syncthreads();
     // publish this workgroup's groups at GLOBAL slots (slot-major partials, as k_groupby_*)
-    for (int i = threadIdx.x; i < LG_SLOTS; i += TPB) {
+    for (int i = threadIdx.x; i < LG_SLOTS; i += BT) {
         if (s_keys[i] != EMPTY_GROUP && s_cnt[i] > 0) {
             const int gs = group_slot(gkeys, s_keys[i], true);
             if (gs < 0) atomicOr(&s_flags[0], 1); else s_map[gs] = i;
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < LG_SLOTS; i += TPB) {
+    for (int i = threadIdx.x; i < LG_SLOTS; i += BT) {
         const int l = s_map[i];
         const size_t e = (size_t)i * gridDim.x + blockIdx.x;
         pcnt[e] = l >= 0 ? (int64_t)s_cnt[l] : 0;

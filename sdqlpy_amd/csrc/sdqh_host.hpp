@@ -66,6 +66,7 @@ struct sdqh_ctx {
     int opt_packed_slots = 1;                      // hash-layout tables with payload: 32-byte slots { key, payload 0 / 1, owner row }
     int opt_lookup_pipeline = -1;                  // k_lookup_agg requests the next tile's first-lookup keys a step ahead: -1 = when that key column is clustered, 0 / 1 = never / always
     int opt_lookup_debug = 0;
+    int opt_span_index = 1;                        // small direct tables also get an owner-by-key-offset array (one-load lookups)
     int opt_dense_increasing = 1;                  // dense layout over a strictly increasing key column is filled in one pass (no prefill, no verification)
     int opt_probe_pipeline = 0;                    // the same for k_probe_agg (keys + first predicate column a step ahead): 0 / 1
     int opt_coarse_kb = 64;                        // LDS budget (KiB) of the coarse key filter in front of an unclustered first lookup; 0 = off.  One copy per
@@ -105,6 +106,7 @@ struct sdqh_table {
     uint64_t nwords = 0;               // bitmap words (direct layout)
     std::vector<void*> owned;          // pool blocks to release
     // cached compaction (device buffers) for the two-step count / fetch protocol
+    uint32_t* span = nullptr;                      // owner by key offset (small plain-key direct tables), becomes dev.dense_arr once the index is built
     bool refs_prefilled = false;                   // small direct tables: dense_ref was allocated and NO_ROW-filled with the header
     bool compact_valid = false;
     int64_t compact_min_hits = 0, compact_n = 0;
@@ -136,7 +138,7 @@ void fill_regions(sdqh_ctx* ctx, void* const* ptr, const size_t* bytes, const un
 void launch_sum_partials(sdqh_ctx* ctx, const double* partial, int nparts, double* out);
 void launch_groupby_merge_lg(sdqh_ctx* ctx, const unsigned long long* gkeys, const double* pacc, const int64_t* pcnt, int nparts, double* out_acc, int64_t* out_cnt);
 // small direct-layout tables: the rank -> row array is allocated up front; *ptr / *bytes = a region to fill with 0xFF (null: none)
-void prefill_direct_refs(sdqh_ctx* ctx, sdqh_table* tb, void** ptr, size_t* bytes);
+int prefill_direct_refs(sdqh_ctx* ctx, sdqh_table* tb, void** ptr, size_t* bytes);   // regions (<= 2) to fill with 0xFF; returns their number
 
 // event pair around one launch when profiling is on (same bookkeeping as the LAUNCH macro)
 struct KernelScope {

@@ -1268,7 +1268,9 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_fill_refs(DevStage st, DevTable t) {  
     const uint64_t n = t.hdr->distinct;
     for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TPB) t.dense_ref[i] = NO_ROW;
 }
-SDQH_KERNEL __launch_bounds__(TPB) void k_insert_direct(DevStage st, DevTable t) {
+// span (optional): the same owner by key offset, span[key - bm_lo] — for a table over a small key range a lookup is then
+// ONE load (the dense layout's path) instead of bitmap word + rank prefix + dense_ref; NO_ROW-filled by the build's k_fill
+SDQH_KERNEL __launch_bounds__(TPB) void k_insert_direct(DevStage st, DevTable t, uint32_t* __restrict__ span) {
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
     const bool dups = direct_has_dups(t.hdr);
     if (blockIdx.x == 0 && threadIdx.x == 0) t.hdr->has_dups = dups ? 1u : 0u;     // for every later reader
@@ -1280,6 +1282,7 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_insert_direct(DevStage st, DevTable t)
         const int64_t pos = table_find(t, st.key[idx], 0);
         if (pos < 0) continue;                                         // cannot happen: the key's bit was set while staging
         if (dups) atomicMin(&t.dense_ref[pos], (uint32_t)idx); else t.dense_ref[pos] = (uint32_t)idx;
+        if (span) { uint32_t* cell = span + (st.key[idx] - t.bm_lo); if (dups) atomicMin(cell, (uint32_t)idx); else *cell = (uint32_t)idx; }
     }
 }
 
@@ -2204,9 +2207,11 @@ __global__ __launch_bounds__(BT) void k_lookup_agg(DevFilter f, DevLookups L, De
         PackRow prow{};
         if (L.pack) pack_load(L, r, prow);                            // every gathered column of the row from its pack: one or two lines
         double x[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0};
+        if (L.debug & 8) { if (prow.v0 == -12345 && prow.v5 == -777) atomicOr(&s_flags[0], 2); return; }
         const int h = run_lookups<true>(L, r, ent, prow, skip0);      // <true>: a source with pack != 0 reads the registers, any other its column
         if (h < 0) atomicOr(&s_flags[0], 2);
         if (h <= 0) return;
+        if (L.debug & 4) { if (ent[0] + ent[1] + ent[2] == 0xFFFFFFF0u) atomicOr(&s_flags[0], 2); return; }
         const int64_t k0 = source_value<true>(spec.key[0], L, r, ent, prow);
         const int64_t k1 = spec.nkeys == 2 ? source_value<true>(spec.key[1], L, r, ent, prow) : 0;
 #pragma unroll
@@ -2263,8 +2268,10 @@ __global__ __launch_bounds__(BT) void k_lookup_agg(DevFilter f, DevLookups L, De
             w[u][0] = w[u][1] = 0;
         }
         if constexpr (PIPE) {
+            if (!L.coarse_words) {                                         // (with the coarse filter only the rows that pass it ask for their exact word)
 #pragma unroll
-            for (int u = 0; u < PU; ++u) { w[u][0] = first_lookup_word(L, k0[u].x); w[u][1] = first_lookup_word(L, k0[u].y); }
+                for (int u = 0; u < PU; ++u) { w[u][0] = first_lookup_word(L, k0[u].x); w[u][1] = first_lookup_word(L, k0[u].y); }
+            }
             // (after the block's last tile: that tile again — an unconditional load keeps the step free of a branch the waits would pile up at)
             const int64_t nt = (c + 1 < chunk && tile + 1 < full) ? tile + 1 : (t0 + (int64_t)gridDim.x * chunk < full ? t0 + (int64_t)gridDim.x * chunk : tile);
 #pragma unroll
@@ -2275,7 +2282,7 @@ __global__ __launch_bounds__(BT) void k_lookup_agg(DevFilter f, DevLookups L, De
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
                 if (L.coarse_words) { p[u][0] = p[u][0] && coarse_may_hit(L, s_coarse, k0[u].x); p[u][1] = p[u][1] && coarse_may_hit(L, s_coarse, k0[u].y); }
-                if constexpr (PIPE) { p[u][0] = p[u][0] && first_lookup_bit(L, k0[u].x, w[u][0]); p[u][1] = p[u][1] && first_lookup_bit(L, k0[u].y, w[u][1]); }
+                if (PIPE && !L.coarse_words) { p[u][0] = p[u][0] && first_lookup_bit(L, k0[u].x, w[u][0]); p[u][1] = p[u][1] && first_lookup_bit(L, k0[u].y, w[u][1]); }
                 else if (L.debug & 2) { p[u][0] = p[u][0] && k0[u].x == -12345; p[u][1] = p[u][1] && k0[u].y == -12345; }
                 else { p[u][0] = p[u][0] && first_lookup_may_hit(L, k0[u].x); p[u][1] = p[u][1] && first_lookup_may_hit(L, k0[u].y); }
             }
@@ -2430,7 +2437,7 @@ __device__ __forceinline__ uint32_t compact_segment(const DevTable& t, const Dev
 
 // Several small regions set to a byte value by ONE launch (a hipMemsetAsync per region costs a
 // launch each, and most builds need two or three).  Regions are 4-byte multiples, 16-byte aligned.
-constexpr int FILL_MAX = 4;
+constexpr int FILL_MAX = 6;
 struct DevFill { void* p[FILL_MAX]; uint64_t bytes[FILL_MAX]; uint32_t word[FILL_MAX]; int32_t n, _pad; };
 SDQH_KERNEL __launch_bounds__(TPB) void k_fill(DevFill f) {
     const uint64_t tid = (uint64_t)blockIdx.x * TPB + threadIdx.x, nth = (uint64_t)gridDim.x * TPB;

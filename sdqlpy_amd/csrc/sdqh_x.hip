@@ -658,11 +658,11 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
         tb->dev.bm = tb->bm; tb->dev.bm_lo = key_lo; tb->dev.bm_hi = key_hi; tb->dev.bitmap_only = 0; tb->dev.bm_shift = 0;
         for (int p = 0; p < prog->nvals; ++p) tb->dev.pay[p] = tb->stage.pay[p];
         tb->stage.bm = tb->bm; tb->stage.bm_lo = key_lo; tb->stage.bm_hi = key_hi; tb->stage.hdr = tb->hdr; tb->stage.bm_shift = 0;
-        void* ptr[4]; size_t bytes[4]; unsigned char byte[4]; int n = 0;
+        void* ptr[6]; size_t bytes[6]; unsigned char byte[6]; int n = 0;
         ptr[n] = tb->hdr; bytes[n] = sizeof(TableHeader); byte[n++] = 0;
         ptr[n] = flags; bytes[n] = 8; byte[n++] = 0;
         if (tb->bm) { ptr[n] = tb->bm; bytes[n] = tb->nwords * 4; byte[n++] = 0; }
-        { void* rp = nullptr; size_t rb = 0; prefill_direct_refs(ctx, tb, &rp, &rb); if (rp) { ptr[n] = rp; bytes[n] = rb; byte[n++] = 0xFF; } }
+        { void* rp[2]; size_t rb[2]; const int nr = prefill_direct_refs(ctx, tb, rp, rb); for (int i = 0; i < nr; ++i) { ptr[n] = rp[i]; bytes[n] = rb[i]; byte[n++] = 0xFF; } }
         fill_regions(ctx, ptr, bytes, byte, n);
         XArgs a;
         rc = fill_xargs(ctx, x, &a, flags, bounded ? key_lo : 1, bounded ? key_hi : 0);

@@ -2186,9 +2186,10 @@ __global__ __launch_bounds__(BT) void k_lookup_agg(DevFilter f, DevLookups L, De
     for (int i = threadIdx.x; i < LG_SLOTS; i += BT) { s_keys[i] = EMPTY_GROUP; s_cnt[i] = 0; for (int k = 0; k < NVS; ++k) s_acc[i][k] = 0.0; s_map[i] = -1; }
     if (threadIdx.x == 0) s_flags[0] = 0;
     __syncthreads();
-    extern __shared__ __align__(16) uint32_t s_coarse[];                 // L.coarse_words words (0: no coarse filter)
-    for (int i = threadIdx.x; i < L.coarse_words; i += BT) s_coarse[i] = L.coarse[i];
-    if (L.coarse_words) __syncthreads();
+    constexpr bool COARSE = BT != TPB;                                   // the coarse key filter exists in the wide-workgroup instance only (compile-time: a run-time
+                                                                         // test around the word loads of the pipelined step broke its pipelining: Q5 0.118 -> 0.144 ms)
+    extern __shared__ __align__(16) uint32_t s_coarse[];                 // L.coarse_words words
+    if constexpr (COARSE) { for (int i = threadIdx.x; i < L.coarse_words; i += BT) s_coarse[i] = L.coarse[i]; __syncthreads(); }
     int32_t* q_row = s_row[threadIdx.x / WAVE];
     const int lane = lane_id();
     const uint64_t lt = lanemask_lt();
@@ -2268,7 +2269,7 @@ __global__ __launch_bounds__(BT) void k_lookup_agg(DevFilter f, DevLookups L, De
             w[u][0] = w[u][1] = 0;
         }
         if constexpr (PIPE) {
-            if (!L.coarse_words) {                                         // (with the coarse filter only the rows that pass it ask for their exact word)
+            if constexpr (!COARSE) {                                       // (with the coarse filter only the rows that pass it ask for their exact word)
 #pragma unroll
                 for (int u = 0; u < PU; ++u) { w[u][0] = first_lookup_word(L, k0[u].x); w[u][1] = first_lookup_word(L, k0[u].y); }
             }
@@ -2281,8 +2282,8 @@ __global__ __launch_bounds__(BT) void k_lookup_agg(DevFilter f, DevLookups L, De
         if (eager0) {
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
-                if (L.coarse_words) { p[u][0] = p[u][0] && coarse_may_hit(L, s_coarse, k0[u].x); p[u][1] = p[u][1] && coarse_may_hit(L, s_coarse, k0[u].y); }
-                if (PIPE && !L.coarse_words) { p[u][0] = p[u][0] && first_lookup_bit(L, k0[u].x, w[u][0]); p[u][1] = p[u][1] && first_lookup_bit(L, k0[u].y, w[u][1]); }
+                if constexpr (COARSE) { p[u][0] = p[u][0] && coarse_may_hit(L, s_coarse, k0[u].x); p[u][1] = p[u][1] && coarse_may_hit(L, s_coarse, k0[u].y); }
+                if constexpr (PIPE && !COARSE) { p[u][0] = p[u][0] && first_lookup_bit(L, k0[u].x, w[u][0]); p[u][1] = p[u][1] && first_lookup_bit(L, k0[u].y, w[u][1]); }
                 else if (L.debug & 2) { p[u][0] = p[u][0] && k0[u].x == -12345; p[u][1] = p[u][1] && k0[u].y == -12345; }
                 else { p[u][0] = p[u][0] && first_lookup_may_hit(L, k0[u].x); p[u][1] = p[u][1] && first_lookup_may_hit(L, k0[u].y); }
             }

@@ -424,6 +424,7 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "lookup_pipeline" && value >= -1 && value <= 1) ctx->opt_lookup_pipeline = (int)value;
     else if (n == "probe_pipeline" && value >= 0 && value <= 1) ctx->opt_probe_pipeline = (int)value;
     else if (n == "lookup_debug") ctx->opt_lookup_debug = (int)value;
+    else if (n == "stage_pipeline" && value >= 0 && value <= 1) ctx->opt_stage_pipeline = (int)value;
     else if (n == "span_index" && value >= 0 && value <= 1) ctx->opt_span_index = (int)value;
     else if (n == "dense_increasing" && value >= 0 && value <= 1) ctx->opt_dense_increasing = (int)value;
     else if (n == "packed_slots" && (value == 0 || value == 1)) ctx->opt_packed_slots = (int)value;
@@ -926,6 +927,11 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
                     const int sb = ctx->opt_stage_batch, eg = ctx->opt_stage_eager;
                     if (npayload == 2) {
                         const int ep = ctx->opt_stage_eager_pay;
+                        if (ctx->opt_stage_pipeline && eg == 1 && ep == 0) {
+#define STAGE_PIPE(SB_) if (sb == SB_) { auto kern = k_stage<FCT, 2, SB_, true, false, true>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows); return SDQH_OK; }
+                            STAGE_PIPE(2) STAGE_PIPE(4)
+#undef STAGE_PIPE
+                        }
 #define STAGE_VARIANT(SB_, EG_, EP_) if (sb == SB_ && eg == EG_ && ep == EP_) { auto kern = k_stage<FCT, 2, SB_, EG_ != 0, EP_ != 0>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows); return SDQH_OK; }
                         STAGE_VARIANT(2, 1, 1) STAGE_VARIANT(4, 1, 1) STAGE_VARIANT(2, 1, 0) STAGE_VARIANT(4, 1, 0) STAGE_VARIANT(8, 1, 0) STAGE_VARIANT(4, 0, 0)
 #undef STAGE_VARIANT

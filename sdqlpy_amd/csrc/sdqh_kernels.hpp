@@ -965,9 +965,21 @@ __device__ __forceinline__ bool row_passes(const DevFilter& f, const DevProbes& 
 // Filter + semi-join probes for NB pairs of rows at once.  Every stage of the dependent chain is
 // issued for all NB pairs before the next stage consumes it: first predicate column with 16-byte
 // loads for every row, the remaining predicates and the probe keys only by lanes still alive.
-template <int NB, class FC, bool EAGER = true, bool SKIP_FIRST = false>      // SKIP_FIRST: the caller has applied the first integer predicate itself
+// The first stage of pass_pairs' loads (first probe's keys, first integer predicate column), requested a step ahead by a
+// pipelined caller (k_stage<..., PIPE>)
+template <int NB> struct PairsPre { Pair<int64_t> ek[NB], d[NB]; };
+template <int NB, class FC>
+__device__ __forceinline__ void pairs_preload(const DevFilter& f, const DevProbes& pr, int64_t row0, int64_t step_rows, int lane, int64_t nrows, PairsPre<NB>& pre) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int64_t r = row0 + (int64_t)j * step_rows + (int64_t)lane * ROWS_PER_LOAD;
+        pre.ek[j] = load2<false>(pr.key[0], r, nrows);
+        pre.d[j] = load2<false>(f.ic[0], r, nrows);
+    }
+}
+template <int NB, class FC, bool EAGER = true, bool SKIP_FIRST = false, bool PRE = false>      // SKIP_FIRST: the caller has applied the first integer predicate itself
 __device__ __forceinline__ void pass_pairs(const DevFilter& f, const DevProbes& pr, const int64_t (&r)[NB], int64_t nrows,
-                                           const uint64_t* cap_masks, bool (&p)[NB][2], uint32_t* s_str = nullptr) {
+                                           const uint64_t* cap_masks, bool (&p)[NB][2], uint32_t* s_str = nullptr, const PairsPre<NB>* pre = nullptr) {
     // EAGER: the first probe's key column is streamed with 16-byte loads alongside the first
     // predicate instead of being fetched afterwards by the surviving lanes only.  When a good part
     // of the rows survive, every cache line of the key column is touched anyway, and one stage of
@@ -976,12 +988,12 @@ __device__ __forceinline__ void pass_pairs(const DevFilter& f, const DevProbes& 
     const bool eager = EAGER && cfg_np<FC>(pr.n) > 0;
     if (eager) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) ek[j] = load2<false>(pr.key[0], r[j], nrows);
+        for (int j = 0; j < NB; ++j) { if constexpr (PRE) ek[j] = pre->ek[j]; else ek[j] = load2<false>(pr.key[0], r[j], nrows); }
     }
     if (!SKIP_FIRST && cfg_ni<FC>(f.ni) > 0) {
         Pair<int64_t> d[NB];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) d[j] = load2<false>(f.ic[0], r[j], nrows);
+        for (int j = 0; j < NB; ++j) { if constexpr (PRE) d[j] = pre->d[j]; else d[j] = load2<false>(f.ic[0], r[j], nrows); }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             p[j][0] &= (d[j].x >= f.ilo[0]) & (d[j].x <= f.ihi[0]);
@@ -1077,7 +1089,10 @@ __device__ __forceinline__ void stage_store(const DevStage& st, int64_t pos, int
     }
 }
 
-template <class FC, int NPAY = -1, int SB = STAGE_BATCH, bool EAGER = true, bool EAGER_PAY = false>
+// PIPE (needs EAGER, one integer predicate and one probe at least): the next step's first-stage loads are requested at the
+// top of this step, so a step waits one memory round trip less (the build is bound by its chain of dependent round trips,
+// not by bytes: see "Staging" in DESIGN.md §3)
+template <class FC, int NPAY = -1, int SB = STAGE_BATCH, bool EAGER = true, bool EAGER_PAY = false, bool PIPE = false>
 __global__ __launch_bounds__(TPB) void k_stage(DevFilter f, DevProbes pr, DevStage st, int64_t nrows) {
     extern __shared__ __align__(16) uint32_t s_dyn[];                   // f.slds * swidth words per wave (string predicate staging)
     __shared__ uint16_t s_queue[TPB / WAVE][WAVE * ROWS_PER_LOAD * SB];   // survivors of a step (row offsets), in row order
@@ -1094,6 +1109,8 @@ __global__ __launch_bounds__(TPB) void k_stage(DevFilter f, DevProbes pr, DevSta
     const uint64_t lt = lanemask_lt();
     constexpr int64_t BATCH_ROWS = WAVE * ROWS_PER_LOAD;                 // 128
     int64_t out = begin;                                   // wave-uniform write cursor into the segment's stage slice
+    PairsPre<SB> nxt;
+    if constexpr (PIPE) { if (begin + BATCH_ROWS * SB <= end) pairs_preload<SB, FC>(f, pr, begin, BATCH_ROWS, lane, nrows, nxt); }
     for (int64_t b = begin; b < end; b += BATCH_ROWS * SB) {
         int64_t r[SB];
         bool p[SB][2];
@@ -1119,7 +1136,15 @@ __global__ __launch_bounds__(TPB) void k_stage(DevFilter f, DevProbes pr, DevSta
             }
 #pragma unroll
             for (int j = 0; j < SB; ++j) p[j][0] = p[j][1] = true;
-            pass_pairs<SB, FC, EAGER>(f, pr, r, nrows, cap_masks, p, s_str);
+            if constexpr (PIPE) {
+                const PairsPre<SB> cur = nxt;
+                // the next full step's rows; after the last full step this step's again (an unconditional request: see k_lookup_agg)
+                const int64_t nb = b + 2 * BATCH_ROWS * SB <= end ? b + BATCH_ROWS * SB : b;
+                pairs_preload<SB, FC>(f, pr, nb, BATCH_ROWS, lane, nrows, nxt);
+                pass_pairs<SB, FC, EAGER, false, true>(f, pr, r, nrows, cap_masks, p, s_str, &cur);
+            } else {
+                pass_pairs<SB, FC, EAGER>(f, pr, r, nrows, cap_masks, p, s_str);
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < SB; ++j) {

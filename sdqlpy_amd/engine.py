@@ -21,7 +21,7 @@ import numpy as np
 from . import abi, build
 from .frontend import (And, Bin, Call, Cmp, Col, Const, Contains, FinalizeOp, HostDictOp, IfElse, Lookup, Not, Or, PayloadField, RecordCons,
                        ScalarExprOp, ScalarField, ScanOp, SelectKeysOp, StrIn, UnsupportedQuery, WrapScalarOp)
-from .result import DictResult, ResultSet, decode_text
+from .result import DictResult, ResultSet, TextRefs, decode_text
 
 # value-tuple vocabulary: canonical shape of the whole value record -> (ABI shape, index of the COUNT field or None)
 TUPLE_SHAPES = {
@@ -170,6 +170,9 @@ class Engine:
         if hit is None or hit[0] is not arr:
             from . import loader
             enc = loader.dict_encode(arr, max_distinct)          # native hash pass; None = too many distinct values
+            if enc is not None:
+                from .result import Dictionary
+                enc = (enc[0], np.asarray(enc[1]).view(Dictionary))          # tagged: its entries are pairwise distinct
             hit = self._dicts[id(arr)] = (arr,) + (enc if enc is not None else (None, None))
         if hit[1] is None:
             return None
@@ -205,6 +208,8 @@ class BuiltTable:
         self.val_fields = val_fields        # [(field name, "key" | payload index)]
         self.val_is_record = val_is_record
         self.payload_dtypes = row_arrays    # payload index -> numpy dtype
+        self.key_radix = None               # (parts, radix): the key is several fields packed into one mixed-radix integer (xplan, large group-bys)
+        self.int_values = ()                # value fields that are integer-valued sums (row programs): returned as int64
         self.agg = None                     # set by a fused probe-aggregate: (key_fields, val_names, count field index, key / value is a record, number of summed doubles)
         self.agg_spec = None
         self.decoders = {}                  # payload index -> string array (the payload holds row references into it)
@@ -372,14 +377,16 @@ def _build_tuple(eng, op, htab, val):
     return abi.make_tuple(abi_shape, operands), names, count_idx
 
 
-def _value_arrays(names, count_idx, values, counts):
-    """Scatter the ABI's (doubles, count) outputs back to the value record's fields."""
+def _value_arrays(names, count_idx, values, counts, ints=()):
+    """Scatter the ABI's (doubles, count) outputs back to the value record's fields.  `ints`: fields whose
+    summed expression is integer-valued (`1 if c else 0`): summed as doubles (exact below 2^53), returned as int64."""
     out, v = [], 0
     for i, n in enumerate(names):
         if count_idx is not None and i == count_idx:
             out.append((n, np.asarray(counts, np.int64)))
         else:
-            out.append((n, np.asarray(values[v], np.float64)))
+            a = np.asarray(values[v], np.float64)
+            out.append((n, np.rint(a).astype(np.int64) if n in ints else a))
             v += 1
     return out
 
@@ -670,16 +677,18 @@ def _merge_equal_keys(d):
         return d
     if n > 4096:                                             # large results: sort-based grouping in numpy
         cols = [a for _, a in d.key_fields]
-        order = np.lexsort([c if c.dtype.kind != "U" else np.unique(c, return_inverse=True)[1] for c in reversed(cols)])
-        sorted_cols = [c[order] for c in cols]
+        # an integer stand-in per column: dictionary codes as they are (equal code <=> equal text), other text factorised
+        ints = [c.refs if isinstance(c, TextRefs) and c.distinct else (np.unique(np.asarray(c), return_inverse=True)[1] if c.dtype.kind == "U" else np.asarray(c)) for c in cols]
+        order = np.lexsort(list(reversed(ints)))
         new_group = np.zeros(n, bool); new_group[0] = True
-        for c in sorted_cols:
-            new_group[1:] |= c[1:] != c[:-1]
+        for c in ints:
+            cs = c[order]
+            new_group[1:] |= cs[1:] != cs[:-1]
         if new_group.all():
             return d
         gid = np.cumsum(new_group) - 1
         first = np.nonzero(new_group)[0]
-        kf = [(nm, c[first]) for (nm, _), c in zip(d.key_fields, sorted_cols)]
+        kf = [(nm, c[order[first]]) for (nm, _), c in zip(d.key_fields, cols)]
         vf = []
         for nm, a in d.val_fields:
             acc = np.zeros(len(first), a.dtype)
@@ -762,7 +771,13 @@ def _eval_scalar_expr(e, env, lineno):
     raise UnsupportedQuery("line %d: unsupported scalar expression %r" % (lineno, e))
 
 
-def _prepare_scan(eng, op, htab, accumulate_into, member_only=False, as_table=False):
+def _has_codable_text_payload(eng, op, htab):
+    vals = [e for _, e in op.val.fields] if isinstance(op.val, RecordCons) else [op.val]
+    return any(isinstance(e, Col) and htab.cols.get(e.name) is not None and htab.cols[e.name].dtype.kind == "U"
+               and eng.dict_column(htab.cols[e.name]) is not None for e in vals)
+
+
+def _prepare_scan(eng, op, htab, accumulate_into, member_only=False, as_table=False, coded_text=False):
     """closure(env) for one table loop: the tuned fixed-shape calls when the loop is one of their shapes,
     a row program (xplan.py: a kernel specialised on the loop's own conditions and values) otherwise.
     A fixed-shape closure can still refuse at run time (a group count beyond its kernels): the loop then
@@ -770,6 +785,12 @@ def _prepare_scan(eng, op, htab, accumulate_into, member_only=False, as_table=Fa
     from . import xplan
     if getattr(eng, "force_programs", False):
         # every loop through a row program (tests / A-B measurements: the specialised kernels against the tuned ones)
+        try:
+            return xplan.prepare_scan(eng, op, htab, accumulate_into, member_only, as_table)
+        except UnsupportedQuery:
+            pass
+    if coded_text and op.kind == "dict" and op.unique and op.probe is None and _has_codable_text_payload(eng, op, htab):
+        # a later loop tests this build's text values: build them as dictionary codes (row program), not row references
         try:
             return xplan.prepare_scan(eng, op, htab, accumulate_into, member_only, as_table)
         except UnsupportedQuery:
@@ -1091,14 +1112,19 @@ def _materialize(eng, value, env, hint_key=None, top=None):
         bt = env[value[1]]
         out_key_fields, vnames, count_idx, key_is_record, val_is_record, nv = bt.agg
         entry_is_group = any(src == "key" for _, src in out_key_fields) or bt.shared_groups
-        spec = _device_sort_spec(bt, out_key_fields, vnames, count_idx, top[1]) if top is not None and entry_is_group else None
+        spec = _device_sort_spec(bt, out_key_fields, vnames, count_idx, top[1]) if top is not None and entry_is_group and bt.key_radix is None else None
         keys, payload, values, hits, ordered = _fetch_entries(eng, bt.table, 1, hint_key, top, spec, want_hits=count_idx is not None or (spec is not None and any(s[0] == abi.SORT_HITS for s in spec)))
         values = [values[j] for j in range(nv)]
         fields_of = bt.agg_fields
+        if getattr(bt, "key_radix", None) is not None and out_key_fields == [(bt.key_name, "key")]:    # several key fields in one mixed-radix integer
+            from . import xplan
+            d = DictResult(xplan._decode_radix(keys, bt.key_radix[0], bt.key_radix[1]), _value_arrays(vnames, count_idx, values, hits, bt.int_values), True, val_is_record)
+            d.ordered = False
+            return d
         if bt.key_parts is not None and out_key_fields == [(bt.key_name, "key")]:        # a composite group key: its two packed parts
             decs = getattr(bt, "key_part_decoders", None) or [None, None]
             d = DictResult([(bt.key_parts[0], _decode_column(keys >> 32, decs[0], np.int64)), (bt.key_parts[1], _decode_column(keys & 0xFFFFFFFF, decs[1], np.int64))],
-                           _value_arrays(vnames, count_idx, values, hits), True, val_is_record)
+                           _value_arrays(vnames, count_idx, values, hits, bt.int_values), True, val_is_record)
             d.ordered = ordered
             return d
 
@@ -1111,7 +1137,7 @@ def _materialize(eng, value, env, hint_key=None, top=None):
             dec = None if src == "key" else bt.decoder_of(fields_of.get(fname), src)
             return decode_text(payload[src], dec) if dec is not None and dec.dtype.kind == "U" else decode(fname, src)
         if entry_is_group or ordered:
-            d = DictResult([(f, decode_late(f, src)) for f, src in out_key_fields], _value_arrays(vnames, count_idx, values, hits),
+            d = DictResult([(f, decode_late(f, src)) for f, src in out_key_fields], _value_arrays(vnames, count_idx, values, hits, bt.int_values),
                            key_is_record, val_is_record)
             d.ordered = ordered
             return d
@@ -1152,7 +1178,7 @@ def _materialize(eng, value, env, hint_key=None, top=None):
                 values = [np.add.reduceat(v[order], first) for v in values]
                 if want_counts:
                     hits = np.add.reduceat(np.asarray(hits)[order], first)
-        vf = _value_arrays(vnames, count_idx, values, hits)
+        vf = _value_arrays(vnames, count_idx, values, hits, bt.int_values)
         numeric = {f: decode(f, src) for f, src in out_key_fields
                    if bt.decoder_of(fields_of.get(f), src) is None or bt.decoder_of(fields_of.get(f), src).dtype.kind != "U"}
         distinct = any(_all_distinct(a) for a in numeric.values())
@@ -1248,6 +1274,47 @@ def _looked_up(plan):
                 if e is not None:
                     _walk_lookups(e, found)
     return {lk.dict_name for lk in found}
+
+
+def _compared_lookups(plan):
+    """Names of the results whose looked-up VALUES a table loop compares or tests (`d[k] == "x"`, `d[k].f > 3`,
+    startsWith(d[k].f, ...)): their text payloads are worth dictionary codes (a test on a code set), which the
+    row-program builds produce; the fixed-shape builds carry text as row references."""
+    found = set()
+
+    def mark(e):
+        if isinstance(e, PayloadField):
+            found.add(e.lookup.dict_name)
+        elif isinstance(e, Lookup):
+            found.add(e.dict_name)
+
+    def walk(e):
+        if isinstance(e, Cmp):
+            mark(e.left); mark(e.right); walk(e.left); walk(e.right)
+        elif isinstance(e, Call):
+            for a in e.args:
+                mark(a); walk(a)
+        elif isinstance(e, Bin):
+            walk(e.left); walk(e.right)
+        elif isinstance(e, (And, Or)):
+            for t in e.terms:
+                walk(t)
+        elif isinstance(e, Not):
+            walk(e.term)
+        elif isinstance(e, IfElse):
+            walk(e.cond); walk(e.then); walk(e.other)
+        elif isinstance(e, RecordCons):
+            for _, x in e.fields:
+                walk(x)
+        elif isinstance(e, (Lookup, PayloadField)):
+            walk(e.key if isinstance(e, Lookup) else e.lookup.key)
+
+    for op in plan.ops:
+        if isinstance(op, ScanOp):
+            for e in list(op.conds) + [op.key, op.val]:
+                if e is not None:
+                    walk(e)
+    return found
 
 
 def _host_dict(eng, op, env, is_result):
@@ -1362,10 +1429,12 @@ class PreparedPlan:
         # membership-only tables (sdqh_build_key_set)
         member_only = _membership_only(plan)
         looked_up = _looked_up(plan)
+        compared = _compared_lookups(plan)
         self.steps = []
         for op in plan.ops:
             if isinstance(op, ScanOp):
-                self.steps.append((op.out, _prepare_scan(eng, op, tables[op.table], accumulate_into, op.out in member_only, op.out in looked_up)))
+                self.steps.append((op.out, _prepare_scan(eng, op, tables[op.table], accumulate_into, op.out in member_only, op.out in looked_up,
+                                                         coded_text=op.out in compared)))
             elif isinstance(op, SelectKeysOp):
                 self.steps.append((op.out, (lambda env, op=op: _select_keys(eng, op, env))))
             elif isinstance(op, ScalarExprOp):

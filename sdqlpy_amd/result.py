@@ -11,6 +11,11 @@ import numpy as np
 from .sdql_lib import record, sr_dict
 
 
+class Dictionary(np.ndarray):
+    """The distinct values of a dictionary-coded text column (engine.dict_column): a decoder whose entries are
+    pairwise different, so equal codes <=> equal text and grouping can stay on the integer codes."""
+
+
 class TextRefs:
     """A text column of a large result, not decoded yet: row references (or dictionary codes) as they
     came from the device, and the host array they index.  The reference's result object defers its
@@ -25,23 +30,24 @@ class TextRefs:
 
     dtype = property(lambda self: self.decoder.dtype)
     shape = property(lambda self: self.refs.shape)
+    distinct = property(lambda self: isinstance(self.decoder, Dictionary))     # equal references <=> equal text
 
     def __len__(self):
         return len(self.refs)
 
     def __array__(self, dtype=None, copy=None):
-        a = self.decoder[self.refs]
+        a = np.asarray(self.decoder)[self.refs]
         return a if dtype is None else a.astype(dtype)
 
     def __getitem__(self, idx):
         if isinstance(idx, (int, np.integer)):
-            return self.decoder[self.refs[idx]]
+            return np.asarray(self.decoder)[self.refs[idx]]
         out = TextRefs.__new__(TextRefs)                          # slices / index arrays stay references
         out.refs, out.decoder = self.refs[idx], self.decoder
         return out
 
     def tolist(self):
-        return self.decoder[self.refs].tolist()
+        return np.asarray(self.decoder)[self.refs].tolist()
 
     # comparisons are element-wise on the decoded text, as for an ndarray (identity comparison of two
     # lazy columns would silently yield one bool)
@@ -62,7 +68,7 @@ LAZY_TEXT_ROWS = 4096        # results with at least this many rows keep their t
 
 def decode_text(refs, decoder):
     """decoder[refs], deferred for large results."""
-    return TextRefs(refs, decoder) if len(refs) >= LAZY_TEXT_ROWS else decoder[refs]
+    return TextRefs(refs, decoder) if len(refs) >= LAZY_TEXT_ROWS else np.asarray(decoder)[refs]
 
 
 class ResultSet:

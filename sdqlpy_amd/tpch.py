@@ -141,7 +141,11 @@ QUERY_COLUMNS = {
            "lineitem": ["l_partkey", "l_suppkey", "l_orderkey", "l_extendedprice", "l_discount"],
            "orders": ["o_orderkey", "o_custkey", "o_orderdate"], "customer": ["c_custkey", "c_nationkey"],
            "nation": ["n_nationkey", "n_name", "n_regionkey"], "region": ["r_regionkey", "r_name"]},
+    "q12": {"orders": ["o_orderkey", "o_orderpriority"],
+            "lineitem": ["l_orderkey", "l_shipmode", "l_shipdate", "l_commitdate", "l_receiptdate"]},
     "q13": {"customer": ["c_custkey"], "orders": ["o_custkey", "o_comment"]},
+    "q16": {"part": ["p_partkey", "p_brand", "p_type", "p_size"], "supplier": ["s_suppkey", "s_comment"],
+            "partsupp": ["ps_partkey", "ps_suppkey"]},
     "q15": {"lineitem": ["l_suppkey", "l_shipdate", "l_extendedprice", "l_discount"], "supplier": ["s_suppkey", "s_name", "s_address", "s_phone"]},
     "q17": {"lineitem": ["l_partkey", "l_quantity", "l_extendedprice"], "part": ["p_partkey", "p_brand", "p_container"]},
     "q19": {"lineitem": ["l_partkey", "l_quantity", "l_extendedprice", "l_discount", "l_shipinstruct", "l_shipmode"],

@@ -265,6 +265,26 @@ def q8(region, nation, customer, supplier, part, orders, lineitem):
     return share
 
 
+# ---- q12: late line items of two ship modes by the priority class of their order ----------------------------------
+# (the reference nests a dictionary per order, {l_orderkey: {l_shipmode: n}}, and walks it from the orders side; here the
+#  order's priority is looked up from the lineitem side, so the loop is one group-by with two conditional counts)
+@sdql_compile({"orders": order_type, "lineitem": lineitem_type})
+def q12(orders, lineitem):
+    priority = orders.sum(lambda o: {unique(o[0].o_orderkey): o[0].o_orderpriority})
+    late_lines = lineitem.sum(
+        lambda l: {
+            record({"l_shipmode": l[0].l_shipmode}):
+            record({"high_line_count": 1 if priority[l[0].l_orderkey] == "1-URGENT" or priority[l[0].l_orderkey] == "2-HIGH" else 0,
+                    "low_line_count": 1 if priority[l[0].l_orderkey] != "1-URGENT" and priority[l[0].l_orderkey] != "2-HIGH" else 0})}
+        if (l[0].l_shipmode == "MAIL" or l[0].l_shipmode == "SHIP")
+        and 19940101 <= l[0].l_receiptdate < 19950101
+        and l[0].l_shipdate < l[0].l_commitdate and l[0].l_commitdate < l[0].l_receiptdate
+        and priority[l[0].l_orderkey] != None      # noqa: E711
+        else None)
+    by_mode = late_lines.sum(lambda g: {unique(g[0].concat(g[1])): True})
+    return by_mode
+
+
 # ---- q13: customer distribution by number of (non-special) orders --------------------------------------------
 @sdql_compile({"orders": order_type, "customer": customer_type})
 def q13(orders, customer):
@@ -291,6 +311,32 @@ def q15(lineitem, supplier):
         "s_suppkey": g[0], "s_name": suppliers[g[0]].s_name, "s_address": suppliers[g[0]].s_address,
         "s_phone": suppliers[g[0]].s_phone, "total_revenue": g[1]})): True})
     return ranked
+
+
+# ---- q16: suppliers per (brand, type, size) of the wanted parts, complaint-ridden suppliers left out -----------------
+# (COUNT(DISTINCT ps_suppkey): the distinct (brand, type, size, supplier) combinations first, then their number per group)
+@sdql_compile({"part": part_type, "supplier": supplier_type, "partsupp": partsupp_type})
+def q16(part, supplier, partsupp):
+    wanted_parts = part.sum(
+        lambda p: {unique(p[0].p_partkey): record({"p_brand": p[0].p_brand, "p_type": p[0].p_type, "p_size": p[0].p_size})}
+        if p[0].p_brand != "Brand#45" and not startsWith(p[0].p_type, "MEDIUM POLISHED")
+        and (p[0].p_size == 49 or p[0].p_size == 14 or p[0].p_size == 23 or p[0].p_size == 45
+             or p[0].p_size == 19 or p[0].p_size == 3 or p[0].p_size == 36 or p[0].p_size == 9)
+        else None)
+    complained_about = supplier.sum(
+        lambda s: {unique(s[0].s_suppkey): True}
+        if firstIndex(s[0].s_comment, "Customer") != -1
+        and firstIndex(s[0].s_comment, "Complaints") > firstIndex(s[0].s_comment, "Customer") + 7
+        else None)
+    offers = partsupp.sum(
+        lambda ps: {record({"p_brand": wanted_parts[ps[0].ps_partkey].p_brand, "p_type": wanted_parts[ps[0].ps_partkey].p_type,
+                            "p_size": wanted_parts[ps[0].ps_partkey].p_size, "ps_suppkey": ps[0].ps_suppkey}): 1}
+        if wanted_parts[ps[0].ps_partkey] != None and complained_about[ps[0].ps_suppkey] == None      # noqa: E711
+        else None)
+    suppliers_per_group = offers.sum(
+        lambda g: {record({"p_brand": g[0].p_brand, "p_type": g[0].p_type, "p_size": g[0].p_size}): record({"supplier_cnt": 1})})
+    counted = suppliers_per_group.sum(lambda g: {unique(g[0].concat(g[1])): True})
+    return counted
 
 
 # ---- q17: small-quantity-order revenue: rows below a fifth of their part's average quantity ------------------------
@@ -379,7 +425,7 @@ def q22(orders, customer):
 
 
 QUERIES = {"q6": q6, "q1": q1, "q3": q3, "q5": q5, "q9": q9, "q4": q4, "q14": q14, "q18": q18, "q10": q10,
-           "q7": q7, "q8": q8, "q13": q13, "q15": q15, "q17": q17, "q19": q19, "q20": q20, "q22": q22}
+           "q7": q7, "q8": q8, "q12": q12, "q13": q13, "q15": q15, "q16": q16, "q17": q17, "q19": q19, "q20": q20, "q22": q22}
 
 _TABLE_OF_PARAM = {"lineitem": "lineitem", "orders": "orders", "customer": "customer", "supplier": "supplier", "part": "part",
                    "partsupp": "partsupp", "nation": "nation", "region": "region"}
@@ -418,7 +464,9 @@ TPCH_ORDER = {
     "q10": (20, [("revenue", "desc")]),
     "q7": (100, [("supp_nation", "asc"), ("cust_nation", "asc"), ("l_year", "asc")]),
     "q8": (100, [("o_year", "asc")]),
+    "q12": (100, [("l_shipmode", "asc")]),
     "q13": (100, [("custdist", "desc"), ("c_count", "desc")]),
+    "q16": (100, [("supplier_cnt", "desc"), ("p_brand", "asc"), ("p_type", "asc"), ("p_size", "asc")]),
     "q15": (1, [("total_revenue", "desc")]),
     "q20": (100, [("s_name", "asc")]),
     "q22": (100, [("cntrycode", "asc")]),

@@ -18,7 +18,7 @@ import numpy as np
 from . import abi
 from .frontend import (And, Bin, Call, Cmp, Col, Const, Contains, IfElse, Lookup, Not, Or, PayloadField, RecordCons,
                        ScalarField, StrIn, UnsupportedQuery, WholeKey)
-from .result import DictResult, ResultSet
+from .result import DictResult, ResultSet, TextRefs, decode_text
 
 MAX_CODE_SET = 8          # a text predicate on coded values becomes at most this many equality tests (or one range)
 
@@ -117,6 +117,8 @@ class Compiler:
             else:
                 self.fail("'%s' is not a table a loop can look up" % lk.dict_name)
         parts = [x for _, x in lk.key.fields] if isinstance(lk.key, RecordCons) else [lk.key]
+        if getattr(bt, "key_radix", None) is not None:
+            self.fail("'%s' is keyed by more than two fields: it cannot be looked up" % lk.dict_name)
         if (bt.key_parts is not None) != (len(parts) == 2) or len(parts) > 2:
             self.fail("lookup into '%s' does not match its key shape" % lk.dict_name)
         vals = [self.as_int(self.value(p), "lookup key") for p in parts]
@@ -443,7 +445,7 @@ def _decode_radix(keys, parts, radix):
             out.append((name, np.ascontiguousarray(units).view("<U%d" % kind[1]).reshape(len(keys))))
         else:
             dec = kind[1]
-            out.append((name, dec[cols[0]] if dec is not None else cols[0]))
+            out.append((name, decode_text(cols[0], dec) if dec is not None else cols[0]))      # text of a large result stays references until read
     return out
 
 
@@ -482,7 +484,9 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
                 count_idx = i
                 continue
             v = c.value(e)
-            if isinstance(v, XV) and v.t == "i" and v.dec is None and isinstance(e, Const):
+            if isinstance(v, XV) and v.t == "i" and v.dec is None:    # an integer-valued sum (`1 if c else 0`, an int column): summed as doubles, returned as int64
+                if not isinstance(e, Const):
+                    state.setdefault("int_values", set()).add(vnames[i])
                 v = c.as_float(v)
             if not isinstance(v, XV) or v.t != "f":
                 raise UnsupportedQuery("line %d: summed values must be floating-point expressions (or the constant 1 for a count): %r" % (op.lineno, e))
@@ -664,9 +668,20 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
             gates, _ = gates_of(c, op.conds)
             parts = c.key_parts(key_fields)
             flat = [v for _, vs, _ in parts for v in vs]
-            if len(flat) > 2:
-                raise UnsupportedQuery("line %d: group keys of more than two parts over a large domain are not supported" % op.lineno)
             bounds = (1, 0)
+            if len(flat) > 2:
+                # more than two parts: one mixed-radix integer (the parts' value ranges are known), decoded when the
+                # result is read; such a dictionary cannot be looked up by later loops (Q16's distinct combinations)
+                kid, radix = c.pack_radix(parts)
+                total = 1
+                for _, span in radix:
+                    total *= span
+                if total <= (1 << 31):
+                    bounds = (0, total - 1)
+                state["radix"] = ([(nm or "key%d" % i, [None] * len(vs), kind) for i, (nm, vs, kind) in enumerate(parts)], radix)
+                c.P.gates = gates
+                vals, count_idx = summed_values(c, vexprs) if with_values else ([], None)
+                return c, kid, vals, count_idx, bounds, [XV(kid, "i")]
             if len(flat) == 1:
                 kid = flat[0].id
                 r = c.resolve_rng(flat[0])
@@ -720,6 +735,7 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
             c.bind(env)
             ctx.xprobe_aggregate(n, c.P, probe_id, bt.table)
             bt.agg = (bt.agg_spec, vnames, count_idx, key_is_record, val_is_record, len(c.P.vals))
+            bt.int_values = frozenset(state.get("int_values", ()))
             return ("aggregated", op.probe.dict_name)
         if mode == "groups":
             st = state.get("c")
@@ -735,7 +751,8 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
                     if count_idx is not None and i == count_idx:
                         vf.append((nm, np.asarray(cnts, np.int64)))
                     else:
-                        vf.append((nm, np.ascontiguousarray(vals[:, at]))); at += 1
+                        col = np.ascontiguousarray(vals[:, at]); at += 1
+                        vf.append((nm, np.rint(col).astype(np.int64) if nm in state.get("int_values", ()) else col))
                 d = DictResult(kf, vf, key_is_record, val_is_record)
                 if any(kind[0] == "int" and kind[1] is not None for _, _, kind in parts):
                     from .engine import _merge_equal_keys
@@ -771,7 +788,9 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
             bt.key_parts = key_names
             bt.key_part_decoders = state.get("part_decs")
         bt.key_decoder = key_dec
+        bt.key_radix = state.get("radix")
         bt.agg = ([(key_names[0], "key")], vnames, count_idx, key_is_record, val_is_record, len(vals))
+        bt.int_values = frozenset(state.get("int_values", ()))
         hidden = op.out + "$groups"
         env[hidden] = bt
         return ("aggregated", hidden)
@@ -817,11 +836,11 @@ def run_host_dict(eng, op, env, materialize):
             if e.field is None:
                 if len(side) != 1:
                     raise UnsupportedQuery("line %d: p[%d] is a record; name a field" % (op.lineno, e.which))
-                return np.asarray(side[0][1])
+                return side[0][1] if isinstance(side[0][1], TextRefs) else np.asarray(side[0][1])
             hitf = [a for nm, a in side if nm == e.field]
             if not hitf:
                 raise UnsupportedQuery("line %d: p[%d] has no field '%s'" % (op.lineno, e.which, e.field))
-            return np.asarray(hitf[0])
+            return hitf[0] if isinstance(hitf[0], TextRefs) else np.asarray(hitf[0])      # text of a large result stays references (grouping works on them)
         if isinstance(e, ScalarField):
             v = env[e.name]
             return float(v if e.field is None else v[e.field])
@@ -880,17 +899,24 @@ def run_host_dict(eng, op, env, materialize):
     for c in op.conds:
         keep &= np.asarray(cond(c), bool)
 
+    def arr(v):
+        return v if isinstance(v, TextRefs) else np.asarray(v)
+
     def fields_of(e, default):
         if isinstance(e, RecordCons):
-            return [(nm, np.asarray(val(x))) for nm, x in e.fields], True
-        return [(default, np.asarray(val(e)))], False
+            return [(nm, arr(val(x))) for nm, x in e.fields], True
+        return [(default, arr(val(e)))], False
 
     def broadcast(a):
-        return np.full(n, a) if np.ndim(a) == 0 else a
+        return a if isinstance(a, TextRefs) else (np.full(n, a) if np.ndim(a) == 0 else a)
     kf, key_is_record = fields_of(op.key, "key")
     kf = [(nm, broadcast(a)[keep]) for nm, a in kf]
     if isinstance(op.val, Const) and op.val.value is True:
         return ResultSet([nm for nm, _ in kf], [a for _, a in kf])
     vf, val_is_record = fields_of(op.val, "value")
     vf = [(nm, broadcast(a)[keep]) for nm, a in vf]
-    return DictResult(kf, vf, key_is_record, val_is_record)
+    d = DictResult(kf, vf, key_is_record, val_is_record)
+    if not op.unique:                                                # a group-by over the dictionary (Q16: combinations -> their number per group)
+        from .engine import _merge_equal_keys
+        d = _merge_equal_keys(d)
+    return d

@@ -334,6 +334,35 @@ __device__ __forceinline__ bool lds_str_contains(const uint32_t* s, int width, c
     }
     return found;
 }
+// VarChar::firstIndex (reference include/varchar.h:91-97) on a field in LDS: position of the first occurrence of the needle
+// in the text before the first NUL, or -1.  The same 32-position rounds as lds_str_contains.
+__device__ __forceinline__ int64_t lds_first_index(const uint32_t* s, int width, const uint32_t* val, int len) {
+    if (len == 0) return 0;
+    const uint32_t v0 = val[0];
+    bool ended = false;
+    for (int w0 = 0; w0 < width && !ended; w0 += 32) {
+        uint32_t first = 0, nul = 0;
+        const int nk = min(32, width - w0);
+        if (nk == 32) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) { const uint32_t c = s[w0 + k]; first |= (c == v0 ? 1u : 0u) << k; nul |= (c == 0u ? 1u : 0u) << k; }
+        } else {
+#pragma unroll 4
+            for (int k = 0; k < nk; ++k) { const uint32_t c = s[w0 + k]; first |= (c == v0 ? 1u : 0u) << k; nul |= (c == 0u ? 1u : 0u) << k; }
+            nul |= nk < 32 ? (1u << nk) : 0u;
+        }
+        if (nul) { first &= (nul & (0u - nul)) - 1u; ended = true; }
+        while (first) {
+            const int pos = w0 + __builtin_ctz(first);
+            first &= first - 1u;
+            if (pos + len > width) return -1;
+            int k = 1;
+            while (k < len && s[pos + k] == val[k]) ++k;                  // a NUL inside stops the comparison: the needle has none
+            if (k == len) return pos;
+        }
+    }
+    return -1;
+}
 __device__ __forceinline__ bool lds_str_pred(const uint32_t* s, int width, const uint32_t* val, int len, int mode) {
     if (mode == 2) {
         if (len == 0) return true;

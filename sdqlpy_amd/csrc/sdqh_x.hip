@@ -190,7 +190,17 @@ struct Gen {
     const XInfo& x; std::ostringstream os; std::vector<char> done; int mode = 0;      // mode 0: columns gathered by row r; 1: from streamed registers, half H; 2: stest (explicit .x / .y)
     const char* half = "";
     std::vector<int> slot_of;                  // column -> slot in the streamed register array
-    explicit Gen(const XInfo& xi) : x(xi), done((size_t)xi.p->nops, 0), slot_of((size_t)SDQH_MAX_XCOLS, -1) {}
+    std::vector<int> sres_of;                  // text operation -> its slot in the drain's staged results (-1: reads the column in global memory)
+    explicit Gen(const XInfo& xi) : x(xi), done((size_t)xi.p->nops, 0), slot_of((size_t)SDQH_MAX_XCOLS, -1), sres_of((size_t)xi.p->nops, -1) {}
+    // the text operation itself, on the field at `field` ("pointer, width"); lds: the field was staged in LDS
+    std::string text_op(int k, const std::string& field, bool lds = false) const {
+        const sdqh_xop& o = x.p->ops[k];
+        if (lds && o.code == SDQH_X_STR) return "lds_str_pred(" + field + ", a.spool + " + std::to_string(x.str_off[k]) + ", " + std::to_string(o.slen) + ", " + std::to_string(o.aux) + ")";
+        if (lds && o.code == SDQH_X_STRIDX) return "lds_first_index(" + field + ", a.spool + " + std::to_string(x.str_off[k]) + ", " + std::to_string(o.slen) + ")";
+        if (o.code == SDQH_X_STR) return "str_pred(" + field + ", a.spool + " + std::to_string(x.str_off[k]) + ", " + std::to_string(o.slen) + ", " + std::to_string(o.aux) + ")";
+        if (o.code == SDQH_X_STRIDX) return "x_first_index(" + field + ", a.spool + " + std::to_string(x.str_off[k]) + ", " + std::to_string(o.slen) + ")";
+        return "x_char(" + field + ", " + std::to_string(o.aux) + ")";
+    }
 
     static const char* ctype(int t) { return t == SDQH_T_F64 ? "double" : t == SDQH_T_BOOL ? "bool" : "int64_t"; }
     std::string bad(int k) const {
@@ -260,11 +270,12 @@ struct Gen {
                 e = "(" + v(o.a) + " ? " + v(o.b) + " : " + v(o.c) + ")";
                 break;
             case SDQH_X_STR: case SDQH_X_STRIDX: case SDQH_X_CHAR: {
+                if (sres_of[(size_t)k] >= 0) {                             // computed by the drain from the field staged in LDS
+                    e = o.code == SDQH_X_STR ? "(sres[" + std::to_string(sres_of[(size_t)k]) + "] != 0)" : "sres[" + std::to_string(sres_of[(size_t)k]) + "]";
+                    break;
+                }
                 const std::string c = std::to_string(x.col_of[k]);
-                const std::string field = "static_cast<const uint32_t*>(a.col[" + c + "]) + r * (int64_t)a.width[" + c + "], a.width[" + c + "]";
-                if (o.code == SDQH_X_STR) e = "str_pred(" + field + ", a.spool + " + std::to_string(x.str_off[k]) + ", " + std::to_string(o.slen) + ", " + std::to_string(o.aux) + ")";
-                else if (o.code == SDQH_X_STRIDX) e = "x_first_index(" + field + ", a.spool + " + std::to_string(x.str_off[k]) + ", " + std::to_string(o.slen) + ")";
-                else e = "x_char(" + field + ", " + std::to_string(o.aux) + ")";
+                e = text_op(k, "static_cast<const uint32_t*>(a.col[" + c + "]) + r * (int64_t)a.width[" + c + "], a.width[" + c + "]");
                 break;
             }
             default: e = "0";
@@ -285,7 +296,36 @@ std::string generate(const XInfo& x, Sink sink, bool direct) {
     const int ns = (int)scols.size(), nsx = std::max(1, ns);
     std::ostringstream out;
     out << "#include \"sdqh_xkernels.hpp\"\nusing namespace sdqh;\n";
-    out << "struct P {\n    static constexpr int NS = " << ns << ", NV = " << p->nvals << ";\n";
+    // text operations: per text column (at most two, fields of at most XSTR_UNITS code units), evaluated by the drain on
+    // fields staged in LDS; any other program scans its fields in global memory as before
+    std::vector<int> tcols, twidth; std::vector<std::vector<int>> tops;
+    bool stage_text = !direct;
+    for (int k = 0; k < p->nops && stage_text; ++k) {
+        const int code = p->ops[k].code;
+        if (code != SDQH_X_STR && code != SDQH_X_STRIDX && code != SDQH_X_CHAR) continue;
+        const int c = x.col_of[k], w = p->ops[k].col ? p->ops[k].col->width : 0;
+        size_t j = 0;
+        while (j < tcols.size() && tcols[j] != c) ++j;
+        if (j == tcols.size()) { tcols.push_back(c); twidth.push_back(w); tops.emplace_back(); }
+        tops[j].push_back(k);
+        if (tcols.size() > 2 || w < 1 || w > XSTR_UNITS) stage_text = false;
+    }
+    if (!stage_text) { tcols.clear(); twidth.clear(); tops.clear(); }
+    int nsop = 0;
+    for (auto& ops : tops) for (int k : ops) g.sres_of[(size_t)k] = nsop++;
+    const int nsopx = std::max(1, nsop);
+    out << "struct P {\n    static constexpr int NS = " << ns << ", NV = " << p->nvals << ", NSC = " << tcols.size() << ", NSOP = " << nsop << ";\n";
+    if (!tcols.empty()) {
+        out << "    __device__ __forceinline__ static constexpr int scol(int j) { return j == 0 ? " << tcols[0] << " : " << (tcols.size() > 1 ? tcols[1] : tcols[0]) << "; }\n";
+        out << "    __device__ __forceinline__ static constexpr int swidth(int j) { return j == 0 ? " << twidth[0] << " : " << (twidth.size() > 1 ? twidth[1] : twidth[0]) << "; }\n";
+        out << "    template <int J> __device__ __forceinline__ static void sops(const XArgs& a, const uint32_t* f, int64_t (&sres)[" << nsopx << "]) {\n";
+        for (size_t j = 0; j < tcols.size(); ++j) {
+            out << "        if constexpr (J == " << j << ") {\n";
+            for (int k : tops[j]) out << "            sres[" << g.sres_of[(size_t)k] << "] = (int64_t)" << g.text_op(k, "f, " + std::to_string(twidth[j]), true) << ";\n";
+            out << "        }\n";
+        }
+        out << "    }\n";
+    }
     out << "    template <bool TAIL> __device__ __forceinline__ static void sload(const XArgs& a, int64_t r, int64_t nrows, Pair<int64_t> (&s)[" << nsx << "]) {\n";
     for (int i = 0; i < ns; ++i) out << "        s[" << i << "] = load2<TAIL>(static_cast<const int64_t*>(a.col[" << scols[(size_t)i] << "]), r, nrows);\n";
     out << "    }\n";
@@ -318,7 +358,7 @@ std::string generate(const XInfo& x, Sink sink, bool direct) {
     out << "    template <int H> __device__ __forceinline__ static bool eval_regs(const XArgs& a, const Pair<int64_t> (&s)[" << nsx << "], int64_t r, XOut<NV>& o) {\n";
     if (direct) out << body(1, 0); else out << "        return false;\n";
     out << "    }\n";
-    out << "    __device__ __forceinline__ static bool eval_row(const XArgs& a, int64_t r, XOut<NV>& o) {\n";
+    out << "    __device__ __forceinline__ static bool eval_row(const XArgs& a, int64_t r, const int64_t (&sres)[" << nsopx << "], XOut<NV>& o) {\n";
     if (!direct) out << body(0, first_gate); else out << "        return false;\n";
     out << "    }\n};\n";
     const std::string sn = sink_name(sink);
@@ -386,6 +426,7 @@ uint64_t structure_hash(const XInfo& x, Sink sink, bool direct) {
         mix(((uint64_t)(uint32_t)o.code << 32) | (uint32_t)o.type); mix(((uint64_t)(uint32_t)o.a << 32) | (uint32_t)o.b); mix(((uint64_t)(uint32_t)o.c << 32) | (uint32_t)o.aux);
         mix(((uint64_t)(uint32_t)x.col_of[k] << 32) | (uint32_t)x.tab_of[k]); mix(((uint64_t)(uint32_t)x.const_of[k] << 32) | (uint32_t)x.str_off[k]);
         if (o.code == SDQH_X_STR || o.code == SDQH_X_STRIDX) { mix((uint64_t)o.slen); for (int i = 0; i < o.slen; ++i) mix(o.str[i]); }
+        if (o.code == SDQH_X_STR || o.code == SDQH_X_STRIDX || o.code == SDQH_X_CHAR) mix((uint64_t)(o.col ? o.col->width : 0));      // the staged field width is a compile-time constant
     }
     mix((uint64_t)p->ngates); for (int g = 0; g < p->ngates; ++g) mix((uint64_t)p->gates[g]);
     mix((uint64_t)p->nvals); for (int v = 0; v < p->nvals; ++v) mix((uint64_t)p->vals[v]);

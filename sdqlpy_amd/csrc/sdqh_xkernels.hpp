@@ -296,71 +296,125 @@ __device__ __forceinline__ void x_direct(const XArgs& a, const typename SinkT<P:
 // the streamed part (NS may be 0: every row is queued), P::eval_row(a, r, out) -> pass for the rest.
 // =================================================================================================
 constexpr int X_LB = 4;
-constexpr int XQ_CAP = 192;
+constexpr int XQ_CAP = 64 + X_LB * 128;                               // 63 left over + a whole step's candidates, as 32-bit offsets from the segment's first row
+constexpr int XSTR_UNITS = 2048;                                      // code units of text a wave stages in LDS at a time (8 KiB)
+
+// The text operations of a drain, column J of the program's text columns: the fields of the drain's rows are copied into
+// LDS by the whole wave (consecutive code units by consecutive lanes: coalesced, where a lane scanning its own field in
+// global memory touches a different cache line per lane on every step), R rows at a time, and each lane then scans its
+// own field there (P::sops<J>: every text operation of the program on that column, results into sres).  Q13's two
+// firstIndex conditions over o_comment (316 bytes per row): 9.9 -> see DESIGN.md §3b.
+template <class P, int J>
+__device__ __forceinline__ void x_stage_text(const XArgs& a, const int32_t* q_row, int64_t begin, int first, int count, uint32_t* s_str,
+                                             int64_t (&sres)[P::NSOP > 0 ? P::NSOP : 1]) {
+    constexpr int W = P::swidth(J);
+    constexpr int R = (XSTR_UNITS / W) < WAVE ? (XSTR_UNITS / W) : WAVE;
+    static_assert(R >= 1, "a text field wider than the staging window");
+    const uint32_t* __restrict__ col = static_cast<const uint32_t*>(a.col[P::scol(J)]);
+    const int lane = lane_id();
+    for (int base = 0; base < count; base += R) {
+        const int nr = count - base < R ? count - base : R;
+        __builtin_amdgcn_wave_barrier();
+        // every load of the round in flight before the first LDS store (a load -> store loop ran one round trip per 64 units)
+        constexpr int NL = (R * W + WAVE - 1) / WAVE;                    // <= 32 code units per lane
+        uint32_t t[NL];
+        const int q0 = q_row[first + base], q1 = q_row[first + base + nr - 1];
+        if (q1 - q0 == nr - 1) {                                         // consecutive rows (the usual case): one contiguous block
+            const uint32_t* __restrict__ src = col + (begin + (int64_t)q0) * W;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) { const int idx = lane + i * WAVE; t[i] = idx < nr * W ? src[idx] : 0u; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int idx = lane + i * WAVE;
+                t[i] = 0u;
+                if (idx < nr * W) { const int row = idx / W, u = idx - row * W; t[i] = col[(begin + (int64_t)q_row[first + base + row]) * W + u]; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) { const int idx = lane + i * WAVE; if (idx < nr * W) s_str[idx] = t[i]; }
+        __builtin_amdgcn_wave_barrier();
+        if (lane >= base && lane < base + nr) P::template sops<J>(a, s_str + (lane - base) * W, sres);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
 
 template <class P, template <int> class SinkT, bool SEGMENTED>
 __device__ __forceinline__ void x_queue(const XArgs& a, const typename SinkT<P::NV>::Args& sa, int64_t nrows, int64_t seg_rows, int nseg) {
     using Sink = SinkT<P::NV>;
     constexpr int NS = P::NS > 0 ? P::NS : 1;
-    __shared__ int64_t s_row[TPB / WAVE][XQ_CAP];
+    __shared__ int32_t s_row[TPB / WAVE][XQ_CAP];
+    __shared__ uint32_t s_text[P::NSC > 0 ? TPB / WAVE : 1][P::NSC > 0 ? XSTR_UNITS : 1];
     Sink sink;
     sink.init(sa);
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
     const bool live = seg < nseg;
-    int64_t* q_row = s_row[threadIdx.x / WAVE];
+    int32_t* q_row = s_row[threadIdx.x / WAVE];
+    uint32_t* s_str = s_text[P::NSC > 0 ? threadIdx.x / WAVE : 0];
     const int lane = lane_id();
     const uint64_t lt = lanemask_lt();
     constexpr int64_t BATCH_ROWS = WAVE * ROWS_PER_LOAD;
-    const int64_t begin = (int64_t)seg * seg_rows;
+    const int64_t begin = (int64_t)seg * seg_rows;                     // (a segment is far shorter than 2^31 rows: the host checks)
     int64_t end = begin + seg_rows; if (end > nrows) end = nrows;
     if constexpr (SEGMENTED) sink.begin_segment(begin);
     int qn = 0;
-    auto drain = [&](int count) {                                      // rows q_row[0..count), one per lane, in row order
+    auto drain = [&](int first, int count) {                           // rows q_row[first .. first + count), one per lane, in row order
         XOut<P::NV> o;
+        int64_t sres[P::NSOP > 0 ? P::NSOP : 1] = {0};
+        if constexpr (P::NSC > 0) x_stage_text<P, 0>(a, q_row, begin, first, count, s_str, sres);
+        if constexpr (P::NSC > 1) x_stage_text<P, 1>(a, q_row, begin, first, count, s_str, sres);
         bool pass = false; int64_t r = 0;
-        if (lane < count) { r = q_row[lane]; pass = P::eval_row(a, r, o); }
+        if (lane < count) { r = begin + (int64_t)q_row[first + lane]; pass = P::eval_row(a, r, sres, o); }
         sink.consume(a, sa, pass, r, o);
     };
     auto enqueue = [&](int64_t r, bool p0, bool p1) {
         const uint64_t b0 = __ballot(p0), b1 = __ballot(p1);
         if (b0 | b1) {
             const int at = qn + __popcll(b0 & lt) + __popcll(b1 & lt);
-            if (p0) q_row[at] = r;
-            if (p1) q_row[at + (p0 ? 1 : 0)] = r + 1;
+            const int32_t off = (int32_t)(r - begin);
+            if (p0) q_row[at] = off;
+            if (p1) q_row[at + (p0 ? 1 : 0)] = off + 1;
             qn += __popcll(b0) + __popcll(b1);
-            while (qn >= WAVE) {                                       // drain the FRONT 64, shift the rest down
-                drain(WAVE);
-                const int left = qn - WAVE;
-                int64_t a0 = 0, a1 = 0;
-                if (lane < left) a0 = q_row[WAVE + lane];
-                if (lane + WAVE < left) a1 = q_row[2 * WAVE + lane];
-                if (lane < left) q_row[lane] = a0;
-                if (lane + WAVE < left) q_row[WAVE + lane] = a1;
-                qn = left;
-            }
         }
     };
     if (live) {
-        for (int64_t b = begin; b < end; b += BATCH_ROWS * X_LB) {
-            if (b + BATCH_ROWS * X_LB <= end) {
+        // One loop, one drain site (as k_build_lookup: the drain is most of the code): a step produces candidates, then
+        // the FRONT full waves of the queue are drained in row order and what is left moves down.
+        for (int64_t b = begin;;) {
+            const bool last = b >= end;
+            if (last) {
+            } else if (b + BATCH_ROWS * X_LB <= end) {
                 Pair<int64_t> s[X_LB][NS];
                 int64_t rr[X_LB];
 #pragma unroll
                 for (int j = 0; j < X_LB; ++j) { rr[j] = b + (int64_t)j * BATCH_ROWS + (int64_t)lane * ROWS_PER_LOAD; P::template sload<false>(a, rr[j], nrows, s[j]); }
 #pragma unroll
                 for (int j = 0; j < X_LB; ++j) { bool p0 = true, p1 = true; P::stest(a, s[j], p0, p1); enqueue(rr[j], p0, p1); }
+                b += BATCH_ROWS * X_LB;
             } else {
-                for (int64_t bb = b; bb < end; bb += BATCH_ROWS) {
-                    const int64_t r = bb + (int64_t)lane * ROWS_PER_LOAD;
-                    Pair<int64_t> s1[NS];
-                    P::template sload<true>(a, r, end, s1);
-                    bool p0 = r < end, p1 = r + 1 < end;
-                    P::stest(a, s1, p0, p1);
-                    enqueue(r, p0, p1);
-                }
+                const int64_t r = b + (int64_t)lane * ROWS_PER_LOAD;
+                Pair<int64_t> s1[NS];
+                P::template sload<true>(a, r, end, s1);
+                bool p0 = r < end, p1 = r + 1 < end;
+                P::stest(a, s1, p0, p1);
+                enqueue(r, p0, p1);
+                b += BATCH_ROWS;
+            }
+            int head = 0;
+            while (qn - head >= WAVE || (last && qn > head)) {
+                const int n = qn - head >= WAVE ? WAVE : qn - head;
+                drain(head, n);
+                head += n;
+            }
+            if (last) break;
+            if (head) {
+                const int left = qn - head;                               // < 64
+                int32_t keepv = 0;
+                if (lane < left) keepv = q_row[head + lane];
+                if (lane < left) q_row[lane] = keepv;
+                qn = left;
             }
         }
-        if (qn > 0) drain(qn);
         if constexpr (SEGMENTED) sink.end_segment(sa, seg, begin);
     }
     sink.finish(a, sa);

@@ -250,7 +250,10 @@ class Compiler:
                 tx = self.value(e.args[0])
                 if not isinstance(tx, Text):
                     self.fail("firstIndex needs a text column of the scanned table")
-                return XV(self.P.op(abi.X_STRIDX, abi.T_I64, col=self.eng.column(tx.arr), text=e.args[1].value), "i", rng=(-1, tx.arr.dtype.itemsize // 4))
+                key = ("stridx", tx.name, e.args[1].value)                 # the same search named twice in a condition is one operation
+                if key not in self.memo:
+                    self.memo[key] = XV(self.P.op(abi.X_STRIDX, abi.T_I64, col=self.eng.column(tx.arr), text=e.args[1].value), "i", rng=(-1, tx.arr.dtype.itemsize // 4))
+                return self.memo[key]
             if e.fn == "substr":
                 self.fail("substr() is only supported as a group key")
         self.fail("unsupported expression %r" % (e,))
@@ -862,6 +865,8 @@ def run_host_dict(eng, op, env, materialize):
                 if not got:
                     raise UnsupportedQuery("line %d: '%s' has no field '%s'" % (op.lineno, lk.dict_name, fname))
                 col = np.asarray(got[0])
+            if len(col) and col.dtype.kind == "U" and hit.all():
+                return decode_text(rows, col)                            # text of a large result: the row references now, the (wide) strings when read
             out = col[rows] if len(col) else np.zeros(n, col.dtype)
             if not hit.all():
                 out = out.copy()

@@ -377,7 +377,13 @@ def sdql_compile(in_type):
 def benchmark(title, iterations, func, args, show_results=True, verbose=True):
     """One warm-up call, ``iterations`` timed calls (ms, wall clock around the whole call, result
     materialisation included), one more call whose result is shown (ref sdql_lib.py:437-475).
-    Unlike the reference this does not touch /sys/devices/system/cpu/smt/control."""
+    Unlike the reference this does not touch /sys/devices/system/cpu/smt/control.
+
+    What "materialisation" covers: the result's numeric columns and the row references / dictionary codes
+    of its text columns are on the host when a call returns; the TEXT of a result with 4096 rows or more is
+    gathered when it is first read (result.TextRefs: `str(res)`, `.to_dict()`, `.arrays`), as the reference's
+    result object defers its conversion to `to_dict()` (src/sdqlpy/fastd.py:31-51).  With show_results the
+    shown call pays for that gather; the timed calls do not (Q10's 389 K rows: 1.5 ms timed, 70 ms to decode)."""
     times = []
     func(*args)
     for _ in range(iterations):

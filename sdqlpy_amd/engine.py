@@ -679,6 +679,24 @@ def _merge_equal_keys(d):
         cols = [a for _, a in d.key_fields]
         # an integer stand-in per column: dictionary codes as they are (equal code <=> equal text), other text factorised
         ints = [c.refs if isinstance(c, TextRefs) and c.distinct else (np.unique(np.asarray(c), return_inverse=True)[1] if c.dtype.kind == "U" else np.asarray(c)) for c in cols]
+        lo = [int(c.min()) for c in ints]
+        span = [int(c.max()) - l + 1 for c, l in zip(ints, lo)]
+        cells = 1
+        for w in span:
+            cells *= w
+        if cells <= _DENSE_MERGE_CELLS:                      # the stand-ins span a small box: bucket the rows, no sort (Q16: 1.2 M rows into 190 K cells)
+            code = np.zeros(n, np.int64)
+            for c, l, w in zip(ints, lo, span):
+                code = code * w + (c - l)
+            rep = np.full(cells, -1, np.int64)
+            rep[code[::-1]] = np.arange(n - 1, -1, -1)       # the first row of every occupied cell
+            occupied = np.nonzero(rep >= 0)[0]
+            if len(occupied) == n:
+                return d
+            rows = rep[occupied]
+            kf = [(nm, c[rows]) for (nm, _), c in zip(d.key_fields, cols)]
+            vf = [(nm, np.bincount(code, weights=a, minlength=cells)[occupied].astype(a.dtype)) for nm, a in d.val_fields]
+            return DictResult(kf, vf, d.key_is_record, d.val_is_record)
         order = np.lexsort(list(reversed(ints)))
         new_group = np.zeros(n, bool); new_group[0] = True
         for c in ints:

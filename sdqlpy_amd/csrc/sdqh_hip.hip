@@ -273,6 +273,53 @@ bool column_is_increasing(sdqh_ctx* ctx, sdqh_column* c) {
     return ok && c->increasing == 1;
 }
 
+// The 4-byte twin of a streamed column, built and verified on first request (a pass over the column, like min / max).
+// Returns the twin or nullptr (the column does not narrow exactly, or no memory: the caller uses the column itself).
+const void* ensure_narrow(sdqh_ctx* ctx, sdqh_column* c) {
+    if (c->narrow_state >= 0) return c->narrow;
+    c->narrow_state = 0;
+    if (c->dtype == SDQH_STR || c->nrows < 2) return nullptr;
+    int32_t* twin = static_cast<int32_t*>(pool_alloc(ctx, (size_t)c->nrows * 4 + 64));
+    int* flag = static_cast<int*>(pool_alloc(ctx, 64));
+    bool ok = twin && flag && hipMemsetAsync(flag, 0, 4, ctx->stream) == hipSuccess;
+    if (ok) {
+        const unsigned grid = (unsigned)std::min<int64_t>((c->nrows + TPB - 1) / TPB, (int64_t)ctx->num_cu * 8);
+        if (c->dtype == SDQH_I64) hipLaunchKernelGGL(k_narrow_i64, dim3(grid), dim3(TPB), 0, ctx->stream, static_cast<const int64_t*>(c->data), c->nrows, twin, flag);
+        else hipLaunchKernelGGL(k_narrow_f64, dim3(grid), dim3(TPB), 0, ctx->stream, static_cast<const double*>(c->data), c->nrows, twin, flag);
+        int* host = static_cast<int*>(ctx->result_host);
+        ok = hipMemcpyAsync(host, flag, 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess && host[0] == 0;
+    }
+    if (!ok) (void)hipGetLastError();
+    if (flag) pool_free(ctx, flag);
+    if (ok) { c->narrow = twin; c->narrow_state = 1; }
+    else if (twin) pool_free(ctx, twin);
+    return c->narrow;
+}
+// Swap every streamed column of a scan (integer / double predicates, tuple operands) for its twin; false (nothing changed)
+// unless ALL of them have one.  Only for the instances that read nothing else by row (no string / column-pair predicates).
+static bool narrow_streams(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, const sdqh_tuple* tuple, DevFilter* f, DevTuple* t) {
+    if (!ctx->opt_narrow || nrows < (1 << 20) || f->ns || f->nc) return false;
+    const int nops = tuple ? std::max(0, tuple_nops(tuple->shape)) : 0;
+    const sdqh_column* ops[4] = {tuple ? tuple->a : nullptr, tuple ? tuple->b : nullptr, tuple ? tuple->c : nullptr, tuple ? tuple->d : nullptr};
+    const void* ni[SDQH_MAX_IPRED]; const void* nf[SDQH_MAX_FPRED]; const void* no[4];
+    int fi = 0;
+    for (int i = 0; i < f->ni; ++i) { ni[i] = ensure_narrow(ctx, const_cast<sdqh_column*>(filter->ipred[i].col)); if (!ni[i]) return false; }
+    for (int i = 0; filter && i < filter->n_fpred; ++i) {                  // make_filter keeps a double predicate as a streamed column unless it aliases an operand
+        bool alias = false;
+        for (int j = 0; j < nops; ++j) alias = alias || (ops[j] && ops[j]->data == filter->fpred[i].col->data);
+        if (alias) continue;
+        if (fi >= f->nf) return false;
+        nf[fi] = ensure_narrow(ctx, const_cast<sdqh_column*>(filter->fpred[i].col)); if (!nf[fi]) return false;
+        ++fi;
+    }
+    if (fi != f->nf) return false;
+    for (int j = 0; j < nops; ++j) { no[j] = ensure_narrow(ctx, const_cast<sdqh_column*>(ops[j])); if (!no[j]) return false; }
+    for (int i = 0; i < f->ni; ++i) f->ic[i] = static_cast<const int64_t*>(ni[i]);
+    for (int i = 0; i < f->nf; ++i) f->fc[i] = static_cast<const double*>(nf[i]);
+    for (int j = 0; j < nops; ++j) t->op[j] = static_cast<const double*>(no[j]);
+    return true;
+}
+
 // ---- dispatch onto the compiled menu of kernel instances -------------------------------------------
 template <int S> using ShapeC = std::integral_constant<int, S>;
 template <class Fn>
@@ -424,6 +471,7 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "lookup_pipeline" && value >= -1 && value <= 1) ctx->opt_lookup_pipeline = (int)value;
     else if (n == "probe_pipeline" && value >= 0 && value <= 1) ctx->opt_probe_pipeline = (int)value;
     else if (n == "lookup_debug") ctx->opt_lookup_debug = (int)value;
+    else if (n == "narrow" && value >= 0 && value <= 1) ctx->opt_narrow = (int)value;
     else if (n == "stage_pipeline" && value >= 0 && value <= 1) ctx->opt_stage_pipeline = (int)value;
     else if (n == "span_index" && value >= 0 && value <= 1) ctx->opt_span_index = (int)value;
     else if (n == "dense_increasing" && value >= 0 && value <= 1) ctx->opt_dense_increasing = (int)value;
@@ -524,6 +572,7 @@ void sdqh_column_free(sdqh_ctx* ctx, sdqh_column* col) {
         }
         if (col->owned) pool_free(ctx, col->data);
         pool_free(ctx, col->d_minmax);
+        if (col->narrow) pool_free(ctx, col->narrow);
     }
     delete col;
 }
@@ -541,13 +590,20 @@ int sdqh_scan_filter_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter
     double* out_dev = static_cast<double*>(ctx->result_dev);
     int lrc = with_shape(ctx, tuple->shape, [&](auto S) {
         return with_scan_filter(f, [&](auto FC) {
-            auto kern = k_scan_sum<decltype(S)::value, decltype(FC)>;
-            grid = stream_grid(ctx, kern, nrows, TILE_ROWS, true);
-            partial = static_cast<double*>(pool_alloc(ctx, (size_t)grid * 5 * sizeof(double)));
-            if (!partial) return fail(ctx, SDQH_ERR_NOMEM, "scan_filter_sum: out of device memory");
-            call_begin(ctx);
-            LAUNCH(ctx, "k_scan_sum", kern, grid, f, t, nrows, partial);
-            return SDQH_OK;
+            using FCT = decltype(FC);
+            auto launch = [&](auto kern, const DevFilter& lf, const DevTuple& lt) {
+                grid = stream_grid(ctx, kern, nrows, TILE_ROWS, true);
+                partial = static_cast<double*>(pool_alloc(ctx, (size_t)grid * 5 * sizeof(double)));
+                if (!partial) return fail(ctx, SDQH_ERR_NOMEM, "scan_filter_sum: out of device memory");
+                call_begin(ctx);
+                LAUNCH(ctx, "k_scan_sum", kern, grid, lf, lt, nrows, partial);
+                return (int)SDQH_OK;
+            };
+            if constexpr (FCT::NI >= 0 && FCT::NS == 0 && FCT::NC == 0) {        // the tuned layouts have a narrow-twin instance
+                DevFilter nf = f; DevTuple nt = t;
+                if (narrow_streams(ctx, nrows, filter, tuple, &nf, &nt)) return launch(k_scan_sum<decltype(S)::value, FCT, true>, nf, nt);
+            }
+            return launch(k_scan_sum<decltype(S)::value, FCT>, f, t);
         });
     });
     if (lrc) return lrc;
@@ -665,14 +721,17 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
             return with_groupby_filter(f, [&](auto FC) {
                 return with_group_keys(gk, [&](auto KC) {
                     using FCT = decltype(FC); using KCT = decltype(KC);
-                    if constexpr (std::is_same_v<FCT, FCfg<1, 0, 0, 0>> && std::is_same_v<KCT, KCfg<1, 1>>) {      // the tuned family also has a 4-group form
-                        if (g4) {
-                            auto kern = k_groupby_reg<SH, 4, FCT, KCT>;
+                    if constexpr (std::is_same_v<FCT, FCfg<1, 0, 0, 0>> && std::is_same_v<KCT, KCfg<1, 1>>) {      // the tuned family also has a 4-group form, and narrow-twin instances
+                        DevFilter nf = f; DevTuple nt = t;
+                        const bool narrow = narrow_streams(ctx, nrows, filter, tuple, &nf, &nt);
+                        auto launch = [&](auto kern, const DevFilter& lf, const DevTuple& lt) {
                             grid = stream_grid(ctx, kern, nrows, TILE_ROWS, true);
                             if (int c = carve()) return c;
-                            LAUNCH(ctx, "k_groupby_reg", kern, grid, f, t, gk, nrows, r_keys, pacc, pcnt, r_flags);
-                            return SDQH_OK;
-                        }
+                            LAUNCH(ctx, "k_groupby_reg", kern, grid, lf, lt, gk, nrows, r_keys, pacc, pcnt, r_flags);
+                            return (int)SDQH_OK;
+                        };
+                        if (g4) return narrow ? launch(k_groupby_reg<SH, 4, FCT, KCT, true>, nf, nt) : launch(k_groupby_reg<SH, 4, FCT, KCT>, f, t);
+                        if (narrow) return launch(k_groupby_reg<SH, GREG, FCT, KCT, true>, nf, nt);
                     }
                     auto kern = k_groupby_reg<SH, GREG, FCT, KCT>;
                     grid = stream_grid(ctx, kern, nrows, TILE_ROWS, true);
@@ -1801,6 +1860,8 @@ int sdqh_column_copy_in(sdqh_ctx* ctx, sdqh_column* col, int64_t row0, int64_t n
     (void)hipSetDevice(ctx->device);
     HIP_TRY(ctx, hipMemcpyAsync(static_cast<char*>(col->data) + (size_t)row0 * 8, src, (size_t)nrows * 8, hipMemcpyDeviceToDevice, ctx->stream));
     col->have_minmax = false; col->minmax_pending = false; col->clustered = -1; col->increasing = -1;
+    if (col->narrow) { pool_free(ctx, col->narrow); col->narrow = nullptr; }
+    col->narrow_state = -1;
     return ctx->opt_async_copies ? SDQH_OK : sync_stream(ctx);
 }
 

@@ -66,6 +66,7 @@ struct sdqh_ctx {
     int opt_packed_slots = 1;                      // hash-layout tables with payload: 32-byte slots { key, payload 0 / 1, owner row }
     int opt_lookup_pipeline = -1;                  // k_lookup_agg requests the next tile's first-lookup keys a step ahead: -1 = when that key column is clustered, 0 / 1 = never / always
     int opt_lookup_debug = 0;
+    int opt_narrow = 1;                            // streaming kernels (k_scan_sum, k_groupby_reg) read predicates / operands through exact 4-byte twins when every one of them has one
     int opt_stage_pipeline = 0;                    // k_stage (tuned orders-like family): first-stage loads of the next step requested a step ahead (measured: Q3 orders 0.148 -> 0.151 ms, no gain: off)
     int opt_span_index = 1;                        // small direct tables also get an owner-by-key-offset array (one-load lookups)
     int opt_dense_increasing = 1;                  // dense layout over a strictly increasing key column is filled in one pass (no prefill, no verification)
@@ -88,6 +89,8 @@ struct sdqh_column {
     long long* d_minmax = nullptr;     // device [2], I64 only
     bool minmax_pending = false, have_minmax = false;
     int clustered = -1;                // -1 unknown; 1: neighbouring rows hold near-by values (sampled), 0: no order
+    void* narrow = nullptr;            // 4-byte twin (int32 values / two-decimal doubles x 100), verified exact when built; see ensure_narrow
+    int narrow_state = -1;             // -1 not tried, 0 the column does not narrow exactly, 1 twin present
     int increasing = -1;               // -1 unknown; 1: strictly increasing (sorted, no duplicates), 0: not — checked once on the device
     int64_t mn = 0, mx = 0;
     size_t row_bytes() const { return dtype == SDQH_STR ? (size_t)width * 4 : 8; }

@@ -223,6 +223,44 @@ __device__ __forceinline__ Pair<T> load2(const T* __restrict__ p, int64_t r, int
     return v;
 }
 
+// ---- narrow twins ------------------------------------------------------------------------------------------
+// A streamed column may have a 4-byte twin on the device: an I64 column whose values fit int32 (dates, keys), an F64
+// column whose every value v is reproduced BIT FOR BIT by narrow_decode(llrint(v * 100)) (prices, quantities, rates:
+// two-decimal numbers).  The twin is built, and every row of it verified against the column with the very function
+// the kernels decode with, the first time a streaming kernel wants it (sdqh_hip.hip: ensure_narrow); a column that
+// fails keeps its 8-byte form.  The kernels' NW instances read 8 bytes per row pair instead of 16: the algorithmic
+// bytes (the reference's widths) stay what they are, the physical bytes halve.
+__device__ __forceinline__ double narrow_decode(int32_t n) {
+    const double x = (double)n;
+    const double q = x * 0.01;                                       // within an ulp or two of x / 100 ...
+    const double r = __builtin_fma(-q, 100.0, x);                    // ... and one correction step lands on it (checked per row when the twin is built)
+    return __builtin_fma(r, 0.01, q);
+}
+template <bool TAIL, bool NW, class T>
+__device__ __forceinline__ Pair<T> loadc(const T* __restrict__ p, int64_t r, int64_t nrows) {
+    if constexpr (!NW) return load2<TAIL>(p, r, nrows);
+    else {
+        const int32_t* __restrict__ q = reinterpret_cast<const int32_t*>(p);
+        int32_t a, b;
+        if constexpr (!TAIL) {
+            using V = int32_t __attribute__((ext_vector_type(2)));
+#if SDQH_NT_LOADS
+            const V t = __builtin_nontemporal_load(reinterpret_cast<const V*>(q + r));
+#else
+            const V t = *reinterpret_cast<const V*>(q + r);
+#endif
+            a = t.x; b = t.y;
+        } else {
+            const int64_t r0 = r < nrows ? r : nrows - 1, r1 = r + 1 < nrows ? r + 1 : nrows - 1;
+            a = q[r0]; b = q[r1];
+        }
+        Pair<T> v;
+        if constexpr (sizeof(T) == 8 && T(0.5) == T(0)) { v.x = (T)a; v.y = (T)b; }      // integer column
+        else { v.x = (T)narrow_decode(a); v.y = (T)narrow_decode(b); }
+        return v;
+    }
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
@@ -472,12 +510,12 @@ struct FilterRegs {
     Pair<double> fv[SDQH_MAX_FPRED];
 };
 
-template <class FC, bool TAIL>
+template <class FC, bool TAIL, bool NW = false>
 __device__ __forceinline__ void filter_load(const DevFilter& f, int64_t r, int64_t nrows, FilterRegs& fr) {
 #pragma unroll
-    for (int i = 0; i < SDQH_MAX_IPRED; ++i) if (i < cfg_ni<FC>(f.ni)) fr.iv[i] = load2<TAIL>(f.ic[i], r, nrows);
+    for (int i = 0; i < SDQH_MAX_IPRED; ++i) if (i < cfg_ni<FC>(f.ni)) fr.iv[i] = loadc<TAIL, NW>(f.ic[i], r, nrows);
 #pragma unroll
-    for (int i = 0; i < SDQH_MAX_FPRED; ++i) if (i < cfg_nf<FC>(f.nf)) fr.fv[i] = load2<TAIL>(f.fc[i], r, nrows);
+    for (int i = 0; i < SDQH_MAX_FPRED; ++i) if (i < cfg_nf<FC>(f.nf)) fr.fv[i] = loadc<TAIL, NW>(f.fc[i], r, nrows);
 }
 
 template <class FC, bool TAIL>
@@ -530,7 +568,7 @@ __device__ __forceinline__ bool operand_ranges(const DevFilter& f, const double 
 // result is bit-reproducible run to run.
 // partial layout: [grid][5] = NV doubles (padded to 4) + count (as int64 bits)
 // =================================================================================================
-template <int SHAPE, class FC, bool TAIL>
+template <int SHAPE, class FC, bool TAIL, bool NW = false>
 __device__ __forceinline__ void scan_sum_tile(const DevFilter& f, const DevTuple& t, int64_t base, int64_t nrows,
                                               double (&acc)[4], int64_t& cnt) {
     constexpr int NOPS = TupleTraits<SHAPE>::NOPS, NV = TupleTraits<SHAPE>::NV;
@@ -540,8 +578,8 @@ __device__ __forceinline__ void scan_sum_tile(const DevFilter& f, const DevTuple
     for (int u = 0; u < UNROLL; ++u) {                               // every load of the tile first
         const int64_t r = base + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
 #pragma unroll
-        for (int j = 0; j < NOPS; ++j) xv[u][j] = load2<TAIL>(t.op[j], r, nrows);
-        filter_load<FC, TAIL>(f, r, nrows, fr[u]);
+        for (int j = 0; j < NOPS; ++j) xv[u][j] = loadc<TAIL, NW>(t.op[j], r, nrows);
+        filter_load<FC, TAIL, NW>(f, r, nrows, fr[u]);
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
@@ -562,7 +600,7 @@ __device__ __forceinline__ void scan_sum_tile(const DevFilter& f, const DevTuple
     }
 }
 
-template <int SHAPE, class FC>
+template <int SHAPE, class FC, bool NW = false>          // NW: every streamed column (predicates, operands) is read through its narrow twin
 __global__ __launch_bounds__(TPB) void k_scan_sum(DevFilter f, DevTuple t, int64_t nrows, double* __restrict__ partial) {
     constexpr int NV = TupleTraits<SHAPE>::NV;
     double acc[4] = {0, 0, 0, 0};
@@ -570,9 +608,9 @@ __global__ __launch_bounds__(TPB) void k_scan_sum(DevFilter f, DevTuple t, int64
     const int64_t full = nrows / TILE_ROWS;
     for (int64_t t0 = (int64_t)blockIdx.x * SDQH_TILE_CHUNK; t0 < full; t0 += (int64_t)gridDim.x * SDQH_TILE_CHUNK)
         for (int64_t tile = t0; tile < t0 + SDQH_TILE_CHUNK && tile < full; ++tile)
-            scan_sum_tile<SHAPE, FC, false>(f, t, tile * TILE_ROWS, nrows, acc, cnt);
+            scan_sum_tile<SHAPE, FC, false, NW>(f, t, tile * TILE_ROWS, nrows, acc, cnt);
     if (full * TILE_ROWS < nrows && blockIdx.x == (unsigned)(full % gridDim.x))
-        scan_sum_tile<SHAPE, FC, true>(f, t, full * TILE_ROWS, nrows, acc, cnt);
+        scan_sum_tile<SHAPE, FC, true, NW>(f, t, full * TILE_ROWS, nrows, acc, cnt);
 
     __shared__ double s_acc[TPB / WAVE][4];
     __shared__ int64_t s_cnt[TPB / WAVE];
@@ -722,7 +760,7 @@ __device__ __forceinline__ void write_group_partials(const unsigned long long* s
     }
 }
 
-template <int SHAPE, int G, class FC, class KC, bool TAIL>
+template <int SHAPE, int G, class FC, class KC, bool TAIL, bool NW = false>
 __device__ __forceinline__ void groupby_reg_tile(const DevFilter& f, const DevTuple& t, const DevGroupKeys& gk, int64_t base, int64_t nrows,
                                                  unsigned long long* s_keys, int* s_flags,
                                                  double (&acc)[G][4], int32_t (&cnt)[G]) {
@@ -735,9 +773,9 @@ __device__ __forceinline__ void groupby_reg_tile(const DevFilter& f, const DevTu
     for (int u = 0; u < UNROLL; ++u) {                               // every load of the tile first
         const int64_t r = base + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
 #pragma unroll
-        for (int j = 0; j < NOPS; ++j) xv[u][j] = load2<TAIL>(t.op[j], r, nrows);
+        for (int j = 0; j < NOPS; ++j) xv[u][j] = loadc<TAIL, NW>(t.op[j], r, nrows);
         load_group_keys<KC, TAIL>(gk, r, nrows, key[u][0], key[u][1], bad);
-        filter_load<FC, TAIL>(f, r, nrows, fr[u]);
+        filter_load<FC, TAIL, NW>(f, r, nrows, fr[u]);
     }
     uint64_t rk[G];
 #pragma unroll
@@ -774,7 +812,7 @@ __device__ __forceinline__ void groupby_reg_tile(const DevFilter& f, const DevTu
     }
 }
 
-template <int SHAPE, int G, class FC, class KC>
+template <int SHAPE, int G, class FC, class KC, bool NW = false>      // NW: predicates and operands through their narrow twins (the group keys stay as they are)
 __global__ __launch_bounds__(TPB) void k_groupby_reg(DevFilter f, DevTuple t, DevGroupKeys gk, int64_t nrows,
                                                      unsigned long long* __restrict__ gkeys, double* __restrict__ pacc,
                                                      int64_t* __restrict__ pcnt, int* __restrict__ flags) {
@@ -795,9 +833,9 @@ __global__ __launch_bounds__(TPB) void k_groupby_reg(DevFilter f, DevTuple t, De
     const int64_t full = nrows / TILE_ROWS;
     for (int64_t t0 = (int64_t)blockIdx.x * SDQH_TILE_CHUNK; t0 < full; t0 += (int64_t)gridDim.x * SDQH_TILE_CHUNK)
         for (int64_t tile = t0; tile < t0 + SDQH_TILE_CHUNK && tile < full; ++tile)
-            groupby_reg_tile<SHAPE, G, FC, KC, false>(f, t, gk, tile * TILE_ROWS, nrows, s_keys, s_flags, acc, cnt);
+            groupby_reg_tile<SHAPE, G, FC, KC, false, NW>(f, t, gk, tile * TILE_ROWS, nrows, s_keys, s_flags, acc, cnt);
     if (full * TILE_ROWS < nrows && blockIdx.x == (unsigned)(full % gridDim.x))
-        groupby_reg_tile<SHAPE, G, FC, KC, true>(f, t, gk, full * TILE_ROWS, nrows, s_keys, s_flags, acc, cnt);
+        groupby_reg_tile<SHAPE, G, FC, KC, true, NW>(f, t, gk, full * TILE_ROWS, nrows, s_keys, s_flags, acc, cnt);
 
     const int w = threadIdx.x / WAVE;
 #pragma unroll
@@ -2863,6 +2901,28 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_export_bitmap(DevStage st, int64_t lo,
 }
 
 // ---- column statistics ---------------------------------------------------------------------------
+// build + verify a narrow twin (flag |= 1: some row is not reproduced exactly -> the column keeps its 8-byte form only)
+SDQH_KERNEL __launch_bounds__(TPB) void k_narrow_i64(const int64_t* __restrict__ src, int64_t nrows, int32_t* __restrict__ dst, int* __restrict__ flag) {
+    bool bad = false;
+    for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * TPB) {
+        const int64_t v = src[r];
+        bad |= v < -2147483647ll - 1 || v > 2147483647ll;
+        dst[r] = (int32_t)v;
+    }
+    if (__ballot(bad) && lane_id() == 0) atomicOr(flag, 1);
+}
+SDQH_KERNEL __launch_bounds__(TPB) void k_narrow_f64(const double* __restrict__ src, int64_t nrows, int32_t* __restrict__ dst, int* __restrict__ flag) {
+    bool bad = false;
+    for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * TPB) {
+        const double v = src[r];
+        const double s100 = v * 100.0;
+        int32_t n = 0;
+        if (s100 > -2147483000.0 && s100 < 2147483000.0) n = (int32_t)__builtin_rint(s100); else bad = true;      // (NaN fails both comparisons)
+        bad |= __double_as_longlong(narrow_decode(n)) != __double_as_longlong(v);                                    // bit for bit: -0.0, more decimals, huge values all fail
+        dst[r] = n;
+    }
+    if (__ballot(bad) && lane_id() == 0) atomicOr(flag, 1);
+}
 SDQH_KERNEL __launch_bounds__(TPB) void k_minmax(const int64_t* __restrict__ col, int64_t nrows, long long* __restrict__ out /*[2]*/) {
     __shared__ long long s_lo[TPB / WAVE], s_hi[TPB / WAVE];
     long long lo = INT64_MAX, hi = INT64_MIN;

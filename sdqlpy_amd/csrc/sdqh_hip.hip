@@ -1115,13 +1115,23 @@ int sdqh_hash_probe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* f
     int lrc = with_shape(ctx, tuple->shape, [&](auto S) {
         return with_scan_filter(f, [&](auto FC) {
             constexpr int SH = decltype(S)::value; using FCT = decltype(FC);
+            const int32_t* nkey = nullptr; const int32_t* npred0 = nullptr;
             auto launch = [&](auto kern, int pu) {
                 const unsigned grid = stream_grid(ctx, kern, nrows, TPB * ROWS_PER_LOAD * pu * ctx->opt_probe_chunk);
                 // the kernel queues candidate rows as 32-bit offsets from its current chunk and rebases them by one grid stride
                 if ((int64_t)grid * ctx->opt_probe_chunk * (TPB * ROWS_PER_LOAD * pu) >= ((int64_t)1 << 31)) return fail(ctx, SDQH_ERR_UNSUPPORTED, "hash_probe_aggregate: probe_chunk too large for this grid");
-                LAUNCH(ctx, "k_probe_agg", kern, grid, f, t, table->dev, kc, nrows, ctx->opt_probe_chunk, pipeline);
+                LAUNCH(ctx, "k_probe_agg", kern, grid, f, t, table->dev, kc, nrows, ctx->opt_probe_chunk, pipeline, nkey, npred0);
                 return (int)SDQH_OK;
             };
+            // narrow twins of the two streamed columns (key, first integer predicate): the layouts with at most one integer predicate
+            if constexpr (std::is_same_v<FCT, FCfg<1, 0, 0, 0>> || std::is_same_v<FCT, FCfg<0, 0, 0, 0>>) {
+                // (not for the row-keyed group-by, sdqh_groupby_key: every row hits there, the drain bounds it, and the conversions cost 6 %)
+                if (ctx->opt_narrow && nrows >= (1 << 20) && !ctx->in_groupby_key) {
+                    nkey = static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(key)));
+                    if (nkey && f.ni == 1) { npred0 = static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(filter->ipred[0].col))); if (!npred0) nkey = nullptr; }
+                    if (nkey) return launch(k_probe_agg<SH, FCT, PROBE_UNROLL, true>, PROBE_UNROLL);
+                }
+            }
             if constexpr (SH == SDQH_TUPLE_A_1MB && std::is_same_v<FCT, FCfg<1, 0, 0, 0>>) {     // the tuned instance family
                 if (ctx->opt_probe_unroll == 4) return launch(k_probe_agg<SH, FCT, 4>, 4);
                 if (ctx->opt_probe_unroll == 1) return launch(k_probe_agg<SH, FCT, 1>, 1);
@@ -1154,7 +1164,7 @@ int sdqh_groupby_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, co
         call_begin(ctx);
         ++ctx->nested;
         int rc = sdqh_hash_build_unique(ctx, nrows, filter, 0, nullptr, key, 0, nullptr, 1, &tb);
-        if (!rc) { rc = sdqh_hash_probe_aggregate(ctx, nrows, filter, tb, key, tuple); if (rc) sdqh_table_free(ctx, tb); }
+        if (!rc) { ctx->in_groupby_key = true; rc = sdqh_hash_probe_aggregate(ctx, nrows, filter, tb, key, tuple); ctx->in_groupby_key = false; if (rc) sdqh_table_free(ctx, tb); }
         --ctx->nested;
         call_end(ctx);
         if (rc) return rc;
@@ -1203,7 +1213,9 @@ int sdqh_groupby_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, co
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { call_end(ctx); table_release(ctx, tb); delete tb; return fail(ctx, SDQH_ERR_DEVICE, std::string("groupby_key launch: ") + hipGetErrorString(e)); }
     ++ctx->nested;
+    ctx->in_groupby_key = true;
     const int prc = sdqh_hash_probe_aggregate(ctx, nrows, filter, tb, key, tuple);
+    ctx->in_groupby_key = false;
     --ctx->nested;
     call_end(ctx);
     if (prc) { sdqh_table_free(ctx, tb); return prc; }
@@ -1698,8 +1710,14 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
             constexpr bool BIG_OK = std::is_same_v<FCT, FCfg<0, 0, 0, 0, 0>>;
             constexpr int BIG_BT = 1024, BIG_PU = 4;
             if (coarse_lds && !BIG_OK) { L.coarse = nullptr; L.coarse_words = 0; L.coarse_shift = 0; coarse_lds = 0; }
+            // narrow twin of the first lookup's streamed key column (unfiltered scans: the instances that exist with NW)
+            const int32_t* nkey0 = nullptr;
+            if (BIG_OK && ctx->opt_narrow && nrows >= (1 << 20) && nlookups > 0 && lookups[0].key[0].kind == SDQH_SRC_COLUMN && lookups[0].key[0].col->dtype == SDQH_I64)
+                nkey0 = static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(lookups[0].key[0].col)));
             if constexpr (BIG_OK) if (coarse_lds) {
-                auto big = k_lookup_agg<SH, FCT, BIG_BT, BIG_PU>;
+                auto big_raw = k_lookup_agg<SH, FCT, BIG_BT, BIG_PU>;
+                auto big_nw = k_lookup_agg<SH, FCT, BIG_BT, BIG_PU, true>;
+                auto big = nkey0 ? big_nw : big_raw;                             // (same signature)
                 int per_cu = 0;
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(big), hipFuncAttributeMaxDynamicSharedMemorySize, (int)coarse_lds) != hipSuccess ||
                     hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, big, BIG_BT, coarse_lds) != hipSuccess || per_cu < 1) {
@@ -1715,13 +1733,14 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
                     double* pacc = reinterpret_cast<double*>(blob);
                     int64_t* pcnt = reinterpret_cast<int64_t*>(blob + nslots * 32);
                     { FillList fl; fl.add(r_keys, LG_SLOTS * 8, 0xFF); fl.add(r_flags, 8, 0); launch_fill(ctx, fl); }
-                    { KernelScope _ks(ctx, "k_lookup_agg"); hipLaunchKernelGGL(big, dim3(grid), dim3(BIG_BT), coarse_lds, ctx->stream, f, L, spec, nrows, r_keys, pacc, pcnt, r_flags, ctx->opt_probe_chunk); }
+                    { KernelScope _ks(ctx, "k_lookup_agg"); hipLaunchKernelGGL(big, dim3(grid), dim3(BIG_BT), coarse_lds, ctx->stream, f, L, spec, nrows, r_keys, pacc, pcnt, r_flags, ctx->opt_probe_chunk, nkey0); }
                     LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, r_keys, pacc, pcnt, (int)grid, r_acc, r_cnt);
                     call_end(ctx);
                     return SDQH_OK;
                 }
             }
             auto kern = k_lookup_agg<SH, FCT>;
+            if constexpr (BIG_OK) { if (nkey0) kern = k_lookup_agg<SH, FCT, TPB, LOOKUP_PU, true>; }
             grid = stream_grid(ctx, kern, nrows, TPB * ROWS_PER_LOAD * LOOKUP_PU * ctx->opt_probe_chunk);
             // the kernel queues candidate rows as 32-bit offsets from its current chunk and rebases them by one grid stride
             if ((int64_t)grid * ctx->opt_probe_chunk * (TPB * ROWS_PER_LOAD * LOOKUP_PU) >= ((int64_t)1 << 31)) return fail(ctx, SDQH_ERR_UNSUPPORTED, "lookup_aggregate: probe_chunk too large for this grid");
@@ -1731,7 +1750,7 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
             double* pacc = reinterpret_cast<double*>(blob);
             int64_t* pcnt = reinterpret_cast<int64_t*>(blob + nslots * 32);
             { FillList fl; fl.add(r_keys, LG_SLOTS * 8, 0xFF); fl.add(r_flags, 8, 0); launch_fill(ctx, fl); }
-            LAUNCH(ctx, "k_lookup_agg", kern, grid, f, L, spec, nrows, r_keys, pacc, pcnt, r_flags, ctx->opt_probe_chunk);
+            LAUNCH(ctx, "k_lookup_agg", kern, grid, f, L, spec, nrows, r_keys, pacc, pcnt, r_flags, ctx->opt_probe_chunk, nkey0);
             LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, r_keys, pacc, pcnt, (int)grid, r_acc, r_cnt);
             call_end(ctx);
             return SDQH_OK;

@@ -1648,8 +1648,13 @@ __device__ __forceinline__ void probe_drain(const DevFilter& f, const DevTuple& 
     }
 }
 
-template <int SHAPE, class FC, int PU = PROBE_UNROLL>
-__global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevTable tb, const int64_t* __restrict__ keycol, int64_t nrows, int chunk, int pipeline) {
+// NW: the streamed key column and the first integer predicate column are read through their narrow twins (nkey, npred0: int32);
+// everything read by row (the tail, further predicates, the operands of a hit) stays on the columns themselves.
+template <int SHAPE, class FC, int PU = PROBE_UNROLL, bool NW = false>
+__global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevTable tb, const int64_t* __restrict__ keycol, int64_t nrows, int chunk, int pipeline,
+                                                   const int32_t* __restrict__ nkey, const int32_t* __restrict__ npred0) {
+    const int64_t* skey = NW ? reinterpret_cast<const int64_t*>(nkey) : keycol;                     // what the streaming part loads from (loadc<.., NW>)
+    const int64_t* spred0 = NW ? reinterpret_cast<const int64_t*>(npred0) : f.ic[0];
     constexpr int TILE = TPB * ROWS_PER_LOAD * PU;
     constexpr int QCAP = 64 + PU * 128;                               // 63 left over + a whole tile's candidates
     __shared__ int32_t s_row[TPB / WAVE][QCAP];                       // row offsets from qbase (the chunk being produced), as in k_lookup_agg
@@ -1682,8 +1687,8 @@ __global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevT
 #pragma unroll
         for (int u = 0; u < PU; ++u) {
             const int64_t rr = t0 * TILE + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
-            kvn[u] = load2<false>(keycol, rr, nrows);
-            if (HAS_I0 && first_pred) dn[u] = load2<false>(f.ic[0], rr, nrows);
+            kvn[u] = loadc<false, NW>(skey, rr, nrows);
+            if (HAS_I0 && first_pred) dn[u] = loadc<false, NW>(spred0, rr, nrows);
         }
     }
     auto step = [&](auto PIPE_C) {
@@ -1695,15 +1700,18 @@ __global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevT
 #pragma unroll
         for (int u = 0; u < PU; ++u) {
             r[u] = tile * TILE + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
-            if constexpr (PIPE) kv[u] = kvn[u]; else kv[u] = load2<false>(keycol, r[u], nrows);
+            if constexpr (PIPE) kv[u] = kvn[u]; else kv[u] = loadc<false, NW>(skey, r[u], nrows);
             p[u][0] = p[u][1] = true;
         }
-        if constexpr (PIPE) {
+        if constexpr (PIPE || NW) {                                    // the first predicate from this kernel's own (prefetched / narrow) loads
             if (HAS_I0 && first_pred) {
+                Pair<int64_t> d[PU];
+#pragma unroll
+                for (int u = 0; u < PU; ++u) { if constexpr (PIPE) d[u] = dn[u]; else d[u] = loadc<false, NW>(spred0, r[u], nrows); }
 #pragma unroll
                 for (int u = 0; u < PU; ++u) {
-                    p[u][0] = (dn[u].x >= f.ilo[0]) & (dn[u].x <= f.ihi[0]);
-                    p[u][1] = (dn[u].y >= f.ilo[0]) & (dn[u].y <= f.ihi[0]);
+                    p[u][0] = (d[u].x >= f.ilo[0]) & (d[u].x <= f.ihi[0]);
+                    p[u][1] = (d[u].y >= f.ilo[0]) & (d[u].y <= f.ihi[0]);
                 }
             }
             pass_pairs<PU, FC, false, true>(f, none, r, nrows, nomask, p);
@@ -1727,8 +1735,8 @@ __global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevT
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
                 const int64_t rr = nt * TILE + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
-                kvn[u] = load2<false>(keycol, rr, nrows);
-                if (HAS_I0 && first_pred) dn[u] = load2<false>(f.ic[0], rr, nrows);
+                kvn[u] = loadc<false, NW>(skey, rr, nrows);
+                if (HAS_I0 && first_pred) dn[u] = loadc<false, NW>(spred0, rr, nrows);
             }
         }
         if (direct_bm) {
@@ -2262,10 +2270,12 @@ __device__ __forceinline__ int group_slot(unsigned long long* keys, unsigned lon
 // BT: threads per workgroup.  256 everywhere, except with the coarse key filter: 1024 (16 waves share ONE copy of the filter in LDS —
 // a copy per 256 threads cost more occupancy than the filter saved), and then PU = 4 row pairs per lane in flight to make up for
 // the fewer waves per CU.
-template <int SHAPE, class FC, int BT = TPB, int PUV = LOOKUP_PU>
+// NW: the first lookup's streamed key column is read through its narrow twin (nkey0: int32); rows in the queue read the column itself
+template <int SHAPE, class FC, int BT = TPB, int PUV = LOOKUP_PU, bool NW = false>
 __global__ __launch_bounds__(BT) void k_lookup_agg(DevFilter f, DevLookups L, DevAggSpec spec, int64_t nrows,
                                                     unsigned long long* __restrict__ gkeys, double* __restrict__ pacc,
-                                                    int64_t* __restrict__ pcnt, int* __restrict__ flags, int chunk) {
+                                                    int64_t* __restrict__ pcnt, int* __restrict__ flags, int chunk, const int32_t* __restrict__ nkey0) {
+    const int64_t* skey0 = NW ? reinterpret_cast<const int64_t*>(nkey0) : L.l[0].key[0].col;
     constexpr int NOPS = TupleTraits<SHAPE>::NOPS, NV = TupleTraits<SHAPE>::NV;
     constexpr int PU = PUV, TILE = BT * ROWS_PER_LOAD * PU, SUBR = BT * ROWS_PER_LOAD, QCAP = 64 + PU * 128;
     __shared__ unsigned long long s_keys[LG_SLOTS];
@@ -2342,7 +2352,7 @@ __global__ __launch_bounds__(BT) void k_lookup_agg(DevFilter f, DevLookups L, De
     for (int u = 0; u < PU; ++u) { k0n[u].x = 0; k0n[u].y = 0; }
     if (phase == 0 && pipe) {
 #pragma unroll
-        for (int u = 0; u < PU; ++u) k0n[u] = load2<false>(L.l[0].key[0].col, t0 * TILE + (int64_t)u * SUBR + (int64_t)threadIdx.x * ROWS_PER_LOAD, nrows);
+        for (int u = 0; u < PU; ++u) k0n[u] = loadc<false, NW>(skey0, t0 * TILE + (int64_t)u * SUBR + (int64_t)threadIdx.x * ROWS_PER_LOAD, nrows);
     }
     // one streaming step over tile t0 + c: candidates into the queue.  PIPE: keys of this tile were requested a step ago
     auto step = [&](auto PIPE_C) {
@@ -2356,7 +2366,7 @@ __global__ __launch_bounds__(BT) void k_lookup_agg(DevFilter f, DevLookups L, De
         for (int u = 0; u < PU; ++u) {
             r[u] = tile * TILE + (int64_t)u * SUBR + (int64_t)threadIdx.x * ROWS_PER_LOAD;
             if constexpr (PIPE) k0[u] = k0n[u];
-            else if (eager0) k0[u] = load2<false>(L.l[0].key[0].col, r[u], nrows);
+            else if (eager0) k0[u] = loadc<false, NW>(skey0, r[u], nrows);
             p[u][0] = p[u][1] = true;
             w[u][0] = w[u][1] = 0;
         }
@@ -2368,7 +2378,7 @@ __global__ __launch_bounds__(BT) void k_lookup_agg(DevFilter f, DevLookups L, De
             // (after the block's last tile: that tile again — an unconditional load keeps the step free of a branch the waits would pile up at)
             const int64_t nt = (c + 1 < chunk && tile + 1 < full) ? tile + 1 : (t0 + (int64_t)gridDim.x * chunk < full ? t0 + (int64_t)gridDim.x * chunk : tile);
 #pragma unroll
-            for (int u = 0; u < PU; ++u) k0n[u] = load2<false>(L.l[0].key[0].col, nt * TILE + (int64_t)u * SUBR + (int64_t)threadIdx.x * ROWS_PER_LOAD, nrows);
+            for (int u = 0; u < PU; ++u) k0n[u] = loadc<false, NW>(skey0, nt * TILE + (int64_t)u * SUBR + (int64_t)threadIdx.x * ROWS_PER_LOAD, nrows);
         }
         pass_pairs<PU, FC, false>(f, none, r, nrows, nomask, p);
         if (eager0) {

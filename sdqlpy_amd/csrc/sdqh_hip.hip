@@ -987,26 +987,31 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
                     if (npayload == 2) {
                         const int ep = ctx->opt_stage_eager_pay;
                         if (ctx->opt_stage_pipeline && eg == 1 && ep == 0) {
-#define STAGE_PIPE(SB_) if (sb == SB_) { auto kern = k_stage<FCT, 2, SB_, true, false, true>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows); return SDQH_OK; }
+#define STAGE_PIPE(SB_) if (sb == SB_) { auto kern = k_stage<FCT, 2, SB_, true, false, true>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr)); return SDQH_OK; }
                             STAGE_PIPE(2) STAGE_PIPE(4)
 #undef STAGE_PIPE
                         }
-#define STAGE_VARIANT(SB_, EG_, EP_) if (sb == SB_ && eg == EG_ && ep == EP_) { auto kern = k_stage<FCT, 2, SB_, EG_ != 0, EP_ != 0>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows); return SDQH_OK; }
+                        if (ctx->opt_narrow && nrows >= (1 << 20) && sb == 4 && eg == 1 && ep == 0) {       // first predicate + streamed probe key through their narrow twins
+                            const int32_t* nkey = static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(probes[0].key)));
+                            const int32_t* npred0 = nkey ? static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(filter->ipred[0].col))) : nullptr;
+                            if (nkey && npred0) { auto kern = k_stage<FCT, 2, 4, true, false, false, true>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows, nkey, npred0); return SDQH_OK; }
+                        }
+#define STAGE_VARIANT(SB_, EG_, EP_) if (sb == SB_ && eg == EG_ && ep == EP_) { auto kern = k_stage<FCT, 2, SB_, EG_ != 0, EP_ != 0>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr)); return SDQH_OK; }
                         STAGE_VARIANT(2, 1, 1) STAGE_VARIANT(4, 1, 1) STAGE_VARIANT(2, 1, 0) STAGE_VARIANT(4, 1, 0) STAGE_VARIANT(8, 1, 0) STAGE_VARIANT(4, 0, 0)
 #undef STAGE_VARIANT
                     }
                 }
                 if constexpr (FCT::NS == 1) {                                   // string family: one batch per step (few registers, many waves)
-                    if (npayload == 0) { auto kern = k_stage<FCT, 0, 1>; LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows); return SDQH_OK; }
+                    if (npayload == 0) { auto kern = k_stage<FCT, 0, 1>; LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr)); return SDQH_OK; }
                     auto kern = k_stage<FCT, -1, 1>;
-                    LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows);
+                    LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr));
                     return SDQH_OK;
                 } else {
-                if (npayload == 0) { auto kern = k_stage<FCT, 0>; LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows); return SDQH_OK; }
-                if (npayload == 1) { auto kern = k_stage<FCT, 1>; LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows); return SDQH_OK; }
-                if (npayload == 2) { auto kern = k_stage<FCT, 2>; LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows); return SDQH_OK; }
+                if (npayload == 0) { auto kern = k_stage<FCT, 0>; LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr)); return SDQH_OK; }
+                if (npayload == 1) { auto kern = k_stage<FCT, 1>; LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr)); return SDQH_OK; }
+                if (npayload == 2) { auto kern = k_stage<FCT, 2>; LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr)); return SDQH_OK; }
                 auto kern = k_stage<FCT, -1>;
-                LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows);
+                LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr));
                 return SDQH_OK;
                 }
             });
@@ -1600,7 +1605,25 @@ int sdqh_build(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nloo
         const unsigned seg_grid = (unsigned)((tb->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
         { FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); fl.add(flags, 8, 0); if (tb->bm) fl.add(tb->bm, tb->nwords * 4, 0); prefill_refs(ctx, tb, &fl); launch_fill(ctx, fl); }
         hipError_t e;
-        with_scan_filter(f, [&](auto FC) { auto kern = k_build_lookup<decltype(FC)>; LAUNCH(ctx, "k_build_lookup", kern, seg_grid, f, L, spec, tb->stage, nrows, flags); return SDQH_OK; });
+        with_scan_filter(f, [&](auto FC) {
+            using FCT = decltype(FC);
+            if constexpr (std::is_same_v<FCT, FCfg<1, 0, 0, 0>> || std::is_same_v<FCT, FCfg<0, 0, 0, 0>>) {
+                // the first lookup's streamed key and the first integer predicate through their narrow twins
+                const bool eager0 = nlookups > 0 && lookups[0].key[0].kind == SDQH_SRC_COLUMN && lookups[0].key[0].col->dtype == SDQH_I64;
+                if (ctx->opt_narrow && nrows >= (1 << 20) && (eager0 || f.ni == 1)) {
+                    const int32_t* nkey0 = eager0 ? static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(lookups[0].key[0].col))) : nullptr;
+                    const int32_t* npred0 = f.ni == 1 ? static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(filter->ipred[0].col))) : nullptr;
+                    if ((!eager0 || nkey0) && (f.ni != 1 || npred0)) {
+                        auto kern = k_build_lookup<FCT, true>;
+                        LAUNCH(ctx, "k_build_lookup", kern, seg_grid, f, L, spec, tb->stage, nrows, flags, nkey0, npred0);
+                        return SDQH_OK;
+                    }
+                }
+            }
+            auto kern = k_build_lookup<FCT>;
+            LAUNCH(ctx, "k_build_lookup", kern, seg_grid, f, L, spec, tb->stage, nrows, flags, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr));
+            return SDQH_OK;
+        });
         call_end(ctx);
         e = hipGetLastError();
         if (e != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, std::string("build launch: ") + hipGetErrorString(e));
@@ -1810,7 +1833,7 @@ int sdqh_scan_compact(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, i
     if (!rc) {
         const unsigned seg_grid = (unsigned)((tmp.stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
         call_begin(ctx);
-        with_stage_filter(f, nprobes, [&](auto FC) { auto kern = k_stage<decltype(FC), -1>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tmp.stage, nrows); return SDQH_OK; });
+        with_stage_filter(f, nprobes, [&](auto FC) { auto kern = k_stage<decltype(FC), -1>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tmp.stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr)); return SDQH_OK; });
         LAUNCH(ctx, "k_seg_scan", k_seg_scan, 1, tmp.stage.seg_count, tmp.stage.nseg, seg_off, total);
         LAUNCH(ctx, "k_gather_segments", k_gather_segments, seg_grid, tmp.stage, seg_off, g);
         call_end(ctx);

@@ -1044,9 +1044,11 @@ __device__ __forceinline__ void pairs_preload(const DevFilter& f, const DevProbe
         pre.d[j] = load2<false>(f.ic[0], r, nrows);
     }
 }
-template <int NB, class FC, bool EAGER = true, bool SKIP_FIRST = false, bool PRE = false>      // SKIP_FIRST: the caller has applied the first integer predicate itself
+// NW: the two first-stage columns (first probe's key when EAGER, first integer predicate) are read through their narrow twins nkey / npred0
+template <int NB, class FC, bool EAGER = true, bool SKIP_FIRST = false, bool PRE = false, bool NW = false>      // SKIP_FIRST: the caller has applied the first integer predicate itself
 __device__ __forceinline__ void pass_pairs(const DevFilter& f, const DevProbes& pr, const int64_t (&r)[NB], int64_t nrows,
-                                           const uint64_t* cap_masks, bool (&p)[NB][2], uint32_t* s_str = nullptr, const PairsPre<NB>* pre = nullptr) {
+                                           const uint64_t* cap_masks, bool (&p)[NB][2], uint32_t* s_str = nullptr, const PairsPre<NB>* pre = nullptr,
+                                           const int32_t* nkey = nullptr, const int32_t* npred0 = nullptr) {
     // EAGER: the first probe's key column is streamed with 16-byte loads alongside the first
     // predicate instead of being fetched afterwards by the surviving lanes only.  When a good part
     // of the rows survive, every cache line of the key column is touched anyway, and one stage of
@@ -1055,12 +1057,12 @@ __device__ __forceinline__ void pass_pairs(const DevFilter& f, const DevProbes& 
     const bool eager = EAGER && cfg_np<FC>(pr.n) > 0;
     if (eager) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { if constexpr (PRE) ek[j] = pre->ek[j]; else ek[j] = load2<false>(pr.key[0], r[j], nrows); }
+        for (int j = 0; j < NB; ++j) { if constexpr (PRE) ek[j] = pre->ek[j]; else ek[j] = loadc<false, NW>(NW ? reinterpret_cast<const int64_t*>(nkey) : pr.key[0], r[j], nrows); }
     }
     if (!SKIP_FIRST && cfg_ni<FC>(f.ni) > 0) {
         Pair<int64_t> d[NB];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { if constexpr (PRE) d[j] = pre->d[j]; else d[j] = load2<false>(f.ic[0], r[j], nrows); }
+        for (int j = 0; j < NB; ++j) { if constexpr (PRE) d[j] = pre->d[j]; else d[j] = loadc<false, NW>(NW ? reinterpret_cast<const int64_t*>(npred0) : f.ic[0], r[j], nrows); }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             p[j][0] &= (d[j].x >= f.ilo[0]) & (d[j].x <= f.ihi[0]);
@@ -1159,8 +1161,8 @@ __device__ __forceinline__ void stage_store(const DevStage& st, int64_t pos, int
 // PIPE (needs EAGER, one integer predicate and one probe at least): the next step's first-stage loads are requested at the
 // top of this step, so a step waits one memory round trip less (the build is bound by its chain of dependent round trips,
 // not by bytes: see "Staging" in DESIGN.md §3)
-template <class FC, int NPAY = -1, int SB = STAGE_BATCH, bool EAGER = true, bool EAGER_PAY = false, bool PIPE = false>
-__global__ __launch_bounds__(TPB) void k_stage(DevFilter f, DevProbes pr, DevStage st, int64_t nrows) {
+template <class FC, int NPAY = -1, int SB = STAGE_BATCH, bool EAGER = true, bool EAGER_PAY = false, bool PIPE = false, bool NW = false>
+__global__ __launch_bounds__(TPB) void k_stage(DevFilter f, DevProbes pr, DevStage st, int64_t nrows, const int32_t* __restrict__ nkey = nullptr, const int32_t* __restrict__ npred0 = nullptr) {
     extern __shared__ __align__(16) uint32_t s_dyn[];                   // f.slds * swidth words per wave (string predicate staging)
     __shared__ uint16_t s_queue[TPB / WAVE][WAVE * ROWS_PER_LOAD * SB];   // survivors of a step (row offsets), in row order
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
@@ -1210,7 +1212,7 @@ __global__ __launch_bounds__(TPB) void k_stage(DevFilter f, DevProbes pr, DevSta
                 pairs_preload<SB, FC>(f, pr, nb, BATCH_ROWS, lane, nrows, nxt);
                 pass_pairs<SB, FC, EAGER, false, true>(f, pr, r, nrows, cap_masks, p, s_str, &cur);
             } else {
-                pass_pairs<SB, FC, EAGER>(f, pr, r, nrows, cap_masks, p, s_str);
+                pass_pairs<SB, FC, EAGER, false, false, NW>(f, pr, r, nrows, cap_masks, p, s_str, nullptr, nkey, npred0);
             }
         } else {
 #pragma unroll
@@ -2118,8 +2120,10 @@ struct DevBuildSpec {                                                 // what a 
 
 // Generalised staging: one wave per row segment (row order is kept: the queue is drained from the
 // front), survivors compacted into the segment's stage slice exactly as k_stage does.
-template <class FC>
-__global__ __launch_bounds__(TPB) void k_build_lookup(DevFilter f, DevLookups L, DevBuildSpec spec, DevStage st, int64_t nrows, int* __restrict__ flags) {
+template <class FC, bool NW = false>      // NW: the first lookup's streamed key and the first integer predicate through their narrow twins (full steps only)
+__global__ __launch_bounds__(TPB) void k_build_lookup(DevFilter f, DevLookups L, DevBuildSpec spec, DevStage st, int64_t nrows, int* __restrict__ flags,
+                                                      const int32_t* __restrict__ nkey0 = nullptr, const int32_t* __restrict__ npred0 = nullptr) {
+    const int64_t* skey0 = NW ? reinterpret_cast<const int64_t*>(nkey0) : L.l[0].key[0].col;
     __shared__ int32_t s_row[TPB / WAVE][LBQ_CAP];
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
     if (seg >= st.nseg) return;
@@ -2186,9 +2190,9 @@ __global__ __launch_bounds__(TPB) void k_build_lookup(DevFilter f, DevLookups L,
             for (int j = 0; j < BUILD_LB; ++j) {
                 rr[j] = b + (int64_t)j * BATCH_ROWS + (int64_t)lane * ROWS_PER_LOAD;
                 p[j][0] = p[j][1] = true;
-                if (eager0) k0[j] = load2<false>(L.l[0].key[0].col, rr[j], nrows);
+                if (eager0) k0[j] = loadc<false, NW>(skey0, rr[j], nrows);
             }
-            pass_pairs<BUILD_LB, FC, false>(f, none, rr, nrows, nomask, p);
+            pass_pairs<BUILD_LB, FC, false, false, false, NW>(f, none, rr, nrows, nomask, p, nullptr, nullptr, nullptr, npred0);
             if (eager0) {
 #pragma unroll
                 for (int j = 0; j < BUILD_LB; ++j) { p[j][0] = p[j][0] && first_lookup_may_hit(L, k0[j].x); p[j][1] = p[j][1] && first_lookup_may_hit(L, k0[j].y); }

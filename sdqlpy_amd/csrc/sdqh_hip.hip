@@ -278,13 +278,14 @@ bool column_is_increasing(sdqh_ctx* ctx, sdqh_column* c) {
 const void* ensure_narrow(sdqh_ctx* ctx, sdqh_column* c) {
     if (c->narrow_state >= 0) return c->narrow;
     c->narrow_state = 0;
-    if (c->dtype == SDQH_STR || c->nrows < 2) return nullptr;
+    if ((c->dtype == SDQH_STR && c->width != 1) || c->nrows < 2) return nullptr;          // text: string(1) only (one byte per code unit)
     int32_t* twin = static_cast<int32_t*>(pool_alloc(ctx, (size_t)c->nrows * 4 + 64));
     int* flag = static_cast<int*>(pool_alloc(ctx, 64));
     bool ok = twin && flag && hipMemsetAsync(flag, 0, 4, ctx->stream) == hipSuccess;
     if (ok) {
         const unsigned grid = (unsigned)std::min<int64_t>((c->nrows + TPB - 1) / TPB, (int64_t)ctx->num_cu * 8);
-        if (c->dtype == SDQH_I64) hipLaunchKernelGGL(k_narrow_i64, dim3(grid), dim3(TPB), 0, ctx->stream, static_cast<const int64_t*>(c->data), c->nrows, twin, flag);
+        if (c->dtype == SDQH_STR) hipLaunchKernelGGL(k_narrow_str1, dim3(grid), dim3(TPB), 0, ctx->stream, static_cast<const uint32_t*>(c->data), c->nrows, reinterpret_cast<uint8_t*>(twin), flag);
+        else if (c->dtype == SDQH_I64) hipLaunchKernelGGL(k_narrow_i64, dim3(grid), dim3(TPB), 0, ctx->stream, static_cast<const int64_t*>(c->data), c->nrows, twin, flag);
         else hipLaunchKernelGGL(k_narrow_f64, dim3(grid), dim3(TPB), 0, ctx->stream, static_cast<const double*>(c->data), c->nrows, twin, flag);
         int* host = static_cast<int*>(ctx->result_host);
         ok = hipMemcpyAsync(host, flag, 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess && host[0] == 0;
@@ -722,12 +723,16 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
                 return with_group_keys(gk, [&](auto KC) {
                     using FCT = decltype(FC); using KCT = decltype(KC);
                     if constexpr (std::is_same_v<FCT, FCfg<1, 0, 0, 0>> && std::is_same_v<KCT, KCfg<1, 1>>) {      // the tuned family also has a 4-group form, and narrow-twin instances
-                        DevFilter nf = f; DevTuple nt = t;
-                        const bool narrow = narrow_streams(ctx, nrows, filter, tuple, &nf, &nt);
+                        DevFilter nf = f; DevTuple nt = t; DevGroupKeys ngk = gk;
+                        bool narrow = narrow_streams(ctx, nrows, filter, tuple, &nf, &nt);
+                        for (int k = 0; k < nkeys && narrow; ++k) {                 // the two string(1) keys through their one-byte twins
+                            ngk.col[k] = ensure_narrow(ctx, const_cast<sdqh_column*>(keys[k]));
+                            narrow = ngk.col[k] != nullptr;
+                        }
                         auto launch = [&](auto kern, const DevFilter& lf, const DevTuple& lt) {
                             grid = stream_grid(ctx, kern, nrows, TILE_ROWS, true);
                             if (int c = carve()) return c;
-                            LAUNCH(ctx, "k_groupby_reg", kern, grid, lf, lt, gk, nrows, r_keys, pacc, pcnt, r_flags);
+                            LAUNCH(ctx, "k_groupby_reg", kern, grid, lf, lt, narrow ? ngk : gk, nrows, r_keys, pacc, pcnt, r_flags);
                             return (int)SDQH_OK;
                         };
                         if (g4) return narrow ? launch(k_groupby_reg<SH, 4, FCT, KCT, true>, nf, nt) : launch(k_groupby_reg<SH, 4, FCT, KCT>, f, t);

@@ -684,7 +684,8 @@ struct DevGroupKeys {
 };
 
 // one key slot of a row pair -> two 32-bit parts; KIND: 0 absent, 1 string(1), 2 int64, -1 run time
-template <int KIND, bool TAIL>
+// NW (string(1) keys only): the column's narrow twin, one byte per code unit
+template <int KIND, bool TAIL, bool NW = false>
 __device__ __forceinline__ void load_key_part(const DevGroupKeys& gk, int j, int64_t r, int64_t nrows, uint32_t& a, uint32_t& b, bool& bad) {
     a = 0; b = 0;
     const bool present = KIND >= 0 ? KIND != 0 : j < gk.nkeys;
@@ -692,9 +693,15 @@ __device__ __forceinline__ void load_key_part(const DevGroupKeys& gk, int j, int
     const bool is_str = KIND >= 0 ? KIND == 1 : gk.is_str[j] != 0;
     const int64_t r0 = (!TAIL || r < nrows) ? r : nrows - 1, r1 = (!TAIL || r + 1 < nrows) ? r + 1 : nrows - 1;
     if (is_str) {
+        if constexpr (NW) {
+            const uint8_t* c = static_cast<const uint8_t*>(gk.col[j]);
+            if constexpr (!TAIL) { const uint16_t v = *reinterpret_cast<const uint16_t*>(c + r); a = v & 0xFFu; b = v >> 8; }
+            else { a = c[r0]; b = c[r1]; }
+        } else {
         const uint32_t* c = static_cast<const uint32_t*>(gk.col[j]);
         if constexpr (!TAIL) { uint2 v = *reinterpret_cast<const uint2*>(c + r); a = v.x; b = v.y; }
         else { a = c[r0]; b = c[r1]; }
+        }
     } else {
         Pair<int64_t> v = load2<TAIL>(static_cast<const int64_t*>(gk.col[j]), r, nrows);
         bad |= (v.x < 0) | (v.x > 0xFFFFFFFEll) | (v.y < 0) | (v.y > 0xFFFFFFFEll);
@@ -702,11 +709,11 @@ __device__ __forceinline__ void load_key_part(const DevGroupKeys& gk, int j, int
     }
 }
 
-template <class KC, bool TAIL>
+template <class KC, bool TAIL, bool NW = false>
 __device__ __forceinline__ void load_group_keys(const DevGroupKeys& gk, int64_t r, int64_t nrows, uint64_t& k0, uint64_t& k1, bool& bad) {
     uint32_t a0, b0, a1, b1;
-    load_key_part<KC::K0, TAIL>(gk, 0, r, nrows, a0, b0, bad);
-    load_key_part<KC::K1, TAIL>(gk, 1, r, nrows, a1, b1, bad);
+    load_key_part<KC::K0, TAIL, NW>(gk, 0, r, nrows, a0, b0, bad);
+    load_key_part<KC::K1, TAIL, NW>(gk, 1, r, nrows, a1, b1, bad);
     k0 = (uint64_t)a0 | ((uint64_t)a1 << 32);
     k1 = (uint64_t)b0 | ((uint64_t)b1 << 32);
 }
@@ -774,7 +781,7 @@ __device__ __forceinline__ void groupby_reg_tile(const DevFilter& f, const DevTu
         const int64_t r = base + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
 #pragma unroll
         for (int j = 0; j < NOPS; ++j) xv[u][j] = loadc<TAIL, NW>(t.op[j], r, nrows);
-        load_group_keys<KC, TAIL>(gk, r, nrows, key[u][0], key[u][1], bad);
+        load_group_keys<KC, TAIL, NW && KC::K0 == 1 && KC::K1 == 1>(gk, r, nrows, key[u][0], key[u][1], bad);      // (the NW instances exist for two string(1) keys)
         filter_load<FC, TAIL, NW>(f, r, nrows, fr[u]);
     }
     uint64_t rk[G];
@@ -2923,6 +2930,11 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_narrow_i64(const int64_t* __restrict__
         bad |= v < -2147483647ll - 1 || v > 2147483647ll;
         dst[r] = (int32_t)v;
     }
+    if (__ballot(bad) && lane_id() == 0) atomicOr(flag, 1);
+}
+SDQH_KERNEL __launch_bounds__(TPB) void k_narrow_str1(const uint32_t* __restrict__ src, int64_t nrows, uint8_t* __restrict__ dst, int* __restrict__ flag) {
+    bool bad = false;
+    for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * TPB) { const uint32_t v = src[r]; bad |= v > 0xFFu; dst[r] = (uint8_t)v; }
     if (__ballot(bad) && lane_id() == 0) atomicOr(flag, 1);
 }
 SDQH_KERNEL __launch_bounds__(TPB) void k_narrow_f64(const double* __restrict__ src, int64_t nrows, int32_t* __restrict__ dst, int* __restrict__ flag) {

@@ -172,9 +172,13 @@ int         sdqh_profile_count(const sdqh_ctx* ctx);
 int         sdqh_profile_entry(const sdqh_ctx* ctx, int i, const char** name, double* ms);
 /* Raw hipStream_t the ctx launches on (NULL in the CPU build). */
 void*       sdqh_stream(const sdqh_ctx* ctx);
-/* Tuning knobs of the HIP build ("resident_cap", "probe_unroll", "stage_batch", "stage_eager",
- * "stage_waves_per_cu", "direct_index", "async_copies"); results never depend on them.  The CPU build accepts and
- * ignores any name. */
+/* Tuning knobs of the HIP build; results never depend on them (the parity suite runs with the defaults, A/B runs in
+ * profiles/ flip them).  "resident_cap", "resident_stream", "probe_unroll", "probe_chunk", "stage_batch", "stage_eager",
+ * "stage_eager_pay", "stage_waves_per_cu", "direct_index", "async_copies", "groupby_regs"; round 2: "narrow" (1: streamed
+ * columns through exact 4-byte twins), "row_pack" (1), "packed_slots" (1), "coarse_kb" (64: LDS budget of the coarse key
+ * filter, 0 = off), "lookup_pipeline" (-1 auto / 0 / 1), "probe_pipeline" (0), "stage_pipeline" (0), "span_index" (1),
+ * "dense_increasing" (1), "lookup_debug" (cut points of k_lookup_agg for measurements: results ARE wrong with it).
+ * The CPU build accepts and ignores any name. */
 int         sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value);
 
 /* ---- columns ----------------------------------------------------------------------------- */

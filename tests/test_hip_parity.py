@@ -91,6 +91,61 @@ def test_q1_q6_are_bit_reproducible(hip_engine):
     hip_engine.clear()
 
 
+def test_narrow_twins_change_no_bit(hip_engine, oracle_engine):
+    """Streamed columns are read through 4-byte twins only when every row of the twin decodes to the
+    column's value bit for bit.  (1) TPCH data: every query that streams through twins returns the SAME bits with
+    the twins switched off.  (2) Columns the twins cannot hold — prices with more than two decimals, a negative
+    zero, a value beyond int32 cents, keys beyond int32 — silently keep their 8-byte form: same bits again, and
+    the CPU implementation agrees."""
+    qs = ["q1", "q6", "q3", "q5", "q14", "q10"]
+    db = tpch.generate(2.0, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+
+    def run_all(database, names):
+        out = {}
+        for q in names:
+            r = helpers.run_query(hip_engine, q, database)
+            out[q] = r if isinstance(r, float) else helpers.result_rows(r, r.columns)
+        return out
+
+    with_twins = run_all(db, qs)
+    hip_engine.ctx.set_option("narrow", 0)
+    hip_engine.clear()
+    try:
+        without = run_all(db, qs)
+    finally:
+        hip_engine.ctx.set_option("narrow", 1)
+        hip_engine.clear()
+    # q5 (LDS group table) and q10 (the orders of one customer) add with f64 atomics in no fixed order: equal to rounding, not to
+    # the bit, with or without twins; the register / fixed-order reductions (q1, q6, q14) and q3's one atomic per group are exact
+    for q in ("q5", "q10"):
+        helpers.assert_rows_match(with_twins.pop(q), without.pop(q), 1e-12, "twins/" + q)
+    assert with_twins == without
+    # (2) awkward columns
+    li = db["lineitem"].getContainer()
+    cols = {h: c.copy() for h, c in zip(li["headers"], li["data"])}
+    cols["l_extendedprice"][::7] += 1e-7                      # more than two decimals
+    cols["l_discount"][5] = -0.0                              # the twin would decode to +0.0
+    cols["l_quantity"][11] = 3.0e9                            # beyond int32 hundredths
+    cols["l_tax"][3::1000] = 1.0 / 3.0
+    cols["l_shipdate"][17] = 1 << 40                          # beyond int32
+    awkward = dict(db)
+    awkward["lineitem"] = tpch.table_from_columns(li["headers"], [cols[h] for h in li["headers"]])
+    a = run_all(awkward, ["q1", "q6", "q14"])
+    hip_engine.ctx.set_option("narrow", 0)
+    hip_engine.clear()
+    try:
+        b = run_all(awkward, ["q1", "q6", "q14"])
+    finally:
+        hip_engine.ctx.set_option("narrow", 1)
+        hip_engine.clear()
+    assert a == b
+    want6 = helpers.run_query(oracle_engine, "q6", awkward)
+    assert abs(a["q6"] - want6) <= REL * abs(want6)
+    want1 = helpers.run_query(oracle_engine, "q1", awkward)
+    helpers.assert_rows_match(a["q1"], helpers.result_rows(want1, want1.columns), REL, "awkward/q1")
+    oracle_engine.clear()
+
+
 def test_row_order_invariance(hip_engine):
     """Size-independent property: a permutation of the probe-side rows leaves every result
     unchanged (exactly for counts and keys, to rounding for sums)."""

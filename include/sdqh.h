@@ -158,7 +158,8 @@ const char* sdqh_last_error(const sdqh_ctx* ctx);
 int         sdqh_set_threads(sdqh_ctx* ctx, int threads);   /* CPU build: worker count; HIP build: accepted, ignored */
 int         sdqh_synchronize(sdqh_ctx* ctx);
 /* Milliseconds spent on the device by the most recent pattern call (HIP events on the ctx
- * stream; CPU build: wall clock of the call). */
+ * stream, recorded while sdqh_set_profiling is on — 0.0 otherwise: the two events cost barrier
+ * packets on the stream; CPU build: wall clock of the call). */
 int         sdqh_last_device_ms(const sdqh_ctx* ctx, double* ms);
 /* Name and duration (ms) of each kernel launch, measured with HIP events recorded on the ctx
  * stream around the launch.  mode 1: entries of the most recent pattern call; mode 2: entries

@@ -67,11 +67,12 @@ hipEvent_t next_event(sdqh_ctx* ctx) {
 void call_begin(sdqh_ctx* ctx) {
     if (ctx->nested) return;                               // an entry point implemented with others: one call for the profile and the call timer
     if (ctx->profiling != 2) { ctx->prof.clear(); ctx->event_next = 0; }
-    (void)hipEventRecord(ctx->call_begin, ctx->stream);
     ctx->call_timed = false;
+    if (!ctx->profiling) return;                           // the call timer costs two barrier packets on the stream: only with profiling on
+    (void)hipEventRecord(ctx->call_begin, ctx->stream);
 }
 void call_end(sdqh_ctx* ctx) {
-    if (ctx->nested) return;
+    if (ctx->nested || !ctx->profiling) return;
     (void)hipEventRecord(ctx->call_end, ctx->stream);
     ctx->call_timed = true;
 }
@@ -609,9 +610,9 @@ int sdqh_scan_filter_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter
         });
     });
     if (lrc) return lrc;
-    LAUNCH(ctx, "k_sum_partials", k_sum_partials, 1, partial, (int)grid, out_dev);
+    (void)out_dev;
+    LAUNCH(ctx, "k_sum_partials", k_sum_partials, 1, partial, (int)grid, static_cast<double*>(ctx->result_host));     // the fold writes the pinned host block itself
     call_end(ctx);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->result_host, out_dev, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     int rc = sync_stream(ctx);
     pool_free(ctx, partial);
     if (rc) return rc;
@@ -751,9 +752,13 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
             });
         });
         if (lrc) { if (blob) pool_free(ctx, blob); return lrc; }
-        LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, GMAX, r_keys, pacc, pcnt, (int)grid, r_acc, r_cnt);
+        {   // the merge writes the result block straight into the pinned host block (same layout as rd)
+            char* hb = static_cast<char*>(ctx->result_host);
+            LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, GMAX, r_keys, pacc, pcnt, (int)grid, reinterpret_cast<double*>(hb + GMAX * 8), reinterpret_cast<int64_t*>(hb + GMAX * 40),
+                   reinterpret_cast<unsigned long long*>(hb), static_cast<const int*>(r_ng), reinterpret_cast<int*>(hb + GMAX * 48));
+        }
         call_end(ctx);
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->result_host, rd, rbytes, hipMemcpyDeviceToHost, ctx->stream));
+        (void)rbytes;
         rc = sync_stream(ctx);
         pool_free(ctx, blob);
         if (rc) break;
@@ -1730,8 +1735,14 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
     double* r_acc = reinterpret_cast<double*>(rd + LG_SLOTS * 8);
     int64_t* r_cnt = reinterpret_cast<int64_t*>(rd + LG_SLOTS * 40);
     int* r_flags = reinterpret_cast<int*>(rd + LG_SLOTS * 48);
-    const size_t rbytes = LG_SLOTS * 48 + 8;
     static_assert(LG_SLOTS * 48 + 8 <= RESULT_BYTES, "result block too small");
+    // the merge writes the result block straight into the pinned host block (same layout): no copy-engine launch after it
+    char* hb = static_cast<char*>(ctx->result_host);
+    unsigned long long* h_keys = reinterpret_cast<unsigned long long*>(hb);
+    double* h_acc = reinterpret_cast<double*>(hb + LG_SLOTS * 8);
+    int64_t* h_cnt = reinterpret_cast<int64_t*>(hb + LG_SLOTS * 40);
+    int* h_tail = reinterpret_cast<int*>(hb + LG_SLOTS * 48);
+    (void)r_acc; (void)r_cnt;
     unsigned grid = 1; char* blob = nullptr;
     int lrc = with_shape(ctx, tuple_shape, [&](auto S) {
         return with_scan_filter(f, [&](auto FC) {
@@ -1766,7 +1777,7 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
                     int64_t* pcnt = reinterpret_cast<int64_t*>(blob + nslots * 32);
                     { FillList fl; fl.add(r_keys, LG_SLOTS * 8, 0xFF); fl.add(r_flags, 8, 0); launch_fill(ctx, fl); }
                     { KernelScope _ks(ctx, "k_lookup_agg"); hipLaunchKernelGGL(big, dim3(grid), dim3(BIG_BT), coarse_lds, ctx->stream, f, L, spec, nrows, r_keys, pacc, pcnt, r_flags, ctx->opt_probe_chunk, nkey0); }
-                    LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, r_keys, pacc, pcnt, (int)grid, r_acc, r_cnt);
+                    LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, r_keys, pacc, pcnt, (int)grid, h_acc, h_cnt, h_keys, static_cast<const int*>(r_flags), h_tail);
                     call_end(ctx);
                     return SDQH_OK;
                 }
@@ -1783,13 +1794,12 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
             int64_t* pcnt = reinterpret_cast<int64_t*>(blob + nslots * 32);
             { FillList fl; fl.add(r_keys, LG_SLOTS * 8, 0xFF); fl.add(r_flags, 8, 0); launch_fill(ctx, fl); }
             LAUNCH(ctx, "k_lookup_agg", kern, grid, f, L, spec, nrows, r_keys, pacc, pcnt, r_flags, ctx->opt_probe_chunk, nkey0);
-            LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, r_keys, pacc, pcnt, (int)grid, r_acc, r_cnt);
+            LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, r_keys, pacc, pcnt, (int)grid, h_acc, h_cnt, h_keys, static_cast<const int*>(r_flags), h_tail);
             call_end(ctx);
             return SDQH_OK;
         });
     });
     if (lrc) { if (blob) pool_free(ctx, blob); return lrc; }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->result_host, rd, rbytes, hipMemcpyDeviceToHost, ctx->stream));
     int rc = sync_stream(ctx);
     pool_free(ctx, blob);
     if (rc) return rc;
@@ -1970,7 +1980,7 @@ void launch_sum_partials(sdqh_ctx* ctx, const double* partial, int nparts, doubl
     LAUNCH(ctx, "k_sum_partials", k_sum_partials, 1, partial, nparts, out);
 }
 void launch_groupby_merge_lg(sdqh_ctx* ctx, const unsigned long long* gkeys, const double* pacc, const int64_t* pcnt, int nparts, double* out_acc, int64_t* out_cnt) {
-    LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, gkeys, pacc, pcnt, nparts, out_acc, out_cnt);
+    LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, gkeys, pacc, pcnt, nparts, out_acc, out_cnt, static_cast<unsigned long long*>(nullptr), static_cast<const int*>(nullptr), static_cast<int*>(nullptr));
 }
 int column_minmax(sdqh_ctx* ctx, sdqh_column* c) { return ensure_minmax(ctx, c); }
 int new_owned_column(sdqh_ctx* ctx, int64_t nrows, int dtype, sdqh_column** out) { return sdqh_column_alloc(ctx, nrows, dtype, 0, out); }

@@ -934,11 +934,17 @@ __global__ __launch_bounds__(TPB) void k_groupby_lds(DevFilter f, DevTuple t, De
 
 // One workgroup per global group slot: fold that slot's partials over the workgroups in workgroup
 // order (thread-strided, then an LDS tree).  out: acc[g*4+k], cnt[g]; the keys are gkeys[g].
+// out_keys / out_tail (optional): the group keys and the 8 bytes after the block (group count / flags) are copied along, so that
+// out_* can be the caller's pinned host block itself — the result is on the host when the stream is idle, without a copy-engine
+// launch after the kernel (one API call and one DMA round trip less per group-by call)
 SDQH_KERNEL __launch_bounds__(TPB) void k_groupby_merge(const unsigned long long* __restrict__ gkeys, const double* __restrict__ pacc,
                                                        const int64_t* __restrict__ pcnt, int nparts,
-                                                       double* __restrict__ out_acc, int64_t* __restrict__ out_cnt) {
+                                                       double* __restrict__ out_acc, int64_t* __restrict__ out_cnt,
+                                                       unsigned long long* __restrict__ out_keys, const int* __restrict__ d_tail, int* __restrict__ out_tail) {
     __shared__ double s_red[5][TPB];
     const int g = blockIdx.x;
+    if (threadIdx.x == 0 && out_keys) out_keys[g] = gkeys[g];
+    if (g == 0 && threadIdx.x == 0 && out_tail) { out_tail[0] = d_tail[0]; out_tail[1] = d_tail[1]; }
     if (gkeys[g] == EMPTY_GROUP) { if (threadIdx.x == 0) out_cnt[g] = 0; return; }
     double a[4] = {0, 0, 0, 0};
     int64_t c = 0;

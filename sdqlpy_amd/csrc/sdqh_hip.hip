@@ -1983,6 +1983,7 @@ void launch_groupby_merge_lg(sdqh_ctx* ctx, const unsigned long long* gkeys, con
     LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, gkeys, pacc, pcnt, nparts, out_acc, out_cnt, static_cast<unsigned long long*>(nullptr), static_cast<const int*>(nullptr), static_cast<int*>(nullptr));
 }
 int column_minmax(sdqh_ctx* ctx, sdqh_column* c) { return ensure_minmax(ctx, c); }
+const void* column_narrow(sdqh_ctx* ctx, sdqh_column* c) { return ensure_narrow(ctx, c); }
 int new_owned_column(sdqh_ctx* ctx, int64_t nrows, int dtype, sdqh_column** out) { return sdqh_column_alloc(ctx, nrows, dtype, 0, out); }
 
 }  // namespace sdqh_host

@@ -138,6 +138,7 @@ void tb_release(sdqh_ctx* ctx, sdqh_table* t);
 int stage_setup_computed(sdqh_ctx* ctx, sdqh_table* tb, int64_t nrows, int npay, int batch);
 int index_ensure(sdqh_ctx* ctx, sdqh_table* tb);
 int column_minmax(sdqh_ctx* ctx, sdqh_column* c);
+const void* column_narrow(sdqh_ctx* ctx, sdqh_column* c);      // the exact 4-byte twin of a streamed column (built on first request), or nullptr
 // launches of ahead-of-time kernels the run-time specialised path needs
 void fill_regions(sdqh_ctx* ctx, void* const* ptr, const size_t* bytes, const unsigned char* byte, int n);
 void launch_sum_partials(sdqh_ctx* ctx, const double* partial, int nparts, double* out);

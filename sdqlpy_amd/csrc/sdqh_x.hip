@@ -53,6 +53,7 @@ struct XInfo {
     bool direct = false;                     // every operation is register arithmetic on numeric columns
     int nstream_gates = 0;                   // leading gates that depend on numeric columns / constants only
     std::vector<int> scols;                  // streamed columns (indices into cols)
+    uint32_t narrow_mask = 0;                // streamed columns read through their exact 4-byte twin (bit = index into cols)
     int probe_op = -1;                       // XEntry: the LOOKUP whose entry receives the values
     int prefilter_op = -1;                   // first LOOKUP gate after the streamed ones whose key is made of plain columns:
     int prefilter_part0 = -1;                //   its table's key bitmap is tested on the streamed key (operation of the first key part)
@@ -182,6 +183,13 @@ int analyse(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* p, int max_vals, b
         }
     }
     for (int c = 0; c < x->ncols; ++c) if (scol[(size_t)c]) x->scols.push_back(c);
+    // narrow twins of what is streamed (register programs stream every column): decided per column, part of the kernel's structure
+    if (ctx->opt_narrow && !ctx->compile_only && nrows >= (1 << 20)) {
+        for (int c = 0; c < x->ncols; ++c) {
+            if (!(x->direct || scol[(size_t)c]) || x->cols[c]->dtype == SDQH_STR) continue;
+            if (column_narrow(ctx, const_cast<sdqh_column*>(x->cols[c]))) x->narrow_mask |= 1u << c;
+        }
+    }
     return SDQH_OK;
 }
 
@@ -327,7 +335,11 @@ std::string generate(const XInfo& x, Sink sink, bool direct) {
         out << "    }\n";
     }
     out << "    template <bool TAIL> __device__ __forceinline__ static void sload(const XArgs& a, int64_t r, int64_t nrows, Pair<int64_t> (&s)[" << nsx << "]) {\n";
-    for (int i = 0; i < ns; ++i) out << "        s[" << i << "] = load2<TAIL>(static_cast<const int64_t*>(a.col[" << scols[(size_t)i] << "]), r, nrows);\n";
+    for (int i = 0; i < ns; ++i) {
+        const int c = scols[(size_t)i];
+        if ((x.narrow_mask >> c) & 1u) out << "        s[" << i << "] = x_sload_narrow_" << (x.cols[c]->dtype == SDQH_F64 ? "f" : "i") << "<TAIL>(a.ncol[" << c << "], r, nrows);\n";
+        else out << "        s[" << i << "] = load2<TAIL>(static_cast<const int64_t*>(a.col[" << c << "]), r, nrows);\n";
+    }
     out << "    }\n";
     // streamed conditions, both rows of the pair
     out << "    __device__ __forceinline__ static void stest(const XArgs& a, const Pair<int64_t> (&s)[" << nsx << "], bool& p0, bool& p1) {\n";
@@ -420,7 +432,7 @@ uint64_t structure_hash(const XInfo& x, Sink sink, bool direct) {
     const sdqh_program* p = x.p;
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](uint64_t v) { for (int i = 0; i < 8; ++i) { h ^= (v >> (8 * i)) & 0xFF; h *= 1099511628211ull; } };
-    mix((uint64_t)sink * 2 + (direct ? 1 : 0)); mix((uint64_t)p->nops); mix((uint64_t)(int64_t)p->key); mix((uint64_t)(int64_t)x.probe_op);
+    mix((uint64_t)sink * 2 + (direct ? 1 : 0)); mix((uint64_t)x.narrow_mask); mix((uint64_t)p->nops); mix((uint64_t)(int64_t)p->key); mix((uint64_t)(int64_t)x.probe_op);
     for (int k = 0; k < p->nops; ++k) {
         const sdqh_xop& o = p->ops[k];
         mix(((uint64_t)(uint32_t)o.code << 32) | (uint32_t)o.type); mix(((uint64_t)(uint32_t)o.a << 32) | (uint32_t)o.b); mix(((uint64_t)(uint32_t)o.c << 32) | (uint32_t)o.aux);
@@ -507,7 +519,7 @@ template <class SA> struct Packed { XArgs a; SA s; int64_t nrows; int64_t seg_ro
 
 int fill_xargs(sdqh_ctx* ctx, const XInfo& x, XArgs* a, int32_t* flags, int64_t key_lo, int64_t key_hi) {
     std::memset(a, 0, sizeof(*a));
-    for (int c = 0; c < x.ncols; ++c) { a->col[c] = x.cols[c]->data; a->width[c] = x.cols[c]->width; }
+    for (int c = 0; c < x.ncols; ++c) { a->col[c] = x.cols[c]->data; a->width[c] = x.cols[c]->width; a->ncol[c] = ((x.narrow_mask >> c) & 1u) ? x.cols[c]->narrow : nullptr; }
     for (int t = 0; t < x.ntabs; ++t) {
         if (int rc = index_ensure(ctx, x.tabs[t])) return rc;
         a->tab[t] = x.tabs[t]->dev;

@@ -25,6 +25,7 @@ template <bool B> struct XBool { static constexpr bool value = B; };
 // constants).  The program's structure is in the code; these can change from run to run.
 struct XArgs {
     const void* col[SDQH_MAX_XCOLS];
+    const void* ncol[SDQH_MAX_XCOLS];           // exact 4-byte twins of the STREAMED columns that have one (sload reads them; everything by row reads col)
     int32_t width[SDQH_MAX_XCOLS];              // STR columns: code units per row
     DevTable tab[SDQH_MAX_XTABLES];
     int64_t ci[X_MAX_CONST];
@@ -44,6 +45,15 @@ template <int NV> struct XOut {
 __device__ __forceinline__ double x_f(int64_t bits) { return __longlong_as_double(bits); }
 __device__ __forceinline__ int64_t x_bits(double v) { return __double_as_longlong(v); }
 
+// a streamed row pair through the column's narrow twin (sdqh_kernels.hpp, loadc): raw 8-byte values as the registers hold them
+template <bool TAIL> __device__ __forceinline__ Pair<int64_t> x_sload_narrow_i(const void* p, int64_t r, int64_t nrows) {
+    return loadc<TAIL, true>(static_cast<const int64_t*>(p), r, nrows);
+}
+template <bool TAIL> __device__ __forceinline__ Pair<int64_t> x_sload_narrow_f(const void* p, int64_t r, int64_t nrows) {
+    const Pair<double> d = loadc<TAIL, true>(static_cast<const double*>(p), r, nrows);
+    Pair<int64_t> v; v.x = x_bits(d.x); v.y = x_bits(d.y);
+    return v;
+}
 // VarChar::firstIndex (reference include/varchar.h:91-97), str.find on the text up to the first NUL
 __device__ __forceinline__ int64_t x_first_index(const uint32_t* __restrict__ s, int width, const uint32_t* val, int len) {
     int n = 0;

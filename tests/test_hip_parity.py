@@ -276,7 +276,7 @@ def test_full_size_q9_and_topk_sf10(hip_engine):
 def test_open_vocabulary_queries_against_the_reference(hip_engine, golden_wide, oracle_engine):
     """q7, q8, q13, q15, q17, q19, q20, q22 through kernels specialised on their own conditions and values
     (row programs), against the reference's results; then at SF 1 against the CPU implementation."""
-    assert helpers.check_wide_goldens(hip_engine, golden_wide, REL, "hip") >= 23
+    assert helpers.check_wide_goldens(hip_engine, golden_wide, REL, "hip") >= 30
     qs = ("q7", "q8", "q13", "q15", "q17", "q19", "q20", "q22")
     db = tpch.generate(1.0, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
     for q in qs:
@@ -293,7 +293,7 @@ def test_open_vocabulary_queries_against_the_reference(hip_engine, golden_wide, 
 def test_every_golden_vector_through_specialised_kernels(hip_engine, golden, golden_more, golden_wide):
     """All reference results again with every table loop forced through a run-time specialised kernel
     (no ahead-of-time kernel shape): the general path must agree with the tuned one on its home turf."""
-    assert helpers.check_all_goldens_as_programs(hip_engine, [golden, golden_more, golden_wide], REL, 1e-10, "hip") >= 70
+    assert helpers.check_all_goldens_as_programs(hip_engine, [golden, golden_more, golden_wide], REL, 1e-10, "hip") >= 76
     hip_engine.clear()
 
 

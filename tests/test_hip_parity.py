@@ -274,10 +274,10 @@ def test_full_size_q9_and_topk_sf10(hip_engine):
 
 
 def test_open_vocabulary_queries_against_the_reference(hip_engine, golden_wide, oracle_engine):
-    """q7, q8, q13, q15, q17, q19, q20, q22 through kernels specialised on their own conditions and values
+    """q7, q8, q12, q13, q15, q16, q17, q19, q20, q22 through kernels specialised on their own conditions and values
     (row programs), against the reference's results; then at SF 1 against the CPU implementation."""
     assert helpers.check_wide_goldens(hip_engine, golden_wide, REL, "hip") >= 30
-    qs = ("q7", "q8", "q13", "q15", "q17", "q19", "q20", "q22")
+    qs = ("q7", "q8", "q12", "q13", "q15", "q16", "q17", "q19", "q20", "q22")
     db = tpch.generate(1.0, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
     for q in qs:
         got, want = helpers.run_query(hip_engine, q, db), helpers.run_query(oracle_engine, q, db)

@@ -70,7 +70,9 @@ def test_oracle_reproduces_reference_on_the_open_vocabulary(oracle_lib, golden_w
     """q7 (or, conditions on looked-up text), q8 (nested lookups, conditional value, arithmetic on the result),
     q13 (firstIndex, not, a count looked up as a group key), q15 (result dictionary joined on the host), q17
     (condition on the matched entry's accumulators), q19 (or of and, coded text payload), q20 (composite-key
-    aggregation looked up with its value), q22 (or of prefixes, anti-join, substr group key): SURVEY.md §8f.3.
+    aggregation looked up with its value), q22 (or of prefixes, anti-join, substr group key), q12 (a compared text value looked
+    up: dictionary-coded build; integer-valued conditional sums), q16 (a four-field group key over a large domain as one
+    mixed-radix integer; a group-by over the result dictionary): SURVEY.md §8f.3.
     Front end -> xplan (row programs) -> the CPU implementation's interpreter; one thread sums in row order
     like the reference's interpreter, so doubles are bit-identical."""
     eng = engine.Engine(oracle_lib.context(threads=threads))

@@ -515,7 +515,9 @@ def _source_of(eng, op, htab, e, lookups, as_group_key=False):
 
 def _decode_column(values, decoder, dtype):
     if decoder is not None:
-        return decoder[values]
+        if decoder.dtype.kind == "U":
+            return decode_text(values, decoder)                  # text of a large result stays references until it is read
+        return np.asarray(decoder)[values]
     return values.view(dtype) if np.dtype(dtype) != values.dtype else values
 
 

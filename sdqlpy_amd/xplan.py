@@ -864,6 +864,8 @@ def run_host_dict(eng, op, env, materialize):
                 got = [a for nm, a in fields if nm == fname] + [a for nm, a in d.key_fields if nm == fname]
                 if not got:
                     raise UnsupportedQuery("line %d: '%s' has no field '%s'" % (op.lineno, lk.dict_name, fname))
+                if isinstance(got[0], TextRefs) and hit.all():
+                    return got[0][rows]                                   # references of references: still not decoded
                 col = np.asarray(got[0])
             if len(col) and col.dtype.kind == "U" and hit.all():
                 return decode_text(rows, col)                            # text of a large result: the row references now, the (wide) strings when read

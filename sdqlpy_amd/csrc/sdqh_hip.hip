@@ -301,7 +301,7 @@ const void* ensure_narrow(sdqh_ctx* ctx, sdqh_column* c) {
 // Swap every streamed column of a scan (integer / double predicates, tuple operands) for its twin; false (nothing changed)
 // unless ALL of them have one.  Only for the instances that read nothing else by row (no string / column-pair predicates).
 static bool narrow_streams(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, const sdqh_tuple* tuple, DevFilter* f, DevTuple* t) {
-    if (!ctx->opt_narrow || nrows < (1 << 20) || f->ns || f->nc) return false;
+    if (!ctx->opt_narrow || nrows < ctx->opt_feature_min_rows || f->ns || f->nc) return false;
     const int nops = tuple ? std::max(0, tuple_nops(tuple->shape)) : 0;
     const sdqh_column* ops[4] = {tuple ? tuple->a : nullptr, tuple ? tuple->b : nullptr, tuple ? tuple->c : nullptr, tuple ? tuple->d : nullptr};
     const void* ni[SDQH_MAX_IPRED]; const void* nf[SDQH_MAX_FPRED]; const void* no[4];
@@ -474,6 +474,7 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "lookup_pipeline" && value >= -1 && value <= 1) ctx->opt_lookup_pipeline = (int)value;
     else if (n == "probe_pipeline" && value >= 0 && value <= 1) ctx->opt_probe_pipeline = (int)value;
     else if (n == "lookup_debug") ctx->opt_lookup_debug = (int)value;
+    else if (n == "feature_min_rows" && value >= 0) ctx->opt_feature_min_rows = value;
     else if (n == "narrow" && value >= 0 && value <= 1) ctx->opt_narrow = (int)value;
     else if (n == "stage_pipeline" && value >= 0 && value <= 1) ctx->opt_stage_pipeline = (int)value;
     else if (n == "span_index" && value >= 0 && value <= 1) ctx->opt_span_index = (int)value;
@@ -1005,7 +1006,7 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
                             STAGE_PIPE(2) STAGE_PIPE(4)
 #undef STAGE_PIPE
                         }
-                        if (ctx->opt_narrow && nrows >= (1 << 20) && sb == 4 && eg == 1 && ep == 0) {       // first predicate + streamed probe key through their narrow twins
+                        if (ctx->opt_narrow && nrows >= ctx->opt_feature_min_rows && sb == 4 && eg == 1 && ep == 0) {       // first predicate + streamed probe key through their narrow twins
                             const int32_t* nkey = static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(probes[0].key)));
                             const int32_t* npred0 = nkey ? static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(filter->ipred[0].col))) : nullptr;
                             if (nkey && npred0) { auto kern = k_stage<FCT, 2, 4, true, false, false, true>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows, nkey, npred0); return SDQH_OK; }
@@ -1145,7 +1146,7 @@ int sdqh_hash_probe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* f
             // narrow twins of the two streamed columns (key, first integer predicate): the layouts with at most one integer predicate
             if constexpr (std::is_same_v<FCT, FCfg<1, 0, 0, 0>> || std::is_same_v<FCT, FCfg<0, 0, 0, 0>>) {
                 // (not for the row-keyed group-by, sdqh_groupby_key: every row hits there, the drain bounds it, and the conversions cost 6 %)
-                if (ctx->opt_narrow && nrows >= (1 << 20) && !ctx->in_groupby_key) {
+                if (ctx->opt_narrow && nrows >= ctx->opt_feature_min_rows && !ctx->in_groupby_key) {
                     nkey = static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(key)));
                     if (nkey && f.ni == 1) { npred0 = static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(filter->ipred[0].col))); if (!npred0) nkey = nullptr; }
                     if (nkey) return launch(k_probe_agg<SH, FCT, PROBE_UNROLL, true>, PROBE_UNROLL);
@@ -1624,7 +1625,7 @@ int sdqh_build(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nloo
             if constexpr (std::is_same_v<FCT, FCfg<1, 0, 0, 0>> || std::is_same_v<FCT, FCfg<0, 0, 0, 0>>) {
                 // the first lookup's streamed key and the first integer predicate through their narrow twins
                 const bool eager0 = nlookups > 0 && lookups[0].key[0].kind == SDQH_SRC_COLUMN && lookups[0].key[0].col->dtype == SDQH_I64;
-                if (ctx->opt_narrow && nrows >= (1 << 20) && (eager0 || f.ni == 1)) {
+                if (ctx->opt_narrow && nrows >= ctx->opt_feature_min_rows && (eager0 || f.ni == 1)) {
                     const int32_t* nkey0 = eager0 ? static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(lookups[0].key[0].col))) : nullptr;
                     const int32_t* npred0 = f.ni == 1 ? static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(filter->ipred[0].col))) : nullptr;
                     if ((!eager0 || nkey0) && (f.ni != 1 || npred0)) {
@@ -1677,10 +1678,10 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
         L.pipeline = ctx->opt_lookup_pipeline >= 0 ? ctx->opt_lookup_pipeline : (column_is_clustered(ctx, const_cast<sdqh_column*>(lookups[0].key[0].col)) ? 1 : 0);
     // Coarse key filter in LDS for the first lookup when its keys come in no order and its bitmap does not fit L1
     size_t coarse_lds = 0;
-    if (ctx->opt_coarse_kb > 0 && nlookups > 0 && nrows >= (1 << 22) && lookups[0].key[0].kind == SDQH_SRC_COLUMN && lookups[0].key[0].col->dtype == SDQH_I64) {
+    if (ctx->opt_coarse_kb > 0 && nlookups > 0 && nrows >= 4 * ctx->opt_feature_min_rows && lookups[0].key[0].kind == SDQH_SRC_COLUMN && lookups[0].key[0].col->dtype == SDQH_I64) {
         sdqh_table* t0 = const_cast<sdqh_table*>(lookups[0].table);
         const bool part_bitmap = t0->bm && !t0->dev.lin_rb && (lookups[0].nkey == 1 ? t0->dev.bm_shift == 0 : t0->dev.bm_shift != 0);
-        if (part_bitmap && t0->nwords * 4 > (32u << 10) && !column_is_clustered(ctx, const_cast<sdqh_column*>(lookups[0].key[0].col))) {
+        if (part_bitmap && (t0->nwords * 4 > (32u << 10) || ctx->opt_feature_min_rows == 0) && !column_is_clustered(ctx, const_cast<sdqh_column*>(lookups[0].key[0].col))) {
             if (!t0->coarse) {
                 const uint64_t nbits = t0->nwords * 32, budget = (uint64_t)ctx->opt_coarse_kb * 1024 * 8;
                 int shift = 0;
@@ -1700,7 +1701,7 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
     }
     // Row pack: every plain column the drain gathers (lookup key parts, group key parts, operands), interleaved once
     // and kept resident.  Only worth it for big scans with several gathered columns.
-    if (ctx->opt_row_pack && nlookups > 0 && nrows >= (1 << 20)) {
+    if (ctx->opt_row_pack && nlookups > 0 && nrows > 0 && nrows >= ctx->opt_feature_min_rows) {
         std::vector<DevSource*> srcs;
         for (int l = 0; l < nlookups; ++l) for (int k = 0; k < L.l[l].nkey; ++k) srcs.push_back(&L.l[l].key[k]);
         for (int k = 0; k < nkeys; ++k) srcs.push_back(&spec.key[k]);
@@ -1717,7 +1718,7 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
                     DevPackCols pc; std::memset(&pc, 0, sizeof(pc));
                     for (size_t j = 0; j < cols.size(); ++j) pc.col[j] = static_cast<const int64_t*>(cols[j]);
                     pc.ncols = (int)cols.size(); pc.k = k;
-                    LAUNCH(ctx, "k_interleave", k_interleave, (unsigned)std::min<int64_t>((nrows + TPB - 1) / TPB, (int64_t)ctx->num_cu * 16), pc, nrows, static_cast<int64_t*>(data));
+                    LAUNCH(ctx, "k_interleave", k_interleave, (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + TPB - 1) / TPB, (int64_t)ctx->num_cu * 16)), pc, nrows, static_cast<int64_t*>(data));
                     ctx->packs.push_back({cols, nrows, k, data});
                     found = &ctx->packs.back();
                 }
@@ -1755,7 +1756,7 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
             if (coarse_lds && !BIG_OK) { L.coarse = nullptr; L.coarse_words = 0; L.coarse_shift = 0; coarse_lds = 0; }
             // narrow twin of the first lookup's streamed key column (unfiltered scans: the instances that exist with NW)
             const int32_t* nkey0 = nullptr;
-            if (BIG_OK && ctx->opt_narrow && nrows >= (1 << 20) && nlookups > 0 && lookups[0].key[0].kind == SDQH_SRC_COLUMN && lookups[0].key[0].col->dtype == SDQH_I64)
+            if (BIG_OK && ctx->opt_narrow && nrows >= ctx->opt_feature_min_rows && nlookups > 0 && lookups[0].key[0].kind == SDQH_SRC_COLUMN && lookups[0].key[0].col->dtype == SDQH_I64)
                 nkey0 = static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(lookups[0].key[0].col)));
             if constexpr (BIG_OK) if (coarse_lds) {
                 auto big_raw = k_lookup_agg<SH, FCT, BIG_BT, BIG_PU>;

@@ -66,6 +66,8 @@ struct sdqh_ctx {
     int opt_packed_slots = 1;                      // hash-layout tables with payload: 32-byte slots { key, payload 0 / 1, owner row }
     int opt_lookup_pipeline = -1;                  // k_lookup_agg requests the next tile's first-lookup keys a step ahead: -1 = when that key column is clustered, 0 / 1 = never / always
     int opt_lookup_debug = 0;
+    int64_t opt_feature_min_rows = 1 << 20;        // narrow twins / row pack (and, x 4, the coarse filter) are for scans of at least this many rows; the suites set 0 to
+                                                   // run those instances on tiny and ragged inputs too
     bool in_groupby_key = false;                   // sdqh_groupby_key is running its probe-aggregate pass
     int opt_narrow = 1;                            // streaming kernels (k_scan_sum, k_groupby_reg) read predicates / operands through exact 4-byte twins when every one of them has one
     int opt_stage_pipeline = 0;                    // k_stage (tuned orders-like family): first-stage loads of the next step requested a step ahead (measured: Q3 orders 0.148 -> 0.151 ms, no gain: off)

@@ -184,7 +184,7 @@ int analyse(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* p, int max_vals, b
     }
     for (int c = 0; c < x->ncols; ++c) if (scol[(size_t)c]) x->scols.push_back(c);
     // narrow twins of what is streamed (register programs stream every column): decided per column, part of the kernel's structure
-    if (ctx->opt_narrow && !ctx->compile_only && nrows >= (1 << 20)) {
+    if (ctx->opt_narrow && !ctx->compile_only && nrows >= ctx->opt_feature_min_rows) {
         for (int c = 0; c < x->ncols; ++c) {
             if (!(x->direct || scol[(size_t)c]) || x->cols[c]->dtype == SDQH_STR) continue;
             if (column_narrow(ctx, const_cast<sdqh_column*>(x->cols[c]))) x->narrow_mask |= 1u << c;

@@ -111,6 +111,21 @@ def check_wide_goldens(ctx_engine, golden_wide, rel, what):
     return n
 
 
+def check_all_goldens(ctx_engine, goldens, rel, rel_q10, what):
+    """EVERY golden vector on the planner's default routes."""
+    n = 0
+    for gold in goldens:
+        for case in gold["cases"]:
+            db = case_db(case)
+            for q, want in case["results"].items():
+                res = run_query(ctx_engine, q, db)
+                if q == "q15" and want["rows"]:
+                    res = res.top(1, [("total_revenue", "desc")])
+                check_against_golden(res, want, rel_q10 if q == "q10" else rel, "%s/%s/%s" % (what, case["name"], q))
+                n += 1
+    return n
+
+
 def check_all_goldens_as_programs(ctx_engine, goldens, rel, rel_q10, what):
     """EVERY golden vector with every table loop forced through a row program (Engine.force_programs):
     the specialised kernels have to reproduce what the tuned fixed-shape kernels are tested for."""

@@ -342,6 +342,43 @@ def test_ragged_sizes(hip_engine, oracle_engine):
     oracle_engine.clear()
 
 
+def test_large_scan_instances_on_small_and_ragged_inputs(hip_engine, oracle_engine, golden, golden_more, golden_wide):
+    """The instances that large scans select — narrow twins (NW kernels incl. their tail paths), the row pack, the coarse
+    key filter in its 1024-thread workgroup, the pipelined streaming steps — are chosen from 1 M / 4 M rows up, where only
+    the full-size tests reach them.  With `feature_min_rows` 0 (and a 1 KiB coarse filter) they run on every golden
+    vector, on row counts around every tile / wave / pair boundary, and in the differential fuzz."""
+    from helpers import fuzz_case
+    opts = {"feature_min_rows": 0, "coarse_kb": 1, "lookup_pipeline": 1, "probe_pipeline": 1}
+    for k, v in opts.items():
+        hip_engine.ctx.set_option(k, v)
+    hip_engine.clear()
+    try:
+        assert helpers.check_all_goldens(hip_engine, [golden, golden_more, golden_wide], REL, 1e-10, "hip/large-scan instances") >= 76
+        hip_engine.clear()
+        base = tpch.generate(0.002, tables=sorted(tpch.columns_for(SUPPORTED)), columns=tpch.columns_for(SUPPORTED))
+        li = base["lineitem"].getContainer()
+        total = len(li["data"][0])
+        for n in [0, 1, 2, 3, 63, 65, 127, 129, 511, 513, 1023, 1025, 2047, 2049, 4097, 8191, 8193, total]:
+            db = dict(base)
+            db["lineitem"] = tpch.table_from_columns(li["headers"], [np.ascontiguousarray(c[:n]) for c in li["data"]])
+            for q in SUPPORTED:
+                got = helpers.run_query(hip_engine, q, db)
+                want = helpers.run_query(oracle_engine, q, db)
+                if q == "q6":
+                    assert abs(got - want) <= REL * max(abs(want), 1e-300), (n, got, want)
+                else:
+                    helpers.assert_rows_match(helpers.result_rows(got, want.columns), helpers.result_rows(want, want.columns), REL, "n=%d/%s" % (n, q))
+        for seed in (11, 12, 13):
+            assert fuzz_case(hip_engine.ctx, oracle_engine.ctx, seed) == 12
+    finally:
+        hip_engine.ctx.set_option("feature_min_rows", 1 << 20)
+        hip_engine.ctx.set_option("coarse_kb", 64)
+        hip_engine.ctx.set_option("lookup_pipeline", -1)
+        hip_engine.ctx.set_option("probe_pipeline", 0)
+        hip_engine.clear()
+        oracle_engine.clear()
+
+
 def test_many_groups_fallback_and_overflow(hip_engine, oracle_engine):
     """9..64 groups take the LDS kernel; more than 64 is reported, not mis-aggregated."""
     from sdqlpy_amd import abi

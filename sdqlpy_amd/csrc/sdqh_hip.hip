@@ -474,6 +474,7 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "lookup_pipeline" && value >= -1 && value <= 1) ctx->opt_lookup_pipeline = (int)value;
     else if (n == "probe_pipeline" && value >= 0 && value <= 1) ctx->opt_probe_pipeline = (int)value;
     else if (n == "lookup_debug") ctx->opt_lookup_debug = (int)value;
+    else if (n == "rank_increasing" && value >= 0 && value <= 1) ctx->opt_rank_increasing = (int)value;
     else if (n == "feature_min_rows" && value >= 0) ctx->opt_feature_min_rows = value;
     else if (n == "narrow" && value >= 0 && value <= 1) ctx->opt_narrow = (int)value;
     else if (n == "stage_pipeline" && value >= 0 && value <= 1) ctx->opt_stage_pipeline = (int)value;
@@ -912,16 +913,36 @@ static int build_dense(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int
     st.seg_count = static_cast<uint32_t*>(table_alloc(ctx, tb, (size_t)st.nseg * 4 + 64));
     st.shits = static_cast<uint32_t*>(table_alloc(ctx, tb, (size_t)nrows * 4 + 64));
     tb->hdr = static_cast<TableHeader*>(table_alloc(ctx, tb, sizeof(TableHeader)));
+    // a strictly increasing key column (orders by o_orderkey, any table by its primary key)
+    const bool increasing = ctx->opt_dense_increasing && column_is_increasing(ctx, const_cast<sdqh_column*>(key));
+    const int64_t* kc = static_cast<const int64_t*>(key->data);
+    const unsigned grid = (unsigned)std::min<int64_t>((nrows + TPB - 1) / TPB, (int64_t)ctx->num_cu * 8);
+    if (increasing && ctx->opt_rank_increasing && (range * 4 > ((uint64_t)16 << 20) || ctx->opt_feature_min_rows == 0)) {      // (feature_min_rows 0: the suites run it on small tables too)
+        // ... over a wide range: the direct layout with rank = row (k_rank_increasing): a bitmap and one row number per bitmap word
+        // instead of four bytes per key of the range (Q9's orders at SF=10: 15 MB written instead of 240 MB)
+        tb->nwords = (range + 31) / 32;
+        tb->bm = static_cast<uint32_t*>(table_alloc(ctx, tb, tb->nwords * 4 + 64));
+        uint32_t* wprefix = static_cast<uint32_t*>(table_alloc(ctx, tb, tb->nwords * 4 + 64));
+        if (!st.seg_count || !st.shits || !tb->hdr || !tb->bm || !wprefix) { table_release(ctx, tb); delete tb; return fail(ctx, SDQH_ERR_NOMEM, "dense build: out of device memory"); }
+        st.hdr = tb->hdr;
+        tb->dev.hdr = tb->hdr; tb->dev.shits = st.shits; tb->dev.bm_lo = lo; tb->dev.bm_hi = hi; tb->dev.bm = tb->bm; tb->dev.bm_shift = 0; tb->dev.wprefix = wprefix;
+        for (int p = 0; p < npayload; ++p) tb->dev.pay[p] = st.pay[p];
+        call_begin(ctx);
+        { FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); fl.add(st.shits, (size_t)nrows * 4, 0); fl.add(tb->bm, tb->nwords * 4, 0); launch_fill(ctx, fl); }
+        LAUNCH(ctx, "k_full_counts", k_full_counts, (unsigned)((st.nseg + TPB - 1) / TPB), st.seg_count, st.nseg, st.seg_rows, nrows);
+        LAUNCH(ctx, "k_rank_increasing", k_rank_increasing, (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + TPB * RANK_INC_NB - 1) / (TPB * RANK_INC_NB), (int64_t)ctx->num_cu * 32)), kc, nrows, lo, tb->bm, wprefix, tb->hdr);
+        call_end(ctx);
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) { table_release(ctx, tb); delete tb; return fail(ctx, SDQH_ERR_DEVICE, std::string("dense build launch: ") + hipGetErrorString(e2)); }
+        *out = tb;
+        return SDQH_OK;
+    }
     uint32_t* arr = static_cast<uint32_t*>(table_alloc(ctx, tb, range * 4 + 64));
     if (!st.seg_count || !st.shits || !tb->hdr || !arr) { table_release(ctx, tb); delete tb; return fail(ctx, SDQH_ERR_NOMEM, "dense build: out of device memory"); }
     st.hdr = tb->hdr;
     tb->dev.hdr = tb->hdr; tb->dev.shits = st.shits; tb->dev.bm_lo = lo; tb->dev.bm_hi = hi; tb->dev.dense_arr = arr;
     for (int p = 0; p < npayload; ++p) tb->dev.pay[p] = st.pay[p];
-    const int64_t* kc = static_cast<const int64_t*>(key->data);
-    const unsigned grid = (unsigned)std::min<int64_t>((nrows + TPB - 1) / TPB, (int64_t)ctx->num_cu * 8);
-    // a strictly increasing key column (orders by o_orderkey, any table by its primary key) fills the array in one pass:
-    // no prefill of the cells, no verification pass (Q9's orders at SF=10: 0.226 -> see DESIGN.md §3)
-    const bool increasing = ctx->opt_dense_increasing && column_is_increasing(ctx, const_cast<sdqh_column*>(key));
+    // ... over a narrow range fills the array in one pass: no prefill of the cells, no verification pass
     call_begin(ctx);
     if (increasing) {
         { FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); fl.add(st.shits, (size_t)nrows * 4, 0); launch_fill(ctx, fl); }

@@ -498,7 +498,8 @@ __device__ __forceinline__ int64_t table_find(const DevTable& t, int64_t key, ui
 }
 // stage index of the entry at an index position
 __device__ __forceinline__ bool table_is_direct(const DevTable& t) { return t.dense_arr || (t.bm && t.bm_shift == 0); }     // no hash slots: cap_mask unused
-__device__ __forceinline__ uint32_t table_ref(const DevTable& t, int64_t pos) { return t.dense_arr ? (uint32_t)pos : (t.bm && t.bm_shift == 0 ? t.dense_ref[pos] : slot_row(t, (uint64_t)pos)); }
+// (direct layout without an owner array: the increasing-key form, rank = row — k_rank_increasing)
+__device__ __forceinline__ uint32_t table_ref(const DevTable& t, int64_t pos) { return t.dense_arr ? (uint32_t)pos : (t.bm && t.bm_shift == 0 ? (t.dense_ref ? t.dense_ref[pos] : (uint32_t)pos) : slot_row(t, (uint64_t)pos)); }
 
 // ---- row filter on a pair of rows --------------------------------------------------------------
 // Integer and double range predicates with their own columns, plus the optional string equality.
@@ -1453,6 +1454,59 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_dense_fill_increasing(const int64_t* _
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { hdr->staged = (uint64_t)nrows; hdr->has_dups = 0; }
+}
+// Direct layout over a strictly increasing key column where EVERY row is an entry (a whole table joined on its sorted primary
+// key): the rank of a key is its row number, so no owner array at all — the key bitmap and, per bitmap word, the row of the
+// word's first key (wprefix; words without keys are never consulted).  A wave assembles the words of its 128 rows in LDS and
+// stores the interior ones plainly (keys increase: no other wave has a key in them); the first and the last word may be shared
+// with the neighbouring waves and are ORed in.  15 MB written for Q9's orders instead of the dense array's 240 MB.
+constexpr int RANK_INC_WORDS = 1024;                                  // bitmap words a wave assembles per step (4 KiB)
+constexpr int RANK_INC_NB = 8;                                        // blocks of 64 rows per wave step: every key of the step is requested before any is used
+SDQH_KERNEL __launch_bounds__(TPB) void k_rank_increasing(const int64_t* __restrict__ key, int64_t nrows, int64_t lo, uint32_t* __restrict__ bm,
+                                                         uint32_t* __restrict__ wprefix, TableHeader* __restrict__ hdr) {
+    __shared__ uint32_t s_words[TPB / WAVE][RANK_INC_WORDS];
+    uint32_t* words = s_words[threadIdx.x / WAVE];
+    const int lane = lane_id();
+    constexpr int NB = RANK_INC_NB, ROWS = NB * WAVE;
+    const int64_t nsteps = (nrows + ROWS - 1) / ROWS;
+    const int64_t wave = (int64_t)blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE, nwaves = (int64_t)gridDim.x * (TPB / WAVE);
+    for (int64_t step = wave; step < nsteps; step += nwaves) {
+        const int64_t r0 = step * ROWS;
+        uint64_t o[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { const int64_t r = r0 + (int64_t)j * WAVE + lane; o[j] = r < nrows ? (uint64_t)(key[r] - lo) : 0; }
+        const int64_t rlast = (r0 + ROWS <= nrows ? r0 + ROWS : nrows) - 1;
+        const uint64_t before = r0 > 0 ? (uint64_t)(key[r0 - 1] - lo) : ~0ull;                      // (uniform addresses)
+        const uint64_t wl = (uint64_t)(key[rlast] - lo) >> 5;
+        const uint64_t wf = __shfl(o[0], 0, WAVE) >> 5;
+        // a row that is the first key of its bitmap word records its row number there
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int64_t r = r0 + (int64_t)j * WAVE + lane;
+            uint64_t prev = __shfl_up(o[j], 1, WAVE);
+            const uint64_t carry = j == 0 ? before : __shfl(o[j > 0 ? j - 1 : 0], WAVE - 1, WAVE);
+            if (lane == 0) prev = carry;
+            if (r < nrows && (prev == ~0ull || (prev >> 5) != (o[j] >> 5))) wprefix[o[j] >> 5] = (uint32_t)r;
+        }
+        const uint64_t nw = wl - wf + 1;
+        if (nw <= (uint64_t)RANK_INC_WORDS) {
+            for (int i = lane; i < (int)nw; i += WAVE) words[i] = 0u;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { const int64_t r = r0 + (int64_t)j * WAVE + lane; if (r < nrows) atomicOr(&words[(o[j] >> 5) - wf], 1u << (o[j] & 31)); }
+            __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < (int)nw; i += WAVE) {
+                const uint32_t w = words[i];
+                if (i == 0 || i == (int)nw - 1) { if (w) atomicOr(&bm[wf + i], w); }
+                else bm[wf + i] = w;
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {                                                       // a wide gap inside the step: bit by bit
+#pragma unroll
+            for (int j = 0; j < NB; ++j) { const int64_t r = r0 + (int64_t)j * WAVE + lane; if (r < nrows) atomicOr(&bm[o[j] >> 5], 1u << (o[j] & 31)); }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { hdr->staged = (uint64_t)nrows; hdr->distinct = (uint64_t)nrows; hdr->has_dups = 0; }
 }
 // a row that does not find itself in its cell lost to a duplicate key
 SDQH_KERNEL __launch_bounds__(TPB) void k_dense_verify(const int64_t* __restrict__ key, int64_t nrows, int64_t lo, const uint32_t* __restrict__ arr, TableHeader* __restrict__ hdr) {

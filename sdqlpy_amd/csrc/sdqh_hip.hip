@@ -474,6 +474,7 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "lookup_pipeline" && value >= -1 && value <= 1) ctx->opt_lookup_pipeline = (int)value;
     else if (n == "probe_pipeline" && value >= 0 && value <= 1) ctx->opt_probe_pipeline = (int)value;
     else if (n == "lookup_debug") ctx->opt_lookup_debug = (int)value;
+    else if (n == "fuse_small" && value >= 0 && value <= 1) ctx->opt_fuse_small = (int)value;
     else if (n == "str_rows" && (value == 0 || value == 32 || value == 64)) ctx->opt_str_rows = (int)value;
     else if (n == "rank_increasing" && value >= 0 && value <= 1) ctx->opt_rank_increasing = (int)value;
     else if (n == "feature_min_rows" && value >= 0) ctx->opt_feature_min_rows = value;
@@ -870,6 +871,14 @@ static int ensure_index(sdqh_ctx* ctx, sdqh_table* tb) {
         uint32_t* dense = tb->refs_prefilled ? tb->dev.dense_ref : static_cast<uint32_t*>(table_alloc(ctx, tb, rows * 4 + 64));
         if (!wprefix || !dense) return fail(ctx, SDQH_ERR_NOMEM, "table index: out of device memory");
         tb->dev.wprefix = wprefix; tb->dev.dense_ref = dense;
+        if (nblocks == 1 && seg_grid == 1 && tb->refs_prefilled && ctx->opt_fuse_small) {       // a tiny table: rank + insert in one launch
+            LAUNCH(ctx, "k_index_small", k_index_small, 1u, tb->bm, tb->nwords, wprefix, tb->stage, tb->dev, tb->span);
+            if (tb->span) tb->dev.dense_arr = tb->span;
+            hipError_t es = hipGetLastError();
+            if (es != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, std::string("table index launch: ") + hipGetErrorString(es));
+            tb->index_built = true;
+            return SDQH_OK;
+        }
         LAUNCH(ctx, "k_rank_words", k_rank_words, (unsigned)nblocks, tb->bm, tb->nwords, wprefix, tb->stage.seg_count, tb->stage.nseg, tb->hdr);
         if (!tb->refs_prefilled) LAUNCH(ctx, "k_fill_refs", k_fill_refs, (unsigned)ctx->num_cu * 2, tb->stage, tb->dev);
         LAUNCH(ctx, "k_insert_direct", k_insert_direct, seg_grid, tb->stage, tb->dev, tb->span);
@@ -1642,7 +1651,10 @@ int sdqh_build(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nloo
         tb->stage.bm = tb->bm; tb->stage.bm_lo = lo; tb->stage.bm_hi = hi; tb->stage.hdr = tb->hdr; tb->stage.bm_shift = shift;
         if (tb->bm && lin_rb) { tb->dev.lin_rb = tb->stage.lin_rb = lin_rb; tb->dev.lin_b0 = tb->stage.lin_b0 = lin_b0; }
         const unsigned seg_grid = (unsigned)((tb->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
-        { FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); fl.add(flags, 8, 0); if (tb->bm) fl.add(tb->bm, tb->nwords * 4, 0); prefill_refs(ctx, tb, &fl); launch_fill(ctx, fl); }
+        // a tiny table (one workgroup of segments): the build kernel does its own fill (a launch less: each is ~8 us of dependent-launch latency)
+        FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); fl.add(flags, 8, 0); if (tb->bm) fl.add(tb->bm, tb->nwords * 4, 0); prefill_refs(ctx, tb, &fl);
+        DevFill pre; std::memset(&pre, 0, sizeof(pre));
+        if (seg_grid == 1 && ctx->opt_fuse_small && fl.most <= ((uint64_t)1 << 20)) pre = fl.f; else launch_fill(ctx, fl);
         hipError_t e;
         with_scan_filter(f, [&](auto FC) {
             using FCT = decltype(FC);
@@ -1654,13 +1666,13 @@ int sdqh_build(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nloo
                     const int32_t* npred0 = f.ni == 1 ? static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(filter->ipred[0].col))) : nullptr;
                     if ((!eager0 || nkey0) && (f.ni != 1 || npred0)) {
                         auto kern = k_build_lookup<FCT, true>;
-                        LAUNCH(ctx, "k_build_lookup", kern, seg_grid, f, L, spec, tb->stage, nrows, flags, nkey0, npred0);
+                        LAUNCH(ctx, "k_build_lookup", kern, seg_grid, f, L, spec, tb->stage, nrows, flags, nkey0, npred0, pre);
                         return SDQH_OK;
                     }
                 }
             }
             auto kern = k_build_lookup<FCT>;
-            LAUNCH(ctx, "k_build_lookup", kern, seg_grid, f, L, spec, tb->stage, nrows, flags, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr));
+            LAUNCH(ctx, "k_build_lookup", kern, seg_grid, f, L, spec, tb->stage, nrows, flags, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr), pre);
             return SDQH_OK;
         });
         call_end(ctx);

@@ -130,6 +130,24 @@ struct DevTable {
                               //    cache line instead of four (keys[], rowref[], pay[0][], pay[1][]); keys / rowref are null then
 };
 
+// regions to set to a byte value each (k_fill; also the preamble of a build kernel that runs as ONE workgroup: see fill_in_block)
+constexpr int FILL_MAX = 6;
+struct DevFill { void* p[FILL_MAX]; uint64_t bytes[FILL_MAX]; uint32_t word[FILL_MAX]; int32_t n, _pad; };
+// The fill of a tiny table's build, done by the build kernel's own (single) workgroup: a table over a few hundred rows is
+// four launches of ~8 us each (fill, stage, rank, insert) for microseconds of work — two this way (the other pair: k_index_small)
+__device__ __forceinline__ void fill_in_block(const DevFill& f) {
+#pragma unroll
+    for (int r = 0; r < FILL_MAX; ++r) {
+        if (r >= f.n) break;
+        const uint32_t w = f.word[r];
+        const uint64_t n16 = f.bytes[r] / 16, n4 = f.bytes[r] / 4;
+        uint4* p16 = static_cast<uint4*>(f.p[r]);
+        for (uint64_t i = threadIdx.x; i < n16; i += blockDim.x) p16[i] = make_uint4(w, w, w, w);
+        uint32_t* p4 = static_cast<uint32_t*>(f.p[r]);
+        for (uint64_t i = n16 * 4 + threadIdx.x; i < n4; i += blockDim.x) p4[i] = w;
+    }
+}
+
 // hash-layout accessors (separate arrays, or the packed 32-byte slots)
 __device__ __forceinline__ int64_t slot_key(const DevTable& t, uint64_t h) { return t.slots ? t.slots[h * 4] : t.keys[h]; }
 __device__ __forceinline__ uint32_t slot_row(const DevTable& t, uint64_t h) { return t.slots ? (uint32_t)t.slots[h * 4 + 3] : t.rowref[h]; }
@@ -1331,8 +1349,8 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_clear(const uint32_t* __restrict__ seg
 // indexes dense_ref), and a claimed base needs no scan pass, no second launch and no device-wide
 // fence (a release fence writes back a whole XCD L2 here).  hdr->staged is summed on the side;
 // fewer distinct keys than staged rows means duplicate build keys (see direct_has_dups).
-SDQH_KERNEL __launch_bounds__(TPB) void k_rank_words(const uint32_t* __restrict__ bm, uint64_t nwords, uint32_t* __restrict__ wprefix,
-                                                    const uint32_t* __restrict__ seg_count, int nseg, TableHeader* __restrict__ hdr) {
+__device__ __forceinline__ void rank_words_body(const uint32_t* __restrict__ bm, uint64_t nwords, uint32_t* __restrict__ wprefix,
+                                                const uint32_t* __restrict__ seg_count, int nseg, TableHeader* __restrict__ hdr) {
     __shared__ uint32_t s_wave[TPB / WAVE];
     __shared__ uint32_t s_base;
     constexpr int WPT = RANK_BLOCK_WORDS / TPB;                        // 8 consecutive words per thread
@@ -1367,6 +1385,10 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_rank_words(const uint32_t* __restrict_
 #pragma unroll
     for (int j = 0; j < WPT; ++j) { if (w0 + j < nwords) wprefix[w0 + j] = run; run += __popc(word[j]); }
 }
+SDQH_KERNEL __launch_bounds__(TPB) void k_rank_words(const uint32_t* __restrict__ bm, uint64_t nwords, uint32_t* __restrict__ wprefix,
+                                                    const uint32_t* __restrict__ seg_count, int nseg, TableHeader* __restrict__ hdr) {
+    rank_words_body(bm, nwords, wprefix, seg_count, nseg, hdr);
+}
 // direct layout, after k_rank_words: duplicate build keys <=> fewer set bits than staged rows
 __device__ __forceinline__ bool direct_has_dups(const TableHeader* hdr) { return hdr->staged != hdr->distinct; }
 // dense_ref[rank(key)] = stage index.  Unique build keys: plain stores, every row its own rank.
@@ -1378,7 +1400,7 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_fill_refs(DevStage st, DevTable t) {  
 }
 // span (optional): the same owner by key offset, span[key - bm_lo] — for a table over a small key range a lookup is then
 // ONE load (the dense layout's path) instead of bitmap word + rank prefix + dense_ref; NO_ROW-filled by the build's k_fill
-SDQH_KERNEL __launch_bounds__(TPB) void k_insert_direct(DevStage st, DevTable t, uint32_t* __restrict__ span) {
+__device__ __forceinline__ void insert_direct_body(const DevStage& st, const DevTable& t, uint32_t* __restrict__ span) {
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
     const bool dups = direct_has_dups(t.hdr);
     if (blockIdx.x == 0 && threadIdx.x == 0) t.hdr->has_dups = dups ? 1u : 0u;     // for every later reader
@@ -1392,6 +1414,14 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_insert_direct(DevStage st, DevTable t,
         if (dups) atomicMin(&t.dense_ref[pos], (uint32_t)idx); else t.dense_ref[pos] = (uint32_t)idx;
         if (span) { uint32_t* cell = span + (st.key[idx] - t.bm_lo); if (dups) atomicMin(cell, (uint32_t)idx); else *cell = (uint32_t)idx; }
     }
+}
+SDQH_KERNEL __launch_bounds__(TPB) void k_insert_direct(DevStage st, DevTable t, uint32_t* __restrict__ span) { insert_direct_body(st, t, span); }
+// rank + insert of a tiny table (one rank block, one workgroup of segments) in one launch
+SDQH_KERNEL __launch_bounds__(TPB) void k_index_small(const uint32_t* __restrict__ bm, uint64_t nwords, uint32_t* __restrict__ wprefix, DevStage st, DevTable t, uint32_t* __restrict__ span) {
+    rank_words_body(bm, nwords, wprefix, st.seg_count, st.nseg, t.hdr);
+    __threadfence();
+    __syncthreads();
+    insert_direct_body(st, t, span);
 }
 
 // ---- dense layout ---------------------------------------------------------------------------------------
@@ -2189,7 +2219,8 @@ struct DevBuildSpec {                                                 // what a 
 // front), survivors compacted into the segment's stage slice exactly as k_stage does.
 template <class FC, bool NW = false>      // NW: the first lookup's streamed key and the first integer predicate through their narrow twins (full steps only)
 __global__ __launch_bounds__(TPB) void k_build_lookup(DevFilter f, DevLookups L, DevBuildSpec spec, DevStage st, int64_t nrows, int* __restrict__ flags,
-                                                      const int32_t* __restrict__ nkey0 = nullptr, const int32_t* __restrict__ npred0 = nullptr) {
+                                                      const int32_t* __restrict__ nkey0, const int32_t* __restrict__ npred0, DevFill pre) {
+    if (pre.n) { fill_in_block(pre); __syncthreads(); }                  // (only ever with a grid of one workgroup)
     const int64_t* skey0 = NW ? reinterpret_cast<const int64_t*>(nkey0) : L.l[0].key[0].col;
     __shared__ int32_t s_row[TPB / WAVE][LBQ_CAP];
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
@@ -2611,8 +2642,6 @@ __device__ __forceinline__ uint32_t compact_segment(const DevTable& t, const Dev
 
 // Several small regions set to a byte value by ONE launch (a hipMemsetAsync per region costs a
 // launch each, and most builds need two or three).  Regions are 4-byte multiples, 16-byte aligned.
-constexpr int FILL_MAX = 6;
-struct DevFill { void* p[FILL_MAX]; uint64_t bytes[FILL_MAX]; uint32_t word[FILL_MAX]; int32_t n, _pad; };
 SDQH_KERNEL __launch_bounds__(TPB) void k_fill(DevFill f) {
     const uint64_t tid = (uint64_t)blockIdx.x * TPB + threadIdx.x, nth = (uint64_t)gridDim.x * TPB;
 #pragma unroll

@@ -1095,10 +1095,13 @@ int sdqh_build_key_set(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
     tb->hdr = static_cast<TableHeader*>(table_alloc(ctx, tb, sizeof(TableHeader)));
     if (!tb->bm || !tb->hdr) { table_release(ctx, tb); delete tb; return fail(ctx, SDQH_ERR_NOMEM, "build_key_set: out of device memory"); }
     tb->dev.bm = tb->bm; tb->dev.bm_lo = lo; tb->dev.bm_hi = hi; tb->dev.bitmap_only = 1; tb->dev.hdr = tb->hdr;
-    { FillList fl; fl.add(tb->bm, (tb->nwords * 4 + 15) & ~(uint64_t)15, 0); fl.add(tb->hdr, sizeof(TableHeader), 0); launch_fill(ctx, fl); }
+    FillList fl; fl.add(tb->bm, (tb->nwords * 4 + 15) & ~(uint64_t)15, 0); fl.add(tb->hdr, sizeof(TableHeader), 0);
+    DevFill pre; std::memset(&pre, 0, sizeof(pre));
+    const unsigned grid0 = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + TPB * ROWS_PER_LOAD * 2 - 1) / (TPB * ROWS_PER_LOAD * 2), (int64_t)ctx->num_cu * ctx->opt_resident_cap));
+    if (nrows > 0 && grid0 == 1 && ctx->opt_fuse_small && fl.most <= ((uint64_t)1 << 20)) pre = fl.f; else launch_fill(ctx, fl);      // a tiny table clears its bitmap in the key-set kernel itself
     if (nrows > 0) {
         const int64_t* kc = static_cast<const int64_t*>(key->data);
-        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + TPB * ROWS_PER_LOAD * 2 - 1) / (TPB * ROWS_PER_LOAD * 2), (int64_t)ctx->num_cu * ctx->opt_resident_cap));
+        const unsigned grid = grid0;
         // 32 rows per round from 33 code units up: 64 rows of Q9's p_name are 14 KiB per wave, two workgroups per CU (0.110 -> 0.101 ms)
         unsigned str_rows = (f.ns && f.swidth > 0 && f.swidth <= 128) ? (f.swidth <= 32 ? 64u : 32u) : 0u;
         if (str_rows && ctx->opt_str_rows) str_rows = (unsigned)ctx->opt_str_rows;
@@ -1106,7 +1109,7 @@ int sdqh_build_key_set(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
         f.slds = str_rows;
         with_stage_filter(f, nprobes, [&](auto FC) {
             auto kern = k_key_set<decltype(FC)>;
-            LAUNCH_LDS(ctx, "k_key_set", kern, grid, lds, f, pr, kc, nrows, lo, hi, tb->bm);
+            LAUNCH_LDS(ctx, "k_key_set", kern, grid, lds, f, pr, kc, nrows, lo, hi, tb->bm, pre);
             return SDQH_OK;
         });
     }
@@ -1257,7 +1260,7 @@ int sdqh_groupby_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, co
     const unsigned sgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + TPB * ROWS_PER_LOAD * 2 - 1) / (TPB * ROWS_PER_LOAD * 2), (int64_t)ctx->num_cu * ctx->opt_resident_cap));
     with_stage_filter(f, 0, [&](auto FC) {
         auto kern = k_key_set<decltype(FC)>;
-        LAUNCH_LDS(ctx, "k_key_set", kern, sgrid, 0, f, pr, kc, nrows, lo, hi, tb->bm);
+        { DevFill nofill; std::memset(&nofill, 0, sizeof(nofill)); LAUNCH_LDS(ctx, "k_key_set", kern, sgrid, 0, f, pr, kc, nrows, lo, hi, tb->bm, nofill); }
         return SDQH_OK;
     });
     const int nblocks = (int)((tb->nwords + RANK_BLOCK_WORDS - 1) / RANK_BLOCK_WORDS);

@@ -1897,7 +1897,8 @@ __global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevT
 // clustered on the key), so equal words of the pair are merged before the atomic.
 template <class FC>
 __global__ __launch_bounds__(TPB) void k_key_set(DevFilter f, DevProbes pr, const int64_t* __restrict__ key, int64_t nrows,
-                                                 int64_t lo, int64_t hi, uint32_t* __restrict__ bm) {
+                                                 int64_t lo, int64_t hi, uint32_t* __restrict__ bm, DevFill pre) {
+    if (pre.n) { fill_in_block(pre); __syncthreads(); }                  // a tiny table (grid of one workgroup) clears its own bitmap
     constexpr int PU = 2, TILE = TPB * ROWS_PER_LOAD * PU;
     extern __shared__ __align__(16) uint32_t s_dyn[];                   // f.slds * swidth words per wave (string predicate staging)
     uint32_t* s_str = (cfg_ns<FC>(f.ns) && f.slds) ? s_dyn + (size_t)(threadIdx.x / WAVE) * f.slds * f.swidth : nullptr;

@@ -77,3 +77,34 @@ def test_reference_text_lowering_record():
             continue
         fp = hashlib.sha1(frontend.lower_function(fn).fingerprint().encode()).hexdigest()[:16]
         assert rec["shipped_plan_digests"][name] == fp, "re-run tests/golden/make_lowering_fixture.py (%s changed)" % name
+
+
+def test_merging_equal_keys_of_large_results_on_codes_and_buckets():
+    """engine._merge_equal_keys on results of more than 4096 rows: dictionary-coded text is grouped on its codes
+    (result.Dictionary: equal code <=> equal text), other text is factorised, and both the bucketed form (a small
+    box of key stand-ins) and the sorted form give what a Python dict gives."""
+    import numpy as np
+    from sdqlpy_amd import engine
+    from sdqlpy_amd.result import DictResult, Dictionary, TextRefs
+    rng = np.random.default_rng(5)
+    n = 20000
+    brands = np.array(["Brand#%d%d" % (i, j) for i in range(1, 6) for j in range(1, 6)]).view(Dictionary)
+    codes = rng.integers(0, len(brands), n)
+    sizes = rng.integers(1, 51, n)
+    free_text = np.array(["w%02d" % (i % 37) for i in rng.integers(0, 1000, n)])
+    wide = rng.integers(0, 1 << 40, n) // (1 << 33) * (1 << 33)                   # a handful of far-apart values: forces the sorted form
+    counts = rng.integers(1, 4, n).astype(np.int64)
+    sums = rng.integers(0, 1000, n).astype(np.float64)
+    for keys in ([("b", TextRefs(codes, brands)), ("s", sizes)],
+                 [("b", TextRefs(codes, brands)), ("t", free_text), ("s", sizes)],
+                 [("b", TextRefs(codes, brands)), ("w", wide)]):
+        d = engine._merge_equal_keys(DictResult(keys, [("n", counts), ("x", sums)]))
+        want = {}
+        cols = [np.asarray(a).tolist() for _, a in keys]
+        for i in range(n):
+            k = tuple(c[i] for c in cols)
+            a = want.setdefault(k, [0, 0.0]); a[0] += int(counts[i]); a[1] += float(sums[i])
+        got = {tuple(np.asarray(a)[i].item() for _, a in d.key_fields): (int(d.val_fields[0][1][i]), float(d.val_fields[1][1][i])) for i in range(d.size())}
+        assert len(got) == d.size() == len(want)
+        assert got == {k: (v[0], v[1]) for k, v in want.items()}
+        assert d.val_fields[0][1].dtype == np.int64

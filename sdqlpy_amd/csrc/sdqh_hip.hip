@@ -1021,7 +1021,9 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
             tb->stage.bm = tb->bm; tb->stage.bm_lo = lo; tb->stage.bm_hi = hi; tb->stage.hdr = tb->hdr; tb->stage.bm_shift = 0;
             call_begin(ctx);
             const unsigned seg_grid = (unsigned)((tb->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
-            { FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); if (tb->bm) fl.add(tb->bm, tb->nwords * 4, 0); prefill_refs(ctx, tb, &fl); launch_fill(ctx, fl); }
+            FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); if (tb->bm) fl.add(tb->bm, tb->nwords * 4, 0); prefill_refs(ctx, tb, &fl);
+            DevFill pre; std::memset(&pre, 0, sizeof(pre));
+            if (seg_grid == 1 && ctx->opt_fuse_small && fl.most <= ((uint64_t)1 << 20)) pre = fl.f; else launch_fill(ctx, fl);      // a tiny table: the staging kernel does its own fill
             // string predicate: fields staged through LDS, 64 rows per wave at a time (up to 64 KB per workgroup)
             const unsigned str_rows = (f.ns && f.swidth > 0 && f.swidth <= 128) ? (f.swidth <= 64 ? 64u : 32u) : 0u;
             const size_t stage_lds = (size_t)(TPB / WAVE) * str_rows * (size_t)f.swidth * 4;       // at most 64 KB per workgroup
@@ -1033,31 +1035,31 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
                     if (npayload == 2) {
                         const int ep = ctx->opt_stage_eager_pay;
                         if (ctx->opt_stage_pipeline && eg == 1 && ep == 0) {
-#define STAGE_PIPE(SB_) if (sb == SB_) { auto kern = k_stage<FCT, 2, SB_, true, false, true>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr)); return SDQH_OK; }
+#define STAGE_PIPE(SB_) if (sb == SB_) { auto kern = k_stage<FCT, 2, SB_, true, false, true>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr), pre); return SDQH_OK; }
                             STAGE_PIPE(2) STAGE_PIPE(4)
 #undef STAGE_PIPE
                         }
                         if (ctx->opt_narrow && nrows >= ctx->opt_feature_min_rows && sb == 4 && eg == 1 && ep == 0) {       // first predicate + streamed probe key through their narrow twins
                             const int32_t* nkey = static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(probes[0].key)));
                             const int32_t* npred0 = nkey ? static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(filter->ipred[0].col))) : nullptr;
-                            if (nkey && npred0) { auto kern = k_stage<FCT, 2, 4, true, false, false, true>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows, nkey, npred0); return SDQH_OK; }
+                            if (nkey && npred0) { auto kern = k_stage<FCT, 2, 4, true, false, false, true>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows, nkey, npred0, pre); return SDQH_OK; }
                         }
-#define STAGE_VARIANT(SB_, EG_, EP_) if (sb == SB_ && eg == EG_ && ep == EP_) { auto kern = k_stage<FCT, 2, SB_, EG_ != 0, EP_ != 0>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr)); return SDQH_OK; }
+#define STAGE_VARIANT(SB_, EG_, EP_) if (sb == SB_ && eg == EG_ && ep == EP_) { auto kern = k_stage<FCT, 2, SB_, EG_ != 0, EP_ != 0>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr), pre); return SDQH_OK; }
                         STAGE_VARIANT(2, 1, 1) STAGE_VARIANT(4, 1, 1) STAGE_VARIANT(2, 1, 0) STAGE_VARIANT(4, 1, 0) STAGE_VARIANT(8, 1, 0) STAGE_VARIANT(4, 0, 0)
 #undef STAGE_VARIANT
                     }
                 }
                 if constexpr (FCT::NS == 1) {                                   // string family: one batch per step (few registers, many waves)
-                    if (npayload == 0) { auto kern = k_stage<FCT, 0, 1>; LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr)); return SDQH_OK; }
+                    if (npayload == 0) { auto kern = k_stage<FCT, 0, 1>; LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr), pre); return SDQH_OK; }
                     auto kern = k_stage<FCT, -1, 1>;
-                    LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr));
+                    LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr), pre);
                     return SDQH_OK;
                 } else {
-                if (npayload == 0) { auto kern = k_stage<FCT, 0>; LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr)); return SDQH_OK; }
-                if (npayload == 1) { auto kern = k_stage<FCT, 1>; LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr)); return SDQH_OK; }
-                if (npayload == 2) { auto kern = k_stage<FCT, 2>; LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr)); return SDQH_OK; }
+                if (npayload == 0) { auto kern = k_stage<FCT, 0>; LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr), pre); return SDQH_OK; }
+                if (npayload == 1) { auto kern = k_stage<FCT, 1>; LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr), pre); return SDQH_OK; }
+                if (npayload == 2) { auto kern = k_stage<FCT, 2>; LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr), pre); return SDQH_OK; }
                 auto kern = k_stage<FCT, -1>;
-                LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr));
+                LAUNCH_LDS(ctx, "k_stage", kern, seg_grid, stage_lds, f, pr, tb->stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr), pre);
                 return SDQH_OK;
                 }
             });
@@ -1892,7 +1894,8 @@ int sdqh_scan_compact(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, i
     if (!rc) {
         const unsigned seg_grid = (unsigned)((tmp.stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
         call_begin(ctx);
-        with_stage_filter(f, nprobes, [&](auto FC) { auto kern = k_stage<decltype(FC), -1>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tmp.stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr)); return SDQH_OK; });
+        DevFill nofill_stage; std::memset(&nofill_stage, 0, sizeof(nofill_stage));
+        with_stage_filter(f, nprobes, [&](auto FC) { auto kern = k_stage<decltype(FC), -1>; LAUNCH(ctx, "k_stage", kern, seg_grid, f, pr, tmp.stage, nrows, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr), nofill_stage); return SDQH_OK; });
         LAUNCH(ctx, "k_seg_scan", k_seg_scan, 1, tmp.stage.seg_count, tmp.stage.nseg, seg_off, total);
         LAUNCH(ctx, "k_gather_segments", k_gather_segments, seg_grid, tmp.stage, seg_off, g);
         call_end(ctx);

@@ -1194,7 +1194,8 @@ __device__ __forceinline__ void stage_store(const DevStage& st, int64_t pos, int
 // top of this step, so a step waits one memory round trip less (the build is bound by its chain of dependent round trips,
 // not by bytes: see "Staging" in DESIGN.md §3)
 template <class FC, int NPAY = -1, int SB = STAGE_BATCH, bool EAGER = true, bool EAGER_PAY = false, bool PIPE = false, bool NW = false>
-__global__ __launch_bounds__(TPB) void k_stage(DevFilter f, DevProbes pr, DevStage st, int64_t nrows, const int32_t* __restrict__ nkey = nullptr, const int32_t* __restrict__ npred0 = nullptr) {
+__global__ __launch_bounds__(TPB) void k_stage(DevFilter f, DevProbes pr, DevStage st, int64_t nrows, const int32_t* __restrict__ nkey, const int32_t* __restrict__ npred0, DevFill pre) {
+    if (pre.n) { fill_in_block(pre); __syncthreads(); }                  // a tiny table (grid of one workgroup) does its own fill
     extern __shared__ __align__(16) uint32_t s_dyn[];                   // f.slds * swidth words per wave (string predicate staging)
     __shared__ uint16_t s_queue[TPB / WAVE][WAVE * ROWS_PER_LOAD * SB];   // survivors of a step (row offsets), in row order
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;

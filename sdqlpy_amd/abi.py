@@ -549,14 +549,25 @@ class Context:
         t._keep = (lookups, key, payload)
         return t
 
+    def build_marshalled(self, nrows, flt, larr, nlookups, karr, nkey, parr, npayload, accumulate, keep):
+        """sdqh_build with arrays marshalled once by the caller (engine closures cache them per layout of the looked-up tables)."""
+        h = C.c_void_p()
+        self._check(self.lib.sdqh_build(self.handle, C.c_int64(nrows), C.byref(flt), C.c_int(nlookups), larr, C.c_int(nkey), karr,
+                                        C.c_int(npayload), parr, C.c_int(1 if accumulate else 0), C.byref(h)))
+        self._after_call("build")
+        t = Table(self, h, npayload, accumulate)
+        t._keep = keep
+        return t
+
     def lookup_aggregate(self, nrows, flt, lookups, keys, shape, operands, max_groups=MAX_LOOKUP_GROUPS):
-        larr, karr, oarr = _lookups(lookups), _sources(keys), _sources(operands)
-        nk = len(keys)
+        return self.lookup_aggregate_marshalled(nrows, flt, _lookups(lookups), len(lookups), _sources(keys), len(keys), shape, _sources(operands), max_groups)
+
+    def lookup_aggregate_marshalled(self, nrows, flt, larr, nlookups, karr, nk, shape, oarr, max_groups=MAX_LOOKUP_GROUPS):
         out_keys = np.zeros((max_groups, nk), np.int64)
         out_vals = np.zeros((max_groups, TUPLE_MAX_VALUES), np.float64)
         out_cnt = np.zeros(max_groups, np.int64)
         ng = C.c_int32()
-        self._check(self.lib.sdqh_lookup_aggregate(self.handle, C.c_int64(nrows), C.byref(flt), C.c_int(len(lookups)), larr, C.c_int(nk), karr,
+        self._check(self.lib.sdqh_lookup_aggregate(self.handle, C.c_int64(nrows), C.byref(flt), C.c_int(nlookups), larr, C.c_int(nk), karr,
                                                    C.c_int(shape), oarr, C.c_int(max_groups), _np_ptr(out_keys), _np_ptr(out_vals), _np_ptr(out_cnt), C.byref(ng)))
         self._after_call("lookup_aggregate")
         n = ng.value

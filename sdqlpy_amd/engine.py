@@ -222,6 +222,13 @@ class BuiltTable:
         self.slot_roots = None              # payload index -> the scanned-row columns it is a function of (_share_spec)
         self.slot_plain = {}                # payload index -> (lo, span) when it holds a plain int column / row number
 
+    def layout_sig(self):
+        """What a loop that looks this table up compiles against: field -> slot, slot dtypes, key shape, and WHICH arrays
+        decode its slots (identities).  Closures cache their marshalled call per signature of the tables they look up."""
+        return (tuple(self.val_fields), tuple(str(d) for d in self.payload_dtypes), None if self.key_parts is None else tuple(self.key_parts),
+                tuple(sorted((k, id(v)) for k, v in self.decoders.items())), tuple(sorted((k, id(v)) for k, v in self.field_decoders.items())),
+                id(self.key_decoder), self.table.npayload, self.table.accumulate)
+
     def slot_of(self, field):
         """"key" | payload index of a value field, or None."""
         if field is None:
@@ -573,7 +580,31 @@ def _prepare_general(eng, op, htab, flt, contains_lookups, accumulate_into=()):
         key_names = [fname or (e.name if isinstance(e, Col) else "key%d" % i) for i, (fname, e) in enumerate(key_fields)]
         accumulate = op.out in accumulate_into
 
+        cached = {}
+
         def run_build(env):
+            # The marshalled call (sources, payload slots, decoders) depends on the layouts of the looked-up tables only, and
+            # those are the same run after run: computed once per layout signature; a run then refreshes the table handles.
+            # (At SF 0.002, where the kernels do nothing, Q5 spent 52 of its 177 us per run in this Python.)
+            bts = [env.get(lk.dict_name) for lk in lookups]
+            sig = tuple(bt.layout_sig() if isinstance(bt, BuiltTable) else None for bt in bts)
+            c = cached.get("c")
+            if c is not None and c[0] == sig:
+                _, larr, karr, nk, parr, npay, val_fields, row_dtypes, slot_decoder, field_decoders, slot_roots, slot_plain, kparts, kpd, kdec = c
+                for i, bt in enumerate(bts):
+                    larr[i].table = bt.table.handle
+                table = ctx.build_marshalled(n, flt, larr, len(bts), karr, nk, parr, npay, accumulate, keep=[bt.table for bt in bts])
+                out = BuiltTable(table, key_names[0], key_is_record, val_fields, val_is_record, row_dtypes)
+                out.decoders, out.field_decoders, out.slot_roots, out.slot_plain = slot_decoder, field_decoders, slot_roots, slot_plain
+                out.key_parts, out.key_part_decoders, out.key_decoder = kparts, kpd, kdec
+                return out
+            bt = _run_build_first(env)
+            look, keyspecs, uniq = bt._marshalled
+            cached["c"] = (sig, abi._lookups(look), abi._sources(keyspecs), len(keyspecs), abi._sources(uniq), len(uniq), bt.val_fields, bt.payload_dtypes,
+                           bt.decoders, bt.field_decoders, bt.slot_roots, bt.slot_plain, bt.key_parts, getattr(bt, "key_part_decoders", None), bt.key_decoder)
+            return bt
+
+        def _run_build_first(env):
             # fields that read the same device values share one payload slot: the text fields of one
             # source row are one row reference (they differ in the host array it indexes), a field that
             # is the looked-up table's key is the lookup key itself
@@ -587,7 +618,8 @@ def _prepare_general(eng, op, htab, flt, contains_lookups, accumulate_into=()):
                 slot_idx.append(j)
             if len(uniq) > abi.MAX_PAYLOAD:
                 raise UnsupportedQuery("line %d: more than %d distinct payload values per entry" % (op.lineno, abi.MAX_PAYLOAD))
-            table = ctx.build(n, flt, resolve_lookups(env), [k.spec(op, env, lookups) for k in key_srcs], uniq, accumulate=accumulate)
+            look, keyspecs = resolve_lookups(env), [k.spec(op, env, lookups) for k in key_srcs]
+            table = ctx.build(n, flt, look, keyspecs, uniq, accumulate=accumulate)
             it = iter(slot_idx)
             val_fields = [(fname, "key" if k else next(it)) for (fname, _), k in zip(vfields, is_key)]
             slot_dtype, slot_decoder = {}, {}
@@ -609,6 +641,7 @@ def _prepare_general(eng, op, htab, flt, contains_lookups, accumulate_into=()):
                 bt.key_parts = key_names
                 bt.key_part_decoders = [k.decode_info(op, env, lookups)[0] for k in key_srcs]
             bt.key_decoder = key_srcs[0].decode_info(op, env, lookups)[0] if len(key_srcs) == 1 else None
+            bt._marshalled = (look, keyspecs, uniq)
             return bt
         return run_build
 
@@ -638,20 +671,33 @@ def _prepare_general(eng, op, htab, flt, contains_lookups, accumulate_into=()):
             operand_srcs.append(_Src("lookup", lookup=j, field=slot[3]))
     _link_key_sources(operand_srcs + key_srcs + [k for ks in lookup_keys for k in ks], lookup_keys)
 
+    cached = {}
+
     def run_lookup_aggregate(env):
-        for o in operand_srcs:
-            if o.kind == "lookup" and np.dtype(o.decode_info(op, env, lookups)[1]) != np.float64:
-                raise UnsupportedQuery("line %d: a looked-up value operand must be a float payload" % op.lineno)
+        # (the marshalled call is cached per layout signature of the looked-up tables, as in run_build)
+        bts = [env.get(lk.dict_name) for lk in lookups]
+        sig = tuple(bt.layout_sig() if isinstance(bt, BuiltTable) else None for bt in bts)
+        c = cached.get("c")
+        if c is None or c[0] != sig:
+            for o in operand_srcs:
+                if o.kind == "lookup" and np.dtype(o.decode_info(op, env, lookups)[1]) != np.float64:
+                    raise UnsupportedQuery("line %d: a looked-up value operand must be a float payload" % op.lineno)
+            look = resolve_lookups(env)
+            keyspecs, opspecs = [k.spec(op, env, lookups) for k in key_srcs], [o.spec(op, env, lookups) for o in operand_srcs]
+            c = cached["c"] = (sig, abi._lookups(look), abi._sources(keyspecs), len(keyspecs), abi._sources(opspecs),
+                               [key_srcs[i].decode_info(op, env, lookups) for i in range(len(key_fields))])
+        _, larr, karr, nk, oarr, key_infos = c
+        for i, bt in enumerate(bts):
+            larr[i].table = bt.table.handle
         try:
-            keys, vals, cnts = ctx.lookup_aggregate(n, flt, resolve_lookups(env), [k.spec(op, env, lookups) for k in key_srcs], abi_shape,
-                                                    [o.spec(op, env, lookups) for o in operand_srcs])
+            keys, vals, cnts = ctx.lookup_aggregate_marshalled(n, flt, larr, len(bts), karr, nk, abi_shape, oarr)
         except abi.SdqhError as exc:
             if exc.code == abi.ERR_OVERFLOW:
                 raise UnsupportedQuery("line %d: more than %d groups" % (op.lineno, abi.MAX_LOOKUP_GROUPS))
             raise
         kf = []
         for i, (fname, e) in enumerate(key_fields):
-            decoder, dtype = key_srcs[i].decode_info(op, env, lookups)
+            decoder, dtype = key_infos[i]
             kf.append((fname or "key%d" % i, _decode_column(keys[:, i].copy(), decoder, dtype)))
         vf = _value_arrays(names, count_idx, [vals[:, j] for j in range(vals.shape[1])], cnts)
         return _merge_equal_keys(DictResult(kf, vf, key_is_record, val_is_record))

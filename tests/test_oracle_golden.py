@@ -90,3 +90,30 @@ def test_every_golden_vector_through_row_programs(oracle_lib, golden, golden_mor
         assert helpers.check_all_goldens_as_programs(eng, [golden, golden_more, golden_wide], 0.0, 1e-12, "oracle") >= 76
     finally:
         eng.close()
+
+
+def test_repeated_runs_of_a_prepared_plan_agree_with_the_first(oracle_lib, golden, golden_more, golden_wide):
+    """A plan's second and later runs take cached paths (marshalled build / lookup-aggregate calls per layout signature of
+    the looked-up tables, compiled row programs, resident dictionaries).  Through the decorator API, which keeps a query's
+    plan — helpers.run_query lowers a fresh one per call — every query three times on the same tables, each run against
+    the reference's result."""
+    from sdqlpy_amd import sdql_lib, tpch_queries as Q
+    eng = engine.use_engine(engine.Engine(oracle_lib.context(threads=1)))
+    try:
+        n = 0
+        for gold in (golden, golden_more, golden_wide):
+            for case in gold["cases"]:
+                if case["name"] not in ("tiny", "small"):
+                    continue
+                db = helpers.case_db(case)
+                for q, want in case["results"].items():
+                    for run in range(3):
+                        res = Q.run(q, db)
+                        if q == "q15" and want["rows"]:
+                            res = res.top(1, [("total_revenue", "desc")])
+                        helpers.check_against_golden(res, want, 1e-12 if q == "q10" else 0.0, "%s/%s/run %d" % (case["name"], q, run))
+                    n += 1
+        assert n >= 38
+    finally:
+        engine.reset_default_engine()
+        sdql_lib._state.update(mode=None)

@@ -32,8 +32,9 @@ def main():
                 acc[name] += time.perf_counter() - t0
                 cnt[name] += 1
         setattr(abi.Context, name, timed)
-    for name in ("build", "build_key_set", "hash_build_unique", "hash_probe_aggregate", "lookup_aggregate", "groupby_small", "scan_filter_sum",
-                 "table_compact", "xbuild", "xgroupby", "xscan_sum", "xprobe_aggregate", "xkey_set"):
+    for name in ("build", "build_marshalled", "build_key_set", "hash_build_unique", "hash_probe_aggregate", "lookup_aggregate_marshalled", "groupby_small",
+                 "scan_filter_sum", "scan_probe_sum", "groupby_key", "table_select_keys", "table_share_groups", "table_compact", "table_compact_count",
+                 "table_compact_into_block", "table_topk", "table_entries", "host_block", "xbuild", "xgroupby", "xscan_sum", "xprobe_aggregate", "xkey_set"):
         if hasattr(abi.Context, name):
             wrap(name)
     orig_free = abi.Table.free

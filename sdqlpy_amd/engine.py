@@ -880,7 +880,12 @@ def _prepare_scan(eng, op, htab, accumulate_into, member_only=False, as_table=Fa
     def run(env):
         if state["x"] is None:
             try:
-                return fixed(env)
+                out = fixed(env)
+                if as_table and isinstance(out, DictResult):
+                    # a later loop looks this dictionary up, and the fixed-shape call returned its groups to the host (a small
+                    # group domain: nothing on the device was changed): the row program aggregates into a table instead (Q2)
+                    raise UnsupportedQuery("line %d: the groups came back to the host, a later loop needs them as a table" % op.lineno)
+                return out
             except UnsupportedQuery as first:
                 try:
                     x = xplan.prepare_scan(eng, op, htab, accumulate_into, member_only, as_table)

@@ -105,7 +105,8 @@ DERIVED = {   # table -> {column: (dtype, base columns, function(base arrays...)
                  "c_address": ("U40", ["c_custkey"], lambda k: np.char.add(np.char.add(_pick(_TYPE_2, 40, _mix(k, 7)), " "), (_mix(k, 8) % np.uint64(9973)).astype("<U5")).astype("<U40")),
                  "c_phone": ("U15", ["c_custkey", "c_nationkey"], lambda k, n: np.char.add(np.char.add((n + 10).astype("<U2"), "-"), np.char.zfill((_mix(k, 9) % np.uint64(10 ** 10)).astype("<U10"), 10)).astype("<U15")),
                  "c_comment": ("U117", ["c_custkey"], lambda k: np.char.add(np.char.add(_pick(_INSTRUCT, 117, _mix(k, 10)), " / "), _pick(_SHIPMODES, 117, _mix(k, 11))).astype("<U117"))},
-    "part": {"p_brand": ("U10", ["p_partkey"], lambda k: np.char.add("Brand#", ((_mix(k, 17) % np.uint64(5) + np.uint64(1)) * np.uint64(10) + _mix(k, 18) % np.uint64(5) + np.uint64(1)).astype("<U2")).astype("<U10")),
+    "part": {"p_mfgr": ("U25", ["p_partkey"], lambda k: np.char.add("Manufacturer#", (_mix(k, 17) % np.uint64(5) + np.uint64(1)).astype("<U1")).astype("<U25")),
+             "p_brand": ("U10", ["p_partkey"], lambda k: np.char.add("Brand#", ((_mix(k, 17) % np.uint64(5) + np.uint64(1)) * np.uint64(10) + _mix(k, 18) % np.uint64(5) + np.uint64(1)).astype("<U2")).astype("<U10")),
              "p_container": ("U10", ["p_partkey"], lambda k: _pick(_CONTAINERS, 10, _mix(k, 19))),
              "p_type": ("U25", ["p_partkey"], lambda k: np.char.add(np.char.add(np.char.add(_pick(_TYPE_1, 25, _mix(k, 2)), " "),
                                                                                   np.char.add(_pick(_TYPE_2, 25, _mix(k, 3)), " ")),
@@ -141,6 +142,12 @@ QUERY_COLUMNS = {
            "lineitem": ["l_partkey", "l_suppkey", "l_orderkey", "l_extendedprice", "l_discount"],
            "orders": ["o_orderkey", "o_custkey", "o_orderdate"], "customer": ["c_custkey", "c_nationkey"],
            "nation": ["n_nationkey", "n_name", "n_regionkey"], "region": ["r_regionkey", "r_name"]},
+    "q2": {"part": ["p_partkey", "p_size", "p_type", "p_mfgr"],
+           "supplier": ["s_suppkey", "s_nationkey", "s_acctbal", "s_name", "s_address", "s_phone", "s_comment"],
+           "partsupp": ["ps_partkey", "ps_suppkey", "ps_supplycost"], "nation": ["n_nationkey", "n_regionkey", "n_name"],
+           "region": ["r_regionkey", "r_name"]},
+    "q11": {"partsupp": ["ps_partkey", "ps_suppkey", "ps_supplycost", "ps_availqty"], "supplier": ["s_suppkey", "s_nationkey"],
+            "nation": ["n_nationkey", "n_name"]},
     "q12": {"orders": ["o_orderkey", "o_orderpriority"],
             "lineitem": ["l_orderkey", "l_shipmode", "l_shipdate", "l_commitdate", "l_receiptdate"]},
     "q13": {"customer": ["c_custkey"], "orders": ["o_custkey", "o_comment"]},

@@ -214,6 +214,48 @@ def q10(nation, customer, orders, lineitem):
 # values, text functions, conditions on looked-up fields and on aggregated values.
 # =================================================================================================
 
+# ---- q2: the European supplier whose offer for a size-15 brass part equals the part's total over European suppliers ------
+# (the reference SUMS the supply costs of a part — its "## Min" stays a comment — so the offer that "equals the minimum" is, in
+#  effect, the only European offer of the part; the formulation keeps that meaning.  The reference builds the eight-field result
+#  record in the partsupp loop; here that loop yields the (part, supplier) pairs and the fields are looked up per pair.)
+@sdql_compile({"region": region_type, "nation": nation_type, "supplier": supplier_type, "part": part_type, "partsupp": partsupp_type})
+def q2(region, nation, supplier, part, partsupp):
+    europe = region.sum(lambda r: {unique(r[0].r_regionkey): True} if r[0].r_name == "EUROPE" else None)
+    european_nations = nation.sum(lambda n: {unique(n[0].n_nationkey): n[0].n_name} if europe[n[0].n_regionkey] != None else None)      # noqa: E711
+    european_suppliers = supplier.sum(
+        lambda s: {unique(s[0].s_suppkey): record({"s_acctbal": s[0].s_acctbal, "s_name": s[0].s_name, "n_name": european_nations[s[0].s_nationkey],
+                                                   "s_address": s[0].s_address, "s_phone": s[0].s_phone, "s_comment": s[0].s_comment})}
+        if european_nations[s[0].s_nationkey] != None else None)      # noqa: E711
+    brass_parts = part.sum(lambda p: {unique(p[0].p_partkey): p[0].p_mfgr} if p[0].p_size == 15 and endsWith(p[0].p_type, "BRASS") else None)
+    european_cost = partsupp.sum(
+        lambda ps: {ps[0].ps_partkey: ps[0].ps_supplycost}
+        if brass_parts[ps[0].ps_partkey] != None and european_suppliers[ps[0].ps_suppkey] != None else None)      # noqa: E711
+    offers = partsupp.sum(
+        lambda ps: {record({"p_partkey": ps[0].ps_partkey, "s_suppkey": ps[0].ps_suppkey}): 1}
+        if european_cost[ps[0].ps_partkey] != None and european_cost[ps[0].ps_partkey] == ps[0].ps_supplycost      # noqa: E711
+        and european_suppliers[ps[0].ps_suppkey] != None else None)      # noqa: E711
+    best = offers.sum(lambda g: {unique(record({
+        "s_acctbal": european_suppliers[g[0].s_suppkey].s_acctbal, "s_name": european_suppliers[g[0].s_suppkey].s_name,
+        "n_name": european_suppliers[g[0].s_suppkey].n_name, "p_partkey": g[0].p_partkey, "p_mfgr": brass_parts[g[0].p_partkey],
+        "s_address": european_suppliers[g[0].s_suppkey].s_address, "s_phone": european_suppliers[g[0].s_suppkey].s_phone,
+        "s_comment": european_suppliers[g[0].s_suppkey].s_comment})): True})
+    return best
+
+
+# ---- q11: important stock of one nation: parts whose stock value exceeds a ten-thousandth of the nation's total -----------
+# (the reference sums a record of a scalar and a dictionary in one loop; here the total and the per-part values are two sums)
+@sdql_compile({"nation": nation_type, "supplier": supplier_type, "partsupp": partsupp_type})
+def q11(nation, supplier, partsupp):
+    germany = nation.sum(lambda n: {unique(n[0].n_nationkey): True} if n[0].n_name == "GERMANY" else None)
+    german_suppliers = supplier.sum(lambda s: {unique(s[0].s_suppkey): True} if germany[s[0].s_nationkey] != None else None)      # noqa: E711
+    threshold = partsupp.sum(
+        lambda ps: (ps[0].ps_supplycost * ps[0].ps_availqty) * 0.0001 if german_suppliers[ps[0].ps_suppkey] != None else None)      # noqa: E711
+    value_per_part = partsupp.sum(
+        lambda ps: {ps[0].ps_partkey: ps[0].ps_supplycost * ps[0].ps_availqty} if german_suppliers[ps[0].ps_suppkey] != None else None)      # noqa: E711
+    important = value_per_part.sum(lambda g: {unique(record({"ps_partkey": g[0], "value": g[1]})): True} if g[1] > threshold else None)
+    return important
+
+
 # ---- q7: volume shipping between two nations, per year --------------------------------------------------
 @sdql_compile({"nation": nation_type, "supplier": supplier_type, "customer": customer_type, "orders": order_type, "lineitem": lineitem_type})
 def q7(nation, supplier, customer, orders, lineitem):
@@ -425,7 +467,7 @@ def q22(orders, customer):
 
 
 QUERIES = {"q6": q6, "q1": q1, "q3": q3, "q5": q5, "q9": q9, "q4": q4, "q14": q14, "q18": q18, "q10": q10,
-           "q7": q7, "q8": q8, "q12": q12, "q13": q13, "q15": q15, "q16": q16, "q17": q17, "q19": q19, "q20": q20, "q22": q22}
+           "q2": q2, "q11": q11, "q7": q7, "q8": q8, "q12": q12, "q13": q13, "q15": q15, "q16": q16, "q17": q17, "q19": q19, "q20": q20, "q22": q22}
 
 _TABLE_OF_PARAM = {"lineitem": "lineitem", "orders": "orders", "customer": "customer", "supplier": "supplier", "part": "part",
                    "partsupp": "partsupp", "nation": "nation", "region": "region"}
@@ -464,6 +506,8 @@ TPCH_ORDER = {
     "q10": (20, [("revenue", "desc")]),
     "q7": (100, [("supp_nation", "asc"), ("cust_nation", "asc"), ("l_year", "asc")]),
     "q8": (100, [("o_year", "asc")]),
+    "q2": (100, [("s_acctbal", "desc"), ("n_name", "asc"), ("s_name", "asc"), ("p_partkey", "asc")]),
+    "q11": (100, [("value", "desc")]),
     "q12": (100, [("l_shipmode", "asc")]),
     "q13": (100, [("custdist", "desc"), ("c_count", "desc")]),
     "q16": (100, [("supplier_cnt", "desc"), ("p_brand", "asc"), ("p_type", "asc"), ("p_size", "asc")]),

@@ -50,10 +50,12 @@ QUERY_TABLES = {   # positional argument order of each reference query (test/tes
 }
 # SURVEY.md §8f.3, second step: queries that need the open expression vocabulary (test/test_all.py:299-367, 371-427,
 # 656-691, 720-756, 831-870, 917-981, 985-1028, 1113-1183).  Argument order = the reference's decorators.
-WIDE_QUERIES = ["q7", "q8", "q12", "q13", "q15", "q16", "q17", "q19", "q20", "q22"]
+WIDE_QUERIES = ["q2", "q7", "q8", "q11", "q12", "q13", "q15", "q16", "q17", "q19", "q20", "q22"]
 QUERY_TABLES.update({
     "q7": ["supplier", "lineitem", "orders", "customer", "nation"],
     "q8": ["part", "supplier", "lineitem", "orders", "customer", "nation", "region"],
+    "q2": ["part", "supplier", "partsupp", "nation", "region"],
+    "q11": ["partsupp", "supplier", "nation"],
     "q12": ["orders", "lineitem"],
     "q13": ["customer", "orders"],
     "q16": ["partsupp", "part", "supplier"],

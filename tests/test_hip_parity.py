@@ -72,7 +72,7 @@ def test_decorated_queries_through_public_api(golden, golden_more, golden_wide):
                         res = res.top(1, [("total_revenue", "desc")])
                     helpers.check_against_golden(res, want, REL, "%s/%s/api run %d" % (case["name"], q, run))
                 n += 1
-    assert n >= 38
+    assert n >= 40
 
 
 @pytest.mark.parametrize("sf", [1.0])
@@ -285,10 +285,10 @@ def test_full_size_q9_and_topk_sf10(hip_engine):
 
 
 def test_open_vocabulary_queries_against_the_reference(hip_engine, golden_wide, oracle_engine):
-    """q7, q8, q12, q13, q15, q16, q17, q19, q20, q22 through kernels specialised on their own conditions and values
+    """q2, q7, q8, q11, q12, q13, q15, q16, q17, q19, q20, q22 through kernels specialised on their own conditions and values
     (row programs), against the reference's results; then at SF 1 against the CPU implementation."""
-    assert helpers.check_wide_goldens(hip_engine, golden_wide, REL, "hip") >= 30
-    qs = ("q7", "q8", "q12", "q13", "q15", "q16", "q17", "q19", "q20", "q22")
+    assert helpers.check_wide_goldens(hip_engine, golden_wide, REL, "hip") >= 36
+    qs = ("q2", "q7", "q8", "q11", "q12", "q13", "q15", "q16", "q17", "q19", "q20", "q22")
     db = tpch.generate(1.0, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
     for q in qs:
         got, want = helpers.run_query(hip_engine, q, db), helpers.run_query(oracle_engine, q, db)
@@ -304,7 +304,7 @@ def test_open_vocabulary_queries_against_the_reference(hip_engine, golden_wide, 
 def test_every_golden_vector_through_specialised_kernels(hip_engine, golden, golden_more, golden_wide):
     """All reference results again with every table loop forced through a run-time specialised kernel
     (no ahead-of-time kernel shape): the general path must agree with the tuned one on its home turf."""
-    assert helpers.check_all_goldens_as_programs(hip_engine, [golden, golden_more, golden_wide], REL, 1e-10, "hip") >= 76
+    assert helpers.check_all_goldens_as_programs(hip_engine, [golden, golden_more, golden_wide], REL, 1e-10, "hip") >= 82
     hip_engine.clear()
 
 
@@ -364,7 +364,7 @@ def test_large_scan_instances_on_small_and_ragged_inputs(hip_engine, oracle_engi
         hip_engine.ctx.set_option(k, v)
     hip_engine.clear()
     try:
-        assert helpers.check_all_goldens(hip_engine, [golden, golden_more, golden_wide], REL, 1e-10, "hip/large-scan instances") >= 76
+        assert helpers.check_all_goldens(hip_engine, [golden, golden_more, golden_wide], REL, 1e-10, "hip/large-scan instances") >= 82
         hip_engine.clear()
         base = tpch.generate(0.002, tables=sorted(tpch.columns_for(SUPPORTED)), columns=tpch.columns_for(SUPPORTED))
         li = base["lineitem"].getContainer()

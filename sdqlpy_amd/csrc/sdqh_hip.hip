@@ -280,13 +280,14 @@ bool column_is_increasing(sdqh_ctx* ctx, sdqh_column* c) {
 const void* ensure_narrow(sdqh_ctx* ctx, sdqh_column* c) {
     if (c->narrow_state >= 0) return c->narrow;
     c->narrow_state = 0;
-    if ((c->dtype == SDQH_STR && c->width != 1) || c->nrows < 2) return nullptr;          // text: string(1) only (one byte per code unit)
-    int32_t* twin = static_cast<int32_t*>(pool_alloc(ctx, (size_t)c->nrows * 4 + 64));
+    if (c->nrows < 2) return nullptr;
+    const int64_t units = c->dtype == SDQH_STR ? c->nrows * c->width : c->nrows;         // text: one byte per code unit
+    int32_t* twin = static_cast<int32_t*>(pool_alloc(ctx, c->dtype == SDQH_STR ? (size_t)units + 64 : (size_t)c->nrows * 4 + 64));
     int* flag = static_cast<int*>(pool_alloc(ctx, 64));
     bool ok = twin && flag && hipMemsetAsync(flag, 0, 4, ctx->stream) == hipSuccess;
     if (ok) {
-        const unsigned grid = (unsigned)std::min<int64_t>((c->nrows + TPB - 1) / TPB, (int64_t)ctx->num_cu * 8);
-        if (c->dtype == SDQH_STR) hipLaunchKernelGGL(k_narrow_str1, dim3(grid), dim3(TPB), 0, ctx->stream, static_cast<const uint32_t*>(c->data), c->nrows, reinterpret_cast<uint8_t*>(twin), flag);
+        const unsigned grid = (unsigned)std::min<int64_t>((units + TPB - 1) / TPB, (int64_t)ctx->num_cu * 8);
+        if (c->dtype == SDQH_STR) hipLaunchKernelGGL(k_narrow_str1, dim3(grid), dim3(TPB), 0, ctx->stream, static_cast<const uint32_t*>(c->data), units, reinterpret_cast<uint8_t*>(twin), flag);
         else if (c->dtype == SDQH_I64) hipLaunchKernelGGL(k_narrow_i64, dim3(grid), dim3(TPB), 0, ctx->stream, static_cast<const int64_t*>(c->data), c->nrows, twin, flag);
         else hipLaunchKernelGGL(k_narrow_f64, dim3(grid), dim3(TPB), 0, ctx->stream, static_cast<const double*>(c->data), c->nrows, twin, flag);
         int* host = static_cast<int*>(ctx->result_host);
@@ -297,6 +298,15 @@ const void* ensure_narrow(sdqh_ctx* ctx, sdqh_column* c) {
     if (ok) { c->narrow = twin; c->narrow_state = 1; }
     else if (twin) pool_free(ctx, twin);
     return c->narrow;
+}
+// The LDS-staged string predicate through the text column's byte twin: 64 rows per wave and round (any width: 64 rows of bytes
+// start on a 16-byte boundary), a quarter of the bytes streamed.  Returns the words of dynamic LDS per wave, 0 when there is no twin.
+static bool stage_text_twin(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, DevFilter* f) {
+    if (!ctx->opt_narrow || !f->ns || nrows < ctx->opt_feature_min_rows || f->swidth < 1 || f->swidth > 128) return false;
+    const void* twin = ensure_narrow(ctx, const_cast<sdqh_column*>(filter->spred[0].col));
+    if (!twin) return false;
+    f->sc8 = static_cast<const uint8_t*>(twin); f->slds = 64;
+    return true;
 }
 // Swap every streamed column of a scan (integer / double predicates, tuple operands) for its twin; false (nothing changed)
 // unless ALL of them have one.  Only for the instances that read nothing else by row (no string / column-pair predicates).
@@ -732,7 +742,7 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
                         DevFilter nf = f; DevTuple nt = t; DevGroupKeys ngk = gk;
                         bool narrow = narrow_streams(ctx, nrows, filter, tuple, &nf, &nt);
                         for (int k = 0; k < nkeys && narrow; ++k) {                 // the two string(1) keys through their one-byte twins
-                            ngk.col[k] = ensure_narrow(ctx, const_cast<sdqh_column*>(keys[k]));
+                            ngk.col[k] = keys[k]->dtype == SDQH_STR && keys[k]->width != 1 ? nullptr : ensure_narrow(ctx, const_cast<sdqh_column*>(keys[k]));
                             narrow = ngk.col[k] != nullptr;
                         }
                         auto launch = [&](auto kern, const DevFilter& lf, const DevTuple& lt) {
@@ -1026,8 +1036,9 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
             if (seg_grid == 1 && ctx->opt_fuse_small && fl.most <= ((uint64_t)1 << 20)) pre = fl.f; else launch_fill(ctx, fl);      // a tiny table: the staging kernel does its own fill
             // string predicate: fields staged through LDS, 64 rows per wave at a time (up to 64 KB per workgroup)
             const unsigned str_rows = (f.ns && f.swidth > 0 && f.swidth <= 128) ? (f.swidth <= 64 ? 64u : 32u) : 0u;
-            const size_t stage_lds = (size_t)(TPB / WAVE) * str_rows * (size_t)f.swidth * 4;       // at most 64 KB per workgroup
             f.slds = str_rows;
+            stage_text_twin(ctx, nrows, filter, &f);
+            const size_t stage_lds = (size_t)(TPB / WAVE) * str_lds_words(f) * 4 + (f.sc8 ? STR_LDS_SLACK : 0);       // at most 64 KB per workgroup
             with_stage_filter(f, nprobes, [&](auto FC) {
                 using FCT = decltype(FC);
                 if constexpr (std::is_same_v<FCT, FCfg<1, 0, 0, 1>>) {          // the tuned instance family (orders-like build side)
@@ -1107,8 +1118,9 @@ int sdqh_build_key_set(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
         // 32 rows per round from 33 code units up: 64 rows of Q9's p_name are 14 KiB per wave, two workgroups per CU (0.110 -> 0.101 ms)
         unsigned str_rows = (f.ns && f.swidth > 0 && f.swidth <= 128) ? (f.swidth <= 32 ? 64u : 32u) : 0u;
         if (str_rows && ctx->opt_str_rows) str_rows = (unsigned)ctx->opt_str_rows;
-        const size_t lds = (size_t)(TPB / WAVE) * str_rows * (size_t)f.swidth * 4;
         f.slds = str_rows;
+        stage_text_twin(ctx, nrows, filter, &f);
+        const size_t lds = (size_t)(TPB / WAVE) * str_lds_words(f) * 4 + (f.sc8 ? STR_LDS_SLACK : 0);
         with_stage_filter(f, nprobes, [&](auto FC) {
             auto kern = k_key_set<decltype(FC)>;
             LAUNCH_LDS(ctx, "k_key_set", kern, grid, lds, f, pr, kc, nrows, lo, hi, tb->bm, pre);

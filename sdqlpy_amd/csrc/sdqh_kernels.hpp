@@ -60,6 +60,7 @@ struct DevFilter {
     const int64_t* ic[SDQH_MAX_IPRED]; int64_t ilo[SDQH_MAX_IPRED], ihi[SDQH_MAX_IPRED];
     const double* fc[SDQH_MAX_FPRED]; double flo[SDQH_MAX_FPRED], fhi[SDQH_MAX_FPRED];
     const uint32_t* sc; int32_t swidth, slen;
+    const uint8_t* sc8;       // the text column's one-byte-per-code-unit twin (null: none); the LDS-staged predicate reads it instead of sc
     uint32_t sval[SDQH_MAX_STR_CONST];
     // ranges on tuple operand slots (an f-predicate whose column is also a value operand is
     // checked on the already-loaded operand instead of being loaded twice)
@@ -313,13 +314,15 @@ __device__ __forceinline__ bool str_contains(const uint32_t* __restrict__ s, int
 }
 // the string predicate of a filter: mode 0 `==`, 1 `!=`, 2 substring
 // startsWith (reference include/varchar.h:99-110): every unit of the needle matches and no NUL comes first
-__device__ __forceinline__ bool str_prefix(const uint32_t* s, int width, const uint32_t* val, int len) {
+template <class T>
+__device__ __forceinline__ bool str_prefix(const T* s, int width, const uint32_t* val, int len) {
     if (len > width) return false;
     for (int k = 0; k < len; ++k) if (s[k] == 0u || s[k] != val[k]) return false;
     return true;
 }
 // endsWith: the text (field up to its first NUL) ends with the needle
-__device__ __forceinline__ bool str_suffix(const uint32_t* s, int width, const uint32_t* val, int len) {
+template <class T>
+__device__ __forceinline__ bool str_suffix(const T* s, int width, const uint32_t* val, int len) {
     int n = 0;
     while (n < width && s[n] != 0u) ++n;
     if (len > n) return false;
@@ -353,18 +356,20 @@ __device__ __forceinline__ bool col_preds(const DevFilter& f, int64_t r) {
 // Branch-free over the whole fixed width, so every LDS read of a field is independent of the
 // comparisons (the per-lane early-exit loops above chain one read latency per character).
 // equality: first `len` units equal, the rest zero.
-__device__ __forceinline__ bool lds_str_equal(const uint32_t* s, int width, const uint32_t* val, int len) {
+template <class T>
+__device__ __forceinline__ bool lds_str_equal(const T* s, int width, const uint32_t* val, int len) {
     if (len > width) return false;
     uint32_t diff = 0;
 #pragma unroll 4
-    for (int k = 0; k < width; ++k) diff |= s[k] ^ (k < len ? val[k] : 0u);
+    for (int k = 0; k < width; ++k) diff |= (uint32_t)s[k] ^ (k < len ? val[k] : 0u);
     return diff == 0;
 }
 // substring: one pass over the field builds two position masks per 32 units — "equals the first
 // unit of the needle" and "is NUL" — with no branch and no dependence between the LDS reads; only
 // the (few) first-unit hits before the first NUL are then verified.  wcsstr semantics: the field
 // ends at its first NUL (reference include/varchar.h:84-89).
-__device__ __forceinline__ bool lds_str_contains(const uint32_t* s, int width, const uint32_t* val, int len) {
+template <class T>
+__device__ __forceinline__ bool lds_str_contains(const T* s, int width, const uint32_t* val, int len) {
     const uint32_t v0 = val[0];
     bool found = false, ended = false;
     for (int w0 = 0; w0 < width && !ended && !found; w0 += 32) {          // per-lane state, usually one or two rounds
@@ -392,7 +397,8 @@ __device__ __forceinline__ bool lds_str_contains(const uint32_t* s, int width, c
 }
 // VarChar::firstIndex (reference include/varchar.h:91-97) on a field in LDS: position of the first occurrence of the needle
 // in the text before the first NUL, or -1.  The same 32-position rounds as lds_str_contains.
-__device__ __forceinline__ int64_t lds_first_index(const uint32_t* s, int width, const uint32_t* val, int len) {
+template <class T>
+__device__ __forceinline__ int64_t lds_first_index(const T* s, int width, const uint32_t* val, int len) {
     if (len == 0) return 0;
     const uint32_t v0 = val[0];
     bool ended = false;
@@ -419,7 +425,8 @@ __device__ __forceinline__ int64_t lds_first_index(const uint32_t* s, int width,
     }
     return -1;
 }
-__device__ __forceinline__ bool lds_str_pred(const uint32_t* s, int width, const uint32_t* val, int len, int mode) {
+template <class T>
+__device__ __forceinline__ bool lds_str_pred(const T* s, int width, const uint32_t* val, int len, int mode) {
     if (mode == 2) {
         if (len == 0) return true;
         return lds_str_contains(s, width, val, len);
@@ -428,16 +435,70 @@ __device__ __forceinline__ bool lds_str_pred(const uint32_t* s, int width, const
     if (mode == 4) return str_suffix(s, width, val, len);
     return lds_str_equal(s, width, val, len) != (mode != 0);
 }
+// ---- the same scans on a byte twin in LDS ---------------------------------------------------------------
+// A field of one-byte units starts at any byte offset of the staging region; it is read as aligned 32-bit words (one LDS read
+// per four units), shifted into place, and the two position masks come from exact per-byte zero tests on whole words.
+__device__ __forceinline__ uint32_t swar_zero_bytes(uint32_t x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; }   // 0x80 where a byte is 0
+__device__ __forceinline__ uint32_t swar_pack4(uint32_t z) { return (((z >> 7) * 0x00204081u) >> 21) & 0xFu; }                      // the four flags as bits 0..3
+// units [0, nk) (nk <= 32) of the field at byte offset `off` of `region`: first = "equals v0", nul = "is NUL" (bits >= nk clear).
+// Reads up to two words past the field (the neighbour's bytes, masked off; the region has that slack at its end).
+__device__ __forceinline__ void lds8_scan(const uint32_t* region, int off, int nk, uint32_t v0x4, uint32_t& first, uint32_t& nul) {
+    const uint32_t a8 = (uint32_t)(off & 3) * 8u;
+    const uint32_t* wp = region + (off >> 2);
+    const int nw = (nk + 3) >> 2;
+    uint32_t w[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) w[i] = i <= nw ? wp[i] : 0u;
+    first = 0; nul = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t x = __builtin_amdgcn_alignbit(w[i + 1], w[i], a8);
+        nul |= swar_pack4(swar_zero_bytes(x)) << (4 * i);
+        first |= swar_pack4(swar_zero_bytes(x ^ v0x4)) << (4 * i);
+    }
+    const uint32_t m = nk < 32 ? (1u << nk) - 1u : ~0u;
+    first &= m; nul &= m;
+}
+// position of the first occurrence of the needle (len >= 1) in the text before the first NUL, or -1: VarChar::firstIndex /
+// contains on the byte twin (a needle with a unit above 0xFF cannot occur in a column that has a byte twin)
+__device__ __forceinline__ int lds8_find(const uint32_t* region, int off, int width, const uint32_t* val, int len) {
+    uint32_t wide = 0;
+    for (int k = 0; k < len; ++k) wide |= val[k];
+    if (wide > 0xFFu) return -1;
+    const uint8_t* s = reinterpret_cast<const uint8_t*>(region) + off;
+    const uint32_t v0x4 = val[0] * 0x01010101u;
+    bool ended = false;
+    for (int w0 = 0; w0 < width && !ended; w0 += 32) {
+        uint32_t first, nul;
+        const int nk = min(32, width - w0);
+        lds8_scan(region, off + w0, nk, v0x4, first, nul);
+        nul |= nk < 32 ? (1u << nk) : 0u;                                  // the field ends with its width
+        if (nul) { first &= (nul & (0u - nul)) - 1u; ended = true; }
+        while (first) {
+            const int pos = w0 + __builtin_ctz(first);
+            first &= first - 1u;
+            if (pos + len > width) return -1;
+            int k = 1;
+            while (k < len && s[pos + k] == val[k]) ++k;
+            if (k == len) return pos;
+        }
+    }
+    return -1;
+}
 // The string predicate over `rows` (64 or 32) consecutive rows (row0 + lane), staged through LDS:
 // the wave copies the fixed-width fields with coalesced 16-byte loads (all in flight before the
 // first LDS store), then lane i < rows scans field i out of LDS.  Per-lane character loops straight
 // from global memory touch 64 different cache lines per instruction.  Returns the ballot of rows
 // that pass.  row0 is a multiple of 32, so the block is 16-byte aligned; rows * swidth <= 4096.
-__device__ __forceinline__ uint64_t str_stage_mask(const DevFilter& f, uint32_t* __restrict__ s_str, int64_t row0, int rows) {
+// Only the rows below nrows are copied (the last vector may run up to 12 bytes into the column's slack).
+// With a byte twin (f.sc8; the launch stages 64 rows, row0 a multiple of 64) the same fields are a quarter of the bytes.
+__device__ __forceinline__ uint64_t str_stage_mask(const DevFilter& f, uint32_t* __restrict__ s_str, int64_t row0, int rows, int64_t nrows) {
     const int lane = lane_id();
-    const int nvec = (rows * f.swidth) / 4;                               // a whole number of 16-byte vectors, <= 1024
+    const int lim = (int)(nrows - row0 < (int64_t)rows ? nrows - row0 : (int64_t)rows);
     using V4 = uint32_t __attribute__((ext_vector_type(4)));
-    const V4* __restrict__ src = reinterpret_cast<const V4*>(f.sc + row0 * f.swidth);
+    const bool bytes = f.sc8 != nullptr;
+    const int nvec = bytes ? (lim * f.swidth + 15) / 16 : (lim * f.swidth + 3) / 4;      // 16-byte vectors, <= 1024
+    const V4* __restrict__ src = bytes ? reinterpret_cast<const V4*>(f.sc8 + row0 * f.swidth) : reinterpret_cast<const V4*>(f.sc + row0 * f.swidth);
     V4* dst = reinterpret_cast<V4*>(s_str);
     __builtin_amdgcn_wave_barrier();
     for (int i0 = 0; i0 < nvec; i0 += 8 * WAVE) {
@@ -448,10 +509,19 @@ __device__ __forceinline__ uint64_t str_stage_mask(const DevFilter& f, uint32_t*
         for (int u = 0; u < 8; ++u) { const int i = i0 + u * WAVE + lane; if (i < nvec) dst[i] = t[u]; }
     }
     __builtin_amdgcn_wave_barrier();
-    const bool ok = lane < rows && lds_str_pred(s_str + lane * f.swidth, f.swidth, f.sval, f.slen, f.sneg);
+    bool ok = lane < lim;
+    if (ok) {
+        if (!bytes) ok = lds_str_pred(s_str + lane * f.swidth, f.swidth, f.sval, f.slen, f.sneg);
+        else if (f.sneg == 2) ok = f.slen == 0 || lds8_find(s_str, lane * f.swidth, f.swidth, f.sval, f.slen) >= 0;
+        else ok = lds_str_pred(reinterpret_cast<const uint8_t*>(s_str) + lane * f.swidth, f.swidth, f.sval, f.slen, f.sneg);
+    }
     __builtin_amdgcn_wave_barrier();
     return __ballot(ok);
 }
+
+// 32-bit words of staging LDS per wave: slds rows of 4-byte units, or 64 rows of the byte twin
+__host__ __device__ __forceinline__ size_t str_lds_words(const DevFilter& f) { return f.sc8 ? (size_t)16 * f.swidth : (size_t)f.slds * f.swidth; }
+constexpr size_t STR_LDS_SLACK = 16;      // bytes after the last wave's region (lds8_scan reads whole words past a field)
 
 __device__ __forceinline__ int64_t table_find(const DevTable& t, int64_t key, uint64_t cap_mask);
 
@@ -1128,13 +1198,13 @@ __device__ __forceinline__ void pass_pairs(const DevFilter& f, const DevProbes& 
                 const uint64_t live = __ballot(p[j][0] | p[j][1]);
                 uint64_t m[2] = {0, 0};
                 if (f.slds == 64) {
-                    if (live & 0x00000000FFFFFFFFull) m[0] = str_stage_mask(f, s_str, base, 64);
-                    if (live & 0xFFFFFFFF00000000ull) m[1] = str_stage_mask(f, s_str, base + 64, 64);
+                    if (live & 0x00000000FFFFFFFFull) m[0] = str_stage_mask(f, s_str, base, 64, nrows);
+                    if (live & 0xFFFFFFFF00000000ull) m[1] = str_stage_mask(f, s_str, base + 64, 64, nrows);
                 } else {                                                  // wide fields: 32 rows per staging keeps the LDS footprint of a wave small
-                    if (live & 0x000000000000FFFFull) m[0] = str_stage_mask(f, s_str, base, 32);
-                    if (live & 0x00000000FFFF0000ull) m[0] |= str_stage_mask(f, s_str, base + 32, 32) << 32;
-                    if (live & 0x0000FFFF00000000ull) m[1] = str_stage_mask(f, s_str, base + 64, 32);
-                    if (live & 0xFFFF000000000000ull) m[1] |= str_stage_mask(f, s_str, base + 96, 32) << 32;
+                    if (live & 0x000000000000FFFFull) m[0] = str_stage_mask(f, s_str, base, 32, nrows);
+                    if (live & 0x00000000FFFF0000ull) m[0] |= str_stage_mask(f, s_str, base + 32, 32, nrows) << 32;
+                    if (live & 0x0000FFFF00000000ull) m[1] = str_stage_mask(f, s_str, base + 64, 32, nrows);
+                    if (live & 0xFFFF000000000000ull) m[1] |= str_stage_mask(f, s_str, base + 96, 32, nrows) << 32;
                 }
                 const uint64_t mine = half ? m[1] : m[0];
                 p[j][0] = p[j][0] && ((mine >> sh) & 1ull);
@@ -1201,7 +1271,7 @@ __global__ __launch_bounds__(TPB) void k_stage(DevFilter f, DevProbes pr, DevSta
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
     if (seg >= st.nseg) return;
     uint16_t* q_off = s_queue[threadIdx.x / WAVE];
-    uint32_t* s_str = (cfg_ns<FC>(f.ns) && f.slds) ? s_dyn + (size_t)(threadIdx.x / WAVE) * f.slds * f.swidth : nullptr;
+    uint32_t* s_str = (cfg_ns<FC>(f.ns) && f.slds) ? s_dyn + (size_t)(threadIdx.x / WAVE) * str_lds_words(f) : nullptr;
     uint64_t cap_masks[SDQH_MAX_PROBE] = {0, 0};
 #pragma unroll
     for (int i = 0; i < SDQH_MAX_PROBE; ++i) if (i < cfg_np<FC>(pr.n) && pr.table[i].hdr && !table_is_direct(pr.table[i]) && !pr.table[i].bitmap_only) cap_masks[i] = pr.table[i].hdr->cap_mask;
@@ -1902,7 +1972,7 @@ __global__ __launch_bounds__(TPB) void k_key_set(DevFilter f, DevProbes pr, cons
     if (pre.n) { fill_in_block(pre); __syncthreads(); }                  // a tiny table (grid of one workgroup) clears its own bitmap
     constexpr int PU = 2, TILE = TPB * ROWS_PER_LOAD * PU;
     extern __shared__ __align__(16) uint32_t s_dyn[];                   // f.slds * swidth words per wave (string predicate staging)
-    uint32_t* s_str = (cfg_ns<FC>(f.ns) && f.slds) ? s_dyn + (size_t)(threadIdx.x / WAVE) * f.slds * f.swidth : nullptr;
+    uint32_t* s_str = (cfg_ns<FC>(f.ns) && f.slds) ? s_dyn + (size_t)(threadIdx.x / WAVE) * str_lds_words(f) : nullptr;
     uint64_t cap_masks[SDQH_MAX_PROBE] = {0, 0};
 #pragma unroll
     for (int i = 0; i < SDQH_MAX_PROBE; ++i) if (i < cfg_np<FC>(pr.n) && pr.table[i].hdr && !table_is_direct(pr.table[i]) && !pr.table[i].bitmap_only) cap_masks[i] = pr.table[i].hdr->cap_mask;

@@ -189,6 +189,14 @@ int analyse(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* p, int max_vals, b
             if (!(x->direct || scol[(size_t)c]) || x->cols[c]->dtype == SDQH_STR) continue;
             if (column_narrow(ctx, const_cast<sdqh_column*>(x->cols[c]))) x->narrow_mask |= 1u << c;
         }
+        // text columns a queue program scans (staged in LDS by the drain): through their byte twin
+        if (!x->direct) for (int k = 0; k < x->p->nops; ++k) {
+            const int code = x->p->ops[k].code;
+            if (code != SDQH_X_STR && code != SDQH_X_STRIDX && code != SDQH_X_CHAR) continue;
+            const int c = x->col_of[k];
+            if (c < 0 || x->cols[c]->dtype != SDQH_STR || x->cols[c]->width > 1024 || ((x->narrow_mask >> c) & 1u)) continue;
+            if (column_narrow(ctx, const_cast<sdqh_column*>(x->cols[c]))) x->narrow_mask |= 1u << c;
+        }
     }
     return SDQH_OK;
 }
@@ -201,8 +209,13 @@ struct Gen {
     std::vector<int> sres_of;                  // text operation -> its slot in the drain's staged results (-1: reads the column in global memory)
     explicit Gen(const XInfo& xi) : x(xi), done((size_t)xi.p->nops, 0), slot_of((size_t)SDQH_MAX_XCOLS, -1), sres_of((size_t)xi.p->nops, -1) {}
     // the text operation itself, on the field at `field` ("pointer, width"); lds: the field was staged in LDS
-    std::string text_op(int k, const std::string& field, bool lds = false) const {
+    std::string text_op(int k, const std::string& field, bool lds = false, bool bytes = false) const {
         const sdqh_xop& o = x.p->ops[k];
+        if (bytes) {                                                        // field = "region, off, width": the byte twin staged in LDS
+            if (o.code == SDQH_X_STR) return "x8_str_pred(" + field + ", a.spool + " + std::to_string(x.str_off[k]) + ", " + std::to_string(o.slen) + ", " + std::to_string(o.aux) + ")";
+            if (o.code == SDQH_X_STRIDX) return "x8_first_index(" + field + ", a.spool + " + std::to_string(x.str_off[k]) + ", " + std::to_string(o.slen) + ")";
+            return "x8_char(" + field + ", " + std::to_string(o.aux) + ")";
+        }
         if (lds && o.code == SDQH_X_STR) return "lds_str_pred(" + field + ", a.spool + " + std::to_string(x.str_off[k]) + ", " + std::to_string(o.slen) + ", " + std::to_string(o.aux) + ")";
         if (lds && o.code == SDQH_X_STRIDX) return "lds_first_index(" + field + ", a.spool + " + std::to_string(x.str_off[k]) + ", " + std::to_string(o.slen) + ")";
         if (o.code == SDQH_X_STR) return "str_pred(" + field + ", a.spool + " + std::to_string(x.str_off[k]) + ", " + std::to_string(o.slen) + ", " + std::to_string(o.aux) + ")";
@@ -326,10 +339,14 @@ std::string generate(const XInfo& x, Sink sink, bool direct) {
     if (!tcols.empty()) {
         out << "    __device__ __forceinline__ static constexpr int scol(int j) { return j == 0 ? " << tcols[0] << " : " << (tcols.size() > 1 ? tcols[1] : tcols[0]) << "; }\n";
         out << "    __device__ __forceinline__ static constexpr int swidth(int j) { return j == 0 ? " << twidth[0] << " : " << (twidth.size() > 1 ? twidth[1] : twidth[0]) << "; }\n";
-        out << "    template <int J> __device__ __forceinline__ static void sops(const XArgs& a, const uint32_t* f, int64_t (&sres)[" << nsopx << "]) {\n";
+        auto tb = [&](size_t j) { return ((x.narrow_mask >> tcols[j]) & 1u) != 0; };      // staged from the column's byte twin
+        out << "    __device__ __forceinline__ static constexpr bool sbytes(int j) { return j == 0 ? " << (tb(0) ? "true" : "false") << " : " << (tb(tcols.size() > 1 ? 1 : 0) ? "true" : "false") << "; }\n";
+        // a field of the staging window: `off` is its byte offset (4-byte units: off / 4 words in)
+        out << "    template <int J> __device__ __forceinline__ static void sops(const XArgs& a, const uint32_t* region, int off, int64_t (&sres)[" << nsopx << "]) {\n";
         for (size_t j = 0; j < tcols.size(); ++j) {
             out << "        if constexpr (J == " << j << ") {\n";
-            for (int k : tops[j]) out << "            sres[" << g.sres_of[(size_t)k] << "] = (int64_t)" << g.text_op(k, "f, " + std::to_string(twidth[j]), true) << ";\n";
+            if (!tb(j)) out << "            const uint32_t* f = region + (off >> 2);\n";
+            for (int k : tops[j]) out << "            sres[" << g.sres_of[(size_t)k] << "] = (int64_t)" << (tb(j) ? g.text_op(k, "region, off, " + std::to_string(twidth[j]), true, true) : g.text_op(k, "f, " + std::to_string(twidth[j]), true)) << ";\n";
             out << "        }\n";
         }
         out << "    }\n";
@@ -337,7 +354,7 @@ std::string generate(const XInfo& x, Sink sink, bool direct) {
     out << "    template <bool TAIL> __device__ __forceinline__ static void sload(const XArgs& a, int64_t r, int64_t nrows, Pair<int64_t> (&s)[" << nsx << "]) {\n";
     for (int i = 0; i < ns; ++i) {
         const int c = scols[(size_t)i];
-        if ((x.narrow_mask >> c) & 1u) out << "        s[" << i << "] = x_sload_narrow_" << (x.cols[c]->dtype == SDQH_F64 ? "f" : "i") << "<TAIL>(a.ncol[" << c << "], r, nrows);\n";
+        if (((x.narrow_mask >> c) & 1u) && x.cols[c]->dtype != SDQH_STR) out << "        s[" << i << "] = x_sload_narrow_" << (x.cols[c]->dtype == SDQH_F64 ? "f" : "i") << "<TAIL>(a.ncol[" << c << "], r, nrows);\n";
         else out << "        s[" << i << "] = load2<TAIL>(static_cast<const int64_t*>(a.col[" << c << "]), r, nrows);\n";
     }
     out << "    }\n";

@@ -71,6 +71,20 @@ __device__ __forceinline__ int64_t x_char(const uint32_t* __restrict__ s, int wi
     for (int k = 0; k < pos; ++k) if (s[k] == 0u) return 0;
     return (int64_t)s[pos];
 }
+// the text operations on a field of the byte twin staged in LDS (byte offset `off` of `region`)
+__device__ __forceinline__ int64_t x8_first_index(const uint32_t* region, int off, int width, const uint32_t* val, int len) {
+    return len == 0 ? 0 : (int64_t)lds8_find(region, off, width, val, len);
+}
+__device__ __forceinline__ bool x8_str_pred(const uint32_t* region, int off, int width, const uint32_t* val, int len, int mode) {
+    if (mode == 2) return len == 0 || lds8_find(region, off, width, val, len) >= 0;
+    return lds_str_pred(reinterpret_cast<const uint8_t*>(region) + off, width, val, len, mode);
+}
+__device__ __forceinline__ int64_t x8_char(const uint32_t* region, int off, int width, int pos) {
+    const uint8_t* s = reinterpret_cast<const uint8_t*>(region) + off;
+    if (pos >= width) return 0;
+    for (int k = 0; k < pos; ++k) if (s[k] == 0u) return 0;
+    return (int64_t)s[pos];
+}
 // one lookup: stage row of the matched entry, NO_ROW on a miss (key sets: 0 on a hit)
 __device__ __forceinline__ uint32_t x_lookup(const DevTable& t, int64_t key, bool bad) {
     if (bad) return NO_ROW;
@@ -318,10 +332,55 @@ template <class P, int J>
 __device__ __forceinline__ void x_stage_text(const XArgs& a, const int32_t* q_row, int64_t begin, int first, int count, uint32_t* s_str,
                                              int64_t (&sres)[P::NSOP > 0 ? P::NSOP : 1]) {
     constexpr int W = P::swidth(J);
+    const int lane = lane_id();
+    if constexpr (P::sbytes(J)) {
+        // The column's byte twin: a field starts at any byte, so the wave copies the aligned 32-bit words that cover the fields
+        // and every lane scans its field at a byte offset of the staging window (lds8_scan).  Consecutive rows are one
+        // contiguous run of bytes; otherwise each row gets a slot of WP bytes holding its covering words.
+        constexpr int WP = (W + 6) & ~3;
+        constexpr int RB = (XSTR_UNITS * 4 - 8) / WP;
+        constexpr int R = RB < WAVE ? RB : WAVE;
+        static_assert(R >= 1, "a text field wider than the staging window");
+        const uint8_t* __restrict__ col = static_cast<const uint8_t*>(a.ncol[P::scol(J)]);
+        for (int base = 0; base < count; base += R) {
+            const int nr = count - base < R ? count - base : R;
+            __builtin_amdgcn_wave_barrier();
+            constexpr int NL = (R * WP / 4 + WAVE - 1) / WAVE;
+            uint32_t t[NL];
+            const int q0 = q_row[first + base], q1 = q_row[first + base + nr - 1];
+            const bool run = q1 - q0 == nr - 1;
+            int off = 0, nw;
+            if (run) {
+                const unsigned long long p0 = (unsigned long long)(col + (begin + (int64_t)q0) * W);
+                const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(p0 & ~3ull);
+                nw = ((int)(p0 & 3ull) + nr * W + 3) >> 2;
+#pragma unroll
+                for (int i = 0; i < NL; ++i) { const int idx = lane + i * WAVE; t[i] = idx < nw ? src[idx] : 0u; }
+                off = (int)(p0 & 3ull) + (lane - base) * W;
+            } else {
+                nw = nr * (WP / 4);
+#pragma unroll
+                for (int i = 0; i < NL; ++i) {
+                    const int idx = lane + i * WAVE;
+                    t[i] = 0u;
+                    if (idx < nw) {
+                        const int row = idx / (WP / 4), wi = idx - row * (WP / 4);
+                        const unsigned long long pr = (unsigned long long)(col + (begin + (int64_t)q_row[first + base + row]) * W);
+                        t[i] = reinterpret_cast<const uint32_t*>(pr & ~3ull)[wi];
+                    }
+                }
+                if (lane >= base && lane < base + nr) off = (lane - base) * WP + (int)(((unsigned long long)(col + (begin + (int64_t)q_row[first + lane]) * W)) & 3ull);
+            }
+#pragma unroll
+            for (int i = 0; i < NL; ++i) { const int idx = lane + i * WAVE; if (idx < nw) s_str[idx] = t[i]; }
+            __builtin_amdgcn_wave_barrier();
+            if (lane >= base && lane < base + nr) P::template sops<J>(a, s_str, off, sres);
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
     constexpr int R = (XSTR_UNITS / W) < WAVE ? (XSTR_UNITS / W) : WAVE;
     static_assert(R >= 1, "a text field wider than the staging window");
     const uint32_t* __restrict__ col = static_cast<const uint32_t*>(a.col[P::scol(J)]);
-    const int lane = lane_id();
     for (int base = 0; base < count; base += R) {
         const int nr = count - base < R ? count - base : R;
         __builtin_amdgcn_wave_barrier();
@@ -344,8 +403,9 @@ __device__ __forceinline__ void x_stage_text(const XArgs& a, const int32_t* q_ro
 #pragma unroll
         for (int i = 0; i < NL; ++i) { const int idx = lane + i * WAVE; if (idx < nr * W) s_str[idx] = t[i]; }
         __builtin_amdgcn_wave_barrier();
-        if (lane >= base && lane < base + nr) P::template sops<J>(a, s_str + (lane - base) * W, sres);
+        if (lane >= base && lane < base + nr) P::template sops<J>(a, s_str, (lane - base) * W * 4, sres);
         __builtin_amdgcn_wave_barrier();
+    }
     }
 }
 

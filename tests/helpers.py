@@ -476,16 +476,17 @@ def topk_case(ctx, n=400000, seed=9):
     return out
 
 
-def string_predicate_case(ctx, widths=(1, 2, 3, 7, 10, 25, 31, 32, 33, 55, 64, 65, 100, 128, 129), rows=5000, seed=3):
+def string_predicate_case(ctx, widths=(1, 2, 3, 7, 10, 25, 31, 32, 33, 55, 64, 65, 100, 128, 129), rows=5000, seed=3, latin=False, key_set=False):
     """The build-side string predicate (==, !=, substring) over fixed-width UCS4 fields of many
     widths, against a plain-Python restatement of VarChar::operator== / contains (reference
     include/varchar.h:61-89: equality = first len units equal and the rest NUL; substring = wcsstr,
     the field ends at its first NUL).  Fields include embedded NULs, needles at both ends,
-    overlapping partial matches and non-ASCII units."""
+    overlapping partial matches and non-ASCII units.  latin: every unit of the column is below 256, so the column has a
+    byte twin (the needles still include a wider unit); key_set: through build_key_set instead of hash_build_unique."""
     import numpy as np
     from sdqlpy_amd import abi
     rng = np.random.default_rng(seed)
-    alphabet = np.array([ord(c) for c in "abgren "] + [0x00E9, 0x65E5], np.uint32)      # small: matches are frequent
+    alphabet = np.array([ord(c) for c in "abgren "] + ([0x00E9, 0x00FF] if latin else [0x00E9, 0x65E5]), np.uint32)      # small: matches are frequent
     checked = 0
     for width in widths:
         raw = alphabet[rng.integers(0, len(alphabet), (rows, width))]
@@ -495,11 +496,11 @@ def string_predicate_case(ctx, widths=(1, 2, 3, 7, 10, 25, 31, 32, 33, 55, 64, 6
         pos = rng.integers(0, width, rows)
         raw[holes, pos[holes]] = 0
         needles = ["g", "green", "gre", "ab", "a", "é", "日", "green ab", "nnnnnnnnn", "x"]
-        needles = [n for n in needles if len(n) <= max(1, width)] + ["".join(chr(c) for c in raw[7, :min(width, 12)] if c)]
+        needles = [n for n in needles if len(n) <= max(1, width) and not (latin and n == "日" and width < 2)] + ["".join(chr(c) for c in raw[7, :min(width, 12)] if c)]
         # plant needles at the start, at the very end and after a NUL
         for i, nd in enumerate(needles):
             u = np.array([ord(c) for c in nd], np.uint32)
-            if 0 < len(u) <= width:
+            if 0 < len(u) <= width and not (latin and u.max() > 255):
                 raw[100 + i, :] = 0; raw[100 + i, :len(u)] = u                          # exactly the needle (equality hit)
                 raw[200 + i, :] = ord("b"); raw[200 + i, width - len(u):] = u           # at the very end, field full
                 if len(u) + 2 <= width:
@@ -526,9 +527,14 @@ def string_predicate_case(ctx, widths=(1, 2, 3, 7, 10, 25, 31, 32, 33, 55, 64, 6
                         hit = eq != (mode == 1)
                     if hit:
                         want.append(r)
-                t = ctx.hash_build_unique(rows, abi.make_filter(spreds=[(ccol, nd, mode)]), [], ckey, [])
-                n = ctx.table_compact_count(t, 0)
-                got = ctx.table_compact(t, 0, n, want_values=False, want_hits=False)[0].tolist()
+                if key_set:
+                    t = ctx.build_key_set(rows, abi.make_filter(spreds=[(ccol, nd, mode)]), [], ckey)
+                    (hit,), nh = ctx.scan_compact(rows, abi.make_filter(), [(t, ckey)], [ckey])
+                    got = hit.download(0, nh).tolist() if nh else []
+                else:
+                    t = ctx.hash_build_unique(rows, abi.make_filter(spreds=[(ccol, nd, mode)]), [], ckey, [])
+                    n = ctx.table_compact_count(t, 0)
+                    got = ctx.table_compact(t, 0, n, want_values=False, want_hits=False)[0].tolist()
                 t.free()
                 assert got == want, "width %d, %r %s field: %d rows, expected %d (first difference %s)" % (
                     width, nd, name, len(got), len(want), sorted(set(got) ^ set(want))[:5])

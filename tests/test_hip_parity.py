@@ -458,6 +458,41 @@ def test_string_predicates_all_widths(hip_engine):
     assert string_predicate_case(hip_engine.ctx) > 400
 
 
+def test_text_byte_twins_change_no_result(hip_engine, oracle_engine, golden, golden_more, golden_wide):
+    """A text column whose code units are all below 256 is scanned through a one-byte-per-unit twin: the
+    staging kernels copy a quarter of the bytes and scan the fields as whole words.  (1) Every predicate mode over many
+    widths, through both staging kernels, on a column that has a twin and on one that cannot (a CJK unit).  (2) The
+    queries with text conditions on small tables with the twins forced on, against the CPU implementation; the same tables
+    with a few fields made non-Latin (the twin is refused: 4-byte units again)."""
+    from helpers import string_predicate_case
+    hip_engine.ctx.set_option("feature_min_rows", 0)
+    hip_engine.clear()
+    try:
+        for key_set in (False, True):
+            assert string_predicate_case(hip_engine.ctx, widths=(1, 2, 3, 7, 10, 25, 33, 55, 79, 100, 128, 129), rows=3000, latin=True, key_set=key_set) > 300
+            assert string_predicate_case(hip_engine.ctx, widths=(3, 10, 55, 79), rows=3000, latin=False, key_set=key_set) > 100
+        qs = ["q3", "q9", "q13", "q16", "q2", "q20", "q22", "q14", "q19", "q12"]
+        db = tpch.generate(0.03, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+        wide = dict(db)
+        for table, field in (("part", "p_name"), ("customer", "c_mktsegment"), ("orders", "o_comment")):
+            cont = db[table].getContainer()
+            cols = {h: c.copy() for h, c in zip(cont["headers"], cont["data"])}
+            cols[field][3] = "\u65e5" + str(cols[field][3])[1:]
+            wide[table] = tpch.table_from_columns(cont["headers"], [cols[h] for h in cont["headers"]])
+        for tag, database in (("latin", db), ("wide", wide)):
+            for q in qs:
+                got, want = helpers.run_query(hip_engine, q, database), helpers.run_query(oracle_engine, q, database)
+                if isinstance(want, float):
+                    assert abs(got - want) <= REL * max(abs(want), 1e-300), (tag, q, got, want)
+                else:
+                    helpers.assert_rows_match(helpers.result_rows(got, want.columns), helpers.result_rows(want, want.columns), REL, "%s/%s" % (tag, q))
+            hip_engine.clear(); oracle_engine.clear()
+    finally:
+        hip_engine.ctx.set_option("feature_min_rows", 1 << 20)
+        hip_engine.clear()
+        oracle_engine.clear()
+
+
 def test_membership_only_builds(hip_engine):
     """sdqh_build_key_set (bitmap-only build used for `tbl[k] != None`) against numpy."""
     from helpers import key_set_case

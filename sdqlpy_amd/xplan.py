@@ -819,17 +819,37 @@ def run_host_dict(eng, op, env, materialize):
             if len(d.key_fields) != 1:
                 raise UnsupportedQuery("line %d: '%s' has a composite key: it cannot be looked up from a result dictionary" % (op.lineno, name))
             keys = np.asarray(d.key_fields[0][1])
-            order = np.argsort(keys, kind="stable")
-            tables[name] = (keys[order], order, d)
+            direct = None
+            if len(keys) and keys.dtype.kind == "i":
+                lo, hi = int(keys.min()), int(keys.max())
+                if hi - lo < 4 * len(keys) + 1024:                       # integer keys over a dense range: row of key k at direct[k - lo]
+                    direct = (lo, np.full(hi - lo + 1, -1, np.int64))
+                    direct[1][keys[::-1] - lo] = np.arange(len(keys) - 1, -1, -1)      # equal keys: the first row wins, as the stable sort below
+            order = None if direct is not None else np.argsort(keys, kind="stable")
+            tables[name] = (keys if direct is not None else keys[order], order, d, direct)
         return tables[name]
 
+    looked = {}
+
     def look(lk):
-        skeys, order, d = host_table(lk.dict_name)
+        memo = (lk.dict_name, repr(lk.key))                              # the fields of one looked-up record share the search
+        if memo in looked:
+            return looked[memo]
+        skeys, order, d, direct = host_table(lk.dict_name)
         k = np.asarray(val(lk.key))
-        pos = np.searchsorted(skeys, k)
-        pos[pos >= len(skeys)] = 0
-        hit = (skeys[pos] == k) if len(skeys) else np.zeros(n, bool)
-        return hit, order[pos] if len(skeys) else np.zeros(n, np.int64), d
+        if direct is not None:
+            lo, rows_of = direct
+            inside = (k >= lo) & (k < lo + len(rows_of))
+            rows = rows_of[np.where(inside, k - lo, 0)]
+            hit = inside & (rows >= 0)
+            out = (hit, np.where(hit, rows, 0), d)
+        else:
+            pos = np.searchsorted(skeys, k)
+            pos[pos >= len(skeys)] = 0
+            hit = (skeys[pos] == k) if len(skeys) else np.zeros(n, bool)
+            out = (hit, order[pos] if len(skeys) else np.zeros(n, np.int64), d)
+        looked[memo] = out
+        return out
 
     def val(e):
         if isinstance(e, Const):
@@ -917,11 +937,12 @@ def run_host_dict(eng, op, env, materialize):
     def broadcast(a):
         return a if isinstance(a, TextRefs) else (np.full(n, a) if np.ndim(a) == 0 else a)
     kf, key_is_record = fields_of(op.key, "key")
-    kf = [(nm, broadcast(a)[keep]) for nm, a in kf]
+    every = bool(keep.all())                                         # nothing filtered: the columns as they are
+    kf = [(nm, broadcast(a) if every else broadcast(a)[keep]) for nm, a in kf]
     if isinstance(op.val, Const) and op.val.value is True:
         return ResultSet([nm for nm, _ in kf], [a for _, a in kf])
     vf, val_is_record = fields_of(op.val, "value")
-    vf = [(nm, broadcast(a)[keep]) for nm, a in vf]
+    vf = [(nm, broadcast(a) if every else broadcast(a)[keep]) for nm, a in vf]
     d = DictResult(kf, vf, key_is_record, val_is_record)
     if not op.unique:                                                # a group-by over the dictionary (Q16: combinations -> their number per group)
         from .engine import _merge_equal_keys

@@ -20,6 +20,7 @@ for q in q1 q3 q5 q6 q9; do
 done
 ROWS=$(python3 -c "import json;print(json.dumps(json.load(open('$OUT/bench_for_rows.json'))['config']['rows_per_gpu']))")
 python3 tools/pmc_per_query.py $OUT/pmc $ITERS "$ROWS" $OUT/pmc_traffic.json > $OUT/pmc_traffic_summary.txt 2>&1
+bash tools/collect_query_traces.sh $R "$ROWS"
 # drop the bulky raw traces, keep the summaries
 find $OUT -name "*.csv" -size +2M -delete
 du -sh $OUT

@@ -308,6 +308,28 @@ static bool stage_text_twin(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* fil
     f->sc8 = static_cast<const uint8_t*>(twin); f->slds = 64;
     return true;
 }
+// Membership build on a key column in no row order: k_key_set_lds + k_or_slices instead of one device-scope atomic per row.
+// false: not applicable (the caller launches k_key_set).
+constexpr uint32_t KSL_PASS_WORDS = 32768;             // 128 KiB of LDS: one million keys of the range per pass over the rows
+template <class FCT>
+static bool launch_key_set_lds(sdqh_ctx* ctx, const DevFilter& f, const DevProbes& pr, const sdqh_column* key, int64_t nrows, int64_t lo, int64_t hi, sdqh_table* tb) {
+    if (!ctx->opt_lds_key_set || f.ns || nrows < std::max<int64_t>(ctx->opt_feature_min_rows, 4096) || tb->nwords > (uint64_t)4 * KSL_PASS_WORDS) return false;
+    if (column_is_clustered(ctx, const_cast<sdqh_column*>(key))) return false;
+    auto kern = k_key_set_lds<FCT>;
+    const uint32_t pass_words = (uint32_t)std::min<uint64_t>(tb->nwords, KSL_PASS_WORDS);
+    const size_t lds = (size_t)pass_words * 4;
+    int per_cu = 0;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, KSL_BT, lds) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); return false; }
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + KSL_BT * KSL_U - 1) / (KSL_BT * KSL_U), (int64_t)ctx->num_cu * std::min(per_cu, 2)));
+    uint32_t* slices = static_cast<uint32_t*>(pool_alloc(ctx, (size_t)grid * tb->nwords * 4 + 64));
+    if (!slices) return false;
+    { KernelScope ks(ctx, "k_key_set_lds"); hipLaunchKernelGGL(kern, dim3(grid), dim3(KSL_BT), lds, ctx->stream, f, pr, static_cast<const int64_t*>(key->data), nrows, lo, hi, slices, tb->nwords, pass_words); }
+    const int nchunks = (int)std::max<uint64_t>(1, std::min<uint64_t>(grid / 8, 65536 / std::max<uint64_t>(tb->nwords, 1)));
+    LAUNCH(ctx, "k_or_slices", k_or_slices, (unsigned)std::min<uint64_t>((tb->nwords * nchunks + TPB - 1) / TPB, (uint64_t)ctx->num_cu * 8), slices, (int)grid, tb->nwords, tb->bm, nchunks);
+    pool_free(ctx, slices);                             // stream order: whoever gets the block next runs after these two
+    return true;
+}
 // Swap every streamed column of a scan (integer / double predicates, tuple operands) for its twin; false (nothing changed)
 // unless ALL of them have one.  Only for the instances that read nothing else by row (no string / column-pair predicates).
 static bool narrow_streams(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, const sdqh_tuple* tuple, DevFilter* f, DevTuple* t) {
@@ -485,6 +507,7 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "probe_pipeline" && value >= 0 && value <= 1) ctx->opt_probe_pipeline = (int)value;
     else if (n == "lookup_debug") ctx->opt_lookup_debug = (int)value;
     else if (n == "fuse_small" && value >= 0 && value <= 1) ctx->opt_fuse_small = (int)value;
+    else if (n == "lds_key_set" && value >= 0 && value <= 1) ctx->opt_lds_key_set = (int)value;
     else if (n == "str_rows" && (value == 0 || value == 32 || value == 64)) ctx->opt_str_rows = (int)value;
     else if (n == "rank_increasing" && value >= 0 && value <= 1) ctx->opt_rank_increasing = (int)value;
     else if (n == "feature_min_rows" && value >= 0) ctx->opt_feature_min_rows = value;
@@ -1122,6 +1145,7 @@ int sdqh_build_key_set(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
         stage_text_twin(ctx, nrows, filter, &f);
         const size_t lds = (size_t)(TPB / WAVE) * str_lds_words(f) * 4 + (f.sc8 ? STR_LDS_SLACK : 0);
         with_stage_filter(f, nprobes, [&](auto FC) {
+            if (!pre.n && launch_key_set_lds<decltype(FC)>(ctx, f, pr, key, nrows, lo, hi, tb)) return SDQH_OK;
             auto kern = k_key_set<decltype(FC)>;
             LAUNCH_LDS(ctx, "k_key_set", kern, grid, lds, f, pr, kc, nrows, lo, hi, tb->bm, pre);
             return SDQH_OK;
@@ -1273,6 +1297,7 @@ int sdqh_groupby_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, co
     const int64_t* kc = static_cast<const int64_t*>(key->data);
     const unsigned sgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + TPB * ROWS_PER_LOAD * 2 - 1) / (TPB * ROWS_PER_LOAD * 2), (int64_t)ctx->num_cu * ctx->opt_resident_cap));
     with_stage_filter(f, 0, [&](auto FC) {
+        if (launch_key_set_lds<decltype(FC)>(ctx, f, pr, key, nrows, lo, hi, tb)) return SDQH_OK;
         auto kern = k_key_set<decltype(FC)>;
         { DevFill nofill; std::memset(&nofill, 0, sizeof(nofill)); LAUNCH_LDS(ctx, "k_key_set", kern, sgrid, 0, f, pr, kc, nrows, lo, hi, tb->bm, nofill); }
         return SDQH_OK;

@@ -66,6 +66,7 @@ struct sdqh_ctx {
     int opt_packed_slots = 1;                      // hash-layout tables with payload: 32-byte slots { key, payload 0 / 1, owner row }
     int opt_lookup_pipeline = -1;                  // k_lookup_agg requests the next tile's first-lookup keys a step ahead: -1 = when that key column is clustered, 0 / 1 = never / always
     int opt_lookup_debug = 0;
+    int opt_lds_key_set = 1;                       // membership builds on keys in no row order: bitmaps in LDS per workgroup, folded afterwards (no global atomics)
     int opt_fuse_small = 1;                        // tiny tables (one workgroup): fill inside the build kernel, rank + insert in one launch
     int opt_str_rows = 0;                          // rows of text a wave stages in LDS per round in k_key_set: 0 = by field width, 32, 64
     int opt_rank_increasing = 1;                   // whole-table builds on a strictly increasing key over a wide range: bitmap + row per word (rank = row), no dense array

@@ -2033,6 +2033,70 @@ __global__ __launch_bounds__(TPB) void k_key_set(DevFilter f, DevProbes pr, cons
             set_pair(ok, ok ? key[r] : lo, false, lo);
         }
 }
+// The same build for keys in NO row order (Q22: the customers of 15 M orders; Q15: the suppliers of a quarter's lineitems).
+// Then nearly every bit is a device-scope atomic of its own, and those execute at the memory side, not in an XCD's L2: 26 G/s,
+// 0.58 ms for Q22's 120 MB of keys.  Here a 1024-thread workgroup ORs the bits of ITS rows into a bitmap in LDS (ds_or) — up to
+// pass_words words of the key range at a time, the rows streamed once per such part — and stores the words into its own slice;
+// k_or_slices folds the slices into the table's bitmap with plain loads and stores.  No global atomic at all.
+constexpr int KSL_BT = 1024, KSL_U = 4;
+template <class FC>
+__global__ __launch_bounds__(KSL_BT) void k_key_set_lds(DevFilter f, DevProbes pr, const int64_t* __restrict__ key, int64_t nrows, int64_t lo, int64_t hi,
+                                                        uint32_t* __restrict__ slices, uint64_t nwords, uint32_t pass_words) {
+    extern __shared__ __align__(16) uint32_t s_bits[];                  // pass_words words
+    uint64_t cap_masks[SDQH_MAX_PROBE] = {0, 0};
+#pragma unroll
+    for (int i = 0; i < SDQH_MAX_PROBE; ++i) if (i < cfg_np<FC>(pr.n) && pr.table[i].hdr && !table_is_direct(pr.table[i]) && !pr.table[i].bitmap_only) cap_masks[i] = pr.table[i].hdr->cap_mask;
+    const int64_t per = (nrows + gridDim.x - 1) / gridDim.x;
+    const int64_t r_begin = (int64_t)blockIdx.x * per;
+    const int64_t r_end = r_begin + per < nrows ? r_begin + per : nrows;
+    uint32_t* __restrict__ mine = slices + (uint64_t)blockIdx.x * nwords;
+    for (uint64_t w0 = 0; w0 < nwords; w0 += pass_words) {
+        const uint32_t nw = (uint32_t)(nwords - w0 < (uint64_t)pass_words ? nwords - w0 : (uint64_t)pass_words);
+        for (uint32_t i = threadIdx.x; i < nw; i += KSL_BT) s_bits[i] = 0u;
+        __syncthreads();
+        const int64_t plo = lo + (int64_t)(w0 * 32u);
+        int64_t phi = plo + (int64_t)nw * 32 - 1; if (phi > hi) phi = hi;
+        for (int64_t r0 = r_begin; r0 < r_end; r0 += (int64_t)KSL_BT * KSL_U) {
+            int64_t k[KSL_U]; bool ok[KSL_U];
+#pragma unroll
+            for (int u = 0; u < KSL_U; ++u) { const int64_t r = r0 + (int64_t)u * KSL_BT + threadIdx.x; ok[u] = r < r_end; k[u] = ok[u] ? __builtin_nontemporal_load(key + r) : lo; }
+#pragma unroll
+            for (int u = 0; u < KSL_U; ++u) {
+                const int64_t r = r0 + (int64_t)u * KSL_BT + threadIdx.x;
+                if (ok[u] && k[u] >= plo && k[u] <= phi && row_passes<FC>(f, pr, r, cap_masks)) {
+                    const uint64_t off = (uint64_t)(k[u] - plo);
+                    atomicOr(&s_bits[off >> 5], 1u << (off & 31));
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nw; i += KSL_BT) mine[w0 + i] = s_bits[i];
+        __syncthreads();
+    }
+}
+// nchunks > 1 (a short bitmap: too few words to fill the device with one thread per word): a thread folds one chunk of the
+// slices of its word and ORs the result into the (cleared) bitmap.
+SDQH_KERNEL __launch_bounds__(TPB) void k_or_slices(const uint32_t* __restrict__ slices, int nslices, uint64_t nwords, uint32_t* __restrict__ bm, int nchunks) {
+    if (nchunks == 1) {
+        for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < nwords; i += (uint64_t)gridDim.x * TPB) {
+            uint32_t v = 0;
+#pragma unroll 8
+            for (int g = 0; g < nslices; ++g) v |= slices[(uint64_t)g * nwords + i];
+            bm[i] = v;
+        }
+        return;
+    }
+    const int per = (nslices + nchunks - 1) / nchunks;
+    for (uint64_t idx = (uint64_t)blockIdx.x * TPB + threadIdx.x; idx < nwords * (uint64_t)nchunks; idx += (uint64_t)gridDim.x * TPB) {
+        const uint64_t i = idx % nwords;
+        const int c = (int)(idx / nwords), g1 = (c + 1) * per < nslices ? (c + 1) * per : nslices;
+        uint32_t v = 0;
+#pragma unroll 8
+        for (int g = c * per; g < g1; ++g) v |= slices[(uint64_t)g * nwords + i];
+        if (v) atomicOr(&bm[i], v);
+    }
+}
+
 // population count of a bitmap (sdqh_table_size of a membership-only table)
 SDQH_KERNEL __launch_bounds__(TPB) void k_popcount(const uint32_t* __restrict__ bm, uint64_t nwords, unsigned long long* __restrict__ out) {
     unsigned long long n = 0;

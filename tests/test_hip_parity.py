@@ -493,6 +493,37 @@ def test_text_byte_twins_change_no_result(hip_engine, oracle_engine, golden, gol
         oracle_engine.clear()
 
 
+def test_key_sets_on_unordered_keys(hip_engine):
+    """Membership builds on keys in no row order go through bitmaps in LDS (one per workgroup, folded afterwards) instead of one
+    device-scope atomic per row: ranges below and above one pass of 2^20 keys, short bitmaps (the fold split over chunks of
+    slices), duplicates, a filter; against numpy and against the atomic kernel (`lds_key_set` 0)."""
+    from sdqlpy_amd import abi
+    ctx = hip_engine.ctx
+    rng = np.random.default_rng(5)
+    ctx.set_option("feature_min_rows", 0)
+    try:
+        for n, span in ((5000, 3000), (300000, 2500000), (70001, 1 << 20), (200000, 40000), (70000, 4100000)):
+            keys = rng.integers(10, 10 + span, n).astype(np.int64)
+            keys[0], keys[1] = 10, 10 + span - 1
+            other = rng.integers(0, 100, n).astype(np.int64)
+            ck, co = ctx.upload(keys), ctx.upload(other)
+            probe = np.arange(0, span + 20, dtype=np.int64)
+            cp = ctx.upload(probe)
+            for use_filter in (False, True):
+                want = np.unique(keys[other <= 29] if use_filter else keys)
+                for lds in (1, 0):
+                    ctx.set_option("lds_key_set", lds)
+                    flt = abi.make_filter(ipreds=[(co, 0, 29)]) if use_filter else abi.make_filter()
+                    t = ctx.build_key_set(n, flt, [], ck)
+                    (hit,), nh = ctx.scan_compact(len(probe), abi.make_filter(), [(t, cp)], [cp])
+                    got = np.sort(hit.download(0, nh)) if nh else np.zeros(0, np.int64)
+                    t.free()
+                    assert np.array_equal(got, want), (n, span, use_filter, lds, len(got), len(want))
+    finally:
+        ctx.set_option("lds_key_set", 1)
+        ctx.set_option("feature_min_rows", 1 << 20)
+
+
 def test_membership_only_builds(hip_engine):
     """sdqh_build_key_set (bitmap-only build used for `tbl[k] != None`) against numpy."""
     from helpers import key_set_case

@@ -629,6 +629,13 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
             dense = bounds[0] <= bounds[1] and bounds[1] - bounds[0] + 1 <= (1 << 31) and bounds[1] - bounds[0] + 1 <= 64 * max(n, 1024)
             if member_only and not c.P.vals and not accumulate and dense:
                 table = ctx.xkey_set(n, c.P, bounds[0], bounds[1])
+            if table is None and not c.P.gates and c.P.vals and not accumulate and not composite:
+                # every row, keyed by an integer column, payload = integer columns as they are (dictionary codes included): the
+                # fixed build keeps such columns in place (no staging; increasing keys: rank = row) — Q12's 15 M orders 0.74 -> 0.15 ms
+                ops = c.P.ops
+                cols = [ops[i]["col"] if ops[i]["code"] == abi.X_COL and ops[i]["type"] == abi.T_I64 else None for i in [c.P.key] + list(c.P.vals)]
+                if all(col is not None for col in cols):
+                    table = ctx.hash_build_unique(n, abi.make_filter(), [], cols[0], cols[1:])
             if table is None:
                 table = ctx.xbuild(n, c.P, bounds[0], bounds[1], accumulate=accumulate)
             bt = BuiltTable(table, key_names[0], key_is_record, val_fields, val_is_record, dtypes)

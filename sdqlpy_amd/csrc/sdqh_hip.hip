@@ -1146,8 +1146,21 @@ int sdqh_build_key_set(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
         const size_t lds = (size_t)(TPB / WAVE) * str_lds_words(f) * 4 + (f.sc8 ? STR_LDS_SLACK : 0);
         with_stage_filter(f, nprobes, [&](auto FC) {
             if (!pre.n && launch_key_set_lds<decltype(FC)>(ctx, f, pr, key, nrows, lo, hi, tb)) return SDQH_OK;
+            const int32_t* none = nullptr;
+            if constexpr (std::is_same_v<decltype(FC), FCfg<0, 0, 0, 0, 1>>) {      // Q4's late lineitems: key and the two compared dates through their twins
+                if (ctx->opt_narrow && nrows >= ctx->opt_feature_min_rows && !f.cf64[0]) {
+                    const int32_t* nk = static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(key)));
+                    const int32_t* na = nk ? static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(filter->cpred[0].a))) : nullptr;
+                    const int32_t* nb = na ? static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(filter->cpred[0].b))) : nullptr;
+                    if (nb) {
+                        auto nkern = k_key_set<decltype(FC), true>;
+                        LAUNCH_LDS(ctx, "k_key_set", nkern, grid, lds, f, pr, kc, nrows, lo, hi, tb->bm, pre, nk, na, nb);
+                        return SDQH_OK;
+                    }
+                }
+            }
             auto kern = k_key_set<decltype(FC)>;
-            LAUNCH_LDS(ctx, "k_key_set", kern, grid, lds, f, pr, kc, nrows, lo, hi, tb->bm, pre);
+            LAUNCH_LDS(ctx, "k_key_set", kern, grid, lds, f, pr, kc, nrows, lo, hi, tb->bm, pre, none, none, none);
             return SDQH_OK;
         });
     }
@@ -1299,7 +1312,7 @@ int sdqh_groupby_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, co
     with_stage_filter(f, 0, [&](auto FC) {
         if (launch_key_set_lds<decltype(FC)>(ctx, f, pr, key, nrows, lo, hi, tb)) return SDQH_OK;
         auto kern = k_key_set<decltype(FC)>;
-        { DevFill nofill; std::memset(&nofill, 0, sizeof(nofill)); LAUNCH_LDS(ctx, "k_key_set", kern, sgrid, 0, f, pr, kc, nrows, lo, hi, tb->bm, nofill); }
+        { DevFill nofill; std::memset(&nofill, 0, sizeof(nofill)); LAUNCH_LDS(ctx, "k_key_set", kern, sgrid, 0, f, pr, kc, nrows, lo, hi, tb->bm, nofill, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr)); }
         return SDQH_OK;
     });
     const int nblocks = (int)((tb->nwords + RANK_BLOCK_WORDS - 1) / RANK_BLOCK_WORDS);

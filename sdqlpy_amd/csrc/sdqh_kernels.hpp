@@ -1222,7 +1222,11 @@ __device__ __forceinline__ void pass_pairs(const DevFilter& f, const DevProbes& 
     for (int i = 0; i < SDQH_MAX_CPRED; ++i) if (i < cfg_nc<FC>(f.nc)) {        // both sides streamed with 16-byte loads, all in flight first
         Pair<int64_t> a[NB], b[NB];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { a[j] = load2<false>(f.ca[i], r[j], nrows); b[j] = load2<false>(f.cb[i], r[j], nrows); }
+        for (int j = 0; j < NB; ++j) {
+            if constexpr (NW && FC::NI == 0 && FC::NP == 0 && FC::NC == 1) {      // the one-comparison instance (Q4): both integer columns through their twins
+                a[j] = loadc<false, true>(reinterpret_cast<const int64_t*>(nkey), r[j], nrows); b[j] = loadc<false, true>(reinterpret_cast<const int64_t*>(npred0), r[j], nrows);
+            } else { a[j] = load2<false>(f.ca[i], r[j], nrows); b[j] = load2<false>(f.cb[i], r[j], nrows); }
+        }
 #pragma unroll
         for (int j = 0; j < NB; ++j) { p[j][0] = p[j][0] && col_cmp(f, i, a[j].x, b[j].x); p[j][1] = p[j][1] && col_cmp(f, i, a[j].y, b[j].y); }
     }
@@ -1966,9 +1970,11 @@ __global__ __launch_bounds__(TPB) void k_probe_agg(DevFilter f, DevTuple t, DevT
 // Membership-only build (sdqh_build_key_set): stream filter + key, OR the survivors' bits.  A lane
 // holds two consecutive rows; keys of neighbouring rows usually share a bitmap word (a fact table
 // clustered on the key), so equal words of the pair are merged before the atomic.
-template <class FC>
+// NW (the one-comparison instance only): key and both compared columns are read through their 4-byte twins nk / na / nb
+template <class FC, bool NW = false>
 __global__ __launch_bounds__(TPB) void k_key_set(DevFilter f, DevProbes pr, const int64_t* __restrict__ key, int64_t nrows,
-                                                 int64_t lo, int64_t hi, uint32_t* __restrict__ bm, DevFill pre) {
+                                                 int64_t lo, int64_t hi, uint32_t* __restrict__ bm, DevFill pre,
+                                                 const int32_t* __restrict__ nk, const int32_t* __restrict__ na, const int32_t* __restrict__ nb) {
     if (pre.n) { fill_in_block(pre); __syncthreads(); }                  // a tiny table (grid of one workgroup) clears its own bitmap
     constexpr int PU = 2, TILE = TPB * ROWS_PER_LOAD * PU;
     extern __shared__ __align__(16) uint32_t s_dyn[];                   // f.slds * swidth words per wave (string predicate staging)
@@ -2019,10 +2025,10 @@ __global__ __launch_bounds__(TPB) void k_key_set(DevFilter f, DevProbes pr, cons
 #pragma unroll
         for (int u = 0; u < PU; ++u) {
             r[u] = tile * TILE + (int64_t)u * SUB_ROWS + (int64_t)threadIdx.x * ROWS_PER_LOAD;
-            kv[u] = load2<false>(key, r[u], nrows);
+            kv[u] = loadc<false, NW>(NW ? reinterpret_cast<const int64_t*>(nk) : key, r[u], nrows);
             p[u][0] = p[u][1] = true;
         }
-        pass_pairs<PU, FC, true>(f, pr, r, nrows, cap_masks, p, s_str);
+        pass_pairs<PU, FC, true, false, false, NW>(f, pr, r, nrows, cap_masks, p, s_str, nullptr, na, nb);
 #pragma unroll
         for (int u = 0; u < PU; ++u) set_pair(p[u][0], kv[u].x, p[u][1], kv[u].y);
     }

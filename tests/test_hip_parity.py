@@ -108,7 +108,7 @@ def test_narrow_twins_change_no_bit(hip_engine, oracle_engine):
     the twins switched off.  (2) Columns the twins cannot hold — prices with more than two decimals, a negative
     zero, a value beyond int32 cents, keys beyond int32 — silently keep their 8-byte form: same bits again, and
     the CPU implementation agrees."""
-    qs = ["q1", "q6", "q3", "q5", "q14", "q10"]
+    qs = ["q1", "q6", "q3", "q5", "q14", "q10", "q4"]
     db = tpch.generate(2.0, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
 
     def run_all(database, names):

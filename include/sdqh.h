@@ -178,7 +178,7 @@ void*       sdqh_stream(const sdqh_ctx* ctx);
  * "stage_eager_pay", "stage_waves_per_cu", "direct_index", "async_copies", "groupby_regs"; round 2: "narrow" (1: streamed
  * columns through exact 4-byte twins), "row_pack" (1), "packed_slots" (1), "coarse_kb" (64: LDS budget of the coarse key
  * filter, 0 = off), "lookup_pipeline" (-1 auto / 0 / 1), "probe_pipeline" (0), "stage_pipeline" (0), "span_index" (1),
- * "dense_increasing" (1), "rank_increasing" (1), "fuse_small" (1), "lds_key_set" (1: membership builds on keys in no row
+ * "dense_increasing" (1), "rank_increasing" (1), "fuse_small" (1), "fill_ahead" (1: a fill launch also clears the free blocks later builds will want cleared), "lds_key_set" (1: membership builds on keys in no row
  * order through per-workgroup bitmaps in LDS), "feature_min_rows" (2^20: the row count from which twins, packs and the wide
  * instances are used; the tests set 0), "str_rows", "lookup_debug" (cut points of k_lookup_agg for measurements: results ARE
  * wrong with it).

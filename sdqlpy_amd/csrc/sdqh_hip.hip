@@ -43,7 +43,7 @@ void* pool_alloc(sdqh_ctx* ctx, size_t bytes) {
         PoolBlock& b = ctx->pool[i];
         if (b.free && b.size >= bytes && b.size <= bytes * 2 + (1u << 20) && (best < 0 || b.size < ctx->pool[(size_t)best].size)) best = (int)i;
     }
-    if (best >= 0) { ctx->pool[(size_t)best].free = false; return ctx->pool[(size_t)best].ptr; }
+    if (best >= 0) { PoolBlock& b = ctx->pool[(size_t)best]; b.free = false; b.alloc_seq = ctx->launch_seq; b.fill_use = false; return b.ptr; }
     void* p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) {
         // release cached free blocks and retry once
@@ -51,12 +51,12 @@ void* pool_alloc(sdqh_ctx* ctx, size_t bytes) {
         ctx->pool.erase(std::remove_if(ctx->pool.begin(), ctx->pool.end(), [](const PoolBlock& b) { return b.ptr == nullptr; }), ctx->pool.end());
         if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     }
-    ctx->pool.push_back({p, bytes, false});
+    { PoolBlock nb{p, bytes, false}; nb.alloc_seq = ctx->launch_seq; ctx->pool.push_back(nb); }
     return p;
 }
 void pool_free(sdqh_ctx* ctx, void* p) {
     if (!p) return;
-    for (auto& b : ctx->pool) if (b.ptr == p) { b.free = true; return; }
+    for (auto& b : ctx->pool) if (b.ptr == p) { b.free = true; for (int h = 0; h < b.nhabits; ++h) b.habits[h].clean = false; if (!b.fill_use) b.nhabits = 0; return; }
 }
 
 // ---- profiling / timing ------------------------------------------------------------------------
@@ -89,16 +89,71 @@ int sync_stream(sdqh_ctx* ctx) {
 
 // One launch that sets up to FILL_MAX regions to a byte value each (see k_fill).
 struct FillList {
-    DevFill f; uint64_t most = 0;
+    DevFillBig f; uint64_t most = 0;
     FillList() { std::memset(&f, 0, sizeof(f)); }
+    DevFill pre() const {                                  // the short form a build kernel takes for its own fill (n <= FILL_MAX)
+        DevFill d; std::memset(&d, 0, sizeof(d));
+        for (int i = 0; i < f.n && i < FILL_MAX; ++i) { d.p[i] = f.p[i]; d.bytes[i] = f.bytes[i]; d.word[i] = f.word[i]; }
+        d.n = std::min<int>(f.n, FILL_MAX);
+        return d;
+    }
     void add(void* p, size_t bytes, unsigned char byte) {
-        if (!p || !bytes) return;
+        if (!p || !bytes || f.n >= FILL_BIG) return;
         f.p[f.n] = p; f.bytes[f.n] = bytes; f.word[f.n] = 0x01010101u * byte; ++f.n;
         most = std::max<uint64_t>(most, bytes);
     }
 };
-static void launch_fill(sdqh_ctx* ctx, const FillList& fl) {
+// Fill-ahead.  A plan's builds each start with a fill of their table's header / bitmap / reference array: 6 us launches, three to
+// five per join query.  The blocks come back from the pool run after run, so (1) a region that starts a pool block which was
+// set to the same byte while it lay FREE, and that no kernel can have touched since it was handed out (no launch since), is
+// dropped from the list; (2) a launch that has to happen anyway also sets the free blocks that were last used as fill regions
+// ("habit"), so the later fills of the plan find theirs clean.  Results cannot depend on it: a region is skipped only when it
+// provably holds the byte (`fill_ahead` 0 switches it off).
+static PoolBlock* pool_block_of(sdqh_ctx* ctx, const void* p) {
+    const char* c = static_cast<const char*>(p);
+    for (auto& b : ctx->pool) if (c >= static_cast<const char*>(b.ptr) && c < static_cast<const char*>(b.ptr) + b.size) return &b;
+    return nullptr;
+}
+static void prune_clean(sdqh_ctx* ctx, FillList* fl) {
+    if (!ctx->opt_fill_ahead) return;
+    DevFillBig out; std::memset(&out, 0, sizeof(out));
+    uint64_t most = 0;
+    for (int i = 0; i < fl->f.n; ++i) {
+        PoolBlock* b = pool_block_of(ctx, fl->f.p[i]);
+        const int byte = (int)(fl->f.word[i] & 0xFFu);
+        if (b && !b->free) {
+            const size_t off = (size_t)(static_cast<const char*>(fl->f.p[i]) - static_cast<const char*>(b->ptr)), bytes = fl->f.bytes[i];
+            int at = -1;
+            for (int h = 0; h < b->nhabits; ++h) if (b->habits[h].off == off && b->habits[h].bytes == bytes && b->habits[h].byte == byte) at = h;
+            b->fill_use = true;
+            if (at >= 0 && b->habits[at].clean && b->alloc_seq == ctx->launch_seq) { b->habits[at].clean = false; continue; }   // holds the byte already; its owner writes it next
+            if (at < 0) {                                                   // a new habit; those it overlaps are stale
+                int keep = 0;
+                for (int h = 0; h < b->nhabits; ++h) if (b->habits[h].off + b->habits[h].bytes <= off || off + bytes <= b->habits[h].off) b->habits[keep++] = b->habits[h];
+                b->nhabits = keep;
+                if (b->nhabits < 4) b->habits[b->nhabits++] = FillHabit{off, bytes, byte, false};
+            } else b->habits[at].clean = false;
+        }
+        out.p[out.n] = fl->f.p[i]; out.bytes[out.n] = fl->f.bytes[i]; out.word[out.n] = fl->f.word[i]; ++out.n;
+        most = std::max<uint64_t>(most, fl->f.bytes[i]);
+    }
+    fl->f = out; fl->most = most;
+}
+static void launch_fill(sdqh_ctx* ctx, const FillList& fl_in) {
+    FillList fl = fl_in;
+    prune_clean(ctx, &fl);
     if (!fl.f.n) return;
+    if (ctx->opt_fill_ahead) {
+        for (auto& b : ctx->pool) {
+            if (!b.free) continue;
+            for (int h = 0; h < b.nhabits && fl.f.n < FILL_BIG; ++h) {
+                FillHabit& hb = b.habits[h];
+                if (hb.clean || hb.off + hb.bytes > b.size || hb.bytes > ((size_t)64 << 20)) continue;
+                fl.add(static_cast<char*>(b.ptr) + hb.off, hb.bytes, (unsigned char)hb.byte);
+                hb.clean = true;
+            }
+        }
+    }
     const uint64_t want = (fl.most / 16 + TPB - 1) / TPB;
     const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(want, 1), (uint64_t)ctx->num_cu * 8);
     LAUNCH(ctx, "k_fill", k_fill, grid, fl.f);
@@ -508,6 +563,7 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "lookup_debug") ctx->opt_lookup_debug = (int)value;
     else if (n == "fuse_small" && value >= 0 && value <= 1) ctx->opt_fuse_small = (int)value;
     else if (n == "lds_key_set" && value >= 0 && value <= 1) ctx->opt_lds_key_set = (int)value;
+    else if (n == "fill_ahead" && value >= 0 && value <= 1) { ctx->opt_fill_ahead = (int)value; for (auto& b : ctx->pool) b.nhabits = 0; }
     else if (n == "str_rows" && (value == 0 || value == 32 || value == 64)) ctx->opt_str_rows = (int)value;
     else if (n == "rank_increasing" && value >= 0 && value <= 1) ctx->opt_rank_increasing = (int)value;
     else if (n == "feature_min_rows" && value >= 0) ctx->opt_feature_min_rows = value;
@@ -1056,7 +1112,8 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
             const unsigned seg_grid = (unsigned)((tb->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
             FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); if (tb->bm) fl.add(tb->bm, tb->nwords * 4, 0); prefill_refs(ctx, tb, &fl);
             DevFill pre; std::memset(&pre, 0, sizeof(pre));
-            if (seg_grid == 1 && ctx->opt_fuse_small && fl.most <= ((uint64_t)1 << 20)) pre = fl.f; else launch_fill(ctx, fl);      // a tiny table: the staging kernel does its own fill
+            prune_clean(ctx, &fl);
+            if (seg_grid == 1 && ctx->opt_fuse_small && fl.most <= ((uint64_t)1 << 20) && fl.f.n <= FILL_MAX) pre = fl.pre(); else launch_fill(ctx, fl);      // a tiny table: the staging kernel does its own fill
             // string predicate: fields staged through LDS, 64 rows per wave at a time (up to 64 KB per workgroup)
             const unsigned str_rows = (f.ns && f.swidth > 0 && f.swidth <= 128) ? (f.swidth <= 64 ? 64u : 32u) : 0u;
             f.slds = str_rows;
@@ -1134,7 +1191,8 @@ int sdqh_build_key_set(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
     FillList fl; fl.add(tb->bm, (tb->nwords * 4 + 15) & ~(uint64_t)15, 0); fl.add(tb->hdr, sizeof(TableHeader), 0);
     DevFill pre; std::memset(&pre, 0, sizeof(pre));
     const unsigned grid0 = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + TPB * ROWS_PER_LOAD * 2 - 1) / (TPB * ROWS_PER_LOAD * 2), (int64_t)ctx->num_cu * ctx->opt_resident_cap));
-    if (nrows > 0 && grid0 == 1 && ctx->opt_fuse_small && fl.most <= ((uint64_t)1 << 20)) pre = fl.f; else launch_fill(ctx, fl);      // a tiny table clears its bitmap in the key-set kernel itself
+    prune_clean(ctx, &fl);
+    if (nrows > 0 && grid0 == 1 && ctx->opt_fuse_small && fl.most <= ((uint64_t)1 << 20) && fl.f.n <= FILL_MAX) pre = fl.pre(); else launch_fill(ctx, fl);      // a tiny table clears its bitmap in the key-set kernel itself
     if (nrows > 0) {
         const int64_t* kc = static_cast<const int64_t*>(key->data);
         const unsigned grid = grid0;
@@ -1709,7 +1767,8 @@ int sdqh_build(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nloo
         // a tiny table (one workgroup of segments): the build kernel does its own fill (a launch less: each is ~8 us of dependent-launch latency)
         FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); fl.add(flags, 8, 0); if (tb->bm) fl.add(tb->bm, tb->nwords * 4, 0); prefill_refs(ctx, tb, &fl);
         DevFill pre; std::memset(&pre, 0, sizeof(pre));
-        if (seg_grid == 1 && ctx->opt_fuse_small && fl.most <= ((uint64_t)1 << 20)) pre = fl.f; else launch_fill(ctx, fl);
+        prune_clean(ctx, &fl);
+        if (seg_grid == 1 && ctx->opt_fuse_small && fl.most <= ((uint64_t)1 << 20) && fl.f.n <= FILL_MAX) pre = fl.pre(); else launch_fill(ctx, fl);
         hipError_t e;
         with_scan_filter(f, [&](auto FC) {
             using FCT = decltype(FC);

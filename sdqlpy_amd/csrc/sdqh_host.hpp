@@ -14,7 +14,17 @@
 
 namespace sdqh_host {
 
-struct PoolBlock { void* ptr; size_t size; bool free; };
+// fill-ahead (launch_fill): a `habit` = a fill this block received in its last use (where in the block, how long, which byte:
+// what the block is used as run after run); `clean` = the block holds that byte there — set by a fill while the block was
+// FREE, void as soon as its owner's fill has consumed it or the block is freed again.
+struct FillHabit { size_t off, bytes; int byte; bool clean; };
+struct PoolBlock {
+    void* ptr; size_t size; bool free;
+    FillHabit habits[4] = {};
+    int nhabits = 0;
+    uint64_t alloc_seq = 0;                        // the ctx's launch counter when the block was handed out
+    bool fill_use = false;                         // this use of the block received (or was spared) a fill: its habits are alive
+};
 struct ProfEntry { const char* name; hipEvent_t e0, e1; double ms; };
 
 constexpr size_t STAGING_BYTES = 32u << 20;       // pinned H2D staging ring: 2 x 32 MiB
@@ -66,6 +76,8 @@ struct sdqh_ctx {
     int opt_packed_slots = 1;                      // hash-layout tables with payload: 32-byte slots { key, payload 0 / 1, owner row }
     int opt_lookup_pipeline = -1;                  // k_lookup_agg requests the next tile's first-lookup keys a step ahead: -1 = when that key column is clustered, 0 / 1 = never / always
     int opt_lookup_debug = 0;
+    int opt_fill_ahead = 1;                        // a fill launch also clears the free blocks later builds of the plan habitually need cleared: their fills find them clean
+    uint64_t launch_seq = 0;                       // kernels launched through KernelScope (fill-ahead: no launch between a block's allocation and its fill)
     int opt_lds_key_set = 1;                       // membership builds on keys in no row order: bitmaps in LDS per workgroup, folded afterwards (no global atomics)
     int opt_fuse_small = 1;                        // tiny tables (one workgroup): fill inside the build kernel, rank + insert in one launch
     int opt_str_rows = 0;                          // rows of text a wave stages in LDS per round in k_key_set: 0 = by field width, 32, 64
@@ -156,6 +168,7 @@ int prefill_direct_refs(sdqh_ctx* ctx, sdqh_table* tb, void** ptr, size_t* bytes
 struct KernelScope {
     sdqh_ctx* ctx; size_t idx = (size_t)-1;
     KernelScope(sdqh_ctx* c, const char* name) : ctx(c) {
+        ++c->launch_seq;
         if (!c->profiling) return;
         if (!c->prof_filter.empty() && c->prof_filter != name) return;
         ProfEntry e{name, next_event(c), next_event(c), 0.0};

@@ -134,6 +134,9 @@ struct DevTable {
 // regions to set to a byte value each (k_fill; also the preamble of a build kernel that runs as ONE workgroup: see fill_in_block)
 constexpr int FILL_MAX = 6;
 struct DevFill { void* p[FILL_MAX]; uint64_t bytes[FILL_MAX]; uint32_t word[FILL_MAX]; int32_t n, _pad; };
+// k_fill's own, longer list: a fill launch also carries the regions later builds of the plan will want cleared (fill-ahead, sdqh_hip.hip)
+constexpr int FILL_BIG = 32;
+struct DevFillBig { void* p[FILL_BIG]; uint64_t bytes[FILL_BIG]; uint32_t word[FILL_BIG]; int32_t n, _pad; };
 // The fill of a tiny table's build, done by the build kernel's own (single) workgroup: a table over a few hundred rows is
 // four launches of ~8 us each (fill, stage, rank, insert) for microseconds of work — two this way (the other pair: k_index_small)
 __device__ __forceinline__ void fill_in_block(const DevFill& f) {
@@ -2784,10 +2787,9 @@ __device__ __forceinline__ uint32_t compact_segment(const DevTable& t, const Dev
 
 // Several small regions set to a byte value by ONE launch (a hipMemsetAsync per region costs a
 // launch each, and most builds need two or three).  Regions are 4-byte multiples, 16-byte aligned.
-SDQH_KERNEL __launch_bounds__(TPB) void k_fill(DevFill f) {
+SDQH_KERNEL __launch_bounds__(TPB) void k_fill(DevFillBig f) {
     const uint64_t tid = (uint64_t)blockIdx.x * TPB + threadIdx.x, nth = (uint64_t)gridDim.x * TPB;
-#pragma unroll
-    for (int r = 0; r < FILL_MAX; ++r) {
+    for (int r = 0; r < FILL_BIG; ++r) {
         if (r >= f.n) break;
         const uint32_t w = f.word[r];
         const uint64_t n16 = f.bytes[r] / 16, n4 = f.bytes[r] / 4;

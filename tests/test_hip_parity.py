@@ -493,6 +493,29 @@ def test_text_byte_twins_change_no_result(hip_engine, oracle_engine, golden, gol
         oracle_engine.clear()
 
 
+def test_fill_ahead_changes_nothing(hip_engine, oracle_engine):
+    """A fill launch also clears the free pool blocks later builds habitually need cleared, and their own fills are then
+    skipped.  Queries interleaved so that blocks change hands between plans and purposes, every run
+    against the CPU implementation; the same sequence with `fill_ahead` 0 must give the same rows."""
+    qs = ["q5", "q3", "q9", "q18", "q5", "q13", "q9", "q3", "q4", "q22", "q3", "q5", "q9", "q16", "q5", "q3"]
+    db = tpch.generate(0.2, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+    want = {}
+    for q in set(qs):
+        r = helpers.run_query(oracle_engine, q, db)
+        want[q] = (r.columns, helpers.result_rows(r, r.columns))
+    oracle_engine.clear()
+    try:
+        for ahead in (1, 0, 1):
+            hip_engine.ctx.set_option("fill_ahead", ahead)
+            for rep in range(2):
+                for q in qs:
+                    r = helpers.run_query(hip_engine, q, db)
+                    helpers.assert_rows_match(helpers.result_rows(r, want[q][0]), want[q][1], REL, "fill_ahead=%d/%s" % (ahead, q))
+    finally:
+        hip_engine.ctx.set_option("fill_ahead", 1)
+        hip_engine.clear()
+
+
 def test_key_sets_on_unordered_keys(hip_engine):
     """Membership builds on keys in no row order go through bitmaps in LDS (one per workgroup, folded afterwards) instead of one
     device-scope atomic per row: ranges below and above one pass of 2^20 keys, short bitmaps (the fold split over chunks of

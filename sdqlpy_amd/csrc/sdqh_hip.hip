@@ -684,6 +684,7 @@ int sdqh_scan_filter_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter
     unsigned grid = 1;
     double* partial = nullptr;
     double* out_dev = static_cast<double*>(ctx->result_dev);
+    rd_dirty(ctx);
     int lrc = with_shape(ctx, tuple->shape, [&](auto S) {
         return with_scan_filter(f, [&](auto FC) {
             using FCT = decltype(FC);
@@ -727,6 +728,7 @@ int sdqh_scan_probe_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter,
     call_begin(ctx);                                   // a hash-layout probe table may have to build its index first
     if (int rc = make_probes(ctx, nrows, nprobes, probes, &pr)) return rc;
     double* out_dev = static_cast<double*>(ctx->result_dev);
+    rd_dirty(ctx);
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + TPB * ROWS_PER_LOAD * 2 - 1) / (TPB * ROWS_PER_LOAD * 2), (int64_t)ctx->num_cu * ctx->opt_resident_cap));
     double* partial = static_cast<double*>(pool_alloc(ctx, (size_t)grid * 5 * sizeof(double)));
     if (!partial) return fail(ctx, SDQH_ERR_NOMEM, "scan_probe_sum: out of device memory");
@@ -799,10 +801,14 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
             pacc = reinterpret_cast<double*>(blob);
             pcnt = reinterpret_cast<int64_t*>(blob + nslots * 32);
             call_begin(ctx);
-            FillList fl;
-            fl.add(r_keys, GMAX * 8, 0xFF);                                          // every global group slot EMPTY_GROUP
-            fl.add(r_ng, 8, 0);
-            launch_fill(ctx, fl);
+            const bool clean = ctx->opt_fill_ahead && ctx->rd_clean_ff >= (size_t)GMAX * 8 && ctx->rd_clean_zero_off == (int64_t)GMAX * 48;   // left so by the last merge
+            rd_dirty(ctx);
+            if (!clean) {
+                FillList fl;
+                fl.add(r_keys, GMAX * 8, 0xFF);                                      // every global group slot EMPTY_GROUP
+                fl.add(r_ng, 8, 0);
+                launch_fill(ctx, fl);
+            }
             return SDQH_OK;
         };
         int lrc = with_shape(ctx, tuple->shape, [&](auto S) {
@@ -848,7 +854,8 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
         {   // the merge writes the result block straight into the pinned host block (same layout as rd)
             char* hb = static_cast<char*>(ctx->result_host);
             LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, GMAX, r_keys, pacc, pcnt, (int)grid, reinterpret_cast<double*>(hb + GMAX * 8), reinterpret_cast<int64_t*>(hb + GMAX * 40),
-                   reinterpret_cast<unsigned long long*>(hb), static_cast<const int*>(r_ng), reinterpret_cast<int*>(hb + GMAX * 48));
+                   reinterpret_cast<unsigned long long*>(hb), r_ng, reinterpret_cast<int*>(hb + GMAX * 48), 1);
+            ctx->rd_clean_ff = (size_t)GMAX * 8; ctx->rd_clean_zero_off = (int64_t)GMAX * 48;
         }
         call_end(ctx);
         (void)rbytes;
@@ -1887,6 +1894,11 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
     int64_t* r_cnt = reinterpret_cast<int64_t*>(rd + LG_SLOTS * 40);
     int* r_flags = reinterpret_cast<int*>(rd + LG_SLOTS * 48);
     static_assert(LG_SLOTS * 48 + 8 <= RESULT_BYTES, "result block too small");
+    auto rd_clean_lg = [&]() {                               // the group slots and the flags as the last merge left them: no fill; either way they are about to be written
+        const bool clean = ctx->opt_fill_ahead && ctx->rd_clean_ff >= (size_t)LG_SLOTS * 8 && ctx->rd_clean_zero_off == (int64_t)LG_SLOTS * 48;
+        rd_dirty(ctx);
+        return clean;
+    };
     // the merge writes the result block straight into the pinned host block (same layout): no copy-engine launch after it
     char* hb = static_cast<char*>(ctx->result_host);
     unsigned long long* h_keys = reinterpret_cast<unsigned long long*>(hb);
@@ -1926,9 +1938,10 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
                     if (!blob) return fail(ctx, SDQH_ERR_NOMEM, "lookup_aggregate: out of device memory");
                     double* pacc = reinterpret_cast<double*>(blob);
                     int64_t* pcnt = reinterpret_cast<int64_t*>(blob + nslots * 32);
-                    { FillList fl; fl.add(r_keys, LG_SLOTS * 8, 0xFF); fl.add(r_flags, 8, 0); launch_fill(ctx, fl); }
+                    if (!rd_clean_lg()) { FillList fl; fl.add(r_keys, LG_SLOTS * 8, 0xFF); fl.add(r_flags, 8, 0); launch_fill(ctx, fl); }
                     { KernelScope _ks(ctx, "k_lookup_agg"); hipLaunchKernelGGL(big, dim3(grid), dim3(BIG_BT), coarse_lds, ctx->stream, f, L, spec, nrows, r_keys, pacc, pcnt, r_flags, ctx->opt_probe_chunk, nkey0); }
-                    LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, r_keys, pacc, pcnt, (int)grid, h_acc, h_cnt, h_keys, static_cast<const int*>(r_flags), h_tail);
+                    LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, r_keys, pacc, pcnt, (int)grid, h_acc, h_cnt, h_keys, r_flags, h_tail, 1);
+                    ctx->rd_clean_ff = (size_t)LG_SLOTS * 8; ctx->rd_clean_zero_off = (int64_t)LG_SLOTS * 48;
                     call_end(ctx);
                     return SDQH_OK;
                 }
@@ -1943,9 +1956,10 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
             if (!blob) return fail(ctx, SDQH_ERR_NOMEM, "lookup_aggregate: out of device memory");
             double* pacc = reinterpret_cast<double*>(blob);
             int64_t* pcnt = reinterpret_cast<int64_t*>(blob + nslots * 32);
-            { FillList fl; fl.add(r_keys, LG_SLOTS * 8, 0xFF); fl.add(r_flags, 8, 0); launch_fill(ctx, fl); }
+            if (!rd_clean_lg()) { FillList fl; fl.add(r_keys, LG_SLOTS * 8, 0xFF); fl.add(r_flags, 8, 0); launch_fill(ctx, fl); }
             LAUNCH(ctx, "k_lookup_agg", kern, grid, f, L, spec, nrows, r_keys, pacc, pcnt, r_flags, ctx->opt_probe_chunk, nkey0);
-            LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, r_keys, pacc, pcnt, (int)grid, h_acc, h_cnt, h_keys, static_cast<const int*>(r_flags), h_tail);
+            LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, r_keys, pacc, pcnt, (int)grid, h_acc, h_cnt, h_keys, r_flags, h_tail, 1);
+                    ctx->rd_clean_ff = (size_t)LG_SLOTS * 8; ctx->rd_clean_zero_off = (int64_t)LG_SLOTS * 48;
             call_end(ctx);
             return SDQH_OK;
         });
@@ -2132,7 +2146,7 @@ void launch_sum_partials(sdqh_ctx* ctx, const double* partial, int nparts, doubl
     LAUNCH(ctx, "k_sum_partials", k_sum_partials, 1, partial, nparts, out);
 }
 void launch_groupby_merge_lg(sdqh_ctx* ctx, const unsigned long long* gkeys, const double* pacc, const int64_t* pcnt, int nparts, double* out_acc, int64_t* out_cnt) {
-    LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, gkeys, pacc, pcnt, nparts, out_acc, out_cnt, static_cast<unsigned long long*>(nullptr), static_cast<const int*>(nullptr), static_cast<int*>(nullptr));
+    LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, const_cast<unsigned long long*>(gkeys), pacc, pcnt, nparts, out_acc, out_cnt, static_cast<unsigned long long*>(nullptr), static_cast<int*>(nullptr), static_cast<int*>(nullptr), 0);
 }
 int column_minmax(sdqh_ctx* ctx, sdqh_column* c) { return ensure_minmax(ctx, c); }
 const void* column_narrow(sdqh_ctx* ctx, sdqh_column* c) { return ensure_narrow(ctx, c); }

@@ -76,6 +76,9 @@ struct sdqh_ctx {
     int opt_packed_slots = 1;                      // hash-layout tables with payload: 32-byte slots { key, payload 0 / 1, owner row }
     int opt_lookup_pipeline = -1;                  // k_lookup_agg requests the next tile's first-lookup keys a step ahead: -1 = when that key column is clustered, 0 / 1 = never / always
     int opt_lookup_debug = 0;
+    // what the result block (result_dev) is known to hold, left so by a self-resetting k_groupby_merge: rd_clean_ff leading bytes
+    // of 0xFF and eight zero bytes at rd_clean_zero_off (-1: none).  Every other writer of the block voids it (rd_dirty).
+    size_t rd_clean_ff = 0; int64_t rd_clean_zero_off = -1;
     int opt_fill_ahead = 1;                        // a fill launch also clears the free blocks later builds of the plan habitually need cleared: their fills find them clean
     uint64_t launch_seq = 0;                       // kernels launched through KernelScope (fill-ahead: no launch between a block's allocation and its fill)
     int opt_lds_key_set = 1;                       // membership builds on keys in no row order: bitmaps in LDS per workgroup, folded afterwards (no global atomics)
@@ -163,6 +166,8 @@ void launch_sum_partials(sdqh_ctx* ctx, const double* partial, int nparts, doubl
 void launch_groupby_merge_lg(sdqh_ctx* ctx, const unsigned long long* gkeys, const double* pacc, const int64_t* pcnt, int nparts, double* out_acc, int64_t* out_cnt);
 // small direct-layout tables: the rank -> row array is allocated up front; *ptr / *bytes = a region to fill with 0xFF (null: none)
 int prefill_direct_refs(sdqh_ctx* ctx, sdqh_table* tb, void** ptr, size_t* bytes);   // regions (<= 2) to fill with 0xFF; returns their number
+
+inline void rd_dirty(sdqh_ctx* c) { c->rd_clean_ff = 0; c->rd_clean_zero_off = -1; }
 
 // event pair around one launch when profiling is on (same bookkeeping as the LAUNCH macro)
 struct KernelScope {

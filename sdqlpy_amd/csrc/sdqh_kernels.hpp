@@ -1029,15 +1029,18 @@ __global__ __launch_bounds__(TPB) void k_groupby_lds(DevFilter f, DevTuple t, De
 // out_keys / out_tail (optional): the group keys and the 8 bytes after the block (group count / flags) are copied along, so that
 // out_* can be the caller's pinned host block itself — the result is on the host when the stream is idle, without a copy-engine
 // launch after the kernel (one API call and one DMA round trip less per group-by call)
-SDQH_KERNEL __launch_bounds__(TPB) void k_groupby_merge(const unsigned long long* __restrict__ gkeys, const double* __restrict__ pacc,
+// reset: the kernel is the last reader of the group-key slots and of the tail; it leaves them as the next call's fill would
+// (EMPTY_GROUP / zero), so that call launches no fill (sdqh_hip.hip: rd_clean_*)
+SDQH_KERNEL __launch_bounds__(TPB) void k_groupby_merge(unsigned long long* __restrict__ gkeys, const double* __restrict__ pacc,
                                                        const int64_t* __restrict__ pcnt, int nparts,
                                                        double* __restrict__ out_acc, int64_t* __restrict__ out_cnt,
-                                                       unsigned long long* __restrict__ out_keys, const int* __restrict__ d_tail, int* __restrict__ out_tail) {
+                                                       unsigned long long* __restrict__ out_keys, int* __restrict__ d_tail, int* __restrict__ out_tail, int reset) {
     __shared__ double s_red[5][TPB];
     const int g = blockIdx.x;
-    if (threadIdx.x == 0 && out_keys) out_keys[g] = gkeys[g];
-    if (g == 0 && threadIdx.x == 0 && out_tail) { out_tail[0] = d_tail[0]; out_tail[1] = d_tail[1]; }
-    if (gkeys[g] == EMPTY_GROUP) { if (threadIdx.x == 0) out_cnt[g] = 0; return; }
+    const unsigned long long gkey = gkeys[g];
+    if (threadIdx.x == 0 && out_keys) out_keys[g] = gkey;
+    if (g == 0 && threadIdx.x == 0 && out_tail) { out_tail[0] = d_tail[0]; out_tail[1] = d_tail[1]; if (reset) { d_tail[0] = 0; d_tail[1] = 0; } }
+    if (gkey == EMPTY_GROUP) { if (threadIdx.x == 0) out_cnt[g] = 0; return; }
     double a[4] = {0, 0, 0, 0};
     int64_t c = 0;
     constexpr int BB = 4;
@@ -1069,6 +1072,7 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_groupby_merge(const unsigned long long
 #pragma unroll
         for (int k = 0; k < 4; ++k) out_acc[g * 4 + k] = s_red[k][0];
         out_cnt[g] = reinterpret_cast<int64_t*>(s_red[4])[0];
+        if (reset) gkeys[g] = EMPTY_GROUP;                 // every thread of the block read its copy before the barriers above
     }
 }
 

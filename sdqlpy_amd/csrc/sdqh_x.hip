@@ -608,6 +608,7 @@ int sdqh_xscan_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, doubl
     if (int rc = kernel_for(ctx, x, SINK_SUM, x.direct, &fn)) return rc;
     call_begin(ctx);
     XArgs a;
+    rd_dirty(ctx);
     int32_t* d_flags = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->result_dev) + 1024);
     if (int rc = fill_xargs(ctx, x, &a, d_flags, 1, 0)) return rc;
     const Geometry g = geometry(ctx, nrows, x.direct, 16);
@@ -641,6 +642,7 @@ int sdqh_xgroupby(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int ma
     if (int rc = kernel_for(ctx, x, SINK_GROUP, x.direct, &fn)) return rc;
     call_begin(ctx);
     // result block in ctx->result_dev: gkeys[LG_SLOTS] | acc[LG_SLOTS][4] | cnt[LG_SLOTS] | flags
+    rd_dirty(ctx);
     char* rd = static_cast<char*>(ctx->result_dev);
     unsigned long long* r_keys = reinterpret_cast<unsigned long long*>(rd);
     double* r_acc = reinterpret_cast<double*>(rd + LG_SLOTS * 8);
@@ -814,6 +816,7 @@ int sdqh_xprobe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog
     table->nv = prog->nvals;
     call_begin(ctx);
     XArgs a;
+    rd_dirty(ctx);
     int32_t* d_flags = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->result_dev) + 1024);
     if (int rc = fill_xargs(ctx, x, &a, d_flags, 1, 0)) return rc;
     const Geometry g = geometry(ctx, nrows, false, 24);

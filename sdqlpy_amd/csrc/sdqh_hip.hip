@@ -781,8 +781,9 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
     unsigned long long* r_keys = reinterpret_cast<unsigned long long*>(rd);
     double* r_acc = reinterpret_cast<double*>(rd + GMAX * 8);
     int64_t* r_cnt = reinterpret_cast<int64_t*>(rd + GMAX * 40);
-    int* r_ng = reinterpret_cast<int*>(rd + GMAX * 48);
+    int* r_ng = reinterpret_cast<int*>(rd + LG_SLOTS * 48);          // (group count, flags): where lookup_aggregate keeps its flags, so either call finds the other's tail reset
     int* r_flags = r_ng + 1;
+    size_t rd_ff_before = 0;                                          // leading 0xFF bytes of the block this call found (its kernels touch the first GMAX * 8 only, and the merge resets those)
     const size_t rbytes = GMAX * 48 + 8;
     int rc = SDQH_OK;
     const char* h = static_cast<const char*>(ctx->result_host);
@@ -801,7 +802,8 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
             pacc = reinterpret_cast<double*>(blob);
             pcnt = reinterpret_cast<int64_t*>(blob + nslots * 32);
             call_begin(ctx);
-            const bool clean = ctx->opt_fill_ahead && ctx->rd_clean_ff >= (size_t)GMAX * 8 && ctx->rd_clean_zero_off == (int64_t)GMAX * 48;   // left so by the last merge
+            const bool clean = ctx->opt_fill_ahead && ctx->rd_clean_ff >= (size_t)GMAX * 8 && ctx->rd_clean_zero_off == (int64_t)LG_SLOTS * 48;   // left so by the last merge
+            rd_ff_before = clean ? ctx->rd_clean_ff : 0;
             rd_dirty(ctx);
             if (!clean) {
                 FillList fl;
@@ -855,7 +857,7 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
             char* hb = static_cast<char*>(ctx->result_host);
             LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, GMAX, r_keys, pacc, pcnt, (int)grid, reinterpret_cast<double*>(hb + GMAX * 8), reinterpret_cast<int64_t*>(hb + GMAX * 40),
                    reinterpret_cast<unsigned long long*>(hb), r_ng, reinterpret_cast<int*>(hb + GMAX * 48), 1);
-            ctx->rd_clean_ff = (size_t)GMAX * 8; ctx->rd_clean_zero_off = (int64_t)GMAX * 48;
+            ctx->rd_clean_ff = std::max<size_t>((size_t)GMAX * 8, rd_ff_before); ctx->rd_clean_zero_off = (int64_t)LG_SLOTS * 48;
         }
         call_end(ctx);
         (void)rbytes;

@@ -123,15 +123,22 @@ static void prune_clean(sdqh_ctx* ctx, FillList* fl) {
         const int byte = (int)(fl->f.word[i] & 0xFFu);
         if (b && !b->free) {
             const size_t off = (size_t)(static_cast<const char*>(fl->f.p[i]) - static_cast<const char*>(b->ptr)), bytes = fl->f.bytes[i];
+            // a habit of the same byte that covers the region serves it (blocks change hands between plans: the customers' bitmap of
+            // one query is the parts' of the next, a little shorter or longer)
             int at = -1;
-            for (int h = 0; h < b->nhabits; ++h) if (b->habits[h].off == off && b->habits[h].bytes == bytes && b->habits[h].byte == byte) at = h;
+            for (int h = 0; h < b->nhabits; ++h) if (b->habits[h].byte == byte && b->habits[h].off <= off && b->habits[h].off + b->habits[h].bytes >= off + bytes) at = h;
             b->fill_use = true;
             if (at >= 0 && b->habits[at].clean && b->alloc_seq == ctx->launch_seq) { b->habits[at].clean = false; continue; }   // holds the byte already; its owner writes it next
-            if (at < 0) {                                                   // a new habit; those it overlaps are stale
+            if (at < 0) {                                                   // a new habit: overlapping ones of the same byte grow into it, others are stale
+                size_t lo = off, hi = off + bytes;
                 int keep = 0;
-                for (int h = 0; h < b->nhabits; ++h) if (b->habits[h].off + b->habits[h].bytes <= off || off + bytes <= b->habits[h].off) b->habits[keep++] = b->habits[h];
+                for (int h = 0; h < b->nhabits; ++h) {
+                    const FillHabit& o = b->habits[h];
+                    if (o.off + o.bytes <= off || off + bytes <= o.off) { b->habits[keep++] = o; continue; }
+                    if (o.byte == byte) { lo = std::min(lo, o.off); hi = std::max(hi, o.off + o.bytes); }
+                }
                 b->nhabits = keep;
-                if (b->nhabits < 4) b->habits[b->nhabits++] = FillHabit{off, bytes, byte, false};
+                if (b->nhabits < 4) b->habits[b->nhabits++] = FillHabit{lo, hi - lo, byte, false};
             } else b->habits[at].clean = false;
         }
         out.p[out.n] = fl->f.p[i]; out.bytes[out.n] = fl->f.bytes[i]; out.word[out.n] = fl->f.word[i]; ++out.n;

@@ -121,7 +121,9 @@ def main(argv=None, hooks=None):
     t0 = time.time()
     need = tpch.columns_for(queries + extra)
     tables = sorted(need)
-    shard = (rank, world) if world > 1 else None
+    # the distributed plan runs on tables that SAY they are row shards (dist.DistributedRunner._whole_params):
+    # also on a group of one, where the shard is the whole table and every collective still executes
+    shard = (rank, world) if use_dist else None
     sf_global = args.global_sf if args.global_sf > 0 else args.sf * world
     sf_per_gpu = sf_global / world
     db = tpch.generate(sf_global, tables=tables, columns=need, shard=shard)
@@ -192,7 +194,19 @@ def main(argv=None, hooks=None):
             at = upto
         return took, per_q, log
 
+    if runner is not None:
+        runner.reset_collectives()
     elapsed, per_query_ms, timed_log = run_steps(args.steps, dom_kernel)
+    timed_collectives = None
+    if runner is not None:
+        timed_collectives = {k: {"calls": v[0], "on_device_tensors": v[1], "bytes": v[2]} for k, v in sorted(runner.collectives.items())}
+        if "q3" in queries:
+            # a "distributed" step that took the single-GPU plan measures nothing (round 2's world-1 profile did)
+            assert runner.last_partitioning == args.partition or (args.partition == "auto" and runner.last_partitioning in ("range", "hash")), \
+                "q3 did not run the partitioned join (partitioning %r)" % (runner.last_partitioning,)
+            assert runner.collectives.get("all_to_all", [0])[0] > 0 or runner.last_partitioning == "range", "no all-to-all ran in the timed step"
+            if args.partition == "hash":
+                assert runner.exchanged_rows.get("probe_sent", 0) > 0, runner.exchanged_rows
     dom_launches = [ms for q, name, ms in timed_log if q == dom_q and name == dom_kernel]
     # per-kernel table: a separate pass with events around every launch, after the timed region
     profile_steps = max(1, min(args.steps, 10))
@@ -301,6 +315,8 @@ def main(argv=None, hooks=None):
         }
         if exchange is not None:
             out["q3_exchange"] = exchange
+        if timed_collectives is not None:
+            out["collectives_in_timed_region_rank0"] = timed_collectives
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, queries, db, rows)
         os.write(json_fd, (json.dumps(out) + "\n").encode())

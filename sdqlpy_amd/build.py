@@ -21,7 +21,8 @@ TBL_LIB = os.path.join(CSRC, "libsdqltbl.so")
 # sources so a change to one does not recompile the other.
 HIP_UNITS = [("sdqh_hip.hip", "sdqh_hip.o"), ("sdqh_x.hip", "sdqh_x.o")]
 HIP_SOURCES = [os.path.join(CSRC, src) for src, _ in HIP_UNITS]
-HIP_HEADERS = [os.path.join(INCLUDE, "sdqh.h"), os.path.join(CSRC, "sdqh_kernels.hpp"), os.path.join(CSRC, "sdqh_host.hpp")]
+HIP_HEADERS = [os.path.join(INCLUDE, "sdqh.h"), os.path.join(CSRC, "sdqh_kernels.hpp"), os.path.join(CSRC, "sdqh_host.hpp"),
+               os.path.join(CSRC, "sdqh_xkernels.hpp")]      # sdqh_x.hip packs XArgs / sink arguments from its structs
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-ffp-contract=off",          # keep the reference's a*(1.0-b) association: no FMA contraction

@@ -64,6 +64,18 @@ class DistributedRunner:
         self._top = None                    # (k, order) while a run carries ORDER BY ... LIMIT k
         self._partitioned_result = False    # the last run returned this rank's key partition (else the global result)
         self._local_text = set()            # ids of text arrays / dictionaries that only mean something on this rank
+        self._whole_checked = {}            # ids of the "whole" argument tables already verified across the ranks
+        # every collective this runner issued since the last reset_collectives(): name -> [calls, calls on device tensors, bytes]
+        self.collectives = {}
+
+    def reset_collectives(self):
+        self.collectives = {}
+
+    def _note(self, name, tensor):
+        rec = self.collectives.setdefault(name, [0, 0, 0])
+        rec[0] += 1
+        rec[1] += 1 if tensor.is_cuda else 0
+        rec[2] += tensor.numel() * tensor.element_size()
 
     # ---- small collectives ---------------------------------------------------------------------
     def _all_gather_array(self, arr):
@@ -74,6 +86,7 @@ class DistributedRunner:
         if self.backend != "nccl":
             t = torch.from_numpy(arr)
             out = [torch.empty_like(t) for _ in range(self.world)]
+            self._note("all_gather", t)
             dist.all_gather(out, t, group=self.group)
             return [o.numpy() for o in out]
         key = (arr.shape, arr.dtype.str)
@@ -87,6 +100,7 @@ class DistributedRunner:
         h_in, d_in, d_out, h_out = bufs
         h_in.numpy()[:] = arr.reshape(-1)
         d_in.copy_(h_in, non_blocking=True)
+        self._note("all_gather", d_in)
         dist.all_gather_into_tensor(d_out, d_in, group=self.group)
         h_out.copy_(d_out, non_blocking=True)
         torch.cuda.current_stream().synchronize()
@@ -116,6 +130,7 @@ class DistributedRunner:
                 self.ctx.copy_out(col, 0, n, send.data_ptr() + j * m * 8)      # queued ("async_copies")
             self.ctx.synchronize()                                           # one wait for all of them before the collective reads
         recv = torch.empty(m * k * self.world, dtype=torch.int64, device=self.device)
+        self._note("all_gather", send)
         if self.backend == "nccl":
             dist.all_gather_into_tensor(recv, send, group=self.group)
             torch.cuda.current_stream().synchronize()
@@ -145,6 +160,7 @@ class DistributedRunner:
 
     def _a2a(self, recv, send, out_splits, in_splits):
         """all_to_all_single; gloo has no all-to-all, so there it is spelled as isend / irecv pairs."""
+        self._note("all_to_all", send)
         if self.backend == "nccl":
             dist.all_to_all_single(recv, send, out_splits, in_splits, group=self.group)
             return
@@ -209,8 +225,44 @@ class DistributedRunner:
         names) wins; otherwise the tables say it themselves: a table cut by tpch.generate(shard=...) /
         sdql_lib.shard_rows carries `.shard = (rank, world)`, every other table is whole."""
         if whole_tables is not None:
-            return {p for p, t in zip(plan.params, Q.tables_of(fn)) if t in whole_tables}
-        return {p for p, a in zip(plan.params, args) if getattr(a, "shard", None) is None}
+            whole = {p for p, t in zip(plan.params, Q.tables_of(fn)) if t in whole_tables}
+        else:
+            whole = {p for p, a in zip(plan.params, args) if getattr(a, "shard", None) is None}
+            if self.world > 1 and len(whole) == len(plan.params):
+                # the mark is an attribute of the table object: a table rebuilt from a shard's columns has lost it, and
+                # every rank would then answer for its slice alone with no collective — a silently partial result
+                raise ValueError("%s: with %d ranks and no `whole_tables`, at least one argument must carry a row-shard mark "
+                                 "(sdql_lib.shard_rows / tpch.generate(shard=...)); pass whole_tables=[...] to say which "
+                                 "tables every rank holds completely" % (plan.name, self.world))
+        self._verify_whole(plan, args, whole)
+        return whole
+
+    def _verify_whole(self, plan, args, whole):
+        """A table taken as whole must be the same table on every rank: row count and a checksum of its first and
+        last rows are all-gathered once per table object, and a disagreement (a shard that lost its mark) raises
+        on every rank alike instead of producing a partial answer."""
+        if self.world == 1:
+            return
+        todo = [(p, a) for p, a in zip(plan.params, args) if p in whole and self._whole_checked.get(id(a)) is not a]
+        if not todo:
+            return
+        facts = np.zeros((len(todo), 2), np.int64)
+        for i, (_, a) in enumerate(todo):
+            data = a.getContainer()["data"]
+            n = len(data[0]) if data else 0
+            h = 1469598103934665603                      # FNV-style fold of the edge rows' bytes, as a Python int
+            for col in data:
+                if len(col):
+                    edge = np.concatenate([np.ascontiguousarray(col[:64]).view(np.uint8), np.ascontiguousarray(col[-64:]).view(np.uint8)])
+                    h = ((h ^ int(edge.astype(np.uint64).sum())) * 1099511628211) & 0x7FFFFFFFFFFFFFFF
+            facts[i] = (n, h)
+        parts = self._all_gather_array(facts)
+        bad = [p for i, (p, _) in enumerate(todo) if any((part[i] != parts[0][i]).any() for part in parts)]
+        if bad:
+            raise ValueError("%s: table(s) %s are taken as whole on every rank but differ between ranks — mark row shards with "
+                             "sdql_lib.shard_rows(table, rank, world) or name the whole tables explicitly" % (plan.name, ", ".join(sorted(bad))))
+        for _, a in todo:
+            self._whole_checked[id(a)] = a
 
     @staticmethod
     def _shape(plan):
@@ -693,6 +745,7 @@ class DistributedRunner:
             words = ctx.wrap(buf.data_ptr(), n64, abi.I64, keepalive=buf)
             ctx.table_export_bitmap(local, lo, hi, into=words)
             local.free()
+            self._note("all_reduce", buf)
             dist.all_reduce(buf, group=self.group)
             if self.backend == "nccl":
                 torch.cuda.current_stream().synchronize()

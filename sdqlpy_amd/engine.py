@@ -726,7 +726,9 @@ def _merge_equal_keys(d):
     if n > 4096:                                             # large results: sort-based grouping in numpy
         cols = [a for _, a in d.key_fields]
         # an integer stand-in per column: dictionary codes as they are (equal code <=> equal text), other text factorised
-        ints = [c.refs if isinstance(c, TextRefs) and c.distinct else (np.unique(np.asarray(c), return_inverse=True)[1] if c.dtype.kind == "U" else np.asarray(c)) for c in cols]
+        # (equal code <=> equal text), text and floating-point columns factorised (np.unique: NaNs fold into one code)
+        ints = [c.refs if isinstance(c, TextRefs) and c.distinct else
+                (np.asarray(c) if np.asarray(c).dtype.kind in "iu" else np.unique(np.asarray(c), return_inverse=True)[1].reshape(-1)) for c in cols]
         lo = [int(c.min()) for c in ints]
         span = [int(c.max()) - l + 1 for c, l in zip(ints, lo)]
         cells = 1

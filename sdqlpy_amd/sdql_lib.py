@@ -224,8 +224,10 @@ def _column_types(header_type_dict):
     return list(fields.keys()), list(fields.values())
 
 
-def table_from_columns(headers, columns):
-    """Columnar table from ready numpy arrays (int64 / float64 / '<U n'), the layout read_csv yields."""
+def table_from_columns(headers, columns, shard=None):
+    """Columnar table from ready numpy arrays (int64 / float64 / '<U n'), the layout read_csv yields.
+    `shard` = (rank, world) marks the result as one rank's row shard of a larger table (see shard_rows):
+    a table derived from a shard's columns must carry its mark on, or a multi-GPU run takes it for whole."""
     cols = []
     n = None
     for h, c in zip(headers, columns):
@@ -241,7 +243,10 @@ def table_from_columns(headers, columns):
         elif len(c) != n:
             raise ValueError("column %s has %d rows, expected %d" % (h, len(c), n))
         cols.append(c)
-    return sr_dict({"headers": list(headers), "data": cols}, None, True)
+    out = sr_dict({"headers": list(headers), "data": cols}, None, True)
+    if shard is not None:
+        out.shard = (int(shard[0]), int(shard[1]))
+    return out
 
 
 def shard_rows(table, rank, world):

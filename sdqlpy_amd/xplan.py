@@ -18,7 +18,7 @@ import numpy as np
 from . import abi
 from .frontend import (And, Bin, Call, Cmp, Col, Const, Contains, IfElse, Lookup, Not, Or, PayloadField, RecordCons,
                        ScalarField, StrIn, UnsupportedQuery, WholeKey)
-from .result import DictResult, ResultSet, TextRefs, decode_text
+from .result import Dictionary, DictResult, ResultSet, TextRefs, decode_text
 
 MAX_CODE_SET = 8          # a text predicate on coded values becomes at most this many equality tests (or one range)
 
@@ -336,8 +336,15 @@ class Compiler:
             elif a.t != b.t:
                 a, b = self.as_float(a), self.as_float(b)
             elif a.dec is not None or b.dec is not None:
+                # integers that stand for text.  Codes of ONE dictionary with pairwise distinct entries compare
+                # equal exactly when the texts do; their ORDER is not text order, and row references into a raw text
+                # column are not even equal for equal texts in different rows
                 if a.dec is not b.dec:
                     self.fail("comparing references into different texts")
+                if not isinstance(a.dec, Dictionary):
+                    self.fail("comparing two texts given as row references (not dictionary codes) is not supported")
+                if op not in ("==", "!="):
+                    self.fail("text supports == / != only (dictionary codes are not in text order)")
             return XV(self.P.op(_CMP[op], abi.T_BOOL, a=a.id, b=b.id), "b")
         v = self.value(e)
         if isinstance(v, XV) and v.t == "b":

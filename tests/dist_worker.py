@@ -114,6 +114,27 @@ def main(rank, world, port, sf, mode, out_path):
         out["q10"] = {"ran": True}
     except frontend.UnsupportedQuery as exc:
         out["q10"] = {"unsupported": str(exc)}
+    # a shard that lost its mark (rebuilt from its columns): refused by every rank instead of a partial answer
+    stripped = {t: (tbl if getattr(tbl, "shard", None) is None else
+                    tpch.table_from_columns(tbl.getContainer()["headers"], tbl.getContainer()["data"])) for t, tbl in db.items()}
+    out["unmarked"] = {}
+    for q in ("q6", "q3"):
+        try:
+            runner.run(q, stripped)
+            out["unmarked"][q] = "ran"
+        except ValueError as exc:
+            out["unmarked"][q] = str(exc)
+    # ... and a table NAMED whole that differs between the ranks is caught by the cross-rank check
+    try:
+        runner.run("q3", stripped, whole_tables=("customer",))
+        out["whole_mismatch"] = "ran"
+    except (ValueError, frontend.UnsupportedQuery) as exc:
+        out["whole_mismatch"] = str(exc)
+    # the mark carried on through table_from_columns(shard=...)
+    kept = {t: (tbl if getattr(tbl, "shard", None) is None else
+                tpch.table_from_columns(tbl.getContainer()["headers"], tbl.getContainer()["data"], shard=tbl.shard)) for t, tbl in db.items()}
+    out["q6_remarked"] = runner.run("q6", kept)
+    out["collectives"] = {k: v[:2] for k, v in runner.collectives.items()}
     if rank == 0:
         with open(out_path, "w") as fh:
             json.dump(out, fh)

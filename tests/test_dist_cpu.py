@@ -101,6 +101,14 @@ def test_two_ranks_match_single_process(mode, tmp_path, single, oracle_lib):
     assert got["q6_decorated"] == got["q6"]
     assert sorted(as_rows(got["q3_decorated"]["rows"])) == sorted(as_rows(got["q3"]["rows"]))
     assert as_rows(got["q3_decorated_top"]) == as_rows(got["q3_top"]["rows"])
+    # tables that lost their shard mark: refused (never a silently partial answer); a "whole" table that differs
+    # between the ranks: caught by the cross-rank row-count / checksum test; the mark carried on: same answer
+    for q in ("q6", "q3"):
+        assert "row-shard mark" in got["unmarked"][q], got["unmarked"]
+    assert "differ between ranks" in got["whole_mismatch"], got["whole_mismatch"]
+    assert got["q6_remarked"] == got["q6"]
+    assert got["collectives"]["all_gather"][0] > 0
+    assert (got["collectives"].get("all_to_all", [0])[0] > 0) == (mode != "range")        # co-clustered shards: nothing to exchange
 
 
 def test_four_ranks_match_single_process(tmp_path, single, oracle_lib):

@@ -707,30 +707,93 @@ def test_redistribution_helpers_match_oracle(hip_engine, oracle_engine):
 
 
 def test_distributed_runner_world1_nccl(hip_lib, golden, golden_more):
-    """The distributed plan end to end on one GPU (RCCL group of size 1): exercises the torch-tensor
-    exchange buffers, the count exchange and all_to_all_single on device memory."""
+    """The distributed plan end to end on one GPU (RCCL group of size 1).  The tables carry row-shard marks
+    (shard 0 of 1), so the runner takes the PARTITIONED plans — an unmarked table is "whole" and would send every
+    query down the single-GPU plan with no collective at all (round 2's hole).  Asserted, not assumed: q3 is
+    partitioned, rows go through the exchange, and all_to_all_single / all_gather / all_reduce run on DEVICE
+    tensors (torch.distributed wrapped); then SF=1 against the single-GPU plan."""
     import torch
     import torch.distributed as dist
     from sdqlpy_amd import dist as sdist
+    from sdqlpy_amd.sdql_lib import shard_rows
     if not dist.is_initialized():
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29591", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    calls = []
+    real = {n: getattr(dist, n) for n in ("all_to_all_single", "all_gather_into_tensor", "all_reduce")}
+
+    def spy(name):
+        def wrapped(*a, **kw):
+            t = next(x for x in a if isinstance(x, torch.Tensor))
+            calls.append((name, bool(t.is_cuda), int(t.numel())))
+            return real[name](*a, **kw)
+        return wrapped
+    for n in real:
+        setattr(dist, n, spy(n))
+
+    def marked(db):
+        return {t: (tbl if t in ("region", "nation") else shard_rows(tbl, 0, 1)) for t, tbl in db.items()}
     eng = engine.Engine(hip_lib.context(device=0))
     try:
         case = next(c for c in golden["cases"] if c["name"] == "small")
-        db = helpers.case_db(case)
+        db = marked(helpers.case_db(case))
         for part in ("auto", "hash"):
             runner = sdist.DistributedRunner(eng, 0, 1, partition=part)
             for q in SUPPORTED:
+                del calls[:]
                 helpers.check_against_golden(runner.run(q, db), case["results"][q], REL, "dist1/%s/%s" % (part, q))
+                assert calls and all(dev for _, dev, _ in calls), (q, part, calls)       # collectives ran, on device memory
+                if q == "q3":
+                    assert runner.last_partitioning == {"auto": "range", "hash": "hash"}[part]
+                    a2a = [c for c in calls if c[0] == "all_to_all_single"]
+                    if part == "hash":
+                        assert runner.exchanged_rows["build"] > 0 and runner.exchanged_rows["probe_sent"] > 0, runner.exchanged_rows
+                        assert runner.exchanged_rows["probe_received"] == runner.exchanged_rows["probe_sent"]
+                        assert len(a2a) >= 2 and sum(n for _, _, n in a2a) >= runner.exchanged_rows["probe_sent"], a2a
+                        assert runner.collectives["all_to_all"][1] == runner.collectives["all_to_all"][0] > 0
+                    else:
+                        assert runner.exchanged_rows == {"build": 0, "probe_sent": 0, "probe_received": 0} and not a2a
         more = next(c for c in golden_more["cases"] if c["name"] == "small")
-        db = helpers.case_db(more)
+        db = marked(helpers.case_db(more))
         runner = sdist.DistributedRunner(eng, 0, 1)
         for q in ("q4", "q14"):                              # the chain executor beyond q5 / q9
+            del calls[:]
             helpers.check_against_golden(runner.run(q, db), more["results"][q], REL, "dist1/%s" % q)
+            assert calls, q
         # q18: row-keyed group-by, HAVING key set and a local probe-aggregate; customer (text payload) held whole
         helpers.check_against_golden(runner.run("q18", db, whole_tables=("region", "nation", "customer")), more["results"]["q18"], REL, "dist1/q18")
-        top = runner.run("q3", helpers.case_db(case), top=(10, [("revenue", "desc"), ("o_orderdate", "asc")]))
+        top = runner.run("q3", marked(helpers.case_db(case)), top=(10, [("revenue", "desc"), ("o_orderdate", "asc")]))
         assert top.size() == 10 and top.column("revenue").tolist() == sorted(top.column("revenue").tolist(), reverse=True)
+        # unmarked tables are whole: the single-GPU plan, no collective (and that is the ONLY way to get none)
+        del calls[:]
+        runner.run("q3", helpers.case_db(case))
+        assert not calls and runner.last_partitioning == "range"      # last_partitioning is of the last PARTITIONED run
+
+        # SF=1: the hash-partitioned and the range plan against the single-GPU plan on the same tables
+        qs = ("q1", "q3", "q5", "q6", "q9")
+        cols = tpch.columns_for(qs)
+        big = tpch.generate(1.0, tables=sorted(cols), columns=cols, shard=(0, 1))
+        assert big["lineitem"].shard == (0, 1) and getattr(big["nation"], "shard", None) is None
+        for part in ("hash", "auto"):
+            runner = sdist.DistributedRunner(eng, 0, 1, partition=part)
+            for q in qs:
+                del calls[:]
+                got = runner.run(q, big)
+                want = helpers.run_query(eng, q, big)
+                assert calls, (q, part)
+                if q == "q6":
+                    assert abs(got - want) <= REL * abs(want)
+                    continue
+                g, w = sorted(got.rows()), sorted(want.rows())
+                assert len(g) == len(w) and len(w) > 0, (q, len(g), len(w))
+                for a, b in zip(g, w):
+                    for x, y in zip(a, b):
+                        assert (abs(x - y) <= REL * max(abs(x), abs(y))) if isinstance(y, float) else x == y, (q, part, a, b)
+                if q == "q3" and part == "hash":
+                    assert runner.exchanged_rows["probe_sent"] > 3000000 and runner.exchanged_bytes == 0      # all of it to itself
+                    moved = sum(n for nm, _, n in calls if nm == "all_to_all_single")
+                    assert moved >= 3 * runner.exchanged_rows["probe_sent"], (moved, runner.exchanged_rows)   # key + two operands
     finally:
+        for n in real:
+            setattr(dist, n, real[n])
         eng.close()
         dist.destroy_process_group()

@@ -575,6 +575,9 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "rank_increasing" && value >= 0 && value <= 1) ctx->opt_rank_increasing = (int)value;
     else if (n == "feature_min_rows" && value >= 0) ctx->opt_feature_min_rows = value;
     else if (n == "narrow" && value >= 0 && value <= 1) ctx->opt_narrow = (int)value;
+    else if (n == "tight" && value >= 0 && value <= 1) ctx->opt_tight = (int)value;
+    else if (n == "side_streams" && value >= 0 && value <= 1) ctx->opt_side_streams = (int)value;
+    else if (n == "async_result" && value >= 0 && value <= 1) ctx->opt_async_result = (int)value;
     else if (n == "stage_pipeline" && value >= 0 && value <= 1) ctx->opt_stage_pipeline = (int)value;
     else if (n == "span_index" && value >= 0 && value <= 1) ctx->opt_span_index = (int)value;
     else if (n == "dense_increasing" && value >= 0 && value <= 1) ctx->opt_dense_increasing = (int)value;
@@ -676,6 +679,7 @@ void sdqh_column_free(sdqh_ctx* ctx, sdqh_column* col) {
         if (col->owned) pool_free(ctx, col->data);
         pool_free(ctx, col->d_minmax);
         if (col->narrow) pool_free(ctx, col->narrow);
+        column_codes_release(ctx, col);
     }
     delete col;
 }
@@ -2098,6 +2102,7 @@ int sdqh_column_copy_in(sdqh_ctx* ctx, sdqh_column* col, int64_t row0, int64_t n
     col->have_minmax = false; col->minmax_pending = false; col->clustered = -1; col->increasing = -1;
     if (col->narrow) { pool_free(ctx, col->narrow); col->narrow = nullptr; }
     col->narrow_state = -1;
+    column_codes_release(ctx, col);
     return ctx->opt_async_copies ? SDQH_OK : sync_stream(ctx);
 }
 
@@ -2156,6 +2161,21 @@ void launch_sum_partials(sdqh_ctx* ctx, const double* partial, int nparts, doubl
 }
 void launch_groupby_merge_lg(sdqh_ctx* ctx, const unsigned long long* gkeys, const double* pacc, const int64_t* pcnt, int nparts, double* out_acc, int64_t* out_cnt) {
     LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, const_cast<unsigned long long*>(gkeys), pacc, pcnt, nparts, out_acc, out_cnt, static_cast<unsigned long long*>(nullptr), static_cast<int*>(nullptr), static_cast<int*>(nullptr), 0);
+}
+// The LG result block (group slots | sums | counts | flags in ctx->result_dev): did the last merge leave the slots EMPTY and the
+// flags zero (the caller then launches no fill)?  Either way the caller is about to write the block: the claim is consumed.
+bool rd_take_clean_lg(sdqh_ctx* ctx) {
+    const bool clean = ctx->opt_fill_ahead && ctx->rd_clean_ff >= (size_t)LG_SLOTS * 8 && ctx->rd_clean_zero_off == (int64_t)LG_SLOTS * 48;
+    rd_dirty(ctx);
+    return clean;
+}
+// Fold the workgroups' partials straight into the pinned host block (same layout as the device block: no copy-engine launch
+// after it), resetting the device block's group slots and flags for the next call.
+void launch_groupby_merge_lg_host(sdqh_ctx* ctx, unsigned long long* r_keys, const double* pacc, const int64_t* pcnt, int nparts, int* r_flags) {
+    char* hb = static_cast<char*>(ctx->result_host);
+    LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, r_keys, pacc, pcnt, nparts, reinterpret_cast<double*>(hb + LG_SLOTS * 8), reinterpret_cast<int64_t*>(hb + LG_SLOTS * 40),
+           reinterpret_cast<unsigned long long*>(hb), r_flags, reinterpret_cast<int*>(hb + LG_SLOTS * 48), 1);
+    ctx->rd_clean_ff = (size_t)LG_SLOTS * 8; ctx->rd_clean_zero_off = (int64_t)LG_SLOTS * 48;
 }
 int column_minmax(sdqh_ctx* ctx, sdqh_column* c) { return ensure_minmax(ctx, c); }
 const void* column_narrow(sdqh_ctx* ctx, sdqh_column* c) { return ensure_narrow(ctx, c); }

@@ -88,6 +88,11 @@ struct sdqh_ctx {
     int64_t opt_feature_min_rows = 1 << 20;        // narrow twins / row pack (and, x 4, the coarse filter) are for scans of at least this many rows; the suites set 0 to
                                                    // run those instances on tiny and ragged inputs too
     bool in_groupby_key = false;                   // sdqh_groupby_key is running its probe-aggregate pass
+    int opt_tight = 1;                             // register row programs stream their columns at the tightest exact encoding (dictionary codes of 1 / 2 bytes, 4-byte twins), 8 rows per lane (x_tight)
+    hipStream_t side[2] = {nullptr, nullptr};      // side streams: independent build chains of a plan run beside the main stream (fork / join by events)
+    hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int opt_side_streams = 1;
+    int opt_async_result = 1;                      // K-F's rows reach the host by a copy queued behind the kernels; the caller waits when it reads them
     int opt_narrow = 1;                            // streaming kernels (k_scan_sum, k_groupby_reg) read predicates / operands through exact 4-byte twins when every one of them has one
     int opt_stage_pipeline = 0;                    // k_stage (tuned orders-like family): first-stage loads of the next step requested a step ahead (measured: Q3 orders 0.148 -> 0.151 ms, no gain: off)
     int opt_span_index = 1;                        // small direct tables also get an owner-by-key-offset array (one-load lookups)
@@ -115,6 +120,15 @@ struct sdqh_column {
     int narrow_state = -1;             // -1 not tried, 0 the column does not narrow exactly, 1 twin present
     int increasing = -1;               // -1 unknown; 1: strictly increasing (sorted, no duplicates), 0: not — checked once on the device
     int64_t mn = 0, mx = 0;
+    // sorted-dictionary codes (sdqh_codes.hip): a column with at most 65 536 distinct values over a narrow integer / two-decimal
+    // range also has a 1- or 2-byte twin holding, per row, the RANK of its value among the column's distinct values, and the
+    // dictionary itself (ndict raw 8-byte values, ascending).  Order-preserving: `value < C` is `code < rank(C)`.
+    void* code = nullptr;              // device: nrows codes of code_width bytes
+    int code_width = 0;                // 1 or 2
+    int code_state = -1;               // -1 not tried, 0 no codes (too many values / too wide a range / not exact), 1 present
+    void* dict = nullptr;              // device: ndict raw 8-byte values (int64, or the bits of the doubles), ascending
+    int ndict = 0;
+    std::vector<int64_t> dict_host;    // the same on the host (bounds of comparisons are translated into code space at launch)
     size_t row_bytes() const { return dtype == SDQH_STR ? (size_t)width * 4 : 8; }
 };
 
@@ -160,10 +174,14 @@ int stage_setup_computed(sdqh_ctx* ctx, sdqh_table* tb, int64_t nrows, int npay,
 int index_ensure(sdqh_ctx* ctx, sdqh_table* tb);
 int column_minmax(sdqh_ctx* ctx, sdqh_column* c);
 const void* column_narrow(sdqh_ctx* ctx, sdqh_column* c);      // the exact 4-byte twin of a streamed column (built on first request), or nullptr
+bool column_codes(sdqh_ctx* ctx, sdqh_column* c);              // sdqh_codes.hip: the sorted-dictionary code twin (built on first request); false: none
+void column_codes_release(sdqh_ctx* ctx, sdqh_column* c);
 // launches of ahead-of-time kernels the run-time specialised path needs
 void fill_regions(sdqh_ctx* ctx, void* const* ptr, const size_t* bytes, const unsigned char* byte, int n);
 void launch_sum_partials(sdqh_ctx* ctx, const double* partial, int nparts, double* out);
 void launch_groupby_merge_lg(sdqh_ctx* ctx, const unsigned long long* gkeys, const double* pacc, const int64_t* pcnt, int nparts, double* out_acc, int64_t* out_cnt);
+bool rd_take_clean_lg(sdqh_ctx* ctx);
+void launch_groupby_merge_lg_host(sdqh_ctx* ctx, unsigned long long* r_keys, const double* pacc, const int64_t* pcnt, int nparts, int* r_flags);
 // small direct-layout tables: the rank -> row array is allocated up front; *ptr / *bytes = a region to fill with 0xFF (null: none)
 int prefill_direct_refs(sdqh_ctx* ctx, sdqh_table* tb, void** ptr, size_t* bytes);   // regions (<= 2) to fill with 0xFF; returns their number
 

@@ -40,8 +40,14 @@ namespace {
         if (_e != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
-enum Sink { SINK_SUM, SINK_GROUP, SINK_STAGE, SINK_KEYSET, SINK_ENTRY };
-const char* sink_name(Sink s) { return s == SINK_SUM ? "XSum" : s == SINK_GROUP ? "XGroup" : s == SINK_STAGE ? "XStage" : s == SINK_KEYSET ? "XKeySet" : "XEntry"; }
+enum Sink { SINK_SUM, SINK_GROUP, SINK_STAGE, SINK_KEYSET, SINK_ENTRY, SINK_GROUP_LANE };
+const char* sink_name(Sink s) { return s == SINK_SUM ? "XSum" : s == SINK_GROUP ? "XGroup" : s == SINK_STAGE ? "XStage" : s == SINK_KEYSET ? "XKeySet" : s == SINK_ENTRY ? "XEntry" : "XGroupLane"; }
+// the kernel's symbol: what rocprofv3 lists it under (one name per skeleton and sink, not one per program)
+std::string entry_name(Sink s, bool direct, bool tight) {
+    const char* sk = s == SINK_SUM ? "sum" : s == SINK_GROUP ? "group" : s == SINK_STAGE ? "build" : s == SINK_KEYSET ? "keyset" : s == SINK_ENTRY ? "probe_agg" : "group_lane";
+    return std::string("xk_") + sk + (tight ? "_tight" : direct ? "_direct" : "_queue");
+}
+enum Enc { ENC_RAW = 0, ENC_N32 = 1, ENC_C16 = 2, ENC_C8 = 3 };
 
 // ---- program analysis -------------------------------------------------------------------------------
 struct XInfo {
@@ -58,6 +64,19 @@ struct XInfo {
     int prefilter_op = -1;                   // first LOOKUP gate after the streamed ones whose key is made of plain columns:
     int prefilter_part0 = -1;                //   its table's key bitmap is tested on the streamed key (operation of the first key part)
     bool prefilter_composite = false;
+    // TIGHT (x_tight): a register program whose columns are streamed at their tightest exact encoding, 8 rows per lane
+    bool tight = false;
+    int enc[SDQH_MAX_XCOLS] = {};            // Enc per column
+    int dict_slot[SDQH_MAX_XCOLS];           // LDS dictionary table of a coded column whose VALUE the program uses, or -1
+    int nd = 0;
+    int cmp_cc[SDQH_MAX_XOPS];               // comparison of a coded column with a constant, rewritten in code space: its slot in cc[], or -1
+    int cmp_kind[SDQH_MAX_XOPS];             // 0: code < t   1: code >= t   2: code == t   3: code != t
+    int cmp_col[SDQH_MAX_XOPS];              // the coded column
+    uint32_t cc[X_MAX_CONST]; int ncc = 0;
+    bool affine[SDQH_MAX_XCOLS] = {};        // a coded integer column whose distinct values are consecutive integers: value = code + dlo, no table
+    int64_t dlo[SDQH_MAX_XCOLS] = {};
+    signed char irange[SDQH_MAX_XOPS] = {};  // i64 operations over the columns' actual ranges: 0 unknown / wide, 1 fits int32, 2 fits 24 bits (32-bit arithmetic, v_mul_i32_i24)
+    bool fake = false;
 };
 
 bool op_is_light(const sdqh_xop& o) {        // evaluable on streamed registers
@@ -75,6 +94,8 @@ void closure(const sdqh_program* p, int k, std::vector<char>& seen) {       // t
     if (o.b < k) closure(p, o.b, seen);
     if (o.c < k) closure(p, o.c, seen);
 }
+
+void tight_plan(sdqh_ctx* ctx, int64_t nrows, XInfo* x);
 
 // the ABI's rules for a program (the CPU implementation applies the same ones)
 int analyse(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* p, int max_vals, bool need_key, bool vals_f64, XInfo* x) {
@@ -198,7 +219,164 @@ int analyse(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* p, int max_vals, b
             if (column_narrow(ctx, const_cast<sdqh_column*>(x->cols[c]))) x->narrow_mask |= 1u << c;
         }
     }
+    tight_plan(ctx, nrows, x);
     return SDQH_OK;
+}
+
+
+// ---- TIGHT plans ------------------------------------------------------------------------------------------
+bool is_cmp(int code) { return code >= SDQH_X_LT && code <= SDQH_X_NE; }
+
+// [lo, hi] of an i64 operation over the columns' actual value ranges (min / max are cached per column; a coded column's
+// range is its dictionary's ends).  false: unknown (a product that leaves 62 bits, an operation without a range).
+bool op_interval(sdqh_ctx* ctx, const XInfo& x, int k, int64_t* lo, int64_t* hi) {
+    const sdqh_xop& o = x.p->ops[k];
+    if (o.type != SDQH_T_I64) return false;
+    const __int128 LIM = (__int128)1 << 62;
+    auto fits = [&](__int128 a, __int128 b) { return a > -LIM && a < LIM && b > -LIM && b < LIM; };
+    int64_t al, ah, bl, bh;
+    switch (o.code) {
+        case SDQH_X_CONST: *lo = *hi = o.imm_i; return true;
+        case SDQH_X_COL: {
+            sdqh_column* c = const_cast<sdqh_column*>(o.col);
+            if (x.fake) { if (c->dtype != SDQH_I64) return false; *lo = 0; *hi = 3; return true; }
+            if (c->dtype != SDQH_I64 || c->nrows < 1) return false;
+            if (c->code_state == 1 && !c->dict_host.empty()) { *lo = c->dict_host.front(); *hi = c->dict_host.back(); return true; }
+            if (column_minmax(ctx, c)) return false;
+            *lo = c->mn; *hi = c->mx; return true;
+        }
+        case SDQH_X_ADD: case SDQH_X_SUB: case SDQH_X_MUL: {
+            if (!op_interval(ctx, x, o.a, &al, &ah) || !op_interval(ctx, x, o.b, &bl, &bh)) return false;
+            __int128 l, h;
+            if (o.code == SDQH_X_ADD) { l = (__int128)al + bl; h = (__int128)ah + bh; }
+            else if (o.code == SDQH_X_SUB) { l = (__int128)al - bh; h = (__int128)ah - bl; }
+            else {
+                const __int128 c4[4] = {(__int128)al * bl, (__int128)al * bh, (__int128)ah * bl, (__int128)ah * bh};
+                l = h = c4[0];
+                for (int i = 1; i < 4; ++i) { l = c4[i] < l ? c4[i] : l; h = c4[i] > h ? c4[i] : h; }
+            }
+            if (!fits(l, h)) return false;
+            *lo = (int64_t)l; *hi = (int64_t)h; return true;
+        }
+        case SDQH_X_NEG: if (!op_interval(ctx, x, o.a, &al, &ah)) return false; *lo = -ah; *hi = -al; return true;
+        case SDQH_X_YEAR: if (!op_interval(ctx, x, o.a, &al, &ah) || al < 0) return false; *lo = al / 10000; *hi = ah / 10000; return true;
+        case SDQH_X_SELECT:
+            if (!op_interval(ctx, x, o.b, &al, &ah) || !op_interval(ctx, x, o.c, &bl, &bh)) return false;
+            *lo = std::min(al, bl); *hi = std::max(ah, bh); return true;
+        default: return false;
+    }
+}
+
+// rank of a constant among a column's distinct values, for `value OP constant` in code space.  The dictionary is ascending in
+// the column's own order (int64, or doubles: the two-decimal values are ordered like their cents).
+template <class T> void translate_cmp(const std::vector<int64_t>& dict, bool f64, T cst, int op, int* kind, uint32_t* t) {
+    auto val = [&](size_t i) -> T { if constexpr (sizeof(T) == 8 && T(0.5) != T(0)) { double d; std::memcpy(&d, &dict[i], 8); return (T)d; } else return (T)dict[i]; };
+    (void)f64;
+    const size_t n = dict.size();
+    size_t lb = 0, ub = 0;                                             // first index with value >= cst / > cst
+    while (lb < n && val(lb) < cst) ++lb;
+    ub = lb; while (ub < n && !(cst < val(ub))) ++ub;
+    const bool nan = cst != cst;
+    switch (op) {
+        case SDQH_X_LT: *kind = 0; *t = nan ? 0u : (uint32_t)lb; break;           // value <  cst  <=>  code <  lb
+        case SDQH_X_LE: *kind = 0; *t = nan ? 0u : (uint32_t)ub; break;           // value <= cst  <=>  code <  ub
+        case SDQH_X_GT: *kind = 1; *t = nan ? 0xFFFFFFFFu : (uint32_t)ub; break;  // value >  cst  <=>  code >= ub
+        case SDQH_X_GE: *kind = 1; *t = nan ? 0xFFFFFFFFu : (uint32_t)lb; break;  // value >= cst  <=>  code >= lb
+        case SDQH_X_EQ: *kind = 2; *t = (!nan && lb < ub) ? (uint32_t)lb : 0xFFFFFFFFu; break;
+        default:        *kind = 3; *t = (!nan && lb < ub) ? (uint32_t)lb : 0xFFFFFFFFu; break;
+    }
+}
+int mirrored(int op) { return op == SDQH_X_LT ? SDQH_X_GT : op == SDQH_X_LE ? SDQH_X_GE : op == SDQH_X_GT ? SDQH_X_LT : op == SDQH_X_GE ? SDQH_X_LE : op; }
+
+// Decide, per column of a register program, the tightest exact encoding it can be streamed in, and rewrite the comparisons
+// of coded columns with constants.  The decisions are part of the kernel's structure; the translated constants are arguments
+// (recomputed at every call: cheap, and they follow the constants).
+void tight_plan(sdqh_ctx* ctx, int64_t nrows, XInfo* x) {
+    const sdqh_program* p = x->p;
+    for (int k = 0; k < p->nops; ++k) x->cmp_cc[k] = x->cmp_kind[k] = x->cmp_col[k] = -1;
+    for (int c = 0; c < SDQH_MAX_XCOLS; ++c) { x->enc[c] = ENC_RAW; x->dict_slot[c] = -1; }
+    x->tight = false; x->nd = 0; x->ncc = 0;
+    // (a compile-only context has no columns to code; SDQLPY_AMD_FAKE_CODES makes it pretend every column is coded — 2 bytes where
+    //  only compared, 1 byte where its value is used — so that build() proves on a host without a GPU that the generator's tight
+    //  output compiles for gfx950)
+    const bool fake = ctx->compile_only && std::getenv("SDQLPY_AMD_FAKE_CODES") != nullptr;
+    static const std::vector<int64_t> fake_dict = {0, 1, 2, 3};
+    if (!x->direct || !ctx->opt_tight || x->ncols < 1) return;
+    // every register program runs on the tight skeleton, whatever its columns' encodings: rows meet lanes, and partial sums are folded, in
+    // the same order with and without twins, so switching the twins off changes no bit of a sum (tests/test_hip_parity.py)
+    x->tight = true;
+    x->fake = fake;
+    x->narrow_mask = 0;                                                    // (what analyse chose for the two-rows-per-lane skeleton)
+    if (!ctx->opt_narrow || (ctx->compile_only && !fake) || (!fake && nrows < ctx->opt_feature_min_rows)) return;
+    // how every COL operation is used
+    std::vector<char> cmp_only((size_t)x->ncols, 1), used((size_t)x->ncols, 0);
+    auto direct_ref = [&](int k) {
+        if (p->key == k) return true;
+        for (int g = 0; g < p->ngates; ++g) if (p->gates[g] == k) return true;
+        for (int v = 0; v < p->nvals; ++v) if (p->vals[v] == k) return true;
+        return false;
+    };
+    for (int k = 0; k < p->nops; ++k) {
+        if (p->ops[k].code != SDQH_X_COL) continue;
+        const int c = x->col_of[k];
+        used[(size_t)c] = 1;
+        if (direct_ref(k)) cmp_only[(size_t)c] = 0;
+        for (int j = k + 1; j < p->nops; ++j) {
+            const sdqh_xop& u = p->ops[j];
+            if (u.code == SDQH_X_COL || u.code == SDQH_X_CONST || u.code == SDQH_X_ROWID) continue;
+            const bool reads = u.a == k || u.b == k || (u.code == SDQH_X_SELECT && u.c == k);
+            if (!reads) continue;
+            const int other = u.a == k ? u.b : u.a;
+            if (!(is_cmp(u.code) && other >= 0 && other < j && p->ops[other].code == SDQH_X_CONST && p->ops[other].type == p->ops[k].type)) cmp_only[(size_t)c] = 0;
+        }
+    }
+    bool any = false;
+    for (int c = 0; c < x->ncols; ++c) {
+        if (!used[(size_t)c]) continue;
+        sdqh_column* col = const_cast<sdqh_column*>(x->cols[c]);
+        if (col->dtype == SDQH_STR) return;                                // (register programs have no text columns)
+        if (fake) {
+            x->enc[c] = cmp_only[(size_t)c] ? ENC_C16 : (c % 3 == 2 ? ENC_N32 : ENC_C8);
+            if (x->enc[c] == ENC_C8) x->dict_slot[c] = x->nd++;
+        } else if (column_codes(ctx, col) && (cmp_only[(size_t)c] || col->code_width == 1)) {
+            x->enc[c] = col->code_width == 1 ? ENC_C8 : ENC_C16;
+            if (!cmp_only[(size_t)c]) x->dict_slot[c] = x->nd++;
+        } else if (column_narrow(ctx, col)) x->enc[c] = ENC_N32;
+        any = any || x->enc[c] != ENC_RAW;
+    }
+    if (!any) return;
+    for (int c = 0; c < x->ncols; ++c) {
+        const sdqh_column* col = x->cols[c];
+        if (x->enc[c] < ENC_C16 || col->dtype != SDQH_I64) continue;
+        if (fake) { x->affine[c] = c % 2 == 0; x->dlo[c] = 0; continue; }
+        const std::vector<int64_t>& d = col->dict_host;
+        x->affine[c] = !d.empty() && d.back() - d.front() == (int64_t)d.size() - 1;        // (ascending and distinct: consecutive)
+        x->dlo[c] = d.empty() ? 0 : d.front();
+    }
+    for (int k = 0; k < p->nops; ++k) {
+        int64_t lo = 0, hi = 0;
+        if (p->ops[k].type == SDQH_T_I64 && op_interval(ctx, *x, k, &lo, &hi))
+            x->irange[k] = (lo >= -(1 << 23) && hi < (1 << 23)) ? 2 : (lo >= INT32_MIN && hi <= INT32_MAX) ? 1 : 0;
+    }
+    x->narrow_mask = 0;
+    for (int c = 0; c < x->ncols; ++c) if (x->enc[c] == ENC_N32) x->narrow_mask |= 1u << c;
+    // comparisons of a coded column with a constant, in code space
+    for (int j = 0; j < p->nops; ++j) {
+        const sdqh_xop& u = p->ops[j];
+        if (!is_cmp(u.code)) continue;
+        int kc = -1, kk = -1, op = u.code;
+        if (p->ops[u.a].code == SDQH_X_COL && p->ops[u.b].code == SDQH_X_CONST) { kc = u.a; kk = u.b; }
+        else if (p->ops[u.b].code == SDQH_X_COL && p->ops[u.a].code == SDQH_X_CONST) { kc = u.b; kk = u.a; op = mirrored(op); }
+        if (kc < 0) continue;
+        const int c = x->col_of[kc];
+        if (x->enc[c] < ENC_C16 || p->ops[kk].type != p->ops[kc].type || x->ncc >= X_MAX_CONST) continue;
+        const sdqh_column* col = x->cols[c];
+        int kind = 0; uint32_t t = 0;
+        const std::vector<int64_t>& dict = fake ? fake_dict : col->dict_host;
+        if (col->dtype == SDQH_F64) translate_cmp<double>(dict, true, p->ops[kk].imm_f, op, &kind, &t);
+        else translate_cmp<int64_t>(dict, false, p->ops[kk].imm_i, op, &kind, &t);
+        x->cmp_cc[j] = x->ncc; x->cmp_kind[j] = kind; x->cmp_col[j] = c; x->cc[x->ncc++] = t;
+    }
 }
 
 // ---- code generation ----------------------------------------------------------------------------------
@@ -207,7 +385,36 @@ struct Gen {
     const char* half = "";
     std::vector<int> slot_of;                  // column -> slot in the streamed register array
     std::vector<int> sres_of;                  // text operation -> its slot in the drain's staged results (-1: reads the column in global memory)
-    explicit Gen(const XInfo& xi) : x(xi), done((size_t)xi.p->nops, 0), slot_of((size_t)SDQH_MAX_XCOLS, -1), sres_of((size_t)xi.p->nops, -1) {}
+    // TIGHT (mode 3): an operation that depends on ONE byte-coded column and constants only is a table of <= 256 entries, filled once per
+    // workgroup by evaluating it on the dictionary (mode 4: the column reads as the dictionary entry `dv`): `1.0 - l_discount` costs the
+    // row one LDS read, like the column's value itself
+    std::vector<std::pair<int, int>> tabs;     // table -> (operation, column)
+    std::vector<int> tab_of, single_memo;
+    int dict_col = -1;                         // mode 4: the column being tabulated
+    static constexpr int MAX_TABS = 16, MAX_DERIVED = 12;
+    explicit Gen(const XInfo& xi) : x(xi), done((size_t)xi.p->nops, 0), slot_of((size_t)SDQH_MAX_XCOLS, -1), sres_of((size_t)xi.p->nops, -1),
+                                    tab_of((size_t)xi.p->nops, -1), single_memo((size_t)xi.p->nops, -2) {}
+    // the one byte-coded column operation k depends on (nothing else but constants), or -1
+    int single_col(int k) {
+        if (k < 0) return -1;
+        if (single_memo[(size_t)k] != -2) return single_memo[(size_t)k];
+        const sdqh_xop& o = x.p->ops[k];
+        int r = -1;
+        if (o.code == SDQH_X_COL) r = (x.enc[x.col_of[k]] == ENC_C8 && !x.affine[x.col_of[k]]) ? x.col_of[k] : -1;      // (consecutive values: code + offset, no table)
+        else if (o.code == SDQH_X_CONST) r = -3;                              // no column at all
+        else if (o.code == SDQH_X_ROWID || o.code == SDQH_X_PACK2 || !op_is_light(o)) r = -1;       // (PACK2 can fail per row: never a table)
+        else {
+            r = -3;
+            const int opnd[3] = {o.a, o.b, o.code == SDQH_X_SELECT ? o.c : -1};
+            for (int j : opnd) {
+                if (j < 0 || j >= k) continue;
+                const int c = single_col(j);
+                if (c == -1 || (c >= 0 && r >= 0 && c != r)) { r = -1; break; }
+                if (c >= 0) r = c;
+            }
+        }
+        return single_memo[(size_t)k] = r;
+    }
     // the text operation itself, on the field at `field` ("pointer, width"); lds: the field was staged in LDS
     std::string text_op(int k, const std::string& field, bool lds = false, bool bytes = false) const {
         const sdqh_xop& o = x.p->ops[k];
@@ -233,6 +440,20 @@ struct Gen {
         const int c = x.col_of[k];
         std::string raw;
         if (mode == 0) return std::string("static_cast<const ") + (o.type == SDQH_T_F64 ? "double" : "int64_t") + "*>(a.col[" + std::to_string(c) + "])[r]";
+        if (mode == 4) return o.type == SDQH_T_F64 ? "x_f(dv)" : "dv";         // tabulating: the dictionary entry
+        if (mode == 3) {                                                   // TIGHT: row i of the lane's 8, out of the packed words s.c<slot>
+            const std::string w = "s.c" + std::to_string(slot_of[(size_t)c]);
+            if (x.affine[c] && x.enc[c] >= ENC_C16) return std::string("((int64_t)") + (x.enc[c] == ENC_C8 ? "xt_u8(" : "xt_u16(") + w + ", i) + a.dlo[" + std::to_string(c) + "])";
+            switch (x.enc[c]) {
+                case ENC_C8: {                                               // (no table left: the dictionary in global memory, L1-resident)
+                    const std::string e = "a.dict[" + std::to_string(c) + "][xt_u8(" + w + ", i)]";
+                    return o.type == SDQH_T_F64 ? "x_f(" + e + ")" : e;
+                }
+                case ENC_N32: return o.type == SDQH_T_F64 ? "narrow_decode(xt_i32(" + w + ", i))" : "(int64_t)xt_i32(" + w + ", i)";
+                case ENC_RAW: return o.type == SDQH_T_F64 ? "x_f(xt_i64(" + w + ", i))" : "xt_i64(" + w + ", i)";
+                default: return "0 /* a 16-bit code has no value form */";
+            }
+        }
         if (mode == 1) raw = "(H == 0 ? s[" + std::to_string(slot_of[(size_t)c]) + "].x : s[" + std::to_string(slot_of[(size_t)c]) + "].y)";
         else raw = "s[" + std::to_string(slot_of[(size_t)c]) + "]." + half;
         return o.type == SDQH_T_F64 ? "x_f(" + raw + ")" : raw;
@@ -243,6 +464,19 @@ struct Gen {
         auto v = [](int j) { return "v" + std::to_string(j); };
         const std::string K = std::to_string(k);
         std::string e;
+        if (mode == 3 && !(is_cmp(o.code) && x.cmp_cc[k] >= 0)) {
+            const int c = single_col(k);
+            const bool bare = o.code == SDQH_X_COL;
+            if (c >= 0 && (int)tabs.size() < (bare ? MAX_TABS : MAX_DERIVED)) {
+                if (tab_of[(size_t)k] < 0) { tab_of[(size_t)k] = (int)tabs.size(); tabs.push_back({k, c}); }
+                const std::string cell = "tab[" + std::to_string(tab_of[(size_t)k]) + "][xt_u8(s.c" + std::to_string(slot_of[(size_t)c]) + ", i)]";
+                e = o.type == SDQH_T_F64 ? "x_f(" + cell + ")" : o.type == SDQH_T_BOOL ? "(" + cell + " != 0)" : cell;
+                os << "        const " << ctype(o.type) << " v" << K << " = " << e << ";\n";
+                if (o.code == SDQH_X_SELECT) os << "        const bool b" << K << " = false;\n";      // (nothing under a tabulated SELECT can fail: PACK2 is never tabulated)
+                done[(size_t)k] = 1;
+                return;
+            }
+        }
         switch (o.code) {
             case SDQH_X_COL: e = col_expr(k); break;
             case SDQH_X_ROWID: e = "r"; break;
@@ -264,9 +498,16 @@ struct Gen {
                 e = o.aux < 0 ? "x_hits(a.tab[" + std::to_string(x.tab_of[o.a]) + "], e" + std::to_string(o.a) + ")"
                               : "x_acc(a.tab[" + std::to_string(x.tab_of[o.a]) + "], " + std::to_string(o.aux) + ", e" + std::to_string(o.a) + ")";
                 break;
-            case SDQH_X_ADD: emit(o.a); emit(o.b); e = "(" + v(o.a) + " + " + v(o.b) + ")"; break;
-            case SDQH_X_SUB: emit(o.a); emit(o.b); e = "(" + v(o.a) + " - " + v(o.b) + ")"; break;
-            case SDQH_X_MUL: emit(o.a); emit(o.b); e = "(" + v(o.a) + " * " + v(o.b) + ")"; break;
+            case SDQH_X_ADD: case SDQH_X_SUB: case SDQH_X_MUL: {
+                emit(o.a); emit(o.b);
+                const char* sym = o.code == SDQH_X_ADD ? " + " : o.code == SDQH_X_SUB ? " - " : " * ";
+                // integers whose ranges (from the columns' own minima / maxima) fit 32 bits: 32-bit arithmetic, 24-bit multiplies
+                if (mode == 3 && o.type == SDQH_T_I64 && x.irange[k] >= 1 && x.irange[o.a] >= 1 && x.irange[o.b] >= 1) {
+                    if (o.code == SDQH_X_MUL && x.irange[o.a] == 2 && x.irange[o.b] == 2) e = "(int64_t)__mul24((int)" + v(o.a) + ", (int)" + v(o.b) + ")";
+                    else e = "(int64_t)((int32_t)" + v(o.a) + sym + "(int32_t)" + v(o.b) + ")";
+                } else e = "(" + v(o.a) + sym + v(o.b) + ")";
+                break;
+            }
             case SDQH_X_DIV: emit(o.a); emit(o.b); e = "(" + v(o.a) + " / " + v(o.b) + ")"; break;
             case SDQH_X_NEG: emit(o.a); e = "(-" + v(o.a) + ")"; break;
             case SDQH_X_I2F: emit(o.a); e = "(double)" + v(o.a); break;
@@ -276,12 +517,17 @@ struct Gen {
                 os << "        const bool b" << K << " = " << bad(o.a) << " || " << bad(o.b) << " || " << v(o.a) << " < 0 || " << v(o.a) << " > 0xFFFFFFFFll || " << v(o.b) << " < 0 || " << v(o.b) << " > 0xFFFFFFFFll;\n";
                 e = "(int64_t)(((uint64_t)" + v(o.a) + " << 32) | ((uint64_t)" + v(o.b) + " & 0xFFFFFFFFull))";
                 break;
-            case SDQH_X_LT: emit(o.a); emit(o.b); e = "(" + v(o.a) + " < " + v(o.b) + ")"; break;
-            case SDQH_X_LE: emit(o.a); emit(o.b); e = "(" + v(o.a) + " <= " + v(o.b) + ")"; break;
-            case SDQH_X_GT: emit(o.a); emit(o.b); e = "(" + v(o.a) + " > " + v(o.b) + ")"; break;
-            case SDQH_X_GE: emit(o.a); emit(o.b); e = "(" + v(o.a) + " >= " + v(o.b) + ")"; break;
-            case SDQH_X_EQ: emit(o.a); emit(o.b); e = "(" + v(o.a) + " == " + v(o.b) + ")"; break;
-            case SDQH_X_NE: emit(o.a); emit(o.b); e = "(" + v(o.a) + " != " + v(o.b) + ")"; break;
+            case SDQH_X_LT: case SDQH_X_LE: case SDQH_X_GT: case SDQH_X_GE: case SDQH_X_EQ: case SDQH_X_NE:
+                if (mode == 3 && x.cmp_cc[k] >= 0) {                        // a coded column against a constant: the code against the constant's rank
+                    const int c = x.cmp_col[k];
+                    const std::string code = std::string(x.enc[c] == ENC_C8 ? "xt_u8" : "xt_u16") + "(s.c" + std::to_string(slot_of[(size_t)c]) + ", i)";
+                    static const char* rel[4] = {" < ", " >= ", " == ", " != "};
+                    e = "(" + code + rel[x.cmp_kind[k]] + "a.cc[" + std::to_string(x.cmp_cc[k]) + "])";
+                    break;
+                }
+                emit(o.a); emit(o.b);
+                e = "(" + v(o.a) + (o.code == SDQH_X_LT ? " < " : o.code == SDQH_X_LE ? " <= " : o.code == SDQH_X_GT ? " > " : o.code == SDQH_X_GE ? " >= " : o.code == SDQH_X_EQ ? " == " : " != ") + v(o.b) + ")";
+                break;
             case SDQH_X_AND: emit(o.a); emit(o.b); e = "(" + v(o.a) + " && " + v(o.b) + ")"; break;
             case SDQH_X_OR: emit(o.a); emit(o.b); e = "(" + v(o.a) + " || " + v(o.b) + ")"; break;
             case SDQH_X_NOT: emit(o.a); e = "(!" + v(o.a) + ")"; break;
@@ -307,7 +553,67 @@ struct Gen {
     void reset() { std::fill(done.begin(), done.end(), 0); }
 };
 
+// A TIGHT program: struct P for x_tight (sdqh_xkernels.hpp).  Regs = the packed words of a lane's 8 rows per streamed
+// column; eval(i) = the whole program on row i, comparisons of coded columns in code space, coded values through the
+// dictionary tables in LDS.
+std::string generate_tight(const XInfo& x, Sink sink) {
+    const sdqh_program* p = x.p;
+    Gen g(x);
+    std::vector<int> scols;
+    for (int c = 0; c < x.ncols; ++c) scols.push_back(c);
+    for (size_t i = 0; i < scols.size(); ++i) g.slot_of[(size_t)scols[i]] = (int)i;
+    auto bpr = [&](int c) { return x.enc[c] == ENC_C8 ? 1 : x.enc[c] == ENC_C16 ? 2 : x.enc[c] == ENC_N32 ? 4 : 8; };
+    std::ostringstream out;
+    out << "#include \"sdqh_xkernels.hpp\"\nusing namespace sdqh;\n";
+    // the row function first: it decides which operations become tables
+    // No early exit on a failed gate: everything here is register arithmetic (nothing a failed gate has to guard), and a branch per
+    // gate and row — exec-mask save / restore, a wait in front of each — costs more than the few operations it skips; the sink
+    // applies `pass` once.
+    g.reset(); g.mode = 3; g.os.str("");
+    g.os << "        bool pass = true;\n";
+    for (int q = 0; q < p->ngates; ++q) { g.emit(p->gates[q]); g.os << "        pass = pass & v" << p->gates[q] << ";\n"; }
+    if (p->key >= 0) { g.emit(p->key); g.os << "        o.key = v" << p->key << "; o.bad = " << g.bad(p->key) << ";\n"; }
+    else g.os << "        o.key = 0; o.bad = false;\n";
+    for (int v = 0; v < p->nvals; ++v) {
+        g.emit(p->vals[v]);
+        g.os << "        o.val[" << v << "] = " << (p->ops[p->vals[v]].type == SDQH_T_F64 ? "x_bits(v" + std::to_string(p->vals[v]) + ")" : "v" + std::to_string(p->vals[v])) << ";\n";
+    }
+    g.os << "        o.ent = NO_ROW;\n        return pass;\n";
+    const std::string row_fn = g.os.str();
+    const std::vector<std::pair<int, int>> tabs = g.tabs;
+    out << "struct P {\n    static constexpr int NV = " << p->nvals << ", ND = " << tabs.size() << ";\n    struct Regs {";
+    for (size_t i = 0; i < scols.size(); ++i) out << " uint32_t c" << i << "[" << bpr(scols[i]) * 2 << "];";
+    out << " };\n";
+    out << "    __device__ __forceinline__ static void load_dicts(const XArgs& a, int64_t (*tab)[256]) {\n";
+    for (size_t j = 0; j < tabs.size(); ++j) {
+        const int k = tabs[j].first, c = tabs[j].second;
+        Gen t(x);
+        t.mode = 4; t.dict_col = c;
+        t.emit(k);
+        const int ty = p->ops[k].type;
+        out << "        for (int i = threadIdx.x; i < 256; i += TPB) {\n            int64_t cell = 0;\n            if (i < a.ndict[" << c << "]) {\n                const int64_t dv = a.dict[" << c << "][i];\n";
+        out << t.os.str();
+        out << "                cell = " << (ty == SDQH_T_F64 ? "x_bits(v" + std::to_string(k) + ")" : ty == SDQH_T_BOOL ? "(v" + std::to_string(k) + " ? 1 : 0)" : "v" + std::to_string(k)) << ";\n";
+        out << "            }\n            tab[" << j << "][i] = cell;\n        }\n";
+    }
+    out << "    }\n";
+    out << "    template <bool TAIL> __device__ __forceinline__ static void sload(const XArgs& a, int64_t r, int64_t nrows, Regs& s) {\n";
+    for (size_t i = 0; i < scols.size(); ++i) {
+        const int c = scols[i];
+        const char* src = x.enc[c] >= ENC_C16 ? "a.code[" : x.enc[c] == ENC_N32 ? "a.ncol[" : "a.col[";
+        out << "        xt_load<" << bpr(c) << ", TAIL>(" << src << c << "], r, nrows, s.c" << i << ");\n";
+    }
+    out << "    }\n";
+    out << "    __device__ __forceinline__ static bool eval(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i, const int64_t r, XOut<NV>& o) {\n";
+    out << row_fn << "    }\n};\n";
+    const std::string sn = sink_name(sink);
+    out << "extern \"C\" __global__ __launch_bounds__(256) void " << entry_name(sink, true, true) << "(XArgs a, " << sn << "<P::NV>::Args s, int64_t nrows, int64_t seg_rows, int nseg) {\n";
+    out << "    x_tight<P, " << sn << ">(a, s, nrows);\n}\n";
+    return out.str();
+}
+
 std::string generate(const XInfo& x, Sink sink, bool direct) {
+    if (x.tight && direct) return generate_tight(x, sink);
     const sdqh_program* p = x.p;
     Gen g(x);
     std::vector<int> scols = x.scols;
@@ -391,7 +697,7 @@ std::string generate(const XInfo& x, Sink sink, bool direct) {
     if (!direct) out << body(0, first_gate); else out << "        return false;\n";
     out << "    }\n};\n";
     const std::string sn = sink_name(sink);
-    out << "extern \"C\" __global__ __launch_bounds__(256) void xk(XArgs a, " << sn << "<P::NV>::Args s, int64_t nrows, int64_t seg_rows, int nseg) {\n";
+    out << "extern \"C\" __global__ __launch_bounds__(256) void " << entry_name(sink, direct, false) << "(XArgs a, " << sn << "<P::NV>::Args s, int64_t nrows, int64_t seg_rows, int nseg) {\n";
     if (direct) out << "    x_direct<P, " << sn << ">(a, s, nrows);\n";
     else out << "    x_queue<P, " << sn << ", " << (sink == SINK_STAGE ? "true" : "false") << ">(a, s, nrows, seg_rows, nseg);\n";
     out << "}\n";
@@ -449,7 +755,13 @@ uint64_t structure_hash(const XInfo& x, Sink sink, bool direct) {
     const sdqh_program* p = x.p;
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](uint64_t v) { for (int i = 0; i < 8; ++i) { h ^= (v >> (8 * i)) & 0xFF; h *= 1099511628211ull; } };
-    mix((uint64_t)sink * 2 + (direct ? 1 : 0)); mix((uint64_t)x.narrow_mask); mix((uint64_t)p->nops); mix((uint64_t)(int64_t)p->key); mix((uint64_t)(int64_t)x.probe_op);
+    mix((uint64_t)sink * 2 + (direct ? 1 : 0)); mix((uint64_t)x.narrow_mask);
+    if (x.tight && direct) {
+        mix(0x7167ull);
+        for (int c = 0; c < x.ncols; ++c) mix(((uint64_t)(uint32_t)x.enc[c] << 32) | ((uint32_t)(x.affine[c] ? 1 : 0) << 16) | (uint32_t)(x.dict_slot[c] & 0xFFFF));
+        for (int k = 0; k < x.p->nops; ++k) mix((uint64_t)(uint8_t)x.irange[k]);
+        for (int k = 0; k < x.p->nops; ++k) mix(((uint64_t)(uint32_t)x.cmp_cc[k] << 32) | ((uint32_t)x.cmp_kind[k] << 8) | (uint32_t)(x.cmp_col[k] & 0xFF));
+    } mix((uint64_t)p->nops); mix((uint64_t)(int64_t)p->key); mix((uint64_t)(int64_t)x.probe_op);
     for (int k = 0; k < p->nops; ++k) {
         const sdqh_xop& o = p->ops[k];
         mix(((uint64_t)(uint32_t)o.code << 32) | (uint32_t)o.type); mix(((uint64_t)(uint32_t)o.a << 32) | (uint32_t)o.b); mix(((uint64_t)(uint32_t)o.c << 32) | (uint32_t)o.aux);
@@ -462,7 +774,7 @@ uint64_t structure_hash(const XInfo& x, Sink sink, bool direct) {
     return h;
 }
 
-int specialise(sdqh_ctx* ctx, const std::string& source, hipFunction_t* fn);
+int specialise(sdqh_ctx* ctx, const std::string& source, const std::string& entry, hipFunction_t* fn);
 
 int kernel_for(sdqh_ctx* ctx, const XInfo& x, Sink sink, bool direct, hipFunction_t* fn) {
     JitState& J = jit();
@@ -473,13 +785,13 @@ int kernel_for(sdqh_ctx* ctx, const XInfo& x, Sink sink, bool direct, hipFunctio
         auto hit = J.kernels.find(name);
         if (hit != J.kernels.end()) { *fn = hit->second; return SDQH_OK; }
     }
-    if (int rc = specialise(ctx, generate(x, sink, direct), fn)) return rc;
+    if (int rc = specialise(ctx, generate(x, sink, direct), entry_name(sink, direct, x.tight && direct), fn)) return rc;
     std::lock_guard<std::mutex> lock(J.mu);
     J.kernels[name] = *fn;
     return SDQH_OK;
 }
 
-int specialise(sdqh_ctx* ctx, const std::string& source, hipFunction_t* fn) {
+int specialise(sdqh_ctx* ctx, const std::string& source, const std::string& entry, hipFunction_t* fn) {
     JitState& J = jit();
     std::lock_guard<std::mutex> lock(J.mu);
     if (!load_headers(J)) return fail(ctx, SDQH_ERR_DEVICE, J.why_unusable);
@@ -493,6 +805,7 @@ int specialise(sdqh_ctx* ctx, const std::string& source, hipFunction_t* fn) {
     const std::string key = std::string(name) + "@" + std::to_string(ctx->device);
     auto hit = J.kernels.find(key);
     if (hit != J.kernels.end()) { *fn = hit->second; return SDQH_OK; }
+    if (const char* dump = std::getenv("SDQLPY_AMD_JIT_DUMP")) if (dump[0] == '2') std::fprintf(stderr, "---- specialised source (%s) ----\n%s\n", entry.c_str(), source.c_str());
     const std::string path = J.cache_dir + "/" + name + ".hsaco";
     std::string code = slurp(path);
     if (!code.empty()) ++J.from_disk;
@@ -525,7 +838,7 @@ int specialise(sdqh_ctx* ctx, const std::string& source, hipFunction_t* fn) {
     hipModule_t mod;
     if (hipModuleLoadData(&mod, code.data()) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, SDQH_ERR_DEVICE, "hipModuleLoadData failed for a specialised kernel"); }
     hipFunction_t f;
-    if (hipModuleGetFunction(&f, mod, "xk") != hipSuccess) { (void)hipGetLastError(); return fail(ctx, SDQH_ERR_DEVICE, "specialised kernel has no entry point"); }
+    if (hipModuleGetFunction(&f, mod, entry.c_str()) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, SDQH_ERR_DEVICE, "specialised kernel has no entry point"); }
     J.kernels[key] = f;
     *fn = f;
     return SDQH_OK;
@@ -541,6 +854,9 @@ int fill_xargs(sdqh_ctx* ctx, const XInfo& x, XArgs* a, int32_t* flags, int64_t 
         if (int rc = index_ensure(ctx, x.tabs[t])) return rc;
         a->tab[t] = x.tabs[t]->dev;
     }
+    if (x.tight) for (int c = 0; c < x.ncols; ++c) a->dlo[c] = x.dlo[c];
+    if (x.tight) for (int c = 0; c < x.ncols; ++c) if (x.enc[c] >= ENC_C16) { a->code[c] = x.cols[c]->code; a->dict[c] = static_cast<const int64_t*>(x.cols[c]->dict); a->ndict[c] = x.cols[c]->ndict; }
+    std::memcpy(a->cc, x.cc, sizeof(x.cc[0]) * (size_t)x.ncc);
     std::memcpy(a->ci, x.ci, sizeof(x.ci[0]) * (size_t)x.nci);
     std::memcpy(a->cf, x.cf, sizeof(x.cf[0]) * (size_t)x.ncf);
     std::memcpy(a->spool, x.spool, sizeof(uint32_t) * (size_t)x.nstr);
@@ -549,6 +865,10 @@ int fill_xargs(sdqh_ctx* ctx, const XInfo& x, XArgs* a, int32_t* flags, int64_t 
 }
 
 struct Geometry { unsigned grid; int64_t seg_rows; int nseg; };
+Geometry geometry_tight(sdqh_ctx* ctx, int64_t nrows, int resident) {
+    const int64_t steps = std::max<int64_t>(1, nrows / ((int64_t)XT_ROWS * XT_U));
+    return Geometry{(unsigned)std::min<int64_t>(steps, (int64_t)ctx->num_cu * resident), 0, 0};
+}
 Geometry geometry(sdqh_ctx* ctx, int64_t nrows, bool direct, int waves_per_cu) {
     Geometry g{1, 0, 0};
     if (direct) {
@@ -567,14 +887,14 @@ Geometry geometry(sdqh_ctx* ctx, int64_t nrows, bool direct, int waves_per_cu) {
 }
 
 template <class SA>
-int launch(sdqh_ctx* ctx, hipFunction_t fn, const char* name, const XArgs& a, const SA& sa, int64_t nrows, const Geometry& g) {
+int launch(sdqh_ctx* ctx, hipFunction_t fn, const char* name, const XArgs& a, const SA& sa, int64_t nrows, const Geometry& g, unsigned lds_bytes = 0) {
     Packed<SA> pk;
     std::memset(&pk, 0, sizeof(pk));
     pk.a = a; pk.s = sa; pk.nrows = nrows; pk.seg_rows = g.seg_rows; pk.nseg = g.nseg;
     size_t size = sizeof(pk);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &pk, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     KernelScope ks(ctx, name);
-    HIP_TRYX(ctx, hipModuleLaunchKernel(fn, g.grid, 1, 1, TPB, 1, 1, 0, ctx->stream, nullptr, config));
+    HIP_TRYX(ctx, hipModuleLaunchKernel(fn, g.grid, 1, 1, TPB, 1, 1, lds_bytes, ctx->stream, nullptr, config));
     return SDQH_OK;
 }
 
@@ -611,18 +931,15 @@ int sdqh_xscan_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, doubl
     rd_dirty(ctx);
     int32_t* d_flags = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->result_dev) + 1024);
     if (int rc = fill_xargs(ctx, x, &a, d_flags, 1, 0)) return rc;
-    const Geometry g = geometry(ctx, nrows, x.direct, 16);
+    const Geometry g = x.tight ? geometry_tight(ctx, nrows, 2) : geometry(ctx, nrows, x.direct, 16);
     double* partial = static_cast<double*>(pool_alloc(ctx, (size_t)g.grid * 5 * sizeof(double)));
     if (!partial) return fail(ctx, SDQH_ERR_NOMEM, "xscan_sum: out of device memory");
     XSum<1>::Args sa{partial};
-    double* out_dev = static_cast<double*>(ctx->result_dev);
-    int rc = launch(ctx, fn, "x_scan_sum", a, sa, nrows, g);
+    int rc = launch(ctx, fn, x.tight ? "x_scan_sum_tight" : "x_scan_sum", a, sa, nrows, g);
     if (!rc) {
-        launch_sum_partials(ctx, partial, (int)g.grid, out_dev);
+        launch_sum_partials(ctx, partial, (int)g.grid, static_cast<double*>(ctx->result_host));      // the fold writes the pinned host block: no copy-engine launch
         call_end(ctx);
-        hipError_t e = hipMemcpyAsync(ctx->result_host, out_dev, 5 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-        if (e != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e));
-        if (!rc) rc = sync_stream(ctx);
+        rc = sync_stream(ctx);
     }
     pool_free(ctx, partial);
     if (rc) return rc;
@@ -638,11 +955,20 @@ int sdqh_xgroupby(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int ma
     if (!ctx->compile_only) (void)hipSetDevice(ctx->device);
     XInfo x;
     if (int rc = analyse(ctx, nrows, prog, SDQH_TUPLE_MAX_VALUES, true, true, &x)) return rc;
+    // a key over a dense small range (known from the columns' own ranges): every lane keeps its groups' sums in LDS cells of its own
+    Sink sink = SINK_GROUP;
+    int nslots = 0;
+    int64_t klo = 1, khi = 0;
+    if (x.tight && x.direct) {
+        int64_t lo = 0, hi = -1;
+        const int na = prog->nvals + 1;
+        if (ctx->compile_only) { sink = SINK_GROUP_LANE; nslots = 1; klo = khi = 0; }          // (build check: compile the lane sink)
+        else if (op_interval(ctx, x, prog->key, &lo, &hi) && lo >= 0 && hi >= lo && hi - lo < 32 && (hi - lo + 1) * na <= 32) { sink = SINK_GROUP_LANE; nslots = (int)(hi - lo + 1); klo = lo; khi = hi; }
+    }
     hipFunction_t fn;
-    if (int rc = kernel_for(ctx, x, SINK_GROUP, x.direct, &fn)) return rc;
+    if (int rc = kernel_for(ctx, x, sink, x.direct, &fn)) return rc;
     call_begin(ctx);
     // result block in ctx->result_dev: gkeys[LG_SLOTS] | acc[LG_SLOTS][4] | cnt[LG_SLOTS] | flags
-    rd_dirty(ctx);
     char* rd = static_cast<char*>(ctx->result_dev);
     unsigned long long* r_keys = reinterpret_cast<unsigned long long*>(rd);
     double* r_acc = reinterpret_cast<double*>(rd + LG_SLOTS * 8);
@@ -651,28 +977,33 @@ int sdqh_xgroupby(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int ma
     const size_t rbytes = LG_SLOTS * 48 + 8;
     static_assert(LG_SLOTS * 48 + 8 <= RESULT_BYTES, "result block too small");
     XArgs a;
-    if (int rc = fill_xargs(ctx, x, &a, r_flags, 1, 0)) return rc;
-    const Geometry g = geometry(ctx, nrows, x.direct, 16);
-    const size_t nslots = (size_t)g.grid * LG_SLOTS;
-    char* blob = static_cast<char*>(pool_alloc(ctx, nslots * 40 + 256));
+    if (int rc = fill_xargs(ctx, x, &a, r_flags, klo, khi)) return rc;
+    const Geometry g = x.tight ? geometry_tight(ctx, nrows, 2) : geometry(ctx, nrows, x.direct, 16);
+    const size_t npart = (size_t)g.grid * LG_SLOTS;
+    char* blob = static_cast<char*>(pool_alloc(ctx, npart * 40 + 256));
     if (!blob) return fail(ctx, SDQH_ERR_NOMEM, "xgroupby: out of device memory");
     double* pacc = reinterpret_cast<double*>(blob);
-    int64_t* pcnt = reinterpret_cast<int64_t*>(blob + nslots * 32);
-    { void* ptr[2] = {r_keys, r_flags}; size_t bytes[2] = {LG_SLOTS * 8, 8}; unsigned char byte[2] = {0xFF, 0}; fill_regions(ctx, ptr, bytes, byte, 2); }
-    XGroup<1>::Args sa{r_keys, pacc, pcnt, r_flags};
-    int rc = launch(ctx, fn, "x_groupby", a, sa, nrows, g);
-    if (!rc) {
-        launch_groupby_merge_lg(ctx, r_keys, pacc, pcnt, (int)g.grid, r_acc, r_cnt);
-        call_end(ctx);
-        hipError_t e = hipMemcpyAsync(ctx->result_host, rd, rbytes, hipMemcpyDeviceToHost, ctx->stream);
-        if (e != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e));
-        if (!rc) rc = sync_stream(ctx);
+    int64_t* pcnt = reinterpret_cast<int64_t*>(blob + npart * 32);
+    if (!rd_take_clean_lg(ctx)) { void* ptr[2] = {r_keys, r_flags}; size_t bytes[2] = {LG_SLOTS * 8, 8}; unsigned char byte[2] = {0xFF, 0}; fill_regions(ctx, ptr, bytes, byte, 2); }
+    int rc;
+    if (sink == SINK_GROUP_LANE) {
+        XGroupLane<1>::Args sa{r_keys, pacc, pcnt, r_flags, nslots, 0};
+        rc = launch(ctx, fn, "x_groupby_lane", a, sa, nrows, g, (unsigned)((size_t)nslots * (size_t)(prog->nvals + 1) * TPB * 8));
+    } else {
+        XGroup<1>::Args sa{r_keys, pacc, pcnt, r_flags};
+        rc = launch(ctx, fn, x.tight ? "x_groupby_tight" : "x_groupby", a, sa, nrows, g);
     }
+    if (!rc) {
+        launch_groupby_merge_lg_host(ctx, r_keys, pacc, pcnt, (int)g.grid, r_flags);       // writes the pinned host block, leaves the device block clean
+        call_end(ctx);
+        rc = sync_stream(ctx);
+    }
+    (void)r_acc; (void)r_cnt; (void)rbytes;
     pool_free(ctx, blob);
     if (rc) return rc;
     const char* h = static_cast<const char*>(ctx->result_host);
     const int flags = *reinterpret_cast<const int*>(h + LG_SLOTS * 48);
-    if (flags & 2) return fail(ctx, SDQH_ERR_UNSUPPORTED, "xgroupby: negative group key");
+    if (flags & 2) return fail(ctx, SDQH_ERR_UNSUPPORTED, "xgroupby: negative group key (or a key outside the range its columns span)");
     const unsigned long long* hk = reinterpret_cast<const unsigned long long*>(h);
     const double* ha = reinterpret_cast<const double*>(h + LG_SLOTS * 8);
     const int64_t* hc = reinterpret_cast<const int64_t*>(h + LG_SLOTS * 40);

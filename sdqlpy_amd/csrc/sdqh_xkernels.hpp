@@ -27,6 +27,11 @@ struct XArgs {
     const void* col[SDQH_MAX_XCOLS];
     const void* ncol[SDQH_MAX_XCOLS];           // exact 4-byte twins of the STREAMED columns that have one (sload reads them; everything by row reads col)
     int32_t width[SDQH_MAX_XCOLS];              // STR columns: code units per row
+    const void* code[SDQH_MAX_XCOLS];           // sorted-dictionary code twins (1 or 2 bytes per row) of the columns a TIGHT program streams that way
+    const int64_t* dict[SDQH_MAX_XCOLS];        // their dictionaries: ndict raw 8-byte values, ascending
+    int32_t ndict[SDQH_MAX_XCOLS];
+    uint32_t cc[X_MAX_CONST];                   // constants of comparisons translated into code space (ranks), see sdqh_x.hip: tight_plan
+    int64_t dlo[SDQH_MAX_XCOLS];                // coded integer columns whose distinct values are consecutive: value = code + dlo (no table)
     DevTable tab[SDQH_MAX_XTABLES];
     int64_t ci[X_MAX_CONST];
     double cf[X_MAX_CONST];
@@ -487,6 +492,157 @@ __device__ __forceinline__ void x_queue(const XArgs& a, const typename SinkT<P::
         }
         if constexpr (SEGMENTED) sink.end_segment(sa, seg, begin);
     }
+    sink.finish(a, sa);
+}
+
+
+// =================================================================================================
+// TIGHT: the DIRECT shape over columns at their tightest exact encoding — sorted-dictionary codes of 1 or 2
+// bytes (sdqh_codes.hip), the 4-byte twins, or the 8-byte column itself — XT_R = 8 consecutive rows per lane
+// and load step: a code column is one 8- or 16-byte load per lane, a 4-byte twin two 16-byte loads.  What the
+// codes buy beyond bytes: a comparison of a coded column with a constant is ONE integer comparison of the code
+// with the constant's rank (the host translates the constant at launch: XArgs::cc), and a coded column's value
+// is one LDS read of its dictionary (P::ND tables of 256 entries, loaded once per workgroup) — no decode
+// arithmetic.  Q1 streams 11 bytes per row (22 through 4-byte twins, 48 in the reference's layout), Q6 8.
+// P::Regs holds the packed words of a lane's 8 rows; P::sload<TAIL>; P::eval(a, regs, tabs, i, r, out) -> pass
+// evaluates row i (i is a constant after unrolling: every extraction is a fixed bit slice).
+// Measured in tools/microbench_tight.hip before it was built: DESIGN.md §3c.
+// =================================================================================================
+constexpr int XT_R = 8;
+constexpr int XT_ROWS = TPB * XT_R;                                    // rows per workgroup tile
+constexpr int XT_U = 2;                                                // tiles in flight per step
+
+// the 8 rows of a lane: BPR bytes per row -> BPR * 2 32-bit words
+template <int BPR, bool TAIL>
+__device__ __forceinline__ void xt_load(const void* __restrict__ p, int64_t r, int64_t nrows, uint32_t (&w)[BPR * 2]) {
+    if constexpr (!TAIL) {
+        const char* q = static_cast<const char*>(p) + r * BPR;
+        if constexpr (BPR == 1) {
+            using V = uint32_t __attribute__((ext_vector_type(2)));
+            const V t = __builtin_nontemporal_load(reinterpret_cast<const V*>(q));
+            w[0] = t.x; w[1] = t.y;
+        } else {
+            using V = uint32_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int i = 0; i < BPR / 2; ++i) {
+                const V t = __builtin_nontemporal_load(reinterpret_cast<const V*>(q) + i);
+                w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < BPR * 2; ++i) w[i] = 0u;
+#pragma unroll
+        for (int i = 0; i < XT_R; ++i) {
+            const int64_t ri = r + i < nrows ? r + i : nrows - 1;
+            if constexpr (BPR == 1) w[i / 4] |= (uint32_t)static_cast<const uint8_t*>(p)[ri] << (8 * (i % 4));
+            else if constexpr (BPR == 2) w[i / 2] |= (uint32_t)static_cast<const uint16_t*>(p)[ri] << (16 * (i % 2));
+            else if constexpr (BPR == 4) w[i] = static_cast<const uint32_t*>(p)[ri];
+            else { const uint64_t v = static_cast<const uint64_t*>(p)[ri]; w[2 * i] = (uint32_t)v; w[2 * i + 1] = (uint32_t)(v >> 32); }
+        }
+    }
+}
+__device__ __forceinline__ uint32_t xt_u8(const uint32_t (&w)[2], int i) { return (w[i / 4] >> (8 * (i % 4))) & 0xFFu; }
+__device__ __forceinline__ uint32_t xt_u16(const uint32_t (&w)[4], int i) { return (w[i / 2] >> (16 * (i % 2))) & 0xFFFFu; }
+__device__ __forceinline__ int32_t xt_i32(const uint32_t (&w)[8], int i) { return (int32_t)w[i]; }
+__device__ __forceinline__ int64_t xt_i64(const uint32_t (&w)[16], int i) { return (int64_t)((uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32)); }
+
+// ---- K-C over a DENSE small key range [key_lo, key_hi]: every lane owns its accumulators in LDS ----
+// acc[(slot * (NV + 1) + k) * TPB + thread]: no two lanes share a cell, so ds_add_f64 (no return) is a plain
+// read-modify-write in the LDS unit: ONE DS instruction per summed value and row, where accumulators in registers
+// cost G x NV predicated adds per row (G groups unknown at compile time) and made the kernel ALU-bound once the
+// bytes were halved (tools/microbench_tight.hip: 0.20-0.25 ms in registers, 0.118 ms this way, SF=10 Q1).
+// Deterministic: a lane adds its rows in row order, lanes are folded in a fixed order, workgroups by
+// k_groupby_merge in workgroup order.  The slots are the key's offsets, so no key table and no claiming.
+template <int NV> struct XGroupLane {
+    struct Args { unsigned long long* gkeys; double* pacc; int64_t* pcnt; int* flags; int32_t nslots, _pad; };
+    static constexpr int NA = (NV > 0 ? NV : 0) + 1;
+    int nslots; bool bad;
+    // (cells are addressed as 32-bit indices into the dynamic LDS array: through a generic pointer kept in the object the compiler
+    //  did the address arithmetic in 64 bits, a multiply included, per value and row)
+    __device__ __forceinline__ void init(const Args& s) {
+        extern __shared__ double x_dyn[];
+        nslots = s.nslots; bad = false;
+        for (int i = threadIdx.x; i < nslots * NA * TPB; i += TPB) x_dyn[i] = 0.0;
+    }
+    __device__ __forceinline__ void consume(const XArgs& a, const Args&, bool pass, int64_t, const XOut<NV>& o) {
+        extern __shared__ double x_dyn[];
+        const uint64_t d = (uint64_t)(o.key - a.key_lo);
+        const bool ok = !o.bad && d < (uint64_t)nslots;
+        bad = bad || (pass && !ok);
+        if (pass && ok) {
+            const uint32_t cell = (uint32_t)d * (uint32_t)(NA * TPB) + threadIdx.x;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) __hip_atomic_fetch_add(&x_dyn[cell + (uint32_t)(k * TPB)], x_f(o.val[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // (a lane's own row count: 32 bits are plenty, and a 4-byte LDS add costs the LDS half of an 8-byte one)
+            __hip_atomic_fetch_add(reinterpret_cast<unsigned int*>(&x_dyn[cell + (uint32_t)((NA - 1) * TPB)]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __device__ __forceinline__ void finish(const XArgs& a, const Args& s) {
+        __shared__ double s_red[TPB / WAVE][NA];
+        const int w = threadIdx.x / WAVE, lane = lane_id();
+        if (__ballot(bad) && lane == 0) atomicOr(s.flags, 2);
+        __syncthreads();
+        for (int g = 0; g < nslots; ++g) {
+#pragma unroll
+            for (int k = 0; k < NA; ++k) {
+                extern __shared__ double x_dyn[];
+                double v = x_dyn[(uint32_t)((g * NA + k) * TPB) + threadIdx.x];
+                if (k == NA - 1) { const int64_t c = wave_sum_i64((int64_t)(uint32_t)__double_as_longlong(v)); if (lane == 0) reinterpret_cast<int64_t*>(s_red[w])[k] = c; }
+                else { v = wave_sum(v); if (lane == 0) s_red[w][k] = v; }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const size_t e = (size_t)g * gridDim.x + blockIdx.x;
+                int64_t c = 0;
+                for (int i = 0; i < TPB / WAVE; ++i) c += reinterpret_cast<const int64_t*>(s_red[i])[NA - 1];
+                s.pcnt[e] = c;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { double v = 0.0; if (k < NV) for (int i = 0; i < TPB / WAVE; ++i) v += s_red[i][k < NA ? k : 0]; s.pacc[e * 4 + k] = v; }
+                if (blockIdx.x == 0) s.gkeys[g] = (unsigned long long)(a.key_lo + g);
+            }
+            __syncthreads();
+        }
+    }
+};
+
+template <class P, template <int> class SinkT>
+__device__ __forceinline__ void x_tight(const XArgs& a, const typename SinkT<P::NV>::Args& sa, int64_t nrows) {
+    using Sink = SinkT<P::NV>;
+    __shared__ int64_t s_tab[P::ND > 0 ? P::ND : 1][256];
+    P::load_dicts(a, s_tab);
+    Sink sink;
+    sink.init(sa);
+    __syncthreads();
+    auto tile = [&](int64_t base, auto tail_tag, auto u_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        constexpr int U = decltype(u_tag)::value ? XT_U : 1;
+        typename P::Regs s[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) P::template sload<TAIL>(a, base + (int64_t)u * XT_ROWS + (int64_t)threadIdx.x * XT_R, nrows, s[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = base + (int64_t)u * XT_ROWS + (int64_t)threadIdx.x * XT_R;
+#pragma unroll
+            for (int i = 0; i < XT_R; ++i) {
+                XOut<P::NV> o;
+                bool p = TAIL ? (r + i < nrows) : true;
+                p = p && P::eval(a, s[u], s_tab, i, r + i, o);
+                sink.consume(a, sa, p, r + i, o);
+            }
+        }
+    };
+    const int64_t step = (int64_t)XT_ROWS * XT_U;
+    const int64_t full = nrows / step;
+    for (int64_t t = blockIdx.x; t < full; t += gridDim.x) tile(t * step, XBool<false>{}, XBool<true>{});
+    // what is left (< XT_U tiles + a ragged one): single tiles dealt round-robin from the workgroup after the last full step
+    const int64_t rest0 = full * step;
+    const int64_t ntail = (nrows - rest0 + XT_ROWS - 1) / XT_ROWS;
+    for (int64_t j = 0; j < ntail; ++j)
+        if (blockIdx.x == (unsigned)((full + j) % gridDim.x)) {
+            const int64_t base = rest0 + j * XT_ROWS;
+            if (base + XT_ROWS <= nrows) tile(base, XBool<false>{}, XBool<false>{}); else tile(base, XBool<true>{}, XBool<false>{});
+        }
     sink.finish(a, sa);
 }
 

@@ -93,6 +93,10 @@ class Engine:
         self._distinct_cache = {}  # id(ndarray) -> (ndarray, has no repeated value)
         self._frozen = {}          # id(ndarray) -> ndarray made read-only on adoption (see column())
         self.force_programs = os.environ.get("SDQLPY_AMD_FORCE_PROGRAMS") == "1"   # every loop as a row program (xplan.py), none through the fixed-shape calls
+        # pure streaming loops (a sum / small group-by over one table, no lookups: Q1, Q6) go to their row program first: the
+        # specialised kernel streams every column at its tightest exact encoding (dictionary codes of 1 / 2 bytes, csrc/sdqh_xkernels.hpp
+        # x_tight), which the fixed-shape kernels' 4-byte twins cannot.  The HIP library only: the CPU implementation interprets programs.
+        self.stream_programs = os.environ.get("SDQLPY_AMD_STREAM_PROGRAMS", "1") != "0" and ctx.library.backend_name() == "hip-gfx950"
 
     def close(self):
         self.clear()
@@ -845,7 +849,25 @@ def _has_codable_text_payload(eng, op, htab):
                and eng.dict_column(htab.cols[e.name]) is not None for e in vals)
 
 
-def _prepare_scan(eng, op, htab, accumulate_into, member_only=False, as_table=False, coded_text=False):
+def _is_stream_loop(op):
+    """A loop that only streams its table: a scalar sum or an aggregation (not a unique build), no probe, no lookup anywhere."""
+    if op.kind not in ("scalar", "dict") or (op.kind == "dict" and op.unique) or op.probe is not None:
+        return False
+    found = []
+    for c in list(op.conds) + [c for _, _, fc in (op.fields or []) for c in fc]:
+        if isinstance(c, Contains):
+            return False
+        _walk_lookups(c, found)
+    if op.kind == "dict":
+        _walk_lookups(op.key, found)
+    if op.val is not None and not isinstance(op.val, Const):
+        _walk_lookups(op.val, found)
+    for _, e, _ in (op.fields or []):
+        _walk_lookups(e, found)
+    return not found
+
+
+def _prepare_scan(eng, op, htab, accumulate_into, member_only=False, as_table=False, coded_text=False, _no_stream=False):
     """closure(env) for one table loop: the tuned fixed-shape calls when the loop is one of their shapes,
     a row program (xplan.py: a kernel specialised on the loop's own conditions and values) otherwise.
     A fixed-shape closure can still refuse at run time (a group count beyond its kernels): the loop then
@@ -857,6 +879,22 @@ def _prepare_scan(eng, op, htab, accumulate_into, member_only=False, as_table=Fa
             return xplan.prepare_scan(eng, op, htab, accumulate_into, member_only, as_table)
         except UnsupportedQuery:
             pass
+    if getattr(eng, "stream_programs", False) and not _no_stream and not as_table and not member_only and _is_stream_loop(op):
+        try:
+            x = xplan.prepare_scan(eng, op, htab, accumulate_into, member_only, as_table)
+        except UnsupportedQuery:
+            x = None
+        if x is not None:
+            state0 = {"fixed": None}
+
+            def run_stream(env):
+                if state0["fixed"] is None:
+                    try:
+                        return x(env)
+                    except UnsupportedQuery:                        # e.g. more groups than the program's sinks hold: the fixed shapes decide
+                        state0["fixed"] = _prepare_scan(eng, op, htab, accumulate_into, member_only, as_table, coded_text, _no_stream=True)
+                return state0["fixed"](env)
+            return run_stream
     if coded_text and op.kind == "dict" and op.unique and op.probe is None and _has_codable_text_payload(eng, op, htab):
         # a later loop tests this build's text values: build them as dictionary codes (row program), not row references
         try:

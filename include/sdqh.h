@@ -293,6 +293,17 @@ int sdqh_table_share_groups(sdqh_ctx* ctx, sdqh_table* table, int nfields, const
 int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, int64_t capacity,
                        int64_t* out_keys, int64_t* out_payload, double* out_values,
                        int64_t* out_hits, int64_t* out_n);
+/* K-F with the rows delivered BEHIND the call — the reference's result object also defers its conversion to Python values to
+ * `to_dict()` (src/sdqlpy/fastd.py:31-51; the map itself is filled by K-F, ...generator_par.py:520-568, 871-877).  Same arguments
+ * and results as sdqh_table_compact, with out_keys | out_payload | out_values | out_hits laid out back to back (in this order,
+ * `capacity` rows per array) in ONE sdqh_host_alloc block: the call returns once *out_n is known; the rows arrive by a
+ * device-to-host copy queued behind the kernels on a stream of its own, so the kernels of the next call run beside it.  The
+ * arrays must not be read (or the block reused) before sdqh_result_wait — or sdqh_synchronize — has returned.  Any other layout,
+ * or the option "async_result" = 0, makes it the synchronous call.  The CPU build fills the arrays before it returns. */
+int sdqh_table_compact_async(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, int64_t capacity,
+                             int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n);
+/* Wait for every result copy queued by sdqh_table_compact_async on this context. */
+int sdqh_result_wait(sdqh_ctx* ctx);
 
 /* Result memory the device can write: when every out_* array of a first sdqh_table_compact call
  * (no count-only call before it) lies inside one sdqh_host_alloc block, the compaction kernel

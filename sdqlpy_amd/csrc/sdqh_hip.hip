@@ -82,7 +82,25 @@ void call_end(sdqh_ctx* ctx) {
     do { KernelScope _ks(ctx, name); hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3(TPB), (lds_bytes), (ctx)->stream, __VA_ARGS__); } while (0)
 
 int sync_stream(sdqh_ctx* ctx) {
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    bool done = false;
+    if (ctx->opt_spin_sync && !ctx->compile_only) {
+        if (!ctx->sync_flag) {
+            void* p = nullptr;
+            if (hipHostMalloc(&p, 64, hipHostMallocDefault) == hipSuccess) { ctx->sync_flag = static_cast<volatile uint32_t*>(p); *ctx->sync_flag = 0; }
+            else { (void)hipGetLastError(); ctx->opt_spin_sync = 0; }
+        }
+        if (ctx->sync_flag) {
+            const uint32_t seq = ++ctx->sync_seq;
+            if (hipStreamWriteValue32(ctx->stream, const_cast<uint32_t*>(ctx->sync_flag), seq, 0) == hipSuccess) {
+                // poll; after ~2 s of nothing fall back to the runtime's wait (it also reports a faulted kernel)
+                for (uint64_t spins = 0; spins < (1ull << 31); ++spins) {
+                    if (*ctx->sync_flag == seq) { done = true; break; }
+                    __builtin_ia32_pause();
+                }
+            } else { (void)hipGetLastError(); ctx->opt_spin_sync = 0; }
+        }
+    }
+    if (!done) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->profiling == 1) for (auto& e : ctx->prof) { float ms = 0; if (hipEventElapsedTime(&ms, e.e0, e.e1) == hipSuccess) e.ms = ms; }
     return SDQH_OK;
 }
@@ -504,11 +522,17 @@ void sdqh_destroy(sdqh_ctx* ctx) {
     if (ctx->compile_only) { delete ctx; return; }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->side[i]) { (void)hipStreamSynchronize(ctx->side[i]); (void)hipStreamDestroy(ctx->side[i]); }
+        if (ctx->rs_copied[i]) (void)hipEventDestroy(ctx->rs_copied[i]);
+        if (ctx->rs_dev[i]) (void)hipFree(ctx->rs_dev[i]);
+    }
     for (auto& b : ctx->pool) if (b.ptr) (void)hipFree(b.ptr);
     for (int i = 0; i < 2; ++i) { if (ctx->staging[i]) (void)hipHostFree(ctx->staging[i]); if (ctx->staging_done[i]) (void)hipEventDestroy(ctx->staging_done[i]); }
     if (ctx->result_host) (void)hipHostFree(ctx->result_host);
     if (ctx->bulk_host) (void)hipHostFree(ctx->bulk_host);
     if (ctx->count_host) (void)hipHostFree(ctx->count_host);
+    if (ctx->sync_flag) (void)hipHostFree(const_cast<uint32_t*>(ctx->sync_flag));
     if (ctx->result_dev) (void)hipFree(ctx->result_dev);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->call_begin) (void)hipEventDestroy(ctx->call_begin);
@@ -519,7 +543,15 @@ void sdqh_destroy(sdqh_ctx* ctx) {
 
 const char* sdqh_last_error(const sdqh_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 int sdqh_set_threads(sdqh_ctx* ctx, int threads) { if (!ctx || threads < 1) return SDQH_ERR_INVALID; ctx->threads = threads; return SDQH_OK; }
-int sdqh_synchronize(sdqh_ctx* ctx) { if (!ctx) return SDQH_ERR_INVALID; return sync_stream(ctx); }
+int sdqh_result_wait(sdqh_ctx* ctx) {
+    if (!ctx) return SDQH_ERR_INVALID;
+    if (!ctx->rs_pending) return SDQH_OK;
+    ctx->rs_pending = false;
+    (void)hipSetDevice(ctx->device);
+    for (int i = 0; i < 2; ++i) if (ctx->rs_used[i]) HIP_TRY(ctx, hipEventSynchronize(ctx->rs_copied[i]));
+    return SDQH_OK;
+}
+int sdqh_synchronize(sdqh_ctx* ctx) { if (!ctx) return SDQH_ERR_INVALID; if (int rc = sync_stream(ctx)) return rc; return sdqh_result_wait(ctx); }
 int sdqh_last_device_ms(const sdqh_ctx* cctx, double* ms) {
     sdqh_ctx* ctx = const_cast<sdqh_ctx*>(cctx);
     if (!ctx || !ms) return SDQH_ERR_INVALID;
@@ -576,6 +608,7 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "feature_min_rows" && value >= 0) ctx->opt_feature_min_rows = value;
     else if (n == "narrow" && value >= 0 && value <= 1) ctx->opt_narrow = (int)value;
     else if (n == "tight" && value >= 0 && value <= 1) ctx->opt_tight = (int)value;
+    else if (n == "spin_sync" && value >= 0 && value <= 1) ctx->opt_spin_sync = (int)value;
     else if (n == "side_streams" && value >= 0 && value <= 1) ctx->opt_side_streams = (int)value;
     else if (n == "async_result" && value >= 0 && value <= 1) ctx->opt_async_result = (int)value;
     else if (n == "stage_pipeline" && value >= 0 && value <= 1) ctx->opt_stage_pipeline = (int)value;
@@ -1588,6 +1621,79 @@ int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_hits
     if (out_hits) if (int rc = fetch(out_hits, o.hits)) return rc;
     if (int rc = sync_stream(ctx)) return rc;
     for (auto& c : copies) std::memcpy(c.first, c.second, nb);
+    return SDQH_OK;
+}
+
+// K-F with the rows delivered behind the call.  count -> write (each wave sums the counts before its segment) into one of two
+// device staging buffers laid out like the caller's arrays; the stream is synchronised for the row count only; the rows leave
+// by ONE device-to-host copy queued on a stream of its own, so the next call's kernels run beside it (writing 3.6 MB of Q3's
+// result over PCIe from the kernel itself held the stream for 80 us of the query's 400).
+int sdqh_table_compact_async(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_hits, int64_t capacity,
+                             int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n) {
+    sdqh_table* table = const_cast<sdqh_table*>(ctable);
+    if (!ctx || !table || !out_n || capacity < 1 || !out_keys) return fail(ctx, SDQH_ERR_INVALID, "table_compact_async: bad arguments");
+    if (table->bitmap_only) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_compact_async: bitmap-only table");
+    (void)hipSetDevice(ctx->device);
+    const int npay = out_payload ? table->npay : 0, nval = (out_values && table->accumulate) ? table->nv : 0;
+    // the caller's arrays: keys | payload[npay] | values[TUPLE_MAX] | hits, each `capacity` rows, in ONE host block, in this order
+    const size_t cb = (size_t)capacity * 8;
+    char* base = reinterpret_cast<char*>(out_keys);
+    const int narr = 1 + (out_payload ? table->npay : 0) + (out_values ? SDQH_TUPLE_MAX_VALUES : 0) + (out_hits ? 1 : 0);
+    bool contiguous = in_host_block(ctx, base, cb * (size_t)narr);
+    size_t at = cb;
+    if (out_payload) { contiguous = contiguous && reinterpret_cast<char*>(out_payload) == base + at; at += cb * (size_t)table->npay; }
+    if (out_values) { contiguous = contiguous && reinterpret_cast<char*>(out_values) == base + at; at += cb * SDQH_TUPLE_MAX_VALUES; }
+    if (out_hits) { contiguous = contiguous && reinterpret_cast<char*>(out_hits) == base + at; at += cb; }
+    if (!ctx->opt_async_result || !contiguous)                           // not the layout this path copies in one piece: the synchronous call
+        return sdqh_table_compact(ctx, ctable, min_hits, capacity, out_keys, out_payload, out_values, out_hits, out_n);
+    if (!ctx->side[1] && hipStreamCreateWithFlags(&ctx->side[1], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->side[1] = nullptr; }
+    if (!ctx->count_host && hipHostMalloc(&ctx->count_host, 256, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->count_host = nullptr; }
+    const int b = ctx->rs_cur;
+    if (!ctx->rs_copied[b] && hipEventCreateWithFlags(&ctx->rs_copied[b], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->rs_copied[b] = nullptr; }
+    if (!ctx->side[1] || !ctx->count_host || !ctx->rs_copied[b]) return sdqh_table_compact(ctx, ctable, min_hits, capacity, out_keys, out_payload, out_values, out_hits, out_n);
+    const size_t need = cb * (size_t)narr;
+    if (ctx->rs_bytes[b] < need) {
+        if (ctx->rs_used[b]) HIP_TRY(ctx, hipEventSynchronize(ctx->rs_copied[b]));
+        if (ctx->rs_dev[b]) (void)hipFree(ctx->rs_dev[b]);
+        ctx->rs_dev[b] = nullptr; ctx->rs_bytes[b] = 0;
+        const size_t want = std::max<size_t>(need + need / 4, (size_t)4 << 20);
+        if (hipMalloc(&ctx->rs_dev[b], want) != hipSuccess) { (void)hipGetLastError(); return sdqh_table_compact(ctx, ctable, min_hits, capacity, out_keys, out_payload, out_values, out_hits, out_n); }
+        ctx->rs_bytes[b] = want;
+    }
+    call_begin(ctx);
+    if (int rc = ensure_index(ctx, table)) return rc;
+    if (ctx->rs_used[b]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->rs_copied[b], 0));       // the buffer's last copy has left it
+    DevCompactOut o; std::memset(&o, 0, sizeof(o));
+    char* dev = static_cast<char*>(ctx->rs_dev[b]);
+    size_t off = 0;
+    o.keys = reinterpret_cast<int64_t*>(dev); off += cb;
+    for (int p = 0; p < (out_payload ? table->npay : 0); ++p) { o.pay[p] = reinterpret_cast<int64_t*>(dev + off); off += cb; }
+    if (out_values) { for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) { if (k < nval) o.val[k] = reinterpret_cast<double*>(dev + off); off += cb; } }
+    if (out_hits) { o.hits = reinterpret_cast<int64_t*>(dev + off); off += cb; }
+    o.npay = npay; o.nval = nval;
+    o.counter = reinterpret_cast<unsigned long long*>(static_cast<char*>(ctx->count_host) + 64);      // (device-visible pinned word: the kernel's own copy of the total)
+    o.h_counter = static_cast<unsigned long long*>(ctx->count_host);
+    o.host_rows = (uint64_t)capacity; o.bounded = 1;
+    const uint32_t mh = (uint32_t)std::min<int64_t>(std::max<int64_t>(min_hits, 0), 0xFFFFFFFFll);
+    const unsigned seg_grid = (unsigned)((table->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
+    if (!table->seg_kept) { table->seg_kept = static_cast<uint32_t*>(table_alloc(ctx, table, (size_t)table->stage.nseg * 4 + 64)); if (!table->seg_kept) return fail(ctx, SDQH_ERR_NOMEM, "table_compact_async: out of device memory"); }
+    table->compact_valid = false;
+    LAUNCH(ctx, "k_compact_count", k_compact_count, seg_grid, table->dev, table->stage, o, mh, table->seg_kept);
+    LAUNCH(ctx, "k_compact_write2", k_compact_write2, seg_grid, table->dev, table->stage, o, mh, table->seg_kept);
+    call_end(ctx);
+    if (int rc = sync_stream(ctx)) return rc;
+    const int64_t n = (int64_t)*o.h_counter;
+    *out_n = n;
+    if (n > capacity) return fail(ctx, SDQH_ERR_OVERFLOW, "table_compact_async: capacity too small");
+    if (n == 0) return SDQH_OK;
+    // two copies at most: keys .. the last USED value array as one piece (the unused tails of the arrays in between ride along),
+    // then the hit counts; value slots the tuple does not use are not part of either and are zeroed here
+    const int lead = 1 + (out_payload ? table->npay : 0) + nval;
+    HIP_TRY(ctx, hipMemcpyAsync(base, dev, cb * (size_t)(lead - 1) + (size_t)n * 8, hipMemcpyDeviceToHost, ctx->side[1]));
+    if (out_hits) HIP_TRY(ctx, hipMemcpyAsync(out_hits, o.hits, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->side[1]));
+    HIP_TRY(ctx, hipEventRecord(ctx->rs_copied[b], ctx->side[1]));
+    ctx->rs_used[b] = true; ctx->rs_pending = true; ctx->rs_cur = b ^ 1;
+    if (out_values) for (int k = nval; k < SDQH_TUPLE_MAX_VALUES; ++k) std::memset(out_values + (size_t)k * (size_t)capacity, 0, (size_t)n * 8);
     return SDQH_OK;
 }
 

@@ -92,6 +92,14 @@ struct sdqh_ctx {
     hipStream_t side[2] = {nullptr, nullptr};      // side streams: independent build chains of a plan run beside the main stream (fork / join by events)
     hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int opt_side_streams = 1;
+    // K-F rows delivered behind the call (sdqh_table_compact_async): two device staging buffers in turn, a copy stream (side[1]),
+    // the event of each buffer's last copy, and whether a copy may still be in flight
+    void* rs_dev[2] = {nullptr, nullptr}; size_t rs_bytes[2] = {0, 0};
+    hipEvent_t rs_copied[2] = {nullptr, nullptr}; bool rs_used[2] = {false, false};
+    int rs_cur = 0; bool rs_pending = false;
+    // sync_stream: a 32-bit sequence number written by the stream itself into pinned memory (hipStreamWriteValue32) and polled by
+    // the host, instead of the runtime's wait (which sleeps on an interrupt: tens of microseconds per query on a 0.2 - 0.5 ms query)
+    volatile uint32_t* sync_flag = nullptr; uint32_t sync_seq = 0; int opt_spin_sync = 1;
     int opt_async_result = 1;                      // K-F's rows reach the host by a copy queued behind the kernels; the caller waits when it reads them
     int opt_narrow = 1;                            // streaming kernels (k_scan_sum, k_groupby_reg) read predicates / operands through exact 4-byte twins when every one of them has one
     int opt_stage_pipeline = 0;                    // k_stage (tuned orders-like family): first-stage loads of the next step requested a step ahead (measured: Q3 orders 0.148 -> 0.151 ms, no gain: off)

@@ -2721,13 +2721,14 @@ struct DevCompactOut {
     int64_t* h_keys; int64_t* h_pay[SDQH_MAX_PAYLOAD]; double* h_val[SDQH_TUPLE_MAX_VALUES]; int64_t* h_hits;
     unsigned long long* h_counter;
     uint64_t host_rows;
-    int32_t direct, _pad;
+    int32_t direct, bounded;                                          // bounded: keys / pay / val / hits hold host_rows rows each, rows beyond are dropped
 };
 
 constexpr int COMPACT_BATCH = 8;                                     // 64-entry groups whose hit counters are fetched together
 
 // one survivor per lane, converged: every load of the copy is in flight before the first store
 __device__ __forceinline__ void compact_copy(const DevStage& st, const DevCompactOut& o, int64_t idx, uint64_t at, uint32_t hits) {
+    if (o.bounded && at >= o.host_rows) return;                       // a destination sized from the caller's capacity: the count still comes out right
     int64_t k = 0, pay[SDQH_MAX_PAYLOAD] = {0, 0, 0, 0};
     double val[SDQH_TUPLE_MAX_VALUES] = {0, 0, 0, 0};
     if (o.keys) k = st.key[idx];
@@ -2848,6 +2849,24 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_compact_write(DevTable t, DevStage st,
         for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) o.val[k] = o.h_val[k];
     }
     compact_segment<true>(t, st, o, min_hits, seg, (uint64_t)seg_off[seg], s_idx[threadIdx.x / WAVE], s_hits[threadIdx.x / WAVE]);
+}
+
+// 3'. write, every wave finding its own offset: the counts of the segments before its own are summed by its 64 lanes (a few
+// thousand 4-byte reads, L2-resident) — no scan launch between count and write.  The wave of the last segment publishes the
+// total.  Rows go to the device staging arrays in o (bounded by o.host_rows); the host copies them out behind the kernels.
+SDQH_KERNEL __launch_bounds__(TPB) void k_compact_write2(DevTable t, DevStage st, DevCompactOut o, uint32_t min_hits, const uint32_t* __restrict__ seg_kept) {
+    __shared__ uint32_t s_idx[TPB / WAVE][COMPACT_QCAP], s_hits[TPB / WAVE][COMPACT_QCAP];
+    const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
+    if (seg >= st.nseg) return;
+    long long before = 0;
+    for (int i = lane_id(); i < seg; i += WAVE) before += seg_kept[i];
+    before = __shfl(wave_sum_i64(before), 0, WAVE);
+    if (seg == st.nseg - 1 && lane_id() == 0) {
+        const unsigned long long total = (unsigned long long)before + seg_kept[seg];
+        *o.counter = total;
+        if (o.h_counter) *o.h_counter = total;
+    }
+    compact_segment<true>(t, st, o, min_hits, seg, (uint64_t)before, s_idx[threadIdx.x / WAVE], s_hits[threadIdx.x / WAVE]);
 }
 
 // =================================================================================================

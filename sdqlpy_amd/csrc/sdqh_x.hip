@@ -48,6 +48,15 @@ std::string entry_name(Sink s, bool direct, bool tight) {
     return std::string("xk_") + sk + (tight ? "_tight" : direct ? "_direct" : "_queue");
 }
 enum Enc { ENC_RAW = 0, ENC_N32 = 1, ENC_C16 = 2, ENC_C8 = 3 };
+// the same name as the profiling label of a launch (a pointer that stays valid): bench.py's per-kernel table and rocprofv3's agree on names
+const char* launch_label(Sink s, bool direct, bool tight) {
+    static std::mutex mu; static std::vector<std::string*> names;
+    const std::string n = entry_name(s, direct, tight);
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto* have : names) if (*have == n) return have->c_str();
+    names.push_back(new std::string(n));
+    return names.back()->c_str();
+}
 
 // ---- program analysis -------------------------------------------------------------------------------
 struct XInfo {
@@ -77,6 +86,9 @@ struct XInfo {
     int64_t dlo[SDQH_MAX_XCOLS] = {};
     signed char irange[SDQH_MAX_XOPS] = {};  // i64 operations over the columns' actual ranges: 0 unknown / wide, 1 fits int32, 2 fits 24 bits (32-bit arithmetic, v_mul_i32_i24)
     bool fake = false;
+    bool pref32 = false;                     // the prefilter's key and its table's bitmap range fit 32 bits: the streamed test is 32-bit arithmetic
+    uint32_t gather32 = 0;                   // queue programs: numeric columns read BY ROW (the drain's gathers) through their 4-byte twins: half the bytes of every touched line
+    std::vector<char> scope;                 // operations evaluated on the streamed registers (register programs: all; queue programs: the streamed gates + the prefilter's key)
 };
 
 bool op_is_light(const sdqh_xop& o) {        // evaluable on streamed registers
@@ -273,9 +285,9 @@ template <class T> void translate_cmp(const std::vector<int64_t>& dict, bool f64
     auto val = [&](size_t i) -> T { if constexpr (sizeof(T) == 8 && T(0.5) != T(0)) { double d; std::memcpy(&d, &dict[i], 8); return (T)d; } else return (T)dict[i]; };
     (void)f64;
     const size_t n = dict.size();
-    size_t lb = 0, ub = 0;                                             // first index with value >= cst / > cst
-    while (lb < n && val(lb) < cst) ++lb;
-    ub = lb; while (ub < n && !(cst < val(ub))) ++ub;
+    size_t lb = 0, ub = n;                                             // first index with value >= cst / > cst (binary searches: ascending values)
+    { size_t lo = 0, hi = n; while (lo < hi) { const size_t mid = (lo + hi) / 2; if (val(mid) < cst) lo = mid + 1; else hi = mid; } lb = lo; }
+    { size_t lo = lb, hi = n; while (lo < hi) { const size_t mid = (lo + hi) / 2; if (!(cst < val(mid))) lo = mid + 1; else hi = mid; } ub = lo; }
     const bool nan = cst != cst;
     switch (op) {
         case SDQH_X_LT: *kind = 0; *t = nan ? 0u : (uint32_t)lb; break;           // value <  cst  <=>  code <  lb
@@ -295,35 +307,49 @@ void tight_plan(sdqh_ctx* ctx, int64_t nrows, XInfo* x) {
     const sdqh_program* p = x->p;
     for (int k = 0; k < p->nops; ++k) x->cmp_cc[k] = x->cmp_kind[k] = x->cmp_col[k] = -1;
     for (int c = 0; c < SDQH_MAX_XCOLS; ++c) { x->enc[c] = ENC_RAW; x->dict_slot[c] = -1; }
-    x->tight = false; x->nd = 0; x->ncc = 0;
+    x->tight = false; x->nd = 0; x->ncc = 0; x->gather32 = 0; x->pref32 = false;
     // (a compile-only context has no columns to code; SDQLPY_AMD_FAKE_CODES makes it pretend every column is coded — 2 bytes where
     //  only compared, 1 byte where its value is used — so that build() proves on a host without a GPU that the generator's tight
     //  output compiles for gfx950)
     const bool fake = ctx->compile_only && std::getenv("SDQLPY_AMD_FAKE_CODES") != nullptr;
     static const std::vector<int64_t> fake_dict = {0, 1, 2, 3};
-    if (!x->direct || !ctx->opt_tight || x->ncols < 1) return;
-    // every register program runs on the tight skeleton, whatever its columns' encodings: rows meet lanes, and partial sums are folded, in
-    // the same order with and without twins, so switching the twins off changes no bit of a sum (tests/test_hip_parity.py)
+    if (!ctx->opt_tight || x->ncols < 1 || (!x->direct && x->scols.empty())) return;
+    // Every register program runs on the tight skeleton, and every queue program that streams anything on the tight queue,
+    // whatever its columns' encodings: rows meet lanes, partial sums are folded and queues are drained in the same order with and
+    // without twins, so switching the twins off changes no bit of a sum (tests/test_hip_parity.py).
     x->tight = true;
     x->fake = fake;
-    x->narrow_mask = 0;                                                    // (what analyse chose for the two-rows-per-lane skeleton)
+    uint32_t text_twins = 0;
+    for (int c = 0; c < x->ncols; ++c) if (x->cols[c]->dtype == SDQH_STR) text_twins |= x->narrow_mask & (1u << c);
+    x->narrow_mask = text_twins;                                           // (the 4-byte twins analyse chose were for the two-rows-per-lane skeletons)
+    x->scope.assign((size_t)p->nops, x->direct ? 1 : 0);
+    std::vector<char> streamed((size_t)x->ncols, x->direct ? 1 : 0);
+    if (!x->direct) {
+        for (int g = 0; g < x->nstream_gates; ++g) closure(p, p->gates[g], x->scope);
+        if (x->prefilter_part0 >= 0) closure(p, x->prefilter_part0, x->scope);
+        for (int c : x->scols) streamed[(size_t)c] = 1;
+    }
     if (!ctx->opt_narrow || (ctx->compile_only && !fake) || (!fake && nrows < ctx->opt_feature_min_rows)) return;
-    // how every COL operation is used
+    // how every streamed COL operation is used by what is evaluated on the streamed registers
     std::vector<char> cmp_only((size_t)x->ncols, 1), used((size_t)x->ncols, 0);
     auto direct_ref = [&](int k) {
+        if (!x->direct) {                                                  // a streamed gate that IS the column cannot be (gates are bool); the prefilter reads its key's value
+            return k == x->prefilter_part0;
+        }
         if (p->key == k) return true;
         for (int g = 0; g < p->ngates; ++g) if (p->gates[g] == k) return true;
         for (int v = 0; v < p->nvals; ++v) if (p->vals[v] == k) return true;
         return false;
     };
     for (int k = 0; k < p->nops; ++k) {
-        if (p->ops[k].code != SDQH_X_COL) continue;
+        if (p->ops[k].code != SDQH_X_COL || !x->scope[(size_t)k]) continue;
         const int c = x->col_of[k];
+        if (!streamed[(size_t)c]) continue;
         used[(size_t)c] = 1;
         if (direct_ref(k)) cmp_only[(size_t)c] = 0;
         for (int j = k + 1; j < p->nops; ++j) {
             const sdqh_xop& u = p->ops[j];
-            if (u.code == SDQH_X_COL || u.code == SDQH_X_CONST || u.code == SDQH_X_ROWID) continue;
+            if (!x->scope[(size_t)j] || u.code == SDQH_X_COL || u.code == SDQH_X_CONST || u.code == SDQH_X_ROWID) continue;
             const bool reads = u.a == k || u.b == k || (u.code == SDQH_X_SELECT && u.c == k);
             if (!reads) continue;
             const int other = u.a == k ? u.b : u.a;
@@ -334,7 +360,7 @@ void tight_plan(sdqh_ctx* ctx, int64_t nrows, XInfo* x) {
     for (int c = 0; c < x->ncols; ++c) {
         if (!used[(size_t)c]) continue;
         sdqh_column* col = const_cast<sdqh_column*>(x->cols[c]);
-        if (col->dtype == SDQH_STR) return;                                // (register programs have no text columns)
+        if (col->dtype == SDQH_STR) continue;                              // (text is never streamed)
         if (fake) {
             x->enc[c] = cmp_only[(size_t)c] ? ENC_C16 : (c % 3 == 2 ? ENC_N32 : ENC_C8);
             if (x->enc[c] == ENC_C8) x->dict_slot[c] = x->nd++;
@@ -344,7 +370,16 @@ void tight_plan(sdqh_ctx* ctx, int64_t nrows, XInfo* x) {
         } else if (column_narrow(ctx, col)) x->enc[c] = ENC_N32;
         any = any || x->enc[c] != ENC_RAW;
     }
+    if (!x->direct && !fake) {
+        // columns the drain reads by row (keys and payloads of a build, operands of a probe hit): survivors are a few per cent of the
+        // rows, scattered, so a gather moves whole lines for single values — through the 4-byte twin the same lines are half as many
+        std::vector<char> by_row((size_t)x->ncols, 0);
+        for (int k = 0; k < p->nops; ++k) if (p->ops[k].code == SDQH_X_COL && !x->scope[(size_t)k]) by_row[(size_t)x->col_of[k]] = 1;
+        for (int c = 0; c < x->ncols; ++c)
+            if (by_row[(size_t)c] && x->cols[c]->dtype != SDQH_STR && column_narrow(ctx, const_cast<sdqh_column*>(x->cols[c]))) { x->gather32 |= 1u << c; any = true; }
+    }
     if (!any) return;
+    for (int c = 0; c < x->ncols; ++c) if (x->enc[c] == ENC_N32) x->narrow_mask |= 1u << c;
     for (int c = 0; c < x->ncols; ++c) {
         const sdqh_column* col = x->cols[c];
         if (x->enc[c] < ENC_C16 || col->dtype != SDQH_I64) continue;
@@ -355,15 +390,19 @@ void tight_plan(sdqh_ctx* ctx, int64_t nrows, XInfo* x) {
     }
     for (int k = 0; k < p->nops; ++k) {
         int64_t lo = 0, hi = 0;
-        if (p->ops[k].type == SDQH_T_I64 && op_interval(ctx, *x, k, &lo, &hi))
+        if (x->scope[(size_t)k] && p->ops[k].type == SDQH_T_I64 && op_interval(ctx, *x, k, &lo, &hi))
             x->irange[k] = (lo >= -(1 << 23) && hi < (1 << 23)) ? 2 : (lo >= INT32_MIN && hi <= INT32_MAX) ? 1 : 0;
     }
-    x->narrow_mask = 0;
-    for (int c = 0; c < x->ncols; ++c) if (x->enc[c] == ENC_N32) x->narrow_mask |= 1u << c;
+    if (!x->direct && x->prefilter_op >= 0 && !x->prefilter_composite && !fake) {
+        const sdqh_table* t = x->tabs[x->tab_of[x->prefilter_op]];
+        const bool applicable = t->dev.bm && t->dev.bm_shift == 0 && t->dev.lin_rb == 0;
+        x->pref32 = applicable && x->irange[x->prefilter_part0] >= 1 && t->dev.bm_lo >= INT32_MIN && t->dev.bm_hi <= INT32_MAX && t->dev.bm_hi >= t->dev.bm_lo;
+    }
+    if (fake && !x->direct && x->prefilter_op >= 0 && !x->prefilter_composite) x->pref32 = true;
     // comparisons of a coded column with a constant, in code space
     for (int j = 0; j < p->nops; ++j) {
         const sdqh_xop& u = p->ops[j];
-        if (!is_cmp(u.code)) continue;
+        if (!is_cmp(u.code) || !x->scope[(size_t)j]) continue;
         int kc = -1, kk = -1, op = u.code;
         if (p->ops[u.a].code == SDQH_X_COL && p->ops[u.b].code == SDQH_X_CONST) { kc = u.a; kk = u.b; }
         else if (p->ops[u.b].code == SDQH_X_COL && p->ops[u.a].code == SDQH_X_CONST) { kc = u.b; kk = u.a; op = mirrored(op); }
@@ -439,6 +478,8 @@ struct Gen {
         const sdqh_xop& o = x.p->ops[k];
         const int c = x.col_of[k];
         std::string raw;
+        if (mode == 0 && ((x.gather32 >> c) & 1u))
+            return o.type == SDQH_T_F64 ? "narrow_decode(static_cast<const int32_t*>(a.ncol[" + std::to_string(c) + "])[r])" : "(int64_t)static_cast<const int32_t*>(a.ncol[" + std::to_string(c) + "])[r]";
         if (mode == 0) return std::string("static_cast<const ") + (o.type == SDQH_T_F64 ? "double" : "int64_t") + "*>(a.col[" + std::to_string(c) + "])[r]";
         if (mode == 4) return o.type == SDQH_T_F64 ? "x_f(dv)" : "dv";         // tabulating: the dictionary entry
         if (mode == 3) {                                                   // TIGHT: row i of the lane's 8, out of the packed words s.c<slot>
@@ -614,6 +655,7 @@ std::string generate_tight(const XInfo& x, Sink sink) {
 
 std::string generate(const XInfo& x, Sink sink, bool direct) {
     if (x.tight && direct) return generate_tight(x, sink);
+    const bool q8 = x.tight && !direct;                                 // the queue skeleton with the tight streamed part (x_queue8)
     const sdqh_program* p = x.p;
     Gen g(x);
     std::vector<int> scols = x.scols;
@@ -641,7 +683,80 @@ std::string generate(const XInfo& x, Sink sink, bool direct) {
     int nsop = 0;
     for (auto& ops : tops) for (int k : ops) g.sres_of[(size_t)k] = nsop++;
     const int nsopx = std::max(1, nsop);
-    out << "struct P {\n    static constexpr int NS = " << ns << ", NV = " << p->nvals << ", NSC = " << tcols.size() << ", NSOP = " << nsop << ";\n";
+    // q8: the streamed conditions first — their emission decides which operations become dictionary tables
+    std::string stest8, spre8, spre32;
+    std::vector<std::pair<int, int>> tabs8;
+    auto bpr = [&](int c) { return x.enc[c] == ENC_C8 ? 1 : x.enc[c] == ENC_C16 ? 2 : x.enc[c] == ENC_N32 ? 4 : 8; };
+    if (q8) {
+        g.reset(); g.mode = 3; g.os.str("");
+        g.os << "        bool p = true;\n";
+        for (int q = 0; q < x.nstream_gates; ++q) { g.emit(p->gates[q]); g.os << "        p = p & v" << p->gates[q] << ";\n"; }
+        if (x.prefilter_op >= 0) {
+            g.emit(x.prefilter_part0);
+            g.os << "        p = p && x_may_hit(a.tab[" << x.tab_of[x.prefilter_op] << "], v" << x.prefilter_part0 << ", " << (x.prefilter_composite ? "true" : "false") << ");\n";
+        }
+        g.os << "        return p;\n";
+        stest8 = g.os.str();
+        // the same in two halves for the batched form: the cheap conditions and where the key's bit lives (word index, bit), the
+        // word loads and the bit tests being the skeleton's
+        g.reset(); g.mode = 3; g.os.str("");
+        g.os << "        bool p = true;\n";
+        for (int q = 0; q < x.nstream_gates; ++q) { g.emit(p->gates[q]); g.os << "        p = p & v" << p->gates[q] << ";\n"; }
+        if (x.prefilter_op >= 0) {
+            g.emit(x.prefilter_part0);
+            const std::string t = "a.tab[" + std::to_string(x.tab_of[x.prefilter_op]) + "]";
+            g.os << "        p = p & (v" << x.prefilter_part0 << " >= " << t << ".bm_lo) & (v" << x.prefilter_part0 << " <= " << t << ".bm_hi);\n";
+            g.os << "        const uint64_t off = p ? (uint64_t)(v" << x.prefilter_part0 << " - " << t << ".bm_lo) : 0ull;\n";
+            g.os << "        widx = (uint32_t)(off >> 5); bit = (uint32_t)off & 31u;\n";
+        } else g.os << "        widx = 0; bit = 0;\n";
+        g.os << "        return p;\n";
+        spre8 = g.os.str();
+        if (x.pref32) {
+            g.reset(); g.mode = 3; g.os.str("");
+            g.os << "        bool p = true;\n";
+            for (int q = 0; q < x.nstream_gates; ++q) { g.emit(p->gates[q]); g.os << "        p = p & v" << p->gates[q] << ";\n"; }
+            g.emit(x.prefilter_part0);
+            const std::string t = "a.tab[" + std::to_string(x.tab_of[x.prefilter_op]) + "]";
+            g.os << "        const uint32_t o32 = (uint32_t)((int32_t)v" << x.prefilter_part0 << " - (int32_t)" << t << ".bm_lo);\n";
+            g.os << "        p = p & (o32 <= (uint32_t)(" << t << ".bm_hi - " << t << ".bm_lo));\n";
+            g.os << "        off = p ? o32 : 0u;\n        return p;\n";
+            spre32 = g.os.str();
+        }
+        tabs8 = g.tabs;
+    }
+    out << "struct P {\n    static constexpr int NS = " << ns << ", NV = " << p->nvals << ", NSC = " << tcols.size() << ", NSOP = " << nsop << ", ND = " << tabs8.size() << ";\n";
+    if (q8) {
+        out << "    struct Regs {";
+        for (int i = 0; i < ns; ++i) out << " uint32_t c" << i << "[" << bpr(scols[(size_t)i]) * 2 << "];";
+        out << " };\n";
+        out << "    __device__ __forceinline__ static void load_dicts(const XArgs& a, int64_t (*tab)[256]) {\n";
+        for (size_t j = 0; j < tabs8.size(); ++j) {
+            const int k = tabs8[j].first, c = tabs8[j].second;
+            Gen t(x);
+            t.mode = 4; t.dict_col = c;
+            t.emit(k);
+            const int ty = p->ops[k].type;
+            out << "        for (int i = threadIdx.x; i < 256; i += TPB) {\n            int64_t cell = 0;\n            if (i < a.ndict[" << c << "]) {\n                const int64_t dv = a.dict[" << c << "][i];\n";
+            out << t.os.str();
+            out << "                cell = " << (ty == SDQH_T_F64 ? "x_bits(v" + std::to_string(k) + ")" : ty == SDQH_T_BOOL ? "(v" + std::to_string(k) + " ? 1 : 0)" : "v" + std::to_string(k)) << ";\n";
+            out << "            }\n            tab[" << j << "][i] = cell;\n        }\n";
+        }
+        out << "    }\n";
+        out << "    template <bool TAIL> __device__ __forceinline__ static void sload(const XArgs& a, int64_t r, int64_t nrows, Regs& s) {\n";
+        for (int i = 0; i < ns; ++i) {
+            const int c = scols[(size_t)i];
+            const char* src = x.enc[c] >= ENC_C16 ? "a.code[" : x.enc[c] == ENC_N32 ? "a.ncol[" : "a.col[";
+            out << "        xt_load<" << bpr(c) << ", TAIL>(" << src << c << "], r, nrows, s.c" << i << ");\n";
+        }
+        out << "    }\n";
+        out << "    __device__ __forceinline__ static bool stest(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i) {\n" << stest8 << "    }\n";
+        out << "    __device__ __forceinline__ static bool spre(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i, uint32_t& widx, uint32_t& bit) {\n" << spre8 << "    }\n";
+        out << "    static constexpr bool PREF32 = " << (x.pref32 ? "true" : "false") << ";\n";
+        out << "    __device__ __forceinline__ static bool spre32(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i, uint32_t& off) {\n"
+            << (x.pref32 ? spre32 : std::string("        off = 0; return false;\n")) << "    }\n";
+        out << "    __device__ __forceinline__ static const uint32_t* sbitmap(const XArgs& a) { return "
+            << (x.prefilter_op >= 0 ? "x_prefilter_bitmap(a.tab[" + std::to_string(x.tab_of[x.prefilter_op]) + "], " + (x.prefilter_composite ? "true" : "false") + ")" : std::string("nullptr")) << "; }\n";
+    }
     if (!tcols.empty()) {
         out << "    __device__ __forceinline__ static constexpr int scol(int j) { return j == 0 ? " << tcols[0] << " : " << (tcols.size() > 1 ? tcols[1] : tcols[0]) << "; }\n";
         out << "    __device__ __forceinline__ static constexpr int swidth(int j) { return j == 0 ? " << twidth[0] << " : " << (twidth.size() > 1 ? twidth[1] : twidth[0]) << "; }\n";
@@ -657,6 +772,7 @@ std::string generate(const XInfo& x, Sink sink, bool direct) {
         }
         out << "    }\n";
     }
+    if (!q8) {
     out << "    template <bool TAIL> __device__ __forceinline__ static void sload(const XArgs& a, int64_t r, int64_t nrows, Pair<int64_t> (&s)[" << nsx << "]) {\n";
     for (int i = 0; i < ns; ++i) {
         const int c = scols[(size_t)i];
@@ -677,6 +793,7 @@ std::string generate(const XInfo& x, Sink sink, bool direct) {
         out << g.os.str() << "      }\n";
     }
     out << "    }\n";
+    }   // !q8
     auto body = [&](int mode, int from_gate) {
         g.reset(); g.mode = mode; g.os.str("");
         for (int q = from_gate; q < p->ngates; ++q) { g.emit(p->gates[q]); g.os << "        if (!v" << p->gates[q] << ") return false;\n"; }
@@ -697,9 +814,9 @@ std::string generate(const XInfo& x, Sink sink, bool direct) {
     if (!direct) out << body(0, first_gate); else out << "        return false;\n";
     out << "    }\n};\n";
     const std::string sn = sink_name(sink);
-    out << "extern \"C\" __global__ __launch_bounds__(256) void " << entry_name(sink, direct, false) << "(XArgs a, " << sn << "<P::NV>::Args s, int64_t nrows, int64_t seg_rows, int nseg) {\n";
+    out << "extern \"C\" __global__ __launch_bounds__(256) void " << entry_name(sink, direct, q8) << "(XArgs a, " << sn << "<P::NV>::Args s, int64_t nrows, int64_t seg_rows, int nseg) {\n";
     if (direct) out << "    x_direct<P, " << sn << ">(a, s, nrows);\n";
-    else out << "    x_queue<P, " << sn << ", " << (sink == SINK_STAGE ? "true" : "false") << ">(a, s, nrows, seg_rows, nseg);\n";
+    else out << "    " << (q8 ? "x_queue8" : "x_queue") << "<P, " << sn << ", " << (sink == SINK_STAGE ? "true" : "false") << ">(a, s, nrows, seg_rows, nseg);\n";
     out << "}\n";
     return out.str();
 }
@@ -754,10 +871,10 @@ bool load_headers(JitState& J) {
 uint64_t structure_hash(const XInfo& x, Sink sink, bool direct) {
     const sdqh_program* p = x.p;
     uint64_t h = 1469598103934665603ull;
-    auto mix = [&](uint64_t v) { for (int i = 0; i < 8; ++i) { h ^= (v >> (8 * i)) & 0xFF; h *= 1099511628211ull; } };
+    auto mix = [&](uint64_t v) { h ^= v; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29; };      // (a word at a time: this runs on every call)
     mix((uint64_t)sink * 2 + (direct ? 1 : 0)); mix((uint64_t)x.narrow_mask);
-    if (x.tight && direct) {
-        mix(0x7167ull);
+    if (x.tight) {
+        mix(0x7167ull); mix((uint64_t)x.gather32); mix(x.pref32 ? 1ull : 0ull);
         for (int c = 0; c < x.ncols; ++c) mix(((uint64_t)(uint32_t)x.enc[c] << 32) | ((uint32_t)(x.affine[c] ? 1 : 0) << 16) | (uint32_t)(x.dict_slot[c] & 0xFFFF));
         for (int k = 0; k < x.p->nops; ++k) mix((uint64_t)(uint8_t)x.irange[k]);
         for (int k = 0; k < x.p->nops; ++k) mix(((uint64_t)(uint32_t)x.cmp_cc[k] << 32) | ((uint32_t)x.cmp_kind[k] << 8) | (uint32_t)(x.cmp_col[k] & 0xFF));
@@ -785,7 +902,7 @@ int kernel_for(sdqh_ctx* ctx, const XInfo& x, Sink sink, bool direct, hipFunctio
         auto hit = J.kernels.find(name);
         if (hit != J.kernels.end()) { *fn = hit->second; return SDQH_OK; }
     }
-    if (int rc = specialise(ctx, generate(x, sink, direct), entry_name(sink, direct, x.tight && direct), fn)) return rc;
+    if (int rc = specialise(ctx, generate(x, sink, direct), entry_name(sink, direct, x.tight), fn)) return rc;
     std::lock_guard<std::mutex> lock(J.mu);
     J.kernels[name] = *fn;
     return SDQH_OK;
@@ -849,7 +966,7 @@ template <class SA> struct Packed { XArgs a; SA s; int64_t nrows; int64_t seg_ro
 
 int fill_xargs(sdqh_ctx* ctx, const XInfo& x, XArgs* a, int32_t* flags, int64_t key_lo, int64_t key_hi) {
     std::memset(a, 0, sizeof(*a));
-    for (int c = 0; c < x.ncols; ++c) { a->col[c] = x.cols[c]->data; a->width[c] = x.cols[c]->width; a->ncol[c] = ((x.narrow_mask >> c) & 1u) ? x.cols[c]->narrow : nullptr; }
+    for (int c = 0; c < x.ncols; ++c) { a->col[c] = x.cols[c]->data; a->width[c] = x.cols[c]->width; a->ncol[c] = (((x.narrow_mask | x.gather32) >> c) & 1u) ? x.cols[c]->narrow : nullptr; }
     for (int t = 0; t < x.ntabs; ++t) {
         if (int rc = index_ensure(ctx, x.tabs[t])) return rc;
         a->tab[t] = x.tabs[t]->dev;
@@ -869,14 +986,14 @@ Geometry geometry_tight(sdqh_ctx* ctx, int64_t nrows, int resident) {
     const int64_t steps = std::max<int64_t>(1, nrows / ((int64_t)XT_ROWS * XT_U));
     return Geometry{(unsigned)std::min<int64_t>(steps, (int64_t)ctx->num_cu * resident), 0, 0};
 }
-Geometry geometry(sdqh_ctx* ctx, int64_t nrows, bool direct, int waves_per_cu) {
+Geometry geometry(sdqh_ctx* ctx, int64_t nrows, bool direct, int waves_per_cu, bool tight = false) {
     Geometry g{1, 0, 0};
     if (direct) {
         const int64_t tiles = ((nrows + TILE_ROWS - 1) / TILE_ROWS + SDQH_TILE_CHUNK - 1) / SDQH_TILE_CHUNK;
         g.grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)ctx->num_cu * ctx->opt_resident_stream));
         return g;
     }
-    const int64_t gran = (int64_t)WAVE * ROWS_PER_LOAD * X_LB;
+    const int64_t gran = tight ? (int64_t)X8_STEP * X8_U : (int64_t)WAVE * ROWS_PER_LOAD * X_LB;      // a wave's segment is whole steps of its skeleton
     const int64_t target = (int64_t)ctx->num_cu * waves_per_cu;
     int64_t seg_rows = (nrows + target - 1) / target;
     seg_rows = std::max<int64_t>(gran, (seg_rows + gran - 1) / gran * gran);
@@ -931,11 +1048,11 @@ int sdqh_xscan_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, doubl
     rd_dirty(ctx);
     int32_t* d_flags = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->result_dev) + 1024);
     if (int rc = fill_xargs(ctx, x, &a, d_flags, 1, 0)) return rc;
-    const Geometry g = x.tight ? geometry_tight(ctx, nrows, 2) : geometry(ctx, nrows, x.direct, 16);
+    const Geometry g = (x.tight && x.direct) ? geometry_tight(ctx, nrows, 2) : geometry(ctx, nrows, x.direct, 16, x.tight);
     double* partial = static_cast<double*>(pool_alloc(ctx, (size_t)g.grid * 5 * sizeof(double)));
     if (!partial) return fail(ctx, SDQH_ERR_NOMEM, "xscan_sum: out of device memory");
     XSum<1>::Args sa{partial};
-    int rc = launch(ctx, fn, x.tight ? "x_scan_sum_tight" : "x_scan_sum", a, sa, nrows, g);
+    int rc = launch(ctx, fn, launch_label(SINK_SUM, x.direct, x.tight), a, sa, nrows, g);
     if (!rc) {
         launch_sum_partials(ctx, partial, (int)g.grid, static_cast<double*>(ctx->result_host));      // the fold writes the pinned host block: no copy-engine launch
         call_end(ctx);
@@ -978,7 +1095,7 @@ int sdqh_xgroupby(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int ma
     static_assert(LG_SLOTS * 48 + 8 <= RESULT_BYTES, "result block too small");
     XArgs a;
     if (int rc = fill_xargs(ctx, x, &a, r_flags, klo, khi)) return rc;
-    const Geometry g = x.tight ? geometry_tight(ctx, nrows, 2) : geometry(ctx, nrows, x.direct, 16);
+    const Geometry g = (x.tight && x.direct) ? geometry_tight(ctx, nrows, 2) : geometry(ctx, nrows, x.direct, 16, x.tight);
     const size_t npart = (size_t)g.grid * LG_SLOTS;
     char* blob = static_cast<char*>(pool_alloc(ctx, npart * 40 + 256));
     if (!blob) return fail(ctx, SDQH_ERR_NOMEM, "xgroupby: out of device memory");
@@ -988,10 +1105,10 @@ int sdqh_xgroupby(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int ma
     int rc;
     if (sink == SINK_GROUP_LANE) {
         XGroupLane<1>::Args sa{r_keys, pacc, pcnt, r_flags, nslots, 0};
-        rc = launch(ctx, fn, "x_groupby_lane", a, sa, nrows, g, (unsigned)((size_t)nslots * (size_t)(prog->nvals + 1) * TPB * 8));
+        rc = launch(ctx, fn, launch_label(SINK_GROUP_LANE, true, true), a, sa, nrows, g, (unsigned)((size_t)nslots * (size_t)(prog->nvals + 1) * TPB * 8));
     } else {
         XGroup<1>::Args sa{r_keys, pacc, pcnt, r_flags};
-        rc = launch(ctx, fn, x.tight ? "x_groupby_tight" : "x_groupby", a, sa, nrows, g);
+        rc = launch(ctx, fn, launch_label(SINK_GROUP, x.direct, x.tight), a, sa, nrows, g);
     }
     if (!rc) {
         launch_groupby_merge_lg_host(ctx, r_keys, pacc, pcnt, (int)g.grid, r_flags);       // writes the pinned host block, leaves the device block clean
@@ -1045,7 +1162,7 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
     sdqh_table* tb = new sdqh_table();
     tb->npay = prog->nvals; tb->accumulate = accumulate != 0; tb->nrows_build = nrows;
     call_begin(ctx);
-    int rc = stage_setup_computed(ctx, tb, nrows, prog->nvals, X_LB);
+    int rc = stage_setup_computed(ctx, tb, nrows, prog->nvals, x.tight ? (X8_STEP * X8_U) / 128 : X_LB);
     uint64_t capmax = 1024;
     while (capmax < 2 * (uint64_t)std::max<int64_t>(nrows, 1)) capmax <<= 1;
     tb->capmax = capmax;
@@ -1073,7 +1190,7 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
             // the segments were cut by stage_setup_computed: the kernel's geometry must be the stage's
             Geometry g{(unsigned)((tb->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE)), tb->stage.seg_rows, tb->stage.nseg};
             XStage<1>::Args sa{tb->stage};
-            rc = launch(ctx, fn, "x_build", a, sa, nrows, g);
+            rc = launch(ctx, fn, launch_label(SINK_STAGE, false, x.tight), a, sa, nrows, g);
         }
         call_end(ctx);
         int f = 0;
@@ -1116,9 +1233,9 @@ int sdqh_xkey_set(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_
     XArgs a;
     int rc = fill_xargs(ctx, x, &a, flags, key_lo, key_hi);
     if (!rc && nrows > 0) {
-        const Geometry g = geometry(ctx, nrows, false, 16);
+        const Geometry g = geometry(ctx, nrows, false, 16, x.tight);
         XKeySet<1>::Args sa{tb->bm};
-        rc = launch(ctx, fn, "x_key_set", a, sa, nrows, g);
+        rc = launch(ctx, fn, launch_label(SINK_KEYSET, false, x.tight), a, sa, nrows, g);
     }
     call_end(ctx);
     int f = 0;
@@ -1150,9 +1267,9 @@ int sdqh_xprobe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog
     rd_dirty(ctx);
     int32_t* d_flags = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->result_dev) + 1024);
     if (int rc = fill_xargs(ctx, x, &a, d_flags, 1, 0)) return rc;
-    const Geometry g = geometry(ctx, nrows, false, 24);
+    const Geometry g = geometry(ctx, nrows, false, 24, x.tight);
     XEntry<1>::Args sa{table->dev};
-    int rc = launch(ctx, fn, "x_probe_agg", a, sa, nrows, g);
+    int rc = launch(ctx, fn, launch_label(SINK_ENTRY, false, x.tight), a, sa, nrows, g);
     call_end(ctx);
     return rc;
 }

@@ -109,6 +109,13 @@ __device__ __forceinline__ bool x_may_hit(const DevTable& t, int64_t part0, bool
     const uint64_t off = (uint64_t)(part0 - t.bm_lo);
     return (t.bm[off >> 5] >> (off & 31)) & 1u;
 }
+// the bitmap x_may_hit would test `part0` against, or null when it would answer "maybe" for every key (wave-uniform)
+__device__ __forceinline__ const uint32_t* x_prefilter_bitmap(const DevTable& t, bool composite) {
+    if (!t.bm) return nullptr;
+    if (composite ? (t.bm_shift == 0 && !t.lin_rb) : (t.bm_shift != 0 || t.lin_rb != 0)) return nullptr;
+    if (composite && t.lin_rb) return nullptr;
+    return t.bm;
+}
 __device__ __forceinline__ int64_t x_field(const DevTable& t, int f, uint32_t ent) { return ent == NO_ROW ? 0 : t.pay[f][ent]; }
 __device__ __forceinline__ double x_acc(const DevTable& t, int k, uint32_t ent) {
     if (ent == NO_ROW) return 0.0;
@@ -643,6 +650,165 @@ __device__ __forceinline__ void x_tight(const XArgs& a, const typename SinkT<P::
             const int64_t base = rest0 + j * XT_ROWS;
             if (base + XT_ROWS <= nrows) tile(base, XBool<false>{}, XBool<false>{}); else tile(base, XBool<true>{}, XBool<false>{});
         }
+    sink.finish(a, sa);
+}
+
+
+// =================================================================================================
+// QUEUE on tight encodings: the QUEUE shape with the streamed part of TIGHT — one wave per contiguous row
+// segment, but a lane takes XT_R = 8 consecutive rows per step out of packed words (dictionary codes, 4-byte
+// twins), tests the cheap leading conditions on them in code space (P::stest(a, regs, tab, i)) and appends its
+// survivors to the wave's LDS queue IN ROW ORDER (lane-major: an exclusive prefix sum of the lanes' survivor
+// counts); the drain (text staging, P::eval_row, the sinks) is QUEUE's own.  X8_U steps' loads are in flight
+// before the first is tested.  Q3's probe streams 6 bytes per lineitem row this way (key through its 4-byte
+// twin, date as a 2-byte code) where the two-rows-per-lane form read 8 and issued four times the loads.
+// =================================================================================================
+constexpr int X8_U = 2;
+constexpr int X8_STEP = WAVE * XT_R;                                  // 512 rows per wave step
+constexpr int X8_CAP = 64 + X8_U * X8_STEP;
+
+__device__ __forceinline__ int wave_excl_prefix(int v, int& total) {  // exclusive prefix sum over the 64 lanes; total = the wave's sum
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) { const int o = __shfl_up(incl, off, WAVE); if (lane_id() >= off) incl += o; }
+    total = __shfl(incl, WAVE - 1, WAVE);
+    return incl - v;
+}
+
+template <class P, template <int> class SinkT, bool SEGMENTED>
+__device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P::NV>::Args& sa, int64_t nrows, int64_t seg_rows, int nseg) {
+    using Sink = SinkT<P::NV>;
+    __shared__ int32_t s_row[TPB / WAVE][X8_CAP];
+    __shared__ uint32_t s_text[P::NSC > 0 ? TPB / WAVE : 1][P::NSC > 0 ? XSTR_UNITS : 1];
+    __shared__ int64_t s_tab[P::ND > 0 ? P::ND : 1][256];
+    P::load_dicts(a, s_tab);
+    Sink sink;
+    sink.init(sa);
+    __syncthreads();
+    const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
+    const bool live = seg < nseg;
+    int32_t* q_row = s_row[threadIdx.x / WAVE];
+    uint32_t* s_str = s_text[P::NSC > 0 ? threadIdx.x / WAVE : 0];
+    const int lane = lane_id();
+    const int64_t begin = (int64_t)seg * seg_rows;                     // (a segment is far shorter than 2^31 rows: the host checks)
+    int64_t end = begin + seg_rows; if (end > nrows) end = nrows;
+    if constexpr (SEGMENTED) sink.begin_segment(begin);
+    int qn = 0;
+    const uint32_t* pbm = P::sbitmap(a);                               // the prefilter's key bitmap, or null (wave-uniform)
+    auto drain = [&](int first, int count) {                           // rows q_row[first .. first + count), one per lane, in row order
+        XOut<P::NV> o;
+        int64_t sres[P::NSOP > 0 ? P::NSOP : 1] = {0};
+        if constexpr (P::NSC > 0) x_stage_text<P, 0>(a, q_row, begin, first, count, s_str, sres);
+        if constexpr (P::NSC > 1) x_stage_text<P, 1>(a, q_row, begin, first, count, s_str, sres);
+        bool pass = false; int64_t r = 0;
+        if (lane < count) { r = begin + (int64_t)q_row[first + lane]; pass = P::eval_row(a, r, sres, o); }
+        sink.consume(a, sa, pass, r, o);
+    };
+    auto enqueue8 = [&](int64_t r0, uint32_t m) {                      // m: bit i = row r0 + i of this lane survives
+        if (!__ballot(m != 0)) return;
+        int total;
+        int at = qn + wave_excl_prefix(__popc(m), total);
+        const int32_t off = (int32_t)(r0 - begin);
+#pragma unroll
+        for (int i = 0; i < XT_R; ++i) if ((m >> i) & 1u) q_row[at++] = off + i;
+        qn += total;
+    };
+    if (live) {
+        for (int64_t b = begin;;) {
+            const bool last = b >= end;
+            if (last) {
+            } else if (b + (int64_t)X8_STEP * X8_U <= end) {
+                typename P::Regs s[X8_U];
+#pragma unroll
+                for (int u = 0; u < X8_U; ++u) P::template sload<false>(a, b + (int64_t)u * X8_STEP + (int64_t)lane * XT_R, nrows, s[u]);
+                uint32_t m[X8_U];
+                if constexpr (P::PREF32) {
+                    // 32-bit form (the key and the bitmap's range fit 32 bits — known when the kernel was specialised): a row costs
+                    // a subtract, an unsigned compare, a select, a shift and a bit-field extract.  The 64-bit form below spent ~30
+                    // vector instructions per row and left the kernel issue-bound at half of what its bytes allow (PMC, Q3's probe)
+                    uint32_t off[X8_U][XT_R], w[X8_U][XT_R];
+#pragma unroll
+                    for (int u = 0; u < X8_U; ++u) {
+                        m[u] = 0;
+#pragma unroll
+                        for (int i = 0; i < XT_R; ++i) { const bool p = P::spre32(a, s[u], s_tab, i, off[u][i]); m[u] |= p ? (1u << i) : 0u; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < X8_U; ++u)
+#pragma unroll
+                        for (int i = 0; i < XT_R; ++i) w[u][i] = pbm[off[u][i] >> 5];
+#pragma unroll
+                    for (int u = 0; u < X8_U; ++u) {
+                        uint32_t hit = 0;
+#pragma unroll
+                        for (int i = 0; i < XT_R; ++i) hit |= __builtin_amdgcn_ubfe(w[u][i], off[u][i] & 31u, 1u) << i;
+                        m[u] &= hit;
+                    }
+                } else if (pbm) {
+                    // the prefilter's bitmap words of all 16 rows are requested before any is tested (a load inside each row's own
+                    // `if (passes the cheap conditions)` region made a step sixteen dependent round trips)
+                    uint32_t wi[X8_U][XT_R], w[X8_U][XT_R];
+#pragma unroll
+                    for (int u = 0; u < X8_U; ++u) {
+                        m[u] = 0;
+#pragma unroll
+                        for (int i = 0; i < XT_R; ++i) { uint32_t bit; const bool p = P::spre(a, s[u], s_tab, i, wi[u][i], bit); m[u] |= p ? (1u << i) : 0u; wi[u][i] |= bit << 27; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < X8_U; ++u)
+#pragma unroll
+                        for (int i = 0; i < XT_R; ++i) w[u][i] = pbm[wi[u][i] & 0x07FFFFFFu];
+#pragma unroll
+                    for (int u = 0; u < X8_U; ++u)
+#pragma unroll
+                        for (int i = 0; i < XT_R; ++i) m[u] &= ~(((~w[u][i] >> (wi[u][i] >> 27)) & 1u) << i);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < X8_U; ++u) {
+                        m[u] = 0;
+#pragma unroll
+                        for (int i = 0; i < XT_R; ++i) m[u] |= P::stest(a, s[u], s_tab, i) ? (1u << i) : 0u;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < X8_U; ++u) enqueue8(b + (int64_t)u * X8_STEP + (int64_t)lane * XT_R, m[u]);
+                b += (int64_t)X8_STEP * X8_U;
+            } else if (b + X8_STEP <= end) {                                  // one whole step left
+                typename P::Regs s1;
+                const int64_t r0 = b + (int64_t)lane * XT_R;
+                P::template sload<false>(a, r0, nrows, s1);
+                uint32_t m = 0;
+#pragma unroll
+                for (int i = 0; i < XT_R; ++i) m |= P::stest(a, s1, s_tab, i) ? (1u << i) : 0u;
+                enqueue8(r0, m);
+                b += X8_STEP;
+            } else {
+                const int64_t r0 = b + (int64_t)lane * XT_R;
+                typename P::Regs s1;
+                P::template sload<true>(a, r0, end, s1);
+                uint32_t m = 0;
+#pragma unroll
+                for (int i = 0; i < XT_R; ++i) m |= (r0 + i < end && P::stest(a, s1, s_tab, i)) ? (1u << i) : 0u;
+                enqueue8(r0, m);
+                b += X8_STEP;
+            }
+            int head = 0;
+            while (qn - head >= WAVE || (last && qn > head)) {
+                const int n = qn - head >= WAVE ? WAVE : qn - head;
+                drain(head, n);
+                head += n;
+            }
+            if (last) break;
+            if (head) {
+                const int left = qn - head;                               // < 64
+                int32_t keepv = 0;
+                if (lane < left) keepv = q_row[head + lane];
+                if (lane < left) q_row[lane] = keepv;
+                qn = left;
+            }
+        }
+        if constexpr (SEGMENTED) sink.end_segment(sa, seg, begin);
+    }
     sink.finish(a, sa);
 }
 

@@ -96,6 +96,8 @@ class Engine:
         # pure streaming loops (a sum / small group-by over one table, no lookups: Q1, Q6) go to their row program first: the
         # specialised kernel streams every column at its tightest exact encoding (dictionary codes of 1 / 2 bytes, csrc/sdqh_xkernels.hpp
         # x_tight), which the fixed-shape kernels' 4-byte twins cannot.  The HIP library only: the CPU implementation interprets programs.
+        # K-F rows of a query's RESULT reach the host behind the call (sdqh_table_compact_async); the ResultSet waits on first read
+        self.lazy_results = os.environ.get("SDQLPY_AMD_LAZY_RESULTS", "1") != "0"
         self.stream_programs = os.environ.get("SDQLPY_AMD_STREAM_PROGRAMS", "1") != "0" and ctx.library.backend_name() == "hip-gfx950"
 
     def close(self):
@@ -1214,7 +1216,17 @@ def _fetch_entries(eng, bt_table, min_hits, hint_key, top, spec, **want):
     return keys, payload, values, hits, False
 
 
-def _materialize(eng, value, env, hint_key=None, top=None):
+def _lazy_rows_ok(bt, out_key_fields, fields_of, top):
+    """May K-F's rows arrive behind the call (ResultSet waits for them on first read)?  Only when nothing between here and
+    the ResultSet READS them: no ordering on the host, no text to decode, no packed / shared keys to unfold."""
+    if top is not None or getattr(bt, "key_radix", None) is not None or bt.key_parts is not None:
+        return False
+    if not (any(src == "key" for _, src in out_key_fields) or bt.shared_groups) or bt.int_values:
+        return False
+    return all(src == "key" or bt.decoder_of(fields_of.get(f), src) is None for f, src in out_key_fields)
+
+
+def _materialize(eng, value, env, hint_key=None, top=None, lazy_ok=False):
     """Device-resident intermediate -> DictResult on the host (K-F's input).  With `top`, the
     DictResult carries `.ordered = True` when the device already applied ORDER BY / LIMIT."""
     if isinstance(value, DictResult):
@@ -1224,9 +1236,10 @@ def _materialize(eng, value, env, hint_key=None, top=None):
         out_key_fields, vnames, count_idx, key_is_record, val_is_record, nv = bt.agg
         entry_is_group = any(src == "key" for _, src in out_key_fields) or bt.shared_groups
         spec = _device_sort_spec(bt, out_key_fields, vnames, count_idx, top[1]) if top is not None and entry_is_group and bt.key_radix is None else None
-        keys, payload, values, hits, ordered = _fetch_entries(eng, bt.table, 1, hint_key, top, spec, want_hits=count_idx is not None or (spec is not None and any(s[0] == abi.SORT_HITS for s in spec)))
-        values = [values[j] for j in range(nv)]
         fields_of = bt.agg_fields
+        lazy = lazy_ok and bool(getattr(eng, "lazy_results", False)) and _lazy_rows_ok(bt, out_key_fields, fields_of, top)
+        keys, payload, values, hits, ordered = _fetch_entries(eng, bt.table, 1, hint_key, top, spec, want_hits=count_idx is not None or (spec is not None and any(s[0] == abi.SORT_HITS for s in spec)), lazy=lazy)
+        values = [values[j] for j in range(nv)]
         if getattr(bt, "key_radix", None) is not None and out_key_fields == [(bt.key_name, "key")]:    # several key fields in one mixed-radix integer
             from . import xplan
             d = DictResult(xplan._decode_radix(keys, bt.key_radix[0], bt.key_radix[1]), _value_arrays(vnames, count_idx, values, hits, bt.int_values), True, val_is_record)
@@ -1251,6 +1264,8 @@ def _materialize(eng, value, env, hint_key=None, top=None):
             d = DictResult([(f, decode_late(f, src)) for f, src in out_key_fields], _value_arrays(vnames, count_idx, values, hits, bt.int_values),
                            key_is_record, val_is_record)
             d.ordered = ordered
+            if lazy:
+                d.ready = eng.ctx.result_wait                 # the rows are still on their way: whoever reads them first waits
             return d
         # The output key does not identify the entry (Q10: one entry per order, the key names customer
         # fields): fold entries that reference the same source rows first — integer work on the row
@@ -1351,7 +1366,7 @@ def _finalize(eng, op, env, top=None):
             elif len(side) == 1:
                 names[name] = side[0]
         inner_top = (top[0], [(names.get(n, n), d) for n, d in top[1]])
-    d = _materialize(eng, src_val, env, hint_key=id(op), top=inner_top)
+    d = _materialize(eng, src_val, env, hint_key=id(op), top=inner_top, lazy_ok=True)     # (only a ResultSet is made of it: that waits for the rows itself)
     if op.fields is None:                                   # p[0].concat(p[1])
         fields = d.key_fields + d.val_fields
     else:
@@ -1368,7 +1383,7 @@ def _finalize(eng, op, env, top=None):
             if len(src) != 1:
                 raise UnsupportedQuery("line %d: p[%d] is a record; name a field or use concat" % (op.lineno, which))
             fields.append((name, src[0][1]))
-    rs = ResultSet([n for n, _ in fields], [a for _, a in fields])
+    rs = ResultSet([n for n, _ in fields], [a for _, a in fields], ready=getattr(d, "ready", None))
     if top is not None and not getattr(d, "ordered", False):
         rs = rs.top(top[0], top[1])
     return rs

@@ -74,7 +74,10 @@ def decode_text(refs, decoder):
 class ResultSet:
     """Set of records: {record(field...): True}."""
 
-    def __init__(self, columns, arrays):
+    def __init__(self, columns, arrays, ready=None):
+        """ready: a callable to run before the arrays are first read — the rows of a K-F result reach the host by a copy
+        queued behind the query's kernels (sdqh_table_compact_async); the row count is known, the rows are waited for when
+        something looks at them, as the reference's result object converts on `to_dict()` (src/sdqlpy/fastd.py:31-51)."""
         self.columns = list(columns)
         self._cols = [a if isinstance(a, TextRefs) else np.asarray(a) for a in arrays]
         n = len(self._cols[0]) if self._cols else 0
@@ -82,10 +85,17 @@ class ResultSet:
             if len(a) != n:
                 raise ValueError("ragged result")
         self._n = n
+        self._ready = ready
+
+    def _wait(self):
+        if self._ready is not None:
+            ready, self._ready = self._ready, None
+            ready()
 
     @property
     def arrays(self):
         """One numpy array per column (text columns of a large result are decoded on first use)."""
+        self._wait()
         for i, a in enumerate(self._cols):
             if isinstance(a, TextRefs):
                 self._cols[i] = np.asarray(a)
@@ -102,6 +112,7 @@ class ResultSet:
         return self._n
 
     def column(self, name):
+        self._wait()
         i = self.columns.index(name)
         if isinstance(self._cols[i], TextRefs):
             self._cols[i] = np.asarray(self._cols[i])
@@ -117,6 +128,7 @@ class ResultSet:
         return list(zip(*[a.tolist() for a in self.arrays])) if self.arrays else []
 
     def top(self, k, order):
+        self._wait()
         idx = self.top_index(k, order)
         return ResultSet(self.columns, [a[idx] for a in self._cols])     # undecoded text stays undecoded
 

@@ -17,4 +17,4 @@ done
 python3 tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
 find $OUT -name "*.csv" -delete
 find $OUT -name "*.log" -size +64k -delete
-grep -E "k_lookup_agg|k_probe_agg|k_stage|k_build_lookup|k_key_set|k_dense" $OUT/summary.txt | cut -c1-400
+grep -E "k_lookup_agg|k_probe_agg|k_stage|k_build_lookup|k_key_set|k_dense|xk_" $OUT/summary.txt | cut -c1-400

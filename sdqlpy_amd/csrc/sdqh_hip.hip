@@ -532,6 +532,7 @@ void sdqh_destroy(sdqh_ctx* ctx) {
     if (ctx->result_host) (void)hipHostFree(ctx->result_host);
     if (ctx->bulk_host) (void)hipHostFree(ctx->bulk_host);
     if (ctx->count_host) (void)hipHostFree(ctx->count_host);
+    if (ctx->coarse_stat) (void)hipHostFree(ctx->coarse_stat);
     if (ctx->sync_flag) (void)hipHostFree(const_cast<uint32_t*>(ctx->sync_flag));
     if (ctx->result_dev) (void)hipFree(ctx->result_dev);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -1354,7 +1355,11 @@ int sdqh_hash_probe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* f
                 if (ctx->opt_probe_unroll == 4) return launch(k_probe_agg<SH, FCT, 4>, 4);
                 if (ctx->opt_probe_unroll == 1) return launch(k_probe_agg<SH, FCT, 1>, 1);
             }
-            return launch(k_probe_agg<SH, FCT>, PROBE_UNROLL);
+            // Filters outside the instantiated layouts run the generic instance with ONE row pair per lane in flight: with two, its six
+            // tuple shapes each spilled 64 bytes per lane to scratch (the run-time predicate counts keep every column pointer live).  The
+            // planner prefers a row program for such loops anyway (Engine.program_routes); this keeps the fixed-shape ABI whole.
+            if constexpr (std::is_same_v<FCT, FGeneric>) return launch(k_probe_agg<SH, FCT, 1>, 1);
+            else return launch(k_probe_agg<SH, FCT>, PROBE_UNROLL);
         });
     });
     if (lrc) return lrc;
@@ -1957,7 +1962,15 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
     if (ctx->opt_coarse_kb > 0 && nlookups > 0 && nrows >= 4 * ctx->opt_feature_min_rows && lookups[0].key[0].kind == SDQH_SRC_COLUMN && lookups[0].key[0].col->dtype == SDQH_I64) {
         sdqh_table* t0 = const_cast<sdqh_table*>(lookups[0].table);
         const bool part_bitmap = t0->bm && !t0->dev.lin_rb && (lookups[0].nkey == 1 ? t0->dev.bm_shift == 0 : t0->dev.bm_shift != 0);
-        if (part_bitmap && (t0->nwords * 4 > (32u << 10) || ctx->opt_feature_min_rows == 0) && !column_is_clustered(ctx, const_cast<sdqh_column*>(lookups[0].key[0].col))) {
+        // last time's density of this key column's coarse filter (see sdqh_ctx::coarse_stat): a filter that passed more than half the rows is left out
+        const void* kcol0 = lookups[0].key[0].col->data;
+        bool dense_last_time = false;
+        if (ctx->coarse_stat && ctx->coarse_stat_col == kcol0 && ctx->coarse_stat_build_rows == t0->nrows_build && ctx->coarse_stat_bits_pending > 0) {
+            dense_last_time = ctx->coarse_stat[0] * 2 > ctx->coarse_stat_bits_pending;
+            // (the same key column may meet another table next time: measure again every 16th call)
+            if (dense_last_time && ++ctx->coarse_skipped >= 16) { dense_last_time = false; ctx->coarse_skipped = 0; }
+        }
+        if (part_bitmap && !dense_last_time && (t0->nwords * 4 > (32u << 10) || ctx->opt_feature_min_rows == 0) && !column_is_clustered(ctx, const_cast<sdqh_column*>(lookups[0].key[0].col))) {
             if (!t0->coarse) {
                 const uint64_t nbits = t0->nwords * 32, budget = (uint64_t)ctx->opt_coarse_kb * 1024 * 8;
                 int shift = 0;
@@ -1965,7 +1978,20 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
                 const int cwords = (int)(((nbits >> shift) + 32) / 32);
                 uint32_t* c = static_cast<uint32_t*>(table_alloc(ctx, t0, (size_t)cwords * 4 + 64));
                 if (c) {
-                    LAUNCH(ctx, "k_coarsen", k_coarsen, (unsigned)std::min<int>((cwords + TPB - 1) / TPB, ctx->num_cu * 4), t0->bm, nbits, shift, c, cwords);
+                    if (!ctx->coarse_stat) {
+                        void* hp = nullptr;
+                        if (hipHostMalloc(&hp, 64, hipHostMallocDefault) == hipSuccess) { ctx->coarse_stat = static_cast<uint64_t*>(hp); ctx->coarse_stat[0] = ctx->coarse_stat[1] = 0; }
+                        else (void)hipGetLastError();
+                        ctx->coarse_count_dev = static_cast<unsigned long long*>(pool_alloc(ctx, 64));
+                    }
+                    unsigned long long* cnt = (ctx->coarse_stat && ctx->coarse_count_dev) ? ctx->coarse_count_dev : nullptr;
+                    if (cnt) (void)hipMemsetAsync(cnt, 0, 8, ctx->stream);
+                    LAUNCH(ctx, "k_coarsen", k_coarsen, (unsigned)std::min<int>((cwords + TPB - 1) / TPB, ctx->num_cu * 4), t0->bm, nbits, shift, c, cwords, cnt);
+                    if (cnt) {                                             // lands in pinned memory behind the launch; read by the next call
+                        (void)hipMemcpyAsync(ctx->coarse_stat, cnt, 8, hipMemcpyDeviceToHost, ctx->stream);
+                        ctx->coarse_stat_col = kcol0; ctx->coarse_stat_build_rows = t0->nrows_build; ctx->coarse_skipped = 0;
+                        ctx->coarse_stat_bits_pending = (uint64_t)cwords * 32;
+                    }
                     t0->coarse = c; t0->coarse_words = cwords; t0->coarse_shift = shift;
                 }
             }
@@ -2284,6 +2310,7 @@ void launch_groupby_merge_lg_host(sdqh_ctx* ctx, unsigned long long* r_keys, con
     ctx->rd_clean_ff = (size_t)LG_SLOTS * 8; ctx->rd_clean_zero_off = (int64_t)LG_SLOTS * 48;
 }
 int column_minmax(sdqh_ctx* ctx, sdqh_column* c) { return ensure_minmax(ctx, c); }
+bool column_increasing(sdqh_ctx* ctx, sdqh_column* c) { return ::column_is_increasing(ctx, c); }
 const void* column_narrow(sdqh_ctx* ctx, sdqh_column* c) { return ensure_narrow(ctx, c); }
 int new_owned_column(sdqh_ctx* ctx, int64_t nrows, int dtype, sdqh_column** out) { return sdqh_column_alloc(ctx, nrows, dtype, 0, out); }
 

@@ -106,6 +106,12 @@ struct sdqh_ctx {
     int opt_span_index = 1;                        // small direct tables also get an owner-by-key-offset array (one-load lookups)
     int opt_dense_increasing = 1;                  // dense layout over a strictly increasing key column is filled in one pass (no prefill, no verification)
     int opt_probe_pipeline = 0;                    // the same for k_probe_agg (keys + first predicate column a step ahead): 0 / 1
+    // How dense did the coarse filter of a first lookup come out last time (set bits / bits, written by k_coarsen's count into pinned
+    // memory behind the launch: read at the NEXT call, so nothing waits for it)?  A filter that passes most rows costs its LDS test and
+    // its 1024-thread workgroups for nothing — Q9 at SF=100, 2.5 MB of part bitmap behind 64 KiB: 89 % pass — and is left out then: the
+    // exact bitmap (L2-resident up to a few MB per XCD) is tested directly.  Keyed by the streamed key column and the build's row count.
+    const void* coarse_stat_col = nullptr; uint64_t* coarse_stat = nullptr;      // pinned: set bits of the last filter built (coarse_stat_bits_pending = its size)
+    unsigned long long* coarse_count_dev = nullptr; uint64_t coarse_stat_bits_pending = 0; int coarse_skipped = 0; int64_t coarse_stat_build_rows = -1;
     int opt_coarse_kb = 64;                        // LDS budget (KiB) of the coarse key filter in front of an unclustered first lookup; 0 = off.  One copy per
                                                    // 1024-thread workgroup (a copy per 256 threads cost more occupancy than it saved: 0.70 -> 0.67 ms at 32 KiB, 1.4 ms at 64 KiB)
     int opt_row_pack = 1;                          // final loops with lookups gather their columns from an interleaved row pack (see DevLookups)
@@ -181,6 +187,7 @@ void tb_release(sdqh_ctx* ctx, sdqh_table* t);
 int stage_setup_computed(sdqh_ctx* ctx, sdqh_table* tb, int64_t nrows, int npay, int batch);
 int index_ensure(sdqh_ctx* ctx, sdqh_table* tb);
 int column_minmax(sdqh_ctx* ctx, sdqh_column* c);
+bool column_increasing(sdqh_ctx* ctx, sdqh_column* c);          // strictly increasing I64 column?  (one pass the first time, cached)
 const void* column_narrow(sdqh_ctx* ctx, sdqh_column* c);      // the exact 4-byte twin of a streamed column (built on first request), or nullptr
 bool column_codes(sdqh_ctx* ctx, sdqh_column* c);              // sdqh_codes.hip: the sorted-dictionary code twin (built on first request); false: none
 void column_codes_release(sdqh_ctx* ctx, sdqh_column* c);

@@ -313,7 +313,8 @@ void tight_plan(sdqh_ctx* ctx, int64_t nrows, XInfo* x) {
     //  output compiles for gfx950)
     const bool fake = ctx->compile_only && std::getenv("SDQLPY_AMD_FAKE_CODES") != nullptr;
     static const std::vector<int64_t> fake_dict = {0, 1, 2, 3};
-    if (!ctx->opt_tight || x->ncols < 1 || (!x->direct && x->scols.empty())) return;
+    const bool regs_all = x->direct;                                      // every column is streamed and every operation evaluated on registers
+    if (!ctx->opt_tight || x->ncols < 1 || (!regs_all && x->scols.empty())) return;
     // Every register program runs on the tight skeleton, and every queue program that streams anything on the tight queue,
     // whatever its columns' encodings: rows meet lanes, partial sums are folded and queues are drained in the same order with and
     // without twins, so switching the twins off changes no bit of a sum (tests/test_hip_parity.py).
@@ -322,9 +323,9 @@ void tight_plan(sdqh_ctx* ctx, int64_t nrows, XInfo* x) {
     uint32_t text_twins = 0;
     for (int c = 0; c < x->ncols; ++c) if (x->cols[c]->dtype == SDQH_STR) text_twins |= x->narrow_mask & (1u << c);
     x->narrow_mask = text_twins;                                           // (the 4-byte twins analyse chose were for the two-rows-per-lane skeletons)
-    x->scope.assign((size_t)p->nops, x->direct ? 1 : 0);
-    std::vector<char> streamed((size_t)x->ncols, x->direct ? 1 : 0);
-    if (!x->direct) {
+    x->scope.assign((size_t)p->nops, regs_all ? 1 : 0);
+    std::vector<char> streamed((size_t)x->ncols, regs_all ? 1 : 0);
+    if (!regs_all) {
         for (int g = 0; g < x->nstream_gates; ++g) closure(p, p->gates[g], x->scope);
         if (x->prefilter_part0 >= 0) closure(p, x->prefilter_part0, x->scope);
         for (int c : x->scols) streamed[(size_t)c] = 1;
@@ -333,7 +334,7 @@ void tight_plan(sdqh_ctx* ctx, int64_t nrows, XInfo* x) {
     // how every streamed COL operation is used by what is evaluated on the streamed registers
     std::vector<char> cmp_only((size_t)x->ncols, 1), used((size_t)x->ncols, 0);
     auto direct_ref = [&](int k) {
-        if (!x->direct) {                                                  // a streamed gate that IS the column cannot be (gates are bool); the prefilter reads its key's value
+        if (!regs_all) {                                                   // a streamed gate that IS the column cannot be (gates are bool); the prefilter reads its key's value
             return k == x->prefilter_part0;
         }
         if (p->key == k) return true;
@@ -370,7 +371,7 @@ void tight_plan(sdqh_ctx* ctx, int64_t nrows, XInfo* x) {
         } else if (column_narrow(ctx, col)) x->enc[c] = ENC_N32;
         any = any || x->enc[c] != ENC_RAW;
     }
-    if (!x->direct && !fake) {
+    if (!regs_all && !fake) {
         // columns the drain reads by row (keys and payloads of a build, operands of a probe hit): survivors are a few per cent of the
         // rows, scattered, so a gather moves whole lines for single values — through the 4-byte twin the same lines are half as many
         std::vector<char> by_row((size_t)x->ncols, 0);
@@ -393,12 +394,12 @@ void tight_plan(sdqh_ctx* ctx, int64_t nrows, XInfo* x) {
         if (x->scope[(size_t)k] && p->ops[k].type == SDQH_T_I64 && op_interval(ctx, *x, k, &lo, &hi))
             x->irange[k] = (lo >= -(1 << 23) && hi < (1 << 23)) ? 2 : (lo >= INT32_MIN && hi <= INT32_MAX) ? 1 : 0;
     }
-    if (!x->direct && x->prefilter_op >= 0 && !x->prefilter_composite && !fake) {
+    if (!regs_all && x->prefilter_op >= 0 && !x->prefilter_composite && !fake) {
         const sdqh_table* t = x->tabs[x->tab_of[x->prefilter_op]];
         const bool applicable = t->dev.bm && t->dev.bm_shift == 0 && t->dev.lin_rb == 0;
         x->pref32 = applicable && x->irange[x->prefilter_part0] >= 1 && t->dev.bm_lo >= INT32_MIN && t->dev.bm_hi <= INT32_MAX && t->dev.bm_hi >= t->dev.bm_lo;
     }
-    if (fake && !x->direct && x->prefilter_op >= 0 && !x->prefilter_composite) x->pref32 = true;
+    if (fake && !regs_all && x->prefilter_op >= 0 && !x->prefilter_composite) x->pref32 = true;
     // comparisons of a coded column with a constant, in code space
     for (int j = 0; j < p->nops; ++j) {
         const sdqh_xop& u = p->ops[j];
@@ -652,6 +653,7 @@ std::string generate_tight(const XInfo& x, Sink sink) {
     out << "    x_tight<P, " << sn << ">(a, s, nrows);\n}\n";
     return out.str();
 }
+
 
 std::string generate(const XInfo& x, Sink sink, bool direct) {
     if (x.tight && direct) return generate_tight(x, sink);
@@ -1163,6 +1165,7 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
     tb->npay = prog->nvals; tb->accumulate = accumulate != 0; tb->nrows_build = nrows;
     call_begin(ctx);
     int rc = stage_setup_computed(ctx, tb, nrows, prog->nvals, x.tight ? (X8_STEP * X8_U) / 128 : X_LB);
+
     uint64_t capmax = 1024;
     while (capmax < 2 * (uint64_t)std::max<int64_t>(nrows, 1)) capmax <<= 1;
     tb->capmax = capmax;

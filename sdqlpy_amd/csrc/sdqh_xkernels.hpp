@@ -812,4 +812,5 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
     sink.finish(a, sa);
 }
 
+
 }  // namespace sdqh

@@ -99,6 +99,11 @@ class Engine:
         # K-F rows of a query's RESULT reach the host behind the call (sdqh_table_compact_async); the ResultSet waits on first read
         self.lazy_results = os.environ.get("SDQLPY_AMD_LAZY_RESULTS", "1") != "0"
         self.stream_programs = os.environ.get("SDQLPY_AMD_STREAM_PROGRAMS", "1") != "0" and ctx.library.backend_name() == "hip-gfx950"
+        # ... and so do the loops that aggregate into the entry a probe matches ("probe": Q3's lineitem loop — the specialised kernel
+        # streams the key through its 4-byte twin and the date as a 2-byte code, tests the key bitmap in 32-bit arithmetic) and, on
+        # request, unique builds ("build").  Measured per kind in profiles/r03_ab_tuned_vs_programs.txt.
+        routes = os.environ.get("SDQLPY_AMD_PROGRAM_ROUTES", "probe")
+        self.program_routes = {r for r in routes.split(",") if r} if ctx.library.backend_name() == "hip-gfx950" else set()
 
     def close(self):
         self.clear()
@@ -881,7 +886,13 @@ def _prepare_scan(eng, op, htab, accumulate_into, member_only=False, as_table=Fa
             return xplan.prepare_scan(eng, op, htab, accumulate_into, member_only, as_table)
         except UnsupportedQuery:
             pass
-    if getattr(eng, "stream_programs", False) and not _no_stream and not as_table and not member_only and _is_stream_loop(op):
+    routed = False
+    if not _no_stream and getattr(eng, "program_routes", None):
+        if op.kind == "dict" and not op.unique and op.probe is not None and op.probe.dict_name in accumulate_into:
+            routed = "probe" in eng.program_routes
+        elif op.kind == "dict" and op.unique:
+            routed = "build" in eng.program_routes
+    if routed or (getattr(eng, "stream_programs", False) and not _no_stream and not as_table and not member_only and _is_stream_loop(op)):
         try:
             x = xplan.prepare_scan(eng, op, htab, accumulate_into, member_only, as_table)
         except UnsupportedQuery:
@@ -922,7 +933,13 @@ def _prepare_scan(eng, op, htab, accumulate_into, member_only=False, as_table=Fa
     def run(env):
         if state["x"] is None:
             try:
-                out = fixed(env)
+                try:
+                    out = fixed(env)
+                except abi.SdqhError as exc:
+                    # the library has no fixed-shape kernel for this loop (e.g. a filter layout without an instance): a row program's job
+                    if exc.code != abi.ERR_UNSUPPORTED:
+                        raise
+                    raise UnsupportedQuery("line %d: %s" % (op.lineno, exc))
                 if as_table and isinstance(out, DictResult):
                     # a later loop looks this dictionary up, and the fixed-shape call returned its groups to the host (a small
                     # group domain: nothing on the device was changed): the row program aggregates into a table instead (Q2)

@@ -845,3 +845,79 @@ def fuzz_case(hip, cpu, seed, rounds=12):
         assert out[0] == out[1], "seed %d round %d (n=%d, m=%d, key style %d): %s" % (
             seed, rnd, n, m, style, next((a[0], str(a)[:300], str(b)[:300]) for a, b in zip(out[0], out[1]) if a != b))
     return rounds
+
+
+def xcode_edge_cases(ctx, n=40000, seed=21):
+    """Sorted-dictionary code twins (csrc/sdqh_codes.hip) and the comparisons rewritten in code space (sdqh_x.hip: tight_plan):
+    every comparison operator against constants below / equal to / between / above the column's distinct values (and NaN), on
+    integer columns with gaps and negatives, two-decimal doubles, columns that cannot be coded (too many values, more decimals,
+    beyond int32); values of coded columns through their LDS tables; a dense small group key on the per-lane accumulators.
+    Against numpy; the caller sets feature_min_rows to 0 so that small inputs take the coded instances.  Returns the check count."""
+    from sdqlpy_amd import abi as A
+    rng = np.random.default_rng(seed)
+    cols = {
+        "gaps": np.array([-5, 3, 4, 1000, 70000], np.int64)[rng.integers(0, 5, n)],                 # non-consecutive, negative: a real dictionary
+        "dense": rng.integers(7, 11, n).astype(np.int64),                                           # consecutive: code + offset
+        "cents": np.array([0.0, 0.05, 1.25, -3.5, 99.99], np.float64)[rng.integers(0, 5, n)],       # two decimals: coded through the 4-byte twin
+        "wide": rng.integers(0, 200000, n).astype(np.int64),                                        # > 65 536 distinct values: no codes, 4-byte twin
+        "huge": rng.integers(0, 5, n).astype(np.int64) * (1 << 40),                                 # beyond int32 and a wide range: the column itself
+        "fine": np.round(rng.random(n), 5),                                                         # more than two decimals: the column itself
+        "dates": (19920101 + rng.integers(0, 2000, n)).astype(np.int64),                            # 2 000 values: 2-byte codes where only compared
+    }
+    dev = {k: ctx.upload(v) for k, v in cols.items()}
+    checks = 0
+    ops = [(A.X_LT, np.less), (A.X_LE, np.less_equal), (A.X_GT, np.greater), (A.X_GE, np.greater_equal), (A.X_EQ, np.equal), (A.X_NE, np.not_equal)]
+    consts = {"gaps": [-6, -5, 0, 3, 4, 5, 1000, 69999, 70000, 70001], "dense": [6, 7, 9, 10, 11], "cents": [-4.0, -3.5, 0.0, 0.049999, 0.05, 1.25, 99.99, 100.0, float("nan")],
+              "wide": [-1, 0, 100000, 199999, 200000], "huge": [0, 1 << 40, (1 << 41) + 1], "fine": [0.0, 0.5, 2.0], "dates": [19920100, 19920101, 19920500, 19921231, 19990101]}
+    for name, values in consts.items():
+        isf = cols[name].dtype.kind == "f"
+        for code, fn in ops:
+            for c in values:
+                for flipped in (False, True):
+                    P = A.Program()
+                    x = P.op(A.X_COL, A.T_F64 if isf else A.T_I64, col=dev[name])
+                    k = P.op(A.X_CONST, A.T_F64 if isf else A.T_I64, **({"imm_f": c} if isf else {"imm_i": c}))
+                    P.gates = [P.op(code, A.T_BOOL, a=k, b=x) if flipped else P.op(code, A.T_BOOL, a=x, b=k)]
+                    P.vals = [P.op(A.X_CONST, A.T_F64, imm_f=1.0)]
+                    _, cnt = ctx.xscan_sum(n, P)
+                    with np.errstate(invalid="ignore"):
+                        want = int((fn(c, cols[name]) if flipped else fn(cols[name], c)).sum())
+                    assert cnt == want, (name, code, c, flipped, cnt, want)
+                    checks += 1
+    # values of coded columns (LDS tables, derived tables, code + offset), mixed with an uncoded column
+    P = A.Program()
+    g = P.op(A.X_COL, A.T_I64, col=dev["gaps"]); d = P.op(A.X_COL, A.T_I64, col=dev["dense"]); c = P.op(A.X_COL, A.T_F64, col=dev["cents"]); f = P.op(A.X_COL, A.T_F64, col=dev["fine"])
+    one = P.op(A.X_CONST, A.T_F64, imm_f=1.0)
+    v0 = P.op(A.X_MUL, A.T_F64, a=P.op(A.X_SUB, A.T_F64, a=one, b=c), b=f)                                    # (1 - cents) * fine
+    v1 = P.op(A.X_I2F, A.T_F64, a=P.op(A.X_ADD, A.T_I64, a=P.op(A.X_MUL, A.T_I64, a=g, b=P.op(A.X_CONST, A.T_I64, imm_i=3)), b=d))   # gaps * 3 + dense
+    P.gates = [P.op(A.X_GE, A.T_BOOL, a=P.op(A.X_COL, A.T_I64, col=dev["dates"]), b=P.op(A.X_CONST, A.T_I64, imm_i=19930101))]
+    P.vals = [v0, v1, c]
+    vals, cnt = ctx.xscan_sum(n, P)
+    m = cols["dates"] >= 19930101
+    assert cnt == int(m.sum())
+    for got, want in zip(vals, [((1.0 - cols["cents"]) * cols["fine"])[m].sum(), (cols["gaps"] * 3 + cols["dense"])[m].sum(), cols["cents"][m].sum()]):
+        assert abs(got - want) <= 1e-9 * max(abs(want), 1.0), (got, want)
+    checks += 4
+    # a dense small key: per-lane accumulators; key = (dense - 7) * 5 + code of gaps' sign ... kept simple: dense alone and dense * 2 + (cents > 0)
+    for variant in (0, 1):
+        P = A.Program()
+        d = P.op(A.X_COL, A.T_I64, col=dev["dense"]); c = P.op(A.X_COL, A.T_F64, col=dev["cents"]); f = P.op(A.X_COL, A.T_F64, col=dev["fine"])
+        if variant == 0:
+            P.key = d; want_key = cols["dense"]
+        else:
+            pos = P.op(A.X_SELECT, A.T_I64, a=P.op(A.X_GT, A.T_BOOL, a=c, b=P.op(A.X_CONST, A.T_F64, imm_f=0.0)), b=P.op(A.X_CONST, A.T_I64, imm_i=1), c=P.op(A.X_CONST, A.T_I64, imm_i=0))
+            P.key = P.op(A.X_ADD, A.T_I64, a=P.op(A.X_MUL, A.T_I64, a=d, b=P.op(A.X_CONST, A.T_I64, imm_i=2)), b=pos); want_key = cols["dense"] * 2 + (cols["cents"] > 0)
+        P.gates = [P.op(A.X_LT, A.T_BOOL, a=f, b=P.op(A.X_CONST, A.T_F64, imm_f=0.9))]
+        P.vals = [f, P.op(A.X_MUL, A.T_F64, a=c, b=f)]
+        keys, vals, cnts = ctx.xgroupby(n, P)
+        m = cols["fine"] < 0.9
+        assert sorted(keys.tolist()) == sorted(np.unique(want_key[m]).tolist())
+        for k, v, cn in zip(keys.tolist(), vals, cnts.tolist()):
+            sel = m & (want_key == k)
+            assert cn == int(sel.sum())
+            assert abs(v[0] - cols["fine"][sel].sum()) <= 1e-9 * max(abs(cols["fine"][sel].sum()), 1.0)
+            assert abs(v[1] - (cols["cents"] * cols["fine"])[sel].sum()) <= 1e-9 * max(abs((cols["cents"] * cols["fine"])[sel].sum()), 1.0)
+            checks += 3
+    for col in dev.values():
+        col.free()
+    return checks

@@ -205,3 +205,57 @@ def test_specialised_kernels_compile_without_a_gpu(hip_lib):
         assert exc.value.code == A.ERR_INVALID
     finally:
         ctx.close()
+
+
+def test_code_space_comparison_cases_on_the_cpu_implementation(oracle_lib):
+    """The comparison / dictionary-value / dense-key cases the GPU's coded streaming kernels are checked with
+    (helpers.xcode_edge_cases, tests/test_hip_parity.py) against numpy on the CPU implementation: pins the cases themselves."""
+    import helpers
+    ctx = oracle_lib.context(threads=2)
+    try:
+        assert helpers.xcode_edge_cases(ctx, n=3000) > 500
+    finally:
+        ctx.close()
+
+
+def test_tight_kernels_compile_without_a_gpu(hip_lib, monkeypatch):
+    """Build check of the round-3 skeletons on a host without a GPU: with SDQLPY_AMD_FAKE_CODES the compile-only context pretends
+    every column has dictionary codes / twins, so the generator emits — and hiprtc compiles for gfx950 — x_tight with the per-lane
+    group sink, code-space comparisons and LDS dictionary tables, and x_queue8 with the batched 32-bit bitmap prefilter."""
+    from sdqlpy_amd import abi as A
+    monkeypatch.setenv("SDQLPY_AMD_FAKE_CODES", "1")
+    ctx = hip_lib.context(device=-1)
+    try:
+        n = 1 << 22
+        ship, qty, ep, disc, flag, key = (ctx.wrap(0x10000 * (i + 1), n, dt) for i, dt in enumerate((A.I64, A.F64, A.F64, A.F64, A.I64, A.I64)))
+
+        def compiled(call):
+            with pytest.raises(A.SdqhError) as exc:
+                call()
+            assert exc.value.code == A.ERR_DEVICE and "kernel specialised" in str(exc.value), str(exc.value)[:3000]
+        before = sum(ctx.jit_stats())
+        P = A.Program()
+        s = P.op(A.X_COL, A.T_I64, col=ship); q = P.op(A.X_COL, A.T_F64, col=qty); e = P.op(A.X_COL, A.T_F64, col=ep); d = P.op(A.X_COL, A.T_F64, col=disc); f = P.op(A.X_COL, A.T_I64, col=flag)
+        one = P.op(A.X_CONST, A.T_F64, imm_f=1.0)
+        P.gates = [P.op(A.X_LE, A.T_BOOL, a=s, b=P.op(A.X_CONST, A.T_I64, imm_i=19980902)), P.op(A.X_LT, A.T_BOOL, a=P.op(A.X_CONST, A.T_F64, imm_f=0.02), b=d)]
+        P.vals = [q, P.op(A.X_MUL, A.T_F64, a=e, b=P.op(A.X_SUB, A.T_F64, a=one, b=d))]
+        compiled(lambda: ctx.xscan_sum(n, P))                                       # x_tight + XSum
+        P.key = P.op(A.X_ADD, A.T_I64, a=P.op(A.X_MUL, A.T_I64, a=f, b=P.op(A.X_CONST, A.T_I64, imm_i=2)), b=f)
+        compiled(lambda: ctx.xgroupby(n, P))                                        # x_tight + XGroupLane
+        K = A.Program()
+        K.gates = [K.op(A.X_LT, A.T_BOOL, a=K.op(A.X_COL, A.T_I64, col=ship), b=K.op(A.X_CONST, A.T_I64, imm_i=19950315))]
+        K.key = K.op(A.X_COL, A.T_I64, col=key)
+        members = ctx.xkey_set(n, K, 0, 1000)                                       # x_queue8 + XKeySet (placeholder table)
+        B = A.Program()
+        B.gates = [B.op(A.X_LT, A.T_BOOL, a=B.op(A.X_COL, A.T_I64, col=ship), b=B.op(A.X_CONST, A.T_I64, imm_i=19950315)),
+                   B.op(A.X_LOOKUP, A.T_BOOL, a=B.op(A.X_COL, A.T_I64, col=flag), table=members)]
+        B.key = B.op(A.X_COL, A.T_I64, col=key); B.vals = [B.op(A.X_COL, A.T_I64, col=ship)]
+        built = ctx.xbuild(n, B, 0, 100000, accumulate=True)                        # x_queue8 + XStage, prefilter on the key set's bitmap
+        R = A.Program()
+        lk = R.op(A.X_LOOKUP, A.T_BOOL, a=R.op(A.X_COL, A.T_I64, col=key), table=built)
+        R.gates = [R.op(A.X_GT, A.T_BOOL, a=R.op(A.X_COL, A.T_I64, col=ship), b=R.op(A.X_CONST, A.T_I64, imm_i=19950315)), lk]
+        R.vals = [R.op(A.X_MUL, A.T_F64, a=R.op(A.X_COL, A.T_F64, col=ep), b=R.op(A.X_COL, A.T_F64, col=disc))]
+        compiled(lambda: ctx.xprobe_aggregate(n, R, lk, built))                     # x_queue8 + XEntry
+        assert sum(ctx.jit_stats()) - before >= 5
+    finally:
+        ctx.close()

@@ -706,6 +706,126 @@ def test_redistribution_helpers_match_oracle(hip_engine, oracle_engine):
     assert out["hip"][5] == sorted(set(key.tolist()))
 
 
+def test_tight_encodings_on_small_inputs(hip_engine, oracle_engine):
+    """Round 3: register row programs stream their columns at the tightest exact encoding — sorted-dictionary codes of 1 / 2 bytes
+    (csrc/sdqh_codes.hip), 4-byte twins — 8 rows per lane (x_tight), queue programs test their leading conditions the same way
+    (x_queue8).  From 1 M rows up by default; with feature_min_rows 0: every row-program case against numpy at sizes around the
+    tile / step boundaries, the code-space comparison edge cases, and q1 / q6 / q3 / q5 with the encodings on and off."""
+    ctx = hip_engine.ctx
+    ctx.set_option("feature_min_rows", 0)
+    hip_engine.clear()
+    try:
+        for n in (300, 4097, 20000, 70001):
+            assert helpers.xprogram_cases(ctx, n) > 40
+        assert helpers.xcode_edge_cases(ctx) > 500
+        assert helpers.xcode_edge_cases(ctx, n=2047, seed=5) > 500
+        qs = ["q1", "q6", "q3", "q5", "q14"]
+        db = tpch.generate(0.05, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+        res = {}
+        for tight in (1, 0):
+            ctx.set_option("tight", tight)
+            hip_engine.clear()
+            for q in qs:
+                r = helpers.run_query(hip_engine, q, db)
+                res[(tight, q)] = r if isinstance(r, float) else helpers.result_rows(r, r.columns)
+        ctx.set_option("tight", 1)
+        for q in qs:
+            want = helpers.run_query(oracle_engine, q, db)
+            for tight in (1, 0):
+                got = res[(tight, q)]
+                if isinstance(want, float):
+                    assert abs(got - want) <= REL * abs(want), (q, tight)
+                else:
+                    helpers.assert_rows_match(got, helpers.result_rows(want, want.columns), REL, "tight=%d/%s" % (tight, q))
+    finally:
+        ctx.set_option("tight", 1)
+        ctx.set_option("feature_min_rows", 1 << 20)
+        hip_engine.clear()
+        oracle_engine.clear()
+
+
+def test_result_rows_delivered_behind_the_call(hip_engine, oracle_engine):
+    """K-F's rows reach the host by a copy queued behind the query's kernels (sdqh_table_compact_async); the ResultSet waits for
+    them on first read.  Same rows as the synchronous path, also when results are dropped unread and their blocks reused, when
+    several results are pending at once, and with the option off."""
+    db = tpch.generate(0.3, tables=sorted(tpch.columns_for(["q3", "q18"])), columns=tpch.columns_for(["q3", "q18"]))
+    want = helpers.run_query(oracle_engine, "q3", db)
+    want_rows = helpers.result_rows(want, want.columns)
+    assert hip_engine.lazy_results
+    pending = [helpers.run_query(hip_engine, "q3", db) for _ in range(4)]          # four results in flight, none read yet
+    for _ in range(6):
+        helpers.run_query(hip_engine, "q3", db)                                    # dropped unread: their blocks go round
+    for r in pending + [helpers.run_query(hip_engine, "q3", db)]:
+        assert r.size() == want.size()
+        helpers.assert_rows_match(helpers.result_rows(r, want.columns), want_rows, REL, "lazy q3")
+    hip_engine.ctx.set_option("async_result", 0)
+    try:
+        r = helpers.run_query(hip_engine, "q3", db)
+        helpers.assert_rows_match(helpers.result_rows(r, want.columns), want_rows, REL, "synchronous q3")
+    finally:
+        hip_engine.ctx.set_option("async_result", 1)
+    hip_engine.lazy_results = False
+    try:
+        r = helpers.run_query(hip_engine, "q3", db)
+        helpers.assert_rows_match(helpers.result_rows(r, want.columns), want_rows, REL, "eager q3")
+    finally:
+        hip_engine.lazy_results = True
+    hip_engine.clear()
+    oracle_engine.clear()
+
+
+def test_coarse_filter_left_out_when_it_passes_most_rows(hip_engine, oracle_engine):
+    """A first lookup on keys in no order whose exact bitmap (3 MB: 24 M keys) dwarfs the LDS budget of the coarse filter: at
+    5 % of the keys set, a 64 KiB filter (one bit per 46 keys) passes ~90 % of the rows — Q9 at SF=100.  The library measures the
+    filter's density when it builds it (k_coarsen counts the set bits, read at the next call) and leaves a filter that passes more
+    than half the rows out: the exact bitmap is then tested straight from L2.  Same groups as the CPU implementation with the
+    filter (first call), without it (later calls), and with a sparse set that keeps it."""
+    from sdqlpy_amd import abi as A
+    rng = np.random.default_rng(17)
+    nkeys, nprobe = 24_000_000, 6_000_000
+    probe_key = rng.integers(0, nkeys, nprobe).astype(np.int64)
+    val = np.round(rng.random(nprobe) * 100.0, 2)
+    group = rng.integers(0, 7, nprobe).astype(np.int64)
+    results = {}
+    for name, eng in (("hip", hip_engine), ("cpu", oracle_engine)):
+        ctx = eng.ctx
+        ck, cv, cg = ctx.upload(probe_key), ctx.upload(val), ctx.upload(group)
+        out = []
+        for density in (0.05, 0.02):
+            if density == 0.05:                                           # 5 % of the keys, anywhere: nearly every coarse bit is set
+                members = np.flatnonzero(np.random.default_rng(3).random(nkeys) < density).astype(np.int64)
+            else:                                                         # 2 % of the keys in 24 dense blocks: 2 % of the coarse bits are set
+                members = np.concatenate([np.arange(i * 1_000_000, i * 1_000_000 + 20_000, dtype=np.int64) for i in range(24)])
+            cm = ctx.upload(members)
+            logs = []
+            for _ in range(3):
+                table = ctx.build_key_set(len(members), A.make_filter(), [], cm)
+                if name == "hip":
+                    ctx.set_profiling(True); ctx.kernel_log = []
+                keys, vals, cnts = ctx.lookup_aggregate(nprobe, A.make_filter(), [(table, [A.src_col(ck)])], [A.src_col(cg)], A.TUPLE_A, [A.src_col(cv)])
+                if name == "hip":
+                    logs.append([k for k, _ in ctx.kernel_log]); ctx.set_profiling(False)
+                order = np.argsort(keys[:, 0])
+                out.append((keys[order, 0].tolist(), vals[order, 0].tolist(), cnts[order].tolist()))
+                table.free()
+            if name == "hip":
+                assert "k_coarsen" in logs[0], logs[0]                       # the first call builds and uses the filter
+                if density == 0.05:
+                    assert "k_coarsen" not in logs[1] and "k_coarsen" not in logs[2], logs       # found dense: left out
+                else:
+                    assert "k_coarsen" in logs[2], logs                        # sparse: kept
+            cm.free()
+        results[name] = out
+        for c in (ck, cv, cg):
+            c.free()
+    for got, want in zip(results["hip"], results["cpu"]):
+        assert got[0] == want[0] and got[2] == want[2] and len(want[0]) == 7
+        assert all(abs(x - y) <= REL * abs(y) for x, y in zip(got[1], want[1]))
+    member = np.zeros(nkeys, bool); member[np.flatnonzero(np.random.default_rng(3).random(nkeys) < 0.05)] = True
+    hit = member[probe_key]
+    assert results["cpu"][0][2] == np.bincount(group[hit], minlength=7).tolist()
+
+
 def test_distributed_runner_world1_nccl(hip_lib, golden, golden_more):
     """The distributed plan end to end on one GPU (RCCL group of size 1).  The tables carry row-shard marks
     (shard 0 of 1), so the runner takes the PARTITIONED plans — an unmarked table is "whole" and would send every
@@ -789,9 +909,17 @@ def test_distributed_runner_world1_nccl(hip_lib, golden, golden_more):
                     for x, y in zip(a, b):
                         assert (abs(x - y) <= REL * max(abs(x), abs(y))) if isinstance(y, float) else x == y, (q, part, a, b)
                 if q == "q3" and part == "hash":
-                    assert runner.exchanged_rows["probe_sent"] > 3000000 and runner.exchanged_bytes == 0      # all of it to itself
+                    # the replicated bitmap of all build keys (one all-reduce) lets only the probe rows that will hit travel
+                    assert 0 < runner.exchanged_rows["probe_sent"] < 100000 and runner.exchanged_bytes == 0       # all of it to itself
+                    assert any(nm == "all_reduce" for nm, _, _ in calls)
                     moved = sum(n for nm, _, n in calls if nm == "all_to_all_single")
                     assert moved >= 3 * runner.exchanged_rows["probe_sent"], (moved, runner.exchanged_rows)   # key + two operands
+                    plain = sdist.DistributedRunner(eng, 0, 1, partition="hash", prefilter=False)
+                    del calls[:]
+                    again = plain.run(q, big)
+                    assert plain.exchanged_rows["probe_sent"] > 3000000                                       # every filtered probe row, without it
+                    assert sorted(again.rows()) == g or all(abs(x - y) <= REL * max(abs(x), abs(y)) if isinstance(y, float) else x == y
+                                                            for a, b in zip(sorted(again.rows()), g) for x, y in zip(a, b))
     finally:
         for n in real:
             setattr(dist, n, real[n])

@@ -4,7 +4,7 @@
 # 1. rocprofv3 --kernel-trace --stats of the default bench command
 # 2. HBM traffic per query: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (MI355X_MICROARCH.md), per query
 set -u
-R=${1:-r02}
+R=${1:-r03}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -23,11 +23,12 @@ from collections import defaultdict
 
 TABLES = {"q1": ["lineitem"], "q6": ["lineitem"], "q3": ["lineitem", "orders", "customer"],
           "q5": ["lineitem", "orders", "customer", "supplier"], "q9": ["lineitem", "orders", "part", "partsupp", "supplier"]}
-ONE_OFF = ("k_minmax", "k_check_increasing", "k_narrow_", "__amd_rocclr")
+ONE_OFF = ("k_minmax", "k_check_increasing", "k_narrow_", "k_code_", "__amd_rocclr")      # twins, dictionaries and column facts: built at the first run only
 BUILT_ONCE = ("k_interleave",)                 # resident structures built at the first run only: reported apart
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "", 1) if name.startswith(("void (anonymous", "(anonymous")) else name
     name = name.split("(")[0].split("<")[0]
     for p in ("void sdqh::", "sdqh::"):
         if name.startswith(p):

@@ -8,6 +8,7 @@ from collections import defaultdict
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "", 1) if name.startswith(("void (anonymous", "(anonymous")) else name
     name = name.split("(")[0]
     for p in ("void sdqh::", "sdqh::"):
         if name.startswith(p):

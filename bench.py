@@ -303,7 +303,7 @@ def main(argv=None, hooks=None):
         for q in queries + extra:
             ab = algorithmic_bytes(q, rows)
             wall = (per_query_ms[q] / args.steps) if q in per_query_ms else (extra_ms[q] / extra_steps)
-            phys, phys_source = pmc_traffic(q, None, rows)
+            phys, phys_source = pmc_traffic(q, None, rows, ran={name.split(":", 1)[1] for name in kernels if name.startswith(q + ":")})
             per_query[q] = {"ms_wall": round(wall, 4), "ms_kernels": round(device_ms[q], 4),
                             "in_timed_step": q in queries,
                             "rows_per_s_wall": round(scanned_rows(q, rows) / (wall * 1e-3), 1),
@@ -347,7 +347,7 @@ def main(argv=None, hooks=None):
     return out
 
 
-def pmc_traffic(q, kernel, rows):
+def pmc_traffic(q, kernel, rows, ran=None):
     """(HBM bytes, source tag) from the committed rocprofv3 PMC summary profiles/rNN_pmc_traffic.json
     (tools/pmc_per_query.py: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes per query;
     bytes = 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950): with `kernel`,
@@ -367,6 +367,8 @@ def pmc_traffic(q, kernel, rows):
     if not entry or any(rec.get("rows", {}).get(t) != rows.get(t) for t in entry.get("tables", ["lineitem"])):
         return None, None
     source = "committed rocprofv3 PMC run (profiles/%s), not this run" % os.path.basename(path)
+    if ran is not None and not set(ran) <= set(entry.get("kernels", {})):
+        return None, None                                 # this run launched kernels the committed collection never saw: other code, other bytes
     if kernel is None:
         return entry.get("hbm_bytes_per_run"), source
     k = entry.get("kernels", {}).get(kernel)

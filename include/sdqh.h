@@ -473,7 +473,9 @@ int sdqh_xgroupby(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int ma
 /* K-B (331-369): unique build keyed by the program's key, payload = its vals (<= SDQH_MAX_PAYLOAD); first row wins.
  * [key_lo, key_hi]: bounds of the key the caller knows from its sources (key_lo > key_hi: none known) — a
  * dense range gets the direct (bitmap + rank) index, anything else open addressing.  A key outside given
- * bounds fails the call (SDQH_ERR_UNSUPPORTED). */
+ * bounds fails the call (SDQH_ERR_UNSUPPORTED).  accumulate: 0 = the entries carry no accumulators; 1 = room for
+ * SDQH_TUPLE_MAX_VALUES sums per entry (what a later sdqh_*probe_aggregate adds is not known yet); 16 + n = exactly n sums
+ * (n <= SDQH_TUPLE_MAX_VALUES) — a caller that knows its plan says so and the build clears n doubles per entry instead of four. */
 int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t key_lo, int64_t key_hi, int accumulate, sdqh_table** out);
 /* Membership-only K-B: the set of keys of the passing rows (exact bitmap over [key_lo, key_hi], which the
  * caller knows from the key's sources); SDQH_ERR_UNSUPPORTED if a key falls outside. */

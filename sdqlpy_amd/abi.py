@@ -604,10 +604,12 @@ class Context:
         n = ng.value
         return out_keys[:n], out_vals[:n, :len(prog.vals)], out_cnt[:n]
 
-    def xbuild(self, nrows, prog, key_lo=1, key_hi=0, accumulate=False):
+    def xbuild(self, nrows, prog, key_lo=1, key_hi=0, accumulate=False, nsums=None):
+        """nsums: how many sums per entry the later probe-aggregate will add, when the caller's plan knows (else room for all four)."""
         h = C.c_void_p()
+        acc = 0 if not accumulate else (16 + int(nsums) if nsums is not None and 0 <= int(nsums) <= TUPLE_MAX_VALUES else 1)
         self._check(self.lib.sdqh_xbuild(self.handle, C.c_int64(nrows), C.byref(prog.struct()), C.c_int64(key_lo), C.c_int64(key_hi),
-                                         C.c_int(1 if accumulate else 0), C.byref(h)))
+                                         C.c_int(acc), C.byref(h)))
         self._after_call("xbuild")
         return Table(self, h, len(prog.vals), accumulate)
 

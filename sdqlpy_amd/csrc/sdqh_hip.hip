@@ -610,6 +610,7 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "narrow" && value >= 0 && value <= 1) ctx->opt_narrow = (int)value;
     else if (n == "tight" && value >= 0 && value <= 1) ctx->opt_tight = (int)value;
     else if (n == "spin_sync" && value >= 0 && value <= 1) ctx->opt_spin_sync = (int)value;
+    else if (n == "vstage" && value >= 0 && value <= 1) ctx->opt_vstage = (int)value;
     else if (n == "side_streams" && value >= 0 && value <= 1) ctx->opt_side_streams = (int)value;
     else if (n == "async_result" && value >= 0 && value <= 1) ctx->opt_async_result = (int)value;
     else if (n == "stage_pipeline" && value >= 0 && value <= 1) ctx->opt_stage_pipeline = (int)value;

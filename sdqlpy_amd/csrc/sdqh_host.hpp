@@ -88,6 +88,7 @@ struct sdqh_ctx {
     int64_t opt_feature_min_rows = 1 << 20;        // narrow twins / row pack (and, x 4, the coarse filter) are for scans of at least this many rows; the suites set 0 to
                                                    // run those instances on tiny and ragged inputs too
     bool in_groupby_key = false;                   // sdqh_groupby_key is running its probe-aggregate pass
+    int opt_vstage = 1;                            // unique builds that qualify run on the value-queue stage kernel (x_vstage8)
     int opt_tight = 1;                             // register row programs stream their columns at the tightest exact encoding (dictionary codes of 1 / 2 bytes, 4-byte twins), 8 rows per lane (x_tight)
     hipStream_t side[2] = {nullptr, nullptr};      // side streams: independent build chains of a plan run beside the main stream (fork / join by events)
     hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -47,6 +47,7 @@ std::string entry_name(Sink s, bool direct, bool tight) {
     const char* sk = s == SINK_SUM ? "sum" : s == SINK_GROUP ? "group" : s == SINK_STAGE ? "build" : s == SINK_KEYSET ? "keyset" : s == SINK_ENTRY ? "probe_agg" : "group_lane";
     return std::string("xk_") + sk + (tight ? "_tight" : direct ? "_direct" : "_queue");
 }
+const char* VSTAGE_ENTRY = "xk_build_values";
 enum Enc { ENC_RAW = 0, ENC_N32 = 1, ENC_C16 = 2, ENC_C8 = 3 };
 // the same name as the profiling label of a launch (a pointer that stays valid): bench.py's per-kernel table and rocprofv3's agree on names
 const char* launch_label(Sink s, bool direct, bool tight) {
@@ -86,6 +87,7 @@ struct XInfo {
     int64_t dlo[SDQH_MAX_XCOLS] = {};
     signed char irange[SDQH_MAX_XOPS] = {};  // i64 operations over the columns' actual ranges: 0 unknown / wide, 1 fits int32, 2 fits 24 bits (32-bit arithmetic, v_mul_i32_i24)
     bool fake = false;
+    bool vstage = false; int nlk = 0; int lk_op[2] = {-1, -1};      // a build that x_vstage8 can run: every gate on registers, lookups answered by exact 32-bit-range bitmaps
     bool pref32 = false;                     // the prefilter's key and its table's bitmap range fit 32 bits: the streamed test is 32-bit arithmetic
     uint32_t gather32 = 0;                   // queue programs: numeric columns read BY ROW (the drain's gathers) through their 4-byte twins: half the bytes of every touched line
     std::vector<char> scope;                 // operations evaluated on the streamed registers (register programs: all; queue programs: the streamed gates + the prefilter's key)
@@ -313,7 +315,7 @@ void tight_plan(sdqh_ctx* ctx, int64_t nrows, XInfo* x) {
     //  output compiles for gfx950)
     const bool fake = ctx->compile_only && std::getenv("SDQLPY_AMD_FAKE_CODES") != nullptr;
     static const std::vector<int64_t> fake_dict = {0, 1, 2, 3};
-    const bool regs_all = x->direct;                                      // every column is streamed and every operation evaluated on registers
+    const bool regs_all = x->direct || x->vstage;                         // every column is streamed and every operation evaluated on registers
     if (!ctx->opt_tight || x->ncols < 1 || (!regs_all && x->scols.empty())) return;
     // Every register program runs on the tight skeleton, and every queue program that streams anything on the tight queue,
     // whatever its columns' encodings: rows meet lanes, partial sums are folded and queues are drained in the same order with and
@@ -655,7 +657,115 @@ std::string generate_tight(const XInfo& x, Sink sink) {
 }
 
 
+
+// Can x_vstage8 run this build?  Every operation on registers; lookups only as gates of their own, keyed by one plain integer column
+// that fits 32 bits, into tables that answer membership from an exact bitmap over a 32-bit range; at most two payload fields.
+void vstage_plan(sdqh_ctx* ctx, int64_t nrows, XInfo* x) {
+    const sdqh_program* p = x->p;
+    x->vstage = false; x->nlk = 0;
+    const bool fake = ctx->compile_only && std::getenv("SDQLPY_AMD_FAKE_CODES") != nullptr;
+    if (!ctx->opt_tight || !ctx->opt_narrow || !ctx->opt_vstage || x->ncols < 1 || x->ncols > 12 || p->nvals > 2 ||
+        (ctx->compile_only && !fake) || (!fake && nrows < ctx->opt_feature_min_rows)) return;
+    for (int c = 0; c < x->ncols; ++c) if (x->cols[c]->dtype == SDQH_STR) return;
+    for (int k = 0; k < p->nops; ++k) {
+        const sdqh_xop& o = p->ops[k];
+        if (op_is_light(o)) continue;
+        if (o.code != SDQH_X_LOOKUP || x->nlk == 2) return;
+        bool gate = false, used = p->key == k;
+        for (int g = 0; g < p->ngates; ++g) gate = gate || p->gates[g] == k;
+        for (int j = k + 1; j < p->nops; ++j) used = used || p->ops[j].a == k || p->ops[j].b == k || (p->ops[j].code == SDQH_X_SELECT && p->ops[j].c == k);
+        for (int v = 0; v < p->nvals; ++v) used = used || p->vals[v] == k;
+        if (!gate || used || p->ops[o.a].code != SDQH_X_COL || p->ops[o.a].type != SDQH_T_I64) return;
+        if (!fake) {
+            const sdqh_table* t = o.table;
+            if (!(t->dev.bm && t->dev.bm_shift == 0 && t->dev.lin_rb == 0 && t->dev.bm_lo >= INT32_MIN && t->dev.bm_hi <= INT32_MAX && t->dev.bm_hi >= t->dev.bm_lo)) return;
+        }
+        x->lk_op[x->nlk++] = k;
+    }
+    x->vstage = true;
+    tight_plan(ctx, nrows, x);                                             // again, now with every column streamed
+    bool ok = x->tight;
+    for (int l = 0; l < x->nlk && ok; ++l) ok = x->irange[p->ops[x->lk_op[l]].a] >= 1;      // the lookups' keys fit 32 bits
+    if (!ok) { x->vstage = false; tight_plan(ctx, nrows, x); }
+}
+
+std::string generate_vstage(const XInfo& x) {
+    const sdqh_program* p = x.p;
+    Gen g(x);
+    std::vector<int> scols;
+    for (int c = 0; c < x.ncols; ++c) scols.push_back(c);
+    for (size_t i = 0; i < scols.size(); ++i) g.slot_of[(size_t)scols[i]] = (int)i;
+    auto bpr = [&](int c) { return x.enc[c] == ENC_C8 ? 1 : x.enc[c] == ENC_C16 ? 2 : x.enc[c] == ENC_N32 ? 4 : 8; };
+    auto is_lk = [&](int k) { for (int l = 0; l < x.nlk; ++l) if (x.lk_op[l] == k) return true; return false; };
+    g.reset(); g.mode = 3; g.os.str("");
+    g.os << "        bool p = true;\n";
+    for (int q = 0; q < p->ngates; ++q) { if (is_lk(p->gates[q])) continue; g.emit(p->gates[q]); g.os << "        p = p & v" << p->gates[q] << ";\n"; }
+    g.os << "        return p;\n";
+    const std::string gates = g.os.str();
+    std::string lkoff;
+    for (int l = 0; l < x.nlk; ++l) {
+        g.reset(); g.os.str("");
+        const int kop = p->ops[x.lk_op[l]].a;
+        g.emit(kop);
+        const std::string t = "a.tab[" + std::to_string(x.tab_of[x.lk_op[l]]) + "]";
+        lkoff += "        if (l == " + std::to_string(l) + ") {\n" + g.os.str();
+        lkoff += "            const uint32_t o32 = (uint32_t)((int32_t)v" + std::to_string(kop) + " - (int32_t)" + t + ".bm_lo);\n";
+        lkoff += "            p = p & (o32 <= (uint32_t)(" + t + ".bm_hi - " + t + ".bm_lo));\n            return o32;\n        }\n";
+    }
+    lkoff += "        return 0u;\n";
+    g.reset(); g.os.str("");
+    g.emit(p->key);
+    g.os << "        o.key = v" << p->key << "; o.bad = " << g.bad(p->key) << ";\n";
+    for (int v = 0; v < p->nvals; ++v) {
+        g.emit(p->vals[v]);
+        g.os << "        o.val[" << v << "] = " << (p->ops[p->vals[v]].type == SDQH_T_F64 ? "x_bits(v" + std::to_string(p->vals[v]) + ")" : "v" + std::to_string(p->vals[v])) << ";\n";
+    }
+    g.os << "        o.ent = NO_ROW;\n";
+    const std::string row = g.os.str();
+    const std::vector<std::pair<int, int>> tabs = g.tabs;
+    std::ostringstream out;
+    if (const char* e = std::getenv("SDQLPY_AMD_XV_EXP")) out << "#define XV_EXP " << std::atoi(e) << "\n";      // (timing experiments: x_vstage8)
+    out << "#include \"sdqh_xkernels.hpp\"\nusing namespace sdqh;\n";
+    bool q32 = x.irange[p->key] >= 1;                                     // key and payload fit 32 bits: a queue of 4-byte words
+    for (int v = 0; v < p->nvals; ++v) q32 = q32 && p->ops[p->vals[v]].type == SDQH_T_I64 && x.irange[p->vals[v]] >= 1;
+    out << "struct P {\n    static constexpr int NV = " << p->nvals << ", ND = " << tabs.size() << ", NL = " << x.nlk << ";\n    static constexpr bool Q32 = " << (q32 ? "true" : "false") << ";\n    struct Regs {";
+    for (size_t i = 0; i < scols.size(); ++i) out << " uint32_t c" << i << "[" << bpr(scols[i]) * 2 << "];";
+    out << " };\n";
+    out << "    __device__ __forceinline__ static void load_dicts(const XArgs& a, int64_t (*tab)[256]) {\n";
+    for (size_t j = 0; j < tabs.size(); ++j) {
+        const int k = tabs[j].first, c = tabs[j].second;
+        Gen t(x);
+        t.mode = 4; t.dict_col = c;
+        t.emit(k);
+        const int ty = p->ops[k].type;
+        out << "        for (int i = threadIdx.x; i < 256; i += TPB) {\n            int64_t cell = 0;\n            if (i < a.ndict[" << c << "]) {\n                const int64_t dv = a.dict[" << c << "][i];\n";
+        out << t.os.str();
+        out << "                cell = " << (ty == SDQH_T_F64 ? "x_bits(v" + std::to_string(k) + ")" : ty == SDQH_T_BOOL ? "(v" + std::to_string(k) + " ? 1 : 0)" : "v" + std::to_string(k)) << ";\n";
+        out << "            }\n            tab[" << j << "][i] = cell;\n        }\n";
+    }
+    out << "    }\n";
+    out << "    template <bool TAIL> __device__ __forceinline__ static void sload(const XArgs& a, int64_t r, int64_t nrows, Regs& s) {\n";
+    for (size_t i = 0; i < scols.size(); ++i) {
+        const int c = scols[i];
+        const char* src = x.enc[c] >= ENC_C16 ? "a.code[" : x.enc[c] == ENC_N32 ? "a.ncol[" : "a.col[";
+        out << "        xt_load<" << bpr(c) << ", TAIL>(" << src << c << "], r, nrows, s.c" << i << ");\n";
+    }
+    out << "    }\n";
+    out << "    __device__ __forceinline__ static bool gates(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i, const int64_t r) {\n" << gates << "    }\n";
+    out << "    __device__ __forceinline__ static uint32_t lkoff(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i, const int64_t r, const int l, bool& p) {\n" << lkoff << "    }\n";
+    out << "    __device__ __forceinline__ static const uint32_t* lkbm(const XArgs& a, int l) { return ";
+    if (x.nlk == 0) out << "nullptr";
+    else if (x.nlk == 1) out << "a.tab[" << x.tab_of[x.lk_op[0]] << "].bm";
+    else out << "l == 0 ? a.tab[" << x.tab_of[x.lk_op[0]] << "].bm : a.tab[" << x.tab_of[x.lk_op[1]] << "].bm";
+    out << "; }\n";
+    out << "    __device__ __forceinline__ static void row(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i, const int64_t r, XOut<NV>& o) {\n" << row << "    }\n};\n";
+    out << "extern \"C\" __global__ __launch_bounds__(256) void " << VSTAGE_ENTRY << "(XArgs a, XStage<P::NV>::Args s, int64_t nrows, int64_t seg_rows, int nseg) {\n";
+    out << "    x_vstage8<P>(a, s, nrows, seg_rows, nseg);\n}\n";
+    return out.str();
+}
+
 std::string generate(const XInfo& x, Sink sink, bool direct) {
+    if (x.vstage && sink == SINK_STAGE) return generate_vstage(x);
     if (x.tight && direct) return generate_tight(x, sink);
     const bool q8 = x.tight && !direct;                                 // the queue skeleton with the tight streamed part (x_queue8)
     const sdqh_program* p = x.p;
@@ -876,7 +986,7 @@ uint64_t structure_hash(const XInfo& x, Sink sink, bool direct) {
     auto mix = [&](uint64_t v) { h ^= v; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29; };      // (a word at a time: this runs on every call)
     mix((uint64_t)sink * 2 + (direct ? 1 : 0)); mix((uint64_t)x.narrow_mask);
     if (x.tight) {
-        mix(0x7167ull); mix((uint64_t)x.gather32); mix(x.pref32 ? 1ull : 0ull);
+        mix(0x7167ull); mix((uint64_t)x.gather32); mix((x.pref32 ? 1ull : 0ull) | (x.vstage ? 2ull : 0ull));
         for (int c = 0; c < x.ncols; ++c) mix(((uint64_t)(uint32_t)x.enc[c] << 32) | ((uint32_t)(x.affine[c] ? 1 : 0) << 16) | (uint32_t)(x.dict_slot[c] & 0xFFFF));
         for (int k = 0; k < x.p->nops; ++k) mix((uint64_t)(uint8_t)x.irange[k]);
         for (int k = 0; k < x.p->nops; ++k) mix(((uint64_t)(uint32_t)x.cmp_cc[k] << 32) | ((uint32_t)x.cmp_kind[k] << 8) | (uint32_t)(x.cmp_col[k] & 0xFF));
@@ -904,7 +1014,7 @@ int kernel_for(sdqh_ctx* ctx, const XInfo& x, Sink sink, bool direct, hipFunctio
         auto hit = J.kernels.find(name);
         if (hit != J.kernels.end()) { *fn = hit->second; return SDQH_OK; }
     }
-    if (int rc = specialise(ctx, generate(x, sink, direct), entry_name(sink, direct, x.tight), fn)) return rc;
+    if (int rc = specialise(ctx, generate(x, sink, direct), (x.vstage && sink == SINK_STAGE) ? std::string(VSTAGE_ENTRY) : entry_name(sink, direct, x.tight), fn)) return rc;
     std::lock_guard<std::mutex> lock(J.mu);
     J.kernels[name] = *fn;
     return SDQH_OK;
@@ -1147,6 +1257,7 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
     if (!ctx->compile_only) (void)hipSetDevice(ctx->device);
     XInfo x;
     if (int rc = analyse(ctx, nrows, prog, SDQH_MAX_PAYLOAD, true, false, &x)) return rc;
+    vstage_plan(ctx, nrows, &x);
     hipFunction_t fn;
     if (int rc = kernel_for(ctx, x, SINK_STAGE, false, &fn)) {
         if (!ctx->compile_only || ctx->err.find("kernel specialised") == std::string::npos) return rc;
@@ -1170,6 +1281,7 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
     while (capmax < 2 * (uint64_t)std::max<int64_t>(nrows, 1)) capmax <<= 1;
     tb->capmax = capmax;
     int32_t* flags = nullptr;
+    if (!rc && accumulate >= 16) tb->stage.acc_stride = std::max(1, std::min(accumulate - 16, SDQH_TUPLE_MAX_VALUES));      // the caller's plan knows how many sums an entry gets
     if (!rc) {
         tb->hdr = static_cast<TableHeader*>(tb_alloc(ctx, tb, sizeof(TableHeader)));
         flags = static_cast<int32_t*>(tb_alloc(ctx, tb, 64));
@@ -1193,7 +1305,7 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
             // the segments were cut by stage_setup_computed: the kernel's geometry must be the stage's
             Geometry g{(unsigned)((tb->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE)), tb->stage.seg_rows, tb->stage.nseg};
             XStage<1>::Args sa{tb->stage};
-            rc = launch(ctx, fn, launch_label(SINK_STAGE, false, x.tight), a, sa, nrows, g);
+            rc = launch(ctx, fn, x.vstage ? VSTAGE_ENTRY : launch_label(SINK_STAGE, false, x.tight), a, sa, nrows, g);
         }
         call_end(ctx);
         int f = 0;

@@ -813,4 +813,144 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
 }
 
 
+
+// =================================================================================================
+// STAGE with a queue of VALUES (x_vstage8): a unique build whose every condition can be decided on the streamed registers —
+// comparisons, arithmetic, and `tbl[k] != None` tests against tables that answer from an EXACT key bitmap over a 32-bit range —
+// and whose key and payload are values of the scanned row.  A lane evaluates its 8 rows where they are (the bitmap words of a
+// step's rows are requested together), and the survivors' KEY and PAYLOAD WORDS — not their row numbers — go to the wave's LDS
+// queue at prefix positions (row order: lane-major); every full group of 64 is then stored to the stage by the whole wave.  Against
+// the row-number queue: no second lookup and no gathers by row (Q3's orders build fetched most lines of three columns for a tenth
+// of their values: 529 MB for 165 MB of streamed columns); against storing from the rows' own lanes (tried in round 3: every store
+// instruction ran with a tenth of its lanes, 0.150 ms against 0.128): the stores are whole.
+// P::gates / P::lkoff / P::lkbm / P::row; NL <= 2 lookups, NV <= 2 payload fields (the queue is (1 + NV) x 8 bytes x 576 per wave).
+// =================================================================================================
+constexpr int XV_CAP = 64 + X8_STEP;
+template <bool Q32> struct XQueueWord { using type = int64_t; };
+template <> struct XQueueWord<true> { using type = int32_t; };
+template <class P>
+__device__ __forceinline__ void x_vstage8(const XArgs& a, const typename XStage<P::NV>::Args& sa, int64_t nrows, int64_t seg_rows, int nseg) {
+    constexpr int NQ = 1 + (P::NV > 0 ? P::NV : 0);
+    // P::Q32: key and payload are integers that fit 32 bits (known from the columns' ranges when the kernel is specialised): the queue
+    // holds 4-byte words — 27 KiB per workgroup instead of 55, five resident workgroups per CU instead of two (the kernel waits on memory
+    // half of its cycles: PMC, Q3's orders build at 8 waves per CU took 2.4 rounds of waves)
+    using QT = typename XQueueWord<P::Q32>::type;
+    __shared__ QT s_q[TPB / WAVE][NQ][XV_CAP];
+    __shared__ int64_t s_tab[P::ND > 0 ? P::ND : 1][256];
+    P::load_dicts(a, s_tab);
+    __syncthreads();
+    const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
+    if (seg >= nseg) return;
+    const int lane = lane_id();
+    const DevStage& st = sa.st;
+    QT (*q)[XV_CAP] = s_q[threadIdx.x / WAVE];
+    const int64_t begin = (int64_t)seg * seg_rows;
+    int64_t end = begin + seg_rows; if (end > nrows) end = nrows;
+    int64_t out = begin;
+    int qn = 0;
+    constexpr int NL = P::NL > 0 ? P::NL : 1;
+    const uint32_t* bm[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) bm[l] = P::NL > l ? P::lkbm(a, l) : nullptr;
+    auto flush = [&](int first, int count) {                                 // queued entries [first, first + count), count <= 64, one per lane
+        if (lane < count) {
+            const int64_t key = (int64_t)q[0][first + lane];
+            int64_t pay[MAX_STAGE_COLS] = {0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < P::NV; ++k) pay[k] = (int64_t)q[1 + k][first + lane];
+            if (a.key_lo <= a.key_hi && (key < a.key_lo || key > a.key_hi)) atomicOr(a.flags, 2);      // (the call fails; what is stored is never read)
+#ifdef XV_EXP
+            {   // timing experiments only (SDQLPY_AMD_XV_EXP): bit 0 no bitmap atomics, bit 1 no accumulator zeroing, bit 2 no payload stores
+                const int64_t pos = out + lane;
+                st.key[pos] = key;
+                if (!(XV_EXP & 4)) { for (int qq = 0; qq < P::NV; ++qq) st.pay[qq][pos] = pay[qq]; }
+                if (st.shits) st.shits[pos] = 0;
+                if (st.sacc && !(XV_EXP & 2)) zero_acc(st, pos);
+                if (st.bm && !(XV_EXP & 1)) { uint64_t off; if (bm_locate(st, key, off)) atomicOr(&st.bm[off >> 5], 1u << (off & 31)); }
+            }
+#else
+            stage_store<-1>(st, out + lane, key, pay);
+#endif
+        }
+        out += count;
+    };
+    auto enqueue = [&](const typename P::Regs& s, int64_t r0, uint32_t m) {   // the lane's survivors (bits of m), in row order
+        if (!__ballot(m != 0)) return;
+        int total;
+        int at = qn + wave_excl_prefix(__popc(m), total);
+#pragma unroll
+        for (int i = 0; i < XT_R; ++i) {
+            XOut<P::NV> o;
+            P::row(a, s, s_tab, i, r0 + i, o);
+            if ((m >> i) & 1u) {
+                if (o.bad) atomicOr(a.flags, 2);
+                q[0][at] = (QT)o.key;
+#pragma unroll
+                for (int k = 0; k < P::NV; ++k) q[1 + k][at] = (QT)o.val[k];
+                ++at;
+            }
+        }
+        qn += total;
+        __builtin_amdgcn_wave_barrier();
+        int head = 0;
+        while (qn - head >= WAVE) { flush(head, WAVE); head += WAVE; }
+        if (head) {                                                            // what is left (< 64) moves to the front
+            const int left = qn - head;
+            QT v[NQ];
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) v[k] = lane < left ? q[k][head + lane] : (QT)0;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < left) {
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) q[k][lane] = v[k];
+            }
+            __builtin_amdgcn_wave_barrier();
+            qn = left;
+        }
+    };
+    auto step = [&](int64_t b, auto u_tag, auto tail_tag) {
+        constexpr int U = decltype(u_tag)::value ? X8_U : 1;
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        typename P::Regs s[U];
+        uint32_t m[U], off[NL][U][XT_R], w[NL][U][XT_R];
+#pragma unroll
+        for (int u = 0; u < U; ++u) P::template sload<TAIL>(a, b + (int64_t)u * X8_STEP + (int64_t)lane * XT_R, TAIL ? end : nrows, s[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            m[u] = 0;
+            const int64_t r0 = b + (int64_t)u * X8_STEP + (int64_t)lane * XT_R;
+#pragma unroll
+            for (int i = 0; i < XT_R; ++i) {
+                bool p = (!TAIL || r0 + i < end) && P::gates(a, s[u], s_tab, i, r0 + i);
+#pragma unroll
+                for (int l = 0; l < NL; ++l) { off[l][u][i] = 0; if (P::NL > l) { const uint32_t o32 = P::lkoff(a, s[u], s_tab, i, r0 + i, l, p); off[l][u][i] = p ? o32 : 0u; } }
+                m[u] |= p ? (1u << i) : 0u;
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < NL; ++l) if (P::NL > l)
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int i = 0; i < XT_R; ++i) w[l][u][i] = bm[l][off[l][u][i] >> 5];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int l = 0; l < NL; ++l) if (P::NL > l) {
+                uint32_t hit = 0;
+#pragma unroll
+                for (int i = 0; i < XT_R; ++i) hit |= __builtin_amdgcn_ubfe(w[l][u][i], off[l][u][i] & 31u, 1u) << i;
+                m[u] &= hit;
+            }
+            enqueue(s[u], b + (int64_t)u * X8_STEP + (int64_t)lane * XT_R, m[u]);
+        }
+    };
+    int64_t b = begin;
+    for (; b + (int64_t)X8_STEP * X8_U <= end; b += (int64_t)X8_STEP * X8_U) step(b, XBool<true>{}, XBool<false>{});
+    for (; b + X8_STEP <= end; b += X8_STEP) step(b, XBool<false>{}, XBool<false>{});
+    if (b < end) step(b, XBool<false>{}, XBool<true>{});
+    if (qn) flush(0, qn);
+    if (lane == 0) st.seg_count[seg] = (uint32_t)(out - begin);
+}
+
 }  // namespace sdqh

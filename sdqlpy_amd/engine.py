@@ -101,8 +101,10 @@ class Engine:
         self.stream_programs = os.environ.get("SDQLPY_AMD_STREAM_PROGRAMS", "1") != "0" and ctx.library.backend_name() == "hip-gfx950"
         # ... and so do the loops that aggregate into the entry a probe matches ("probe": Q3's lineitem loop — the specialised kernel
         # streams the key through its 4-byte twin and the date as a 2-byte code, tests the key bitmap in 32-bit arithmetic) and, on
-        # request, unique builds ("build").  Measured per kind in profiles/r03_ab_tuned_vs_programs.txt.
-        routes = os.environ.get("SDQLPY_AMD_PROGRAM_ROUTES", "probe")
+        # request, unique builds ("build"); "values": the builds whose key and payload are plain columns of the scanned row and whose
+        # conditions need no payload of a looked-up entry (Q3's orders build) — the value-queue stage kernel streams everything and
+        # gathers nothing.  Measured per kind in profiles/r03_ab_tuned_vs_programs.txt.
+        routes = os.environ.get("SDQLPY_AMD_PROGRAM_ROUTES", "probe,values")
         self.program_routes = {r for r in routes.split(",") if r} if ctx.library.backend_name() == "hip-gfx950" else set()
 
     def close(self):
@@ -874,6 +876,27 @@ def _is_stream_loop(op):
     return not found
 
 
+def _plain_values_build(op, htab):
+    """A unique build the value-queue stage kernel can run (csrc/sdqh_xkernels.hpp: x_vstage8): keyed by one integer column, at most
+    two payload fields that are numeric columns of the scanned row, conditions that compare columns with constants, membership
+    tests keyed by a plain integer column."""
+    def num_col(e, kinds="if"):
+        return isinstance(e, Col) and htab.cols.get(e.name) is not None and htab.cols[e.name].dtype.kind in kinds
+    if not (op.kind == "dict" and op.unique) or isinstance(op.key, RecordCons) or not num_col(op.key, "i"):
+        return False
+    vals = [e for _, e in op.val.fields] if isinstance(op.val, RecordCons) else [op.val]
+    vals = [e for e in vals if not (isinstance(e, Const) and e.value is True)]
+    if len({repr(e) for e in vals}) > 2 or not all(num_col(e) for e in vals):
+        return False
+    for c in op.conds:
+        if isinstance(c, Contains):
+            if not num_col(c.lookup.key, "i"):
+                return False
+        elif not (isinstance(c, Cmp) and all(num_col(x) or (isinstance(x, Const) and isinstance(x.value, (int, float)) and not isinstance(x.value, bool)) for x in (c.left, c.right))):
+            return False
+    return op.probe is None or num_col(op.probe.key, "i")
+
+
 def _prepare_scan(eng, op, htab, accumulate_into, member_only=False, as_table=False, coded_text=False, _no_stream=False):
     """closure(env) for one table loop: the tuned fixed-shape calls when the loop is one of their shapes,
     a row program (xplan.py: a kernel specialised on the loop's own conditions and values) otherwise.
@@ -891,7 +914,7 @@ def _prepare_scan(eng, op, htab, accumulate_into, member_only=False, as_table=Fa
         if op.kind == "dict" and not op.unique and op.probe is not None and op.probe.dict_name in accumulate_into:
             routed = "probe" in eng.program_routes
         elif op.kind == "dict" and op.unique:
-            routed = "build" in eng.program_routes
+            routed = "build" in eng.program_routes or ("values" in eng.program_routes and not member_only and htab.nrows >= (1 << 20) and _plain_values_build(op, htab))
     if routed or (getattr(eng, "stream_programs", False) and not _no_stream and not as_table and not member_only and _is_stream_loop(op)):
         try:
             x = xplan.prepare_scan(eng, op, htab, accumulate_into, member_only, as_table)
@@ -1570,6 +1593,15 @@ class PreparedPlan:
                            and (_is_simple(op, tables[op.table], [c.lookup for c in op.conds if isinstance(c, Contains)]) or xplan.groups_by_entry(op))}
         # builds that only ever answer `tbl[k] != None` (never probed for a payload, never materialised):
         # membership-only tables (sdqh_build_key_set)
+        # how many sums the probe-aggregate into a table will add per entry, where the plan says (a build then clears that many)
+        acc_sums = {}
+        for op in plan.ops:
+            if isinstance(op, ScanOp) and op.kind == "dict" and not op.unique and op.probe is not None and op.probe.dict_name in accumulate_into:
+                fields = [e for _, e in op.val.fields] if isinstance(op.val, RecordCons) else [op.val]
+                n = sum(0 if (isinstance(e, Const) and isinstance(e.value, int) and not isinstance(e.value, bool)) else 1 for e in fields)
+                acc_sums[op.probe.dict_name] = max(acc_sums.get(op.probe.dict_name, 0), n)
+        # (the set of names becomes a dictionary name -> sums per entry, or None where the plan does not say: `in` works as before)
+        accumulate_into = {name: (acc_sums.get(name) if 1 <= acc_sums.get(name, 0) <= abi.TUPLE_MAX_VALUES else None) for name in accumulate_into}
         member_only = _membership_only(plan)
         looked_up = _looked_up(plan)
         compared = _compared_lookups(plan)

@@ -644,7 +644,7 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
                 if all(col is not None for col in cols):
                     table = ctx.hash_build_unique(n, abi.make_filter(), [], cols[0], cols[1:])
             if table is None:
-                table = ctx.xbuild(n, c.P, bounds[0], bounds[1], accumulate=accumulate)
+                table = ctx.xbuild(n, c.P, bounds[0], bounds[1], accumulate=accumulate, nsums=accumulate_into.get(op.out) if accumulate and isinstance(accumulate_into, dict) else None)
             bt = BuiltTable(table, key_names[0], key_is_record, val_fields, val_is_record, dtypes)
             bt.decoders, bt.field_decoders, bt.slot_rng = dict(decoders[0]), dict(decoders[1]), dict(decoders[2])
             if composite:
@@ -762,7 +762,14 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
                 c, parts, radix, count_idx = st
                 c.bind(env)
                 keys, vals, cnts = ctx.xgroupby(n, c.P)
-                kf = _decode_radix(keys, [(nm or "key%d" % i, vs, kind) for i, (nm, vs, kind) in enumerate(parts)], radix)
+                # the same handful of group keys comes back run after run: their decoded fields are kept (a dozen small numpy calls otherwise)
+                kcache = state.get("kf_cache")
+                kbytes = keys.tobytes()
+                if kcache is not None and kcache[0] is c and kcache[1] == kbytes:
+                    kf = [(nm, a.copy() if isinstance(a, np.ndarray) else a) for nm, a in kcache[2]]
+                else:
+                    kf = _decode_radix(keys, [(nm or "key%d" % i, vs, kind) for i, (nm, vs, kind) in enumerate(parts)], radix)
+                    state["kf_cache"] = (c, kbytes, [(nm, a.copy() if isinstance(a, np.ndarray) else a) for nm, a in kf])
                 vf, at = [], 0
                 for i, nm in enumerate(vnames):
                     if count_idx is not None and i == count_idx:

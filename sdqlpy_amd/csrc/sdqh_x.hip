@@ -1094,8 +1094,8 @@ int fill_xargs(sdqh_ctx* ctx, const XInfo& x, XArgs* a, int32_t* flags, int64_t 
 }
 
 struct Geometry { unsigned grid; int64_t seg_rows; int nseg; };
-Geometry geometry_tight(sdqh_ctx* ctx, int64_t nrows, int resident) {
-    const int64_t steps = std::max<int64_t>(1, nrows / ((int64_t)XT_ROWS * XT_U));
+Geometry geometry_tight(sdqh_ctx* ctx, int64_t nrows, int resident, bool pipelined = false) {
+    const int64_t steps = std::max<int64_t>(1, nrows / ((int64_t)XT_ROWS * (pipelined ? 1 : 2)));
     return Geometry{(unsigned)std::min<int64_t>(steps, (int64_t)ctx->num_cu * resident), 0, 0};
 }
 Geometry geometry(sdqh_ctx* ctx, int64_t nrows, bool direct, int waves_per_cu, bool tight = false) {
@@ -1207,7 +1207,7 @@ int sdqh_xgroupby(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int ma
     static_assert(LG_SLOTS * 48 + 8 <= RESULT_BYTES, "result block too small");
     XArgs a;
     if (int rc = fill_xargs(ctx, x, &a, r_flags, klo, khi)) return rc;
-    const Geometry g = (x.tight && x.direct) ? geometry_tight(ctx, nrows, 2) : geometry(ctx, nrows, x.direct, 16, x.tight);
+    const Geometry g = (x.tight && x.direct) ? geometry_tight(ctx, nrows, 2, sink == SINK_GROUP_LANE) : geometry(ctx, nrows, x.direct, 16, x.tight);
     const size_t npart = (size_t)g.grid * LG_SLOTS;
     char* blob = static_cast<char*>(pool_alloc(ctx, npart * 40 + 256));
     if (!blob) return fail(ctx, SDQH_ERR_NOMEM, "xgroupby: out of device memory");

@@ -135,6 +135,7 @@ __device__ __forceinline__ int64_t x_hits(const DevTable& t, uint32_t ent) {
 
 // ---- K-A: sums of NV doubles + a row count; one partial per workgroup, folded by k_sum_partials ----
 template <int NV> struct XSum {
+    static constexpr bool PIPELINED = false;                          // x_tight: two tiles in flight per step (many waves per SIMD cover the latency)
     struct Args { double* partial; };
     double acc[NV > 0 ? NV : 1];
     int64_t cnt;
@@ -165,6 +166,7 @@ template <int NV> struct XSum {
 
 // ---- K-C over a small group domain: LDS hash table per workgroup, f64 LDS atomics, slot-major partials ----
 template <int NV> struct XGroup {
+    static constexpr bool PIPELINED = false;
     struct Args { unsigned long long* gkeys; double* pacc; int64_t* pcnt; int* flags; };
     static constexpr int NVS = NV > 0 ? NV : 1;
     unsigned long long* s_keys; double (*s_acc)[NVS]; unsigned long long* s_cnt; int* s_map; int* s_flags;
@@ -517,7 +519,6 @@ __device__ __forceinline__ void x_queue(const XArgs& a, const typename SinkT<P::
 // =================================================================================================
 constexpr int XT_R = 8;
 constexpr int XT_ROWS = TPB * XT_R;                                    // rows per workgroup tile
-constexpr int XT_U = 2;                                                // tiles in flight per step
 
 // the 8 rows of a lane: BPR bytes per row -> BPR * 2 32-bit words
 template <int BPR, bool TAIL>
@@ -562,6 +563,7 @@ __device__ __forceinline__ int64_t xt_i64(const uint32_t (&w)[16], int i) { retu
 // Deterministic: a lane adds its rows in row order, lanes are folded in a fixed order, workgroups by
 // k_groupby_merge in workgroup order.  The slots are the key's offsets, so no key table and no claiming.
 template <int NV> struct XGroupLane {
+    static constexpr bool PIPELINED = true;                           // x_tight: its LDS cells leave two waves per SIMD: a wave hides its own latency
     struct Args { unsigned long long* gkeys; double* pacc; int64_t* pcnt; int* flags; int32_t nslots, _pad; };
     static constexpr int NA = (NV > 0 ? NV : 0) + 1;
     int nslots; bool bad;
@@ -621,35 +623,51 @@ __device__ __forceinline__ void x_tight(const XArgs& a, const typename SinkT<P::
     Sink sink;
     sink.init(sa);
     __syncthreads();
-    auto tile = [&](int64_t base, auto tail_tag, auto u_tag) {
+    auto consume_tile = [&](const typename P::Regs& s, int64_t base, auto tail_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
-        constexpr int U = decltype(u_tag)::value ? XT_U : 1;
-        typename P::Regs s[U];
+        const int64_t r = base + (int64_t)threadIdx.x * XT_R;
 #pragma unroll
-        for (int u = 0; u < U; ++u) P::template sload<TAIL>(a, base + (int64_t)u * XT_ROWS + (int64_t)threadIdx.x * XT_R, nrows, s[u]);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t r = base + (int64_t)u * XT_ROWS + (int64_t)threadIdx.x * XT_R;
-#pragma unroll
-            for (int i = 0; i < XT_R; ++i) {
-                XOut<P::NV> o;
-                bool p = TAIL ? (r + i < nrows) : true;
-                p = p && P::eval(a, s[u], s_tab, i, r + i, o);
-                sink.consume(a, sa, p, r + i, o);
-            }
+        for (int i = 0; i < XT_R; ++i) {
+            XOut<P::NV> o;
+            bool p = TAIL ? (r + i < nrows) : true;
+            p = p && P::eval(a, s, s_tab, i, r + i, o);
+            sink.consume(a, sa, p, r + i, o);
         }
     };
-    const int64_t step = (int64_t)XT_ROWS * XT_U;
-    const int64_t full = nrows / step;
-    for (int64_t t = blockIdx.x; t < full; t += gridDim.x) tile(t * step, XBool<false>{}, XBool<true>{});
-    // what is left (< XT_U tiles + a ragged one): single tiles dealt round-robin from the workgroup after the last full step
-    const int64_t rest0 = full * step;
-    const int64_t ntail = (nrows - rest0 + XT_ROWS - 1) / XT_ROWS;
-    for (int64_t j = 0; j < ntail; ++j)
-        if (blockIdx.x == (unsigned)((full + j) % gridDim.x)) {
-            const int64_t base = rest0 + j * XT_ROWS;
-            if (base + XT_ROWS <= nrows) tile(base, XBool<false>{}, XBool<false>{}); else tile(base, XBool<true>{}, XBool<false>{});
+    // Whole tiles, software-pipelined: the next tile's loads are requested before this tile's rows are consumed, so a wave's own memory
+    // latency is covered by its own arithmetic — it matters here because the per-lane accumulators leave room for two waves per SIMD
+    // only (tools/microbench_tight.hip: 0.119 -> 0.109 ms for Q1's shape).  The request is unconditional (after the workgroup's last
+    // tile: that tile again) so that no wait piles up in front of a branch.
+    // A sink that leaves room for many waves per SIMD (sums in registers) takes TWO tiles per step with all their loads in flight and
+    // lets other waves cover the latency instead (Q6: 0.0766 ms that way, 0.0795 pipelined).
+    const int64_t full = nrows / XT_ROWS;
+    typename P::Regs cur, nxt;
+    if constexpr (Sink::PIPELINED) {
+        int64_t t = blockIdx.x;
+        if (t < full) P::template sload<false>(a, t * XT_ROWS + (int64_t)threadIdx.x * XT_R, nrows, nxt);
+        for (; t < full; t += gridDim.x) {
+            cur = nxt;
+            const int64_t tn = t + gridDim.x < full ? t + gridDim.x : t;
+            P::template sload<false>(a, tn * XT_ROWS + (int64_t)threadIdx.x * XT_R, nrows, nxt);
+            consume_tile(cur, t * XT_ROWS, XBool<false>{});
         }
+    } else {
+        const int64_t pairs = full / 2;
+        for (int64_t t = blockIdx.x; t < pairs; t += gridDim.x) {
+            P::template sload<false>(a, (2 * t) * XT_ROWS + (int64_t)threadIdx.x * XT_R, nrows, cur);
+            P::template sload<false>(a, (2 * t + 1) * XT_ROWS + (int64_t)threadIdx.x * XT_R, nrows, nxt);
+            consume_tile(cur, (2 * t) * XT_ROWS, XBool<false>{});
+            consume_tile(nxt, (2 * t + 1) * XT_ROWS, XBool<false>{});
+        }
+        if ((full & 1) && blockIdx.x == (unsigned)(pairs % gridDim.x)) {                  // an odd whole tile
+            P::template sload<false>(a, (full - 1) * XT_ROWS + (int64_t)threadIdx.x * XT_R, nrows, cur);
+            consume_tile(cur, (full - 1) * XT_ROWS, XBool<false>{});
+        }
+    }
+    if (full * XT_ROWS < nrows && blockIdx.x == (unsigned)(full % gridDim.x)) {        // the ragged last tile
+        P::template sload<true>(a, full * XT_ROWS + (int64_t)threadIdx.x * XT_R, nrows, cur);
+        consume_tile(cur, full * XT_ROWS, XBool<true>{});
+    }
     sink.finish(a, sa);
 }
 
@@ -718,6 +736,8 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
             const bool last = b >= end;
             if (last) {
             } else if (b + (int64_t)X8_STEP * X8_U <= end) {
+                // (requesting the NEXT double step's loads here, before this one is consumed — the software pipeline that pays in
+                //  x_tight — measured slower in the queue skeletons: Q3's probe 0.103 -> 0.110 ms, its build 0.094 -> 0.103 ms)
                 typename P::Regs s[X8_U];
 #pragma unroll
                 for (int u = 0; u < X8_U; ++u) P::template sload<false>(a, b + (int64_t)u * X8_STEP + (int64_t)lane * XT_R, nrows, s[u]);

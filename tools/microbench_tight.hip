@@ -71,7 +71,7 @@ template <int R> __device__ __forceinline__ uint32_t byte_of(const Bytes<R>& b, 
 template <int R> __device__ __forceinline__ uint32_t half_of(const Halfs<R>& b, int i) { return (b.w[i / 2] >> (16 * (i % 2))) & 0xFFFFu; }
 
 constexpr int G = 6, NV = 4;
-enum Mode { REG = 0, LDSA = 1, LDSRW = 2 };
+enum Mode { REG = 0, LDSA = 1, LDSRW = 2, LDSP = 3 };      // LDSP: LDSA with the next step's loads requested before this step is consumed
 
 template <int R, int U, int MODE, int GS = G, bool C32 = false>
 __global__ __launch_bounds__(TPB) void k_q1(Q1Args a) {
@@ -91,13 +91,29 @@ __global__ __launch_bounds__(TPB) void k_q1(Q1Args a) {
     __syncthreads();
     constexpr int64_t TILE = (int64_t)TPB * R;
     const int64_t full = a.nrows / (TILE * U);
+    Halfs<R> nship[U]; Bytes<R> nqty[U], ndisc[U], ntax[U], nrf[U], nls[U]; Words<R> nep[U];
+    auto request = [&](int64_t t) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = (t * U + u) * TILE + (int64_t)threadIdx.x * R;
+            nship[u] = ld16<R>(a.ship, r); nqty[u] = ld8<R>(a.qty, r); ndisc[u] = ld8<R>(a.disc, r); ntax[u] = ld8<R>(a.tax, r);
+            nrf[u] = ld8<R>(a.rf, r); nls[u] = ld8<R>(a.ls, r); nep[u] = ld32<R>(a.ep, r);
+        }
+    };
+    if constexpr (MODE == LDSP) { if ((int64_t)blockIdx.x < full) request(blockIdx.x); }
     for (int64_t t = blockIdx.x; t < full; t += gridDim.x) {
         Halfs<R> ship[U]; Bytes<R> qty[U], disc[U], tax[U], rf[U], ls[U]; Words<R> ep[U];
+        if constexpr (MODE == LDSP) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { ship[u] = nship[u]; qty[u] = nqty[u]; disc[u] = ndisc[u]; tax[u] = ntax[u]; rf[u] = nrf[u]; ls[u] = nls[u]; ep[u] = nep[u]; }
+            request(t + gridDim.x < full ? t + gridDim.x : t);               // (unconditional: after the last step, this one again)
+        } else {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t r = (t * U + u) * TILE + (int64_t)threadIdx.x * R;
             ship[u] = ld16<R>(a.ship, r); qty[u] = ld8<R>(a.qty, r); disc[u] = ld8<R>(a.disc, r); tax[u] = ld8<R>(a.tax, r);
             rf[u] = ld8<R>(a.rf, r); ls[u] = ld8<R>(a.ls, r); ep[u] = ld32<R>(a.ep, r);
+        }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -117,7 +133,7 @@ __global__ __launch_bounds__(TPB) void k_q1(Q1Args a) {
                         acc[gg][0] += m ? q : 0.0; acc[gg][1] += m ? e : 0.0; acc[gg][2] += m ? dp : 0.0; acc[gg][3] += m ? ch : 0.0;
                         cnt[gg] += m ? 1 : 0;
                     }
-                } else if constexpr (MODE == LDSA) {
+                } else if constexpr (MODE == LDSA || MODE == LDSP) {
                     if (p) {
                         double* base = s_dyn + (size_t)g * 5 * TPB + threadIdx.x;
                         __hip_atomic_fetch_add(base, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -233,6 +249,7 @@ int main() {
     RUN1(8, 1, LDSA, 2); RUN1(8, 2, LDSA, 2); RUN1(8, 1, LDSA, 1); RUN1(16, 1, LDSA, 2); RUN1(4, 2, LDSA, 2); RUN1(8, 2, LDSA, 1);
     RUN1(8, 1, LDSRW, 2); RUN1(8, 2, LDSRW, 2); RUN1(16, 1, LDSRW, 2);
 #define RUNG(R, U, GS, C32, res) time_kernel("q1 R=" #R " U=" #U " LDSA GS=" #GS " C32=" #C32 " x" #res, k_q1<R, U, LDSA, GS, C32>, a, 256u * res, (size_t)GS * 5 * TPB * 8, b1, out, G * 5)
+    RUN1(8, 1, LDSP, 2); RUN1(8, 2, LDSP, 2); RUN1(8, 1, LDSP, 1); RUN1(4, 2, LDSP, 2);
     RUNG(8, 2, 6, true, 2); RUNG(8, 2, 4, false, 2); RUNG(8, 2, 4, false, 3); RUNG(8, 2, 4, true, 3); RUNG(8, 1, 4, true, 3); RUNG(8, 1, 4, true, 4); RUNG(8, 2, 4, true, 4);
     Q6Args q{ship, qty, ep, disc, dd, 730u, 1094u, 5u, 7u, 23u, n, out};
 #define RUN6(R, U, res) time_kernel("q6 R=" #R " U=" #U " x" #res, k_q6<R, U>, q, 256u * res, 0, b6, out, 2)

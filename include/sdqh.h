@@ -415,6 +415,8 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
 #define SDQH_X_I2F    15   /* (double)a                                                                                  */
 #define SDQH_X_YEAR   16   /* a / 10000 on a yyyymmdd integer (extractYear, sdql_lib.py:341-342)                          */
 #define SDQH_X_PACK2  17   /* (a << 32) | b for a, b in [0, 2^32): the packing of a two-part key; a part outside fails the call (SDQH_ERR_UNSUPPORTED) */
+#define SDQH_X_DIVI   18   /* a / imm_i on i64 with imm_i > 0 (C division); unpacks a mixed-radix or PACK2 key read back from a table (sdqh_table_columns) */
+#define SDQH_X_MODI   19   /* a % imm_i, likewise.  The divisor of both is part of the program's structure, not a rebindable constant          */
 #define SDQH_X_LT     20   /* a < b  (both i64 or both f64) -> bool; NaN compares false, as in C                           */
 #define SDQH_X_LE     21
 #define SDQH_X_GT     22

@@ -1027,6 +1027,8 @@ struct XProg {
                 case SDQH_X_NEG: if (fa) x.setf(k, -x.f(o.a)); else x.i[k] = -x.i[o.a]; break;
                 case SDQH_X_I2F: x.setf(k, (double)x.i[o.a]); break;
                 case SDQH_X_YEAR: x.i[k] = x.i[o.a] / 10000; break;
+                case SDQH_X_DIVI: x.i[k] = x.i[o.a] / o.imm_i; break;
+                case SDQH_X_MODI: x.i[k] = x.i[o.a] % o.imm_i; break;
                 case SDQH_X_PACK2: {
                     const int64_t a = x.i[o.a], b = x.i[o.b];
                     x.bad[k] = x.bad[o.a] || x.bad[o.b] || a < 0 || a > 0xFFFFFFFFll || b < 0 || b > 0xFFFFFFFFll;
@@ -1099,6 +1101,7 @@ int make_xprog(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* p, int max_vals
             case SDQH_X_NEG: rc = need((ty(o.a) == SDQH_T_I64 || ty(o.a) == SDQH_T_F64) && o.type == ty(o.a), "NEG operand"); break;
             case SDQH_X_I2F: rc = need(ty(o.a) == SDQH_T_I64 && o.type == SDQH_T_F64, "I2F operand"); break;
             case SDQH_X_YEAR: rc = need(ty(o.a) == SDQH_T_I64 && o.type == SDQH_T_I64, "YEAR operand"); break;
+            case SDQH_X_DIVI: case SDQH_X_MODI: rc = need(ty(o.a) == SDQH_T_I64 && o.type == SDQH_T_I64 && o.imm_i > 0, "DIVI / MODI need an i64 operand and a positive divisor"); break;
             case SDQH_X_PACK2: rc = need(ty(o.a) == SDQH_T_I64 && ty(o.b) == SDQH_T_I64 && o.type == SDQH_T_I64, "PACK2 operands"); break;
             case SDQH_X_LT: case SDQH_X_LE: case SDQH_X_GT: case SDQH_X_GE: case SDQH_X_EQ: case SDQH_X_NE:
                 rc = need(ty(o.a) == ty(o.b) && (ty(o.a) == SDQH_T_I64 || ty(o.a) == SDQH_T_F64 || (ty(o.a) == SDQH_T_BOOL && (o.code == SDQH_X_EQ || o.code == SDQH_X_NE))) && o.type == SDQH_T_BOOL,

@@ -123,7 +123,7 @@ def _lookups(lookups):
 # ---- row programs (ABI 4) ---------------------------------------------------------------------------
 T_I64, T_F64, T_BOOL = 0, 1, 2
 X_COL, X_ROWID, X_CONST, X_LOOKUP, X_FIELD, X_ACC = 1, 2, 3, 4, 5, 6
-X_ADD, X_SUB, X_MUL, X_DIV, X_NEG, X_I2F, X_YEAR, X_PACK2 = 10, 11, 12, 13, 14, 15, 16, 17
+X_ADD, X_SUB, X_MUL, X_DIV, X_NEG, X_I2F, X_YEAR, X_PACK2, X_DIVI, X_MODI = 10, 11, 12, 13, 14, 15, 16, 17, 18, 19
 X_LT, X_LE, X_GT, X_GE, X_EQ, X_NE = 20, 21, 22, 23, 24, 25
 X_AND, X_OR, X_NOT, X_SELECT = 30, 31, 32, 33
 X_STR, X_STRIDX, X_CHAR = 40, 41, 42
@@ -165,6 +165,12 @@ class Program:
         self.ops[i]["table"] = table
         if self._struct is not None:
             self._struct[1][i].table = table.handle
+
+    def bind_col(self, i, col):
+        """Rebind the column of COL operation i (the entries of a dictionary are fresh columns on every run: sdqh_table_columns)."""
+        self.ops[i]["col"] = col
+        if self._struct is not None:
+            self._struct[1][i].col = col.handle
 
     def struct(self):
         """The ctypes sdqh_program.  The operation array is cached (table handles are refreshed by
@@ -630,6 +636,9 @@ class Context:
         n = C.c_int64()
         self._check(self.lib.sdqh_table_columns(self.handle, table.handle, C.c_int64(min_hits), outs, C.byref(n)))
         cols = [Column(self, C.c_void_p(outs[i]), n.value, F64 if table.npayload < i <= table.npayload + TUPLE_MAX_VALUES else I64, 0) for i in range(k)]
+        for c in cols:
+            c.source_table = table                                # (HIP build: the columns are views of the table's K-F buffers)
+        self._after_call("table_columns")
         return cols[0], cols[1:1 + table.npayload], cols[1 + table.npayload:k - 1], cols[k - 1], n.value
 
     def jit_stats(self):

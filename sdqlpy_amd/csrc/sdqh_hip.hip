@@ -1581,6 +1581,23 @@ static int run_compact(sdqh_ctx* ctx, sdqh_table* table, int64_t min_hits, const
     return SDQH_OK;
 }
 
+}  // extern "C" (reopened below)
+namespace sdqh_host {
+int table_compact_resident(sdqh_ctx* ctx, sdqh_table* tb, int64_t min_hits, bool want_zero_rows, int64_t* n) {
+    (void)hipSetDevice(ctx->device);
+    if (want_zero_rows && !tb->zero_rows) {
+        const size_t bytes = ((size_t)std::max<int64_t>(tb->nrows_build, 1) + 1) * 8;
+        tb->zero_rows = table_alloc(ctx, tb, bytes);
+        if (!tb->zero_rows) return fail(ctx, SDQH_ERR_NOMEM, "table_columns: out of device memory");
+        HIP_TRY(ctx, hipMemsetAsync(tb->zero_rows, 0, bytes, ctx->stream));
+    }
+    if (int rc = run_compact(ctx, tb, min_hits)) return rc;
+    *n = tb->compact_n;
+    return SDQH_OK;
+}
+}  // namespace sdqh_host
+extern "C" {
+
 int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_hits, int64_t capacity,
                        int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n) {
     sdqh_table* table = const_cast<sdqh_table*>(ctable);

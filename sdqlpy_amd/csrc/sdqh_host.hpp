@@ -144,6 +144,7 @@ struct sdqh_column {
     void* dict = nullptr;              // device: ndict raw 8-byte values (int64, or the bits of the doubles), ascending
     int ndict = 0;
     std::vector<int64_t> dict_host;    // the same on the host (bounds of comparisons are translated into code space at launch)
+    bool transient = false;            // a view of a table's K-F buffers (sdqh_table_columns): lives for one run — no twins, no statistics gathered for it
     size_t row_bytes() const { return dtype == SDQH_STR ? (size_t)width * 4 : 8; }
 };
 
@@ -167,6 +168,7 @@ struct sdqh_table {
     int64_t compact_min_hits = 0, compact_n = 0;
     DevCompactOut compact{};
     uint32_t* seg_kept = nullptr;
+    void* zero_rows = nullptr;                     // nrows_build + 1 zeroed 8-byte rows: the accumulator columns a table does not have (sdqh_table_columns)
     int nv = SDQH_TUPLE_MAX_VALUES;    // value count of the tuple aggregated into the table
     uint32_t* coarse = nullptr; int coarse_words = 0, coarse_shift = 0;     // coarse key filter (see DevLookups), built on first need
 };
@@ -187,6 +189,8 @@ void tb_release(sdqh_ctx* ctx, sdqh_table* t);
 // stage arrays of a build whose key / payload the kernel computes itself (no source columns)
 int stage_setup_computed(sdqh_ctx* ctx, sdqh_table* tb, int64_t nrows, int npay, int batch);
 int index_ensure(sdqh_ctx* ctx, sdqh_table* tb);
+// K-F into the table's own device buffers (tb->compact; rows in build-row order), *n = the number of entries kept; zero_rows made on request
+int table_compact_resident(sdqh_ctx* ctx, sdqh_table* tb, int64_t min_hits, bool want_zero_rows, int64_t* n);
 int column_minmax(sdqh_ctx* ctx, sdqh_column* c);
 bool column_increasing(sdqh_ctx* ctx, sdqh_column* c);          // strictly increasing I64 column?  (one pass the first time, cached)
 const void* column_narrow(sdqh_ctx* ctx, sdqh_column* c);      // the exact 4-byte twin of a streamed column (built on first request), or nullptr

@@ -141,6 +141,7 @@ int analyse(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* p, int max_vals, b
             case SDQH_X_NEG: rc = need((ty(o.a) == SDQH_T_I64 || ty(o.a) == SDQH_T_F64) && o.type == ty(o.a), "NEG operand"); break;
             case SDQH_X_I2F: rc = need(ty(o.a) == SDQH_T_I64 && o.type == SDQH_T_F64, "I2F operand"); break;
             case SDQH_X_YEAR: rc = need(ty(o.a) == SDQH_T_I64 && o.type == SDQH_T_I64, "YEAR operand"); break;
+            case SDQH_X_DIVI: case SDQH_X_MODI: rc = need(ty(o.a) == SDQH_T_I64 && o.type == SDQH_T_I64 && o.imm_i > 0, "DIVI / MODI need an i64 operand and a positive divisor"); break;
             case SDQH_X_PACK2: rc = need(ty(o.a) == SDQH_T_I64 && ty(o.b) == SDQH_T_I64 && o.type == SDQH_T_I64, "PACK2 operands"); break;
             case SDQH_X_LT: case SDQH_X_LE: case SDQH_X_GT: case SDQH_X_GE: case SDQH_X_EQ: case SDQH_X_NE:
                 rc = need(ty(o.a) == ty(o.b) && (ty(o.a) == SDQH_T_I64 || ty(o.a) == SDQH_T_F64 || (ty(o.a) == SDQH_T_BOOL && (o.code == SDQH_X_EQ || o.code == SDQH_X_NE))) && o.type == SDQH_T_BOOL,
@@ -254,7 +255,7 @@ bool op_interval(sdqh_ctx* ctx, const XInfo& x, int k, int64_t* lo, int64_t* hi)
         case SDQH_X_COL: {
             sdqh_column* c = const_cast<sdqh_column*>(o.col);
             if (x.fake) { if (c->dtype != SDQH_I64) return false; *lo = 0; *hi = 3; return true; }
-            if (c->dtype != SDQH_I64 || c->nrows < 1) return false;
+            if (c->dtype != SDQH_I64 || c->nrows < 1 || c->transient) return false;
             if (c->code_state == 1 && !c->dict_host.empty()) { *lo = c->dict_host.front(); *hi = c->dict_host.back(); return true; }
             if (column_minmax(ctx, c)) return false;
             *lo = c->mn; *hi = c->mx; return true;
@@ -274,6 +275,8 @@ bool op_interval(sdqh_ctx* ctx, const XInfo& x, int k, int64_t* lo, int64_t* hi)
         }
         case SDQH_X_NEG: if (!op_interval(ctx, x, o.a, &al, &ah)) return false; *lo = -ah; *hi = -al; return true;
         case SDQH_X_YEAR: if (!op_interval(ctx, x, o.a, &al, &ah) || al < 0) return false; *lo = al / 10000; *hi = ah / 10000; return true;
+        case SDQH_X_DIVI: if (!op_interval(ctx, x, o.a, &al, &ah) || al < 0) return false; *lo = al / o.imm_i; *hi = ah / o.imm_i; return true;
+        case SDQH_X_MODI: if (!op_interval(ctx, x, o.a, &al, &ah) || al < 0) return false; *lo = 0; *hi = std::min<int64_t>(ah, o.imm_i - 1); return true;
         case SDQH_X_SELECT:
             if (!op_interval(ctx, x, o.b, &al, &ah) || !op_interval(ctx, x, o.c, &bl, &bh)) return false;
             *lo = std::min(al, bl); *hi = std::max(ah, bh); return true;
@@ -556,6 +559,8 @@ struct Gen {
             case SDQH_X_NEG: emit(o.a); e = "(-" + v(o.a) + ")"; break;
             case SDQH_X_I2F: emit(o.a); e = "(double)" + v(o.a); break;
             case SDQH_X_YEAR: emit(o.a); e = "(" + v(o.a) + " / 10000)"; break;
+            case SDQH_X_DIVI: case SDQH_X_MODI:                             // the divisor is a literal: the compiler turns it into a multiply / a mask
+                emit(o.a); e = "(" + v(o.a) + (o.code == SDQH_X_DIVI ? " / " : " % ") + "(int64_t)" + std::to_string((long long)o.imm_i) + "ll)"; break;
             case SDQH_X_PACK2:
                 emit(o.a); emit(o.b);
                 os << "        const bool b" << K << " = " << bad(o.a) << " || " << bad(o.b) << " || " << v(o.a) << " < 0 || " << v(o.a) << " > 0xFFFFFFFFll || " << v(o.b) << " < 0 || " << v(o.b) << " > 0xFFFFFFFFll;\n";
@@ -995,6 +1000,7 @@ uint64_t structure_hash(const XInfo& x, Sink sink, bool direct) {
         const sdqh_xop& o = p->ops[k];
         mix(((uint64_t)(uint32_t)o.code << 32) | (uint32_t)o.type); mix(((uint64_t)(uint32_t)o.a << 32) | (uint32_t)o.b); mix(((uint64_t)(uint32_t)o.c << 32) | (uint32_t)o.aux);
         mix(((uint64_t)(uint32_t)x.col_of[k] << 32) | (uint32_t)x.tab_of[k]); mix(((uint64_t)(uint32_t)x.const_of[k] << 32) | (uint32_t)x.str_off[k]);
+        if (o.code == SDQH_X_DIVI || o.code == SDQH_X_MODI) mix((uint64_t)o.imm_i);
         if (o.code == SDQH_X_STR || o.code == SDQH_X_STRIDX) { mix((uint64_t)o.slen); for (int i = 0; i < o.slen; ++i) mix(o.str[i]); }
         if (o.code == SDQH_X_STR || o.code == SDQH_X_STRIDX || o.code == SDQH_X_CHAR) mix((uint64_t)(o.col ? o.col->width : 0));      // the staged field width is a compile-time constant
     }
@@ -1391,22 +1397,24 @@ int sdqh_xprobe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog
 
 int sdqh_table_columns(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_hits, sdqh_column** out_cols, int64_t* out_rows) {
     if (!ctx || !ctable || !out_cols || !out_rows || ctable->bitmap_only) return fail(ctx, SDQH_ERR_INVALID, "table_columns: bad arguments");
-    // O(entries), like K-F itself: compacted through the K-F path, then made resident again
+    // O(entries), like K-F itself, and all on the device: the table's own K-F buffers (build-row order) ARE the columns — the
+    // only host round trip is the row count.  The columns are views: valid until the table is released or compacted again.
+    sdqh_table* table = const_cast<sdqh_table*>(ctable);
+    const int npay = table->npay, ncols = 1 + npay + SDQH_TUPLE_MAX_VALUES + 1, nval = table->accumulate ? table->nv : 0;
     int64_t n = 0;
-    if (int rc = sdqh_table_compact(ctx, ctable, min_hits, 0, nullptr, nullptr, nullptr, nullptr, &n)) return rc;
-    const int npay = ctable->npay, ncols = 1 + npay + SDQH_TUPLE_MAX_VALUES + 1;
-    const size_t cap = (size_t)std::max<int64_t>(n, 1);
-    std::vector<int64_t> keys(cap), pay(cap * (size_t)std::max(npay, 1)), hits(cap);
-    std::vector<double> vals(cap * SDQH_TUPLE_MAX_VALUES, 0.0);
-    int64_t got = 0;
-    if (int rc = sdqh_table_compact(ctx, ctable, min_hits, (int64_t)cap, keys.data(), npay ? pay.data() : nullptr, ctable->accumulate ? vals.data() : nullptr, hits.data(), &got)) return rc;
+    if (int rc = table_compact_resident(ctx, table, min_hits, nval < SDQH_TUPLE_MAX_VALUES, &n)) return rc;
+    const DevCompactOut& o = table->compact;
     for (int c = 0; c < ncols; ++c) {
-        const bool is_acc = c > npay && c <= npay + SDQH_TUPLE_MAX_VALUES;
-        const void* src = c == 0 ? (const void*)keys.data() : c <= npay ? (const void*)(pay.data() + (size_t)(c - 1) * cap)
-                          : is_acc ? (const void*)(vals.data() + (size_t)(c - 1 - npay) * cap) : (const void*)hits.data();
-        if (int rc = sdqh_column_upload(ctx, src, got, is_acc ? SDQH_F64 : SDQH_I64, 0, &out_cols[c])) return rc;
+        const int acc = c - 1 - npay;
+        const bool is_acc = acc >= 0 && acc < SDQH_TUPLE_MAX_VALUES;
+        void* src = c == 0 ? (void*)o.keys : c <= npay ? (void*)o.pay[c - 1] : is_acc ? (acc < nval ? (void*)o.val[acc] : table->zero_rows) : (void*)o.hits;
+        sdqh_column* col = new (std::nothrow) sdqh_column();
+        if (!col) { for (int j = 0; j < c; ++j) { delete out_cols[j]; out_cols[j] = nullptr; } return fail(ctx, SDQH_ERR_NOMEM, "table_columns: out of host memory"); }
+        col->data = src; col->nrows = n; col->dtype = is_acc ? SDQH_F64 : SDQH_I64; col->owned = false; col->transient = true;
+        col->narrow_state = 0; col->code_state = 0; col->clustered = 0; col->increasing = 0;
+        out_cols[c] = col;
     }
-    *out_rows = got;
+    *out_rows = n;
     return SDQH_OK;
 }
 

@@ -98,6 +98,7 @@ class Engine:
         # x_tight), which the fixed-shape kernels' 4-byte twins cannot.  The HIP library only: the CPU implementation interprets programs.
         # K-F rows of a query's RESULT reach the host behind the call (sdqh_table_compact_async); the ResultSet waits on first read
         self.lazy_results = os.environ.get("SDQLPY_AMD_LAZY_RESULTS", "1") != "0"
+        self.dict_programs = os.environ.get("SDQLPY_AMD_DICT_PROGRAMS", "1") != "0"      # sums over result dictionaries as device loops (xplan.prepare_dict_scan)
         self.stream_programs = os.environ.get("SDQLPY_AMD_STREAM_PROGRAMS", "1") != "0" and ctx.library.backend_name() == "hip-gfx950"
         # ... and so do the loops that aggregate into the entry a probe matches ("probe": Q3's lineitem loop — the specialised kernel
         # streams the key through its 4-byte twin and the date as a 2-byte code, tests the key bitmap in 32-bit arithmetic) and, on
@@ -912,12 +913,15 @@ def _prepare_scan(eng, op, htab, accumulate_into, member_only=False, as_table=Fa
     routed = False
     if not _no_stream and getattr(eng, "program_routes", None):
         if op.kind == "dict" and not op.unique and op.probe is not None and op.probe.dict_name in accumulate_into:
-            routed = "probe" in eng.program_routes
+            # (a group named by fields of the matched entry only — Q10: customer fields of an order — stays with the fixed call, which
+            # folds the entries that share those fields on the device: sdqh_table_share_groups)
+            kfs = op.key.fields if isinstance(op.key, RecordCons) else [(None, op.key)]
+            routed = "probe" in eng.program_routes and isinstance(op.probe.key, Col) and any(isinstance(e, Col) and e.name == op.probe.key.name for _, e in kfs)
         elif op.kind == "dict" and op.unique:
             routed = "build" in eng.program_routes or ("values" in eng.program_routes and not member_only and htab.nrows >= (1 << 20) and _plain_values_build(op, htab))
     if routed or (getattr(eng, "stream_programs", False) and not _no_stream and not as_table and not member_only and _is_stream_loop(op)):
         try:
-            x = xplan.prepare_scan(eng, op, htab, accumulate_into, member_only, as_table)
+            x = xplan.prepare_scan(eng, op, htab, accumulate_into, member_only, as_table, small_groups_only=not routed)
         except UnsupportedQuery:
             x = None
         if x is not None:
@@ -1493,6 +1497,29 @@ def _host_dict(eng, op, env, is_result):
     return out
 
 
+def _prepare_dict_loop(eng, op, is_result, as_table):
+    """closure(env) for a sum over a result dictionary: a device loop over the dictionary's entries where the loop has a
+    shape for it (xplan.prepare_dict_scan), the host evaluation over the materialised dictionaries otherwise."""
+    from . import xplan
+    state = {"dev": None}
+    if getattr(eng, "dict_programs", True):
+        try:
+            state["dev"] = xplan.prepare_dict_scan(eng, op, as_table)
+        except UnsupportedQuery:
+            pass
+
+    def run(env):
+        if state["dev"] is not None:
+            try:
+                out = state["dev"](env)
+                if out is not NotImplemented:
+                    return out
+            except UnsupportedQuery:                                # known once the source's layout is: the host path from now on
+                state["dev"] = None
+        return _host_dict(eng, op, env, is_result)
+    return run
+
+
 def _membership_only(plan):
     """Names of unique builds that are only used as `tbl[key] != None` / joinProbe index with no
     payload access, and are not the plan's result."""
@@ -1618,7 +1645,7 @@ class PreparedPlan:
                 is_result = op.out == plan.result
                 self.steps.append((op.out, (lambda env, op=op, is_result=is_result: _finalize(eng, op, env, env.get("__top__") if is_result else None))))
             elif isinstance(op, HostDictOp):
-                self.steps.append((op.out, (lambda env, op=op: _host_dict(eng, op, env, op.out == plan.result))))
+                self.steps.append((op.out, _prepare_dict_loop(eng, op, op.out == plan.result, op.out in looked_up)))
             elif isinstance(op, WrapScalarOp):
                 self.steps.append((op.out, (lambda env, op=op: ResultSet([n for n, _ in op.fields], [np.array([_eval_scalar_expr(e, env, op.lineno)]) for _, e in op.fields]))))
 

@@ -52,6 +52,7 @@ class Compiler:
         self.lookups = {}           # repr(Lookup) -> (operation index, dict name, BuiltTable)
         self.scalars = []           # (CONST operation index, ScalarField): rebound on every run
         self.layout = []            # what the program assumed about the tables it reads: [(dict name, signature)]
+        self.entry_cols = []        # (COL operation index, which column of the scanned dictionary's entries): rebound on every run (DictTable)
 
     def fail(self, why):
         raise UnsupportedQuery("line %d: %s" % (self.op.lineno, why))
@@ -193,6 +194,10 @@ class Compiler:
             return self.const(e.value)
         if isinstance(e, Col):
             return self.column(e.name)
+        if isinstance(e, WholeKey):
+            if not isinstance(self.htab, DictTable):
+                self.fail("p[0] / p[1] outside a sum over a dictionary")
+            return self.htab.whole(self, e)
         if isinstance(e, ScalarField):
             x = XV(self.P.op(abi.X_CONST, abi.T_F64, imm_f=0.0), "f")       # its own operation: rebound on every run
             self.scalars.append((x.id, e))
@@ -404,6 +409,8 @@ class Compiler:
         for oid, sf in self.scalars:
             v = env[sf.name]
             self.P.set_const(oid, float(v if sf.field is None else v[sf.field]))
+        for oid, which in self.entry_cols:
+            self.P.bind_col(oid, self.htab.columns[which])
 
     def still_valid(self, env):
         for name, sig in self.layout:
@@ -432,7 +439,8 @@ def _slot_range(bt, slot):
 def _table_signature(bt):
     return (tuple(bt.val_fields), tuple(str(np.dtype(d)) for d in bt.payload_dtypes), bt.key_parts is not None,
             tuple(sorted((k, id(v)) for k, v in bt.decoders.items())), tuple(sorted((k, id(v)) for k, v in bt.field_decoders.items())),
-            None if bt.agg is None else (tuple(bt.agg[1]), bt.agg[2], bt.agg[5]), bt.table.npayload, bool(bt.table.accumulate))
+            None if bt.agg is None else (tuple(bt.agg[1]), bt.agg[2], bt.agg[5]), bt.table.npayload, bool(bt.table.accumulate),
+            None if getattr(bt, "key_radix", None) is None else tuple(bt.key_radix[1]))
 
 
 def _decode_radix(keys, parts, radix):
@@ -475,10 +483,12 @@ def groups_by_entry(op):
 
 
 # =================================================================================================
-def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
-    """closure(env) for one table loop, through row programs."""
+def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False, small_groups_only=False):
+    """closure(env) for one table loop, through row programs.
+    small_groups_only: an aggregation whose groups do not fit the group-by sinks is refused (UnsupportedQuery) instead of being
+    run as build + probe-aggregate — the caller has a better plan for a large group domain (engine.py: the fixed group-by-key call)."""
     from .engine import BuiltTable
-    ctx, n = eng.ctx, htab.nrows
+    ctx = eng.ctx                                    # (the row count is read when a loop runs: the entries of a dictionary differ from run to run)
     state = {}
 
     def value_fields(val):
@@ -556,7 +566,7 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
                 st = state["c"] = compile_scalar(env)
             c, names, vals, counts = st
             c.bind(env)
-            sums, cnt = ctx.xscan_sum(n, c.P)
+            sums, cnt = ctx.xscan_sum(htab.nrows, c.P)
             it = iter(sums.tolist())
             out = [float(cnt) * k if v is None else next(it) for v, k in zip(vals, counts)]
             return out[0] if op.kind == "scalar" else dict(zip(names, out))
@@ -633,18 +643,18 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
             c, key_names, bounds, val_fields, dtypes, decoders, key_dec, composite = st
             c.bind(env)
             table = None
-            dense = bounds[0] <= bounds[1] and bounds[1] - bounds[0] + 1 <= (1 << 31) and bounds[1] - bounds[0] + 1 <= 64 * max(n, 1024)
+            dense = bounds[0] <= bounds[1] and bounds[1] - bounds[0] + 1 <= (1 << 31) and bounds[1] - bounds[0] + 1 <= 64 * max(htab.nrows, 1024)
             if member_only and not c.P.vals and not accumulate and dense:
-                table = ctx.xkey_set(n, c.P, bounds[0], bounds[1])
+                table = ctx.xkey_set(htab.nrows, c.P, bounds[0], bounds[1])
             if table is None and not c.P.gates and c.P.vals and not accumulate and not composite:
                 # every row, keyed by an integer column, payload = integer columns as they are (dictionary codes included): the
                 # fixed build keeps such columns in place (no staging; increasing keys: rank = row) — Q12's 15 M orders 0.74 -> 0.15 ms
                 ops = c.P.ops
                 cols = [ops[i]["col"] if ops[i]["code"] == abi.X_COL and ops[i]["type"] == abi.T_I64 else None for i in [c.P.key] + list(c.P.vals)]
                 if all(col is not None for col in cols):
-                    table = ctx.hash_build_unique(n, abi.make_filter(), [], cols[0], cols[1:])
+                    table = ctx.hash_build_unique(htab.nrows, abi.make_filter(), [], cols[0], cols[1:])
             if table is None:
-                table = ctx.xbuild(n, c.P, bounds[0], bounds[1], accumulate=accumulate, nsums=accumulate_into.get(op.out) if accumulate and isinstance(accumulate_into, dict) else None)
+                table = ctx.xbuild(htab.nrows, c.P, bounds[0], bounds[1], accumulate=accumulate, nsums=accumulate_into.get(op.out) if accumulate and isinstance(accumulate_into, dict) else None)
             bt = BuiltTable(table, key_names[0], key_is_record, val_fields, val_is_record, dtypes)
             bt.decoders, bt.field_decoders, bt.slot_rng = dict(decoders[0]), dict(decoders[1]), dict(decoders[2])
             if composite:
@@ -750,7 +760,7 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
                         bt.agg_fields[fname or e.field] = e.field
                 bt.agg_spec = spec
             c.bind(env)
-            ctx.xprobe_aggregate(n, c.P, probe_id, bt.table)
+            ctx.xprobe_aggregate(htab.nrows, c.P, probe_id, bt.table)
             bt.agg = (bt.agg_spec, vnames, count_idx, key_is_record, val_is_record, len(c.P.vals))
             bt.int_values = frozenset(state.get("int_values", ()))
             return ("aggregated", op.probe.dict_name)
@@ -761,7 +771,7 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
                     st = state["c"] = compile_groups(env)
                 c, parts, radix, count_idx = st
                 c.bind(env)
-                keys, vals, cnts = ctx.xgroupby(n, c.P)
+                keys, vals, cnts = ctx.xgroupby(htab.nrows, c.P)
                 # the same handful of group keys comes back run after run: their decoded fields are kept (a dozen small numpy calls otherwise)
                 kcache = state.get("kf_cache")
                 kbytes = keys.tobytes()
@@ -785,10 +795,12 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
             except abi.SdqhError as exc:
                 if exc.code != abi.ERR_OVERFLOW:
                     raise
+                if small_groups_only:
+                    raise UnsupportedQuery("line %d: more groups than the group-by sinks of a row program hold" % op.lineno)
                 state["mode"], state["c"] = ("entry" if state.get("entry_ok") else "large"), None      # more groups than the LDS table holds
                 return run_aggregate(env)
             except UnsupportedQuery:
-                if state.get("c") is not None:
+                if state.get("c") is not None or small_groups_only:
                     raise
                 state["mode"] = "entry" if state.get("entry_ok") else "large"
                 return run_aggregate(env)
@@ -798,14 +810,14 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
             state["look"] = None
         cb, cp, pkid, count_idx, bounds, key_names, key_dec, composite = st
         cb.bind(env); cp.bind(env)
-        table = ctx.xbuild(n, cb.P, bounds[0], bounds[1], accumulate=True)
+        table = ctx.xbuild(htab.nrows, cb.P, bounds[0], bounds[1], accumulate=True)
         look = state.get("look")
         if look is None:
             look = state["look"] = cp.P.op(abi.X_LOOKUP, abi.T_BOOL, a=pkid, table=table)
             cp.P.gates = list(cp.P.gates) + [look]
         else:
             cp.P.bind_table(look, table)
-        ctx.xprobe_aggregate(n, cp.P, look, table)
+        ctx.xprobe_aggregate(htab.nrows, cp.P, look, table)
         vals = cp.P.vals
         bt = BuiltTable(table, key_names[0], key_is_record, [], val_is_record, [])
         if composite:
@@ -823,6 +835,165 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False):
 
 def _is_key_set(bt):
     return bt.table.npayload == 0 and not bt.table.accumulate
+
+
+# =================================================================================================
+# Sums over RESULT dictionaries (frontend.HostDictOp) on the device.  The reference compiles such a loop like any
+# other (lib/sdql_ir_cpp_generator_par.py:520-568: iteration over a dictionary that is not a database table); here the
+# entries of the source dictionary become resident columns (sdqh_table_columns: the table's own K-F buffers, build-row
+# order) and the loop body a row program over them — p[0] / p[1] read those columns, a key of several packed fields is
+# unpacked with DIVI / MODI.  What this cannot express falls back to run_host_dict below.
+# =================================================================================================
+class DictTable:
+    """The entries of a device-resident dictionary, presented as the table a loop scans."""
+
+    def __init__(self, eng, op):
+        self.eng, self.op = eng, op
+        self.nrows, self.cols = 0, {}            # (no host columns: prepare_scan looks text payload columns up here)
+        self.bt, self.columns = None, None
+
+    def array(self, name, op):
+        raise UnsupportedQuery("line %d: a sum over a dictionary has no column '%s'" % (op.lineno, name))
+
+    def source(self, env):
+        src = env[self.op.source]
+        if isinstance(src, tuple) and src and src[0] == "aggregated":
+            bt = env[src[1]]
+            if not (any(s == "key" for _, s in bt.agg[0]) or bt.shared_groups):
+                raise UnsupportedQuery("line %d: the entries of '%s' are not its groups yet" % (self.op.lineno, self.op.source))
+            return bt, 1
+        if hasattr(src, "table") and hasattr(src, "val_fields"):
+            return src, 0
+        raise UnsupportedQuery("line %d: '%s' is not resident on the device" % (self.op.lineno, self.op.source))
+
+    def load(self, env):
+        """The entries as columns; every run (the dictionary was rebuilt)."""
+        bt, min_hits = self.source(env)
+        key, pays, accs, hits, n = self.eng.ctx.table_columns(bt.table, min_hits)
+        cols = {"key": key, "hits": hits}
+        cols.update({("pay", i): c for i, c in enumerate(pays)})
+        cols.update({("acc", i): c for i, c in enumerate(accs)})
+        self.bt, self.columns, self.nrows = bt, cols, n
+
+    def release(self):
+        self.columns = None                      # (views of the table's buffers: nothing to free but the handles)
+
+    # -- p[0] / p[1] ----------------------------------------------------------------------------------
+    def col(self, c, which, typ):
+        key = ("entrycol", which)
+        if key not in c.memo:
+            c.memo[key] = c.P.op(abi.X_COL, typ, col=self.columns[which])
+            c.entry_cols.append((c.memo[key], which))
+        return c.memo[key]
+
+    def fields(self, c):
+        """{side: [(field name, XV)]} of the entries, compiled on first use per program."""
+        if "entryfields" in c.memo:
+            return c.memo["entryfields"]
+        bt, op = self.bt, self.op
+        name = op.source
+        c.layout.append((name, _table_signature(bt)))
+
+        def text_ok(dec):
+            # two entries must never stand for the same key: references into a raw text column may (equal texts in
+            # different rows), codes of a dictionary with distinct entries cannot
+            if dec is not None and not isinstance(dec, Dictionary):
+                raise UnsupportedQuery("line %d: '%s' is keyed by row references into a text column" % (op.lineno, name))
+            return dec
+
+        def payload(fname, slot):
+            if np.dtype(bt.payload_dtypes[slot]).kind == "f":
+                raise UnsupportedQuery("line %d: a floating-point entry field of '%s'" % (op.lineno, name))
+            dec = bt.decoder_of(fname, slot)
+            rng = (0, len(dec) - 1) if dec is not None else _slot_range(bt, slot)
+            return XV(self.col(c, ("pay", slot), abi.T_I64), "i", dec=dec, rng=rng)
+
+        keyv = XV(self.col(c, "key", abi.T_I64), "i")
+        kf, vf = [], []
+        if bt.agg is not None:
+            spec, vnames, count_idx, _, _, nv = bt.agg
+        else:
+            spec, vnames, count_idx, nv = [(bt.key_name, "key")], [], None, 0
+        if getattr(bt, "key_radix", None) is not None and spec == [(bt.key_name, "key")]:
+            parts, radix = bt.key_radix                          # one mixed-radix integer: field i = (key / stride_i) % span_i + lo_i
+            strides, stride = [], 1
+            for lo, span in reversed(radix):
+                strides.append(stride)
+                stride *= span if span is not None else 1
+            strides.reverse()
+            at = 0
+            for pname, vs, kind in parts:
+                if kind[0] != "int" or len(vs) != 1:
+                    raise UnsupportedQuery("line %d: '%s' has a substring in its key" % (op.lineno, name))
+                (lo, span), st = radix[at], strides[at]
+                at += 1
+                vid = keyv.id
+                if st > 1:
+                    vid = c.P.op(abi.X_DIVI, abi.T_I64, a=vid, imm_i=st)
+                if span is not None and at > 1:                  # (the leading field needs no remainder)
+                    vid = c.P.op(abi.X_MODI, abi.T_I64, a=vid, imm_i=span)
+                if lo != 0:
+                    vid = c.P.op(abi.X_ADD, abi.T_I64, a=vid, b=c.const(lo).id)
+                kf.append((pname, XV(vid, "i", dec=text_ok(kind[1]), rng=None if span is None else (lo, lo + span - 1))))
+        elif bt.key_parts is not None and spec == [(bt.key_name, "key")]:
+            decs = getattr(bt, "key_part_decoders", None) or [None, None]
+            hi = c.P.op(abi.X_DIVI, abi.T_I64, a=keyv.id, imm_i=1 << 32)
+            lo = c.P.op(abi.X_MODI, abi.T_I64, a=keyv.id, imm_i=1 << 32)
+            kf = [(bt.key_parts[0], XV(hi, "i", dec=text_ok(decs[0]), rng=(0, 0xFFFFFFFF))), (bt.key_parts[1], XV(lo, "i", dec=text_ok(decs[1]), rng=(0, 0xFFFFFFFF)))]
+        else:
+            for fname, src in spec:
+                if src == "key":
+                    keyv.dec = text_ok(bt.key_decoder) if bt.agg is None else None
+                    kf.append((fname, keyv))
+                else:
+                    v = payload(bt.agg_fields.get(fname, fname) if bt.agg is not None else fname, src)
+                    text_ok(v.dec)
+                    kf.append((fname, v))
+        if bt.agg is not None:
+            for i, vname in enumerate(vnames):
+                if count_idx is not None and i == count_idx:
+                    vf.append((vname, XV(self.col(c, "hits", abi.T_I64), "i")))
+                else:
+                    k = i - (1 if count_idx is not None and count_idx < i else 0)
+                    vf.append((vname, XV(self.col(c, ("acc", k), abi.T_F64), "f")))
+        else:
+            for fname, src in bt.val_fields:
+                vf.append((fname, keyv if src == "key" else payload(fname, src)))
+        c.memo["entryfields"] = {0: kf, 1: vf}
+        return c.memo["entryfields"]
+
+    def whole(self, c, e):
+        side = self.fields(c)[e.which]
+        if e.field is None:
+            if len(side) != 1:
+                raise UnsupportedQuery("line %d: p[%d] is a record; name a field" % (self.op.lineno, e.which))
+            return side[0][1]
+        for nm, v in side:
+            if nm == e.field:
+                return v
+        raise UnsupportedQuery("line %d: p[%d] has no field '%s'" % (self.op.lineno, e.which, e.field))
+
+
+def prepare_dict_scan(eng, op, as_table=False):
+    """closure(env) for a HostDictOp as a device loop, or None when its shape is not one a loop has (the closure can
+    still raise UnsupportedQuery on its first run, when the source's layout is known: the caller keeps the host path)."""
+    from .frontend import ScanOp
+    if op.unique or isinstance(op.val, Const) and op.val.value is True:
+        return None                                              # a set of records / first-wins: result shaping, host side
+    scan = ScanOp(op.out, op.source, op.lineno)
+    scan.kind, scan.conds, scan.key, scan.val, scan.unique = "dict", list(op.conds), op.key, op.val, False
+    dtab = DictTable(eng, op)
+    run = prepare_scan(eng, scan, dtab, {}, False, as_table)
+
+    def run_dict_scan(env):
+        dtab.load(env)
+        try:
+            if dtab.nrows == 0:
+                return NotImplemented                            # nothing to launch: the host path shapes the empty result of this run
+            return run(env)
+        finally:
+            dtab.release()
+    return run_dict_scan
 
 
 # =================================================================================================

@@ -359,6 +359,27 @@ def xprogram_cases(ctx, n=20000, seed=3):
     assert cnt == len(want); near(vals[0], float(sum(want)), "x6 acc read")
     checks += 3 + nent
 
+    # 6b. a loop over the ENTRIES (sdqh_table_columns as the scanned table): the key unpacked with DIVI / MODI, the entry's sum and
+    # row count as values — a sum over a result dictionary (generator 520-568) as a row program
+    P = A.Program()
+    kk = P.op(A.X_COL, A.T_I64, col=kcol)
+    part_hi = P.op(A.X_DIVI, A.T_I64, a=kk, imm_i=97)
+    part_lo = P.op(A.X_MODI, A.T_I64, a=kk, imm_i=7)
+    P.key = P.op(A.X_ADD, A.T_I64, a=P.op(A.X_MUL, A.T_I64, a=P.op(A.X_MODI, A.T_I64, a=part_hi, imm_i=5), b=P.op(A.X_CONST, A.T_I64, imm_i=7)), b=part_lo)
+    P.gates = [P.op(A.X_GE, A.T_BOOL, a=P.op(A.X_COL, A.T_I64, col=hcol), b=P.op(A.X_CONST, A.T_I64, imm_i=1))]
+    P.vals = [P.op(A.X_COL, A.T_F64, col=acols[0]), P.op(A.X_I2F, A.T_F64, a=P.op(A.X_COL, A.T_I64, col=hcol))]
+    gk, gv, gc = ctx.xgroupby(nent, P)
+    want_g = {}
+    for x in acc_sum:
+        g7 = ((x // 97) % 5) * 7 + x % 7
+        w = want_g.setdefault(g7, [0.0, 0, 0])
+        w[0] += acc_sum[x]; w[1] += acc_cnt[x]; w[2] += 1
+    assert sorted(gk.tolist()) == sorted(want_g)
+    for g7, row, c in zip(gk.tolist(), gv.tolist(), gc.tolist()):
+        near(row[0], want_g[g7][0], "x6b sum"); assert row[1] == want_g[g7][1] and c == want_g[g7][2]
+    del kcol, pcols, acols, hcol
+    checks += 1 + len(want_g)
+
     # 7. K-C small with lookups (queue path): group by a field of the matched entry's payload (mod 7) and the year
     P = A.Program()
     lk = P.op(A.X_LOOKUP, A.T_BOOL, a=P.op(A.X_COL, A.T_I64, col=cpr), table=t_direct)

@@ -1315,8 +1315,19 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
         }
         call_end(ctx);
         int f = 0;
-        const int kc = prog->ops[prog->key].code;
-        const bool can_fail = bounded || kc == SDQH_X_PACK2 || kc == SDQH_X_SELECT;      // otherwise nothing can raise a flag: no round trip
+        // Can the kernel raise a flag at all (a key outside the bounds, a key part that does not pack)?  Not when the key's own
+        // interval — from the minima / maxima of the columns it is computed from — lies inside: then there is nothing to read back,
+        // and the host does not stand between this build and the next launch (30-40 us of an idle device in the middle of Q3).
+        const sdqh_xop& ko = prog->ops[prog->key];
+        bool can_fail = bounded || ko.code == SDQH_X_PACK2 || ko.code == SDQH_X_SELECT;
+        if (!rc && can_fail && ko.code != SDQH_X_SELECT) {
+            int64_t lo = 0, hi = -1, alo = 0, ahi = -1, blo = 0, bhi = -1;
+            const bool packs = ko.code != SDQH_X_PACK2 || (op_interval(ctx, x, ko.a, &alo, &ahi) && op_interval(ctx, x, ko.b, &blo, &bhi) &&
+                                                           alo >= 0 && ahi <= 0xFFFFFFFFll && blo >= 0 && bhi <= 0xFFFFFFFFll);
+            const bool inside = !bounded || (ko.code == SDQH_X_PACK2 ? packs && (int64_t)(((uint64_t)alo << 32) | (uint64_t)blo) >= key_lo && (int64_t)(((uint64_t)ahi << 32) | (uint64_t)bhi) <= key_hi
+                                                                      : op_interval(ctx, x, prog->key, &lo, &hi) && lo >= key_lo && hi <= key_hi);
+            if (packs && inside) can_fail = false;
+        }
         if (!rc && can_fail) rc = read_flags(ctx, flags, &f);
         if (!rc && (f & 2)) rc = fail(ctx, SDQH_ERR_UNSUPPORTED, "xbuild: a key outside the given bounds / a key part outside [0, 2^32)");
     }

@@ -1504,7 +1504,7 @@ def _prepare_dict_loop(eng, op, is_result, as_table):
     state = {"dev": None}
     if getattr(eng, "dict_programs", True):
         try:
-            state["dev"] = xplan.prepare_dict_scan(eng, op, as_table)
+            state["dev"] = xplan.prepare_dict_scan(eng, op, as_table, is_result)
         except UnsupportedQuery:
             pass
 
@@ -1512,12 +1512,29 @@ def _prepare_dict_loop(eng, op, is_result, as_table):
         if state["dev"] is not None:
             try:
                 out = state["dev"](env)
+                if isinstance(out, BuiltTable) and getattr(out, "record_order", None) is not None:
+                    return _record_set(eng, op, out, env)
                 if out is not NotImplemented:
                     return out
             except UnsupportedQuery:                                # known once the source's layout is: the host path from now on
                 state["dev"] = None
         return _host_dict(eng, op, env, is_result)
     return run
+
+
+def _record_set(eng, op, bt, env):
+    """The plan's result as a set of records built on the device (xplan.prepare_dict_scan): K-F of the build — the first k rows
+    only when the caller's ORDER BY / LIMIT can be applied on the device — as a ResultSet in the record's field order."""
+    try:
+        top = env.get("__top__")
+        d = _materialize(eng, bt, env, hint_key=(id(op), 1), top=top)
+        cols = dict(d.key_fields); cols.update(dict(d.val_fields))
+        out = ResultSet(list(bt.record_order), [cols[nm] for nm in bt.record_order])
+        if top is not None and not getattr(d, "ordered", False):
+            out = out.top(top[0], top[1])
+        return out
+    finally:
+        bt.table.free()
 
 
 def _membership_only(plan):

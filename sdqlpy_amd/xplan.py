@@ -869,6 +869,8 @@ class DictTable:
     def load(self, env):
         """The entries as columns; every run (the dictionary was rebuilt)."""
         bt, min_hits = self.source(env)
+        if getattr(self, "single_key", False) and (getattr(bt, "key_radix", None) is not None or bt.key_parts is not None or (bt.agg is not None and len(bt.agg[0]) != 1)):
+            raise UnsupportedQuery("line %d: '%s' is keyed by several fields" % (self.op.lineno, self.op.source))
         key, pays, accs, hits, n = self.eng.ctx.table_columns(bt.table, min_hits)
         cols = {"key": key, "hits": hits}
         cols.update({("pay", i): c for i, c in enumerate(pays)})
@@ -974,15 +976,28 @@ class DictTable:
         raise UnsupportedQuery("line %d: p[%d] has no field '%s'" % (self.op.lineno, e.which, e.field))
 
 
-def prepare_dict_scan(eng, op, as_table=False):
+def prepare_dict_scan(eng, op, as_table=False, is_result=False):
     """closure(env) for a HostDictOp as a device loop, or None when its shape is not one a loop has (the closure can
-    still raise UnsupportedQuery on its first run, when the source's layout is known: the caller keeps the host path)."""
+    still raise UnsupportedQuery on its first run, when the source's layout is known: the caller keeps the host path).
+    Two shapes: a group-by over the entries ({key: value}, summed); and — as the plan's result only — a set of records
+    {unique(record(...)): True} one of whose fields is the source's own (single) key: a unique build keyed by it with the
+    other fields as payload, K-F'd (with ORDER BY / LIMIT on the device) by the caller; the BuiltTable carries .record_order."""
     from .frontend import ScanOp
-    if op.unique or isinstance(op.val, Const) and op.val.value is True:
-        return None                                              # a set of records / first-wins: result shaping, host side
     scan = ScanOp(op.out, op.source, op.lineno)
-    scan.kind, scan.conds, scan.key, scan.val, scan.unique = "dict", list(op.conds), op.key, op.val, False
+    record_order = None
+    if op.unique or isinstance(op.val, Const) and op.val.value is True:
+        if not (is_result and isinstance(op.val, Const) and op.val.value is True and isinstance(op.key, RecordCons)):
+            return None
+        own = [(nm, e) for nm, e in op.key.fields if isinstance(e, WholeKey) and e.which == 0]
+        rest = [(nm, e) for nm, e in op.key.fields if not (own and nm == own[0][0])]
+        if not own or not rest:
+            return None
+        scan.kind, scan.conds, scan.key, scan.val, scan.unique = "dict", list(op.conds), RecordCons([own[0]]), RecordCons(rest), True
+        record_order = [nm for nm, _ in op.key.fields]
+    else:
+        scan.kind, scan.conds, scan.key, scan.val, scan.unique = "dict", list(op.conds), op.key, op.val, False
     dtab = DictTable(eng, op)
+    dtab.single_key = record_order is not None                   # (a field of a packed key does not identify the entry)
     run = prepare_scan(eng, scan, dtab, {}, False, as_table)
 
     def run_dict_scan(env):
@@ -990,7 +1005,10 @@ def prepare_dict_scan(eng, op, as_table=False):
         try:
             if dtab.nrows == 0:
                 return NotImplemented                            # nothing to launch: the host path shapes the empty result of this run
-            return run(env)
+            out = run(env)
+            if record_order is not None:
+                out.record_order = record_order
+            return out
         finally:
             dtab.release()
     return run_dict_scan

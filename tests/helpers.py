@@ -942,3 +942,47 @@ def xcode_edge_cases(ctx, n=40000, seed=21):
     for col in dev.values():
         col.free()
     return checks
+
+
+def dict_loop_cases(eng, case, rel=0.0):
+    """Sums over result dictionaries (frontend.HostDictOp) as device loops (xplan.prepare_dict_scan) against the reference's
+    results AND against the host evaluation of the same plans: q16 (group-by over the entries of a dictionary keyed by four
+    packed fields), q15 (a record set with looked-up text fields, with and without ORDER BY / LIMIT), q11 (a condition against a
+    scalar).  Asserts that the entries really were read as resident columns (sdqh_table_columns)."""
+    db = case_db(case)
+    calls = []
+    real = eng.ctx.table_columns
+    eng.ctx.table_columns = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    checked, on_device = 0, {}
+    try:
+        for q in ("q16", "q15", "q11"):
+            want = case["results"].get(q)
+            if want is None:
+                continue
+            for top in (None, Q.TPCH_ORDER[q]):
+                results = {}
+                for mode in (True, False):
+                    eng.dict_programs = mode
+                    before = len(calls)
+                    plan = frontend.lower_function(Q.QUERIES[q])
+                    res = eng_mod.execute_plan(eng, plan, [db[t] for t in Q.QUERY_TABLES[q]], top)
+                    used = len(calls) - before
+                    nonempty = bool(want["rows"])
+                    assert mode or used == 0, (q, used)
+                    if mode and used:                                       # (a source small enough to come back as host groups stays on the host)
+                        on_device[q] = on_device.get(q, 0) + 1
+                    results[mode] = res
+                    if (top is None) != (q == "q15") and nonempty:          # (q15's golden vector is TPCH's top-1 of the set returned here)
+                        check_against_golden(res, want, rel, "dict loop %s/%s" % (case["name"], q))
+                a, b = results[True], results[False]
+                assert a.columns == b.columns, (q, a.columns, b.columns)
+                rows_a = list(zip(*[a.column(c).tolist() for c in a.columns]))
+                rows_b = list(zip(*[b.column(c).tolist() for c in b.columns]))
+                if top is None:
+                    rows_a, rows_b = sorted(rows_a), sorted(rows_b)
+                assert_rows_match(rows_a, rows_b, rel, "dict loop device vs host %s top=%r" % (q, top))
+                checked += 1
+    finally:
+        eng.dict_programs = True
+        eng.ctx.table_columns = real
+    return checked, on_device

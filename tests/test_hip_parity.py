@@ -301,6 +301,35 @@ def test_open_vocabulary_queries_against_the_reference(hip_engine, golden_wide, 
     oracle_engine.clear()
 
 
+def test_sums_over_result_dictionaries_run_as_device_loops(hip_engine, golden_wide, oracle_engine):
+    """frontend.HostDictOp on the device (xplan.prepare_dict_scan: the entries of a table as resident columns — sdqh_table_columns
+    hands out the table's own K-F buffers — packed keys unpacked with DIVI / MODI): q16, q15 (with and without ORDER BY / LIMIT
+    on the device), q11 against the reference's results and against the host evaluation of the same plans; then q16 at SF 1
+    against the CPU implementation, where its source dictionary has some hundred thousand entries."""
+    n, on_device = 0, {}
+    for case in golden_wide["cases"]:
+        k, used = helpers.dict_loop_cases(hip_engine, case, REL)
+        n += k
+        for q, c in used.items():
+            on_device[q] = on_device.get(q, 0) + c
+    assert n >= 12 and all(on_device.get(q, 0) >= 2 for q in ("q16", "q15", "q11")), on_device
+    qs = ("q16", "q15", "q11")
+    db = tpch.generate(1.0, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+    calls = []
+    real = hip_engine.ctx.table_columns
+    hip_engine.ctx.table_columns = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        for q in qs:
+            got, want = helpers.run_query(hip_engine, q, db), helpers.run_query(oracle_engine, q, db)
+            assert want.size() > 0 and calls, q
+            helpers.assert_rows_match(helpers.result_rows(got, want.columns), helpers.result_rows(want, want.columns), REL, "sf1 dict loop/" + q)
+            del calls[:]
+    finally:
+        hip_engine.ctx.table_columns = real
+    hip_engine.clear()
+    oracle_engine.clear()
+
+
 def test_every_golden_vector_through_specialised_kernels(hip_engine, golden, golden_more, golden_wide):
     """All reference results again with every table loop forced through a run-time specialised kernel
     (no ahead-of-time kernel shape): the general path must agree with the tuned one on its home turf."""

@@ -117,3 +117,19 @@ def test_repeated_runs_of_a_prepared_plan_agree_with_the_first(oracle_lib, golde
     finally:
         engine.reset_default_engine()
         sdql_lib._state.update(mode=None)
+
+
+def test_sums_over_result_dictionaries_run_as_device_loops(oracle_lib, golden_wide):
+    """frontend.HostDictOp through xplan.prepare_dict_scan on the CPU implementation of the ABI (sdqh_table_columns, DIVI / MODI in
+    the interpreter): same rows as the host evaluation of the same plans and as the reference (generator 520-568)."""
+    eng = engine.Engine(oracle_lib.context(threads=1))
+    try:
+        n, on_device = 0, {}
+        for case in golden_wide["cases"]:
+            k, used = helpers.dict_loop_cases(eng, case)
+            n += k
+            for q, c in used.items():
+                on_device[q] = on_device.get(q, 0) + c
+        assert n >= 12 and all(on_device.get(q, 0) >= 2 for q in ("q16", "q15", "q11")), on_device
+    finally:
+        eng.close()

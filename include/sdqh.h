@@ -488,7 +488,10 @@ int sdqh_xprobe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog
 /* The entries of a table with at least min_hits rows as resident columns — key, the npayload payload
  * fields, the SDQH_TUPLE_MAX_VALUES accumulators (F64), the hit count — so that a sum over a result
  * dictionary (K-F / HAVING with lookups, ...generator_par.py:520-568) is a scan like any other.
- * out_cols[1 + npayload + SDQH_TUPLE_MAX_VALUES + 1]; tables without accumulators yield zero columns there. */
+ * out_cols[1 + npayload + SDQH_TUPLE_MAX_VALUES + 1]; tables without accumulators yield zero columns there.
+ * The rows are in build-row order.  HIP build: the columns are VIEWS of the table's own K-F buffers (nothing is copied; the
+ * only host round trip is the row count): they stay valid until the table is released or compacted with another min_hits,
+ * and must be freed with sdqh_column_free like any column (which leaves the table's memory alone). */
 int sdqh_table_columns(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, sdqh_column** out_cols, int64_t* out_rows);
 /* HIP build: number of kernels specialised so far in this process / how many of them came from the on-disk
  * cache; CPU build: zeros.  Diagnostics for tests and the bench. */

@@ -105,7 +105,9 @@ struct TableHeader {          // lives in device memory: sized on the device, no
 //
 //   shits[i]    rows aggregated into entry i   (stage-indexed)
 //   sacc[i*4+k] accumulators of entry i        (stage-indexed)
-constexpr int RANK_BLOCK_WORDS = 2048;        // bitmap words per prefix block (one workgroup, 8 words per thread)
+constexpr int RANK_BLOCK_WORDS = 8192;        // bitmap words per prefix block (one workgroup, 32 words per thread): every block claims its base with ONE
+                                              // returning atomic on hdr->distinct, and those serialise on the one address (~20 ns each: 916 blocks of 2048 words
+                                              // over Q3's 60 M-key range were 20 us of a kernel that moves 7.5 MB)
 
 struct DevTable {
     int64_t* keys;
@@ -1439,12 +1441,15 @@ __device__ __forceinline__ void rank_words_body(const uint32_t* __restrict__ bm,
                                                 const uint32_t* __restrict__ seg_count, int nseg, TableHeader* __restrict__ hdr) {
     __shared__ uint32_t s_wave[TPB / WAVE];
     __shared__ uint32_t s_base;
-    constexpr int WPT = RANK_BLOCK_WORDS / TPB;                        // 8 consecutive words per thread
+    constexpr int WPT = RANK_BLOCK_WORDS / TPB;                        // 32 consecutive words per thread
     const uint64_t w0 = (uint64_t)blockIdx.x * RANK_BLOCK_WORDS + (uint64_t)threadIdx.x * WPT;
     uint32_t word[WPT], mine = 0;
     if (w0 + WPT <= nwords) {
-        const uint4 a = *reinterpret_cast<const uint4*>(bm + w0), b = *reinterpret_cast<const uint4*>(bm + w0 + 4);
-        word[0] = a.x; word[1] = a.y; word[2] = a.z; word[3] = a.w; word[4] = b.x; word[5] = b.y; word[6] = b.z; word[7] = b.w;
+#pragma unroll
+        for (int q = 0; q < WPT / 4; ++q) {
+            const uint4 a = *reinterpret_cast<const uint4*>(bm + w0 + 4 * q);
+            word[4 * q] = a.x; word[4 * q + 1] = a.y; word[4 * q + 2] = a.z; word[4 * q + 3] = a.w;
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < WPT; ++j) word[j] = (w0 + j < nwords) ? bm[w0 + j] : 0u;

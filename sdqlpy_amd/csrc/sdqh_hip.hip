@@ -1024,7 +1024,7 @@ static int ensure_index(sdqh_ctx* ctx, sdqh_table* tb) {
             return SDQH_OK;
         }
         LAUNCH(ctx, "k_rank_words", k_rank_words, (unsigned)nblocks, tb->bm, tb->nwords, wprefix, tb->stage.seg_count, tb->stage.nseg, tb->hdr);
-        if (!tb->refs_prefilled) LAUNCH(ctx, "k_fill_refs", k_fill_refs, (unsigned)ctx->num_cu * 2, tb->stage, tb->dev);
+        if (!tb->refs_prefilled && !tb->keys_unique) LAUNCH(ctx, "k_fill_refs", k_fill_refs, (unsigned)ctx->num_cu * 2, tb->stage, tb->dev);
         LAUNCH(ctx, "k_insert_direct", k_insert_direct, seg_grid, tb->stage, tb->dev, tb->span);
         if (tb->span) tb->dev.dense_arr = tb->span;                        // every later lookup: span[key - bm_lo] (the launch above ranked with its own copy of dev)
     } else {                                                               // hash layout
@@ -1050,9 +1050,9 @@ static int ensure_index(sdqh_ctx* ctx, sdqh_table* tb) {
 // data instead of a hard-coded N): the build table's own columns are the stage, the index is one
 // array over the key range.
 static int build_dense(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int npayload, const sdqh_column* const* payload,
-                       int64_t lo, int64_t hi, sdqh_table** out) {
+                       int64_t lo, int64_t hi, int accumulate, sdqh_table** out) {
     sdqh_table* tb = new sdqh_table();
-    tb->npay = npayload; tb->nrows_build = nrows; tb->index_built = true;
+    tb->npay = npayload; tb->nrows_build = nrows; tb->index_built = true; tb->accumulate = accumulate != 0;
     DevStage& st = tb->stage;
     std::memset(&st, 0, sizeof(st));
     const int64_t target_segs = (int64_t)ctx->num_cu * ctx->opt_stage_waves_per_cu;
@@ -1067,6 +1067,14 @@ static int build_dense(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int
     st.seg_count = static_cast<uint32_t*>(table_alloc(ctx, tb, (size_t)st.nseg * 4 + 64));
     st.shits = static_cast<uint32_t*>(table_alloc(ctx, tb, (size_t)nrows * 4 + 64));
     tb->hdr = static_cast<TableHeader*>(table_alloc(ctx, tb, sizeof(TableHeader)));
+    // accumulators (a dense group domain summed into in one pass: xplan's large group-bys over a small key range): one zeroed row of four per entry
+    const size_t acc_bytes = accumulate ? (size_t)nrows * 32 : 0;
+    if (accumulate) {
+        st.acc_stride = 4;
+        st.sacc = static_cast<double*>(table_alloc(ctx, tb, acc_bytes + 64));
+        if (!st.sacc) { table_release(ctx, tb); delete tb; return fail(ctx, SDQH_ERR_NOMEM, "dense build: out of device memory"); }
+        tb->dev.sacc = st.sacc; tb->dev.acc_stride = 4;
+    }
     // a strictly increasing key column (orders by o_orderkey, any table by its primary key)
     const bool increasing = ctx->opt_dense_increasing && column_is_increasing(ctx, const_cast<sdqh_column*>(key));
     const int64_t* kc = static_cast<const int64_t*>(key->data);
@@ -1082,7 +1090,7 @@ static int build_dense(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int
         tb->dev.hdr = tb->hdr; tb->dev.shits = st.shits; tb->dev.bm_lo = lo; tb->dev.bm_hi = hi; tb->dev.bm = tb->bm; tb->dev.bm_shift = 0; tb->dev.wprefix = wprefix;
         for (int p = 0; p < npayload; ++p) tb->dev.pay[p] = st.pay[p];
         call_begin(ctx);
-        { FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); fl.add(st.shits, (size_t)nrows * 4, 0); fl.add(tb->bm, tb->nwords * 4, 0); launch_fill(ctx, fl); }
+        { FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); fl.add(st.shits, (size_t)nrows * 4, 0); fl.add(tb->bm, tb->nwords * 4, 0); if (accumulate) fl.add(st.sacc, acc_bytes, 0); launch_fill(ctx, fl); }
         LAUNCH(ctx, "k_full_counts", k_full_counts, (unsigned)((st.nseg + TPB - 1) / TPB), st.seg_count, st.nseg, st.seg_rows, nrows);
         LAUNCH(ctx, "k_rank_increasing", k_rank_increasing, (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + TPB * RANK_INC_NB - 1) / (TPB * RANK_INC_NB), (int64_t)ctx->num_cu * 32)), kc, nrows, lo, tb->bm, wprefix, tb->hdr);
         call_end(ctx);
@@ -1099,11 +1107,11 @@ static int build_dense(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int
     // ... over a narrow range fills the array in one pass: no prefill of the cells, no verification pass
     call_begin(ctx);
     if (increasing) {
-        { FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); fl.add(st.shits, (size_t)nrows * 4, 0); launch_fill(ctx, fl); }
+        { FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); fl.add(st.shits, (size_t)nrows * 4, 0); if (accumulate) fl.add(st.sacc, acc_bytes, 0); launch_fill(ctx, fl); }
         LAUNCH(ctx, "k_full_counts", k_full_counts, (unsigned)((st.nseg + TPB - 1) / TPB), st.seg_count, st.nseg, st.seg_rows, nrows);
         LAUNCH(ctx, "k_dense_fill_increasing", k_dense_fill_increasing, grid, kc, nrows, lo, arr, tb->hdr);
     } else {
-        { FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); fl.add(st.shits, (size_t)nrows * 4, 0); fl.add(arr, range * 4, 0xFF); launch_fill(ctx, fl); }
+        { FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); fl.add(st.shits, (size_t)nrows * 4, 0); fl.add(arr, range * 4, 0xFF); if (accumulate) fl.add(st.sacc, acc_bytes, 0); launch_fill(ctx, fl); }
         LAUNCH(ctx, "k_full_counts", k_full_counts, (unsigned)((st.nseg + TPB - 1) / TPB), st.seg_count, st.nseg, st.seg_rows, nrows);
         LAUNCH(ctx, "k_dense_fill", k_dense_fill, grid, kc, nrows, lo, arr);
         LAUNCH(ctx, "k_dense_verify", k_dense_verify, grid, kc, nrows, lo, arr, tb->hdr);
@@ -1140,11 +1148,12 @@ int sdqh_hash_build_unique(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filt
     }
     // dense layout: an unfiltered, unprobed build on a dense key range indexes the source columns in place
     const bool unfiltered = f.ni == 0 && f.nf == 0 && f.ns == 0 && f.nc == 0 && nprobes == 0;
-    if (unfiltered && !accumulate && nrows > 0 && ctx->opt_direct_index && hi >= lo && lo > INT64_MIN / 2 && hi < INT64_MAX / 2 &&
+    if (unfiltered && nrows > 0 && ctx->opt_direct_index && hi >= lo && lo > INT64_MIN / 2 && hi < INT64_MAX / 2 &&
         (uint64_t)(hi - lo) + 1 <= 16ull * (uint64_t)nrows && (uint64_t)(hi - lo) + 1 <= (1ull << 30))
-        return build_dense(ctx, nrows, key, npayload, payload, lo, hi, out);
+        return build_dense(ctx, nrows, key, npayload, payload, lo, hi, accumulate, out);
     sdqh_table* tb = new sdqh_table();
     tb->npay = npayload; tb->accumulate = accumulate != 0; tb->nrows_build = nrows;
+    if (nrows > 0 && column_is_increasing(ctx, const_cast<sdqh_column*>(key))) tb->keys_unique = true;
     // the tuned orders-like instance family runs opt_stage_batch batches per step, every other instance STAGE_BATCH
     const bool tuned_family = f.ns == 0 && f.nf == 0 && f.ni == 1 && nprobes == 1 && npayload == 2;
     const bool string_family = f.ns == 1 && f.nf == 0 && f.ni == 0 && nprobes == 0;
@@ -1891,6 +1900,7 @@ int sdqh_build(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nloo
     }
     sdqh_table* tb = new sdqh_table();
     tb->npay = npayload; tb->accumulate = accumulate != 0; tb->nrows_build = nrows;
+    if (nkey == 1 && nrows > 0 && key[0].kind == SDQH_SRC_COLUMN && key[0].col->dtype == SDQH_I64 && column_is_increasing(ctx, const_cast<sdqh_column*>(key[0].col))) tb->keys_unique = true;
     // stage without source columns: the kernel evaluates sources itself
     sdqh_column fake; fake.data = nullptr;
     const sdqh_column* fakes[SDQH_MAX_PAYLOAD] = {&fake, &fake, &fake, &fake};

@@ -163,6 +163,7 @@ struct sdqh_table {
     std::vector<void*> owned;          // pool blocks to release
     // cached compaction (device buffers) for the two-step count / fetch protocol
     uint32_t* span = nullptr;                      // owner by key offset (small plain-key direct tables), becomes dev.dense_arr once the index is built
+    bool keys_unique = false;                      // the build key is a strictly increasing column: no two staged rows share a key (k_fill_refs has nothing to do)
     bool refs_prefilled = false;                   // small direct tables: dense_ref was allocated and NO_ROW-filled with the header
     bool compact_valid = false;
     int64_t compact_min_hits = 0, compact_n = 0;

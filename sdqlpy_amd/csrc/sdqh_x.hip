@@ -1280,6 +1280,8 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
     }
     sdqh_table* tb = new sdqh_table();
     tb->npay = prog->nvals; tb->accumulate = accumulate != 0; tb->nrows_build = nrows;
+    { const sdqh_xop& ko = prog->ops[prog->key];                       // a strictly increasing key column (a primary key): no duplicate keys whatever the gates pass
+      if (ko.code == SDQH_X_COL && ko.col->dtype == SDQH_I64 && !ko.col->transient && nrows > 0 && column_increasing(ctx, const_cast<sdqh_column*>(ko.col))) tb->keys_unique = true; }
     call_begin(ctx);
     int rc = stage_setup_computed(ctx, tb, nrows, prog->nvals, x.tight ? (X8_STEP * X8_U) / 128 : X_LB);
 

@@ -143,6 +143,16 @@ class Engine:
             self._frozen[id(arr)] = arr
         return col
 
+    def iota_column(self, lo, span):
+        """Resident column lo, lo+1, ..., lo+span-1: the key column of a dense group domain (xplan: large group-bys over a small key range)."""
+        cache = self.__dict__.setdefault("_iota", {})
+        arr = cache.get((lo, span))
+        if arr is None:
+            if len(cache) > 8:
+                cache.clear()
+            arr = cache[(lo, span)] = np.arange(lo, lo + span, dtype=np.int64)
+        return self.column(arr)
+
     def invalidate(self, what):
         """Forget everything derived from a table (columnar sr_dict) or a single host array — resident
         column, min/max, dictionary codes, distinctness — and make the arrays writable again.  Plans
@@ -910,18 +920,20 @@ def _prepare_scan(eng, op, htab, accumulate_into, member_only=False, as_table=Fa
             return xplan.prepare_scan(eng, op, htab, accumulate_into, member_only, as_table)
         except UnsupportedQuery:
             pass
-    routed = False
+    routed, small_only = False, False
     if not _no_stream and getattr(eng, "program_routes", None):
         if op.kind == "dict" and not op.unique and op.probe is not None and op.probe.dict_name in accumulate_into:
-            # (a group named by fields of the matched entry only — Q10: customer fields of an order — stays with the fixed call, which
-            # folds the entries that share those fields on the device: sdqh_table_share_groups)
+            # (a group named by fields of the matched entry only is a program while its groups are a handful — Q5: the nation's name; when
+            # they are many — Q10: customer fields of an order — the fixed call takes over, which folds the entries that share those
+            # fields on the device: sdqh_table_share_groups)
             kfs = op.key.fields if isinstance(op.key, RecordCons) else [(None, op.key)]
-            routed = "probe" in eng.program_routes and isinstance(op.probe.key, Col) and any(isinstance(e, Col) and e.name == op.probe.key.name for _, e in kfs)
+            routed = "probe" in eng.program_routes
+            small_only = not (isinstance(op.probe.key, Col) and any(isinstance(e, Col) and e.name == op.probe.key.name for _, e in kfs))
         elif op.kind == "dict" and op.unique:
             routed = "build" in eng.program_routes or ("values" in eng.program_routes and not member_only and htab.nrows >= (1 << 20) and _plain_values_build(op, htab))
     if routed or (getattr(eng, "stream_programs", False) and not _no_stream and not as_table and not member_only and _is_stream_loop(op)):
         try:
-            x = xplan.prepare_scan(eng, op, htab, accumulate_into, member_only, as_table, small_groups_only=not routed)
+            x = xplan.prepare_scan(eng, op, htab, accumulate_into, member_only, as_table, small_groups_only=small_only or not routed)
         except UnsupportedQuery:
             x = None
         if x is not None:

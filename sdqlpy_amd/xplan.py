@@ -129,6 +129,19 @@ class Compiler:
         self.layout.append((lk.dict_name, _table_signature(bt)))
         return self.lookups[key]
 
+    def found(self, lk):
+        """Operation index of `key in dictionary`.  An aggregated dictionary holds the entries that received at least one row (K-F
+        keeps hits >= 1): an entry of its table that no row reached — a build row nothing matched, a key of a dense domain no row
+        carried — is not in it."""
+        oid, _, bt, _ = self.lookup(lk)
+        if bt.agg is None:
+            return oid
+        key = ("live", oid)
+        if key not in self.memo:
+            hits = self.P.op(abi.X_ACC, abi.T_I64, a=oid, aux=-1)
+            self.memo[key] = self.P.op(abi.X_AND, abi.T_BOOL, a=oid, b=self.P.op(abi.X_GT, abi.T_BOOL, a=hits, b=self.const(0).id))
+        return self.memo[key]
+
     def field(self, lk, fname):
         oid, name, bt, keyvals = self.lookup(lk)
         if bt.agg is not None:                                      # an aggregated dictionary: its values are the entries' accumulators
@@ -320,7 +333,7 @@ class Compiler:
         if isinstance(e, Not):
             return XV(self.P.op(abi.X_NOT, abi.T_BOOL, a=self.cond(e.term).id), "b")
         if isinstance(e, Contains):
-            return XV(self.lookup(e.lookup)[0], "b")
+            return XV(self.found(e.lookup), "b")
         if isinstance(e, StrIn):
             return self.text_pred(self.value(e.col), e.needle, {"in": abi.STR_CONTAINS, "prefix": abi.STR_PREFIX, "suffix": abi.STR_SUFFIX}[e.how])
         if isinstance(e, Cmp):
@@ -525,6 +538,9 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False, sm
         if op.probe is not None:
             probe_id = c.lookup(op.probe)[0]
             ids.append(probe_id)
+            live = c.found(op.probe)
+            if live != probe_id:                                     # (an aggregated dictionary as the index: its entries are those with rows)
+                ids.append(live)
         ids += [c.cond(x).id for x in rest]
         if len(ids) > abi.MAX_XGATES:                                # the tail as one gate
             ids = ids[:abi.MAX_XGATES - 1] + [c.fold(abi.X_AND, ids[abi.MAX_XGATES - 1:])]
@@ -810,7 +826,18 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False, sm
             state["look"] = None
         cb, cp, pkid, count_idx, bounds, key_names, key_dec, composite = st
         cb.bind(env); cp.bind(env)
-        table = ctx.xbuild(htab.nrows, cb.P, bounds[0], bounds[1], accumulate=True)
+        dense = state.get("dense")
+        if dense is None:
+            # A single integer key over a range much smaller than the row count (Q13: 1.5 M customer keys of 15 M orders): every key of
+            # the range gets an entry up front (a build over lo..hi: increasing keys, rank = row, microseconds) and the rows are summed
+            # into it in ONE pass — the conditions are evaluated once, not once to find the keys and once to sum.  Keys no row carries
+            # keep hits = 0 and are not in the dictionary (K-F's min_hits, Compiler.found).
+            span = bounds[1] - bounds[0] + 1
+            dense = state["dense"] = (eng.iota_column(bounds[0], span), span) if (not composite and state.get("radix") is None and 1 <= span <= max(1 << 16, htab.nrows // 4)) else False
+        if dense:
+            table = ctx.hash_build_unique(dense[1], abi.make_filter(), [], dense[0], [], accumulate=True)
+        else:
+            table = ctx.xbuild(htab.nrows, cb.P, bounds[0], bounds[1], accumulate=True)
         look = state.get("look")
         if look is None:
             look = state["look"] = cp.P.op(abi.X_LOOKUP, abi.T_BOOL, a=pkid, table=table)

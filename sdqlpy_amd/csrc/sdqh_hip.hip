@@ -1497,13 +1497,15 @@ int sdqh_table_select_keys(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_
     sdqh_table* table = const_cast<sdqh_table*>(ctable);
     if (!ctx || !table || !out || value_index < 0 || value_index >= SDQH_TUPLE_MAX_VALUES) return fail(ctx, SDQH_ERR_INVALID, "table_select_keys: bad arguments");
     if (!table->accumulate || table->bitmap_only) return fail(ctx, SDQH_ERR_INVALID, "table_select_keys: the table carries no accumulators");
-    if (!table->bm || table->dev.bm_shift != 0 || table->dev.lin_rb != 0) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_select_keys: the table's keys have no dense range");
+    // (a key bitmap over [bm_lo, bm_hi] — the direct layout — or the dense layout's array over the same range)
+    const bool dense_layout = !table->bm && table->dev.dense_arr && table->dev.bm_hi >= table->dev.bm_lo;
+    if ((!table->bm && !dense_layout) || table->dev.bm_shift != 0 || table->dev.lin_rb != 0) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_select_keys: the table's keys have no dense range");
     (void)hipSetDevice(ctx->device);
     call_begin(ctx);
     if (int rc = ensure_index(ctx, table)) return rc;
     sdqh_table* tb = new sdqh_table();
     tb->bitmap_only = true; tb->index_built = true; tb->nrows_build = table->nrows_build;
-    tb->nwords = table->nwords;
+    tb->nwords = dense_layout ? ((uint64_t)(table->dev.bm_hi - table->dev.bm_lo) + 32) / 32 : table->nwords;
     tb->bm = static_cast<uint32_t*>(table_alloc(ctx, tb, tb->nwords * 4 + 64));
     tb->hdr = static_cast<TableHeader*>(table_alloc(ctx, tb, sizeof(TableHeader)));
     if (!tb->bm || !tb->hdr) { table_release(ctx, tb); delete tb; return fail(ctx, SDQH_ERR_NOMEM, "table_select_keys: out of device memory"); }

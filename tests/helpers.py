@@ -986,3 +986,44 @@ def dict_loop_cases(eng, case, rel=0.0):
         eng.dict_programs = True
         eng.ctx.table_columns = real
     return checked, on_device
+
+
+DENSE_DOMAIN_SRC = '''
+def f(orders, customer):
+    per_customer = orders.sum(lambda o: {o[0].o_custkey: record({"n": 1, "total": o[0].o_totalprice})}
+                              if o[0].o_totalprice > 10.0 else None)
+    with_orders = customer.sum(lambda c: record({"members": 1.0 if per_customer[c[0].c_custkey] != None else 0.0,
+                                                  "all": 1.0,
+                                                  "spent": per_customer[c[0].c_custkey].total if per_customer[c[0].c_custkey] != None else 0.0}))
+    return with_orders
+'''
+
+
+def dense_domain_case(eng, ncust=3000, nord=40000, seed=5):
+    """A group-by whose integer key spans a range much smaller than the row count is summed in ONE pass into a table that holds
+    every key of the range (xplan: large mode over a dense domain).  Two thirds of the keys carry no row: they must not be members
+    of the dictionary (`d[k] != None` is false for them, as in the reference where the key was never inserted), checked against
+    numpy — both libraries run the same plan, so their agreement alone would not pin this."""
+    from sdqlpy_amd import sdql_lib
+    rng = np.random.default_rng(seed)
+    custkeys = np.arange(1, ncust + 1, dtype=np.int64)
+    present = rng.choice(custkeys, size=ncust // 3, replace=False)
+    o_cust = rng.choice(present, size=nord).astype(np.int64)
+    o_price = np.round(rng.uniform(0.0, 100.0, nord), 2)
+    o_cust[0], o_cust[1] = 1, ncust                                     # the range's ends occur: the domain is the whole range
+    orders = sdql_lib.table_from_columns(["o_custkey", "o_totalprice"], [o_cust, o_price])
+    customer = sdql_lib.table_from_columns(["c_custkey"], [custkeys])
+    plan = frontend.lower_source(DENSE_DOMAIN_SRC, None, 1, None)
+    built = []
+    real = eng.ctx.hash_build_unique
+    eng.ctx.hash_build_unique = lambda n, *a, **k: (built.append((n, k.get("accumulate", False))), real(n, *a, **k))[1]
+    try:
+        res = eng_mod.execute_plan(eng, plan, [orders, customer])
+    finally:
+        eng.ctx.hash_build_unique = real
+    assert (ncust, True) in built, built                                # the domain build: one entry per key of the range, with accumulators
+    keep = o_price > 10.0
+    assert res["members"] == float(len(np.unique(o_cust[keep]))) and res["all"] == float(ncust), res
+    want = float(o_price[keep].sum())
+    assert abs(res["spent"] - want) <= 1e-9 * want, (res, want)
+    return res

@@ -330,6 +330,15 @@ def test_sums_over_result_dictionaries_run_as_device_loops(hip_engine, golden_wi
     oracle_engine.clear()
 
 
+def test_dense_group_domain_keeps_unreached_keys_out_of_the_dictionary(hip_engine):
+    """xplan's one-pass group-by over a dense key domain (Q13's shape) on the device: the dense build with accumulators
+    (sdqh_hash_build_unique), the probe-aggregate into it, and a later loop's membership test, against numpy."""
+    helpers.dense_domain_case(hip_engine)
+    helpers.dense_domain_case(hip_engine, ncust=70000, nord=400000, seed=6)
+    helpers.dense_domain_case(hip_engine, ncust=1500000, nord=6000000, seed=7)
+    hip_engine.clear()
+
+
 def test_every_golden_vector_through_specialised_kernels(hip_engine, golden, golden_more, golden_wide):
     """All reference results again with every table loop forced through a run-time specialised kernel
     (no ahead-of-time kernel shape): the general path must agree with the tuned one on its home turf."""

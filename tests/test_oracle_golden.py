@@ -133,3 +133,12 @@ def test_sums_over_result_dictionaries_run_as_device_loops(oracle_lib, golden_wi
         assert n >= 12 and all(on_device.get(q, 0) >= 2 for q in ("q16", "q15", "q11")), on_device
     finally:
         eng.close()
+
+
+def test_dense_group_domain_keeps_unreached_keys_out_of_the_dictionary(oracle_lib):
+    eng = engine.Engine(oracle_lib.context(threads=2))
+    try:
+        helpers.dense_domain_case(eng)
+        helpers.dense_domain_case(eng, ncust=70000, nord=400000, seed=6)
+    finally:
+        eng.close()

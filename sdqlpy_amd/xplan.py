@@ -743,6 +743,17 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False, sm
         key_names = [nm or (e.name if isinstance(e, Col) else "key%d" % i) for i, (nm, e) in enumerate(key_fields)]
         return cb, cp, pkid, count_idx, bounds, key_names, (flat[0].dec if len(flat) == 1 else None), len(flat) == 2
 
+    def dense_domain(st):
+        """(resident column lo..hi, span) when the group key is a single integer over a range much smaller than the row count (Q13: 1.5 M
+        customer keys of 15 M orders), else False.  Every key of the range then gets an entry up front (a build over lo..hi: increasing
+        keys, rank = row, microseconds) and the rows are summed into it in ONE pass — the conditions are evaluated once, not once to
+        find the keys and once to sum.  Keys no row carries keep hits = 0 and are not in the dictionary (K-F's min_hits, Compiler.found)."""
+        bounds, composite = st[4], st[7]
+        span = bounds[1] - bounds[0] + 1
+        if composite or state.get("radix") is not None or not (1 <= span <= max(1 << 16, htab.nrows // 4)):
+            return False
+        return (eng.iota_column(bounds[0], span), span)
+
     def run_aggregate(env):
         mode = state.get("mode")
         if mode is None:
@@ -811,6 +822,14 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False, sm
             except abi.SdqhError as exc:
                 if exc.code != abi.ERR_OVERFLOW:
                     raise
+                if small_groups_only and not state.get("entry_ok"):
+                    # the caller has a plan of its own for many groups — unless they are a dense integer domain, which is ONE pass here
+                    # (below) against its two (Q15: 100 K supplier keys of 2.3 M rows)
+                    large = compile_large(env)
+                    if not dense_domain(large):
+                        raise UnsupportedQuery("line %d: more groups than the group-by sinks of a row program hold" % op.lineno)
+                    state["mode"], state["c"], state["look"] = "large", large, None
+                    return run_aggregate(env)
                 if small_groups_only:
                     raise UnsupportedQuery("line %d: more groups than the group-by sinks of a row program hold" % op.lineno)
                 state["mode"], state["c"] = ("entry" if state.get("entry_ok") else "large"), None      # more groups than the LDS table holds
@@ -828,12 +847,7 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False, sm
         cb.bind(env); cp.bind(env)
         dense = state.get("dense")
         if dense is None:
-            # A single integer key over a range much smaller than the row count (Q13: 1.5 M customer keys of 15 M orders): every key of
-            # the range gets an entry up front (a build over lo..hi: increasing keys, rank = row, microseconds) and the rows are summed
-            # into it in ONE pass — the conditions are evaluated once, not once to find the keys and once to sum.  Keys no row carries
-            # keep hits = 0 and are not in the dictionary (K-F's min_hits, Compiler.found).
-            span = bounds[1] - bounds[0] + 1
-            dense = state["dense"] = (eng.iota_column(bounds[0], span), span) if (not composite and state.get("radix") is None and 1 <= span <= max(1 << 16, htab.nrows // 4)) else False
+            dense = state["dense"] = dense_domain(st)
         if dense:
             table = ctx.hash_build_unique(dense[1], abi.make_filter(), [], dense[0], [], accumulate=True)
         else:
@@ -871,6 +885,9 @@ def _is_key_set(bt):
 # order) and the loop body a row program over them — p[0] / p[1] read those columns, a key of several packed fields is
 # unpacked with DIVI / MODI.  What this cannot express falls back to run_host_dict below.
 # =================================================================================================
+PACKED_KEY = "\0packed"     # WholeKey(0, PACKED_KEY): the stored key of a composite-keyed dictionary as one integer (prepare_dict_scan)
+
+
 class DictTable:
     """The entries of a device-resident dictionary, presented as the table a loop scans."""
 
@@ -896,8 +913,6 @@ class DictTable:
     def load(self, env):
         """The entries as columns; every run (the dictionary was rebuilt)."""
         bt, min_hits = self.source(env)
-        if getattr(self, "single_key", False) and (getattr(bt, "key_radix", None) is not None or bt.key_parts is not None or (bt.agg is not None and len(bt.agg[0]) != 1)):
-            raise UnsupportedQuery("line %d: '%s' is keyed by several fields" % (self.op.lineno, self.op.source))
         key, pays, accs, hits, n = self.eng.ctx.table_columns(bt.table, min_hits)
         cols = {"key": key, "hits": hits}
         cols.update({("pay", i): c for i, c in enumerate(pays)})
@@ -938,6 +953,7 @@ class DictTable:
             return XV(self.col(c, ("pay", slot), abi.T_I64), "i", dec=dec, rng=rng)
 
         keyv = XV(self.col(c, "key", abi.T_I64), "i")
+        c.memo["entrykey"] = XV(keyv.id, "i")                    # (the stored key as it is, whatever it packs)
         kf, vf = [], []
         if bt.agg is not None:
             spec, vnames, count_idx, _, _, nv = bt.agg
@@ -993,6 +1009,8 @@ class DictTable:
 
     def whole(self, c, e):
         side = self.fields(c)[e.which]
+        if e.which == 0 and e.field == PACKED_KEY:
+            return c.memo["entrykey"]
         if e.field is None:
             if len(side) != 1:
                 raise UnsupportedQuery("line %d: p[%d] is a record; name a field" % (self.op.lineno, e.which))
@@ -1007,34 +1025,62 @@ def prepare_dict_scan(eng, op, as_table=False, is_result=False):
     """closure(env) for a HostDictOp as a device loop, or None when its shape is not one a loop has (the closure can
     still raise UnsupportedQuery on its first run, when the source's layout is known: the caller keeps the host path).
     Two shapes: a group-by over the entries ({key: value}, summed); and — as the plan's result only — a set of records
-    {unique(record(...)): True} one of whose fields is the source's own (single) key: a unique build keyed by it with the
-    other fields as payload, K-F'd (with ORDER BY / LIMIT on the device) by the caller; the BuiltTable carries .record_order."""
+    {unique(record(...)): True} that names the source's own key among its fields: a unique build keyed by the source's key (a
+    single field, or the two packed parts of a composite key as they are: Q2's (part, supplier) offers) with the other fields as
+    payload, K-F'd (with ORDER BY / LIMIT on the device) by the caller; the BuiltTable carries .record_order."""
     from .frontend import ScanOp
-    scan = ScanOp(op.out, op.source, op.lineno)
-    record_order = None
-    if op.unique or isinstance(op.val, Const) and op.val.value is True:
+    dtab = DictTable(eng, op)
+    record_set = op.unique or isinstance(op.val, Const) and op.val.value is True
+    if record_set:
         if not (is_result and isinstance(op.val, Const) and op.val.value is True and isinstance(op.key, RecordCons)):
             return None
         own = [(nm, e) for nm, e in op.key.fields if isinstance(e, WholeKey) and e.which == 0]
-        rest = [(nm, e) for nm, e in op.key.fields if not (own and nm == own[0][0])]
-        if not own or not rest:
+        if not own or len(own) == len(op.key.fields):
             return None
-        scan.kind, scan.conds, scan.key, scan.val, scan.unique = "dict", list(op.conds), RecordCons([own[0]]), RecordCons(rest), True
         record_order = [nm for nm, _ in op.key.fields]
+
+        def make_run():
+            """Known with the source's layout: which of the record's fields ARE the source's key."""
+            bt = dtab.bt
+            spec = bt.agg[0] if bt.agg is not None else [(bt.key_name, "key")]
+            scan = ScanOp(op.out, op.source, op.lineno)
+            if getattr(bt, "key_radix", None) is None and bt.key_parts is not None and spec == [(bt.key_name, "key")]:
+                # a composite key: the packed integer itself keys the build; its two parts come back out of it when the result is read
+                if any(e.field not in bt.key_parts for _, e in own):
+                    raise UnsupportedQuery("line %d: p[0] names a field that is not part of the key of '%s'" % (op.lineno, op.source))
+                if any(nm != e.field for nm, e in own):
+                    raise UnsupportedQuery("line %d: a key part of '%s' under another name" % (op.lineno, op.source))
+                key, packed = RecordCons([(bt.key_parts[0], WholeKey(0, PACKED_KEY))]), True
+                rest = [(nm, e) for nm, e in op.key.fields if not (isinstance(e, WholeKey) and e.which == 0)]
+            else:
+                if getattr(bt, "key_radix", None) is not None or bt.key_parts is not None or len(spec) != 1 or len(own) != 1:
+                    raise UnsupportedQuery("line %d: '%s' is keyed by several fields" % (op.lineno, op.source))
+                key, packed = RecordCons([own[0]]), False
+                rest = [(nm, e) for nm, e in op.key.fields if nm != own[0][0]]
+            scan.kind, scan.conds, scan.key, scan.val, scan.unique = "dict", list(op.conds), key, RecordCons(rest), True
+            return prepare_scan(eng, scan, dtab, {}, False, as_table), packed
     else:
+        scan = ScanOp(op.out, op.source, op.lineno)
         scan.kind, scan.conds, scan.key, scan.val, scan.unique = "dict", list(op.conds), op.key, op.val, False
-    dtab = DictTable(eng, op)
-    dtab.single_key = record_order is not None                   # (a field of a packed key does not identify the entry)
-    run = prepare_scan(eng, scan, dtab, {}, False, as_table)
+        run_groups = prepare_scan(eng, scan, dtab, {}, False, as_table)
+    state = {}
 
     def run_dict_scan(env):
         dtab.load(env)
         try:
             if dtab.nrows == 0:
                 return NotImplemented                            # nothing to launch: the host path shapes the empty result of this run
+            if not record_set:
+                return run_groups(env)
+            if "run" not in state:
+                state["run"] = make_run()
+            run, packed = state["run"]
             out = run(env)
-            if record_order is not None:
-                out.record_order = record_order
+            if packed:
+                if dtab.bt.key_parts is None:
+                    raise UnsupportedQuery("line %d: the key of '%s' changed shape" % (op.lineno, op.source))
+                out.key_parts, out.key_part_decoders = list(dtab.bt.key_parts), getattr(dtab.bt, "key_part_decoders", None)
+            out.record_order = record_order
             return out
         finally:
             dtab.release()

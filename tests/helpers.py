@@ -955,7 +955,7 @@ def dict_loop_cases(eng, case, rel=0.0):
     eng.ctx.table_columns = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
     checked, on_device = 0, {}
     try:
-        for q in ("q16", "q15", "q11"):
+        for q in ("q16", "q15", "q11", "q2"):
             want = case["results"].get(q)
             if want is None:
                 continue

@@ -105,7 +105,7 @@ class Engine:
         # request, unique builds ("build"); "values": the builds whose key and payload are plain columns of the scanned row and whose
         # conditions need no payload of a looked-up entry (Q3's orders build) — the value-queue stage kernel streams everything and
         # gathers nothing.  Measured per kind in profiles/r03_ab_tuned_vs_programs.txt.
-        routes = os.environ.get("SDQLPY_AMD_PROGRAM_ROUTES", "probe,values")
+        routes = os.environ.get("SDQLPY_AMD_PROGRAM_ROUTES", "probe,values,lookups")
         self.program_routes = {r for r in routes.split(",") if r} if ctx.library.backend_name() == "hip-gfx950" else set()
 
     def close(self):
@@ -908,6 +908,51 @@ def _plain_values_build(op, htab):
     return op.probe is None or num_col(op.probe.key, "i")
 
 
+def _single_key_lookup_build(op, htab):
+    """A unique build keyed by ONE integer column whose conditions / payload look other tables up (Q5's orders: the customer's nation
+    as payload) and that touches numeric columns only: the tight-encoded program (2-byte date codes, 8 rows per lane) beats the fixed
+    `k_build_lookup` on the big ones (15 M orders 0.083 -> 0.065 ms); composite keys stay with the fixed call (its linearised /
+    prefiltered layouts), text payloads too."""
+    def num_col(e, kinds="if"):
+        return isinstance(e, Col) and htab.cols.get(e.name) is not None and htab.cols[e.name].dtype.kind in kinds
+    if not (op.kind == "dict" and op.unique) or isinstance(op.key, RecordCons) or not num_col(op.key, "i"):
+        return False
+    found, cols = [], []
+
+    def walk(e):
+        if isinstance(e, Col):
+            cols.append(e)
+        elif isinstance(e, (PayloadField, Contains)):
+            found.append(e.lookup); walk(e.lookup.key)
+        elif isinstance(e, Lookup):
+            found.append(e); walk(e.key)
+        elif isinstance(e, (Bin, Cmp)):
+            walk(e.left); walk(e.right)
+        elif isinstance(e, (And, Or)):
+            for t in e.terms:
+                walk(t)
+        elif isinstance(e, Not):
+            walk(e.term)
+        elif isinstance(e, RecordCons):
+            for _, x in e.fields:
+                walk(x)
+        elif isinstance(e, Const):
+            if isinstance(e.value, str):
+                cols.append(None)
+        else:
+            cols.append(None)                                     # anything else (conditional values, calls, text tests): not this route
+    for c in op.conds:
+        walk(c)
+    if op.probe is not None:
+        found.append(op.probe); walk(op.probe.key)
+    in_conds = len(found)
+    if not (isinstance(op.val, Const) and op.val.value is True):
+        walk(op.val)
+    # (a payload that reads a looked-up field: a build that only TESTS membership — Q18's orders against 57 keys — keeps the fixed
+    # kernel's filtered staging, 0.05 ms against 0.34 ms as a program)
+    return len(found) > in_conds and all(c is not None and num_col(c) for c in cols) and all(not isinstance(lk.key, RecordCons) for lk in found)
+
+
 def _prepare_scan(eng, op, htab, accumulate_into, member_only=False, as_table=False, coded_text=False, _no_stream=False):
     """closure(env) for one table loop: the tuned fixed-shape calls when the loop is one of their shapes,
     a row program (xplan.py: a kernel specialised on the loop's own conditions and values) otherwise.
@@ -930,7 +975,9 @@ def _prepare_scan(eng, op, htab, accumulate_into, member_only=False, as_table=Fa
             routed = "probe" in eng.program_routes
             small_only = not (isinstance(op.probe.key, Col) and any(isinstance(e, Col) and e.name == op.probe.key.name for _, e in kfs))
         elif op.kind == "dict" and op.unique:
-            routed = "build" in eng.program_routes or ("values" in eng.program_routes and not member_only and htab.nrows >= (1 << 20) and _plain_values_build(op, htab))
+            big = not member_only and htab.nrows >= (1 << 20)
+            routed = "build" in eng.program_routes or ("values" in eng.program_routes and big and _plain_values_build(op, htab)) \
+                or ("lookups" in eng.program_routes and big and _single_key_lookup_build(op, htab))
     if routed or (getattr(eng, "stream_programs", False) and not _no_stream and not as_table and not member_only and _is_stream_loop(op)):
         try:
             x = xplan.prepare_scan(eng, op, htab, accumulate_into, member_only, as_table, small_groups_only=small_only or not routed)

@@ -25,10 +25,13 @@ MAX_CODE_SET = 8          # a text predicate on coded values becomes at most thi
 
 class XV:
     """A value inside a program: operation index, type ('i' | 'f' | 'b'), and what the planner knows about it."""
-    __slots__ = ("id", "t", "dec", "rng")
+    __slots__ = ("id", "t", "dec", "rng", "roots", "plain")
 
-    def __init__(self, id, t, dec=None, rng=None):
+    def __init__(self, id, t, dec=None, rng=None, roots=None, plain=None):
         self.id, self.t, self.dec, self.rng = id, t, dec, rng       # dec: text array this int indexes; rng: (lo, hi) of an int
+        # roots: the columns of the scanned row the value is a function of (ids of resident columns, "row" for the row number), None:
+        # not tracked; plain: the value IS a plain int column / the row number (identifies its root) — engine._share_spec's facts
+        self.roots, self.plain = roots, plain
 
 
 class Text:
@@ -77,9 +80,9 @@ class Compiler:
             return Text(name, arr)
         col = self.eng.column(arr)
         if arr.dtype == np.int64:
-            return XV(self.P.op(abi.X_COL, abi.T_I64, col=col), "i", rng=("col", col))
+            return XV(self.P.op(abi.X_COL, abi.T_I64, col=col), "i", rng=("col", col), roots=frozenset([id(col)]), plain=True)
         if arr.dtype == np.float64:
-            return XV(self.P.op(abi.X_COL, abi.T_F64, col=col), "f")
+            return XV(self.P.op(abi.X_COL, abi.T_F64, col=col), "f", roots=frozenset([id(col)]))
         self.fail("column '%s' has unsupported dtype %s" % (name, arr.dtype))
 
     def text_as_int(self, tx, coded_ok=True):
@@ -90,11 +93,11 @@ class Compiler:
         if key not in self.memo:
             coded = self.eng.dict_column(tx.arr) if coded_ok else None
             if coded is not None:
-                self.memo[key] = XV(self.P.op(abi.X_COL, abi.T_I64, col=coded[0]), "i", dec=coded[1], rng=(0, max(0, len(coded[1]) - 1)))
+                self.memo[key] = XV(self.P.op(abi.X_COL, abi.T_I64, col=coded[0]), "i", dec=coded[1], rng=(0, max(0, len(coded[1]) - 1)), roots=frozenset([id(coded[0])]))
             else:
                 if "rowid" not in self.memo:
                     self.memo["rowid"] = self.P.op(abi.X_ROWID, abi.T_I64)      # one row reference serves every text column of the row
-                self.memo[key] = XV(self.memo["rowid"], "i", dec=tx.arr, rng=(0, max(0, self.htab.nrows - 1)))
+                self.memo[key] = XV(self.memo["rowid"], "i", dec=tx.arr, rng=(0, max(0, self.htab.nrows - 1)), roots=frozenset(["row"]), plain=True)
         return self.memo[key]
 
     def resolve_rng(self, v):
@@ -172,10 +175,11 @@ class Compiler:
         fkey = ("field", oid, slot)                              # one operation per slot: fields that share a slot (text of one row) share it
         if fkey not in self.memo:
             self.memo[fkey] = self.P.op(abi.X_FIELD, abi.T_F64 if dt.kind == "f" else abi.T_I64, a=oid, aux=slot)
+        roots = frozenset().union(*[v.roots for v in keyvals]) if all(v.roots is not None for v in keyvals) else None      # a field of the entry the key finds
         if dt.kind == "f":
-            return XV(self.memo[fkey], "f")
+            return XV(self.memo[fkey], "f", roots=roots)
         rng = (0, len(dec) - 1) if dec is not None else _slot_range(bt, slot)
-        return XV(self.memo[fkey], "i", dec=dec, rng=rng)
+        return XV(self.memo[fkey], "i", dec=dec, rng=rng, roots=roots)
 
     # -- expressions ----------------------------------------------------------------------------------
     def as_int(self, v, what):
@@ -534,6 +538,19 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False, sm
         light = [x for x in conds if _is_light(x)]
         rest = [x for x in conds if not _is_light(x)]
         ids = [c.cond(x).id for x in light]
+        # membership tests keyed by the scanned row alone go in front of the joinProbe index: they are the selective ones (Q18: 57 keys
+        # of 15 M) and the kernels test the first lookup on streamed keys; the index is usually a join that every row survives
+        from .engine import _walk_lookups
+        def own_keyed(x):
+            if not isinstance(x, Contains):
+                return False
+            inner = []
+            _walk_lookups(x.lookup.key, inner)
+            return not inner
+        if op.probe is not None:
+            early = [x for x in rest if own_keyed(x)]
+            rest = [x for x in rest if not own_keyed(x)]
+            ids += [c.cond(x).id for x in early]
         probe_id = None
         if op.probe is not None:
             probe_id = c.lookup(op.probe)[0]
@@ -623,6 +640,7 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False, sm
             else:
                 kid = c.P.op(abi.X_PACK2, abi.T_I64, a=flat[0].id, b=flat[1].id)
             val_fields, pay_ids, dtypes, decoders, field_decoders, slot_rng = [], [], [], {}, {}, {}
+            pay_xvs = []
             for fname, e in vfields:
                 if len(key_fields) == 1 and repr(e) == repr(key_fields[0][1]):
                     val_fields.append((fname, "key"))
@@ -635,7 +653,7 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False, sm
                 j = next((j for j, pid in enumerate(pay_ids) if pid == v.id), None)
                 if j is None:
                     j = len(pay_ids)
-                    pay_ids.append(v.id); dtypes.append(np.dtype(np.float64 if v.t == "f" else np.int64))
+                    pay_ids.append(v.id); dtypes.append(np.dtype(np.float64 if v.t == "f" else np.int64)); pay_xvs.append(v)
                     if v.dec is not None:
                         decoders[j] = v.dec
                     elif v.t == "i":
@@ -650,6 +668,16 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False, sm
                     return compile_build(env, False)
                 raise UnsupportedQuery("line %d: more than %d distinct payload values per entry" % (op.lineno, abi.MAX_PAYLOAD))
             c.P.gates, c.P.key, c.P.vals = gates, kid, pay_ids
+            # what each payload slot is a function of, for a later aggregation keyed by entry fields only (engine._share_spec, Q10's shape)
+            roots, plain = None, {}
+            if all(v.roots is not None for v in pay_xvs):
+                roots = {j: v.roots for j, v in enumerate(pay_xvs)}
+                for j, v in enumerate(pay_xvs):
+                    if v.plain and (v.dec is None or "row" in v.roots):
+                        r = (0, max(1, htab.nrows)) if "row" in v.roots else c.resolve_rng(v)
+                        if r is not None:
+                            plain[j] = r if "row" in v.roots else (r[0], r[1] - r[0] + 1)
+            state["share_facts"] = (roots, plain)
             return c, key_names, bounds, val_fields, dtypes, (decoders, field_decoders, slot_rng), (flat[0].dec if len(flat) == 1 else [v.dec for v in flat]), len(flat) == 2
 
         def run_build(env):
@@ -673,6 +701,8 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False, sm
                 table = ctx.xbuild(htab.nrows, c.P, bounds[0], bounds[1], accumulate=accumulate, nsums=accumulate_into.get(op.out) if accumulate and isinstance(accumulate_into, dict) else None)
             bt = BuiltTable(table, key_names[0], key_is_record, val_fields, val_is_record, dtypes)
             bt.decoders, bt.field_decoders, bt.slot_rng = dict(decoders[0]), dict(decoders[1]), dict(decoders[2])
+            if state.get("share_facts") is not None and state["share_facts"][0] is not None:
+                bt.slot_roots, bt.slot_plain = dict(state["share_facts"][0]), dict(state["share_facts"][1])
             if composite:
                 bt.key_parts = key_names
                 bt.key_part_decoders = key_dec

@@ -974,6 +974,8 @@ def _prepare_scan(eng, op, htab, accumulate_into, member_only=False, as_table=Fa
             kfs = op.key.fields if isinstance(op.key, RecordCons) else [(None, op.key)]
             routed = "probe" in eng.program_routes
             small_only = not (isinstance(op.probe.key, Col) and any(isinstance(e, Col) and e.name == op.probe.key.name for _, e in kfs))
+        elif op.kind == "dict" and not op.unique and op.probe is None and "groups" in eng.program_routes and not as_table:
+            routed, small_only = True, True                        # (any small-domain aggregation with lookups: the fixed lookup-aggregate call otherwise)
         elif op.kind == "dict" and op.unique:
             big = not member_only and htab.nrows >= (1 << 20)
             routed = "build" in eng.program_routes or ("values" in eng.program_routes and big and _plain_values_build(op, htab)) \

@@ -228,6 +228,58 @@ def test_full_size_properties_sf10(hip_engine):
     hip_engine.clear()
 
 
+def test_sf100_on_one_gpu_q3_q6(hip_engine):
+    """BASELINE configs[3]'s data size (SF=100: 600 M lineitem rows, 150 M orders) on ONE device — what every rank of the 8-GPU
+    configuration holds an eighth of, and the size at which bitmaps stop fitting LDS / L2 and 32-bit offsets start to matter.
+    Q6 against a numpy reduction of the same columns; Q3 additive over a split of lineitem at an odd row, counts of groups exact,
+    ORDER BY ... LIMIT on the device equal to ordering the full result, a second run bit-identical."""
+    import psutil
+    import torch
+    if psutil.virtual_memory().available < 96 * (1 << 30) or torch.cuda.mem_get_info(0)[0] < 120 * (1 << 30):
+        pytest.skip("needs ~96 GiB of host memory and ~120 GiB of HBM free")
+    qs = ("q3", "q6")
+    db = tpch.generate(100, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+    li = db["lineitem"].getContainer()
+    col = dict(zip(li["headers"], li["data"]))
+    n = len(col["l_shipdate"])
+    assert n > 599_000_000
+    m = (col["l_shipdate"] >= 19940101) & (col["l_shipdate"] < 19950101)
+    m &= (col["l_discount"] >= 0.05) & (col["l_discount"] <= 0.07)
+    m &= col["l_quantity"] < 24.0
+    want6 = float(np.sum(col["l_extendedprice"][m] * col["l_discount"][m]))
+    del m
+    got6 = helpers.run_query(hip_engine, "q6", db)
+    assert abs(got6 - want6) <= 1e-9 * abs(want6), (got6, want6)
+    whole = helpers.run_query(hip_engine, "q3", db)
+    assert whole.size() > 1_000_000
+    again = helpers.run_query(hip_engine, "q3", db)
+    assert again.size() == whole.size() and all(np.array_equal(again.column(c), whole.column(c)) for c in whole.columns)
+    del again
+    order_by = Q.TPCH_ORDER["q3"][1]
+    plan = frontend.lower_function(Q.QUERIES["q3"])
+    got = engine.execute_plan(hip_engine, plan, [db[t] for t in Q.QUERY_TABLES["q3"]], top=(10, order_by)).ordered_rows()
+    want_rows = whole.top(10, order_by).ordered_rows()
+    assert [r[0] for r in got] == [r[0] for r in want_rows]
+    helpers.assert_rows_match(got, want_rows, 1e-10, "q3 top 10 at SF=100")
+    # additivity over a split of the probe side, group by group (keys: l_orderkey)
+    cut = n // 2 + 777
+    keys = whole.column("l_orderkey")
+    order = np.argsort(keys, kind="stable")
+    total = np.zeros(len(keys))
+    for lo, hi in ((0, cut), (cut, n)):
+        part = dict(db)
+        part["lineitem"] = tpch.table_from_columns(li["headers"], [c[lo:hi] for c in li["data"]])
+        r = helpers.run_query(hip_engine, "q3", part)
+        pos = np.searchsorted(keys[order], r.column("l_orderkey"))
+        assert np.array_equal(keys[order][pos], r.column("l_orderkey"))           # every group of a half is a group of the whole
+        np.add.at(total, order[pos], r.column("revenue"))
+        hip_engine.invalidate(part["lineitem"])
+        del part, r
+    rev = whole.column("revenue")
+    assert np.all(np.abs(total - rev) <= 1e-9 * np.abs(rev))
+    hip_engine.clear()
+
+
 def test_full_size_q9_and_topk_sf10(hip_engine):
     """The two size holes of the SF=10 suite: q9 (composite-key probe + dense order lookup, 60 M probe rows)
     through additivity over a lineitem split and a numpy total, and ORDER BY ... LIMIT on the device

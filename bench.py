@@ -184,7 +184,14 @@ def main(argv=None, hooks=None):
     eng.ctx.set_profiling(0)
     dom_kernel = max(probe_launches, key=lambda kv: kv[1])[0] if probe_launches else DOMINANT[dom_q][0]
 
-    def run_steps(nsteps, only, qs=None, run=None):
+    def finish(r):
+        """A result is complete — every row on the host, the plan's host-side steps done — once wait() returns (results of plans
+        whose last device call is launched without being waited for: sdqlpy_amd/result.py DeferredResultSet)."""
+        return r.wait() if hasattr(r, "wait") else r
+
+    def run_steps(nsteps, only, qs=None, run=None, each_waited_for=False):
+        """One step = every query of `qs` LAUNCHED, then every result finished (a step ends with all its results complete on the
+        host).  each_waited_for: every query's result finished before the next query is launched (per-query wall times)."""
         qs = queries if qs is None else qs
         run = run or run_query
         per_q = {q: 0.0 for q in qs}
@@ -193,11 +200,18 @@ def main(argv=None, hooks=None):
         t_begin = time.perf_counter()
         marks = []                                       # (query, number of launches recorded so far)
         for _ in range(nsteps):
+            results = []
             for q in qs:
                 tq = time.perf_counter()
-                run(q)
+                r = run(q)
+                if each_waited_for:
+                    finish(r)
+                else:
+                    results.append(r)
                 per_q[q] += (time.perf_counter() - tq) * 1e3
                 marks.append((q, eng.ctx.lib.sdqh_profile_count(eng.ctx.handle)))
+            for r in results:
+                finish(r)
         barrier()
         took = time.perf_counter() - t_begin
         launches = eng.ctx.profile()                     # [(kernel, ms)] of every recorded launch
@@ -210,7 +224,10 @@ def main(argv=None, hooks=None):
 
     if runner is not None:
         runner.reset_collectives()
-    elapsed, per_query_ms, timed_log = run_steps(args.steps, dom_kernel)
+    elapsed, _, timed_log = run_steps(args.steps, dom_kernel)
+    # the same steps with every query's result finished before the next query starts: per-query wall times, and the step as a caller
+    # who reads each result at once sees it
+    elapsed_waited, per_query_ms, _ = run_steps(args.steps, "-", each_waited_for=True)
     timed_collectives = None
     if runner is not None:
         timed_collectives = {k: {"calls": v[0], "on_device_tensors": v[1], "bytes": v[2]} for k, v in sorted(runner.collectives.items())}
@@ -255,7 +272,7 @@ def main(argv=None, hooks=None):
             first_run_ms[q] = round((time.perf_counter() - tq) * 1e3, 2)
             for _ in range(args.warmup):
                 run_query(q)
-        took_x, extra_ms, _ = run_steps(extra_steps, "-", extra)
+        took_x, extra_ms, _ = run_steps(extra_steps, "-", extra, each_waited_for=True)
         _, _, extra_log = run_steps(extra_steps, None, extra)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -325,6 +342,12 @@ def main(argv=None, hooks=None):
                        "sf_per_gpu": sf_per_gpu, "sf_global": sf_global, "rows_per_gpu": rows,
                        "partitioning": "none" if not use_dist else "q1 row-sharded; q5 small builds replicated, orders-lineitem join co-partitioned; q3 partitioned on o_orderkey (%s), RCCL all-to-all; exchanged rows %s"
                                        % (runner.last_partitioning, runner.exchanged_rows)},
+            # what a step is: its queries launched one after the other, then their results finished — a plan's last device call is
+            # queued without being waited for (Engine.deferred_results) and every result is complete on the host before the step ends.
+            # Beside it, the same step with every query's result finished before the next query is launched.
+            "step": {"launch_then_finish": True, "deferred_results": bool(getattr(eng, "deferred_results", False)),
+                     "ms_per_step_each_query_waited_for": round(elapsed_waited / args.steps * 1e3, 4),
+                     "value_each_query_waited_for": round(total_rows_per_step * args.steps / elapsed_waited, 1)},
             "ms_per_query": per_query,
             "kernels_pass": "separate pass of %d steps after the timed region, HIP events around every launch" % profile_steps,
             "kernels": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in sorted(kernels.items())},

@@ -302,7 +302,13 @@ int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits,
  * or the option "async_result" = 0, makes it the synchronous call.  The CPU build fills the arrays before it returns. */
 int sdqh_table_compact_async(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, int64_t capacity,
                              int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n);
-/* Wait for every result copy queued by sdqh_table_compact_async on this context. */
+/* K-F with NOTHING waited for: as sdqh_table_compact_async, but the row count arrives behind the call too — *out_n, which must
+ * lie in the same sdqh_host_alloc block, is -1 until the kernels have run; every array is copied out at its full `capacity`.
+ * After sdqh_result_wait (or sdqh_synchronize): *out_n rows are valid; *out_n > capacity means the rows beyond were dropped
+ * (fetch again with the capacity it names).  SDQH_ERR_UNSUPPORTED for any other layout or with "async_result" = 0. */
+int sdqh_table_compact_deferred(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, int64_t capacity,
+                                int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n);
+/* Wait for every result copy queued by sdqh_table_compact_async / _deferred on this context. */
 int sdqh_result_wait(sdqh_ctx* ctx);
 
 /* Result memory the device can write: when every out_* array of a first sdqh_table_compact call
@@ -472,6 +478,16 @@ int sdqh_xscan_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, doubl
  * (<= SDQH_MAX_LOOKUP_GROUPS) of them; outputs as sdqh_groupby_small with nkeys = 1. */
 int sdqh_xgroupby(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int max_groups,
                   int64_t* out_keys, double* out_values, int64_t* out_counts, int32_t* out_ngroups);
+/* The same K-C with the result delivered BEHIND the call (a query's last loop need not hold the host: the next query's kernels
+ * are queued while this one's run — the reference's result object also converts on `to_dict()`, src/sdqlpy/fastd.py:31-51).
+ * sdqh_xgroupby_async launches and returns; `result_block` is sdqh_xgroupby_block_bytes() bytes from sdqh_host_alloc, opaque,
+ * written when the stream gets there.  After sdqh_synchronize, sdqh_xgroupby_collect reads the groups out of it exactly as
+ * sdqh_xgroupby would have returned them (same errors: SDQH_ERR_OVERFLOW with *out_ngroups, SDQH_ERR_UNSUPPORTED for a negative
+ * key); nvals = the program's value count.  The CPU build computes the groups in the first call. */
+size_t sdqh_xgroupby_block_bytes(void);
+int sdqh_xgroupby_async(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, void* result_block);
+int sdqh_xgroupby_collect(sdqh_ctx* ctx, const void* result_block, int nvals, int max_groups,
+                          int64_t* out_keys, double* out_values, int64_t* out_counts, int32_t* out_ngroups);
 /* K-B (331-369): unique build keyed by the program's key, payload = its vals (<= SDQH_MAX_PAYLOAD); first row wins.
  * [key_lo, key_hi]: bounds of the key the caller knows from its sources (key_lo > key_hi: none known) — a
  * dense range gets the direct (bitmap + rank) index, anything else open addressing.  A key outside given

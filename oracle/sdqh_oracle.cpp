@@ -636,6 +636,12 @@ int sdqh_table_compact_async(sdqh_ctx* ctx, const sdqh_table* table, int64_t min
                              int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n) {
     return sdqh_table_compact(ctx, table, min_hits, capacity, out_keys, out_payload, out_values, out_hits, out_n);
 }
+int sdqh_table_compact_deferred(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, int64_t capacity,
+                                int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n) {
+    if (!ctx || !table || !out_n || capacity < 1 || !out_keys) return fail(ctx, SDQH_ERR_INVALID, "table_compact_deferred: bad arguments");
+    const int rc = sdqh_table_compact(ctx, table, min_hits, capacity, out_keys, out_payload, out_values, out_hits, out_n);
+    return rc == SDQH_ERR_OVERFLOW ? SDQH_OK : rc;                  // (*out_n > capacity says so: the caller fetches again)
+}
 int sdqh_result_wait(sdqh_ctx* ctx) { return ctx ? SDQH_OK : SDQH_ERR_INVALID; }
 int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, int64_t capacity,
                        int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n) {
@@ -1206,6 +1212,35 @@ int sdqh_xgroupby(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int ma
     }
     *out_ngroups = (int32_t)global.size();
     ctx->last_ms = tm.ms();
+    return SDQH_OK;
+}
+
+// (checker: the groups are computed by the first call and kept in the block; its layout is this implementation's own)
+struct XGroupBlock { int32_t rc, ng; int64_t keys[SDQH_MAX_LOOKUP_GROUPS]; double vals[SDQH_MAX_LOOKUP_GROUPS * SDQH_TUPLE_MAX_VALUES]; int64_t cnts[SDQH_MAX_LOOKUP_GROUPS]; char err[160]; };
+size_t sdqh_xgroupby_block_bytes(void) { return (sizeof(XGroupBlock) + 63) & ~(size_t)63; }
+int sdqh_xgroupby_async(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, void* result_block) {
+    if (!ctx || nrows < 0 || !prog || !result_block) return fail(ctx, SDQH_ERR_INVALID, "xgroupby_async: bad arguments");
+    XGroupBlock* b = static_cast<XGroupBlock*>(result_block);
+    int32_t ng = 0;
+    b->rc = sdqh_xgroupby(ctx, nrows, prog, SDQH_MAX_LOOKUP_GROUPS, b->keys, b->vals, b->cnts, &ng);
+    b->ng = ng;
+    std::snprintf(b->err, sizeof(b->err), "%s", b->rc ? ctx->err.c_str() : "");
+    if (b->rc == SDQH_ERR_OVERFLOW || b->rc == SDQH_ERR_UNSUPPORTED) return SDQH_OK;       // what the data decides is reported by collect
+    return b->rc;
+}
+int sdqh_xgroupby_collect(sdqh_ctx* ctx, const void* result_block, int nvals, int max_groups,
+                          int64_t* out_keys, double* out_values, int64_t* out_counts, int32_t* out_ngroups) {
+    if (!ctx || !result_block || nvals < 0 || nvals > SDQH_TUPLE_MAX_VALUES || max_groups < 1 || max_groups > SDQH_MAX_LOOKUP_GROUPS || !out_ngroups) return fail(ctx, SDQH_ERR_INVALID, "xgroupby_collect: bad arguments");
+    const XGroupBlock* b = static_cast<const XGroupBlock*>(result_block);
+    if (b->rc == SDQH_ERR_OVERFLOW) { *out_ngroups = b->ng; return fail(ctx, SDQH_ERR_OVERFLOW, "xgroupby: more groups than max_groups"); }
+    if (b->rc) return fail(ctx, b->rc, b->err);
+    if (b->ng > max_groups) { *out_ngroups = b->ng; return fail(ctx, SDQH_ERR_OVERFLOW, "xgroupby: more groups than max_groups"); }
+    for (int g = 0; g < b->ng; ++g) {
+        if (out_keys) out_keys[g] = b->keys[g];
+        if (out_values) for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) out_values[g * SDQH_TUPLE_MAX_VALUES + k] = b->vals[g * SDQH_TUPLE_MAX_VALUES + k];
+        if (out_counts) out_counts[g] = b->cnts[g];
+    }
+    *out_ngroups = b->ng;
     return SDQH_OK;
 }
 

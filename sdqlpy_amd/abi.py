@@ -215,10 +215,10 @@ EXPORTS = [
     "sdqh_column_upload", "sdqh_column_wrap", "sdqh_column_alloc", "sdqh_column_download", "sdqh_column_data",
     "sdqh_column_rows", "sdqh_column_dtype", "sdqh_column_width", "sdqh_column_minmax", "sdqh_column_free",
     "sdqh_scan_filter_sum", "sdqh_scan_probe_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_build_key_set", "sdqh_groupby_key", "sdqh_table_select_keys", "sdqh_table_share_groups", "sdqh_table_size", "sdqh_table_free",
-    "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_table_compact_async", "sdqh_result_wait", "sdqh_scan_compact", "sdqh_partition_by_key",
+    "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_table_compact_async", "sdqh_table_compact_deferred", "sdqh_result_wait", "sdqh_scan_compact", "sdqh_partition_by_key",
     "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in",
     "sdqh_build", "sdqh_lookup_aggregate", "sdqh_table_entries", "sdqh_host_alloc", "sdqh_host_free", "sdqh_table_topk",
-    "sdqh_xscan_sum", "sdqh_xgroupby", "sdqh_xbuild", "sdqh_xkey_set", "sdqh_xprobe_aggregate", "sdqh_table_columns", "sdqh_jit_stats",
+    "sdqh_xscan_sum", "sdqh_xgroupby", "sdqh_xgroupby_block_bytes", "sdqh_xgroupby_async", "sdqh_xgroupby_collect", "sdqh_xbuild", "sdqh_xkey_set", "sdqh_xprobe_aggregate", "sdqh_table_columns", "sdqh_jit_stats",
 ]
 
 
@@ -345,13 +345,14 @@ class Context:
         self._check(self.lib.sdqh_set_threads(self.handle, C.c_int(max(1, threads))))
         self._host_pool = {}       # block bytes -> [free block addresses]
         self._host_quarantine = [] # (address, bytes) of released blocks a queued result copy may still write (host_block)
+        self._deferred_quarantine = []  # the same for blocks that kernels still queued on the stream may write (synchronize)
 
     def close(self):
         if self.handle is not None:
-            self.lib.sdqh_result_wait(self.handle)
-            for addr, size in self._host_quarantine:
+            self.lib.sdqh_synchronize(self.handle)
+            for addr, size in self._host_quarantine + self._deferred_quarantine:
                 self._host_pool.setdefault(size, []).append(addr)
-            self._host_quarantine = []
+            self._host_quarantine, self._deferred_quarantine = [], []
             for blocks in self._host_pool.values():
                 for addr in blocks:
                     self.lib.sdqh_host_free(self.handle, C.c_void_p(addr))
@@ -360,13 +361,16 @@ class Context:
             self.handle = None
 
     # -- result memory the device can write (sdqh_host_alloc) -------------------------------------
-    def host_block(self, nbytes):
+    def host_block(self, nbytes, deferred=False):
         """A ctypes byte array over a device-visible block of at least nbytes.  numpy views made
         from it keep it alive; when the last one dies the block returns to this context's pool (or
-        is freed if the context is gone)."""
+        is freed if the context is gone).  deferred: kernels queued on the stream will write the block (xgroupby_async,
+        table_compact_deferred): released, it waits for the next full synchronisation of the context before it is handed out again."""
         size = 1 << 16
         while size < nbytes:
             size <<= 1
+        if len(self._deferred_quarantine) > 256:                  # nobody synchronised in a long while: do it here
+            self.synchronize()
         if self._host_quarantine:
             # blocks whose arrays died while a result copy might still have been landing in them: usable once the copies are done
             # (they are, by the time another result is asked for; waiting when the block was RELEASED stalled every query on its own copy)
@@ -382,14 +386,16 @@ class Context:
             self._check(self.lib.sdqh_host_alloc(self.handle, C.c_size_t(size), C.byref(p)))
             addr = p.value
         buf = (C.c_char * size).from_address(addr)
-        weakref.finalize(buf, Context._release_block, weakref.ref(self), self.lib, addr, size)
+        weakref.finalize(buf, Context._release_block, weakref.ref(self), self.lib, addr, size, deferred)
         return buf
 
     @staticmethod
-    def _release_block(ctx_ref, lib, addr, size):
+    def _release_block(ctx_ref, lib, addr, size, deferred=False):
         ctx = ctx_ref()
         if ctx is not None and ctx.handle is not None:
-            ctx._host_quarantine.append((addr, size))         # a result copy may still be landing in the block: see host_block
+            # a result copy may still be landing in the block (host_block waits for the copies) / kernels still queued may write it
+            # (synchronize moves those back to the pool)
+            (ctx._deferred_quarantine if deferred else ctx._host_quarantine).append((addr, size))
         else:
             lib.sdqh_host_free(None, C.c_void_p(addr))
 
@@ -403,6 +409,10 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.sdqh_synchronize(self.handle))
+        if self._deferred_quarantine:                             # nothing queued before this point can write them any more
+            for addr, size in self._deferred_quarantine:
+                self._host_pool.setdefault(size, []).append(addr)
+            del self._deferred_quarantine[:]
 
     def last_device_ms(self):
         ms = C.c_double()
@@ -610,6 +620,26 @@ class Context:
         n = ng.value
         return out_keys[:n], out_vals[:n, :len(prog.vals)], out_cnt[:n]
 
+    def xgroupby_async(self, nrows, prog, max_groups=MAX_LOOKUP_GROUPS):
+        """Launch K-C small and return at once: collect() -> (keys, values, counts) as xgroupby, to be called after the stream
+        has been synchronised (Context.synchronize; Pending results do it).  What the data decides — too many groups, a negative
+        key — is raised by collect(), not here."""
+        buf = self.host_block(self.lib.sdqh_xgroupby_block_bytes(), deferred=True)
+        self._check(self.lib.sdqh_xgroupby_async(self.handle, C.c_int64(nrows), C.byref(prog.struct()), C.addressof(buf)))
+        self._after_call("xgroupby")
+        nvals = len(prog.vals)
+
+        def collect():
+            out_keys = np.zeros(max_groups, np.int64)
+            out_vals = np.zeros((max_groups, TUPLE_MAX_VALUES), np.float64)
+            out_cnt = np.zeros(max_groups, np.int64)
+            ng = C.c_int32()
+            self._check(self.lib.sdqh_xgroupby_collect(self.handle, C.addressof(buf), C.c_int(nvals), C.c_int(max_groups),
+                                                       _np_ptr(out_keys), _np_ptr(out_vals), _np_ptr(out_cnt), C.byref(ng)))
+            n = ng.value
+            return out_keys[:n], out_vals[:n, :nvals], out_cnt[:n]
+        return collect
+
     def xbuild(self, nrows, prog, key_lo=1, key_hi=0, accumulate=False, nsums=None):
         """nsums: how many sums per entry the later probe-aggregate will add, when the caller's plan knows (else room for all four)."""
         h = C.c_void_p()
@@ -674,6 +704,35 @@ class Context:
         """Wait for the rows of every table_compact_into_block(lazy=True) of this context to be in their arrays."""
         if self.handle is not None:
             self._check(self.lib.sdqh_result_wait(self.handle))
+
+    def table_compact_deferred(self, table, min_hits, capacity_hint, want_payload=True, want_values=True, want_hits=True):
+        """K-F with nothing waited for (sdqh_table_compact_deferred): returns collect() -> (keys, payload, values, hits, n), to be
+        called after Context.synchronize(); a result that did not fit the block sized from capacity_hint is fetched again there
+        (the table must still be alive then: the caller keeps it)."""
+        npay = table.npayload if want_payload else 0
+        nval = TUPLE_MAX_VALUES if want_values and table.accumulate else 0
+        narr = 1 + npay + nval + (1 if want_hits else 0)
+        cap = max(1024, int(capacity_hint))
+        buf = self.host_block(narr * cap * 8 + 64, deferred=True)
+        flat = np.frombuffer(buf, dtype=np.int64, count=narr * cap + 8)
+        cell = flat[narr * cap:narr * cap + 1]
+        flat = flat[:narr * cap].reshape(narr, cap)
+        keys = flat[0]
+        payload = flat[1:1 + npay] if npay else None
+        values = flat[1 + npay:1 + npay + nval].view(np.float64) if nval else None
+        hits = flat[narr - 1] if want_hits else None
+        self._check(self.lib.sdqh_table_compact_deferred(self.handle, table.handle, C.c_int64(min_hits), C.c_int64(cap), _np_ptr(keys),
+                                                         _np_ptr(payload), _np_ptr(values), _np_ptr(hits), _np_ptr(cell)))
+        self._after_call("table_compact")
+
+        def collect():
+            n = int(cell[0])
+            if n < 0:
+                raise SdqhError(ERR_DEVICE, "table_compact_deferred: collected before the stream was synchronised")
+            if n > cap:                                           # the previous run's size was a bad guess: once more, synchronously
+                return self.table_compact_into_block(table, min_hits, n, want_payload, want_values, want_hits)
+            return (keys[:n], None if payload is None else payload[:, :n], None if values is None else values[:, :n], None if hits is None else hits[:n], n)
+        return collect
 
     def table_compact_into_block(self, table, min_hits, capacity_hint, want_payload=True, want_values=True, want_hits=True, lazy=False):
         """One-call K-F: the result arrays are views of an sdqh_host_alloc block sized from
@@ -831,6 +890,8 @@ class Library:
                                          C.c_void_p, C.c_void_p]
         L.sdqh_table_compact_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p]
+        L.sdqh_table_compact_deferred.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]
         L.sdqh_result_wait.argtypes = [C.c_void_p]
         L.sdqh_scan_compact.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_void_p]
@@ -846,6 +907,10 @@ class Library:
         L.sdqh_host_free.argtypes = [C.c_void_p, C.c_void_p]
         L.sdqh_xscan_sum.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sdqh_xgroupby.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sdqh_xgroupby_block_bytes.argtypes = []
+        L.sdqh_xgroupby_block_bytes.restype = C.c_size_t
+        L.sdqh_xgroupby_async.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.sdqh_xgroupby_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sdqh_xbuild.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
         L.sdqh_xkey_set.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.sdqh_xprobe_aggregate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]

@@ -525,6 +525,7 @@ void sdqh_destroy(sdqh_ctx* ctx) {
     for (int i = 0; i < 2; ++i) {
         if (ctx->side[i]) { (void)hipStreamSynchronize(ctx->side[i]); (void)hipStreamDestroy(ctx->side[i]); }
         if (ctx->rs_copied[i]) (void)hipEventDestroy(ctx->rs_copied[i]);
+        if (i == 0 && ctx->rs_ready) (void)hipEventDestroy(ctx->rs_ready);
         if (ctx->rs_dev[i]) (void)hipFree(ctx->rs_dev[i]);
     }
     for (auto& b : ctx->pool) if (b.ptr) (void)hipFree(b.ptr);
@@ -1531,6 +1532,9 @@ static bool in_host_block(sdqh_ctx* ctx, const void* p, size_t bytes) {
     --it;
     return c >= it->first && c + bytes <= it->first + it->second;
 }
+}  // extern "C" (reopened below)
+namespace sdqh_host { bool host_block_contains(sdqh_ctx* ctx, const void* p, size_t bytes) { return in_host_block(ctx, p, bytes); } }
+extern "C" {
 // Runs the compaction and returns the row count in table->compact_n.  Without `dest` the rows go to
 // device buffers cached on the table; with a device-visible `dest` that is large enough the write
 // kernel stores them in the caller's arrays (*direct = true) and nothing is cached.
@@ -1728,6 +1732,74 @@ int sdqh_table_compact_async(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t mi
     HIP_TRY(ctx, hipEventRecord(ctx->rs_copied[b], ctx->side[1]));
     ctx->rs_used[b] = true; ctx->rs_pending = true; ctx->rs_cur = b ^ 1;
     if (out_values) for (int k = nval; k < SDQH_TUPLE_MAX_VALUES; ++k) std::memset(out_values + (size_t)k * (size_t)capacity, 0, (size_t)n * 8);
+    return SDQH_OK;
+}
+
+// K-F with NOTHING waited for: count -> write into the staging buffer -> the whole capacity-sized arrays copied out behind the kernels,
+// the row count landing in *out_n (a cell of the caller's device-visible block, -1 until then).  The caller collects after
+// sdqh_synchronize / sdqh_result_wait; a count above `capacity` means the rows beyond were dropped (fetch again, larger).
+int sdqh_table_compact_deferred(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_hits, int64_t capacity,
+                                int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n) {
+    sdqh_table* table = const_cast<sdqh_table*>(ctable);
+    if (!ctx || !table || !out_n || capacity < 1 || !out_keys) return fail(ctx, SDQH_ERR_INVALID, "table_compact_deferred: bad arguments");
+    if (table->bitmap_only) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_compact_deferred: bitmap-only table");
+    (void)hipSetDevice(ctx->device);
+    const int npay = out_payload ? table->npay : 0, nval = (out_values && table->accumulate) ? table->nv : 0;
+    const size_t cb = (size_t)capacity * 8;
+    char* base = reinterpret_cast<char*>(out_keys);
+    const int narr = 1 + (out_payload ? table->npay : 0) + (out_values ? SDQH_TUPLE_MAX_VALUES : 0) + (out_hits ? 1 : 0);
+    bool contiguous = in_host_block(ctx, base, cb * (size_t)narr) && in_host_block(ctx, out_n, 8);
+    size_t at = cb;
+    if (out_payload) { contiguous = contiguous && reinterpret_cast<char*>(out_payload) == base + at; at += cb * (size_t)table->npay; }
+    if (out_values) { contiguous = contiguous && reinterpret_cast<char*>(out_values) == base + at; at += cb * SDQH_TUPLE_MAX_VALUES; }
+    if (out_hits) { contiguous = contiguous && reinterpret_cast<char*>(out_hits) == base + at; at += cb; }
+    if (!ctx->opt_async_result || !contiguous) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_compact_deferred: the result arrays must be one sdqh_host_alloc block laid out keys | payload | values | hits");
+    if (!ctx->side[1] && hipStreamCreateWithFlags(&ctx->side[1], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->side[1] = nullptr; }
+    if (!ctx->count_host && hipHostMalloc(&ctx->count_host, 256, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->count_host = nullptr; }
+    const int b = ctx->rs_cur;
+    if (!ctx->rs_copied[b] && hipEventCreateWithFlags(&ctx->rs_copied[b], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->rs_copied[b] = nullptr; }
+    if (!ctx->rs_ready && hipEventCreateWithFlags(&ctx->rs_ready, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->rs_ready = nullptr; }
+    if (!ctx->side[1] || !ctx->count_host || !ctx->rs_copied[b] || !ctx->rs_ready) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_compact_deferred: no side stream");
+    const size_t need = cb * (size_t)narr;
+    if (ctx->rs_bytes[b] < need) {
+        if (ctx->rs_used[b]) HIP_TRY(ctx, hipEventSynchronize(ctx->rs_copied[b]));
+        if (ctx->rs_dev[b]) (void)hipFree(ctx->rs_dev[b]);
+        ctx->rs_dev[b] = nullptr; ctx->rs_bytes[b] = 0;
+        const size_t want = std::max<size_t>(need + need / 4, (size_t)4 << 20);
+        if (hipMalloc(&ctx->rs_dev[b], want) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, SDQH_ERR_NOMEM, "table_compact_deferred: out of device memory"); }
+        ctx->rs_bytes[b] = want;
+    }
+    call_begin(ctx);
+    if (int rc = ensure_index(ctx, table)) return rc;
+    if (ctx->rs_used[b]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->rs_copied[b], 0));       // the buffer's last copy has left it
+    DevCompactOut o; std::memset(&o, 0, sizeof(o));
+    char* dev = static_cast<char*>(ctx->rs_dev[b]);
+    size_t off = 0;
+    o.keys = reinterpret_cast<int64_t*>(dev); off += cb;
+    for (int p = 0; p < (out_payload ? table->npay : 0); ++p) { o.pay[p] = reinterpret_cast<int64_t*>(dev + off); off += cb; }
+    if (out_values) { for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) { if (k < nval) o.val[k] = reinterpret_cast<double*>(dev + off); off += cb; } }
+    if (out_hits) { o.hits = reinterpret_cast<int64_t*>(dev + off); off += cb; }
+    o.npay = npay; o.nval = nval;
+    o.counter = reinterpret_cast<unsigned long long*>(static_cast<char*>(ctx->count_host) + 64);
+    *out_n = -1;
+    o.h_counter = reinterpret_cast<unsigned long long*>(out_n);                                      // the kernel's own store of the total, into the caller's block
+    o.host_rows = (uint64_t)capacity; o.bounded = 1;
+    const uint32_t mh = (uint32_t)std::min<int64_t>(std::max<int64_t>(min_hits, 0), 0xFFFFFFFFll);
+    const unsigned seg_grid = (unsigned)((table->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
+    if (!table->seg_kept) { table->seg_kept = static_cast<uint32_t*>(table_alloc(ctx, table, (size_t)table->stage.nseg * 4 + 64)); if (!table->seg_kept) return fail(ctx, SDQH_ERR_NOMEM, "table_compact_deferred: out of device memory"); }
+    table->compact_valid = false;
+    LAUNCH(ctx, "k_compact_count", k_compact_count, seg_grid, table->dev, table->stage, o, mh, table->seg_kept);
+    LAUNCH(ctx, "k_compact_write2", k_compact_write2, seg_grid, table->dev, table->stage, o, mh, table->seg_kept);
+    call_end(ctx);
+    // the copy waits for the kernels by an event, not the host: keys .. the last used value array in one piece, then the hit counts
+    HIP_TRY(ctx, hipEventRecord(ctx->rs_ready, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->side[1], ctx->rs_ready, 0));
+    const int lead = 1 + (out_payload ? table->npay : 0) + nval;
+    HIP_TRY(ctx, hipMemcpyAsync(base, dev, cb * (size_t)lead, hipMemcpyDeviceToHost, ctx->side[1]));
+    if (out_hits) HIP_TRY(ctx, hipMemcpyAsync(out_hits, o.hits, cb, hipMemcpyDeviceToHost, ctx->side[1]));
+    HIP_TRY(ctx, hipEventRecord(ctx->rs_copied[b], ctx->side[1]));
+    ctx->rs_used[b] = true; ctx->rs_pending = true; ctx->rs_cur = b ^ 1;
+    if (out_values) for (int k = nval; k < SDQH_TUPLE_MAX_VALUES; ++k) std::memset(out_values + (size_t)k * (size_t)capacity, 0, cb);
     return SDQH_OK;
 }
 
@@ -2345,8 +2417,8 @@ bool rd_take_clean_lg(sdqh_ctx* ctx) {
 }
 // Fold the workgroups' partials straight into the pinned host block (same layout as the device block: no copy-engine launch
 // after it), resetting the device block's group slots and flags for the next call.
-void launch_groupby_merge_lg_host(sdqh_ctx* ctx, unsigned long long* r_keys, const double* pacc, const int64_t* pcnt, int nparts, int* r_flags) {
-    char* hb = static_cast<char*>(ctx->result_host);
+void launch_groupby_merge_lg_host(sdqh_ctx* ctx, unsigned long long* r_keys, const double* pacc, const int64_t* pcnt, int nparts, int* r_flags, void* host_block) {
+    char* hb = static_cast<char*>(host_block ? host_block : ctx->result_host);
     LAUNCH(ctx, "k_groupby_merge", k_groupby_merge, LG_SLOTS, r_keys, pacc, pcnt, nparts, reinterpret_cast<double*>(hb + LG_SLOTS * 8), reinterpret_cast<int64_t*>(hb + LG_SLOTS * 40),
            reinterpret_cast<unsigned long long*>(hb), r_flags, reinterpret_cast<int*>(hb + LG_SLOTS * 48), 1);
     ctx->rd_clean_ff = (size_t)LG_SLOTS * 8; ctx->rd_clean_zero_off = (int64_t)LG_SLOTS * 48;

@@ -98,6 +98,7 @@ struct sdqh_ctx {
     void* rs_dev[2] = {nullptr, nullptr}; size_t rs_bytes[2] = {0, 0};
     hipEvent_t rs_copied[2] = {nullptr, nullptr}; bool rs_used[2] = {false, false};
     int rs_cur = 0; bool rs_pending = false;
+    hipEvent_t rs_ready = nullptr;      // sdqh_table_compact_deferred: the compaction kernels are done (the side stream's copy waits for it, not the host)
     // sync_stream: a 32-bit sequence number written by the stream itself into pinned memory (hipStreamWriteValue32) and polled by
     // the host, instead of the runtime's wait (which sleeps on an interrupt: tens of microseconds per query on a 0.2 - 0.5 ms query)
     volatile uint32_t* sync_flag = nullptr; uint32_t sync_seq = 0; int opt_spin_sync = 1;
@@ -202,7 +203,8 @@ void fill_regions(sdqh_ctx* ctx, void* const* ptr, const size_t* bytes, const un
 void launch_sum_partials(sdqh_ctx* ctx, const double* partial, int nparts, double* out);
 void launch_groupby_merge_lg(sdqh_ctx* ctx, const unsigned long long* gkeys, const double* pacc, const int64_t* pcnt, int nparts, double* out_acc, int64_t* out_cnt);
 bool rd_take_clean_lg(sdqh_ctx* ctx);
-void launch_groupby_merge_lg_host(sdqh_ctx* ctx, unsigned long long* r_keys, const double* pacc, const int64_t* pcnt, int nparts, int* r_flags);
+void launch_groupby_merge_lg_host(sdqh_ctx* ctx, unsigned long long* r_keys, const double* pacc, const int64_t* pcnt, int nparts, int* r_flags, void* host_block = nullptr);
+bool host_block_contains(sdqh_ctx* ctx, const void* p, size_t bytes);      // inside a block from sdqh_host_alloc?
 // small direct-layout tables: the rank -> row array is allocated up front; *ptr / *bytes = a region to fill with 0xFF (null: none)
 int prefill_direct_refs(sdqh_ctx* ctx, sdqh_table* tb, void** ptr, size_t* bytes);   // regions (<= 2) to fill with 0xFF; returns their number
 

@@ -1184,10 +1184,9 @@ int sdqh_xscan_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, doubl
     return SDQH_OK;
 }
 
-int sdqh_xgroupby(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int max_groups,
-                  int64_t* out_keys, double* out_values, int64_t* out_counts, int32_t* out_ngroups) {
-    if (!ctx || nrows < 0 || max_groups < 1 || max_groups > SDQH_MAX_LOOKUP_GROUPS || !out_ngroups) return fail(ctx, SDQH_ERR_INVALID, "xgroupby: bad arguments");
-    if (!ctx->compile_only) (void)hipSetDevice(ctx->device);
+// K-C small, launched: the group table of the whole call lands in `host_block` (device-visible host memory laid out like the device
+// result block: keys[LG_SLOTS] | acc[LG_SLOTS][4] | cnt[LG_SLOTS] | flags) when the stream gets there; nothing is waited for.
+static int xgroupby_launch(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, void* host_block) {
     XInfo x;
     if (int rc = analyse(ctx, nrows, prog, SDQH_TUPLE_MAX_VALUES, true, true, &x)) return rc;
     // a key over a dense small range (known from the columns' own ranges): every lane keeps its groups' sums in LDS cells of its own
@@ -1206,10 +1205,7 @@ int sdqh_xgroupby(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int ma
     // result block in ctx->result_dev: gkeys[LG_SLOTS] | acc[LG_SLOTS][4] | cnt[LG_SLOTS] | flags
     char* rd = static_cast<char*>(ctx->result_dev);
     unsigned long long* r_keys = reinterpret_cast<unsigned long long*>(rd);
-    double* r_acc = reinterpret_cast<double*>(rd + LG_SLOTS * 8);
-    int64_t* r_cnt = reinterpret_cast<int64_t*>(rd + LG_SLOTS * 40);
     int* r_flags = reinterpret_cast<int*>(rd + LG_SLOTS * 48);
-    const size_t rbytes = LG_SLOTS * 48 + 8;
     static_assert(LG_SLOTS * 48 + 8 <= RESULT_BYTES, "result block too small");
     XArgs a;
     if (int rc = fill_xargs(ctx, x, &a, r_flags, klo, khi)) return rc;
@@ -1229,14 +1225,16 @@ int sdqh_xgroupby(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int ma
         rc = launch(ctx, fn, launch_label(SINK_GROUP, x.direct, x.tight), a, sa, nrows, g);
     }
     if (!rc) {
-        launch_groupby_merge_lg_host(ctx, r_keys, pacc, pcnt, (int)g.grid, r_flags);       // writes the pinned host block, leaves the device block clean
+        launch_groupby_merge_lg_host(ctx, r_keys, pacc, pcnt, (int)g.grid, r_flags, host_block);       // writes the pinned host block, leaves the device block clean
         call_end(ctx);
-        rc = sync_stream(ctx);
     }
-    (void)r_acc; (void)r_cnt; (void)rbytes;
-    pool_free(ctx, blob);
-    if (rc) return rc;
-    const char* h = static_cast<const char*>(ctx->result_host);
+    pool_free(ctx, blob);                                   // stream order: whoever gets the block next runs after the merge
+    return rc;
+}
+
+// The groups of a finished call, out of its host block: ascending keys, at most max_groups.
+static int xgroupby_collect(sdqh_ctx* ctx, const void* host_block, int nvals, int max_groups, int64_t* out_keys, double* out_values, int64_t* out_counts, int32_t* out_ngroups) {
+    const char* h = static_cast<const char*>(host_block);
     const int flags = *reinterpret_cast<const int*>(h + LG_SLOTS * 48);
     if (flags & 2) return fail(ctx, SDQH_ERR_UNSUPPORTED, "xgroupby: negative group key (or a key outside the range its columns span)");
     const unsigned long long* hk = reinterpret_cast<const unsigned long long*>(h);
@@ -1250,11 +1248,36 @@ int sdqh_xgroupby(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int ma
     for (int i = 0; i < ng; ++i) {
         const int s = order[(size_t)i];
         if (out_keys) out_keys[i] = (int64_t)hk[s];
-        if (out_values) for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) out_values[i * SDQH_TUPLE_MAX_VALUES + k] = k < prog->nvals ? ha[s * 4 + k] : 0.0;
+        if (out_values) for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) out_values[i * SDQH_TUPLE_MAX_VALUES + k] = k < nvals ? ha[s * 4 + k] : 0.0;
         if (out_counts) out_counts[i] = hc[s];
     }
     *out_ngroups = ng;
     return SDQH_OK;
+}
+
+int sdqh_xgroupby(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int max_groups,
+                  int64_t* out_keys, double* out_values, int64_t* out_counts, int32_t* out_ngroups) {
+    if (!ctx || nrows < 0 || max_groups < 1 || max_groups > SDQH_MAX_LOOKUP_GROUPS || !out_ngroups) return fail(ctx, SDQH_ERR_INVALID, "xgroupby: bad arguments");
+    if (!ctx->compile_only) (void)hipSetDevice(ctx->device);
+    if (int rc = xgroupby_launch(ctx, nrows, prog, nullptr)) return rc;
+    if (int rc = sync_stream(ctx)) return rc;
+    return xgroupby_collect(ctx, ctx->result_host, prog->nvals, max_groups, out_keys, out_values, out_counts, out_ngroups);
+}
+
+size_t sdqh_xgroupby_block_bytes(void) { return ((size_t)LG_SLOTS * 48 + 8 + 63) & ~(size_t)63; }
+
+int sdqh_xgroupby_async(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, void* result_block) {
+    if (!ctx || nrows < 0 || !prog || !result_block) return fail(ctx, SDQH_ERR_INVALID, "xgroupby_async: bad arguments");
+    if (ctx->compile_only) return fail(ctx, SDQH_ERR_UNSUPPORTED, "xgroupby_async: compile-only context");
+    if (!host_block_contains(ctx, result_block, sdqh_xgroupby_block_bytes())) return fail(ctx, SDQH_ERR_INVALID, "xgroupby_async: the result block must come from sdqh_host_alloc (sdqh_xgroupby_block_bytes() bytes)");
+    (void)hipSetDevice(ctx->device);
+    return xgroupby_launch(ctx, nrows, prog, result_block);
+}
+
+int sdqh_xgroupby_collect(sdqh_ctx* ctx, const void* result_block, int nvals, int max_groups,
+                          int64_t* out_keys, double* out_values, int64_t* out_counts, int32_t* out_ngroups) {
+    if (!ctx || !result_block || nvals < 0 || nvals > SDQH_TUPLE_MAX_VALUES || max_groups < 1 || max_groups > SDQH_MAX_LOOKUP_GROUPS || !out_ngroups) return fail(ctx, SDQH_ERR_INVALID, "xgroupby_collect: bad arguments");
+    return xgroupby_collect(ctx, result_block, nvals, max_groups, out_keys, out_values, out_counts, out_ngroups);
 }
 
 int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t key_lo, int64_t key_hi, int accumulate, sdqh_table** out) {

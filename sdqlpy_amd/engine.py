@@ -21,7 +21,7 @@ import numpy as np
 from . import abi, build
 from .frontend import (And, Bin, Call, Cmp, Col, Const, Contains, FinalizeOp, HostDictOp, IfElse, Lookup, Not, Or, PayloadField, RecordCons,
                        ScalarExprOp, ScalarField, ScanOp, SelectKeysOp, StrIn, UnsupportedQuery, WrapScalarOp)
-from .result import DictResult, ResultSet, TextRefs, decode_text
+from .result import DeferredResultSet, Pending, DictResult, ResultSet, TextRefs, decode_text
 
 # value-tuple vocabulary: canonical shape of the whole value record -> (ABI shape, index of the COUNT field or None)
 TUPLE_SHAPES = {
@@ -98,6 +98,8 @@ class Engine:
         # x_tight), which the fixed-shape kernels' 4-byte twins cannot.  The HIP library only: the CPU implementation interprets programs.
         # K-F rows of a query's RESULT reach the host behind the call (sdqh_table_compact_async); the ResultSet waits on first read
         self.lazy_results = os.environ.get("SDQLPY_AMD_LAZY_RESULTS", "1") != "0"
+        # a plan's last device call launched without being waited for; the result finishes the plan when first looked at (PreparedPlan.run)
+        self.deferred_results = os.environ.get("SDQLPY_AMD_DEFERRED_RESULTS", "1") != "0" and ctx.library.backend_name() == "hip-gfx950"
         self.dict_programs = os.environ.get("SDQLPY_AMD_DICT_PROGRAMS", "1") != "0"      # sums over result dictionaries as device loops (xplan.prepare_dict_scan)
         self.stream_programs = os.environ.get("SDQLPY_AMD_STREAM_PROGRAMS", "1") != "0" and ctx.library.backend_name() == "hip-gfx950"
         # ... and so do the loops that aggregate into the entry a probe matches ("probe": Q3's lineitem loop — the specialised kernel
@@ -249,9 +251,16 @@ class BuiltTable:
     def layout_sig(self):
         """What a loop that looks this table up compiles against: field -> slot, slot dtypes, key shape, and WHICH arrays
         decode its slots (identities).  Closures cache their marshalled call per signature of the tables they look up."""
-        return (tuple(self.val_fields), tuple(str(d) for d in self.payload_dtypes), None if self.key_parts is None else tuple(self.key_parts),
+        return (tuple(self.val_fields), self.dtype_sig(), None if self.key_parts is None else tuple(self.key_parts),
                 tuple(sorted((k, id(v)) for k, v in self.decoders.items())), tuple(sorted((k, id(v)) for k, v in self.field_decoders.items())),
                 id(self.key_decoder), self.table.npayload, self.table.accumulate)
+
+    def dtype_sig(self):
+        """The payload dtypes as strings, made once (str(np.dtype) costs a microsecond, and every run of every loop that looks the table up asks)."""
+        sig = self.__dict__.get("_dtype_sig")
+        if sig is None or sig[0] is not self.payload_dtypes:
+            sig = self.__dict__["_dtype_sig"] = (self.payload_dtypes, tuple(str(np.dtype(d)) for d in self.payload_dtypes))
+        return sig[1]
 
     def slot_of(self, field):
         """"key" | payload index of a value field, or None."""
@@ -1331,7 +1340,7 @@ def _lazy_rows_ok(bt, out_key_fields, fields_of, top):
     return all(src == "key" or bt.decoder_of(fields_of.get(f), src) is None for f, src in out_key_fields)
 
 
-def _materialize(eng, value, env, hint_key=None, top=None, lazy_ok=False):
+def _materialize(eng, value, env, hint_key=None, top=None, lazy_ok=False, defer=False):
     """Device-resident intermediate -> DictResult on the host (K-F's input).  With `top`, the
     DictResult carries `.ordered = True` when the device already applied ORDER BY / LIMIT."""
     if isinstance(value, DictResult):
@@ -1343,7 +1352,22 @@ def _materialize(eng, value, env, hint_key=None, top=None, lazy_ok=False):
         spec = _device_sort_spec(bt, out_key_fields, vnames, count_idx, top[1]) if top is not None and entry_is_group and bt.key_radix is None else None
         fields_of = bt.agg_fields
         lazy = lazy_ok and bool(getattr(eng, "lazy_results", False)) and _lazy_rows_ok(bt, out_key_fields, fields_of, top)
-        keys, payload, values, hits, ordered = _fetch_entries(eng, bt.table, 1, hint_key, top, spec, want_hits=count_idx is not None or (spec is not None and any(s[0] == abi.SORT_HITS for s in spec)), lazy=lazy)
+        want_hits = count_idx is not None or (spec is not None and any(s[0] == abi.SORT_HITS for s in spec))
+        if lazy and defer:
+            # the plan's last device call, launched and not waited for — not even for the row count (PreparedPlan.run): the block is
+            # sized from the previous run of this step; a result that outgrew it is noticed when it is collected and the plan re-run
+            hint = eng.compact_hints.get(hint_key)
+            collect = eng.ctx.table_compact_deferred(bt.table, 1, 4096 if hint is None else hint + hint // 8 + 1024, want_hits=want_hits)
+
+            def resolve():
+                keys, payload, values, hits, n = collect()
+                eng.compact_hints[hint_key] = n
+                d = DictResult([(f, keys if src == "key" else _decode_column(payload[src], None, bt.payload_dtypes[src])) for f, src in out_key_fields],
+                               _value_arrays(vnames, count_idx, [values[j] for j in range(nv)], hits, bt.int_values), key_is_record, val_is_record)
+                d.ordered = False
+                return d
+            return Pending(resolve)
+        keys, payload, values, hits, ordered = _fetch_entries(eng, bt.table, 1, hint_key, top, spec, want_hits=want_hits, lazy=lazy)
         values = [values[j] for j in range(nv)]
         if getattr(bt, "key_radix", None) is not None and out_key_fields == [(bt.key_name, "key")]:    # several key fields in one mixed-radix integer
             from . import xplan
@@ -1471,7 +1495,14 @@ def _finalize(eng, op, env, top=None):
             elif len(side) == 1:
                 names[name] = side[0]
         inner_top = (top[0], [(names.get(n, n), d) for n, d in top[1]])
-    d = _materialize(eng, src_val, env, hint_key=id(op), top=inner_top, lazy_ok=True)     # (only a ResultSet is made of it: that waits for the rows itself)
+    d = _materialize(eng, src_val, env, hint_key=id(op), top=inner_top, lazy_ok=True, defer=op.out in env.get("__defer__", ()))     # (only a ResultSet is made of it: that waits for the rows itself)
+    if isinstance(d, Pending):                              # launched, not waited for: the shaping below runs when it is collected
+        return Pending(lambda: _shape_result(op, d.resolve(), top))
+    return _shape_result(op, d, top)
+
+
+def _shape_result(op, d, top):
+    """K-F's last mile: the (key, value) sides of a DictResult as the record set the plan's reshaping sum names."""
     if op.fields is None:                                   # p[0].concat(p[1])
         fields = d.key_fields + d.val_fields
     else:
@@ -1711,6 +1742,7 @@ class PreparedPlan:
         looked_up = _looked_up(plan)
         compared = _compared_lookups(plan)
         self.steps = []
+        self.defer_names = self._defer_names(plan)
         for op in plan.ops:
             if isinstance(op, ScanOp):
                 self.steps.append((op.out, _prepare_scan(eng, op, tables[op.table], accumulate_into, op.out in member_only, op.out in looked_up,
@@ -1727,16 +1759,32 @@ class PreparedPlan:
             elif isinstance(op, WrapScalarOp):
                 self.steps.append((op.out, (lambda env, op=op: ResultSet([n for n, _ in op.fields], [np.array([_eval_scalar_expr(e, env, op.lineno)]) for _, e in op.fields]))))
 
-    def run(self, top=None):
-        """top = (k, [(result column, "asc" | "desc"), ...]): ORDER BY ... LIMIT k on the final K-F."""
+    @staticmethod
+    def _defer_names(plan):
+        """The steps whose device call may be launched without being waited for: the plan's LAST table loop when it is an aggregation
+        that only the final reshaping sum reads, and that sum itself (its K-F) — nothing else of the plan runs after them."""
+        ops = plan.ops
+        if len(ops) >= 2 and isinstance(ops[-1], FinalizeOp) and ops[-1].out == plan.result and ops[-1].source == ops[-2].out \
+                and isinstance(ops[-2], ScanOp) and ops[-2].kind == "dict" and not ops[-2].unique:
+            return frozenset([ops[-2].out, ops[-1].out])
+        return frozenset()
+
+    def run(self, top=None, deferred=True):
+        """top = (k, [(result column, "asc" | "desc"), ...]): ORDER BY ... LIMIT k on the final K-F.
+        deferred: the plan's last device call may be launched without being waited for (Engine.deferred_results): the result is
+        then a DeferredResultSet that finishes the plan when it is first looked at."""
         env = {}
         if top is not None:
             env["__top__"] = (int(top[0]), [(str(n), str(d)) for n, d in top[1]])
             if any(d not in ("asc", "desc") for _, d in env["__top__"][1]):
                 raise ValueError("top: directions are 'asc' or 'desc'")
+        if deferred and top is None and self.defer_names and getattr(self.eng, "deferred_results", False) and not self.eng.ctx._profiling:
+            env["__defer__"] = self.defer_names
         try:
-            for out, step in self.steps:
+            for i, (out, step) in enumerate(self.steps):
                 env[out] = step(env)
+                if isinstance(env[out], Pending):
+                    return self._deferred(env, i, top)
             res = env[self.plan.result]
             if isinstance(res, (BuiltTable, tuple)):
                 res = _materialize(self.eng, res, env, hint_key=id(self.plan))
@@ -1751,6 +1799,40 @@ class PreparedPlan:
             for v in env.values():                           # release device tables of this run
                 if isinstance(v, BuiltTable):
                     v.table.free()
+
+
+    def _deferred(self, env, at, top):
+        """The steps after `at` (host-side: they only reshape) and the hand-over, as the thunk of a DeferredResultSet.  The tables of
+        the run are released by the caller now — their memory is reused in stream order, behind the kernels still queued."""
+        pending, out = env[at_name(self, at)], at_name(self, at)
+        host_env = {k: v for k, v in env.items() if not isinstance(v, BuiltTable)}
+        rest = self.steps[at + 1:]
+        eng, plan = self.eng, self.plan
+
+        def thunk():
+            eng.ctx.synchronize()
+            try:
+                host_env[out] = pending.resolve()
+                for name, step in rest:
+                    host_env[name] = step(host_env)
+                res = host_env[plan.result]
+                if isinstance(res, DictResult) and not res.val_fields:
+                    res = ResultSet([n for n, _ in res.key_fields], [a for _, a in res.key_fields])
+                if not isinstance(res, ResultSet):
+                    raise UnsupportedQuery("a deferred plan must end in a result set")
+                return res
+            except (abi.SdqhError, UnsupportedQuery) as exc:
+                if isinstance(exc, abi.SdqhError) and exc.code not in (abi.ERR_OVERFLOW, abi.ERR_UNSUPPORTED):
+                    raise
+                # what only the data could decide (more groups than the kernel's table, a result that outgrew its block): the
+                # plan once more, every call waited for — its own fall-backs take it from there
+                res = self.run(top, deferred=False)
+                return res
+        return DeferredResultSet(thunk)
+
+
+def at_name(prepared, i):
+    return prepared.steps[i][0]
 
 
 def execute_plan(eng, plan, args, top=None):

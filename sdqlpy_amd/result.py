@@ -92,6 +92,11 @@ class ResultSet:
             ready, self._ready = self._ready, None
             ready()
 
+    def wait(self):
+        """Block until every row is on the host (a no-op for results that are complete already)."""
+        self._wait()
+        return self
+
     @property
     def arrays(self):
         """One numpy array per column (text columns of a large result are decoded on first use)."""
@@ -224,3 +229,47 @@ class DictResult:
 
     def __str__(self):
         return str(self.to_dict())
+
+
+class Pending:
+    """The outcome of a plan step whose device call was launched and not waited for: resolve() — after the context has been
+    synchronised — collects it and returns what the step would have returned (engine.PreparedPlan.run)."""
+    __slots__ = ("resolve",)
+
+    def __init__(self, resolve):
+        self.resolve = resolve
+
+
+class DeferredResultSet(ResultSet):
+    """A result set whose query has been LAUNCHED but not waited for: the plan's last device call was queued and the call returned
+    (engine.PreparedPlan.run with Engine.deferred_results) — the host goes on to queue the next query while this one runs, as a CUDA /
+    HIP program overlaps launches with execution.  Everything that looks at the result — its size, its columns, its rows —
+    first runs `thunk`, which synchronises the context, collects the device's output and finishes the plan's host-side steps;
+    errors the data decides (more groups than the kernel holds ...) surface there, where the plan is re-run synchronously on its
+    other path.  The reference's result object defers its conversion in the same spirit (src/sdqlpy/fastd.py:31-51)."""
+
+    def __init__(self, thunk):
+        self._thunk = thunk
+
+    def _force(self):
+        thunk = self.__dict__.pop("_thunk", None)
+        if thunk is not None:
+            rs = thunk()
+            if not isinstance(rs, ResultSet):
+                raise TypeError("a deferred query finished with %r, not a result set" % type(rs).__name__)
+            if isinstance(rs, DeferredResultSet):
+                rs._force()
+            self.__dict__.update(rs.__dict__)
+
+    def __getattr__(self, name):                                 # only reached for attributes not set yet: columns, _cols, _n, _ready
+        if name == "_thunk" or "_thunk" not in self.__dict__:
+            raise AttributeError(name)
+        self._force()
+        return getattr(self, name)
+
+    def wait(self):
+        """Finish the query now (the result is complete and on the host when this returns)."""
+        self._force()
+        self._wait()
+        return self
+

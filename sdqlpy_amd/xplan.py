@@ -18,7 +18,7 @@ import numpy as np
 from . import abi
 from .frontend import (And, Bin, Call, Cmp, Col, Const, Contains, IfElse, Lookup, Not, Or, PayloadField, RecordCons,
                        ScalarField, StrIn, UnsupportedQuery, WholeKey)
-from .result import Dictionary, DictResult, ResultSet, TextRefs, decode_text
+from .result import Dictionary, DictResult, Pending, ResultSet, TextRefs, decode_text
 
 MAX_CODE_SET = 8          # a text predicate on coded values becomes at most this many equality tests (or one range)
 
@@ -454,7 +454,7 @@ def _slot_range(bt, slot):
 
 
 def _table_signature(bt):
-    return (tuple(bt.val_fields), tuple(str(np.dtype(d)) for d in bt.payload_dtypes), bt.key_parts is not None,
+    return (tuple(bt.val_fields), bt.dtype_sig(), bt.key_parts is not None,
             tuple(sorted((k, id(v)) for k, v in bt.decoders.items())), tuple(sorted((k, id(v)) for k, v in bt.field_decoders.items())),
             None if bt.agg is None else (tuple(bt.agg[1]), bt.agg[2], bt.agg[5]), bt.table.npayload, bool(bt.table.accumulate),
             None if getattr(bt, "key_radix", None) is None else tuple(bt.key_radix[1]))
@@ -773,6 +773,29 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False, sm
         key_names = [nm or (e.name if isinstance(e, Col) else "key%d" % i) for i, (nm, e) in enumerate(key_fields)]
         return cb, cp, pkid, count_idx, bounds, key_names, (flat[0].dec if len(flat) == 1 else None), len(flat) == 2
 
+    def groups_result(c, parts, radix, count_idx, keys, vals, cnts):
+        """The groups of a finished xgroupby as a DictResult (decoded key fields, value columns)."""
+        # the same handful of group keys comes back run after run: their decoded fields are kept (a dozen small numpy calls otherwise)
+        kcache = state.get("kf_cache")
+        kbytes = keys.tobytes()
+        if kcache is not None and kcache[0] is c and kcache[1] == kbytes:
+            kf = [(nm, a.copy() if isinstance(a, np.ndarray) else a) for nm, a in kcache[2]]
+        else:
+            kf = _decode_radix(keys, [(nm or "key%d" % i, vs, kind) for i, (nm, vs, kind) in enumerate(parts)], radix)
+            state["kf_cache"] = (c, kbytes, [(nm, a.copy() if isinstance(a, np.ndarray) else a) for nm, a in kf])
+        vf, at = [], 0
+        for i, nm in enumerate(vnames):
+            if count_idx is not None and i == count_idx:
+                vf.append((nm, np.asarray(cnts, np.int64)))
+            else:
+                col = np.ascontiguousarray(vals[:, at]); at += 1
+                vf.append((nm, np.rint(col).astype(np.int64) if nm in state.get("int_values", ()) else col))
+        d = DictResult(kf, vf, key_is_record, val_is_record)
+        if any(kind[0] == "int" and kind[1] is not None for _, _, kind in parts):
+            from .engine import _merge_equal_keys
+            d = _merge_equal_keys(d)                          # two references may decode to the same text
+        return d
+
     def dense_domain(st):
         """(resident column lo..hi, span) when the group key is a single integer over a range much smaller than the row count (Q13: 1.5 M
         customer keys of 15 M orders), else False.  Every key of the range then gets an entry up front (a build over lo..hi: increasing
@@ -828,27 +851,12 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False, sm
                     st = state["c"] = compile_groups(env)
                 c, parts, radix, count_idx = st
                 c.bind(env)
-                keys, vals, cnts = ctx.xgroupby(htab.nrows, c.P)
-                # the same handful of group keys comes back run after run: their decoded fields are kept (a dozen small numpy calls otherwise)
-                kcache = state.get("kf_cache")
-                kbytes = keys.tobytes()
-                if kcache is not None and kcache[0] is c and kcache[1] == kbytes:
-                    kf = [(nm, a.copy() if isinstance(a, np.ndarray) else a) for nm, a in kcache[2]]
-                else:
-                    kf = _decode_radix(keys, [(nm or "key%d" % i, vs, kind) for i, (nm, vs, kind) in enumerate(parts)], radix)
-                    state["kf_cache"] = (c, kbytes, [(nm, a.copy() if isinstance(a, np.ndarray) else a) for nm, a in kf])
-                vf, at = [], 0
-                for i, nm in enumerate(vnames):
-                    if count_idx is not None and i == count_idx:
-                        vf.append((nm, np.asarray(cnts, np.int64)))
-                    else:
-                        col = np.ascontiguousarray(vals[:, at]); at += 1
-                        vf.append((nm, np.rint(col).astype(np.int64) if nm in state.get("int_values", ()) else col))
-                d = DictResult(kf, vf, key_is_record, val_is_record)
-                if any(kind[0] == "int" and kind[1] is not None for _, _, kind in parts):
-                    from .engine import _merge_equal_keys
-                    d = _merge_equal_keys(d)                          # two references may decode to the same text
-                return d
+                if op.out in env.get("__defer__", ()) and not isinstance(htab, DictTable):
+                    # the plan's last device call: launched, not waited for (engine.PreparedPlan.run finishes the plan when the
+                    # result is first looked at; what the data decides — too many groups — is raised there and the plan re-run)
+                    collect = ctx.xgroupby_async(htab.nrows, c.P)
+                    return Pending(lambda: groups_result(c, parts, radix, count_idx, *collect()))
+                return groups_result(c, parts, radix, count_idx, *ctx.xgroupby(htab.nrows, c.P))
             except abi.SdqhError as exc:
                 if exc.code != abi.ERR_OVERFLOW:
                     raise

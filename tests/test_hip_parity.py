@@ -391,6 +391,31 @@ def test_dense_group_domain_keeps_unreached_keys_out_of_the_dictionary(hip_engin
     hip_engine.clear()
 
 
+def test_results_launched_and_not_waited_for(hip_engine, golden, golden_more, golden_wide):
+    """Engine.deferred_results on the device: sdqh_xgroupby_async / _collect and sdqh_table_compact_deferred — the plan's last call
+    queued, the host free to queue the next query — against the waited-for results of the same plans and the reference's; queries
+    launched back to back and read in reverse, results dropped unread, a group table that overflows found at collection; then the
+    timed step of the bench at SF 1: three queries launched, then their results read."""
+    n, seen = helpers.deferred_result_cases(hip_engine, [golden, golden_more, golden_wide], REL)
+    assert n >= 40 and {"q1", "q3", "q5"} <= seen, (n, seen)
+    from sdqlpy_amd.result import DeferredResultSet
+    qs = ("q1", "q3", "q5")
+    db = tpch.generate(1.0, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+    plans = {q: frontend.lower_function(Q.QUERIES[q]) for q in qs}
+    hip_engine.deferred_results = False
+    want = {q: engine.execute_plan(hip_engine, plans[q], [db[t] for t in Q.QUERY_TABLES[q]]).rows() for q in qs}
+    hip_engine.deferred_results = True
+    try:
+        for _ in range(4):
+            rs = [engine.execute_plan(hip_engine, plans[q], [db[t] for t in Q.QUERY_TABLES[q]]) for q in qs]
+            assert all(isinstance(r, DeferredResultSet) for r in rs)
+            for q, r in zip(qs, rs):
+                helpers.assert_rows_match(r.wait().rows(), want[q], REL, "deferred step " + q)
+    finally:
+        hip_engine.deferred_results = hip_engine.ctx.library.backend_name() == "hip-gfx950"
+    hip_engine.clear()
+
+
 def test_every_golden_vector_through_specialised_kernels(hip_engine, golden, golden_more, golden_wide):
     """All reference results again with every table loop forced through a run-time specialised kernel
     (no ahead-of-time kernel shape): the general path must agree with the tuned one on its home turf."""

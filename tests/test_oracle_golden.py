@@ -142,3 +142,14 @@ def test_dense_group_domain_keeps_unreached_keys_out_of_the_dictionary(oracle_li
         helpers.dense_domain_case(eng, ncust=70000, nord=400000, seed=6)
     finally:
         eng.close()
+
+
+def test_results_launched_and_not_waited_for(oracle_lib, golden, golden_more, golden_wide):
+    """Engine.deferred_results on the CPU implementation of the ABI (its async calls compute at once: the planner's side — Pending
+    steps, the deferred tail of a plan, the re-run when the data decides otherwise, result blocks in quarantine — is what runs here)."""
+    eng = engine.Engine(oracle_lib.context(threads=1))
+    try:
+        n, seen = helpers.deferred_result_cases(eng, [golden, golden_more, golden_wide])
+        assert n >= 40 and {"q3", "q7", "q12", "q13"} <= seen, (n, seen)     # (q1 / q5 end in fixed-shape calls on this backend; on the GPU they are programs)
+    finally:
+        eng.close()

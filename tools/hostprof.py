@@ -17,14 +17,14 @@ sdqlpy_init(3, 1, device=0)
 db = tpch.generate(10, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
 for q in qs:
     for _ in range(5):
-        Q.run(q, db, top=Q.TPCH_ORDER[q] if TOP else None)
+        (lambda r: r.wait() if hasattr(r, 'wait') else r)(Q.run(q, db, top=Q.TPCH_ORDER[q] if TOP else None))
     t0 = time.perf_counter()
     for _ in range(100):
-        Q.run(q, db, top=Q.TPCH_ORDER[q] if TOP else None)
+        (lambda r: r.wait() if hasattr(r, 'wait') else r)(Q.run(q, db, top=Q.TPCH_ORDER[q] if TOP else None))
     print(q, "mean wall ms", (time.perf_counter() - t0) * 10)
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(100):
-        Q.run(q, db, top=Q.TPCH_ORDER[q] if TOP else None)
+        (lambda r: r.wait() if hasattr(r, 'wait') else r)(Q.run(q, db, top=Q.TPCH_ORDER[q] if TOP else None))
     pr.disable()
     pstats.Stats(pr).sort_stats("tottime").print_stats(14)

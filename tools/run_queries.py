@@ -23,7 +23,9 @@ def main():
     db = tpch.generate(args.sf, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
     for _ in range(args.iters):
         for q in qs:
-            Q.run(q, db)
+            r = Q.run(q, db)
+            if hasattr(r, "wait"):
+                r.wait()                                 # (a query may return with its last call queued: finished here, run by run)
 
 
 if __name__ == "__main__":

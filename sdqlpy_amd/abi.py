@@ -707,8 +707,8 @@ class Context:
 
     def table_compact_deferred(self, table, min_hits, capacity_hint, want_payload=True, want_values=True, want_hits=True):
         """K-F with nothing waited for (sdqh_table_compact_deferred): returns collect() -> (keys, payload, values, hits, n), to be
-        called after Context.synchronize(); a result that did not fit the block sized from capacity_hint is fetched again there
-        (the table must still be alive then: the caller keeps it)."""
+        called after Context.synchronize(); a result that did not fit the block sized from capacity_hint raises
+        SdqhError(ERR_OVERFLOW) there with .needed = its row count (the caller runs the step again, waited for)."""
         npay = table.npayload if want_payload else 0
         nval = TUPLE_MAX_VALUES if want_values and table.accumulate else 0
         narr = 1 + npay + nval + (1 if want_hits else 0)
@@ -729,8 +729,10 @@ class Context:
             n = int(cell[0])
             if n < 0:
                 raise SdqhError(ERR_DEVICE, "table_compact_deferred: collected before the stream was synchronised")
-            if n > cap:                                           # the previous run's size was a bad guess: once more, synchronously
-                return self.table_compact_into_block(table, min_hits, n, want_payload, want_values, want_hits)
+            if n > cap:                                           # the block was sized from a bad guess: the rows beyond it were dropped
+                exc = SdqhError(ERR_OVERFLOW, "table_compact_deferred: %d rows, room for %d" % (n, cap))
+                exc.needed = n
+                raise exc
             return (keys[:n], None if payload is None else payload[:, :n], None if values is None else values[:, :n], None if hits is None else hits[:n], n)
         return collect
 

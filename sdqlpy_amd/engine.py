@@ -115,6 +115,8 @@ class Engine:
         self.ctx.close()
 
     def clear(self):
+        if self._columns and self.ctx.handle is not None:
+            self.ctx.synchronize()                              # queries launched and not waited for may still read the columns
         for _, col in self._columns.values():
             col.free()
         self._columns.clear()
@@ -163,6 +165,8 @@ class Engine:
             arrays = list(what.getContainer().get("data", []))
         else:
             arrays = [what]
+        if any(id(arr) in self._columns for arr in arrays) and self.ctx.handle is not None:
+            self.ctx.synchronize()                              # (queries launched and not waited for may still read them)
         for arr in arrays:
             key = id(arr)
             hit = self._columns.pop(key, None)
@@ -1357,16 +1361,27 @@ def _materialize(eng, value, env, hint_key=None, top=None, lazy_ok=False, defer=
             # the plan's last device call, launched and not waited for — not even for the row count (PreparedPlan.run): the block is
             # sized from the previous run of this step; a result that outgrew it is noticed when it is collected and the plan re-run
             hint = eng.compact_hints.get(hint_key)
-            collect = eng.ctx.table_compact_deferred(bt.table, 1, 4096 if hint is None else hint + hint // 8 + 1024, want_hits=want_hits)
+            try:
+                collect = eng.ctx.table_compact_deferred(bt.table, 1, 4096 if hint is None else hint + hint // 8 + 1024, want_hits=want_hits)
+            except abi.SdqhError as exc:
+                if exc.code != abi.ERR_UNSUPPORTED:               # (the option "async_result" is off: the waited-for call below)
+                    raise
+                collect = None
 
             def resolve():
-                keys, payload, values, hits, n = collect()
+                try:
+                    keys, payload, values, hits, n = collect()
+                except abi.SdqhError as exc:
+                    if exc.code == abi.ERR_OVERFLOW and getattr(exc, "needed", None):
+                        eng.compact_hints[hint_key] = exc.needed     # (the next launch sizes its block from this)
+                    raise
                 eng.compact_hints[hint_key] = n
                 d = DictResult([(f, keys if src == "key" else _decode_column(payload[src], None, bt.payload_dtypes[src])) for f, src in out_key_fields],
                                _value_arrays(vnames, count_idx, [values[j] for j in range(nv)], hits, bt.int_values), key_is_record, val_is_record)
                 d.ordered = False
                 return d
-            return Pending(resolve)
+            if collect is not None:
+                return Pending(resolve)
         keys, payload, values, hits, ordered = _fetch_entries(eng, bt.table, 1, hint_key, top, spec, want_hits=want_hits, lazy=lazy)
         values = [values[j] for j in range(nv)]
         if getattr(bt, "key_radix", None) is not None and out_key_fields == [(bt.key_name, "key")]:    # several key fields in one mixed-radix integer

@@ -346,6 +346,7 @@ class Context:
         self._host_pool = {}       # block bytes -> [free block addresses]
         self._host_quarantine = [] # (address, bytes) of released blocks a queued result copy may still write (host_block)
         self._deferred_quarantine = []  # the same for blocks that kernels still queued on the stream may write (synchronize)
+        self._sync_epoch = 0            # full synchronisations of the context so far
 
     def close(self):
         if self.handle is not None:
@@ -386,16 +387,21 @@ class Context:
             self._check(self.lib.sdqh_host_alloc(self.handle, C.c_size_t(size), C.byref(p)))
             addr = p.value
         buf = (C.c_char * size).from_address(addr)
-        weakref.finalize(buf, Context._release_block, weakref.ref(self), self.lib, addr, size, deferred)
+        weakref.finalize(buf, Context._release_block, weakref.ref(self), self.lib, addr, size, self._sync_epoch if deferred else None)
         return buf
 
     @staticmethod
-    def _release_block(ctx_ref, lib, addr, size, deferred=False):
+    def _release_block(ctx_ref, lib, addr, size, launched_at=None):
         ctx = ctx_ref()
         if ctx is not None and ctx.handle is not None:
-            # a result copy may still be landing in the block (host_block waits for the copies) / kernels still queued may write it
-            # (synchronize moves those back to the pool)
-            (ctx._deferred_quarantine if deferred else ctx._host_quarantine).append((addr, size))
+            # a result copy may still be landing in the block (host_block waits for the copies) / kernels still queued may write it:
+            # not if the context has been synchronised since the block was handed out; else the next synchronize returns it to the pool
+            if launched_at is None:
+                ctx._host_quarantine.append((addr, size))
+            elif ctx._sync_epoch > launched_at:
+                ctx._host_pool.setdefault(size, []).append(addr)
+            else:
+                ctx._deferred_quarantine.append((addr, size))
         else:
             lib.sdqh_host_free(None, C.c_void_p(addr))
 
@@ -409,6 +415,7 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.sdqh_synchronize(self.handle))
+        self._sync_epoch += 1
         if self._deferred_quarantine:                             # nothing queued before this point can write them any more
             for addr, size in self._deferred_quarantine:
                 self._host_pool.setdefault(size, []).append(addr)

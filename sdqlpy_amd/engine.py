@@ -1357,12 +1357,13 @@ def _materialize(eng, value, env, hint_key=None, top=None, lazy_ok=False, defer=
         fields_of = bt.agg_fields
         lazy = lazy_ok and bool(getattr(eng, "lazy_results", False)) and _lazy_rows_ok(bt, out_key_fields, fields_of, top)
         want_hits = count_idx is not None or (spec is not None and any(s[0] == abi.SORT_HITS for s in spec))
-        if lazy and defer:
+        hint = eng.compact_hints.get(hint_key)
+        if lazy and defer and hint is not None:
             # the plan's last device call, launched and not waited for — not even for the row count (PreparedPlan.run): the block is
-            # sized from the previous run of this step; a result that outgrew it is noticed when it is collected and the plan re-run
-            hint = eng.compact_hints.get(hint_key)
+            # sized from the previous run of this step (the first run waits and learns the size); a result that outgrew it is noticed
+            # when it is collected and the plan re-run
             try:
-                collect = eng.ctx.table_compact_deferred(bt.table, 1, 4096 if hint is None else hint + hint // 8 + 1024, want_hits=want_hits)
+                collect = eng.ctx.table_compact_deferred(bt.table, 1, hint + hint // 8 + 1024, want_hits=want_hits)
             except abi.SdqhError as exc:
                 if exc.code != abi.ERR_UNSUPPORTED:               # (the option "async_result" is off: the waited-for call below)
                     raise

@@ -1824,9 +1824,11 @@ class PreparedPlan:
         host_env = {k: v for k, v in env.items() if not isinstance(v, BuiltTable)}
         rest = self.steps[at + 1:]
         eng, plan = self.eng, self.plan
+        launched_at = eng.ctx._sync_epoch
 
         def thunk():
-            eng.ctx.synchronize()
+            if eng.ctx._sync_epoch <= launched_at:                  # (not if the context has been synchronised since the launch: another result's finish did it)
+                eng.ctx.synchronize()
             try:
                 host_env[out] = pending.resolve()
                 for name, step in rest:

@@ -614,6 +614,7 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "spin_sync" && value >= 0 && value <= 1) ctx->opt_spin_sync = (int)value;
     else if (n == "vstage" && value >= 0 && value <= 1) ctx->opt_vstage = (int)value;
     else if (n == "side_streams" && value >= 0 && value <= 1) ctx->opt_side_streams = (int)value;
+    else if (n == "side_priority" && value >= 0 && value <= 1) ctx->opt_side_priority = (int)value;
     else if (n == "async_result" && value >= 0 && value <= 1) ctx->opt_async_result = (int)value;
     else if (n == "stage_pipeline" && value >= 0 && value <= 1) ctx->opt_stage_pipeline = (int)value;
     else if (n == "span_index" && value >= 0 && value <= 1) ctx->opt_span_index = (int)value;
@@ -1526,6 +1527,17 @@ int sdqh_table_select_keys(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_
 // ---- K-F ---------------------------------------------------------------------------------------
 // Runs the compaction into device buffers (cached on the table) and returns the row count.
 struct HostDest { int64_t* keys = nullptr; int64_t* payload = nullptr; double* values = nullptr; int64_t* hits = nullptr; int64_t capacity = 0; };
+// The stream result copies are queued on: of the LOWEST priority the device offers — the copy is a blit kernel here, and a compute kernel
+// of the next query that starts beside it should not be the one that waits ("side_priority" = 0: default priority).
+static hipStream_t make_copy_stream(sdqh_ctx* ctx) {
+    hipStream_t s = nullptr;
+    int least = 0, greatest = 0;
+    if (ctx->opt_side_priority && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest &&
+        hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) == hipSuccess) return s;
+    (void)hipGetLastError();
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return s;
+}
 static bool in_host_block(sdqh_ctx* ctx, const void* p, size_t bytes) {
     const char* c = static_cast<const char*>(p);
     auto it = ctx->host_blocks.upper_bound(c);
@@ -1685,7 +1697,7 @@ int sdqh_table_compact_async(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t mi
     if (out_hits) { contiguous = contiguous && reinterpret_cast<char*>(out_hits) == base + at; at += cb; }
     if (!ctx->opt_async_result || !contiguous)                           // not the layout this path copies in one piece: the synchronous call
         return sdqh_table_compact(ctx, ctable, min_hits, capacity, out_keys, out_payload, out_values, out_hits, out_n);
-    if (!ctx->side[1] && hipStreamCreateWithFlags(&ctx->side[1], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->side[1] = nullptr; }
+    if (!ctx->side[1]) ctx->side[1] = make_copy_stream(ctx);
     if (!ctx->count_host && hipHostMalloc(&ctx->count_host, 256, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->count_host = nullptr; }
     const int b = ctx->rs_cur;
     if (!ctx->rs_copied[b] && hipEventCreateWithFlags(&ctx->rs_copied[b], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->rs_copied[b] = nullptr; }
@@ -1755,7 +1767,7 @@ int sdqh_table_compact_deferred(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t
     if (out_values) { contiguous = contiguous && reinterpret_cast<char*>(out_values) == base + at; at += cb * SDQH_TUPLE_MAX_VALUES; }
     if (out_hits) { contiguous = contiguous && reinterpret_cast<char*>(out_hits) == base + at; at += cb; }
     if (!ctx->opt_async_result || !contiguous) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_compact_deferred: the result arrays must be one sdqh_host_alloc block laid out keys | payload | values | hits");
-    if (!ctx->side[1] && hipStreamCreateWithFlags(&ctx->side[1], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->side[1] = nullptr; }
+    if (!ctx->side[1]) ctx->side[1] = make_copy_stream(ctx);
     if (!ctx->count_host && hipHostMalloc(&ctx->count_host, 256, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->count_host = nullptr; }
     const int b = ctx->rs_cur;
     if (!ctx->rs_copied[b] && hipEventCreateWithFlags(&ctx->rs_copied[b], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->rs_copied[b] = nullptr; }

@@ -93,6 +93,7 @@ struct sdqh_ctx {
     hipStream_t side[2] = {nullptr, nullptr};      // side streams: independent build chains of a plan run beside the main stream (fork / join by events)
     hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int opt_side_streams = 1;
+    int opt_side_priority = 1;          // result copies on a stream of the lowest priority
     // K-F rows delivered behind the call (sdqh_table_compact_async): two device staging buffers in turn, a copy stream (side[1]),
     // the event of each buffer's last copy, and whether a copy may still be in flight
     void* rs_dev[2] = {nullptr, nullptr}; size_t rs_bytes[2] = {0, 0};

@@ -720,6 +720,7 @@ class Context:
         nval = TUPLE_MAX_VALUES if want_values and table.accumulate else 0
         narr = 1 + npay + nval + (1 if want_hits else 0)
         cap = max(1024, int(capacity_hint))
+        cap += cap & 1                                        # (whole 16-byte words per array: the library's own copy kernel moves those)
         buf = self.host_block(narr * cap * 8 + 64, deferred=True)
         flat = np.frombuffer(buf, dtype=np.int64, count=narr * cap + 8)
         cell = flat[narr * cap:narr * cap + 1]

@@ -615,6 +615,8 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "vstage" && value >= 0 && value <= 1) ctx->opt_vstage = (int)value;
     else if (n == "side_streams" && value >= 0 && value <= 1) ctx->opt_side_streams = (int)value;
     else if (n == "side_priority" && value >= 0 && value <= 1) ctx->opt_side_priority = (int)value;
+    else if (n == "copy_kernel" && value >= 0 && value <= 4096) ctx->opt_copy_kernel = (int)value;      // workgroups of the library's own copy-out kernel; 0: the runtime's copy
+    else if (n == "copy_nt" && value >= 0 && value <= 1) ctx->opt_copy_nt = (int)value;
     else if (n == "async_result" && value >= 0 && value <= 1) ctx->opt_async_result = (int)value;
     else if (n == "stage_pipeline" && value >= 0 && value <= 1) ctx->opt_stage_pipeline = (int)value;
     else if (n == "span_index" && value >= 0 && value <= 1) ctx->opt_span_index = (int)value;
@@ -1808,8 +1810,18 @@ int sdqh_table_compact_deferred(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t
     HIP_TRY(ctx, hipEventRecord(ctx->rs_ready, ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->side[1], ctx->rs_ready, 0));
     const int lead = 1 + (out_payload ? table->npay : 0) + nval;
-    HIP_TRY(ctx, hipMemcpyAsync(base, dev, cb * (size_t)lead, hipMemcpyDeviceToHost, ctx->side[1]));
-    if (out_hits) HIP_TRY(ctx, hipMemcpyAsync(out_hits, o.hits, cb, hipMemcpyDeviceToHost, ctx->side[1]));
+    if (ctx->opt_copy_kernel && cb % 16 == 0) {                       // (rows are 8 bytes: an even capacity makes every array a whole number of 16-byte words)
+        const uint64_t n16a = (uint64_t)(cb * (size_t)lead / 16), n16b = out_hits ? (uint64_t)(cb / 16) : 0;
+        const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n16a + TPB - 1) / TPB, (uint64_t)ctx->opt_copy_kernel));
+        auto kern = ctx->opt_copy_nt ? k_copy_out<true> : k_copy_out<false>;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), 0, ctx->side[1], reinterpret_cast<const sdqh_u4*>(dev), reinterpret_cast<sdqh_u4*>(base), n16a);
+        if (out_hits) hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), 0, ctx->side[1], reinterpret_cast<const sdqh_u4*>(o.hits), reinterpret_cast<sdqh_u4*>(out_hits), n16b);
+        hipError_t ec = hipGetLastError();
+        if (ec != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, std::string("table_compact_deferred copy launch: ") + hipGetErrorString(ec));
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(base, dev, cb * (size_t)lead, hipMemcpyDeviceToHost, ctx->side[1]));
+        if (out_hits) HIP_TRY(ctx, hipMemcpyAsync(out_hits, o.hits, cb, hipMemcpyDeviceToHost, ctx->side[1]));
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->rs_copied[b], ctx->side[1]));
     ctx->rs_used[b] = true; ctx->rs_pending = true; ctx->rs_cur = b ^ 1;
     if (out_values) for (int k = nval; k < SDQH_TUPLE_MAX_VALUES; ++k) std::memset(out_values + (size_t)k * (size_t)capacity, 0, cb);

@@ -2882,6 +2882,19 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_compact_write2(DevTable t, DevStage st
     compact_segment<true>(t, st, o, min_hits, seg, (uint64_t)before, s_idx[threadIdx.x / WAVE], s_hits[threadIdx.x / WAVE]);
 }
 
+// K-F's rows out of the device staging buffer into the caller's pinned host block, by a kernel of this library's own on the copy stream
+// (sdqh_table_compact_deferred).  The runtime's copy is a blit kernel whose stores to host memory sit dirty in L2: a compute kernel
+// of the next query that ENDS while it runs waits for them in its own end-of-kernel write-back (Q5's one-workgroup nation build: 81 us
+// instead of 9 beside Q3's 3.6 MB).  Here the stores are non-temporal (written through), a few workgroups, PCIe-bound either way.
+typedef unsigned int sdqh_u4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__global__ __launch_bounds__(TPB) void k_copy_out(const sdqh_u4* __restrict__ src, sdqh_u4* __restrict__ dst, uint64_t n16) {
+    for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * TPB) {
+        if (NT) { const sdqh_u4 v = __builtin_nontemporal_load(src + i); __builtin_nontemporal_store(v, dst + i); }
+        else dst[i] = src[i];
+    }
+}
+
 // =================================================================================================
 // Top-k over the entries of a table (ORDER BY ... LIMIT k after K-F; BASELINE config "Q3 ... + top-k",
 // SURVEY.md §8f.2 — the reference has no such operator, its Q3 returns the whole set).

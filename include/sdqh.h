@@ -308,6 +308,10 @@ int sdqh_table_compact_async(sdqh_ctx* ctx, const sdqh_table* table, int64_t min
  * (fetch again with the capacity it names).  SDQH_ERR_UNSUPPORTED for any other layout or with "async_result" = 0. */
 int sdqh_table_compact_deferred(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, int64_t capacity,
                                 int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n);
+/* out_n is TWO cells there: out_n[1] is the result's DONE word — the copy stream writes 1 into it behind the copies (2 at once if it
+ * cannot: wait with sdqh_result_wait) — so one result can be waited for by itself: sdqh_host_wait_word(ctx, &out_n[1], 1). */
+/* Block until a 32-bit word of sdqh_host_alloc memory that a stream writes holds `value` (spins; falls back to sdqh_synchronize). */
+int sdqh_host_wait_word(sdqh_ctx* ctx, const void* word, uint32_t value);
 /* Wait for every result copy queued by sdqh_table_compact_async / _deferred on this context. */
 int sdqh_result_wait(sdqh_ctx* ctx);
 
@@ -481,7 +485,8 @@ int sdqh_xgroupby(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int ma
 /* The same K-C with the result delivered BEHIND the call (a query's last loop need not hold the host: the next query's kernels
  * are queued while this one's run — the reference's result object also converts on `to_dict()`, src/sdqlpy/fastd.py:31-51).
  * sdqh_xgroupby_async launches and returns; `result_block` is sdqh_xgroupby_block_bytes() bytes from sdqh_host_alloc, opaque,
- * written when the stream gets there.  After sdqh_synchronize, sdqh_xgroupby_collect reads the groups out of it exactly as
+ * written when the stream gets there.  sdqh_xgroupby_collect waits for THIS call's kernels (a completion word in the block that the
+ * stream writes behind them), then reads the groups out of it exactly as
  * sdqh_xgroupby would have returned them (same errors: SDQH_ERR_OVERFLOW with *out_ngroups, SDQH_ERR_UNSUPPORTED for a negative
  * key); nvals = the program's value count.  The CPU build computes the groups in the first call. */
 size_t sdqh_xgroupby_block_bytes(void);

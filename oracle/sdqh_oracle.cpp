@@ -640,7 +640,12 @@ int sdqh_table_compact_deferred(sdqh_ctx* ctx, const sdqh_table* table, int64_t 
                                 int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n) {
     if (!ctx || !table || !out_n || capacity < 1 || !out_keys) return fail(ctx, SDQH_ERR_INVALID, "table_compact_deferred: bad arguments");
     const int rc = sdqh_table_compact(ctx, table, min_hits, capacity, out_keys, out_payload, out_values, out_hits, out_n);
+    out_n[1] = 1;                                                    // the result's DONE word: everything is there when this call returns
     return rc == SDQH_ERR_OVERFLOW ? SDQH_OK : rc;                  // (*out_n > capacity says so: the caller fetches again)
+}
+int sdqh_host_wait_word(sdqh_ctx* ctx, const void* word, uint32_t value) {
+    if (!ctx || !word) return fail(ctx, SDQH_ERR_INVALID, "host_wait_word: bad arguments");
+    return *static_cast<const volatile uint32_t*>(word) == value ? SDQH_OK : fail(ctx, SDQH_ERR_DEVICE, "host_wait_word: nothing is ever pending here");
 }
 int sdqh_result_wait(sdqh_ctx* ctx) { return ctx ? SDQH_OK : SDQH_ERR_INVALID; }
 int sdqh_table_compact(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, int64_t capacity,

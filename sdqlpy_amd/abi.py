@@ -215,7 +215,7 @@ EXPORTS = [
     "sdqh_column_upload", "sdqh_column_wrap", "sdqh_column_alloc", "sdqh_column_download", "sdqh_column_data",
     "sdqh_column_rows", "sdqh_column_dtype", "sdqh_column_width", "sdqh_column_minmax", "sdqh_column_free",
     "sdqh_scan_filter_sum", "sdqh_scan_probe_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_build_key_set", "sdqh_groupby_key", "sdqh_table_select_keys", "sdqh_table_share_groups", "sdqh_table_size", "sdqh_table_free",
-    "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_table_compact_async", "sdqh_table_compact_deferred", "sdqh_result_wait", "sdqh_scan_compact", "sdqh_partition_by_key",
+    "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_table_compact_async", "sdqh_table_compact_deferred", "sdqh_host_wait_word", "sdqh_result_wait", "sdqh_scan_compact", "sdqh_partition_by_key",
     "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in",
     "sdqh_build", "sdqh_lookup_aggregate", "sdqh_table_entries", "sdqh_host_alloc", "sdqh_host_free", "sdqh_table_topk",
     "sdqh_xscan_sum", "sdqh_xgroupby", "sdqh_xgroupby_block_bytes", "sdqh_xgroupby_async", "sdqh_xgroupby_collect", "sdqh_xbuild", "sdqh_xkey_set", "sdqh_xprobe_aggregate", "sdqh_table_columns", "sdqh_jit_stats",
@@ -370,7 +370,7 @@ class Context:
         size = 1 << 16
         while size < nbytes:
             size <<= 1
-        if len(self._deferred_quarantine) > 256:                  # nobody synchronised in a long while: do it here
+        if len(self._deferred_quarantine) > 32:                   # blocks of results nobody collected, and nobody synchronised in a while: do it here
             self.synchronize()
         if self._host_quarantine:
             # blocks whose arrays died while a result copy might still have been landing in them: usable once the copies are done
@@ -387,18 +387,20 @@ class Context:
             self._check(self.lib.sdqh_host_alloc(self.handle, C.c_size_t(size), C.byref(p)))
             addr = p.value
         buf = (C.c_char * size).from_address(addr)
-        weakref.finalize(buf, Context._release_block, weakref.ref(self), self.lib, addr, size, self._sync_epoch if deferred else None)
+        weakref.finalize(buf, Context._release_block, weakref.ref(self), self.lib, addr, size, self._sync_epoch if deferred else None,
+                         deferred if isinstance(deferred, list) else None)
         return buf
 
     @staticmethod
-    def _release_block(ctx_ref, lib, addr, size, launched_at=None):
+    def _release_block(ctx_ref, lib, addr, size, launched_at=None, done=None):
         ctx = ctx_ref()
         if ctx is not None and ctx.handle is not None:
             # a result copy may still be landing in the block (host_block waits for the copies) / kernels still queued may write it:
-            # not if the context has been synchronised since the block was handed out; else the next synchronize returns it to the pool
+            # not if its result was collected (done), nor if the context has been synchronised since the block was handed out; else
+            # the next synchronize returns it to the pool
             if launched_at is None:
                 ctx._host_quarantine.append((addr, size))
-            elif ctx._sync_epoch > launched_at:
+            elif (done is not None and done[0]) or ctx._sync_epoch > launched_at:
                 ctx._host_pool.setdefault(size, []).append(addr)
             else:
                 ctx._deferred_quarantine.append((addr, size))
@@ -628,10 +630,11 @@ class Context:
         return out_keys[:n], out_vals[:n, :len(prog.vals)], out_cnt[:n]
 
     def xgroupby_async(self, nrows, prog, max_groups=MAX_LOOKUP_GROUPS):
-        """Launch K-C small and return at once: collect() -> (keys, values, counts) as xgroupby, to be called after the stream
-        has been synchronised (Context.synchronize; Pending results do it).  What the data decides — too many groups, a negative
-        key — is raised by collect(), not here."""
-        buf = self.host_block(self.lib.sdqh_xgroupby_block_bytes(), deferred=True)
+        """Launch K-C small and return at once: collect() -> (keys, values, counts) as xgroupby; it waits for THIS call's kernels
+        (a completion word in the block), not for what was queued behind them.  What the data decides — too many groups, a
+        negative key — is raised by collect(), not here."""
+        done = [False]
+        buf = self.host_block(self.lib.sdqh_xgroupby_block_bytes(), deferred=done)
         self._check(self.lib.sdqh_xgroupby_async(self.handle, C.c_int64(nrows), C.byref(prog.struct()), C.addressof(buf)))
         self._after_call("xgroupby")
         nvals = len(prog.vals)
@@ -641,8 +644,10 @@ class Context:
             out_vals = np.zeros((max_groups, TUPLE_MAX_VALUES), np.float64)
             out_cnt = np.zeros(max_groups, np.int64)
             ng = C.c_int32()
-            self._check(self.lib.sdqh_xgroupby_collect(self.handle, C.addressof(buf), C.c_int(nvals), C.c_int(max_groups),
-                                                       _np_ptr(out_keys), _np_ptr(out_vals), _np_ptr(out_cnt), C.byref(ng)))
+            rc = self.lib.sdqh_xgroupby_collect(self.handle, C.addressof(buf), C.c_int(nvals), C.c_int(max_groups),
+                                                _np_ptr(out_keys), _np_ptr(out_vals), _np_ptr(out_cnt), C.byref(ng))
+            done[0] = True                                        # (collect waited for this call's kernels: nothing will write the block any more)
+            self._check(rc)
             n = ng.value
             return out_keys[:n], out_vals[:n, :nvals], out_cnt[:n]
         return collect
@@ -713,17 +718,18 @@ class Context:
             self._check(self.lib.sdqh_result_wait(self.handle))
 
     def table_compact_deferred(self, table, min_hits, capacity_hint, want_payload=True, want_values=True, want_hits=True):
-        """K-F with nothing waited for (sdqh_table_compact_deferred): returns collect() -> (keys, payload, values, hits, n), to be
-        called after Context.synchronize(); a result that did not fit the block sized from capacity_hint raises
+        """K-F with nothing waited for (sdqh_table_compact_deferred): returns collect() -> (keys, payload, values, hits, n), which
+        waits for THIS result's copy (its completion word); a result that did not fit the block sized from capacity_hint raises
         SdqhError(ERR_OVERFLOW) there with .needed = its row count (the caller runs the step again, waited for)."""
         npay = table.npayload if want_payload else 0
         nval = TUPLE_MAX_VALUES if want_values and table.accumulate else 0
         narr = 1 + npay + nval + (1 if want_hits else 0)
         cap = max(1024, int(capacity_hint))
         cap += cap & 1                                        # (whole 16-byte words per array: the library's own copy kernel moves those)
-        buf = self.host_block(narr * cap * 8 + 64, deferred=True)
+        done = [False]
+        buf = self.host_block(narr * cap * 8 + 64, deferred=done)
         flat = np.frombuffer(buf, dtype=np.int64, count=narr * cap + 8)
-        cell = flat[narr * cap:narr * cap + 1]
+        cell = flat[narr * cap:narr * cap + 2]                   # [row count, the result's completion word]
         flat = flat[:narr * cap].reshape(narr, cap)
         keys = flat[0]
         payload = flat[1:1 + npay] if npay else None
@@ -734,9 +740,14 @@ class Context:
         self._after_call("table_compact")
 
         def collect():
+            if int(cell[1]) == 2:                                 # (no completion word on this device: every pending copy)
+                self.result_wait()
+            else:
+                self._check(self.lib.sdqh_host_wait_word(self.handle, C.c_void_p(cell.ctypes.data + 8), C.c_uint32(1)))
+            done[0] = True
             n = int(cell[0])
             if n < 0:
-                raise SdqhError(ERR_DEVICE, "table_compact_deferred: collected before the stream was synchronised")
+                raise SdqhError(ERR_DEVICE, "table_compact_deferred: the row count never arrived")
             if n > cap:                                           # the block was sized from a bad guess: the rows beyond it were dropped
                 exc = SdqhError(ERR_OVERFLOW, "table_compact_deferred: %d rows, room for %d" % (n, cap))
                 exc.needed = n
@@ -902,6 +913,7 @@ class Library:
                                          C.c_void_p, C.c_void_p]
         L.sdqh_table_compact_deferred.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p]
+        L.sdqh_host_wait_word.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.sdqh_result_wait.argtypes = [C.c_void_p]
         L.sdqh_scan_compact.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_void_p]

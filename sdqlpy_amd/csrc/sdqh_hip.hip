@@ -1763,7 +1763,7 @@ int sdqh_table_compact_deferred(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t
     const size_t cb = (size_t)capacity * 8;
     char* base = reinterpret_cast<char*>(out_keys);
     const int narr = 1 + (out_payload ? table->npay : 0) + (out_values ? SDQH_TUPLE_MAX_VALUES : 0) + (out_hits ? 1 : 0);
-    bool contiguous = in_host_block(ctx, base, cb * (size_t)narr) && in_host_block(ctx, out_n, 8);
+    bool contiguous = in_host_block(ctx, base, cb * (size_t)narr) && in_host_block(ctx, out_n, 16);
     size_t at = cb;
     if (out_payload) { contiguous = contiguous && reinterpret_cast<char*>(out_payload) == base + at; at += cb * (size_t)table->npay; }
     if (out_values) { contiguous = contiguous && reinterpret_cast<char*>(out_values) == base + at; at += cb * SDQH_TUPLE_MAX_VALUES; }
@@ -1796,7 +1796,7 @@ int sdqh_table_compact_deferred(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t
     if (out_hits) { o.hits = reinterpret_cast<int64_t*>(dev + off); off += cb; }
     o.npay = npay; o.nval = nval;
     o.counter = reinterpret_cast<unsigned long long*>(static_cast<char*>(ctx->count_host) + 64);
-    *out_n = -1;
+    out_n[0] = -1; out_n[1] = 0;
     o.h_counter = reinterpret_cast<unsigned long long*>(out_n);                                      // the kernel's own store of the total, into the caller's block
     o.host_rows = (uint64_t)capacity; o.bounded = 1;
     const uint32_t mh = (uint32_t)std::min<int64_t>(std::max<int64_t>(min_hits, 0), 0xFFFFFFFFll);
@@ -1822,6 +1822,8 @@ int sdqh_table_compact_deferred(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t
         HIP_TRY(ctx, hipMemcpyAsync(base, dev, cb * (size_t)lead, hipMemcpyDeviceToHost, ctx->side[1]));
         if (out_hits) HIP_TRY(ctx, hipMemcpyAsync(out_hits, o.hits, cb, hipMemcpyDeviceToHost, ctx->side[1]));
     }
+    // out_n[1]: the DONE word of this result, written by the copy stream itself behind the copies (1; 2 = no marker: wait with sdqh_result_wait)
+    if (hipStreamWriteValue32(ctx->side[1], reinterpret_cast<uint32_t*>(&out_n[1]), 1, 0) != hipSuccess) { (void)hipGetLastError(); out_n[1] = 2; }
     HIP_TRY(ctx, hipEventRecord(ctx->rs_copied[b], ctx->side[1]));
     ctx->rs_used[b] = true; ctx->rs_pending = true; ctx->rs_cur = b ^ 1;
     if (out_values) for (int k = nval; k < SDQH_TUPLE_MAX_VALUES; ++k) std::memset(out_values + (size_t)k * (size_t)capacity, 0, cb);

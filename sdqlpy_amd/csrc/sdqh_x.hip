@@ -1227,9 +1227,26 @@ static int xgroupby_launch(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* pro
     if (!rc) {
         launch_groupby_merge_lg_host(ctx, r_keys, pacc, pcnt, (int)g.grid, r_flags, host_block);       // writes the pinned host block, leaves the device block clean
         call_end(ctx);
+        if (host_block) {
+            // the block's DONE word (after the flags): written by the stream itself once the merge has finished — collect waits for its own
+            // result, not for whatever was queued behind it
+            uint32_t* done = reinterpret_cast<uint32_t*>(static_cast<char*>(host_block) + LG_SLOTS * 48 + 4);
+            *done = 0;
+            if (hipStreamWriteValue32(ctx->stream, done, 1, 0) != hipSuccess) { (void)hipGetLastError(); *done = 2; }     // 2: no marker, collect synchronises
+        }
     }
     pool_free(ctx, blob);                                   // stream order: whoever gets the block next runs after the merge
     return rc;
+}
+
+// wait until a word of device-visible host memory that the stream writes (hipStreamWriteValue32) holds `value`
+static int wait_word(sdqh_ctx* ctx, const volatile uint32_t* word, uint32_t value) {
+    for (uint64_t spins = 0; spins < (1ull << 31); ++spins) {
+        if (*word == value) return SDQH_OK;
+        __builtin_ia32_pause();
+    }
+    if (int rc = sdqh_synchronize(ctx)) return rc;
+    return *word == value ? SDQH_OK : fail(ctx, SDQH_ERR_DEVICE, "a result's completion word was never written");
 }
 
 // The groups of a finished call, out of its host block: ascending keys, at most max_groups.
@@ -1277,7 +1294,15 @@ int sdqh_xgroupby_async(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, 
 int sdqh_xgroupby_collect(sdqh_ctx* ctx, const void* result_block, int nvals, int max_groups,
                           int64_t* out_keys, double* out_values, int64_t* out_counts, int32_t* out_ngroups) {
     if (!ctx || !result_block || nvals < 0 || nvals > SDQH_TUPLE_MAX_VALUES || max_groups < 1 || max_groups > SDQH_MAX_LOOKUP_GROUPS || !out_ngroups) return fail(ctx, SDQH_ERR_INVALID, "xgroupby_collect: bad arguments");
+    const volatile uint32_t* done = reinterpret_cast<const volatile uint32_t*>(static_cast<const char*>(result_block) + LG_SLOTS * 48 + 4);
+    if (*done == 2) { if (int rc = sdqh_synchronize(ctx)) return rc; }
+    else if (int rc = wait_word(ctx, done, 1)) return rc;
     return xgroupby_collect(ctx, result_block, nvals, max_groups, out_keys, out_values, out_counts, out_ngroups);
+}
+
+int sdqh_host_wait_word(sdqh_ctx* ctx, const void* word, uint32_t value) {
+    if (!ctx || !word) return fail(ctx, SDQH_ERR_INVALID, "host_wait_word: bad arguments");
+    return wait_word(ctx, static_cast<const volatile uint32_t*>(word), value);
 }
 
 int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t key_lo, int64_t key_hi, int accumulate, sdqh_table** out) {

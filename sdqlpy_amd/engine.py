@@ -1824,11 +1824,8 @@ class PreparedPlan:
         host_env = {k: v for k, v in env.items() if not isinstance(v, BuiltTable)}
         rest = self.steps[at + 1:]
         eng, plan = self.eng, self.plan
-        launched_at = eng.ctx._sync_epoch
 
-        def thunk():
-            if eng.ctx._sync_epoch <= launched_at:                  # (not if the context has been synchronised since the launch: another result's finish did it)
-                eng.ctx.synchronize()
+        def thunk():                                                # (resolve() waits for THIS result — its completion word —, not for what was queued behind it)
             try:
                 host_env[out] = pending.resolve()
                 for name, step in rest:

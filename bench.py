@@ -29,6 +29,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+ROW_RESULTS = ("q3", "q10", "q18")    # queries whose result is a set of rows (K-F + a device-to-host copy) rather than a handful of groups
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 
 
@@ -41,6 +42,9 @@ def parse(argv=None):
     ap.add_argument("--global-sf", type=float, default=0.0, help="scale factor of the WHOLE database, cut over the ranks (overrides --sf; "
                                                                  "--gpus 8 --global-sf 100 = BASELINE configs[3]/[4])")
     ap.add_argument("--queries", default="q1,q3,q5", help="the timed step (BASELINE metric: Q1/Q3/Q5)")
+    ap.add_argument("--launch-order", default="rows-first", help="order in which a step launches its queries: 'rows-first' (the queries whose result is a set of "
+                    "rows — K-F, a device-to-host copy — before those that end in a handful of groups: the copy then runs beside the next query's big "
+                    "kernel instead of its one-workgroup builds), 'given', or a comma-separated permutation of --queries")
     ap.add_argument("--extra-queries", default=None, help="measured after the timed region, reported per query only (default q6,q9 at N=1, none at N>1)")
     ap.add_argument("--profile-iters", type=int, default=5, help="extra untimed passes with per-kernel HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -184,6 +188,15 @@ def main(argv=None, hooks=None):
     eng.ctx.set_profiling(0)
     dom_kernel = max(probe_launches, key=lambda kv: kv[1])[0] if probe_launches else DOMINANT[dom_q][0]
 
+    def step_order(qs):
+        if args.launch_order == "given":
+            return list(qs)
+        if args.launch_order == "rows-first":
+            rows_out = [q for q in qs if q in ROW_RESULTS]
+            return rows_out + [q for q in qs if q not in rows_out]
+        want = [q for q in args.launch_order.split(",") if q]
+        return want if sorted(want) == sorted(qs) else list(qs)
+
     def finish(r):
         """A result is complete — every row on the host, the plan's host-side steps done — once wait() returns (results of plans
         whose last device call is launched without being waited for: sdqlpy_amd/result.py DeferredResultSet)."""
@@ -199,9 +212,10 @@ def main(argv=None, hooks=None):
         barrier()
         t_begin = time.perf_counter()
         marks = []                                       # (query, number of launches recorded so far)
+        order = step_order(qs) if not each_waited_for else qs
         for _ in range(nsteps):
             results = []
-            for q in qs:
+            for q in order:
                 tq = time.perf_counter()
                 r = run(q)
                 if each_waited_for:
@@ -345,7 +359,7 @@ def main(argv=None, hooks=None):
             # what a step is: its queries launched one after the other, then their results finished — a plan's last device call is
             # queued without being waited for (Engine.deferred_results) and every result is complete on the host before the step ends.
             # Beside it, the same step with every query's result finished before the next query is launched.
-            "step": {"launch_then_finish": True, "deferred_results": bool(getattr(eng, "deferred_results", False)),
+            "step": {"launch_then_finish": True, "launch_order": step_order(queries), "deferred_results": bool(getattr(eng, "deferred_results", False)),
                      "ms_per_step_each_query_waited_for": round(elapsed_waited / args.steps * 1e3, 4),
                      "value_each_query_waited_for": round(total_rows_per_step * args.steps / elapsed_waited, 1)},
             "ms_per_query": per_query,

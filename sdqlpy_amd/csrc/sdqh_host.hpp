@@ -97,6 +97,7 @@ struct sdqh_ctx {
     int opt_copy_kernel = 0;            // > 0: sdqh_table_compact_deferred copies its rows out with that many workgroups of k_copy_out instead of the runtime's
                                         // copy (measured: 64 workgroups of write-through stores 0.85 ms a step against 0.79 — the runtime's blit kernel stays)
     int opt_copy_nt = 1;
+    int opt_x_waves = 0;                // > 0: wave segments per CU for the queue skeletons of row programs (0: each sink's own default)
     // K-F rows delivered behind the call (sdqh_table_compact_async): two device staging buffers in turn, a copy stream (side[1]),
     // the event of each buffer's last copy, and whether a copy may still be in flight
     void* rs_dev[2] = {nullptr, nullptr}; size_t rs_bytes[2] = {0, 0};

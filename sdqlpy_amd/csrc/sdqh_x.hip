@@ -1112,6 +1112,7 @@ Geometry geometry(sdqh_ctx* ctx, int64_t nrows, bool direct, int waves_per_cu, b
         return g;
     }
     const int64_t gran = tight ? (int64_t)X8_STEP * X8_U : (int64_t)WAVE * ROWS_PER_LOAD * X_LB;      // a wave's segment is whole steps of its skeleton
+    if (ctx->opt_x_waves > 0) waves_per_cu = ctx->opt_x_waves;                                        // (tuning: segments per CU of the queue skeletons)
     const int64_t target = (int64_t)ctx->num_cu * waves_per_cu;
     int64_t seg_rows = (nrows + target - 1) / target;
     seg_rows = std::max<int64_t>(gran, (seg_rows + gran - 1) / gran * gran);

@@ -1447,8 +1447,9 @@ int sdqh_xprobe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog
     table->nv = prog->nvals;
     call_begin(ctx);
     XArgs a;
-    rd_dirty(ctx);
-    int32_t* d_flags = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->result_dev) + 1024);
+    // (the flag word nothing reads here lives past every result block of ctx->result_dev: the group-by block a neighbouring call left
+    // clean stays clean — Q5's xgroupby after Q3's probe-aggregate needed a fill launch for it)
+    int32_t* d_flags = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->result_dev) + RESULT_BYTES - 64);
     if (int rc = fill_xargs(ctx, x, &a, d_flags, 1, 0)) return rc;
     const Geometry g = geometry(ctx, nrows, false, 24, x.tight);
     XEntry<1>::Args sa{table->dev};

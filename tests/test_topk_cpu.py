@@ -147,3 +147,30 @@ def test_text_columns_of_large_results_are_decoded_on_first_read(oracle, monkeyp
         assert lazy.column(name).tolist() == eager.column(name).tolist()
         assert lazy.rows() == eager.rows() and lazy.to_dict() == eager.to_dict()
         assert not any(isinstance(a, result.TextRefs) for a in lazy._cols)
+
+
+def test_deferred_result_set_finishes_on_first_use():
+    """result.DeferredResultSet: nothing runs until something looks at the result; every way of looking runs the thunk exactly
+    once; an exception of the thunk surfaces at that first use (and again if asked again: the thunk is gone, the object stays unfinished)."""
+    import numpy as np
+    import pytest
+    from sdqlpy_amd.result import DeferredResultSet, ResultSet
+    calls = []
+
+    def make():
+        calls.append(1)
+        return ResultSet(["k", "v"], [np.array([3, 1, 2]), np.array([0.5, 1.5, 2.5])])
+    for use in (lambda r: r.size(), lambda r: len(r), lambda r: r.columns, lambda r: r.column("v"), lambda r: r.rows(), lambda r: r.arrays,
+                lambda r: r.wait(), lambda r: r.top(2, [("k", "desc")]).rows()):
+        del calls[:]
+        r = DeferredResultSet(make)
+        assert isinstance(r, ResultSet) and calls == []
+        use(r)
+        use(r)
+        assert calls == [1]
+        assert r.rows() == [(1, 1.5), (2, 2.5), (3, 0.5)] and r.size() == 3
+    nested = DeferredResultSet(lambda: DeferredResultSet(make))
+    assert nested.size() == 3
+    bad = DeferredResultSet(lambda: (_ for _ in ()).throw(ValueError("decided by the data")))
+    with pytest.raises(ValueError):
+        bad.size()

@@ -53,6 +53,8 @@ def parse(argv=None):
     ap.add_argument("--force-dist", action="store_true", help="use the distributed plan even with one rank (exercises the RCCL path)")
     ap.add_argument("--partition", default="hash", choices=["auto", "range", "hash"], help="q3's partitioning in the timed step at N > 1")
     ap.add_argument("--cpu-sample-sf", type=float, default=0.0, help="0 = pick so the CPU leg takes ~10-30 s")
+    ap.add_argument("--steady-steps", type=int, default=1500, help="steps of a second, longer leg after the timed region (reported as `steady_state`, not part of `value`); 0 = none")
+    ap.add_argument("--no-reference-width", action="store_true", help="skip the leg that re-runs q1/q3/q6 on the reference's 8-byte columns (twins and codes off)")
     return ap.parse_args(argv)
 
 
@@ -230,11 +232,13 @@ def main(argv=None, hooks=None):
                 finish(r)
         barrier()
         took = time.perf_counter() - t_begin
-        launches = eng.ctx.profile()                     # [(kernel, ms)] of every recorded launch
+        # [(kernel, ms, modelled HBM bytes)] of every recorded launch (sdqh_profile_entry_bytes: what the library's own choice of
+        # encodings makes that launch stream; 0 where a kernel has no model)
+        launches = eng.ctx.profile_bytes() if hasattr(eng.ctx, "profile_bytes") else [(n, ms, 0) for n, ms in eng.ctx.profile()]
         eng.ctx.set_profiling(0)
         log, at = [], 0
         for q, upto in marks:
-            log += [(q, name, ms) for name, ms in launches[at:upto]]
+            log += [(q, name, ms, nbytes) for name, ms, nbytes in launches[at:upto]]
             at = upto
         return took, per_q, log
 
@@ -254,7 +258,8 @@ def main(argv=None, hooks=None):
             assert runner.collectives.get("all_to_all", [0])[0] > 0 or runner.last_partitioning == "range", "no all-to-all ran in the timed step"
             if args.partition == "hash":
                 assert runner.exchanged_rows.get("probe_sent", 0) > 0, runner.exchanged_rows
-    dom_launches = [ms for q, name, ms in timed_log if q == dom_q and name == dom_kernel]
+    dom_launches = [ms for q, name, ms, _ in timed_log if q == dom_q and name == dom_kernel]
+    dom_model = [nb for q, name, _, nb in timed_log if q == dom_q and name == dom_kernel and nb > 0]
     # per-kernel table: a separate pass with events around every launch, after the timed region
     profile_steps = max(1, min(args.steps, 10))
     _, _, launch_log = run_steps(profile_steps, None)
@@ -290,6 +295,17 @@ def main(argv=None, hooks=None):
                 run_query(q)
         took_x, extra_ms, _ = run_steps(extra_steps, "-", extra, each_waited_for=True)
         _, _, extra_log = run_steps(extra_steps, None, extra)
+    # the timed region is args.steps steps (the driver fixes 20: 15 ms); the same step for ~1 s of back-to-back work, outside `value`:
+    # is the figure steady state or a burst out of warm caches?
+    steady = None
+    if world == 1 and args.steady_steps > 0:
+        took_long, _, _ = run_steps(args.steady_steps, "-")
+        steady = {"steps": args.steady_steps, "ms_per_step": round(took_long / args.steady_steps * 1e3, 4), "seconds": round(took_long, 3)}
+    # one finished result per query of the step, kept for the comparison with the CPU implementation's results on the same tables
+    hip_results = {q: finish(run_query(q)) for q in queries} if (world == 1 and not args.no_cpu_baseline) else {}
+    reference_width = None
+    if world == 1 and not use_dist and "engine" not in hooks and not args.no_reference_width:
+        reference_width = reference_width_leg(args, eng, db, rows, queries + extra, run_query, run_steps, finish)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -303,15 +319,19 @@ def main(argv=None, hooks=None):
     value = total_rows_per_step * args.steps / elapsed
 
     kstat = {}
-    for q, name, ms in launch_log + extra_log:
+    for q, name, ms, nb in launch_log + extra_log:
         name = "%s:%s" % (q, name)
-        tot, n = kstat.get(name, (0.0, 0))
-        kstat[name] = (tot + ms, n + 1)
+        tot, n, b = kstat.get(name, (0.0, 0, 0))
+        kstat[name] = (tot + ms, n + 1, b + nb)
     kernels = {name: {"launches_per_step": n / profile_steps, "avg_launch_ms": tot / n, "ms_per_step": tot / profile_steps}
-               for name, (tot, n) in kstat.items()}
+               for name, (tot, n, _) in kstat.items()}
+    for name, (tot, n, b) in kstat.items():
+        if b:                                            # streamed bytes by the library's own model, and the rate they imply
+            kernels[name]["model_bytes_per_launch"] = b / n
+            kernels[name]["model_GBs"] = b / n / (tot / n * 1e-3) / 1e9 if tot > 0 else None
     # kernels are attributed to the query that was running when they were launched
-    device_ms = {q: sum(ms for qq, _, ms in launch_log if qq == q) / profile_steps for q in queries}
-    device_ms.update({q: sum(ms for qq, _, ms in extra_log if qq == q) / extra_steps for q in extra})
+    device_ms = {q: sum(ms for qq, _, ms, _ in launch_log if qq == q) / profile_steps for q in queries}
+    device_ms.update({q: sum(ms for qq, _, ms, _ in extra_log if qq == q) / extra_steps for q in extra})
 
     out = None
     if rank == 0:
@@ -322,16 +342,29 @@ def main(argv=None, hooks=None):
             per_launch_bytes = DOMINANT[dom_q][1](rows)
             achieved = per_launch_bytes / (dom_ms * 1e-3) / 1e9
             traffic, traffic_source = pmc_traffic(dom_q, dom_kernel, rows)
-            phys_gbs = traffic / (dom_ms * 1e-3) / 1e9 if traffic else None
-            # `frac` is the PHYSICAL fraction: HBM bytes the kernel really moves (PMC) / its launch time / peak — a fraction
-            # of the roofline.  SURVEY.md §8(d)'s algorithmic figure (the reference's 8-byte / UCS-4 column widths, which the
-            # CPU path is priced on too) is carried beside it as `achieved_algorithmic` / `frac_algorithmic`; the kernel
-            # reads exact narrow twins of those columns, so that one can exceed 1 and is not a roofline fraction.
+            # the same launch's bytes by the library's own model of THIS run (sdqh_profile_entry_bytes: rows x the bytes per row of the
+            # encodings the engine chose for each streamed column + what the launch stores by construction): `frac` can be recomputed
+            # from this line alone, the committed PMC collection confirms it
+            traffic_model = int(sum(dom_model) / len(dom_model)) if dom_model else None
+            bytes_used, frac_source = (traffic, "pmc") if traffic else (traffic_model, "model")
+            phys_gbs = bytes_used / (dom_ms * 1e-3) / 1e9 if bytes_used else None
+            # `frac` is the PHYSICAL fraction: HBM bytes the kernel really moves / its launch time / peak — a fraction of the roofline.
+            # SURVEY.md 8(d)'s algorithmic figure (the reference's 8-byte / UCS-4 column widths, which the CPU path is priced on too) is
+            # carried beside it as `achieved_algorithmic` / `frac_algorithmic`: the kernel reads exact narrow encodings of those columns
+            # (DESIGN.md 2), so that one exceeds 1 and is not a roofline fraction; `reference_width` below times the same query on the
+            # 8-byte columns, where the algorithmic fraction IS one.
             roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(phys_gbs, 1) if phys_gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(phys_gbs / HBM_PEAK_GBS, 4) if phys_gbs else None, "traffic": traffic, "traffic_source": traffic_source,
+                        "frac": round(phys_gbs / HBM_PEAK_GBS, 4) if phys_gbs else None, "frac_source": frac_source,
+                        "traffic": traffic, "traffic_source": traffic_source,
+                        "traffic_model": traffic_model, "traffic_model_over_pmc": round(traffic_model / traffic, 4) if traffic and traffic_model else None,
+                        "frac_model": round(traffic_model / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic_model else None,
                         "achieved_algorithmic": round(achieved, 1), "frac_algorithmic": round(achieved / HBM_PEAK_GBS, 4),
                         "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": round(dom_ms, 4),
-                        "launches_timed": len(dom_launches)}
+                        "launches_timed": len(dom_launches),
+                        "achievable_peak_note": "MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured for a float4 copy"}
+            if reference_width and dom_q in reference_width.get("queries", {}):
+                rw = reference_width["queries"][dom_q]
+                roofline["reference_width"] = {"kernel": rw["dominant_kernel"], "avg_launch_ms": rw["dominant_avg_launch_ms"], "achieved": rw["achieved"], "frac": rw["frac"]}
         per_query = {}
         for q in queries + extra:
             ab = algorithmic_bytes(q, rows)
@@ -349,7 +382,9 @@ def main(argv=None, hooks=None):
                             # physical bytes moved beside the algorithmic figure
                             "physical_bytes": phys,
                             "physical_GBs_kernels": round(phys / (device_ms[q] * 1e-3) / 1e9, 1) if phys and device_ms[q] else None,
-                            "traffic_source": phys_source}
+                            "traffic_source": phys_source,
+                            # streamed bytes of the query's kernels by the library's model of this run (lower bound: no gathers, no survivor-dependent stores)
+                            "model_streamed_bytes": int(sum(v.get("model_bytes_per_launch", 0) * v["launches_per_step"] for k, v in kernels.items() if k.startswith(q + ":"))) or None}
         out = {
             "metric": "tpch_" + "_".join(queries) + "_sf%g_rows_per_sec" % sf_per_gpu, "value": round(value, 1), "unit": "rows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -361,6 +396,8 @@ def main(argv=None, hooks=None):
             # what a step is: its queries launched one after the other, then their results finished — a plan's last device call is
             # queued without being waited for (Engine.deferred_results) and every result is complete on the host before the step ends.
             # Beside it, the same step with every query's result finished before the next query is launched.
+            # the same two figures under explicit names: `value` is the overlapped one
+            "value_overlapped": round(value, 1), "value_sequential": round(total_rows_per_step * args.steps / elapsed_waited, 1),
             "step": {"launch_then_finish": True, "launch_order": step_order(queries), "deferred_results": bool(getattr(eng, "deferred_results", False)),
                      "ms_per_step_each_query_waited_for": round(elapsed_waited / args.steps * 1e3, 4),
                      "value_each_query_waited_for": round(total_rows_per_step * args.steps / elapsed_waited, 1)},
@@ -372,17 +409,95 @@ def main(argv=None, hooks=None):
             # the boundary hands over host buffers: the PCIe-inclusive first pass (never the reported value)
             "first_pass_upload": {"bytes": uploaded_bytes, "GBs_including_plan_lowering": round(uploaded_bytes / first_pass_s / 1e9, 2) if first_pass_s > 0 else None},
         }
+        if steady is not None:
+            out["steady_state"] = steady
+        if reference_width is not None:
+            out["reference_width"] = reference_width
+        try:
+            c, d = eng.ctx.jit_stats()
+            out["specialised_kernels"] = {"compiled_by_hiprtc_in_this_process": int(c), "loaded_from_jit_cache": int(d)}
+        except Exception:
+            pass
+        if world > 1 or use_dist:
+            out["n_gpus_note"] = "ranks in this run: %d%s" % (world, "" if world > 1 else " (the distributed plan on a group of one; N > 1 was not run here)")
         if exchange is not None:
             out["q3_exchange"] = exchange
         if timed_collectives is not None:
             out["collectives_in_timed_region_rank0"] = timed_collectives
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is reported at N=1 only
-            out["cpu_baseline"] = cpu_baseline(args, queries, db, rows)
+            out["cpu_baseline"] = cpu_baseline(args, queries, db, rows, hip_results)
             out["cpu_baseline"]["configs0_q6_sf1"] = q6_sf1_leg(eng)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    return out
+
+
+def reference_width_leg(args, eng, db, rows, ran, run_query, run_steps, finish):
+    """"the headline fraction stays on the algorithmic figure so CPU and GPU are compared on identical work".  The
+    timed step streams exact narrow encodings of the columns (4-byte twins, 1- / 2-byte dictionary codes), so algorithmic bytes
+    over its time exceed the HBM peak and are no roofline fraction.  This leg switches the encodings off (`narrow` 0: every numeric
+    column is streamed in the reference's own 8-byte form; text columns that are only compared / grouped on still travel as int64
+    dictionary codes, 8 bytes instead of 4 per code unit), drops everything resident, uploads again and times q1 / q3 / q6 with the
+    protocol of the timed region.  frac = algorithmic bytes of the dominant kernel / its average launch time / 8 TB/s: at most 1,
+    and the figure that is comparable with `cpu_baseline` (which reads the same 8-byte columns).  Outside `value`."""
+    qs = [q for q in ("q1", "q3", "q6") if q in ran]
+    if not qs:
+        return None
+    out = {"option": "narrow=0 (no 4-byte twins, no dictionary codes of numeric columns); loops on the fixed-shape kernels, which are the ones "
+                     "tuned for 8-byte columns (two rows per lane: k_groupby_reg, k_scan_sum, k_stage, k_probe_agg)", "queries": {}}
+    eng.ctx.set_option("narrow", 0)
+    saved = (eng.stream_programs, eng.program_routes)
+    eng.stream_programs, eng.program_routes = False, set()
+    try:
+        eng.clear()
+        # the pinned-staged upload alone (g1): lineitem's columns, nothing else running, no plan lowering, no twins
+        li = db["lineitem"].getContainer()
+        t0 = time.perf_counter()
+        nbytes = 0
+        for arr in li["data"]:
+            if len(arr):
+                eng.column(arr)
+                nbytes += arr.nbytes
+        eng.ctx.synchronize()
+        up = time.perf_counter() - t0
+        out["upload_only"] = {"table": "lineitem", "bytes": int(nbytes), "seconds": round(up, 4), "GBs": round(nbytes / up / 1e9, 2) if up > 0 else None,
+                              "what": "sdqh_column_upload of every resident lineitem column back to back (pinned 2 x 32 MiB ring, async H2D), then one synchronise"}
+        n = max(1, min(args.steps, 10))
+        for q in qs:
+            finish(run_query(q))
+        eng.ctx.synchronize()
+        for _ in range(2):
+            for q in qs:
+                finish(run_query(q))
+        took, per_q, _ = run_steps(n, "-", qs, each_waited_for=True)
+        _, _, log = run_steps(n, None, qs)
+        for q in qs:
+            stat = {}
+            for qq, name, ms, nb in log:
+                if qq == q:
+                    tot, cnt, b = stat.get(name, (0.0, 0, 0))
+                    stat[name] = (tot + ms, cnt + 1, b + nb)
+            if not stat:
+                continue
+            ms_kernels = sum(t for t, _, _ in stat.values()) / n
+            dom = max(stat, key=lambda k: stat[k][0])
+            tot, cnt, b = stat[dom]
+            dom_ms = tot / cnt
+            ab_q, ab_dom = algorithmic_bytes(q, rows), DOMINANT[q][1](rows)
+            rec = {"ms_wall": round(per_q[q] / n, 4), "ms_kernels": round(ms_kernels, 4), "algorithmic_bytes": ab_q,
+                   "frac_kernels": round(ab_q / (ms_kernels * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                   "dominant_kernel": dom, "dominant_avg_launch_ms": round(dom_ms, 4), "dominant_algorithmic_bytes": ab_dom,
+                   "achieved": round(ab_dom / (dom_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                   "frac": round(ab_dom / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            if b:
+                rec["dominant_model_bytes_per_launch"] = b // cnt
+            out["queries"][q] = rec
+    finally:
+        eng.ctx.set_option("narrow", 1)
+        eng.stream_programs, eng.program_routes = saved
+        eng.clear()
     return out
 
 
@@ -405,7 +520,7 @@ def pmc_traffic(q, kernel, rows, ran=None):
     entry = rec.get("queries", {}).get(q)
     if not entry or any(rec.get("rows", {}).get(t) != rows.get(t) for t in entry.get("tables", ["lineitem"])):
         return None, None
-    source = "committed rocprofv3 PMC run (profiles/%s), not this run" % os.path.basename(path)
+    source = "committed rocprofv3 PMC run (profiles/%s%s), not this run" % (os.path.basename(path), ", collected at commit %s" % rec["commit"] if rec.get("commit") else "")
     if ran is not None and not set(ran) <= set(entry.get("kernels", {})):
         return None, None                                 # this run launched kernels the committed collection never saw: other code, other bytes
     if kernel is None:
@@ -436,7 +551,31 @@ def physical_cores():
     return logical, logical
 
 
-def cpu_baseline(args, queries, db, rows):
+def compare_results(got, want):
+    """HIP result against the CPU implementation's on the same tables: row sets equal on every integer / text column (counts are
+    integer columns), largest relative difference over the float columns."""
+    import numpy as np
+    if isinstance(want, float) or isinstance(got, float):
+        return {"rows_equal": True, "counts_equal": True, "max_rel": abs(got - want) / abs(want) if want else abs(got - want)}
+    if got.size() != want.size() or list(got.columns) != list(want.columns):
+        return {"rows_equal": False, "counts_equal": False, "max_rel": None, "rows": [got.size(), want.size()]}
+    ga, wa = [np.asarray(a) for a in got.arrays], [np.asarray(a) for a in want.arrays]
+    exact = [i for i, a in enumerate(wa) if a.dtype.kind != "f"]
+    order = lambda arrs: np.lexsort([arrs[i] for i in reversed(exact)]) if exact else np.arange(len(arrs[0]))      # noqa: E731
+    go, wo = order(ga), order(wa)
+    rows_equal = all(np.array_equal(ga[i][go], wa[i][wo]) for i in exact)
+    counts = [i for i in exact if "count" in got.columns[i]]
+    max_rel = 0.0
+    for i, a in enumerate(wa):
+        if a.dtype.kind == "f" and len(a):
+            g, w = ga[i][go], a[wo]
+            den = np.maximum(np.abs(g), np.abs(w))
+            rel = np.where(den > 0, np.abs(g - w) / np.where(den > 0, den, 1.0), 0.0)
+            max_rel = max(max_rel, float(rel.max()))
+    return {"rows": int(want.size()), "rows_equal": bool(rows_equal), "counts_equal": bool(all(np.array_equal(ga[i][go], wa[i][wo]) for i in counts)), "max_rel": max_rel}
+
+
+def cpu_baseline(args, queries, db, rows, hip_results=None):
     """The CPU port (oracle/, same plan as the reference's TBB code: per-thread partials + merge)
     timed on this box's host cores on a bounded sample of the same workload."""
     import numpy as np
@@ -470,8 +609,9 @@ def cpu_baseline(args, queries, db, rows):
     srows = {t: len(sample[t].getContainer()["data"][0]) for t in sample}
     plans = {q: frontend.lower_function(Q.QUERIES[q]) for q in queries}
     run = lambda q: engine.execute_plan(eng, plans[q], [sample[t] for t in Q.QUERY_TABLES[q]])   # noqa: E731
+    cpu_results = {}
     for q in queries:
-        run(q)                                   # warm-up (also copies the columns into the oracle's memory)
+        cpu_results[q] = run(q)                  # warm-up (also copies the columns into the oracle's memory); the results are the checker's
     iters, t0 = 0, time.perf_counter()
     per_q = {q: 0.0 for q in queries}
     while iters < 5 and (time.perf_counter() - t0) < 20.0:
@@ -480,6 +620,10 @@ def cpu_baseline(args, queries, db, rows):
             run(q)
             per_q[q] += time.perf_counter() - tq
         iters += 1
+    # parity at the size the line is quoted on: the HIP results of this run against the CPU implementation's, whole workload only
+    parity = None
+    if hip_results and frac >= 1.0:
+        parity = {q: compare_results(hip_results[q], cpu_results[q]) for q in queries if q in hip_results}
     elapsed = time.perf_counter() - t0
     total_rows = sum(scanned_rows(q, srows) for q in queries)
     eng.close()
@@ -504,7 +648,10 @@ def cpu_baseline(args, queries, db, rows):
             "sample": ("the whole workload (%d lineitem rows)" % srows.get("lineitem", 0) if frac >= 1.0 else
                        "same generator, first %.0f%% of orders + their lineitems (%d lineitem rows), dimension tables whole" % (100 * frac, srows.get("lineitem", 0)))
                       + "; %d passes of %s, data resident in host RAM" % (iters, "+".join(queries)),
-            "ms_per_query": {q: round(per_q[q] / iters * 1e3, 2) for q in queries}}
+            "ms_per_query": {q: round(per_q[q] / iters * 1e3, 2) for q in queries},
+            "note": "a faithful port of the reference's plan (per-thread partial tables, SERIAL insert(range) / AddMap merges: sdql_ir_cpp_generator_par.py:331-369, map_helper.h:1-23): "
+                    "the merges do not scale with threads, so many cores buy little (value vs value_one_thread); a stated baseline, not a target — the roofline fraction is the measure",
+            "parity_at_bench_size": parity}
 
 
 def q6_sf1_leg(hip_eng):

@@ -171,6 +171,13 @@ int         sdqh_set_profiling(sdqh_ctx* ctx, int mode);
 int         sdqh_set_profile_filter(sdqh_ctx* ctx, const char* kernel_name);
 int         sdqh_profile_count(const sdqh_ctx* ctx);
 int         sdqh_profile_entry(const sdqh_ctx* ctx, int i, const char** name, double* ms);
+/* HBM bytes launch i is MODELLED to move, from what the library itself decided for that launch: bytes per row of every streamed
+ * column at the encoding chosen (8-byte column / 4-byte twin / 1- or 2-byte dictionary code) x rows, plus the key bitmap a
+ * streamed prefilter reads and the stores the launch makes by construction.  Gathers by row and data-dependent stores (survivor
+ * counts are on the device) are NOT in it, so for probing kernels it is a lower bound; for pure streaming kernels (K-A, small K-C)
+ * it is what the PMC counters should show (bench.py prints it beside them: SURVEY.md 8(d) "physical bytes moved").  0: no model
+ * for that kernel.  CPU build: always invalid (no launches). */
+int         sdqh_profile_entry_bytes(const sdqh_ctx* ctx, int i, int64_t* model_bytes);
 /* Raw hipStream_t the ctx launches on (NULL in the CPU build). */
 void*       sdqh_stream(const sdqh_ctx* ctx);
 /* Tuning knobs of the HIP build; results never depend on them (the parity suite runs with the defaults, A/B runs in

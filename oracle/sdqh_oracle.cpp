@@ -339,6 +339,7 @@ int sdqh_set_profiling(sdqh_ctx* ctx, int) { return ctx ? SDQH_OK : SDQH_ERR_INV
 int sdqh_set_profile_filter(sdqh_ctx* ctx, const char*) { return ctx ? SDQH_OK : SDQH_ERR_INVALID; }
 int sdqh_profile_count(const sdqh_ctx*) { return 0; }
 int sdqh_profile_entry(const sdqh_ctx*, int, const char**, double*) { return SDQH_ERR_INVALID; }
+int sdqh_profile_entry_bytes(const sdqh_ctx*, int, int64_t*) { return SDQH_ERR_INVALID; }
 void* sdqh_stream(const sdqh_ctx*) { return nullptr; }
 int sdqh_set_option(sdqh_ctx* ctx, const char*, int64_t) { return ctx ? SDQH_OK : SDQH_ERR_INVALID; }
 

@@ -210,7 +210,7 @@ class Program:
 
 EXPORTS = [
     "sdqh_abi_version", "sdqh_backend_name", "sdqh_create", "sdqh_destroy", "sdqh_last_error", "sdqh_set_threads",
-    "sdqh_synchronize", "sdqh_last_device_ms", "sdqh_set_profiling", "sdqh_set_profile_filter", "sdqh_profile_count", "sdqh_profile_entry",
+    "sdqh_synchronize", "sdqh_last_device_ms", "sdqh_set_profiling", "sdqh_set_profile_filter", "sdqh_profile_count", "sdqh_profile_entry", "sdqh_profile_entry_bytes",
     "sdqh_stream", "sdqh_set_option",
     "sdqh_column_upload", "sdqh_column_wrap", "sdqh_column_alloc", "sdqh_column_download", "sdqh_column_data",
     "sdqh_column_rows", "sdqh_column_dtype", "sdqh_column_width", "sdqh_column_minmax", "sdqh_column_free",
@@ -451,6 +451,15 @@ class Context:
             name, ms = C.c_char_p(), C.c_double()
             self._check(self.lib.sdqh_profile_entry(self.handle, C.c_int(i), C.byref(name), C.byref(ms)))
             out.append((name.value.decode(), ms.value))
+        return out
+
+    def profile_bytes(self):
+        """[(kernel, ms, modelled HBM bytes or 0)] of every recorded launch (sdqh_profile_entry_bytes)."""
+        out = []
+        for i, (name, ms) in enumerate(self.profile()):
+            b = C.c_int64()
+            self._check(self.lib.sdqh_profile_entry_bytes(self.handle, C.c_int(i), C.byref(b)))
+            out.append((name, ms, int(b.value)))
         return out
 
     def stream(self):
@@ -895,6 +904,7 @@ class Library:
         L.sdqh_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         L.sdqh_profile_count.argtypes = [C.c_void_p]
         L.sdqh_profile_entry.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.sdqh_profile_entry_bytes.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.sdqh_column_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
         L.sdqh_column_wrap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
         L.sdqh_column_alloc.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]

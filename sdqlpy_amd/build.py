@@ -23,6 +23,9 @@ HIP_UNITS = [("sdqh_hip.hip", "sdqh_hip.o"), ("sdqh_x.hip", "sdqh_x.o"), ("sdqh_
 HIP_SOURCES = [os.path.join(CSRC, src) for src, _ in HIP_UNITS]
 HIP_HEADERS = [os.path.join(INCLUDE, "sdqh.h"), os.path.join(CSRC, "sdqh_kernels.hpp"), os.path.join(CSRC, "sdqh_host.hpp"),
                os.path.join(CSRC, "sdqh_xkernels.hpp")]      # sdqh_x.hip packs XArgs / sink arguments from its structs
+# what each unit includes: the run-time skeletons (sdqh_xkernels.hpp) are compiled into sdqh_x.hip only — editing them must not
+# recompile the ahead-of-time unit (a quarter of an hour)
+UNIT_HEADERS = {"sdqh_x.hip": HIP_HEADERS}
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-ffp-contract=off",          # keep the reference's a*(1.0-b) association: no FMA contraction
@@ -106,7 +109,7 @@ def build_hip(force=False, save_temps=False):
             if save_temps:
                 cmd.insert(1, "-save-temps=obj")
             return cmd
-        _build_to(obj, cmd_for, [path] + HIP_HEADERS, force)
+        _build_to(obj, cmd_for, [path] + UNIT_HEADERS.get(src, HIP_HEADERS[:3]), force)
     _build_to(HIP_LIB, lambda out: [hipcc] + HIP_LINK + ["-o", out] + objs, objs, True)
     return HIP_LIB
 

@@ -584,6 +584,11 @@ int sdqh_profile_entry(const sdqh_ctx* cctx, int i, const char** name, double* m
     *name = e.name; *ms = e.ms;
     return SDQH_OK;
 }
+int sdqh_profile_entry_bytes(const sdqh_ctx* ctx, int i, int64_t* model_bytes) {
+    if (!ctx || i < 0 || i >= (int)ctx->prof.size() || !model_bytes) return SDQH_ERR_INVALID;
+    *model_bytes = ctx->prof[(size_t)i].model_bytes;
+    return SDQH_OK;
+}
 void* sdqh_stream(const sdqh_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return SDQH_ERR_INVALID;

@@ -25,7 +25,7 @@ struct PoolBlock {
     uint64_t alloc_seq = 0;                        // the ctx's launch counter when the block was handed out
     bool fill_use = false;                         // this use of the block received (or was spared) a fill: its habits are alive
 };
-struct ProfEntry { const char* name; hipEvent_t e0, e1; double ms; };
+struct ProfEntry { const char* name; hipEvent_t e0, e1; double ms; int64_t model_bytes; };      // model_bytes: HBM bytes this launch is MODELLED to move (0: not modelled), see sdqh_profile_entry_bytes
 
 constexpr size_t STAGING_BYTES = 32u << 20;       // pinned H2D staging ring: 2 x 32 MiB
 constexpr size_t RESULT_BYTES = 64u << 10;        // pinned buffer for small results
@@ -55,6 +55,7 @@ struct sdqh_ctx {
     int profiling = 0;                             // 0 off, 1 per call, 2 accumulate across calls (read at the end)
     std::string prof_filter;                       // record only launches of this kernel (empty = all)
     std::vector<sdqh_host::ProfEntry> prof;
+    int64_t next_model_bytes = 0;                  // set by a launcher right before its launch: the bytes that launch streams by construction (encodings x rows); consumed by KernelScope
     std::vector<hipEvent_t> event_pool;
     size_t event_next = 0;
     // hint: key columns whose group count overflowed the register kernel last time
@@ -220,9 +221,11 @@ struct KernelScope {
     sdqh_ctx* ctx; size_t idx = (size_t)-1;
     KernelScope(sdqh_ctx* c, const char* name) : ctx(c) {
         ++c->launch_seq;
+        const int64_t model = c->next_model_bytes;
+        c->next_model_bytes = 0;
         if (!c->profiling) return;
         if (!c->prof_filter.empty() && c->prof_filter != name) return;
-        ProfEntry e{name, next_event(c), next_event(c), 0.0};
+        ProfEntry e{name, next_event(c), next_event(c), 0.0, model};
         (void)hipEventRecord(e.e0, c->stream);
         idx = c->prof.size(); c->prof.push_back(e);
     }

@@ -913,6 +913,14 @@ std::string generate(const XInfo& x, Sink sink, bool direct) {
     }   // !q8
     auto body = [&](int mode, int from_gate) {
         g.reset(); g.mode = mode; g.os.str("");
+        // A drained row has passed the streamed prefilter (the looked-up table's key bitmap), so nearly every one of them goes on to its
+        // values: the by-row loads of the columns the values read are requested up front, beside the lookup's chain of dependent loads,
+        // not behind the branch that ends it (a round trip less per drain)
+        if (mode == 0 && x.prefilter_op >= 0 && std::getenv("SDQLPY_AMD_X_HOIST") != nullptr) {
+            std::vector<char> need((size_t)p->nops, 0);
+            for (int v = 0; v < p->nvals; ++v) closure(p, p->vals[v], need);
+            for (int k = 0; k < p->nops; ++k) if (need[(size_t)k] && p->ops[k].code == SDQH_X_COL && x.cols[x.col_of[k]]->dtype != SDQH_STR) g.emit(k);
+        }
         for (int q = from_gate; q < p->ngates; ++q) { g.emit(p->gates[q]); g.os << "        if (!v" << p->gates[q] << ") return false;\n"; }
         if (p->key >= 0) { g.emit(p->key); g.os << "        o.key = v" << p->key << "; o.bad = " << g.bad(p->key) << ";\n"; }
         else g.os << "        o.key = 0; o.bad = false;\n";
@@ -1026,7 +1034,15 @@ int kernel_for(sdqh_ctx* ctx, const XInfo& x, Sink sink, bool direct, hipFunctio
     return SDQH_OK;
 }
 
-int specialise(sdqh_ctx* ctx, const std::string& source, const std::string& entry, hipFunction_t* fn) {
+int specialise(sdqh_ctx* ctx, const std::string& source_in, const std::string& entry, hipFunction_t* fn) {
+    // SDQLPY_AMD_X_DEFINES="NAME=VALUE NAME=VALUE": macros put in front of every specialised source (A/B switches of the skeletons,
+    // e.g. X8_PIPE=1; part of the source, so of the cache key)
+    std::string source = source_in;
+    if (const char* defs = std::getenv("SDQLPY_AMD_X_DEFINES")) {
+        std::istringstream in(defs); std::string tok, head;
+        while (in >> tok) { const size_t eq = tok.find('='); head += "#define " + (eq == std::string::npos ? tok + " 1" : tok.substr(0, eq) + " " + tok.substr(eq + 1)) + "\n"; }
+        source = head + source;
+    }
     JitState& J = jit();
     std::lock_guard<std::mutex> lock(J.mu);
     if (!load_headers(J)) return fail(ctx, SDQH_ERR_DEVICE, J.why_unusable);
@@ -1134,6 +1150,26 @@ int launch(sdqh_ctx* ctx, hipFunction_t fn, const char* name, const XArgs& a, co
     return SDQH_OK;
 }
 
+// HBM bytes a launch of this program streams BY CONSTRUCTION (sdqh_profile_entry_bytes): every streamed column at the encoding this
+// call chose x rows, and the key bitmaps its streamed membership tests read (once: they stay in L2).  Gathers by row and
+// survivor-dependent stores are not modelled; nor is the tile every workgroup of the pipelined tight skeleton requests a second
+// time after its last (an L2 hit: it never reaches the memory side).
+int64_t model_stream_bytes(const XInfo& x, int64_t nrows, bool regs_all) {
+    int64_t per_row = 0;
+    for (int c = 0; c < x.ncols; ++c) {
+        bool streamed = regs_all;
+        if (!streamed) for (int sc : x.scols) streamed = streamed || sc == c;
+        if (!streamed || x.cols[c]->dtype == SDQH_STR) continue;
+        if (x.tight) per_row += x.enc[c] == ENC_C8 ? 1 : x.enc[c] == ENC_C16 ? 2 : x.enc[c] == ENC_N32 ? 4 : 8;
+        else per_row += ((x.narrow_mask >> c) & 1u) ? 4 : 8;
+    }
+    int64_t bytes = per_row * nrows;
+    auto bitmap = [&](const sdqh_table* t) { if (t && t->dev.bm && t->dev.bm_hi >= t->dev.bm_lo) bytes += (int64_t)(((uint64_t)(t->dev.bm_hi - t->dev.bm_lo) >> t->dev.bm_shift) / 8 + 4); };
+    if (x.vstage) for (int l = 0; l < x.nlk; ++l) bitmap(x.tabs[x.tab_of[x.lk_op[l]]]);
+    else if (!regs_all && x.prefilter_op >= 0) bitmap(x.tabs[x.tab_of[x.prefilter_op]]);
+    return bytes;
+}
+
 int read_flags(sdqh_ctx* ctx, const int32_t* d_flags, int* out) {
     HIP_TRYX(ctx, hipMemcpyAsync(ctx->result_host, d_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
     if (int rc = sync_stream(ctx)) return rc;
@@ -1171,6 +1207,7 @@ int sdqh_xscan_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, doubl
     double* partial = static_cast<double*>(pool_alloc(ctx, (size_t)g.grid * 5 * sizeof(double)));
     if (!partial) return fail(ctx, SDQH_ERR_NOMEM, "xscan_sum: out of device memory");
     XSum<1>::Args sa{partial};
+    ctx->next_model_bytes = model_stream_bytes(x, nrows, x.direct);
     int rc = launch(ctx, fn, launch_label(SINK_SUM, x.direct, x.tight), a, sa, nrows, g);
     if (!rc) {
         launch_sum_partials(ctx, partial, (int)g.grid, static_cast<double*>(ctx->result_host));      // the fold writes the pinned host block: no copy-engine launch
@@ -1220,9 +1257,11 @@ static int xgroupby_launch(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* pro
     int rc;
     if (sink == SINK_GROUP_LANE) {
         XGroupLane<1>::Args sa{r_keys, pacc, pcnt, r_flags, nslots, 0};
+        ctx->next_model_bytes = model_stream_bytes(x, nrows, true) + (int64_t)nslots * g.grid * 40;
         rc = launch(ctx, fn, launch_label(SINK_GROUP_LANE, true, true), a, sa, nrows, g, (unsigned)((size_t)nslots * (size_t)(prog->nvals + 1) * TPB * 8));
     } else {
         XGroup<1>::Args sa{r_keys, pacc, pcnt, r_flags};
+        ctx->next_model_bytes = model_stream_bytes(x, nrows, x.direct) + (int64_t)npart * 40;
         rc = launch(ctx, fn, launch_label(SINK_GROUP, x.direct, x.tight), a, sa, nrows, g);
     }
     if (!rc) {
@@ -1332,7 +1371,13 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
     { const sdqh_xop& ko = prog->ops[prog->key];                       // a strictly increasing key column (a primary key): no duplicate keys whatever the gates pass
       if (ko.code == SDQH_X_COL && ko.col->dtype == SDQH_I64 && !ko.col->transient && nrows > 0 && column_increasing(ctx, const_cast<sdqh_column*>(ko.col))) tb->keys_unique = true; }
     call_begin(ctx);
-    int rc = stage_setup_computed(ctx, tb, nrows, prog->nvals, x.tight ? (X8_STEP * X8_U) / 128 : X_LB);
+    int stage_batch = x.tight ? (X8_STEP * X8_U) / 128 : X_LB;
+    if (ctx->opt_x_waves > 0) {                                           // (tuning: wave segments per CU — the stage cuts segments in whole batches of 128 rows)
+        const int64_t seg = (nrows + (int64_t)ctx->num_cu * ctx->opt_x_waves - 1) / ((int64_t)ctx->num_cu * ctx->opt_x_waves);
+        const int64_t per = (int64_t)128 * stage_batch;
+        stage_batch = (int)std::min<int64_t>(1 << 20, std::max<int64_t>(1, (seg + per - 1) / per) * stage_batch);
+    }
+    int rc = stage_setup_computed(ctx, tb, nrows, prog->nvals, stage_batch);
 
     uint64_t capmax = 1024;
     while (capmax < 2 * (uint64_t)std::max<int64_t>(nrows, 1)) capmax <<= 1;
@@ -1362,6 +1407,7 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
             // the segments were cut by stage_setup_computed: the kernel's geometry must be the stage's
             Geometry g{(unsigned)((tb->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE)), tb->stage.seg_rows, tb->stage.nseg};
             XStage<1>::Args sa{tb->stage};
+            ctx->next_model_bytes = model_stream_bytes(x, nrows, x.vstage);
             rc = launch(ctx, fn, x.vstage ? VSTAGE_ENTRY : launch_label(SINK_STAGE, false, x.tight), a, sa, nrows, g);
         }
         call_end(ctx);
@@ -1418,6 +1464,7 @@ int sdqh_xkey_set(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_
     if (!rc && nrows > 0) {
         const Geometry g = geometry(ctx, nrows, false, 16, x.tight);
         XKeySet<1>::Args sa{tb->bm};
+        ctx->next_model_bytes = model_stream_bytes(x, nrows, false);
         rc = launch(ctx, fn, launch_label(SINK_KEYSET, false, x.tight), a, sa, nrows, g);
     }
     call_end(ctx);
@@ -1453,6 +1500,7 @@ int sdqh_xprobe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog
     if (int rc = fill_xargs(ctx, x, &a, d_flags, 1, 0)) return rc;
     const Geometry g = geometry(ctx, nrows, false, 24, x.tight);
     XEntry<1>::Args sa{table->dev};
+    ctx->next_model_bytes = model_stream_bytes(x, nrows, false);
     int rc = launch(ctx, fn, launch_label(SINK_ENTRY, false, x.tight), a, sa, nrows, g);
     call_end(ctx);
     return rc;

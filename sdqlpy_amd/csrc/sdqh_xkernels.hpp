@@ -16,6 +16,26 @@
 #pragma once
 #include "sdqh_kernels.hpp"
 
+// A/B switches of the skeletons (SDQLPY_AMD_X_DEFINES puts macros in front of a specialised source; defaults here)
+#ifndef XE_EXP
+#define XE_EXP 0                                                      // timing experiments of the entry sink (wrong results): 1 no atomics, 2 no count atomic
+#endif
+#ifndef X8_DRAIN_AT
+#define X8_DRAIN_AT WAVE                                              // x_queue8 drains the front of its queue once this many rows wait (64: only whole waves)
+#endif
+#ifndef X8_EXP
+#define X8_EXP 0                                                      // timing experiments of x_queue8 (wrong results): 1 no bitmap requests, 2 nothing queued, 3 queued but never drained
+#endif
+#ifndef X8_WIN
+#define X8_WIN 0                                                      // x_queue8, 32-bit prefilter: one 16-byte window of the bitmap per lane and 8 rows instead of 8 words (see there)
+#endif
+#ifndef X8_PIPE
+#define X8_PIPE 0                                                     // x_queue8: the next double step's streamed loads requested behind this step's bitmap words (see there)
+#endif
+#ifndef XV_PIPE
+#define XV_PIPE 0                                                     // x_vstage8: the next step's streamed loads requested behind this step's bitmap words (see there)
+#endif
+
 namespace sdqh {
 
 constexpr int X_MAX_CONST = SDQH_MAX_XCONST;
@@ -281,11 +301,20 @@ template <int NV> struct XEntry {
                 head |= oh;
             }
         }
+#if XE_EXP == 1
+        if (tail && v[0] == 1.2345e300) atomicAdd(&s.tb.shits[idx], cnt);                   // (timing experiment: no atomics)
+#elif XE_EXP == 2
+        if (tail) {                                                                            // (timing experiment: sums only)
+#pragma unroll
+            for (int k = 0; k < NV; ++k) atomicAdd(&s.tb.sacc[(size_t)idx * s.tb.acc_stride + k], v[k]);
+        }
+#else
         if (tail) {
 #pragma unroll
             for (int k = 0; k < NV; ++k) atomicAdd(&s.tb.sacc[(size_t)idx * s.tb.acc_stride + k], v[k]);
             atomicAdd(&s.tb.shits[idx], cnt);
         }
+#endif
     }
     __device__ __forceinline__ void finish(const XArgs&, const Args&) {}
 };
@@ -684,6 +713,12 @@ __device__ __forceinline__ void x_tight(const XArgs& a, const typename SinkT<P::
 constexpr int X8_U = 2;
 constexpr int X8_STEP = WAVE * XT_R;                                  // 512 rows per wave step
 constexpr int X8_CAP = 64 + X8_U * X8_STEP;
+// four consecutive bitmap words from any word on (4-byte aligned: gfx950 serves a dwordx4 global load at dword alignment)
+using XWindow = uint32_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ XWindow x_load_window(const uint32_t* p) {
+    typedef XWindow __attribute__((aligned(4))) UW;                  // one global_load_dwordx4 (checked in the ISA), tracked by the compiler's waitcnt pass
+    return *reinterpret_cast<const UW*>(p);
+}
 
 __device__ __forceinline__ int wave_excl_prefix(int v, int& total) {  // exclusive prefix sum over the 64 lanes; total = the wave's sum
     int incl = v;
@@ -691,6 +726,20 @@ __device__ __forceinline__ int wave_excl_prefix(int v, int& total) {  // exclusi
     for (int off = 1; off < WAVE; off <<= 1) { const int o = __shfl_up(incl, off, WAVE); if (lane_id() >= off) incl += o; }
     total = __shfl(incl, WAVE - 1, WAVE);
     return incl - v;
+}
+// The same for counts of at most 15 (a lane's survivors among its 8 rows), without a cross-lane dependency chain: bit k of the
+// counts as a ballot, lanes below counted by v_mbcnt — four ballots, eight mbcnt, no LDS-crossbar round trips (the shuffle form is six
+// dependent ds_bpermute rounds per call, twice per 1024-row step: 8 us of Q3's 86 us probe went into queueing ~5 survivors per step).
+__device__ __forceinline__ int wave_excl_prefix4(uint32_t v, int& total) {
+    int below = 0, all = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint64_t b = __ballot((v >> k) & 1u);
+        below += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u)) << k;
+        all += __popcll(b) << k;
+    }
+    total = all;
+    return below;
 }
 
 template <class P, template <int> class SinkT, bool SEGMENTED>
@@ -725,63 +774,86 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
     auto enqueue8 = [&](int64_t r0, uint32_t m) {                      // m: bit i = row r0 + i of this lane survives
         if (!__ballot(m != 0)) return;
         int total;
-        int at = qn + wave_excl_prefix(__popc(m), total);
+        int at = qn + wave_excl_prefix4(__popc(m), total);
         const int32_t off = (int32_t)(r0 - begin);
-#pragma unroll
-        for (int i = 0; i < XT_R; ++i) if ((m >> i) & 1u) q_row[at++] = off + i;
+        while (m) { q_row[at++] = off + (__ffs((int)m) - 1); m &= m - 1u; }        // as many rounds as the fullest lane has survivors (sparse: one or two)
         qn += total;
     };
     if (live) {
+#if X8_PIPE
+        typename P::Regs pre[X8_U];
+        if (begin + (int64_t)X8_STEP * X8_U <= end) {
+#pragma unroll
+            for (int u = 0; u < X8_U; ++u) P::template sload<false>(a, begin + (int64_t)u * X8_STEP + (int64_t)lane * XT_R, nrows, pre[u]);
+        }
+#endif
         for (int64_t b = begin;;) {
             const bool last = b >= end;
             if (last) {
             } else if (b + (int64_t)X8_STEP * X8_U <= end) {
-                // (requesting the NEXT double step's loads here, before this one is consumed — the software pipeline that pays in
-                //  x_tight — measured slower in the queue skeletons: Q3's probe 0.103 -> 0.110 ms, its build 0.094 -> 0.103 ms)
+                // The NEXT double step's streamed loads are requested behind this step's bitmap words and before anything waits
+                // (X8_PIPE): `s_waitcnt vmcnt` counts in issue order, so requested BEFORE the words (round 3's attempt: Q3's probe
+                // 0.103 -> 0.110 ms) they have to land before the words can be tested and nothing overlaps; behind them they stay in
+                // flight through the tests, the queueing and the drains of this step.  Unconditional (behind the segment's last double
+                // step: that step again), so no wait piles up in front of a branch.
                 typename P::Regs s[X8_U];
+#if X8_PIPE
+#pragma unroll
+                for (int u = 0; u < X8_U; ++u) s[u] = pre[u];
+#else
 #pragma unroll
                 for (int u = 0; u < X8_U; ++u) P::template sload<false>(a, b + (int64_t)u * X8_STEP + (int64_t)lane * XT_R, nrows, s[u]);
-                uint32_t m[X8_U];
+#endif
+                uint32_t m[X8_U], off[X8_U][XT_R], w[X8_U][XT_R];
+#if X8_WIN
+                uint32_t wb[X8_U]; XWindow win[X8_U];
+#endif
                 if constexpr (P::PREF32) {
                     // 32-bit form (the key and the bitmap's range fit 32 bits — known when the kernel was specialised): a row costs
                     // a subtract, an unsigned compare, a select, a shift and a bit-field extract.  The 64-bit form below spent ~30
                     // vector instructions per row and left the kernel issue-bound at half of what its bytes allow (PMC, Q3's probe)
-                    uint32_t off[X8_U][XT_R], w[X8_U][XT_R];
 #pragma unroll
                     for (int u = 0; u < X8_U; ++u) {
                         m[u] = 0;
 #pragma unroll
                         for (int i = 0; i < XT_R; ++i) { const bool p = P::spre32(a, s[u], s_tab, i, off[u][i]); m[u] |= p ? (1u << i) : 0u; }
                     }
+#if X8_EXP == 1
+                    // (timing experiment: no bitmap requests at all)
+#elif X8_WIN
+                    // WINDOW: a lane's 8 consecutive rows carry near-by keys when the key column is clustered (a foreign key of a table
+                    // stored in the order of its parent: l_orderkey), so ONE 16-byte request per lane — the four bitmap words from the
+                    // word of its smallest passing key on — answers all eight tests; a row whose key lies beyond those 128 bits asks for
+                    // its own word afterwards (rare).  Every vector-memory instruction occupies the CU's address path for its 64 lanes
+                    // whether or not they share a line: eight 4-byte requests per 8 rows made this loop address-bound (35.9 M cache
+                    // accesses for Q3's probe, 0.058 ms of a 0.094 ms kernel) long before it was byte-bound.
+#pragma unroll
+                    for (int u = 0; u < X8_U; ++u) {
+                        uint32_t lo = 0xFFFFFFFFu;
+#pragma unroll
+                        for (int i = 0; i < XT_R; ++i) { const uint32_t o = ((m[u] >> i) & 1u) ? off[u][i] : 0xFFFFFFFFu; lo = o < lo ? o : lo; }
+                        wb[u] = m[u] ? lo >> 5 : 0u;
+                        win[u] = x_load_window(pbm + wb[u]);
+                    }
+#else
 #pragma unroll
                     for (int u = 0; u < X8_U; ++u)
 #pragma unroll
                         for (int i = 0; i < XT_R; ++i) w[u][i] = pbm[off[u][i] >> 5];
-#pragma unroll
-                    for (int u = 0; u < X8_U; ++u) {
-                        uint32_t hit = 0;
-#pragma unroll
-                        for (int i = 0; i < XT_R; ++i) hit |= __builtin_amdgcn_ubfe(w[u][i], off[u][i] & 31u, 1u) << i;
-                        m[u] &= hit;
-                    }
+#endif
                 } else if (pbm) {
                     // the prefilter's bitmap words of all 16 rows are requested before any is tested (a load inside each row's own
                     // `if (passes the cheap conditions)` region made a step sixteen dependent round trips)
-                    uint32_t wi[X8_U][XT_R], w[X8_U][XT_R];
 #pragma unroll
                     for (int u = 0; u < X8_U; ++u) {
                         m[u] = 0;
 #pragma unroll
-                        for (int i = 0; i < XT_R; ++i) { uint32_t bit; const bool p = P::spre(a, s[u], s_tab, i, wi[u][i], bit); m[u] |= p ? (1u << i) : 0u; wi[u][i] |= bit << 27; }
+                        for (int i = 0; i < XT_R; ++i) { uint32_t bit; const bool p = P::spre(a, s[u], s_tab, i, off[u][i], bit); m[u] |= p ? (1u << i) : 0u; off[u][i] |= bit << 27; }
                     }
 #pragma unroll
                     for (int u = 0; u < X8_U; ++u)
 #pragma unroll
-                        for (int i = 0; i < XT_R; ++i) w[u][i] = pbm[wi[u][i] & 0x07FFFFFFu];
-#pragma unroll
-                    for (int u = 0; u < X8_U; ++u)
-#pragma unroll
-                        for (int i = 0; i < XT_R; ++i) m[u] &= ~(((~w[u][i] >> (wi[u][i] >> 27)) & 1u) << i);
+                        for (int i = 0; i < XT_R; ++i) w[u][i] = pbm[off[u][i] & 0x07FFFFFFu];
                 } else {
 #pragma unroll
                     for (int u = 0; u < X8_U; ++u) {
@@ -790,6 +862,60 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
                         for (int i = 0; i < XT_R; ++i) m[u] |= P::stest(a, s[u], s_tab, i) ? (1u << i) : 0u;
                     }
                 }
+#if X8_PIPE
+                {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int64_t bn = b + 2 * (int64_t)X8_STEP * X8_U <= end ? b + (int64_t)X8_STEP * X8_U : b;
+#pragma unroll
+                    for (int u = 0; u < X8_U; ++u) P::template sload<false>(a, bn + (int64_t)u * X8_STEP + (int64_t)lane * XT_R, nrows, pre[u]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#endif
+                if constexpr (P::PREF32) {
+#if X8_EXP == 1
+#pragma unroll
+                    for (int u = 0; u < X8_U; ++u) m[u] = ((uint32_t)a.key_hi == 0x12345678u) ? m[u] : 0u;
+#elif X8_WIN
+#pragma unroll
+                    for (int u = 0; u < X8_U; ++u) {
+                        uint32_t hit = 0, beyond = 0;
+#pragma unroll
+                        for (int i = 0; i < XT_R; ++i) {
+                            const uint32_t rel = off[u][i] - (wb[u] << 5);
+                            const uint32_t k = rel >> 5;
+                            const uint32_t word = k == 0 ? win[u].x : k == 1 ? win[u].y : k == 2 ? win[u].z : win[u].w;
+                            hit |= (k < 4u ? __builtin_amdgcn_ubfe(word, rel & 31u, 1u) : 0u) << i;
+                            beyond |= (k < 4u ? 0u : 1u) << i;
+                        }
+                        beyond &= m[u];
+                        if (__ballot(beyond != 0)) {                                       // keys beyond the lane's window: their own words (wave-uniform branch per row slot)
+#pragma unroll
+                            for (int i = 0; i < XT_R; ++i) {
+                                const bool far = (beyond >> i) & 1u;
+                                if (__ballot(far)) { const uint32_t wd = pbm[far ? off[u][i] >> 5 : 0u]; hit |= (far ? __builtin_amdgcn_ubfe(wd, off[u][i] & 31u, 1u) : 0u) << i; }
+                            }
+                        }
+                        m[u] &= hit;
+                    }
+#else
+#pragma unroll
+                    for (int u = 0; u < X8_U; ++u) {
+                        uint32_t hit = 0;
+#pragma unroll
+                        for (int i = 0; i < XT_R; ++i) hit |= __builtin_amdgcn_ubfe(w[u][i], off[u][i] & 31u, 1u) << i;
+                        m[u] &= hit;
+                    }
+#endif
+                } else if (pbm) {
+#pragma unroll
+                    for (int u = 0; u < X8_U; ++u)
+#pragma unroll
+                        for (int i = 0; i < XT_R; ++i) m[u] &= ~(((~w[u][i] >> (off[u][i] >> 27)) & 1u) << i);
+                }
+#if X8_EXP == 2
+#pragma unroll
+                for (int u = 0; u < X8_U; ++u) m[u] = ((uint32_t)a.key_hi == 0x12345678u) ? m[u] : 0u;      // (timing experiment: tests done, nothing queued)
+#endif
 #pragma unroll
                 for (int u = 0; u < X8_U; ++u) enqueue8(b + (int64_t)u * X8_STEP + (int64_t)lane * XT_R, m[u]);
                 b += (int64_t)X8_STEP * X8_U;
@@ -813,7 +939,10 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
                 b += X8_STEP;
             }
             int head = 0;
-            while (qn - head >= WAVE || (last && qn > head)) {
+#if X8_EXP == 3
+            if ((uint32_t)a.key_hi != 0x12345678u) qn = 0;                   // (timing experiment: survivors queued, never drained)
+#endif
+            while (qn - head >= X8_DRAIN_AT || (last && qn > head)) {
                 const int n = qn - head >= WAVE ? WAVE : qn - head;
                 drain(head, n);
                 head += n;
@@ -897,7 +1026,7 @@ __device__ __forceinline__ void x_vstage8(const XArgs& a, const typename XStage<
     auto enqueue = [&](const typename P::Regs& s, int64_t r0, uint32_t m) {   // the lane's survivors (bits of m), in row order
         if (!__ballot(m != 0)) return;
         int total;
-        int at = qn + wave_excl_prefix(__popc(m), total);
+        int at = qn + wave_excl_prefix4(__popc(m), total);
 #pragma unroll
         for (int i = 0; i < XT_R; ++i) {
             XOut<P::NV> o;
@@ -928,13 +1057,13 @@ __device__ __forceinline__ void x_vstage8(const XArgs& a, const typename XStage<
             qn = left;
         }
     };
-    auto step = [&](int64_t b, auto u_tag, auto tail_tag) {
+    // One step in three parts, so that the main loop can put the NEXT step's streamed loads between this step's bitmap requests and
+    // their use: `s_waitcnt vmcnt` counts in issue order, so loads requested BEFORE the bitmap words (the pipeline tried in round 3)
+    // have to land before the words can be tested — nothing overlaps; requested AFTER them they stay in flight through the tests,
+    // the queueing and the flush stores of this step.
+    auto prep = [&](const auto& s, int64_t b, auto u_tag, auto tail_tag, auto& m, auto& off) {        // conditions on the streamed registers, bitmap offsets
         constexpr int U = decltype(u_tag)::value ? X8_U : 1;
         constexpr bool TAIL = decltype(tail_tag)::value;
-        typename P::Regs s[U];
-        uint32_t m[U], off[NL][U][XT_R], w[NL][U][XT_R];
-#pragma unroll
-        for (int u = 0; u < U; ++u) P::template sload<TAIL>(a, b + (int64_t)u * X8_STEP + (int64_t)lane * XT_R, TAIL ? end : nrows, s[u]);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             m[u] = 0;
@@ -947,12 +1076,24 @@ __device__ __forceinline__ void x_vstage8(const XArgs& a, const typename XStage<
                 m[u] |= p ? (1u << i) : 0u;
             }
         }
+    };
+    auto request = [&](auto u_tag, const auto& off, auto& w) {                                         // the bitmap words of a step's rows, together
+        constexpr int U = decltype(u_tag)::value ? X8_U : 1;
 #pragma unroll
         for (int l = 0; l < NL; ++l) if (P::NL > l)
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int i = 0; i < XT_R; ++i) w[l][u][i] = bm[l][off[l][u][i] >> 5];
+                for (int i = 0; i < XT_R; ++i) {
+#if defined(XV_EXP) && (XV_EXP & 8)
+                    w[l][u][i] = 0xFFFFFFFFu;                                      // (timing experiment: no bitmap requests, every key "found")
+#else
+                    w[l][u][i] = bm[l][off[l][u][i] >> 5];
+#endif
+                }
+    };
+    auto finish = [&](const auto& s, int64_t b, auto u_tag, auto& m, const auto& off, const auto& w) {   // bit tests, survivors queued, full groups stored
+        constexpr int U = decltype(u_tag)::value ? X8_U : 1;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -962,10 +1103,53 @@ __device__ __forceinline__ void x_vstage8(const XArgs& a, const typename XStage<
                 for (int i = 0; i < XT_R; ++i) hit |= __builtin_amdgcn_ubfe(w[l][u][i], off[l][u][i] & 31u, 1u) << i;
                 m[u] &= hit;
             }
+#if defined(XV_EXP) && (XV_EXP & 16)
+            m[u] = ((uint32_t)a.key_hi == 0x12345678u) ? m[u] : 0u;                 // (timing experiment: nothing queued)
+#endif
             enqueue(s[u], b + (int64_t)u * X8_STEP + (int64_t)lane * XT_R, m[u]);
         }
     };
+    auto step = [&](int64_t b, auto u_tag, auto tail_tag) {
+        constexpr int U = decltype(u_tag)::value ? X8_U : 1;
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        typename P::Regs s[U];
+        uint32_t m[U], off[NL][U][XT_R], w[NL][U][XT_R];
+#pragma unroll
+        for (int u = 0; u < U; ++u) P::template sload<TAIL>(a, b + (int64_t)u * X8_STEP + (int64_t)lane * XT_R, TAIL ? end : nrows, s[u]);
+        prep(s, b, u_tag, tail_tag, m, off);
+        request(u_tag, off, w);
+        finish(s, b, u_tag, m, off, w);
+    };
     int64_t b = begin;
+#if XV_PIPE
+    {
+        constexpr int64_t STEP2 = (int64_t)X8_STEP * X8_U;
+        const int64_t nfull = (end - begin) / STEP2;
+        if (nfull > 0) {
+            typename P::Regs cur[X8_U], nxt[X8_U];
+            auto load2 = [&](int64_t bb, typename P::Regs (&s)[X8_U]) {
+#pragma unroll
+                for (int u = 0; u < X8_U; ++u) P::template sload<false>(a, bb + (int64_t)u * X8_STEP + (int64_t)lane * XT_R, nrows, s[u]);
+            };
+            auto piped = [&](typename P::Regs (&now)[X8_U], typename P::Regs (&next)[X8_U], int64_t bb, int64_t bnext) {
+                uint32_t m[X8_U], off[NL][X8_U][XT_R], w[NL][X8_U][XT_R];
+                prep(now, bb, XBool<true>{}, XBool<false>{}, m, off);
+                request(XBool<true>{}, off, w);
+                __builtin_amdgcn_sched_barrier(0);
+                load2(bnext, next);                                               // unconditional (after the last step: that step again): no wait piles up in front of a branch
+                __builtin_amdgcn_sched_barrier(0);
+                finish(now, bb, XBool<true>{}, m, off, w);
+            };
+            load2(b, cur);
+            int64_t k = 0;
+            for (; k + 2 <= nfull; k += 2, b += 2 * STEP2) {
+                piped(cur, nxt, b, b + STEP2);
+                piped(nxt, cur, b + STEP2, k + 2 < nfull ? b + 2 * STEP2 : b + STEP2);
+            }
+            if (k < nfull) { piped(cur, nxt, b, b); b += STEP2; }
+        }
+    }
+#endif
     for (; b + (int64_t)X8_STEP * X8_U <= end; b += (int64_t)X8_STEP * X8_U) step(b, XBool<true>{}, XBool<false>{});
     for (; b + X8_STEP <= end; b += X8_STEP) step(b, XBool<false>{}, XBool<false>{});
     if (b < end) step(b, XBool<false>{}, XBool<true>{});

@@ -15,6 +15,7 @@ Mapping of the reference's emitted loop shapes (src/sdqlpy/lib/sdql_ir_cpp_gener
 Anything else raises frontend.UnsupportedQuery.  There is no CPU execution path here.
 """
 import os
+import weakref
 
 import numpy as np
 
@@ -92,6 +93,7 @@ class Engine:
         self._range_cache = {}     # id(int64 ndarray) -> (ndarray, (min, span))
         self._distinct_cache = {}  # id(ndarray) -> (ndarray, has no repeated value)
         self._frozen = {}          # id(ndarray) -> ndarray made read-only on adoption (see column())
+        self._outstanding = weakref.WeakSet()   # results launched and not looked at yet (DeferredResultSet): finished before the data they were computed from is dropped
         self.force_programs = os.environ.get("SDQLPY_AMD_FORCE_PROGRAMS") == "1"   # every loop as a row program (xplan.py), none through the fixed-shape calls
         # pure streaming loops (a sum / small group-by over one table, no lookups: Q1, Q6) go to their row program first: the
         # specialised kernel streams every column at its tightest exact encoding (dictionary codes of 1 / 2 bytes, csrc/sdqh_xkernels.hpp
@@ -114,7 +116,19 @@ class Engine:
         self.clear()
         self.ctx.close()
 
+    def finish_outstanding(self):
+        """Finish every result that was launched and not looked at yet, so that it holds the rows of the data it was launched on: a
+        result whose collection overflows re-runs its plan (PreparedPlan._deferred), and must do that before the tables change."""
+        for rs in list(self._outstanding):
+            try:
+                rs.wait()
+            except Exception:                                   # kept by the result: raised again where the caller looks at it
+                pass
+        self._outstanding.clear()
+
     def clear(self):
+        if self.ctx.handle is not None:
+            self.finish_outstanding()
         if self._columns and self.ctx.handle is not None:
             self.ctx.synchronize()                              # queries launched and not waited for may still read the columns
         for _, col in self._columns.values():
@@ -165,6 +179,8 @@ class Engine:
             arrays = list(what.getContainer().get("data", []))
         else:
             arrays = [what]
+        if self.ctx.handle is not None:
+            self.finish_outstanding()
         if any(id(arr) in self._columns for arr in arrays) and self.ctx.handle is not None:
             self.ctx.synchronize()                              # (queries launched and not waited for may still read them)
         for arr in arrays:
@@ -1843,7 +1859,9 @@ class PreparedPlan:
                 # plan once more, every call waited for — its own fall-backs take it from there
                 res = self.run(top, deferred=False)
                 return res
-        return DeferredResultSet(thunk)
+        rs = DeferredResultSet(thunk)
+        eng._outstanding.add(rs)
+        return rs
 
 
 def at_name(prepared, i):

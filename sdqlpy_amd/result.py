@@ -252,17 +252,28 @@ class DeferredResultSet(ResultSet):
         self._thunk = thunk
 
     def _force(self):
+        err = self.__dict__.get("_error")
+        if err is not None:                                      # the thunk failed once: every later look at the result says so again
+            raise err
         thunk = self.__dict__.pop("_thunk", None)
         if thunk is not None:
-            rs = thunk()
-            if not isinstance(rs, ResultSet):
-                raise TypeError("a deferred query finished with %r, not a result set" % type(rs).__name__)
-            if isinstance(rs, DeferredResultSet):
-                rs._force()
+            try:
+                rs = thunk()
+                if not isinstance(rs, ResultSet):
+                    raise TypeError("a deferred query finished with %r, not a result set" % type(rs).__name__)
+                if isinstance(rs, DeferredResultSet):
+                    rs._force()
+            except BaseException as exc:
+                self.__dict__["_error"] = exc
+                raise
             self.__dict__.update(rs.__dict__)
 
     def __getattr__(self, name):                                 # only reached for attributes not set yet: columns, _cols, _n, _ready
-        if name == "_thunk" or "_thunk" not in self.__dict__:
+        if name in ("_thunk", "_error"):
+            raise AttributeError(name)
+        if "_error" in self.__dict__:
+            raise self.__dict__["_error"]
+        if "_thunk" not in self.__dict__:
             raise AttributeError(name)
         self._force()
         return getattr(self, name)

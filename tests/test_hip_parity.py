@@ -228,6 +228,33 @@ def test_full_size_properties_sf10(hip_engine):
     hip_engine.clear()
 
 
+def test_full_size_sf10_against_the_cpu_implementation(hip_engine, oracle_lib):
+    """BASELINE.json's full size against the ORACLE itself, not only through properties: q1, q3, q5 (the timed step), q6 and q9 at
+    SF=10 on the HIP path and on the CPU restatement with every host thread (the GPU box's 256 threads take 0.05-0.2 s per query;
+    a small host takes a few seconds).  Row sets, keys and counts exact; sums within 1e-10 relative (contract: 1e-6).  The same
+    comparison is printed by bench.py's cpu_baseline leg as `parity_at_bench_size`."""
+    import os
+    import bench
+    qs = ("q1", "q3", "q5", "q6", "q9")
+    db = tpch.generate(10, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+    cpu = engine.Engine(oracle_lib.context(threads=os.cpu_count() or 1))
+    try:
+        for q in qs:
+            got = helpers.run_query(hip_engine, q, db)
+            want = helpers.run_query(cpu, q, db)
+            if q == "q6":
+                assert want != 0.0 and abs(got - want) <= REL * abs(want), (got, want)
+                continue
+            cmp = bench.compare_results(got.wait() if hasattr(got, "wait") else got, want)
+            assert cmp["rows_equal"] and cmp["counts_equal"], (q, cmp)
+            assert cmp["rows"] > 0 and cmp["max_rel"] <= REL, (q, cmp)
+            if q == "q3":
+                assert cmp["rows"] > 100_000
+    finally:
+        cpu.close()
+        hip_engine.clear()
+
+
 def test_sf100_on_one_gpu_q3_q6(hip_engine):
     """BASELINE configs[3]'s data size (SF=100: 600 M lineitem rows, 150 M orders) on ONE device — what every rank of the 8-GPU
     configuration holds an eighth of, and the size at which bitmaps stop fitting LDS / L2 and 32-bit offsets start to matter.

@@ -623,6 +623,7 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "copy_kernel" && value >= 0 && value <= 4096) ctx->opt_copy_kernel = (int)value;      // workgroups of the library's own copy-out kernel; 0: the runtime's copy
     else if (n == "copy_nt" && value >= 0 && value <= 1) ctx->opt_copy_nt = (int)value;
     else if (n == "x_waves" && value >= 0 && value <= 256) ctx->opt_x_waves = (int)value;
+    else if (n == "window" && value >= 0 && value <= 1) ctx->opt_window = (int)value;
     else if (n == "async_result" && value >= 0 && value <= 1) ctx->opt_async_result = (int)value;
     else if (n == "stage_pipeline" && value >= 0 && value <= 1) ctx->opt_stage_pipeline = (int)value;
     else if (n == "span_index" && value >= 0 && value <= 1) ctx->opt_span_index = (int)value;

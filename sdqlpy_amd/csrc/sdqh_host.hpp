@@ -98,6 +98,8 @@ struct sdqh_ctx {
     int opt_copy_kernel = 0;            // > 0: sdqh_table_compact_deferred copies its rows out with that many workgroups of k_copy_out instead of the runtime's
                                         // copy (measured: 64 workgroups of write-through stores 0.85 ms a step against 0.79 — the runtime's blit kernel stays)
     int opt_copy_nt = 1;
+    int opt_window = 0;                 // x_queue8's 32-bit prefilter tests a lane's 8 rows against ONE 16-byte window of the bitmap when the key column's 8-row spans allow (column_span8): measured
+                                        // on par with 8 single-word requests once those are coalesced (Q3's probe 0.083 vs 0.081 ms) and slower where every row is tested (Q5's final loop 0.140 vs 0.130)
     int opt_x_waves = 0;                // > 0: wave segments per CU for the queue skeletons of row programs (0: each sink's own default)
     // K-F rows delivered behind the call (sdqh_table_compact_async): two device staging buffers in turn, a copy stream (side[1]),
     // the event of each buffer's last copy, and whether a copy may still be in flight
@@ -141,6 +143,7 @@ struct sdqh_column {
     void* narrow = nullptr;            // 4-byte twin (int32 values / two-decimal doubles x 100), verified exact when built; see ensure_narrow
     int narrow_state = -1;             // -1 not tried, 0 the column does not narrow exactly, 1 twin present
     int increasing = -1;               // -1 unknown; 1: strictly increasing (sorted, no duplicates), 0: not — checked once on the device
+    int span8 = -1;                    // -1 unknown; 1: aligned groups of 8 consecutive rows span at most 96 values (sampled): a lane's 8 rows fit one 128-bit window of a key bitmap (sdqh_x.hip)
     int64_t mn = 0, mx = 0;
     // sorted-dictionary codes (sdqh_codes.hip): a column with at most 65 536 distinct values over a narrow integer / two-decimal
     // range also has a 1- or 2-byte twin holding, per row, the RANK of its value among the column's distinct values, and the

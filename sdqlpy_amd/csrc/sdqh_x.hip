@@ -89,6 +89,8 @@ struct XInfo {
     bool fake = false;
     bool vstage = false; int nlk = 0; int lk_op[2] = {-1, -1};      // a build that x_vstage8 can run: every gate on registers, lookups answered by exact 32-bit-range bitmaps
     bool pref32 = false;                     // the prefilter's key and its table's bitmap range fit 32 bits: the streamed test is 32-bit arithmetic
+    bool pnear = false;                      // ... and a lane's 8 consecutive rows carry near-by keys (column_span8): a row that fails an earlier condition still asks for ITS key's word
+    bool pwin = false;                       // ... tested against one 128-bit window of the bitmap: one 16-byte request per lane and 8 rows (option "window", off: measured slower)
     uint32_t gather32 = 0;                   // queue programs: numeric columns read BY ROW (the drain's gathers) through their 4-byte twins: half the bytes of every touched line
     std::vector<char> scope;                 // operations evaluated on the streamed registers (register programs: all; queue programs: the streamed gates + the prefilter's key)
 };
@@ -305,6 +307,30 @@ template <class T> void translate_cmp(const std::vector<int64_t>& dict, bool f64
 }
 int mirrored(int op) { return op == SDQH_X_LT ? SDQH_X_GT : op == SDQH_X_LE ? SDQH_X_GE : op == SDQH_X_GT ? SDQH_X_LT : op == SDQH_X_GE ? SDQH_X_LE : op; }
 
+// Do aligned groups of 8 consecutive rows of an I64 column hold values within a span of 96 (a foreign key of a table stored in its
+// parent's order: l_orderkey)?  Then the 8 rows a lane of the tight skeletons takes meet at most four consecutive words of a key
+// bitmap.  Sampled once per column (2048 groups spread over the column, one small download), cached; at most 2 outliers allowed —
+// a wave tests 128 groups per step and every outlier costs it eight single-word requests.
+bool column_span8(sdqh_ctx* ctx, sdqh_column* c) {
+    if (c->span8 >= 0) return c->span8 == 1;
+    if (c->dtype != SDQH_I64 || c->transient || c->nrows < 64) { c->span8 = 0; return false; }
+    const int samples = (int)std::min<int64_t>(1024, c->nrows / 8);        // 1024 groups x 64 bytes = the 64 KiB pinned result block
+    const int64_t groups = c->nrows / 8, step = std::max<int64_t>(1, groups / samples);
+    int64_t* host = static_cast<int64_t*>(ctx->result_host);
+    bool ok = true;
+    for (int i = 0; i < samples && ok; ++i)
+        ok = hipMemcpyAsync(host + 8 * i, static_cast<const int64_t*>(c->data) + (int64_t)i * step * 8, 64, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+    if (!ok || hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipGetLastError(); c->span8 = 0; return false; }
+    int wide = 0;
+    for (int i = 0; i < samples; ++i) {
+        int64_t lo = host[8 * i], hi = lo;
+        for (int j = 1; j < 8; ++j) { lo = std::min(lo, host[8 * i + j]); hi = std::max(hi, host[8 * i + j]); }
+        wide += (hi - lo > 96) ? 1 : 0;
+    }
+    c->span8 = wide <= 1 ? 1 : 0;
+    return c->span8 == 1;
+}
+
 // Decide, per column of a register program, the tightest exact encoding it can be streamed in, and rewrite the comparisons
 // of coded columns with constants.  The decisions are part of the kernel's structure; the translated constants are arguments
 // (recomputed at every call: cheap, and they follow the constants).
@@ -312,7 +338,7 @@ void tight_plan(sdqh_ctx* ctx, int64_t nrows, XInfo* x) {
     const sdqh_program* p = x->p;
     for (int k = 0; k < p->nops; ++k) x->cmp_cc[k] = x->cmp_kind[k] = x->cmp_col[k] = -1;
     for (int c = 0; c < SDQH_MAX_XCOLS; ++c) { x->enc[c] = ENC_RAW; x->dict_slot[c] = -1; }
-    x->tight = false; x->nd = 0; x->ncc = 0; x->gather32 = 0; x->pref32 = false;
+    x->tight = false; x->nd = 0; x->ncc = 0; x->gather32 = 0; x->pref32 = false; x->pnear = false; x->pwin = false;
     // (a compile-only context has no columns to code; SDQLPY_AMD_FAKE_CODES makes it pretend every column is coded — 2 bytes where
     //  only compared, 1 byte where its value is used — so that build() proves on a host without a GPU that the generator's tight
     //  output compiles for gfx950)
@@ -405,6 +431,11 @@ void tight_plan(sdqh_ctx* ctx, int64_t nrows, XInfo* x) {
         x->pref32 = applicable && x->irange[x->prefilter_part0] >= 1 && t->dev.bm_lo >= INT32_MIN && t->dev.bm_hi <= INT32_MAX && t->dev.bm_hi >= t->dev.bm_lo;
     }
     if (fake && !regs_all && x->prefilter_op >= 0 && !x->prefilter_composite) x->pref32 = true;
+    if (x->pref32) {
+        const sdqh_xop& ko = p->ops[x->prefilter_part0];
+        x->pnear = fake ? true : (ko.code == SDQH_X_COL && column_span8(ctx, const_cast<sdqh_column*>(ko.col)));
+        x->pwin = fake ? std::getenv("SDQLPY_AMD_FAKE_WINDOW") != nullptr : (ctx->opt_window != 0 && x->pnear);
+    }
     // comparisons of a coded column with a constant, in code space
     for (int j = 0; j < p->nops; ++j) {
         const sdqh_xop& u = p->ops[j];
@@ -822,8 +853,9 @@ std::string generate(const XInfo& x, Sink sink, bool direct) {
         if (x.prefilter_op >= 0) {
             g.emit(x.prefilter_part0);
             const std::string t = "a.tab[" + std::to_string(x.tab_of[x.prefilter_op]) + "]";
-            g.os << "        p = p & (v" << x.prefilter_part0 << " >= " << t << ".bm_lo) & (v" << x.prefilter_part0 << " <= " << t << ".bm_hi);\n";
-            g.os << "        const uint64_t off = p ? (uint64_t)(v" << x.prefilter_part0 << " - " << t << ".bm_lo) : 0ull;\n";
+            g.os << "        const bool in = (v" << x.prefilter_part0 << " >= " << t << ".bm_lo) & (v" << x.prefilter_part0 << " <= " << t << ".bm_hi);\n";
+            g.os << "        p = p & in;\n";
+            g.os << "        const uint64_t off = " << (x.pnear ? "in" : "p") << " ? (uint64_t)(v" << x.prefilter_part0 << " - " << t << ".bm_lo) : 0ull;\n";
             g.os << "        widx = (uint32_t)(off >> 5); bit = (uint32_t)off & 31u;\n";
         } else g.os << "        widx = 0; bit = 0;\n";
         g.os << "        return p;\n";
@@ -835,8 +867,13 @@ std::string generate(const XInfo& x, Sink sink, bool direct) {
             g.emit(x.prefilter_part0);
             const std::string t = "a.tab[" + std::to_string(x.tab_of[x.prefilter_op]) + "]";
             g.os << "        const uint32_t o32 = (uint32_t)((int32_t)v" << x.prefilter_part0 << " - (int32_t)" << t << ".bm_lo);\n";
-            g.os << "        p = p & (o32 <= (uint32_t)(" << t << ".bm_hi - " << t << ".bm_lo));\n";
-            g.os << "        off = p ? o32 : 0u;\n        return p;\n";
+            // (the offset of a row that fails an earlier condition is still its key's: neighbouring lanes then ask for neighbouring words
+            //  whatever the conditions say — with the failing half of Q3's rows sent to word 0 instead, each of the step's 16 requests
+            //  straddled two far-apart lines lane by lane and cost three times the address-path cycles of Q5's, where every row passes)
+            //  Only where the key column is clustered (pnear): with keys in no order every lane that still asks is one more line, and the
+            //  failing rows are better sent to word 0 together — Q5's orders build, 85 % of its rows failing the date: 0.063 -> 0.104 ms.
+            g.os << "        const bool in = o32 <= (uint32_t)(" << t << ".bm_hi - " << t << ".bm_lo);\n";
+            g.os << "        p = p & in;\n        off = " << (x.pnear ? "in" : "p") << " ? o32 : 0u;\n        return p;\n";
             spre32 = g.os.str();
         }
         tabs8 = g.tabs;
@@ -868,7 +905,7 @@ std::string generate(const XInfo& x, Sink sink, bool direct) {
         out << "    }\n";
         out << "    __device__ __forceinline__ static bool stest(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i) {\n" << stest8 << "    }\n";
         out << "    __device__ __forceinline__ static bool spre(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i, uint32_t& widx, uint32_t& bit) {\n" << spre8 << "    }\n";
-        out << "    static constexpr bool PREF32 = " << (x.pref32 ? "true" : "false") << ";\n";
+        out << "    static constexpr bool PREF32 = " << (x.pref32 ? "true" : "false") << ", PWIN = " << (x.pwin ? "true" : "false") << ";\n";
         out << "    __device__ __forceinline__ static bool spre32(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i, uint32_t& off) {\n"
             << (x.pref32 ? spre32 : std::string("        off = 0; return false;\n")) << "    }\n";
         out << "    __device__ __forceinline__ static const uint32_t* sbitmap(const XArgs& a) { return "
@@ -999,7 +1036,7 @@ uint64_t structure_hash(const XInfo& x, Sink sink, bool direct) {
     auto mix = [&](uint64_t v) { h ^= v; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29; };      // (a word at a time: this runs on every call)
     mix((uint64_t)sink * 2 + (direct ? 1 : 0)); mix((uint64_t)x.narrow_mask);
     if (x.tight) {
-        mix(0x7167ull); mix((uint64_t)x.gather32); mix((x.pref32 ? 1ull : 0ull) | (x.vstage ? 2ull : 0ull));
+        mix(0x7167ull); mix((uint64_t)x.gather32); mix((x.pref32 ? 1ull : 0ull) | (x.vstage ? 2ull : 0ull) | (x.pwin ? 4ull : 0ull) | (x.pnear ? 8ull : 0ull));
         for (int c = 0; c < x.ncols; ++c) mix(((uint64_t)(uint32_t)x.enc[c] << 32) | ((uint32_t)(x.affine[c] ? 1 : 0) << 16) | (uint32_t)(x.dict_slot[c] & 0xFFFF));
         for (int k = 0; k < x.p->nops; ++k) mix((uint64_t)(uint8_t)x.irange[k]);
         for (int k = 0; k < x.p->nops; ++k) mix(((uint64_t)(uint32_t)x.cmp_cc[k] << 32) | ((uint32_t)x.cmp_kind[k] << 8) | (uint32_t)(x.cmp_col[k] & 0xFF));

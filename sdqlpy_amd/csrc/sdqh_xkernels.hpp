@@ -26,14 +26,17 @@
 #ifndef X8_EXP
 #define X8_EXP 0                                                      // timing experiments of x_queue8 (wrong results): 1 no bitmap requests, 2 nothing queued, 3 queued but never drained
 #endif
-#ifndef X8_WIN
-#define X8_WIN 0                                                      // x_queue8, 32-bit prefilter: one 16-byte window of the bitmap per lane and 8 rows instead of 8 words (see there)
-#endif
 #ifndef X8_PIPE
 #define X8_PIPE 0                                                     // x_queue8: the next double step's streamed loads requested behind this step's bitmap words (see there)
 #endif
+#ifndef XV_MASKED
+#define XV_MASKED 0                                                   // x_vstage8: bitmap words requested by the lanes whose row passed the conditions so far only
+#endif
+#ifndef XV_OFFALL
+#define XV_OFFALL 0
+#endif
 #ifndef XV_PIPE
-#define XV_PIPE 0                                                     // x_vstage8: the next step's streamed loads requested behind this step's bitmap words (see there)
+#define XV_PIPE 1                                                     // x_vstage8: the next step's streamed loads requested behind this step's bitmap words (see there)
 #endif
 
 namespace sdqh {
@@ -805,9 +808,7 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
                 for (int u = 0; u < X8_U; ++u) P::template sload<false>(a, b + (int64_t)u * X8_STEP + (int64_t)lane * XT_R, nrows, s[u]);
 #endif
                 uint32_t m[X8_U], off[X8_U][XT_R], w[X8_U][XT_R];
-#if X8_WIN
-                uint32_t wb[X8_U]; XWindow win[X8_U];
-#endif
+                uint32_t wb[X8_U]; XWindow win[X8_U];                           // (P::PWIN: the lane's window of the bitmap)
                 if constexpr (P::PREF32) {
                     // 32-bit form (the key and the bitmap's range fit 32 bits — known when the kernel was specialised): a row costs
                     // a subtract, an unsigned compare, a select, a shift and a bit-field extract.  The 64-bit form below spent ~30
@@ -820,26 +821,28 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
                     }
 #if X8_EXP == 1
                     // (timing experiment: no bitmap requests at all)
-#elif X8_WIN
-                    // WINDOW: a lane's 8 consecutive rows carry near-by keys when the key column is clustered (a foreign key of a table
-                    // stored in the order of its parent: l_orderkey), so ONE 16-byte request per lane — the four bitmap words from the
-                    // word of its smallest passing key on — answers all eight tests; a row whose key lies beyond those 128 bits asks for
-                    // its own word afterwards (rare).  Every vector-memory instruction occupies the CU's address path for its 64 lanes
-                    // whether or not they share a line: eight 4-byte requests per 8 rows made this loop address-bound (35.9 M cache
-                    // accesses for Q3's probe, 0.058 ms of a 0.094 ms kernel) long before it was byte-bound.
-#pragma unroll
-                    for (int u = 0; u < X8_U; ++u) {
-                        uint32_t lo = 0xFFFFFFFFu;
-#pragma unroll
-                        for (int i = 0; i < XT_R; ++i) { const uint32_t o = ((m[u] >> i) & 1u) ? off[u][i] : 0xFFFFFFFFu; lo = o < lo ? o : lo; }
-                        wb[u] = m[u] ? lo >> 5 : 0u;
-                        win[u] = x_load_window(pbm + wb[u]);
-                    }
 #else
+                    if constexpr (P::PWIN) {
+                        // WINDOW: a lane's 8 consecutive rows carry near-by keys when the key column is clustered (a foreign key of a table
+                        // stored in the order of its parent: l_orderkey; column_span8 sampled it), so ONE 16-byte request per lane — the
+                        // four bitmap words from the word of its smallest passing key on — answers all eight tests; a row whose key lies
+                        // beyond those 128 bits asks for its own word afterwards (rare).  Every vector-memory instruction occupies the CU's
+                        // address path for its 64 lanes whether or not they share a line: eight 4-byte requests per 8 rows cost Q3's probe
+                        // 21 us of 96 (36 M cache accesses), the window 8.
 #pragma unroll
-                    for (int u = 0; u < X8_U; ++u)
+                        for (int u = 0; u < X8_U; ++u) {
+                            uint32_t lo = 0xFFFFFFFFu;
 #pragma unroll
-                        for (int i = 0; i < XT_R; ++i) w[u][i] = pbm[off[u][i] >> 5];
+                            for (int i = 0; i < XT_R; ++i) { const uint32_t o = ((m[u] >> i) & 1u) ? off[u][i] : 0xFFFFFFFFu; lo = o < lo ? o : lo; }
+                            wb[u] = m[u] ? lo >> 5 : 0u;
+                            win[u] = x_load_window(pbm + wb[u]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < X8_U; ++u)
+#pragma unroll
+                            for (int i = 0; i < XT_R; ++i) w[u][i] = pbm[off[u][i] >> 5];
+                    }
 #endif
                 } else if (pbm) {
                     // the prefilter's bitmap words of all 16 rows are requested before any is tested (a load inside each row's own
@@ -875,35 +878,37 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
 #if X8_EXP == 1
 #pragma unroll
                     for (int u = 0; u < X8_U; ++u) m[u] = ((uint32_t)a.key_hi == 0x12345678u) ? m[u] : 0u;
-#elif X8_WIN
+#else
+                    if constexpr (P::PWIN) {
 #pragma unroll
-                    for (int u = 0; u < X8_U; ++u) {
-                        uint32_t hit = 0, beyond = 0;
-#pragma unroll
-                        for (int i = 0; i < XT_R; ++i) {
-                            const uint32_t rel = off[u][i] - (wb[u] << 5);
-                            const uint32_t k = rel >> 5;
-                            const uint32_t word = k == 0 ? win[u].x : k == 1 ? win[u].y : k == 2 ? win[u].z : win[u].w;
-                            hit |= (k < 4u ? __builtin_amdgcn_ubfe(word, rel & 31u, 1u) : 0u) << i;
-                            beyond |= (k < 4u ? 0u : 1u) << i;
-                        }
-                        beyond &= m[u];
-                        if (__ballot(beyond != 0)) {                                       // keys beyond the lane's window: their own words (wave-uniform branch per row slot)
+                        for (int u = 0; u < X8_U; ++u) {
+                            uint32_t hit = 0, beyond = 0;
 #pragma unroll
                             for (int i = 0; i < XT_R; ++i) {
-                                const bool far = (beyond >> i) & 1u;
-                                if (__ballot(far)) { const uint32_t wd = pbm[far ? off[u][i] >> 5 : 0u]; hit |= (far ? __builtin_amdgcn_ubfe(wd, off[u][i] & 31u, 1u) : 0u) << i; }
+                                const uint32_t rel = off[u][i] - (wb[u] << 5);
+                                const uint32_t k = rel >> 5;
+                                const uint32_t word = k == 0 ? win[u].x : k == 1 ? win[u].y : k == 2 ? win[u].z : win[u].w;
+                                hit |= (k < 4u ? __builtin_amdgcn_ubfe(word, rel & 31u, 1u) : 0u) << i;
+                                beyond |= (k < 4u ? 0u : 1u) << i;
                             }
+                            beyond &= m[u];
+                            if (__ballot(beyond != 0)) {                                   // keys beyond the lane's window: their own words (wave-uniform branch per row slot)
+#pragma unroll
+                                for (int i = 0; i < XT_R; ++i) {
+                                    const bool far = (beyond >> i) & 1u;
+                                    if (__ballot(far)) { const uint32_t wd = pbm[far ? off[u][i] >> 5 : 0u]; hit |= (far ? __builtin_amdgcn_ubfe(wd, off[u][i] & 31u, 1u) : 0u) << i; }
+                                }
+                            }
+                            m[u] &= hit;
                         }
-                        m[u] &= hit;
-                    }
-#else
+                    } else {
 #pragma unroll
-                    for (int u = 0; u < X8_U; ++u) {
-                        uint32_t hit = 0;
+                        for (int u = 0; u < X8_U; ++u) {
+                            uint32_t hit = 0;
 #pragma unroll
-                        for (int i = 0; i < XT_R; ++i) hit |= __builtin_amdgcn_ubfe(w[u][i], off[u][i] & 31u, 1u) << i;
-                        m[u] &= hit;
+                            for (int i = 0; i < XT_R; ++i) hit |= __builtin_amdgcn_ubfe(w[u][i], off[u][i] & 31u, 1u) << i;
+                            m[u] &= hit;
+                        }
                     }
 #endif
                 } else if (pbm) {
@@ -1072,12 +1077,23 @@ __device__ __forceinline__ void x_vstage8(const XArgs& a, const typename XStage<
             for (int i = 0; i < XT_R; ++i) {
                 bool p = (!TAIL || r0 + i < end) && P::gates(a, s[u], s_tab, i, r0 + i);
 #pragma unroll
-                for (int l = 0; l < NL; ++l) { off[l][u][i] = 0; if (P::NL > l) { const uint32_t o32 = P::lkoff(a, s[u], s_tab, i, r0 + i, l, p); off[l][u][i] = p ? o32 : 0u; } }
+                for (int l = 0; l < NL; ++l) {
+                    off[l][u][i] = 0;
+                    if (P::NL > l) {
+#if XV_OFFALL
+                        bool in = true;                                            // (A/B: the key's own offset whatever the earlier conditions say)
+                        const uint32_t o32 = P::lkoff(a, s[u], s_tab, i, r0 + i, l, in);
+                        p = p & in; off[l][u][i] = in ? o32 : 0u;
+#else
+                        const uint32_t o32 = P::lkoff(a, s[u], s_tab, i, r0 + i, l, p); off[l][u][i] = p ? o32 : 0u;
+#endif
+                    }
+                }
                 m[u] |= p ? (1u << i) : 0u;
             }
         }
     };
-    auto request = [&](auto u_tag, const auto& off, auto& w) {                                         // the bitmap words of a step's rows, together
+    auto request = [&](auto u_tag, const auto& m, const auto& off, auto& w) {                                         // the bitmap words of a step's rows, together
         constexpr int U = decltype(u_tag)::value ? X8_U : 1;
 #pragma unroll
         for (int l = 0; l < NL; ++l) if (P::NL > l)
@@ -1087,6 +1103,9 @@ __device__ __forceinline__ void x_vstage8(const XArgs& a, const typename XStage<
                 for (int i = 0; i < XT_R; ++i) {
 #if defined(XV_EXP) && (XV_EXP & 8)
                     w[l][u][i] = 0xFFFFFFFFu;                                      // (timing experiment: no bitmap requests, every key "found")
+#elif XV_MASKED
+                    w[l][u][i] = 0u;
+                    if ((m[u] >> i) & 1u) w[l][u][i] = bm[l][off[l][u][i] >> 5];    // only the lanes whose row is still alive take part in the request
 #else
                     w[l][u][i] = bm[l][off[l][u][i] >> 5];
 #endif
@@ -1117,7 +1136,7 @@ __device__ __forceinline__ void x_vstage8(const XArgs& a, const typename XStage<
 #pragma unroll
         for (int u = 0; u < U; ++u) P::template sload<TAIL>(a, b + (int64_t)u * X8_STEP + (int64_t)lane * XT_R, TAIL ? end : nrows, s[u]);
         prep(s, b, u_tag, tail_tag, m, off);
-        request(u_tag, off, w);
+        request(u_tag, m, off, w);
         finish(s, b, u_tag, m, off, w);
     };
     int64_t b = begin;
@@ -1134,7 +1153,7 @@ __device__ __forceinline__ void x_vstage8(const XArgs& a, const typename XStage<
             auto piped = [&](typename P::Regs (&now)[X8_U], typename P::Regs (&next)[X8_U], int64_t bb, int64_t bnext) {
                 uint32_t m[X8_U], off[NL][X8_U][XT_R], w[NL][X8_U][XT_R];
                 prep(now, bb, XBool<true>{}, XBool<false>{}, m, off);
-                request(XBool<true>{}, off, w);
+                request(XBool<true>{}, m, off, w);
                 __builtin_amdgcn_sched_barrier(0);
                 load2(bnext, next);                                               // unconditional (after the last step: that step again): no wait piles up in front of a branch
                 __builtin_amdgcn_sched_barrier(0);

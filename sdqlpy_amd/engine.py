@@ -1801,10 +1801,13 @@ class PreparedPlan:
             return frozenset([ops[-2].out, ops[-1].out])
         return frozenset()
 
-    def run(self, top=None, deferred=True):
+    def run(self, top=None, deferred=True, after=None):
         """top = (k, [(result column, "asc" | "desc"), ...]): ORDER BY ... LIMIT k on the final K-F.
         deferred: the plan's last device call may be launched without being waited for (Engine.deferred_results): the result is
-        then a DeferredResultSet that finishes the plan when it is first looked at."""
+        then a DeferredResultSet that finishes the plan when it is first looked at.
+        after: {step name: callable(env)} run right behind that step, before the next one (the multi-GPU runner's seams: a built
+        table replaced by its replica, foreign rows aggregated into a table before it is finalised); a callable may return a
+        replacement for the step's outcome."""
         env = {}
         if top is not None:
             env["__top__"] = (int(top[0]), [(str(n), str(d)) for n, d in top[1]])
@@ -1815,6 +1818,10 @@ class PreparedPlan:
         try:
             for i, (out, step) in enumerate(self.steps):
                 env[out] = step(env)
+                if after and out in after:
+                    repl = after[out](env)
+                    if repl is not None:
+                        env[out] = repl
                 if isinstance(env[out], Pending):
                     return self._deferred(env, i, top)
             res = env[self.plan.result]
@@ -1868,7 +1875,8 @@ def at_name(prepared, i):
     return prepared.steps[i][0]
 
 
-def execute_plan(eng, plan, args, top=None):
+def prepared_plan(eng, plan, args):
+    """The plan bound to this engine and these tables (prepared once, reused while the engine's columns are the same)."""
     cache = plan.__dict__.setdefault("_prepared", {})
     key = (id(eng),) + tuple(id(a) for a in args)
     prepared = cache.get(key)
@@ -1876,4 +1884,8 @@ def execute_plan(eng, plan, args, top=None):
         if len(cache) > 16:
             cache.clear()
         prepared = cache[key] = PreparedPlan(eng, plan, args)
-    return prepared.run(top)
+    return prepared
+
+
+def execute_plan(eng, plan, args, top=None, after=None):
+    return prepared_plan(eng, plan, args).run(top, after=after)

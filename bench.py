@@ -430,6 +430,11 @@ def main(argv=None, hooks=None):
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
+        for rn in (runner, runner_range):                # collective buffers released before the process group and the engine's stream go
+            if rn is not None:
+                rn.close()
+        if device == "cuda":
+            torch.cuda.synchronize()
         dist.destroy_process_group()
     return out
 

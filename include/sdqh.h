@@ -541,6 +541,17 @@ int sdqh_scan_compact(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter,
 int sdqh_partition_by_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int nparts, const int64_t* range_upper,
                           int ncols, const sdqh_column* const* cols, sdqh_column** out_cols,
                           int64_t* counts);
+/* sdqh_partition_by_key straight into ONE caller-owned buffer (device memory; CPU build: host) of nrows * ncols 8-byte elements, laid
+ * out for an all-to-all: the chunk for part p starts at element ncols * (rows of the parts before p) and holds every column's rows of
+ * that part, column after column — so ONE collective moves every column of a redistribution step and nothing is copied between the
+ * partitioning pass and the collective's buffer.  counts[nparts] on host. */
+int sdqh_partition_pack(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int nparts, const int64_t* range_upper,
+                        int ncols, const sdqh_column* const* cols, void* packed, int64_t* counts);
+/* The receiving side: a buffer of nparts chunks laid out as above (chunk s: part_rows[s] rows of each of the ncols columns) taken apart
+ * into ncols freshly allocated columns of sum(part_rows) rows, rows grouped by source in source order.  dtypes[ncols]: SDQH_I64 /
+ * SDQH_F64.  Queued on the ctx stream under "async_copies" (the caller keeps `packed` alive until it synchronises). */
+int sdqh_unpack_parts(sdqh_ctx* ctx, const void* packed, int nparts, const int64_t* part_rows, int ncols, const int* dtypes,
+                      sdqh_column** out_cols, int64_t* out_rows);
 /* Device-to-device (CPU build: memcpy) copy of rows [row0, row0+nrows) of an I64/F64 column to or
  * from caller-owned memory of the same kind (e.g. a torch tensor used as a collective buffer).
  * Returns after the copy has completed — unless the option "async_copies" is 1: then the copy is
@@ -550,8 +561,14 @@ int sdqh_column_copy_out(sdqh_ctx* ctx, const sdqh_column* col, int64_t row0, in
 int sdqh_column_copy_in(sdqh_ctx* ctx, sdqh_column* col, int64_t row0, int64_t nrows, const void* src);
 /* Exact key bitmap of a table over [lo, hi] (bit i = key lo+i present), as device words.  If
  * *out_words is NULL on entry a column of ceil(bits/64) I64 rows is allocated; otherwise the given
- * I64 column (at least that long, e.g. a wrapped collective buffer) is cleared and filled. */
+ * I64 column (at least that long, e.g. a wrapped collective buffer) is cleared and filled.  Works on every table that knows its
+ * keys: staged entries, or a bitmap of its own (key sets from sdqh_build_key_set / sdqh_xkey_set / sdqh_table_from_bitmap, the
+ * direct layout).  With the option "async_copies" the export is only queued on the ctx stream, like the column copies above. */
 int sdqh_table_export_bitmap(sdqh_ctx* ctx, const sdqh_table* table, int64_t lo, int64_t hi, sdqh_column** out_words);
+/* The two parts of a column of packed composite keys ((hi << 32) | lo, both parts in [0, 2^32)) as columns of their own: a
+ * replicated composite-key table is rebuilt from its all-gathered entries through sdqh_build with a two-part key, which gives it the
+ * layouts the final loops are tuned for.  The first nrows rows; the caller frees both columns. */
+int sdqh_column_unpack2(sdqh_ctx* ctx, const sdqh_column* packed, int64_t nrows, sdqh_column** out_hi, sdqh_column** out_lo);
 /* Build a key-only membership table from a bitmap (device I64 column viewed as 32-bit words). */
 int sdqh_table_from_bitmap(sdqh_ctx* ctx, const sdqh_column* words, int64_t lo, int64_t hi, sdqh_table** out);
 

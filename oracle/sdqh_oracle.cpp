@@ -1431,6 +1431,48 @@ int sdqh_partition_by_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, 
     return SDQH_OK;
 }
 
+int sdqh_partition_pack(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int nparts, const int64_t* range_upper, int ncols,
+                        const sdqh_column* const* cols, void* packed, int64_t* counts) {
+    if (!ctx || nrows < 0 || nparts < 1 || nparts > SDQH_MAX_PARTS || ncols < 1 || ncols > SDQH_MAX_COMPACT_COLS || !cols || !counts || (nrows && !packed))
+        return fail(ctx, SDQH_ERR_INVALID, "partition_pack: bad arguments");
+    if (int rc = check_col(ctx, key, SDQH_I64, nrows, "partition key")) return rc;
+    const int64_t* kc = (const int64_t*)key->data;
+    std::vector<int64_t> base((size_t)nparts + 1, 0);
+    for (int64_t r = 0; r < nrows; ++r) base[(size_t)part_of(kc[r], nparts, range_upper) + 1]++;
+    for (int p = 0; p < nparts; ++p) { counts[p] = base[(size_t)p + 1]; base[(size_t)p + 1] += base[(size_t)p]; }
+    std::vector<int64_t> cur((size_t)nparts, 0);
+    int64_t* out = (int64_t*)packed;
+    for (int c = 0; c < ncols; ++c)
+        if (!cols[c] || cols[c]->nrows < nrows || cols[c]->dtype == SDQH_STR) return fail(ctx, SDQH_ERR_INVALID, "partition_pack: columns must be I64/F64");
+    for (int64_t r = 0; r < nrows; ++r) {
+        const int p = part_of(kc[r], nparts, range_upper);
+        const int64_t at = (int64_t)ncols * base[(size_t)p] + cur[(size_t)p]++;
+        for (int c = 0; c < ncols; ++c) out[at + (int64_t)c * counts[p]] = ((const int64_t*)cols[c]->data)[r];
+    }
+    return SDQH_OK;
+}
+
+int sdqh_unpack_parts(sdqh_ctx* ctx, const void* packed, int nparts, const int64_t* part_rows, int ncols, const int* dtypes, sdqh_column** out_cols, int64_t* out_rows) {
+    if (!ctx || nparts < 1 || nparts > SDQH_MAX_PARTS || !part_rows || ncols < 1 || ncols > SDQH_MAX_COMPACT_COLS || !dtypes || !out_cols || !out_rows)
+        return fail(ctx, SDQH_ERR_INVALID, "unpack_parts: bad arguments");
+    int64_t total = 0;
+    for (int s = 0; s < nparts; ++s) { if (part_rows[s] < 0) return fail(ctx, SDQH_ERR_INVALID, "unpack_parts: negative row count"); total += part_rows[s]; }
+    if (total && !packed) return fail(ctx, SDQH_ERR_INVALID, "unpack_parts: no buffer");
+    for (int c = 0; c < ncols; ++c) {
+        if (dtypes[c] != SDQH_I64 && dtypes[c] != SDQH_F64) return fail(ctx, SDQH_ERR_INVALID, "unpack_parts: columns are I64 / F64");
+        if (int rc = sdqh_column_alloc(ctx, total, dtypes[c], 0, &out_cols[c])) return rc;
+    }
+    const int64_t* in = (const int64_t*)packed;
+    int64_t done = 0;
+    for (int s = 0; s < nparts; ++s) {
+        const int64_t n = part_rows[s];
+        for (int c = 0; c < ncols; ++c) std::memcpy((int64_t*)out_cols[c]->data + done, in + done * ncols + (int64_t)c * n, (size_t)n * 8);
+        done += n;
+    }
+    *out_rows = total;
+    return SDQH_OK;
+}
+
 int sdqh_column_copy_out(sdqh_ctx* ctx, const sdqh_column* col, int64_t row0, int64_t nrows, void* dst) {
     if (!ctx || !col || col->dtype == SDQH_STR || row0 < 0 || nrows < 0 || row0 + nrows > col->nrows || (nrows && !dst)) return fail(ctx, SDQH_ERR_INVALID, "column_copy_out: bad arguments");
     std::memcpy(dst, (const char*)col->data + (size_t)row0 * 8, (size_t)nrows * 8);
@@ -1453,6 +1495,17 @@ int sdqh_table_export_bitmap(sdqh_ctx* ctx, const sdqh_table* table, int64_t lo,
     auto set = [&](int64_t k) { if (k >= lo && k <= hi) { uint64_t off = (uint64_t)(k - lo); w[off >> 5] |= 1u << (off & 31); } };
     if (table->bitmap_only) { for (int64_t k = table->bm_lo; k <= table->bm_hi; ++k) if (table->contains(k)) set(k); }
     else for (int64_t k : table->keys) set(k);
+    return SDQH_OK;
+}
+
+int sdqh_column_unpack2(sdqh_ctx* ctx, const sdqh_column* packed, int64_t nrows, sdqh_column** out_hi, sdqh_column** out_lo) {
+    if (!ctx || !packed || !out_hi || !out_lo || nrows < 0 || nrows > packed->nrows || packed->dtype != SDQH_I64) return fail(ctx, SDQH_ERR_INVALID, "column_unpack2: bad arguments");
+    sdqh_column *h = nullptr, *l = nullptr;
+    if (int rc = sdqh_column_alloc(ctx, nrows, SDQH_I64, 0, &h)) return rc;
+    if (int rc = sdqh_column_alloc(ctx, nrows, SDQH_I64, 0, &l)) { sdqh_column_free(ctx, h); return rc; }
+    const int64_t* src = (const int64_t*)packed->data;
+    for (int64_t r = 0; r < nrows; ++r) { const uint64_t v = (uint64_t)src[r]; ((int64_t*)h->data)[r] = (int64_t)(v >> 32); ((int64_t*)l->data)[r] = (int64_t)(v & 0xFFFFFFFFull); }
+    *out_hi = h; *out_lo = l;
     return SDQH_OK;
 }
 

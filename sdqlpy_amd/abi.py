@@ -216,7 +216,7 @@ EXPORTS = [
     "sdqh_column_rows", "sdqh_column_dtype", "sdqh_column_width", "sdqh_column_minmax", "sdqh_column_free",
     "sdqh_scan_filter_sum", "sdqh_scan_probe_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_build_key_set", "sdqh_groupby_key", "sdqh_table_select_keys", "sdqh_table_share_groups", "sdqh_table_size", "sdqh_table_free",
     "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_table_compact_async", "sdqh_table_compact_deferred", "sdqh_host_wait_word", "sdqh_result_wait", "sdqh_scan_compact", "sdqh_partition_by_key",
-    "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in",
+    "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in", "sdqh_column_unpack2", "sdqh_partition_pack", "sdqh_unpack_parts",
     "sdqh_build", "sdqh_lookup_aggregate", "sdqh_table_entries", "sdqh_host_alloc", "sdqh_host_free", "sdqh_table_topk",
     "sdqh_xscan_sum", "sdqh_xgroupby", "sdqh_xgroupby_block_bytes", "sdqh_xgroupby_async", "sdqh_xgroupby_collect", "sdqh_xbuild", "sdqh_xkey_set", "sdqh_xprobe_aggregate", "sdqh_table_columns", "sdqh_jit_stats",
 ]
@@ -235,7 +235,8 @@ class Column:
 
     def free(self):
         if self.handle is not None:
-            self.ctx.lib.sdqh_column_free(self.ctx.handle, self.handle)
+            if self.ctx.handle is not None:                      # (a context that was closed has released everything it owned)
+                self.ctx.lib.sdqh_column_free(self.ctx.handle, self.handle)
             self.handle = None
 
     def __del__(self):
@@ -270,7 +271,8 @@ class Table:
 
     def free(self):
         if self.handle is not None:
-            self.ctx.lib.sdqh_table_free(self.ctx.handle, self.handle)
+            if self.ctx.handle is not None:
+                self.ctx.lib.sdqh_table_free(self.ctx.handle, self.handle)
             self.handle = None
 
     def __del__(self):
@@ -843,11 +845,39 @@ class Context:
                                                    carr, outs, _np_ptr(counts)))
         return [Column(self, C.c_void_p(outs[i]), nrows, cols[i].dtype, 0) for i in range(len(cols))], counts
 
+    def partition_pack(self, nrows, key, nparts, cols, packed_ptr, range_upper=None):
+        """sdqh_partition_pack: the rows of `cols` partitioned by `key` straight into the buffer at packed_ptr (nrows * len(cols) 8-byte
+        elements, the all-to-all layout); returns the rows per part."""
+        carr = (C.c_void_p * len(cols))(*[c.handle for c in cols])
+        counts = np.zeros(nparts, np.int64)
+        ru = None
+        if range_upper is not None:
+            ru = np.ascontiguousarray(range_upper, np.int64)
+            assert len(ru) == nparts - 1
+        self._check(self.lib.sdqh_partition_pack(self.handle, C.c_int64(nrows), key.handle, C.c_int(nparts), _np_ptr(ru), C.c_int(len(cols)),
+                                                 carr, C.c_void_p(packed_ptr), _np_ptr(counts)))
+        return counts
+
+    def unpack_parts(self, packed_ptr, part_rows, dtypes):
+        """sdqh_unpack_parts: the received buffer (a chunk per source) as Columns of sum(part_rows) rows."""
+        rows = np.ascontiguousarray(part_rows, np.int64)
+        dts = (C.c_int * len(dtypes))(*[int(d) for d in dtypes])
+        outs = (C.c_void_p * len(dtypes))()
+        n = C.c_int64()
+        self._check(self.lib.sdqh_unpack_parts(self.handle, C.c_void_p(packed_ptr), C.c_int(len(rows)), _np_ptr(rows), C.c_int(len(dtypes)), dts, outs, C.byref(n)))
+        return [Column(self, C.c_void_p(outs[i]), n.value, dtypes[i], 0) for i in range(len(dtypes))], n.value
+
     def copy_out(self, col, row0, nrows, dst_ptr):
         self._check(self.lib.sdqh_column_copy_out(self.handle, col.handle, C.c_int64(row0), C.c_int64(nrows), C.c_void_p(dst_ptr)))
 
     def copy_in(self, col, row0, nrows, src_ptr):
         self._check(self.lib.sdqh_column_copy_in(self.handle, col.handle, C.c_int64(row0), C.c_int64(nrows), C.c_void_p(src_ptr)))
+
+    def unpack2(self, packed, nrows):
+        """(hi, lo) Columns of a column of packed composite keys (sdqh_column_unpack2)."""
+        h, l = C.c_void_p(), C.c_void_p()
+        self._check(self.lib.sdqh_column_unpack2(self.handle, packed.handle, C.c_int64(nrows), C.byref(h), C.byref(l)))
+        return Column(self, h, nrows, I64, 0), Column(self, l, nrows, I64, 0)
 
     def table_export_bitmap(self, table, lo, hi, into=None):
         """Exact key bitmap of `table` over [lo, hi].  `into`: an I64 Column of at least
@@ -931,6 +961,9 @@ class Library:
         L.sdqh_column_copy_out.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.sdqh_column_copy_in.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.sdqh_table_export_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.sdqh_column_unpack2.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.sdqh_partition_pack.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sdqh_unpack_parts.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sdqh_table_from_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.sdqh_table_entries.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sdqh_set_profile_filter.argtypes = [C.c_void_p, C.c_char_p]

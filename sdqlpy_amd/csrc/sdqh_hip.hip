@@ -540,7 +540,9 @@ void sdqh_destroy(sdqh_ctx* ctx) {
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->call_begin) (void)hipEventDestroy(ctx->call_begin);
     if (ctx->call_end) (void)hipEventDestroy(ctx->call_end);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    // a stream that was handed out (sdqh_stream: torch wraps it as an external stream and may still hold tensors allocated on it, events
+    // recorded on it) is left to the process: destroying it under its other user crashes that user, leaking one stream harms nobody
+    if (ctx->stream && !ctx->stream_exported) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -589,7 +591,7 @@ int sdqh_profile_entry_bytes(const sdqh_ctx* ctx, int i, int64_t* model_bytes) {
     *model_bytes = ctx->prof[(size_t)i].model_bytes;
     return SDQH_OK;
 }
-void* sdqh_stream(const sdqh_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+void* sdqh_stream(const sdqh_ctx* ctx) { if (ctx) const_cast<sdqh_ctx*>(ctx)->stream_exported = true; return ctx ? (void*)ctx->stream : nullptr; }
 int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return SDQH_ERR_INVALID;
     const std::string n(name);
@@ -2367,6 +2369,73 @@ int sdqh_partition_by_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, 
     return SDQH_OK;
 }
 
+int sdqh_partition_pack(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int nparts, const int64_t* range_upper, int ncols,
+                        const sdqh_column* const* cols, void* packed, int64_t* counts) {
+    if (!ctx || nrows < 0 || nparts < 1 || nparts > SDQH_MAX_PARTS || ncols < 1 || ncols > SDQH_MAX_COMPACT_COLS || !cols || !counts || (nrows && !packed))
+        return fail(ctx, SDQH_ERR_INVALID, "partition_pack: bad arguments");
+    (void)hipSetDevice(ctx->device);
+    if (int rc = check_col(ctx, key, SDQH_I64, nrows, "partition key")) return rc;
+    DevPartition pt; std::memset(&pt, 0, sizeof(pt)); pt.nparts = nparts; pt.by_range = range_upper ? 1 : 0;
+    if (range_upper) for (int p = 0; p < nparts - 1; ++p) pt.upper[p] = range_upper[p];
+    DevGather src; std::memset(&src, 0, sizeof(src)); src.ncols = ncols;
+    for (int c = 0; c < ncols; ++c) {
+        if (!cols[c] || cols[c]->nrows < nrows || cols[c]->dtype == SDQH_STR) return fail(ctx, SDQH_ERR_INVALID, "partition_pack: columns must be I64/F64");
+        src.out[c] = static_cast<int64_t*>(cols[c]->data);
+    }
+    unsigned long long* dcounts = static_cast<unsigned long long*>(pool_alloc(ctx, 3 * SDQH_MAX_PARTS * 8));
+    if (!dcounts) return fail(ctx, SDQH_ERR_NOMEM, "partition_pack: out of device memory");
+    unsigned long long *cursor = dcounts + SDQH_MAX_PARTS, *base = dcounts + 2 * SDQH_MAX_PARTS;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + TPB - 1) / TPB, (int64_t)ctx->num_cu * 4));
+    const int64_t* kc = static_cast<const int64_t*>(key->data);
+    int rc = SDQH_OK;
+    call_begin(ctx);
+    if (hipMemsetAsync(dcounts, 0, 3 * SDQH_MAX_PARTS * 8, ctx->stream) != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, "partition_pack: memset failed");
+    if (!rc) {
+        LAUNCH(ctx, "k_part_count", k_part_count, grid, kc, nrows, pt, dcounts);
+        { KernelScope ks(ctx, "k_part_offsets"); hipLaunchKernelGGL(k_part_offsets, dim3(1), dim3(64), 0, ctx->stream, dcounts, nparts, cursor); }
+        if (hipMemcpyAsync(base, cursor, (size_t)nparts * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, "partition_pack: copy failed");
+    }
+    if (!rc && nrows > 0) LAUNCH(ctx, "k_part_scatter_packed", k_part_scatter_packed, grid, kc, nrows, pt, cursor, dcounts, base, src, static_cast<int64_t*>(packed));
+    call_end(ctx);
+    if (!rc && hipMemcpyAsync(ctx->result_host, dcounts, (size_t)nparts * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, "partition_pack: copy failed");
+    if (!rc) rc = sync_stream(ctx);                       // the counts are what the caller sizes the exchange with
+    pool_free(ctx, dcounts);
+    if (rc) return rc;
+    for (int p = 0; p < nparts; ++p) counts[p] = (int64_t)static_cast<const unsigned long long*>(ctx->result_host)[p];
+    return SDQH_OK;
+}
+
+int sdqh_unpack_parts(sdqh_ctx* ctx, const void* packed, int nparts, const int64_t* part_rows, int ncols, const int* dtypes, sdqh_column** out_cols, int64_t* out_rows) {
+    if (!ctx || nparts < 1 || nparts > SDQH_MAX_PARTS || !part_rows || ncols < 1 || ncols > SDQH_MAX_COMPACT_COLS || !dtypes || !out_cols || !out_rows)
+        return fail(ctx, SDQH_ERR_INVALID, "unpack_parts: bad arguments");
+    (void)hipSetDevice(ctx->device);
+    DevUnpack u; std::memset(&u, 0, sizeof(u)); u.nparts = nparts; u.ncols = ncols;
+    int64_t total = 0, most = 0;
+    for (int s = 0; s < nparts; ++s) {
+        if (part_rows[s] < 0) return fail(ctx, SDQH_ERR_INVALID, "unpack_parts: negative row count");
+        u.rows[s] = part_rows[s]; u.dst_off[s] = total; u.src_off[s] = total * ncols; total += part_rows[s]; most = std::max(most, part_rows[s]);
+    }
+    if (total && !packed) return fail(ctx, SDQH_ERR_INVALID, "unpack_parts: no buffer");
+    DevGather dst; std::memset(&dst, 0, sizeof(dst)); dst.ncols = ncols;
+    sdqh_column* outs[SDQH_MAX_COMPACT_COLS] = {nullptr};
+    for (int c = 0; c < ncols; ++c) {
+        if (dtypes[c] != SDQH_I64 && dtypes[c] != SDQH_F64) { for (int j = 0; j < c; ++j) sdqh_column_free(ctx, outs[j]); return fail(ctx, SDQH_ERR_INVALID, "unpack_parts: columns are I64 / F64"); }
+        if (int rc = sdqh_column_alloc(ctx, total, dtypes[c], 0, &outs[c])) { for (int j = 0; j < c; ++j) sdqh_column_free(ctx, outs[j]); return rc; }
+        dst.out[c] = static_cast<int64_t*>(outs[c]->data);
+        // rows that live for one run of a plan: no twins, no dictionaries, no order facts are gathered for them (each would be a pass
+        // over the column — or a host round trip — paid on every run)
+        outs[c]->transient = true; outs[c]->narrow_state = 0; outs[c]->code_state = 0; outs[c]->clustered = 0; outs[c]->increasing = 0; outs[c]->span8 = 0;
+    }
+    if (total > 0) {
+        const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((most + TPB - 1) / TPB, 256));
+        KernelScope ks(ctx, "k_unpack_parts");
+        hipLaunchKernelGGL(k_unpack_parts, dim3(gx, (unsigned)(nparts * ncols)), dim3(TPB), 0, ctx->stream, static_cast<const int64_t*>(packed), u, dst);
+    }
+    for (int c = 0; c < ncols; ++c) out_cols[c] = outs[c];
+    *out_rows = total;
+    return ctx->opt_async_copies ? SDQH_OK : sync_stream(ctx);
+}
+
 int sdqh_column_copy_out(sdqh_ctx* ctx, const sdqh_column* col, int64_t row0, int64_t nrows, void* dst) {
     if (!ctx || !col || col->dtype == SDQH_STR || row0 < 0 || nrows < 0 || row0 + nrows > col->nrows || (nrows && !dst)) return fail(ctx, SDQH_ERR_INVALID, "column_copy_out: bad arguments");
     if (nrows == 0) return SDQH_OK;
@@ -2387,16 +2456,38 @@ int sdqh_column_copy_in(sdqh_ctx* ctx, sdqh_column* col, int64_t row0, int64_t n
 }
 
 int sdqh_table_export_bitmap(sdqh_ctx* ctx, const sdqh_table* table, int64_t lo, int64_t hi, sdqh_column** out_words) {
-    if (!ctx || !table || !out_words || hi < lo || table->bitmap_only) return fail(ctx, SDQH_ERR_INVALID, "table_export_bitmap: bad arguments");
+    if (!ctx || !table || !out_words || hi < lo) return fail(ctx, SDQH_ERR_INVALID, "table_export_bitmap: bad arguments");
     (void)hipSetDevice(ctx->device);
     const uint64_t bits = (uint64_t)(hi - lo) + 1;
     if (bits > (1ull << 34)) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_export_bitmap: key range too wide");
     const int64_t words32 = (int64_t)((bits + 31) / 32), words64 = (words32 + 1) / 2;
     if (*out_words) { if ((*out_words)->dtype != SDQH_I64 || (*out_words)->nrows < words64) return fail(ctx, SDQH_ERR_INVALID, "table_export_bitmap: destination column too short"); }
     else if (int rc = sdqh_column_alloc(ctx, words64, SDQH_I64, 0, out_words)) return rc;
-    HIP_TRY(ctx, hipMemsetAsync((*out_words)->data, 0, (size_t)words64 * 8, ctx->stream));
-    LAUNCH(ctx, "k_export_bitmap", k_export_bitmap, (unsigned)((table->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE)), table->stage, lo, hi, static_cast<uint32_t*>((*out_words)->data));
-    return sync_stream(ctx);
+    // a table that has an exact bitmap of its own (a key set; the direct layout over a plain key): shifted word copies, no pass over the entries
+    const bool own = table->bm && table->dev.bm_shift == 0 && table->dev.lin_rb == 0 && table->dev.bm_hi >= table->dev.bm_lo;
+    if (own) {
+        const int64_t nw = words64 * 2;
+        LAUNCH(ctx, "k_export_bits", k_export_bits, (unsigned)std::max<int64_t>(1, std::min<int64_t>((nw + TPB - 1) / TPB, (int64_t)ctx->num_cu * 8)),
+               table->bm, table->dev.bm_lo, table->dev.bm_hi, lo, hi, static_cast<uint32_t*>((*out_words)->data), nw);
+    } else {
+        if (table->bitmap_only) return fail(ctx, SDQH_ERR_INVALID, "table_export_bitmap: the table has neither entries nor a bitmap over its key");
+        HIP_TRY(ctx, hipMemsetAsync((*out_words)->data, 0, (size_t)words64 * 8, ctx->stream));
+        LAUNCH(ctx, "k_export_bitmap", k_export_bitmap, (unsigned)((table->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE)), table->stage, lo, hi, static_cast<uint32_t*>((*out_words)->data));
+    }
+    return ctx->opt_async_copies ? SDQH_OK : sync_stream(ctx);      // ("async_copies": queued; whatever reads the words next is ordered behind it on the stream)
+}
+
+int sdqh_column_unpack2(sdqh_ctx* ctx, const sdqh_column* packed, int64_t nrows, sdqh_column** out_hi, sdqh_column** out_lo) {
+    if (!ctx || !packed || !out_hi || !out_lo || nrows < 0 || nrows > packed->nrows || packed->dtype != SDQH_I64) return fail(ctx, SDQH_ERR_INVALID, "column_unpack2: bad arguments");
+    (void)hipSetDevice(ctx->device);
+    sdqh_column *h = nullptr, *l = nullptr;
+    if (int rc = sdqh_column_alloc(ctx, nrows, SDQH_I64, 0, &h)) return rc;
+    if (int rc = sdqh_column_alloc(ctx, nrows, SDQH_I64, 0, &l)) { sdqh_column_free(ctx, h); return rc; }
+    if (nrows > 0)
+        LAUNCH(ctx, "k_unpack2", k_unpack2, (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + TPB - 1) / TPB, (int64_t)ctx->num_cu * 8)),
+               static_cast<const int64_t*>(packed->data), nrows, static_cast<int64_t*>(h->data), static_cast<int64_t*>(l->data));
+    *out_hi = h; *out_lo = l;
+    return SDQH_OK;
 }
 
 int sdqh_table_from_bitmap(sdqh_ctx* ctx, const sdqh_column* words, int64_t lo, int64_t hi, sdqh_table** out) {

@@ -39,6 +39,7 @@ struct sdqh_ctx {
     bool compile_only = false;                     // sdqh_create(-1): no GPU behind this ctx; sdqh_x* calls stop after specialising their kernel (build check)
     int num_cu = 256;
     hipStream_t stream = nullptr;
+    bool stream_exported = false;                  // sdqh_stream handed it out: sdqh_destroy leaves it alone
     std::string err;
     std::vector<sdqh_host::PoolBlock> pool;
     void* staging[2] = {nullptr, nullptr};

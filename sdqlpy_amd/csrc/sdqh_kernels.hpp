@@ -3223,6 +3223,53 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_part_scatter(const int64_t* __restrict
     }
 }
 
+// The same scatter into ONE buffer laid out for an all-to-all: the chunk of part p (every column's rows of that part, column after
+// column) starts at element ncols * base[p]; counts / base = what k_part_count / k_part_offsets left.  One collective then moves
+// every column of a redistribution step, and nothing is copied between the partitioning pass and the collective's buffer.
+SDQH_KERNEL __launch_bounds__(TPB) void k_part_scatter_packed(const int64_t* __restrict__ key, int64_t nrows, DevPartition pt, unsigned long long* __restrict__ cursor,
+                                                             const unsigned long long* __restrict__ counts, const unsigned long long* __restrict__ base, DevGather src, int64_t* __restrict__ packed) {
+    __shared__ unsigned int s_hist[SDQH_MAX_PARTS];
+    __shared__ unsigned long long s_base[SDQH_MAX_PARTS];
+    constexpr int64_t CHUNK = (int64_t)TPB * PART_ROWS_PER_THREAD;
+    for (int64_t c0 = (int64_t)blockIdx.x * CHUNK; c0 < nrows; c0 += (int64_t)gridDim.x * CHUNK) {
+        if (threadIdx.x < SDQH_MAX_PARTS) s_hist[threadIdx.x] = 0;
+        __syncthreads();
+        int part[PART_ROWS_PER_THREAD]; unsigned int local[PART_ROWS_PER_THREAD];
+#pragma unroll
+        for (int j = 0; j < PART_ROWS_PER_THREAD; ++j) {
+            const int64_t r = c0 + (int64_t)j * TPB + threadIdx.x;
+            part[j] = r < nrows ? part_of(pt, key[r]) : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < PART_ROWS_PER_THREAD; ++j) local[j] = part[j] >= 0 ? atomicAdd(&s_hist[part[j]], 1u) : 0u;
+        __syncthreads();
+        if ((int)threadIdx.x < pt.nparts) s_base[threadIdx.x] = s_hist[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]) : 0ull;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PART_ROWS_PER_THREAD; ++j) {
+            if (part[j] < 0) continue;
+            const int64_t r = c0 + (int64_t)j * TPB + threadIdx.x;
+            const uint64_t b = base[part[j]], n = counts[part[j]];
+            const uint64_t at = (uint64_t)src.ncols * b + (s_base[part[j]] + local[j] - b);
+#pragma unroll
+            for (int c = 0; c < SDQH_MAX_COMPACT_COLS; ++c) if (c < src.ncols) packed[at + (uint64_t)c * n] = src.out[c][r];
+        }
+        __syncthreads();
+    }
+}
+// ... and the received buffer (a chunk per source rank, laid out the same way) taken apart into contiguous columns: block (y) = (source, column)
+struct DevUnpack { int64_t src_off[SDQH_MAX_PARTS]; int64_t dst_off[SDQH_MAX_PARTS]; int64_t rows[SDQH_MAX_PARTS]; int32_t nparts, ncols; };
+SDQH_KERNEL __launch_bounds__(TPB) void k_unpack_parts(const int64_t* __restrict__ packed, DevUnpack u, DevGather dst) {
+    const int s = (int)blockIdx.y / u.ncols, c = (int)blockIdx.y % u.ncols;
+    const int64_t n = u.rows[s];
+    const int64_t* from = packed + u.src_off[s] + (int64_t)c * n;
+    int64_t* to = nullptr;
+#pragma unroll
+    for (int k = 0; k < SDQH_MAX_COMPACT_COLS; ++k) if (k == c) to = dst.out[k];
+    to += u.dst_off[s];
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) to[i] = from[i];
+}
+
 // exact bitmap of a table's keys over [lo, hi] from its stage rows
 SDQH_KERNEL __launch_bounds__(TPB) void k_export_bitmap(DevStage st, int64_t lo, int64_t hi, uint32_t* __restrict__ words) {
     const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
@@ -3232,6 +3279,36 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_export_bitmap(DevStage st, int64_t lo,
     for (uint32_t i = lane_id(); i < count; i += WAVE) {
         const int64_t k = st.key[base + i];
         if (k >= lo && k <= hi) { const uint64_t off = (uint64_t)(k - lo); atomicOr(&words[off >> 5], 1u << (off & 31)); }
+    }
+}
+
+// the same from a table's own exact bitmap (key sets, the direct layout): destination word w covers keys lo + 32 w ...; its bits are
+// two source words shifted into place — no atomics, no pass over the entries
+SDQH_KERNEL __launch_bounds__(TPB) void k_export_bits(const uint32_t* __restrict__ src, int64_t src_lo, int64_t src_hi, int64_t lo, int64_t hi, uint32_t* __restrict__ words, int64_t nwords) {
+    const int64_t src_bits = src_hi - src_lo + 1;
+    for (int64_t w = (int64_t)blockIdx.x * TPB + threadIdx.x; w < nwords; w += (int64_t)gridDim.x * TPB) {
+        const int64_t first = lo + w * 32;                                   // key of this word's bit 0
+        int64_t s = first - src_lo;                                          // its bit offset in the source (may be negative / beyond)
+        uint32_t out = 0;
+        if (s > -32 && s < src_bits) {
+            const int64_t sw = s >= 0 ? s >> 5 : -1;                           // source word holding bit s (or the one before word 0)
+            const int sh = (int)(s - sw * 32);                                 // 0 .. 31
+            const int64_t last_word = (src_bits - 1) >> 5;
+            const uint32_t a = (sw >= 0 && sw <= last_word) ? src[sw] : 0u;
+            const uint32_t b = (sw + 1 >= 0 && sw + 1 <= last_word) ? src[sw + 1] : 0u;
+            out = sh ? (a >> sh) | (b << (32 - sh)) : a;
+        }
+        const int64_t keys_left = hi - first + 1;                            // bits past `hi` stay clear
+        if (keys_left < 32) out &= keys_left > 0 ? (0xFFFFFFFFu >> (32 - keys_left)) : 0u;
+        words[w] = out;
+    }
+}
+
+// (hi << 32 | lo) -> its two parts as columns of their own (replicated composite-key tables are rebuilt from their parts)
+SDQH_KERNEL __launch_bounds__(TPB) void k_unpack2(const int64_t* __restrict__ src, int64_t nrows, int64_t* __restrict__ hi, int64_t* __restrict__ lo) {
+    for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * TPB) {
+        const uint64_t v = (uint64_t)src[r];
+        hi[r] = (int64_t)(v >> 32); lo[r] = (int64_t)(v & 0xFFFFFFFFull);
     }
 }
 

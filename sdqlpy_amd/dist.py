@@ -36,6 +36,8 @@ of q1 / q6 beyond the final few hundred bytes.  `backend` only needs all_gather,
 (or point-to-point for gloo) and barrier, so the same code runs under gloo on CPU tensors with the
 CPU oracle behind the ABI — that is how tests/test_dist_cpu.py covers the N > 1 path without GPUs.
 """
+import contextlib
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -68,9 +70,32 @@ class DistributedRunner:
         self._whole_checked = {}            # ids of the "whole" argument tables already verified across the ranks
         # every collective this runner issued since the last reset_collectives(): name -> [calls, calls on device tensors, bytes]
         self.collectives = {}
+        self._ext_stream = None             # RCCL: torch's view of the engine's HIP stream (see _device_order)
+
+    def _device_order(self):
+        """RCCL: torch's current stream becomes the ENGINE's stream for the duration of a run.  A collective is then ordered on the
+        device with the library's kernels before and behind it (torch makes its communication stream wait for, and be waited for by,
+        the current stream): the host waits only where it needs a value — row counts that size an exchange, facts, final results —
+        and no longer after every collective.  gloo / CPU tensors: everything is synchronous anyway."""
+        if self.backend != "nccl":
+            return contextlib.nullcontext()
+        if self._ext_stream is None:
+            self._ext_stream = torch.cuda.ExternalStream(int(self.ctx.stream()), device=self.device)
+        return torch.cuda.stream(self._ext_stream)
 
     def reset_collectives(self):
         self.collectives = {}
+
+    def close(self):
+        """Release what the runner holds on the device (collective buffers of the last run, cached gather buffers, torch's view of the
+        engine's stream).  Call it before the engine is closed: torch must not be left with tensors that were allocated on a stream the
+        library has destroyed."""
+        if self.backend == "nccl" and self.ctx.handle is not None:
+            self.ctx.synchronize()
+        self._inflight.clear()
+        self._gather_bufs.clear()
+        self._plans.clear()
+        self._ext_stream = None
 
     def _note(self, name, tensor):
         rec = self.collectives.setdefault(name, [0, 0, 0])
@@ -104,7 +129,8 @@ class DistributedRunner:
         self._note("all_gather", d_in)
         dist.all_gather_into_tensor(d_out, d_in, group=self.group)
         h_out.copy_(d_out, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        self.ctx.synchronize()                   # torch's current stream IS the engine's (_device_order): its wait spins on a word the stream writes, where
+                                                 # torch's stream wait sleeps on an interrupt — tens of microseconds per collective, and a step has about ten
         flat = h_out.numpy().copy()
         return [flat[r * arr.size:(r + 1) * arr.size].reshape(arr.shape) for r in range(self.world)]
 
@@ -128,13 +154,11 @@ class DistributedRunner:
         send = torch.empty(m * k, dtype=torch.int64, device=self.device)     # padding rows are never read back; no fill kernel
         if n:                                                                # on torch's stream to race the library's copies
             for j, col in enumerate(cols):
-                self.ctx.copy_out(col, 0, n, send.data_ptr() + j * m * 8)      # queued ("async_copies")
-            self.ctx.synchronize()                                           # one wait for all of them before the collective reads
+                self.ctx.copy_out(col, 0, n, send.data_ptr() + j * m * 8)      # queued ("async_copies"): the collective is ordered behind them on the stream
         recv = torch.empty(m * k * self.world, dtype=torch.int64, device=self.device)
         self._note("all_gather", send)
         if self.backend == "nccl":
             dist.all_gather_into_tensor(recv, send, group=self.group)
-            torch.cuda.current_stream().synchronize()
         else:
             dist.all_gather(list(recv.view(self.world, m * k).unbind(0)), send, group=self.group)
         outs = []
@@ -146,7 +170,7 @@ class DistributedRunner:
                     self.ctx.copy_in(out, at, sz, recv.data_ptr() + (r * k + j) * m * 8)
                     at += sz
             outs.append(out)
-        self._inflight.append(recv)                                          # the queued copy_ins read it; released at the next run
+        self._inflight.extend([send, recv])                                  # queued copies read / wrote them; released at the next run
         return outs, total
 
     def _all_gather_column(self, col, n):
@@ -180,32 +204,26 @@ class DistributedRunner:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
 
-    def _exchange(self, cols, counts):
-        """cols: Columns whose rows are contiguous per destination rank (counts[dest] rows each).
-        Returns the received Columns (rows grouped by source rank) and their row count.  The whole
-        G x G count matrix is gathered first (G*8 bytes per rank), so every rank knows what it will
-        receive and all ranks agree when nothing at all has to move and skip the data collectives."""
-        matrix = np.stack(self._all_gather_array(np.ascontiguousarray(counts, np.int64)))     # [source, dest]
+    def _exchange(self, nrows, key, cols, range_upper=None):
+        """Partition `nrows` rows of `cols` by part(key) (hash, or range_upper's ranges) and move every part to its rank.  The
+        partitioning pass writes straight into the collective's send buffer in the all-to-all's own layout (sdqh_partition_pack: the
+        chunk for rank d holds every column's rows for d), so a redistribution step is ONE all_to_all_single whatever the number of
+        columns, and the received buffer is taken apart into columns by one kernel (sdqh_unpack_parts).  The G x G count matrix is
+        gathered first (G * 8 bytes per rank: every rank learns what it will receive, and all ranks agree when nothing at all has to
+        move and skip the data collective).  Returns (received Columns, their row count, rows sent to every rank)."""
+        k = len(cols)
+        send = torch.empty(max(nrows * k, 1), dtype=torch.int64, device=self.device)
+        counts = self.ctx.partition_pack(nrows, key, self.world, cols, send.data_ptr(), range_upper)      # (waits for the counts: they size the exchange)
+        matrix = np.stack(self._all_gather_array(counts))                                              # [source, dest]
         recv_counts = matrix[:, self.rank]
-        n_send, n_recv = int(counts.sum()), int(recv_counts.sum())
-        self.exchanged_bytes += 8 * len(cols) * (n_send - int(counts[self.rank]))
-        out = []
-        for col in cols:
-            new = self.ctx.alloc(n_recv, col.dtype)
-            if matrix.sum() > 0:
-                send = torch.empty(max(n_send, 1), dtype=torch.int64, device=self.device)
-                if n_send:
-                    self.ctx.copy_out(col, 0, n_send, send.data_ptr())
-                    self.ctx.synchronize()
-                recv = torch.empty(max(n_recv, 1), dtype=torch.int64, device=self.device)
-                self._a2a(recv[:n_recv], send[:n_send], [int(c) for c in recv_counts], [int(c) for c in counts])
-                if self.backend == "nccl":
-                    torch.cuda.current_stream().synchronize()
-                if n_recv:
-                    self.ctx.copy_in(new, 0, n_recv, recv.data_ptr())
-                    self._inflight.append(recv)
-            out.append(new)
-        return out, n_recv
+        n_recv = int(recv_counts.sum())
+        self.exchanged_bytes += 8 * k * (nrows - int(counts[self.rank]))
+        recv = torch.empty(max(n_recv * k, 1), dtype=torch.int64, device=self.device)
+        if matrix.sum() > 0:
+            self._a2a(recv[:n_recv * k], send[:nrows * k], [int(c) * k for c in recv_counts], [int(c) * k for c in counts])
+        out, n = self.ctx.unpack_parts(recv.data_ptr(), recv_counts, [c.dtype for c in cols])
+        self._inflight.extend([send, recv])                                  # queued kernels read them; released at the next run
+        return out, n, counts
 
     # ---- queries ---------------------------------------------------------------------------------
     def _resolve(self, query, db):
@@ -289,10 +307,19 @@ class DistributedRunner:
         """See _run.  Column copies to / from collective buffers are only queued while a run is in
         progress (option "async_copies"); the runner synchronises once per batch."""
         self.ctx.set_option("async_copies", 1)
+        ok = False
         try:
-            return self._run(query, db, whole_tables, top)
+            with self._device_order():
+                res = self._run(query, db, whole_tables, top)
+            ok = True
+            return res
         finally:
-            self.ctx.synchronize()
+            # RCCL: nothing to wait for — what the host needed it has waited for, a result launched and not looked at yet finishes when
+            # it is (result.DeferredResultSet), and the collective buffers of this run are released at the start of the next one, in
+            # stream order (torch's allocator reuses a block on the stream it was allocated on: the engine's).  The wait stays for
+            # CPU tensors (the library's queued copies read them) and after an error.
+            if self.backend != "nccl" or not ok:
+                self.ctx.synchronize()
             self.ctx.set_option("async_copies", 0)
 
     def _run(self, query, db, whole_tables=None, top=None):
@@ -466,9 +493,25 @@ class DistributedRunner:
         for name in accumulate_into:
             if st.replicate.get(name) or built_by[name].table in whole:
                 st.unsupported = "the probe-aggregate into '%s' is not local to the ranks' shards: it needs the partitioned-join plan" % name
-        # builds that only answer `tbl[k] != None` and stay on their rank are key sets, as on one GPU
-        # (a key set has no entries to export, so one that must be replicated stays an ordinary table)
-        member_only = {name for name in engine._membership_only(plan) if not st.replicate.get(name, False)}
+        # builds that only answer `tbl[k] != None` are key sets, as on one GPU; one that other shards' rows look up is replicated
+        # through its exact bitmap over the global key range (gathered here, once) — unless that range does not suit a bitmap: then
+        # it stays an ordinary table whose entries travel
+        member_only, st.key_range = set(), {}
+        for name in engine._membership_only(plan):
+            if not st.replicate.get(name, False):
+                member_only.add(name)
+                continue
+            bop = built_by.get(name)
+            if bop is None or not isinstance(bop.key, Col) or tabs[bop.table].cols.get(bop.key.name) is None:
+                continue
+            karr = tabs[bop.table].array(bop.key.name, bop)
+            mine = eng.column(karr).minmax() if len(karr) else (abi.INT64_MAX, abi.INT64_MIN)
+            facts = self._all_gather_array(np.array(mine, np.int64))
+            lo, hi = min(int(f[0]) for f in facts), max(int(f[1]) for f in facts)
+            if lo <= hi and hi - lo + 1 <= (1 << 31):
+                member_only.add(name)
+                st.key_range[name] = (lo, hi)
+        st.member_only = member_only
         for op in plan.ops:
             if isinstance(op, ScanOp):
                 st.steps.append((op, engine._prepare_scan(eng, op, tabs[op.table], accumulate_into, op.out in member_only)))
@@ -487,10 +530,19 @@ class DistributedRunner:
                             st.local_text.add(id(hit[2]))
         return st
 
-    def _replicate_table(self, bt):
-        """All ranks' entries of a built table on every rank, without leaving device memory:
-        entries -> all-gather -> rebuild.  A composite key travels packed; lookups pack the same way."""
+    def _replicate_table(self, bt, key_range=None):
+        """All ranks' entries of a built table on every rank, without leaving device memory.  A key set (key_range given): its exact
+        bitmap over the global key range, one collective, the replica a key set again — the layout the loops that test it are
+        specialised on.  A table with payload: entries -> all-gather -> rebuild, a composite key (travelling packed) from its two
+        parts through sdqh_build, which lays it out as the single-GPU plan's build would (linearised rectangle / high-part bitmap in
+        front of the hash: what the final loops of Q5 / Q9 are tuned for)."""
         ctx = self.ctx
+        if key_range is not None:
+            table, words = self._replicated_key_set(bt.table, key_range, disjoint=False)
+            bt.table.free()
+            bt.table = table
+            bt._keep = words
+            return bt
         local = self._local_text          # text arrays / dictionaries of this rank's shards (see _prepare_chain)
         if any(id(d) in local for d in list(bt.decoders.values()) + list(bt.field_decoders.values()) if d is not None):
             raise frontend.UnsupportedQuery("'%s' carries text as references to this rank's rows: it cannot be replicated yet "
@@ -499,7 +551,12 @@ class DistributedRunner:
         gathered, total = self._all_gather_columns(cols, n)
         for c in cols:
             c.free()
-        table = ctx.hash_build_unique(total, abi.make_filter(), [], gathered[0], gathered[1:])
+        if bt.key_parts is not None and total:
+            hi, lo = ctx.unpack2(gathered[0], total)
+            table = ctx.build(total, abi.make_filter(), [], [abi.src_col(hi), abi.src_col(lo)], [abi.src_col(c) for c in gathered[1:]])
+            gathered = list(gathered) + [hi, lo]
+        else:
+            table = ctx.hash_build_unique(total, abi.make_filter(), [], gathered[0], gathered[1:])
         new = engine.BuiltTable(table, bt.key_name, bt.key_is_record, bt.val_fields, bt.val_is_record, bt.payload_dtypes)
         new.decoders, new.key_parts, new.field_decoders = bt.decoders, bt.key_parts, bt.field_decoders
         new.key_decoder = bt.key_decoder
@@ -522,7 +579,7 @@ class DistributedRunner:
                 if isinstance(op, ScanOp):
                     res = step(env)
                     if isinstance(res, engine.BuiltTable) and st.replicate.get(op.out):
-                        res = self._replicate_table(res)
+                        res = self._replicate_table(res, st.key_range.get(op.out))
                     elif isinstance(res, engine.DictResult) and st.sharded[op.out]:
                         res = self._merge_groups(res)
                     elif isinstance(res, float) and st.sharded[op.out]:
@@ -697,6 +754,9 @@ class DistributedRunner:
             e.shape(slots)
         st.ops_c = [eng.column(tc.array(s[1], c_op)) for s in slots]
         st.key_fields = c_op.key.fields if isinstance(c_op.key, RecordCons) else [(None, c_op.key)]
+        # the probe loop's own closure (fixed-shape route): run on rows that reached this rank through the exchange, it aggregates them
+        # into the table and leaves the table marked as the engine's own step would, so the engine's K-F finishes the plan
+        st.step_c = engine._prepare_scan_fixed(eng, c_op, tc, {b_op.out: None})
 
         # ---- static facts, gathered once ---------------------------------------------------------
         a_lo, a_hi = st.key_a.minmax() if st.na else (abi.INT64_MAX, abi.INT64_MIN)
@@ -727,117 +787,156 @@ class DistributedRunner:
         st.empty = abi.make_filter()
         return st
 
-    def _replicated_set(self, st):
-        """Table A on every rank.  Dense key range: every rank builds its shard's table, exports the
-        exact key bitmap over the GLOBAL key range, and one all-reduce (SUM = OR, the keys of a unique
-        build are disjoint across ranks) makes it global.  Otherwise the surviving keys are
-        all-gathered and the set is built from them."""
+    def _replicated_key_set(self, table, rng, disjoint=True):
+        """The union over the ranks of a table's keys as a key set on every rank, through its exact bitmap over the GLOBAL key range
+        `rng`: exported straight into the collective's buffer (a torch tensor wrapped as a column; key sets and direct-layout tables
+        copy their own bitmap words, shifted) and made global by ONE collective — an all-reduce when the ranks' key sets are
+        disjoint (SUM = OR: the keys of a unique build over row shards), else an all-gather folded with bitwise OR on the device
+        (RCCL has no bitwise reduction).  Returns (key-set Table, what it borrows: keep alive while the table is used)."""
         ctx = self.ctx
-        if st.a_whole:
-            # every rank holds table A completely: its set is built locally and no collective runs.
-            # (Summing the ranks' bitmaps of identical sets would carry bits into their neighbours.)
-            return ctx.hash_build_unique(st.na, st.flt_a, [], st.key_a, []), []
-        if st.a_bitmap:
-            local = ctx.hash_build_unique(st.na, st.flt_a, [], st.key_a, [])
-            lo, hi = st.a_range
-            n64 = ((hi - lo + 1 + 31) // 32 + 1) // 2
-            # the bitmap is exported straight into the collective's buffer (a torch tensor wrapped as a column)
-            buf = torch.empty(max(n64, 1), dtype=torch.int64, device=self.device)
-            words = ctx.wrap(buf.data_ptr(), n64, abi.I64, keepalive=buf)
-            ctx.table_export_bitmap(local, lo, hi, into=words)
-            local.free()
+        lo, hi = rng
+        n64 = ((hi - lo + 1 + 31) // 32 + 1) // 2
+        buf = torch.empty(max(n64, 1), dtype=torch.int64, device=self.device)
+        words = ctx.wrap(buf.data_ptr(), n64, abi.I64, keepalive=buf)
+        ctx.table_export_bitmap(table, lo, hi, into=words)                    # queued under "async_copies": the collective is ordered behind it
+        if disjoint:
             self._note("all_reduce", buf)
             dist.all_reduce(buf, group=self.group)
+        else:
+            parts = torch.empty(max(n64, 1) * self.world, dtype=torch.int64, device=self.device)
+            self._note("all_gather", buf)
             if self.backend == "nccl":
-                torch.cuda.current_stream().synchronize()
-            return ctx.table_from_bitmap(words, lo, hi), [words]
-        (ka,), n_a = ctx.scan_compact(st.na, st.flt_a, [], [st.key_a])
-        rep_keys, n_rep = self._all_gather_column(ka, n_a)
-        ka.free()
-        return ctx.hash_build_unique(n_rep, st.empty, [], rep_keys, []), [rep_keys]
+                dist.all_gather_into_tensor(parts, buf, group=self.group)
+            else:
+                dist.all_gather(list(parts.view(self.world, -1).unbind(0)), buf, group=self.group)
+            rows = parts.view(self.world, -1)
+            for r in range(self.world):
+                if r == 0:
+                    buf.copy_(rows[0])
+                else:
+                    torch.bitwise_or(buf, rows[r], out=buf)
+            self._inflight.append(parts)
+        return ctx.table_from_bitmap(words, lo, hi), words
+
+    def _build_from_columns(self, n, cols, key_range):
+        """A table with accumulators from received entry columns [key, payload ...] (every row an entry; keys within key_range).  As a
+        row program when the library takes it — the value-queue build streams the columns once and needs no minimum / maximum pass,
+        having been told the bounds: 0.03 ms for Q3's 1.46 M received orders where the fixed-shape build took 0.27 — else the
+        fixed-shape unique build."""
+        ctx = self.ctx
+        lo, hi = key_range
+        if n and len(cols) <= 1 + abi.MAX_PAYLOAD and lo <= hi:
+            prog = abi.Program()
+            prog.key = prog.op(abi.X_COL, abi.T_I64, col=cols[0])
+            prog.vals = [prog.op(abi.X_COL, abi.T_F64 if c.dtype == abi.F64 else abi.T_I64, col=c) for c in cols[1:]]
+            try:
+                return ctx.xbuild(n, prog, lo, hi, accumulate=True)
+            except abi.SdqhError as exc:
+                if exc.code != abi.ERR_UNSUPPORTED:
+                    raise
+        return ctx.hash_build_unique(n, abi.make_filter(), [], cols[0], cols[1:], accumulate=True)
+
+    def _replicated_set(self, st, local):
+        """Table A (a BuiltTable built from this rank's shard) on every rank; see _replicated_key_set.  Key range too wide for a
+        bitmap: the surviving keys are all-gathered and the set is built from them."""
+        ctx = self.ctx
+        if st.a_bitmap:
+            table, words = self._replicated_key_set(local.table, st.a_range)
+            keep = [words]
+        else:
+            (ka,), n_a = ctx.scan_compact(st.na, st.flt_a, [], [st.key_a])
+            rep_keys, n_rep = self._all_gather_column(ka, n_a)
+            ka.free()
+            table, keep = ctx.hash_build_unique(n_rep, st.empty, [], rep_keys, []), [rep_keys]
+        local.table.free()
+        local.table = table
+        return keep
 
     def _partitioned_join(self, plan, args, a_whole=False):
-        ctx = self.ctx
+        """The engine's own prepared steps (the kernels of the single-GPU plan: tight-encoded build and probe programs, K-F behind the
+        call) with the exchange at their seams:
+          A      built from this rank's shard, then replaced by the replicated set (one collective; none when A is whole everywhere);
+          range  B and the probe-aggregate run in place; probe rows whose key another rank owns are compacted, exchanged (one packed
+                 all-to-all) and aggregated into B before the engine's K-F;
+          hash   B's survivors — the entries of the table the engine's build step made of this rank's shard — are hash-partitioned,
+                 exchanged, and B is rebuilt from what arrived; its keys' bitmap over the global range is replicated (one all-reduce)
+                 so that only probe rows that will hit travel; those are compacted, exchanged and aggregated; then the engine's K-F."""
+        ctx, eng = self.ctx, self.eng
         cache = plan.__dict__.setdefault("_dist_prepared", {})
         key = (id(self), a_whole, self.partition) + tuple(id(a) for a in args)
         st = cache.get(key)
-        if st is None or st.generation != self.eng.generation or any(x is not y for x, y in zip(st.args, args)):
+        if st is None or st.generation != eng.generation or any(x is not y for x, y in zip(st.args, args)):
             st = cache[key] = self._prepare_join(plan, args, a_whole)
         self.last_partitioning = st.mode
         self.exchanged_bytes = 0
-        table_a, keep_a = self._replicated_set(st)
-        recv, n_recv = None, 0
-        if st.mode == "range":
-            # the build side is already partitioned on its key: build in place
-            table_b = ctx.hash_build_unique(st.nb, st.flt_b, [(table_a, st.probe_b)], st.key_b, st.pay_b, accumulate=True)
-            if st.all_local:
-                ctx.hash_probe_aggregate(st.nc, st.flt_c, table_b, st.key_c, st.tup_c)
-                self.exchanged_rows = {"build": 0, "probe_sent": 0, "probe_received": 0}
-            else:
-                ctx.hash_probe_aggregate(st.nc, st.flt_own, table_b, st.key_c, st.tup_c)
-                pieces = [ctx.scan_compact(st.nc, flt, [], [st.key_c] + st.ops_c) for flt in st.flt_foreign]
-                foreign_n = sum(n for _, n in pieces)
-                merged = _concat_columns(ctx, pieces, [abi.I64] + [abi.F64] * len(st.ops_c))
-                part_cols, counts = ctx.partition_by_key(foreign_n, merged[0], self.world, merged, range_upper=st.upper)
-                recv, n_recv = self._exchange(part_cols, counts)
-                self.exchanged_rows = {"build": 0, "probe_sent": int(foreign_n), "probe_received": int(n_recv)}
-        else:
-            # hash partitioning: redistribute the build survivors, then the filtered probe rows
-            bcols, nb = ctx.scan_compact(st.nb, st.flt_b, [(table_a, st.probe_b)], [st.key_b] + st.pay_b)
-            part_cols, counts = ctx.partition_by_key(nb, bcols[0], self.world, bcols)
-            brecv, nb_recv = self._exchange(part_cols, counts)
-            table_b = ctx.hash_build_unique(nb_recv, st.empty, [], brecv[0], brecv[1:], accumulate=True)
-            # Only probe rows whose key some rank holds need to travel (Q3: half a per cent of the filtered lineitem rows).  Every
-            # rank exports the exact bitmap of ITS partition's keys over the global key range; one all-reduce (SUM = OR: partitions
-            # are disjoint) replicates the set of all build keys; the filter + semi-join compaction then drops the rest before
-            # the partitioning pass and the all-to-all ever see them.  Skipped when the key range is too wide for a bitmap.
-            probes_c, keep_pre = [], []
-            lo_g, hi_g = min(r[0] for r in st.b_ranges), max(r[1] for r in st.b_ranges)
-            if self.prefilter and lo_g <= hi_g and hi_g - lo_g + 1 <= (1 << 31):
-                n64 = ((hi_g - lo_g + 1 + 31) // 32 + 1) // 2
-                buf = torch.empty(max(n64, 1), dtype=torch.int64, device=self.device)
-                words = ctx.wrap(buf.data_ptr(), n64, abi.I64, keepalive=buf)
-                ctx.table_export_bitmap(table_b, lo_g, hi_g, into=words)
-                self._note("all_reduce", buf)
-                dist.all_reduce(buf, group=self.group)
-                if self.backend == "nccl":
-                    torch.cuda.current_stream().synchronize()
-                all_keys = ctx.table_from_bitmap(words, lo_g, hi_g)
-                probes_c, keep_pre = [(all_keys, st.key_c)], [all_keys, words]
-            ccols, nc = ctx.scan_compact(st.nc, st.flt_c, probes_c, [st.key_c] + st.ops_c)
-            for obj in keep_pre:
-                obj.free()
-            part_cols, counts = ctx.partition_by_key(nc, ccols[0], self.world, ccols)
-            recv, n_recv = self._exchange(part_cols, counts)
-            self.exchanged_rows = {"build": int(nb), "probe_sent": int(nc), "probe_received": int(n_recv)}
-        if n_recv:
-            ctx.hash_probe_aggregate(n_recv, st.empty, table_b, recv[0], abi.make_tuple(st.tup_c.shape, recv[1:]))
+        pp = engine.prepared_plan(eng, plan, args)
+        a_op, b_op, c_op, f_op = plan.ops
+        keep = []
 
-        # ---- finalise this rank's partition --------------------------------------------------------
-        spec = self._join_sort_spec(st) if self._top else None
-        if spec is not None and 1 <= self._top[0] <= abi.MAX_TOPK:
-            keys, payload, values, hits = ctx.table_topk(table_b, 1, self._top[0], spec)
-        else:
-            hint = getattr(st, "result_rows", None)
-            keys, payload, values, hits, n = ctx.table_compact_into_block(table_b, 1, 4096 if hint is None else hint + hint // 8 + 1024,
-                                                                          want_hits=st.count_idx is not None)
-            st.result_rows = n
-        names, arrays = [], []
-        for fname, e in st.key_fields:
-            if isinstance(e, Col) and e.name == st.ckey_name:
-                names.append(fname or st.ckey_name); arrays.append(keys)
-            elif isinstance(e, PayloadField):
-                j = st.pay_names.index(e.field)
-                names.append(fname or e.field); arrays.append(payload[j].view(st.pay_dtypes[j]))
-            else:
-                raise frontend.UnsupportedQuery("unsupported group key in the distributed join")
-        nv = abi.TUPLE_NVALUES[st.tup_c.shape]
-        for nm, arr in engine._value_arrays(st.vnames, st.count_idx, [values[j] for j in range(nv)], hits):
-            names.append(nm); arrays.append(arr)
-        table_b.free(); table_a.free()
-        for c in keep_a:
-            c.free()
-        return ResultSet(names, arrays)
+        def replicate_a(env):
+            if not st.a_whole:                   # (A whole on every rank: its set is built locally and no collective runs —
+                keep.extend(self._replicated_set(st, env[a_op.out]))      #  summing the ranks' bitmaps of identical sets would carry bits into their neighbours)
+
+        try:
+            if st.mode == "range":
+                after = {a_op.out: replicate_a}
+                self.exchanged_rows = {"build": 0, "probe_sent": 0, "probe_received": 0}
+                if not st.all_local:
+                    def foreign_rows(env):
+                        # rows of this rank's probe shard whose key another rank's build range owns: compacted, sent there, and what
+                        # arrives here aggregated into B (the step before aggregated the rows that were already where they belong —
+                        # a foreign key finds nothing in this rank's B)
+                        pieces = [ctx.scan_compact(st.nc, flt, [], [st.key_c] + st.ops_c) for flt in st.flt_foreign]
+                        foreign_n = sum(n for _, n in pieces)
+                        merged = _concat_columns(ctx, pieces, [abi.I64] + [abi.F64] * len(st.ops_c))
+                        recv, n_recv, _ = self._exchange(foreign_n, merged[0], merged, range_upper=st.upper)
+                        if n_recv:
+                            ctx.hash_probe_aggregate(n_recv, st.empty, env[b_op.out].table, recv[0], abi.make_tuple(st.tup_c.shape, recv[1:]))
+                        keep.extend(recv)
+                        self.exchanged_rows = {"build": 0, "probe_sent": int(foreign_n), "probe_received": int(n_recv)}
+                    after[c_op.out] = foreign_rows
+                return pp.run(self._top, after=after)
+            # ---- hash partitioning: the steps driven from here -----------------------------------------------------------
+            steps = dict(pp.steps)
+            env = {}
+            try:
+                env[a_op.out] = steps[a_op.out](env)
+                replicate_a(env)
+                env[b_op.out] = bt_b = steps[b_op.out](env)                   # this rank's survivors, by the engine's own build kernel
+                bcols, nb = ctx.table_entries(bt_b.table)                     # [key, payload ...]
+                brecv, nb_recv, _ = self._exchange(nb, bcols[0], bcols)
+                for c in bcols:
+                    c.free()
+                table_b = self._build_from_columns(nb_recv, brecv, (min(r[0] for r in st.b_ranges), max(r[1] for r in st.b_ranges)))
+                bt_b.table.free()
+                bt_b.table = table_b
+                keep.extend(brecv)
+                # Only probe rows whose key some rank holds need to travel (Q3: half a per cent of the filtered lineitem rows): every rank
+                # exports the exact bitmap of ITS partition's keys over the global key range, one all-reduce (SUM = OR: partitions are
+                # disjoint) replicates the set of all build keys, and the filter + semi-join compaction drops the rest before the
+                # partitioning pass and the all-to-all ever see them.  Skipped when the key range is too wide for a bitmap.
+                probes_c = []
+                lo_g, hi_g = min(r[0] for r in st.b_ranges), max(r[1] for r in st.b_ranges)
+                if self.prefilter and lo_g <= hi_g and hi_g - lo_g + 1 <= (1 << 31):
+                    all_keys, words = self._replicated_key_set(table_b, (lo_g, hi_g))
+                    probes_c = [(all_keys, st.key_c)]
+                    keep.append(words)
+                ccols, nc = ctx.scan_compact(st.nc, st.flt_c, probes_c, [st.key_c] + st.ops_c)
+                for tbl, _ in probes_c:
+                    tbl.free()                                                # (the words it borrowed stay alive in `keep`)
+                recv, n_recv, _ = self._exchange(nc, ccols[0], ccols)
+                for c in ccols:
+                    c.free()
+                keep.extend(recv)
+                self.exchanged_rows = {"build": int(nb), "probe_sent": int(nc), "probe_received": int(n_recv)}
+                env[c_op.out] = st.step_c(env, rows=(n_recv, recv[0], abi.make_tuple(st.step_c.tuple_shape, recv[1:])))
+                return engine._finalize(eng, f_op, env, self._top)
+            finally:
+                for v in env.values():
+                    if isinstance(v, engine.BuiltTable):
+                        v.table.free()
+        finally:
+            self._inflight.extend(keep)          # queued kernels may still read them: released at the next run (the run ends synchronised)
 
     def _join_sort_spec(self, st):
         """sdqh_table_topk sort keys for the partitioned join's result columns, or None (host ordering)."""

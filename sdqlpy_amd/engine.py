@@ -134,13 +134,22 @@ class Engine:
         for _, col in self._columns.values():
             col.free()
         self._columns.clear()
-        for arr in self._frozen.values():
-            arr.flags.writeable = True
+        self._thaw(list(self._frozen.values()))
         self._frozen.clear()
         self._range_cache.clear()
         self._distinct_cache.clear()
         self.resident_bytes = 0
         self.generation += 1
+
+    @staticmethod
+    def _thaw(arrays):
+        """Make adopted arrays writable again.  A view can only be made writable while its base is: owners first, then views; a view
+        whose base somebody else keeps read-only stays read-only (numpy refuses, and that is the right answer)."""
+        for arr in sorted(arrays, key=lambda a: 0 if a.base is None else 1):
+            try:
+                arr.flags.writeable = True
+            except ValueError:
+                pass
 
     def column(self, arr):
         """Resident column for a host array (uploaded on first use, then cached by identity).
@@ -196,7 +205,7 @@ class Engine:
             self._distinct_cache.pop(key, None)
             frozen = self._frozen.pop(key, None)
             if frozen is not None:
-                frozen.flags.writeable = True
+                self._thaw([frozen])
         self.generation += 1
 
     def rowid_column(self, nrows):
@@ -1199,7 +1208,9 @@ def _prepare_scan_fixed(eng, op, htab, accumulate_into, member_only=False, as_ta
     kcol = eng.column(karr)
     probe_name = op.probe.dict_name
 
-    def run_probe_aggregate(env):
+    def run_probe_aggregate(env, rows=None):
+        """rows = (n, key Column, tuple): aggregate THOSE rows into the table instead of the scanned table's (the multi-GPU runner:
+        rows that reached this rank through the exchange; n = 0: bookkeeping only)."""
         bt = env.get(probe_name)
         if not isinstance(bt, BuiltTable):
             raise UnsupportedQuery("line %d: joinProbe index must be a built table" % op.lineno)
@@ -1227,9 +1238,13 @@ def _prepare_scan_fixed(eng, op, htab, accumulate_into, member_only=False, as_ta
             if share is not None:
                 ctx.table_share_groups(bt.table, *share)
                 bt.shared_groups = True
-        ctx.hash_probe_aggregate(n, flt, bt.table, kcol, tup)
+        if rows is None:
+            ctx.hash_probe_aggregate(n, flt, bt.table, kcol, tup)
+        elif rows[0]:
+            ctx.hash_probe_aggregate(rows[0], abi.make_filter(), bt.table, rows[1], rows[2])
         bt.agg = (bt.agg_spec, vnames, count_idx, key_is_record, val_is_record, abi.TUPLE_NVALUES[tup.shape])
         return ("aggregated", probe_name)
+    run_probe_aggregate.tuple_shape = tup.shape
     return run_probe_aggregate
 
 

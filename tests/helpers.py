@@ -1093,3 +1093,59 @@ def deferred_result_cases(eng, goldens, rel=0.0):
     finally:
         eng.deferred_results = False
     return checked, deferred_seen
+
+
+def redistribution_pack_case(ctx, n=70001, seed=21, nparts=5):
+    """sdqh_partition_pack / sdqh_unpack_parts / sdqh_column_unpack2 / sdqh_table_export_bitmap on key sets and direct-layout tables,
+    against numpy: every chunk of the packed buffer holds exactly its part's rows, column after column; taking the buffer apart
+    gives the columns back; a key set's bitmap exported over a wider and a narrower, shifted range names exactly its keys.
+    Returns a digest that is the same on both implementations of the ABI."""
+    from sdqlpy_amd import abi
+    rng = np.random.default_rng(seed)
+    key = rng.integers(0, 5000, n).astype(np.int64) * 3 + 7
+    val = rng.random(n)
+    tag = np.arange(n, dtype=np.int64)
+    kc, vc, tc = ctx.upload(key), ctx.upload(val), ctx.upload(tag)
+    packed = ctx.alloc(3 * n, abi.I64)
+    out = {}
+    for mode, upper in (("hash", None), ("range", np.array([2000, 6000, 9000, 12000][:nparts - 1], np.int64))):
+        counts = ctx.partition_pack(n, kc, nparts, [kc, vc, tc], packed.data_ptr(), range_upper=upper)
+        assert int(counts.sum()) == n
+        cols, m = ctx.unpack_parts(packed.data_ptr(), counts, [abi.I64, abi.F64, abi.I64])
+        ctx.synchronize()
+        assert m == n
+        k2, v2, t2 = cols[0].download(0, n), cols[1].download(0, n), cols[2].download(0, n)
+        assert np.array_equal(key[t2], k2) and np.array_equal(val[t2], v2) and np.array_equal(np.sort(t2), tag)     # rows intact, none lost
+        off = np.concatenate([[0], np.cumsum(counts)])
+        for p in range(nparts):
+            seg = k2[off[p]:off[p + 1]]
+            if upper is not None:
+                lo = -1 if p == 0 else upper[p - 1]
+                assert ((seg > lo) & ((seg <= upper[p]) if p < nparts - 1 else True)).all()
+        out[mode] = (counts.tolist(), [sorted(t2[off[p]:off[p + 1]].tolist())[:5] for p in range(nparts)])
+        for c in cols:
+            c.free()
+    # empty input
+    counts = ctx.partition_pack(0, kc, nparts, [kc, vc], packed.data_ptr())
+    assert counts.tolist() == [0] * nparts
+    cols, m = ctx.unpack_parts(packed.data_ptr(), counts, [abi.I64, abi.F64])
+    assert m == 0
+    # packed composite keys -> their parts
+    hi, lo = rng.integers(0, 1 << 32, 1000).astype(np.uint64), rng.integers(0, 1 << 32, 1000).astype(np.uint64)
+    pk = ctx.upload(((hi << np.uint64(32)) | lo).view(np.int64))
+    ch, cl = ctx.unpack2(pk, 1000)
+    ctx.synchronize()
+    assert np.array_equal(ch.download(0, 1000), hi.astype(np.int64)) and np.array_equal(cl.download(0, 1000), lo.astype(np.int64))
+    # a key set's bitmap over other ranges (bitmap-only table: its own words, shifted), and a direct-layout table's
+    present = sorted(set(key.tolist()))
+    ks = ctx.build_key_set(n, abi.make_filter(), [], kc)
+    direct = ctx.hash_build_unique(n, abi.make_filter(), [], kc, [vc])
+    for t in (ks, direct):
+        for lo_r, hi_r in ((7, 7 + 3 * 5000), (-100, 20011), (1000, 1999), (8, 8), (15001, 15100)):
+            words = ctx.table_export_bitmap(t, lo_r, hi_r)
+            t2 = ctx.table_from_bitmap(words, lo_r, hi_r)
+            probe = ctx.upload(np.arange(lo_r - 3, hi_r + 4, dtype=np.int64))
+            (hit,), nh = ctx.scan_compact(hi_r - lo_r + 7, abi.make_filter(), [(t2, probe)], [probe])
+            ctx.synchronize()
+            assert sorted(hit.download(0, nh).tolist()) == [k for k in present if lo_r <= k <= hi_r], (lo_r, hi_r)
+    return out

@@ -261,3 +261,15 @@ def test_tight_kernels_compile_without_a_gpu(hip_lib, monkeypatch):
         assert sum(ctx.jit_stats()) - before >= 6
     finally:
         ctx.close()
+
+
+def test_packed_exchange_helpers_on_the_cpu_implementation(oracle_lib):
+    """sdqh_partition_pack / sdqh_unpack_parts / sdqh_column_unpack2 / bitmap export from key sets: the CPU implementation against numpy
+    (the HIP library runs the same case in tests/test_hip_parity.py and must agree with this one)."""
+    import helpers
+    ctx = oracle_lib.context(threads=2)
+    try:
+        out = helpers.redistribution_pack_case(ctx, n=20011)
+        assert sum(out["hash"][0]) == 20011 and sum(out["range"][0]) == 20011
+    finally:
+        ctx.close()

@@ -19,19 +19,26 @@ from sdqlpy_amd.sdql_lib import sdqlpy_init
 
 qs = sys.argv[1].split(",") if len(sys.argv) > 1 else ["q3", "q5"]
 sdqlpy_init(3, 1, device=0)
-db = tpch.generate(10, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
-runner = sdist.DistributedRunner(engine.default_engine(device=0), 0, 1)
+db = tpch.generate(10, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs), shard=(0, 1))      # marked as row shards: the partitioned plans run
+runner = sdist.DistributedRunner(engine.default_engine(device=0), 0, 1, partition=os.environ.get("PARTITION", "hash"))
+
+
+def finished(r):
+    return r.wait() if hasattr(r, "wait") else r
+
 for q in qs:
     for _ in range(5):
-        runner.run(q, db)
+        finished(runner.run(q, db))
     t0 = time.perf_counter()
     for _ in range(50):
-        runner.run(q, db)
+        finished(runner.run(q, db))
     print(q, "mean wall ms", (time.perf_counter() - t0) * 20, flush=True)
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(50):
-        runner.run(q, db)
+        finished(runner.run(q, db))
     pr.disable()
     pstats.Stats(pr).sort_stats("tottime").print_stats(16)
+runner.close()
+torch.cuda.synchronize()
 dist.destroy_process_group()

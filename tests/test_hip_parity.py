@@ -1169,7 +1169,7 @@ def test_sf100_on_one_gpu_q5_q9(hip_engine):
         whole = whole.wait() if hasattr(whole, "wait") else whole
         assert whole.size() > 0
         again = helpers.run_query(hip_engine, q, db)
-        assert sorted(again.rows()) == sorted(whole.rows())
+        _rows_match(again, whole, "sf100/%s/again" % q)                  # (group sums through LDS atomics: the order of the adds is not fixed)
         value_cols = [c for c in whole.columns if whole.column(c).dtype.kind == "f"]
         key_cols = [c for c in whole.columns if c not in value_cols]
         cut = n // 2 + 333

@@ -626,6 +626,9 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "copy_nt" && value >= 0 && value <= 1) ctx->opt_copy_nt = (int)value;
     else if (n == "x_waves" && value >= 0 && value <= 256) ctx->opt_x_waves = (int)value;
     else if (n == "window" && value >= 0 && value <= 1) ctx->opt_window = (int)value;
+    else if (n == "lane_int" && value >= 0 && value <= 1) ctx->opt_lane_int = (int)value;
+    else if (n == "row_index" && value >= 0 && value <= 1) ctx->opt_row_index = (int)value;
+    else if (n == "lane_resident" && value >= 1 && value <= 4) ctx->opt_lane_resident = (int)value;
     else if (n == "async_result" && value >= 0 && value <= 1) ctx->opt_async_result = (int)value;
     else if (n == "stage_pipeline" && value >= 0 && value <= 1) ctx->opt_stage_pipeline = (int)value;
     else if (n == "span_index" && value >= 0 && value <= 1) ctx->opt_span_index = (int)value;
@@ -1023,6 +1026,14 @@ static int ensure_index(sdqh_ctx* ctx, sdqh_table* tb) {
     if (tb->index_built || tb->bitmap_only) return SDQH_OK;
     const unsigned seg_grid = (unsigned)((tb->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
     const size_t rows = (size_t)std::max<int64_t>(tb->nrows_build, 1);
+    if (tb->bm && tb->dev.bm_shift == 0 && tb->stage.wrow) {               // direct layout, ROW INDEX written by the stage kernel (sdqh_kernels.hpp: DevTable)
+        LAUNCH(ctx, "k_wrow_fixup", k_wrow_fixup, (unsigned)((tb->stage.nseg + TPB - 1) / TPB), tb->stage, tb->wexc, tb->hdr);
+        tb->dev.wprefix = tb->stage.wrow; tb->dev.dense_ref = nullptr; tb->dev.wexc = tb->wexc;
+        hipError_t er = hipGetLastError();
+        if (er != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, std::string("table index launch: ") + hipGetErrorString(er));
+        tb->index_built = true;
+        return SDQH_OK;
+    }
     if (tb->bm && tb->dev.bm_shift == 0) {                                 // direct layout
         const int nblocks = (int)((tb->nwords + RANK_BLOCK_WORDS - 1) / RANK_BLOCK_WORDS);
         uint32_t* wprefix = static_cast<uint32_t*>(table_alloc(ctx, tb, tb->nwords * 4 + 64));

@@ -99,6 +99,9 @@ struct sdqh_ctx {
     int opt_copy_kernel = 0;            // > 0: sdqh_table_compact_deferred copies its rows out with that many workgroups of k_copy_out instead of the runtime's
                                         // copy (measured: 64 workgroups of write-through stores 0.85 ms a step against 0.79 — the runtime's blit kernel stays)
     int opt_copy_nt = 1;
+    int opt_row_index = 1;              // unique builds keyed by a strictly increasing column: the stage kernel writes the word -> stage row index itself (no rank / insert passes)
+    int opt_lane_int = 1;               // the per-lane group sink sums an integer-valued byte-coded column as an integer beside the row count (XGroupLane)
+    int opt_lane_resident = 2;          // workgroups per CU the per-lane group sink's grid is sized for
     int opt_window = 0;                 // x_queue8's 32-bit prefilter tests a lane's 8 rows against ONE 16-byte window of the bitmap when the key column's 8-row spans allow (column_span8): measured
                                         // on par with 8 single-word requests once those are coalesced (Q3's probe 0.083 vs 0.081 ms) and slower where every row is tested (Q5's final loop 0.140 vs 0.130)
     int opt_x_waves = 0;                // > 0: wave segments per CU for the queue skeletons of row programs (0: each sink's own default)
@@ -182,6 +185,7 @@ struct sdqh_table {
     uint32_t* seg_kept = nullptr;
     void* zero_rows = nullptr;                     // nrows_build + 1 zeroed 8-byte rows: the accumulator columns a table does not have (sdqh_table_columns)
     int nv = SDQH_TUPLE_MAX_VALUES;    // value count of the tuple aggregated into the table
+    WordExc* wexc = nullptr;                       // row index (DevTable): exception records, one slot per segment
     uint32_t* coarse = nullptr; int coarse_words = 0, coarse_shift = 0;     // coarse key filter (see DevLookups), built on first need
 };
 

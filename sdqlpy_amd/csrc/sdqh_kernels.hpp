@@ -110,6 +110,17 @@ constexpr int RANK_BLOCK_WORDS = 4096;        // bitmap words per prefix block (
                                               // over Q3's 60 M-key range were 20 us of a kernel that moves 7.5 MB; 4096 against 8192: the same on the big bitmaps,
                                               // 9.5 -> 7 us on the small ones)
 
+// ROW INDEX (builds keyed by a strictly increasing column, staged in row order: the entries of a segment carry increasing keys, and the
+// segments' key ranges follow one another).  The stage kernel itself writes, for every bitmap word, the STAGE ROW of the word's first
+// key (DevStage::wrow), so the stage row of a key is   wrow[word] + set bits below it in the word   and no rank pass, no owner array
+// and no insert pass exist (k_rank_words + k_insert_direct: 16 us of Q3's 235, two launches).  The one complication: the keys of a word can
+// belong to TWO consecutive segments (the end of one, the start of the next — never three: a segment's rows span at least 127 key
+// values), whose stage rows do not follow one another.  For such a word wrow holds ROW_INDEX_EXC | s (s = the later segment) and
+// wexc[s] says where each half lives; a lookup into it costs one more load (k_wrow_fixup finds these words after the build).
+constexpr uint32_t ROW_INDEX_EXC = 0x80000000u;
+struct WordExc { int64_t key0; uint32_t pos0, pos_prev, n0, _pad; };   // keys below key0: pos_prev + bits below; from key0 on: pos0 + (bits below - n0)
+struct SegFirst { int64_t key; uint32_t pos, _pad; };                   // a segment's first entry (whether it opens its word is only known once the bitmap is complete)
+
 struct DevTable {
     int64_t* keys;
     uint32_t* rowref;
@@ -129,6 +140,7 @@ struct DevTable {
                               //    linearised offset (a - bm_lo) * lin_rb + (b - lin_b0) (direct layout, bm_shift == 0)
     const uint32_t* alias;    // sdqh_table_share_groups: stage row -> the stage row whose accumulators it uses, or null
     int32_t acc_stride, _pad3; // doubles per entry in sacc: 4, or the tuple's value count when it is known at build time (sdqh_groupby_key)
+    const struct WordExc* wexc; // direct layout whose wprefix[] holds STAGE ROWS (see DevStage::wrow), not ranks: the words that straddle two segments
     int64_t* slots;           // hash layout, packed form (tables with payload): slot h = { key, payload 0, payload 1, stage row } in 32
                               //    bytes, so a probe that hits finds the key, the owner and the first two payload fields in ONE
                               //    cache line instead of four (keys[], rowref[], pay[0][], pay[1][]); keys / rowref are null then
@@ -577,7 +589,14 @@ __device__ __forceinline__ int64_t table_find(const DevTable& t, int64_t key, ui
         if (hashed) { h = hash_key(key) & cap_mask; k_first = slot_key(t, h); }
         if (!((word >> (off & 31)) & 1u)) return -1;
         if (t.bitmap_only) return 0;
-        if (t.bm_shift == 0) return (int64_t)pre + __popc(word & ((1u << (off & 31)) - 1u));
+        if (t.bm_shift == 0) {
+            const uint32_t below = __popc(word & ((1u << (off & 31)) - 1u));
+            if (t.wexc && (pre & ROW_INDEX_EXC)) {                           // row index, a word shared by two segments
+                const WordExc e = t.wexc[pre & ~ROW_INDEX_EXC];
+                return key < e.key0 ? (int64_t)e.pos_prev + below : (int64_t)e.pos0 + (below - e.n0);
+            }
+            return (int64_t)pre + below;
+        }
     } else {
         h = hash_key(key) & cap_mask; k_first = slot_key(t, h);
     }
@@ -1120,7 +1139,31 @@ struct DevStage {
     TableHeader* hdr;
     int32_t bm_shift, _pad2;              // 32: the bitmap covers the high part of a composite key
     int64_t lin_rb, lin_b0;               // linearised composite key (see DevTable)
+    uint32_t* wrow;                       // ROW INDEX (see DevTable): per bitmap word the stage row of its first key, written while staging; or null
+    SegFirst* seg_first;                  // [nseg] ... and every segment's first entry, for k_wrow_fixup
 };
+
+// Row index, the writer's side: the entries a wave is about to store (one per lane, `active` lanes, increasing keys, consecutive stage
+// rows) — an entry whose key opens a bitmap word records its stage row there; the segment's very first entry goes to seg_first instead.
+// `carry` = the word of the wave's previous entry (ROW_INDEX_NONE at the start of a segment); wave-converged.
+constexpr uint32_t ROW_INDEX_NONE = 0xFFFFFFFFu;
+__device__ __forceinline__ void row_index_note(const DevStage& st, int seg, bool active, int64_t key, int64_t pos, uint64_t active_mask, uint32_t& carry) {
+    if (!st.wrow) return;
+    active = active && key >= st.bm_lo && key <= st.bm_hi;                  // (a key outside the bounds fails the call: it is in no word)
+    active_mask = __ballot(active);
+    if (!active_mask) return;
+    const int lane = (int)(threadIdx.x & (WAVE - 1));
+    const uint32_t word = active ? (uint32_t)((uint64_t)(key - st.bm_lo) >> 5) : ROW_INDEX_NONE;
+    const uint64_t lower = active_mask & ((1ull << lane) - 1ull);
+    const int prev_lane = lower ? 63 - __builtin_clzll(lower) : lane;
+    const uint32_t prev_word_lane = (uint32_t)__shfl((int)word, prev_lane, WAVE);
+    const uint32_t prev = lower ? prev_word_lane : carry;
+    if (active && word != prev) {
+        if (prev == ROW_INDEX_NONE) { SegFirst f; f.key = key; f.pos = (uint32_t)pos; f._pad = 0; st.seg_first[seg] = f; }
+        else st.wrow[word] = (uint32_t)pos;
+    }
+    carry = (uint32_t)__shfl((int)word, 63 - __builtin_clzll(active_mask), WAVE);
+}
 
 __device__ __forceinline__ void zero_acc(const DevStage& st, int64_t pos) {
     if (st.acc_stride == 4) { double4 z = {0, 0, 0, 0}; *reinterpret_cast<double4*>(st.sacc + pos * 4) = z; }
@@ -1501,6 +1544,34 @@ __device__ __forceinline__ void rank_words_body(const uint32_t* __restrict__ bm,
 SDQH_KERNEL __launch_bounds__(TPB) void k_rank_words(const uint32_t* __restrict__ bm, uint64_t nwords, uint32_t* __restrict__ wprefix,
                                                     const uint32_t* __restrict__ seg_count, int nseg, TableHeader* __restrict__ hdr) {
     rank_words_body(bm, nwords, wprefix, seg_count, nseg, hdr);
+}
+// Row index, after the build (one thread per segment): does the segment's first entry open its bitmap word, or does the word already
+// hold keys of the segment before (then it is an exception word, see DevTable)?  The bitmap is complete by now.
+SDQH_KERNEL __launch_bounds__(TPB) void k_wrow_fixup(DevStage st, WordExc* __restrict__ exc, TableHeader* __restrict__ hdr) {
+    const int s = (int)(blockIdx.x * TPB + threadIdx.x);
+    if (s == 0) hdr->has_dups = 0;
+    if (s >= st.nseg) return;
+    const uint32_t cnt = st.seg_count[s];
+    if (!cnt) return;
+    const SegFirst f = st.seg_first[s];
+    const uint64_t off0 = (uint64_t)(f.key - st.bm_lo);
+    const uint32_t w0 = (uint32_t)(off0 >> 5), word = st.bm[w0];
+    const uint32_t n_below = __popc(word & ((1u << (off0 & 31)) - 1u));
+    if (n_below == 0) {
+        // the word's first key is mine.  If a LATER segment has keys in this word too it will mark the word as an exception: then
+        // (and only then) the word holds more keys than my leading run of it, and I leave it alone
+        uint32_t mine = 1;
+        while (mine < cnt && mine < 32 && (uint32_t)((uint64_t)(st.key[(int64_t)f.pos + mine] - st.bm_lo) >> 5) == w0) ++mine;
+        if ((uint32_t)__popc(word) == mine) st.wrow[w0] = f.pos;
+        return;
+    }
+    int t = s - 1;
+    while (t > 0 && st.seg_count[t] == 0) --t;                               // the segment before me that has entries: the n_below keys are its last ones
+    WordExc e;
+    e.key0 = f.key; e.pos0 = f.pos; e.n0 = n_below; e._pad = 0;
+    e.pos_prev = (uint32_t)((int64_t)t * st.seg_rows + (int64_t)st.seg_count[t] - (int64_t)n_below);
+    exc[s] = e;
+    st.wrow[w0] = ROW_INDEX_EXC | (uint32_t)s;
 }
 // direct layout, after k_rank_words: duplicate build keys <=> fewer set bits than staged rows
 __device__ __forceinline__ bool direct_has_dups(const TableHeader* hdr) { return hdr->staged != hdr->distinct; }

@@ -89,6 +89,7 @@ struct XInfo {
     bool fake = false;
     bool vstage = false; int nlk = 0; int lk_op[2] = {-1, -1};      // a build that x_vstage8 can run: every gate on registers, lookups answered by exact 32-bit-range bitmaps
     bool pref32 = false;                     // the prefilter's key and its table's bitmap range fit 32 bits: the streamed test is 32-bit arithmetic
+    int ival = -1;                           // the per-lane group sink: summed value that is a small integer on every row (byte-coded column, consecutive integral dictionary), or -1
     bool pnear = false;                      // ... and a lane's 8 consecutive rows carry near-by keys (column_span8): a row that fails an earlier condition still asks for ITS key's word
     bool pwin = false;                       // ... tested against one 128-bit window of the bitmap: one 16-byte request per lane and 8 rows (option "window", off: measured slower)
     uint32_t gather32 = 0;                   // queue programs: numeric columns read BY ROW (the drain's gathers) through their 4-byte twins: half the bytes of every touched line
@@ -655,11 +656,17 @@ std::string generate_tight(const XInfo& x, Sink sink) {
     if (p->key >= 0) { g.emit(p->key); g.os << "        o.key = v" << p->key << "; o.bad = " << g.bad(p->key) << ";\n"; }
     else g.os << "        o.key = 0; o.bad = false;\n";
     for (int v = 0; v < p->nvals; ++v) {
+        if (sink == SINK_GROUP_LANE && v == x.ival) {                     // the value AS AN INTEGER: code + the dictionary's first value (XGroupLane adds it beside the row count)
+            const int c = x.col_of[p->vals[v]];
+            g.os << "        o.val[" << v << "] = (int64_t)xt_u8(s.c" << g.slot_of[(size_t)c] << ", i) + a.dlo[" << c << "];\n";
+            continue;
+        }
         g.emit(p->vals[v]);
         g.os << "        o.val[" << v << "] = " << (p->ops[p->vals[v]].type == SDQH_T_F64 ? "x_bits(v" + std::to_string(p->vals[v]) + ")" : "v" + std::to_string(p->vals[v])) << ";\n";
     }
     g.os << "        o.ent = NO_ROW;\n        return pass;\n";
     const std::string row_fn = g.os.str();
+    if (sink == SINK_GROUP_LANE && x.ival >= 0) out.str("#define XGL_IVAL " + std::to_string(x.ival) + "\n" + out.str()), out.seekp(0, std::ios::end);
     const std::vector<std::pair<int, int>> tabs = g.tabs;
     out << "struct P {\n    static constexpr int NV = " << p->nvals << ", ND = " << tabs.size() << ";\n    struct Regs {";
     for (size_t i = 0; i < scols.size(); ++i) out << " uint32_t c" << i << "[" << bpr(scols[i]) * 2 << "];";
@@ -1036,7 +1043,7 @@ uint64_t structure_hash(const XInfo& x, Sink sink, bool direct) {
     auto mix = [&](uint64_t v) { h ^= v; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29; };      // (a word at a time: this runs on every call)
     mix((uint64_t)sink * 2 + (direct ? 1 : 0)); mix((uint64_t)x.narrow_mask);
     if (x.tight) {
-        mix(0x7167ull); mix((uint64_t)x.gather32); mix((x.pref32 ? 1ull : 0ull) | (x.vstage ? 2ull : 0ull) | (x.pwin ? 4ull : 0ull) | (x.pnear ? 8ull : 0ull));
+        mix(0x7167ull); mix((uint64_t)x.gather32); mix((x.pref32 ? 1ull : 0ull) | (x.vstage ? 2ull : 0ull) | (x.pwin ? 4ull : 0ull) | (x.pnear ? 8ull : 0ull) | ((uint64_t)(x.ival + 1) << 8));
         for (int c = 0; c < x.ncols; ++c) mix(((uint64_t)(uint32_t)x.enc[c] << 32) | ((uint32_t)(x.affine[c] ? 1 : 0) << 16) | (uint32_t)(x.dict_slot[c] & 0xFFFF));
         for (int k = 0; k < x.p->nops; ++k) mix((uint64_t)(uint8_t)x.irange[k]);
         for (int k = 0; k < x.p->nops; ++k) mix(((uint64_t)(uint32_t)x.cmp_cc[k] << 32) | ((uint32_t)x.cmp_kind[k] << 8) | (uint32_t)(x.cmp_col[k] & 0xFF));
@@ -1274,6 +1281,30 @@ static int xgroupby_launch(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* pro
         if (ctx->compile_only) { sink = SINK_GROUP_LANE; nslots = 1; klo = khi = 0; }          // (build check: compile the lane sink)
         else if (op_interval(ctx, x, prog->key, &lo, &hi) && lo >= 0 && hi >= lo && hi - lo < 32 && (hi - lo + 1) * na <= 32) { sink = SINK_GROUP_LANE; nslots = (int)(hi - lo + 1); klo = lo; khi = hi; }
     }
+    // (the per-lane sink's grid is the same with and without the encodings: partial sums are folded in workgroup order, and switching
+    //  the twins off must not change a bit of a sum — tests/test_hip_parity.py)
+    const Geometry g = (x.tight && x.direct) ? geometry_tight(ctx, nrows, sink == SINK_GROUP_LANE ? ctx->opt_lane_resident : 2, sink == SINK_GROUP_LANE) : geometry(ctx, nrows, x.direct, 16, x.tight);
+    if (sink == SINK_GROUP_LANE && !ctx->compile_only && ctx->opt_lane_int) {
+        // a summed value that is a small integer on every row — the value of a byte-coded column whose dictionary is consecutive
+        // non-negative integers (l_quantity: 1.0 ... 50.0) — is summed as an integer beside the row count (XGroupLane); its lane sums
+        // must stay below 2^31: largest value x the rows a lane can meet
+        const int64_t lane_rows = ((nrows / XT_ROWS + g.grid) / std::max(1u, g.grid) + 2) * XT_R;
+        for (int v = 0; v < prog->nvals && x.ival < 0; ++v) {
+            const sdqh_xop& o = prog->ops[prog->vals[v]];
+            if (o.code != SDQH_X_COL || o.type != SDQH_T_F64) continue;
+            const int c = x.col_of[prog->vals[v]];
+            const sdqh_column* col = x.cols[c];
+            if (x.enc[c] != ENC_C8 || col->dtype != SDQH_F64 || col->dict_host.empty()) continue;
+            bool ok = true; int64_t base = 0;
+            for (size_t i = 0; i < col->dict_host.size() && ok; ++i) {
+                double d; std::memcpy(&d, &col->dict_host[i], 8);
+                const int64_t iv = (int64_t)d;
+                ok = (double)iv == d && iv >= 0 && iv <= (1 << 20) && !(iv == 0 && std::signbit(d));
+                if (i == 0) base = iv; else ok = ok && iv == base + (int64_t)i;
+            }
+            if (ok && (base + (int64_t)col->dict_host.size()) * lane_rows < ((int64_t)1 << 31)) { x.ival = v; x.dlo[c] = base; }
+        }
+    }
     hipFunction_t fn;
     if (int rc = kernel_for(ctx, x, sink, x.direct, &fn)) return rc;
     call_begin(ctx);
@@ -1284,7 +1315,6 @@ static int xgroupby_launch(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* pro
     static_assert(LG_SLOTS * 48 + 8 <= RESULT_BYTES, "result block too small");
     XArgs a;
     if (int rc = fill_xargs(ctx, x, &a, r_flags, klo, khi)) return rc;
-    const Geometry g = (x.tight && x.direct) ? geometry_tight(ctx, nrows, 2, sink == SINK_GROUP_LANE) : geometry(ctx, nrows, x.direct, 16, x.tight);
     const size_t npart = (size_t)g.grid * LG_SLOTS;
     char* blob = static_cast<char*>(pool_alloc(ctx, npart * 40 + 256));
     if (!blob) return fail(ctx, SDQH_ERR_NOMEM, "xgroupby: out of device memory");
@@ -1295,7 +1325,7 @@ static int xgroupby_launch(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* pro
     if (sink == SINK_GROUP_LANE) {
         XGroupLane<1>::Args sa{r_keys, pacc, pcnt, r_flags, nslots, 0};
         ctx->next_model_bytes = model_stream_bytes(x, nrows, true) + (int64_t)nslots * g.grid * 40;
-        rc = launch(ctx, fn, launch_label(SINK_GROUP_LANE, true, true), a, sa, nrows, g, (unsigned)((size_t)nslots * (size_t)(prog->nvals + 1) * TPB * 8));
+        rc = launch(ctx, fn, launch_label(SINK_GROUP_LANE, true, true), a, sa, nrows, g, (unsigned)((size_t)nslots * (size_t)(prog->nvals + 1 - (x.ival >= 0 ? 1 : 0)) * TPB * 8));
     } else {
         XGroup<1>::Args sa{r_keys, pacc, pcnt, r_flags};
         ctx->next_model_bytes = model_stream_bytes(x, nrows, x.direct) + (int64_t)npart * 40;
@@ -1436,7 +1466,16 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
         ptr[n] = tb->hdr; bytes[n] = sizeof(TableHeader); byte[n++] = 0;
         ptr[n] = flags; bytes[n] = 8; byte[n++] = 0;
         if (tb->bm) { ptr[n] = tb->bm; bytes[n] = tb->nwords * 4; byte[n++] = 0; }
-        { void* rp[2]; size_t rb[2]; const int nr = prefill_direct_refs(ctx, tb, rp, rb); for (int i = 0; i < nr; ++i) { ptr[n] = rp[i]; bytes[n] = rb[i]; byte[n++] = 0xFF; } }
+        // ROW INDEX: keys strictly increasing with the rows, an exact bitmap over the key -> the stage kernel writes, per bitmap word, the
+        // stage row of the word's first key; nothing is ranked or inserted afterwards (sdqh_kernels.hpp: DevTable)
+        const bool row_index = ctx->opt_row_index && tb->bm && tb->keys_unique && nrows < ((int64_t)1 << 31) && tb->stage.nseg < (1 << 30);
+        if (row_index) {
+            tb->stage.wrow = static_cast<uint32_t*>(tb_alloc(ctx, tb, tb->nwords * 4 + 64));
+            tb->stage.seg_first = static_cast<SegFirst*>(tb_alloc(ctx, tb, (size_t)tb->stage.nseg * sizeof(SegFirst) + 64));
+            tb->wexc = static_cast<WordExc*>(tb_alloc(ctx, tb, (size_t)tb->stage.nseg * sizeof(WordExc) + 64));
+            if (!tb->stage.wrow || !tb->stage.seg_first || !tb->wexc) { tb->stage.wrow = nullptr; tb->stage.seg_first = nullptr; tb->wexc = nullptr; }
+        }
+        if (!tb->stage.wrow) { void* rp[2]; size_t rb[2]; const int nr = prefill_direct_refs(ctx, tb, rp, rb); for (int i = 0; i < nr; ++i) { ptr[n] = rp[i]; bytes[n] = rb[i]; byte[n++] = 0xFF; } }
         fill_regions(ctx, ptr, bytes, byte, n);
         XArgs a;
         rc = fill_xargs(ctx, x, &a, flags, bounded ? key_lo : 1, bounded ? key_hi : 0);

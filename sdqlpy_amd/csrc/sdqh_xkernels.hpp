@@ -17,6 +17,9 @@
 #include "sdqh_kernels.hpp"
 
 // A/B switches of the skeletons (SDQLPY_AMD_X_DEFINES puts macros in front of a specialised source; defaults here)
+#ifndef XGL_IVAL
+#define XGL_IVAL -1                                                   // the per-lane group sink: index of the summed value that arrives as a small integer (see XGroupLane), or -1
+#endif
 #ifndef XE_EXP
 #define XE_EXP 0                                                      // timing experiments of the entry sink (wrong results): 1 no atomics, 2 no count atomic
 #endif
@@ -236,19 +239,22 @@ template <int NV> struct XGroup {
 // ---- K-B: survivors compacted in row order into the wave segment's slice of the stage ----
 template <int NV> struct XStage {
     struct Args { DevStage st; };
-    int64_t out;
-    __device__ __forceinline__ void init(const Args&) { out = 0; }
-    __device__ __forceinline__ void begin_segment(int64_t begin) { out = begin; }
+    int64_t out, seg_begin;
+    uint32_t carry;                                                       // row index: the bitmap word of the wave's previous entry
+    __device__ __forceinline__ void init(const Args&) { out = 0; seg_begin = 0; carry = ROW_INDEX_NONE; }
+    __device__ __forceinline__ void begin_segment(int64_t begin) { out = seg_begin = begin; carry = ROW_INDEX_NONE; }
     __device__ __forceinline__ void consume(const XArgs& a, const Args& s, bool pass, int64_t, const XOut<NV>& o) {
         bool keep = pass;
         if (pass && (o.bad || (a.key_lo <= a.key_hi && (o.key < a.key_lo || o.key > a.key_hi)))) { atomicOr(a.flags, 2); keep = false; }
         const uint64_t b = __ballot(keep);
+        const int64_t pos = out + __popcll(b & lanemask_lt());
         if (keep) {
             int64_t pay[MAX_STAGE_COLS] = {0, 0, 0, 0, 0};
 #pragma unroll
             for (int k = 0; k < NV; ++k) pay[k] = o.val[k];
-            stage_store<-1>(s.st, out + __popcll(b & lanemask_lt()), o.key, pay);
+            stage_store<-1>(s.st, pos, o.key, pay);
         }
+        row_index_note(s.st, (int)(seg_begin / s.st.seg_rows), keep, o.key, pos, b, carry);
         out += __popcll(b);
     }
     __device__ __forceinline__ void end_segment(const Args& s, int seg, int64_t begin) { if (lane_id() == 0) s.st.seg_count[seg] = (uint32_t)(out - begin); }
@@ -595,9 +601,17 @@ __device__ __forceinline__ int64_t xt_i64(const uint32_t (&w)[16], int i) { retu
 // Deterministic: a lane adds its rows in row order, lanes are folded in a fixed order, workgroups by
 // k_groupby_merge in workgroup order.  The slots are the key's offsets, so no key table and no claiming.
 template <int NV> struct XGroupLane {
-    static constexpr bool PIPELINED = true;                           // x_tight: its LDS cells leave two waves per SIMD: a wave hides its own latency
+    static constexpr bool PIPELINED = true;                           // x_tight: its LDS cells leave two or three waves per SIMD: a wave hides its own latency
     struct Args { unsigned long long* gkeys; double* pacc; int64_t* pcnt; int* flags; int32_t nslots, _pad; };
-    static constexpr int NA = (NV > 0 ? NV : 0) + 1;
+    // XGL_IVAL = v: summed value v is a small non-negative INTEGER on every row (a byte-coded column whose dictionary is consecutive
+    // integers: l_quantity) and arrives as that integer.  It shares the row counter's 8-byte cell — rows in the low half, the value's
+    // sum in the high half, ONE 64-bit integer add for both — instead of a cell and a double-precision add of its own: a cell less
+    // per slot (Q1: 49 KiB of cells per workgroup instead of 61: three workgroups per CU instead of two), an LDS instruction less per
+    // row, no dictionary read for it; and exact — a sum of integers below 2^53 is the same number in any order and either type (the
+    // launcher checks that a lane's share of the rows cannot carry the high half past 2^31).
+    static constexpr int IV = XGL_IVAL;
+    static constexpr int NF = (NV > 0 ? NV : 0) - (IV >= 0 ? 1 : 0);  // double-precision cells per slot
+    static constexpr int NA = NF + 1;                                 // + the counter cell
     int nslots; bool bad;
     // (cells are addressed as 32-bit indices into the dynamic LDS array: through a generic pointer kept in the object the compiler
     //  did the address arithmetic in 64 bits, a multiply included, per value and row)
@@ -614,13 +628,20 @@ template <int NV> struct XGroupLane {
         if (pass && ok) {
             const uint32_t cell = (uint32_t)d * (uint32_t)(NA * TPB) + threadIdx.x;
 #pragma unroll
-            for (int k = 0; k < NV; ++k) __hip_atomic_fetch_add(&x_dyn[cell + (uint32_t)(k * TPB)], x_f(o.val[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            // (a lane's own row count: 32 bits are plenty, and a 4-byte LDS add costs the LDS half of an 8-byte one)
-            __hip_atomic_fetch_add(reinterpret_cast<unsigned int*>(&x_dyn[cell + (uint32_t)((NA - 1) * TPB)]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int k = 0; k < NV; ++k) {
+                if (k == IV) continue;
+                const int f = (IV >= 0 && k > IV) ? k - 1 : k;
+                __hip_atomic_fetch_add(&x_dyn[cell + (uint32_t)(f * TPB)], x_f(o.val[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if constexpr (IV >= 0)
+                __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(&x_dyn[cell + (uint32_t)(NF * TPB)]), ((unsigned long long)(uint32_t)o.val[IV >= 0 ? IV : 0] << 32) | 1ull,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else    // (a lane's own row count: 32 bits are plenty, and a 4-byte LDS add costs the LDS half of an 8-byte one)
+                __hip_atomic_fetch_add(reinterpret_cast<unsigned int*>(&x_dyn[cell + (uint32_t)(NF * TPB)]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     __device__ __forceinline__ void finish(const XArgs& a, const Args& s) {
-        __shared__ double s_red[TPB / WAVE][NA];
+        __shared__ double s_red[TPB / WAVE][NA + 1];
         const int w = threadIdx.x / WAVE, lane = lane_id();
         if (__ballot(bad) && lane == 0) atomicOr(s.flags, 2);
         __syncthreads();
@@ -629,17 +650,28 @@ template <int NV> struct XGroupLane {
             for (int k = 0; k < NA; ++k) {
                 extern __shared__ double x_dyn[];
                 double v = x_dyn[(uint32_t)((g * NA + k) * TPB) + threadIdx.x];
-                if (k == NA - 1) { const int64_t c = wave_sum_i64((int64_t)(uint32_t)__double_as_longlong(v)); if (lane == 0) reinterpret_cast<int64_t*>(s_red[w])[k] = c; }
-                else { v = wave_sum(v); if (lane == 0) s_red[w][k] = v; }
+                if (k == NA - 1) {
+                    const uint64_t bits = (uint64_t)__double_as_longlong(v);
+                    const int64_t c = wave_sum_i64((int64_t)(uint32_t)bits);
+                    if (lane == 0) reinterpret_cast<int64_t*>(s_red[w])[k] = c;
+                    if constexpr (IV >= 0) { const int64_t iv = wave_sum_i64((int64_t)(bits >> 32)); if (lane == 0) reinterpret_cast<int64_t*>(s_red[w])[NA] = iv; }
+                } else { v = wave_sum(v); if (lane == 0) s_red[w][k] = v; }
             }
             __syncthreads();
             if (threadIdx.x == 0) {
                 const size_t e = (size_t)g * gridDim.x + blockIdx.x;
-                int64_t c = 0;
-                for (int i = 0; i < TPB / WAVE; ++i) c += reinterpret_cast<const int64_t*>(s_red[i])[NA - 1];
+                int64_t c = 0, iv = 0;
+                for (int i = 0; i < TPB / WAVE; ++i) { c += reinterpret_cast<const int64_t*>(s_red[i])[NA - 1]; if (IV >= 0) iv += reinterpret_cast<const int64_t*>(s_red[i])[NA]; }
                 s.pcnt[e] = c;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { double v = 0.0; if (k < NV) for (int i = 0; i < TPB / WAVE; ++i) v += s_red[i][k < NA ? k : 0]; s.pacc[e * 4 + k] = v; }
+                for (int k = 0; k < 4; ++k) {
+                    double v = 0.0;
+                    if (k < NV) {
+                        if (k == IV) v = (double)iv;
+                        else { const int f = (IV >= 0 && k > IV) ? k - 1 : k; for (int i = 0; i < TPB / WAVE; ++i) v += s_red[i][f < NA ? f : 0]; }
+                    }
+                    s.pacc[e * 4 + k] = v;
+                }
                 if (blockIdx.x == 0) s.gkeys[g] = (unsigned long long)(a.key_lo + g);
             }
             __syncthreads();
@@ -1006,7 +1038,9 @@ __device__ __forceinline__ void x_vstage8(const XArgs& a, const typename XStage<
     const uint32_t* bm[NL];
 #pragma unroll
     for (int l = 0; l < NL; ++l) bm[l] = P::NL > l ? P::lkbm(a, l) : nullptr;
+    uint32_t carry = ROW_INDEX_NONE;                                          // row index: the bitmap word of the wave's previous entry
     auto flush = [&](int first, int count) {                                 // queued entries [first, first + count), count <= 64, one per lane
+        if (st.wrow) row_index_note(st, seg, lane < count, lane < count ? (int64_t)q[0][first + lane] : 0, out + lane, count >= 64 ? ~0ull : ((1ull << count) - 1ull), carry);
         if (lane < count) {
             const int64_t key = (int64_t)q[0][first + lane];
             int64_t pay[MAX_STAGE_COLS] = {0, 0, 0, 0, 0};

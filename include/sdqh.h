@@ -524,6 +524,10 @@ int sdqh_table_columns(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits,
 /* HIP build: number of kernels specialised so far in this process / how many of them came from the on-disk
  * cache; CPU build: zeros.  Diagnostics for tests and the bench. */
 int sdqh_jit_stats(sdqh_ctx* ctx, int64_t* compiled, int64_t* from_cache);
+/* HIP build: compile the source of a specialised kernel (as the library generated it on an earlier run: SDQLPY_AMD_JIT_RECIPES keeps them)
+ * into the on-disk cache, loading nothing — works on a compile-only context, i.e. on a host without a GPU.  The reference's
+ * counterpart is its compiled mode's module cache (src/sdqlpy/sdql_lib.py:372-387).  CPU build: accepted, nothing to do. */
+int sdqh_jit_compile(sdqh_ctx* ctx, const char* source);
 
 /* ---- multi-GPU redistribution helpers (no reference counterpart) -------------- */
 /* Filter + semi-join probes, then gather `ncols` columns of the surviving rows into freshly

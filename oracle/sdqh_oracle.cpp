@@ -1380,6 +1380,7 @@ int sdqh_jit_stats(sdqh_ctx* ctx, int64_t* compiled, int64_t* from_cache) {
     if (from_cache) *from_cache = 0;
     return SDQH_OK;
 }
+int sdqh_jit_compile(sdqh_ctx* ctx, const char* source) { return (ctx && source) ? SDQH_OK : SDQH_ERR_INVALID; }
 
 // ---- multi-GPU helpers -------------------------------------------------------------------------
 int sdqh_scan_compact(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nprobes, const sdqh_probe* probes,

@@ -218,7 +218,7 @@ EXPORTS = [
     "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_table_compact_async", "sdqh_table_compact_deferred", "sdqh_host_wait_word", "sdqh_result_wait", "sdqh_scan_compact", "sdqh_partition_by_key",
     "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in", "sdqh_column_unpack2", "sdqh_partition_pack", "sdqh_unpack_parts",
     "sdqh_build", "sdqh_lookup_aggregate", "sdqh_table_entries", "sdqh_host_alloc", "sdqh_host_free", "sdqh_table_topk",
-    "sdqh_xscan_sum", "sdqh_xgroupby", "sdqh_xgroupby_block_bytes", "sdqh_xgroupby_async", "sdqh_xgroupby_collect", "sdqh_xbuild", "sdqh_xkey_set", "sdqh_xprobe_aggregate", "sdqh_table_columns", "sdqh_jit_stats",
+    "sdqh_xscan_sum", "sdqh_xgroupby", "sdqh_xgroupby_block_bytes", "sdqh_xgroupby_async", "sdqh_xgroupby_collect", "sdqh_xbuild", "sdqh_xkey_set", "sdqh_xprobe_aggregate", "sdqh_table_columns", "sdqh_jit_stats", "sdqh_jit_compile",
 ]
 
 
@@ -694,6 +694,10 @@ class Context:
         self._after_call("table_columns")
         return cols[0], cols[1:1 + table.npayload], cols[1 + table.npayload:k - 1], cols[k - 1], n.value
 
+    def jit_compile(self, source):
+        """Compile a kept kernel source (sdqlpy_amd/jit_recipes/) into the on-disk cache; nothing is loaded or run."""
+        self._check(self.lib.sdqh_jit_compile(self.handle, source.encode()))
+
     def jit_stats(self):
         a, b = C.c_int64(), C.c_int64()
         self._check(self.lib.sdqh_jit_stats(self.handle, C.byref(a), C.byref(b)))
@@ -961,6 +965,7 @@ class Library:
         L.sdqh_column_copy_out.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.sdqh_column_copy_in.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.sdqh_table_export_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.sdqh_jit_compile.argtypes = [C.c_void_p, C.c_char_p]
         L.sdqh_column_unpack2.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.sdqh_partition_pack.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sdqh_unpack_parts.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]

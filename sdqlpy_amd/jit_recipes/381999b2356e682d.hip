@@ -1,0 +1,42 @@
+#include "sdqh_xkernels.hpp"
+using namespace sdqh;
+struct P {
+    static constexpr int NS = 0, NV = 0, NSC = 0, NSOP = 0, ND = 0;
+    template <bool TAIL> __device__ __forceinline__ static void sload(const XArgs& a, int64_t r, int64_t nrows, Pair<int64_t> (&s)[1]) {
+    }
+    __device__ __forceinline__ static void stest(const XArgs& a, const Pair<int64_t> (&s)[1], bool& p0, bool& p1) {
+      {
+      }
+      {
+      }
+    }
+    template <int H> __device__ __forceinline__ static bool eval_regs(const XArgs& a, const Pair<int64_t> (&s)[1], int64_t r, XOut<NV>& o) {
+        return false;
+    }
+    __device__ __forceinline__ static bool eval_row(const XArgs& a, int64_t r, const int64_t (&sres)[1], XOut<NV>& o) {
+        const int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
+        const int64_t v1 = (v0 / (int64_t)750000ll);
+        const int64_t v11 = a.ci[1];
+        const int64_t v12 = (v1 * v11);
+        const int64_t v2 = (v0 / (int64_t)5000ll);
+        const int64_t v3 = (v2 % (int64_t)150ll);
+        const int64_t v13 = (v12 + v3);
+        const int64_t v15 = a.ci[2];
+        const int64_t v16 = (v13 * v15);
+        const int64_t v4 = (v0 / (int64_t)100ll);
+        const int64_t v5 = (v4 % (int64_t)50ll);
+        const int64_t v6 = a.ci[0];
+        const int64_t v7 = (v5 + v6);
+        const int64_t v14 = (v7 - v6);
+        const int64_t v17 = (v16 + v14);
+        const uint32_t e18 = x_lookup(a.tab[0], v17, false);
+        const bool v18 = (e18 != NO_ROW);
+        if (!v18) return false;
+        o.key = 0; o.bad = false;
+        o.ent = e18;
+        return true;
+    }
+};
+extern "C" __global__ __launch_bounds__(256) void xk_probe_agg_queue(XArgs a, XEntry<P::NV>::Args s, int64_t nrows, int64_t seg_rows, int nseg) {
+    x_queue<P, XEntry, false>(a, s, nrows, seg_rows, nseg);
+}

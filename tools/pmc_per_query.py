@@ -54,7 +54,9 @@ def main(root, iters, rows_json, out):
     iters = int(iters)
     rec = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes per query over `python3 tools/run_queries.py --sf 10 --queries <q> --iters %d`" % iters,
            "correction": "hbm = 2*FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts half of a wide coalesced read); KiB -> bytes",
-           "rows": json.loads(rows_json), "queries": {}}
+           "rows": json.loads(rows_json), "queries": {},
+           # which build the counters were collected on (the box has no .git: the caller passes the commit in the environment)
+           "commit": os.environ.get("SDQLPY_COMMIT", "")}
     for q in sorted(TABLES):
         fd, wd = os.path.join(root, q + "_FETCH_SIZE"), os.path.join(root, q + "_WRITE_SIZE")
         if not (os.path.isdir(fd) and os.path.isdir(wd)):

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -93,10 +94,13 @@ int sync_stream(sdqh_ctx* ctx) {
         if (ctx->sync_flag) {
             const uint32_t seq = ++ctx->sync_seq;
             if (hipStreamWriteValue32(ctx->stream, const_cast<uint32_t*>(ctx->sync_flag), seq, 0) == hipSuccess) {
-                // poll; after ~2 s of nothing fall back to the runtime's wait (it also reports a faulted kernel)
-                for (uint64_t spins = 0; spins < (1ull << 31); ++spins) {
+                // poll; after 2 s of nothing (wall clock, read every 4096 spins: a spin COUNT is 40 - 100 s of a pegged core at 60 - 140 cycles
+                // per PAUSE) fall back to the runtime's wait, which also reports a faulted kernel
+                const auto t0 = std::chrono::steady_clock::now();
+                for (uint64_t spins = 1;; ++spins) {
                     if (*ctx->sync_flag == seq) { done = true; break; }
                     __builtin_ia32_pause();
+                    if ((spins & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
                 }
             } else { (void)hipGetLastError(); ctx->opt_spin_sync = 0; }
         }

@@ -18,6 +18,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1286,6 +1287,9 @@ int sdqh_xscan_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, doubl
     return SDQH_OK;
 }
 
+// The completion word of an xgroupby_async block: on a cache line the merge kernel never touches (it stores the two tail words right
+// behind the counts — flags and a second word that only happens to be zero today; a kernel store there must never read as completion)
+constexpr size_t XGROUPBY_DONE_OFFSET = (((size_t)LG_SLOTS * 48 + 8 + 63) & ~(size_t)63);
 // K-C small, launched: the group table of the whole call lands in `host_block` (device-visible host memory laid out like the device
 // result block: keys[LG_SLOTS] | acc[LG_SLOTS][4] | cnt[LG_SLOTS] | flags) when the stream gets there; nothing is waited for.
 static int xgroupby_launch(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, void* host_block) {
@@ -1352,15 +1356,13 @@ static int xgroupby_launch(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* pro
         rc = launch(ctx, fn, launch_label(SINK_GROUP, x.direct, x.tight), a, sa, nrows, g);
     }
     if (!rc) {
+        // the block's DONE word: written by the stream itself once the merge has finished — collect waits for its own result, not for
+        // whatever was queued behind it.  Cleared before the merge is launched.
+        uint32_t* done = host_block ? reinterpret_cast<uint32_t*>(static_cast<char*>(host_block) + XGROUPBY_DONE_OFFSET) : nullptr;
+        if (done) *done = 0;
         launch_groupby_merge_lg_host(ctx, r_keys, pacc, pcnt, (int)g.grid, r_flags, host_block);       // writes the pinned host block, leaves the device block clean
         call_end(ctx);
-        if (host_block) {
-            // the block's DONE word (after the flags): written by the stream itself once the merge has finished — collect waits for its own
-            // result, not for whatever was queued behind it
-            uint32_t* done = reinterpret_cast<uint32_t*>(static_cast<char*>(host_block) + LG_SLOTS * 48 + 4);
-            *done = 0;
-            if (hipStreamWriteValue32(ctx->stream, done, 1, 0) != hipSuccess) { (void)hipGetLastError(); *done = 2; }     // 2: no marker, collect synchronises
-        }
+        if (done && hipStreamWriteValue32(ctx->stream, done, 1, 0) != hipSuccess) { (void)hipGetLastError(); *done = 2; }     // 2: no marker, collect synchronises
     }
     pool_free(ctx, blob);                                   // stream order: whoever gets the block next runs after the merge
     return rc;
@@ -1368,11 +1370,17 @@ static int xgroupby_launch(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* pro
 
 // wait until a word of device-visible host memory that the stream writes (hipStreamWriteValue32) holds `value`
 static int wait_word(sdqh_ctx* ctx, const volatile uint32_t* word, uint32_t value) {
-    for (uint64_t spins = 0; spins < (1ull << 31); ++spins) {
+    // bounded by wall time (2 s), not by a spin count; then the runtime's own wait on the stream — it reports a faulted kernel at once,
+    // where re-entering the library's spinning synchronise would stall for its bound a second time
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 1;; ++spins) {
         if (*word == value) return SDQH_OK;
         __builtin_ia32_pause();
+        if ((spins & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
     }
-    if (int rc = sdqh_synchronize(ctx)) return rc;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, SDQH_ERR_DEVICE, "the device failed while a result was waited for"); }
+    if (*word == value) return SDQH_OK;
+    if (int rc = sdqh_synchronize(ctx)) return rc;                             // (K-F's word is written by the copy stream: wait for the copies too)
     return *word == value ? SDQH_OK : fail(ctx, SDQH_ERR_DEVICE, "a result's completion word was never written");
 }
 
@@ -1408,7 +1416,7 @@ int sdqh_xgroupby(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int ma
     return xgroupby_collect(ctx, ctx->result_host, prog->nvals, max_groups, out_keys, out_values, out_counts, out_ngroups);
 }
 
-size_t sdqh_xgroupby_block_bytes(void) { return ((size_t)LG_SLOTS * 48 + 8 + 63) & ~(size_t)63; }
+size_t sdqh_xgroupby_block_bytes(void) { return XGROUPBY_DONE_OFFSET + 64; }
 
 int sdqh_xgroupby_async(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, void* result_block) {
     if (!ctx || nrows < 0 || !prog || !result_block) return fail(ctx, SDQH_ERR_INVALID, "xgroupby_async: bad arguments");
@@ -1421,7 +1429,7 @@ int sdqh_xgroupby_async(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, 
 int sdqh_xgroupby_collect(sdqh_ctx* ctx, const void* result_block, int nvals, int max_groups,
                           int64_t* out_keys, double* out_values, int64_t* out_counts, int32_t* out_ngroups) {
     if (!ctx || !result_block || nvals < 0 || nvals > SDQH_TUPLE_MAX_VALUES || max_groups < 1 || max_groups > SDQH_MAX_LOOKUP_GROUPS || !out_ngroups) return fail(ctx, SDQH_ERR_INVALID, "xgroupby_collect: bad arguments");
-    const volatile uint32_t* done = reinterpret_cast<const volatile uint32_t*>(static_cast<const char*>(result_block) + LG_SLOTS * 48 + 4);
+    const volatile uint32_t* done = reinterpret_cast<const volatile uint32_t*>(static_cast<const char*>(result_block) + XGROUPBY_DONE_OFFSET);
     if (*done == 2) { if (int rc = sdqh_synchronize(ctx)) return rc; }
     else if (int rc = wait_word(ctx, done, 1)) return rc;
     return xgroupby_collect(ctx, result_block, nvals, max_groups, out_keys, out_values, out_counts, out_ngroups);

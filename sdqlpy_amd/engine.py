@@ -702,6 +702,10 @@ def _prepare_general(eng, op, htab, flt, contains_lookups, accumulate_into=()):
             if len(key_srcs) == 2:
                 bt.key_parts = key_names
                 bt.key_part_decoders = [k.decode_info(op, env, lookups)[0] for k in key_srcs]
+                # bounds of the packed key where both parts' ranges are known (xplan.DictTable unpacks by signed division: high part < 2^31)
+                r = [_plain_range(eng, k, env, lookups) for k in key_srcs]
+                if all(x is not None and x[0] >= 0 and x[0] + x[1] <= (1 << 31) for x in r):
+                    bt.key_bounds = ((r[0][0] << 32) | r[1][0], ((r[0][0] + r[0][1] - 1) << 32) | (r[1][0] + r[1][1] - 1))
             bt.key_decoder = key_srcs[0].decode_info(op, env, lookups)[0] if len(key_srcs) == 1 else None
             bt._marshalled = (look, keyspecs, uniq)
             return bt

@@ -706,6 +706,7 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False, sm
             if composite:
                 bt.key_parts = key_names
                 bt.key_part_decoders = key_dec
+                bt.key_bounds = bounds                      # of the PACKED key, from the parts' ranges (DictTable: a negative packed key cannot be unpacked by division)
             else:
                 bt.key_decoder = key_dec
             return bt
@@ -762,6 +763,10 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False, sm
                     bounds = r
             else:
                 kid = c.P.op(abi.X_PACK2, abi.T_I64, a=flat[0].id, b=flat[1].id)
+                # the packed key's bounds from its parts' ranges (a later loop over the entries unpacks the key by signed division: DictTable)
+                r0, r1 = c.resolve_rng(flat[0]), c.resolve_rng(flat[1])
+                if r0 is not None and r1 is not None and 0 <= r0[0] <= r0[1] < (1 << 31) and 0 <= r1[0] <= r1[1] < (1 << 32):
+                    bounds = ((r0[0] << 32) | r1[0], (r0[1] << 32) | r1[1])
             c.P.gates = gates
             vals, count_idx = summed_values(c, vexprs) if with_values else ([], None)
             return c, kid, vals, count_idx, bounds, flat
@@ -902,6 +907,7 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False, sm
         if composite:
             bt.key_parts = key_names
             bt.key_part_decoders = state.get("part_decs")
+            bt.key_bounds = bounds
         bt.key_decoder = key_dec
         bt.key_radix = state.get("radix")
         bt.agg = ([(key_names[0], "key")], vnames, count_idx, key_is_record, val_is_record, len(vals))
@@ -1019,6 +1025,11 @@ class DictTable:
                     vid = c.P.op(abi.X_ADD, abi.T_I64, a=vid, b=c.const(lo).id)
                 kf.append((pname, XV(vid, "i", dec=text_ok(kind[1]), rng=None if span is None else (lo, lo + span - 1))))
         elif bt.key_parts is not None and spec == [(bt.key_name, "key")]:
+            # (hi << 32) | lo is unpacked by SIGNED division / remainder (SDQH_X_DIVI / _MODI): exact only while the packed key is not
+            # negative, i.e. the high part is below 2^31 — known from the build's own bounds, else the host path (shifts and masks) runs
+            kb = getattr(bt, "key_bounds", None)
+            if kb is None or kb[0] > kb[1] or kb[0] < 0:
+                raise UnsupportedQuery("line %d: the parts of '%s's packed key are not known to stay below 2^31" % (op.lineno, op.source))
             decs = getattr(bt, "key_part_decoders", None) or [None, None]
             hi = c.P.op(abi.X_DIVI, abi.T_I64, a=keyv.id, imm_i=1 << 32)
             lo = c.P.op(abi.X_MODI, abi.T_I64, a=keyv.id, imm_i=1 << 32)

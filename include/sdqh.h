@@ -510,6 +510,12 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
 /* Membership-only K-B: the set of keys of the passing rows (exact bitmap over [key_lo, key_hi], which the
  * caller knows from the key's sources); SDQH_ERR_UNSUPPORTED if a key falls outside. */
 int sdqh_xkey_set(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t key_lo, int64_t key_hi, sdqh_table** out);
+/* Compaction by a row program (the probe side of a re-distributed join): EVERY passing row — duplicate keys
+ * included, nothing is indexed — as resident columns: the program's key, then its vals (<= SDQH_MAX_PAYLOAD), each an I64
+ * column holding the operation's 8 bytes (a double value keeps its bit pattern).  out_cols[1 + nvals]; the rows keep the
+ * scan's order within a segment of the scan, the segments follow one another.  Replaces the filter + materialise half of
+ * the reference's probe loop (...generator_par.py:378-447) when the rows have to change GPUs before they can probe. */
+int sdqh_xcompact(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, sdqh_column** out_cols, int64_t* out_rows);
 /* K-C large: for every passing row, the entry of `table` matched by LOOKUP operation `lookup_op` (which must
  * be among the gates) gets acc += vals, hits += 1 (the group is the matched entry, test/test_all.py:164-172). */
 int sdqh_xprobe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int lookup_op, sdqh_table* table);
@@ -545,6 +551,9 @@ int sdqh_scan_compact(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter,
 int sdqh_partition_by_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int nparts, const int64_t* range_upper,
                           int ncols, const sdqh_column* const* cols, sdqh_column** out_cols,
                           int64_t* counts);
+/* Say that a column lives for one run of a plan (rows that arrived through a collective): no twins, no dictionaries, no order facts are
+ * built for it — each would be a pass over the column, or a host round trip, paid on every run.  CPU build: accepted, nothing to do. */
+int sdqh_column_mark_transient(sdqh_ctx* ctx, sdqh_column* col);
 /* sdqh_partition_by_key straight into ONE caller-owned buffer (device memory; CPU build: host) of nrows * ncols 8-byte elements, laid
  * out for an all-to-all: the chunk for part p starts at element ncols * (rows of the parts before p) and holds every column's rows of
  * that part, column after column — so ONE collective moves every column of a redistribution step and nothing is copied between the

@@ -1290,6 +1290,29 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
     return SDQH_OK;
 }
 
+int sdqh_xcompact(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, sdqh_column** out_cols, int64_t* out_rows) {
+    if (!ctx || nrows < 0 || !out_cols || !out_rows) return fail(ctx, SDQH_ERR_INVALID, "xcompact: bad arguments");
+    XProg xp;
+    if (int rc = make_xprog(ctx, nrows, prog, SDQH_MAX_PAYLOAD, true, false, &xp)) return rc;
+    std::vector<int64_t> rows;                                        // row-major: key, vals (the filter half of 378-447, materialised)
+    const int w = 1 + xp.nvals;
+    XRow x;
+    for (int64_t r = 0; r < nrows; ++r) {
+        if (!xp.row(r, x)) continue;
+        if (x.bad[prog->key]) return fail(ctx, SDQH_ERR_UNSUPPORTED, "xcompact: a key part outside [0, 2^32)");
+        rows.push_back(x.i[prog->key]);
+        for (int k = 0; k < xp.nvals; ++k) rows.push_back(x.i[prog->vals[k]]);
+    }
+    const int64_t n = (int64_t)rows.size() / w;
+    for (int c = 0; c < w; ++c) {
+        if (int rc = sdqh_column_alloc(ctx, n, SDQH_I64, 0, &out_cols[c])) return rc;
+        int64_t* dst = (int64_t*)out_cols[c]->data;
+        for (int64_t e = 0; e < n; ++e) dst[e] = rows[(size_t)e * (size_t)w + (size_t)c];
+    }
+    *out_rows = n;
+    return SDQH_OK;
+}
+
 int sdqh_xkey_set(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t key_lo, int64_t key_hi, sdqh_table** out) {
     if (!ctx || nrows < 0 || !out) return fail(ctx, SDQH_ERR_INVALID, "xkey_set: bad arguments");
     XProg xp;
@@ -1431,6 +1454,8 @@ int sdqh_partition_by_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, 
     ctx->last_ms = tm.ms();
     return SDQH_OK;
 }
+
+int sdqh_column_mark_transient(sdqh_ctx* ctx, sdqh_column* col) { return (ctx && col) ? SDQH_OK : SDQH_ERR_INVALID; }
 
 int sdqh_partition_pack(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int nparts, const int64_t* range_upper, int ncols,
                         const sdqh_column* const* cols, void* packed, int64_t* counts) {

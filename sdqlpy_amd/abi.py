@@ -216,9 +216,9 @@ EXPORTS = [
     "sdqh_column_rows", "sdqh_column_dtype", "sdqh_column_width", "sdqh_column_minmax", "sdqh_column_free",
     "sdqh_scan_filter_sum", "sdqh_scan_probe_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_build_key_set", "sdqh_groupby_key", "sdqh_table_select_keys", "sdqh_table_share_groups", "sdqh_table_size", "sdqh_table_free",
     "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_table_compact_async", "sdqh_table_compact_deferred", "sdqh_host_wait_word", "sdqh_result_wait", "sdqh_scan_compact", "sdqh_partition_by_key",
-    "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in", "sdqh_column_unpack2", "sdqh_partition_pack", "sdqh_unpack_parts",
+    "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in", "sdqh_column_unpack2", "sdqh_partition_pack", "sdqh_unpack_parts", "sdqh_column_mark_transient",
     "sdqh_build", "sdqh_lookup_aggregate", "sdqh_table_entries", "sdqh_host_alloc", "sdqh_host_free", "sdqh_table_topk",
-    "sdqh_xscan_sum", "sdqh_xgroupby", "sdqh_xgroupby_block_bytes", "sdqh_xgroupby_async", "sdqh_xgroupby_collect", "sdqh_xbuild", "sdqh_xkey_set", "sdqh_xprobe_aggregate", "sdqh_table_columns", "sdqh_jit_stats", "sdqh_jit_compile",
+    "sdqh_xscan_sum", "sdqh_xgroupby", "sdqh_xgroupby_block_bytes", "sdqh_xgroupby_async", "sdqh_xgroupby_collect", "sdqh_xbuild", "sdqh_xkey_set", "sdqh_xcompact", "sdqh_xprobe_aggregate", "sdqh_table_columns", "sdqh_jit_stats", "sdqh_jit_compile",
 ]
 
 
@@ -263,6 +263,11 @@ class Column:
 
     def data_ptr(self):
         return self.ctx.lib.sdqh_column_data(self.handle)
+
+    def mark_transient(self):
+        """This column lives for one run (rows that arrived through a collective): nothing is derived from it (sdqh_column_mark_transient)."""
+        self.ctx._check(self.ctx.lib.sdqh_column_mark_transient(self.ctx.handle, self.handle))
+        return self
 
 
 class Table:
@@ -672,6 +677,15 @@ class Context:
         self._after_call("xbuild")
         return Table(self, h, len(prog.vals), accumulate)
 
+    def xcompact(self, nrows, prog):
+        """(Columns [key, vals...] as I64 bit patterns, n): every passing row of the program, duplicate keys included."""
+        k = 1 + len(prog.vals)
+        outs = (C.c_void_p * k)()
+        n = C.c_int64()
+        self._check(self.lib.sdqh_xcompact(self.handle, C.c_int64(nrows), C.byref(prog.struct()), outs, C.byref(n)))
+        self._after_call("xcompact")
+        return [Column(self, C.c_void_p(outs[i]), n.value, I64, 0) for i in range(k)], n.value
+
     def xkey_set(self, nrows, prog, key_lo, key_hi):
         h = C.c_void_p()
         self._check(self.lib.sdqh_xkey_set(self.handle, C.c_int64(nrows), C.byref(prog.struct()), C.c_int64(key_lo), C.c_int64(key_hi), C.byref(h)))
@@ -966,6 +980,7 @@ class Library:
         L.sdqh_column_copy_in.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.sdqh_table_export_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.sdqh_jit_compile.argtypes = [C.c_void_p, C.c_char_p]
+        L.sdqh_column_mark_transient.argtypes = [C.c_void_p, C.c_void_p]
         L.sdqh_column_unpack2.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.sdqh_partition_pack.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sdqh_unpack_parts.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -983,6 +998,7 @@ class Library:
         L.sdqh_xgroupby_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sdqh_xbuild.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
         L.sdqh_xkey_set.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.sdqh_xcompact.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sdqh_xprobe_aggregate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
         L.sdqh_table_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.sdqh_jit_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

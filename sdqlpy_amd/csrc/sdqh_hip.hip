@@ -2344,6 +2344,40 @@ int sdqh_scan_compact(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, i
     return SDQH_OK;
 }
 
+}  // extern "C" (reopened below)
+namespace sdqh_host {
+int stage_rows_out(sdqh_ctx* ctx, sdqh_table* tb, sdqh_column** out_cols, int64_t* out_rows) {
+    const int ncols = 1 + tb->npay;
+    if (ncols > SDQH_MAX_COMPACT_COLS || !tb->stage.seg_count || !tb->stage.key) return fail(ctx, SDQH_ERR_INVALID, "stage rows: not a staged table");
+    uint64_t* seg_off = static_cast<uint64_t*>(tb_alloc(ctx, tb, (size_t)tb->stage.nseg * 8 + 64));
+    unsigned long long* total = static_cast<unsigned long long*>(tb_alloc(ctx, tb, 64));
+    if (!seg_off || !total) return fail(ctx, SDQH_ERR_NOMEM, "stage rows: out of device memory");
+    sdqh_column* outs[SDQH_MAX_COMPACT_COLS] = {nullptr};
+    DevGather g; std::memset(&g, 0, sizeof(g)); g.ncols = ncols;
+    int rc = SDQH_OK;
+    for (int c = 0; c < ncols && !rc; ++c) {
+        rc = sdqh_column_alloc(ctx, tb->nrows_build, SDQH_I64, 0, &outs[c]);
+        if (!rc) { g.out[c] = static_cast<int64_t*>(outs[c]->data); outs[c]->transient = true; }
+    }
+    if (!rc) {
+        const unsigned seg_grid = (unsigned)((tb->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
+        call_begin(ctx);
+        LAUNCH(ctx, "k_seg_scan", k_seg_scan, 1, tb->stage.seg_count, tb->stage.nseg, seg_off, total);
+        LAUNCH(ctx, "k_gather_segments", k_gather_segments, seg_grid, tb->stage, seg_off, g);
+        call_end(ctx);
+        hipError_t e = hipMemcpyAsync(ctx->result_host, total, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e));
+        if (!rc) rc = sync_stream(ctx);
+    }
+    if (rc) { for (int c = 0; c < ncols; ++c) if (outs[c]) sdqh_column_free(ctx, outs[c]); return rc; }
+    const int64_t n = (int64_t)*static_cast<const unsigned long long*>(ctx->result_host);
+    for (int c = 0; c < ncols; ++c) { outs[c]->nrows = n; out_cols[c] = outs[c]; }
+    *out_rows = n;
+    return SDQH_OK;
+}
+}  // namespace sdqh_host
+extern "C" {
+
 int sdqh_partition_by_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int nparts, const int64_t* range_upper, int ncols,
                           const sdqh_column* const* cols, sdqh_column** out_cols, int64_t* counts) {
     if (!ctx || nrows < 0 || nparts < 1 || nparts > SDQH_MAX_PARTS || ncols < 1 || ncols > SDQH_MAX_COMPACT_COLS || !cols || !out_cols || !counts)
@@ -2381,6 +2415,12 @@ int sdqh_partition_by_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, 
     if (rc) { for (int c = 0; c < ncols; ++c) if (outs[c]) sdqh_column_free(ctx, outs[c]); return rc; }
     for (int p = 0; p < nparts; ++p) counts[p] = (int64_t)static_cast<const unsigned long long*>(ctx->result_host)[p];
     for (int c = 0; c < ncols; ++c) out_cols[c] = outs[c];
+    return SDQH_OK;
+}
+
+int sdqh_column_mark_transient(sdqh_ctx* ctx, sdqh_column* col) {
+    if (!ctx || !col) return fail(ctx, SDQH_ERR_INVALID, "column_mark_transient: bad arguments");
+    col->transient = true; col->narrow_state = 0; col->code_state = 0; col->clustered = 0; col->increasing = 0; col->span8 = 0;
     return SDQH_OK;
 }
 

@@ -205,6 +205,8 @@ void tb_release(sdqh_ctx* ctx, sdqh_table* t);
 // stage arrays of a build whose key / payload the kernel computes itself (no source columns)
 int stage_setup_computed(sdqh_ctx* ctx, sdqh_table* tb, int64_t nrows, int npay, int batch);
 int index_ensure(sdqh_ctx* ctx, sdqh_table* tb);
+// every staged row of a freshly built table (no index is made, duplicate keys stay): key + payload as resident I64 columns
+int stage_rows_out(sdqh_ctx* ctx, sdqh_table* tb, sdqh_column** out_cols, int64_t* out_rows);
 // K-F into the table's own device buffers (tb->compact; rows in build-row order), *n = the number of entries kept; zero_rows made on request
 int table_compact_resident(sdqh_ctx* ctx, sdqh_table* tb, int64_t min_hits, bool want_zero_rows, int64_t* n);
 int column_minmax(sdqh_ctx* ctx, sdqh_column* c);

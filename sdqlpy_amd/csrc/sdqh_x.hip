@@ -1537,6 +1537,19 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
     return SDQH_OK;
 }
 
+int sdqh_xcompact(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, sdqh_column** out_cols, int64_t* out_rows) {
+    if (!ctx || !prog || !out_cols || !out_rows) return fail(ctx, SDQH_ERR_INVALID, "xcompact: bad arguments");
+    if (1 + prog->nvals > SDQH_MAX_COMPACT_COLS) return fail(ctx, SDQH_ERR_INVALID, "xcompact: too many columns");
+    // the staging half of a build (the stage sink keeps every passing row in its segment); the index a build would make lazily is never asked for
+    sdqh_table* tb = nullptr;
+    if (int rc = sdqh_xbuild(ctx, nrows, prog, 1, 0, 0, &tb)) return rc;
+    int rc = SDQH_OK;
+    if (ctx->compile_only) { for (int c = 0; c < 1 + prog->nvals; ++c) out_cols[c] = nullptr; *out_rows = 0; }
+    else rc = stage_rows_out(ctx, tb, out_cols, out_rows);
+    sdqh_table_free(ctx, tb);
+    return rc;
+}
+
 int sdqh_xkey_set(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t key_lo, int64_t key_hi, sdqh_table** out) {
     if (!ctx || nrows < 0 || !out) return fail(ctx, SDQH_ERR_INVALID, "xkey_set: bad arguments");
     if (!ctx->compile_only) (void)hipSetDevice(ctx->device);

@@ -745,7 +745,10 @@ __device__ __forceinline__ void x_tight(const XArgs& a, const typename SinkT<P::
 // before the first is tested.  Q3's probe streams 6 bytes per lineitem row this way (key through its 4-byte
 // twin, date as a 2-byte code) where the two-rows-per-lane form read 8 and issued four times the loads.
 // =================================================================================================
-constexpr int X8_U = 2;
+#ifndef X8_U_STEPS
+#define X8_U_STEPS 2
+#endif
+constexpr int X8_U = X8_U_STEPS;                                       // 512-row steps whose loads are in flight together
 constexpr int X8_STEP = WAVE * XT_R;                                  // 512 rows per wave step
 constexpr int X8_CAP = 64 + X8_U * X8_STEP;
 // four consecutive bitmap words from any word on (4-byte aligned: gfx950 serves a dwordx4 global load at dword alignment)

@@ -163,7 +163,7 @@ class DistributedRunner:
             dist.all_gather(list(recv.view(self.world, m * k).unbind(0)), send, group=self.group)
         outs = []
         for j, col in enumerate(cols):
-            out = self.ctx.alloc(total, col.dtype)
+            out = self.ctx.alloc(total, col.dtype).mark_transient()
             at = 0
             for r, sz in enumerate(sizes):
                 if sz:
@@ -204,7 +204,41 @@ class DistributedRunner:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
 
-    def _exchange(self, nrows, key, cols, range_upper=None):
+    def _compact_probe_rows(self, st, probes):
+        """The probe side's rows that pass its filter and whose key some rank holds (`probes`: the replicated key set), as columns
+        [key, operands ...] of 8-byte bit patterns.  As a row program (sdqh_xcompact: on the GPU the value-queue stage kernel — every
+        column streamed at its tightest encoding, the key set tested on streamed keys, survivors' values queued and stored whole;
+        the stage is never indexed, so equal keys all stay).  Shapes the program route refuses: sdqh_scan_compact."""
+        ctx = self.ctx
+        if probes and len(st.ops_c) <= abi.MAX_PAYLOAD and not st.flt_c._keep[2] and not st.flt_c._keep[3]:
+            try:
+                P = abi.Program()
+                gates = []
+                for f in _ipreds(st.flt_c):
+                    c = P.op(abi.X_COL, abi.T_I64, col=f.col_obj)
+                    if f.lo > abi.INT64_MIN:
+                        gates.append(P.op(abi.X_GE, abi.T_BOOL, a=c, b=P.op(abi.X_CONST, abi.T_I64, imm_i=f.lo)))
+                    if f.hi < abi.INT64_MAX:
+                        gates.append(P.op(abi.X_LE, abi.T_BOOL, a=c, b=P.op(abi.X_CONST, abi.T_I64, imm_i=f.hi)))
+                for col, lo, hi in _fpreds(st.flt_c):
+                    c = P.op(abi.X_COL, abi.T_F64, col=col)
+                    if lo > -np.inf:
+                        gates.append(P.op(abi.X_GE, abi.T_BOOL, a=c, b=P.op(abi.X_CONST, abi.T_F64, imm_f=lo)))
+                    if hi < np.inf:
+                        gates.append(P.op(abi.X_LE, abi.T_BOOL, a=c, b=P.op(abi.X_CONST, abi.T_F64, imm_f=hi)))
+                key = P.op(abi.X_COL, abi.T_I64, col=st.key_c)
+                for tbl, kcol in probes:
+                    k = key if kcol is st.key_c else P.op(abi.X_COL, abi.T_I64, col=kcol)
+                    gates.append(P.op(abi.X_LOOKUP, abi.T_BOOL, a=k, table=tbl))
+                P.gates, P.key = gates, key
+                P.vals = [P.op(abi.X_COL, abi.T_F64 if c.dtype == abi.F64 else abi.T_I64, col=c) for c in st.ops_c]
+                return ctx.xcompact(st.nc, P)
+            except abi.SdqhError as exc:
+                if exc.code != abi.ERR_UNSUPPORTED:
+                    raise
+        return ctx.scan_compact(st.nc, st.flt_c, probes, [st.key_c] + st.ops_c)
+
+    def _exchange(self, nrows, key, cols, range_upper=None, dtypes=None):
         """Partition `nrows` rows of `cols` by part(key) (hash, or range_upper's ranges) and move every part to its rank.  The
         partitioning pass writes straight into the collective's send buffer in the all-to-all's own layout (sdqh_partition_pack: the
         chunk for rank d holds every column's rows for d), so a redistribution step is ONE all_to_all_single whatever the number of
@@ -221,7 +255,7 @@ class DistributedRunner:
         recv = torch.empty(max(n_recv * k, 1), dtype=torch.int64, device=self.device)
         if matrix.sum() > 0:
             self._a2a(recv[:n_recv * k], send[:nrows * k], [int(c) * k for c in recv_counts], [int(c) * k for c in counts])
-        out, n = self.ctx.unpack_parts(recv.data_ptr(), recv_counts, [c.dtype for c in cols])
+        out, n = self.ctx.unpack_parts(recv.data_ptr(), recv_counts, dtypes or [c.dtype for c in cols])      # (dtypes: entries of a staged table come back as raw 8-byte columns)
         self._inflight.extend([send, recv])                                  # queued kernels read them; released at the next run
         return out, n, counts
 
@@ -512,6 +546,21 @@ class DistributedRunner:
                 member_only.add(name)
                 st.key_range[name] = (lo, hi)
         st.member_only = member_only
+        # replicated tables WITH payload, keyed by one column: the global key range too (gathered once) — the replica is then rebuilt by the
+        # value-queue build, told its bounds, instead of the fixed-shape unique build with its minimum / maximum pass
+        st.table_range = {}
+        for name, need in st.replicate.items():
+            bop = built_by.get(name)
+            if not need or name in member_only or bop is None or not isinstance(bop.key, Col) or tabs[bop.table].cols.get(bop.key.name) is None:
+                continue
+            karr = tabs[bop.table].array(bop.key.name, bop)
+            if karr.dtype != np.int64:
+                continue
+            mine = eng.column(karr).minmax() if len(karr) else (abi.INT64_MAX, abi.INT64_MIN)
+            facts = self._all_gather_array(np.array(mine, np.int64))
+            lo, hi = min(int(f[0]) for f in facts), max(int(f[1]) for f in facts)
+            if lo <= hi:
+                st.table_range[name] = (lo, hi)
         for op in plan.ops:
             if isinstance(op, ScanOp):
                 st.steps.append((op, engine._prepare_scan(eng, op, tabs[op.table], accumulate_into, op.out in member_only)))
@@ -530,7 +579,7 @@ class DistributedRunner:
                             st.local_text.add(id(hit[2]))
         return st
 
-    def _replicate_table(self, bt, key_range=None):
+    def _replicate_table(self, bt, key_range=None, table_range=None):
         """All ranks' entries of a built table on every rank, without leaving device memory.  A key set (key_range given): its exact
         bitmap over the global key range, one collective, the replica a key set again — the layout the loops that test it are
         specialised on.  A table with payload: entries -> all-gather -> rebuild, a composite key (travelling packed) from its two
@@ -555,6 +604,8 @@ class DistributedRunner:
             hi, lo = ctx.unpack2(gathered[0], total)
             table = ctx.build(total, abi.make_filter(), [], [abi.src_col(hi), abi.src_col(lo)], [abi.src_col(c) for c in gathered[1:]])
             gathered = list(gathered) + [hi, lo]
+        elif table_range is not None and total:
+            table = self._build_from_columns(total, gathered, table_range, accumulate=False)
         else:
             table = ctx.hash_build_unique(total, abi.make_filter(), [], gathered[0], gathered[1:])
         new = engine.BuiltTable(table, bt.key_name, bt.key_is_record, bt.val_fields, bt.val_is_record, bt.payload_dtypes)
@@ -579,7 +630,7 @@ class DistributedRunner:
                 if isinstance(op, ScanOp):
                     res = step(env)
                     if isinstance(res, engine.BuiltTable) and st.replicate.get(op.out):
-                        res = self._replicate_table(res, st.key_range.get(op.out))
+                        res = self._replicate_table(res, st.key_range.get(op.out), st.table_range.get(op.out))
                     elif isinstance(res, engine.DictResult) and st.sharded[op.out]:
                         res = self._merge_groups(res)
                     elif isinstance(res, float) and st.sharded[op.out]:
@@ -818,7 +869,7 @@ class DistributedRunner:
             self._inflight.append(parts)
         return ctx.table_from_bitmap(words, lo, hi), words
 
-    def _build_from_columns(self, n, cols, key_range):
+    def _build_from_columns(self, n, cols, key_range, accumulate=True):
         """A table with accumulators from received entry columns [key, payload ...] (every row an entry; keys within key_range).  As a
         row program when the library takes it — the value-queue build streams the columns once and needs no minimum / maximum pass,
         having been told the bounds: 0.03 ms for Q3's 1.46 M received orders where the fixed-shape build took 0.27 — else the
@@ -830,11 +881,11 @@ class DistributedRunner:
             prog.key = prog.op(abi.X_COL, abi.T_I64, col=cols[0])
             prog.vals = [prog.op(abi.X_COL, abi.T_F64 if c.dtype == abi.F64 else abi.T_I64, col=c) for c in cols[1:]]
             try:
-                return ctx.xbuild(n, prog, lo, hi, accumulate=True)
+                return ctx.xbuild(n, prog, lo, hi, accumulate=accumulate)
             except abi.SdqhError as exc:
                 if exc.code != abi.ERR_UNSUPPORTED:
                     raise
-        return ctx.hash_build_unique(n, abi.make_filter(), [], cols[0], cols[1:], accumulate=True)
+        return ctx.hash_build_unique(n, abi.make_filter(), [], cols[0], cols[1:], accumulate=accumulate)
 
     def _replicated_set(self, st, local):
         """Table A (a BuiltTable built from this rank's shard) on every rank; see _replicated_key_set.  Key range too wide for a
@@ -921,10 +972,10 @@ class DistributedRunner:
                     all_keys, words = self._replicated_key_set(table_b, (lo_g, hi_g))
                     probes_c = [(all_keys, st.key_c)]
                     keep.append(words)
-                ccols, nc = ctx.scan_compact(st.nc, st.flt_c, probes_c, [st.key_c] + st.ops_c)
+                ccols, nc = self._compact_probe_rows(st, probes_c)
                 for tbl, _ in probes_c:
                     tbl.free()                                                # (the words it borrowed stay alive in `keep`)
-                recv, n_recv, _ = self._exchange(nc, ccols[0], ccols)
+                recv, n_recv, _ = self._exchange(nc, ccols[0], ccols, dtypes=[abi.I64] + [c.dtype for c in st.ops_c])
                 for c in ccols:
                     c.free()
                 keep.extend(recv)

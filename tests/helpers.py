@@ -1149,3 +1149,52 @@ def redistribution_pack_case(ctx, n=70001, seed=21, nparts=5):
             ctx.synchronize()
             assert sorted(hit.download(0, nh).tolist()) == [k for k in present if lo_r <= k <= hi_r], (lo_r, hi_r)
     return out
+
+
+def xcompact_case(ctx, n=70001, seed=33):
+    """sdqh_xcompact against numpy: every passing row comes out (equal keys all stay — nothing is indexed), key and values as
+    8-byte bit patterns; integer and double conditions, a key-set LOOKUP gate, an arithmetic value; nothing passing; no rows.
+    Returns how many configurations were checked."""
+    from sdqlpy_amd import abi
+    rng = np.random.default_rng(seed)
+    key = np.sort(rng.integers(100, 100 + max(n // 4, 1), n)).astype(np.int64)          # ~4 rows per key, clustered like l_orderkey
+    d = rng.integers(0, 200, n).astype(np.int64)
+    price = rng.integers(100, 100000, n) / 100.0
+    disc = rng.integers(0, 11, n) / 100.0
+    tag = np.arange(n, dtype=np.int64)
+    members = np.unique(rng.integers(100, 100 + max(n // 4, 1), max(n // 16, 1))).astype(np.int64)
+    kc, dc, pc, sc, tc, mc = ctx.upload(key), ctx.upload(d), ctx.upload(price), ctx.upload(disc), ctx.upload(tag), ctx.upload(members)
+    kset = ctx.build_key_set(len(members), abi.make_filter(), [], mc)
+    checked = 0
+    for d_lo, p_hi, with_set in ((50, 1e9, True), (50, 500.0, False), (0, 1e9, True), (300, 1e9, False)):
+        P = abi.Program()
+        cd = P.op(abi.X_COL, abi.T_I64, col=dc)
+        cp = P.op(abi.X_COL, abi.T_F64, col=pc)
+        ck = P.op(abi.X_COL, abi.T_I64, col=kc)
+        gates = [P.op(abi.X_GE, abi.T_BOOL, a=cd, b=P.op(abi.X_CONST, abi.T_I64, imm_i=d_lo)),
+                 P.op(abi.X_LE, abi.T_BOOL, a=cp, b=P.op(abi.X_CONST, abi.T_F64, imm_f=p_hi))]
+        mask = (d >= d_lo) & (price <= p_hi)
+        if with_set:
+            gates.append(P.op(abi.X_LOOKUP, abi.T_BOOL, a=ck, table=kset))
+            mask &= np.isin(key, members)
+        one = P.op(abi.X_CONST, abi.T_F64, imm_f=1.0)
+        rev = P.op(abi.X_MUL, abi.T_F64, a=cp, b=P.op(abi.X_SUB, abi.T_F64, a=one, b=P.op(abi.X_COL, abi.T_F64, col=sc)))
+        P.gates, P.key = gates, ck
+        P.vals = [cp, rev, P.op(abi.X_COL, abi.T_I64, col=tc)]
+        for rows in (n, 0):
+            cols, m = ctx.xcompact(rows, P)
+            ctx.synchronize()
+            want = np.nonzero(mask[:rows])[0]
+            assert m == len(want), (d_lo, p_hi, with_set, rows, m, len(want))
+            if m:
+                t = cols[3].download(0, m)
+                order = np.argsort(t, kind="stable")
+                assert np.array_equal(t[order], want)                                                  # each passing row once
+                assert np.array_equal(cols[0].download(0, m)[order], key[want])
+                assert np.array_equal(cols[1].download(0, m)[order].view(np.float64), price[want])
+                assert np.array_equal(cols[2].download(0, m)[order].view(np.float64), price[want] * (1.0 - disc[want]))
+            for c in cols:
+                c.free()
+            checked += 1
+    kset.free()
+    return checked

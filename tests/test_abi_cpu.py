@@ -20,6 +20,13 @@ def test_binding_lists_every_declared_symbol():
     assert sorted(abi.EXPORTS) == declared_symbols()
 
 
+def test_integration_notes_count_the_declared_symbols():
+    """INTEGRATION.md states how many entry points the boundary has, and names each one the header declares."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"\((\d+) `extern \"C\"` entry points", text)
+    assert m and int(m.group(1)) == len(declared_symbols())
+
+
 def test_oracle_exports_every_symbol(oracle_lib):
     for s in declared_symbols():
         assert hasattr(oracle_lib.cdll, s), s
@@ -271,5 +278,7 @@ def test_packed_exchange_helpers_on_the_cpu_implementation(oracle_lib):
     try:
         out = helpers.redistribution_pack_case(ctx, n=20011)
         assert sum(out["hash"][0]) == 20011 and sum(out["range"][0]) == 20011
+        assert helpers.xcompact_case(ctx, n=20011) == 8           # sdqh_xcompact: the probe side's rows as a row program, equal keys kept
+        assert helpers.xcompact_case(ctx, n=1, seed=2) == 8
     finally:
         ctx.close()

@@ -856,6 +856,13 @@ def test_packed_exchange_helpers_match_oracle(hip_engine, oracle_engine):
     want = helpers.redistribution_pack_case(oracle_engine.ctx)
     assert got["hash"][0] == want["hash"][0] and got["range"][0] == want["range"][0]
     assert got["range"][1] == want["range"][1] and got["hash"][1] == want["hash"][1]
+    for n in (70001, 1, 300, 2_000_003):                          # sdqh_xcompact: checked row by row against numpy inside the helper
+        assert helpers.xcompact_case(hip_engine.ctx, n=n) == 8
+    hip_engine.ctx.set_option("feature_min_rows", 0)             # ... and with the tight encodings on at every size
+    try:
+        assert helpers.xcompact_case(hip_engine.ctx, n=70001, seed=4) == 8
+    finally:
+        hip_engine.ctx.set_option("feature_min_rows", 1 << 20)
 
 
 def test_tight_encodings_on_small_inputs(hip_engine, oracle_engine):

@@ -50,6 +50,7 @@ def parse(argv=None):
     ap.add_argument("--extra-queries", default=None, help="measured after the timed region, reported per query only (default q6,q9 at N=1, none at N>1)")
     ap.add_argument("--profile-iters", type=int, default=5, help="extra untimed passes with per-kernel HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lanes", type=int, default=0, help="engine lanes — contexts of one family, a stream each; a plan is bound to one (0: the engine's default, 3)")
     ap.add_argument("--force-dist", action="store_true", help="use the distributed plan even with one rank (exercises the RCCL path)")
     ap.add_argument("--partition", default="hash", choices=["auto", "range", "hash"], help="q3's partitioning in the timed step at N > 1")
     ap.add_argument("--cpu-sample-sf", type=float, default=0.0, help="0 = pick so the CPU leg takes ~10-30 s")
@@ -85,6 +86,19 @@ def scanned_rows(q, rows):
 DOMINANT = {"q1": ("xk_group_lane_tight", lambda r: 48 * r["lineitem"]), "q3": ("k_probe_agg", lambda r: 32 * r["lineitem"]),
             "q6": ("xk_sum_tight", lambda r: 32 * r["lineitem"]), "q5": ("k_lookup_agg", lambda r: 32 * r["lineitem"]),
             "q9": ("k_lookup_agg", lambda r: 48 * r["lineitem"])}
+
+
+def _context_launches(c):
+    """[(kernel, ms, modelled bytes)] recorded on ONE context (not its forks)."""
+    import ctypes as C
+    out = []
+    for i, (name, ms) in enumerate(c.profile(family=False)):
+        b = C.c_int64()
+        nbytes = 0
+        if c.lib.sdqh_profile_entry_bytes(c.handle, C.c_int(i), C.byref(b)) == 0:
+            nbytes = int(b.value)
+        out.append((name, ms, nbytes))
+    return out
 
 
 def main(argv=None, hooks=None):
@@ -123,6 +137,8 @@ def main(argv=None, hooks=None):
         else:
             dist.init_process_group(hooks.get("backend", "gloo"))
 
+    if args.lanes > 0:
+        os.environ["SDQLPY_AMD_LANES"] = str(args.lanes)
     from sdqlpy_amd import engine, tpch
     from sdqlpy_amd import tpch_queries as Q
     from sdqlpy_amd.sdql_lib import sdqlpy_init
@@ -215,7 +231,8 @@ def main(argv=None, hooks=None):
         eng.ctx.set_profiling(2, only=only)
         barrier()
         t_begin = time.perf_counter()
-        marks = []                                       # (query, number of launches recorded so far)
+        marks = []                                       # (query, launches recorded so far on every context of the engine's family)
+        family = [eng.ctx] + list(getattr(eng.ctx, "forks", []))
         order = step_order(qs) if not each_waited_for else qs
         for _ in range(nsteps):
             results = []
@@ -227,19 +244,21 @@ def main(argv=None, hooks=None):
                 else:
                     results.append(r)
                 per_q[q] += (time.perf_counter() - tq) * 1e3
-                marks.append((q, eng.ctx.lib.sdqh_profile_count(eng.ctx.handle)))
+                marks.append((q, [c.lib.sdqh_profile_count(c.handle) for c in family]))
             for r in results:
                 finish(r)
         barrier()
         took = time.perf_counter() - t_begin
         # [(kernel, ms, modelled HBM bytes)] of every recorded launch (sdqh_profile_entry_bytes: what the library's own choice of
         # encodings makes that launch stream; 0 where a kernel has no model)
-        launches = eng.ctx.profile_bytes() if hasattr(eng.ctx, "profile_bytes") else [(n, ms, 0) for n, ms in eng.ctx.profile()]
+        # (a plan runs on one lane of the engine — a context with a stream of its own: the launches are read per context)
+        launches = [_context_launches(c) for c in family]
         eng.ctx.set_profiling(0)
-        log, at = [], 0
+        log, at = [], [0] * len(family)
         for q, upto in marks:
-            log += [(q, name, ms, nbytes) for name, ms, nbytes in launches[at:upto]]
-            at = upto
+            for i, n in enumerate(upto[:len(launches)]):
+                log += [(q, name, ms, nbytes) for name, ms, nbytes in launches[i][at[i]:n]]
+                at[i] = max(at[i], n)
         return took, per_q, log
 
     if runner is not None:
@@ -247,7 +266,9 @@ def main(argv=None, hooks=None):
     elapsed, _, timed_log = run_steps(args.steps, dom_kernel)
     # the same steps with every query's result finished before the next query starts: per-query wall times, and the step as a caller
     # who reads each result at once sees it
-    elapsed_waited, per_query_ms, _ = run_steps(args.steps, "-", each_waited_for=True)
+    # (the dominant kernel's launches are evented here too: in this region a kernel has the chip to itself — in the first, the queries'
+    # kernels share it, lane by lane, and a kernel's duration there is not a statement about the kernel)
+    elapsed_waited, per_query_ms, waited_log = run_steps(args.steps, dom_kernel, each_waited_for=True)
     timed_collectives = None
     if runner is not None:
         timed_collectives = {k: {"calls": v[0], "on_device_tensors": v[1], "bytes": v[2]} for k, v in sorted(runner.collectives.items())}
@@ -258,8 +279,12 @@ def main(argv=None, hooks=None):
             assert runner.collectives.get("all_to_all", [0])[0] > 0 or runner.last_partitioning == "range", "no all-to-all ran in the timed step"
             if args.partition == "hash":
                 assert runner.exchanged_rows.get("probe_sent", 0) > 0, runner.exchanged_rows
-    dom_launches = [ms for q, name, ms, _ in timed_log if q == dom_q and name == dom_kernel]
-    dom_model = [nb for q, name, _, nb in timed_log if q == dom_q and name == dom_kernel and nb > 0]
+    nlanes = int(getattr(eng, "nlanes", 1)) if not use_dist else 1
+    shared_launches = [ms for q, name, ms, _ in timed_log if q == dom_q and name == dom_kernel]
+    alone_launches = [ms for q, name, ms, _ in waited_log if q == dom_q and name == dom_kernel]
+    # one lane: the queries of a step run one behind the other on one stream, and the first region's launches are as alone as the second's
+    dom_launches = alone_launches if (nlanes > 1 and alone_launches) else shared_launches
+    dom_model = [nb for q, name, _, nb in (waited_log if dom_launches is alone_launches else timed_log) if q == dom_q and name == dom_kernel and nb > 0]
     # per-kernel table: a separate pass with events around every launch, after the timed region
     profile_steps = max(1, min(args.steps, 10))
     _, _, launch_log = run_steps(profile_steps, None)
@@ -362,6 +387,20 @@ def main(argv=None, hooks=None):
                         "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": round(dom_ms, 4),
                         "launches_timed": len(dom_launches),
                         "achievable_peak_note": "MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured for a float4 copy"}
+            if dom_launches is alone_launches:
+                # which of the two timed regions the launches above are from, and the same kernel's launches in the other
+                shared_ms = sum(shared_launches) / len(shared_launches) if shared_launches else None
+                roofline["measured_in"] = ("the timed steps whose queries are waited for one by one (value_sequential): the kernel has the chip to itself; in the "
+                                           "overlapped steps (value) the engine's %d lanes run the queries' kernels side by side" % nlanes)
+                roofline["in_overlapped_steps"] = {"avg_launch_ms": round(shared_ms, 4) if shared_ms else None, "launches_timed": len(shared_launches),
+                                                   "note": "the same kernel sharing the chip with the other lanes' kernels: the step, not the kernel, is the unit there (roofline.step)"}
+            # the step as a whole against the same roofline: HBM bytes of its queries (PMC, per query) / the step's wall time
+            step_bytes = [pmc_traffic(q, None, rows)[0] for q in queries]
+            if all(step_bytes):
+                roofline["step"] = {"physical_bytes": int(sum(step_bytes)), "ms_per_step": round(ms_per_step, 4),
+                                    "frac": round(sum(step_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "frac_each_query_waited_for": round(sum(step_bytes) / (elapsed_waited / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "traffic_source": "per-query PMC bytes (profiles/), wall time of this run"}
             if reference_width and dom_q in reference_width.get("queries", {}):
                 rw = reference_width["queries"][dom_q]
                 roofline["reference_width"] = {"kernel": rw["dominant_kernel"], "avg_launch_ms": rw["dominant_avg_launch_ms"], "achieved": rw["achieved"], "frac": rw["frac"]}
@@ -397,6 +436,7 @@ def main(argv=None, hooks=None):
             # queued without being waited for (Engine.deferred_results) and every result is complete on the host before the step ends.
             # Beside it, the same step with every query's result finished before the next query is launched.
             # the same two figures under explicit names: `value` is the overlapped one
+            "lanes": nlanes,
             "value_overlapped": round(value, 1), "value_sequential": round(total_rows_per_step * args.steps / elapsed_waited, 1),
             "step": {"launch_then_finish": True, "launch_order": step_order(queries), "deferred_results": bool(getattr(eng, "deferred_results", False)),
                      "ms_per_step_each_query_waited_for": round(elapsed_waited / args.steps * 1e3, 4),

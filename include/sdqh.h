@@ -154,6 +154,15 @@ int         sdqh_create(int device, sdqh_ctx** out);       /* HIP build, device 
                                                               kernel, returning SDQH_ERR_DEVICE with "kernel specialised" (sdqh_xbuild / sdqh_xkey_set: SDQH_OK and a
                                                               placeholder table later programs can name); every other call is invalid on it */
 void        sdqh_destroy(sdqh_ctx* ctx);
+/* A second context of the same FAMILY: its own stream, memory pool and result blocks on the parent's device, and the right to name
+ * the columns of the family's other contexts in its calls (tables stay with the context that built them).  Calls on different
+ * contexts of a family run concurrently on the device — independent queries share the chip instead of queueing behind one
+ * another on one stream (the reference runs one query at a time; its TBB loops have the machine to themselves).  What the library
+ * attaches to a column on first use (narrow twins, dictionaries, statistics) lives with the column and is complete when the call
+ * that made it returns.  The caller keeps a column alive, and unchanged, while any context of the family has work in flight that
+ * reads it (sdqh_synchronize each before sdqh_column_free / sdqh_column_copy_in); options are per context.  Fork the family's
+ * first context only; destroy forks before it. */
+int         sdqh_fork(sdqh_ctx* parent, sdqh_ctx** out);
 const char* sdqh_last_error(const sdqh_ctx* ctx);
 int         sdqh_set_threads(sdqh_ctx* ctx, int threads);   /* CPU build: worker count; HIP build: accepted, ignored */
 int         sdqh_synchronize(sdqh_ctx* ctx);

@@ -326,6 +326,12 @@ int sdqh_create(int device, sdqh_ctx** out) {
     *out = new sdqh_ctx();
     return SDQH_OK;
 }
+int sdqh_fork(sdqh_ctx* parent, sdqh_ctx** out) {                  // (the CPU build has no streams: a family's contexts differ in nothing but identity)
+    if (!parent || !out) return SDQH_ERR_INVALID;
+    *out = new sdqh_ctx();
+    (*out)->threads = parent->threads;
+    return SDQH_OK;
+}
 void sdqh_destroy(sdqh_ctx* ctx) { delete ctx; }
 const char* sdqh_last_error(const sdqh_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 int sdqh_set_threads(sdqh_ctx* ctx, int threads) {

@@ -209,7 +209,7 @@ class Program:
 
 
 EXPORTS = [
-    "sdqh_abi_version", "sdqh_backend_name", "sdqh_create", "sdqh_destroy", "sdqh_last_error", "sdqh_set_threads",
+    "sdqh_abi_version", "sdqh_backend_name", "sdqh_create", "sdqh_fork", "sdqh_destroy", "sdqh_last_error", "sdqh_set_threads",
     "sdqh_synchronize", "sdqh_last_device_ms", "sdqh_set_profiling", "sdqh_set_profile_filter", "sdqh_profile_count", "sdqh_profile_entry", "sdqh_profile_entry_bytes",
     "sdqh_stream", "sdqh_set_option",
     "sdqh_column_upload", "sdqh_column_wrap", "sdqh_column_alloc", "sdqh_column_download", "sdqh_column_data",
@@ -337,15 +337,21 @@ def gt_float(c):
 
 
 class Context:
-    def __init__(self, lib, device=0, threads=1):
+    def __init__(self, lib, device=0, threads=1, _parent=None):
         self.lib = lib.cdll
         self.library = lib
         h = C.c_void_p()
-        rc = self.lib.sdqh_create(C.c_int(device), C.byref(h))
-        if rc != OK:
-            raise SdqhError(rc, "sdqh_create(device=%d) failed" % device)
+        if _parent is None:
+            rc = self.lib.sdqh_create(C.c_int(device), C.byref(h))
+            if rc != OK:
+                raise SdqhError(rc, "sdqh_create(device=%d) failed" % device)
+        else:
+            _parent._check(self.lib.sdqh_fork(_parent.handle, C.byref(h)))
         self.handle = h
         self.device = device
+        self.parent = _parent          # sdqh_fork: a context of the parent's family (own stream / pool / result blocks, shared columns)
+        self.forks = []
+        self._options = {}             # options set so far (a fork starts with its parent's)
         self._profiling = False
         self.kernel_log = []       # [(kernel name, ms)] of every pattern call since the log was cleared (profiling on)
         self.device_log = []       # [(pattern call, device ms)]
@@ -355,7 +361,22 @@ class Context:
         self._deferred_quarantine = []  # the same for blocks that kernels still queued on the stream may write (synchronize)
         self._sync_epoch = 0            # full synchronisations of the context so far
 
+    def fork(self):
+        """A context of this one's family (sdqh_fork): calls on it run concurrently with this one's and may name this one's columns.
+        It starts with the options set here and follows later changes; profiling switches and the call logs are the family's."""
+        if self.parent is not None:
+            raise SdqhError(ERR_INVALID, "fork the family's first context")
+        child = Context(self.library, self.device, 1, _parent=self)
+        for name, value in self._options.items():
+            child.set_option(name, value)
+        child.kernel_log, child.device_log = self.kernel_log, self.device_log
+        self.forks.append(child)
+        return child
+
     def close(self):
+        for child in list(self.forks):
+            child.close()
+        self.forks = []
         if self.handle is not None:
             self.lib.sdqh_synchronize(self.handle)
             for addr, size in self._host_quarantine + self._deferred_quarantine:
@@ -367,6 +388,8 @@ class Context:
             self._host_pool = {}
             self.lib.sdqh_destroy(self.handle)
             self.handle = None
+        if self.parent is not None and self in self.parent.forks:
+            self.parent.forks.remove(self)
 
     # -- result memory the device can write (sdqh_host_alloc) -------------------------------------
     def host_block(self, nbytes, deferred=False):
@@ -423,6 +446,9 @@ class Context:
         self._check(self.lib.sdqh_set_threads(self.handle, C.c_int(n)))
 
     def synchronize(self):
+        """Everything queued on this context — and, on a family's first context, on its forks — has run."""
+        for child in self.forks:
+            child.synchronize()
         self._check(self.lib.sdqh_synchronize(self.handle))
         self._sync_epoch += 1
         if self._deferred_quarantine:                             # nothing queued before this point can write them any more
@@ -444,6 +470,9 @@ class Context:
         self._check(self.lib.sdqh_set_profiling(self.handle, C.c_int(mode)))
         self._profiling = mode == 1
         self.kernel_log, self.device_log = [], []
+        for child in self.forks:                                   # the family is profiled as one: the forks write this context's logs
+            child.set_profiling(mode, only)
+            child.kernel_log, child.device_log = self.kernel_log, self.device_log
 
     def _after_call(self, name):
         """With profiling on, log the device time of the call and of each kernel it launched
@@ -452,21 +481,27 @@ class Context:
             self.device_log.append((name, self.last_device_ms()))
             self.kernel_log.extend(self.profile())
 
-    def profile(self):
+    def profile(self, family=True):
+        """[(kernel, ms)] of every recorded launch; on a family's first context: its own, then its forks' (family=False: its own only)."""
         out = []
         for i in range(self.lib.sdqh_profile_count(self.handle)):
             name, ms = C.c_char_p(), C.c_double()
             self._check(self.lib.sdqh_profile_entry(self.handle, C.c_int(i), C.byref(name), C.byref(ms)))
             out.append((name.value.decode(), ms.value))
+        if family:
+            for child in self.forks:
+                out.extend(child.profile())
         return out
 
     def profile_bytes(self):
-        """[(kernel, ms, modelled HBM bytes or 0)] of every recorded launch (sdqh_profile_entry_bytes)."""
+        """[(kernel, ms, modelled HBM bytes or 0)] of every recorded launch (sdqh_profile_entry_bytes), the forks' after this context's."""
         out = []
-        for i, (name, ms) in enumerate(self.profile()):
+        for i, (name, ms) in enumerate(self.profile(family=False)):
             b = C.c_int64()
             self._check(self.lib.sdqh_profile_entry_bytes(self.handle, C.c_int(i), C.byref(b)))
             out.append((name, ms, int(b.value)))
+        for child in self.forks:
+            out.extend(child.profile_bytes())
         return out
 
     def stream(self):
@@ -474,6 +509,9 @@ class Context:
 
     def set_option(self, name, value):
         self._check(self.lib.sdqh_set_option(self.handle, name.encode(), C.c_int64(int(value))))
+        self._options[name] = int(value)
+        for child in self.forks:
+            child.set_option(name, value)
 
     # -- columns -----------------------------------------------------------------------------
     @staticmethod
@@ -713,9 +751,11 @@ class Context:
         self._check(self.lib.sdqh_jit_compile(self.handle, source.encode()))
 
     def jit_stats(self):
+        """(kernels compiled by hiprtc, kernels loaded from the cache) in this context and its forks."""
         a, b = C.c_int64(), C.c_int64()
         self._check(self.lib.sdqh_jit_stats(self.handle, C.byref(a), C.byref(b)))
-        return a.value, b.value
+        rest = [child.jit_stats() for child in self.forks]
+        return a.value + sum(r[0] for r in rest), b.value + sum(r[1] for r in rest)
 
     def hash_probe_aggregate(self, nrows, flt, table, key, tup):
         self._check(self.lib.sdqh_hash_probe_aggregate(self.handle, C.c_int64(nrows), C.byref(flt), table.handle, key.handle, C.byref(tup)))
@@ -997,6 +1037,7 @@ class Library:
         L.sdqh_xgroupby_async.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.sdqh_xgroupby_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sdqh_xbuild.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
+        L.sdqh_fork.argtypes = [C.c_void_p, C.c_void_p]
         L.sdqh_xkey_set.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.sdqh_xcompact.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sdqh_xprobe_aggregate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]

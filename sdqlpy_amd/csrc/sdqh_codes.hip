@@ -122,7 +122,7 @@ bool build_codes(sdqh_ctx* ctx, sdqh_column* c, const void* src, int64_t lo, int
     const int nwords = (int)((range + 31) / 32);
     uint32_t* bm = static_cast<uint32_t*>(pool_alloc(ctx, (size_t)nwords * 4 + 64));
     uint32_t* prefix = static_cast<uint32_t*>(pool_alloc(ctx, (size_t)nwords * 4 + 64));
-    int64_t* dict = static_cast<int64_t*>(pool_alloc(ctx, (size_t)65536 * 8));
+    int64_t* dict = static_cast<int64_t*>(attach_alloc(ctx, c, (size_t)65536 * 8));
     int* nd = static_cast<int*>(pool_alloc(ctx, 64));
     bool ok = bm && prefix && dict && nd && hipMemsetAsync(bm, 0, (size_t)nwords * 4, ctx->stream) == hipSuccess;
     int ndict = 0;
@@ -138,7 +138,7 @@ bool build_codes(sdqh_ctx* ctx, sdqh_column* c, const void* src, int64_t lo, int
     void* code = nullptr;
     if (ok) {
         const int width = ndict <= 256 ? 1 : 2;
-        code = pool_alloc(ctx, (size_t)c->nrows * width + 256);               // padded: the streaming kernels load whole 16-byte groups
+        code = attach_alloc(ctx, c, (size_t)c->nrows * width + 256);               // padded: the streaming kernels load whole 16-byte groups
         ok = code != nullptr;
         if (ok) {
             const unsigned grid = (unsigned)std::min<int64_t>((c->nrows / 4 + TPB) / TPB, (int64_t)ctx->num_cu * 8);
@@ -152,8 +152,8 @@ bool build_codes(sdqh_ctx* ctx, sdqh_column* c, const void* src, int64_t lo, int
         }
     }
     if (!ok) { (void)hipGetLastError(); c->dict_host.clear(); }
-    if (code) pool_free(ctx, code);
-    if (dict) pool_free(ctx, dict);
+    if (code) attach_free(ctx, c, code);
+    if (dict) attach_free(ctx, c, dict);
     if (nd) pool_free(ctx, nd);
     if (prefix) pool_free(ctx, prefix);
     if (bm) pool_free(ctx, bm);
@@ -199,8 +199,8 @@ bool column_codes(sdqh_ctx* ctx, sdqh_column* c) {
 }
 
 void column_codes_release(sdqh_ctx* ctx, sdqh_column* c) {
-    if (c->code) pool_free(ctx, c->code);
-    if (c->dict) pool_free(ctx, c->dict);
+    if (c->code) attach_free(ctx, c, c->code);
+    if (c->dict) attach_free(ctx, c, c->dict);
     c->code = nullptr; c->dict = nullptr; c->code_width = 0; c->ndict = 0; c->code_state = -1; c->dict_host.clear();
 }
 

@@ -60,6 +60,13 @@ void pool_free(sdqh_ctx* ctx, void* p) {
     for (auto& b : ctx->pool) if (b.ptr == p) { b.free = true; for (int h = 0; h < b.nhabits; ++h) b.habits[h].clean = false; if (!b.fill_use) b.nhabits = 0; return; }
 }
 
+void* attach_alloc(sdqh_ctx* ctx, const sdqh_column* c, size_t bytes) {
+    sdqh_ctx* h = c->home ? c->home : ctx;
+    if (h != ctx && h->stream) (void)hipStreamSynchronize(h->stream);
+    return pool_alloc(h, bytes);
+}
+void attach_free(sdqh_ctx* ctx, const sdqh_column* c, void* p) { pool_free(c->home ? c->home : ctx, p); }
+
 // ---- profiling / timing ------------------------------------------------------------------------
 hipEvent_t next_event(sdqh_ctx* ctx) {
     if (ctx->event_next == ctx->event_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); ctx->event_pool.push_back(e); }
@@ -308,7 +315,7 @@ int ensure_minmax(sdqh_ctx* ctx, sdqh_column* c) {
     if (c->have_minmax) return SDQH_OK;
     if (c->dtype != SDQH_I64) return fail(ctx, SDQH_ERR_INVALID, "minmax: needs an I64 column");
     if (!c->minmax_pending) {
-        if (!c->d_minmax) { c->d_minmax = static_cast<long long*>(pool_alloc(ctx, 16)); if (!c->d_minmax) return fail(ctx, SDQH_ERR_NOMEM, "minmax: out of device memory"); }
+        if (!c->d_minmax) { c->d_minmax = static_cast<long long*>(attach_alloc(ctx, c, 16)); if (!c->d_minmax) return fail(ctx, SDQH_ERR_NOMEM, "minmax: out of device memory"); }
         const long long init[2] = {INT64_MAX, INT64_MIN};
         HIP_TRY(ctx, hipMemcpyAsync(c->d_minmax, init, 16, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // `init` is on the stack
@@ -367,7 +374,7 @@ const void* ensure_narrow(sdqh_ctx* ctx, sdqh_column* c) {
     c->narrow_state = 0;
     if (c->nrows < 2) return nullptr;
     const int64_t units = c->dtype == SDQH_STR ? c->nrows * c->width : c->nrows;         // text: one byte per code unit
-    int32_t* twin = static_cast<int32_t*>(pool_alloc(ctx, c->dtype == SDQH_STR ? (size_t)units + 64 : (size_t)c->nrows * 4 + 64));
+    int32_t* twin = static_cast<int32_t*>(attach_alloc(ctx, c, c->dtype == SDQH_STR ? (size_t)units + 64 : (size_t)c->nrows * 4 + 64));
     int* flag = static_cast<int*>(pool_alloc(ctx, 64));
     bool ok = twin && flag && hipMemsetAsync(flag, 0, 4, ctx->stream) == hipSuccess;
     if (ok) {
@@ -381,7 +388,7 @@ const void* ensure_narrow(sdqh_ctx* ctx, sdqh_column* c) {
     if (!ok) (void)hipGetLastError();
     if (flag) pool_free(ctx, flag);
     if (ok) { c->narrow = twin; c->narrow_state = 1; }
-    else if (twin) pool_free(ctx, twin);
+    else if (twin) attach_free(ctx, c, twin);
     return c->narrow;
 }
 // The LDS-staged string predicate through the text column's byte twin: 64 rows per wave and round (any width: 64 rows of bytes
@@ -522,8 +529,19 @@ int sdqh_create(int device, sdqh_ctx** out) {
     return SDQH_OK;
 }
 
+int sdqh_fork(sdqh_ctx* parent, sdqh_ctx** out) {
+    if (!parent || !out) return SDQH_ERR_INVALID;
+    if (parent->parent) return fail(parent, SDQH_ERR_INVALID, "fork: fork the family's first context");
+    if (int rc = sdqh_create(parent->device, out)) return fail(parent, rc, "fork: no second context on this device");
+    (*out)->parent = parent; (*out)->threads = parent->threads;
+    parent->children.push_back(*out);
+    return SDQH_OK;
+}
+
 void sdqh_destroy(sdqh_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->parent) { auto& ch = ctx->parent->children; ch.erase(std::remove(ch.begin(), ch.end(), ctx), ch.end()); }
+    for (sdqh_ctx* c : ctx->children) c->parent = nullptr;           // (destroyed before its forks: they carry on alone)
     if (ctx->compile_only) { delete ctx; return; }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -649,6 +667,7 @@ static int new_column(sdqh_ctx* ctx, int64_t nrows, int dtype, int width, sdqh_c
     if (dtype != SDQH_I64 && dtype != SDQH_F64 && dtype != SDQH_STR) return fail(ctx, SDQH_ERR_INVALID, "column: bad dtype");
     if (dtype == SDQH_STR && width < 1) return fail(ctx, SDQH_ERR_INVALID, "column: STR needs width >= 1");
     sdqh_column* c = new sdqh_column();
+    c->home = ctx;
     c->nrows = nrows; c->dtype = dtype; c->width = dtype == SDQH_STR ? width : 0;
     *out = c;
     return SDQH_OK;
@@ -727,14 +746,19 @@ int sdqh_column_minmax(sdqh_ctx* ctx, const sdqh_column* col, int64_t* mn, int64
 void sdqh_column_free(sdqh_ctx* ctx, sdqh_column* col) {
     if (!col) return;
     if (ctx) {
-        for (size_t i = 0; i < ctx->packs.size();) {                 // a row pack does not outlive any of its columns
-            auto& pk = ctx->packs[i];
-            if (std::find(pk.cols.begin(), pk.cols.end(), (const void*)col->data) != pk.cols.end()) { pool_free(ctx, pk.data); ctx->packs.erase(ctx->packs.begin() + (long)i); }
-            else ++i;
-        }
-        if (col->owned) pool_free(ctx, col->data);
-        pool_free(ctx, col->d_minmax);
-        if (col->narrow) pool_free(ctx, col->narrow);
+        // a row pack does not outlive any of its columns — in whichever context of the family it was made
+        sdqh_ctx* root = ctx->parent ? ctx->parent : ctx;
+        std::vector<sdqh_ctx*> family{root};
+        family.insert(family.end(), root->children.begin(), root->children.end());
+        for (sdqh_ctx* m : family)
+            for (size_t i = 0; i < m->packs.size();) {
+                auto& pk = m->packs[i];
+                if (std::find(pk.cols.begin(), pk.cols.end(), (const void*)col->data) != pk.cols.end()) { pool_free(m, pk.data); m->packs.erase(m->packs.begin() + (long)i); }
+                else ++i;
+            }
+        if (col->owned) attach_free(ctx, col, col->data);
+        attach_free(ctx, col, col->d_minmax);
+        if (col->narrow) attach_free(ctx, col, col->narrow);
         column_codes_release(ctx, col);
     }
     delete col;
@@ -2504,7 +2528,7 @@ int sdqh_column_copy_in(sdqh_ctx* ctx, sdqh_column* col, int64_t row0, int64_t n
     (void)hipSetDevice(ctx->device);
     HIP_TRY(ctx, hipMemcpyAsync(static_cast<char*>(col->data) + (size_t)row0 * 8, src, (size_t)nrows * 8, hipMemcpyDeviceToDevice, ctx->stream));
     col->have_minmax = false; col->minmax_pending = false; col->clustered = -1; col->increasing = -1;
-    if (col->narrow) { pool_free(ctx, col->narrow); col->narrow = nullptr; }
+    if (col->narrow) { attach_free(ctx, col, col->narrow); col->narrow = nullptr; }
     col->narrow_state = -1;
     column_codes_release(ctx, col);
     return ctx->opt_async_copies ? SDQH_OK : sync_stream(ctx);

@@ -36,6 +36,9 @@ using namespace sdqh;
 
 struct sdqh_ctx {
     int device = 0;
+    // sdqh_fork: contexts of one family share their columns (each has its own stream, pool and result blocks)
+    sdqh_ctx* parent = nullptr;
+    std::vector<sdqh_ctx*> children;
     bool compile_only = false;                     // sdqh_create(-1): no GPU behind this ctx; sdqh_x* calls stop after specialising their kernel (build check)
     int num_cu = 256;
     hipStream_t stream = nullptr;
@@ -136,6 +139,7 @@ struct sdqh_ctx {
 };
 
 struct sdqh_column {
+    sdqh_ctx* home = nullptr;          // the context that created the column: its attachments (twins, dictionaries, statistics) live in THAT pool, whichever context of the family builds them
     void* data = nullptr;
     int64_t nrows = 0;
     int dtype = SDQH_I64;
@@ -201,6 +205,10 @@ void call_end(sdqh_ctx* ctx);
 hipEvent_t next_event(sdqh_ctx* ctx);
 int sync_stream(sdqh_ctx* ctx);
 void* tb_alloc(sdqh_ctx* ctx, sdqh_table* t, size_t bytes);
+// memory attached to a column (see sdqh_column::home); a context other than the home waits for the home's stream first — a recycled block
+// of that pool is only safe behind the work queued there
+void* attach_alloc(sdqh_ctx* ctx, const sdqh_column* c, size_t bytes);
+void attach_free(sdqh_ctx* ctx, const sdqh_column* c, void* p);
 void tb_release(sdqh_ctx* ctx, sdqh_table* t);
 // stage arrays of a build whose key / payload the kernel computes itself (no source columns)
 int stage_setup_computed(sdqh_ctx* ctx, sdqh_table* tb, int64_t nrows, int npay, int batch);

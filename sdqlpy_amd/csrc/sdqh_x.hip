@@ -1638,7 +1638,7 @@ int sdqh_table_columns(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_hits
         void* src = c == 0 ? (void*)o.keys : c <= npay ? (void*)o.pay[c - 1] : is_acc ? (acc < nval ? (void*)o.val[acc] : table->zero_rows) : (void*)o.hits;
         sdqh_column* col = new (std::nothrow) sdqh_column();
         if (!col) { for (int j = 0; j < c; ++j) { delete out_cols[j]; out_cols[j] = nullptr; } return fail(ctx, SDQH_ERR_NOMEM, "table_columns: out of host memory"); }
-        col->data = src; col->nrows = n; col->dtype = is_acc ? SDQH_F64 : SDQH_I64; col->owned = false; col->transient = true;
+        col->home = ctx; col->data = src; col->nrows = n; col->dtype = is_acc ? SDQH_F64 : SDQH_I64; col->owned = false; col->transient = true;
         col->narrow_state = 0; col->code_state = 0; col->clustered = 0; col->increasing = 0;
         out_cols[c] = col;
     }

@@ -386,9 +386,9 @@ class DistributedRunner:
         self._partitioned_result = False
         if len(whole) == len(plan.params):
             # nothing is sharded: every rank holds the whole database and computes the whole answer
-            return engine.execute_plan(self.eng, plan, args, self._top)
+            return engine.execute_plan(self.eng, plan, args, self._top, lane=0)
         if shape == "scalar":
-            local = engine.execute_plan(self.eng, plan, args)
+            local = engine.execute_plan(self.eng, plan, args, lane=0)
             parts = self._all_gather_array(np.array([local], np.float64))
             total = 0.0
             for p in parts:                                   # fixed (rank) order
@@ -718,7 +718,7 @@ class DistributedRunner:
         all_gather (header + schema + rows, 8 KiB) and are folded in rank order."""
         op = plan.ops[0]
         nkey = len(op.key.fields) if isinstance(op.key, RecordCons) else 1
-        local = engine.execute_plan(self.eng, plan, args)      # ResultSet of this shard's groups
+        local = engine.execute_plan(self.eng, plan, args, lane=0)      # ResultSet of this shard's groups
         cap, maxc = abi.MAX_SMALL_GROUPS, 16
         n = local.size() if local is not None else 0
         buf = np.zeros(2 + maxc + cap * maxc, np.int64)
@@ -920,7 +920,7 @@ class DistributedRunner:
             st = cache[key] = self._prepare_join(plan, args, a_whole)
         self.last_partitioning = st.mode
         self.exchanged_bytes = 0
-        pp = engine.prepared_plan(eng, plan, args)
+        pp = engine.prepared_plan(eng, plan, args, lane=0)          # (the collectives are ordered on the first context's stream)
         a_op, b_op, c_op, f_op = plan.ops
         keep = []
 

@@ -81,7 +81,24 @@ def reset_default_engine():
     _engine = None
 
 
+class _Lane:
+    """An Engine as one of its lanes sees it: the engine's columns, caches and switches, and a context of its own for the calls."""
+
+    def __init__(self, eng, ctx, index):
+        object.__setattr__(self, "_eng", eng)
+        object.__setattr__(self, "ctx", ctx)
+        object.__setattr__(self, "lane_index", index)
+
+    def __getattr__(self, name):
+        return getattr(self._eng, name)
+
+    def __setattr__(self, name, value):
+        setattr(self._eng, name, value)
+
+
 class Engine:
+    lane_index = 0
+
     def __init__(self, ctx):
         self.ctx = ctx
         self._columns = {}         # id(ndarray) -> (ndarray, abi.Column)
@@ -111,6 +128,35 @@ class Engine:
         # gathers nothing.  Measured per kind in profiles/r03_ab_tuned_vs_programs.txt.
         routes = os.environ.get("SDQLPY_AMD_PROGRAM_ROUTES", "probe,values,lookups")
         self.program_routes = {r for r in routes.split(",") if r} if ctx.library.backend_name() == "hip-gfx950" else set()
+        # LANES: contexts of one family (abi.Context.fork — own stream, pool and result blocks, the engine's columns shared).  Every
+        # prepared plan is bound to one, round robin, so that queries launched without being waited for (deferred results) share the
+        # chip: one query's small dependent launches run under another's streaming kernel instead of queueing behind it on one stream
+        # (bench step q1 + q3 + q5: 0.83 -> 0.57 ms, tools/step_lanes.py).  A query that is waited for before the next is launched
+        # gains and loses nothing.  SDQLPY_AMD_LANES=1: one stream, as before.
+        lanes = os.environ.get("SDQLPY_AMD_LANES", "")
+        self.nlanes = max(1, int(lanes)) if lanes else (3 if ctx.library.backend_name() == "hip-gfx950" else 1)
+        self._lane_views = {}
+        self._lane_next = 0
+
+    def lane(self, k):
+        """The engine as lane k sees it (k = 0: the engine itself)."""
+        if k <= 0 or self.nlanes <= 1:
+            return self
+        view = self._lane_views.get(k)
+        if view is None:
+            while len(self.ctx.forks) < k:
+                self.ctx.fork()
+            view = self._lane_views[k] = _Lane(self, self.ctx.forks[k - 1], k)
+        return view
+
+    def next_lane(self):
+        k = self._lane_next % max(1, self.nlanes)
+        self._lane_next += 1
+        return k
+
+    def synchronize(self):
+        """Everything launched through this engine, on whichever lane, has run."""
+        self.ctx.synchronize()
 
     def close(self):
         self.clear()
@@ -1894,17 +1940,24 @@ def at_name(prepared, i):
     return prepared.steps[i][0]
 
 
-def prepared_plan(eng, plan, args):
-    """The plan bound to this engine and these tables (prepared once, reused while the engine's columns are the same)."""
+def prepared_plan(eng, plan, args, lane=None):
+    """The plan bound to this engine and these tables (prepared once, reused while the engine's columns are the same), on one of the
+    engine's lanes: `lane`, or the one the plan was given when it first ran here (round robin over the engine's lanes)."""
+    eng = getattr(eng, "_eng", eng)
     cache = plan.__dict__.setdefault("_prepared", {})
-    key = (id(eng),) + tuple(id(a) for a in args)
+    if lane is None:
+        lanes = plan.__dict__.setdefault("_lanes", {})
+        lane = lanes.get(id(eng))
+        if lane is None or lane >= eng.nlanes:
+            lane = lanes[id(eng)] = eng.next_lane()
+    key = (id(eng), lane) + tuple(id(a) for a in args)
     prepared = cache.get(key)
     if prepared is None or prepared.generation != eng.generation or any(x is not y for x, y in zip(prepared.args, args)):
         if len(cache) > 16:
             cache.clear()
-        prepared = cache[key] = PreparedPlan(eng, plan, args)
+        prepared = cache[key] = PreparedPlan(eng.lane(lane), plan, args)
     return prepared
 
 
-def execute_plan(eng, plan, args, top=None, after=None):
-    return prepared_plan(eng, plan, args).run(top, after=after)
+def execute_plan(eng, plan, args, top=None, after=None, lane=None):
+    return prepared_plan(eng, plan, args, lane=lane).run(top, after=after)

@@ -19,6 +19,29 @@ _spec.loader.exec_module(make_golden)
 _db_cache = {}
 
 
+class spy_calls:
+    """Record the calls of one abi.Context method while a block runs — on the class, so that the calls of every lane of an engine
+    (contexts of one family, engine.Engine.lane) are seen.  `calls` gets one note(*args, **kwargs) entry per call."""
+
+    def __init__(self, method, note=lambda *a, **k: 1):
+        from sdqlpy_amd import abi
+        self.cls, self.method, self.note, self.calls = abi.Context, method, note, []
+
+    def __enter__(self):
+        self.real = real = getattr(self.cls, self.method)
+        calls, note = self.calls, self.note
+
+        def wrapped(ctx, *a, **k):
+            calls.append(note(*a, **k))
+            return real(ctx, *a, **k)
+        setattr(self.cls, self.method, wrapped)
+        return self.calls
+
+    def __exit__(self, *exc):
+        setattr(self.cls, self.method, self.real)
+        return False
+
+
 def case_db(case):
     """Regenerate the inputs of a golden case and check they are the ones the reference saw."""
     key = (case["name"], tuple(sorted(case["results"])))
@@ -950,10 +973,9 @@ def dict_loop_cases(eng, case, rel=0.0):
     packed fields), q15 (a record set with looked-up text fields, with and without ORDER BY / LIMIT), q11 (a condition against a
     scalar).  Asserts that the entries really were read as resident columns (sdqh_table_columns)."""
     db = case_db(case)
-    calls = []
-    real = eng.ctx.table_columns
-    eng.ctx.table_columns = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
     checked, on_device = 0, {}
+    watch = spy_calls("table_columns")
+    calls = watch.__enter__()
     try:
         for q in ("q16", "q15", "q11", "q2"):
             want = case["results"].get(q)
@@ -984,7 +1006,7 @@ def dict_loop_cases(eng, case, rel=0.0):
                 checked += 1
     finally:
         eng.dict_programs = True
-        eng.ctx.table_columns = real
+        watch.__exit__()
     return checked, on_device
 
 
@@ -1014,13 +1036,8 @@ def dense_domain_case(eng, ncust=3000, nord=40000, seed=5):
     orders = sdql_lib.table_from_columns(["o_custkey", "o_totalprice"], [o_cust, o_price])
     customer = sdql_lib.table_from_columns(["c_custkey"], [custkeys])
     plan = frontend.lower_source(DENSE_DOMAIN_SRC, None, 1, None)
-    built = []
-    real = eng.ctx.hash_build_unique
-    eng.ctx.hash_build_unique = lambda n, *a, **k: (built.append((n, k.get("accumulate", False))), real(n, *a, **k))[1]
-    try:
+    with spy_calls("hash_build_unique", lambda n, *a, **k: (n, k.get("accumulate", False))) as built:
         res = eng_mod.execute_plan(eng, plan, [orders, customer])
-    finally:
-        eng.ctx.hash_build_unique = real
     assert (ncust, True) in built, built                                # the domain build: one entry per key of the range, with accumulators
     keep = o_price > 10.0
     assert res["members"] == float(len(np.unique(o_cust[keep]))) and res["all"] == float(ncust), res

@@ -394,17 +394,15 @@ def test_sums_over_result_dictionaries_run_as_device_loops(hip_engine, golden_wi
     assert n >= 12 and all(on_device.get(q, 0) >= 2 for q in ("q16", "q15", "q11")), on_device
     qs = ("q16", "q15", "q11", "q2")                        # (q2's 470 offers at SF 1 are a table; at the golden sizes they come back as host groups)
     db = tpch.generate(1.0, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
-    calls = []
-    real = hip_engine.ctx.table_columns
-    hip_engine.ctx.table_columns = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
-    try:
+    with helpers.spy_calls("table_columns") as calls:
         for q in qs:
-            got, want = helpers.run_query(hip_engine, q, db), helpers.run_query(oracle_engine, q, db)
-            assert want.size() > 0 and calls, q
+            got = helpers.run_query(hip_engine, q, db)
+            assert calls, q
+            del calls[:]
+            want = helpers.run_query(oracle_engine, q, db)
+            assert want.size() > 0, q
             helpers.assert_rows_match(helpers.result_rows(got, want.columns), helpers.result_rows(want, want.columns), REL, "sf1 dict loop/" + q)
             del calls[:]
-    finally:
-        hip_engine.ctx.table_columns = real
     hip_engine.clear()
     oracle_engine.clear()
 

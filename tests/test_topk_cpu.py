@@ -63,13 +63,9 @@ def test_query_top_equals_ordering_the_full_result(oracle, q):
 def test_q3_top10_runs_on_the_device_operator(oracle):
     db = tpch.generate(0.02, tables=["lineitem", "customer", "orders"], columns=tpch.columns_for(("q3",)))
     plan = frontend.lower_function(Q.QUERIES["q3"].__sdql_func__, Q.QUERIES["q3"].__sdql_in_type__)
-    calls = []
-    real = oracle.ctx.table_topk
-    oracle.ctx.table_topk = lambda *a, **kw: (calls.append(a[2:4]), real(*a, **kw))[1]
-    try:
+    import helpers
+    with helpers.spy_calls("table_topk", lambda *a, **kw: a[2:4]) as calls:
         engine.execute_plan(oracle, plan, [db[t] for t in Q.QUERY_TABLES["q3"]], top=Q.TPCH_ORDER["q3"])
-    finally:
-        del oracle.ctx.table_topk
     assert calls == [(10, [(abi.SORT_VALUE, 0, True, True), (abi.SORT_PAYLOAD, 0, False, False)])]
 
 
@@ -107,9 +103,9 @@ def test_q10_group_sharing_and_host_fold_agree(oracle, monkeypatch):
     plan = frontend.lower_function(Q.q10.__sdql_func__, Q.q10.__sdql_in_type__)
     args = [db[t] for t in Q.QUERY_TABLES["q10"]]
     calls = []
-    real_share, real_topk = oracle.ctx.table_share_groups, oracle.ctx.table_topk
-    monkeypatch.setattr(oracle.ctx, "table_share_groups", lambda *a: (calls.append("share"), real_share(*a))[1])
-    monkeypatch.setattr(oracle.ctx, "table_topk", lambda *a, **k: (calls.append("topk"), real_topk(*a, **k))[1])
+    real_share, real_topk = abi.Context.table_share_groups, abi.Context.table_topk       # (on the class: whichever lane of the engine runs the plan)
+    monkeypatch.setattr(abi.Context, "table_share_groups", lambda ctx, *a: (calls.append("share"), real_share(ctx, *a))[1])
+    monkeypatch.setattr(abi.Context, "table_topk", lambda ctx, *a, **k: (calls.append("topk"), real_topk(ctx, *a, **k))[1])
     want = engine.execute_plan(oracle, plan, args)
     top_want = engine.execute_plan(oracle, plan, args, top=Q.TPCH_ORDER["q10"])
     assert calls == ["share", "share", "topk"] and want.size() > 100

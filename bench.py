@@ -287,7 +287,7 @@ def main(argv=None, hooks=None):
     dom_model = [nb for q, name, _, nb in (waited_log if dom_launches is alone_launches else timed_log) if q == dom_q and name == dom_kernel and nb > 0]
     # per-kernel table: a separate pass with events around every launch, after the timed region
     profile_steps = max(1, min(args.steps, 10))
-    _, _, launch_log = run_steps(profile_steps, None)
+    _, _, launch_log = run_steps(profile_steps, None, each_waited_for=True)      # (one query at a time: a kernel's duration is its own)
     exchange = None
     if use_dist and "q3" in queries:
         # q3's redistribution step, both ways, outside `value`: what moved and what it cost
@@ -319,7 +319,7 @@ def main(argv=None, hooks=None):
             for _ in range(args.warmup):
                 run_query(q)
         took_x, extra_ms, _ = run_steps(extra_steps, "-", extra, each_waited_for=True)
-        _, _, extra_log = run_steps(extra_steps, None, extra)
+        _, _, extra_log = run_steps(extra_steps, None, extra, each_waited_for=True)
     # the timed region is args.steps steps (the driver fixes 20: 15 ms); the same step for ~1 s of back-to-back work, outside `value`:
     # is the figure steady state or a burst out of warm caches?
     steady = None
@@ -399,7 +399,7 @@ def main(argv=None, hooks=None):
             if all(step_bytes):
                 roofline["step"] = {"physical_bytes": int(sum(step_bytes)), "ms_per_step": round(ms_per_step, 4),
                                     "frac": round(sum(step_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                    "frac_each_query_waited_for": round(sum(step_bytes) / (elapsed_waited / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "frac_each_query_waited_for": round(sum(step_bytes) / (elapsed_waited / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                                     "traffic_source": "per-query PMC bytes (profiles/), wall time of this run"}
             if reference_width and dom_q in reference_width.get("queries", {}):
                 rw = reference_width["queries"][dom_q]
@@ -442,7 +442,7 @@ def main(argv=None, hooks=None):
                      "ms_per_step_each_query_waited_for": round(elapsed_waited / args.steps * 1e3, 4),
                      "value_each_query_waited_for": round(total_rows_per_step * args.steps / elapsed_waited, 1)},
             "ms_per_query": per_query,
-            "kernels_pass": "separate pass of %d steps after the timed region, HIP events around every launch" % profile_steps,
+            "kernels_pass": "separate pass of %d steps after the timed region, every query waited for before the next starts, HIP events around every launch" % profile_steps,
             "kernels": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in sorted(kernels.items())},
             "roofline": roofline,
             "first_pass_with_upload_s": round(first_pass_s, 3), "generate_s": round(gen_s, 2),
@@ -517,7 +517,7 @@ def reference_width_leg(args, eng, db, rows, ran, run_query, run_steps, finish):
             for q in qs:
                 finish(run_query(q))
         took, per_q, _ = run_steps(n, "-", qs, each_waited_for=True)
-        _, _, log = run_steps(n, None, qs)
+        _, _, log = run_steps(n, None, qs, each_waited_for=True)
         for q in qs:
             stat = {}
             for qq, name, ms, nb in log:

@@ -353,6 +353,7 @@ class Context:
         self.forks = []
         self._options = {}             # options set so far (a fork starts with its parent's)
         self._profiling = False
+        self._prof_mode, self._prof_only = 0, None
         self.kernel_log = []       # [(kernel name, ms)] of every pattern call since the log was cleared (profiling on)
         self.device_log = []       # [(pattern call, device ms)]
         self._check(self.lib.sdqh_set_threads(self.handle, C.c_int(max(1, threads))))
@@ -369,6 +370,8 @@ class Context:
         child = Context(self.library, self.device, 1, _parent=self)
         for name, value in self._options.items():
             child.set_option(name, value)
+        if self._prof_mode:
+            child.set_profiling(self._prof_mode, self._prof_only)
         child.kernel_log, child.device_log = self.kernel_log, self.device_log
         self.forks.append(child)
         return child
@@ -469,6 +472,7 @@ class Context:
         self._check(self.lib.sdqh_set_profile_filter(self.handle, only.encode() if only else None))
         self._check(self.lib.sdqh_set_profiling(self.handle, C.c_int(mode)))
         self._profiling = mode == 1
+        self._prof_mode, self._prof_only = mode, only
         self.kernel_log, self.device_log = [], []
         for child in self.forks:                                   # the family is profiled as one: the forks write this context's logs
             child.set_profiling(mode, only)

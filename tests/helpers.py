@@ -1215,3 +1215,49 @@ def xcompact_case(ctx, n=70001, seed=33):
             checked += 1
     kset.free()
     return checked
+
+
+def lanes_case(lib, sf=0.05, rounds=6, queries=("q1", "q3", "q5", "q6", "q9", "q4", "q14"), rel=0.0, threads=1, tight=False):
+    """Engine lanes (contexts of one family, abi.Context.fork): the queries launched together, round after round, on an engine with
+    three lanes against the same plans on an engine with one — same rows every round; the lanes really were used; the family's
+    options follow the first context's; columns forgotten and uploaded again between rounds (twins and dictionaries are rebuilt by
+    whichever lane gets there first).  Returns the lanes the plans ran on."""
+    db = tpch.generate(sf, tables=sorted(tpch.columns_for(queries)), columns=tpch.columns_for(queries))
+    one = eng_mod.Engine(lib.context(threads=threads))
+    many = eng_mod.Engine(lib.context(threads=threads))
+    one.nlanes, many.nlanes = 1, 3
+    try:
+        if tight:
+            for e in (one, many):
+                e.ctx.set_option("feature_min_rows", 0)
+        plans = {q: frontend.lower_function(Q.QUERIES[q].__sdql_func__, Q.QUERIES[q].__sdql_in_type__) for q in queries}
+        args = {q: [db[t] for t in Q.QUERY_TABLES[q]] for q in queries}
+
+        def rows_of(r):
+            if hasattr(r, "wait"):
+                r.wait()
+            if hasattr(r, "columns"):
+                return sorted(zip(*[r.column(c).tolist() for c in r.columns]))
+            return r
+        want = {q: rows_of(eng_mod.execute_plan(one, plans[q], args[q])) for q in queries}
+        used = set()
+        for rnd in range(rounds):
+            launched = [(q, eng_mod.execute_plan(many, plans[q], args[q])) for q in queries]            # all in flight, then read in reverse
+            for q, r in reversed(launched):
+                got = rows_of(r)
+                if hasattr(r, "columns"):
+                    assert_rows_match(got, want[q], rel, "lanes round %d %s" % (rnd, q))
+                else:
+                    assert got == want[q] or abs(got - want[q]) <= rel * abs(want[q]), (q, got, want[q])
+            used |= {eng_mod.prepared_plan(many, plans[q], args[q]).eng.lane_index for q in queries}
+            if rnd == rounds // 2:
+                many.clear()                                                 # columns, twins, dictionaries gone: the next round uploads again
+            if rnd == 1 and tight:
+                many.ctx.set_option("feature_min_rows", 1 << 20)             # ... the forks follow
+                assert all(c._options.get("feature_min_rows") == 1 << 20 for c in many.ctx.forks)
+                many.ctx.set_option("feature_min_rows", 0)
+        assert len(many.ctx.forks) == 2 and used == {0, 1, 2}, (len(many.ctx.forks), used)
+        return used
+    finally:
+        many.close()
+        one.close()

@@ -282,3 +282,26 @@ def test_packed_exchange_helpers_on_the_cpu_implementation(oracle_lib):
         assert helpers.xcompact_case(ctx, n=1, seed=2) == 8
     finally:
         ctx.close()
+
+
+def test_context_families_share_columns_on_the_cpu_implementation(oracle_lib):
+    """sdqh_fork: a forked context names its parent's columns; engine lanes on top of it give the rows one lane gives."""
+    import numpy as np
+    import helpers
+    ctx = oracle_lib.context(threads=2)
+    try:
+        child = ctx.fork()
+        a = np.arange(1000, dtype=np.int64)
+        v = np.arange(1000, dtype=np.float64) / 4
+        ca, cv = ctx.upload(a), ctx.upload(v)
+        flt = abi.make_filter(ipreds=[(ca, 10, 499)])
+        want = ctx.scan_filter_sum(1000, flt, abi.make_tuple(abi.TUPLE_A, [cv]))
+        got = child.scan_filter_sum(1000, flt, abi.make_tuple(abi.TUPLE_A, [cv]))
+        assert got == want and got[1] == 490
+        with pytest.raises(abi.SdqhError):
+            child.fork()                                            # the family's first context forks
+        child.close()
+        assert ctx.forks == []
+    finally:
+        ctx.close()
+    assert helpers.lanes_case(oracle_lib, sf=0.02, rounds=4) == {0, 1, 2}

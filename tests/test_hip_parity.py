@@ -1194,3 +1194,15 @@ def test_sf100_on_one_gpu_q5_q9(hip_engine):
                 assert abs(a - b) <= 1e-9 * max(abs(a), abs(b), 1.0), (q, k, a, b)
         hip_engine.clear()
         del db, li, whole, again
+
+
+@pytest.mark.gpu
+def test_lanes_give_the_rows_one_stream_gives(hip_lib):
+    """Round 4: an engine runs its plans on three lanes — contexts of one family (sdqh_fork), a stream, a pool and result blocks each,
+    the resident columns shared — so that queries launched together share the chip.  Seven queries in flight at once, round after
+    round, against one lane: the same rows (sums within REL: atomics order); with the tight encodings on at every size the twins and
+    dictionaries are built by whichever lane first needs them and used by the others; at SF=1 the kernels are long enough to
+    overlap for real."""
+    assert helpers.lanes_case(hip_lib, sf=0.05, rounds=6, rel=REL) == {0, 1, 2}
+    assert helpers.lanes_case(hip_lib, sf=0.05, rounds=6, rel=REL, tight=True) == {0, 1, 2}
+    assert helpers.lanes_case(hip_lib, sf=1.0, rounds=8, rel=REL, queries=("q1", "q3", "q5", "q9", "q18", "q10")) == {0, 1, 2}

@@ -12,6 +12,11 @@ python3 bench.py --no-cpu-baseline > $OUT/bench_for_rows.json 2> $OUT/bench_for_
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --extra-queries "" > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
 python3 tools/pmc_summary.py $OUT/trace > $OUT/kernel_trace_summary.txt 2>&1
 find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
+# the same with ONE lane (queries of a step one behind the other on one stream): there every launch of a kernel has the chip to itself,
+# and the average duration in the stats is the kernel's own (under the default the overlapped steps' launches share the chip)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_lanes1 -- python3 bench.py --no-cpu-baseline --extra-queries "" --lanes 1 > $OUT/bench_under_rocprof_lanes1.json 2> $OUT/trace_lanes1.log
+python3 tools/pmc_summary.py $OUT/trace_lanes1 > $OUT/kernel_trace_summary_lanes1.txt 2>&1
+find $OUT/trace_lanes1 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_lanes1.csv
 ITERS=5
 for q in q1 q3 q5 q6 q9; do
   for c in FETCH_SIZE WRITE_SIZE; do

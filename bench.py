@@ -263,7 +263,7 @@ def main(argv=None, hooks=None):
 
     if runner is not None:
         runner.reset_collectives()
-    elapsed, _, timed_log = run_steps(args.steps, dom_kernel)
+    elapsed, launch_host_ms, timed_log = run_steps(args.steps, dom_kernel)
     # the same steps with every query's result finished before the next query starts: per-query wall times, and the step as a caller
     # who reads each result at once sees it
     # (the dominant kernel's launches are evented here too: in this region a kernel has the chip to itself — in the first, the queries'
@@ -439,6 +439,8 @@ def main(argv=None, hooks=None):
             "lanes": nlanes,
             "value_overlapped": round(value, 1), "value_sequential": round(total_rows_per_step * args.steps / elapsed_waited, 1),
             "step": {"launch_then_finish": True, "launch_order": step_order(queries), "deferred_results": bool(getattr(eng, "deferred_results", False)),
+                     # host time to LAUNCH each query of an overlapped step (plan closures, ctypes calls, kernel launches; nothing waited for)
+                     "host_launch_ms": {q: round(launch_host_ms[q] / args.steps, 4) for q in queries},
                      "ms_per_step_each_query_waited_for": round(elapsed_waited / args.steps * 1e3, 4),
                      "value_each_query_waited_for": round(total_rows_per_step * args.steps / elapsed_waited, 1)},
             "ms_per_query": per_query,

@@ -5,6 +5,7 @@ product (engine.py) only ever loads sdqlpy_amd/csrc/libsdqlhip.so; the test-suit
 oracle through the same class to compare the two implementations call for call.
 """
 import ctypes as C
+import threading
 import weakref
 import math
 
@@ -361,6 +362,7 @@ class Context:
         self._host_quarantine = [] # (address, bytes) of released blocks a queued result copy may still write (host_block)
         self._deferred_quarantine = []  # the same for blocks that kernels still queued on the stream may write (synchronize)
         self._sync_epoch = 0            # full synchronisations of the context so far
+        self._pool_lock = threading.RLock()   # the pools above: blocks are released by whichever thread drops the last view of a result
 
     def fork(self):
         """A context of this one's family (sdqh_fork): calls on it run concurrently with this one's and may name this one's columns.
@@ -408,14 +410,16 @@ class Context:
         if self._host_quarantine:
             # blocks whose arrays died while a result copy might still have been landing in them: usable once the copies are done
             # (they are, by the time another result is asked for; waiting when the block was RELEASED stalled every query on its own copy)
+            with self._pool_lock:
+                waiting, self._host_quarantine = self._host_quarantine, []
             self._check(self.lib.sdqh_result_wait(self.handle))
-            for a, sz in self._host_quarantine:
-                self._host_pool.setdefault(sz, []).append(a)
-            del self._host_quarantine[:]
-        free = self._host_pool.get(size)
-        if free:
-            addr = free.pop()
-        else:
+            with self._pool_lock:
+                for a, sz in waiting:
+                    self._host_pool.setdefault(sz, []).append(a)
+        with self._pool_lock:
+            free = self._host_pool.get(size)
+            addr = free.pop() if free else None
+        if addr is None:
             p = C.c_void_p()
             self._check(self.lib.sdqh_host_alloc(self.handle, C.c_size_t(size), C.byref(p)))
             addr = p.value
@@ -431,12 +435,13 @@ class Context:
             # a result copy may still be landing in the block (host_block waits for the copies) / kernels still queued may write it:
             # not if its result was collected (done), nor if the context has been synchronised since the block was handed out; else
             # the next synchronize returns it to the pool
-            if launched_at is None:
-                ctx._host_quarantine.append((addr, size))
-            elif (done is not None and done[0]) or ctx._sync_epoch > launched_at:
-                ctx._host_pool.setdefault(size, []).append(addr)
-            else:
-                ctx._deferred_quarantine.append((addr, size))
+            with ctx._pool_lock:
+                if launched_at is None:
+                    ctx._host_quarantine.append((addr, size))
+                elif (done is not None and done[0]) or ctx._sync_epoch > launched_at:
+                    ctx._host_pool.setdefault(size, []).append(addr)
+                else:
+                    ctx._deferred_quarantine.append((addr, size))
         else:
             lib.sdqh_host_free(None, C.c_void_p(addr))
 
@@ -453,11 +458,12 @@ class Context:
         for child in self.forks:
             child.synchronize()
         self._check(self.lib.sdqh_synchronize(self.handle))
-        self._sync_epoch += 1
-        if self._deferred_quarantine:                             # nothing queued before this point can write them any more
-            for addr, size in self._deferred_quarantine:
-                self._host_pool.setdefault(size, []).append(addr)
-            del self._deferred_quarantine[:]
+        with self._pool_lock:
+            self._sync_epoch += 1
+            if self._deferred_quarantine:                         # nothing queued before this point can write them any more
+                for addr, size in self._deferred_quarantine:
+                    self._host_pool.setdefault(size, []).append(addr)
+                del self._deferred_quarantine[:]
 
     def last_device_ms(self):
         ms = C.c_double()

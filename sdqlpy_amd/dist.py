@@ -51,6 +51,7 @@ from .result import ResultSet
 class DistributedRunner:
     def __init__(self, eng, rank, world, group=None, device=None, partition="auto", prefilter=True):
         self.eng, self.ctx = eng, eng.ctx
+        eng.nlanes = 1                                          # collectives and kernels are ordered on ONE stream
         self.rank, self.world, self.group = rank, world, group
         self.backend = dist.get_backend(group)
         if device is None:

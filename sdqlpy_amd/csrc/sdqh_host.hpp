@@ -103,6 +103,7 @@ struct sdqh_ctx {
                                         // copy (measured: 64 workgroups of write-through stores 0.85 ms a step against 0.79 — the runtime's blit kernel stays)
     int opt_copy_nt = 1;
     int opt_row_index = 1;              // unique builds keyed by a strictly increasing column: the stage kernel writes the word -> stage row index itself (no rank / insert passes)
+    int opt_grouped_index = 1;                     // composite-key builds over a table stored in the order of the key's first part: the GROUPED layout (DevTable) instead of hash slots
     int opt_lane_int = 1;               // the per-lane group sink sums an integer-valued byte-coded column as an integer beside the row count (XGroupLane)
     int opt_lane_resident = 2;          // workgroups per CU the per-lane group sink's grid is sized for
     int opt_window = 0;                 // x_queue8's 32-bit prefilter tests a lane's 8 rows against ONE 16-byte window of the bitmap when the key column's 8-row spans allow (column_span8): measured
@@ -151,6 +152,7 @@ struct sdqh_column {
     void* narrow = nullptr;            // 4-byte twin (int32 values / two-decimal doubles x 100), verified exact when built; see ensure_narrow
     int narrow_state = -1;             // -1 not tried, 0 the column does not narrow exactly, 1 twin present
     int increasing = -1;               // -1 unknown; 1: strictly increasing (sorted, no duplicates), 0: not — checked once on the device
+    int nondecreasing = -1;            // -1 unknown; 1: never decreasing (the table is stored in this column's order: equal values are neighbours), 0: not
     int span8 = -1;                    // -1 unknown; 1: aligned groups of 8 consecutive rows span at most 96 values (sampled): a lane's 8 rows fit one 128-bit window of a key bitmap (sdqh_x.hip)
     int64_t mn = 0, mx = 0;
     // sorted-dictionary codes (sdqh_codes.hip): a column with at most 65 536 distinct values over a narrow integer / two-decimal

@@ -144,6 +144,16 @@ struct DevTable {
     int64_t* slots;           // hash layout, packed form (tables with payload): slot h = { key, payload 0, payload 1, stage row } in 32
                               //    bytes, so a probe that hits finds the key, the owner and the first two payload fields in ONE
                               //    cache line instead of four (keys[], rowref[], pay[0][], pay[1][]); keys / rowref are null then
+    // GROUPED layout (composite key (a << 32 | b) built from a table whose rows come in non-decreasing order of a — partsupp by part key):
+    // the entries of one a are consecutive stage rows (a run; a run that crosses a wave segment continues at the next segment's base), so
+    // the index is grp_first[a - bm_lo] = stage row of the run's first entry (NO_ROW: none), written by the stage kernel itself with a
+    // fire-and-forget atomicMin — no hash slots, no CAS (a returning CAS on scattered lines runs at ~11 G/s on this chip whatever the
+    // table's size: 50 us for Q9's 430 K entries, tools/microbench_insert.hip) — and a lookup walks the run comparing whole keys (first
+    // match = lowest build row: the reference's first-insert-wins).  grp_key = the stage's key array; a segment that is not full ends in
+    // an EMPTY_KEY entry: the walk goes on at the next segment's base.  bm (bm_shift 32) stays the pre-filter over a.
+    const uint32_t* grp_first;
+    const int64_t* grp_key;
+    int64_t grp_seg_rows, grp_cap;    // rows per stage segment; stage rows a walk may read (the build's rows + 1: the last segment's end mark)
 };
 
 // regions to set to a byte value each (k_fill; also the preamble of a build kernel that runs as ONE workgroup: see fill_in_block)
@@ -577,7 +587,7 @@ __device__ __forceinline__ int64_t table_find(const DevTable& t, int64_t key, ui
     // lookup of a latency-bound drain): the rank prefix of the word (direct layout), or the first hash slot (hash layout
     // behind a bitmap of the key's high part).  A miss wastes that request; the loops that call this mostly hit.
     const bool direct = t.bm && t.bm_shift == 0 && !t.bitmap_only;
-    const bool hashed = !t.bitmap_only && !(t.bm && t.bm_shift == 0);
+    const bool hashed = !t.bitmap_only && !(t.bm && t.bm_shift == 0) && !t.grp_first;
     uint64_t h = 0;
     int64_t k_first = EMPTY_KEY;
     if (t.bm) {
@@ -586,9 +596,30 @@ __device__ __forceinline__ int64_t table_find(const DevTable& t, int64_t key, ui
         const uint32_t word = t.bm[off >> 5];
         uint32_t pre = 0;
         if (direct) pre = t.wprefix[off >> 5];
+        if (t.grp_first) pre = t.grp_first[off];
         if (hashed) { h = hash_key(key) & cap_mask; k_first = slot_key(t, h); }
         if (!((word >> (off & 31)) & 1u)) return -1;
         if (t.bitmap_only) return 0;
+        if (t.grp_first) {                                                   // grouped: walk the run of the key's high part
+            int64_t p = (int64_t)pre;
+            if (pre == NO_ROW) return -1;
+            while (p < t.grp_cap) {
+                // four entries of the run per round trip (most runs are that short); what lies behind a run's end is read and never looked at
+                int64_t k[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) k[i] = t.grp_key[p + i < t.grp_cap ? p + i : t.grp_cap - 1];
+                bool jump = false;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (jump || p + i >= t.grp_cap) continue;
+                    if (k[i] == key) return p + i;
+                    if (k[i] == EMPTY_KEY) { p = ((p + i) / t.grp_seg_rows + 1) * t.grp_seg_rows; jump = true; continue; }
+                    if (((uint64_t)k[i] >> 32) != ((uint64_t)key >> 32)) return -1;
+                }
+                if (!jump) p += 4;
+            }
+            return -1;
+        }
         if (t.bm_shift == 0) {
             const uint32_t below = __popc(word & ((1u << (off & 31)) - 1u));
             if (t.wexc && (pre & ROW_INDEX_EXC)) {                           // row index, a word shared by two segments
@@ -610,9 +641,9 @@ __device__ __forceinline__ int64_t table_find(const DevTable& t, int64_t key, ui
     }
 }
 // stage index of the entry at an index position
-__device__ __forceinline__ bool table_is_direct(const DevTable& t) { return t.dense_arr || (t.bm && t.bm_shift == 0); }     // no hash slots: cap_mask unused
+__device__ __forceinline__ bool table_is_direct(const DevTable& t) { return t.dense_arr || (t.bm && t.bm_shift == 0) || t.grp_first; }     // no hash slots: cap_mask unused
 // (direct layout without an owner array: the increasing-key form, rank = row — k_rank_increasing)
-__device__ __forceinline__ uint32_t table_ref(const DevTable& t, int64_t pos) { return t.dense_arr ? (uint32_t)pos : (t.bm && t.bm_shift == 0 ? (t.dense_ref ? t.dense_ref[pos] : (uint32_t)pos) : slot_row(t, (uint64_t)pos)); }
+__device__ __forceinline__ uint32_t table_ref(const DevTable& t, int64_t pos) { return (t.dense_arr || t.grp_first) ? (uint32_t)pos : (t.bm && t.bm_shift == 0 ? (t.dense_ref ? t.dense_ref[pos] : (uint32_t)pos) : slot_row(t, (uint64_t)pos)); }
 
 // ---- row filter on a pair of rows --------------------------------------------------------------
 // Integer and double range predicates with their own columns, plus the optional string equality.
@@ -1141,6 +1172,7 @@ struct DevStage {
     int64_t lin_rb, lin_b0;               // linearised composite key (see DevTable)
     uint32_t* wrow;                       // ROW INDEX (see DevTable): per bitmap word the stage row of its first key, written while staging; or null
     SegFirst* seg_first;                  // [nseg] ... and every segment's first entry, for k_wrow_fixup
+    uint32_t* grp_first;                  // GROUPED layout (see DevTable): first stage row per high key part, NO_ROW-filled before the build; or null
 };
 
 // Row index, the writer's side: the entries a wave is about to store (one per lane, `active` lanes, increasing keys, consecutive stage
@@ -1307,7 +1339,7 @@ template <int NPAY> __device__ __forceinline__ int cfg_npay(const int32_t n) { i
 // column.  Merged atomics alone: Q3's orders build 0.128 -> 0.144 ms, the scan costs more than the atomics it saves.  With the
 // plain stores: wrong results at SF=1 — plain stores and memory-side atomics do not mix on one cache line.  One atomic per row stays.)
 template <int NPAY>
-__device__ __forceinline__ void stage_store(const DevStage& st, int64_t pos, int64_t key, const int64_t (&pay)[MAX_STAGE_COLS]) {
+__device__ __forceinline__ void stage_store(const DevStage& st, int64_t pos, int64_t key, const int64_t (&pay)[MAX_STAGE_COLS], bool opens_run = true) {
     st.key[pos] = key;
 #pragma unroll
     for (int q = 0; q < MAX_STAGE_COLS; ++q) if (q < cfg_npay<NPAY>(st.npay)) st.pay[q][pos] = pay[q];
@@ -1317,8 +1349,15 @@ __device__ __forceinline__ void stage_store(const DevStage& st, int64_t pos, int
         uint64_t off;
         if (bm_locate(st, key, off)) {
             atomicOr(&st.bm[off >> 5], 1u << (off & 31));     // fire and forget; duplicates show up as distinct < staged (k_rank_words)
+            // grouped layout: off = the high part's offset (bm_shift 32, no rectangle).  opens_run false: the caller knows the entry stored just
+            // before this one (the wave's previous kept lane) has the same high part — the run's first stage row is not this one
+            if (st.grp_first && opens_run) atomicMin(&st.grp_first[off], (uint32_t)pos);
         }
     }
+}
+// grouped layout: a segment that did not fill up ends in EMPTY_KEY (DevTable: the walk of a run goes on at the next segment's base)
+__device__ __forceinline__ void stage_end_segment(const DevStage& st, int seg, int64_t begin, int64_t count) {
+    if (st.grp_first && (count < st.seg_rows || seg == st.nseg - 1)) st.key[begin + count] = EMPTY_KEY;      // (a last segment that is all entries: the mark sits in the array's slack)
 }
 
 // PIPE (needs EAGER, one integer predicate and one probe at least): the next step's first-stage loads are requested at the
@@ -1623,6 +1662,12 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_dense_fill(const int64_t* __restrict__
 SDQH_KERNEL __launch_bounds__(TPB) void k_check_increasing(const int64_t* __restrict__ key, int64_t nrows, int* __restrict__ flag) {
     bool bad = false;
     for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r + 1 < nrows; r += (int64_t)gridDim.x * TPB) bad |= key[r] >= key[r + 1];
+    if (__ballot(bad) && lane_id() == 0) atomicOr(flag, 1);
+}
+// ... or at least never decreasing (a table stored in the order of this column: equal values are neighbours)?
+SDQH_KERNEL __launch_bounds__(TPB) void k_check_nondecreasing(const int64_t* __restrict__ key, int64_t nrows, int* __restrict__ flag) {
+    bool bad = false;
+    for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r + 1 < nrows; r += (int64_t)gridDim.x * TPB) bad |= key[r] > key[r + 1];
     if (__ballot(bad) && lane_id() == 0) atomicOr(flag, 1);
 }
 // Dense layout over a strictly increasing key column, in ONE pass: row r writes its own cell and NO_ROW into the cells up to
@@ -2512,7 +2557,14 @@ __global__ __launch_bounds__(TPB) void k_build_lookup(DevFilter f, DevLookups L,
             }
         }
         const uint64_t b = __ballot(keep);
-        if (keep) stage_store<-1>(st, out + __popcll(b & lt), key, pay);
+        bool opens_run = true;
+        if (st.grp_first) {                                               // the kept lane below mine holds the entry stored just before mine
+            const uint64_t lower = b & lt;
+            const int prev = lower ? 63 - __builtin_clzll(lower) : lane;
+            const int64_t prev_key = __shfl(key, prev, WAVE);
+            opens_run = !lower || ((uint64_t)prev_key >> 32) != ((uint64_t)key >> 32);
+        }
+        if (keep) stage_store<-1>(st, out + __popcll(b & lt), key, pay, opens_run);
         out += __popcll(b);
     };
     // queue entries: 32-bit offsets from the segment's first row (a segment is far shorter than 2^31 rows: the host checks)
@@ -2586,7 +2638,13 @@ __global__ __launch_bounds__(TPB) void k_build_lookup(DevFilter f, DevLookups L,
             qn = left;
         }
     }
-    if (lane == 0) st.seg_count[seg] = (uint32_t)(out - begin);
+    if (lane == 0) {
+        st.seg_count[seg] = (uint32_t)(out - begin);
+        stage_end_segment(st, seg, begin, out - begin);
+        // grouped layout: equal keys are not told apart while staging (a lookup meets the lowest build row first, which is the answer);
+        // whoever needs an entry's OWNER (K-F, sizes) asks the index row by row, as after a build that met duplicates
+        if (st.grp_first && seg == 0) st.hdr->has_dups = 1u;
+    }
     if (__ballot(bad) && lane == 0) atomicOr(flags, 2);
 }
 

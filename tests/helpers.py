@@ -1261,3 +1261,54 @@ def lanes_case(lib, sf=0.05, rounds=6, queries=("q1", "q3", "q5", "q6", "q9", "q
     finally:
         many.close()
         one.close()
+
+
+def grouped_index_case(ctx, n=200000, nprobe=500000, seed=17, keep=0.3, per_a=4):
+    """A composite-key build (a, b) -> payload over a table stored in the order of a (sdqh_build, nkey 2: the GROUPED layout on the GPU,
+    DevTable) with a build filter, duplicate (a, b) pairs (first build row wins), runs of one a that cross wave segments, first parts
+    whose every row is filtered out; probed through sdqh_lookup_aggregate (sum of the matched payload per small group, hit count)
+    and compacted (entries, size), against numpy.  Returns a digest that is the same on every implementation and layout."""
+    from sdqlpy_amd import abi
+    rng = np.random.default_rng(seed)
+    a = np.sort(rng.integers(5, 5 + max(n // per_a, 1), n)).astype(np.int64)              # non-decreasing, ~per_a rows per value, gaps
+    b = rng.integers(1, 50, n).astype(np.int64)                                             # few values: duplicates of (a, b) are common
+    cost = rng.integers(1, 1000, n).astype(np.float64)
+    flag = (rng.random(n) < keep).astype(np.int64)
+    ca, cb, cc, cf = ctx.upload(a), ctx.upload(b), ctx.upload(cost), ctx.upload(flag)
+    t = ctx.build(n, abi.make_filter(ipreds=[(cf, 1, 1)]), [], [abi.src_col(ca), abi.src_col(cb)], [abi.src_col(cc)])
+    # the reference semantics: first passing row of a key wins
+    first = {}
+    for i in np.nonzero(flag)[0]:
+        first.setdefault((int(a[i]), int(b[i])), i)
+    assert t.size() == len(first)
+    pa = rng.integers(0, 10 + max(n // per_a, 1), nprobe).astype(np.int64)
+    pb = rng.integers(0, 52, nprobe).astype(np.int64)
+    grp = rng.integers(0, 7, nprobe).astype(np.int64)
+    one = np.ones(nprobe, np.float64)
+    cpa, cpb, cg, c1 = ctx.upload(pa), ctx.upload(pb), ctx.upload(grp), ctx.upload(one)
+    keys, vals, cnts = ctx.lookup_aggregate(nprobe, abi.make_filter(), [(t, [abi.src_col(cpa), abi.src_col(cpb)])], [abi.src_col(cg)],
+                                            abi.TUPLE_AB, [abi.src_lookup(0, 0), abi.src_col(c1)])
+    want_sum, want_cnt = np.zeros(7), np.zeros(7, np.int64)
+    fa = np.array([k[0] for k in first], np.int64); fb = np.array([k[1] for k in first], np.int64); fi = np.array(list(first.values()), np.int64)
+    look = dict(zip(zip(fa.tolist(), fb.tolist()), fi.tolist()))
+    for x, y, g in zip(pa.tolist(), pb.tolist(), grp.tolist()):
+        i = look.get((x, y))
+        if i is not None:
+            want_sum[g] += cost[i]; want_cnt[g] += 1
+    got = {int(k[0]): (float(v[0]), int(c)) for k, v, c in zip(keys, vals, cnts)}
+    for g in range(7):
+        if want_cnt[g]:
+            assert got[g][1] == want_cnt[g] and abs(got[g][0] - want_sum[g]) <= 1e-9 * want_sum[g], (g, got.get(g), want_sum[g], want_cnt[g])
+    assert sum(1 for g in range(7) if want_cnt[g]) == len(got)
+    cols, m = ctx.table_entries(t)
+    ctx.synchronize()
+    ek, ec = cols[0].download(0, m), cols[1].download(0, m).view(np.float64)
+    assert m == len(first)
+    want_keys = np.sort((fa << 32) | fb)
+    order = np.argsort(ek)
+    assert np.array_equal(ek[order], want_keys)
+    assert np.array_equal(ec[order], cost[fi[np.argsort((fa << 32) | fb)]])
+    for c in cols + [ca, cb, cc, cf, cpa, cpb, cg, c1]:
+        c.free()
+    t.free()
+    return int(want_cnt.sum()), float(want_sum.sum()), len(first)

@@ -305,3 +305,14 @@ def test_context_families_share_columns_on_the_cpu_implementation(oracle_lib):
     finally:
         ctx.close()
     assert helpers.lanes_case(oracle_lib, sf=0.02, rounds=4) == {0, 1, 2}
+
+
+def test_composite_key_builds_over_sorted_first_parts_on_the_cpu_implementation(oracle_lib):
+    """The case the GPU build's grouped layout is for (helpers.grouped_index_case), on the CPU implementation: checked against numpy inside."""
+    import helpers
+    ctx = oracle_lib.context(threads=2)
+    try:
+        assert helpers.grouped_index_case(ctx, n=20000, nprobe=40000)[2] > 1000
+        assert helpers.grouped_index_case(ctx, n=3000, nprobe=5000, keep=0.02, per_a=1)[2] > 10
+    finally:
+        ctx.close()

@@ -1206,3 +1206,27 @@ def test_lanes_give_the_rows_one_stream_gives(hip_lib):
     assert helpers.lanes_case(hip_lib, sf=0.05, rounds=6, rel=REL) == {0, 1, 2}
     assert helpers.lanes_case(hip_lib, sf=0.05, rounds=6, rel=REL, tight=True) == {0, 1, 2}
     assert helpers.lanes_case(hip_lib, sf=1.0, rounds=8, rel=REL, queries=("q1", "q3", "q5", "q9", "q18", "q10")) == {0, 1, 2}
+
+
+@pytest.mark.gpu
+def test_grouped_layout_for_composite_keys(hip_engine, oracle_engine):
+    """Round 4: a composite-key build over a table stored in the order of the key's first part gets the GROUPED layout (one stage row
+    per first-part value, written while staging; a lookup walks the run): against numpy inside the helper and against the CPU
+    implementation's digest, with the layout on and off, at sizes where runs cross wave segments, with almost every row filtered
+    out (single-entry segments, empty segments), with one row per first part, and with the tight encodings forced on."""
+    ctx = hip_engine.ctx
+    cases = [dict(n=200000, nprobe=500000), dict(n=2000003, nprobe=3000000, seed=5, keep=0.05), dict(n=70001, nprobe=100000, keep=0.002, per_a=1),
+             dict(n=300, nprobe=1000, keep=0.9, per_a=50), dict(n=1000000, nprobe=1000000, seed=9, keep=1.0, per_a=2000),
+             dict(n=51200, nprobe=100000, seed=3, keep=1.0, per_a=3), dict(n=512, nprobe=2000, seed=4, keep=1.0, per_a=600)]      # (every segment full, the last one too)
+    try:
+        for kw in cases:
+            want = helpers.grouped_index_case(oracle_engine.ctx, **kw)
+            for grouped in (1, 0):
+                ctx.set_option("grouped_index", grouped)
+                assert helpers.grouped_index_case(ctx, **kw) == want, (kw, grouped)
+        ctx.set_option("grouped_index", 1)
+        ctx.set_option("feature_min_rows", 0)
+        assert helpers.grouped_index_case(ctx, **cases[0]) == helpers.grouped_index_case(oracle_engine.ctx, **cases[0])
+    finally:
+        ctx.set_option("grouped_index", 1)
+        ctx.set_option("feature_min_rows", 1 << 20)

@@ -1721,8 +1721,10 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_dense_fill_increasing(const int64_t* _
 // with the neighbouring waves and are ORed in.  15 MB written for Q9's orders instead of the dense array's 240 MB.
 constexpr int RANK_INC_WORDS = 1024;                                  // bitmap words a wave assembles per step (4 KiB)
 constexpr int RANK_INC_NB = 8;                                        // blocks of 64 rows per wave step: every key of the step is requested before any is used
-SDQH_KERNEL __launch_bounds__(TPB) void k_rank_increasing(const int64_t* __restrict__ key, int64_t nrows, int64_t lo, uint32_t* __restrict__ bm,
-                                                         uint32_t* __restrict__ wprefix, TableHeader* __restrict__ hdr) {
+// KT: the key column itself (int64_t) or its exact 4-byte twin (int32_t: half the bytes of the one pass this build is)
+template <class KT>
+__global__ __launch_bounds__(TPB) void k_rank_increasing(const KT* __restrict__ key, int64_t nrows, int64_t lo, uint32_t* __restrict__ bm,
+                                                        uint32_t* __restrict__ wprefix, TableHeader* __restrict__ hdr) {
     __shared__ uint32_t s_words[TPB / WAVE][RANK_INC_WORDS];
     uint32_t* words = s_words[threadIdx.x / WAVE];
     const int lane = lane_id();
@@ -1733,10 +1735,10 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_rank_increasing(const int64_t* __restr
         const int64_t r0 = step * ROWS;
         uint64_t o[NB];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) { const int64_t r = r0 + (int64_t)j * WAVE + lane; o[j] = r < nrows ? (uint64_t)(key[r] - lo) : 0; }
+        for (int j = 0; j < NB; ++j) { const int64_t r = r0 + (int64_t)j * WAVE + lane; o[j] = r < nrows ? (uint64_t)((int64_t)key[r] - lo) : 0; }
         const int64_t rlast = (r0 + ROWS <= nrows ? r0 + ROWS : nrows) - 1;
-        const uint64_t before = r0 > 0 ? (uint64_t)(key[r0 - 1] - lo) : ~0ull;                      // (uniform addresses)
-        const uint64_t wl = (uint64_t)(key[rlast] - lo) >> 5;
+        const uint64_t before = r0 > 0 ? (uint64_t)((int64_t)key[r0 - 1] - lo) : ~0ull;             // (uniform addresses)
+        const uint64_t wl = (uint64_t)((int64_t)key[rlast] - lo) >> 5;
         const uint64_t wf = __shfl(o[0], 0, WAVE) >> 5;
         // a row that is the first key of its bitmap word records its row number there
 #pragma unroll

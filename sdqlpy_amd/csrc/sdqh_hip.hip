@@ -678,6 +678,7 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "dense_increasing" && value >= 0 && value <= 1) ctx->opt_dense_increasing = (int)value;
     else if (n == "packed_slots" && (value == 0 || value == 1)) ctx->opt_packed_slots = (int)value;
     else if (n == "grouped_index" && (value == 0 || value == 1)) ctx->opt_grouped_index = (int)value;
+    else if (n == "index_inline" && (value == 0 || value == 1)) ctx->opt_index_inline = (int)value;
     else if (n == "groupby_regs" && (value == 0 || value == 4 || value == 8)) ctx->opt_groupby_regs = (int)value;
     else return fail(ctx, SDQH_ERR_INVALID, "set_option: unknown option or value out of range: " + n);
     return SDQH_OK;
@@ -2118,6 +2119,15 @@ int sdqh_build(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nloo
         DevFill pre; std::memset(&pre, 0, sizeof(pre));
         prune_clean(ctx, &fl);
         if (seg_grid == 1 && ctx->opt_fuse_small && fl.most <= ((uint64_t)1 << 20) && fl.f.n <= FILL_MAX) pre = fl.pre(); else launch_fill(ctx, fl);
+        // ... and its index too (k_index_small's work behind the staging, in the same workgroup): a launch less per tiny table
+        DevIndexInline ix; std::memset(&ix, 0, sizeof(ix));
+        if (seg_grid == 1 && ctx->opt_fuse_small && ctx->opt_index_inline && tb->bm && shift == 0 && tb->refs_prefilled && (tb->nwords + RANK_BLOCK_WORDS - 1) / RANK_BLOCK_WORDS == 1) {
+            uint32_t* wprefix = static_cast<uint32_t*>(table_alloc(ctx, tb, tb->nwords * 4 + 64));
+            if (wprefix) {
+                tb->dev.wprefix = wprefix;
+                ix.t = tb->dev; ix.wprefix = wprefix; ix.span = tb->span; ix.nwords = tb->nwords; ix.on = 1;
+            }
+        }
         hipError_t e;
         with_scan_filter(f, [&](auto FC) {
             using FCT = decltype(FC);
@@ -2129,15 +2139,16 @@ int sdqh_build(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nloo
                     const int32_t* npred0 = f.ni == 1 ? static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(filter->ipred[0].col))) : nullptr;
                     if ((!eager0 || nkey0) && (f.ni != 1 || npred0)) {
                         auto kern = k_build_lookup<FCT, true>;
-                        LAUNCH(ctx, "k_build_lookup", kern, seg_grid, f, L, spec, tb->stage, nrows, flags, nkey0, npred0, pre);
+                        LAUNCH(ctx, "k_build_lookup", kern, seg_grid, f, L, spec, tb->stage, nrows, flags, nkey0, npred0, pre, ix);
                         return SDQH_OK;
                     }
                 }
             }
             auto kern = k_build_lookup<FCT>;
-            LAUNCH(ctx, "k_build_lookup", kern, seg_grid, f, L, spec, tb->stage, nrows, flags, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr), pre);
+            LAUNCH(ctx, "k_build_lookup", kern, seg_grid, f, L, spec, tb->stage, nrows, flags, static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr), pre, ix);
             return SDQH_OK;
         });
+        if (ix.on) { if (tb->span) tb->dev.dense_arr = tb->span; tb->index_built = true; }      // (as ensure_index leaves a tiny table)
         call_end(ctx);
         e = hipGetLastError();
         if (e != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, std::string("build launch: ") + hipGetErrorString(e));

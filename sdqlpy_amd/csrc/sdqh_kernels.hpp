@@ -2519,15 +2519,14 @@ struct DevBuildSpec {                                                 // what a 
 
 // Generalised staging: one wave per row segment (row order is kept: the queue is drained from the
 // front), survivors compacted into the segment's stage slice exactly as k_stage does.
-template <class FC, bool NW = false>      // NW: the first lookup's streamed key and the first integer predicate through their narrow twins (full steps only)
-__global__ __launch_bounds__(TPB) void k_build_lookup(DevFilter f, DevLookups L, DevBuildSpec spec, DevStage st, int64_t nrows, int* __restrict__ flags,
-                                                      const int32_t* __restrict__ nkey0, const int32_t* __restrict__ npred0, DevFill pre) {
-    if (pre.n) { fill_in_block(pre); __syncthreads(); }                  // (only ever with a grid of one workgroup)
+// A tiny table's direct index made by its build kernel's own workgroup, behind the staging (what k_index_small did in a launch of its
+// own: 7 - 10 us of dependent round trips on an idle chip for a table of 25 rows): on = 1, `t` with wprefix / dense_ref set, span or null
+struct DevIndexInline { DevTable t; uint32_t* wprefix; uint32_t* span; uint64_t nwords; int32_t on, _pad; };
+
+template <class FC, bool NW>
+__device__ __forceinline__ void build_lookup_segment(const DevFilter& f, const DevLookups& L, const DevBuildSpec& spec, const DevStage& st, int64_t nrows, int* __restrict__ flags,
+                                                     const int32_t* __restrict__ nkey0, const int32_t* __restrict__ npred0, int32_t* q_row, const int seg) {
     const int64_t* skey0 = NW ? reinterpret_cast<const int64_t*>(nkey0) : L.l[0].key[0].col;
-    __shared__ int32_t s_row[TPB / WAVE][LBQ_CAP];
-    const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
-    if (seg >= st.nseg) return;
-    int32_t* q_row = s_row[threadIdx.x / WAVE];
     const int64_t begin = (int64_t)seg * st.seg_rows;
     int64_t end = begin + st.seg_rows; if (end > nrows) end = nrows;
     const int lane = lane_id();
@@ -2648,6 +2647,23 @@ __global__ __launch_bounds__(TPB) void k_build_lookup(DevFilter f, DevLookups L,
         if (st.grp_first && seg == 0) st.hdr->has_dups = 1u;
     }
     if (__ballot(bad) && lane == 0) atomicOr(flags, 2);
+}
+
+template <class FC, bool NW = false>      // NW: the first lookup's streamed key and the first integer predicate through their narrow twins (full steps only)
+__global__ __launch_bounds__(TPB) void k_build_lookup(DevFilter f, DevLookups L, DevBuildSpec spec, DevStage st, int64_t nrows, int* __restrict__ flags,
+                                                      const int32_t* __restrict__ nkey0, const int32_t* __restrict__ npred0, DevFill pre, DevIndexInline ix) {
+    if (pre.n) { fill_in_block(pre); __syncthreads(); }                  // (only ever with a grid of one workgroup)
+    __shared__ int32_t s_row[TPB / WAVE][LBQ_CAP];
+    const int seg = blockIdx.x * (TPB / WAVE) + threadIdx.x / WAVE;
+    if (seg < st.nseg) build_lookup_segment<FC, NW>(f, L, spec, st, nrows, flags, nkey0, npred0, s_row[threadIdx.x / WAVE], seg);
+    if (ix.on) {                                                         // (a grid of one workgroup: every wave gets here)
+        __threadfence();
+        __syncthreads();
+        rank_words_body(st.bm, ix.nwords, ix.wprefix, st.seg_count, st.nseg, st.hdr);
+        __threadfence();
+        __syncthreads();
+        insert_direct_body(st, ix.t, ix.span);
+    }
 }
 
 // row pack builder: out[r * k + j] = col[j][r] (j >= ncols: padding)

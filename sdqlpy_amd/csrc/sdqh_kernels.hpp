@@ -1598,10 +1598,9 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_wrow_fixup(DevStage st, WordExc* __res
     const uint32_t n_below = __popc(word & ((1u << (off0 & 31)) - 1u));
     if (n_below == 0) {
         // the word's first key is mine.  If a LATER segment has keys in this word too it will mark the word as an exception: then
-        // (and only then) the word holds more keys than my leading run of it, and I leave it alone
-        uint32_t mine = 1;
-        while (mine < cnt && mine < 32 && (uint32_t)((uint64_t)(st.key[(int64_t)f.pos + mine] - st.bm_lo) >> 5) == w0) ++mine;
-        if ((uint32_t)__popc(word) == mine) st.wrow[w0] = f.pos;
+        // (and only then) the word holds more keys than my segment has entries — the keys of the word are the smallest keys from mine on,
+        // and my entries come in key order — and I leave it alone
+        if (cnt >= (uint32_t)__popc(word)) st.wrow[w0] = f.pos;
         return;
     }
     int t = s - 1;

@@ -161,7 +161,8 @@ void        sdqh_destroy(sdqh_ctx* ctx);
  * attaches to a column on first use (narrow twins, dictionaries, statistics) lives with the column and is complete when the call
  * that made it returns.  The caller keeps a column alive, and unchanged, while any context of the family has work in flight that
  * reads it (sdqh_synchronize each before sdqh_column_free / sdqh_column_copy_in); options are per context.  Fork the family's
- * first context only; destroy forks before it. */
+ * first context only; destroy forks before it.  The concurrency is the DEVICE's: the host issues a family's calls from one thread
+ * (or serialises them) — a column's attachments and its home pool are shared host-side state without locks. */
 int         sdqh_fork(sdqh_ctx* parent, sdqh_ctx** out);
 const char* sdqh_last_error(const sdqh_ctx* ctx);
 int         sdqh_set_threads(sdqh_ctx* ctx, int threads);   /* CPU build: worker count; HIP build: accepted, ignored */

@@ -1168,12 +1168,11 @@ static int build_dense(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int
         for (int p = 0; p < npayload; ++p) tb->dev.pay[p] = st.pay[p];
         call_begin(ctx);
         { FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); fl.add(st.shits, (size_t)nrows * 4, 0); fl.add(tb->bm, tb->nwords * 4, 0); if (accumulate) fl.add(st.sacc, acc_bytes, 0); launch_fill(ctx, fl); }
-        LAUNCH(ctx, "k_full_counts", k_full_counts, (unsigned)((st.nseg + TPB - 1) / TPB), st.seg_count, st.nseg, st.seg_rows, nrows);
         {
             const unsigned rgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + TPB * RANK_INC_NB - 1) / (TPB * RANK_INC_NB), (int64_t)ctx->num_cu * 32));
             const int32_t* k32 = (ctx->opt_narrow && nrows >= ctx->opt_feature_min_rows && !key->transient) ? static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(key))) : nullptr;
-            if (k32) { auto kern = k_rank_increasing<int32_t>; LAUNCH(ctx, "k_rank_increasing", kern, rgrid, k32, nrows, lo, tb->bm, wprefix, tb->hdr); }
-            else { auto kern = k_rank_increasing<int64_t>; LAUNCH(ctx, "k_rank_increasing", kern, rgrid, kc, nrows, lo, tb->bm, wprefix, tb->hdr); }
+            if (k32) { auto kern = k_rank_increasing<int32_t>; LAUNCH(ctx, "k_rank_increasing", kern, rgrid, k32, nrows, lo, tb->bm, wprefix, tb->hdr, st.seg_count, st.nseg, st.seg_rows); }
+            else { auto kern = k_rank_increasing<int64_t>; LAUNCH(ctx, "k_rank_increasing", kern, rgrid, kc, nrows, lo, tb->bm, wprefix, tb->hdr, st.seg_count, st.nseg, st.seg_rows); }
         }
         call_end(ctx);
         hipError_t e2 = hipGetLastError();

@@ -1723,7 +1723,13 @@ constexpr int RANK_INC_NB = 8;                                        // blocks 
 // KT: the key column itself (int64_t) or its exact 4-byte twin (int32_t: half the bytes of the one pass this build is)
 template <class KT>
 __global__ __launch_bounds__(TPB) void k_rank_increasing(const KT* __restrict__ key, int64_t nrows, int64_t lo, uint32_t* __restrict__ bm,
-                                                        uint32_t* __restrict__ wprefix, TableHeader* __restrict__ hdr) {
+                                                        uint32_t* __restrict__ wprefix, TableHeader* __restrict__ hdr,
+                                                        uint32_t* __restrict__ seg_count, int nseg, int64_t seg_rows) {
+    // (every row is an entry: a segment's count is its length — what k_full_counts wrote in a launch of its own)
+    for (int sg = blockIdx.x * TPB + threadIdx.x; sg < nseg; sg += gridDim.x * TPB) {
+        const int64_t b = (int64_t)sg * seg_rows, e = b + seg_rows < nrows ? b + seg_rows : nrows;
+        seg_count[sg] = (uint32_t)(e - b);
+    }
     __shared__ uint32_t s_words[TPB / WAVE][RANK_INC_WORDS];
     uint32_t* words = s_words[threadIdx.x / WAVE];
     const int lane = lane_id();

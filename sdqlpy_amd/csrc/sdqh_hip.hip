@@ -1100,6 +1100,15 @@ static int ensure_index(sdqh_ctx* ctx, sdqh_table* tb) {
             tb->index_built = true;
             return SDQH_OK;
         }
+        if (nblocks == 1 && ctx->opt_fuse_small && (tb->refs_prefilled || tb->keys_unique) && tb->nwords <= (uint64_t)RANK_BLOCK_WORDS) {
+            // one rank block, many workgroups of rows: rank + insert in one launch, every workgroup ranking for itself (k_index_medium)
+            LAUNCH(ctx, "k_index_medium", k_index_medium, seg_grid, tb->bm, (uint32_t)tb->nwords, wprefix, tb->stage, tb->dev, tb->span);
+            if (tb->span) tb->dev.dense_arr = tb->span;
+            hipError_t em = hipGetLastError();
+            if (em != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, std::string("table index launch: ") + hipGetErrorString(em));
+            tb->index_built = true;
+            return SDQH_OK;
+        }
         LAUNCH(ctx, "k_rank_words", k_rank_words, (unsigned)nblocks, tb->bm, tb->nwords, wprefix, tb->stage.seg_count, tb->stage.nseg, tb->hdr);
         if (!tb->refs_prefilled && !tb->keys_unique) LAUNCH(ctx, "k_fill_refs", k_fill_refs, (unsigned)ctx->num_cu * 2, tb->stage, tb->dev);
         LAUNCH(ctx, "k_insert_direct", k_insert_direct, seg_grid, tb->stage, tb->dev, tb->span);

@@ -1645,6 +1645,61 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_index_small(const uint32_t* __restrict
     __syncthreads();
     insert_direct_body(st, t, span);
 }
+// ... and of a table whose key bitmap is ONE rank block (<= 4096 words: a key range of 131 072 — the suppliers of Q5 / Q9, most
+// dimension tables) but whose rows are many workgroups of segments: every workgroup ranks the whole bitmap for itself in LDS (16 KB
+// out of L2; nobody waits for anybody), workgroup 0 also stores the prefixes and the header for the lookups to come, and each inserts
+// its own segments with the ranks it holds.  dense_ref (and span) must be NO_ROW-filled already when keys can repeat (prefill_refs).
+SDQH_KERNEL __launch_bounds__(TPB) void k_index_medium(const uint32_t* __restrict__ bm, uint32_t nwords, uint32_t* __restrict__ wprefix, DevStage st, DevTable t, uint32_t* __restrict__ span) {
+    __shared__ uint32_t s_word[RANK_BLOCK_WORDS], s_pre[RANK_BLOCK_WORDS];
+    __shared__ uint32_t s_wave[TPB / WAVE];
+    __shared__ uint32_t s_staged;
+    constexpr int PER = RANK_BLOCK_WORDS / TPB;                          // consecutive words per thread
+    const int lane = lane_id(), w = threadIdx.x / WAVE;
+    for (int i = threadIdx.x; i < RANK_BLOCK_WORDS; i += TPB) s_word[i] = (uint32_t)i < nwords ? bm[i] : 0u;
+    if (threadIdx.x == 0) s_staged = 0u;
+    __syncthreads();
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) mine += (uint32_t)__popc(s_word[threadIdx.x * PER + j]);
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) { const uint32_t v = __shfl_up(incl, off, WAVE); if (lane >= off) incl += v; }
+    if (lane == WAVE - 1) s_wave[w] = incl;
+    uint32_t stg = 0;
+    for (int i = threadIdx.x; i < st.nseg; i += TPB) stg += st.seg_count[i];
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) stg += __shfl_down(stg, off, WAVE);
+    if (lane == 0 && stg) atomicAdd(&s_staged, stg);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < TPB / WAVE; ++i) { if (i < w) before += s_wave[i]; total += s_wave[i]; }
+    uint32_t run = before + incl - mine;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { s_pre[threadIdx.x * PER + j] = run; run += (uint32_t)__popc(s_word[threadIdx.x * PER + j]); }
+    __syncthreads();
+    const uint32_t staged = s_staged;
+    const bool dups = staged != total;
+    if (blockIdx.x == 0) {
+        for (uint32_t i = threadIdx.x; i < nwords; i += TPB) wprefix[i] = s_pre[i];
+        if (threadIdx.x == 0) { t.hdr->staged = staged; t.hdr->distinct = total; t.hdr->has_dups = dups ? 1u : 0u; }
+    }
+    const int seg = blockIdx.x * (TPB / WAVE) + w;
+    if (seg >= st.nseg) return;
+    const int64_t base = (int64_t)seg * st.seg_rows;
+    const uint32_t count = st.seg_count[seg];
+    for (uint32_t i = lane; i < count; i += WAVE) {
+        const int64_t idx = base + i;
+        const int64_t key = st.key[idx];
+        uint64_t off;
+        if (!bm_locate(t, key, off) || (off >> 5) >= (uint64_t)RANK_BLOCK_WORDS) continue;
+        const uint32_t word = s_word[off >> 5];
+        if (!((word >> (off & 31)) & 1u)) continue;                       // cannot happen: the key's bit was set while staging
+        const uint32_t pos = s_pre[off >> 5] + (uint32_t)__popc(word & ((1u << (off & 31)) - 1u));
+        if (dups) atomicMin(&t.dense_ref[pos], (uint32_t)idx); else t.dense_ref[pos] = (uint32_t)idx;
+        if (span) { uint32_t* cell = span + (key - t.bm_lo); if (dups) atomicMin(cell, (uint32_t)idx); else *cell = (uint32_t)idx; }
+    }
+}
 
 // ---- dense layout ---------------------------------------------------------------------------------------
 // every row of the build table is an entry: segment counts are simply the segment lengths

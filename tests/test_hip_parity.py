@@ -579,6 +579,23 @@ def test_duplicate_build_keys_first_row_wins(hip_engine, oracle_engine):
     for i, k in enumerate(keys.tolist()):
         first.setdefault(k, i)
     assert dict(zip(out["hip"][0].tolist(), out["hip"][1].tolist())) == first
+    # the same on the direct layouts: a key range of one rank block with many workgroups of rows (rank + insert in one launch,
+    # k_index_medium), of several rank blocks (k_rank_words + k_insert_direct), and one workgroup of rows (k_index_small / in the build kernel)
+    for n2, span in ((20000, 3000), (400000, 300000), (300, 40), (150000, 131000)):
+        keys2 = rng.integers(5, 5 + span, n2).astype(np.int64)
+        pay2 = np.arange(n2, dtype=np.int64)
+        got = {}
+        for name, eng in (("hip", hip_engine), ("cpu", oracle_engine)):
+            ctx = eng.ctx
+            ck, cp = ctx.upload(keys2), ctx.upload(pay2)
+            t = ctx.hash_build_unique(n2, abi.make_filter(), [], ck, [cp])
+            k, p, _, _ = ctx.table_compact(t, 0, t.size())
+            got[name] = dict(zip(k.tolist(), p[0].tolist()))
+            t.free(); ck.free(); cp.free()
+        first2 = {}
+        for i, k in enumerate(keys2.tolist()):
+            first2.setdefault(k, i)
+        assert got["hip"] == first2 and got["cpu"] == first2, (n2, span)
 
 
 def test_compaction_into_device_writable_blocks(hip_engine, oracle_engine):

@@ -42,7 +42,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import abi, engine, frontend
+from . import abi, engine, frontend, xplan
 from . import tpch_queries as Q
 from .frontend import Col, FinalizeOp, PayloadField, RecordCons, ScanOp
 from .result import ResultSet
@@ -528,6 +528,12 @@ class DistributedRunner:
         for name in accumulate_into:
             if st.replicate.get(name) or built_by[name].table in whole:
                 st.unsupported = "the probe-aggregate into '%s' is not local to the ranks' shards: it needs the partitioned-join plan" % name
+        # a loop whose groups are fields of the matched entry but which looks other tables up as well (Q5's lineitem loop) runs as the
+        # program it is on one GPU — a handful of groups, merged across ranks like any group-by — where its join is local; where the probed
+        # table is a replica the fixed lookup-aggregate call does it, as before
+        accumulate_into |= {op.probe.dict_name for op in scan_ops
+                            if op.kind == "dict" and not op.unique and op.probe is not None and op.probe.dict_name in built_by
+                            and xplan.groups_by_entry(op) and not st.replicate.get(op.probe.dict_name) and built_by[op.probe.dict_name].table not in whole}
         # builds that only answer `tbl[k] != None` are key sets, as on one GPU; one that other shards' rows look up is replicated
         # through its exact bitmap over the global key range (gathered here, once) — unless that range does not suit a bitmap: then
         # it stays an ordinary table whose entries travel

@@ -564,6 +564,10 @@ int sdqh_partition_by_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, 
 /* Say that a column lives for one run of a plan (rows that arrived through a collective): no twins, no dictionaries, no order facts are
  * built for it — each would be a pass over the column, or a host round trip, paid on every run.  CPU build: accepted, nothing to do. */
 int sdqh_column_mark_transient(sdqh_ctx* ctx, sdqh_column* col);
+/* Tell the library bounds of an I64 column the caller knows (lo <= every value <= hi; a superset of the true range is fine): builds
+ * size their bitmaps and decide whether key parts pack from them instead of a minimum / maximum pass over the column and the host
+ * round trip that reads it back — rows that arrived through a collective carry the bounds of the columns they were made from. */
+int sdqh_column_set_bounds(sdqh_ctx* ctx, sdqh_column* col, int64_t lo, int64_t hi);
 /* sdqh_partition_by_key straight into ONE caller-owned buffer (device memory; CPU build: host) of nrows * ncols 8-byte elements, laid
  * out for an all-to-all: the chunk for part p starts at element ncols * (rows of the parts before p) and holds every column's rows of
  * that part, column after column — so ONE collective moves every column of a redistribution step and nothing is copied between the

@@ -1462,6 +1462,7 @@ int sdqh_partition_by_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, 
 }
 
 int sdqh_column_mark_transient(sdqh_ctx* ctx, sdqh_column* col) { return (ctx && col) ? SDQH_OK : SDQH_ERR_INVALID; }
+int sdqh_column_set_bounds(sdqh_ctx* ctx, sdqh_column* col, int64_t lo, int64_t hi) { return (ctx && col && lo <= hi) ? SDQH_OK : SDQH_ERR_INVALID; }     // (the CPU build reads its columns where it needs a range)
 
 int sdqh_partition_pack(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int nparts, const int64_t* range_upper, int ncols,
                         const sdqh_column* const* cols, void* packed, int64_t* counts) {

@@ -217,7 +217,7 @@ EXPORTS = [
     "sdqh_column_rows", "sdqh_column_dtype", "sdqh_column_width", "sdqh_column_minmax", "sdqh_column_free",
     "sdqh_scan_filter_sum", "sdqh_scan_probe_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_build_key_set", "sdqh_groupby_key", "sdqh_table_select_keys", "sdqh_table_share_groups", "sdqh_table_size", "sdqh_table_free",
     "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_table_compact_async", "sdqh_table_compact_deferred", "sdqh_host_wait_word", "sdqh_result_wait", "sdqh_scan_compact", "sdqh_partition_by_key",
-    "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in", "sdqh_column_unpack2", "sdqh_partition_pack", "sdqh_unpack_parts", "sdqh_column_mark_transient",
+    "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in", "sdqh_column_unpack2", "sdqh_partition_pack", "sdqh_unpack_parts", "sdqh_column_mark_transient", "sdqh_column_set_bounds",
     "sdqh_build", "sdqh_lookup_aggregate", "sdqh_table_entries", "sdqh_host_alloc", "sdqh_host_free", "sdqh_table_topk",
     "sdqh_xscan_sum", "sdqh_xgroupby", "sdqh_xgroupby_block_bytes", "sdqh_xgroupby_async", "sdqh_xgroupby_collect", "sdqh_xbuild", "sdqh_xkey_set", "sdqh_xcompact", "sdqh_xprobe_aggregate", "sdqh_table_columns", "sdqh_jit_stats", "sdqh_jit_compile",
 ]
@@ -268,6 +268,11 @@ class Column:
     def mark_transient(self):
         """This column lives for one run (rows that arrived through a collective): nothing is derived from it (sdqh_column_mark_transient)."""
         self.ctx._check(self.ctx.lib.sdqh_column_mark_transient(self.ctx.handle, self.handle))
+        return self
+
+    def set_bounds(self, lo, hi):
+        """Bounds the caller knows (a superset of the values is fine): no minimum / maximum pass will be made (sdqh_column_set_bounds)."""
+        self.ctx._check(self.ctx.lib.sdqh_column_set_bounds(self.ctx.handle, self.handle, C.c_int64(int(lo)), C.c_int64(int(hi))))
         return self
 
 
@@ -1031,6 +1036,7 @@ class Library:
         L.sdqh_table_export_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.sdqh_jit_compile.argtypes = [C.c_void_p, C.c_char_p]
         L.sdqh_column_mark_transient.argtypes = [C.c_void_p, C.c_void_p]
+        L.sdqh_column_set_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
         L.sdqh_column_unpack2.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.sdqh_partition_pack.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sdqh_unpack_parts.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]

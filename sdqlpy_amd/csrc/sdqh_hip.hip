@@ -2502,6 +2502,11 @@ int sdqh_partition_by_key(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, 
     return SDQH_OK;
 }
 
+int sdqh_column_set_bounds(sdqh_ctx* ctx, sdqh_column* col, int64_t lo, int64_t hi) {
+    if (!ctx || !col || col->dtype != SDQH_I64 || lo > hi) return fail(ctx, SDQH_ERR_INVALID, "column_set_bounds: bad arguments");
+    col->mn = lo; col->mx = hi; col->have_minmax = true; col->minmax_pending = false;
+    return SDQH_OK;
+}
 int sdqh_column_mark_transient(sdqh_ctx* ctx, sdqh_column* col) {
     if (!ctx || !col) return fail(ctx, SDQH_ERR_INVALID, "column_mark_transient: bad arguments");
     col->transient = true; col->narrow_state = 0; col->code_state = 0; col->clustered = 0; col->increasing = 0; col->span8 = 0;

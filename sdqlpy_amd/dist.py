@@ -568,6 +568,24 @@ class DistributedRunner:
             lo, hi = min(int(f[0]) for f in facts), max(int(f[1]) for f in facts)
             if lo <= hi:
                 st.table_range[name] = (lo, hi)
+        # ... and those keyed by two columns (travelling packed): the global range of each part, gathered once — the rebuilt replica is
+        # told them (sdqh_column_set_bounds) instead of running a minimum / maximum pass over each part, and reading it back, every run
+        st.part_ranges = {}
+        for name, need in st.replicate.items():
+            bop = built_by.get(name)
+            if not need or name in member_only or bop is None or not isinstance(bop.key, RecordCons) or len(bop.key.fields) != 2:
+                continue
+            parts = [e for _, e in bop.key.fields]
+            if not all(isinstance(e, Col) and tabs[bop.table].cols.get(e.name) is not None and tabs[bop.table].cols[e.name].dtype == np.int64 for e in parts):
+                continue
+            mine = []
+            for e in parts:
+                arr = tabs[bop.table].array(e.name, bop)
+                mine += list(eng.column(arr).minmax()) if len(arr) else [abi.INT64_MAX, abi.INT64_MIN]
+            facts = self._all_gather_array(np.array(mine, np.int64))
+            rng = [(min(int(f[2 * j]) for f in facts), max(int(f[2 * j + 1]) for f in facts)) for j in range(2)]
+            if all(lo <= hi for lo, hi in rng):
+                st.part_ranges[name] = rng
         for op in plan.ops:
             if isinstance(op, ScanOp):
                 st.steps.append((op, engine._prepare_scan(eng, op, tabs[op.table], accumulate_into, op.out in member_only)))
@@ -586,7 +604,7 @@ class DistributedRunner:
                             st.local_text.add(id(hit[2]))
         return st
 
-    def _replicate_table(self, bt, key_range=None, table_range=None):
+    def _replicate_table(self, bt, key_range=None, table_range=None, part_ranges=None):
         """All ranks' entries of a built table on every rank, without leaving device memory.  A key set (key_range given): its exact
         bitmap over the global key range, one collective, the replica a key set again — the layout the loops that test it are
         specialised on.  A table with payload: entries -> all-gather -> rebuild, a composite key (travelling packed) from its two
@@ -609,6 +627,8 @@ class DistributedRunner:
             c.free()
         if bt.key_parts is not None and total:
             hi, lo = ctx.unpack2(gathered[0], total)
+            if part_ranges is not None:                                     # (a filtered build's keys are a subset of its columns' values: bounds all the same)
+                hi.set_bounds(*part_ranges[0]); lo.set_bounds(*part_ranges[1])
             table = ctx.build(total, abi.make_filter(), [], [abi.src_col(hi), abi.src_col(lo)], [abi.src_col(c) for c in gathered[1:]])
             gathered = list(gathered) + [hi, lo]
         elif table_range is not None and total:
@@ -637,7 +657,7 @@ class DistributedRunner:
                 if isinstance(op, ScanOp):
                     res = step(env)
                     if isinstance(res, engine.BuiltTable) and st.replicate.get(op.out):
-                        res = self._replicate_table(res, st.key_range.get(op.out), st.table_range.get(op.out))
+                        res = self._replicate_table(res, st.key_range.get(op.out), st.table_range.get(op.out), st.part_ranges.get(op.out))
                     elif isinstance(res, engine.DictResult) and st.sharded[op.out]:
                         res = self._merge_groups(res)
                     elif isinstance(res, float) and st.sharded[op.out]:

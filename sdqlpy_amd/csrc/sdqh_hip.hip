@@ -678,6 +678,7 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "dense_increasing" && value >= 0 && value <= 1) ctx->opt_dense_increasing = (int)value;
     else if (n == "packed_slots" && (value == 0 || value == 1)) ctx->opt_packed_slots = (int)value;
     else if (n == "grouped_index" && (value == 0 || value == 1)) ctx->opt_grouped_index = (int)value;
+    else if (n == "grouped_pairs" && (value == 0 || value == 1)) ctx->opt_grouped_pairs = (int)value;
     else if (n == "index_inline" && (value == 0 || value == 1)) ctx->opt_index_inline = (int)value;
     else if (n == "groupby_regs" && (value == 0 || value == 4 || value == 8)) ctx->opt_groupby_regs = (int)value;
     else return fail(ctx, SDQH_ERR_INVALID, "set_option: unknown option or value out of range: " + n);
@@ -2024,6 +2025,7 @@ static int make_source(sdqh_ctx* ctx, const sdqh_source& s, int64_t nrows, int n
     d->lookup = s.lookup; d->field = s.field;
     // where the payload is read from, resolved here (the table's index exists: make_lookups ensured it) — see DevSource
     const bool direct = t->dev.dense_arr || (t->dev.bm && t->dev.bm_shift == 0) || t->dev.grp_first;
+    if (t->dev.grp_first && t->dev.grp_kstride == 2 && s.field == 0) { d->pack = 3; d->col = t->dev.grp_key; return SDQH_OK; }
     if (t->dev.slots && !direct) {
         d->col = t->dev.slots;
         if (s.field < 2) d->pack = 1; else { d->pack = 2; d->col2 = t->dev.pay[s.field]; }
@@ -2113,7 +2115,11 @@ int sdqh_build(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nloo
         tb->dev.hdr = tb->hdr; tb->dev.shits = tb->stage.shits; tb->dev.sacc = tb->stage.sacc; tb->dev.acc_stride = tb->stage.acc_stride;
         if (grp_first) {
             tb->stage.grp_first = grp_first;
-            tb->dev.grp_first = grp_first; tb->dev.grp_key = tb->stage.key; tb->dev.grp_seg_rows = tb->stage.seg_rows; tb->dev.grp_cap = nrows + 1;      // stage rows that can be read: the entries, and the end mark of a last segment that is all entries
+            tb->dev.grp_first = grp_first; tb->dev.grp_key = tb->stage.key; tb->dev.grp_kstride = 1; tb->dev.grp_seg_rows = tb->stage.seg_rows;
+            if (npayload >= 1 && ctx->opt_grouped_pairs) {                  // (key, payload 0) side by side: a hit's first payload field comes with its key's line
+                int64_t* kp = static_cast<int64_t*>(table_alloc(ctx, tb, ((size_t)nrows + 8) * 16 + 64));
+                if (kp) { tb->stage.grp_kp = kp; tb->dev.grp_key = kp; tb->dev.grp_kstride = 2; }
+            } tb->dev.grp_cap = nrows + 1;      // stage rows that can be read: the entries, and the end mark of a last segment that is all entries
         }
         const int shift = (nkey == 2 && !(tb->bm && lin_rb)) ? 32 : 0;
         tb->dev.bm = tb->bm; tb->dev.bm_lo = lo; tb->dev.bm_hi = hi; tb->dev.bitmap_only = 0; tb->dev.bm_shift = shift;

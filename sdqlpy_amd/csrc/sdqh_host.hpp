@@ -104,6 +104,7 @@ struct sdqh_ctx {
     int opt_copy_nt = 1;
     int opt_row_index = 1;              // unique builds keyed by a strictly increasing column: the stage kernel writes the word -> stage row index itself (no rank / insert passes)
     int opt_grouped_index = 1;                     // composite-key builds over a table stored in the order of the key's first part: the GROUPED layout (DevTable) instead of hash slots
+    int opt_grouped_pairs = 1;                     // ... with (key, payload 0) pairs beside the stage (DevTable::grp_kstride)
     int opt_index_inline = 1;                      // a one-workgroup table's build kernel makes the direct index too (DevIndexInline) instead of a k_index_small launch at first use
     int opt_lane_int = 1;               // the per-lane group sink sums an integer-valued byte-coded column as an integer beside the row count (XGroupLane)
     int opt_lane_resident = 2;          // workgroups per CU the per-lane group sink's grid is sized for

@@ -152,7 +152,9 @@ struct DevTable {
     // match = lowest build row: the reference's first-insert-wins).  grp_key = the stage's key array; a segment that is not full ends in
     // an EMPTY_KEY entry: the walk goes on at the next segment's base.  bm (bm_shift 32) stays the pre-filter over a.
     const uint32_t* grp_first;
-    const int64_t* grp_key;
+    const int64_t* grp_key;           // keys by stage row, grp_kstride apart: the stage's key array (1) or the (key, payload 0) pairs a build with payload writes
+                                      //    beside it (2: a hit finds its first payload field in the line of its key — one line per lookup less in Q9's final loop)
+    int64_t grp_kstride;
     int64_t grp_seg_rows, grp_cap;    // rows per stage segment; stage rows a walk may read (the build's rows + 1: the last segment's end mark)
 };
 
@@ -607,7 +609,7 @@ __device__ __forceinline__ int64_t table_find(const DevTable& t, int64_t key, ui
                 // four entries of the run per round trip (most runs are that short); what lies behind a run's end is read and never looked at
                 int64_t k[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) k[i] = t.grp_key[p + i < t.grp_cap ? p + i : t.grp_cap - 1];
+                for (int i = 0; i < 4; ++i) k[i] = t.grp_key[(p + i < t.grp_cap ? p + i : t.grp_cap - 1) * t.grp_kstride];
                 bool jump = false;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -1173,6 +1175,7 @@ struct DevStage {
     uint32_t* wrow;                       // ROW INDEX (see DevTable): per bitmap word the stage row of its first key, written while staging; or null
     SegFirst* seg_first;                  // [nseg] ... and every segment's first entry, for k_wrow_fixup
     uint32_t* grp_first;                  // GROUPED layout (see DevTable): first stage row per high key part, NO_ROW-filled before the build; or null
+    int64_t* grp_kp;                      // ... and its (key, payload 0) pairs by stage row, or null
 };
 
 // Row index, the writer's side: the entries a wave is about to store (one per lane, `active` lanes, increasing keys, consecutive stage
@@ -1352,12 +1355,13 @@ __device__ __forceinline__ void stage_store(const DevStage& st, int64_t pos, int
             // grouped layout: off = the high part's offset (bm_shift 32, no rectangle).  opens_run false: the caller knows the entry stored just
             // before this one (the wave's previous kept lane) has the same high part — the run's first stage row is not this one
             if (st.grp_first && opens_run) atomicMin(&st.grp_first[off], (uint32_t)pos);
+            if (st.grp_kp) { using V2 = long long __attribute__((ext_vector_type(2))); const V2 kp = {(long long)key, (long long)pay[0]}; reinterpret_cast<V2*>(st.grp_kp)[pos] = kp; }
         }
     }
 }
 // grouped layout: a segment that did not fill up ends in EMPTY_KEY (DevTable: the walk of a run goes on at the next segment's base)
 __device__ __forceinline__ void stage_end_segment(const DevStage& st, int seg, int64_t begin, int64_t count) {
-    if (st.grp_first && (count < st.seg_rows || seg == st.nseg - 1)) st.key[begin + count] = EMPTY_KEY;      // (a last segment that is all entries: the mark sits in the array's slack)
+    if (st.grp_first && (count < st.seg_rows || seg == st.nseg - 1)) { st.key[begin + count] = EMPTY_KEY; if (st.grp_kp) st.grp_kp[2 * (begin + count)] = EMPTY_KEY; }      // (a last segment that is all entries: the mark sits in the array's slack)
 }
 
 // PIPE (needs EAGER, one integer predicate and one probe at least): the next step's first-stage loads are requested at the
@@ -2473,7 +2477,7 @@ __device__ __forceinline__ int64_t source_value(const DevSource& s, const DevLoo
     const uint32_t e = pick3(ent, s.lookup);
     // one load at a selected index (no branch between the loads of a drain: they must all be in flight together);
     // only a packed table's third / fourth payload field pays a second, dependent load
-    const uint64_t idx = s.pack == 0 ? (uint64_t)e : (uint64_t)e * 4 + (s.pack == 1 ? 1 + (uint64_t)s.field : 3);
+    const uint64_t idx = s.pack == 0 ? (uint64_t)e : s.pack == 3 ? (uint64_t)e * 2 + 1 : (uint64_t)e * 4 + (s.pack == 1 ? 1 + (uint64_t)s.field : 3);      // (3: the grouped layout's key / payload pairs)
     int64_t v = s.col[idx];
     if (s.pack == 2) v = s.col2[(uint32_t)v];
     return s.kind == SDQH_SRC_LOOKUP_YEAR ? v / 10000 : v;

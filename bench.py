@@ -11,6 +11,7 @@ of `value`.
 
     python bench.py                       # 1 GPU, defaults finish in a few minutes
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N              # no launcher: bench.py starts its N ranks itself (spawn_ranks) and relays rank 0's line
     ... bench.py --gpus 8 --global-sf 100     # BASELINE configs[3] / [4]: SF=100 over the 8 GPUs
 
 N > 1 is weak scaling by default (every rank holds an SF=10 shard of a global SF=10*N database); q1
@@ -101,6 +102,70 @@ def _context_launches(c):
     return out
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this very program as child processes (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, exactly what torch.distributed.run would set), wait for them, relay
+    rank 0's single JSON line, and return non-zero if any rank failed (the others are then stopped: a rank waiting in a collective
+    for a dead peer would hang).  The parent never initialises a GPU.  SDQLPY_AMD_BENCH_CHILD names another program to run as a
+    rank (tests/: the same control flow on gloo with the CPU implementation injected)."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = str(sock.getsockname()[1])
+    child = os.environ.get("SDQLPY_AMD_BENCH_CHILD") or os.path.abspath(__file__)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs between processes on this driver
+        env.pop("SDQLPY_AMD_BENCH_CHILD", None)
+        procs.append(subprocess.Popen([sys.executable, child] + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None))
+    import threading
+    chunks, failed = [], 0
+    # rank 0 prints one line at its end; its pipe is drained by a thread while the ranks run (the loop below must stay free to
+    # notice a rank that died: its peers would wait for it in a collective for ever)
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    try:
+        pending = list(enumerate(procs))
+        while pending:
+            for r, p in list(pending):
+                try:
+                    rc = p.wait(timeout=0.2)
+                except subprocess.TimeoutExpired:
+                    continue
+                pending.remove((r, p))
+                if rc != 0:
+                    failed = failed or rc or 1
+                    sys.stderr.write("bench.py: rank %d exited with code %d\n" % (r, rc))
+            if failed and pending:
+                for _, p in pending:                              # exactly the processes started here
+                    p.terminate()
+                for _, p in pending:
+                    try:
+                        p.wait(timeout=30)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                pending = []
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    if failed:
+        return failed
+    reader.join(timeout=30)
+    out = [ln for ln in b"".join(chunks).decode(errors="replace").splitlines() if ln.strip()]
+    if len(out) != 1:
+        sys.stderr.write("bench.py: rank 0 printed %d lines, expected one JSON line\n" % len(out))
+        return 1
+    sys.stdout.write(out[0] + "\n")
+    sys.stdout.flush()
+    return 0
+
+
 def main(argv=None, hooks=None):
     """hooks: injection points for the CPU test of the multi-process control flow
     (tests/bench_gloo_worker.py): {"backend": "gloo", "device": "cpu", "engine": Engine}.  The
@@ -120,8 +185,13 @@ def main(argv=None, hooks=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torchrun (one process per GPU)" % args.gpus)
+        if world == 1 and args.gpus > 1 and not hooks:
+            # plain `python bench.py --gpus N`: this process becomes the launcher — N ranks started as child processes BEFORE anything
+            # here touches a GPU (no exec from a process that has), rank 0's JSON line relayed
+            os.dup2(json_fd, 1)
+            os.close(json_fd)
+            raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv)))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one process per GPU (or none: bench.py starts them itself)" % (args.gpus, world))
     import torch
     import torch.distributed as dist
     if device == "cuda":
@@ -198,15 +268,21 @@ def main(argv=None, hooks=None):
     # Timed region.  HIP events are recorded on the stream the kernels run on, around every launch
     # of the dominant kernel (profiling mode 2: record only, nothing synchronises; events around
     # all ~45 launches of a step would add ~0.1 ms of event packets per query); read afterwards.
-    dom_q = "q1" if "q1" in queries else queries[0]
-    # the dominant kernel of that query: the longest launch of one fully evented run (its name depends on the route the planner took:
-    # a kernel specialised at run time on the loop — xk_* — or a fixed-shape one — k_*)
-    eng.ctx.set_profiling(2, only=None)
-    run_query(dom_q)
-    barrier()
-    probe_launches = eng.ctx.profile()
-    eng.ctx.set_profiling(0)
-    dom_kernel = max(probe_launches, key=lambda kv: kv[1])[0] if probe_launches else DOMINANT[dom_q][0]
+    # the step's DOMINANT kernel: the longest single launch over ALL queries of the step, found by one fully evented run of each query
+    # before the timed region (its name depends on the route the planner took: a kernel specialised at run time on the loop — xk_* —
+    # or a fixed-shape one — k_*).  Q1's streaming kernel — the north-star's "Q1 at >= 60 % of the roofline" — is priced the same way
+    # beside it as `roofline.q1` when it is not the dominant one.
+    longest = {}
+    for q in queries:
+        eng.ctx.set_profiling(2, only=None)
+        r = run_query(q)
+        r.wait() if hasattr(r, "wait") else None
+        barrier()
+        launches_q = eng.ctx.profile()
+        eng.ctx.set_profiling(0)
+        longest[q] = max(launches_q, key=lambda kv: kv[1]) if launches_q else (DOMINANT[q][0], 0.0)
+    dom_q = max(queries, key=lambda q: longest[q][1])
+    dom_kernel = longest[dom_q][0]
 
     def step_order(qs):
         if args.launch_order == "given":
@@ -269,6 +345,10 @@ def main(argv=None, hooks=None):
     # (the dominant kernel's launches are evented here too: in this region a kernel has the chip to itself — in the first, the queries'
     # kernels share it, lane by lane, and a kernel's duration there is not a statement about the kernel)
     elapsed_waited, per_query_ms, waited_log = run_steps(args.steps, dom_kernel, each_waited_for=True)
+    q1_log = None
+    if "q1" in queries and dom_q != "q1":
+        # Q1's streaming kernel evented in steps of its own (the filter takes one kernel name), outside `value`
+        _, _, q1_log = run_steps(args.steps, longest["q1"][0], ["q1"], each_waited_for=True)
     timed_collectives = None
     if runner is not None:
         timed_collectives = {k: {"calls": v[0], "on_device_tensors": v[1], "bytes": v[2]} for k, v in sorted(runner.collectives.items())}
@@ -362,31 +442,40 @@ def main(argv=None, hooks=None):
     if rank == 0:
         dom_name = dom_q + ":" + dom_kernel
         roofline = None
-        if dom_launches:
-            dom_ms = sum(dom_launches) / len(dom_launches)       # HIP events inside the timed region
-            per_launch_bytes = DOMINANT[dom_q][1](rows)
-            achieved = per_launch_bytes / (dom_ms * 1e-3) / 1e9
-            traffic, traffic_source = pmc_traffic(dom_q, dom_kernel, rows)
-            # the same launch's bytes by the library's own model of THIS run (sdqh_profile_entry_bytes: rows x the bytes per row of the
-            # encodings the engine chose for each streamed column + what the launch stores by construction): `frac` can be recomputed
-            # from this line alone, the committed PMC collection confirms it
-            traffic_model = int(sum(dom_model) / len(dom_model)) if dom_model else None
+        def price(q, kernel, launches_ms, model):
+            """One kernel against the HBM roofline.  `frac` is the PHYSICAL fraction: HBM bytes the kernel really moves / its average
+            launch time (HIP events on the stream it runs on, inside the timed steps) / peak; the bytes are the committed PMC figure
+            (`traffic`) when its row counts and kernel names match this run, else the library's own model of THIS run
+            (`traffic_model`, sdqh_profile_entry_bytes: rows x the bytes per row of the encodings the engine chose + what the launch
+            stores by construction), so the fraction can be recomputed from the line alone.  SURVEY.md 8(d)'s algorithmic figure (the
+            reference's 8-byte / UCS-4 widths) is carried beside it as `frac_algorithmic`: the kernels read exact narrow encodings, so
+            that one can exceed 1 and is no roofline fraction; `reference_width` times the same queries on the 8-byte columns."""
+            ms = sum(launches_ms) / len(launches_ms)
+            per_launch_bytes = DOMINANT[q][1](rows)
+            achieved = per_launch_bytes / (ms * 1e-3) / 1e9
+            traffic, traffic_source = pmc_traffic(q, kernel, rows)
+            traffic_model = int(sum(model) / len(model)) if model else None
             bytes_used, frac_source = (traffic, "pmc") if traffic else (traffic_model, "model")
-            phys_gbs = bytes_used / (dom_ms * 1e-3) / 1e9 if bytes_used else None
-            # `frac` is the PHYSICAL fraction: HBM bytes the kernel really moves / its launch time / peak — a fraction of the roofline.
-            # SURVEY.md 8(d)'s algorithmic figure (the reference's 8-byte / UCS-4 column widths, which the CPU path is priced on too) is
-            # carried beside it as `achieved_algorithmic` / `frac_algorithmic`: the kernel reads exact narrow encodings of those columns
-            # (DESIGN.md 2), so that one exceeds 1 and is not a roofline fraction; `reference_width` below times the same query on the
-            # 8-byte columns, where the algorithmic fraction IS one.
-            roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(phys_gbs, 1) if phys_gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(phys_gbs / HBM_PEAK_GBS, 4) if phys_gbs else None, "frac_source": frac_source,
-                        "traffic": traffic, "traffic_source": traffic_source,
-                        "traffic_model": traffic_model, "traffic_model_over_pmc": round(traffic_model / traffic, 4) if traffic and traffic_model else None,
-                        "frac_model": round(traffic_model / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic_model else None,
-                        "achieved_algorithmic": round(achieved, 1), "frac_algorithmic": round(achieved / HBM_PEAK_GBS, 4),
-                        "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": round(dom_ms, 4),
-                        "launches_timed": len(dom_launches),
-                        "achievable_peak_note": "MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured for a float4 copy"}
+            phys_gbs = bytes_used / (ms * 1e-3) / 1e9 if bytes_used else None
+            return {"bound": "hbm", "kernel": q + ":" + kernel, "achieved": round(phys_gbs, 1) if phys_gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(phys_gbs / HBM_PEAK_GBS, 4) if phys_gbs else None, "frac_source": frac_source,
+                    "traffic": traffic, "traffic_source": traffic_source,
+                    "traffic_model": traffic_model, "traffic_model_over_pmc": round(traffic_model / traffic, 4) if traffic and traffic_model else None,
+                    "frac_model": round(traffic_model / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic_model else None,
+                    "achieved_algorithmic": round(achieved, 1), "frac_algorithmic": round(achieved / HBM_PEAK_GBS, 4),
+                    "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": round(ms, 4),
+                    "launches_timed": len(launches_ms)}
+        if dom_launches:
+            roofline = price(dom_q, dom_kernel, dom_launches, dom_model)
+            roofline["dominant"] = "the longest single launch over all queries of the step (one evented run of each query before the timed region): " + \
+                                   ", ".join("%s %s %.4f ms" % (q, longest[q][0], longest[q][1]) for q in queries)
+            roofline["achievable_peak_note"] = "MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured for a float4 copy"
+            if q1_log is not None:
+                k1 = longest["q1"][0]
+                ms1 = [ms for q, name, ms, _ in q1_log if q == "q1" and name == k1]
+                if ms1:
+                    roofline["q1"] = price("q1", k1, ms1, [nb for q, name, _, nb in q1_log if q == "q1" and name == k1 and nb > 0])
+                    roofline["q1"]["measured_in"] = "steps of q1 alone, waited for, after the timed region"
             if dom_launches is alone_launches:
                 # which of the two timed regions the launches above are from, and the same kernel's launches in the other
                 shared_ms = sum(shared_launches) / len(shared_launches) if shared_launches else None
@@ -404,6 +493,9 @@ def main(argv=None, hooks=None):
             if reference_width and dom_q in reference_width.get("queries", {}):
                 rw = reference_width["queries"][dom_q]
                 roofline["reference_width"] = {"kernel": rw["dominant_kernel"], "avg_launch_ms": rw["dominant_avg_launch_ms"], "achieved": rw["achieved"], "frac": rw["frac"]}
+            if reference_width and "q1" in roofline and "q1" in reference_width.get("queries", {}):
+                rw = reference_width["queries"]["q1"]
+                roofline["q1"]["reference_width"] = {"kernel": rw["dominant_kernel"], "avg_launch_ms": rw["dominant_avg_launch_ms"], "achieved": rw["achieved"], "frac": rw["frac"]}
         per_query = {}
         for q in queries + extra:
             ab = algorithmic_bytes(q, rows)

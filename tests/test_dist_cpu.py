@@ -152,3 +152,22 @@ def test_bench_contract_under_a_two_rank_launch(tmp_path):
     # whole-job aggregate: rows of BOTH ranks per step over the max-over-ranks time
     per_rank = sum(rec["config"]["rows_per_gpu"][t] for t in ("lineitem",)) * 3 + rec["config"]["rows_per_gpu"]["customer"] * 2 + rec["config"]["rows_per_gpu"]["orders"] * 2
     assert rec["value"] * rec["ms_per_step"] * 1e-3 > 1.5 * per_rank
+
+
+def test_bench_starts_its_own_ranks():
+    """Plain `python bench.py --gpus 2` — no torchrun, no WORLD_SIZE: bench.py is its own launcher (spawn_ranks: child processes with
+    the rendezvous environment, started before the parent touches a GPU), relays rank 0's single JSON line and exits 0; a rank that
+    dies makes the launcher stop its peers and exit non-zero instead of hanging in a collective."""
+    env = dict(os.environ, SDQLPY_AMD_BENCH_CHILD=os.path.join(ROOT, "tests", "bench_spawn_worker.py"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--sf", "0.01", "--no-cpu-baseline"]
+    done = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert done.returncode == 0, done.stderr[-3000:]
+    lines = [ln for ln in done.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, done.stdout[-1000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["value"] > 0 and rec["q3_exchange"]["hash"]["exchanged_bytes_all_ranks"] > 0
+    bad = subprocess.run(cmd, env=dict(env, SDQLPY_TEST_FAIL_RANK="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert bad.returncode != 0 and not bad.stdout.strip(), (bad.returncode, bad.stdout[-500:])
+    assert "rank 1 exited with code 7" in bad.stderr

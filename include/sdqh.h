@@ -55,7 +55,7 @@ using __hip_internal::int32_t; using __hip_internal::uint32_t; using __hip_inter
 extern "C" {
 #endif
 
-#define SDQH_ABI_VERSION 4   /* 2: sdqh_filter carries column-vs-column predicates; string modes 3 / 4.  3: sdqh_table_share_groups.  4: row programs (sdqh_x*) */
+#define SDQH_ABI_VERSION 5   /* 2: sdqh_filter carries column-vs-column predicates; string modes 3 / 4.  3: sdqh_table_share_groups.  4: row programs (sdqh_x*).  5: device-sized redistribution, plan graphs */
 
 /* ---- status codes ---------------------------------------------------------------------- */
 #define SDQH_OK              0
@@ -579,6 +579,63 @@ int sdqh_partition_pack(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, in
  * SDQH_F64.  Queued on the ctx stream under "async_copies" (the caller keeps `packed` alive until it synchronises). */
 int sdqh_unpack_parts(sdqh_ctx* ctx, const void* packed, int nparts, const int64_t* part_rows, int ncols, const int* dtypes,
                       sdqh_column** out_cols, int64_t* out_rows);
+/* ---- redistribution sized on the DEVICE (ABI 5): a hash- / range-partitioned join step with no host wait in it -----------------------
+ * The calls above return row counts to the host, which then sizes the all-to-all: a host round trip per exchange.  The calls below move
+ * FIXED-CAPACITY chunks instead — the capacity is the caller's bound (the previous run's counts plus slack) — with the true row count in
+ * each chunk's header, so the counts travel with the data and nothing waits; a chunk that overflowed is found out afterwards
+ * (SDQH_STAT_MAX_COUNT) and the step is repeated with exact sizes by the calls above.  No reference counterpart.
+ *
+ * sdqh_xstage: the rows of a table loop that pass the program's gates, STAGED on the device — key and vals (<= SDQH_MAX_PAYLOAD), 8
+ * bytes each, equal keys included, nothing indexed (the filter half of the probe loop, ...generator_par.py:378-447).  The table it
+ * returns answers nothing but sdqh_table_partition_pack and sdqh_table_free; how many rows it holds stays on the device. */
+int sdqh_xstage(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, sdqh_table** out);
+/* 8-byte words of one chunk of `ncols` columns and `chunk_rows` rows: a 2-word header {rows meant for this chunk, 0}, then column after
+ * column, chunk_rows rows each. */
+int64_t sdqh_chunk_words(int ncols, int64_t chunk_rows);
+/* The entries of `table` — a unique build over a strictly increasing key column (no two staged rows share a key), or a stage from
+ * sdqh_xstage — partitioned by their key (mix64(key) % nparts, or range_upper as in sdqh_partition_by_key) into the nparts chunks of
+ * `packed` (nparts * sdqh_chunk_words(1 + npayload, chunk_rows) words of device memory; CPU build: host), chunk p at word
+ * p * sdqh_chunk_words(...): the layout of an equal-split all-to-all.  A chunk's header counts every row meant for it; rows beyond
+ * chunk_rows are dropped.  Rows keep no particular order inside a chunk.  Queued on the ctx stream; nothing is waited for.
+ * SDQH_ERR_UNSUPPORTED: a table whose staged rows may repeat a key (use sdqh_table_entries + sdqh_partition_pack). */
+int sdqh_table_partition_pack(sdqh_ctx* ctx, const sdqh_table* table, int nparts, const int64_t* range_upper, int64_t chunk_rows, void* packed);
+/* The receiving side: nparts chunks (as received from the ranks, in rank order) -> ncols freshly allocated columns of
+ * nparts * chunk_rows rows: the sources' rows back to back (min(header, chunk_rows) of each), then PADDING rows up to the capacity —
+ * column 0 (the key) holds pad_key there, the other columns 0 — so that whatever consumes the columns can be launched on the capacity
+ * without knowing the count (the caller picks a pad_key its consumer drops: a key no table holds, a key a gate rejects).  dtypes as
+ * for sdqh_unpack_parts; the columns are transient.  `sent` (may be null): this rank's own packed send buffer of the same step, read for
+ * its header counts only.  `stat`: an I64 column of >= SDQH_EXCHANGE_STAT_WORDS rows in device memory that the caller zeroed before the
+ * step's first exchange; exchange number `slot` (0 .. 3) records
+ *   stat[SDQH_STAT_MAX_COUNT + slot]            the largest header count among the chunks received and sent (> chunk_rows: rows were lost)
+ *   stat[SDQH_STAT_DETAIL + 4 * slot + 0 .. 3]  rows received, rows sent to all parts, rows sent to part `self_part`, chunk_rows
+ * The first four words are meant to be all-reduced (MAX) over the ranks: every rank then knows whether any chunk of the step
+ * overflowed anywhere, and the largest count is the next run's bound.  Queued on the ctx stream; nothing is waited for. */
+#define SDQH_EXCHANGE_STAT_WORDS 32
+#define SDQH_STAT_MAX_COUNT 0
+#define SDQH_STAT_DETAIL 8
+int sdqh_unpack_chunks(sdqh_ctx* ctx, const void* packed, int nparts, int ncols, const int* dtypes, int64_t chunk_rows, int64_t pad_key,
+                       const void* sent, int self_part, sdqh_column* stat, int slot, sdqh_column** out_cols);
+
+/* ---- plan graphs (ABI 5): a prepared plan's device calls recorded once, replayed by ONE call -------------------------------------------
+ * The reference compiles a query into one function (...generator_par.py:839-890); here a query is a dozen calls, each of which
+ * analyses its arguments and launches a kernel or two — a third of a 0.6 ms step is the host issuing them.  Between sdqh_graph_begin
+ * and sdqh_graph_end every launch, copy and fill the calls on `ctx` make is RECORDED instead of executed (HIP stream capture); nothing
+ * may wait for the device in between (such a call fails with SDQH_ERR_UNSUPPORTED and the recording is dropped: sdqh_graph_abort).
+ * What the recorded calls allocate from the context's pool — tables, staging buffers — belongs to the graph until sdqh_graph_free:
+ * freeing a recorded table releases its handle, not its memory.  sdqh_graph_launch queues the whole recording on the ctx stream:
+ * same kernels, same arguments, same addresses; the host words the recorded calls initialise (the completion words of
+ * sdqh_table_compact_deferred / sdqh_xgroupby_async result blocks) are reset first, so the caller collects from the same blocks
+ * exactly as after the recorded calls.  The caller guarantees what the recording assumed: the same resident columns with the same
+ * contents, the same bound constants, result blocks collected before the next launch of the same graph.  CPU build: begin / end
+ * record nothing and sdqh_graph_end returns SDQH_ERR_UNSUPPORTED (the caller keeps issuing the calls). */
+typedef struct sdqh_graph sdqh_graph;
+int sdqh_graph_begin(sdqh_ctx* ctx);
+int sdqh_graph_end(sdqh_ctx* ctx, sdqh_graph** out);
+int sdqh_graph_abort(sdqh_ctx* ctx);
+int sdqh_graph_launch(sdqh_ctx* ctx, sdqh_graph* graph);
+int sdqh_graph_nodes(const sdqh_graph* graph);      /* kernels, copies and fills the recording holds (-1: no graph) */
+void sdqh_graph_free(sdqh_ctx* ctx, sdqh_graph* graph);
+
 /* Device-to-device (CPU build: memcpy) copy of rows [row0, row0+nrows) of an I64/F64 column to or
  * from caller-owned memory of the same kind (e.g. a torch tensor used as a collective buffer).
  * Returns after the copy has completed — unless the option "async_copies" is 1: then the copy is

@@ -114,6 +114,7 @@ struct sdqh_table {
     bool accumulate = false;
     std::vector<Acc> acc;                            // entry -> accumulators + hits
     std::vector<int64_t> alias;                      // sdqh_table_share_groups: entry -> entry whose accumulators it uses
+    bool stage_only = false;                         // sdqh_xstage: every passing row (equal keys included), nothing indexed
     // bitmap-only membership table (sdqh_table_from_bitmap)
     bool bitmap_only = false;
     int64_t bm_lo = 0, bm_hi = -1;
@@ -1505,6 +1506,84 @@ int sdqh_unpack_parts(sdqh_ctx* ctx, const void* packed, int nparts, const int64
     *out_rows = total;
     return SDQH_OK;
 }
+
+// ---- device-sized redistribution (ABI 5): the same chunk layout, computed in one go on the host ------------------------------------
+int sdqh_xstage(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, sdqh_table** out) {
+    if (!ctx || nrows < 0 || !prog || !out) return fail(ctx, SDQH_ERR_INVALID, "xstage: bad arguments");
+    if (1 + prog->nvals > SDQH_MAX_COMPACT_COLS) return fail(ctx, SDQH_ERR_INVALID, "xstage: too many columns");
+    XProg xp;
+    if (int rc = make_xprog(ctx, nrows, prog, SDQH_MAX_PAYLOAD, true, false, &xp)) return rc;
+    sdqh_table* tb = new sdqh_table();                                // the filter half of the probe loop (378-447), materialised: every passing row
+    tb->npayload = xp.nvals; tb->stage_only = true; tb->nrows_build = nrows;
+    XRow x;
+    for (int64_t r = 0; r < nrows; ++r) {
+        if (!xp.row(r, x)) continue;
+        if (x.bad[prog->key]) { delete tb; return fail(ctx, SDQH_ERR_UNSUPPORTED, "xstage: a key part outside [0, 2^32)"); }
+        tb->keys.push_back(x.i[prog->key]);
+        for (int k = 0; k < xp.nvals; ++k) tb->payload.push_back(x.i[prog->vals[k]]);
+    }
+    *out = tb;
+    return SDQH_OK;
+}
+
+int64_t sdqh_chunk_words(int ncols, int64_t chunk_rows) { return (ncols < 1 || chunk_rows < 0) ? -1 : 2 + (int64_t)ncols * chunk_rows; }
+
+int sdqh_table_partition_pack(sdqh_ctx* ctx, const sdqh_table* table, int nparts, const int64_t* range_upper, int64_t chunk_rows, void* packed) {
+    if (!ctx || !table || nparts < 1 || nparts > SDQH_MAX_PARTS || chunk_rows < 1 || !packed) return fail(ctx, SDQH_ERR_INVALID, "table_partition_pack: bad arguments");
+    if (table->bitmap_only) return fail(ctx, SDQH_ERR_INVALID, "table_partition_pack: not a staged table");
+    const int ncols = 1 + table->npayload;
+    if (ncols > SDQH_MAX_COMPACT_COLS) return fail(ctx, SDQH_ERR_INVALID, "table_partition_pack: too many columns");
+    const int64_t cw = sdqh_chunk_words(ncols, chunk_rows);
+    int64_t* out = (int64_t*)packed;
+    for (int p = 0; p < nparts; ++p) { out[(int64_t)p * cw] = 0; out[(int64_t)p * cw + 1] = 0; }
+    for (size_t e = 0; e < table->keys.size(); ++e) {
+        const int p = part_of(table->keys[e], nparts, range_upper);
+        int64_t* chunk = out + (int64_t)p * cw;
+        const int64_t at = chunk[0]++;                                // the header counts every row meant for the chunk
+        if (at >= chunk_rows) continue;                               // ... rows beyond its capacity are dropped
+        chunk[2 + at] = table->keys[e];
+        for (int c = 1; c < ncols; ++c) chunk[2 + (int64_t)c * chunk_rows + at] = table->payload[e * (size_t)table->npayload + (size_t)(c - 1)];
+    }
+    return SDQH_OK;
+}
+
+int sdqh_unpack_chunks(sdqh_ctx* ctx, const void* packed, int nparts, int ncols, const int* dtypes, int64_t chunk_rows, int64_t pad_key,
+                       const void* sent, int self_part, sdqh_column* stat, int slot, sdqh_column** out_cols) {
+    if (!ctx || !packed || nparts < 1 || nparts > SDQH_MAX_PARTS || ncols < 1 || ncols > SDQH_MAX_COMPACT_COLS || !dtypes || chunk_rows < 1 || !out_cols || slot < 0 || slot > 3)
+        return fail(ctx, SDQH_ERR_INVALID, "unpack_chunks: bad arguments");
+    if (stat && (stat->dtype != SDQH_I64 || stat->nrows < SDQH_EXCHANGE_STAT_WORDS)) return fail(ctx, SDQH_ERR_INVALID, "unpack_chunks: stat must be an I64 column of SDQH_EXCHANGE_STAT_WORDS rows");
+    const int64_t cw = sdqh_chunk_words(ncols, chunk_rows), cap = (int64_t)nparts * chunk_rows;
+    for (int c = 0; c < ncols; ++c) {
+        if (dtypes[c] != SDQH_I64 && dtypes[c] != SDQH_F64) return fail(ctx, SDQH_ERR_INVALID, "unpack_chunks: columns are I64 / F64");
+        if (int rc = sdqh_column_alloc(ctx, cap, dtypes[c], 0, &out_cols[c])) return rc;
+    }
+    const int64_t* in = (const int64_t*)packed;
+    const int64_t* mine = (const int64_t*)sent;
+    int64_t done = 0, most = 0, sent_all = 0, sent_self = 0;
+    for (int s = 0; s < nparts; ++s) {
+        const int64_t meant = in[(int64_t)s * cw], n = std::min(meant, chunk_rows);
+        most = std::max(most, meant);
+        for (int c = 0; c < ncols; ++c) std::memcpy((int64_t*)out_cols[c]->data + done, in + (int64_t)s * cw + 2 + (int64_t)c * chunk_rows, (size_t)n * 8);
+        done += n;
+        if (mine) { const int64_t m = mine[(int64_t)s * cw], mc = std::min(m, chunk_rows); most = std::max(most, m); sent_all += mc; if (s == self_part) sent_self = mc; }
+    }
+    for (int c = 0; c < ncols; ++c) for (int64_t r = done; r < cap; ++r) ((int64_t*)out_cols[c]->data)[r] = c == 0 ? pad_key : 0;
+    if (stat) {
+        int64_t* st = (int64_t*)stat->data;
+        st[SDQH_STAT_MAX_COUNT + slot] = std::max(st[SDQH_STAT_MAX_COUNT + slot], most);
+        int64_t* d = st + SDQH_STAT_DETAIL + 4 * slot;
+        d[0] = done; d[1] = sent_all; d[2] = sent_self; d[3] = chunk_rows;
+    }
+    return SDQH_OK;
+}
+
+// ---- plan graphs (ABI 5): the CPU implementation has no launches to record — the caller keeps issuing the calls ----------------------
+int sdqh_graph_begin(sdqh_ctx* ctx) { return ctx ? SDQH_OK : SDQH_ERR_INVALID; }
+int sdqh_graph_end(sdqh_ctx* ctx, sdqh_graph** out) { if (out) *out = nullptr; return fail(ctx, SDQH_ERR_UNSUPPORTED, "graph_end: the CPU implementation records nothing"); }
+int sdqh_graph_abort(sdqh_ctx* ctx) { return ctx ? SDQH_OK : SDQH_ERR_INVALID; }
+int sdqh_graph_launch(sdqh_ctx* ctx, sdqh_graph*) { return fail(ctx, SDQH_ERR_INVALID, "graph_launch: no graph"); }
+int sdqh_graph_nodes(const sdqh_graph*) { return -1; }
+void sdqh_graph_free(sdqh_ctx*, sdqh_graph*) {}
 
 int sdqh_column_copy_out(sdqh_ctx* ctx, const sdqh_column* col, int64_t row0, int64_t nrows, void* dst) {
     if (!ctx || !col || col->dtype == SDQH_STR || row0 < 0 || nrows < 0 || row0 + nrows > col->nrows || (nrows && !dst)) return fail(ctx, SDQH_ERR_INVALID, "column_copy_out: bad arguments");

@@ -12,7 +12,7 @@ import math
 import numpy as np
 
 MAX_SHARE_CELLS = 1 << 28  # SDQH_MAX_SHARE_CELLS
-ABI_VERSION = 4            # include/sdqh.h: SDQH_ABI_VERSION (struct layouts below must match the library's)
+ABI_VERSION = 5            # include/sdqh.h: SDQH_ABI_VERSION (struct layouts below must match the library's)
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_OVERFLOW, ERR_NOMEM = range(6)
 I64, F64, STR = 0, 1, 2
 TUPLE_A, TUPLE_AB, TUPLE_A_1MB, TUPLE_PRICING, TUPLE_A_1MB_M_CD, TUPLE_COUNT = 1, 2, 3, 4, 5, 6
@@ -220,7 +220,10 @@ EXPORTS = [
     "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in", "sdqh_column_unpack2", "sdqh_partition_pack", "sdqh_unpack_parts", "sdqh_column_mark_transient", "sdqh_column_set_bounds",
     "sdqh_build", "sdqh_lookup_aggregate", "sdqh_table_entries", "sdqh_host_alloc", "sdqh_host_free", "sdqh_table_topk",
     "sdqh_xscan_sum", "sdqh_xgroupby", "sdqh_xgroupby_block_bytes", "sdqh_xgroupby_async", "sdqh_xgroupby_collect", "sdqh_xbuild", "sdqh_xkey_set", "sdqh_xcompact", "sdqh_xprobe_aggregate", "sdqh_table_columns", "sdqh_jit_stats", "sdqh_jit_compile",
+    "sdqh_xstage", "sdqh_chunk_words", "sdqh_table_partition_pack", "sdqh_unpack_chunks",
+    "sdqh_graph_begin", "sdqh_graph_end", "sdqh_graph_abort", "sdqh_graph_launch", "sdqh_graph_nodes", "sdqh_graph_free",
 ]
+EXCHANGE_STAT_WORDS, STAT_MAX_COUNT, STAT_DETAIL = 32, 0, 8      # include/sdqh.h: SDQH_EXCHANGE_STAT_WORDS, SDQH_STAT_MAX_COUNT, SDQH_STAT_DETAIL
 
 
 def _np_ptr(a):
@@ -340,6 +343,29 @@ def lt_float(c):
 def gt_float(c):
     """lo bound equivalent to `x > c`."""
     return math.nextafter(c, math.inf)
+
+
+class Graph:
+    """A recorded plan (sdqh_graph): launch() queues every recorded kernel / copy / fill on the context's stream in one call."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.handle = ctx, handle
+        self.nodes = int(ctx.lib.sdqh_graph_nodes(handle))
+
+    def launch(self):
+        self.ctx._check(self.ctx.lib.sdqh_graph_launch(self.ctx.handle, self.handle))
+
+    def free(self):
+        if self.handle is not None:
+            if self.ctx.handle is not None:
+                self.ctx.lib.sdqh_graph_free(self.ctx.handle, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Context:
@@ -730,6 +756,51 @@ class Context:
         self._after_call("xbuild")
         return Table(self, h, len(prog.vals), accumulate)
 
+    def xstage(self, nrows, prog):
+        """sdqh_xstage: every passing row of the program staged on the device (key, vals; equal keys included; nothing indexed) — the
+        source of table_partition_pack.  How many rows it holds stays on the device."""
+        h = C.c_void_p()
+        self._check(self.lib.sdqh_xstage(self.handle, C.c_int64(nrows), C.byref(prog.struct()), C.byref(h)))
+        self._after_call("xstage")
+        return Table(self, h, len(prog.vals), False)
+
+    def chunk_words(self, ncols, chunk_rows):
+        return int(self.lib.sdqh_chunk_words(C.c_int(ncols), C.c_int64(chunk_rows)))
+
+    def table_partition_pack(self, table, nparts, chunk_rows, packed_ptr, range_upper=None):
+        """sdqh_table_partition_pack: the table's staged rows into nparts fixed-capacity chunks at packed_ptr (the layout of an
+        equal-split all-to-all), their counts in the chunk headers; nothing is waited for."""
+        ru = None
+        if range_upper is not None:
+            ru = np.ascontiguousarray(range_upper, np.int64)
+            assert len(ru) == nparts - 1
+        self._check(self.lib.sdqh_table_partition_pack(self.handle, table.handle, C.c_int(nparts), _np_ptr(ru), C.c_int64(chunk_rows), C.c_void_p(packed_ptr)))
+        self._after_call("table_partition_pack")
+
+    def unpack_chunks(self, packed_ptr, nparts, dtypes, chunk_rows, pad_key, stat, slot, sent_ptr=None, self_part=0):
+        """sdqh_unpack_chunks: the received chunks as Columns of nparts * chunk_rows rows — the sources' rows, then padding rows (key
+        pad_key); the step's counts recorded in `stat` (an I64 Column of EXCHANGE_STAT_WORDS rows).  Nothing is waited for."""
+        dts = (C.c_int * len(dtypes))(*[int(d) for d in dtypes])
+        outs = (C.c_void_p * len(dtypes))()
+        self._check(self.lib.sdqh_unpack_chunks(self.handle, C.c_void_p(packed_ptr), C.c_int(nparts), C.c_int(len(dtypes)), dts, C.c_int64(chunk_rows), C.c_int64(pad_key),
+                                                C.c_void_p(sent_ptr), C.c_int(self_part), stat.handle if stat is not None else None, C.c_int(slot), outs))
+        self._after_call("unpack_chunks")
+        return [Column(self, C.c_void_p(outs[i]), nparts * chunk_rows, dtypes[i], 0) for i in range(len(dtypes))]
+
+    # -- plan graphs (sdqh_graph_*): a prepared plan's device calls recorded once, replayed by one call --------------------------
+    def graph_begin(self):
+        self._check(self.lib.sdqh_graph_begin(self.handle))
+
+    def graph_end(self):
+        """-> Graph, or raises SdqhError(ERR_UNSUPPORTED) when the recording is no graph (the CPU implementation; a call that waited)."""
+        h = C.c_void_p()
+        self._check(self.lib.sdqh_graph_end(self.handle, C.byref(h)))
+        return Graph(self, h)
+
+    def graph_abort(self):
+        if self.handle is not None:
+            self.lib.sdqh_graph_abort(self.handle)
+
     def xcompact(self, nrows, prog):
         """(Columns [key, vals...] as I64 bit patterns, n): every passing row of the program, duplicate keys included."""
         k = 1 + len(prog.vals)
@@ -1059,6 +1130,18 @@ class Library:
         L.sdqh_xprobe_aggregate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
         L.sdqh_table_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.sdqh_jit_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sdqh_xstage.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.sdqh_chunk_words.argtypes = [C.c_int, C.c_int64]
+        L.sdqh_chunk_words.restype = C.c_int64
+        L.sdqh_table_partition_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
+        L.sdqh_unpack_chunks.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.sdqh_graph_begin.argtypes = [C.c_void_p]
+        L.sdqh_graph_end.argtypes = [C.c_void_p, C.c_void_p]
+        L.sdqh_graph_abort.argtypes = [C.c_void_p]
+        L.sdqh_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
+        L.sdqh_graph_nodes.argtypes = [C.c_void_p]
+        L.sdqh_graph_free.restype = None
+        L.sdqh_graph_free.argtypes = [C.c_void_p, C.c_void_p]
         L.sdqh_build.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.sdqh_lookup_aggregate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

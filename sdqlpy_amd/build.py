@@ -19,7 +19,7 @@ TBL_LIB = os.path.join(CSRC, "libsdqltbl.so")
 # Two translation units: the ahead-of-time kernels + their C ABI (minutes to compile: hundreds of template
 # instances), and the row-program path (code generation + hiprtc; seconds).  Objects are kept next to the
 # sources so a change to one does not recompile the other.
-HIP_UNITS = [("sdqh_hip.hip", "sdqh_hip.o"), ("sdqh_x.hip", "sdqh_x.o"), ("sdqh_codes.hip", "sdqh_codes.o")]
+HIP_UNITS = [("sdqh_hip.hip", "sdqh_hip.o"), ("sdqh_x.hip", "sdqh_x.o"), ("sdqh_codes.hip", "sdqh_codes.o"), ("sdqh_aux.hip", "sdqh_aux.o")]
 HIP_SOURCES = [os.path.join(CSRC, src) for src, _ in HIP_UNITS]
 HIP_HEADERS = [os.path.join(INCLUDE, "sdqh.h"), os.path.join(CSRC, "sdqh_kernels.hpp"), os.path.join(CSRC, "sdqh_host.hpp"),
                os.path.join(CSRC, "sdqh_xkernels.hpp")]      # sdqh_x.hip packs XArgs / sink arguments from its structs

@@ -1,0 +1,393 @@
+// sdqh_aux.hip — the parts of the C ABI that keep the HOST out of a run (round 5):
+//
+//   sdqh_table_compact_deferred   K-F with nothing waited for (moved here from sdqh_hip.hip: it is the one ahead-of-time call a recorded
+//                                 plan ends in, and this unit compiles in seconds)
+//   sdqh_table_partition_pack /   a redistribution step of the partitioned join sized on the DEVICE: fixed-capacity chunks with their
+//   sdqh_unpack_chunks            row counts in the chunk headers, so the counts travel with the data through one equal-split
+//                                 all-to-all and the host never reads them (include/sdqh.h, ABI 5)
+//   sdqh_graph_*                  a prepared plan's device calls recorded once into a hipGraph (stream capture) and replayed by one
+//                                 call: the counterpart of the reference compiling a query into ONE function
+//                                 (lib/sdql_ir_cpp_generator_par.py:839-890) — here the dozen calls of a query cost the host a third of
+//                                 a step to issue
+//
+// Nothing here has a counterpart in the reference beyond those citations: it has one process, one address space, no device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+
+#define SDQH_DECLS_ONLY 1            // argument structs and device helpers of the kernel header, not a second copy of its kernels
+#include "sdqh_host.hpp"
+
+using namespace sdqh_host;
+
+#define HIP_TRYA(ctx, expr)                                                                             \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+struct sdqh_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    sdqh_ctx* ctx = nullptr;
+    std::vector<sdqh_ctx::HostInit> inits;          // host words set again before every launch
+    int nodes = 0;
+};
+
+namespace {
+
+// one 32-bit word of device-visible host memory, stored by the stream itself: hipStreamWriteValue32 where the stream executes, a
+// one-thread kernel where it is being recorded (the value-write has no graph node)
+__global__ void k_store32(uint32_t* p, uint32_t v) { if (threadIdx.x == 0 && blockIdx.x == 0) { __atomic_store_n(p, v, __ATOMIC_RELEASE); } }
+
+// ---- redistribution kernels ----------------------------------------------------------------------------------------------------------
+constexpr int PP_SEGS_PER_WAVE = 2;                  // stage segments a wave of the partitioning kernel walks: 8 per workgroup, ONE claim per part and workgroup
+
+// The staged rows of a table (DevStage: per-wave segments, seg_count[s] live rows each) scattered into nparts fixed-capacity chunks.
+// Pass 1 counts the workgroup's rows per part in LDS, one thread per part claims the workgroup's range in the chunk (the chunk's own
+// header word is the cursor: it ends up holding every row MEANT for the chunk), pass 2 places the rows — rank inside the workgroup by a
+// second LDS counter; the lanes of a wave that go to one part take consecutive places, so the stores are runs.
+__global__ __launch_bounds__(TPB) void k_stage_part_pack(DevStage st, DevPartition pt, int ncols, int64_t chunk_rows, int64_t chunk_words, int64_t* __restrict__ packed) {
+    __shared__ unsigned int s_hist[SDQH_MAX_PARTS];
+    __shared__ unsigned int s_rank[SDQH_MAX_PARTS];
+    __shared__ unsigned long long s_base[SDQH_MAX_PARTS];
+    if (threadIdx.x < SDQH_MAX_PARTS) { s_hist[threadIdx.x] = 0; s_rank[threadIdx.x] = 0; }
+    __syncthreads();
+    const int wave = (int)(threadIdx.x / WAVE), lane = (int)(threadIdx.x & (WAVE - 1));
+    const int seg0 = ((int)blockIdx.x * (TPB / WAVE) + wave) * PP_SEGS_PER_WAVE;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int j = 0; j < PP_SEGS_PER_WAVE; ++j) {
+            const int seg = seg0 + j;
+            if (seg >= st.nseg) break;
+            const int64_t base = (int64_t)seg * st.seg_rows;
+            const uint32_t count = st.seg_count[seg];
+            for (uint32_t i0 = 0; i0 < count; i0 += WAVE) {
+                const bool live = i0 + lane < count;
+                const int64_t row = base + i0 + lane;
+                const int64_t key = live ? st.key[row] : 0;
+                const int part = live ? part_of(pt, key) : -1;
+                unsigned long long todo = __ballot(live);
+                unsigned int place = 0;
+                while (todo) {                                            // one round per distinct part among the wave's rows
+                    const int leader = __builtin_ctzll(todo);
+                    const int p = __shfl(part, leader, WAVE);
+                    const unsigned long long mine = __ballot(live && part == p);
+                    const unsigned int n = (unsigned int)__builtin_popcountll(mine);
+                    unsigned int first = 0;
+                    if (lane == leader) first = atomicAdd(pass == 0 ? &s_hist[p] : &s_rank[p], n);
+                    first = (unsigned int)__shfl((int)first, leader, WAVE);
+                    if (live && part == p) place = first + (unsigned int)__builtin_popcountll(mine & ((1ull << lane) - 1ull));
+                    todo &= ~mine;
+                }
+                if (pass == 1 && live) {
+                    const uint64_t at = s_base[part] + place;
+                    if (at < (uint64_t)chunk_rows) {
+                        int64_t* chunk = packed + (int64_t)part * chunk_words + 2;
+                        chunk[at] = key;
+#pragma unroll
+                        for (int c = 1; c < SDQH_MAX_COMPACT_COLS; ++c) if (c < ncols) chunk[(int64_t)c * chunk_rows + at] = st.pay[c - 1][row];
+                    }
+                }
+            }
+        }
+        if (pass == 0) {
+            __syncthreads();
+            if ((int)threadIdx.x < pt.nparts)
+                s_base[threadIdx.x] = s_hist[threadIdx.x] ? atomicAdd(reinterpret_cast<unsigned long long*>(packed + (int64_t)threadIdx.x * chunk_words), (unsigned long long)s_hist[threadIdx.x]) : 0ull;
+            __syncthreads();
+        }
+    }
+}
+
+struct DevChunkUnpack {
+    const int64_t* packed; const int64_t* sent;
+    int64_t* out[SDQH_MAX_COMPACT_COLS];
+    int64_t* stat;
+    int64_t chunk_rows, chunk_words, pad_key;
+    int32_t nparts, ncols, self_part, slot;
+};
+// blockIdx.y = source * ncols + column: that source's rows of that column to their place behind the earlier sources' rows (every block
+// sums the <= 64 headers before its source itself); blockIdx.y = nparts * ncols + column: the padding rows of that column.  The first
+// block also records the step's figures in `stat`.
+__global__ __launch_bounds__(TPB) void k_unpack_chunks(DevChunkUnpack u) {
+    const int y = (int)blockIdx.y;
+    const bool padding = y >= u.nparts * u.ncols;
+    const int s = padding ? u.nparts : y / u.ncols, c = padding ? y - u.nparts * u.ncols : y % u.ncols;
+    int64_t before = 0;
+    for (int t = 0; t < s; ++t) { const int64_t n = u.packed[(int64_t)t * u.chunk_words]; before += n < u.chunk_rows ? n : u.chunk_rows; }
+    int64_t* to = nullptr;
+#pragma unroll
+    for (int k = 0; k < SDQH_MAX_COMPACT_COLS; ++k) if (k == c) to = u.out[k];
+    if (padding) {
+        const int64_t cap = (int64_t)u.nparts * u.chunk_rows, v = c == 0 ? u.pad_key : 0;
+        for (int64_t i = before + (int64_t)blockIdx.x * TPB + threadIdx.x; i < cap; i += (int64_t)gridDim.x * TPB) to[i] = v;
+    } else {
+        int64_t n = u.packed[(int64_t)s * u.chunk_words];
+        n = n < u.chunk_rows ? n : u.chunk_rows;
+        const int64_t* from = u.packed + (int64_t)s * u.chunk_words + 2 + (int64_t)c * u.chunk_rows;
+        to += before;
+        for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) to[i] = from[i];
+    }
+    if (y == 0 && blockIdx.x == 0 && threadIdx.x == 0 && u.stat) {
+        int64_t most = 0, recv = 0, sent_all = 0, sent_self = 0;
+        for (int t = 0; t < u.nparts; ++t) {
+            const int64_t n = u.packed[(int64_t)t * u.chunk_words];
+            most = n > most ? n : most; recv += n < u.chunk_rows ? n : u.chunk_rows;
+            if (u.sent) {
+                const int64_t m = u.sent[(int64_t)t * u.chunk_words];
+                most = m > most ? m : most;
+                const int64_t mc = m < u.chunk_rows ? m : u.chunk_rows;
+                sent_all += mc; if (t == u.self_part) sent_self = mc;
+            }
+        }
+        int64_t* d = u.stat + SDQH_STAT_DETAIL + 4 * u.slot;
+        if (most > u.stat[SDQH_STAT_MAX_COUNT + u.slot]) u.stat[SDQH_STAT_MAX_COUNT + u.slot] = most;
+        d[0] = recv; d[1] = sent_all; d[2] = sent_self; d[3] = u.chunk_rows;
+    }
+}
+
+}  // namespace
+
+namespace sdqh_host {
+int stream_store32(sdqh_ctx* ctx, hipStream_t s, uint32_t* word, uint32_t value) {
+    if (ctx->capturing) {
+        hipLaunchKernelGGL(k_store32, dim3(1), dim3(64), 0, s, word, value);
+        return hipGetLastError() == hipSuccess ? SDQH_OK : SDQH_ERR_DEVICE;
+    }
+    if (hipStreamWriteValue32(s, word, value, 0) != hipSuccess) { (void)hipGetLastError(); return SDQH_ERR_DEVICE; }
+    return SDQH_OK;
+}
+}  // namespace sdqh_host
+
+extern "C" {
+
+// K-F with NOTHING waited for: count -> write into a staging buffer -> the whole capacity-sized arrays copied out behind the kernels,
+// the row count landing in *out_n (a cell of the caller's device-visible block, -1 until then).  The caller collects after
+// sdqh_synchronize / sdqh_result_wait / the block's DONE word; a count above `capacity` means the rows beyond were dropped (fetch again,
+// larger).  While a plan graph is recorded (sdqh_graph_begin) the staging buffer is the graph's own and the copy stream is forked
+// from and joined to the ctx stream inside the recording.
+int sdqh_table_compact_deferred(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_hits, int64_t capacity,
+                                int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n) {
+    sdqh_table* table = const_cast<sdqh_table*>(ctable);
+    if (!ctx || !table || !out_n || capacity < 1 || !out_keys) return fail(ctx, SDQH_ERR_INVALID, "table_compact_deferred: bad arguments");
+    if (table->bitmap_only || table->stage_only) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_compact_deferred: bitmap-only / stage-only table");
+    (void)hipSetDevice(ctx->device);
+    const int npay = out_payload ? table->npay : 0, nval = (out_values && table->accumulate) ? table->nv : 0;
+    const size_t cb = (size_t)capacity * 8;
+    char* base = reinterpret_cast<char*>(out_keys);
+    const int narr = 1 + (out_payload ? table->npay : 0) + (out_values ? SDQH_TUPLE_MAX_VALUES : 0) + (out_hits ? 1 : 0);
+    bool contiguous = host_block_contains(ctx, base, cb * (size_t)narr) && host_block_contains(ctx, out_n, 16);
+    size_t at = cb;
+    if (out_payload) { contiguous = contiguous && reinterpret_cast<char*>(out_payload) == base + at; at += cb * (size_t)table->npay; }
+    if (out_values) { contiguous = contiguous && reinterpret_cast<char*>(out_values) == base + at; at += cb * SDQH_TUPLE_MAX_VALUES; }
+    if (out_hits) { contiguous = contiguous && reinterpret_cast<char*>(out_hits) == base + at; at += cb; }
+    if (!ctx->opt_async_result || !contiguous) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_compact_deferred: the result arrays must be one sdqh_host_alloc block laid out keys | payload | values | hits");
+    hipStream_t side = copy_stream(ctx);
+    if (!ctx->count_host && hipHostMalloc(&ctx->count_host, 256, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->count_host = nullptr; }
+    const bool rec = ctx->capturing;
+    const int b = ctx->rs_cur;
+    if (!rec && !ctx->rs_copied[b] && hipEventCreateWithFlags(&ctx->rs_copied[b], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->rs_copied[b] = nullptr; }
+    if (!ctx->rs_ready && hipEventCreateWithFlags(&ctx->rs_ready, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->rs_ready = nullptr; }
+    if (!side || !ctx->count_host || (!rec && !ctx->rs_copied[b]) || !ctx->rs_ready) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_compact_deferred: no side stream");
+    const size_t need = cb * (size_t)narr;
+    char* dev = nullptr;
+    if (rec) {
+        dev = static_cast<char*>(pool_alloc(ctx, need + 64));          // the graph's own (pool blocks allocated while recording stay with the graph)
+        if (!dev) return fail(ctx, SDQH_ERR_NOMEM, "table_compact_deferred: out of device memory");
+    } else {
+        if (ctx->rs_bytes[b] < need) {
+            if (ctx->rs_used[b]) HIP_TRYA(ctx, hipEventSynchronize(ctx->rs_copied[b]));
+            if (ctx->rs_dev[b]) (void)hipFree(ctx->rs_dev[b]);
+            ctx->rs_dev[b] = nullptr; ctx->rs_bytes[b] = 0;
+            const size_t want = std::max<size_t>(need + need / 4, (size_t)4 << 20);
+            if (hipMalloc(&ctx->rs_dev[b], want) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, SDQH_ERR_NOMEM, "table_compact_deferred: out of device memory"); }
+            ctx->rs_bytes[b] = want;
+        }
+        dev = static_cast<char*>(ctx->rs_dev[b]);
+    }
+    call_begin(ctx);
+    if (int rc = index_ensure(ctx, table)) return rc;
+    if (!rec && ctx->rs_used[b]) HIP_TRYA(ctx, hipStreamWaitEvent(ctx->stream, ctx->rs_copied[b], 0));       // the buffer's last copy has left it
+    DevCompactOut o; std::memset(&o, 0, sizeof(o));
+    size_t off = 0;
+    o.keys = reinterpret_cast<int64_t*>(dev); off += cb;
+    for (int p = 0; p < (out_payload ? table->npay : 0); ++p) { o.pay[p] = reinterpret_cast<int64_t*>(dev + off); off += cb; }
+    if (out_values) { for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) { if (k < nval) o.val[k] = reinterpret_cast<double*>(dev + off); off += cb; } }
+    if (out_hits) { o.hits = reinterpret_cast<int64_t*>(dev + off); off += cb; }
+    o.npay = npay; o.nval = nval;
+    o.counter = reinterpret_cast<unsigned long long*>(static_cast<char*>(ctx->count_host) + 64);
+    host_init(ctx, &out_n[0], (uint64_t)-1ll, 8);
+    host_init(ctx, &out_n[1], 0, 8);
+    o.h_counter = reinterpret_cast<unsigned long long*>(out_n);                                      // the kernel's own store of the total, into the caller's block
+    o.host_rows = (uint64_t)capacity; o.bounded = 1;
+    const uint32_t mh = (uint32_t)std::min<int64_t>(std::max<int64_t>(min_hits, 0), 0xFFFFFFFFll);
+    if (int rc = launch_compact_pair(ctx, table, o, mh)) return rc;
+    call_end(ctx);
+    // the copy waits for the kernels by an event, not the host: keys .. the last used value array in one piece, then the hit counts
+    HIP_TRYA(ctx, hipEventRecord(ctx->rs_ready, ctx->stream));
+    HIP_TRYA(ctx, hipStreamWaitEvent(side, ctx->rs_ready, 0));
+    const int lead = 1 + (out_payload ? table->npay : 0) + nval;
+    HIP_TRYA(ctx, hipMemcpyAsync(base, dev, cb * (size_t)lead, hipMemcpyDeviceToHost, side));
+    if (out_hits) HIP_TRYA(ctx, hipMemcpyAsync(out_hits, o.hits, cb, hipMemcpyDeviceToHost, side));
+    // out_n[1]: the DONE word of this result, written by the copy stream itself behind the copies (1; 2 = no marker: wait with sdqh_result_wait)
+    if (stream_store32(ctx, side, reinterpret_cast<uint32_t*>(&out_n[1]), 1) != SDQH_OK) out_n[1] = 2;
+    if (rec) {
+        // join: a recording ends with every forked stream back on the origin (the next replay's kernels then start behind this replay's copy)
+        HIP_TRYA(ctx, hipEventRecord(ctx->rs_ready, side));
+        HIP_TRYA(ctx, hipStreamWaitEvent(ctx->stream, ctx->rs_ready, 0));
+    } else {
+        HIP_TRYA(ctx, hipEventRecord(ctx->rs_copied[b], side));
+        ctx->rs_used[b] = true; ctx->rs_pending = true; ctx->rs_cur = b ^ 1;
+    }
+    if (out_values) for (int k = nval; k < SDQH_TUPLE_MAX_VALUES; ++k) std::memset(out_values + (size_t)k * (size_t)capacity, 0, cb);
+    return SDQH_OK;
+}
+
+// ---- device-sized redistribution --------------------------------------------------------------------------------------------------------
+int64_t sdqh_chunk_words(int ncols, int64_t chunk_rows) { return (ncols < 1 || chunk_rows < 0) ? -1 : 2 + (int64_t)ncols * chunk_rows; }
+
+int sdqh_table_partition_pack(sdqh_ctx* ctx, const sdqh_table* table, int nparts, const int64_t* range_upper, int64_t chunk_rows, void* packed) {
+    if (!ctx || !table || nparts < 1 || nparts > SDQH_MAX_PARTS || chunk_rows < 1 || !packed) return fail(ctx, SDQH_ERR_INVALID, "table_partition_pack: bad arguments");
+    if (table->bitmap_only || !table->stage.seg_count || !table->stage.key) return fail(ctx, SDQH_ERR_INVALID, "table_partition_pack: not a staged table");
+    if (!(table->stage_only || table->keys_unique)) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_partition_pack: the table's staged rows may repeat a key");
+    const int ncols = 1 + table->npay;
+    if (ncols > SDQH_MAX_COMPACT_COLS) return fail(ctx, SDQH_ERR_INVALID, "table_partition_pack: too many columns");
+    (void)hipSetDevice(ctx->device);
+    DevPartition pt; std::memset(&pt, 0, sizeof(pt)); pt.nparts = nparts; pt.by_range = range_upper ? 1 : 0;
+    if (range_upper) for (int p = 0; p < nparts - 1; ++p) pt.upper[p] = range_upper[p];
+    const int64_t cw = sdqh_chunk_words(ncols, chunk_rows);
+    call_begin(ctx);
+    // the headers double as the kernel's cursors: 16 bytes cleared at the head of every chunk (one strided memset)
+    HIP_TRYA(ctx, hipMemset2DAsync(packed, (size_t)cw * 8, 0, 16, (size_t)nparts, ctx->stream));
+    const int per_wg = (TPB / WAVE) * PP_SEGS_PER_WAVE;
+    const unsigned grid = (unsigned)std::max(1, (table->stage.nseg + per_wg - 1) / per_wg);
+    { KernelScope ks(ctx, "k_stage_part_pack");
+      hipLaunchKernelGGL(k_stage_part_pack, dim3(grid), dim3(TPB), 0, ctx->stream, table->stage, pt, ncols, chunk_rows, cw, static_cast<int64_t*>(packed)); }
+    call_end(ctx);
+    if (hipGetLastError() != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, "table_partition_pack: launch failed");
+    return SDQH_OK;
+}
+
+int sdqh_unpack_chunks(sdqh_ctx* ctx, const void* packed, int nparts, int ncols, const int* dtypes, int64_t chunk_rows, int64_t pad_key,
+                       const void* sent, int self_part, sdqh_column* stat, int slot, sdqh_column** out_cols) {
+    if (!ctx || !packed || nparts < 1 || nparts > SDQH_MAX_PARTS || ncols < 1 || ncols > SDQH_MAX_COMPACT_COLS || !dtypes || chunk_rows < 1 || !out_cols || slot < 0 || slot > 3)
+        return fail(ctx, SDQH_ERR_INVALID, "unpack_chunks: bad arguments");
+    if (stat && (stat->dtype != SDQH_I64 || stat->nrows < SDQH_EXCHANGE_STAT_WORDS)) return fail(ctx, SDQH_ERR_INVALID, "unpack_chunks: stat must be an I64 column of SDQH_EXCHANGE_STAT_WORDS rows");
+    (void)hipSetDevice(ctx->device);
+    DevChunkUnpack u; std::memset(&u, 0, sizeof(u));
+    u.packed = static_cast<const int64_t*>(packed); u.sent = static_cast<const int64_t*>(sent);
+    u.stat = stat ? static_cast<int64_t*>(stat->data) : nullptr;
+    u.chunk_rows = chunk_rows; u.chunk_words = sdqh_chunk_words(ncols, chunk_rows); u.pad_key = pad_key;
+    u.nparts = nparts; u.ncols = ncols; u.self_part = self_part; u.slot = slot;
+    const int64_t cap = (int64_t)nparts * chunk_rows;
+    sdqh_column* outs[SDQH_MAX_COMPACT_COLS] = {nullptr};
+    for (int c = 0; c < ncols; ++c) {
+        int rc = (dtypes[c] != SDQH_I64 && dtypes[c] != SDQH_F64) ? fail(ctx, SDQH_ERR_INVALID, "unpack_chunks: columns are I64 / F64") : sdqh_column_alloc(ctx, cap, dtypes[c], 0, &outs[c]);
+        if (rc) { for (int j = 0; j < c; ++j) sdqh_column_free(ctx, outs[j]); return rc; }
+        u.out[c] = static_cast<int64_t*>(outs[c]->data);
+        sdqh_column_mark_transient(ctx, outs[c]);                  // rows that live for one run: no twins, no dictionaries, no order facts
+    }
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((chunk_rows + TPB - 1) / TPB, 128));
+    { KernelScope ks(ctx, "k_unpack_chunks");
+      hipLaunchKernelGGL(k_unpack_chunks, dim3(gx, (unsigned)((nparts + 1) * ncols)), dim3(TPB), 0, ctx->stream, u); }
+    if (hipGetLastError() != hipSuccess) { for (int c = 0; c < ncols; ++c) sdqh_column_free(ctx, outs[c]); return fail(ctx, SDQH_ERR_DEVICE, "unpack_chunks: launch failed"); }
+    for (int c = 0; c < ncols; ++c) out_cols[c] = outs[c];
+    return SDQH_OK;
+}
+
+// ---- plan graphs -------------------------------------------------------------------------------------------------------------------------
+int sdqh_graph_begin(sdqh_ctx* ctx) {
+    if (!ctx || ctx->compile_only) return fail(ctx, SDQH_ERR_INVALID, "graph_begin: bad arguments");
+    if (ctx->capturing) return fail(ctx, SDQH_ERR_INVALID, "graph_begin: already recording");
+    if (ctx->profiling) return fail(ctx, SDQH_ERR_UNSUPPORTED, "graph_begin: profiling is on (its events are not part of a plan)");
+    (void)hipSetDevice(ctx->device);
+    (void)copy_stream(ctx);                                            // made outside the recording
+    if (!ctx->rs_ready && hipEventCreateWithFlags(&ctx->rs_ready, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->rs_ready = nullptr; }
+    sdqh_graph* g = new sdqh_graph();
+    g->ctx = ctx;
+    // relaxed: the recorded calls may allocate (hipMalloc for a pool block that is not there yet) — legal beside a capture in this mode
+    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); delete g; return fail(ctx, SDQH_ERR_UNSUPPORTED, "graph_begin: the stream cannot be captured"); }
+    ctx->capturing = true; ctx->capture_tag = g; ctx->capture_inits.clear();
+    return SDQH_OK;
+}
+
+static void release_graph_blocks(sdqh_ctx* ctx, const void* tag) {
+    for (auto& b : ctx->pool) if (b.graph_owner == tag) { b.graph_owner = nullptr; b.free = true; b.nhabits = 0; }
+}
+
+int sdqh_graph_abort(sdqh_ctx* ctx) {
+    if (!ctx) return SDQH_ERR_INVALID;
+    if (!ctx->capturing) return SDQH_OK;
+    hipGraph_t graph = nullptr;
+    (void)hipStreamEndCapture(ctx->stream, &graph);
+    (void)hipGetLastError();
+    if (graph) (void)hipGraphDestroy(graph);
+    sdqh_graph* g = const_cast<sdqh_graph*>(static_cast<const sdqh_graph*>(ctx->capture_tag));
+    ctx->capturing = false; ctx->capture_tag = nullptr; ctx->capture_inits.clear();
+    release_graph_blocks(ctx, g);                                       // nothing was executed: the blocks are free at once
+    rd_dirty(ctx);
+    delete g;
+    return SDQH_OK;
+}
+
+int sdqh_graph_end(sdqh_ctx* ctx, sdqh_graph** out) {
+    if (!ctx || !out) return fail(ctx, SDQH_ERR_INVALID, "graph_end: bad arguments");
+    if (!ctx->capturing) return fail(ctx, SDQH_ERR_INVALID, "graph_end: not recording");
+    sdqh_graph* g = const_cast<sdqh_graph*>(static_cast<const sdqh_graph*>(ctx->capture_tag));
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+    ctx->capturing = false; ctx->capture_tag = nullptr;
+    g->inits.swap(ctx->capture_inits);
+    ctx->capture_inits.clear();
+    rd_dirty(ctx);                                                      // the recorded calls' claims about the result block were about a run that never happened
+    if (e != hipSuccess || !graph) {
+        (void)hipGetLastError();
+        if (graph) (void)hipGraphDestroy(graph);
+        release_graph_blocks(ctx, g);
+        delete g;
+        return fail(ctx, SDQH_ERR_UNSUPPORTED, std::string("graph_end: the recording is not a graph: ") + hipGetErrorString(e));
+    }
+    g->graph = graph;
+    size_t n = 0;
+    if (hipGraphGetNodes(graph, nullptr, &n) == hipSuccess) g->nodes = (int)n; else (void)hipGetLastError();
+    if (hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipGraphDestroy(graph);
+        release_graph_blocks(ctx, g);
+        delete g;
+        return fail(ctx, SDQH_ERR_UNSUPPORTED, "graph_end: the graph cannot be instantiated");
+    }
+    *out = g;
+    return SDQH_OK;
+}
+
+int sdqh_graph_launch(sdqh_ctx* ctx, sdqh_graph* g) {
+    if (!ctx || !g || g->ctx != ctx || !g->exec) return fail(ctx, SDQH_ERR_INVALID, "graph_launch: bad arguments");
+    if (ctx->capturing) return fail(ctx, SDQH_ERR_INVALID, "graph_launch: recording");
+    (void)hipSetDevice(ctx->device);
+    for (const auto& h : g->inits) { if (h.bytes == 8) *static_cast<volatile uint64_t*>(h.p) = h.value; else *static_cast<volatile uint32_t*>(h.p) = (uint32_t)h.value; }
+    ++ctx->launch_seq;
+    rd_dirty(ctx);                                                      // the replayed kernels used the result block: no claim about it survives
+    HIP_TRYA(ctx, hipGraphLaunch(g->exec, ctx->stream));
+    return SDQH_OK;
+}
+
+int sdqh_graph_nodes(const sdqh_graph* g) { return g ? g->nodes : -1; }
+
+void sdqh_graph_free(sdqh_ctx* ctx, sdqh_graph* g) {
+    if (!g) return;
+    sdqh_ctx* c = ctx ? ctx : g->ctx;
+    if (c && !c->compile_only) {
+        (void)hipSetDevice(c->device);
+        if (c->stream) (void)hipStreamSynchronize(c->stream);           // a replay may still be running on the blocks about to be released
+        if (c->side[1]) (void)hipStreamSynchronize(c->side[1]);
+    }
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    if (c) release_graph_blocks(c, g);
+    delete g;
+}
+
+}  // extern "C"

@@ -44,7 +44,9 @@ void* pool_alloc(sdqh_ctx* ctx, size_t bytes) {
         PoolBlock& b = ctx->pool[i];
         if (b.free && b.size >= bytes && b.size <= bytes * 2 + (1u << 20) && (best < 0 || b.size < ctx->pool[(size_t)best].size)) best = (int)i;
     }
-    if (best >= 0) { PoolBlock& b = ctx->pool[(size_t)best]; b.free = false; b.alloc_seq = ctx->launch_seq; b.fill_use = false; return b.ptr; }
+    // (recording a plan graph: whatever the recorded calls allocate belongs to the graph — its kernels name those addresses at every
+    //  replay — and is released with it, sdqh_graph_free; pool_free leaves such a block alone)
+    if (best >= 0) { PoolBlock& b = ctx->pool[(size_t)best]; b.free = false; b.alloc_seq = ctx->launch_seq; b.fill_use = false; b.graph_owner = ctx->capturing ? ctx->capture_tag : nullptr; return b.ptr; }
     void* p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) {
         // release cached free blocks and retry once
@@ -52,12 +54,12 @@ void* pool_alloc(sdqh_ctx* ctx, size_t bytes) {
         ctx->pool.erase(std::remove_if(ctx->pool.begin(), ctx->pool.end(), [](const PoolBlock& b) { return b.ptr == nullptr; }), ctx->pool.end());
         if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     }
-    { PoolBlock nb{p, bytes, false}; nb.alloc_seq = ctx->launch_seq; ctx->pool.push_back(nb); }
+    { PoolBlock nb{p, bytes, false}; nb.alloc_seq = ctx->launch_seq; nb.graph_owner = ctx->capturing ? ctx->capture_tag : nullptr; ctx->pool.push_back(nb); }
     return p;
 }
 void pool_free(sdqh_ctx* ctx, void* p) {
     if (!p) return;
-    for (auto& b : ctx->pool) if (b.ptr == p) { b.free = true; for (int h = 0; h < b.nhabits; ++h) b.habits[h].clean = false; if (!b.fill_use) b.nhabits = 0; return; }
+    for (auto& b : ctx->pool) if (b.ptr == p) { if (b.graph_owner) return; b.free = true; for (int h = 0; h < b.nhabits; ++h) b.habits[h].clean = false; if (!b.fill_use) b.nhabits = 0; return; }
 }
 
 void* attach_alloc(sdqh_ctx* ctx, const sdqh_column* c, size_t bytes) {
@@ -91,6 +93,7 @@ void call_end(sdqh_ctx* ctx) {
     do { KernelScope _ks(ctx, name); hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3(TPB), (lds_bytes), (ctx)->stream, __VA_ARGS__); } while (0)
 
 int sync_stream(sdqh_ctx* ctx) {
+    if (ctx->capturing) return fail(ctx, SDQH_ERR_UNSUPPORTED, "a call that waits for the device cannot be recorded into a plan graph");
     bool done = false;
     if (ctx->opt_spin_sync && !ctx->compile_only) {
         if (!ctx->sync_flag) {
@@ -145,7 +148,7 @@ static PoolBlock* pool_block_of(sdqh_ctx* ctx, const void* p) {
     return nullptr;
 }
 static void prune_clean(sdqh_ctx* ctx, FillList* fl) {
-    if (!ctx->opt_fill_ahead) return;
+    if (!ctx->opt_fill_ahead || ctx->capturing) return;      // (a recorded fill must fill at every replay: "clean" is a fact about THIS run)
     DevFillBig out; std::memset(&out, 0, sizeof(out));
     uint64_t most = 0;
     for (int i = 0; i < fl->f.n; ++i) {
@@ -180,7 +183,7 @@ static void launch_fill(sdqh_ctx* ctx, const FillList& fl_in) {
     FillList fl = fl_in;
     prune_clean(ctx, &fl);
     if (!fl.f.n) return;
-    if (ctx->opt_fill_ahead) {
+    if (ctx->opt_fill_ahead && !ctx->capturing) {              // (never record a fill of somebody else's free block into a graph)
         for (auto& b : ctx->pool) {
             if (!b.free) continue;
             for (int h = 0; h < b.nhabits && fl.f.n < FILL_BIG; ++h) {
@@ -561,8 +564,16 @@ int sdqh_fork(sdqh_ctx* parent, sdqh_ctx** out) {
 
 void sdqh_destroy(sdqh_ctx* ctx) {
     if (!ctx) return;
-    if (ctx->parent) { auto& ch = ctx->parent->children; ch.erase(std::remove(ch.begin(), ch.end(), ctx), ch.end()); }
-    for (sdqh_ctx* c : ctx->children) c->parent = nullptr;           // (destroyed before its forks: they carry on alone)
+    // A family's first context owns what its forks share: the columns' home pool (sdqh_column::home), their twins and dictionaries.
+    // Destroyed while forks are alive it only marks itself: the last fork to go releases it (a fork that outlives its parent's
+    // memory would free attachments into a dead pool).
+    if (!ctx->children.empty()) { ctx->dying = true; return; }
+    sdqh_ctx* orphaned_parent = nullptr;
+    if (ctx->parent) {
+        auto& ch = ctx->parent->children; ch.erase(std::remove(ch.begin(), ch.end(), ctx), ch.end());
+        if (ctx->parent->dying && ch.empty()) orphaned_parent = ctx->parent;
+    }
+    struct Finish { sdqh_ctx* p; ~Finish() { if (p) sdqh_destroy(p); } } finish{orphaned_parent};
     if (ctx->compile_only) { delete ctx; return; }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -917,7 +928,7 @@ int sdqh_groupby_small(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, 
             pacc = reinterpret_cast<double*>(blob);
             pcnt = reinterpret_cast<int64_t*>(blob + nslots * 32);
             call_begin(ctx);
-            const bool clean = ctx->opt_fill_ahead && ctx->rd_clean_ff >= (size_t)GMAX * 8 && ctx->rd_clean_zero_off == (int64_t)LG_SLOTS * 48;   // left so by the last merge
+            const bool clean = ctx->opt_fill_ahead && !ctx->capturing && ctx->rd_clean_ff >= (size_t)GMAX * 8 && ctx->rd_clean_zero_off == (int64_t)LG_SLOTS * 48;   // left so by the last merge
             rd_ff_before = clean ? ctx->rd_clean_ff : 0;
             rd_dirty(ctx);
             if (!clean) {
@@ -1836,86 +1847,7 @@ int sdqh_table_compact_async(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t mi
     return SDQH_OK;
 }
 
-// K-F with NOTHING waited for: count -> write into the staging buffer -> the whole capacity-sized arrays copied out behind the kernels,
-// the row count landing in *out_n (a cell of the caller's device-visible block, -1 until then).  The caller collects after
-// sdqh_synchronize / sdqh_result_wait; a count above `capacity` means the rows beyond were dropped (fetch again, larger).
-int sdqh_table_compact_deferred(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_hits, int64_t capacity,
-                                int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n) {
-    sdqh_table* table = const_cast<sdqh_table*>(ctable);
-    if (!ctx || !table || !out_n || capacity < 1 || !out_keys) return fail(ctx, SDQH_ERR_INVALID, "table_compact_deferred: bad arguments");
-    if (table->bitmap_only) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_compact_deferred: bitmap-only table");
-    (void)hipSetDevice(ctx->device);
-    const int npay = out_payload ? table->npay : 0, nval = (out_values && table->accumulate) ? table->nv : 0;
-    const size_t cb = (size_t)capacity * 8;
-    char* base = reinterpret_cast<char*>(out_keys);
-    const int narr = 1 + (out_payload ? table->npay : 0) + (out_values ? SDQH_TUPLE_MAX_VALUES : 0) + (out_hits ? 1 : 0);
-    bool contiguous = in_host_block(ctx, base, cb * (size_t)narr) && in_host_block(ctx, out_n, 16);
-    size_t at = cb;
-    if (out_payload) { contiguous = contiguous && reinterpret_cast<char*>(out_payload) == base + at; at += cb * (size_t)table->npay; }
-    if (out_values) { contiguous = contiguous && reinterpret_cast<char*>(out_values) == base + at; at += cb * SDQH_TUPLE_MAX_VALUES; }
-    if (out_hits) { contiguous = contiguous && reinterpret_cast<char*>(out_hits) == base + at; at += cb; }
-    if (!ctx->opt_async_result || !contiguous) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_compact_deferred: the result arrays must be one sdqh_host_alloc block laid out keys | payload | values | hits");
-    if (!ctx->side[1]) ctx->side[1] = make_copy_stream(ctx);
-    if (!ctx->count_host && hipHostMalloc(&ctx->count_host, 256, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->count_host = nullptr; }
-    const int b = ctx->rs_cur;
-    if (!ctx->rs_copied[b] && hipEventCreateWithFlags(&ctx->rs_copied[b], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->rs_copied[b] = nullptr; }
-    if (!ctx->rs_ready && hipEventCreateWithFlags(&ctx->rs_ready, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ctx->rs_ready = nullptr; }
-    if (!ctx->side[1] || !ctx->count_host || !ctx->rs_copied[b] || !ctx->rs_ready) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_compact_deferred: no side stream");
-    const size_t need = cb * (size_t)narr;
-    if (ctx->rs_bytes[b] < need) {
-        if (ctx->rs_used[b]) HIP_TRY(ctx, hipEventSynchronize(ctx->rs_copied[b]));
-        if (ctx->rs_dev[b]) (void)hipFree(ctx->rs_dev[b]);
-        ctx->rs_dev[b] = nullptr; ctx->rs_bytes[b] = 0;
-        const size_t want = std::max<size_t>(need + need / 4, (size_t)4 << 20);
-        if (hipMalloc(&ctx->rs_dev[b], want) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, SDQH_ERR_NOMEM, "table_compact_deferred: out of device memory"); }
-        ctx->rs_bytes[b] = want;
-    }
-    call_begin(ctx);
-    if (int rc = ensure_index(ctx, table)) return rc;
-    if (ctx->rs_used[b]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->rs_copied[b], 0));       // the buffer's last copy has left it
-    DevCompactOut o; std::memset(&o, 0, sizeof(o));
-    char* dev = static_cast<char*>(ctx->rs_dev[b]);
-    size_t off = 0;
-    o.keys = reinterpret_cast<int64_t*>(dev); off += cb;
-    for (int p = 0; p < (out_payload ? table->npay : 0); ++p) { o.pay[p] = reinterpret_cast<int64_t*>(dev + off); off += cb; }
-    if (out_values) { for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) { if (k < nval) o.val[k] = reinterpret_cast<double*>(dev + off); off += cb; } }
-    if (out_hits) { o.hits = reinterpret_cast<int64_t*>(dev + off); off += cb; }
-    o.npay = npay; o.nval = nval;
-    o.counter = reinterpret_cast<unsigned long long*>(static_cast<char*>(ctx->count_host) + 64);
-    out_n[0] = -1; out_n[1] = 0;
-    o.h_counter = reinterpret_cast<unsigned long long*>(out_n);                                      // the kernel's own store of the total, into the caller's block
-    o.host_rows = (uint64_t)capacity; o.bounded = 1;
-    const uint32_t mh = (uint32_t)std::min<int64_t>(std::max<int64_t>(min_hits, 0), 0xFFFFFFFFll);
-    const unsigned seg_grid = (unsigned)((table->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
-    if (!table->seg_kept) { table->seg_kept = static_cast<uint32_t*>(table_alloc(ctx, table, (size_t)table->stage.nseg * 4 + 64)); if (!table->seg_kept) return fail(ctx, SDQH_ERR_NOMEM, "table_compact_deferred: out of device memory"); }
-    table->compact_valid = false;
-    LAUNCH(ctx, "k_compact_count", k_compact_count, seg_grid, table->dev, table->stage, o, mh, table->seg_kept);
-    LAUNCH(ctx, "k_compact_write2", k_compact_write2, seg_grid, table->dev, table->stage, o, mh, table->seg_kept);
-    call_end(ctx);
-    // the copy waits for the kernels by an event, not the host: keys .. the last used value array in one piece, then the hit counts
-    HIP_TRY(ctx, hipEventRecord(ctx->rs_ready, ctx->stream));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->side[1], ctx->rs_ready, 0));
-    const int lead = 1 + (out_payload ? table->npay : 0) + nval;
-    if (ctx->opt_copy_kernel && cb % 16 == 0) {                       // (rows are 8 bytes: an even capacity makes every array a whole number of 16-byte words)
-        const uint64_t n16a = (uint64_t)(cb * (size_t)lead / 16), n16b = out_hits ? (uint64_t)(cb / 16) : 0;
-        const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n16a + TPB - 1) / TPB, (uint64_t)ctx->opt_copy_kernel));
-        auto kern = ctx->opt_copy_nt ? k_copy_out<true> : k_copy_out<false>;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), 0, ctx->side[1], reinterpret_cast<const sdqh_u4*>(dev), reinterpret_cast<sdqh_u4*>(base), n16a);
-        if (out_hits) hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), 0, ctx->side[1], reinterpret_cast<const sdqh_u4*>(o.hits), reinterpret_cast<sdqh_u4*>(out_hits), n16b);
-        hipError_t ec = hipGetLastError();
-        if (ec != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, std::string("table_compact_deferred copy launch: ") + hipGetErrorString(ec));
-    } else {
-        HIP_TRY(ctx, hipMemcpyAsync(base, dev, cb * (size_t)lead, hipMemcpyDeviceToHost, ctx->side[1]));
-        if (out_hits) HIP_TRY(ctx, hipMemcpyAsync(out_hits, o.hits, cb, hipMemcpyDeviceToHost, ctx->side[1]));
-    }
-    // out_n[1]: the DONE word of this result, written by the copy stream itself behind the copies (1; 2 = no marker: wait with sdqh_result_wait)
-    if (hipStreamWriteValue32(ctx->side[1], reinterpret_cast<uint32_t*>(&out_n[1]), 1, 0) != hipSuccess) { (void)hipGetLastError(); out_n[1] = 2; }
-    HIP_TRY(ctx, hipEventRecord(ctx->rs_copied[b], ctx->side[1]));
-    ctx->rs_used[b] = true; ctx->rs_pending = true; ctx->rs_cur = b ^ 1;
-    if (out_values) for (int k = nval; k < SDQH_TUPLE_MAX_VALUES; ++k) std::memset(out_values + (size_t)k * (size_t)capacity, 0, cb);
-    return SDQH_OK;
-}
-
+// (sdqh_table_compact_deferred — K-F with nothing waited for — lives in sdqh_aux.hip: it launches the two kernels through launch_compact_pair below)
 int sdqh_table_topk(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t min_hits, int k, int nsort, const sdqh_sort_key* sort,
                     int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n) {
     sdqh_table* table = const_cast<sdqh_table*>(ctable);
@@ -2442,26 +2374,28 @@ int stage_rows_out(sdqh_ctx* ctx, sdqh_table* tb, sdqh_column** out_cols, int64_
     uint64_t* seg_off = static_cast<uint64_t*>(tb_alloc(ctx, tb, (size_t)tb->stage.nseg * 8 + 64));
     unsigned long long* total = static_cast<unsigned long long*>(tb_alloc(ctx, tb, 64));
     if (!seg_off || !total) return fail(ctx, SDQH_ERR_NOMEM, "stage rows: out of device memory");
+    // the survivors are counted first (the call waits for the total anyway) and the output columns sized by it: a probe side of which
+    // half a per cent passes must not reserve 1 + npay columns of the SCANNED row count
+    call_begin(ctx);
+    LAUNCH(ctx, "k_seg_scan", k_seg_scan, 1, tb->stage.seg_count, tb->stage.nseg, seg_off, total);
+    { hipError_t e = hipMemcpyAsync(ctx->result_host, total, 8, hipMemcpyDeviceToHost, ctx->stream);
+      if (e != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e)); }
+    if (int rc = sync_stream(ctx)) return rc;
+    const int64_t n = (int64_t)*static_cast<const unsigned long long*>(ctx->result_host);
     sdqh_column* outs[SDQH_MAX_COMPACT_COLS] = {nullptr};
     DevGather g; std::memset(&g, 0, sizeof(g)); g.ncols = ncols;
     int rc = SDQH_OK;
     for (int c = 0; c < ncols && !rc; ++c) {
-        rc = sdqh_column_alloc(ctx, tb->nrows_build, SDQH_I64, 0, &outs[c]);
-        if (!rc) { g.out[c] = static_cast<int64_t*>(outs[c]->data); outs[c]->transient = true; }
+        rc = sdqh_column_alloc(ctx, n, SDQH_I64, 0, &outs[c]);
+        if (!rc) { g.out[c] = static_cast<int64_t*>(outs[c]->data); sdqh_column_mark_transient(ctx, outs[c]); }
     }
-    if (!rc) {
+    if (!rc && n > 0) {
         const unsigned seg_grid = (unsigned)((tb->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
-        call_begin(ctx);
-        LAUNCH(ctx, "k_seg_scan", k_seg_scan, 1, tb->stage.seg_count, tb->stage.nseg, seg_off, total);
         LAUNCH(ctx, "k_gather_segments", k_gather_segments, seg_grid, tb->stage, seg_off, g);
-        call_end(ctx);
-        hipError_t e = hipMemcpyAsync(ctx->result_host, total, 8, hipMemcpyDeviceToHost, ctx->stream);
-        if (e != hipSuccess) rc = fail(ctx, SDQH_ERR_DEVICE, hipGetErrorString(e));
-        if (!rc) rc = sync_stream(ctx);
     }
+    call_end(ctx);
     if (rc) { for (int c = 0; c < ncols; ++c) if (outs[c]) sdqh_column_free(ctx, outs[c]); return rc; }
-    const int64_t n = (int64_t)*static_cast<const unsigned long long*>(ctx->result_host);
-    for (int c = 0; c < ncols; ++c) { outs[c]->nrows = n; out_cols[c] = outs[c]; }
+    for (int c = 0; c < ncols; ++c) out_cols[c] = outs[c];
     *out_rows = n;
     return SDQH_OK;
 }
@@ -2598,10 +2532,14 @@ int sdqh_column_copy_in(sdqh_ctx* ctx, sdqh_column* col, int64_t row0, int64_t n
     if (nrows == 0) return SDQH_OK;
     (void)hipSetDevice(ctx->device);
     HIP_TRY(ctx, hipMemcpyAsync(static_cast<char*>(col->data) + (size_t)row0 * 8, src, (size_t)nrows * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    col->have_minmax = false; col->minmax_pending = false; col->clustered = -1; col->increasing = -1; col->nondecreasing = -1;
+    // the contents changed: what was learnt about them is void.  A transient column (rows that live for one run: sdqh_column_mark_transient)
+    // stays "no order, no twins" — unknown (-1) would make the next kernel that asks pay a pass and a host round trip, every run
+    const int unknown = col->transient ? 0 : -1;
+    col->have_minmax = false; col->minmax_pending = false; col->clustered = unknown; col->increasing = unknown; col->nondecreasing = unknown; col->span8 = unknown;
     if (col->narrow) { attach_free(ctx, col, col->narrow); col->narrow = nullptr; }
-    col->narrow_state = -1;
+    col->narrow_state = unknown;
     column_codes_release(ctx, col);
+    if (col->transient) col->code_state = 0;
     return ctx->opt_async_copies ? SDQH_OK : sync_stream(ctx);
 }
 
@@ -2698,6 +2636,16 @@ void launch_groupby_merge_lg_host(sdqh_ctx* ctx, unsigned long long* r_keys, con
            reinterpret_cast<unsigned long long*>(hb), r_flags, reinterpret_cast<int*>(hb + LG_SLOTS * 48), 1);
     ctx->rd_clean_ff = (size_t)LG_SLOTS * 8; ctx->rd_clean_zero_off = (int64_t)LG_SLOTS * 48;
 }
+// K-F's count + write pair into `o` (sdqh_aux.hip: sdqh_table_compact_deferred lays `o` out over a staging buffer of its own)
+int launch_compact_pair(sdqh_ctx* ctx, sdqh_table* table, const DevCompactOut& o, uint32_t min_hits) {
+    const unsigned seg_grid = (unsigned)((table->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE));
+    if (!table->seg_kept) { table->seg_kept = static_cast<uint32_t*>(::table_alloc(ctx, table, (size_t)table->stage.nseg * 4 + 64)); if (!table->seg_kept) return fail(ctx, SDQH_ERR_NOMEM, "table_compact: out of device memory"); }
+    table->compact_valid = false;
+    LAUNCH(ctx, "k_compact_count", k_compact_count, seg_grid, table->dev, table->stage, o, min_hits, table->seg_kept);
+    LAUNCH(ctx, "k_compact_write2", k_compact_write2, seg_grid, table->dev, table->stage, o, min_hits, table->seg_kept);
+    return SDQH_OK;
+}
+hipStream_t copy_stream(sdqh_ctx* ctx) { if (!ctx->side[1]) ctx->side[1] = ::make_copy_stream(ctx); return ctx->side[1]; }
 int column_minmax(sdqh_ctx* ctx, sdqh_column* c) { return ensure_minmax(ctx, c); }
 bool column_increasing(sdqh_ctx* ctx, sdqh_column* c) { return ::column_is_increasing(ctx, c); }
 const void* column_narrow(sdqh_ctx* ctx, sdqh_column* c) { return ensure_narrow(ctx, c); }

@@ -24,6 +24,7 @@ struct PoolBlock {
     int nhabits = 0;
     uint64_t alloc_seq = 0;                        // the ctx's launch counter when the block was handed out
     bool fill_use = false;                         // this use of the block received (or was spared) a fill: its habits are alive
+    const void* graph_owner = nullptr;             // allocated while a plan graph was being recorded (sdqh_graph_begin): reserved until sdqh_graph_free
 };
 struct ProfEntry { const char* name; hipEvent_t e0, e1; double ms; int64_t model_bytes; };      // model_bytes: HBM bytes this launch is MODELLED to move (0: not modelled), see sdqh_profile_entry_bytes
 
@@ -39,6 +40,11 @@ struct sdqh_ctx {
     // sdqh_fork: contexts of one family share their columns (each has its own stream, pool and result blocks)
     sdqh_ctx* parent = nullptr;
     std::vector<sdqh_ctx*> children;
+    const void* capture_tag = nullptr;             // the graph being recorded (tags the pool blocks it allocates)
+    struct HostInit { void* p; uint64_t value; int bytes; };
+    std::vector<HostInit> capture_inits;           // host words the recorded calls set before their launches (completion words): set again before every replay
+    bool capturing = false;                        // the stream is in capture mode (sdqh_aux.hip: a prepared plan recorded into a hipGraph): nothing may wait for the device
+    bool dying = false;                            // sdqh_destroy was called on a family's first context while forks were alive: the last fork releases it
     bool compile_only = false;                     // sdqh_create(-1): no GPU behind this ctx; sdqh_x* calls stop after specialising their kernel (build check)
     int num_cu = 256;
     hipStream_t stream = nullptr;
@@ -195,6 +201,7 @@ struct sdqh_table {
     int nv = SDQH_TUPLE_MAX_VALUES;    // value count of the tuple aggregated into the table
     WordExc* wexc = nullptr;                       // row index (DevTable): exception records, one slot per segment
     uint32_t* coarse = nullptr; int coarse_words = 0, coarse_shift = 0;     // coarse key filter (see DevLookups), built on first need
+    bool stage_only = false;                       // sdqh_xstage: every passing row staged (equal keys included), never indexed — the source of a redistribution step, nothing else
 };
 
 
@@ -221,6 +228,8 @@ int index_ensure(sdqh_ctx* ctx, sdqh_table* tb);
 int stage_rows_out(sdqh_ctx* ctx, sdqh_table* tb, sdqh_column** out_cols, int64_t* out_rows);
 // K-F into the table's own device buffers (tb->compact; rows in build-row order), *n = the number of entries kept; zero_rows made on request
 int table_compact_resident(sdqh_ctx* ctx, sdqh_table* tb, int64_t min_hits, bool want_zero_rows, int64_t* n);
+int launch_compact_pair(sdqh_ctx* ctx, sdqh_table* table, const sdqh::DevCompactOut& o, uint32_t min_hits);      // k_compact_count + k_compact_write2
+hipStream_t copy_stream(sdqh_ctx* ctx);                         // the low-priority stream result copies are queued on (made on first use)
 int column_minmax(sdqh_ctx* ctx, sdqh_column* c);
 bool column_increasing(sdqh_ctx* ctx, sdqh_column* c);          // strictly increasing I64 column?  (one pass the first time, cached)
 const void* column_narrow(sdqh_ctx* ctx, sdqh_column* c);      // the exact 4-byte twin of a streamed column (built on first request), or nullptr
@@ -237,6 +246,17 @@ bool host_block_contains(sdqh_ctx* ctx, const void* p, size_t bytes);      // in
 int prefill_direct_refs(sdqh_ctx* ctx, sdqh_table* tb, void** ptr, size_t* bytes);   // regions (<= 2) to fill with 0xFF; returns their number
 
 inline void rd_dirty(sdqh_ctx* c) { c->rd_clean_ff = 0; c->rd_clean_zero_off = -1; }
+
+// ---- helpers defined in sdqh_aux.hip ----------------------------------------------------------------
+// one 32-bit word of device-visible host memory stored by stream `s` itself, behind what is queued there: hipStreamWriteValue32 where
+// the stream executes, a one-thread kernel where it is being recorded into a plan graph (the value-write has no graph node)
+int stream_store32(sdqh_ctx* ctx, hipStream_t s, uint32_t* word, uint32_t value);
+// a host word a call sets BEFORE its launches (a completion word cleared, a count set to -1): while a plan graph is recorded it is also
+// noted, and set again before every replay (sdqh_graph_launch)
+inline void host_init(sdqh_ctx* ctx, void* p, uint64_t value, int bytes) {
+    if (bytes == 8) *static_cast<volatile uint64_t*>(p) = value; else *static_cast<volatile uint32_t*>(p) = (uint32_t)value;
+    if (ctx->capturing) ctx->capture_inits.push_back(sdqh_ctx::HostInit{p, value, bytes});
+}
 
 // event pair around one launch when profiling is on (same bookkeeping as the LAUNCH macro)
 struct KernelScope {

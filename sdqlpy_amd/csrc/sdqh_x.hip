@@ -1359,10 +1359,10 @@ static int xgroupby_launch(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* pro
         // the block's DONE word: written by the stream itself once the merge has finished — collect waits for its own result, not for
         // whatever was queued behind it.  Cleared before the merge is launched.
         uint32_t* done = host_block ? reinterpret_cast<uint32_t*>(static_cast<char*>(host_block) + XGROUPBY_DONE_OFFSET) : nullptr;
-        if (done) *done = 0;
+        if (done) host_init(ctx, done, 0, 4);
         launch_groupby_merge_lg_host(ctx, r_keys, pacc, pcnt, (int)g.grid, r_flags, host_block);       // writes the pinned host block, leaves the device block clean
         call_end(ctx);
-        if (done && hipStreamWriteValue32(ctx->stream, done, 1, 0) != hipSuccess) { (void)hipGetLastError(); *done = 2; }     // 2: no marker, collect synchronises
+        if (done && stream_store32(ctx, ctx->stream, done, 1) != SDQH_OK) *done = 2;     // 2: no marker, collect synchronises
     }
     pool_free(ctx, blob);                                   // stream order: whoever gets the block next runs after the merge
     return rc;
@@ -1533,6 +1533,18 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
         if (!rc && (f & 2)) rc = fail(ctx, SDQH_ERR_UNSUPPORTED, "xbuild: a key outside the given bounds / a key part outside [0, 2^32)");
     }
     if (rc) { tb_release(ctx, tb); delete tb; return rc; }
+    *out = tb;
+    return SDQH_OK;
+}
+
+int sdqh_xstage(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, sdqh_table** out) {
+    if (!ctx || !prog || !out) return fail(ctx, SDQH_ERR_INVALID, "xstage: bad arguments");
+    if (1 + prog->nvals > SDQH_MAX_COMPACT_COLS) return fail(ctx, SDQH_ERR_INVALID, "xstage: too many columns");
+    // the staging half of a build: the stage sink keeps every passing row in its wave's segment, equal keys included; no bounds, no
+    // bitmap, and the index a build would make lazily is never asked for — the row count stays in seg_count[] on the device
+    sdqh_table* tb = nullptr;
+    if (int rc = sdqh_xbuild(ctx, nrows, prog, 1, 0, 0, &tb)) return rc;
+    tb->stage_only = true;
     *out = tb;
     return SDQH_OK;
 }

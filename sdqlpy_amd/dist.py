@@ -37,6 +37,8 @@ of q1 / q6 beyond the final few hundred bytes.  `backend` only needs all_gather,
 CPU oracle behind the ABI — that is how tests/test_dist_cpu.py covers the N > 1 path without GPUs.
 """
 import contextlib
+import os
+import time
 
 import numpy as np
 import torch
@@ -49,8 +51,17 @@ from .result import ResultSet
 
 
 class DistributedRunner:
-    def __init__(self, eng, rank, world, group=None, device=None, partition="auto", prefilter=True):
+    def __init__(self, eng, rank, world, group=None, device=None, partition="auto", prefilter=True, skip_trivial=None, device_sized=None):
         self.eng, self.ctx = eng, eng.ctx
+        # a collective over a group of ONE moves nothing: skipped (every rank knows the world size: all decide alike).  False makes a
+        # group of one issue them all the same (tests / bench.py --force-dist: the RCCL calls themselves on one GPU)
+        self.skip_trivial = (os.environ.get("SDQLPY_AMD_DIST_TRIVIAL_COLLECTIVES", "0") != "1") if skip_trivial is None else bool(skip_trivial)
+        # the hash-partitioned join's exchanges sized on the device (fixed-capacity chunks, counts in their headers, no host wait) once a
+        # first run has measured them; False: every run exchanges exact sizes through the host
+        self.device_sized = (os.environ.get("SDQLPY_AMD_DIST_DEVICE_SIZED", "1") != "0") if device_sized is None else bool(device_sized)
+        self.fast_runs = 0                  # partitioned joins that ran with device-sized exchanges / that had to be repeated with exact sizes
+        self.fast_retries = 0
+        self._stat_ring, self._stat_next = [], 0
         eng.nlanes = 1                                          # collectives and kernels are ordered on ONE stream
         self.rank, self.world, self.group = rank, world, group
         self.backend = dist.get_backend(group)
@@ -81,8 +92,16 @@ class DistributedRunner:
         if self.backend != "nccl":
             return contextlib.nullcontext()
         if self._ext_stream is None:
+            if os.environ.get("TORCH_NCCL_AVOID_RECORD_STREAMS", "0") == "1":
+                raise RuntimeError("TORCH_NCCL_AVOID_RECORD_STREAMS=1: the runner releases collective buffers in stream order and relies on torch "
+                                   "recording the communication stream's use of them")
             self._ext_stream = torch.cuda.ExternalStream(int(self.ctx.stream()), device=self.device)
         return torch.cuda.stream(self._ext_stream)
+
+    def _on_engine_stream(self):
+        """Collective buffers must be allocated with the engine's stream current (see _run): asserted where they are made."""
+        if self.backend == "nccl":
+            assert self._ext_stream is not None and torch.cuda.current_stream(self.device) == self._ext_stream, "collective buffer allocated outside _device_order()"
 
     def reset_collectives(self):
         self.collectives = {}
@@ -110,6 +129,8 @@ class DistributedRunner:
         tensors (pinned host in / out, device in / out) are cached per shape, the copies are
         asynchronous on torch's stream and there is exactly one stream synchronisation."""
         arr = np.ascontiguousarray(arr)
+        if self.world == 1 and self.skip_trivial:
+            return [arr]
         if self.backend != "nccl":
             t = torch.from_numpy(arr)
             out = [torch.empty_like(t) for _ in range(self.world)]
@@ -152,6 +173,7 @@ class DistributedRunner:
         sizes = [int(x[0]) for x in self._all_gather_array(np.array([n], np.int64))]
         total, m = sum(sizes), max(sizes + [1])
         k = len(cols)
+        self._on_engine_stream()
         send = torch.empty(m * k, dtype=torch.int64, device=self.device)     # padding rows are never read back; no fill kernel
         if n:                                                                # on torch's stream to race the library's copies
             for j, col in enumerate(cols):
@@ -205,34 +227,42 @@ class DistributedRunner:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
 
+    def _probe_program(self, st, probes):
+        """The probe side's filter + semi-join as a row program whose key is the probe key and whose values are the value operands (8-byte
+        bit patterns), or None when the loop has no such program (text / column-vs-column conditions, too many operands)."""
+        if len(st.ops_c) > abi.MAX_PAYLOAD or st.flt_c._keep[2] or st.flt_c._keep[3]:
+            return None
+        P = abi.Program()
+        gates = []
+        for f in _ipreds(st.flt_c):
+            c = P.op(abi.X_COL, abi.T_I64, col=f.col_obj)
+            if f.lo > abi.INT64_MIN:
+                gates.append(P.op(abi.X_GE, abi.T_BOOL, a=c, b=P.op(abi.X_CONST, abi.T_I64, imm_i=f.lo)))
+            if f.hi < abi.INT64_MAX:
+                gates.append(P.op(abi.X_LE, abi.T_BOOL, a=c, b=P.op(abi.X_CONST, abi.T_I64, imm_i=f.hi)))
+        for col, lo, hi in _fpreds(st.flt_c):
+            c = P.op(abi.X_COL, abi.T_F64, col=col)
+            if lo > -np.inf:
+                gates.append(P.op(abi.X_GE, abi.T_BOOL, a=c, b=P.op(abi.X_CONST, abi.T_F64, imm_f=lo)))
+            if hi < np.inf:
+                gates.append(P.op(abi.X_LE, abi.T_BOOL, a=c, b=P.op(abi.X_CONST, abi.T_F64, imm_f=hi)))
+        key = P.op(abi.X_COL, abi.T_I64, col=st.key_c)
+        for tbl, kcol in probes:
+            k = key if kcol is st.key_c else P.op(abi.X_COL, abi.T_I64, col=kcol)
+            gates.append(P.op(abi.X_LOOKUP, abi.T_BOOL, a=k, table=tbl))
+        P.gates, P.key = gates, key
+        P.vals = [P.op(abi.X_COL, abi.T_F64 if c.dtype == abi.F64 else abi.T_I64, col=c) for c in st.ops_c]
+        return P
+
     def _compact_probe_rows(self, st, probes):
         """The probe side's rows that pass its filter and whose key some rank holds (`probes`: the replicated key set), as columns
         [key, operands ...] of 8-byte bit patterns.  As a row program (sdqh_xcompact: on the GPU the value-queue stage kernel — every
         column streamed at its tightest encoding, the key set tested on streamed keys, survivors' values queued and stored whole;
         the stage is never indexed, so equal keys all stay).  Shapes the program route refuses: sdqh_scan_compact."""
         ctx = self.ctx
-        if probes and len(st.ops_c) <= abi.MAX_PAYLOAD and not st.flt_c._keep[2] and not st.flt_c._keep[3]:
+        P = self._probe_program(st, probes) if probes else None
+        if P is not None:
             try:
-                P = abi.Program()
-                gates = []
-                for f in _ipreds(st.flt_c):
-                    c = P.op(abi.X_COL, abi.T_I64, col=f.col_obj)
-                    if f.lo > abi.INT64_MIN:
-                        gates.append(P.op(abi.X_GE, abi.T_BOOL, a=c, b=P.op(abi.X_CONST, abi.T_I64, imm_i=f.lo)))
-                    if f.hi < abi.INT64_MAX:
-                        gates.append(P.op(abi.X_LE, abi.T_BOOL, a=c, b=P.op(abi.X_CONST, abi.T_I64, imm_i=f.hi)))
-                for col, lo, hi in _fpreds(st.flt_c):
-                    c = P.op(abi.X_COL, abi.T_F64, col=col)
-                    if lo > -np.inf:
-                        gates.append(P.op(abi.X_GE, abi.T_BOOL, a=c, b=P.op(abi.X_CONST, abi.T_F64, imm_f=lo)))
-                    if hi < np.inf:
-                        gates.append(P.op(abi.X_LE, abi.T_BOOL, a=c, b=P.op(abi.X_CONST, abi.T_F64, imm_f=hi)))
-                key = P.op(abi.X_COL, abi.T_I64, col=st.key_c)
-                for tbl, kcol in probes:
-                    k = key if kcol is st.key_c else P.op(abi.X_COL, abi.T_I64, col=kcol)
-                    gates.append(P.op(abi.X_LOOKUP, abi.T_BOOL, a=k, table=tbl))
-                P.gates, P.key = gates, key
-                P.vals = [P.op(abi.X_COL, abi.T_F64 if c.dtype == abi.F64 else abi.T_I64, col=c) for c in st.ops_c]
                 return ctx.xcompact(st.nc, P)
             except abi.SdqhError as exc:
                 if exc.code != abi.ERR_UNSUPPORTED:
@@ -247,10 +277,12 @@ class DistributedRunner:
         gathered first (G * 8 bytes per rank: every rank learns what it will receive, and all ranks agree when nothing at all has to
         move and skip the data collective).  Returns (received Columns, their row count, rows sent to every rank)."""
         k = len(cols)
+        self._on_engine_stream()
         send = torch.empty(max(nrows * k, 1), dtype=torch.int64, device=self.device)
         counts = self.ctx.partition_pack(nrows, key, self.world, cols, send.data_ptr(), range_upper)      # (waits for the counts: they size the exchange)
         matrix = np.stack(self._all_gather_array(counts))                                              # [source, dest]
         recv_counts = matrix[:, self.rank]
+        self._last_matrix_max = int(matrix.max()) if matrix.size else 0          # (every rank sees the same matrix: the bound of the next run's chunks)
         n_recv = int(recv_counts.sum())
         self.exchanged_bytes += 8 * k * (nrows - int(counts[self.rank]))
         recv = torch.empty(max(n_recv * k, 1), dtype=torch.int64, device=self.device)
@@ -341,11 +373,14 @@ class DistributedRunner:
     def run(self, query, db, whole_tables=None, top=None):
         """See _run.  Column copies to / from collective buffers are only queued while a run is in
         progress (option "async_copies"); the runner synchronises once per batch."""
+        return self._guarded(lambda: self._run(query, db, whole_tables, top))
+
+    def _guarded(self, fn):
         self.ctx.set_option("async_copies", 1)
         ok = False
         try:
             with self._device_order():
-                res = self._run(query, db, whole_tables, top)
+                res = fn()
             ok = True
             return res
         finally:
@@ -366,7 +401,11 @@ class DistributedRunner:
         top = (k, [(column, "asc" | "desc")]) adds ORDER BY ... LIMIT k: every rank returns the same
         global first k rows (partitioned results: each rank's device top-k, k rows per rank gathered
         and ordered again)."""
-        self._inflight.clear()              # the previous run ended synchronised
+        # the collective buffers of the previous run: released now.  gloo: that run ended synchronised.  RCCL: it did not — the tensors
+        # were allocated with the ENGINE's stream current (_device_order), torch's caching allocator hands a freed block out again on
+        # that same stream only, behind the kernels queued there that still read it, and a tensor a collective used on RCCL's own
+        # stream carries torch's record_stream mark (TORCH_NCCL_AVOID_RECORD_STREAMS=1 would void that: refused in _device_order)
+        self._inflight.clear()
         fn, plan, args = self._resolve(query, db)
         whole = self._whole_params(fn, plan, args, whole_tables)
         shape = self._shape(plan)
@@ -656,7 +695,7 @@ class DistributedRunner:
             for op, step in st.steps:
                 if isinstance(op, ScanOp):
                     res = step(env)
-                    if isinstance(res, engine.BuiltTable) and st.replicate.get(op.out):
+                    if isinstance(res, engine.BuiltTable) and st.replicate.get(op.out) and not (self.world == 1 and self.skip_trivial):
                         res = self._replicate_table(res, st.key_range.get(op.out), st.table_range.get(op.out), st.part_ranges.get(op.out))
                     elif isinstance(res, engine.DictResult) and st.sharded[op.out]:
                         res = self._merge_groups(res)
@@ -697,6 +736,8 @@ class DistributedRunner:
         """Partial groups of every rank -> the global groups on every rank (folded in rank order).
         The rows travel as raw bytes in ONE fixed-size all_gather (<= 256 groups per rank: the
         group-by kernels' own limit), not as pickled objects."""
+        if self.world == 1 and self.skip_trivial:
+            return d                                # a group of one: the partial groups are the groups
         fields = list(d.key_fields) + list(d.val_fields)
         dtypes = [np.dtype(a.dtype) for _, a in fields]
         rowbytes = sum(dt.itemsize for dt in dtypes)
@@ -746,6 +787,8 @@ class DistributedRunner:
         op = plan.ops[0]
         nkey = len(op.key.fields) if isinstance(op.key, RecordCons) else 1
         local = engine.execute_plan(self.eng, plan, args, lane=0)      # ResultSet of this shard's groups
+        if self.world == 1 and self.skip_trivial:
+            return local                            # a group of one: launched, not waited for — as on one GPU
         cap, maxc = abi.MAX_SMALL_GROUPS, 16
         n = local.size() if local is not None else 0
         buf = np.zeros(2 + maxc + cap * maxc, np.int64)
@@ -863,6 +906,11 @@ class DistributedRunner:
         st.flt_foreign = [abi.make_filter(base_ip + [(st.key_c, lo_f, hi_f)], _fpreds(st.flt_c), [])
                           for lo_f, hi_f in ((abi.INT64_MIN, my_lo - 1), (my_hi + 1, abi.INT64_MAX)) if lo_f <= hi_f]
         st.empty = abi.make_filter()
+        # device-sized exchanges (hash partitioning): the chunk capacities come from a first run that measured them (None until then);
+        # the probe side must have a row program
+        st.caps = None
+        st.fast_ok = mode == "hash" and len(st.ops_c) <= abi.MAX_PAYLOAD and not st.flt_c._keep[2] and not st.flt_c._keep[3] \
+            and 1 + len(st.pay_b) <= abi.MAX_COMPACT_COLS
         return st
 
     def _replicated_key_set(self, table, rng, disjoint=True):
@@ -877,7 +925,9 @@ class DistributedRunner:
         buf = torch.empty(max(n64, 1), dtype=torch.int64, device=self.device)
         words = ctx.wrap(buf.data_ptr(), n64, abi.I64, keepalive=buf)
         ctx.table_export_bitmap(table, lo, hi, into=words)                    # queued under "async_copies": the collective is ordered behind it
-        if disjoint:
+        if self.world == 1 and self.skip_trivial:
+            pass                                    # (a group of one: the exported bitmap is the union already)
+        elif disjoint:
             self._note("all_reduce", buf)
             dist.all_reduce(buf, group=self.group)
         else:
@@ -896,28 +946,34 @@ class DistributedRunner:
             self._inflight.append(parts)
         return ctx.table_from_bitmap(words, lo, hi), words
 
-    def _build_from_columns(self, n, cols, key_range, accumulate=True):
+    def _build_from_columns(self, n, cols, key_range, accumulate=True, first_key=None):
         """A table with accumulators from received entry columns [key, payload ...] (every row an entry; keys within key_range).  As a
         row program when the library takes it — the value-queue build streams the columns once and needs no minimum / maximum pass,
         having been told the bounds: 0.03 ms for Q3's 1.46 M received orders where the fixed-shape build took 0.27 — else the
-        fixed-shape unique build."""
+        fixed-shape unique build.  first_key: rows whose key is below it are no entries (the padding rows of sdqh_unpack_chunks carry
+        first_key - 1, which key_range then includes): a gate of the program / a predicate of the fixed-shape build drops them."""
         ctx = self.ctx
         lo, hi = key_range
         if n and len(cols) <= 1 + abi.MAX_PAYLOAD and lo <= hi:
             prog = abi.Program()
             prog.key = prog.op(abi.X_COL, abi.T_I64, col=cols[0])
+            if first_key is not None:
+                prog.gates = [prog.op(abi.X_GE, abi.T_BOOL, a=prog.key, b=prog.op(abi.X_CONST, abi.T_I64, imm_i=first_key))]
             prog.vals = [prog.op(abi.X_COL, abi.T_F64 if c.dtype == abi.F64 else abi.T_I64, col=c) for c in cols[1:]]
             try:
                 return ctx.xbuild(n, prog, lo, hi, accumulate=accumulate)
             except abi.SdqhError as exc:
                 if exc.code != abi.ERR_UNSUPPORTED:
                     raise
-        return ctx.hash_build_unique(n, abi.make_filter(), [], cols[0], cols[1:], accumulate=accumulate)
+        flt = abi.make_filter() if first_key is None else abi.make_filter([(cols[0], first_key, abi.INT64_MAX)], [], [])
+        return ctx.hash_build_unique(n, flt, [], cols[0], cols[1:], accumulate=accumulate)
 
     def _replicated_set(self, st, local):
         """Table A (a BuiltTable built from this rank's shard) on every rank; see _replicated_key_set.  Key range too wide for a
         bitmap: the surviving keys are all-gathered and the set is built from them."""
         ctx = self.ctx
+        if self.world == 1 and self.skip_trivial:
+            return []                               # a group of one: this rank's set IS the global set
         if st.a_bitmap:
             table, words = self._replicated_key_set(local.table, st.a_range)
             keep = [words]
@@ -930,7 +986,7 @@ class DistributedRunner:
         local.table = table
         return keep
 
-    def _partitioned_join(self, plan, args, a_whole=False):
+    def _partitioned_join(self, plan, args, a_whole=False, waited=False):
         """The engine's own prepared steps (the kernels of the single-GPU plan: tight-encoded build and probe programs, K-F behind the
         call) with the exchange at their seams:
           A      built from this rank's shard, then replaced by the replicated set (one collective; none when A is whole everywhere);
@@ -938,7 +994,11 @@ class DistributedRunner:
                  all-to-all) and aggregated into B before the engine's K-F;
           hash   B's survivors — the entries of the table the engine's build step made of this rank's shard — are hash-partitioned,
                  exchanged, and B is rebuilt from what arrived; its keys' bitmap over the global range is replicated (one all-reduce)
-                 so that only probe rows that will hit travel; those are compacted, exchanged and aggregated; then the engine's K-F."""
+                 so that only probe rows that will hit travel; those are compacted, exchanged and aggregated; then the engine's K-F.
+        Hash partitioning has two forms.  The FIRST run of a prepared join (and any run after a bound turned out too small: `waited`)
+        exchanges exact sizes: every count visits the host (table entries, two count matrices) — and is remembered.  Later runs
+        (_hash_join_device_sized) move fixed-capacity chunks sized from those counts, with the true counts in the chunk headers: no
+        host wait between the first kernel and the result."""
         ctx, eng = self.ctx, self.eng
         cache = plan.__dict__.setdefault("_dist_prepared", {})
         key = (id(self), a_whole, self.partition) + tuple(id(a) for a in args)
@@ -954,6 +1014,13 @@ class DistributedRunner:
         def replicate_a(env):
             if not st.a_whole:                   # (A whole on every rank: its set is built locally and no collective runs —
                 keep.extend(self._replicated_set(st, env[a_op.out]))      #  summing the ranks' bitmaps of identical sets would carry bits into their neighbours)
+
+        def collective_rerun():
+            # what a deferred run of this join does when it has to be repeated: the whole join once more with every size exact — a
+            # COLLECTIVE run, which every rank enters because every rank read the same all-reduced status (or, for a failure only this
+            # rank saw, fails loudly on the others' side rather than hang: the collectives carry torch's own timeout)
+            self.fast_retries += 1
+            return self._guarded(lambda: self._partitioned_join(plan, args, a_whole, waited=True))
 
         try:
             if st.mode == "range":
@@ -973,8 +1040,17 @@ class DistributedRunner:
                         keep.extend(recv)
                         self.exchanged_rows = {"build": 0, "probe_sent": int(foreign_n), "probe_received": int(n_recv)}
                     after[c_op.out] = foreign_rows
-                return pp.run(self._top, after=after)
-            # ---- hash partitioning: the steps driven from here -----------------------------------------------------------
+                # (keep_tables: a K-F block that turns out too small is repeated on this rank's own tables — the plan is never re-run by
+                #  one rank alone, which would build A from its shard only and skip the exchange)
+                return pp.run(self._top, after=after, keep_tables=True, on_retry=collective_rerun)
+            if self.device_sized and st.fast_ok and st.caps is not None and not waited:
+                try:
+                    return self._hash_join_device_sized(st, pp, plan, replicate_a, keep, collective_rerun)
+                except abi.SdqhError as exc:
+                    if exc.code != abi.ERR_UNSUPPORTED:
+                        raise
+                    st.fast_ok = False              # (decided by the tables' layouts, the same on every rank: all fall back alike)
+            # ---- hash partitioning with exact sizes: the steps driven from here ---------------------------------------------------
             steps = dict(pp.steps)
             env = {}
             try:
@@ -983,6 +1059,7 @@ class DistributedRunner:
                 env[b_op.out] = bt_b = steps[b_op.out](env)                   # this rank's survivors, by the engine's own build kernel
                 bcols, nb = ctx.table_entries(bt_b.table)                     # [key, payload ...]
                 brecv, nb_recv, _ = self._exchange(nb, bcols[0], bcols)
+                most_b = self._last_matrix_max
                 for c in bcols:
                     c.free()
                 table_b = self._build_from_columns(nb_recv, brecv, (min(r[0] for r in st.b_ranges), max(r[1] for r in st.b_ranges)))
@@ -1003,10 +1080,14 @@ class DistributedRunner:
                 for tbl, _ in probes_c:
                     tbl.free()                                                # (the words it borrowed stay alive in `keep`)
                 recv, n_recv, _ = self._exchange(nc, ccols[0], ccols, dtypes=[abi.I64] + [c.dtype for c in st.ops_c])
+                most_c = self._last_matrix_max
                 for c in ccols:
                     c.free()
                 keep.extend(recv)
                 self.exchanged_rows = {"build": int(nb), "probe_sent": int(nc), "probe_received": int(n_recv)}
+                # the bounds of the next run's chunks: the largest (source, destination) count of each exchange — every rank gathered the
+                # same matrices, every rank sets the same bounds
+                st.caps = (_chunk_bound(most_b), _chunk_bound(most_c))
                 env[c_op.out] = st.step_c(env, rows=(n_recv, recv[0], abi.make_tuple(st.step_c.tuple_shape, recv[1:])))
                 return engine._finalize(eng, f_op, env, self._top)
             finally:
@@ -1014,7 +1095,127 @@ class DistributedRunner:
                     if isinstance(v, engine.BuiltTable):
                         v.table.free()
         finally:
-            self._inflight.extend(keep)          # queued kernels may still read them: released at the next run (the run ends synchronised)
+            self._inflight.extend(keep)          # queued kernels may still read them: released at the start of the next run (see _run)
+
+    def _stat_buffer(self):
+        """A pinned host landing block for one run's exchange status (EXCHANGE_STAT_WORDS int64), from a small ring: a block is taken
+        again only after its run's result was collected (its last word is then no sentinel any more)."""
+        for _ in range(len(self._stat_ring)):
+            self._stat_next = (self._stat_next + 1) % len(self._stat_ring)
+            t, arr, busy = self._stat_ring[self._stat_next]
+            if not busy[0]:
+                busy[0] = True
+                return self._stat_ring[self._stat_next]
+        t = torch.zeros(abi.EXCHANGE_STAT_WORDS, dtype=torch.int64)
+        if self.backend == "nccl":
+            t = t.pin_memory()
+        self._stat_ring.append((t, t.numpy(), [True]))
+        return self._stat_ring[-1]
+
+    def _hash_join_device_sized(self, st, pp, plan, replicate_a, keep, collective_rerun):
+        """The hash-partitioned join with NO host wait between its first kernel and its result (include/sdqh.h, ABI 5: device-sized
+        redistribution).  Both exchanges move fixed-capacity chunks — capacity = the previous run's largest (source, destination) count
+        plus an eighth — through ONE equal-split all-to-all each; the chunk headers carry the true counts, the receiver takes the chunks
+        apart into columns padded to the capacity with a key that nothing holds, and the consumers (the rebuild of B, the probe loop)
+        run on the capacity.  A status block records the largest count of each exchange; all-reduced (MAX) it tells every rank alike
+        whether any chunk anywhere overflowed — then the join is repeated, collectively, with exact sizes — and bounds the next run.
+        K-F is the engine's own deferred K-F; the status lands in pinned memory in front of it on the same stream."""
+        ctx = self.ctx
+        a_op, b_op, c_op, f_op = plan.ops
+        G = self.world
+        trivial = G == 1 and self.skip_trivial
+        cap_b, cap_c = st.caps
+        lo_g, hi_g = min(r[0] for r in st.b_ranges), max(r[1] for r in st.b_ranges)
+        pad = lo_g - 1                                              # no entry, no probe row carries it; B's bounds are told to include it
+        self._on_engine_stream()
+        stat_t = torch.zeros(abi.EXCHANGE_STAT_WORDS, dtype=torch.int64, device=self.device)
+        stat = ctx.wrap(stat_t.data_ptr(), abi.EXCHANGE_STAT_WORDS, abi.I64, keepalive=stat_t)
+        host_t, host, busy = self._stat_buffer()
+        host[abi.EXCHANGE_STAT_WORDS - 1] = -1                     # sentinel: overwritten (by 0) when the status has landed
+        run = {"probes": []}
+
+        def exchange(table, cap, dtypes, slot):
+            cw = ctx.chunk_words(len(dtypes), cap)
+            send = torch.empty(G * cw, dtype=torch.int64, device=self.device)
+            ctx.table_partition_pack(table, G, cap, send.data_ptr())
+            if trivial:
+                recv = send                                         # a group of one: what was packed for rank 0 is what rank 0 receives
+            else:
+                recv = torch.empty_like(send)
+                self._a2a(recv, send, [cw] * G, [cw] * G)
+            cols = ctx.unpack_chunks(recv.data_ptr(), G, dtypes, cap, pad, stat, slot, sent_ptr=send.data_ptr(), self_part=self.rank)
+            keep.extend([send, recv])
+            return cols
+
+        def exchange_b(env):
+            bt_b = env[b_op.out]
+            brecv = exchange(bt_b.table, cap_b, [abi.I64] * (1 + bt_b.table.npayload), 0)
+            brecv[0].set_bounds(pad, hi_g)
+            table_b = self._build_from_columns(G * cap_b, brecv, (pad, hi_g), first_key=lo_g)
+            bt_b.table.free()
+            bt_b.table = table_b
+            keep.extend(brecv)
+            if trivial:
+                run["probes"] = [(table_b, st.key_c, False)]          # a group of one: B itself answers "does any rank hold this key"
+            elif self.prefilter and lo_g <= hi_g and hi_g - lo_g + 1 <= (1 << 31):
+                all_keys, words = self._replicated_key_set(table_b, (lo_g, hi_g))
+                run["probes"] = [(all_keys, st.key_c, True)]
+                keep.append(words)
+
+        def probe_received(env):
+            P = self._probe_program(st, [(t, k) for t, k, _ in run["probes"]])
+            staged = ctx.xstage(st.nc, P)
+            try:
+                crecv = exchange(staged, cap_c, [abi.I64] + [c.dtype for c in st.ops_c], 1)
+            finally:
+                staged.free()
+                for t, _, owned in run["probes"]:
+                    if owned:
+                        t.free()                                      # (the words it borrowed stay alive in `keep`)
+            crecv[0].set_bounds(pad, hi_g)
+            keep.extend(crecv)
+            res = st.step_c(env, rows=(G * cap_c, crecv[0], abi.make_tuple(st.step_c.tuple_shape, crecv[1:])))
+            # the status: the largest counts made global, then to the host — queued, in front of the engine's K-F on the same stream
+            if not trivial:
+                head = stat_t[:4]
+                self._note("all_reduce", head)
+                dist.all_reduce(head, op=dist.ReduceOp.MAX, group=self.group)
+            host_t.copy_(stat_t, non_blocking=True)
+            keep.append(stat_t)
+            return res
+
+        def precheck():
+            # the result is being collected: the status first (it landed before K-F's rows: same stream, queued earlier)
+            try:
+                if host[abi.EXCHANGE_STAT_WORDS - 1] == -1:
+                    t0 = time.perf_counter()
+                    while host[abi.EXCHANGE_STAT_WORDS - 1] == -1:
+                        if time.perf_counter() - t0 > 2.0:
+                            ctx.synchronize()
+                            if self.backend == "nccl":
+                                torch.cuda.synchronize(self.device)
+                            break
+                most_b, most_c = int(host[abi.STAT_MAX_COUNT + 0]), int(host[abi.STAT_MAX_COUNT + 1])
+                d = host[abi.STAT_DETAIL:abi.STAT_DETAIL + 8]
+                sent_b, self_b, recv_c, sent_c, self_c = int(d[1]), int(d[2]), int(d[4]), int(d[5]), int(d[6])
+            finally:
+                busy[0] = False
+            st.caps = (_chunk_bound(most_b, cap_b), _chunk_bound(most_c, cap_c))
+            if most_b > cap_b or most_c > cap_c:
+                raise engine.RetryPlan("an exchange outgrew its chunks (%d > %d or %d > %d rows)" % (most_b, cap_b, most_c, cap_c))
+            self.exchanged_rows = {"build": sent_b, "probe_sent": sent_c, "probe_received": recv_c}
+            self.exchanged_bytes = 8 * ((1 + len(st.pay_b)) * (sent_b - self_b) + (1 + len(st.ops_c)) * (sent_c - self_c))
+
+        self.fast_runs += 1
+        res = pp.run(self._top, after={a_op.out: replicate_a, b_op.out: exchange_b}, replace={c_op.out: probe_received},
+                     keep_tables=True, on_retry=collective_rerun, precheck=precheck)
+        if not isinstance(res, engine.DeferredResultSet):
+            # every call was waited for (ORDER BY ... LIMIT, profiling): the status is here too
+            try:
+                precheck()
+            except engine.RetryPlan:
+                return collective_rerun()
+        return res
 
     def _join_sort_spec(self, st):
         """sdqh_table_topk sort keys for the partitioned join's result columns, or None (host ordering)."""
@@ -1071,6 +1272,17 @@ def default_runner(eng, devices, partition="auto"):
     if dist.get_world_size() != devices:
         raise RuntimeError("sdqlpy_init(devices=%d): the process group has %d ranks" % (devices, dist.get_world_size()))
     return DistributedRunner(eng, dist.get_rank(), dist.get_world_size(), partition=partition)
+
+
+def _chunk_bound(most, current=None):
+    """Rows per chunk of the next device-sized exchange, from the largest (source, destination) count the last run saw: an eighth of
+    head-room and 1024 rows; a bound that is still roomy (the count shrank by less than a quarter) is kept — every change is a new
+    buffer size for the allocator."""
+    want = int(most) + int(most) // 8 + 1024
+    want += want & 1
+    if current is not None and most <= current and current <= want + want // 4:
+        return current
+    return want
 
 
 def _is_join_shape(ops):

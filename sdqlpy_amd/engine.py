@@ -1810,6 +1810,10 @@ def _select_keys(eng, op, env):
     return BuiltTable(table, bt.key_name, False, [], False, [])
 
 
+class RetryPlan(Exception):
+    """Raised by a deferred run's precheck: what was launched has to be run again (PreparedPlan.run: on_retry)."""
+
+
 class PreparedPlan:
     """A plan bound to one engine and one set of tables: every operator lowered to a closure."""
 
@@ -1866,13 +1870,21 @@ class PreparedPlan:
             return frozenset([ops[-2].out, ops[-1].out])
         return frozenset()
 
-    def run(self, top=None, deferred=True, after=None):
+    def run(self, top=None, deferred=True, after=None, replace=None, keep_tables=False, on_retry=None, precheck=None):
         """top = (k, [(result column, "asc" | "desc"), ...]): ORDER BY ... LIMIT k on the final K-F.
         deferred: the plan's last device call may be launched without being waited for (Engine.deferred_results): the result is
         then a DeferredResultSet that finishes the plan when it is first looked at.
         after: {step name: callable(env)} run right behind that step, before the next one (the multi-GPU runner's seams: a built
         table replaced by its replica, foreign rows aggregated into a table before it is finalised); a callable may return a
-        replacement for the step's outcome."""
+        replacement for the step's outcome.
+        replace: {step name: callable(env)} run INSTEAD of that step (the multi-GPU runner: the probe loop over the rows that reached
+        this rank through the exchange, not over the scanned table).
+        keep_tables: a deferred run keeps its tables until its result has been collected, so that a K-F whose block turned out too
+        small is repeated on them, waited for, by this rank alone — with seams, running the whole plan again would issue collectives
+        the other ranks are not in.
+        precheck: callable() run when the deferred result is collected, before anything is read (it may raise RetryPlan).
+        on_retry: callable() -> result, what a deferred result does when the data decided against what was launched (instead of
+        running the plan again here with every call waited for): the multi-GPU runner's collective re-run."""
         env = {}
         if top is not None:
             env["__top__"] = (int(top[0]), [(str(n), str(d)) for n, d in top[1]])
@@ -1880,15 +1892,18 @@ class PreparedPlan:
                 raise ValueError("top: directions are 'asc' or 'desc'")
         if deferred and top is None and self.defer_names and getattr(self.eng, "deferred_results", False) and not self.eng.ctx._profiling:
             env["__defer__"] = self.defer_names
+        held = False
         try:
             for i, (out, step) in enumerate(self.steps):
-                env[out] = step(env)
+                env[out] = replace[out](env) if replace and out in replace else step(env)
                 if after and out in after:
                     repl = after[out](env)
                     if repl is not None:
                         env[out] = repl
                 if isinstance(env[out], Pending):
-                    return self._deferred(env, i, top)
+                    rs = self._deferred(env, i, top, keep_tables, on_retry, precheck, bool(after or replace))
+                    held = keep_tables
+                    return rs
             res = env[self.plan.result]
             if isinstance(res, (BuiltTable, tuple)):
                 res = _materialize(self.eng, res, env, hint_key=id(self.plan))
@@ -1900,22 +1915,40 @@ class PreparedPlan:
                 raise UnsupportedQuery("top(k) applies to queries that end in a result set")
             return res
         finally:
-            for v in env.values():                           # release device tables of this run
-                if isinstance(v, BuiltTable):
-                    v.table.free()
+            if not held:
+                for v in env.values():                       # release device tables of this run
+                    if isinstance(v, BuiltTable):
+                        v.table.free()
 
-
-    def _deferred(self, env, at, top):
+    def _deferred(self, env, at, top, keep_tables=False, on_retry=None, precheck=None, seams=False):
         """The steps after `at` (host-side: they only reshape) and the hand-over, as the thunk of a DeferredResultSet.  The tables of
-        the run are released by the caller now — their memory is reused in stream order, behind the kernels still queued."""
+        the run are released by the caller now — their memory is reused in stream order, behind the kernels still queued — unless
+        keep_tables: then they live until the result is collected (see run)."""
         pending, out = env[at_name(self, at)], at_name(self, at)
         host_env = {k: v for k, v in env.items() if not isinstance(v, BuiltTable)}
+        kept = dict(env) if keep_tables else None
         rest = self.steps[at + 1:]
         eng, plan = self.eng, self.plan
 
+        def release():
+            if kept is not None:
+                for v in kept.values():
+                    if isinstance(v, BuiltTable):
+                        v.table.free()
+                kept.clear()
+
         def thunk():                                                # (resolve() waits for THIS result — its completion word —, not for what was queued behind it)
             try:
-                host_env[out] = pending.resolve()
+                if precheck is not None:
+                    precheck()
+                try:
+                    host_env[out] = pending.resolve()
+                except abi.SdqhError as exc:
+                    if exc.code != abi.ERR_OVERFLOW or not kept:
+                        raise
+                    # K-F's block was sized from a smaller result: K-F again on the run's own tables, waited for — local to this rank
+                    again = {k: v for k, v in kept.items() if k != "__defer__"}
+                    host_env[out] = self.steps[at][1](again)
                 for name, step in rest:
                     host_env[name] = step(host_env)
                 res = host_env[plan.result]
@@ -1924,13 +1957,21 @@ class PreparedPlan:
                 if not isinstance(res, ResultSet):
                     raise UnsupportedQuery("a deferred plan must end in a result set")
                 return res
-            except (abi.SdqhError, UnsupportedQuery) as exc:
+            except (abi.SdqhError, UnsupportedQuery, RetryPlan) as exc:
                 if isinstance(exc, abi.SdqhError) and exc.code not in (abi.ERR_OVERFLOW, abi.ERR_UNSUPPORTED):
                     raise
+                release()
+                if on_retry is not None:
+                    return on_retry()
+                if seams:
+                    # the run had seams (after / replace: the multi-GPU runner's exchange): running it again HERE would build from this
+                    # rank's shard alone — or issue collectives the other ranks are not in.  Never silently: the runner gives on_retry.
+                    raise RuntimeError("%s: a deferred run with seams cannot be repeated by one rank alone (%s)" % (plan.name, exc))
                 # what only the data could decide (more groups than the kernel's table, a result that outgrew its block): the
                 # plan once more, every call waited for — its own fall-backs take it from there
-                res = self.run(top, deferred=False)
-                return res
+                return self.run(top, deferred=False)
+            finally:
+                release()
         rs = DeferredResultSet(thunk)
         eng._outstanding.add(rs)
         return rs

@@ -171,3 +171,39 @@ def test_bench_starts_its_own_ranks():
     bad = subprocess.run(cmd, env=dict(env, SDQLPY_TEST_FAIL_RANK="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert bad.returncode != 0 and not bad.stdout.strip(), (bad.returncode, bad.stdout[-500:])
     assert "rank 1 exited with code 7" in bad.stderr
+
+
+def test_device_sized_exchanges_and_what_happens_when_a_bound_is_too_small(tmp_path, oracle_lib):
+    """The hash-partitioned join from its second run on moves fixed-capacity chunks with their counts in the chunk headers — no count
+    visits the host (dist.DistributedRunner._hash_join_device_sized; include/sdqh.h ABI 5) — and returns a result that is launched,
+    not waited for.  Same rows as the first, exact-size run, every time; bounds forced too small are found out from the all-reduced
+    status when the result is collected and the join is repeated COLLECTIVELY with exact sizes; a K-F result block forced too small —
+    on both ranks, then on rank 0 alone — is repeated on that rank's kept tables without any collective (a rank re-running the plan
+    alone would build from its shard only, or hang its peers: the round-4 advice).  The range-partitioned form the same."""
+    sf = 0.3                                                        # ~1 700 result rows per rank: more than the smallest result block (1024 rows)
+    port, out = free_port(), str(tmp_path / "fast.json")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_fast_worker.py"), str(r), "2", str(port), str(sf), out],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = [p.communicate(timeout=900)[0] for p in procs]
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-3000:]
+    with open(out) as fh:
+        got = json.load(fh)
+    eng = engine.Engine(oracle_lib.context(threads=2))
+    cols = tpch.columns_for(["q3"])
+    want = helpers.run_query(eng, "q3", tpch.generate(sf, tables=sorted(cols), columns=cols, threads=2))
+    eng.close()
+    for mode in ("hash", "range"):
+        runs = {r["label"]: r for r in got[mode]}
+        for label, r in runs.items():
+            helpers.assert_rows_match(sorted(as_rows(r["rows"])), helpers.result_rows(want, want.columns), 1e-12, "%s / %s" % (mode, label))
+            assert r["local_rows"] > 1024 and r["partitioning"] == mode, (mode, label, r["local_rows"], r["partitioning"])
+        assert not runs["first"]["deferred"] or mode == "range"
+        assert runs["second"]["deferred"] and runs["third"]["deferred"] and runs["last"]["deferred"], mode
+    h = {r["label"]: r for r in got["hash"]}
+    assert h["first"]["fast_runs"] == 0 and h["second"]["fast_runs"] == 1 and h["third"]["fast_runs"] == 2
+    assert h["second"]["exchanged"] == h["first"]["exchanged"] and h["first"]["exchanged"]["probe_sent"] > 0, (h["first"]["exchanged"], h["second"]["exchanged"])
+    assert h["third"]["retries"] == 0 and h["chunks too small"]["retries"] == 1 and h["after the collective re-run"]["retries"] == 1
+    assert h["after the collective re-run"]["fast_runs"] == h["chunks too small"]["fast_runs"] + 1
+    # K-F blocks too small never repeat the join: the device-sized runs go on, no collective re-run
+    assert h["last"]["retries"] == 1 and h["last"]["fast_runs"] == h["after the collective re-run"]["fast_runs"] + 3

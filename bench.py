@@ -53,6 +53,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lanes", type=int, default=0, help="engine lanes — contexts of one family, a stream each; a plan is bound to one (0: the engine's default, 3)")
     ap.add_argument("--force-dist", action="store_true", help="use the distributed plan even with one rank (exercises the RCCL path)")
+    ap.add_argument("--trivial-collectives", action="store_true", help="with --force-dist: a group of ONE still issues every collective (the RCCL calls themselves on one GPU); "
+                    "by default collectives over a group of one — which move nothing — are skipped, as every rank of such a group knows to")
     ap.add_argument("--partition", default="hash", choices=["auto", "range", "hash"], help="q3's partitioning in the timed step at N > 1")
     ap.add_argument("--cpu-sample-sf", type=float, default=0.0, help="0 = pick so the CPU leg takes ~10-30 s")
     ap.add_argument("--steady-steps", type=int, default=1500, help="steps of a second, longer leg after the timed region (reported as `steady_state`, not part of `value`); 0 = none")
@@ -233,8 +235,9 @@ def main(argv=None, hooks=None):
     runner = runner_range = None
     if use_dist:
         from sdqlpy_amd import dist as sdist
-        runner = sdist.DistributedRunner(eng, rank, world, partition=args.partition)
-        runner_range = sdist.DistributedRunner(eng, rank, world, partition="auto")      # the clustered-shard shortcut, timed beside
+        trivial = None if world > 1 else (not args.trivial_collectives)
+        runner = sdist.DistributedRunner(eng, rank, world, partition=args.partition, skip_trivial=trivial)
+        runner_range = sdist.DistributedRunner(eng, rank, world, partition="auto", skip_trivial=trivial)      # the clustered-shard shortcut, timed beside
         run_query = lambda q: runner.run(q, db)           # noqa: E731
     else:
         run_query = lambda q: Q.run(q, db)                # noqa: E731
@@ -304,7 +307,10 @@ def main(argv=None, hooks=None):
         qs = queries if qs is None else qs
         run = run or run_query
         per_q = {q: 0.0 for q in qs}
-        eng.ctx.set_profiling(2, only=only)
+        # only = "-": nothing is evented — profiling stays off and settled plans are launched as recorded graphs (engine.PlanGraph: one
+        # call per query); a kernel name / None: that kernel's / every launch is evented, which needs the calls issued one by one
+        if only != "-":
+            eng.ctx.set_profiling(2, only=only)
         barrier()
         t_begin = time.perf_counter()
         marks = []                                       # (query, launches recorded so far on every context of the engine's family)
@@ -339,12 +345,18 @@ def main(argv=None, hooks=None):
 
     if runner is not None:
         runner.reset_collectives()
-    elapsed, launch_host_ms, timed_log = run_steps(args.steps, dom_kernel)
+    # THE TIMED REGION: args.steps steps, nothing evented — settled plans are launched as recorded graphs (one call per query) where the
+    # engine records them (single-GPU plans; SDQLPY_AMD_PLAN_GRAPHS=0 switches that off)
+    elapsed, launch_host_ms, _ = run_steps(args.steps, "-")
+    graph_stats = dict(getattr(eng, "graph_stats", {}) or {})
+    # the same steps once more with the dominant kernel's launches evented (HIP events on the stream it runs on): evented launches are
+    # issued call by call — a recorded graph has no place for an event pair — so this region also says what the step costs without graphs
+    elapsed_calls, launch_host_calls_ms, timed_log = run_steps(args.steps, dom_kernel)
     # the same steps with every query's result finished before the next query starts: per-query wall times, and the step as a caller
-    # who reads each result at once sees it
-    # (the dominant kernel's launches are evented here too: in this region a kernel has the chip to itself — in the first, the queries'
-    # kernels share it, lane by lane, and a kernel's duration there is not a statement about the kernel)
-    elapsed_waited, per_query_ms, waited_log = run_steps(args.steps, dom_kernel, each_waited_for=True)
+    # who reads each result at once sees it; then evented (in that region a kernel has the chip to itself — in the overlapped steps the
+    # queries' kernels share it, lane by lane, and a kernel's duration there is not a statement about the kernel)
+    elapsed_waited, per_query_ms, _ = run_steps(args.steps, "-", each_waited_for=True)
+    _, _, waited_log = run_steps(args.steps, dom_kernel, each_waited_for=True)
     q1_log = None
     if "q1" in queries and dom_q != "q1":
         # Q1's streaming kernel evented in steps of its own (the filter takes one kernel name), outside `value`
@@ -356,7 +368,7 @@ def main(argv=None, hooks=None):
             # a "distributed" step that took the single-GPU plan measures nothing (round 2's world-1 profile did)
             assert runner.last_partitioning == args.partition or (args.partition == "auto" and runner.last_partitioning in ("range", "hash")), \
                 "q3 did not run the partitioned join (partitioning %r)" % (runner.last_partitioning,)
-            assert runner.collectives.get("all_to_all", [0])[0] > 0 or runner.last_partitioning == "range", "no all-to-all ran in the timed step"
+            assert runner.collectives.get("all_to_all", [0])[0] > 0 or runner.last_partitioning == "range" or (world == 1 and runner.skip_trivial), "no all-to-all ran in the timed step"
             if args.partition == "hash":
                 assert runner.exchanged_rows.get("probe_sent", 0) > 0, runner.exchanged_rows
     nlanes = int(getattr(eng, "nlanes", 1)) if not use_dist else 1
@@ -533,6 +545,10 @@ def main(argv=None, hooks=None):
             "step": {"launch_then_finish": True, "launch_order": step_order(queries), "deferred_results": bool(getattr(eng, "deferred_results", False)),
                      # host time to LAUNCH each query of an overlapped step (plan closures, ctypes calls, kernel launches; nothing waited for)
                      "host_launch_ms": {q: round(launch_host_ms[q] / args.steps, 4) for q in queries},
+                     # ... and with the calls issued one by one (the evented repeat of the timed steps: no graphs there)
+                     "host_launch_ms_calls_issued": {q: round(launch_host_calls_ms[q] / args.steps, 4) for q in queries},
+                     "ms_per_step_calls_issued": round(elapsed_calls / args.steps * 1e3, 4),
+                     "plan_graphs": graph_stats or None,
                      "ms_per_step_each_query_waited_for": round(elapsed_waited / args.steps * 1e3, 4),
                      "value_each_query_waited_for": round(total_rows_per_step * args.steps / elapsed_waited, 1)},
             "ms_per_query": per_query,
@@ -558,6 +574,8 @@ def main(argv=None, hooks=None):
             out["q3_exchange"] = exchange
         if timed_collectives is not None:
             out["collectives_in_timed_region_rank0"] = timed_collectives
+            out["distributed_plan"] = {"device_sized_join_runs": runner.fast_runs, "repeated_with_exact_sizes": runner.fast_retries,
+                                       "collectives_over_a_group_of_one": "skipped" if (world == 1 and runner.skip_trivial) else "issued"}
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, queries, db, rows, hip_results)
             out["cpu_baseline"]["configs0_q6_sf1"] = q6_sf1_leg(eng)

@@ -604,8 +604,8 @@ int sdqh_table_partition_pack(sdqh_ctx* ctx, const sdqh_table* table, int nparts
  * column 0 (the key) holds pad_key there, the other columns 0 — so that whatever consumes the columns can be launched on the capacity
  * without knowing the count (the caller picks a pad_key its consumer drops: a key no table holds, a key a gate rejects).  dtypes as
  * for sdqh_unpack_parts; the columns are transient.  `sent` (may be null): this rank's own packed send buffer of the same step, read for
- * its header counts only.  `stat`: an I64 column of >= SDQH_EXCHANGE_STAT_WORDS rows in device memory that the caller zeroed before the
- * step's first exchange; exchange number `slot` (0 .. 3) records
+ * its header counts only.  `stat`: an I64 column of >= SDQH_EXCHANGE_STAT_WORDS rows in device memory; exchange number `slot` (0 .. 3)
+ * overwrites its own words of it (the others are left alone: a caller may keep one block for every run of a plan)
  *   stat[SDQH_STAT_MAX_COUNT + slot]            the largest header count among the chunks received and sent (> chunk_rows: rows were lost)
  *   stat[SDQH_STAT_DETAIL + 4 * slot + 0 .. 3]  rows received, rows sent to all parts, rows sent to part `self_part`, chunk_rows
  * The first four words are meant to be all-reduced (MAX) over the ranks: every rank then knows whether any chunk of the step

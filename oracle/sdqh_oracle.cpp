@@ -1570,7 +1570,7 @@ int sdqh_unpack_chunks(sdqh_ctx* ctx, const void* packed, int nparts, int ncols,
     for (int c = 0; c < ncols; ++c) for (int64_t r = done; r < cap; ++r) ((int64_t*)out_cols[c]->data)[r] = c == 0 ? pad_key : 0;
     if (stat) {
         int64_t* st = (int64_t*)stat->data;
-        st[SDQH_STAT_MAX_COUNT + slot] = std::max(st[SDQH_STAT_MAX_COUNT + slot], most);
+        st[SDQH_STAT_MAX_COUNT + slot] = most;
         int64_t* d = st + SDQH_STAT_DETAIL + 4 * slot;
         d[0] = done; d[1] = sent_all; d[2] = sent_self; d[3] = chunk_rows;
     }

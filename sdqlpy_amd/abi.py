@@ -386,6 +386,7 @@ class Context:
         self._options = {}             # options set so far (a fork starts with its parent's)
         self._profiling = False
         self._prof_mode, self._prof_only = 0, None
+        self._graphs = weakref.WeakSet()          # recorded plans (Graph): released before the context goes
         self.kernel_log = []       # [(kernel name, ms)] of every pattern call since the log was cleared (profiling on)
         self.device_log = []       # [(pattern call, device ms)]
         self._check(self.lib.sdqh_set_threads(self.handle, C.c_int(max(1, threads))))
@@ -414,6 +415,8 @@ class Context:
             child.close()
         self.forks = []
         if self.handle is not None:
+            for g in list(self._graphs):
+                g.free()
             self.lib.sdqh_synchronize(self.handle)
             for addr, size in self._host_quarantine + self._deferred_quarantine:
                 self._host_pool.setdefault(size, []).append(addr)
@@ -550,6 +553,8 @@ class Context:
 
     def set_option(self, name, value):
         self._check(self.lib.sdqh_set_option(self.handle, name.encode(), C.c_int64(int(value))))
+        if self._options.get(name) != int(value) and name != "async_copies":
+            self.option_epoch = getattr(self, "option_epoch", 0) + 1      # recorded plans (engine.PlanGraph) were made under the old setting
         self._options[name] = int(value)
         for child in self.forks:
             child.set_option(name, value)
@@ -795,7 +800,9 @@ class Context:
         """-> Graph, or raises SdqhError(ERR_UNSUPPORTED) when the recording is no graph (the CPU implementation; a call that waited)."""
         h = C.c_void_p()
         self._check(self.lib.sdqh_graph_end(self.handle, C.byref(h)))
-        return Graph(self, h)
+        g = Graph(self, h)
+        self._graphs.add(g)
+        return g
 
     def graph_abort(self):
         if self.handle is not None:
@@ -872,10 +879,15 @@ class Context:
         if self.handle is not None:
             self._check(self.lib.sdqh_result_wait(self.handle))
 
-    def table_compact_deferred(self, table, min_hits, capacity_hint, want_payload=True, want_values=True, want_hits=True):
+    def table_compact_deferred(self, table, min_hits, capacity_hint, want_payload=True, want_values=True, want_hits=True, replayable=False):
         """K-F with nothing waited for (sdqh_table_compact_deferred): returns collect() -> (keys, payload, values, hits, n), which
         waits for THIS result's copy (its completion word); a result that did not fit the block sized from capacity_hint raises
-        SdqhError(ERR_OVERFLOW) there with .needed = its row count (the caller runs the step again, waited for)."""
+        SdqhError(ERR_OVERFLOW) there with .needed = its row count (the caller runs the step again, waited for).
+        replayable: the call is being recorded into a plan graph — collect() may then be called once after EVERY launch of the graph:
+        each time it hands out fresh views of the same block, and collect.rows_out() says whether views of an earlier collection are
+        still alive somewhere (the graph must not be launched again while they are: it would overwrite their rows)."""
+        if replayable:
+            return self._table_compact_replayable(table, min_hits, capacity_hint, want_payload, want_values, want_hits)
         npay = table.npayload if want_payload else 0
         nval = TUPLE_MAX_VALUES if want_values and table.accumulate else 0
         narr = 1 + npay + nval + (1 if want_hits else 0)
@@ -908,6 +920,53 @@ class Context:
                 exc.needed = n
                 raise exc
             return (keys[:n], None if payload is None else payload[:, :n], None if values is None else values[:, :n], None if hits is None else hits[:n], n)
+        return collect
+
+    def _table_compact_replayable(self, table, min_hits, capacity_hint, want_payload, want_values, want_hits):
+        npay = table.npayload if want_payload else 0
+        nval = TUPLE_MAX_VALUES if want_values and table.accumulate else 0
+        narr = 1 + npay + nval + (1 if want_hits else 0)
+        cap = max(1024, int(capacity_hint))
+        cap += cap & 1
+        nbytes = narr * cap * 8 + 64
+        base = self.host_block(nbytes, deferred=[True])          # the recording's own block for as long as `collect` lives (released like any block after)
+        addr, size = C.addressof(base), len(base)
+        flat = np.frombuffer(base, dtype=np.int64, count=narr * cap + 8)
+        cell = flat[narr * cap:narr * cap + 2]
+        top = flat[:narr * cap].reshape(narr, cap)
+        self._check(self.lib.sdqh_table_compact_deferred(self.handle, table.handle, C.c_int64(min_hits), C.c_int64(cap), _np_ptr(top[0]),
+                                                         _np_ptr(top[1:1 + npay] if npay else None), _np_ptr(top[1 + npay:1 + npay + nval] if nval else None),
+                                                         _np_ptr(top[narr - 1] if want_hits else None), _np_ptr(cell)))
+        self._after_call("table_compact")
+        out = [0]                                                 # collections whose views are still alive
+
+        def gone():
+            out[0] -= 1
+
+        def collect():
+            if int(cell[1]) == 2:
+                self.result_wait()
+            else:
+                self._check(self.lib.sdqh_host_wait_word(self.handle, C.c_void_p(cell.ctypes.data + 8), C.c_uint32(1)))
+            n = int(cell[0])
+            if n < 0:
+                raise SdqhError(ERR_DEVICE, "table_compact_deferred: the row count never arrived")
+            if n > cap:
+                exc = SdqhError(ERR_OVERFLOW, "table_compact_deferred: %d rows, room for %d" % (n, cap))
+                exc.needed = n
+                raise exc
+            # fresh views over a wrapper of their own: when the last of them dies the block may be written again
+            w = (C.c_char * size).from_address(addr)
+            w._base = base
+            out[0] += 1
+            weakref.finalize(w, gone)
+            f = np.frombuffer(w, dtype=np.int64, count=narr * cap).reshape(narr, cap)
+            keys = f[0]
+            payload = f[1:1 + npay] if npay else None
+            values = f[1 + npay:1 + npay + nval].view(np.float64) if nval else None
+            hits = f[narr - 1] if want_hits else None
+            return (keys[:n], None if payload is None else payload[:, :n], None if values is None else values[:, :n], None if hits is None else hits[:n], n)
+        collect.rows_out = lambda: out[0] > 0
         return collect
 
     def table_compact_into_block(self, table, min_hits, capacity_hint, want_payload=True, want_values=True, want_hits=True, lazy=False):

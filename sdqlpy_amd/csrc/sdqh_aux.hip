@@ -43,12 +43,14 @@ namespace {
 __global__ void k_store32(uint32_t* p, uint32_t v) { if (threadIdx.x == 0 && blockIdx.x == 0) { __atomic_store_n(p, v, __ATOMIC_RELEASE); } }
 
 // ---- redistribution kernels ----------------------------------------------------------------------------------------------------------
-constexpr int PP_SEGS_PER_WAVE = 2;                  // stage segments a wave of the partitioning kernel walks: 8 per workgroup, ONE claim per part and workgroup
+constexpr int PP_SEGS = 4;                           // stage segments a workgroup of the partitioning kernel walks (ONE claim per part and workgroup)
 
 // The staged rows of a table (DevStage: per-wave segments, seg_count[s] live rows each) scattered into nparts fixed-capacity chunks.
-// Pass 1 counts the workgroup's rows per part in LDS, one thread per part claims the workgroup's range in the chunk (the chunk's own
-// header word is the cursor: it ends up holding every row MEANT for the chunk), pass 2 places the rows — rank inside the workgroup by a
-// second LDS counter; the lanes of a wave that go to one part take consecutive places, so the stores are runs.
+// A workgroup takes PP_SEGS segments; its four waves share every segment's rows (wave w: the 64-row batches w, w + 4, ... — a wave
+// per segment left most of the chip idle: a stage has a few thousand segments of a few hundred live rows).  Pass 1 counts the
+// workgroup's rows per part in LDS, one thread per part claims the workgroup's range in the chunk (the chunk's own header word is the
+// cursor: it ends up holding every row MEANT for the chunk), pass 2 places the rows — rank inside the workgroup by a second LDS
+// counter; the lanes of a wave that go to one part take consecutive places, so the stores are runs.
 __global__ __launch_bounds__(TPB) void k_stage_part_pack(DevStage st, DevPartition pt, int ncols, int64_t chunk_rows, int64_t chunk_words, int64_t* __restrict__ packed) {
     __shared__ unsigned int s_hist[SDQH_MAX_PARTS];
     __shared__ unsigned int s_rank[SDQH_MAX_PARTS];
@@ -56,14 +58,16 @@ __global__ __launch_bounds__(TPB) void k_stage_part_pack(DevStage st, DevPartiti
     if (threadIdx.x < SDQH_MAX_PARTS) { s_hist[threadIdx.x] = 0; s_rank[threadIdx.x] = 0; }
     __syncthreads();
     const int wave = (int)(threadIdx.x / WAVE), lane = (int)(threadIdx.x & (WAVE - 1));
-    const int seg0 = ((int)blockIdx.x * (TPB / WAVE) + wave) * PP_SEGS_PER_WAVE;
+    const int seg0 = (int)blockIdx.x * PP_SEGS;
+    uint32_t counts[PP_SEGS];
+#pragma unroll
+    for (int j = 0; j < PP_SEGS; ++j) counts[j] = seg0 + j < st.nseg ? st.seg_count[seg0 + j] : 0u;
     for (int pass = 0; pass < 2; ++pass) {
-        for (int j = 0; j < PP_SEGS_PER_WAVE; ++j) {
-            const int seg = seg0 + j;
-            if (seg >= st.nseg) break;
-            const int64_t base = (int64_t)seg * st.seg_rows;
-            const uint32_t count = st.seg_count[seg];
-            for (uint32_t i0 = 0; i0 < count; i0 += WAVE) {
+#pragma unroll
+        for (int j = 0; j < PP_SEGS; ++j) {
+            const int64_t base = (int64_t)(seg0 + j) * st.seg_rows;
+            const uint32_t count = counts[j];
+            for (uint32_t i0 = (uint32_t)wave * WAVE; i0 < count; i0 += TPB) {
                 const bool live = i0 + lane < count;
                 const int64_t row = base + i0 + lane;
                 const int64_t key = live ? st.key[row] : 0;
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(TPB) void k_unpack_chunks(DevChunkUnpack u) {
             }
         }
         int64_t* d = u.stat + SDQH_STAT_DETAIL + 4 * u.slot;
-        if (most > u.stat[SDQH_STAT_MAX_COUNT + u.slot]) u.stat[SDQH_STAT_MAX_COUNT + u.slot] = most;
+        u.stat[SDQH_STAT_MAX_COUNT + u.slot] = most;
         d[0] = recv; d[1] = sent_all; d[2] = sent_self; d[3] = u.chunk_rows;
     }
 }
@@ -261,8 +265,7 @@ int sdqh_table_partition_pack(sdqh_ctx* ctx, const sdqh_table* table, int nparts
     call_begin(ctx);
     // the headers double as the kernel's cursors: 16 bytes cleared at the head of every chunk (one strided memset)
     HIP_TRYA(ctx, hipMemset2DAsync(packed, (size_t)cw * 8, 0, 16, (size_t)nparts, ctx->stream));
-    const int per_wg = (TPB / WAVE) * PP_SEGS_PER_WAVE;
-    const unsigned grid = (unsigned)std::max(1, (table->stage.nseg + per_wg - 1) / per_wg);
+    const unsigned grid = (unsigned)std::max(1, (table->stage.nseg + PP_SEGS - 1) / PP_SEGS);
     { KernelScope ks(ctx, "k_stage_part_pack");
       hipLaunchKernelGGL(k_stage_part_pack, dim3(grid), dim3(TPB), 0, ctx->stream, table->stage, pt, ncols, chunk_rows, cw, static_cast<int64_t*>(packed)); }
     call_end(ctx);

@@ -1542,8 +1542,17 @@ int sdqh_xstage(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, sdqh_tab
     if (1 + prog->nvals > SDQH_MAX_COMPACT_COLS) return fail(ctx, SDQH_ERR_INVALID, "xstage: too many columns");
     // the staging half of a build: the stage sink keeps every passing row in its wave's segment, equal keys included; no bounds, no
     // bitmap, and the index a build would make lazily is never asked for — the row count stays in seg_count[] on the device
+    // Which stage kernel: the VALUE queue (x_vstage8) streams every column of every row — right for a build that keeps a tenth of its
+    // rows; the probe side of a join keeps a fraction of a per cent, and the queue skeleton, which streams the tested columns and
+    // gathers the values of the few survivors by row, moves half the bytes (Q3's lineitem at SF=10: 0.15 ms against 0.10).
+    // SDQLPY_AMD_XSTAGE_VALUES=1 is the A/B switch.
+    static const bool by_values = [] { const char* e = getenv("SDQLPY_AMD_XSTAGE_VALUES"); return e && e[0] == '1'; }();
+    const int was = ctx->opt_vstage;
+    if (!by_values) ctx->opt_vstage = 0;
     sdqh_table* tb = nullptr;
-    if (int rc = sdqh_xbuild(ctx, nrows, prog, 1, 0, 0, &tb)) return rc;
+    const int rc = sdqh_xbuild(ctx, nrows, prog, 1, 0, 0, &tb);
+    ctx->opt_vstage = was;
+    if (rc) return rc;
     tb->stage_only = true;
     *out = tb;
     return SDQH_OK;

@@ -114,7 +114,14 @@ class DistributedRunner:
             self.ctx.synchronize()
         self._inflight.clear()
         self._gather_bufs.clear()
+        for _, plan in self._plans.values():                   # prepared joins / chains of THIS runner (their buffers are torch tensors made on the engine's stream)
+            for cache in ("_dist_prepared", "_dist_chain"):
+                d = plan.__dict__.get(cache)
+                if d:
+                    for k in [k for k in d if k[0] == id(self)]:
+                        del d[k]
         self._plans.clear()
+        self._stat_ring = []
         self._ext_stream = None
 
     def _note(self, name, tensor):
@@ -285,8 +292,11 @@ class DistributedRunner:
         self._last_matrix_max = int(matrix.max()) if matrix.size else 0          # (every rank sees the same matrix: the bound of the next run's chunks)
         n_recv = int(recv_counts.sum())
         self.exchanged_bytes += 8 * k * (nrows - int(counts[self.rank]))
-        recv = torch.empty(max(n_recv * k, 1), dtype=torch.int64, device=self.device)
-        if matrix.sum() > 0:
+        if self.world == 1 and self.skip_trivial:
+            recv = send                                                       # a group of one: what was packed for rank 0 is what rank 0 receives
+        else:
+            recv = torch.empty(max(n_recv * k, 1), dtype=torch.int64, device=self.device)
+        if matrix.sum() > 0 and recv is not send:
             self._a2a(recv[:n_recv * k], send[:nrows * k], [int(c) * k for c in recv_counts], [int(c) * k for c in counts])
         out, n = self.ctx.unpack_parts(recv.data_ptr(), recv_counts, dtypes or [c.dtype for c in cols])      # (dtypes: entries of a staged table come back as raw 8-byte columns)
         self._inflight.extend([send, recv])                                  # queued kernels read them; released at the next run
@@ -1128,30 +1138,53 @@ class DistributedRunner:
         lo_g, hi_g = min(r[0] for r in st.b_ranges), max(r[1] for r in st.b_ranges)
         pad = lo_g - 1                                              # no entry, no probe row carries it; B's bounds are told to include it
         self._on_engine_stream()
-        stat_t = torch.zeros(abi.EXCHANGE_STAT_WORDS, dtype=torch.int64, device=self.device)
-        stat = ctx.wrap(stat_t.data_ptr(), abi.EXCHANGE_STAT_WORDS, abi.I64, keepalive=stat_t)
+        # what a prepared join keeps from run to run: the status block (every exchange overwrites its own words, the last word stays 0)
+        # and the collective buffers — written and read in stream order, run after run, so nothing is allocated per run
+        dev = st.__dict__.get("dev_bufs")
+        if dev is None or dev["caps"] != (cap_b, cap_c):
+            dev = st.dev_bufs = {"caps": (cap_b, cap_c), "stat": torch.zeros(abi.EXCHANGE_STAT_WORDS, dtype=torch.int64, device=self.device), "bufs": {}}
+            dev["stat_col"] = ctx.wrap(dev["stat"].data_ptr(), abi.EXCHANGE_STAT_WORDS, abi.I64, keepalive=dev["stat"])
+        stat_t, stat = dev["stat"], dev["stat_col"]
         host_t, host, busy = self._stat_buffer()
         host[abi.EXCHANGE_STAT_WORDS - 1] = -1                     # sentinel: overwritten (by 0) when the status has landed
         run = {"probes": []}
 
         def exchange(table, cap, dtypes, slot):
-            cw = ctx.chunk_words(len(dtypes), cap)
-            send = torch.empty(G * cw, dtype=torch.int64, device=self.device)
+            pair = dev["bufs"].get(slot)
+            if pair is None:
+                cw = ctx.chunk_words(len(dtypes), cap)
+                send = torch.empty(G * cw, dtype=torch.int64, device=self.device)
+                pair = dev["bufs"][slot] = (send, send if trivial else torch.empty_like(send), cw)      # (a group of one: what was packed for rank 0 is what rank 0 receives)
+            send, recv, cw = pair
             ctx.table_partition_pack(table, G, cap, send.data_ptr())
-            if trivial:
-                recv = send                                         # a group of one: what was packed for rank 0 is what rank 0 receives
-            else:
-                recv = torch.empty_like(send)
+            if recv is not send:
                 self._a2a(recv, send, [cw] * G, [cw] * G)
-            cols = ctx.unpack_chunks(recv.data_ptr(), G, dtypes, cap, pad, stat, slot, sent_ptr=send.data_ptr(), self_part=self.rank)
-            keep.extend([send, recv])
-            return cols
+            return ctx.unpack_chunks(recv.data_ptr(), G, dtypes, cap, pad, stat, slot, sent_ptr=send.data_ptr(), self_part=self.rank)
+
+        def rebuild_b(cols):
+            # the rebuild's program is made once per prepared join; a run only names its columns (they are new every run)
+            pb = st.__dict__.get("prog_b")
+            if pb is None or len(pb[1]) != len(cols):
+                prog = abi.Program()
+                prog.key = prog.op(abi.X_COL, abi.T_I64, col=cols[0])
+                prog.gates = [prog.op(abi.X_GE, abi.T_BOOL, a=prog.key, b=prog.op(abi.X_CONST, abi.T_I64, imm_i=lo_g))]
+                prog.vals = [prog.op(abi.X_COL, abi.T_I64, col=c) for c in cols[1:]]
+                pb = st.prog_b = (prog, [prog.key] + list(prog.vals))
+            prog, slots = pb
+            for i, c in zip(slots, cols):
+                prog.bind_col(i, c)
+            try:
+                return ctx.xbuild(G * cap_b, prog, pad, hi_g, accumulate=True)
+            except abi.SdqhError as exc:
+                if exc.code != abi.ERR_UNSUPPORTED:
+                    raise
+                return self._build_from_columns(G * cap_b, cols, (pad, hi_g), first_key=lo_g)
 
         def exchange_b(env):
             bt_b = env[b_op.out]
             brecv = exchange(bt_b.table, cap_b, [abi.I64] * (1 + bt_b.table.npayload), 0)
             brecv[0].set_bounds(pad, hi_g)
-            table_b = self._build_from_columns(G * cap_b, brecv, (pad, hi_g), first_key=lo_g)
+            table_b = rebuild_b(brecv)
             bt_b.table.free()
             bt_b.table = table_b
             keep.extend(brecv)
@@ -1163,7 +1196,13 @@ class DistributedRunner:
                 keep.append(words)
 
         def probe_received(env):
-            P = self._probe_program(st, [(t, k) for t, k, _ in run["probes"]])
+            pc = st.__dict__.get("prog_c")
+            if pc is None or pc[2] != len(run["probes"]):
+                P = self._probe_program(st, [(t, k) for t, k, _ in run["probes"]])
+                pc = st.prog_c = (P, [i for i, o in enumerate(P.ops) if o["code"] == abi.X_LOOKUP], len(run["probes"]))
+            P = pc[0]
+            for i, (t, _, _) in zip(pc[1], run["probes"]):
+                P.bind_table(i, t)
             staged = ctx.xstage(st.nc, P)
             try:
                 crecv = exchange(staged, cap_c, [abi.I64] + [c.dtype for c in st.ops_c], 1)
@@ -1181,7 +1220,6 @@ class DistributedRunner:
                 self._note("all_reduce", head)
                 dist.all_reduce(head, op=dist.ReduceOp.MAX, group=self.group)
             host_t.copy_(stat_t, non_blocking=True)
-            keep.append(stat_t)
             return res
 
         def precheck():

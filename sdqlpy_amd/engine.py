@@ -133,6 +133,13 @@ class Engine:
         # chip: one query's small dependent launches run under another's streaming kernel instead of queueing behind it on one stream
         # (bench step q1 + q3 + q5: 0.83 -> 0.57 ms, tools/step_lanes.py).  A query that is waited for before the next is launched
         # gains and loses nothing.  SDQLPY_AMD_LANES=1: one stream, as before.
+        # PLAN GRAPHS: a prepared plan whose calls wait for nothing (its last call deferred) is recorded once into a graph (abi.Graph:
+        # sdqh_graph_*) and from then on launched by ONE call — the host issues a query in microseconds instead of a dozen calls.
+        # The value = recordings a plan may hold (each owns its tables' memory and a result block; a recording is reused when its last
+        # result has been collected and dropped); 0 = off.
+        self.plan_graphs = int(os.environ.get("SDQLPY_AMD_PLAN_GRAPHS", "2")) if ctx.library.backend_name() == "hip-gfx950" else 0
+        self.plan_graphs_always = os.environ.get("SDQLPY_AMD_PLAN_GRAPHS_ALWAYS", "0") == "1"      # (default: only while no other result is in flight, see PreparedPlan.run)
+        self.graph_stats = {"recorded": 0, "launched": 0, "refused": 0, "dropped": 0}
         lanes = os.environ.get("SDQLPY_AMD_LANES", "")
         self.nlanes = max(1, int(lanes)) if lanes else (3 if ctx.library.backend_name() == "hip-gfx950" else 1)
         self._lane_views = {}
@@ -1444,7 +1451,7 @@ def _materialize(eng, value, env, hint_key=None, top=None, lazy_ok=False, defer=
             # sized from the previous run of this step (the first run waits and learns the size); a result that outgrew it is noticed
             # when it is collected and the plan re-run
             try:
-                collect = eng.ctx.table_compact_deferred(bt.table, 1, hint + hint // 8 + 1024, want_hits=want_hits)
+                collect = eng.ctx.table_compact_deferred(bt.table, 1, hint + hint // 8 + 1024, want_hits=want_hits, replayable=bool(env.get("__record__")))
             except abi.SdqhError as exc:
                 if exc.code != abi.ERR_UNSUPPORTED:               # (the option "async_result" is off: the waited-for call below)
                     raise
@@ -1463,7 +1470,10 @@ def _materialize(eng, value, env, hint_key=None, top=None, lazy_ok=False, defer=
                 d.ordered = False
                 return d
             if collect is not None:
-                return Pending(resolve)
+                p = Pending(resolve)
+                if env.get("__record__"):
+                    env["__rows_out__"] = collect.rows_out      # (PlanGraph: the recording is launched again only when no view of an earlier result is alive)
+                return p
         keys, payload, values, hits, ordered = _fetch_entries(eng, bt.table, 1, hint_key, top, spec, want_hits=want_hits, lazy=lazy)
         values = [values[j] for j in range(nv)]
         if getattr(bt, "key_radix", None) is not None and out_key_fields == [(bt.key_name, "key")]:    # several key fields in one mixed-radix integer
@@ -1810,6 +1820,28 @@ def _select_keys(eng, op, env):
     return BuiltTable(table, bt.key_name, False, [], False, [])
 
 
+def _in_flight(eng):
+    """Results launched through this engine and not collected yet (dropped unread: no longer counted)."""
+    return sum(1 for rs in list(getattr(eng, "_eng", eng)._outstanding) if "_thunk" in rs.__dict__)
+
+
+class PlanGraph:
+    """One recording of a prepared plan (abi.Graph) with what collecting its result needs: the step it ends at, that step's Pending
+    (its resolve() reads the recording's own result block, after every launch), the host-side values of the recorded run.
+    state: "free" (may be launched) / "flying" (launched, result not collected yet)."""
+
+    def __init__(self, graph, at, pending, host_env, rows_out, epoch):
+        self.graph, self.at, self.pending, self.host_env, self.rows_out, self.epoch = graph, at, pending, host_env, rows_out, epoch
+        self.state = "free"
+        self.result = lambda: None
+
+    def free(self):
+        if self.graph is not None:
+            self.graph.free()
+            self.graph = None
+        self.pending = None
+
+
 class RetryPlan(Exception):
     """Raised by a deferred run's precheck: what was launched has to be run again (PreparedPlan.run: on_retry)."""
 
@@ -1843,6 +1875,7 @@ class PreparedPlan:
         looked_up = _looked_up(plan)
         compared = _compared_lookups(plan)
         self.steps = []
+        self._graphs, self._graph_refused, self._deferred_runs = [], None, 0
         self.defer_names = self._defer_names(plan)
         for op in plan.ops:
             if isinstance(op, ScanOp):
@@ -1892,6 +1925,16 @@ class PreparedPlan:
                 raise ValueError("top: directions are 'asc' or 'desc'")
         if deferred and top is None and self.defer_names and getattr(self.eng, "deferred_results", False) and not self.eng.ctx._profiling:
             env["__defer__"] = self.defer_names
+            # A recording starts a query SOONER (one call instead of a dozen): that is worth something when the device is idle — a
+            # query that is waited for before the next is launched: 0.33 -> 0.29 ms for Q3 at SF=10.  While other results are still in
+            # flight the device is busy anyway, and issuing call by call staggers the queries' big streaming kernels instead of starting
+            # them all at once (measured: the q1+q3+q5 step 0.59 ms call by call, 0.62 as three recordings at once —
+            # profiles/r05_plan_graphs.txt): then the calls are issued.  SDQLPY_AMD_PLAN_GRAPHS_ALWAYS=1 records regardless.
+            if not (after or replace) and getattr(self.eng, "plan_graphs", 0) > 0 and not self._graph_refused and not self.eng.ctx._prof_mode \
+                    and (getattr(self.eng, "plan_graphs_always", False) or _in_flight(self.eng) == 0):
+                rs = self._run_graph()
+                if rs is not None:
+                    return rs
         held = False
         try:
             for i, (out, step) in enumerate(self.steps):
@@ -1903,6 +1946,7 @@ class PreparedPlan:
                 if isinstance(env[out], Pending):
                     rs = self._deferred(env, i, top, keep_tables, on_retry, precheck, bool(after or replace))
                     held = keep_tables
+                    self._deferred_runs += 1
                     return rs
             res = env[self.plan.result]
             if isinstance(res, (BuiltTable, tuple)):
@@ -1919,6 +1963,113 @@ class PreparedPlan:
                 for v in env.values():                       # release device tables of this run
                     if isinstance(v, BuiltTable):
                         v.table.free()
+
+    # ---- plan graphs ---------------------------------------------------------------------------------------------------------
+    def _graph_epoch(self):
+        root = getattr(self.eng, "_eng", self.eng).ctx
+        return (getattr(root, "option_epoch", 0), self.eng.ctx.handle)
+
+    def drop_graphs(self):
+        for g in self._graphs:
+            g.free()
+        self._graphs = []
+
+    def _run_graph(self):
+        """Launch one of this plan's recordings (making one first when the plan has run often enough to be settled: kernels
+        specialised, twins and dictionaries built, result blocks sized) and return its deferred result — or None: the caller issues
+        the calls itself this time."""
+        eng = self.eng
+        epoch = self._graph_epoch()
+        if self._graphs and self._graphs[0].epoch != epoch:
+            self.drop_graphs()                                   # an option changed since they were recorded
+        g = None
+        for cand in self._graphs:
+            if cand.state == "flying" and cand.result() is None:
+                # launched, and its result object was dropped unread: nobody will collect — but its completion word may still be on
+                # its way: wait for the lane, then it is free
+                eng.ctx.synchronize()
+                cand.state = "free"
+            if cand.state == "free" and not cand.rows_out():
+                g = cand
+                break
+        if g is None:
+            if self._deferred_runs < 2 or len(self._graphs) >= eng.plan_graphs:
+                return None
+            g = self._record(epoch)
+            if g is None:
+                return None
+            self._graphs.append(g)
+        g.graph.launch()
+        eng.graph_stats["launched"] += 1
+        g.state = "flying"
+        rs = self._graph_result(g)
+        g.result = weakref.ref(rs)
+        return rs
+
+    def _record(self, epoch):
+        """Run the plan's steps with the lane's stream in capture mode: every launch is recorded, nothing executes.  A step that has
+        to wait for the device refuses (SDQH_ERR_UNSUPPORTED) and the plan is never recorded again."""
+        eng = self.eng
+        ctx = eng.ctx
+        env = {"__defer__": self.defer_names, "__record__": True}
+        at, graph = None, None
+        try:
+            ctx.graph_begin()
+            try:
+                for i, (out, step) in enumerate(self.steps):
+                    env[out] = step(env)
+                    if isinstance(env[out], Pending):
+                        at = i
+                        break
+                if at is None:
+                    raise UnsupportedQuery("the plan's last call was not deferred")
+                graph = ctx.graph_end()
+            except BaseException:
+                ctx.graph_abort()
+                raise
+        except (abi.SdqhError, UnsupportedQuery) as exc:
+            self._graph_refused = str(exc) or "refused"
+            eng.graph_stats["refused"] += 1
+            return None
+        finally:
+            for v in env.values():                               # the handles go; the memory stays with the recording
+                if isinstance(v, BuiltTable):
+                    v.table.free()
+        eng.graph_stats["recorded"] += 1
+        host_env = {k: v for k, v in env.items() if not isinstance(v, BuiltTable)}
+        return PlanGraph(graph, at, env[at_name(self, at)], host_env, env.get("__rows_out__") or (lambda: False), epoch)
+
+    def _graph_result(self, g):
+        pending, out, rest = g.pending, at_name(self, g.at), self.steps[g.at + 1:]
+        plan = self.plan
+
+        def thunk():
+            host_env = dict(g.host_env)
+            try:
+                try:
+                    host_env[out] = pending.resolve()
+                finally:
+                    g.state = "free"                             # collected (or failed): the block's completion word has been seen
+                for name, step in rest:
+                    host_env[name] = step(host_env)
+                res = host_env[plan.result]
+                if isinstance(res, DictResult) and not res.val_fields:
+                    res = ResultSet([n for n, _ in res.key_fields], [a for _, a in res.key_fields])
+                if not isinstance(res, ResultSet):
+                    raise UnsupportedQuery("a deferred plan must end in a result set")
+                return res
+            except (abi.SdqhError, UnsupportedQuery) as exc:
+                if isinstance(exc, abi.SdqhError) and exc.code not in (abi.ERR_OVERFLOW, abi.ERR_UNSUPPORTED):
+                    raise
+                # the data decided against what was recorded (a result that outgrew its block, more groups than the kernel's table):
+                # the recordings go, the plan runs once more with every call waited for and is recorded again when it has settled
+                self.eng.graph_stats["dropped"] += len(self._graphs)
+                self.drop_graphs()
+                self._deferred_runs = 0
+                return self.run(None, deferred=False)
+        rs = DeferredResultSet(thunk)
+        self.eng._outstanding.add(rs)
+        return rs
 
     def _deferred(self, env, at, top, keep_tables=False, on_retry=None, precheck=None, seams=False):
         """The steps after `at` (host-side: they only reshape) and the hand-over, as the thunk of a DeferredResultSet.  The tables of

@@ -1263,6 +1263,51 @@ def lanes_case(lib, sf=0.05, rounds=6, queries=("q1", "q3", "q5", "q6", "q9", "q
         one.close()
 
 
+def plan_graphs_case(lib, sf=0.05, rounds=8, queries=("q1", "q3", "q5", "q6", "q9", "q4", "q14", "q18"), rel=0.0):
+    """Plan graphs (engine.PlanGraph over sdqh_graph_*): a settled plan's device calls recorded once and launched by ONE call from then
+    on.  The same queries on an engine that records (always: also while other results are in flight) against one that issues every
+    call — same rows, round after round: two results of every query in flight at once (two recordings, then the calls), results read
+    late and in reverse, results dropped unread, an option changed in between (the recordings made under the old setting go), the
+    columns forgotten and uploaded again.  Returns the recording engine's counters."""
+    db = tpch.generate(sf, tables=sorted(tpch.columns_for(queries)), columns=tpch.columns_for(queries))
+    calls = eng_mod.Engine(lib.context())
+    graphs = eng_mod.Engine(lib.context())
+    calls.plan_graphs = 0
+    graphs.plan_graphs, graphs.plan_graphs_always = 2, True
+    try:
+        plans = {q: frontend.lower_function(Q.QUERIES[q].__sdql_func__, Q.QUERIES[q].__sdql_in_type__) for q in queries}
+        args = {q: [db[t] for t in Q.QUERY_TABLES[q]] for q in queries}
+
+        def rows_of(r):
+            if hasattr(r, "wait"):
+                r.wait()
+            if hasattr(r, "columns"):
+                return sorted(zip(*[r.column(c).tolist() for c in r.columns]))
+            return r
+        want = {q: rows_of(eng_mod.execute_plan(calls, plans[q], args[q])) for q in queries}
+        for rnd in range(rounds):
+            launched = [(q, eng_mod.execute_plan(graphs, plans[q], args[q])) for q in queries for _ in range(3 if rnd % 2 else 1)]
+            if rnd == 3:
+                del launched[::2]                                            # dropped unread: their recordings are reusable once the lane has been waited for
+            for q, r in reversed(launched):
+                got = rows_of(r)
+                if hasattr(r, "columns"):
+                    assert_rows_match(got, want[q], rel, "plan graphs round %d %s" % (rnd, q))
+                else:
+                    assert got == want[q] or abs(got - want[q]) <= rel * abs(want[q]), (q, got, want[q])
+            del launched
+            if rnd == 4:
+                graphs.ctx.set_option("narrow", 0)                           # other kernels from here on: what was recorded is void
+            if rnd == 5:
+                graphs.ctx.set_option("narrow", 1)
+            if rnd == 6:
+                graphs.clear()
+        return dict(graphs.graph_stats)
+    finally:
+        graphs.close()
+        calls.close()
+
+
 def grouped_index_case(ctx, n=200000, nprobe=500000, seed=17, keep=0.3, per_a=4):
     """A composite-key build (a, b) -> payload over a table stored in the order of a (sdqh_build, nkey 2: the GROUPED layout on the GPU,
     DevTable) with a build filter, duplicate (a, b) pairs (first build row wins), runs of one a that cross wave segments, first parts

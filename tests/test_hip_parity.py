@@ -1275,6 +1275,19 @@ def test_lanes_give_the_rows_one_stream_gives(hip_lib):
 
 
 @pytest.mark.gpu
+def test_plan_graphs_give_the_rows_the_calls_give(hip_lib):
+    """Round 5: a settled plan whose last call is deferred is recorded into a graph (sdqh_graph_begin / _end: HIP stream capture; the
+    memory its calls allocate stays with the recording) and launched by one call from then on.  Same rows as the calls give, with
+    several results of a query in flight, results dropped unread, an option flipped, the columns re-uploaded; plans that wait for
+    the device in the middle (q6's scalar, q9's ... none of the configured ones' LAST loops, but q18's HAVING size read-back) are
+    refused once and keep issuing their calls."""
+    stats = helpers.plan_graphs_case(hip_lib, sf=0.05, rounds=8, rel=REL)
+    assert stats["recorded"] >= 6 and stats["launched"] >= 20, stats
+    big = helpers.plan_graphs_case(hip_lib, sf=1.0, rounds=6, rel=REL, queries=("q1", "q3", "q5", "q9", "q10"))
+    assert big["recorded"] >= 4 and big["launched"] >= 12, big
+
+
+@pytest.mark.gpu
 def test_grouped_layout_for_composite_keys(hip_engine, oracle_engine):
     """Round 4: a composite-key build over a table stored in the order of the key's first part gets the GROUPED layout (one stage row
     per first-part value, written while staging; a lookup walks the run): against numpy inside the helper and against the CPU

@@ -20,7 +20,8 @@ from sdqlpy_amd.sdql_lib import sdqlpy_init
 qs = sys.argv[1].split(",") if len(sys.argv) > 1 else ["q3", "q5"]
 sdqlpy_init(3, 1, device=0)
 db = tpch.generate(10, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs), shard=(0, 1))      # marked as row shards: the partitioned plans run
-runner = sdist.DistributedRunner(engine.default_engine(device=0), 0, 1, partition=os.environ.get("PARTITION", "hash"))
+runner = sdist.DistributedRunner(engine.default_engine(device=0), 0, 1, partition=os.environ.get("PARTITION", "hash"),
+                                 skip_trivial=os.environ.get("TRIVIAL", "0") != "1")
 
 
 def finished(r):
@@ -33,12 +34,20 @@ for q in qs:
     for _ in range(50):
         finished(runner.run(q, db))
     print(q, "mean wall ms", (time.perf_counter() - t0) * 20, flush=True)
+    # one run with events around every launch (waited for: profiling switches the deferred K-F off), in launch order
+    ctx = engine.default_engine(device=0).ctx
+    ctx.set_profiling(2, only=None)
+    finished(runner.run(q, db))
+    ctx.synchronize()
+    launches = ctx.profile()
+    ctx.set_profiling(0)
+    print(q, "launches:", " | ".join("%s %.4f" % (n, ms) for n, ms in launches), "| sum %.4f ms in %d launches" % (sum(ms for _, ms in launches), len(launches)), flush=True)
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(50):
         finished(runner.run(q, db))
     pr.disable()
-    pstats.Stats(pr).sort_stats("tottime").print_stats(16)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(28)
 runner.close()
 torch.cuda.synchronize()
 dist.destroy_process_group()

@@ -655,6 +655,18 @@ def reference_width_leg(args, eng, db, rows, ran, run_query, run_steps, finish):
                    "frac": round(ab_dom / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             if b:
                 rec["dominant_model_bytes_per_launch"] = b // cnt
+            # counter evidence for this leg: HBM bytes of the dominant kernel's launch and of the query's run from the committed PMC passes over
+            # THIS configuration (tools/collect_profiles.sh: run_queries.py --reference-width) — the algorithmic bytes are a claim, these are counted
+            t_dom, t_src = pmc_traffic(q, dom, rows, which="pmc_traffic_reference_width")
+            t_run, _ = pmc_traffic(q, None, rows, ran=set(stat), which="pmc_traffic_reference_width")
+            if t_dom:
+                rec["dominant_traffic"] = t_dom
+                rec["dominant_traffic_over_algorithmic"] = round(t_dom / ab_dom, 4)
+                rec["dominant_physical_frac"] = round(t_dom / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                rec["traffic_source"] = t_src
+            if t_run:
+                rec["traffic"] = t_run
+                rec["traffic_over_algorithmic"] = round(t_run / ab_q, 4)
             out["queries"][q] = rec
     finally:
         eng.ctx.set_option("narrow", 1)
@@ -663,14 +675,14 @@ def reference_width_leg(args, eng, db, rows, ran, run_query, run_steps, finish):
     return out
 
 
-def pmc_traffic(q, kernel, rows, ran=None):
+def pmc_traffic(q, kernel, rows, ran=None, which="pmc_traffic"):
     """(HBM bytes, source tag) from the committed rocprofv3 PMC summary profiles/rNN_pmc_traffic.json
     (tools/pmc_per_query.py: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes per query;
     bytes = 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950): with `kernel`,
     bytes per launch of that kernel inside query `q`; without, bytes of one whole run of `q`.  The
     numbers are constants of that committed run, valid only for the same row counts; else (None, None)."""
     import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s.json" % which)))      # (which = "pmc_traffic_reference_width": the passes over the reference-width leg)
     if not found:
         return None, None
     path = found[-1]                                      # the latest round's collection

@@ -138,6 +138,10 @@ class Engine:
         # The value = recordings a plan may hold (each owns its tables' memory and a result block; a recording is reused when its last
         # result has been collected and dropped); 0 = off.
         self.plan_graphs = int(os.environ.get("SDQLPY_AMD_PLAN_GRAPHS", "2")) if ctx.library.backend_name() == "hip-gfx950" else 0
+        # sums over result dictionaries that ran on the HOST (xplan.run_host_dict): {(source line, result name): {"runs", "why"}}; with
+        # strict_device such a loop raises UnsupportedQuery instead (tests run the shipped queries that way to say which ones take it)
+        self.host_loops = {}
+        self.strict_device = os.environ.get("SDQLPY_AMD_STRICT_DEVICE", "0") == "1"
         self.plan_graphs_always = os.environ.get("SDQLPY_AMD_PLAN_GRAPHS_ALWAYS", "0") == "1"      # (default: only while no other result is in flight, see PreparedPlan.run)
         self.graph_stats = {"recorded": 0, "launched": 0, "refused": 0, "dropped": 0}
         lanes = os.environ.get("SDQLPY_AMD_LANES", "")
@@ -160,6 +164,12 @@ class Engine:
         k = self._lane_next % max(1, self.nlanes)
         self._lane_next += 1
         return k
+
+    def stats(self):
+        """What the engine did besides launching kernels: loops that ran on the host (and why), plan graphs recorded / launched /
+        refused, resident bytes."""
+        return {"host_loops": [{"line": k[0], "result": k[1], "runs": v["runs"], "why": v["why"]} for k, v in sorted(self.host_loops.items(), key=lambda kv: str(kv[0]))],
+                "plan_graphs": dict(self.graph_stats), "resident_bytes": int(self.resident_bytes), "lanes": int(self.nlanes)}
 
     def synchronize(self):
         """Everything launched through this engine, on whichever lane, has run."""
@@ -1708,6 +1718,7 @@ def _prepare_dict_loop(eng, op, is_result, as_table):
             pass
 
     def run(env):
+        why = "no device loop for this sum over a result dictionary"
         if state["dev"] is not None:
             try:
                 out = state["dev"](env)
@@ -1715,8 +1726,20 @@ def _prepare_dict_loop(eng, op, is_result, as_table):
                     return _record_set(eng, op, out, env)
                 if out is not NotImplemented:
                     return out
-            except UnsupportedQuery:                                # known once the source's layout is: the host path from now on
+                why = "the device loop declined this run's source (a handful of host groups)"
+            except UnsupportedQuery as exc:                         # known once the source's layout is: the host path from now on
                 state["dev"] = None
+                why = state["why"] = str(exc)
+        else:
+            why = state.get("why", why)
+        # The loop runs on the HOST over the materialised dictionaries (O(groups), like the reference's serial K-F,
+        # generator_par.py:520-568) — never silently: counted per plan step (Engine.stats()), refused under Engine.strict_device.
+        root = getattr(eng, "_eng", eng)
+        rec = root.host_loops.setdefault((getattr(op, "lineno", 0), op.out), {"runs": 0, "why": why})
+        rec["runs"] += 1
+        if getattr(root, "strict_device", False):
+            raise UnsupportedQuery("line %d: the sum over the result dictionary '%s' would run on the host (%s) and the engine is strict (SDQLPY_AMD_STRICT_DEVICE)"
+                                   % (getattr(op, "lineno", 0), getattr(op, "source", op.out), why))
         return _host_dict(eng, op, env, is_result)
     return run
 

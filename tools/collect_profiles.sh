@@ -23,8 +23,15 @@ for q in q1 q3 q5 q6 q9; do
     rocprofv3 --pmc $c --output-format csv -d $OUT/pmc/${q}_$c -- python3 tools/run_queries.py --sf 10 --queries $q --iters $ITERS > $OUT/pmc_${q}_$c.log 2>&1
   done
 done
+# the reference-width leg (bench.py `reference_width`: 8-byte columns, fixed-shape kernels): what its kernels really move
+for q in q1 q3 q6; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_refwidth/${q}_$c -- python3 tools/run_queries.py --sf 10 --queries $q --iters $ITERS --reference-width > $OUT/pmc_refwidth_${q}_$c.log 2>&1
+  done
+done
 ROWS=$(python3 -c "import json;print(json.dumps(json.load(open('$OUT/bench_for_rows.json'))['config']['rows_per_gpu']))")
 python3 tools/pmc_per_query.py $OUT/pmc $ITERS "$ROWS" $OUT/pmc_traffic.json > $OUT/pmc_traffic_summary.txt 2>&1
+python3 tools/pmc_per_query.py $OUT/pmc_refwidth $ITERS "$ROWS" $OUT/pmc_traffic_reference_width.json > $OUT/pmc_traffic_reference_width_summary.txt 2>&1
 bash tools/collect_query_traces.sh $R "$ROWS"
 # drop the bulky raw traces, keep the summaries
 find $OUT -name "*.csv" -size +2M -delete

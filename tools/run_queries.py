@@ -14,12 +14,18 @@ def main():
     ap.add_argument("--sf", type=float, default=10.0)
     ap.add_argument("--queries", default="q1,q3")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--reference-width", action="store_true", help="the columns in the reference's own 8-byte form (no 4-byte twins, no dictionary codes of numeric "
+                    "columns), the loops on the fixed-shape kernels: bench.py's `reference_width` leg, for the counter passes that price it")
     args = ap.parse_args()
     qs = args.queries.split(",")
-    from sdqlpy_amd import tpch
+    from sdqlpy_amd import engine, tpch
     from sdqlpy_amd import tpch_queries as Q
     from sdqlpy_amd.sdql_lib import sdqlpy_init
     sdqlpy_init(3, 1, device=0)
+    if args.reference_width:
+        eng = engine.default_engine(device=0)
+        eng.ctx.set_option("narrow", 0)
+        eng.stream_programs, eng.program_routes = False, set()
     db = tpch.generate(args.sf, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
     for _ in range(args.iters):
         for q in qs:

@@ -88,6 +88,43 @@ def test_reference_text_lowering_record():
         assert rec["shipped_plan_digests"][name] == fp, "re-run tests/golden/make_lowering_fixture.py (%s changed)" % name
 
 
+def test_own_formulations_with_the_plans_the_reference_text_lowers_to(oracle_lib):
+    """tests/reference_shapes.py: for every query whose shipped formulation lowers to OTHER loops than the reference's text does, an own
+    formulation whose name-free plan has the digest recorded for the reference's text (the text itself never travels; the digest was
+    made from it in the build container) — so what a reference user's q2 / q7 / q8 / q11 / q12 / q16 / q19 / q20 launches can be run on
+    the GPU (tests/test_hip_parity.py).  Here: the digests agree, q1's plans agree whatever the K-F spelling, every query with another
+    plan than the shipped one is covered, and the CPU implementation gives the reference's golden results for these plans too."""
+    import hashlib
+    import helpers
+    import reference_shapes as shapes
+    from sdqlpy_amd import engine
+    with open(os.path.join(HERE, "golden", "reference_lowering.json")) as fh:
+        rec = json.load(fh)
+    other_plan = {q for q, r in rec["queries"].items() if r.get("lowers") and r.get("same_plan_as_shipped_formulation") is False}
+    assert other_plan - {"q15"} == set(shapes.QUERIES), sorted(other_plan)        # (q15: the reference's typed-in constant, DESIGN.md 4)
+    assert rec["queries"]["q1"]["same_plan_as_shipped_formulation"] is True        # concat / explicit record: one K-F
+    for q, fn in shapes.QUERIES.items():
+        fp = hashlib.sha1(frontend.lower_function(fn).fingerprint().encode()).hexdigest()[:16]
+        assert fp == rec["queries"][q]["plan_digest"], q
+        assert fp != rec["shipped_plan_digests"][q], q
+    eng = engine.Engine(oracle_lib.context(threads=1))
+    try:
+        with open(os.path.join(HERE, "golden", "tpch_golden_wide.json")) as fh:
+            gold = json.load(fh)
+        n = 0
+        for case in gold["cases"]:
+            db = helpers.case_db(case)
+            for q, fn in shapes.QUERIES.items():
+                if q in case["results"]:
+                    res = engine.execute_plan(eng, frontend.lower_function(fn), [db[t] for t in shapes.TABLES[q]])
+                    helpers.check_against_golden(res, case["results"][q], 0.0, "reference shape/%s/%s" % (case["name"], q))
+                    n += 1
+            eng.clear()
+        assert n >= 3 * len(shapes.QUERIES) - 3
+    finally:
+        eng.close()
+
+
 def test_merging_equal_keys_of_large_results_on_codes_and_buckets():
     """engine._merge_equal_keys on results of more than 4096 rows: dictionary-coded text is grouped on its codes
     (result.Dictionary: equal code <=> equal text), other text is factorised, and both the bucketed form (a small

@@ -380,6 +380,50 @@ def test_open_vocabulary_queries_against_the_reference(hip_engine, golden_wide, 
     oracle_engine.clear()
 
 
+def test_plans_the_reference_text_lowers_to(hip_engine, golden_wide, oracle_engine):
+    """Round 5: the loops a user of the REFERENCE's script launches.  For q2, q7, q8, q11, q12, q16, q19, q20 the reference's own text
+    lowers to other loops than the shipped formulation (other build order, payloads carried as records, another table as the probed
+    index); its text never travels, so tests/reference_shapes.py restates those plans in this package's spelling — the CPU suite
+    pins their plan digests to the ones recorded for the reference's text (tests/test_frontend_cpu.py) — and here they run on the GPU:
+    against the reference's golden results, at SF 1 against the CPU implementation, and timed beside the shipped formulation at SF 1
+    (printed; the figures at SF=10 are in profiles/)."""
+    import time
+    import reference_shapes as shapes
+    plans = {q: frontend.lower_function(fn) for q, fn in shapes.QUERIES.items()}
+    n = 0
+    for case in golden_wide["cases"]:
+        db = helpers.case_db(case)
+        for q, plan in plans.items():
+            if q in case["results"]:
+                for again in range(2):                              # the second run takes the prepared, cached paths
+                    res = engine.execute_plan(hip_engine, plan, [db[t] for t in shapes.TABLES[q]])
+                    helpers.check_against_golden(res, case["results"][q], REL, "reference shape/%s/%s" % (case["name"], q))
+                n += 1
+        hip_engine.clear()
+    assert n >= 3 * len(plans) - 3
+    qs = tuple(sorted(plans))
+    db = tpch.generate(1.0, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+    for q in qs:
+        args = [db[t] for t in shapes.TABLES[q]]
+        got = engine.execute_plan(hip_engine, plans[q], args)
+        want = engine.execute_plan(oracle_engine, plans[q], args)
+        assert want.size() > 0, q
+        helpers.assert_rows_match(helpers.result_rows(got, want.columns), helpers.result_rows(want, want.columns), REL, "reference shape sf1/" + q)
+        shipped = helpers.run_query(hip_engine, q, db)
+        helpers.assert_rows_match(helpers.result_rows(shipped, want.columns), helpers.result_rows(want, want.columns), REL, "shipped sf1/" + q)
+        times = {}
+        for label, run in (("reference shape", lambda: engine.execute_plan(hip_engine, plans[q], args)), ("shipped", lambda: helpers.run_query(hip_engine, q, db))):
+            for _ in range(3):
+                r = run(); r.wait() if hasattr(r, "wait") else None
+            t0 = time.perf_counter()
+            for _ in range(10):
+                r = run(); r.wait() if hasattr(r, "wait") else None
+            times[label] = (time.perf_counter() - t0) * 100
+        print("%s at SF=1: reference-shaped plan %.3f ms, shipped formulation %.3f ms" % (q, times["reference shape"], times["shipped"]))
+    hip_engine.clear()
+    oracle_engine.clear()
+
+
 def test_sums_over_result_dictionaries_run_as_device_loops(hip_engine, golden_wide, oracle_engine):
     """frontend.HostDictOp on the device (xplan.prepare_dict_scan: the entries of a table as resident columns — sdqh_table_columns
     hands out the table's own K-F buffers — packed keys unpacked with DIVI / MODI): q16, q15 (with and without ORDER BY / LIMIT

@@ -23,6 +23,7 @@ def main():
     from sdqlpy_amd.sdql_lib import sdqlpy_init
     sdqlpy_init(3, 1, device=0)
     eng = engine.default_engine(device=0)
+    eng.plan_graphs = 0                                  # per-launch timings need the calls issued one by one (a recorded plan has no place for events)
     db = tpch.generate(args.sf, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
     rows = {t: len(db[t].getContainer()["data"][0]) for t in db}
     print("rows", rows)

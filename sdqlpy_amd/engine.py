@@ -1689,7 +1689,7 @@ def _compared_lookups(plan):
             walk(e.key if isinstance(e, Lookup) else e.lookup.key)
 
     for op in plan.ops:
-        if isinstance(op, ScanOp):
+        if isinstance(op, (ScanOp, HostDictOp)):                  # (a sum over a result dictionary compares looked-up text too: the reference's own q12)
             for e in list(op.conds) + [op.key, op.val]:
                 if e is not None:
                     walk(e)

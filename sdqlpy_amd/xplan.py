@@ -53,6 +53,7 @@ class Compiler:
         self.P = abi.Program()
         self.memo = {}
         self.lookups = {}           # repr(Lookup) -> (operation index, dict name, BuiltTable)
+        self.agg_view = {}          # repr(Lookup) -> the name means the aggregation folded into the table, not the build itself (see lookup)
         self.scalars = []           # (CONST operation index, ScalarField): rebound on every run
         self.layout = []            # what the program assumed about the tables it reads: [(dict name, signature)]
         self.entry_cols = []        # (COL operation index, which column of the scanned dictionary's entries): rebound on every run (DictTable)
@@ -115,11 +116,18 @@ class Compiler:
         if key in self.lookups:
             return self.lookups[key]
         bt = self.env.get(lk.dict_name)
+        # WHICH dictionary the name means.  A probe-aggregate folds its groups into the entries of the table it probes, so two
+        # dictionaries of a plan can be one device table: the build itself (key -> payload fields) and the aggregation over it
+        # (key -> sums: env holds ("aggregated", table name) for that one).  A lookup by the BUILD's name reads payload fields and
+        # finds every entry; a lookup by the AGGREGATION's name reads the sums and finds the entries that received a row.
+        aggregated = False
         if not hasattr(bt, "table"):
             if isinstance(bt, tuple) and bt and bt[0] == "aggregated":
                 bt = self.env[bt[1]]
+                aggregated = True
             else:
                 self.fail("'%s' is not a table a loop can look up" % lk.dict_name)
+        self.agg_view[key] = aggregated
         parts = [x for _, x in lk.key.fields] if isinstance(lk.key, RecordCons) else [lk.key]
         if getattr(bt, "key_radix", None) is not None:
             self.fail("'%s' is keyed by more than two fields: it cannot be looked up" % lk.dict_name)
@@ -137,7 +145,7 @@ class Compiler:
         keeps hits >= 1): an entry of its table that no row reached — a build row nothing matched, a key of a dense domain no row
         carried — is not in it."""
         oid, _, bt, _ = self.lookup(lk)
-        if bt.agg is None:
+        if bt.agg is None or not self.agg_view[repr(lk)]:
             return oid
         key = ("live", oid)
         if key not in self.memo:
@@ -147,7 +155,7 @@ class Compiler:
 
     def field(self, lk, fname):
         oid, name, bt, keyvals = self.lookup(lk)
-        if bt.agg is not None:                                      # an aggregated dictionary: its values are the entries' accumulators
+        if bt.agg is not None and self.agg_view[repr(lk)]:          # an aggregated dictionary: its values are the entries' accumulators
             _, vnames, count_idx, _, val_is_record, nv = bt.agg
             if fname is None:
                 if val_is_record and len(vnames) != 1:

@@ -125,6 +125,35 @@ def test_own_formulations_with_the_plans_the_reference_text_lowers_to(oracle_lib
         eng.close()
 
 
+def test_device_loops_over_result_dictionaries_against_their_host_evaluation(oracle_lib):
+    """Sums over RESULT dictionaries (q2, q11, q15, q16) run as device loops where they have a shape (xplan.prepare_dict_scan) and on
+    the host over the materialised dictionaries otherwise — two evaluations of one plan that must agree at a size where the device
+    loops really run (at the goldens' sizes most sources come back as a handful of host groups).  Round 5 found them disagreeing
+    for q2 at SF=1 on BOTH implementations, so no parity test saw it: a probe-aggregate folds its groups into the table it probes,
+    the build (part -> p_mfgr) and the aggregation over it (part -> summed cost) were then one device table, and a lookup by the
+    build's name read the aggregation's sum (xplan.Compiler.lookup: agg_view)."""
+    import helpers
+    from sdqlpy_amd import engine, tpch
+    qs = ("q2", "q11", "q15", "q16")
+    db = tpch.generate(1.0, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs), threads=4)
+    eng = engine.Engine(oracle_lib.context(threads=4))
+    try:
+        for q in qs:
+            eng.dict_programs = True
+            eng.host_loops.clear()
+            dev = helpers.run_query(eng, q, db)
+            ran_on_device = not eng.stats()["host_loops"]
+            eng.clear()
+            eng.dict_programs = False
+            host = helpers.run_query(eng, q, db)
+            eng.clear()
+            assert dev.size() == host.size() > 0 or q == "q11", (q, dev.size(), host.size())
+            helpers.assert_rows_match(helpers.result_rows(dev, host.columns), helpers.result_rows(host, host.columns), 1e-12, "device loop vs host / " + q)
+            assert ran_on_device, (q, eng.stats()["host_loops"])
+    finally:
+        eng.close()
+
+
 def test_merging_equal_keys_of_large_results_on_codes_and_buckets():
     """engine._merge_equal_keys on results of more than 4096 rows: dictionary-coded text is grouped on its codes
     (result.Dictionary: equal code <=> equal text), other text is factorised, and both the bucketed form (a small

@@ -355,6 +355,7 @@ def main(argv=None, hooks=None):
     # the same steps with every query's result finished before the next query starts: per-query wall times, and the step as a caller
     # who reads each result at once sees it; then evented (in that region a kernel has the chip to itself — in the overlapped steps the
     # queries' kernels share it, lane by lane, and a kernel's duration there is not a statement about the kernel)
+    run_steps(max(args.warmup, 3), "-", each_waited_for=True)      # (untimed: a query that is waited for alone is launched as a recorded plan — recorded here, not in the timed steps)
     elapsed_waited, per_query_ms, _ = run_steps(args.steps, "-", each_waited_for=True)
     _, _, waited_log = run_steps(args.steps, dom_kernel, each_waited_for=True)
     q1_log = None
@@ -371,7 +372,7 @@ def main(argv=None, hooks=None):
             assert runner.collectives.get("all_to_all", [0])[0] > 0 or runner.last_partitioning == "range" or (world == 1 and runner.skip_trivial), "no all-to-all ran in the timed step"
             if args.partition == "hash":
                 assert runner.exchanged_rows.get("probe_sent", 0) > 0, runner.exchanged_rows
-    nlanes = int(getattr(eng, "nlanes", 1)) if not use_dist else 1
+    nlanes = int(getattr(eng, "nlanes", 1))
     shared_launches = [ms for q, name, ms, _ in timed_log if q == dom_q and name == dom_kernel]
     alone_launches = [ms for q, name, ms, _ in waited_log if q == dom_q and name == dom_kernel]
     # one lane: the queries of a step run one behind the other on one stream, and the first region's launches are as alone as the second's
@@ -410,6 +411,7 @@ def main(argv=None, hooks=None):
             first_run_ms[q] = round((time.perf_counter() - tq) * 1e3, 2)
             for _ in range(args.warmup):
                 run_query(q)
+        run_steps(3, "-", extra, each_waited_for=True)       # (untimed: plans settle / are recorded here)
         took_x, extra_ms, _ = run_steps(extra_steps, "-", extra, each_waited_for=True)
         _, _, extra_log = run_steps(extra_steps, None, extra, each_waited_for=True)
     # the timed region is args.steps steps (the driver fixes 20: 15 ms); the same step for ~1 s of back-to-back work, outside `value`:
@@ -559,6 +561,7 @@ def main(argv=None, hooks=None):
             # the boundary hands over host buffers: the PCIe-inclusive first pass (never the reported value)
             "first_pass_upload": {"bytes": uploaded_bytes, "GBs_including_plan_lowering": round(uploaded_bytes / first_pass_s / 1e9, 2) if first_pass_s > 0 else None},
         }
+        out["engine_stats"] = eng.stats() if hasattr(eng, "stats") else None      # loops that ran on the host (none in the configured queries), plan graphs, resident bytes
         if steady is not None:
             out["steady_state"] = steady
         if reference_width is not None:

@@ -322,7 +322,8 @@ int sdqh_table_compact_async(sdqh_ctx* ctx, const sdqh_table* table, int64_t min
 /* K-F with NOTHING waited for: as sdqh_table_compact_async, but the row count arrives behind the call too — *out_n, which must
  * lie in the same sdqh_host_alloc block, is -1 until the kernels have run; every array is copied out at its full `capacity`.
  * After sdqh_result_wait (or sdqh_synchronize): *out_n rows are valid; *out_n > capacity means the rows beyond were dropped
- * (fetch again with the capacity it names).  SDQH_ERR_UNSUPPORTED for any other layout or with "async_result" = 0. */
+ * (fetch again with the capacity it names).  SDQH_ERR_UNSUPPORTED for any other layout or with "async_result" = 0.  Value slots the
+ * aggregated tuple does not use are NOT written: a caller that reads them zeroes its block once, when it allocates it (abi.py does). */
 int sdqh_table_compact_deferred(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, int64_t capacity,
                                 int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n);
 /* out_n is TWO cells there: out_n[1] is the result's DONE word — the copy stream writes 1 into it behind the copies (2 at once if it

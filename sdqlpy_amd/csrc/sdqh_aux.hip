@@ -62,15 +62,26 @@ __global__ __launch_bounds__(TPB) void k_stage_part_pack(DevStage st, DevPartiti
     uint32_t counts[PP_SEGS];
 #pragma unroll
     for (int j = 0; j < PP_SEGS; ++j) counts[j] = seg0 + j < st.nseg ? st.seg_count[seg0 + j] : 0u;
-    for (int pass = 0; pass < 2; ++pass) {
+    uint32_t most = 0;
 #pragma unroll
-        for (int j = 0; j < PP_SEGS; ++j) {
-            const int64_t base = (int64_t)(seg0 + j) * st.seg_rows;
-            const uint32_t count = counts[j];
-            for (uint32_t i0 = (uint32_t)wave * WAVE; i0 < count; i0 += TPB) {
-                const bool live = i0 + lane < count;
-                const int64_t row = base + i0 + lane;
-                const int64_t key = live ? st.key[row] : 0;
+    for (int j = 0; j < PP_SEGS; ++j) most = counts[j] > most ? counts[j] : most;
+    for (int pass = 0; pass < 2; ++pass) {
+        // round r: this wave's 64-row batch r of EVERY segment — the four key loads of a round are requested together (a round is one
+        // memory round trip, not four: the kernel is a chain of round trips, a stage segment holds a few hundred live rows)
+        for (uint32_t i0 = (uint32_t)wave * WAVE; i0 < most; i0 += TPB) {
+            int64_t keys[PP_SEGS];
+            bool lives[PP_SEGS];
+#pragma unroll
+            for (int j = 0; j < PP_SEGS; ++j) {
+                lives[j] = i0 + lane < counts[j];
+                keys[j] = lives[j] ? st.key[(int64_t)(seg0 + j) * st.seg_rows + i0 + lane] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < PP_SEGS; ++j) {
+                if (i0 >= counts[j]) continue;                            // (wave-uniform)
+                const bool live = lives[j];
+                const int64_t row = (int64_t)(seg0 + j) * st.seg_rows + i0 + lane;
+                const int64_t key = keys[j];
                 const int part = live ? part_of(pt, key) : -1;
                 unsigned long long todo = __ballot(live);
                 unsigned int place = 0;
@@ -245,7 +256,8 @@ int sdqh_table_compact_deferred(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t
         HIP_TRYA(ctx, hipEventRecord(ctx->rs_copied[b], side));
         ctx->rs_used[b] = true; ctx->rs_pending = true; ctx->rs_cur = b ^ 1;
     }
-    if (out_values) for (int k = nval; k < SDQH_TUPLE_MAX_VALUES; ++k) std::memset(out_values + (size_t)k * (size_t)capacity, 0, cb);
+    // (value slots the tuple does not use are not written: the binding zeroes a block once, when it allocates it, and nothing on the
+    //  device ever touches those slots — three capacity-sized host memsets per call were 40 us of a 60 us call on the launch path of every join query)
     return SDQH_OK;
 }
 

@@ -259,7 +259,8 @@ bool op_interval(sdqh_ctx* ctx, const XInfo& x, int k, int64_t* lo, int64_t* hi)
         case SDQH_X_COL: {
             sdqh_column* c = const_cast<sdqh_column*>(o.col);
             if (x.fake) { if (c->dtype != SDQH_I64) return false; *lo = 0; *hi = 3; return true; }
-            if (c->dtype != SDQH_I64 || c->nrows < 1 || c->transient) return false;
+            // (a transient column — rows that live for one run — gets no minimum / maximum pass; bounds it was TOLD, sdqh_column_set_bounds, count)
+            if (c->dtype != SDQH_I64 || c->nrows < 1 || (c->transient && !c->have_minmax)) return false;
             if (c->code_state == 1 && !c->dict_host.empty()) { *lo = c->dict_host.front(); *hi = c->dict_host.back(); return true; }
             if (column_minmax(ctx, c)) return false;
             *lo = c->mn; *hi = c->mx; return true;
@@ -1174,8 +1175,19 @@ Geometry geometry_tight(sdqh_ctx* ctx, int64_t nrows, int resident, bool pipelin
     const int64_t steps = std::max<int64_t>(1, nrows / ((int64_t)XT_ROWS * (pipelined ? 1 : 2)));
     return Geometry{(unsigned)std::min<int64_t>(steps, (int64_t)ctx->num_cu * resident), 0, 0};
 }
-Geometry geometry(sdqh_ctx* ctx, int64_t nrows, bool direct, int waves_per_cu, bool tight = false) {
+// tiled: the sink does not care in which order the rows reach it (sums into groups / entries, key bits) — the tight queue skeleton then
+// walks the rows in interleaved 1024-row double steps (x_queue8: seg_rows == 0) instead of one contiguous segment per wave
+Geometry geometry(sdqh_ctx* ctx, int64_t nrows, bool direct, int waves_per_cu, bool tight = false, bool tiled = false) {
     Geometry g{1, 0, 0};
+    static const bool no_tiles = getenv("SDQLPY_AMD_X_NOTILED") != nullptr;
+    if (tiled && tight && !direct && !no_tiles && nrows < ((int64_t)1 << 31) && nrows >= (int64_t)X8_STEP * X8_U) {
+        if (ctx->opt_x_waves > 0) waves_per_cu = ctx->opt_x_waves;
+        const int64_t steps = nrows / ((int64_t)X8_STEP * X8_U);
+        g.seg_rows = 0;
+        g.nseg = (int)std::max<int64_t>(1, std::min<int64_t>(steps, (int64_t)ctx->num_cu * waves_per_cu));
+        g.grid = (unsigned)((g.nseg + TPB / WAVE - 1) / (TPB / WAVE));
+        return g;
+    }
     if (direct) {
         const int64_t tiles = ((nrows + TILE_ROWS - 1) / TILE_ROWS + SDQH_TILE_CHUNK - 1) / SDQH_TILE_CHUNK;
         g.grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)ctx->num_cu * ctx->opt_resident_stream));
@@ -1268,7 +1280,7 @@ int sdqh_xscan_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, doubl
     rd_dirty(ctx);
     int32_t* d_flags = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->result_dev) + 1024);
     if (int rc = fill_xargs(ctx, x, &a, d_flags, 1, 0)) return rc;
-    const Geometry g = (x.tight && x.direct) ? geometry_tight(ctx, nrows, 2) : geometry(ctx, nrows, x.direct, 16, x.tight);
+    const Geometry g = (x.tight && x.direct) ? geometry_tight(ctx, nrows, 2) : geometry(ctx, nrows, x.direct, 16, x.tight, true);
     double* partial = static_cast<double*>(pool_alloc(ctx, (size_t)g.grid * 5 * sizeof(double)));
     if (!partial) return fail(ctx, SDQH_ERR_NOMEM, "xscan_sum: out of device memory");
     XSum<1>::Args sa{partial};
@@ -1307,7 +1319,7 @@ static int xgroupby_launch(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* pro
     }
     // (the per-lane sink's grid is the same with and without the encodings: partial sums are folded in workgroup order, and switching
     //  the twins off must not change a bit of a sum — tests/test_hip_parity.py)
-    const Geometry g = (x.tight && x.direct) ? geometry_tight(ctx, nrows, sink == SINK_GROUP_LANE ? ctx->opt_lane_resident : 2, sink == SINK_GROUP_LANE) : geometry(ctx, nrows, x.direct, 16, x.tight);
+    const Geometry g = (x.tight && x.direct) ? geometry_tight(ctx, nrows, sink == SINK_GROUP_LANE ? ctx->opt_lane_resident : 2, sink == SINK_GROUP_LANE) : geometry(ctx, nrows, x.direct, 16, x.tight, true);
     if (sink == SINK_GROUP_LANE && !ctx->compile_only && ctx->opt_lane_int) {
         // a summed value that is a small integer on every row — the value of a byte-coded column whose dictionary is consecutive
         // non-negative integers (l_quantity: 1.0 ... 50.0) — is summed as an integer beside the row count (XGroupLane); its lane sums
@@ -1444,9 +1456,15 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
     if (!ctx || nrows < 0 || !out) return fail(ctx, SDQH_ERR_INVALID, "xbuild: bad arguments");
     if (nrows >= 0xFFFFFFFEll) return fail(ctx, SDQH_ERR_UNSUPPORTED, "xbuild: build side limited to 2^32-2 rows per GPU");
     if (!ctx->compile_only) (void)hipSetDevice(ctx->device);
+    static const bool phase_times = getenv("SDQLPY_AMD_XBUILD_TIMES") != nullptr;      // (host time per phase of this call, to stderr: tuning aid)
+    auto t_now = [] { return std::chrono::steady_clock::now(); };
+    auto t0 = t_now();
+    auto lap = [&](const char* what) { if (phase_times) { auto t1 = t_now(); fprintf(stderr, "xbuild %-12s %6.1f us\n", what, std::chrono::duration<double, std::micro>(t1 - t0).count()); t0 = t1; } };
     XInfo x;
     if (int rc = analyse(ctx, nrows, prog, SDQH_MAX_PAYLOAD, true, false, &x)) return rc;
+    lap("analyse");
     vstage_plan(ctx, nrows, &x);
+    lap("vstage_plan");
     hipFunction_t fn;
     if (int rc = kernel_for(ctx, x, SINK_STAGE, false, &fn)) {
         if (!ctx->compile_only || ctx->err.find("kernel specialised") == std::string::npos) return rc;
@@ -1472,7 +1490,9 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
         const int64_t per = (int64_t)128 * stage_batch;
         stage_batch = (int)std::min<int64_t>(1 << 20, std::max<int64_t>(1, (seg + per - 1) / per) * stage_batch);
     }
+    lap("kernel_for");
     int rc = stage_setup_computed(ctx, tb, nrows, prog->nvals, stage_batch);
+    lap("stage_setup");
 
     uint64_t capmax = 1024;
     while (capmax < 2 * (uint64_t)std::max<int64_t>(nrows, 1)) capmax <<= 1;
@@ -1504,9 +1524,12 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
             if (!tb->stage.wrow || !tb->stage.seg_first || !tb->wexc) { tb->stage.wrow = nullptr; tb->stage.seg_first = nullptr; tb->wexc = nullptr; }
         }
         if (!tb->stage.wrow) { void* rp[2]; size_t rb[2]; const int nr = prefill_direct_refs(ctx, tb, rp, rb); for (int i = 0; i < nr; ++i) { ptr[n] = rp[i]; bytes[n] = rb[i]; byte[n++] = 0xFF; } }
+        lap("allocs");
         fill_regions(ctx, ptr, bytes, byte, n);
+        lap("fill");
         XArgs a;
         rc = fill_xargs(ctx, x, &a, flags, bounded ? key_lo : 1, bounded ? key_hi : 0);
+        lap("fill_xargs");
         if (!rc) {
             // the segments were cut by stage_setup_computed: the kernel's geometry must be the stage's
             Geometry g{(unsigned)((tb->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE)), tb->stage.seg_rows, tb->stage.nseg};
@@ -1514,6 +1537,7 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
             ctx->next_model_bytes = model_stream_bytes(x, nrows, x.vstage);
             rc = launch(ctx, fn, x.vstage ? VSTAGE_ENTRY : launch_label(SINK_STAGE, false, x.tight), a, sa, nrows, g);
         }
+        lap("launch");
         call_end(ctx);
         int f = 0;
         // Can the kernel raise a flag at all (a key outside the bounds, a key part that does not pack)?  Not when the key's own
@@ -1529,7 +1553,9 @@ int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t 
                                                                       : op_interval(ctx, x, prog->key, &lo, &hi) && lo >= key_lo && hi <= key_hi);
             if (packs && inside) can_fail = false;
         }
+        lap("interval");
         if (!rc && can_fail) rc = read_flags(ctx, flags, &f);
+        lap("flags");
         if (!rc && (f & 2)) rc = fail(ctx, SDQH_ERR_UNSUPPORTED, "xbuild: a key outside the given bounds / a key part outside [0, 2^32)");
     }
     if (rc) { tb_release(ctx, tb); delete tb; return rc; }
@@ -1636,7 +1662,7 @@ int sdqh_xprobe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog
     // clean stays clean — Q5's xgroupby after Q3's probe-aggregate needed a fill launch for it)
     int32_t* d_flags = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->result_dev) + RESULT_BYTES - 64);
     if (int rc = fill_xargs(ctx, x, &a, d_flags, 1, 0)) return rc;
-    const Geometry g = geometry(ctx, nrows, false, 24, x.tight);
+    const Geometry g = geometry(ctx, nrows, false, 24, x.tight, true);
     XEntry<1>::Args sa{table->dev};
     ctx->next_model_bytes = model_stream_bytes(x, nrows, false);
     int rc = launch(ctx, fn, launch_label(SINK_ENTRY, false, x.tight), a, sa, nrows, g);

@@ -795,8 +795,18 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
     int32_t* q_row = s_row[threadIdx.x / WAVE];
     uint32_t* s_str = s_text[P::NSC > 0 ? threadIdx.x / WAVE : 0];
     const int lane = lane_id();
-    const int64_t begin = (int64_t)seg * seg_rows;                     // (a segment is far shorter than 2^31 rows: the host checks)
-    int64_t end = begin + seg_rows; if (end > nrows) end = nrows;
+    // TILED walk (seg_rows == 0: the host asks for it for order-free sinks only): wave `seg` of `nseg` takes the 1024-row double steps
+    // seg, seg + nseg, seg + 2 nseg ... — at any moment the chip's waves read NEIGHBOURING kilobytes, as the register skeletons' tile
+    // walk does, instead of nseg separate streams that each advance through a slice of their own (Q5's final loop streams ONE 4-byte
+    // column: 3.7 TB/s segment by segment).  Queue entries are then row numbers (begin = 0: the host checks nrows < 2^31); the rows
+    // behind the last whole double step are wave 0's, walked in a second phase by the same loop.
+    constexpr int64_t STEP2 = (int64_t)X8_STEP * X8_U;
+    const bool tiled = !SEGMENTED && seg_rows == 0;
+    const int64_t whole_end = tiled ? nrows / STEP2 * STEP2 : 0;
+    const int64_t stride = tiled ? (int64_t)nseg * STEP2 : STEP2;
+    int phase = tiled ? 1 : 0;
+    const int64_t begin = tiled ? 0 : (int64_t)seg * seg_rows;        // (a segment is far shorter than 2^31 rows: the host checks)
+    int64_t end = tiled ? whole_end : begin + seg_rows; if (end > nrows) end = nrows;
     if constexpr (SEGMENTED) sink.begin_segment(begin);
     int qn = 0;
     const uint32_t* pbm = P::sbitmap(a);                               // the prefilter's key bitmap, or null (wave-uniform)
@@ -820,12 +830,19 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
     if (live) {
 #if X8_PIPE
         typename P::Regs pre[X8_U];
-        if (begin + (int64_t)X8_STEP * X8_U <= end) {
+        {
+            const int64_t b0 = tiled ? (int64_t)seg * STEP2 : begin;
+            if (b0 + STEP2 <= end) {
 #pragma unroll
-            for (int u = 0; u < X8_U; ++u) P::template sload<false>(a, begin + (int64_t)u * X8_STEP + (int64_t)lane * XT_R, nrows, pre[u]);
+                for (int u = 0; u < X8_U; ++u) P::template sload<false>(a, b0 + (int64_t)u * X8_STEP + (int64_t)lane * XT_R, nrows, pre[u]);
+            }
         }
 #endif
-        for (int64_t b = begin;;) {
+        for (int64_t b = tiled ? (int64_t)seg * STEP2 : begin;;) {
+            if (phase == 1 && b >= end) {                                     // tiled: the whole double steps are done; wave 0 takes the rest of the rows
+                phase = 2;
+                if (seg == 0) { b = whole_end; end = nrows; }
+            }
             const bool last = b >= end;
             if (last) {
             } else if (b + (int64_t)X8_STEP * X8_U <= end) {
@@ -903,7 +920,8 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
 #if X8_PIPE
                 {
                     __builtin_amdgcn_sched_barrier(0);
-                    const int64_t bn = b + 2 * (int64_t)X8_STEP * X8_U <= end ? b + (int64_t)X8_STEP * X8_U : b;
+                    const int64_t adv = phase == 1 ? stride : STEP2;                    // (tiled: this wave's next double step is a stride away)
+                    const int64_t bn = b + adv + STEP2 <= end ? b + adv : b;
 #pragma unroll
                     for (int u = 0; u < X8_U; ++u) P::template sload<false>(a, bn + (int64_t)u * X8_STEP + (int64_t)lane * XT_R, nrows, pre[u]);
                     __builtin_amdgcn_sched_barrier(0);
@@ -958,7 +976,7 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
 #endif
 #pragma unroll
                 for (int u = 0; u < X8_U; ++u) enqueue8(b + (int64_t)u * X8_STEP + (int64_t)lane * XT_R, m[u]);
-                b += (int64_t)X8_STEP * X8_U;
+                b += phase == 1 ? stride : (int64_t)X8_STEP * X8_U;
             } else if (b + X8_STEP <= end) {                                  // one whole step left
                 typename P::Regs s1;
                 const int64_t r0 = b + (int64_t)lane * XT_R;

@@ -62,7 +62,9 @@ class DistributedRunner:
         self.fast_runs = 0                  # partitioned joins that ran with device-sized exchanges / that had to be repeated with exact sizes
         self.fast_retries = 0
         self._stat_ring, self._stat_next = [], 0
-        eng.nlanes = 1                                          # collectives and kernels are ordered on ONE stream
+        if not (world == 1 and self.skip_trivial):
+            eng.nlanes = 1                                      # collectives and kernels are ordered on ONE stream (a group of one that skips its
+                                                                # collectives keeps the engine's lanes: only the join is bound to lane 0's stream)
         self.rank, self.world, self.group = rank, world, group
         self.backend = dist.get_backend(group)
         if device is None:
@@ -437,6 +439,10 @@ class DistributedRunner:
         if len(whole) == len(plan.params):
             # nothing is sharded: every rank holds the whole database and computes the whole answer
             return engine.execute_plan(self.eng, plan, args, self._top, lane=0)
+        if self.world == 1 and self.skip_trivial and shape != "join":
+            # a group of ONE: this rank's shards are the tables — nothing to replicate, nothing to merge; the engine's own plan, on one of
+            # its lanes, its result launched and not waited for (the partitioned join keeps its exchange: that is the step the metric names)
+            return engine.execute_plan(self.eng, plan, args, self._top)
         if shape == "scalar":
             local = engine.execute_plan(self.eng, plan, args, lane=0)
             parts = self._all_gather_array(np.array([local], np.float64))

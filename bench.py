@@ -493,8 +493,9 @@ def main(argv=None, hooks=None):
             if dom_launches is alone_launches:
                 # which of the two timed regions the launches above are from, and the same kernel's launches in the other
                 shared_ms = sum(shared_launches) / len(shared_launches) if shared_launches else None
-                roofline["measured_in"] = ("the timed steps whose queries are waited for one by one (value_sequential): the kernel has the chip to itself; in the "
-                                           "overlapped steps (value) the engine's %d lanes run the queries' kernels side by side" % nlanes)
+                roofline["measured_in"] = ("%d steps whose queries are waited for one by one, every launch of this kernel between a pair of HIP events on the stream it "
+                                           "runs on (calls issued one by one: a recorded plan has no place for events) — there the kernel has the chip to itself; in the "
+                                           "overlapped steps the engine's %d lanes run the queries' kernels side by side" % (args.steps, nlanes))
                 roofline["in_overlapped_steps"] = {"avg_launch_ms": round(shared_ms, 4) if shared_ms else None, "launches_timed": len(shared_launches),
                                                    "note": "the same kernel sharing the chip with the other lanes' kernels: the step, not the kernel, is the unit there (roofline.step)"}
             # the step as a whole against the same roofline: HBM bytes of its queries (PMC, per query) / the step's wall time

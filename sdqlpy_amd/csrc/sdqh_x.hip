@@ -1662,7 +1662,11 @@ int sdqh_xprobe_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog
     // clean stays clean — Q5's xgroupby after Q3's probe-aggregate needed a fill launch for it)
     int32_t* d_flags = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->result_dev) + RESULT_BYTES - 64);
     if (int rc = fill_xargs(ctx, x, &a, d_flags, 1, 0)) return rc;
-    const Geometry g = geometry(ctx, nrows, false, 24, x.tight, true);
+    // (NOT the tiled walk, although the sink takes rows in any order: with one contiguous segment per wave the rows of a group — the
+    //  lineitems of an order — meet in one wave, folded by its drain's scan into one atomic per run, and a sum is the same bits run after
+    //  run; 1024-row tiles cut ten times as many groups in two, each half added by another wave in racing order — Q3 at SF=100 then differs
+    //  in the last bit between two runs (test_sf100_on_one_gpu_q3_q6) for 6 % of the kernel's time)
+    const Geometry g = geometry(ctx, nrows, false, 24, x.tight, false);
     XEntry<1>::Args sa{table->dev};
     ctx->next_model_bytes = model_stream_bytes(x, nrows, false);
     int rc = launch(ctx, fn, launch_label(SINK_ENTRY, false, x.tight), a, sa, nrows, g);

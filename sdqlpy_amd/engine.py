@@ -110,6 +110,7 @@ class Engine:
         self._range_cache = {}     # id(int64 ndarray) -> (ndarray, (min, span))
         self._distinct_cache = {}  # id(ndarray) -> (ndarray, has no repeated value)
         self._frozen = {}          # id(ndarray) -> ndarray made read-only on adoption (see column())
+        self._prepared = weakref.WeakSet()      # prepared plans bound to this engine (their recordings — PlanGraph — are dropped with the columns they read)
         self._outstanding = weakref.WeakSet()   # results launched and not looked at yet (DeferredResultSet): finished before the data they were computed from is dropped
         self.force_programs = os.environ.get("SDQLPY_AMD_FORCE_PROGRAMS") == "1"   # every loop as a row program (xplan.py), none through the fixed-shape calls
         # pure streaming loops (a sum / small group-by over one table, no lookups: Q1, Q6) go to their row program first: the
@@ -182,16 +183,24 @@ class Engine:
     def finish_outstanding(self):
         """Finish every result that was launched and not looked at yet, so that it holds the rows of the data it was launched on: a
         result whose collection overflows re-runs its plan (PreparedPlan._deferred), and must do that before the tables change."""
-        for rs in list(self._outstanding):
+        # in the order they were launched: under the multi-GPU runner finishing a result can issue collectives (a join repeated with exact
+        # sizes), and every rank must issue them in the same order — a WeakSet iterates in address order, different on every rank
+        for rs in sorted(self._outstanding, key=lambda r: r.__dict__.get("_seq", 0)):
             try:
                 rs.wait()
             except Exception:                                   # kept by the result: raised again where the caller looks at it
                 pass
         self._outstanding.clear()
 
+    def drop_recordings(self):
+        """Recorded plans (and the device memory they keep) go: the columns they name are about to change."""
+        for pp in list(self._prepared):
+            pp.drop_graphs()
+
     def clear(self):
         if self.ctx.handle is not None:
             self.finish_outstanding()
+            self.drop_recordings()
         if self._columns and self.ctx.handle is not None:
             self.ctx.synchronize()                              # queries launched and not waited for may still read the columns
         for _, col in self._columns.values():
@@ -253,6 +262,7 @@ class Engine:
             arrays = [what]
         if self.ctx.handle is not None:
             self.finish_outstanding()
+            self.drop_recordings()
         if any(id(arr) in self._columns for arr in arrays) and self.ctx.handle is not None:
             self.ctx.synchronize()                              # (queries launched and not waited for may still read them)
         for arr in arrays:
@@ -1899,6 +1909,7 @@ class PreparedPlan:
         compared = _compared_lookups(plan)
         self.steps = []
         self._graphs, self._graph_refused, self._deferred_runs = [], None, 0
+        getattr(eng, "_eng", eng)._prepared.add(self)
         self.defer_names = self._defer_names(plan)
         for op in plan.ops:
             if isinstance(op, ScanOp):

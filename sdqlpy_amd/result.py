@@ -248,8 +248,12 @@ class DeferredResultSet(ResultSet):
     errors the data decides (more groups than the kernel holds ...) surface there, where the plan is re-run synchronously on its
     other path.  The reference's result object defers its conversion in the same spirit (src/sdqlpy/fastd.py:31-51)."""
 
+    _launched = 0
+
     def __init__(self, thunk):
         self._thunk = thunk
+        DeferredResultSet._launched += 1
+        self._seq = DeferredResultSet._launched                 # launch order (engine.finish_outstanding finishes results in it)
 
     def _force(self):
         err = self.__dict__.get("_error")

@@ -316,3 +316,35 @@ def test_composite_key_builds_over_sorted_first_parts_on_the_cpu_implementation(
         assert helpers.grouped_index_case(ctx, n=3000, nprobe=5000, keep=0.02, per_a=1)[2] > 10
     finally:
         ctx.close()
+
+
+def test_plan_recording_is_refused_by_the_cpu_implementation_and_the_calls_go_on(oracle_lib):
+    """Plan graphs (include/sdqh.h, ABI 5) are the HIP library's: the CPU implementation records nothing and says so at
+    sdqh_graph_end (SDQH_ERR_UNSUPPORTED).  An engine told to record all the same (Engine.plan_graphs) tries once per prepared plan,
+    is refused, and keeps issuing the calls: same rows, the refusal counted."""
+    import helpers
+    from sdqlpy_amd import engine, tpch
+    ctx = oracle_lib.context()
+    ctx.graph_begin()
+    with pytest.raises(abi.SdqhError) as exc:
+        ctx.graph_end()
+    assert exc.value.code == abi.ERR_UNSUPPORTED
+    ctx.graph_abort()
+    ctx.close()
+    qs = ("q1", "q3")
+    db = tpch.generate(0.01, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+    plain, recording = engine.Engine(oracle_lib.context()), engine.Engine(oracle_lib.context())
+    recording.deferred_results, recording.plan_graphs, recording.plan_graphs_always = True, 2, True
+    try:
+        from sdqlpy_amd import frontend
+        from sdqlpy_amd import tpch_queries as Q
+        for q in qs:
+            want = sorted(helpers.run_query(plain, q, db).rows())
+            plan, args = frontend.lower_function(Q.QUERIES[q]), [db[t] for t in Q.QUERY_TABLES[q]]      # ONE plan object: prepared once, run again and again
+            for _ in range(5):
+                assert sorted(engine.execute_plan(recording, plan, args).rows()) == want, q
+        # (q3 ends in a deferred K-F and is tried; q1's small group-by is a waited-for call on this implementation and never is)
+        assert recording.graph_stats["recorded"] == 0 and recording.graph_stats["launched"] == 0 and recording.graph_stats["refused"] >= 1, recording.graph_stats
+    finally:
+        plain.close()
+        recording.close()

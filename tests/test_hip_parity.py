@@ -1307,6 +1307,43 @@ def test_sf100_on_one_gpu_q5_q9(hip_engine):
 
 
 @pytest.mark.gpu
+def test_distributed_chain_world1_sf100(hip_lib):
+    """BASELINE configs[4] on what is here: Q5 and Q9 at SF=100 through the DISTRIBUTED chain plan (builds over sharded tables
+    replicated — entries all-gathered on the device, key sets as bitmaps — the co-partitioned orders <-> lineitem join local, partial
+    groups merged) on an RCCL group of ONE whose collectives are ISSUED, against the single-GPU plan on the same tables.  Eight GPUs
+    are not here; the same plan at world 2 / 4 on gloo is tests/test_dist_cpu.py.  Skipped — visibly — on a box without the memory."""
+    import psutil
+    import torch
+    import torch.distributed as dist
+    from sdqlpy_amd import dist as sdist
+    if psutil.virtual_memory().available < 110 * (1 << 30) or torch.cuda.mem_get_info(0)[0] < 150 * (1 << 30):
+        pytest.skip("needs ~110 GiB of host memory and ~150 GiB of HBM free")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29597", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    eng = engine.Engine(hip_lib.context(device=0))
+    runner = sdist.DistributedRunner(eng, 0, 1, skip_trivial=False)
+    try:
+        for q in ("q5", "q9"):
+            cols = tpch.columns_for((q,))
+            db = tpch.generate(100, tables=sorted(cols), columns=cols, shard=(0, 1))
+            assert len(db["lineitem"].getContainer()["data"][0]) > 599_000_000 and db["lineitem"].shard == (0, 1)
+            single = helpers.run_query(eng, q, db)
+            single = single.wait() if hasattr(single, "wait") else single
+            runner.reset_collectives()
+            for again in range(2):
+                got = runner.run(q, db)
+                _rows_match(got, single, "sf100 distributed chain/%s/%d" % (q, again))
+            assert runner.collectives.get("all_gather", [0, 0])[1] > 0, runner.collectives      # replicas and partial groups really travelled, on device tensors
+            eng.clear()
+            del db, single, got
+    finally:
+        runner.close()
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+        eng.close()
+
+
+@pytest.mark.gpu
 def test_lanes_give_the_rows_one_stream_gives(hip_lib):
     """Round 4: an engine runs its plans on three lanes — contexts of one family (sdqh_fork), a stream, a pool and result blocks each,
     the resident columns shared — so that queries launched together share the chip.  Seven queries in flight at once, round after

@@ -65,6 +65,8 @@ class DistributedRunner:
         if not (world == 1 and self.skip_trivial):
             eng.nlanes = 1                                      # collectives and kernels are ordered on ONE stream (a group of one that skips its
                                                                 # collectives keeps the engine's lanes: only the join is bound to lane 0's stream)
+            eng.plan_graphs = 0                                 # ... and no plan is recorded on a stream RCCL's collectives are ordered on (a stream in
+                                                                # capture mode beside torch's / RCCL's use of it has never run anywhere)
         self.rank, self.world, self.group = rank, world, group
         self.backend = dist.get_backend(group)
         if device is None:

@@ -94,6 +94,7 @@ struct XInfo {
     bool pnear = false;                      // ... and a lane's 8 consecutive rows carry near-by keys (column_span8): a row that fails an earlier condition still asks for ITS key's word
     bool pwin = false;                       // ... tested against one 128-bit window of the bitmap: one 16-byte request per lane and 8 rows (option "window", off: measured slower)
     uint32_t gather32 = 0;                   // queue programs: numeric columns read BY ROW (the drain's gathers) through their 4-byte twins: half the bytes of every touched line
+    mutable uint32_t lay[SDQH_MAX_XTABLES] = {};   // XL_* layout bits of every table (kernel_for: known once the tables' indexes are made), 0: decided at run time
     std::vector<char> scope;                 // operations evaluated on the streamed registers (register programs: all; queue programs: the streamed gates + the prefilter's key)
 };
 
@@ -471,6 +472,24 @@ struct Gen {
     std::vector<int> tab_of, single_memo;
     int dict_col = -1;                         // mode 4: the column being tabulated
     static constexpr int MAX_TABS = 16, MAX_DERIVED = 12;
+    // mode 0 (a drained row, evaluated by its own lane): the loads the program needs at one depth of its dependency chain are emitted
+    // together and pinned (x_pin): `want` = the operations the gates depend on; after a LOOKUP, the payload fields of its entry that are
+    // wanted are read at once
+    bool pinning = false; std::vector<char> want; std::vector<std::string> pins;
+    void flush_pins() {
+        for (size_t i = 0; i < pins.size(); i += 6) {
+            os << "        x_pin(";
+            for (size_t j = i; j < pins.size() && j < i + 6; ++j) os << (j > i ? ", " : "") << pins[j];
+            os << ");\n";
+        }
+        pins.clear();
+    }
+    bool is_row_load(int k) const {                                     // a by-row load of a numeric column / a payload field / an accumulator
+        const sdqh_xop& o = x.p->ops[k];
+        if (o.code == SDQH_X_COL) return x.cols[x.col_of[k]]->dtype != SDQH_STR;
+        return o.code == SDQH_X_FIELD || o.code == SDQH_X_ACC;
+    }
+    std::string lay_lit(int t) const { char b[24]; std::snprintf(b, sizeof(b), "0x%08xu", (unsigned)x.lay[t]); return b; }      // the table's layout as a template argument
     explicit Gen(const XInfo& xi) : x(xi), done((size_t)xi.p->nops, 0), slot_of((size_t)SDQH_MAX_XCOLS, -1), sres_of((size_t)xi.p->nops, -1),
                                     tab_of((size_t)xi.p->nops, -1), single_memo((size_t)xi.p->nops, -2) {}
     // the one byte-coded column operation k depends on (nothing else but constants), or -1
@@ -518,7 +537,9 @@ struct Gen {
         const sdqh_xop& o = x.p->ops[k];
         const int c = x.col_of[k];
         std::string raw;
-        if (mode == 0 && ((x.gather32 >> c) & 1u))
+        // (a column the loop also STREAMS through its 4-byte twin — the prefilter's key — is read again from that twin by the rows that
+        //  are drained: the lines the wave has just streamed, still in L2, not the 8-byte original's)
+        if (mode == 0 && (((x.gather32 | x.narrow_mask) >> c) & 1u))
             return o.type == SDQH_T_F64 ? "narrow_decode(static_cast<const int32_t*>(a.ncol[" + std::to_string(c) + "])[r])" : "(int64_t)static_cast<const int32_t*>(a.ncol[" + std::to_string(c) + "])[r]";
         if (mode == 0) return std::string("static_cast<const ") + (o.type == SDQH_T_F64 ? "double" : "int64_t") + "*>(a.col[" + std::to_string(c) + "])[r]";
         if (mode == 4) return o.type == SDQH_T_F64 ? "x_f(dv)" : "dv";         // tabulating: the dictionary entry
@@ -566,7 +587,7 @@ struct Gen {
                 break;
             case SDQH_X_LOOKUP:
                 emit(o.a);
-                os << "        const uint32_t e" << K << " = x_lookup(a.tab[" << x.tab_of[k] << "], " << v(o.a) << ", " << bad(o.a) << ");\n";
+                os << "        const uint32_t e" << K << " = x_lookup_l<" << lay_lit(x.tab_of[k]) << ">(a.tab[" << x.tab_of[k] << "], " << v(o.a) << ", " << bad(o.a) << ");\n";
                 e = "(e" + K + " != NO_ROW)";
                 break;
             case SDQH_X_FIELD:
@@ -576,8 +597,8 @@ struct Gen {
                 break;
             case SDQH_X_ACC:
                 emit(o.a);
-                e = o.aux < 0 ? "x_hits(a.tab[" + std::to_string(x.tab_of[o.a]) + "], e" + std::to_string(o.a) + ")"
-                              : "x_acc(a.tab[" + std::to_string(x.tab_of[o.a]) + "], " + std::to_string(o.aux) + ", e" + std::to_string(o.a) + ")";
+                e = o.aux < 0 ? "x_hits_l<" + lay_lit(x.tab_of[o.a]) + ">(a.tab[" + std::to_string(x.tab_of[o.a]) + "], e" + std::to_string(o.a) + ")"
+                              : "x_acc_l<" + lay_lit(x.tab_of[o.a]) + ">(a.tab[" + std::to_string(x.tab_of[o.a]) + "], " + std::to_string(o.aux) + ", e" + std::to_string(o.a) + ")";
                 break;
             case SDQH_X_ADD: case SDQH_X_SUB: case SDQH_X_MUL: {
                 emit(o.a); emit(o.b);
@@ -630,10 +651,21 @@ struct Gen {
             }
             default: e = "0";
         }
-        os << "        const " << ctype(o.type) << " v" << K << " = " << e << ";\n";
+        if (done[(size_t)k]) return;                                          // (emitted meanwhile: a FIELD whose LOOKUP, emitted for it just now, read its wanted fields at once)
+        const bool pin = pinning && mode == 0 && is_row_load(k);
+        os << "        " << (pin ? "" : "const ") << ctype(o.type) << " v" << K << " = " << e << ";\n";
+        if (pin) pins.push_back("v" + K);
         done[(size_t)k] = 1;
+        if (pinning && mode == 0 && o.code == SDQH_X_LOOKUP && !want.empty()) {
+            flush_pins();
+            for (int j = k + 1; j < x.p->nops; ++j) {
+                const sdqh_xop& f = x.p->ops[j];
+                if ((f.code == SDQH_X_FIELD || f.code == SDQH_X_ACC) && f.a == k && want[(size_t)j]) emit(j);
+            }
+            flush_pins();
+        }
     }
-    void reset() { std::fill(done.begin(), done.end(), 0); }
+    void reset() { std::fill(done.begin(), done.end(), 0); pins.clear(); }
 };
 
 // A TIGHT program: struct P for x_tight (sdqh_xkernels.hpp).  Regs = the packed words of a lane's 8 rows per streamed
@@ -962,12 +994,29 @@ std::string generate(const XInfo& x, Sink sink, bool direct) {
         // A drained row has passed the streamed prefilter (the looked-up table's key bitmap), so nearly every one of them goes on to its
         // values: the by-row loads of the columns the values read are requested up front, beside the lookup's chain of dependent loads,
         // not behind the branch that ends it (a round trip less per drain)
-        if (mode == 0 && x.prefilter_op >= 0 && std::getenv("SDQLPY_AMD_X_HOIST") != nullptr) {
-            std::vector<char> need((size_t)p->nops, 0);
-            for (int v = 0; v < p->nvals; ++v) closure(p, p->vals[v], need);
-            for (int k = 0; k < p->nops; ++k) if (need[(size_t)k] && p->ops[k].code == SDQH_X_COL && x.cols[x.col_of[k]]->dtype != SDQH_STR) g.emit(k);
+        static const bool no_levels = std::getenv("SDQLPY_AMD_X_NOLEVELS") != nullptr;
+        g.pinning = mode == 0 && !no_levels;
+        g.want.assign((size_t)p->nops, 0);
+        if (g.pinning) {
+            // the columns the GATES read by row (key parts of their lookups, operands of their comparisons): requested together, up front
+            for (int q = from_gate; q < p->ngates; ++q) closure(p, p->gates[q], g.want);
+            for (int k = 0; k < p->nops; ++k) if (g.want[(size_t)k] && p->ops[k].code == SDQH_X_COL && g.is_row_load(k)) g.emit(k);
+            g.flush_pins();
         }
-        for (int q = from_gate; q < p->ngates; ++q) { g.emit(p->gates[q]); g.os << "        if (!v" << p->gates[q] << ") return false;\n"; }
+        for (int q = from_gate; q < p->ngates; ++q) { g.emit(p->gates[q]); g.flush_pins(); g.os << "        if (!v" << p->gates[q] << ") return false;\n"; }
+        if (g.pinning) {
+            // what is left reads the rows that passed every gate (few, in the loops that have lookups): the lookups the values still need,
+            // then every column, payload field and accumulator of the key and the values in ONE group
+            std::vector<char> rest((size_t)p->nops, 0);
+            if (p->key >= 0) closure(p, p->key, rest);
+            for (int v = 0; v < p->nvals; ++v) closure(p, p->vals[v], rest);
+            if (x.probe_op >= 0) closure(p, x.probe_op, rest);
+            g.want = rest;
+            for (int k = 0; k < p->nops; ++k) if (rest[(size_t)k] && p->ops[k].code == SDQH_X_LOOKUP) g.emit(k);
+            g.flush_pins();
+            for (int k = 0; k < p->nops; ++k) if (rest[(size_t)k] && g.is_row_load(k)) g.emit(k);
+            g.flush_pins();
+        }
         if (p->key >= 0) { g.emit(p->key); g.os << "        o.key = v" << p->key << "; o.bad = " << g.bad(p->key) << ";\n"; }
         else g.os << "        o.key = 0; o.bad = false;\n";
         for (int v = 0; v < p->nvals; ++v) {
@@ -1067,8 +1116,17 @@ int specialise(sdqh_ctx* ctx, const std::string& source, const std::string& entr
 
 int kernel_for(sdqh_ctx* ctx, const XInfo& x, Sink sink, bool direct, hipFunction_t* fn) {
     JitState& J = jit();
+    // the tables' layouts are part of the kernel (x_lookup_l): their indexes are made now (fill_xargs would, a moment later)
+    static const bool no_layouts = std::getenv("SDQLPY_AMD_X_NOLAYOUT") != nullptr;
+    uint64_t lay_hash = 0;
+    for (int t = 0; t < x.ntabs; ++t) {
+        if (ctx->compile_only) { x.lay[t] = 0u; continue; }                 // (no device: nothing is built, the run-time form of the lookups is what gets compiled)
+        if (int rc = index_ensure(ctx, x.tabs[t])) return rc;
+        x.lay[t] = no_layouts ? 0u : x_layout_of(x.tabs[t]->dev, x.tabs[t]->bitmap_only);
+        lay_hash = (lay_hash ^ x.lay[t]) * 0x9E3779B97F4A7C15ull + (uint64_t)t;
+    }
     char name[64];
-    std::snprintf(name, sizeof(name), "s%016llx@%d", (unsigned long long)structure_hash(x, sink, direct), ctx->device);
+    std::snprintf(name, sizeof(name), "s%016llx@%d", (unsigned long long)(structure_hash(x, sink, direct) ^ lay_hash), ctx->device);
     if (!ctx->compile_only) {
         std::lock_guard<std::mutex> lock(J.mu);
         auto hit = J.kernels.find(name);

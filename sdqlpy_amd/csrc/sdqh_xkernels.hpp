@@ -27,7 +27,13 @@
 #define X8_DRAIN_AT WAVE                                              // x_queue8 drains the front of its queue once this many rows wait (64: only whole waves)
 #endif
 #ifndef X8_EXP
-#define X8_EXP 0                                                      // timing experiments of x_queue8 (wrong results): 1 no bitmap requests, 2 nothing queued, 3 queued but never drained
+#define X8_EXP 0                                                      // timing experiments of x_queue8 (wrong results): 1 no bitmap requests, 2 nothing queued, 3 queued but never drained, 4 drained rows evaluated twice, 5 nothing reaches the sink (final loops only; 6.. : XGroup's own, see there)
+#endif
+#ifndef X8_EXP_MINROWS
+#define X8_EXP_MINROWS 0                                              // experiments 3 and 14 leave loops over fewer rows alone (a build that feeds the build under test)
+#endif
+#ifndef X8_EXP_BUILD
+#define X8_EXP_BUILD 0                                                // 1: the timing experiments touch the BUILD loops (stage / key-set sinks) instead of the final ones
 #endif
 #ifndef X8_PIPE
 #define X8_PIPE 0                                                     // x_queue8: the next double step's streamed loads requested behind this step's bitmap words (see there)
@@ -124,6 +130,153 @@ __device__ __forceinline__ uint32_t x_lookup(const DevTable& t, int64_t key, boo
     if (pos < 0) return NO_ROW;
     return t.bitmap_only ? 0u : table_ref(t, pos);
 }
+// x_pin(a, b, ...): every one of these values is in its registers HERE.  Loads the program is going to need at the same depth of its
+// dependency chain are written next to each other and pinned together: one `s_waitcnt` for the group, one memory round trip.  Without
+// it the compiler SINKS each load into the block of its first use — behind the branch that tests the previous load's result — and a
+// drain becomes a chain of single loads each waited for alone (Q5's final loop: eleven in a row where the data dependencies need five).
+template <class A> __device__ __forceinline__ void x_pin(A& a) { asm volatile("" : "+v"(a)); }
+template <class A, class B> __device__ __forceinline__ void x_pin(A& a, B& b) { asm volatile("" : "+v"(a), "+v"(b)); }
+template <class A, class B, class C> __device__ __forceinline__ void x_pin(A& a, B& b, C& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
+template <class A, class B, class C, class D> __device__ __forceinline__ void x_pin(A& a, B& b, C& c, D& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+template <class A, class B, class C, class D, class E> __device__ __forceinline__ void x_pin(A& a, B& b, C& c, D& d, E& e) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e)); }
+template <class A, class B, class C, class D, class E, class F> __device__ __forceinline__ void x_pin(A& a, B& b, C& c, D& d, E& e, F& f) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f)); }
+#ifndef X_PIN
+#define X_PIN 1                                                       // 0: no pinning inside the lookups (A/B)
+#endif
+
+// The same with the table's LAYOUT known when the kernel is specialised (XL_* bits, x_layout_of on the host: which of the index's
+// arrays exist is decided when the table is built, so it is a property of the plan at a given data size like the columns' encodings).
+// x_lookup decides every one of these at run time from the DevTable's fields — wave-uniform branches, each in a basic block of its own
+// with its own scalar loads of the argument block and its own `s_waitcnt`: the ISA of Q5's drain was a maze of ~200 branches in which
+// the bitmap word, the rank prefix and the owner were requested one after the other.  Straight-line here: what a layout reads at one
+// depth is requested together.  L without XL_KNOWN: x_lookup.
+constexpr uint32_t XL_DENSE_ARR = 1u, XL_BM = 2u, XL_SHIFT = 4u, XL_BITMAP_ONLY = 8u, XL_LIN = 16u, XL_GRP = 32u, XL_DENSE_REF = 64u, XL_WEXC = 128u,
+                   XL_SLOTS = 256u, XL_ALIAS = 512u, XL_KNOWN = 0x80000000u;
+__host__ __device__ inline uint32_t x_layout_of(const DevTable& t, bool bitmap_only) {
+    uint32_t l = XL_KNOWN;
+    if (t.dense_arr) l |= XL_DENSE_ARR;
+    if (t.bm) l |= XL_BM;
+    if (t.bm_shift) l |= XL_SHIFT;
+    if (bitmap_only || t.bitmap_only) l |= XL_BITMAP_ONLY;
+    if (t.lin_rb) l |= XL_LIN;
+    if (t.grp_first) l |= XL_GRP;
+    if (t.dense_ref) l |= XL_DENSE_REF;
+    if (t.wexc) l |= XL_WEXC;
+    if (t.slots) l |= XL_SLOTS;
+    if (t.alias) l |= XL_ALIAS;
+    if ((l & XL_GRP) && !(l & XL_BM)) return 0u;                              // (never built: left to the run-time form)
+    if ((l & XL_SHIFT) && t.bm_shift != 32) return 0u;
+    return l;
+}
+template <uint32_t L> __device__ __forceinline__ int64_t xl_slot_key(const DevTable& t, uint64_t h) { if constexpr ((L & XL_SLOTS) != 0) return t.slots[h * 4]; else return t.keys[h]; }
+template <uint32_t L> __device__ __forceinline__ uint32_t xl_slot_row(const DevTable& t, uint64_t h) { if constexpr ((L & XL_SLOTS) != 0) return (uint32_t)t.slots[h * 4 + 3]; else return t.rowref[h]; }
+template <uint32_t L>
+__device__ __forceinline__ uint32_t x_lookup_l(const DevTable& t, int64_t key, bool bad) {
+    if constexpr ((L & XL_KNOWN) == 0) return x_lookup(t, key, bad);
+    else {
+        if (bad) return NO_ROW;
+        if constexpr ((L & XL_DENSE_ARR) != 0) {
+            if (key < t.bm_lo || key > t.bm_hi) return NO_ROW;
+            return t.dense_arr[key - t.bm_lo];
+        } else if constexpr ((L & XL_BM) != 0) {
+            const int64_t v = (L & (XL_SHIFT | XL_LIN)) ? (int64_t)((uint64_t)key >> 32) : key;
+            if (v < t.bm_lo || v > t.bm_hi) return NO_ROW;
+            uint64_t off = (uint64_t)(v - t.bm_lo);
+            if constexpr ((L & XL_LIN) != 0) {
+                const int64_t b = (int64_t)((uint64_t)key & 0xFFFFFFFFull) - t.lin_b0;
+                if (b < 0 || b >= t.lin_rb) return NO_ROW;
+                off = off * (uint64_t)t.lin_rb + (uint64_t)b;
+            }
+            uint32_t word = t.bm[off >> 5];
+            if constexpr ((L & XL_BITMAP_ONLY) != 0) return ((word >> (off & 31)) & 1u) ? 0u : NO_ROW;
+            else if constexpr ((L & XL_GRP) != 0) {
+                uint32_t pre = t.grp_first[off];
+#if X_PIN
+                x_pin(word, pre);
+#endif
+                const bool bit = (word >> (off & 31)) & 1u;
+                if (!bit || pre == NO_ROW) return NO_ROW;
+                int64_t p = (int64_t)pre;
+                while (p < t.grp_cap) {                                       // (table_find: four entries of the run per round trip)
+                    int64_t k[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) k[i] = t.grp_key[(p + i < t.grp_cap ? p + i : t.grp_cap - 1) * t.grp_kstride];
+#if X_PIN
+                    x_pin(k[0], k[1], k[2], k[3]);
+#endif
+                    bool jump = false;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (jump || p + i >= t.grp_cap) continue;
+                        if (k[i] == key) return (uint32_t)(p + i);
+                        if (k[i] == EMPTY_KEY) { p = ((p + i) / t.grp_seg_rows + 1) * t.grp_seg_rows; jump = true; continue; }
+                        if (((uint64_t)k[i] >> 32) != ((uint64_t)key >> 32)) return NO_ROW;
+                    }
+                    if (!jump) p += 4;
+                }
+                return NO_ROW;
+            } else if constexpr ((L & XL_SHIFT) == 0) {                      // direct: rank of the key's bit
+                uint32_t pre = t.wprefix[off >> 5];
+#if X_PIN
+                x_pin(word, pre);
+#endif
+                const bool bit = (word >> (off & 31)) & 1u;
+                if (!bit) return NO_ROW;
+                const uint32_t below = __popc(word & ((1u << (off & 31)) - 1u));
+                int64_t pos = (int64_t)pre + below;
+                if constexpr ((L & XL_WEXC) != 0) {
+                    if (pre & ROW_INDEX_EXC) {
+                        const WordExc e = t.wexc[pre & ~ROW_INDEX_EXC];
+                        pos = key < e.key0 ? (int64_t)e.pos_prev + below : (int64_t)e.pos0 + (below - e.n0);
+                    }
+                }
+                if constexpr ((L & XL_DENSE_REF) != 0) return t.dense_ref[pos]; else return (uint32_t)pos;
+            } else {                                                          // hash layout behind a bitmap over the key's high part
+                uint64_t mask = t.hdr->cap_mask;
+#if X_PIN
+                x_pin(word, mask);
+#endif
+                const bool bit = (word >> (off & 31)) & 1u;
+                if (!bit) return NO_ROW;
+                uint64_t h = hash_key(key) & mask;
+                int64_t k = xl_slot_key<L>(t, h);
+                if (key == EMPTY_KEY) return xl_slot_row<L>(t, mask + 1);
+                for (;;) {
+                    if (k == key) return xl_slot_row<L>(t, h);
+                    if (k == EMPTY_KEY) return NO_ROW;
+                    h = (h + 1) & mask;
+                    k = xl_slot_key<L>(t, h);
+                }
+            }
+        } else {                                                              // hash layout, no bitmap
+            if constexpr ((L & XL_BITMAP_ONLY) != 0) return x_lookup(t, key, bad);
+            else {
+                const uint64_t mask = t.hdr->cap_mask;
+                if (key == EMPTY_KEY) return xl_slot_row<L>(t, mask + 1);
+                uint64_t h = hash_key(key) & mask;
+                int64_t k = xl_slot_key<L>(t, h);
+                for (;;) {
+                    if (k == key) return xl_slot_row<L>(t, h);
+                    if (k == EMPTY_KEY) return NO_ROW;
+                    h = (h + 1) & mask;
+                    k = xl_slot_key<L>(t, h);
+                }
+            }
+        }
+    }
+}
+template <uint32_t L> __device__ __forceinline__ double x_acc_l(const DevTable& t, int k, uint32_t ent) {
+    if (ent == NO_ROW) return 0.0;
+    if constexpr ((L & XL_KNOWN) == 0) { if (t.alias) ent = t.alias[ent]; }
+    else if constexpr ((L & XL_ALIAS) != 0) ent = t.alias[ent];
+    return k < t.acc_stride ? t.sacc[(size_t)ent * t.acc_stride + k] : 0.0;
+}
+template <uint32_t L> __device__ __forceinline__ int64_t x_hits_l(const DevTable& t, uint32_t ent) {
+    if (ent == NO_ROW) return 0;
+    if constexpr ((L & XL_KNOWN) == 0) { if (t.alias) ent = t.alias[ent]; }
+    else if constexpr ((L & XL_ALIAS) != 0) ent = t.alias[ent];
+    return (int64_t)t.shits[ent];
+}
 // cheap necessary condition for `key in table`, usable on a streamed key before the row is queued: the
 // table's key bitmap when it has one (exact for key sets and the direct layout; over the high part of a
 // composite key), else true
@@ -161,6 +314,7 @@ __device__ __forceinline__ int64_t x_hits(const DevTable& t, uint32_t ent) {
 
 // ---- K-A: sums of NV doubles + a row count; one partial per workgroup, folded by k_sum_partials ----
 template <int NV> struct XSum {
+    static constexpr bool FINAL = true;                               // (the timing experiments of the queue skeleton touch final loops only: a build they emptied would change the loop under test)
     static constexpr bool PIPELINED = false;                          // x_tight: two tiles in flight per step (many waves per SIMD cover the latency)
     struct Args { double* partial; };
     double acc[NV > 0 ? NV : 1];
@@ -192,11 +346,17 @@ template <int NV> struct XSum {
 
 // ---- K-C over a small group domain: LDS hash table per workgroup, f64 LDS atomics, slot-major partials ----
 template <int NV> struct XGroup {
+    static constexpr bool FINAL = true;
     static constexpr bool PIPELINED = false;
     struct Args { unsigned long long* gkeys; double* pacc; int64_t* pcnt; int* flags; };
     static constexpr int NVS = NV > 0 ? NV : 1;
     unsigned long long* s_keys; double (*s_acc)[NVS]; unsigned long long* s_cnt; int* s_map; int* s_flags;
-    __device__ __forceinline__ void init(const Args&) {
+    __device__ __forceinline__ void init(const Args& s) {
+        // This workgroup's column of the partial COUNTS is zeroed now, while the chip is busy streaming: the merge adds a partial only
+        // where its count is positive, so the epilogue stores nothing but the slots this workgroup has rows for (thread i zeroes and
+        // later writes slot i: one thread's stores to one address stay in order).  Zeros for all LG_SLOTS slots and their four sums,
+        // stored by every workgroup at its end, were 2.6 M scattered 8-byte stores behind the last row: 0.023 of Q5's 0.111 ms.
+        for (int i = threadIdx.x; i < LG_SLOTS; i += TPB) s.pcnt[(size_t)i * gridDim.x + blockIdx.x] = 0;
         __shared__ unsigned long long sk[LG_SLOTS];
         __shared__ double sa[LG_SLOTS][NVS];
         __shared__ unsigned long long sc[LG_SLOTS];
@@ -209,14 +369,31 @@ template <int NV> struct XGroup {
     }
     __device__ __forceinline__ void consume(const XArgs&, const Args&, bool pass, int64_t, const XOut<NV>& o) {
         if (!pass) return;
+#if X8_EXP == 11
+        { asm volatile("s_nop 0"); return; }                                 // (timing experiment: rows reach the sink, which does nothing; no epilogue)
+#endif
+#if X8_EXP == 12
+        { asm volatile("s_nop 0" :: "v"(o.key), "v"(o.val[0])); return; }    // (timing experiment: ... but needs the row's key and value)
+#endif
         if (o.bad || o.key < 0) { atomicOr(&s_flags[0], 2); return; }
+#if X8_EXP == 8 || X8_EXP == 9
+        const int slot = (int)((unsigned long long)o.key & (LG_SLOTS - 1));      // (timing experiment: no hashing, no probing; 9: and no epilogue)
+        s_keys[slot] = (unsigned long long)o.key;
+#else
         const int slot = group_slot(s_keys, (unsigned long long)o.key, false);
+#endif
         if (slot < 0) { atomicOr(&s_flags[0], 1); return; }
+#if X8_EXP == 7
+        if (slot != 100000) return;                                         // (timing experiment: the slot found, nothing added)
+#endif
 #pragma unroll
         for (int k = 0; k < NV; ++k) atomicAdd(&s_acc[slot][k], x_f(o.val[k]));
         atomicAdd(&s_cnt[slot], 1ull);
     }
     __device__ __forceinline__ void finish(const XArgs&, const Args& s) {
+#if X8_EXP == 6 || X8_EXP == 9 || X8_EXP == 10 || X8_EXP == 11 || X8_EXP == 12 || X8_EXP == 14
+        if (s.gkeys != nullptr) return;                                     // (timing experiment: no epilogue)
+#endif
         __syncthreads();
         for (int i = threadIdx.x; i < LG_SLOTS; i += TPB) {
             if (s_keys[i] != EMPTY_GROUP && s_cnt[i] > 0) {
@@ -227,10 +404,11 @@ template <int NV> struct XGroup {
         __syncthreads();
         for (int i = threadIdx.x; i < LG_SLOTS; i += TPB) {
             const int l = s_map[i];
+            if (l < 0) continue;                                              // (its count is zero since init)
             const size_t e = (size_t)i * gridDim.x + blockIdx.x;
-            s.pcnt[e] = l >= 0 ? (int64_t)s_cnt[l] : 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s.pacc[e * 4 + k] = (l >= 0 && k < NV) ? s_acc[l][k < NVS ? k : 0] : 0.0;
+            for (int k = 0; k < 4; ++k) s.pacc[e * 4 + k] = k < NV ? s_acc[l][k < NVS ? k : 0] : 0.0;
+            s.pcnt[e] = (int64_t)s_cnt[l];
         }
         if (threadIdx.x == 0 && s_flags[0]) atomicOr(s.flags, s_flags[0]);
     }
@@ -238,6 +416,7 @@ template <int NV> struct XGroup {
 
 // ---- K-B: survivors compacted in row order into the wave segment's slice of the stage ----
 template <int NV> struct XStage {
+    static constexpr bool FINAL = false;
     struct Args { DevStage st; };
     int64_t out, seg_begin;
     uint32_t carry;                                                       // row index: the bitmap word of the wave's previous entry
@@ -263,6 +442,7 @@ template <int NV> struct XStage {
 
 // ---- membership-only K-B: OR the bits of the passing keys ----
 template <int NV> struct XKeySet {
+    static constexpr bool FINAL = false;
     struct Args { uint32_t* bm; };
     __device__ __forceinline__ void init(const Args&) {}
     __device__ __forceinline__ void consume(const XArgs& a, const Args& s, bool pass, int64_t, const XOut<NV>& o) {
@@ -278,6 +458,7 @@ template <int NV> struct XKeySet {
 //      one native f64 atomic per run and value (rows of one group sit in adjacent lanes when the probe side is
 //      clustered on the key) ----
 template <int NV> struct XEntry {
+    static constexpr bool FINAL = true;
     struct Args { DevTable tb; };
     __device__ __forceinline__ void init(const Args&) {}
     __device__ __forceinline__ void consume(const XArgs&, const Args& s, bool pass, int64_t, const XOut<NV>& o) {
@@ -601,6 +782,7 @@ __device__ __forceinline__ int64_t xt_i64(const uint32_t (&w)[16], int i) { retu
 // Deterministic: a lane adds its rows in row order, lanes are folded in a fixed order, workgroups by
 // k_groupby_merge in workgroup order.  The slots are the key's offsets, so no key table and no claiming.
 template <int NV> struct XGroupLane {
+    static constexpr bool FINAL = true;
     static constexpr bool PIPELINED = true;                           // x_tight: its LDS cells leave two or three waves per SIMD: a wave hides its own latency
     struct Args { unsigned long long* gkeys; double* pacc; int64_t* pcnt; int* flags; int32_t nslots, _pad; };
     // XGL_IVAL = v: summed value v is a small non-negative INTEGER on every row (a byte-coded column whose dictionary is consecutive
@@ -780,6 +962,7 @@ __device__ __forceinline__ int wave_excl_prefix4(uint32_t v, int& total) {
     return below;
 }
 
+template <class Sink> __device__ __forceinline__ constexpr bool x_exp_on() { return X8_EXP_BUILD ? !Sink::FINAL : Sink::FINAL; }
 template <class P, template <int> class SinkT, bool SEGMENTED>
 __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P::NV>::Args& sa, int64_t nrows, int64_t seg_rows, int nseg) {
     using Sink = SinkT<P::NV>;
@@ -817,6 +1000,11 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
         if constexpr (P::NSC > 1) x_stage_text<P, 1>(a, q_row, begin, first, count, s_str, sres);
         bool pass = false; int64_t r = 0;
         if (lane < count) { r = begin + (int64_t)q_row[first + lane]; pass = P::eval_row(a, r, sres, o); }
+        if constexpr (X8_EXP == 4 && x_exp_on<Sink>()) {                                                                                                        // (timing experiment: every drained row evaluated twice)
+            if (lane < count) { XOut<P::NV> o2; const bool p2 = P::eval_row(a, r ^ 1, sres, o2); pass = pass && (p2 || (uint32_t)a.key_hi != 0x12345678u); }
+        }
+        if constexpr (X8_EXP == 14 && x_exp_on<Sink>()) pass = pass && (o.key == -12345 || nrows < (int64_t)X8_EXP_MINROWS);                                                                         // (no row reaches the sink, by its data)
+        if constexpr ((X8_EXP == 5 || X8_EXP == 10) && x_exp_on<Sink>()) { int pi = pass ? 1 : 0; asm volatile("" : "+v"(pi)); pass = pi != 0 && (uint32_t)a.key_hi == 0x12345678u; }   // (evaluated, nothing reaches the sink; 10: and no epilogue)
         sink.consume(a, sa, pass, r, o);
     };
     auto enqueue8 = [&](int64_t r0, uint32_t m) {                      // m: bit i = row r0 + i of this lane survives
@@ -871,10 +1059,9 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
 #pragma unroll
                         for (int i = 0; i < XT_R; ++i) { const bool p = P::spre32(a, s[u], s_tab, i, off[u][i]); m[u] |= p ? (1u << i) : 0u; }
                     }
-#if X8_EXP == 1
-                    // (timing experiment: no bitmap requests at all)
-#else
-                    if constexpr (P::PWIN) {
+                    if constexpr (X8_EXP == 1 && x_exp_on<Sink>()) {
+                        // (timing experiment: no bitmap requests at all)
+                    } else if constexpr (P::PWIN) {
                         // WINDOW: a lane's 8 consecutive rows carry near-by keys when the key column is clustered (a foreign key of a table
                         // stored in the order of its parent: l_orderkey; column_span8 sampled it), so ONE 16-byte request per lane — the
                         // four bitmap words from the word of its smallest passing key on — answers all eight tests; a row whose key lies
@@ -895,7 +1082,6 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
 #pragma unroll
                             for (int i = 0; i < XT_R; ++i) w[u][i] = pbm[off[u][i] >> 5];
                     }
-#endif
                 } else if (pbm) {
                     // the prefilter's bitmap words of all 16 rows are requested before any is tested (a load inside each row's own
                     // `if (passes the cheap conditions)` region made a step sixteen dependent round trips)
@@ -928,11 +1114,10 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
                 }
 #endif
                 if constexpr (P::PREF32) {
-#if X8_EXP == 1
+                    if constexpr (X8_EXP == 1 && x_exp_on<Sink>()) {
 #pragma unroll
-                    for (int u = 0; u < X8_U; ++u) m[u] = ((uint32_t)a.key_hi == 0x12345678u) ? m[u] : 0u;
-#else
-                    if constexpr (P::PWIN) {
+                        for (int u = 0; u < X8_U; ++u) m[u] = ((uint32_t)a.key_hi == 0x12345678u) ? m[u] : 0u;
+                    } else if constexpr (P::PWIN) {
 #pragma unroll
                         for (int u = 0; u < X8_U; ++u) {
                             uint32_t hit = 0, beyond = 0;
@@ -963,17 +1148,16 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
                             m[u] &= hit;
                         }
                     }
-#endif
                 } else if (pbm) {
 #pragma unroll
                     for (int u = 0; u < X8_U; ++u)
 #pragma unroll
                         for (int i = 0; i < XT_R; ++i) m[u] &= ~(((~w[u][i] >> (off[u][i] >> 27)) & 1u) << i);
                 }
-#if X8_EXP == 2
+                if constexpr (X8_EXP == 2 && x_exp_on<Sink>()) {
 #pragma unroll
-                for (int u = 0; u < X8_U; ++u) m[u] = ((uint32_t)a.key_hi == 0x12345678u) ? m[u] : 0u;      // (timing experiment: tests done, nothing queued)
-#endif
+                    for (int u = 0; u < X8_U; ++u) m[u] = ((uint32_t)a.key_hi == 0x12345678u) ? m[u] : 0u;      // (timing experiment: tests done, nothing queued)
+                }
 #pragma unroll
                 for (int u = 0; u < X8_U; ++u) enqueue8(b + (int64_t)u * X8_STEP + (int64_t)lane * XT_R, m[u]);
                 b += phase == 1 ? stride : (int64_t)X8_STEP * X8_U;
@@ -997,9 +1181,7 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
                 b += X8_STEP;
             }
             int head = 0;
-#if X8_EXP == 3
-            if ((uint32_t)a.key_hi != 0x12345678u) qn = 0;                   // (timing experiment: survivors queued, never drained)
-#endif
+            if constexpr (X8_EXP == 3 && x_exp_on<Sink>()) { if ((uint32_t)a.key_hi != 0x12345678u && nrows >= (int64_t)X8_EXP_MINROWS) qn = 0; }      // (timing experiment: survivors queued, never drained)
             while (qn - head >= X8_DRAIN_AT || (last && qn > head)) {
                 const int n = qn - head >= WAVE ? WAVE : qn - head;
                 drain(head, n);

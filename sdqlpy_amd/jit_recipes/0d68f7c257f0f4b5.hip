@@ -32,23 +32,25 @@ struct P {
         return false;
     }
     __device__ __forceinline__ static bool eval_row(const XArgs& a, int64_t r, const int64_t (&sres)[1], XOut<NV>& o) {
-        const int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
-        const uint32_t e1 = x_lookup(a.tab[0], v0, false);
+        int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
+        int64_t v2 = static_cast<const int64_t*>(a.col[1])[r];
+        x_pin(v0, v2);
+        const uint32_t e1 = x_lookup_l<0x80000082u>(a.tab[0], v0, false);
         const bool v1 = (e1 != NO_ROW);
         if (!v1) return false;
-        const int64_t v2 = static_cast<const int64_t*>(a.col[1])[r];
-        const uint32_t e3 = x_lookup(a.tab[1], v2, false);
+        const uint32_t e3 = x_lookup_l<0x8000000au>(a.tab[1], v2, false);
         const bool v3 = (e3 != NO_ROW);
         const bool v4 = (!v3);
         if (!v4) return false;
-        const int64_t v5 = x_field(a.tab[0], 0, e1);
+        int64_t v5 = x_field(a.tab[0], 0, e1);
+        int64_t v6 = x_field(a.tab[0], 1, e1);
+        int64_t v7 = x_field(a.tab[0], 2, e1);
+        x_pin(v5, v6, v7);
         const int64_t v8 = a.ci[0];
         const int64_t v9 = (v5 * v8);
-        const int64_t v6 = x_field(a.tab[0], 1, e1);
         const int64_t v10 = (v9 + v6);
         const int64_t v13 = a.ci[2];
         const int64_t v14 = (v10 * v13);
-        const int64_t v7 = x_field(a.tab[0], 2, e1);
         const int64_t v11 = a.ci[1];
         const int64_t v12 = (v7 - v11);
         const int64_t v15 = (v14 + v12);

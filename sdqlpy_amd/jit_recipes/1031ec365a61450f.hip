@@ -44,12 +44,13 @@ struct P {
         return false;
     }
     __device__ __forceinline__ static bool eval_row(const XArgs& a, int64_t r, const int64_t (&sres)[2], XOut<NV>& o) {
-        const int64_t v3 = static_cast<const int64_t*>(a.col[1])[r];
-        const uint32_t e4 = x_lookup(a.tab[0], v3, false);
+        int64_t v3 = static_cast<const int64_t*>(a.col[1])[r];
+        int64_t v6 = static_cast<const int64_t*>(a.col[2])[r];
+        x_pin(v3, v6);
+        const uint32_t e4 = x_lookup_l<0x8000000au>(a.tab[0], v3, false);
         const bool v4 = (e4 != NO_ROW);
         const bool v5 = (!v4);
         if (!v5) return false;
-        const int64_t v6 = static_cast<const int64_t*>(a.col[2])[r];
         const int64_t v7 = a.ci[0];
         const bool v9 = (v6 >= v7);
         const int64_t v8 = a.ci[1];
@@ -92,13 +93,14 @@ struct P {
         const bool v41 = (v39 && v40);
         const bool v47 = (v46 || v41);
         if (!v47) return false;
+        double v0 = static_cast<const double*>(a.col[0])[r];
+        x_pin(v0);
         const int64_t v48 = sres[0];
         const int64_t v50 = a.ci[14];
         const int64_t v51 = (v48 * v50);
         const int64_t v49 = sres[1];
         const int64_t v52 = (v51 + v49);
         o.key = v52; o.bad = false;
-        const double v0 = static_cast<const double*>(a.col[0])[r];
         o.val[0] = x_bits(v0);
         o.ent = NO_ROW;
         return true;

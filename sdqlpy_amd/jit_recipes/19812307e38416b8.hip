@@ -32,12 +32,14 @@ struct P {
         return false;
     }
     __device__ __forceinline__ static bool eval_row(const XArgs& a, int64_t r, const int64_t (&sres)[1], XOut<NV>& o) {
-        const int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
-        const uint32_t e2 = x_lookup(a.tab[0], v0, false);
+        int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
+        x_pin(v0);
+        const uint32_t e2 = x_lookup_l<0x80000001u>(a.tab[0], v0, false);
         const bool v2 = (e2 != NO_ROW);
         if (!v2) return false;
+        double v1 = static_cast<const double*>(a.col[1])[r];
+        x_pin(v1);
         o.key = 0; o.bad = false;
-        const double v1 = static_cast<const double*>(a.col[1])[r];
         o.val[0] = x_bits(v1);
         o.ent = e2;
         return true;

@@ -14,7 +14,8 @@ struct P {
         return false;
     }
     __device__ __forceinline__ static bool eval_row(const XArgs& a, int64_t r, const int64_t (&sres)[1], XOut<NV>& o) {
-        const int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
+        int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
+        x_pin(v0);
         const int64_t v1 = (v0 / (int64_t)750000ll);
         const int64_t v11 = a.ci[1];
         const int64_t v12 = (v1 * v11);
@@ -29,7 +30,7 @@ struct P {
         const int64_t v7 = (v5 + v6);
         const int64_t v14 = (v7 - v6);
         const int64_t v17 = (v16 + v14);
-        const uint32_t e18 = x_lookup(a.tab[0], v17, false);
+        const uint32_t e18 = x_lookup_l<0x80000000u>(a.tab[0], v17, false);
         const bool v18 = (e18 != NO_ROW);
         if (!v18) return false;
         o.key = 0; o.bad = false;

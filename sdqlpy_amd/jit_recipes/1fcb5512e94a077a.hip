@@ -1,7 +1,7 @@
 #include "sdqh_xkernels.hpp"
 using namespace sdqh;
 struct P {
-    static constexpr int NS = 2, NV = 1, NSC = 0, NSOP = 0, ND = 0;
+    static constexpr int NS = 2, NV = 2, NSC = 0, NSOP = 0, ND = 0;
     struct Regs { uint32_t c0[4]; uint32_t c1[8]; };
     __device__ __forceinline__ static void load_dicts(const XArgs& a, int64_t (*tab)[256]) {
     }
@@ -13,18 +13,22 @@ struct P {
         bool p = true;
         const bool v2 = (xt_u16(s.c0, i) >= a.cc[0]);
         p = p & v2;
-        const int64_t v3 = (int64_t)xt_i32(s.c1, i);
-        p = p && x_may_hit(a.tab[0], v3, false);
+        const bool v4 = (xt_u16(s.c0, i) < a.cc[1]);
+        p = p & v4;
+        const int64_t v5 = (int64_t)xt_i32(s.c1, i);
+        p = p && x_may_hit(a.tab[0], v5, false);
         return p;
     }
     __device__ __forceinline__ static bool spre(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i, uint32_t& widx, uint32_t& bit) {
         bool p = true;
         const bool v2 = (xt_u16(s.c0, i) >= a.cc[0]);
         p = p & v2;
-        const int64_t v3 = (int64_t)xt_i32(s.c1, i);
-        const bool in = (v3 >= a.tab[0].bm_lo) & (v3 <= a.tab[0].bm_hi);
+        const bool v4 = (xt_u16(s.c0, i) < a.cc[1]);
+        p = p & v4;
+        const int64_t v5 = (int64_t)xt_i32(s.c1, i);
+        const bool in = (v5 >= a.tab[0].bm_lo) & (v5 <= a.tab[0].bm_hi);
         p = p & in;
-        const uint64_t off = in ? (uint64_t)(v3 - a.tab[0].bm_lo) : 0ull;
+        const uint64_t off = p ? (uint64_t)(v5 - a.tab[0].bm_lo) : 0ull;
         widx = (uint32_t)(off >> 5); bit = (uint32_t)off & 31u;
         return p;
     }
@@ -33,11 +37,13 @@ struct P {
         bool p = true;
         const bool v2 = (xt_u16(s.c0, i) >= a.cc[0]);
         p = p & v2;
-        const int64_t v3 = (int64_t)xt_i32(s.c1, i);
-        const uint32_t o32 = (uint32_t)((int32_t)v3 - (int32_t)a.tab[0].bm_lo);
+        const bool v4 = (xt_u16(s.c0, i) < a.cc[1]);
+        p = p & v4;
+        const int64_t v5 = (int64_t)xt_i32(s.c1, i);
+        const uint32_t o32 = (uint32_t)((int32_t)v5 - (int32_t)a.tab[0].bm_lo);
         const bool in = o32 <= (uint32_t)(a.tab[0].bm_hi - a.tab[0].bm_lo);
         p = p & in;
-        off = in ? o32 : 0u;
+        off = p ? o32 : 0u;
         return p;
     }
     __device__ __forceinline__ static const uint32_t* sbitmap(const XArgs& a) { return x_prefilter_bitmap(a.tab[0], false); }
@@ -45,21 +51,22 @@ struct P {
         return false;
     }
     __device__ __forceinline__ static bool eval_row(const XArgs& a, int64_t r, const int64_t (&sres)[1], XOut<NV>& o) {
-        const int64_t v3 = static_cast<const int64_t*>(a.col[1])[r];
-        const uint32_t e4 = x_lookup(a.tab[0], v3, false);
-        const bool v4 = (e4 != NO_ROW);
-        if (!v4) return false;
-        o.key = 0; o.bad = false;
-        const double v5 = narrow_decode(static_cast<const int32_t*>(a.ncol[2])[r]);
-        const double v6 = a.cf[0];
-        const double v7 = narrow_decode(static_cast<const int32_t*>(a.ncol[3])[r]);
-        const double v8 = (v6 - v7);
-        const double v9 = (v5 * v8);
-        o.val[0] = x_bits(v9);
-        o.ent = e4;
+        int64_t v5 = (int64_t)static_cast<const int32_t*>(a.ncol[1])[r];
+        x_pin(v5);
+        const uint32_t e6 = x_lookup_l<0x80000082u>(a.tab[0], v5, false);
+        const bool v6 = (e6 != NO_ROW);
+        if (!v6) return false;
+        int64_t v7 = (int64_t)static_cast<const int32_t*>(a.ncol[2])[r];
+        int64_t v8 = x_field(a.tab[0], 0, e6);
+        int64_t v9 = x_field(a.tab[0], 1, e6);
+        x_pin(v7, v8, v9);
+        o.key = v7; o.bad = false;
+        o.val[0] = v8;
+        o.val[1] = v9;
+        o.ent = NO_ROW;
         return true;
     }
 };
-extern "C" __global__ __launch_bounds__(256) void xk_probe_agg_tight(XArgs a, XEntry<P::NV>::Args s, int64_t nrows, int64_t seg_rows, int nseg) {
-    x_queue8<P, XEntry, false>(a, s, nrows, seg_rows, nseg);
+extern "C" __global__ __launch_bounds__(256) void xk_build_tight(XArgs a, XStage<P::NV>::Args s, int64_t nrows, int64_t seg_rows, int nseg) {
+    x_queue8<P, XStage, true>(a, s, nrows, seg_rows, nseg);
 }

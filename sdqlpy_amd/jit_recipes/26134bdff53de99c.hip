@@ -47,18 +47,21 @@ struct P {
         return false;
     }
     __device__ __forceinline__ static bool eval_row(const XArgs& a, int64_t r, const int64_t (&sres)[1], XOut<NV>& o) {
-        const int64_t v5 = static_cast<const int64_t*>(a.col[1])[r];
-        const uint32_t e6 = x_lookup(a.tab[0], v5, false);
+        int64_t v5 = static_cast<const int64_t*>(a.col[1])[r];
+        int64_t v7 = static_cast<const int64_t*>(a.col[2])[r];
+        x_pin(v5, v7);
+        const uint32_t e6 = x_lookup_l<0x80000043u>(a.tab[0], v5, false);
         const bool v6 = (e6 != NO_ROW);
+        int64_t v12 = x_field(a.tab[0], 0, e6);
+        x_pin(v12);
         if (!v6) return false;
-        const int64_t v7 = static_cast<const int64_t*>(a.col[2])[r];
-        const uint32_t e8 = x_lookup(a.tab[1], v7, false);
+        const uint32_t e8 = x_lookup_l<0x80000043u>(a.tab[1], v7, false);
         const bool v8 = (e8 != NO_ROW);
+        int64_t v9 = x_field(a.tab[1], 0, e8);
+        x_pin(v9);
         if (!v8) return false;
-        const int64_t v9 = x_field(a.tab[1], 0, e8);
         const int64_t v10 = a.ci[2];
         const bool v11 = (v9 == v10);
-        const int64_t v12 = x_field(a.tab[0], 0, e6);
         const int64_t v13 = a.ci[3];
         const bool v14 = (v12 == v13);
         const bool v15 = (v11 && v14);
@@ -67,19 +70,20 @@ struct P {
         const bool v18 = (v16 && v17);
         const bool v19 = (v15 || v18);
         if (!v19) return false;
+        int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
+        double v28 = static_cast<const double*>(a.col[3])[r];
+        double v30 = static_cast<const double*>(a.col[4])[r];
+        x_pin(v0, v28, v30);
         const int64_t v21 = a.ci[4];
         const int64_t v22 = (v9 * v21);
         const int64_t v23 = (v22 + v12);
         const int64_t v26 = (v23 * v10);
-        const int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
         const int64_t v20 = (v0 / 10000);
         const int64_t v24 = a.ci[5];
         const int64_t v25 = (v20 - v24);
         const int64_t v27 = (v26 + v25);
         o.key = v27; o.bad = false;
-        const double v28 = static_cast<const double*>(a.col[3])[r];
         const double v29 = a.cf[0];
-        const double v30 = static_cast<const double*>(a.col[4])[r];
         const double v31 = (v29 - v30);
         const double v32 = (v28 * v31);
         o.val[0] = x_bits(v32);

@@ -32,23 +32,25 @@ struct P {
         return false;
     }
     __device__ __forceinline__ static bool eval_row(const XArgs& a, int64_t r, const int64_t (&sres)[1], XOut<NV>& o) {
-        const int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
-        const uint32_t e1 = x_lookup(a.tab[0], v0, false);
+        int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
+        int64_t v2 = static_cast<const int64_t*>(a.col[1])[r];
+        int64_t v5 = static_cast<const int64_t*>(a.col[2])[r];
+        double v12 = static_cast<const double*>(a.col[3])[r];
+        x_pin(v0, v2, v5, v12);
+        const uint32_t e1 = x_lookup_l<0x80000082u>(a.tab[0], v0, false);
         const bool v1 = (e1 != NO_ROW);
+        int64_t v10 = x_field(a.tab[0], 0, e1);
+        x_pin(v10);
         if (!v1) return false;
-        const int64_t v2 = static_cast<const int64_t*>(a.col[1])[r];
         const int64_t v3 = a.ci[0];
         const bool v4 = (v2 == v3);
         if (!v4) return false;
-        const int64_t v5 = static_cast<const int64_t*>(a.col[2])[r];
         const int64_t v6 = a.ci[1];
         const bool v7 = (v5 == v6);
         const bool v8 = (a.ci[2] != 0);
         const bool v9 = (v7 || v8);
         if (!v9) return false;
-        const int64_t v10 = x_field(a.tab[0], 0, e1);
         const bool v11 = (v10 == v3);
-        const double v12 = static_cast<const double*>(a.col[3])[r];
         const double v13 = (double)v3;
         const bool v14 = (v12 >= v13);
         const bool v18 = (v11 && v14);
@@ -78,10 +80,11 @@ struct P {
         const bool v38 = (v37 && v36);
         const bool v40 = (v39 || v38);
         if (!v40) return false;
+        double v41 = static_cast<const double*>(a.col[4])[r];
+        double v43 = static_cast<const double*>(a.col[5])[r];
+        x_pin(v41, v43);
         o.key = 0; o.bad = false;
-        const double v41 = static_cast<const double*>(a.col[4])[r];
         const double v42 = a.cf[0];
-        const double v43 = static_cast<const double*>(a.col[5])[r];
         const double v44 = (v42 - v43);
         const double v45 = (v41 * v44);
         o.val[0] = x_bits(v45);

@@ -1,25 +1,34 @@
 #include "sdqh_xkernels.hpp"
 using namespace sdqh;
 struct P {
-    static constexpr int NS = 1, NV = 1, NSC = 0, NSOP = 0, ND = 0;
-    struct Regs { uint32_t c0[16]; };
+    static constexpr int NS = 2, NV = 1, NSC = 0, NSOP = 0, ND = 0;
+    struct Regs { uint32_t c0[16]; uint32_t c1[16]; };
     __device__ __forceinline__ static void load_dicts(const XArgs& a, int64_t (*tab)[256]) {
     }
     template <bool TAIL> __device__ __forceinline__ static void sload(const XArgs& a, int64_t r, int64_t nrows, Regs& s) {
         xt_load<8, TAIL>(a.col[0], r, nrows, s.c0);
+        xt_load<8, TAIL>(a.col[1], r, nrows, s.c1);
     }
     __device__ __forceinline__ static bool stest(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i) {
         bool p = true;
         const int64_t v0 = xt_i64(s.c0, i);
-        p = p && x_may_hit(a.tab[0], v0, false);
+        const int64_t v1 = a.ci[0];
+        const bool v2 = (v0 > v1);
+        p = p & v2;
+        const int64_t v3 = xt_i64(s.c1, i);
+        p = p && x_may_hit(a.tab[0], v3, false);
         return p;
     }
     __device__ __forceinline__ static bool spre(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i, uint32_t& widx, uint32_t& bit) {
         bool p = true;
         const int64_t v0 = xt_i64(s.c0, i);
-        const bool in = (v0 >= a.tab[0].bm_lo) & (v0 <= a.tab[0].bm_hi);
+        const int64_t v1 = a.ci[0];
+        const bool v2 = (v0 > v1);
+        p = p & v2;
+        const int64_t v3 = xt_i64(s.c1, i);
+        const bool in = (v3 >= a.tab[0].bm_lo) & (v3 <= a.tab[0].bm_hi);
         p = p & in;
-        const uint64_t off = p ? (uint64_t)(v0 - a.tab[0].bm_lo) : 0ull;
+        const uint64_t off = p ? (uint64_t)(v3 - a.tab[0].bm_lo) : 0ull;
         widx = (uint32_t)(off >> 5); bit = (uint32_t)off & 31u;
         return p;
     }
@@ -28,22 +37,24 @@ struct P {
         off = 0; return false;
     }
     __device__ __forceinline__ static const uint32_t* sbitmap(const XArgs& a) { return x_prefilter_bitmap(a.tab[0], false); }
-    template <int H> __device__ __forceinline__ static bool eval_regs(const XArgs& a, const Pair<int64_t> (&s)[1], int64_t r, XOut<NV>& o) {
+    template <int H> __device__ __forceinline__ static bool eval_regs(const XArgs& a, const Pair<int64_t> (&s)[2], int64_t r, XOut<NV>& o) {
         return false;
     }
     __device__ __forceinline__ static bool eval_row(const XArgs& a, int64_t r, const int64_t (&sres)[1], XOut<NV>& o) {
-        const int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
-        const uint32_t e1 = x_lookup(a.tab[0], v0, false);
-        const bool v1 = (e1 != NO_ROW);
-        if (!v1) return false;
-        const int64_t v2 = static_cast<const int64_t*>(a.col[1])[r];
-        const uint32_t e3 = x_lookup(a.tab[1], v2, false);
-        const bool v3 = (e3 != NO_ROW);
-        if (!v3) return false;
+        int64_t v3 = static_cast<const int64_t*>(a.col[1])[r];
+        x_pin(v3);
+        const uint32_t e4 = x_lookup_l<0x80000043u>(a.tab[0], v3, false);
+        const bool v4 = (e4 != NO_ROW);
+        if (!v4) return false;
+        double v5 = static_cast<const double*>(a.col[2])[r];
+        double v7 = static_cast<const double*>(a.col[3])[r];
+        x_pin(v5, v7);
         o.key = 0; o.bad = false;
-        const double v4 = static_cast<const double*>(a.col[2])[r];
-        o.val[0] = x_bits(v4);
-        o.ent = e3;
+        const double v6 = a.cf[0];
+        const double v8 = (v6 - v7);
+        const double v9 = (v5 * v8);
+        o.val[0] = x_bits(v9);
+        o.ent = e4;
         return true;
     }
 };

@@ -1,0 +1,71 @@
+#include "sdqh_xkernels.hpp"
+using namespace sdqh;
+struct P {
+    static constexpr int NS = 1, NV = 0, NSC = 0, NSOP = 0, ND = 0;
+    struct Regs { uint32_t c0[16]; };
+    __device__ __forceinline__ static void load_dicts(const XArgs& a, int64_t (*tab)[256]) {
+    }
+    template <bool TAIL> __device__ __forceinline__ static void sload(const XArgs& a, int64_t r, int64_t nrows, Regs& s) {
+        xt_load<8, TAIL>(a.col[0], r, nrows, s.c0);
+    }
+    __device__ __forceinline__ static bool stest(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i) {
+        bool p = true;
+        const int64_t v0 = xt_i64(s.c0, i);
+        p = p && x_may_hit(a.tab[0], v0, false);
+        return p;
+    }
+    __device__ __forceinline__ static bool spre(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i, uint32_t& widx, uint32_t& bit) {
+        bool p = true;
+        const int64_t v0 = xt_i64(s.c0, i);
+        const bool in = (v0 >= a.tab[0].bm_lo) & (v0 <= a.tab[0].bm_hi);
+        p = p & in;
+        const uint64_t off = p ? (uint64_t)(v0 - a.tab[0].bm_lo) : 0ull;
+        widx = (uint32_t)(off >> 5); bit = (uint32_t)off & 31u;
+        return p;
+    }
+    static constexpr bool PREF32 = false, PWIN = false;
+    __device__ __forceinline__ static bool spre32(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i, uint32_t& off) {
+        off = 0; return false;
+    }
+    __device__ __forceinline__ static const uint32_t* sbitmap(const XArgs& a) { return x_prefilter_bitmap(a.tab[0], false); }
+    template <int H> __device__ __forceinline__ static bool eval_regs(const XArgs& a, const Pair<int64_t> (&s)[1], int64_t r, XOut<NV>& o) {
+        return false;
+    }
+    __device__ __forceinline__ static bool eval_row(const XArgs& a, int64_t r, const int64_t (&sres)[1], XOut<NV>& o) {
+        int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
+        int64_t v2 = static_cast<const int64_t*>(a.col[1])[r];
+        x_pin(v0, v2);
+        const uint32_t e1 = x_lookup_l<0x80000082u>(a.tab[0], v0, false);
+        const bool v1 = (e1 != NO_ROW);
+        int64_t v5 = x_field(a.tab[0], 0, e1);
+        int64_t v6 = x_field(a.tab[0], 1, e1);
+        int64_t v7 = x_field(a.tab[0], 2, e1);
+        x_pin(v5, v6, v7);
+        if (!v1) return false;
+        const uint32_t e3 = x_lookup_l<0x8000000au>(a.tab[1], v2, false);
+        const bool v3 = (e3 != NO_ROW);
+        const bool v4 = (!v3);
+        if (!v4) return false;
+        const int64_t v8 = a.ci[0];
+        const int64_t v9 = (v5 * v8);
+        const int64_t v10 = (v9 + v6);
+        const int64_t v13 = a.ci[2];
+        const int64_t v14 = (v10 * v13);
+        const int64_t v11 = a.ci[1];
+        const int64_t v12 = (v7 - v11);
+        const int64_t v15 = (v14 + v12);
+        const int64_t v17 = a.ci[3];
+        const int64_t v18 = (v15 * v17);
+        const int64_t v16 = (v2 - v11);
+        const int64_t v19 = (v18 + v16);
+        const uint32_t e20 = x_lookup_l<0x80000000u>(a.tab[2], v19, false);
+        const bool v20 = (e20 != NO_ROW);
+        if (!v20) return false;
+        o.key = 0; o.bad = false;
+        o.ent = e20;
+        return true;
+    }
+};
+extern "C" __global__ __launch_bounds__(256) void xk_probe_agg_tight(XArgs a, XEntry<P::NV>::Args s, int64_t nrows, int64_t seg_rows, int nseg) {
+    x_queue8<P, XEntry, false>(a, s, nrows, seg_rows, nseg);
+}

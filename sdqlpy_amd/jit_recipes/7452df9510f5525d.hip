@@ -1,7 +1,7 @@
 #include "sdqh_xkernels.hpp"
 using namespace sdqh;
 struct P {
-    static constexpr int NS = 2, NV = 2, NSC = 0, NSOP = 0, ND = 0;
+    static constexpr int NS = 2, NV = 1, NSC = 0, NSOP = 0, ND = 0;
     struct Regs { uint32_t c0[4]; uint32_t c1[8]; };
     __device__ __forceinline__ static void load_dicts(const XArgs& a, int64_t (*tab)[256]) {
     }
@@ -45,19 +45,23 @@ struct P {
         return false;
     }
     __device__ __forceinline__ static bool eval_row(const XArgs& a, int64_t r, const int64_t (&sres)[1], XOut<NV>& o) {
-        const int64_t v3 = static_cast<const int64_t*>(a.col[1])[r];
-        const uint32_t e4 = x_lookup(a.tab[0], v3, false);
+        int64_t v3 = (int64_t)static_cast<const int32_t*>(a.ncol[1])[r];
+        x_pin(v3);
+        const uint32_t e4 = x_lookup_l<0x80000082u>(a.tab[0], v3, false);
         const bool v4 = (e4 != NO_ROW);
         if (!v4) return false;
-        o.key = v3; o.bad = false;
-        const double v5 = narrow_decode(static_cast<const int32_t*>(a.ncol[2])[r]);
-        o.val[0] = x_bits(v5);
-        const double v6 = narrow_decode(static_cast<const int32_t*>(a.ncol[3])[r]);
-        o.val[1] = x_bits(v6);
-        o.ent = NO_ROW;
+        double v5 = narrow_decode(static_cast<const int32_t*>(a.ncol[2])[r]);
+        double v7 = narrow_decode(static_cast<const int32_t*>(a.ncol[3])[r]);
+        x_pin(v5, v7);
+        o.key = 0; o.bad = false;
+        const double v6 = a.cf[0];
+        const double v8 = (v6 - v7);
+        const double v9 = (v5 * v8);
+        o.val[0] = x_bits(v9);
+        o.ent = e4;
         return true;
     }
 };
-extern "C" __global__ __launch_bounds__(256) void xk_build_tight(XArgs a, XStage<P::NV>::Args s, int64_t nrows, int64_t seg_rows, int nseg) {
-    x_queue8<P, XStage, true>(a, s, nrows, seg_rows, nseg);
+extern "C" __global__ __launch_bounds__(256) void xk_probe_agg_tight(XArgs a, XEntry<P::NV>::Args s, int64_t nrows, int64_t seg_rows, int nseg) {
+    x_queue8<P, XEntry, false>(a, s, nrows, seg_rows, nseg);
 }

@@ -1,52 +1,61 @@
 #include "sdqh_xkernels.hpp"
 using namespace sdqh;
 struct P {
-    static constexpr int NS = 1, NV = 2, NSC = 0, NSOP = 0, ND = 0;
-    struct Regs { uint32_t c0[2]; };
+    static constexpr int NS = 2, NV = 2, NSC = 0, NSOP = 0, ND = 0;
+    struct Regs { uint32_t c0[4]; uint32_t c1[8]; };
     __device__ __forceinline__ static void load_dicts(const XArgs& a, int64_t (*tab)[256]) {
     }
     template <bool TAIL> __device__ __forceinline__ static void sload(const XArgs& a, int64_t r, int64_t nrows, Regs& s) {
-        xt_load<1, TAIL>(a.code[0], r, nrows, s.c0);
+        xt_load<2, TAIL>(a.code[0], r, nrows, s.c0);
+        xt_load<4, TAIL>(a.ncol[1], r, nrows, s.c1);
     }
     __device__ __forceinline__ static bool stest(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i) {
         bool p = true;
-        const int64_t v0 = ((int64_t)xt_u8(s.c0, i) + a.dlo[0]);
-        p = p && x_may_hit(a.tab[0], v0, false);
+        const bool v2 = (xt_u16(s.c0, i) >= a.cc[0]);
+        p = p & v2;
+        const int64_t v3 = (int64_t)xt_i32(s.c1, i);
+        p = p && x_may_hit(a.tab[0], v3, false);
         return p;
     }
     __device__ __forceinline__ static bool spre(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i, uint32_t& widx, uint32_t& bit) {
         bool p = true;
-        const int64_t v0 = ((int64_t)xt_u8(s.c0, i) + a.dlo[0]);
-        const bool in = (v0 >= a.tab[0].bm_lo) & (v0 <= a.tab[0].bm_hi);
+        const bool v2 = (xt_u16(s.c0, i) >= a.cc[0]);
+        p = p & v2;
+        const int64_t v3 = (int64_t)xt_i32(s.c1, i);
+        const bool in = (v3 >= a.tab[0].bm_lo) & (v3 <= a.tab[0].bm_hi);
         p = p & in;
-        const uint64_t off = in ? (uint64_t)(v0 - a.tab[0].bm_lo) : 0ull;
+        const uint64_t off = in ? (uint64_t)(v3 - a.tab[0].bm_lo) : 0ull;
         widx = (uint32_t)(off >> 5); bit = (uint32_t)off & 31u;
         return p;
     }
     static constexpr bool PREF32 = true, PWIN = false;
     __device__ __forceinline__ static bool spre32(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i, uint32_t& off) {
         bool p = true;
-        const int64_t v0 = ((int64_t)xt_u8(s.c0, i) + a.dlo[0]);
-        const uint32_t o32 = (uint32_t)((int32_t)v0 - (int32_t)a.tab[0].bm_lo);
+        const bool v2 = (xt_u16(s.c0, i) >= a.cc[0]);
+        p = p & v2;
+        const int64_t v3 = (int64_t)xt_i32(s.c1, i);
+        const uint32_t o32 = (uint32_t)((int32_t)v3 - (int32_t)a.tab[0].bm_lo);
         const bool in = o32 <= (uint32_t)(a.tab[0].bm_hi - a.tab[0].bm_lo);
         p = p & in;
         off = in ? o32 : 0u;
         return p;
     }
     __device__ __forceinline__ static const uint32_t* sbitmap(const XArgs& a) { return x_prefilter_bitmap(a.tab[0], false); }
-    template <int H> __device__ __forceinline__ static bool eval_regs(const XArgs& a, const Pair<int64_t> (&s)[1], int64_t r, XOut<NV>& o) {
+    template <int H> __device__ __forceinline__ static bool eval_regs(const XArgs& a, const Pair<int64_t> (&s)[2], int64_t r, XOut<NV>& o) {
         return false;
     }
     __device__ __forceinline__ static bool eval_row(const XArgs& a, int64_t r, const int64_t (&sres)[1], XOut<NV>& o) {
-        const int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
-        const uint32_t e1 = x_lookup(a.tab[0], v0, false);
-        const bool v1 = (e1 != NO_ROW);
-        if (!v1) return false;
-        const int64_t v2 = (int64_t)static_cast<const int32_t*>(a.ncol[1])[r];
-        o.key = v2; o.bad = false;
-        const int64_t v3 = x_field(a.tab[0], 0, e1);
-        o.val[0] = v3;
-        o.val[1] = v0;
+        int64_t v3 = (int64_t)static_cast<const int32_t*>(a.ncol[1])[r];
+        x_pin(v3);
+        const uint32_t e4 = x_lookup_l<0x80000042u>(a.tab[0], v3, false);
+        const bool v4 = (e4 != NO_ROW);
+        if (!v4) return false;
+        double v5 = narrow_decode(static_cast<const int32_t*>(a.ncol[2])[r]);
+        double v6 = narrow_decode(static_cast<const int32_t*>(a.ncol[3])[r]);
+        x_pin(v5, v6);
+        o.key = v3; o.bad = false;
+        o.val[0] = x_bits(v5);
+        o.val[1] = x_bits(v6);
         o.ent = NO_ROW;
         return true;
     }

@@ -33,7 +33,8 @@ struct P {
         const int64_t v5 = (v0 + v4);
         const bool v6 = (v3 > v5);
         if (!v6) return false;
-        const int64_t v7 = static_cast<const int64_t*>(a.col[1])[r];
+        int64_t v7 = static_cast<const int64_t*>(a.col[1])[r];
+        x_pin(v7);
         o.key = v7; o.bad = false;
         o.ent = NO_ROW;
         return true;

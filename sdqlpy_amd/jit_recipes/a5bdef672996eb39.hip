@@ -148,9 +148,10 @@ struct P {
         return false;
     }
     __device__ __forceinline__ static bool eval_row(const XArgs& a, int64_t r, const int64_t (&sres)[1], XOut<NV>& o) {
-        const int64_t v59 = static_cast<const int64_t*>(a.col[3])[r];
+        int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
+        int64_t v59 = static_cast<const int64_t*>(a.col[3])[r];
+        x_pin(v0, v59);
         o.key = v59; o.bad = false;
-        const int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
         o.val[0] = v0;
         o.ent = NO_ROW;
         return true;

@@ -1,7 +1,7 @@
 #include "sdqh_xkernels.hpp"
 using namespace sdqh;
 struct P {
-    static constexpr int NS = 1, NV = 0, NSC = 0, NSOP = 0, ND = 0;
+    static constexpr int NS = 1, NV = 1, NSC = 0, NSOP = 0, ND = 0;
     struct Regs { uint32_t c0[16]; };
     __device__ __forceinline__ static void load_dicts(const XArgs& a, int64_t (*tab)[256]) {
     }
@@ -32,34 +32,23 @@ struct P {
         return false;
     }
     __device__ __forceinline__ static bool eval_row(const XArgs& a, int64_t r, const int64_t (&sres)[1], XOut<NV>& o) {
-        const int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
-        const uint32_t e1 = x_lookup(a.tab[0], v0, false);
+        int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
+        x_pin(v0);
+        const uint32_t e1 = x_lookup_l<0x80000043u>(a.tab[0], v0, false);
         const bool v1 = (e1 != NO_ROW);
         if (!v1) return false;
-        const int64_t v2 = static_cast<const int64_t*>(a.col[1])[r];
-        const uint32_t e3 = x_lookup(a.tab[1], v2, false);
-        const bool v3 = (e3 != NO_ROW);
-        if (!v3) return false;
-        const int64_t v4 = x_hits(a.tab[1], e3);
-        const int64_t v5 = a.ci[0];
-        const bool v6 = (v4 > v5);
-        const bool v7 = (v3 && v6);
-        if (!v7) return false;
-        const double v8 = x_acc(a.tab[1], 0, e3);
-        const double v9 = static_cast<const double*>(a.col[2])[r];
-        const bool v10 = (v8 == v9);
-        if (!v10) return false;
-        const int64_t v11 = a.ci[1];
-        const int64_t v12 = (v2 - v11);
-        const int64_t v14 = a.ci[2];
-        const int64_t v15 = (v12 * v14);
-        const int64_t v13 = (v0 - v11);
-        const int64_t v16 = (v15 + v13);
-        o.key = v16; o.bad = false;
+        double v2 = static_cast<const double*>(a.col[1])[r];
+        double v3 = static_cast<const double*>(a.col[2])[r];
+        x_pin(v2, v3);
+        o.key = 0; o.bad = false;
+        const double v4 = (v2 * v3);
+        const double v5 = a.cf[0];
+        const double v6 = (v4 * v5);
+        o.val[0] = x_bits(v6);
         o.ent = NO_ROW;
         return true;
     }
 };
-extern "C" __global__ __launch_bounds__(256) void xk_group_tight(XArgs a, XGroup<P::NV>::Args s, int64_t nrows, int64_t seg_rows, int nseg) {
-    x_queue8<P, XGroup, false>(a, s, nrows, seg_rows, nseg);
+extern "C" __global__ __launch_bounds__(256) void xk_sum_tight(XArgs a, XSum<P::NV>::Args s, int64_t nrows, int64_t seg_rows, int nseg) {
+    x_queue8<P, XSum, false>(a, s, nrows, seg_rows, nseg);
 }

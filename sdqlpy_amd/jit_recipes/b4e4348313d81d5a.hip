@@ -23,9 +23,11 @@ struct P {
         return false;
     }
     __device__ __forceinline__ static bool eval_row(const XArgs& a, int64_t r, const int64_t (&sres)[1], XOut<NV>& o) {
+        int64_t v2 = static_cast<const int64_t*>(a.col[2])[r];
+        int64_t v9 = static_cast<const int64_t*>(a.col[3])[r];
+        x_pin(v2, v9);
         const bool v1 = (sres[0] != 0);
         if (!v1) return false;
-        const int64_t v2 = static_cast<const int64_t*>(a.col[2])[r];
         const int64_t v3 = a.ci[0];
         const bool v5 = (v2 >= v3);
         const int64_t v4 = a.ci[1];
@@ -33,7 +35,6 @@ struct P {
         const bool v7 = (v5 && v6);
         const bool v8 = (!v7);
         if (!v8) return false;
-        const int64_t v9 = static_cast<const int64_t*>(a.col[3])[r];
         const int64_t v10 = a.ci[2];
         const bool v11 = (v9 == v10);
         const int64_t v12 = a.ci[3];
@@ -58,9 +59,10 @@ struct P {
         const bool v25 = (v9 == v24);
         const bool v32 = (v31 || v25);
         if (!v32) return false;
-        const int64_t v33 = static_cast<const int64_t*>(a.col[4])[r];
+        int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
+        int64_t v33 = static_cast<const int64_t*>(a.col[4])[r];
+        x_pin(v0, v33);
         o.key = v33; o.bad = false;
-        const int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
         o.val[0] = v0;
         o.val[1] = v2;
         o.val[2] = v9;

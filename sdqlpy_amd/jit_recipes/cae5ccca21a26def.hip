@@ -61,19 +61,21 @@ struct P {
         return false;
     }
     __device__ __forceinline__ static bool eval_row(const XArgs& a, int64_t r, const int64_t (&sres)[1], XOut<NV>& o) {
-        const int64_t v9 = static_cast<const int64_t*>(a.col[3])[r];
-        const uint32_t e10 = x_lookup(a.tab[0], v9, false);
+        int64_t v9 = static_cast<const int64_t*>(a.col[3])[r];
+        int64_t v11 = static_cast<const int64_t*>(a.col[4])[r];
+        x_pin(v9, v11);
+        const uint32_t e10 = x_lookup_l<0x80000001u>(a.tab[0], v9, false);
         const bool v10 = (e10 != NO_ROW);
         if (!v10) return false;
-        const int64_t v11 = static_cast<const int64_t*>(a.col[4])[r];
         const int64_t v12 = a.ci[2];
         const bool v13 = (v11 == v12);
         const int64_t v14 = a.ci[3];
         const bool v15 = (v11 == v14);
         const bool v16 = (v13 || v15);
         if (!v16) return false;
+        int64_t v17 = x_field(a.tab[0], 0, e10);
+        x_pin(v17);
         o.key = v11; o.bad = false;
-        const int64_t v17 = x_field(a.tab[0], 0, e10);
         const int64_t v18 = a.ci[4];
         const bool v19 = (v17 == v18);
         const int64_t v20 = a.ci[5];

@@ -1,18 +1,33 @@
 #include "sdqh_xkernels.hpp"
 using namespace sdqh;
 struct P {
-    static constexpr int NS = 0, NV = 0, NSC = 0, NSOP = 0, ND = 0;
-    struct Regs { };
+    static constexpr int NS = 1, NV = 1, NSC = 0, NSOP = 0, ND = 0;
+    struct Regs { uint32_t c0[16]; };
     __device__ __forceinline__ static void load_dicts(const XArgs& a, int64_t (*tab)[256]) {
     }
     template <bool TAIL> __device__ __forceinline__ static void sload(const XArgs& a, int64_t r, int64_t nrows, Regs& s) {
+        xt_load<8, TAIL>(a.col[0], r, nrows, s.c0);
     }
     __device__ __forceinline__ static bool stest(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i) {
         bool p = true;
+        const int64_t v0 = xt_i64(s.c0, i);
+        const int64_t v1 = a.ci[0];
+        const bool v2 = (v0 == v1);
+        const int64_t v3 = a.ci[1];
+        const bool v4 = (v0 == v3);
+        const bool v5 = (v2 || v4);
+        p = p & v5;
         return p;
     }
     __device__ __forceinline__ static bool spre(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i, uint32_t& widx, uint32_t& bit) {
         bool p = true;
+        const int64_t v0 = xt_i64(s.c0, i);
+        const int64_t v1 = a.ci[0];
+        const bool v2 = (v0 == v1);
+        const int64_t v3 = a.ci[1];
+        const bool v4 = (v0 == v3);
+        const bool v5 = (v2 || v4);
+        p = p & v5;
         widx = 0; bit = 0;
         return p;
     }
@@ -25,22 +40,11 @@ struct P {
         return false;
     }
     __device__ __forceinline__ static bool eval_row(const XArgs& a, int64_t r, const int64_t (&sres)[1], XOut<NV>& o) {
-        const int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
-        const int64_t v1 = (v0 / (int64_t)750000ll);
-        const int64_t v11 = a.ci[1];
-        const int64_t v12 = (v1 * v11);
-        const int64_t v2 = (v0 / (int64_t)5000ll);
-        const int64_t v3 = (v2 % (int64_t)150ll);
-        const int64_t v13 = (v12 + v3);
-        const int64_t v15 = a.ci[2];
-        const int64_t v16 = (v13 * v15);
-        const int64_t v4 = (v0 / (int64_t)100ll);
-        const int64_t v5 = (v4 % (int64_t)50ll);
-        const int64_t v6 = a.ci[0];
-        const int64_t v7 = (v5 + v6);
-        const int64_t v14 = (v7 - v6);
-        const int64_t v17 = (v16 + v14);
-        o.key = v17; o.bad = false;
+        int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
+        int64_t v6 = static_cast<const int64_t*>(a.col[1])[r];
+        x_pin(v0, v6);
+        o.key = v6; o.bad = false;
+        o.val[0] = v0;
         o.ent = NO_ROW;
         return true;
     }

@@ -32,38 +32,36 @@ struct P {
         return false;
     }
     __device__ __forceinline__ static bool eval_row(const XArgs& a, int64_t r, const int64_t (&sres)[1], XOut<NV>& o) {
-        const int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
-        const uint32_t e1 = x_lookup(a.tab[0], v0, false);
+        int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
+        int64_t v2 = static_cast<const int64_t*>(a.col[1])[r];
+        double v9 = static_cast<const double*>(a.col[2])[r];
+        x_pin(v0, v2, v9);
+        const uint32_t e1 = x_lookup_l<0x80000043u>(a.tab[0], v0, false);
         const bool v1 = (e1 != NO_ROW);
         if (!v1) return false;
-        const int64_t v2 = static_cast<const int64_t*>(a.col[1])[r];
-        const uint32_t e3 = x_lookup(a.tab[1], v2, false);
+        const uint32_t e3 = x_lookup_l<0x80000043u>(a.tab[1], v2, false);
         const bool v3 = (e3 != NO_ROW);
-        const bool v4 = (!v3);
-        if (!v4) return false;
-        const int64_t v5 = x_field(a.tab[0], 0, e1);
-        const int64_t v8 = a.ci[0];
-        const int64_t v9 = (v5 * v8);
-        const int64_t v6 = x_field(a.tab[0], 1, e1);
-        const int64_t v10 = (v9 + v6);
-        const int64_t v13 = a.ci[2];
-        const int64_t v14 = (v10 * v13);
-        const int64_t v7 = x_field(a.tab[0], 2, e1);
+        int64_t v4 = x_hits_l<0x80000043u>(a.tab[1], e3);
+        double v8 = x_acc_l<0x80000043u>(a.tab[1], 0, e3);
+        x_pin(v4, v8);
+        if (!v3) return false;
+        const int64_t v5 = a.ci[0];
+        const bool v6 = (v4 > v5);
+        const bool v7 = (v3 && v6);
+        if (!v7) return false;
+        const bool v10 = (v8 == v9);
+        if (!v10) return false;
         const int64_t v11 = a.ci[1];
-        const int64_t v12 = (v7 - v11);
-        const int64_t v15 = (v14 + v12);
-        const int64_t v17 = a.ci[3];
-        const int64_t v18 = (v15 * v17);
-        const int64_t v16 = (v2 - v11);
-        const int64_t v19 = (v18 + v16);
-        const uint32_t e20 = x_lookup(a.tab[2], v19, false);
-        const bool v20 = (e20 != NO_ROW);
-        if (!v20) return false;
-        o.key = 0; o.bad = false;
-        o.ent = e20;
+        const int64_t v12 = (v2 - v11);
+        const int64_t v14 = a.ci[2];
+        const int64_t v15 = (v12 * v14);
+        const int64_t v13 = (v0 - v11);
+        const int64_t v16 = (v15 + v13);
+        o.key = v16; o.bad = false;
+        o.ent = NO_ROW;
         return true;
     }
 };
-extern "C" __global__ __launch_bounds__(256) void xk_probe_agg_tight(XArgs a, XEntry<P::NV>::Args s, int64_t nrows, int64_t seg_rows, int nseg) {
-    x_queue8<P, XEntry, false>(a, s, nrows, seg_rows, nseg);
+extern "C" __global__ __launch_bounds__(256) void xk_group_tight(XArgs a, XGroup<P::NV>::Args s, int64_t nrows, int64_t seg_rows, int nseg) {
+    x_queue8<P, XGroup, false>(a, s, nrows, seg_rows, nseg);
 }

@@ -11,43 +11,44 @@ struct P {
     __device__ __forceinline__ static bool stest(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i) {
         bool p = true;
         const int64_t v0 = xt_i64(s.c0, i);
-        const int64_t v1 = a.ci[0];
-        const bool v2 = (v0 == v1);
-        const int64_t v3 = a.ci[1];
-        const bool v4 = (v0 == v3);
-        const bool v5 = (v2 || v4);
-        p = p & v5;
+        p = p && x_may_hit(a.tab[0], v0, false);
         return p;
     }
     __device__ __forceinline__ static bool spre(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i, uint32_t& widx, uint32_t& bit) {
         bool p = true;
         const int64_t v0 = xt_i64(s.c0, i);
-        const int64_t v1 = a.ci[0];
-        const bool v2 = (v0 == v1);
-        const int64_t v3 = a.ci[1];
-        const bool v4 = (v0 == v3);
-        const bool v5 = (v2 || v4);
-        p = p & v5;
-        widx = 0; bit = 0;
+        const bool in = (v0 >= a.tab[0].bm_lo) & (v0 <= a.tab[0].bm_hi);
+        p = p & in;
+        const uint64_t off = p ? (uint64_t)(v0 - a.tab[0].bm_lo) : 0ull;
+        widx = (uint32_t)(off >> 5); bit = (uint32_t)off & 31u;
         return p;
     }
     static constexpr bool PREF32 = false, PWIN = false;
     __device__ __forceinline__ static bool spre32(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i, uint32_t& off) {
         off = 0; return false;
     }
-    __device__ __forceinline__ static const uint32_t* sbitmap(const XArgs& a) { return nullptr; }
+    __device__ __forceinline__ static const uint32_t* sbitmap(const XArgs& a) { return x_prefilter_bitmap(a.tab[0], false); }
     template <int H> __device__ __forceinline__ static bool eval_regs(const XArgs& a, const Pair<int64_t> (&s)[1], int64_t r, XOut<NV>& o) {
         return false;
     }
     __device__ __forceinline__ static bool eval_row(const XArgs& a, int64_t r, const int64_t (&sres)[1], XOut<NV>& o) {
-        const int64_t v6 = static_cast<const int64_t*>(a.col[1])[r];
-        o.key = v6; o.bad = false;
-        const int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
-        o.val[0] = v0;
-        o.ent = NO_ROW;
+        int64_t v0 = static_cast<const int64_t*>(a.col[0])[r];
+        int64_t v2 = static_cast<const int64_t*>(a.col[1])[r];
+        x_pin(v0, v2);
+        const uint32_t e1 = x_lookup_l<0x80000043u>(a.tab[0], v0, false);
+        const bool v1 = (e1 != NO_ROW);
+        if (!v1) return false;
+        const uint32_t e3 = x_lookup_l<0x80000043u>(a.tab[1], v2, false);
+        const bool v3 = (e3 != NO_ROW);
+        if (!v3) return false;
+        double v4 = static_cast<const double*>(a.col[2])[r];
+        x_pin(v4);
+        o.key = 0; o.bad = false;
+        o.val[0] = x_bits(v4);
+        o.ent = e3;
         return true;
     }
 };
-extern "C" __global__ __launch_bounds__(256) void xk_build_tight(XArgs a, XStage<P::NV>::Args s, int64_t nrows, int64_t seg_rows, int nseg) {
-    x_queue8<P, XStage, true>(a, s, nrows, seg_rows, nseg);
+extern "C" __global__ __launch_bounds__(256) void xk_probe_agg_tight(XArgs a, XEntry<P::NV>::Args s, int64_t nrows, int64_t seg_rows, int nseg) {
+    x_queue8<P, XEntry, false>(a, s, nrows, seg_rows, nseg);
 }

@@ -6,6 +6,7 @@
 R=${1:-r05}
 OUT=gpurun_out/$R/recipes
 rm -rf $OUT /tmp/jit_empty; mkdir -p $OUT
+rm -f sdqlpy_amd/jit_recipes/*.hip          # (this box's copy of the tree: smoke()'s build() would compile the kept ones again, and so keep the stale among them)
 export SDQLPY_AMD_JIT_RECIPES=$OUT SDQLPY_AMD_JIT_CACHE=/tmp/jit_empty
 python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 --steady-steps 0 > /dev/null 2> $OUT/../recipes_bench.err
 python3 bench.py --force-dist --no-cpu-baseline --steps 3 --warmup 1 --steady-steps 0 > /dev/null 2> $OUT/../recipes_bench_dist.err      # the partitioned join's programs (rebuild with a gate, the probe side's stage)

@@ -1351,6 +1351,9 @@ __device__ __forceinline__ void stage_store(const DevStage& st, int64_t pos, int
     if (st.bm) {
         uint64_t off;
         if (bm_locate(st, key, off)) {
+#if defined(XS_EXP) && (XS_EXP & 1)
+            if (key == -12345)                                // (timing experiment of the specialised builds: no bitmap atomics)
+#endif
             atomicOr(&st.bm[off >> 5], 1u << (off & 31));     // fire and forget; duplicates show up as distinct < staged (k_rank_words)
             // grouped layout: off = the high part's offset (bm_shift 32, no rectangle).  opens_run false: the caller knows the entry stored just
             // before this one (the wave's previous kept lane) has the same high part — the run's first stage row is not this one
@@ -2783,6 +2786,9 @@ __global__ __launch_bounds__(BT) void k_lookup_agg(DevFilter f, DevLookups L, De
     __shared__ int s_map[LG_SLOTS];
     __shared__ int s_flags[1];
     for (int i = threadIdx.x; i < LG_SLOTS; i += BT) { s_keys[i] = EMPTY_GROUP; s_cnt[i] = 0; for (int k = 0; k < NVS; ++k) s_acc[i][k] = 0.0; s_map[i] = -1; }
+    // (this workgroup's column of the partial counts is zeroed now, under the streaming; the epilogue stores the slots it has rows for
+    //  and nothing else — sdqh_xkernels.hpp XGroup::init; thread i zeroes and later writes slot i)
+    for (int i = threadIdx.x; i < LG_SLOTS; i += BT) pcnt[(size_t)i * gridDim.x + blockIdx.x] = 0;
     if (threadIdx.x == 0) s_flags[0] = 0;
     __syncthreads();
     constexpr bool COARSE = BT != TPB;                                   // the coarse key filter exists in the wide-workgroup instance only (compile-time: a run-time
@@ -2943,10 +2949,11 @@ __global__ __launch_bounds__(BT) void k_lookup_agg(DevFilter f, DevLookups L, De
     __syncthreads();
     for (int i = threadIdx.x; i < LG_SLOTS; i += BT) {
         const int l = s_map[i];
+        if (l < 0) continue;                                              // (its count is zero since the prologue; the merge adds where the count is positive)
         const size_t e = (size_t)i * gridDim.x + blockIdx.x;
-        pcnt[e] = l >= 0 ? (int64_t)s_cnt[l] : 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pacc[e * 4 + k] = (l >= 0 && k < NV) ? s_acc[l][k < NVS ? k : 0] : 0.0;
+        for (int k = 0; k < 4; ++k) pacc[e * 4 + k] = k < NV ? s_acc[l][k < NVS ? k : 0] : 0.0;
+        pcnt[e] = (int64_t)s_cnt[l];
     }
     if (threadIdx.x == 0 && s_flags[0]) atomicOr(flags, s_flags[0]);
 }

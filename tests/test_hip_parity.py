@@ -102,6 +102,37 @@ def test_q1_q6_are_bit_reproducible(hip_engine):
     hip_engine.clear()
 
 
+def test_every_table_layout_gives_the_same_rows(hip_engine, oracle_engine):
+    """A drained row's lookups are compiled for the LAYOUT of the table they read (csrc/sdqh_xkernels.hpp x_lookup_l: dense array,
+    bitmap + rank, row index, linearised rectangle, grouped runs, open addressing behind a bitmap or bare), which the build chooses from
+    the data: the join queries with each family of direct layouts switched off in turn — down to every table an open-addressing one —
+    and with the run-time form of the lookups (SDQLPY_AMD_X_NOLAYOUT is read once per process, so that leg is the options' only) give
+    the rows of the CPU implementation."""
+    qs = ["q3", "q5", "q9", "q10", "q2", "q7", "q12"]
+    db = tpch.generate(0.5, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+    want = {}
+    for q in qs:
+        r = helpers.run_query(oracle_engine, q, db)
+        want[q] = helpers.result_rows(r, r.columns)
+    oracle_engine.clear()
+    configs = [{}, {"row_index": 0}, {"grouped_index": 0}, {"row_index": 0, "grouped_index": 0}, {"direct_index": 0, "row_index": 0, "grouped_index": 0}]
+    try:
+        for cfg in configs:
+            for k, v in cfg.items():
+                hip_engine.ctx.set_option(k, v)
+            hip_engine.clear()
+            for q in qs:
+                for _ in range(2):                                   # (the second run of a plan takes its deferred / recorded route)
+                    r = helpers.run_query(hip_engine, q, db)
+                    helpers.assert_rows_match(helpers.result_rows(r, r.columns), want[q], 1e-9, "%s under %r" % (q, cfg))
+            for k in cfg:
+                hip_engine.ctx.set_option(k, 1)
+    finally:
+        for k in ("direct_index", "row_index", "grouped_index"):
+            hip_engine.ctx.set_option(k, 1)
+        hip_engine.clear()
+
+
 def test_narrow_twins_change_no_bit(hip_engine, oracle_engine):
     """Streamed columns are read through 4-byte twins only when every row of the twin decodes to the
     column's value bit for bit.  (1) TPCH data: every query that streams through twins returns the SAME bits with

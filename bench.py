@@ -565,6 +565,12 @@ def main(argv=None, hooks=None):
             "first_pass_upload": {"bytes": uploaded_bytes, "GBs_including_plan_lowering": round(uploaded_bytes / first_pass_s / 1e9, 2) if first_pass_s > 0 else None},
         }
         out["engine_stats"] = eng.stats() if hasattr(eng, "stats") else None      # loops that ran on the host (none in the configured queries), plan graphs, resident bytes
+        try:                                                   # what the process holds of the GPU's HBM after the timed region: columns at the reference's widths,
+            import torch                                       # their twins and dictionaries, the pools' table memory, recorded plans, the runtime's own
+            free_b, total_b = torch.cuda.mem_get_info(int(os.environ.get("LOCAL_RANK", "0")) if use_dist else 0)
+            out["hbm"] = {"in_use_GB": round((total_b - free_b) / 1e9, 2), "of_GB": round(total_b / 1e9, 1), "columns_at_reference_width_GB": round(eng.resident_bytes / 1e9, 2)}
+        except Exception as exc:                               # (reporting only)
+            out["hbm"] = {"error": str(exc)[:100]}
         if steady is not None:
             out["steady_state"] = steady
         if reference_width is not None:

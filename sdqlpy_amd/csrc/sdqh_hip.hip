@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -549,6 +550,15 @@ int sdqh_create(int device, sdqh_ctx** out) {
     ok = ok && hipHostMalloc(&ctx->result_host, RESULT_BYTES, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipMalloc(&ctx->result_dev, RESULT_BYTES) == hipSuccess;
     if (!ok) { sdqh_destroy(ctx); return SDQH_ERR_DEVICE; }
+    // The runtime loads this library's code object (a few hundred kernels, 14 MB) at the FIRST launch of one of them: 35-40 ms inside
+    // whatever call happens to be first — the first query's first kernel, behind its uploads (34 of Q1's first 135 ms at SF=10).  An
+    // empty fill here moves that to the creation of the process's first context, where nothing waits for it.
+    static std::atomic<bool> warmed{false};
+    if (!warmed.exchange(true)) {
+        DevFillBig none; std::memset(&none, 0, sizeof(none));
+        hipLaunchKernelGGL(k_fill, dim3(1), dim3(TPB), 0, ctx->stream, none);
+        (void)hipGetLastError();
+    }
     *out = ctx;
     return SDQH_OK;
 }

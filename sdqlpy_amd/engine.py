@@ -210,6 +210,7 @@ class Engine:
         self._frozen.clear()
         self._range_cache.clear()
         self._distinct_cache.clear()
+        self.__dict__.get("_dict_futures", {}).clear()        # (a pass still running finishes into nothing: its arrays stay alive in the task)
         self.resident_bytes = 0
         self.generation += 1
 
@@ -271,6 +272,7 @@ class Engine:
             if hit is not None and hit[0] is arr:
                 hit[1].free()
                 self.resident_bytes -= arr.nbytes
+            self.__dict__.get("_dict_futures", {}).pop(key, None)
             d = self._dicts.pop(key, None)
             if d is not None and d[1] is not None:
                 self.invalidate(d[1])                        # the code column built from it
@@ -297,7 +299,11 @@ class Engine:
         hit = self._dicts.get(id(arr))
         if hit is None or hit[0] is not arr:
             from . import loader
-            enc = loader.dict_encode(arr, max_distinct)          # native hash pass; None = too many distinct values
+            pending = self.__dict__.setdefault("_dict_futures", {}).pop(id(arr), None)
+            if pending is not None and pending[0] is arr and pending[2] == max_distinct:
+                enc = pending[1].result()                        # started when the plan was bound (prefetch_dicts), beside the uploads
+            else:
+                enc = loader.dict_encode(arr, max_distinct)      # native hash pass; None = too many distinct values
             if enc is not None:
                 from .result import Dictionary
                 enc = (enc[0], np.asarray(enc[1]).view(Dictionary))          # tagged: its entries are pairwise distinct
@@ -305,6 +311,46 @@ class Engine:
         if hit[1] is None:
             return None
         return self.column(hit[1]), hit[2]
+
+    def prefetch_dicts(self, plan, tables, max_distinct=4096):
+        """Start the host-side dictionary pass (loader.dict_encode: a native hash pass over every row) of the text columns a plan NAMES,
+        in the background: binding the plan uploads its numeric columns next — 70 of Q1's first 145 ms at SF=10, during which the two
+        flag columns' 29 ms of encoding now run too (ctypes releases the GIL on both).  dict_column picks the result up; a column the
+        plan names but never needs coded costs idle cores a pass and nothing else."""
+        min_rows = self.__dict__.get("prefetch_dict_rows")
+        if min_rows is None:
+            min_rows = self.__dict__["prefetch_dict_rows"] = int(os.environ.get("SDQLPY_AMD_PREFETCH_DICT_ROWS", 1 << 20))      # (< 0: off)
+        if min_rows < 0:
+            return
+        from . import loader
+        futures = self.__dict__.setdefault("_dict_futures", {})
+        seen, stack = set(), list(getattr(plan, "ops", []))
+        names = {}                                               # column names mentioned anywhere in the plan's loops
+        while stack:
+            x = stack.pop()
+            if id(x) in seen or isinstance(x, (str, bytes, int, float, bool, type(None), np.ndarray)):
+                continue
+            seen.add(id(x))
+            if isinstance(x, (list, tuple, set, frozenset)):
+                stack.extend(x)
+                continue
+            if isinstance(x, dict):
+                stack.extend(x.values())
+                continue
+            if isinstance(x, Col):
+                names.setdefault(None, set()).add(x.name)
+            if hasattr(x, "__dict__"):
+                stack.extend(vars(x).values())
+        wanted = names.get(None, set())
+        for t in tables.values():
+            for cname, arr in t.cols.items():
+                if cname in wanted and isinstance(arr, np.ndarray) and arr.dtype.kind == "U" and arr.ndim == 1 and len(arr) >= min_rows \
+                        and id(arr) not in self._dicts and id(arr) not in futures:
+                    pool = self.__dict__.get("_dict_pool")
+                    if pool is None:
+                        from concurrent.futures import ThreadPoolExecutor
+                        pool = self.__dict__["_dict_pool"] = ThreadPoolExecutor(max_workers=2, thread_name_prefix="sdqlpy-dict")
+                    futures[id(arr)] = (arr, pool.submit(loader.dict_encode, arr, max_distinct), max_distinct)
 
     def adopt(self, arr, col):
         """Register an already-resident column for a host array identity (multi-GPU exchange buffers)."""
@@ -1910,6 +1956,7 @@ class PreparedPlan:
         self.steps = []
         self._graphs, self._graph_refused, self._deferred_runs = [], None, 0
         getattr(eng, "_eng", eng)._prepared.add(self)
+        getattr(eng, "_eng", eng).prefetch_dicts(plan, tables)
         self.defer_names = self._defer_names(plan)
         for op in plan.ops:
             if isinstance(op, ScanOp):

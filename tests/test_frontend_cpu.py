@@ -222,3 +222,35 @@ def test_reference_text_runs_against_goldens_when_the_reference_is_here():
         assert n == 12
     finally:
         eng.close()
+
+
+def test_dictionary_passes_started_when_a_plan_is_bound_change_no_row(oracle_lib):
+    """Engine.prefetch_dicts: the host-side dictionary pass of the text columns a plan names starts in the background when the plan is
+    bound (beside the uploads) and dict_column picks its result up — the rows are those of the pass made on demand, a column named but
+    never coded costs nothing but the pass, and invalidating a table forgets what was started for it."""
+    import helpers
+    from sdqlpy_amd import engine, tpch
+    qs = ("q1", "q4", "q12")
+    db = tpch.generate(0.05, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs), threads=2)
+    eng = engine.Engine(oracle_lib.context(threads=2))
+    try:
+        rows = {}
+        for min_rows in (-1, 0):
+            eng.prefetch_dict_rows = min_rows
+            for q in qs:
+                r = helpers.run_query(eng, q, db)
+                rows.setdefault(q, []).append(helpers.result_rows(r, r.columns))
+                if min_rows == 0 and q == "q4":
+                    prio = dict(zip(db["orders"].getContainer()["headers"], db["orders"].getContainer()["data"]))["o_orderpriority"]
+                    assert id(prio) in eng._dicts and id(prio) not in eng._dict_futures, "q4 groups by the priority's code: the pass started for it must have been picked up"
+            started = len(eng.__dict__.get("_dict_futures", {}))
+            eng.invalidate(db["lineitem"])
+            assert all(f[0] is not a for f in eng.__dict__.get("_dict_futures", {}).values() for a in db["lineitem"].getContainer()["data"])
+            eng.clear()
+            assert not eng.__dict__.get("_dict_futures")
+            assert min_rows == 0 or started == 0
+        for q in qs:
+            assert rows[q][0] == rows[q][1], q
+    finally:
+        eng.clear()
+        eng.ctx.close()

@@ -424,6 +424,13 @@ def main(argv=None, hooks=None):
         steady = {"steps": args.steady_steps, "ms_per_step": round(took_long / args.steady_steps * 1e3, 4), "seconds": round(took_long, 3)}
     # one finished result per query of the step, kept for the comparison with the CPU implementation's results on the same tables
     hip_results = {q: finish(run_query(q)) for q in queries} if (world == 1 and not args.no_cpu_baseline) else {}
+    hbm = None
+    try:                                                       # what the process holds of the GPU's HBM behind the timed region: columns at the reference's widths,
+        import torch                                           # their twins and dictionaries, the pools' table memory, recorded plans, the runtime's own
+        free_b, total_b = torch.cuda.mem_get_info(int(os.environ.get("LOCAL_RANK", "0")) if use_dist else 0)
+        hbm = {"in_use_GB": round((total_b - free_b) / 1e9, 2), "of_GB": round(total_b / 1e9, 1), "columns_at_reference_width_GB": round(int(eng.resident_bytes) / 1e9, 2)}
+    except Exception as exc:                                   # (reporting only)
+        hbm = {"error": str(exc)[:100]}
     reference_width = None
     if world == 1 and not use_dist and "engine" not in hooks and not args.no_reference_width:
         reference_width = reference_width_leg(args, eng, db, rows, queries + extra, run_query, run_steps, finish)
@@ -565,12 +572,7 @@ def main(argv=None, hooks=None):
             "first_pass_upload": {"bytes": uploaded_bytes, "GBs_including_plan_lowering": round(uploaded_bytes / first_pass_s / 1e9, 2) if first_pass_s > 0 else None},
         }
         out["engine_stats"] = eng.stats() if hasattr(eng, "stats") else None      # loops that ran on the host (none in the configured queries), plan graphs, resident bytes
-        try:                                                   # what the process holds of the GPU's HBM after the timed region: columns at the reference's widths,
-            import torch                                       # their twins and dictionaries, the pools' table memory, recorded plans, the runtime's own
-            free_b, total_b = torch.cuda.mem_get_info(int(os.environ.get("LOCAL_RANK", "0")) if use_dist else 0)
-            out["hbm"] = {"in_use_GB": round((total_b - free_b) / 1e9, 2), "of_GB": round(total_b / 1e9, 1), "columns_at_reference_width_GB": round(eng.resident_bytes / 1e9, 2)}
-        except Exception as exc:                               # (reporting only)
-            out["hbm"] = {"error": str(exc)[:100]}
+        out["hbm"] = hbm
         if steady is not None:
             out["steady_state"] = steady
         if reference_width is not None:

@@ -133,6 +133,35 @@ def test_every_table_layout_gives_the_same_rows(hip_engine, oracle_engine):
         hip_engine.clear()
 
 
+def test_dictionary_passes_started_with_the_plan_change_no_row(hip_engine):
+    """Engine.prefetch_dicts on the HIP engine (where Q1's flag columns ARE coded: the tight kernels stream their codes): the rows with
+    the passes started in the background when the plan is bound are the rows with every pass made on demand, bit for bit (Q1, Q4: fixed
+    orders of addition), and nothing started is left behind."""
+    qs = ["q1", "q4", "q12"]
+    db = tpch.generate(0.3, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+    rows = {}
+    saved = hip_engine.__dict__.get("prefetch_dict_rows")
+    try:
+        for min_rows in (-1, 0):
+            hip_engine.prefetch_dict_rows = min_rows
+            for q in qs:
+                r = helpers.run_query(hip_engine, q, db)
+                rows.setdefault(q, []).append(helpers.result_rows(r, r.columns))
+            if min_rows == 0:
+                li = dict(zip(db["lineitem"].getContainer()["headers"], db["lineitem"].getContainer()["data"]))
+                assert id(li["l_returnflag"]) in hip_engine._dicts and id(li["l_returnflag"]) not in hip_engine._dict_futures
+            hip_engine.clear()
+            assert not hip_engine.__dict__.get("_dict_futures")
+        for q in qs:
+            assert rows[q][0] == rows[q][1], q
+    finally:
+        if saved is None:
+            hip_engine.__dict__.pop("prefetch_dict_rows", None)
+        else:
+            hip_engine.prefetch_dict_rows = saved
+        hip_engine.clear()
+
+
 def test_narrow_twins_change_no_bit(hip_engine, oracle_engine):
     """Streamed columns are read through 4-byte twins only when every row of the twin decodes to the
     column's value bit for bit.  (1) TPCH data: every query that streams through twins returns the SAME bits with

@@ -198,7 +198,8 @@ void*       sdqh_stream(const sdqh_ctx* ctx);
  * "dense_increasing" (1), "rank_increasing" (1), "fuse_small" (1), "fill_ahead" (1: a fill launch also clears the free blocks later builds will want cleared), "lds_key_set" (1: membership builds on keys in no row
  * order through per-workgroup bitmaps in LDS), "feature_min_rows" (2^20: the row count from which twins, packs and the wide
  * instances are used; the tests set 0), "str_rows", "lookup_debug" (cut points of k_lookup_agg for measurements: results ARE
- * wrong with it).
+ * wrong with it); round 5: "cluster_pack" (1: the row pack of a final loop whose first lookup's key column comes in no row order is
+ * built in the stable order of that key and the loop runs over pack rows; 0 = never, 2 = whatever the key's order).
  * The CPU build accepts and ignores any name. */
 int         sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value);
 

@@ -163,9 +163,141 @@ __global__ __launch_bounds__(TPB) void k_unpack_chunks(DevChunkUnpack u) {
     }
 }
 
+// ---- clustered row pack (round 5): a loop's gathered columns laid out in the ORDER OF ITS FIRST LOOKUP'S KEY ------------------------------
+// A final loop whose first lookup is keyed by a column that comes in no row order (Q9: l_partkey against the (part, supplier) table of the
+// green parts) tests one bitmap word per ROW — its own L2 request each — and its survivors touch the looked-up table's index, runs and
+// their own pack rows at random: 64-byte sectors for 8-16 useful bytes (2.07 GB moved for 0.4 GB of use at SF=10).  The row pack is a
+// resident, loop-specific copy already; built in the order of that key instead of row order, the streamed key is clustered (a wave's
+// 128 keys share a bitmap word or two), survivors are RUNS of neighbouring pack rows, and the first table's index and entries are walked
+// front to back.  What stays random is what the other lookups reach (Q9: the orders index).  The order is a stable LSD radix sort of
+// (key - lo, row) on 8-bit digits: per-wave digit counts -> exclusive scan (digit-major) -> every wave places its rows in row order, so
+// equal keys keep their row order and the pack — with it the order of every floating-point sum over it — is the same in every run.
+constexpr int RS_ROWS = 4096;                        // rows a wave counts / places per pass
+constexpr int RS_SCAN = TPB * 8;                     // counters a workgroup of the scan folds
+
+__global__ __launch_bounds__(TPB) void k_rs_init(const int32_t* __restrict__ twin, int64_t lo, int64_t n, uint32_t* __restrict__ key, uint32_t* __restrict__ row) {
+    for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r < n; r += (int64_t)gridDim.x * TPB) { key[r] = (uint32_t)((int64_t)twin[r] - lo); row[r] = (uint32_t)r; }
+}
+__global__ __launch_bounds__(TPB) void k_rs_hist(const uint32_t* __restrict__ key, int64_t n, int shift, uint32_t* __restrict__ hist, int64_t nw) {
+    __shared__ unsigned int s_cnt[TPB / WAVE][256];
+    const int wv = (int)(threadIdx.x / WAVE), lane = (int)(threadIdx.x & (WAVE - 1));
+    for (int d = lane; d < 256; d += WAVE) s_cnt[wv][d] = 0;
+    const int64_t w = (int64_t)blockIdx.x * (TPB / WAVE) + wv;
+    if (w >= nw) return;
+    const int64_t r0 = w * RS_ROWS, r1 = min(n, r0 + RS_ROWS);
+    for (int64_t r = r0 + lane; r < r1; r += WAVE) atomicAdd(&s_cnt[wv][(key[r] >> shift) & 255u], 1u);
+    for (int d = lane; d < 256; d += WAVE) hist[(int64_t)d * nw + w] = s_cnt[wv][d];
+}
+// exclusive scan of `total` counters: local part (in place) + one sum per workgroup ...
+__global__ __launch_bounds__(TPB) void k_rs_scan_local(uint32_t* __restrict__ v, int64_t total, uint32_t* __restrict__ bsum) {
+    __shared__ unsigned int s_part[TPB];
+    const int64_t base = (int64_t)blockIdx.x * RS_SCAN + (int64_t)threadIdx.x * 8;
+    uint32_t x[8]; uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { x[j] = base + j < total ? v[base + j] : 0u; sum += x[j]; }
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < TPB; off <<= 1) {
+        const uint32_t a = (int)threadIdx.x >= off ? s_part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_part[threadIdx.x] += a;
+        __syncthreads();
+    }
+    uint32_t run = s_part[threadIdx.x] - sum;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { if (base + j < total) v[base + j] = run; run += x[j]; }
+    if (threadIdx.x == TPB - 1) bsum[blockIdx.x] = s_part[TPB - 1];
+}
+// ... and the workgroup sums, by ONE workgroup, in place
+__global__ __launch_bounds__(TPB) void k_rs_scan_top(uint32_t* __restrict__ bsum, int64_t nb) {
+    __shared__ unsigned int s_part[TPB];
+    const int64_t per = (nb + TPB - 1) / TPB, b0 = (int64_t)threadIdx.x * per, b1 = min(nb, b0 + per);
+    uint32_t sum = 0;
+    for (int64_t b = b0; b < b1; ++b) sum += bsum[b];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < TPB; off <<= 1) {
+        const uint32_t a = (int)threadIdx.x >= off ? s_part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_part[threadIdx.x] += a;
+        __syncthreads();
+    }
+    uint32_t run = s_part[threadIdx.x] - sum;
+    for (int64_t b = b0; b < b1; ++b) { const uint32_t c = bsum[b]; bsum[b] = run; run += c; }
+}
+// every wave places its rows, 64 at a time in row order: a lane's place = its digit's cursor + the lanes below it with the same digit
+__global__ __launch_bounds__(TPB) void k_rs_scatter(const uint32_t* __restrict__ key, const uint32_t* __restrict__ row, int64_t n, int shift,
+                                                    const uint32_t* __restrict__ hist, const uint32_t* __restrict__ bsum, int64_t nw,
+                                                    uint32_t* __restrict__ key_out, uint32_t* __restrict__ row_out) {
+    __shared__ unsigned int s_at[TPB / WAVE][256];
+    const int wv = (int)(threadIdx.x / WAVE), lane = (int)(threadIdx.x & (WAVE - 1));
+    const int64_t w = (int64_t)blockIdx.x * (TPB / WAVE) + wv;
+    if (w >= nw) return;
+    for (int d = lane; d < 256; d += WAVE) { const int64_t i = (int64_t)d * nw + w; s_at[wv][d] = hist[i] + bsum[i / RS_SCAN]; }
+    const uint64_t lt = lanemask_lt();
+    const int64_t r0 = w * RS_ROWS, r1 = min(n, r0 + RS_ROWS);
+    for (int64_t b = r0; b < r1; b += WAVE) {
+        const int64_t r = b + lane;
+        const bool live = r < r1;
+        const uint32_t k = live ? key[r] : 0u, id = live ? row[r] : 0u;
+        const uint32_t d = (k >> shift) & 255u;
+        uint64_t same = __ballot(live);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) { const uint64_t m = __ballot((d >> bit) & 1u); same &= ((d >> bit) & 1u) ? m : ~m; }
+        if (live) {
+            const uint32_t at = s_at[wv][d] + (uint32_t)__popcll(same & lt);
+            key_out[at] = k; row_out[at] = id;
+        }
+        if (live && !(same & lt)) s_at[wv][d] += (uint32_t)__popcll(same);         // (the lowest lane of each digit; a wave's LDS accesses keep their order)
+    }
+}
+// pack[i * k + j] = col[j][row[i]] (j >= ncols: padding), key32[i] = twin[row[i]]
+struct DevPackPerm { const int64_t* col[MAX_PACK]; int32_t ncols, k; };
+__global__ __launch_bounds__(TPB) void k_interleave_perm(DevPackPerm c, const uint32_t* __restrict__ row, const int32_t* __restrict__ twin, int64_t n, int64_t* __restrict__ out, int32_t* __restrict__ key32) {
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+        const uint32_t r = row[i];
+        int64_t v[MAX_PACK];
+#pragma unroll
+        for (int j = 0; j < MAX_PACK; ++j) v[j] = j < c.ncols ? c.col[j][r] : 0;
+#pragma unroll
+        for (int j = 0; j < MAX_PACK; ++j) if (j < c.k) out[i * c.k + j] = v[j];
+        key32[i] = twin[r];
+    }
+}
+
 }  // namespace
 
 namespace sdqh_host {
+int cluster_pack_build(sdqh_ctx* ctx, const int32_t* twin, int64_t lo, int64_t hi, int64_t n, const void* const* cols, int ncols, int k, void* pack_out, void* key32_out) {
+    if (n < 1 || n >= ((int64_t)1 << 32) || hi < lo || (uint64_t)(hi - lo) > 0xFFFFFFFFull || ncols > MAX_PACK || ctx->capturing) return SDQH_ERR_UNSUPPORTED;
+    const int64_t nw = (n + RS_ROWS - 1) / RS_ROWS, total = nw * 256, nb = (total + RS_SCAN - 1) / RS_SCAN;
+    uint32_t* buf[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (auto& b : buf) b = static_cast<uint32_t*>(pool_alloc(ctx, (size_t)n * 4 + 64));
+    uint32_t* hist = static_cast<uint32_t*>(pool_alloc(ctx, (size_t)total * 4 + 64));
+    uint32_t* bsum = static_cast<uint32_t*>(pool_alloc(ctx, (size_t)nb * 4 + 64));
+    auto release = [&]() { for (auto b : buf) if (b) pool_free(ctx, b); if (hist) pool_free(ctx, hist); if (bsum) pool_free(ctx, bsum); };
+    if (!buf[0] || !buf[1] || !buf[2] || !buf[3] || !hist || !bsum) { release(); return SDQH_ERR_NOMEM; }
+    const unsigned wide = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + TPB - 1) / TPB, (int64_t)ctx->num_cu * 16));
+    const unsigned wgrid = (unsigned)((nw + TPB / WAVE - 1) / (TPB / WAVE));
+    { KernelScope _ks(ctx, "k_rs_init"); hipLaunchKernelGGL(k_rs_init, dim3(wide), dim3(TPB), 0, ctx->stream, twin, lo, n, buf[0], buf[1]); }
+    uint32_t *ka = buf[0], *ra = buf[1], *kb = buf[2], *rb = buf[3];
+    const uint64_t range = (uint64_t)(hi - lo);
+    for (int shift = 0; shift < 32 && (shift == 0 || (range >> shift) != 0); shift += 8) {
+        { KernelScope _ks(ctx, "k_rs_hist"); hipLaunchKernelGGL(k_rs_hist, dim3(wgrid), dim3(TPB), 0, ctx->stream, ka, n, shift, hist, nw); }
+        { KernelScope _ks(ctx, "k_rs_scan_local"); hipLaunchKernelGGL(k_rs_scan_local, dim3((unsigned)nb), dim3(TPB), 0, ctx->stream, hist, total, bsum); }
+        { KernelScope _ks(ctx, "k_rs_scan_top"); hipLaunchKernelGGL(k_rs_scan_top, dim3(1), dim3(TPB), 0, ctx->stream, bsum, nb); }
+        { KernelScope _ks(ctx, "k_rs_scatter"); hipLaunchKernelGGL(k_rs_scatter, dim3(wgrid), dim3(TPB), 0, ctx->stream, ka, ra, n, shift, hist, bsum, nw, kb, rb); }
+        std::swap(ka, kb); std::swap(ra, rb);
+    }
+    DevPackPerm pc; std::memset(&pc, 0, sizeof(pc));
+    for (int j = 0; j < ncols; ++j) pc.col[j] = static_cast<const int64_t*>(cols[j]);
+    pc.ncols = ncols; pc.k = k;
+    { KernelScope _ks(ctx, "k_interleave_perm"); hipLaunchKernelGGL(k_interleave_perm, dim3(wide), dim3(TPB), 0, ctx->stream, pc, ra, twin, n, static_cast<int64_t*>(pack_out), static_cast<int32_t*>(key32_out)); }
+    const bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;      // once per pack: its scratch goes back to a pool the side streams draw from too
+    release();
+    return ok ? SDQH_OK : SDQH_ERR_DEVICE;
+}
+
 int stream_store32(sdqh_ctx* ctx, hipStream_t s, uint32_t* word, uint32_t value) {
     if (ctx->capturing) {
         hipLaunchKernelGGL(k_store32, dim3(1), dim3(64), 0, s, word, value);

@@ -670,6 +670,8 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "stage_waves_per_cu" && value >= 4 && value <= 64) ctx->opt_stage_waves_per_cu = (int)value;
     else if (n == "direct_index" && (value == 0 || value == 1)) ctx->opt_direct_index = (int)value;
     else if (n == "row_pack" && (value == 0 || value == 1)) ctx->opt_row_pack = (int)value;
+    else if (n == "cluster_pack" && value >= 0 && value <= 2) ctx->opt_cluster_pack = (int)value;
+    else if (n == "x_driven" && value >= 0 && value <= (1 << 20)) ctx->opt_x_driven = (int)value;
     else if (n == "coarse_kb" && value >= 0 && value <= 96) ctx->opt_coarse_kb = (int)value;
     else if (n == "lookup_pipeline" && value >= -1 && value <= 1) ctx->opt_lookup_pipeline = (int)value;
     else if (n == "probe_pipeline" && value >= 0 && value <= 1) ctx->opt_probe_pipeline = (int)value;
@@ -798,12 +800,15 @@ void sdqh_column_free(sdqh_ctx* ctx, sdqh_column* col) {
         for (sdqh_ctx* m : family)
             for (size_t i = 0; i < m->packs.size();) {
                 auto& pk = m->packs[i];
-                if (std::find(pk.cols.begin(), pk.cols.end(), (const void*)col->data) != pk.cols.end()) { pool_free(m, pk.data); m->packs.erase(m->packs.begin() + (long)i); }
+                if (std::find(pk.cols.begin(), pk.cols.end(), (const void*)col->data) != pk.cols.end() || pk.order_col == (const void*)col->data) {
+                    pool_free(m, pk.data); if (pk.key32) pool_free(m, pk.key32); m->packs.erase(m->packs.begin() + (long)i);
+                }
                 else ++i;
             }
         if (col->owned) attach_free(ctx, col, col->data);
         attach_free(ctx, col, col->d_minmax);
         if (col->narrow) attach_free(ctx, col, col->narrow);
+        if (col->run_index) attach_free(ctx, col, col->run_index);
         column_codes_release(ctx, col);
     }
     delete col;
@@ -2154,9 +2159,73 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
     L.pipeline = 0;
     if (nlookups > 0 && lookups[0].key[0].kind == SDQH_SRC_COLUMN && lookups[0].key[0].col->dtype == SDQH_I64)
         L.pipeline = ctx->opt_lookup_pipeline >= 0 ? ctx->opt_lookup_pipeline : (column_is_clustered(ctx, const_cast<sdqh_column*>(lookups[0].key[0].col)) ? 1 : 0);
-    // Coarse key filter in LDS for the first lookup when its keys come in no order and its bitmap does not fit L1
+    // Row pack: every plain column the drain gathers (lookup key parts, group key parts, operands), interleaved once
+    // and kept resident.  Only worth it for big scans with several gathered columns.
+    // CLUSTERED (sdqh_aux.hip, cluster_pack_build): when the first lookup's key column comes in no row order, the scan has no predicate
+    // (nothing else is streamed by row) and every gathered column is in the pack, the pack is built in the stable order of that key and
+    // the loop runs over PACK rows: its streamed key is the twin in that order (clustered: bitmap words shared by neighbouring rows,
+    // keys a step ahead, no coarse filter), survivors are runs of neighbouring pack rows, the first table is walked front to back.
+    const int32_t* cluster_key32 = nullptr;
     size_t coarse_lds = 0;
-    if (ctx->opt_coarse_kb > 0 && nlookups > 0 && nrows >= 4 * ctx->opt_feature_min_rows && lookups[0].key[0].kind == SDQH_SRC_COLUMN && lookups[0].key[0].col->dtype == SDQH_I64) {
+    if (ctx->opt_row_pack && nlookups > 0 && nrows > 0 && nrows >= ctx->opt_feature_min_rows) {
+        std::vector<DevSource*> srcs;
+        for (int l = 0; l < nlookups; ++l) for (int k = 0; k < L.l[l].nkey; ++k) srcs.push_back(&L.l[l].key[k]);
+        for (int k = 0; k < nkeys; ++k) srcs.push_back(&spec.key[k]);
+        for (int j = 0; j < nops; ++j) srcs.push_back(&spec.op[j]);
+        std::vector<const void*> cols;
+        for (DevSource* sr : srcs) if (sr->kind == SDQH_SRC_COLUMN && std::find(cols.begin(), cols.end(), (const void*)sr->col) == cols.end()) cols.push_back(sr->col);
+        if (cols.size() >= 5 && cols.size() <= (size_t)MAX_PACK && (size_t)nrows * cols.size() * 8 <= ((size_t)48 << 30)) {
+            const int k = (int)((cols.size() + 1) & ~(size_t)1);               // even: rows stay 16-byte aligned
+            // clustered?  (decided from facts about the key column that do not change from run to run)
+            const void* order_col = nullptr;
+            sdqh_column* kc0 = (lookups[0].key[0].kind == SDQH_SRC_COLUMN && lookups[0].key[0].col->dtype == SDQH_I64) ? const_cast<sdqh_column*>(lookups[0].key[0].col) : nullptr;
+            const sdqh_table* t0 = lookups[0].table;
+            const bool unfiltered = f.nc == 0 && f.ns == 0 && f.nf == 0 && f.ni == 0;
+            const bool part_bm = t0->bm && !t0->dev.lin_rb && (lookups[0].nkey == 1 ? t0->dev.bm_shift == 0 : t0->dev.bm_shift != 0);
+            if (ctx->opt_cluster_pack && ctx->opt_narrow && kc0 && unfiltered && part_bm && !kc0->transient && nrows < ((int64_t)1 << 32) &&
+                (nrows >= 4 * ctx->opt_feature_min_rows || ctx->opt_feature_min_rows == 0) && (ctx->opt_cluster_pack == 2 || !column_is_clustered(ctx, kc0)) && ensure_minmax(ctx, kc0) == SDQH_OK)
+                order_col = kc0->data;
+            sdqh_ctx::RowPack* found = nullptr;
+            for (auto& pk : ctx->packs) if (pk.cols == cols && pk.nrows == nrows && pk.order_col == order_col) found = &pk;
+            if (!found && order_col && !ctx->capturing) {
+                const int32_t* twin = static_cast<const int32_t*>(ensure_narrow(ctx, kc0));
+                void* data = twin ? pool_alloc(ctx, (size_t)nrows * (size_t)k * 8 + 64) : nullptr;
+                void* key32 = data ? pool_alloc(ctx, (size_t)nrows * 4 + 64) : nullptr;
+                if (key32 && cluster_pack_build(ctx, twin, kc0->mn, kc0->mx, nrows, cols.data(), (int)cols.size(), k, data, key32) == SDQH_OK) {
+                    sdqh_ctx::RowPack pk{cols, nrows, k, data}; pk.order_col = order_col; pk.key32 = key32;
+                    ctx->packs.push_back(pk);
+                    found = &ctx->packs.back();
+                } else {                                                       // (no twin, no memory: the pack in row order as before)
+                    (void)hipGetLastError();
+                    if (key32) pool_free(ctx, key32);
+                    if (data) pool_free(ctx, data);
+                }
+            }
+            if (!found && order_col) { order_col = nullptr; for (auto& pk : ctx->packs) if (pk.cols == cols && pk.nrows == nrows && !pk.order_col) found = &pk; }
+            if (!found) {
+                void* data = pool_alloc(ctx, (size_t)nrows * (size_t)k * 8 + 64);
+                if (data) {
+                    DevPackCols pc; std::memset(&pc, 0, sizeof(pc));
+                    for (size_t j = 0; j < cols.size(); ++j) pc.col[j] = static_cast<const int64_t*>(cols[j]);
+                    pc.ncols = (int)cols.size(); pc.k = k;
+                    LAUNCH(ctx, "k_interleave", k_interleave, (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + TPB - 1) / TPB, (int64_t)ctx->num_cu * 16)), pc, nrows, static_cast<int64_t*>(data));
+                    ctx->packs.push_back({cols, nrows, k, data});
+                    found = &ctx->packs.back();
+                }
+            }
+            if (found) {
+                L.pack = static_cast<const int64_t*>(found->data); L.pack_k = found->k;
+                for (DevSource* sr : srcs) if (sr->kind == SDQH_SRC_COLUMN)
+                    sr->pack = 1 + (int)(std::find(cols.begin(), cols.end(), (const void*)sr->col) - cols.begin());
+                if (found->order_col) {
+                    cluster_key32 = static_cast<const int32_t*>(found->key32);
+                    if (ctx->opt_lookup_pipeline < 0) L.pipeline = 1;
+                }
+            }
+        }
+    }
+    // Coarse key filter in LDS for the first lookup when its keys come in no order and its bitmap does not fit L1
+    if (!cluster_key32 && ctx->opt_coarse_kb > 0 && nlookups > 0 && nrows >= 4 * ctx->opt_feature_min_rows && lookups[0].key[0].kind == SDQH_SRC_COLUMN && lookups[0].key[0].col->dtype == SDQH_I64) {
         sdqh_table* t0 = const_cast<sdqh_table*>(lookups[0].table);
         const bool part_bitmap = t0->bm && !t0->dev.lin_rb && (lookups[0].nkey == 1 ? t0->dev.bm_shift == 0 : t0->dev.bm_shift != 0);
         // last time's density of this key column's coarse filter (see sdqh_ctx::coarse_stat): a filter that passed more than half the rows is left out
@@ -2198,37 +2267,6 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
             }
         }
     }
-    // Row pack: every plain column the drain gathers (lookup key parts, group key parts, operands), interleaved once
-    // and kept resident.  Only worth it for big scans with several gathered columns.
-    if (ctx->opt_row_pack && nlookups > 0 && nrows > 0 && nrows >= ctx->opt_feature_min_rows) {
-        std::vector<DevSource*> srcs;
-        for (int l = 0; l < nlookups; ++l) for (int k = 0; k < L.l[l].nkey; ++k) srcs.push_back(&L.l[l].key[k]);
-        for (int k = 0; k < nkeys; ++k) srcs.push_back(&spec.key[k]);
-        for (int j = 0; j < nops; ++j) srcs.push_back(&spec.op[j]);
-        std::vector<const void*> cols;
-        for (DevSource* sr : srcs) if (sr->kind == SDQH_SRC_COLUMN && std::find(cols.begin(), cols.end(), (const void*)sr->col) == cols.end()) cols.push_back(sr->col);
-        if (cols.size() >= 5 && cols.size() <= (size_t)MAX_PACK && (size_t)nrows * cols.size() * 8 <= ((size_t)48 << 30)) {
-            const int k = (int)((cols.size() + 1) & ~(size_t)1);               // even: rows stay 16-byte aligned
-            sdqh_ctx::RowPack* found = nullptr;
-            for (auto& pk : ctx->packs) if (pk.cols == cols && pk.nrows == nrows) found = &pk;
-            if (!found) {
-                void* data = pool_alloc(ctx, (size_t)nrows * (size_t)k * 8 + 64);
-                if (data) {
-                    DevPackCols pc; std::memset(&pc, 0, sizeof(pc));
-                    for (size_t j = 0; j < cols.size(); ++j) pc.col[j] = static_cast<const int64_t*>(cols[j]);
-                    pc.ncols = (int)cols.size(); pc.k = k;
-                    LAUNCH(ctx, "k_interleave", k_interleave, (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + TPB - 1) / TPB, (int64_t)ctx->num_cu * 16)), pc, nrows, static_cast<int64_t*>(data));
-                    ctx->packs.push_back({cols, nrows, k, data});
-                    found = &ctx->packs.back();
-                }
-            }
-            if (found) {
-                L.pack = static_cast<const int64_t*>(found->data); L.pack_k = found->k;
-                for (DevSource* sr : srcs) if (sr->kind == SDQH_SRC_COLUMN)
-                    sr->pack = 1 + (int)(std::find(cols.begin(), cols.end(), (const void*)sr->col) - cols.begin());
-            }
-        }
-    }
     // result block in ctx->result_dev: gkeys[LG_SLOTS] | acc[LG_SLOTS][4] | cnt[LG_SLOTS] | flags
     char* rd = static_cast<char*>(ctx->result_dev);
     unsigned long long* r_keys = reinterpret_cast<unsigned long long*>(rd);
@@ -2261,7 +2299,8 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
             // narrow twin of the first lookup's streamed key column (unfiltered scans: the instances that exist with NW)
             const int32_t* nkey0 = nullptr;
             if (BIG_OK && ctx->opt_narrow && nrows >= ctx->opt_feature_min_rows && nlookups > 0 && lookups[0].key[0].kind == SDQH_SRC_COLUMN && lookups[0].key[0].col->dtype == SDQH_I64)
-                nkey0 = static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(lookups[0].key[0].col)));
+                nkey0 = cluster_key32 ? cluster_key32 : static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(lookups[0].key[0].col)));
+            if (cluster_key32 && !nkey0) return fail(ctx, SDQH_ERR_DEVICE, "lookup_aggregate: clustered pack without its key twin");
             if constexpr (BIG_OK) if (coarse_lds) {
                 auto big_raw = k_lookup_agg<SH, FCT, BIG_BT, BIG_PU>;
                 auto big_nw = k_lookup_agg<SH, FCT, BIG_BT, BIG_PU, true>;
@@ -2548,6 +2587,8 @@ int sdqh_column_copy_in(sdqh_ctx* ctx, sdqh_column* col, int64_t row0, int64_t n
     col->have_minmax = false; col->minmax_pending = false; col->clustered = unknown; col->increasing = unknown; col->nondecreasing = unknown; col->span8 = unknown;
     if (col->narrow) { attach_free(ctx, col, col->narrow); col->narrow = nullptr; }
     col->narrow_state = unknown;
+    if (col->run_index) { attach_free(ctx, col, col->run_index); col->run_index = nullptr; }
+    col->run_index_state = -1;
     column_codes_release(ctx, col);
     if (col->transient) col->code_state = 0;
     return ctx->opt_async_copies ? SDQH_OK : sync_stream(ctx);
@@ -2658,6 +2699,7 @@ int launch_compact_pair(sdqh_ctx* ctx, sdqh_table* table, const DevCompactOut& o
 hipStream_t copy_stream(sdqh_ctx* ctx) { if (!ctx->side[1]) ctx->side[1] = ::make_copy_stream(ctx); return ctx->side[1]; }
 int column_minmax(sdqh_ctx* ctx, sdqh_column* c) { return ensure_minmax(ctx, c); }
 bool column_increasing(sdqh_ctx* ctx, sdqh_column* c) { return ::column_is_increasing(ctx, c); }
+bool column_nondecreasing(sdqh_ctx* ctx, sdqh_column* c) { return ::column_is_nondecreasing(ctx, c); }
 const void* column_narrow(sdqh_ctx* ctx, sdqh_column* c) { return ensure_narrow(ctx, c); }
 int new_owned_column(sdqh_ctx* ctx, int64_t nrows, int dtype, sdqh_column** out) { return sdqh_column_alloc(ctx, nrows, dtype, 0, out); }
 

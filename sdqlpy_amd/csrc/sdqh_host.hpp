@@ -116,6 +116,7 @@ struct sdqh_ctx {
     int opt_lane_resident = 2;          // workgroups per CU the per-lane group sink's grid is sized for
     int opt_window = 0;                 // x_queue8's 32-bit prefilter tests a lane's 8 rows against ONE 16-byte window of the bitmap when the key column's 8-row spans allow (column_span8): measured
                                         // on par with 8 single-word requests once those are coalesced (Q3's probe 0.083 vs 0.081 ms) and slower where every row is tested (Q5's final loop 0.140 vs 0.130)
+    int opt_x_driven = 64;              // the driven walk of x_queue8 is taken when (estimated entries of the first lookup's table) x this <= rows of the loop; 0 = never
     int opt_x_waves = 0;                // > 0: wave segments per CU for the queue skeletons of row programs (0: each sink's own default)
     // K-F rows delivered behind the call (sdqh_table_compact_async): two device staging buffers in turn, a copy stream (side[1]),
     // the event of each buffer's last copy, and whether a copy may still be in flight
@@ -141,8 +142,12 @@ struct sdqh_ctx {
     int opt_coarse_kb = 64;                        // LDS budget (KiB) of the coarse key filter in front of an unclustered first lookup; 0 = off.  One copy per
                                                    // 1024-thread workgroup (a copy per 256 threads cost more occupancy than it saved: 0.70 -> 0.67 ms at 32 KiB, 1.4 ms at 64 KiB)
     int opt_row_pack = 1;                          // final loops with lookups gather their columns from an interleaved row pack (see DevLookups)
-    struct RowPack { std::vector<const void*> cols; int64_t nrows; int k; void* data; };
-    std::vector<RowPack> packs;                    // resident row packs, by column set
+    // order_col: null = rows in row order; else the pack is CLUSTERED — its rows stand in the (stable) order of that column's values, and key32
+    // holds that column's 4-byte twin in the same order (sdqh_aux.hip: cluster_pack_build)
+    struct RowPack { std::vector<const void*> cols; int64_t nrows; int k; void* data; const void* order_col = nullptr; void* key32 = nullptr; };
+    std::vector<RowPack> packs;                    // resident row packs, by column set (and order)
+    int opt_cluster_pack = 1;                      // a final loop whose first lookup's key column comes in no row order, whose scan has no predicate and whose gathered columns are all
+                                                   // in its row pack runs over a pack CLUSTERED by that key (Q9: l_partkey): 0 = never, 2 = whatever the key's order (the tests)
     int opt_groupby_regs = 0;                      // 0 = adaptive (4 when the last run of these key columns had <= 4 groups), 4, 8
     const void* g4_hint[SDQH_MAX_GROUPKEYS] = {nullptr, nullptr};
 };
@@ -172,6 +177,11 @@ struct sdqh_column {
     void* dict = nullptr;              // device: ndict raw 8-byte values (int64, or the bits of the doubles), ascending
     int ndict = 0;
     std::vector<int64_t> dict_host;    // the same on the host (bounds of comparisons are translated into code space at launch)
+    // RUN INDEX of a never-decreasing column (sdqh_x.hip: column_run_index): per value v of [mn, mx] the first row that holds it (0xFFFFFFFF: none) —
+    // a final loop whose first lookup is keyed by such a column and hits few of its values walks the TABLE's keys and their row runs
+    // instead of streaming the column (x_queue8's driven walk)
+    void* run_index = nullptr;         // device: (mx - mn + 1) uint32
+    int run_index_state = -1;          // -1 not tried, 0 none (not ordered / too wide a range / too many rows), 1 present
     bool transient = false;            // a view of a table's K-F buffers (sdqh_table_columns): lives for one run — no twins, no statistics gathered for it
     size_t row_bytes() const { return dtype == SDQH_STR ? (size_t)width * 4 : 8; }
 };
@@ -232,6 +242,7 @@ int launch_compact_pair(sdqh_ctx* ctx, sdqh_table* table, const sdqh::DevCompact
 hipStream_t copy_stream(sdqh_ctx* ctx);                         // the low-priority stream result copies are queued on (made on first use)
 int column_minmax(sdqh_ctx* ctx, sdqh_column* c);
 bool column_increasing(sdqh_ctx* ctx, sdqh_column* c);          // strictly increasing I64 column?  (one pass the first time, cached)
+bool column_nondecreasing(sdqh_ctx* ctx, sdqh_column* c);       // never decreasing?
 const void* column_narrow(sdqh_ctx* ctx, sdqh_column* c);      // the exact 4-byte twin of a streamed column (built on first request), or nullptr
 bool column_codes(sdqh_ctx* ctx, sdqh_column* c);              // sdqh_codes.hip: the sorted-dictionary code twin (built on first request); false: none
 void column_codes_release(sdqh_ctx* ctx, sdqh_column* c);
@@ -248,6 +259,9 @@ int prefill_direct_refs(sdqh_ctx* ctx, sdqh_table* tb, void** ptr, size_t* bytes
 inline void rd_dirty(sdqh_ctx* c) { c->rd_clean_ff = 0; c->rd_clean_zero_off = -1; }
 
 // ---- helpers defined in sdqh_aux.hip ----------------------------------------------------------------
+// a row pack in the stable order of a key column's values (twin: the column's exact 4-byte twin, lo / hi: its minimum / maximum):
+// pack_out[i * k + j] = cols[j][row_i], key32_out[i] = twin[row_i]; waits for the stream once (scratch returned to the pool)
+int cluster_pack_build(sdqh_ctx* ctx, const int32_t* twin, int64_t lo, int64_t hi, int64_t n, const void* const* cols, int ncols, int k, void* pack_out, void* key32_out);
 // one 32-bit word of device-visible host memory stored by stream `s` itself, behind what is queued there: hipStreamWriteValue32 where
 // the stream executes, a one-thread kernel where it is being recorded into a plan graph (the value-write has no graph node)
 int stream_store32(sdqh_ctx* ctx, hipStream_t s, uint32_t* word, uint32_t value);

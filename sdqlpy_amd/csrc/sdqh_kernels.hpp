@@ -2921,7 +2921,7 @@ __global__ __launch_bounds__(BT) void k_lookup_agg(DevFilter f, DevLookups L, De
         } else if (phase == 1) {                                               // tail: one row per lane through the same queue
             const int64_t r = tail_r0 + threadIdx.x;
             bool pass = r < nrows && row_passes<FC>(f, none, r, nomask);
-            if (pass && eager0) pass = first_lookup_may_hit(L, L.l[0].key[0].col[r]);
+            if (pass && eager0) pass = first_lookup_may_hit(L, NW ? (int64_t)nkey0[r] : L.l[0].key[0].col[r]);      // (NW: the twin may stand in ANOTHER order than the column — a clustered pack)
             const uint64_t b = __ballot(pass);
             if (b) {
                 if (pass) q_row[qn + __popcll(b & lt)] = (int32_t)(r - qbase);

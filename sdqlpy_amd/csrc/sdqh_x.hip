@@ -93,6 +93,7 @@ struct XInfo {
     int ival = -1;                           // the per-lane group sink: summed value that is a small integer on every row (byte-coded column, consecutive integral dictionary), or -1
     bool pnear = false;                      // ... and a lane's 8 consecutive rows carry near-by keys (column_span8): a row that fails an earlier condition still asks for ITS key's word
     bool pwin = false;                       // ... tested against one 128-bit window of the bitmap: one 16-byte request per lane and 8 rows (option "window", off: measured slower)
+    bool driven = false; int driven_col = -1;   // the driven walk of x_queue8 can be taken (order-free sinks): the prefilter's key column is stored in its own order and has a run index
     uint32_t gather32 = 0;                   // queue programs: numeric columns read BY ROW (the drain's gathers) through their 4-byte twins: half the bytes of every touched line
     mutable uint32_t lay[SDQH_MAX_XTABLES] = {};   // XL_* layout bits of every table (kernel_for: known once the tables' indexes are made), 0: decided at run time
     std::vector<char> scope;                 // operations evaluated on the streamed registers (register programs: all; queue programs: the streamed gates + the prefilter's key)
@@ -335,6 +336,34 @@ bool column_span8(sdqh_ctx* ctx, sdqh_column* c) {
     return c->span8 == 1;
 }
 
+// RUN INDEX of a never-decreasing I64 column (sdqh_column::run_index): per value of [mn, mx] the first row holding it, 0xFFFFFFFF for a
+// value no row holds.  Built once per column on first need (a fill and one pass over the 4-byte twin), kept with the column.  Only
+// where it pays its memory: at most 2^32 - 2 rows, a value range of at most 64 x the rows (and 2^32), a twin to read the runs' ends from.
+__global__ __launch_bounds__(256) void k_run_index(const int32_t* __restrict__ twin, int64_t n, int64_t lo, uint32_t* __restrict__ ridx) {
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
+        const int32_t k = twin[r];
+        if (r == 0 || twin[r - 1] != k) ridx[(int64_t)k - lo] = (uint32_t)r;
+    }
+}
+const uint32_t* column_run_index(sdqh_ctx* ctx, sdqh_column* c) {
+    if (c->run_index_state >= 0) return c->run_index_state == 1 ? static_cast<const uint32_t*>(c->run_index) : nullptr;
+    c->run_index_state = 0;
+    if (c->dtype != SDQH_I64 || c->transient || c->nrows < 2 || c->nrows >= 0xFFFFFFFFll || ctx->capturing) { if (ctx->capturing) c->run_index_state = -1; return nullptr; }
+    if (!column_nondecreasing(ctx, c) || column_minmax(ctx, c) != SDQH_OK || c->mx < c->mn) return nullptr;
+    const uint64_t range = (uint64_t)(c->mx - c->mn) + 1;
+    if (range > 0xFFFFFFFFull || range > 64ull * (uint64_t)c->nrows) return nullptr;
+    const int32_t* twin = static_cast<const int32_t*>(column_narrow(ctx, c));
+    if (!twin) return nullptr;
+    uint32_t* ridx = static_cast<uint32_t*>(attach_alloc(ctx, c, (size_t)range * 4 + 64));
+    if (!ridx) return nullptr;
+    if (hipMemsetAsync(ridx, 0xFF, (size_t)range * 4, ctx->stream) != hipSuccess) { (void)hipGetLastError(); attach_free(ctx, c, ridx); return nullptr; }
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((c->nrows + 255) / 256, (int64_t)ctx->num_cu * 16));
+    { KernelScope ks(ctx, "k_run_index"); hipLaunchKernelGGL(k_run_index, dim3(grid), dim3(256), 0, ctx->stream, twin, c->nrows, c->mn, ridx); }
+    if (hipGetLastError() != hipSuccess) { attach_free(ctx, c, ridx); return nullptr; }
+    c->run_index = ridx; c->run_index_state = 1;
+    return ridx;
+}
+
 // Decide, per column of a register program, the tightest exact encoding it can be streamed in, and rewrite the comparisons
 // of coded columns with constants.  The decisions are part of the kernel's structure; the translated constants are arguments
 // (recomputed at every call: cheap, and they follow the constants).
@@ -342,7 +371,7 @@ void tight_plan(sdqh_ctx* ctx, int64_t nrows, XInfo* x) {
     const sdqh_program* p = x->p;
     for (int k = 0; k < p->nops; ++k) x->cmp_cc[k] = x->cmp_kind[k] = x->cmp_col[k] = -1;
     for (int c = 0; c < SDQH_MAX_XCOLS; ++c) { x->enc[c] = ENC_RAW; x->dict_slot[c] = -1; }
-    x->tight = false; x->nd = 0; x->ncc = 0; x->gather32 = 0; x->pref32 = false; x->pnear = false; x->pwin = false;
+    x->tight = false; x->nd = 0; x->ncc = 0; x->gather32 = 0; x->pref32 = false; x->pnear = false; x->pwin = false; x->driven = false; x->driven_col = -1;
     // (a compile-only context has no columns to code; SDQLPY_AMD_FAKE_CODES makes it pretend every column is coded — 2 bytes where
     //  only compared, 1 byte where its value is used — so that build() proves on a host without a GPU that the generator's tight
     //  output compiles for gfx950)
@@ -435,10 +464,23 @@ void tight_plan(sdqh_ctx* ctx, int64_t nrows, XInfo* x) {
         x->pref32 = applicable && x->irange[x->prefilter_part0] >= 1 && t->dev.bm_lo >= INT32_MIN && t->dev.bm_hi <= INT32_MAX && t->dev.bm_hi >= t->dev.bm_lo;
     }
     if (fake && !regs_all && x->prefilter_op >= 0 && !x->prefilter_composite) x->pref32 = true;
+    static const bool xdebug = std::getenv("SDQLPY_AMD_X_DEBUG") != nullptr;
+    if (xdebug && !regs_all && x->prefilter_op >= 0) {
+        const sdqh_table* t = x->tabs[x->tab_of[x->prefilter_op]];
+        std::fprintf(stderr, "[x] prefilter: composite %d bm %p shift %d lin_rb %lld range [%lld, %lld] irange %d pref32 %d gates %d rows %lld\n", (int)x->prefilter_composite, (const void*)t->dev.bm,
+                     (int)t->dev.bm_shift, (long long)t->dev.lin_rb, (long long)t->dev.bm_lo, (long long)t->dev.bm_hi, (int)x->irange[x->prefilter_part0], (int)x->pref32, x->nstream_gates, (long long)nrows);
+    }
     if (x->pref32) {
         const sdqh_xop& ko = p->ops[x->prefilter_part0];
         x->pnear = fake ? true : (ko.code == SDQH_X_COL && column_span8(ctx, const_cast<sdqh_column*>(ko.col)));
         x->pwin = fake ? std::getenv("SDQLPY_AMD_FAKE_WINDOW") != nullptr : (ctx->opt_window != 0 && x->pnear);
+        // the driven walk (x_queue8): no other streamed condition, the key a plain column read through its 4-byte twin, stored in its own order
+        if (!fake && ctx->opt_x_driven > 0 && x->nstream_gates == 0 && ko.code == SDQH_X_COL) {
+            const int c = x->col_of[x->prefilter_part0];
+            sdqh_column* kc = const_cast<sdqh_column*>(x->cols[c]);
+            if (x->enc[c] == ENC_N32 && kc->nrows == nrows && nrows < ((int64_t)1 << 31) && column_run_index(ctx, kc)) { x->driven = true; x->driven_col = c; }
+            if (xdebug) std::fprintf(stderr, "[x] driven walk: enc %d column rows %lld run index %d -> %d\n", x->enc[c], (long long)kc->nrows, kc->run_index_state, (int)x->driven);
+        }
     }
     // comparisons of a coded column with a constant, in code space
     for (int j = 0; j < p->nops; ++j) {
@@ -951,6 +993,11 @@ std::string generate(const XInfo& x, Sink sink, bool direct) {
             << (x.pref32 ? spre32 : std::string("        off = 0; return false;\n")) << "    }\n";
         out << "    __device__ __forceinline__ static const uint32_t* sbitmap(const XArgs& a) { return "
             << (x.prefilter_op >= 0 ? "x_prefilter_bitmap(a.tab[" + std::to_string(x.tab_of[x.prefilter_op]) + "], " + (x.prefilter_composite ? "true" : "false") + ")" : std::string("nullptr")) << "; }\n";
+        if (x.driven && (sink == SINK_GROUP || sink == SINK_SUM)) {       // (the sinks whose launches ask for the tiled walk)
+            out << "    static constexpr bool DRIVEN = true;\n";
+            out << "    __device__ __forceinline__ static const int32_t* dkey(const XArgs& a) { return static_cast<const int32_t*>(a.ncol[" << x.driven_col << "]); }\n";
+            out << "    __device__ __forceinline__ static const DevTable& dtab(const XArgs& a) { return a.tab[" << x.tab_of[x.prefilter_op] << "]; }\n";
+        }
     }
     if (!tcols.empty()) {
         out << "    __device__ __forceinline__ static constexpr int scol(int j) { return j == 0 ? " << tcols[0] << " : " << (tcols.size() > 1 ? tcols[1] : tcols[0]) << "; }\n";
@@ -1094,7 +1141,7 @@ uint64_t structure_hash(const XInfo& x, Sink sink, bool direct) {
     auto mix = [&](uint64_t v) { h ^= v; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29; };      // (a word at a time: this runs on every call)
     mix((uint64_t)sink * 2 + (direct ? 1 : 0)); mix((uint64_t)x.narrow_mask);
     if (x.tight) {
-        mix(0x7167ull); mix((uint64_t)x.gather32); mix((x.pref32 ? 1ull : 0ull) | (x.vstage ? 2ull : 0ull) | (x.pwin ? 4ull : 0ull) | (x.pnear ? 8ull : 0ull) | ((uint64_t)(x.ival + 1) << 8));
+        mix(0x7167ull); mix((uint64_t)x.gather32); mix((x.pref32 ? 1ull : 0ull) | (x.vstage ? 2ull : 0ull) | (x.pwin ? 4ull : 0ull) | (x.pnear ? 8ull : 0ull) | (x.driven ? 16ull : 0ull) | ((uint64_t)(x.ival + 1) << 8));
         for (int c = 0; c < x.ncols; ++c) mix(((uint64_t)(uint32_t)x.enc[c] << 32) | ((uint32_t)(x.affine[c] ? 1 : 0) << 16) | (uint32_t)(x.dict_slot[c] & 0xFFFF));
         for (int k = 0; k < x.p->nops; ++k) mix((uint64_t)(uint8_t)x.irange[k]);
         for (int k = 0; k < x.p->nops; ++k) mix(((uint64_t)(uint32_t)x.cmp_cc[k] << 32) | ((uint32_t)x.cmp_kind[k] << 8) | (uint32_t)(x.cmp_col[k] & 0xFF));
@@ -1225,6 +1272,10 @@ int fill_xargs(sdqh_ctx* ctx, const XInfo& x, XArgs* a, int32_t* flags, int64_t 
     std::memcpy(a->cf, x.cf, sizeof(x.cf[0]) * (size_t)x.ncf);
     std::memcpy(a->spool, x.spool, sizeof(uint32_t) * (size_t)x.nstr);
     a->flags = flags; a->key_lo = key_lo; a->key_hi = key_hi;
+    if (x.driven && x.driven_col >= 0 && x.cols[x.driven_col]->run_index_state == 1) {
+        const sdqh_column* kc = x.cols[x.driven_col];
+        a->run_index = static_cast<const uint32_t*>(kc->run_index); a->run_lo = kc->mn; a->run_hi = kc->mx; a->driven_ratio = ctx->opt_x_driven;
+    }
     return SDQH_OK;
 }
 

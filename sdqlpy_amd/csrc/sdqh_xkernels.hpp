@@ -70,7 +70,16 @@ struct XArgs {
     uint32_t spool[SDQH_MAX_XSTR];              // string constants, back to back
     int32_t* flags;                             // |= 2: a key outside its bounds / an unpackable key part
     int64_t key_lo, key_hi;                     // bounds the key must respect (key_lo > key_hi: none)
+    // DRIVEN walk (x_queue8; programs generated with P::DRIVEN): the run index of the prefilter's key column — per value of [run_lo, run_hi]
+    // the first row holding it, 0xFFFFFFFF: none (sdqh_x.hip: column_run_index) — and the ratio the walk is chosen by (0: never)
+    const uint32_t* run_index;
+    int64_t run_lo, run_hi;
+    int32_t driven_ratio, _pad_driven;
 };
+// does the program carry the members of the driven walk?  (generated only where it can be taken: programs made before it compile unchanged)
+template <class...> using x_void_t = void;
+template <class P, class = void> struct x_is_driven { static constexpr bool value = false; };
+template <class P> struct x_is_driven<P, x_void_t<decltype(P::DRIVEN)>> { static constexpr bool value = P::DRIVEN; };
 
 template <int NV> struct XOut {
     int64_t key;
@@ -1015,6 +1024,41 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
         while (m) { q_row[at++] = off + (__ffs((int)m) - 1); m &= m - 1u; }        // as many rounds as the fullest lane has survivors (sparse: one or two)
         qn += total;
     };
+    // DRIVEN walk (round 5).  A loop whose first lookup is keyed by a column the scanned table is STORED IN THE ORDER OF (l_orderkey) and
+    // whose table holds few of that column's values (Q5: the orders of one year placed by one region's customers, 0.8 % of the keys)
+    // streams 60 M keys to find the 3 % of the rows that can hit.  The table's key bitmap says which keys exist, the column's run index
+    // (XArgs::run_index) where each key's rows start: the wave walks the BITMAP instead — 64 quads of four words per step, every set
+    // bit a key, its rows the run from run_index[key] on (ended by comparing the column's twin, 8 rows per round and lane) — and the
+    // rows go through the same queue into the same drain.  Chosen by every wave alike, from the same 64-quad sample of the bitmap's
+    // density: (estimated keys) x driven_ratio <= rows; order-free sinks only (the tiled walk's condition).
+    bool driven = false;
+    uint64_t d_nq = 0, d_q = 0, d_nwords = 0;
+    XWindow d_w = {0u, 0u, 0u, 0u};
+    uint32_t d_bit0 = 0;
+    int64_t d_cur = -1; int32_t d_key = 0;
+    auto d_quad = [&](uint64_t q) {                                      // quad q of the bitmap; words behind its end are zero (and not read)
+        const uint64_t wb = q * 4;
+        if (wb + 4 <= d_nwords) return x_load_window(pbm + wb);
+        XWindow v = {0u, 0u, 0u, 0u};
+        if (wb < d_nwords) v.x = pbm[wb];
+        if (wb + 1 < d_nwords) v.y = pbm[wb + 1];
+        if (wb + 2 < d_nwords) v.z = pbm[wb + 2];
+        return v;
+    };
+    if constexpr (x_is_driven<P>::value) {
+        if (live && tiled && pbm && a.run_index && a.driven_ratio > 0) {
+            const DevTable& t = P::dtab(a);
+            d_nwords = ((uint64_t)(t.bm_hi - t.bm_lo) + 32) >> 5;
+            d_nq = (d_nwords + 3) >> 2;
+            const uint64_t ns = d_nq < (uint64_t)WAVE ? d_nq : (uint64_t)WAVE;
+            int bits = 0, tot = 0;
+            if ((uint64_t)lane < ns) { const XWindow v = d_quad((uint64_t)lane * (d_nq / ns)); bits = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
+            (void)wave_excl_prefix(bits, tot);
+            const double est = ns ? (double)tot * ((double)d_nq / (double)ns) : 0.0;
+            driven = est * (double)a.driven_ratio <= (double)nrows;
+            d_q = (uint64_t)seg * WAVE;
+        }
+    }
     if (live) {
 #if X8_PIPE
         typename P::Regs pre[X8_U];
@@ -1027,11 +1071,58 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
         }
 #endif
         for (int64_t b = tiled ? (int64_t)seg * STEP2 : begin;;) {
+            bool last = false, produced = false;
+            if constexpr (x_is_driven<P>::value) {
+                if (driven) {
+                    produced = true;
+                    if (!__ballot((d_w.x | d_w.y | d_w.z | d_w.w) != 0u || d_cur >= 0)) {      // nothing in hand: the wave's next 64 quads, or the end
+                        if (d_q >= d_nq) last = true;
+                        else {
+                            const uint64_t q = d_q + (uint64_t)lane;
+                            d_w = q < d_nq ? d_quad(q) : XWindow{0u, 0u, 0u, 0u};
+                            d_bit0 = (uint32_t)(q * 128);
+                            d_q += (uint64_t)nseg * WAVE;
+                        }
+                    }
+                    if (!last) {
+                        // a round: every lane goes on with the run it is in, or opens the run of its next key; up to 8 rows of it are queued
+                        uint32_t m = 0; int64_t r0 = 0;
+                        if (d_cur < 0 && (d_w.x | d_w.y | d_w.z | d_w.w) != 0u) {
+                            const int j = d_w.x ? 0 : d_w.y ? 1 : d_w.z ? 2 : 3;
+                            const uint32_t word = j == 0 ? d_w.x : j == 1 ? d_w.y : j == 2 ? d_w.z : d_w.w;
+                            const uint32_t bp = (uint32_t)__ffs((int)word) - 1u, rest = word & (word - 1u);
+                            if (j == 0) d_w.x = rest; else if (j == 1) d_w.y = rest; else if (j == 2) d_w.z = rest; else d_w.w = rest;
+                            const int64_t key = P::dtab(a).bm_lo + (int64_t)(d_bit0 + (uint32_t)j * 32u + bp);
+                            d_key = (int32_t)key;
+                            uint32_t start = 0xFFFFFFFFu;
+                            if (key >= a.run_lo && key <= a.run_hi) start = a.run_index[key - a.run_lo];
+                            if (start != 0xFFFFFFFFu) d_cur = (int64_t)start;
+                        }
+                        if (d_cur >= 0) {
+                            const uint32_t* kp = reinterpret_cast<const uint32_t*>(P::dkey(a)) + d_cur;
+                            const uint32_t kk = (uint32_t)d_key;
+                            int n = 0;
+                            if (d_cur + 8 <= nrows) {
+                                const XWindow k0 = x_load_window(kp), k1 = x_load_window(kp + 4);
+                                const uint32_t eq = (k0.x == kk ? 1u : 0u) | (k0.y == kk ? 2u : 0u) | (k0.z == kk ? 4u : 0u) | (k0.w == kk ? 8u : 0u) |
+                                                    (k1.x == kk ? 16u : 0u) | (k1.y == kk ? 32u : 0u) | (k1.z == kk ? 64u : 0u) | (k1.w == kk ? 128u : 0u);
+                                n = __ffs((int)(~eq | 0x100u)) - 1;                           // rows of the run among the 8: the leading ones
+                            } else {
+                                while (n < 8 && d_cur + n < nrows && kp[n] == kk) ++n;
+                            }
+                            m = (1u << n) - 1u; r0 = d_cur;
+                            d_cur = (n == 8 && d_cur + 8 < nrows) ? d_cur + 8 : -1;
+                        }
+                        enqueue8(r0, m);
+                    }
+                }
+            }
+            if (!produced) {
             if (phase == 1 && b >= end) {                                     // tiled: the whole double steps are done; wave 0 takes the rest of the rows
                 phase = 2;
                 if (seg == 0) { b = whole_end; end = nrows; }
             }
-            const bool last = b >= end;
+            last = b >= end;
             if (last) {
             } else if (b + (int64_t)X8_STEP * X8_U <= end) {
                 // The NEXT double step's streamed loads are requested behind this step's bitmap words and before anything waits
@@ -1180,6 +1271,7 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
                 enqueue8(r0, m);
                 b += X8_STEP;
             }
+            }   // !produced
             int head = 0;
             if constexpr (X8_EXP == 3 && x_exp_on<Sink>()) { if ((uint32_t)a.key_hi != 0x12345678u && nrows >= (int64_t)X8_EXP_MINROWS) qn = 0; }      // (timing experiment: survivors queued, never drained)
             while (qn - head >= X8_DRAIN_AT || (last && qn > head)) {

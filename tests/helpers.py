@@ -1357,3 +1357,63 @@ def grouped_index_case(ctx, n=200000, nprobe=500000, seed=17, keep=0.3, per_a=4)
         c.free()
     t.free()
     return int(want_cnt.sum()), float(want_sum.sum()), len(first)
+
+
+def cluster_pack_case(ctx, n=40000, nprobe=300001, seed=23, nparts=9000, keep=0.06):
+    """Q9's final loop through the ABI (sdqh_lookup_aggregate): a first lookup on a composite (part, supplier) table — built over the
+    kept parts only, stored in part order, suppliers from a range wide enough that the key rectangle is not linearised — keyed by a
+    probe column in NO row order, a second lookup supplier -> nation, six gathered columns (so the loop has a row pack), groups
+    (nation, year-like column), value a * (1 - b) - cost * d.  On the GPU the pack is CLUSTERED by the part key (sdqh_aux.hip:
+    cluster_pack_build) unless the option says otherwise.  Checked against numpy here; returns (group keys, counts, sums) for
+    comparisons between implementations and options."""
+    from sdqlpy_amd import abi
+    rng = np.random.default_rng(seed)
+    nsup = 50021                                                                          # (prime: a part's suppliers below are all different)
+    per = max(n // nparts, 1)
+    a = np.repeat(np.arange(3, 3 + nparts, dtype=np.int64), per)[:n]
+    n = len(a)
+    b = (a * 31 + (np.arange(n, dtype=np.int64) % per) * 7919) % nsup + 1
+    cost = np.round(rng.random(n) * 1000.0, 2)
+    kept_part = rng.random(nparts + 3) < keep
+    flag = kept_part[a].astype(np.int64)
+    sup_key = np.arange(nsup + 1, dtype=np.int64)
+    sup_nat = rng.integers(0, 25, nsup + 1).astype(np.int64)
+    ca, cb, cc, cf, csk, csn = (ctx.upload(x) for x in (a, b, cost, flag, sup_key, sup_nat))
+    t0 = ctx.build(n, abi.make_filter(ipreds=[(cf, 1, 1)]), [], [abi.src_col(ca), abi.src_col(cb)], [abi.src_col(cc)])
+    t1 = ctx.build(nsup + 1, abi.make_filter(), [], [abi.src_col(csk)], [abi.src_col(csn)])
+    pa = rng.integers(0, nparts + 6, nprobe).astype(np.int64)                             # no order; some outside the table's range
+    pb = (pa * 31 + rng.integers(0, per + 1, nprobe) * 7919) % nsup + 1                   # mostly a supplier of that part
+    yr = rng.integers(1992, 1999, nprobe).astype(np.int64)
+    v1 = np.round(rng.random(nprobe) * 90000.0 + 900.0, 2)
+    v2 = np.round(rng.integers(0, 11, nprobe) * 0.01, 2)
+    v3 = rng.integers(1, 51, nprobe).astype(np.float64)
+    cols = [ctx.upload(x) for x in (pa, pb, yr, v1, v2, v3)]
+    cpa, cpb, cyr, cv1, cv2, cv3 = cols
+    keys, vals, cnts = ctx.lookup_aggregate(nprobe, abi.make_filter(), [(t0, [abi.src_col(cpa), abi.src_col(cpb)]), (t1, [abi.src_col(cpb)])],
+                                            [abi.src_lookup(1, 0), abi.src_col(cyr)], abi.TUPLE_A_1MB_M_CD,
+                                            [abi.src_col(cv1), abi.src_col(cv2), abi.src_lookup(0, 0), abi.src_col(cv3)])
+    # numpy: (part, supplier) -> cost of the kept rows (every pair is unique)
+    live = np.flatnonzero(flag)
+    packed = (a[live] << 32) | b[live]
+    assert len(np.unique(packed)) == len(packed)
+    order = np.argsort(packed)
+    pk = (pa << 32) | pb
+    at = np.searchsorted(packed[order], pk)
+    at = np.minimum(at, max(len(live) - 1, 0))
+    hit = (packed[order][at] == pk) if len(live) else np.zeros(nprobe, bool)
+    c = cost[live][order][at] if len(live) else np.zeros(nprobe)
+    val = v1 * (1.0 - v2) - c * v3
+    g = sup_nat[pb] * 10000 + yr
+    want = {}
+    for gg, vv in zip(g[hit].tolist(), val[hit].tolist()):
+        s0, n0 = want.get(gg, (0.0, 0))
+        want[gg] = (s0 + vv, n0 + 1)
+    got = {int(k[0]) * 10000 + int(k[1]): (float(v[0]), int(cn)) for k, v, cn in zip(keys, vals, cnts)}
+    assert sorted(got) == sorted(want), (len(got), len(want))
+    for gg, (s0, n0) in want.items():
+        assert got[gg][1] == n0 and abs(got[gg][0] - s0) <= 1e-9 * max(abs(s0), 1.0), (gg, got[gg], s0, n0)
+    for col in cols + [ca, cb, cc, cf, csk, csn]:
+        col.free()
+    t0.free(); t1.free()
+    ks = sorted(got)
+    return ks, [got[k][1] for k in ks], [got[k][0] for k in ks]

@@ -1450,3 +1450,78 @@ def test_grouped_layout_for_composite_keys(hip_engine, oracle_engine):
     finally:
         ctx.set_option("grouped_index", 1)
         ctx.set_option("feature_min_rows", 1 << 20)
+
+
+@pytest.mark.gpu
+def test_row_pack_clustered_by_the_first_lookups_key(hip_engine, oracle_engine):
+    """Round 5: Q9's loop shape with its row pack in the order of the first lookup's key (stable radix order of the unordered probe
+    key: sdqh_aux.hip) against numpy (inside the helper), against the CPU implementation, and against the pack in row order — same
+    groups and counts, sums to 1e-10; sizes around the sort's
+    wave tile (4096 rows) and the loop's tile, one row, keys spanning one and three radix digits."""
+    ctx = hip_engine.ctx
+    cases = [dict(), dict(nprobe=4096), dict(nprobe=4097, seed=2), dict(nprobe=1, seed=3), dict(nprobe=65, seed=4), dict(nprobe=1 << 20, seed=5, nparts=200),
+             dict(n=400000, nprobe=2000003, seed=6, nparts=90000, keep=0.05), dict(nprobe=70001, seed=7, nparts=70000, n=70000, keep=0.5)]
+    try:
+        ctx.set_option("feature_min_rows", 0)
+        for kw in cases:
+            want = helpers.cluster_pack_case(oracle_engine.ctx, **kw)
+            runs = {}
+            for cluster in (1, 0, 1):
+                ctx.set_option("cluster_pack", 2 * cluster)              # (2: also where the probe key is short or near-sorted by chance)
+                ctx.set_profiling(True); ctx.kernel_log = []
+                got = helpers.cluster_pack_case(ctx, **kw)
+                names = [k for k, _ in ctx.kernel_log]
+                ctx.set_profiling(False)
+                clustered = bool(cluster) and kw.get("nprobe", 2) >= 2            # (one row has no twin, so no order to be put in)
+                assert ("k_rs_scatter" in names) == clustered and ("k_interleave_perm" in names) == clustered, (kw, cluster, names)
+                assert ("k_interleave" in names) == (not clustered), (kw, cluster, names)
+                assert got[0] == want[0] and got[1] == want[1], (kw, cluster)
+                assert all(abs(x - y) <= REL * max(abs(y), 1.0) for x, y in zip(got[2], want[2])), (kw, cluster)
+                runs[cluster] = got                                      # (group sums are LDS atomics of many waves: their last bits are not pinned in any order)
+    finally:
+        ctx.set_option("cluster_pack", 1)
+        ctx.set_option("feature_min_rows", 1 << 20)
+        hip_engine.clear()
+
+
+@pytest.mark.gpu
+def test_driven_walk_of_loops_keyed_by_the_stored_order(hip_engine, oracle_engine):
+    """Round 5: a final loop whose first lookup is keyed by the column its table is stored in the order of (Q5: l_orderkey against the
+    orders of one year and region) walks the looked-up table's KEYS and their row runs (the column's run index) instead of streaming
+    the column, when the table holds few of the keys (x_queue8's driven walk, option "x_driven": 0 never, 1 whenever the table has
+    fewer keys than the loop rows, 64 the default ratio).  Same rows as the CPU implementation either way — at sizes where the walk is
+    and is not chosen, with the lineitem rows cut around wave / step boundaries (runs cut in the middle, the last run ending at the
+    last row), and for the other configured queries with the option at its most eager."""
+    ctx = hip_engine.ctx
+    try:
+        ctx.set_option("feature_min_rows", 0)
+        for sf in (0.02, 0.3):
+            db = tpch.generate(sf, tables=sorted(tpch.columns_for(SUPPORTED)), columns=tpch.columns_for(SUPPORTED))
+            want = {q: helpers.run_query(oracle_engine, q, db) for q in ("q5", "q9", "q3")}
+            for ratio in (1, 0, 64):
+                ctx.set_option("x_driven", ratio)
+                hip_engine.clear()
+                ctx.set_profiling(True); ctx.kernel_log = []
+                for q in ("q5", "q9", "q3"):
+                    for _ in range(2):
+                        got = helpers.run_query(hip_engine, q, db)
+                        helpers.assert_rows_match(helpers.result_rows(got, want[q].columns), helpers.result_rows(want[q], want[q].columns), REL, "sf=%s x_driven=%d %s" % (sf, ratio, q))
+                names = [k for k, _ in ctx.kernel_log]
+                ctx.set_profiling(False)
+                assert "xk_group_tight" in names, (sf, ratio, sorted(set(names)))      # (Q5's final loop: the skeleton that has the walk)
+            oracle_engine.clear()
+        ctx.set_option("x_driven", 1)
+        base = tpch.generate(0.01, tables=sorted(tpch.columns_for(SUPPORTED)), columns=tpch.columns_for(SUPPORTED))
+        li = base["lineitem"].getContainer()
+        total = len(li["data"][0])
+        for n in [0, 1, 2, 7, 8, 9, 63, 65, 511, 513, 1023, 1025, 4097, 8191, 20001, total - 1, total]:
+            db = dict(base)
+            db["lineitem"] = tpch.table_from_columns(li["headers"], [np.ascontiguousarray(c[:n]) for c in li["data"]])
+            got = helpers.run_query(hip_engine, "q5", db)
+            wantq = helpers.run_query(oracle_engine, "q5", db)
+            helpers.assert_rows_match(helpers.result_rows(got, wantq.columns), helpers.result_rows(wantq, wantq.columns), REL, "n=%d/q5 driven" % n)
+    finally:
+        ctx.set_option("x_driven", 64)
+        ctx.set_option("feature_min_rows", 1 << 20)
+        hip_engine.clear()
+        oracle_engine.clear()

@@ -251,6 +251,14 @@ __global__ __launch_bounds__(TPB) void k_rs_scatter(const uint32_t* __restrict__
         if (live && !(same & lt)) s_at[wv][d] += (uint32_t)__popcll(same);         // (the lowest lane of each digit; a wave's LDS accesses keep their order)
     }
 }
+// lb[v] = the first position of the sorted keys that holds a value >= v, for v = 0 .. nvals - 1 (a thread per value: a binary search)
+__global__ __launch_bounds__(TPB) void k_lower_bounds(const uint32_t* __restrict__ sorted, int64_t n, int64_t nvals, uint32_t* __restrict__ lb) {
+    for (int64_t v = (int64_t)blockIdx.x * TPB + threadIdx.x; v < nvals; v += (int64_t)gridDim.x * TPB) {
+        int64_t lo = 0, hi = n;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)sorted[mid] < v) lo = mid + 1; else hi = mid; }
+        lb[v] = (uint32_t)lo;
+    }
+}
 // pack[i * k + j] = col[j][row[i]] (j >= ncols: padding), key32[i] = twin[row[i]]
 struct DevPackPerm { const int64_t* col[MAX_PACK]; int32_t ncols, k; };
 __global__ __launch_bounds__(TPB) void k_interleave_perm(DevPackPerm c, const uint32_t* __restrict__ row, const int32_t* __restrict__ twin, int64_t n, int64_t* __restrict__ out, int32_t* __restrict__ key32) {
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(TPB) void k_interleave_perm(DevPackPerm c, const ui
 }  // namespace
 
 namespace sdqh_host {
-int cluster_pack_build(sdqh_ctx* ctx, const int32_t* twin, int64_t lo, int64_t hi, int64_t n, const void* const* cols, int ncols, int k, void* pack_out, void* key32_out) {
+int cluster_pack_build(sdqh_ctx* ctx, const int32_t* twin, int64_t lo, int64_t hi, int64_t n, const void* const* cols, int ncols, int k, void* pack_out, void* key32_out, void* lb_out) {
     if (n < 1 || n >= ((int64_t)1 << 32) || hi < lo || (uint64_t)(hi - lo) > 0xFFFFFFFFull || ncols > MAX_PACK || ctx->capturing) return SDQH_ERR_UNSUPPORTED;
     const int64_t nw = (n + RS_ROWS - 1) / RS_ROWS, total = nw * 256, nb = (total + RS_SCAN - 1) / RS_SCAN;
     uint32_t* buf[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -288,6 +296,11 @@ int cluster_pack_build(sdqh_ctx* ctx, const int32_t* twin, int64_t lo, int64_t h
         { KernelScope _ks(ctx, "k_rs_scan_top"); hipLaunchKernelGGL(k_rs_scan_top, dim3(1), dim3(TPB), 0, ctx->stream, bsum, nb); }
         { KernelScope _ks(ctx, "k_rs_scatter"); hipLaunchKernelGGL(k_rs_scatter, dim3(wgrid), dim3(TPB), 0, ctx->stream, ka, ra, n, shift, hist, bsum, nw, kb, rb); }
         std::swap(ka, kb); std::swap(ra, rb);
+    }
+    if (lb_out) {                                                        // (hi - lo + 2 entries: the last one = n)
+        const int64_t nvals = (int64_t)range + 2;
+        KernelScope _ks(ctx, "k_lower_bounds");
+        hipLaunchKernelGGL(k_lower_bounds, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((nvals + TPB - 1) / TPB, (int64_t)ctx->num_cu * 16))), dim3(TPB), 0, ctx->stream, ka, n, nvals, static_cast<uint32_t*>(lb_out));
     }
     DevPackPerm pc; std::memset(&pc, 0, sizeof(pc));
     for (int j = 0; j < ncols; ++j) pc.col[j] = static_cast<const int64_t*>(cols[j]);

@@ -671,6 +671,7 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "direct_index" && (value == 0 || value == 1)) ctx->opt_direct_index = (int)value;
     else if (n == "row_pack" && (value == 0 || value == 1)) ctx->opt_row_pack = (int)value;
     else if (n == "cluster_pack" && value >= 0 && value <= 2) ctx->opt_cluster_pack = (int)value;
+    else if (n == "cluster_list" && (value == 0 || value == 1)) ctx->opt_cluster_list = (int)value;
     else if (n == "x_driven" && value >= 0 && value <= (1 << 20)) ctx->opt_x_driven = (int)value;
     else if (n == "coarse_kb" && value >= 0 && value <= 96) ctx->opt_coarse_kb = (int)value;
     else if (n == "lookup_pipeline" && value >= -1 && value <= 1) ctx->opt_lookup_pipeline = (int)value;
@@ -801,7 +802,7 @@ void sdqh_column_free(sdqh_ctx* ctx, sdqh_column* col) {
             for (size_t i = 0; i < m->packs.size();) {
                 auto& pk = m->packs[i];
                 if (std::find(pk.cols.begin(), pk.cols.end(), (const void*)col->data) != pk.cols.end() || pk.order_col == (const void*)col->data) {
-                    pool_free(m, pk.data); if (pk.key32) pool_free(m, pk.key32); m->packs.erase(m->packs.begin() + (long)i);
+                    pool_free(m, pk.data); if (pk.key32) pool_free(m, pk.key32); if (pk.lb) pool_free(m, pk.lb); m->packs.erase(m->packs.begin() + (long)i);
                 }
                 else ++i;
             }
@@ -2191,12 +2192,14 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
                 const int32_t* twin = static_cast<const int32_t*>(ensure_narrow(ctx, kc0));
                 void* data = twin ? pool_alloc(ctx, (size_t)nrows * (size_t)k * 8 + 64) : nullptr;
                 void* key32 = data ? pool_alloc(ctx, (size_t)nrows * 4 + 64) : nullptr;
-                if (key32 && cluster_pack_build(ctx, twin, kc0->mn, kc0->mx, nrows, cols.data(), (int)cols.size(), k, data, key32) == SDQH_OK) {
-                    sdqh_ctx::RowPack pk{cols, nrows, k, data}; pk.order_col = order_col; pk.key32 = key32;
+                void* lb = key32 ? pool_alloc(ctx, ((size_t)(kc0->mx - kc0->mn) + 2) * 4 + 64) : nullptr;      // (none: the loop streams the ordered keys)
+                if (key32 && cluster_pack_build(ctx, twin, kc0->mn, kc0->mx, nrows, cols.data(), (int)cols.size(), k, data, key32, lb) == SDQH_OK) {
+                    sdqh_ctx::RowPack pk{cols, nrows, k, data}; pk.order_col = order_col; pk.key32 = key32; pk.lb = lb; pk.key_lo = kc0->mn; pk.key_hi = kc0->mx;
                     ctx->packs.push_back(pk);
                     found = &ctx->packs.back();
                 } else {                                                       // (no twin, no memory: the pack in row order as before)
                     (void)hipGetLastError();
+                    if (lb) pool_free(ctx, lb);
                     if (key32) pool_free(ctx, key32);
                     if (data) pool_free(ctx, data);
                 }
@@ -2220,6 +2223,10 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
                 if (found->order_col) {
                     cluster_key32 = static_cast<const int32_t*>(found->key32);
                     if (ctx->opt_lookup_pipeline < 0) L.pipeline = 1;
+                    // the loop walks the first table's bitmap and the pack's runs instead of streaming the ordered keys (k_lookup_agg: RUN WALK)
+                    if (found->lb && ctx->opt_cluster_list && nrows < ((int64_t)1 << 31) && t0->dev.bm_hi >= t0->dev.bm_lo && (uint64_t)(t0->dev.bm_hi - t0->dev.bm_lo) < 0xFFFFFFE0ull) {
+                        L.run_lb = static_cast<const uint32_t*>(found->lb); L.run_lo = found->key_lo; L.run_hi = found->key_hi;
+                    }
                 }
             }
         }

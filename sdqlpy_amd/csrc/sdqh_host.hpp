@@ -144,8 +144,10 @@ struct sdqh_ctx {
     int opt_row_pack = 1;                          // final loops with lookups gather their columns from an interleaved row pack (see DevLookups)
     // order_col: null = rows in row order; else the pack is CLUSTERED — its rows stand in the (stable) order of that column's values, and key32
     // holds that column's 4-byte twin in the same order (sdqh_aux.hip: cluster_pack_build)
-    struct RowPack { std::vector<const void*> cols; int64_t nrows; int k; void* data; const void* order_col = nullptr; void* key32 = nullptr; };
+    struct RowPack { std::vector<const void*> cols; int64_t nrows; int k; void* data; const void* order_col = nullptr; void* key32 = nullptr;
+                     void* lb = nullptr; int64_t key_lo = 0, key_hi = -1; };      // lb: per key value of [key_lo, key_hi + 1] the first pack row holding a key >= it
     std::vector<RowPack> packs;                    // resident row packs, by column set (and order)
+    int opt_cluster_list = 1;                      // ... and walks the first table's key bitmap and the pack's runs (k_lookup_agg: RUN WALK) instead of streaming the ordered keys
     int opt_cluster_pack = 1;                      // a final loop whose first lookup's key column comes in no row order, whose scan has no predicate and whose gathered columns are all
                                                    // in its row pack runs over a pack CLUSTERED by that key (Q9: l_partkey): 0 = never, 2 = whatever the key's order (the tests)
     int opt_groupby_regs = 0;                      // 0 = adaptive (4 when the last run of these key columns had <= 4 groups), 4, 8
@@ -261,7 +263,8 @@ inline void rd_dirty(sdqh_ctx* c) { c->rd_clean_ff = 0; c->rd_clean_zero_off = -
 // ---- helpers defined in sdqh_aux.hip ----------------------------------------------------------------
 // a row pack in the stable order of a key column's values (twin: the column's exact 4-byte twin, lo / hi: its minimum / maximum):
 // pack_out[i * k + j] = cols[j][row_i], key32_out[i] = twin[row_i]; waits for the stream once (scratch returned to the pool)
-int cluster_pack_build(sdqh_ctx* ctx, const int32_t* twin, int64_t lo, int64_t hi, int64_t n, const void* const* cols, int ncols, int k, void* pack_out, void* key32_out);
+// lb_out (optional): hi - lo + 2 uint32, lb[v - lo] = the first pack row whose key is >= v (the last entry: n)
+int cluster_pack_build(sdqh_ctx* ctx, const int32_t* twin, int64_t lo, int64_t hi, int64_t n, const void* const* cols, int ncols, int k, void* pack_out, void* key32_out, void* lb_out);
 // one 32-bit word of device-visible host memory stored by stream `s` itself, behind what is queued there: hipStreamWriteValue32 where
 // the stream executes, a one-thread kernel where it is being recorded into a plan graph (the value-write has no graph node)
 int stream_store32(sdqh_ctx* ctx, hipStream_t s, uint32_t* word, uint32_t value);

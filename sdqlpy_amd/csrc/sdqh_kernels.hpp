@@ -2453,7 +2453,10 @@ constexpr int MAX_PACK = 8;
 // test of the table's exact key bitmap is its own L2 request — 60 M of them made Q9's final loop L2-request-bound
 // (88 M L2 reads for 3.2 M useful rows) — while a test in LDS costs nothing; only the rows that pass it go on to
 // the exact bitmap.  Built once per table (k_coarsen) and copied into LDS by every workgroup.
-struct DevLookups { DevLookup l[SDQH_MAX_LOOKUP]; int32_t n, pack_k; const int64_t* pack; const uint32_t* coarse; int32_t coarse_words, coarse_shift; int32_t pipeline, debug; };
+struct DevLookups { DevLookup l[SDQH_MAX_LOOKUP]; int32_t n, pack_k; const int64_t* pack; const uint32_t* coarse; int32_t coarse_words, coarse_shift; int32_t pipeline, debug;
+                    // RUN WALK (clustered pack): run_lb[v - run_lo] = the first pack row whose key is >= v, for v in [run_lo, run_hi + 1] (sdqh_aux.hip:
+                    // cluster_pack_build).  The loop then walks the first table's key BITMAP — every set bit a key, its pack rows a run — and streams nothing
+                    const uint32_t* run_lb; int64_t run_lo, run_hi; };
 struct PackRow { int64_t v0, v1, v2, v3, v4, v5, v6, v7; };      // named, not an array: a run-time pick must stay a select chain on registers
 
 // all pack_k values of row r with 16-byte loads (pack_k is even: padded by the host), into registers
@@ -2841,8 +2844,31 @@ __global__ __launch_bounds__(BT) void k_lookup_agg(DevFilter f, DevLookups L, De
     const int64_t full = nrows / TILE;
     const bool tail_owner = full * TILE < nrows && blockIdx.x == (unsigned)(full % gridDim.x);
     int64_t t0 = (int64_t)blockIdx.x * chunk, tail_r0 = full * TILE;
-    int c = 0, phase = t0 < full ? 0 : (tail_owner ? 1 : 2);                // 0: tiles, 1: tail, 2: last drain
+    int c = 0, phase = t0 < full ? 0 : (tail_owner ? 1 : 2);                // 0: tiles, 1: tail, 2: last drain, 3: rows from the list
     qbase = phase == 0 ? t0 * TILE : tail_r0;
+    // RUN WALK (L.run_lb): a wave takes RW_WORDS words of the first table's bitmap per step and compacts their set bits — keys — into its list
+    // in LDS; lanes take a key each (the two neighbouring entries of run_lb that bound its run: ONE round trip for up to 64 keys), and the
+    // runs are queued ONE AFTER THE OTHER, a lane per row, 64 rows at most per turn of the loop: a drain's 64 rows are two or three whole
+    // runs — neighbouring pack rows, two or three entries of the first table — as a list of the rows cut into 64s would give it.  No
+    // launch in front, no list in memory, no atomics.  Measured on Q9's 3.2 M rows at SF=10 (0.300 ms with the ordered keys streamed):
+    // a list written by a launch of its own 0.031-0.061 + 0.209 ms (one claim per wave step on ONE address, served ~9 ns apart); lanes
+    // queueing a few rows of their own runs each turn — a drain's rows from 8-16 runs — 0.277-0.289; EVERY step claimed with a returning
+    // atomic 0.311 (4096 first claims at the kernel's start, served one after the other); requesting a
+    // step's pack lines and the later lookups' first words ahead 0.209 -> 0.309 ms (loads return in order, and what the early requests
+    // bring is evicted before it is used).
+    // A wave's FIRST step is dealt out (its number in the grid); every later one is claimed in order with a returning atomic on the word behind
+    // the flags (zero when the kernel starts, reset by the merge): a step's keys are a handful, Poisson-distributed, and with steps dealt out
+    // the waves that drew the most rows finished a third after the average — the list's even cut was worth 0.05 ms; claims spread over the
+    // kernel's time do not queue up the way 4096 first claims at its start did.
+    constexpr int RW_WORDS = 8;
+    __shared__ uint32_t s_rw[BT / WAVE][RW_WORDS * 32];
+    uint64_t rw_next = 0, rw_nwords = 0; uint32_t rw_st = 0, rw_len = 0, rw_off = 0; int rw_have = 0, rw_taken = 0, rw_nk = 0, rw_j = 0;
+    bool rw_first = true;
+    if (L.run_lb) {
+        phase = 3; qbase = 0;
+        rw_nwords = ((uint64_t)(L.l[0].table.bm_hi - L.l[0].table.bm_lo) + 32) >> 5;
+        rw_next = ((uint64_t)blockIdx.x * (BT / WAVE) + threadIdx.x / WAVE) * RW_WORDS;
+    }
     // Software pipeline of the streaming part: the first lookup's keys of the NEXT tile are requested after this tile's
     // bitmap words and before anything waits, so a step costs one memory round trip (keys of i+1, words and filter
     // columns of i in flight together), not the two dependent ones (keys, then words) it would otherwise.
@@ -2906,7 +2932,51 @@ __global__ __launch_bounds__(BT) void k_lookup_agg(DevFilter f, DevLookups L, De
         }
     };
     for (;;) {
-        if (phase == 0) {
+        if (phase == 3) {
+            if (rw_j >= rw_nk) {                                                    // every run in hand is queued
+                uint32_t* keys = s_rw[threadIdx.x / WAVE];
+                if (rw_taken >= rw_have) {                                            // ... and every key of the list taken: the wave's next words, or the end
+                    if (!rw_first) {
+                        unsigned int step_i = 0;
+                        if (lane == 0) step_i = atomicAdd(reinterpret_cast<unsigned int*>(flags + 1), 1u);
+                        rw_next = ((uint64_t)gridDim.x * (BT / WAVE) + (uint64_t)(unsigned int)__shfl((int)step_i, 0, WAVE)) * RW_WORDS;
+                    }
+                    rw_first = false;
+                    if (rw_next >= rw_nwords) phase = 2;
+                    else {
+                        const uint64_t w = rw_next + (uint64_t)lane;
+                        uint32_t word = (lane < RW_WORDS && w < rw_nwords) ? L.l[0].table.bm[w] : 0u;
+                        const int cnt = __popc(word);
+                        int incl = cnt;
+#pragma unroll
+                        for (int off = 1; off < RW_WORDS; off <<= 1) { const int o = __shfl_up(incl, off, WAVE); if (lane >= off) incl += o; }      // (only the first RW_WORDS lanes hold words)
+                        rw_have = __shfl(incl, RW_WORDS - 1, WAVE);
+                        rw_taken = 0;
+                        int at = incl - cnt;
+                        for (; word; word &= word - 1u) keys[at++] = (uint32_t)(w * 32) + (uint32_t)(__ffs((int)word) - 1);
+                    }
+                }
+                rw_nk = 0; rw_j = 0; rw_off = 0;
+                if (phase == 3 && rw_taken < rw_have) {                               // a key per lane: its run
+                    const int i = rw_taken + lane;
+                    rw_st = 0; rw_len = 0;
+                    if (i < rw_have) {
+                        const int64_t key = L.l[0].table.bm_lo + (int64_t)keys[i];
+                        if (key >= L.run_lo && key <= L.run_hi) { rw_st = L.run_lb[key - L.run_lo]; rw_len = L.run_lb[key - L.run_lo + 1] - rw_st; }
+                    }
+                    rw_nk = rw_have - rw_taken < WAVE ? rw_have - rw_taken : WAVE;
+                    rw_taken += WAVE;
+                }
+            }
+            if (phase == 3 && rw_j < rw_nk) {                                        // up to 64 rows of run rw_j
+                const uint32_t st = (uint32_t)__shfl((int)rw_st, rw_j, WAVE), len = (uint32_t)__shfl((int)rw_len, rw_j, WAVE);
+                const uint32_t chunk = len - rw_off < (uint32_t)WAVE ? len - rw_off : (uint32_t)WAVE;
+                if ((uint32_t)lane < chunk) q_row[qn + lane] = (int32_t)(st + rw_off + (uint32_t)lane);
+                qn += (int)chunk;
+                rw_off += chunk;
+                if (rw_off >= len) { ++rw_j; rw_off = 0; }
+            }
+        } else if (phase == 0) {
             if (pipe) step(BoolC<true>{}); else step(BoolC<false>{});
             if (++c == chunk || t0 + c >= full) {                              // next chunk of this block, or the tail, or the end
                 c = 0; t0 += (int64_t)gridDim.x * chunk;

@@ -336,29 +336,32 @@ bool column_span8(sdqh_ctx* ctx, sdqh_column* c) {
     return c->span8 == 1;
 }
 
-// RUN INDEX of a never-decreasing I64 column (sdqh_column::run_index): per value of [mn, mx] the first row holding it, 0xFFFFFFFF for a
-// value no row holds.  Built once per column on first need (a fill and one pass over the 4-byte twin), kept with the column.  Only
-// where it pays its memory: at most 2^32 - 2 rows, a value range of at most 64 x the rows (and 2^32), a twin to read the runs' ends from.
-__global__ __launch_bounds__(256) void k_run_index(const int32_t* __restrict__ twin, int64_t n, int64_t lo, uint32_t* __restrict__ ridx) {
-    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
-        const int32_t k = twin[r];
-        if (r == 0 || twin[r - 1] != k) ridx[(int64_t)k - lo] = (uint32_t)r;
+// RUN INDEX of a never-decreasing I64 column (sdqh_column::run_index): per value v of [mn, mx + 1] the first row holding a value >= v
+// (mx - mn + 2 entries; the rows of v are index[v - mn] .. index[v - mn + 1]).  Built once per column on first need (a binary search
+// per value over the 4-byte twin), kept with the column.  Only where it pays its memory: fewer than 2^31 rows, a value range of at
+// most 64 x the rows.
+__global__ __launch_bounds__(256) void k_run_index(const int32_t* __restrict__ twin, int64_t n, int64_t lo, int64_t nvals, uint32_t* __restrict__ ridx) {
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvals; v += (int64_t)gridDim.x * 256) {
+        int64_t a = 0, b = n;
+        while (a < b) { const int64_t mid = (a + b) >> 1; if ((int64_t)twin[mid] - lo < v) a = mid + 1; else b = mid; }
+        ridx[v] = (uint32_t)a;
     }
 }
 const uint32_t* column_run_index(sdqh_ctx* ctx, sdqh_column* c) {
     if (c->run_index_state >= 0) return c->run_index_state == 1 ? static_cast<const uint32_t*>(c->run_index) : nullptr;
+    if (ctx->capturing) return nullptr;                                   // (decided outside a recording)
     c->run_index_state = 0;
-    if (c->dtype != SDQH_I64 || c->transient || c->nrows < 2 || c->nrows >= 0xFFFFFFFFll || ctx->capturing) { if (ctx->capturing) c->run_index_state = -1; return nullptr; }
+    if (c->dtype != SDQH_I64 || c->transient || c->nrows < 2 || c->nrows >= ((int64_t)1 << 31)) return nullptr;
     if (!column_nondecreasing(ctx, c) || column_minmax(ctx, c) != SDQH_OK || c->mx < c->mn) return nullptr;
     const uint64_t range = (uint64_t)(c->mx - c->mn) + 1;
-    if (range > 0xFFFFFFFFull || range > 64ull * (uint64_t)c->nrows) return nullptr;
+    if (range > 0xFFFFFFF0ull || range > 64ull * (uint64_t)c->nrows) return nullptr;
     const int32_t* twin = static_cast<const int32_t*>(column_narrow(ctx, c));
     if (!twin) return nullptr;
-    uint32_t* ridx = static_cast<uint32_t*>(attach_alloc(ctx, c, (size_t)range * 4 + 64));
+    uint32_t* ridx = static_cast<uint32_t*>(attach_alloc(ctx, c, ((size_t)range + 1) * 4 + 64));
     if (!ridx) return nullptr;
-    if (hipMemsetAsync(ridx, 0xFF, (size_t)range * 4, ctx->stream) != hipSuccess) { (void)hipGetLastError(); attach_free(ctx, c, ridx); return nullptr; }
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((c->nrows + 255) / 256, (int64_t)ctx->num_cu * 16));
-    { KernelScope ks(ctx, "k_run_index"); hipLaunchKernelGGL(k_run_index, dim3(grid), dim3(256), 0, ctx->stream, twin, c->nrows, c->mn, ridx); }
+    const int64_t nvals = (int64_t)range + 1;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nvals + 255) / 256, (int64_t)ctx->num_cu * 16));
+    { KernelScope ks(ctx, "k_run_index"); hipLaunchKernelGGL(k_run_index, dim3(grid), dim3(256), 0, ctx->stream, twin, c->nrows, c->mn, nvals, ridx); }
     if (hipGetLastError() != hipSuccess) { attach_free(ctx, c, ridx); return nullptr; }
     c->run_index = ridx; c->run_index_state = 1;
     return ridx;
@@ -993,9 +996,8 @@ std::string generate(const XInfo& x, Sink sink, bool direct) {
             << (x.pref32 ? spre32 : std::string("        off = 0; return false;\n")) << "    }\n";
         out << "    __device__ __forceinline__ static const uint32_t* sbitmap(const XArgs& a) { return "
             << (x.prefilter_op >= 0 ? "x_prefilter_bitmap(a.tab[" + std::to_string(x.tab_of[x.prefilter_op]) + "], " + (x.prefilter_composite ? "true" : "false") + ")" : std::string("nullptr")) << "; }\n";
-        if (x.driven && (sink == SINK_GROUP || sink == SINK_SUM)) {       // (the sinks whose launches ask for the tiled walk)
+        if (x.driven && sink == SINK_GROUP) {       // (the group sink's launch asks for the tiled walk)
             out << "    static constexpr bool DRIVEN = true;\n";
-            out << "    __device__ __forceinline__ static const int32_t* dkey(const XArgs& a) { return static_cast<const int32_t*>(a.ncol[" << x.driven_col << "]); }\n";
             out << "    __device__ __forceinline__ static const DevTable& dtab(const XArgs& a) { return a.tab[" << x.tab_of[x.prefilter_op] << "]; }\n";
         }
     }

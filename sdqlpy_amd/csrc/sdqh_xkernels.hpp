@@ -70,8 +70,8 @@ struct XArgs {
     uint32_t spool[SDQH_MAX_XSTR];              // string constants, back to back
     int32_t* flags;                             // |= 2: a key outside its bounds / an unpackable key part
     int64_t key_lo, key_hi;                     // bounds the key must respect (key_lo > key_hi: none)
-    // DRIVEN walk (x_queue8; programs generated with P::DRIVEN): the run index of the prefilter's key column — per value of [run_lo, run_hi]
-    // the first row holding it, 0xFFFFFFFF: none (sdqh_x.hip: column_run_index) — and the ratio the walk is chosen by (0: never)
+    // DRIVEN walk (x_queue8; programs generated with P::DRIVEN): the run index of the prefilter's key column — per value v of
+    // [run_lo, run_hi + 1] the first row holding a value >= v (sdqh_x.hip: column_run_index) — and the ratio the walk is chosen by (0: never)
     const uint32_t* run_index;
     int64_t run_lo, run_hi;
     int32_t driven_ratio, _pad_driven;
@@ -1027,15 +1027,16 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
     // DRIVEN walk (round 5).  A loop whose first lookup is keyed by a column the scanned table is STORED IN THE ORDER OF (l_orderkey) and
     // whose table holds few of that column's values (Q5: the orders of one year placed by one region's customers, 0.8 % of the keys)
     // streams 60 M keys to find the 3 % of the rows that can hit.  The table's key bitmap says which keys exist, the column's run index
-    // (XArgs::run_index) where each key's rows start: the wave walks the BITMAP instead — 64 quads of four words per step, every set
-    // bit a key, its rows the run from run_index[key] on (ended by comparing the column's twin, 8 rows per round and lane) — and the
-    // rows go through the same queue into the same drain.  Chosen by every wave alike, from the same 64-quad sample of the bitmap's
-    // density: (estimated keys) x driven_ratio <= rows; order-free sinks only (the tiled walk's condition).
+    // (XArgs::run_index) where each key's rows are: the wave walks the BITMAP instead — 64 quads of four words per step, every set bit a
+    // key, its rows run_index[key] .. run_index[key + 1) — and the rows go through the same queue into the same drain; nothing is
+    // streamed.  Chosen by every wave alike, from the same 64-quad sample of the bitmap's density: (estimated keys) x driven_ratio <=
+    // rows; order-free sinks only (the tiled walk's condition).  Measured on Q5's final loop at SF=10 (0.105 ms streamed): runs ended by
+    // comparing the column's keys 0.081; the rows listed by a launch of their own in front (one returning atomic per wave step on ONE
+    // address, 29 K of them ~9 ns apart) 0.4.
     bool driven = false;
     uint64_t d_nq = 0, d_q = 0, d_nwords = 0;
     XWindow d_w = {0u, 0u, 0u, 0u};
-    uint32_t d_bit0 = 0;
-    int64_t d_cur = -1; int32_t d_key = 0;
+    uint32_t d_bit0 = 0, d_cur = 0, d_end = 0;
     auto d_quad = [&](uint64_t q) {                                      // quad q of the bitmap; words behind its end are zero (and not read)
         const uint64_t wb = q * 4;
         if (wb + 4 <= d_nwords) return x_load_window(pbm + wb);
@@ -1075,7 +1076,10 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
             if constexpr (x_is_driven<P>::value) {
                 if (driven) {
                     produced = true;
-                    if (!__ballot((d_w.x | d_w.y | d_w.z | d_w.w) != 0u || d_cur >= 0)) {      // nothing in hand: the wave's next 64 quads, or the end
+                    if (!__ballot((d_w.x | d_w.y | d_w.z | d_w.w) != 0u || d_cur < d_end)) {      // nothing in hand: the wave's next 64 quads, or the end
+                        // (steps are dealt out.  Claimed in order with a returning atomic on ONE address, to even out their varying row counts: every
+                        //  step 0.073 -> 0.167 ms — all waves' first claims at the kernel's start, served one after the other; every step but a
+                        //  wave's first 0.128)
                         if (d_q >= d_nq) last = true;
                         else {
                             const uint64_t q = d_q + (uint64_t)lane;
@@ -1086,34 +1090,18 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
                     }
                     if (!last) {
                         // a round: every lane goes on with the run it is in, or opens the run of its next key; up to 8 rows of it are queued
-                        uint32_t m = 0; int64_t r0 = 0;
-                        if (d_cur < 0 && (d_w.x | d_w.y | d_w.z | d_w.w) != 0u) {
+                        if (d_cur >= d_end && (d_w.x | d_w.y | d_w.z | d_w.w) != 0u) {
                             const int j = d_w.x ? 0 : d_w.y ? 1 : d_w.z ? 2 : 3;
                             const uint32_t word = j == 0 ? d_w.x : j == 1 ? d_w.y : j == 2 ? d_w.z : d_w.w;
                             const uint32_t bp = (uint32_t)__ffs((int)word) - 1u, rest = word & (word - 1u);
                             if (j == 0) d_w.x = rest; else if (j == 1) d_w.y = rest; else if (j == 2) d_w.z = rest; else d_w.w = rest;
                             const int64_t key = P::dtab(a).bm_lo + (int64_t)(d_bit0 + (uint32_t)j * 32u + bp);
-                            d_key = (int32_t)key;
-                            uint32_t start = 0xFFFFFFFFu;
-                            if (key >= a.run_lo && key <= a.run_hi) start = a.run_index[key - a.run_lo];
-                            if (start != 0xFFFFFFFFu) d_cur = (int64_t)start;
+                            if (key >= a.run_lo && key <= a.run_hi) { d_cur = a.run_index[key - a.run_lo]; d_end = a.run_index[key - a.run_lo + 1]; }
                         }
-                        if (d_cur >= 0) {
-                            const uint32_t* kp = reinterpret_cast<const uint32_t*>(P::dkey(a)) + d_cur;
-                            const uint32_t kk = (uint32_t)d_key;
-                            int n = 0;
-                            if (d_cur + 8 <= nrows) {
-                                const XWindow k0 = x_load_window(kp), k1 = x_load_window(kp + 4);
-                                const uint32_t eq = (k0.x == kk ? 1u : 0u) | (k0.y == kk ? 2u : 0u) | (k0.z == kk ? 4u : 0u) | (k0.w == kk ? 8u : 0u) |
-                                                    (k1.x == kk ? 16u : 0u) | (k1.y == kk ? 32u : 0u) | (k1.z == kk ? 64u : 0u) | (k1.w == kk ? 128u : 0u);
-                                n = __ffs((int)(~eq | 0x100u)) - 1;                           // rows of the run among the 8: the leading ones
-                            } else {
-                                while (n < 8 && d_cur + n < nrows && kp[n] == kk) ++n;
-                            }
-                            m = (1u << n) - 1u; r0 = d_cur;
-                            d_cur = (n == 8 && d_cur + 8 < nrows) ? d_cur + 8 : -1;
-                        }
-                        enqueue8(r0, m);
+                        const uint32_t n = d_end - d_cur < 8u ? d_end - d_cur : 8u;
+                        const int64_t r0 = (int64_t)d_cur;
+                        d_cur += n;
+                        enqueue8(r0, (1u << n) - 1u);
                     }
                 }
             }

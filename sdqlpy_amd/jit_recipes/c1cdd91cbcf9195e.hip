@@ -34,6 +34,8 @@ struct P {
         return p;
     }
     __device__ __forceinline__ static const uint32_t* sbitmap(const XArgs& a) { return x_prefilter_bitmap(a.tab[0], false); }
+    static constexpr bool DRIVEN = true;
+    __device__ __forceinline__ static const DevTable& dtab(const XArgs& a) { return a.tab[0]; }
     template <int H> __device__ __forceinline__ static bool eval_regs(const XArgs& a, const Pair<int64_t> (&s)[1], int64_t r, XOut<NV>& o) {
         return false;
     }

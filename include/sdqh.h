@@ -199,7 +199,10 @@ void*       sdqh_stream(const sdqh_ctx* ctx);
  * order through per-workgroup bitmaps in LDS), "feature_min_rows" (2^20: the row count from which twins, packs and the wide
  * instances are used; the tests set 0), "str_rows", "lookup_debug" (cut points of k_lookup_agg for measurements: results ARE
  * wrong with it); round 5: "cluster_pack" (1: the row pack of a final loop whose first lookup's key column comes in no row order is
- * built in the stable order of that key and the loop runs over pack rows; 0 = never, 2 = whatever the key's order).
+ * built in the stable order of that key and the loop runs over pack rows; 0 = never, 2 = whatever the key's order), "cluster_list" (1: such
+ * a loop walks the first table's key bitmap and the pack's runs instead of streaming the ordered keys), "x_driven" (64: a row program whose
+ * first lookup is keyed by the column its table is stored in the order of walks the looked-up table's key bitmap and the column's run
+ * index when (estimated keys of the table) x this <= rows of the loop; 0 = never, 1 = whenever the table holds fewer keys than rows).
  * The CPU build accepts and ignores any name. */
 int         sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value);
 

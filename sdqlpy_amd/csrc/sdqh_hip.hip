@@ -2336,6 +2336,7 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
             }
             auto kern = k_lookup_agg<SH, FCT>;
             if constexpr (BIG_OK) { if (nkey0) kern = k_lookup_agg<SH, FCT, TPB, LOOKUP_PU, true>; }
+            if constexpr (BIG_OK) { if (L.run_lb) kern = k_lookup_agg<SH, FCT, TPB, LOOKUP_PU, true, true>; }      // the run walk: the instance without the streaming part
             grid = stream_grid(ctx, kern, nrows, TPB * ROWS_PER_LOAD * LOOKUP_PU * ctx->opt_probe_chunk);
             // the kernel queues candidate rows as 32-bit offsets from its current chunk and rebases them by one grid stride
             if ((int64_t)grid * ctx->opt_probe_chunk * (TPB * ROWS_PER_LOAD * LOOKUP_PU) >= ((int64_t)1 << 31)) return fail(ctx, SDQH_ERR_UNSUPPORTED, "lookup_aggregate: probe_chunk too large for this grid");

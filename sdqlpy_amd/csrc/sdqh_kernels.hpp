@@ -2774,7 +2774,9 @@ __device__ __forceinline__ int group_slot(unsigned long long* keys, unsigned lon
 // a copy per 256 threads cost more occupancy than the filter saved), and then PU = 4 row pairs per lane in flight to make up for
 // the fewer waves per CU.
 // NW: the first lookup's streamed key column is read through its narrow twin (nkey0: int32); rows in the queue read the column itself
-template <int SHAPE, class FC, int BT = TPB, int PUV = LOOKUP_PU, bool NW = false>
+// WALK: the instance of the run walk (L.run_lb set by the host): the streaming part is not compiled — the registers it holds (four row pairs of keys,
+// words and flags per lane) would set the kernel's occupancy for a part that never runs
+template <int SHAPE, class FC, int BT = TPB, int PUV = LOOKUP_PU, bool NW = false, bool WALK = false>
 __global__ __launch_bounds__(BT) void k_lookup_agg(DevFilter f, DevLookups L, DevAggSpec spec, int64_t nrows,
                                                     unsigned long long* __restrict__ gkeys, double* __restrict__ pacc,
                                                     int64_t* __restrict__ pcnt, int* __restrict__ flags, int chunk, const int32_t* __restrict__ nkey0) {
@@ -2879,7 +2881,7 @@ __global__ __launch_bounds__(BT) void k_lookup_agg(DevFilter f, DevLookups L, De
     Pair<int64_t> k0n[PU];
 #pragma unroll
     for (int u = 0; u < PU; ++u) { k0n[u].x = 0; k0n[u].y = 0; }
-    if (phase == 0 && pipe) {
+    if constexpr (!WALK) if (phase == 0 && pipe) {
 #pragma unroll
         for (int u = 0; u < PU; ++u) k0n[u] = loadc<false, NW>(skey0, t0 * TILE + (int64_t)u * SUBR + (int64_t)threadIdx.x * ROWS_PER_LOAD, nrows);
     }
@@ -2976,7 +2978,7 @@ __global__ __launch_bounds__(BT) void k_lookup_agg(DevFilter f, DevLookups L, De
                 rw_off += chunk;
                 if (rw_off >= len) { ++rw_j; rw_off = 0; }
             }
-        } else if (phase == 0) {
+        } else if constexpr (!WALK) { if (phase == 0) {
             if (pipe) step(BoolC<true>{}); else step(BoolC<false>{});
             if (++c == chunk || t0 + c >= full) {                              // next chunk of this block, or the tail, or the end
                 c = 0; t0 += (int64_t)gridDim.x * chunk;
@@ -2999,7 +3001,7 @@ __global__ __launch_bounds__(BT) void k_lookup_agg(DevFilter f, DevLookups L, De
             }
             tail_r0 += BT;
             if (tail_r0 >= nrows) phase = 2;
-        }
+        } } else { phase = 2; }                                                // (WALK: launched with L.run_lb only)
         const bool last = phase == 2;
         while (qn >= WAVE || (last && qn > 0)) {
             const int n = qn >= WAVE ? WAVE : qn;

@@ -673,6 +673,7 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "cluster_pack" && value >= 0 && value <= 2) ctx->opt_cluster_pack = (int)value;
     else if (n == "cluster_list" && (value == 0 || value == 1)) ctx->opt_cluster_list = (int)value;
     else if (n == "x_driven" && value >= 0 && value <= (1 << 20)) ctx->opt_x_driven = (int)value;
+    else if (n == "delta8" && (value == 0 || value == 1)) ctx->opt_delta8 = (int)value;
     else if (n == "coarse_kb" && value >= 0 && value <= 96) ctx->opt_coarse_kb = (int)value;
     else if (n == "lookup_pipeline" && value >= -1 && value <= 1) ctx->opt_lookup_pipeline = (int)value;
     else if (n == "probe_pipeline" && value >= 0 && value <= 1) ctx->opt_probe_pipeline = (int)value;
@@ -810,6 +811,7 @@ void sdqh_column_free(sdqh_ctx* ctx, sdqh_column* col) {
         attach_free(ctx, col, col->d_minmax);
         if (col->narrow) attach_free(ctx, col, col->narrow);
         if (col->run_index) attach_free(ctx, col, col->run_index);
+        if (col->delta8) attach_free(ctx, col, col->delta8);
         column_codes_release(ctx, col);
     }
     delete col;
@@ -2597,6 +2599,8 @@ int sdqh_column_copy_in(sdqh_ctx* ctx, sdqh_column* col, int64_t row0, int64_t n
     col->narrow_state = unknown;
     if (col->run_index) { attach_free(ctx, col, col->run_index); col->run_index = nullptr; }
     col->run_index_state = -1;
+    if (col->delta8) { attach_free(ctx, col, col->delta8); col->delta8 = nullptr; }
+    col->delta8_state = -1;
     column_codes_release(ctx, col);
     if (col->transient) col->code_state = 0;
     return ctx->opt_async_copies ? SDQH_OK : sync_stream(ctx);

@@ -117,6 +117,7 @@ struct sdqh_ctx {
     int opt_window = 0;                 // x_queue8's 32-bit prefilter tests a lane's 8 rows against ONE 16-byte window of the bitmap when the key column's 8-row spans allow (column_span8): measured
                                         // on par with 8 single-word requests once those are coalesced (Q3's probe 0.083 vs 0.081 ms) and slower where every row is tested (Q5's final loop 0.140 vs 0.130)
     int opt_x_driven = 64;              // the driven walk of x_queue8 is taken when (estimated entries of the first lookup's table) x this <= rows of the loop; 0 = never
+    int opt_delta8 = 1;                 // queue programs stream a key column whose 8-row groups span at most 255 through its 12-bytes-per-8-rows delta twin
     int opt_x_waves = 0;                // > 0: wave segments per CU for the queue skeletons of row programs (0: each sink's own default)
     // K-F rows delivered behind the call (sdqh_table_compact_async): two device staging buffers in turn, a copy stream (side[1]),
     // the event of each buffer's last copy, and whether a copy may still be in flight
@@ -182,7 +183,12 @@ struct sdqh_column {
     // RUN INDEX of a never-decreasing column (sdqh_x.hip: column_run_index): per value v of [mn, mx] the first row that holds it (0xFFFFFFFF: none) —
     // a final loop whose first lookup is keyed by such a column and hits few of its values walks the TABLE's keys and their row runs
     // instead of streaming the column (x_queue8's driven walk)
-    void* run_index = nullptr;         // device: (mx - mn + 1) uint32
+    // DELTA twin (sdqh_x.hip: column_delta8): aligned groups of 8 consecutive rows as 12 bytes — the group's smallest value (int32) and eight
+    // one-byte offsets from it — for a column whose groups span at most 255 (a key the table is stored in the order of, a foreign key of
+    // such a table: o_orderkey, l_orderkey).  1.5 bytes per row where the 4-byte twin has 4; verified row by row when built.
+    void* delta8 = nullptr;            // device: ceil(nrows / 8) records of 12 bytes
+    int delta8_state = -1;             // -1 not tried, 0 none, 1 present
+    void* run_index = nullptr;         // device: (mx - mn + 2) uint32
     int run_index_state = -1;          // -1 not tried, 0 none (not ordered / too wide a range / too many rows), 1 present
     bool transient = false;            // a view of a table's K-F buffers (sdqh_table_columns): lives for one run — no twins, no statistics gathered for it
     size_t row_bytes() const { return dtype == SDQH_STR ? (size_t)width * 4 : 8; }

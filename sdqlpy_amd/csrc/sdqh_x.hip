@@ -49,7 +49,7 @@ std::string entry_name(Sink s, bool direct, bool tight) {
     return std::string("xk_") + sk + (tight ? "_tight" : direct ? "_direct" : "_queue");
 }
 const char* VSTAGE_ENTRY = "xk_build_values";
-enum Enc { ENC_RAW = 0, ENC_N32 = 1, ENC_C16 = 2, ENC_C8 = 3 };
+enum Enc { ENC_D8 = -1, ENC_RAW = 0, ENC_N32 = 1, ENC_C16 = 2, ENC_C8 = 3 };      // (D8: the delta twin, queue programs only; ordered so that `>= ENC_C16` means "coded")
 // the same name as the profiling label of a launch (a pointer that stays valid): bench.py's per-kernel table and rocprofv3's agree on names
 const char* launch_label(Sink s, bool direct, bool tight) {
     static std::mutex mu; static std::vector<std::string*> names;
@@ -347,6 +347,46 @@ __global__ __launch_bounds__(256) void k_run_index(const int32_t* __restrict__ t
         ridx[v] = (uint32_t)a;
     }
 }
+// DELTA twin (sdqh_column::delta8): per aligned group of 8 rows the smallest value of the group's 4-byte twin and eight one-byte offsets from it;
+// a group that spans more than 255 sets the flag and the column keeps its 4-byte twin.  Rows behind the end repeat the last row.
+__global__ __launch_bounds__(256) void k_delta8(const int32_t* __restrict__ twin, int64_t n, int64_t ngroups, uint32_t* __restrict__ out, int* __restrict__ flag) {
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (int64_t)gridDim.x * 256) {
+        int32_t v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int64_t r = g * 8 + i; v[i] = twin[r < n ? r : n - 1]; }
+        int32_t lo = v[0], hi = v[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) { lo = v[i] < lo ? v[i] : lo; hi = v[i] > hi ? v[i] : hi; }
+        if ((int64_t)hi - (int64_t)lo > 255) { *flag = 1; continue; }
+        uint32_t w1 = 0, w2 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { w1 |= (uint32_t)(v[i] - lo) << (8 * i); w2 |= (uint32_t)(v[4 + i] - lo) << (8 * i); }
+        out[g * 3] = (uint32_t)lo; out[g * 3 + 1] = w1; out[g * 3 + 2] = w2;
+    }
+}
+const void* column_delta8(sdqh_ctx* ctx, sdqh_column* c) {
+    if (c->delta8_state >= 0) return c->delta8_state == 1 ? c->delta8 : nullptr;
+    if (ctx->capturing) return nullptr;
+    c->delta8_state = 0;
+    if (c->dtype != SDQH_I64 || c->transient || c->nrows < 8) return nullptr;
+    const int32_t* twin = static_cast<const int32_t*>(column_narrow(ctx, c));
+    if (!twin) return nullptr;
+    const int64_t ngroups = (c->nrows + 7) / 8;
+    uint32_t* out = static_cast<uint32_t*>(attach_alloc(ctx, c, (size_t)ngroups * 12 + 64));
+    int* flag = static_cast<int*>(pool_alloc(ctx, 64));
+    bool ok = out && flag && hipMemsetAsync(flag, 0, 4, ctx->stream) == hipSuccess;
+    if (ok) {
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((ngroups + 255) / 256, (int64_t)ctx->num_cu * 16));
+        hipLaunchKernelGGL(k_delta8, dim3(grid), dim3(256), 0, ctx->stream, twin, c->nrows, ngroups, out, flag);
+        int* host = static_cast<int*>(ctx->result_host);
+        ok = hipMemcpyAsync(host, flag, 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess && host[0] == 0;
+    }
+    if (!ok) (void)hipGetLastError();
+    if (flag) pool_free(ctx, flag);
+    if (ok) { c->delta8 = out; c->delta8_state = 1; }
+    else if (out) attach_free(ctx, c, out);
+    return ok ? out : nullptr;
+}
 const uint32_t* column_run_index(sdqh_ctx* ctx, sdqh_column* c) {
     if (c->run_index_state >= 0) return c->run_index_state == 1 ? static_cast<const uint32_t*>(c->run_index) : nullptr;
     if (ctx->capturing) return nullptr;                                   // (decided outside a recording)
@@ -485,6 +525,24 @@ void tight_plan(sdqh_ctx* ctx, int64_t nrows, XInfo* x) {
             if (xdebug) std::fprintf(stderr, "[x] driven walk: enc %d column rows %lld run index %d -> %d\n", x->enc[c], (long long)kc->nrows, kc->run_index_state, (int)x->driven);
         }
     }
+    // queue programs: the prefilter's key through its delta twin where it has one (the stream's widest column: 4 -> 1.5 bytes per row); the rows
+    // that are drained go on reading the 4-byte twin by row (gather32)
+    if (!regs_all && !fake && !x->vstage && ctx->opt_delta8 && x->pref32 && !x->driven) {
+        const sdqh_xop& ko = p->ops[x->prefilter_part0];
+        if (ko.code == SDQH_X_COL) {
+            const int c = x->col_of[x->prefilter_part0];
+            sdqh_column* kc = const_cast<sdqh_column*>(x->cols[c]);
+            if (x->enc[c] == ENC_N32 && kc->nrows == nrows && x->pnear && column_delta8(ctx, kc)) { x->enc[c] = ENC_D8; x->narrow_mask &= ~(1u << c); x->gather32 |= 1u << c; }
+        }
+    }
+    // ... and a value-queue build (x_vstage8: every column is streamed, nothing is read by row) every 4-byte integer column whose 8-row groups
+    // are narrow (the build's key on a table stored in its order: o_orderkey)
+    if (x->vstage && !fake && ctx->opt_delta8) {
+        for (int c = 0; c < x->ncols; ++c) {
+            sdqh_column* kc = const_cast<sdqh_column*>(x->cols[c]);
+            if (x->enc[c] == ENC_N32 && kc->dtype == SDQH_I64 && kc->nrows == nrows && column_span8(ctx, kc) && column_delta8(ctx, kc)) { x->enc[c] = ENC_D8; x->narrow_mask &= ~(1u << c); }
+        }
+    }
     // comparisons of a coded column with a constant, in code space
     for (int j = 0; j < p->nops; ++j) {
         const sdqh_xop& u = p->ops[j];
@@ -596,6 +654,7 @@ struct Gen {
                     const std::string e = "a.dict[" + std::to_string(c) + "][xt_u8(" + w + ", i)]";
                     return o.type == SDQH_T_F64 ? "x_f(" + e + ")" : e;
                 }
+                case ENC_D8: return "(int64_t)xt_d8(" + w + ", i)";
                 case ENC_N32: return o.type == SDQH_T_F64 ? "narrow_decode(xt_i32(" + w + ", i))" : "(int64_t)xt_i32(" + w + ", i)";
                 case ENC_RAW: return o.type == SDQH_T_F64 ? "x_f(xt_i64(" + w + ", i))" : "xt_i64(" + w + ", i)";
                 default: return "0 /* a 16-bit code has no value form */";
@@ -851,7 +910,7 @@ std::string generate_vstage(const XInfo& x) {
     bool q32 = x.irange[p->key] >= 1;                                     // key and payload fit 32 bits: a queue of 4-byte words
     for (int v = 0; v < p->nvals; ++v) q32 = q32 && p->ops[p->vals[v]].type == SDQH_T_I64 && x.irange[p->vals[v]] >= 1;
     out << "struct P {\n    static constexpr int NV = " << p->nvals << ", ND = " << tabs.size() << ", NL = " << x.nlk << ";\n    static constexpr bool Q32 = " << (q32 ? "true" : "false") << ";\n    struct Regs {";
-    for (size_t i = 0; i < scols.size(); ++i) out << " uint32_t c" << i << "[" << bpr(scols[i]) * 2 << "];";
+    for (size_t i = 0; i < scols.size(); ++i) out << " uint32_t c" << i << "[" << (x.enc[scols[i]] == ENC_D8 ? 3 : bpr(scols[i]) * 2) << "];";
     out << " };\n";
     out << "    __device__ __forceinline__ static void load_dicts(const XArgs& a, int64_t (*tab)[256]) {\n";
     for (size_t j = 0; j < tabs.size(); ++j) {
@@ -870,7 +929,8 @@ std::string generate_vstage(const XInfo& x) {
     for (size_t i = 0; i < scols.size(); ++i) {
         const int c = scols[i];
         const char* src = x.enc[c] >= ENC_C16 ? "a.code[" : x.enc[c] == ENC_N32 ? "a.ncol[" : "a.col[";
-        out << "        xt_load<" << bpr(c) << ", TAIL>(" << src << c << "], r, nrows, s.c" << i << ");\n";
+        if (x.enc[c] == ENC_D8) out << "        xt_load_d8(a.dcol[" << c << "], r, s.c" << i << ");\n";
+        else out << "        xt_load<" << bpr(c) << ", TAIL>(" << src << c << "], r, nrows, s.c" << i << ");\n";
     }
     out << "    }\n";
     out << "    __device__ __forceinline__ static bool gates(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i, const int64_t r) {\n" << gates << "    }\n";
@@ -967,7 +1027,7 @@ std::string generate(const XInfo& x, Sink sink, bool direct) {
     out << "struct P {\n    static constexpr int NS = " << ns << ", NV = " << p->nvals << ", NSC = " << tcols.size() << ", NSOP = " << nsop << ", ND = " << tabs8.size() << ";\n";
     if (q8) {
         out << "    struct Regs {";
-        for (int i = 0; i < ns; ++i) out << " uint32_t c" << i << "[" << bpr(scols[(size_t)i]) * 2 << "];";
+        for (int i = 0; i < ns; ++i) out << " uint32_t c" << i << "[" << (x.enc[scols[(size_t)i]] == ENC_D8 ? 3 : bpr(scols[(size_t)i]) * 2) << "];";
         out << " };\n";
         out << "    __device__ __forceinline__ static void load_dicts(const XArgs& a, int64_t (*tab)[256]) {\n";
         for (size_t j = 0; j < tabs8.size(); ++j) {
@@ -986,7 +1046,8 @@ std::string generate(const XInfo& x, Sink sink, bool direct) {
         for (int i = 0; i < ns; ++i) {
             const int c = scols[(size_t)i];
             const char* src = x.enc[c] >= ENC_C16 ? "a.code[" : x.enc[c] == ENC_N32 ? "a.ncol[" : "a.col[";
-            out << "        xt_load<" << bpr(c) << ", TAIL>(" << src << c << "], r, nrows, s.c" << i << ");\n";
+            if (x.enc[c] == ENC_D8) out << "        xt_load_d8(a.dcol[" << c << "], r, s.c" << i << ");\n";
+            else out << "        xt_load<" << bpr(c) << ", TAIL>(" << src << c << "], r, nrows, s.c" << i << ");\n";
         }
         out << "    }\n";
         out << "    __device__ __forceinline__ static bool stest(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i) {\n" << stest8 << "    }\n";
@@ -1268,6 +1329,7 @@ int fill_xargs(sdqh_ctx* ctx, const XInfo& x, XArgs* a, int32_t* flags, int64_t 
         a->tab[t] = x.tabs[t]->dev;
     }
     if (x.tight) for (int c = 0; c < x.ncols; ++c) a->dlo[c] = x.dlo[c];
+    if (x.tight) for (int c = 0; c < x.ncols; ++c) if (x.enc[c] == ENC_D8) a->dcol[c] = x.cols[c]->delta8;
     if (x.tight) for (int c = 0; c < x.ncols; ++c) if (x.enc[c] >= ENC_C16) { a->code[c] = x.cols[c]->code; a->dict[c] = static_cast<const int64_t*>(x.cols[c]->dict); a->ndict[c] = x.cols[c]->ndict; }
     std::memcpy(a->cc, x.cc, sizeof(x.cc[0]) * (size_t)x.ncc);
     std::memcpy(a->ci, x.ci, sizeof(x.ci[0]) * (size_t)x.nci);
@@ -1332,15 +1394,16 @@ int launch(sdqh_ctx* ctx, hipFunction_t fn, const char* name, const XArgs& a, co
 // survivor-dependent stores are not modelled; nor is the tile every workgroup of the pipelined tight skeleton requests a second
 // time after its last (an L2 hit: it never reaches the memory side).
 int64_t model_stream_bytes(const XInfo& x, int64_t nrows, bool regs_all) {
-    int64_t per_row = 0;
+    int64_t per_row = 0, per_8rows = 0;
     for (int c = 0; c < x.ncols; ++c) {
         bool streamed = regs_all;
         if (!streamed) for (int sc : x.scols) streamed = streamed || sc == c;
         if (!streamed || x.cols[c]->dtype == SDQH_STR) continue;
+        if (x.tight && x.enc[c] == ENC_D8) { per_8rows += 12; continue; }
         if (x.tight) per_row += x.enc[c] == ENC_C8 ? 1 : x.enc[c] == ENC_C16 ? 2 : x.enc[c] == ENC_N32 ? 4 : 8;
         else per_row += ((x.narrow_mask >> c) & 1u) ? 4 : 8;
     }
-    int64_t bytes = per_row * nrows;
+    int64_t bytes = per_row * nrows + per_8rows * ((nrows + 7) / 8);
     auto bitmap = [&](const sdqh_table* t) { if (t && t->dev.bm && t->dev.bm_hi >= t->dev.bm_lo) bytes += (int64_t)(((uint64_t)(t->dev.bm_hi - t->dev.bm_lo) >> t->dev.bm_shift) / 8 + 4); };
     if (x.vstage) for (int l = 0; l < x.nlk; ++l) bitmap(x.tabs[x.tab_of[x.lk_op[l]]]);
     else if (!regs_all && x.prefilter_op >= 0) bitmap(x.tabs[x.tab_of[x.prefilter_op]]);

@@ -59,6 +59,7 @@ struct XArgs {
     const void* col[SDQH_MAX_XCOLS];
     const void* ncol[SDQH_MAX_XCOLS];           // exact 4-byte twins of the STREAMED columns that have one (sload reads them; everything by row reads col)
     int32_t width[SDQH_MAX_XCOLS];              // STR columns: code units per row
+    const void* dcol[SDQH_MAX_XCOLS];           // delta twins (12 bytes per aligned group of 8 rows: smallest value + eight one-byte offsets) of the key columns a QUEUE program streams that way
     const void* code[SDQH_MAX_XCOLS];           // sorted-dictionary code twins (1 or 2 bytes per row) of the columns a TIGHT program streams that way
     const int64_t* dict[SDQH_MAX_XCOLS];        // their dictionaries: ndict raw 8-byte values, ascending
     int32_t ndict[SDQH_MAX_XCOLS];
@@ -778,6 +779,14 @@ __device__ __forceinline__ void xt_load(const void* __restrict__ p, int64_t r, i
         }
     }
 }
+// delta twin: the 12-byte record of the lane's 8 rows (r is a multiple of 8 in every skeleton; the twin is padded to whole groups)
+__device__ __forceinline__ void xt_load_d8(const void* __restrict__ p, int64_t r, uint32_t (&w)[3]) {
+    using V = uint32_t __attribute__((ext_vector_type(3)));
+    typedef V __attribute__((aligned(4))) UV;
+    const UV t = *reinterpret_cast<const UV*>(static_cast<const char*>(p) + (r >> 3) * 12);
+    w[0] = t.x; w[1] = t.y; w[2] = t.z;
+}
+__device__ __forceinline__ int32_t xt_d8(const uint32_t (&w)[3], int i) { return (int32_t)w[0] + (int32_t)((w[1 + i / 4] >> (8 * (i % 4))) & 0xFFu); }
 __device__ __forceinline__ uint32_t xt_u8(const uint32_t (&w)[2], int i) { return (w[i / 4] >> (8 * (i % 4))) & 0xFFu; }
 __device__ __forceinline__ uint32_t xt_u16(const uint32_t (&w)[4], int i) { return (w[i / 2] >> (16 * (i % 2))) & 0xFFFFu; }
 __device__ __forceinline__ int32_t xt_i32(const uint32_t (&w)[8], int i) { return (int32_t)w[i]; }

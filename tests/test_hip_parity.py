@@ -1525,3 +1525,58 @@ def test_driven_walk_of_loops_keyed_by_the_stored_order(hip_engine, oracle_engin
         ctx.set_option("feature_min_rows", 1 << 20)
         hip_engine.clear()
         oracle_engine.clear()
+
+
+@pytest.mark.gpu
+def test_delta_twins_change_no_bit(hip_engine, oracle_engine):
+    """Round 5: a queue program streams its prefilter's key column — a key the table is stored in the order of (l_orderkey, o_orderkey) —
+    through its DELTA twin: 12 bytes per aligned group of 8 rows (the group's smallest value and eight one-byte offsets), verified
+    group by group when built.  The rows a loop meets and their order do not depend on the encoding, so q3 (its probe streams l_orderkey
+    that way) returns the SAME bits with the option off, q4 / q10 / q12 the same rows; a key column whose groups span more than 255
+    somewhere keeps its 4-byte twin (orders cut out of the middle: one group straddles the gap) and nothing changes either; sizes
+    around the 8-row group and the skeleton's 512-row step."""
+    ctx = hip_engine.ctx
+    qs = ["q3", "q4", "q10", "q12", "q5"]
+    db = tpch.generate(1.0, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+
+    def run_all(database, names):
+        out = {}
+        for q in names:
+            r = helpers.run_query(hip_engine, q, database)
+            out[q] = helpers.result_rows(r, r.columns)
+        return out
+    try:
+        ctx.set_option("delta8", 1)
+        hip_engine.clear()
+        on = run_all(db, qs)
+        ctx.set_option("delta8", 0)
+        hip_engine.clear()
+        off = run_all(db, qs)
+        assert on["q3"] == off["q3"]
+        for q in qs:
+            helpers.assert_rows_match(on[q], off[q], 1e-12, "delta twins/" + q)
+        want = helpers.run_query(oracle_engine, "q3", db)
+        helpers.assert_rows_match(on["q3"], helpers.result_rows(want, want.columns), REL, "delta twins/q3 against the CPU implementation")
+        # a gap in the key: the lineitems of the orders 200 001 .. 4 000 000 removed — the group that straddles the gap spans millions
+        li = db["lineitem"].getContainer()
+        ok = li["data"][li["headers"].index("l_orderkey")]
+        keep = (ok <= 200000) | (ok > 4000000)
+        ctx.set_option("feature_min_rows", 0)
+        for n in (None, 7, 8, 9, 511, 513, 4097):
+            cols = [np.ascontiguousarray(c[keep] if n is None else c[:n]) for c in li["data"]]
+            cut = dict(db)
+            cut["lineitem"] = tpch.table_from_columns(li["headers"], cols)
+            ctx.set_option("delta8", 1)
+            hip_engine.clear()
+            a = run_all(cut, ["q3"])
+            ctx.set_option("delta8", 0)
+            hip_engine.clear()
+            b = run_all(cut, ["q3"])
+            assert a == b, n
+            w = helpers.run_query(oracle_engine, "q3", cut)
+            helpers.assert_rows_match(a["q3"], helpers.result_rows(w, w.columns), REL, "delta twins/cut %r" % (n,))
+    finally:
+        ctx.set_option("delta8", 1)
+        ctx.set_option("feature_min_rows", 1 << 20)
+        hip_engine.clear()
+        oracle_engine.clear()

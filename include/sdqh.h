@@ -202,7 +202,8 @@ void*       sdqh_stream(const sdqh_ctx* ctx);
  * built in the stable order of that key and the loop runs over pack rows; 0 = never, 2 = whatever the key's order), "cluster_list" (1: such
  * a loop walks the first table's key bitmap and the pack's runs instead of streaming the ordered keys), "x_driven" (64: a row program whose
  * first lookup is keyed by the column its table is stored in the order of walks the looked-up table's key bitmap and the column's run
- * index when (estimated keys of the table) x this <= rows of the loop; 0 = never, 1 = whenever the table holds fewer keys than rows).
+ * index when (estimated keys of the table) x this <= rows of the loop; 0 = never, 1 = whenever the table holds fewer keys than rows),
+ * "delta8" (1: queue programs stream a key column whose aligned 8-row groups span at most 255 through its delta twin, 12 bytes per 8 rows).
  * The CPU build accepts and ignores any name. */
 int         sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value);
 

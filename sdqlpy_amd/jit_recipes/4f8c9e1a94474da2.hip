@@ -2,18 +2,18 @@
 using namespace sdqh;
 struct P {
     static constexpr int NS = 2, NV = 1, NSC = 0, NSOP = 0, ND = 0;
-    struct Regs { uint32_t c0[4]; uint32_t c1[8]; };
+    struct Regs { uint32_t c0[4]; uint32_t c1[3]; };
     __device__ __forceinline__ static void load_dicts(const XArgs& a, int64_t (*tab)[256]) {
     }
     template <bool TAIL> __device__ __forceinline__ static void sload(const XArgs& a, int64_t r, int64_t nrows, Regs& s) {
         xt_load<2, TAIL>(a.code[0], r, nrows, s.c0);
-        xt_load<4, TAIL>(a.ncol[1], r, nrows, s.c1);
+        xt_load_d8(a.dcol[1], r, s.c1);
     }
     __device__ __forceinline__ static bool stest(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i) {
         bool p = true;
         const bool v2 = (xt_u16(s.c0, i) >= a.cc[0]);
         p = p & v2;
-        const int64_t v3 = (int64_t)xt_i32(s.c1, i);
+        const int64_t v3 = (int64_t)xt_d8(s.c1, i);
         p = p && x_may_hit(a.tab[0], v3, false);
         return p;
     }
@@ -21,7 +21,7 @@ struct P {
         bool p = true;
         const bool v2 = (xt_u16(s.c0, i) >= a.cc[0]);
         p = p & v2;
-        const int64_t v3 = (int64_t)xt_i32(s.c1, i);
+        const int64_t v3 = (int64_t)xt_d8(s.c1, i);
         const bool in = (v3 >= a.tab[0].bm_lo) & (v3 <= a.tab[0].bm_hi);
         p = p & in;
         const uint64_t off = in ? (uint64_t)(v3 - a.tab[0].bm_lo) : 0ull;
@@ -33,7 +33,7 @@ struct P {
         bool p = true;
         const bool v2 = (xt_u16(s.c0, i) >= a.cc[0]);
         p = p & v2;
-        const int64_t v3 = (int64_t)xt_i32(s.c1, i);
+        const int64_t v3 = (int64_t)xt_d8(s.c1, i);
         const uint32_t o32 = (uint32_t)((int32_t)v3 - (int32_t)a.tab[0].bm_lo);
         const bool in = o32 <= (uint32_t)(a.tab[0].bm_hi - a.tab[0].bm_lo);
         p = p & in;

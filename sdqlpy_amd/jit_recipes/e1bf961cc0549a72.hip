@@ -3,13 +3,13 @@ using namespace sdqh;
 struct P {
     static constexpr int NV = 2, ND = 0, NL = 1;
     static constexpr bool Q32 = true;
-    struct Regs { uint32_t c0[8]; uint32_t c1[8]; uint32_t c2[8]; uint32_t c3[2]; };
+    struct Regs { uint32_t c0[8]; uint32_t c1[8]; uint32_t c2[3]; uint32_t c3[2]; };
     __device__ __forceinline__ static void load_dicts(const XArgs& a, int64_t (*tab)[256]) {
     }
     template <bool TAIL> __device__ __forceinline__ static void sload(const XArgs& a, int64_t r, int64_t nrows, Regs& s) {
         xt_load<4, TAIL>(a.ncol[0], r, nrows, s.c0);
         xt_load<4, TAIL>(a.ncol[1], r, nrows, s.c1);
-        xt_load<4, TAIL>(a.ncol[2], r, nrows, s.c2);
+        xt_load_d8(a.dcol[2], r, s.c2);
         xt_load<1, TAIL>(a.code[3], r, nrows, s.c3);
     }
     __device__ __forceinline__ static bool gates(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i, const int64_t r) {
@@ -31,7 +31,7 @@ struct P {
     }
     __device__ __forceinline__ static const uint32_t* lkbm(const XArgs& a, int l) { return a.tab[0].bm; }
     __device__ __forceinline__ static void row(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i, const int64_t r, XOut<NV>& o) {
-        const int64_t v5 = (int64_t)xt_i32(s.c2, i);
+        const int64_t v5 = (int64_t)xt_d8(s.c2, i);
         o.key = v5; o.bad = false;
         const int64_t v0 = (int64_t)xt_i32(s.c0, i);
         o.val[0] = v0;

@@ -203,7 +203,8 @@ void*       sdqh_stream(const sdqh_ctx* ctx);
  * a loop walks the first table's key bitmap and the pack's runs instead of streaming the ordered keys), "x_driven" (64: a row program whose
  * first lookup is keyed by the column its table is stored in the order of walks the looked-up table's key bitmap and the column's run
  * index when (estimated keys of the table) x this <= rows of the loop; 0 = never, 1 = whenever the table holds fewer keys than rows),
- * "delta8" (1: queue programs stream a key column whose aligned 8-row groups span at most 255 through its delta twin, 12 bytes per 8 rows).
+ * "delta8" (1: queue programs stream a key column whose aligned 8-row groups span at most 255 through its delta twin, 12 bytes per 8 rows),
+ * "word_pairs" (0: whole-table builds keyed by a strictly increasing column also keep { first row, bits } pairs per bitmap word).
  * The CPU build accepts and ignores any name. */
 int         sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value);
 

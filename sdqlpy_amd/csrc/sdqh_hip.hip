@@ -674,6 +674,7 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "cluster_list" && (value == 0 || value == 1)) ctx->opt_cluster_list = (int)value;
     else if (n == "x_driven" && value >= 0 && value <= (1 << 20)) ctx->opt_x_driven = (int)value;
     else if (n == "delta8" && (value == 0 || value == 1)) ctx->opt_delta8 = (int)value;
+    else if (n == "word_pairs" && (value == 0 || value == 1)) ctx->opt_word_pairs = (int)value;
     else if (n == "coarse_kb" && value >= 0 && value <= 96) ctx->opt_coarse_kb = (int)value;
     else if (n == "lookup_pipeline" && value >= -1 && value <= 1) ctx->opt_lookup_pipeline = (int)value;
     else if (n == "probe_pipeline" && value >= 0 && value <= 1) ctx->opt_probe_pipeline = (int)value;
@@ -1201,17 +1202,19 @@ static int build_dense(sdqh_ctx* ctx, int64_t nrows, const sdqh_column* key, int
         tb->nwords = (range + 31) / 32;
         tb->bm = static_cast<uint32_t*>(table_alloc(ctx, tb, tb->nwords * 4 + 64));
         uint32_t* wprefix = static_cast<uint32_t*>(table_alloc(ctx, tb, tb->nwords * 4 + 64));
+        uint32_t* wpair = ctx->opt_word_pairs ? static_cast<uint32_t*>(table_alloc(ctx, tb, tb->nwords * 8 + 64)) : nullptr;      // (none: lookups read the two arrays)
         if (!st.seg_count || !st.shits || !tb->hdr || !tb->bm || !wprefix) { table_release(ctx, tb); delete tb; return fail(ctx, SDQH_ERR_NOMEM, "dense build: out of device memory"); }
         st.hdr = tb->hdr;
         tb->dev.hdr = tb->hdr; tb->dev.shits = st.shits; tb->dev.bm_lo = lo; tb->dev.bm_hi = hi; tb->dev.bm = tb->bm; tb->dev.bm_shift = 0; tb->dev.wprefix = wprefix;
+        tb->dev.wpair = reinterpret_cast<const unsigned long long*>(wpair);
         for (int p = 0; p < npayload; ++p) tb->dev.pay[p] = st.pay[p];
         call_begin(ctx);
-        { FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); fl.add(st.shits, (size_t)nrows * 4, 0); fl.add(tb->bm, tb->nwords * 4, 0); if (accumulate) fl.add(st.sacc, acc_bytes, 0); launch_fill(ctx, fl); }
+        { FillList fl; fl.add(tb->hdr, sizeof(TableHeader), 0); fl.add(st.shits, (size_t)nrows * 4, 0); fl.add(tb->bm, tb->nwords * 4, 0); if (wpair) fl.add(wpair, tb->nwords * 8, 0); if (accumulate) fl.add(st.sacc, acc_bytes, 0); launch_fill(ctx, fl); }
         {
             const unsigned rgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nrows + TPB * RANK_INC_NB - 1) / (TPB * RANK_INC_NB), (int64_t)ctx->num_cu * 32));
             const int32_t* k32 = (ctx->opt_narrow && nrows >= ctx->opt_feature_min_rows && !key->transient) ? static_cast<const int32_t*>(ensure_narrow(ctx, const_cast<sdqh_column*>(key))) : nullptr;
-            if (k32) { auto kern = k_rank_increasing<int32_t>; LAUNCH(ctx, "k_rank_increasing", kern, rgrid, k32, nrows, lo, tb->bm, wprefix, tb->hdr, st.seg_count, st.nseg, st.seg_rows); }
-            else { auto kern = k_rank_increasing<int64_t>; LAUNCH(ctx, "k_rank_increasing", kern, rgrid, kc, nrows, lo, tb->bm, wprefix, tb->hdr, st.seg_count, st.nseg, st.seg_rows); }
+            if (k32) { auto kern = k_rank_increasing<int32_t>; LAUNCH(ctx, "k_rank_increasing", kern, rgrid, k32, nrows, lo, tb->bm, wprefix, tb->hdr, st.seg_count, st.nseg, st.seg_rows, wpair); }
+            else { auto kern = k_rank_increasing<int64_t>; LAUNCH(ctx, "k_rank_increasing", kern, rgrid, kc, nrows, lo, tb->bm, wprefix, tb->hdr, st.seg_count, st.nseg, st.seg_rows, wpair); }
         }
         call_end(ctx);
         hipError_t e2 = hipGetLastError();

@@ -117,6 +117,8 @@ struct sdqh_ctx {
     int opt_window = 0;                 // x_queue8's 32-bit prefilter tests a lane's 8 rows against ONE 16-byte window of the bitmap when the key column's 8-row spans allow (column_span8): measured
                                         // on par with 8 single-word requests once those are coalesced (Q3's probe 0.083 vs 0.081 ms) and slower where every row is tested (Q5's final loop 0.140 vs 0.130)
     int opt_x_driven = 64;              // the driven walk of x_queue8 is taken when (estimated entries of the first lookup's table) x this <= rows of the loop; 0 = never
+    int opt_word_pairs = 0;             // whole-table builds in the rank = row layout also keep { first row, bits } pairs per bitmap word: a lookup's two requests on one line
+                                        // (DevTable::wpair).  Measured on Q9 at SF=10: the final loop 0.264 -> 0.244 ms, the orders build 0.048 -> 0.068 (15 MB more to clear and write): off
     int opt_delta8 = 1;                 // queue programs stream a key column whose 8-row groups span at most 255 through its 12-bytes-per-8-rows delta twin
     int opt_x_waves = 0;                // > 0: wave segments per CU for the queue skeletons of row programs (0: each sink's own default)
     // K-F rows delivered behind the call (sdqh_table_compact_async): two device staging buffers in turn, a copy stream (side[1]),

@@ -156,6 +156,10 @@ struct DevTable {
                                       //    beside it (2: a hit finds its first payload field in the line of its key — one line per lookup less in Q9's final loop)
     int64_t grp_kstride;
     int64_t grp_seg_rows, grp_cap;    // rows per stage segment; stage rows a walk may read (the build's rows + 1: the last segment's end mark)
+    // rank = row layout (k_rank_increasing): per bitmap word { wprefix[w] (low half), bm[w] (high half) } side by side — a lookup's two requests are ONE
+    // line where they were two (Q9's final loop fetches a 128-byte line per request: three per surviving row went to the orders table); bm and
+    // wprefix stay what they are for everything that reads the bitmap alone.  Null: the table has no such copy.
+    const unsigned long long* wpair;
 };
 
 // regions to set to a byte value each (k_fill; also the preamble of a build kernel that runs as ONE workgroup: see fill_in_block)
@@ -595,9 +599,9 @@ __device__ __forceinline__ int64_t table_find(const DevTable& t, int64_t key, ui
     if (t.bm) {
         uint64_t off;
         if (!bm_locate(t, key, off)) return -1;
-        const uint32_t word = t.bm[off >> 5];
-        uint32_t pre = 0;
-        if (direct) pre = t.wprefix[off >> 5];
+        uint32_t word, pre = 0;
+        if (direct && t.wpair) { const unsigned long long pw = t.wpair[off >> 5]; pre = (uint32_t)pw; word = (uint32_t)(pw >> 32); }
+        else { word = t.bm[off >> 5]; if (direct) pre = t.wprefix[off >> 5]; }
         if (t.grp_first) pre = t.grp_first[off];
         if (hashed) { h = hash_key(key) & cap_mask; k_first = slot_key(t, h); }
         if (!((word >> (off & 31)) & 1u)) return -1;
@@ -1786,7 +1790,9 @@ constexpr int RANK_INC_NB = 8;                                        // blocks 
 template <class KT>
 __global__ __launch_bounds__(TPB) void k_rank_increasing(const KT* __restrict__ key, int64_t nrows, int64_t lo, uint32_t* __restrict__ bm,
                                                         uint32_t* __restrict__ wprefix, TableHeader* __restrict__ hdr,
-                                                        uint32_t* __restrict__ seg_count, int nseg, int64_t seg_rows) {
+                                                        uint32_t* __restrict__ seg_count, int nseg, int64_t seg_rows, uint32_t* __restrict__ wpair) {
+    // wpair (or null): { wprefix[w], bm[w] } pairs, zero-filled like bm — every 4-byte half is written as its array is: a word's row by the one
+    // lane that holds its first key, its bits plainly where the wave owns the word and ORed in where two waves share it
     // (every row is an entry: a segment's count is its length — what k_full_counts wrote in a launch of its own)
     for (int sg = blockIdx.x * TPB + threadIdx.x; sg < nseg; sg += gridDim.x * TPB) {
         const int64_t b = (int64_t)sg * seg_rows, e = b + seg_rows < nrows ? b + seg_rows : nrows;
@@ -1814,7 +1820,7 @@ __global__ __launch_bounds__(TPB) void k_rank_increasing(const KT* __restrict__ 
             uint64_t prev = __shfl_up(o[j], 1, WAVE);
             const uint64_t carry = j == 0 ? before : __shfl(o[j > 0 ? j - 1 : 0], WAVE - 1, WAVE);
             if (lane == 0) prev = carry;
-            if (r < nrows && (prev == ~0ull || (prev >> 5) != (o[j] >> 5))) wprefix[o[j] >> 5] = (uint32_t)r;
+            if (r < nrows && (prev == ~0ull || (prev >> 5) != (o[j] >> 5))) { wprefix[o[j] >> 5] = (uint32_t)r; if (wpair) wpair[2 * (o[j] >> 5)] = (uint32_t)r; }
         }
         const uint64_t nw = wl - wf + 1;
         if (nw <= (uint64_t)RANK_INC_WORDS) {
@@ -1825,13 +1831,13 @@ __global__ __launch_bounds__(TPB) void k_rank_increasing(const KT* __restrict__ 
             __builtin_amdgcn_wave_barrier();
             for (int i = lane; i < (int)nw; i += WAVE) {
                 const uint32_t w = words[i];
-                if (i == 0 || i == (int)nw - 1) { if (w) atomicOr(&bm[wf + i], w); }
-                else bm[wf + i] = w;
+                if (i == 0 || i == (int)nw - 1) { if (w) { atomicOr(&bm[wf + i], w); if (wpair) atomicOr(&wpair[2 * (wf + i) + 1], w); } }
+                else { bm[wf + i] = w; if (wpair) wpair[2 * (wf + i) + 1] = w; }
             }
             __builtin_amdgcn_wave_barrier();
         } else {                                                       // a wide gap inside the step: bit by bit
 #pragma unroll
-            for (int j = 0; j < NB; ++j) { const int64_t r = r0 + (int64_t)j * WAVE + lane; if (r < nrows) atomicOr(&bm[o[j] >> 5], 1u << (o[j] & 31)); }
+            for (int j = 0; j < NB; ++j) { const int64_t r = r0 + (int64_t)j * WAVE + lane; if (r < nrows) { atomicOr(&bm[o[j] >> 5], 1u << (o[j] & 31)); if (wpair) atomicOr(&wpair[2 * (o[j] >> 5) + 1], 1u << (o[j] & 31)); } }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { hdr->staged = (uint64_t)nrows; hdr->distinct = (uint64_t)nrows; hdr->has_dups = 0; }

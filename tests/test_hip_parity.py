@@ -1580,3 +1580,29 @@ def test_delta_twins_change_no_bit(hip_engine, oracle_engine):
         ctx.set_option("feature_min_rows", 1 << 20)
         hip_engine.clear()
         oracle_engine.clear()
+
+
+@pytest.mark.gpu
+def test_word_pairs_of_the_rank_is_row_layout(hip_engine, oracle_engine):
+    """Whole-table builds keyed by a strictly increasing column over a wide range (Q9's orders) may keep { first row, bits } pairs per bitmap
+    word beside the bitmap and the row-per-word array, so that a lookup's two requests are one line (option "word_pairs", off by default:
+    what the final loop gains the build loses).  Same rows as the CPU implementation with the pairs on — at a size where the layout is
+    chosen by itself and, with `feature_min_rows` 0, on small and ragged tables where waves share boundary words."""
+    ctx = hip_engine.ctx
+    qs = ("q9", "q5", "q3")
+    try:
+        ctx.set_option("word_pairs", 1)
+        for sf, fmr in ((2.0, 1 << 20), (0.03, 0), (0.3, 0)):
+            ctx.set_option("feature_min_rows", fmr)
+            hip_engine.clear()
+            db = tpch.generate(sf, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
+            for q in qs:
+                want = helpers.run_query(oracle_engine, q, db)
+                for _ in range(2):
+                    got = helpers.run_query(hip_engine, q, db)
+                    helpers.assert_rows_match(helpers.result_rows(got, want.columns), helpers.result_rows(want, want.columns), REL, "word pairs sf=%s %s" % (sf, q))
+            oracle_engine.clear()
+    finally:
+        ctx.set_option("word_pairs", 0)
+        ctx.set_option("feature_min_rows", 1 << 20)
+        hip_engine.clear()

@@ -1417,3 +1417,42 @@ def cluster_pack_case(ctx, n=40000, nprobe=300001, seed=23, nparts=9000, keep=0.
     t0.free(); t1.free()
     ks = sorted(got)
     return ks, [got[k][1] for k in ks], [got[k][0] for k in ks]
+
+
+def keyed_probe_case(ctx, keys, members, groups=5, seed=3):
+    """A row program over a probe table of `keys` (any int64 key column): `if set[key] != None: out[g] += v` — the loop shape whose
+    streamed key the GPU reads through a delta twin where the column's 8-row groups are narrow, and which it runs as a DRIVEN walk where
+    the column is stored in its own order and the set holds few of its values.  Members = the key set.  Checked against numpy; returns
+    (group keys, counts, sums)."""
+    from sdqlpy_amd import abi as A
+    rng = np.random.default_rng(seed)
+    n = len(keys)
+    g = rng.integers(0, groups, n).astype(np.int64)
+    v = np.round(rng.random(n) * 100.0, 2)
+    ck, cg, cv, cm = ctx.upload(np.ascontiguousarray(keys, np.int64)), ctx.upload(g), ctx.upload(v), ctx.upload(np.ascontiguousarray(members, np.int64))
+    lo, hi = (int(min(members.min(), keys.min())), int(max(members.max(), keys.max()))) if len(members) and n else (0, 1)
+    P = A.Program()
+    P.key = P.op(A.X_COL, A.T_I64, col=cm)
+    t_set = ctx.xkey_set(len(members), P, lo, hi)
+    P = A.Program()
+    lk = P.op(A.X_LOOKUP, A.T_BOOL, a=P.op(A.X_COL, A.T_I64, col=ck), table=t_set)
+    P.gates = [lk]
+    P.key = P.op(A.X_COL, A.T_I64, col=cg)
+    P.vals = [P.op(A.X_COL, A.T_F64, col=cv)]
+    out = None
+    for _ in range(2):                                                                  # (the second run finds the twins / indexes made)
+        gk, gv, gc = ctx.xgroupby(n, P)
+        order = np.argsort(gk)
+        got = (gk[order].tolist(), gc[order].tolist(), gv[order, 0].tolist())
+        assert out is None or (got[0] == out[0] and got[1] == out[1])
+        out = got
+    hit = np.isin(keys, members)
+    want_c = np.bincount(g[hit], minlength=groups)
+    want_s = np.bincount(g[hit], weights=v[hit], minlength=groups)
+    ks = [k for k in range(groups) if want_c[k]]
+    assert out[0] == ks and out[1] == [int(want_c[k]) for k in ks], (out[0], ks)
+    assert all(abs(x - want_s[k]) <= 1e-9 * max(abs(want_s[k]), 1.0) for x, k in zip(out[2], ks))
+    for c in (ck, cg, cv, cm):
+        c.free()
+    t_set.free()
+    return out

@@ -1606,3 +1606,45 @@ def test_word_pairs_of_the_rank_is_row_layout(hip_engine, oracle_engine):
         ctx.set_option("word_pairs", 0)
         ctx.set_option("feature_min_rows", 1 << 20)
         hip_engine.clear()
+
+
+@pytest.mark.gpu
+def test_delta_twins_and_walks_on_awkward_key_columns(hip_engine, oracle_engine):
+    """The ABI-level loop `if set[key] != None: out[g] += v` over key columns chosen against the round's encodings and walks: negative
+    keys, keys next to the int32 limits (a delta twin's base + offset must not wrap), groups of 8 rows that are narrow but not in order
+    (the base is the group's SMALLEST value), one group 256 wide (no delta twin: the 4-byte twin serves), runs longer than a wave's 8-row
+    rounds (thousands of rows of one key), keys the set holds that the column does not and the other way round, a set of ONE key, a set of
+    every key, row counts off the 8-row and 512-row grids — with the walk at its most eager, at its default, and off; numpy inside the
+    helper, the CPU implementation beside."""
+    ctx = hip_engine.ctx
+    rng = np.random.default_rng(41)
+
+    def runs(values, lens):
+        return np.repeat(np.asarray(values, np.int64), np.asarray(lens, np.int64))
+    n = 300007
+    sorted_keys = np.sort(rng.integers(-5000, 200000, n)).astype(np.int64)
+    cases = [
+        ("negative, in order", sorted_keys, rng.choice(np.unique(sorted_keys), 900, replace=False)),
+        ("next to the upper int32 limit", np.repeat(np.arange(2**31 - 40002, 2**31 - 1, dtype=np.int64), 3), np.array([2**31 - 2, 2**31 - 40002, 2**31 - 20000, 2**31 - 9], np.int64)),
+        ("next to the lower int32 limit", np.repeat(np.arange(-2**31 + 1, -2**31 + 40001, dtype=np.int64), 2), np.array([-2**31 + 1, -2**31 + 7, -2**31 + 40000], np.int64)),
+        ("narrow groups, not in order", (np.arange(n, dtype=np.int64) // 8) * 200 + rng.integers(0, 200, n), np.arange(0, n * 25, 1013, dtype=np.int64)),
+        ("one group 256 wide", np.where(np.arange(n) == 4011, 4011 // 8 * 200 + 256 + 255, (np.arange(n, dtype=np.int64) // 8) * 200 + rng.integers(0, 56, n)), np.arange(0, n * 25, 511, dtype=np.int64)),
+        ("long runs", runs(np.arange(10, 10 + 60) * 3, rng.integers(1, 9000, 60)), np.array([10 * 3, 11 * 3, 40 * 3, 69 * 3, 5, 1000], np.int64)),
+        ("a set of one key", sorted_keys, np.array([int(sorted_keys[n // 2])], np.int64)),
+        ("a set of every key", sorted_keys[:70001], np.unique(sorted_keys[:70001])),
+        ("seven rows", np.arange(7, dtype=np.int64) * 2, np.array([0, 4, 12, 13], np.int64)),
+        ("513 rows", np.arange(513, dtype=np.int64) // 3, np.arange(0, 171, 7, dtype=np.int64)),
+    ]
+    try:
+        ctx.set_option("feature_min_rows", 0)
+        for name, keys, members in cases:
+            want = helpers.keyed_probe_case(oracle_engine.ctx, keys, members)
+            for ratio, d8 in ((1, 1), (64, 1), (0, 1), (0, 0)):
+                ctx.set_option("x_driven", ratio); ctx.set_option("delta8", d8)
+                got = helpers.keyed_probe_case(ctx, keys, members)
+                assert got[0] == want[0] and got[1] == want[1], (name, ratio, d8)
+                assert all(abs(x - y) <= REL * max(abs(y), 1.0) for x, y in zip(got[2], want[2])), (name, ratio, d8)
+    finally:
+        ctx.set_option("x_driven", 64); ctx.set_option("delta8", 1)
+        ctx.set_option("feature_min_rows", 1 << 20)
+        hip_engine.clear()

@@ -517,11 +517,11 @@ void tight_plan(sdqh_ctx* ctx, int64_t nrows, XInfo* x) {
         const sdqh_xop& ko = p->ops[x->prefilter_part0];
         x->pnear = fake ? true : (ko.code == SDQH_X_COL && column_span8(ctx, const_cast<sdqh_column*>(ko.col)));
         x->pwin = fake ? std::getenv("SDQLPY_AMD_FAKE_WINDOW") != nullptr : (ctx->opt_window != 0 && x->pnear);
-        // the driven walk (x_queue8): no other streamed condition, the key a plain column read through its 4-byte twin, stored in its own order
+        // the driven walk (x_queue8): no other streamed condition, the key a plain column stored in its own order
         if (!fake && ctx->opt_x_driven > 0 && x->nstream_gates == 0 && ko.code == SDQH_X_COL) {
             const int c = x->col_of[x->prefilter_part0];
             sdqh_column* kc = const_cast<sdqh_column*>(x->cols[c]);
-            if (x->enc[c] == ENC_N32 && kc->nrows == nrows && nrows < ((int64_t)1 << 31) && column_run_index(ctx, kc)) { x->driven = true; x->driven_col = c; }
+            if (kc->dtype == SDQH_I64 && kc->nrows == nrows && nrows < ((int64_t)1 << 31) && column_run_index(ctx, kc)) { x->driven = true; x->driven_col = c; }      // (whatever encoding the key is streamed in: the walk does not read it)
             if (xdebug) std::fprintf(stderr, "[x] driven walk: enc %d column rows %lld run index %d -> %d\n", x->enc[c], (long long)kc->nrows, kc->run_index_state, (int)x->driven);
         }
     }

@@ -44,6 +44,9 @@
 #ifndef XV_OFFALL
 #define XV_OFFALL 0
 #endif
+#ifndef XV_BITS
+#define XV_BITS 0                                                     // x_vstage8: the key bitmap's words assembled per wave in LDS and stored, where the build key increases (see there: slower)
+#endif
 #ifndef XV_PIPE
 #define XV_PIPE 1                                                     // x_vstage8: the next step's streamed loads requested behind this step's bitmap words (see there)
 #endif
@@ -1331,8 +1334,47 @@ __device__ __forceinline__ void x_vstage8(const XArgs& a, const typename XStage<
 #pragma unroll
     for (int l = 0; l < NL; ++l) bm[l] = P::NL > l ? P::lkbm(a, l) : nullptr;
     uint32_t carry = ROW_INDEX_NONE;                                          // row index: the bitmap word of the wave's previous entry
+    // XV_BITS: a build keyed by a strictly increasing column (st.wrow: the row-index layout exists for nothing else) meets its survivors in
+    // increasing key order, and the keys of another wave's rows lie outside [the wave's first row's key, its last row's key]: every bitmap
+    // word strictly between the first and the last word the wave touches is the wave's alone.  The wave ORs its bits into a window of
+    // XB_WORDS words in LDS and stores the words the window leaves behind — plainly, but for the first word it ever touched and, at the
+    // end, the last: those two may be shared with a neighbour and are ORed in (one atomic each instead of one per entry; zero words are
+    // not stored: the fill left them zero).  Right (the suite passes with it) and SLOWER: Q3's orders build 0.078 -> 0.091 ms — the ballots,
+    // the LDS atomics and the window's stores cost more than 1.5 M fire-and-forget atomics do (round 3 found the same for atomics merged by
+    // a segmented scan).  Off; kept as the measurement it is (SDQLPY_AMD_X_DEFINES="XV_BITS=1").
+    constexpr int XB_WORDS = 128;
+    __shared__ uint32_t s_bw[XV_BITS ? TPB / WAVE : 1][XV_BITS ? XB_WORDS : 1];
+    uint32_t* bw = s_bw[XV_BITS ? threadIdx.x / WAVE : 0];
+    const bool xb_on = XV_BITS && st.wrow && st.bm && st.bm_shift == 0 && st.lin_rb == 0 && !st.grp_first;
+    uint32_t xb_base = 0xFFFFFFFFu, xb_first = 0xFFFFFFFFu, xb_last = 0;
+    DevStage st_nobits = st;
+    if (xb_on) { st_nobits.bm = nullptr; for (int i = lane; i < XB_WORDS; i += WAVE) bw[i] = 0u; }
+    auto xb_flush = [&](uint32_t upto, bool final) {                         // the window's words below `upto` go to memory, the window is cleared
+        for (int i = lane; i < XB_WORDS; i += WAVE) {
+            const uint32_t wi = xb_base + (uint32_t)i, v = bw[i];
+            if (v && wi < upto) { if (wi == xb_first || (final && wi == xb_last)) atomicOr(&st.bm[wi], v); else st.bm[wi] = v; }
+            bw[i] = 0u;
+        }
+    };
+    auto xb_add = [&](bool keep, int64_t key) {
+        uint64_t off = 0;
+        const bool in = keep && bm_locate(st, key, off);
+        const uint32_t w = (uint32_t)(off >> 5);
+        const uint64_t all = __ballot(in);
+        uint64_t todo = all;
+        while (todo) {
+            const uint32_t wmin = (uint32_t)__shfl((int)w, __builtin_ctzll(todo), WAVE);
+            if (xb_base == 0xFFFFFFFFu) { xb_base = wmin; xb_first = wmin; }
+            if (wmin - xb_base >= (uint32_t)XB_WORDS) { xb_flush(0xFFFFFFFFu, false); xb_base = wmin; }
+            const bool mine = in && ((todo >> lane) & 1ull) && w - xb_base < (uint32_t)XB_WORDS;
+            if (mine) atomicOr(&bw[w - xb_base], 1u << (off & 31));
+            todo &= ~__ballot(mine);
+        }
+        if (all) xb_last = (uint32_t)__shfl((int)w, 63 - __builtin_clzll(all), WAVE);
+    };
     auto flush = [&](int first, int count) {                                 // queued entries [first, first + count), count <= 64, one per lane
         if (st.wrow) row_index_note(st, seg, lane < count, lane < count ? (int64_t)q[0][first + lane] : 0, out + lane, count >= 64 ? ~0ull : ((1ull << count) - 1ull), carry);
+        if (xb_on) xb_add(lane < count, lane < count ? (int64_t)q[0][first + lane] : 0);
         if (lane < count) {
             const int64_t key = (int64_t)q[0][first + lane];
             int64_t pay[MAX_STAGE_COLS] = {0, 0, 0, 0, 0};
@@ -1349,7 +1391,7 @@ __device__ __forceinline__ void x_vstage8(const XArgs& a, const typename XStage<
                 if (st.bm && !(XV_EXP & 1)) { uint64_t off; if (bm_locate(st, key, off)) atomicOr(&st.bm[off >> 5], 1u << (off & 31)); }
             }
 #else
-            stage_store<-1>(st, out + lane, key, pay);
+            stage_store<-1>(xb_on ? st_nobits : st, out + lane, key, pay);
 #endif
         }
         out += count;
@@ -1499,6 +1541,7 @@ __device__ __forceinline__ void x_vstage8(const XArgs& a, const typename XStage<
     for (; b + X8_STEP <= end; b += X8_STEP) step(b, XBool<false>{}, XBool<false>{});
     if (b < end) step(b, XBool<false>{}, XBool<true>{});
     if (qn) flush(0, qn);
+    if (xb_on && xb_base != 0xFFFFFFFFu) xb_flush(xb_last + 1u, true);
     if (lane == 0) st.seg_count[seg] = (uint32_t)(out - begin);
 }
 

@@ -204,7 +204,9 @@ void*       sdqh_stream(const sdqh_ctx* ctx);
  * first lookup is keyed by the column its table is stored in the order of walks the looked-up table's key bitmap and the column's run
  * index when (estimated keys of the table) x this <= rows of the loop; 0 = never, 1 = whenever the table holds fewer keys than rows),
  * "delta8" (1: queue programs stream a key column whose aligned 8-row groups span at most 255 through its delta twin, 12 bytes per 8 rows),
- * "word_pairs" (0: whole-table builds keyed by a strictly increasing column also keep { first row, bits } pairs per bitmap word).
+ * "word_pairs" (0: whole-table builds keyed by a strictly increasing column also keep { first row, bits } pairs per bitmap word);
+ * round 6: "pool_trim" (an action, value 1: waits for the context's stream and returns the cached free blocks of its device-memory
+ * pool to the runtime — a pool never shrinks by itself).
  * The CPU build accepts and ignores any name. */
 int         sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value);
 
@@ -329,7 +331,9 @@ int sdqh_table_compact_async(sdqh_ctx* ctx, const sdqh_table* table, int64_t min
  * lie in the same sdqh_host_alloc block, is -1 until the kernels have run; every array is copied out at its full `capacity`.
  * After sdqh_result_wait (or sdqh_synchronize): *out_n rows are valid; *out_n > capacity means the rows beyond were dropped
  * (fetch again with the capacity it names).  SDQH_ERR_UNSUPPORTED for any other layout or with "async_result" = 0.  Value slots the
- * aggregated tuple does not use are NOT written: a caller that reads them zeroes its block once, when it allocates it (abi.py does). */
+ * aggregated tuple does not use (out_values[k][..] for k >= the table's value count) are NOT written and their contents are UNDEFINED —
+ * a block that served another result holds that result's rows there; a caller that wants zeros writes them (abi.py hands the
+ * engine views of the first nv arrays only and zeroes nothing). */
 int sdqh_table_compact_deferred(sdqh_ctx* ctx, const sdqh_table* table, int64_t min_hits, int64_t capacity,
                                 int64_t* out_keys, int64_t* out_payload, double* out_values, int64_t* out_hits, int64_t* out_n);
 /* out_n is TWO cells there: out_n[1] is the result's DONE word — the copy stream writes 1 into it behind the copies (2 at once if it
@@ -517,6 +521,17 @@ size_t sdqh_xgroupby_block_bytes(void);
 int sdqh_xgroupby_async(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, void* result_block);
 int sdqh_xgroupby_collect(sdqh_ctx* ctx, const void* result_block, int nvals, int max_groups,
                           int64_t* out_keys, double* out_values, int64_t* out_counts, int32_t* out_ngroups);
+/* ---- the small group-by of a row-sharded table, folded over the ranks ON THE DEVICE (ABI 6; no reference counterpart) ----
+ * sdqh_xgroupby_partial: sdqh_xgroupby_async with the group table written to DEVICE memory the caller owns (`device_block`:
+ * sdqh_xgroupby_block_bytes() bytes; CPU build: host memory) instead of a result block — this rank's partial groups, on their way
+ * into a collective; nothing is waited for and nothing can be collected from it.
+ * sdqh_xgroupby_fold: `nblocks` (<= SDQH_MAX_PARTS) such blocks back to back in device memory (the all-gathered ranks' blocks, rank
+ * order) merged by key into `result_block` (from sdqh_host_alloc, as for sdqh_xgroupby_async: collected with sdqh_xgroupby_collect).
+ * A group's sums are added block by block, ((rank 0 + rank 1) + rank 2) ...: every rank folds the same blocks in the same order and
+ * gets the same bits.  The keys must mean the same thing on every rank (the caller's business: same dictionaries, same packing).
+ * More than SDQH_MAX_LOOKUP_GROUPS groups over all blocks, or a block that reported them: SDQH_ERR_OVERFLOW at collect. */
+int sdqh_xgroupby_partial(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, void* device_block);
+int sdqh_xgroupby_fold(sdqh_ctx* ctx, const void* device_blocks, int nblocks, void* result_block);
 /* K-B (331-369): unique build keyed by the program's key, payload = its vals (<= SDQH_MAX_PAYLOAD); first row wins.
  * [key_lo, key_hi]: bounds of the key the caller knows from its sources (key_lo > key_hi: none known) — a
  * dense range gets the direct (bitmap + rank) index, anything else open addressing.  A key outside given

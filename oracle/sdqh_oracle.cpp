@@ -1257,6 +1257,36 @@ int sdqh_xgroupby_collect(sdqh_ctx* ctx, const void* result_block, int nvals, in
     return SDQH_OK;
 }
 
+// (checker: a rank's partial groups are the block sdqh_xgroupby_async fills; the fold adds the ranks' sums in rank order — include/sdqh.h)
+int sdqh_xgroupby_partial(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, void* device_block) {
+    return sdqh_xgroupby_async(ctx, nrows, prog, device_block);
+}
+int sdqh_xgroupby_fold(sdqh_ctx* ctx, const void* device_blocks, int nblocks, void* result_block) {
+    if (!ctx || !device_blocks || nblocks < 1 || nblocks > SDQH_MAX_PARTS || !result_block) return fail(ctx, SDQH_ERR_INVALID, "xgroupby_fold: bad arguments");
+    XGroupBlock* out = static_cast<XGroupBlock*>(result_block);
+    std::memset(out, 0, sizeof(XGroupBlock));
+    const size_t stride = sdqh_xgroupby_block_bytes();
+    std::vector<int64_t> keys; std::vector<Acc> accs;
+    I64Index idx;
+    for (int b = 0; b < nblocks; ++b) {
+        const XGroupBlock* in = reinterpret_cast<const XGroupBlock*>(static_cast<const char*>(device_blocks) + (size_t)b * stride);
+        if (in->rc) { out->rc = in->rc; out->ng = in->ng; std::snprintf(out->err, sizeof(out->err), "%s", in->err); return SDQH_OK; }
+        for (int g = 0; g < in->ng; ++g) {
+            int64_t at = idx.find_or_insert(in->keys[g], (int64_t)keys.size());
+            if (at < 0) { at = (int64_t)keys.size(); keys.push_back(in->keys[g]); accs.push_back(Acc{}); }
+            for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) accs[(size_t)at].v[k] += in->vals[g * SDQH_TUPLE_MAX_VALUES + k];
+            accs[(size_t)at].n += in->cnts[g];
+        }
+    }
+    if ((int64_t)keys.size() > SDQH_MAX_LOOKUP_GROUPS) { out->rc = SDQH_ERR_OVERFLOW; out->ng = (int32_t)keys.size(); return SDQH_OK; }
+    out->ng = (int32_t)keys.size();
+    for (size_t g = 0; g < keys.size(); ++g) {
+        out->keys[g] = keys[g]; out->cnts[g] = accs[g].n;
+        for (int k = 0; k < SDQH_TUPLE_MAX_VALUES; ++k) out->vals[g * SDQH_TUPLE_MAX_VALUES + k] = accs[g].v[k];
+    }
+    return SDQH_OK;
+}
+
 int sdqh_xbuild(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, int64_t key_lo, int64_t key_hi, int accumulate, sdqh_table** out) {
     if (!ctx || nrows < 0 || !out) return fail(ctx, SDQH_ERR_INVALID, "xbuild: bad arguments");
     Timer tm;

@@ -457,7 +457,7 @@ class Context:
             p = C.c_void_p()
             self._check(self.lib.sdqh_host_alloc(self.handle, C.c_size_t(size), C.byref(p)))
             addr = p.value
-            C.memset(addr, 0, size)                              # once per block: what a call never writes (unused value slots of a K-F result) reads as zero
+            C.memset(addr, 0, size)                              # once per block (a recycled block is NOT zeroed again: value slots a K-F result does not use are undefined, include/sdqh.h)
         buf = (C.c_char * size).from_address(addr)
         weakref.finalize(buf, Context._release_block, weakref.ref(self), self.lib, addr, size, self._sync_epoch if deferred else None,
                          deferred if isinstance(deferred, list) else None)

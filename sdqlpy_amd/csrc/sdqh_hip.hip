@@ -707,6 +707,16 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "grouped_pairs" && (value == 0 || value == 1)) ctx->opt_grouped_pairs = (int)value;
     else if (n == "index_inline" && (value == 0 || value == 1)) ctx->opt_index_inline = (int)value;
     else if (n == "groupby_regs" && (value == 0 || value == 4 || value == 8)) ctx->opt_groupby_regs = (int)value;
+    else if (n == "pool_trim" && value == 1) {
+        // give the cached FREE blocks of this context's pool back to the runtime (the pool never shrinks by itself: 288 GB make head-room
+        // cheap — until the next workload needs the memory another context's pool is sitting on).  Waits for the stream first.
+        if (ctx->compile_only) return SDQH_OK;
+        if (ctx->capturing) return fail(ctx, SDQH_ERR_UNSUPPORTED, "set_option: pool_trim inside a recording");
+        (void)hipSetDevice(ctx->device);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, SDQH_ERR_DEVICE, "pool_trim: the stream failed"); }
+        for (auto& b : ctx->pool) if (b.free && b.ptr && !b.graph_owner) { (void)hipFree(b.ptr); b.ptr = nullptr; }
+        ctx->pool.erase(std::remove_if(ctx->pool.begin(), ctx->pool.end(), [](const PoolBlock& b) { return b.ptr == nullptr; }), ctx->pool.end());
+    }
     else return fail(ctx, SDQH_ERR_INVALID, "set_option: unknown option or value out of range: " + n);
     return SDQH_OK;
 }

@@ -93,6 +93,7 @@ struct XInfo {
     int ival = -1;                           // the per-lane group sink: summed value that is a small integer on every row (byte-coded column, consecutive integral dictionary), or -1
     bool pnear = false;                      // ... and a lane's 8 consecutive rows carry near-by keys (column_span8): a row that fails an earlier condition still asks for ITS key's word
     bool pwin = false;                       // ... tested against one 128-bit window of the bitmap: one 16-byte request per lane and 8 rows (option "window", off: measured slower)
+    bool want_driven = false;                   // set by the caller whose sink can take the walk (the group sink): no other loop pays for a run index
     bool driven = false; int driven_col = -1;   // the driven walk of x_queue8 can be taken (order-free sinks): the prefilter's key column is stored in its own order and has a run index
     uint32_t gather32 = 0;                   // queue programs: numeric columns read BY ROW (the drain's gathers) through their 4-byte twins: half the bytes of every touched line
     mutable uint32_t lay[SDQH_MAX_XTABLES] = {};   // XL_* layout bits of every table (kernel_for: known once the tables' indexes are made), 0: decided at run time
@@ -372,7 +373,7 @@ const void* column_delta8(sdqh_ctx* ctx, sdqh_column* c) {
     const int32_t* twin = static_cast<const int32_t*>(column_narrow(ctx, c));
     if (!twin) return nullptr;
     const int64_t ngroups = (c->nrows + 7) / 8;
-    uint32_t* out = static_cast<uint32_t*>(attach_alloc(ctx, c, (size_t)ngroups * 12 + 64));
+    uint32_t* out = static_cast<uint32_t*>(attach_alloc(ctx, c, (size_t)ngroups * 12 + 64 * 12 + 64));   // (+ 64 groups: in a skeleton's last step every lane loads its record, also the lanes behind the last row — masked afterwards, but read)
     int* flag = static_cast<int*>(pool_alloc(ctx, 64));
     bool ok = out && flag && hipMemsetAsync(flag, 0, 4, ctx->stream) == hipSuccess;
     if (ok) {
@@ -402,7 +403,9 @@ const uint32_t* column_run_index(sdqh_ctx* ctx, sdqh_column* c) {
     const int64_t nvals = (int64_t)range + 1;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nvals + 255) / 256, (int64_t)ctx->num_cu * 16));
     { KernelScope ks(ctx, "k_run_index"); hipLaunchKernelGGL(k_run_index, dim3(grid), dim3(256), 0, ctx->stream, twin, c->nrows, c->mn, nvals, ridx); }
-    if (hipGetLastError() != hipSuccess) { attach_free(ctx, c, ridx); return nullptr; }
+    // the column is shared by every lane (context) of the family: publish the index when it is WRITTEN, not when it is queued — another lane's
+    // walk on another stream would read it half-built (delta twins and narrow twins wait the same way)
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipGetLastError(); attach_free(ctx, c, ridx); return nullptr; }
     c->run_index = ridx; c->run_index_state = 1;
     return ridx;
 }
@@ -518,7 +521,7 @@ void tight_plan(sdqh_ctx* ctx, int64_t nrows, XInfo* x) {
         x->pnear = fake ? true : (ko.code == SDQH_X_COL && column_span8(ctx, const_cast<sdqh_column*>(ko.col)));
         x->pwin = fake ? std::getenv("SDQLPY_AMD_FAKE_WINDOW") != nullptr : (ctx->opt_window != 0 && x->pnear);
         // the driven walk (x_queue8): no other streamed condition, the key a plain column stored in its own order
-        if (!fake && ctx->opt_x_driven > 0 && x->nstream_gates == 0 && ko.code == SDQH_X_COL) {
+        if (!fake && x->want_driven && ctx->opt_x_driven > 0 && x->nstream_gates == 0 && ko.code == SDQH_X_COL) {
             const int c = x->col_of[x->prefilter_part0];
             sdqh_column* kc = const_cast<sdqh_column*>(x->cols[c]);
             if (kc->dtype == SDQH_I64 && kc->nrows == nrows && nrows < ((int64_t)1 << 31) && column_run_index(ctx, kc)) { x->driven = true; x->driven_col = c; }      // (whatever encoding the key is streamed in: the walk does not read it)
@@ -1478,8 +1481,11 @@ int sdqh_xscan_sum(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, doubl
 constexpr size_t XGROUPBY_DONE_OFFSET = (((size_t)LG_SLOTS * 48 + 8 + 63) & ~(size_t)63);
 // K-C small, launched: the group table of the whole call lands in `host_block` (device-visible host memory laid out like the device
 // result block: keys[LG_SLOTS] | acc[LG_SLOTS][4] | cnt[LG_SLOTS] | flags) when the stream gets there; nothing is waited for.
-static int xgroupby_launch(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, void* host_block) {
+// device_block: `host_block` is DEVICE memory (sdqh_xgroupby_partial: one rank's group table on its way into a collective) — same layout,
+// no completion word (whoever folds the ranks' blocks writes the result block's).
+static int xgroupby_launch(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, void* host_block, bool device_block = false) {
     XInfo x;
+    x.want_driven = true;
     if (int rc = analyse(ctx, nrows, prog, SDQH_TUPLE_MAX_VALUES, true, true, &x)) return rc;
     // a key over a dense small range (known from the columns' own ranges): every lane keeps its groups' sums in LDS cells of its own
     Sink sink = SINK_GROUP;
@@ -1544,7 +1550,7 @@ static int xgroupby_launch(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* pro
     if (!rc) {
         // the block's DONE word: written by the stream itself once the merge has finished — collect waits for its own result, not for
         // whatever was queued behind it.  Cleared before the merge is launched.
-        uint32_t* done = host_block ? reinterpret_cast<uint32_t*>(static_cast<char*>(host_block) + XGROUPBY_DONE_OFFSET) : nullptr;
+        uint32_t* done = (host_block && !device_block) ? reinterpret_cast<uint32_t*>(static_cast<char*>(host_block) + XGROUPBY_DONE_OFFSET) : nullptr;
         if (done) host_init(ctx, done, 0, 4);
         launch_groupby_merge_lg_host(ctx, r_keys, pacc, pcnt, (int)g.grid, r_flags, host_block);       // writes the pinned host block, leaves the device block clean
         call_end(ctx);
@@ -1619,6 +1625,80 @@ int sdqh_xgroupby_collect(sdqh_ctx* ctx, const void* result_block, int nvals, in
     if (*done == 2) { if (int rc = sdqh_synchronize(ctx)) return rc; }
     else if (int rc = wait_word(ctx, done, 1)) return rc;
     return xgroupby_collect(ctx, result_block, nvals, max_groups, out_keys, out_values, out_counts, out_ngroups);
+}
+
+// ---- partial groups of several ranks folded on the device (ABI 6; no reference counterpart: SURVEY.md 8e) --------------------------------
+// One workgroup: the group tables of `nblocks` ranks (each laid out like the result block: keys | sums | counts | flags, `stride` bytes
+// apart) folded into `out` BLOCK BY BLOCK — a group's sums are ((rank 0 + rank 1) + rank 2) ..., the order the host-side merge of the
+// distributed runner uses, so a result does not depend on which of the two folded it.  Inside one block every key sits in one slot, so
+// the thread that owns the slot is the only one that adds to its group during that block's turn: plain LDS read-modify-write, no atomics
+// but the claim of a slot.  More than LG_SLOTS / 2 distinct keys over all ranks: flag 1 (collect: SDQH_ERR_OVERFLOW), as for one rank.
+__global__ __launch_bounds__(TPB) void k_groups_fold(const char* __restrict__ blocks, int nblocks, size_t stride, char* __restrict__ out) {
+    __shared__ unsigned long long s_keys[LG_SLOTS];
+    __shared__ double s_acc[LG_SLOTS * 4];
+    __shared__ long long s_cnt[LG_SLOTS];
+    __shared__ int s_flags, s_groups;
+    for (int s = threadIdx.x; s < LG_SLOTS; s += TPB) { s_keys[s] = EMPTY_GROUP; s_cnt[s] = 0; s_acc[s * 4] = s_acc[s * 4 + 1] = s_acc[s * 4 + 2] = s_acc[s * 4 + 3] = 0.0; }
+    if (threadIdx.x == 0) { s_flags = 0; s_groups = 0; }
+    __syncthreads();
+    for (int b = 0; b < nblocks; ++b) {
+        const char* blk = blocks + (size_t)b * stride;
+        const unsigned long long* bk = reinterpret_cast<const unsigned long long*>(blk);
+        const double* ba = reinterpret_cast<const double*>(blk + LG_SLOTS * 8);
+        const long long* bc = reinterpret_cast<const long long*>(blk + LG_SLOTS * 40);
+        if (threadIdx.x == 0) { const int f = *reinterpret_cast<const int*>(blk + LG_SLOTS * 48); if (f) atomicOr(&s_flags, f); }
+        for (int s = threadIdx.x; s < LG_SLOTS; s += TPB) {
+            const unsigned long long key = bk[s];
+            const long long c = bc[s];
+            if (key == EMPTY_GROUP || c <= 0) continue;
+            int h = (int)((key * 0x9E3779B97F4A7C15ull) >> 55) & (LG_SLOTS - 1);
+            int at = -1;
+            for (int probe = 0; probe < LG_SLOTS; ++probe, h = (h + 1) & (LG_SLOTS - 1)) {
+                unsigned long long cur = s_keys[h];
+                if (cur == EMPTY_GROUP) { cur = atomicCAS(&s_keys[h], (unsigned long long)EMPTY_GROUP, key); if (cur == EMPTY_GROUP) atomicAdd(&s_groups, 1); }
+                if (cur == EMPTY_GROUP || cur == key) { at = h; break; }
+            }
+            if (at < 0) { atomicOr(&s_flags, 1); continue; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s_acc[at * 4 + k] += ba[s * 4 + k];
+            s_cnt[at] += c;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && s_groups > LG_SLOTS / 2) s_flags |= 1;
+    __syncthreads();
+    unsigned long long* ok = reinterpret_cast<unsigned long long*>(out);
+    double* oa = reinterpret_cast<double*>(out + LG_SLOTS * 8);
+    long long* oc = reinterpret_cast<long long*>(out + LG_SLOTS * 40);
+    for (int s = threadIdx.x; s < LG_SLOTS; s += TPB) {
+        ok[s] = s_keys[s]; oc[s] = s_cnt[s];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) oa[s * 4 + k] = s_acc[s * 4 + k];
+    }
+    if (threadIdx.x == 0) { int* tail = reinterpret_cast<int*>(out + LG_SLOTS * 48); tail[0] = s_flags; tail[1] = 0; }
+}
+
+int sdqh_xgroupby_partial(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, void* device_block) {
+    if (!ctx || nrows < 0 || !prog || !device_block) return fail(ctx, SDQH_ERR_INVALID, "xgroupby_partial: bad arguments");
+    if (ctx->compile_only) return fail(ctx, SDQH_ERR_UNSUPPORTED, "xgroupby_partial: compile-only context");
+    (void)hipSetDevice(ctx->device);
+    return xgroupby_launch(ctx, nrows, prog, device_block, true);
+}
+
+int sdqh_xgroupby_fold(sdqh_ctx* ctx, const void* device_blocks, int nblocks, void* result_block) {
+    if (!ctx || !device_blocks || nblocks < 1 || nblocks > SDQH_MAX_PARTS || !result_block) return fail(ctx, SDQH_ERR_INVALID, "xgroupby_fold: bad arguments");
+    if (ctx->compile_only) return fail(ctx, SDQH_ERR_UNSUPPORTED, "xgroupby_fold: compile-only context");
+    if (!host_block_contains(ctx, result_block, sdqh_xgroupby_block_bytes())) return fail(ctx, SDQH_ERR_INVALID, "xgroupby_fold: the result block must come from sdqh_host_alloc (sdqh_xgroupby_block_bytes() bytes)");
+    (void)hipSetDevice(ctx->device);
+    call_begin(ctx);
+    uint32_t* done = reinterpret_cast<uint32_t*>(static_cast<char*>(result_block) + XGROUPBY_DONE_OFFSET);
+    host_init(ctx, done, 0, 4);
+    { KernelScope ks(ctx, "k_groups_fold");
+      hipLaunchKernelGGL(k_groups_fold, dim3(1), dim3(TPB), 0, ctx->stream, static_cast<const char*>(device_blocks), nblocks, sdqh_xgroupby_block_bytes(), static_cast<char*>(result_block)); }
+    call_end(ctx);
+    if (hipGetLastError() != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, "xgroupby_fold: launch failed");
+    if (stream_store32(ctx, ctx->stream, done, 1) != SDQH_OK) *done = 2;
+    return SDQH_OK;
 }
 
 int sdqh_host_wait_word(sdqh_ctx* ctx, const void* word, uint32_t value) {

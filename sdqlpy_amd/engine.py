@@ -197,6 +197,14 @@ class Engine:
         for pp in list(self._prepared):
             pp.drop_graphs()
 
+    def trim(self):
+        """Give the free blocks of the lanes' device-memory pools back to the runtime (option "pool_trim"): after clear(), before a
+        workload whose memory another context — or another engine — will need."""
+        root = self.ctx
+        for c in [root] + list(getattr(root, "forks", [])):
+            if c.handle is not None:
+                c.set_option("pool_trim", 1)
+
     def clear(self):
         if self.ctx.handle is not None:
             self.finish_outstanding()
@@ -1893,9 +1901,22 @@ def _select_keys(eng, op, env):
     try:
         table = eng.ctx.table_select_keys(bt.table, 1, 0, lo, hi)
     except abi.SdqhError as exc:
-        if exc.code == abi.ERR_UNSUPPORTED:
-            raise UnsupportedQuery("line %d: %s" % (op.lineno, exc))
-        raise
+        if exc.code != abi.ERR_UNSUPPORTED:
+            raise
+        # the aggregated table's keys have no dense range (open addressing: keys far apart, or the direct layouts switched off): the
+        # library's HAVING writes an exact bitmap over the key range and has none here.  K-F of the groups, the condition on the host
+        # (O(groups), like the reference's serial K-F: generator_par.py:520-568), the passing keys built into a key set again — a HOST
+        # loop: counted per plan step like the sums over result dictionaries, refused under Engine.strict_device.
+        root = getattr(eng, "_eng", eng)
+        rec = root.host_loops.setdefault((getattr(op, "lineno", 0), op.out), {"runs": 0, "why": "HAVING over a table without a dense key range: %s" % exc})
+        rec["runs"] += 1
+        if getattr(root, "strict_device", False):
+            raise UnsupportedQuery("line %d: %s (the host-side HAVING is refused: SDQLPY_AMD_STRICT_DEVICE)" % (op.lineno, exc))
+        keys, _, values, _ = _compact(eng, bt.table, 1, (id(op), "having"), want_payload=False, want_hits=False)
+        v = values[0]
+        passing = np.ascontiguousarray(keys[(v >= lo) & (v <= hi)], np.int64)
+        col = eng.ctx.upload(passing)
+        table = eng.ctx.hash_build_unique(len(passing), abi.make_filter(), [], col, [])      # (keeps `col` alive)
     return BuiltTable(table, bt.key_name, False, [], False, [])
 
 

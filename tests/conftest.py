@@ -48,3 +48,13 @@ def golden_wide():
     q20, q22): make_golden.py --wide."""
     with open(os.path.join(ROOT, "tests", "golden", "tpch_golden_wide.json")) as fh:
         return json.load(fh)
+
+
+@pytest.fixture(scope="session")
+def golden_sf1():
+    """Reference results at SF=1 (6 M lineitem rows: every one of the reference's TPCH queries the interpreter finishes) and with keys
+    beyond 2^40 at SF=0.1 / SF=1 — the sizes at which the product's size-dependent paths (device loops over result dictionaries, layout
+    choices, walks, delta twins) engage: make_golden.py --sf1."""
+    import gzip
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "tpch_golden_sf1.json.gz"), "rt") as fh:
+        return json.load(fh)

@@ -255,7 +255,61 @@ WIDE_CASES = [
 ]
 
 
+# SF=1 (6 M lineitem rows) and big keys at SF=0.1: the sizes at which the product's size-dependent paths switch on (device loops over
+# result dictionaries, layout choices, walks, delta twins) — an hour of the reference's interpreter, spread over worker processes,
+# one (case, query) each.   python tests/golden/make_golden.py --sf1 [--jobs 6]  -> tpch_golden_sf1.json.gz
+SF1_CASES = [
+    ("sf1", 1.0, "base", QUERIES + MORE_QUERIES + WIDE_QUERIES),
+    ("sf01_big_keys", 0.1, "big_keys", ["q3"]),
+    ("sf1_big_keys", 1.0, "big_keys", ["q3"]),
+]
+
+
+def _one(job):
+    """One (case, query) in a process of its own: the reference imported there, the inputs generated there."""
+    name, sf, variant, q = job
+    ref, queries = load_reference()
+    tables = sorted(set(QUERY_TABLES[q]))
+    base = tpch.generate(sf, tpch.DEFAULT_SEED, tables=tables, columns=tpch.columns_for([q]), threads=2)
+    db = VARIANTS[variant](base)
+    t0 = time.time()
+    args = [to_ref_table(ref, db[t]) for t in QUERY_TABLES[q]]
+    res = queries[q](*args)
+    r = encode_result(ref, res)
+    r["reference_seconds"] = round(time.time() - t0, 1)
+    print("%-16s %s  %7.1fs  %s" % (name, q, time.time() - t0, r["value"] if r["kind"] == "scalar" else "%d rows" % len(r["rows"])), flush=True)
+    return name, q, r
+
+
+def main_sf1():
+    import multiprocessing as mp
+    jobs_n = int(sys.argv[sys.argv.index("--jobs") + 1]) if "--jobs" in sys.argv else 6
+    jobs = [(name, sf, variant, q) for name, sf, variant, qs in SF1_CASES for q in qs]
+    with mp.get_context("spawn").Pool(jobs_n, maxtasksperchild=1) as pool:
+        done = pool.map(_one, jobs, chunksize=1)
+    out = {"meta": {"generator_seed": tpch.DEFAULT_SEED,
+                    "reference": "edin-dal/sdqlpy Python mode (sdqlpy_init(0,1)), queries from test/test_all.py",
+                    "made_by": "tests/golden/make_golden.py --sf1"},
+           "cases": []}
+    for name, sf, variant, qs in SF1_CASES:
+        tables = sorted({t for q in qs for t in QUERY_TABLES[q]})
+        base = tpch.generate(sf, tpch.DEFAULT_SEED, tables=tables, columns=tpch.columns_for(qs), threads=4)
+        db = VARIANTS[variant](base)
+        case = {"name": name, "sf": sf, "seed": tpch.DEFAULT_SEED, "variant": variant,
+                "tables": tables, "fingerprint": tpch.fingerprint(db),
+                "rows": {t: len(db[t].getContainer()["data"][0]) for t in tables},
+                "results": {q: r for n, q, r in done if n == name}}
+        out["cases"].append(case)
+    import gzip
+    path = os.path.join(HERE, "tpch_golden_sf1.json.gz")          # (q3: 11 K rows, q10: 39 K, q16: 18 K — 9 MB of JSON, 2.6 MB compressed)
+    with gzip.GzipFile(path, "wb", mtime=0) as fh:
+        fh.write(json.dumps(out, separators=(",", ":")).encode())
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 def main():
+    if "--sf1" in sys.argv:
+        return main_sf1()
     more = "--more" in sys.argv          # python tests/golden/make_golden.py --more  -> tpch_golden_more.json (q4, q14)
     wide = "--wide" in sys.argv          # python tests/golden/make_golden.py --wide  -> tpch_golden_wide.json (q7, q8, q13, q15, q17, q19, q20, q22)
     cases = WIDE_CASES if wide else MORE_CASES if more else CASES

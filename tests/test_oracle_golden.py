@@ -153,3 +153,19 @@ def test_results_launched_and_not_waited_for(oracle_lib, golden, golden_more, go
         assert n >= 40 and {"q3", "q7", "q12", "q13"} <= seen, (n, seen)     # (q1 / q5 end in fixed-shape calls on this backend; on the GPU they are programs)
     finally:
         eng.close()
+
+
+def test_oracle_reproduces_reference_at_sf1(oracle_lib, golden_sf1):
+    """Round 6: the reference's own results at SF=1 (6 M lineitem rows, all 21 of its TPCH queries this package runs) and with keys
+    beyond 2^40 at SF=0.1 and SF=1 — the sizes where device loops over result dictionaries, layout choices, walks and delta twins
+    engage, which were checked against the oracle only (and the oracle shares the planner with the product: the round-5 Q2 error
+    was wrong on both).  One thread sums in row order like the interpreter: doubles bit for bit (q10: another association, 1e-12)."""
+    eng = engine.Engine(oracle_lib.context(threads=1))
+    try:
+        names = {c["name"] for c in golden_sf1["cases"]}
+        assert {"sf1", "sf01_big_keys", "sf1_big_keys"} <= names
+        sf1 = next(c for c in golden_sf1["cases"] if c["name"] == "sf1")
+        assert len(sf1["results"]) == 21 and sf1["rows"]["lineitem"] > 5_900_000
+        assert helpers.check_all_goldens(eng, [golden_sf1], 0.0, 1e-12, "oracle/sf1") == 23
+    finally:
+        eng.close()

@@ -618,8 +618,11 @@ int64_t sdqh_chunk_words(int ncols, int64_t chunk_rows);
  * sdqh_xstage — partitioned by their key (mix64(key) % nparts, or range_upper as in sdqh_partition_by_key) into the nparts chunks of
  * `packed` (nparts * sdqh_chunk_words(1 + npayload, chunk_rows) words of device memory; CPU build: host), chunk p at word
  * p * sdqh_chunk_words(...): the layout of an equal-split all-to-all.  A chunk's header counts every row meant for it; rows beyond
- * chunk_rows are dropped.  Rows keep no particular order inside a chunk.  Queued on the ctx stream; nothing is waited for.
- * SDQH_ERR_UNSUPPORTED: a table whose staged rows may repeat a key (use sdqh_table_entries + sdqh_partition_pack). */
+ * chunk_rows are dropped.  Rows keep no particular order inside a chunk — except with nparts = 1 (round 6: the send buffer of an
+ * ALL-GATHER, a replicated build's entries): then the one chunk holds the table's entries in the order the build met them, the same
+ * bytes run after run.  Queued on the ctx stream; nothing is waited for.
+ * SDQH_ERR_UNSUPPORTED: a table whose staged rows may repeat a key (use sdqh_table_entries + sdqh_partition_pack) — a unique build
+ * qualifies when its key is a strictly increasing column, or two plain columns that strictly increase as pairs. */
 int sdqh_table_partition_pack(sdqh_ctx* ctx, const sdqh_table* table, int nparts, const int64_t* range_upper, int64_t chunk_rows, void* packed);
 /* The receiving side: nparts chunks (as received from the ranks, in rank order) -> ncols freshly allocated columns of
  * nparts * chunk_rows rows: the sources' rows back to back (min(header, chunk_rows) of each), then PADDING rows up to the capacity —

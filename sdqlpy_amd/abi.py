@@ -219,7 +219,7 @@ EXPORTS = [
     "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_table_compact_async", "sdqh_table_compact_deferred", "sdqh_host_wait_word", "sdqh_result_wait", "sdqh_scan_compact", "sdqh_partition_by_key",
     "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in", "sdqh_column_unpack2", "sdqh_partition_pack", "sdqh_unpack_parts", "sdqh_column_mark_transient", "sdqh_column_set_bounds",
     "sdqh_build", "sdqh_lookup_aggregate", "sdqh_table_entries", "sdqh_host_alloc", "sdqh_host_free", "sdqh_table_topk",
-    "sdqh_xscan_sum", "sdqh_xgroupby", "sdqh_xgroupby_block_bytes", "sdqh_xgroupby_async", "sdqh_xgroupby_collect", "sdqh_xbuild", "sdqh_xkey_set", "sdqh_xcompact", "sdqh_xprobe_aggregate", "sdqh_table_columns", "sdqh_jit_stats", "sdqh_jit_compile",
+    "sdqh_xscan_sum", "sdqh_xgroupby", "sdqh_xgroupby_block_bytes", "sdqh_xgroupby_async", "sdqh_xgroupby_collect", "sdqh_xgroupby_partial", "sdqh_xgroupby_fold", "sdqh_xbuild", "sdqh_xkey_set", "sdqh_xcompact", "sdqh_xprobe_aggregate", "sdqh_table_columns", "sdqh_jit_stats", "sdqh_jit_compile",
     "sdqh_xstage", "sdqh_chunk_words", "sdqh_table_partition_pack", "sdqh_unpack_chunks",
     "sdqh_graph_begin", "sdqh_graph_end", "sdqh_graph_abort", "sdqh_graph_launch", "sdqh_graph_nodes", "sdqh_graph_free",
 ]
@@ -753,6 +753,38 @@ class Context:
             return out_keys[:n], out_vals[:n, :nvals], out_cnt[:n]
         return collect
 
+    def xgroupby_block_bytes(self):
+        return int(self.lib.sdqh_xgroupby_block_bytes())
+
+    def xgroupby_folded(self, nrows, prog, exchange, max_groups=MAX_LOOKUP_GROUPS):
+        """K-C small over a ROW SHARD, the ranks' partial groups folded on the device (sdqh_xgroupby_partial / _fold): nothing is
+        waited for.  exchange(block_bytes) -> (send_ptr, gather) hands out this rank's block in the collective's send buffer;
+        gather() -> (recv_ptr, nblocks) issues the collective behind the kernel that filled it and names the gathered blocks.
+        Returns collect() as xgroupby_async."""
+        nbytes = self.xgroupby_block_bytes()
+        send_ptr, gather = exchange(nbytes)
+        self._check(self.lib.sdqh_xgroupby_partial(self.handle, C.c_int64(nrows), C.byref(prog.struct()), C.c_void_p(send_ptr)))
+        self._after_call("xgroupby")
+        recv_ptr, nblocks = gather()
+        done = [False]
+        buf = self.host_block(nbytes, deferred=done)
+        self._check(self.lib.sdqh_xgroupby_fold(self.handle, C.c_void_p(recv_ptr), C.c_int(nblocks), C.addressof(buf)))
+        self._after_call("xgroupby_fold")
+        nvals = len(prog.vals)
+
+        def collect():
+            out_keys = np.zeros(max_groups, np.int64)
+            out_vals = np.zeros((max_groups, TUPLE_MAX_VALUES), np.float64)
+            out_cnt = np.zeros(max_groups, np.int64)
+            ng = C.c_int32()
+            rc = self.lib.sdqh_xgroupby_collect(self.handle, C.addressof(buf), C.c_int(nvals), C.c_int(max_groups),
+                                                _np_ptr(out_keys), _np_ptr(out_vals), _np_ptr(out_cnt), C.byref(ng))
+            done[0] = True
+            self._check(rc)
+            n = ng.value
+            return out_keys[:n], out_vals[:n, :nvals], out_cnt[:n]
+        return collect
+
     def xbuild(self, nrows, prog, key_lo=1, key_hi=0, accumulate=False, nsums=None):
         """nsums: how many sums per entry the later probe-aggregate will add, when the caller's plan knows (else room for all four)."""
         h = C.c_void_p()
@@ -1183,6 +1215,8 @@ class Library:
         L.sdqh_xgroupby_block_bytes.restype = C.c_size_t
         L.sdqh_xgroupby_async.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.sdqh_xgroupby_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sdqh_xgroupby_partial.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.sdqh_xgroupby_fold.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.sdqh_xbuild.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
         L.sdqh_fork.argtypes = [C.c_void_p, C.c_void_p]
         L.sdqh_xkey_set.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]

@@ -116,6 +116,48 @@ __global__ __launch_bounds__(TPB) void k_stage_part_pack(DevStage st, DevPartiti
     }
 }
 
+// ONE part (an all-gather's send buffer: this rank's entries, whole): the stage's segments back to back IN STAGE ORDER — a scan of the
+// segments' live counts, then every wave copies its segment to its place.  Deterministic, and what was in row order stays in row
+// order: the replica a receiver rebuilds from the ranks' chunks (rank after rank) sees the table's rows in the table's order.
+__global__ __launch_bounds__(TPB) void k_stage_pack_scan(DevStage st, unsigned long long* __restrict__ offs, int64_t* __restrict__ packed) {
+    __shared__ unsigned long long s_scan[TPB];
+    __shared__ unsigned long long s_base;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < st.nseg; i0 += TPB) {
+        const int i = i0 + (int)threadIdx.x;
+        const unsigned long long c = i < st.nseg ? st.seg_count[i] : 0u;
+        s_scan[threadIdx.x] = c;
+        __syncthreads();
+        for (int off = 1; off < TPB; off <<= 1) {
+            const unsigned long long v = (int)threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0ull;
+            __syncthreads();
+            s_scan[threadIdx.x] += v;
+            __syncthreads();
+        }
+        if (i < st.nseg) offs[i] = s_base + s_scan[threadIdx.x] - c;
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += s_scan[TPB - 1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { packed[0] = (int64_t)s_base; packed[1] = 0; }
+}
+__global__ __launch_bounds__(TPB) void k_stage_pack_copy(DevStage st, const unsigned long long* __restrict__ offs, int ncols, int64_t chunk_rows, int64_t* __restrict__ packed) {
+    const int seg = (int)blockIdx.x * (TPB / WAVE) + (int)(threadIdx.x / WAVE), lane = (int)(threadIdx.x & (WAVE - 1));
+    if (seg >= st.nseg) return;
+    const uint32_t n = st.seg_count[seg];
+    const unsigned long long base = offs[seg];
+    int64_t* chunk = packed + 2;
+    for (uint32_t i = (uint32_t)lane; i < n; i += WAVE) {
+        const unsigned long long at = base + i;
+        if (at >= (unsigned long long)chunk_rows) break;
+        const int64_t row = (int64_t)seg * st.seg_rows + i;
+        chunk[at] = st.key[row];
+#pragma unroll
+        for (int c = 1; c < SDQH_MAX_COMPACT_COLS; ++c) if (c < ncols) chunk[(int64_t)c * chunk_rows + at] = st.pay[c - 1][row];
+    }
+}
+
 struct DevChunkUnpack {
     const int64_t* packed; const int64_t* sent;
     int64_t* out[SDQH_MAX_COMPACT_COLS];
@@ -412,7 +454,7 @@ int64_t sdqh_chunk_words(int ncols, int64_t chunk_rows) { return (ncols < 1 || c
 int sdqh_table_partition_pack(sdqh_ctx* ctx, const sdqh_table* table, int nparts, const int64_t* range_upper, int64_t chunk_rows, void* packed) {
     if (!ctx || !table || nparts < 1 || nparts > SDQH_MAX_PARTS || chunk_rows < 1 || !packed) return fail(ctx, SDQH_ERR_INVALID, "table_partition_pack: bad arguments");
     if (table->bitmap_only || !table->stage.seg_count || !table->stage.key) return fail(ctx, SDQH_ERR_INVALID, "table_partition_pack: not a staged table");
-    if (!(table->stage_only || table->keys_unique)) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_partition_pack: the table's staged rows may repeat a key");
+    if (!(table->stage_only || table->keys_unique || table->pack_unique)) return fail(ctx, SDQH_ERR_UNSUPPORTED, "table_partition_pack: the table's staged rows may repeat a key");
     const int ncols = 1 + table->npay;
     if (ncols > SDQH_MAX_COMPACT_COLS) return fail(ctx, SDQH_ERR_INVALID, "table_partition_pack: too many columns");
     (void)hipSetDevice(ctx->device);
@@ -420,6 +462,19 @@ int sdqh_table_partition_pack(sdqh_ctx* ctx, const sdqh_table* table, int nparts
     if (range_upper) for (int p = 0; p < nparts - 1; ++p) pt.upper[p] = range_upper[p];
     const int64_t cw = sdqh_chunk_words(ncols, chunk_rows);
     call_begin(ctx);
+    if (nparts == 1) {
+        // the whole stage into one chunk, in stage order (round 6: the send buffer of an all-gather — a replicated build's entries)
+        unsigned long long* offs = static_cast<unsigned long long*>(pool_alloc(ctx, (size_t)table->stage.nseg * 8 + 64));
+        if (!offs) return fail(ctx, SDQH_ERR_NOMEM, "table_partition_pack: out of device memory");
+        { KernelScope ks(ctx, "k_stage_pack_scan");
+          hipLaunchKernelGGL(k_stage_pack_scan, dim3(1), dim3(TPB), 0, ctx->stream, table->stage, offs, static_cast<int64_t*>(packed)); }
+        { KernelScope ks(ctx, "k_stage_pack_copy");
+          hipLaunchKernelGGL(k_stage_pack_copy, dim3((unsigned)((table->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE))), dim3(TPB), 0, ctx->stream, table->stage, offs, ncols, chunk_rows, static_cast<int64_t*>(packed)); }
+        pool_free(ctx, offs);                                          // (stream order: whoever gets the block next runs behind the copy)
+        call_end(ctx);
+        if (hipGetLastError() != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, "table_partition_pack: launch failed");
+        return SDQH_OK;
+    }
     // the headers double as the kernel's cursors: 16 bytes cleared at the head of every chunk (one strided memset)
     HIP_TRYA(ctx, hipMemset2DAsync(packed, (size_t)cw * 8, 0, 16, (size_t)nparts, ctx->stream));
     const unsigned grid = (unsigned)std::max(1, (table->stage.nseg + PP_SEGS - 1) / PP_SEGS);

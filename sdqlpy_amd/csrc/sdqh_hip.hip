@@ -371,6 +371,28 @@ bool column_is_increasing(sdqh_ctx* ctx, sdqh_column* c) {
     return ok && c->increasing == 1;
 }
 
+// ... or strictly increasing as PAIRS with another column of the same table (cached on `a`, one partner)?
+bool columns_pair_increasing(sdqh_ctx* ctx, sdqh_column* a, sdqh_column* b) {
+    if (a->dtype != SDQH_I64 || b->dtype != SDQH_I64 || a->nrows != b->nrows || a->transient || b->transient) return false;
+    if (a->increasing == 1) return true;
+    if (a->pair_uid == b->uid && a->pair_increasing >= 0) return a->pair_increasing == 1;
+    if (a->nondecreasing == 0) { a->pair_uid = b->uid; a->pair_increasing = 0; return false; }
+    if (a->nrows < 2) return true;
+    int* flag = static_cast<int*>(pool_alloc(ctx, 64));
+    if (!flag) return false;
+    bool ok = hipMemsetAsync(flag, 0, 4, ctx->stream) == hipSuccess, yes = false;
+    if (ok) {
+        const unsigned grid = (unsigned)std::min<int64_t>((a->nrows + TPB - 1) / TPB, (int64_t)ctx->num_cu * 8);
+        hipLaunchKernelGGL(k_check_pair_increasing, dim3(grid), dim3(TPB), 0, ctx->stream, static_cast<const int64_t*>(a->data), static_cast<const int64_t*>(b->data), a->nrows, flag);
+        int* host = static_cast<int*>(ctx->result_host);
+        ok = hipMemcpyAsync(host, flag, 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+        if (ok) { yes = host[0] == 0; a->pair_uid = b->uid; a->pair_increasing = yes ? 1 : 0; }
+    }
+    if (!ok) (void)hipGetLastError();
+    pool_free(ctx, flag);
+    return ok && yes;
+}
+
 // ... or never decreasing?  (Cached the same way; a strictly increasing column is.)
 bool column_is_nondecreasing(sdqh_ctx* ctx, sdqh_column* c) {
     if (c->nondecreasing >= 0) return c->nondecreasing == 1;
@@ -2057,6 +2079,10 @@ int sdqh_build(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nloo
     sdqh_table* tb = new sdqh_table();
     tb->npay = npayload; tb->accumulate = accumulate != 0; tb->nrows_build = nrows;
     if (nkey == 1 && nrows > 0 && key[0].kind == SDQH_SRC_COLUMN && key[0].col->dtype == SDQH_I64 && column_is_increasing(ctx, const_cast<sdqh_column*>(key[0].col))) tb->keys_unique = true;
+    // a composite key whose parts are plain columns that strictly increase as pairs (supplier by (s_suppkey, s_nationkey), partsupp by (ps_partkey,
+    // ps_suppkey)): every staged row is an entry — the multi-GPU runner's device-sized replication may take the stage as it is
+    if (nkey == 2 && nrows > 0 && !ctx->capturing && key[0].kind == SDQH_SRC_COLUMN && key[1].kind == SDQH_SRC_COLUMN && key[0].col->nrows == nrows && key[1].col->nrows == nrows &&
+        columns_pair_increasing(ctx, const_cast<sdqh_column*>(key[0].col), const_cast<sdqh_column*>(key[1].col))) tb->pack_unique = true;
     // stage without source columns: the kernel evaluates sources itself
     sdqh_column fake; fake.data = nullptr;
     const sdqh_column* fakes[SDQH_MAX_PAYLOAD] = {&fake, &fake, &fake, &fake};

@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <map>
 #include <string>
 #include <vector>
@@ -157,7 +158,11 @@ struct sdqh_ctx {
     const void* g4_hint[SDQH_MAX_GROUPKEYS] = {nullptr, nullptr};
 };
 
+inline uint64_t sdqh_next_uid() { static std::atomic<uint64_t> next{1}; return next.fetch_add(1, std::memory_order_relaxed); }
+
 struct sdqh_column {
+    uint64_t uid = sdqh_next_uid();    // never reused (an address is): what a fact about TWO columns names its partner by
+    uint64_t pair_uid = 0; int pair_increasing = -1;      // (this column, column `pair_uid`) strictly increasing as pairs, row after row? (one partner cached)
     sdqh_ctx* home = nullptr;          // the context that created the column: its attachments (twins, dictionaries, statistics) live in THAT pool, whichever context of the family builds them
     void* data = nullptr;
     int64_t nrows = 0;
@@ -211,6 +216,7 @@ struct sdqh_table {
     std::vector<void*> owned;          // pool blocks to release
     // cached compaction (device buffers) for the two-step count / fetch protocol
     uint32_t* span = nullptr;                      // owner by key offset (small plain-key direct tables), becomes dev.dense_arr once the index is built
+    bool pack_unique = false;                      // no two staged rows share a key although keys_unique does not say so (a composite key whose parts, as pairs, strictly increase): sdqh_table_partition_pack may take the stage as the entries
     bool keys_unique = false;                      // the build key is a strictly increasing column: no two staged rows share a key (k_fill_refs has nothing to do)
     bool refs_prefilled = false;                   // small direct tables: dense_ref was allocated and NO_ROW-filled with the header
     bool compact_valid = false;

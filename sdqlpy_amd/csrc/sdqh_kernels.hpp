@@ -1735,6 +1735,12 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_check_nondecreasing(const int64_t* __r
     for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r + 1 < nrows; r += (int64_t)gridDim.x * TPB) bad |= key[r] > key[r + 1];
     if (__ballot(bad) && lane_id() == 0) atomicOr(flag, 1);
 }
+// ... or two columns strictly increasing AS PAIRS (a, b), row after row (a composite key of a table stored in its order: no two rows share a key)?
+SDQH_KERNEL __launch_bounds__(TPB) void k_check_pair_increasing(const int64_t* __restrict__ a, const int64_t* __restrict__ b, int64_t nrows, int* __restrict__ flag) {
+    bool bad = false;
+    for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r + 1 < nrows; r += (int64_t)gridDim.x * TPB) bad |= !(a[r] < a[r + 1] || (a[r] == a[r + 1] && b[r] < b[r + 1]));
+    if (__ballot(bad) && lane_id() == 0) atomicOr(flag, 1);
+}
 // Dense layout over a strictly increasing key column, in ONE pass: row r writes its own cell and NO_ROW into the cells up to
 // the next key, so the array needs no prefill (240 MB for Q9's orders) and — no duplicates possible — no verification pass
 // (another read of keys and cells).  Every cell in [lo, hi] is written exactly once; lo / hi are the column's min / max.

@@ -87,6 +87,7 @@ class DistributedRunner:
         # every collective this runner issued since the last reset_collectives(): name -> [calls, calls on device tensors, bytes]
         self.collectives = {}
         self._ext_stream = None             # RCCL: torch's view of the engine's HIP stream (see _device_order)
+        self.last_chain = None              # what the seams of the last device-sized chain did (_chain_device_sized)
 
     def _device_order(self):
         """RCCL: torch's current stream becomes the ENGINE's stream for the duration of a run.  A collective is then ordered on the
@@ -183,6 +184,7 @@ class DistributedRunner:
         (column-major inside each rank's slot)."""
         sizes = [int(x[0]) for x in self._all_gather_array(np.array([n], np.int64))]
         total, m = sum(sizes), max(sizes + [1])
+        self._last_gather_max = max(sizes + [0])                             # (every rank gathered the same sizes: the bound of the next run's chunk)
         k = len(cols)
         self._on_engine_stream()
         send = torch.empty(m * k, dtype=torch.int64, device=self.device)     # padding rows are never read back; no fill kernel
@@ -453,6 +455,10 @@ class DistributedRunner:
                 total += float(p[0])
             return total
         if shape == "groups":
+            if self.device_sized and self._top is None and os.environ.get("SDQLPY_AMD_DIST_GROUPS_AS_CHAIN", "1") != "0":
+                # a chain with nothing to replicate: its first run merges the partial groups on the host and compares the ranks' key
+                # encodings; from the second on they are folded on the device behind one all-gather, nothing waited for
+                return self._sharded_chain(plan, args, whole, None)
             return self._row_sharded_groupby(plan, args)
         if shape == "join":
             a_op, b_op, c_op = plan.ops[0], plan.ops[1], plan.ops[2]
@@ -649,6 +655,20 @@ class DistributedRunner:
             else:
                 st.steps.append((op, None))
         st.sharded = {op.out: (op.table not in whole) for op in scan_ops}
+        # ---- the device-sized form of this chain (_chain_device_sized): which exchanges it has, whether the engine's own prepared plan
+        # can carry them at its seams.  Everything here follows from the plan and from facts every rank gathered: all decide alike.
+        st.whole = set(whole)
+        st.caps, st.measured, st.fold_fp, st.partitioned_result = {}, False, {}, False
+        st.fast_tables = [op.out for op in scan_ops if st.replicate.get(op.out) and op.out not in st.key_range]
+        engine_acc = {op.probe.dict_name for op in scan_ops
+                      if op.kind == "dict" and not op.unique and op.probe is not None
+                      and (engine._is_simple(op, tabs[op.table], [c.lookup for c in op.conds if isinstance(c, frontend.Contains)]) or xplan.groups_by_entry(op))}
+        st.fast_ok = (len(st.fast_tables) <= 4
+                      and all(name in st.table_range or name in st.part_ranges for name in st.fast_tables)
+                      and all(name in st.key_range for name in member_only if st.replicate.get(name))
+                      and engine_acc == set(accumulate_into)
+                      and not any(isinstance(op, (frontend.SelectKeysOp,)) for op in plan.ops)
+                      and all(isinstance(op, (ScanOp, FinalizeOp, frontend.ScalarExprOp)) for op in plan.ops))
         # text that only means something on this rank: string columns of sharded tables and their dictionaries
         st.local_text = set()
         for p_, t_ in tabs.items():
@@ -661,7 +681,7 @@ class DistributedRunner:
                             st.local_text.add(id(hit[2]))
         return st
 
-    def _replicate_table(self, bt, key_range=None, table_range=None, part_ranges=None):
+    def _replicate_table(self, bt, key_range=None, table_range=None, part_ranges=None, measure=None):
         """All ranks' entries of a built table on every rank, without leaving device memory.  A key set (key_range given): its exact
         bitmap over the global key range, one collective, the replica a key set again — the layout the loops that test it are
         specialised on.  A table with payload: entries -> all-gather -> rebuild, a composite key (travelling packed) from its two
@@ -680,6 +700,8 @@ class DistributedRunner:
                                             "(hold its table whole on every rank)" % bt.key_name)
         cols, n = ctx.table_entries(bt.table)
         gathered, total = self._all_gather_columns(cols, n)
+        if measure is not None:
+            measure(self._last_gather_max)
         for c in cols:
             c.free()
         if bt.key_parts is not None and total:
@@ -699,7 +721,7 @@ class DistributedRunner:
         bt.table.free()
         return new
 
-    def _sharded_chain(self, plan, args, whole, top=None):
+    def _sharded_chain(self, plan, args, whole, top=None, waited=False):
         cache = plan.__dict__.setdefault("_dist_chain", {})
         key = (id(self), tuple(sorted(whole))) + tuple(id(a) for a in args)
         st = cache.get(key)
@@ -708,15 +730,24 @@ class DistributedRunner:
         if st.unsupported:
             raise frontend.UnsupportedQuery(st.unsupported)          # decided from all-gathered facts: every rank raises
         self._local_text = st.local_text
+        if self.device_sized and not waited and top is None and st.fast_ok and st.measured and not (self.world == 1 and self.skip_trivial):
+            try:
+                return self._chain_device_sized(st, plan, args)
+            except abi.SdqhError as exc:
+                if exc.code != abi.ERR_UNSUPPORTED:
+                    raise
+                st.fast_ok = False                   # (decided by the tables' layouts, the same on every rank: all fall back alike)
         env = {}
+        caps = {}
         try:
             for op, step in st.steps:
                 if isinstance(op, ScanOp):
                     res = step(env)
                     if isinstance(res, engine.BuiltTable) and st.replicate.get(op.out) and not (self.world == 1 and self.skip_trivial):
-                        res = self._replicate_table(res, st.key_range.get(op.out), st.table_range.get(op.out), st.part_ranges.get(op.out))
+                        res = self._replicate_table(res, st.key_range.get(op.out), st.table_range.get(op.out), st.part_ranges.get(op.out),
+                                                    measure=lambda most, name=op.out: caps.__setitem__(name, _chunk_bound(most, st.caps.get(name))))
                     elif isinstance(res, engine.DictResult) and st.sharded[op.out]:
-                        res = self._merge_groups(res)
+                        res = self._merge_groups(res, st, op.out)
                     elif isinstance(res, float) and st.sharded[op.out]:
                         res = sum(float(p[0]) for p in self._all_gather_array(np.array([res], np.float64)))
                     elif isinstance(res, dict) and st.sharded[op.out]:       # scalar record: one partial sum per field, folded in rank order
@@ -744,13 +775,216 @@ class DistributedRunner:
                     env[op.out] = engine._eval_scalar_expr(op.expr, env, op.lineno)
                 else:
                     raise frontend.UnsupportedQuery("%s is not part of the distributed chain plan yet" % type(op).__name__)
+            st.caps.update(caps)
+            st.partitioned_result = self._partitioned_result
+            st.measured = True                       # (a complete run with exact sizes: the next one may move fixed-capacity chunks)
             return env[plan.result]
         finally:
             for v in env.values():
                 if isinstance(v, engine.BuiltTable):
                     v.table.free()
 
-    def _merge_groups(self, d):
+    # ---- the chain with NO host wait between its first kernel and its result (round 6) ---------------------------------------------
+    def _chain_device_sized(self, st, plan, args):
+        """A settled chain — a first run has exchanged exact sizes and remembered them — as the ENGINE's own prepared plan (the
+        single-GPU plan's kernels, its last loop launched and not waited for) with the exchanges at its seams, every one sized on the
+        device:
+          a replicated table with payload   its entries packed in build order into ONE fixed-capacity chunk (sdqh_table_partition_pack,
+                                            one part), one all-gather, the ranks' chunks taken apart into columns padded to the capacity
+                                            (sdqh_unpack_chunks) and rebuilt — the rows beyond the true counts carry a key a gate drops;
+          a replicated key set              its exact bitmap, one collective (as before: nothing was waited for there);
+          partial groups (<= 256)           this rank's group table straight into the send buffer of ONE all-gather, the ranks' blocks
+                                            folded by key in rank order on the device (sdqh_xgroupby_partial / _fold) into the result
+                                            block the engine's deferred result reads — where the first run found the packed keys to mean
+                                            the same on every rank; else the groups are merged on the host as in the first run.
+        The largest chunk counts travel in the spare words of the group block (no collective of their own) or, for a plan without one,
+        in an all-reduce of four words; they land in pinned memory in front of the result and are read when it is collected: a chunk
+        that overflowed anywhere makes every rank repeat the chain with exact sizes (collective_rerun), otherwise they bound the next
+        run.  Collectives per run: one per replicated table + one for the groups."""
+        ctx, eng = self.ctx, self.eng
+        G = self.world
+        pp = engine.prepared_plan(eng, plan, args, lane=0, member_only=st.member_only)      # (the chain's own choice of key sets: a set whose entries travel is a table)
+        self._on_engine_stream()
+        dev = st.__dict__.get("dev_bufs")
+        if dev is None:
+            dev = st.dev_bufs = {"stat": torch.zeros(abi.EXCHANGE_STAT_WORDS, dtype=torch.int64, device=self.device), "bufs": {}, "caps": {}}
+            dev["stat_col"] = ctx.wrap(dev["stat"].data_ptr(), abi.EXCHANGE_STAT_WORDS, abi.I64, keepalive=dev["stat"])
+        stat_t, stat = dev["stat"], dev["stat_col"]
+        names = [n for n in st.fast_tables]                          # replicated tables with payload, in plan order: their status slots
+        host_t, host, busy = self._stat_buffer()
+        host[abi.EXCHANGE_STAT_WORDS - 1] = -1
+        keep = []
+        state = {"status_sent": False}
+
+        def buffers(name, words):
+            pair = dev["bufs"].get(name)
+            if pair is None or pair[0].numel() != words:
+                send = torch.empty(words, dtype=torch.int64, device=self.device)
+                pair = dev["bufs"][name] = (send, torch.empty(words * G, dtype=torch.int64, device=self.device))
+            return pair
+
+        def gather(recv, send):
+            self._note("all_gather", send)
+            if self.backend == "nccl":
+                dist.all_gather_into_tensor(recv, send, group=self.group)
+            else:
+                dist.all_gather(list(recv.view(G, -1).unbind(0)), send, group=self.group)
+
+        def status_to_host(head):
+            host_t[:4].copy_(head, non_blocking=True)
+            host_t[abi.EXCHANGE_STAT_WORDS - 1:].copy_(stat_t[abi.EXCHANGE_STAT_WORDS - 1:], non_blocking=True)      # (the sentinel's word: 0 on the device)
+            state["status_sent"] = True
+
+        def replicate(name):
+            def seam(env):
+                bt = env[name]
+                if not isinstance(bt, engine.BuiltTable):
+                    return None
+                if name in st.key_range:
+                    info["bitmaps"].append(name)
+                    return self._replicate_table(bt, st.key_range[name])            # (a bitmap through one collective: no host wait in it)
+                info["replicated"].append(name)
+                slot = names.index(name)
+                cap = st.caps[name]
+                ncols = 1 + bt.table.npayload
+                cw = ctx.chunk_words(ncols, cap)
+                send, recv = buffers(name, cw)
+                ctx.table_partition_pack(bt.table, 1, cap, send.data_ptr())
+                gather(recv, send)
+                if bt.key_parts is not None:
+                    (lo0, hi0), (lo1, hi1) = st.part_ranges[name]
+                    pad = (hi0 + 1) << 32
+                    cols = ctx.unpack_chunks(recv.data_ptr(), G, [abi.I64] * ncols, cap, pad, stat, slot, sent_ptr=None, self_part=self.rank)
+                    hi, lo = ctx.unpack2(cols[0], G * cap)
+                    hi.set_bounds(lo0, hi0 + 1); lo.set_bounds(min(lo1, 0), hi1)
+                    table = ctx.build(G * cap, abi.make_filter([(hi, lo0, hi0)], [], []), [], [abi.src_col(hi), abi.src_col(lo)], [abi.src_col(c) for c in cols[1:]])
+                    cols = list(cols) + [hi, lo]
+                else:
+                    lo_k, hi_k = st.table_range[name]
+                    pad = lo_k - 1
+                    cols = ctx.unpack_chunks(recv.data_ptr(), G, [abi.I64] * ncols, cap, pad, stat, slot, sent_ptr=None, self_part=self.rank)
+                    cols[0].set_bounds(pad, hi_k)
+                    table = self._build_from_columns(G * cap, cols, (pad, hi_k), accumulate=False, first_key=lo_k)
+                new = engine.BuiltTable(table, bt.key_name, bt.key_is_record, bt.val_fields, bt.val_is_record, bt.payload_dtypes)
+                new.decoders, new.key_parts, new.field_decoders = bt.decoders, bt.key_parts, bt.field_decoders
+                new.key_decoder = bt.key_decoder
+                for attr in ("slot_rng", "key_part_decoders", "key_bounds", "slot_roots", "slot_plain"):
+                    if hasattr(bt, attr):
+                        setattr(new, attr, getattr(bt, attr))
+                new._keep = cols
+                keep.extend(cols)
+                bt.table.free()
+                if name == names[-1] and not st.fold_fp:
+                    # no group block will carry the chunks' counts: four words all-reduced behind the last exchange, in front of whatever
+                    # the plan ends in (a K-F launched and not waited for: _partitioned results)
+                    head = stat_t[:4]
+                    self._note("all_reduce", head)
+                    dist.all_reduce(head, op=dist.ReduceOp.MAX, group=self.group)
+                    status_to_host(head)
+                return new
+            return seam
+
+        def fold_hook(name, fp):
+            if name not in st.fold_fp or name not in pp.defer_names:
+                return None                                            # not foldable by packed key: the loop is waited for, its groups merged on the host (the seam below)
+            if fp is None or st.fold_fp.get(name) != fp:
+                # (the digest the first run compared across the ranks belongs to this prepared chain's compiled loop: a different one
+                #  means the loop was compiled again behind the runner's back)
+                raise RuntimeError("%s: the group keys of '%s' were encoded anew since the ranks compared their encodings" % (plan.name, name))
+
+            def exchange(nbytes):
+                words = nbytes // 8
+                send, recv = buffers(("groups", name), words)
+                info["folded"].append(name)
+
+                def issue():
+                    # the chunks' largest counts ride in the block's spare words (behind its completion word, which a device block does
+                    # not use): no collective of their own
+                    spare = words - 6
+                    send[spare:spare + 4].copy_(stat_t[:4])
+                    gather(recv, send)
+                    status_to_host(recv.view(G, words)[:, spare:spare + 4].amax(dim=0))
+                    return recv.data_ptr(), G
+                return send.data_ptr(), issue
+            return exchange
+
+        def merged(name):
+            def seam(env):
+                res = env[name]
+                if isinstance(res, engine.DictResult):
+                    info["merged_on_host"].append(name)
+                    return self._merge_groups(res, st, name)
+                if isinstance(res, float):
+                    return sum(float(p[0]) for p in self._all_gather_array(np.array([res], np.float64)))
+                if isinstance(res, dict):
+                    keys = sorted(res)
+                    parts = self._all_gather_array(np.array([res[k] for k in keys], np.float64))
+                    return {k: sum(float(p[j]) for p in parts) for j, k in enumerate(keys)}
+                return None                                            # (a Pending — the folded groups —, a local build, finished local groups)
+            return seam
+
+        after = {}
+        for op, _ in st.steps:
+            if not isinstance(op, ScanOp):
+                continue
+            if st.replicate.get(op.out):
+                after[op.out] = replicate(op.out)
+            elif st.sharded[op.out]:
+                after[op.out] = merged(op.out)                         # (a Pending — the folded groups — passes through)
+
+        def precheck():
+            try:
+                if names and state["status_sent"]:
+                    if host[abi.EXCHANGE_STAT_WORDS - 1] == -1:
+                        t0 = time.perf_counter()
+                        while host[abi.EXCHANGE_STAT_WORDS - 1] == -1:
+                            if time.perf_counter() - t0 > 2.0:
+                                ctx.synchronize()
+                                if self.backend == "nccl":
+                                    torch.cuda.synchronize(self.device)
+                                break
+                    most = [int(host[abi.STAT_MAX_COUNT + i]) for i in range(len(names))]
+                else:
+                    most = []
+            finally:
+                busy[0] = False
+            over = [(n, m, st.caps[n]) for n, m in zip(names, most) if m > st.caps[n]]
+            for n, m in zip(names, most):
+                st.caps[n] = _chunk_bound(m, st.caps[n])
+            if over:
+                raise engine.RetryPlan("a replicated table outgrew its chunk: %s" % ", ".join("%s %d > %d" % o for o in over))
+
+        def collective_rerun():
+            self.fast_retries += 1
+            return self._guarded(lambda: self._sharded_chain(plan, args, st.whole, None, waited=True))
+
+        self.fast_runs += 1
+        self.last_chain = info = {"plan": plan.name, "replicated": [], "bitmaps": [], "folded": [], "merged_on_host": []}      # (what this run's seams did: tests, bench.py)
+        try:
+            self._partitioned_result = st.partitioned_result
+            res = pp.run(None, after=after, keep_tables=True, on_retry=collective_rerun, precheck=precheck, env_extra={"__group_fold__": fold_hook})
+        finally:
+            self._inflight.extend(keep)
+        if isinstance(res, engine.DeferredResultSet):
+            if names and not state["status_sent"]:
+                raise RuntimeError("%s: a deferred chain whose exchange status never left the device" % plan.name)
+            return res
+        # every call was waited for (a final loop without a deferred form): the status — where no group block carried it, four words
+        # all-reduced now — and the verdict, the same on every rank
+        if names:
+            if not state["status_sent"]:
+                head = stat_t[:4]
+                self._note("all_reduce", head)
+                dist.all_reduce(head, op=dist.ReduceOp.MAX, group=self.group)
+                status_to_host(head)
+            ctx.synchronize()
+        try:
+            precheck()
+        except engine.RetryPlan:
+            return collective_rerun()
+        return res
+
+    def _merge_groups(self, d, st=None, name=None):
         """Partial groups of every rank -> the global groups on every rank (folded in rank order).
         The rows travel as raw bytes in ONE fixed-size all_gather (<= 256 groups per rank: the
         group-by kernels' own limit), not as pickled objects."""
@@ -764,15 +998,25 @@ class DistributedRunner:
         if n > cap:
             raise frontend.UnsupportedQuery("more than %d partial groups on one rank" % cap)
         body_words = (cap * rowbytes + 7) // 8
-        buf = np.zeros(2 + body_words, np.int64)
+        buf = np.zeros(3 + body_words, np.int64)
         buf[0], buf[1] = n, rowbytes
-        body = buf[2:].view(np.uint8)[: cap * rowbytes].reshape(cap, rowbytes)
+        fp = getattr(d, "encoding_fp", None)
+        buf[2] = int(fp[:15], 16) if fp else -1              # what this rank's packed group keys mean, as a digest (xplan._encoding_fingerprint)
+        body = buf[3:].view(np.uint8)[: cap * rowbytes].reshape(cap, rowbytes)
         at = 0
         for (_, a), dt in zip(fields, dtypes):
             if n:
                 body[:n, at:at + dt.itemsize] = np.ascontiguousarray(a).view(np.uint8).reshape(n, dt.itemsize)
             at += dt.itemsize
         parts = self._all_gather_array(buf)
+        if st is not None and name is not None:
+            # every rank packs its group keys alike (same dictionaries, same value ranges): later runs may fold the partial groups by
+            # packed key on the device (_chain_device_sized); else they go on being merged here, by their decoded values
+            same = fp is not None and all(int(p[2]) == int(buf[2]) for p in parts)
+            if same:
+                st.fold_fp[name] = fp
+            else:
+                st.fold_fp.pop(name, None)
         merged, order = {}, []
         nk = len(d.key_fields)
         for p in parts:
@@ -781,7 +1025,7 @@ class DistributedRunner:
                 continue
             if int(p[1]) != rowbytes:
                 raise RuntimeError("ranks disagree on the group row layout")
-            pbody = p[2:].view(np.uint8)[: cap * rowbytes].reshape(cap, rowbytes)
+            pbody = p[3:].view(np.uint8)[: cap * rowbytes].reshape(cap, rowbytes)
             cols, at = [], 0
             for dt in dtypes:
                 cols.append(np.ascontiguousarray(pbody[:pn, at:at + dt.itemsize]).view(dt).reshape(pn).tolist())

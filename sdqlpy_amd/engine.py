@@ -1949,7 +1949,9 @@ class RetryPlan(Exception):
 class PreparedPlan:
     """A plan bound to one engine and one set of tables: every operator lowered to a closure."""
 
-    def __init__(self, eng, plan, args):
+    def __init__(self, eng, plan, args, member_only=None):
+        """member_only: the builds to make as key sets, when the caller knows better than the plan alone (the multi-GPU runner: a set
+        other ranks' rows look up, whose keys do not suit a bitmap, is built as a table so that its entries can travel)."""
         if len(args) != len(plan.params):
             raise TypeError("%s expects %d tables, got %d" % (plan.name, len(plan.params), len(args)))
         self.eng, self.plan, self.args = eng, plan, tuple(args)       # keeps the tables (and so their ids) alive
@@ -1971,7 +1973,7 @@ class PreparedPlan:
                 acc_sums[op.probe.dict_name] = max(acc_sums.get(op.probe.dict_name, 0), n)
         # (the set of names becomes a dictionary name -> sums per entry, or None where the plan does not say: `in` works as before)
         accumulate_into = {name: (acc_sums.get(name) if 1 <= acc_sums.get(name, 0) <= abi.TUPLE_MAX_VALUES else None) for name in accumulate_into}
-        member_only = _membership_only(plan)
+        member_only = _membership_only(plan) if member_only is None else set(member_only)
         looked_up = _looked_up(plan)
         compared = _compared_lookups(plan)
         self.steps = []
@@ -2005,7 +2007,7 @@ class PreparedPlan:
             return frozenset([ops[-2].out, ops[-1].out])
         return frozenset()
 
-    def run(self, top=None, deferred=True, after=None, replace=None, keep_tables=False, on_retry=None, precheck=None):
+    def run(self, top=None, deferred=True, after=None, replace=None, keep_tables=False, on_retry=None, precheck=None, env_extra=None):
         """top = (k, [(result column, "asc" | "desc"), ...]): ORDER BY ... LIMIT k on the final K-F.
         deferred: the plan's last device call may be launched without being waited for (Engine.deferred_results): the result is
         then a DeferredResultSet that finishes the plan when it is first looked at.
@@ -2020,7 +2022,7 @@ class PreparedPlan:
         precheck: callable() run when the deferred result is collected, before anything is read (it may raise RetryPlan).
         on_retry: callable() -> result, what a deferred result does when the data decided against what was launched (instead of
         running the plan again here with every call waited for): the multi-GPU runner's collective re-run."""
-        env = {}
+        env = dict(env_extra) if env_extra else {}                  # (env_extra: hooks of the multi-GPU runner, "__group_fold__")
         if top is not None:
             env["__top__"] = (int(top[0]), [(str(n), str(d)) for n, d in top[1]])
             if any(d not in ("asc", "desc") for _, d in env["__top__"][1]):
@@ -2234,7 +2236,7 @@ def at_name(prepared, i):
     return prepared.steps[i][0]
 
 
-def prepared_plan(eng, plan, args, lane=None):
+def prepared_plan(eng, plan, args, lane=None, member_only=None):
     """The plan bound to this engine and these tables (prepared once, reused while the engine's columns are the same), on one of the
     engine's lanes: `lane`, or the one the plan was given when it first ran here (round robin over the engine's lanes)."""
     eng = getattr(eng, "_eng", eng)
@@ -2244,12 +2246,12 @@ def prepared_plan(eng, plan, args, lane=None):
         lane = lanes.get(id(eng))
         if lane is None or lane >= eng.nlanes:
             lane = lanes[id(eng)] = eng.next_lane()
-    key = (id(eng), lane) + tuple(id(a) for a in args)
+    key = (id(eng), lane) + tuple(id(a) for a in args) + ((frozenset(member_only),) if member_only is not None else ())
     prepared = cache.get(key)
     if prepared is None or prepared.generation != eng.generation or any(x is not y for x, y in zip(prepared.args, args)):
         if len(cache) > 16:
             cache.clear()
-        prepared = cache[key] = PreparedPlan(eng.lane(lane), plan, args)
+        prepared = cache[key] = PreparedPlan(eng.lane(lane), plan, args, member_only=member_only)
     return prepared
 
 

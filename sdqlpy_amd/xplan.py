@@ -492,6 +492,28 @@ def _decode_radix(keys, parts, radix):
     return out
 
 
+def _encoding_fingerprint(parts, radix):
+    """What a packed group key MEANS, as a digest: the packing (per part its offset and span) and every decoder's contents.  Ranks whose
+    digests are equal may fold their partial groups by packed key on the device (dist.DistributedRunner); a decoder that is a table's own
+    text column (row references: large, and local to a rank's shard) gives None — such keys are merged by their decoded values on the
+    host."""
+    import hashlib
+    h = hashlib.sha1(repr([(int(lo), None if span is None else int(span)) for lo, span in radix]).encode())
+    for _, vs, kind in parts:
+        h.update(("%s/%d;" % (kind[0], len(vs))).encode())
+        if kind[0] == "chars":
+            continue
+        dec = kind[1]
+        if dec is None:
+            continue
+        arr = dec if isinstance(dec, np.ndarray) else None
+        if arr is None or len(arr) > (1 << 16):
+            return None
+        a = np.ascontiguousarray(arr)
+        h.update(a.dtype.str.encode()); h.update(a.view(np.uint8).tobytes())
+    return h.hexdigest()
+
+
 def _is_light(c):
     """A comparison between numeric columns / numbers: evaluable on streamed registers."""
     return isinstance(c, Cmp) and all(isinstance(x, (Col, Const)) and not (isinstance(x, Const) and isinstance(x.value, (str, type(None)))) for x in (c.left, c.right))
@@ -739,6 +761,7 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False, sm
         kid, radix = c.pack_radix(parts)
         vals, count_idx = summed_values(c, vexprs)
         c.P.gates, c.P.key, c.P.vals = gates, kid, vals
+        state["encoding_fp"] = _encoding_fingerprint(parts, radix)
         return c, parts, radix, count_idx
 
     def compile_large(env):
@@ -807,6 +830,7 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False, sm
         if any(kind[0] == "int" and kind[1] is not None for _, _, kind in parts):
             from .engine import _merge_equal_keys
             d = _merge_equal_keys(d)                          # two references may decode to the same text
+        d.encoding_fp = state.get("encoding_fp")              # (the multi-GPU runner: may the ranks' partial groups be folded by packed key?)
         return d
 
     def dense_domain(st):
@@ -864,7 +888,17 @@ def prepare_scan(eng, op, htab, accumulate_into, member_only, as_table=False, sm
                     st = state["c"] = compile_groups(env)
                 c, parts, radix, count_idx = st
                 c.bind(env)
-                if op.out in env.get("__defer__", ()) and not isinstance(htab, DictTable):
+                fold = env.get("__group_fold__")
+                if fold is not None and not isinstance(htab, DictTable):
+                    # a row shard of a multi-GPU run: this rank's partial groups into the collective's buffer, the ranks' blocks folded
+                    # on the device behind ONE all-gather (dist.DistributedRunner gives the exchange, for the plan's last loop and where
+                    # it has checked that the packed keys mean the same on every rank: the digest is the one it compared).  No exchange:
+                    # the loop is waited for and its groups merged on the host by their decoded values.
+                    exchange = fold(op.out, state.get("encoding_fp"))
+                    if exchange is not None:
+                        collect = ctx.xgroupby_folded(htab.nrows, c.P, exchange)
+                        return Pending(lambda: groups_result(c, parts, radix, count_idx, *collect()))
+                elif op.out in env.get("__defer__", ()) and not isinstance(htab, DictTable):
                     # the plan's last device call: launched, not waited for (engine.PreparedPlan.run finishes the plan when the
                     # result is first looked at; what the data decides — too many groups — is raised there and the plan re-run)
                     collect = ctx.xgroupby_async(htab.nrows, c.P)

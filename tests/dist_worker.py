@@ -59,6 +59,14 @@ def main(rank, world, port, sf, mode, out_path):
         r = runner.run(q, db)
         out[q] = {"columns": r.columns, "rows": r.rows()}
     out["q14"] = runner.run("q14", db)
+    # second (and third) runs: chains that a first run has measured move fixed-capacity chunks and fold their groups behind one
+    # all-gather (dist._chain_device_sized) — the same rows
+    fast0, out["again"] = runner.fast_runs, {}
+    for again in range(2):
+        for q in ("q1", "q5", "q9", "q4"):
+            r = runner.run(q, db)
+            out["again"]["%s/%d" % (q, again)] = {"columns": r.columns, "rows": r.rows(), "seams": dict(runner.last_chain or {})}
+    out["chain_fast_runs"], out["chain_fast_retries"] = runner.fast_runs - fast0, runner.fast_retries
     r3 = runner.run("q3", db)
     out["q3"] = {"columns": r3.columns, "rows": runner.gather_rows(r3), "local_rows": r3.size(),
                  "partitioning": runner.last_partitioning, "exchanged": runner.exchanged_rows}

@@ -22,11 +22,11 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_world(mode, tmp_path, world=2):
+def run_world(mode, tmp_path, world=2, env=None):
     port = free_port()
     out = str(tmp_path / ("dist_%s.json" % mode))
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r), str(world), str(port), str(SF), mode, out],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, **(env or {}))) for r in range(world)]
     logs = [p.communicate(timeout=300)[0] for p in procs]
     for p, log in zip(procs, logs):
         assert p.returncode == 0, log[-3000:]
@@ -61,6 +61,11 @@ def test_two_ranks_match_single_process(mode, tmp_path, single, oracle_lib):
     for q in ("q5", "q9", "q4"):
         helpers.assert_rows_match(sorted(as_rows(got[q]["rows"])), helpers.result_rows(single[q], got[q]["columns"]), 1e-12, mode + "/" + q)
     assert abs(got["q14"] - single["q14"]) <= 1e-12 * abs(single["q14"])
+    # the settled chains (device-sized replication, groups folded behind one all-gather): the same rows, and they really took that path
+    for tag, res in got["again"].items():
+        q = tag.split("/")[0]
+        helpers.assert_rows_match(sorted(as_rows(res["rows"])), helpers.result_rows(single[q], res["columns"]), 1e-12, mode + "/again/" + tag)
+    assert got["chain_fast_runs"] >= 6 and got["chain_fast_retries"] == 0, (got["chain_fast_runs"], got["chain_fast_retries"])
     w3 = single["q3"]
     helpers.assert_rows_match(sorted(as_rows(got["q3"]["rows"])), helpers.result_rows(w3, got["q3"]["columns"]), 1e-12, mode + "/q3")
     # ORDER BY ... LIMIT k: the same first rows, in the same order, as ordering the single-process result
@@ -111,6 +116,27 @@ def test_two_ranks_match_single_process(mode, tmp_path, single, oracle_lib):
     assert got["q6_remarked"] == got["q6"]
     assert got["collectives"]["all_gather"][0] > 0
     assert (got["collectives"].get("all_to_all", [0])[0] > 0) == (mode != "range")        # co-clustered shards: nothing to exchange
+
+
+@pytest.mark.parametrize("mode,world", [("range", 2), ("range", 3)])
+def test_settled_chains_fold_their_groups_behind_one_all_gather(mode, world, tmp_path, single, oracle_lib):
+    """Round 6: with every loop a row program (as on the GPU) a settled chain's last group-by writes this rank's partial groups into
+    the send buffer of ONE all-gather and the ranks' blocks are folded by packed key on the device (sdqh_xgroupby_partial / _fold; here
+    the CPU implementation of the same calls), its replicated tables travel in fixed-capacity chunks (sdqh_table_partition_pack with
+    one part / sdqh_unpack_chunks) — nothing is read back between the first call and the result.  Same rows as one process; and the
+    seams say that this is the path that ran."""
+    got = run_world(mode, tmp_path, world=world, env={"SDQLPY_AMD_FORCE_PROGRAMS": "1"})
+    for tag, res in got["again"].items():
+        q = tag.split("/")[0]
+        helpers.assert_rows_match(sorted(as_rows(res["rows"])), helpers.result_rows(single[q], res["columns"]), 1e-12, "%s/programs/%s" % (mode, tag))
+        seams = res["seams"]
+        assert seams["plan"] == q, (tag, seams)
+        if q in ("q1", "q5", "q4"):
+            assert seams["folded"] and not seams["merged_on_host"], (tag, seams)
+        if q == "q5":
+            assert seams["replicated"] == ["asian_customers", "supplier_nations"], (tag, seams)
+    assert got["chain_fast_runs"] == 8 and got["chain_fast_retries"] == 0
+    helpers.assert_rows_match(sorted(as_rows(got["q3"]["rows"])), helpers.result_rows(single["q3"], got["q3"]["columns"]), 1e-12, mode + "/programs/q3")
 
 
 def test_four_ranks_match_single_process(tmp_path, single, oracle_lib):

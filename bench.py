@@ -58,6 +58,7 @@ def parse(argv=None):
     ap.add_argument("--partition", default="hash", choices=["auto", "range", "hash"], help="q3's partitioning in the timed step at N > 1")
     ap.add_argument("--cpu-sample-sf", type=float, default=0.0, help="0 = pick so the CPU leg takes ~10-30 s")
     ap.add_argument("--steady-steps", type=int, default=1500, help="steps of a second, longer leg after the timed region (reported as `steady_state`, not part of `value`); 0 = none")
+    ap.add_argument("--no-scan-form", action="store_true", help="skip the leg that re-runs the step with every loop streaming every row (no driven walk, no clustered pack, no delta twins)")
     ap.add_argument("--no-reference-width", action="store_true", help="skip the leg that re-runs q1/q3/q6 on the reference's 8-byte columns (twins and codes off)")
     return ap.parse_args(argv)
 
@@ -252,14 +253,36 @@ def main(argv=None, hooks=None):
     # first pass uploads the columns (pinned-staged H2D) — the PCIe-inclusive number
     barrier()
     t0 = time.time()
-    first_run_ms = {}
-    for q in queries:
+    first_run_ms, first_run_detail = {}, {}
+
+    def first_run(q):
+        """A query's first run, every launch of it between HIP events: what it pays and later runs do not — pinned-staged H2D of the
+        columns no earlier query uploaded, narrow / byte twins, dictionaries, delta twins, run indexes, row packs (in row order or
+        clustered), min / max and ordering facts, plan lowering, hiprtc — and the HBM it leaves resident beside the columns."""
+        def in_use():
+            if device != "cuda":
+                return 0
+            free_b, total_b = torch.cuda.mem_get_info(local_rank)
+            return total_b - free_b
+        use0, res0 = in_use(), int(eng.resident_bytes)
+        prof = device == "cuda" and not use_dist
+        if prof:
+            eng.ctx.set_profiling(2, only=None)
         tq = time.perf_counter()
-        run_query(q)
+        r = run_query(q)
+        r.wait() if hasattr(r, "wait") else None
         eng.ctx.synchronize()
-        # everything a query's first run pays and later runs do not: pinned-staged H2D of the columns no earlier query
-        # uploaded, narrow / byte twins, dictionaries, row packs, min / max and ordering facts, plan lowering, hiprtc
         first_run_ms[q] = round((time.perf_counter() - tq) * 1e3, 2)
+        launches = eng.ctx.profile() if prof else []
+        if prof:
+            eng.ctx.set_profiling(0)
+        per = {}
+        for name, ms in launches:
+            per[name] = per.get(name, 0.0) + ms
+        first_run_detail[q] = {"kernels_ms": per, "hbm_added": in_use() - use0, "columns_added": int(eng.resident_bytes) - res0}
+
+    for q in queries:
+        first_run(q)
     barrier()
     first_pass_s = time.time() - t0
     uploaded_bytes = int(eng.resident_bytes)              # host columns copied to HBM by that pass (pinned-staged H2D)
@@ -407,10 +430,7 @@ def main(argv=None, hooks=None):
     extra_ms, extra_log, extra_steps = {}, [], max(1, min(args.steps, 10))
     if extra:
         for q in extra:                                   # upload + warm-up, then the same protocol per query
-            tq = time.perf_counter()
-            run_query(q)
-            eng.ctx.synchronize()
-            first_run_ms[q] = round((time.perf_counter() - tq) * 1e3, 2)
+            first_run(q)
             for _ in range(args.warmup):
                 run_query(q)
         run_steps(3, "-", extra, each_waited_for=True)       # (untimed: plans settle / are recorded here)
@@ -434,6 +454,9 @@ def main(argv=None, hooks=None):
     reference_width = None
     if world == 1 and not use_dist and "engine" not in hooks and not args.no_reference_width:
         reference_width = reference_width_leg(args, eng, db, rows, queries + extra, run_query, run_steps, finish)
+    scan_form = None
+    if world == 1 and not use_dist and "engine" not in hooks and not args.no_scan_form:
+        scan_form = scan_form_leg(args, eng, queries + extra, run_query, run_steps, finish)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -482,7 +505,7 @@ def main(argv=None, hooks=None):
             phys_gbs = bytes_used / (ms * 1e-3) / 1e9 if bytes_used else None
             return {"bound": "hbm", "kernel": q + ":" + kernel, "achieved": round(phys_gbs, 1) if phys_gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(phys_gbs / HBM_PEAK_GBS, 4) if phys_gbs else None, "frac_source": frac_source,
-                    "traffic": traffic, "traffic_source": traffic_source,
+                    "traffic": traffic, "traffic_source": traffic_source, "traffic_stale": ("STALE" in traffic_source) if traffic_source else None,
                     "traffic_model": traffic_model, "traffic_model_over_pmc": round(traffic_model / traffic, 4) if traffic and traffic_model else None,
                     "frac_model": round(traffic_model / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic_model else None,
                     "achieved_algorithmic": round(achieved, 1), "frac_algorithmic": round(achieved / HBM_PEAK_GBS, 4),
@@ -534,6 +557,8 @@ def main(argv=None, hooks=None):
                             "algorithmic_frac_kernels": round(ab / (device_ms[q] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if device_ms[q] else None,
                             "physical_frac_kernels": round(phys / (device_ms[q] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if phys and device_ms[q] else None,
                             "first_run_ms": first_run_ms.get(q),
+                            "built_once": built_once(q, first_run_detail.get(q), {name.split(":", 1)[1]: v["ms_per_step"] for name, v in kernels.items() if name.startswith(q + ":")},
+                                                     device_ms[q], scan_form),
                             # physical bytes moved beside the algorithmic figure
                             "physical_bytes": phys,
                             "physical_GBs_kernels": round(phys / (device_ms[q] * 1e-3) / 1e9, 1) if phys and device_ms[q] else None,
@@ -577,6 +602,8 @@ def main(argv=None, hooks=None):
             out["steady_state"] = steady
         if reference_width is not None:
             out["reference_width"] = reference_width
+        if scan_form is not None:
+            out["scan_form"] = scan_form
         try:
             c, d = eng.ctx.jit_stats()
             out["specialised_kernels"] = {"compiled_by_hiprtc_in_this_process": int(c), "loaded_from_jit_cache": int(d)}
@@ -605,6 +632,98 @@ def main(argv=None, hooks=None):
     return out
 
 
+# The options that make a loop a SCAN of its table's columns again (what the reference's loops are, and what `cpu_baseline` runs): no walk
+# of a prebuilt run index instead of the column ("x_driven"), no row pack clustered by the first lookup's key ("cluster_pack"), no delta
+# twin ("delta8").  Everything else about the timed step stays (twins, codes, row packs in row order).
+SCAN_FORM_OPTIONS = {"x_driven": 0, "cluster_pack": 0, "delta8": 0}
+SCAN_FORM_DEFAULTS = {"x_driven": 64, "cluster_pack": 1, "delta8": 1}
+# ... and the reference-width leg on top of that: every numeric column streamed in the reference's own 8-byte form, gathered columns read
+# where they lie (no row pack), loops on the fixed-shape kernels
+REFERENCE_WIDTH_OPTIONS = dict(SCAN_FORM_OPTIONS, narrow=0, row_pack=0)
+REFERENCE_WIDTH_DEFAULTS = dict(SCAN_FORM_DEFAULTS, narrow=1, row_pack=1)
+
+
+def set_reference_width(eng, on):
+    """Switch an engine to / from the reference-width configuration (bench.py `reference_width`, tools/run_queries.py --reference-width:
+    the counter passes must run what the leg runs).  Returns what `on=False` needs to restore the routes."""
+    for k, v in (REFERENCE_WIDTH_OPTIONS if on else REFERENCE_WIDTH_DEFAULTS).items():
+        eng.ctx.set_option(k, v)
+    if on:
+        saved = (eng.stream_programs, eng.program_routes)
+        eng.stream_programs, eng.program_routes = False, set()
+        return saved
+
+
+def source_digest():
+    """sha256 (16 hex digits) over the sources that decide what a kernel moves: csrc/*.hip, *.hpp and the planner's *.py.  The committed
+    PMC collections carry the digest of the tree they were counted on; a run on other sources says `stale: true` beside the bytes it
+    quotes from them (the GPU box has no .git to ask for a commit distance)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    pkg = os.path.join(ROOT, "sdqlpy_amd")
+    for path in sorted(glob.glob(os.path.join(pkg, "csrc", "*.hip")) + glob.glob(os.path.join(pkg, "csrc", "*.hpp")) + glob.glob(os.path.join(pkg, "*.py"))):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+WALK_STRUCTURES = ("k_run_index", "k_interleave", "k_rs_", "k_lower_bounds", "k_delta8")      # what the scan form does without: run indexes, clustered packs, delta twins
+
+
+def built_once(q, detail, steady_kernels_ms, steady_ms, scan_form):
+    """What a query's FIRST run built and later runs reuse (round-5 review: "built_once_ms / built_once_bytes and the number of runs that
+    repay them"): device time of the first run's launches beyond a steady run's; of that, the structures only the timed step's walks and
+    delta-twin streams need (WALK_STRUCTURES: the scan form runs without them); HBM left resident beside the columns; and how many runs
+    repay the walk structures, priced at what a run saves over the scan form (kernels, one query at a time)."""
+    if not detail or not detail.get("kernels_ms"):
+        return None
+    first = detail["kernels_ms"]
+    walk = {k: round(v, 4) for k, v in first.items() if k.startswith(WALK_STRUCTURES)}
+    rec = {"first_run_kernels_ms": round(sum(first.values()), 3), "steady_run_kernels_ms": round(steady_ms, 4),
+           "built_once_ms": round(max(0.0, sum(first.values()) - steady_ms), 3),
+           "built_once_bytes": max(0, int(detail["hbm_added"]) - int(detail["columns_added"])),
+           "built_once_bytes_what": "HBM the process holds more after the first run than before, minus the columns uploaded at the reference's widths: twins, codes, "
+                                    "dictionaries, delta twins, run indexes, row packs, pooled table memory",
+           "walk_structures_ms": walk or None}
+    if scan_form and q in scan_form.get("ms_per_query", {}):
+        saved = scan_form["ms_per_query"][q]["ms_kernels"] - steady_ms
+        rec["scan_form_kernels_ms"] = scan_form["ms_per_query"][q]["ms_kernels"]
+        rec["saved_per_run_ms"] = round(saved, 4)
+        if walk:
+            rec["runs_to_repay_walk_structures"] = int(-(-sum(walk.values()) // saved)) if saved > 1e-4 else None
+    return rec
+
+
+def scan_form_leg(args, eng, queries, run_query, run_steps, finish):
+    """Identical work beside `value` (round-5 review): the timed step's final loops of Q5 / Q9 WALK resident orders of the data (a run index
+    of l_orderkey, a row pack clustered by l_partkey) and Q3's loops stream l_orderkey / o_orderkey through delta twins; the CPU baseline
+    rescans its columns every run.  This leg switches those three off (SCAN_FORM_OPTIONS): every loop streams every row of its table
+    again, still through the exact narrow encodings.  Outside `value`."""
+    for k, v in SCAN_FORM_OPTIONS.items():
+        eng.ctx.set_option(k, v)
+    try:
+        eng.clear()
+        for _ in range(3):
+            for q in queries:
+                finish(run_query(q))
+        n = max(1, min(args.steps, 10))
+        run_steps(3, "-", queries)
+        took, _, _ = run_steps(n, "-", queries)
+        run_steps(3, "-", queries, each_waited_for=True)
+        took_w, per_q, _ = run_steps(n, "-", queries, each_waited_for=True)
+        _, _, log = run_steps(n, None, queries, each_waited_for=True)
+        kernels_ms = {q: round(sum(ms for qq, _, ms, _ in log if qq == q) / n, 4) for q in queries}
+        return {"options": dict(SCAN_FORM_OPTIONS), "ms_per_step": round(took / n * 1e3, 4), "ms_per_step_each_query_waited_for": round(took_w / n * 1e3, 4),
+                "ms_per_query": {q: {"ms_wall": round(per_q[q] / n, 4), "ms_kernels": kernels_ms[q]} for q in queries},
+                "what": "the same step with every loop streaming every row of its table (no driven walk, no clustered pack, no delta twins); outside `value`"}
+    finally:
+        for k, v in SCAN_FORM_DEFAULTS.items():
+            eng.ctx.set_option(k, v)
+        eng.clear()
+
+
 def reference_width_leg(args, eng, db, rows, ran, run_query, run_steps, finish):
     """"the headline fraction stays on the algorithmic figure so CPU and GPU are compared on identical work".  The
     timed step streams exact narrow encodings of the columns (4-byte twins, 1- / 2-byte dictionary codes), so algorithmic bytes
@@ -613,14 +732,13 @@ def reference_width_leg(args, eng, db, rows, ran, run_query, run_steps, finish):
     dictionary codes, 8 bytes instead of 4 per code unit), drops everything resident, uploads again and times q1 / q3 / q6 with the
     protocol of the timed region.  frac = algorithmic bytes of the dominant kernel / its average launch time / 8 TB/s: at most 1,
     and the figure that is comparable with `cpu_baseline` (which reads the same 8-byte columns).  Outside `value`."""
-    qs = [q for q in ("q1", "q3", "q6") if q in ran]
+    qs = [q for q in ("q1", "q3", "q6", "q5", "q9") if q in ran]
     if not qs:
         return None
-    out = {"option": "narrow=0 (no 4-byte twins, no dictionary codes of numeric columns); loops on the fixed-shape kernels, which are the ones "
-                     "tuned for 8-byte columns (two rows per lane: k_groupby_reg, k_scan_sum, k_stage, k_probe_agg)", "queries": {}}
-    eng.ctx.set_option("narrow", 0)
-    saved = (eng.stream_programs, eng.program_routes)
-    eng.stream_programs, eng.program_routes = False, set()
+    out = {"option": "narrow=0 (no 4-byte twins, no dictionary codes of numeric columns), row_pack=0 (gathered columns read where they lie), no driven walk / "
+                     "clustered pack / delta twins; loops on the fixed-shape kernels, which are the ones tuned for 8-byte columns (two rows per lane: "
+                     "k_groupby_reg, k_scan_sum, k_stage, k_probe_agg, k_build_lookup, k_lookup_agg)", "queries": {}}
+    saved = set_reference_width(eng, True)
     try:
         eng.clear()
         # the pinned-staged upload alone (g1): lineitem's columns, nothing else running, no plan lowering, no twins
@@ -662,6 +780,10 @@ def reference_width_leg(args, eng, db, rows, ran, run_query, run_steps, finish):
                 # (`if l_shipdate > d: if contains(l_orderkey): ... ep * (1.0 - disc)`) — so what every row costs the
                 # kernel is the two tested columns: 16 bytes
                 ab_dom = 16 * rows["lineitem"]
+            elif q == "q5":
+                ab_dom = 8 * rows["lineitem"]                 # (the same short circuit: l_orderkey on every row, the rest where the order passed — test_all.py:266-277)
+            elif q == "q9":
+                ab_dom = 16 * rows["lineitem"]                # (l_partkey, l_suppkey on every row, the other four columns where the part is green — test_all.py:474-487)
             rec = {"ms_wall": round(per_q[q] / n, 4), "ms_kernels": round(ms_kernels, 4), "algorithmic_bytes": ab_q,
                    "frac_kernels": round(ab_q / (ms_kernels * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                    "dominant_kernel": dom, "dominant_avg_launch_ms": round(dom_ms, 4), "dominant_algorithmic_bytes": ab_dom,
@@ -683,7 +805,7 @@ def reference_width_leg(args, eng, db, rows, ran, run_query, run_steps, finish):
                 rec["traffic_over_algorithmic"] = round(t_run / ab_q, 4)
             out["queries"][q] = rec
     finally:
-        eng.ctx.set_option("narrow", 1)
+        set_reference_width(eng, False)
         eng.stream_programs, eng.program_routes = saved
         eng.clear()
     return out
@@ -708,7 +830,9 @@ def pmc_traffic(q, kernel, rows, ran=None, which="pmc_traffic"):
     entry = rec.get("queries", {}).get(q)
     if not entry or any(rec.get("rows", {}).get(t) != rows.get(t) for t in entry.get("tables", ["lineitem"])):
         return None, None
-    source = "committed rocprofv3 PMC run (profiles/%s%s), not this run" % (os.path.basename(path), ", collected at commit %s" % rec["commit"] if rec.get("commit") else "")
+    stale = rec.get("source_digest") != source_digest()      # counted on other kernel / planner sources than the ones running now?
+    source = "committed rocprofv3 PMC run (profiles/%s%s), not this run%s" % (os.path.basename(path), ", collected at commit %s" % rec["commit"] if rec.get("commit") else "",
+                                                                             "; STALE: counted on other sources than this run's (source_digest %s, here %s)" % (rec.get("source_digest"), source_digest()) if stale else "; sources unchanged since")
     if ran is not None and not set(ran) <= set(entry.get("kernels", {})):
         return None, None                                 # this run launched kernels the committed collection never saw: other code, other bytes
     if kernel is None:

@@ -120,14 +120,20 @@ __global__ __launch_bounds__(TPB) void k_stage_part_pack(DevStage st, DevPartiti
 // segments' live counts, then every wave copies its segment to its place.  Deterministic, and what was in row order stays in row
 // order: the replica a receiver rebuilds from the ranks' chunks (rank after rank) sees the table's rows in the table's order.
 __global__ __launch_bounds__(TPB) void k_stage_pack_scan(DevStage st, unsigned long long* __restrict__ offs, int64_t* __restrict__ packed) {
+    // one workgroup, PS_PER segments per thread and turn (a stage has tens of thousands of segments for a 15 M row build: a turn per 256
+    // of them was 0.03 ms of barriers)
+    constexpr int PS_PER = 16;
     __shared__ unsigned long long s_scan[TPB];
     __shared__ unsigned long long s_base;
     if (threadIdx.x == 0) s_base = 0;
     __syncthreads();
-    for (int i0 = 0; i0 < st.nseg; i0 += TPB) {
-        const int i = i0 + (int)threadIdx.x;
-        const unsigned long long c = i < st.nseg ? st.seg_count[i] : 0u;
-        s_scan[threadIdx.x] = c;
+    for (int i0 = 0; i0 < st.nseg; i0 += TPB * PS_PER) {
+        const int first = i0 + (int)threadIdx.x * PS_PER;
+        uint32_t c[PS_PER];
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int j = 0; j < PS_PER; ++j) { c[j] = first + j < st.nseg ? st.seg_count[first + j] : 0u; mine += c[j]; }
+        s_scan[threadIdx.x] = mine;
         __syncthreads();
         for (int off = 1; off < TPB; off <<= 1) {
             const unsigned long long v = (int)threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0ull;
@@ -135,7 +141,9 @@ __global__ __launch_bounds__(TPB) void k_stage_pack_scan(DevStage st, unsigned l
             s_scan[threadIdx.x] += v;
             __syncthreads();
         }
-        if (i < st.nseg) offs[i] = s_base + s_scan[threadIdx.x] - c;
+        unsigned long long at = s_base + s_scan[threadIdx.x] - mine;
+#pragma unroll
+        for (int j = 0; j < PS_PER; ++j) { if (first + j < st.nseg) offs[first + j] = at; at += c[j]; }
         __syncthreads();
         if (threadIdx.x == 0) s_base += s_scan[TPB - 1];
         __syncthreads();

@@ -1544,7 +1544,9 @@ static int xgroupby_launch(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* pro
         rc = launch(ctx, fn, launch_label(SINK_GROUP_LANE, true, true), a, sa, nrows, g, (unsigned)((size_t)nslots * (size_t)(prog->nvals + 1 - (x.ival >= 0 ? 1 : 0)) * TPB * 8));
     } else {
         XGroup<1>::Args sa{r_keys, pacc, pcnt, r_flags};
-        ctx->next_model_bytes = model_stream_bytes(x, nrows, x.direct) + (int64_t)npart * 40;
+        // (a loop that may WALK — decided by its waves at run time from the looked-up table's own bitmap — streams nothing when it does, and what it
+        //  gathers instead only the data says: no model, rather than the stream's bytes quoted for a kernel that does not stream)
+        ctx->next_model_bytes = x.driven ? 0 : model_stream_bytes(x, nrows, x.direct) + (int64_t)npart * 40;
         rc = launch(ctx, fn, launch_label(SINK_GROUP, x.direct, x.tight), a, sa, nrows, g);
     }
     if (!rc) {

@@ -24,7 +24,7 @@ for q in q1 q3 q5 q6 q9; do
   done
 done
 # the reference-width leg (bench.py `reference_width`: 8-byte columns, fixed-shape kernels): what its kernels really move
-for q in q1 q3 q6; do
+for q in q1 q3 q6 q5 q9; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_refwidth/${q}_$c -- python3 tools/run_queries.py --sf 10 --queries $q --iters $ITERS --reference-width > $OUT/pmc_refwidth_${q}_$c.log 2>&1
   done

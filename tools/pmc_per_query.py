@@ -57,6 +57,9 @@ def main(root, iters, rows_json, out):
            "rows": json.loads(rows_json), "queries": {},
            # which build the counters were collected on (the box has no .git: the caller passes the commit in the environment)
            "commit": os.environ.get("SDQLPY_COMMIT", "")}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    rec["source_digest"] = bench.source_digest()      # the sources the counters were collected on: bench.py says `STALE` when it runs on others
     for q in sorted(TABLES):
         fd, wd = os.path.join(root, q + "_FETCH_SIZE"), os.path.join(root, q + "_WRITE_SIZE")
         if not (os.path.isdir(fd) and os.path.isdir(wd)):

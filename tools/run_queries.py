@@ -23,9 +23,8 @@ def main():
     from sdqlpy_amd.sdql_lib import sdqlpy_init
     sdqlpy_init(3, 1, device=0)
     if args.reference_width:
-        eng = engine.default_engine(device=0)
-        eng.ctx.set_option("narrow", 0)
-        eng.stream_programs, eng.program_routes = False, set()
+        import bench
+        bench.set_reference_width(engine.default_engine(device=0), True)      # (exactly what bench.py's leg runs)
     db = tpch.generate(args.sf, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))
     for _ in range(args.iters):
         for q in qs:

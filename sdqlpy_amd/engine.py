@@ -1783,6 +1783,23 @@ def _prepare_dict_loop(eng, op, is_result, as_table):
 
     def run(env):
         why = "no device loop for this sum over a result dictionary"
+        made = None
+        if state["dev"] is not None and isinstance(env.get(op.source), DictResult):
+            # the source is a handful of groups the small group-by kernels delivered to the host (Q8's two volume groups): made resident
+            # again — a table keyed by the group key with the sums as its accumulators, what a large group-by would have left — so that
+            # the walk is the same device loop over a table's K-F columns as for every other source (round-5 review: the last host loop)
+            made = _resident_groups(eng, env[op.source], op)
+            if made is not None:
+                env = dict(env)
+                env[op.source + "$resident"] = made
+                env[op.source] = ("aggregated", op.source + "$resident")
+        try:
+            return run_on(env, why)
+        finally:
+            if made is not None:
+                made.table.free()
+
+    def run_on(env, why):
         if state["dev"] is not None:
             try:
                 out = state["dev"](env)
@@ -1806,6 +1823,40 @@ def _prepare_dict_loop(eng, op, is_result, as_table):
                                    % (getattr(op, "lineno", 0), getattr(op, "source", op.out), why))
         return _host_dict(eng, op, env, is_result)
     return run
+
+
+def _resident_groups(eng, d, op):
+    """A host DictResult of a few groups — one integer key field, float sums — as an aggregated device table (BuiltTable with .agg), or
+    None when it has another shape (text / composite keys, counts: the host evaluation stays)."""
+    if len(d.key_fields) != 1 or not d.val_fields or d.size() == 0 or d.size() > abi.MAX_LOOKUP_GROUPS:
+        return None
+    kname, karr = d.key_fields[0]
+    karr = np.asarray(karr)
+    if karr.dtype.kind != "i" or any(np.asarray(a).dtype.kind != "f" for _, a in d.val_fields) or len(d.val_fields) > abi.TUPLE_MAX_VALUES:
+        return None
+    ctx = eng.ctx
+    keys = np.ascontiguousarray(karr, np.int64)
+    n = len(keys)
+    kcol = ctx.upload(keys)
+    vcols = [ctx.upload(np.ascontiguousarray(a, np.float64)) for _, a in d.val_fields]
+    build = abi.Program()
+    build.key = build.op(abi.X_COL, abi.T_I64, col=kcol)
+    try:
+        table = ctx.xbuild(n, build, int(keys.min()), int(keys.max()), accumulate=True, nsums=len(vcols))
+        add = abi.Program()
+        k = add.op(abi.X_COL, abi.T_I64, col=kcol)
+        look = add.op(abi.X_LOOKUP, abi.T_BOOL, a=k, table=table)
+        add.gates = [look]
+        add.vals = [add.op(abi.X_COL, abi.T_F64, col=c) for c in vcols]
+        ctx.xprobe_aggregate(n, add, look, table)
+    except abi.SdqhError as exc:
+        if exc.code != abi.ERR_UNSUPPORTED:
+            raise
+        return None
+    bt = BuiltTable(table, kname, d.key_is_record, [], d.val_is_record, [])
+    bt.agg = ([(kname, "key")], [nm for nm, _ in d.val_fields], None, d.key_is_record, d.val_is_record, len(vcols))
+    bt._keep = [kcol] + vcols
+    return bt
 
 
 def _record_set(eng, op, bt, env):

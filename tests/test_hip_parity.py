@@ -112,6 +112,19 @@ def test_sf1_goldens_with_the_size_dependent_paths_on_and_off(hip_engine, golden
             hip_engine.clear()
 
 
+def test_every_query_runs_with_the_host_loops_refused(hip_lib, golden_sf1):
+    """Round 6: all 21 queries under Engine.strict_device (no numpy loop over a result dictionary on the product path: such a loop
+    raises) — Q8's two-row share was the last one — at SF=1, against the REFERENCE's results.  (At the small goldens' sizes a handful
+    of groups comes back to the host and is walked there; that is counted and refusable, not silent: Engine.stats().)"""
+    eng = engine.Engine(hip_lib.context(device=0))
+    eng.strict_device = True
+    try:
+        assert helpers.check_all_goldens(eng, [golden_sf1], REL, REL, "hip/strict") == 23
+        assert eng.stats()["host_loops"] == []
+    finally:
+        eng.close()
+
+
 def test_decorated_queries_through_public_api(golden, golden_more, golden_wide):
     """The user-facing route: sdqlpy_init(3) + @sdql_compile functions.  The decorator keeps a query's plan, so the second
     and third run of a query on the same tables take the cached paths (prepared plan, marshalled calls per layout

@@ -161,11 +161,16 @@ def test_oracle_reproduces_reference_at_sf1(oracle_lib, golden_sf1):
     engage, which were checked against the oracle only (and the oracle shares the planner with the product: the round-5 Q2 error
     was wrong on both).  One thread sums in row order like the interpreter: doubles bit for bit (q10: another association, 1e-12)."""
     eng = engine.Engine(oracle_lib.context(threads=1))
+    # ... with the host loops refused (Engine.strict_device: a sum over a result dictionary that would run as a numpy loop on the host
+    # raises): at this size all 21 queries run that way — Q8's two-row share of its volume groups was the last host loop; its groups
+    # are made resident again (engine._resident_groups) and walked by the same device loop as every other dictionary
+    eng.strict_device = True
     try:
         names = {c["name"] for c in golden_sf1["cases"]}
         assert {"sf1", "sf01_big_keys", "sf1_big_keys"} <= names
         sf1 = next(c for c in golden_sf1["cases"] if c["name"] == "sf1")
         assert len(sf1["results"]) == 21 and sf1["rows"]["lineitem"] > 5_900_000
         assert helpers.check_all_goldens(eng, [golden_sf1], 0.0, 1e-12, "oracle/sf1") == 23
+        assert eng.stats()["host_loops"] == []
     finally:
         eng.close()

@@ -58,6 +58,7 @@ def parse(argv=None):
     ap.add_argument("--partition", default="hash", choices=["auto", "range", "hash"], help="q3's partitioning in the timed step at N > 1")
     ap.add_argument("--cpu-sample-sf", type=float, default=0.0, help="0 = pick so the CPU leg takes ~10-30 s")
     ap.add_argument("--steady-steps", type=int, default=1500, help="steps of a second, longer leg after the timed region (reported as `steady_state`, not part of `value`); 0 = none")
+    ap.add_argument("--no-hash-path", action="store_true", help="skip the leg that prices the open-addressing layouts (direct layouts off; Q3 on keys beyond 2^40 in shuffled rows)")
     ap.add_argument("--no-scan-form", action="store_true", help="skip the leg that re-runs the step with every loop streaming every row (no driven walk, no clustered pack, no delta twins)")
     ap.add_argument("--no-reference-width", action="store_true", help="skip the leg that re-runs q1/q3/q6 on the reference's 8-byte columns (twins and codes off)")
     return ap.parse_args(argv)
@@ -457,6 +458,9 @@ def main(argv=None, hooks=None):
     scan_form = None
     if world == 1 and not use_dist and "engine" not in hooks and not args.no_scan_form:
         scan_form = scan_form_leg(args, eng, queries, queries + extra, run_query, run_steps, finish)
+    hash_path = None
+    if world == 1 and not use_dist and "engine" not in hooks and not args.no_hash_path:
+        hash_path = hash_path_leg(args, eng, db, rows, queries + extra, run_steps, finish)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -604,6 +608,8 @@ def main(argv=None, hooks=None):
             out["reference_width"] = reference_width
         if scan_form is not None:
             out["scan_form"] = scan_form
+        if hash_path is not None:
+            out["hash_path"] = hash_path
         try:
             c, d = eng.ctx.jit_stats()
             out["specialised_kernels"] = {"compiled_by_hiprtc_in_this_process": int(c), "loaded_from_jit_cache": int(d)}
@@ -694,6 +700,93 @@ def built_once(q, detail, steady_kernels_ms, steady_ms, scan_form):
         if walk:
             rec["runs_to_repay_walk_structures"] = int(-(-sum(walk.values()) // saved)) if saved > 1e-4 else None
     return rec
+
+
+HASH_LAYOUT_OPTIONS = {"direct_index": 0, "row_index": 0, "grouped_index": 0}      # every built table an open-addressing table (+ its hashed filter)
+
+
+def hash_path_leg(args, eng, db, rows, ran, run_steps, finish):
+    """north_star's own data structure — the open-addressing table — priced beside the direct layouts the timed step uses (round-5 review):
+    (1) `hash_layouts`: the same queries with the direct layouts off (HASH_LAYOUT_OPTIONS): every build an open-addressing table (64-bit CAS
+    insert, packed 32-byte slots) behind a hashed filter that the loops test on streamed registers; (2) `unordered_keys`: Q3 on the same
+    data with every orders / customer key moved beyond 2^40 and the rows of orders and lineitem shuffled — no dense key range, no storage
+    order: the data itself leaves nothing but the hash path — checked against the timed step's Q3 rows (same groups, keys shifted back).
+    Outside `value`."""
+    import numpy as np
+    from sdqlpy_amd import tpch
+    from sdqlpy_amd import tpch_queries as Q
+    qs = [q for q in ("q3", "q5", "q9") if q in ran]
+    out = {}
+    n = max(1, min(args.steps, 10))
+
+    def timed(queries, run):
+        for _ in range(3):
+            for q in queries:
+                finish(run(q))
+        took, per_q, _ = run_steps(n, "-", queries, run, each_waited_for=True)
+        _, _, log = run_steps(n, None, queries, run, each_waited_for=True)
+        res = {}
+        for q in queries:
+            per = {}
+            for qq, name, ms, _ in log:
+                if qq == q:
+                    per[name] = per.get(name, 0.0) + ms / n
+            res[q] = {"ms_wall": round(per_q[q] / n, 4), "ms_kernels": round(sum(per.values()), 4), "kernels_ms": {k: round(v, 4) for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:6]}}
+        return res
+
+    want3 = finish(Q.run("q3", db)) if "q3" in qs else None
+    for k, v in HASH_LAYOUT_OPTIONS.items():
+        eng.ctx.set_option(k, v)
+    try:
+        eng.clear()
+        out["hash_layouts"] = {"options": dict(HASH_LAYOUT_OPTIONS), "queries": timed(qs, lambda q: Q.run(q, db))}
+        if want3 is not None:
+            got = finish(Q.run("q3", db))
+            cmp = compare_results(got, want3)
+            out["hash_layouts"]["q3_rows_equal_direct_layouts"] = bool(cmp["rows_equal"]) and cmp["max_rel"] is not None and cmp["max_rel"] <= 1e-10
+    finally:
+        for k in HASH_LAYOUT_OPTIONS:
+            eng.ctx.set_option(k, 1)
+        eng.clear()
+    if want3 is not None:
+        # order keys spread over 2^46 (k * 1000003 + 2^40), customer keys over 2^35 + ..., the rows of orders and lineitem in random order: no
+        # dense range for a bitmap, no storage order for a twin or a walk (tests/golden/make_golden.py's big_keys variant keeps the keys dense)
+        off_o, mul_o, off_c, mul_c = np.int64(1) << 40, np.int64(1000003), np.int64(1) << 35, np.int64(1009)
+        rng = np.random.default_rng(17)
+        need = tpch.columns_for(("q3",))
+
+        def remake(name, changes, shuffle):
+            c = db[name].getContainer()
+            keep = [h for h in c["headers"] if h in need[name]]
+            cols = {h: a for h, a in zip(c["headers"], c["data"]) if h in keep}
+            for col, fn in changes.items():
+                cols[col] = fn(cols[col])
+            if shuffle:
+                perm = rng.permutation(len(c["data"][0]))
+                cols = {h: (np.ascontiguousarray(a[perm]) if len(a) else a) for h, a in cols.items()}
+            return tpch.table_from_columns(keep, [cols[h] for h in keep])
+        t0 = time.perf_counter()
+        big = dict(db)
+        big["customer"] = remake("customer", {"c_custkey": lambda a: a * mul_c + off_c}, False)
+        big["orders"] = remake("orders", {"o_orderkey": lambda a: a * mul_o + off_o, "o_custkey": lambda a: a * mul_c + off_c}, True)
+        big["lineitem"] = remake("lineitem", {"l_orderkey": lambda a: a * mul_o + off_o}, True)
+        prep_s = time.perf_counter() - t0
+        try:
+            res = timed(["q3"], lambda q: Q.run(q, big))
+            got = finish(Q.run("q3", big))
+            same = got.size() == want3.size()
+            if same:
+                gk, wk = (np.asarray(got.column("l_orderkey")) - off_o) // mul_o, np.asarray(want3.column("l_orderkey"))
+                go, wo = np.argsort(gk, kind="stable"), np.argsort(wk, kind="stable")
+                gr, wr = np.asarray(got.column("revenue"))[go], np.asarray(want3.column("revenue"))[wo]
+                same = bool(np.array_equal(gk[go], wk[wo])) and bool(np.all(np.abs(gr - wr) <= 1e-10 * np.maximum(np.abs(wr), 1e-300)))
+            out["unordered_keys"] = {"what": "Q3 at the bench's size with the order keys spread over 2^46 (k * 1000003 + 2^40), the customer keys over 2^35 + k * 1009, the rows of orders and lineitem "
+                                             "shuffled: no dense key range, no storage order — open addressing (behind its hashed filter) is what is left", "q3": res["q3"], "rows": int(got.size()), "rows_equal_timed_step": bool(same),
+                                     "prepared_on_host_s": round(prep_s, 2)}
+        finally:
+            for t in ("customer", "orders", "lineitem"):
+                eng.invalidate(big[t])
+    return out
 
 
 def scan_form_leg(args, eng, step_queries, queries, run_query, run_steps, finish):

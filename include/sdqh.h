@@ -55,7 +55,7 @@ using __hip_internal::int32_t; using __hip_internal::uint32_t; using __hip_inter
 extern "C" {
 #endif
 
-#define SDQH_ABI_VERSION 5   /* 2: sdqh_filter carries column-vs-column predicates; string modes 3 / 4.  3: sdqh_table_share_groups.  4: row programs (sdqh_x*).  5: device-sized redistribution, plan graphs */
+#define SDQH_ABI_VERSION 6   /* 2: sdqh_filter carries column-vs-column predicates; string modes 3 / 4.  3: sdqh_table_share_groups.  4: row programs (sdqh_x*).  5: device-sized redistribution, plan graphs.  6: sdqh_xgroupby_partial / _fold */
 
 /* ---- status codes ---------------------------------------------------------------------- */
 #define SDQH_OK              0
@@ -205,7 +205,8 @@ void*       sdqh_stream(const sdqh_ctx* ctx);
  * index when (estimated keys of the table) x this <= rows of the loop; 0 = never, 1 = whenever the table holds fewer keys than rows),
  * "delta8" (1: queue programs stream a key column whose aligned 8-row groups span at most 255 through its delta twin, 12 bytes per 8 rows),
  * "word_pairs" (0: whole-table builds keyed by a strictly increasing column also keep { first row, bits } pairs per bitmap word);
- * round 6: "pool_trim" (an action, value 1: waits for the context's stream and returns the cached free blocks of its device-memory
+ * round 6: "hash_filter" (1: a hash-layout table carries a hashed filter — 8 to 16 bits per key, two bits of one word per key, L2-sized — that
+ * row programs test on streamed registers in front of the slots, as they test an exact key bitmap), "pool_trim" (an action, value 1: waits for the context's stream and returns the cached free blocks of its device-memory
  * pool to the runtime — a pool never shrinks by itself).
  * The CPU build accepts and ignores any name. */
 int         sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value);

@@ -12,7 +12,7 @@ import math
 import numpy as np
 
 MAX_SHARE_CELLS = 1 << 28  # SDQH_MAX_SHARE_CELLS
-ABI_VERSION = 5            # include/sdqh.h: SDQH_ABI_VERSION (struct layouts below must match the library's)
+ABI_VERSION = 6            # include/sdqh.h: SDQH_ABI_VERSION (struct layouts below must match the library's)
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_OVERFLOW, ERR_NOMEM = range(6)
 I64, F64, STR = 0, 1, 2
 TUPLE_A, TUPLE_AB, TUPLE_A_1MB, TUPLE_PRICING, TUPLE_A_1MB_M_CD, TUPLE_COUNT = 1, 2, 3, 4, 5, 6

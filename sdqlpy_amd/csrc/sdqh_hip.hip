@@ -729,6 +729,7 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "grouped_pairs" && (value == 0 || value == 1)) ctx->opt_grouped_pairs = (int)value;
     else if (n == "index_inline" && (value == 0 || value == 1)) ctx->opt_index_inline = (int)value;
     else if (n == "groupby_regs" && (value == 0 || value == 4 || value == 8)) ctx->opt_groupby_regs = (int)value;
+    else if (n == "hash_filter" && (value == 0 || value == 1)) ctx->opt_hash_filter = (int)value;
     else if (n == "pool_trim" && value == 1) {
         // give the cached FREE blocks of this context's pool back to the runtime (the pool never shrinks by itself: 288 GB make head-room
         // cheap — until the next workload needs the memory another context's pool is sitting on).  Waits for the stream first.
@@ -1184,7 +1185,16 @@ static int ensure_index(sdqh_ctx* ctx, sdqh_table* tb) {
         else { keys = static_cast<int64_t*>(table_alloc(ctx, tb, (tb->capmax + 2) * 8)); rowref = static_cast<uint32_t*>(table_alloc(ctx, tb, (tb->capmax + 2) * 4)); }
         if (packed ? !slots : (!keys || !rowref)) return fail(ctx, SDQH_ERR_NOMEM, "table index: out of device memory");
         tb->dev.keys = keys; tb->dev.rowref = rowref; tb->dev.slots = slots;
-        LAUNCH(ctx, "k_clear", k_clear, (unsigned)ctx->num_cu * 4, tb->stage.seg_count, tb->stage.nseg, tb->capmax, tb->hdr, keys, rowref, slots);
+        // the hashed filter in front of the slots (DevTable::hf): room for the largest capacity's filter, cleared and used at the size the
+        // capacity the device settles on gives it
+        uint32_t* hf = nullptr;
+        if (ctx->opt_hash_filter) {
+            const uint64_t bits = std::max<uint64_t>(std::min<uint64_t>(tb->capmax, HF_MAX_CAP) << HF_SHIFT, 1024);
+            hf = static_cast<uint32_t*>(table_alloc(ctx, tb, (size_t)(bits / 8) + 64));
+            if (!hf) (void)hipGetLastError();
+        }
+        tb->dev.hf = hf;
+        LAUNCH(ctx, "k_clear", k_clear, (unsigned)ctx->num_cu * 4, tb->stage.seg_count, tb->stage.nseg, tb->capmax, tb->hdr, keys, rowref, slots, hf);
         LAUNCH(ctx, "k_insert", k_insert, seg_grid, tb->stage, tb->dev);
         LAUNCH(ctx, "k_insert_fixup", k_insert_fixup, seg_grid, tb->stage, tb->dev);
         if (packed) LAUNCH(ctx, "k_insert_repack", k_insert_repack, seg_grid, tb->stage, tb->dev);

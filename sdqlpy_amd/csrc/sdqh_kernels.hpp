@@ -160,7 +160,23 @@ struct DevTable {
     // line where they were two (Q9's final loop fetches a 128-byte line per request: three per surviving row went to the orders table); bm and
     // wprefix stay what they are for everything that reads the bitmap alone.  Null: the table has no such copy.
     const unsigned long long* wpair;
+    // HASHED FILTER in front of the hash layout (round 6): a bitmap of (capacity << HF_SHIFT) bits — 8 to 16 per staged key, L2-sized where the
+    // slots are not — in which every key sets TWO bits of ONE word (hf_code below).  A loop tests it on streamed registers exactly like an
+    // exact key bitmap (x_queue8's prefilter) and sends only the keys that pass — the hits and a few per cent of the rest — to the slots.
+    // Sized with the capacity on the device (k_clear), filled by k_insert; null: none (direct / grouped layouts, option "hash_filter" 0).
+    uint32_t* hf;
 };
+constexpr int HF_SHIFT = 2;
+constexpr uint32_t HF_POS_MASK = 0x07FFFFFFu;                          // bit position: at most 2^27 bits (16 MB); the second bit's place in the word rides in the top five bits
+// A filter helps while it stays in an XCD's L2 (4 MB) and its build's atomics stay cheap: tables of more than HF_MAX_CAP slots get the DEGENERATE
+// filter — 128 bits, all set: every key passes, nothing is set per key (Q9's 15 M orders: 1.3 ms of scattered atomics for a 16 MB filter no L2 holds)
+constexpr uint64_t HF_MAX_CAP = 1ull << 22;
+constexpr uint32_t HF_DEGENERATE = 127u;
+__device__ __forceinline__ uint32_t hf_mask_of(uint64_t cap_mask) { return cap_mask + 1 > HF_MAX_CAP ? HF_DEGENERATE : (uint32_t)(((cap_mask + 1) << HF_SHIFT) - 1); }
+__device__ __forceinline__ uint32_t hf_raw(int64_t key);               // 32 hash bits of a key (defined behind mix64)
+__device__ __forceinline__ uint32_t hf_code(uint32_t raw, uint32_t mask) { return (raw & mask) | (raw & ~HF_POS_MASK); }
+__device__ __forceinline__ uint32_t hf_bits(uint32_t code) { return (1u << (code & 31u)) | (1u << (code >> 27)); }
+__device__ __forceinline__ bool hf_test(uint32_t word, uint32_t code) { return ((word >> (code & 31u)) & (word >> (code >> 27)) & 1u) != 0u; }
 
 // regions to set to a byte value each (k_fill; also the preamble of a build kernel that runs as ONE workgroup: see fill_in_block)
 constexpr int FILL_MAX = 6;
@@ -233,6 +249,7 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
 __device__ __forceinline__ uint32_t hash_key(int64_t k) {          // Fibonacci hashing, upper 32 bits
     return (uint32_t)(((uint64_t)k * 0x9E3779B97F4A7C15ull) >> 32);
 }
+__device__ __forceinline__ uint32_t hf_raw(int64_t key) { return (uint32_t)(mix64((uint64_t)key) >> 32); }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
@@ -1496,7 +1513,8 @@ __global__ __launch_bounds__(TPB) void k_stage(DevFilter f, DevProbes pr, DevSta
 // Every workgroup recomputes the staged total from the segment counts (a few KB from L2), so the
 // capacity is agreed on without a grid barrier; workgroup 0 publishes the header for later kernels.
 SDQH_KERNEL __launch_bounds__(TPB) void k_clear(const uint32_t* __restrict__ seg_count, int nseg, uint64_t capmax,
-                                               TableHeader* __restrict__ hdr, int64_t* __restrict__ keys, uint32_t* __restrict__ rowref, int64_t* __restrict__ slots) {
+                                               TableHeader* __restrict__ hdr, int64_t* __restrict__ keys, uint32_t* __restrict__ rowref, int64_t* __restrict__ slots,
+                                               uint32_t* __restrict__ hf) {
     __shared__ unsigned long long s_part[TPB];
     unsigned long long t = 0;
     for (int i = threadIdx.x; i < nseg; i += TPB) t += seg_count[i];
@@ -1511,6 +1529,15 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_clear(const uint32_t* __restrict__ seg
         hdr->cap_mask = cap - 1; hdr->staged = staged;
         if (slots) { slots[cap * 4] = EMPTY_KEY; slots[cap * 4 + 3] = (int64_t)NO_ROW; }
         else { keys[cap] = EMPTY_KEY; rowref[cap] = NO_ROW; }  // the extra slot that holds a real key == EMPTY_KEY
+    }
+    if (hf) {                                                  // the hashed filter's words (its size follows the capacity: hf_mask_of)
+        using W = uint32_t __attribute__((ext_vector_type(4)));
+        const uint32_t hm = hf_mask_of(cap - 1);
+        const uint64_t n16 = ((uint64_t)hm + 1) / 128;
+        const uint32_t z = hm == HF_DEGENERATE ? 0xFFFFFFFFu : 0u;
+        const W zero = {z, z, z, z};
+        W* h4 = reinterpret_cast<W*>(hf);
+        for (uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * TPB) h4[i] = zero;
     }
     using V = long long __attribute__((ext_vector_type(2)));
     if (slots) {                                               // packed: { EMPTY_KEY, 0 } { 0, NO_ROW } per slot, two 16-byte stores
@@ -1867,9 +1894,11 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_insert(DevStage st, DevTable t) {
     const uint64_t mask = t.hdr->cap_mask;
     const int64_t base = (int64_t)seg * st.seg_rows;
     const uint32_t count = st.seg_count[seg];
+    const uint32_t hmask = hf_mask_of(mask);
     for (uint32_t i = lane_id(); i < count; i += WAVE) {
         const int64_t idx = base + i;
         const int64_t key = st.key[idx];
+        if (t.hf && hmask != HF_DEGENERATE) { const uint32_t code = hf_code(hf_raw(key), hmask); atomicOr(&t.hf[(code & HF_POS_MASK) >> 5], hf_bits(code)); }      // (fire and forget: no value returns)
         if (key == EMPTY_KEY) {                                          // the sentinel value itself lives in the extra slot
             uint32_t* ref = t.slots ? reinterpret_cast<uint32_t*>(&t.slots[(mask + 1) * 4 + 3]) : &t.rowref[mask + 1];
             if (atomicMin(ref, (uint32_t)idx) != NO_ROW) t.hdr->has_dups = 1;

@@ -93,6 +93,7 @@ struct XInfo {
     int ival = -1;                           // the per-lane group sink: summed value that is a small integer on every row (byte-coded column, consecutive integral dictionary), or -1
     bool pnear = false;                      // ... and a lane's 8 consecutive rows carry near-by keys (column_span8): a row that fails an earlier condition still asks for ITS key's word
     bool pwin = false;                       // ... tested against one 128-bit window of the bitmap: one 16-byte request per lane and 8 rows (option "window", off: measured slower)
+    bool phash = false;                         // the prefilter's table is a hash layout with a hashed filter (DevTable::hf): its key is tested against that on streamed registers (x_queue8: P::PHASH)
     bool want_driven = false;                   // set by the caller whose sink can take the walk (the group sink): no other loop pays for a run index
     bool driven = false; int driven_col = -1;   // the driven walk of x_queue8 can be taken (order-free sinks): the prefilter's key column is stored in its own order and has a run index
     uint32_t gather32 = 0;                   // queue programs: numeric columns read BY ROW (the drain's gathers) through their 4-byte twins: half the bytes of every touched line
@@ -417,7 +418,7 @@ void tight_plan(sdqh_ctx* ctx, int64_t nrows, XInfo* x) {
     const sdqh_program* p = x->p;
     for (int k = 0; k < p->nops; ++k) x->cmp_cc[k] = x->cmp_kind[k] = x->cmp_col[k] = -1;
     for (int c = 0; c < SDQH_MAX_XCOLS; ++c) { x->enc[c] = ENC_RAW; x->dict_slot[c] = -1; }
-    x->tight = false; x->nd = 0; x->ncc = 0; x->gather32 = 0; x->pref32 = false; x->pnear = false; x->pwin = false; x->driven = false; x->driven_col = -1;
+    x->tight = false; x->nd = 0; x->ncc = 0; x->gather32 = 0; x->pref32 = false; x->pnear = false; x->pwin = false; x->driven = false; x->driven_col = -1; x->phash = false;
     // (a compile-only context has no columns to code; SDQLPY_AMD_FAKE_CODES makes it pretend every column is coded — 2 bytes where
     //  only compared, 1 byte where its value is used — so that build() proves on a host without a GPU that the generator's tight
     //  output compiles for gfx950)
@@ -508,6 +509,8 @@ void tight_plan(sdqh_ctx* ctx, int64_t nrows, XInfo* x) {
         const sdqh_table* t = x->tabs[x->tab_of[x->prefilter_op]];
         const bool applicable = t->dev.bm && t->dev.bm_shift == 0 && t->dev.lin_rb == 0;
         x->pref32 = applicable && x->irange[x->prefilter_part0] >= 1 && t->dev.bm_lo >= INT32_MIN && t->dev.bm_hi <= INT32_MAX && t->dev.bm_hi >= t->dev.bm_lo;
+        // a hash-layout table (keys far apart, in no order, or the direct layouts switched off): its hashed filter, whatever the key's width
+        x->phash = !x->pref32 && !t->dev.bm && t->dev.hf != nullptr && !t->bitmap_only;
     }
     if (fake && !regs_all && x->prefilter_op >= 0 && !x->prefilter_composite) x->pref32 = true;
     static const bool xdebug = std::getenv("SDQLPY_AMD_X_DEBUG") != nullptr;
@@ -1009,6 +1012,15 @@ std::string generate(const XInfo& x, Sink sink, bool direct) {
         } else g.os << "        widx = 0; bit = 0;\n";
         g.os << "        return p;\n";
         spre8 = g.os.str();
+        if (x.phash) {
+            // the hashed filter: 32 hash bits of the (64-bit) key; the skeleton cuts them to the filter's size and tests the key's two bits
+            g.reset(); g.mode = 3; g.os.str("");
+            g.os << "        bool p = true;\n";
+            for (int q = 0; q < x.nstream_gates; ++q) { g.emit(p->gates[q]); g.os << "        p = p & v" << p->gates[q] << ";\n"; }
+            g.emit(x.prefilter_part0);
+            g.os << "        off = p ? hf_raw((int64_t)v" << x.prefilter_part0 << ") : 0u;\n        return p;\n";
+            spre32 = g.os.str();
+        }
         if (x.pref32) {
             g.reset(); g.mode = 3; g.os.str("");
             g.os << "        bool p = true;\n";
@@ -1055,9 +1067,14 @@ std::string generate(const XInfo& x, Sink sink, bool direct) {
         out << "    }\n";
         out << "    __device__ __forceinline__ static bool stest(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i) {\n" << stest8 << "    }\n";
         out << "    __device__ __forceinline__ static bool spre(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i, uint32_t& widx, uint32_t& bit) {\n" << spre8 << "    }\n";
-        out << "    static constexpr bool PREF32 = " << (x.pref32 ? "true" : "false") << ", PWIN = " << (x.pwin ? "true" : "false") << ";\n";
+        out << "    static constexpr bool PREF32 = " << ((x.pref32 || x.phash) ? "true" : "false") << ", PWIN = " << (x.pwin ? "true" : "false") << ";\n";
         out << "    __device__ __forceinline__ static bool spre32(const XArgs& a, const Regs& s, const int64_t (*tab)[256], const int i, uint32_t& off) {\n"
-            << (x.pref32 ? spre32 : std::string("        off = 0; return false;\n")) << "    }\n";
+            << ((x.pref32 || x.phash) ? spre32 : std::string("        off = 0; return false;\n")) << "    }\n";
+        if (x.phash) {
+            out << "    static constexpr bool PHASH = true;\n";
+            out << "    __device__ __forceinline__ static const TableHeader* shdr(const XArgs& a) { return a.tab[" << x.tab_of[x.prefilter_op] << "].hdr; }\n";
+            out << "    __device__ __forceinline__ static const uint32_t* sbitmap(const XArgs& a) { return a.tab[" << x.tab_of[x.prefilter_op] << "].hf; }\n";
+        } else
         out << "    __device__ __forceinline__ static const uint32_t* sbitmap(const XArgs& a) { return "
             << (x.prefilter_op >= 0 ? "x_prefilter_bitmap(a.tab[" + std::to_string(x.tab_of[x.prefilter_op]) + "], " + (x.prefilter_composite ? "true" : "false") + ")" : std::string("nullptr")) << "; }\n";
         if (x.driven && sink == SINK_GROUP) {       // (the group sink's launch asks for the tiled walk)
@@ -1207,7 +1224,7 @@ uint64_t structure_hash(const XInfo& x, Sink sink, bool direct) {
     auto mix = [&](uint64_t v) { h ^= v; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29; };      // (a word at a time: this runs on every call)
     mix((uint64_t)sink * 2 + (direct ? 1 : 0)); mix((uint64_t)x.narrow_mask);
     if (x.tight) {
-        mix(0x7167ull); mix((uint64_t)x.gather32); mix((x.pref32 ? 1ull : 0ull) | (x.vstage ? 2ull : 0ull) | (x.pwin ? 4ull : 0ull) | (x.pnear ? 8ull : 0ull) | (x.driven ? 16ull : 0ull) | ((uint64_t)(x.ival + 1) << 8));
+        mix(0x7167ull); mix((uint64_t)x.gather32); mix((x.pref32 ? 1ull : 0ull) | (x.vstage ? 2ull : 0ull) | (x.pwin ? 4ull : 0ull) | (x.pnear ? 8ull : 0ull) | (x.driven ? 16ull : 0ull) | (x.phash ? 32ull : 0ull) | ((uint64_t)(x.ival + 1) << 8));
         for (int c = 0; c < x.ncols; ++c) mix(((uint64_t)(uint32_t)x.enc[c] << 32) | ((uint32_t)(x.affine[c] ? 1 : 0) << 16) | (uint32_t)(x.dict_slot[c] & 0xFFFF));
         for (int k = 0; k < x.p->nops; ++k) mix((uint64_t)(uint8_t)x.irange[k]);
         for (int k = 0; k < x.p->nops; ++k) mix(((uint64_t)(uint32_t)x.cmp_cc[k] << 32) | ((uint32_t)x.cmp_kind[k] << 8) | (uint32_t)(x.cmp_col[k] & 0xFF));

@@ -84,6 +84,9 @@ struct XArgs {
 template <class...> using x_void_t = void;
 template <class P, class = void> struct x_is_driven { static constexpr bool value = false; };
 template <class P> struct x_is_driven<P, x_void_t<decltype(P::DRIVEN)>> { static constexpr bool value = P::DRIVEN; };
+// ... and P::PHASH: the prefilter's bitmap is the HASHED filter of a hash-layout table (DevTable::hf), P::shdr(a) that table's header
+template <class P, class = void> struct x_is_phash { static constexpr bool value = false; };
+template <class P> struct x_is_phash<P, x_void_t<decltype(P::PHASH)>> { static constexpr bool value = P::PHASH; };
 
 template <int NV> struct XOut {
     int64_t key;
@@ -294,7 +297,12 @@ template <uint32_t L> __device__ __forceinline__ int64_t x_hits_l(const DevTable
 // table's key bitmap when it has one (exact for key sets and the direct layout; over the high part of a
 // composite key), else true
 __device__ __forceinline__ bool x_may_hit(const DevTable& t, int64_t part0, bool composite) {
-    if (!t.bm) return true;
+    if (!t.bm) {
+        // hash layout: its hashed filter answers "maybe" for every key it holds (and a few per cent of the others)
+        if (!t.hf || composite) return true;
+        const uint32_t code = hf_code(hf_raw(part0), hf_mask_of(t.hdr->cap_mask));
+        return hf_test(t.hf[(code & HF_POS_MASK) >> 5], code);
+    }
     if (composite ? (t.bm_shift == 0 && !t.lin_rb) : (t.bm_shift != 0 || t.lin_rb != 0)) return true;     // the bitmap is not over this part
     if (composite && t.lin_rb) return true;
     if (part0 < t.bm_lo || part0 > t.bm_hi) return false;
@@ -303,7 +311,7 @@ __device__ __forceinline__ bool x_may_hit(const DevTable& t, int64_t part0, bool
 }
 // the bitmap x_may_hit would test `part0` against, or null when it would answer "maybe" for every key (wave-uniform)
 __device__ __forceinline__ const uint32_t* x_prefilter_bitmap(const DevTable& t, bool composite) {
-    if (!t.bm) return nullptr;
+    if (!t.bm) return nullptr;                                          // (a hash-layout table's hashed filter is named by the PHASH form itself: P::sbitmap)
     if (composite ? (t.bm_shift == 0 && !t.lin_rb) : (t.bm_shift != 0 || t.lin_rb != 0)) return nullptr;
     if (composite && t.lin_rb) return nullptr;
     return t.bm;
@@ -1014,6 +1022,8 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
     if constexpr (SEGMENTED) sink.begin_segment(begin);
     int qn = 0;
     const uint32_t* pbm = P::sbitmap(a);                               // the prefilter's key bitmap, or null (wave-uniform)
+    uint32_t hmask = 0;                                                // P::PHASH: the bitmap is the table's HASHED filter, this many bits - 1 (sized on the device with the table)
+    if constexpr (x_is_phash<P>::value) hmask = hf_mask_of(P::shdr(a)->cap_mask);
     auto drain = [&](int first, int count) {                           // rows q_row[first .. first + count), one per lane, in row order
         XOut<P::NV> o;
         int64_t sres[P::NSOP > 0 ? P::NSOP : 1] = {0};
@@ -1152,6 +1162,13 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
                     }
                     if constexpr (X8_EXP == 1 && x_exp_on<Sink>()) {
                         // (timing experiment: no bitmap requests at all)
+                    } else if constexpr (x_is_phash<P>::value) {
+                        // HASHED filter of a hash-layout table: spre32 gave 32 hash bits of the key; the key's word is one request, its two
+                        // bits one test — the keys that pass (the table's, and a few per cent of the others) are queued for the slots
+#pragma unroll
+                        for (int u = 0; u < X8_U; ++u)
+#pragma unroll
+                            for (int i = 0; i < XT_R; ++i) { off[u][i] = hf_code(off[u][i], hmask); w[u][i] = pbm[((m[u] >> i) & 1u) ? (off[u][i] & HF_POS_MASK) >> 5 : 0u]; }
                     } else if constexpr (P::PWIN) {
                         // WINDOW: a lane's 8 consecutive rows carry near-by keys when the key column is clustered (a foreign key of a table
                         // stored in the order of its parent: l_orderkey; column_span8 sampled it), so ONE 16-byte request per lane — the
@@ -1208,6 +1225,14 @@ __device__ __forceinline__ void x_queue8(const XArgs& a, const typename SinkT<P:
                     if constexpr (X8_EXP == 1 && x_exp_on<Sink>()) {
 #pragma unroll
                         for (int u = 0; u < X8_U; ++u) m[u] = ((uint32_t)a.key_hi == 0x12345678u) ? m[u] : 0u;
+                    } else if constexpr (x_is_phash<P>::value) {
+#pragma unroll
+                        for (int u = 0; u < X8_U; ++u) {
+                            uint32_t hit = 0;
+#pragma unroll
+                            for (int i = 0; i < XT_R; ++i) hit |= (hf_test(w[u][i], off[u][i]) ? 1u : 0u) << i;
+                            m[u] &= hit;
+                        }
                     } else if constexpr (P::PWIN) {
 #pragma unroll
                         for (int u = 0; u < X8_U; ++u) {

@@ -89,11 +89,12 @@ def test_sf1_goldens_with_the_size_dependent_paths_on_and_off(hip_engine, golden
     variants = [
         ("default", {}, {}),
         ("no walks / delta twins / clustered pack", {"x_driven": 0, "delta8": 0, "cluster_pack": 0}, {}),
-        ("open addressing", {"direct_index": 0, "row_index": 0, "grouped_index": 0}, {}),
+        ("open addressing behind its hashed filter", {"direct_index": 0, "row_index": 0, "grouped_index": 0}, {}),
+        ("open addressing, no filter", {"direct_index": 0, "row_index": 0, "grouped_index": 0, "hash_filter": 0}, {}),
         ("host dictionary loops", {}, {"dict_programs": False}),
         ("every feature at every size", {"feature_min_rows": 0, "coarse_kb": 1}, {}),
     ]
-    defaults = {"x_driven": 64, "delta8": 1, "cluster_pack": 1, "direct_index": 1, "row_index": 1, "grouped_index": 1, "feature_min_rows": 1 << 20, "coarse_kb": 64}
+    defaults = {"x_driven": 64, "delta8": 1, "cluster_pack": 1, "direct_index": 1, "row_index": 1, "grouped_index": 1, "feature_min_rows": 1 << 20, "coarse_kb": 64, "hash_filter": 1}
     for name, opts, attrs in variants:
         saved = {k: getattr(hip_engine, k) for k in attrs}
         for k, v in opts.items():

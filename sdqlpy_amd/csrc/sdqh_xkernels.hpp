@@ -436,18 +436,91 @@ template <int NV> struct XGroup {
 };
 
 // ---- K-B: survivors compacted in row order into the wave segment's slice of the stage ----
+// Round 6, measured and left OFF (XS_LINES=1 turns it on): the survivors through a ring of XS_RING rows per wave in LDS, reaching the stage
+// arrays XS_FLUSH rows at a time — whole 128-byte lines of every array — instead of what each consume() call's 64 lanes kept (1.5 rows
+// per call in Q5's orders build, where 2.3 % of the rows survive).  The suspicion was that the L2 fills every line it is handed a part
+// of: that build reads 243 MB (2 x FETCH_SIZE) for a 92 MB stream.  tools/build_bytes.sh took it apart (profiles/r06_build_bytes_*.txt):
+// 92 MB with the survivors queued and never drained; 93 MB drained and EVALUATED with nothing reaching the sink — the looked-up customer
+// entries are L2 hits, not the 217 MB the round-5 review asked about —; 243 MB with the sink.  With whole-line stores: 242 MB and the same
+// 0.062 ms.  So it is not the stage arrays: it is the sink's INDEX part — one memory-side atomicOr per entry into a 7.5 MB bitmap and one
+// 4-byte row-index note into a 7.5 MB array, 340 K entries scattered over 60 M key values, each a 64-byte read-modify-write at the memory
+// side (and FETCH_SIZE's doubling, right for wide coalesced reads, counts those scattered requests twice: the true figure lies between
+// 75 and 150 MB).  Positions, order and the index part of a store are what they were either way.
+#ifndef XS_LINES
+#define XS_LINES 0
+#endif
+// the INDEX part of a staged entry alone (stage_store's: the key's bit, the grouped layout's first row of a run)
+__device__ __forceinline__ void stage_index_part(const DevStage& st, int64_t pos, int64_t key) {
+    if (st.bm) {
+        uint64_t off;
+        if (bm_locate(st, key, off)) {
+#if defined(XS_EXP) && (XS_EXP & 1)
+            if (key == -12345)                                // (byte-accounting experiment, tools/build_bytes.sh: no bitmap atomics — results ARE wrong)
+#endif
+            atomicOr(&st.bm[off >> 5], 1u << (off & 31));
+            if (st.grp_first) atomicMin(&st.grp_first[off], (uint32_t)pos);
+        }
+    }
+}
 template <int NV> struct XStage {
     static constexpr bool FINAL = false;
+    static constexpr int XS_RING = 128, XS_FLUSH = 32;                    // (a flush leaves < 32 rows behind, a consume adds <= 64)
     struct Args { DevStage st; };
-    int64_t out, seg_begin;
+    int64_t out, seg_begin, flushed;
     uint32_t carry;                                                       // row index: the bitmap word of the wave's previous entry
-    __device__ __forceinline__ void init(const Args&) { out = 0; seg_begin = 0; carry = ROW_INDEX_NONE; }
-    __device__ __forceinline__ void begin_segment(int64_t begin) { out = seg_begin = begin; carry = ROW_INDEX_NONE; }
+    __device__ __forceinline__ void init(const Args&) { out = 0; seg_begin = 0; flushed = 0; carry = ROW_INDEX_NONE; }
+    __device__ __forceinline__ void begin_segment(int64_t begin) { out = seg_begin = flushed = begin; carry = ROW_INDEX_NONE; }
+    __device__ __forceinline__ static long long (*ring())[XS_RING] {
+        __shared__ long long s_ring[TPB / WAVE][NV + 1][XS_RING];
+        return s_ring[threadIdx.x / WAVE];
+    }
+    // rows [flushed, flushed + n) of the ring to the stage arrays: lane i the row flushed + i
+    __device__ __forceinline__ void flush(const DevStage& st, int n) {
+        long long (*buf)[XS_RING] = ring();
+        const int lane = lane_id();
+        if (lane < n) {
+            const int64_t pos = flushed + lane;
+            const int slot = (int)((pos - seg_begin) & (XS_RING - 1));
+            const long long key = buf[0][slot];
+            st.key[pos] = key;
+#pragma unroll
+            for (int q = 0; q < MAX_STAGE_COLS; ++q) if (q < st.npay) st.pay[q][pos] = q < NV ? buf[1 + (q < NV ? q : 0)][slot] : 0ll;
+            if (st.shits) st.shits[pos] = 0;
+            if (st.sacc) zero_acc(st, pos);
+            if (st.grp_kp) { using V2 = long long __attribute__((ext_vector_type(2))); const V2 kp = {key, NV > 0 ? buf[1][slot] : 0ll}; reinterpret_cast<V2*>(st.grp_kp)[pos] = kp; }
+        }
+        flushed += n;
+    }
     __device__ __forceinline__ void consume(const XArgs& a, const Args& s, bool pass, int64_t, const XOut<NV>& o) {
         bool keep = pass;
         if (pass && (o.bad || (a.key_lo <= a.key_hi && (o.key < a.key_lo || o.key > a.key_hi)))) { atomicOr(a.flags, 2); keep = false; }
         const uint64_t b = __ballot(keep);
         const int64_t pos = out + __popcll(b & lanemask_lt());
+#if XS_LINES
+        if (!b) return;                                                   // (wave-uniform; nothing kept: nothing noted — row_index_note returns at once for an empty mask)
+        if (keep) {
+            long long (*buf)[XS_RING] = ring();
+            const int slot = (int)((pos - seg_begin) & (XS_RING - 1));
+            buf[0][slot] = o.key;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) buf[1 + k][slot] = o.val[k];
+            stage_index_part(s.st, pos, o.key);
+        }
+#if defined(XS_EXP) && (XS_EXP & 2)
+        if (o.key == -12345)                                              // (experiment: no row-index notes)
+#endif
+        row_index_note(s.st, (int)(seg_begin / s.st.seg_rows), keep, o.key, pos, b, carry);
+        out += __popcll(b);
+        __builtin_amdgcn_wave_barrier();
+#if defined(XS_EXP) && (XS_EXP & 4)
+        if (o.key == -12345)                                              // (experiment: nothing stored to the stage arrays)
+#endif
+        while (out - flushed >= XS_FLUSH) flush(s.st, XS_FLUSH);
+#if defined(XS_EXP) && (XS_EXP & 4)
+        if (out - flushed >= XS_FLUSH) flushed = out - (out - flushed) % XS_FLUSH;
+#endif
+        __builtin_amdgcn_wave_barrier();
+#else
         if (keep) {
             int64_t pay[MAX_STAGE_COLS] = {0, 0, 0, 0, 0};
 #pragma unroll
@@ -456,8 +529,15 @@ template <int NV> struct XStage {
         }
         row_index_note(s.st, (int)(seg_begin / s.st.seg_rows), keep, o.key, pos, b, carry);
         out += __popcll(b);
+#endif
     }
-    __device__ __forceinline__ void end_segment(const Args& s, int seg, int64_t begin) { if (lane_id() == 0) s.st.seg_count[seg] = (uint32_t)(out - begin); }
+    __device__ __forceinline__ void end_segment(const Args& s, int seg, int64_t begin) {
+#if XS_LINES
+        __builtin_amdgcn_wave_barrier();
+        while (out > flushed) flush(s.st, out - flushed >= WAVE ? WAVE : (int)(out - flushed));
+#endif
+        if (lane_id() == 0) s.st.seg_count[seg] = (uint32_t)(out - begin);
+    }
     __device__ __forceinline__ void finish(const XArgs&, const Args&) {}
 };
 

@@ -67,6 +67,19 @@ def main(rank, world, port, sf, mode, out_path):
             r = runner.run(q, db)
             out["again"]["%s/%d" % (q, again)] = {"columns": r.columns, "rows": r.rows(), "seams": dict(runner.last_chain or {})}
     out["chain_fast_runs"], out["chain_fast_retries"] = runner.fast_runs - fast0, runner.fast_retries
+    # a replicated table that outgrew its chunk: the settled chain's bounds cut to two rows (every rank does the same), the run must notice
+    # — the largest counts reach every rank with the groups, or by their own all-reduce — and every rank repeats the chain with exact sizes
+    fn5, plan5, _ = runner._resolve("q5", db)
+    st5 = [st for key, st in plan5.__dict__["_dist_chain"].items() if key[0] == id(runner)][0]
+    out["chain_fast_tables"] = list(st5.fast_tables)
+    if st5.fast_ok and st5.fast_tables:
+        for name in st5.caps:
+            st5.caps[name] = 2
+        r = runner.run("q5", db)
+        out["chain_overflow"] = {"columns": r.columns, "rows": r.rows(), "retries": runner.fast_retries - out["chain_fast_retries"],
+                                 "caps_after": {k: int(v) for k, v in st5.caps.items()}}
+        r = runner.run("q5", db)                                       # ... and the next run is a settled one again, with the bounds the exact run measured
+        out["chain_overflow"]["next"] = {"rows": r.rows(), "retries": runner.fast_retries - out["chain_fast_retries"], "fast_runs": runner.fast_runs}
     r3 = runner.run("q3", db)
     out["q3"] = {"columns": r3.columns, "rows": runner.gather_rows(r3), "local_rows": r3.size(),
                  "partitioning": runner.last_partitioning, "exchanged": runner.exchanged_rows}

@@ -1372,6 +1372,61 @@ def test_distributed_plans_world1_full_size(hip_lib):
         eng.close()
 
 
+def test_settled_chains_world1_wait_for_nothing(hip_lib):
+    """Round 6: the chain plans (q1, q5, q9) at SF=10 on an RCCL group of one whose collectives are ISSUED, from their second run on: a
+    replicated table travels as one fixed-capacity chunk behind one all-gather (sdqh_table_partition_pack with one part /
+    sdqh_unpack_chunks), the partial groups are folded on the device behind one more (sdqh_xgroupby_partial / _fold) — at most three
+    collectives per query, all on device tensors, and the seams say that this is what ran.  Against the single-GPU plan on the same
+    tables; then q5 with its chunk bounds cut to two rows: noticed when the result is collected, the chain repeated with exact sizes."""
+    import torch
+    import torch.distributed as dist
+    from sdqlpy_amd import dist as sdist
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29599", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    eng = engine.Engine(hip_lib.context(device=0))
+    runner = sdist.DistributedRunner(eng, 0, 1, skip_trivial=False)
+    try:
+        qs = ("q1", "q5", "q9")
+        cols = tpch.columns_for(qs)
+        db = tpch.generate(10.0, tables=sorted(cols), columns=cols, shard=(0, 1))
+        want = {q: helpers.run_query(eng, q, db) for q in qs}
+        want = {q: (r.wait() if hasattr(r, "wait") else r) for q, r in want.items()}
+        for q in qs:
+            _rows_match(runner.run(q, db), want[q], "settled/%s/first (exact sizes)" % q)
+            for again in range(3):
+                runner.reset_collectives()
+                runner.last_chain = None
+                got = runner.run(q, db)
+                seams = dict(runner.last_chain or {})
+                calls = {k: v[:2] for k, v in runner.collectives.items()}
+                _rows_match(got, want[q], "settled/%s/%d" % (q, again))
+                if q == "q9":
+                    # (its replicated (part, supplier) table is keyed by pairs that do NOT increase row after row in partsupp — the suppliers of
+                    #  a part come in the generator's order — so the library cannot take the stage for the entries: sdqh_table_partition_pack
+                    #  refuses, every rank alike, and the chain keeps exchanging exact sizes)
+                    continue
+                assert seams.get("plan") == q, (q, seams)
+                assert sum(c[0] for c in calls.values()) <= 3 and all(c[0] == c[1] for c in calls.values()), (q, calls)
+                if q in ("q1", "q5"):
+                    assert seams["folded"] and not seams["merged_on_host"], (q, seams)
+                if q == "q5":
+                    assert seams["replicated"] == ["supplier_nations"], seams        # (on a group of one the customers' join is co-partitioned)
+        assert runner.fast_runs >= 6 and runner.fast_retries == 0
+        fn5, plan5, _ = runner._resolve("q5", db)
+        st5 = [st for key, st in plan5.__dict__["_dist_chain"].items() if key[0] == id(runner)][0]
+        for name in st5.caps:
+            st5.caps[name] = 2
+        _rows_match(runner.run("q5", db), want["q5"], "settled/q5/after an overflow")
+        assert runner.fast_retries == 1 and all(v > 2 for v in st5.caps.values()), (runner.fast_retries, st5.caps)
+        _rows_match(runner.run("q5", db), want["q5"], "settled/q5/settled again")
+        assert runner.fast_retries == 1
+    finally:
+        runner.close()
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+        eng.close()
+
+
 def test_distributed_hash_join_world1_sf100(hip_lib):
     """BASELINE configs[3]'s data size on one device: the hash-partitioned q3 at SF=100 (32-bit offsets in the partitioning pass, a
     75 MB bitmap through the all-reduce, 15 M build rows and 3 M probe rows through the all-to-all of an RCCL group of one), its first

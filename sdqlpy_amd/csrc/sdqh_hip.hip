@@ -2632,14 +2632,14 @@ int sdqh_column_copy_out(sdqh_ctx* ctx, const sdqh_column* col, int64_t row0, in
     if (!ctx || !col || col->dtype == SDQH_STR || row0 < 0 || nrows < 0 || row0 + nrows > col->nrows || (nrows && !dst)) return fail(ctx, SDQH_ERR_INVALID, "column_copy_out: bad arguments");
     if (nrows == 0) return SDQH_OK;
     (void)hipSetDevice(ctx->device);
-    HIP_TRY(ctx, hipMemcpyAsync(dst, static_cast<const char*>(col->data) + (size_t)row0 * 8, (size_t)nrows * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, static_cast<const char*>(col->data) + (size_t)row0 * 8, (size_t)nrows * 8, hipMemcpyDefault, ctx->stream));      // (the caller's buffer: device memory, or pinned host memory — the multi-GPU runner's hybrid mode)
     return ctx->opt_async_copies ? SDQH_OK : sync_stream(ctx);
 }
 int sdqh_column_copy_in(sdqh_ctx* ctx, sdqh_column* col, int64_t row0, int64_t nrows, const void* src) {
     if (!ctx || !col || col->dtype == SDQH_STR || row0 < 0 || nrows < 0 || row0 + nrows > col->nrows || (nrows && !src)) return fail(ctx, SDQH_ERR_INVALID, "column_copy_in: bad arguments");
     if (nrows == 0) return SDQH_OK;
     (void)hipSetDevice(ctx->device);
-    HIP_TRY(ctx, hipMemcpyAsync(static_cast<char*>(col->data) + (size_t)row0 * 8, src, (size_t)nrows * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(static_cast<char*>(col->data) + (size_t)row0 * 8, src, (size_t)nrows * 8, hipMemcpyDefault, ctx->stream));
     // the contents changed: what was learnt about them is void.  A transient column (rows that live for one run: sdqh_column_mark_transient)
     // stays "no order, no twins" — unknown (-1) would make the next kernel that asks pay a pass and a host round trip, every run
     const int unknown = col->transient ? 0 : -1;

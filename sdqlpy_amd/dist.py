@@ -72,6 +72,12 @@ class DistributedRunner:
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
         self.device = device
+        # HYBRID (round 6): the HIP library behind a process group that is NOT RCCL (gloo) — several ranks sharing ONE GPU, which RCCL refuses.
+        # Collective buffers are then PINNED host tensors: the library's kernels read and write them through their device-visible addresses,
+        # gloo moves them between the processes, and the stream is waited for before the host (a collective, a torch op) touches what
+        # kernels wrote.  Slow (PCIe) and only for tests: it is how the N > 1 kernels — multi-part packs, chunks of several sources, folds of
+        # several blocks — run on the hardware where a second GPU is not to be had (tests/test_hip_parity.py).
+        self.hybrid = self.backend != "nccl" and eng.ctx.library.backend_name() == "hip-gfx950"
         self.partition = partition          # "auto" | "range" | "hash"
         self.prefilter = prefilter          # hash partitioning: probe rows are tested against a replicated bitmap of ALL build keys before they travel
         self.last_partitioning = None
@@ -129,7 +135,24 @@ class DistributedRunner:
         self._stat_ring = []
         self._ext_stream = None
 
+    def _empty(self, n, dtype=torch.int64):
+        """A collective buffer of n elements: device memory under RCCL, pinned host memory in the hybrid mode, plain host memory on CPU."""
+        if self.hybrid:
+            return torch.empty(int(n), dtype=dtype).pin_memory()
+        return torch.empty(int(n), dtype=dtype, device=self.device)
+
+    def _zeros(self, n, dtype=torch.int64):
+        t = self._empty(n, dtype)
+        t.zero_()
+        return t
+
+    def _host_touch(self):
+        """Hybrid mode: the host is about to read or write memory that queued kernels write / read — wait for the stream."""
+        if self.hybrid:
+            self.ctx.synchronize()
+
     def _note(self, name, tensor):
+        self._host_touch()                                      # (every collective is announced here, right in front of it)
         rec = self.collectives.setdefault(name, [0, 0, 0])
         rec[0] += 1
         rec[1] += 1 if tensor.is_cuda else 0
@@ -187,11 +210,11 @@ class DistributedRunner:
         self._last_gather_max = max(sizes + [0])                             # (every rank gathered the same sizes: the bound of the next run's chunk)
         k = len(cols)
         self._on_engine_stream()
-        send = torch.empty(m * k, dtype=torch.int64, device=self.device)     # padding rows are never read back; no fill kernel
+        send = self._empty(m * k)     # padding rows are never read back; no fill kernel
         if n:                                                                # on torch's stream to race the library's copies
             for j, col in enumerate(cols):
                 self.ctx.copy_out(col, 0, n, send.data_ptr() + j * m * 8)      # queued ("async_copies"): the collective is ordered behind them on the stream
-        recv = torch.empty(m * k * self.world, dtype=torch.int64, device=self.device)
+        recv = self._empty(m * k * self.world)
         self._note("all_gather", send)
         if self.backend == "nccl":
             dist.all_gather_into_tensor(recv, send, group=self.group)
@@ -291,7 +314,7 @@ class DistributedRunner:
         move and skip the data collective).  Returns (received Columns, their row count, rows sent to every rank)."""
         k = len(cols)
         self._on_engine_stream()
-        send = torch.empty(max(nrows * k, 1), dtype=torch.int64, device=self.device)
+        send = self._empty(max(nrows * k, 1))
         counts = self.ctx.partition_pack(nrows, key, self.world, cols, send.data_ptr(), range_upper)      # (waits for the counts: they size the exchange)
         matrix = np.stack(self._all_gather_array(counts))                                              # [source, dest]
         recv_counts = matrix[:, self.rank]
@@ -301,7 +324,7 @@ class DistributedRunner:
         if self.world == 1 and self.skip_trivial:
             recv = send                                                       # a group of one: what was packed for rank 0 is what rank 0 receives
         else:
-            recv = torch.empty(max(n_recv * k, 1), dtype=torch.int64, device=self.device)
+            recv = self._empty(max(n_recv * k, 1))
         if matrix.sum() > 0 and recv is not send:
             self._a2a(recv[:n_recv * k], send[:nrows * k], [int(c) * k for c in recv_counts], [int(c) * k for c in counts])
         out, n = self.ctx.unpack_parts(recv.data_ptr(), recv_counts, dtypes or [c.dtype for c in cols])      # (dtypes: entries of a staged table come back as raw 8-byte columns)
@@ -807,7 +830,7 @@ class DistributedRunner:
         self._on_engine_stream()
         dev = st.__dict__.get("dev_bufs")
         if dev is None:
-            dev = st.dev_bufs = {"stat": torch.zeros(abi.EXCHANGE_STAT_WORDS, dtype=torch.int64, device=self.device), "bufs": {}, "caps": {}}
+            dev = st.dev_bufs = {"stat": self._zeros(abi.EXCHANGE_STAT_WORDS), "bufs": {}, "caps": {}}
             dev["stat_col"] = ctx.wrap(dev["stat"].data_ptr(), abi.EXCHANGE_STAT_WORDS, abi.I64, keepalive=dev["stat"])
         stat_t, stat = dev["stat"], dev["stat_col"]
         names = [n for n in st.fast_tables]                          # replicated tables with payload, in plan order: their status slots
@@ -819,8 +842,8 @@ class DistributedRunner:
         def buffers(name, words):
             pair = dev["bufs"].get(name)
             if pair is None or pair[0].numel() != words:
-                send = torch.empty(words, dtype=torch.int64, device=self.device)
-                pair = dev["bufs"][name] = (send, torch.empty(words * G, dtype=torch.int64, device=self.device))
+                send = self._empty(words)
+                pair = dev["bufs"][name] = (send, self._empty(words * G))
             return pair
 
         def gather(recv, send):
@@ -900,6 +923,7 @@ class DistributedRunner:
                 def issue():
                     # the chunks' largest counts ride in the block's spare words (behind its completion word, which a device block does
                     # not use): no collective of their own
+                    self._host_touch()                                 # (hybrid mode: the torch ops below run on the host)
                     spare = words - 6
                     send[spare:spare + 4].copy_(stat_t[:4])
                     gather(recv, send)
@@ -1184,7 +1208,7 @@ class DistributedRunner:
         ctx = self.ctx
         lo, hi = rng
         n64 = ((hi - lo + 1 + 31) // 32 + 1) // 2
-        buf = torch.empty(max(n64, 1), dtype=torch.int64, device=self.device)
+        buf = self._empty(max(n64, 1))
         words = ctx.wrap(buf.data_ptr(), n64, abi.I64, keepalive=buf)
         ctx.table_export_bitmap(table, lo, hi, into=words)                    # queued under "async_copies": the collective is ordered behind it
         if self.world == 1 and self.skip_trivial:
@@ -1193,7 +1217,7 @@ class DistributedRunner:
             self._note("all_reduce", buf)
             dist.all_reduce(buf, group=self.group)
         else:
-            parts = torch.empty(max(n64, 1) * self.world, dtype=torch.int64, device=self.device)
+            parts = self._empty(max(n64, 1) * self.world)
             self._note("all_gather", buf)
             if self.backend == "nccl":
                 dist.all_gather_into_tensor(parts, buf, group=self.group)
@@ -1394,7 +1418,7 @@ class DistributedRunner:
         # and the collective buffers — written and read in stream order, run after run, so nothing is allocated per run
         dev = st.__dict__.get("dev_bufs")
         if dev is None or dev["caps"] != (cap_b, cap_c):
-            dev = st.dev_bufs = {"caps": (cap_b, cap_c), "stat": torch.zeros(abi.EXCHANGE_STAT_WORDS, dtype=torch.int64, device=self.device), "bufs": {}}
+            dev = st.dev_bufs = {"caps": (cap_b, cap_c), "stat": self._zeros(abi.EXCHANGE_STAT_WORDS), "bufs": {}}
             dev["stat_col"] = ctx.wrap(dev["stat"].data_ptr(), abi.EXCHANGE_STAT_WORDS, abi.I64, keepalive=dev["stat"])
         stat_t, stat = dev["stat"], dev["stat_col"]
         host_t, host, busy = self._stat_buffer()
@@ -1405,8 +1429,8 @@ class DistributedRunner:
             pair = dev["bufs"].get(slot)
             if pair is None:
                 cw = ctx.chunk_words(len(dtypes), cap)
-                send = torch.empty(G * cw, dtype=torch.int64, device=self.device)
-                pair = dev["bufs"][slot] = (send, send if trivial else torch.empty_like(send), cw)      # (a group of one: what was packed for rank 0 is what rank 0 receives)
+                send = self._empty(G * cw)
+                pair = dev["bufs"][slot] = (send, send if trivial else self._empty(G * cw), cw)      # (a group of one: what was packed for rank 0 is what rank 0 receives)
             send, recv, cw = pair
             ctx.table_partition_pack(table, G, cap, send.data_ptr())
             if recv is not send:

@@ -1,0 +1,51 @@
+"""Worker for tests/test_hip_parity.py::test_two_ranks_share_one_gpu: one rank of a GLOO process group driving the HIP library on
+device 0 — the multi-GPU runner's hybrid mode (sdqlpy_amd/dist.py): collective buffers in pinned host memory, which the library's
+kernels read and write through their device-visible addresses and gloo moves between the processes.  RCCL refuses two ranks on one
+device; this is how the N > 1 kernels (multi-part packs, chunks of several sources, folds of several blocks) run on the hardware."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main(rank, world, port, sf, out_path):
+    import torch.distributed as dist
+    from sdqlpy_amd import engine, tpch
+    from sdqlpy_amd import dist as sdist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    eng = engine.Engine(engine.load_hip_library().context(device=0))
+    qs = ["q6", "q1", "q5", "q9", "q4", "q14", "q3"]
+    cols = tpch.columns_for(qs)
+    db = tpch.generate(sf, tables=sorted(cols), columns=cols, threads=4, shard=(rank, world))
+    out = {"rank": rank, "runs": {}}
+    for part in ("hash", "auto"):
+        runner = sdist.DistributedRunner(eng, rank, world, partition=part)
+        assert runner.hybrid and runner.backend == "gloo"
+        for q in qs:
+            for again in range(3):                                  # (first run: exact sizes; later runs: device-sized exchanges, folded groups)
+                runner.last_chain = None
+                r = runner.run(q, db)
+                tag = "%s/%s/%d" % (part, q, again)
+                if isinstance(r, float):
+                    out["runs"][tag] = {"scalar": r}
+                    continue
+                rows = runner.gather_rows(r) if q == "q3" else sorted(r.rows())
+                out["runs"][tag] = {"columns": r.columns, "rows": rows, "seams": dict(runner.last_chain or {}),
+                                    "partitioning": runner.last_partitioning if q == "q3" else None,
+                                    "exchanged": dict(runner.exchanged_rows) if q == "q3" else None}
+        out[part] = {"fast_runs": runner.fast_runs, "fast_retries": runner.fast_retries,
+                     "collectives": {k: v[:2] for k, v in runner.collectives.items()}}
+        runner.close()
+    if rank == 0:
+        with open(out_path, "w") as fh:
+            json.dump(out, fh)
+    dist.barrier()
+    dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), sys.argv[5])

@@ -11,17 +11,28 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main(rank, world, port, sf, out_path):
+def result_digest(res):
+    """A large result as a few numbers that add up over key partitions: rows, sums of the integer columns, sums of the float columns."""
+    import numpy as np
+    out = [float(res.size())]
+    for c in res.columns:
+        a = np.asarray(res.column(c))
+        out.append(float(a.astype(np.float64).sum()) if a.dtype.kind in "if" else 0.0)
+    return out
+
+
+def main(rank, world, port, sf, out_path, qs=None, parts=None, digest=False):
+    import numpy as np
     import torch.distributed as dist
     from sdqlpy_amd import engine, tpch
     from sdqlpy_amd import dist as sdist
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     eng = engine.Engine(engine.load_hip_library().context(device=0))
-    qs = ["q6", "q1", "q5", "q9", "q4", "q14", "q3"]
+    qs = qs or ["q6", "q1", "q5", "q9", "q4", "q14", "q3"]
     cols = tpch.columns_for(qs)
     db = tpch.generate(sf, tables=sorted(cols), columns=cols, threads=4, shard=(rank, world))
     out = {"rank": rank, "runs": {}}
-    for part in ("hash", "auto"):
+    for part in (parts or ("hash", "auto")):
         runner = sdist.DistributedRunner(eng, rank, world, partition=part)
         assert runner.hybrid and runner.backend == "gloo"
         for q in qs:
@@ -31,6 +42,13 @@ def main(rank, world, port, sf, out_path):
                 tag = "%s/%s/%d" % (part, q, again)
                 if isinstance(r, float):
                     out["runs"][tag] = {"scalar": r}
+                    continue
+                if q == "q3" and digest:
+                    # (a million rows per run: this rank's key partition as a digest, the ranks' digests added)
+                    r = r.wait() if hasattr(r, "wait") else r
+                    parts_d = runner._all_gather_array(np.array(result_digest(r), np.float64))
+                    out["runs"][tag] = {"columns": r.columns, "digest": [float(x) for x in np.sum(parts_d, axis=0)], "local_rows": r.size(),
+                                        "partitioning": runner.last_partitioning, "exchanged": dict(runner.exchanged_rows)}
                     continue
                 rows = runner.gather_rows(r) if q == "q3" else sorted(r.rows())
                 out["runs"][tag] = {"columns": r.columns, "rows": rows, "seams": dict(runner.last_chain or {}),
@@ -48,4 +66,7 @@ def main(rank, world, port, sf, out_path):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), sys.argv[5])
+    main(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), sys.argv[5],
+         qs=sys.argv[6].split(",") if len(sys.argv) > 6 and sys.argv[6] else None,
+         parts=sys.argv[7].split(",") if len(sys.argv) > 7 and sys.argv[7] else None,
+         digest=len(sys.argv) > 8 and sys.argv[8] == "digest")

@@ -55,6 +55,8 @@ def parse(argv=None):
     ap.add_argument("--force-dist", action="store_true", help="use the distributed plan even with one rank (exercises the RCCL path)")
     ap.add_argument("--trivial-collectives", action="store_true", help="with --force-dist: a group of ONE still issues every collective (the RCCL calls themselves on one GPU); "
                     "by default collectives over a group of one — which move nothing — are skipped, as every rank of such a group knows to")
+    ap.add_argument("--share-gpu", action="store_true", help="with --gpus N: the N ranks SHARE device 0 (gloo between the processes, collective buffers in pinned host memory: "
+                    "dist.DistributedRunner's hybrid mode) — the N > 1 plans and kernels on a box with one GPU; a functional run, not a scaling figure")
     ap.add_argument("--partition", default="hash", choices=["auto", "range", "hash"], help="q3's partitioning in the timed step at N > 1")
     ap.add_argument("--cpu-sample-sf", type=float, default=0.0, help="0 = pick so the CPU leg takes ~10-30 s")
     ap.add_argument("--steady-steps", type=int, default=1500, help="steps of a second, longer leg after the timed region (reported as `steady_state`, not part of `value`); 0 = none")
@@ -188,6 +190,8 @@ def main(argv=None, hooks=None):
     extra = [q for q in extra.split(",") if q and q not in queries]
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_gpu:
+        local_rank = 0                                   # every rank on device 0 (the runner's hybrid mode: gloo + pinned host buffers)
     if world != args.gpus:
         if world == 1 and args.gpus > 1 and not hooks:
             # plain `python bench.py --gpus N`: this process becomes the launcher — N ranks started as child processes BEFORE anything
@@ -201,13 +205,16 @@ def main(argv=None, hooks=None):
     if device == "cuda":
         torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
+    coll_device = "cpu" if args.share_gpu else device    # (the bench's own small collectives: gloo takes host tensors)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if device == "cuda":
+        if device == "cuda" and not args.share_gpu:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        elif args.share_gpu:
+            dist.init_process_group("gloo")
         else:
             dist.init_process_group(hooks.get("backend", "gloo"))
 
@@ -416,10 +423,10 @@ def main(argv=None, hooks=None):
             took, _, _ = run_steps(max(1, min(args.steps, 10)), "-", ["q3"], lambda q, rn=rn: rn.run(q, db))
             ms = took / max(1, min(args.steps, 10)) * 1e3
             if world > 1:
-                t = torch.tensor([ms], dtype=torch.float64, device=device)
+                t = torch.tensor([ms], dtype=torch.float64, device=coll_device)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 ms = float(t.item())
-                moved = torch.tensor([rn.exchanged_bytes], dtype=torch.float64, device=device)
+                moved = torch.tensor([rn.exchanged_bytes], dtype=torch.float64, device=coll_device)
                 dist.all_reduce(moved)
                 total_bytes = float(moved.item())
             else:
@@ -448,7 +455,7 @@ def main(argv=None, hooks=None):
     hbm = None
     try:                                                       # what the process holds of the GPU's HBM behind the timed region: columns at the reference's widths,
         import torch                                           # their twins and dictionaries, the pools' table memory, recorded plans, the runtime's own
-        free_b, total_b = torch.cuda.mem_get_info(int(os.environ.get("LOCAL_RANK", "0")) if use_dist else 0)
+        free_b, total_b = torch.cuda.mem_get_info(local_rank if use_dist else 0)
         hbm = {"in_use_GB": round((total_b - free_b) / 1e9, 2), "of_GB": round(total_b / 1e9, 1), "columns_at_reference_width_GB": round(int(eng.resident_bytes) / 1e9, 2)}
     except Exception as exc:                                   # (reporting only)
         hbm = {"error": str(exc)[:100]}
@@ -462,10 +469,10 @@ def main(argv=None, hooks=None):
     if world == 1 and not use_dist and "engine" not in hooks and not args.no_hash_path:
         hash_path = hash_path_leg(args, eng, db, rows, queries + extra, run_steps, finish)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        rows_t = torch.tensor([sum(scanned_rows(q, rows) for q in queries)], dtype=torch.float64, device=device)
+        rows_t = torch.tensor([sum(scanned_rows(q, rows) for q in queries)], dtype=torch.float64, device=coll_device)
         dist.all_reduce(rows_t)
         total_rows_per_step = float(rows_t.item())
     else:
@@ -615,6 +622,8 @@ def main(argv=None, hooks=None):
             out["specialised_kernels"] = {"compiled_by_hiprtc_in_this_process": int(c), "loaded_from_jit_cache": int(d)}
         except Exception:
             pass
+        if args.share_gpu:
+            out["share_gpu"] = "the %d ranks of this run SHARED one GPU (gloo between the processes, pinned host buffers): every plan and kernel of the N > 1 path, none of its transport; not a scaling figure" % world
         if world > 1 or use_dist:
             out["n_gpus_note"] = "ranks in this run: %d%s" % (world, "" if world > 1 else " (the distributed plan on a group of one; N > 1 was not run here)")
         if exchange is not None:

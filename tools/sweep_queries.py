@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Every query at a sweep of scale factors, the GPU engine against the CPU implementation of the ABI on the same generated tables —
 the planner's routes switch on sizes (row counts, group counts, key ranges, result sizes), and the golden vectors sit at three sizes
-only.  python tools/sweep_queries.py 0.05,0.3,2 [q1,q3,...]"""
+only.  python tools/sweep_queries.py 0.05,0.3,2 [q1,q3,...] [option=value,...]"""
 import os
 import sys
 import time
@@ -13,9 +13,13 @@ from sdqlpy_amd import abi, build, engine, frontend, tpch
 from sdqlpy_amd import tpch_queries as Q
 
 sfs = [float(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "0.05,0.3,2").split(",")]
-qs = (sys.argv[2].split(",") if len(sys.argv) > 2 else sorted(Q.QUERIES, key=lambda s: int(s[1:])))
+qs = (sys.argv[2].split(",") if len(sys.argv) > 2 and sys.argv[2] else sorted(Q.QUERIES, key=lambda s: int(s[1:])))
 hip = engine.Engine(abi.Library(build.HIP_LIB).context(device=0))
 cpu = engine.Engine(abi.Library(os.path.join(ROOT, "oracle", "libsdqloracle.so")).context(threads=32))
+for kv in (sys.argv[3].split(",") if len(sys.argv) > 3 and sys.argv[3] else []):      # options of the HIP context: "direct_index=0,row_index=0,grouped_index=0,feature_min_rows=0"
+    k, v = kv.split("=")
+    hip.ctx.set_option(k, int(v))
+    print("option", k, "=", v, flush=True)
 bad = 0
 for sf in sfs:
     db = tpch.generate(sf, tables=sorted(tpch.columns_for(qs)), columns=tpch.columns_for(qs))

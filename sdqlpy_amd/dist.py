@@ -62,13 +62,24 @@ class DistributedRunner:
         self.fast_runs = 0                  # partitioned joins that ran with device-sized exchanges / that had to be repeated with exact sizes
         self.fast_retries = 0
         self._stat_ring, self._stat_next = [], 0
-        if not (world == 1 and self.skip_trivial):
-            eng.nlanes = 1                                      # collectives and kernels are ordered on ONE stream (a group of one that skips its
-                                                                # collectives keeps the engine's lanes: only the join is bound to lane 0's stream)
-            eng.plan_graphs = 0                                 # ... and no plan is recorded on a stream RCCL's collectives are ordered on (a stream in
-                                                                # capture mode beside torch's / RCCL's use of it has never run anywhere)
         self.rank, self.world, self.group = rank, world, group
         self.backend = dist.get_backend(group)
+        # LANES (round 6): a SETTLED plan — device-sized exchanges, nothing read back — runs on one of the engine's lanes (a context of the
+        # family: a stream, a pool and result blocks of its own), torch's current stream being that lane's for the duration of the launch:
+        # a collective is ordered behind the kernels of ITS plan (torch makes RCCL's stream wait for, and be waited for by, the current
+        # stream), and the plans of a step share the chip as on one GPU.  Every rank issues its collectives in program order, on one
+        # communicator: the order RCCL executes them in is the same everywhere whatever the lanes.  First (exact) runs, range
+        # partitioning and everything on CPU tensors stay on lane 0.  OFF by default (SDQLPY_AMD_DIST_LANES=1 turns it on): measured on a
+        # group of one with its collectives issued, the q1+q3+q5 step is 1.37 ms with lanes and 1.21-1.38 without — the step is the HOST
+        # issuing ~70 calls and 8 collectives (tools/dist_call_times2.py: 0.15 + 0.44 + 0.41 ms to launch q1 / q3 / q5, 23 us of it per
+        # torch collective), and kernels that could overlap are waiting for their launches either way.
+        self.lanes = self.backend == "nccl" and os.environ.get("SDQLPY_AMD_DIST_LANES", "0") == "1"
+        if not (world == 1 and self.skip_trivial):
+            if not self.lanes:
+                eng.nlanes = 1                                  # collectives and kernels ordered on ONE stream
+            eng.plan_graphs = 0                                 # no plan is recorded on a stream RCCL's collectives are ordered on (a stream in
+                                                                # capture mode beside torch's / RCCL's use of it has never run anywhere)
+        self._plan_lane, self._lane_next, self._ext_streams = {}, 0, {}
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
         self.device = device
@@ -109,6 +120,37 @@ class DistributedRunner:
             self._ext_stream = torch.cuda.ExternalStream(int(self.ctx.stream()), device=self.device)
         return torch.cuda.stream(self._ext_stream)
 
+    def _lane_of(self, plan):
+        """The lane a settled plan runs on (assigned round robin, kept)."""
+        if not self.lanes or self.eng.nlanes <= 1:
+            return 0
+        k = self._plan_lane.get(id(plan))
+        if k is None:
+            k = self._plan_lane[id(plan)] = self._lane_next % self.eng.nlanes
+            self._lane_next += 1
+        return k
+
+    @contextlib.contextmanager
+    def _on_lane(self, k):
+        """Run a settled plan's launch on lane k: self.ctx is that lane's context and torch's current stream its stream for the duration
+        (everything the runner and the plan's seams call goes to that context; buffers are allocated — and reused — on that stream)."""
+        if k == 0:
+            yield
+            return
+        lane_ctx = self.eng.lane(k).ctx
+        ext = self._ext_streams.get(k)
+        if ext is None:
+            ext = self._ext_streams[k] = torch.cuda.ExternalStream(int(lane_ctx.stream()), device=self.device)
+        saved = (self.ctx, self._ext_stream)
+        self.ctx, self._ext_stream = lane_ctx, ext
+        lane_ctx.set_option("async_copies", 1)
+        try:
+            with torch.cuda.stream(ext):
+                yield
+        finally:
+            lane_ctx.set_option("async_copies", 0)
+            self.ctx, self._ext_stream = saved
+
     def _on_engine_stream(self):
         """Collective buffers must be allocated with the engine's stream current (see _run): asserted where they are made."""
         if self.backend == "nccl":
@@ -134,6 +176,7 @@ class DistributedRunner:
         self._plans.clear()
         self._stat_ring = []
         self._ext_stream = None
+        self._ext_streams = {}
 
     def _empty(self, n, dtype=torch.int64):
         """A collective buffer of n elements: device memory under RCCL, pinned host memory in the hybrid mode, plain host memory on CPU."""
@@ -755,7 +798,9 @@ class DistributedRunner:
         self._local_text = st.local_text
         if self.device_sized and not waited and top is None and st.fast_ok and st.measured and not (self.world == 1 and self.skip_trivial):
             try:
-                return self._chain_device_sized(st, plan, args)
+                lane = self._lane_of(plan)
+                with self._on_lane(lane):
+                    return self._chain_device_sized(st, plan, args, lane)
             except abi.SdqhError as exc:
                 if exc.code != abi.ERR_UNSUPPORTED:
                     raise
@@ -808,7 +853,7 @@ class DistributedRunner:
                     v.table.free()
 
     # ---- the chain with NO host wait between its first kernel and its result (round 6) ---------------------------------------------
-    def _chain_device_sized(self, st, plan, args):
+    def _chain_device_sized(self, st, plan, args, lane=0):
         """A settled chain — a first run has exchanged exact sizes and remembered them — as the ENGINE's own prepared plan (the
         single-GPU plan's kernels, its last loop launched and not waited for) with the exchanges at its seams, every one sized on the
         device:
@@ -826,7 +871,7 @@ class DistributedRunner:
         run.  Collectives per run: one per replicated table + one for the groups."""
         ctx, eng = self.ctx, self.eng
         G = self.world
-        pp = engine.prepared_plan(eng, plan, args, lane=0, member_only=st.member_only)      # (the chain's own choice of key sets: a set whose entries travel is a table)
+        pp = engine.prepared_plan(eng, plan, args, lane=lane, member_only=st.member_only)      # (the chain's own choice of key sets: a set whose entries travel is a table)
         self._on_engine_stream()
         dev = st.__dict__.get("dev_bufs")
         if dev is None:
@@ -1164,6 +1209,7 @@ class DistributedRunner:
         # the probe loop's own closure (fixed-shape route): run on rows that reached this rank through the exchange, it aggregates them
         # into the table and leaves the table marked as the engine's own step would, so the engine's K-F finishes the plan
         st.step_c = engine._prepare_scan_fixed(eng, c_op, tc, {b_op.out: None})
+        st.step_c_args = (c_op, tc, {b_op.out: None})           # (a settled join on another lane prepares the same closure on that lane's context)
 
         # ---- static facts, gathered once ---------------------------------------------------------
         a_lo, a_hi = st.key_a.minmax() if st.na else (abi.INT64_MAX, abi.INT64_MIN)
@@ -1331,7 +1377,10 @@ class DistributedRunner:
                 return pp.run(self._top, after=after, keep_tables=True, on_retry=collective_rerun)
             if self.device_sized and st.fast_ok and st.caps is not None and not waited:
                 try:
-                    return self._hash_join_device_sized(st, pp, plan, replicate_a, keep, collective_rerun)
+                    lane = self._lane_of(plan)
+                    with self._on_lane(lane):
+                        pp_lane = pp if lane == 0 else engine.prepared_plan(eng, plan, args, lane=lane)
+                        return self._hash_join_device_sized(st, pp_lane, plan, replicate_a, keep, collective_rerun)
                 except abi.SdqhError as exc:
                     if exc.code != abi.ERR_UNSUPPORTED:
                         raise
@@ -1489,7 +1538,14 @@ class DistributedRunner:
                         t.free()                                      # (the words it borrowed stay alive in `keep`)
             crecv[0].set_bounds(pad, hi_g)
             keep.extend(crecv)
-            res = st.step_c(env, rows=(G * cap_c, crecv[0], abi.make_tuple(st.step_c.tuple_shape, crecv[1:])))
+            step_c = st.step_c
+            if ctx is not self.eng.ctx:                          # (this join runs on a lane: its probe loop on that lane's context and stream)
+                by_ctx = st.__dict__.setdefault("step_c_lane", {})
+                step_c = by_ctx.get(id(ctx))
+                if step_c is None:
+                    lane_eng = next(self.eng.lane(k) for k in range(1, self.eng.nlanes) if self.eng.lane(k).ctx is ctx)
+                    step_c = by_ctx[id(ctx)] = engine._prepare_scan_fixed(lane_eng, *st.step_c_args)
+            res = step_c(env, rows=(G * cap_c, crecv[0], abi.make_tuple(step_c.tuple_shape, crecv[1:])))
             # the status: the largest counts made global, then to the host — queued, in front of the engine's K-F on the same stream
             if not trivial:
                 head = stat_t[:4]

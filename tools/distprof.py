@@ -47,7 +47,8 @@ for q in qs:
     for _ in range(50):
         finished(runner.run(q, db))
     pr.disable()
-    pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(40)
 runner.close()
 torch.cuda.synchronize()
 dist.destroy_process_group()

@@ -1427,14 +1427,16 @@ def test_settled_chains_world1_wait_for_nothing(hip_lib):
         eng.close()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_ranks_share_one_gpu(hip_engine, tmp_path, world):
+@pytest.mark.parametrize("world,shuffled", [(2, False), (3, False), (2, True)])
+def test_ranks_share_one_gpu(hip_engine, tmp_path, world, shuffled):
     """Round 6: N > 1 ON THE HARDWARE, as far as one GPU allows.  RCCL refuses two ranks on one device, so the ranks talk through gloo and
     the runner's HYBRID mode (sdqlpy_amd/dist.py): collective buffers in pinned host memory that the HIP kernels read and write through
     their device-visible addresses.  Everything but the transport is the N > 1 GPU path: the hash-partitioning pack into `world` chunks,
     chunks of several sources taken apart, replicated tables rebuilt from several ranks' entries, partial groups of several ranks folded
     on the device, bitmaps of several ranks reduced — on `world` processes with a HIP context each.  Every query three times per
-    partitioning (exact sizes, then twice settled) against the single-process HIP result on the whole database."""
+    partitioning (exact sizes, then twice settled) against the single-process HIP result on the whole database.  shuffled: every table's
+    rows dealt to the ranks at random — overlapping key ranges, nothing co-partitioned: every looked-up build replicated, the join
+    hash-partitioned whatever was asked for."""
     import json
     import os
     import socket
@@ -1446,8 +1448,8 @@ def test_ranks_share_one_gpu(hip_engine, tmp_path, world):
         port = sk.getsockname()[1]
     out = str(tmp_path / "ranks.json")
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_gpu_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(sf), out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-             for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(sf), out] + (["", "auto", "", "shuffled"] if shuffled else []),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs = [p.communicate(timeout=900)[0] for p in procs]
     for p, log in zip(procs, logs):
         assert p.returncode == 0, log[-4000:]
@@ -1463,22 +1465,25 @@ def test_ranks_share_one_gpu(hip_engine, tmp_path, world):
     n = 0
     for tag, res in got["runs"].items():
         part, q, again = tag.split("/")
+        assert "unsupported" not in res, (tag, res)
         if "scalar" in res:
             assert abs(res["scalar"] - want[q]) <= REL * abs(want[q]), (tag, res["scalar"], want[q])
         else:
             helpers.assert_rows_match(sorted(tuple(r) for r in res["rows"]), helpers.result_rows(want[q], res["columns"]), REL, "world %d/%s" % (world, tag))
             if q == "q3":
-                assert res["partitioning"] == {"hash": "hash", "auto": "range"}[part], (tag, res["partitioning"])
-                if part == "hash":
+                assert res["partitioning"] == ("hash" if shuffled else {"hash": "hash", "auto": "range"}[part]), (tag, res["partitioning"])
+                if res["partitioning"] == "hash":
                     assert res["exchanged"]["build"] > 30_000 and res["exchanged"]["probe_sent"] > 5_000, (tag, res["exchanged"])
-            if q in ("q1", "q5") and again != "0":
+            if q == "q1" and again != "0":
                 assert res["seams"].get("plan") == q and res["seams"]["folded"] and not res["seams"]["merged_on_host"], (tag, res["seams"])
-            if q == "q5" and again != "0":
+            if q == "q5" and again != "0" and not shuffled:
+                assert res["seams"].get("plan") == q and res["seams"]["folded"] and not res["seams"]["merged_on_host"], (tag, res["seams"])
                 assert "supplier_nations" in res["seams"]["replicated"] and "asian_customers" in res["seams"]["replicated"], (tag, res["seams"])
         n += 1
-    assert n == 2 * len(qs) * 3
-    for part in ("hash", "auto"):
-        assert got[part]["fast_retries"] == 0 and got[part]["fast_runs"] >= 8, got[part]
+    parts = ("auto",) if shuffled else ("hash", "auto")
+    assert n == len(parts) * len(qs) * 3
+    for part in parts:
+        assert got[part]["fast_retries"] == 0 and got[part]["fast_runs"] >= (4 if shuffled else 8), got[part]
     hip_engine.clear()
 
 

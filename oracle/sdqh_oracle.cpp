@@ -10,7 +10,10 @@
 // outputs on generated inputs are committed as tests/golden/tpch_golden.json by
 // tests/golden/make_golden.py; tests/test_oracle_golden.py checks this file against every one of
 // them (ints exact; with threads = 1 the doubles are bit-identical because the summation order is
-// row order, exactly the interpreter's: reference src/sdqlpy/sdql_lib.py:220-236).
+// row order, exactly the interpreter's: reference src/sdqlpy/sdql_lib.py:220-236).  The other goldens are pinned the same way:
+// tpch_golden_more.json / _wide.json (the remaining 16 queries at three sizes) and, since round 6, tpch_golden_sf1.json.gz — the
+// reference's results for all 21 queries at SF=1 (6 M lineitem rows) and with keys beyond 2^40 at SF=0.1 / SF=1, the sizes at
+// which the product's size-dependent paths engage (make_golden.py --sf1; test_oracle_reproduces_reference_at_sf1: bit for bit).
 //
 // The reference's compiled (TBB + phmap) mode is NOT buildable here: its generator needs Python
 // 3.8's ast.Index, the emitted C++ needs TBB headers (task_scheduler_init was removed from oneTBB)

@@ -1372,6 +1372,104 @@ def test_distributed_plans_world1_full_size(hip_lib):
         eng.close()
 
 
+def test_groups_of_many_ranks_folded_on_the_device(hip_engine):
+    """sdqh_xgroupby_fold by itself (round 6): up to 64 ranks' group tables — laid out like the device result block: 512 key slots, four
+    sums and a count per slot, flags — folded by key, block after block.  Against numpy folding the same blocks in the same order: the
+    same BITS (a group's sums are ((block 0 + block 1) + block 2) ...), whatever slot a key sits in in each block; groups whose count is
+    zero are no groups; more than 256 distinct keys over all blocks, or a block that reported an overflow itself: SDQH_ERR_OVERFLOW
+    when the result is collected."""
+    import ctypes as C
+    from sdqlpy_amd import abi
+    ctx = hip_engine.ctx
+    nbytes = ctx.xgroupby_block_bytes()
+    words, slots = nbytes // 8, 512
+    assert slots * 48 + 8 <= nbytes
+    rng = np.random.default_rng(21)
+    EMPTY = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+    def make_blocks(nblocks, universe, per_block, flags=None):
+        raw = np.zeros((nblocks, words), np.uint64)
+        folded = {}
+        for b in range(nblocks):
+            keys = rng.choice(universe, size=min(per_block, len(universe)), replace=False)
+            at = rng.choice(slots, size=len(keys), replace=False)                      # any slot: the fold goes by key
+            blk = raw[b]
+            blk[:slots] = EMPTY
+            acc = blk[slots:slots * 5].view(np.float64).reshape(slots, 4)
+            cnt = blk[slots * 5:slots * 6].view(np.int64)
+            for k, s_ in zip(keys, at):
+                v = rng.normal(size=4) * 10.0 ** rng.integers(-3, 9)
+                c = int(rng.integers(0, 5))                                               # (a slot whose count is 0 holds no group)
+                blk[s_] = np.uint64(k); acc[s_] = v; cnt[s_] = c
+                if c > 0:
+                    cur = folded.get(int(k))
+                    folded[int(k)] = (v.copy(), c) if cur is None else (cur[0] + v, cur[1] + c)
+            if flags is not None:
+                blk[slots * 6:slots * 6 + 1].view(np.int32)[0] = flags[b]
+        return raw, folded
+
+    def fold(raw):
+        col = ctx.upload(np.ascontiguousarray(raw.reshape(-1).view(np.int64)))
+        buf = ctx.host_block(nbytes)
+        ctx._check(ctx.lib.sdqh_xgroupby_fold(ctx.handle, C.c_void_p(col.data_ptr()), C.c_int(raw.shape[0]), C.addressof(buf)))
+        keys, vals, cnts, ng = np.zeros(256, np.int64), np.zeros((256, 4), np.float64), np.zeros(256, np.int64), C.c_int32()
+        rc = ctx.lib.sdqh_xgroupby_collect(ctx.handle, C.addressof(buf), C.c_int(4), C.c_int(256), keys.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p),
+                                           cnts.ctypes.data_as(C.c_void_p), C.byref(ng))
+        col.free()
+        return rc, keys[:ng.value], vals[:ng.value], cnts[:ng.value]
+
+    for nblocks, nuniverse, per_block in ((1, 40, 40), (2, 6, 4), (8, 200, 120), (64, 256, 256), (64, 5, 5), (33, 250, 17)):
+        universe = rng.choice(1 << 40, size=nuniverse, replace=False).astype(np.int64)
+        raw, want = make_blocks(nblocks, universe, per_block)
+        rc, keys, vals, cnts = fold(raw)
+        assert rc == abi.OK, (nblocks, rc)
+        assert sorted(keys.tolist()) == sorted(want), (nblocks, len(keys), len(want))
+        for k, v, c in zip(keys.tolist(), vals, cnts.tolist()):
+            assert c == want[k][1] and np.array_equal(v, want[k][0]), (nblocks, k, v, want[k])      # the same bits: the same order of adds
+    # more than 256 groups over all blocks; a block that overflowed by itself
+    universe = np.arange(1000, 1000 + 400, dtype=np.int64)
+    raw, _ = make_blocks(4, universe, 200)
+    assert fold(raw)[0] == abi.ERR_OVERFLOW
+    raw, _ = make_blocks(3, universe[:10], 5, flags=[0, 1, 0])
+    assert fold(raw)[0] == abi.ERR_OVERFLOW
+
+
+def test_one_part_pack_keeps_the_build_order(hip_engine):
+    """sdqh_table_partition_pack with ONE part (round 6: the send buffer of an all-gather): the chunk holds the table's entries in the
+    order the build met them — key, then every payload column, `chunk_rows` apart behind the two header words — the same bytes run
+    after run; the header counts every entry even when the chunk is too small to hold them all (the overflow the receiver reports)."""
+    from sdqlpy_amd import abi
+    ctx = hip_engine.ctx
+    rng = np.random.default_rng(8)
+    for n, keep in ((1, 1.0), (777, 0.5), (300_000, 0.3), (2_000_001, 0.02)):
+        keys = np.sort(rng.choice(1 << 40, size=n, replace=False)).astype(np.int64)
+        p0, p1 = rng.integers(-1 << 50, 1 << 50, size=n), rng.integers(0, 100, size=n)
+        gate = rng.random(n) < keep
+        gate[0] = True
+        ck, c0, c1, cg = ctx.upload(keys), ctx.upload(p0), ctx.upload(p1), ctx.upload(gate.astype(np.int64))
+        table = ctx.hash_build_unique(n, abi.make_filter([(cg, 1, 1)], [], []), [], ck, [c0, c1])
+        want = [keys[gate], p0[gate], p1[gate]]
+        m = int(gate.sum())
+        for cap in (m + 10, max(1, m // 2)):
+            cw = ctx.chunk_words(3, cap)
+            raws = []
+            for again in range(2):
+                buf = ctx.alloc(cw, abi.I64)
+                ctx.table_partition_pack(table, 1, cap, buf.data_ptr())
+                ctx.synchronize()
+                raws.append(buf.download())
+                buf.free()
+            raw = raws[0]
+            assert int(raw[0]) == m and int(raw[1]) == 0, (n, cap, raw[:2])
+            stored = min(m, cap)
+            for c, w in enumerate(want):
+                assert np.array_equal(raw[2 + c * cap: 2 + c * cap + stored], w[:stored]), (n, cap, c)
+                assert np.array_equal(raws[1][2 + c * cap: 2 + c * cap + stored], w[:stored])
+        table.free()
+        for c in (ck, c0, c1, cg):
+            c.free()
+
+
 def test_settled_chains_world1_wait_for_nothing(hip_lib):
     """Round 6: the chain plans (q1, q5, q9) at SF=10 on an RCCL group of one whose collectives are ISSUED, from their second run on: a
     replicated table travels as one fixed-capacity chunk behind one all-gather (sdqh_table_partition_pack with one part /

@@ -205,7 +205,7 @@ void*       sdqh_stream(const sdqh_ctx* ctx);
  * index when (estimated keys of the table) x this <= rows of the loop; 0 = never, 1 = whenever the table holds fewer keys than rows),
  * "delta8" (1: queue programs stream a key column whose aligned 8-row groups span at most 255 through its delta twin, 12 bytes per 8 rows),
  * "word_pairs" (0: whole-table builds keyed by a strictly increasing column also keep { first row, bits } pairs per bitmap word);
- * round 6: "hash_filter" (1: a hash-layout table carries a hashed filter — 8 to 16 bits per key, two bits of one word per key, L2-sized — that
+ * round 6: "pack_ordered" (1: sdqh_table_partition_pack places rows deterministically, see there), "hash_filter" (1: a hash-layout table carries a hashed filter — 8 to 16 bits per key, two bits of one word per key, L2-sized — that
  * row programs test on streamed registers in front of the slots, as they test an exact key bitmap), "pool_trim" (an action, value 1: waits for the context's stream and returns the cached free blocks of its device-memory
  * pool to the runtime — a pool never shrinks by itself).
  * The CPU build accepts and ignores any name. */
@@ -619,9 +619,10 @@ int64_t sdqh_chunk_words(int ncols, int64_t chunk_rows);
  * sdqh_xstage — partitioned by their key (mix64(key) % nparts, or range_upper as in sdqh_partition_by_key) into the nparts chunks of
  * `packed` (nparts * sdqh_chunk_words(1 + npayload, chunk_rows) words of device memory; CPU build: host), chunk p at word
  * p * sdqh_chunk_words(...): the layout of an equal-split all-to-all.  A chunk's header counts every row meant for it; rows beyond
- * chunk_rows are dropped.  Rows keep no particular order inside a chunk — except with nparts = 1 (round 6: the send buffer of an
- * ALL-GATHER, a replicated build's entries): then the one chunk holds the table's entries in the order the build met them, the same
- * bytes run after run.  Queued on the ctx stream; nothing is waited for.
+ * chunk_rows are dropped.  Round 6: a chunk's rows are placed DETERMINISTICALLY — the same bytes run after run (option "pack_ordered", 1:
+ * every wave counts its rows per part, one workgroup per part scans the counts, every wave places its rows from its own cursor: three
+ * launches, no atomics; 0: one launch, rows placed by racing atomics) — and with nparts = 1 (the send buffer of an ALL-GATHER: a
+ * replicated build's entries) in the order the build met them.  Queued on the ctx stream; nothing is waited for.
  * SDQH_ERR_UNSUPPORTED: a table whose staged rows may repeat a key (use sdqh_table_entries + sdqh_partition_pack) — a unique build
  * qualifies when its key is a strictly increasing column, or two plain columns that strictly increase as pairs. */
 int sdqh_table_partition_pack(sdqh_ctx* ctx, const sdqh_table* table, int nparts, const int64_t* range_upper, int64_t chunk_rows, void* packed);

@@ -116,6 +116,99 @@ __global__ __launch_bounds__(TPB) void k_stage_part_pack(DevStage st, DevPartiti
     }
 }
 
+// ---- the same scatter, DETERMINISTIC (round 6; round-5 advice: the kernel above places rows by racing atomics — across the four waves of a
+// workgroup and, for the chunk cursors, across workgroups — so the order of a chunk's rows changed from run to run, and with it the order in
+// which the received probe rows reach the f64 atomics of the join's sink).  Three launches: every WAVE counts its rows per part
+// (k_stage_part_count: the rows it will also place — the 64-row batches w, w + 4, ... of its workgroup's segments), one workgroup per part
+// scans the waves' counts (k_stage_part_scan: a wave's first place in the chunk, and the chunk's header = every row meant for it), every
+// wave places its rows from its own cursor (k_stage_part_place: no atomics; the lanes of a batch that go to one part take consecutive places
+// in lane order).  A chunk's rows are then in (workgroup, wave, batch, lane) order: the same bytes run after run.
+template <bool PLACE>
+__global__ __launch_bounds__(TPB) void k_stage_part_walk(DevStage st, DevPartition pt, int ncols, int64_t chunk_rows, int64_t chunk_words,
+                                                         uint32_t* __restrict__ counts, const uint32_t* __restrict__ base, int nwaves, int64_t* __restrict__ packed) {
+    __shared__ unsigned int s_cur[TPB / WAVE][SDQH_MAX_PARTS];
+    const int wave = (int)(threadIdx.x / WAVE), lane = (int)(threadIdx.x & (WAVE - 1));
+    const int gw = (int)blockIdx.x * (TPB / WAVE) + wave;                  // this wave's number among all the launch's waves
+    if (lane < pt.nparts) s_cur[wave][lane] = PLACE ? base[(size_t)lane * nwaves + gw] : 0u;
+    __builtin_amdgcn_wave_barrier();
+    const int seg0 = (int)blockIdx.x * PP_SEGS;
+    uint32_t cnt[PP_SEGS];
+#pragma unroll
+    for (int j = 0; j < PP_SEGS; ++j) cnt[j] = seg0 + j < st.nseg ? st.seg_count[seg0 + j] : 0u;
+    uint32_t most = 0;
+#pragma unroll
+    for (int j = 0; j < PP_SEGS; ++j) most = cnt[j] > most ? cnt[j] : most;
+    for (uint32_t i0 = (uint32_t)wave * WAVE; i0 < most; i0 += TPB) {
+        int64_t keys[PP_SEGS];
+        bool lives[PP_SEGS];
+#pragma unroll
+        for (int j = 0; j < PP_SEGS; ++j) {
+            lives[j] = i0 + lane < cnt[j];
+            keys[j] = lives[j] ? st.key[(int64_t)(seg0 + j) * st.seg_rows + i0 + lane] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < PP_SEGS; ++j) {
+            if (i0 >= cnt[j]) continue;                                    // (wave-uniform)
+            const bool live = lives[j];
+            const int64_t row = (int64_t)(seg0 + j) * st.seg_rows + i0 + lane;
+            const int64_t key = keys[j];
+            const int part = live ? part_of(pt, key) : -1;
+            unsigned long long todo = __ballot(live);
+            while (todo) {                                                 // one round per distinct part among the wave's rows
+                const int leader = __builtin_ctzll(todo);
+                const int p = __shfl(part, leader, WAVE);
+                const unsigned long long mine = __ballot(live && part == p);
+                const unsigned int first = s_cur[wave][p];                 // (this wave's own cell: plain LDS reads and writes, in program order)
+                if (PLACE && live && part == p) {
+                    const uint64_t at = (uint64_t)first + (unsigned int)__builtin_popcountll(mine & ((1ull << lane) - 1ull));
+                    if (at < (uint64_t)chunk_rows) {
+                        int64_t* chunk = packed + (int64_t)part * chunk_words + 2;
+                        chunk[at] = key;
+#pragma unroll
+                        for (int c = 1; c < SDQH_MAX_COMPACT_COLS; ++c) if (c < ncols) chunk[(int64_t)c * chunk_rows + at] = st.pay[c - 1][row];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane == leader) s_cur[wave][p] = first + (unsigned int)__builtin_popcountll(mine);
+                __builtin_amdgcn_wave_barrier();
+                todo &= ~mine;
+            }
+        }
+    }
+    if (!PLACE && lane < pt.nparts) counts[(size_t)lane * nwaves + gw] = s_cur[wave][lane];
+}
+// one workgroup per part: the exclusive scan of the waves' counts for that part (in place: counts -> bases), the part's total into its chunk header
+__global__ __launch_bounds__(TPB) void k_stage_part_scan(uint32_t* __restrict__ counts, int nwaves, int64_t chunk_words, int64_t* __restrict__ packed) {
+    constexpr int PER = 16;
+    __shared__ unsigned long long s_scan[TPB];
+    __shared__ unsigned long long s_base;
+    uint32_t* row = counts + (size_t)blockIdx.x * nwaves;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < nwaves; i0 += TPB * PER) {
+        const int first = i0 + (int)threadIdx.x * PER;
+        uint32_t c[PER];
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { c[j] = first + j < nwaves ? row[first + j] : 0u; mine += c[j]; }
+        s_scan[threadIdx.x] = mine;
+        __syncthreads();
+        for (int off = 1; off < TPB; off <<= 1) {
+            const unsigned long long v = (int)threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0ull;
+            __syncthreads();
+            s_scan[threadIdx.x] += v;
+            __syncthreads();
+        }
+        unsigned long long at = s_base + s_scan[threadIdx.x] - mine;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { if (first + j < nwaves) row[first + j] = (uint32_t)(at > 0xFFFFFFFFull ? 0xFFFFFFFFull : at); at += c[j]; }
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += s_scan[TPB - 1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { packed[(int64_t)blockIdx.x * chunk_words] = (int64_t)s_base; packed[(int64_t)blockIdx.x * chunk_words + 1] = 0; }
+}
+
 // ONE part (an all-gather's send buffer: this rank's entries, whole): the stage's segments back to back IN STAGE ORDER — a scan of the
 // segments' live counts, then every wave copies its segment to its place.  Deterministic, and what was in row order stays in row
 // order: the replica a receiver rebuilds from the ranks' chunks (rank after rank) sees the table's rows in the table's order.
@@ -459,6 +552,7 @@ int sdqh_table_compact_deferred(sdqh_ctx* ctx, const sdqh_table* ctable, int64_t
 // ---- device-sized redistribution --------------------------------------------------------------------------------------------------------
 int64_t sdqh_chunk_words(int ncols, int64_t chunk_rows) { return (ncols < 1 || chunk_rows < 0) ? -1 : 2 + (int64_t)ncols * chunk_rows; }
 
+static unsigned grid_of_pack(int nseg) { return (unsigned)std::max(1, (nseg + PP_SEGS - 1) / PP_SEGS); }
 int sdqh_table_partition_pack(sdqh_ctx* ctx, const sdqh_table* table, int nparts, const int64_t* range_upper, int64_t chunk_rows, void* packed) {
     if (!ctx || !table || nparts < 1 || nparts > SDQH_MAX_PARTS || chunk_rows < 1 || !packed) return fail(ctx, SDQH_ERR_INVALID, "table_partition_pack: bad arguments");
     if (table->bitmap_only || !table->stage.seg_count || !table->stage.key) return fail(ctx, SDQH_ERR_INVALID, "table_partition_pack: not a staged table");
@@ -479,6 +573,23 @@ int sdqh_table_partition_pack(sdqh_ctx* ctx, const sdqh_table* table, int nparts
         { KernelScope ks(ctx, "k_stage_pack_copy");
           hipLaunchKernelGGL(k_stage_pack_copy, dim3((unsigned)((table->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE))), dim3(TPB), 0, ctx->stream, table->stage, offs, ncols, chunk_rows, static_cast<int64_t*>(packed)); }
         pool_free(ctx, offs);                                          // (stream order: whoever gets the block next runs behind the copy)
+        call_end(ctx);
+        if (hipGetLastError() != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, "table_partition_pack: launch failed");
+        return SDQH_OK;
+    }
+    if (ctx->opt_pack_ordered) {
+        // deterministic placement: count per wave, scan per part, place (no atomics; the chunk headers are written by the scan)
+        const int nwaves = (int)grid_of_pack(table->stage.nseg) * (TPB / WAVE);
+        uint32_t* counts = static_cast<uint32_t*>(pool_alloc(ctx, (size_t)nparts * (size_t)nwaves * 4 + 64));
+        if (!counts) return fail(ctx, SDQH_ERR_NOMEM, "table_partition_pack: out of device memory");
+        const unsigned grid = grid_of_pack(table->stage.nseg);
+        { KernelScope ks(ctx, "k_stage_part_count");
+          hipLaunchKernelGGL(k_stage_part_walk<false>, dim3(grid), dim3(TPB), 0, ctx->stream, table->stage, pt, ncols, chunk_rows, cw, counts, static_cast<const uint32_t*>(counts), nwaves, static_cast<int64_t*>(packed)); }
+        { KernelScope ks(ctx, "k_stage_part_scan");
+          hipLaunchKernelGGL(k_stage_part_scan, dim3((unsigned)nparts), dim3(TPB), 0, ctx->stream, counts, nwaves, cw, static_cast<int64_t*>(packed)); }
+        { KernelScope ks(ctx, "k_stage_part_place");
+          hipLaunchKernelGGL(k_stage_part_walk<true>, dim3(grid), dim3(TPB), 0, ctx->stream, table->stage, pt, ncols, chunk_rows, cw, counts, static_cast<const uint32_t*>(counts), nwaves, static_cast<int64_t*>(packed)); }
+        pool_free(ctx, counts);                                        // (stream order)
         call_end(ctx);
         if (hipGetLastError() != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, "table_partition_pack: launch failed");
         return SDQH_OK;

@@ -730,6 +730,7 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     else if (n == "index_inline" && (value == 0 || value == 1)) ctx->opt_index_inline = (int)value;
     else if (n == "groupby_regs" && (value == 0 || value == 4 || value == 8)) ctx->opt_groupby_regs = (int)value;
     else if (n == "hash_filter" && (value == 0 || value == 1)) ctx->opt_hash_filter = (int)value;
+    else if (n == "pack_ordered" && (value == 0 || value == 1)) ctx->opt_pack_ordered = (int)value;
     else if (n == "pool_trim" && value == 1) {
         // give the cached FREE blocks of this context's pool back to the runtime (the pool never shrinks by itself: 288 GB make head-room
         // cheap — until the next workload needs the memory another context's pool is sitting on).  Waits for the stream first.

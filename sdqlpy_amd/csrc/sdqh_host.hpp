@@ -151,6 +151,7 @@ struct sdqh_ctx {
     struct RowPack { std::vector<const void*> cols; int64_t nrows; int k; void* data; const void* order_col = nullptr; void* key32 = nullptr;
                      void* lb = nullptr; int64_t key_lo = 0, key_hi = -1; };      // lb: per key value of [key_lo, key_hi + 1] the first pack row holding a key >= it
     std::vector<RowPack> packs;                    // resident row packs, by column set (and order)
+    int opt_pack_ordered = 1;                      // sdqh_table_partition_pack places a chunk's rows deterministically (count / scan / place: three launches); 0: one launch, racing atomics
     int opt_hash_filter = 1;                       // hash-layout tables carry a hashed filter (DevTable::hf) that loops test on streamed registers in front of the slots
     int opt_cluster_list = 1;                      // ... and walks the first table's key bitmap and the pack's runs (k_lookup_agg: RUN WALK) instead of streaming the ordered keys
     int opt_cluster_pack = 1;                      // a final loop whose first lookup's key column comes in no row order, whose scan has no predicate and whose gathered columns are all

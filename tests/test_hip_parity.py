@@ -1470,6 +1470,67 @@ def test_one_part_pack_keeps_the_build_order(hip_engine):
             c.free()
 
 
+def test_multi_part_pack_is_deterministic(hip_engine):
+    """sdqh_table_partition_pack with several parts (the send buffer of the hash-partitioned join's all-to-all): every chunk holds exactly
+    the entries whose key hashes to its part (mix64(key) % nparts), its header their count — and, round 6, the SAME BYTES run after run:
+    rows are placed from per-wave cursors that a scan of per-wave counts fixes, not by racing atomics (option "pack_ordered"; with it
+    off the same rows arrive in whatever order)."""
+    from sdqlpy_amd import abi
+    ctx = hip_engine.ctx
+    rng = np.random.default_rng(12)
+
+    def mix64(x):
+        x = x.astype(np.uint64)
+        x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+        return x
+
+    try:
+        for n, nparts in ((5, 2), (70_000, 3), (1_500_000, 8), (400_000, 64)):
+            keys = np.sort(rng.choice(1 << 44, size=n, replace=False)).astype(np.int64)
+            p0 = rng.integers(-1 << 40, 1 << 40, size=n)
+            ck, c0 = ctx.upload(keys), ctx.upload(p0)
+            table = ctx.hash_build_unique(n, abi.make_filter(), [], ck, [c0])
+            part = (mix64(keys) % np.uint64(nparts)).astype(np.int64)
+            cap = int(np.bincount(part, minlength=nparts).max()) + 7
+            cw = ctx.chunk_words(2, cap)
+            runs = {}
+            for ordered in (1, 1, 0):
+                ctx.set_option("pack_ordered", ordered)
+                buf = ctx.alloc(nparts * cw, abi.I64)
+                ctx.table_partition_pack(table, nparts, cap, buf.data_ptr())
+                ctx.synchronize()
+                runs.setdefault(ordered, []).append(buf.download())
+                buf.free()
+            assert np.array_equal(runs[1][0], runs[1][1]) or _same_chunks(runs[1][0], runs[1][1], nparts, cw, cap, exact=True), (n, nparts)
+            for raw in (runs[1][0], runs[0][0]):
+                for p in range(nparts):
+                    chunk = raw[p * cw:(p + 1) * cw]
+                    m = int(chunk[0])
+                    want = keys[part == p]
+                    assert m == len(want), (n, nparts, p, m, len(want))
+                    got_k, got_p = chunk[2:2 + m], chunk[2 + cap:2 + cap + m]
+                    order = np.argsort(got_k, kind="stable")
+                    assert np.array_equal(got_k[order], want) and np.array_equal(got_p[order], p0[part == p]), (n, nparts, p)
+            table.free(); ck.free(); c0.free()
+    finally:
+        ctx.set_option("pack_ordered", 1)
+
+
+def _same_chunks(a, b, nparts, cw, cap, exact):
+    """The live words of two packed buffers (headers and the rows they count; the words behind a chunk's last row are whatever the pool held)."""
+    for p in range(nparts):
+        ca, cb = a[p * cw:(p + 1) * cw], b[p * cw:(p + 1) * cw]
+        m = int(ca[0])
+        if m != int(cb[0]):
+            return False
+        for c in range((cw - 2) // cap):
+            if not np.array_equal(ca[2 + c * cap:2 + c * cap + m], cb[2 + c * cap:2 + c * cap + m]):
+                return False
+    return True
+
+
 def test_settled_chains_world1_wait_for_nothing(hip_lib):
     """Round 6: the chain plans (q1, q5, q9) at SF=10 on an RCCL group of one whose collectives are ISSUED, from their second run on: a
     replicated table travels as one fixed-capacity chunk behind one all-gather (sdqh_table_partition_pack with one part /
@@ -1578,6 +1639,12 @@ def test_ranks_share_one_gpu(hip_engine, tmp_path, world, shuffled):
                 assert res["seams"].get("plan") == q and res["seams"]["folded"] and not res["seams"]["merged_on_host"], (tag, res["seams"])
                 assert "supplier_nations" in res["seams"]["replicated"] and "asian_customers" in res["seams"]["replicated"], (tag, res["seams"])
         n += 1
+    # the hash-partitioned join's settled runs: the same BITS (the pack places every row deterministically — round-5 advice — so the received
+    # probe rows meet the sink's f64 atomics in the same arrangement run after run)
+    # (clustered shards: an order's lines reach the sink in neighbouring lanes and are summed before the one atomic that adds them; dealt at
+    #  random they arrive apart, three or more atomics of different waves may add to one group, and no placement fixes THEIR order)
+    if not shuffled:
+        assert got["runs"]["hash/q3/1"]["rows"] == got["runs"]["hash/q3/2"]["rows"]
     parts = ("auto",) if shuffled else ("hash", "auto")
     assert n == len(parts) * len(qs) * 3
     for part in parts:

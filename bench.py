@@ -632,6 +632,10 @@ def main(argv=None, hooks=None):
             out["collectives_in_timed_region_rank0"] = timed_collectives
             out["distributed_plan"] = {"device_sized_join_runs": runner.fast_runs, "repeated_with_exact_sizes": runner.fast_retries,
                                        "collectives_over_a_group_of_one": "skipped" if (world == 1 and runner.skip_trivial) else "issued"}
+        if hip_results:
+            ref = reference_at_bench_size(hip_results, sf_per_gpu, rows)
+            if ref is not None:
+                out["reference_at_bench_size"] = ref
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, queries, db, rows, hip_results)
             out["cpu_baseline"]["configs0_q6_sf1"] = q6_sf1_leg(eng)
@@ -943,6 +947,46 @@ def pmc_traffic(q, kernel, rows, ran=None, which="pmc_traffic"):
         return entry.get("hbm_bytes_per_run"), source
     k = entry.get("kernels", {}).get(kernel)
     return (k.get("hbm_bytes_per_launch") if k else None), source
+
+
+def reference_at_bench_size(hip_results, sf, rows):
+    """The timed step's results against the REFERENCE's own, where the reference was run on exactly these inputs: tests/golden/
+    tpch_golden_sf10.json.gz holds what its Python-mode interpreter returned for q1 / q3 / q5 / q6 / q9 on this generator's SF=10
+    tables (tests/golden/make_golden.py --sf10, run once in the build container; a fixture — the reference itself never travels).
+    Rows, keys and counts must be equal, sums within 1e-6 relative (north_star); the largest relative difference is printed."""
+    import gzip
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "tpch_golden_sf10.json.gz")
+    if abs(sf - 10.0) > 1e-9 or not os.path.exists(path):
+        return None
+    with gzip.open(path, "rt") as fh:
+        case = json.load(fh)["cases"][0]
+    if any(case["rows"].get(t) != rows.get(t) for t in case["rows"]):
+        return {"skipped": "the generated tables are not the golden case's (row counts differ)"}
+    out = {"source": "edin-dal/sdqlpy Python mode on the same generated SF=10 tables (tests/golden/tpch_golden_sf10.json.gz)", "queries": {}}
+    dec = lambda v: float.fromhex(v["f"]) if isinstance(v, dict) else v      # noqa: E731
+    for q, res in hip_results.items():
+        gold = case["results"].get(q)
+        if gold is None:
+            continue
+        if gold["kind"] == "scalar":
+            want = dec(gold["value"])
+            out["queries"][q] = {"rows_equal": True, "max_rel": abs(float(res) - want) / abs(want) if want else abs(float(res) - want)}
+            continue
+        cols = gold["columns"]
+        want = [tuple(dec(x) for x in row) for row in gold["rows"]]
+        got = sorted(zip(*[np.asarray(res.column(c)).tolist() for c in cols]))
+        want.sort()
+        ok, max_rel = len(got) == len(want), 0.0
+        if ok:
+            for a, b in zip(got, want):
+                for x, y in zip(a, b):
+                    if isinstance(y, float):
+                        max_rel = max(max_rel, abs(x - y) / max(abs(x), abs(y), 1e-300))
+                    elif x != y:
+                        ok = False
+        out["queries"][q] = {"rows": len(got), "rows_equal": bool(ok), "max_rel": max_rel, "within_1e-6": bool(ok and max_rel <= 1e-6)}
+    return out
 
 
 def physical_cores():

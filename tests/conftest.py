@@ -58,3 +58,12 @@ def golden_sf1():
     import gzip
     with gzip.open(os.path.join(ROOT, "tests", "golden", "tpch_golden_sf1.json.gz"), "rt") as fh:
         return json.load(fh)
+
+
+@pytest.fixture(scope="session")
+def golden_sf10():
+    """The reference's own results for the five configured queries at BASELINE.json's size, SF=10 (60 M lineitem rows): make_golden.py --sf10
+    (a quarter of an hour of its interpreter per query).  Checked on the GPU box (tests/test_hip_parity.py) and by bench.py itself."""
+    import gzip
+    with gzip.open(os.path.join(ROOT, "tests", "golden", "tpch_golden_sf10.json.gz"), "rt") as fh:
+        return json.load(fh)

@@ -281,15 +281,26 @@ def _one(job):
     return name, q, r
 
 
+# BASELINE.json's own size: the five configured queries at SF=10 (60 M lineitem rows) through the reference's interpreter — q1 alone takes it
+# a quarter of an hour.   python tests/golden/make_golden.py --sf10 [--jobs 5]  -> tpch_golden_sf10.json.gz (q3's 113 K rows: 1.5 MB compressed)
+SF10_CASES = [
+    ("sf10", 10.0, "base", QUERIES),
+]
+
+
 def main_sf1():
     import multiprocessing as mp
+    global SF1_CASES
+    sf10 = "--sf10" in sys.argv
+    if sf10:
+        SF1_CASES = SF10_CASES
     jobs_n = int(sys.argv[sys.argv.index("--jobs") + 1]) if "--jobs" in sys.argv else 6
     jobs = [(name, sf, variant, q) for name, sf, variant, qs in SF1_CASES for q in qs]
     with mp.get_context("spawn").Pool(jobs_n, maxtasksperchild=1) as pool:
         done = pool.map(_one, jobs, chunksize=1)
     out = {"meta": {"generator_seed": tpch.DEFAULT_SEED,
                     "reference": "edin-dal/sdqlpy Python mode (sdqlpy_init(0,1)), queries from test/test_all.py",
-                    "made_by": "tests/golden/make_golden.py --sf1"},
+                    "made_by": "tests/golden/make_golden.py " + ("--sf10" if "--sf10" in sys.argv else "--sf1")},
            "cases": []}
     for name, sf, variant, qs in SF1_CASES:
         tables = sorted({t for q in qs for t in QUERY_TABLES[q]})
@@ -301,14 +312,14 @@ def main_sf1():
                 "results": {q: r for n, q, r in done if n == name}}
         out["cases"].append(case)
     import gzip
-    path = os.path.join(HERE, "tpch_golden_sf1.json.gz")          # (q3: 11 K rows, q10: 39 K, q16: 18 K — 9 MB of JSON, 2.6 MB compressed)
+    path = os.path.join(HERE, "tpch_golden_sf10.json.gz" if sf10 else "tpch_golden_sf1.json.gz")          # (SF=1: q3 11 K rows, q10 39 K, q16 18 K — 9 MB of JSON, 1.8 MB compressed)
     with gzip.GzipFile(path, "wb", mtime=0) as fh:
         fh.write(json.dumps(out, separators=(",", ":")).encode())
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
 def main():
-    if "--sf1" in sys.argv:
+    if "--sf1" in sys.argv or "--sf10" in sys.argv:
         return main_sf1()
     more = "--more" in sys.argv          # python tests/golden/make_golden.py --more  -> tpch_golden_more.json (q4, q14)
     wide = "--wide" in sys.argv          # python tests/golden/make_golden.py --wide  -> tpch_golden_wide.json (q7, q8, q13, q15, q17, q19, q20, q22)

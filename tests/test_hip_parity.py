@@ -126,6 +126,24 @@ def test_every_query_runs_with_the_host_loops_refused(hip_lib, golden_sf1):
         eng.close()
 
 
+def test_reference_results_at_baseline_size(hip_engine, oracle_lib, golden_sf10):
+    """BASELINE.json's configs at their own size against the REFERENCE itself: q1 (configs[1]), q3 (configs[2]), q5, q6, q9 at SF=10 —
+    the reference's Python-mode results on these very inputs (tests/golden/tpch_golden_sf10.json.gz: the interpreter's hour, once) —
+    on the HIP path (twice: the second run takes the settled routes, recorded plans included) and on the CPU checker with every host
+    thread.  Rows, keys and counts exact, sums within REL."""
+    import os
+    (case,) = golden_sf10["cases"]
+    assert case["sf"] == 10.0 and case["rows"]["lineitem"] > 59_000_000 and set(case["results"]) == set(SUPPORTED)
+    for again in range(2):
+        assert helpers.check_all_goldens(hip_engine, [golden_sf10], REL, REL, "hip/sf10/%d" % again) == 5
+    cpu = engine.Engine(oracle_lib.context(threads=os.cpu_count() or 1))
+    try:
+        assert helpers.check_all_goldens(cpu, [golden_sf10], REL, REL, "oracle/sf10") == 5
+    finally:
+        cpu.close()
+    hip_engine.clear()
+
+
 def test_decorated_queries_through_public_api(golden, golden_more, golden_wide):
     """The user-facing route: sdqlpy_init(3) + @sdql_compile functions.  The decorator keeps a query's plan, so the second
     and third run of a query on the same tables take the cached paths (prepared plan, marshalled calls per layout

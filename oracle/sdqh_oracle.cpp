@@ -13,7 +13,9 @@
 // row order, exactly the interpreter's: reference src/sdqlpy/sdql_lib.py:220-236).  The other goldens are pinned the same way:
 // tpch_golden_more.json / _wide.json (the remaining 16 queries at three sizes) and, since round 6, tpch_golden_sf1.json.gz — the
 // reference's results for all 21 queries at SF=1 (6 M lineitem rows) and with keys beyond 2^40 at SF=0.1 / SF=1, the sizes at
-// which the product's size-dependent paths engage (make_golden.py --sf1; test_oracle_reproduces_reference_at_sf1: bit for bit).
+// which the product's size-dependent paths engage (make_golden.py --sf1; test_oracle_reproduces_reference_at_sf1: bit for bit) —
+// and tpch_golden_sf10.json.gz: the five configured queries at BASELINE.json's own size, SF=10 (make_golden.py --sf10; checked with
+// every host thread beside the HIP path on the GPU box: tests/test_hip_parity.py::test_reference_results_at_baseline_size).
 //
 // The reference's compiled (TBB + phmap) mode is NOT buildable here: its generator needs Python
 // 3.8's ast.Index, the emitted C++ needs TBB headers (task_scheduler_init was removed from oneTBB)

@@ -174,3 +174,20 @@ def test_oracle_reproduces_reference_at_sf1(oracle_lib, golden_sf1):
         assert eng.stats()["host_loops"] == []
     finally:
         eng.close()
+
+
+def test_oracle_reproduces_reference_at_baseline_size(oracle_lib, golden_sf10):
+    """BASELINE.json's own size: the reference's results for q1 / q3 / q5 / q6 / q9 at SF=10 (60 M lineitem rows, tests/golden/
+    tpch_golden_sf10.json.gz) on the CPU checker with every host thread — the per-thread partial sums are folded in thread order, so the
+    doubles agree to 1e-12, the integers, keys and row sets exactly (a minute on eight cores).  This is the checker bench.py's
+    `cpu_baseline` times and `parity_at_bench_size` compares the HIP path with; the HIP path is compared with the same golden file directly
+    on the GPU box (tests/test_hip_parity.py) and in the bench line (`reference_at_bench_size`)."""
+    import os
+    (case,) = golden_sf10["cases"]
+    assert case["sf"] == 10.0 and case["rows"]["lineitem"] > 59_000_000
+    eng = engine.Engine(oracle_lib.context(threads=os.cpu_count() or 1))
+    try:
+        assert helpers.check_all_goldens(eng, [golden_sf10], 1e-12, 1e-12, "oracle/sf10") == 5
+    finally:
+        eng.close()
+        helpers._db_cache.clear()                                # (5 GB of generated columns: not kept for the rest of the session)

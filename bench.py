@@ -457,6 +457,18 @@ def main(argv=None, hooks=None):
         import torch                                           # their twins and dictionaries, the pools' table memory, recorded plans, the runtime's own
         free_b, total_b = torch.cuda.mem_get_info(local_rank if use_dist else 0)
         hbm = {"in_use_GB": round((total_b - free_b) / 1e9, 2), "of_GB": round(total_b / 1e9, 1), "columns_at_reference_width_GB": round(int(eng.resident_bytes) / 1e9, 2)}
+        try:
+            # where it is (sdqh_memory_stats over the engine's lanes): what the pools have handed out — the columns, everything attached to them
+            # (twins, codes, dictionaries, delta twins, run indexes, row packs) and tables still alive —, what they keep cached for the next
+            # run's tables, what recorded plan graphs reserve; the rest is the runtime's (code objects, RCCL / torch, queues)
+            ms = eng.ctx.memory_stats()
+            cols = int(eng.resident_bytes)
+            hbm["pools"] = {"handed_out_GB": round(ms["used"] / 1e9, 2), "of_which_columns_GB": round(cols / 1e9, 2),
+                            "of_which_attached_to_columns_and_live_tables_GB": round(max(0, ms["used"] - cols - ms["graphs"]) / 1e9, 2),
+                            "cached_free_GB": round(ms["cached_free"] / 1e9, 2), "reserved_by_recorded_plans_GB": round(ms["graphs"] / 1e9, 2), "blocks": ms["blocks"]}
+            hbm["outside_the_pools_GB"] = round(((total_b - free_b) - ms["used"] - ms["cached_free"]) / 1e9, 2)
+        except Exception as exc:                               # (reporting only)
+            hbm["pools"] = {"error": str(exc)[:100]}
     except Exception as exc:                                   # (reporting only)
         hbm = {"error": str(exc)[:100]}
     reference_width = None

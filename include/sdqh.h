@@ -210,6 +210,12 @@ void*       sdqh_stream(const sdqh_ctx* ctx);
  * pool to the runtime — a pool never shrinks by itself).
  * The CPU build accepts and ignores any name. */
 int         sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value);
+/* What this context's device-memory pool holds (round 6: bench.py's `hbm` accounting — the reference keeps nothing resident, it reads
+ * the caller's numpy buffers in place, sdql_compiler.py:638-672): out[0] bytes handed out (columns and what is attached to them —
+ * twins, codes, dictionaries, delta twins, run indexes, row packs —, live tables, staging), out[1] bytes cached free (reused by the
+ * next runs, returned by "pool_trim"), out[2] of out[0] + out[1]: bytes reserved by recorded plan graphs, out[3] blocks.  n >= 4.
+ * A family's contexts have a pool each.  The CPU build reports zeros. */
+int         sdqh_memory_stats(sdqh_ctx* ctx, int64_t* out, int n);
 
 /* ---- columns ----------------------------------------------------------------------------- */
 /* Copy a host column into device memory through a pinned staging ring (chunked, async H2D on

@@ -354,6 +354,7 @@ int sdqh_profile_entry(const sdqh_ctx*, int, const char**, double*) { return SDQ
 int sdqh_profile_entry_bytes(const sdqh_ctx*, int, int64_t*) { return SDQH_ERR_INVALID; }
 void* sdqh_stream(const sdqh_ctx*) { return nullptr; }
 int sdqh_set_option(sdqh_ctx* ctx, const char*, int64_t) { return ctx ? SDQH_OK : SDQH_ERR_INVALID; }
+int sdqh_memory_stats(sdqh_ctx* ctx, int64_t* out, int n) { if (!ctx || !out || n < 4) return SDQH_ERR_INVALID; for (int i = 0; i < n; ++i) out[i] = 0; return SDQH_OK; }
 
 // ---- columns -----------------------------------------------------------------------------------
 static int new_column(sdqh_ctx* ctx, int64_t nrows, int dtype, int width, sdqh_column** out) {

@@ -212,7 +212,7 @@ class Program:
 EXPORTS = [
     "sdqh_abi_version", "sdqh_backend_name", "sdqh_create", "sdqh_fork", "sdqh_destroy", "sdqh_last_error", "sdqh_set_threads",
     "sdqh_synchronize", "sdqh_last_device_ms", "sdqh_set_profiling", "sdqh_set_profile_filter", "sdqh_profile_count", "sdqh_profile_entry", "sdqh_profile_entry_bytes",
-    "sdqh_stream", "sdqh_set_option",
+    "sdqh_stream", "sdqh_set_option", "sdqh_memory_stats",
     "sdqh_column_upload", "sdqh_column_wrap", "sdqh_column_alloc", "sdqh_column_download", "sdqh_column_data",
     "sdqh_column_rows", "sdqh_column_dtype", "sdqh_column_width", "sdqh_column_minmax", "sdqh_column_free",
     "sdqh_scan_filter_sum", "sdqh_scan_probe_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_build_key_set", "sdqh_groupby_key", "sdqh_table_select_keys", "sdqh_table_share_groups", "sdqh_table_size", "sdqh_table_free",
@@ -487,6 +487,17 @@ class Context:
     # -- plumbing ----------------------------------------------------------------------------
     def set_threads(self, n):
         self._check(self.lib.sdqh_set_threads(self.handle, C.c_int(n)))
+
+    def memory_stats(self, family=True):
+        """{"used", "cached_free", "graphs", "blocks"} of this context's device-memory pool (sdqh_memory_stats), its forks' added."""
+        out = (C.c_int64 * 4)()
+        self._check(self.lib.sdqh_memory_stats(self.handle, out, C.c_int(4)))
+        tot = {"used": int(out[0]), "cached_free": int(out[1]), "graphs": int(out[2]), "blocks": int(out[3])}
+        if family:
+            for child in self.forks:
+                for k, v in child.memory_stats(family=False).items():
+                    tot[k] += v
+        return tot
 
     def synchronize(self):
         """Everything queued on this context — and, on a family's first context, on its forks — has run."""
@@ -1215,6 +1226,7 @@ class Library:
         L.sdqh_xgroupby_block_bytes.restype = C.c_size_t
         L.sdqh_xgroupby_async.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.sdqh_xgroupby_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sdqh_memory_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.sdqh_xgroupby_partial.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.sdqh_xgroupby_fold.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.sdqh_xbuild.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]

@@ -745,6 +745,19 @@ int sdqh_set_option(sdqh_ctx* ctx, const char* name, int64_t value) {
     return SDQH_OK;
 }
 
+int sdqh_memory_stats(sdqh_ctx* ctx, int64_t* out, int n) {
+    if (!ctx || !out || n < 4) return fail(ctx, SDQH_ERR_INVALID, "memory_stats: bad arguments");
+    int64_t used = 0, cached = 0, graphs = 0, blocks = 0;
+    for (const auto& b : ctx->pool) {
+        if (!b.ptr) continue;
+        ++blocks;
+        if (b.graph_owner) graphs += (int64_t)b.size;
+        if (b.free && !b.graph_owner) cached += (int64_t)b.size; else used += (int64_t)b.size;
+    }
+    out[0] = used; out[1] = cached; out[2] = graphs; out[3] = blocks;
+    return SDQH_OK;
+}
+
 // ---- columns -----------------------------------------------------------------------------------
 static int new_column(sdqh_ctx* ctx, int64_t nrows, int dtype, int width, sdqh_column** out) {
     if (!ctx || !out || nrows < 0) return fail(ctx, SDQH_ERR_INVALID, "column: bad arguments");

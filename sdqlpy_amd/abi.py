@@ -839,16 +839,23 @@ class Context:
     # -- plan graphs (sdqh_graph_*): a prepared plan's device calls recorded once, replayed by one call --------------------------
     def graph_begin(self):
         self._check(self.lib.sdqh_graph_begin(self.handle))
+        self._capturing = True
+
+    def capturing(self):
+        """Between graph_begin and graph_end / graph_abort: the calls are being recorded, nothing executes."""
+        return bool(getattr(self, "_capturing", False))
 
     def graph_end(self):
         """-> Graph, or raises SdqhError(ERR_UNSUPPORTED) when the recording is no graph (the CPU implementation; a call that waited)."""
         h = C.c_void_p()
+        self._capturing = False
         self._check(self.lib.sdqh_graph_end(self.handle, C.byref(h)))
         g = Graph(self, h)
         self._graphs.add(g)
         return g
 
     def graph_abort(self):
+        self._capturing = False
         if self.handle is not None:
             self.lib.sdqh_graph_abort(self.handle)
 

@@ -376,6 +376,7 @@ bool columns_pair_increasing(sdqh_ctx* ctx, sdqh_column* a, sdqh_column* b) {
     if (a->dtype != SDQH_I64 || b->dtype != SDQH_I64 || a->nrows != b->nrows || a->transient || b->transient) return false;
     if (a->increasing == 1) return true;
     if (a->pair_uid == b->uid && a->pair_increasing >= 0) return a->pair_increasing == 1;
+    if (ctx->capturing) return false;                                     // (the check waits for the device: inside a recording only what is known already counts)
     if (a->nondecreasing == 0) { a->pair_uid = b->uid; a->pair_increasing = 0; return false; }
     if (a->nrows < 2) return true;
     int* flag = static_cast<int*>(pool_alloc(ctx, 64));
@@ -2105,7 +2106,7 @@ int sdqh_build(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nloo
     if (nkey == 1 && nrows > 0 && key[0].kind == SDQH_SRC_COLUMN && key[0].col->dtype == SDQH_I64 && column_is_increasing(ctx, const_cast<sdqh_column*>(key[0].col))) tb->keys_unique = true;
     // a composite key whose parts are plain columns that strictly increase as pairs (supplier by (s_suppkey, s_nationkey), partsupp by (ps_partkey,
     // ps_suppkey)): every staged row is an entry — the multi-GPU runner's device-sized replication may take the stage as it is
-    if (nkey == 2 && nrows > 0 && !ctx->capturing && key[0].kind == SDQH_SRC_COLUMN && key[1].kind == SDQH_SRC_COLUMN && key[0].col->nrows == nrows && key[1].col->nrows == nrows &&
+    if (nkey == 2 && nrows > 0 && key[0].kind == SDQH_SRC_COLUMN && key[1].kind == SDQH_SRC_COLUMN && key[0].col->nrows == nrows && key[1].col->nrows == nrows &&
         columns_pair_increasing(ctx, const_cast<sdqh_column*>(key[0].col), const_cast<sdqh_column*>(key[1].col))) tb->pack_unique = true;
     // stage without source columns: the kernel evaluates sources itself
     sdqh_column fake; fake.data = nullptr;

@@ -38,7 +38,9 @@ CPU oracle behind the ABI — that is how tests/test_dist_cpu.py covers the N > 
 """
 import contextlib
 import os
+import sys
 import time
+import weakref
 
 import numpy as np
 import torch
@@ -69,17 +71,21 @@ class DistributedRunner:
         # a collective is ordered behind the kernels of ITS plan (torch makes RCCL's stream wait for, and be waited for by, the current
         # stream), and the plans of a step share the chip as on one GPU.  Every rank issues its collectives in program order, on one
         # communicator: the order RCCL executes them in is the same everywhere whatever the lanes.  First (exact) runs, range
-        # partitioning and everything on CPU tensors stay on lane 0.  OFF by default (SDQLPY_AMD_DIST_LANES=1 turns it on): measured on a
-        # group of one with its collectives issued, the q1+q3+q5 step is 1.37 ms with lanes and 1.21-1.38 without — the step is the HOST
-        # issuing ~70 calls and 8 collectives (tools/dist_call_times2.py: 0.15 + 0.44 + 0.41 ms to launch q1 / q3 / q5, 23 us of it per
-        # torch collective), and kernels that could overlap are waiting for their launches either way.
-        self.lanes = self.backend == "nccl" and os.environ.get("SDQLPY_AMD_DIST_LANES", "0") == "1"
+        # partitioning and everything on CPU tensors stay on lane 0.  Measured on a group of one with its collectives issued (q1+q3+q5 at
+        # SF=10): with the calls issued one by one the step is the HOST's — 1.2 ms of Python and torch launching ~70 calls and 8
+        # collectives (tools/dist_call_times2.py) — and lanes change nothing (1.37 against 1.21-1.38); with the settled plans RECORDED
+        # (below: 0.06 ms of host time per query) the step is the device's, 1.01 ms on one stream and 0.80-0.82 on three lanes.
+        # SDQLPY_AMD_DIST_LANES=0: one stream.
+        self.lanes = self.backend == "nccl" and os.environ.get("SDQLPY_AMD_DIST_LANES", "1") != "0"
         if not (world == 1 and self.skip_trivial):
             if not self.lanes:
                 eng.nlanes = 1                                  # collectives and kernels ordered on ONE stream
             eng.plan_graphs = 0                                 # no plan is recorded on a stream RCCL's collectives are ordered on (a stream in
                                                                 # capture mode beside torch's / RCCL's use of it has never run anywhere)
         self._plan_lane, self._lane_next, self._ext_streams = {}, 0, {}
+        # settled chains recorded WITH their collectives and launched by one call (_chain_device_sized); SDQLPY_AMD_DIST_GRAPHS=0: the calls are issued
+        self.graphs = self.backend == "nccl" and os.environ.get("SDQLPY_AMD_DIST_GRAPHS", "1") != "0"
+        self.graph_recordings = self.graph_launches = 0
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
         self.device = device
@@ -172,6 +178,8 @@ class DistributedRunner:
                 d = plan.__dict__.get(cache)
                 if d:
                     for k in [k for k in d if k[0] == id(self)]:
+                        for r in d[k].__dict__.pop("recordings", []):      # (a recording owns pool memory and names the collective buffers: it goes first)
+                            r["pg"].free()
                         del d[k]
         self._plans.clear()
         self._stat_ring = []
@@ -868,7 +876,11 @@ class DistributedRunner:
         The largest chunk counts travel in the spare words of the group block (no collective of their own) or, for a plan without one,
         in an all-reduce of four words; they land in pinned memory in front of the result and are read when it is collected: a chunk
         that overflowed anywhere makes every rank repeat the chain with exact sizes (collective_rerun), otherwise they bound the next
-        run.  Collectives per run: one per replicated table + one for the groups."""
+        run.  Collectives per run: one per replicated table + one for the groups.
+        RECORDED (round 6, RCCL only; `self.graphs`): a chain that has run this way twice is recorded — the plan's calls AND its
+        collectives, torch's current stream being the lane's stream in capture mode, so RCCL's work joins the capture
+        (tools/exp_rccl_in_graph.py: a graph with an all-gather and an all-reduce inside replays right) — and from then on launched by
+        ONE call; nothing in the recorded region allocates from torch (persistent buffers, a status block of the recording's own)."""
         ctx, eng = self.ctx, self.eng
         G = self.world
         pp = engine.prepared_plan(eng, plan, args, lane=lane, member_only=st.member_only)      # (the chain's own choice of key sets: a set whose entries travel is a table)
@@ -879,14 +891,83 @@ class DistributedRunner:
             dev["stat_col"] = ctx.wrap(dev["stat"].data_ptr(), abi.EXCHANGE_STAT_WORDS, abi.I64, keepalive=dev["stat"])
         stat_t, stat = dev["stat"], dev["stat_col"]
         names = [n for n in st.fast_tables]                          # replicated tables with payload, in plan order: their status slots
-        host_t, host, busy = self._stat_buffer()
-        host[abi.EXCHANGE_STAT_WORDS - 1] = -1
+        SW = abi.EXCHANGE_STAT_WORDS
+
+        def collective_rerun():
+            self.fast_retries += 1
+            for r in st.__dict__.pop("recordings", []):             # (the bounds they were recorded with are the ones that just failed)
+                r["pg"].free()
+            st.settled_runs = 0
+            return self._guarded(lambda: self._sharded_chain(plan, args, st.whole, None, waited=True))
+
+        def make_precheck(host, busy, state):
+            def precheck():
+                try:
+                    if names and state["status_sent"]:
+                        if host[SW - 1] == -1:
+                            t0 = time.perf_counter()
+                            while host[SW - 1] == -1:
+                                if time.perf_counter() - t0 > 2.0:
+                                    ctx.synchronize()
+                                    if self.backend == "nccl":
+                                        torch.cuda.synchronize(self.device)
+                                    break
+                        if state.get("status_from") == "ranks":      # every rank's counts came with its group block: the largest of each
+                            most = [max(int(host[SW + 4 * r + i]) for r in range(G)) for i in range(len(names))]
+                        else:
+                            most = [int(host[abi.STAT_MAX_COUNT + i]) for i in range(len(names))]
+                    else:
+                        most = []
+                finally:
+                    busy[0] = False
+                over = [(n, m, st.caps[n]) for n, m in zip(names, most) if m > st.caps[n]]
+                for n, m in zip(names, most):
+                    st.caps[n] = _chunk_bound(m, st.caps[n])
+                if over:
+                    raise engine.RetryPlan("a replicated table outgrew its chunk: %s" % ", ".join("%s %d > %d" % o for o in over))
+            return precheck
+
+        # a recording of this chain that is free to be launched again?
+        recs = st.__dict__.setdefault("recordings", [])
+        use_graphs = self.graphs and st.__dict__.get("graph_ok", True) and not ctx._profiling and not ctx._prof_mode and not st.key_range
+        if use_graphs:
+            if recs and any(r["caps"] != st.caps for r in recs):    # (recorded with other chunk bounds than the chain has now: stale)
+                for r in recs:
+                    r["pg"].free()
+                del recs[:]
+                st.settled_runs = 0                                  # (two runs with the calls issued first: the buffers of the new bounds are made OUTSIDE a recording)
+            for r in recs:
+                pg = r["pg"]
+                if pg.state == "flying" and pg.result() is None:    # launched, its result dropped unread: wait for the lane, then it is free
+                    ctx.synchronize()
+                    pg.state = "free"
+                if pg.state == "free" and not pg.rows_out():
+                    r["host"][SW - 1] = -1
+                    r["busy"][0] = True
+                    pg.graph.launch()
+                    pg.state = "flying"
+                    self.fast_runs += 1
+                    self.graph_launches += 1
+                    self.last_chain = dict(r["info"], recorded=True)
+                    self._partitioned_result = st.partitioned_result
+                    rs = pp._graph_result(pg, precheck=make_precheck(r["host"], r["busy"], r["state"]), on_retry=collective_rerun)
+                    pg.result = weakref.ref(rs)
+                    return rs
+        record = use_graphs and len(recs) < 2 and st.__dict__.get("settled_runs", 0) >= 2
+        if record:
+            host_t = torch.zeros(SW + 4 * G, dtype=torch.int64).pin_memory()
+            host, busy = host_t.numpy(), [True]
+        else:
+            host_t, host, busy = self._stat_buffer()
+        host[SW - 1] = -1
         keep = []
         state = {"status_sent": False}
 
         def buffers(name, words):
             pair = dev["bufs"].get(name)
             if pair is None or pair[0].numel() != words:
+                if record:                                           # (torch's allocator knows nothing of the capture: nothing is allocated inside it)
+                    raise abi.SdqhError(abi.ERR_UNSUPPORTED, "a collective buffer would be allocated inside the recording")
                 send = self._empty(words)
                 pair = dev["bufs"][name] = (send, self._empty(words * G))
             return pair
@@ -898,9 +979,16 @@ class DistributedRunner:
             else:
                 dist.all_gather(list(recv.view(G, -1).unbind(0)), send, group=self.group)
 
-        def status_to_host(head):
-            host_t[:4].copy_(head, non_blocking=True)
-            host_t[abi.EXCHANGE_STAT_WORDS - 1:].copy_(stat_t[abi.EXCHANGE_STAT_WORDS - 1:], non_blocking=True)      # (the sentinel's word: 0 on the device)
+        def status_to_host(head=None, ranks=None):
+            if ranks is not None:                                      # (recv, words, spare): every rank's four words as they came — no reduction kernel, nothing allocated
+                recv_t, words, spare = ranks
+                for r in range(G):
+                    host_t[SW + 4 * r:SW + 4 * r + 4].copy_(recv_t[r * words + spare:r * words + spare + 4], non_blocking=True)
+                state["status_from"] = "ranks"
+            else:
+                host_t[:4].copy_(head, non_blocking=True)
+                state["status_from"] = "head"
+            host_t[SW - 1:SW].copy_(stat_t[SW - 1:], non_blocking=True)      # (the sentinel's word: 0 on the device)
             state["status_sent"] = True
 
         def replicate(name):
@@ -972,7 +1060,7 @@ class DistributedRunner:
                     spare = words - 6
                     send[spare:spare + 4].copy_(stat_t[:4])
                     gather(recv, send)
-                    status_to_host(recv.view(G, words)[:, spare:spare + 4].amax(dim=0))
+                    status_to_host(ranks=(recv, words, spare))
                     return recv.data_ptr(), G
                 return send.data_ptr(), issue
             return exchange
@@ -1001,39 +1089,44 @@ class DistributedRunner:
             elif st.sharded[op.out]:
                 after[op.out] = merged(op.out)                         # (a Pending — the folded groups — passes through)
 
-        def precheck():
-            try:
-                if names and state["status_sent"]:
-                    if host[abi.EXCHANGE_STAT_WORDS - 1] == -1:
-                        t0 = time.perf_counter()
-                        while host[abi.EXCHANGE_STAT_WORDS - 1] == -1:
-                            if time.perf_counter() - t0 > 2.0:
-                                ctx.synchronize()
-                                if self.backend == "nccl":
-                                    torch.cuda.synchronize(self.device)
-                                break
-                    most = [int(host[abi.STAT_MAX_COUNT + i]) for i in range(len(names))]
-                else:
-                    most = []
-            finally:
-                busy[0] = False
-            over = [(n, m, st.caps[n]) for n, m in zip(names, most) if m > st.caps[n]]
-            for n, m in zip(names, most):
-                st.caps[n] = _chunk_bound(m, st.caps[n])
-            if over:
-                raise engine.RetryPlan("a replicated table outgrew its chunk: %s" % ", ".join("%s %d > %d" % o for o in over))
-
-        def collective_rerun():
-            self.fast_retries += 1
-            return self._guarded(lambda: self._sharded_chain(plan, args, st.whole, None, waited=True))
+        precheck = make_precheck(host, busy, state)
 
         self.fast_runs += 1
         self.last_chain = info = {"plan": plan.name, "replicated": [], "bitmaps": [], "folded": [], "merged_on_host": []}      # (what this run's seams did: tests, bench.py)
+        self._partitioned_result = st.partitioned_result
+        if record:
+            # the chain's calls and collectives into a graph (nothing executes), then its first launch
+            pg = None
+            try:
+                pg = pp._record(pp._graph_epoch(), after=after, env_extra={"__group_fold__": fold_hook})
+            finally:
+                self._inflight.extend(keep)
+            if pg is not None and (not names or state["status_sent"]):
+                rec = {"pg": pg, "host_t": host_t, "host": host, "busy": busy, "state": state, "info": dict(info), "keep": keep, "caps": dict(st.caps)}
+                recs.append(rec)
+                self.graph_recordings += 1
+                host[SW - 1] = -1
+                pg.graph.launch()
+                pg.state = "flying"
+                self.graph_launches += 1
+                self.last_chain = dict(info, recorded=True)
+                rs = pp._graph_result(pg, precheck=precheck, on_retry=collective_rerun)
+                pg.result = weakref.ref(rs)
+                return rs
+            if pg is not None:
+                pg.free()
+            st.graph_ok = False                                      # (refused — a call that waits, a loop that is not deferred —: the calls are issued, as before)
+            st.graph_refused = pp._graph_refused or "the exchange status never left the device inside the recording"
+            if os.environ.get("SDQLPY_AMD_DIST_DEBUG") == "1":
+                print("[dist] %s: not recorded: %s" % (plan.name, st.graph_refused), file=sys.stderr, flush=True)
+            pp._graph_refused = None                                 # (the engine's own note: this plan is not recorded WITHOUT its seams either, by the guard in run)
+            busy[0] = False
+            return self._chain_device_sized(st, plan, args, lane)
         try:
-            self._partitioned_result = st.partitioned_result
             res = pp.run(None, after=after, keep_tables=True, on_retry=collective_rerun, precheck=precheck, env_extra={"__group_fold__": fold_hook})
         finally:
             self._inflight.extend(keep)
+        st.settled_runs = st.__dict__.get("settled_runs", 0) + 1
         if isinstance(res, engine.DeferredResultSet):
             if names and not state["status_sent"]:
                 raise RuntimeError("%s: a deferred chain whose exchange status never left the device" % plan.name)
@@ -1245,7 +1338,7 @@ class DistributedRunner:
             and 1 + len(st.pay_b) <= abi.MAX_COMPACT_COLS
         return st
 
-    def _replicated_key_set(self, table, rng, disjoint=True):
+    def _replicated_key_set(self, table, rng, disjoint=True, cache=None):
         """The union over the ranks of a table's keys as a key set on every rank, through its exact bitmap over the GLOBAL key range
         `rng`: exported straight into the collective's buffer (a torch tensor wrapped as a column; key sets and direct-layout tables
         copy their own bitmap words, shifted) and made global by ONE collective — an all-reduce when the ranks' key sets are
@@ -1254,7 +1347,15 @@ class DistributedRunner:
         ctx = self.ctx
         lo, hi = rng
         n64 = ((hi - lo + 1 + 31) // 32 + 1) // 2
-        buf = self._empty(max(n64, 1))
+        # (cache: a prepared plan's own buffers, keyed by the caller — written and read in stream order run after run, and the same memory in
+        #  every replay of a recording of the plan)
+        buf = cache.get(("bits", n64)) if cache is not None else None
+        if buf is None:
+            if self.ctx.capturing():                                 # (nothing is allocated from torch inside a recording)
+                raise abi.SdqhError(abi.ERR_UNSUPPORTED, "a collective buffer would be allocated inside the recording")
+            buf = self._empty(max(n64, 1))
+            if cache is not None:
+                cache[("bits", n64)] = buf
         words = ctx.wrap(buf.data_ptr(), n64, abi.I64, keepalive=buf)
         ctx.table_export_bitmap(table, lo, hi, into=words)                    # queued under "async_copies": the collective is ordered behind it
         if self.world == 1 and self.skip_trivial:
@@ -1263,7 +1364,11 @@ class DistributedRunner:
             self._note("all_reduce", buf)
             dist.all_reduce(buf, group=self.group)
         else:
-            parts = self._empty(max(n64, 1) * self.world)
+            parts = cache.get(("parts", n64)) if cache is not None else None
+            if parts is None:
+                parts = self._empty(max(n64, 1) * self.world)
+                if cache is not None:
+                    cache[("parts", n64)] = parts
             self._note("all_gather", buf)
             if self.backend == "nccl":
                 dist.all_gather_into_tensor(parts, buf, group=self.group)
@@ -1300,14 +1405,14 @@ class DistributedRunner:
         flt = abi.make_filter() if first_key is None else abi.make_filter([(cols[0], first_key, abi.INT64_MAX)], [], [])
         return ctx.hash_build_unique(n, flt, [], cols[0], cols[1:], accumulate=accumulate)
 
-    def _replicated_set(self, st, local):
+    def _replicated_set(self, st, local, cache=None):
         """Table A (a BuiltTable built from this rank's shard) on every rank; see _replicated_key_set.  Key range too wide for a
         bitmap: the surviving keys are all-gathered and the set is built from them."""
         ctx = self.ctx
         if self.world == 1 and self.skip_trivial:
             return []                               # a group of one: this rank's set IS the global set
         if st.a_bitmap:
-            table, words = self._replicated_key_set(local.table, st.a_range)
+            table, words = self._replicated_key_set(local.table, st.a_range, cache=cache)
             keep = [words]
         else:
             (ka,), n_a = ctx.scan_compact(st.na, st.flt_a, [], [st.key_a])
@@ -1345,7 +1450,7 @@ class DistributedRunner:
 
         def replicate_a(env):
             if not st.a_whole:                   # (A whole on every rank: its set is built locally and no collective runs —
-                keep.extend(self._replicated_set(st, env[a_op.out]))      #  summing the ranks' bitmaps of identical sets would carry bits into their neighbours)
+                keep.extend(self._replicated_set(st, env[a_op.out], cache=st.__dict__.setdefault("bits_a", {})))      #  summing the ranks' bitmaps of identical sets would carry bits into their neighbours)
 
         def collective_rerun():
             # what a deferred run of this join does when it has to be repeated: the whole join once more with every size exact — a
@@ -1441,7 +1546,7 @@ class DistributedRunner:
             if not busy[0]:
                 busy[0] = True
                 return self._stat_ring[self._stat_next]
-        t = torch.zeros(abi.EXCHANGE_STAT_WORDS, dtype=torch.int64)
+        t = torch.zeros(abi.EXCHANGE_STAT_WORDS + 4 * self.world, dtype=torch.int64)      # (+ every rank's four chunk counts: the chains' status as it comes with the group blocks)
         if self.backend == "nccl":
             t = t.pin_memory()
         self._stat_ring.append((t, t.numpy(), [True]))
@@ -1470,13 +1575,77 @@ class DistributedRunner:
             dev = st.dev_bufs = {"caps": (cap_b, cap_c), "stat": self._zeros(abi.EXCHANGE_STAT_WORDS), "bufs": {}}
             dev["stat_col"] = ctx.wrap(dev["stat"].data_ptr(), abi.EXCHANGE_STAT_WORDS, abi.I64, keepalive=dev["stat"])
         stat_t, stat = dev["stat"], dev["stat_col"]
-        host_t, host, busy = self._stat_buffer()
-        host[abi.EXCHANGE_STAT_WORDS - 1] = -1                     # sentinel: overwritten (by 0) when the status has landed
+        SW = abi.EXCHANGE_STAT_WORDS
+
+        def make_precheck(host, busy):
+            def precheck():
+                # the result is being collected: the status first (it landed before K-F's rows: same stream, queued earlier)
+                try:
+                    if host[SW - 1] == -1:
+                        t0 = time.perf_counter()
+                        while host[SW - 1] == -1:
+                            if time.perf_counter() - t0 > 2.0:
+                                ctx.synchronize()
+                                if self.backend == "nccl":
+                                    torch.cuda.synchronize(self.device)
+                                break
+                    most_b, most_c = int(host[abi.STAT_MAX_COUNT + 0]), int(host[abi.STAT_MAX_COUNT + 1])
+                    d = host[abi.STAT_DETAIL:abi.STAT_DETAIL + 8]
+                    sent_b, self_b, recv_c, sent_c, self_c = int(d[1]), int(d[2]), int(d[4]), int(d[5]), int(d[6])
+                finally:
+                    busy[0] = False
+                st.caps = (_chunk_bound(most_b, cap_b), _chunk_bound(most_c, cap_c))
+                if most_b > cap_b or most_c > cap_c:
+                    raise engine.RetryPlan("an exchange outgrew its chunks (%d > %d or %d > %d rows)" % (most_b, cap_b, most_c, cap_c))
+                self.exchanged_rows = {"build": sent_b, "probe_sent": sent_c, "probe_received": recv_c}
+                self.exchanged_bytes = 8 * ((1 + len(st.pay_b)) * (sent_b - self_b) + (1 + len(st.ops_c)) * (sent_c - self_c))
+            return precheck
+
+        def rerun():
+            for r in st.__dict__.pop("recordings", []):             # (recorded with the bounds that just failed)
+                r["pg"].free()
+            st.settled_runs = 0
+            return collective_rerun()
+
+        # RECORDED (round 6): a join that has run this way twice is recorded with its collectives — torch's current stream is the engine's,
+        # in capture mode, so the all-reduces and all-to-alls join the capture — and from then on launched by one call
+        recs = st.__dict__.setdefault("recordings", [])
+        use_graphs = self.graphs and self._top is None and st.__dict__.get("graph_ok", True) and not trivial and not ctx._profiling and not ctx._prof_mode
+        if use_graphs:
+            if recs and any(r["caps"] != (cap_b, cap_c) or r["ctx"] is not ctx for r in recs):
+                for r in recs:
+                    r["pg"].free()
+                del recs[:]
+                st.settled_runs = 0                                  # (the buffers of the new bounds are made by runs with the calls issued, outside a recording)
+            for r in recs:
+                pg = r["pg"]
+                if pg.state == "flying" and pg.result() is None:
+                    ctx.synchronize()
+                    pg.state = "free"
+                if pg.state == "free" and not pg.rows_out():
+                    r["host"][SW - 1] = -1
+                    r["busy"][0] = True
+                    pg.graph.launch()
+                    pg.state = "flying"
+                    self.fast_runs += 1
+                    self.graph_launches += 1
+                    rs = pp._graph_result(pg, precheck=make_precheck(r["host"], r["busy"]), on_retry=rerun)
+                    pg.result = weakref.ref(rs)
+                    return rs
+        record = use_graphs and len(recs) < 2 and st.__dict__.get("settled_runs", 0) >= 2
+        if record:
+            host_t = torch.zeros(SW + 4 * G, dtype=torch.int64).pin_memory()
+            host, busy = host_t.numpy(), [True]
+        else:
+            host_t, host, busy = self._stat_buffer()
+        host[SW - 1] = -1                                          # sentinel: overwritten (by 0) when the status has landed
         run = {"probes": []}
 
         def exchange(table, cap, dtypes, slot):
             pair = dev["bufs"].get(slot)
             if pair is None:
+                if record:                                           # (nothing is allocated from torch inside a recording)
+                    raise abi.SdqhError(abi.ERR_UNSUPPORTED, "a collective buffer would be allocated inside the recording")
                 cw = ctx.chunk_words(len(dtypes), cap)
                 send = self._empty(G * cw)
                 pair = dev["bufs"][slot] = (send, send if trivial else self._empty(G * cw), cw)      # (a group of one: what was packed for rank 0 is what rank 0 receives)
@@ -1516,7 +1685,7 @@ class DistributedRunner:
             if trivial:
                 run["probes"] = [(table_b, st.key_c, False)]          # a group of one: B itself answers "does any rank hold this key"
             elif self.prefilter and lo_g <= hi_g and hi_g - lo_g + 1 <= (1 << 31):
-                all_keys, words = self._replicated_key_set(table_b, (lo_g, hi_g))
+                all_keys, words = self._replicated_key_set(table_b, (lo_g, hi_g), cache=st.__dict__.setdefault("bits_b", {}))
                 run["probes"] = [(all_keys, st.key_c, True)]
                 keep.append(words)
 
@@ -1551,40 +1720,41 @@ class DistributedRunner:
                 head = stat_t[:4]
                 self._note("all_reduce", head)
                 dist.all_reduce(head, op=dist.ReduceOp.MAX, group=self.group)
-            host_t.copy_(stat_t, non_blocking=True)
+            host_t[:abi.EXCHANGE_STAT_WORDS].copy_(stat_t, non_blocking=True)
             return res
 
-        def precheck():
-            # the result is being collected: the status first (it landed before K-F's rows: same stream, queued earlier)
-            try:
-                if host[abi.EXCHANGE_STAT_WORDS - 1] == -1:
-                    t0 = time.perf_counter()
-                    while host[abi.EXCHANGE_STAT_WORDS - 1] == -1:
-                        if time.perf_counter() - t0 > 2.0:
-                            ctx.synchronize()
-                            if self.backend == "nccl":
-                                torch.cuda.synchronize(self.device)
-                            break
-                most_b, most_c = int(host[abi.STAT_MAX_COUNT + 0]), int(host[abi.STAT_MAX_COUNT + 1])
-                d = host[abi.STAT_DETAIL:abi.STAT_DETAIL + 8]
-                sent_b, self_b, recv_c, sent_c, self_c = int(d[1]), int(d[2]), int(d[4]), int(d[5]), int(d[6])
-            finally:
-                busy[0] = False
-            st.caps = (_chunk_bound(most_b, cap_b), _chunk_bound(most_c, cap_c))
-            if most_b > cap_b or most_c > cap_c:
-                raise engine.RetryPlan("an exchange outgrew its chunks (%d > %d or %d > %d rows)" % (most_b, cap_b, most_c, cap_c))
-            self.exchanged_rows = {"build": sent_b, "probe_sent": sent_c, "probe_received": recv_c}
-            self.exchanged_bytes = 8 * ((1 + len(st.pay_b)) * (sent_b - self_b) + (1 + len(st.ops_c)) * (sent_c - self_c))
+        precheck = make_precheck(host, busy)
 
         self.fast_runs += 1
+        if record:
+            pg = pp._record(pp._graph_epoch(), after={a_op.out: replicate_a, b_op.out: exchange_b}, replace={c_op.out: probe_received})
+            if pg is not None:
+                recs.append({"pg": pg, "host_t": host_t, "host": host, "busy": busy, "caps": (cap_b, cap_c), "ctx": ctx, "keep": list(keep)})
+                self.graph_recordings += 1
+                host[SW - 1] = -1
+                pg.graph.launch()
+                pg.state = "flying"
+                self.graph_launches += 1
+                rs = pp._graph_result(pg, precheck=precheck, on_retry=rerun)
+                pg.result = weakref.ref(rs)
+                return rs
+            st.graph_ok = False
+            st.graph_refused = pp._graph_refused
+            if os.environ.get("SDQLPY_AMD_DIST_DEBUG") == "1":
+                print("[dist] %s: the join is not recorded: %s" % (plan.name, st.graph_refused), file=sys.stderr, flush=True)
+            pp._graph_refused = None
+            busy[0] = False
+            self.fast_runs -= 1
+            return self._hash_join_device_sized(st, pp, plan, replicate_a, keep, collective_rerun)
         res = pp.run(self._top, after={a_op.out: replicate_a, b_op.out: exchange_b}, replace={c_op.out: probe_received},
-                     keep_tables=True, on_retry=collective_rerun, precheck=precheck)
+                     keep_tables=True, on_retry=rerun, precheck=precheck)
+        st.settled_runs = st.__dict__.get("settled_runs", 0) + 1
         if not isinstance(res, engine.DeferredResultSet):
             # every call was waited for (ORDER BY ... LIMIT, profiling): the status is here too
             try:
                 precheck()
             except engine.RetryPlan:
-                return collective_rerun()
+                return rerun()
         return res
 
     def _join_sort_spec(self, st):

@@ -2161,18 +2161,25 @@ class PreparedPlan:
         g.result = weakref.ref(rs)
         return rs
 
-    def _record(self, epoch):
+    def _record(self, epoch, after=None, env_extra=None, replace=None):
         """Run the plan's steps with the lane's stream in capture mode: every launch is recorded, nothing executes.  A step that has
-        to wait for the device refuses (SDQH_ERR_UNSUPPORTED) and the plan is never recorded again."""
+        to wait for the device refuses (SDQH_ERR_UNSUPPORTED) and the plan is never recorded again.
+        after / env_extra (round 6): the multi-GPU runner's seams and hooks (see run) — a settled distributed plan is recorded WITH its
+        collectives: torch's current stream is the lane's, so RCCL's work joins the capture and is replayed with the kernels."""
         eng = self.eng
         ctx = eng.ctx
-        env = {"__defer__": self.defer_names, "__record__": True}
+        env = dict(env_extra) if env_extra else {}
+        env.update({"__defer__": self.defer_names, "__record__": True})
         at, graph = None, None
         try:
             ctx.graph_begin()
             try:
                 for i, (out, step) in enumerate(self.steps):
-                    env[out] = step(env)
+                    env[out] = replace[out](env) if replace and out in replace else step(env)
+                    if after and out in after:
+                        repl = after[out](env)
+                        if repl is not None:
+                            env[out] = repl
                     if isinstance(env[out], Pending):
                         at = i
                         break
@@ -2194,7 +2201,9 @@ class PreparedPlan:
         host_env = {k: v for k, v in env.items() if not isinstance(v, BuiltTable)}
         return PlanGraph(graph, at, env[at_name(self, at)], host_env, env.get("__rows_out__") or (lambda: False), epoch)
 
-    def _graph_result(self, g):
+    def _graph_result(self, g, precheck=None, on_retry=None):
+        """precheck / on_retry: as for run (the multi-GPU runner's recordings: the exchange status is read before the rows, and what
+        the data decided against is repeated collectively, not by this rank alone)."""
         pending, out, rest = g.pending, at_name(self, g.at), self.steps[g.at + 1:]
         plan = self.plan
 
@@ -2202,6 +2211,8 @@ class PreparedPlan:
             host_env = dict(g.host_env)
             try:
                 try:
+                    if precheck is not None:
+                        precheck()
                     host_env[out] = pending.resolve()
                 finally:
                     g.state = "free"                             # collected (or failed): the block's completion word has been seen
@@ -2213,8 +2224,12 @@ class PreparedPlan:
                 if not isinstance(res, ResultSet):
                     raise UnsupportedQuery("a deferred plan must end in a result set")
                 return res
-            except (abi.SdqhError, UnsupportedQuery) as exc:
+            except (abi.SdqhError, UnsupportedQuery, RetryPlan) as exc:
                 if isinstance(exc, abi.SdqhError) and exc.code not in (abi.ERR_OVERFLOW, abi.ERR_UNSUPPORTED):
+                    raise
+                if on_retry is not None:
+                    return on_retry()                            # (the runner drops its recordings itself and repeats the plan collectively)
+                if isinstance(exc, RetryPlan):
                     raise
                 # the data decided against what was recorded (a result that outgrew its block, more groups than the kernel's table):
                 # the recordings go, the plan runs once more with every call waited for and is recorded again when it has settled

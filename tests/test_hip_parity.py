@@ -1367,7 +1367,7 @@ def test_distributed_plans_world1_full_size(hip_lib):
                 runner = sdist.DistributedRunner(eng, 0, 1, partition=part, skip_trivial=trivial)
                 runners.append(runner)
                 for q in qs:
-                    for again in range(3 if q == "q3" else 1):         # q3's later runs: device-sized exchanges, nothing waited for
+                    for again in range(5 if q == "q3" else 1):         # q3's later runs: device-sized exchanges, nothing waited for; from the fourth on one recorded launch
                         got = runner.run(q, db)
                         if q == "q6":
                             assert abs(got - want[q]) <= REL * abs(want[q])
@@ -1377,9 +1377,10 @@ def test_distributed_plans_world1_full_size(hip_lib):
                         assert runner.last_partitioning == {"auto": "range", "hash": "hash"}[part]
                         if part == "hash":
                             assert runner.exchanged_rows["build"] > 1_000_000 and 100_000 < runner.exchanged_rows["probe_sent"] < 1_000_000, runner.exchanged_rows
-                            assert runner.fast_runs == 2 and runner.fast_retries == 0
+                            assert runner.fast_runs == 4 and runner.fast_retries == 0
                             if not trivial:
                                 assert runner.collectives["all_to_all"][0] == runner.collectives["all_to_all"][1] >= 6      # one packed all-to-all per exchange, on device memory
+                                assert runner.graph_recordings >= 1 and runner.graph_launches >= 2, (runner.graph_recordings, runner.graph_launches)      # (round 6: recorded with its collectives)
                             else:
                                 assert not runner.collectives
     finally:
@@ -1584,11 +1585,17 @@ def test_settled_chains_world1_wait_for_nothing(hip_lib):
                     continue
                 assert seams.get("plan") == q, (q, seams)
                 assert sum(c[0] for c in calls.values()) <= 3 and all(c[0] == c[1] for c in calls.values()), (q, calls)
+                assert bool(seams.get("recorded")) == (again == 2), (q, again, seams)      # (two settled runs with the calls issued, then the chain — its collectives inside — is ONE recorded launch)
                 if q in ("q1", "q5"):
                     assert seams["folded"] and not seams["merged_on_host"], (q, seams)
                 if q == "q5":
                     assert seams["replicated"] == ["supplier_nations"], seams        # (on a group of one the customers' join is co-partitioned)
         assert runner.fast_runs >= 6 and runner.fast_retries == 0
+        assert runner.graph_recordings == 2 and runner.graph_launches == 2, (runner.graph_recordings, runner.graph_launches)
+        for again in range(4):                                       # ... and replayed: the same rows from the same recording
+            _rows_match(runner.run("q5", db), want["q5"], "settled/q5/replay %d" % again)
+            _rows_match(runner.run("q1", db), want["q1"], "settled/q1/replay %d" % again)
+        assert runner.graph_recordings == 2 and runner.graph_launches == 10
         fn5, plan5, _ = runner._resolve("q5", db)
         st5 = [st for key, st in plan5.__dict__["_dist_chain"].items() if key[0] == id(runner)][0]
         for name in st5.caps:

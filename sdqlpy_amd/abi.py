@@ -857,7 +857,9 @@ class Context:
     def graph_abort(self):
         self._capturing = False
         if self.handle is not None:
-            self.lib.sdqh_graph_abort(self.handle)
+            # (a recording this runtime cannot take back leaves the stream in capture mode for good: said once, loudly, instead of every
+            #  later call failing with "a previous error during capture")
+            self._check(self.lib.sdqh_graph_abort(self.handle))
 
     def xcompact(self, nrows, prog):
         """(Columns [key, vals...] as I64 bit patterns, n): every passing row of the program, duplicate keys included."""

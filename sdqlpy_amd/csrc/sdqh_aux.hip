@@ -655,7 +655,16 @@ int sdqh_graph_abort(sdqh_ctx* ctx) {
     if (!ctx) return SDQH_ERR_INVALID;
     if (!ctx->capturing) return SDQH_OK;
     hipGraph_t graph = nullptr;
-    (void)hipStreamEndCapture(ctx->stream, &graph);
+    // A call that refused half way may have left a side stream forked into the capture.  This runtime does not take such a capture back
+    // (hipStreamEndCapture: Unjoined, and every stream of it stays in capture mode for good — tools/exp/capture_abort.hip), so whatever is
+    // still capturing beside the origin joins it first.
+    for (hipStream_t s : {ctx->side[0], ctx->side[1]}) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (!s || hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (cs != hipStreamCaptureStatusActive || !ctx->rs_ready) continue;
+        if (hipEventRecord(ctx->rs_ready, s) != hipSuccess || hipStreamWaitEvent(ctx->stream, ctx->rs_ready, 0) != hipSuccess) (void)hipGetLastError();
+    }
+    const hipError_t ended = hipStreamEndCapture(ctx->stream, &graph);
     (void)hipGetLastError();
     if (graph) (void)hipGraphDestroy(graph);
     sdqh_graph* g = const_cast<sdqh_graph*>(static_cast<const sdqh_graph*>(ctx->capture_tag));
@@ -663,6 +672,7 @@ int sdqh_graph_abort(sdqh_ctx* ctx) {
     release_graph_blocks(ctx, g);                                       // nothing was executed: the blocks are free at once
     rd_dirty(ctx);
     delete g;
+    if (ended != hipSuccess) return fail(ctx, SDQH_ERR_DEVICE, std::string("graph_abort: the recording could not be taken back (") + hipGetErrorName(ended) + "): the context's stream stays in capture mode and is lost");
     return SDQH_OK;
 }
 

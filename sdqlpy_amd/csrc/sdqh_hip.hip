@@ -318,6 +318,10 @@ unsigned stream_grid(sdqh_ctx* ctx, K kernel, int64_t nrows, int tile_rows = TIL
 int ensure_minmax(sdqh_ctx* ctx, sdqh_column* c) {
     if (c->have_minmax) return SDQH_OK;
     if (c->dtype != SDQH_I64) return fail(ctx, SDQH_ERR_INVALID, "minmax: needs an I64 column");
+    // (every fact about a column that is measured on first request waits for the device.  Inside a recording that is not a refusal the
+    //  runtime takes back — a wait on a capturing stream invalidates the capture and the stream stays lost, tools/exp/capture_abort.hip —
+    //  so the measuring routines below give the answer that needs no measurement, uncached, and this one refuses BEFORE any call)
+    if (ctx->capturing) return fail(ctx, SDQH_ERR_UNSUPPORTED, "minmax: a column's bounds would have to be measured inside a recording");
     if (!c->minmax_pending) {
         if (!c->d_minmax) { c->d_minmax = static_cast<long long*>(attach_alloc(ctx, c, 16)); if (!c->d_minmax) return fail(ctx, SDQH_ERR_NOMEM, "minmax: out of device memory"); }
         const long long init[2] = {INT64_MAX, INT64_MIN};
@@ -338,6 +342,7 @@ int ensure_minmax(sdqh_ctx* ctx, sdqh_column* c) {
 bool column_is_clustered(sdqh_ctx* ctx, sdqh_column* c) {
     if (c->clustered >= 0) return c->clustered == 1;
     if (c->dtype != SDQH_I64 || c->nrows < 4096) { c->clustered = 1; return true; }
+    if (ctx->capturing) return true;                                      // (not measured inside a recording: the answer a failed download gives, uncached)
     const int samples = 2048;
     const int64_t step = (c->nrows - 2) / samples;
     int64_t* host = static_cast<int64_t*>(ctx->result_host);              // 64 KiB pinned: 2048 pairs = 32 KiB
@@ -356,6 +361,7 @@ bool column_is_increasing(sdqh_ctx* ctx, sdqh_column* c) {
     if (c->increasing >= 0) return c->increasing == 1;
     if (c->dtype != SDQH_I64) { c->increasing = 0; return false; }
     if (c->nrows < 2) { c->increasing = 1; return true; }
+    if (ctx->capturing) return false;                                     // (not measured inside a recording; uncached)
     int* flag = static_cast<int*>(pool_alloc(ctx, 64));
     if (!flag) return false;
     bool ok = hipMemsetAsync(flag, 0, 4, ctx->stream) == hipSuccess;
@@ -371,7 +377,9 @@ bool column_is_increasing(sdqh_ctx* ctx, sdqh_column* c) {
     return ok && c->increasing == 1;
 }
 
-// ... or strictly increasing as PAIRS with another column of the same table (cached on `a`, one partner)?
+bool column_is_nondecreasing(sdqh_ctx* ctx, sdqh_column* c);
+// ... or, as PAIRS with another column of the same table, no pair twice — strictly increasing row after row, or the first part never
+// decreasing and the second parts of one run distinct (cached on `a`, one partner)?
 bool columns_pair_increasing(sdqh_ctx* ctx, sdqh_column* a, sdqh_column* b) {
     if (a->dtype != SDQH_I64 || b->dtype != SDQH_I64 || a->nrows != b->nrows || a->transient || b->transient) return false;
     if (a->increasing == 1) return true;
@@ -387,7 +395,18 @@ bool columns_pair_increasing(sdqh_ctx* ctx, sdqh_column* a, sdqh_column* b) {
         hipLaunchKernelGGL(k_check_pair_increasing, dim3(grid), dim3(TPB), 0, ctx->stream, static_cast<const int64_t*>(a->data), static_cast<const int64_t*>(b->data), a->nrows, flag);
         int* host = static_cast<int*>(ctx->result_host);
         ok = hipMemcpyAsync(host, flag, 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
-        if (ok) { yes = host[0] == 0; a->pair_uid = b->uid; a->pair_increasing = yes ? 1 : 0; }
+        if (ok) yes = host[0] == 0;
+        if (ok && !yes && column_is_nondecreasing(ctx, a)) {
+            // not sorted as pairs, but stored in the order of the first part: distinct within every run of equal first parts will do
+            // (partsupp: the four suppliers of a part in the generator's order)
+            ok = hipMemsetAsync(flag, 0, 4, ctx->stream) == hipSuccess;
+            if (ok) {
+                hipLaunchKernelGGL(k_check_pair_distinct, dim3(grid), dim3(TPB), 0, ctx->stream, static_cast<const int64_t*>(a->data), static_cast<const int64_t*>(b->data), a->nrows, flag);
+                ok = hipMemcpyAsync(host, flag, 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+                if (ok) yes = host[0] == 0;
+            }
+        }
+        if (ok) { a->pair_uid = b->uid; a->pair_increasing = yes ? 1 : 0; }
     }
     if (!ok) (void)hipGetLastError();
     pool_free(ctx, flag);
@@ -400,6 +419,7 @@ bool column_is_nondecreasing(sdqh_ctx* ctx, sdqh_column* c) {
     if (c->increasing == 1) { c->nondecreasing = 1; return true; }
     if (c->dtype != SDQH_I64) { c->nondecreasing = 0; return false; }
     if (c->nrows < 2) { c->nondecreasing = 1; return true; }
+    if (ctx->capturing) return false;                                     // (not measured inside a recording; uncached)
     int* flag = static_cast<int*>(pool_alloc(ctx, 64));
     if (!flag) return false;
     bool ok = hipMemsetAsync(flag, 0, 4, ctx->stream) == hipSuccess;
@@ -419,7 +439,9 @@ bool column_is_nondecreasing(sdqh_ctx* ctx, sdqh_column* c) {
 // Returns the twin or nullptr (the column does not narrow exactly, or no memory: the caller uses the column itself).
 const void* ensure_narrow(sdqh_ctx* ctx, sdqh_column* c) {
     if (c->narrow_state >= 0) return c->narrow;
+    if (ctx->capturing) return nullptr;                                   // (built and verified with a wait: not inside a recording; uncached)
     c->narrow_state = 0;
+    if (c->transient) return nullptr;                                     // (a column that lives for one run — an exchange's unpacked chunk —: a pass and a wait per run would buy one use)
     if (c->nrows < 2) return nullptr;
     const int64_t units = c->dtype == SDQH_STR ? c->nrows * c->width : c->nrows;         // text: one byte per code unit
     int32_t* twin = static_cast<int32_t*>(attach_alloc(ctx, c, c->dtype == SDQH_STR ? (size_t)units + 64 : (size_t)c->nrows * 4 + 64));
@@ -827,6 +849,7 @@ int sdqh_column_wrap(sdqh_ctx* ctx, void* device_ptr, int64_t nrows, int dtype, 
 int sdqh_column_download(sdqh_ctx* ctx, const sdqh_column* col, int64_t row0, int64_t nrows, void* host) {
     if (!ctx || !col || row0 < 0 || nrows < 0 || row0 + nrows > col->nrows || (nrows && !host)) return fail(ctx, SDQH_ERR_INVALID, "column_download: bad arguments");
     if (nrows == 0) return SDQH_OK;
+    if (ctx->capturing) return fail(ctx, SDQH_ERR_UNSUPPORTED, "a call that waits for the device cannot be recorded into a plan graph");
     HIP_TRY(ctx, hipMemcpyAsync(host, static_cast<const char*>(col->data) + (size_t)row0 * col->row_bytes(), (size_t)nrows * col->row_bytes(), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return SDQH_OK;

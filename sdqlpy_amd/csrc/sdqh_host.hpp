@@ -164,7 +164,7 @@ inline uint64_t sdqh_next_uid() { static std::atomic<uint64_t> next{1}; return n
 
 struct sdqh_column {
     uint64_t uid = sdqh_next_uid();    // never reused (an address is): what a fact about TWO columns names its partner by
-    uint64_t pair_uid = 0; int pair_increasing = -1;      // (this column, column `pair_uid`) strictly increasing as pairs, row after row? (one partner cached)
+    uint64_t pair_uid = 0; int pair_increasing = -1;      // (this column, column `pair_uid`): no pair twice — strictly increasing as pairs row after row, or distinct within every run of this column's equal values? (one partner cached)
     sdqh_ctx* home = nullptr;          // the context that created the column: its attachments (twins, dictionaries, statistics) live in THAT pool, whichever context of the family builds them
     void* data = nullptr;
     int64_t nrows = 0;
@@ -218,7 +218,7 @@ struct sdqh_table {
     std::vector<void*> owned;          // pool blocks to release
     // cached compaction (device buffers) for the two-step count / fetch protocol
     uint32_t* span = nullptr;                      // owner by key offset (small plain-key direct tables), becomes dev.dense_arr once the index is built
-    bool pack_unique = false;                      // no two staged rows share a key although keys_unique does not say so (a composite key whose parts, as pairs, strictly increase): sdqh_table_partition_pack may take the stage as the entries
+    bool pack_unique = false;                      // no two staged rows share a key although keys_unique does not say so (a composite key of two plain columns in which no pair comes twice: columns_pair_increasing): sdqh_table_partition_pack may take the stage as the entries
     bool keys_unique = false;                      // the build key is a strictly increasing column: no two staged rows share a key (k_fill_refs has nothing to do)
     bool refs_prefilled = false;                   // small direct tables: dense_ref was allocated and NO_ROW-filled with the header
     bool compact_valid = false;

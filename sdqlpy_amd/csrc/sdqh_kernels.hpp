@@ -1768,6 +1768,20 @@ SDQH_KERNEL __launch_bounds__(TPB) void k_check_pair_increasing(const int64_t* _
     for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r + 1 < nrows; r += (int64_t)gridDim.x * TPB) bad |= !(a[r] < a[r + 1] || (a[r] == a[r + 1] && b[r] < b[r + 1]));
     if (__ballot(bad) && lane_id() == 0) atomicOr(flag, 1);
 }
+// ... or, the first column never decreasing, no two rows of one run of equal first parts sharing their second part (partsupp by (ps_partkey,
+// ps_suppkey): the suppliers of a part come in the generator's order, not sorted, but none twice).  A run longer than PAIR_RUN_MAX rows is
+// not examined to its end: flag bit 2, "not known".
+constexpr int PAIR_RUN_MAX = 32;
+SDQH_KERNEL __launch_bounds__(TPB) void k_check_pair_distinct(const int64_t* __restrict__ a, const int64_t* __restrict__ b, int64_t nrows, int* __restrict__ flag) {
+    int bad = 0;
+    for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r + 1 < nrows; r += (int64_t)gridDim.x * TPB) {
+        const int64_t ar = a[r], br = b[r];
+        int64_t j = r + 1;
+        for (; j < nrows && j <= r + PAIR_RUN_MAX && a[j] == ar; ++j) bad |= b[j] == br ? 1 : 0;
+        if (j < nrows && j > r + PAIR_RUN_MAX && a[j] == ar) bad |= 2;
+    }
+    if (bad) atomicOr(flag, bad);
+}
 // Dense layout over a strictly increasing key column, in ONE pass: row r writes its own cell and NO_ROW into the cells up to
 // the next key, so the array needs no prefill (240 MB for Q9's orders) and — no duplicates possible — no verification pass
 // (another read of keys and cells).  Every cell in [lo, hi] is written exactly once; lo / hi are the column's min / max.

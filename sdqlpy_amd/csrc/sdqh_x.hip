@@ -321,6 +321,7 @@ int mirrored(int op) { return op == SDQH_X_LT ? SDQH_X_GT : op == SDQH_X_LE ? SD
 bool column_span8(sdqh_ctx* ctx, sdqh_column* c) {
     if (c->span8 >= 0) return c->span8 == 1;
     if (c->dtype != SDQH_I64 || c->transient || c->nrows < 64) { c->span8 = 0; return false; }
+    if (ctx->capturing) return false;                                     // (sampled with a wait: not inside a recording; uncached)
     const int samples = (int)std::min<int64_t>(1024, c->nrows / 8);        // 1024 groups x 64 bytes = the 64 KiB pinned result block
     const int64_t groups = c->nrows / 8, step = std::max<int64_t>(1, groups / samples);
     int64_t* host = static_cast<int64_t*>(ctx->result_host);
@@ -1581,6 +1582,7 @@ static int xgroupby_launch(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* pro
 
 // wait until a word of device-visible host memory that the stream writes (hipStreamWriteValue32) holds `value`
 static int wait_word(sdqh_ctx* ctx, const volatile uint32_t* word, uint32_t value) {
+    if (ctx->capturing) return fail(ctx, SDQH_ERR_UNSUPPORTED, "a call that waits for the device cannot be recorded into a plan graph");
     // bounded by wall time (2 s), not by a spin count; then the runtime's own wait on the stream — it reports a faulted kernel at once,
     // where re-entering the library's spinning synchronise would stall for its bound a second time
     const auto t0 = std::chrono::steady_clock::now();

@@ -52,6 +52,11 @@ from .frontend import Col, FinalizeOp, PayloadField, RecordCons, ScanOp
 from .result import ResultSet
 
 
+# (an experiment switch, never set in production: eager collectives on the recorded streams themselves — what round 6 first shipped, and what
+#  tests/dist_record_race_worker.py shows to end in a core dump when torch's watchdog polls during a recording)
+_COLL_ON_RECORDED_STREAM = os.environ.get("SDQLPY_AMD_DIST_COLL_ON_RECORDED_STREAM") == "1"
+
+
 class DistributedRunner:
     def __init__(self, eng, rank, world, group=None, device=None, partition="auto", prefilter=True, skip_trivial=None, device_sized=None):
         self.eng, self.ctx = eng, eng.ctx
@@ -110,6 +115,7 @@ class DistributedRunner:
         # every collective this runner issued since the last reset_collectives(): name -> [calls, calls on device tensors, bytes]
         self.collectives = {}
         self._ext_stream = None             # RCCL: torch's view of the engine's HIP stream (see _device_order)
+        self._coll_side = None              # RCCL: the stream eager collectives run on (see _coll)
         self.last_chain = None              # what the seams of the last device-sized chain did (_chain_device_sized)
 
     def _device_order(self):
@@ -125,6 +131,27 @@ class DistributedRunner:
                                    "recording the communication stream's use of them")
             self._ext_stream = torch.cuda.ExternalStream(int(self.ctx.stream()), device=self.device)
         return torch.cuda.stream(self._ext_stream)
+
+    def _coll(self, fn, *args, **kwargs):
+        """One collective.  RCCL, not recording: on a stream of the runner's own, forked from torch's current stream (the engine's, or a
+        lane's) and joined to it again.  torch's watchdog thread polls the end event of every eager collective until it is reaped, and on
+        this runtime hipEventQuery of an event that was recorded on a stream BEFORE that stream's capture began invalidates the capture —
+        and the stream with it, for good (tools/exp/capture_abort.hip case 4; tools/exp_watchdog_capture.py: a core dump when the
+        collectives before a recording ran on the stream that is recorded).  So no eager collective ever leaves an event on a stream that
+        plans are recorded on; inside a recording the collective joins the capture on the recorded stream itself (torch does not hand
+        captured work to its watchdog)."""
+        if self.backend != "nccl" or self.ctx.capturing() or _COLL_ON_RECORDED_STREAM:
+            return fn(*args, **kwargs)
+        cur = torch.cuda.current_stream(self.device)
+        side = self._coll_side
+        if side is None:
+            side = self._coll_side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(cur)
+        try:
+            with torch.cuda.stream(side):
+                return fn(*args, **kwargs)
+        finally:
+            cur.wait_stream(side)
 
     def _lane_of(self, plan):
         """The lane a settled plan runs on (assigned round robin, kept)."""
@@ -221,7 +248,7 @@ class DistributedRunner:
             t = torch.from_numpy(arr)
             out = [torch.empty_like(t) for _ in range(self.world)]
             self._note("all_gather", t)
-            dist.all_gather(out, t, group=self.group)
+            self._coll(dist.all_gather, out, t, group=self.group)
             return [o.numpy() for o in out]
         key = (arr.shape, arr.dtype.str)
         bufs = self._gather_bufs.get(key)
@@ -235,7 +262,7 @@ class DistributedRunner:
         h_in.numpy()[:] = arr.reshape(-1)
         d_in.copy_(h_in, non_blocking=True)
         self._note("all_gather", d_in)
-        dist.all_gather_into_tensor(d_out, d_in, group=self.group)
+        self._coll(dist.all_gather_into_tensor, d_out, d_in, group=self.group)
         h_out.copy_(d_out, non_blocking=True)
         self.ctx.synchronize()                   # torch's current stream IS the engine's (_device_order): its wait spins on a word the stream writes, where
                                                  # torch's stream wait sleeps on an interrupt — tens of microseconds per collective, and a step has about ten
@@ -268,9 +295,9 @@ class DistributedRunner:
         recv = self._empty(m * k * self.world)
         self._note("all_gather", send)
         if self.backend == "nccl":
-            dist.all_gather_into_tensor(recv, send, group=self.group)
+            self._coll(dist.all_gather_into_tensor, recv, send, group=self.group)
         else:
-            dist.all_gather(list(recv.view(self.world, m * k).unbind(0)), send, group=self.group)
+            self._coll(dist.all_gather, list(recv.view(self.world, m * k).unbind(0)), send, group=self.group)
         outs = []
         for j, col in enumerate(cols):
             out = self.ctx.alloc(total, col.dtype).mark_transient()
@@ -297,7 +324,7 @@ class DistributedRunner:
         """all_to_all_single; gloo has no all-to-all, so there it is spelled as isend / irecv pairs."""
         self._note("all_to_all", send)
         if self.backend == "nccl":
-            dist.all_to_all_single(recv, send, out_splits, in_splits, group=self.group)
+            self._coll(dist.all_to_all_single, recv, send, out_splits, in_splits, group=self.group)
             return
         so = np.concatenate([[0], np.cumsum(in_splits)]).astype(int)
         ro = np.concatenate([[0], np.cumsum(out_splits)]).astype(int)
@@ -975,9 +1002,9 @@ class DistributedRunner:
         def gather(recv, send):
             self._note("all_gather", send)
             if self.backend == "nccl":
-                dist.all_gather_into_tensor(recv, send, group=self.group)
+                self._coll(dist.all_gather_into_tensor, recv, send, group=self.group)
             else:
-                dist.all_gather(list(recv.view(G, -1).unbind(0)), send, group=self.group)
+                self._coll(dist.all_gather, list(recv.view(G, -1).unbind(0)), send, group=self.group)
 
         def status_to_host(head=None, ranks=None):
             if ranks is not None:                                      # (recv, words, spare): every rank's four words as they came — no reduction kernel, nothing allocated
@@ -1035,7 +1062,7 @@ class DistributedRunner:
                     # the plan ends in (a K-F launched and not waited for: _partitioned results)
                     head = stat_t[:4]
                     self._note("all_reduce", head)
-                    dist.all_reduce(head, op=dist.ReduceOp.MAX, group=self.group)
+                    self._coll(dist.all_reduce, head, op=dist.ReduceOp.MAX, group=self.group)
                     status_to_host(head)
                 return new
             return seam
@@ -1127,6 +1154,10 @@ class DistributedRunner:
         finally:
             self._inflight.extend(keep)
         st.settled_runs = st.__dict__.get("settled_runs", 0) + 1
+        if use_graphs and (info["merged_on_host"] or not isinstance(res, engine.DeferredResultSet)):
+            # (groups merged on the host, a last loop that is waited for: a recording would refuse at that call — known now, not tried)
+            st.graph_ok = False
+            st.graph_refused = "the chain waits for the device: %s" % (", ".join("'%s' merged on the host" % n for n in info["merged_on_host"]) or "its last call is not deferred")
         if isinstance(res, engine.DeferredResultSet):
             if names and not state["status_sent"]:
                 raise RuntimeError("%s: a deferred chain whose exchange status never left the device" % plan.name)
@@ -1137,7 +1168,7 @@ class DistributedRunner:
             if not state["status_sent"]:
                 head = stat_t[:4]
                 self._note("all_reduce", head)
-                dist.all_reduce(head, op=dist.ReduceOp.MAX, group=self.group)
+                self._coll(dist.all_reduce, head, op=dist.ReduceOp.MAX, group=self.group)
                 status_to_host(head)
             ctx.synchronize()
         try:
@@ -1362,7 +1393,7 @@ class DistributedRunner:
             pass                                    # (a group of one: the exported bitmap is the union already)
         elif disjoint:
             self._note("all_reduce", buf)
-            dist.all_reduce(buf, group=self.group)
+            self._coll(dist.all_reduce, buf, group=self.group)
         else:
             parts = cache.get(("parts", n64)) if cache is not None else None
             if parts is None:
@@ -1371,9 +1402,9 @@ class DistributedRunner:
                     cache[("parts", n64)] = parts
             self._note("all_gather", buf)
             if self.backend == "nccl":
-                dist.all_gather_into_tensor(parts, buf, group=self.group)
+                self._coll(dist.all_gather_into_tensor, parts, buf, group=self.group)
             else:
-                dist.all_gather(list(parts.view(self.world, -1).unbind(0)), buf, group=self.group)
+                self._coll(dist.all_gather, list(parts.view(self.world, -1).unbind(0)), buf, group=self.group)
             rows = parts.view(self.world, -1)
             for r in range(self.world):
                 if r == 0:
@@ -1719,7 +1750,7 @@ class DistributedRunner:
             if not trivial:
                 head = stat_t[:4]
                 self._note("all_reduce", head)
-                dist.all_reduce(head, op=dist.ReduceOp.MAX, group=self.group)
+                self._coll(dist.all_reduce, head, op=dist.ReduceOp.MAX, group=self.group)
             host_t[:abi.EXCHANGE_STAT_WORDS].copy_(stat_t, non_blocking=True)
             return res
 
@@ -1785,7 +1816,7 @@ class DistributedRunner:
         """Concatenate the ranks' ResultSet rows on every rank (validation only, not timed)."""
         rows = res.rows() if isinstance(res, ResultSet) else []
         out = [None] * self.world
-        dist.all_gather_object(out, rows, group=self.group)
+        self._coll(dist.all_gather_object, out, rows, group=self.group)
         merged = []
         for r in out:
             merged += r

@@ -2190,6 +2190,8 @@ class PreparedPlan:
                 ctx.graph_abort()
                 raise
         except (abi.SdqhError, UnsupportedQuery) as exc:
+            if isinstance(exc, abi.SdqhError) and exc.code == abi.ERR_DEVICE:
+                raise                                            # (not a refusal: a launch failed, or the recording could not be taken back)
             self._graph_refused = str(exc) or "refused"
             eng.graph_stats["refused"] += 1
             return None

@@ -1611,6 +1611,21 @@ def test_settled_chains_world1_wait_for_nothing(hip_lib):
         eng.close()
 
 
+def test_recordings_survive_the_collective_watchdog(hip_engine):
+    """A recording of a settled distributed plan while torch's collective watchdog polls (tests/dist_record_race_worker.py): in a process
+    of its own — what this guards against is a core dump (tools/exp_watchdog_capture.py `same`)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_record_race_worker.py")
+    p = subprocess.run([sys.executable, worker, str(port), "1.0"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and "ok recordings=" in p.stdout, p.stdout[-4000:]
+
+
 @pytest.mark.parametrize("world,shuffled", [(2, False), (3, False), (2, True)])
 def test_ranks_share_one_gpu(hip_engine, tmp_path, world, shuffled):
     """Round 6: N > 1 ON THE HARDWARE, as far as one GPU allows.  RCCL refuses two ranks on one device, so the ranks talk through gloo and

@@ -1578,19 +1578,21 @@ def test_settled_chains_world1_wait_for_nothing(hip_lib):
                 seams = dict(runner.last_chain or {})
                 calls = {k: v[:2] for k, v in runner.collectives.items()}
                 _rows_match(got, want[q], "settled/%s/%d" % (q, again))
-                if q == "q9":
-                    # (its replicated (part, supplier) table is keyed by pairs that do NOT increase row after row in partsupp — the suppliers of
-                    #  a part come in the generator's order — so the library cannot take the stage for the entries: sdqh_table_partition_pack
-                    #  refuses, every rank alike, and the chain keeps exchanging exact sizes)
-                    continue
                 assert seams.get("plan") == q, (q, seams)
                 assert sum(c[0] for c in calls.values()) <= 3 and all(c[0] == c[1] for c in calls.values()), (q, calls)
+                if q == "q9":
+                    # (its replicated (part, supplier) table is keyed by pairs that do NOT increase row after row in partsupp — the suppliers of
+                    #  a part come in the generator's order — but no pair comes twice, which the library checks once per column pair: the
+                    #  stage travels as one chunk.  Its last loop is the fixed-shape lookup kernel, waited for, its groups merged on the
+                    #  host: settled, never recorded)
+                    assert seams["replicated"] == ["green_costs"] and seams["merged_on_host"] == ["profit"] and not seams.get("recorded"), seams
+                    continue
                 assert bool(seams.get("recorded")) == (again == 2), (q, again, seams)      # (two settled runs with the calls issued, then the chain — its collectives inside — is ONE recorded launch)
                 if q in ("q1", "q5"):
                     assert seams["folded"] and not seams["merged_on_host"], (q, seams)
                 if q == "q5":
                     assert seams["replicated"] == ["supplier_nations"], seams        # (on a group of one the customers' join is co-partitioned)
-        assert runner.fast_runs >= 6 and runner.fast_retries == 0
+        assert runner.fast_runs >= 9 and runner.fast_retries == 0
         assert runner.graph_recordings == 2 and runner.graph_launches == 2, (runner.graph_recordings, runner.graph_launches)
         for again in range(4):                                       # ... and replayed: the same rows from the same recording
             _rows_match(runner.run("q5", db), want["q5"], "settled/q5/replay %d" % again)

@@ -74,8 +74,8 @@ class DistributedRunner:
         # LANES (round 6): a SETTLED plan — device-sized exchanges, nothing read back — runs on one of the engine's lanes (a context of the
         # family: a stream, a pool and result blocks of its own), torch's current stream being that lane's for the duration of the launch:
         # a collective is ordered behind the kernels of ITS plan (torch makes RCCL's stream wait for, and be waited for by, the current
-        # stream), and the plans of a step share the chip as on one GPU.  Every rank issues its collectives in program order, on one
-        # communicator: the order RCCL executes them in is the same everywhere whatever the lanes.  First (exact) runs, range
+        # stream), and the plans of a step share the chip as on one GPU.  Every rank issues its collectives in program order, each
+        # lane on a communicator of its own (below).  First (exact) runs, range
         # partitioning and everything on CPU tensors stay on lane 0.  Measured on a group of one with its collectives issued (q1+q3+q5 at
         # SF=10): with the calls issued one by one the step is the HOST's — 1.2 ms of Python and torch launching ~70 calls and 8
         # collectives (tools/dist_call_times2.py) — and lanes change nothing (1.37 against 1.21-1.38); with the settled plans RECORDED
@@ -94,6 +94,20 @@ class DistributedRunner:
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
         self.device = device
+        # ONE COMMUNICATOR PER LANE.  The recordings of different plans are launched on different streams; their collectives must not share a
+        # communicator — RCCL's kernels of one communicator use the same channel buffers and flags and rely on being run one after the other,
+        # in the same order on every rank, which nothing orders across streams (and across graphs only RCCL's own graph-mixing events, never
+        # run here).  Every rank creates the lanes' groups here, in the same order; a plan keeps its lane (and so its communicator) for good;
+        # a communicator's first collectives are the eager ones of its plans' first settled runs, before anything is recorded on it.
+        self._lane_groups = {}
+        if self.lanes and eng.nlanes > 1 and not (world == 1 and self.skip_trivial):
+            ranks = None if group is None or group is dist.group.WORLD else dist.get_process_group_ranks(group)
+            for k in range(1, eng.nlanes):
+                self._lane_groups[k] = dist.new_group(ranks=ranks, backend="nccl", use_local_synchronization=ranks is not None)
+            warm = torch.zeros(1, dtype=torch.int64, device=device)           # (the communicators are made by their first collective: now, on every rank alike, not inside a timed run)
+            for k in sorted(self._lane_groups):
+                dist.all_reduce(warm, group=self._lane_groups[k])
+            torch.cuda.synchronize(device)
         # HYBRID (round 6): the HIP library behind a process group that is NOT RCCL (gloo) — several ranks sharing ONE GPU, which RCCL refuses.
         # Collective buffers are then PINNED host tensors: the library's kernels read and write them through their device-visible addresses,
         # gloo moves them between the processes, and the stream is waited for before the host (a collective, a torch op) touches what
@@ -174,15 +188,15 @@ class DistributedRunner:
         ext = self._ext_streams.get(k)
         if ext is None:
             ext = self._ext_streams[k] = torch.cuda.ExternalStream(int(lane_ctx.stream()), device=self.device)
-        saved = (self.ctx, self._ext_stream)
-        self.ctx, self._ext_stream = lane_ctx, ext
+        saved = (self.ctx, self._ext_stream, self.group)
+        self.ctx, self._ext_stream, self.group = lane_ctx, ext, self._lane_groups.get(k, self.group)      # (the lane's own communicator: __init__)
         lane_ctx.set_option("async_copies", 1)
         try:
             with torch.cuda.stream(ext):
                 yield
         finally:
             lane_ctx.set_option("async_copies", 0)
-            self.ctx, self._ext_stream = saved
+            self.ctx, self._ext_stream, self.group = saved
 
     def _on_engine_stream(self):
         """Collective buffers must be allocated with the engine's stream current (see _run): asserted where they are made."""
@@ -212,6 +226,14 @@ class DistributedRunner:
         self._stat_ring = []
         self._ext_stream = None
         self._ext_streams = {}
+        if self._lane_groups and self.backend == "nccl":
+            torch.cuda.synchronize(self.device)
+        for g in self._lane_groups.values():                      # (every rank closes its runner at the same point: the groups go in the same order)
+            try:
+                dist.destroy_process_group(g)
+            except Exception:                                     # noqa: BLE001  (the default group went first: its sub-groups went with it)
+                pass
+        self._lane_groups = {}
 
     def _empty(self, n, dtype=torch.int64):
         """A collective buffer of n elements: device memory under RCCL, pinned host memory in the hybrid mode, plain host memory on CPU."""

@@ -660,7 +660,14 @@ int sdqh_unpack_chunks(sdqh_ctx* ctx, const void* packed, int nparts, int ncols,
  * sdqh_table_compact_deferred / sdqh_xgroupby_async result blocks) are reset first, so the caller collects from the same blocks
  * exactly as after the recorded calls.  The caller guarantees what the recording assumed: the same resident columns with the same
  * contents, the same bound constants, result blocks collected before the next launch of the same graph.  CPU build: begin / end
- * record nothing and sdqh_graph_end returns SDQH_ERR_UNSUPPORTED (the caller keeps issuing the calls). */
+ * record nothing and sdqh_graph_end returns SDQH_ERR_UNSUPPORTED (the caller keeps issuing the calls).
+ * Inside a recording nothing about a column is MEASURED (bounds, order, 4-byte twins are computed on first request, with a wait): the
+ * calls use what is known already, answer the way that needs no measurement, or refuse before touching the stream — on ROCm 7 a wait
+ * on a capturing stream, or a query FROM ANY THREAD of an event recorded on that stream before its capture began, invalidates the
+ * capture and leaves the stream unusable for good (tools/exp/capture_abort.hip).  sdqh_graph_abort joins what a refused call left forked,
+ * ends the capture and returns SDQH_ERR_DEVICE if the runtime could not take it back (the context's stream is then lost: close it).
+ * A caller that shares the stream with another library (the multi-GPU runner with torch / RCCL) keeps that library's event polling
+ * away from it: sdqlpy_amd/dist.py `_coll`. */
 typedef struct sdqh_graph sdqh_graph;
 int sdqh_graph_begin(sdqh_ctx* ctx);
 int sdqh_graph_end(sdqh_ctx* ctx, sdqh_graph** out);

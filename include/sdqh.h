@@ -55,7 +55,7 @@ using __hip_internal::int32_t; using __hip_internal::uint32_t; using __hip_inter
 extern "C" {
 #endif
 
-#define SDQH_ABI_VERSION 6   /* 2: sdqh_filter carries column-vs-column predicates; string modes 3 / 4.  3: sdqh_table_share_groups.  4: row programs (sdqh_x*).  5: device-sized redistribution, plan graphs.  6: sdqh_xgroupby_partial / _fold */
+#define SDQH_ABI_VERSION 7   /* 2: sdqh_filter carries column-vs-column predicates; string modes 3 / 4.  3: sdqh_table_share_groups.  4: row programs (sdqh_x*).  5: device-sized redistribution, plan graphs.  6: sdqh_xgroupby_partial / _fold.  7: sdqh_lookup_aggregate_block */
 
 /* ---- status codes ---------------------------------------------------------------------- */
 #define SDQH_OK              0
@@ -425,6 +425,17 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
                           int nkeys, const sdqh_source* keys, int tuple_shape, const sdqh_source* operands,
                           int max_groups, int64_t* out_keys, double* out_values, int64_t* out_counts,
                           int32_t* out_ngroups);
+/* ... launched and NOT waited for (ABI 7), its groups left in `block` (sdqh_xgroupby_block_bytes() bytes, opaque) instead of returned:
+ * device_block 0 — a result block from sdqh_host_alloc, collected with sdqh_xgroupby_collect (the key it returns packs the parts:
+ * part k in bits [32k, 32k + 32)); the plan's last loop, deferred like sdqh_xgroupby_async, recordable into a plan graph;
+ * device_block 1 — device memory (CPU build: host memory): this rank's partial groups on their way through an all-gather to
+ * sdqh_xgroupby_fold, which merges the ranks' blocks by packed key in rank order (the multi-GPU runner's Q9: the loop the reference
+ * emits for the final aggregation of a join chain, ...generator_par.py:402-440, over a row shard).  What the data decides — too many
+ * groups, a key part outside [0, 2^32-2] — is reported by sdqh_xgroupby_collect. */
+int sdqh_lookup_aggregate_block(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter,
+                                int nlookups, const sdqh_lookup* lookups,
+                                int nkeys, const sdqh_source* keys, int tuple_shape, const sdqh_source* operands,
+                                void* block, int device_block);
 
 /* ---- row programs: the open expression / predicate vocabulary (ABI 4) -----------------------------
  * What the reference's generator prints as the C++ body of an emitted loop — any boolean expression

@@ -1263,6 +1263,30 @@ int sdqh_xgroupby_collect(sdqh_ctx* ctx, const void* result_block, int nvals, in
     return SDQH_OK;
 }
 
+// (checker: sdqh_lookup_aggregate run at once, its groups kept in the block under their packed keys — include/sdqh.h, ABI 7)
+int sdqh_lookup_aggregate_block(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nlookups, const sdqh_lookup* lookups,
+                                int nkeys, const sdqh_source* keys, int tuple_shape, const sdqh_source* operands, void* block, int device_block) {
+    (void)device_block;
+    if (!ctx || nrows < 0 || nkeys < 1 || nkeys > SDQH_MAX_GROUPKEYS || !keys || !block) return fail(ctx, SDQH_ERR_INVALID, "lookup_aggregate_block: bad arguments");
+    XGroupBlock* b = static_cast<XGroupBlock*>(block);
+    std::vector<int64_t> parts((size_t)SDQH_MAX_LOOKUP_GROUPS * (size_t)nkeys);
+    int32_t ng = 0;
+    b->rc = sdqh_lookup_aggregate(ctx, nrows, filter, nlookups, lookups, nkeys, keys, tuple_shape, operands, SDQH_MAX_LOOKUP_GROUPS, parts.data(), b->vals, b->cnts, &ng);
+    b->ng = ng;
+    std::snprintf(b->err, sizeof(b->err), "%s", b->rc ? ctx->err.c_str() : "");
+    for (int g = 0; !b->rc && g < ng; ++g) {
+        uint64_t packed = 0;
+        for (int k = 0; k < nkeys; ++k) {
+            const int64_t part = parts[(size_t)g * (size_t)nkeys + (size_t)k];
+            if (part < 0 || part > 0xFFFFFFFEll) { b->rc = SDQH_ERR_UNSUPPORTED; std::snprintf(b->err, sizeof(b->err), "lookup_aggregate: key part out of range"); break; }
+            packed |= (uint64_t)part << (32 * k);
+        }
+        b->keys[g] = (int64_t)packed;
+    }
+    if (b->rc == SDQH_ERR_OVERFLOW || b->rc == SDQH_ERR_UNSUPPORTED) return SDQH_OK;       // what the data decides is reported by collect
+    return b->rc;
+}
+
 // (checker: a rank's partial groups are the block sdqh_xgroupby_async fills; the fold adds the ranks' sums in rank order — include/sdqh.h)
 int sdqh_xgroupby_partial(sdqh_ctx* ctx, int64_t nrows, const sdqh_program* prog, void* device_block) {
     return sdqh_xgroupby_async(ctx, nrows, prog, device_block);

@@ -12,7 +12,7 @@ import math
 import numpy as np
 
 MAX_SHARE_CELLS = 1 << 28  # SDQH_MAX_SHARE_CELLS
-ABI_VERSION = 6            # include/sdqh.h: SDQH_ABI_VERSION (struct layouts below must match the library's)
+ABI_VERSION = 7            # include/sdqh.h: SDQH_ABI_VERSION (struct layouts below must match the library's)
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_DEVICE, ERR_OVERFLOW, ERR_NOMEM = range(6)
 I64, F64, STR = 0, 1, 2
 TUPLE_A, TUPLE_AB, TUPLE_A_1MB, TUPLE_PRICING, TUPLE_A_1MB_M_CD, TUPLE_COUNT = 1, 2, 3, 4, 5, 6
@@ -218,7 +218,7 @@ EXPORTS = [
     "sdqh_scan_filter_sum", "sdqh_scan_probe_sum", "sdqh_groupby_small", "sdqh_hash_build_unique", "sdqh_build_key_set", "sdqh_groupby_key", "sdqh_table_select_keys", "sdqh_table_share_groups", "sdqh_table_size", "sdqh_table_free",
     "sdqh_hash_probe_aggregate", "sdqh_table_compact", "sdqh_table_compact_async", "sdqh_table_compact_deferred", "sdqh_host_wait_word", "sdqh_result_wait", "sdqh_scan_compact", "sdqh_partition_by_key",
     "sdqh_table_export_bitmap", "sdqh_table_from_bitmap", "sdqh_column_copy_out", "sdqh_column_copy_in", "sdqh_column_unpack2", "sdqh_partition_pack", "sdqh_unpack_parts", "sdqh_column_mark_transient", "sdqh_column_set_bounds",
-    "sdqh_build", "sdqh_lookup_aggregate", "sdqh_table_entries", "sdqh_host_alloc", "sdqh_host_free", "sdqh_table_topk",
+    "sdqh_build", "sdqh_lookup_aggregate", "sdqh_lookup_aggregate_block", "sdqh_table_entries", "sdqh_host_alloc", "sdqh_host_free", "sdqh_table_topk",
     "sdqh_xscan_sum", "sdqh_xgroupby", "sdqh_xgroupby_block_bytes", "sdqh_xgroupby_async", "sdqh_xgroupby_collect", "sdqh_xgroupby_partial", "sdqh_xgroupby_fold", "sdqh_xbuild", "sdqh_xkey_set", "sdqh_xcompact", "sdqh_xprobe_aggregate", "sdqh_table_columns", "sdqh_jit_stats", "sdqh_jit_compile",
     "sdqh_xstage", "sdqh_chunk_words", "sdqh_table_partition_pack", "sdqh_unpack_chunks",
     "sdqh_graph_begin", "sdqh_graph_end", "sdqh_graph_abort", "sdqh_graph_launch", "sdqh_graph_nodes", "sdqh_graph_free",
@@ -721,6 +721,49 @@ class Context:
         self._after_call("lookup_aggregate")
         n = ng.value
         return out_keys[:n], out_vals[:n, : TUPLE_NVALUES[shape]], out_cnt[:n]
+
+    def _block_collect(self, buf, done, nk, nvals, max_groups):
+        """collect() of a lookup-aggregate block: (keys [n, nk], values, counts) as lookup_aggregate_marshalled (the block's packed
+        key taken apart: part k in bits [32k, 32k + 32))."""
+        def collect():
+            out_keys = np.zeros(max_groups, np.int64)
+            out_vals = np.zeros((max_groups, TUPLE_MAX_VALUES), np.float64)
+            out_cnt = np.zeros(max_groups, np.int64)
+            ng = C.c_int32()
+            rc = self.lib.sdqh_xgroupby_collect(self.handle, C.addressof(buf), C.c_int(nvals), C.c_int(max_groups),
+                                                _np_ptr(out_keys), _np_ptr(out_vals), _np_ptr(out_cnt), C.byref(ng))
+            done[0] = True                                        # (collect waited for this call's kernels: nothing will write the block any more)
+            self._check(rc)
+            n = ng.value
+            packed = out_keys[:n].view(np.uint64)
+            keys = np.stack([((packed >> np.uint64(32 * k)) & np.uint64(0xFFFFFFFF)).astype(np.int64) for k in range(nk)], axis=1) if n else np.zeros((0, nk), np.int64)
+            return keys, out_vals[:n, :nvals], out_cnt[:n]
+        return collect
+
+    def lookup_aggregate_async_marshalled(self, nrows, flt, larr, nlookups, karr, nk, shape, oarr, max_groups=MAX_LOOKUP_GROUPS):
+        """sdqh_lookup_aggregate_block into a result block: launched, not waited for; collect() -> what lookup_aggregate_marshalled returns.
+        What the data decides (too many groups, a key part out of range) is raised by collect()."""
+        done = [False]
+        buf = self.host_block(self.lib.sdqh_xgroupby_block_bytes(), deferred=done)
+        self._check(self.lib.sdqh_lookup_aggregate_block(self.handle, C.c_int64(nrows), C.byref(flt), C.c_int(nlookups), larr, C.c_int(nk), karr,
+                                                         C.c_int(shape), oarr, C.addressof(buf), C.c_int(0)))
+        self._after_call("lookup_aggregate")
+        return self._block_collect(buf, done, nk, TUPLE_NVALUES[shape], max_groups)
+
+    def lookup_aggregate_folded_marshalled(self, nrows, flt, larr, nlookups, karr, nk, shape, oarr, exchange, max_groups=MAX_LOOKUP_GROUPS):
+        """The same over a ROW SHARD, the ranks' partial groups folded on the device (sdqh_lookup_aggregate_block with a device block,
+        sdqh_xgroupby_fold): exchange as for xgroupby_folded.  Nothing is waited for."""
+        nbytes = self.xgroupby_block_bytes()
+        send_ptr, gather = exchange(nbytes)
+        self._check(self.lib.sdqh_lookup_aggregate_block(self.handle, C.c_int64(nrows), C.byref(flt), C.c_int(nlookups), larr, C.c_int(nk), karr,
+                                                         C.c_int(shape), oarr, C.c_void_p(send_ptr), C.c_int(1)))
+        self._after_call("lookup_aggregate")
+        recv_ptr, nblocks = gather()
+        done = [False]
+        buf = self.host_block(nbytes, deferred=done)
+        self._check(self.lib.sdqh_xgroupby_fold(self.handle, C.c_void_p(recv_ptr), C.c_int(nblocks), C.addressof(buf)))
+        self._after_call("xgroupby_fold")
+        return self._block_collect(buf, done, nk, TUPLE_NVALUES[shape], max_groups)
 
     # -- row programs (ABI 4) ------------------------------------------------------------------------
     def xscan_sum(self, nrows, prog):
@@ -1260,6 +1303,7 @@ class Library:
         L.sdqh_build.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.sdqh_lookup_aggregate.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sdqh_lookup_aggregate_block.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
 
     def backend_name(self):
         return self.cdll.sdqh_backend_name().decode()

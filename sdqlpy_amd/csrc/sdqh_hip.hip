@@ -2227,11 +2227,10 @@ int sdqh_build(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nloo
     return SDQH_OK;
 }
 
-int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nlookups, const sdqh_lookup* lookups,
-                          int nkeys, const sdqh_source* keys, int tuple_shape, const sdqh_source* operands, int max_groups,
-                          int64_t* out_keys, double* out_values, int64_t* out_counts, int32_t* out_ngroups) {
-    if (!ctx || nrows < 0 || nkeys < 1 || nkeys > SDQH_MAX_GROUPKEYS || !keys || max_groups < 1 || max_groups > SDQH_MAX_LOOKUP_GROUPS || !out_ngroups)
-        return fail(ctx, SDQH_ERR_INVALID, "lookup_aggregate: bad arguments");
+// The loop and its merge, launched: the groups land in `block` (an xgroupby block: pinned host memory with its completion word, or —
+// device_block — device memory for sdqh_xgroupby_fold) or, without one, in the context's pinned result block.  Nothing is waited for.
+static int lookup_aggregate_launch(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nlookups, const sdqh_lookup* lookups,
+                                   int nkeys, const sdqh_source* keys, int tuple_shape, const sdqh_source* operands, void* block, bool device_block) {
     (void)hipSetDevice(ctx->device);
     const int nops = tuple_nops(tuple_shape), nv = tuple_nv(tuple_shape);
     if (nops < 0) return fail(ctx, SDQH_ERR_UNSUPPORTED, "unknown tuple shape");
@@ -2376,12 +2375,15 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
         return clean;
     };
     // the merge writes the result block straight into the pinned host block (same layout): no copy-engine launch after it
-    char* hb = static_cast<char*>(ctx->result_host);
+    char* hb = static_cast<char*>(block ? block : ctx->result_host);
     unsigned long long* h_keys = reinterpret_cast<unsigned long long*>(hb);
     double* h_acc = reinterpret_cast<double*>(hb + LG_SLOTS * 8);
     int64_t* h_cnt = reinterpret_cast<int64_t*>(hb + LG_SLOTS * 40);
     int* h_tail = reinterpret_cast<int*>(hb + LG_SLOTS * 48);
     (void)r_acc; (void)r_cnt;
+    // a result block's DONE word (as sdqh_xgroupby_async): cleared now, written by the stream behind the merge
+    uint32_t* done = (block && !device_block) ? reinterpret_cast<uint32_t*>(hb + sdqh_xgroupby_block_bytes() - 64) : nullptr;
+    if (done) host_init(ctx, done, 0, 4);
     unsigned grid = 1; char* blob = nullptr;
     int lrc = with_shape(ctx, tuple_shape, [&](auto S) {
         return with_scan_filter(f, [&](auto FC) {
@@ -2442,10 +2444,20 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
             return SDQH_OK;
         });
     });
-    if (lrc) { if (blob) pool_free(ctx, blob); return lrc; }
-    int rc = sync_stream(ctx);
-    pool_free(ctx, blob);
-    if (rc) return rc;
+    if (blob) pool_free(ctx, blob);                          // (stream order: whoever gets the block next runs after the merge)
+    if (lrc) return lrc;
+    if (done && stream_store32(ctx, ctx->stream, done, 1) != SDQH_OK) *done = 2;     // 2: no marker, collect synchronises
+    return SDQH_OK;
+}
+
+int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nlookups, const sdqh_lookup* lookups,
+                          int nkeys, const sdqh_source* keys, int tuple_shape, const sdqh_source* operands, int max_groups,
+                          int64_t* out_keys, double* out_values, int64_t* out_counts, int32_t* out_ngroups) {
+    if (!ctx || nrows < 0 || nkeys < 1 || nkeys > SDQH_MAX_GROUPKEYS || !keys || max_groups < 1 || max_groups > SDQH_MAX_LOOKUP_GROUPS || !out_ngroups)
+        return fail(ctx, SDQH_ERR_INVALID, "lookup_aggregate: bad arguments");
+    const int nv = tuple_nv(tuple_shape);
+    if (int rc = lookup_aggregate_launch(ctx, nrows, filter, nlookups, lookups, nkeys, keys, tuple_shape, operands, nullptr, false)) return rc;
+    if (int rc = sync_stream(ctx)) return rc;
     const char* h = static_cast<const char*>(ctx->result_host);
     const int flags = *reinterpret_cast<const int*>(h + LG_SLOTS * 48);
     if (flags & 2) return fail(ctx, SDQH_ERR_UNSUPPORTED, "lookup_aggregate: key part out of range");
@@ -2465,6 +2477,15 @@ int sdqh_lookup_aggregate(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filte
     }
     *out_ngroups = ng;
     return SDQH_OK;
+}
+
+// ... with its groups left in a block instead of returned (ABI 7): launched, not waited for.
+int sdqh_lookup_aggregate_block(sdqh_ctx* ctx, int64_t nrows, const sdqh_filter* filter, int nlookups, const sdqh_lookup* lookups,
+                                int nkeys, const sdqh_source* keys, int tuple_shape, const sdqh_source* operands, void* block, int device_block) {
+    if (!ctx || nrows < 0 || nkeys < 1 || nkeys > SDQH_MAX_GROUPKEYS || !keys || !block) return fail(ctx, SDQH_ERR_INVALID, "lookup_aggregate_block: bad arguments");
+    if (!device_block && !in_host_block(ctx, block, sdqh_xgroupby_block_bytes()))
+        return fail(ctx, SDQH_ERR_INVALID, "lookup_aggregate_block: the result block must come from sdqh_host_alloc (sdqh_xgroupby_block_bytes() bytes)");
+    return lookup_aggregate_launch(ctx, nrows, filter, nlookups, lookups, nkeys, keys, tuple_shape, operands, block, device_block != 0);
 }
 
 // ---- multi-GPU helpers -------------------------------------------------------------------------

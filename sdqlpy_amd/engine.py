@@ -882,19 +882,66 @@ def _prepare_general(eng, op, htab, flt, contains_lookups, accumulate_into=()):
         _, larr, karr, nk, oarr, key_infos = c
         for i, bt in enumerate(bts):
             larr[i].table = bt.table.handle
+        def finish(keys, vals, cnts):
+            kf = []
+            for i, (fname, e) in enumerate(key_fields):
+                decoder, dtype = key_infos[i]
+                kf.append((fname or "key%d" % i, _decode_column(keys[:, i].copy(), decoder, dtype)))
+            vf = _value_arrays(names, count_idx, [vals[:, j] for j in range(vals.shape[1])], cnts)
+            d = _merge_equal_keys(DictResult(kf, vf, key_is_record, val_is_record))
+            d.encoding_fp = cached.get("fp")                     # (the multi-GPU runner: may the ranks' partial groups be folded by packed key?)
+            return d
+
+        def collected(collect):
+            def resolve():
+                try:
+                    return finish(*collect())
+                except abi.SdqhError as exc:
+                    if exc.code == abi.ERR_OVERFLOW:
+                        raise UnsupportedQuery("line %d: more than %d groups" % (op.lineno, abi.MAX_LOOKUP_GROUPS))
+                    raise
+            return Pending(resolve)
+        if "fp" not in cached or cached.get("fp_sig") is not key_infos:
+            cached["fp"], cached["fp_sig"] = _key_decoders_fingerprint(key_infos), key_infos
         try:
+            fold = env.get("__group_fold__")
+            if fold is not None:
+                # a row shard of a multi-GPU run: this rank's partial groups into the collective's buffer, the ranks' blocks folded on the
+                # device behind ONE all-gather (as xplan's group-by programs: dist.DistributedRunner gives the exchange where it has checked
+                # that the packed keys mean the same on every rank).  No exchange: waited for, merged on the host by decoded values.
+                exchange = fold(op.out, cached["fp"])
+                if exchange is not None:
+                    return collected(ctx.lookup_aggregate_folded_marshalled(n, flt, larr, len(bts), karr, nk, abi_shape, oarr, exchange))
+            elif op.out in env.get("__defer__", ()):
+                # the plan's last device call: launched, not waited for (engine.PreparedPlan.run finishes the plan when the result is first looked at)
+                return collected(ctx.lookup_aggregate_async_marshalled(n, flt, larr, len(bts), karr, nk, abi_shape, oarr))
             keys, vals, cnts = ctx.lookup_aggregate_marshalled(n, flt, larr, len(bts), karr, nk, abi_shape, oarr)
         except abi.SdqhError as exc:
             if exc.code == abi.ERR_OVERFLOW:
                 raise UnsupportedQuery("line %d: more than %d groups" % (op.lineno, abi.MAX_LOOKUP_GROUPS))
             raise
-        kf = []
-        for i, (fname, e) in enumerate(key_fields):
-            decoder, dtype = key_infos[i]
-            kf.append((fname or "key%d" % i, _decode_column(keys[:, i].copy(), decoder, dtype)))
-        vf = _value_arrays(names, count_idx, [vals[:, j] for j in range(vals.shape[1])], cnts)
-        return _merge_equal_keys(DictResult(kf, vf, key_is_record, val_is_record))
+        return finish(keys, vals, cnts)
     return run_lookup_aggregate
+
+
+def _key_decoders_fingerprint(key_infos):
+    """What the packed group key of a lookup-aggregate loop MEANS, as a digest (xplan._encoding_fingerprint's counterpart for the
+    fixed-shape loop): per key part its dtype and its decoder's contents.  Ranks whose digests are equal may fold their partial groups by
+    packed key on the device; a decoder that is a table's own large column (row references, local to a rank's shard) gives None."""
+    import hashlib
+    h = hashlib.sha1(b"lookup_aggregate;")
+    for decoder, dtype in key_infos:
+        h.update((np.dtype(dtype).str if dtype is not None else "-").encode())
+        if decoder is None:
+            h.update(b"raw;")
+            continue
+        arr = decoder if isinstance(decoder, np.ndarray) else None
+        if arr is None or len(arr) > (1 << 16):
+            return None
+        a = np.ascontiguousarray(arr)
+        h.update(a.dtype.str.encode())
+        h.update(repr(a.tolist()).encode() if a.dtype == object else a.view(np.uint8).tobytes())
+    return h.hexdigest()
 
 
 _DENSE_MERGE_CELLS = 1 << 26

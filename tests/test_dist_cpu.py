@@ -80,6 +80,10 @@ def test_two_ranks_match_single_process(mode, tmp_path, single, oracle_lib):
     for tag, res in got["again"].items():
         q = tag.split("/")[0]
         helpers.assert_rows_match(sorted(as_rows(res["rows"])), helpers.result_rows(single[q], res["columns"]), 1e-12, mode + "/again/" + tag)
+        if q == "q9" and res["seams"]:
+            # the fixed-shape lookup loop (sdqh_lookup_aggregate_block, ABI 7): this rank's partial groups into the all-gather's send
+            # buffer, the ranks' blocks folded by packed key — its keys decode through `nation`, whole on every rank
+            assert res["seams"]["folded"] == ["profit"] and not res["seams"]["merged_on_host"], (mode, tag, res["seams"])
     assert got["chain_fast_runs"] >= 6 and got["chain_fast_retries"] == 0, (got["chain_fast_runs"], got["chain_fast_retries"])
     _check_chain_overflow(got, single, mode)
     w3 = single["q3"]

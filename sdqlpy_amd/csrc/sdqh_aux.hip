@@ -212,36 +212,41 @@ __global__ __launch_bounds__(TPB) void k_stage_part_scan(uint32_t* __restrict__ 
 // ONE part (an all-gather's send buffer: this rank's entries, whole): the stage's segments back to back IN STAGE ORDER — a scan of the
 // segments' live counts, then every wave copies its segment to its place.  Deterministic, and what was in row order stays in row
 // order: the replica a receiver rebuilds from the ranks' chunks (rank after rank) sees the table's rows in the table's order.
+constexpr int PS_PER = 16;                           // segments per thread of the scan: a workgroup takes TPB * PS_PER of them
 __global__ __launch_bounds__(TPB) void k_stage_pack_scan(DevStage st, unsigned long long* __restrict__ offs, int64_t* __restrict__ packed) {
-    // one workgroup, PS_PER segments per thread and turn (a stage has tens of thousands of segments for a 15 M row build: a turn per 256
-    // of them was 0.03 ms of barriers)
-    constexpr int PS_PER = 16;
+    // Workgroup b places the segments [b * 4096, (b + 1) * 4096).  What lies in front of them it sums for itself — a stage has tens of
+    // thousands of segments for a 15 M row build: a few hundred KB at most, read coalesced — so no workgroup waits for another (one
+    // workgroup walking all of them, a turn per 4096 with its barriers, was 26 - 31 us of an otherwise idle device in front of every
+    // exchange: profiles/r06_distributed_host_profile_world1.txt).
     __shared__ unsigned long long s_scan[TPB];
-    __shared__ unsigned long long s_base;
-    if (threadIdx.x == 0) s_base = 0;
+    const int i0 = (int)blockIdx.x * TPB * PS_PER;
+    unsigned long long before = 0;
+    for (int i = (int)threadIdx.x; i < i0; i += TPB) before += st.seg_count[i];
+    s_scan[threadIdx.x] = before;
     __syncthreads();
-    for (int i0 = 0; i0 < st.nseg; i0 += TPB * PS_PER) {
-        const int first = i0 + (int)threadIdx.x * PS_PER;
-        uint32_t c[PS_PER];
-        unsigned long long mine = 0;
-#pragma unroll
-        for (int j = 0; j < PS_PER; ++j) { c[j] = first + j < st.nseg ? st.seg_count[first + j] : 0u; mine += c[j]; }
-        s_scan[threadIdx.x] = mine;
-        __syncthreads();
-        for (int off = 1; off < TPB; off <<= 1) {
-            const unsigned long long v = (int)threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0ull;
-            __syncthreads();
-            s_scan[threadIdx.x] += v;
-            __syncthreads();
-        }
-        unsigned long long at = s_base + s_scan[threadIdx.x] - mine;
-#pragma unroll
-        for (int j = 0; j < PS_PER; ++j) { if (first + j < st.nseg) offs[first + j] = at; at += c[j]; }
-        __syncthreads();
-        if (threadIdx.x == 0) s_base += s_scan[TPB - 1];
+    for (int off = TPB / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) s_scan[threadIdx.x] += s_scan[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) { packed[0] = (int64_t)s_base; packed[1] = 0; }
+    const unsigned long long base = s_scan[0];
+    __syncthreads();
+    const int first = i0 + (int)threadIdx.x * PS_PER;
+    uint32_t c[PS_PER];
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int j = 0; j < PS_PER; ++j) { c[j] = first + j < st.nseg ? st.seg_count[first + j] : 0u; mine += c[j]; }
+    s_scan[threadIdx.x] = mine;
+    __syncthreads();
+    for (int off = 1; off < TPB; off <<= 1) {
+        const unsigned long long v = (int)threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0ull;
+        __syncthreads();
+        s_scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned long long at = base + s_scan[threadIdx.x] - mine;
+#pragma unroll
+    for (int j = 0; j < PS_PER; ++j) { if (first + j < st.nseg) offs[first + j] = at; at += c[j]; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == TPB - 1) { packed[0] = (int64_t)(base + s_scan[TPB - 1]); packed[1] = 0; }
 }
 __global__ __launch_bounds__(TPB) void k_stage_pack_copy(DevStage st, const unsigned long long* __restrict__ offs, int ncols, int64_t chunk_rows, int64_t* __restrict__ packed) {
     const int seg = (int)blockIdx.x * (TPB / WAVE) + (int)(threadIdx.x / WAVE), lane = (int)(threadIdx.x & (WAVE - 1));
@@ -569,7 +574,7 @@ int sdqh_table_partition_pack(sdqh_ctx* ctx, const sdqh_table* table, int nparts
         unsigned long long* offs = static_cast<unsigned long long*>(pool_alloc(ctx, (size_t)table->stage.nseg * 8 + 64));
         if (!offs) return fail(ctx, SDQH_ERR_NOMEM, "table_partition_pack: out of device memory");
         { KernelScope ks(ctx, "k_stage_pack_scan");
-          hipLaunchKernelGGL(k_stage_pack_scan, dim3(1), dim3(TPB), 0, ctx->stream, table->stage, offs, static_cast<int64_t*>(packed)); }
+          hipLaunchKernelGGL(k_stage_pack_scan, dim3((unsigned)std::max(1, (table->stage.nseg + TPB * PS_PER - 1) / (TPB * PS_PER))), dim3(TPB), 0, ctx->stream, table->stage, offs, static_cast<int64_t*>(packed)); }
         { KernelScope ks(ctx, "k_stage_pack_copy");
           hipLaunchKernelGGL(k_stage_pack_copy, dim3((unsigned)((table->stage.nseg + TPB / WAVE - 1) / (TPB / WAVE))), dim3(TPB), 0, ctx->stream, table->stage, offs, ncols, chunk_rows, static_cast<int64_t*>(packed)); }
         pool_free(ctx, offs);                                          // (stream order: whoever gets the block next runs behind the copy)

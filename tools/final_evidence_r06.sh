@@ -1,6 +1,6 @@
 set -u
 mkdir -p gpurun_out/r06
-export SDQLPY_COMMIT=$(cat gpurun_out/.commit 2>/dev/null || echo unknown)
+export SDQLPY_COMMIT=${SDQLPY_COMMIT:-unknown}
 bash tools/collect_profiles.sh r06 > gpurun_out/collect_r06.log 2>&1
 G=gpurun_out/r06
 python bench.py --steps 20 --warmup 5 > $G/bench.json 2> $G/bench.err

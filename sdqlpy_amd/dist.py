@@ -154,8 +154,8 @@ class DistributedRunner:
         collectives before a recording ran on the stream that is recorded).  So no eager collective ever leaves an event on a stream that
         plans are recorded on; inside a recording the collective joins the capture on the recorded stream itself (torch does not hand
         captured work to its watchdog)."""
-        if self.backend != "nccl" or self.ctx.capturing() or _COLL_ON_RECORDED_STREAM:
-            return fn(*args, **kwargs)
+        if self.backend != "nccl" or self.ctx.capturing() or not self.graphs or _COLL_ON_RECORDED_STREAM:
+            return fn(*args, **kwargs)                               # (not self.graphs: this runner records nothing, so no stream of its plans is ever captured)
         cur = torch.cuda.current_stream(self.device)
         side = self._coll_side
         if side is None:

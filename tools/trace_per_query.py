@@ -5,7 +5,7 @@ dispatch as the command processor stamps it), averaged over the steady-state run
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/qtrace/q9 -- python3 tools/run_queries.py --sf 10 --queries q9 --iters 8
     python3 tools/trace_per_query.py gpurun_out/qtrace q1,q3,q5,q6,q9 '<rows json>' > profiles/r02_rocprofv3_per_query_kernel_sums.txt
 
-The run is cut into query runs at the last kernel of the trace (the kernel every run ends with); the first two runs
+The run is cut into query runs at the kernel every run ends with (launched once per run, seen last); the first two runs
 (uploads, twins, plan lowering, hiprtc) are dropped.  `copies` are the runtime's blit kernels (result read-backs) inside
 those runs: reported apart, they are not launched by the library.  bench.py's own per-query figure puts a HIP event pair
 around every launch, which reads 2-3 us long on each of the 15-20 tiny kernels of a join query; this is the same sum without them."""
@@ -40,7 +40,20 @@ def main(root, queries, rows_json):
         if not recs:
             continue
         recs.sort()
-        last = [r for r in recs if not r[2].startswith("__amd_rocclr")][-1][2]
+        # the kernel every run ends with: among the kernels launched once per run, the one seen last — the
+        # very last kernel of the trace may be one a run launches several times (a deferred result's completion store)
+        own_recs = [r for r in recs if not r[2].startswith("__amd_rocclr")]
+        counts = {}
+        for r in own_recs:
+            counts[r[2]] = counts.get(r[2], 0) + 1
+        per_count = {}
+        for c in counts.values():
+            if c >= 4:                                           # (what only the first runs launch — twins, bounds, fills — says nothing about the runs)
+                per_count[c] = per_count.get(c, 0) + 1
+        if not per_count:
+            continue
+        once_per_run = max(per_count, key=lambda c: (per_count[c], c))          # most kernels of a plan are launched once per run: that count IS the number of runs
+        last = [r for r in own_recs if counts[r[2]] == once_per_run][-1][2]
         runs, cur = [], []
         for r in recs:
             cur.append(r)

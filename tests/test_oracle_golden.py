@@ -150,7 +150,9 @@ def test_results_launched_and_not_waited_for(oracle_lib, golden, golden_more, go
     eng = engine.Engine(oracle_lib.context(threads=1))
     try:
         n, seen = helpers.deferred_result_cases(eng, [golden, golden_more, golden_wide])
-        assert n >= 40 and {"q3", "q7", "q12", "q13"} <= seen, (n, seen)     # (q1 / q5 end in fixed-shape calls on this backend; on the GPU they are programs)
+        # (q5 / q9 end in the fixed-shape lookup loop: deferred through sdqh_lookup_aggregate_block, ABI 7; q1 ends in a fixed-shape call
+        #  without a deferred form on this backend — on the GPU it is a program)
+        assert n >= 40 and {"q3", "q5", "q7", "q9", "q12", "q13"} <= seen, (n, seen)
     finally:
         eng.close()
 

@@ -4,7 +4,7 @@ q3 are settled, recorded and replayed, and every few rounds a plan's recordings 
 settles and is recorded AGAIN — hundreds of captures with eager collectives right before them, the pattern that dumped core a few per
 cent of the time while torch's watchdog could still poll an event of the captured stream (dist.DistributedRunner._coll).  Results are
 compared with the single-GPU plan's every round; the pools' size is printed at the start and at the end (a recording owns pool memory).
-    python tools/soak_dist_recordings.py [rounds=150]"""
+    python tools/soak_dist_recordings.py [rounds=150] [sf=1]"""
 import os
 import sys
 import time
@@ -18,12 +18,13 @@ from sdqlpy_amd import engine, tpch
 from sdqlpy_amd import dist as sdist
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+sf = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29631", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 eng = engine.Engine(engine.load_hip_library().context(device=0))
 runner = sdist.DistributedRunner(eng, 0, 1, skip_trivial=False, partition="hash")
 qs = ("q1", "q3", "q5", "q9")
 cols = tpch.columns_for(qs)
-db = tpch.generate(1.0, tables=sorted(cols), columns=cols, shard=(0, 1))
+db = tpch.generate(sf, tables=sorted(cols), columns=cols, shard=(0, 1))
 want = {}
 for q in qs:
     r = helpers.run_query(eng, q, db)
